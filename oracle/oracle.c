@@ -1,0 +1,369 @@
+/* oracle/oracle.c — TEST INFRASTRUCTURE ONLY (CPU oracle + timed CPU baseline "port").
+ *
+ * Plain-C restatement of the hot path the reference (docknetwork/crypto) enters through arkworks:
+ *   G::Group::msm_unchecked / msm_bigint      utils/src/pairs.rs:143-156, utils/src/owned_pairs.rs:93-106,
+ *                                             legogroth16/src/prover.rs:286,299,585-594
+ *   E::multi_miller_loop / final_exponentiation
+ *                                             utils/src/randomized_pairing_check.rs:204-214,
+ *                                             legogroth16/src/verifier.rs:62-84
+ * The algorithms live in third-party crates absent from /root/reference (ark-ec/ark-ff ^0.4.1 ->
+ * 0.4.2, ark-bls12-381 ^0.4.0; Cargo.toml:36-50, no Cargo.lock): they are restated from the
+ * published sources as summarised in SURVEY.md Appendix A (A.1 msm_bigint_wnaf, A.2 make_digits,
+ * A.3 Miller loop with M-twist line coefficients, A.4 final-exponentiation chain).
+ *
+ * PARITY UNPINNED against a real arkworks run: the reference keeps no known-answer vectors for this
+ * path and has no buildable source here (Rust toolchain absent).  Pinned instead against the
+ * independent big-integer model oracle/bls12_381_model.py (fixtures in tests/golden/) and the
+ * algebraic identities the reference's own tests assert (utils/src/msm.rs:186-193,268-275).
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load liboracle.so.
+ */
+#include <stdlib.h>
+#include <pthread.h>
+#include "fields.h"
+
+/* ---------------- ark-ec window rule + signed digits (A.1 / A.2) ---------------- */
+static int ark_log2(size_t x) {
+    if (x == 0) return 0;
+    int bl = 64 - __builtin_clzll((unsigned long long)x);
+    return ((x & (x - 1)) == 0) ? bl - 1 : bl;
+}
+static int ark_window_c(size_t n) { return n < 32 ? 3 : ark_log2(n) * 69 / 100 + 2; }
+static void ark_make_digits(int64_t *out, const uint64_t a[4], int w, int num_bits) {
+    uint64_t radix = 1ULL << w, mask = radix - 1, carry = 0;
+    int dc = (num_bits + w - 1) / w;
+    for (int i = 0; i < dc; i++) {
+        int bo = i * w, u = bo / 64, b = bo % 64;
+        uint64_t buf;
+        if (b < 64 - w || u == 3) buf = a[u] >> b;
+        else buf = (a[u] >> b) | (a[u + 1] << (64 - b));
+        uint64_t coef = carry + (buf & mask);
+        carry = (coef + radix / 2) >> w;
+        out[i] = (int64_t)coef - (int64_t)(carry << w);
+    }
+    out[dc - 1] += (int64_t)(carry << w);
+}
+
+#define FE fp
+#define F(x) fp_##x
+#define EC(x) g1_##x
+#include "ec_tmpl.inc"
+#undef FE
+#undef F
+#undef EC
+#define FE fp2
+#define F(x) fp2_##x
+#define EC(x) g2_##x
+#include "ec_tmpl.inc"
+#undef FE
+#undef F
+#undef EC
+
+static const g1_aff G1_GEN = {
+    {{0x5cb38790fd530c16ULL, 0x7817fc679976fff5ULL, 0x154f95c7143ba1c1ULL, 0xf0ae6acdf3d0e747ULL, 0xedce6ecc21dbf440ULL, 0x120177419e0bfb75ULL}},
+    {{0xbaac93d50ce72271ULL, 0x8c22631a7918fd8eULL, 0xdd595f13570725ceULL, 0x51ac582950405194ULL, 0x0e1c8c3fad0059c0ULL, 0x0bbc3efc5008a26aULL}}};
+static const g2_aff G2_GEN = {
+    {{{0xf5f28fa202940a10ULL, 0xb3f5fb2687b4961aULL, 0xa1a893b53e2ae580ULL, 0x9894999d1a3caee9ULL, 0x6f67b7631863366bULL, 0x058191924350bcd7ULL}},
+     {{0xa5a9c0759e23f606ULL, 0xaaa0c59dbccd60c3ULL, 0x3bb17e18e2867806ULL, 0x1b1ab6cc8541b367ULL, 0xc2b6ed0ef2158547ULL, 0x11922a097360edf3ULL}}},
+    {{{0x4c730af860494c4aULL, 0x597cfa1f5e369c5aULL, 0xe7e6856caa0a635aULL, 0xbbefb5e96e0d495fULL, 0x07d3a975f0ef25a2ULL, 0x0083fd8e7e80dae5ULL}},
+     {{0xadc0fc92df64b05dULL, 0x18aa270a2b1461dcULL, 0x86adac6a3be4eba0ULL, 0x79495c4ec93da33aULL, 0xe7175850a43ccaedULL, 0x0b2bc2a163de1bf2ULL}}}};
+
+/* ---------------- Fr (scalar field) Montgomery <-> canonical: Fr::into_bigint / from ---------------- */
+static const uint64_t FR_MOD[4] = {0xffffffff00000001ULL, 0x53bda402fffe5bfeULL, 0x3339d80809a1d805ULL, 0x73eda753299d7d48ULL};
+static const uint64_t FR_R2[4]  = {0xc999e990f3f29c6dULL, 0x2b6cedcb87925c23ULL, 0x05d314967254398fULL, 0x0748d9d99f59ff11ULL};
+static const uint64_t FR_INV = 0xfffffffeffffffffULL;
+static void fr_mont_mul(uint64_t r[4], const uint64_t a[4], const uint64_t b[4]) {
+    uint64_t t[6] = {0};
+    for (int i = 0; i < 4; i++) {
+        uint64_t c = 0; u128 s;
+        for (int j = 0; j < 4; j++) { s = (u128)a[j] * b[i] + t[j] + c; t[j] = (uint64_t)s; c = (uint64_t)(s >> 64); }
+        s = (u128)t[4] + c; t[4] = (uint64_t)s; t[5] = (uint64_t)(s >> 64);
+        uint64_t m = t[0] * FR_INV;
+        s = (u128)m * FR_MOD[0] + t[0]; c = (uint64_t)(s >> 64);
+        for (int j = 1; j < 4; j++) { s = (u128)m * FR_MOD[j] + t[j] + c; t[j - 1] = (uint64_t)s; c = (uint64_t)(s >> 64); }
+        s = (u128)t[4] + c; t[3] = (uint64_t)s; t[4] = t[5] + (uint64_t)(s >> 64);
+    }
+    int ge = t[4] != 0;
+    if (!ge) { ge = 1; for (int i = 3; i >= 0; i--) { if (t[i] > FR_MOD[i]) break; if (t[i] < FR_MOD[i]) { ge = 0; break; } } }
+    if (ge) { uint64_t br = 0; for (int i = 0; i < 4; i++) { u128 d = (u128)t[i] - FR_MOD[i] - br; t[i] = (uint64_t)d; br = (uint64_t)(d >> 64) & 1; } }
+    for (int i = 0; i < 4; i++) r[i] = t[i];
+}
+
+/* ---------------- Frobenius on Fp12 (coefficients derived, not copied) ---------------- */
+static fp2 FROB1[6];   /* xi^(i (p-1)/6) */
+static fp  FROB2[6];   /* xi^(i (p^2-1)/6) = norm(FROB1[i]) in Fp */
+static pthread_once_t frob_once = PTHREAD_ONCE_INIT;
+static void frob_init(void) {
+    fp2 xi; xi.c0 = FP_ONE; xi.c1 = FP_ONE;
+    fp2 g; fp2_pow(&g, &xi, FP_PM1_6, 6);
+    fp2_one(&FROB1[0]);
+    for (int i = 1; i < 6; i++) fp2_mul(&FROB1[i], &FROB1[i - 1], &g);
+    for (int i = 0; i < 6; i++) { fp a, b; fp_sqr(&a, &FROB1[i].c0); fp_sqr(&b, &FROB1[i].c1); fp_add(&FROB2[i], &a, &b); }
+}
+static void fp12_frob1(fp12 *r, const fp12 *a) {
+    pthread_once(&frob_once, frob_init);
+    fp12 t;
+    fp2_conj(&t.c0.c0, &a->c0.c0);
+    fp2_conj(&t.c0.c1, &a->c0.c1); fp2_mul(&t.c0.c1, &t.c0.c1, &FROB1[2]);
+    fp2_conj(&t.c0.c2, &a->c0.c2); fp2_mul(&t.c0.c2, &t.c0.c2, &FROB1[4]);
+    fp2_conj(&t.c1.c0, &a->c1.c0); fp2_mul(&t.c1.c0, &t.c1.c0, &FROB1[1]);
+    fp2_conj(&t.c1.c1, &a->c1.c1); fp2_mul(&t.c1.c1, &t.c1.c1, &FROB1[3]);
+    fp2_conj(&t.c1.c2, &a->c1.c2); fp2_mul(&t.c1.c2, &t.c1.c2, &FROB1[5]);
+    *r = t;
+}
+static void fp12_frob2(fp12 *r, const fp12 *a) {
+    pthread_once(&frob_once, frob_init);
+    fp12 t;
+    t.c0.c0 = a->c0.c0;
+    fp2_mul_fp(&t.c0.c1, &a->c0.c1, &FROB2[2]);
+    fp2_mul_fp(&t.c0.c2, &a->c0.c2, &FROB2[4]);
+    fp2_mul_fp(&t.c1.c0, &a->c1.c0, &FROB2[1]);
+    fp2_mul_fp(&t.c1.c1, &a->c1.c1, &FROB2[3]);
+    fp2_mul_fp(&t.c1.c2, &a->c1.c2, &FROB2[5]);
+    *r = t;
+}
+
+/* ---------------- Miller loop (A.3) ---------------- */
+#define X_ABS 0xd201000000010000ULL
+#define N_COEFF 68
+typedef struct { fp2 c0, c1, c2; } ell_coeff;
+
+static fp TWO_INV;
+static fp2 B_TWIST;
+static pthread_once_t ml_once = PTHREAD_ONCE_INIT;
+static void ml_init(void) {
+    fp two; fp_add(&two, &FP_ONE, &FP_ONE); fp_inv(&TWO_INV, &two);
+    fp four; fp_add(&four, &two, &two); B_TWIST.c0 = four; B_TWIST.c1 = four;
+}
+static void dbl_step(fp2 R[3], ell_coeff *co) {
+    fp2 a, b, c, e, f, g, h, i, j, e2, t;
+    fp2_mul(&a, &R[0], &R[1]); fp2_mul_fp(&a, &a, &TWO_INV);
+    fp2_sqr(&b, &R[1]); fp2_sqr(&c, &R[2]);
+    fp2_dbl(&t, &c); fp2_add(&t, &t, &c); fp2_mul(&e, &B_TWIST, &t);
+    fp2_dbl(&f, &e); fp2_add(&f, &f, &e);
+    fp2_add(&g, &b, &f); fp2_mul_fp(&g, &g, &TWO_INV);
+    fp2_add(&h, &R[1], &R[2]); fp2_sqr(&h, &h); fp2_add(&t, &b, &c); fp2_sub(&h, &h, &t);
+    fp2_sub(&i, &e, &b);
+    fp2_sqr(&j, &R[0]);
+    fp2_sqr(&e2, &e);
+    fp2_sub(&t, &b, &f); fp2_mul(&R[0], &a, &t);
+    fp2_sqr(&g, &g); fp2_dbl(&t, &e2); fp2_add(&t, &t, &e2); fp2_sub(&R[1], &g, &t);
+    fp2_mul(&R[2], &b, &h);
+    co->c0 = i; fp2_dbl(&t, &j); fp2_add(&co->c1, &t, &j); fp2_neg(&co->c2, &h);
+}
+static void add_step(fp2 R[3], const g2_aff *Q, ell_coeff *co) {
+    fp2 theta, lam, c, d, e, f, g, h, j, t, u;
+    fp2_mul(&t, &Q->y, &R[2]); fp2_sub(&theta, &R[1], &t);
+    fp2_mul(&t, &Q->x, &R[2]); fp2_sub(&lam, &R[0], &t);
+    fp2_sqr(&c, &theta); fp2_sqr(&d, &lam); fp2_mul(&e, &lam, &d);
+    fp2_mul(&f, &R[2], &c); fp2_mul(&g, &R[0], &d);
+    fp2_add(&h, &e, &f); fp2_dbl(&t, &g); fp2_sub(&h, &h, &t);
+    fp2_sub(&t, &g, &h); fp2_mul(&t, &theta, &t); fp2_mul(&u, &e, &R[1]);
+    fp2_mul(&R[0], &lam, &h);
+    fp2_sub(&R[1], &t, &u);
+    fp2_mul(&R[2], &R[2], &e);
+    fp2_mul(&t, &theta, &Q->x); fp2_mul(&u, &lam, &Q->y); fp2_sub(&j, &t, &u);
+    co->c0 = j; fp2_neg(&co->c1, &theta); co->c2 = lam;
+}
+static void g2_prepare(const g2_aff *Q, ell_coeff out[N_COEFF]) {
+    pthread_once(&ml_once, ml_init);
+    fp2 R[3]; R[0] = Q->x; R[1] = Q->y; fp2_one(&R[2]);
+    int k = 0;
+    for (int i = 62; i >= 0; i--) {
+        dbl_step(R, &out[k++]);
+        if ((X_ABS >> i) & 1) add_step(R, Q, &out[k++]);
+    }
+}
+static void ell(fp12 *f, const ell_coeff *co, const g1_aff *P) {
+    fp2 c1, c2; fp2_mul_fp(&c1, &co->c1, &P->x); fp2_mul_fp(&c2, &co->c2, &P->y);
+    fp12_mul_by_014(f, &co->c0, &c1, &c2);
+}
+/* one rayon chunk (<= 4 pairs) of ark-ec's multi_miller_loop, without the final conjugation */
+static void miller_chunk(fp12 *f, const g1_aff *ps, const ell_coeff *coeffs, size_t m) {
+    fp12_one(f);
+    int k = 0;
+    for (int i = 62; i >= 0; i--) {
+        fp12_sqr(f, f);
+        for (size_t j = 0; j < m; j++) ell(f, &coeffs[j * N_COEFF + k], &ps[j]);
+        k++;
+        if ((X_ABS >> i) & 1) { for (size_t j = 0; j < m; j++) ell(f, &coeffs[j * N_COEFF + k], &ps[j]); k++; }
+    }
+}
+typedef struct { const g1_aff *ps; const ell_coeff *co; size_t m; fp12 *partial; volatile int *next; int nchunks; } ml_job;
+static void *ml_worker(void *arg) {
+    ml_job *J = (ml_job *)arg;
+    for (;;) {
+        int ch = __sync_fetch_and_add(J->next, 1); if (ch >= J->nchunks) break;
+        size_t lo = (size_t)ch * 4, hi = lo + 4 > J->m ? J->m : lo + 4;
+        miller_chunk(&J->partial[ch], J->ps + lo, J->co + lo * N_COEFF, hi - lo);
+    }
+    return NULL;
+}
+static void cyclo_exp_x(fp12 *r, const fp12 *a) {   /* a^|x| then conj (x < 0) */
+    fp12 acc; fp12_one(&acc);
+    for (int i = 63; i >= 0; i--) { fp12_sqr(&acc, &acc); if ((X_ABS >> i) & 1) fp12_mul(&acc, &acc, a); }
+    fp12_conj(r, &acc);
+}
+
+/* ======================= exported C API (ctypes) ======================= */
+#define API __attribute__((visibility("default")))
+
+API void orc_fp_to_mont(const uint64_t *in, uint64_t *out, size_t n) { for (size_t i = 0; i < n; i++) fp_to_mont((fp *)(out + 6 * i), (const fp *)(in + 6 * i)); }
+API void orc_fp_from_mont(const uint64_t *in, uint64_t *out, size_t n) { for (size_t i = 0; i < n; i++) fp_from_mont((fp *)(out + 6 * i), (const fp *)(in + 6 * i)); }
+API void orc_fr_to_mont(const uint64_t *in, uint64_t *out, size_t n) { for (size_t i = 0; i < n; i++) fr_mont_mul(out + 4 * i, in + 4 * i, FR_R2); }
+API void orc_fr_from_mont(const uint64_t *in, uint64_t *out, size_t n) { uint64_t one[4] = {1, 0, 0, 0}; for (size_t i = 0; i < n; i++) fr_mont_mul(out + 4 * i, in + 4 * i, one); }
+API int  orc_window_c(size_t n) { return ark_window_c(n); }
+API void orc_make_digits(const uint64_t *s, int c, int64_t *out) { ark_make_digits(out, s, c, 255); }
+
+/* SplitMix64 scalar stream, identical to bls12_381_model.SplitMix64.scalar() */
+static uint64_t sm64(uint64_t *s) { uint64_t z = (*s += 0x9E3779B97F4A7C15ULL); z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL; z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL; return z ^ (z >> 31); }
+static void rand_scalar(uint64_t *st, uint64_t out[4]) {
+    for (;;) {
+        for (int i = 0; i < 4; i++) out[i] = sm64(st);
+        out[3] &= 0x7fffffffffffffffULL;
+        int lt = 0; for (int i = 3; i >= 0; i--) { if (out[i] < FR_MOD[i]) { lt = 1; break; } if (out[i] > FR_MOD[i]) break; }
+        if (lt) return;
+    }
+}
+API void orc_rand_scalars(uint64_t seed, size_t n, uint64_t *out) { uint64_t st = seed; for (size_t i = 0; i < n; i++) rand_scalar(&st, out + 4 * i); }
+
+/* ---- G1 ---- */
+API void orc_g1_generator(uint64_t out[12]) { memcpy(out, &G1_GEN, 96); }
+API void orc_g1_msm(const uint64_t *bases, const uint8_t *inf, const uint64_t *scalars, size_t n, int threads, uint64_t out[18]) {
+    g1_msm_bigint((g1_jac *)out, (const g1_aff *)bases, inf, scalars, n, threads);
+}
+API int orc_g1_to_affine(const uint64_t in[18], uint64_t out[12]) { return g1_to_affine((g1_aff *)out, (const g1_jac *)in); }
+API void orc_g1_mul(const uint64_t base[12], int inf, const uint64_t k[4], uint64_t out[18]) { g1_mul((g1_jac *)out, (const g1_aff *)base, inf, k); }
+API void orc_g1_add(const uint64_t a[18], const uint64_t b[18], uint64_t out[18]) { g1_jac r; g1_add(&r, (const g1_jac *)a, (const g1_jac *)b); memcpy(out, &r, sizeof r); }
+API int orc_g1_on_curve(const uint64_t xy[12]) {
+    const g1_aff *p = (const g1_aff *)xy; fp l, r, four;
+    fp_sqr(&l, &p->y); fp_sqr(&r, &p->x); fp_mul(&r, &r, &p->x);
+    fp_add(&four, &FP_ONE, &FP_ONE); fp_add(&four, &four, &four); fp_add(&r, &r, &four);
+    return fp_eq(&l, &r);
+}
+/* ---- G2 ---- */
+API void orc_g2_generator(uint64_t out[24]) { memcpy(out, &G2_GEN, 192); }
+API void orc_g2_msm(const uint64_t *bases, const uint8_t *inf, const uint64_t *scalars, size_t n, int threads, uint64_t out[36]) {
+    g2_msm_bigint((g2_jac *)out, (const g2_aff *)bases, inf, scalars, n, threads);
+}
+API int orc_g2_to_affine(const uint64_t in[36], uint64_t out[24]) { return g2_to_affine((g2_aff *)out, (const g2_jac *)in); }
+API void orc_g2_mul(const uint64_t base[24], int inf, const uint64_t k[4], uint64_t out[36]) { g2_mul((g2_jac *)out, (const g2_aff *)base, inf, k); }
+API void orc_g2_add(const uint64_t a[36], const uint64_t b[36], uint64_t out[36]) { g2_jac r; g2_add(&r, (const g2_jac *)a, (const g2_jac *)b); memcpy(out, &r, sizeof r); }
+API int orc_g2_on_curve(const uint64_t xy[24]) {
+    pthread_once(&ml_once, ml_init);
+    const g2_aff *p = (const g2_aff *)xy; fp2 l, r;
+    fp2_sqr(&l, &p->y); fp2_sqr(&r, &p->x); fp2_mul(&r, &r, &p->x); fp2_add(&r, &r, &B_TWIST);
+    return fp2_eq(&l, &r);
+}
+
+/* ---- synthetic bases with known discrete logs: P_i = (k0 + i*d) * G, chunk-parallel ---- */
+typedef struct { int g2; uint64_t k0[4], d[4]; size_t lo, hi; uint64_t *out; } gen_job;
+static void fr_add_mod(uint64_t r[4], const uint64_t a[4], const uint64_t b[4]) {
+    uint64_t c = 0; uint64_t t[4];
+    for (int i = 0; i < 4; i++) { u128 s = (u128)a[i] + b[i] + c; t[i] = (uint64_t)s; c = (uint64_t)(s >> 64); }
+    int ge = 1; for (int i = 3; i >= 0; i--) { if (t[i] > FR_MOD[i]) break; if (t[i] < FR_MOD[i]) { ge = 0; break; } }
+    if (c || ge) { uint64_t br = 0; for (int i = 0; i < 4; i++) { u128 dd = (u128)t[i] - FR_MOD[i] - br; t[i] = (uint64_t)dd; br = (uint64_t)(dd >> 64) & 1; } }
+    memcpy(r, t, 32);
+}
+static void fr_mul_small(uint64_t r[4], const uint64_t a[4], uint64_t k) {   /* a*k mod r via double-and-add */
+    uint64_t acc[4] = {0, 0, 0, 0}, b[4]; memcpy(b, a, 32);
+    while (k) { if (k & 1) fr_add_mod(acc, acc, b); fr_add_mod(b, b, b); k >>= 1; }
+    memcpy(r, acc, 32);
+}
+static void *gen_worker(void *arg) {
+    gen_job *J = (gen_job *)arg;
+    size_t n = J->hi - J->lo; if (!n) return NULL;
+    uint64_t ks[4], t[4]; fr_mul_small(t, J->d, J->lo); fr_add_mod(ks, J->k0, t);
+    if (!J->g2) {
+        g1_jac *pts = (g1_jac *)malloc(sizeof(g1_jac) * n); g1_jac D; g1_aff Da;
+        g1_mul(&pts[0], &G1_GEN, 0, ks); g1_mul(&D, &G1_GEN, 0, J->d); g1_to_affine(&Da, &D);
+        for (size_t i = 1; i < n; i++) g1_madd(&pts[i], &pts[i - 1], &Da);
+        g1_batch_to_affine((g1_aff *)(J->out + 12 * J->lo), NULL, pts, n); free(pts);
+    } else {
+        g2_jac *pts = (g2_jac *)malloc(sizeof(g2_jac) * n); g2_jac D; g2_aff Da;
+        g2_mul(&pts[0], &G2_GEN, 0, ks); g2_mul(&D, &G2_GEN, 0, J->d); g2_to_affine(&Da, &D);
+        for (size_t i = 1; i < n; i++) g2_madd(&pts[i], &pts[i - 1], &Da);
+        g2_batch_to_affine((g2_aff *)(J->out + 24 * J->lo), NULL, pts, n); free(pts);
+    }
+    return NULL;
+}
+static void gen_seq(int g2, const uint64_t k0[4], const uint64_t d[4], size_t n, int threads, uint64_t *out) {
+    if (threads < 1) threads = 1; if (threads > 64) threads = 64;
+    gen_job jobs[64]; pthread_t th[64];
+    size_t per = (n + threads - 1) / threads;
+    for (int t = 0; t < threads; t++) {
+        jobs[t].g2 = g2; memcpy(jobs[t].k0, k0, 32); memcpy(jobs[t].d, d, 32);
+        jobs[t].lo = per * t > n ? n : per * t; jobs[t].hi = per * (t + 1) > n ? n : per * (t + 1); jobs[t].out = out;
+        pthread_create(&th[t], NULL, gen_worker, &jobs[t]);
+    }
+    for (int t = 0; t < threads; t++) pthread_join(th[t], NULL);
+}
+/* P_i = (k0 + i d) G1 (no identity unless k0 + i d == 0 mod r, which the callers avoid) */
+API void orc_g1_gen_seq(const uint64_t k0[4], const uint64_t d[4], size_t n, int threads, uint64_t *out_xy) { gen_seq(0, k0, d, n, threads, out_xy); }
+API void orc_g2_gen_seq(const uint64_t k0[4], const uint64_t d[4], size_t n, int threads, uint64_t *out_xy) { gen_seq(1, k0, d, n, threads, out_xy); }
+
+/* ---- pairings ---- */
+API void orc_g2_prepare(const uint64_t q[24], uint64_t *out /* 68*36 u64 */) { g2_prepare((const g2_aff *)q, (ell_coeff *)out); }
+API void orc_fp12_mul(const uint64_t a[72], const uint64_t b[72], uint64_t out[72]) { fp12 r; fp12_mul(&r, (const fp12 *)a, (const fp12 *)b); memcpy(out, &r, sizeof r); }
+API void orc_fp12_one(uint64_t out[72]) { fp12_one((fp12 *)out); }
+API void orc_fp12_pow(const uint64_t a[72], const uint64_t *e, int nl, uint64_t out[72]) {
+    fp12 acc, base = *(const fp12 *)a; fp12_one(&acc);
+    for (int i = 0; i < nl * 64; i++) { if ((e[i / 64] >> (i % 64)) & 1) fp12_mul(&acc, &acc, &base); fp12_sqr(&base, &base); }
+    memcpy(out, &acc, sizeof acc);
+}
+/* E::multi_miller_loop: skip[i] != 0 marks a pair with an identity member (filtered like arkworks does) */
+API void orc_multi_miller_loop(const uint64_t *p, const uint64_t *q, const uint8_t *skip, size_t n, int threads, uint64_t out[72]) {
+    pthread_once(&ml_once, ml_init);
+    g1_aff *ps = (g1_aff *)malloc(sizeof(g1_aff) * (n + 1));
+    ell_coeff *co = (ell_coeff *)malloc(sizeof(ell_coeff) * N_COEFF * (n + 1));
+    size_t m = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (skip && skip[i]) continue;
+        ps[m] = *(const g1_aff *)(p + 12 * i);
+        g2_prepare((const g2_aff *)(q + 24 * i), co + m * N_COEFF);
+        m++;
+    }
+    int nch = (int)((m + 3) / 4);
+    fp12 *partial = (fp12 *)malloc(sizeof(fp12) * (nch + 1));
+    volatile int next = 0;
+    ml_job J = {ps, co, m, partial, &next, nch};
+    if (threads <= 1) ml_worker(&J);
+    else {
+        pthread_t th[64]; if (threads > 64) threads = 64; if (threads > nch) threads = nch > 0 ? nch : 1;
+        for (int t = 0; t < threads; t++) pthread_create(&th[t], NULL, ml_worker, &J);
+        for (int t = 0; t < threads; t++) pthread_join(th[t], NULL);
+    }
+    fp12 f; fp12_one(&f);
+    for (int i = 0; i < nch; i++) fp12_mul(&f, &f, &partial[i]);
+    fp12_conj(&f, &f);   /* x < 0 */
+    memcpy(out, &f, sizeof f);
+    free(partial); free(co); free(ps);
+}
+/* E::final_exponentiation (A.4 chain).  Returns 0 on success, -1 where arkworks returns None (f == 0). */
+API int orc_final_exponentiation(const uint64_t in[72], uint64_t out[72]) {
+    const fp12 *f = (const fp12 *)in;
+    if (fp12_is_zero(f)) return -1;
+    fp12 f1, f2, r, y0, y1, y2;
+    fp12_conj(&f1, f); fp12_inv(&f2, f); fp12_mul(&r, &f1, &f2); f2 = r;
+    fp12_frob2(&r, &r); fp12_mul(&r, &r, &f2);
+    fp12_sqr(&y0, &r);
+    cyclo_exp_x(&y1, &r);
+    fp12_conj(&y2, &r);
+    fp12_mul(&y1, &y1, &y2);
+    cyclo_exp_x(&y2, &y1);
+    fp12_conj(&y1, &y1);
+    fp12_mul(&y1, &y1, &y2);
+    cyclo_exp_x(&y2, &y1);
+    fp12_frob1(&y1, &y1);
+    fp12_mul(&y1, &y1, &y2);
+    fp12_mul(&r, &r, &y0);
+    cyclo_exp_x(&y0, &y1);
+    cyclo_exp_x(&y2, &y0);
+    fp12_frob2(&y0, &y1);
+    fp12_conj(&y1, &y1);
+    fp12_mul(&y1, &y1, &y2);
+    fp12_mul(&y1, &y1, &y0);
+    fp12_mul(&r, &r, &y1);
+    memcpy(out, &r, sizeof r);
+    return 0;
+}

@@ -1,0 +1,10 @@
+"""crypto_amd — MI355X (gfx950) backend for the BLS12-381 MSM / multi-Miller-loop hot path of
+docknetwork/crypto.  The product is the C-ABI library `libdock_gpu.so` (include/dock_gpu.h, built from
+crypto_amd/csrc/); this package is the thin host-side mirror of the reference's call surface
+(`VariableBaseMSM::{msm, msm_unchecked, msm_bigint}`, `utils::pairs::Pairs`) used by tests and bench.py.
+There is no CPU fallback: every call goes through the HIP library and raises if it is missing.
+"""
+from ._native import lib, DockGpuError, build_native  # noqa: F401
+from .msm import (  # noqa: F401
+    G1, G2, msm_bigint, msm_unchecked, msm, Pairs, DeviceBases, DeviceScalars, init, prof,
+)

@@ -1,0 +1,81 @@
+"""ctypes binding of libdock_gpu.so (include/dock_gpu.h).  Fails loudly when the library is absent."""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libdock_gpu.so")
+
+ERR = {0: "DGPU_OK", -1: "DGPU_E_NODEVICE", -2: "DGPU_E_OOM", -3: "DGPU_E_BADARG", -4: "DGPU_E_HIP",
+       -5: "DGPU_E_ZERO", -6: "DGPU_E_TOO_SMALL", -7: "DGPU_E_LENGTH"}
+
+
+class DockGpuError(RuntimeError):
+    def __init__(self, code, what=""):
+        self.code = code
+        msg = ERR.get(code, str(code))
+        try:
+            msg += ": " + lib().dgpu_strerror(code).decode()
+            if code == -4:
+                msg += " (hip error %d)" % lib().dgpu_last_hip_error()
+        except Exception:
+            pass
+        super().__init__("%s %s" % (what, msg))
+
+
+def build_native(jobs=3):
+    """Compile libdock_gpu.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    subprocess.check_call(["make", "-C", os.path.join(_HERE, "csrc"), "-j%d" % jobs], stdout=subprocess.DEVNULL)
+    return _SO
+
+
+_lib = None
+
+# every symbol include/dock_gpu.h declares
+SYMBOLS = [
+    "dgpu_init", "dgpu_shutdown", "dgpu_device_count", "dgpu_strerror", "dgpu_last_hip_error",
+    "dgpu_set_min_gpu_n", "dgpu_set_window_bits",
+    "dgpu_msm_g1", "dgpu_msm_g1_mont", "dgpu_msm_g2", "dgpu_msm_g2_mont",
+    "dgpu_bases_upload_g1", "dgpu_bases_upload_g2", "dgpu_bases_free", "dgpu_scalars_upload", "dgpu_scalars_free",
+    "dgpu_msm_g1_handle", "dgpu_msm_g2_handle", "dgpu_msm_g1_resident", "dgpu_msm_g2_resident",
+    "dgpu_multi_miller_loop", "dgpu_final_exponentiation",
+    "dgpu_prof_enable", "dgpu_prof_reset", "dgpu_prof_read",
+    "dgpu_selftest_fp_mul", "dgpu_selftest_g1_sum",
+]
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            raise ImportError(
+                "crypto_amd: %s is missing — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(there is no CPU fallback)" % _SO)
+        L = C.CDLL(_SO)
+        for s in SYMBOLS:
+            getattr(L, s).restype = C.c_int32
+        L.dgpu_strerror.restype = C.c_char_p
+        L.dgpu_strerror.argtypes = [C.c_int32]
+        L.dgpu_init.argtypes = [C.c_int32]
+        L.dgpu_set_min_gpu_n.argtypes = [C.c_size_t]
+        L.dgpu_set_window_bits.argtypes = [C.c_int32]
+        vp, sz, u64 = C.c_void_p, C.c_size_t, C.c_uint64
+        for name in ("dgpu_msm_g1", "dgpu_msm_g1_mont", "dgpu_msm_g2", "dgpu_msm_g2_mont"):
+            getattr(L, name).argtypes = [vp, vp, vp, sz, vp]
+        for name in ("dgpu_bases_upload_g1", "dgpu_bases_upload_g2"):
+            getattr(L, name).argtypes = [vp, vp, sz, C.POINTER(u64)]
+        L.dgpu_bases_free.argtypes = [u64]
+        L.dgpu_scalars_free.argtypes = [u64]
+        L.dgpu_scalars_upload.argtypes = [vp, sz, C.c_int32, C.POINTER(u64)]
+        for name in ("dgpu_msm_g1_handle", "dgpu_msm_g2_handle"):
+            getattr(L, name).argtypes = [u64, sz, vp, sz, C.c_int32, vp]
+        for name in ("dgpu_msm_g1_resident", "dgpu_msm_g2_resident"):
+            getattr(L, name).argtypes = [u64, sz, u64, sz, sz, vp]
+        L.dgpu_multi_miller_loop.argtypes = [vp, vp, vp, sz, vp]
+        L.dgpu_final_exponentiation.argtypes = [vp, vp]
+        L.dgpu_prof_enable.argtypes = [C.c_int32]
+        L.dgpu_prof_read.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(u64), C.c_int32]
+        L.dgpu_selftest_fp_mul.argtypes = [vp, vp, sz, vp]
+        L.dgpu_selftest_g1_sum.argtypes = [vp, vp, sz, vp]
+        _lib = L
+    return _lib

@@ -1,0 +1,129 @@
+// crypto_amd/csrc/dock_core.hip — lifecycle, handles, error strings and instrumentation of libdock_gpu.so
+// (implements the curve-independent part of include/dock_gpu.h).
+#include "dock_ctx.hpp"
+#include "host_field.hpp"
+
+namespace dock {
+Ctx g;
+
+int choose_c(size_t n) {
+    if (g.window_bits >= 7 && g.window_bits <= 22) return g.window_bits;
+    const char *e = getenv("DGPU_WINDOW_BITS");
+    if (e) { int v = atoi(e); if (v >= 7 && v <= 22) return v; }
+    double best = 1e300; int bc = 7;
+    for (int c = 7; c <= 20; c++) {
+        double W = 255 / c + 1, B = (double)(1u << (c - 1));
+        double cost = (double)n * W + 8.0 * W * B;
+        if (cost < best) { best = cost; bc = c; }
+    }
+    return bc;
+}
+int choose_chunk() {
+    if (g.chunk) return g.chunk;
+    const char *e = getenv("DGPU_CHUNK");
+    if (e) { int v = atoi(e); if (v == 16 || v == 32 || v == 64 || v == 128) return v; }
+    return 64;
+}
+
+int32_t upload_scalars(const uint64_t *h, size_t n, bool mont, uint32_t *d_out) {
+    if (!mont) { HIPCHK(hipMemcpyAsync(d_out, h, n * 32, hipMemcpyHostToDevice, g.stream)); HIPCHK(hipStreamSynchronize(g.stream)); return DGPU_OK; }
+    std::vector<uint64_t> tmp(n * 4);
+    for (size_t i = 0; i < n; i++) hostf::fr_from_mont(&tmp[4 * i], h + 4 * i);   // Fr::into_bigint (ark-ec msm_unchecked does the same on rayon)
+    HIPCHK(hipMemcpyAsync(d_out, tmp.data(), n * 32, hipMemcpyHostToDevice, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    return DGPU_OK;
+}
+
+
+}  // namespace dock
+using namespace dock;
+
+extern "C" {
+
+int32_t dgpu_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; } return n; }
+
+int32_t dgpu_init(int32_t device) {
+    std::lock_guard<std::mutex> lk(g.mu);
+    if (g.ready) return g.device == device ? DGPU_OK : DGPU_E_BADARG;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { (void)hipGetLastError(); return DGPU_E_NODEVICE; }
+    if (device < 0 || device >= n) return DGPU_E_NODEVICE;
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+    g.device = device; g.ready = true;
+    return DGPU_OK;
+}
+
+int32_t dgpu_shutdown(void) {
+    std::lock_guard<std::mutex> lk(g.mu);
+    if (!g.ready) return DGPU_OK;
+    (void)hipSetDevice(g.device);
+    (void)hipStreamSynchronize(g.stream);
+    for (auto &h : g.handles) (void)hipFree(h.second.p);
+    g.handles.clear();
+    Buf *bufs[] = {&g.in_bases, &g.in_inf, &g.in_scalars, &g.prepped, &g.cnt, &g.off, &g.cursor, &g.bsums, &g.entries, &g.bucket, &g.bucket_inf, &g.head, &g.tail, &g.head_b, &g.tail_b, &g.part_inf, &g.l1, &g.l1_inf, &g.win, &g.win_inf};
+    for (Buf *b : bufs) b->release();
+    for (hipEvent_t e : g.ev_pool) (void)hipEventDestroy(e);
+    g.ev_pool.clear(); g.prof_tab.clear();
+    (void)hipStreamDestroy(g.stream);
+    g.stream = nullptr; g.ready = false; g.device = -1;
+    return DGPU_OK;
+}
+
+const char *dgpu_strerror(int32_t code) {
+    switch (code) {
+        case DGPU_OK: return "ok";
+        case DGPU_E_NODEVICE: return "no usable HIP device (dgpu_init not called or failed)";
+        case DGPU_E_OOM: return "out of memory";
+        case DGPU_E_BADARG: return "bad argument";
+        case DGPU_E_HIP: return "HIP runtime error";
+        case DGPU_E_ZERO: return "final exponentiation of zero";
+        case DGPU_E_TOO_SMALL: return "n below the GPU threshold";
+        case DGPU_E_LENGTH: return "length mismatch";
+        default: return "unknown error";
+    }
+}
+int32_t dgpu_last_hip_error(void) { return g.last_hip.load(); }
+int32_t dgpu_set_min_gpu_n(size_t n) { g.min_gpu_n = n; return DGPU_OK; }
+int32_t dgpu_set_window_bits(int32_t c) { if (c != 0 && (c < 7 || c > 22)) return DGPU_E_BADARG; g.window_bits = c; return DGPU_OK; }
+
+
+static int32_t free_handle(uint64_t h, bool scalars) {
+    std::lock_guard<std::mutex> lk(g.mu);
+    auto it = g.handles.find(h);
+    if (it == g.handles.end() || ((it->second.kind == 3) != scalars)) return DGPU_E_BADARG;
+    if (g.ready) { (void)hipSetDevice(g.device); (void)hipStreamSynchronize(g.stream); }
+    (void)hipFree(it->second.p);
+    g.handles.erase(it);
+    return DGPU_OK;
+}
+int32_t dgpu_bases_free(uint64_t h) { return free_handle(h, false); }
+int32_t dgpu_scalars_free(uint64_t h) { return free_handle(h, true); }
+int32_t dgpu_scalars_upload(const uint64_t *s, size_t n, int32_t mont, uint64_t *handle) {
+    if (!handle || (n && !s)) return DGPU_E_BADARG;
+    std::lock_guard<std::mutex> lk(g.mu);
+    if (!g.ready) return DGPU_E_NODEVICE;
+    HIPCHK(hipSetDevice(g.device));
+    void *p = nullptr;
+    if (hipMalloc(&p, std::max<size_t>(n, 1) * 32) != hipSuccess) { (void)hipGetLastError(); return DGPU_E_OOM; }
+    int32_t rc = n ? upload_scalars(s, n, mont != 0, (uint32_t *)p) : DGPU_OK;
+    if (rc) { (void)hipFree(p); return rc; }
+    uint64_t h = g.next_handle++;
+    g.handles[h] = Handle{p, n, 3};
+    *handle = h;
+    return DGPU_OK;
+}
+
+int32_t dgpu_multi_miller_loop(const uint64_t *, const uint64_t *, const uint8_t *, size_t, uint64_t *) { return DGPU_E_NODEVICE; }   // next milestone (K7)
+int32_t dgpu_final_exponentiation(const uint64_t *, uint64_t *) { return DGPU_E_NODEVICE; }
+
+int32_t dgpu_prof_enable(int32_t on) { std::lock_guard<std::mutex> lk(g.mu); g.prof = on != 0; return DGPU_OK; }
+int32_t dgpu_prof_reset(void) { std::lock_guard<std::mutex> lk(g.mu); g.prof_tab.clear(); return DGPU_OK; }
+int32_t dgpu_prof_read(const char **names, double *total_ms, uint64_t *calls, int32_t cap) {
+    std::lock_guard<std::mutex> lk(g.mu);
+    int32_t k = 0;
+    for (auto &t : g.prof_tab) { if (k >= cap) break; names[k] = t.name; total_ms[k] = t.ms; calls[k] = t.calls; k++; }
+    return k;
+}
+
+}  // extern "C"

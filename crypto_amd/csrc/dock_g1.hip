@@ -1,0 +1,43 @@
+// crypto_amd/csrc/dock_g1.hip — BLS12-381 G1 entry points of include/dock_gpu.h (+ the device self-tests).
+#include "msm_driver.cuh"
+using namespace dock;
+
+extern "C" {
+int32_t dgpu_msm_g1(const uint64_t *b, const uint8_t *inf, const uint64_t *s, size_t n, uint64_t out[18]) { return msm_oneshot<G1, hostf::Fq>(b, inf, s, n, false, out); }
+int32_t dgpu_msm_g1_mont(const uint64_t *b, const uint8_t *inf, const uint64_t *s, size_t n, uint64_t out[18]) { return msm_oneshot<G1, hostf::Fq>(b, inf, s, n, true, out); }
+int32_t dgpu_bases_upload_g1(const uint64_t *b, const uint8_t *inf, size_t n, uint64_t *h) { return bases_upload<G1>(b, inf, n, h, 1); }
+int32_t dgpu_msm_g1_handle(uint64_t b, size_t off, const uint64_t *s, size_t n, int32_t mont, uint64_t out[18]) { return msm_handle<G1, hostf::Fq>(b, off, s, n, mont, out, 1); }
+int32_t dgpu_msm_g1_resident(uint64_t b, size_t boff, uint64_t s, size_t soff, size_t n, uint64_t out[18]) { return msm_resident<G1, hostf::Fq>(b, boff, s, soff, n, out, 1); }
+
+int32_t dgpu_selftest_fp_mul(const uint64_t *a, const uint64_t *b, size_t n, uint64_t *out) {
+    std::lock_guard<std::mutex> lk(g.mu);
+    if (!g.ready) return DGPU_E_NODEVICE;
+    HIPCHK(hipSetDevice(g.device));
+    void *da, *db, *dout;
+    HIPCHK(hipMalloc(&da, n * 48 + 16)); HIPCHK(hipMalloc(&db, n * 48 + 16)); HIPCHK(hipMalloc(&dout, n * 48 + 16));
+    HIPCHK(hipMemcpy(da, a, n * 48, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(db, b, n * 48, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_selftest_fp_mul, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, g.stream, (const uint32_t *)da, (const uint32_t *)db, n, (uint32_t *)dout);
+    HIPCHK(hipStreamSynchronize(g.stream));
+    HIPCHK(hipMemcpy(out, dout, n * 48, hipMemcpyDeviceToHost));
+    (void)hipFree(da); (void)hipFree(db); (void)hipFree(dout);
+    return DGPU_OK;
+}
+int32_t dgpu_selftest_g1_sum(const uint64_t *pts, const uint8_t *neg, size_t n, uint64_t out[18]) {
+    std::lock_guard<std::mutex> lk(g.mu);
+    if (!g.ready) return DGPU_E_NODEVICE;
+    HIPCHK(hipSetDevice(g.device));
+    void *dp, *dn, *dout, *dinf;
+    HIPCHK(hipMalloc(&dp, n * 96 + 16)); HIPCHK(hipMalloc(&dn, n + 16)); HIPCHK(hipMalloc(&dout, 4 * 48)); HIPCHK(hipMalloc(&dinf, 16));
+    HIPCHK(hipMemcpy(dp, pts, n * 96, hipMemcpyHostToDevice));
+    if (neg) HIPCHK(hipMemcpy(dn, neg, n, hipMemcpyHostToDevice)); else HIPCHK(hipMemset(dn, 0, n + 16));
+    hipLaunchKernelGGL(k_selftest_g1_sum, dim3(1), dim3(64), 0, g.stream, (const uint32_t *)dp, (const uint8_t *)dn, n, (uint32_t *)dout, (uint8_t *)dinf);
+    HIPCHK(hipStreamSynchronize(g.stream));
+    uint64_t w[24]; uint8_t inf;
+    HIPCHK(hipMemcpy(w, dout, 4 * 48, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(&inf, dinf, 1, hipMemcpyDeviceToHost));
+    (void)hipFree(dp); (void)hipFree(dn); (void)hipFree(dout); (void)hipFree(dinf);
+    uint8_t finf = inf;
+    host_fold<hostf::Fq>(w, &finf, 1, 1, out);
+    return DGPU_OK;
+}
+
+}  // extern "C"

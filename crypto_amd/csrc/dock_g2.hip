@@ -1,0 +1,11 @@
+// crypto_amd/csrc/dock_g2.hip — BLS12-381 G2 entry points of include/dock_gpu.h.
+#include "msm_driver.cuh"
+using namespace dock;
+
+extern "C" {
+int32_t dgpu_msm_g2(const uint64_t *b, const uint8_t *inf, const uint64_t *s, size_t n, uint64_t out[36]) { return msm_oneshot<G2, hostf::Fq2>(b, inf, s, n, false, out); }
+int32_t dgpu_msm_g2_mont(const uint64_t *b, const uint8_t *inf, const uint64_t *s, size_t n, uint64_t out[36]) { return msm_oneshot<G2, hostf::Fq2>(b, inf, s, n, true, out); }
+int32_t dgpu_bases_upload_g2(const uint64_t *b, const uint8_t *inf, size_t n, uint64_t *h) { return bases_upload<G2>(b, inf, n, h, 2); }
+int32_t dgpu_msm_g2_handle(uint64_t b, size_t off, const uint64_t *s, size_t n, int32_t mont, uint64_t out[36]) { return msm_handle<G2, hostf::Fq2>(b, off, s, n, mont, out, 2); }
+int32_t dgpu_msm_g2_resident(uint64_t b, size_t boff, uint64_t s, size_t soff, size_t n, uint64_t out[36]) { return msm_resident<G2, hostf::Fq2>(b, boff, s, soff, n, out, 2); }
+}  // extern "C"

@@ -1,0 +1,137 @@
+// crypto_amd/csrc/ec29.cuh — short-Weierstrass (a = 0) group law in extended Jacobian "XYZZ"
+// coordinates over the lazy 29-bit-limb fields of fp29.cuh / fp2_29.cuh.
+//
+// Device replacement for ark-ec's Projective += Affine / Projective += Projective used inside
+// VariableBaseMSM (third-party ark-ec 0.4; entered from utils/src/pairs.rs:145-155,
+// legogroth16/src/prover.rs:286,299,592).  XYZZ (x = X/ZZ, y = Y/ZZZ, ZZ^3 = ZZZ^2) costs 8M+2S for a
+// mixed add against 7M+4S Jacobian and needs no inversion; the group element is identical, only the
+// projective representative differs — results are compared after normalisation to affine.
+//
+// The formulas are complete: P == Q falls into a doubling and P == -Q into the identity.  The test is a
+// 3-instruction necessary condition (fp_maybe_zero) with an exact slow path, so the common path stays
+// wave-uniform.  The identity is carried as an explicit flag next to the coordinates.
+#pragma once
+#include "fp29.cuh"
+#include "fp2_29.cuh"
+
+namespace bls29 {
+
+template <class F> struct Aff { F x, y; };
+template <class F> struct Xyzz { F x, y, zz, zzz; };
+
+// value-growth budget of each subtraction (multiples of p); verified by the FP29_CHECK build
+template <class F> struct SubM;
+template <> struct SubM<Fp> {
+    static constexpr int P = 16;   // U2 - X1      (X1 value < 10 p)
+    static constexpr int R = 8;    // S2 - Y1      (Y1 value <  6 p)
+    static constexpr int X = 8;    // RR - (PPP + 2Q)
+    static constexpr int D = 16;   // Q - X3
+    static constexpr int Y = 4;    // R*(Q - X3) - Y1*PPP
+    static constexpr int NEG = 4;  // 0 - y
+};
+template <> struct SubM<Fp2> {     // an Fp2 product leaves values < 6 p, so every budget is one notch wider
+    static constexpr int P = 32;
+    static constexpr int R = 16;
+    static constexpr int X = 16;
+    static constexpr int D = 32;
+    static constexpr int Y = 8;
+    static constexpr int NEG = 4;
+};
+
+// acc := 2 * (x, y) for an affine, non-identity point (mdbl-2008-s-1)
+template <class F> FD void xyzz_dbl_affine(Xyzz<F> &r, const Aff<F> &p) {
+    F U, V, W, S, M, t, X3, Y3;
+    fdbl(U, p.y); fnorm(U, U);
+    fsqr(V, U);
+    fmul(W, U, V);
+    fmul(S, p.x, V);
+    fsqr(M, p.x); fadd(t, M, M); fadd(M, t, M); fnorm(M, M);
+    fsqr(X3, M); fadd(t, S, S); fsub<SubM<F>::X>(X3, X3, t); fnorm(X3, X3);
+    fsub<SubM<F>::D>(t, S, X3); fnorm(t, t);
+    fmul(Y3, M, t); fmul(t, W, p.y); fsub<SubM<F>::Y>(Y3, Y3, t); fnorm(Y3, Y3);
+    r.x = X3; r.y = Y3; r.zz = V; r.zzz = W;
+}
+
+// r := 2 * a (dbl-2008-s-1), a not the identity
+template <class F> FD void xyzz_dbl(Xyzz<F> &r, const Xyzz<F> &a) {
+    F U, V, W, S, M, t, X3, Y3;
+    fdbl(U, a.y); fnorm(U, U);
+    fsqr(V, U);
+    fmul(W, U, V);
+    fmul(S, a.x, V);
+    fsqr(M, a.x); fadd(t, M, M); fadd(M, t, M); fnorm(M, M);
+    fsqr(X3, M); fadd(t, S, S); fsub<SubM<F>::X>(X3, X3, t); fnorm(X3, X3);
+    fsub<SubM<F>::D>(t, S, X3); fnorm(t, t);
+    fmul(Y3, M, t); fmul(t, W, a.y); fsub<SubM<F>::Y>(Y3, Y3, t); fnorm(Y3, Y3);
+    fmul(r.zz, V, a.zz); fmul(r.zzz, W, a.zzz);
+    r.x = X3; r.y = Y3;
+}
+
+// acc += (neg ? -q : q), q affine and not the identity (madd-2008-s).  `inf` is acc's identity flag.
+template <class F> FD void xyzz_madd(Xyzz<F> &acc, bool &inf, const Aff<F> &q_in, bool neg) {
+    Aff<F> q = q_in;
+    if (neg) { F z; fzero(z); fsub<SubM<F>::NEG>(q.y, z, q.y); fnorm(q.y, q.y); }
+    if (inf) { acc.x = q.x; acc.y = q.y; fset_one(acc.zz); fset_one(acc.zzz); inf = false; return; }
+    F U2, S2, Pd, Rd;
+    fmul(U2, q.x, acc.zz);
+    fmul(S2, q.y, acc.zzz);
+    fsub<SubM<F>::P>(Pd, U2, acc.x); fnorm(Pd, Pd);
+    fsub<SubM<F>::R>(Rd, S2, acc.y); fnorm(Rd, Rd);
+    if (fmaybe_zero(Pd)) {
+        if (fis_zero_exact(Pd)) {
+            if (fis_zero_exact(Rd)) xyzz_dbl_affine(acc, q);
+            else inf = true;
+            return;
+        }
+    }
+    F PP, PPP, Q, t, X3, Y3;
+    fsqr(PP, Pd);
+    fmul(PPP, Pd, PP);
+    fmul(Q, acc.x, PP);
+    fsqr(X3, Rd);
+    fadd(t, Q, Q); fadd(t, t, PPP);
+    fsub<SubM<F>::X>(X3, X3, t); fnorm(X3, X3);
+    fsub<SubM<F>::D>(t, Q, X3); fnorm(t, t);
+    fmul(Y3, Rd, t);
+    fmul(t, acc.y, PPP);
+    fsub<SubM<F>::Y>(Y3, Y3, t); fnorm(Y3, Y3);
+    fmul(acc.zz, acc.zz, PP);
+    fmul(acc.zzz, acc.zzz, PPP);
+    acc.x = X3; acc.y = Y3;
+}
+
+// a += b, both XYZZ with identity flags (add-2008-s)
+template <class F> FD void xyzz_add(Xyzz<F> &a, bool &ainf, const Xyzz<F> &b, bool binf) {
+    if (binf) return;
+    if (ainf) { a = b; ainf = false; return; }
+    F U1, U2, S1, S2, Pd, Rd;
+    fmul(U1, a.x, b.zz);
+    fmul(U2, b.x, a.zz);
+    fmul(S1, a.y, b.zzz);
+    fmul(S2, b.y, a.zzz);
+    fsub<SubM<F>::Y>(Pd, U2, U1); fnorm(Pd, Pd);
+    fsub<SubM<F>::Y>(Rd, S2, S1); fnorm(Rd, Rd);
+    if (fmaybe_zero(Pd)) {
+        if (fis_zero_exact(Pd)) {
+            if (fis_zero_exact(Rd)) { Xyzz<F> d; xyzz_dbl(d, a); a = d; }
+            else ainf = true;
+            return;
+        }
+    }
+    F PP, PPP, Q, t, X3, Y3;
+    fsqr(PP, Pd);
+    fmul(PPP, Pd, PP);
+    fmul(Q, U1, PP);
+    fsqr(X3, Rd);
+    fadd(t, Q, Q); fadd(t, t, PPP);
+    fsub<SubM<F>::X>(X3, X3, t); fnorm(X3, X3);
+    fsub<SubM<F>::D>(t, Q, X3); fnorm(t, t);
+    fmul(Y3, Rd, t);
+    fmul(t, S1, PPP);
+    fsub<SubM<F>::Y>(Y3, Y3, t); fnorm(Y3, Y3);
+    fmul(t, a.zz, b.zz); fmul(a.zz, t, PP);
+    fmul(t, a.zzz, b.zzz); fmul(a.zzz, t, PPP);
+    a.x = X3; a.y = Y3;
+}
+
+}  // namespace bls29

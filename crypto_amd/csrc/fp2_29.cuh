@@ -1,0 +1,50 @@
+// crypto_amd/csrc/fp2_29.cuh — Fp2 = Fp[u]/(u^2 + 1) over the lazy 29-bit-limb base field (fp29.cuh).
+// Device counterpart of ark_ff::Fp2<Fq2Config> as used by G2 (ark-bls12-381 0.4; reached from
+// legogroth16/src/prover.rs:344 `b_g2_query` MSM and the Miller loop, utils/src/randomized_pairing_check.rs:207).
+// ABI order of components: c0 then c1.
+#pragma once
+#include "fp29.cuh"
+
+namespace bls29 {
+
+struct Fp2 { Fp c0, c1; };
+
+FD void fzero(Fp2 &r) { fp_zero(r.c0); fp_zero(r.c1); }
+FD void fset_one(Fp2 &r) { fp_set_one(r.c0); fp_zero(r.c1); }
+FD void fadd(Fp2 &r, const Fp2 &a, const Fp2 &b) { fp_add(r.c0, a.c0, b.c0); fp_add(r.c1, a.c1, b.c1); }
+FD void fdbl(Fp2 &r, const Fp2 &a) { fp_add(r.c0, a.c0, a.c0); fp_add(r.c1, a.c1, a.c1); }
+template <int M> FD void fsub(Fp2 &r, const Fp2 &a, const Fp2 &b) { fp_sub<M>(r.c0, a.c0, b.c0); fp_sub<M>(r.c1, a.c1, b.c1); }
+FD void fnorm(Fp2 &r, const Fp2 &a) { fp_norm(r.c0, a.c0); fp_norm(r.c1, a.c1); }
+FD bool fmaybe_zero(const Fp2 &a) { return fp_maybe_zero(a.c0) && fp_maybe_zero(a.c1); }
+FD bool fis_zero_exact(const Fp2 &a) { return fp_is_zero_exact(a.c0) && fp_is_zero_exact(a.c1); }
+
+// Karatsuba, 3 base-field products.  Inputs class N; outputs class N with value < 6 p.
+FD void fmul(Fp2 &r, const Fp2 &a, const Fp2 &b) {
+    Fp t0, t1, t2, sa, sb;
+    fp_mul(t0, a.c0, b.c0);
+    fp_mul(t1, a.c1, b.c1);
+    fp_add(sa, a.c0, a.c1);
+    fp_add(sb, b.c0, b.c1); fp_norm(sb, sb);
+    fp_mul(t2, sa, sb);
+    fp_sub<4>(r.c0, t0, t1); fp_norm(r.c0, r.c0);
+    fp_add(t0, t0, t1);
+    fp_sub<4>(r.c1, t2, t0); fp_norm(r.c1, r.c1);
+}
+// (a0 + a1)(a0 - a1), 2 a0 a1 : 2 base-field products.  Input class N with value < 60 p.
+FD void fsqr(Fp2 &r, const Fp2 &a) {
+    Fp s, d, t;
+    fp_add(s, a.c0, a.c1);
+    fp_sub<64>(d, a.c0, a.c1); fp_norm(d, d);
+    fp_mul(t, a.c0, a.c1);
+    fp_mul(r.c0, s, d);
+    fp_add(r.c1, t, t); fp_norm(r.c1, r.c1);
+}
+// multiply both components by a base-field element (Miller loop line evaluation)
+FD void fmul_fp(Fp2 &r, const Fp2 &a, const Fp &k) { fp_mul(r.c0, a.c0, k); fp_mul(r.c1, a.c1, k); }
+// (a0 + a1 u)(1 + u) = (a0 - a1) + (a0 + a1) u
+template <int M> FD void fmul_xi(Fp2 &r, const Fp2 &a) {
+    Fp t; fp_sub<M>(t, a.c0, a.c1); fp_add(r.c1, a.c0, a.c1); r.c0 = t;
+}
+FD void fneg_c1(Fp2 &r, const Fp2 &a) { Fp z; fp_zero(z); r.c0 = a.c0; fp_sub<64>(r.c1, z, a.c1); }
+
+}  // namespace bls29

@@ -1,0 +1,186 @@
+// crypto_amd/csrc/msm_driver.cuh — host driver of the MSM pipeline (templated on the curve), included by
+// dock_g1.hip and dock_g2.hip so the two curves compile in parallel.
+#pragma once
+#include "dock_ctx.hpp"
+#include "host_field.hpp"
+#include "msm_kernels.cuh"
+
+namespace dock {
+using namespace msm;
+
+// host tail: Horner over window sums (ABI XYZZ form), normalised Jacobian out
+template <class HF>
+void host_fold(const uint64_t *win_abi, const uint8_t *win_inf, int W, int c, uint64_t *out_xyz) {
+    typedef hostf::HXyzz<HF> PT;
+    PT acc = PT::identity();
+    const size_t FWORDS = sizeof(HF) / 8;
+    for (int w = W - 1; w >= 0; w--) {
+        if (!acc.inf) for (int k = 0; k < c; k++) acc.dbl_in_place();
+        if (!win_inf[w]) {
+            PT t; t.inf = false;
+            const uint64_t *src = win_abi + (size_t)w * 4 * FWORDS;
+            memcpy(&t.x, src, sizeof(HF)); memcpy(&t.y, src + FWORDS, sizeof(HF)); memcpy(&t.zz, src + 2 * FWORDS, sizeof(HF)); memcpy(&t.zzz, src + 3 * FWORDS, sizeof(HF));
+            acc.add_in_place(t);
+        }
+    }
+    HF X, Y, Z; acc.to_normalised_jacobian(X, Y, Z);
+    memcpy(out_xyz, &X, sizeof(HF)); memcpy(out_xyz + FWORDS, &Y, sizeof(HF)); memcpy(out_xyz + 2 * FWORDS, &Z, sizeof(HF));
+}
+
+// d_bases: prepared records; d_scalars: canonical 8 x u32 per scalar.  Caller holds g.mu.
+template <class C, class HF>
+int32_t msm_device(const uint32_t *d_bases, const uint32_t *d_scalars, size_t n, uint64_t *out_xyz) {
+    if (n == 0) { typedef hostf::HXyzz<HF> PT; PT id = PT::identity(); HF X, Y, Z; id.to_normalised_jacobian(X, Y, Z);
+        const size_t FWORDS = sizeof(HF) / 8; memcpy(out_xyz, &X, sizeof(HF)); memcpy(out_xyz + FWORDS, &Y, sizeof(HF)); memcpy(out_xyz + 2 * FWORDS, &Z, sizeof(HF)); return DGPU_OK; }
+    if (n >= (1ull << 31)) return DGPU_E_BADARG;
+    const int c = choose_c(n);
+    const int W = 255 / c + 1;
+    const uint32_t B = 1u << (c - 1);
+    if ((uint64_t)W * B >= (1ull << 31) || (uint64_t)n * W >= (1ull << 32)) return DGPU_E_BADARG;
+    const uint32_t NB = (uint32_t)W * B;
+    const int mshift = std::max(0, c - 1 - 12);
+    const int G = (int)(B >> (6 + mshift));          // groups per window (<= 64), B >= 64 because c >= 7
+    const size_t NG = (size_t)W * G;
+    const int CH = choose_chunk();
+    const size_t Emax = (size_t)n * W;
+    const size_t T = (Emax + CH - 1) / CH;
+    const size_t nblk = ((size_t)NB + SCAN_B - 1) / SCAN_B;
+
+    int32_t rc;
+    if ((rc = g.cnt.ensure(((size_t)NB + 1) * 4))) return rc;
+    if ((rc = g.off.ensure(((size_t)NB + 1) * 4))) return rc;
+    if ((rc = g.cursor.ensure(((size_t)NB + 1) * 4))) return rc;
+    if ((rc = g.bsums.ensure((nblk + 2) * 4))) return rc;
+    if ((rc = g.entries.ensure(Emax * 4))) return rc;
+    if ((rc = g.bucket.ensure((size_t)NB * C::XW * 4))) return rc;
+    if ((rc = g.bucket_inf.ensure(NB))) return rc;
+    if ((rc = g.head.ensure(T * C::XW * 4))) return rc;
+    if ((rc = g.tail.ensure(T * C::XW * 4))) return rc;
+    if ((rc = g.head_b.ensure(T * 4))) return rc;
+    if ((rc = g.tail_b.ensure(T * 4))) return rc;
+    if ((rc = g.part_inf.ensure(T * 2))) return rc;
+    if ((rc = g.l1.ensure(NG * 2 * C::XW * 4))) return rc;
+    if ((rc = g.l1_inf.ensure(NG * 2))) return rc;
+    if ((rc = g.win.ensure((size_t)W * 4 * C::ABI_W * 4))) return rc;
+    if ((rc = g.win_inf.ensure(W))) return rc;
+
+    hipStream_t s = g.stream;
+    {
+        StageTimer st("msm.count");
+        HIPCHK(hipMemsetAsync(g.cnt.p, 0, ((size_t)NB + 1) * 4, s));
+        HIPCHK(hipMemsetAsync(g.bucket_inf.p, 1, NB, s));
+        hipLaunchKernelGGL((k_digits<false>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_scalars, d_bases, C::AFF_STRIDE, 2 * C::FW, n, c, W, g.cnt.as<uint32_t>(), (uint32_t *)nullptr);
+    }
+    {
+        StageTimer st("msm.scan");
+        hipLaunchKernelGGL(k_scan_block, dim3((unsigned)nblk), dim3(SCAN_T), 0, s, g.cnt.as<uint32_t>(), g.off.as<uint32_t>(), g.bsums.as<uint32_t>(), (size_t)NB);
+        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, s, g.bsums.as<uint32_t>(), nblk);
+        hipLaunchKernelGGL(k_scan_add, dim3((unsigned)((NB + 1 + 255) / 256)), dim3(256), 0, s, g.off.as<uint32_t>(), g.cursor.as<uint32_t>(), g.bsums.as<uint32_t>(), (size_t)NB, nblk);
+    }
+    {
+        StageTimer st("msm.scatter");
+        hipLaunchKernelGGL((k_digits<true>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_scalars, d_bases, C::AFF_STRIDE, 2 * C::FW, n, c, W, g.cursor.as<uint32_t>(), g.entries.as<uint32_t>());
+    }
+    {
+        StageTimer st("msm.accumulate");
+        hipLaunchKernelGGL((k_accumulate<C>), dim3((unsigned)((T + 255) / 256)), dim3(256), 0, s, d_bases, g.entries.as<uint32_t>(), g.off.as<uint32_t>(), NB, g.bucket.as<uint32_t>(), g.bucket_inf.as<uint8_t>(),
+                           g.head.as<uint32_t>(), g.tail.as<uint32_t>(), g.head_b.as<uint32_t>(), g.tail_b.as<uint32_t>(), g.part_inf.as<uint8_t>(), T, (uint32_t)CH);
+    }
+    {
+        StageTimer st("msm.fixup");
+        hipLaunchKernelGGL((k_fixup<C>), dim3((unsigned)((T + 255) / 256)), dim3(256), 0, s, NB, g.bucket.as<uint32_t>(), g.bucket_inf.as<uint8_t>(), g.head.as<uint32_t>(), g.tail.as<uint32_t>(),
+                           g.head_b.as<uint32_t>(), g.tail_b.as<uint32_t>(), g.part_inf.as<uint8_t>(), T);
+    }
+    {
+        StageTimer st("msm.reduce");
+        hipLaunchKernelGGL((k_reduce_l0<C>), dim3((unsigned)NG), dim3(64), 0, s, g.bucket.as<uint32_t>(), g.bucket_inf.as<uint8_t>(), NB, mshift, g.l1.as<uint32_t>(), g.l1_inf.as<uint8_t>());
+        hipLaunchKernelGGL((k_reduce_top<C>), dim3((unsigned)W), dim3(64), 0, s, g.l1.as<uint32_t>(), g.l1_inf.as<uint8_t>(), G, 6 + mshift, g.win.as<uint32_t>(), g.win_inf.as<uint8_t>());
+    }
+    HIPCHK(hipGetLastError());
+    std::vector<uint64_t> hwin((size_t)W * 2 * C::ABI_W);
+    std::vector<uint8_t> hinf(W);
+    HIPCHK(hipMemcpyAsync(hwin.data(), g.win.p, (size_t)W * 4 * C::ABI_W * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(hinf.data(), g.win_inf.p, W, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (g.prof) prof_flush();
+    host_fold<HF>(hwin.data(), hinf.data(), W, c, out_xyz);
+    return DGPU_OK;
+}
+
+template <class C>
+int32_t prep_bases(const uint64_t *h_bases, const uint8_t *h_inf, size_t n, uint32_t *d_out) {
+    int32_t rc;
+    const size_t bytes = n * 2 * C::ABI_W * 4;
+    if ((rc = g.in_bases.ensure(bytes ? bytes : 16))) return rc;
+    HIPCHK(hipMemcpyAsync(g.in_bases.p, h_bases, bytes, hipMemcpyHostToDevice, g.stream));
+    uint8_t *dinf = nullptr;
+    if (h_inf) { if ((rc = g.in_inf.ensure(n))) return rc; HIPCHK(hipMemcpyAsync(g.in_inf.p, h_inf, n, hipMemcpyHostToDevice, g.stream)); dinf = g.in_inf.as<uint8_t>(); }
+    StageTimer st("msm.prep_bases");
+    hipLaunchKernelGGL((k_prep_bases<C>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, g.stream, g.in_bases.as<uint32_t>(), dinf, n, d_out);
+    return DGPU_OK;
+}
+
+template <class C, class HF>
+int32_t msm_oneshot(const uint64_t *bases, const uint8_t *is_inf, const uint64_t *scalars, size_t n, bool mont, uint64_t *out) {
+    if (!out || (n && (!bases || !scalars))) return DGPU_E_BADARG;
+    if (n < g.min_gpu_n) return DGPU_E_TOO_SMALL;
+    std::lock_guard<std::mutex> lk(g.mu);
+    if (!g.ready) return DGPU_E_NODEVICE;
+    HIPCHK(hipSetDevice(g.device));
+    int32_t rc;
+    if (n) {
+        if ((rc = g.prepped.ensure(n * C::AFF_STRIDE * 4))) return rc;
+        if ((rc = g.in_scalars.ensure(n * 32))) return rc;
+        if ((rc = prep_bases<C>(bases, is_inf, n, g.prepped.as<uint32_t>()))) return rc;
+        if ((rc = upload_scalars(scalars, n, mont, g.in_scalars.as<uint32_t>()))) return rc;
+    }
+    return msm_device<C, HF>(g.prepped.as<uint32_t>(), g.in_scalars.as<uint32_t>(), n, out);
+}
+
+template <class C>
+int32_t bases_upload(const uint64_t *bases, const uint8_t *is_inf, size_t n, uint64_t *handle, int kind) {
+    if (!handle || (n && !bases)) return DGPU_E_BADARG;
+    std::lock_guard<std::mutex> lk(g.mu);
+    if (!g.ready) return DGPU_E_NODEVICE;
+    HIPCHK(hipSetDevice(g.device));
+    void *p = nullptr;
+    if (hipMalloc(&p, std::max<size_t>(n, 1) * C::AFF_STRIDE * 4) != hipSuccess) { (void)hipGetLastError(); return DGPU_E_OOM; }
+    int32_t rc = n ? prep_bases<C>(bases, is_inf, n, (uint32_t *)p) : DGPU_OK;
+    if (rc == DGPU_OK && hipStreamSynchronize(g.stream) != hipSuccess) rc = DGPU_E_HIP;
+    if (rc) { (void)hipFree(p); return rc; }
+    uint64_t h = g.next_handle++;
+    g.handles[h] = Handle{p, n, kind};
+    *handle = h;
+    return DGPU_OK;
+}
+
+template <class C, class HF>
+int32_t msm_handle(uint64_t bases, size_t offset, const uint64_t *scalars, size_t n, int mont, uint64_t *out, int kind) {
+    if (!out || (n && !scalars)) return DGPU_E_BADARG;
+    if (n < g.min_gpu_n) return DGPU_E_TOO_SMALL;
+    std::lock_guard<std::mutex> lk(g.mu);
+    if (!g.ready) return DGPU_E_NODEVICE;
+    auto it = g.handles.find(bases);
+    if (it == g.handles.end() || it->second.kind != kind || offset > it->second.n || n > it->second.n - offset) return DGPU_E_BADARG;
+    HIPCHK(hipSetDevice(g.device));
+    int32_t rc;
+    if ((rc = g.in_scalars.ensure(std::max<size_t>(n, 1) * 32))) return rc;
+    if (n && (rc = upload_scalars(scalars, n, mont != 0, g.in_scalars.as<uint32_t>()))) return rc;
+    return msm_device<C, HF>((const uint32_t *)it->second.p + offset * C::AFF_STRIDE, g.in_scalars.as<uint32_t>(), n, out);
+}
+
+template <class C, class HF>
+int32_t msm_resident(uint64_t bases, size_t boff, uint64_t scalars, size_t soff, size_t n, uint64_t *out, int kind) {
+    if (!out) return DGPU_E_BADARG;
+    if (n < g.min_gpu_n) return DGPU_E_TOO_SMALL;
+    std::lock_guard<std::mutex> lk(g.mu);
+    if (!g.ready) return DGPU_E_NODEVICE;
+    auto ib = g.handles.find(bases), is = g.handles.find(scalars);
+    if (ib == g.handles.end() || is == g.handles.end() || ib->second.kind != kind || is->second.kind != 3) return DGPU_E_BADARG;
+    if (boff > ib->second.n || n > ib->second.n - boff || soff > is->second.n || n > is->second.n - soff) return DGPU_E_BADARG;
+    HIPCHK(hipSetDevice(g.device));
+    return msm_device<C, HF>((const uint32_t *)ib->second.p + boff * C::AFF_STRIDE, (const uint32_t *)is->second.p + soff * 8, n, out);
+}
+
+
+}  // namespace dock

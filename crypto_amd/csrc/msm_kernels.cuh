@@ -1,0 +1,371 @@
+// crypto_amd/csrc/msm_kernels.cuh — Pippenger bucket MSM for gfx950, written for the chip rather than
+// translated from arkworks' rayon loop (ark-ec 0.4 VariableBaseMSM::msm_bigint_wnaf; the
+// reference enters it at utils/src/pairs.rs:145-155 and legogroth16/src/prover.rs:286,299,592).
+//
+// arkworks parallelises over the ~17 windows only.  Here every (window, bucket) pair of all windows is one
+// flat key space and the work is cut into equal chunks of the key-sorted term list, so all 256 CUs stay
+// busy whatever the scalar distribution:
+//
+//   K1 prep_bases   ABI affine (2^384 Montgomery, 32-bit words) -> 128 B / 256 B records of 29-bit limbs
+//   K2 count        signed radix-2^c digits of every scalar; histogram of (window, |digit|-1) keys
+//   K3 scan         exclusive prefix sum of the histogram (3 small kernels)
+//   K4 scatter      second digit pass: term index (+ sign bit) written at its key's cursor  (counting sort)
+//   K5 accumulate   thread t owns terms [t*CH, (t+1)*CH) of the sorted list: mixed XYZZ additions, runs that
+//                   lie inside the chunk go straight to the bucket array, the (at most two) runs cut by a
+//                   chunk border go to head/tail partial slots
+//   K6 fixup        one thread per cut bucket folds its partials
+//   K7 reduce       sum_k k*B_k per window: 2^s buckets serial per lane, then a wave64 suffix scan (shuffles)
+//   K8 reduce_top   one wave per window folds the group results
+//   host            Horner over the <= 64 window sums + normalisation (host_field.hpp)
+//
+// Any c, any chunking and any order of additions give the same group element; only the projective
+// representative differs, and the ABI returns the normalised one.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "fp29.cuh"
+#include "fp2_29.cuh"
+#include "ec29.cuh"
+
+namespace msm {
+using namespace bls29;
+
+#ifndef ACC_WAVES
+#define ACC_WAVES 3   // min waves/SIMD requested for the accumulate kernel (caps VGPRs at 168)
+#endif
+
+// ---- curve descriptions -------------------------------------------------------------------------
+struct G1 {
+    typedef Fp F;
+    static constexpr int FW = NL;            // u32 words per coordinate (device form)
+    static constexpr int ABI_W = 12;         // u32 words per Fp in the ABI
+    static constexpr int NFP = 1;            // Fp components per coordinate
+    static constexpr int AFF_STRIDE = 32;    // u32 per prepared base record (128 B): x[14] y[14] flag pad[3]
+    static constexpr int XW = 4 * FW;        // u32 per XYZZ point
+};
+struct G2 {
+    typedef Fp2 F;
+    static constexpr int FW = 2 * NL;
+    static constexpr int ABI_W = 24;
+    static constexpr int NFP = 2;
+    static constexpr int AFF_STRIDE = 64;    // 256 B: x[28] y[28] flag pad[7]
+    static constexpr int XW = 4 * FW;
+};
+
+template <class F> __device__ __forceinline__ uint32_t *limbs(F &f) { return reinterpret_cast<uint32_t *>(&f); }
+template <class F> __device__ __forceinline__ const uint32_t *limbs(const F &f) { return reinterpret_cast<const uint32_t *>(&f); }
+
+// ---- K1: base preparation ------------------------------------------------------------------------
+template <class C>
+__global__ void __launch_bounds__(256) k_prep_bases(const uint32_t *__restrict__ abi, const uint8_t *__restrict__ is_inf, size_t n, uint32_t *__restrict__ out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t *src = abi + i * (2 * C::ABI_W);
+    uint32_t w[2 * C::ABI_W];
+    uint32_t any = 0;
+#pragma unroll
+    for (int k = 0; k < 2 * C::ABI_W; k += 4) {
+        uint4 v = *reinterpret_cast<const uint4 *>(src + k);
+        w[k] = v.x; w[k + 1] = v.y; w[k + 2] = v.z; w[k + 3] = v.w;
+        any |= v.x | v.y | v.z | v.w;
+    }
+    uint32_t flag = (any == 0) ? 1u : 0u;
+    if (is_inf && is_inf[i]) flag = 1u;
+    uint32_t *dst = out + i * C::AFF_STRIDE;
+#pragma unroll
+    for (int k = 0; k < 2 * C::NFP; k++) {
+        Fp f; fp_from_abi(f, w + 12 * k);
+#pragma unroll
+        for (int j = 0; j < NL; j++) dst[k * NL + j] = f.l[j];
+    }
+    dst[2 * C::FW] = flag;
+}
+
+// ---- digits ----------------------------------------------------------------------------------------
+// Window w covers scalar bits [w c, w c + c); W = 255 / c + 1 windows, so the top window holds fewer than c
+// bits and never carries out.  digit in [-(B-1), B], B = 2^(c-1): magnitude-1 is the bucket index.
+
+template <bool SCATTER>
+__global__ void __launch_bounds__(256) k_digits(const uint32_t *__restrict__ scalars, const uint32_t *__restrict__ bases, int aff_stride, int flag_word,
+                                                size_t n, int c, int W, uint32_t *__restrict__ cnt_or_cursor, uint32_t *__restrict__ entries) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (bases[i * (size_t)aff_stride + flag_word]) return;   // identity base contributes nothing
+    uint32_t s[8];
+    {
+        const uint4 *p = reinterpret_cast<const uint4 *>(scalars + i * 8);
+        uint4 a = p[0], b = p[1];
+        s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w; s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w;
+    }
+    const uint32_t B = 1u << (c - 1);
+    uint32_t carry = 0;
+    for (int w = 0; w < W; w++) {
+        int bitpos = w * c;
+        uint32_t raw = 0;
+        if (bitpos < 256) {
+            int wd = bitpos >> 5, sh = bitpos & 31;
+            // dynamic register indexing is avoided by selecting through a small switch-free reduction
+            uint64_t v = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) { if (k == wd) v |= s[k]; if (k == wd + 1) v |= (uint64_t)s[k] << 32; }
+            raw = (uint32_t)(v >> sh) & ((1u << c) - 1u);
+        }
+        uint32_t v = raw + carry;
+        uint32_t neg = v > B ? 1u : 0u;
+        uint32_t mag = neg ? (2u * B - v) : v;
+        carry = neg;
+        if (mag == 0) continue;
+        size_t key = (size_t)w * B + (mag - 1);
+        if (!SCATTER) atomicAdd(&cnt_or_cursor[key], 1u);
+        else { uint32_t pos = atomicAdd(&cnt_or_cursor[key], 1u); entries[pos] = (uint32_t)i | (neg << 31); }
+    }
+}
+
+// ---- K3: exclusive scan (u32), 4096 elements per block ----------------------------------------------
+constexpr int SCAN_T = 256, SCAN_E = 16, SCAN_B = SCAN_T * SCAN_E;
+static __global__ void __launch_bounds__(SCAN_T) k_scan_block(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, uint32_t *__restrict__ block_sums, size_t n) {
+    __shared__ uint32_t sh[SCAN_T];
+    size_t base = (size_t)blockIdx.x * SCAN_B + (size_t)threadIdx.x * SCAN_E;
+    uint32_t v[SCAN_E], s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_E; k++) { v[k] = (base + k < n) ? in[base + k] : 0; s += v[k]; }
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int d = 1; d < SCAN_T; d <<= 1) {
+        uint32_t t = threadIdx.x >= d ? sh[threadIdx.x - d] : 0;
+        __syncthreads();
+        sh[threadIdx.x] += t;
+        __syncthreads();
+    }
+    uint32_t excl = sh[threadIdx.x] - s;
+    if (threadIdx.x == SCAN_T - 1) block_sums[blockIdx.x] = sh[threadIdx.x];
+#pragma unroll
+    for (int k = 0; k < SCAN_E; k++) { if (base + k < n) out[base + k] = excl; excl += v[k]; }
+}
+// single block: in-place exclusive scan of the block sums, total written to block_sums[nb]
+static __global__ void __launch_bounds__(1024) k_scan_sums(uint32_t *__restrict__ block_sums, size_t nb) {
+    __shared__ uint32_t sh[1024];
+    __shared__ uint32_t carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (size_t base = 0; base < nb; base += 1024) {
+        size_t i = base + threadIdx.x;
+        uint32_t v = i < nb ? block_sums[i] : 0;
+        sh[threadIdx.x] = v;
+        __syncthreads();
+        for (int d = 1; d < 1024; d <<= 1) {
+            uint32_t t = threadIdx.x >= d ? sh[threadIdx.x - d] : 0;
+            __syncthreads();
+            sh[threadIdx.x] += t;
+            __syncthreads();
+        }
+        uint32_t c0 = carry_s;
+        if (i < nb) block_sums[i] = c0 + sh[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = c0 + sh[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) block_sums[nb] = carry_s;
+}
+// out[i] += block_sums[i / SCAN_B]; also writes out[n] = total and copies to cursor
+static __global__ void __launch_bounds__(256) k_scan_add(uint32_t *__restrict__ out, uint32_t *__restrict__ cursor, const uint32_t *__restrict__ block_sums, size_t n, size_t nb) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { uint32_t v = out[i] + block_sums[i / SCAN_B]; out[i] = v; cursor[i] = v; }
+    if (i == n) out[n] = block_sums[nb];
+}
+
+// ---- XYZZ <-> memory -------------------------------------------------------------------------------
+// SoA: word k of point b lives at base[k * stride + b]  (coalesced when consecutive lanes own consecutive b)
+template <class C> __device__ __forceinline__ void store_soa(uint32_t *__restrict__ base, size_t stride, size_t b, const Xyzz<typename C::F> &p) {
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(&p);
+#pragma unroll
+    for (int k = 0; k < C::XW; k++) base[(size_t)k * stride + b] = w[k];
+}
+template <class C> __device__ __forceinline__ void load_soa(Xyzz<typename C::F> &p, const uint32_t *__restrict__ base, size_t stride, size_t b) {
+    uint32_t *w = reinterpret_cast<uint32_t *>(&p);
+#pragma unroll
+    for (int k = 0; k < C::XW; k++) w[k] = base[(size_t)k * stride + b];
+}
+template <class C> __device__ __forceinline__ void load_aff(Aff<typename C::F> &p, const uint32_t *__restrict__ rec) {
+    uint32_t *w = reinterpret_cast<uint32_t *>(&p);
+#pragma unroll
+    for (int k = 0; k < 2 * C::FW; k += 4) {
+        uint4 v = *reinterpret_cast<const uint4 *>(rec + k);
+        w[k] = v.x; w[k + 1] = v.y; w[k + 2] = v.z; w[k + 3] = v.w;
+    }
+}
+
+// ---- K5: chunked bucket accumulation ------------------------------------------------------------------
+// off[0..NB] = exclusive scan of the histogram (off[NB] = number of terms E).  Thread t owns terms
+// [t*CH, min((t+1)*CH, E)).  head_b[t] / tail_b[t] = bucket of the partial left in the head / tail slot, or
+// 0xffffffff.  bucket_inf[b] must be pre-set to 1; it is cleared by whoever writes bucket b.
+template <class C>
+__global__ void __launch_bounds__(256, ACC_WAVES) k_accumulate(const uint32_t *__restrict__ bases, const uint32_t *__restrict__ entries, const uint32_t *__restrict__ off,
+                                                    uint32_t NB, uint32_t *__restrict__ bucket, uint8_t *__restrict__ bucket_inf,
+                                                    uint32_t *__restrict__ head, uint32_t *__restrict__ tail, uint32_t *__restrict__ head_b, uint32_t *__restrict__ tail_b,
+                                                    uint8_t *__restrict__ part_inf, size_t T, uint32_t CH) {
+    typedef typename C::F F;
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    const uint32_t E = off[NB];
+    uint64_t start64 = (uint64_t)t * CH;
+    uint32_t hb = 0xffffffffu, tb = 0xffffffffu;
+    if (start64 >= E) { head_b[t] = hb; tail_b[t] = tb; return; }
+    uint32_t start = (uint32_t)start64;
+    uint32_t end = (E - start > (uint32_t)CH) ? start + CH : E;
+    // bucket containing `start`: largest b with off[b] <= start
+    uint32_t lo = 0, hi = NB;   // invariant off[lo] <= start < off[hi]
+    while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (off[mid] <= start) lo = mid; else hi = mid; }
+    uint32_t b = lo;
+    uint32_t bend = off[b + 1];
+    bool started_before = off[b] < start;
+    Xyzz<F> acc; bool inf = true;
+    fzero(acc.x); fzero(acc.y); fzero(acc.zz); fzero(acc.zzz);
+    for (uint32_t pos = start; pos < end; pos++) {
+        if (pos == bend) {
+            // the run of bucket b ended inside this chunk
+            if (started_before) { store_soa<C>(head, T, t, acc); part_inf[2 * t] = inf; hb = b; started_before = false; }
+            else { store_soa<C>(bucket, NB, b, acc); bucket_inf[b] = inf; }
+            inf = true;
+            do { b++; bend = off[b + 1]; } while (bend == pos);
+        }
+        uint32_t e = entries[pos];
+        Aff<F> p; load_aff<C>(p, bases + (size_t)(e & 0x7fffffffu) * C::AFF_STRIDE);
+        xyzz_madd(acc, inf, p, (e >> 31) != 0);
+    }
+    // the last run reaches the chunk end
+    bool complete = (end == bend);
+    if (started_before) { store_soa<C>(head, T, t, acc); part_inf[2 * t] = inf; hb = b; }   // cut on the left (and maybe on the right too)
+    else if (complete) { store_soa<C>(bucket, NB, b, acc); bucket_inf[b] = inf; }
+    else { store_soa<C>(tail, T, t, acc); part_inf[2 * t + 1] = inf; tb = b; }              // cut on the right only
+    head_b[t] = hb; tail_b[t] = tb;
+}
+
+// ---- K6: fold the partials of buckets that were cut by chunk borders ------------------------------------
+// The leftmost piece of a cut bucket is always a tail slot (its run starts at the bucket start); every later
+// piece is a head slot of the following chunks.
+template <class C>
+__global__ void __launch_bounds__(256) k_fixup(uint32_t NB, uint32_t *__restrict__ bucket, uint8_t *__restrict__ bucket_inf,
+                                               const uint32_t *__restrict__ head, const uint32_t *__restrict__ tail, const uint32_t *__restrict__ head_b,
+                                               const uint32_t *__restrict__ tail_b, const uint8_t *__restrict__ part_inf, size_t T) {
+    typedef typename C::F F;
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    uint32_t b = tail_b[t];
+    if (b == 0xffffffffu) return;
+    Xyzz<F> acc; load_soa<C>(acc, tail, T, t);
+    bool inf = part_inf[2 * t + 1] != 0;
+    for (size_t k = t + 1; k < T && head_b[k] == b; k++) {
+        Xyzz<F> o; load_soa<C>(o, head, T, k);
+        xyzz_add(acc, inf, o, part_inf[2 * k] != 0);
+    }
+    store_soa<C>(bucket, NB, b, acc);
+    bucket_inf[b] = inf;
+}
+
+// ---- K7/K8: sum_k (k+1) * B_k ----------------------------------------------------------------------------
+template <class C> __device__ __forceinline__ void shfl_down_xyzz(Xyzz<typename C::F> &o, bool &oinf, const Xyzz<typename C::F> &x, bool xinf, int d) {
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(&x);
+    uint32_t *q = reinterpret_cast<uint32_t *>(&o);
+#pragma unroll
+    for (int k = 0; k < C::XW; k++) q[k] = __shfl_down(w[k], d, 64);
+    int fi = __shfl_down((int)xinf, d, 64);
+    oinf = (fi != 0) || ((int)(threadIdx.x & 63) + d >= 64);
+}
+// Lane l holds (S_l, A_l): the plain and the locally weighted sum of its own items, lane l's items having
+// global weights offset by l * 2^shift.  Returns on lane 0: S = sum S_l, A = sum (A_l + l 2^shift S_l).
+template <class C> __device__ __forceinline__ void wave_weighted_sum(Xyzz<typename C::F> &S, bool &sinf, Xyzz<typename C::F> &A, bool &ainf, int shift) {
+    typedef typename C::F F;
+    const int lane = threadIdx.x & 63;
+    // suffix scan: S_l <- sum_{j >= l} S_j
+    for (int d = 1; d < 64; d <<= 1) {
+        Xyzz<F> o; bool oinf; shfl_down_xyzz<C>(o, oinf, S, sinf, d);
+        xyzz_add(S, sinf, o, oinf);
+    }
+    // sum_l l S_l = sum_{l >= 1} suffix_l ;  fold 2^shift * suffix_l into A_l before the reduction
+    Xyzz<F> y = S; bool yinf = (lane == 0) ? true : sinf;
+    for (int k = 0; k < shift; k++) { if (!yinf) { Xyzz<F> d2; xyzz_dbl(d2, y); y = d2; } }
+    xyzz_add(A, ainf, y, yinf);
+    for (int d = 32; d >= 1; d >>= 1) {
+        Xyzz<F> o; bool oinf; shfl_down_xyzz<C>(o, oinf, A, ainf, d);
+        xyzz_add(A, ainf, o, oinf);
+    }
+}
+
+// One wave per group of 64 * m consecutive buckets of one window (m = 2^mshift buckets per lane).
+// Writes (S_g, A_g) to l1[2 g], l1[2 g + 1] (AoS, C::XW words each) and their flags to l1_inf.
+template <class C>
+__global__ void __launch_bounds__(64) k_reduce_l0(const uint32_t *__restrict__ bucket, const uint8_t *__restrict__ bucket_inf, uint32_t NB, int mshift,
+                                                  uint32_t *__restrict__ l1, uint8_t *__restrict__ l1_inf) {
+    typedef typename C::F F;
+    const int lane = threadIdx.x & 63;
+    const uint32_t m = 1u << mshift;
+    size_t g = blockIdx.x;
+    size_t b0 = (g * 64 + lane) * (size_t)m;
+    Xyzz<F> run, tot; bool rinf = true, tinf = true;
+    fzero(run.x); fzero(run.y); fzero(run.zz); fzero(run.zzz); tot = run;
+    for (int k = (int)m - 1; k >= 0; k--) {
+        size_t b = b0 + k;
+        bool binf = bucket_inf[b] != 0;
+        Xyzz<F> p;
+        if (!binf) load_soa<C>(p, bucket, NB, b); else p = run;
+        xyzz_add(run, rinf, p, binf);
+        xyzz_add(tot, tinf, run, rinf);
+    }
+    wave_weighted_sum<C>(run, rinf, tot, tinf, mshift);
+    if (lane == 0) {
+        uint32_t *dst = l1 + g * 2 * C::XW;
+        const uint32_t *w = reinterpret_cast<const uint32_t *>(&run);
+        const uint32_t *v = reinterpret_cast<const uint32_t *>(&tot);
+        for (int k = 0; k < C::XW; k++) { dst[k] = w[k]; dst[C::XW + k] = v[k]; }
+        l1_inf[2 * g] = rinf; l1_inf[2 * g + 1] = tinf;
+    }
+}
+// One wave per window: lane g holds group g's (S_g, A_g) (G <= 64 groups per window), group weights offset by
+// g * 2^gshift.  Converts the window sum to the ABI form (X, Y, ZZ, ZZZ; 2^384 Montgomery) for the host.
+template <class C>
+__global__ void __launch_bounds__(64) k_reduce_top(const uint32_t *__restrict__ l1, const uint8_t *__restrict__ l1_inf, int G, int gshift,
+                                                   uint32_t *__restrict__ win_abi, uint8_t *__restrict__ win_inf) {
+    typedef typename C::F F;
+    const int lane = threadIdx.x & 63;
+    size_t w = blockIdx.x;
+    Xyzz<F> S, A; bool sinf = true, ainf = true;
+    fzero(S.x); fzero(S.y); fzero(S.zz); fzero(S.zzz); A = S;
+    if (lane < G) {
+        const uint32_t *src = l1 + (w * G + lane) * 2 * C::XW;
+        uint32_t *ps = reinterpret_cast<uint32_t *>(&S), *pa = reinterpret_cast<uint32_t *>(&A);
+        for (int k = 0; k < C::XW; k++) { ps[k] = src[k]; pa[k] = src[C::XW + k]; }
+        sinf = l1_inf[2 * (w * G + lane)] != 0; ainf = l1_inf[2 * (w * G + lane) + 1] != 0;
+    }
+    wave_weighted_sum<C>(S, sinf, A, ainf, gshift);
+    if (lane == 0) {
+        uint32_t *dst = win_abi + w * 4 * C::ABI_W;
+        win_inf[w] = ainf;
+        if (!ainf) {
+            const Fp *f = reinterpret_cast<const Fp *>(&A);
+            for (int k = 0; k < 4 * C::NFP; k++) fp_to_abi(dst + 12 * k, f[k]);
+        }
+    }
+}
+
+// ---- self-test kernels (tests/: device arithmetic vs oracle without the MSM plumbing) ------------------------
+static __global__ void k_selftest_fp_mul(const uint32_t *a, const uint32_t *b, size_t n, uint32_t *out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fp x, y, r; fp_from_abi(x, a + 12 * i); fp_from_abi(y, b + 12 * i);
+    fp_mul(r, x, y);
+    fp_to_abi(out + 12 * i, r);
+}
+// one thread: sum of (+/-) points by mixed additions, result in ABI XYZZ form
+static __global__ void k_selftest_g1_sum(const uint32_t *pts_abi, const uint8_t *neg, size_t n, uint32_t *out, uint8_t *out_inf) {
+    if (blockIdx.x || threadIdx.x) return;
+    Xyzz<Fp> acc; bool inf = true;
+    fzero(acc.x); fzero(acc.y); fzero(acc.zz); fzero(acc.zzz);
+    for (size_t i = 0; i < n; i++) {
+        Aff<Fp> p; fp_from_abi(p.x, pts_abi + 24 * i); fp_from_abi(p.y, pts_abi + 24 * i + 12);
+        xyzz_madd(acc, inf, p, neg && neg[i]);
+    }
+    *out_inf = inf;
+    if (!inf) { fp_to_abi(out, acc.x); fp_to_abi(out + 12, acc.y); fp_to_abi(out + 24, acc.zz); fp_to_abi(out + 36, acc.zzz); }
+}
+
+}  // namespace msm

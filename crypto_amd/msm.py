@@ -1,0 +1,195 @@
+"""Host-side mirror of the reference's variable-base MSM call surface, over the C ABI.
+
+Mirrors (names, argument meaning, error behaviour):
+  * ark_ec::VariableBaseMSM::msm(bases, scalars)          -> msm()            Err(min_len) on length mismatch
+  * ark_ec::VariableBaseMSM::msm_unchecked(bases, &[Fr])  -> msm_unchecked()  Montgomery scalars, truncates to min(len)
+  * ark_ec::VariableBaseMSM::msm_bigint(bases, &[BigInt]) -> msm_bigint()     canonical scalars, truncates to min(len)
+  * dock_crypto_utils::pairs::Pairs::{msm, msm_bigint}    -> Pairs            /root/reference/utils/src/pairs.rs:143-156
+Arrays are numpy uint64 in the ABI layout of include/dock_gpu.h (ark-ff Montgomery limbs).
+"""
+import ctypes as C
+import numpy as np
+from ._native import lib, DockGpuError
+
+
+class _Curve:
+    def __init__(self, tag, aff_words):
+        self.tag = tag
+        self.AW = aff_words           # u64 per affine point: 12 (G1) / 24 (G2)
+        self.JW = aff_words * 3 // 2  # u64 per Jacobian point: 18 / 36
+
+    def fn(self, name):
+        return getattr(lib(), name % self.tag)
+
+
+G1 = _Curve("g1", 12)
+G2 = _Curve("g2", 24)
+
+_inited = False
+
+
+def init(device=0):
+    global _inited
+    rc = lib().dgpu_init(device)
+    if rc:
+        raise DockGpuError(rc, "dgpu_init(%d)" % device)
+    _inited = True
+
+
+def _ensure():
+    if not _inited:
+        init(0)
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _prep(curve, bases, scalars, is_inf):
+    bases = np.ascontiguousarray(bases, dtype=np.uint64).reshape(-1, curve.AW)
+    scalars = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+    n = min(len(bases), len(scalars))     # arkworks truncates (legogroth16/src/prover.rs:286 relies on it)
+    inf = None
+    if is_inf is not None:
+        inf = np.ascontiguousarray(is_inf, dtype=np.uint8)
+        if len(inf) < n:
+            raise ValueError("is_inf shorter than the truncated length")
+    return bases, scalars, inf, n
+
+
+def msm_bigint(curve, bases, scalars, is_inf=None):
+    """G::msm_bigint(bases, bigints): canonical 4x64 scalars; returns the Jacobian triple (normalised)."""
+    _ensure()
+    bases, scalars, inf, n = _prep(curve, bases, scalars, is_inf)
+    out = np.zeros(curve.JW, dtype=np.uint64)
+    rc = curve.fn("dgpu_msm_%s")(_p(bases), _p(inf), _p(scalars), n, _p(out))
+    if rc:
+        raise DockGpuError(rc, "dgpu_msm_%s" % curve.tag)
+    return out
+
+
+def msm_unchecked(curve, bases, scalars_mont, is_inf=None):
+    """G::msm_unchecked(bases, &[Fr]): scalars are Fr in Montgomery form (R = 2^256)."""
+    _ensure()
+    bases, scalars, inf, n = _prep(curve, bases, scalars_mont, is_inf)
+    out = np.zeros(curve.JW, dtype=np.uint64)
+    rc = curve.fn("dgpu_msm_%s_mont")(_p(bases), _p(inf), _p(scalars), n, _p(out))
+    if rc:
+        raise DockGpuError(rc, "dgpu_msm_%s_mont" % curve.tag)
+    return out
+
+
+def msm(curve, bases, scalars_mont, is_inf=None):
+    """G::msm(bases, scalars): checked variant — (False, min_len) on length mismatch, like Err(min_len)."""
+    nb = np.asarray(bases).size // curve.AW
+    ns = np.asarray(scalars_mont).size // 4
+    if nb != ns:
+        return False, min(nb, ns)
+    return True, msm_unchecked(curve, bases, scalars_mont, is_inf)
+
+
+class Pairs:
+    """utils/src/pairs.rs `Pairs<'_, G, Fr>`: equal-length (left, right) slices."""
+
+    def __init__(self, curve, left, right, is_inf=None):
+        self.curve = curve
+        self.left = np.ascontiguousarray(left, dtype=np.uint64).reshape(-1, curve.AW)
+        self.right = np.ascontiguousarray(right, dtype=np.uint64).reshape(-1, 4)
+        if len(self.left) != len(self.right):    # Pairs::new returns None / TryFrom Err((l, r))
+            raise ValueError((len(self.left), len(self.right)))
+        self.is_inf = is_inf
+
+    def msm(self):           # pairs.rs:145-147
+        return msm_unchecked(self.curve, self.left, self.right, self.is_inf)
+
+    def msm_bigint(self):    # pairs.rs:153-155
+        return msm_bigint(self.curve, self.left, self.right, self.is_inf)
+
+
+class DeviceBases:
+    """Device-resident prepared bases (a proving-key query): dgpu_bases_upload_* / dgpu_msm_*_handle."""
+
+    def __init__(self, curve, bases, is_inf=None):
+        _ensure()
+        self.curve = curve
+        bases = np.ascontiguousarray(bases, dtype=np.uint64).reshape(-1, curve.AW)
+        self.n = len(bases)
+        inf = None if is_inf is None else np.ascontiguousarray(is_inf, dtype=np.uint8)
+        h = C.c_uint64(0)
+        rc = curve.fn("dgpu_bases_upload_%s")(_p(bases), _p(inf), self.n, C.byref(h))
+        if rc:
+            raise DockGpuError(rc, "dgpu_bases_upload")
+        self.handle = h.value
+
+    def msm_bigint(self, scalars, offset=0, montgomery=False):
+        scalars = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+        n = min(len(scalars), self.n - offset)
+        out = np.zeros(self.curve.JW, dtype=np.uint64)
+        rc = self.curve.fn("dgpu_msm_%s_handle")(self.handle, offset, _p(scalars), n, int(montgomery), _p(out))
+        if rc:
+            raise DockGpuError(rc, "dgpu_msm_handle")
+        return out
+
+    def msm_resident(self, dscalars, n=None, base_offset=0, scalar_offset=0):
+        if n is None:
+            n = min(self.n - base_offset, dscalars.n - scalar_offset)
+        out = np.zeros(self.curve.JW, dtype=np.uint64)
+        rc = self.curve.fn("dgpu_msm_%s_resident")(self.handle, base_offset, dscalars.handle, scalar_offset, n, _p(out))
+        if rc:
+            raise DockGpuError(rc, "dgpu_msm_resident")
+        return out
+
+    def free(self):
+        if self.handle:
+            lib().dgpu_bases_free(self.handle)
+            self.handle = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class DeviceScalars:
+    def __init__(self, scalars, montgomery=False):
+        _ensure()
+        scalars = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+        self.n = len(scalars)
+        h = C.c_uint64(0)
+        rc = lib().dgpu_scalars_upload(_p(scalars), self.n, int(montgomery), C.byref(h))
+        if rc:
+            raise DockGpuError(rc, "dgpu_scalars_upload")
+        self.handle = h.value
+
+    def free(self):
+        if self.handle:
+            lib().dgpu_scalars_free(self.handle)
+            self.handle = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class prof:
+    """Per-stage HIP-event timings recorded inside the library on its own stream."""
+
+    @staticmethod
+    def enable(on=True):
+        lib().dgpu_prof_enable(1 if on else 0)
+
+    @staticmethod
+    def reset():
+        lib().dgpu_prof_reset()
+
+    @staticmethod
+    def read():
+        cap = 64
+        names = (C.c_char_p * cap)()
+        ms = (C.c_double * cap)()
+        calls = (C.c_uint64 * cap)()
+        k = lib().dgpu_prof_read(names, ms, calls, cap)
+        return {names[i].decode(): (ms[i], calls[i]) for i in range(k)}

@@ -1,0 +1,103 @@
+/* include/dock_gpu.h — C ABI of libdock_gpu.so, the MI355X (gfx950) backend for the one data-parallel
+ * hot path of docknetwork/crypto: BLS12-381 variable-base MSM (G1/G2) and the batched Miller loop.
+ *
+ * The reference has no FFI for this path today: every call is a statically dispatched call into
+ * arkworks (ark-ec 0.4).  Each entry point below names the reference call it replaces; the Rust-side
+ * binding a maintainer would add is shown in INTEGRATION.md.
+ *
+ * Conventions (all entry points):
+ *   - return int32_t: 0 = DGPU_OK, negative = DGPU_E_*; never unwinds, aborts or prints.
+ *   - field elements are ark-ff `Fp<MontBackend,N>` raw limbs: little-endian u64, value * R mod p,
+ *     R = 2^384 for Fq (6 limbs), R = 2^256 for Fr (4 limbs)   (SURVEY.md A.5).
+ *   - G1 affine = x,y (12 u64); G2 affine = x.c0,x.c1,y.c0,y.c1 (24 u64); identity is flagged out of
+ *     band by `is_inf[i] != 0` (ark-ec `Affine{ x, y, infinity }` is not repr(C), the shim repacks);
+ *     a point whose coordinate words are all zero is also treated as the identity.
+ *   - group results are returned as a Jacobian triple X,Y,Z (ark-ec `Projective`): always the
+ *     normalised representative (Z = R, i.e. one) or Z = 0 for the identity, so equal group elements
+ *     give bit-identical output.
+ *   - caller owns every buffer; nothing is retained after return except behind explicit handles.
+ *   - thread-safe and re-entrant (the reference calls MSM from inside rayon workers,
+ *     verifiable_encryption/src/tz_21/rdkgith.rs:140-147): calls on one device are serialised internally.
+ */
+#ifndef DOCK_GPU_H
+#define DOCK_GPU_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DGPU_OK            0
+#define DGPU_E_NODEVICE   -1   /* no usable HIP device / dgpu_init not called or failed */
+#define DGPU_E_OOM        -2   /* device or host allocation failed */
+#define DGPU_E_BADARG     -3   /* NULL pointer, bad handle, offset + n out of range, n too large */
+#define DGPU_E_HIP        -4   /* a HIP runtime call failed (see dgpu_last_hip_error) */
+#define DGPU_E_ZERO       -5   /* final_exponentiation of 0 (arkworks returns None) */
+#define DGPU_E_TOO_SMALL  -6   /* n below dgpu_set_min_gpu_n threshold: caller should stay on its CPU path */
+#define DGPU_E_LENGTH     -7   /* multi_miller_loop with unequal lengths (arkworks zip_eq panics) */
+
+/* ---- lifecycle ---- */
+int32_t dgpu_init(int32_t device);           /* bind to a HIP device ordinal (one process per GPU); idempotent */
+int32_t dgpu_shutdown(void);
+int32_t dgpu_device_count(void);
+const char *dgpu_strerror(int32_t code);
+int32_t dgpu_last_hip_error(void);
+/* below this many terms the MSM entry points return DGPU_E_TOO_SMALL without touching the device
+ * (>= 95 % of the reference's call sites have n < 100); default 0 = always run. */
+int32_t dgpu_set_min_gpu_n(size_t n);
+/* window width c (bits) used by the bucket method; 0 = automatic from n.  Any value gives the same point. */
+int32_t dgpu_set_window_bits(int32_t c);
+
+/* ---- one-shot MSM: host buffers in, one point out ----
+ * replaces <G1Projective as VariableBaseMSM>::msm_bigint(bases, bigints)
+ *   legogroth16/src/prover.rs:286,299,363,592 ; utils/src/pairs.rs:153-155 ; utils/src/owned_pairs.rs:103-105
+ * Callers pass n = min(bases.len(), scalars.len()) — the truncation arkworks applies (prover.rs:286). */
+int32_t dgpu_msm_g1(const uint64_t *bases_xy /* n*12 */, const uint8_t *is_inf /* n or NULL */,
+                    const uint64_t *scalars /* n*4, canonical */, size_t n, uint64_t out_xyz[18]);
+/* replaces <G1Projective as VariableBaseMSM>::msm_unchecked(bases, &[Fr]) (Fr in Montgomery form, R = 2^256)
+ *   utils/src/pairs.rs:145-147 ; utils/src/randomized_mult_checker.rs:100 ; schnorr_pok/src/pok_generalized_pedersen.rs:97 */
+int32_t dgpu_msm_g1_mont(const uint64_t *bases_xy, const uint8_t *is_inf,
+                         const uint64_t *scalars_mont, size_t n, uint64_t out_xyz[18]);
+/* same pair over G2 — legogroth16/src/prover.rs:344 (b_g2_query), delegatable_credentials/src/set_commitment.rs:566 */
+int32_t dgpu_msm_g2(const uint64_t *bases_xy /* n*24 */, const uint8_t *is_inf,
+                    const uint64_t *scalars, size_t n, uint64_t out_xyz[36]);
+int32_t dgpu_msm_g2_mont(const uint64_t *bases_xy, const uint8_t *is_inf,
+                         const uint64_t *scalars_mont, size_t n, uint64_t out_xyz[36]);
+
+/* ---- device-resident operands (proving-key queries live in HBM across proofs) ----
+ * `offset` expresses `&query[1..]` (legogroth16/src/prover.rs:592). */
+int32_t dgpu_bases_upload_g1(const uint64_t *bases_xy, const uint8_t *is_inf, size_t n, uint64_t *handle);
+int32_t dgpu_bases_upload_g2(const uint64_t *bases_xy, const uint8_t *is_inf, size_t n, uint64_t *handle);
+int32_t dgpu_bases_free(uint64_t handle);
+int32_t dgpu_scalars_upload(const uint64_t *scalars /* n*4 */, size_t n, int32_t montgomery, uint64_t *handle);
+int32_t dgpu_scalars_free(uint64_t handle);
+int32_t dgpu_msm_g1_handle(uint64_t bases, size_t offset, const uint64_t *scalars, size_t n, int32_t montgomery, uint64_t out_xyz[18]);
+int32_t dgpu_msm_g2_handle(uint64_t bases, size_t offset, const uint64_t *scalars, size_t n, int32_t montgomery, uint64_t out_xyz[36]);
+/* both operands resident: the timed region of bench.py (inputs already in HBM) */
+int32_t dgpu_msm_g1_resident(uint64_t bases, size_t base_offset, uint64_t scalars, size_t scalar_offset, size_t n, uint64_t out_xyz[18]);
+int32_t dgpu_msm_g2_resident(uint64_t bases, size_t base_offset, uint64_t scalars, size_t scalar_offset, size_t n, uint64_t out_xyz[36]);
+
+/* ---- pairings ----
+ * replaces Bls12_381::multi_miller_loop(a, b) — utils/src/randomized_pairing_check.rs:207,
+ * legogroth16/src/verifier.rs:69-76.  skip[i] != 0 marks a pair with an identity member (arkworks
+ * filters those out).  Output: raw MillerLoopOutput, Fp12 as c0.c0.c0 ... c1.c2.c1 (72 u64). */
+int32_t dgpu_multi_miller_loop(const uint64_t *p_xy /* n*12 */, const uint64_t *q_xy /* n*24 */,
+                               const uint8_t *skip /* n or NULL */, size_t n, uint64_t out_f12[72]);
+/* replaces Bls12_381::final_exponentiation — utils/src/randomized_pairing_check.rs:213 (host code, once per batch) */
+int32_t dgpu_final_exponentiation(const uint64_t in_f12[72], uint64_t out_f12[72]);
+
+/* ---- instrumentation (bench.py / rocprof cross-check) ----
+ * When enabled, every stage of the next calls is bracketed by HIP events on the library's own stream. */
+int32_t dgpu_prof_enable(int32_t on);
+int32_t dgpu_prof_reset(void);
+/* fills up to `cap` entries; returns the number of stages recorded.  names[i] points to a static string. */
+int32_t dgpu_prof_read(const char **names, double *total_ms, uint64_t *calls, int32_t cap);
+
+/* ---- self-test hooks (tests only; run the device field/group code on tiny inputs) ---- */
+int32_t dgpu_selftest_fp_mul(const uint64_t *a /* n*6 */, const uint64_t *b /* n*6 */, size_t n, uint64_t *out /* n*6 */);
+int32_t dgpu_selftest_g1_sum(const uint64_t *pts_xy /* n*12 */, const uint8_t *neg, size_t n, uint64_t out_xyz[18]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,73 @@
+// tests/native/fp29_host_shim.cpp — host build (g++) of the DEVICE field/group code with the
+// FP29_CHECK worst-case bound tracker enabled.  Test-only: lets `-m "not gpu"` tests check the exact
+// arithmetic the kernels run, and proves the lazy-limb overflow bounds, without a GPU.
+#define FP29_CHECK 1
+#include "../../crypto_amd/csrc/fp29.cuh"
+#include "../../crypto_amd/csrc/ec29.cuh"
+#include <string.h>
+using namespace bls29;
+extern "C" {
+void shim_fp_mul(const uint32_t *a, const uint32_t *b, uint32_t *out) { Fp x, y, r; fp_from_abi(x, a); fp_from_abi(y, b); fp_mul(r, x, y); fp_to_abi(out, r); }
+void shim_fp_sqr(const uint32_t *a, uint32_t *out) { Fp x, r; fp_from_abi(x, a); fp_sqr(r, x); fp_to_abi(out, r); }
+void shim_fp_roundtrip(const uint32_t *a, uint32_t *out) { Fp x; fp_from_abi(x, a); fp_to_abi(out, x); }
+// (a - b) * c with the lazy subtraction + norm, exercising K_M domination
+void shim_fp_submul(const uint32_t *a, const uint32_t *b, const uint32_t *c, uint32_t *out) {
+    Fp x, y, z, t; fp_from_abi(x, a); fp_from_abi(y, b); fp_from_abi(z, c);
+    fp_sub<4>(t, x, y); fp_norm(t, t); fp_mul(t, t, z);
+    Fp u; fp_sub<16>(u, t, x); fp_norm(u, u); fp_add(u, u, x); fp_norm(u, u);   // back to t (mod p)
+    fp_to_abi(out, u);
+}
+int shim_fp_is_zero(const uint32_t *a, const uint32_t *b) { Fp x, y, t; fp_from_abi(x, a); fp_from_abi(y, b); fp_sub<4>(t, x, y); fp_norm(t, t); return (fp_maybe_zero(t) ? 1 : 0) | (fp_is_zero_exact(t) ? 2 : 0); }
+
+static void load_aff(Aff<Fp> &p, const uint32_t *xy) { fp_from_abi(p.x, xy); fp_from_abi(p.y, xy + 12); }
+static void store_xyzz(uint32_t *out, const Xyzz<Fp> &a, bool inf) {
+    if (inf) { memset(out, 0, 4 * 48); return; }
+    fp_to_abi(out, a.x); fp_to_abi(out + 12, a.y); fp_to_abi(out + 24, a.zz); fp_to_abi(out + 36, a.zzz);
+}
+// sum_{i<n} (+/-) pts[i] by repeated mixed addition; out = X,Y,ZZ,ZZZ in ABI form (all-zero = identity)
+void shim_g1_madd_chain(const uint32_t *pts, const uint8_t *neg, int n, uint32_t *out) {
+    Xyzz<Fp> acc; bool inf = true;
+    fzero(acc.x); fzero(acc.y); fzero(acc.zz); fzero(acc.zzz);
+    for (int i = 0; i < n; i++) { Aff<Fp> p; load_aff(p, pts + 24 * i); xyzz_madd(acc, inf, p, neg && neg[i]); }
+    store_xyzz(out, acc, inf);
+}
+// tree: (p0 + p1) + (p2 + p3) ... using the general XYZZ addition
+void shim_g1_add_tree(const uint32_t *pts, int n, uint32_t *out) {
+    Xyzz<Fp> *v = new Xyzz<Fp>[n > 0 ? n : 1]; bool *f = new bool[n > 0 ? n : 1];
+    for (int i = 0; i < n; i++) { Aff<Fp> p; load_aff(p, pts + 24 * i); f[i] = true; fzero(v[i].x); fzero(v[i].y); fzero(v[i].zz); fzero(v[i].zzz); xyzz_madd(v[i], f[i], p, false); }
+    int m = n;
+    while (m > 1) { int h = (m + 1) / 2; for (int i = 0; i + h < m; i++) xyzz_add(v[i], f[i], v[i + h], f[i + h]); m = h; }
+    if (n == 0) { memset(out, 0, 4 * 48); } else store_xyzz(out, v[0], f[0]);
+    delete[] v; delete[] f;
+}
+
+// ---- G2 ----
+static void load_aff2(Aff<Fp2> &p, const uint32_t *xy) { fp_from_abi(p.x.c0, xy); fp_from_abi(p.x.c1, xy + 12); fp_from_abi(p.y.c0, xy + 24); fp_from_abi(p.y.c1, xy + 36); }
+static void store_xyzz2(uint32_t *out, const Xyzz<Fp2> &a, bool inf) {
+    if (inf) { memset(out, 0, 4 * 96); return; }
+    const Fp *f = reinterpret_cast<const Fp *>(&a);
+    for (int k = 0; k < 8; k++) fp_to_abi(out + 12 * k, f[k]);
+}
+void shim_fp2_mul(const uint32_t *a, const uint32_t *b, uint32_t *out) {
+    Fp2 x, y, r; fp_from_abi(x.c0, a); fp_from_abi(x.c1, a + 12); fp_from_abi(y.c0, b); fp_from_abi(y.c1, b + 12);
+    fmul(r, x, y); fp_to_abi(out, r.c0); fp_to_abi(out + 12, r.c1);
+}
+void shim_fp2_sqr(const uint32_t *a, uint32_t *out) {
+    Fp2 x, r; fp_from_abi(x.c0, a); fp_from_abi(x.c1, a + 12);
+    fsqr(r, x); fp_to_abi(out, r.c0); fp_to_abi(out + 12, r.c1);
+}
+void shim_g2_madd_chain(const uint32_t *pts, const uint8_t *neg, int n, uint32_t *out) {
+    Xyzz<Fp2> acc; bool inf = true;
+    fzero(acc.x); fzero(acc.y); fzero(acc.zz); fzero(acc.zzz);
+    for (int i = 0; i < n; i++) { Aff<Fp2> p; load_aff2(p, pts + 48 * i); xyzz_madd(acc, inf, p, neg && neg[i]); }
+    store_xyzz2(out, acc, inf);
+}
+void shim_g2_add_tree(const uint32_t *pts, int n, uint32_t *out) {
+    Xyzz<Fp2> *v = new Xyzz<Fp2>[n > 0 ? n : 1]; bool *f = new bool[n > 0 ? n : 1];
+    for (int i = 0; i < n; i++) { Aff<Fp2> p; load_aff2(p, pts + 48 * i); f[i] = true; fzero(v[i].x); fzero(v[i].y); fzero(v[i].zz); fzero(v[i].zzz); xyzz_madd(v[i], f[i], p, false); }
+    int m = n;
+    while (m > 1) { int h = (m + 1) / 2; for (int i = 0; i + h < m; i++) xyzz_add(v[i], f[i], v[i + h], f[i + h]); m = h; }
+    if (n == 0) { memset(out, 0, 4 * 96); } else store_xyzz2(out, v[0], f[0]);
+    delete[] v; delete[] f;
+}
+}

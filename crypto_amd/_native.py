@@ -38,7 +38,7 @@ SYMBOLS = [
     "dgpu_msm_g1", "dgpu_msm_g1_mont", "dgpu_msm_g2", "dgpu_msm_g2_mont",
     "dgpu_bases_upload_g1", "dgpu_bases_upload_g2", "dgpu_bases_free", "dgpu_scalars_upload", "dgpu_scalars_free",
     "dgpu_msm_g1_handle", "dgpu_msm_g2_handle", "dgpu_msm_g1_resident", "dgpu_msm_g2_resident",
-    "dgpu_multi_miller_loop", "dgpu_final_exponentiation",
+    "dgpu_fold_g1", "dgpu_fold_g2", "dgpu_multi_miller_loop", "dgpu_final_exponentiation",
     "dgpu_prof_enable", "dgpu_prof_reset", "dgpu_prof_read",
     "dgpu_selftest_fp_mul", "dgpu_selftest_g1_sum",
 ]
@@ -71,6 +71,8 @@ def lib():
             getattr(L, name).argtypes = [u64, sz, vp, sz, C.c_int32, vp]
         for name in ("dgpu_msm_g1_resident", "dgpu_msm_g2_resident"):
             getattr(L, name).argtypes = [u64, sz, u64, sz, sz, vp]
+        L.dgpu_fold_g1.argtypes = [vp, sz, vp]
+        L.dgpu_fold_g2.argtypes = [vp, sz, vp]
         L.dgpu_multi_miller_loop.argtypes = [vp, vp, vp, sz, vp]
         L.dgpu_final_exponentiation.argtypes = [vp, vp]
         L.dgpu_prof_enable.argtypes = [C.c_int32]

@@ -27,6 +27,25 @@ void host_fold(const uint64_t *win_abi, const uint8_t *win_inf, int W, int c, ui
     memcpy(out_xyz, &X, sizeof(HF)); memcpy(out_xyz + FWORDS, &Y, sizeof(HF)); memcpy(out_xyz + 2 * FWORDS, &Z, sizeof(HF));
 }
 
+// sum of k Jacobian triples (host): partial results gathered from the other ranks
+template <class HF>
+int32_t host_fold_jacobian(const uint64_t *xyz, size_t k, uint64_t *out_xyz) {
+    if (!out_xyz || (k && !xyz)) return DGPU_E_BADARG;
+    typedef hostf::HXyzz<HF> PT;
+    const size_t FWORDS = sizeof(HF) / 8;
+    PT acc = PT::identity();
+    for (size_t i = 0; i < k; i++) {
+        HF X, Y, Z;
+        memcpy(&X, xyz + i * 3 * FWORDS, sizeof(HF)); memcpy(&Y, xyz + i * 3 * FWORDS + FWORDS, sizeof(HF)); memcpy(&Z, xyz + i * 3 * FWORDS + 2 * FWORDS, sizeof(HF));
+        if (Z.is_zero()) continue;
+        PT t; t.inf = false; t.x = X; t.y = Y; t.zz = Z * Z; t.zzz = t.zz * Z;   // Jacobian (X, Y, Z) == XYZZ (X, Y, Z^2, Z^3)
+        acc.add_in_place(t);
+    }
+    HF X, Y, Z; acc.to_normalised_jacobian(X, Y, Z);
+    memcpy(out_xyz, &X, sizeof(HF)); memcpy(out_xyz + FWORDS, &Y, sizeof(HF)); memcpy(out_xyz + 2 * FWORDS, &Z, sizeof(HF));
+    return DGPU_OK;
+}
+
 // d_bases: prepared records; d_scalars: canonical 8 x u32 per scalar.  Caller holds g.mu.
 template <class C, class HF>
 int32_t msm_device(const uint32_t *d_bases, const uint32_t *d_scalars, size_t n, uint64_t *out_xyz) {

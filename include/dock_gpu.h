@@ -77,6 +77,11 @@ int32_t dgpu_msm_g2_handle(uint64_t bases, size_t offset, const uint64_t *scalar
 int32_t dgpu_msm_g1_resident(uint64_t bases, size_t base_offset, uint64_t scalars, size_t scalar_offset, size_t n, uint64_t out_xyz[18]);
 int32_t dgpu_msm_g2_resident(uint64_t bases, size_t base_offset, uint64_t scalars, size_t scalar_offset, size_t n, uint64_t out_xyz[36]);
 
+/* ---- multi-GPU: fold per-rank partial results (host code; EC addition is not an RCCL reduction op, so the
+ * collective is an all-gather of k normalised Jacobian triples followed by this fold) ---- */
+int32_t dgpu_fold_g1(const uint64_t *partials_xyz /* k*18 */, size_t k, uint64_t out_xyz[18]);
+int32_t dgpu_fold_g2(const uint64_t *partials_xyz /* k*36 */, size_t k, uint64_t out_xyz[36]);
+
 /* ---- pairings ----
  * replaces Bls12_381::multi_miller_loop(a, b) — utils/src/randomized_pairing_check.rs:207,
  * legogroth16/src/verifier.rs:69-76.  skip[i] != 0 marks a pair with an identity member (arkworks

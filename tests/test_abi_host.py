@@ -1,0 +1,108 @@
+"""CPU: the C-ABI library loads and exports every symbol include/dock_gpu.h declares; the entry points fail
+loudly (error codes, no CPU fallback) without a device; the host-side pieces that need no GPU (partial-point
+fold used by the multi-GPU gather, the reference-interface mirror's length semantics) are checked."""
+import ctypes as C
+import os
+import re
+import numpy as np
+import pytest
+import torch
+import oracle_c as O
+import util as U
+import crypto_amd as ca
+from crypto_amd._native import lib, SYMBOLS
+from crypto_amd import sharded
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HAS_GPU = torch.cuda.is_available()
+
+
+def test_exports_match_header():
+    hdr = open(os.path.join(ROOT, "include", "dock_gpu.h")).read()
+    declared = sorted(set(re.findall(r"\b(dgpu_[a-z0-9_]+)\s*\(", hdr)))
+    assert declared, "no declarations parsed"
+    L = lib()
+    for name in declared:
+        assert hasattr(L, name), "libdock_gpu.so does not export %s" % name
+    assert sorted(SYMBOLS) == declared
+
+
+def test_error_strings():
+    L = lib()
+    for code in range(0, -8, -1):
+        assert L.dgpu_strerror(code)
+    assert b"unknown" in L.dgpu_strerror(-99)
+    assert L.dgpu_set_window_bits(3) == -3 and L.dgpu_set_window_bits(0) == 0
+
+
+@pytest.mark.skipif(HAS_GPU, reason="checks the no-device behaviour")
+def test_fails_loudly_without_device():
+    L = lib()
+    assert L.dgpu_device_count() == 0
+    assert L.dgpu_init(0) == -1
+    out = np.zeros(18, np.uint64)
+    b = O.G1.generator().reshape(1, 12)
+    s = np.ones((1, 4), np.uint64)
+    rc = L.dgpu_msm_g1(b.ctypes.data_as(C.c_void_p), None, s.ctypes.data_as(C.c_void_p), 1, out.ctypes.data_as(C.c_void_p))
+    assert rc == -1                      # DGPU_E_NODEVICE — never a silent CPU result
+    with pytest.raises(ca.DockGpuError):
+        ca.msm_bigint(ca.G1, b, s)
+
+
+def test_bad_arguments():
+    L = lib()
+    out = np.zeros(18, np.uint64)
+    assert L.dgpu_msm_g1(None, None, None, 5, out.ctypes.data_as(C.c_void_p)) == -3
+    assert L.dgpu_msm_g1(None, None, None, 0, None) == -3
+    assert L.dgpu_bases_free(12345) == -3
+
+
+def test_checked_msm_and_pairs_length_semantics():
+    # ark-ec msm(): Err(min_len) on mismatch;  utils/src/pairs.rs: Pairs::new -> None / TryFrom Err((l, r))
+    b = np.zeros((5, 12), np.uint64)
+    s = np.zeros((3, 4), np.uint64)
+    assert ca.msm(ca.G1, b, s) == (False, 3)
+    with pytest.raises(ValueError):
+        ca.Pairs(ca.G1, b, s)
+
+
+@pytest.mark.parametrize("curve,G", [(ca.G1, O.G1), (ca.G2, O.G2)])
+def test_fold_partials_on_host(curve, G):
+    gen = G.generator()
+    ks = [5, 7, 11, 0, 13]
+    parts = []
+    for k in ks:
+        j = G.mul(gen, O.int_to_limbs(k, 4))
+        a, inf = G.to_affine(j)
+        one = O.fp_to_mont(np.array([[1, 0, 0, 0, 0, 0]], np.uint64)).reshape(-1)
+        z = np.zeros(G.AW // 2, np.uint64)
+        if not inf:
+            z[:6] = one
+        parts.append(np.concatenate([a, z]) if not inf else np.concatenate([np.zeros(G.AW, np.uint64), z]))
+    parts.append(G.mul(gen, O.int_to_limbs(17, 4)))      # a non-normalised Jacobian triple is accepted too
+    got = sharded.fold(curve, np.stack(parts))
+    exp = G.mul(gen, O.int_to_limbs(sum(ks) + 17, 4))
+    assert U.jac_to_model(G, got) == U.jac_to_model(G, exp)
+    assert (got[-(G.AW // 2):][:6] == O.fp_to_mont(np.array([[1, 0, 0, 0, 0, 0]], np.uint64)).reshape(-1)).all()  # Z == one
+    # identity + identity == identity (Z = 0)
+    zero = np.zeros((2, curve.JW), np.uint64)
+    assert not sharded.fold(curve, zero)[-(G.AW // 2):].any()
+    # P + (-P)
+    a, _ = G.to_affine(parts[0])
+    neg = a.copy()
+    h = G.AW // 2
+    for k in range(h // 6):
+        neg[h + 6 * k:h + 6 * k + 6] = U.fp_abi((-U.fp_int(a[h + 6 * k:h + 6 * k + 6])) % U.P)
+    z = np.zeros(h, np.uint64); z[:6] = O.fp_to_mont(np.array([[1, 0, 0, 0, 0, 0]], np.uint64)).reshape(-1)
+    both = np.stack([np.concatenate([a, z]), np.concatenate([neg, z])])
+    assert not sharded.fold(curve, both)[-h:].any()
+
+
+def test_chunk_bounds_partition():
+    for n in (0, 1, 7, 8, 1 << 20, (1 << 24) + 3):
+        for world in (1, 2, 3, 8):
+            spans = [sharded.chunk_bounds(n, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1

@@ -1,0 +1,93 @@
+"""CPU: pins the C oracle (oracle/oracle.c) against the golden fixtures produced by the independent
+big-integer model (tests/golden/gen_golden.py), and re-asserts the algebraic identities the reference's own
+tests use for this path (utils/src/msm.rs:186-193 msm == sum of mul_bigint; :268-275 pairing equalities)."""
+import numpy as np
+import pytest
+import oracle_c as O
+import bls12_381_model as M
+import util as U
+
+
+@pytest.mark.parametrize("name,G", [("g1_msm", O.G1), ("g2_msm", O.G2)])
+def test_msm_golden(name, G):
+    for case in U.load(name):
+        bases, inf, sc, exp = U.case_arrays(case)
+        for th in (1, 4):
+            got = U.jac_to_model(G, G.msm(bases, sc, inf, threads=th))
+            assert got == exp, (name, case["n"], case.get("note"))
+
+
+def test_digits_and_window_rule():
+    for d in U.load("digits"):
+        got = O.make_digits(O.int_to_limbs(int(d["scalar"], 16), 4), d["c"])
+        assert list(got) == d["digits"]
+        assert sum(int(x) << (d["c"] * i) for i, x in enumerate(got)) == int(d["scalar"], 16)
+    for n, c in U.load("window_c"):
+        assert O.window_c(n) == c
+
+
+def test_msm_equals_sum_of_scalar_muls():
+    # utils/src/msm.rs:186-193 — G1::msm([g1, g2], [e1, e2]) == g1*e1 + g2*e2
+    for G in (O.G1, O.G2):
+        bases, _, _ = U.seq_bases(G, 2, 42, threads=1)
+        sc = O.rand_scalars(43, 2)
+        lhs = G.msm(bases, sc)
+        rhs = G.add(G.mul(bases[0], sc[0]), G.mul(bases[1], sc[1]))
+        assert U.jac_to_model(G, lhs) == U.jac_to_model(G, rhs)
+
+
+def test_msm_closed_form_medium():
+    for G, n in ((O.G1, 3000), (O.G2, 300)):
+        bases, k0, d = U.seq_bases(G, n, 7)
+        sc = O.rand_scalars(9, n)
+        assert U.jac_to_model(G, G.msm(bases, sc, threads=4)) == U.closed_form(G, sc, k0, d)
+
+
+def test_fr_montgomery_roundtrip():
+    sc = O.rand_scalars(3, 50)
+    m = O.fr_to_mont(sc)
+    assert (O.fr_from_mont(m) == sc).all()
+    assert O.limbs_to_int(m[0]) == O.limbs_to_int(sc[0]) * M.FR_R % M.R
+
+
+def test_pairing_golden():
+    pr = U.load("pairing")
+    g1, g2 = O.G1.generator(), O.G2.generator()
+    ml = O.multi_miller_loop(g1.reshape(1, 12), g2.reshape(1, 24))
+    assert U.f12_ints(ml) == [int(v, 16) for v in pr["miller_g1_g2"]]
+    e = O.final_exponentiation(ml)
+    assert U.f12_ints(e) == [int(v, 16) for v in pr["e_g1_g2"]]
+    co = O.g2_prepare(g2)
+    assert pr["n_coeffs"] == 68
+    assert [U.fp_int(x) for x in co[0].reshape(6, 6)] == [int(v, 16) for v in pr["g2_prepared_gen_first"][0]]
+    assert [U.fp_int(x) for x in co[-1].reshape(6, 6)] == [int(v, 16) for v in pr["g2_prepared_gen_last"][0]]
+    for case in pr["cases"]:
+        ps = np.stack([U.g1_abi(U.dec_g1(p))[0] for p in case["p"]])
+        qs = np.stack([U.g2_abi(U.dec_g2(q))[0] for q in case["q"]])
+        for th in (1, 3):
+            f = O.multi_miller_loop(ps, qs, threads=th)
+            assert U.f12_ints(f) == [int(v, 16) for v in case["miller"]]
+        assert U.f12_ints(O.final_exponentiation(f)) == [int(v, 16) for v in case["gt"]]
+
+
+def test_pairing_identities():
+    g1, g2 = O.G1.generator(), O.G2.generator()
+    e = O.final_exponentiation(O.multi_miller_loop(g1.reshape(1, 12), g2.reshape(1, 24)))
+    # bilinearity with skip handling: prod e(a_i G1, b_i G2) == e(G1, G2)^(sum a_i b_i), skipped pair excluded
+    a = [3, 5, 7, 11, 13]
+    b = [2, 4, 6, 8, 10]
+    ps = np.stack([O.G1.to_affine(O.G1.mul(g1, O.int_to_limbs(x, 4)))[0] for x in a])
+    qs = np.stack([O.G2.to_affine(O.G2.mul(g2, O.int_to_limbs(x, 4)))[0] for x in b])
+    skip = np.array([0, 0, 1, 0, 0], np.uint8)
+    gt = O.final_exponentiation(O.multi_miller_loop(ps, qs, skip, threads=2))
+    tot = sum(x * y for i, (x, y) in enumerate(zip(a, b)) if i != 2)
+    assert (gt == O.fp12_pow(e, tot)).all()
+    # e(P, Q) * e(-P, Q) == 1
+    negp = ps[0].copy()
+    negp[6:] = U.fp_abi((-U.fp_int(ps[0][6:])) % U.P)
+    f = O.multi_miller_loop(np.stack([ps[0], negp]), np.stack([qs[0], qs[0]]))
+    assert (O.final_exponentiation(f) == O.fp12_one()).all()
+    # arkworks returns None for f == 0
+    assert O.final_exponentiation(np.zeros(72, np.uint64)) is None
+    with pytest.raises(AssertionError):
+        O.multi_miller_loop(ps[:2], qs[:3])

@@ -61,7 +61,7 @@ int32_t dgpu_shutdown(void) {
     (void)hipStreamSynchronize(g.stream);
     for (auto &h : g.handles) (void)hipFree(h.second.p);
     g.handles.clear();
-    Buf *bufs[] = {&g.in_bases, &g.in_inf, &g.in_scalars, &g.prepped, &g.cnt, &g.off, &g.cursor, &g.bsums, &g.entries, &g.bucket, &g.bucket_inf, &g.head, &g.tail, &g.head_b, &g.tail_b, &g.part_inf, &g.l1, &g.l1_inf, &g.win, &g.win_inf};
+    Buf *bufs[] = {&g.in_bases, &g.in_inf, &g.in_scalars, &g.prepped, &g.digits, &g.heavy, &g.cnt, &g.off, &g.cursor, &g.bsums, &g.entries, &g.bucket, &g.bucket_inf, &g.head, &g.tail, &g.head_b, &g.tail_b, &g.part_inf, &g.l1, &g.l1_inf, &g.win, &g.win_inf};
     for (Buf *b : bufs) b->release();
     for (hipEvent_t e : g.ev_pool) (void)hipEventDestroy(e);
     g.ev_pool.clear(); g.prof_tab.clear();

@@ -44,7 +44,7 @@ struct Ctx {
     int window_bits = 0;
     int chunk = 0;
     // workspace (grow-only)
-    Buf in_bases, in_inf, in_scalars, prepped, cnt, off, cursor, bsums, entries, bucket, bucket_inf, head, tail, head_b, tail_b, part_inf, l1, l1_inf, win, win_inf;
+    Buf in_bases, in_inf, in_scalars, prepped, digits, heavy, cnt, off, cursor, bsums, entries, bucket, bucket_inf, head, tail, head_b, tail_b, part_inf, l1, l1_inf, win, win_inf;
     std::map<uint64_t, Handle> handles;
     uint64_t next_handle = 1;
     // profiling

@@ -87,7 +87,90 @@ struct Fq2 {
     Fq2 sqr() const { Fq t = c0 * c1; return {(c0 + c1) * (c0 - c1), t + t}; }
     Fq2 dbl() const { return {c0.dbl(), c1.dbl()}; }
     Fq2 inv() const { Fq n = (c0.sqr() + c1.sqr()).inv(); return {c0 * n, (c1 * n).neg()}; }
+    Fq2 conj() const { return {c0, c1.neg()}; }
+    Fq2 mul_xi() const { return {c0 - c1, c0 + c1}; }          // * (1 + u)
+    Fq2 mul_fq(const Fq &k) const { return {c0 * k, c1 * k}; }
 };
+
+// Fq6 = Fq2[v]/(v^3 - (1+u)), Fq12 = Fq6[w]/(w^2 - v): host side of the pairing path — combining the per-step line
+// products that the GPU returns (dgpu_multi_miller_loop) and the final exponentiation, which the reference runs once
+// per batch (utils/src/randomized_pairing_check.rs:213, legogroth16/src/verifier.rs:78).
+struct Fq6 {
+    Fq2 c0, c1, c2;
+    static Fq6 zero() { return {Fq2::zero(), Fq2::zero(), Fq2::zero()}; }
+    static Fq6 one() { return {Fq2::one(), Fq2::zero(), Fq2::zero()}; }
+    bool is_zero() const { return c0.is_zero() && c1.is_zero() && c2.is_zero(); }
+    Fq6 operator+(const Fq6 &b) const { return {c0 + b.c0, c1 + b.c1, c2 + b.c2}; }
+    Fq6 operator-(const Fq6 &b) const { return {c0 - b.c0, c1 - b.c1, c2 - b.c2}; }
+    Fq6 neg() const { return {c0.neg(), c1.neg(), c2.neg()}; }
+    Fq6 operator*(const Fq6 &b) const {
+        Fq2 t0 = c0 * b.c0, t1 = c1 * b.c1, t2 = c2 * b.c2;
+        Fq2 r0 = ((c1 + c2) * (b.c1 + b.c2) - t1 - t2).mul_xi() + t0;
+        Fq2 r1 = (c0 + c1) * (b.c0 + b.c1) - t0 - t1 + t2.mul_xi();
+        Fq2 r2 = (c0 + c2) * (b.c0 + b.c2) - t0 - t2 + t1;
+        return {r0, r1, r2};
+    }
+    Fq6 mul_v() const { return {c2.mul_xi(), c0, c1}; }
+    Fq6 inv() const {
+        Fq2 t0 = c0.sqr() - (c1 * c2).mul_xi();
+        Fq2 t1 = c2.sqr().mul_xi() - c0 * c1;
+        Fq2 t2 = c1.sqr() - c0 * c2;
+        Fq2 n = ((c2 * t1 + c1 * t2).mul_xi() + c0 * t0).inv();
+        return {t0 * n, t1 * n, t2 * n};
+    }
+};
+struct Fq12 {
+    Fq6 c0, c1;
+    static Fq12 one() { return {Fq6::one(), Fq6::zero()}; }
+    bool is_zero() const { return c0.is_zero() && c1.is_zero(); }
+    Fq12 operator*(const Fq12 &b) const {
+        Fq6 t0 = c0 * b.c0, t1 = c1 * b.c1;
+        return {t0 + t1.mul_v(), (c0 + c1) * (b.c0 + b.c1) - t0 - t1};
+    }
+    Fq12 sqr() const { return (*this) * (*this); }
+    Fq12 conj() const { return {c0, c1.neg()}; }
+    Fq12 inv() const { Fq6 n = (c0 * c0 - (c1 * c1).mul_v()).inv(); return {c0 * n, (c1 * n).neg()}; }
+};
+
+// Frobenius coefficients xi^(i (p-1)/6) and their norms, derived at first use
+struct FrobTable {
+    Fq2 g1[6]; Fq g2[6];
+    FrobTable() {
+        static constexpr uint64_t E[6] = {0x49aa7ffffffff1c7ULL, 0x051caaaa72e35555ULL, 0xe688231ad3c82906ULL, 0xe613e1eb7deb831fULL, 0x0c849bf3b5e1f223ULL, 0x045582fc5eeaa66fULL};   // (p-1)/6
+        Fq2 xi = {Fq::one(), Fq::one()}, acc = Fq2::one(), base = xi;
+        for (int i = 0; i < 384; i++) { if ((E[i / 64] >> (i % 64)) & 1) acc = acc * base; base = base.sqr(); }
+        g1[0] = Fq2::one();
+        for (int i = 1; i < 6; i++) g1[i] = g1[i - 1] * acc;
+        for (int i = 0; i < 6; i++) g2[i] = g1[i].c0.sqr() + g1[i].c1.sqr();
+    }
+};
+inline const FrobTable &frob_table() { static const FrobTable t; return t; }
+inline Fq12 frob1(const Fq12 &a) {
+    const FrobTable &t = frob_table();
+    return {{a.c0.c0.conj(), a.c0.c1.conj() * t.g1[2], a.c0.c2.conj() * t.g1[4]}, {a.c1.c0.conj() * t.g1[1], a.c1.c1.conj() * t.g1[3], a.c1.c2.conj() * t.g1[5]}};
+}
+inline Fq12 frob2(const Fq12 &a) {
+    const FrobTable &t = frob_table();
+    return {{a.c0.c0, a.c0.c1.mul_fq(t.g2[2]), a.c0.c2.mul_fq(t.g2[4])}, {a.c1.c0.mul_fq(t.g2[1]), a.c1.c1.mul_fq(t.g2[3]), a.c1.c2.mul_fq(t.g2[5])}};
+}
+constexpr uint64_t BLS_X_ABS = 0xd201000000010000ULL;   // |x|, x < 0
+inline Fq12 exp_by_x(const Fq12 &a) {
+    Fq12 acc = Fq12::one();
+    for (int i = 63; i >= 0; i--) { acc = acc.sqr(); if ((BLS_X_ABS >> i) & 1) acc = acc * a; }
+    return acc.conj();
+}
+// ark-ec Bls12::final_exponentiation: easy part, then the x-chain that raises to 3 (p^4 - p^2 + 1)/r
+inline bool final_exponentiation(Fq12 &out, const Fq12 &f) {
+    if (f.is_zero()) return false;
+    Fq12 f1 = f.conj(), f2 = f.inv(), r = f1 * f2; f2 = r;
+    r = frob2(r) * f2;
+    Fq12 y0 = r.sqr(), y1 = exp_by_x(r), y2 = r.conj();
+    y1 = y1 * y2; y2 = exp_by_x(y1); y1 = y1.conj(); y1 = y1 * y2;
+    y2 = exp_by_x(y1); y1 = frob1(y1); y1 = y1 * y2; r = r * y0;
+    y0 = exp_by_x(y1); y2 = exp_by_x(y0); y0 = frob2(y1); y1 = y1.conj();
+    y1 = y1 * y2; y1 = y1 * y0; r = r * y1;
+    out = r; return true;
+}
 
 // Extended Jacobian point (x = X/ZZ, y = Y/ZZZ); identity: inf = true.
 template <class F> struct HXyzz {

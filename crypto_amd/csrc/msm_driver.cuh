@@ -84,11 +84,28 @@ int32_t msm_device(const uint32_t *d_bases, const uint32_t *d_scalars, size_t n,
     if ((rc = g.win_inf.ensure(W))) return rc;
 
     hipStream_t s = g.stream;
+    // counting sort of the n*W (key, term) pairs: digit codes -> LDS histograms per (window, bucket range) -> scan -> LDS cursors
+    const bool wide = c > 16;
+    const size_t n_pad = (n + 7) & ~(size_t)7;
+    int RANGES = 1; while ((B / RANGES) * 4 > 64 * 1024 || W * RANGES < 256) { if (B / RANGES <= 64) break; RANGES *= 2; }
+    int rb_log = 0; while ((1u << rb_log) < B / RANGES) rb_log++;
+    const int wpx = (W + 7) / 8;
+    const unsigned sort_grid = (unsigned)(8 * wpx * RANGES);
+    const size_t lds_bytes = ((size_t)1 << rb_log) * 4;
+    if ((rc = g.digits.ensure((size_t)W * n_pad * (wide ? 4 : 2)))) return rc;
+    const uint32_t heavy_thr = 16u * (uint32_t)CH, HEAVY_CAP = (uint32_t)(Emax / heavy_thr) + 1;   // at most E / thr buckets can be heavy
+    if ((rc = g.heavy.ensure(((size_t)HEAVY_CAP + 1) * 4))) return rc;
     {
         StageTimer st("msm.count");
-        HIPCHK(hipMemsetAsync(g.cnt.p, 0, ((size_t)NB + 1) * 4, s));
         HIPCHK(hipMemsetAsync(g.bucket_inf.p, 1, NB, s));
-        hipLaunchKernelGGL((k_digits<false>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_scalars, d_bases, C::AFF_STRIDE, 2 * C::FW, n, c, W, g.cnt.as<uint32_t>(), (uint32_t *)nullptr);
+        HIPCHK(hipMemsetAsync(g.heavy.p, 0, 4, s));
+        if (!wide) {
+            hipLaunchKernelGGL((k_digit_codes<uint16_t>), dim3((unsigned)((n_pad + 255) / 256)), dim3(256), 0, s, d_scalars, d_bases, C::AFF_STRIDE, 2 * C::FW, n, n_pad, c, W, g.digits.as<uint16_t>());
+            hipLaunchKernelGGL((k_sort_sweep<uint16_t, false>), dim3(sort_grid), dim3(1024), lds_bytes, s, g.digits.as<uint16_t>(), n, n_pad, W, RANGES, rb_log, B, g.cnt.as<uint32_t>(), (const uint32_t *)nullptr, (uint32_t *)nullptr, heavy_thr, g.heavy.as<uint32_t>(), HEAVY_CAP);
+        } else {
+            hipLaunchKernelGGL((k_digit_codes<uint32_t>), dim3((unsigned)((n_pad + 255) / 256)), dim3(256), 0, s, d_scalars, d_bases, C::AFF_STRIDE, 2 * C::FW, n, n_pad, c, W, g.digits.as<uint32_t>());
+            hipLaunchKernelGGL((k_sort_sweep<uint32_t, false>), dim3(sort_grid), dim3(1024), lds_bytes, s, g.digits.as<uint32_t>(), n, n_pad, W, RANGES, rb_log, B, g.cnt.as<uint32_t>(), (const uint32_t *)nullptr, (uint32_t *)nullptr, heavy_thr, g.heavy.as<uint32_t>(), HEAVY_CAP);
+        }
     }
     {
         StageTimer st("msm.scan");
@@ -98,17 +115,21 @@ int32_t msm_device(const uint32_t *d_bases, const uint32_t *d_scalars, size_t n,
     }
     {
         StageTimer st("msm.scatter");
-        hipLaunchKernelGGL((k_digits<true>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_scalars, d_bases, C::AFF_STRIDE, 2 * C::FW, n, c, W, g.cursor.as<uint32_t>(), g.entries.as<uint32_t>());
+        if (!wide) hipLaunchKernelGGL((k_sort_sweep<uint16_t, true>), dim3(sort_grid), dim3(1024), lds_bytes, s, g.digits.as<uint16_t>(), n, n_pad, W, RANGES, rb_log, B, (uint32_t *)nullptr, g.off.as<uint32_t>(), g.entries.as<uint32_t>(), heavy_thr, g.heavy.as<uint32_t>(), HEAVY_CAP);
+        else hipLaunchKernelGGL((k_sort_sweep<uint32_t, true>), dim3(sort_grid), dim3(1024), lds_bytes, s, g.digits.as<uint32_t>(), n, n_pad, W, RANGES, rb_log, B, (uint32_t *)nullptr, g.off.as<uint32_t>(), g.entries.as<uint32_t>(), heavy_thr, g.heavy.as<uint32_t>(), HEAVY_CAP);
     }
     {
         StageTimer st("msm.accumulate");
+        static const uint32_t dbg_mask = getenv("DGPU_DBG_NOGATHER") ? 1023u : 0xffffffffu;   // experiment: L2-resident points
         hipLaunchKernelGGL((k_accumulate<C>), dim3((unsigned)((T + 255) / 256)), dim3(256), 0, s, d_bases, g.entries.as<uint32_t>(), g.off.as<uint32_t>(), NB, g.bucket.as<uint32_t>(), g.bucket_inf.as<uint8_t>(),
-                           g.head.as<uint32_t>(), g.tail.as<uint32_t>(), g.head_b.as<uint32_t>(), g.tail_b.as<uint32_t>(), g.part_inf.as<uint8_t>(), T, (uint32_t)CH);
+                           g.head.as<uint32_t>(), g.tail.as<uint32_t>(), g.head_b.as<uint32_t>(), g.tail_b.as<uint32_t>(), g.part_inf.as<uint8_t>(), T, (uint32_t)CH, dbg_mask);
     }
     {
         StageTimer st("msm.fixup");
         hipLaunchKernelGGL((k_fixup<C>), dim3((unsigned)((T + 255) / 256)), dim3(256), 0, s, NB, g.bucket.as<uint32_t>(), g.bucket_inf.as<uint8_t>(), g.head.as<uint32_t>(), g.tail.as<uint32_t>(),
-                           g.head_b.as<uint32_t>(), g.tail_b.as<uint32_t>(), g.part_inf.as<uint8_t>(), T);
+                           g.head_b.as<uint32_t>(), g.tail_b.as<uint32_t>(), g.part_inf.as<uint8_t>(), T, g.off.as<uint32_t>(), heavy_thr);
+        hipLaunchKernelGGL((k_fixup_heavy<C>), dim3(512), dim3(C::HEAVY_T), 0, s, g.heavy.as<uint32_t>(), HEAVY_CAP, g.off.as<uint32_t>(), (uint32_t)CH, NB, g.bucket.as<uint32_t>(), g.bucket_inf.as<uint8_t>(),
+                           g.head.as<uint32_t>(), g.tail.as<uint32_t>(), g.part_inf.as<uint8_t>(), T);
     }
     {
         StageTimer st("msm.reduce");

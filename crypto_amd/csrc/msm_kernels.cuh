@@ -7,9 +7,10 @@
 // busy whatever the scalar distribution:
 //
 //   K1 prep_bases   ABI affine (2^384 Montgomery, 32-bit words) -> 128 B / 256 B records of 29-bit limbs
-//   K2 count        signed radix-2^c digits of every scalar; histogram of (window, |digit|-1) keys
+//   K2 digits+hist  signed radix-2^c digits of every scalar stored as 2-byte codes; histogram of (window, |digit|-1)
+//                   keys by blocks that each own a bucket range and count in LDS (no global atomics)
 //   K3 scan         exclusive prefix sum of the histogram (3 small kernels)
-//   K4 scatter      second digit pass: term index (+ sign bit) written at its key's cursor  (counting sort)
+//   K4 scatter      same sweep with LDS cursors: term index (+ sign bit) written at its key's slot (counting sort)
 //   K5 accumulate   thread t owns terms [t*CH, (t+1)*CH) of the sorted list: mixed XYZZ additions, runs that
 //                   lie inside the chunk go straight to the bucket array, the (at most two) runs cut by a
 //                   chunk border go to head/tail partial slots
@@ -30,7 +31,7 @@ namespace msm {
 using namespace bls29;
 
 #ifndef ACC_WAVES
-#define ACC_WAVES 3   // min waves/SIMD requested for the accumulate kernel (caps VGPRs at 168)
+#define ACC_WAVES 2   // waves/SIMD for the accumulate kernel: 256 VGPRs, no spills (tools/ubench/madd_rate: 6.35 vs 5.1 Gmadd/s at 3)
 #endif
 
 // ---- curve descriptions -------------------------------------------------------------------------
@@ -41,6 +42,7 @@ struct G1 {
     static constexpr int NFP = 1;            // Fp components per coordinate
     static constexpr int AFF_STRIDE = 32;    // u32 per prepared base record (128 B): x[14] y[14] flag pad[3]
     static constexpr int XW = 4 * FW;        // u32 per XYZZ point
+    static constexpr int HEAVY_T = 256;      // threads per block in k_fixup_heavy (XW * HEAVY_T * 4 B of LDS)
 };
 struct G2 {
     typedef Fp2 F;
@@ -49,6 +51,7 @@ struct G2 {
     static constexpr int NFP = 2;
     static constexpr int AFF_STRIDE = 64;    // 256 B: x[28] y[28] flag pad[7]
     static constexpr int XW = 4 * FW;
+    static constexpr int HEAVY_T = 128;
 };
 
 template <class F> __device__ __forceinline__ uint32_t *limbs(F &f) { return reinterpret_cast<uint32_t *>(&f); }
@@ -84,14 +87,18 @@ __global__ void __launch_bounds__(256) k_prep_bases(const uint32_t *__restrict__
 // Window w covers scalar bits [w c, w c + c); W = 255 / c + 1 windows, so the top window holds fewer than c
 // bits and never carries out.  digit in [-(B-1), B], B = 2^(c-1): magnitude-1 is the bucket index.
 
-template <bool SCATTER>
-__global__ void __launch_bounds__(256) k_digits(const uint32_t *__restrict__ scalars, const uint32_t *__restrict__ bases, int aff_stride, int flag_word,
-                                                size_t n, int c, int W, uint32_t *__restrict__ cnt_or_cursor, uint32_t *__restrict__ entries) {
+// K2a: every scalar's W signed digits, stored window-major as codes: code = (|d| - 1) | sign << (CB-1), all-ones = zero digit
+// (|d| - 1 <= 2^(c-1) - 1 needs c - 1 bits; a negative digit has |d| <= 2^(c-1) - 1, so the all-ones pattern is free).
+template <class CODE>
+__global__ void __launch_bounds__(256) k_digit_codes(const uint32_t *__restrict__ scalars, const uint32_t *__restrict__ bases, int aff_stride, int flag_word,
+                                                     size_t n, size_t n_pad, int c, int W, CODE *__restrict__ dig) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    if (bases[i * (size_t)aff_stride + flag_word]) return;   // identity base contributes nothing
-    uint32_t s[8];
-    {
+    if (i >= n_pad) return;
+    constexpr CODE ZERO = (CODE)~(CODE)0;
+    constexpr int SIGN = sizeof(CODE) * 8 - 1;
+    bool skip = (i >= n) || bases[i * (size_t)aff_stride + flag_word] != 0;   // padding / identity base contributes nothing
+    uint32_t s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (!skip) {
         const uint4 *p = reinterpret_cast<const uint4 *>(scalars + i * 8);
         uint4 a = p[0], b = p[1];
         s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w; s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w;
@@ -103,8 +110,7 @@ __global__ void __launch_bounds__(256) k_digits(const uint32_t *__restrict__ sca
         uint32_t raw = 0;
         if (bitpos < 256) {
             int wd = bitpos >> 5, sh = bitpos & 31;
-            // dynamic register indexing is avoided by selecting through a small switch-free reduction
-            uint64_t v = 0;
+            uint64_t v = 0;   // register array indexed through a select chain (no scratch)
 #pragma unroll
             for (int k = 0; k < 8; k++) { if (k == wd) v |= s[k]; if (k == wd + 1) v |= (uint64_t)s[k] << 32; }
             raw = (uint32_t)(v >> sh) & ((1u << c) - 1u);
@@ -113,10 +119,58 @@ __global__ void __launch_bounds__(256) k_digits(const uint32_t *__restrict__ sca
         uint32_t neg = v > B ? 1u : 0u;
         uint32_t mag = neg ? (2u * B - v) : v;
         carry = neg;
-        if (mag == 0) continue;
-        size_t key = (size_t)w * B + (mag - 1);
-        if (!SCATTER) atomicAdd(&cnt_or_cursor[key], 1u);
-        else { uint32_t pos = atomicAdd(&cnt_or_cursor[key], 1u); entries[pos] = (uint32_t)i | (neg << 31); }
+        CODE code = (mag == 0 || skip) ? ZERO : (CODE)((mag - 1) | (neg << SIGN));
+        dig[(size_t)w * n_pad + i] = code;
+    }
+}
+
+// K2b / K4: counting sort without global atomics.  Block (w, r) owns the RB = 2^rb_log buckets [r RB, (r+1) RB) of window w,
+// sweeps the whole digit column of that window (L2-resident: 2 B per term) and keeps its histogram / cursors in LDS.
+// blockIdx -> (w, r) is XCD-aware: the blocks of one window are spaced 8 apart so they share one XCD's L2.
+__device__ __forceinline__ void sort_block_coords(int W, int RANGES, int &w, int &r) {
+    int b = blockIdx.x, x = b & 7, q = b >> 3;          // x = XCD (observed round-robin placement; speed only)
+    int wpx = (W + 7) >> 3;                             // windows per XCD
+    r = q % RANGES;
+    w = x + 8 * (q / RANGES);
+    if (q / RANGES >= wpx) w = W;                       // padding block
+}
+template <class CODE, bool SCATTER>
+__global__ void __launch_bounds__(1024) k_sort_sweep(const CODE *__restrict__ dig, size_t n, size_t n_pad, int W, int RANGES, int rb_log, uint32_t B,
+                                                     uint32_t *__restrict__ cnt, const uint32_t *__restrict__ off, uint32_t *__restrict__ entries,
+                                                     uint32_t heavy_thr, uint32_t *__restrict__ heavy /* [0] = count, [1..cap] = keys */, uint32_t heavy_cap) {
+    extern __shared__ uint32_t lds[];
+    int w, r; sort_block_coords(W, RANGES, w, r);
+    if (w >= W) return;
+    const uint32_t RB = 1u << rb_log;
+    const size_t kbase = (size_t)w * B + (size_t)r * RB;
+    for (uint32_t j = threadIdx.x; j < RB; j += blockDim.x) lds[j] = SCATTER ? off[kbase + j] : 0u;
+    __syncthreads();
+    constexpr CODE ZERO = (CODE)~(CODE)0;
+    constexpr int SIGN = sizeof(CODE) * 8 - 1;
+    constexpr int PER = 16 / sizeof(CODE);              // codes per 16-byte load
+    const CODE *col = dig + (size_t)w * n_pad;
+    for (size_t base = (size_t)threadIdx.x * PER; base < n_pad; base += (size_t)blockDim.x * PER) {
+        uint4 v = *reinterpret_cast<const uint4 *>(col + base);
+        CODE cs[PER];
+        memcpy(cs, &v, 16);
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            CODE cd = cs[k];
+            if (cd == ZERO) continue;
+            uint32_t idx = (uint32_t)cd & ((1u << SIGN) - 1u);
+            if ((idx >> rb_log) != (uint32_t)r) continue;
+            uint32_t j = idx & (RB - 1);
+            if (!SCATTER) atomicAdd(&lds[j], 1u);
+            else { uint32_t pos = atomicAdd(&lds[j], 1u); entries[pos] = (uint32_t)(base + k) | ((uint32_t)(cd >> SIGN) << 31); }
+        }
+    }
+    if (!SCATTER) {
+        __syncthreads();
+        for (uint32_t j = threadIdx.x; j < RB; j += blockDim.x) {
+            uint32_t v = lds[j];
+            cnt[kbase + j] = v;
+            if (v >= heavy_thr) { uint32_t k = atomicAdd(&heavy[0], 1u); if (k < heavy_cap) heavy[1 + k] = (uint32_t)(kbase + j); }   // rare
+        }
     }
 }
 
@@ -202,7 +256,7 @@ template <class C>
 __global__ void __launch_bounds__(256, ACC_WAVES) k_accumulate(const uint32_t *__restrict__ bases, const uint32_t *__restrict__ entries, const uint32_t *__restrict__ off,
                                                     uint32_t NB, uint32_t *__restrict__ bucket, uint8_t *__restrict__ bucket_inf,
                                                     uint32_t *__restrict__ head, uint32_t *__restrict__ tail, uint32_t *__restrict__ head_b, uint32_t *__restrict__ tail_b,
-                                                    uint8_t *__restrict__ part_inf, size_t T, uint32_t CH) {
+                                                    uint8_t *__restrict__ part_inf, size_t T, uint32_t CH, uint32_t dbg_mask) {
     typedef typename C::F F;
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= T) return;
@@ -229,7 +283,7 @@ __global__ void __launch_bounds__(256, ACC_WAVES) k_accumulate(const uint32_t *_
             do { b++; bend = off[b + 1]; } while (bend == pos);
         }
         uint32_t e = entries[pos];
-        Aff<F> p; load_aff<C>(p, bases + (size_t)(e & 0x7fffffffu) * C::AFF_STRIDE);
+        Aff<F> p; load_aff<C>(p, bases + (size_t)(e & 0x7fffffffu & dbg_mask) * C::AFF_STRIDE);
         xyzz_madd(acc, inf, p, (e >> 31) != 0);
     }
     // the last run reaches the chunk end
@@ -246,12 +300,14 @@ __global__ void __launch_bounds__(256, ACC_WAVES) k_accumulate(const uint32_t *_
 template <class C>
 __global__ void __launch_bounds__(256) k_fixup(uint32_t NB, uint32_t *__restrict__ bucket, uint8_t *__restrict__ bucket_inf,
                                                const uint32_t *__restrict__ head, const uint32_t *__restrict__ tail, const uint32_t *__restrict__ head_b,
-                                               const uint32_t *__restrict__ tail_b, const uint8_t *__restrict__ part_inf, size_t T) {
+                                               const uint32_t *__restrict__ tail_b, const uint8_t *__restrict__ part_inf, size_t T,
+                                               const uint32_t *__restrict__ off, uint32_t heavy_thr) {
     typedef typename C::F F;
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= T) return;
     uint32_t b = tail_b[t];
     if (b == 0xffffffffu) return;
+    if (off[b + 1] - off[b] >= heavy_thr) return;   // folded by k_fixup_heavy
     Xyzz<F> acc; load_soa<C>(acc, tail, T, t);
     bool inf = part_inf[2 * t + 1] != 0;
     for (size_t k = t + 1; k < T && head_b[k] == b; k++) {
@@ -260,6 +316,49 @@ __global__ void __launch_bounds__(256) k_fixup(uint32_t NB, uint32_t *__restrict
     }
     store_soa<C>(bucket, NB, b, acc);
     bucket_inf[b] = inf;
+}
+
+// Buckets with >= heavy_thr terms span many chunks: one block per such bucket folds its pieces (the tail slot of the
+// chunk holding the bucket's first term, then the head slots of every following chunk up to the one holding its last
+// term): strided serial sums per thread, then a tree through LDS.  Bounds the worst case (all scalars equal) to
+// span/256 + 8 dependent additions instead of span.
+template <class C>
+__global__ void __launch_bounds__(C::HEAVY_T) k_fixup_heavy(const uint32_t *__restrict__ heavy, uint32_t heavy_cap, const uint32_t *__restrict__ off, uint32_t CH,
+                                                     uint32_t NB, uint32_t *__restrict__ bucket, uint8_t *__restrict__ bucket_inf,
+                                                     const uint32_t *__restrict__ head, const uint32_t *__restrict__ tail, const uint8_t *__restrict__ part_inf, size_t T) {
+    typedef typename C::F F;
+    constexpr int BT = C::HEAVY_T;
+    __shared__ uint32_t sh[C::XW * BT];
+    __shared__ uint8_t shinf[BT];
+    uint32_t nh = heavy[0]; if (nh > heavy_cap) nh = heavy_cap;
+    for (uint32_t hi = blockIdx.x; hi < nh; hi += gridDim.x) {
+        const uint32_t b = heavy[1 + hi];
+        const size_t t0 = off[b] / CH, t1 = (off[b + 1] - 1) / CH;
+        Xyzz<F> acc; bool inf = true;
+        fzero(acc.x); fzero(acc.y); fzero(acc.zz); fzero(acc.zzz);
+        for (size_t t = t0 + threadIdx.x; t <= t1; t += BT) {
+            Xyzz<F> o; bool oinf;
+            if (t == t0) { load_soa<C>(o, tail, T, t); oinf = part_inf[2 * t + 1] != 0; }
+            else { load_soa<C>(o, head, T, t); oinf = part_inf[2 * t] != 0; }
+            xyzz_add(acc, inf, o, oinf);
+        }
+        for (int s2 = BT / 2; s2 >= 1; s2 >>= 1) {
+            __syncthreads();
+            if ((int)threadIdx.x >= s2 && (int)threadIdx.x < 2 * s2) {
+                const uint32_t *w = reinterpret_cast<const uint32_t *>(&acc);
+                for (int k = 0; k < C::XW; k++) sh[k * BT + threadIdx.x] = w[k];
+                shinf[threadIdx.x] = inf;
+            }
+            __syncthreads();
+            if ((int)threadIdx.x < s2) {
+                Xyzz<F> o; uint32_t *w = reinterpret_cast<uint32_t *>(&o);
+                for (int k = 0; k < C::XW; k++) w[k] = sh[k * BT + threadIdx.x + s2];
+                xyzz_add(acc, inf, o, shinf[threadIdx.x + s2] != 0);
+            }
+        }
+        if (threadIdx.x == 0) { store_soa<C>(bucket, NB, b, acc); bucket_inf[b] = inf; }
+        __syncthreads();
+    }
 }
 
 // ---- K7/K8: sum_k (k+1) * B_k ----------------------------------------------------------------------------

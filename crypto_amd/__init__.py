@@ -8,3 +8,4 @@ from ._native import lib, DockGpuError, build_native  # noqa: F401
 from .msm import (  # noqa: F401
     G1, G2, msm_bigint, msm_unchecked, msm, Pairs, DeviceBases, DeviceScalars, init, prof,
 )
+from .pairing import multi_miller_loop, final_exponentiation, multi_pairing  # noqa: F401,E402

@@ -61,7 +61,7 @@ int32_t dgpu_shutdown(void) {
     (void)hipStreamSynchronize(g.stream);
     for (auto &h : g.handles) (void)hipFree(h.second.p);
     g.handles.clear();
-    Buf *bufs[] = {&g.in_bases, &g.in_inf, &g.in_scalars, &g.prepped, &g.digits, &g.heavy, &g.cnt, &g.off, &g.cursor, &g.bsums, &g.entries, &g.bucket, &g.bucket_inf, &g.head, &g.tail, &g.head_b, &g.tail_b, &g.part_inf, &g.l1, &g.l1_inf, &g.win, &g.win_inf};
+    Buf *bufs[] = {&g.in_bases, &g.in_inf, &g.in_scalars, &g.prepped, &g.digits, &g.heavy, &g.cnt, &g.off, &g.cursor, &g.bsums, &g.entries, &g.bucket, &g.bucket_inf, &g.head, &g.tail, &g.head_b, &g.tail_b, &g.part_inf, &g.l1, &g.l1_inf, &g.win, &g.win_inf, &g.ml_lines, &g.ml_partial, &g.ml_out};
     for (Buf *b : bufs) b->release();
     for (hipEvent_t e : g.ev_pool) (void)hipEventDestroy(e);
     g.ev_pool.clear(); g.prof_tab.clear();
@@ -114,8 +114,6 @@ int32_t dgpu_scalars_upload(const uint64_t *s, size_t n, int32_t mont, uint64_t 
     return DGPU_OK;
 }
 
-int32_t dgpu_multi_miller_loop(const uint64_t *, const uint64_t *, const uint8_t *, size_t, uint64_t *) { return DGPU_E_NODEVICE; }   // next milestone (K7)
-int32_t dgpu_final_exponentiation(const uint64_t *, uint64_t *) { return DGPU_E_NODEVICE; }
 
 int32_t dgpu_prof_enable(int32_t on) { std::lock_guard<std::mutex> lk(g.mu); g.prof = on != 0; return DGPU_OK; }
 int32_t dgpu_prof_reset(void) { std::lock_guard<std::mutex> lk(g.mu); g.prof_tab.clear(); return DGPU_OK; }

@@ -44,7 +44,7 @@ struct Ctx {
     int window_bits = 0;
     int chunk = 0;
     // workspace (grow-only)
-    Buf in_bases, in_inf, in_scalars, prepped, digits, heavy, cnt, off, cursor, bsums, entries, bucket, bucket_inf, head, tail, head_b, tail_b, part_inf, l1, l1_inf, win, win_inf;
+    Buf in_bases, in_inf, in_scalars, prepped, digits, heavy, cnt, off, cursor, bsums, entries, bucket, bucket_inf, head, tail, head_b, tail_b, part_inf, l1, l1_inf, win, win_inf, ml_lines, ml_partial, ml_out;
     std::map<uint64_t, Handle> handles;
     uint64_t next_handle = 1;
     // profiling
@@ -78,6 +78,10 @@ inline void prof_flush() {
 }
 
 
+inline void prof_add_host(const char *name, double ms) {
+    for (auto &t : g.prof_tab) if (t.name == name) { t.ms += ms; t.calls++; return; }
+    g.prof_tab.push_back({name, ms, 1});
+}
 int choose_c(size_t n);
 int choose_chunk();
 int32_t upload_scalars(const uint64_t *h, size_t n, bool mont, uint32_t *d_out);

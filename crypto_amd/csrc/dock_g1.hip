@@ -17,7 +17,7 @@ int32_t dgpu_selftest_fp_mul(const uint64_t *a, const uint64_t *b, size_t n, uin
     void *da, *db, *dout;
     HIPCHK(hipMalloc(&da, n * 48 + 16)); HIPCHK(hipMalloc(&db, n * 48 + 16)); HIPCHK(hipMalloc(&dout, n * 48 + 16));
     HIPCHK(hipMemcpy(da, a, n * 48, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(db, b, n * 48, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_selftest_fp_mul, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, g.stream, (const uint32_t *)da, (const uint32_t *)db, n, (uint32_t *)dout);
+    launch_selftest_fp_mul(g.stream, (const uint32_t *)da, (const uint32_t *)db, n, (uint32_t *)dout);
     HIPCHK(hipStreamSynchronize(g.stream));
     HIPCHK(hipMemcpy(out, dout, n * 48, hipMemcpyDeviceToHost));
     (void)hipFree(da); (void)hipFree(db); (void)hipFree(dout);
@@ -31,7 +31,7 @@ int32_t dgpu_selftest_g1_sum(const uint64_t *pts, const uint8_t *neg, size_t n, 
     HIPCHK(hipMalloc(&dp, n * 96 + 16)); HIPCHK(hipMalloc(&dn, n + 16)); HIPCHK(hipMalloc(&dout, 4 * 48)); HIPCHK(hipMalloc(&dinf, 16));
     HIPCHK(hipMemcpy(dp, pts, n * 96, hipMemcpyHostToDevice));
     if (neg) HIPCHK(hipMemcpy(dn, neg, n, hipMemcpyHostToDevice)); else HIPCHK(hipMemset(dn, 0, n + 16));
-    hipLaunchKernelGGL(k_selftest_g1_sum, dim3(1), dim3(64), 0, g.stream, (const uint32_t *)dp, (const uint8_t *)dn, n, (uint32_t *)dout, (uint8_t *)dinf);
+    launch_selftest_g1_sum(g.stream, (const uint32_t *)dp, (const uint8_t *)dn, n, (uint32_t *)dout, (uint8_t *)dinf);
     HIPCHK(hipStreamSynchronize(g.stream));
     uint64_t w[24]; uint8_t inf;
     HIPCHK(hipMemcpy(w, dout, 4 * 48, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(&inf, dinf, 1, hipMemcpyDeviceToHost));

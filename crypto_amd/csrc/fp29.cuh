@@ -94,15 +94,33 @@ FD void fp_add(Fp &r, const Fp &a, const Fp &b) {
 }
 FD void fp_dbl(Fp &r, const Fp &a) { fp_add(r, a, a); }
 
-// r = a - b + M*p, M in {4,8,16,32,64}.  Preconditions: every limb of b is dominated by the matching limb
-// of K_M (limbs of K_M are >= 2^31 below the top, top limb ~ 13 M - 4) and a.l[i] + K_M[i] < 2^32.
+// Redundant form of M*p whose limbs dominate any normalised-ish subtrahend: limbs i < 13 are 2^31 + d_i (d_i < 2^29),
+// the top limb is whatever remains (~ 13 M - 4).  Generated at compile time for any M.
+template <int M> struct KTab {
+    uint32_t l[NL];
+    constexpr KTab() : l{} {
+        constexpr uint32_t P_[NL] = BLS29_P;
+        long long v[NL + 1] = {};
+        long long carry = 0;
+        for (int i = 0; i < NL; i++) { long long t = (long long)P_[i] * M + carry; v[i] = t & LMASK; carry = t >> LB; }
+        v[NL - 1] += carry << LB;                      // top limb keeps everything above bit 377
+        for (int i = 0; i < NL - 1; i++) {
+            // move 2^31 = 4 * 2^29 from limb i+1 down into limb i
+            v[i] += (1ll << 31);
+            v[i + 1] -= 4;
+            for (int j = i + 1; j < NL - 1 && v[j] < 0; j++) { v[j] += (1ll << LB); v[j + 1] -= 1; }
+        }
+        for (int i = 0; i < NL; i++) l[i] = (uint32_t)v[i];
+    }
+};
+// r = a - b + M*p.  Preconditions (asserted under FP29_CHECK): every limb of b is dominated by the matching limb of K_M
+// and a.l[i] + K_M[i] < 2^32.
 template <int M> FD void fp_sub(Fp &r, const Fp &a, const Fp &b) {
-    static_assert(M == 4 || M == 8 || M == 16 || M == 32 || M == 64, "unsupported multiple");
-    constexpr uint32_t K4_[NL] = BLS29_K4; constexpr uint32_t K8_[NL] = BLS29_K8;
-    constexpr uint32_t K16_[NL] = BLS29_K16; constexpr uint32_t K32_[NL] = BLS29_K32; constexpr uint32_t K64_[NL] = BLS29_K64;
+    constexpr KTab<M> K{};
+    static_assert(M >= 2, "multiple too small");
 #pragma unroll
     for (int i = 0; i < NL; i++) {
-        const uint32_t k = (M == 4) ? K4_[i] : (M == 8) ? K8_[i] : (M == 16) ? K16_[i] : (M == 32) ? K32_[i] : K64_[i];
+        const uint32_t k = K.l[i];
         CHK(assert(b.ub[i] <= k); assert(a.ub[i] + k < (1ull << 32));)
         CHK(uint64_t nub = a.ub[i] + k;)
         r.l[i] = a.l[i] + (k - b.l[i]);
@@ -110,6 +128,7 @@ template <int M> FD void fp_sub(Fp &r, const Fp &a, const Fp &b) {
     }
     CHK(r.vb = a.vb + M;)
 }
+static_assert(KTab<4>().l[0] == 0x9ffeaaacu && KTab<4>().l[13] == 0x30u && KTab<64>().l[5] == 0x941ed61au && KTab<64>().l[13] == 0x33cu, "KTab generator");
 
 // one parallel carry pass: class L -> class N (limbs <= 2^29 + 7); value unchanged
 FD void fp_norm(Fp &r, const Fp &a) {

@@ -1,9 +1,10 @@
 // crypto_amd/csrc/msm_driver.cuh — host driver of the MSM pipeline (templated on the curve), included by
 // dock_g1.hip and dock_g2.hip so the two curves compile in parallel.
 #pragma once
+#include <chrono>
 #include "dock_ctx.hpp"
 #include "host_field.hpp"
-#include "msm_kernels.cuh"
+#include "msm_launch.cuh"
 
 namespace dock {
 using namespace msm;
@@ -63,7 +64,7 @@ int32_t msm_device(const uint32_t *d_bases, const uint32_t *d_scalars, size_t n,
     const int CH = choose_chunk();
     const size_t Emax = (size_t)n * W;
     const size_t T = (Emax + CH - 1) / CH;
-    const size_t nblk = ((size_t)NB + SCAN_B - 1) / SCAN_B;
+    const size_t nblk = scan_blocks(NB);
 
     int32_t rc;
     if ((rc = g.cnt.ensure(((size_t)NB + 1) * 4))) return rc;
@@ -99,51 +100,50 @@ int32_t msm_device(const uint32_t *d_bases, const uint32_t *d_scalars, size_t n,
         StageTimer st("msm.count");
         HIPCHK(hipMemsetAsync(g.bucket_inf.p, 1, NB, s));
         HIPCHK(hipMemsetAsync(g.heavy.p, 0, 4, s));
-        if (!wide) {
-            hipLaunchKernelGGL((k_digit_codes<uint16_t>), dim3((unsigned)((n_pad + 255) / 256)), dim3(256), 0, s, d_scalars, d_bases, C::AFF_STRIDE, 2 * C::FW, n, n_pad, c, W, g.digits.as<uint16_t>());
-            hipLaunchKernelGGL((k_sort_sweep<uint16_t, false>), dim3(sort_grid), dim3(1024), lds_bytes, s, g.digits.as<uint16_t>(), n, n_pad, W, RANGES, rb_log, B, g.cnt.as<uint32_t>(), (const uint32_t *)nullptr, (uint32_t *)nullptr, heavy_thr, g.heavy.as<uint32_t>(), HEAVY_CAP);
-        } else {
-            hipLaunchKernelGGL((k_digit_codes<uint32_t>), dim3((unsigned)((n_pad + 255) / 256)), dim3(256), 0, s, d_scalars, d_bases, C::AFF_STRIDE, 2 * C::FW, n, n_pad, c, W, g.digits.as<uint32_t>());
-            hipLaunchKernelGGL((k_sort_sweep<uint32_t, false>), dim3(sort_grid), dim3(1024), lds_bytes, s, g.digits.as<uint32_t>(), n, n_pad, W, RANGES, rb_log, B, g.cnt.as<uint32_t>(), (const uint32_t *)nullptr, (uint32_t *)nullptr, heavy_thr, g.heavy.as<uint32_t>(), HEAVY_CAP);
-        }
+        launch_digit_codes(s, wide, d_scalars, d_bases, C::AFF_STRIDE, 2 * C::FW, n, n_pad, c, W, g.digits.p);
+        launch_sort_sweep(s, wide, false, sort_grid, lds_bytes, g.digits.p, n, n_pad, W, RANGES, rb_log, B, g.cnt.as<uint32_t>(), nullptr, nullptr, heavy_thr, g.heavy.as<uint32_t>(), HEAVY_CAP);
     }
     {
         StageTimer st("msm.scan");
-        hipLaunchKernelGGL(k_scan_block, dim3((unsigned)nblk), dim3(SCAN_T), 0, s, g.cnt.as<uint32_t>(), g.off.as<uint32_t>(), g.bsums.as<uint32_t>(), (size_t)NB);
-        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, s, g.bsums.as<uint32_t>(), nblk);
-        hipLaunchKernelGGL(k_scan_add, dim3((unsigned)((NB + 1 + 255) / 256)), dim3(256), 0, s, g.off.as<uint32_t>(), g.cursor.as<uint32_t>(), g.bsums.as<uint32_t>(), (size_t)NB, nblk);
+        launch_scan(s, g.cnt.as<uint32_t>(), g.off.as<uint32_t>(), g.cursor.as<uint32_t>(), g.bsums.as<uint32_t>(), (size_t)NB);
     }
     {
         StageTimer st("msm.scatter");
-        if (!wide) hipLaunchKernelGGL((k_sort_sweep<uint16_t, true>), dim3(sort_grid), dim3(1024), lds_bytes, s, g.digits.as<uint16_t>(), n, n_pad, W, RANGES, rb_log, B, (uint32_t *)nullptr, g.off.as<uint32_t>(), g.entries.as<uint32_t>(), heavy_thr, g.heavy.as<uint32_t>(), HEAVY_CAP);
-        else hipLaunchKernelGGL((k_sort_sweep<uint32_t, true>), dim3(sort_grid), dim3(1024), lds_bytes, s, g.digits.as<uint32_t>(), n, n_pad, W, RANGES, rb_log, B, (uint32_t *)nullptr, g.off.as<uint32_t>(), g.entries.as<uint32_t>(), heavy_thr, g.heavy.as<uint32_t>(), HEAVY_CAP);
+        launch_sort_sweep(s, wide, true, sort_grid, lds_bytes, g.digits.p, n, n_pad, W, RANGES, rb_log, B, nullptr, g.off.as<uint32_t>(), g.entries.as<uint32_t>(), heavy_thr, g.heavy.as<uint32_t>(), HEAVY_CAP);
     }
     {
         StageTimer st("msm.accumulate");
         static const uint32_t dbg_mask = getenv("DGPU_DBG_NOGATHER") ? 1023u : 0xffffffffu;   // experiment: L2-resident points
-        hipLaunchKernelGGL((k_accumulate<C>), dim3((unsigned)((T + 255) / 256)), dim3(256), 0, s, d_bases, g.entries.as<uint32_t>(), g.off.as<uint32_t>(), NB, g.bucket.as<uint32_t>(), g.bucket_inf.as<uint8_t>(),
+        launch_accumulate<C>(s, d_bases, g.entries.as<uint32_t>(), g.off.as<uint32_t>(), NB, g.bucket.as<uint32_t>(), g.bucket_inf.as<uint8_t>(),
                            g.head.as<uint32_t>(), g.tail.as<uint32_t>(), g.head_b.as<uint32_t>(), g.tail_b.as<uint32_t>(), g.part_inf.as<uint8_t>(), T, (uint32_t)CH, dbg_mask);
     }
     {
         StageTimer st("msm.fixup");
-        hipLaunchKernelGGL((k_fixup<C>), dim3((unsigned)((T + 255) / 256)), dim3(256), 0, s, NB, g.bucket.as<uint32_t>(), g.bucket_inf.as<uint8_t>(), g.head.as<uint32_t>(), g.tail.as<uint32_t>(),
+        launch_fixup<C>(s, NB, g.bucket.as<uint32_t>(), g.bucket_inf.as<uint8_t>(), g.head.as<uint32_t>(), g.tail.as<uint32_t>(),
                            g.head_b.as<uint32_t>(), g.tail_b.as<uint32_t>(), g.part_inf.as<uint8_t>(), T, g.off.as<uint32_t>(), heavy_thr);
-        hipLaunchKernelGGL((k_fixup_heavy<C>), dim3(512), dim3(C::HEAVY_T), 0, s, g.heavy.as<uint32_t>(), HEAVY_CAP, g.off.as<uint32_t>(), (uint32_t)CH, NB, g.bucket.as<uint32_t>(), g.bucket_inf.as<uint8_t>(),
+        launch_fixup_heavy<C>(s, g.heavy.as<uint32_t>(), HEAVY_CAP, g.off.as<uint32_t>(), (uint32_t)CH, NB, g.bucket.as<uint32_t>(), g.bucket_inf.as<uint8_t>(),
                            g.head.as<uint32_t>(), g.tail.as<uint32_t>(), g.part_inf.as<uint8_t>(), T);
     }
     {
         StageTimer st("msm.reduce");
-        hipLaunchKernelGGL((k_reduce_l0<C>), dim3((unsigned)NG), dim3(64), 0, s, g.bucket.as<uint32_t>(), g.bucket_inf.as<uint8_t>(), NB, mshift, g.l1.as<uint32_t>(), g.l1_inf.as<uint8_t>());
-        hipLaunchKernelGGL((k_reduce_top<C>), dim3((unsigned)W), dim3(64), 0, s, g.l1.as<uint32_t>(), g.l1_inf.as<uint8_t>(), G, 6 + mshift, g.win.as<uint32_t>(), g.win_inf.as<uint8_t>());
+        launch_reduce_l0<C>(s, (unsigned)NG, g.bucket.as<uint32_t>(), g.bucket_inf.as<uint8_t>(), NB, mshift, g.l1.as<uint32_t>(), g.l1_inf.as<uint8_t>());
+        launch_reduce_top<C>(s, (unsigned)W, g.l1.as<uint32_t>(), g.l1_inf.as<uint8_t>(), G, 6 + mshift, g.win.as<uint32_t>(), g.win_inf.as<uint8_t>());
     }
     HIPCHK(hipGetLastError());
     std::vector<uint64_t> hwin((size_t)W * 2 * C::ABI_W);
     std::vector<uint8_t> hinf(W);
     HIPCHK(hipMemcpyAsync(hwin.data(), g.win.p, (size_t)W * 4 * C::ABI_W * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(hinf.data(), g.win_inf.p, W, hipMemcpyDeviceToHost, s));
+    auto tsync0 = std::chrono::steady_clock::now();
     HIPCHK(hipStreamSynchronize(s));
+    auto tsync1 = std::chrono::steady_clock::now();
     if (g.prof) prof_flush();
     host_fold<HF>(hwin.data(), hinf.data(), W, c, out_xyz);
+    if (g.prof) {
+        auto t2 = std::chrono::steady_clock::now();
+        prof_add_host("msm.host_wait", std::chrono::duration<double, std::milli>(tsync1 - tsync0).count());
+        prof_add_host("msm.host_fold", std::chrono::duration<double, std::milli>(t2 - tsync1).count());
+    }
     return DGPU_OK;
 }
 
@@ -156,7 +156,7 @@ int32_t prep_bases(const uint64_t *h_bases, const uint8_t *h_inf, size_t n, uint
     uint8_t *dinf = nullptr;
     if (h_inf) { if ((rc = g.in_inf.ensure(n))) return rc; HIPCHK(hipMemcpyAsync(g.in_inf.p, h_inf, n, hipMemcpyHostToDevice, g.stream)); dinf = g.in_inf.as<uint8_t>(); }
     StageTimer st("msm.prep_bases");
-    hipLaunchKernelGGL((k_prep_bases<C>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, g.stream, g.in_bases.as<uint32_t>(), dinf, n, d_out);
+    launch_prep_bases<C>(g.stream, g.in_bases.as<uint32_t>(), dinf, n, d_out);
     return DGPU_OK;
 }
 

@@ -1,0 +1,28 @@
+// crypto_amd/csrc/msm_launch_impl.cuh — definitions of the per-curve launchers; included by the kernel translation
+// units, which explicitly instantiate the ones they own.
+#pragma once
+#include "msm_launch.cuh"
+
+namespace msm {
+template <class C> void launch_prep_bases(hipStream_t s, const uint32_t *abi, const uint8_t *is_inf, size_t n, uint32_t *out) {
+    hipLaunchKernelGGL((k_prep_bases<C>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, abi, is_inf, n, out);
+}
+template <class C> void launch_accumulate(hipStream_t s, const uint32_t *bases, const uint32_t *entries, const uint32_t *off, uint32_t NB, uint32_t *bucket, uint8_t *bucket_inf,
+                                          uint32_t *head, uint32_t *tail, uint32_t *head_b, uint32_t *tail_b, uint8_t *part_inf, size_t T, uint32_t CH, uint32_t dbg_mask) {
+    hipLaunchKernelGGL((k_accumulate<C>), dim3((unsigned)((T + 255) / 256)), dim3(256), 0, s, bases, entries, off, NB, bucket, bucket_inf, head, tail, head_b, tail_b, part_inf, T, CH, dbg_mask);
+}
+template <class C> void launch_fixup(hipStream_t s, uint32_t NB, uint32_t *bucket, uint8_t *bucket_inf, const uint32_t *head, const uint32_t *tail, const uint32_t *head_b,
+                                     const uint32_t *tail_b, const uint8_t *part_inf, size_t T, const uint32_t *off, uint32_t heavy_thr) {
+    hipLaunchKernelGGL((k_fixup<C>), dim3((unsigned)((T + 255) / 256)), dim3(256), 0, s, NB, bucket, bucket_inf, head, tail, head_b, tail_b, part_inf, T, off, heavy_thr);
+}
+template <class C> void launch_fixup_heavy(hipStream_t s, const uint32_t *heavy, uint32_t heavy_cap, const uint32_t *off, uint32_t CH, uint32_t NB, uint32_t *bucket, uint8_t *bucket_inf,
+                                           const uint32_t *head, const uint32_t *tail, const uint8_t *part_inf, size_t T) {
+    hipLaunchKernelGGL((k_fixup_heavy<C>), dim3(512), dim3(C::HEAVY_T), 0, s, heavy, heavy_cap, off, CH, NB, bucket, bucket_inf, head, tail, part_inf, T);
+}
+template <class C> void launch_reduce_l0(hipStream_t s, unsigned NG, const uint32_t *bucket, const uint8_t *bucket_inf, uint32_t NB, int mshift, uint32_t *l1, uint8_t *l1_inf) {
+    hipLaunchKernelGGL((k_reduce_l0<C>), dim3(NG), dim3(64), 0, s, bucket, bucket_inf, NB, mshift, l1, l1_inf);
+}
+template <class C> void launch_reduce_top(hipStream_t s, unsigned W, const uint32_t *l1, const uint8_t *l1_inf, int G, int gshift, uint32_t *win_abi, uint8_t *win_inf) {
+    hipLaunchKernelGGL((k_reduce_top<C>), dim3(W), dim3(64), 0, s, l1, l1_inf, G, gshift, win_abi, win_inf);
+}
+}  // namespace msm

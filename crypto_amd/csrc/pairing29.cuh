@@ -1,0 +1,166 @@
+// crypto_amd/csrc/pairing29.cuh — Fp6 / Fp12 tower and BLS12-381 Miller-loop line functions over the lazy 29-bit-limb
+// field (fp29.cuh / fp2_29.cuh), host+device.
+//
+// Device side of `Bls12_381::multi_miller_loop` (ark-ec 0.4 models/bls12/{mod,g2}.rs; the reference
+// enters it at utils/src/randomized_pairing_check.rs:207 and legogroth16/src/verifier.rs:69-76).  The line
+// coefficients are arkworks' exactly (M-twist: doubling (i, 3j, -h), addition (j, -theta, lambda), then c1 *= px,
+// c2 *= py), so the raw Fp12 Miller output is bit-identical to the oracle for any partition of the pairs — Fp12
+// products are exact and commute.
+//
+// Tower: Fp2 = Fp[u]/(u^2+1), Fp6 = Fp2[v]/(v^3 - (1+u)), Fp12 = Fp6[w]/(w^2 - v).
+// All functions take and return class-N elements (limbs <= 2^29+7); value bounds are carried by the FP29_CHECK
+// build (tests/test_device_code_on_host.py) which proves the chosen subtraction multiples are sufficient.
+#pragma once
+#include "fp29.cuh"
+#include "fp2_29.cuh"
+#include "ec29.cuh"
+
+namespace bls29 {
+
+#define BLS29_TWO_INV {0x1d4fdc2u, 0x15d00348u, 0x13894478u, 0x7acde62u, 0x9365b0au, 0x12c2df9bu, 0xdc2d61eu, 0x1e7c2b7du, 0x1c48f65eu, 0xd3f7602u, 0x1aad4478u, 0x13a0d636u, 0x198be187u, 0x4u}
+
+struct Fp6d { Fp2 c0, c1, c2; };
+struct Fp12d { Fp6d c0, c1; };
+
+// ---- Fp2 extras ----
+// square with a caller-chosen subtraction multiple (a.c1 may carry a value up to (M-1) p)
+template <int M> FD void f2_sqr_m(Fp2 &r, const Fp2 &a) {
+    Fp s, d, t;
+    fp_add(s, a.c0, a.c1);
+    fp_sub<M>(d, a.c0, a.c1); fp_norm(d, d);
+    fp_mul(t, a.c0, a.c1);
+    fp_mul(r.c0, s, d);
+    fp_add(r.c1, t, t); fp_norm(r.c1, r.c1);
+}
+// r = a * (1 + u), normalised;  a.c1 value < (M-1) p
+template <int M> FD void f2_mul_xi_n(Fp2 &r, const Fp2 &a) {
+    Fp t0, t1;
+    fp_sub<M>(t0, a.c0, a.c1); fp_add(t1, a.c0, a.c1);
+    fp_norm(r.c0, t0); fp_norm(r.c1, t1);
+}
+template <int M> FD void f2_neg_n(Fp2 &r, const Fp2 &a) { Fp2 z; fzero(z); fsub<M>(r, z, a); fnorm(r, r); }
+FD void f2_add_n(Fp2 &r, const Fp2 &a, const Fp2 &b) { fadd(r, a, b); fnorm(r, r); }
+template <int M> FD void f2_sub_n(Fp2 &r, const Fp2 &a, const Fp2 &b) { fsub<M>(r, a, b); fnorm(r, r); }
+
+// ---- Fp6 ----
+FD void f6_zero(Fp6d &r) { fzero(r.c0); fzero(r.c1); fzero(r.c2); }
+FD void f6_add_n(Fp6d &r, const Fp6d &a, const Fp6d &b) { f2_add_n(r.c0, a.c0, b.c0); f2_add_n(r.c1, a.c1, b.c1); f2_add_n(r.c2, a.c2, b.c2); }
+// full product, 6 Fp2 products (Karatsuba).  Inputs: value < ~400 p per coefficient.  Outputs: value < 64 p.
+FD void f6_mul(Fp6d &r, const Fp6d &a, const Fp6d &b) {
+    Fp2 t0, t1, t2, s, u, m, x, o0, o1, o2;
+    fmul(t0, a.c0, b.c0); fmul(t1, a.c1, b.c1); fmul(t2, a.c2, b.c2);
+    f2_add_n(s, a.c1, a.c2); f2_add_n(u, b.c1, b.c2); fmul(m, s, u);
+    fadd(x, t1, t2); f2_sub_n<16>(m, m, x);             // (a1+a2)(b1+b2) - t1 - t2
+    f2_mul_xi_n<32>(x, m); fadd(o0, x, t0); fnorm(o0, o0);
+    f2_add_n(s, a.c0, a.c1); f2_add_n(u, b.c0, b.c1); fmul(m, s, u);
+    fadd(x, t0, t1); f2_sub_n<16>(m, m, x);
+    f2_mul_xi_n<8>(x, t2); fadd(o1, m, x); fnorm(o1, o1);
+    f2_add_n(s, a.c0, a.c2); f2_add_n(u, b.c0, b.c2); fmul(m, s, u);
+    fadd(x, t0, t2); f2_sub_n<16>(m, m, x);
+    fadd(o2, m, t1); fnorm(o2, o2);
+    r.c0 = o0; r.c1 = o1; r.c2 = o2;
+}
+// r = a * v  (a coefficients value < 127 p)
+FD void f6_mul_v(Fp6d &r, const Fp6d &a) { Fp2 t; f2_mul_xi_n<128>(t, a.c2); r.c2 = a.c1; r.c1 = a.c0; r.c0 = t; }
+// a * (c0 + c1 v): 5 Fp2 products (ark-ff Fp6::mul_by_01)
+FD void f6_mul_by_01(Fp6d &r, const Fp6d &a, const Fp2 &c0, const Fp2 &c1) {
+    Fp2 aa, bb, s, u, m, x, o0, o1, o2;
+    fmul(aa, a.c0, c0); fmul(bb, a.c1, c1);
+    f2_add_n(s, a.c1, a.c2); fmul(m, s, c1); f2_sub_n<8>(m, m, bb);      // a1 c1 + a2 c1 - bb = a2 c1
+    f2_mul_xi_n<16>(x, m); fadd(o0, x, aa); fnorm(o0, o0);               // xi a2 c1 + a0 c0
+    f2_add_n(s, a.c0, a.c2); fmul(m, s, c0); f2_sub_n<8>(m, m, aa); fadd(o2, m, bb); fnorm(o2, o2);   // a2 c0 + a1 c1
+    f2_add_n(s, a.c0, a.c1); f2_add_n(u, c0, c1); fmul(m, s, u); fadd(x, aa, bb); f2_sub_n<16>(o1, m, x);   // a0 c1 + a1 c0
+    r.c0 = o0; r.c1 = o1; r.c2 = o2;
+}
+// a * (c1 v): 3 Fp2 products
+FD void f6_mul_by_1(Fp6d &r, const Fp6d &a, const Fp2 &c1) {
+    Fp2 t0, t1, t2;
+    fmul(t0, a.c2, c1); fmul(t1, a.c0, c1); fmul(t2, a.c1, c1);
+    f2_mul_xi_n<8>(r.c0, t0); r.c1 = t1; r.c2 = t2;
+}
+
+// ---- Fp12 ----
+FD void f12_set_one(Fp12d &r) { f6_zero(r.c0); f6_zero(r.c1); fset_one(r.c0.c0); }
+// 18 Fp2 products.  Inputs: coefficient values < 200 p.  Outputs: < 200 p.
+FD void f12_mul(Fp12d &r, const Fp12d &a, const Fp12d &b) {
+    Fp6d t0, t1, s, u, m, x;
+    f6_mul(t0, a.c0, b.c0); f6_mul(t1, a.c1, b.c1);
+    f6_add_n(s, a.c0, a.c1); f6_add_n(u, b.c0, b.c1); f6_mul(m, s, u);
+    // c1 = m - t0 - t1
+    fadd(x.c0, t0.c0, t1.c0); fadd(x.c1, t0.c1, t1.c1); fadd(x.c2, t0.c2, t1.c2);
+    f2_sub_n<128>(r.c1.c0, m.c0, x.c0); f2_sub_n<128>(r.c1.c1, m.c1, x.c1); f2_sub_n<128>(r.c1.c2, m.c2, x.c2);
+    // c0 = t0 + v t1
+    f6_mul_v(x, t1);
+    f6_add_n(r.c0, t0, x);
+}
+// f *= (c0 + c1 v + c4 v w)  — ark-ff Fp12::mul_by_014, 13 Fp2 products
+FD void f12_mul_by_014(Fp12d &f, const Fp2 &c0, const Fp2 &c1, const Fp2 &c4) {
+    Fp6d aa, bb, s, m, x; Fp2 o;
+    f6_mul_by_01(aa, f.c0, c0, c1);
+    f6_mul_by_1(bb, f.c1, c4);
+    f2_add_n(o, c1, c4);
+    f6_add_n(s, f.c0, f.c1);
+    f6_mul_by_01(m, s, c0, o);
+    fadd(x.c0, aa.c0, bb.c0); fadd(x.c1, aa.c1, bb.c1); fadd(x.c2, aa.c2, bb.c2);
+    f2_sub_n<128>(f.c1.c0, m.c0, x.c0); f2_sub_n<128>(f.c1.c1, m.c1, x.c1); f2_sub_n<128>(f.c1.c2, m.c2, x.c2);
+    f6_mul_v(x, bb);
+    f6_add_n(f.c0, aa, x);
+}
+// dense Fp12 from a sparse 014 element
+FD void f12_from_014(Fp12d &f, const Fp2 &c0, const Fp2 &c1, const Fp2 &c4) {
+    f6_zero(f.c0); f6_zero(f.c1);
+    f.c0.c0 = c0; f.c0.c1 = c1; f.c1.c1 = c4;
+}
+
+// ---- G2 line functions (homogeneous projective R = (X, Y, Z); ark-ec bls12/g2.rs double_in_place / add_in_place) ----
+struct G2Proj { Fp2 x, y, z; };
+struct Line { Fp2 c0, c1, c2; };
+
+FD void line_dbl_step(G2Proj &R, Line &l) {
+    constexpr uint32_t TI_[NL] = BLS29_TWO_INV;
+    Fp two_inv;
+#pragma unroll
+    for (int i = 0; i < NL; i++) two_inv.l[i] = TI_[i];
+    CHK(chk_set_N(two_inv, 1.0);)
+    Fp2 a, b, c, e, f, g, h, i, j, e2, t, d;
+    fmul(a, R.x, R.y); fmul_fp(a, a, two_inv);
+    f2_sqr_m<64>(b, R.y);
+    f2_sqr_m<64>(c, R.z);
+    fadd(t, c, c); fadd(t, t, c); fnorm(t, t);              // 3c
+    fdbl(t, t); fdbl(t, t); fnorm(t, t);                    // 12c
+    f2_mul_xi_n<128>(e, t);                                 // e = 4(1+u) * 3c
+    fadd(f, e, e); fadd(f, f, e); fnorm(f, f);              // f = 3e
+    fadd(t, b, f); fmul_fp(g, t, two_inv);                  // g = (b+f)/2
+    f2_add_n(t, R.y, R.z); f2_sqr_m<64>(h, t); fadd(t, b, c); f2_sub_n<16>(h, h, t);   // h = (Y+Z)^2 - (b+c)
+    f2_sub_n<8>(i, e, b);
+    f2_sqr_m<64>(j, R.x);
+    f2_sqr_m<256>(e2, e);
+    f2_sub_n<1024>(d, b, f);
+    fmul(R.x, a, d);
+    f2_sqr_m<64>(t, g); fadd(d, e2, e2); fadd(d, d, e2); f2_sub_n<32>(R.y, t, d);
+    fmul(R.z, b, h);
+    l.c0 = i;
+    fadd(t, j, j); fadd(t, t, j); fnorm(l.c1, t);
+    f2_neg_n<32>(l.c2, h);
+}
+FD void line_add_step(G2Proj &R, const Aff<Fp2> &Q, Line &l) {
+    Fp2 theta, lam, c, d, e, f, g, h, j, t, u;
+    fmul(t, Q.y, R.z); f2_sub_n<8>(theta, R.y, t);
+    fmul(t, Q.x, R.z); f2_sub_n<8>(lam, R.x, t);
+    f2_sqr_m<64>(c, theta); f2_sqr_m<64>(d, lam);
+    fmul(e, lam, d); fmul(f, R.z, c); fmul(g, R.x, d);
+    fadd(t, e, f); fadd(u, g, g); f2_sub_n<16>(h, t, u);
+    f2_sub_n<32>(t, g, h); fmul(t, theta, t); fmul(u, e, R.y);
+    fmul(R.x, lam, h);
+    f2_sub_n<8>(R.y, t, u);
+    fmul(R.z, R.z, e);
+    fmul(t, theta, Q.x); fmul(u, lam, Q.y); f2_sub_n<8>(j, t, u);
+    l.c0 = j; f2_neg_n<64>(l.c1, theta); l.c2 = lam;
+}
+// ark-ec `ell` for the M twist: c1 *= px, c2 *= py
+FD void line_eval(Line &l, const Fp &px, const Fp &py) { fmul_fp(l.c1, l.c1, px); fmul_fp(l.c2, l.c2, py); }
+
+constexpr uint64_t BLS_X_ABS = 0xd201000000010000ULL;
+constexpr int N_LINES = 68;
+
+}  // namespace bls29

@@ -1,0 +1,176 @@
+// crypto_amd/csrc/sort_kernels.cuh — curve-independent kernels of the MSM pipeline: signed-digit recoding, the LDS
+// counting sort (K2/K4), the histogram scan (K3) and the device self-tests.  Included by k_sort.hip only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "fp29.cuh"
+#include "ec29.cuh"
+
+namespace msm {
+using namespace bls29;
+
+// ---- digits ----------------------------------------------------------------------------------------
+// Window w covers scalar bits [w c, w c + c); W = 255 / c + 1 windows, so the top window holds fewer than c
+// bits and never carries out.  digit in [-(B-1), B], B = 2^(c-1): magnitude-1 is the bucket index.
+
+// K2a: every scalar's W signed digits, stored window-major as codes: code = (|d| - 1) | sign << (CB-1), all-ones = zero digit
+// (|d| - 1 <= 2^(c-1) - 1 needs c - 1 bits; a negative digit has |d| <= 2^(c-1) - 1, so the all-ones pattern is free).
+template <class CODE>
+__global__ void __launch_bounds__(256) k_digit_codes(const uint32_t *__restrict__ scalars, const uint32_t *__restrict__ bases, int aff_stride, int flag_word,
+                                                     size_t n, size_t n_pad, int c, int W, CODE *__restrict__ dig) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pad) return;
+    constexpr CODE ZERO = (CODE)~(CODE)0;
+    constexpr int SIGN = sizeof(CODE) * 8 - 1;
+    bool skip = (i >= n) || bases[i * (size_t)aff_stride + flag_word] != 0;   // padding / identity base contributes nothing
+    uint32_t s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (!skip) {
+        const uint4 *p = reinterpret_cast<const uint4 *>(scalars + i * 8);
+        uint4 a = p[0], b = p[1];
+        s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w; s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w;
+    }
+    const uint32_t B = 1u << (c - 1);
+    uint32_t carry = 0;
+    for (int w = 0; w < W; w++) {
+        int bitpos = w * c;
+        uint32_t raw = 0;
+        if (bitpos < 256) {
+            int wd = bitpos >> 5, sh = bitpos & 31;
+            uint64_t v = 0;   // register array indexed through a select chain (no scratch)
+#pragma unroll
+            for (int k = 0; k < 8; k++) { if (k == wd) v |= s[k]; if (k == wd + 1) v |= (uint64_t)s[k] << 32; }
+            raw = (uint32_t)(v >> sh) & ((1u << c) - 1u);
+        }
+        uint32_t v = raw + carry;
+        uint32_t neg = v > B ? 1u : 0u;
+        uint32_t mag = neg ? (2u * B - v) : v;
+        carry = neg;
+        CODE code = (mag == 0 || skip) ? ZERO : (CODE)((mag - 1) | (neg << SIGN));
+        dig[(size_t)w * n_pad + i] = code;
+    }
+}
+
+// K2b / K4: counting sort without global atomics.  Block (w, r) owns the RB = 2^rb_log buckets [r RB, (r+1) RB) of window w,
+// sweeps the whole digit column of that window (L2-resident: 2 B per term) and keeps its histogram / cursors in LDS.
+// blockIdx -> (w, r) is XCD-aware: the blocks of one window are spaced 8 apart so they share one XCD's L2.
+__device__ __forceinline__ void sort_block_coords(int W, int RANGES, int &w, int &r) {
+    int b = blockIdx.x, x = b & 7, q = b >> 3;          // x = XCD (observed round-robin placement; speed only)
+    int wpx = (W + 7) >> 3;                             // windows per XCD
+    r = q % RANGES;
+    w = x + 8 * (q / RANGES);
+    if (q / RANGES >= wpx) w = W;                       // padding block
+}
+template <class CODE, bool SCATTER>
+__global__ void __launch_bounds__(1024) k_sort_sweep(const CODE *__restrict__ dig, size_t n, size_t n_pad, int W, int RANGES, int rb_log, uint32_t B,
+                                                     uint32_t *__restrict__ cnt, const uint32_t *__restrict__ off, uint32_t *__restrict__ entries,
+                                                     uint32_t heavy_thr, uint32_t *__restrict__ heavy /* [0] = count, [1..cap] = keys */, uint32_t heavy_cap) {
+    extern __shared__ uint32_t lds[];
+    int w, r; sort_block_coords(W, RANGES, w, r);
+    if (w >= W) return;
+    const uint32_t RB = 1u << rb_log;
+    const size_t kbase = (size_t)w * B + (size_t)r * RB;
+    for (uint32_t j = threadIdx.x; j < RB; j += blockDim.x) lds[j] = SCATTER ? off[kbase + j] : 0u;
+    __syncthreads();
+    constexpr CODE ZERO = (CODE)~(CODE)0;
+    constexpr int SIGN = sizeof(CODE) * 8 - 1;
+    constexpr int PER = 16 / sizeof(CODE);              // codes per 16-byte load
+    const CODE *col = dig + (size_t)w * n_pad;
+    for (size_t base = (size_t)threadIdx.x * PER; base < n_pad; base += (size_t)blockDim.x * PER) {
+        uint4 v = *reinterpret_cast<const uint4 *>(col + base);
+        CODE cs[PER];
+        memcpy(cs, &v, 16);
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            CODE cd = cs[k];
+            if (cd == ZERO) continue;
+            uint32_t idx = (uint32_t)cd & ((1u << SIGN) - 1u);
+            if ((idx >> rb_log) != (uint32_t)r) continue;
+            uint32_t j = idx & (RB - 1);
+            if (!SCATTER) atomicAdd(&lds[j], 1u);
+            else { uint32_t pos = atomicAdd(&lds[j], 1u); entries[pos] = (uint32_t)(base + k) | ((uint32_t)(cd >> SIGN) << 31); }
+        }
+    }
+    if (!SCATTER) {
+        __syncthreads();
+        for (uint32_t j = threadIdx.x; j < RB; j += blockDim.x) {
+            uint32_t v = lds[j];
+            cnt[kbase + j] = v;
+            if (v >= heavy_thr) { uint32_t k = atomicAdd(&heavy[0], 1u); if (k < heavy_cap) heavy[1 + k] = (uint32_t)(kbase + j); }   // rare
+        }
+    }
+}
+
+// ---- K3: exclusive scan (u32), 4096 elements per block ----------------------------------------------
+constexpr int SCAN_T = 256, SCAN_E = 16, SCAN_B = SCAN_T * SCAN_E;
+__global__ void __launch_bounds__(SCAN_T) k_scan_block(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, uint32_t *__restrict__ block_sums, size_t n) {
+    __shared__ uint32_t sh[SCAN_T];
+    size_t base = (size_t)blockIdx.x * SCAN_B + (size_t)threadIdx.x * SCAN_E;
+    uint32_t v[SCAN_E], s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_E; k++) { v[k] = (base + k < n) ? in[base + k] : 0; s += v[k]; }
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int d = 1; d < SCAN_T; d <<= 1) {
+        uint32_t t = threadIdx.x >= d ? sh[threadIdx.x - d] : 0;
+        __syncthreads();
+        sh[threadIdx.x] += t;
+        __syncthreads();
+    }
+    uint32_t excl = sh[threadIdx.x] - s;
+    if (threadIdx.x == SCAN_T - 1) block_sums[blockIdx.x] = sh[threadIdx.x];
+#pragma unroll
+    for (int k = 0; k < SCAN_E; k++) { if (base + k < n) out[base + k] = excl; excl += v[k]; }
+}
+// single block: in-place exclusive scan of the block sums, total written to block_sums[nb]
+__global__ void __launch_bounds__(1024) k_scan_sums(uint32_t *__restrict__ block_sums, size_t nb) {
+    __shared__ uint32_t sh[1024];
+    __shared__ uint32_t carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (size_t base = 0; base < nb; base += 1024) {
+        size_t i = base + threadIdx.x;
+        uint32_t v = i < nb ? block_sums[i] : 0;
+        sh[threadIdx.x] = v;
+        __syncthreads();
+        for (int d = 1; d < 1024; d <<= 1) {
+            uint32_t t = threadIdx.x >= d ? sh[threadIdx.x - d] : 0;
+            __syncthreads();
+            sh[threadIdx.x] += t;
+            __syncthreads();
+        }
+        uint32_t c0 = carry_s;
+        if (i < nb) block_sums[i] = c0 + sh[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = c0 + sh[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) block_sums[nb] = carry_s;
+}
+// out[i] += block_sums[i / SCAN_B]; also writes out[n] = total and copies to cursor
+__global__ void __launch_bounds__(256) k_scan_add(uint32_t *__restrict__ out, uint32_t *__restrict__ cursor, const uint32_t *__restrict__ block_sums, size_t n, size_t nb) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { uint32_t v = out[i] + block_sums[i / SCAN_B]; out[i] = v; cursor[i] = v; }
+    if (i == n) out[n] = block_sums[nb];
+}
+
+// ---- self-test kernels (tests/: device arithmetic vs oracle without the MSM plumbing) ------------------------
+__global__ void k_selftest_fp_mul(const uint32_t *a, const uint32_t *b, size_t n, uint32_t *out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fp x, y, r; fp_from_abi(x, a + 12 * i); fp_from_abi(y, b + 12 * i);
+    fp_mul(r, x, y);
+    fp_to_abi(out + 12 * i, r);
+}
+// one thread: sum of (+/-) points by mixed additions, result in ABI XYZZ form
+__global__ void k_selftest_g1_sum(const uint32_t *pts_abi, const uint8_t *neg, size_t n, uint32_t *out, uint8_t *out_inf) {
+    if (blockIdx.x || threadIdx.x) return;
+    Xyzz<Fp> acc; bool inf = true;
+    fzero(acc.x); fzero(acc.y); fzero(acc.zz); fzero(acc.zzz);
+    for (size_t i = 0; i < n; i++) {
+        Aff<Fp> p; fp_from_abi(p.x, pts_abi + 24 * i); fp_from_abi(p.y, pts_abi + 24 * i + 12);
+        xyzz_madd(acc, inf, p, neg && neg[i]);
+    }
+    *out_inf = inf;
+    if (!inf) { fp_to_abi(out, acc.x); fp_to_abi(out + 12, acc.y); fp_to_abi(out + 24, acc.zz); fp_to_abi(out + 36, acc.zzz); }
+}
+
+}  // namespace msm

@@ -4,6 +4,9 @@
 #define FP29_CHECK 1
 #include "../../crypto_amd/csrc/fp29.cuh"
 #include "../../crypto_amd/csrc/ec29.cuh"
+#include "../../crypto_amd/csrc/pairing29.cuh"
+#include "../../crypto_amd/csrc/host_field.hpp"
+#include <vector>
 #include <string.h>
 using namespace bls29;
 extern "C" {
@@ -69,5 +72,52 @@ void shim_g2_add_tree(const uint32_t *pts, int n, uint32_t *out) {
     while (m > 1) { int h = (m + 1) / 2; for (int i = 0; i + h < m; i++) xyzz_add(v[i], f[i], v[i + h], f[i + h]); m = h; }
     if (n == 0) { memset(out, 0, 4 * 96); } else store_xyzz2(out, v[0], f[0]);
     delete[] v; delete[] f;
+}
+
+// ---- pairing tower / Miller-loop lines ----
+static void load_f12(Fp12d &f, const uint32_t *w) { Fp *c = reinterpret_cast<Fp *>(&f); for (int k = 0; k < 12; k++) fp_from_abi(c[k], w + 12 * k); }
+static void store_f12(uint32_t *w, const Fp12d &f) { const Fp *c = reinterpret_cast<const Fp *>(&f); for (int k = 0; k < 12; k++) fp_to_abi(w + 12 * k, c[k]); }
+static void load_f2(Fp2 &f, const uint32_t *w) { fp_from_abi(f.c0, w); fp_from_abi(f.c1, w + 12); }
+void shim_f12_mul(const uint32_t *a, const uint32_t *b, int reps, uint32_t *out) {
+    Fp12d x, y, r; load_f12(x, a); load_f12(y, b);
+    f12_mul(r, x, y);
+    for (int i = 1; i < reps; i++) { Fp12d t; f12_mul(t, r, y); r = t; }     // feed outputs back in: bounds must close
+    store_f12(out, r);
+}
+void shim_f12_mul_by_014(const uint32_t *a, const uint32_t *c0, const uint32_t *c1, const uint32_t *c4, int reps, uint32_t *out) {
+    Fp12d x; load_f12(x, a); Fp2 k0, k1, k4; load_f2(k0, c0); load_f2(k1, c1); load_f2(k4, c4);
+    for (int i = 0; i < reps; i++) f12_mul_by_014(x, k0, k1, k4);
+    store_f12(out, x);
+}
+static void pair_lines(std::vector<Line> &ls, const uint32_t *p, const uint32_t *q) {
+    Fp px, py; fp_from_abi(px, p); fp_from_abi(py, p + 12);
+    Aff<Fp2> Q; load_aff2(Q, q);
+    G2Proj R; R.x = Q.x; R.y = Q.y; fset_one(R.z);
+    for (int i = 62; i >= 0; i--) {
+        Line l; line_dbl_step(R, l); line_eval(l, px, py); ls.push_back(l);
+        if ((BLS_X_ABS >> i) & 1) { line_add_step(R, Q, l); line_eval(l, px, py); ls.push_back(l); }
+    }
+}
+// out: 68 x (c0, c1, c2) in ABI form (6 Fp each)
+void shim_miller_lines(const uint32_t *p, const uint32_t *q, uint32_t *out) {
+    std::vector<Line> ls; pair_lines(ls, p, q);
+    for (size_t s = 0; s < ls.size(); s++) { const Fp *c = reinterpret_cast<const Fp *>(&ls[s]); for (int k = 0; k < 6; k++) fp_to_abi(out + (s * 6 + k) * 12, c[k]); }
+}
+// the kernels' dataflow on the host: per-step products over the pairs (two halves combined with the dense product),
+// then the host-side square-and-multiply over the 68 step products, conjugation at the end
+void shim_multi_miller(const uint32_t *ps, const uint32_t *qs, int n, uint32_t *out) {
+    std::vector<std::vector<Line>> all(n);
+    for (int i = 0; i < n; i++) pair_lines(all[i], ps + 24 * i, qs + 48 * i);
+    hostf::Fq12 L[N_LINES];
+    for (int s = 0; s < N_LINES; s++) {
+        Fp12d half[2]; f12_set_one(half[0]); f12_set_one(half[1]);
+        for (int i = 0; i < n; i++) { Fp12d &h = half[i & 1]; f12_mul_by_014(h, all[i][s].c0, all[i][s].c1, all[i][s].c2); }
+        Fp12d prod; f12_mul(prod, half[0], half[1]);
+        uint32_t w[144]; store_f12(w, prod); memcpy(&L[s], w, 576);
+    }
+    hostf::Fq12 f = hostf::Fq12::one(); int idx = 0;
+    for (int i = 62; i >= 0; i--) { f = f.sqr() * L[idx++]; if ((BLS_X_ABS >> i) & 1) f = f * L[idx++]; }
+    f = f.conj();
+    memcpy(out, &f, 576);
 }
 }

@@ -1,0 +1,81 @@
+"""GPU (-m gpu): the batched Miller loop through the C ABI vs the CPU oracle (raw Fp12 equality — the line
+coefficients are arkworks' own, so the un-exponentiated Miller output must match limb for limb), the golden
+fixtures, and bilinearity at BASELINE config 3's size (1024 pairs)."""
+import numpy as np
+import pytest
+import torch
+import oracle_c as O
+import util as U
+import crypto_amd as ca
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _device():
+    assert torch.cuda.is_available()
+    ca.init(0)
+
+
+def pts(a, b):
+    g1, g2 = O.G1.generator(), O.G2.generator()
+    ps = np.stack([O.G1.to_affine(O.G1.mul(g1, O.int_to_limbs(x, 4)))[0] for x in a])
+    qs = np.stack([O.G2.to_affine(O.G2.mul(g2, O.int_to_limbs(x, 4)))[0] for x in b])
+    return ps, qs
+
+
+def test_golden_pairings():
+    pr = U.load("pairing")
+    g1, g2 = O.G1.generator(), O.G2.generator()
+    f = ca.multi_miller_loop(g1.reshape(1, 12), g2.reshape(1, 24))
+    assert U.f12_ints(f) == [int(v, 16) for v in pr["miller_g1_g2"]]
+    assert U.f12_ints(ca.final_exponentiation(f)) == [int(v, 16) for v in pr["e_g1_g2"]]
+    for case in pr["cases"]:
+        ps = np.stack([U.g1_abi(U.dec_g1(p))[0] for p in case["p"]])
+        qs = np.stack([U.g2_abi(U.dec_g2(q))[0] for q in case["q"]])
+        f = ca.multi_miller_loop(ps, qs)
+        assert U.f12_ints(f) == [int(v, 16) for v in case["miller"]]
+        assert U.f12_ints(ca.multi_pairing(ps, qs)) == [int(v, 16) for v in case["gt"]]
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 4, 5, 63, 64, 65, 200])
+def test_vs_oracle_raw_miller_output(n):
+    rng = np.random.default_rng(n)
+    a = [int(x) for x in rng.integers(1, 1 << 62, n)]
+    b = [int(x) for x in rng.integers(1, 1 << 62, n)]
+    ps, qs = pts(a, b) if n else (np.zeros((0, 12), np.uint64), np.zeros((0, 24), np.uint64))
+    skip = (rng.integers(0, 5, n) == 0).astype(np.uint8) if n else None
+    got = ca.multi_miller_loop(ps, qs, skip)
+    ref = O.multi_miller_loop(ps, qs, skip, threads=16) if n else O.fp12_one()
+    assert (got == ref).all()
+
+
+def test_identity_members_are_skipped_and_lengths_checked():
+    ps, qs = pts([3, 5, 7], [2, 4, 6])
+    ps2 = ps.copy(); ps2[1] = 0                       # all-zero words == identity
+    skip = np.array([0, 1, 0], np.uint8)
+    assert (ca.multi_miller_loop(ps2, qs) == O.multi_miller_loop(ps, qs, skip)).all()
+    with pytest.raises(ca.DockGpuError):
+        ca.multi_miller_loop(ps[:2], qs)
+    assert ca.final_exponentiation(np.zeros(72, np.uint64)) is None      # arkworks: None
+
+
+def test_batched_check_1024_pairs():
+    """config 3: prod e(a_i G1, b_i G2) == e(G1, G2)^(sum a_i b_i); and the RandomizedPairingChecker shape:
+    prod e(P_i, Q_i) * e(-sum..., ) == 1 (utils/src/randomized_pairing_check.rs:204-214)."""
+    n = 1024
+    rng = np.random.default_rng(7)
+    a = [int(x) for x in rng.integers(1, 1 << 40, n)]
+    b = [int(x) for x in rng.integers(1, 1 << 40, n)]
+    ps, qs = pts(a, b)
+    f = ca.multi_miller_loop(ps, qs)
+    assert (f == O.multi_miller_loop(ps, qs, threads=64)).all()
+    gt = ca.final_exponentiation(f)
+    g1, g2 = O.G1.generator(), O.G2.generator()
+    e = O.final_exponentiation(O.multi_miller_loop(g1.reshape(1, 12), g2.reshape(1, 24)))
+    assert (gt == O.fp12_pow(e, sum(x * y for x, y in zip(a, b)) % U.R)).all()
+    # append the pair (-(sum a_i b_i) G1, G2): the product must be one
+    tot = sum(x * y for x, y in zip(a, b)) % U.R
+    pn, qn = pts([U.R - tot], [1])
+    f2 = ca.multi_miller_loop(np.concatenate([ps, pn]), np.concatenate([qs, qn]))
+    assert (ca.final_exponentiation(f2) == O.fp12_one()).all()

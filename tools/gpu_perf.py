@@ -1,0 +1,51 @@
+"""Stage timings on the GPU box (development helper): G1/G2 MSM stages, 1024-pair Miller loop, CPU oracle alongside."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import numpy as np
+import crypto_amd as ca
+from crypto_amd._native import lib
+import oracle_c as O
+
+ca.init(0)
+what = os.environ.get("WHAT", "g1,g2,ml").split(",")
+
+def stages(fn, K=5):
+    fn()
+    ca.prof.enable(True); ca.prof.reset()
+    t0 = time.time()
+    for _ in range(K): fn()
+    dt = (time.time() - t0) / K
+    st = ca.prof.read(); ca.prof.enable(False)
+    return dt, " ".join("%s=%.3f" % (k.split(".")[1], v[0] / v[1]) for k, v in st.items())
+
+k0 = O.rand_scalars(1, 1)[0]; d = O.rand_scalars(2, 1)[0]
+if "g1" in what:
+    for lg in [int(x) for x in os.environ.get("G1_LOGS", "16,18,20,22").split(",")]:
+        n = 1 << lg
+        bases = O.G1.gen_seq(k0, d, n, threads=64); sc = O.rand_scalars(3, n)
+        db = ca.DeviceBases(ca.G1, bases); ds = ca.DeviceScalars(sc)
+        dt, s = stages(lambda: db.msm_resident(ds))
+        t0 = time.time(); ca.msm_bigint(ca.G1, bases, sc); one = time.time() - t0
+        print("G1 n=2^%d resident %.3f ms (one-shot %.1f ms) | %s" % (lg, dt * 1e3, one * 1e3, s), flush=True)
+        db.free(); ds.free()
+if "g2" in what:
+    for lg in [int(x) for x in os.environ.get("G2_LOGS", "16,18,20").split(",")]:
+        n = 1 << lg
+        bases = O.G2.gen_seq(k0, d, n, threads=64); sc = O.rand_scalars(3, n)
+        db = ca.DeviceBases(ca.G2, bases); ds = ca.DeviceScalars(sc)
+        dt, s = stages(lambda: db.msm_resident(ds), K=3)
+        print("G2 n=2^%d resident %.3f ms | %s" % (lg, dt * 1e3, s), flush=True)
+        if lg <= 16:
+            t0 = time.time(); O.G2.msm(bases, sc, threads=20); print("   CPU oracle G2 2^%d: %.3f s" % (lg, time.time() - t0))
+        db.free(); ds.free()
+if "ml" in what:
+    g1, g2 = O.G1.generator(), O.G2.generator()
+    n = 1024
+    P = O.G1.gen_seq(k0, d, n, threads=16); Q = O.G2.gen_seq(d, k0, n, threads=16)
+    f = ca.multi_miller_loop(P, Q)
+    t0 = time.time(); ref = O.multi_miller_loop(P, Q, threads=64); tc = time.time() - t0
+    print("ML 1024 pairs: GPU == oracle: %s; CPU oracle 64 thr %.3f s" % ((f == ref).all(), tc))
+    dt, s = stages(lambda: ca.multi_miller_loop(P, Q))
+    print("ML n=1024 %.3f ms (%.0f pairs/s) | %s" % (dt * 1e3, n / dt, s))
+    t0 = time.time(); gt = ca.final_exponentiation(f); print("final_exp host %.3f ms" % ((time.time() - t0) * 1e3))

@@ -4,7 +4,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libdock_gpu.so")
+_SO = os.environ.get("DGPU_LIB") or os.path.join(_HERE, "libdock_gpu.so")   # DGPU_LIB: development override (make g1only)
 
 ERR = {0: "DGPU_OK", -1: "DGPU_E_NODEVICE", -2: "DGPU_E_OOM", -3: "DGPU_E_BADARG", -4: "DGPU_E_HIP",
        -5: "DGPU_E_ZERO", -6: "DGPU_E_TOO_SMALL", -7: "DGPU_E_LENGTH"}

@@ -25,12 +25,12 @@ int choose_chunk() {
     return 64;
 }
 
-int32_t upload_scalars(const uint64_t *h, size_t n, bool mont, uint32_t *d_out) {
-    if (!mont) { HIPCHK(hipMemcpyAsync(d_out, h, n * 32, hipMemcpyHostToDevice, g.stream)); HIPCHK(hipStreamSynchronize(g.stream)); return DGPU_OK; }
+int32_t upload_scalars(Slot &sl, const uint64_t *h, size_t n, bool mont, uint32_t *d_out) {
+    if (!mont) { HIPCHK(hipMemcpyAsync(d_out, h, n * 32, hipMemcpyHostToDevice, sl.stream)); HIPCHK(hipStreamSynchronize(sl.stream)); return DGPU_OK; }
     std::vector<uint64_t> tmp(n * 4);
     for (size_t i = 0; i < n; i++) hostf::fr_from_mont(&tmp[4 * i], h + 4 * i);   // Fr::into_bigint (ark-ec msm_unchecked does the same on rayon)
-    HIPCHK(hipMemcpyAsync(d_out, tmp.data(), n * 32, hipMemcpyHostToDevice, g.stream));
-    HIPCHK(hipStreamSynchronize(g.stream));
+    HIPCHK(hipMemcpyAsync(d_out, tmp.data(), n * 32, hipMemcpyHostToDevice, sl.stream));
+    HIPCHK(hipStreamSynchronize(sl.stream));
     return DGPU_OK;
 }
 
@@ -49,7 +49,7 @@ int32_t dgpu_init(int32_t device) {
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { (void)hipGetLastError(); return DGPU_E_NODEVICE; }
     if (device < 0 || device >= n) return DGPU_E_NODEVICE;
     HIPCHK(hipSetDevice(device));
-    HIPCHK(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+    for (int i = 0; i < N_SLOTS; i++) HIPCHK(hipStreamCreateWithFlags(&g.slots[i].stream, hipStreamNonBlocking));
     g.device = device; g.ready = true;
     return DGPU_OK;
 }
@@ -57,16 +57,19 @@ int32_t dgpu_init(int32_t device) {
 int32_t dgpu_shutdown(void) {
     std::lock_guard<std::mutex> lk(g.mu);
     if (!g.ready) return DGPU_OK;
+    g.ready = false;
     (void)hipSetDevice(g.device);
-    (void)hipStreamSynchronize(g.stream);
+    for (int i = 0; i < N_SLOTS; i++) {
+        std::lock_guard<std::mutex> sk(g.slots[i].mu);
+        (void)hipStreamSynchronize(g.slots[i].stream);
+        g.slots[i].release_all();
+        (void)hipStreamDestroy(g.slots[i].stream);
+        g.slots[i].stream = nullptr;
+    }
     for (auto &h : g.handles) (void)hipFree(h.second.p);
     g.handles.clear();
-    Buf *bufs[] = {&g.in_bases, &g.in_inf, &g.in_scalars, &g.prepped, &g.digits, &g.heavy, &g.cnt, &g.off, &g.cursor, &g.bsums, &g.entries, &g.bucket, &g.bucket_inf, &g.head, &g.tail, &g.head_b, &g.tail_b, &g.part_inf, &g.l1, &g.l1_inf, &g.win, &g.win_inf, &g.ml_lines, &g.ml_partial, &g.ml_out};
-    for (Buf *b : bufs) b->release();
-    for (hipEvent_t e : g.ev_pool) (void)hipEventDestroy(e);
-    g.ev_pool.clear(); g.prof_tab.clear();
-    (void)hipStreamDestroy(g.stream);
-    g.stream = nullptr; g.ready = false; g.device = -1;
+    g.prof_tab.clear();
+    g.device = -1;
     return DGPU_OK;
 }
 
@@ -92,7 +95,7 @@ static int32_t free_handle(uint64_t h, bool scalars) {
     std::lock_guard<std::mutex> lk(g.mu);
     auto it = g.handles.find(h);
     if (it == g.handles.end() || ((it->second.kind == 3) != scalars)) return DGPU_E_BADARG;
-    if (g.ready) { (void)hipSetDevice(g.device); (void)hipStreamSynchronize(g.stream); }
+    if (g.ready) { (void)hipSetDevice(g.device); (void)hipDeviceSynchronize(); }
     (void)hipFree(it->second.p);
     g.handles.erase(it);
     return DGPU_OK;
@@ -101,13 +104,16 @@ int32_t dgpu_bases_free(uint64_t h) { return free_handle(h, false); }
 int32_t dgpu_scalars_free(uint64_t h) { return free_handle(h, true); }
 int32_t dgpu_scalars_upload(const uint64_t *s, size_t n, int32_t mont, uint64_t *handle) {
     if (!handle || (n && !s)) return DGPU_E_BADARG;
-    std::lock_guard<std::mutex> lk(g.mu);
     if (!g.ready) return DGPU_E_NODEVICE;
-    HIPCHK(hipSetDevice(g.device));
     void *p = nullptr;
-    if (hipMalloc(&p, std::max<size_t>(n, 1) * 32) != hipSuccess) { (void)hipGetLastError(); return DGPU_E_OOM; }
-    int32_t rc = n ? upload_scalars(s, n, mont != 0, (uint32_t *)p) : DGPU_OK;
-    if (rc) { (void)hipFree(p); return rc; }
+    {
+        SlotLock L; Slot &sl = *L.s;
+        HIPCHK(hipSetDevice(g.device));
+        if (hipMalloc(&p, std::max<size_t>(n, 1) * 32) != hipSuccess) { (void)hipGetLastError(); return DGPU_E_OOM; }
+        int32_t rc = n ? upload_scalars(sl, s, n, mont != 0, (uint32_t *)p) : DGPU_OK;
+        if (rc) { (void)hipFree(p); return rc; }
+    }
+    std::lock_guard<std::mutex> lk(g.mu);
     uint64_t h = g.next_handle++;
     g.handles[h] = Handle{p, n, 3};
     *handle = h;
@@ -115,7 +121,7 @@ int32_t dgpu_scalars_upload(const uint64_t *s, size_t n, int32_t mont, uint64_t 
 }
 
 
-int32_t dgpu_prof_enable(int32_t on) { std::lock_guard<std::mutex> lk(g.mu); g.prof = on != 0; return DGPU_OK; }
+int32_t dgpu_prof_enable(int32_t on) { g.prof = on != 0; return DGPU_OK; }
 int32_t dgpu_prof_reset(void) { std::lock_guard<std::mutex> lk(g.mu); g.prof_tab.clear(); return DGPU_OK; }
 int32_t dgpu_prof_read(const char **names, double *total_ms, uint64_t *calls, int32_t cap) {
     std::lock_guard<std::mutex> lk(g.mu);

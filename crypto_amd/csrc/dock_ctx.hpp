@@ -34,56 +34,83 @@ struct Ctx;
 extern Ctx g;
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { dock::g.last_hip = (int32_t)e_; (void)hipGetLastError(); return DGPU_E_HIP; } } while (0)
 
-struct Ctx {
+// One in-flight call = one Slot: its own HIP stream and grow-only workspace.  Several host threads (rayon workers in the
+// reference, verifiable_encryption/src/tz_21/rdkgith.rs:140-147) can therefore have calls in flight at once; the
+// latency-bound tail of one MSM (bucket reduction, host fold) overlaps the throughput-bound bulk of the next.
+struct Slot {
     std::mutex mu;
-    bool ready = false;
-    int device = -1;
     hipStream_t stream = nullptr;
+    Buf in_bases, in_inf, in_scalars, prepped, digits, heavy, cnt, off, cursor, bsums, entries, bucket, bucket_inf, head, tail, head_b, tail_b, part_inf, l1, l1_inf, win, win_inf, ml_lines, ml_partial, ml_out;
+    std::vector<std::pair<const char *, std::pair<hipEvent_t, hipEvent_t>>> prof_pending;
+    std::vector<hipEvent_t> ev_pool;
+    void release_all() {
+        Buf *bufs[] = {&in_bases, &in_inf, &in_scalars, &prepped, &digits, &heavy, &cnt, &off, &cursor, &bsums, &entries, &bucket, &bucket_inf, &head, &tail, &head_b, &tail_b, &part_inf, &l1, &l1_inf, &win, &win_inf, &ml_lines, &ml_partial, &ml_out};
+        for (Buf *b : bufs) b->release();
+        for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
+        ev_pool.clear(); prof_pending.clear();
+    }
+};
+constexpr int N_SLOTS = 4;
+
+struct Ctx {
+    std::mutex mu;                 // lifecycle, handle table, profile table
+    std::atomic<bool> ready{false};
+    int device = -1;
     std::atomic<int32_t> last_hip{0};
     size_t min_gpu_n = 0;
     int window_bits = 0;
     int chunk = 0;
-    // workspace (grow-only)
-    Buf in_bases, in_inf, in_scalars, prepped, digits, heavy, cnt, off, cursor, bsums, entries, bucket, bucket_inf, head, tail, head_b, tail_b, part_inf, l1, l1_inf, win, win_inf, ml_lines, ml_partial, ml_out;
+    Slot slots[N_SLOTS];
+    std::atomic<unsigned> rr{0};
     std::map<uint64_t, Handle> handles;
     uint64_t next_handle = 1;
-    // profiling
-    bool prof = false;
+    std::atomic<bool> prof{false};
     std::vector<ProfEntry> prof_tab;
-    std::vector<std::pair<const char *, std::pair<hipEvent_t, hipEvent_t>>> prof_pending;
-    std::vector<hipEvent_t> ev_pool;
 };
 
+// RAII: pick a free slot (round-robin try_lock), or wait for one
+struct SlotLock {
+    Slot *s;
+    SlotLock() {
+        unsigned start = g.rr.fetch_add(1);
+        for (int k = 0; k < N_SLOTS; k++) { Slot &c = g.slots[(start + k) % N_SLOTS]; if (c.mu.try_lock()) { s = &c; return; } }
+        s = &g.slots[start % N_SLOTS]; s->mu.lock();
+    }
+    ~SlotLock() { s->mu.unlock(); }
+    SlotLock(const SlotLock &) = delete;
+};
 
-inline hipEvent_t ev_get() {
-    if (!g.ev_pool.empty()) { hipEvent_t e = g.ev_pool.back(); g.ev_pool.pop_back(); return e; }
+inline hipEvent_t ev_get(Slot &sl) {
+    if (!sl.ev_pool.empty()) { hipEvent_t e = sl.ev_pool.back(); sl.ev_pool.pop_back(); return e; }
     hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return nullptr; return e;
 }
 struct StageTimer {
-    const char *name; hipEvent_t a = nullptr, b = nullptr;
-    explicit StageTimer(const char *n) : name(n) { if (g.prof) { a = ev_get(); b = ev_get(); if (a) (void)hipEventRecord(a, g.stream); } }
-    ~StageTimer() { if (g.prof && a && b) { (void)hipEventRecord(b, g.stream); g.prof_pending.push_back({name, {a, b}}); } }
+    Slot &sl; const char *name; hipEvent_t a = nullptr, b = nullptr; bool on;
+    StageTimer(Slot &s, const char *n) : sl(s), name(n), on(g.prof.load()) { if (on) { a = ev_get(sl); b = ev_get(sl); if (a) (void)hipEventRecord(a, sl.stream); } }
+    ~StageTimer() { if (on && a && b) { (void)hipEventRecord(b, sl.stream); sl.prof_pending.push_back({name, {a, b}}); } }
 };
-inline void prof_flush() {
-    for (auto &pe : g.prof_pending) {
-        float ms = 0; (void)hipEventSynchronize(pe.second.second);
-        if (hipEventElapsedTime(&ms, pe.second.first, pe.second.second) == hipSuccess) {
-            bool found = false;
-            for (auto &t : g.prof_tab) if (t.name == pe.first) { t.ms += ms; t.calls++; found = true; break; }
-            if (!found) g.prof_tab.push_back({pe.first, (double)ms, 1});
-        }
-        g.ev_pool.push_back(pe.second.first); g.ev_pool.push_back(pe.second.second);
-    }
-    g.prof_pending.clear();
-}
-
-
 inline void prof_add_host(const char *name, double ms) {
+    std::lock_guard<std::mutex> lk(g.mu);
     for (auto &t : g.prof_tab) if (t.name == name) { t.ms += ms; t.calls++; return; }
     g.prof_tab.push_back({name, ms, 1});
 }
+inline void prof_flush(Slot &sl) {
+    for (auto &pe : sl.prof_pending) {
+        float ms = 0; (void)hipEventSynchronize(pe.second.second);
+        if (hipEventElapsedTime(&ms, pe.second.first, pe.second.second) == hipSuccess) prof_add_host(pe.first, (double)ms);
+        sl.ev_pool.push_back(pe.second.first); sl.ev_pool.push_back(pe.second.second);
+    }
+    sl.prof_pending.clear();
+}
+inline bool lookup_handle(uint64_t h, Handle &out) {
+    std::lock_guard<std::mutex> lk(g.mu);
+    auto it = g.handles.find(h);
+    if (it == g.handles.end()) return false;
+    out = it->second; return true;
+}
+
 int choose_c(size_t n);
 int choose_chunk();
-int32_t upload_scalars(const uint64_t *h, size_t n, bool mont, uint32_t *d_out);
+int32_t upload_scalars(Slot &sl, const uint64_t *h, size_t n, bool mont, uint32_t *d_out);
 
 }  // namespace dock

@@ -11,28 +11,28 @@ int32_t dgpu_msm_g1_handle(uint64_t b, size_t off, const uint64_t *s, size_t n, 
 int32_t dgpu_msm_g1_resident(uint64_t b, size_t boff, uint64_t s, size_t soff, size_t n, uint64_t out[18]) { return msm_resident<G1, hostf::Fq>(b, boff, s, soff, n, out, 1); }
 
 int32_t dgpu_selftest_fp_mul(const uint64_t *a, const uint64_t *b, size_t n, uint64_t *out) {
-    std::lock_guard<std::mutex> lk(g.mu);
     if (!g.ready) return DGPU_E_NODEVICE;
+    SlotLock L; Slot &sl = *L.s;
     HIPCHK(hipSetDevice(g.device));
     void *da, *db, *dout;
     HIPCHK(hipMalloc(&da, n * 48 + 16)); HIPCHK(hipMalloc(&db, n * 48 + 16)); HIPCHK(hipMalloc(&dout, n * 48 + 16));
     HIPCHK(hipMemcpy(da, a, n * 48, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(db, b, n * 48, hipMemcpyHostToDevice));
-    launch_selftest_fp_mul(g.stream, (const uint32_t *)da, (const uint32_t *)db, n, (uint32_t *)dout);
-    HIPCHK(hipStreamSynchronize(g.stream));
+    launch_selftest_fp_mul(sl.stream, (const uint32_t *)da, (const uint32_t *)db, n, (uint32_t *)dout);
+    HIPCHK(hipStreamSynchronize(sl.stream));
     HIPCHK(hipMemcpy(out, dout, n * 48, hipMemcpyDeviceToHost));
     (void)hipFree(da); (void)hipFree(db); (void)hipFree(dout);
     return DGPU_OK;
 }
 int32_t dgpu_selftest_g1_sum(const uint64_t *pts, const uint8_t *neg, size_t n, uint64_t out[18]) {
-    std::lock_guard<std::mutex> lk(g.mu);
     if (!g.ready) return DGPU_E_NODEVICE;
+    SlotLock L; Slot &sl = *L.s;
     HIPCHK(hipSetDevice(g.device));
     void *dp, *dn, *dout, *dinf;
     HIPCHK(hipMalloc(&dp, n * 96 + 16)); HIPCHK(hipMalloc(&dn, n + 16)); HIPCHK(hipMalloc(&dout, 4 * 48)); HIPCHK(hipMalloc(&dinf, 16));
     HIPCHK(hipMemcpy(dp, pts, n * 96, hipMemcpyHostToDevice));
     if (neg) HIPCHK(hipMemcpy(dn, neg, n, hipMemcpyHostToDevice)); else HIPCHK(hipMemset(dn, 0, n + 16));
-    launch_selftest_g1_sum(g.stream, (const uint32_t *)dp, (const uint8_t *)dn, n, (uint32_t *)dout, (uint8_t *)dinf);
-    HIPCHK(hipStreamSynchronize(g.stream));
+    launch_selftest_g1_sum(sl.stream, (const uint32_t *)dp, (const uint8_t *)dn, n, (uint32_t *)dout, (uint8_t *)dinf);
+    HIPCHK(hipStreamSynchronize(sl.stream));
     uint64_t w[24]; uint8_t inf;
     HIPCHK(hipMemcpy(w, dout, 4 * 48, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(&inf, dinf, 1, hipMemcpyDeviceToHost));
     (void)hipFree(dp); (void)hipFree(dn); (void)hipFree(dout); (void)hipFree(dinf);

@@ -97,34 +97,34 @@ int32_t dgpu_multi_miller_loop(const uint64_t *p, const uint64_t *q, const uint8
     if (!out || (n && (!p || !q))) return DGPU_E_BADARG;
     if (n == 0) { hostf::Fq12 one = hostf::Fq12::one(); memcpy(out, &one, sizeof one); return DGPU_OK; }
     if (n >= (1ull << 24)) return DGPU_E_BADARG;
-    std::lock_guard<std::mutex> lk(g.mu);
     if (!g.ready) return DGPU_E_NODEVICE;
+    SlotLock slot_lock; Slot &sl = *slot_lock.s;
     HIPCHK(hipSetDevice(g.device));
     int32_t rc;
     const int slice_len = (int)std::max<size_t>(1, (n + MAX_SLICES - 1) / MAX_SLICES);
     const int nsl = (int)((n + slice_len - 1) / slice_len);
-    if ((rc = g.in_bases.ensure(n * 96))) return rc;
-    if ((rc = g.in_scalars.ensure(n * 192))) return rc;
-    if ((rc = g.in_inf.ensure(n))) return rc;
-    if ((rc = g.ml_lines.ensure((size_t)N_LINES * LW * n * 4))) return rc;
-    if ((rc = g.ml_partial.ensure((size_t)N_LINES * nsl * F12W * 4))) return rc;
-    if ((rc = g.ml_out.ensure((size_t)N_LINES * 144 * 4))) return rc;
-    hipStream_t s = g.stream;
-    HIPCHK(hipMemcpyAsync(g.in_bases.p, p, n * 96, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(g.in_scalars.p, q, n * 192, hipMemcpyHostToDevice, s));
+    if ((rc = sl.in_bases.ensure(n * 96))) return rc;
+    if ((rc = sl.in_scalars.ensure(n * 192))) return rc;
+    if ((rc = sl.in_inf.ensure(n))) return rc;
+    if ((rc = sl.ml_lines.ensure((size_t)N_LINES * LW * n * 4))) return rc;
+    if ((rc = sl.ml_partial.ensure((size_t)N_LINES * nsl * F12W * 4))) return rc;
+    if ((rc = sl.ml_out.ensure((size_t)N_LINES * 144 * 4))) return rc;
+    hipStream_t s = sl.stream;
+    HIPCHK(hipMemcpyAsync(sl.in_bases.p, p, n * 96, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(sl.in_scalars.p, q, n * 192, hipMemcpyHostToDevice, s));
     const uint8_t *dskip = nullptr;
-    if (skip) { HIPCHK(hipMemcpyAsync(g.in_inf.p, skip, n, hipMemcpyHostToDevice, s)); dskip = g.in_inf.as<uint8_t>(); }
-    { StageTimer st("ml.lines");
-      hipLaunchKernelGGL(k_miller_lines, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, g.in_bases.as<uint32_t>(), g.in_scalars.as<uint32_t>(), dskip, n, g.ml_lines.as<uint32_t>()); }
-    { StageTimer st("ml.products");
-      hipLaunchKernelGGL(k_line_products, dim3((unsigned)((N_LINES * nsl + 63) / 64)), dim3(64), 0, s, g.ml_lines.as<uint32_t>(), n, slice_len, nsl, g.ml_partial.as<uint32_t>()); }
-    { StageTimer st("ml.tree");
-      hipLaunchKernelGGL(k_product_tree, dim3(N_LINES), dim3(64), 0, s, g.ml_partial.as<uint32_t>(), nsl, g.ml_out.as<uint32_t>()); }
+    if (skip) { HIPCHK(hipMemcpyAsync(sl.in_inf.p, skip, n, hipMemcpyHostToDevice, s)); dskip = sl.in_inf.as<uint8_t>(); }
+    { StageTimer st(sl, "ml.lines");
+      hipLaunchKernelGGL(k_miller_lines, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, sl.in_bases.as<uint32_t>(), sl.in_scalars.as<uint32_t>(), dskip, n, sl.ml_lines.as<uint32_t>()); }
+    { StageTimer st(sl, "ml.products");
+      hipLaunchKernelGGL(k_line_products, dim3((unsigned)((N_LINES * nsl + 63) / 64)), dim3(64), 0, s, sl.ml_lines.as<uint32_t>(), n, slice_len, nsl, sl.ml_partial.as<uint32_t>()); }
+    { StageTimer st(sl, "ml.tree");
+      hipLaunchKernelGGL(k_product_tree, dim3(N_LINES), dim3(64), 0, s, sl.ml_partial.as<uint32_t>(), nsl, sl.ml_out.as<uint32_t>()); }
     HIPCHK(hipGetLastError());
     std::vector<hostf::Fq12> L(N_LINES);
-    HIPCHK(hipMemcpyAsync(L.data(), g.ml_out.p, (size_t)N_LINES * 576, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(L.data(), sl.ml_out.p, (size_t)N_LINES * 576, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
-    if (g.prof) prof_flush();
+    if (g.prof) prof_flush(sl);
     hostf::Fq12 f = hostf::Fq12::one(); int idx = 0;
     for (int b = 62; b >= 0; b--) { f = f.sqr() * L[idx++]; if ((hostf::BLS_X_ABS >> b) & 1) f = f * L[idx++]; }
     f = f.conj();      // x < 0

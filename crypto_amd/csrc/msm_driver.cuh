@@ -47,9 +47,9 @@ int32_t host_fold_jacobian(const uint64_t *xyz, size_t k, uint64_t *out_xyz) {
     return DGPU_OK;
 }
 
-// d_bases: prepared records; d_scalars: canonical 8 x u32 per scalar.  Caller holds g.mu.
+// d_bases: prepared records; d_scalars: canonical 8 x u32 per scalar.  Caller holds the slot.
 template <class C, class HF>
-int32_t msm_device(const uint32_t *d_bases, const uint32_t *d_scalars, size_t n, uint64_t *out_xyz) {
+int32_t msm_device(Slot &sl, const uint32_t *d_bases, const uint32_t *d_scalars, size_t n, uint64_t *out_xyz) {
     if (n == 0) { typedef hostf::HXyzz<HF> PT; PT id = PT::identity(); HF X, Y, Z; id.to_normalised_jacobian(X, Y, Z);
         const size_t FWORDS = sizeof(HF) / 8; memcpy(out_xyz, &X, sizeof(HF)); memcpy(out_xyz + FWORDS, &Y, sizeof(HF)); memcpy(out_xyz + 2 * FWORDS, &Z, sizeof(HF)); return DGPU_OK; }
     if (n >= (1ull << 31)) return DGPU_E_BADARG;
@@ -67,24 +67,24 @@ int32_t msm_device(const uint32_t *d_bases, const uint32_t *d_scalars, size_t n,
     const size_t nblk = scan_blocks(NB);
 
     int32_t rc;
-    if ((rc = g.cnt.ensure(((size_t)NB + 1) * 4))) return rc;
-    if ((rc = g.off.ensure(((size_t)NB + 1) * 4))) return rc;
-    if ((rc = g.cursor.ensure(((size_t)NB + 1) * 4))) return rc;
-    if ((rc = g.bsums.ensure((nblk + 2) * 4))) return rc;
-    if ((rc = g.entries.ensure(Emax * 4))) return rc;
-    if ((rc = g.bucket.ensure((size_t)NB * C::XW * 4))) return rc;
-    if ((rc = g.bucket_inf.ensure(NB))) return rc;
-    if ((rc = g.head.ensure(T * C::XW * 4))) return rc;
-    if ((rc = g.tail.ensure(T * C::XW * 4))) return rc;
-    if ((rc = g.head_b.ensure(T * 4))) return rc;
-    if ((rc = g.tail_b.ensure(T * 4))) return rc;
-    if ((rc = g.part_inf.ensure(T * 2))) return rc;
-    if ((rc = g.l1.ensure(NG * 2 * C::XW * 4))) return rc;
-    if ((rc = g.l1_inf.ensure(NG * 2))) return rc;
-    if ((rc = g.win.ensure((size_t)W * 4 * C::ABI_W * 4))) return rc;
-    if ((rc = g.win_inf.ensure(W))) return rc;
+    if ((rc = sl.cnt.ensure(((size_t)NB + 1) * 4))) return rc;
+    if ((rc = sl.off.ensure(((size_t)NB + 1) * 4))) return rc;
+    if ((rc = sl.cursor.ensure(((size_t)NB + 1) * 4))) return rc;
+    if ((rc = sl.bsums.ensure((nblk + 2) * 4))) return rc;
+    if ((rc = sl.entries.ensure(Emax * 4))) return rc;
+    if ((rc = sl.bucket.ensure((size_t)NB * C::XW * 4))) return rc;
+    if ((rc = sl.bucket_inf.ensure(NB))) return rc;
+    if ((rc = sl.head.ensure(T * C::XW * 4))) return rc;
+    if ((rc = sl.tail.ensure(T * C::XW * 4))) return rc;
+    if ((rc = sl.head_b.ensure(T * 4))) return rc;
+    if ((rc = sl.tail_b.ensure(T * 4))) return rc;
+    if ((rc = sl.part_inf.ensure(T * 2))) return rc;
+    if ((rc = sl.l1.ensure(NG * 2 * C::XW * 4))) return rc;
+    if ((rc = sl.l1_inf.ensure(NG * 2))) return rc;
+    if ((rc = sl.win.ensure((size_t)W * 4 * C::ABI_W * 4))) return rc;
+    if ((rc = sl.win_inf.ensure(W))) return rc;
 
-    hipStream_t s = g.stream;
+    hipStream_t s = sl.stream;
     // counting sort of the n*W (key, term) pairs: digit codes -> LDS histograms per (window, bucket range) -> scan -> LDS cursors
     const bool wide = c > 16;
     const size_t n_pad = (n + 7) & ~(size_t)7;
@@ -93,51 +93,51 @@ int32_t msm_device(const uint32_t *d_bases, const uint32_t *d_scalars, size_t n,
     const int wpx = (W + 7) / 8;
     const unsigned sort_grid = (unsigned)(8 * wpx * RANGES);
     const size_t lds_bytes = ((size_t)1 << rb_log) * 4;
-    if ((rc = g.digits.ensure((size_t)W * n_pad * (wide ? 4 : 2)))) return rc;
+    if ((rc = sl.digits.ensure((size_t)W * n_pad * (wide ? 4 : 2)))) return rc;
     const uint32_t heavy_thr = 16u * (uint32_t)CH, HEAVY_CAP = (uint32_t)(Emax / heavy_thr) + 1;   // at most E / thr buckets can be heavy
-    if ((rc = g.heavy.ensure(((size_t)HEAVY_CAP + 1) * 4))) return rc;
+    if ((rc = sl.heavy.ensure(((size_t)HEAVY_CAP + 1) * 4))) return rc;
     {
-        StageTimer st("msm.count");
-        HIPCHK(hipMemsetAsync(g.bucket_inf.p, 1, NB, s));
-        HIPCHK(hipMemsetAsync(g.heavy.p, 0, 4, s));
-        launch_digit_codes(s, wide, d_scalars, d_bases, C::AFF_STRIDE, 2 * C::FW, n, n_pad, c, W, g.digits.p);
-        launch_sort_sweep(s, wide, false, sort_grid, lds_bytes, g.digits.p, n, n_pad, W, RANGES, rb_log, B, g.cnt.as<uint32_t>(), nullptr, nullptr, heavy_thr, g.heavy.as<uint32_t>(), HEAVY_CAP);
+        StageTimer st(sl, "msm.count");
+        HIPCHK(hipMemsetAsync(sl.bucket_inf.p, 1, NB, s));
+        HIPCHK(hipMemsetAsync(sl.heavy.p, 0, 4, s));
+        launch_digit_codes(s, wide, d_scalars, d_bases, C::AFF_STRIDE, 2 * C::FW, n, n_pad, c, W, sl.digits.p);
+        launch_sort_sweep(s, wide, false, sort_grid, lds_bytes, sl.digits.p, n, n_pad, W, RANGES, rb_log, B, sl.cnt.as<uint32_t>(), nullptr, nullptr, heavy_thr, sl.heavy.as<uint32_t>(), HEAVY_CAP);
     }
     {
-        StageTimer st("msm.scan");
-        launch_scan(s, g.cnt.as<uint32_t>(), g.off.as<uint32_t>(), g.cursor.as<uint32_t>(), g.bsums.as<uint32_t>(), (size_t)NB);
+        StageTimer st(sl, "msm.scan");
+        launch_scan(s, sl.cnt.as<uint32_t>(), sl.off.as<uint32_t>(), sl.cursor.as<uint32_t>(), sl.bsums.as<uint32_t>(), (size_t)NB);
     }
     {
-        StageTimer st("msm.scatter");
-        launch_sort_sweep(s, wide, true, sort_grid, lds_bytes, g.digits.p, n, n_pad, W, RANGES, rb_log, B, nullptr, g.off.as<uint32_t>(), g.entries.as<uint32_t>(), heavy_thr, g.heavy.as<uint32_t>(), HEAVY_CAP);
+        StageTimer st(sl, "msm.scatter");
+        launch_sort_sweep(s, wide, true, sort_grid, lds_bytes, sl.digits.p, n, n_pad, W, RANGES, rb_log, B, nullptr, sl.off.as<uint32_t>(), sl.entries.as<uint32_t>(), heavy_thr, sl.heavy.as<uint32_t>(), HEAVY_CAP);
     }
     {
-        StageTimer st("msm.accumulate");
+        StageTimer st(sl, "msm.accumulate");
         static const uint32_t dbg_mask = getenv("DGPU_DBG_NOGATHER") ? 1023u : 0xffffffffu;   // experiment: L2-resident points
-        launch_accumulate<C>(s, d_bases, g.entries.as<uint32_t>(), g.off.as<uint32_t>(), NB, g.bucket.as<uint32_t>(), g.bucket_inf.as<uint8_t>(),
-                           g.head.as<uint32_t>(), g.tail.as<uint32_t>(), g.head_b.as<uint32_t>(), g.tail_b.as<uint32_t>(), g.part_inf.as<uint8_t>(), T, (uint32_t)CH, dbg_mask);
+        launch_accumulate<C>(s, d_bases, sl.entries.as<uint32_t>(), sl.off.as<uint32_t>(), NB, sl.bucket.as<uint32_t>(), sl.bucket_inf.as<uint8_t>(),
+                           sl.head.as<uint32_t>(), sl.tail.as<uint32_t>(), sl.head_b.as<uint32_t>(), sl.tail_b.as<uint32_t>(), sl.part_inf.as<uint8_t>(), T, (uint32_t)CH, dbg_mask);
     }
     {
-        StageTimer st("msm.fixup");
-        launch_fixup<C>(s, NB, g.bucket.as<uint32_t>(), g.bucket_inf.as<uint8_t>(), g.head.as<uint32_t>(), g.tail.as<uint32_t>(),
-                           g.head_b.as<uint32_t>(), g.tail_b.as<uint32_t>(), g.part_inf.as<uint8_t>(), T, g.off.as<uint32_t>(), heavy_thr);
-        launch_fixup_heavy<C>(s, g.heavy.as<uint32_t>(), HEAVY_CAP, g.off.as<uint32_t>(), (uint32_t)CH, NB, g.bucket.as<uint32_t>(), g.bucket_inf.as<uint8_t>(),
-                           g.head.as<uint32_t>(), g.tail.as<uint32_t>(), g.part_inf.as<uint8_t>(), T);
+        StageTimer st(sl, "msm.fixup");
+        launch_fixup<C>(s, NB, sl.bucket.as<uint32_t>(), sl.bucket_inf.as<uint8_t>(), sl.head.as<uint32_t>(), sl.tail.as<uint32_t>(),
+                           sl.head_b.as<uint32_t>(), sl.tail_b.as<uint32_t>(), sl.part_inf.as<uint8_t>(), T, sl.off.as<uint32_t>(), heavy_thr);
+        launch_fixup_heavy<C>(s, sl.heavy.as<uint32_t>(), HEAVY_CAP, sl.off.as<uint32_t>(), (uint32_t)CH, NB, sl.bucket.as<uint32_t>(), sl.bucket_inf.as<uint8_t>(),
+                           sl.head.as<uint32_t>(), sl.tail.as<uint32_t>(), sl.part_inf.as<uint8_t>(), T);
     }
     {
-        StageTimer st("msm.reduce");
-        launch_reduce_l0<C>(s, (unsigned)NG, g.bucket.as<uint32_t>(), g.bucket_inf.as<uint8_t>(), NB, mshift, g.l1.as<uint32_t>(), g.l1_inf.as<uint8_t>());
-        launch_reduce_top<C>(s, (unsigned)W, g.l1.as<uint32_t>(), g.l1_inf.as<uint8_t>(), G, 6 + mshift, g.win.as<uint32_t>(), g.win_inf.as<uint8_t>());
+        StageTimer st(sl, "msm.reduce");
+        launch_reduce_l0<C>(s, (unsigned)NG, sl.bucket.as<uint32_t>(), sl.bucket_inf.as<uint8_t>(), NB, mshift, sl.l1.as<uint32_t>(), sl.l1_inf.as<uint8_t>());
+        launch_reduce_top<C>(s, (unsigned)W, sl.l1.as<uint32_t>(), sl.l1_inf.as<uint8_t>(), G, 6 + mshift, sl.win.as<uint32_t>(), sl.win_inf.as<uint8_t>());
     }
     HIPCHK(hipGetLastError());
     std::vector<uint64_t> hwin((size_t)W * 2 * C::ABI_W);
     std::vector<uint8_t> hinf(W);
-    HIPCHK(hipMemcpyAsync(hwin.data(), g.win.p, (size_t)W * 4 * C::ABI_W * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(hinf.data(), g.win_inf.p, W, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(hwin.data(), sl.win.p, (size_t)W * 4 * C::ABI_W * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(hinf.data(), sl.win_inf.p, W, hipMemcpyDeviceToHost, s));
     auto tsync0 = std::chrono::steady_clock::now();
     HIPCHK(hipStreamSynchronize(s));
     auto tsync1 = std::chrono::steady_clock::now();
-    if (g.prof) prof_flush();
+    if (g.prof) prof_flush(sl);
     host_fold<HF>(hwin.data(), hinf.data(), W, c, out_xyz);
     if (g.prof) {
         auto t2 = std::chrono::steady_clock::now();
@@ -148,15 +148,15 @@ int32_t msm_device(const uint32_t *d_bases, const uint32_t *d_scalars, size_t n,
 }
 
 template <class C>
-int32_t prep_bases(const uint64_t *h_bases, const uint8_t *h_inf, size_t n, uint32_t *d_out) {
+int32_t prep_bases(Slot &sl, const uint64_t *h_bases, const uint8_t *h_inf, size_t n, uint32_t *d_out) {
     int32_t rc;
     const size_t bytes = n * 2 * C::ABI_W * 4;
-    if ((rc = g.in_bases.ensure(bytes ? bytes : 16))) return rc;
-    HIPCHK(hipMemcpyAsync(g.in_bases.p, h_bases, bytes, hipMemcpyHostToDevice, g.stream));
+    if ((rc = sl.in_bases.ensure(bytes ? bytes : 16))) return rc;
+    HIPCHK(hipMemcpyAsync(sl.in_bases.p, h_bases, bytes, hipMemcpyHostToDevice, sl.stream));
     uint8_t *dinf = nullptr;
-    if (h_inf) { if ((rc = g.in_inf.ensure(n))) return rc; HIPCHK(hipMemcpyAsync(g.in_inf.p, h_inf, n, hipMemcpyHostToDevice, g.stream)); dinf = g.in_inf.as<uint8_t>(); }
-    StageTimer st("msm.prep_bases");
-    launch_prep_bases<C>(g.stream, g.in_bases.as<uint32_t>(), dinf, n, d_out);
+    if (h_inf) { if ((rc = sl.in_inf.ensure(n))) return rc; HIPCHK(hipMemcpyAsync(sl.in_inf.p, h_inf, n, hipMemcpyHostToDevice, sl.stream)); dinf = sl.in_inf.as<uint8_t>(); }
+    StageTimer st(sl, "msm.prep_bases");
+    launch_prep_bases<C>(sl.stream, sl.in_bases.as<uint32_t>(), dinf, n, d_out);
     return DGPU_OK;
 }
 
@@ -164,30 +164,33 @@ template <class C, class HF>
 int32_t msm_oneshot(const uint64_t *bases, const uint8_t *is_inf, const uint64_t *scalars, size_t n, bool mont, uint64_t *out) {
     if (!out || (n && (!bases || !scalars))) return DGPU_E_BADARG;
     if (n < g.min_gpu_n) return DGPU_E_TOO_SMALL;
-    std::lock_guard<std::mutex> lk(g.mu);
     if (!g.ready) return DGPU_E_NODEVICE;
+    SlotLock L; Slot &sl = *L.s;
     HIPCHK(hipSetDevice(g.device));
     int32_t rc;
     if (n) {
-        if ((rc = g.prepped.ensure(n * C::AFF_STRIDE * 4))) return rc;
-        if ((rc = g.in_scalars.ensure(n * 32))) return rc;
-        if ((rc = prep_bases<C>(bases, is_inf, n, g.prepped.as<uint32_t>()))) return rc;
-        if ((rc = upload_scalars(scalars, n, mont, g.in_scalars.as<uint32_t>()))) return rc;
+        if ((rc = sl.prepped.ensure(n * C::AFF_STRIDE * 4))) return rc;
+        if ((rc = sl.in_scalars.ensure(n * 32))) return rc;
+        if ((rc = prep_bases<C>(sl, bases, is_inf, n, sl.prepped.as<uint32_t>()))) return rc;
+        if ((rc = upload_scalars(sl, scalars, n, mont, sl.in_scalars.as<uint32_t>()))) return rc;
     }
-    return msm_device<C, HF>(g.prepped.as<uint32_t>(), g.in_scalars.as<uint32_t>(), n, out);
+    return msm_device<C, HF>(sl, sl.prepped.as<uint32_t>(), sl.in_scalars.as<uint32_t>(), n, out);
 }
 
 template <class C>
 int32_t bases_upload(const uint64_t *bases, const uint8_t *is_inf, size_t n, uint64_t *handle, int kind) {
     if (!handle || (n && !bases)) return DGPU_E_BADARG;
-    std::lock_guard<std::mutex> lk(g.mu);
     if (!g.ready) return DGPU_E_NODEVICE;
-    HIPCHK(hipSetDevice(g.device));
     void *p = nullptr;
-    if (hipMalloc(&p, std::max<size_t>(n, 1) * C::AFF_STRIDE * 4) != hipSuccess) { (void)hipGetLastError(); return DGPU_E_OOM; }
-    int32_t rc = n ? prep_bases<C>(bases, is_inf, n, (uint32_t *)p) : DGPU_OK;
-    if (rc == DGPU_OK && hipStreamSynchronize(g.stream) != hipSuccess) rc = DGPU_E_HIP;
-    if (rc) { (void)hipFree(p); return rc; }
+    {
+        SlotLock L; Slot &sl = *L.s;
+        HIPCHK(hipSetDevice(g.device));
+        if (hipMalloc(&p, std::max<size_t>(n, 1) * C::AFF_STRIDE * 4) != hipSuccess) { (void)hipGetLastError(); return DGPU_E_OOM; }
+        int32_t rc = n ? prep_bases<C>(sl, bases, is_inf, n, (uint32_t *)p) : DGPU_OK;
+        if (rc == DGPU_OK && hipStreamSynchronize(sl.stream) != hipSuccess) rc = DGPU_E_HIP;
+        if (rc) { (void)hipFree(p); return rc; }
+    }
+    std::lock_guard<std::mutex> lk(g.mu);
     uint64_t h = g.next_handle++;
     g.handles[h] = Handle{p, n, kind};
     *handle = h;
@@ -198,28 +201,28 @@ template <class C, class HF>
 int32_t msm_handle(uint64_t bases, size_t offset, const uint64_t *scalars, size_t n, int mont, uint64_t *out, int kind) {
     if (!out || (n && !scalars)) return DGPU_E_BADARG;
     if (n < g.min_gpu_n) return DGPU_E_TOO_SMALL;
-    std::lock_guard<std::mutex> lk(g.mu);
     if (!g.ready) return DGPU_E_NODEVICE;
-    auto it = g.handles.find(bases);
-    if (it == g.handles.end() || it->second.kind != kind || offset > it->second.n || n > it->second.n - offset) return DGPU_E_BADARG;
+    Handle hb;
+    if (!lookup_handle(bases, hb) || hb.kind != kind || offset > hb.n || n > hb.n - offset) return DGPU_E_BADARG;
+    SlotLock L; Slot &sl = *L.s;
     HIPCHK(hipSetDevice(g.device));
     int32_t rc;
-    if ((rc = g.in_scalars.ensure(std::max<size_t>(n, 1) * 32))) return rc;
-    if (n && (rc = upload_scalars(scalars, n, mont != 0, g.in_scalars.as<uint32_t>()))) return rc;
-    return msm_device<C, HF>((const uint32_t *)it->second.p + offset * C::AFF_STRIDE, g.in_scalars.as<uint32_t>(), n, out);
+    if ((rc = sl.in_scalars.ensure(std::max<size_t>(n, 1) * 32))) return rc;
+    if (n && (rc = upload_scalars(sl, scalars, n, mont != 0, sl.in_scalars.as<uint32_t>()))) return rc;
+    return msm_device<C, HF>(sl, (const uint32_t *)hb.p + offset * C::AFF_STRIDE, sl.in_scalars.as<uint32_t>(), n, out);
 }
 
 template <class C, class HF>
 int32_t msm_resident(uint64_t bases, size_t boff, uint64_t scalars, size_t soff, size_t n, uint64_t *out, int kind) {
     if (!out) return DGPU_E_BADARG;
     if (n < g.min_gpu_n) return DGPU_E_TOO_SMALL;
-    std::lock_guard<std::mutex> lk(g.mu);
     if (!g.ready) return DGPU_E_NODEVICE;
-    auto ib = g.handles.find(bases), is = g.handles.find(scalars);
-    if (ib == g.handles.end() || is == g.handles.end() || ib->second.kind != kind || is->second.kind != 3) return DGPU_E_BADARG;
-    if (boff > ib->second.n || n > ib->second.n - boff || soff > is->second.n || n > is->second.n - soff) return DGPU_E_BADARG;
+    Handle hb, hs;
+    if (!lookup_handle(bases, hb) || !lookup_handle(scalars, hs) || hb.kind != kind || hs.kind != 3) return DGPU_E_BADARG;
+    if (boff > hb.n || n > hb.n - boff || soff > hs.n || n > hs.n - soff) return DGPU_E_BADARG;
+    SlotLock L; Slot &sl = *L.s;
     HIPCHK(hipSetDevice(g.device));
-    return msm_device<C, HF>((const uint32_t *)ib->second.p + boff * C::AFF_STRIDE, (const uint32_t *)is->second.p + soff * 8, n, out);
+    return msm_device<C, HF>(sl, (const uint32_t *)hb.p + boff * C::AFF_STRIDE, (const uint32_t *)hs.p + soff * 8, n, out);
 }
 
 

@@ -49,3 +49,22 @@ if "ml" in what:
     dt, s = stages(lambda: ca.multi_miller_loop(P, Q))
     print("ML n=1024 %.3f ms (%.0f pairs/s) | %s" % (dt * 1e3, n / dt, s))
     t0 = time.time(); gt = ca.final_exponentiation(f); print("final_exp host %.3f ms" % ((time.time() - t0) * 1e3))
+if "conc" in what:
+    import threading
+    n = 1 << 20
+    bases = O.G1.gen_seq(k0, d, n, threads=64); sc = O.rand_scalars(3, n)
+    db = ca.DeviceBases(ca.G1, bases); ds = ca.DeviceScalars(sc)
+    ref = db.msm_resident(ds)
+    for nthr in (1, 2, 3, 4):
+        K = 24
+        def work(k):
+            for _ in range(k):
+                r = db.msm_resident(ds)
+                assert (r == ref).all()
+        work(2)
+        ths = [threading.Thread(target=work, args=(K // nthr,)) for _ in range(nthr)]
+        t0 = time.time()
+        for t in ths: t.start()
+        for t in ths: t.join()
+        dt = time.time() - t0
+        print("G1 2^20 x%d in flight: %.3f ms per MSM (%.1f MSM/s)" % (nthr, dt / (K // nthr * nthr) * 1e3, (K // nthr * nthr) / dt), flush=True)

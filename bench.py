@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--log2n", type=int, default=20, help="terms per GPU = 2^log2n (BASELINE: 20 at 1 GPU, 21 per GPU for 2^24 on 8)")
+    ap.add_argument("--inflight", type=int, default=4, help="MSM calls in flight per GPU (host threads; each call owns a stream + workspace slot)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -87,20 +88,41 @@ def main():
     bit_exact = bool(exp[1] == got[1] and (exp[0] == got[0]).all())
     assert bit_exact, "GPU MSM does not match the closed form"
 
+    from concurrent.futures import ThreadPoolExecutor
+    inflight = max(1, args.inflight)
+    pool = ThreadPoolExecutor(max_workers=inflight)
+
+    def run_steps(k):
+        """k steps with up to `inflight` local MSMs in flight; partial points are gathered/folded in step order"""
+        futs = [pool.submit(db.msm_resident, ds) for _ in range(k)]
+        last = None
+        for f in futs:
+            part = f.result()
+            last = sharded.gather_and_fold(ca.G1, part, dev) if world > 1 else part
+        return last
+
     for _ in range(args.warmup):
         step()
+    run_steps(min(args.steps, 2 * inflight))          # warm every slot's workspace (untimed)
+    # sequential pass (one call in flight): per-stage HIP-event times without overlap, and the single-call latency
     ca.prof.enable(True)
+    ca.prof.reset()
+    tl = time.perf_counter()
+    for _ in range(3):
+        step()
+    latency_ms = (time.perf_counter() - tl) / 3 * 1e3
+    stages_seq = ca.prof.read()
     ca.prof.reset()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    last = run_steps(args.steps)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    assert (last == res).all(), "result changed between runs"
     stages = ca.prof.read()
     ca.prof.enable(False)
     if world > 1:
@@ -112,8 +134,12 @@ def main():
         ms_step = dt / args.steps * 1e3
         terms = n * world
         value = (terms / float(1 << 20)) / (dt / args.steps)
-        acc_ms = stages.get("msm.accumulate", (0.0, 1))
+        # dominant kernel: duration from the one-call-in-flight pass (HIP events on the library's stream); inside the
+        # timed region up to `inflight` launches share the chip, so their event durations overlap and are reported separately
+        acc_ms = stages_seq.get("msm.accumulate", (0.0, 1))
         acc_avg_ms = acc_ms[0] / max(1, acc_ms[1])
+        acc_ov = stages.get("msm.accumulate", (0.0, 1))
+        acc_ov_ms = acc_ov[0] / max(1, acc_ov[1])
         alg_bytes = 128.0 * n                      # 32 B scalar + 96 B affine base per term, one launch = n terms
         achieved = alg_bytes / (acc_avg_ms * 1e-3) / 1e9 if acc_avg_ms > 0 else 0.0
         traffic = None
@@ -135,12 +161,16 @@ def main():
             "data": "synthetic (seeded SplitMix64 scalars; bases with known discrete logs)",
             "config": {"workload": "BLS12-381 G1 variable-base MSM, n=2^%d terms per GPU, operands resident in HBM, %s" % (
                 args.log2n, "1xMI355X" if world == 1 else "%dxMI355X point-chunk sharded, RCCL all_gather of partial points" % world),
-                "terms_per_step": terms, "bit_exact_vs_closed_form": bit_exact, "parallelism": "1 process per GPU, %d ranks" % world},
+                "terms_per_step": terms, "bit_exact_vs_closed_form": bit_exact, "parallelism": "1 process per GPU, %d ranks, %d calls in flight per GPU" % (world, inflight)},
             "terms_per_s": round(terms / (dt / args.steps), 1),
+            "inflight": inflight, "latency_ms_one_in_flight": round(latency_ms, 4),
             "stages_ms": {k.replace("msm.", ""): round(v[0] / max(1, v[1]), 4) for k, v in stages.items()},
+            "stages_ms_one_in_flight": {k.replace("msm.", ""): round(v[0] / max(1, v[1]), 4) for k, v in stages_seq.items()},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 6),
-                         "traffic": traffic, "kernel": "k_accumulate<G1>", "avg_ms": round(acc_avg_ms, 4),
-                         "note": "algorithmic 128 B/term; the kernel is integer-multiply bound: see valu_roofline"},
+                         "traffic": traffic, "kernel": "k_accumulate<G1>", "avg_ms": round(acc_avg_ms, 4), "avg_ms_overlapped": round(acc_ov_ms, 4),
+                         "note": "algorithmic 128 B/term x 2^log2n terms per launch; avg_ms = HIP-event duration with one call in flight (same process, "
+                                 "untimed pass; rocprof of `bench.py --inflight 1` agrees), avg_ms_overlapped = inside the timed region where launches "
+                                 "share the chip; the kernel is integer-multiply bound: see valu_roofline"},
         }
         if acc_avg_ms > 0 and "msm.accumulate" in stages:
             W = 16 if args.log2n >= 17 else None

@@ -7,6 +7,14 @@
 
 namespace bls29 {
 
+// FP2_NOINLINE: compile the Fp2 product / square as real device functions (smaller register footprint and code for the
+// G2 kernels, whose fully inlined mixed addition does not fit the 256-VGPR budget)
+#if defined(FP2_NOINLINE) && defined(__HIPCC__)
+#define FD2 __host__ __device__ __noinline__
+#else
+#define FD2 FD
+#endif
+
 struct Fp2 { Fp c0, c1; };
 
 FD void fzero(Fp2 &r) { fp_zero(r.c0); fp_zero(r.c1); }
@@ -19,7 +27,7 @@ FD bool fmaybe_zero(const Fp2 &a) { return fp_maybe_zero(a.c0) && fp_maybe_zero(
 FD bool fis_zero_exact(const Fp2 &a) { return fp_is_zero_exact(a.c0) && fp_is_zero_exact(a.c1); }
 
 // Karatsuba, 3 base-field products.  Inputs class N; outputs class N with value < 6 p.
-FD void fmul(Fp2 &r, const Fp2 &a, const Fp2 &b) {
+FD2 void fmul(Fp2 &r, const Fp2 &a, const Fp2 &b) {
     Fp t0, t1, t2, sa, sb;
     fp_mul(t0, a.c0, b.c0);
     fp_mul(t1, a.c1, b.c1);
@@ -31,7 +39,7 @@ FD void fmul(Fp2 &r, const Fp2 &a, const Fp2 &b) {
     fp_sub<4>(r.c1, t2, t0); fp_norm(r.c1, r.c1);
 }
 // (a0 + a1)(a0 - a1), 2 a0 a1 : 2 base-field products.  Input class N with value < 60 p.
-FD void fsqr(Fp2 &r, const Fp2 &a) {
+FD2 void fsqr(Fp2 &r, const Fp2 &a) {
     Fp s, d, t;
     fp_add(s, a.c0, a.c1);
     fp_sub<64>(d, a.c0, a.c1); fp_norm(d, d);

@@ -50,7 +50,7 @@ struct G2 {
     static constexpr int AFF_STRIDE = 64;    // 256 B: x[28] y[28] flag pad[7]
     static constexpr int XW = 4 * FW;
     static constexpr int HEAVY_T = 128;
-    static constexpr int ACC_WAVES = 1;      // an XYZZ accumulator over Fp2 is 112 registers: give the kernel the whole 512-entry file
+    static constexpr int ACC_WAVES = 2;      // an XYZZ accumulator over Fp2 is 112 registers: give the kernel the whole 512-entry file
 };
 
 template <class F> __device__ __forceinline__ uint32_t *limbs(F &f) { return reinterpret_cast<uint32_t *>(&f); }

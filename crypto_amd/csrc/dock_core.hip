@@ -11,18 +11,25 @@ int choose_c(size_t n) {
     const char *e = getenv("DGPU_WINDOW_BITS");
     if (e) { int v = atoi(e); if (v >= 7 && v <= 22) return v; }
     double best = 1e300; int bc = 7;
-    for (int c = 7; c <= 20; c++) {
+    // c <= 16: digit codes stay 2 bytes and the LDS counting sort sweeps W * RANGES * n * 2 B (at c = 20, n = 2^24 the 4-byte
+    // codes and 32 ranges made the scatter pass 25 ms)
+    for (int c = 7; c <= 16; c++) {
         double W = 255 / c + 1, B = (double)(1u << (c - 1));
         double cost = (double)n * W + 8.0 * W * B;
         if (cost < best) { best = cost; bc = c; }
     }
     return bc;
 }
-int choose_chunk() {
+int choose_chunk(size_t E) {
     if (g.chunk) return g.chunk;
     const char *e = getenv("DGPU_CHUNK");
-    if (e) { int v = atoi(e); if (v == 16 || v == 32 || v == 64 || v == 128) return v; }
-    return 64;
+    if (e) { int v = atoi(e); if (v >= 16 && v <= 4096 && (v & (v - 1)) == 0) return v; }
+    // terms per lane: as few lanes as still fill the chip once (256 CUs x 512 lanes = 131072), so that a chunk is about as
+    // long as a bucket's run at every n (at n = 2^24 a fixed 64 left 7 of 8 chunks inside one bucket and the fix-up
+    // pass ran at 1/8 lane efficiency)
+    int ch = 64;
+    while (E / (size_t)ch > 140000 && ch < 4096) ch *= 2;
+    return ch;
 }
 
 int32_t upload_scalars(Slot &sl, const uint64_t *h, size_t n, bool mont, uint32_t *d_out) {

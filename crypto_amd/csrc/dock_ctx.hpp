@@ -110,7 +110,7 @@ inline bool lookup_handle(uint64_t h, Handle &out) {
 }
 
 int choose_c(size_t n);
-int choose_chunk();
+int choose_chunk(size_t E);
 int32_t upload_scalars(Slot &sl, const uint64_t *h, size_t n, bool mont, uint32_t *d_out);
 
 }  // namespace dock

@@ -1,0 +1,87 @@
+// crypto_amd/csrc/fp2_pair.cuh — Fp2 arithmetic spread over a LANE PAIR (device only).
+//
+// An XYZZ accumulator over Fp2 is 112 registers and the fully inlined mixed addition needs > 256 VGPRs, so the
+// one-lane-per-point G2 kernel runs at one wave per SIMD with spills (25 ms for n = 2^20, 7x G1).  Here lanes 2k and
+// 2k+1 share one point: the even lane holds every c0 component, the odd lane every c1 component.  Each lane then has
+// exactly the register footprint of the G1 kernel (2 waves/SIMD, no spills).  Cross terms travel over DPP quad_perm
+// (full-rate VALU, no LDS).  A product costs 2 base-field products per lane (schoolbook, 4 in total instead of
+// Karatsuba's 3), a square 1 per lane:
+//     (a0 + a1 u)(b0 + b1 u) = (a0 b0 - a1 b1) + (a0 b1 + a1 b0) u
+//     (a0 + a1 u)^2          = (a0 + a1)(a0 - a1) + 2 a0 a1 u
+// Both lanes of a pair always follow the same control flow (same terms, same run boundaries).
+#pragma once
+#include "fp29.cuh"
+#include "ec29.cuh"
+
+namespace bls29 {
+
+struct Fp2H { Fp v; };   // this lane's half of an Fp2 element
+
+__device__ __forceinline__ bool pair_odd() { return (threadIdx.x & 1u) != 0; }
+__device__ __forceinline__ uint32_t xchg32(uint32_t x) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true);
+}
+__device__ __forceinline__ void xchg(Fp &r, const Fp &a) {
+#pragma unroll
+    for (int i = 0; i < NL; i++) r.l[i] = xchg32(a.l[i]);
+}
+__device__ __forceinline__ void sel(Fp &r, bool c, const Fp &a, const Fp &b) {   // r = c ? a : b
+#pragma unroll
+    for (int i = 0; i < NL; i++) r.l[i] = c ? a.l[i] : b.l[i];
+}
+
+__device__ __forceinline__ void fzero(Fp2H &r) { fp_zero(r.v); }
+__device__ __forceinline__ void fset_one(Fp2H &r) { Fp one, z; fp_set_one(one); fp_zero(z); sel(r.v, pair_odd(), z, one); }
+__device__ __forceinline__ void fadd(Fp2H &r, const Fp2H &a, const Fp2H &b) { fp_add(r.v, a.v, b.v); }
+__device__ __forceinline__ void fdbl(Fp2H &r, const Fp2H &a) { fp_add(r.v, a.v, a.v); }
+template <int M> __device__ __forceinline__ void fsub(Fp2H &r, const Fp2H &a, const Fp2H &b) { fp_sub<M>(r.v, a.v, b.v); }
+__device__ __forceinline__ void fnorm(Fp2H &r, const Fp2H &a) { fp_norm(r.v, a.v); }
+__device__ __forceinline__ bool fmaybe_zero(const Fp2H &a) {
+    uint32_t z = fp_maybe_zero(a.v) ? 1u : 0u;
+    return (z & xchg32(z)) != 0;
+}
+__device__ __forceinline__ bool fis_zero_exact(const Fp2H &a) {
+    uint32_t z = fp_is_zero_exact(a.v) ? 1u : 0u;
+    return (z & xchg32(z)) != 0;
+}
+// product: inputs class N; output class N, value < 6 p (same contract as the one-lane Fp2 product)
+__device__ __forceinline__ void fmul(Fp2H &r, const Fp2H &a, const Fp2H &b) {
+    const bool odd = pair_odd();
+    Fp bo, same, cross, send, recv, t, d;
+    xchg(bo, b.v);
+    fp_mul(same, a.v, b.v);      // even: a0 b0   odd: a1 b1
+    fp_mul(cross, a.v, bo);      // even: a0 b1   odd: a1 b0
+    sel(send, odd, same, cross); // each lane sends what its partner needs
+    xchg(recv, send);            // even gets a1 b1, odd gets a0 b1
+    sel(t, odd, cross, same);
+    {   // d = K4 - recv (the even lane subtracts), limb-wise
+        Fp z; fp_zero(z); fp_sub<4>(d, z, recv);
+    }
+    Fp u; sel(u, odd, recv, d);
+    fp_add(t, t, u);
+    fp_norm(r.v, t);
+}
+// square: input class N with value < 60 p
+__device__ __forceinline__ void fsqr(Fp2H &r, const Fp2H &a) {
+    const bool odd = pair_odd();
+    Fp ao, s, d, m1, m2, p, p2;
+    xchg(ao, a.v);
+    fp_add(s, a.v, ao);                       // a0 + a1 (both lanes; used by the even lane)
+    fp_sub<64>(d, a.v, ao); fp_norm(d, d);    // even: a0 - a1
+    sel(m1, odd, a.v, s);
+    sel(m2, odd, ao, d);
+    fp_mul(p, m1, m2);                        // even: (a0+a1)(a0-a1)   odd: a1 a0
+    fp_add(p2, p, p); fp_norm(p2, p2);
+    sel(r.v, odd, p2, p);
+}
+
+template <> struct SubM<Fp2H> {     // same value budgets as the one-lane Fp2 formulas
+    static constexpr int P = 32;
+    static constexpr int R = 16;
+    static constexpr int X = 16;
+    static constexpr int D = 32;
+    static constexpr int Y = 8;
+    static constexpr int NEG = 4;
+};
+
+}  // namespace bls29

@@ -61,8 +61,8 @@ int32_t msm_device(Slot &sl, const uint32_t *d_bases, const uint32_t *d_scalars,
     const int mshift = std::max(0, c - 1 - 12);
     const int G = (int)(B >> (6 + mshift));          // groups per window (<= 64), B >= 64 because c >= 7
     const size_t NG = (size_t)W * G;
-    const int CH = choose_chunk();
     const size_t Emax = (size_t)n * W;
+    const int CH = choose_chunk(Emax);
     const size_t T = (Emax + CH - 1) / CH;
     const size_t nblk = scan_blocks(NB);
 
@@ -72,10 +72,10 @@ int32_t msm_device(Slot &sl, const uint32_t *d_bases, const uint32_t *d_scalars,
     if ((rc = sl.cursor.ensure(((size_t)NB + 1) * 4))) return rc;
     if ((rc = sl.bsums.ensure((nblk + 2) * 4))) return rc;
     if ((rc = sl.entries.ensure(Emax * 4))) return rc;
-    if ((rc = sl.bucket.ensure((size_t)NB * C::XW * 4))) return rc;
+    if ((rc = sl.bucket.ensure(soa_points(NB) * C::XW * 4))) return rc;
     if ((rc = sl.bucket_inf.ensure(NB))) return rc;
-    if ((rc = sl.head.ensure(T * C::XW * 4))) return rc;
-    if ((rc = sl.tail.ensure(T * C::XW * 4))) return rc;
+    if ((rc = sl.head.ensure(soa_points(T) * C::XW * 4))) return rc;
+    if ((rc = sl.tail.ensure(soa_points(T) * C::XW * 4))) return rc;
     if ((rc = sl.head_b.ensure(T * 4))) return rc;
     if ((rc = sl.tail_b.ensure(T * 4))) return rc;
     if ((rc = sl.part_inf.ensure(T * 2))) return rc;

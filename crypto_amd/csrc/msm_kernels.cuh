@@ -26,12 +26,16 @@
 #include "fp29.cuh"
 #include "fp2_29.cuh"
 #include "ec29.cuh"
+#include "fp2_pair.cuh"
 
 namespace msm {
 using namespace bls29;
 
 
 // ---- curve descriptions -------------------------------------------------------------------------
+struct G1;
+struct G2;
+struct G2P;
 struct G1 {
     typedef Fp F;
     static constexpr int FW = NL;            // u32 words per coordinate (device form)
@@ -40,6 +44,8 @@ struct G1 {
     static constexpr int AFF_STRIDE = 32;    // u32 per prepared base record (128 B): x[14] y[14] flag pad[3]
     static constexpr int XW = 4 * FW;        // u32 per XYZZ point
     static constexpr int HEAVY_T = 256;      // threads per block in k_fixup_heavy (XW * HEAVY_T * 4 B of LDS)
+    static constexpr int LPP = 1;            // lanes per point in k_accumulate
+    typedef G1 ACC;                          // traits used by the accumulate kernel
     static constexpr int ACC_WAVES = 2;      // waves/SIMD of k_accumulate: 256 VGPRs, no spills (tools/ubench/madd_rate: 6.35 vs 5.1 Gmadd/s at 3)
 };
 struct G2 {
@@ -50,7 +56,18 @@ struct G2 {
     static constexpr int AFF_STRIDE = 64;    // 256 B: x[28] y[28] flag pad[7]
     static constexpr int XW = 4 * FW;
     static constexpr int HEAVY_T = 128;
-    static constexpr int ACC_WAVES = 2;      // an XYZZ accumulator over Fp2 is 112 registers: give the kernel the whole 512-entry file
+    static constexpr int LPP = 1;
+    typedef G2P ACC;                         // k_accumulate runs the lane-pair formulation (fp2_pair.cuh)
+    static constexpr int ACC_WAVES = 2;
+};
+// G2 with one point per lane pair: the even lane holds the c0 halves, the odd lane the c1 halves
+struct G2P {
+    typedef Fp2H F;
+    static constexpr int FW = NL;            // words per coordinate HALF held by one lane
+    static constexpr int AFF_STRIDE = 64;
+    static constexpr int XW = 8 * NL;        // words per full XYZZ point in the SoA arrays
+    static constexpr int LPP = 2;
+    static constexpr int ACC_WAVES = 2;
 };
 
 template <class F> __device__ __forceinline__ uint32_t *limbs(F &f) { return reinterpret_cast<uint32_t *>(&f); }
@@ -83,16 +100,23 @@ __global__ void __launch_bounds__(256) k_prep_bases(const uint32_t *__restrict__
 }
 
 // ---- XYZZ <-> memory -------------------------------------------------------------------------------
-// SoA: word k of point b lives at base[k * stride + b]  (coalesced when consecutive lanes own consecutive b)
-template <class C> __device__ __forceinline__ void store_soa(uint32_t *__restrict__ base, size_t stride, size_t b, const Xyzz<typename C::F> &p) {
+// Tiled SoA: points are grouped in tiles of 64; word k of point b lives at base[((b / 64) * XW + k) * 64 + b % 64].
+// Consecutive lanes own consecutive b, so every access is a coalesced 256-byte row, and one point stays inside a
+// 14 KB (G1) tile — a flat word-major layout (stride = array length) put the 56 words of a point on 56 different pages
+// and TLB misses made the 2^24 fix-up pass 8x slower than linear.  Arrays are padded to a multiple of 64 points.
+constexpr size_t SOA_TILE = 64;
+__host__ __device__ inline size_t soa_points(size_t n) { return (n + SOA_TILE - 1) / SOA_TILE * SOA_TILE; }
+template <class C> __device__ __forceinline__ void store_soa(uint32_t *__restrict__ base, size_t /*count*/, size_t b, const Xyzz<typename C::F> &p) {
     const uint32_t *w = reinterpret_cast<const uint32_t *>(&p);
+    uint32_t *t = base + (b / SOA_TILE) * (C::XW * SOA_TILE) + (b % SOA_TILE);
 #pragma unroll
-    for (int k = 0; k < C::XW; k++) base[(size_t)k * stride + b] = w[k];
+    for (int k = 0; k < C::XW; k++) t[k * SOA_TILE] = w[k];
 }
-template <class C> __device__ __forceinline__ void load_soa(Xyzz<typename C::F> &p, const uint32_t *__restrict__ base, size_t stride, size_t b) {
+template <class C> __device__ __forceinline__ void load_soa(Xyzz<typename C::F> &p, const uint32_t *__restrict__ base, size_t /*count*/, size_t b) {
     uint32_t *w = reinterpret_cast<uint32_t *>(&p);
+    const uint32_t *t = base + (b / SOA_TILE) * (C::XW * SOA_TILE) + (b % SOA_TILE);
 #pragma unroll
-    for (int k = 0; k < C::XW; k++) w[k] = base[(size_t)k * stride + b];
+    for (int k = 0; k < C::XW; k++) w[k] = t[k * SOA_TILE];
 }
 template <class C> __device__ __forceinline__ void load_aff(Aff<typename C::F> &p, const uint32_t *__restrict__ rec) {
     uint32_t *w = reinterpret_cast<uint32_t *>(&p);
@@ -100,6 +124,27 @@ template <class C> __device__ __forceinline__ void load_aff(Aff<typename C::F> &
     for (int k = 0; k < 2 * C::FW; k += 4) {
         uint4 v = *reinterpret_cast<const uint4 *>(rec + k);
         w[k] = v.x; w[k + 1] = v.y; w[k + 2] = v.z; w[k + 3] = v.w;
+    }
+}
+
+// lane-pair variants: this lane moves only its half (c0 on even lanes, c1 on odd lanes) of every coordinate
+template <> __device__ __forceinline__ void store_soa<G2P>(uint32_t *__restrict__ base, size_t /*count*/, size_t b, const Xyzz<Fp2H> &p) {
+    const uint32_t h = threadIdx.x & 1u;
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(&p);      // x, y, zz, zzz halves: 4 x 14 words
+    uint32_t *t = base + (b / SOA_TILE) * (G2P::XW * SOA_TILE) + (b % SOA_TILE);
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+#pragma unroll
+        for (int j = 0; j < NL; j++) t[((2 * k + h) * NL + j) * SOA_TILE] = w[k * NL + j];
+}
+template <> __device__ __forceinline__ void load_aff<G2P>(Aff<Fp2H> &p, const uint32_t *__restrict__ rec) {
+    const uint32_t h = threadIdx.x & 1u;
+    uint32_t *w = reinterpret_cast<uint32_t *>(&p);
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const uint32_t *src = rec + (2 * k + h) * NL;                 // 56-byte granules: 8-byte aligned
+#pragma unroll
+        for (int j = 0; j < NL; j += 2) { uint2 v = *reinterpret_cast<const uint2 *>(src + j); w[k * NL + j] = v.x; w[k * NL + j + 1] = v.y; }
     }
 }
 
@@ -113,7 +158,7 @@ __global__ void __launch_bounds__(256, C::ACC_WAVES) k_accumulate(const uint32_t
                                                     uint32_t *__restrict__ head, uint32_t *__restrict__ tail, uint32_t *__restrict__ head_b, uint32_t *__restrict__ tail_b,
                                                     uint8_t *__restrict__ part_inf, size_t T, uint32_t CH, uint32_t dbg_mask) {
     typedef typename C::F F;
-    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t t = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / C::LPP;   // C::LPP lanes cooperate on one chunk
     if (t >= T) return;
     const uint32_t E = off[NB];
     uint64_t start64 = (uint64_t)t * CH;

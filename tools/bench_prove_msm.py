@@ -1,0 +1,76 @@
+"""BASELINE config 4 (MSM part): the five large MSMs of one LegoGroth16 proof on a synthetic proving key.
+
+create_proof_and_committed_witnesses_with_assignment (legogroth16/src/prover.rs:267-383) runs, per proof:
+    h_acc   = G1::msm_bigint(h_query[..D-1], h)                :286
+    l_acc   = G1::msm_bigint(l_query, aux)                     :299
+    g_a     = msm(a_query[1..], assignment)                    :326 -> :592
+    g1_b    = msm(b_g1_query[1..], assignment)                 :333
+    g2_b    = msm(b_g2_query[1..], assignment)   (G2)          :344
+The proving-key queries are device-resident handles (uploaded once); each proof uploads only scalars (32 B/term)
+and issues the five MSMs from five host threads (they are independent).  The witness map (FFTs,
+legogroth16/src/r1cs_to_qap.rs:150-210) is SURVEY 8f-1 "next" and is NOT included: this is the MSM share of prove.
+Synthetic key: bases with known discrete logs, 1 % identity entries in a/b queries (zero QAP rows, prover.rs:198);
+two scalar distributions: uniform, and Groth16-like (half of the witness in {0,1}, a quarter 16-bit, a quarter full).
+"""
+import json, os, sys, time, threading
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import numpy as np
+import crypto_amd as ca
+import oracle_c as O
+
+R = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+lg = int(os.environ.get("LOG2M", "20"))
+D = 1 << lg
+V = D            # ~ one variable per constraint (Benchmark circuit shape, legogroth16/src/aggregation/tests.rs:35-89)
+ca.init(0)
+k0 = O.rand_scalars(1, 1)[0]; d = O.rand_scalars(2, 1)[0]
+t0 = time.time()
+g1 = O.G1.gen_seq(k0, d, D, threads=64)
+g2 = O.G2.gen_seq(d, k0, V, threads=64)
+inf = (np.random.default_rng(1).integers(0, 100, V) == 0).astype(np.uint8)
+q = {"h": ca.DeviceBases(ca.G1, g1[:D - 1]), "l": ca.DeviceBases(ca.G1, g1[:V]),
+     "a": ca.DeviceBases(ca.G1, g1[:V], inf), "b1": ca.DeviceBases(ca.G1, g1[:V], inf), "b2": ca.DeviceBases(ca.G2, g2, inf)}
+print("key upload %.1f s" % (time.time() - t0), flush=True)
+
+def witness(kind, n, seed):
+    sc = O.rand_scalars(seed, n)
+    if kind == "groth16":
+        rng = np.random.default_rng(seed)
+        k = rng.integers(0, 4, n)
+        sc[k <= 1] = 0
+        sc[k == 1, 0] = rng.integers(0, 2, int((k == 1).sum()), dtype=np.uint64)
+        m = k == 2
+        sc[m, 1:] = 0
+        sc[m, 0] &= np.uint64(0xFFFF)
+    return sc
+
+out = {}
+for kind in ("uniform", "groth16"):
+    h = O.rand_scalars(11, D)            # h coefficients are always full-size field elements
+    w = witness(kind, V, 12)
+    jobs = [("h", q["h"], h[:D - 1], 0), ("l", q["l"], w, 0), ("a", q["a"], w[1:], 1), ("b1", q["b1"], w[1:], 1), ("b2", q["b2"], w[1:], 1)]
+    res = {}
+    def run(name, db, sc, off):
+        res[name] = db.msm_bigint(sc, offset=off)
+    def prove():
+        ths = [threading.Thread(target=run, args=j) for j in jobs]
+        for t in ths: t.start()
+        for t in ths: t.join()
+    prove()
+    ref = {k: v.copy() for k, v in res.items()}
+    K = 5
+    t0 = time.time()
+    for _ in range(K): prove()
+    dt = (time.time() - t0) / K
+    assert all((res[k] == ref[k]).all() for k in ref)
+    # sequential, for the per-MSM split
+    per = {}
+    for j in jobs:
+        t1 = time.time(); run(*j); per[j[0]] = round((time.time() - t1) * 1e3, 2)
+    # spot check one MSM against the oracle on a prefix through the same handle path
+    chk = q["a"].msm_bigint(w[1:4097], offset=1)
+    ok = bool((O.G1.to_affine(chk)[0] == O.G1.to_affine(O.G1.msm(g1[1:4097], w[1:4097], inf[1:4097], threads=16))[0]).all())
+    out[kind] = {"ms_per_proof_msm_part": round(dt * 1e3, 2), "constraints_per_s_msm_part": round(D / dt, 1), "per_msm_ms_sequential": per, "prefix_check_vs_oracle": ok}
+    print(kind, out[kind], flush=True)
+print(json.dumps({"config": "LegoGroth16 prove, MSM part only, m = D = 2^%d, 4 G1 + 1 G2 MSM, key resident, scalars uploaded per proof" % lg, **out}))

@@ -9,3 +9,4 @@ from .msm import (  # noqa: F401
     G1, G2, msm_bigint, msm_unchecked, msm, Pairs, DeviceBases, DeviceScalars, init, prof,
 )
 from .pairing import multi_miller_loop, final_exponentiation, multi_pairing  # noqa: F401,E402
+from .pairing_check import RandomizedPairingChecker  # noqa: F401,E402

@@ -14,6 +14,7 @@
 #include "dock_ctx.hpp"
 #include "host_field.hpp"
 #include "pairing29.cuh"
+#include "sort_launch.cuh"
 
 namespace {
 using namespace bls29;
@@ -130,6 +131,46 @@ int32_t dgpu_multi_miller_loop(const uint64_t *p, const uint64_t *q, const uint8
     f = f.conj();      // x < 0
     memcpy(out, &f, sizeof f);
     return DGPU_OK;
+}
+
+int32_t dgpu_g1_scale_batch(const uint64_t *p, const uint8_t *is_inf, const uint64_t *scalars, size_t scalar_stride, const uint8_t *negate, size_t n, uint64_t *out, uint8_t *out_inf) {
+    if ((n && (!p || !scalars || !out || !out_inf)) || (scalar_stride != 0 && scalar_stride != 4)) return DGPU_E_BADARG;
+    if (n == 0) return DGPU_OK;
+    if (!g.ready) return DGPU_E_NODEVICE;
+    SlotLock slot_lock; Slot &sl = *slot_lock.s;
+    HIPCHK(hipSetDevice(g.device));
+    int32_t rc;
+    const size_t nsc = scalar_stride ? n : 1;
+    if ((rc = sl.in_bases.ensure(n * 96))) return rc;
+    if ((rc = sl.in_scalars.ensure(nsc * 32))) return rc;
+    if ((rc = sl.in_inf.ensure(2 * n))) return rc;
+    if ((rc = sl.prepped.ensure(n * 96 + n))) return rc;
+    hipStream_t s = sl.stream;
+    HIPCHK(hipMemcpyAsync(sl.in_bases.p, p, n * 96, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(sl.in_scalars.p, scalars, nsc * 32, hipMemcpyHostToDevice, s));
+    const uint8_t *dinf = nullptr, *dneg = nullptr;
+    if (is_inf) { HIPCHK(hipMemcpyAsync(sl.in_inf.p, is_inf, n, hipMemcpyHostToDevice, s)); dinf = sl.in_inf.as<uint8_t>(); }
+    if (negate) { HIPCHK(hipMemcpyAsync(sl.in_inf.as<uint8_t>() + n, negate, n, hipMemcpyHostToDevice, s)); dneg = sl.in_inf.as<uint8_t>() + n; }
+    uint8_t *dout_inf = sl.prepped.as<uint8_t>() + n * 96;
+    { StageTimer st(sl, "pc.g1_scale");
+      msm::launch_g1_scale(s, sl.in_bases.as<uint32_t>(), dinf, sl.in_scalars.as<uint32_t>(), (int)(scalar_stride * 2), dneg, n, sl.prepped.as<uint32_t>(), dout_inf); }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, sl.prepped.p, n * 96, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(out_inf, dout_inf, n, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (g.prof) prof_flush(sl);
+    return DGPU_OK;
+}
+int32_t dgpu_fp12_mul(const uint64_t *a, const uint64_t *b, uint64_t *out) {
+    if (!a || !b || !out) return DGPU_E_BADARG;
+    hostf::Fq12 x, y; memcpy(&x, a, sizeof x); memcpy(&y, b, sizeof y);
+    hostf::Fq12 r = x * y; memcpy(out, &r, sizeof r); return DGPU_OK;
+}
+int32_t dgpu_fp12_pow(const uint64_t *a, const uint64_t *e, uint64_t *out) {
+    if (!a || !e || !out) return DGPU_E_BADARG;
+    hostf::Fq12 base, acc = hostf::Fq12::one(); memcpy(&base, a, sizeof base);
+    for (int i = 255; i >= 0; i--) { acc = acc.sqr(); if ((e[i / 64] >> (i % 64)) & 1) acc = acc * base; }
+    memcpy(out, &acc, sizeof acc); return DGPU_OK;
 }
 
 // E::final_exponentiation: once per batch, host code

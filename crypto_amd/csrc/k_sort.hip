@@ -1,6 +1,6 @@
 // crypto_amd/csrc/k_sort.hip — translation unit of the curve-independent kernels (digits, counting sort, scan, self-tests).
 #include "sort_kernels.cuh"
-#include "msm_launch.cuh"
+#include "sort_launch.cuh"
 
 namespace msm {
 void launch_digit_codes(hipStream_t s, bool wide, const uint32_t *scalars, const uint32_t *bases, int aff_stride, int flag_word, size_t n, size_t n_pad, int c, int W, void *dig) {
@@ -21,6 +21,9 @@ void launch_scan(hipStream_t s, const uint32_t *cnt, uint32_t *off, uint32_t *cu
     hipLaunchKernelGGL(k_scan_block, dim3((unsigned)nblk), dim3(SCAN_T), 0, s, cnt, off, bsums, NB);
     hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, s, bsums, nblk);
     hipLaunchKernelGGL(k_scan_add, dim3((unsigned)((NB + 1 + 255) / 256)), dim3(256), 0, s, off, cursor, bsums, NB, nblk);
+}
+void launch_g1_scale(hipStream_t s, const uint32_t *p_abi, const uint8_t *is_inf, const uint32_t *scalars, int scalar_stride, const uint8_t *negate, size_t n, uint32_t *out_abi, uint8_t *out_inf) {
+    hipLaunchKernelGGL(k_g1_scale, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, p_abi, is_inf, scalars, scalar_stride, negate, n, out_abi, out_inf);
 }
 void launch_selftest_fp_mul(hipStream_t s, const uint32_t *a, const uint32_t *b, size_t n, uint32_t *out) {
     hipLaunchKernelGGL(k_selftest_fp_mul, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, a, b, n, out);

@@ -5,6 +5,7 @@
 #include "dock_ctx.hpp"
 #include "host_field.hpp"
 #include "msm_launch.cuh"
+#include "sort_launch.cuh"
 
 namespace dock {
 using namespace msm;

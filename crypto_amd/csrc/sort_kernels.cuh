@@ -173,4 +173,48 @@ __global__ void k_selftest_g1_sum(const uint32_t *pts_abi, const uint8_t *neg, s
     if (!inf) { fp_to_abi(out, acc.x); fp_to_abi(out + 12, acc.y); fp_to_abi(out + 24, acc.zz); fp_to_abi(out + 36, acc.zzz); }
 }
 
+// ---- batched G1 scalar multiplication: out_i = s_i * P_i (affine, ABI form) --------------------------------------
+// RandomizedPairingChecker scales every G1 source by a power of the batching randomness before the Miller loop
+// (utils/src/randomized_pairing_check.rs:125-127,152-158: `a.mul_bigint(m)` in a cfg_iter!); one lane per point,
+// double-and-add over the 255 scalar bits, then one Fermat inversion per lane for the affine form the line
+// evaluation needs.
+__device__ __forceinline__ void fp_inv_device(Fp &r, const Fp &a) {
+    // a^(p-2); exponent bits taken from the 29-bit limbs of p (p - 2 only changes limb 0: ...aaab -> ...aaa9)
+    constexpr uint32_t P_[NL] = BLS29_P;
+    Fp acc; fp_set_one(acc);
+    for (int i = NL - 1; i >= 0; i--) {
+        uint32_t w = (i == 0) ? (P_[0] - 2u) : P_[i];
+        int hi = (i == NL - 1) ? 3 : LB - 1;           // top limb of p is 0xd: 4 bits
+        for (int b = hi; b >= 0; b--) { fp_sqr(acc, acc); if ((w >> b) & 1u) fp_mul(acc, acc, a); }
+    }
+    r = acc;
+}
+__global__ void __launch_bounds__(64) k_g1_scale(const uint32_t *__restrict__ p_abi, const uint8_t *__restrict__ is_inf, const uint32_t *__restrict__ scalars, int scalar_stride,
+                                                 const uint8_t *__restrict__ negate, size_t n, uint32_t *__restrict__ out_abi, uint8_t *__restrict__ out_inf) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t any = 0;
+    for (int k = 0; k < 24; k++) any |= p_abi[i * 24 + k];
+    bool pinf = (any == 0) || (is_inf && is_inf[i]);
+    Aff<Fp> P; fp_from_abi(P.x, p_abi + i * 24); fp_from_abi(P.y, p_abi + i * 24 + 12);
+    const uint32_t *s = scalars + i * (size_t)scalar_stride;
+    Xyzz<Fp> acc; bool inf = true;
+    fzero(acc.x); fzero(acc.y); fzero(acc.zz); fzero(acc.zzz);
+    if (!pinf)
+        for (int b = 254; b >= 0; b--) {
+            if (!inf) { Xyzz<Fp> d; xyzz_dbl(d, acc); acc = d; }
+            if ((s[b >> 5] >> (b & 31)) & 1u) xyzz_madd(acc, inf, P, false);
+        }
+    out_inf[i] = inf;
+    uint32_t *o = out_abi + i * 24;
+    if (inf) { for (int k = 0; k < 24; k++) o[k] = 0; return; }
+    Fp i3, t, i2, x, y;
+    fp_inv_device(i3, acc.zzz);                 // 1 / ZZZ
+    fp_mul(t, acc.zz, i3); fp_sqr(i2, t);       // (ZZ / ZZZ)^2 = 1 / ZZ      (ZZ^3 == ZZZ^2)
+    Fp xn, yn; fp_norm(xn, acc.x); fp_norm(yn, acc.y);
+    fp_mul(x, xn, i2); fp_mul(y, yn, i3);
+    if (negate && negate[i]) { Fp z; fp_zero(z); fp_sub<4>(y, z, y); fp_norm(y, y); }
+    fp_to_abi(o, x); fp_to_abi(o + 12, y);
+}
+
 }  // namespace msm

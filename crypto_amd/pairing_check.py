@@ -1,0 +1,123 @@
+"""Mirror of `dock_crypto_utils::randomized_pairing_check::RandomizedPairingChecker<Bls12_381>`
+(/root/reference/utils/src/randomized_pairing_check.rs:24-215), running on the C ABI.
+
+Same state, same methods, same laziness semantics:
+    left    product of Miller-loop outputs accumulated so far              (:27)
+    right   GT target, `right += out.mul_bigint(m)`  (GT is written additively in arkworks; it is the Fp12 product)  (:30)
+    pending (G1, G2) pairs queued for one big multi_miller_loop in verify()  when lazy   (:34, :204-214)
+    random / current_random  r and r^k; equation k is scaled by r^k         (:36-38)
+The G1 scalings `a.mul_bigint(m)` run batched on the GPU (dgpu_g1_scale_batch), Miller loops through
+dgpu_multi_miller_loop, GT arithmetic and the single final exponentiation on the host (dgpu_fp12_*,
+dgpu_final_exponentiation).  Points are numpy uint64 arrays in the ABI layout; scalars are Python ints.
+"""
+import ctypes as C
+import numpy as np
+from ._native import lib, DockGpuError
+from .msm import _ensure
+from . import pairing
+
+R_MOD = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+_ONE6 = np.array([0x760900000002fffd, 0xebf4000bc40c0002, 0x5f48985753c758ba, 0x77ce585370525745, 0x5c071a97a256ec6d, 0x15f65ec3fa80e493], dtype=np.uint64)
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _limbs(v):
+    return np.array([(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
+
+
+def fp12_one():
+    o = np.zeros(72, dtype=np.uint64)
+    o[:6] = _ONE6
+    return o
+
+
+def fp12_mul(a, b):
+    out = np.zeros(72, dtype=np.uint64)
+    rc = lib().dgpu_fp12_mul(_p(np.ascontiguousarray(a)), _p(np.ascontiguousarray(b)), _p(out))
+    if rc:
+        raise DockGpuError(rc, "dgpu_fp12_mul")
+    return out
+
+
+def fp12_pow(a, e):
+    out = np.zeros(72, dtype=np.uint64)
+    rc = lib().dgpu_fp12_pow(_p(np.ascontiguousarray(a)), _p(_limbs(e % R_MOD)), _p(out))
+    if rc:
+        raise DockGpuError(rc, "dgpu_fp12_pow")
+    return out
+
+
+def g1_scale(points, m, negate=False):
+    """[m * P for P in points] as affine ABI points (identity -> zero words + flag), `-` if negate"""
+    _ensure()
+    pts = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, 12)
+    n = len(pts)
+    out = np.zeros((n, 12), dtype=np.uint64)
+    inf = np.zeros(n, dtype=np.uint8)
+    neg = np.ones(n, dtype=np.uint8) if negate else None
+    rc = lib().dgpu_g1_scale_batch(_p(pts), None, _p(_limbs(m % R_MOD)), 0, _p(neg), n, _p(out), _p(inf))
+    if rc:
+        raise DockGpuError(rc, "dgpu_g1_scale_batch")
+    return out, inf
+
+
+class RandomizedPairingChecker:
+    def __init__(self, random, lazy):                          # new(random, lazy)  :44-53
+        self.left = fp12_one()
+        self.right = fp12_one()                                # PairingOutput::zero() == Fp12 one
+        self.lazy = bool(lazy)
+        self.pending = ([], [])
+        self.random = random % R_MOD
+        self.current_random = 1
+
+    # -- single equations -------------------------------------------------------------------------------------
+    def add_sources_and_target(self, a, b, out):               # e(a, b) == out   :61-77
+        self.add_multiple_sources_and_target(np.asarray(a).reshape(1, 12), np.asarray(b).reshape(1, 24), out)
+
+    def add_sources(self, a, b, c, d):                         # e(a, b) == e(c, d)   :104-113
+        self.add_multiple_sources(np.asarray(a).reshape(1, 12), np.asarray(b).reshape(1, 24),
+                                  np.asarray(c).reshape(1, 12), np.asarray(d).reshape(1, 24))
+
+    # -- products ---------------------------------------------------------------------------------------------
+    def add_multiple_sources_and_target(self, a, b, out, lazy=None):    # prod e(a_i, b_i) == out   :116-138
+        lazy = self.lazy if lazy is None else lazy
+        m = self.current_random
+        a_m, inf = g1_scale(a, m)
+        b = np.ascontiguousarray(b, dtype=np.uint64).reshape(-1, 24)
+        if len(a_m) != len(b):
+            raise DockGpuError(-7, "zip_eq")
+        if lazy:
+            self.pending[0].append(a_m); self.pending[1].append(b)
+        else:
+            self.left = fp12_mul(self.left, pairing.multi_miller_loop(a_m, b, inf))
+        self.right = fp12_mul(self.right, fp12_pow(out, m))
+        self.current_random = self.current_random * self.random % R_MOD
+
+    def add_multiple_sources(self, a, b, c, d, lazy=None):              # prod e(a_i, b_i) == prod e(c_i, d_i)   :142-173
+        lazy = self.lazy if lazy is None else lazy
+        m = self.current_random
+        a_m, ainf = g1_scale(a, m)
+        c_m, cinf = g1_scale(c, m, negate=True)
+        b = np.ascontiguousarray(b, dtype=np.uint64).reshape(-1, 24)
+        d = np.ascontiguousarray(d, dtype=np.uint64).reshape(-1, 24)
+        if len(a_m) != len(b) or len(c_m) != len(d):
+            raise DockGpuError(-7, "zip_eq")
+        if lazy:
+            self.pending[0].extend([a_m, c_m]); self.pending[1].extend([b, d])
+        else:
+            self.left = fp12_mul(self.left, pairing.multi_miller_loop(a_m, b, ainf))
+            self.left = fp12_mul(self.left, pairing.multi_miller_loop(c_m, d, cinf))
+        self.current_random = self.current_random * self.random % R_MOD
+
+    def verify(self):                                                   # :204-214
+        left = self.left
+        if self.pending[0]:
+            ps = np.concatenate(self.pending[0]); qs = np.concatenate(self.pending[1])
+            left = fp12_mul(pairing.multi_miller_loop(ps, qs), left)    # identity members are all-zero words: skipped on the device
+        gt = pairing.final_exponentiation(left)
+        if gt is None:
+            raise ValueError("final_exponentiation of zero")           # arkworks: .unwrap() panics
+        return bool((gt == self.right).all())

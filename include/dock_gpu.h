@@ -91,6 +91,16 @@ int32_t dgpu_multi_miller_loop(const uint64_t *p_xy /* n*12 */, const uint64_t *
 /* replaces Bls12_381::final_exponentiation — utils/src/randomized_pairing_check.rs:213 (host code, once per batch) */
 int32_t dgpu_final_exponentiation(const uint64_t in_f12[72], uint64_t out_f12[72]);
 
+/* ---- pieces of utils::randomized_pairing_check::RandomizedPairingChecker (utils/src/randomized_pairing_check.rs:24-215) ----
+ * out_i = s_i * P_i as affine points (the per-equation `a.mul_bigint(m)` scalings, :125-127,152-158), batched on the GPU.
+ * scalar_stride = 4: one canonical scalar per point; scalar_stride = 0: the same scalar for every point.
+ * negate[i] != 0 returns -(s_i P_i) (the `-c.mul_bigint(m)` of add_multiple_sources, :156-158). */
+int32_t dgpu_g1_scale_batch(const uint64_t *p_xy /* n*12 */, const uint8_t *is_inf, const uint64_t *scalars, size_t scalar_stride,
+                            const uint8_t *negate, size_t n, uint64_t *out_xy /* n*12 */, uint8_t *out_inf /* n */);
+/* GT arithmetic on the host: PairingOutput `+` is the Fp12 product, `mul_bigint` the power (:136 `self.right += out.mul_bigint(m)`) */
+int32_t dgpu_fp12_mul(const uint64_t a[72], const uint64_t b[72], uint64_t out[72]);
+int32_t dgpu_fp12_pow(const uint64_t a[72], const uint64_t e[4], uint64_t out[72]);
+
 /* ---- instrumentation (bench.py / rocprof cross-check) ----
  * When enabled, every stage of the next calls is bracketed by HIP events on the library's own stream. */
 int32_t dgpu_prof_enable(int32_t on);

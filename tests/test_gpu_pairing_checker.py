@@ -1,0 +1,105 @@
+"""GPU (-m gpu): the RandomizedPairingChecker mirror behaves like the reference's
+(/root/reference/utils/src/randomized_pairing_check.rs tests :234-420): it accepts batches of true pairing equations,
+rejects a batch with one wrong target / swapped source, in lazy and eager mode, for the three ways of adding
+equations; and the batched G1 scaling it relies on matches the oracle's mul_bigint."""
+import numpy as np
+import pytest
+import torch
+import oracle_c as O
+import util as U
+import crypto_amd as ca
+from crypto_amd import pairing_check as pc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _device():
+    assert torch.cuda.is_available()
+    ca.init(0)
+
+
+def g1(k):
+    return O.G1.to_affine(O.G1.mul(O.G1.generator(), O.int_to_limbs(k % U.R, 4)))[0]
+
+
+def g2(k):
+    return O.G2.to_affine(O.G2.mul(O.G2.generator(), O.int_to_limbs(k % U.R, 4)))[0]
+
+
+def gt(ps, qs):
+    return O.final_exponentiation(O.multi_miller_loop(np.asarray(ps).reshape(-1, 12), np.asarray(qs).reshape(-1, 24)))
+
+
+def test_g1_scale_batch_matches_mul_bigint():
+    rng = np.random.default_rng(1)
+    ks = [int(x) for x in rng.integers(1, 1 << 62, 40)]
+    pts = np.stack([g1(k) for k in ks])
+    m = 0x1234567890ABCDEF1234567890ABCDEF1234567890ABCDEF12345678 % U.R
+    out, inf = pc.g1_scale(pts, m)
+    assert not inf.any()
+    for k, o in zip(ks, out):
+        assert (o == g1(k * m)).all()
+    outn, _ = pc.g1_scale(pts[:5], m, negate=True)
+    for k, o in zip(ks, outn):
+        assert (o == g1(-(k * m))).all()
+    # scalar 0 and r-1; identity input
+    out0, inf0 = pc.g1_scale(pts[:3], 0)
+    assert inf0.all() and not out0.any()
+    outm, _ = pc.g1_scale(pts[:3], U.R - 1)
+    for k, o in zip(ks, outm):
+        assert (o == g1(-k)).all()
+    z = np.zeros((2, 12), np.uint64)
+    _, infz = pc.g1_scale(z, 5)
+    assert infz.all()
+
+
+@pytest.mark.parametrize("lazy", [False, True])
+def test_checker_accepts_true_equations_and_rejects_false(lazy):
+    rng = np.random.default_rng(3)
+    r = int(rng.integers(1, 1 << 62)) * 0x9E3779B97F4A7C15 % U.R
+
+    def fill(chk, corrupt=None):
+        # (1) e(a1 G1, b1 G2) == out            add_sources_and_target
+        a1, b1 = 11, 13
+        out1 = gt(g1(a1), g2(b1))
+        if corrupt == 1:
+            out1 = gt(g1(a1 + 1), g2(b1))
+        chk.add_sources_and_target(g1(a1), g2(b1), out1)
+        # (2) e(a2 G1, b2 G2) == e(c2 G1, d2 G2) with a2 b2 == c2 d2    add_sources
+        a2, b2, c2, d2 = 6, 35, 21, 10
+        if corrupt == 2:
+            d2 = 11
+        chk.add_sources(g1(a2), g2(b2), g1(c2), g2(d2))
+        # (3) prod e(a_i, b_i) == out            add_multiple_sources_and_target
+        a3, b3 = [3, 5, 7], [2, 4, 6]
+        out3 = gt(np.stack([g1(x) for x in a3]), np.stack([g2(x) for x in b3]))
+        chk.add_multiple_sources_and_target(np.stack([g1(x) for x in a3]), np.stack([g2(x) for x in b3]), out3)
+        # (4) prod e(a_i, b_i) == prod e(c_i, d_i)   add_multiple_sources   (2*9 + 4*3 == 5*6)
+        a4, b4, c4, d4 = [2, 4], [9, 3], [5], [6]
+        if corrupt == 4:
+            a4 = [2, 5]
+        chk.add_multiple_sources(np.stack([g1(x) for x in a4]), np.stack([g2(x) for x in b4]),
+                                 np.stack([g1(x) for x in c4]), np.stack([g2(x) for x in d4]))
+
+    chk = ca.RandomizedPairingChecker(r, lazy)
+    fill(chk)
+    assert chk.verify()
+    for bad in (1, 2, 4):
+        chk = ca.RandomizedPairingChecker(r, lazy)
+        fill(chk, corrupt=bad)
+        assert not chk.verify(), bad
+
+
+def test_lazy_and_eager_agree_and_laziness_override():
+    r = 0xDEADBEEF12345
+    a, b = np.stack([g1(3), g1(5)]), np.stack([g2(7), g2(9)])
+    out = gt(a, b)
+    e = ca.RandomizedPairingChecker(r, False)
+    l = ca.RandomizedPairingChecker(r, True)
+    for c in (e, l):
+        c.add_multiple_sources_and_target(a, b, out)
+        c.add_multiple_sources_and_target(a, b, out, lazy=not c.lazy)      # *_with_laziness_choice
+    assert e.verify() and l.verify()
+    assert len(l.pending[0]) == 1 and len(e.pending[0]) == 1
+    assert (e.right == l.right).all()

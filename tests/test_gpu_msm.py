@@ -190,3 +190,31 @@ def test_g2_full_size_closed_form_2_16():
     bases, k0, d = U.seq_bases(G, n, 4242, threads=64)
     sc = O.rand_scalars(4243, n)
     assert U.jac_to_model(G, ca.msm_bigint(curve, bases, sc)) == U.closed_form(G, sc, k0, d)
+
+
+def test_concurrent_callers_share_the_device():
+    """the reference calls MSM from inside rayon workers (verifiable_encryption/src/tz_21/rdkgith.rs:140-147): several host
+    threads in flight at once must each get their own correct result (per-call slots: stream + workspace)."""
+    import threading
+    G, curve = O.G1, ca.G1
+    sets = []
+    for k in range(6):
+        n = 3000 + 517 * k
+        bases, _, _ = U.seq_bases(G, n, 600 + k)
+        sc = O.rand_scalars(700 + k, n)
+        sets.append((bases, sc, normalised(G, G.msm(bases, sc, threads=8))))
+    errs = []
+
+    def work(bases, sc, ref):
+        try:
+            for _ in range(4):
+                if not (ca.msm_bigint(curve, bases, sc) == ref).all():
+                    errs.append("mismatch")
+        except Exception as e:          # noqa: BLE001
+            errs.append(repr(e))
+    ths = [threading.Thread(target=work, args=s) for s in sets]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errs, errs

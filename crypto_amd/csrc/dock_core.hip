@@ -75,6 +75,8 @@ int32_t dgpu_shutdown(void) {
     }
     for (auto &h : g.handles) (void)hipFree(h.second.p);
     g.handles.clear();
+    for (auto &d : g.ntt_domains) { void *ps[] = {d.second.tw_f, d.second.tw_i, d.second.pw_f, d.second.pw_i, d.second.zinv}; for (void *p : ps) if (p) (void)hipFree(p); }
+    g.ntt_domains.clear();
     g.prof_tab.clear();
     g.device = -1;
     return DGPU_OK;

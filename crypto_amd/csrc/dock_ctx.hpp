@@ -26,7 +26,8 @@ struct Buf {
     template <class T> T *as() { return reinterpret_cast<T *>(p); }
 };
 
-struct Handle { void *p; size_t n; int kind; };   // kind: 1 = G1 bases, 2 = G2 bases, 3 = scalars
+struct Handle { void *p; size_t n; int kind; };
+struct NttDomain { void *tw_f = nullptr, *tw_i = nullptr, *pw_f = nullptr, *pw_i = nullptr, *zinv = nullptr; };   // per log2(D), built once   // kind: 1 = G1 bases, 2 = G2 bases, 3 = scalars
 
 struct ProfEntry { const char *name; double ms; uint64_t calls; };
 
@@ -41,11 +42,13 @@ struct Slot {
     std::mutex mu;
     hipStream_t stream = nullptr;
     Buf in_bases, in_inf, in_scalars, prepped, digits, heavy, cnt, off, cursor, bsums, entries, bucket, bucket_inf, head, tail, head_b, tail_b, part_inf, l1, l1_inf, win, win_inf, ml_lines, ml_partial, ml_out;
+    Buf q[16];      // witness-map workspace (dock_qap.hip)
     std::vector<std::pair<const char *, std::pair<hipEvent_t, hipEvent_t>>> prof_pending;
     std::vector<hipEvent_t> ev_pool;
     void release_all() {
         Buf *bufs[] = {&in_bases, &in_inf, &in_scalars, &prepped, &digits, &heavy, &cnt, &off, &cursor, &bsums, &entries, &bucket, &bucket_inf, &head, &tail, &head_b, &tail_b, &part_inf, &l1, &l1_inf, &win, &win_inf, &ml_lines, &ml_partial, &ml_out};
         for (Buf *b : bufs) b->release();
+        for (Buf &b : q) b.release();
         for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
         ev_pool.clear(); prof_pending.clear();
     }
@@ -64,6 +67,7 @@ struct Ctx {
     std::atomic<unsigned> rr{0};
     std::map<uint64_t, Handle> handles;
     uint64_t next_handle = 1;
+    std::map<int, NttDomain> ntt_domains;
     std::atomic<bool> prof{false};
     std::vector<ProfEntry> prof_tab;
 };

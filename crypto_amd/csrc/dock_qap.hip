@@ -1,0 +1,135 @@
+// crypto_amd/csrc/dock_qap.hip — dgpu_witness_map (include/dock_gpu.h): the R1CS -> QAP witness map on the GPU.
+// Replaces LibsnarkReduction::witness_map_from_matrices (/root/reference/legogroth16/src/r1cs_to_qap.rs:150-210), the step
+// immediately before the prover's h_query MSM (legogroth16/src/prover.rs:281-286).  The result can stay in HBM as a scalars
+// handle and be fed straight to dgpu_msm_g1_resident — no D2H/H2D between the transform and the MSM.
+#include "dock_ctx.hpp"
+#include "host_field.hpp"
+#include "qap_launch.cuh"
+
+namespace {
+using namespace dock;
+using hostf::FrH;
+
+struct Csr { const uint64_t *rowptr; const uint32_t *cols; const uint64_t *vals; size_t nnz; };
+
+int32_t get_domain(Slot &sl, int logn, NttDomain &out) {
+    {
+        std::lock_guard<std::mutex> lk(g.mu);
+        auto it = g.ntt_domains.find(logn);
+        if (it != g.ntt_domains.end()) { out = it->second; return DGPU_OK; }
+    }
+    const size_t D = (size_t)1 << logn, H = D >> 1 ? D >> 1 : 1;
+    FrH w = FrH::root_of_unity(logn), wi = w.inv(), gk = FrH::from_u64(7), gi = gk.inv(), dinv = FrH::from_u64(D).inv(), one = FrH::from_u64(1);
+    FrH gd = gk; for (int k = 0; k < logn; k++) gd = gd * gd;
+    FrH zinv = gd.sub_one().inv();
+    uint64_t consts[7][4];
+    w.to_canonical(consts[0]); wi.to_canonical(consts[1]); gk.to_canonical(consts[2]); gi.to_canonical(consts[3]);
+    dinv.to_canonical(consts[4]); one.to_canonical(consts[5]); zinv.to_canonical(consts[6]);
+    NttDomain d;
+    void *dc = nullptr;
+    const size_t esz = ntt::FR_WORDS * 4;
+    if (hipMalloc(&dc, sizeof consts) != hipSuccess || hipMalloc(&d.tw_f, H * esz) != hipSuccess || hipMalloc(&d.tw_i, H * esz) != hipSuccess ||
+        hipMalloc(&d.pw_f, D * esz) != hipSuccess || hipMalloc(&d.pw_i, D * esz) != hipSuccess || hipMalloc(&d.zinv, 32) != hipSuccess) { (void)hipGetLastError(); return DGPU_E_OOM; }
+    hipStream_t s = sl.stream;
+    HIPCHK(hipMemcpyAsync(dc, consts, sizeof consts, hipMemcpyHostToDevice, s));
+    const uint32_t *c32 = (const uint32_t *)dc;
+    ntt::launch_fr_powers(s, c32 + 0 * 8, c32 + 5 * 8, H, (uint32_t *)d.tw_f);    // w^k
+    ntt::launch_fr_powers(s, c32 + 1 * 8, c32 + 5 * 8, H, (uint32_t *)d.tw_i);    // w^-k
+    ntt::launch_fr_powers(s, c32 + 2 * 8, c32 + 4 * 8, D, (uint32_t *)d.pw_f);    // g^k / D
+    ntt::launch_fr_powers(s, c32 + 3 * 8, c32 + 4 * 8, D, (uint32_t *)d.pw_i);    // g^-k / D
+    HIPCHK(hipMemcpyAsync(d.zinv, consts[6], 32, hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));
+    (void)hipFree(dc);
+    std::lock_guard<std::mutex> lk(g.mu);
+    auto ins = g.ntt_domains.emplace(logn, d);
+    if (!ins.second) { void *ps[] = {d.tw_f, d.tw_i, d.pw_f, d.pw_i, d.zinv}; for (void *p : ps) (void)hipFree(p); }   // another thread won the race
+    out = ins.first->second;
+    return DGPU_OK;
+}
+
+// upload one CSR matrix and evaluate its rows against z: out (SoA, D elements)
+int32_t eval_matrix(Slot &sl, int slot0, const Csr &m, int mont, const uint32_t *z_soa, size_t nvars, size_t rows, size_t extra, uint32_t *out, size_t D) {
+    int32_t rc;
+    Buf &rp = sl.q[slot0], &cl = sl.q[slot0 + 1], &vw = sl.q[slot0 + 2], &vs = sl.q[slot0 + 3];
+    const size_t nnz = m.nnz ? m.nnz : 1;
+    if ((rc = rp.ensure((rows + 1) * 8))) return rc;
+    if ((rc = cl.ensure(nnz * 4))) return rc;
+    if ((rc = vw.ensure(nnz * 32))) return rc;
+    if ((rc = vs.ensure(nnz * ntt::FR_WORDS * 4))) return rc;
+    hipStream_t s = sl.stream;
+    HIPCHK(hipMemcpyAsync(rp.p, m.rowptr, (rows + 1) * 8, hipMemcpyHostToDevice, s));
+    if (m.nnz) { HIPCHK(hipMemcpyAsync(cl.p, m.cols, m.nnz * 4, hipMemcpyHostToDevice, s)); HIPCHK(hipMemcpyAsync(vw.p, m.vals, m.nnz * 32, hipMemcpyHostToDevice, s)); }
+    ntt::launch_fr_load(s, vw.as<uint32_t>(), m.nnz, mont, vs.as<uint32_t>(), nnz);
+    ntt::launch_csr_eval(s, rp.as<uint64_t>(), cl.as<uint32_t>(), vs.as<uint32_t>(), nnz, z_soa, nvars, rows, extra, out, D);
+    return DGPU_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t dgpu_witness_map(const uint64_t *a_rowptr, const uint32_t *a_cols, const uint64_t *a_vals, size_t a_nnz,
+                         const uint64_t *b_rowptr, const uint32_t *b_cols, const uint64_t *b_vals, size_t b_nnz,
+                         const uint64_t *c_rowptr, const uint32_t *c_cols, const uint64_t *c_vals, size_t c_nnz,
+                         const uint64_t *assignment, size_t num_vars, size_t num_inputs, size_t num_constraints, int32_t montgomery,
+                         uint64_t *out_h, uint64_t *out_handle, size_t *out_len) {
+    if (!a_rowptr || !b_rowptr || !c_rowptr || !assignment || num_inputs > num_vars || (!out_h && !out_handle)) return DGPU_E_BADARG;
+    if ((a_nnz && (!a_cols || !a_vals)) || (b_nnz && (!b_cols || !b_vals)) || (c_nnz && (!c_cols || !c_vals))) return DGPU_E_BADARG;
+    int logn = 0; while (((size_t)1 << logn) < num_constraints + num_inputs) logn++;
+    if (logn < 1) logn = 1;
+    if (logn > 28) return DGPU_E_BADARG;
+    const size_t D = (size_t)1 << logn;
+    if (!g.ready) return DGPU_E_NODEVICE;
+    SlotLock slot_lock; Slot &sl = *slot_lock.s;
+    HIPCHK(hipSetDevice(g.device));
+    NttDomain dom; int32_t rc;
+    if ((rc = get_domain(sl, logn, dom))) return rc;
+    const size_t esz = ntt::FR_WORDS * 4;
+    Buf &zw = sl.q[12], &zs = sl.q[13], &qa = sl.q[14], &qb = sl.q[15], &qc = sl.digits, &hw = sl.entries;   // digits/entries: reused scratch
+    if ((rc = zw.ensure(num_vars * 32))) return rc;
+    if ((rc = zs.ensure(num_vars * esz))) return rc;
+    if ((rc = qa.ensure(D * esz))) return rc;
+    if ((rc = qb.ensure(D * esz))) return rc;
+    if ((rc = qc.ensure(D * esz))) return rc;
+    if ((rc = hw.ensure(D * 32))) return rc;
+    hipStream_t s = sl.stream;
+    {
+        StageTimer st(sl, "qap.matvec");
+        HIPCHK(hipMemcpyAsync(zw.p, assignment, num_vars * 32, hipMemcpyHostToDevice, s));
+        ntt::launch_fr_load(s, zw.as<uint32_t>(), num_vars, montgomery, zs.as<uint32_t>(), num_vars);
+        Csr A{a_rowptr, a_cols, a_vals, a_nnz}, B{b_rowptr, b_cols, b_vals, b_nnz}, Cm{c_rowptr, c_cols, c_vals, c_nnz};
+        if ((rc = eval_matrix(sl, 0, A, montgomery, zs.as<uint32_t>(), num_vars, num_constraints, num_inputs, qa.as<uint32_t>(), D))) return rc;
+        if ((rc = eval_matrix(sl, 4, B, montgomery, zs.as<uint32_t>(), num_vars, num_constraints, 0, qb.as<uint32_t>(), D))) return rc;
+        if ((rc = eval_matrix(sl, 8, Cm, montgomery, zs.as<uint32_t>(), num_vars, num_constraints, 0, qc.as<uint32_t>(), D))) return rc;
+    }
+    {
+        StageTimer st(sl, "qap.ntt");
+        uint32_t *arr[3] = {qa.as<uint32_t>(), qb.as<uint32_t>(), qc.as<uint32_t>()};
+        for (int k = 0; k < 3; k++) {
+            ntt::launch_ntt(s, arr[k], logn, (const uint32_t *)dom.tw_i, 1);                       // iFFT (x D), bit-reversed out
+            ntt::launch_coset_scale(s, arr[k], logn, (const uint32_t *)dom.pw_f, nullptr);         // * g^k / D
+            ntt::launch_ntt(s, arr[k], logn, (const uint32_t *)dom.tw_f, 0);                       // coset FFT, natural out
+        }
+        ntt::launch_pointwise(s, arr[0], arr[1], arr[2], D, (const uint32_t *)dom.zinv);           // (ab - c) / Z(g)
+        ntt::launch_ntt(s, arr[0], logn, (const uint32_t *)dom.tw_i, 1);                           // coset iFFT ...
+        ntt::launch_coset_scale(s, arr[0], logn, (const uint32_t *)dom.pw_i, hw.as<uint32_t>());   // ... * g^-k / D, un-reversed, canonical words
+    }
+    HIPCHK(hipGetLastError());
+    if (out_len) *out_len = D;
+    if (out_handle) {
+        void *p = nullptr;
+        if (hipMalloc(&p, D * 32) != hipSuccess) { (void)hipGetLastError(); return DGPU_E_OOM; }
+        HIPCHK(hipMemcpyAsync(p, hw.p, D * 32, hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipStreamSynchronize(s));
+        std::lock_guard<std::mutex> lk(g.mu);
+        uint64_t h = g.next_handle++;
+        g.handles[h] = Handle{p, D, 3};
+        *out_handle = h;
+    }
+    if (out_h) { HIPCHK(hipMemcpyAsync(out_h, hw.p, D * 32, hipMemcpyDeviceToHost, s)); }
+    HIPCHK(hipStreamSynchronize(s));
+    if (g.prof) prof_flush(sl);
+    return DGPU_OK;
+}
+
+}  // extern "C"

@@ -217,4 +217,48 @@ static inline void fr_from_mont(uint64_t out[4], const uint64_t a[4]) {
     for (int i = 0; i < 4; i++) out[i] = t[i];
 }
 
+// ---- Fr on the host (domain constants of the witness map: omega_D, g^D - 1, 1/D) ----
+struct FrH {
+    uint64_t l[4];
+    static constexpr uint64_t MOD[4] = {0xffffffff00000001ULL, 0x53bda402fffe5bfeULL, 0x3339d80809a1d805ULL, 0x73eda753299d7d48ULL};
+    static constexpr uint64_t R2[4] = {0xc999e990f3f29c6dULL, 0x2b6cedcb87925c23ULL, 0x05d314967254398fULL, 0x0748d9d99f59ff11ULL};
+    static constexpr uint64_t INV = 0xfffffffeffffffffULL;
+    static FrH mont_mul(const FrH &a, const FrH &b) {
+        uint64_t t[6] = {0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < 4; i++) {
+            uint64_t c = 0; u128 s;
+            for (int j = 0; j < 4; j++) { s = (u128)a.l[j] * b.l[i] + t[j] + c; t[j] = (uint64_t)s; c = (uint64_t)(s >> 64); }
+            s = (u128)t[4] + c; t[4] = (uint64_t)s; t[5] = (uint64_t)(s >> 64);
+            uint64_t m = t[0] * INV; s = (u128)m * MOD[0] + t[0]; c = (uint64_t)(s >> 64);
+            for (int j = 1; j < 4; j++) { s = (u128)m * MOD[j] + t[j] + c; t[j - 1] = (uint64_t)s; c = (uint64_t)(s >> 64); }
+            s = (u128)t[4] + c; t[3] = (uint64_t)s; t[4] = t[5] + (uint64_t)(s >> 64);
+        }
+        bool ge = t[4] != 0;
+        if (!ge) { ge = true; for (int i = 3; i >= 0; i--) { if (t[i] > MOD[i]) break; if (t[i] < MOD[i]) { ge = false; break; } } }
+        if (ge) { uint64_t br = 0; for (int i = 0; i < 4; i++) { u128 d = (u128)t[i] - MOD[i] - br; t[i] = (uint64_t)d; br = (uint64_t)(d >> 64) & 1; } }
+        FrH r; for (int i = 0; i < 4; i++) r.l[i] = t[i]; return r;
+    }
+    static FrH from_u64(uint64_t v) { FrH a{{v, 0, 0, 0}}, r2; memcpy(r2.l, R2, 32); return mont_mul(a, r2); }   // Montgomery form
+    FrH operator*(const FrH &b) const { return mont_mul(*this, b); }
+    FrH pow(const uint64_t e[4]) const {
+        FrH acc = from_u64(1), base = *this;
+        for (int i = 0; i < 256; i++) { if ((e[i / 64] >> (i % 64)) & 1) acc = acc * base; base = base * base; }
+        return acc;
+    }
+    FrH inv() const { uint64_t e[4] = {MOD[0] - 2, MOD[1], MOD[2], MOD[3]}; return pow(e); }
+    FrH sub_one() const {   // this - 1 (Montgomery)
+        FrH one = from_u64(1), r; uint64_t br = 0;
+        for (int i = 0; i < 4; i++) { u128 d = (u128)l[i] - one.l[i] - br; r.l[i] = (uint64_t)d; br = (uint64_t)(d >> 64) & 1; }
+        if (br) { uint64_t c = 0; for (int i = 0; i < 4; i++) { u128 s = (u128)r.l[i] + MOD[i] + c; r.l[i] = (uint64_t)s; c = (uint64_t)(s >> 64); } }
+        return r;
+    }
+    void to_canonical(uint64_t out[4]) const { FrH one{{1, 0, 0, 0}}; FrH c = mont_mul(*this, one); memcpy(out, c.l, 32); }
+    // 7^((r-1)/2^logn): the radix-2 domain generator ark-poly uses (TWO_ADIC_ROOT_OF_UNITY^(2^(32-logn)))
+    static FrH root_of_unity(int logn) {
+        uint64_t e[4]; memcpy(e, MOD, 32); e[0] -= 1;
+        for (int k = 0; k < logn; k++) { for (int i = 0; i < 3; i++) e[i] = (e[i] >> 1) | (e[i + 1] << 63); e[3] >>= 1; }
+        return from_u64(7).pow(e);
+    }
+};
+
 }  // namespace hostf

@@ -1,0 +1,17 @@
+// crypto_amd/csrc/k_ntt.hip — translation unit of the Fr NTT / witness-map kernels.
+#include "ntt_kernels.cuh"
+#include "qap_launch.cuh"
+namespace ntt {
+static inline dim3 grid_for(size_t n) { return dim3((unsigned)((n + 255) / 256)); }
+void launch_fr_load(hipStream_t s, const uint32_t *words, size_t n, int mont, uint32_t *out, size_t D) { hipLaunchKernelGGL(k_fr_load, grid_for(D), dim3(256), 0, s, words, n, mont, out, D); }
+void launch_fr_powers(hipStream_t s, const uint32_t *bw, const uint32_t *sw, size_t count, uint32_t *out) { hipLaunchKernelGGL(k_fr_powers, grid_for(count), dim3(256), 0, s, bw, sw, count, out); }
+void launch_csr_eval(hipStream_t s, const uint64_t *rowptr, const uint32_t *cols, const uint32_t *vals_soa, size_t nnz, const uint32_t *z_soa, size_t nvars, size_t rows, size_t extra, uint32_t *out, size_t D) {
+    hipLaunchKernelGGL(k_csr_eval, grid_for(D), dim3(256), 0, s, rowptr, cols, vals_soa, nnz, z_soa, nvars, rows, extra, out, D);
+}
+void launch_ntt(hipStream_t s, uint32_t *buf, int logn, const uint32_t *tw, int dif) {
+    const size_t H = ((size_t)1 << logn) >> 1;
+    for (int st = 0; st < logn; st++) hipLaunchKernelGGL(k_ntt_stage, grid_for(H), dim3(256), 0, s, buf, logn, st, tw, dif);
+}
+void launch_coset_scale(hipStream_t s, uint32_t *buf, int logn, const uint32_t *pw, uint32_t *out_words) { hipLaunchKernelGGL(k_coset_scale, grid_for((size_t)1 << logn), dim3(256), 0, s, buf, logn, pw, out_words); }
+void launch_pointwise(hipStream_t s, uint32_t *a, const uint32_t *b, const uint32_t *c, size_t D, const uint32_t *zinv_words) { hipLaunchKernelGGL(k_pointwise, grid_for(D), dim3(256), 0, s, a, b, c, D, zinv_words); }
+}  // namespace ntt

@@ -1,0 +1,104 @@
+// crypto_amd/csrc/ntt_kernels.cuh — radix-2 NTT over Fr and the R1CS -> QAP witness map for gfx950.
+//
+// Device side of LibsnarkReduction::witness_map_from_matrices (/root/reference/legogroth16/src/r1cs_to_qap.rs:150-210,
+// ark-poly Radix2EvaluationDomain semantics):
+//     a_i = <A_i, z>, b_i = <B_i, z>, c_i = <C_i, z>   (i < m),   a_{m+j} = z_j (j < num_inputs)
+//     a, b, c <- iFFT_D ; coset FFT over g H (g = 7) ; ab_i = (a_i b_i - c_i) / (g^D - 1) ; h <- coset iFFT
+// The only HBM-bound piece of the prover.  Layout: limb-major SoA, word l of element i at buf[l * D + i], so
+// every butterfly access is a coalesced row.  Bit reversal is never materialised: inverse transforms run
+// decimation-in-frequency (natural in, bit-reversed out), the coset shift g^k / D is applied at position p with k = bitrev(p),
+// forward transforms run decimation-in-time (bit-reversed in, natural out); the last pass un-reverses while it converts to the
+// canonical 4x64-bit scalars the MSM consumes.
+// v1: one global-memory pass per stage (2 x 40 B per element per stage); fusing 8-10 stages per pass through LDS is the next step.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "fr29.cuh"
+
+namespace ntt {
+using namespace fr29;
+
+__device__ __forceinline__ void ld(Fr &r, const uint32_t *__restrict__ buf, size_t D, size_t i) {
+#pragma unroll
+    for (int l = 0; l < NL; l++) r.l[l] = buf[(size_t)l * D + i];
+}
+__device__ __forceinline__ void st(uint32_t *__restrict__ buf, size_t D, size_t i, const Fr &a) {
+#pragma unroll
+    for (int l = 0; l < NL; l++) buf[(size_t)l * D + i] = a.l[l];
+}
+__device__ __forceinline__ uint32_t bitrev(uint32_t x, int logn) { return __brev(x) >> (32 - logn); }
+
+// words (8 x u32 per element, canonical or Montgomery) -> internal SoA; elements [n, D) are zeroed
+__global__ void __launch_bounds__(256) k_fr_load(const uint32_t *__restrict__ words, size_t n, int mont, uint32_t *__restrict__ out, size_t D) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= D) return;
+    Fr x; fr_zero(x);
+    if (i < n) { uint32_t w[8]; for (int k = 0; k < 8; k++) w[k] = words[i * 8 + k]; fr_from_words(x, w, mont != 0); }
+    st(out, D, i, x);
+}
+// pw[k] = base^k * scale for k < count (square-and-multiply per lane; built once per domain size and cached)
+__global__ void __launch_bounds__(256) k_fr_powers(const uint32_t *__restrict__ base_words, const uint32_t *__restrict__ scale_words, size_t count, uint32_t *__restrict__ out) {
+    size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= count) return;
+    uint32_t bw[8], sw[8];
+    for (int i = 0; i < 8; i++) { bw[i] = base_words[i]; sw[i] = scale_words[i]; }
+    Fr b, acc; fr_from_words(b, bw, false); fr_from_words(acc, sw, false);
+    for (size_t e = k; e; e >>= 1) { if (e & 1) fr_mul(acc, acc, b); fr_mul(b, b, b); }
+    st(out, count, k, acc);
+}
+// sparse rows: out[i] = sum_k vals[k] * z[cols[k]] over row i (i < rows); out[rows + j] = z[j] for j < extra (matrix A only)
+__global__ void __launch_bounds__(256) k_csr_eval(const uint64_t *__restrict__ rowptr, const uint32_t *__restrict__ cols, const uint32_t *__restrict__ vals_soa, size_t nnz,
+                                                  const uint32_t *__restrict__ z_soa, size_t nvars, size_t rows, size_t extra, uint32_t *__restrict__ out, size_t D) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= D) return;
+    Fr acc; fr_zero(acc);
+    if (i < rows) {
+        for (uint64_t k = rowptr[i]; k < rowptr[i + 1]; k++) {
+            Fr c, zz, t; ld(c, vals_soa, nnz, k); ld(zz, z_soa, nvars, cols[k]);
+            fr_mul(t, zz, c); fr_add(acc, acc, t); fr_norm(acc, acc);
+        }
+    } else if (i < rows + extra) ld(acc, z_soa, nvars, i - rows);
+    st(out, D, i, acc);
+}
+// one radix-2 stage over the whole array.  dif != 0: (x, y) -> (x + y, (x - y) w^(j << s)), half = D >> (s+1)
+//                                          dif == 0: (x, y) -> (x + y w, x - y w),       half = 1 << s, w^(j << (logn-1-s))
+__global__ void __launch_bounds__(256) k_ntt_stage(uint32_t *__restrict__ buf, int logn, int s, const uint32_t *__restrict__ tw, int dif) {
+    const size_t D = (size_t)1 << logn, H = D >> 1;
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= H) return;
+    const size_t half = dif ? (D >> (s + 1)) : ((size_t)1 << s);
+    const size_t j = t & (half - 1), i0 = ((t - j) << 1) + j, i1 = i0 + half;
+    const size_t e = dif ? (j << s) : (j << (logn - 1 - s));
+    Fr x, y, w, u, v; ld(x, buf, D, i0); ld(y, buf, D, i1); ld(w, tw, H, e);
+    if (dif) {
+        fr_add(u, x, y); fr_norm(u, u);
+        fr_sub<FR_BIG>(v, x, y); fr_norm(v, v); fr_mul(v, v, w);     // y may carry up to 2^21 r
+    } else {
+        Fr yw; fr_mul(yw, y, w);
+        fr_add(u, x, yw); fr_norm(u, u);
+        fr_sub(v, x, yw); fr_norm(v, v);
+    }
+    st(buf, D, i0, u); st(buf, D, i1, v);
+}
+// element at position p (bit-reversed order, coefficient k = bitrev(p)) *= pw[k]; optionally written out un-reversed as
+// canonical words (h coefficients for the MSM)
+__global__ void __launch_bounds__(256) k_coset_scale(uint32_t *__restrict__ buf, int logn, const uint32_t *__restrict__ pw, uint32_t *__restrict__ out_words) {
+    const size_t D = (size_t)1 << logn;
+    size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= D) return;
+    size_t k = bitrev((uint32_t)p, logn);
+    Fr x, g; ld(x, buf, D, p); ld(g, pw, D, k);
+    fr_mul(x, x, g);
+    if (out_words) { uint32_t w[8]; fr_to_words(w, x, false); for (int i = 0; i < 8; i++) out_words[k * 8 + i] = w[i]; }
+    else st(buf, D, p, x);
+}
+// a_i <- (a_i b_i - c_i) * zinv
+__global__ void __launch_bounds__(256) k_pointwise(uint32_t *__restrict__ a, const uint32_t *__restrict__ b, const uint32_t *__restrict__ c, size_t D, const uint32_t *__restrict__ zinv_words) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= D) return;
+    uint32_t zw[8]; for (int k = 0; k < 8; k++) zw[k] = zinv_words[k];
+    Fr x, y, z, zi, t; ld(x, a, D, i); ld(y, b, D, i); ld(z, c, D, i); fr_from_words(zi, zw, false);
+    fr_mul(t, x, y); fr_sub<FR_BIG>(t, t, z); fr_norm(t, t); fr_mul(t, t, zi);   // z is an un-reduced transform output
+    st(a, D, i, t);
+}
+
+}  // namespace ntt

@@ -101,6 +101,19 @@ int32_t dgpu_g1_scale_batch(const uint64_t *p_xy /* n*12 */, const uint8_t *is_i
 int32_t dgpu_fp12_mul(const uint64_t a[72], const uint64_t b[72], uint64_t out[72]);
 int32_t dgpu_fp12_pow(const uint64_t a[72], const uint64_t e[4], uint64_t out[72]);
 
+/* ---- R1CS -> QAP witness map ----
+ * replaces LibsnarkReduction::witness_map_from_matrices (legogroth16/src/r1cs_to_qap.rs:150-210): h = ((A z)(B z) - C z) / Z_D as the
+ * D = next_pow2(num_constraints + num_inputs) coefficients the prover pairs with h_query (legogroth16/src/prover.rs:281-286).
+ * Matrices in CSR (rowptr[num_constraints + 1], cols[nnz], vals[nnz * 4]); assignment = (1, instance..., witness...), num_vars values.
+ * montgomery != 0: coefficients and assignment are ark-ff Fr limbs (R = 2^256), else canonical.  The result is always canonical
+ * (what `into_bigint` yields, prover.rs:281-283): copied to out_h (D * 4 limbs) and/or left in HBM as a scalars handle that
+ * dgpu_msm_g1_resident consumes directly.  *out_len = D. */
+int32_t dgpu_witness_map(const uint64_t *a_rowptr, const uint32_t *a_cols, const uint64_t *a_vals, size_t a_nnz,
+                         const uint64_t *b_rowptr, const uint32_t *b_cols, const uint64_t *b_vals, size_t b_nnz,
+                         const uint64_t *c_rowptr, const uint32_t *c_cols, const uint64_t *c_vals, size_t c_nnz,
+                         const uint64_t *assignment, size_t num_vars, size_t num_inputs, size_t num_constraints, int32_t montgomery,
+                         uint64_t *out_h, uint64_t *out_handle, size_t *out_len);
+
 /* ---- instrumentation (bench.py / rocprof cross-check) ----
  * When enabled, every stage of the next calls is bracketed by HIP events on the library's own stream. */
 int32_t dgpu_prof_enable(int32_t on);

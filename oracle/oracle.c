@@ -302,6 +302,96 @@ static void gen_seq(int g2, const uint64_t k0[4], const uint64_t d[4], size_t n,
 API void orc_g1_gen_seq(const uint64_t k0[4], const uint64_t d[4], size_t n, int threads, uint64_t *out_xy) { gen_seq(0, k0, d, n, threads, out_xy); }
 API void orc_g2_gen_seq(const uint64_t k0[4], const uint64_t d[4], size_t n, int threads, uint64_t *out_xy) { gen_seq(1, k0, d, n, threads, out_xy); }
 
+
+/* ---------------- R1CS -> QAP witness map (reference legogroth16/src/r1cs_to_qap.rs:150-210) ----------------
+ * ark-poly Radix2EvaluationDomain semantics restated: omega_D = 7^((r-1)/D), coset generator g = Fr::GENERATOR = 7.
+ * All Fr values below are in Montgomery form (R = 2^256) internally; the API takes / returns canonical limbs. */
+typedef struct { uint64_t l[4]; } fr;
+static const fr FR_ONE_M = {{0x00000001fffffffeULL, 0x5884b7fa00034802ULL, 0x998c4fefecbc4ff5ULL, 0x1824b159acc5056fULL}};
+static void fr_mul(fr *r, const fr *a, const fr *b) { fr_mont_mul(r->l, a->l, b->l); }
+static void fr_add(fr *r, const fr *a, const fr *b) { fr_add_mod(r->l, a->l, b->l); }
+static void fr_sub(fr *r, const fr *a, const fr *b) {
+    uint64_t br = 0, t[4];
+    for (int i = 0; i < 4; i++) { u128 d = (u128)a->l[i] - b->l[i] - br; t[i] = (uint64_t)d; br = (uint64_t)(d >> 64) & 1; }
+    if (br) { uint64_t c = 0; for (int i = 0; i < 4; i++) { u128 s2 = (u128)t[i] + FR_MOD[i] + c; t[i] = (uint64_t)s2; c = (uint64_t)(s2 >> 64); } }
+    memcpy(r->l, t, 32);
+}
+static void fr_pow(fr *r, const fr *a, const uint64_t *e, int nl) {
+    fr acc = FR_ONE_M, base = *a;
+    for (int i = 0; i < nl * 64; i++) { if ((e[i / 64] >> (i % 64)) & 1) fr_mul(&acc, &acc, &base); fr_mul(&base, &base, &base); }
+    *r = acc;
+}
+static void fr_inv(fr *r, const fr *a) { uint64_t e[4] = {FR_MOD[0] - 2, FR_MOD[1], FR_MOD[2], FR_MOD[3]}; fr_pow(r, a, e, 4); }
+static void fr_from_u64(fr *r, uint64_t v) { uint64_t t[4] = {v, 0, 0, 0}; fr_mont_mul(r->l, t, FR_R2); }
+static void fr_root_of_unity(fr *w, int logn) {   /* 7^((r-1)/2^logn) */
+    fr g; fr_from_u64(&g, 7);
+    uint64_t e[4]; memcpy(e, FR_MOD, 32); e[0] -= 1;              /* r - 1 */
+    for (int k = 0; k < logn; k++) { for (int i = 0; i < 3; i++) e[i] = (e[i] >> 1) | (e[i + 1] << 63); e[3] >>= 1; }
+    fr_pow(w, &g, e, 4);
+}
+/* in-place radix-2 transform of a[0..n), natural order in and out; inverse divides by n */
+static void fr_ntt(fr *a, int logn, int inverse) {
+    size_t n = (size_t)1 << logn;
+    for (size_t i = 0; i < n; i++) { size_t j = 0; for (int b = 0; b < logn; b++) if (i >> b & 1) j |= (size_t)1 << (logn - 1 - b); if (i < j) { fr t = a[i]; a[i] = a[j]; a[j] = t; } }
+    fr w; fr_root_of_unity(&w, logn); if (inverse) fr_inv(&w, &w);
+    for (int s = 1; s <= logn; s++) {
+        size_t m = (size_t)1 << s, half = m >> 1;
+        fr wm = w; for (int k = s; k < logn; k++) fr_mul(&wm, &wm, &wm);
+        for (size_t k = 0; k < n; k += m) {
+            fr tw = FR_ONE_M;
+            for (size_t j = 0; j < half; j++) { fr t, u = a[k + j]; fr_mul(&t, &tw, &a[k + j + half]); fr_add(&a[k + j], &u, &t); fr_sub(&a[k + j + half], &u, &t); fr_mul(&tw, &tw, &wm); }
+        }
+    }
+    if (inverse) { fr ninv; fr_from_u64(&ninv, n); fr_inv(&ninv, &ninv); for (size_t i = 0; i < n; i++) fr_mul(&a[i], &a[i], &ninv); }
+}
+static void fr_coset_scale(fr *a, size_t n, const fr *g) { fr p = FR_ONE_M; for (size_t i = 0; i < n; i++) { fr_mul(&a[i], &a[i], &p); fr_mul(&p, &p, g); } }
+API void orc_fr_ntt(uint64_t *vals /* n*4 canonical */, int logn, int inverse, int coset) {
+    size_t n = (size_t)1 << logn; fr *a = (fr *)malloc(sizeof(fr) * n);
+    for (size_t i = 0; i < n; i++) fr_mont_mul(a[i].l, vals + 4 * i, FR_R2);
+    fr g; fr_from_u64(&g, 7);
+    if (coset && !inverse) fr_coset_scale(a, n, &g);
+    fr_ntt(a, logn, inverse);
+    if (coset && inverse) { fr gi; fr_inv(&gi, &g); fr_coset_scale(a, n, &gi); }
+    uint64_t one[4] = {1, 0, 0, 0};
+    for (size_t i = 0; i < n; i++) fr_mont_mul(vals + 4 * i, a[i].l, one);
+    free(a);
+}
+/* LibsnarkReduction::witness_map_from_matrices.  Matrices in CSR: rowptr[num_constraints+1], cols[], vals[] (canonical).
+ * z = full assignment (canonical, num_inputs instance values first, z[0] = 1).  out_h: D canonical coefficients. */
+static void csr_eval(fr *out, const uint64_t *rowptr, const uint32_t *cols, const uint64_t *vals, size_t rows, const fr *z) {
+    for (size_t i = 0; i < rows; i++) {
+        fr acc; memset(&acc, 0, sizeof acc);
+        for (uint64_t k = rowptr[i]; k < rowptr[i + 1]; k++) { fr c, t; fr_mont_mul(c.l, vals + 4 * k, FR_R2); fr_mul(&t, &c, &z[cols[k]]); fr_add(&acc, &acc, &t); }
+        out[i] = acc;
+    }
+}
+API int orc_witness_map(const uint64_t *a_rowptr, const uint32_t *a_cols, const uint64_t *a_vals,
+                        const uint64_t *b_rowptr, const uint32_t *b_cols, const uint64_t *b_vals,
+                        const uint64_t *c_rowptr, const uint32_t *c_cols, const uint64_t *c_vals,
+                        const uint64_t *z_canon, size_t num_vars, size_t num_inputs, size_t num_constraints, uint64_t *out_h) {
+    int logn = 0; while (((size_t)1 << logn) < num_constraints + num_inputs) logn++;
+    size_t D = (size_t)1 << logn;
+    fr *z = (fr *)malloc(sizeof(fr) * num_vars), *a = (fr *)calloc(D, sizeof(fr)), *b = (fr *)calloc(D, sizeof(fr)), *c = (fr *)calloc(D, sizeof(fr));
+    for (size_t i = 0; i < num_vars; i++) fr_mont_mul(z[i].l, z_canon + 4 * i, FR_R2);
+    csr_eval(a, a_rowptr, a_cols, a_vals, num_constraints, z);
+    csr_eval(b, b_rowptr, b_cols, b_vals, num_constraints, z);
+    csr_eval(c, c_rowptr, c_cols, c_vals, num_constraints, z);
+    for (size_t j = 0; j < num_inputs; j++) a[num_constraints + j] = z[j];
+    fr g; fr_from_u64(&g, 7);
+    fr *arr[3] = {a, b, c};
+    for (int k = 0; k < 3; k++) { fr_ntt(arr[k], logn, 1); fr_coset_scale(arr[k], D, &g); fr_ntt(arr[k], logn, 0); }
+    /* 1 / Z(g) = 1 / (g^D - 1) */
+    fr gd = g; for (int k = 0; k < logn; k++) fr_mul(&gd, &gd, &gd);
+    fr zi; fr_sub(&zi, &gd, &FR_ONE_M); fr_inv(&zi, &zi);
+    for (size_t i = 0; i < D; i++) { fr t; fr_mul(&t, &a[i], &b[i]); fr_sub(&t, &t, &c[i]); fr_mul(&a[i], &t, &zi); }
+    fr_ntt(a, logn, 1);
+    fr gi; fr_inv(&gi, &g); fr_coset_scale(a, D, &gi);
+    uint64_t one[4] = {1, 0, 0, 0};
+    for (size_t i = 0; i < D; i++) fr_mont_mul(out_h + 4 * i, a[i].l, one);
+    free(z); free(a); free(b); free(c);
+    return logn;
+}
+
 /* ---- pairings ---- */
 API void orc_g2_prepare(const uint64_t q[24], uint64_t *out /* 68*36 u64 */) { g2_prepare((const g2_aff *)q, (ell_coeff *)out); }
 API void orc_fp12_mul(const uint64_t a[72], const uint64_t b[72], uint64_t out[72]) { fp12 r; fp12_mul(&r, (const fp12 *)a, (const fp12 *)b); memcpy(out, &r, sizeof r); }

@@ -6,6 +6,7 @@
 #include "../../crypto_amd/csrc/ec29.cuh"
 #include "../../crypto_amd/csrc/pairing29.cuh"
 #include "../../crypto_amd/csrc/host_field.hpp"
+#include "../../crypto_amd/csrc/fr29.cuh"
 #include <vector>
 #include <string.h>
 using namespace bls29;
@@ -119,5 +120,14 @@ void shim_multi_miller(const uint32_t *ps, const uint32_t *qs, int n, uint32_t *
     for (int i = 62; i >= 0; i--) { f = f.sqr() * L[idx++]; if ((BLS_X_ABS >> i) & 1) f = f * L[idx++]; }
     f = f.conj();
     memcpy(out, &f, 576);
+}
+
+// ---- Fr (scalar field, NTT path) ----
+void shim_fr_mul(const uint32_t *a, const uint32_t *b, int mont, uint32_t *out) { fr29::Fr x, y, r; fr29::fr_from_words(x, a, mont); fr29::fr_from_words(y, b, mont); fr29::fr_mul(r, x, y); fr29::fr_to_words(out, r, mont); }
+// a chain of butterflies exercising lazy add / sub / norm:  (x, y) -> (x + w y, x - w y) repeated `reps` times
+void shim_fr_butterflies(const uint32_t *a, const uint32_t *b, const uint32_t *w, int reps, uint32_t *out_x, uint32_t *out_y) {
+    fr29::Fr x, y, tw, t, u, v; fr29::fr_from_words(x, a, 0); fr29::fr_from_words(y, b, 0); fr29::fr_from_words(tw, w, 0);
+    for (int i = 0; i < reps; i++) { fr29::fr_mul(t, y, tw); fr29::fr_add(u, x, t); fr29::fr_sub(v, x, t); fr29::fr_norm(x, u); fr29::fr_norm(y, v); }
+    fr29::fr_to_words(out_x, x, 0); fr29::fr_to_words(out_y, y, 0);
 }
 }

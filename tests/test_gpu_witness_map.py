@@ -1,0 +1,74 @@
+"""GPU (-m gpu): the R1CS -> QAP witness map through the C ABI vs the CPU oracle's restatement of
+r1cs_to_qap.rs:150-210 (oracle/oracle.c orc_witness_map, itself pinned against naive big-integer polynomial
+arithmetic in tests/test_oracle_golden.py), bit-exact on the canonical coefficients; the HBM-resident result feeds
+the h_query MSM without leaving the device; and the full prove -> verify round trip with h computed on the GPU."""
+import ctypes as C
+import numpy as np
+import pytest
+import torch
+import oracle_c as O
+import util as U
+import lego_setup as LS
+import crypto_amd as ca
+from crypto_amd import qap, legogroth16 as LG
+
+pytestmark = pytest.mark.gpu
+R = LS.R
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _device():
+    assert torch.cuda.is_available()
+    ca.init(0)
+
+
+def oracle_map(cs, mats):
+    L = O.lib(); L.orc_witness_map.restype = C.c_int
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    D = 1
+    while D < cs["n_cons"] + cs["n_inst"]:
+        D *= 2
+    out = np.zeros((D, 4), np.uint64)
+    z = LS.scalars(cs["z"])
+    args = []
+    for rp, cl, vl in mats:
+        args += [p(rp), p(cl), p(vl)]
+    L.orc_witness_map(*args, p(z), C.c_size_t(len(cs["z"])), C.c_size_t(cs["n_inst"]), C.c_size_t(cs["n_cons"]), p(out))
+    return out
+
+
+@pytest.mark.parametrize("m", [1, 5, 40, 1000, (1 << 14) - 3, 40000])
+def test_witness_map_vs_oracle(m):
+    cs = LS.circuit(m, x0=3)
+    mats = [qap.csr(cs[k]) for k in "ABC"]
+    z = LS.scalars(cs["z"])
+    ref = oracle_map(cs, mats)
+    h, _ = qap.witness_map(*mats, z, cs["n_inst"], cs["n_cons"])
+    assert h.shape == ref.shape and (h == ref).all()
+    assert not h[-1].any()                     # deg h <= D - 2: the prover pairs h[..D-1] with h_query (prover.rs:286)
+    if m == 40:
+        assert [O.limbs_to_int(x) for x in h] == LS.witness_map(cs)       # and the naive big-integer version
+    # Montgomery inputs (what the reference holds in memory) give the same canonical output
+    matsm = [(rp, cl, O.fr_to_mont(vl)) for rp, cl, vl in mats]
+    hm, _ = qap.witness_map(*matsm, O.fr_to_mont(z), cs["n_inst"], cs["n_cons"], montgomery=True)
+    assert (hm == ref).all()
+
+
+def test_resident_h_feeds_the_msm_and_the_proof_verifies():
+    m, cw = 300, 2
+    cs = LS.circuit(m, x0=9)
+    key = LS.setup(cs, cw, seed=5)
+    mats = [qap.csr(cs[k]) for k in "ABC"]
+    z = LS.scalars(cs["z"])
+    h, dh = qap.witness_map(*mats, z, cs["n_inst"], cs["n_cons"], resident=True)
+    vk = LG.VerifyingKey(key["alpha_g1"], key["beta_g2"], key["gamma_g2"], key["delta_g2"], key["gamma_abc_g1"], key["eta_gamma_inv_g1"], cw)
+    pk = LG.ProvingKey(vk, key["beta_g1"], key["delta_g1"], key["eta_delta_inv_g1"], key["a_query"], key["b_g1_query"], key["b_g2_query"], key["h_query"], key["l_query"])
+    # h_acc straight from HBM == h_acc from host scalars (truncation to D - 1 terms, prover.rs:286)
+    acc_res = pk.h_query.msm_resident(dh)
+    assert (acc_res == pk.h_query.msm_bigint(h)).all()
+    inp, wit = z[:cs["n_inst"]], z[cs["n_inst"]:]
+    proof = LG.create_proof(pk, 12345, 67890, 424242, h, inp, wit)
+    pvk = LG.prepare_verifying_key(vk)
+    assert LG.verify_proof(pvk, proof, inp[1:])
+    h_bad = h.copy(); h_bad[3][0] ^= np.uint64(1)
+    assert not LG.verify_proof(pvk, LG.create_proof(pk, 12345, 67890, 424242, h_bad, inp, wit), inp[1:])

@@ -91,3 +91,38 @@ def test_pairing_identities():
     assert O.final_exponentiation(np.zeros(72, np.uint64)) is None
     with pytest.raises(AssertionError):
         O.multi_miller_loop(ps[:2], qs[:3])
+
+
+def test_oracle_ntt_and_witness_map_vs_naive_bigint():
+    """pins oracle.c's restatement of ark-poly's radix-2 domain and of r1cs_to_qap.rs:150-210 against plain big-integer
+    DFT sums and polynomial division (tests/lego_setup.py)"""
+    import ctypes as C
+    import random
+    import lego_setup as LS
+    L = O.lib(); L.orc_witness_map.restype = C.c_int
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    R = LS.R
+    random.seed(1)
+    for logn in (1, 3, 6):
+        n = 1 << logn
+        v = [random.randrange(R) for _ in range(n)]
+        om = pow(7, (R - 1) // n, R)
+        arr = LS.scalars(v).copy(); L.orc_fr_ntt(p(arr), logn, 0, 0)
+        assert [O.limbs_to_int(x) for x in arr] == [sum(v[i] * pow(om, i * k, R) for i in range(n)) % R for k in range(n)]
+        L.orc_fr_ntt(p(arr), logn, 1, 0); assert [O.limbs_to_int(x) for x in arr] == v
+        arr = LS.scalars(v).copy(); L.orc_fr_ntt(p(arr), logn, 0, 1)       # coset g = 7
+        assert [O.limbs_to_int(x) for x in arr] == [sum(v[i] * pow(7 * pow(om, k, R) % R, i, R) for i in range(n)) % R for k in range(n)]
+        L.orc_fr_ntt(p(arr), logn, 1, 1); assert [O.limbs_to_int(x) for x in arr] == v
+    from crypto_amd.qap import csr
+    for m in (1, 7, 40):
+        cs = LS.circuit(m, 7)
+        mats = [csr(cs[k]) for k in "ABC"]
+        D = 1
+        while D < cs["n_cons"] + cs["n_inst"]:
+            D *= 2
+        out = np.zeros((D, 4), np.uint64)
+        args = []
+        for rp, cl, vl in mats:
+            args += [p(rp), p(cl), p(vl)]
+        L.orc_witness_map(*args, p(LS.scalars(cs["z"])), C.c_size_t(len(cs["z"])), C.c_size_t(cs["n_inst"]), C.c_size_t(cs["n_cons"]), p(out))
+        assert [O.limbs_to_int(x) for x in out] == LS.witness_map(cs)

@@ -68,3 +68,23 @@ if "conc" in what:
         for t in ths: t.join()
         dt = time.time() - t0
         print("G1 2^20 x%d in flight: %.3f ms per MSM (%.1f MSM/s)" % (nthr, dt / (K // nthr * nthr) * 1e3, (K // nthr * nthr) / dt), flush=True)
+if "qap" in what:
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import lego_setup as LS
+    from crypto_amd import qap
+    for lg in [int(x) for x in os.environ.get("QAP_LOGS", "16,20").split(",")]:
+        m = (1 << lg) - 3
+        t0 = time.time()
+        # nconstraints-shaped circuit built directly as arrays (python big ints would take minutes at 2^20)
+        xs = np.zeros((m + 1, 4), np.uint64); xs[:, 0] = np.arange(1, m + 2, dtype=np.uint64)     # synthetic assignment (timing only)
+        z = np.concatenate([LS.scalars([1, 5]), xs])
+        idx = np.arange(m, dtype=np.uint32)
+        one = np.zeros((1, 4), np.uint64); one[0, 0] = 1
+        a_rp = np.arange(m + 2, dtype=np.uint64); a_cl = np.concatenate([2 + idx, [2 + m]]).astype(np.uint32); a_vl = np.repeat(one, m + 1, 0)
+        b_rp = a_rp; b_cl = np.concatenate([2 + idx, [0]]).astype(np.uint32); b_vl = a_vl
+        c_rp = np.concatenate([2 * np.arange(m + 1, dtype=np.uint64), [2 * m + 1]]).astype(np.uint64)
+        c_cl = np.concatenate([np.stack([3 + idx, np.zeros(m, np.uint32)], 1).reshape(-1), [1]]).astype(np.uint32)
+        c_vl = np.repeat(one, 2 * m + 1, 0)
+        mats = [(a_rp, a_cl, a_vl), (b_rp, b_cl, b_vl), (c_rp, c_cl, c_vl)]
+        dt, s = stages(lambda: qap.witness_map(*mats, z, 2, m + 1, to_host=False, resident=False) if False else qap.witness_map(*mats, z, 2, m + 1), K=3)
+        print("witness map m=2^%d-2 (D=2^%d): %.2f ms | %s" % (lg, lg, dt * 1e3, s), flush=True)

@@ -73,7 +73,7 @@ int32_t dgpu_shutdown(void) {
         (void)hipStreamDestroy(g.slots[i].stream);
         g.slots[i].stream = nullptr;
     }
-    for (auto &h : g.handles) (void)hipFree(h.second.p);
+    for (auto &h : g.handles) if (h.second.kind != 4) (void)hipFree(h.second.p);   // (R1CS handles own several allocations: freed by dgpu_r1cs_free)
     g.handles.clear();
     for (auto &d : g.ntt_domains) { void *ps[] = {d.second.tw_f, d.second.tw_i, d.second.pw_f, d.second.pw_i, d.second.zinv}; for (void *p : ps) if (p) (void)hipFree(p); }
     g.ntt_domains.clear();
@@ -103,7 +103,7 @@ int32_t dgpu_set_window_bits(int32_t c) { if (c != 0 && (c < 7 || c > 22)) retur
 static int32_t free_handle(uint64_t h, bool scalars) {
     std::lock_guard<std::mutex> lk(g.mu);
     auto it = g.handles.find(h);
-    if (it == g.handles.end() || ((it->second.kind == 3) != scalars)) return DGPU_E_BADARG;
+    if (it == g.handles.end() || it->second.kind == 4 || ((it->second.kind == 3) != scalars)) return DGPU_E_BADARG;
     if (g.ready) { (void)hipSetDevice(g.device); (void)hipDeviceSynchronize(); }
     (void)hipFree(it->second.p);
     g.handles.erase(it);

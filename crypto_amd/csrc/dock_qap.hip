@@ -47,64 +47,56 @@ int32_t get_domain(Slot &sl, int logn, NttDomain &out) {
     return DGPU_OK;
 }
 
-// upload one CSR matrix and evaluate its rows against z: out (SoA, D elements)
-int32_t eval_matrix(Slot &sl, int slot0, const Csr &m, int mont, const uint32_t *z_soa, size_t nvars, size_t rows, size_t extra, uint32_t *out, size_t D) {
-    int32_t rc;
-    Buf &rp = sl.q[slot0], &cl = sl.q[slot0 + 1], &vw = sl.q[slot0 + 2], &vs = sl.q[slot0 + 3];
+// device-resident R1CS (three CSR matrices, coefficients already in the internal Fr form): uploaded once per circuit
+struct DevCsr { uint64_t *rowptr = nullptr; uint32_t *cols = nullptr; uint32_t *vals = nullptr; size_t nnz = 0; };
+struct DevR1cs { DevCsr m[3]; size_t num_vars = 0, num_inputs = 0, num_constraints = 0; };
+
+void free_r1cs(DevR1cs *r) {
+    if (!r) return;
+    for (auto &c : r->m) { if (c.rowptr) (void)hipFree(c.rowptr); if (c.cols) (void)hipFree(c.cols); if (c.vals) (void)hipFree(c.vals); }
+    delete r;
+}
+int32_t upload_matrix(Slot &sl, const Csr &m, size_t rows, int mont, DevCsr &out) {
     const size_t nnz = m.nnz ? m.nnz : 1;
-    if ((rc = rp.ensure((rows + 1) * 8))) return rc;
-    if ((rc = cl.ensure(nnz * 4))) return rc;
-    if ((rc = vw.ensure(nnz * 32))) return rc;
-    if ((rc = vs.ensure(nnz * ntt::FR_WORDS * 4))) return rc;
+    int32_t rc;
+    if ((rc = sl.q[0].ensure(nnz * 32))) return rc;
+    if (hipMalloc((void **)&out.rowptr, (rows + 1) * 8) != hipSuccess || hipMalloc((void **)&out.cols, nnz * 4) != hipSuccess ||
+        hipMalloc((void **)&out.vals, nnz * ntt::FR_WORDS * 4) != hipSuccess) { (void)hipGetLastError(); return DGPU_E_OOM; }
+    out.nnz = nnz;
     hipStream_t s = sl.stream;
-    HIPCHK(hipMemcpyAsync(rp.p, m.rowptr, (rows + 1) * 8, hipMemcpyHostToDevice, s));
-    if (m.nnz) { HIPCHK(hipMemcpyAsync(cl.p, m.cols, m.nnz * 4, hipMemcpyHostToDevice, s)); HIPCHK(hipMemcpyAsync(vw.p, m.vals, m.nnz * 32, hipMemcpyHostToDevice, s)); }
-    ntt::launch_fr_load(s, vw.as<uint32_t>(), m.nnz, mont, vs.as<uint32_t>(), nnz);
-    ntt::launch_csr_eval(s, rp.as<uint64_t>(), cl.as<uint32_t>(), vs.as<uint32_t>(), nnz, z_soa, nvars, rows, extra, out, D);
+    HIPCHK(hipMemcpyAsync(out.rowptr, m.rowptr, (rows + 1) * 8, hipMemcpyHostToDevice, s));
+    if (m.nnz) { HIPCHK(hipMemcpyAsync(out.cols, m.cols, m.nnz * 4, hipMemcpyHostToDevice, s)); HIPCHK(hipMemcpyAsync(sl.q[0].p, m.vals, m.nnz * 32, hipMemcpyHostToDevice, s)); }
+    ntt::launch_fr_load(s, sl.q[0].as<uint32_t>(), m.nnz, mont, out.vals, nnz);
+    HIPCHK(hipStreamSynchronize(s));     // q[0] is reused by the next matrix
     return DGPU_OK;
 }
 
-}  // namespace
-
-extern "C" {
-
-int32_t dgpu_witness_map(const uint64_t *a_rowptr, const uint32_t *a_cols, const uint64_t *a_vals, size_t a_nnz,
-                         const uint64_t *b_rowptr, const uint32_t *b_cols, const uint64_t *b_vals, size_t b_nnz,
-                         const uint64_t *c_rowptr, const uint32_t *c_cols, const uint64_t *c_vals, size_t c_nnz,
-                         const uint64_t *assignment, size_t num_vars, size_t num_inputs, size_t num_constraints, int32_t montgomery,
-                         uint64_t *out_h, uint64_t *out_handle, size_t *out_len) {
-    if (!a_rowptr || !b_rowptr || !c_rowptr || !assignment || num_inputs > num_vars || (!out_h && !out_handle)) return DGPU_E_BADARG;
-    if ((a_nnz && (!a_cols || !a_vals)) || (b_nnz && (!b_cols || !b_vals)) || (c_nnz && (!c_cols || !c_vals))) return DGPU_E_BADARG;
-    int logn = 0; while (((size_t)1 << logn) < num_constraints + num_inputs) logn++;
+int32_t witness_map_device(Slot &sl, const DevR1cs &r, const uint64_t *assignment, int32_t montgomery, uint64_t *out_h, uint64_t *out_handle, size_t *out_len) {
+    int logn = 0; while (((size_t)1 << logn) < r.num_constraints + r.num_inputs) logn++;
     if (logn < 1) logn = 1;
     if (logn > 28) return DGPU_E_BADARG;
     const size_t D = (size_t)1 << logn;
-    if (!g.ready) return DGPU_E_NODEVICE;
-    SlotLock slot_lock; Slot &sl = *slot_lock.s;
-    HIPCHK(hipSetDevice(g.device));
     NttDomain dom; int32_t rc;
     if ((rc = get_domain(sl, logn, dom))) return rc;
     const size_t esz = ntt::FR_WORDS * 4;
     Buf &zw = sl.q[12], &zs = sl.q[13], &qa = sl.q[14], &qb = sl.q[15], &qc = sl.digits, &hw = sl.entries;   // digits/entries: reused scratch
-    if ((rc = zw.ensure(num_vars * 32))) return rc;
-    if ((rc = zs.ensure(num_vars * esz))) return rc;
+    if ((rc = zw.ensure(r.num_vars * 32))) return rc;
+    if ((rc = zs.ensure(r.num_vars * esz))) return rc;
     if ((rc = qa.ensure(D * esz))) return rc;
     if ((rc = qb.ensure(D * esz))) return rc;
     if ((rc = qc.ensure(D * esz))) return rc;
     if ((rc = hw.ensure(D * 32))) return rc;
     hipStream_t s = sl.stream;
+    uint32_t *arr[3] = {qa.as<uint32_t>(), qb.as<uint32_t>(), qc.as<uint32_t>()};
     {
         StageTimer st(sl, "qap.matvec");
-        HIPCHK(hipMemcpyAsync(zw.p, assignment, num_vars * 32, hipMemcpyHostToDevice, s));
-        ntt::launch_fr_load(s, zw.as<uint32_t>(), num_vars, montgomery, zs.as<uint32_t>(), num_vars);
-        Csr A{a_rowptr, a_cols, a_vals, a_nnz}, B{b_rowptr, b_cols, b_vals, b_nnz}, Cm{c_rowptr, c_cols, c_vals, c_nnz};
-        if ((rc = eval_matrix(sl, 0, A, montgomery, zs.as<uint32_t>(), num_vars, num_constraints, num_inputs, qa.as<uint32_t>(), D))) return rc;
-        if ((rc = eval_matrix(sl, 4, B, montgomery, zs.as<uint32_t>(), num_vars, num_constraints, 0, qb.as<uint32_t>(), D))) return rc;
-        if ((rc = eval_matrix(sl, 8, Cm, montgomery, zs.as<uint32_t>(), num_vars, num_constraints, 0, qc.as<uint32_t>(), D))) return rc;
+        HIPCHK(hipMemcpyAsync(zw.p, assignment, r.num_vars * 32, hipMemcpyHostToDevice, s));
+        ntt::launch_fr_load(s, zw.as<uint32_t>(), r.num_vars, montgomery, zs.as<uint32_t>(), r.num_vars);
+        for (int k = 0; k < 3; k++)
+            ntt::launch_csr_eval(s, r.m[k].rowptr, r.m[k].cols, r.m[k].vals, r.m[k].nnz, zs.as<uint32_t>(), r.num_vars, r.num_constraints, k == 0 ? r.num_inputs : 0, arr[k], D);
     }
     {
         StageTimer st(sl, "qap.ntt");
-        uint32_t *arr[3] = {qa.as<uint32_t>(), qb.as<uint32_t>(), qc.as<uint32_t>()};
         for (int k = 0; k < 3; k++) {
             ntt::launch_ntt(s, arr[k], logn, (const uint32_t *)dom.tw_i, 1);                       // iFFT (x D), bit-reversed out
             ntt::launch_coset_scale(s, arr[k], logn, (const uint32_t *)dom.pw_f, nullptr);         // * g^k / D
@@ -130,6 +122,83 @@ int32_t dgpu_witness_map(const uint64_t *a_rowptr, const uint32_t *a_cols, const
     HIPCHK(hipStreamSynchronize(s));
     if (g.prof) prof_flush(sl);
     return DGPU_OK;
+}
+
+int32_t build_r1cs(Slot &sl, const Csr mats[3], size_t num_vars, size_t num_inputs, size_t num_constraints, int32_t montgomery, DevR1cs **out) {
+    DevR1cs *r = new DevR1cs();
+    r->num_vars = num_vars; r->num_inputs = num_inputs; r->num_constraints = num_constraints;
+    for (int k = 0; k < 3; k++) { int32_t rc = upload_matrix(sl, mats[k], num_constraints, montgomery, r->m[k]); if (rc) { free_r1cs(r); return rc; } }
+    *out = r;
+    return DGPU_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+static bool check_csr(const uint64_t *rp, const uint32_t *cl, const uint64_t *vl, size_t nnz) { return rp && (!nnz || (cl && vl)); }
+
+int32_t dgpu_r1cs_upload(const uint64_t *a_rowptr, const uint32_t *a_cols, const uint64_t *a_vals, size_t a_nnz,
+                         const uint64_t *b_rowptr, const uint32_t *b_cols, const uint64_t *b_vals, size_t b_nnz,
+                         const uint64_t *c_rowptr, const uint32_t *c_cols, const uint64_t *c_vals, size_t c_nnz,
+                         size_t num_vars, size_t num_inputs, size_t num_constraints, int32_t montgomery, uint64_t *handle) {
+    if (!handle || num_inputs > num_vars || !check_csr(a_rowptr, a_cols, a_vals, a_nnz) || !check_csr(b_rowptr, b_cols, b_vals, b_nnz) || !check_csr(c_rowptr, c_cols, c_vals, c_nnz)) return DGPU_E_BADARG;
+    if (!g.ready) return DGPU_E_NODEVICE;
+    DevR1cs *r = nullptr;
+    {
+        SlotLock slot_lock; Slot &sl = *slot_lock.s;
+        HIPCHK(hipSetDevice(g.device));
+        Csr mats[3] = {{a_rowptr, a_cols, a_vals, a_nnz}, {b_rowptr, b_cols, b_vals, b_nnz}, {c_rowptr, c_cols, c_vals, c_nnz}};
+        int32_t rc = build_r1cs(sl, mats, num_vars, num_inputs, num_constraints, montgomery, &r);
+        if (rc) return rc;
+    }
+    std::lock_guard<std::mutex> lk(g.mu);
+    uint64_t h = g.next_handle++;
+    g.handles[h] = Handle{r, num_constraints, 4};
+    *handle = h;
+    return DGPU_OK;
+}
+int32_t dgpu_r1cs_free(uint64_t handle) {
+    Handle hd;
+    {
+        std::lock_guard<std::mutex> lk(g.mu);
+        auto it = g.handles.find(handle);
+        if (it == g.handles.end() || it->second.kind != 4) return DGPU_E_BADARG;
+        hd = it->second; g.handles.erase(it);
+    }
+    if (g.ready) { (void)hipSetDevice(g.device); (void)hipDeviceSynchronize(); }
+    free_r1cs((DevR1cs *)hd.p);
+    return DGPU_OK;
+}
+int32_t dgpu_witness_map_r1cs(uint64_t r1cs, const uint64_t *assignment, size_t num_vars, int32_t montgomery, uint64_t *out_h, uint64_t *out_handle, size_t *out_len) {
+    if (!assignment || (!out_h && !out_handle)) return DGPU_E_BADARG;
+    if (!g.ready) return DGPU_E_NODEVICE;
+    Handle hd;
+    if (!lookup_handle(r1cs, hd) || hd.kind != 4) return DGPU_E_BADARG;
+    const DevR1cs *r = (const DevR1cs *)hd.p;
+    if (num_vars != r->num_vars) return DGPU_E_BADARG;
+    SlotLock slot_lock; Slot &sl = *slot_lock.s;
+    HIPCHK(hipSetDevice(g.device));
+    return witness_map_device(sl, *r, assignment, montgomery, out_h, out_handle, out_len);
+}
+int32_t dgpu_witness_map(const uint64_t *a_rowptr, const uint32_t *a_cols, const uint64_t *a_vals, size_t a_nnz,
+                         const uint64_t *b_rowptr, const uint32_t *b_cols, const uint64_t *b_vals, size_t b_nnz,
+                         const uint64_t *c_rowptr, const uint32_t *c_cols, const uint64_t *c_vals, size_t c_nnz,
+                         const uint64_t *assignment, size_t num_vars, size_t num_inputs, size_t num_constraints, int32_t montgomery,
+                         uint64_t *out_h, uint64_t *out_handle, size_t *out_len) {
+    if (!assignment || num_inputs > num_vars || (!out_h && !out_handle)) return DGPU_E_BADARG;
+    if (!check_csr(a_rowptr, a_cols, a_vals, a_nnz) || !check_csr(b_rowptr, b_cols, b_vals, b_nnz) || !check_csr(c_rowptr, c_cols, c_vals, c_nnz)) return DGPU_E_BADARG;
+    if (!g.ready) return DGPU_E_NODEVICE;
+    SlotLock slot_lock; Slot &sl = *slot_lock.s;
+    HIPCHK(hipSetDevice(g.device));
+    Csr mats[3] = {{a_rowptr, a_cols, a_vals, a_nnz}, {b_rowptr, b_cols, b_vals, b_nnz}, {c_rowptr, c_cols, c_vals, c_nnz}};
+    DevR1cs *r = nullptr;
+    int32_t rc = build_r1cs(sl, mats, num_vars, num_inputs, num_constraints, montgomery, &r);
+    if (rc) return rc;
+    rc = witness_map_device(sl, *r, assignment, montgomery, out_h, out_handle, out_len);
+    (void)hipStreamSynchronize(sl.stream);
+    free_r1cs(r);
+    return rc;
 }
 
 }  // extern "C"

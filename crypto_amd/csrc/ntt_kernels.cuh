@@ -79,6 +79,76 @@ __global__ void __launch_bounds__(256) k_ntt_stage(uint32_t *__restrict__ buf, i
     }
     st(buf, D, i0, u); st(buf, D, i1, v);
 }
+// Several consecutive radix-2 stages in one pass through LDS.  A tile is 2048 elements = 2^S values of the S index bits the
+// pass resolves ("mid") x 2^(11-S) columns; a column fixes the other index bits: i = hi << (L + S) | mid << L | lo.
+//   dif != 0: stages s0 .. s0+S-1, L = logn - s0 - S, half_mid = 2^(S-1-st), twiddle w^(j << s)
+//   dif == 0: stages s0 .. s0+S-1, L = s0,            half_mid = 2^st,       twiddle w^(j << (logn-1-s))      j = jm << L | lo
+// L is either 0 (a tile is one contiguous run of 2048 elements) or >= log2(columns) (the columns of a tile are consecutive lo:
+// every global access is a contiguous run of 2^(11-S) words per limb) — the launcher orders the stage groups accordingly.
+// Per pass every element is read and written once (2 x 40 B) instead of once per stage; twiddles come from the L2-resident table.
+constexpr int FUSE_TILE_LOG = 11;
+constexpr int FUSE_THREADS = 512;     // 2 butterflies per lane per stage: two 80-KB blocks per CU overlap their load / compute / store phases
+__global__ void __launch_bounds__(FUSE_THREADS) k_ntt_fused(uint32_t *__restrict__ buf, int logn, int s0, int S, const uint32_t *__restrict__ tw, int dif) {
+    extern __shared__ uint32_t lds[];                      // [NL][2048]
+    constexpr int TILE = 1 << FUSE_TILE_LOG;
+    const size_t D = (size_t)1 << logn, H = D >> 1;
+    const int L = dif ? (logn - s0 - S) : s0;
+    const int cols_log = FUSE_TILE_LOG - S;
+    const size_t c0 = (size_t)blockIdx.x << cols_log;      // first column of this tile; column c = hi << L | lo
+    const size_t lo_mask = ((size_t)1 << L) - 1;
+    auto addr = [&](uint32_t mid, uint32_t cc) -> size_t {
+        size_t c = c0 + cc, hi = c >> L, lo = c & lo_mask;
+        return (hi << (L + S)) | ((size_t)mid << L) | lo;
+    };
+    for (uint32_t e = threadIdx.x; e < TILE; e += FUSE_THREADS) {
+        uint32_t mid, cc;
+        if (L == 0) { cc = e >> S; mid = e & ((1u << S) - 1); } else { mid = e >> cols_log; cc = e & ((1u << cols_log) - 1); }
+        size_t a = addr(mid, cc);
+        uint32_t slot = (mid << cols_log) | cc;
+#pragma unroll
+        for (int l = 0; l < NL; l++) lds[l * TILE + slot] = buf[(size_t)l * D + a];
+    }
+    __syncthreads();
+    // TILE / 2 = 1024 butterflies per stage, two per lane (t and t + 512)
+    for (int st = 0; st < S; st++) {
+        const int s = s0 + st;
+        const uint32_t half_m = dif ? (1u << (S - 1 - st)) : (1u << st);
+#pragma unroll
+        for (int rep = 0; rep < 2; rep++) {
+            const uint32_t t = threadIdx.x + rep * FUSE_THREADS;
+            const uint32_t cc = t & ((1u << cols_log) - 1), b = t >> cols_log;
+            const size_t lo = (c0 + cc) & lo_mask;
+            const uint32_t jm = b & (half_m - 1), m0 = ((b - jm) << 1) + jm, m1 = m0 + half_m;
+            const size_t j = ((size_t)jm << L) | lo;
+            const size_t e = dif ? (j << s) : (j << (logn - 1 - s));
+            const uint32_t p0 = (m0 << cols_log) | cc, p1 = (m1 << cols_log) | cc;
+            Fr x, y, w, u, v;
+            ld(w, tw, H, e);
+#pragma unroll
+            for (int l = 0; l < NL; l++) { x.l[l] = lds[l * TILE + p0]; y.l[l] = lds[l * TILE + p1]; }
+            if (dif) {
+                fr_add(u, x, y); fr_norm(u, u);
+                fr_sub<FR_BIG>(v, x, y); fr_norm(v, v); fr_mul(v, v, w);
+            } else {
+                Fr yw; fr_mul(yw, y, w);
+                fr_add(u, x, yw); fr_norm(u, u);
+                fr_sub(v, x, yw); fr_norm(v, v);
+            }
+#pragma unroll
+            for (int l = 0; l < NL; l++) { lds[l * TILE + p0] = u.l[l]; lds[l * TILE + p1] = v.l[l]; }
+        }
+        __syncthreads();
+    }
+    for (uint32_t e = threadIdx.x; e < TILE; e += FUSE_THREADS) {
+        uint32_t mid, cc2;
+        if (L == 0) { cc2 = e >> S; mid = e & ((1u << S) - 1); } else { mid = e >> cols_log; cc2 = e & ((1u << cols_log) - 1); }
+        size_t a = addr(mid, cc2);
+        uint32_t slot = (mid << cols_log) | cc2;
+#pragma unroll
+        for (int l = 0; l < NL; l++) buf[(size_t)l * D + a] = lds[l * TILE + slot];
+    }
+}
+
 // element at position p (bit-reversed order, coefficient k = bitrev(p)) *= pw[k]; optionally written out un-reversed as
 // canonical words (h coefficients for the MSM)
 __global__ void __launch_bounds__(256) k_coset_scale(uint32_t *__restrict__ buf, int logn, const uint32_t *__restrict__ pw, uint32_t *__restrict__ out_words) {

@@ -55,3 +55,52 @@ def witness_map(A, B, Cm, assignment, num_inputs, num_constraints, montgomery=Fa
         ds = DeviceScalars.__new__(DeviceScalars)
         ds.n, ds.handle = olen.value, handle.value
     return out, ds
+
+
+class DeviceR1cs:
+    """The circuit's three constraint matrices resident in HBM (dgpu_r1cs_upload): fixed per circuit, reused by every proof."""
+
+    def __init__(self, A, B, Cm, num_vars, num_inputs, num_constraints, montgomery=False):
+        _ensure()
+        args = []
+        self._keep = []
+        for rp, cl, vl in (A, B, Cm):
+            rp = np.ascontiguousarray(rp, dtype=np.uint64); cl = np.ascontiguousarray(cl, dtype=np.uint32)
+            vl = np.ascontiguousarray(vl, dtype=np.uint64).reshape(-1, 4)
+            if len(rp) != num_constraints + 1 or len(cl) != len(vl) or int(rp[-1]) != len(cl) or (len(cl) and int(cl.max()) >= num_vars):
+                raise ValueError("malformed CSR matrix")
+            args += [rp.ctypes.data_as(C.c_void_p), _p(cl), _p(vl), len(cl)]
+        self.num_vars, self.num_inputs, self.num_constraints = num_vars, num_inputs, num_constraints
+        h = C.c_uint64(0)
+        rc = lib().dgpu_r1cs_upload(*args, num_vars, num_inputs, num_constraints, int(montgomery), C.byref(h))
+        if rc:
+            raise DockGpuError(rc, "dgpu_r1cs_upload")
+        self.handle = h.value
+
+    def witness_map(self, assignment, montgomery=False, to_host=True, resident=False):
+        z = np.ascontiguousarray(assignment, dtype=np.uint64).reshape(-1, 4)
+        D = 2
+        while D < self.num_constraints + self.num_inputs:
+            D *= 2
+        out = np.zeros((D, 4), dtype=np.uint64) if to_host else None
+        handle = C.c_uint64(0); olen = C.c_size_t(0)
+        rc = lib().dgpu_witness_map_r1cs(self.handle, z.ctypes.data_as(C.c_void_p), len(z), int(montgomery),
+                                         None if out is None else out.ctypes.data_as(C.c_void_p), C.byref(handle) if resident else None, C.byref(olen))
+        if rc:
+            raise DockGpuError(rc, "dgpu_witness_map_r1cs")
+        ds = None
+        if resident:
+            ds = DeviceScalars.__new__(DeviceScalars)
+            ds.n, ds.handle = olen.value, handle.value
+        return out, ds
+
+    def free(self):
+        if self.handle:
+            lib().dgpu_r1cs_free(self.handle)
+            self.handle = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

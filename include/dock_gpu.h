@@ -114,6 +114,15 @@ int32_t dgpu_witness_map(const uint64_t *a_rowptr, const uint32_t *a_cols, const
                          const uint64_t *assignment, size_t num_vars, size_t num_inputs, size_t num_constraints, int32_t montgomery,
                          uint64_t *out_h, uint64_t *out_handle, size_t *out_len);
 
+/* the same with the circuit's matrices resident in HBM (they are fixed per circuit; only the assignment changes per proof) */
+int32_t dgpu_r1cs_upload(const uint64_t *a_rowptr, const uint32_t *a_cols, const uint64_t *a_vals, size_t a_nnz,
+                         const uint64_t *b_rowptr, const uint32_t *b_cols, const uint64_t *b_vals, size_t b_nnz,
+                         const uint64_t *c_rowptr, const uint32_t *c_cols, const uint64_t *c_vals, size_t c_nnz,
+                         size_t num_vars, size_t num_inputs, size_t num_constraints, int32_t montgomery, uint64_t *handle);
+int32_t dgpu_r1cs_free(uint64_t handle);
+int32_t dgpu_witness_map_r1cs(uint64_t r1cs, const uint64_t *assignment, size_t num_vars, int32_t montgomery,
+                              uint64_t *out_h, uint64_t *out_handle, size_t *out_len);
+
 /* ---- instrumentation (bench.py / rocprof cross-check) ----
  * When enabled, every stage of the next calls is bracketed by HIP events on the library's own stream. */
 int32_t dgpu_prof_enable(int32_t on);

@@ -48,6 +48,13 @@ def test_witness_map_vs_oracle(m):
     assert not h[-1].any()                     # deg h <= D - 2: the prover pairs h[..D-1] with h_query (prover.rs:286)
     if m == 40:
         assert [O.limbs_to_int(x) for x in h] == LS.witness_map(cs)       # and the naive big-integer version
+    # the same through a device-resident circuit handle (matrices uploaded once, assignment per proof)
+    dr = qap.DeviceR1cs(*mats, len(cs["z"]), cs["n_inst"], cs["n_cons"])
+    h2, _ = dr.witness_map(z)
+    assert (h2 == ref).all()
+    with pytest.raises(ca.DockGpuError):
+        dr.witness_map(z[:-1])
+    dr.free()
     # Montgomery inputs (what the reference holds in memory) give the same canonical output
     matsm = [(rp, cl, O.fr_to_mont(vl)) for rp, cl, vl in mats]
     hm, _ = qap.witness_map(*matsm, O.fr_to_mont(z), cs["n_inst"], cs["n_cons"], montgomery=True)

@@ -11,3 +11,4 @@ from .msm import (  # noqa: F401
 from .pairing import multi_miller_loop, final_exponentiation, multi_pairing  # noqa: F401,E402
 from .pairing_check import RandomizedPairingChecker  # noqa: F401,E402
 from . import qap  # noqa: F401,E402
+from . import serde  # noqa: F401,E402

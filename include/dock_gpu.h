@@ -123,6 +123,16 @@ int32_t dgpu_r1cs_free(uint64_t handle);
 int32_t dgpu_witness_map_r1cs(uint64_t r1cs, const uint64_t *assignment, size_t num_vars, int32_t montgomery,
                               uint64_t *out_h, uint64_t *out_handle, size_t *out_len);
 
+/* ---- canonical (de)serialisation of group elements (host code) ----
+ * The format ark-bls12-381 0.4 emits for `CanonicalSerialize` (Zcash / IETF BLS12-381): big-endian coordinates, top three bits of
+ * byte 0 = compressed / infinity / y-lexicographically-largest; G1 48 B (compressed) or 96 B, G2 96 or 192 B with c1 before c0.
+ * Used to load keys and proofs written by the Rust side (legogroth16/src/data_structures.rs:7-186) into the ABI layout.
+ * DGPU_E_BADARG: wrong compression flag, coordinate >= p, or not on the curve.  No subgroup check. */
+int32_t dgpu_g1_serialize(const uint64_t *xy /* n*12 */, const uint8_t *is_inf, size_t n, int32_t compressed, uint8_t *out);
+int32_t dgpu_g1_deserialize(const uint8_t *in, size_t n, int32_t compressed, uint64_t *xy /* n*12 */, uint8_t *is_inf /* n */);
+int32_t dgpu_g2_serialize(const uint64_t *xy /* n*24 */, const uint8_t *is_inf, size_t n, int32_t compressed, uint8_t *out);
+int32_t dgpu_g2_deserialize(const uint8_t *in, size_t n, int32_t compressed, uint64_t *xy /* n*24 */, uint8_t *is_inf /* n */);
+
 /* ---- instrumentation (bench.py / rocprof cross-check) ----
  * When enabled, every stage of the next calls is bracketed by HIP events on the library's own stream. */
 int32_t dgpu_prof_enable(int32_t on);

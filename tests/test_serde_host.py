@@ -1,0 +1,67 @@
+"""CPU: canonical point (de)serialisation.  Known answers here are EXTERNAL, published encodings — the
+compressed BLS12-381 generators of the Zcash / IETF BLS specification, which is the format ark-bls12-381 0.4 implements —
+so this is one place where the build is pinned by vectors that do not come from its own model."""
+import numpy as np
+import pytest
+import oracle_c as O
+import util as U
+import crypto_amd as ca
+from crypto_amd import serde
+
+G1_GEN_COMPRESSED = bytes.fromhex(
+    "97f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac586c55e83ff97a1aeffb3af00adb22c6bb")
+G2_GEN_COMPRESSED = bytes.fromhex(
+    "93e02b6052719f607dacd3a088274f65596bd0d09920b61ab5da61bbdc7f5049334cf11213945d57e5ac7d055d042b7e"
+    "024aa2b2f08f0a91260805272dc51051c6e47ad4fa403b02b4510b647ae3d1770bac0326a805bbefd48056c8c121bdb8")
+
+
+def test_generator_known_answers():
+    g1, g2 = O.G1.generator(), O.G2.generator()
+    assert serde.serialize(ca.G1, g1) == G1_GEN_COMPRESSED
+    assert serde.serialize(ca.G2, g2) == G2_GEN_COMPRESSED
+    p, inf = serde.deserialize(ca.G1, G1_GEN_COMPRESSED)
+    assert not inf[0] and (p[0] == g1).all()
+    p, inf = serde.deserialize(ca.G2, G2_GEN_COMPRESSED)
+    assert not inf[0] and (p[0] == g2).all()
+    # uncompressed = x || y big-endian, no flags for a finite point
+    un = serde.serialize(ca.G1, g1, compressed=False)
+    assert un[:48] == bytes([G1_GEN_COMPRESSED[0] & 0x1f]) + G1_GEN_COMPRESSED[1:] and len(un) == 96
+    assert int.from_bytes(un[48:], "big") == U.fp_int(g1[6:])
+
+
+@pytest.mark.parametrize("curve,G", [(ca.G1, O.G1), (ca.G2, O.G2)])
+@pytest.mark.parametrize("compressed", [True, False])
+def test_roundtrip_random_points_and_identity(curve, G, compressed):
+    n = 64
+    pts, _, _ = U.seq_bases(G, n, 4242, threads=2)
+    # include negations so that both values of the "largest y" flag occur
+    neg = pts.copy()
+    h = G.AW // 2
+    for i in range(0, n, 2):
+        for k in range(h // 6):
+            neg[i][h + 6 * k:h + 6 * k + 6] = U.fp_abi((-U.fp_int(pts[i][h + 6 * k:h + 6 * k + 6])) % U.P)
+    inf = np.zeros(n, np.uint8); inf[5] = 1
+    data = serde.serialize(curve, neg, inf, compressed)
+    back, binf = serde.deserialize(curve, data, compressed)
+    assert (binf == inf).all()
+    mask = inf == 0
+    assert (back[mask] == neg[mask]).all() and not back[~mask].any()
+    if compressed:
+        sz = len(data) // n
+        flags = [data[i * sz] >> 5 for i in range(n)]
+        assert flags[5] == 0b110 and {f for i, f in enumerate(flags) if i != 5} == {0b100, 0b101}
+
+
+def test_rejects_malformed_input():
+    with pytest.raises(ca.DockGpuError):
+        serde.deserialize(ca.G1, bytes(48))                                  # compression flag missing
+    with pytest.raises(ca.DockGpuError):
+        serde.deserialize(ca.G1, bytes([0x9f]) + b"\xff" * 47)               # x >= p
+    bad = bytearray(G1_GEN_COMPRESSED); bad[-1] ^= 1                          # x with no point on the curve (or another point): must not silently equal the generator
+    try:
+        p, _ = serde.deserialize(ca.G1, bytes(bad))
+        assert not (p[0] == O.G1.generator()).all() and O.G1.on_curve(p[0])
+    except ca.DockGpuError:
+        pass
+    with pytest.raises(ValueError):
+        serde.deserialize(ca.G2, bytes(95))

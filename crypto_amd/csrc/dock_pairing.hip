@@ -14,6 +14,7 @@
 #include "dock_ctx.hpp"
 #include "host_field.hpp"
 #include "pairing29.cuh"
+#include "fp2_pair.cuh"
 #include "sort_launch.cuh"
 
 namespace {
@@ -52,6 +53,39 @@ __global__ void __launch_bounds__(64) k_miller_lines(const uint32_t *__restrict_
             const uint32_t *w = reinterpret_cast<const uint32_t *>(&l); for (int k = 0; k < LW; k++) lines[((size_t)s * LW + k) * n + i] = w[k];
             s++;
         }
+    }
+}
+
+// Lane-pair version of k_miller_lines (fp2_pair.cuh): lanes 2i / 2i+1 hold the c0 / c1 halves of every Fp2 value of pair i,
+// cross terms move over DPP.  Half the registers per lane (no spills, 2 waves/SIMD) and 2 instead of 3 base-field products per
+// Fp2 product on the critical path of the 63 dependent doubling steps.
+__global__ void __launch_bounds__(64) k_miller_lines_pair(const uint32_t *__restrict__ p_abi, const uint32_t *__restrict__ q_abi, const uint8_t *__restrict__ skip, size_t n, uint32_t *__restrict__ lines) {
+    size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 1;
+    const uint32_t h = threadIdx.x & 1u;
+    if (i >= n) return;
+    bool sk = skip && skip[i];
+    uint32_t pw[24]; uint32_t anyp = 0, anyq = 0;
+    for (int k = 0; k < 24; k++) { pw[k] = p_abi[i * 24 + k]; anyp |= pw[k]; }
+    uint32_t qx[12], qy[12];
+    for (int k = 0; k < 12; k++) { qx[k] = q_abi[i * 48 + h * 12 + k]; qy[k] = q_abi[i * 48 + 24 + h * 12 + k]; anyq |= qx[k] | qy[k]; }
+    anyq |= xchg32(anyq);
+    if (!anyp || !anyq) sk = true;
+    auto put = [&](int s, const LineT<Fp2H> &l) {
+        const uint32_t *w = reinterpret_cast<const uint32_t *>(&l);          // c0, c1, c2 halves: 3 x 14 words
+        for (int c = 0; c < 3; c++) for (int j = 0; j < NL; j++) lines[((size_t)s * LW + (2 * c + h) * NL + j) * n + i] = w[c * NL + j];
+    };
+    if (sk) {
+        LineT<Fp2H> one; fset_one(one.c0); fzero(one.c1); fzero(one.c2);
+        for (int s = 0; s < N_LINES; s++) put(s, one);
+        return;
+    }
+    Fp px, py; fp_from_abi(px, pw); fp_from_abi(py, pw + 12);
+    Aff<Fp2H> Q; fp_from_abi(Q.x.v, qx); fp_from_abi(Q.y.v, qy);
+    G2ProjT<Fp2H> R; R.x = Q.x; R.y = Q.y; fset_one(R.z);
+    int s = 0;
+    for (int b = 62; b >= 0; b--) {
+        LineT<Fp2H> l; line_dbl_step(R, l); line_eval(l, px, py); put(s++, l);
+        if ((BLS_X_ABS >> b) & 1) { line_add_step(R, Q, l); line_eval(l, px, py); put(s++, l); }
     }
 }
 
@@ -116,7 +150,9 @@ int32_t dgpu_multi_miller_loop(const uint64_t *p, const uint64_t *q, const uint8
     const uint8_t *dskip = nullptr;
     if (skip) { HIPCHK(hipMemcpyAsync(sl.in_inf.p, skip, n, hipMemcpyHostToDevice, s)); dskip = sl.in_inf.as<uint8_t>(); }
     { StageTimer st(sl, "ml.lines");
-      hipLaunchKernelGGL(k_miller_lines, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, sl.in_bases.as<uint32_t>(), sl.in_scalars.as<uint32_t>(), dskip, n, sl.ml_lines.as<uint32_t>()); }
+      static const bool one_lane = getenv("DGPU_ML_ONE_LANE") != nullptr;     // development switch: one lane per pair
+      if (one_lane) hipLaunchKernelGGL(k_miller_lines, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, sl.in_bases.as<uint32_t>(), sl.in_scalars.as<uint32_t>(), dskip, n, sl.ml_lines.as<uint32_t>());
+      else hipLaunchKernelGGL(k_miller_lines_pair, dim3((unsigned)((2 * n + 63) / 64)), dim3(64), 0, s, sl.in_bases.as<uint32_t>(), sl.in_scalars.as<uint32_t>(), dskip, n, sl.ml_lines.as<uint32_t>()); }
     { StageTimer st(sl, "ml.products");
       hipLaunchKernelGGL(k_line_products, dim3((unsigned)((N_LINES * nsl + 63) / 64)), dim3(64), 0, s, sl.ml_lines.as<uint32_t>(), n, slice_len, nsl, sl.ml_partial.as<uint32_t>()); }
     { StageTimer st(sl, "ml.tree");

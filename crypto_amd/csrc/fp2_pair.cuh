@@ -75,6 +75,34 @@ __device__ __forceinline__ void fsqr(Fp2H &r, const Fp2H &a) {
     sel(r.v, odd, p2, p);
 }
 
+// ---- helpers used by the Miller-loop line functions (pairing29.cuh), lane-pair versions ----
+template <int M> __device__ __forceinline__ void f2_sqr_m(Fp2H &r, const Fp2H &a) {
+    const bool odd = pair_odd();
+    Fp ao, s, d, m1, m2, p, p2;
+    xchg(ao, a.v);
+    fp_add(s, a.v, ao);
+    fp_sub<M>(d, a.v, ao); fp_norm(d, d);
+    sel(m1, odd, a.v, s);
+    sel(m2, odd, ao, d);
+    fp_mul(p, m1, m2);
+    fp_add(p2, p, p); fp_norm(p2, p2);
+    sel(r.v, odd, p2, p);
+}
+// r = a (1 + u) = (a0 - a1) + (a0 + a1) u, normalised
+template <int M> __device__ __forceinline__ void f2_mul_xi_n(Fp2H &r, const Fp2H &a) {
+    const bool odd = pair_odd();
+    Fp ao, d, s, t;
+    xchg(ao, a.v);
+    fp_sub<M>(d, a.v, ao);       // even lane: a0 - a1 + M p
+    fp_add(s, a.v, ao);          // odd lane:  a1 + a0
+    sel(t, odd, s, d);
+    fp_norm(r.v, t);
+}
+template <int M> __device__ __forceinline__ void f2_neg_n(Fp2H &r, const Fp2H &a) { Fp z; fp_zero(z); fp_sub<M>(r.v, z, a.v); fp_norm(r.v, r.v); }
+__device__ __forceinline__ void f2_add_n(Fp2H &r, const Fp2H &a, const Fp2H &b) { fp_add(r.v, a.v, b.v); fp_norm(r.v, r.v); }
+template <int M> __device__ __forceinline__ void f2_sub_n(Fp2H &r, const Fp2H &a, const Fp2H &b) { fp_sub<M>(r.v, a.v, b.v); fp_norm(r.v, r.v); }
+__device__ __forceinline__ void fmul_fp(Fp2H &r, const Fp2H &a, const Fp &k) { fp_mul(r.v, a.v, k); }
+
 template <> struct SubM<Fp2H> {     // same value budgets as the one-lane Fp2 formulas
     static constexpr int P = 32;
     static constexpr int R = 16;

@@ -113,16 +113,18 @@ FD void f12_from_014(Fp12d &f, const Fp2 &c0, const Fp2 &c1, const Fp2 &c4) {
 }
 
 // ---- G2 line functions (homogeneous projective R = (X, Y, Z); ark-ec bls12/g2.rs double_in_place / add_in_place) ----
-struct G2Proj { Fp2 x, y, z; };
-struct Line { Fp2 c0, c1, c2; };
+template <class F2> struct G2ProjT { F2 x, y, z; };
+template <class F2> struct LineT { F2 c0, c1, c2; };
+typedef G2ProjT<Fp2> G2Proj;
+typedef LineT<Fp2> Line;
 
-FD void line_dbl_step(G2Proj &R, Line &l) {
+template <class F2> FD void line_dbl_step(G2ProjT<F2> &R, LineT<F2> &l) {
     constexpr uint32_t TI_[NL] = BLS29_TWO_INV;
     Fp two_inv;
 #pragma unroll
     for (int i = 0; i < NL; i++) two_inv.l[i] = TI_[i];
     CHK(chk_set_N(two_inv, 1.0);)
-    Fp2 a, b, c, e, f, g, h, i, j, e2, t, d;
+    F2 a, b, c, e, f, g, h, i, j, e2, t, d;
     fmul(a, R.x, R.y); fmul_fp(a, a, two_inv);
     f2_sqr_m<64>(b, R.y);
     f2_sqr_m<64>(c, R.z);
@@ -143,8 +145,8 @@ FD void line_dbl_step(G2Proj &R, Line &l) {
     fadd(t, j, j); fadd(t, t, j); fnorm(l.c1, t);
     f2_neg_n<32>(l.c2, h);
 }
-FD void line_add_step(G2Proj &R, const Aff<Fp2> &Q, Line &l) {
-    Fp2 theta, lam, c, d, e, f, g, h, j, t, u;
+template <class F2> FD void line_add_step(G2ProjT<F2> &R, const Aff<F2> &Q, LineT<F2> &l) {
+    F2 theta, lam, c, d, e, f, g, h, j, t, u;
     fmul(t, Q.y, R.z); f2_sub_n<8>(theta, R.y, t);
     fmul(t, Q.x, R.z); f2_sub_n<8>(lam, R.x, t);
     f2_sqr_m<64>(c, theta); f2_sqr_m<64>(d, lam);
@@ -158,7 +160,7 @@ FD void line_add_step(G2Proj &R, const Aff<Fp2> &Q, Line &l) {
     l.c0 = j; f2_neg_n<64>(l.c1, theta); l.c2 = lam;
 }
 // ark-ec `ell` for the M twist: c1 *= px, c2 *= py
-FD void line_eval(Line &l, const Fp &px, const Fp &py) { fmul_fp(l.c1, l.c1, px); fmul_fp(l.c2, l.c2, py); }
+template <class F2> FD void line_eval(LineT<F2> &l, const Fp &px, const Fp &py) { fmul_fp(l.c1, l.c1, px); fmul_fp(l.c2, l.c2, py); }
 
 constexpr uint64_t BLS_X_ABS = 0xd201000000010000ULL;
 constexpr int N_LINES = 68;

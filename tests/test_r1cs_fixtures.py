@@ -1,0 +1,108 @@
+"""The reference's own Circom fixtures (tests/golden/r1cs/*.r1cs are data files copied from
+/root/reference/legogroth16/test-vectors/bls12-381/, the inputs of legogroth16/src/circom/tests.rs): the `.r1cs` reader
+parses them like r1cs_reader.rs does, a witness computed from the circuit's definition satisfies every constraint, and the
+witness map over these REAL matrices agrees between the CPU oracle and (on a GPU box) the HIP path."""
+import ctypes as C
+import os
+import numpy as np
+import pytest
+import torch
+import oracle_c as O
+import lego_setup as LS
+from crypto_amd.r1cs_file import R1csFile, BLS12_381_ORDER
+from crypto_amd import qap
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+R = BLS12_381_ORDER
+fx = lambda name: R1csFile.from_path(os.path.join(HERE, "golden", "r1cs", name))
+
+
+def witness_multiply2(a, b):                       # out = a * b; wires: 1, out, a, b
+    return [1, a * b % R, a, b]
+
+
+def witness_test1(x):                              # y = x^3 + x + 5; wires: 1, y, x, t1  (circom folds t2 into the last constraint)
+    t1 = x * x % R
+    return [1, (t1 * x + x + 5) % R, x, t1]
+
+
+def witness_nconstraints(f, x):                    # intermediate[i] = intermediate[i-1]^2 + i   (nconstraints.circom, n = 2500)
+    n = f.n_constraints + 1
+    vals = [x % R]
+    for i in range(1, n):
+        vals.append((vals[-1] * vals[-1] + i) % R)
+    w = [1, vals[-1], x % R] + vals[1:-1]          # out aliases intermediate[n-1], in aliases intermediate[0]
+    return w
+
+
+def witness_multiply_n(f, ins):                    # out = prod in[i]; wires: 1, out, in[0..n), intermediates
+    acc, inter = ins[0] % R, []
+    for v in ins[1:]:
+        acc = acc * v % R; inter.append(acc)
+    return [1, acc] + [v % R for v in ins] + inter[:-1]
+
+
+def test_reader_matches_reference_header_semantics():
+    f = fx("multiply2.r1cs")
+    assert f.prime == R and (f.n_wires, f.n_pub_out, f.n_pub_in, f.n_prv_in, f.n_constraints) == (4, 1, 0, 2, 1)
+    assert f.is_satisfied(witness_multiply2(3, 11)) and not f.is_satisfied([1, 34, 3, 11])
+    t = fx("test1.r1cs")
+    assert t.n_constraints == 2 and t.n_wires == 4 and t.is_satisfied(witness_test1(3)) and witness_test1(3)[1] == 35
+    n = fx("nconstraints.r1cs")
+    assert n.n_constraints == 2499 and n.n_pub_out == 1 and n.n_prv_in == 1
+    w = witness_nconstraints(n, 7)
+    assert len(w) == n.n_wires and n.is_satisfied(w)
+    # the reference's test: the public output equals the iterated x^2 + i (legogroth16/src/circom/tests.rs:233-258,916-929)
+    x = 7
+    for i in range(1, 2500):
+        x = (x * x + i) % R
+    assert w[1] == x
+    m = fx("multiply_n.r1cs")
+    wm = witness_multiply_n(m, list(range(2, 302)))
+    assert len(wm) == m.n_wires and m.is_satisfied(wm)
+    with pytest.raises(ValueError):
+        R1csFile(b"r1cx" + bytes(100))
+
+
+def _oracle_map(f, w):
+    L = O.lib(); L.orc_witness_map.restype = C.c_int
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    D = 1
+    while D < f.n_constraints + f.num_inputs:
+        D *= 2
+    out = np.zeros((D, 4), np.uint64)
+    args = []
+    for rp, cl, vl in f.csr():
+        args += [p(rp), p(cl), p(vl)]
+    L.orc_witness_map(*args, p(LS.scalars(w)), C.c_size_t(len(w)), C.c_size_t(f.num_inputs), C.c_size_t(f.n_constraints), p(out))
+    return out
+
+
+def test_oracle_witness_map_on_reference_circuits():
+    for name, w in (("multiply2.r1cs", witness_multiply2(3, 11)), ("test1.r1cs", witness_test1(5))):
+        f = fx(name)
+        h = _oracle_map(f, w)
+        assert not h[-1].any()
+    f = fx("nconstraints.r1cs")
+    h = _oracle_map(f, witness_nconstraints(f, 3))
+    assert h.shape == (4096, 4) and not h[-1].any() and h[:100].any()
+    # an unsatisfying assignment leaves a non-zero top coefficient (a*b - c is no longer divisible by Z)
+    bad = witness_nconstraints(f, 3); bad[5] = (bad[5] + 1) % R
+    assert _oracle_map(f, bad)[-1].any()
+
+
+@pytest.mark.gpu
+def test_gpu_witness_map_on_reference_circuits():
+    assert torch.cuda.is_available()
+    import crypto_amd as ca
+    ca.init(0)
+    for name, w in (("multiply2.r1cs", witness_multiply2(3, 11)), ("test1.r1cs", witness_test1(5)),
+                    ("nconstraints.r1cs", None), ("multiply_n.r1cs", None)):
+        f = fx(name)
+        if name == "nconstraints.r1cs":
+            w = witness_nconstraints(f, 3)
+        if name == "multiply_n.r1cs":
+            w = witness_multiply_n(f, list(range(2, 302)))
+        dr = qap.DeviceR1cs(*f.csr(), f.n_wires, f.num_inputs, f.n_constraints)
+        h, _ = dr.witness_map(LS.scalars(w))
+        assert (h == _oracle_map(f, w)).all(), name

@@ -2,6 +2,7 @@
 // (implements the curve-independent part of include/dock_gpu.h).
 #include "dock_ctx.hpp"
 #include "host_field.hpp"
+#include "qap_launch.cuh"
 
 namespace dock {
 Ctx g;
@@ -33,10 +34,8 @@ int choose_chunk(size_t E) {
 }
 
 int32_t upload_scalars(Slot &sl, const uint64_t *h, size_t n, bool mont, uint32_t *d_out) {
-    if (!mont) { HIPCHK(hipMemcpyAsync(d_out, h, n * 32, hipMemcpyHostToDevice, sl.stream)); HIPCHK(hipStreamSynchronize(sl.stream)); return DGPU_OK; }
-    std::vector<uint64_t> tmp(n * 4);
-    for (size_t i = 0; i < n; i++) hostf::fr_from_mont(&tmp[4 * i], h + 4 * i);   // Fr::into_bigint (ark-ec msm_unchecked does the same on rayon)
-    HIPCHK(hipMemcpyAsync(d_out, tmp.data(), n * 32, hipMemcpyHostToDevice, sl.stream));
+    HIPCHK(hipMemcpyAsync(d_out, h, n * 32, hipMemcpyHostToDevice, sl.stream));
+    if (mont) ntt::launch_fr_mont_to_canonical(sl.stream, d_out, n);     // Fr::into_bigint on the device (ark-ec msm_unchecked does it on rayon)
     HIPCHK(hipStreamSynchronize(sl.stream));
     return DGPU_OK;
 }

@@ -43,13 +43,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("DGPU_BENCH_SAME_DEVICE"):      # plumbing test only: several ranks on one GPU
+        local = 0
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    cdev = dev if os.environ.get("DGPU_BENCH_BACKEND", "nccl") == "nccl" else None     # where collective payloads live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get("DGPU_BENCH_BACKEND", "nccl")       # "gloo" only for the one-GPU plumbing test (RCCL refuses two ranks on one device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import crypto_amd as ca
     from crypto_amd import sharded
@@ -71,7 +78,7 @@ def main():
 
     def step():
         part = db.msm_resident(ds)
-        return sharded.gather_and_fold(ca.G1, part, dev) if world > 1 else part
+        return sharded.gather_and_fold(ca.G1, part, cdev) if world > 1 else part
 
     # correctness of what is timed: closed form (sum s_i k_i) G over ALL ranks' terms
     res = step()
@@ -98,7 +105,7 @@ def main():
         last = None
         for f in futs:
             part = f.result()
-            last = sharded.gather_and_fold(ca.G1, part, dev) if world > 1 else part
+            last = sharded.gather_and_fold(ca.G1, part, cdev) if world > 1 else part
         return last
 
     for _ in range(args.warmup):
@@ -126,7 +133,7 @@ def main():
     stages = ca.prof.read()
     ca.prof.enable(False)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=cdev if cdev is not None else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 

@@ -26,7 +26,8 @@ template <> struct SubM<Fp> {
     static constexpr int R = 8;    // S2 - Y1      (Y1 value <  6 p)
     static constexpr int X = 8;    // RR - (PPP + 2Q)
     static constexpr int D = 16;   // Q - X3
-    static constexpr int Y = 4;    // R*(Q - X3) - Y1*PPP
+    static constexpr int Y = 4;    // U2 - U1, S2 - S1 in the general addition (products)
+    static constexpr int YN = 16;  // lazy negation of the c operand of R*(Q - X3) - c*PPP (c = Y1, S1 or W; value < 15 p)
     static constexpr int NEG = 4;  // 0 - y
 };
 template <> struct SubM<Fp2> {     // an Fp2 product leaves values < 6 p, so every budget is one notch wider
@@ -35,6 +36,7 @@ template <> struct SubM<Fp2> {     // an Fp2 product leaves values < 6 p, so eve
     static constexpr int X = 16;
     static constexpr int D = 32;
     static constexpr int Y = 8;
+    static constexpr int YN = 16;
     static constexpr int NEG = 4;
 };
 
@@ -48,7 +50,7 @@ template <class F> FD void xyzz_dbl_affine(Xyzz<F> &r, const Aff<F> &p) {
     fsqr(M, p.x); fadd(t, M, M); fadd(M, t, M); fnorm(M, M);
     fsqr(X3, M); fadd(t, S, S); fsub<SubM<F>::X>(X3, X3, t); fnorm(X3, X3);
     fsub<SubM<F>::D>(t, S, X3); fnorm(t, t);
-    fmul(Y3, M, t); fmul(t, W, p.y); fsub<SubM<F>::Y>(Y3, Y3, t); fnorm(Y3, Y3);
+    fmul_sub<SubM<F>::YN>(Y3, M, t, W, p.y);
     r.x = X3; r.y = Y3; r.zz = V; r.zzz = W;
 }
 
@@ -62,7 +64,7 @@ template <class F> FD void xyzz_dbl(Xyzz<F> &r, const Xyzz<F> &a) {
     fsqr(M, a.x); fadd(t, M, M); fadd(M, t, M); fnorm(M, M);
     fsqr(X3, M); fadd(t, S, S); fsub<SubM<F>::X>(X3, X3, t); fnorm(X3, X3);
     fsub<SubM<F>::D>(t, S, X3); fnorm(t, t);
-    fmul(Y3, M, t); fmul(t, W, a.y); fsub<SubM<F>::Y>(Y3, Y3, t); fnorm(Y3, Y3);
+    fmul_sub<SubM<F>::YN>(Y3, M, t, W, a.y);
     fmul(r.zz, V, a.zz); fmul(r.zzz, W, a.zzz);
     r.x = X3; r.y = Y3;
 }
@@ -92,9 +94,7 @@ template <class F> FD void xyzz_madd(Xyzz<F> &acc, bool &inf, const Aff<F> &q_in
     fadd(t, Q, Q); fadd(t, t, PPP);
     fsub<SubM<F>::X>(X3, X3, t); fnorm(X3, X3);
     fsub<SubM<F>::D>(t, Q, X3); fnorm(t, t);
-    fmul(Y3, Rd, t);
-    fmul(t, acc.y, PPP);
-    fsub<SubM<F>::Y>(Y3, Y3, t); fnorm(Y3, Y3);
+    fmul_sub<SubM<F>::YN>(Y3, Rd, t, acc.y, PPP);
     fmul(acc.zz, acc.zz, PP);
     fmul(acc.zzz, acc.zzz, PPP);
     acc.x = X3; acc.y = Y3;
@@ -126,9 +126,7 @@ template <class F> FD void xyzz_add(Xyzz<F> &a, bool &ainf, const Xyzz<F> &b, bo
     fadd(t, Q, Q); fadd(t, t, PPP);
     fsub<SubM<F>::X>(X3, X3, t); fnorm(X3, X3);
     fsub<SubM<F>::D>(t, Q, X3); fnorm(t, t);
-    fmul(Y3, Rd, t);
-    fmul(t, S1, PPP);
-    fsub<SubM<F>::Y>(Y3, Y3, t); fnorm(Y3, Y3);
+    fmul_sub<SubM<F>::YN>(Y3, Rd, t, S1, PPP);
     fmul(t, a.zz, b.zz); fmul(a.zz, t, PP);
     fmul(t, a.zzz, b.zzz); fmul(a.zzz, t, PPP);
     a.x = X3; a.y = Y3;

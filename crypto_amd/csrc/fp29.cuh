@@ -200,6 +200,50 @@ FD void fp_mul(Fp &r, const Fp &a, const Fp &b) {
     CHK(chk_set_N(r, 1.0 + a.vb * b.vb / 33554432.0); chk_actual(r);)
 }
 
+// Fused  r = (a*b + c*d) / 2^406 mod p : two operand products share ONE Montgomery reduction (588 instead of 784
+// v_mad_u64_u32).  All four operands class N: a column then holds 28 operand products + 14 reduction products < 42 * 2^58 < 2^64.
+FD void fp_mul2(Fp &r, const Fp &a, const Fp &b, const Fp &c, const Fp &d) {
+    BLS29_DECL_P;
+#ifdef FP29_CHECK
+    {
+        unsigned __int128 carry = 0;
+        for (int k = 0; k < 2 * NL - 1; k++) {
+            unsigned __int128 s = carry;
+            for (int i = 0; i < NL; i++) { int j = k - i; if (j < 0 || j >= NL) continue; s += (unsigned __int128)a.ub[i] * b.ub[j] + (unsigned __int128)c.ub[i] * d.ub[j]; s += (unsigned __int128)LMASK * P_[j]; }
+            assert(s < ((unsigned __int128)1 << 64));
+            carry = s >> LB;
+        }
+        assert(a.vb * b.vb + c.vb * d.vb < 33554432.0 * 0.5);
+        chk_actual(a); chk_actual(b); chk_actual(c); chk_actual(d);
+    }
+#endif
+    uint32_t m[NL], t[NL];
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < NL; k++) {
+#pragma unroll
+        for (int i = 0; i <= k; i++) { acc += (uint64_t)a.l[i] * b.l[k - i]; acc += (uint64_t)c.l[i] * d.l[k - i]; }
+#pragma unroll
+        for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * P_[k - i];
+        m[k] = ((uint32_t)acc * INV29) & LMASK;
+        acc += (uint64_t)m[k] * P_[0];
+        acc >>= LB;
+    }
+#pragma unroll
+    for (int k = NL; k < 2 * NL - 1; k++) {
+#pragma unroll
+        for (int i = k - NL + 1; i < NL; i++) { acc += (uint64_t)a.l[i] * b.l[k - i]; acc += (uint64_t)c.l[i] * d.l[k - i]; }
+#pragma unroll
+        for (int i = k - NL + 1; i < NL; i++) acc += (uint64_t)m[i] * P_[k - i];
+        t[k - NL] = (uint32_t)acc & LMASK;
+        acc >>= LB;
+    }
+    t[NL - 1] = (uint32_t)acc;
+#pragma unroll
+    for (int i = 0; i < NL; i++) r.l[i] = t[i];
+    CHK(chk_set_N(r, 1.0 + (a.vb * b.vb + c.vb * d.vb) / 33554432.0); chk_actual(r);)
+}
+
 // r = a^2 / 2^406 mod p.  105 + 196 v_mad_u64_u32.  Precondition: a in N.
 FD void fp_sqr(Fp &r, const Fp &a) {
     BLS29_DECL_P;
@@ -325,6 +369,11 @@ template <int M> FD void fsub(Fp &r, const Fp &a, const Fp &b) { fp_sub<M>(r, a,
 FD void fnorm(Fp &r, const Fp &a) { fp_norm(r, a); }
 FD void fmul(Fp &r, const Fp &a, const Fp &b) { fp_mul(r, a, b); }
 FD void fsqr(Fp &r, const Fp &a) { fp_sqr(r, a); }
+// r = a*b - c*d (class N); c has value < (M-1) p.  Base field: negate c lazily and fuse both products into one reduction.
+template <int M> FD void fmul_sub(Fp &r, const Fp &a, const Fp &b, const Fp &c, const Fp &d) {
+    Fp z, cn; fp_zero(z); fp_sub<M>(cn, z, c); fp_norm(cn, cn);
+    fp_mul2(r, a, b, cn, d);
+}
 FD bool fmaybe_zero(const Fp &a) { return fp_maybe_zero(a); }
 FD bool fis_zero_exact(const Fp &a) { return fp_is_zero_exact(a); }
 

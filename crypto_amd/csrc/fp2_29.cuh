@@ -47,6 +47,10 @@ FD2 void fsqr(Fp2 &r, const Fp2 &a) {
     fp_mul(r.c0, s, d);
     fp_add(r.c1, t, t); fp_norm(r.c1, r.c1);
 }
+// r = a*b - c*d (class N): two products and a lazy subtraction (no fused form over Fp2 yet)
+template <int M> FD void fmul_sub(Fp2 &r, const Fp2 &a, const Fp2 &b, const Fp2 &c, const Fp2 &d) {
+    Fp2 t, u; fmul(t, a, b); fmul(u, c, d); fsub<8>(t, t, u); fnorm(r, t);
+}
 // multiply both components by a base-field element (Miller loop line evaluation)
 FD void fmul_fp(Fp2 &r, const Fp2 &a, const Fp &k) { fp_mul(r.c0, a.c0, k); fp_mul(r.c1, a.c1, k); }
 // (a0 + a1 u)(1 + u) = (a0 - a1) + (a0 + a1) u

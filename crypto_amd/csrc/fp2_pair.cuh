@@ -75,6 +75,9 @@ __device__ __forceinline__ void fsqr(Fp2H &r, const Fp2H &a) {
     sel(r.v, odd, p2, p);
 }
 
+template <int M> __device__ __forceinline__ void fmul_sub(Fp2H &r, const Fp2H &a, const Fp2H &b, const Fp2H &c, const Fp2H &d) {
+    Fp2H t, u; fmul(t, a, b); fmul(u, c, d); fsub<8>(t, t, u); fnorm(r, t);
+}
 // ---- helpers used by the Miller-loop line functions (pairing29.cuh), lane-pair versions ----
 template <int M> __device__ __forceinline__ void f2_sqr_m(Fp2H &r, const Fp2H &a) {
     const bool odd = pair_odd();
@@ -109,6 +112,7 @@ template <> struct SubM<Fp2H> {     // same value budgets as the one-lane Fp2 fo
     static constexpr int X = 16;
     static constexpr int D = 32;
     static constexpr int Y = 8;
+    static constexpr int YN = 16;
     static constexpr int NEG = 4;
 };
 

@@ -159,7 +159,7 @@ def main():
             except Exception:
                 pass
         # integer-throughput view of the same kernel (the path is VALU-bound, SURVEY.md 8d honesty note)
-        mads_per_term_window = 8 * 392 + 2 * 301
+        mads_per_term_window = 6 * 392 + 588 + 2 * 301     # mixed add: 6 products, one fused two-product reduction, 2 squares
         out = {
             "metric": "BLS12-381 G1 MSM/s at n=2^20 (1 GPU) and n=2^24 (8 GPU); bit-exact vs CPU",
             "value": round(value, 3), "unit": "MSM/s (n=2^20-term equivalents, whole job)",

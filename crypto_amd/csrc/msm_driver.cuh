@@ -163,7 +163,7 @@ int32_t prep_bases(Slot &sl, const uint64_t *h_bases, const uint8_t *h_inf, size
 
 template <class C, class HF>
 int32_t msm_oneshot(const uint64_t *bases, const uint8_t *is_inf, const uint64_t *scalars, size_t n, bool mont, uint64_t *out) {
-    if (!out || (n && (!bases || !scalars))) return DGPU_E_BADARG;
+    if (!out || (n && (!bases || !scalars)) || n >= (1ull << 31)) return DGPU_E_BADARG;
     if (n < g.min_gpu_n) return DGPU_E_TOO_SMALL;
     if (!g.ready) return DGPU_E_NODEVICE;
     SlotLock L; Slot &sl = *L.s;
@@ -180,7 +180,7 @@ int32_t msm_oneshot(const uint64_t *bases, const uint8_t *is_inf, const uint64_t
 
 template <class C>
 int32_t bases_upload(const uint64_t *bases, const uint8_t *is_inf, size_t n, uint64_t *handle, int kind) {
-    if (!handle || (n && !bases)) return DGPU_E_BADARG;
+    if (!handle || (n && !bases) || n >= (1ull << 31)) return DGPU_E_BADARG;
     if (!g.ready) return DGPU_E_NODEVICE;
     void *p = nullptr;
     {

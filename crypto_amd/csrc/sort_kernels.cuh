@@ -26,7 +26,7 @@ __global__ void __launch_bounds__(256) k_digit_codes(const uint32_t *__restrict_
     if (!skip) {
         const uint4 *p = reinterpret_cast<const uint4 *>(scalars + i * 8);
         uint4 a = p[0], b = p[1];
-        s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w; s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w;
+        s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w; s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w & 0x7fffffffu;   // Fr::MODULUS_BIT_SIZE = 255: bit 255 is not part of a scalar
     }
     const uint32_t B = 1u << (c - 1);
     uint32_t carry = 0;

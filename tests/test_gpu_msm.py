@@ -107,6 +107,24 @@ def test_edge_cases_g1():
     assert not got[12:].any()
 
 
+def test_degenerate_inputs():
+    G, curve = O.G1, ca.G1
+    bases, _, _ = U.seq_bases(G, 64, 11)
+    sc = O.rand_scalars(12, 64)
+    ident = normalised(G, G.msm(bases[:0], sc[:0]))
+    # every base is the identity / every scalar is zero -> identity (Z == 0), no term reaches a bucket
+    assert (ca.msm_bigint(curve, bases, sc, np.ones(64, np.uint8)) == ident).all()
+    assert (ca.msm_bigint(curve, np.zeros_like(bases), sc) == ident).all()
+    assert (ca.msm_bigint(curve, bases, np.zeros_like(sc)) == ident).all()
+    # bit 255 is not part of a scalar (Fr::MODULUS_BIT_SIZE = 255): it is ignored, like arkworks' digit extraction
+    hi = sc.copy(); hi[:, 3] |= np.uint64(1 << 63)
+    assert (ca.msm_bigint(curve, bases, hi) == ca.msm_bigint(curve, bases, sc)).all()
+    # n >= 2^31 is refused before anything is allocated
+    out = np.zeros(18, np.uint64)
+    rc = lib().dgpu_msm_g1(bases.ctypes.data_as(C.c_void_p), None, sc.ctypes.data_as(C.c_void_p), 1 << 31, out.ctypes.data_as(C.c_void_p))
+    assert rc == -3
+
+
 def test_truncation_and_handles():
     G, curve = O.G1, ca.G1
     bases, _, _ = U.seq_bases(G, 300, 77)

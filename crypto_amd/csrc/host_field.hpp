@@ -127,7 +127,30 @@ struct Fq12 {
         Fq6 t0 = c0 * b.c0, t1 = c1 * b.c1;
         return {t0 + t1.mul_v(), (c0 + c1) * (b.c0 + b.c1) - t0 - t1};
     }
-    Fq12 sqr() const { return (*this) * (*this); }
+    // complex squaring: (c0 + c1 w)^2 = (c0 + c1)(c0 + v c1) - c0 c1 - v c0 c1  +  2 c0 c1 w      (2 Fq6 products instead of 3)
+    Fq12 sqr() const {
+        Fq6 ab = c0 * c1;
+        Fq6 t = (c0 + c1) * (c0 + c1.mul_v());
+        return {t - ab - ab.mul_v(), ab + ab};
+    }
+    // Granger-Scott squaring for elements of the cyclotomic subgroup (after the easy part of the final exponentiation):
+    // with Fq4 = Fq2[s]/(s^2 - xi), sq4(a, b) = (a^2 + xi b^2, 2ab); 9 Fq2 squarings instead of 12 Fq2 products
+    Fq12 cyclotomic_sqr() const {
+        const Fq2 &z0 = c0.c0, &z4 = c0.c1, &z3 = c0.c2, &z2 = c1.c0, &z1 = c1.c1, &z5 = c1.c2;
+        auto sq4 = [](const Fq2 &a, const Fq2 &b, Fq2 &r0, Fq2 &r1) { Fq2 a2 = a.sqr(), b2 = b.sqr(); r0 = a2 + b2.mul_xi(); r1 = (a + b).sqr() - a2 - b2; };
+        Fq2 t0, t1, t2, t3, t4, t5;
+        sq4(z0, z1, t0, t1); sq4(z2, z3, t2, t3); sq4(z4, z5, t4, t5);
+        auto three_minus_two = [](const Fq2 &t, const Fq2 &z) { Fq2 d = t - z; return d + d + t; };   // 3t - 2z
+        auto three_plus_two = [](const Fq2 &t, const Fq2 &z) { Fq2 d = t + z; return d + d + t; };    // 3t + 2z
+        Fq12 r;
+        r.c0.c0 = three_minus_two(t0, z0);
+        r.c0.c1 = three_minus_two(t2, z4);
+        r.c0.c2 = three_minus_two(t4, z3);
+        r.c1.c0 = three_plus_two(t5.mul_xi(), z2);
+        r.c1.c1 = three_plus_two(t1, z1);
+        r.c1.c2 = three_plus_two(t3, z5);
+        return r;
+    }
     Fq12 conj() const { return {c0, c1.neg()}; }
     Fq12 inv() const { Fq6 n = (c0 * c0 - (c1 * c1).mul_v()).inv(); return {c0 * n, (c1 * n).neg()}; }
 };
@@ -156,7 +179,7 @@ inline Fq12 frob2(const Fq12 &a) {
 constexpr uint64_t BLS_X_ABS = 0xd201000000010000ULL;   // |x|, x < 0
 inline Fq12 exp_by_x(const Fq12 &a) {
     Fq12 acc = Fq12::one();
-    for (int i = 63; i >= 0; i--) { acc = acc.sqr(); if ((BLS_X_ABS >> i) & 1) acc = acc * a; }
+    for (int i = 63; i >= 0; i--) { acc = acc.cyclotomic_sqr(); if ((BLS_X_ABS >> i) & 1) acc = acc * a; }   // a is in the cyclotomic subgroup
     return acc.conj();
 }
 // ark-ec Bls12::final_exponentiation: easy part, then the x-chain that raises to 3 (p^4 - p^2 + 1)/r
@@ -164,7 +187,7 @@ inline bool final_exponentiation(Fq12 &out, const Fq12 &f) {
     if (f.is_zero()) return false;
     Fq12 f1 = f.conj(), f2 = f.inv(), r = f1 * f2; f2 = r;
     r = frob2(r) * f2;
-    Fq12 y0 = r.sqr(), y1 = exp_by_x(r), y2 = r.conj();
+    Fq12 y0 = r.cyclotomic_sqr(), y1 = exp_by_x(r), y2 = r.conj();
     y1 = y1 * y2; y2 = exp_by_x(y1); y1 = y1.conj(); y1 = y1 * y2;
     y2 = exp_by_x(y1); y1 = frob1(y1); y1 = y1 * y2; r = r * y0;
     y0 = exp_by_x(y1); y2 = exp_by_x(y0); y0 = frob2(y1); y1 = y1.conj();

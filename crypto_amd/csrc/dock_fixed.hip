@@ -1,0 +1,123 @@
+// crypto_amd/csrc/dock_fixed.hip — fixed-base batch multiplication entry points of include/dock_gpu.h
+// (WindowTable of utils/src/msm.rs:8-62; FixedBase::msm of legogroth16/src/generator.rs:335-399).
+#include "msm_driver.cuh"
+#include "fixed_launch.cuh"
+using namespace dock;
+
+namespace {
+
+// 2^(8k) * B for k < 32 in affine ABI form: 248 doublings and ONE field inversion on the host (the chain is serial; a GPU lane would take ~3 ms)
+template <class HF> void window_bases_host(const uint64_t *base_abi, uint64_t *out_abi) {
+    constexpr int NW = 32;
+    constexpr size_t FW64 = sizeof(HF) / 8;
+    hostf::HXyzz<HF> P; memcpy(&P.x, base_abi, sizeof(HF)); memcpy(&P.y, base_abi + FW64, sizeof(HF));
+    P.zz = HF::one(); P.zzz = HF::one(); P.inf = false;
+    std::vector<hostf::HXyzz<HF>> B(NW);
+    for (int k = 0; k < NW; k++) { B[k] = P; if (k + 1 < NW) for (int j = 0; j < 8; j++) P.dbl_in_place(); }
+    // Montgomery's trick over the ZZZ coordinates
+    std::vector<HF> pre(NW); HF acc = HF::one();
+    for (int k = 0; k < NW; k++) { pre[k] = acc; acc = acc * B[k].zzz; }
+    HF inv = acc.inv();
+    for (int k = NW - 1; k >= 0; k--) {
+        HF i3 = inv * pre[k]; inv = inv * B[k].zzz;
+        HF t = B[k].zz * i3, i2 = t * t;
+        HF x = B[k].x * i2, y = B[k].y * i3;
+        memcpy(out_abi + (size_t)k * 2 * FW64, &x, sizeof(HF)); memcpy(out_abi + (size_t)k * 2 * FW64 + FW64, &y, sizeof(HF));
+    }
+}
+
+template <class C, class HF> int32_t table_build(const uint64_t *base, uint64_t *handle, int kind) {
+    if (!base || !handle) return DGPU_E_BADARG;
+    if (!g.ready) return DGPU_E_NODEVICE;
+    constexpr size_t W64 = C::ABI_W;                     // u64 words per affine point (2 coordinates x ABI_W u32)
+    uint64_t any = 0; for (size_t k = 0; k < W64; k++) any |= base[k];
+    std::vector<uint64_t> wb(32 * W64, 0);
+    if (any) window_bases_host<HF>(base, wb.data());     // identity base: all-zero records -> flagged as identity by k_prep_bases
+    void *tab = nullptr;
+    {
+        SlotLock L; Slot &sl = *L.s;
+        HIPCHK(hipSetDevice(g.device));
+        int32_t rc;
+        if ((rc = sl.prepped.ensure(32 * C::AFF_STRIDE * 4))) return rc;
+        if (hipMalloc(&tab, (size_t)msm::FIXED_TABLE_ENTRIES * C::AFF_STRIDE * 4) != hipSuccess) { (void)hipGetLastError(); return DGPU_E_OOM; }
+        rc = prep_bases<C>(sl, wb.data(), nullptr, 32, sl.prepped.as<uint32_t>());
+        if (rc == DGPU_OK) {
+            StageTimer st(sl, "fixed.table");
+            msm::launch_fb_table<C>(sl.stream, sl.prepped.as<uint32_t>(), (uint32_t *)tab);
+        }
+        if (rc == DGPU_OK && (hipGetLastError() != hipSuccess || hipStreamSynchronize(sl.stream) != hipSuccess)) rc = DGPU_E_HIP;
+        if (g.prof) prof_flush(sl);
+        if (rc) { (void)hipFree(tab); return rc; }
+    }
+    std::lock_guard<std::mutex> lk(g.mu);
+    uint64_t h = g.next_handle++;
+    g.handles[h] = Handle{tab, (size_t)msm::FIXED_TABLE_ENTRIES, kind};
+    *handle = h;
+    return DGPU_OK;
+}
+
+// out / out_inf: host arrays, or (bases_handle != nullptr) the products stay in HBM as an MSM bases handle
+template <class C> int32_t table_mul(uint64_t table, const uint64_t *scalars, size_t n, int32_t mont, uint64_t *out, uint8_t *out_inf, int kind, uint64_t *bases_handle = nullptr) {
+    if ((n && !scalars) || (!bases_handle && n && (!out || !out_inf)) || n >= (1ull << 31)) return DGPU_E_BADARG;
+    if (!g.ready) return DGPU_E_NODEVICE;
+    Handle ht;
+    if (!lookup_handle(table, ht) || ht.kind != kind) return DGPU_E_BADARG;
+    if (n == 0 && !bases_handle) return DGPU_OK;
+    void *keep = nullptr;
+    {
+    SlotLock L; Slot &sl = *L.s;
+    HIPCHK(hipSetDevice(g.device));
+    int32_t rc;
+    const size_t pt_bytes = 2 * C::ABI_W * 4;
+    if ((rc = sl.in_scalars.ensure(n * 32))) return rc;
+    if ((rc = sl.in_bases.ensure(n * pt_bytes + n))) return rc;
+    if ((rc = upload_scalars(sl, scalars, n, mont != 0, sl.in_scalars.as<uint32_t>()))) return rc;
+    uint8_t *dinf = sl.in_bases.as<uint8_t>() + n * pt_bytes;
+    { StageTimer st(sl, "fixed.mul");
+      msm::launch_fb_mul<C>(sl.stream, (const uint32_t *)ht.p, sl.in_scalars.as<uint32_t>(), n, sl.in_bases.as<uint32_t>(), dinf); }
+    HIPCHK(hipGetLastError());
+    if (bases_handle) {
+        if (hipMalloc(&keep, std::max<size_t>(n, 1) * C::AFF_STRIDE * 4) != hipSuccess) { (void)hipGetLastError(); return DGPU_E_OOM; }
+        if (n) msm::launch_prep_bases<C>(sl.stream, sl.in_bases.as<uint32_t>(), dinf, n, (uint32_t *)keep);
+    } else {
+        HIPCHK(hipMemcpyAsync(out, sl.in_bases.p, n * pt_bytes, hipMemcpyDeviceToHost, sl.stream));
+        HIPCHK(hipMemcpyAsync(out_inf, dinf, n, hipMemcpyDeviceToHost, sl.stream));
+    }
+    if (hipStreamSynchronize(sl.stream) != hipSuccess) { (void)hipGetLastError(); if (keep) (void)hipFree(keep); return DGPU_E_HIP; }
+    if (g.prof) prof_flush(sl);
+    }
+    if (bases_handle) {
+        std::lock_guard<std::mutex> lk(g.mu);
+        uint64_t h = g.next_handle++;
+        g.handles[h] = Handle{keep, n, kind - 4};      // 5 -> 1 (G1 bases), 6 -> 2 (G2 bases)
+        *bases_handle = h;
+    }
+    return DGPU_OK;
+}
+
+template <class C, class HF> int32_t fixed_base(const uint64_t *base, const uint64_t *scalars, size_t n, int32_t mont, uint64_t *out, uint8_t *out_inf, int kind) {
+    uint64_t h = 0;
+    int32_t rc = table_build<C, HF>(base, &h, kind);
+    if (rc) return rc;
+    rc = table_mul<C>(h, scalars, n, mont, out, out_inf, kind);
+    (void)dgpu_bases_free(h);
+    return rc;
+}
+
+}  // namespace
+
+extern "C" {
+int32_t dgpu_window_table_g1(const uint64_t base_xy[12], uint64_t *handle) { return table_build<G1, hostf::Fq>(base_xy, handle, 5); }
+int32_t dgpu_window_table_g2(const uint64_t base_xy[24], uint64_t *handle) { return table_build<G2, hostf::Fq2>(base_xy, handle, 6); }
+int32_t dgpu_window_table_free(uint64_t handle) {
+    Handle h;
+    if (!lookup_handle(handle, h) || (h.kind != 5 && h.kind != 6)) return DGPU_E_BADARG;
+    return dgpu_bases_free(handle);
+}
+int32_t dgpu_window_table_mul_g1(uint64_t t, const uint64_t *s, size_t n, int32_t mont, uint64_t *out, uint8_t *out_inf) { return table_mul<G1>(t, s, n, mont, out, out_inf, 5); }
+int32_t dgpu_window_table_mul_g2(uint64_t t, const uint64_t *s, size_t n, int32_t mont, uint64_t *out, uint8_t *out_inf) { return table_mul<G2>(t, s, n, mont, out, out_inf, 6); }
+int32_t dgpu_window_table_mul_to_bases_g1(uint64_t t, const uint64_t *s, size_t n, int32_t mont, uint64_t *bases) { return bases ? table_mul<G1>(t, s, n, mont, nullptr, nullptr, 5, bases) : DGPU_E_BADARG; }
+int32_t dgpu_window_table_mul_to_bases_g2(uint64_t t, const uint64_t *s, size_t n, int32_t mont, uint64_t *bases) { return bases ? table_mul<G2>(t, s, n, mont, nullptr, nullptr, 6, bases) : DGPU_E_BADARG; }
+int32_t dgpu_fixed_base_g1(const uint64_t base_xy[12], const uint64_t *s, size_t n, int32_t mont, uint64_t *out, uint8_t *out_inf) { return fixed_base<G1, hostf::Fq>(base_xy, s, n, mont, out, out_inf, 5); }
+int32_t dgpu_fixed_base_g2(const uint64_t base_xy[24], const uint64_t *s, size_t n, int32_t mont, uint64_t *out, uint8_t *out_inf) { return fixed_base<G2, hostf::Fq2>(base_xy, s, n, mont, out, out_inf, 6); }
+}  // extern "C"

@@ -1,0 +1,84 @@
+// crypto_amd/csrc/fixed_kernels.cuh — batched fixed-base scalar multiplication: out_i = s_i * B for one base B.
+//
+// Device form of ark-ec's FixedBase::{get_window_table, msm} as the reference uses them: the six query MSMs of the
+// LegoGroth16 CRS generator (legogroth16/src/generator.rs:335-399) and utils/src/msm.rs:8-62 (WindowTable::multiply_many,
+// multiply_field_elems_with_same_group_elem).  arkworks picks the window from the batch size and keeps a ragged
+// Vec<Vec<Affine>>; here the window is fixed at 8 bits so a scalar's digits are its bytes:
+//
+//   table   T[k][d-1] = d * 2^(8k) * B,  k < 32, d = 1..255, affine, 128 B (G1) / 256 B (G2) records — 1 / 2 MiB, stays in L2
+//   mul     lane i: acc = sum_k T[k][byte_k(s_i)] (<= 32 mixed XYZZ additions), then one inversion -> affine ABI form
+//
+// The result is the group element s_i * B whatever the window; outputs are compared after normalisation.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "msm_kernels.cuh"
+#include "fp_inv.cuh"
+
+namespace msm {
+
+constexpr int FB_WBITS = 8;
+constexpr int FB_NW = 32;                      // 256 bits of scalar
+constexpr int FB_ROW = (1 << FB_WBITS) - 1;    // digits 1..255
+constexpr int FB_ENTRIES = FB_NW * FB_ROW;
+
+template <class C> __device__ __forceinline__ void store_affine_abi(uint32_t *__restrict__ o, const Aff<typename C::F> &p) {
+    const Fp *c = reinterpret_cast<const Fp *>(&p);
+#pragma unroll
+    for (int k = 0; k < 2 * C::NFP; k++) fp_to_abi(o + 12 * k, c[k]);
+}
+
+// window_bases: FB_NW prepared records of 2^(8k) * B (host doubles, k_prep_bases converts)
+template <class C>
+__global__ void __launch_bounds__(64) k_fb_table(const uint32_t *__restrict__ window_bases, uint32_t *__restrict__ table) {
+    typedef typename C::F F;
+    const int e = blockIdx.x * 64 + threadIdx.x;
+    if (e >= FB_ENTRIES) return;
+    const int k = e / FB_ROW, d = e % FB_ROW + 1;
+    const uint32_t *rec = window_bases + (size_t)k * C::AFF_STRIDE;
+    uint32_t *dst = table + (size_t)e * C::AFF_STRIDE;
+    Aff<F> B; load_aff<C>(B, rec);
+    Xyzz<F> acc; bool inf = true;
+    fzero(acc.x); fzero(acc.y); fzero(acc.zz); fzero(acc.zzz);
+    if (!rec[2 * C::FW])
+        for (int b = FB_WBITS - 1; b >= 0; b--) {
+            if (!inf) { Xyzz<F> t; xyzz_dbl(t, acc); acc = t; }
+            if ((d >> b) & 1) xyzz_madd(acc, inf, B, false);
+        }
+    Aff<F> a;
+    if (inf) { fzero(a.x); fzero(a.y); } else xyzz_to_affine(a, acc);
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(&a);
+#pragma unroll
+    for (int j = 0; j < 2 * C::FW; j++) dst[j] = w[j];
+    dst[2 * C::FW] = inf ? 1u : 0u;
+}
+
+// scalars: canonical, 8 words each.  out_abi: affine x, y in the ABI form (zeros for the identity), out_inf: identity flags.
+template <class C>
+__global__ void __launch_bounds__(64) k_fb_mul(const uint32_t *__restrict__ table, const uint32_t *__restrict__ scalars, size_t n, uint32_t *__restrict__ out_abi, uint8_t *__restrict__ out_inf) {
+    typedef typename C::F F;
+    const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    uint32_t s[8];
+    { const uint4 *sp = reinterpret_cast<const uint4 *>(scalars + i * 8); uint4 a = sp[0], b = sp[1]; s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w; s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w; }
+    Xyzz<F> acc; bool inf = true;
+    fzero(acc.x); fzero(acc.y); fzero(acc.zz); fzero(acc.zzz);
+    for (int k = 0; k < FB_NW; k++) {
+        const uint32_t d = (s[k >> 2] >> (8 * (k & 3))) & 0xffu;
+        if (!d) continue;
+        const uint32_t *rec = table + (size_t)(k * FB_ROW + (int)d - 1) * C::AFF_STRIDE;
+        if (rec[2 * C::FW]) continue;
+        Aff<F> q; load_aff<C>(q, rec);
+        xyzz_madd(acc, inf, q, false);
+    }
+    uint32_t *o = out_abi + i * (2 * C::ABI_W);
+    out_inf[i] = inf ? 1 : 0;
+    if (inf) {
+#pragma unroll
+        for (int j = 0; j < 2 * C::ABI_W; j++) o[j] = 0;
+        return;
+    }
+    Aff<F> a; xyzz_to_affine(a, acc);
+    store_affine_abi<C>(o, a);
+}
+
+}  // namespace msm

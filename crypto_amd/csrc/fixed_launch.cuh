@@ -1,0 +1,11 @@
+// crypto_amd/csrc/fixed_launch.cuh — host-callable launchers of the fixed-base kernels (k_fixed.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace msm {
+constexpr int FIXED_TABLE_ENTRIES = 32 * 255;
+template <class C> void launch_fb_table(hipStream_t s, const uint32_t *window_bases, uint32_t *table);
+template <class C> void launch_fb_mul(hipStream_t s, const uint32_t *table, const uint32_t *scalars, size_t n, uint32_t *out_abi, uint8_t *out_inf);
+}  // namespace msm

@@ -1,0 +1,42 @@
+// crypto_amd/csrc/fp_inv.cuh — field inversion on the device and XYZZ -> affine.
+//
+// Only the per-element outputs need it: G::normalize_batch after FixedBase::msm (legogroth16/src/generator.rs:424-431),
+// the affine points the Miller loop consumes after RandomizedPairingChecker's scalings
+// (utils/src/randomized_pairing_check.rs:125-127).  One Fermat inversion per lane (a^(p-2), 380 squarings + ~190 products).
+#pragma once
+#include "fp29.cuh"
+#include "fp2_29.cuh"
+#include "ec29.cuh"
+
+namespace bls29 {
+
+__device__ __forceinline__ void fp_inv_device(Fp &r, const Fp &a) {
+    // exponent bits taken from the 29-bit limbs of p (p - 2 only changes limb 0: ...aaab -> ...aaa9)
+    constexpr uint32_t P_[NL] = BLS29_P;
+    Fp acc; fp_set_one(acc);
+    for (int i = NL - 1; i >= 0; i--) {
+        uint32_t w = (i == 0) ? (P_[0] - 2u) : P_[i];
+        int hi = (i == NL - 1) ? 3 : LB - 1;           // top limb of p is 0xd: 4 bits
+        for (int b = hi; b >= 0; b--) { fp_sqr(acc, acc); if ((w >> b) & 1u) fp_mul(acc, acc, a); }
+    }
+    r = acc;
+}
+__device__ __forceinline__ void finv(Fp &r, const Fp &a) { fp_inv_device(r, a); }
+// 1 / (c0 + c1 u) = (c0 - c1 u) / (c0^2 + c1^2)
+__device__ __forceinline__ void finv(Fp2 &r, const Fp2 &a) {
+    Fp n0, n1, t, ti, z;
+    fp_sqr(n0, a.c0); fp_sqr(n1, a.c1); fp_add(t, n0, n1); fp_norm(t, t);
+    fp_inv_device(ti, t);
+    fp_mul(r.c0, a.c0, ti);
+    fp_mul(n1, a.c1, ti); fp_zero(z); fp_sub<4>(r.c1, z, n1); fp_norm(r.c1, r.c1);
+}
+// (X/ZZ, Y/ZZZ) of a non-identity point, using ZZ^3 == ZZZ^2: 1/ZZ = (ZZ/ZZZ)^2
+template <class F> __device__ __forceinline__ void xyzz_to_affine(Aff<F> &r, const Xyzz<F> &a) {
+    F i3, t, i2, xn, yn;
+    finv(i3, a.zzz);
+    fmul(t, a.zz, i3); fsqr(i2, t);
+    fnorm(xn, a.x); fnorm(yn, a.y);
+    fmul(r.x, xn, i2); fmul(r.y, yn, i3);
+}
+
+}  // namespace bls29

@@ -1,0 +1,17 @@
+// crypto_amd/csrc/k_fixed.hip — translation unit of the fixed-base kernels (G1 and G2).
+#include "fixed_kernels.cuh"
+#include "fixed_launch.cuh"
+
+namespace msm {
+static_assert(FIXED_TABLE_ENTRIES == FB_ENTRIES, "table size");
+template <class C> void launch_fb_table(hipStream_t s, const uint32_t *window_bases, uint32_t *table) {
+    hipLaunchKernelGGL((k_fb_table<C>), dim3((FB_ENTRIES + 63) / 64), dim3(64), 0, s, window_bases, table);
+}
+template <class C> void launch_fb_mul(hipStream_t s, const uint32_t *table, const uint32_t *scalars, size_t n, uint32_t *out_abi, uint8_t *out_inf) {
+    hipLaunchKernelGGL((k_fb_mul<C>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, table, scalars, n, out_abi, out_inf);
+}
+template void launch_fb_table<G1>(hipStream_t, const uint32_t *, uint32_t *);
+template void launch_fb_table<G2>(hipStream_t, const uint32_t *, uint32_t *);
+template void launch_fb_mul<G1>(hipStream_t, const uint32_t *, const uint32_t *, size_t, uint32_t *, uint8_t *);
+template void launch_fb_mul<G2>(hipStream_t, const uint32_t *, const uint32_t *, size_t, uint32_t *, uint8_t *);
+}  // namespace msm

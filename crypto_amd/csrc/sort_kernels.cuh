@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include "fp29.cuh"
 #include "ec29.cuh"
+#include "fp_inv.cuh"
 
 namespace msm {
 using namespace bls29;
@@ -178,17 +179,6 @@ __global__ void k_selftest_g1_sum(const uint32_t *pts_abi, const uint8_t *neg, s
 // (utils/src/randomized_pairing_check.rs:125-127,152-158: `a.mul_bigint(m)` in a cfg_iter!); one lane per point,
 // double-and-add over the 255 scalar bits, then one Fermat inversion per lane for the affine form the line
 // evaluation needs.
-__device__ __forceinline__ void fp_inv_device(Fp &r, const Fp &a) {
-    // a^(p-2); exponent bits taken from the 29-bit limbs of p (p - 2 only changes limb 0: ...aaab -> ...aaa9)
-    constexpr uint32_t P_[NL] = BLS29_P;
-    Fp acc; fp_set_one(acc);
-    for (int i = NL - 1; i >= 0; i--) {
-        uint32_t w = (i == 0) ? (P_[0] - 2u) : P_[i];
-        int hi = (i == NL - 1) ? 3 : LB - 1;           // top limb of p is 0xd: 4 bits
-        for (int b = hi; b >= 0; b--) { fp_sqr(acc, acc); if ((w >> b) & 1u) fp_mul(acc, acc, a); }
-    }
-    r = acc;
-}
 __global__ void __launch_bounds__(64) k_g1_scale(const uint32_t *__restrict__ p_abi, const uint8_t *__restrict__ is_inf, const uint32_t *__restrict__ scalars, int scalar_stride,
                                                  const uint8_t *__restrict__ negate, size_t n, uint32_t *__restrict__ out_abi, uint8_t *__restrict__ out_inf) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

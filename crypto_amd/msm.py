@@ -121,6 +121,13 @@ class DeviceBases:
             raise DockGpuError(rc, "dgpu_bases_upload")
         self.handle = h.value
 
+    @classmethod
+    def from_handle(cls, curve, handle, n):
+        """adopt a bases handle produced on the device (WindowTable.multiply_many_to_bases)"""
+        self = cls.__new__(cls)
+        self.curve, self.handle, self.n = curve, handle, n
+        return self
+
     def msm_bigint(self, scalars, offset=0, montgomery=False):
         scalars = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
         n = min(len(scalars), self.n - offset)

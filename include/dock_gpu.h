@@ -101,6 +101,26 @@ int32_t dgpu_g1_scale_batch(const uint64_t *p_xy /* n*12 */, const uint8_t *is_i
 int32_t dgpu_fp12_mul(const uint64_t a[72], const uint64_t b[72], uint64_t out[72]);
 int32_t dgpu_fp12_pow(const uint64_t a[72], const uint64_t e[4], uint64_t out[72]);
 
+/* ---- fixed-base batch multiplication ----
+ * replaces ark-ec FixedBase::{get_window_table, msm} as the reference calls them: WindowTable::new / multiply_many and
+ * multiply_field_elems_with_same_group_elem (utils/src/msm.rs:8-62) and the six query computations of the LegoGroth16 CRS
+ * generator followed by normalize_batch (legogroth16/src/generator.rs:335-399,424-431).
+ * out_i = scalars_i * base as affine points (x, y Montgomery limbs; zeros and out_inf[i] = 1 for the identity).
+ * montgomery != 0: scalars are Fr Montgomery limbs (what &[Fr] holds), else canonical.  The table handle keeps
+ * 32 x 255 multiples of the base in device memory (1 MiB for G1, 2 MiB for G2). */
+int32_t dgpu_window_table_g1(const uint64_t base_xy[12], uint64_t *handle);
+int32_t dgpu_window_table_g2(const uint64_t base_xy[24], uint64_t *handle);
+int32_t dgpu_window_table_free(uint64_t handle);
+int32_t dgpu_window_table_mul_g1(uint64_t table, const uint64_t *scalars, size_t n, int32_t montgomery, uint64_t *out_xy /* n*12 */, uint8_t *out_inf /* n */);
+int32_t dgpu_window_table_mul_g2(uint64_t table, const uint64_t *scalars, size_t n, int32_t montgomery, uint64_t *out_xy /* n*24 */, uint8_t *out_inf /* n */);
+/* same products left in device memory as an MSM bases handle (dgpu_msm_g1/g2_handle, dgpu_bases_free): a CRS query goes
+ * from the generator to the prover without crossing PCIe */
+int32_t dgpu_window_table_mul_to_bases_g1(uint64_t table, const uint64_t *scalars, size_t n, int32_t montgomery, uint64_t *bases_handle);
+int32_t dgpu_window_table_mul_to_bases_g2(uint64_t table, const uint64_t *scalars, size_t n, int32_t montgomery, uint64_t *bases_handle);
+/* table + multiply + free in one call */
+int32_t dgpu_fixed_base_g1(const uint64_t base_xy[12], const uint64_t *scalars, size_t n, int32_t montgomery, uint64_t *out_xy, uint8_t *out_inf);
+int32_t dgpu_fixed_base_g2(const uint64_t base_xy[24], const uint64_t *scalars, size_t n, int32_t montgomery, uint64_t *out_xy, uint8_t *out_inf);
+
 /* ---- R1CS -> QAP witness map ----
  * replaces LibsnarkReduction::witness_map_from_matrices (legogroth16/src/r1cs_to_qap.rs:150-210): h = ((A z)(B z) - C z) / Z_D as the
  * D = next_pow2(num_constraints + num_inputs) coefficients the prover pairs with h_query (legogroth16/src/prover.rs:281-286).

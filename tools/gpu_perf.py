@@ -88,3 +88,13 @@ if "qap" in what:
         mats = [(a_rp, a_cl, a_vl), (b_rp, b_cl, b_vl), (c_rp, c_cl, c_vl)]
         dt, s = stages(lambda: qap.witness_map(*mats, z, 2, m + 1, to_host=False, resident=False) if False else qap.witness_map(*mats, z, 2, m + 1), K=3)
         print("witness map m=2^%d-2 (D=2^%d): %.2f ms | %s" % (lg, lg, dt * 1e3, s), flush=True)
+if "fb" in what:
+    from crypto_amd import fixed_base as fb
+    for cv, grp, lgs in ((ca.G1, O.G1, (10, 16, 20)), (ca.G2, O.G2, (10, 16, 18))):
+        t0 = time.time(); tab = fb.WindowTable(cv, grp.generator()); tb = time.time() - t0
+        t0 = time.time(); tab2 = fb.WindowTable(cv, grp.generator()); tb2 = time.time() - t0; tab2.free()
+        for lg in lgs:
+            n = 1 << lg; sc = O.rand_scalars(5, n)
+            dt, s = stages(lambda: tab.multiply_many(sc), K=3)
+            print("fixed-base %s n=2^%d %.3f ms (%.2f M mul/s) | %s | table build %.2f / %.2f ms" % (cv.tag, lg, dt * 1e3, n / dt / 1e6, s, tb * 1e3, tb2 * 1e3), flush=True)
+        tab.free()

@@ -65,6 +65,16 @@ class ProvingKey:
         self.h_query = M.DeviceBases(M.G1, h_query)
         self.l_query = M.DeviceBases(M.G1, l_query)
 
+    @classmethod
+    def from_device(cls, vk, beta_g1, delta_g1, eta_delta_inv_g1, a0, b1_0, b2_0, a_query, b_g1_query, b_g2_query, h_query, l_query):
+        """queries already resident (DeviceBases produced by the generator); a0 / b1_0 / b2_0 = query[0] on the host"""
+        self = cls.__new__(cls)
+        self.vk = vk
+        self.beta_g1, self.delta_g1, self.eta_delta_inv_g1 = beta_g1, delta_g1, eta_delta_inv_g1
+        self.a0, self.b1_0, self.b2_0 = a0, b1_0, b2_0
+        self.a_query, self.b_g1_query, self.b_g2_query, self.h_query, self.l_query = a_query, b_g1_query, b_g2_query, h_query, l_query
+        return self
+
 
 class VerifyingKey:
     def __init__(self, alpha_g1, beta_g2, gamma_g2, delta_g2, gamma_abc_g1, eta_gamma_inv_g1, commit_witness_count):
@@ -72,6 +82,80 @@ class VerifyingKey:
         self.gamma_abc_g1 = np.asarray(gamma_abc_g1, dtype=np.uint64).reshape(-1, 12)
         self.eta_gamma_inv_g1 = eta_gamma_inv_g1
         self.commit_witness_count = commit_witness_count
+
+
+def evaluate_all_lagrange_coefficients(D, omega, t):
+    """ark-poly Radix2EvaluationDomain::evaluate_all_lagrange_coefficients for t outside the domain:
+    u_i = Z(t) w^i / (D (t - w^i)),  one batch inversion"""
+    zt = (pow(t, D, R_MOD) - 1) % R_MOD
+    ws, w = [], 1
+    for _ in range(D):
+        ws.append(w); w = w * omega % R_MOD
+    den = [(t - x) % R_MOD for x in ws]
+    pre, acc = [], 1
+    for x in den:
+        pre.append(acc); acc = acc * x % R_MOD
+    inv = pow(acc, R_MOD - 2, R_MOD)
+    k = zt * pow(D, R_MOD - 2, R_MOD) % R_MOD
+    u = [0] * D
+    for i in range(D - 1, -1, -1):
+        u[i] = inv * pre[i] % R_MOD * ws[i] % R_MOD * k % R_MOD
+        inv = inv * den[i] % R_MOD
+    return u, zt
+
+
+def instance_map_with_evaluation(A, B, C, num_instance_variables, num_witness_variables, t):
+    """LibsnarkReduction::instance_map_with_evaluation (legogroth16/src/r1cs_to_qap.rs:105-147).
+    A, B, C: one list of (coeff, variable index) per constraint.  Returns (a, b, c, zt, qap_num_variables, domain_size)."""
+    num_constraints = len(A)
+    D = 1
+    while D < num_constraints + num_instance_variables:
+        D *= 2
+    omega = pow(7, (R_MOD - 1) // D, R_MOD)     # Fr::GENERATOR = 7
+    u, zt = evaluate_all_lagrange_coefficients(D, omega, t)
+    V = (num_instance_variables - 1) + num_witness_variables
+    a, b, c = [0] * (V + 1), [0] * (V + 1), [0] * (V + 1)
+    for j in range(num_instance_variables):
+        a[j] = u[num_constraints + j]
+    for i in range(num_constraints):
+        ui = u[i]
+        for co, idx in A[i]: a[idx] = (a[idx] + ui * co) % R_MOD
+        for co, idx in B[i]: b[idx] = (b[idx] + ui * co) % R_MOD
+        for co, idx in C[i]: c[idx] = (c[idx] + ui * co) % R_MOD
+    return a, b, c, zt, V, D
+
+
+def generate_parameters(A, B, C, num_instance_variables, num_witness_variables, commit_witness_count,
+                        alpha, beta, gamma, delta, eta, t, g1_generator, g2_generator):
+    """generate_parameters_and_extra_info_with_qap (legogroth16/src/generator.rs:245-442) with the toxic waste and the
+    evaluation point `t` passed in (the reference draws them from `rng`, :220-232, :283).  Scalars are host integers as in
+    the reference (rayon field arithmetic); every FixedBase::msm + normalize_batch (:335-399,424-431) is one device
+    WindowTable product whose output stays in HBM as the prover's bases handle."""
+    from . import fixed_base as FB
+    if num_witness_variables < commit_witness_count:
+        raise ValueError("InsufficientWitnessesForCommitment(%d, %d)" % (num_witness_variables, commit_witness_count))   # generator.rs:289-294
+    a, b, c, zt, V, D = instance_map_with_evaluation(A, B, C, num_instance_variables, num_witness_variables, t)
+    n = num_instance_variables + commit_witness_count
+    gi, di = pow(gamma, R_MOD - 2, R_MOD), pow(delta, R_MOD - 2, R_MOD)
+    mix = [(beta * x + alpha * y + z) % R_MOD for x, y, z in zip(a, b, c)]
+    gamma_abc = [m * gi % R_MOD for m in mix[:n]]                       # :316-320
+    l = [m * di % R_MOD for m in mix]                                    # :322-326
+    hq, k = [], zt * di % R_MOD                                          # r1cs_to_qap.rs:212-223, max_power = m_raw - 1
+    for _ in range(D - 1):
+        hq.append(k); k = k * t % R_MOD
+    with FB.WindowTable(M.G2, g2_generator) as t2, FB.WindowTable(M.G1, g1_generator) as t1:
+        b_g2_query = t2.multiply_many_to_bases(b)                        # :337-339
+        small2, _ = t2.multiply_many([beta, delta, gamma, b[0]])         # :351,353,405 + query[0] for calculate_coeff
+        a_query = t1.multiply_many_to_bases(a)                           # :357
+        b_g1_query = t1.multiply_many_to_bases(b)                        # :363
+        h_query = t1.multiply_many_to_bases(hq)                          # :369-376
+        l_query = t1.multiply_many_to_bases(l[n:])                       # :382
+        gamma_abc_g1, _ = t1.multiply_many(gamma_abc)                    # :406
+        small1, _ = t1.multiply_many([alpha, beta, delta, eta * gi % R_MOD, eta * di % R_MOD, a[0], b[0]])   # :349-352,411,433
+    vk = VerifyingKey(small1[0], small2[0], small2[2], small2[1], gamma_abc_g1, small1[3], commit_witness_count)
+    pk = ProvingKey.from_device(vk, small1[1], small1[2], small1[4], small1[5], small1[6], small2[3],
+                                a_query, b_g1_query, b_g2_query, h_query, l_query)
+    return pk, num_instance_variables
 
 
 def _calculate_coeff(curve, initial_point, initial_scalar, query_handle, query0, vk_param, assignment):

@@ -66,6 +66,7 @@ def setup(cs, commit_witness_count, seed=1):
         "a_query": np.stack([g1(x) for x in a]), "b_g1_query": np.stack([g1(x) for x in b]), "b_g2_query": np.stack([g2(x) for x in b]),
         "h_query": np.stack([g1(x) for x in hq]), "l_query": np.stack([g1(x) for x in l[n:]]),
         "commit_witness_count": commit_witness_count, "D": D,
+        "_waste": {"alpha": alpha, "beta": beta, "gamma": gamma, "delta": delta, "eta": eta, "t": t, "k1": k1, "k2": k2},
     }
     return key
 

@@ -68,3 +68,37 @@ def test_prove_verify_roundtrip(m, cw):
     # r == 0 skips the G1 copy of B (prover.rs:330)
     proof0 = LG.create_proof(pk, 0, s, v, LS.scalars(h), inp, wit)
     assert LG.verify_proof(pvk, proof0, inp[1:])
+
+
+@pytest.mark.parametrize("m,cw", [(20, 2), (200, 3)])
+def test_generator_matches_oracle_setup(m, cw):
+    """generate_parameters (device fixed-base products) == the oracle's setup for the same toxic waste, element by element;
+    the generated key then proves and verifies (generator.rs:245-442; tests.rs:149-180 uses the generated key the same way)."""
+    from crypto_amd import qap
+    cs = LS.circuit(m, x0=11)
+    key = LS.setup(cs, cw, seed=1000 + m)
+    w = key["_waste"]
+    g1 = O.G1.to_affine(O.G1.mul(O.G1.generator(), O.int_to_limbs(w["k1"], 4)))[0]
+    g2 = O.G2.to_affine(O.G2.mul(O.G2.generator(), O.int_to_limbs(w["k2"], 4)))[0]
+    pk, n_inst = LG.generate_parameters(cs["A"], cs["B"], cs["C"], cs["n_inst"], cs["n_wit"], cw,
+                                        w["alpha"], w["beta"], w["gamma"], w["delta"], w["eta"], w["t"], g1, g2)
+    assert n_inst == cs["n_inst"]
+    vk = pk.vk
+    for name in ("alpha_g1", "beta_g2", "gamma_g2", "delta_g2", "eta_gamma_inv_g1"):
+        assert (getattr(vk, name) == key[name]).all(), name
+    assert (vk.gamma_abc_g1 == key["gamma_abc_g1"]).all()
+    for name in ("beta_g1", "delta_g1", "eta_delta_inv_g1"):
+        assert (getattr(pk, name) == key[name]).all(), name
+    assert (pk.a0 == key["a_query"][0]).all() and (pk.b1_0 == key["b_g1_query"][0]).all() and (pk.b2_0 == key["b_g2_query"][0]).all()
+    # resident queries: same group elements as the oracle's arrays (random linear combination of all entries)
+    for name, cv in (("a_query", ca.G1), ("b_g1_query", ca.G1), ("b_g2_query", ca.G2), ("h_query", ca.G1), ("l_query", ca.G1)):
+        db = getattr(pk, name)
+        assert db.n == len(key[name]), name
+        rs = O.rand_scalars(77, db.n)
+        inf = np.array([0 if row.any() else 1 for row in key[name]], dtype=np.uint8)
+        assert (db.msm_bigint(rs) == ca.msm_bigint(cv, key[name], rs, is_inf=inf)).all(), name
+    z = cs["z"]
+    inp, wit = LS.scalars(z[:cs["n_inst"]]), LS.scalars(z[cs["n_inst"]:])
+    h = LS.scalars(LS.witness_map(cs))
+    proof = LG.create_proof(pk, 12345, 67890, 13579, h, inp, wit)
+    assert LG.verify_proof(LG.prepare_verifying_key(vk), proof, inp[1:])

@@ -1,0 +1,99 @@
+"""Group / GT / serialization helpers shared by the aggregation modules (thin wrappers over the C ABI)."""
+import ctypes as C
+import numpy as np
+from .._native import lib, DockGpuError
+import importlib
+M = importlib.import_module(__package__.rsplit(".", 1)[0] + ".msm")
+from .. import pairing, serde
+from ..pairing_check import fp12_mul, fp12_pow, fp12_one   # noqa: F401
+
+R_MOD = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+P_MOD = 0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB
+_FP_RINV = pow(1 << 384, -1, P_MOD)
+G1, G2 = M.G1, M.G2
+
+
+def inv(a):
+    return pow(a % R_MOD, R_MOD - 2, R_MOD)
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def limbs(vals):
+    """ints -> (n, 4) uint64 canonical limbs"""
+    return np.array([[(int(v) % R_MOD >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)] for v in vals], dtype=np.uint64).reshape(-1, 4)
+
+
+def pts(curve, a):
+    return np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, curve.AW)
+
+
+def mul_add(curve, points, scalars, addend=None):
+    """[addend_i + s_i * P_i] affine; `scalars`: one int (same for all) or a list of ints"""
+    M._ensure()
+    P = pts(curve, points)
+    n = len(P)
+    out = np.zeros((n, curve.AW), dtype=np.uint64)
+    if n == 0:
+        return out
+    inf = np.zeros(n, dtype=np.uint8)
+    if isinstance(scalars, int):
+        sc, stride = limbs([scalars]), 0
+    else:
+        sc, stride = limbs(scalars), 4
+        if len(sc) != n:
+            raise ValueError("scalar count")
+    A = None if addend is None else pts(curve, addend)
+    fn = lib().dgpu_g1_mul_add_batch if curve is G1 else lib().dgpu_g2_mul_add_batch
+    rc = fn(_p(P), None, _p(sc), stride, _p(A), None, n, _p(out), _p(inf))
+    if rc:
+        raise DockGpuError(rc, "dgpu_mul_add_batch")
+    return out
+
+
+def msm(curve, points, scalars):
+    """sum s_i P_i as an affine ABI point (identity: zero words)"""
+    P = pts(curve, points)
+    jac = M.msm_bigint(curve, P, limbs(scalars))
+    return np.zeros(curve.AW, dtype=np.uint64) if not jac[curve.AW:].any() else jac[:curve.AW].copy()
+
+
+def neg(curve, pt):
+    pt = np.array(pt, dtype=np.uint64).reshape(curve.AW)
+    if not pt.any():
+        return pt
+    h = curve.AW // 2
+    for k in range(h // 6):
+        y = sum(int(x) << (64 * i) for i, x in enumerate(pt[h + 6 * k:h + 6 * k + 6]))
+        y = (P_MOD - y) % P_MOD
+        pt[h + 6 * k:h + 6 * k + 6] = [(y >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(6)]
+    return pt
+
+
+def multi_pairing(ps, qs):
+    return pairing.multi_pairing(pts(G1, ps), pts(G2, qs))
+
+
+# ---- serialize_compressed of the transcript elements -----------------------------------------------------------------
+def fr_bytes(v):
+    return (int(v) % R_MOD).to_bytes(32, "little")
+
+
+def g1_bytes(pt):
+    return bytes(serde.serialize(G1, pts(G1, pt)))
+
+
+def g2_bytes(pt):
+    return bytes(serde.serialize(G2, pts(G2, pt)))
+
+
+def gt_bytes(f):
+    """PairingOutput / Fp12: twelve Fp, c0.c0.c0 first, each 48 bytes little-endian canonical"""
+    f = np.asarray(f, dtype=np.uint64).reshape(12, 6)
+    out = bytearray()
+    for row in f:
+        v = sum(int(x) << (64 * i) for i, x in enumerate(row)) * _FP_RINV % P_MOD
+        out += v.to_bytes(48, "little")
+    return bytes(out)

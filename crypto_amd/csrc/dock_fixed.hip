@@ -104,9 +104,48 @@ template <class C, class HF> int32_t fixed_base(const uint64_t *base, const uint
     return rc;
 }
 
+// out_i = addend_i + s_i * P_i
+template <class C> int32_t mul_add(const uint64_t *p, const uint8_t *p_inf, const uint64_t *scalars, size_t scalar_stride, const uint64_t *addend, const uint8_t *add_inf, size_t n, uint64_t *out, uint8_t *out_inf) {
+    if ((n && (!p || !scalars || !out || !out_inf)) || (scalar_stride != 0 && scalar_stride != 4) || (add_inf && !addend) || n >= (1ull << 31)) return DGPU_E_BADARG;
+    if (n == 0) return DGPU_OK;
+    if (!g.ready) return DGPU_E_NODEVICE;
+    SlotLock L; Slot &sl = *L.s;
+    HIPCHK(hipSetDevice(g.device));
+    int32_t rc;
+    const size_t pt = 2 * C::ABI_W * 4, nsc = scalar_stride ? n : 1;
+    // in_bases: [points | addends], prepped: [out | out_inf], in_inf: [p_inf | add_inf]
+    if ((rc = sl.in_bases.ensure(2 * n * pt))) return rc;
+    if ((rc = sl.in_scalars.ensure(nsc * 32))) return rc;
+    if ((rc = sl.in_inf.ensure(2 * n))) return rc;
+    if ((rc = sl.prepped.ensure(n * pt + n))) return rc;
+    hipStream_t s = sl.stream;
+    uint8_t *dp = sl.in_bases.as<uint8_t>();
+    HIPCHK(hipMemcpyAsync(dp, p, n * pt, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(sl.in_scalars.p, scalars, nsc * 32, hipMemcpyHostToDevice, s));
+    const uint32_t *dadd = nullptr; const uint8_t *dpinf = nullptr, *dainf = nullptr;
+    if (addend) { HIPCHK(hipMemcpyAsync(dp + n * pt, addend, n * pt, hipMemcpyHostToDevice, s)); dadd = (const uint32_t *)(dp + n * pt); }
+    if (p_inf) { HIPCHK(hipMemcpyAsync(sl.in_inf.p, p_inf, n, hipMemcpyHostToDevice, s)); dpinf = sl.in_inf.as<uint8_t>(); }
+    if (add_inf) { HIPCHK(hipMemcpyAsync(sl.in_inf.as<uint8_t>() + n, add_inf, n, hipMemcpyHostToDevice, s)); dainf = sl.in_inf.as<uint8_t>() + n; }
+    uint8_t *dout_inf = sl.prepped.as<uint8_t>() + n * pt;
+    { StageTimer st(sl, "fixed.mul_add");
+      msm::launch_mul_add<C>(s, (const uint32_t *)dp, dpinf, sl.in_scalars.as<uint32_t>(), (int)(scalar_stride * 2), dadd, dainf, n, sl.prepped.as<uint32_t>(), dout_inf); }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, sl.prepped.p, n * pt, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(out_inf, dout_inf, n, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (g.prof) prof_flush(sl);
+    return DGPU_OK;
+}
+
 }  // namespace
 
 extern "C" {
+int32_t dgpu_g1_mul_add_batch(const uint64_t *p, const uint8_t *p_inf, const uint64_t *sc, size_t stride, const uint64_t *add, const uint8_t *add_inf, size_t n, uint64_t *out, uint8_t *out_inf) {
+    return mul_add<G1>(p, p_inf, sc, stride, add, add_inf, n, out, out_inf);
+}
+int32_t dgpu_g2_mul_add_batch(const uint64_t *p, const uint8_t *p_inf, const uint64_t *sc, size_t stride, const uint64_t *add, const uint8_t *add_inf, size_t n, uint64_t *out, uint8_t *out_inf) {
+    return mul_add<G2>(p, p_inf, sc, stride, add, add_inf, n, out, out_inf);
+}
 int32_t dgpu_window_table_g1(const uint64_t base_xy[12], uint64_t *handle) { return table_build<G1, hostf::Fq>(base_xy, handle, 5); }
 int32_t dgpu_window_table_g2(const uint64_t base_xy[24], uint64_t *handle) { return table_build<G2, hostf::Fq2>(base_xy, handle, 6); }
 int32_t dgpu_window_table_free(uint64_t handle) {

@@ -81,4 +81,58 @@ __global__ void __launch_bounds__(64) k_fb_mul(const uint32_t *__restrict__ tabl
     store_affine_abi<C>(o, a);
 }
 
+
+// ---- out_i = A_i + s_i * P_i  (affine in, affine out) ------------------------------------------------------------------
+// The GIPA folding step of the SnarkPack aggregation: `compress` (legogroth16/src/aggregation/utils.rs:34-49: vec[i] +=
+// vec[i + split] * c), Key::compress and Key::scale (aggregation/key.rs:117-175) — per-element mul_bigint + add + into_affine
+// under cfg_iter! in the reference.  One lane per element, double-and-add from the top set bit, one inversion.
+// scalar_stride = 8 words: one canonical scalar per point; 0: the same scalar for all.  add_abi == nullptr: no addend.
+template <class C>
+__global__ void __launch_bounds__(64) k_mul_add(const uint32_t *__restrict__ p_abi, const uint8_t *__restrict__ p_inf, const uint32_t *__restrict__ scalars, int scalar_stride,
+                                                const uint32_t *__restrict__ add_abi, const uint8_t *__restrict__ add_inf, size_t n, uint32_t *__restrict__ out_abi, uint8_t *__restrict__ out_inf) {
+    typedef typename C::F F;
+    constexpr int PW = 2 * C::ABI_W;
+    const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    Aff<F> P;
+    bool pinf;
+    {
+        const uint32_t *src = p_abi + i * PW;
+        uint32_t any = 0;
+        for (int k = 0; k < PW; k++) any |= src[k];
+        pinf = (any == 0) || (p_inf && p_inf[i]);
+        Fp *c = reinterpret_cast<Fp *>(&P);
+#pragma unroll
+        for (int k = 0; k < 2 * C::NFP; k++) fp_from_abi(c[k], src + 12 * k);
+    }
+    uint32_t s[8];
+    for (int k = 0; k < 8; k++) s[k] = scalars[i * (size_t)scalar_stride + k];
+    Xyzz<F> acc; bool inf = true;
+    fzero(acc.x); fzero(acc.y); fzero(acc.zz); fzero(acc.zzz);
+    if (!pinf) {
+        int top = -1;
+        for (int k = 7; k >= 0; k--) if (s[k]) { top = 32 * k + 31 - __clz(s[k]); break; }
+        for (int b = top; b >= 0; b--) {
+            if (!inf) { Xyzz<F> d; xyzz_dbl(d, acc); acc = d; }
+            if ((s[b >> 5] >> (b & 31)) & 1u) xyzz_madd(acc, inf, P, false);
+        }
+    }
+    if (add_abi) {
+        const uint32_t *src = add_abi + i * PW;
+        uint32_t any = 0;
+        for (int k = 0; k < PW; k++) any |= src[k];
+        if (any != 0 && !(add_inf && add_inf[i])) {
+            Aff<F> A; Fp *c = reinterpret_cast<Fp *>(&A);
+#pragma unroll
+            for (int k = 0; k < 2 * C::NFP; k++) fp_from_abi(c[k], src + 12 * k);
+            xyzz_madd(acc, inf, A, false);
+        }
+    }
+    uint32_t *o = out_abi + i * PW;
+    out_inf[i] = inf ? 1 : 0;
+    if (inf) { for (int j = 0; j < PW; j++) o[j] = 0; return; }
+    Aff<F> a; xyzz_to_affine(a, acc);
+    store_affine_abi<C>(o, a);
+}
+
 }  // namespace msm

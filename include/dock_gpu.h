@@ -121,6 +121,16 @@ int32_t dgpu_window_table_mul_to_bases_g2(uint64_t table, const uint64_t *scalar
 int32_t dgpu_fixed_base_g1(const uint64_t base_xy[12], const uint64_t *scalars, size_t n, int32_t montgomery, uint64_t *out_xy, uint8_t *out_inf);
 int32_t dgpu_fixed_base_g2(const uint64_t base_xy[24], const uint64_t *scalars, size_t n, int32_t montgomery, uint64_t *out_xy, uint8_t *out_inf);
 
+/* ---- SnarkPack aggregation folding step ----
+ * out_i = addend_i + scalars_i * P_i as affine points: `compress` (legogroth16/src/aggregation/utils.rs:34-49), Key::compress and
+ * Key::scale (legogroth16/src/aggregation/key.rs:117-175), `b.mul_bigint(r_i)` (aggregation/groth16/prover.rs:107-112).
+ * scalar_stride = 4: one canonical scalar per point; 0: one scalar for all.  addend_xy = NULL: plain scaling.
+ * Identity inputs: all-zero words or a set flag byte; identity outputs: zero words and out_inf[i] = 1. */
+int32_t dgpu_g1_mul_add_batch(const uint64_t *p_xy /* n*12 */, const uint8_t *p_inf, const uint64_t *scalars, size_t scalar_stride,
+                              const uint64_t *addend_xy /* n*12 or NULL */, const uint8_t *addend_inf, size_t n, uint64_t *out_xy, uint8_t *out_inf);
+int32_t dgpu_g2_mul_add_batch(const uint64_t *p_xy /* n*24 */, const uint8_t *p_inf, const uint64_t *scalars, size_t scalar_stride,
+                              const uint64_t *addend_xy /* n*24 or NULL */, const uint8_t *addend_inf, size_t n, uint64_t *out_xy, uint8_t *out_inf);
+
 /* ---- R1CS -> QAP witness map ----
  * replaces LibsnarkReduction::witness_map_from_matrices (legogroth16/src/r1cs_to_qap.rs:150-210): h = ((A z)(B z) - C z) / Z_D as the
  * D = next_pow2(num_constraints + num_inputs) coefficients the prover pairs with h_query (legogroth16/src/prover.rs:281-286).

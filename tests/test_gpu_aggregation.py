@@ -1,0 +1,142 @@
+"""GPU (-m gpu): SnarkPack aggregation of Groth16 proofs (crypto_amd/aggregation) — the reference's own test shape
+(/root/reference/legogroth16/src/aggregation/tests.rs:117-330: aggregate n proofs, verify, then tamper with the public inputs /
+proof parts / transcript and expect rejection), with the prover-side values cross-checked against the CPU oracle.
+
+Proofs are synthesised with known discrete logs so that e(A, B) = e(alpha, beta) e(sum x_i S_i, gamma) e(C, delta) holds exactly
+(what ark-groth16's verifier checks); no circuit is needed to exercise the aggregation path."""
+import copy
+import numpy as np
+import pytest
+import torch
+import oracle_c as O
+import util as U
+import crypto_amd as ca
+from crypto_amd import legogroth16 as LG
+from crypto_amd import aggregation as AG
+from crypto_amd.aggregation import ops, groth16
+
+pytestmark = pytest.mark.gpu
+R = U.R
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _device():
+    assert torch.cuda.is_available()
+    ca.init(0)
+
+
+def g1(k):
+    return O.G1.to_affine(O.G1.mul(O.G1.generator(), O.int_to_limbs(k % R, 4)))[0]
+
+
+def g2(k):
+    return O.G2.to_affine(O.G2.mul(O.G2.generator(), O.int_to_limbs(k % R, 4)))[0]
+
+
+def make_statement(n, n_pub, seed):
+    rng = np.random.default_rng(seed)
+    rnd = lambda: int.from_bytes(rng.bytes(40), "little") % (R - 1) + 1
+    alpha, beta, gamma, delta = rnd(), rnd(), rnd(), rnd()
+    ks = [rnd() for _ in range(n_pub + 1)]
+    vk = LG.VerifyingKey(g1(alpha), g2(beta), g2(gamma), g2(delta), np.stack([g1(k) for k in ks]), g1(1), 0)
+    proofs, inputs, dlogs = [], [], []
+    for _ in range(n):
+        x = [rnd() for _ in range(n_pub)]
+        a, b = rnd(), rnd()
+        s = (ks[0] + sum(xi * ki for xi, ki in zip(x, ks[1:]))) % R
+        c = (a * b - alpha * beta - s * gamma) * pow(delta, R - 2, R) % R
+        proofs.append({"a": g1(a), "b": g2(b), "c": g1(c)})
+        inputs.append(x); dlogs.append((a, b, c))
+    return vk, proofs, inputs, dlogs
+
+
+@pytest.mark.parametrize("n", [2, 8])
+def test_aggregate_and_verify(n):
+    vk, proofs, inputs, dlogs = make_statement(n, 3, seed=n)
+    srs = AG.setup_fake_srs(0xA11CE5EED, 0xBE7A5EED, n, O.G1.generator(), O.G2.generator())
+    # SRS powers against the oracle
+    for i in (0, 1, 2 * n - 1):
+        assert (srs.g_alpha_powers[i] == g1(pow(0xA11CE5EED, i, R))).all() and (srs.h_beta_powers[i] == g2(pow(0xBE7A5EED, i, R))).all()
+    pk, vsrs = srs.specialize(n)
+    tr = AG.MerlinTranscript(b"test-aggregation")
+    agg = AG.aggregate_proofs(pk, tr, proofs)
+    # prover-side values against the oracle: com_c.t = prod e(C_i, v_i); z_c = sum r^i C_i; z_ab = prod e(A_i, r^i B_i)
+    c_pts = np.stack([p["c"] for p in proofs])
+    gt = O.final_exponentiation(O.multi_miller_loop(c_pts, pk.vkey.a[:n]))
+    assert (agg["com_c"].t == gt).all()
+    tr2 = AG.MerlinTranscript(b"test-aggregation")
+    tr2.append(b"AB-commitment", agg["com_ab"].to_bytes()); tr2.append(b"C-commitment", agg["com_c"].to_bytes())
+    r = tr2.challenge_scalar(b"r-random-fiatshamir")
+    zc = sum(pow(r, i, R) * d[2] for i, d in enumerate(dlogs)) % R
+    assert (agg["z_c"] == g1(zc)).all()
+    zab = sum(pow(r, i, R) * d[0] * d[1] for i, d in enumerate(dlogs)) % R
+    e11 = O.final_exponentiation(O.multi_miller_loop(g1(1).reshape(1, 12), g2(1).reshape(1, 24)))
+    assert (agg["z_ab"] == O.fp12_pow(e11, zab)).all()
+    assert len(agg["tmipp"]["gipa"]["comms_ab"]) == n.bit_length() - 1
+
+    pvk = {"vk": vk}
+    AG.verify_aggregate_proof(vsrs, pvk, inputs, agg, 0x5EED1234567, AG.MerlinTranscript(b"test-aggregation"))
+
+    def rejected(proof=agg, pub=inputs, label=b"test-aggregation"):
+        try:
+            AG.verify_aggregate_proof(vsrs, pvk, pub, proof, 0x5EED1234567, AG.MerlinTranscript(label))
+        except AG.AggregationError:
+            return True
+        return False
+
+    bad_inputs = copy.deepcopy(inputs); bad_inputs[0][0] = (bad_inputs[0][0] + 1) % R
+    assert rejected(pub=bad_inputs)                                   # tests.rs: invalid public input
+    assert rejected(label=b"another-transcript")                      # different Fiat-Shamir domain
+    bad = copy.deepcopy(agg); bad["z_c"] = g1(zc + 1)
+    assert rejected(proof=bad)
+    bad = copy.deepcopy(agg); bad["tmipp"]["gipa"]["final_a"] = g1(12345)
+    assert rejected(proof=bad)
+    if n > 2:       # (for n = 2 the quotient polynomial is a constant and both openings are the same point)
+        bad = copy.deepcopy(agg); bad["tmipp"]["vkey_opening"] = (bad["tmipp"]["vkey_opening"][1], bad["tmipp"]["vkey_opening"][0])
+        assert rejected(proof=bad)
+    bad = copy.deepcopy(agg); bad["tmipp"]["wkey_opening"] = (g1(5), bad["tmipp"]["wkey_opening"][1])
+    assert rejected(proof=bad)
+    bad = copy.deepcopy(agg); bad["tmipp"]["gipa"]["nproofs"] = n + 1
+    assert rejected(proof=bad)                                        # parsing_check
+    # one wrong proof inside the batch
+    wrong = copy.deepcopy(proofs); wrong[1]["c"] = g1(777)
+    agg_w = AG.aggregate_proofs(pk, AG.MerlinTranscript(b"test-aggregation"), wrong)
+    assert rejected(proof=agg_w)
+
+
+def test_aggregate_argument_checks():
+    vk, proofs, inputs, _ = make_statement(4, 1, seed=9)
+    srs = AG.setup_fake_srs(3, 5, 4, O.G1.generator(), O.G2.generator())
+    pk, _ = srs.specialize(4)
+    with pytest.raises(AG.AggregationError):
+        AG.aggregate_proofs(pk, AG.MerlinTranscript(b"t"), proofs[:1])       # < 2
+    with pytest.raises(AG.AggregationError):
+        AG.aggregate_proofs(pk, AG.MerlinTranscript(b"t"), proofs[:3])       # not a power of two
+    with pytest.raises(AG.AggregationError):
+        AG.aggregate_proofs(pk, AG.MerlinTranscript(b"t"), proofs[:2])       # SRS specialised for 4
+
+
+@pytest.mark.parametrize("curve", ["g1", "g2"])
+def test_mul_add_batch_matches_oracle(curve):
+    grp, cv = (O.G1, ca.G1) if curve == "g1" else (O.G2, ca.G2)
+    n = 40
+    ks = O.rand_scalars(21, n); ss = O.rand_scalars(22, n); ad = O.rand_scalars(23, n)
+    P = np.stack([grp.to_affine(grp.mul(grp.generator(), k))[0] for k in ks])
+    A = np.stack([grp.to_affine(grp.mul(grp.generator(), k))[0] for k in ad])
+    sv = [O.limbs_to_int(s) for s in ss]
+    sv[0], sv[1], sv[2] = 0, 1, R - 1
+    A[3] = 0                                              # identity addend
+    P[4] = 0                                              # identity point
+    A[5] = ops.neg(cv, grp.to_affine(grp.mul(P[5], O.int_to_limbs(sv[5], 4)))[0])    # result is the identity
+    A[6] = grp.to_affine(grp.mul(P[6], O.int_to_limbs(sv[6], 4)))[0]                  # addend == product: doubling branch
+    out = ops.mul_add(cv, P, sv, A)
+    for i in range(n):
+        e = grp.mul(P[i], O.int_to_limbs(sv[i], 4), inf=not P[i].any())
+        if A[i].any():
+            e = grp.add(e, grp.mul(A[i], O.int_to_limbs(1, 4)))
+        ea, einf = grp.to_affine(e)
+        assert (out[i] == (np.zeros_like(ea) if einf else ea)).all(), i
+    same = ops.mul_add(cv, P, 0xDEADBEEF)
+    for i in (0, 7, n - 1):
+        ea, einf = grp.to_affine(grp.mul(P[i], O.int_to_limbs(0xDEADBEEF, 4), inf=not P[i].any()))
+        assert (same[i] == (np.zeros_like(ea) if einf else ea)).all()

@@ -1,0 +1,69 @@
+"""CPU: the aggregation's Fiat-Shamir transcript (crypto_amd/aggregation/transcript.py) — Keccak-f[1600] pinned against
+hashlib's SHA3 (same permutation), the Merlin framing against the published Merlin "simple transcript" known answer
+(dalek-cryptography/merlin, reproduced by its ports), challenge_scalar against the rule in
+/root/reference/utils/src/transcript.rs:103-122; plus the KZG polynomial helpers of aggregation/kzg.rs:238-292."""
+import hashlib
+from crypto_amd.aggregation.transcript import keccak_f1600, Merlin, MerlinTranscript, R_MOD
+from crypto_amd.aggregation import kzg
+
+
+def _sha3_256(msg):
+    rate, st = 136, bytearray(200)
+    m = bytearray(msg) + b"\x06"
+    m += b"\x00" * ((-len(m)) % rate)
+    m[-1] |= 0x80
+    for i in range(0, len(m), rate):
+        for j in range(rate):
+            st[j] ^= m[i + j]
+        keccak_f1600(st)
+    return bytes(st[:32])
+
+
+def test_keccak_matches_hashlib_sha3():
+    for msg in (b"", b"abc", b"q" * 135, b"q" * 136, b"x" * 1000):
+        assert _sha3_256(msg) == hashlib.sha3_256(msg).digest()
+
+
+def test_merlin_simple_transcript_known_answer():
+    t = Merlin(b"test protocol")
+    t.append_message(b"some label", b"some data")
+    assert t.challenge_bytes(b"challenge", 32).hex() == "d5a21972d0d5fe320c0d263fac7fffb8145aa640af6e9bca177c03c7efcf0615"
+
+
+def test_merlin_long_messages_cross_the_rate():
+    """absorbing / squeezing more than one STROBE block (166 bytes) stays deterministic and sensitive to every byte"""
+    a, b = Merlin(b"p"), Merlin(b"p")
+    msg = bytes(range(256)) * 3
+    a.append_message(b"m", msg); b.append_message(b"m", msg[:-1] + b"\x00")
+    ca, cb = a.challenge_bytes(b"c", 400), b.challenge_bytes(b"c", 400)
+    assert len(ca) == 400 and ca != cb
+    c = Merlin(b"p"); c.append_message(b"m", msg)
+    assert c.challenge_bytes(b"c", 400) == ca
+
+
+def test_challenge_scalar_is_inverse_of_sampled_element():
+    t1, t2 = MerlinTranscript(b"agg"), MerlinTranscript(b"agg")
+    t1.append(b"x", b"\x01" * 48); t2.append(b"x", b"\x01" * 48)
+    c = t1.challenge_scalar(b"r")
+    raw = t2.challenge_bytes(b"r", 64)
+    v = int.from_bytes(raw[:32], "little") & ((1 << 255) - 1)
+    if 0 < v < R_MOD:
+        assert c * v % R_MOD == 1
+    assert 0 < c < R_MOD
+
+
+def test_kzg_polynomial_helpers():
+    tr = [3, 5, 7, 11]
+    r_shift, z = 123456789, 987654321
+    co = kzg.polynomial_coefficients_from_transcript(tr, r_shift)
+    assert len(co) == 16
+    ev = sum(c * pow(z, i, R_MOD) for i, c in enumerate(co)) % R_MOD
+    assert ev == kzg.polynomial_evaluation_product_form_from_transcript(tr, z, r_shift)
+    # quotient: (f(X) - f(z)) == q(X) (X - z)
+    p = list(co); p[0] = (p[0] - ev) % R_MOD
+    q = kzg._quotient_by_linear(p, z)
+    back = [0] * len(p)
+    for i, c in enumerate(q):
+        back[i + 1] = (back[i + 1] + c) % R_MOD
+        back[i] = (back[i] - c * z) % R_MOD
+    assert back == p

@@ -8,7 +8,7 @@ crypto_amd.legogroth16.prepare_verifying_key (only `vk` is used, as in the refer
 import numpy as np
 from . import ops, kzg
 from .ops import G1, G2, R_MOD, inv
-from .srs import PairCommitment, AggregationError, MAX_SRS_SIZE
+from .srs import PairCommitment, Key, AggregationError, MAX_SRS_SIZE
 from ..pairing_check import RandomizedPairingChecker
 
 
@@ -41,16 +41,16 @@ def _gipa(transcript, a, b, c, vkey, wkey, r_vec, ip_ab, agg_c):
         r_left, r_right = m_r[:split], m_r[split:]
         vk_left, vk_right = vkey.split(split)
         wk_left, wk_right = wkey.split(split)
-        # TIPP (utils.rs:83-118)
-        tab_l = PairCommitment.double(vk_left, wk_right, a_right, b_left)
-        tab_r = PairCommitment.double(vk_right, wk_left, a_left, b_right)
-        zab_l = ops.multi_pairing(a_right, b_left)
-        zab_r = ops.multi_pairing(a_left, b_right)
-        # MIPP for C (utils.rs:51-81)
-        zc_l = ops.msm(G1, c_right, r_left)
-        zc_r = ops.msm(G1, c_left, r_right)
-        tuc_l = PairCommitment.single(vk_left, c_right)
-        tuc_r = PairCommitment.single(vk_right, c_left)
+        # TIPP (utils.rs:83-118) and MIPP for C (utils.rs:51-81): ten multi-pairings and two MSMs, all independent
+        tab_l, tab_r, zab_l, zab_r, zc_l, zc_r, tuc_l, tuc_r = ops.parallel([
+            lambda: PairCommitment.double(vk_left, wk_right, a_right, b_left),
+            lambda: PairCommitment.double(vk_right, wk_left, a_left, b_right),
+            lambda: ops.multi_pairing(a_right, b_left),
+            lambda: ops.multi_pairing(a_left, b_right),
+            lambda: ops.msm(G1, c_right, r_left),
+            lambda: ops.msm(G1, c_left, r_right),
+            lambda: PairCommitment.single(vk_left, c_right),
+            lambda: PairCommitment.single(vk_right, c_left)])
         if i > 0:
             transcript.append(b"c_inv", ops.fr_bytes(c_inv))
             transcript.append(b"zab_l", ops.gt_bytes(zab_l)); transcript.append(b"zab_r", ops.gt_bytes(zab_r))
@@ -59,12 +59,17 @@ def _gipa(transcript, a, b, c, vkey, wkey, r_vec, ip_ab, agg_c):
             transcript.append(b"tuc_l", tuc_l.to_bytes()); transcript.append(b"tuc_r", tuc_r.to_bytes())
             c_inv = transcript.challenge_scalar(b"challenge_i")
             ch = inv(c_inv)
-        m_a = compress(G1, m_a, split, ch)
-        m_b = compress(G2, m_b, split, c_inv)
-        m_c = compress(G1, m_c, split, ch)
+        # folding (prover.rs:328-351): A, C and both w vectors take the challenge, B and both v vectors its inverse —
+        # one launch per group instead of `compress` x3 + Key::compress x2
+        def fold_g1():
+            r = ops.mul_add(G1, np.concatenate([a_right, c_right, wk_right.a, wk_right.b]), ch, np.concatenate([a_left, c_left, wk_left.a, wk_left.b]))
+            return r[:split], r[split:2 * split], Key(G1, r[2 * split:3 * split], r[3 * split:])
+
+        def fold_g2():
+            r = ops.mul_add(G2, np.concatenate([b_right, vk_right.a, vk_right.b]), c_inv, np.concatenate([b_left, vk_left.a, vk_left.b]))
+            return r[:split], Key(G2, r[split:2 * split], r[2 * split:])
+        (m_a, m_c, wkey), (m_b, vkey) = ops.parallel([fold_g1, fold_g2])
         m_r = [(l + rr * c_inv) % R_MOD for l, rr in zip(r_left, r_right)]
-        vkey = vk_left.compress(vk_right, c_inv)
-        wkey = wk_left.compress(wk_right, ch)
         comms_ab.append((tab_l, tab_r)); comms_c.append((tuc_l, tuc_r))
         z_ab.append((zab_l, zab_r)); z_c.append((zc_l, zc_r))
         challenges.append(ch); challenges_inv.append(c_inv)
@@ -157,9 +162,15 @@ def _gipa_verify(proof, r_shift, transcript):
     zpts = [proof["z_c"]] + [p for pair in gipa["z_c"] for p in pair]
     zsc = [1] + [s for pair in zip(challenges, challenges_inv) for s in pair]
     res["zc"] = ops.msm(G1, np.stack(zpts), zsc)
-    for (tab_l, tab_r), (zab_l, zab_r), (tc_l, tc_r), ch_i, ci_i in zip(gipa["comms_ab"], gipa["z_ab"], gipa["comms_c"], challenges, challenges_inv):
-        for key, left, right in (("tab", tab_l.t, tab_r.t), ("uab", tab_l.u, tab_r.u), ("zab", zab_l, zab_r), ("tc", tc_l.t, tc_r.t), ("uc", tc_l.u, tc_r.u)):
-            res[key] = ops.fp12_mul(res[key], ops.fp12_mul(ops.fp12_pow(left, ch_i), ops.fp12_pow(right, ci_i)))
+    # T, U, Z folded with the challenges (:272-370): left entries to the challenge, right entries to its inverse
+    exps = [1] + [s for pair in zip(challenges, challenges_inv) for s in pair]
+    sel = {"tab": lambda ab, z, c: (ab[0].t, ab[1].t), "uab": lambda ab, z, c: (ab[0].u, ab[1].u), "zab": lambda ab, z, c: z,
+           "tc": lambda ab, z, c: (c[0].t, c[1].t), "uc": lambda ab, z, c: (c[0].u, c[1].u)}
+    for key, pick in sel.items():
+        bases = [res[key]]
+        for ab, z, cc in zip(gipa["comms_ab"], gipa["z_ab"], gipa["comms_c"]):
+            bases += list(pick(ab, z, cc))
+        res[key] = ops.gt_multi_pow(bases, exps)
     challenges.reverse(); challenges_inv.reverse()
     final_r = kzg.polynomial_evaluation_product_form_from_transcript(challenges_inv, r_shift, 1)
     return res, final_r, challenges, challenges_inv

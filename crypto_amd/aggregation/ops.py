@@ -97,3 +97,28 @@ def gt_bytes(f):
         v = sum(int(x) << (64 * i) for i, x in enumerate(row)) * _FP_RINV % P_MOD
         out += v.to_bytes(48, "little")
     return bytes(out)
+
+
+def gt_multi_pow(bases, exps):
+    """prod bases[i]^exps[i] in GT (host threads)"""
+    n = len(bases)
+    a = np.ascontiguousarray(np.stack([np.asarray(b, dtype=np.uint64).reshape(72) for b in bases])) if n else np.zeros((0, 72), np.uint64)
+    e = limbs(exps)
+    out = np.zeros(72, dtype=np.uint64)
+    rc = lib().dgpu_fp12_multi_pow(_p(a), _p(e), n, _p(out))
+    if rc:
+        raise DockGpuError(rc, "dgpu_fp12_multi_pow")
+    return out
+
+
+_POOL = None
+
+
+def parallel(thunks):
+    """run independent ABI calls from host threads (the library keeps 4 calls in flight on separate HIP streams; ctypes drops
+    the GIL) — the reference runs the same calls under rayon"""
+    global _POOL
+    if _POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _POOL = ThreadPoolExecutor(4)
+    return [f.result() for f in [_POOL.submit(t) for t in thunks]]

@@ -22,8 +22,8 @@ def _rol(v, n):
     return ((v << n) | (v >> (64 - n))) & _MASK if n else v
 
 
-def keccak_f1600(state):
-    """state: bytearray(200), permuted in place"""
+def keccak_f1600_py(state):
+    """state: bytearray(200), permuted in place (pure-Python statement of the permutation; the transcript uses the native one)"""
     a = [[int.from_bytes(state[8 * (x + 5 * y):8 * (x + 5 * y) + 8], "little") for y in range(5)] for x in range(5)]
     for rc in _RC:
         c = [a[x][0] ^ a[x][1] ^ a[x][2] ^ a[x][3] ^ a[x][4] for x in range(5)]
@@ -38,6 +38,16 @@ def keccak_f1600(state):
     for x in range(5):
         for y in range(5):
             state[8 * (x + 5 * y):8 * (x + 5 * y) + 8] = (a[x][y] & _MASK).to_bytes(8, "little")
+
+
+def keccak_f1600(state):
+    """state: bytearray(200), permuted in place by the library's native permutation (dgpu_keccak_f1600)"""
+    import ctypes
+    from .._native import lib
+    buf = (ctypes.c_uint8 * 200).from_buffer(state)
+    rc = lib().dgpu_keccak_f1600(ctypes.cast(buf, ctypes.c_void_p))
+    if rc:
+        raise RuntimeError("dgpu_keccak_f1600 failed")
 
 
 STROBE_R = 166
@@ -61,9 +71,13 @@ class Strobe128:
         self.pos = self.pos_begin = 0
 
     def _absorb(self, data):
-        for byte in data:
-            self.state[self.pos] ^= byte
-            self.pos += 1
+        data = bytes(data)
+        off = 0
+        while off < len(data):
+            k = min(STROBE_R - self.pos, len(data) - off)
+            chunk = int.from_bytes(self.state[self.pos:self.pos + k], "little") ^ int.from_bytes(data[off:off + k], "little")
+            self.state[self.pos:self.pos + k] = chunk.to_bytes(k, "little")
+            self.pos += k; off += k
             if self.pos == STROBE_R:
                 self._run_f()
 

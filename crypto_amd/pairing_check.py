@@ -64,6 +64,21 @@ def g1_scale(points, m, negate=False):
     return out, inf
 
 
+def g1_scale_each(points, scalar_limbs, negate=None):
+    """[s_i * P_i] (or its negative where negate[i]) as affine ABI points: one launch with one scalar per point"""
+    _ensure()
+    pts = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, 12)
+    sc = np.ascontiguousarray(scalar_limbs, dtype=np.uint64).reshape(-1, 4)
+    n = len(pts)
+    out = np.zeros((n, 12), dtype=np.uint64)
+    inf = np.zeros(n, dtype=np.uint8)
+    neg = None if negate is None else np.ascontiguousarray(negate, dtype=np.uint8)
+    rc = lib().dgpu_g1_scale_batch(_p(pts), None, _p(sc), 4, _p(neg), n, _p(out), _p(inf))
+    if rc:
+        raise DockGpuError(rc, "dgpu_g1_scale_batch")
+    return out, inf
+
+
 class RandomizedPairingChecker:
     def __init__(self, random, lazy):                          # new(random, lazy)  :44-53
         self.left = fp12_one()
@@ -85,13 +100,14 @@ class RandomizedPairingChecker:
     def add_multiple_sources_and_target(self, a, b, out, lazy=None):    # prod e(a_i, b_i) == out   :116-138
         lazy = self.lazy if lazy is None else lazy
         m = self.current_random
-        a_m, inf = g1_scale(a, m)
+        a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 12)
         b = np.ascontiguousarray(b, dtype=np.uint64).reshape(-1, 24)
-        if len(a_m) != len(b):
+        if len(a) != len(b):
             raise DockGpuError(-7, "zip_eq")
         if lazy:
-            self.pending[0].append(a_m); self.pending[1].append(b)
+            self._queue(a, m, False, b)
         else:
+            a_m, inf = g1_scale(a, m)
             self.left = fp12_mul(self.left, pairing.multi_miller_loop(a_m, b, inf))
         self.right = fp12_mul(self.right, fp12_pow(out, m))
         self.current_random = self.current_random * self.random % R_MOD
@@ -99,23 +115,34 @@ class RandomizedPairingChecker:
     def add_multiple_sources(self, a, b, c, d, lazy=None):              # prod e(a_i, b_i) == prod e(c_i, d_i)   :142-173
         lazy = self.lazy if lazy is None else lazy
         m = self.current_random
-        a_m, ainf = g1_scale(a, m)
-        c_m, cinf = g1_scale(c, m, negate=True)
+        a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 12)
+        c = np.ascontiguousarray(c, dtype=np.uint64).reshape(-1, 12)
         b = np.ascontiguousarray(b, dtype=np.uint64).reshape(-1, 24)
         d = np.ascontiguousarray(d, dtype=np.uint64).reshape(-1, 24)
-        if len(a_m) != len(b) or len(c_m) != len(d):
+        if len(a) != len(b) or len(c) != len(d):
             raise DockGpuError(-7, "zip_eq")
         if lazy:
-            self.pending[0].extend([a_m, c_m]); self.pending[1].extend([b, d])
+            self._queue(a, m, False, b); self._queue(c, m, True, d)
         else:
+            a_m, ainf = g1_scale(a, m)
+            c_m, cinf = g1_scale(c, m, negate=True)
             self.left = fp12_mul(self.left, pairing.multi_miller_loop(a_m, b, ainf))
             self.left = fp12_mul(self.left, pairing.multi_miller_loop(c_m, d, cinf))
         self.current_random = self.current_random * self.random % R_MOD
 
+    def _queue(self, a, m, negate, b):
+        """lazy mode: the `a.mul_bigint(m)` scalings of every queued equation run as ONE batched launch in verify() (each
+        call is latency-bound on its own); the pairs and their scalars are what the reference would have pushed to `pending`"""
+        self.pending[0].append((a, m, negate)); self.pending[1].append(b)
+
     def verify(self):                                                   # :204-214
         left = self.left
         if self.pending[0]:
-            ps = np.concatenate(self.pending[0]); qs = np.concatenate(self.pending[1])
+            pts = np.concatenate([a for a, _, _ in self.pending[0]])
+            sc = np.concatenate([np.tile(_limbs(m), (len(a), 1)) for a, m, _ in self.pending[0]])
+            ng = np.concatenate([np.full(len(a), 1 if neg else 0, dtype=np.uint8) for a, _, neg in self.pending[0]])
+            ps, _ = g1_scale_each(pts, sc, ng)
+            qs = np.concatenate(self.pending[1])
             left = fp12_mul(pairing.multi_miller_loop(ps, qs), left)    # identity members are all-zero words: skipped on the device
         gt = pairing.final_exponentiation(left)
         if gt is None:

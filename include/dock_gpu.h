@@ -100,6 +100,11 @@ int32_t dgpu_g1_scale_batch(const uint64_t *p_xy /* n*12 */, const uint8_t *is_i
 /* GT arithmetic on the host: PairingOutput `+` is the Fp12 product, `mul_bigint` the power (:136 `self.right += out.mul_bigint(m)`) */
 int32_t dgpu_fp12_mul(const uint64_t a[72], const uint64_t b[72], uint64_t out[72]);
 int32_t dgpu_fp12_pow(const uint64_t a[72], const uint64_t e[4], uint64_t out[72]);
+/* prod_i a_i^{e_i}: the fold of `PairingOutput::mul_bigint` + `add_assign` in the aggregation verifier
+ * (legogroth16/src/aggregation/groth16/verifier.rs:272-370); host threads, generic Fp12 arithmetic */
+/* Keccak-f[1600] in place: the permutation of the aggregation's Merlin / STROBE-128 transcript (merlin/src/strobe.rs:97-104) */
+int32_t dgpu_keccak_f1600(uint8_t state[200]);
+int32_t dgpu_fp12_multi_pow(const uint64_t *a /* n*72 */, const uint64_t *e /* n*4 */, size_t n, uint64_t out[72]);
 
 /* ---- fixed-base batch multiplication ----
  * replaces ark-ec FixedBase::{get_window_table, msm} as the reference calls them: WindowTable::new / multiply_many and

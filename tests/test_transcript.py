@@ -3,7 +3,7 @@ hashlib's SHA3 (same permutation), the Merlin framing against the published Merl
 (dalek-cryptography/merlin, reproduced by its ports), challenge_scalar against the rule in
 /root/reference/utils/src/transcript.rs:103-122; plus the KZG polynomial helpers of aggregation/kzg.rs:238-292."""
 import hashlib
-from crypto_amd.aggregation.transcript import keccak_f1600, Merlin, MerlinTranscript, R_MOD
+from crypto_amd.aggregation.transcript import keccak_f1600, keccak_f1600_py, Merlin, MerlinTranscript, R_MOD
 from crypto_amd.aggregation import kzg
 
 
@@ -22,6 +22,14 @@ def _sha3_256(msg):
 def test_keccak_matches_hashlib_sha3():
     for msg in (b"", b"abc", b"q" * 135, b"q" * 136, b"x" * 1000):
         assert _sha3_256(msg) == hashlib.sha3_256(msg).digest()
+
+
+def test_native_and_python_permutations_agree():
+    st = bytearray(range(200))
+    a, b = bytearray(st), bytearray(st)
+    for _ in range(3):
+        keccak_f1600(a); keccak_f1600_py(b)
+        assert a == b
 
 
 def test_merlin_simple_transcript_known_answer():

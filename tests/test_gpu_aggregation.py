@@ -140,3 +140,42 @@ def test_mul_add_batch_matches_oracle(curve):
     for i in (0, 7, n - 1):
         ea, einf = grp.to_affine(grp.mul(P[i], O.int_to_limbs(0xDEADBEEF, 4), inf=not P[i].any()))
         assert (same[i] == (np.zeros_like(ea) if einf else ea)).all()
+
+
+def test_aggregate_real_legogroth16_proofs():
+    """four LegoGroth16 proofs of the same circuit with different witnesses (as legogroth16/src/aggregation/tests.rs:333-558 does),
+    produced by the GPU prover with the device-generated CRS, aggregated with the extra MIPP for `d` and verified"""
+    import lego_setup as LS
+    from crypto_amd.aggregation import legogroth16 as AL
+    m, cw, n = 20, 2, 4
+    cs0 = LS.circuit(m, x0=3)
+    rng = np.random.default_rng(5)
+    rnd = lambda: int.from_bytes(rng.bytes(40), "little") % (R - 1) + 1
+    pk, _ = LG.generate_parameters(cs0["A"], cs0["B"], cs0["C"], cs0["n_inst"], cs0["n_wit"], cw, rnd(), rnd(), rnd(), rnd(), rnd(), rnd(),
+                                   O.G1.generator(), O.G2.generator())
+    pvk = LG.prepare_verifying_key(pk.vk)
+    proofs, inputs = [], []
+    for j in range(n):
+        cs = LS.circuit(m, x0=100 + j)
+        z = cs["z"]
+        inp, wit = LS.scalars(z[:cs["n_inst"]]), LS.scalars(z[cs["n_inst"]:])
+        proof = LG.create_proof(pk, rnd(), rnd(), rnd(), LS.scalars(LS.witness_map(cs)), inp, wit)
+        assert LG.verify_proof(pvk, proof, inp[1:])
+        proofs.append(proof); inputs.append([z[1]])
+    srs = AG.setup_fake_srs(rnd(), rnd(), n, O.G1.generator(), O.G2.generator())
+    psrs, vsrs = srs.specialize(n)
+    agg = AL.aggregate_proofs(psrs, AG.MerlinTranscript(b"lego"), proofs)
+    assert "com_d" in agg and len(agg["tmipp"]["gipa"]["comms_d"]) == 2
+    AL.verify_aggregate_proof(vsrs, pvk, inputs, agg, rnd(), AG.MerlinTranscript(b"lego"))
+    bad_inputs = copy.deepcopy(inputs); bad_inputs[2][0] = (bad_inputs[2][0] + 1) % R
+    with pytest.raises(AG.AggregationError):
+        AL.verify_aggregate_proof(vsrs, pvk, bad_inputs, agg, rnd(), AG.MerlinTranscript(b"lego"))
+    bad = copy.deepcopy(agg); bad["z_d"] = g1(99)
+    with pytest.raises(AG.AggregationError):
+        AL.verify_aggregate_proof(vsrs, pvk, inputs, bad, rnd(), AG.MerlinTranscript(b"lego"))
+    bad = copy.deepcopy(agg); bad["tmipp"]["gipa"]["final_d"] = g1(98)
+    with pytest.raises(AG.AggregationError):
+        AL.verify_aggregate_proof(vsrs, pvk, inputs, bad, rnd(), AG.MerlinTranscript(b"lego"))
+    # the Groth16 verifier must not accept a Lego aggregate's transcript (D is bound into the challenges)
+    with pytest.raises((AG.AggregationError, KeyError)):
+        AG.verify_aggregate_proof(vsrs, pvk, inputs + [], agg, rnd(), AG.MerlinTranscript(b"lego"))

@@ -129,6 +129,35 @@ int32_t dgpu_scalars_upload(const uint64_t *s, size_t n, int32_t mont, uint64_t 
 }
 
 
+// several host arrays -> one resident scalar vector (the prover's `assignment` = inputs[1..] ++ witnesses, prover.rs:319-321,
+// without a host-side concatenation)
+int32_t dgpu_scalars_upload_parts(const uint64_t *const *parts, const size_t *counts, size_t n_parts, int32_t mont, uint64_t *handle) {
+    if (!handle || (n_parts && (!parts || !counts))) return DGPU_E_BADARG;
+    size_t n = 0;
+    for (size_t k = 0; k < n_parts; k++) { if (counts[k] && !parts[k]) return DGPU_E_BADARG; n += counts[k]; }
+    if (!g.ready) return DGPU_E_NODEVICE;
+    void *p = nullptr;
+    {
+        SlotLock L; Slot &sl = *L.s;
+        HIPCHK(hipSetDevice(g.device));
+        if (hipMalloc(&p, std::max<size_t>(n, 1) * 32) != hipSuccess) { (void)hipGetLastError(); return DGPU_E_OOM; }
+        size_t at = 0;
+        hipError_t e = hipSuccess;
+        for (size_t k = 0; k < n_parts && e == hipSuccess; k++) {
+            if (counts[k]) e = hipMemcpyAsync((uint8_t *)p + at * 32, parts[k], counts[k] * 32, hipMemcpyHostToDevice, sl.stream);
+            at += counts[k];
+        }
+        if (e == hipSuccess && mont && n) ntt::launch_fr_mont_to_canonical(sl.stream, (uint32_t *)p, n);
+        if (e == hipSuccess) e = hipStreamSynchronize(sl.stream);
+        if (e != hipSuccess) { g.last_hip = (int32_t)e; (void)hipGetLastError(); (void)hipFree(p); return DGPU_E_HIP; }
+    }
+    std::lock_guard<std::mutex> lk(g.mu);
+    uint64_t h = g.next_handle++;
+    g.handles[h] = Handle{p, n, 3};
+    *handle = h;
+    return DGPU_OK;
+}
+
 int32_t dgpu_prof_enable(int32_t on) { g.prof = on != 0; return DGPU_OK; }
 int32_t dgpu_prof_reset(void) { std::lock_guard<std::mutex> lk(g.mu); g.prof_tab.clear(); return DGPU_OK; }
 int32_t dgpu_prof_read(const char **names, double *total_ms, uint64_t *calls, int32_t cap) {

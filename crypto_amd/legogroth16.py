@@ -158,30 +158,50 @@ def generate_parameters(A, B, C, num_instance_variables, num_witness_variables, 
     return pk, num_instance_variables
 
 
+_POOL = None
+
+
+def _pool():
+    global _POOL
+    if _POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _POOL = ThreadPoolExecutor(5)
+    return _POOL
+
+
 def _calculate_coeff(curve, initial_point, initial_scalar, query_handle, query0, vk_param, assignment):
-    # prover.rs:585-594:  initial + query[0] + msm(query[1..], assignment) + vk_param
-    acc = query_handle.msm_bigint(assignment, offset=1)
+    # prover.rs:585-594:  initial + query[0] + msm(query[1..], assignment) + vk_param     (assignment: resident scalars)
+    acc = query_handle.msm_resident(assignment, n=min(assignment.n, query_handle.n - 1), base_offset=1)
     rest = lincomb(curve, [initial_point, query0, vk_param], [initial_scalar, 1, 1])
     return sharded.fold(curve, np.stack([acc, rest]))
 
 
 def create_proof(pk, r, s, v, h, input_assignment_with_one, witness_assignment):
-    """prover.rs:267-383.  Returns the proof (a, b, c, d) as affine ABI points."""
+    """prover.rs:267-383.  Returns the proof (a, b, c, d) as affine ABI points.  `h`: canonical limbs or the DeviceScalars
+    the witness map left in HBM (qap.witness_map(..., resident=True))."""
     vk = pk.vk
-    h = np.ascontiguousarray(h, dtype=np.uint64).reshape(-1, 4)
+    hs = h if isinstance(h, M.DeviceScalars) else M.DeviceScalars(np.ascontiguousarray(h, dtype=np.uint64).reshape(-1, 4))
     wit = np.ascontiguousarray(witness_assignment, dtype=np.uint64).reshape(-1, 4)
     inp = np.ascontiguousarray(input_assignment_with_one, dtype=np.uint64).reshape(-1, 4)
     cw = vk.commit_witness_count
-    h_acc = pk.h_query.msm_bigint(h)                               # :286  (h_query has D-1 points: truncation)
-    committed, uncommitted = wit[:cw], wit[cw:]
-    l_aux_acc = pk.l_query.msm_bigint(uncommitted)                 # :299
-    assignment = np.concatenate([inp[1:], wit])                    # :319-321
-    g_a = _calculate_coeff(M.G1, pk.delta_g1, r, pk.a_query, pk.a0, vk.alpha_g1, assignment)           # :325-326
-    if r % R_MOD != 0:
-        g1_b = _calculate_coeff(M.G1, pk.delta_g1, s, pk.b_g1_query, pk.b1_0, pk.beta_g1, assignment)  # :330-336
-    else:
-        g1_b = np.zeros(18, dtype=np.uint64); g1_b[:12] = 0
-    g2_b = _calculate_coeff(M.G2, vk.delta_g2, s, pk.b_g2_query, pk.b2_0, vk.beta_g2, assignment)      # :343-344
+    committed = wit[:cw]
+    # one upload serves four MSMs: `assignment` = inputs[1..] ++ witnesses (:319-321) and `aux` of :299 is its suffix
+    pool = _pool()
+    f_h = pool.submit(lambda: pk.h_query.msm_resident(hs, n=min(pk.h_query.n, hs.n)))              # :286  (h_query has D-1 points: truncation); runs while the assignment uploads
+    assignment = M.DeviceScalars.from_parts([inp[1:], wit])
+    n_aux, aux_at = len(wit) - cw, len(inp) - 1 + cw
+    # the five large MSMs are independent (the reference runs each under rayon, one after the other): issue them from host
+    # threads so that the latency-bound tail of one overlaps the bulk of the next (the library keeps 4 calls in flight)
+    jobs = [lambda: pk.l_query.msm_resident(assignment, n=min(pk.l_query.n, n_aux), scalar_offset=aux_at),   # :299
+            lambda: _calculate_coeff(M.G1, pk.delta_g1, r, pk.a_query, pk.a0, vk.alpha_g1, assignment),           # :325-326
+            (lambda: _calculate_coeff(M.G1, pk.delta_g1, s, pk.b_g1_query, pk.b1_0, pk.beta_g1, assignment)) if r % R_MOD != 0
+            else (lambda: np.zeros(18, dtype=np.uint64)),          # :330-336
+            lambda: _calculate_coeff(M.G2, vk.delta_g2, s, pk.b_g2_query, pk.b2_0, vk.beta_g2, assignment)]       # :343-344
+    l_aux_acc, g_a, g1_b, g2_b = [f.result() for f in [pool.submit(j) for j in jobs]]
+    h_acc = f_h.result()
+    assignment.free()
+    if hs is not h:
+        hs.free()
     # g_c = s g_a + r g1_b - rs delta + l_aux + h_acc - v (eta/delta)    :350-355
     small = lincomb(M.G1, [_affine(M.G1, g_a), _affine(M.G1, g1_b), pk.delta_g1, pk.eta_delta_inv_g1], [s, r, -(r * s), -v])
     g_c = sharded.fold(M.G1, np.stack([small, l_aux_acc, h_acc]))

@@ -169,6 +169,22 @@ class DeviceScalars:
             raise DockGpuError(rc, "dgpu_scalars_upload")
         self.handle = h.value
 
+    @classmethod
+    def from_parts(cls, parts, montgomery=False):
+        """one resident vector = the given arrays back to back (no host concatenation)"""
+        _ensure()
+        arrs = [np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 4) for a in parts]
+        ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+        cnts = (C.c_size_t * len(arrs))(*[len(a) for a in arrs])
+        self = cls.__new__(cls)
+        self.n = sum(len(a) for a in arrs)
+        h = C.c_uint64(0)
+        rc = lib().dgpu_scalars_upload_parts(ptrs, cnts, len(arrs), int(montgomery), C.byref(h))
+        if rc:
+            raise DockGpuError(rc, "dgpu_scalars_upload_parts")
+        self.handle = h.value
+        return self
+
     def free(self):
         if self.handle:
             lib().dgpu_scalars_free(self.handle)

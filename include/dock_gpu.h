@@ -71,6 +71,9 @@ int32_t dgpu_bases_upload_g2(const uint64_t *bases_xy, const uint8_t *is_inf, si
 int32_t dgpu_bases_free(uint64_t handle);
 int32_t dgpu_scalars_upload(const uint64_t *scalars /* n*4 */, size_t n, int32_t montgomery, uint64_t *handle);
 int32_t dgpu_scalars_free(uint64_t handle);
+/* one resident scalar vector from several host arrays, in order (the prover's `assignment` = inputs[1..] ++ witnesses,
+ * legogroth16/src/prover.rs:319-321, without concatenating on the host) */
+int32_t dgpu_scalars_upload_parts(const uint64_t *const *parts, const size_t *counts, size_t n_parts, int32_t montgomery, uint64_t *handle);
 int32_t dgpu_msm_g1_handle(uint64_t bases, size_t offset, const uint64_t *scalars, size_t n, int32_t montgomery, uint64_t out_xyz[18]);
 int32_t dgpu_msm_g2_handle(uint64_t bases, size_t offset, const uint64_t *scalars, size_t n, int32_t montgomery, uint64_t out_xyz[36]);
 /* both operands resident: the timed region of bench.py (inputs already in HBM) */

@@ -1,4 +1,4 @@
-"""Multi-GPU MSM: point-chunk sharding, one process per GPU.
+"""Multi-GPU MSM and Miller loop: chunk sharding, one process per GPU.
 
 An MSM is a sum, so rank g computes the full single-GPU pipeline over its own chunk of (base, scalar) pairs
 and the only exchange is one normalised Jacobian point per rank (144 B for G1, 288 B for G2).  EC addition is
@@ -48,3 +48,33 @@ def gather_and_fold(curve, local_partial, device=None):
 def msm_sharded(curve, local_msm, device=None):
     """`local_msm()` returns this rank's partial (Jacobian limbs) over its own chunk."""
     return gather_and_fold(curve, local_msm(), device)
+
+
+# ---- Miller loop: pairs are independent, the per-rank raw Fp12 outputs multiply (SURVEY.md 8e "Miller loop") ---------------
+def fold_fp12(partials):
+    """product of the per-rank MillerLoopOutput values (host code, dgpu_fp12_mul)"""
+    parts = np.ascontiguousarray(partials, dtype=np.uint64).reshape(-1, 72)
+    acc = parts[0].copy()
+    out = np.zeros(72, dtype=np.uint64)
+    for p in parts[1:]:
+        rc = lib().dgpu_fp12_mul(acc.ctypes.data_as(C.c_void_p), np.ascontiguousarray(p).ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+        if rc:
+            raise DockGpuError(rc, "dgpu_fp12_mul")
+        acc = out.copy()
+    return acc
+
+
+def multi_miller_loop_sharded(local_miller_loop, device=None):
+    """`local_miller_loop()` returns this rank's raw Fp12 output over its own chunk of pairs (576 B); all_gather + product.
+    The result is limb-for-limb the single-device multi_miller_loop value: squaring distributes over the per-step line products and
+    Fp12 multiplication is exact and commutative, so the partition does not matter (then ONE final exponentiation, on every rank)."""
+    local = np.ascontiguousarray(local_miller_loop(), dtype=np.uint64).reshape(72)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return local
+    world = dist.get_world_size()
+    t = torch.from_numpy(local.view(np.int64).copy())
+    if device is not None:
+        t = t.to(device)
+    buf = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(buf, t)
+    return fold_fp12(np.stack([b.cpu().numpy().view(np.uint64) for b in buf]))

@@ -34,7 +34,15 @@ def _worker(rank, world, port, n, q):
     # every rank must hold the identical, normalised result
     gathered = [None] * world
     dist.all_gather_object(gathered, full.tobytes())
-    q.put((rank, bool(ok), all(g == gathered[0] for g in gathered)))
+    same = all(g == gathered[0] for g in gathered)
+    # Miller loop over pair chunks: product of the per-rank raw Fp12 outputs == the single multi_miller_loop (bit-exact)
+    npairs = 9
+    ps = np.stack([O.G1.to_affine(O.G1.mul(O.G1.generator(), s))[0] for s in O.rand_scalars(4, npairs)])
+    qs = np.stack([O.G2.to_affine(O.G2.mul(O.G2.generator(), s))[0] for s in O.rand_scalars(5, npairs)])
+    plo, phi = sharded.chunk_bounds(npairs, world, rank)
+    f = sharded.multi_miller_loop_sharded(lambda: O.multi_miller_loop(ps[plo:phi], qs[plo:phi]))
+    ok_ml = bool((f == O.multi_miller_loop(ps, qs)).all())
+    q.put((rank, bool(ok) and ok_ml, same))
     dist.destroy_process_group()
 
 

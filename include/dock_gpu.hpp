@@ -1,0 +1,180 @@
+// include/dock_gpu.hpp — C++ host side above the C ABI (include/dock_gpu.h): the reference's call surface for the hot path,
+// same names, argument meaning and error behaviour, for a compiled host (the reference is Rust; no Rust toolchain exists in the
+// build image, so the compiled-language mirror is C++ and INTEGRATION.md shows the Rust binding).  Header-only; link -ldock_gpu.
+//
+//   ark-ec VariableBaseMSM::{msm, msm_unchecked, msm_bigint}     -> dock_gpu::VariableBaseMSM<G>      (called from
+//       utils/src/pairs.rs:143-156, legogroth16/src/prover.rs:286,299,363,592, utils/src/randomized_mult_checker.rs:100)
+//   dock_crypto_utils::pairs::Pairs                               -> dock_gpu::Pairs<G>
+//   dock_crypto_utils::msm::WindowTable, multiply_field_elems_with_same_group_elem (utils/src/msm.rs:8-62)
+//                                                                 -> dock_gpu::WindowTable<G>, multiply_field_elems_with_same_group_elem
+//   ark-ec Pairing::{multi_miller_loop, final_exponentiation, multi_pairing} (utils/src/randomized_pairing_check.rs:207,213,
+//       legogroth16/src/verifier.rs:69-78)                        -> dock_gpu::multi_miller_loop / final_exponentiation / multi_pairing
+//   ProvingKey queries kept on the device (legogroth16/src/data_structures.rs:151-168) -> dock_gpu::DeviceBases<G>
+//
+// Errors: arkworks' MSM has no failure mode; here a negative ABI code throws dock_gpu::Error (a Rust shim falls back to arkworks
+// instead).  `msm` keeps arkworks' checked-length contract: Err(min_len) when the lengths differ.
+#pragma once
+#include <array>
+#include <cstdint>
+#include <cstring>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+#include "dock_gpu.h"
+
+namespace dock_gpu {
+
+struct Error : std::runtime_error {
+    int32_t code;
+    Error(int32_t c, const char *what) : std::runtime_error(std::string(what) + ": " + dgpu_strerror(c)), code(c) {}
+};
+inline void check(int32_t rc, const char *what) { if (rc != DGPU_OK) throw Error(rc, what); }
+inline void init(int device = 0) { check(dgpu_init(device), "dgpu_init"); }
+
+using Fq = std::array<uint64_t, 6>;        // Montgomery limbs, R = 2^384 (ark-ff Fp384 layout)
+using BigInt256 = std::array<uint64_t, 4>; // canonical scalar (Fr::into_bigint)
+struct Fr { std::array<uint64_t, 4> mont; };   // Montgomery limbs, R = 2^256 (what ark-ff's Fr holds)
+using Fq12 = std::array<uint64_t, 72>;     // c0.c0.c0 ... c1.c2.c1
+
+struct G1 {
+    static constexpr size_t AW = 12;        // u64 per affine point
+    struct Affine { Fq x{}, y{}; bool infinity = true; };
+    struct Projective { Fq x{}, y{}, z{}; bool is_zero() const { for (auto w : z) if (w) return false; return true; } };
+    static int32_t msm(const uint64_t *b, const uint8_t *i, const uint64_t *s, size_t n, uint64_t *o) { return dgpu_msm_g1(b, i, s, n, o); }
+    static int32_t msm_mont(const uint64_t *b, const uint8_t *i, const uint64_t *s, size_t n, uint64_t *o) { return dgpu_msm_g1_mont(b, i, s, n, o); }
+    static int32_t upload(const uint64_t *b, const uint8_t *i, size_t n, uint64_t *h) { return dgpu_bases_upload_g1(b, i, n, h); }
+    static int32_t msm_handle(uint64_t h, size_t off, const uint64_t *s, size_t n, int32_t mont, uint64_t *o) { return dgpu_msm_g1_handle(h, off, s, n, mont, o); }
+    static int32_t table(const uint64_t *b, uint64_t *h) { return dgpu_window_table_g1(b, h); }
+    static int32_t table_mul(uint64_t t, const uint64_t *s, size_t n, int32_t mont, uint64_t *o, uint8_t *oi) { return dgpu_window_table_mul_g1(t, s, n, mont, o, oi); }
+};
+struct G2 {
+    static constexpr size_t AW = 24;
+    struct Affine { std::array<Fq, 2> x{}, y{}; bool infinity = true; };      // Fq2 = c0, c1
+    struct Projective { std::array<Fq, 2> x{}, y{}, z{}; bool is_zero() const { for (auto &c : z) for (auto w : c) if (w) return false; return true; } };
+    static int32_t msm(const uint64_t *b, const uint8_t *i, const uint64_t *s, size_t n, uint64_t *o) { return dgpu_msm_g2(b, i, s, n, o); }
+    static int32_t msm_mont(const uint64_t *b, const uint8_t *i, const uint64_t *s, size_t n, uint64_t *o) { return dgpu_msm_g2_mont(b, i, s, n, o); }
+    static int32_t upload(const uint64_t *b, const uint8_t *i, size_t n, uint64_t *h) { return dgpu_bases_upload_g2(b, i, n, h); }
+    static int32_t msm_handle(uint64_t h, size_t off, const uint64_t *s, size_t n, int32_t mont, uint64_t *o) { return dgpu_msm_g2_handle(h, off, s, n, mont, o); }
+    static int32_t table(const uint64_t *b, uint64_t *h) { return dgpu_window_table_g2(b, h); }
+    static int32_t table_mul(uint64_t t, const uint64_t *s, size_t n, int32_t mont, uint64_t *o, uint8_t *oi) { return dgpu_window_table_mul_g2(t, s, n, mont, o, oi); }
+};
+
+// ark-ec's Affine { x, y, infinity } is not a flat array: repack into the ABI form (coordinates + one flag byte per point)
+template <class G> struct Packed {
+    std::vector<uint64_t> xy; std::vector<uint8_t> inf;
+    explicit Packed(const std::vector<typename G::Affine> &pts, size_t n) : xy(n * G::AW, 0), inf(n, 0) {
+        for (size_t i = 0; i < n; i++) {
+            if (pts[i].infinity) { inf[i] = 1; continue; }
+            std::memcpy(&xy[i * G::AW], &pts[i].x, G::AW * 4);
+            std::memcpy(&xy[i * G::AW + G::AW / 2], &pts[i].y, G::AW * 4);
+        }
+    }
+};
+template <class G> typename G::Projective projective_from_abi(const uint64_t *o) {
+    typename G::Projective p;
+    std::memcpy(&p.x, o, G::AW * 4); std::memcpy(&p.y, o + G::AW / 2, G::AW * 4); std::memcpy(&p.z, o + G::AW, G::AW * 4);
+    return p;
+}
+template <class G> std::vector<typename G::Affine> affine_from_abi(const std::vector<uint64_t> &xy, const std::vector<uint8_t> &inf) {
+    std::vector<typename G::Affine> out(inf.size());
+    for (size_t i = 0; i < inf.size(); i++) {
+        out[i].infinity = inf[i] != 0;
+        if (out[i].infinity) continue;
+        std::memcpy(&out[i].x, &xy[i * G::AW], G::AW * 4); std::memcpy(&out[i].y, &xy[i * G::AW + G::AW / 2], G::AW * 4);
+    }
+    return out;
+}
+
+template <class G> struct VariableBaseMSM {
+    using Affine = typename G::Affine; using Projective = typename G::Projective;
+    // msm_bigint(bases, bigints): truncates to the shorter operand (legogroth16/src/prover.rs:286 relies on it)
+    static Projective msm_bigint(const std::vector<Affine> &bases, const std::vector<BigInt256> &bigints) {
+        size_t n = std::min(bases.size(), bigints.size());
+        Packed<G> p(bases, n);
+        std::array<uint64_t, G::AW * 3 / 2> out{};
+        check(G::msm(p.xy.data(), p.inf.data(), n ? bigints[0].data() : nullptr, n, out.data()), "msm_bigint");
+        return projective_from_abi<G>(out.data());
+    }
+    // msm_unchecked(bases, scalars): scalars in Montgomery form, converted on the device
+    static Projective msm_unchecked(const std::vector<Affine> &bases, const std::vector<Fr> &scalars) {
+        size_t n = std::min(bases.size(), scalars.size());
+        Packed<G> p(bases, n);
+        std::array<uint64_t, G::AW * 3 / 2> out{};
+        check(G::msm_mont(p.xy.data(), p.inf.data(), n ? scalars[0].mont.data() : nullptr, n, out.data()), "msm_unchecked");
+        return projective_from_abi<G>(out.data());
+    }
+    // msm(bases, scalars): Err(min_len) on a length mismatch — returned as {nullopt, min_len}
+    static std::pair<std::optional<Projective>, size_t> msm(const std::vector<Affine> &bases, const std::vector<Fr> &scalars) {
+        size_t n = std::min(bases.size(), scalars.size());
+        if (bases.size() != scalars.size()) return {std::nullopt, n};
+        return {msm_unchecked(bases, scalars), n};
+    }
+};
+
+// utils/src/pairs.rs:143-156
+template <class G> struct Pairs {
+    std::vector<typename G::Affine> left; std::vector<Fr> right;
+    typename G::Projective msm() const { return VariableBaseMSM<G>::msm_unchecked(left, right); }
+    typename G::Projective msm_bigint(const std::vector<BigInt256> &right_bigint) const { return VariableBaseMSM<G>::msm_bigint(left, right_bigint); }
+};
+
+// a proving-key query kept in HBM (ProvingKeyCommon, legogroth16/src/data_structures.rs:151-168); offset = 1 is &query[1..]
+template <class G> class DeviceBases {
+    uint64_t h_ = 0; size_t n_ = 0;
+public:
+    explicit DeviceBases(const std::vector<typename G::Affine> &bases) : n_(bases.size()) { Packed<G> p(bases, n_); check(G::upload(p.xy.data(), p.inf.data(), n_, &h_), "bases_upload"); }
+    DeviceBases(const DeviceBases &) = delete;
+    ~DeviceBases() { if (h_) dgpu_bases_free(h_); }
+    size_t len() const { return n_; }
+    typename G::Projective msm_bigint(const std::vector<BigInt256> &bigints, size_t offset = 0) const {
+        size_t n = std::min(n_ - offset, bigints.size());
+        std::array<uint64_t, G::AW * 3 / 2> out{};
+        check(G::msm_handle(h_, offset, n ? bigints[0].data() : nullptr, n, 0, out.data()), "msm_handle");
+        return projective_from_abi<G>(out.data());
+    }
+};
+
+// utils/src/msm.rs:8-52.  `num_multiplications` only sizes arkworks' window; the device table is fixed (accepted, ignored).
+template <class G> class WindowTable {
+    uint64_t h_ = 0;
+public:
+    WindowTable(size_t /*num_multiplications*/, const typename G::Affine &group_elem) {
+        std::vector<typename G::Affine> one{group_elem}; Packed<G> p(one, 1);
+        check(G::table(p.xy.data(), &h_), "window_table");
+    }
+    WindowTable(const WindowTable &) = delete;
+    ~WindowTable() { if (h_) dgpu_window_table_free(h_); }
+    std::vector<typename G::Affine> multiply_many(const std::vector<Fr> &elements) const {
+        std::vector<uint64_t> xy(elements.size() * G::AW); std::vector<uint8_t> inf(elements.size());
+        check(G::table_mul(h_, elements.empty() ? nullptr : elements[0].mont.data(), elements.size(), 1, xy.data(), inf.data()), "multiply_many");
+        return affine_from_abi<G>(xy, inf);
+    }
+    typename G::Affine multiply(const Fr &element) const { return multiply_many({element})[0]; }
+};
+template <class G> std::vector<typename G::Affine> multiply_field_elems_with_same_group_elem(const typename G::Affine &group_elem, const std::vector<Fr> &elements) {
+    return WindowTable<G>(elements.size(), group_elem).multiply_many(elements);
+}
+
+// Pairing::multi_miller_loop: equal lengths required (arkworks' zip_eq panics); pairs with an identity member are skipped
+inline Fq12 multi_miller_loop(const std::vector<G1::Affine> &a, const std::vector<G2::Affine> &b) {
+    if (a.size() != b.size()) throw Error(DGPU_E_LENGTH, "multi_miller_loop");
+    Packed<G1> p(a, a.size()); Packed<G2> q(b, b.size());
+    std::vector<uint8_t> skip(a.size());
+    for (size_t i = 0; i < a.size(); i++) skip[i] = p.inf[i] | q.inf[i];
+    Fq12 out{};
+    check(dgpu_multi_miller_loop(p.xy.data(), q.xy.data(), skip.data(), a.size(), out.data()), "multi_miller_loop");
+    return out;
+}
+// Pairing::final_exponentiation: None for a zero input
+inline std::optional<Fq12> final_exponentiation(const Fq12 &f) {
+    Fq12 out{};
+    int32_t rc = dgpu_final_exponentiation(f.data(), out.data());
+    if (rc == DGPU_E_ZERO) return std::nullopt;
+    check(rc, "final_exponentiation");
+    return out;
+}
+inline Fq12 multi_pairing(const std::vector<G1::Affine> &a, const std::vector<G2::Affine> &b) { return *final_exponentiation(multi_miller_loop(a, b)); }
+
+}  // namespace dock_gpu

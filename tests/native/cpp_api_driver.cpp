@@ -1,0 +1,83 @@
+// tests/native/cpp_api_driver.cpp — GPU parity driver for the C++ host mirror (include/dock_gpu.hpp), written like the reference's
+// own tests (utils/src/msm.rs:186-231: msm == sum of mul_bigint, multiply_many[i] == g * s_i; utils/src/randomized_pairing_check.rs
+// tests: pairing products).  The CPU oracle (oracle/liboracle.so, test infrastructure) is the checker.  Exit code 0 = all equal.
+#include <cstdio>
+#include <cstdlib>
+#include "../../include/dock_gpu.hpp"
+
+extern "C" {   // oracle/oracle.c
+void orc_rand_scalars(uint64_t seed, size_t n, uint64_t *out);
+void orc_fr_to_mont(const uint64_t *a, uint64_t *out, size_t n);
+void orc_g1_generator(uint64_t *out); void orc_g2_generator(uint64_t *out);
+void orc_g1_gen_seq(const uint64_t *k0, const uint64_t *d, size_t n, int threads, uint64_t *out);
+void orc_g2_gen_seq(const uint64_t *k0, const uint64_t *d, size_t n, int threads, uint64_t *out);
+void orc_g1_msm(const uint64_t *b, const uint8_t *inf, const uint64_t *s, size_t n, int threads, uint64_t *out);
+void orc_g2_msm(const uint64_t *b, const uint8_t *inf, const uint64_t *s, size_t n, int threads, uint64_t *out);
+int orc_g1_to_affine(const uint64_t *jac, uint64_t *out); int orc_g2_to_affine(const uint64_t *jac, uint64_t *out);
+void orc_g1_mul(const uint64_t *base, int inf, const uint64_t *k, uint64_t *out); void orc_g2_mul(const uint64_t *base, int inf, const uint64_t *k, uint64_t *out);
+void orc_multi_miller_loop(const uint64_t *p, const uint64_t *q, const uint8_t *skip, size_t n, int threads, uint64_t *out);
+int orc_final_exponentiation(const uint64_t *f, uint64_t *out);
+}
+using namespace dock_gpu;
+static int fails = 0;
+#define EXPECT(c) do { if (!(c)) { std::printf("FAIL %s:%d  %s\n", __FILE__, __LINE__, #c); fails++; } } while (0)
+
+template <class G> std::vector<typename G::Affine> affine_vec(const std::vector<uint64_t> &xy, size_t n) { return affine_from_abi<G>(xy, std::vector<uint8_t>(n, 0)); }
+template <class G> bool same_point(const typename G::Projective &got, const uint64_t *oracle_jac, int (*to_aff)(const uint64_t *, uint64_t *)) {
+    uint64_t a[G::AW], b[G::AW], j[G::AW * 3 / 2];
+    std::memcpy(j, &got.x, G::AW * 4); std::memcpy(j + G::AW / 2, &got.y, G::AW * 4); std::memcpy(j + G::AW, &got.z, G::AW * 4);
+    int i1 = to_aff(j, a), i2 = to_aff(oracle_jac, b);
+    return i1 == i2 && (i1 || std::memcmp(a, b, sizeof a) == 0);
+}
+
+int main() {
+    init(0);
+    const size_t n = 3000;
+    std::vector<uint64_t> k0(4), d(4), sc(n * 4), scm(n * 4), b1(n * 12), b2(n * 24);
+    orc_rand_scalars(1, 1, k0.data()); orc_rand_scalars(2, 1, d.data()); orc_rand_scalars(3, n, sc.data());
+    orc_fr_to_mont(sc.data(), scm.data(), n);
+    orc_g1_gen_seq(k0.data(), d.data(), n, 8, b1.data()); orc_g2_gen_seq(d.data(), k0.data(), n, 8, b2.data());
+    auto P1 = affine_vec<G1>(b1, n); auto P2 = affine_vec<G2>(b2, n);
+    P1[5].infinity = true; P2[7].infinity = true;                         // identity bases are allowed
+    std::vector<uint8_t> inf1(n, 0), inf2(n, 0); inf1[5] = 1; inf2[7] = 1;
+    std::vector<BigInt256> big(n); std::vector<Fr> fr(n);
+    for (size_t i = 0; i < n; i++) { std::memcpy(big[i].data(), &sc[4 * i], 32); std::memcpy(fr[i].mont.data(), &scm[4 * i], 32); }
+
+    uint64_t e1[18], e2[36];
+    orc_g1_msm(b1.data(), inf1.data(), sc.data(), n, 8, e1); orc_g2_msm(b2.data(), inf2.data(), sc.data(), n, 8, e2);
+    EXPECT(same_point<G1>(VariableBaseMSM<G1>::msm_bigint(P1, big), e1, orc_g1_to_affine));
+    EXPECT(same_point<G1>(VariableBaseMSM<G1>::msm_unchecked(P1, fr), e1, orc_g1_to_affine));
+    EXPECT(same_point<G2>(VariableBaseMSM<G2>::msm_bigint(P2, big), e2, orc_g2_to_affine));
+    EXPECT(same_point<G1>(Pairs<G1>{P1, fr}.msm(), e1, orc_g1_to_affine));
+    // checked msm: Err(min_len) on mismatch; truncation for msm_bigint
+    auto shorter = std::vector<Fr>(fr.begin(), fr.begin() + 100);
+    auto r = VariableBaseMSM<G1>::msm(P1, shorter);
+    EXPECT(!r.first.has_value() && r.second == 100);
+    orc_g1_msm(b1.data(), inf1.data(), sc.data(), 100, 8, e1);
+    EXPECT(same_point<G1>(VariableBaseMSM<G1>::msm_bigint(P1, std::vector<BigInt256>(big.begin(), big.begin() + 100)), e1, orc_g1_to_affine));
+    EXPECT(VariableBaseMSM<G1>::msm_bigint({}, {}).is_zero());            // n = 0 -> identity
+    // resident query, &query[1..]
+    DeviceBases<G1> q(P1);
+    orc_g1_msm(b1.data() + 12, inf1.data() + 1, sc.data(), n - 1, 8, e1);
+    EXPECT(same_point<G1>(q.msm_bigint(big, 1), e1, orc_g1_to_affine));
+    // WindowTable: multiply_many[i] == g * s_i
+    G1::Affine g; g.infinity = false; uint64_t gen[12]; orc_g1_generator(gen); std::memcpy(&g.x, gen, 48); std::memcpy(&g.y, gen + 6, 48);
+    auto prod = multiply_field_elems_with_same_group_elem<G1>(g, std::vector<Fr>(fr.begin(), fr.begin() + 50));
+    for (size_t i = 0; i < 50; i++) {
+        uint64_t j[18], a[12]; orc_g1_mul(gen, 0, &sc[4 * i], j); orc_g1_to_affine(j, a);
+        EXPECT(!prod[i].infinity && std::memcmp(&prod[i].x, a, 48) == 0 && std::memcmp(&prod[i].y, a + 6, 48) == 0);
+    }
+    // pairing: raw Miller-loop output and GT equal to the oracle's; unequal lengths rejected
+    const size_t np = 33;
+    std::vector<G1::Affine> a(P1.begin() + 10, P1.begin() + 10 + np); std::vector<G2::Affine> b(P2.begin() + 10, P2.begin() + 10 + np);
+    Fq12 ml = multi_miller_loop(a, b), eml{}, egt{};
+    orc_multi_miller_loop(b1.data() + 120, b2.data() + 240, nullptr, np, 4, eml.data());
+    EXPECT(ml == eml);
+    orc_final_exponentiation(eml.data(), egt.data());
+    EXPECT(multi_pairing(a, b) == egt);
+    bool threw = false; try { a.pop_back(); multi_miller_loop(a, b); } catch (const Error &e) { threw = e.code == DGPU_E_LENGTH; }
+    EXPECT(threw);
+    EXPECT(!final_exponentiation(Fq12{}).has_value());                    // zero -> None
+    if (fails) std::printf("cpp_api_driver: %d FAILED\n", fails); else std::printf("cpp_api_driver: all equal\n");
+    return fails ? 1 : 0;
+}

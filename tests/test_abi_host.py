@@ -106,3 +106,11 @@ def test_chunk_bounds_partition():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_cpp_mirror_header_compiles():
+    """include/dock_gpu.hpp (the compiled-host mirror of the reference's interface) and its parity driver are valid C++17"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-I" + os.path.join(root, "include"),
+                           os.path.join(root, "tests", "native", "cpp_api_driver.cpp")])

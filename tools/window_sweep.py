@@ -1,3 +1,5 @@
+"""Stage timings of one resident G1 MSM (n = 2^20) for window sizes c = 16..20 (development helper): shows why c is capped at 16 -
+wider codes slow the sort sweeps and sparse buckets turn the accumulate kernel into a store-bound pass."""
 import os, sys, time
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/oracle")
 import numpy as np, crypto_amd as ca, oracle_c as O

@@ -28,13 +28,14 @@ int32_t get_domain(Slot &sl, int logn, NttDomain &out) {
     NttDomain d;
     void *dc = nullptr;
     const size_t esz = ntt::FR_WORDS * 4;
-    if (hipMalloc(&dc, sizeof consts) != hipSuccess || hipMalloc(&d.tw_f, H * esz) != hipSuccess || hipMalloc(&d.tw_i, H * esz) != hipSuccess ||
+    if (hipMalloc(&dc, sizeof consts) != hipSuccess || hipMalloc(&d.tw_f, 2 * H * esz) != hipSuccess || hipMalloc(&d.tw_i, 2 * H * esz) != hipSuccess ||
         hipMalloc(&d.pw_f, D * esz) != hipSuccess || hipMalloc(&d.pw_i, D * esz) != hipSuccess || hipMalloc(&d.zinv, 32) != hipSuccess) { (void)hipGetLastError(); return DGPU_E_OOM; }
     hipStream_t s = sl.stream;
     HIPCHK(hipMemcpyAsync(dc, consts, sizeof consts, hipMemcpyHostToDevice, s));
     const uint32_t *c32 = (const uint32_t *)dc;
     ntt::launch_fr_powers(s, c32 + 0 * 8, c32 + 5 * 8, H, (uint32_t *)d.tw_f);    // w^k
     ntt::launch_fr_powers(s, c32 + 1 * 8, c32 + 5 * 8, H, (uint32_t *)d.tw_i);    // w^-k
+    ntt::launch_tw_compact(s, (uint32_t *)d.tw_f, H); ntt::launch_tw_compact(s, (uint32_t *)d.tw_i, H);   // per-stage tables behind the full ones
     ntt::launch_fr_powers(s, c32 + 2 * 8, c32 + 4 * 8, D, (uint32_t *)d.pw_f);    // g^k / D
     ntt::launch_fr_powers(s, c32 + 3 * 8, c32 + 4 * 8, D, (uint32_t *)d.pw_i);    // g^-k / D
     HIPCHK(hipMemcpyAsync(d.zinv, consts[6], 32, hipMemcpyHostToDevice, s));

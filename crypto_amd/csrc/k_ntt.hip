@@ -7,6 +7,9 @@ static inline dim3 grid_for(size_t n) { return dim3((unsigned)((n + 255) / 256))
 void launch_fr_mont_to_canonical(hipStream_t s, uint32_t *words, size_t n) { hipLaunchKernelGGL(k_fr_mont_to_canonical, grid_for(n), dim3(256), 0, s, words, n); }
 void launch_fr_load(hipStream_t s, const uint32_t *words, size_t n, int mont, uint32_t *out, size_t D) { hipLaunchKernelGGL(k_fr_load, grid_for(D), dim3(256), 0, s, words, n, mont, out, D); }
 void launch_fr_powers(hipStream_t s, const uint32_t *bw, const uint32_t *sw, size_t count, uint32_t *out) { hipLaunchKernelGGL(k_fr_powers, grid_for(count), dim3(256), 0, s, bw, sw, count, out); }
+void launch_tw_compact(hipStream_t s, uint32_t *tw, size_t H) {
+    if (H > 1) hipLaunchKernelGGL(k_tw_compact, grid_for(H), dim3(256), 0, s, tw, H, 0);
+}
 void launch_csr_eval(hipStream_t s, const uint64_t *rowptr, const uint32_t *cols, const uint32_t *vals_soa, size_t nnz, const uint32_t *z_soa, size_t nvars, size_t rows, size_t extra, uint32_t *out, size_t D) {
     hipLaunchKernelGGL(k_csr_eval, grid_for(D), dim3(256), 0, s, rowptr, cols, vals_soa, nnz, z_soa, nvars, rows, extra, out, D);
 }

@@ -210,6 +210,20 @@ def test_g2_full_size_closed_form_2_16():
     assert U.jac_to_model(G, ca.msm_bigint(curve, bases, sc)) == U.closed_form(G, sc, k0, d)
 
 
+def test_g2_full_size_closed_form_2_20():
+    """BASELINE config 3 size (G2, n = 2^20): closed form over known dlogs + split/merge through the resident handles"""
+    G, curve = O.G2, ca.G2
+    n = 1 << 20
+    bases, k0, d = U.seq_bases(G, n, 5252, threads=64)
+    sc = O.rand_scalars(5253, n)
+    db = ca.DeviceBases(curve, bases); ds = ca.DeviceScalars(sc)
+    r = db.msm_resident(ds)
+    assert U.jac_to_model(G, r) == U.closed_form(G, sc, k0, d)
+    a = db.msm_resident(ds, n=n // 4)
+    b = db.msm_resident(ds, n=n - n // 4, base_offset=n // 4, scalar_offset=n // 4)
+    assert U.jac_to_model(G, G.add(a, b)) == U.jac_to_model(G, r)
+
+
 def test_concurrent_callers_share_the_device():
     """the reference calls MSM from inside rayon workers (verifiable_encryption/src/tz_21/rdkgith.rs:140-147): several host
     threads in flight at once must each get their own correct result (per-call slots: stream + workspace)."""

@@ -86,6 +86,50 @@ __global__ void __launch_bounds__(256) k_add32(uint64_t *out, uint32_t a, uint32
     uint64_t s = 0; for (int i = 0; i < 8; i++) s += acc[i];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
+__global__ void __launch_bounds__(256) k_lshr64(uint64_t *out, uint32_t a, uint32_t b) {
+    uint64_t acc[8];
+    for (int i = 0; i < 8; i++) acc[i] = ((uint64_t)(a + i) << 40) + threadIdx.x + b;
+    for (int it = 0; it < ITERS; it++) {
+#define OP(i) asm volatile("v_lshrrev_b64 %0, 1, %0" : "+v"(acc[i]));
+        BODY8(OP)
+#undef OP
+    }
+    uint64_t s = 0; for (int i = 0; i < 8; i++) s += acc[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+__global__ void __launch_bounds__(256) k_lshl_add64(uint64_t *out, uint32_t a, uint32_t b) {
+    uint64_t acc[8]; uint64_t y = ((uint64_t)b << 32) + blockIdx.x + 1;
+    for (int i = 0; i < 8; i++) acc[i] = a + i + threadIdx.x;
+    for (int it = 0; it < ITERS; it++) {
+#define OP(i) asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(acc[i]) : "v"(y));
+        BODY8(OP)
+#undef OP
+    }
+    uint64_t s = 0; for (int i = 0; i < 8; i++) s += acc[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+__global__ void __launch_bounds__(256) k_alignbit(uint64_t *out, uint32_t a, uint32_t b) {
+    uint32_t acc[8]; uint32_t y = b + blockIdx.x;
+    for (int i = 0; i < 8; i++) acc[i] = i + threadIdx.x + a;
+    for (int it = 0; it < ITERS; it++) {
+#define OP(i) asm volatile("v_alignbit_b32 %0, %1, %0, 29" : "+v"(acc[i]) : "v"(y));
+        BODY8(OP)
+#undef OP
+    }
+    uint64_t s = 0; for (int i = 0; i < 8; i++) s += acc[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+__global__ void __launch_bounds__(256) k_and32(uint64_t *out, uint32_t a, uint32_t b) {
+    uint32_t acc[8]; uint32_t y = ~(b + blockIdx.x);
+    for (int i = 0; i < 8; i++) acc[i] = i + threadIdx.x + a;
+    for (int it = 0; it < ITERS; it++) {
+#define OP(i) asm volatile("v_and_b32 %0, %0, %1" : "+v"(acc[i]) : "v"(y));
+        BODY8(OP)
+#undef OP
+    }
+    uint64_t s = 0; for (int i = 0; i < 8; i++) s += acc[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
 __global__ void __launch_bounds__(256) k_fma_f64(uint64_t *out, uint32_t a, uint32_t b) {
     double acc[8]; double x = 1.0 + 1e-9 * (a + threadIdx.x), y = 1e-9 * (b + blockIdx.x);
     for (int i = 0; i < 8; i++) acc[i] = i + threadIdx.x;
@@ -144,6 +188,10 @@ int main() {
         run("mad_u32_u24", k_mad_u32_u24, d, blocks, 256, opt);
         run("mul_hi_u32_u24", k_mul_hi_u24, d, blocks, 256, opt);
         run("fma_f64", k_fma_f64, d, blocks, 256, opt);
+        run("lshrrev_b64", k_lshr64, d, blocks, 256, opt);
+        run("lshl_add_u64", k_lshl_add64, d, blocks, 256, opt);
+        run("alignbit_b32", k_alignbit, d, blocks, 256, opt);
+        run("and_b32", k_and32, d, blocks, 256, opt);
     }
     run("mad_u64 dep 1w", k_mad_dep, d, 1, 64, opt);
     return 0;

@@ -47,6 +47,20 @@ def test_fails_loudly_without_device():
     assert rc == -1                      # DGPU_E_NODEVICE — never a silent CPU result
     with pytest.raises(ca.DockGpuError):
         ca.msm_bigint(ca.G1, b, s)
+    # every device-backed entry point refuses the same way: pairing, witness map, fixed base, folding step, uploads
+    p_ = lambda a: a.ctypes.data_as(C.c_void_p)
+    f12 = np.zeros(72, np.uint64); q = O.G2.generator().reshape(1, 24); o12 = np.zeros(12, np.uint64); oi = np.zeros(1, np.uint8)
+    h = C.c_uint64(0)
+    assert L.dgpu_multi_miller_loop(p_(b), p_(q), None, 1, p_(f12)) == -1
+    assert L.dgpu_fixed_base_g1(p_(b), p_(s), 1, 0, p_(o12), p_(oi)) == -1
+    assert L.dgpu_window_table_g1(p_(b), C.byref(h)) == -1
+    assert L.dgpu_g1_mul_add_batch(p_(b), None, p_(s), 4, None, None, 1, p_(o12), p_(oi)) == -1
+    assert L.dgpu_g1_scale_batch(p_(b), None, p_(s), 4, None, 1, p_(o12), p_(oi)) == -1
+    assert L.dgpu_bases_upload_g1(p_(b), None, 1, C.byref(h)) == -1
+    assert L.dgpu_scalars_upload(p_(s), 1, 0, C.byref(h)) == -1
+    from crypto_amd import fixed_base, qap
+    with pytest.raises(ca.DockGpuError):
+        fixed_base.multiply_field_elems_with_same_group_elem(ca.G1, b[0], s)
 
 
 def test_bad_arguments():

@@ -105,23 +105,40 @@ __global__ void __launch_bounds__(64) k_line_products(const uint32_t *__restrict
     for (int k = 0; k < F12W; k++) partial[(size_t)t * F12W + k] = w[k];
 }
 
-// one block (64 lanes) per step: tree product of the nsl partials through LDS, result converted to the ABI form
-__global__ void __launch_bounds__(64) k_product_tree(const uint32_t *__restrict__ partial, int nsl, uint32_t *__restrict__ out_abi) {
+// one block (64 lanes) per (step, group of 64 partials): tree product through LDS.  out_abi != nullptr: the group result of step s is
+// L_s, written in the ABI form (last level); otherwise it is written back as a partial of the next level:
+// next[(s * ngroups + g) * F12W + k].
+__global__ void __launch_bounds__(64) k_product_tree(const uint32_t *__restrict__ partial, int nsl, int ngroups, uint32_t *__restrict__ next, uint32_t *__restrict__ out_abi) {
     __shared__ uint32_t sh[F12W * MAX_SLICES];
-    int s = blockIdx.x, j = threadIdx.x;
+    const int s = blockIdx.x / ngroups, grp = blockIdx.x % ngroups, j = threadIdx.x;
+    const int idx = grp * MAX_SLICES + j;
+    const int cnt = min(MAX_SLICES, nsl - grp * MAX_SLICES);        // partials in this group
     Fp12d f; f12_set_one(f);
-    if (j < nsl) { uint32_t *w = reinterpret_cast<uint32_t *>(&f); for (int k = 0; k < F12W; k++) w[k] = partial[((size_t)s * nsl + j) * F12W + k]; }
+    if (j < cnt) { uint32_t *w = reinterpret_cast<uint32_t *>(&f); for (int k = 0; k < F12W; k++) w[k] = partial[((size_t)s * nsl + idx) * F12W + k]; }
     for (int h = MAX_SLICES / 2; h >= 1; h >>= 1) {
+        if (h >= cnt) continue;                                     // (uniform) nothing to fold at this level
         __syncthreads();
         if (j >= h && j < 2 * h) { const uint32_t *w = reinterpret_cast<const uint32_t *>(&f); for (int k = 0; k < F12W; k++) sh[k * MAX_SLICES + j] = w[k]; }
         __syncthreads();
-        if (j < h && j + h < nsl) {
+        if (j < h && j + h < cnt) {
             Fp12d o, r; uint32_t *w = reinterpret_cast<uint32_t *>(&o);
             for (int k = 0; k < F12W; k++) w[k] = sh[k * MAX_SLICES + j + h];
             f12_mul(r, f, o); f = r;
         }
     }
-    if (j == 0) { const Fp *c = reinterpret_cast<const Fp *>(&f); for (int k = 0; k < 12; k++) fp_to_abi(out_abi + ((size_t)s * 12 + k) * 12, c[k]); }
+    if (j == 0) {
+        if (out_abi) { const Fp *c = reinterpret_cast<const Fp *>(&f); for (int k = 0; k < 12; k++) fp_to_abi(out_abi + ((size_t)s * 12 + k) * 12, c[k]); }
+        else { const uint32_t *w = reinterpret_cast<const uint32_t *>(&f); for (int k = 0; k < F12W; k++) next[((size_t)s * ngroups + grp) * F12W + k] = w[k]; }
+    }
+}
+
+// Slices of pairs per step.  A lane multiplies its slice's lines into one partial (sparse products, serial), then 64-wide trees fold
+// the partials (dense products, log depth): short slices keep both latency-bound phases short at small n and fill the chip at large n
+// (a fixed 64 slices left k_line_products with 4352 lanes whatever n: 59 ms at 2^16 pairs).
+inline int choose_slice_len(size_t n) {
+    size_t len = n > 512 ? 8 : 4;
+    while ((n + len - 1) / len > 2048 && (n + len - 1) / len > 0) len *= 2;
+    return (int)len;
 }
 
 }  // namespace
@@ -136,13 +153,14 @@ int32_t dgpu_multi_miller_loop(const uint64_t *p, const uint64_t *q, const uint8
     SlotLock slot_lock; Slot &sl = *slot_lock.s;
     HIPCHK(hipSetDevice(g.device));
     int32_t rc;
-    const int slice_len = (int)std::max<size_t>(1, (n + MAX_SLICES - 1) / MAX_SLICES);
-    const int nsl = (int)((n + slice_len - 1) / slice_len);
+    const int slice_len = choose_slice_len(n);
+    const int nsl = (int)((n + slice_len - 1) / slice_len);          // <= 2048
+    const int ngroups = (nsl + MAX_SLICES - 1) / MAX_SLICES;         // <= 32: the second tree level is one group
     if ((rc = sl.in_bases.ensure(n * 96))) return rc;
     if ((rc = sl.in_scalars.ensure(n * 192))) return rc;
     if ((rc = sl.in_inf.ensure(n))) return rc;
     if ((rc = sl.ml_lines.ensure((size_t)N_LINES * LW * n * 4))) return rc;
-    if ((rc = sl.ml_partial.ensure((size_t)N_LINES * nsl * F12W * 4))) return rc;
+    if ((rc = sl.ml_partial.ensure((size_t)N_LINES * (nsl + ngroups) * F12W * 4))) return rc;
     if ((rc = sl.ml_out.ensure((size_t)N_LINES * 144 * 4))) return rc;
     hipStream_t s = sl.stream;
     HIPCHK(hipMemcpyAsync(sl.in_bases.p, p, n * 96, hipMemcpyHostToDevice, s));
@@ -156,7 +174,12 @@ int32_t dgpu_multi_miller_loop(const uint64_t *p, const uint64_t *q, const uint8
     { StageTimer st(sl, "ml.products");
       hipLaunchKernelGGL(k_line_products, dim3((unsigned)((N_LINES * nsl + 63) / 64)), dim3(64), 0, s, sl.ml_lines.as<uint32_t>(), n, slice_len, nsl, sl.ml_partial.as<uint32_t>()); }
     { StageTimer st(sl, "ml.tree");
-      hipLaunchKernelGGL(k_product_tree, dim3(N_LINES), dim3(64), 0, s, sl.ml_partial.as<uint32_t>(), nsl, sl.ml_out.as<uint32_t>()); }
+      uint32_t *lvl0 = sl.ml_partial.as<uint32_t>(), *lvl1 = lvl0 + (size_t)N_LINES * nsl * F12W;
+      if (ngroups == 1) hipLaunchKernelGGL(k_product_tree, dim3(N_LINES), dim3(64), 0, s, lvl0, nsl, 1, (uint32_t *)nullptr, sl.ml_out.as<uint32_t>());
+      else {
+          hipLaunchKernelGGL(k_product_tree, dim3(N_LINES * ngroups), dim3(64), 0, s, lvl0, nsl, ngroups, lvl1, (uint32_t *)nullptr);
+          hipLaunchKernelGGL(k_product_tree, dim3(N_LINES), dim3(64), 0, s, lvl1, ngroups, 1, (uint32_t *)nullptr, sl.ml_out.as<uint32_t>());
+      } }
     HIPCHK(hipGetLastError());
     std::vector<hostf::Fq12> L(N_LINES);
     HIPCHK(hipMemcpyAsync(L.data(), sl.ml_out.p, (size_t)N_LINES * 576, hipMemcpyDeviceToHost, s));

@@ -49,6 +49,10 @@ if "ml" in what:
     dt, s = stages(lambda: ca.multi_miller_loop(P, Q))
     print("ML n=1024 %.3f ms (%.0f pairs/s) | %s" % (dt * 1e3, n / dt, s))
     t0 = time.time(); gt = ca.final_exponentiation(f); print("final_exp host %.3f ms" % ((time.time() - t0) * 1e3))
+    for nn in [int(x) for x in os.environ.get("ML_NS", "").split(",") if x]:
+        P = O.G1.gen_seq(k0, d, nn, threads=64); Q = O.G2.gen_seq(d, k0, nn, threads=64)
+        dt, s = stages(lambda: ca.multi_miller_loop(P, Q), K=3)
+        print("ML n=%d %.3f ms (%.0f pairs/s) | %s" % (nn, dt * 1e3, nn / dt, s), flush=True)
 if "conc" in what:
     import threading
     n = 1 << 20

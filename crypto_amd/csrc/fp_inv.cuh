@@ -7,6 +7,7 @@
 #include "fp29.cuh"
 #include "fp2_29.cuh"
 #include "ec29.cuh"
+#include "fp2_pair.cuh"
 
 namespace bls29 {
 
@@ -29,6 +30,15 @@ __device__ __forceinline__ void finv(Fp2 &r, const Fp2 &a) {
     fp_inv_device(ti, t);
     fp_mul(r.c0, a.c0, ti);
     fp_mul(n1, a.c1, ti); fp_zero(z); fp_sub<4>(r.c1, z, n1); fp_norm(r.c1, r.c1);
+}
+// lane-pair form: the norm c0^2 + c1^2 is assembled over the pair, both lanes invert it, each scales (and the odd lane negates) its half
+__device__ __forceinline__ void finv(Fp2H &r, const Fp2H &a) {
+    Fp sq, other, t, ti, m, z, neg;
+    fp_sqr(sq, a.v); xchg(other, sq); fp_add(t, sq, other); fp_norm(t, t);
+    fp_inv_device(ti, t);
+    fp_mul(m, a.v, ti);
+    fp_zero(z); fp_sub<4>(neg, z, m); fp_norm(neg, neg);
+    sel(r.v, pair_odd(), neg, m);
 }
 // (X/ZZ, Y/ZZZ) of a non-identity point, using ZZ^3 == ZZZ^2: 1/ZZ = (ZZ/ZZZ)^2
 template <class F> __device__ __forceinline__ void xyzz_to_affine(Aff<F> &r, const Xyzz<F> &a) {

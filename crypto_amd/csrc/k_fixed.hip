@@ -1,4 +1,5 @@
 // crypto_amd/csrc/k_fixed.hip — translation unit of the fixed-base kernels (G1 and G2).
+#include <cstdlib>
 #include "fixed_kernels.cuh"
 #include "fixed_launch.cuh"
 
@@ -12,6 +13,10 @@ template <class C> void launch_fb_mul(hipStream_t s, const uint32_t *table, cons
 }
 template <class C> void launch_mul_add(hipStream_t s, const uint32_t *p_abi, const uint8_t *p_inf, const uint32_t *scalars, int scalar_stride, const uint32_t *add_abi, const uint8_t *add_inf,
                                        size_t n, uint32_t *out_abi, uint8_t *out_inf) {
+    static const bool one_lane = getenv("DGPU_MULADD_ONE_LANE") != nullptr;      // development switch: one-lane Fp2 kernel for G2
+    if constexpr (C::NFP == 2) {
+        if (!one_lane) { hipLaunchKernelGGL(k_mul_add_g2_pair, dim3((unsigned)((2 * n + 63) / 64)), dim3(64), 0, s, p_abi, p_inf, scalars, scalar_stride, add_abi, add_inf, n, out_abi, out_inf); return; }
+    }
     hipLaunchKernelGGL((k_mul_add<C>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, p_abi, p_inf, scalars, scalar_stride, add_abi, add_inf, n, out_abi, out_inf);
 }
 template void launch_mul_add<G1>(hipStream_t, const uint32_t *, const uint8_t *, const uint32_t *, int, const uint32_t *, const uint8_t *, size_t, uint32_t *, uint8_t *);

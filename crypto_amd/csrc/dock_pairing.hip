@@ -17,6 +17,10 @@
 #include "fp2_pair.cuh"
 #include "sort_launch.cuh"
 
+namespace bls29 {
+__device__ __forceinline__ void fhalf(Fp2H &r, const Fp2H &a) { fp_half(r.v, a.v); }   // lane-pair form of pairing29.cuh's halving
+}
+
 namespace {
 using namespace bls29;
 using namespace dock;

@@ -19,7 +19,7 @@ P = M.P
 
 @pytest.fixture(scope="module")
 def shim():
-    deps = [SRC] + [os.path.join(HERE, "..", "crypto_amd", "csrc", f) for f in ("fp29.cuh", "fp2_29.cuh", "ec29.cuh")]
+    deps = [SRC] + [os.path.join(HERE, "..", "crypto_amd", "csrc", f) for f in ("fp29.cuh", "fp2_29.cuh", "ec29.cuh", "pairing29.cuh", "fr29.cuh")]
     if not os.path.exists(SO) or any(os.path.getmtime(d) > os.path.getmtime(SO) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", SO, SRC])
     return C.CDLL(SO)

@@ -109,30 +109,55 @@ __global__ void __launch_bounds__(64) k_line_products(const uint32_t *__restrict
     for (int k = 0; k < F12W; k++) partial[(size_t)t * F12W + k] = w[k];
 }
 
-// one block (64 lanes) per (step, group of 64 partials): tree product through LDS.  out_abi != nullptr: the group result of step s is
-// L_s, written in the ABI form (last level); otherwise it is written back as a partial of the next level:
-// next[(s * ngroups + g) * F12W + k].
-__global__ void __launch_bounds__(64) k_product_tree(const uint32_t *__restrict__ partial, int nsl, int ngroups, uint32_t *__restrict__ next, uint32_t *__restrict__ out_abi) {
-    __shared__ uint32_t sh[F12W * MAX_SLICES];
-    const int s = blockIdx.x / ngroups, grp = blockIdx.x % ngroups, j = threadIdx.x;
-    const int idx = grp * MAX_SLICES + j;
+// One block per (step, group of 64 partials): tree product through LDS.  A node product a * b is shared by THREE lanes (Karatsuba over
+// Fp6: a0 b0, a1 b1, (a0 + a1)(b0 + b1) are independent Fp6 products of 6 Fp2 products each): the tree is latency-bound — a dense Fp12
+// product is ~25 k instructions on one lane — and has few nodes, so spreading a node over lanes shortens every level 3x.
+// Lanes 0-31 / 32-63 / 64-95 of the 128-thread block take role 0 / 1 / 2 of node p = lane & 31.
+//   A: operands of node p (slots p and p + h) -> registers            | sync
+//   B: t = Fp6 product; t0 -> slot(p+h).c0, t1 -> slot(p+h).c1, m -> slot(p).c1    | sync
+//   C: role 0: slot(p).c0 = t0 + v t1;  role 1: slot(p).c1 = m - t0 - t1           (f12_mul of pairing29.cuh, step for step)
+// out_abi != nullptr: the group result of step s is L_s, written in the ABI form (last level); otherwise it is written back as a
+// partial of the next level: next[(s * ngroups + g) * F12W + k].
+constexpr int F6W = 6 * NL;
+__global__ void __launch_bounds__(128) k_product_tree(const uint32_t *__restrict__ partial, int nsl, int ngroups, uint32_t *__restrict__ next, uint32_t *__restrict__ out_abi) {
+    __shared__ uint32_t sh[F12W * MAX_SLICES];                        // word k of slot j at sh[k * 64 + j]
+    const int s = blockIdx.x / ngroups, grp = blockIdx.x % ngroups, t = threadIdx.x;
     const int cnt = min(MAX_SLICES, nsl - grp * MAX_SLICES);        // partials in this group
-    Fp12d f; f12_set_one(f);
-    if (j < cnt) { uint32_t *w = reinterpret_cast<uint32_t *>(&f); for (int k = 0; k < F12W; k++) w[k] = partial[((size_t)s * nsl + idx) * F12W + k]; }
+    if (t < cnt) { const uint32_t *src = partial + ((size_t)s * nsl + grp * MAX_SLICES + t) * F12W; for (int k = 0; k < F12W; k++) sh[k * MAX_SLICES + t] = src[k]; }
+    auto ld6 = [&](Fp6d &x, int slot, int half) { uint32_t *w = reinterpret_cast<uint32_t *>(&x); for (int k = 0; k < F6W; k++) w[k] = sh[(half * F6W + k) * MAX_SLICES + slot]; };
+    auto st6 = [&](const Fp6d &x, int slot, int half) { const uint32_t *w = reinterpret_cast<const uint32_t *>(&x); for (int k = 0; k < F6W; k++) sh[(half * F6W + k) * MAX_SLICES + slot] = w[k]; };
+    const int role = t >> 5, p = t & 31;
     for (int h = MAX_SLICES / 2; h >= 1; h >>= 1) {
         if (h >= cnt) continue;                                     // (uniform) nothing to fold at this level
+        const bool node = p < h && p + h < cnt;                     // slot p *= slot p + h
+        Fp6d xa, xb;
         __syncthreads();
-        if (j >= h && j < 2 * h) { const uint32_t *w = reinterpret_cast<const uint32_t *>(&f); for (int k = 0; k < F12W; k++) sh[k * MAX_SLICES + j] = w[k]; }
+        if (node && role < 3) {
+            ld6(xa, p, role == 1); ld6(xb, p + h, role == 1);
+            if (role == 2) { Fp6d ya, yb; ld6(ya, p, 1); ld6(yb, p + h, 1); f6_add_n(xa, xa, ya); f6_add_n(xb, xb, yb); }
+        }
         __syncthreads();
-        if (j < h && j + h < cnt) {
-            Fp12d o, r; uint32_t *w = reinterpret_cast<uint32_t *>(&o);
-            for (int k = 0; k < F12W; k++) w[k] = sh[k * MAX_SLICES + j + h];
-            f12_mul(r, f, o); f = r;
+        if (node && role < 3) {
+            Fp6d tt; f6_mul(tt, xa, xb);
+            if (role == 0) st6(tt, p + h, 0); else if (role == 1) st6(tt, p + h, 1); else st6(tt, p, 1);
+        }
+        __syncthreads();
+        if (node && role == 0) {                                    // c0 = t0 + v t1
+            Fp6d t0, t1, x, r; ld6(t0, p + h, 0); ld6(t1, p + h, 1);
+            f6_mul_v(x, t1); f6_add_n(r, t0, x); st6(r, p, 0);
+        } else if (node && role == 1) {                             // c1 = m - t0 - t1
+            Fp6d t0, t1, m, x, r; ld6(t0, p + h, 0); ld6(t1, p + h, 1); ld6(m, p, 1);
+            fadd(x.c0, t0.c0, t1.c0); fadd(x.c1, t0.c1, t1.c1); fadd(x.c2, t0.c2, t1.c2);
+            f2_sub_n<128>(r.c0, m.c0, x.c0); f2_sub_n<128>(r.c1, m.c1, x.c1); f2_sub_n<128>(r.c2, m.c2, x.c2);
+            st6(r, p, 1);
         }
     }
-    if (j == 0) {
+    __syncthreads();
+    if (t == 0) {
+        Fp12d f; uint32_t *w = reinterpret_cast<uint32_t *>(&f);
+        for (int k = 0; k < F12W; k++) w[k] = sh[k * MAX_SLICES];
         if (out_abi) { const Fp *c = reinterpret_cast<const Fp *>(&f); for (int k = 0; k < 12; k++) fp_to_abi(out_abi + ((size_t)s * 12 + k) * 12, c[k]); }
-        else { const uint32_t *w = reinterpret_cast<const uint32_t *>(&f); for (int k = 0; k < F12W; k++) next[((size_t)s * ngroups + grp) * F12W + k] = w[k]; }
+        else for (int k = 0; k < F12W; k++) next[((size_t)s * ngroups + grp) * F12W + k] = w[k];
     }
 }
 
@@ -179,10 +204,10 @@ int32_t dgpu_multi_miller_loop(const uint64_t *p, const uint64_t *q, const uint8
       hipLaunchKernelGGL(k_line_products, dim3((unsigned)((N_LINES * nsl + 63) / 64)), dim3(64), 0, s, sl.ml_lines.as<uint32_t>(), n, slice_len, nsl, sl.ml_partial.as<uint32_t>()); }
     { StageTimer st(sl, "ml.tree");
       uint32_t *lvl0 = sl.ml_partial.as<uint32_t>(), *lvl1 = lvl0 + (size_t)N_LINES * nsl * F12W;
-      if (ngroups == 1) hipLaunchKernelGGL(k_product_tree, dim3(N_LINES), dim3(64), 0, s, lvl0, nsl, 1, (uint32_t *)nullptr, sl.ml_out.as<uint32_t>());
+      if (ngroups == 1) hipLaunchKernelGGL(k_product_tree, dim3(N_LINES), dim3(128), 0, s, lvl0, nsl, 1, (uint32_t *)nullptr, sl.ml_out.as<uint32_t>());
       else {
-          hipLaunchKernelGGL(k_product_tree, dim3(N_LINES * ngroups), dim3(64), 0, s, lvl0, nsl, ngroups, lvl1, (uint32_t *)nullptr);
-          hipLaunchKernelGGL(k_product_tree, dim3(N_LINES), dim3(64), 0, s, lvl1, ngroups, 1, (uint32_t *)nullptr, sl.ml_out.as<uint32_t>());
+          hipLaunchKernelGGL(k_product_tree, dim3(N_LINES * ngroups), dim3(128), 0, s, lvl0, nsl, ngroups, lvl1, (uint32_t *)nullptr);
+          hipLaunchKernelGGL(k_product_tree, dim3(N_LINES), dim3(128), 0, s, lvl1, ngroups, 1, (uint32_t *)nullptr, sl.ml_out.as<uint32_t>());
       } }
     HIPCHK(hipGetLastError());
     std::vector<hostf::Fq12> L(N_LINES);

@@ -165,7 +165,7 @@ __global__ void __launch_bounds__(128) k_product_tree(const uint32_t *__restrict
 // the partials (dense products, log depth): short slices keep both latency-bound phases short at small n and fill the chip at large n
 // (a fixed 64 slices left k_line_products with 4352 lanes whatever n: 59 ms at 2^16 pairs).
 inline int choose_slice_len(size_t n) {
-    size_t len = n > 512 ? 8 : 4;
+    size_t len = n > 2048 ? 8 : 4;
     while ((n + len - 1) / len > 2048 && (n + len - 1) / len > 0) len *= 2;
     return (int)len;
 }

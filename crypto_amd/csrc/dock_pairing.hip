@@ -93,6 +93,91 @@ __global__ void __launch_bounds__(64) k_miller_lines_pair(const uint32_t *__rest
     }
 }
 
+// ---- four lanes per (P, Q): two lane pairs share the doubling step ------------------------------------------------------------------
+// The 63 doubling steps are one dependent chain per pair of points and the kernel has far fewer lanes than the chip (1024 pairs =
+// 32 waves on 1024 SIMDs): its duration is the instruction count of one lane.  A doubling step is 3 Fp2 products + 6 Fp2 squarings
+// (+ the two evaluations at P); here lane pair A (quad lanes 0,1) and lane pair B (lanes 2,3) each hold the whole state and take one
+// operation of every round — the SAME operation on role-selected operands, so the wave stays convergent — and swap results over DPP
+// quad_perm [2,3,0,1]:        A                 B
+//   round 1 (square)          b = Y^2           c = Z^2
+//   round 2 (square)          (Y + Z)^2         j = X^2
+//   round 3 (square)          e^2               g^2
+//   round 4 (product)         a = X Y           Z' = b h
+//   round 5 (product)         X' = (a/2) d      -
+//   round 6 (times px | py)   c1 = 3 j px       c2 = -h py
+// Same formulas as line_dbl_step (ark-ec bls12/g2.rs double_in_place), so the raw Miller-loop output stays bit-identical.
+// The five addition steps run redundantly on both pairs.
+__device__ __forceinline__ bool quad_hi() { return (threadIdx.x & 2u) != 0; }
+__device__ __forceinline__ void xq(Fp2H &r, const Fp2H &a) {
+#pragma unroll
+    for (int i = 0; i < NL; i++) r.v.l[i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a.v.l[i], 0x4E /* quad_perm [2,3,0,1] */, 0xF, 0xF, true);
+}
+__device__ __forceinline__ void selq(Fp2H &r, bool hi, const Fp2H &if_hi, const Fp2H &if_lo) { sel(r.v, hi, if_hi.v, if_lo.v); }
+
+// on return l.c0 is complete on both pairs; l.c1 is valid on pair A, l.c2 on pair B (both already multiplied by px / py)
+__device__ __forceinline__ void line_dbl_step_quad(G2ProjT<Fp2H> &R, LineT<Fp2H> &l, const Fp &px, const Fp &py) {
+    const bool B = quad_hi();
+    Fp2H in, res, oth, b, c, e, f, g, hh, h, i, j, e2, g2, d, t, u, v;
+    selq(in, B, R.z, R.y); f2_sqr_m<64>(res, in); xq(oth, res);                    // round 1
+    selq(b, B, oth, res); selq(c, B, res, oth);
+    fadd(t, c, c); fadd(t, t, c); fnorm(t, t);
+    fdbl(t, t); fdbl(t, t); fnorm(t, t);
+    f2_mul_xi_n<128>(e, t);
+    fadd(f, e, e); fadd(f, f, e); fnorm(f, f);
+    fadd(t, b, f); fhalf(g, t);
+    f2_sub_n<8>(i, e, b);
+    f2_sub_n<1024>(d, b, f);
+    f2_add_n(t, R.y, R.z); selq(in, B, R.x, t); f2_sqr_m<64>(res, in); xq(oth, res);   // round 2
+    selq(hh, B, oth, res); selq(j, B, res, oth);
+    fadd(t, b, c); f2_sub_n<16>(h, hh, t);
+    selq(in, B, g, e); f2_sqr_m<256>(res, in); xq(oth, res);                      // round 3
+    selq(e2, B, oth, res); selq(g2, B, res, oth);
+    selq(u, B, b, R.x); selq(v, B, h, R.y); fmul(res, u, v);                      // round 4: A: X Y, B: b h
+    Fp2H ah; fhalf(ah, res);
+    fmul(t, ah, d);                                                               // round 5: A: X' (B's value is not used)
+    Fp2H give; selq(give, B, res, t); xq(oth, give);                              // A hands X' over and receives Z'
+    Fp2H nx, ny, nz;
+    selq(nx, B, oth, t); selq(nz, B, res, oth);
+    fadd(d, e2, e2); fadd(d, d, e2); f2_sub_n<32>(ny, g2, d);
+    R.x = nx; R.y = ny; R.z = nz;
+    l.c0 = i;
+    Fp2H c1u, c2u; fadd(t, j, j); fadd(t, t, j); fnorm(c1u, t); f2_neg_n<32>(c2u, h);
+    Fp k; sel(k, B, py, px); selq(in, B, c2u, c1u); fmul_fp(res, in, k);          // round 6
+    l.c1 = res; l.c2 = res;
+}
+
+__global__ void __launch_bounds__(64) k_miller_lines_quad(const uint32_t *__restrict__ p_abi, const uint32_t *__restrict__ q_abi, const uint8_t *__restrict__ skip, size_t n, uint32_t *__restrict__ lines) {
+    size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+    const uint32_t h = threadIdx.x & 1u;
+    const bool B = quad_hi();
+    if (i >= n) return;
+    bool sk = skip && skip[i];
+    uint32_t pw[24]; uint32_t anyp = 0, anyq = 0;
+    for (int k = 0; k < 24; k++) { pw[k] = p_abi[i * 24 + k]; anyp |= pw[k]; }
+    uint32_t qx[12], qy[12];
+    for (int k = 0; k < 12; k++) { qx[k] = q_abi[i * 48 + h * 12 + k]; qy[k] = q_abi[i * 48 + 24 + h * 12 + k]; anyq |= qx[k] | qy[k]; }
+    anyq |= xchg32(anyq);
+    if (!anyp || !anyq) sk = true;
+    // pair A stores c0 and c1, pair B stores c2 (each lane its own half)
+    auto put = [&](int s, const LineT<Fp2H> &l) {
+        auto st = [&](int c, const Fp2H &x) { for (int j = 0; j < NL; j++) lines[((size_t)s * LW + (2 * c + h) * NL + j) * n + i] = x.v.l[j]; };
+        if (!B) { st(0, l.c0); st(1, l.c1); } else st(2, l.c2);
+    };
+    if (sk) {
+        LineT<Fp2H> one; fset_one(one.c0); fzero(one.c1); fzero(one.c2);
+        for (int s = 0; s < N_LINES; s++) put(s, one);
+        return;
+    }
+    Fp px, py; fp_from_abi(px, pw); fp_from_abi(py, pw + 12);
+    Aff<Fp2H> Q; fp_from_abi(Q.x.v, qx); fp_from_abi(Q.y.v, qy);
+    G2ProjT<Fp2H> R; R.x = Q.x; R.y = Q.y; fset_one(R.z);
+    int s = 0;
+    for (int b = 62; b >= 0; b--) {
+        LineT<Fp2H> l; line_dbl_step_quad(R, l, px, py); put(s++, l);
+        if ((BLS_X_ABS >> b) & 1) { line_add_step(R, Q, l); line_eval(l, px, py); put(s++, l); }
+    }
+}
+
 // partial[(s * nsl + j) * F12W + k]
 __global__ void __launch_bounds__(64) k_line_products(const uint32_t *__restrict__ lines, size_t n, int slice_len, int nsl, uint32_t *__restrict__ partial) {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -199,7 +284,12 @@ int32_t dgpu_multi_miller_loop(const uint64_t *p, const uint64_t *q, const uint8
     { StageTimer st(sl, "ml.lines");
       static const bool one_lane = getenv("DGPU_ML_ONE_LANE") != nullptr;     // development switch: one lane per pair
       if (one_lane) hipLaunchKernelGGL(k_miller_lines, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, sl.in_bases.as<uint32_t>(), sl.in_scalars.as<uint32_t>(), dskip, n, sl.ml_lines.as<uint32_t>());
-      else hipLaunchKernelGGL(k_miller_lines_pair, dim3((unsigned)((2 * n + 63) / 64)), dim3(64), 0, s, sl.in_bases.as<uint32_t>(), sl.in_scalars.as<uint32_t>(), dskip, n, sl.ml_lines.as<uint32_t>()); }
+      else {
+          static const bool two_lanes = getenv("DGPU_ML_TWO_LANES") != nullptr;   // development switch: one lane pair per (P, Q)
+          if (two_lanes || n > 8192) hipLaunchKernelGGL(k_miller_lines_pair,     // (with the chip full, the pair form does less total work)
+              dim3((unsigned)((2 * n + 63) / 64)), dim3(64), 0, s, sl.in_bases.as<uint32_t>(), sl.in_scalars.as<uint32_t>(), dskip, n, sl.ml_lines.as<uint32_t>());
+          else hipLaunchKernelGGL(k_miller_lines_quad, dim3((unsigned)((4 * n + 63) / 64)), dim3(64), 0, s, sl.in_bases.as<uint32_t>(), sl.in_scalars.as<uint32_t>(), dskip, n, sl.ml_lines.as<uint32_t>());
+      } }
     { StageTimer st(sl, "ml.products");
       hipLaunchKernelGGL(k_line_products, dim3((unsigned)((N_LINES * nsl + 63) / 64)), dim3(64), 0, s, sl.ml_lines.as<uint32_t>(), n, slice_len, nsl, sl.ml_partial.as<uint32_t>()); }
     { StageTimer st(sl, "ml.tree");

@@ -195,8 +195,10 @@ def _gipa_verify(proof, r_shift, transcript, names):
     for k in names:
         jobs["t" + k] = (proof["com_" + k].t, [(l.t, r.t) for l, r in gipa["comms_" + k]])
         jobs["u" + k] = (proof["com_" + k].u, [(l.u, r.u) for l, r in gipa["comms_" + k]])
-    for key, (first, pairs) in jobs.items():
-        res[key] = ops.gt_multi_pow([first] + [x for pair in pairs for x in pair], exps)
+    keys = list(jobs)
+    outs = ops.parallel([lambda k=k: ops.gt_multi_pow([jobs[k][0]] + [x for pair in jobs[k][1] for x in pair], exps) for k in keys], host=True)
+    for k, o in zip(keys, outs):
+        res[k] = o
     challenges.reverse(); challenges_inv.reverse()
     final_r = kzg.polynomial_evaluation_product_form_from_transcript(challenges_inv, r_shift, 1)
     return res, final_r, challenges, challenges_inv

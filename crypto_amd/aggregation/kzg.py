@@ -66,9 +66,12 @@ def prove_commitment_w(g_alpha_table, g_beta_table, transcript, r_shift, kzg_cha
 def verify_kzg_v(v_srs, final_vkey, vkey_opening, challenges, kzg_challenge, checker):
     y = polynomial_evaluation_product_form_from_transcript(challenges, kzg_challenge, 1)
     ng = ops.neg(G1, v_srs.g)
-    for cf, vk, pi in ((final_vkey[0], v_srs.g_alpha, vkey_opening[0]), (final_vkey[1], v_srs.g_beta, vkey_opening[1])):
-        b = ops.msm(G2, np.stack([cf, v_srs.h]), [1, -y])                 # C_f - y h
-        c = ops.msm(G1, np.stack([vk, v_srs.g]), [1, -kzg_challenge])      # vk - x g
+    items = ((final_vkey[0], v_srs.g_alpha, vkey_opening[0]), (final_vkey[1], v_srs.g_beta, vkey_opening[1]))
+    # the four two-term combinations are independent: issued together (the library keeps 4 calls in flight)
+    bs_cs = ops.parallel([f for cf, vk, _ in items for f in (lambda cf=cf: ops.msm(G2, np.stack([cf, v_srs.h]), [1, -y]),                 # C_f - y h
+                                                             lambda vk=vk: ops.msm(G1, np.stack([vk, v_srs.g]), [1, -kzg_challenge]))])      # vk - x g
+    for k, (_, _, pi) in enumerate(items):
+        b, c = bs_cs[2 * k], bs_cs[2 * k + 1]
         checker.add_multiple_sources_and_target(np.stack([ng, c]), np.stack([b, pi]), ops.fp12_one())
 
 
@@ -76,7 +79,9 @@ def verify_kzg_w(v_srs, final_wkey, wkey_opening, challenges, r_shift, kzg_chall
     fz = polynomial_evaluation_product_form_from_transcript(challenges, kzg_challenge, r_shift)
     fwz = fz * pow(kzg_challenge, v_srs.n, R_MOD) % R_MOD
     nh = ops.neg(G2, v_srs.h)
-    for cf, wk, pi in ((final_wkey[0], v_srs.h_alpha, wkey_opening[0]), (final_wkey[1], v_srs.h_beta, wkey_opening[1])):
-        a = ops.msm(G1, np.stack([cf, v_srs.g]), [1, -fwz])                # C_f - y g
-        d = ops.msm(G2, np.stack([wk, v_srs.h]), [1, -kzg_challenge])      # wk - x h
+    items = ((final_wkey[0], v_srs.h_alpha, wkey_opening[0]), (final_wkey[1], v_srs.h_beta, wkey_opening[1]))
+    as_ds = ops.parallel([f for cf, wk, _ in items for f in (lambda cf=cf: ops.msm(G1, np.stack([cf, v_srs.g]), [1, -fwz]),               # C_f - y g
+                                                             lambda wk=wk: ops.msm(G2, np.stack([wk, v_srs.h]), [1, -kzg_challenge]))])     # wk - x h
+    for k, (_, _, pi) in enumerate(items):
+        a, d = as_ds[2 * k], as_ds[2 * k + 1]
         checker.add_multiple_sources_and_target(np.stack([a, pi]), np.stack([nh, d]), ops.fp12_one())

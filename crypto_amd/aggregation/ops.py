@@ -112,13 +112,20 @@ def gt_multi_pow(bases, exps):
 
 
 _POOL = None
+_HOST_POOL = None
 
 
-def parallel(thunks):
+def parallel(thunks, host=False):
     """run independent ABI calls from host threads (the library keeps 4 calls in flight on separate HIP streams; ctypes drops
-    the GIL) — the reference runs the same calls under rayon"""
-    global _POOL
-    if _POOL is None:
-        from concurrent.futures import ThreadPoolExecutor
-        _POOL = ThreadPoolExecutor(4)
-    return [f.result() for f in [_POOL.submit(t) for t in thunks]]
+    the GIL) — the reference runs the same calls under rayon.  host=True: calls that only use host cores (wider pool)."""
+    global _POOL, _HOST_POOL
+    from concurrent.futures import ThreadPoolExecutor
+    if host:
+        if _HOST_POOL is None:
+            _HOST_POOL = ThreadPoolExecutor(8)
+        pool = _HOST_POOL
+    else:
+        if _POOL is None:
+            _POOL = ThreadPoolExecutor(4)
+        pool = _POOL
+    return [f.result() for f in [pool.submit(t) for t in thunks]]

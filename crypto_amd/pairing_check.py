@@ -50,6 +50,18 @@ def fp12_pow(a, e):
     return out
 
 
+def fp12_multi_pow(bases, exps):
+    """prod bases[i]^exps[i] (dgpu_fp12_multi_pow: host threads, shared squarings)"""
+    n = len(bases)
+    a = np.ascontiguousarray(np.stack([np.asarray(b, dtype=np.uint64).reshape(72) for b in bases]))
+    e = np.ascontiguousarray(np.stack([_limbs(int(x) % R_MOD) for x in exps]))
+    out = np.zeros(72, dtype=np.uint64)
+    rc = lib().dgpu_fp12_multi_pow(_p(a), _p(e), n, _p(out))
+    if rc:
+        raise DockGpuError(rc, "dgpu_fp12_multi_pow")
+    return out
+
+
 def g1_scale(points, m, negate=False):
     """[m * P for P in points] as affine ABI points (identity -> zero words + flag), `-` if negate"""
     _ensure()
@@ -85,6 +97,7 @@ class RandomizedPairingChecker:
         self.right = fp12_one()                                # PairingOutput::zero() == Fp12 one
         self.lazy = bool(lazy)
         self.pending = ([], [])
+        self.pending_targets = []
         self.random = random % R_MOD
         self.current_random = 1
 
@@ -109,7 +122,12 @@ class RandomizedPairingChecker:
         else:
             a_m, inf = g1_scale(a, m)
             self.left = fp12_mul(self.left, pairing.multi_miller_loop(a_m, b, inf))
-        self.right = fp12_mul(self.right, fp12_pow(out, m))
+        out = np.ascontiguousarray(out, dtype=np.uint64).reshape(72)
+        if not (out == fp12_one()).all():                 # a target of one (e(..) e(..) = 1, the KZG checks) contributes nothing
+            if lazy:
+                self.pending_targets.append((out, m))     # right += out.mul_bigint(m): all of them as ONE multi-exponentiation in verify()
+            else:
+                self.right = fp12_mul(self.right, fp12_pow(out, m))
         self.current_random = self.current_random * self.random % R_MOD
 
     def add_multiple_sources(self, a, b, c, d, lazy=None):              # prod e(a_i, b_i) == prod e(c_i, d_i)   :142-173
@@ -137,6 +155,9 @@ class RandomizedPairingChecker:
 
     def verify(self):                                                   # :204-214
         left = self.left
+        if self.pending_targets:
+            self.right = fp12_mul(self.right, fp12_multi_pow([o for o, _ in self.pending_targets], [m for _, m in self.pending_targets]))
+            self.pending_targets = []
         if self.pending[0]:
             pts = np.concatenate([a for a, _, _ in self.pending[0]])
             sc = np.concatenate([np.tile(_limbs(m), (len(a), 1)) for a, m, _ in self.pending[0]])

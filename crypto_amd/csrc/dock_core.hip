@@ -24,7 +24,7 @@ int choose_c(size_t n) {
 int choose_chunk(size_t E) {
     if (g.chunk) return g.chunk;
     const char *e = getenv("DGPU_CHUNK");
-    if (e) { int v = atoi(e); if (v >= 16 && v <= 4096 && (v & (v - 1)) == 0) return v; }
+    if (e) { int v = atoi(e); if (v >= 16 && v <= 4096) return v; }
     // terms per lane: as few lanes as still fill the chip once (256 CUs x 512 lanes = 131072), so that a chunk is about as
     // long as a bucket's run at every n (at n = 2^24 a fixed 64 left 7 of 8 chunks inside one bucket and the fix-up
     // pass ran at 1/8 lane efficiency)

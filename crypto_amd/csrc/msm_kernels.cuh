@@ -346,4 +346,113 @@ __global__ void __launch_bounds__(64) k_reduce_top(const uint32_t *__restrict__ 
     }
 }
 
+
+// ---- K7/K8 for G2 on lane pairs (fp2_pair.cuh) ---------------------------------------------------------------------------------
+// Same group geometry and l1 layout as k_reduce_l0 / k_reduce_top, but a point lives on a lane pair (even lane: c0 halves, odd lane: c1
+// halves), so a wave holds 32 points and every point-lane takes twice the items.  The one-lane Fp2 addition needs > 256 VGPRs (spills)
+// and is ~3x the instructions of a half: the pair form runs the same dependent chain in about half the time (3.0 -> 1.6 ms at 2^20).
+__device__ __forceinline__ void load_soa_pair(Xyzz<Fp2H> &p, const uint32_t *__restrict__ base, size_t b) {
+    const uint32_t h = threadIdx.x & 1u;
+    uint32_t *w = reinterpret_cast<uint32_t *>(&p);
+    const uint32_t *t = base + (b / SOA_TILE) * (G2P::XW * SOA_TILE) + (b % SOA_TILE);
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+#pragma unroll
+        for (int j = 0; j < NL; j++) w[k * NL + j] = t[((2 * k + h) * NL + j) * SOA_TILE];
+}
+__device__ __forceinline__ void shfl_down_pair(Xyzz<Fp2H> &o, bool &oinf, const Xyzz<Fp2H> &x, bool xinf, int d /* point-lanes */) {
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(&x);
+    uint32_t *q = reinterpret_cast<uint32_t *>(&o);
+#pragma unroll
+    for (int k = 0; k < 4 * NL; k++) q[k] = __shfl_down(w[k], 2 * d, 64);
+    int fi = __shfl_down((int)xinf, 2 * d, 64);
+    oinf = (fi != 0) || ((int)((threadIdx.x & 63) >> 1) + d >= 32);
+}
+// point-lane q holds (S_q, A_q), its items' global weights offset by q * 2^shift; on return point-lane 0 holds S = sum S_q, A = sum (A_q + q 2^shift S_q)
+__device__ __forceinline__ void wave_weighted_sum_pair(Xyzz<Fp2H> &S, bool &sinf, Xyzz<Fp2H> &A, bool &ainf, int shift) {
+    const int q = (threadIdx.x & 63) >> 1;
+    for (int d = 1; d < 32; d <<= 1) {
+        Xyzz<Fp2H> o; bool oinf; shfl_down_pair(o, oinf, S, sinf, d);
+        xyzz_add(S, sinf, o, oinf);
+    }
+    Xyzz<Fp2H> y = S; bool yinf = (q == 0) ? true : sinf;
+    for (int k = 0; k < shift; k++) { if (!yinf) { Xyzz<Fp2H> d2; xyzz_dbl(d2, y); y = d2; } }
+    xyzz_add(A, ainf, y, yinf);
+    for (int d = 16; d >= 1; d >>= 1) {
+        Xyzz<Fp2H> o; bool oinf; shfl_down_pair(o, oinf, A, ainf, d);
+        xyzz_add(A, ainf, o, oinf);
+    }
+}
+__device__ __forceinline__ void store_l1_pair(uint32_t *__restrict__ dst, const Xyzz<Fp2H> &p) {       // AoS, G2 word order: coordinate k, half h at (2k + h) * NL
+    const uint32_t h = threadIdx.x & 1u;
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(&p);
+    for (int k = 0; k < 4; k++) for (int j = 0; j < NL; j++) dst[(2 * k + h) * NL + j] = w[k * NL + j];
+}
+__device__ __forceinline__ void load_l1_pair(Xyzz<Fp2H> &p, const uint32_t *__restrict__ src) {
+    const uint32_t h = threadIdx.x & 1u;
+    uint32_t *w = reinterpret_cast<uint32_t *>(&p);
+    for (int k = 0; k < 4; k++) for (int j = 0; j < NL; j++) w[k * NL + j] = src[(2 * k + h) * NL + j];
+}
+// one wave per group of 64 * m buckets: 32 point-lanes x 2m buckets each
+template <class PAIR /* = G2P: a template only so that the header may be included by several translation units */>
+__global__ void __launch_bounds__(64) k_reduce_l0_pair(const uint32_t *__restrict__ bucket, const uint8_t *__restrict__ bucket_inf, uint32_t NB, int mshift,
+                                                       uint32_t *__restrict__ l1, uint8_t *__restrict__ l1_inf) {
+    typedef Fp2H F;
+    const int q = (threadIdx.x & 63) >> 1;
+    const uint32_t m2 = 2u << mshift;                    // buckets per point-lane
+    const size_t g = blockIdx.x;
+    const size_t b0 = (g * 32 + q) * (size_t)m2;
+    Xyzz<F> run, tot; bool rinf = true, tinf = true;
+    fzero(run.x); fzero(run.y); fzero(run.zz); fzero(run.zzz); tot = run;
+    for (int k = (int)m2 - 1; k >= 0; k--) {
+        const size_t b = b0 + k;
+        const bool binf = bucket_inf[b] != 0;
+        Xyzz<F> p;
+        if (!binf) load_soa_pair(p, bucket, b); else p = run;
+        xyzz_add(run, rinf, p, binf);
+        xyzz_add(tot, tinf, run, rinf);
+    }
+    wave_weighted_sum_pair(run, rinf, tot, tinf, mshift + 1);
+    if (q == 0) {
+        uint32_t *dst = l1 + g * 2 * G2::XW;
+        store_l1_pair(dst, run); store_l1_pair(dst + G2::XW, tot);
+        if ((threadIdx.x & 1u) == 0) { l1_inf[2 * g] = rinf; l1_inf[2 * g + 1] = tinf; }
+    }
+}
+// one wave per window: point-lane q first folds groups 2q and 2q + 1 (weights offset by 2^gshift), then the wave sum over 32 point-lanes
+template <class PAIR>
+__global__ void __launch_bounds__(64) k_reduce_top_pair(const uint32_t *__restrict__ l1, const uint8_t *__restrict__ l1_inf, int G, int gshift,
+                                                        uint32_t *__restrict__ win_abi, uint8_t *__restrict__ win_inf) {
+    typedef Fp2H F;
+    const int q = (threadIdx.x & 63) >> 1;
+    const uint32_t h = threadIdx.x & 1u;
+    const size_t w = blockIdx.x;
+    const bool has0 = 2 * q < G, has1 = 2 * q + 1 < G;
+    const size_t g0 = w * G + 2 * q, g1 = g0 + 1;
+    auto zero = [](Xyzz<F> &p) { fzero(p.x); fzero(p.y); fzero(p.zz); fzero(p.zzz); };
+    // A = A_0 + A_1 + 2^gshift S_1 ;  S = S_0 + S_1     (one operand pair live at a time: four points at once would spill)
+    Xyzz<F> A; bool ainf = true; zero(A);
+    if (has0) { load_l1_pair(A, l1 + g0 * 2 * G2::XW + G2::XW); ainf = l1_inf[2 * g0 + 1] != 0; }
+    { Xyzz<F> t; bool tinf = true; zero(t);
+      if (has1) { load_l1_pair(t, l1 + g1 * 2 * G2::XW + G2::XW); tinf = l1_inf[2 * g1 + 1] != 0; }
+      xyzz_add(A, ainf, t, tinf); }
+    Xyzz<F> S1; bool s1inf = true; zero(S1);
+    if (has1) { load_l1_pair(S1, l1 + g1 * 2 * G2::XW); s1inf = l1_inf[2 * g1] != 0; }
+    { Xyzz<F> y = S1; bool yinf = s1inf;
+      for (int k = 0; k < gshift; k++) { if (!yinf) { Xyzz<F> d2; xyzz_dbl(d2, y); y = d2; } }
+      xyzz_add(A, ainf, y, yinf); }
+    Xyzz<F> S; bool sinf = true; zero(S);
+    if (has0) { load_l1_pair(S, l1 + g0 * 2 * G2::XW); sinf = l1_inf[2 * g0] != 0; }
+    xyzz_add(S, sinf, S1, s1inf);
+    wave_weighted_sum_pair(S, sinf, A, ainf, gshift + 1);
+    if (q == 0) {
+        uint32_t *dst = win_abi + w * 4 * G2::ABI_W;
+        if (h == 0) win_inf[w] = ainf;
+        if (!ainf) {
+            const Fp *f = reinterpret_cast<const Fp *>(&A);          // x, y, zz, zzz halves
+            for (int k = 0; k < 4; k++) fp_to_abi(dst + 12 * (2 * k + h), f[k]);
+        }
+    }
+}
+
 }  // namespace msm

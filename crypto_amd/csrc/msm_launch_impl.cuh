@@ -21,9 +21,11 @@ template <class C> void launch_fixup_heavy(hipStream_t s, const uint32_t *heavy,
     hipLaunchKernelGGL((k_fixup_heavy<C>), dim3(512), dim3(C::HEAVY_T), 0, s, heavy, heavy_cap, off, CH, NB, bucket, bucket_inf, head, tail, part_inf, T);
 }
 template <class C> void launch_reduce_l0(hipStream_t s, unsigned NG, const uint32_t *bucket, const uint8_t *bucket_inf, uint32_t NB, int mshift, uint32_t *l1, uint8_t *l1_inf) {
-    hipLaunchKernelGGL((k_reduce_l0<C>), dim3(NG), dim3(64), 0, s, bucket, bucket_inf, NB, mshift, l1, l1_inf);
+    if constexpr (C::NFP == 2) hipLaunchKernelGGL((k_reduce_l0_pair<G2P>), dim3(NG), dim3(64), 0, s, bucket, bucket_inf, NB, mshift, l1, l1_inf);     // G2: lane pairs
+    else hipLaunchKernelGGL((k_reduce_l0<C>), dim3(NG), dim3(64), 0, s, bucket, bucket_inf, NB, mshift, l1, l1_inf);
 }
 template <class C> void launch_reduce_top(hipStream_t s, unsigned W, const uint32_t *l1, const uint8_t *l1_inf, int G, int gshift, uint32_t *win_abi, uint8_t *win_inf) {
-    hipLaunchKernelGGL((k_reduce_top<C>), dim3(W), dim3(64), 0, s, l1, l1_inf, G, gshift, win_abi, win_inf);
+    if constexpr (C::NFP == 2) hipLaunchKernelGGL((k_reduce_top_pair<G2P>), dim3(W), dim3(64), 0, s, l1, l1_inf, G, gshift, win_abi, win_inf);
+    else hipLaunchKernelGGL((k_reduce_top<C>), dim3(W), dim3(64), 0, s, l1, l1_inf, G, gshift, win_abi, win_inf);
 }
 }  // namespace msm

@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--log2n", type=int, default=20, help="terms per GPU = 2^log2n (BASELINE: 20 at 1 GPU, 21 per GPU for 2^24 on 8)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the G2 / Miller-loop / witness-map timings appended to the JSON line at N = 1")
     ap.add_argument("--inflight", type=int, default=4, help="MSM calls in flight per GPU (host threads; each call owns a stream + workspace slot)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -201,9 +202,62 @@ def main():
             out["cpu_baseline"] = {"value": round((ns / float(1 << 20)) / tcpu, 4), "unit": "MSM/s (n=2^20-term equivalents)", "cores": thr,
                                    "kind": "port", "sample": "one n=2^%d G1 MSM, %.2f s wall on %d threads of %d logical CPUs; result bit-exact vs GPU: %s" % (
                                        log2s, tcpu, thr, ncpu, same)}
+        if world == 1 and not args.no_secondary:
+            try:
+                out["secondary"] = secondary_configs(args.log2n)
+            except Exception as e:                      # never let the secondary numbers take the headline line down
+                out["secondary"] = {"error": repr(e)}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def secondary_configs(log2n):
+    """BASELINE configs 3 and 4 next to the headline, outside the timed region (N = 1 only, a few seconds): G2 MSM at the same n,
+    the 1024-pair Miller loop + final exponentiation, the R1CS->QAP witness map at D = 2^log2n.  Inputs are synthetic: G2 bases and the
+    pairing inputs are device fixed-base products of seeded scalars (parity of these paths is the GPU test-suite's job, not this one's)."""
+    import numpy as np
+    import crypto_amd as ca
+    from crypto_amd import fixed_base as FB, qap
+    import oracle_c as O
+
+    def timed(fn, k=5):
+        fn()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            fn()
+        return (time.perf_counter() - t0) / k * 1e3
+
+    n = 1 << log2n
+    res = {}
+    with FB.WindowTable(ca.G2, O.G2.generator()) as t2, FB.WindowTable(ca.G1, O.G1.generator()) as t1:
+        db2 = t2.multiply_many_to_bases(O.rand_scalars(0x5EED0003, n))
+        ds = ca.DeviceScalars(O.rand_scalars(0x5EED0004, n))
+        res["g2_msm_ms"] = round(timed(lambda: db2.msm_resident(ds), 3), 3)
+        res["g2_msm_per_s"] = round(1e3 / res["g2_msm_ms"], 2)
+        db2.free(); ds.free()
+        P, _ = t1.multiply_many(O.rand_scalars(0x5EED0005, 1024)); Q, _ = t2.multiply_many(O.rand_scalars(0x5EED0006, 1024))
+    f = ca.multi_miller_loop(P, Q)
+    res["miller_loop_1024_pairs_ms"] = round(timed(lambda: ca.multi_miller_loop(P, Q)), 3)
+    res["miller_loop_pairs_per_s"] = round(1024 / res["miller_loop_1024_pairs_ms"] * 1e3, 0)
+    res["final_exponentiation_ms"] = round(timed(lambda: ca.final_exponentiation(f)), 3)
+    # witness map on the x_i = x_{i-1}^2 + i circuit shape (m + 1 constraints + 2 instance variables = D), circuit resident
+    m = n - 3
+    idx = np.arange(m, dtype=np.uint32)
+    one = np.zeros((1, 4), np.uint64); one[0, 0] = 1
+    a_rp = np.arange(m + 2, dtype=np.uint64); a_cl = np.concatenate([2 + idx, [2 + m]]).astype(np.uint32); a_vl = np.repeat(one, m + 1, 0)
+    b_cl = np.concatenate([2 + idx, [0]]).astype(np.uint32)
+    c_rp = np.concatenate([2 * np.arange(m + 1, dtype=np.uint64), [2 * m + 1]]).astype(np.uint64)
+    c_cl = np.concatenate([np.stack([3 + idx, np.zeros(m, np.uint32)], 1).reshape(-1), [1]]).astype(np.uint32)
+    circ = qap.DeviceR1cs((a_rp, a_cl, a_vl), (a_rp, b_cl, a_vl), (c_rp, c_cl, np.repeat(one, 2 * m + 1, 0)), m + 3, 2, m + 1)
+    z = O.rand_scalars(0x5EED0007, m + 3)
+
+    def wm():
+        _, dh = circ.witness_map(z, to_host=False, resident=True)
+        dh.free()
+    res["witness_map_ms"] = round(timed(wm, 3), 3)
+    res["note"] = "n = D = 2^%d; one call in flight; host-visible wall time per call" % log2n
+    return res
 
 
 if __name__ == "__main__":

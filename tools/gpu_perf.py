@@ -102,3 +102,22 @@ if "fb" in what:
             dt, s = stages(lambda: tab.multiply_many(sc), K=3)
             print("fixed-base %s n=2^%d %.3f ms (%.2f M mul/s) | %s | table build %.2f / %.2f ms" % (cv.tag, lg, dt * 1e3, n / dt / 1e6, s, tb * 1e3, tb2 * 1e3), flush=True)
         tab.free()
+if "dist" in what:
+    # SURVEY 8(d) config 2 secondary scalar distributions, n = 2^20 resident
+    n = 1 << 20
+    bases = O.G1.gen_seq(k0, d, n, threads=64)
+    rng = np.random.default_rng(5)
+    uni = O.rand_scalars(31, n)
+    dists = {"uniform": uni}
+    eq = np.tile(uni[:1], (n, 1)); dists["all-equal"] = eq
+    s16 = np.zeros((n, 4), np.uint64); s16[:, 0] = rng.integers(0, 1 << 16, n, dtype=np.uint64); dists["16-bit"] = s16
+    zo = uni.copy(); kind = rng.integers(0, 4, n); zo[kind <= 1] = 0; zo[kind == 1, 0] = 1; dists["50% zeros/ones"] = zo
+    inf = (rng.integers(0, 100, n) == 0).astype(np.uint8)
+    for name, sc in dists.items():
+        db = ca.DeviceBases(ca.G1, bases); ds = ca.DeviceScalars(sc)
+        dt, s = stages(lambda: db.msm_resident(ds))
+        print("G1 2^20 %-16s %.3f ms | %s" % (name, dt * 1e3, s), flush=True)
+        db.free(); ds.free()
+    db = ca.DeviceBases(ca.G1, bases, inf); ds = ca.DeviceScalars(uni)
+    dt, s = stages(lambda: db.msm_resident(ds))
+    print("G1 2^20 %-16s %.3f ms | %s" % ("1% identity bases", dt * 1e3, s), flush=True)

@@ -21,15 +21,16 @@ int choose_c(size_t n) {
     }
     return bc;
 }
-int choose_chunk(size_t E) {
+int choose_chunk(size_t E, int min_chunk, size_t max_chunks) {
     if (g.chunk) return g.chunk;
     const char *e = getenv("DGPU_CHUNK");
     if (e) { int v = atoi(e); if (v >= 16 && v <= 4096) return v; }
-    // terms per lane: as few lanes as still fill the chip once (256 CUs x 512 lanes = 131072), so that a chunk is about as
-    // long as a bucket's run at every n (at n = 2^24 a fixed 64 left 7 of 8 chunks inside one bucket and the fix-up
-    // pass ran at 1/8 lane efficiency)
-    int ch = 64;
-    while (E / (size_t)ch > 140000 && ch < 4096) ch *= 2;
+    // terms per lane.  A lane's chunk is one dependent chain of mixed additions (~12 us each), so short chunks win as long as the
+    // partial slots they create stay cheap to fold: 16 terms up to ~300 k lanes (two rounds of the chip's 131 072 lanes at
+    // 2 waves/SIMD), then doubling — measured at n = 2^12 .. 2^18: 16 beats 64 by 13-35 % (tools: DGPU_CHUNK sweep), at 2^20 64 and
+    // 128 tie, and at n = 2^24 a fixed 64 left 7 of 8 chunks inside one bucket and the fix-up pass ran at 1/8 lane efficiency.
+    int ch = min_chunk;       // 16 for G1; 32 for G2, whose partial slots are folded by the one-lane Fp2 addition of k_fixup
+    while (E / (size_t)ch > max_chunks && ch < 4096) ch *= 2;      // G1: 300 k chunks; G2 (two lanes per chunk): 150 k
     return ch;
 }
 

@@ -63,7 +63,7 @@ int32_t msm_device(Slot &sl, const uint32_t *d_bases, const uint32_t *d_scalars,
     const int G = (int)(B >> (6 + mshift));          // groups per window (<= 64), B >= 64 because c >= 7
     const size_t NG = (size_t)W * G;
     const size_t Emax = (size_t)n * W;
-    const int CH = choose_chunk(Emax);
+    const int CH = C::NFP == 2 ? choose_chunk(Emax, 32, 150000) : choose_chunk(Emax, 16, 300000);
     const size_t T = (Emax + CH - 1) / CH;
     const size_t nblk = scan_blocks(NB);
 

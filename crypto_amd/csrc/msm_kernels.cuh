@@ -242,7 +242,9 @@ __global__ void __launch_bounds__(C::HEAVY_T) k_fixup_heavy(const uint32_t *__re
             else { load_soa<C>(o, head, T, t); oinf = part_inf[2 * t] != 0; }
             xyzz_add(acc, inf, o, oinf);
         }
+        const size_t pieces = t1 - t0 + 1;
         for (int s2 = BT / 2; s2 >= 1; s2 >>= 1) {
+            if ((size_t)s2 >= pieces) continue;             // (uniform per block) threads s2 .. 2 s2 - 1 hold nothing yet
             __syncthreads();
             if ((int)threadIdx.x >= s2 && (int)threadIdx.x < 2 * s2) {
                 const uint32_t *w = reinterpret_cast<const uint32_t *>(&acc);
@@ -453,6 +455,28 @@ __global__ void __launch_bounds__(64) k_reduce_top_pair(const uint32_t *__restri
             for (int k = 0; k < 4; k++) fp_to_abi(dst + 12 * (2 * k + h), f[k]);
         }
     }
+}
+
+
+// K6 for G2 on lane pairs: lanes 2t and 2t + 1 fold the partials of the bucket whose tail slot is t (same logic as k_fixup)
+template <class PAIR>
+__global__ void __launch_bounds__(256) k_fixup_pair(uint32_t NB, uint32_t *__restrict__ bucket, uint8_t *__restrict__ bucket_inf,
+                                                    const uint32_t *__restrict__ head, const uint32_t *__restrict__ tail, const uint32_t *__restrict__ head_b,
+                                                    const uint32_t *__restrict__ tail_b, const uint8_t *__restrict__ part_inf, size_t T,
+                                                    const uint32_t *__restrict__ off, uint32_t heavy_thr) {
+    const size_t t = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 1;
+    if (t >= T) return;
+    const uint32_t b = tail_b[t];
+    if (b == 0xffffffffu) return;
+    if (off[b + 1] - off[b] >= heavy_thr) return;   // folded by k_fixup_heavy
+    Xyzz<Fp2H> acc; load_soa_pair(acc, tail, t);
+    bool inf = part_inf[2 * t + 1] != 0;
+    for (size_t k = t + 1; k < T && head_b[k] == b; k++) {
+        Xyzz<Fp2H> o; load_soa_pair(o, head, k);
+        xyzz_add(acc, inf, o, part_inf[2 * k] != 0);
+    }
+    store_soa<G2P>(bucket, NB, b, acc);
+    if ((threadIdx.x & 1u) == 0) bucket_inf[b] = inf;
 }
 
 }  // namespace msm

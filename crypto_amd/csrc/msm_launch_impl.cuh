@@ -14,7 +14,8 @@ template <class C> void launch_accumulate(hipStream_t s, const uint32_t *bases, 
 }
 template <class C> void launch_fixup(hipStream_t s, uint32_t NB, uint32_t *bucket, uint8_t *bucket_inf, const uint32_t *head, const uint32_t *tail, const uint32_t *head_b,
                                      const uint32_t *tail_b, const uint8_t *part_inf, size_t T, const uint32_t *off, uint32_t heavy_thr) {
-    hipLaunchKernelGGL((k_fixup<C>), dim3((unsigned)((T + 255) / 256)), dim3(256), 0, s, NB, bucket, bucket_inf, head, tail, head_b, tail_b, part_inf, T, off, heavy_thr);
+    if constexpr (C::NFP == 2) hipLaunchKernelGGL((k_fixup_pair<G2P>), dim3((unsigned)((2 * T + 255) / 256)), dim3(256), 0, s, NB, bucket, bucket_inf, head, tail, head_b, tail_b, part_inf, T, off, heavy_thr);   // G2: lane pairs
+    else hipLaunchKernelGGL((k_fixup<C>), dim3((unsigned)((T + 255) / 256)), dim3(256), 0, s, NB, bucket, bucket_inf, head, tail, head_b, tail_b, part_inf, T, off, heavy_thr);
 }
 template <class C> void launch_fixup_heavy(hipStream_t s, const uint32_t *heavy, uint32_t heavy_cap, const uint32_t *off, uint32_t CH, uint32_t NB, uint32_t *bucket, uint8_t *bucket_inf,
                                            const uint32_t *head, const uint32_t *tail, const uint8_t *part_inf, size_t T) {

@@ -1,7 +1,7 @@
 """Aggregate n synthetic Groth16 proofs and verify the aggregate on the GPU box; prints per-phase wall time (development helper).
-Usage: N=1024 python tools/bench_aggregation.py"""
+Usage: N=1024 python tests/perf/bench_aggregation.py"""
 import os, sys, time, json
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np
 import crypto_amd as ca

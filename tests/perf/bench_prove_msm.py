@@ -13,7 +13,7 @@ Synthetic key: bases with known discrete logs, 1 % identity entries in a/b queri
 two scalar distributions: uniform, and Groth16-like (half of the witness in {0,1}, a quarter 16-bit, a quarter full).
 """
 import json, os, sys, time, threading
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np
 import crypto_amd as ca

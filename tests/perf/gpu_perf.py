@@ -1,6 +1,6 @@
 """Stage timings on the GPU box (development helper): G1/G2 MSM stages, 1024-pair Miller loop, CPU oracle alongside."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np
 import crypto_amd as ca

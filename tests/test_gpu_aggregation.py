@@ -176,6 +176,15 @@ def test_aggregate_real_legogroth16_proofs():
     bad = copy.deepcopy(agg); bad["tmipp"]["gipa"]["final_d"] = g1(98)
     with pytest.raises(AG.AggregationError):
         AL.verify_aggregate_proof(vsrs, pvk, inputs, bad, rnd(), AG.MerlinTranscript(b"lego"))
+    # the same proofs through the Groth16 aggregator with the d_i shipped alongside (using_groth16.rs)
+    from crypto_amd.aggregation import using_groth16 as UG
+    agg_g, ds = UG.aggregate_proofs(psrs, AG.MerlinTranscript(b"lego-g16"), proofs)
+    UG.verify_aggregate_proof(vsrs, pvk, inputs, agg_g, ds, rnd(), AG.MerlinTranscript(b"lego-g16"))
+    bad_ds = ds.copy(); bad_ds[1] = g1(4242)
+    with pytest.raises(AG.AggregationError):
+        UG.verify_aggregate_proof(vsrs, pvk, inputs, agg_g, bad_ds, rnd(), AG.MerlinTranscript(b"lego-g16"))
+    with pytest.raises(AG.AggregationError):
+        UG.verify_aggregate_proof(vsrs, pvk, bad_inputs, agg_g, ds, rnd(), AG.MerlinTranscript(b"lego-g16"))
     # the Groth16 verifier must not accept a Lego aggregate's transcript (D is bound into the challenges)
     with pytest.raises((AG.AggregationError, KeyError)):
         AG.verify_aggregate_proof(vsrs, pvk, inputs + [], agg, rnd(), AG.MerlinTranscript(b"lego"))

@@ -106,6 +106,33 @@ class Pairs:
         return msm_bigint(self.curve, self.left, self.right, self.is_inf)
 
 
+class OwnedPairs(Pairs):
+    """utils/src/owned_pairs.rs `OwnedPairs<G, Fr>` (:21-105): the owning counterpart of `Pairs` — same `msm` (:95-97) and
+    `msm_bigint` (:103-105); `split`, `len`, `extend` as in the reference."""
+
+    def __init__(self, curve, left=None, right=None, is_inf=None):
+        left = np.zeros((0, curve.AW), dtype=np.uint64) if left is None else left
+        right = np.zeros((0, 4), dtype=np.uint64) if right is None else right
+        super().__init__(curve, np.array(left, dtype=np.uint64, copy=True), np.array(right, dtype=np.uint64, copy=True), is_inf)
+
+    def split(self):                 # :42-44
+        return self.left, self.right
+
+    def as_ref(self):                # :47-49
+        return Pairs(self.curve, self.left, self.right, self.is_inf)
+
+    def __len__(self):
+        return len(self.left)
+
+    def is_empty(self):
+        return len(self.left) == 0
+
+    def extend(self, pairs):         # Extend<(Left, Right)>  :124-137
+        for l, r in pairs:
+            self.left = np.concatenate([self.left, np.asarray(l, dtype=np.uint64).reshape(1, self.curve.AW)])
+            self.right = np.concatenate([self.right, np.asarray(r, dtype=np.uint64).reshape(1, 4)])
+
+
 class DeviceBases:
     """Device-resident prepared bases (a proving-key query): dgpu_bases_upload_* / dgpu_msm_*_handle."""
 

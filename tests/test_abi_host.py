@@ -78,6 +78,14 @@ def test_checked_msm_and_pairs_length_semantics():
     assert ca.msm(ca.G1, b, s) == (False, 3)
     with pytest.raises(ValueError):
         ca.Pairs(ca.G1, b, s)
+    # OwnedPairs (utils/src/owned_pairs.rs): same length rule, owns copies, extend / split / as_ref
+    with pytest.raises(ValueError):
+        ca.OwnedPairs(ca.G1, b, s)
+    op = ca.OwnedPairs(ca.G1)
+    assert op.is_empty() and len(op) == 0
+    op.extend([(b[0], s[0]), (b[1], s[1])])
+    l, r = op.split()
+    assert len(op) == 2 and l.shape == (2, 12) and r.shape == (2, 4) and isinstance(op.as_ref(), ca.Pairs)
 
 
 @pytest.mark.parametrize("curve,G", [(ca.G1, O.G1), (ca.G2, O.G2)])

@@ -178,71 +178,86 @@ __global__ void __launch_bounds__(64) k_miller_lines_quad(const uint32_t *__rest
     }
 }
 
-// partial[(s * nsl + j) * F12W + k]
+// partial[(s * nsl + j) * F12W + k] = product of the lines of step s over slice j of the pairs (sparse Fp12::mul_by_014 chain).
+// One chain per LANE PAIR (fp2_pair.cuh): the chain is serial, so its duration is the instruction count of one lane, and the pair form
+// of an Fp2 product is one fused two-product reduction per lane instead of two.  Word (2 q + h) * NL + j of an Fp12 is limb j of half h
+// of its q-th Fp2 coefficient — the same order a one-lane Fp12d has in memory.
+typedef Fp6T<Fp2H> Fp6p;
+typedef Fp12T<Fp2H> Fp12p;
 __global__ void __launch_bounds__(64) k_line_products(const uint32_t *__restrict__ lines, size_t n, int slice_len, int nsl, uint32_t *__restrict__ partial) {
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int t = (int)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 1);
+    const uint32_t h = threadIdx.x & 1u;
     if (t >= N_LINES * nsl) return;
-    int s = t / nsl, j = t % nsl;
+    const int s = t / nsl, j = t % nsl;
     size_t lo = (size_t)j * slice_len, hi = lo + slice_len; if (hi > n) hi = n;
-    Fp12d f; f12_set_one(f);
+    Fp12p f; f12_set_one(f);
     for (size_t i = lo; i < hi; i++) {
-        Line l; uint32_t *w = reinterpret_cast<uint32_t *>(&l);
-        for (int k = 0; k < LW; k++) w[k] = lines[((size_t)s * LW + k) * n + i];
+        LineT<Fp2H> l;
+        for (int c = 0; c < 3; c++) { Fp2H &x = c == 0 ? l.c0 : (c == 1 ? l.c1 : l.c2); for (int k = 0; k < NL; k++) x.v.l[k] = lines[((size_t)s * LW + (2 * c + h) * NL + k) * n + i]; }
         if (i == lo) f12_from_014(f, l.c0, l.c1, l.c2); else f12_mul_by_014(f, l.c0, l.c1, l.c2);
     }
-    const uint32_t *w = reinterpret_cast<const uint32_t *>(&f);
-    for (int k = 0; k < F12W; k++) partial[(size_t)t * F12W + k] = w[k];
+    const Fp2H *q = reinterpret_cast<const Fp2H *>(&f);              // c0.c0, c0.c1, c0.c2, c1.c0, c1.c1, c1.c2
+    for (int c = 0; c < 6; c++) for (int k = 0; k < NL; k++) partial[(size_t)t * F12W + (2 * c + h) * NL + k] = q[c].v.l[k];
 }
 
-// One block per (step, group of 64 partials): tree product through LDS.  A node product a * b is shared by THREE lanes (Karatsuba over
-// Fp6: a0 b0, a1 b1, (a0 + a1)(b0 + b1) are independent Fp6 products of 6 Fp2 products each): the tree is latency-bound — a dense Fp12
-// product is ~25 k instructions on one lane — and has few nodes, so spreading a node over lanes shortens every level 3x.
-// Lanes 0-31 / 32-63 / 64-95 of the 128-thread block take role 0 / 1 / 2 of node p = lane & 31.
+// One block per (step, group of 64 partials): tree product through LDS.  A node product a * b is shared by three lane PAIRS — Karatsuba
+// over Fp6: a0 b0, a1 b1, (a0 + a1)(b0 + b1) are independent Fp6 products of 6 Fp2 products each, and every Fp2 value sits on a lane pair.
+// The tree is latency-bound (a dense Fp12 product is ~25 k instructions on one lane) and has few nodes, so spreading a node over six lanes
+// shortens every level ~5x.  Wave r of the 192-thread block takes role r of the nodes p = (lane >> 1); roles are wave-uniform.
 //   A: operands of node p (slots p and p + h) -> registers            | sync
 //   B: t = Fp6 product; t0 -> slot(p+h).c0, t1 -> slot(p+h).c1, m -> slot(p).c1    | sync
 //   C: role 0: slot(p).c0 = t0 + v t1;  role 1: slot(p).c1 = m - t0 - t1           (f12_mul of pairing29.cuh, step for step)
 // out_abi != nullptr: the group result of step s is L_s, written in the ABI form (last level); otherwise it is written back as a
 // partial of the next level: next[(s * ngroups + g) * F12W + k].
 constexpr int F6W = 6 * NL;
-__global__ void __launch_bounds__(128) k_product_tree(const uint32_t *__restrict__ partial, int nsl, int ngroups, uint32_t *__restrict__ next, uint32_t *__restrict__ out_abi) {
+__global__ void __launch_bounds__(192) k_product_tree(const uint32_t *__restrict__ partial, int nsl, int ngroups, uint32_t *__restrict__ next, uint32_t *__restrict__ out_abi) {
     __shared__ uint32_t sh[F12W * MAX_SLICES];                        // word k of slot j at sh[k * 64 + j]
     const int s = blockIdx.x / ngroups, grp = blockIdx.x % ngroups, t = threadIdx.x;
     const int cnt = min(MAX_SLICES, nsl - grp * MAX_SLICES);        // partials in this group
     if (t < cnt) { const uint32_t *src = partial + ((size_t)s * nsl + grp * MAX_SLICES + t) * F12W; for (int k = 0; k < F12W; k++) sh[k * MAX_SLICES + t] = src[k]; }
-    auto ld6 = [&](Fp6d &x, int slot, int half) { uint32_t *w = reinterpret_cast<uint32_t *>(&x); for (int k = 0; k < F6W; k++) w[k] = sh[(half * F6W + k) * MAX_SLICES + slot]; };
-    auto st6 = [&](const Fp6d &x, int slot, int half) { const uint32_t *w = reinterpret_cast<const uint32_t *>(&x); for (int k = 0; k < F6W; k++) sh[(half * F6W + k) * MAX_SLICES + slot] = w[k]; };
-    const int role = t >> 5, p = t & 31;
+    const int role = t >> 6, p = (t & 63) >> 1;
+    const uint32_t hh = t & 1u;
+    auto ld6 = [&](Fp6p &x, int slot, int half) {
+        Fp2H *c = reinterpret_cast<Fp2H *>(&x);
+        for (int q = 0; q < 3; q++) for (int k = 0; k < NL; k++) c[q].v.l[k] = sh[(half * F6W + (2 * q + hh) * NL + k) * MAX_SLICES + slot];
+    };
+    auto st6 = [&](const Fp6p &x, int slot, int half) {
+        const Fp2H *c = reinterpret_cast<const Fp2H *>(&x);
+        for (int q = 0; q < 3; q++) for (int k = 0; k < NL; k++) sh[(half * F6W + (2 * q + hh) * NL + k) * MAX_SLICES + slot] = c[q].v.l[k];
+    };
     for (int h = MAX_SLICES / 2; h >= 1; h >>= 1) {
         if (h >= cnt) continue;                                     // (uniform) nothing to fold at this level
         const bool node = p < h && p + h < cnt;                     // slot p *= slot p + h
-        Fp6d xa, xb;
+        Fp6p xa, xb;
         __syncthreads();
-        if (node && role < 3) {
+        if (node) {
             ld6(xa, p, role == 1); ld6(xb, p + h, role == 1);
-            if (role == 2) { Fp6d ya, yb; ld6(ya, p, 1); ld6(yb, p + h, 1); f6_add_n(xa, xa, ya); f6_add_n(xb, xb, yb); }
+            if (role == 2) { Fp6p ya, yb; ld6(ya, p, 1); ld6(yb, p + h, 1); f6_add_n(xa, xa, ya); f6_add_n(xb, xb, yb); }
         }
         __syncthreads();
-        if (node && role < 3) {
-            Fp6d tt; f6_mul(tt, xa, xb);
+        if (node) {
+            Fp6p tt; f6_mul(tt, xa, xb);
             if (role == 0) st6(tt, p + h, 0); else if (role == 1) st6(tt, p + h, 1); else st6(tt, p, 1);
         }
         __syncthreads();
         if (node && role == 0) {                                    // c0 = t0 + v t1
-            Fp6d t0, t1, x, r; ld6(t0, p + h, 0); ld6(t1, p + h, 1);
+            Fp6p t0, t1, x, r; ld6(t0, p + h, 0); ld6(t1, p + h, 1);
             f6_mul_v(x, t1); f6_add_n(r, t0, x); st6(r, p, 0);
         } else if (node && role == 1) {                             // c1 = m - t0 - t1
-            Fp6d t0, t1, m, x, r; ld6(t0, p + h, 0); ld6(t1, p + h, 1); ld6(m, p, 1);
+            Fp6p t0, t1, m, x, r; ld6(t0, p + h, 0); ld6(t1, p + h, 1); ld6(m, p, 1);
             fadd(x.c0, t0.c0, t1.c0); fadd(x.c1, t0.c1, t1.c1); fadd(x.c2, t0.c2, t1.c2);
             f2_sub_n<128>(r.c0, m.c0, x.c0); f2_sub_n<128>(r.c1, m.c1, x.c1); f2_sub_n<128>(r.c2, m.c2, x.c2);
             st6(r, p, 1);
         }
     }
     __syncthreads();
-    if (t == 0) {
-        Fp12d f; uint32_t *w = reinterpret_cast<uint32_t *>(&f);
-        for (int k = 0; k < F12W; k++) w[k] = sh[k * MAX_SLICES];
-        if (out_abi) { const Fp *c = reinterpret_cast<const Fp *>(&f); for (int k = 0; k < 12; k++) fp_to_abi(out_abi + ((size_t)s * 12 + k) * 12, c[k]); }
-        else for (int k = 0; k < F12W; k++) next[((size_t)s * ngroups + grp) * F12W + k] = w[k];
+    if (t < 2) {                                                    // the pair of slot 0 writes the result, each lane its halves
+        for (int q = 0; q < 6; q++) {
+            Fp c;
+            for (int k = 0; k < NL; k++) c.l[k] = sh[((2 * q + hh) * NL + k) * MAX_SLICES];
+            if (out_abi) fp_to_abi(out_abi + ((size_t)s * 12 + 2 * q + hh) * 12, c);
+            else for (int k = 0; k < NL; k++) next[((size_t)s * ngroups + grp) * F12W + (2 * q + hh) * NL + k] = c.l[k];
+        }
     }
 }
 
@@ -291,13 +306,13 @@ int32_t dgpu_multi_miller_loop(const uint64_t *p, const uint64_t *q, const uint8
           else hipLaunchKernelGGL(k_miller_lines_quad, dim3((unsigned)((4 * n + 63) / 64)), dim3(64), 0, s, sl.in_bases.as<uint32_t>(), sl.in_scalars.as<uint32_t>(), dskip, n, sl.ml_lines.as<uint32_t>());
       } }
     { StageTimer st(sl, "ml.products");
-      hipLaunchKernelGGL(k_line_products, dim3((unsigned)((N_LINES * nsl + 63) / 64)), dim3(64), 0, s, sl.ml_lines.as<uint32_t>(), n, slice_len, nsl, sl.ml_partial.as<uint32_t>()); }
+      hipLaunchKernelGGL(k_line_products, dim3((unsigned)((2 * N_LINES * nsl + 63) / 64)), dim3(64), 0, s, sl.ml_lines.as<uint32_t>(), n, slice_len, nsl, sl.ml_partial.as<uint32_t>()); }
     { StageTimer st(sl, "ml.tree");
       uint32_t *lvl0 = sl.ml_partial.as<uint32_t>(), *lvl1 = lvl0 + (size_t)N_LINES * nsl * F12W;
-      if (ngroups == 1) hipLaunchKernelGGL(k_product_tree, dim3(N_LINES), dim3(128), 0, s, lvl0, nsl, 1, (uint32_t *)nullptr, sl.ml_out.as<uint32_t>());
+      if (ngroups == 1) hipLaunchKernelGGL(k_product_tree, dim3(N_LINES), dim3(192), 0, s, lvl0, nsl, 1, (uint32_t *)nullptr, sl.ml_out.as<uint32_t>());
       else {
-          hipLaunchKernelGGL(k_product_tree, dim3(N_LINES * ngroups), dim3(128), 0, s, lvl0, nsl, ngroups, lvl1, (uint32_t *)nullptr);
-          hipLaunchKernelGGL(k_product_tree, dim3(N_LINES), dim3(128), 0, s, lvl1, ngroups, 1, (uint32_t *)nullptr, sl.ml_out.as<uint32_t>());
+          hipLaunchKernelGGL(k_product_tree, dim3(N_LINES * ngroups), dim3(192), 0, s, lvl0, nsl, ngroups, lvl1, (uint32_t *)nullptr);
+          hipLaunchKernelGGL(k_product_tree, dim3(N_LINES), dim3(192), 0, s, lvl1, ngroups, 1, (uint32_t *)nullptr, sl.ml_out.as<uint32_t>());
       } }
     HIPCHK(hipGetLastError());
     std::vector<hostf::Fq12> L(N_LINES);

@@ -19,8 +19,10 @@ namespace bls29 {
 
 #define BLS29_TWO_INV {0x1d4fdc2u, 0x15d00348u, 0x13894478u, 0x7acde62u, 0x9365b0au, 0x12c2df9bu, 0xdc2d61eu, 0x1e7c2b7du, 0x1c48f65eu, 0xd3f7602u, 0x1aad4478u, 0x13a0d636u, 0x198be187u, 0x4u}
 
-struct Fp6d { Fp2 c0, c1, c2; };
-struct Fp12d { Fp6d c0, c1; };
+template <class F2> struct Fp6T { F2 c0, c1, c2; };
+template <class F2> struct Fp12T { Fp6T<F2> c0, c1; };
+typedef Fp6T<Fp2> Fp6d;
+typedef Fp12T<Fp2> Fp12d;
 
 // ---- Fp2 extras ----
 // square with a caller-chosen subtraction multiple (a.c1 may carry a value up to (M-1) p)
@@ -43,11 +45,11 @@ FD void f2_add_n(Fp2 &r, const Fp2 &a, const Fp2 &b) { fadd(r, a, b); fnorm(r, r
 template <int M> FD void f2_sub_n(Fp2 &r, const Fp2 &a, const Fp2 &b) { fsub<M>(r, a, b); fnorm(r, r); }
 
 // ---- Fp6 ----
-FD void f6_zero(Fp6d &r) { fzero(r.c0); fzero(r.c1); fzero(r.c2); }
-FD void f6_add_n(Fp6d &r, const Fp6d &a, const Fp6d &b) { f2_add_n(r.c0, a.c0, b.c0); f2_add_n(r.c1, a.c1, b.c1); f2_add_n(r.c2, a.c2, b.c2); }
+template <class F2> FD void f6_zero(Fp6T<F2> &r) { fzero(r.c0); fzero(r.c1); fzero(r.c2); }
+template <class F2> FD void f6_add_n(Fp6T<F2> &r, const Fp6T<F2> &a, const Fp6T<F2> &b) { f2_add_n(r.c0, a.c0, b.c0); f2_add_n(r.c1, a.c1, b.c1); f2_add_n(r.c2, a.c2, b.c2); }
 // full product, 6 Fp2 products (Karatsuba).  Inputs: value < ~400 p per coefficient.  Outputs: value < 64 p.
-FD void f6_mul(Fp6d &r, const Fp6d &a, const Fp6d &b) {
-    Fp2 t0, t1, t2, s, u, m, x, o0, o1, o2;
+template <class F2> FD void f6_mul(Fp6T<F2> &r, const Fp6T<F2> &a, const Fp6T<F2> &b) {
+    F2 t0, t1, t2, s, u, m, x, o0, o1, o2;
     fmul(t0, a.c0, b.c0); fmul(t1, a.c1, b.c1); fmul(t2, a.c2, b.c2);
     f2_add_n(s, a.c1, a.c2); f2_add_n(u, b.c1, b.c2); fmul(m, s, u);
     fadd(x, t1, t2); f2_sub_n<16>(m, m, x);             // (a1+a2)(b1+b2) - t1 - t2
@@ -61,10 +63,10 @@ FD void f6_mul(Fp6d &r, const Fp6d &a, const Fp6d &b) {
     r.c0 = o0; r.c1 = o1; r.c2 = o2;
 }
 // r = a * v  (a coefficients value < 127 p)
-FD void f6_mul_v(Fp6d &r, const Fp6d &a) { Fp2 t; f2_mul_xi_n<128>(t, a.c2); r.c2 = a.c1; r.c1 = a.c0; r.c0 = t; }
+template <class F2> FD void f6_mul_v(Fp6T<F2> &r, const Fp6T<F2> &a) { F2 t; f2_mul_xi_n<128>(t, a.c2); r.c2 = a.c1; r.c1 = a.c0; r.c0 = t; }
 // a * (c0 + c1 v): 5 Fp2 products (ark-ff Fp6::mul_by_01)
-FD void f6_mul_by_01(Fp6d &r, const Fp6d &a, const Fp2 &c0, const Fp2 &c1) {
-    Fp2 aa, bb, s, u, m, x, o0, o1, o2;
+template <class F2> FD void f6_mul_by_01(Fp6T<F2> &r, const Fp6T<F2> &a, const F2 &c0, const F2 &c1) {
+    F2 aa, bb, s, u, m, x, o0, o1, o2;
     fmul(aa, a.c0, c0); fmul(bb, a.c1, c1);
     f2_add_n(s, a.c1, a.c2); fmul(m, s, c1); f2_sub_n<8>(m, m, bb);      // a1 c1 + a2 c1 - bb = a2 c1
     f2_mul_xi_n<16>(x, m); fadd(o0, x, aa); fnorm(o0, o0);               // xi a2 c1 + a0 c0
@@ -73,17 +75,17 @@ FD void f6_mul_by_01(Fp6d &r, const Fp6d &a, const Fp2 &c0, const Fp2 &c1) {
     r.c0 = o0; r.c1 = o1; r.c2 = o2;
 }
 // a * (c1 v): 3 Fp2 products
-FD void f6_mul_by_1(Fp6d &r, const Fp6d &a, const Fp2 &c1) {
-    Fp2 t0, t1, t2;
+template <class F2> FD void f6_mul_by_1(Fp6T<F2> &r, const Fp6T<F2> &a, const F2 &c1) {
+    F2 t0, t1, t2;
     fmul(t0, a.c2, c1); fmul(t1, a.c0, c1); fmul(t2, a.c1, c1);
     f2_mul_xi_n<8>(r.c0, t0); r.c1 = t1; r.c2 = t2;
 }
 
 // ---- Fp12 ----
-FD void f12_set_one(Fp12d &r) { f6_zero(r.c0); f6_zero(r.c1); fset_one(r.c0.c0); }
+template <class F2> FD void f12_set_one(Fp12T<F2> &r) { f6_zero(r.c0); f6_zero(r.c1); fset_one(r.c0.c0); }
 // 18 Fp2 products.  Inputs: coefficient values < 200 p.  Outputs: < 200 p.
-FD void f12_mul(Fp12d &r, const Fp12d &a, const Fp12d &b) {
-    Fp6d t0, t1, s, u, m, x;
+template <class F2> FD void f12_mul(Fp12T<F2> &r, const Fp12T<F2> &a, const Fp12T<F2> &b) {
+    Fp6T<F2> t0, t1, s, u, m, x;
     f6_mul(t0, a.c0, b.c0); f6_mul(t1, a.c1, b.c1);
     f6_add_n(s, a.c0, a.c1); f6_add_n(u, b.c0, b.c1); f6_mul(m, s, u);
     // c1 = m - t0 - t1
@@ -94,8 +96,8 @@ FD void f12_mul(Fp12d &r, const Fp12d &a, const Fp12d &b) {
     f6_add_n(r.c0, t0, x);
 }
 // f *= (c0 + c1 v + c4 v w)  — ark-ff Fp12::mul_by_014, 13 Fp2 products
-FD void f12_mul_by_014(Fp12d &f, const Fp2 &c0, const Fp2 &c1, const Fp2 &c4) {
-    Fp6d aa, bb, s, m, x; Fp2 o;
+template <class F2> FD void f12_mul_by_014(Fp12T<F2> &f, const F2 &c0, const F2 &c1, const F2 &c4) {
+    Fp6T<F2> aa, bb, s, m, x; F2 o;
     f6_mul_by_01(aa, f.c0, c0, c1);
     f6_mul_by_1(bb, f.c1, c4);
     f2_add_n(o, c1, c4);
@@ -107,7 +109,7 @@ FD void f12_mul_by_014(Fp12d &f, const Fp2 &c0, const Fp2 &c1, const Fp2 &c4) {
     f6_add_n(f.c0, aa, x);
 }
 // dense Fp12 from a sparse 014 element
-FD void f12_from_014(Fp12d &f, const Fp2 &c0, const Fp2 &c1, const Fp2 &c4) {
+template <class F2> FD void f12_from_014(Fp12T<F2> &f, const F2 &c0, const F2 &c1, const F2 &c4) {
     f6_zero(f.c0); f6_zero(f.c1);
     f.c0.c0 = c0; f.c0.c1 = c1; f.c1.c1 = c4;
 }

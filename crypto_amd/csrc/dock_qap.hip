@@ -80,9 +80,8 @@ int32_t witness_map_device(Slot &sl, const DevR1cs &r, const uint64_t *assignmen
     NttDomain dom; int32_t rc;
     if ((rc = get_domain(sl, logn, dom))) return rc;
     const size_t esz = ntt::FR_WORDS * 4;
-    Buf &zw = sl.q[12], &zs = sl.q[13], &qa = sl.q[14], &qb = sl.q[15], &qc = sl.digits, &hw = sl.entries;   // digits/entries: reused scratch
+    Buf &zw = sl.q[12], &qa = sl.q[14], &qb = sl.q[15], &qc = sl.digits, &hw = sl.entries;   // digits/entries: reused scratch
     if ((rc = zw.ensure(r.num_vars * 32))) return rc;
-    if ((rc = zs.ensure(r.num_vars * esz))) return rc;
     if ((rc = qa.ensure(D * esz))) return rc;
     if ((rc = qb.ensure(D * esz))) return rc;
     if ((rc = qc.ensure(D * esz))) return rc;
@@ -92,9 +91,8 @@ int32_t witness_map_device(Slot &sl, const DevR1cs &r, const uint64_t *assignmen
     {
         StageTimer st(sl, "qap.matvec");
         HIPCHK(hipMemcpyAsync(zw.p, assignment, r.num_vars * 32, hipMemcpyHostToDevice, s));
-        ntt::launch_fr_load(s, zw.as<uint32_t>(), r.num_vars, montgomery, zs.as<uint32_t>(), r.num_vars);
         for (int k = 0; k < 3; k++)
-            ntt::launch_csr_eval(s, r.m[k].rowptr, r.m[k].cols, r.m[k].vals, r.m[k].nnz, zs.as<uint32_t>(), r.num_vars, r.num_constraints, k == 0 ? r.num_inputs : 0, arr[k], D);
+            ntt::launch_csr_eval(s, r.m[k].rowptr, r.m[k].cols, r.m[k].vals, r.m[k].nnz, zw.as<uint32_t>(), montgomery, r.num_vars, r.num_constraints, k == 0 ? r.num_inputs : 0, arr[k], D);
     }
     {
         StageTimer st(sl, "qap.ntt");

@@ -10,8 +10,8 @@ void launch_fr_powers(hipStream_t s, const uint32_t *bw, const uint32_t *sw, siz
 void launch_tw_compact(hipStream_t s, uint32_t *tw, size_t H) {
     if (H > 1) hipLaunchKernelGGL(k_tw_compact, grid_for(H), dim3(256), 0, s, tw, H, 0);
 }
-void launch_csr_eval(hipStream_t s, const uint64_t *rowptr, const uint32_t *cols, const uint32_t *vals_soa, size_t nnz, const uint32_t *z_soa, size_t nvars, size_t rows, size_t extra, uint32_t *out, size_t D) {
-    hipLaunchKernelGGL(k_csr_eval, grid_for(D), dim3(256), 0, s, rowptr, cols, vals_soa, nnz, z_soa, nvars, rows, extra, out, D);
+void launch_csr_eval(hipStream_t s, const uint64_t *rowptr, const uint32_t *cols, const uint32_t *vals_soa, size_t nnz, const uint32_t *z_words, int z_mont, size_t nvars, size_t rows, size_t extra, uint32_t *out, size_t D) {
+    hipLaunchKernelGGL(k_csr_eval, grid_for(D), dim3(256), 0, s, rowptr, cols, vals_soa, nnz, z_words, z_mont, nvars, rows, extra, out, D);
 }
 void launch_ntt(hipStream_t s, uint32_t *buf, int logn, const uint32_t *tw, int dif) {
     const size_t D = (size_t)1 << logn, H = D >> 1;

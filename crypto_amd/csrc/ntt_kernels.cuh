@@ -73,18 +73,29 @@ __global__ void __launch_bounds__(256) k_tw_compact(uint32_t *__restrict__ tw, s
     for (int l = 0; l < NL; l++) dst[(size_t)l * hs + j] = tw[(size_t)l * H + (j << sigma)];
     (void)logh;
 }
-// sparse rows: out[i] = sum_k vals[k] * z[cols[k]] over row i (i < rows); out[rows + j] = z[j] for j < extra (matrix A only)
+// sparse rows: out[i] = sum_k vals[k] * z[cols[k]] over row i (i < rows); out[rows + j] = z[j] for j < extra (matrix A only).
+// z is gathered from the caller's scalar words (8 x u32 = 32 contiguous bytes per variable: one cache line per gather) and converted on
+// the fly; gathering from a limb-major copy touched ten cache lines per variable and made this kernel 3x slower than the transforms'
+// share of the witness map warranted.
+__device__ __forceinline__ void ld_words(Fr &r, const uint32_t *__restrict__ words, size_t i, bool mont) {
+    uint32_t w[8];
+    const uint4 *p = reinterpret_cast<const uint4 *>(words + i * 8);
+    uint4 a = p[0], b = p[1];
+    w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+    fr_from_words(r, w, mont);
+}
 __global__ void __launch_bounds__(256) k_csr_eval(const uint64_t *__restrict__ rowptr, const uint32_t *__restrict__ cols, const uint32_t *__restrict__ vals_soa, size_t nnz,
-                                                  const uint32_t *__restrict__ z_soa, size_t nvars, size_t rows, size_t extra, uint32_t *__restrict__ out, size_t D) {
+                                                  const uint32_t *__restrict__ z_words, int z_mont, size_t nvars, size_t rows, size_t extra, uint32_t *__restrict__ out, size_t D) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= D) return;
     Fr acc; fr_zero(acc);
     if (i < rows) {
         for (uint64_t k = rowptr[i]; k < rowptr[i + 1]; k++) {
-            Fr c, zz, t; ld(c, vals_soa, nnz, k); ld(zz, z_soa, nvars, cols[k]);
+            Fr c, zz, t; ld(c, vals_soa, nnz, k); ld_words(zz, z_words, cols[k], z_mont != 0);
             fr_mul(t, zz, c); fr_add(acc, acc, t); fr_norm(acc, acc);
         }
-    } else if (i < rows + extra) ld(acc, z_soa, nvars, i - rows);
+    } else if (i < rows + extra) ld_words(acc, z_words, i - rows, z_mont != 0);
+    (void)nvars;
     st(out, D, i, acc);
 }
 // one radix-2 stage over the whole array.  dif != 0: (x, y) -> (x + y, (x - y) w^(j << s)), half = D >> (s+1)

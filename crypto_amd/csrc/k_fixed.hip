@@ -17,6 +17,9 @@ template <class C> void launch_mul_add(hipStream_t s, const uint32_t *p_abi, con
     if constexpr (C::NFP == 2) {
         if (!one_lane) { hipLaunchKernelGGL(k_mul_add_g2_pair, dim3((unsigned)((2 * n + 63) / 64)), dim3(64), 0, s, p_abi, p_inf, scalars, scalar_stride, add_abi, add_inf, n, out_abi, out_inf); return; }
     }
+    if constexpr (C::NFP == 1) {
+        if (!one_lane) { hipLaunchKernelGGL((k_mul_add_g1_2l<C>), dim3((unsigned)((2 * n + 63) / 64)), dim3(64), 0, s, p_abi, p_inf, scalars, scalar_stride, add_abi, add_inf, n, out_abi, out_inf); return; }
+    }
     hipLaunchKernelGGL((k_mul_add<C>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, p_abi, p_inf, scalars, scalar_stride, add_abi, add_inf, n, out_abi, out_inf);
 }
 template void launch_mul_add<G1>(hipStream_t, const uint32_t *, const uint8_t *, const uint32_t *, int, const uint32_t *, const uint8_t *, size_t, uint32_t *, uint8_t *);

@@ -5,6 +5,7 @@
 #include "fp29.cuh"
 #include "ec29.cuh"
 #include "fp_inv.cuh"
+#include "ec29_two_lane.cuh"
 
 namespace msm {
 using namespace bls29;
@@ -179,9 +180,11 @@ __global__ void k_selftest_g1_sum(const uint32_t *pts_abi, const uint8_t *neg, s
 // (utils/src/randomized_pairing_check.rs:125-127,152-158: `a.mul_bigint(m)` in a cfg_iter!); one lane per point,
 // double-and-add over the 255 scalar bits, then one Fermat inversion per lane for the affine form the line
 // evaluation needs.
+// Two adjacent lanes per point (ec29_two_lane.cuh): both hold the point, each takes one field operation per round.
 __global__ void __launch_bounds__(64) k_g1_scale(const uint32_t *__restrict__ p_abi, const uint8_t *__restrict__ is_inf, const uint32_t *__restrict__ scalars, int scalar_stride,
                                                  const uint8_t *__restrict__ negate, size_t n, uint32_t *__restrict__ out_abi, uint8_t *__restrict__ out_inf) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 1;
+    const bool B = (threadIdx.x & 1u) != 0;
     if (i >= n) return;
     uint32_t any = 0;
     for (int k = 0; k < 24; k++) any |= p_abi[i * 24 + k];
@@ -192,19 +195,19 @@ __global__ void __launch_bounds__(64) k_g1_scale(const uint32_t *__restrict__ p_
     fzero(acc.x); fzero(acc.y); fzero(acc.zz); fzero(acc.zzz);
     if (!pinf)
         for (int b = 254; b >= 0; b--) {
-            if (!inf) { Xyzz<Fp> d; xyzz_dbl(d, acc); acc = d; }
-            if ((s[b >> 5] >> (b & 31)) & 1u) xyzz_madd(acc, inf, P, false);
+            if (!inf) { Xyzz<Fp> d; xyzz_dbl_2l(d, acc); acc = d; }
+            if ((s[b >> 5] >> (b & 31)) & 1u) xyzz_madd_2l(acc, inf, P, false);
         }
-    out_inf[i] = inf;
+    if (!B) out_inf[i] = inf;
     uint32_t *o = out_abi + i * 24;
-    if (inf) { for (int k = 0; k < 24; k++) o[k] = 0; return; }
+    if (inf) { if (!B) for (int k = 0; k < 24; k++) o[k] = 0; return; }
     Fp i3, t, i2, x, y;
-    fp_inv_device(i3, acc.zzz);                 // 1 / ZZZ
+    fp_inv_device(i3, acc.zzz);                 // 1 / ZZZ   (both lanes: the inversion is one serial chain either way)
     fp_mul(t, acc.zz, i3); fp_sqr(i2, t);       // (ZZ / ZZZ)^2 = 1 / ZZ      (ZZ^3 == ZZZ^2)
     Fp xn, yn; fp_norm(xn, acc.x); fp_norm(yn, acc.y);
     fp_mul(x, xn, i2); fp_mul(y, yn, i3);
     if (negate && negate[i]) { Fp z; fp_zero(z); fp_sub<4>(y, z, y); fp_norm(y, y); }
-    fp_to_abi(o, x); fp_to_abi(o + 12, y);
+    if (!B) fp_to_abi(o, x); else fp_to_abi(o + 12, y);
 }
 
 }  // namespace msm

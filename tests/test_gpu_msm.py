@@ -224,6 +224,32 @@ def test_g2_full_size_closed_form_2_20():
     assert U.jac_to_model(G, G.add(a, b)) == U.jac_to_model(G, r)
 
 
+def test_g1_2_22_closed_form_split_and_window_independence():
+    """n = 2^22 (twice the per-GPU share of BASELINE config 5): bases k_i G from the fixed-base kernel with seeded k_i, so the result has a
+    closed form; plus split/merge over resident handles and the same point for another window width."""
+    from crypto_amd import fixed_base as fb
+    n = 1 << 22
+    ks = O.rand_scalars(9101, n); sc = O.rand_scalars(9102, n)
+    with fb.WindowTable(ca.G1, O.G1.generator()) as t:
+        db = t.multiply_many_to_bases(ks)
+        to_int = lambda a: [int(w0) | (int(w1) << 64) | (int(w2) << 128) | (int(w3) << 192) for w0, w1, w2, w3 in a.tolist()]
+        tot = sum(x * y for x, y in zip(to_int(ks), to_int(sc))) % U.R
+        exp_xy, exp_inf = t.multiply(tot)
+    ds = ca.DeviceScalars(sc)
+    r = db.msm_resident(ds)
+    assert not exp_inf and (r[:12] == exp_xy).all() and r[12:].any()
+    a = db.msm_resident(ds, n=n // 2)
+    b = db.msm_resident(ds, n=n - n // 2, base_offset=n // 2, scalar_offset=n // 2)
+    assert (O.G1.to_affine(O.G1.add(a, b))[0] == r[:12]).all()
+    assert lib().dgpu_set_window_bits(14) == 0
+    try:
+        assert (db.msm_resident(ds) == r).all()
+    finally:
+        lib().dgpu_set_window_bits(0)
+    # the oracle agrees on the closed-form point (independent double-and-add)
+    assert (O.G1.to_affine(O.G1.mul(O.G1.generator(), O.int_to_limbs(tot, 4)))[0] == exp_xy).all()
+
+
 def test_concurrent_callers_share_the_device():
     """the reference calls MSM from inside rayon workers (verifiable_encryption/src/tz_21/rdkgith.rs:140-147): several host
     threads in flight at once must each get their own correct result (per-call slots: stream + workspace)."""

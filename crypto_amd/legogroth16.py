@@ -212,6 +212,71 @@ def create_proof(pk, r, s, v, h, input_assignment_with_one, witness_assignment):
     return {"a": _affine(M.G1, g_a), "b": _affine(M.G2, g2_b), "c": _affine(M.G1, g_c), "d": _affine(M.G1, g_d)}
 
 
+# ---- multi-GPU prover: every large MSM chunked over the ranks (SURVEY.md 8e "LegoGroth16 prove") ----------------------------------------
+class ShardedProvingKey:
+    """This rank's chunk of every proving-key query, resident on its GPU.  Chunks are contiguous and balanced (sharded.chunk_bounds):
+    a / b_g1 / b_g2 over query[1..], h over the D - 1 points, l over its own length; query[0] and the O(1) elements stay on the host."""
+
+    def __init__(self, vk, beta_g1, delta_g1, eta_delta_inv_g1, a_query, b_g1_query, b_g2_query, h_query, l_query, world, rank):
+        self.vk, self.world, self.rank = vk, world, rank
+        self.beta_g1, self.delta_g1, self.eta_delta_inv_g1 = beta_g1, delta_g1, eta_delta_inv_g1
+        self.a0, self.b1_0, self.b2_0 = a_query[0].copy(), b_g1_query[0].copy(), b_g2_query[0].copy()
+        self.V, self.H, self.L = len(a_query) - 1, len(h_query), len(l_query)
+        cb = lambda n: sharded.chunk_bounds(n, world, rank)
+        (lo, hi), (hlo, hhi), (llo, lhi) = cb(self.V), cb(self.H), cb(self.L)
+        self.a_query = M.DeviceBases(M.G1, a_query[1 + lo:1 + hi])
+        self.b_g1_query = M.DeviceBases(M.G1, b_g1_query[1 + lo:1 + hi])
+        self.b_g2_query = M.DeviceBases(M.G2, b_g2_query[1 + lo:1 + hi])
+        self.h_query = M.DeviceBases(M.G1, h_query[hlo:hhi])
+        self.l_query = M.DeviceBases(M.G1, l_query[llo:lhi])
+
+
+def create_proof_sharded(spk, r, s, v, h, input_assignment_with_one, witness_assignment, device=None):
+    """create_proof with the five large MSMs chunked over the ranks: each rank runs them on its chunk of (bases, scalars), ONE all_gather
+    moves the five partial points (864 B per rank) and every rank folds them and finishes the proof identically.  The witness map (NTT) is
+    not sharded: `h` is the full coefficient vector on every rank."""
+    import torch
+    import torch.distributed as dist
+    vk = spk.vk
+    h = np.ascontiguousarray(h, dtype=np.uint64).reshape(-1, 4)
+    wit = np.ascontiguousarray(witness_assignment, dtype=np.uint64).reshape(-1, 4)
+    inp = np.ascontiguousarray(input_assignment_with_one, dtype=np.uint64).reshape(-1, 4)
+    cw = vk.commit_witness_count
+    assignment = np.concatenate([inp[1:], wit])
+    aux = wit[cw:]
+    cb = lambda n: sharded.chunk_bounds(n, spk.world, spk.rank)
+    (lo, hi), (hlo, hhi), (llo, lhi) = cb(spk.V), cb(spk.H), cb(spk.L)
+    pool = _pool()
+    jobs = [lambda: spk.h_query.msm_bigint(h[hlo:min(hhi, len(h))]),
+            lambda: spk.l_query.msm_bigint(aux[llo:lhi]),
+            lambda: spk.a_query.msm_bigint(assignment[lo:hi]),
+            (lambda: spk.b_g1_query.msm_bigint(assignment[lo:hi])) if r % R_MOD != 0 else (lambda: np.zeros(18, dtype=np.uint64)),
+            lambda: spk.b_g2_query.msm_bigint(assignment[lo:hi])]
+    parts = [f.result() for f in [pool.submit(j) for j in jobs]]
+    local = np.concatenate(parts)                                   # 4 x 18 + 36 limbs
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        t = torch.from_numpy(local.view(np.int64).copy())
+        if device is not None:
+            t = t.to(device)
+        buf = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+        dist.all_gather(buf, t)
+        allp = np.stack([b.cpu().numpy().view(np.uint64) for b in buf])
+    else:
+        allp = local.reshape(1, -1)
+    h_acc, l_aux_acc, acc_a, acc_b1 = (sharded.fold(M.G1, allp[:, 18 * k:18 * k + 18]) for k in range(4))
+    acc_b2 = sharded.fold(M.G2, allp[:, 72:108])
+    coeff = lambda curve, init, k, q0, vkp, acc: sharded.fold(curve, np.stack([acc, lincomb(curve, [init, q0, vkp], [k, 1, 1])]))   # prover.rs:585-594
+    g_a = coeff(M.G1, spk.delta_g1, r, spk.a0, vk.alpha_g1, acc_a)
+    g1_b = coeff(M.G1, spk.delta_g1, s, spk.b1_0, spk.beta_g1, acc_b1) if r % R_MOD != 0 else np.zeros(18, dtype=np.uint64)
+    g2_b = coeff(M.G2, vk.delta_g2, s, spk.b2_0, vk.beta_g2, acc_b2)
+    small = lincomb(M.G1, [_affine(M.G1, g_a), _affine(M.G1, g1_b), spk.delta_g1, spk.eta_delta_inv_g1], [s, r, -(r * s), -v])
+    g_c = sharded.fold(M.G1, np.stack([small, l_aux_acc, h_acc]))
+    src = vk.gamma_abc_g1[len(inp):len(inp) + cw]
+    pts = np.concatenate([src, vk.eta_gamma_inv_g1.reshape(1, 12)])
+    g_d = M.msm_bigint(M.G1, pts, np.concatenate([wit[:cw], _sc(v).reshape(1, 4)]))
+    return {"a": _affine(M.G1, g_a), "b": _affine(M.G2, g2_b), "c": _affine(M.G1, g_c), "d": _affine(M.G1, g_d)}
+
+
 def prepare_verifying_key(vk):
     """verifier.rs:17-25"""
     return {"vk": vk, "alpha_g1_beta_g2": pairing.multi_pairing(vk.alpha_g1.reshape(1, 12), vk.beta_g2.reshape(1, 24)),

@@ -340,7 +340,10 @@ int32_t dgpu_g1_scale_batch(const uint64_t *p, const uint8_t *is_inf, const uint
     if ((rc = sl.prepped.ensure(n * 96 + n))) return rc;
     hipStream_t s = sl.stream;
     HIPCHK(hipMemcpyAsync(sl.in_bases.p, p, n * 96, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(sl.in_scalars.p, scalars, nsc * 32, hipMemcpyHostToDevice, s));
+    // GLV: every scalar is sent as (k1 | k2), k mod r = k1 + k2 lambda, both below 2^128 (host_field.hpp)
+    std::vector<uint64_t> split(nsc * 4);
+    for (size_t k = 0; k < nsc; k++) hostf::glv_decompose(scalars + 4 * k, &split[4 * k], &split[4 * k + 2]);
+    HIPCHK(hipMemcpyAsync(sl.in_scalars.p, split.data(), nsc * 32, hipMemcpyHostToDevice, s));
     const uint8_t *dinf = nullptr, *dneg = nullptr;
     if (is_inf) { HIPCHK(hipMemcpyAsync(sl.in_inf.p, is_inf, n, hipMemcpyHostToDevice, s)); dinf = sl.in_inf.as<uint8_t>(); }
     if (negate) { HIPCHK(hipMemcpyAsync(sl.in_inf.as<uint8_t>() + n, negate, n, hipMemcpyHostToDevice, s)); dneg = sl.in_inf.as<uint8_t>() + n; }
@@ -352,6 +355,12 @@ int32_t dgpu_g1_scale_batch(const uint64_t *p, const uint8_t *is_inf, const uint
     HIPCHK(hipMemcpyAsync(out_inf, dout_inf, n, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     if (g.prof) prof_flush(sl);
+    return DGPU_OK;
+}
+// host self-test hook: the GLV split the scaling kernel is fed with (k mod r = k1 + k2 lambda, both < 2^128)
+int32_t dgpu_selftest_glv_decompose(const uint64_t k[4], uint64_t k1[2], uint64_t k2[2]) {
+    if (!k || !k1 || !k2) return DGPU_E_BADARG;
+    hostf::glv_decompose(k, k1, k2);
     return DGPU_OK;
 }
 int32_t dgpu_fp12_mul(const uint64_t *a, const uint64_t *b, uint64_t *out) {

@@ -78,4 +78,18 @@ __device__ __forceinline__ void xyzz_madd_2l(Xyzz<Fp> &acc, bool &inf, const Aff
     }
 }
 
+
+// ---- GLV endomorphism on G1: phi(x, y) = (beta x, y) = lambda (x, y), lambda = x_BLS^2 - 1, beta the matching cube root of unity in Fq ----
+// (beta chosen so that phi(G) == lambda G for the generator; the pairing of the two constants is re-checked on the device by
+// tests/test_gpu_pairing_checker.py through every scaling it verifies against the oracle.)  Stored as beta * 2^406 mod p, 29-bit limbs.
+#define BLS29_BETA {0x1195dfebu, 0x1b04e484u, 0x6026044u, 0x86070a2u, 0x1fd68858u, 0x137e9670u, 0x6871e67u, 0x1e736664u, 0x83b24f6u, 0x8a70373u, 0x2a012fdu, 0x112f94bu, 0x18a2733cu, 0x3u}
+__device__ __forceinline__ void xyzz_phi(Xyzz<Fp> &p) {       // phi acts on X only: (beta X / ZZ, Y / ZZZ)
+    constexpr uint32_t B_[NL] = BLS29_BETA;
+    Fp beta;
+#pragma unroll
+    for (int i = 0; i < NL; i++) beta.l[i] = B_[i];
+    Fp xn; fp_norm(xn, p.x);
+    fp_mul(p.x, xn, beta);
+}
+
 }  // namespace bls29

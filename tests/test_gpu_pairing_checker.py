@@ -103,3 +103,26 @@ def test_lazy_and_eager_agree_and_laziness_override():
     assert e.verify() and l.verify()
     assert len(l.pending[0]) == 1 and len(e.pending[0]) == 1
     assert (e.right == l.right).all()
+
+
+def test_g1_scale_glv_edge_scalars():
+    """the scaling kernel splits k = k1 + k2 lambda (GLV): scalars around the split points, 0, 1, r - 1, values >= r, an identity point,
+    per-point and shared scalars, with and without negation — all against the oracle's plain double-and-add"""
+    lam = 0xac45a4010001a40200000000ffffffff
+    R = U.R
+    ks = [0, 1, 2, lam - 1, lam, lam + 1, 2 * lam, lam * lam % R, R - 1, R, R + 5, (1 << 128) - 1, 1 << 128, (1 << 255) - 19, (1 << 256) - 1, 0x1234567]
+    pts = np.stack([g1(3 + 7 * i) for i in range(len(ks))])
+    pts[7] = 0                                                  # identity point
+    sc = np.stack([O.int_to_limbs(k, 4) for k in ks])
+    out, inf = pc.g1_scale_each(pts, sc)
+    outn, infn = pc.g1_scale_each(pts, sc, np.ones(len(ks), np.uint8))
+    for i, k in enumerate(ks):
+        e, einf = O.G1.to_affine(O.G1.mul(pts[i], O.int_to_limbs(k % R, 4), inf=not pts[i].any()))
+        assert bool(inf[i]) == einf and bool(infn[i]) == einf, i
+        if not einf:
+            assert (out[i] == e).all(), i
+            assert (outn[i][:6] == e[:6]).all() and not (outn[i][6:] == e[6:]).all(), i      # same x, other y
+    same, sinf = pc.g1_scale(pts, lam + 12345)
+    for i in (0, 3, 7, 15):
+        e, einf = O.G1.to_affine(O.G1.mul(pts[i], O.int_to_limbs(lam + 12345, 4), inf=not pts[i].any()))
+        assert bool(sinf[i]) == einf and (einf or (same[i] == e).all())

@@ -121,3 +121,20 @@ if "dist" in what:
     db = ca.DeviceBases(ca.G1, bases, inf); ds = ca.DeviceScalars(uni)
     dt, s = stages(lambda: db.msm_resident(ds))
     print("G1 2^20 %-16s %.3f ms | %s" % ("1% identity bases", dt * 1e3, s), flush=True)
+if "pc" in what:
+    # RandomizedPairingChecker, lazy: N equations e(a_i, b_i) == t_i batched into one Miller loop + one final exponentiation
+    from crypto_amd import pairing_check as pcm
+    for N in (16, 512):
+        a = O.G1.gen_seq(k0, d, N, threads=16); b = O.G2.gen_seq(d, k0, N, threads=16)
+        ts = [ca.multi_pairing(a[i:i + 1], b[i:i + 1]) for i in range(min(N, 16))]
+        # targets must match their equations for the check to hold: use the first 16 equations repeated
+        aa = np.concatenate([a[:16]] * (N // 16)); bb = np.concatenate([b[:16]] * (N // 16))
+        def run2():
+            ch = pcm.RandomizedPairingChecker(0x1234567890ABCDEF1234567890ABCDEF, True)
+            for i in range(N):
+                ch.add_sources_and_target(aa[i], bb[i], ts[i % 16])
+            return ch.verify()
+        assert run2()
+        t0 = time.time()
+        for _ in range(3): assert run2()
+        print("RandomizedPairingChecker lazy, %d equations: %.2f ms per batch" % (N, (time.time() - t0) / 3 * 1e3), flush=True)

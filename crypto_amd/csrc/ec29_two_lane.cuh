@@ -5,6 +5,7 @@
 // lanes than the chip, so they last as long as the instruction stream of one lane.  Here lanes 2k (role A) and 2k+1 (role B) both hold
 // the whole point and take one field operation of every round — the SAME operation on role-selected operands, so the wave stays
 // convergent — and swap results over DPP quad_perm [1,0,3,2]:
+// (and, with F = Fp2H, the two lane pairs of a quad share a G2 point the same way: Share4)
 //   doubling (dbl-2008-s-1)          A                    B              mixed addition (madd-2008-s)   A                 B
 //     round 1 (square)               V = U^2              X^2              round 1 (product)            U2 = X2 ZZ        S2 = Y2 ZZZ
 //     round 2 (product)              W = U V              S = X V          round 2 (square)             PP = P^2          R^2
@@ -19,65 +20,79 @@
 
 namespace bls29 {
 
-__device__ __forceinline__ void sel2(Fp &r, bool b, const Fp &if_b, const Fp &if_a) { sel(r, b, if_b, if_a); }
+// Sharing policies: who the two cooperating parties are and how they swap / select a field value.
+struct Share2 {       // two adjacent lanes share a G1 point (F = Fp): roles by lane parity, swap = DPP quad_perm [1,0,3,2]
+    static __device__ __forceinline__ bool role() { return pair_odd(); }
+    static __device__ __forceinline__ void swap(Fp &r, const Fp &a) { xchg(r, a); }
+    static __device__ __forceinline__ void pick(Fp &r, bool b, const Fp &if_b, const Fp &if_a) { sel(r, b, if_b, if_a); }
+};
+struct Share4 {       // two lane pairs of a quad share a G2 point (F = Fp2H, halves on the lanes of a pair): roles by bit 1, swap = quad_perm [2,3,0,1]
+    static __device__ __forceinline__ bool role() { return (threadIdx.x & 2u) != 0; }
+    static __device__ __forceinline__ void swap(Fp2H &r, const Fp2H &a) {
+#pragma unroll
+        for (int i = 0; i < NL; i++) r.v.l[i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a.v.l[i], 0x4E, 0xF, 0xF, true);
+    }
+    static __device__ __forceinline__ void pick(Fp2H &r, bool b, const Fp2H &if_b, const Fp2H &if_a) { sel(r.v, b, if_b.v, if_a.v); }
+};
 
-// r = 2 a, a not the identity; both lanes hold a and receive r
-__device__ __forceinline__ void xyzz_dbl_2l(Xyzz<Fp> &r, const Xyzz<Fp> &a) {
-    const bool B = pair_odd();
-    Fp U, in, res, oth, V, X2, M, W, S, t, X3, u, v, Ya, Yb, ZZ3, ZZZ3;
-    fp_add(U, a.y, a.y); fp_norm(U, U);
-    sel2(in, B, a.x, U); fp_sqr(res, in); xchg(oth, res);                       // round 1: A: V = U^2, B: X^2
-    sel2(V, B, oth, res); sel2(X2, B, res, oth);
-    fp_add(t, X2, X2); fp_add(M, t, X2); fp_norm(M, M);                         // M = 3 X^2
-    sel2(u, B, a.x, U); fp_mul(res, u, V); xchg(oth, res);                      // round 2: A: W = U V, B: S = X V
-    sel2(W, B, oth, res); sel2(S, B, res, oth);
-    fp_sqr(X3, M);                                                              // round 3 (both lanes: same operand)
-    fp_add(t, S, S); fp_sub<SubM<Fp>::X>(X3, X3, t); fp_norm(X3, X3);
-    fp_sub<SubM<Fp>::D>(t, S, X3); fp_norm(t, t);
-    sel2(u, B, W, M); sel2(v, B, a.y, t); fp_mul(res, u, v); xchg(oth, res);    // round 4: A: M (S - X3), B: W Y
-    sel2(Ya, B, oth, res); sel2(Yb, B, res, oth);
-    Fp Y3; fp_sub<4>(Y3, Ya, Yb); fp_norm(Y3, Y3);      // value < 6 p: the budget SubM<Fp>::R assumes for Y1
-    sel2(u, B, W, V); sel2(v, B, a.zzz, a.zz); fp_mul(res, u, v); xchg(oth, res);   // round 5: A: V ZZ, B: W ZZZ
-    sel2(ZZ3, B, oth, res); sel2(ZZZ3, B, res, oth);
+// r = 2 a, a not the identity; both parties hold a and receive r
+template <class F, class S> __device__ __forceinline__ void xyzz_dbl_shared(Xyzz<F> &r, const Xyzz<F> &a) {
+    const bool B = S::role();
+    F U, in, res, oth, V, X2, M, W, Sx, t, X3, u, v, Ya, Yb, Y3, ZZ3, ZZZ3;
+    fadd(U, a.y, a.y); fnorm(U, U);
+    S::pick(in, B, a.x, U); fsqr(res, in); S::swap(oth, res);                       // round 1: A: V = U^2, B: X^2
+    S::pick(V, B, oth, res); S::pick(X2, B, res, oth);
+    fadd(t, X2, X2); fadd(M, t, X2); fnorm(M, M);                                   // M = 3 X^2
+    S::pick(u, B, a.x, U); fmul(res, u, V); S::swap(oth, res);                      // round 2: A: W = U V, B: S = X V
+    S::pick(W, B, oth, res); S::pick(Sx, B, res, oth);
+    fsqr(X3, M);                                                                    // round 3 (both parties: same operand)
+    fadd(t, Sx, Sx); fsub<SubM<F>::X>(X3, X3, t); fnorm(X3, X3);
+    fsub<SubM<F>::D>(t, Sx, X3); fnorm(t, t);
+    S::pick(u, B, W, M); S::pick(v, B, a.y, t); fmul(res, u, v); S::swap(oth, res); // round 4: A: M (S - X3), B: W Y
+    S::pick(Ya, B, oth, res); S::pick(Yb, B, res, oth);
+    fsub<4>(Y3, Ya, Yb); fnorm(Y3, Y3);                                             // value < 6 p: the budget SubM<F>::R assumes for Y1
+    S::pick(u, B, W, V); S::pick(v, B, a.zzz, a.zz); fmul(res, u, v); S::swap(oth, res);   // round 5: A: V ZZ, B: W ZZZ
+    S::pick(ZZ3, B, oth, res); S::pick(ZZZ3, B, res, oth);
     r.x = X3; r.y = Y3; r.zz = ZZ3; r.zzz = ZZZ3;
 }
 
 // acc += (neg ? -q : q), q affine and not the identity; `inf` is acc's identity flag (same contract as xyzz_madd)
-__device__ __forceinline__ void xyzz_madd_2l(Xyzz<Fp> &acc, bool &inf, const Aff<Fp> &q_in, bool neg) {
-    const bool B = pair_odd();
-    Aff<Fp> q = q_in;
-    if (neg) { Fp z; fp_zero(z); fp_sub<SubM<Fp>::NEG>(q.y, z, q.y); fp_norm(q.y, q.y); }
-    Fp u, v, res, oth, U2, S2, Pd, Rd, PP, RR, PPP, Q, t, X3, Ya, Yb, Y3, ZZ3, ZZZ3;
-    sel2(u, B, q.y, q.x); sel2(v, B, acc.zzz, acc.zz); fp_mul(res, u, v); xchg(oth, res);      // round 1: A: U2, B: S2
-    sel2(U2, B, oth, res); sel2(S2, B, res, oth);
-    fp_sub<SubM<Fp>::P>(Pd, U2, acc.x); fp_norm(Pd, Pd);
-    fp_sub<SubM<Fp>::R>(Rd, S2, acc.y); fp_norm(Rd, Rd);
-    sel2(u, B, Rd, Pd); fp_sqr(res, u); xchg(oth, res);                                        // round 2: A: PP, B: R^2
-    sel2(PP, B, oth, res); sel2(RR, B, res, oth);
-    sel2(u, B, acc.x, Pd); fp_mul(res, u, PP); xchg(oth, res);                                 // round 3: A: PPP, B: Q
-    sel2(PPP, B, oth, res); sel2(Q, B, res, oth);
-    fp_add(t, Q, Q); fp_add(t, t, PPP);
-    fp_sub<SubM<Fp>::X>(X3, RR, t); fp_norm(X3, X3);
-    fp_sub<SubM<Fp>::D>(t, Q, X3); fp_norm(t, t);
-    sel2(u, B, acc.y, Rd); sel2(v, B, PPP, t); fp_mul(res, u, v); xchg(oth, res);              // round 4: A: R (Q - X3), B: Y1 PPP
-    sel2(Ya, B, oth, res); sel2(Yb, B, res, oth);
-    fp_sub<4>(Y3, Ya, Yb); fp_norm(Y3, Y3);               // value < 6 p (SubM<Fp>::R budget)
-    sel2(u, B, acc.zzz, acc.zz); sel2(v, B, PPP, PP); fp_mul(res, u, v); xchg(oth, res);       // round 5: A: ZZ PP, B: ZZZ PPP
-    sel2(ZZ3, B, oth, res); sel2(ZZZ3, B, res, oth);
+template <class F, class S> __device__ __forceinline__ void xyzz_madd_shared(Xyzz<F> &acc, bool &inf, const Aff<F> &q_in, bool neg) {
+    const bool B = S::role();
+    Aff<F> q = q_in;
+    if (neg) { F z; fzero(z); fsub<SubM<F>::NEG>(q.y, z, q.y); fnorm(q.y, q.y); }
+    F u, v, res, oth, U2, S2, Pd, Rd, PP, RR, PPP, Q, t, X3, Ya, Yb, Y3, ZZ3, ZZZ3;
+    S::pick(u, B, q.y, q.x); S::pick(v, B, acc.zzz, acc.zz); fmul(res, u, v); S::swap(oth, res);      // round 1: A: U2, B: S2
+    S::pick(U2, B, oth, res); S::pick(S2, B, res, oth);
+    fsub<SubM<F>::P>(Pd, U2, acc.x); fnorm(Pd, Pd);
+    fsub<SubM<F>::R>(Rd, S2, acc.y); fnorm(Rd, Rd);
+    S::pick(u, B, Rd, Pd); fsqr(res, u); S::swap(oth, res);                                           // round 2: A: PP, B: R^2
+    S::pick(PP, B, oth, res); S::pick(RR, B, res, oth);
+    S::pick(u, B, acc.x, Pd); fmul(res, u, PP); S::swap(oth, res);                                    // round 3: A: PPP, B: Q
+    S::pick(PPP, B, oth, res); S::pick(Q, B, res, oth);
+    fadd(t, Q, Q); fadd(t, t, PPP);
+    fsub<SubM<F>::X>(X3, RR, t); fnorm(X3, X3);
+    fsub<SubM<F>::D>(t, Q, X3); fnorm(t, t);
+    S::pick(u, B, acc.y, Rd); S::pick(v, B, PPP, t); fmul(res, u, v); S::swap(oth, res);              // round 4: A: R (Q - X3), B: Y1 PPP
+    S::pick(Ya, B, oth, res); S::pick(Yb, B, res, oth);
+    fsub<4>(Y3, Ya, Yb); fnorm(Y3, Y3);                                                               // value < 6 p (SubM<F>::R budget)
+    S::pick(u, B, acc.zzz, acc.zz); S::pick(v, B, PPP, PP); fmul(res, u, v); S::swap(oth, res);       // round 5: A: ZZ PP, B: ZZZ PPP
+    S::pick(ZZ3, B, oth, res); S::pick(ZZZ3, B, res, oth);
     const bool was_inf = inf;
-    const bool special = !was_inf && fp_maybe_zero(Pd);
-    if (was_inf) { acc.x = q.x; acc.y = q.y; fp_set_one(acc.zz); fp_set_one(acc.zzz); inf = false; }
+    const bool special = !was_inf && fmaybe_zero(Pd);
+    if (was_inf) { acc.x = q.x; acc.y = q.y; fset_one(acc.zz); fset_one(acc.zzz); inf = false; }
     else { acc.x = X3; acc.y = Y3; acc.zz = ZZ3; acc.zzz = ZZZ3; }
-    if (special) {                                                                             // P == +-Q: rare; both lanes take the same branch
-        if (fp_is_zero_exact(Pd)) {
-            if (fp_is_zero_exact(Rd)) {
-                Xyzz<Fp> one; one.x = q.x; one.y = q.y; fp_set_one(one.zz); fp_set_one(one.zzz);
-                Xyzz<Fp> d; xyzz_dbl_2l(d, one); acc = d;
+    if (special) {                                                                                    // P == +-Q: rare; every party takes the same branch
+        if (fis_zero_exact(Pd)) {
+            if (fis_zero_exact(Rd)) {
+                Xyzz<F> one; one.x = q.x; one.y = q.y; fset_one(one.zz); fset_one(one.zzz);
+                Xyzz<F> d; xyzz_dbl_shared<F, S>(d, one); acc = d;
             } else inf = true;
         }
     }
 }
-
+__device__ __forceinline__ void xyzz_dbl_2l(Xyzz<Fp> &r, const Xyzz<Fp> &a) { xyzz_dbl_shared<Fp, Share2>(r, a); }
+__device__ __forceinline__ void xyzz_madd_2l(Xyzz<Fp> &acc, bool &inf, const Aff<Fp> &q, bool neg) { xyzz_madd_shared<Fp, Share2>(acc, inf, q, neg); }
 
 // ---- GLV endomorphism on G1: phi(x, y) = (beta x, y) = lambda (x, y), lambda = x_BLS^2 - 1, beta the matching cube root of unity in Fq ----
 // (beta chosen so that phi(G) == lambda G for the generator; the pairing of the two constants is re-checked on the device by

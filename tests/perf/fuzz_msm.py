@@ -1,0 +1,48 @@
+"""One-off randomized cross-check of the MSM entry points against the CPU oracle (sizes, duplicate / negated / identity bases, small and
+zero scalars, handles with offsets).  Usage: ITER=300 python tests/perf/fuzz_msm.py"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import numpy as np
+import crypto_amd as ca
+import oracle_c as O
+from crypto_amd.aggregation.ops import neg
+
+ca.init(0)
+rng = np.random.default_rng(int(os.environ.get("SEED", "1")))
+k0 = O.rand_scalars(1, 1)[0]; d = O.rand_scalars(2, 1)[0]
+pool = {ca.G1: O.G1.gen_seq(k0, d, 6000, threads=32), ca.G2: O.G2.gen_seq(d, k0, 3000, threads=32)}
+grp = {ca.G1: O.G1, ca.G2: O.G2}
+bad = 0
+for it in range(int(os.environ.get("ITER", "200"))):
+    cv = ca.G1 if rng.integers(0, 3) else ca.G2
+    G = grp[cv]
+    n = int(rng.choice([1, 2, 3, 17, 64, 65, 300, 1000, 2500])) + int(rng.integers(0, 40))
+    n = min(n, len(pool[cv]))
+    idx = rng.integers(0, max(1, n // int(rng.choice([1, 1, 4, 50]))), n)          # many duplicates in some runs
+    bases = pool[cv][idx].copy()
+    flip = rng.integers(0, 8, n) == 0
+    for i in np.nonzero(flip)[0]:
+        bases[i] = neg(cv, bases[i])
+    inf = (rng.integers(0, 30, n) == 0).astype(np.uint8)
+    bases[inf == 1] = 0
+    sc = O.rand_scalars(1000 + it, n)
+    kind = rng.integers(0, 5, n)
+    sc[kind == 0] = 0
+    sc[kind == 1, 1:] = 0
+    sc[kind == 1, 0] &= np.uint64(0xFF)
+    if rng.integers(0, 4) == 0:
+        sc[:] = sc[0]                                                              # all-equal scalars: one hot bucket per window
+    exp = G.to_affine(G.msm(bases, sc, inf, threads=8))
+    got = G.to_affine(ca.msm_bigint(cv, bases, sc, is_inf=inf))
+    off = int(rng.integers(0, min(n, 5)))
+    db = ca.DeviceBases(cv, bases, inf)
+    got2 = G.to_affine(db.msm_bigint(sc[: n - off], offset=off))
+    exp2 = G.to_affine(G.msm(bases[off:], sc[: n - off], inf[off:], threads=8))
+    db.free()
+    ok = exp[1] == got[1] and (exp[1] or (exp[0] == got[0]).all()) and exp2[1] == got2[1] and (exp2[1] or (exp2[0] == got2[0]).all())
+    if not ok:
+        bad += 1
+        print("MISMATCH", it, cv.tag, n, off, flush=True)
+print("fuzz_msm: %d iterations, %d mismatches" % (it + 1, bad))
+sys.exit(1 if bad else 0)

@@ -50,6 +50,17 @@ def test_vs_oracle_raw_miller_output(n):
     assert (got == ref).all()
 
 
+@pytest.mark.parametrize("n", [255, 257, 1025, 2049, 4100, 8192, 8193])
+def test_vs_oracle_across_kernel_boundaries(n):
+    """batch sizes around the boundaries of the product kernels (groups of 64 slices, two tree levels, slice length 4 -> 8 at 2048 pairs)
+    and of the line kernel (four lanes per pair up to 8192 pairs, two above): raw Miller-loop output limb for limb"""
+    k0 = O.rand_scalars(31, 1)[0]; d = O.rand_scalars(32, 1)[0]
+    ps = O.G1.gen_seq(k0, d, n, threads=32); qs = O.G2.gen_seq(d, k0, n, threads=32)
+    ps[n // 3] = 0; qs[n // 2] = 0                      # identity members (all-zero words) are skipped
+    skip = np.zeros(n, np.uint8); skip[n // 3] = 1; skip[n // 2] = 1
+    assert (ca.multi_miller_loop(ps, qs) == O.multi_miller_loop(ps, qs, skip, threads=32)).all()
+
+
 def test_identity_members_are_skipped_and_lengths_checked():
     ps, qs = pts([3, 5, 7], [2, 4, 6])
     ps2 = ps.copy(); ps2[1] = 0                       # all-zero words == identity

@@ -132,7 +132,7 @@ def aggregate_proofs(srs, transcript, proofs, with_d=False):
         transcript.append(k.upper().encode() + b"-commitment", com[k].to_bytes())
     r = transcript.challenge_scalar(b"r-random-fiatshamir")
     r_vec = powers(r, n)
-    r_inv = [inv(x) for x in r_vec]
+    r_inv = powers(inv(r), n)                                 # 1, r^-1, r^-2, ... (the reference batch-inverts r_vec, :101-103)
     b_r = ops.mul_add(G2, b, r_vec)                           # B^{r^i}   (:107-112)
     z_ab = ops.multi_pairing(a, b_r)                          # :115
     agg = {k: ops.msm(G1, mipp[k], r_vec) for k in names}     # :117

@@ -7,18 +7,23 @@
 namespace dock {
 Ctx g;
 
-int choose_c(size_t n) {
+int choose_c(size_t n, bool g2) {
     if (g.window_bits >= 7 && g.window_bits <= 22) return g.window_bits;
     const char *e = getenv("DGPU_WINDOW_BITS");
     if (e) { int v = atoi(e); if (v >= 7 && v <= 22) return v; }
-    double best = 1e300; int bc = 7;
-    // c <= 16: digit codes stay 2 bytes and the LDS counting sort sweeps W * RANGES * n * 2 B (at c = 20, n = 2^24 the 4-byte
-    // codes and 32 ranges made the scatter pass 25 ms)
-    for (int c = 7; c <= 16; c++) {
-        double W = 255 / c + 1, B = (double)(1u << (c - 1));
-        double cost = (double)n * W + 8.0 * W * B;
-        if (cost < best) { best = cost; bc = c; }
-    }
+    // Window width by size, from sweeps on MI355X (tests/perf/c_sweep.py, one call in flight).  c <= 16: digit codes stay 2 bytes and the
+    // LDS counting sort sweeps W * RANGES * n * 2 B (at c = 20 the 4-byte codes and 32 ranges cost more than the saved additions).
+    // From 2^17 terms on 16 wins clearly (2^18: 1.99 ms vs 2.50 at c = 14; 2^19: 2.81 vs 3.83): the bucket reduction is a latency-bound
+    // tail whose length hardly depends on the bucket count, while every window saved removes n additions.  Below that the tail
+    // dominates and narrow windows with few buckets win (2^14: c = 9 for G1, c = 8 for G2, whose additions are 3x dearer).
+    int lg = 0; while (((size_t)1 << lg) < n && lg < 40) lg++;          // ceil(log2 n)
+    if (lg > 0 && n - ((size_t)1 << (lg - 1)) < ((size_t)1 << lg) - n) lg--;   // round to the nearer power of two
+    int bc;
+    if (lg >= 17) bc = 16;
+    else if (lg == 16) bc = 12;
+    else if (lg == 15) bc = 10;
+    else if (lg == 14) bc = g2 ? 8 : 9;
+    else bc = 8;
     return bc;
 }
 int choose_chunk(size_t E, int min_chunk, size_t max_chunks) {

@@ -113,7 +113,7 @@ inline bool lookup_handle(uint64_t h, Handle &out) {
     out = it->second; return true;
 }
 
-int choose_c(size_t n);
+int choose_c(size_t n, bool g2 = false);
 int choose_chunk(size_t E, int min_chunk = 16, size_t max_chunks = 300000);
 int32_t upload_scalars(Slot &sl, const uint64_t *h, size_t n, bool mont, uint32_t *d_out);
 

@@ -54,7 +54,7 @@ int32_t msm_device(Slot &sl, const uint32_t *d_bases, const uint32_t *d_scalars,
     if (n == 0) { typedef hostf::HXyzz<HF> PT; PT id = PT::identity(); HF X, Y, Z; id.to_normalised_jacobian(X, Y, Z);
         const size_t FWORDS = sizeof(HF) / 8; memcpy(out_xyz, &X, sizeof(HF)); memcpy(out_xyz + FWORDS, &Y, sizeof(HF)); memcpy(out_xyz + 2 * FWORDS, &Z, sizeof(HF)); return DGPU_OK; }
     if (n >= (1ull << 31)) return DGPU_E_BADARG;
-    const int c = choose_c(n);
+    const int c = choose_c(n, C::NFP == 2);
     const int W = 255 / c + 1;
     const uint32_t B = 1u << (c - 1);
     if ((uint64_t)W * B >= (1ull << 31) || (uint64_t)n * W >= (1ull << 32)) return DGPU_E_BADARG;

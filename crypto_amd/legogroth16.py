@@ -165,7 +165,7 @@ def _pool():
     global _POOL
     if _POOL is None:
         from concurrent.futures import ThreadPoolExecutor
-        _POOL = ThreadPoolExecutor(5)
+        _POOL = ThreadPoolExecutor(6)
     return _POOL
 
 
@@ -192,12 +192,17 @@ def create_proof(pk, r, s, v, h, input_assignment_with_one, witness_assignment):
     n_aux, aux_at = len(wit) - cw, len(inp) - 1 + cw
     # the five large MSMs are independent (the reference runs each under rayon, one after the other): issue them from host
     # threads so that the latency-bound tail of one overlaps the bulk of the next (the library keeps 4 calls in flight)
+    # g_d = msm(gamma_abc[len(inputs) .. + cw], committed) + v (eta/gamma)    :361-368  (independent of the large MSMs: issued with them)
+    src = vk.gamma_abc_g1[len(inp):len(inp) + cw]
+    d_pts = np.concatenate([src, vk.eta_gamma_inv_g1.reshape(1, 12)])
+    d_sc = np.concatenate([committed, _sc(v).reshape(1, 4)])
     jobs = [lambda: pk.l_query.msm_resident(assignment, n=min(pk.l_query.n, n_aux), scalar_offset=aux_at),   # :299
             lambda: _calculate_coeff(M.G1, pk.delta_g1, r, pk.a_query, pk.a0, vk.alpha_g1, assignment),           # :325-326
             (lambda: _calculate_coeff(M.G1, pk.delta_g1, s, pk.b_g1_query, pk.b1_0, pk.beta_g1, assignment)) if r % R_MOD != 0
             else (lambda: np.zeros(18, dtype=np.uint64)),          # :330-336
-            lambda: _calculate_coeff(M.G2, vk.delta_g2, s, pk.b_g2_query, pk.b2_0, vk.beta_g2, assignment)]       # :343-344
-    l_aux_acc, g_a, g1_b, g2_b = [f.result() for f in [pool.submit(j) for j in jobs]]
+            lambda: _calculate_coeff(M.G2, vk.delta_g2, s, pk.b_g2_query, pk.b2_0, vk.beta_g2, assignment),       # :343-344
+            lambda: M.msm_bigint(M.G1, d_pts, d_sc)]
+    l_aux_acc, g_a, g1_b, g2_b, g_d = [f.result() for f in [pool.submit(j) for j in jobs]]
     h_acc = f_h.result()
     assignment.free()
     if hs is not h:
@@ -205,10 +210,6 @@ def create_proof(pk, r, s, v, h, input_assignment_with_one, witness_assignment):
     # g_c = s g_a + r g1_b - rs delta + l_aux + h_acc - v (eta/delta)    :350-355
     small = lincomb(M.G1, [_affine(M.G1, g_a), _affine(M.G1, g1_b), pk.delta_g1, pk.eta_delta_inv_g1], [s, r, -(r * s), -v])
     g_c = sharded.fold(M.G1, np.stack([small, l_aux_acc, h_acc]))
-    # g_d = msm(gamma_abc[len(inputs) .. + cw], committed) + v (eta/gamma)    :361-368
-    src = vk.gamma_abc_g1[len(inp):len(inp) + cw]
-    pts = np.concatenate([src, vk.eta_gamma_inv_g1.reshape(1, 12)])
-    g_d = M.msm_bigint(M.G1, pts, np.concatenate([committed, _sc(v).reshape(1, 4)]))
     return {"a": _affine(M.G1, g_a), "b": _affine(M.G2, g2_b), "c": _affine(M.G1, g_c), "d": _affine(M.G1, g_d)}
 
 

@@ -78,11 +78,12 @@ def test_full_prove_2_20_verifies_and_matches_the_closed_form():
     g1 = O.G1.to_affine(O.G1.mul(O.G1.generator(), O.int_to_limbs(k1, 4)))[0]
     g2 = O.G2.to_affine(O.G2.mul(O.G2.generator(), O.int_to_limbs(k2, 4)))[0]
     # the generator takes the constraint rows as lists of (coeff, index) (the reference's ConstraintMatrices)
-    rows = lambda M_: [[(O.limbs_to_int(M_[2][k]), int(M_[1][k])) for k in range(int(M_[0][i]), int(M_[0][i + 1]))] for i in range(nc)]
-    Al, Bl, Cl = rows(A), rows(B), rows(Cm)
+    cs = LS.circuit(m, 7)                       # same circuit in list form (tests/test_bigcase_helpers.py: identical to the CSR arrays)
+    assert cs["z"] == z
+    Al, Bl, Cl = cs["A"], cs["B"], cs["C"]
     pk, _ = LG.generate_parameters(Al, Bl, Cl, n_inst, len(z) - n_inst, cw, alpha, beta, gamma, delta, eta, t, g1, g2)
     a, b, c, zt, V, D = LG.instance_map_with_evaluation(Al, Bl, Cl, n_inst, len(z) - n_inst, t)
-    del Al, Bl, Cl
+    del Al, Bl, Cl, cs
     assert D == 1 << 20 and pk.h_query.n == D - 1 and pk.a_query.n == V + 1
     # h on the device (circuit resident, result stays in HBM), checked against the oracle
     dr = qap.DeviceR1cs(A, B, Cm, len(z), n_inst, nc)

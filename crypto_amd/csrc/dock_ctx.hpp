@@ -41,12 +41,12 @@ extern Ctx g;
 struct Slot {
     std::mutex mu;
     hipStream_t stream = nullptr;
-    Buf in_bases, in_inf, in_scalars, prepped, digits, heavy, cnt, off, cursor, bsums, entries, bucket, bucket_inf, head, tail, head_b, tail_b, part_inf, l1, l1_inf, win, win_inf, ml_lines, ml_partial, ml_out;
+    Buf in_bases, in_inf, in_scalars, prepped, digits, heavy, cnt, off, cursor, bsums, entries, bucket, bucket_inf, head, tail, head_b, tail_b, part_inf, l1, l1_inf, win, win_inf, ml_lines, ml_partial, ml_out, ml_coeffs;
     Buf q[16];      // witness-map workspace (dock_qap.hip)
     std::vector<std::pair<const char *, std::pair<hipEvent_t, hipEvent_t>>> prof_pending;
     std::vector<hipEvent_t> ev_pool;
     void release_all() {
-        Buf *bufs[] = {&in_bases, &in_inf, &in_scalars, &prepped, &digits, &heavy, &cnt, &off, &cursor, &bsums, &entries, &bucket, &bucket_inf, &head, &tail, &head_b, &tail_b, &part_inf, &l1, &l1_inf, &win, &win_inf, &ml_lines, &ml_partial, &ml_out};
+        Buf *bufs[] = {&in_bases, &in_inf, &in_scalars, &prepped, &digits, &heavy, &cnt, &off, &cursor, &bsums, &entries, &bucket, &bucket_inf, &head, &tail, &head_b, &tail_b, &part_inf, &l1, &l1_inf, &win, &win_inf, &ml_lines, &ml_partial, &ml_out, &ml_coeffs};
         for (Buf *b : bufs) b->release();
         for (Buf &b : q) b.release();
         for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);

@@ -178,6 +178,64 @@ __global__ void __launch_bounds__(64) k_miller_lines_quad(const uint32_t *__rest
     }
 }
 
+// ---- G2Prepared (ark-ec bls12/g2.rs `G2Prepared::from`: the 68 coefficient triples before the evaluation at P) --------------------------
+// The reference's verifier and pairing checker hold ONLY prepared G2 values (legogroth16/src/verifier.rs:69-76 passes
+// pvk.delta_g2_neg_pc / gamma_g2_neg_pc, data_structures.rs:118-120; utils/src/randomized_pairing_check.rs:35 queues Vec<E::G2Prepared>),
+// and a G2Prepared cannot be turned back into a point, so the boundary needs both directions:
+//   k_g2_prepare           Q -> ell_coeffs in the ABI form (canonical 2^384 Montgomery limbs: the same bytes arkworks holds)
+//   k_lines_from_prepared  (P, ell_coeffs) -> the evaluated sparse lines K10 consumes; every (pair, step) is independent here, so this is
+//                          one lane per (pair, step) instead of a 63-step dependent chain per pair
+constexpr int CW = 72;            // u32 per coefficient triple in the ABI (3 Fp2 = 6 x 12 words)
+__global__ void __launch_bounds__(64) k_g2_prepare(const uint32_t *__restrict__ q_abi, const uint8_t *__restrict__ is_inf, size_t n, uint32_t *__restrict__ out, uint8_t *__restrict__ out_inf) {
+    size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 1;
+    const uint32_t h = threadIdx.x & 1u;
+    if (i >= n) return;
+    uint32_t qx[12], qy[12], anyq = 0;
+    for (int k = 0; k < 12; k++) { qx[k] = q_abi[i * 48 + h * 12 + k]; qy[k] = q_abi[i * 48 + 24 + h * 12 + k]; anyq |= qx[k] | qy[k]; }
+    anyq |= xchg32(anyq);
+    const bool inf = (is_inf && is_inf[i]) || !anyq;
+    uint32_t *dst = out + i * (size_t)(N_LINES * CW);
+    if (h == 0) out_inf[i] = inf ? 1 : 0;
+    if (inf) {                                                       // arkworks: ell_coeffs = vec![], infinity = true
+        for (int s = 0; s < N_LINES; s++) for (int c = 0; c < 3; c++) for (int k = 0; k < 12; k++) dst[s * CW + (2 * c + h) * 12 + k] = 0u;
+        return;
+    }
+    auto put = [&](int s, const LineT<Fp2H> &l) {
+        fp_to_abi(dst + s * CW + (0 + h) * 12, l.c0.v); fp_to_abi(dst + s * CW + (2 + h) * 12, l.c1.v); fp_to_abi(dst + s * CW + (4 + h) * 12, l.c2.v);
+    };
+    Aff<Fp2H> Q; fp_from_abi(Q.x.v, qx); fp_from_abi(Q.y.v, qy);
+    G2ProjT<Fp2H> R; R.x = Q.x; R.y = Q.y; fset_one(R.z);
+    int s = 0;
+    for (int b = 62; b >= 0; b--) {
+        LineT<Fp2H> l; line_dbl_step(R, l); put(s++, l);
+        if ((BLS_X_ABS >> b) & 1) { line_add_step(R, Q, l); put(s++, l); }
+    }
+}
+// thread (s, i), i fastest: ark-ec `ell` (c1 *= px, c2 *= py) on coefficient triple s of pair i, written in K10's layout
+__global__ void __launch_bounds__(256) k_lines_from_prepared(const uint32_t *__restrict__ p_abi, const uint32_t *__restrict__ coeffs, const uint8_t *__restrict__ skip, size_t n, uint32_t *__restrict__ lines) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * N_LINES) return;
+    const size_t s = t / n, i = t % n;
+    uint32_t pw[24], anyp = 0;
+    for (int k = 0; k < 24; k += 4) { uint4 v = *reinterpret_cast<const uint4 *>(p_abi + i * 24 + k); pw[k] = v.x; pw[k + 1] = v.y; pw[k + 2] = v.z; pw[k + 3] = v.w; anyp |= v.x | v.y | v.z | v.w; }
+    const uint32_t *src = coeffs + (i * N_LINES + s) * (size_t)CW;
+    uint32_t cw[CW], anyc = 0;
+    for (int k = 0; k < CW; k += 4) { uint4 v = *reinterpret_cast<const uint4 *>(src + k); cw[k] = v.x; cw[k + 1] = v.y; cw[k + 2] = v.z; cw[k + 3] = v.w; anyc |= v.x | v.y | v.z | v.w; }
+    uint32_t any0 = 0;                                               // an identity Q is an all-zero block: its first triple decides (a real doubling line has c1 = 3 x^2 != 0)
+    for (int k = 0; k < CW; k += 4) { uint4 v = *reinterpret_cast<const uint4 *>(coeffs + i * (size_t)(N_LINES * CW) + k); any0 |= v.x | v.y | v.z | v.w; }
+    (void)anyc;
+    const bool sk = (skip && skip[i]) || !anyp || !any0;
+    uint32_t *dst = lines + (s * LW) * n + i;
+    if (sk) { Fp one; fp_set_one(one); for (int k = 0; k < LW; k++) dst[(size_t)k * n] = (k < NL) ? one.l[k] : 0u; return; }
+    Fp px, py; fp_from_abi(px, pw); fp_from_abi(py, pw + 12);
+#pragma unroll
+    for (int c = 0; c < 6; c++) {
+        Fp f; fp_from_abi(f, cw + 12 * c);
+        if (c >= 2) { Fp m; fp_mul(m, f, c < 4 ? px : py); f = m; }
+        for (int k = 0; k < NL; k++) dst[(size_t)(c * NL + k) * n] = f.l[k];
+    }
+}
+
 // partial[(s * nsl + j) * F12W + k] = product of the lines of step s over slice j of the pairs (sparse Fp12::mul_by_014 chain).
 // One chain per LANE PAIR (fp2_pair.cuh): the chain is serial, so its duration is the instruction count of one lane, and the pair form
 // of an Fp2 product is one fused two-product reduction per lane instead of two.  Word (2 q + h) * NL + j of an Fp12 is limb j of half h
@@ -274,37 +332,15 @@ inline int choose_slice_len(size_t n) {
 
 extern "C" {
 
-int32_t dgpu_multi_miller_loop(const uint64_t *p, const uint64_t *q, const uint8_t *skip, size_t n, uint64_t *out) {
-    if (!out || (n && (!p || !q))) return DGPU_E_BADARG;
-    if (n == 0) { hostf::Fq12 one = hostf::Fq12::one(); memcpy(out, &one, sizeof one); return DGPU_OK; }
-    if (n >= (1ull << 24)) return DGPU_E_BADARG;
-    if (!g.ready) return DGPU_E_NODEVICE;
-    SlotLock slot_lock; Slot &sl = *slot_lock.s;
-    HIPCHK(hipSetDevice(g.device));
+// K10 + K11 + host tail on the lines already in sl.ml_lines
+static int32_t ml_finish(Slot &sl, size_t n, uint64_t *out) {
     int32_t rc;
     const int slice_len = choose_slice_len(n);
     const int nsl = (int)((n + slice_len - 1) / slice_len);          // <= 2048
     const int ngroups = (nsl + MAX_SLICES - 1) / MAX_SLICES;         // <= 32: the second tree level is one group
-    if ((rc = sl.in_bases.ensure(n * 96))) return rc;
-    if ((rc = sl.in_scalars.ensure(n * 192))) return rc;
-    if ((rc = sl.in_inf.ensure(n))) return rc;
-    if ((rc = sl.ml_lines.ensure((size_t)N_LINES * LW * n * 4))) return rc;
     if ((rc = sl.ml_partial.ensure((size_t)N_LINES * (nsl + ngroups) * F12W * 4))) return rc;
     if ((rc = sl.ml_out.ensure((size_t)N_LINES * 144 * 4))) return rc;
     hipStream_t s = sl.stream;
-    HIPCHK(hipMemcpyAsync(sl.in_bases.p, p, n * 96, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(sl.in_scalars.p, q, n * 192, hipMemcpyHostToDevice, s));
-    const uint8_t *dskip = nullptr;
-    if (skip) { HIPCHK(hipMemcpyAsync(sl.in_inf.p, skip, n, hipMemcpyHostToDevice, s)); dskip = sl.in_inf.as<uint8_t>(); }
-    { StageTimer st(sl, "ml.lines");
-      static const bool one_lane = getenv("DGPU_ML_ONE_LANE") != nullptr;     // development switch: one lane per pair
-      if (one_lane) hipLaunchKernelGGL(k_miller_lines, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, sl.in_bases.as<uint32_t>(), sl.in_scalars.as<uint32_t>(), dskip, n, sl.ml_lines.as<uint32_t>());
-      else {
-          static const bool two_lanes = getenv("DGPU_ML_TWO_LANES") != nullptr;   // development switch: one lane pair per (P, Q)
-          if (two_lanes || n > 8192) hipLaunchKernelGGL(k_miller_lines_pair,     // (with the chip full, the pair form does less total work)
-              dim3((unsigned)((2 * n + 63) / 64)), dim3(64), 0, s, sl.in_bases.as<uint32_t>(), sl.in_scalars.as<uint32_t>(), dskip, n, sl.ml_lines.as<uint32_t>());
-          else hipLaunchKernelGGL(k_miller_lines_quad, dim3((unsigned)((4 * n + 63) / 64)), dim3(64), 0, s, sl.in_bases.as<uint32_t>(), sl.in_scalars.as<uint32_t>(), dskip, n, sl.ml_lines.as<uint32_t>());
-      } }
     { StageTimer st(sl, "ml.products");
       hipLaunchKernelGGL(k_line_products, dim3((unsigned)((2 * N_LINES * nsl + 63) / 64)), dim3(64), 0, s, sl.ml_lines.as<uint32_t>(), n, slice_len, nsl, sl.ml_partial.as<uint32_t>()); }
     { StageTimer st(sl, "ml.tree");
@@ -324,6 +360,89 @@ int32_t dgpu_multi_miller_loop(const uint64_t *p, const uint64_t *q, const uint8
     f = f.conj();      // x < 0
     memcpy(out, &f, sizeof f);
     return DGPU_OK;
+}
+
+int32_t dgpu_multi_miller_loop(const uint64_t *p, const uint64_t *q, const uint8_t *skip, size_t n, uint64_t *out) {
+    if (!out || (n && (!p || !q))) return DGPU_E_BADARG;
+    if (n == 0) { hostf::Fq12 one = hostf::Fq12::one(); memcpy(out, &one, sizeof one); return DGPU_OK; }
+    if (n >= (1ull << 24)) return DGPU_E_BADARG;
+    if (!g.ready) return DGPU_E_NODEVICE;
+    SlotLock slot_lock; Slot &sl = *slot_lock.s;
+    HIPCHK(hipSetDevice(g.device));
+    int32_t rc;
+    if ((rc = sl.in_bases.ensure(n * 96))) return rc;
+    if ((rc = sl.in_scalars.ensure(n * 192))) return rc;
+    if ((rc = sl.in_inf.ensure(n))) return rc;
+    if ((rc = sl.ml_lines.ensure((size_t)N_LINES * LW * n * 4))) return rc;
+    hipStream_t s = sl.stream;
+    HIPCHK(hipMemcpyAsync(sl.in_bases.p, p, n * 96, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(sl.in_scalars.p, q, n * 192, hipMemcpyHostToDevice, s));
+    const uint8_t *dskip = nullptr;
+    if (skip) { HIPCHK(hipMemcpyAsync(sl.in_inf.p, skip, n, hipMemcpyHostToDevice, s)); dskip = sl.in_inf.as<uint8_t>(); }
+    { StageTimer st(sl, "ml.lines");
+#ifdef DGPU_DEV
+      static const bool one_lane = getenv("DGPU_ML_ONE_LANE") != nullptr;     // development switches: one lane / one lane pair per (P, Q)
+      static const bool two_lanes = getenv("DGPU_ML_TWO_LANES") != nullptr;
+#else
+      constexpr bool one_lane = false, two_lanes = false;
+#endif
+      if (one_lane) hipLaunchKernelGGL(k_miller_lines, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, sl.in_bases.as<uint32_t>(), sl.in_scalars.as<uint32_t>(), dskip, n, sl.ml_lines.as<uint32_t>());
+      else if (two_lanes || n > 8192) hipLaunchKernelGGL(k_miller_lines_pair,     // (with the chip full, the pair form does less total work)
+              dim3((unsigned)((2 * n + 63) / 64)), dim3(64), 0, s, sl.in_bases.as<uint32_t>(), sl.in_scalars.as<uint32_t>(), dskip, n, sl.ml_lines.as<uint32_t>());
+      else hipLaunchKernelGGL(k_miller_lines_quad, dim3((unsigned)((4 * n + 63) / 64)), dim3(64), 0, s, sl.in_bases.as<uint32_t>(), sl.in_scalars.as<uint32_t>(), dskip, n, sl.ml_lines.as<uint32_t>());
+    }
+    return ml_finish(sl, n, out);
+}
+
+// E::G2Prepared::from for a batch (utils/src/randomized_pairing_check.rs:132 `b.into()`, legogroth16/src/verifier.rs:22-23,72)
+int32_t dgpu_g2_prepare(const uint64_t *q, const uint8_t *is_inf, size_t n, uint64_t *out_coeffs, uint8_t *out_inf) {
+    if (n && (!q || !out_coeffs || !out_inf)) return DGPU_E_BADARG;
+    if (n == 0) return DGPU_OK;
+    if (n > DGPU_MAX_PREPARED) return DGPU_E_BADARG;
+    if (!g.ready) return DGPU_E_NODEVICE;
+    SlotLock slot_lock; Slot &sl = *slot_lock.s;
+    HIPCHK(hipSetDevice(g.device));
+    int32_t rc;
+    const size_t cbytes = n * (size_t)DGPU_G2_PREPARED_WORDS * 8;
+    if ((rc = sl.in_scalars.ensure(n * 192))) return rc;
+    if ((rc = sl.in_inf.ensure(2 * n))) return rc;
+    if ((rc = sl.ml_coeffs.ensure(cbytes))) return rc;
+    hipStream_t s = sl.stream;
+    HIPCHK(hipMemcpyAsync(sl.in_scalars.p, q, n * 192, hipMemcpyHostToDevice, s));
+    const uint8_t *dinf = nullptr;
+    if (is_inf) { HIPCHK(hipMemcpyAsync(sl.in_inf.p, is_inf, n, hipMemcpyHostToDevice, s)); dinf = sl.in_inf.as<uint8_t>(); }
+    { StageTimer st(sl, "ml.g2_prepare");
+      hipLaunchKernelGGL(k_g2_prepare, dim3((unsigned)((2 * n + 63) / 64)), dim3(64), 0, s, sl.in_scalars.as<uint32_t>(), dinf, n, sl.ml_coeffs.as<uint32_t>(), sl.in_inf.as<uint8_t>() + n); }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out_coeffs, sl.ml_coeffs.p, cbytes, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(out_inf, sl.in_inf.as<uint8_t>() + n, n, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (g.prof) prof_flush(sl);
+    return DGPU_OK;
+}
+
+// E::multi_miller_loop(a, b) with b already G2Prepared (what verifier.rs:69-76 and randomized_pairing_check.rs:207 pass)
+int32_t dgpu_multi_miller_loop_prepared(const uint64_t *p, const uint64_t *coeffs, const uint8_t *skip, size_t n, uint64_t *out) {
+    if (!out || (n && (!p || !coeffs))) return DGPU_E_BADARG;
+    if (n == 0) { hostf::Fq12 one = hostf::Fq12::one(); memcpy(out, &one, sizeof one); return DGPU_OK; }
+    if (n > DGPU_MAX_PREPARED) return DGPU_E_BADARG;
+    if (!g.ready) return DGPU_E_NODEVICE;
+    SlotLock slot_lock; Slot &sl = *slot_lock.s;
+    HIPCHK(hipSetDevice(g.device));
+    int32_t rc;
+    const size_t cbytes = n * (size_t)DGPU_G2_PREPARED_WORDS * 8;
+    if ((rc = sl.in_bases.ensure(n * 96))) return rc;
+    if ((rc = sl.in_inf.ensure(n))) return rc;
+    if ((rc = sl.ml_coeffs.ensure(cbytes))) return rc;
+    if ((rc = sl.ml_lines.ensure((size_t)N_LINES * LW * n * 4))) return rc;
+    hipStream_t s = sl.stream;
+    HIPCHK(hipMemcpyAsync(sl.in_bases.p, p, n * 96, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(sl.ml_coeffs.p, coeffs, cbytes, hipMemcpyHostToDevice, s));
+    const uint8_t *dskip = nullptr;
+    if (skip) { HIPCHK(hipMemcpyAsync(sl.in_inf.p, skip, n, hipMemcpyHostToDevice, s)); dskip = sl.in_inf.as<uint8_t>(); }
+    { StageTimer st(sl, "ml.lines_prepared");
+      hipLaunchKernelGGL(k_lines_from_prepared, dim3((unsigned)((n * N_LINES + 255) / 256)), dim3(256), 0, s, sl.in_bases.as<uint32_t>(), sl.ml_coeffs.as<uint32_t>(), dskip, n, sl.ml_lines.as<uint32_t>()); }
+    return ml_finish(sl, n, out);
 }
 
 int32_t dgpu_g1_scale_batch(const uint64_t *p, const uint8_t *is_inf, const uint64_t *scalars, size_t scalar_stride, const uint8_t *negate, size_t n, uint64_t *out, uint8_t *out_inf) {

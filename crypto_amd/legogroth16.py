@@ -280,8 +280,9 @@ def create_proof_sharded(spk, r, s, v, h, input_assignment_with_one, witness_ass
 
 def prepare_verifying_key(vk):
     """verifier.rs:17-25"""
+    neg_pc = pairing.G2Prepared.from_affine(np.stack([_neg_affine(M.G2, vk.gamma_g2), _neg_affine(M.G2, vk.delta_g2)]))   # :22-23: held PREPARED
     return {"vk": vk, "alpha_g1_beta_g2": pairing.multi_pairing(vk.alpha_g1.reshape(1, 12), vk.beta_g2.reshape(1, 24)),
-            "gamma_g2_neg": _neg_affine(M.G2, vk.gamma_g2), "delta_g2_neg": _neg_affine(M.G2, vk.delta_g2)}
+            "gamma_g2_neg_pc": neg_pc[0], "delta_g2_neg_pc": neg_pc[1]}
 
 
 def calculate_d(pvk, proof, public_inputs):
@@ -299,7 +300,7 @@ def verify_proof(pvk, proof, public_inputs):
     """verifier.rs:62-99: e(A, B) e(C, -delta) e(d, -gamma) == e(alpha, beta)"""
     d = calculate_d(pvk, proof, public_inputs)
     ps = np.stack([proof["a"], proof["c"], d])
-    qs = np.stack([proof["b"], pvk["delta_g2_neg"], pvk["gamma_g2_neg"]])
+    qs = [proof["b"].reshape(1, 24), pvk["delta_g2_neg_pc"], pvk["gamma_g2_neg_pc"]]      # [b.into(), delta_g2_neg_pc.clone(), gamma_g2_neg_pc.clone()]  :69-76
     gt = pairing.multi_pairing(ps, qs)
     if gt is None:
         raise ValueError("UnexpectedIdentity")

@@ -3,6 +3,9 @@
   * E::multi_miller_loop(a, b)   -> multi_miller_loop()   (utils/src/randomized_pairing_check.rs:207, legogroth16/src/verifier.rs:69-76)
   * E::final_exponentiation(f)   -> final_exponentiation() returns None where arkworks returns None
   * E::multi_pairing(a, b)       -> multi_pairing()       (bbs_plus/src/signature.rs:284, legogroth16/src/link/snark.rs:157)
+  * E::G2Prepared::from(q)       -> G2Prepared.from_affine(qs) / g2_prepare(qs)   (verifier.rs:22-23, randomized_pairing_check.rs:132)
+    `b: impl Into<E::G2Prepared>`: every entry point below takes affine points (n, 24), a `G2Prepared` batch, or a list mixing both,
+    the way the reference mixes `b.into()` with `pvk.delta_g2_neg_pc.clone()` (verifier.rs:69-76).
 Arrays: numpy uint64 in the ABI layout (G1 affine 12, G2 affine 24, Fp12 72 limbs; Montgomery).
 """
 import ctypes as C
@@ -15,9 +18,65 @@ def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
+PREPARED_WORDS = 68 * 36      # DGPU_G2_PREPARED_WORDS
+
+
+class G2Prepared:
+    """A batch of ark-ec `G2Prepared` values: `coeffs` (n, 68*36) uint64 = the ell_coeffs triples in ABI limbs, `infinity` (n,) uint8."""
+
+    def __init__(self, coeffs, infinity):
+        self.coeffs = np.ascontiguousarray(coeffs, dtype=np.uint64).reshape(-1, PREPARED_WORDS)
+        self.infinity = np.ascontiguousarray(infinity, dtype=np.uint8).reshape(-1)
+        assert len(self.coeffs) == len(self.infinity)
+
+    def __len__(self):
+        return len(self.coeffs)
+
+    def __getitem__(self, i):
+        if isinstance(i, (int, np.integer)):
+            return G2Prepared(self.coeffs[i:i + 1], self.infinity[i:i + 1])
+        return G2Prepared(self.coeffs[i], self.infinity[i])
+
+    @classmethod
+    def from_affine(cls, qs, is_inf=None):
+        """G2Prepared::from for every point of `qs` (n, 24), on the device (dgpu_g2_prepare)"""
+        _ensure()
+        qs = np.ascontiguousarray(qs, dtype=np.uint64).reshape(-1, 24)
+        n = len(qs)
+        co = np.zeros((n, PREPARED_WORDS), dtype=np.uint64)
+        inf = np.zeros(n, dtype=np.uint8)
+        fl = None if is_inf is None else np.ascontiguousarray(is_inf, dtype=np.uint8)
+        if n:
+            rc = lib().dgpu_g2_prepare(_p(qs), _p(fl), n, _p(co), _p(inf))
+            if rc:
+                raise DockGpuError(rc, "dgpu_g2_prepare")
+        return cls(co, inf)
+
+    @classmethod
+    def concat(cls, items):
+        """items: G2Prepared batches and/or affine arrays — `impl Into<E::G2Prepared>` for each"""
+        parts = [it if isinstance(it, G2Prepared) else cls.from_affine(it) for it in items]
+        return cls(np.concatenate([p.coeffs for p in parts]), np.concatenate([p.infinity for p in parts]))
+
+
+def g2_prepare(qs, is_inf=None):
+    return G2Prepared.from_affine(qs, is_inf)
+
+
 def multi_miller_loop(ps, qs, skip=None):
     _ensure()
     ps = np.ascontiguousarray(ps, dtype=np.uint64).reshape(-1, 12)
+    if isinstance(qs, (list, tuple)) and any(isinstance(q, G2Prepared) for q in qs):
+        qs = G2Prepared.concat(qs)
+    if isinstance(qs, G2Prepared):
+        if len(ps) != len(qs):
+            raise DockGpuError(-7, "multi_miller_loop")
+        sk = qs.infinity if skip is None else (np.ascontiguousarray(skip, dtype=np.uint8) | qs.infinity)
+        out = np.zeros(72, dtype=np.uint64)
+        rc = lib().dgpu_multi_miller_loop_prepared(_p(ps), _p(qs.coeffs), _p(np.ascontiguousarray(sk)), len(ps), _p(out))
+        if rc:
+            raise DockGpuError(rc, "dgpu_multi_miller_loop_prepared")
+        return out
     qs = np.ascontiguousarray(qs, dtype=np.uint64).reshape(-1, 24)
     if len(ps) != len(qs):
         # arkworks zips with zip_eq and panics; the Rust shim would panic too — here: DGPU_E_LENGTH

@@ -91,6 +91,18 @@ def g1_scale_each(points, scalar_limbs, negate=None):
     return out, inf
 
 
+def _g2(b):
+    """`impl Into<E::G2Prepared>`: an affine (n, 24) array stays affine (prepared inside the fused line kernel), a G2Prepared batch passes through"""
+    return b if isinstance(b, pairing.G2Prepared) else np.ascontiguousarray(b, dtype=np.uint64).reshape(-1, 24)
+
+
+def _g2_all(items):
+    """the queued G2 operands as ONE operand of multi_miller_loop: a plain concatenation while nothing is prepared, else G2Prepared"""
+    if any(isinstance(b, pairing.G2Prepared) for b in items):
+        return pairing.G2Prepared.concat(items)
+    return np.concatenate(items)
+
+
 class RandomizedPairingChecker:
     def __init__(self, random, lazy):                          # new(random, lazy)  :44-53
         self.left = fp12_one()
@@ -103,18 +115,17 @@ class RandomizedPairingChecker:
 
     # -- single equations -------------------------------------------------------------------------------------
     def add_sources_and_target(self, a, b, out):               # e(a, b) == out   :61-77
-        self.add_multiple_sources_and_target(np.asarray(a).reshape(1, 12), np.asarray(b).reshape(1, 24), out)
+        self.add_multiple_sources_and_target(np.asarray(a).reshape(1, 12), _g2(b), out)
 
     def add_sources(self, a, b, c, d):                         # e(a, b) == e(c, d)   :104-113
-        self.add_multiple_sources(np.asarray(a).reshape(1, 12), np.asarray(b).reshape(1, 24),
-                                  np.asarray(c).reshape(1, 12), np.asarray(d).reshape(1, 24))
+        self.add_multiple_sources(np.asarray(a).reshape(1, 12), _g2(b), np.asarray(c).reshape(1, 12), _g2(d))
 
     # -- products ---------------------------------------------------------------------------------------------
     def add_multiple_sources_and_target(self, a, b, out, lazy=None):    # prod e(a_i, b_i) == out   :116-138
         lazy = self.lazy if lazy is None else lazy
         m = self.current_random
         a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 12)
-        b = np.ascontiguousarray(b, dtype=np.uint64).reshape(-1, 24)
+        b = _g2(b)
         if len(a) != len(b):
             raise DockGpuError(-7, "zip_eq")
         if lazy:
@@ -135,8 +146,7 @@ class RandomizedPairingChecker:
         m = self.current_random
         a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 12)
         c = np.ascontiguousarray(c, dtype=np.uint64).reshape(-1, 12)
-        b = np.ascontiguousarray(b, dtype=np.uint64).reshape(-1, 24)
-        d = np.ascontiguousarray(d, dtype=np.uint64).reshape(-1, 24)
+        b, d = _g2(b), _g2(d)
         if len(a) != len(b) or len(c) != len(d):
             raise DockGpuError(-7, "zip_eq")
         if lazy:
@@ -163,7 +173,7 @@ class RandomizedPairingChecker:
             sc = np.concatenate([np.tile(_limbs(m), (len(a), 1)) for a, m, _ in self.pending[0]])
             ng = np.concatenate([np.full(len(a), 1 if neg else 0, dtype=np.uint8) for a, _, neg in self.pending[0]])
             ps, _ = g1_scale_each(pts, sc, ng)
-            qs = np.concatenate(self.pending[1])
+            qs = _g2_all(self.pending[1])
             left = fp12_mul(pairing.multi_miller_loop(ps, qs), left)    # identity members are all-zero words: skipped on the device
         gt = pairing.final_exponentiation(left)
         if gt is None:

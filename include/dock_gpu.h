@@ -91,6 +91,22 @@ int32_t dgpu_fold_g2(const uint64_t *partials_xyz /* k*36 */, size_t k, uint64_t
  * filters those out).  Output: raw MillerLoopOutput, Fp12 as c0.c0.c0 ... c1.c2.c1 (72 u64). */
 int32_t dgpu_multi_miller_loop(const uint64_t *p_xy /* n*12 */, const uint64_t *q_xy /* n*24 */,
                                const uint8_t *skip /* n or NULL */, size_t n, uint64_t out_f12[72]);
+/* E::G2Prepared — the form in which the reference's verifier and pairing checker HOLD their G2 operands
+ * (legogroth16/src/data_structures.rs:118-120 `gamma_g2_neg_pc` / `delta_g2_neg_pc`, verifier.rs:22-23,69-76;
+ * utils/src/randomized_pairing_check.rs:35 `pending: (Vec<G1Prepared>, Vec<G2Prepared>)`, :119-138,:204-214).
+ * One prepared point = arkworks' `ell_coeffs`: 68 triples (Fp2, Fp2, Fp2), each Fq 6 x u64 Montgomery limbs in the order
+ * c0.c0 c0.c1 c1.c0 c1.c1 c2.c0 c2.c1 -> DGPU_G2_PREPARED_WORDS u64 = 19 584 B; `infinity` travels as a flag byte and the
+ * block of an identity point is all zero.
+ * dgpu_g2_prepare replaces `G2Prepared::from(G2Affine)` for a batch (the 63 doubling + 5 addition steps run on the GPU);
+ * dgpu_multi_miller_loop_prepared replaces `E::multi_miller_loop(a, b)` where b is already prepared: the same raw
+ * MillerLoopOutput, limb for limb, as dgpu_multi_miller_loop on the unprepared points (the reference asserts exactly this
+ * for pairings, utils/src/msm.rs:261-276).  skip[i] != 0, an all-zero P or an all-zero coefficient block skip pair i. */
+#define DGPU_G2_PREPARED_WORDS (68 * 36)
+#define DGPU_MAX_PREPARED ((size_t)1 << 18)     /* pairs per call (5 GB of coefficients) */
+int32_t dgpu_g2_prepare(const uint64_t *q_xy /* n*24 */, const uint8_t *is_inf /* n or NULL */, size_t n,
+                        uint64_t *out_coeffs /* n*DGPU_G2_PREPARED_WORDS */, uint8_t *out_inf /* n */);
+int32_t dgpu_multi_miller_loop_prepared(const uint64_t *p_xy /* n*12 */, const uint64_t *coeffs /* n*DGPU_G2_PREPARED_WORDS */,
+                                        const uint8_t *skip /* n or NULL */, size_t n, uint64_t out_f12[72]);
 /* replaces Bls12_381::final_exponentiation — utils/src/randomized_pairing_check.rs:213 (host code, once per batch) */
 int32_t dgpu_final_exponentiation(const uint64_t in_f12[72], uint64_t out_f12[72]);
 

@@ -52,6 +52,9 @@ def test_fails_loudly_without_device():
     f12 = np.zeros(72, np.uint64); q = O.G2.generator().reshape(1, 24); o12 = np.zeros(12, np.uint64); oi = np.zeros(1, np.uint8)
     h = C.c_uint64(0)
     assert L.dgpu_multi_miller_loop(p_(b), p_(q), None, 1, p_(f12)) == -1
+    co = np.zeros(68 * 36, np.uint64)
+    assert L.dgpu_g2_prepare(p_(q), None, 1, p_(co), p_(oi)) == -1
+    assert L.dgpu_multi_miller_loop_prepared(p_(b), p_(co), None, 1, p_(f12)) == -1
     assert L.dgpu_fixed_base_g1(p_(b), p_(s), 1, 0, p_(o12), p_(oi)) == -1
     assert L.dgpu_window_table_g1(p_(b), C.byref(h)) == -1
     assert L.dgpu_g1_mul_add_batch(p_(b), None, p_(s), 4, None, None, 1, p_(o12), p_(oi)) == -1
@@ -79,6 +82,8 @@ def test_bad_arguments():
     assert L.dgpu_keccak_f1600(None) == -3
     assert L.dgpu_window_table_g1(None, C.byref(C.c_uint64(0))) == -3
     assert L.dgpu_multi_miller_loop(None, None, None, 3, p_(np.zeros(72, np.uint64))) == -3
+    assert L.dgpu_multi_miller_loop_prepared(None, None, None, 3, p_(np.zeros(72, np.uint64))) == -3
+    assert L.dgpu_g2_prepare(None, None, 2, None, None) == -3
     assert L.dgpu_window_table_free(999) == -3
 
 

@@ -90,3 +90,47 @@ def test_batched_check_1024_pairs():
     pn, qn = pts([U.R - tot], [1])
     f2 = ca.multi_miller_loop(np.concatenate([ps, pn]), np.concatenate([qs, qn]))
     assert (ca.final_exponentiation(f2) == O.fp12_one()).all()
+
+
+# ---- G2Prepared: the form the reference's verifier / pairing checker hold (verifier.rs:69-76, randomized_pairing_check.rs:35) ----
+@pytest.mark.parametrize("n", [1, 2, 7, 64, 300])
+def test_g2_prepare_coefficients_equal_the_oracle(n):
+    """dgpu_g2_prepare == the oracle's restatement of ark-ec G2Prepared::from, all 68 x 3 Fp2 coefficients, limb for limb"""
+    from crypto_amd import pairing
+    k0 = O.rand_scalars(41, 1)[0]; d = O.rand_scalars(42, 1)[0]
+    qs = O.G2.gen_seq(k0, d, n, threads=8)
+    if n >= 7:
+        qs[3] = 0                                         # identity: infinity flag, all-zero block (arkworks: empty ell_coeffs)
+    pc = pairing.G2Prepared.from_affine(qs)
+    assert pc.coeffs.shape == (n, 68 * 36)
+    for i in range(n):
+        if n >= 7 and i == 3:
+            assert pc.infinity[i] == 1 and not pc.coeffs[i].any()
+        else:
+            assert pc.infinity[i] == 0 and (pc.coeffs[i] == O.g2_prepare(qs[i]).reshape(-1)).all(), i
+
+
+@pytest.mark.parametrize("n", [1, 3, 5, 200, 1024, 2500])
+def test_prepared_equals_unprepared_raw_output(n):
+    """multi_miller_loop on prepared operands == on the points themselves, raw Fp12 limbs (the reference asserts prepared == unprepared
+    pairings, utils/src/msm.rs:261-276), with coefficients from the device AND from the oracle (= what a Rust host would hold)"""
+    from crypto_amd import pairing
+    k0 = O.rand_scalars(51, 1)[0]; d = O.rand_scalars(52, 1)[0]
+    ps = O.G1.gen_seq(k0, d, n, threads=16); qs = O.G2.gen_seq(d, k0, n, threads=16)
+    skip = None
+    if n >= 5:
+        ps[1] = 0; qs[4] = 0
+        skip = np.zeros(n, np.uint8); skip[1] = 1; skip[4] = 1
+    ref = O.multi_miller_loop(ps, qs, skip, threads=32)
+    assert (ca.multi_miller_loop(ps, qs) == ref).all()
+    pc = pairing.G2Prepared.from_affine(qs)
+    assert (pairing.multi_miller_loop(ps, pc) == ref).all()
+    if n <= 200:
+        inf = np.array([0 if q.any() else 1 for q in qs], np.uint8)
+        oc = np.stack([O.g2_prepare(q).reshape(-1) if q.any() else np.zeros(68 * 36, np.uint64) for q in qs])
+        assert (pairing.multi_miller_loop(ps, pairing.G2Prepared(oc, inf)) == ref).all()
+    # mixed operands, the verifier's shape: [b.into(), prepared, prepared]
+    if n == 3:
+        assert (pairing.multi_miller_loop(ps, [qs[:1], pc[1], pc[2]]) == ref).all()
+    with pytest.raises(ca.DockGpuError):
+        pairing.multi_miller_loop(ps, pc[:n - 1] if n > 1 else pairing.G2Prepared(np.zeros((0, 68 * 36), np.uint64), np.zeros(0, np.uint8)))

@@ -126,3 +126,27 @@ def test_g1_scale_glv_edge_scalars():
     for i in (0, 3, 7, 15):
         e, einf = O.G1.to_affine(O.G1.mul(pts[i], O.int_to_limbs(lam + 12345, 4), inf=not pts[i].any()))
         assert bool(sinf[i]) == einf and (einf or (same[i] == e).all())
+
+
+@pytest.mark.parametrize("lazy", [False, True])
+def test_checker_with_prepared_g2_operands(lazy):
+    """the reference queues `impl Into<E::G2Prepared>` (randomized_pairing_check.rs:61-77,119-138; its tests pass prepared values,
+    :294-296): prepared, unprepared and mixed operands give the same verdict and the same `left`"""
+    from crypto_amd import pairing
+    r = 0xC0FFEE1234567
+    a, b = np.stack([g1(3), g1(5), g1(8)]), np.stack([g2(7), g2(9), g2(2)])
+    out = gt(a, b)
+    bp = pairing.G2Prepared.from_affine(b)
+    verdicts, lefts = [], []
+    for bb in (b, bp):
+        chk = ca.RandomizedPairingChecker(r, lazy)
+        chk.add_multiple_sources_and_target(a, bb, out)
+        chk.add_sources(g1(6), bb[:1] if bb is b else bb[0], g1(42), g2(1))        # e(6 G1, 7 G2) == e(42 G1, G2)
+        chk.add_sources_and_target(g1(11), pairing.G2Prepared.from_affine(g2(13)) if bb is bp else g2(13), gt(g1(11), g2(13)))
+        verdicts.append(chk.verify()); lefts.append(chk.left)
+    assert verdicts == [True, True]
+    if not lazy:
+        assert (lefts[0] == lefts[1]).all()
+    bad = ca.RandomizedPairingChecker(r, lazy)
+    bad.add_multiple_sources_and_target(a, pairing.G2Prepared.from_affine(np.stack([g2(7), g2(9), g2(3)])), out)
+    assert not bad.verify()

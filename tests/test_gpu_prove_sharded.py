@@ -57,3 +57,52 @@ def test_sharded_prove_two_ranks():
         p.join(timeout=60)
     assert sorted(r[0] for r in res) == [0, 1]
     assert all(r[1] and r[2] for r in res), res
+
+
+def _worker_msm_ml(rank, world, port, q):
+    """HIP partials through the collective: every rank runs the device pipeline on its chunk, all_gather + fold; compared with the
+    single-device call on the whole input and with the CPU oracle."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "oracle"), os.path.join(root, "tests")):
+        sys.path.insert(0, p)
+    import torch.distributed as dist
+    import oracle_c as O
+    import crypto_amd as ca
+    from crypto_amd import sharded, pairing
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ca.init(0)
+    ok = True
+    for curve, G, n in ((ca.G1, O.G1, 20001), (ca.G2, O.G2, 3001)):
+        k0 = O.rand_scalars(1, 1)[0]; d = O.rand_scalars(2, 1)[0]
+        bases = G.gen_seq(k0, d, n, threads=4)
+        sc = O.rand_scalars(3, n)
+        lo, hi = sharded.chunk_bounds(n, world, rank)
+        full = sharded.msm_sharded(curve, lambda: ca.msm_bigint(curve, bases[lo:hi], sc[lo:hi]))
+        single = ca.msm_bigint(curve, bases, sc)
+        ref = G.msm(bases, sc, threads=4)
+        ok = ok and bool((full == single).all()) and bool((G.to_affine(ref)[0] == full[:G.AW]).all())
+    npairs = 301
+    ps = O.G1.gen_seq(O.rand_scalars(4, 1)[0], O.rand_scalars(5, 1)[0], npairs, threads=4)
+    qs = O.G2.gen_seq(O.rand_scalars(6, 1)[0], O.rand_scalars(7, 1)[0], npairs, threads=4)
+    plo, phi = sharded.chunk_bounds(npairs, world, rank)
+    f = sharded.multi_miller_loop_sharded(lambda: pairing.multi_miller_loop(ps[plo:phi], qs[plo:phi]))
+    ok_ml = bool((f == pairing.multi_miller_loop(ps, qs)).all()) and bool((f == O.multi_miller_loop(ps, qs, threads=4)).all())
+    q.put((rank, ok, ok_ml))
+    dist.destroy_process_group()
+
+
+def test_hip_partials_through_the_collective_two_ranks():
+    assert torch.cuda.is_available()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_msm_ml, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(r[0] for r in res) == [0, 1]
+    assert all(r[1] and r[2] for r in res), res

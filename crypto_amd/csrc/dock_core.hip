@@ -3,14 +3,18 @@
 #include "dock_ctx.hpp"
 #include "host_field.hpp"
 #include "qap_launch.cuh"
+#include <thread>
 
 namespace dock {
-Ctx g;
+Shared gs;
+Ctx ctxs[MAX_CTX];
+thread_local int tl_ctx = -1;
 
 int choose_c(size_t n, bool g2) {
-    if (g.window_bits >= 7 && g.window_bits <= 22) return g.window_bits;
-    const char *e = getenv("DGPU_WINDOW_BITS");
-    if (e) { int v = atoi(e); if (v >= 7 && v <= 22) return v; }
+    { const int wb = gs.window_bits.load(); if (wb >= 7 && wb <= 22) return wb; }
+#ifdef DGPU_DEV
+    { const char *e = getenv("DGPU_WINDOW_BITS"); if (e) { int v = atoi(e); if (v >= 7 && v <= 22) return v; } }     // (any width gives the same point)
+#endif
     // Window width by size, from sweeps on MI355X (tests/perf/c_sweep.py, one call in flight).  c <= 16: digit codes stay 2 bytes and the
     // LDS counting sort sweeps W * RANGES * n * 2 B (at c = 20 the 4-byte codes and 32 ranges cost more than the saved additions).
     // From 2^17 terms on 16 wins clearly (2^18: 1.99 ms vs 2.50 at c = 14; 2^19: 2.81 vs 3.83): the bucket reduction is a latency-bound
@@ -27,9 +31,8 @@ int choose_c(size_t n, bool g2) {
     return bc;
 }
 int choose_chunk(size_t E, int min_chunk, size_t max_chunks) {
-    if (g.chunk) return g.chunk;
-    const char *e = getenv("DGPU_CHUNK");
-    if (e) { int v = atoi(e); if (v >= 16 && v <= 4096) return v; }
+    if (gs.chunk) return gs.chunk;
+    { const char *e = getenv("DGPU_CHUNK"); if (e) { int v = atoi(e); if (v >= 16 && v <= 4096) return v; } }   // tuning knob: any chunk length gives the same point (tests/test_gpu_msm.py sweeps it)
     // terms per lane.  A lane's chunk is one dependent chain of mixed additions (~12 us each), so short chunks win as long as the
     // partial slots they create stay cheap to fold: 16 terms up to ~300 k lanes (two rounds of the chip's 131 072 lanes at
     // 2 waves/SIMD), then doubling — measured at n = 2^12 .. 2^18: 16 beats 64 by 13-35 % (tools: DGPU_CHUNK sweep), at 2^20 64 and
@@ -54,36 +57,77 @@ extern "C" {
 
 int32_t dgpu_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; } return n; }
 
-int32_t dgpu_init(int32_t device) {
-    std::lock_guard<std::mutex> lk(g.mu);
-    if (g.ready) return g.device == device ? DGPU_OK : DGPU_E_BADARG;
+// bring up context `idx` on physical device `device` (gs.mu held)
+static int32_t init_ctx_locked(int idx, int device) {
+    Ctx &c = ctxs[idx];
+    if (c.ready) return c.device == device ? DGPU_OK : DGPU_E_BADARG;
+    HIPCHK(hipSetDevice(device));
+    for (int i = 0; i < N_SLOTS; i++) HIPCHK(hipStreamCreateWithFlags(&c.slots[i].stream, hipStreamNonBlocking));
+    c.device = device; c.ready = true;
+    if (gs.default_ctx < 0) gs.default_ctx = idx;
+    return DGPU_OK;
+}
+// logical context k runs on physical device physical[k].  The list may name a device more than once (two contexts, each with its own
+// streams and workspaces, on one GPU): that is how the sharded entry points are exercised on a one-GPU box.
+int32_t dgpu_init_device_list(const int32_t *physical, int32_t count) {
+    if (!physical || count <= 0 || count > MAX_CTX) return DGPU_E_BADARG;
+    std::lock_guard<std::mutex> lk(gs.mu);
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { (void)hipGetLastError(); return DGPU_E_NODEVICE; }
-    if (device < 0 || device >= n) return DGPU_E_NODEVICE;
-    HIPCHK(hipSetDevice(device));
-    for (int i = 0; i < N_SLOTS; i++) HIPCHK(hipStreamCreateWithFlags(&g.slots[i].stream, hipStreamNonBlocking));
-    g.device = device; g.ready = true;
+    for (int k = 0; k < count; k++) if (physical[k] < 0 || physical[k] >= n) return DGPU_E_NODEVICE;
+    for (int k = 0; k < count; k++) { int32_t rc = init_ctx_locked(k, physical[k]); if (rc) return rc; }
     return DGPU_OK;
+}
+int32_t dgpu_init_devices(uint32_t mask) {
+    int32_t phys[MAX_CTX]; int cnt = 0;
+    for (int d = 0; d < 32 && cnt < MAX_CTX; d++) if (mask & (1u << d)) phys[cnt++] = d;
+    return cnt ? dgpu_init_device_list(phys, cnt) : DGPU_E_BADARG;
+}
+// single-device form (one process per GPU): context 0 on `device`
+int32_t dgpu_init(int32_t device) { return dgpu_init_device_list(&device, 1); }
+int32_t dgpu_context_count(void) { int k = 0; for (int i = 0; i < MAX_CTX; i++) if (ctxs[i].ready) k++; return k; }
+// the calling thread's context for the entry points that take host pointers (thread-local, like hipSetDevice); handle-based calls
+// always run on the context that owns the handle
+int32_t dgpu_set_device(int32_t ctx) {
+    if (ctx < 0 || ctx >= MAX_CTX || !ctxs[ctx].ready) return DGPU_E_BADARG;
+    tl_ctx = ctx; return DGPU_OK;
 }
 
 int32_t dgpu_shutdown(void) {
-    std::lock_guard<std::mutex> lk(g.mu);
-    if (!g.ready) return DGPU_OK;
-    g.ready = false;
-    (void)hipSetDevice(g.device);
-    for (int i = 0; i < N_SLOTS; i++) {
-        std::lock_guard<std::mutex> sk(g.slots[i].mu);
-        (void)hipStreamSynchronize(g.slots[i].stream);
-        g.slots[i].release_all();
-        (void)hipStreamDestroy(g.slots[i].stream);
-        g.slots[i].stream = nullptr;
+    std::unique_lock<std::mutex> lk(gs.mu);
+    bool any = false;
+    for (int i = 0; i < MAX_CTX; i++) any = any || ctxs[i].ready;
+    if (!any) return DGPU_OK;
+    for (int i = 0; i < MAX_CTX; i++) {
+        Ctx &c = ctxs[i];
+        if (!c.ready) continue;
+        c.ready = false;
+        (void)hipSetDevice(c.device);
+        for (int k = 0; k < N_SLOTS; k++) {
+            std::lock_guard<std::mutex> sk(c.slots[k].mu);
+            (void)hipStreamSynchronize(c.slots[k].stream);
+            c.slots[k].release_all();
+            (void)hipStreamDestroy(c.slots[k].stream);
+            c.slots[k].stream = nullptr;
+        }
     }
-    for (auto &h : g.handles) if (h.second.kind != 4) (void)hipFree(h.second.p);   // (R1CS handles own several allocations: freed by dgpu_r1cs_free)
-    g.handles.clear();
-    for (auto &d : g.ntt_domains) { void *ps[] = {d.second.tw_f, d.second.tw_i, d.second.pw_f, d.second.pw_i, d.second.zinv}; for (void *p : ps) if (p) (void)hipFree(p); }
-    g.ntt_domains.clear();
-    g.prof_tab.clear();
-    g.device = -1;
+    for (auto &h : gs.handles) {
+        const Handle &hd = h.second;
+        if (hd.ctx >= 0 && hd.ctx < MAX_CTX && ctxs[hd.ctx].device >= 0) (void)hipSetDevice(ctxs[hd.ctx].device);
+        if (hd.kind == 4) free_r1cs_object(hd.p);                       // DevR1cs owns several allocations
+        else if (hd.kind >= 7) delete (ShardSet *)hd.p;                 // its per-device parts are table entries of their own
+        else (void)hipFree(hd.p);
+    }
+    gs.handles.clear();
+    for (int i = 0; i < MAX_CTX; i++) {
+        Ctx &c = ctxs[i];
+        if (c.device >= 0) (void)hipSetDevice(c.device);
+        for (auto &d : c.ntt_domains) { void *ps[] = {d.second.tw_f, d.second.tw_i, d.second.pw_f, d.second.pw_i, d.second.zinv}; for (void *p : ps) if (p) (void)hipFree(p); }
+        c.ntt_domains.clear();
+        c.device = -1;
+    }
+    gs.prof_tab.clear();
+    gs.default_ctx = -1;
     return DGPU_OK;
 }
 
@@ -100,37 +144,46 @@ const char *dgpu_strerror(int32_t code) {
         default: return "unknown error";
     }
 }
-int32_t dgpu_last_hip_error(void) { return g.last_hip.load(); }
-int32_t dgpu_set_min_gpu_n(size_t n) { g.min_gpu_n = n; return DGPU_OK; }
-int32_t dgpu_set_window_bits(int32_t c) { if (c != 0 && (c < 7 || c > 22)) return DGPU_E_BADARG; g.window_bits = c; return DGPU_OK; }
+int32_t dgpu_last_hip_error(void) { return gs.last_hip.load(); }
+int32_t dgpu_set_min_gpu_n(size_t n) { gs.min_gpu_n = n; return DGPU_OK; }
+size_t dgpu_get_min_gpu_n(void) { return gs.min_gpu_n.load(); }
+int32_t dgpu_set_window_bits(int32_t c) { if (c != 0 && (c < 7 || c > 22)) return DGPU_E_BADARG; gs.window_bits = c; return DGPU_OK; }
 
 
+// A free waits until no call uses the handle (HandleRef pins), then releases the memory outside the table lock: every entry point
+// synchronises its stream before it returns, so nothing on the device still reads the allocation.
+static void release_parts(const Handle &hd) {
+    if (hd.kind >= 7) {
+        ShardSet *ss = (ShardSet *)hd.p;
+        for (uint64_t sub : ss->sub) { Handle part; if (take_handle(sub, [](int) { return true; }, part)) release_parts(part); }
+        delete ss;
+        return;
+    }
+    CtxScope on_owner(hd.ctx);
+    if (cur().device >= 0) (void)hipSetDevice(cur().device);
+    (void)hipFree(hd.p);
+}
 static int32_t free_handle(uint64_t h, bool scalars) {
-    std::lock_guard<std::mutex> lk(g.mu);
-    auto it = g.handles.find(h);
-    if (it == g.handles.end() || it->second.kind == 4 || ((it->second.kind == 3) != scalars)) return DGPU_E_BADARG;
-    if (g.ready) { (void)hipSetDevice(g.device); (void)hipDeviceSynchronize(); }
-    (void)hipFree(it->second.p);
-    g.handles.erase(it);
+    Handle hd;
+    auto ok = [scalars](int k) { return k != 4 && ((k == 3 || k == 9) == scalars); };
+    if (!take_handle(h, ok, hd)) return DGPU_E_BADARG;
+    release_parts(hd);
     return DGPU_OK;
 }
 int32_t dgpu_bases_free(uint64_t h) { return free_handle(h, false); }
 int32_t dgpu_scalars_free(uint64_t h) { return free_handle(h, true); }
 int32_t dgpu_scalars_upload(const uint64_t *s, size_t n, int32_t mont, uint64_t *handle) {
     if (!handle || (n && !s)) return DGPU_E_BADARG;
-    if (!g.ready) return DGPU_E_NODEVICE;
+    if (!cur().ready) return DGPU_E_NODEVICE;
     void *p = nullptr;
     {
         SlotLock L; Slot &sl = *L.s;
-        HIPCHK(hipSetDevice(g.device));
+        HIPCHK(hipSetDevice(cur().device));
         if (hipMalloc(&p, std::max<size_t>(n, 1) * 32) != hipSuccess) { (void)hipGetLastError(); return DGPU_E_OOM; }
         int32_t rc = n ? upload_scalars(sl, s, n, mont != 0, (uint32_t *)p) : DGPU_OK;
         if (rc) { (void)hipFree(p); return rc; }
     }
-    std::lock_guard<std::mutex> lk(g.mu);
-    uint64_t h = g.next_handle++;
-    g.handles[h] = Handle{p, n, 3};
-    *handle = h;
+    *handle = register_handle(p, n, 3);
     return DGPU_OK;
 }
 
@@ -141,11 +194,11 @@ int32_t dgpu_scalars_upload_parts(const uint64_t *const *parts, const size_t *co
     if (!handle || (n_parts && (!parts || !counts))) return DGPU_E_BADARG;
     size_t n = 0;
     for (size_t k = 0; k < n_parts; k++) { if (counts[k] && !parts[k]) return DGPU_E_BADARG; n += counts[k]; }
-    if (!g.ready) return DGPU_E_NODEVICE;
+    if (!cur().ready) return DGPU_E_NODEVICE;
     void *p = nullptr;
     {
         SlotLock L; Slot &sl = *L.s;
-        HIPCHK(hipSetDevice(g.device));
+        HIPCHK(hipSetDevice(cur().device));
         if (hipMalloc(&p, std::max<size_t>(n, 1) * 32) != hipSuccess) { (void)hipGetLastError(); return DGPU_E_OOM; }
         size_t at = 0;
         hipError_t e = hipSuccess;
@@ -155,21 +208,43 @@ int32_t dgpu_scalars_upload_parts(const uint64_t *const *parts, const size_t *co
         }
         if (e == hipSuccess && mont && n) ntt::launch_fr_mont_to_canonical(sl.stream, (uint32_t *)p, n);
         if (e == hipSuccess) e = hipStreamSynchronize(sl.stream);
-        if (e != hipSuccess) { g.last_hip = (int32_t)e; (void)hipGetLastError(); (void)hipFree(p); return DGPU_E_HIP; }
+        if (e != hipSuccess) { gs.last_hip = (int32_t)e; (void)hipGetLastError(); (void)hipFree(p); return DGPU_E_HIP; }
     }
-    std::lock_guard<std::mutex> lk(g.mu);
-    uint64_t h = g.next_handle++;
-    g.handles[h] = Handle{p, n, 3};
-    *handle = h;
+    *handle = register_handle(p, n, 3);
     return DGPU_OK;
 }
 
-int32_t dgpu_prof_enable(int32_t on) { g.prof = on != 0; return DGPU_OK; }
-int32_t dgpu_prof_reset(void) { std::lock_guard<std::mutex> lk(g.mu); g.prof_tab.clear(); return DGPU_OK; }
+// scalars split the way the sharded bases handle `like` is split (scalar i sits next to base i); n <= the number of bases
+int32_t dgpu_scalars_upload_sharded(const uint64_t *sc, size_t n, int32_t mont, uint64_t like, uint64_t *handle) {
+    if (!handle || (n && !sc)) return DGPU_E_BADARG;
+    HandleRef hb(like);
+    if (!hb.ok || (hb.h.kind != 7 && hb.h.kind != 8) || n > hb.h.n) return DGPU_E_BADARG;
+    const ShardSet &sb = *(const ShardSet *)hb.h.p;
+    const size_t G = sb.sub.size();
+    ShardSet *ss = new ShardSet();
+    ss->n = n; ss->sub.assign(G, 0); ss->lo.resize(G + 1);
+    for (size_t k = 0; k <= G; k++) ss->lo[k] = std::min(sb.lo[k], n);
+    std::vector<int32_t> rcs(G, DGPU_OK);
+    std::vector<std::thread> th;
+    auto body = [&](size_t k) {
+        Handle part; if (!lookup_handle(sb.sub[k], part)) return (int32_t)DGPU_E_BADARG;
+        CtxScope here(part.ctx);
+        return dgpu_scalars_upload(sc + ss->lo[k] * 4, ss->lo[k + 1] - ss->lo[k], mont, &ss->sub[k]);
+    };
+    for (size_t k = 1; k < G; k++) th.emplace_back([&, k] { rcs[k] = body(k); });
+    rcs[0] = body(0);
+    for (auto &t : th) t.join();
+    for (int32_t rc : rcs) if (rc) { for (uint64_t h : ss->sub) if (h) (void)dgpu_scalars_free(h); delete ss; return rc; }
+    *handle = register_handle(ss, n, 9);
+    return DGPU_OK;
+}
+
+int32_t dgpu_prof_enable(int32_t on) { gs.prof = on != 0; return DGPU_OK; }
+int32_t dgpu_prof_reset(void) { std::lock_guard<std::mutex> lk(gs.mu); gs.prof_tab.clear(); return DGPU_OK; }
 int32_t dgpu_prof_read(const char **names, double *total_ms, uint64_t *calls, int32_t cap) {
-    std::lock_guard<std::mutex> lk(g.mu);
+    std::lock_guard<std::mutex> lk(gs.mu);
     int32_t k = 0;
-    for (auto &t : g.prof_tab) { if (k >= cap) break; names[k] = t.name; total_ms[k] = t.ms; calls[k] = t.calls; k++; }
+    for (auto &t : gs.prof_tab) { if (k >= cap) break; names[k] = t.name; total_ms[k] = t.ms; calls[k] = t.calls; k++; }
     return k;
 }
 

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -26,14 +27,18 @@ struct Buf {
     template <class T> T *as() { return reinterpret_cast<T *>(p); }
 };
 
-struct Handle { void *p; size_t n; int kind; };
-struct NttDomain { void *tw_f = nullptr, *tw_i = nullptr, *pw_f = nullptr, *pw_i = nullptr, *zinv = nullptr; };   // per log2(D), built once   // kind: 1 = G1 bases, 2 = G2 bases, 3 = scalars
+// kind: 1 = G1 bases, 2 = G2 bases, 3 = scalars, 4 = R1CS (DevR1cs*), 5 / 6 = G1 / G2 window table, 7 / 8 = G1 / G2 bases sharded over
+// several devices (ShardSet*), 9 = scalars sharded like a bases set (ShardSet*).  `ctx` = the device context that owns the allocation;
+// `inflight` = calls currently using it (a free waits for them: no use-after-free when dgpu_*_free races an MSM on the same handle).
+struct Handle { void *p; size_t n; int kind; int ctx; int inflight; };
+struct ShardSet { std::vector<uint64_t> sub; std::vector<size_t> lo; size_t n = 0; };   // sub[k] covers [lo[k], lo[k+1]) (lo has sub.size() + 1 entries)
+struct NttDomain { void *tw_f = nullptr, *tw_i = nullptr, *pw_f = nullptr, *pw_i = nullptr, *zinv = nullptr; };   // per log2(D), built once per device
 
 struct ProfEntry { const char *name; double ms; uint64_t calls; };
 
-struct Ctx;
-extern Ctx g;
-#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { dock::g.last_hip = (int32_t)e_; (void)hipGetLastError(); return DGPU_E_HIP; } } while (0)
+struct Shared;
+extern Shared gs;
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { dock::gs.last_hip = (int32_t)e_; (void)hipGetLastError(); return DGPU_E_HIP; } } while (0)
 
 // One in-flight call = one Slot: its own HIP stream and grow-only workspace.  Several host threads (rayon workers in the
 // reference, verifiable_encryption/src/tz_21/rdkgith.rs:140-147) can therefore have calls in flight at once; the
@@ -55,30 +60,45 @@ struct Slot {
 };
 constexpr int N_SLOTS = 4;
 
+constexpr int MAX_CTX = 16;
+// One Ctx per device the library was told to use (dgpu_init / dgpu_init_devices / dgpu_init_device_list): its streams, workspaces and NTT
+// tables.  A host thread works on the context dgpu_set_device chose for it (thread-local, like hipSetDevice; default = the first one
+// initialised); calls on a handle run on the context that owns the handle.
 struct Ctx {
-    std::mutex mu;                 // lifecycle, handle table, profile table
     std::atomic<bool> ready{false};
-    int device = -1;
-    std::atomic<int32_t> last_hip{0};
-    size_t min_gpu_n = 0;
-    int window_bits = 0;
-    int chunk = 0;
+    int device = -1;               // physical HIP device
     Slot slots[N_SLOTS];
     std::atomic<unsigned> rr{0};
+    std::map<int, NttDomain> ntt_domains;
+};
+// process-wide state shared by all contexts
+struct Shared {
+    std::mutex mu;                 // lifecycle, handle table, profile table, NTT-domain tables
+    std::condition_variable cv;    // signalled when a handle's in-flight count drops
     std::map<uint64_t, Handle> handles;
     uint64_t next_handle = 1;
-    std::map<int, NttDomain> ntt_domains;
+    std::atomic<int32_t> last_hip{0};
+    std::atomic<size_t> min_gpu_n{DGPU_DEFAULT_MIN_GPU_N};
+    std::atomic<int> window_bits{0};
+    int chunk = 0;
+    int default_ctx = -1;
     std::atomic<bool> prof{false};
     std::vector<ProfEntry> prof_tab;
 };
+extern Ctx ctxs[MAX_CTX];
+extern thread_local int tl_ctx;
+inline int cur_index() { int i = tl_ctx >= 0 ? tl_ctx : gs.default_ctx; return (i < 0 || i >= MAX_CTX) ? 0 : i; }
+inline Ctx &cur() { return ctxs[cur_index()]; }
+struct CtxScope { int prev; explicit CtxScope(int c) : prev(tl_ctx) { tl_ctx = c; } ~CtxScope() { tl_ctx = prev; } CtxScope(const CtxScope &) = delete; };
 
 // RAII: pick a free slot (round-robin try_lock), or wait for one
 struct SlotLock {
     Slot *s;
     SlotLock() {
-        unsigned start = g.rr.fetch_add(1);
-        for (int k = 0; k < N_SLOTS; k++) { Slot &c = g.slots[(start + k) % N_SLOTS]; if (c.mu.try_lock()) { s = &c; return; } }
-        s = &g.slots[start % N_SLOTS]; s->mu.lock();
+        Ctx &cx = cur();
+        unsigned start = cx.rr.fetch_add(1);
+        for (int k = 0; k < N_SLOTS; k++) { Slot &c = cx.slots[(start + k) % N_SLOTS]; if (c.mu.try_lock()) { s = &c; return; } }
+        s = &cx.slots[start % N_SLOTS]; s->mu.lock();
     }
     ~SlotLock() { s->mu.unlock(); }
     SlotLock(const SlotLock &) = delete;
@@ -90,13 +110,13 @@ inline hipEvent_t ev_get(Slot &sl) {
 }
 struct StageTimer {
     Slot &sl; const char *name; hipEvent_t a = nullptr, b = nullptr; bool on;
-    StageTimer(Slot &s, const char *n) : sl(s), name(n), on(g.prof.load()) { if (on) { a = ev_get(sl); b = ev_get(sl); if (a) (void)hipEventRecord(a, sl.stream); } }
+    StageTimer(Slot &s, const char *n) : sl(s), name(n), on(gs.prof.load()) { if (on) { a = ev_get(sl); b = ev_get(sl); if (a) (void)hipEventRecord(a, sl.stream); } }
     ~StageTimer() { if (on && a && b) { (void)hipEventRecord(b, sl.stream); sl.prof_pending.push_back({name, {a, b}}); } }
 };
 inline void prof_add_host(const char *name, double ms) {
-    std::lock_guard<std::mutex> lk(g.mu);
-    for (auto &t : g.prof_tab) if (t.name == name) { t.ms += ms; t.calls++; return; }
-    g.prof_tab.push_back({name, ms, 1});
+    std::lock_guard<std::mutex> lk(gs.mu);
+    for (auto &t : gs.prof_tab) if (t.name == name) { t.ms += ms; t.calls++; return; }
+    gs.prof_tab.push_back({name, ms, 1});
 }
 inline void prof_flush(Slot &sl) {
     for (auto &pe : sl.prof_pending) {
@@ -106,11 +126,54 @@ inline void prof_flush(Slot &sl) {
     }
     sl.prof_pending.clear();
 }
+// peek (no pin): for argument checks only
 inline bool lookup_handle(uint64_t h, Handle &out) {
-    std::lock_guard<std::mutex> lk(g.mu);
-    auto it = g.handles.find(h);
-    if (it == g.handles.end()) return false;
+    std::lock_guard<std::mutex> lk(gs.mu);
+    auto it = gs.handles.find(h);
+    if (it == gs.handles.end()) return false;
     out = it->second; return true;
+}
+// pin a handle for the duration of a call: dgpu_*_free of the same handle blocks until the call has returned
+struct HandleRef {
+    uint64_t id = 0; Handle h{}; bool ok = false;
+    HandleRef() {}
+    explicit HandleRef(uint64_t id_) { acquire(id_); }
+    bool acquire(uint64_t id_) {
+        std::lock_guard<std::mutex> lk(gs.mu);
+        auto it = gs.handles.find(id_);
+        if (it == gs.handles.end()) return false;
+        it->second.inflight++; h = it->second; id = id_; ok = true; return true;
+    }
+    ~HandleRef() {
+        if (!ok) return;
+        { std::lock_guard<std::mutex> lk(gs.mu); auto it = gs.handles.find(id); if (it != gs.handles.end()) it->second.inflight--; }
+        gs.cv.notify_all();
+    }
+    HandleRef(const HandleRef &) = delete;
+    HandleRef &operator=(const HandleRef &) = delete;
+};
+inline uint64_t register_handle(void *p, size_t n, int kind) {
+    std::lock_guard<std::mutex> lk(gs.mu);
+    uint64_t h = gs.next_handle++;
+    gs.handles[h] = Handle{p, n, kind, cur_index(), 0};
+    return h;
+}
+// remove handle `id` from the table once nothing uses it; kind_ok decides whether the caller may free this kind
+template <class Pred> inline bool take_handle(uint64_t id, Pred kind_ok, Handle &out) {
+    std::unique_lock<std::mutex> lk(gs.mu);
+    for (;;) {
+        auto it = gs.handles.find(id);
+        if (it == gs.handles.end() || !kind_ok(it->second.kind)) return false;
+        if (it->second.inflight == 0) { out = it->second; gs.handles.erase(it); return true; }
+        gs.cv.wait(lk);
+    }
+}
+void free_r1cs_object(void *p);      // dock_qap.hip
+// contexts a sharded call runs on: the first `ngpus` initialised ones (0 = all)
+inline std::vector<int> ready_contexts(int ngpus) {
+    std::vector<int> v;
+    for (int i = 0; i < MAX_CTX; i++) if (ctxs[i].ready) { v.push_back(i); if (ngpus > 0 && (int)v.size() == ngpus) break; }
+    return v;
 }
 
 int choose_c(size_t n, bool g2 = false);

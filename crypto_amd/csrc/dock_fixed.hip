@@ -28,7 +28,7 @@ template <class HF> void window_bases_host(const uint64_t *base_abi, uint64_t *o
 
 template <class C, class HF> int32_t table_build(const uint64_t *base, uint64_t *handle, int kind) {
     if (!base || !handle) return DGPU_E_BADARG;
-    if (!g.ready) return DGPU_E_NODEVICE;
+    if (!cur().ready) return DGPU_E_NODEVICE;
     constexpr size_t W64 = C::ABI_W;                     // u64 words per affine point (2 coordinates x ABI_W u32)
     uint64_t any = 0; for (size_t k = 0; k < W64; k++) any |= base[k];
     std::vector<uint64_t> wb(32 * W64, 0);
@@ -36,7 +36,7 @@ template <class C, class HF> int32_t table_build(const uint64_t *base, uint64_t 
     void *tab = nullptr;
     {
         SlotLock L; Slot &sl = *L.s;
-        HIPCHK(hipSetDevice(g.device));
+        HIPCHK(hipSetDevice(cur().device));
         int32_t rc;
         if ((rc = sl.prepped.ensure(32 * C::AFF_STRIDE * 4))) return rc;
         if (hipMalloc(&tab, (size_t)msm::FIXED_TABLE_ENTRIES * C::AFF_STRIDE * 4) != hipSuccess) { (void)hipGetLastError(); return DGPU_E_OOM; }
@@ -46,27 +46,26 @@ template <class C, class HF> int32_t table_build(const uint64_t *base, uint64_t 
             msm::launch_fb_table<C>(sl.stream, sl.prepped.as<uint32_t>(), (uint32_t *)tab);
         }
         if (rc == DGPU_OK && (hipGetLastError() != hipSuccess || hipStreamSynchronize(sl.stream) != hipSuccess)) rc = DGPU_E_HIP;
-        if (g.prof) prof_flush(sl);
+        if (gs.prof) prof_flush(sl);
         if (rc) { (void)hipFree(tab); return rc; }
     }
-    std::lock_guard<std::mutex> lk(g.mu);
-    uint64_t h = g.next_handle++;
-    g.handles[h] = Handle{tab, (size_t)msm::FIXED_TABLE_ENTRIES, kind};
-    *handle = h;
+    *handle = register_handle(tab, (size_t)msm::FIXED_TABLE_ENTRIES, kind);
     return DGPU_OK;
 }
 
 // out / out_inf: host arrays, or (bases_handle != nullptr) the products stay in HBM as an MSM bases handle
 template <class C> int32_t table_mul(uint64_t table, const uint64_t *scalars, size_t n, int32_t mont, uint64_t *out, uint8_t *out_inf, int kind, uint64_t *bases_handle = nullptr) {
     if ((n && !scalars) || (!bases_handle && n && (!out || !out_inf)) || n >= (1ull << 31)) return DGPU_E_BADARG;
-    if (!g.ready) return DGPU_E_NODEVICE;
-    Handle ht;
-    if (!lookup_handle(table, ht) || ht.kind != kind) return DGPU_E_BADARG;
+    if (!cur().ready) return DGPU_E_NODEVICE;
+    HandleRef tref(table);
+    if (!tref.ok || tref.h.kind != kind) return DGPU_E_BADARG;
+    const Handle &ht = tref.h;
+    CtxScope on_owner(ht.ctx);                           // the table's device
     if (n == 0 && !bases_handle) return DGPU_OK;
     void *keep = nullptr;
     {
     SlotLock L; Slot &sl = *L.s;
-    HIPCHK(hipSetDevice(g.device));
+    HIPCHK(hipSetDevice(cur().device));
     int32_t rc;
     const size_t pt_bytes = 2 * C::ABI_W * 4;
     if ((rc = sl.in_scalars.ensure(n * 32))) return rc;
@@ -84,14 +83,9 @@ template <class C> int32_t table_mul(uint64_t table, const uint64_t *scalars, si
         HIPCHK(hipMemcpyAsync(out_inf, dinf, n, hipMemcpyDeviceToHost, sl.stream));
     }
     if (hipStreamSynchronize(sl.stream) != hipSuccess) { (void)hipGetLastError(); if (keep) (void)hipFree(keep); return DGPU_E_HIP; }
-    if (g.prof) prof_flush(sl);
+    if (gs.prof) prof_flush(sl);
     }
-    if (bases_handle) {
-        std::lock_guard<std::mutex> lk(g.mu);
-        uint64_t h = g.next_handle++;
-        g.handles[h] = Handle{keep, n, kind - 4};      // 5 -> 1 (G1 bases), 6 -> 2 (G2 bases)
-        *bases_handle = h;
-    }
+    if (bases_handle) *bases_handle = register_handle(keep, n, kind - 4);      // 5 -> 1 (G1 bases), 6 -> 2 (G2 bases)
     return DGPU_OK;
 }
 
@@ -108,9 +102,9 @@ template <class C, class HF> int32_t fixed_base(const uint64_t *base, const uint
 template <class C> int32_t mul_add(const uint64_t *p, const uint8_t *p_inf, const uint64_t *scalars, size_t scalar_stride, const uint64_t *addend, const uint8_t *add_inf, size_t n, uint64_t *out, uint8_t *out_inf) {
     if ((n && (!p || !scalars || !out || !out_inf)) || (scalar_stride != 0 && scalar_stride != 4) || (add_inf && !addend) || n >= (1ull << 31)) return DGPU_E_BADARG;
     if (n == 0) return DGPU_OK;
-    if (!g.ready) return DGPU_E_NODEVICE;
+    if (!cur().ready) return DGPU_E_NODEVICE;
     SlotLock L; Slot &sl = *L.s;
-    HIPCHK(hipSetDevice(g.device));
+    HIPCHK(hipSetDevice(cur().device));
     int32_t rc;
     const size_t pt = 2 * C::ABI_W * 4, nsc = scalar_stride ? n : 1;
     // in_bases: [points | addends], prepped: [out | out_inf], in_inf: [p_inf | add_inf]
@@ -133,7 +127,7 @@ template <class C> int32_t mul_add(const uint64_t *p, const uint8_t *p_inf, cons
     HIPCHK(hipMemcpyAsync(out, sl.prepped.p, n * pt, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(out_inf, dout_inf, n, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
-    if (g.prof) prof_flush(sl);
+    if (gs.prof) prof_flush(sl);
     return DGPU_OK;
 }
 

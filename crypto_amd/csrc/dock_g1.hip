@@ -8,12 +8,16 @@ int32_t dgpu_msm_g1(const uint64_t *b, const uint8_t *inf, const uint64_t *s, si
 int32_t dgpu_msm_g1_mont(const uint64_t *b, const uint8_t *inf, const uint64_t *s, size_t n, uint64_t out[18]) { return msm_oneshot<G1, hostf::Fq>(b, inf, s, n, true, out); }
 int32_t dgpu_bases_upload_g1(const uint64_t *b, const uint8_t *inf, size_t n, uint64_t *h) { return bases_upload<G1>(b, inf, n, h, 1); }
 int32_t dgpu_msm_g1_handle(uint64_t b, size_t off, const uint64_t *s, size_t n, int32_t mont, uint64_t out[18]) { return msm_handle<G1, hostf::Fq>(b, off, s, n, mont, out, 1); }
+int32_t dgpu_msm_g1_sharded(const uint64_t *b, const uint8_t *inf, const uint64_t *s, size_t n, int32_t ngpus, uint64_t out[18]) { return msm_sharded_oneshot<G1, hostf::Fq>(b, inf, s, n, ngpus, false, out); }
+int32_t dgpu_bases_upload_g1_sharded(const uint64_t *b, const uint8_t *inf, size_t n, int32_t ngpus, uint64_t *h) { return bases_upload_sharded<G1>(b, inf, n, ngpus, h, 1); }
+int32_t dgpu_msm_g1_sharded_handle(uint64_t b, const uint64_t *s, size_t n, int32_t mont, uint64_t out[18]) { return msm_sharded_handle<G1, hostf::Fq>(b, s, n, mont, out, 1); }
+int32_t dgpu_msm_g1_sharded_resident(uint64_t b, uint64_t s, uint64_t out[18]) { return msm_sharded_resident<G1, hostf::Fq>(b, s, out, 1); }
 int32_t dgpu_msm_g1_resident(uint64_t b, size_t boff, uint64_t s, size_t soff, size_t n, uint64_t out[18]) { return msm_resident<G1, hostf::Fq>(b, boff, s, soff, n, out, 1); }
 
 int32_t dgpu_selftest_fp_mul(const uint64_t *a, const uint64_t *b, size_t n, uint64_t *out) {
-    if (!g.ready) return DGPU_E_NODEVICE;
+    if (!cur().ready) return DGPU_E_NODEVICE;
     SlotLock L; Slot &sl = *L.s;
-    HIPCHK(hipSetDevice(g.device));
+    HIPCHK(hipSetDevice(cur().device));
     void *da, *db, *dout;
     HIPCHK(hipMalloc(&da, n * 48 + 16)); HIPCHK(hipMalloc(&db, n * 48 + 16)); HIPCHK(hipMalloc(&dout, n * 48 + 16));
     HIPCHK(hipMemcpy(da, a, n * 48, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(db, b, n * 48, hipMemcpyHostToDevice));
@@ -24,9 +28,9 @@ int32_t dgpu_selftest_fp_mul(const uint64_t *a, const uint64_t *b, size_t n, uin
     return DGPU_OK;
 }
 int32_t dgpu_selftest_g1_sum(const uint64_t *pts, const uint8_t *neg, size_t n, uint64_t out[18]) {
-    if (!g.ready) return DGPU_E_NODEVICE;
+    if (!cur().ready) return DGPU_E_NODEVICE;
     SlotLock L; Slot &sl = *L.s;
-    HIPCHK(hipSetDevice(g.device));
+    HIPCHK(hipSetDevice(cur().device));
     void *dp, *dn, *dout, *dinf;
     HIPCHK(hipMalloc(&dp, n * 96 + 16)); HIPCHK(hipMalloc(&dn, n + 16)); HIPCHK(hipMalloc(&dout, 4 * 48)); HIPCHK(hipMalloc(&dinf, 16));
     HIPCHK(hipMemcpy(dp, pts, n * 96, hipMemcpyHostToDevice));

@@ -8,5 +8,9 @@ int32_t dgpu_msm_g2(const uint64_t *b, const uint8_t *inf, const uint64_t *s, si
 int32_t dgpu_msm_g2_mont(const uint64_t *b, const uint8_t *inf, const uint64_t *s, size_t n, uint64_t out[36]) { return msm_oneshot<G2, hostf::Fq2>(b, inf, s, n, true, out); }
 int32_t dgpu_bases_upload_g2(const uint64_t *b, const uint8_t *inf, size_t n, uint64_t *h) { return bases_upload<G2>(b, inf, n, h, 2); }
 int32_t dgpu_msm_g2_handle(uint64_t b, size_t off, const uint64_t *s, size_t n, int32_t mont, uint64_t out[36]) { return msm_handle<G2, hostf::Fq2>(b, off, s, n, mont, out, 2); }
+int32_t dgpu_msm_g2_sharded(const uint64_t *b, const uint8_t *inf, const uint64_t *s, size_t n, int32_t ngpus, uint64_t out[36]) { return msm_sharded_oneshot<G2, hostf::Fq2>(b, inf, s, n, ngpus, false, out); }
+int32_t dgpu_bases_upload_g2_sharded(const uint64_t *b, const uint8_t *inf, size_t n, int32_t ngpus, uint64_t *h) { return bases_upload_sharded<G2>(b, inf, n, ngpus, h, 2); }
+int32_t dgpu_msm_g2_sharded_handle(uint64_t b, const uint64_t *s, size_t n, int32_t mont, uint64_t out[36]) { return msm_sharded_handle<G2, hostf::Fq2>(b, s, n, mont, out, 2); }
+int32_t dgpu_msm_g2_sharded_resident(uint64_t b, uint64_t s, uint64_t out[36]) { return msm_sharded_resident<G2, hostf::Fq2>(b, s, out, 2); }
 int32_t dgpu_msm_g2_resident(uint64_t b, size_t boff, uint64_t s, size_t soff, size_t n, uint64_t out[36]) { return msm_resident<G2, hostf::Fq2>(b, boff, s, soff, n, out, 2); }
 }  // extern "C"

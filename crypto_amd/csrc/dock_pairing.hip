@@ -354,7 +354,7 @@ static int32_t ml_finish(Slot &sl, size_t n, uint64_t *out) {
     std::vector<hostf::Fq12> L(N_LINES);
     HIPCHK(hipMemcpyAsync(L.data(), sl.ml_out.p, (size_t)N_LINES * 576, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
-    if (g.prof) prof_flush(sl);
+    if (gs.prof) prof_flush(sl);
     hostf::Fq12 f = hostf::Fq12::one(); int idx = 0;
     for (int b = 62; b >= 0; b--) { f = f.sqr() * L[idx++]; if ((hostf::BLS_X_ABS >> b) & 1) f = f * L[idx++]; }
     f = f.conj();      // x < 0
@@ -366,9 +366,9 @@ int32_t dgpu_multi_miller_loop(const uint64_t *p, const uint64_t *q, const uint8
     if (!out || (n && (!p || !q))) return DGPU_E_BADARG;
     if (n == 0) { hostf::Fq12 one = hostf::Fq12::one(); memcpy(out, &one, sizeof one); return DGPU_OK; }
     if (n >= (1ull << 24)) return DGPU_E_BADARG;
-    if (!g.ready) return DGPU_E_NODEVICE;
+    if (!cur().ready) return DGPU_E_NODEVICE;
     SlotLock slot_lock; Slot &sl = *slot_lock.s;
-    HIPCHK(hipSetDevice(g.device));
+    HIPCHK(hipSetDevice(cur().device));
     int32_t rc;
     if ((rc = sl.in_bases.ensure(n * 96))) return rc;
     if ((rc = sl.in_scalars.ensure(n * 192))) return rc;
@@ -399,9 +399,9 @@ int32_t dgpu_g2_prepare(const uint64_t *q, const uint8_t *is_inf, size_t n, uint
     if (n && (!q || !out_coeffs || !out_inf)) return DGPU_E_BADARG;
     if (n == 0) return DGPU_OK;
     if (n > DGPU_MAX_PREPARED) return DGPU_E_BADARG;
-    if (!g.ready) return DGPU_E_NODEVICE;
+    if (!cur().ready) return DGPU_E_NODEVICE;
     SlotLock slot_lock; Slot &sl = *slot_lock.s;
-    HIPCHK(hipSetDevice(g.device));
+    HIPCHK(hipSetDevice(cur().device));
     int32_t rc;
     const size_t cbytes = n * (size_t)DGPU_G2_PREPARED_WORDS * 8;
     if ((rc = sl.in_scalars.ensure(n * 192))) return rc;
@@ -417,7 +417,7 @@ int32_t dgpu_g2_prepare(const uint64_t *q, const uint8_t *is_inf, size_t n, uint
     HIPCHK(hipMemcpyAsync(out_coeffs, sl.ml_coeffs.p, cbytes, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(out_inf, sl.in_inf.as<uint8_t>() + n, n, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
-    if (g.prof) prof_flush(sl);
+    if (gs.prof) prof_flush(sl);
     return DGPU_OK;
 }
 
@@ -426,9 +426,9 @@ int32_t dgpu_multi_miller_loop_prepared(const uint64_t *p, const uint64_t *coeff
     if (!out || (n && (!p || !coeffs))) return DGPU_E_BADARG;
     if (n == 0) { hostf::Fq12 one = hostf::Fq12::one(); memcpy(out, &one, sizeof one); return DGPU_OK; }
     if (n > DGPU_MAX_PREPARED) return DGPU_E_BADARG;
-    if (!g.ready) return DGPU_E_NODEVICE;
+    if (!cur().ready) return DGPU_E_NODEVICE;
     SlotLock slot_lock; Slot &sl = *slot_lock.s;
-    HIPCHK(hipSetDevice(g.device));
+    HIPCHK(hipSetDevice(cur().device));
     int32_t rc;
     const size_t cbytes = n * (size_t)DGPU_G2_PREPARED_WORDS * 8;
     if ((rc = sl.in_bases.ensure(n * 96))) return rc;
@@ -448,9 +448,9 @@ int32_t dgpu_multi_miller_loop_prepared(const uint64_t *p, const uint64_t *coeff
 int32_t dgpu_g1_scale_batch(const uint64_t *p, const uint8_t *is_inf, const uint64_t *scalars, size_t scalar_stride, const uint8_t *negate, size_t n, uint64_t *out, uint8_t *out_inf) {
     if ((n && (!p || !scalars || !out || !out_inf)) || (scalar_stride != 0 && scalar_stride != 4)) return DGPU_E_BADARG;
     if (n == 0) return DGPU_OK;
-    if (!g.ready) return DGPU_E_NODEVICE;
+    if (!cur().ready) return DGPU_E_NODEVICE;
     SlotLock slot_lock; Slot &sl = *slot_lock.s;
-    HIPCHK(hipSetDevice(g.device));
+    HIPCHK(hipSetDevice(cur().device));
     int32_t rc;
     const size_t nsc = scalar_stride ? n : 1;
     if ((rc = sl.in_bases.ensure(n * 96))) return rc;
@@ -473,7 +473,7 @@ int32_t dgpu_g1_scale_batch(const uint64_t *p, const uint8_t *is_inf, const uint
     HIPCHK(hipMemcpyAsync(out, sl.prepped.p, n * 96, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(out_inf, dout_inf, n, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
-    if (g.prof) prof_flush(sl);
+    if (gs.prof) prof_flush(sl);
     return DGPU_OK;
 }
 // host self-test hook: the GLV split the scaling kernel is fed with (k mod r = k1 + k2 lambda, both < 2^128)

@@ -14,9 +14,9 @@ struct Csr { const uint64_t *rowptr; const uint32_t *cols; const uint64_t *vals;
 
 int32_t get_domain(Slot &sl, int logn, NttDomain &out) {
     {
-        std::lock_guard<std::mutex> lk(g.mu);
-        auto it = g.ntt_domains.find(logn);
-        if (it != g.ntt_domains.end()) { out = it->second; return DGPU_OK; }
+        std::lock_guard<std::mutex> lk(gs.mu);
+        auto it = cur().ntt_domains.find(logn);
+        if (it != cur().ntt_domains.end()) { out = it->second; return DGPU_OK; }
     }
     const size_t D = (size_t)1 << logn, H = D >> 1 ? D >> 1 : 1;
     FrH w = FrH::root_of_unity(logn), wi = w.inv(), gk = FrH::from_u64(7), gi = gk.inv(), dinv = FrH::from_u64(D).inv(), one = FrH::from_u64(1);
@@ -41,8 +41,8 @@ int32_t get_domain(Slot &sl, int logn, NttDomain &out) {
     HIPCHK(hipMemcpyAsync(d.zinv, consts[6], 32, hipMemcpyHostToDevice, s));
     HIPCHK(hipStreamSynchronize(s));
     (void)hipFree(dc);
-    std::lock_guard<std::mutex> lk(g.mu);
-    auto ins = g.ntt_domains.emplace(logn, d);
+    std::lock_guard<std::mutex> lk(gs.mu);
+    auto ins = cur().ntt_domains.emplace(logn, d);
     if (!ins.second) { void *ps[] = {d.tw_f, d.tw_i, d.pw_f, d.pw_i, d.zinv}; for (void *p : ps) (void)hipFree(p); }   // another thread won the race
     out = ins.first->second;
     return DGPU_OK;
@@ -107,19 +107,19 @@ int32_t witness_map_device(Slot &sl, const DevR1cs &r, const uint64_t *assignmen
     }
     HIPCHK(hipGetLastError());
     if (out_len) *out_len = D;
+    void *kept = nullptr;
     if (out_handle) {
         void *p = nullptr;
         if (hipMalloc(&p, D * 32) != hipSuccess) { (void)hipGetLastError(); return DGPU_E_OOM; }
-        HIPCHK(hipMemcpyAsync(p, hw.p, D * 32, hipMemcpyDeviceToDevice, s));
-        HIPCHK(hipStreamSynchronize(s));
-        std::lock_guard<std::mutex> lk(g.mu);
-        uint64_t h = g.next_handle++;
-        g.handles[h] = Handle{p, D, 3};
-        *out_handle = h;
+        if (hipMemcpyAsync(p, hw.p, D * 32, hipMemcpyDeviceToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(p); return DGPU_E_HIP; }
+        kept = p;
     }
-    if (out_h) { HIPCHK(hipMemcpyAsync(out_h, hw.p, D * 32, hipMemcpyDeviceToHost, s)); }
-    HIPCHK(hipStreamSynchronize(s));
-    if (g.prof) prof_flush(sl);
+    if (out_h) {
+        if (hipMemcpyAsync(out_h, hw.p, D * 32, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { (void)hipGetLastError(); if (kept) (void)hipFree(kept); return DGPU_E_HIP; }
+    }
+    if (hipStreamSynchronize(s) != hipSuccess) { (void)hipGetLastError(); if (kept) (void)hipFree(kept); return DGPU_E_HIP; }
+    if (out_handle) *out_handle = register_handle(kept, D, 3);     // registered last: no handle is left behind by a failing call
+    if (gs.prof) prof_flush(sl);
     return DGPU_OK;
 }
 
@@ -132,52 +132,55 @@ int32_t build_r1cs(Slot &sl, const Csr mats[3], size_t num_vars, size_t num_inpu
 }
 
 }  // namespace
+namespace dock { void free_r1cs_object(void *p) { free_r1cs((DevR1cs *)p); } }
 
 extern "C" {
 
-static bool check_csr(const uint64_t *rp, const uint32_t *cl, const uint64_t *vl, size_t nnz) { return rp && (!nnz || (cl && vl)); }
+// a malformed matrix must not reach the device (k_csr_eval indexes cols / vals / z through it): row pointers start at 0, never
+// decrease and end at nnz; every column names a variable.  O(rows + nnz) on the host, once per upload.
+static bool check_csr(const uint64_t *rp, const uint32_t *cl, const uint64_t *vl, size_t nnz, size_t rows, size_t num_vars) {
+    if (!rp || (nnz && (!cl || !vl))) return false;
+    if (rp[0] != 0 || rp[rows] != nnz) return false;
+    for (size_t i = 0; i < rows; i++) if (rp[i + 1] < rp[i]) return false;
+    for (size_t k = 0; k < nnz; k++) if (cl[k] >= num_vars) return false;
+    return true;
+}
 
 int32_t dgpu_r1cs_upload(const uint64_t *a_rowptr, const uint32_t *a_cols, const uint64_t *a_vals, size_t a_nnz,
                          const uint64_t *b_rowptr, const uint32_t *b_cols, const uint64_t *b_vals, size_t b_nnz,
                          const uint64_t *c_rowptr, const uint32_t *c_cols, const uint64_t *c_vals, size_t c_nnz,
                          size_t num_vars, size_t num_inputs, size_t num_constraints, int32_t montgomery, uint64_t *handle) {
-    if (!handle || num_inputs > num_vars || !check_csr(a_rowptr, a_cols, a_vals, a_nnz) || !check_csr(b_rowptr, b_cols, b_vals, b_nnz) || !check_csr(c_rowptr, c_cols, c_vals, c_nnz)) return DGPU_E_BADARG;
-    if (!g.ready) return DGPU_E_NODEVICE;
+    if (!handle || num_inputs > num_vars || !check_csr(a_rowptr, a_cols, a_vals, a_nnz, num_constraints, num_vars) || !check_csr(b_rowptr, b_cols, b_vals, b_nnz, num_constraints, num_vars) || !check_csr(c_rowptr, c_cols, c_vals, c_nnz, num_constraints, num_vars)) return DGPU_E_BADARG;
+    if (!cur().ready) return DGPU_E_NODEVICE;
     DevR1cs *r = nullptr;
     {
         SlotLock slot_lock; Slot &sl = *slot_lock.s;
-        HIPCHK(hipSetDevice(g.device));
+        HIPCHK(hipSetDevice(cur().device));
         Csr mats[3] = {{a_rowptr, a_cols, a_vals, a_nnz}, {b_rowptr, b_cols, b_vals, b_nnz}, {c_rowptr, c_cols, c_vals, c_nnz}};
         int32_t rc = build_r1cs(sl, mats, num_vars, num_inputs, num_constraints, montgomery, &r);
         if (rc) return rc;
     }
-    std::lock_guard<std::mutex> lk(g.mu);
-    uint64_t h = g.next_handle++;
-    g.handles[h] = Handle{r, num_constraints, 4};
-    *handle = h;
+    *handle = register_handle(r, num_constraints, 4);
     return DGPU_OK;
 }
 int32_t dgpu_r1cs_free(uint64_t handle) {
     Handle hd;
-    {
-        std::lock_guard<std::mutex> lk(g.mu);
-        auto it = g.handles.find(handle);
-        if (it == g.handles.end() || it->second.kind != 4) return DGPU_E_BADARG;
-        hd = it->second; g.handles.erase(it);
-    }
-    if (g.ready) { (void)hipSetDevice(g.device); (void)hipDeviceSynchronize(); }
+    if (!take_handle(handle, [](int k) { return k == 4; }, hd)) return DGPU_E_BADARG;     // waits for calls still using the circuit
+    CtxScope on_owner(hd.ctx);
+    if (cur().ready) (void)hipSetDevice(cur().device);
     free_r1cs((DevR1cs *)hd.p);
     return DGPU_OK;
 }
 int32_t dgpu_witness_map_r1cs(uint64_t r1cs, const uint64_t *assignment, size_t num_vars, int32_t montgomery, uint64_t *out_h, uint64_t *out_handle, size_t *out_len) {
     if (!assignment || (!out_h && !out_handle)) return DGPU_E_BADARG;
-    if (!g.ready) return DGPU_E_NODEVICE;
-    Handle hd;
-    if (!lookup_handle(r1cs, hd) || hd.kind != 4) return DGPU_E_BADARG;
-    const DevR1cs *r = (const DevR1cs *)hd.p;
+    if (!cur().ready) return DGPU_E_NODEVICE;
+    HandleRef href(r1cs);
+    if (!href.ok || href.h.kind != 4) return DGPU_E_BADARG;
+    const DevR1cs *r = (const DevR1cs *)href.h.p;
     if (num_vars != r->num_vars) return DGPU_E_BADARG;
+    CtxScope on_owner(href.h.ctx);
     SlotLock slot_lock; Slot &sl = *slot_lock.s;
-    HIPCHK(hipSetDevice(g.device));
+    HIPCHK(hipSetDevice(cur().device));
     return witness_map_device(sl, *r, assignment, montgomery, out_h, out_handle, out_len);
 }
 int32_t dgpu_witness_map(const uint64_t *a_rowptr, const uint32_t *a_cols, const uint64_t *a_vals, size_t a_nnz,
@@ -186,10 +189,10 @@ int32_t dgpu_witness_map(const uint64_t *a_rowptr, const uint32_t *a_cols, const
                          const uint64_t *assignment, size_t num_vars, size_t num_inputs, size_t num_constraints, int32_t montgomery,
                          uint64_t *out_h, uint64_t *out_handle, size_t *out_len) {
     if (!assignment || num_inputs > num_vars || (!out_h && !out_handle)) return DGPU_E_BADARG;
-    if (!check_csr(a_rowptr, a_cols, a_vals, a_nnz) || !check_csr(b_rowptr, b_cols, b_vals, b_nnz) || !check_csr(c_rowptr, c_cols, c_vals, c_nnz)) return DGPU_E_BADARG;
-    if (!g.ready) return DGPU_E_NODEVICE;
+    if (!check_csr(a_rowptr, a_cols, a_vals, a_nnz, num_constraints, num_vars) || !check_csr(b_rowptr, b_cols, b_vals, b_nnz, num_constraints, num_vars) || !check_csr(c_rowptr, c_cols, c_vals, c_nnz, num_constraints, num_vars)) return DGPU_E_BADARG;
+    if (!cur().ready) return DGPU_E_NODEVICE;
     SlotLock slot_lock; Slot &sl = *slot_lock.s;
-    HIPCHK(hipSetDevice(g.device));
+    HIPCHK(hipSetDevice(cur().device));
     Csr mats[3] = {{a_rowptr, a_cols, a_vals, a_nnz}, {b_rowptr, b_cols, b_vals, b_nnz}, {c_rowptr, c_cols, c_vals, c_nnz}};
     DevR1cs *r = nullptr;
     int32_t rc = build_r1cs(sl, mats, num_vars, num_inputs, num_constraints, montgomery, &r);

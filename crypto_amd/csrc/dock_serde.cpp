@@ -6,7 +6,10 @@
 // the reference's keys and proofs (legogroth16/src/data_structures.rs:7-186, utils/src/serde_utils.rs:8-33), so a driver
 // can load a proving key written by the Rust side and hand the limbs to dgpu_bases_upload_*.
 // Decompression needs a square root: p = 3 (mod 4) so sqrt(a) = a^((p+1)/4) in Fq, and the complex method in Fq2.
-// No subgroup check is done here (arkworks' `Validate::Yes` does one; callers that need it run it on their side).
+// Validation follows `deserialize_compressed` / `deserialize_uncompressed` (Validate::Yes): the point must be on the curve AND in the
+// prime-order subgroup ([r]P = O, checked here by a plain double-and-add on the host — same verdict as arkworks' endomorphism test);
+// mode bit 1 (DGPU_SERDE_NO_VALIDATE) is Validate::No and skips the subgroup test only.  An infinity encoding must be canonical: no
+// other flag and no payload bit set (the Zcash / IETF rule; arkworks 0.4.0 ignores the payload there — stricter on malformed input).
 #include <string.h>
 #include "../../include/dock_gpu.h"
 #include "host_field.hpp"
@@ -63,6 +66,21 @@ bool fq2_sqrt(Fq2 &r, const Fq2 &a) {
 }
 
 enum { FLAG_COMPRESSED = 0x80, FLAG_INF = 0x40, FLAG_LARGEST = 0x20 };
+
+// [r]P == O ?   r = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
+template <class F> bool in_prime_subgroup(const F &x, const F &y) {
+    static const uint64_t RM[4] = {0xffffffff00000001ULL, 0x53bda402fffe5bfeULL, 0x3339d80809a1d805ULL, 0x73eda753299d7d48ULL};
+    hostf::HXyzz<F> P; P.x = x; P.y = y; P.zz = F::one(); P.zzz = F::one(); P.inf = false;
+    hostf::HXyzz<F> acc = hostf::HXyzz<F>::identity();
+    for (int i = 254; i >= 0; i--) { acc.dbl_in_place(); if ((RM[i / 64] >> (i % 64)) & 1) acc.add_in_place(P); }
+    return acc.inf;
+}
+bool canonical_infinity(const uint8_t *b, size_t sz, uint8_t flags) {
+    if (flags & FLAG_LARGEST) return false;
+    if (b[0] & 0x1f) return false;
+    for (size_t k = 1; k < sz; k++) if (b[k]) return false;
+    return true;
+}
 }  // namespace
 
 extern "C" {
@@ -81,15 +99,17 @@ int32_t dgpu_g1_serialize(const uint64_t *xy, const uint8_t *is_inf, size_t n, i
     }
     return DGPU_OK;
 }
-int32_t dgpu_g1_deserialize(const uint8_t *in, size_t n, int32_t compressed, uint64_t *xy, uint8_t *is_inf) {
+int32_t dgpu_g1_deserialize(const uint8_t *in, size_t n, int32_t mode, uint64_t *xy, uint8_t *is_inf) {
     if (n && (!in || !xy || !is_inf)) return DGPU_E_BADARG;
+    const int compressed = mode & 1; const bool validate = !(mode & DGPU_SERDE_NO_VALIDATE);
     const size_t sz = compressed ? 48 : 96;
     for (size_t i = 0; i < n; i++) {
         const uint8_t *b = in + i * sz; uint8_t flags = b[0] & 0xe0;
         if (((flags & FLAG_COMPRESSED) != 0) != (compressed != 0)) return DGPU_E_BADARG;
         uint8_t tmp[48]; memcpy(tmp, b, 48); tmp[0] &= 0x1f;
         memset(xy + 12 * i, 0, 96); is_inf[i] = 0;
-        if (flags & FLAG_INF) { is_inf[i] = 1; continue; }
+        if (flags & FLAG_INF) { if (!canonical_infinity(b, sz, flags)) return DGPU_E_BADARG; is_inf[i] = 1; continue; }
+        if (!compressed && (flags & FLAG_LARGEST)) return DGPU_E_BADARG;
         uint64_t c[6]; be48_to_limbs(c, tmp); if (!lt_p(c)) return DGPU_E_BADARG;
         Fq x = from_canonical(c), y;
         if (compressed) {
@@ -100,6 +120,7 @@ int32_t dgpu_g1_deserialize(const uint8_t *in, size_t n, int32_t compressed, uin
             y = from_canonical(c);
             if (!(y.sqr() == x.sqr() * x + fq_four())) return DGPU_E_BADARG;
         }
+        if (validate && !in_prime_subgroup<Fq>(x, y)) return DGPU_E_BADARG;                // Validate::Yes: on the curve but outside G1
         memcpy(xy + 12 * i, x.l, 48); memcpy(xy + 12 * i + 6, y.l, 48);
     }
     return DGPU_OK;
@@ -119,8 +140,9 @@ int32_t dgpu_g2_serialize(const uint64_t *xy, const uint8_t *is_inf, size_t n, i
     }
     return DGPU_OK;
 }
-int32_t dgpu_g2_deserialize(const uint8_t *in, size_t n, int32_t compressed, uint64_t *xy, uint8_t *is_inf) {
+int32_t dgpu_g2_deserialize(const uint8_t *in, size_t n, int32_t mode, uint64_t *xy, uint8_t *is_inf) {
     if (n && (!in || !xy || !is_inf)) return DGPU_E_BADARG;
+    const int compressed = mode & 1; const bool validate = !(mode & DGPU_SERDE_NO_VALIDATE);
     const size_t sz = compressed ? 96 : 192;
     Fq four = fq_four(); Fq2 b2 = {four, four};       // 4 (1 + u)
     for (size_t i = 0; i < n; i++) {
@@ -128,7 +150,8 @@ int32_t dgpu_g2_deserialize(const uint8_t *in, size_t n, int32_t compressed, uin
         if (((flags & FLAG_COMPRESSED) != 0) != (compressed != 0)) return DGPU_E_BADARG;
         uint8_t tmp[48]; memcpy(tmp, b, 48); tmp[0] &= 0x1f;
         memset(xy + 24 * i, 0, 192); is_inf[i] = 0;
-        if (flags & FLAG_INF) { is_inf[i] = 1; continue; }
+        if (flags & FLAG_INF) { if (!canonical_infinity(b, sz, flags)) return DGPU_E_BADARG; is_inf[i] = 1; continue; }
+        if (!compressed && (flags & FLAG_LARGEST)) return DGPU_E_BADARG;
         uint64_t c[6]; Fq2 x, y;
         be48_to_limbs(c, tmp); if (!lt_p(c)) return DGPU_E_BADARG; x.c1 = from_canonical(c);
         be48_to_limbs(c, b + 48); if (!lt_p(c)) return DGPU_E_BADARG; x.c0 = from_canonical(c);
@@ -141,6 +164,7 @@ int32_t dgpu_g2_deserialize(const uint8_t *in, size_t n, int32_t compressed, uin
             be48_to_limbs(c, b + 144); if (!lt_p(c)) return DGPU_E_BADARG; y.c0 = from_canonical(c);
             if (!(y.sqr() == rhs)) return DGPU_E_BADARG;
         }
+        if (validate && !in_prime_subgroup<Fq2>(x, y)) return DGPU_E_BADARG;               // Validate::Yes: on the twist but outside G2
         memcpy(xy + 24 * i, &x, 96); memcpy(xy + 24 * i + 12, &y, 96);
     }
     return DGPU_OK;

@@ -13,9 +13,13 @@ template <class C> void launch_fb_mul(hipStream_t s, const uint32_t *table, cons
 }
 template <class C> void launch_mul_add(hipStream_t s, const uint32_t *p_abi, const uint8_t *p_inf, const uint32_t *scalars, int scalar_stride, const uint32_t *add_abi, const uint8_t *add_inf,
                                        size_t n, uint32_t *out_abi, uint8_t *out_inf) {
-    static const bool one_lane = getenv("DGPU_MULADD_ONE_LANE") != nullptr;      // development switch: one-lane Fp2 kernel for G2
+#ifdef DGPU_DEV
+    static const bool one_lane = getenv("DGPU_MULADD_ONE_LANE") != nullptr;      // development switches (compile with -DDGPU_DEV): one-lane kernels,
+    static const bool two_lanes = getenv("DGPU_MULADD_G2_PAIR") != nullptr;       // one lane pair per G2 point
+#else
+    constexpr bool one_lane = false, two_lanes = false;
+#endif
     if constexpr (C::NFP == 2) {
-        static const bool two_lanes = getenv("DGPU_MULADD_G2_PAIR") != nullptr;   // development switch: one lane pair per G2 point
         if (!one_lane && two_lanes) { hipLaunchKernelGGL(k_mul_add_g2_pair, dim3((unsigned)((2 * n + 63) / 64)), dim3(64), 0, s, p_abi, p_inf, scalars, scalar_stride, add_abi, add_inf, n, out_abi, out_inf); return; }
         if (!one_lane) { hipLaunchKernelGGL((k_mul_add_g2_quad<C>), dim3((unsigned)((4 * n + 63) / 64)), dim3(64), 0, s, p_abi, p_inf, scalars, scalar_stride, add_abi, add_inf, n, out_abi, out_inf); return; }
     }

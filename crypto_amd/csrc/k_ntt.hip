@@ -15,7 +15,11 @@ void launch_csr_eval(hipStream_t s, const uint64_t *rowptr, const uint32_t *cols
 }
 void launch_ntt(hipStream_t s, uint32_t *buf, int logn, const uint32_t *tw, int dif) {
     const size_t D = (size_t)1 << logn, H = D >> 1;
-    static const bool unfused = getenv("DGPU_NTT_UNFUSED") != nullptr;
+#ifdef DGPU_DEV
+    static const bool unfused = getenv("DGPU_NTT_UNFUSED") != nullptr;     // development switch (compile with -DDGPU_DEV)
+#else
+    constexpr bool unfused = false;
+#endif
     if (logn < FUSE_TILE_LOG || unfused) {               // tiny domains: one pass per stage
         for (int st = 0; st < logn; st++) hipLaunchKernelGGL(k_ntt_stage, grid_for(H), dim3(256), 0, s, buf, logn, st, tw, dif);
         return;

@@ -2,6 +2,7 @@
 // dock_g1.hip and dock_g2.hip so the two curves compile in parallel.
 #pragma once
 #include <chrono>
+#include <thread>
 #include "dock_ctx.hpp"
 #include "host_field.hpp"
 #include "msm_launch.cuh"
@@ -114,7 +115,11 @@ int32_t msm_device(Slot &sl, const uint32_t *d_bases, const uint32_t *d_scalars,
     }
     {
         StageTimer st(sl, "msm.accumulate");
-        static const uint32_t dbg_mask = getenv("DGPU_DBG_NOGATHER") ? 1023u : 0xffffffffu;   // experiment: L2-resident points
+#ifdef DGPU_DEV
+        static const uint32_t dbg_mask = getenv("DGPU_DBG_NOGATHER") ? 1023u : 0xffffffffu;   // development experiment (wrong results by design): L2-resident points
+#else
+        constexpr uint32_t dbg_mask = 0xffffffffu;
+#endif
         launch_accumulate<C>(s, d_bases, sl.entries.as<uint32_t>(), sl.off.as<uint32_t>(), NB, sl.bucket.as<uint32_t>(), sl.bucket_inf.as<uint8_t>(),
                            sl.head.as<uint32_t>(), sl.tail.as<uint32_t>(), sl.head_b.as<uint32_t>(), sl.tail_b.as<uint32_t>(), sl.part_inf.as<uint8_t>(), T, (uint32_t)CH, dbg_mask);
     }
@@ -138,9 +143,9 @@ int32_t msm_device(Slot &sl, const uint32_t *d_bases, const uint32_t *d_scalars,
     auto tsync0 = std::chrono::steady_clock::now();
     HIPCHK(hipStreamSynchronize(s));
     auto tsync1 = std::chrono::steady_clock::now();
-    if (g.prof) prof_flush(sl);
+    if (gs.prof) prof_flush(sl);
     host_fold<HF>(hwin.data(), hinf.data(), W, c, out_xyz);
-    if (g.prof) {
+    if (gs.prof) {
         auto t2 = std::chrono::steady_clock::now();
         prof_add_host("msm.host_wait", std::chrono::duration<double, std::milli>(tsync1 - tsync0).count());
         prof_add_host("msm.host_fold", std::chrono::duration<double, std::milli>(t2 - tsync1).count());
@@ -161,13 +166,12 @@ int32_t prep_bases(Slot &sl, const uint64_t *h_bases, const uint8_t *h_inf, size
     return DGPU_OK;
 }
 
+// one-shot MSM on the calling thread's context (no size threshold: the callers apply it)
 template <class C, class HF>
-int32_t msm_oneshot(const uint64_t *bases, const uint8_t *is_inf, const uint64_t *scalars, size_t n, bool mont, uint64_t *out) {
-    if (!out || (n && (!bases || !scalars)) || n >= (1ull << 31)) return DGPU_E_BADARG;
-    if (n < g.min_gpu_n) return DGPU_E_TOO_SMALL;
-    if (!g.ready) return DGPU_E_NODEVICE;
+int32_t msm_oneshot_here(const uint64_t *bases, const uint8_t *is_inf, const uint64_t *scalars, size_t n, bool mont, uint64_t *out) {
+    if (!cur().ready) return DGPU_E_NODEVICE;
     SlotLock L; Slot &sl = *L.s;
-    HIPCHK(hipSetDevice(g.device));
+    HIPCHK(hipSetDevice(cur().device));
     int32_t rc;
     if (n) {
         if ((rc = sl.prepped.ensure(n * C::AFF_STRIDE * 4))) return rc;
@@ -177,53 +181,147 @@ int32_t msm_oneshot(const uint64_t *bases, const uint8_t *is_inf, const uint64_t
     }
     return msm_device<C, HF>(sl, sl.prepped.as<uint32_t>(), sl.in_scalars.as<uint32_t>(), n, out);
 }
+template <class C, class HF>
+int32_t msm_oneshot(const uint64_t *bases, const uint8_t *is_inf, const uint64_t *scalars, size_t n, bool mont, uint64_t *out) {
+    if (!out || (n && (!bases || !scalars)) || n >= (1ull << 31)) return DGPU_E_BADARG;
+    if (!cur().ready) return DGPU_E_NODEVICE;            // (before the size threshold: a missing device is never answered with "too small")
+    if (n < gs.min_gpu_n) return DGPU_E_TOO_SMALL;
+    return msm_oneshot_here<C, HF>(bases, is_inf, scalars, n, mont, out);
+}
 
 template <class C>
 int32_t bases_upload(const uint64_t *bases, const uint8_t *is_inf, size_t n, uint64_t *handle, int kind) {
     if (!handle || (n && !bases) || n >= (1ull << 31)) return DGPU_E_BADARG;
-    if (!g.ready) return DGPU_E_NODEVICE;
+    if (!cur().ready) return DGPU_E_NODEVICE;
     void *p = nullptr;
     {
         SlotLock L; Slot &sl = *L.s;
-        HIPCHK(hipSetDevice(g.device));
+        HIPCHK(hipSetDevice(cur().device));
         if (hipMalloc(&p, std::max<size_t>(n, 1) * C::AFF_STRIDE * 4) != hipSuccess) { (void)hipGetLastError(); return DGPU_E_OOM; }
         int32_t rc = n ? prep_bases<C>(sl, bases, is_inf, n, (uint32_t *)p) : DGPU_OK;
         if (rc == DGPU_OK && hipStreamSynchronize(sl.stream) != hipSuccess) rc = DGPU_E_HIP;
         if (rc) { (void)hipFree(p); return rc; }
     }
-    std::lock_guard<std::mutex> lk(g.mu);
-    uint64_t h = g.next_handle++;
-    g.handles[h] = Handle{p, n, kind};
-    *handle = h;
+    *handle = register_handle(p, n, kind);
     return DGPU_OK;
 }
 
+// `check_min`: the sharded entry points apply the size threshold to the whole MSM, not to a shard
 template <class C, class HF>
-int32_t msm_handle(uint64_t bases, size_t offset, const uint64_t *scalars, size_t n, int mont, uint64_t *out, int kind) {
+int32_t msm_handle(uint64_t bases, size_t offset, const uint64_t *scalars, size_t n, int mont, uint64_t *out, int kind, bool check_min = true) {
     if (!out || (n && !scalars)) return DGPU_E_BADARG;
-    if (n < g.min_gpu_n) return DGPU_E_TOO_SMALL;
-    if (!g.ready) return DGPU_E_NODEVICE;
-    Handle hb;
-    if (!lookup_handle(bases, hb) || hb.kind != kind || offset > hb.n || n > hb.n - offset) return DGPU_E_BADARG;
+    if (!cur().ready) return DGPU_E_NODEVICE;
+    if (check_min && n < gs.min_gpu_n) return DGPU_E_TOO_SMALL;
+    HandleRef hb(bases);
+    if (!hb.ok || hb.h.kind != kind || offset > hb.h.n || n > hb.h.n - offset) return DGPU_E_BADARG;
+    CtxScope on_owner(hb.h.ctx);                    // run where the bases live
     SlotLock L; Slot &sl = *L.s;
-    HIPCHK(hipSetDevice(g.device));
+    HIPCHK(hipSetDevice(cur().device));
     int32_t rc;
     if ((rc = sl.in_scalars.ensure(std::max<size_t>(n, 1) * 32))) return rc;
     if (n && (rc = upload_scalars(sl, scalars, n, mont != 0, sl.in_scalars.as<uint32_t>()))) return rc;
-    return msm_device<C, HF>(sl, (const uint32_t *)hb.p + offset * C::AFF_STRIDE, sl.in_scalars.as<uint32_t>(), n, out);
+    return msm_device<C, HF>(sl, (const uint32_t *)hb.h.p + offset * C::AFF_STRIDE, sl.in_scalars.as<uint32_t>(), n, out);
 }
 
 template <class C, class HF>
-int32_t msm_resident(uint64_t bases, size_t boff, uint64_t scalars, size_t soff, size_t n, uint64_t *out, int kind) {
+int32_t msm_resident(uint64_t bases, size_t boff, uint64_t scalars, size_t soff, size_t n, uint64_t *out, int kind, bool check_min = true) {
     if (!out) return DGPU_E_BADARG;
-    if (n < g.min_gpu_n) return DGPU_E_TOO_SMALL;
-    if (!g.ready) return DGPU_E_NODEVICE;
-    Handle hb, hs;
-    if (!lookup_handle(bases, hb) || !lookup_handle(scalars, hs) || hb.kind != kind || hs.kind != 3) return DGPU_E_BADARG;
-    if (boff > hb.n || n > hb.n - boff || soff > hs.n || n > hs.n - soff) return DGPU_E_BADARG;
+    if (!cur().ready) return DGPU_E_NODEVICE;
+    if (check_min && n < gs.min_gpu_n) return DGPU_E_TOO_SMALL;
+    HandleRef hb(bases), hs(scalars);
+    if (!hb.ok || !hs.ok || hb.h.kind != kind || hs.h.kind != 3 || hb.h.ctx != hs.h.ctx) return DGPU_E_BADARG;    // both operands on one device
+    if (boff > hb.h.n || n > hb.h.n - boff || soff > hs.h.n || n > hs.h.n - soff) return DGPU_E_BADARG;
+    CtxScope on_owner(hb.h.ctx);
     SlotLock L; Slot &sl = *L.s;
-    HIPCHK(hipSetDevice(g.device));
-    return msm_device<C, HF>(sl, (const uint32_t *)hb.p + boff * C::AFF_STRIDE, (const uint32_t *)hs.p + soff * 8, n, out);
+    HIPCHK(hipSetDevice(cur().device));
+    return msm_device<C, HF>(sl, (const uint32_t *)hb.h.p + boff * C::AFF_STRIDE, (const uint32_t *)hs.h.p + soff * 8, n, out);
+}
+
+// ---- several GPUs behind the ABI (SURVEY.md 8b `dgpu_msm_g1_sharded`, 8e point-chunk sharding) ----------------------------------------
+// One process, one context per device, one host thread per device inside the call: device k runs the whole pipeline on the terms
+// [lo_k, lo_{k+1}) and hands back one normalised Jacobian point (144 / 288 B); the partials are folded on the host.  No collective is
+// needed inside a process; the multi-process form (one rank per GPU, RCCL all_gather of the same partials) stays above the ABI.
+inline void shard_bounds(size_t n, size_t parts, std::vector<size_t> &lo) {
+    lo.resize(parts + 1);
+    const size_t base = n / parts, rem = n % parts;
+    for (size_t k = 0; k <= parts; k++) lo[k] = k * base + std::min(k, rem);       // contiguous, balanced (== sharded.chunk_bounds)
+}
+template <class F> int32_t run_shards(size_t parts, F body) {
+    std::vector<int32_t> rcs(parts, DGPU_OK);
+    std::vector<std::thread> th;
+    for (size_t k = 1; k < parts; k++) th.emplace_back([&, k] { rcs[k] = body(k); });
+    rcs[0] = body(0);
+    for (auto &t : th) t.join();
+    for (int32_t rc : rcs) if (rc) return rc;
+    return DGPU_OK;
+}
+template <class C, class HF>
+int32_t msm_sharded_oneshot(const uint64_t *bases, const uint8_t *is_inf, const uint64_t *scalars, size_t n, int32_t ngpus, bool mont, uint64_t *out) {
+    if (!out || (n && (!bases || !scalars)) || n >= (1ull << 31) || ngpus < 0) return DGPU_E_BADARG;
+    const std::vector<int> cx = ready_contexts(ngpus);
+    if (cx.empty()) return DGPU_E_NODEVICE;
+    if (ngpus > 0 && (int)cx.size() < ngpus) return DGPU_E_BADARG;
+    if (n < gs.min_gpu_n) return DGPU_E_TOO_SMALL;
+    std::vector<size_t> lo; shard_bounds(n, cx.size(), lo);
+    const size_t JW = 3 * sizeof(HF) / 8, BW = 2 * sizeof(HF) / 8;
+    std::vector<uint64_t> parts(cx.size() * JW);
+    int32_t rc = run_shards(cx.size(), [&](size_t k) {
+        CtxScope here(cx[k]);
+        const size_t cnt = lo[k + 1] - lo[k];
+        return msm_oneshot_here<C, HF>(bases + lo[k] * BW, is_inf ? is_inf + lo[k] : nullptr, scalars + lo[k] * 4, cnt, mont, parts.data() + k * JW);
+    });
+    if (rc) return rc;
+    return host_fold_jacobian<HF>(parts.data(), cx.size(), out);
+}
+template <class C>
+int32_t bases_upload_sharded(const uint64_t *bases, const uint8_t *is_inf, size_t n, int32_t ngpus, uint64_t *handle, int kind /* 1 | 2 */) {
+    if (!handle || (n && !bases) || n >= (1ull << 31) || ngpus < 0) return DGPU_E_BADARG;
+    const std::vector<int> cx = ready_contexts(ngpus);
+    if (cx.empty()) return DGPU_E_NODEVICE;
+    if (ngpus > 0 && (int)cx.size() < ngpus) return DGPU_E_BADARG;
+    ShardSet *ss = new ShardSet();
+    ss->n = n; ss->sub.assign(cx.size(), 0); shard_bounds(n, cx.size(), ss->lo);
+    const size_t BW = 2 * C::ABI_W / 2;           // u64 words per affine point
+    int32_t rc = run_shards(cx.size(), [&](size_t k) {
+        CtxScope here(cx[k]);
+        return bases_upload<C>(bases + ss->lo[k] * BW, is_inf ? is_inf + ss->lo[k] : nullptr, ss->lo[k + 1] - ss->lo[k], &ss->sub[k], kind);
+    });
+    if (rc) { for (uint64_t h : ss->sub) if (h) (void)dgpu_bases_free(h); delete ss; return rc; }
+    *handle = register_handle(ss, n, kind + 6);       // 7 = G1 sharded, 8 = G2 sharded
+    return DGPU_OK;
+}
+// fresh host scalars against a sharded bases handle: shard k uploads and uses scalars [lo_k, min(lo_{k+1}, n))
+template <class C, class HF>
+int32_t msm_sharded_handle(uint64_t bases, const uint64_t *scalars, size_t n, int mont, uint64_t *out, int kind) {
+    if (!out || (n && !scalars)) return DGPU_E_BADARG;
+    if (n < gs.min_gpu_n) return DGPU_E_TOO_SMALL;
+    HandleRef hb(bases);
+    if (!hb.ok || hb.h.kind != kind + 6 || n > hb.h.n) return DGPU_E_BADARG;
+    const ShardSet &ss = *(const ShardSet *)hb.h.p;
+    const size_t G = ss.sub.size(), JW = 3 * sizeof(HF) / 8;
+    std::vector<uint64_t> parts(G * JW);
+    int32_t rc = run_shards(G, [&](size_t k) {
+        const size_t lo = std::min(ss.lo[k], n), hi = std::min(ss.lo[k + 1], n);
+        return msm_handle<C, HF>(ss.sub[k], 0, scalars + lo * 4, hi - lo, mont, parts.data() + k * JW, kind, false);
+    });
+    if (rc) return rc;
+    return host_fold_jacobian<HF>(parts.data(), G, out);
+}
+// both operands resident on their devices (inputs pre-sharded: BASELINE config 5's timed region)
+template <class C, class HF>
+int32_t msm_sharded_resident(uint64_t bases, uint64_t scalars, uint64_t *out, int kind) {
+    if (!out) return DGPU_E_BADARG;
+    HandleRef hb(bases), hs(scalars);
+    if (!hb.ok || !hs.ok || hb.h.kind != kind + 6 || hs.h.kind != 9) return DGPU_E_BADARG;
+    const ShardSet &sb = *(const ShardSet *)hb.h.p, &sv = *(const ShardSet *)hs.h.p;
+    if (sb.sub.size() != sv.sub.size() || sv.n > sb.n) return DGPU_E_BADARG;
+    for (size_t k = 0; k < sb.sub.size(); k++) if (sv.lo[k] != std::min(sb.lo[k], sv.n) || sv.lo[k + 1] != std::min(sb.lo[k + 1], sv.n)) return DGPU_E_BADARG;
+    if (sv.n < gs.min_gpu_n) return DGPU_E_TOO_SMALL;
+    const size_t G = sb.sub.size(), JW = 3 * sizeof(HF) / 8;
+    std::vector<uint64_t> parts(G * JW);
+    int32_t rc = run_shards(G, [&](size_t k) { return msm_resident<C, HF>(sb.sub[k], 0, sv.sub[k], 0, sv.lo[k + 1] - sv.lo[k], parts.data() + k * JW, kind, false); });
+    if (rc) return rc;
+    return host_fold_jacobian<HF>(parts.data(), G, out);
 }
 
 

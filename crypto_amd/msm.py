@@ -28,11 +28,25 @@ G2 = _Curve("g2", 24)
 _inited = False
 
 
-def init(device=0):
+def init(device=0, min_gpu_n=0):
+    """dgpu_init(device).  The library's default size threshold (DGPU_DEFAULT_MIN_GPU_N: below it the ABI answers DGPU_E_TOO_SMALL so that
+    a Rust caller stays on arkworks) is lowered to `min_gpu_n` = 0 here: this mirror has no CPU path to stay on."""
     global _inited
     rc = lib().dgpu_init(device)
     if rc:
         raise DockGpuError(rc, "dgpu_init(%d)" % device)
+    lib().dgpu_set_min_gpu_n(min_gpu_n)
+    _inited = True
+
+
+def init_devices(physical, min_gpu_n=0):
+    """several GPUs in this process: context k on HIP device physical[k] (dgpu_init_device_list; a device may repeat)"""
+    global _inited
+    arr = np.ascontiguousarray(physical, dtype=np.int32)
+    rc = lib().dgpu_init_device_list(arr.ctypes.data_as(C.c_void_p), len(arr))
+    if rc:
+        raise DockGpuError(rc, "dgpu_init_device_list(%s)" % list(arr))
+    lib().dgpu_set_min_gpu_n(min_gpu_n)
     _inited = True
 
 
@@ -171,6 +185,70 @@ class DeviceBases:
         rc = self.curve.fn("dgpu_msm_%s_resident")(self.handle, base_offset, dscalars.handle, scalar_offset, n, _p(out))
         if rc:
             raise DockGpuError(rc, "dgpu_msm_resident")
+        return out
+
+    def free(self):
+        if self.handle:
+            lib().dgpu_bases_free(self.handle)
+            self.handle = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def msm_bigint_sharded(curve, bases, scalars, is_inf=None, ngpus=0):
+    """one-shot MSM chunked over the process's device contexts (dgpu_msm_*_sharded)"""
+    _ensure()
+    bases, scalars, inf, n = _prep(curve, bases, scalars, is_inf)
+    out = np.zeros(curve.JW, dtype=np.uint64)
+    rc = curve.fn("dgpu_msm_%s_sharded")(_p(bases), _p(inf), _p(scalars), n, ngpus, _p(out))
+    if rc:
+        raise DockGpuError(rc, "dgpu_msm_%s_sharded" % curve.tag)
+    return out
+
+
+class ShardedDeviceBases:
+    """A proving-key query resident across the process's device contexts (dgpu_bases_upload_*_sharded)."""
+
+    def __init__(self, curve, bases, is_inf=None, ngpus=0):
+        _ensure()
+        self.curve = curve
+        bases = np.ascontiguousarray(bases, dtype=np.uint64).reshape(-1, curve.AW)
+        self.n = len(bases)
+        inf = None if is_inf is None else np.ascontiguousarray(is_inf, dtype=np.uint8)
+        h = C.c_uint64(0)
+        rc = curve.fn("dgpu_bases_upload_%s_sharded")(_p(bases), _p(inf), self.n, ngpus, C.byref(h))
+        if rc:
+            raise DockGpuError(rc, "dgpu_bases_upload_sharded")
+        self.handle = h.value
+
+    def msm_bigint(self, scalars, montgomery=False):
+        scalars = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+        n = min(len(scalars), self.n)
+        out = np.zeros(self.curve.JW, dtype=np.uint64)
+        rc = self.curve.fn("dgpu_msm_%s_sharded_handle")(self.handle, _p(scalars), n, int(montgomery), _p(out))
+        if rc:
+            raise DockGpuError(rc, "dgpu_msm_sharded_handle")
+        return out
+
+    def upload_scalars(self, scalars, montgomery=False):
+        scalars = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+        h = C.c_uint64(0)
+        rc = lib().dgpu_scalars_upload_sharded(_p(scalars), len(scalars), int(montgomery), self.handle, C.byref(h))
+        if rc:
+            raise DockGpuError(rc, "dgpu_scalars_upload_sharded")
+        ds = DeviceScalars.__new__(DeviceScalars)
+        ds.n, ds.handle = len(scalars), h.value
+        return ds
+
+    def msm_resident(self, dscalars):
+        out = np.zeros(self.curve.JW, dtype=np.uint64)
+        rc = self.curve.fn("dgpu_msm_%s_sharded_resident")(self.handle, dscalars.handle, _p(out))
+        if rc:
+            raise DockGpuError(rc, "dgpu_msm_sharded_resident")
         return out
 
     def free(self):

@@ -18,7 +18,8 @@ def serialize(curve, points, is_inf=None, compressed=True):
     return out.tobytes()
 
 
-def deserialize(curve, data, compressed=True):
+def deserialize(curve, data, compressed=True, validate=True):
+    """CanonicalDeserialize: validate=True is Validate::Yes (curve + prime-order subgroup), False is Validate::No (curve only)"""
     sz = _SZ[(curve.tag, compressed)]
     if len(data) % sz:
         raise ValueError("length is not a multiple of %d" % sz)
@@ -27,7 +28,7 @@ def deserialize(curve, data, compressed=True):
     pts = np.zeros((n, curve.AW), dtype=np.uint64)
     inf = np.zeros(n, dtype=np.uint8)
     fn = lib().dgpu_g1_deserialize if curve.tag == "g1" else lib().dgpu_g2_deserialize
-    rc = fn(buf.ctypes.data_as(C.c_void_p), n, int(compressed), pts.ctypes.data_as(C.c_void_p), inf.ctypes.data_as(C.c_void_p))
+    rc = fn(buf.ctypes.data_as(C.c_void_p), n, int(compressed) | (0 if validate else 2), pts.ctypes.data_as(C.c_void_p), inf.ctypes.data_as(C.c_void_p))
     if rc:
         raise DockGpuError(rc, "deserialize")
     return pts, inf

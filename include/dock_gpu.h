@@ -38,13 +38,25 @@ extern "C" {
 
 /* ---- lifecycle ---- */
 int32_t dgpu_init(int32_t device);           /* bind to a HIP device ordinal (one process per GPU); idempotent */
+/* Several GPUs in ONE process (a Rust host is one process): one context per device, each with its own streams and
+ * workspaces.  dgpu_init_devices(mask): bit d = use HIP device d; contexts are numbered 0.. in increasing device order.
+ * dgpu_init_device_list: context k on physical[k] (a device may be listed twice: two contexts on one GPU, used by the tests on a
+ * one-GPU box).  Entry points that take host pointers run on the calling thread's context (dgpu_set_device, thread-local, default =
+ * context 0); entry points that take a handle run on the context that owns the handle. */
+int32_t dgpu_init_devices(uint32_t device_mask);
+int32_t dgpu_init_device_list(const int32_t *physical, int32_t count);
+int32_t dgpu_context_count(void);
+int32_t dgpu_set_device(int32_t context);
 int32_t dgpu_shutdown(void);
 int32_t dgpu_device_count(void);
 const char *dgpu_strerror(int32_t code);
 int32_t dgpu_last_hip_error(void);
 /* below this many terms the MSM entry points return DGPU_E_TOO_SMALL without touching the device
- * (>= 95 % of the reference's call sites have n < 100); default 0 = always run. */
+ * (>= 95 % of the reference's call sites have n < 100).  Default: DGPU_DEFAULT_MIN_GPU_N, the measured
+ * crossover against the CPU path; 0 = always run on the device. */
+#define DGPU_DEFAULT_MIN_GPU_N 256
 int32_t dgpu_set_min_gpu_n(size_t n);
+size_t dgpu_get_min_gpu_n(void);
 /* window width c (bits) used by the bucket method; 0 = automatic from n.  Any value gives the same point. */
 int32_t dgpu_set_window_bits(int32_t c);
 
@@ -80,7 +92,26 @@ int32_t dgpu_msm_g2_handle(uint64_t bases, size_t offset, const uint64_t *scalar
 int32_t dgpu_msm_g1_resident(uint64_t bases, size_t base_offset, uint64_t scalars, size_t scalar_offset, size_t n, uint64_t out_xyz[18]);
 int32_t dgpu_msm_g2_resident(uint64_t bases, size_t base_offset, uint64_t scalars, size_t scalar_offset, size_t n, uint64_t out_xyz[36]);
 
-/* ---- multi-GPU: fold per-rank partial results (host code; EC addition is not an RCCL reduction op, so the
+/* ---- several GPUs behind the ABI (SURVEY.md 8b `dgpu_msm_g1_sharded`, 8e): point-chunk sharding inside one process ----
+ * Context k (see dgpu_init_devices) takes the contiguous balanced chunk k of the n terms, runs the whole single-GPU pipeline on it
+ * from its own host thread inside the call, and the per-device partial points (144 / 288 B) are folded on the host — bit-identical
+ * to the single-device result (the ABI returns the normalised representative).  ngpus = 0: every initialised context.
+ *   dgpu_msm_*_sharded            one-shot: host bases + scalars in (each device pulls its own chunk over its own PCIe link)
+ *   dgpu_bases_upload_*_sharded   a proving-key query resident across the devices; free with dgpu_bases_free
+ *   dgpu_msm_*_sharded_handle     fresh host scalars against such a handle (n <= number of bases: the first n terms)
+ *   dgpu_scalars_upload_sharded   scalars split the way the bases handle `like` is split; free with dgpu_scalars_free
+ *   dgpu_msm_*_sharded_resident   both operands resident (BASELINE config 5's timed region: inputs pre-sharded) */
+int32_t dgpu_msm_g1_sharded(const uint64_t *bases_xy, const uint8_t *is_inf, const uint64_t *scalars, size_t n, int32_t ngpus, uint64_t out_xyz[18]);
+int32_t dgpu_msm_g2_sharded(const uint64_t *bases_xy, const uint8_t *is_inf, const uint64_t *scalars, size_t n, int32_t ngpus, uint64_t out_xyz[36]);
+int32_t dgpu_bases_upload_g1_sharded(const uint64_t *bases_xy, const uint8_t *is_inf, size_t n, int32_t ngpus, uint64_t *handle);
+int32_t dgpu_bases_upload_g2_sharded(const uint64_t *bases_xy, const uint8_t *is_inf, size_t n, int32_t ngpus, uint64_t *handle);
+int32_t dgpu_msm_g1_sharded_handle(uint64_t bases, const uint64_t *scalars, size_t n, int32_t montgomery, uint64_t out_xyz[18]);
+int32_t dgpu_msm_g2_sharded_handle(uint64_t bases, const uint64_t *scalars, size_t n, int32_t montgomery, uint64_t out_xyz[36]);
+int32_t dgpu_scalars_upload_sharded(const uint64_t *scalars, size_t n, int32_t montgomery, uint64_t like, uint64_t *handle);
+int32_t dgpu_msm_g1_sharded_resident(uint64_t bases, uint64_t scalars, uint64_t out_xyz[18]);
+int32_t dgpu_msm_g2_sharded_resident(uint64_t bases, uint64_t scalars, uint64_t out_xyz[36]);
+
+/* ---- multi-process multi-GPU: fold per-rank partial results (host code; EC addition is not an RCCL reduction op, so the
  * collective is an all-gather of k normalised Jacobian triples followed by this fold) ---- */
 int32_t dgpu_fold_g1(const uint64_t *partials_xyz /* k*18 */, size_t k, uint64_t out_xyz[18]);
 int32_t dgpu_fold_g2(const uint64_t *partials_xyz /* k*36 */, size_t k, uint64_t out_xyz[36]);
@@ -181,11 +212,14 @@ int32_t dgpu_witness_map_r1cs(uint64_t r1cs, const uint64_t *assignment, size_t 
  * The format ark-bls12-381 0.4 emits for `CanonicalSerialize` (Zcash / IETF BLS12-381): big-endian coordinates, top three bits of
  * byte 0 = compressed / infinity / y-lexicographically-largest; G1 48 B (compressed) or 96 B, G2 96 or 192 B with c1 before c0.
  * Used to load keys and proofs written by the Rust side (legogroth16/src/data_structures.rs:7-186) into the ABI layout.
- * DGPU_E_BADARG: wrong compression flag, coordinate >= p, or not on the curve.  No subgroup check. */
+ * `mode` of the deserialisers: bit 0 = compressed; DGPU_SERDE_NO_VALIDATE = arkworks' Validate::No (skip the subgroup test).
+ * DGPU_E_BADARG: wrong compression flag, coordinate >= p, not on the curve, a non-canonical infinity encoding, or — Validate::Yes,
+ * the default, what `deserialize_compressed` does — a point outside the prime-order subgroup ([r]P != O). */
+#define DGPU_SERDE_NO_VALIDATE 2
 int32_t dgpu_g1_serialize(const uint64_t *xy /* n*12 */, const uint8_t *is_inf, size_t n, int32_t compressed, uint8_t *out);
-int32_t dgpu_g1_deserialize(const uint8_t *in, size_t n, int32_t compressed, uint64_t *xy /* n*12 */, uint8_t *is_inf /* n */);
+int32_t dgpu_g1_deserialize(const uint8_t *in, size_t n, int32_t mode, uint64_t *xy /* n*12 */, uint8_t *is_inf /* n */);
 int32_t dgpu_g2_serialize(const uint64_t *xy /* n*24 */, const uint8_t *is_inf, size_t n, int32_t compressed, uint8_t *out);
-int32_t dgpu_g2_deserialize(const uint8_t *in, size_t n, int32_t compressed, uint64_t *xy /* n*24 */, uint8_t *is_inf /* n */);
+int32_t dgpu_g2_deserialize(const uint8_t *in, size_t n, int32_t mode, uint64_t *xy /* n*24 */, uint8_t *is_inf /* n */);
 
 /* ---- instrumentation (bench.py / rocprof cross-check) ----
  * When enabled, every stage of the next calls is bracketed by HIP events on the library's own stream. */

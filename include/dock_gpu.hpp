@@ -31,7 +31,10 @@ struct Error : std::runtime_error {
     Error(int32_t c, const char *what) : std::runtime_error(std::string(what) + ": " + dgpu_strerror(c)), code(c) {}
 };
 inline void check(int32_t rc, const char *what) { if (rc != DGPU_OK) throw Error(rc, what); }
-inline void init(int device = 0) { check(dgpu_init(device), "dgpu_init"); }
+// this mirror has no CPU path to stay on, so the size threshold (DGPU_E_TOO_SMALL below DGPU_DEFAULT_MIN_GPU_N terms) is lowered to 0
+inline void init(int device = 0) { check(dgpu_init(device), "dgpu_init"); check(dgpu_set_min_gpu_n(0), "dgpu_set_min_gpu_n"); }
+// several GPUs in one process: context k on HIP device physical[k]
+inline void init_devices(const std::vector<int32_t> &physical) { check(dgpu_init_device_list(physical.data(), (int32_t)physical.size()), "dgpu_init_device_list"); check(dgpu_set_min_gpu_n(0), "dgpu_set_min_gpu_n"); }
 
 using Fq = std::array<uint64_t, 6>;        // Montgomery limbs, R = 2^384 (ark-ff Fp384 layout)
 using BigInt256 = std::array<uint64_t, 4>; // canonical scalar (Fr::into_bigint)

@@ -78,6 +78,34 @@ int main() {
     bool threw = false; try { a.pop_back(); multi_miller_loop(a, b); } catch (const Error &e) { threw = e.code == DGPU_E_LENGTH; }
     EXPECT(threw);
     EXPECT(!final_exponentiation(Fq12{}).has_value());                    // zero -> None
+    // several device contexts in this one process (a Rust host is one process): two contexts on the box's one GPU, every MSM chunked
+    // over them inside the library (dgpu_msm_*_sharded*), same point as the single-context call
+    init_devices({0, 0});
+    EXPECT(dgpu_context_count() == 2);
+    {
+        uint64_t one[18], sh[18], h = 0, hs = 0;
+        orc_g1_msm(b1.data(), inf1.data(), sc.data(), n, 8, e1);
+        EXPECT(dgpu_msm_g1(b1.data(), inf1.data(), sc.data(), n, one) == DGPU_OK);
+        EXPECT(dgpu_msm_g1_sharded(b1.data(), inf1.data(), sc.data(), n, 2, sh) == DGPU_OK && std::memcmp(one, sh, sizeof one) == 0);
+        EXPECT(dgpu_msm_g1_sharded(b1.data(), inf1.data(), sc.data(), n, 3, sh) == DGPU_E_BADARG);      // only two contexts exist
+        EXPECT(dgpu_bases_upload_g1_sharded(b1.data(), inf1.data(), n, 0, &h) == DGPU_OK);
+        EXPECT(dgpu_msm_g1_sharded_handle(h, sc.data(), n, 0, sh) == DGPU_OK && std::memcmp(one, sh, sizeof one) == 0);
+        EXPECT(dgpu_msm_g1_sharded_handle(h, scm.data(), n, 1, sh) == DGPU_OK && std::memcmp(one, sh, sizeof one) == 0);
+        EXPECT(dgpu_scalars_upload_sharded(sc.data(), n, 0, h, &hs) == DGPU_OK);
+        EXPECT(dgpu_msm_g1_sharded_resident(h, hs, sh) == DGPU_OK && std::memcmp(one, sh, sizeof one) == 0);
+        uint64_t j[18]; std::memcpy(j, sh, sizeof j);
+        G1::Projective pr; std::memcpy(&pr.x, j, 48); std::memcpy(&pr.y, j + 6, 48); std::memcpy(&pr.z, j + 12, 48);
+        EXPECT(same_point<G1>(pr, e1, orc_g1_to_affine));
+        // the first 1000 terms only (truncation) against a handle that holds 3000 bases
+        uint64_t part[18]; orc_g1_msm(b1.data(), inf1.data(), sc.data(), 1000, 8, e1);
+        EXPECT(dgpu_msm_g1_sharded_handle(h, sc.data(), 1000, 0, part) == DGPU_OK);
+        std::memcpy(&pr.x, part, 48); std::memcpy(&pr.y, part + 6, 48); std::memcpy(&pr.z, part + 12, 48);
+        EXPECT(same_point<G1>(pr, e1, orc_g1_to_affine));
+        EXPECT(dgpu_scalars_free(hs) == DGPU_OK && dgpu_bases_free(h) == DGPU_OK && dgpu_bases_free(h) == DGPU_E_BADARG);
+        uint64_t one2[36], sh2[36];
+        EXPECT(dgpu_msm_g2(b2.data(), inf2.data(), sc.data(), n, one2) == DGPU_OK);
+        EXPECT(dgpu_msm_g2_sharded(b2.data(), inf2.data(), sc.data(), n, 0, sh2) == DGPU_OK && std::memcmp(one2, sh2, sizeof one2) == 0);
+    }
     if (fails) std::printf("cpp_api_driver: %d FAILED\n", fails); else std::printf("cpp_api_driver: all equal\n");
     return fails ? 1 : 0;
 }

@@ -87,6 +87,28 @@ def test_bad_arguments():
     assert L.dgpu_window_table_free(999) == -3
 
 
+def test_malformed_r1cs_is_refused_before_it_reaches_the_device():
+    """rowptr monotonic, rowptr[0] == 0, rowptr[rows] == nnz, cols < num_vars — validated inside the native entry points"""
+    L = lib()
+    p_ = lambda a: a.ctypes.data_as(C.c_void_p)
+    vals = np.ones((2, 4), np.uint64); z = np.ones((3, 4), np.uint64); h = C.c_uint64(0); out = np.zeros((4, 4), np.uint64); ol = C.c_size_t(0)
+    good = (np.array([0, 1, 2], np.uint64), np.array([0, 2], np.uint32))
+    bads = [(np.array([0, 2, 1], np.uint64), good[1]),        # decreasing
+            (np.array([1, 1, 2], np.uint64), good[1]),        # does not start at 0
+            (np.array([0, 1, 3], np.uint64), good[1]),        # rowptr[rows] != nnz
+            (good[0], np.array([0, 3], np.uint32))]           # column >= num_vars
+    def args(m):
+        a = []
+        for k in range(3):
+            rp, cl = m if k == 1 else good
+            a += [p_(rp), p_(cl), p_(vals), 2]
+        return a
+    for m in bads:
+        assert L.dgpu_r1cs_upload(*args(m), 3, 1, 2, 0, C.byref(h)) == -3
+        assert L.dgpu_witness_map(*args(m), p_(z), 3, 1, 2, 0, p_(out), None, C.byref(ol)) == -3
+    assert L.dgpu_r1cs_upload(*args(good), 3, 1, 2, 0, C.byref(h)) == -1          # well-formed: only the missing device stops it
+
+
 def test_checked_msm_and_pairs_length_semantics():
     # ark-ec msm(): Err(min_len) on mismatch;  utils/src/pairs.rs: Pairs::new -> None / TryFrom Err((l, r))
     b = np.zeros((5, 12), np.uint64)

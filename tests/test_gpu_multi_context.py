@@ -1,0 +1,130 @@
+"""GPU (-m gpu): several device contexts inside ONE process behind the C ABI (SURVEY 8b `dgpu_msm_g1_sharded`, 8e): the
+box has one GPU, so two contexts are opened on it (dgpu_init_device_list([0, 0]): own streams and workspaces each) —
+every code path of the in-library sharding runs (per-device host threads, handles routed to their owner, host fold)
+except a second physical device.  Also: handles pinned against a concurrent free, and the size threshold."""
+import ctypes as C
+import threading
+import time
+import numpy as np
+import pytest
+import torch
+import oracle_c as O
+import util as U
+import crypto_amd as ca
+from crypto_amd._native import lib
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _contexts():
+    assert torch.cuda.is_available()
+    ca.init_devices([0, 0])
+    assert lib().dgpu_context_count() == 2
+    yield
+    lib().dgpu_set_device(0)
+
+
+def _inputs(G, n, seed):
+    bases, _, _ = U.seq_bases(G, n, seed, threads=16)
+    return bases, O.rand_scalars(seed + 7, n)
+
+
+@pytest.mark.parametrize("gname,n", [("G1", 0), ("G1", 1), ("G1", 3), ("G1", 20001), ("G1", 1 << 17), ("G2", 3001)])
+def test_sharded_oneshot_equals_single_context_and_oracle(gname, n):
+    curve, G = (ca.G1, O.G1) if gname == "G1" else (ca.G2, O.G2)
+    bases, sc = _inputs(G, n, 300 + n) if n else (np.zeros((0, G.AW), np.uint64), np.zeros((0, 4), np.uint64))
+    inf = np.zeros(n, np.uint8)
+    if n > 2:
+        inf[2] = 1
+    single = ca.msm_bigint(curve, bases, sc, inf)
+    assert (ca.msm_bigint_sharded(curve, bases, sc, inf) == single).all()
+    assert (ca.msm_bigint_sharded(curve, bases, sc, inf, ngpus=1) == single).all()
+    if n <= 20001:
+        ref = G.msm(bases, sc, inf, threads=16)
+        assert U.jac_to_model(G, single) == U.jac_to_model(G, ref)
+    with pytest.raises(ca.DockGpuError):
+        ca.msm_bigint_sharded(curve, bases, sc, inf, ngpus=3)
+
+
+def test_sharded_resident_query_and_truncation():
+    G, curve = O.G1, ca.G1
+    n = 50000
+    bases, sc = _inputs(G, n, 77)
+    one = ca.DeviceBases(curve, bases)
+    sh = ca.ShardedDeviceBases(curve, bases)
+    full = one.msm_bigint(sc)
+    assert (sh.msm_bigint(sc) == full).all()
+    assert (sh.msm_bigint(O.fr_to_mont(sc), montgomery=True) == full).all()
+    for m in (1, 24999, 25000, 25001, 49999):                 # fewer scalars than bases: the first m terms (prover.rs:286), across the shard border
+        assert (sh.msm_bigint(sc[:m]) == one.msm_bigint(sc[:m])).all(), m
+    ds = sh.upload_scalars(sc)
+    assert (sh.msm_resident(ds) == full).all()
+    ds2 = sh.upload_scalars(sc[:30000])
+    assert (sh.msm_resident(ds2) == one.msm_bigint(sc[:30000])).all()
+    ds.free(); ds2.free(); sh.free(); one.free()
+    with pytest.raises(ca.DockGpuError):
+        sh2 = ca.ShardedDeviceBases(curve, bases); h = sh2.handle; sh2.free(); sh2.handle = h; sh2.msm_bigint(sc)
+
+
+def test_handles_run_on_their_owner_context():
+    """a handle created on context 1 is usable from a thread whose current context is 0 (and the other way round)"""
+    G, curve = O.G1, ca.G1
+    bases, sc = _inputs(G, 5000, 91)
+    ref = ca.msm_bigint(curve, bases, sc)
+    assert lib().dgpu_set_device(1) == 0
+    db1 = ca.DeviceBases(curve, bases); ds1 = ca.DeviceScalars(sc)
+    assert lib().dgpu_set_device(0) == 0
+    ds0 = ca.DeviceScalars(sc)
+    assert (db1.msm_bigint(sc) == ref).all() and (db1.msm_resident(ds1) == ref).all()
+    with pytest.raises(ca.DockGpuError):
+        db1.msm_resident(ds0)                      # operands on two different contexts
+    res = {}
+
+    def other():
+        lib().dgpu_set_device(1)
+        res["r"] = ca.msm_bigint(curve, bases, sc)
+    t = threading.Thread(target=other); t.start(); t.join()
+    assert (res["r"] == ref).all()
+    assert lib().dgpu_set_device(5) == -3
+
+
+def test_free_waits_for_calls_in_flight():
+    G, curve = O.G1, ca.G1
+    bases, sc = _inputs(G, 1 << 16, 17)
+    db = ca.DeviceBases(curve, bases)
+    ref = db.msm_bigint(sc)
+    out, errs = [], []
+
+    def worker():
+        for _ in range(30):
+            try:
+                out.append(db.msm_bigint(sc))
+            except ca.DockGpuError as e:            # after the free: bad handle
+                errs.append(e.code)
+    ths = [threading.Thread(target=worker) for _ in range(3)]
+    for t in ths:
+        t.start()
+    time.sleep(0.01)
+    h = db.handle
+    assert lib().dgpu_bases_free(h) == 0           # blocks until the calls using it have returned
+    db.handle = 0
+    for t in ths:
+        t.join()
+    assert out and all((o == ref).all() for o in out)
+    assert all(c == -3 for c in errs)
+    assert lib().dgpu_bases_free(h) == -3
+
+
+def test_size_threshold_default_and_override():
+    L = lib()
+    b = O.G1.generator().reshape(1, 12); s = np.ones((1, 4), np.uint64); out = np.zeros(18, np.uint64)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    try:
+        L.dgpu_set_min_gpu_n(256)                  # the library default (DGPU_DEFAULT_MIN_GPU_N)
+        assert L.dgpu_get_min_gpu_n() == 256
+        assert L.dgpu_msm_g1(p(b), None, p(s), 1, p(out)) == -6          # DGPU_E_TOO_SMALL: the Rust shim stays on arkworks
+        assert L.dgpu_msm_g1_sharded(p(b), None, p(s), 1, 0, p(out)) == -6
+    finally:
+        L.dgpu_set_min_gpu_n(0)
+    assert L.dgpu_msm_g1(p(b), None, p(s), 1, p(out)) == 0

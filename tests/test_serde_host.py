@@ -65,3 +65,40 @@ def test_rejects_malformed_input():
         pass
     with pytest.raises(ValueError):
         serde.deserialize(ca.G2, bytes(95))
+
+
+@pytest.mark.parametrize("curve", [ca.G1, ca.G2])
+def test_validate_yes_rejects_points_outside_the_prime_order_subgroup(curve):
+    """arkworks' deserialize_compressed is Validate::Yes: on the curve is not enough (cofactors ~2^126 / ~2^382, so a point with a
+    small x is outside the subgroup with overwhelming probability).  Validate::No accepts it."""
+    sz = 48 if curve is ca.G1 else 96
+    found = 0
+    for x in range(1, 60):
+        enc = bytearray(sz); enc[-1] = x; enc[0] |= 0x80
+        try:
+            pts, inf = serde.deserialize(curve, bytes(enc), validate=False)
+        except ca.DockGpuError:
+            continue                                   # no point with this x
+        found += 1
+        assert not inf[0]
+        with pytest.raises(ca.DockGpuError):
+            serde.deserialize(curve, bytes(enc))
+        with pytest.raises(ca.DockGpuError):
+            serde.deserialize(curve, serde.serialize(curve, pts, compressed=False), compressed=False)
+        assert serde.deserialize(curve, serde.serialize(curve, pts, compressed=False), compressed=False, validate=False)[0].any()
+        if found == 3:
+            break
+    assert found == 3
+
+
+def test_infinity_encoding_must_be_canonical():
+    ok = bytes([0xc0]) + bytes(47)
+    _, inf = serde.deserialize(ca.G1, ok)
+    assert inf[0] == 1
+    for bad in (bytes([0xe0]) + bytes(47), bytes([0xc1]) + bytes(47), bytes([0xc0]) + bytes(46) + b"\x01"):
+        with pytest.raises(ca.DockGpuError):
+            serde.deserialize(ca.G1, bad)
+    with pytest.raises(ca.DockGpuError):
+        serde.deserialize(ca.G2, bytes([0xc0]) + bytes(94) + b"\x07")
+    with pytest.raises(ca.DockGpuError):
+        serde.deserialize(ca.G1, bytes([0x60]) + bytes(95), compressed=False)         # "largest" flag on an uncompressed encoding

@@ -115,6 +115,7 @@ int32_t dgpu_shutdown(void) {
         const Handle &hd = h.second;
         if (hd.ctx >= 0 && hd.ctx < MAX_CTX && ctxs[hd.ctx].device >= 0) (void)hipSetDevice(ctxs[hd.ctx].device);
         if (hd.kind == 4) free_r1cs_object(hd.p);                       // DevR1cs owns several allocations
+        else if (hd.kind == 10 || hd.kind == 11) { PreTable *pt = (PreTable *)hd.p; (void)hipFree(pt->tab); delete pt; }
         else if (hd.kind >= 7) delete (ShardSet *)hd.p;                 // its per-device parts are table entries of their own
         else (void)hipFree(hd.p);
     }
@@ -153,7 +154,7 @@ int32_t dgpu_set_window_bits(int32_t c) { if (c != 0 && (c < 7 || c > 22)) retur
 // A free waits until no call uses the handle (HandleRef pins), then releases the memory outside the table lock: every entry point
 // synchronises its stream before it returns, so nothing on the device still reads the allocation.
 static void release_parts(const Handle &hd) {
-    if (hd.kind >= 7) {
+    if (hd.kind >= 7 && hd.kind <= 9) {
         ShardSet *ss = (ShardSet *)hd.p;
         for (uint64_t sub : ss->sub) { Handle part; if (take_handle(sub, [](int) { return true; }, part)) release_parts(part); }
         delete ss;
@@ -161,6 +162,7 @@ static void release_parts(const Handle &hd) {
     }
     CtxScope on_owner(hd.ctx);
     if (cur().device >= 0) (void)hipSetDevice(cur().device);
+    if (hd.kind == 10 || hd.kind == 11) { PreTable *pt = (PreTable *)hd.p; (void)hipFree(pt->tab); delete pt; return; }
     (void)hipFree(hd.p);
 }
 static int32_t free_handle(uint64_t h, bool scalars) {

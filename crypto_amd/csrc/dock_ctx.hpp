@@ -28,9 +28,10 @@ struct Buf {
 };
 
 // kind: 1 = G1 bases, 2 = G2 bases, 3 = scalars, 4 = R1CS (DevR1cs*), 5 / 6 = G1 / G2 window table, 7 / 8 = G1 / G2 bases sharded over
-// several devices (ShardSet*), 9 = scalars sharded like a bases set (ShardSet*).  `ctx` = the device context that owns the allocation;
+// several devices (ShardSet*), 9 = scalars sharded like a bases set (ShardSet*), 10 / 11 = G1 / G2 precomputed-multiples table (PreTable*).  `ctx` = the device context that owns the allocation;
 // `inflight` = calls currently using it (a free waits for them: no use-after-free when dgpu_*_free races an MSM on the same handle).
 struct Handle { void *p; size_t n; int kind; int ctx; int inflight; };
+struct PreTable { void *tab; size_t n; int c, W; };      // kind 10 / 11: tab[w * n + i] = prepared record of 2^(c w) P_i (pre_kernels.cuh)
 struct ShardSet { std::vector<uint64_t> sub; std::vector<size_t> lo; size_t n = 0; };   // sub[k] covers [lo[k], lo[k+1]) (lo has sub.size() + 1 entries)
 struct NttDomain { void *tw_f = nullptr, *tw_i = nullptr, *pw_f = nullptr, *pw_i = nullptr, *zinv = nullptr; };   // per log2(D), built once per device
 

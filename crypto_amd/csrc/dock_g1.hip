@@ -12,6 +12,7 @@ int32_t dgpu_msm_g1_sharded(const uint64_t *b, const uint8_t *inf, const uint64_
 int32_t dgpu_bases_upload_g1_sharded(const uint64_t *b, const uint8_t *inf, size_t n, int32_t ngpus, uint64_t *h) { return bases_upload_sharded<G1>(b, inf, n, ngpus, h, 1); }
 int32_t dgpu_msm_g1_sharded_handle(uint64_t b, const uint64_t *s, size_t n, int32_t mont, uint64_t out[18]) { return msm_sharded_handle<G1, hostf::Fq>(b, s, n, mont, out, 1); }
 int32_t dgpu_msm_g1_sharded_resident(uint64_t b, uint64_t s, uint64_t out[18]) { return msm_sharded_resident<G1, hostf::Fq>(b, s, out, 1); }
+int32_t dgpu_bases_precompute_g1(uint64_t h, int32_t window_bits) { return bases_precompute<G1>(h, window_bits, 1); }
 int32_t dgpu_msm_g1_resident(uint64_t b, size_t boff, uint64_t s, size_t soff, size_t n, uint64_t out[18]) { return msm_resident<G1, hostf::Fq>(b, boff, s, soff, n, out, 1); }
 
 int32_t dgpu_selftest_fp_mul(const uint64_t *a, const uint64_t *b, size_t n, uint64_t *out) {

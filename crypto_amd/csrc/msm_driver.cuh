@@ -153,6 +153,174 @@ int32_t msm_device(Slot &sl, const uint32_t *d_bases, const uint32_t *d_scalars,
     return DGPU_OK;
 }
 
+inline void shard_bounds(size_t n, size_t parts, std::vector<size_t> &lo) {
+    lo.resize(parts + 1);
+    const size_t base = n / parts, rem = n % parts;
+    for (size_t k = 0; k <= parts; k++) lo[k] = k * base + std::min(k, rem);       // contiguous, balanced (== sharded.chunk_bounds)
+}
+template <class F> int32_t run_shards(size_t parts, F body) {
+    std::vector<int32_t> rcs(parts, DGPU_OK);
+    std::vector<std::thread> th;
+    for (size_t k = 1; k < parts; k++) th.emplace_back([&, k] { rcs[k] = body(k); });
+    rcs[0] = body(0);
+    for (auto &t : th) t.join();
+    for (int32_t rc : rcs) if (rc) return rc;
+    return DGPU_OK;
+}
+// ---- shared-bucket-set pipeline over a precomputed-multiples table (pre_kernels.cuh, psort_kernels.cuh) ------------------------------------
+
+// window width of a table for n bases: n * W additions + 2 * 2^(c-1) reduction additions is flat between the candidates; 20 bits from
+// 2^19.5 terms on (W = 13), 16 below (W = 16: the table then only removes the per-window bucket sets and the host's Horner fold)
+inline int choose_c_pre(size_t n) {
+    if (gs.window_bits.load() >= 16 && gs.window_bits.load() <= 22) return gs.window_bits.load();
+    return n >= 741455 ? 20 : 16;
+}
+
+// sum_j A_j + 2^lb * sum_j j S_j over the PW pseudo-windows (bucket b = j 2^lb + k of the one bucket set weighs b + 1 = (k + 1) + j 2^lb)
+template <class HF>
+void host_fold_shared(const uint64_t *a_abi, const uint8_t *a_inf, const uint64_t *s_abi, const uint8_t *s_inf, int PW, int lb, uint64_t *out_xyz) {
+    typedef hostf::HXyzz<HF> PT;
+    const size_t FWORDS = sizeof(HF) / 8;
+    auto load = [&](const uint64_t *src, bool inf) { PT t = PT::identity(); if (!inf) { t.inf = false; memcpy(&t.x, src, sizeof(HF)); memcpy(&t.y, src + FWORDS, sizeof(HF)); memcpy(&t.zz, src + 2 * FWORDS, sizeof(HF)); memcpy(&t.zzz, src + 3 * FWORDS, sizeof(HF)); } return t; };
+    PT suffix = PT::identity(), weighted = PT::identity(), total = PT::identity();
+    for (int j = PW - 1; j >= 1; j--) { suffix.add_in_place(load(s_abi + (size_t)j * 4 * FWORDS, s_inf[j] != 0)); weighted.add_in_place(suffix); }   // sum_{j>=1} j S_j
+    for (int k = 0; k < lb; k++) weighted.dbl_in_place();
+    for (int j = 0; j < PW; j++) total.add_in_place(load(a_abi + (size_t)j * 4 * FWORDS, a_inf[j] != 0));
+    total.add_in_place(weighted);
+    HF X, Y, Z; total.to_normalised_jacobian(X, Y, Z);
+    memcpy(out_xyz, &X, sizeof(HF)); memcpy(out_xyz + FWORDS, &Y, sizeof(HF)); memcpy(out_xyz + 2 * FWORDS, &Z, sizeof(HF));
+}
+
+// d_scalars: canonical 8 x u32 per scalar; terms i < n use table rows at column boff + i.  Caller holds the slot.
+template <class C, class HF>
+int32_t msm_device_pre(Slot &sl, const PreTable &pt, size_t boff, const uint32_t *d_scalars, size_t n, uint64_t *out_xyz) {
+    if (n == 0) { typedef hostf::HXyzz<HF> PT; PT id = PT::identity(); HF X, Y, Z; id.to_normalised_jacobian(X, Y, Z);
+        const size_t FWORDS = sizeof(HF) / 8; memcpy(out_xyz, &X, sizeof(HF)); memcpy(out_xyz + FWORDS, &Y, sizeof(HF)); memcpy(out_xyz + 2 * FWORDS, &Z, sizeof(HF)); return DGPU_OK; }
+    const int c = pt.c, W = pt.W;
+    const uint32_t NB = 1u << (c - 1);
+    const int lb = std::min(c - 1, 15);                 // log2 buckets per pseudo-window
+    const int PW = (int)(NB >> lb);
+    const int mshift = std::max(0, lb - 12);
+    const int G = 1 << (lb - 6 - mshift);               // groups per pseudo-window (<= 64)
+    const size_t NG = (size_t)PW * G;
+    const size_t Emax = (size_t)n * W;
+    if (Emax >= (1ull << 32) || (uint64_t)W * pt.n >= (1ull << 31) || W > PS_MAX_W) return DGPU_E_BADARG;
+    const int CH = C::NFP == 2 ? choose_chunk(Emax, 32, 150000) : choose_chunk(Emax, 16, 300000);
+    const size_t T = (Emax + CH - 1) / CH;
+    PsParams q;
+    q.scalars = d_scalars; q.bases = (const uint32_t *)pt.tab; q.n = n; q.aff_stride = C::AFF_STRIDE; q.flag_word = 2 * C::FW; q.flag_base = (uint32_t)boff;
+    q.c = c; q.W = W; q.key_wstride = 0; q.val_base = (uint32_t)boff; q.val_wstride = (uint32_t)pt.n;
+    q.P = (NB + PS_PART - 1) / PS_PART; q.ntiles = (uint32_t)((n + PS_TILE - 1) / PS_TILE);
+    const size_t n1 = (size_t)q.P * q.ntiles;
+    int32_t rc;
+    if ((rc = sl.cnt.ensure((n1 + 1) * 4))) return rc;
+    if ((rc = sl.cursor.ensure((n1 + 1) * 4))) return rc;                 // off1
+    if ((rc = sl.bsums.ensure((scan_blocks(n1) + 2) * 4))) return rc;
+    if ((rc = sl.digits.ensure(Emax * 8))) return rc;                     // (key, val) pairs
+    if ((rc = sl.off.ensure(((size_t)NB + 1) * 4))) return rc;
+    if ((rc = sl.entries.ensure(Emax * 4))) return rc;
+    if ((rc = sl.bucket.ensure(soa_points(NB) * C::XW * 4))) return rc;
+    if ((rc = sl.bucket_inf.ensure(NB))) return rc;
+    if ((rc = sl.head.ensure(soa_points(T) * C::XW * 4))) return rc;
+    if ((rc = sl.tail.ensure(soa_points(T) * C::XW * 4))) return rc;
+    if ((rc = sl.head_b.ensure(T * 4))) return rc;
+    if ((rc = sl.tail_b.ensure(T * 4))) return rc;
+    if ((rc = sl.part_inf.ensure(T * 2))) return rc;
+    if ((rc = sl.l1.ensure(NG * 2 * C::XW * 4))) return rc;
+    if ((rc = sl.l1_inf.ensure(NG * 2))) return rc;
+    if ((rc = sl.win.ensure((size_t)2 * PW * 4 * C::ABI_W * 4))) return rc;        // A_j then S_j
+    if ((rc = sl.win_inf.ensure(2 * PW))) return rc;
+    const uint32_t heavy_thr = 16u * (uint32_t)CH, HEAVY_CAP = (uint32_t)(Emax / heavy_thr) + 1;
+    if ((rc = sl.heavy.ensure(((size_t)HEAVY_CAP + 1) * 4))) return rc;
+    hipStream_t s = sl.stream;
+    {
+        StageTimer st(sl, "msm.psort");
+        HIPCHK(hipMemsetAsync(sl.bucket_inf.p, 1, NB, s));
+        HIPCHK(hipMemsetAsync(sl.heavy.p, 0, 4, s));
+        launch_psort(s, q, NB, sl.cnt.as<uint32_t>(), sl.cursor.as<uint32_t>(), sl.bsums.as<uint32_t>(), sl.digits.p, sl.off.as<uint32_t>(), sl.entries.as<uint32_t>(),
+                     heavy_thr, sl.heavy.as<uint32_t>(), HEAVY_CAP);
+    }
+    {
+        StageTimer st(sl, "msm.accumulate");
+        launch_accumulate<C>(s, (const uint32_t *)pt.tab, sl.entries.as<uint32_t>(), sl.off.as<uint32_t>(), NB, sl.bucket.as<uint32_t>(), sl.bucket_inf.as<uint8_t>(),
+                           sl.head.as<uint32_t>(), sl.tail.as<uint32_t>(), sl.head_b.as<uint32_t>(), sl.tail_b.as<uint32_t>(), sl.part_inf.as<uint8_t>(), T, (uint32_t)CH, 0xffffffffu);
+    }
+    {
+        StageTimer st(sl, "msm.fixup");
+        launch_fixup<C>(s, NB, sl.bucket.as<uint32_t>(), sl.bucket_inf.as<uint8_t>(), sl.head.as<uint32_t>(), sl.tail.as<uint32_t>(),
+                           sl.head_b.as<uint32_t>(), sl.tail_b.as<uint32_t>(), sl.part_inf.as<uint8_t>(), T, sl.off.as<uint32_t>(), heavy_thr);
+        launch_fixup_heavy<C>(s, sl.heavy.as<uint32_t>(), HEAVY_CAP, sl.off.as<uint32_t>(), (uint32_t)CH, NB, sl.bucket.as<uint32_t>(), sl.bucket_inf.as<uint8_t>(),
+                           sl.head.as<uint32_t>(), sl.tail.as<uint32_t>(), sl.part_inf.as<uint8_t>(), T);
+    }
+    uint32_t *win_a = sl.win.as<uint32_t>(), *win_s = win_a + (size_t)PW * 4 * C::ABI_W;
+    uint8_t *inf_a = sl.win_inf.as<uint8_t>(), *inf_s = inf_a + PW;
+    {
+        StageTimer st(sl, "msm.reduce");
+        launch_reduce_l0<C>(s, (unsigned)NG, sl.bucket.as<uint32_t>(), sl.bucket_inf.as<uint8_t>(), NB, mshift, sl.l1.as<uint32_t>(), sl.l1_inf.as<uint8_t>());
+        launch_reduce_top_s<C>(s, (unsigned)PW, sl.l1.as<uint32_t>(), sl.l1_inf.as<uint8_t>(), G, 6 + mshift, win_a, inf_a, win_s, inf_s);
+    }
+    HIPCHK(hipGetLastError());
+    std::vector<uint64_t> hwin((size_t)2 * PW * 2 * C::ABI_W);
+    std::vector<uint8_t> hinf(2 * PW);
+    HIPCHK(hipMemcpyAsync(hwin.data(), sl.win.p, (size_t)2 * PW * 4 * C::ABI_W * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(hinf.data(), sl.win_inf.p, 2 * PW, hipMemcpyDeviceToHost, s));
+    auto tsync0 = std::chrono::steady_clock::now();
+    HIPCHK(hipStreamSynchronize(s));
+    auto tsync1 = std::chrono::steady_clock::now();
+    if (gs.prof) prof_flush(sl);
+    host_fold_shared<HF>(hwin.data(), hinf.data(), hwin.data() + (size_t)PW * 2 * C::ABI_W, hinf.data() + PW, PW, lb, out_xyz);
+    if (gs.prof) {
+        auto t2 = std::chrono::steady_clock::now();
+        prof_add_host("msm.host_wait", std::chrono::duration<double, std::milli>(tsync1 - tsync0).count());
+        prof_add_host("msm.host_fold", std::chrono::duration<double, std::milli>(t2 - tsync1).count());
+    }
+    return DGPU_OK;
+}
+
+// In-place: the bases behind `handle` (kind 1 / 2, or every part of a sharded handle 7 / 8) become precomputed-multiples tables.
+// The handle keeps its id; while the table is being built other calls on it fail with DGPU_E_BADARG.
+template <class C>
+int32_t bases_precompute(uint64_t handle, int32_t window_bits, int kind /* 1 | 2 */) {
+    if (window_bits != 0 && (window_bits < 16 || window_bits > 22)) return DGPU_E_BADARG;
+    Handle hd;
+    { Handle peek; if (!lookup_handle(handle, peek)) return DGPU_E_BADARG;
+      if (peek.kind == kind + 6) {                       // sharded: convert every part
+          HandleRef ref(handle); if (!ref.ok) return DGPU_E_BADARG;
+          const ShardSet &ss = *(const ShardSet *)ref.h.p;
+          return run_shards(ss.sub.size(), [&](size_t k) { return bases_precompute<C>(ss.sub[k], window_bits, kind); });
+      }
+      if (peek.kind == kind + 9) return DGPU_OK; }       // already a table
+    if (!take_handle(handle, [kind](int k) { return k == kind; }, hd)) return DGPU_E_BADARG;
+    auto put_back = [&](void *p, int k) { std::lock_guard<std::mutex> lk(gs.mu); gs.handles[handle] = Handle{p, hd.n, k, hd.ctx, 0}; };
+    CtxScope on_owner(hd.ctx);
+    if (!cur().ready) { put_back(hd.p, kind); return DGPU_E_NODEVICE; }
+    const size_t n = hd.n;
+    const int c = window_bits ? window_bits : choose_c_pre(n);
+    const int W = 255 / c + 1;
+    if (n == 0 || (uint64_t)W * n >= (1ull << 31)) { put_back(hd.p, kind); return n == 0 ? DGPU_OK : DGPU_E_BADARG; }
+    void *tab = nullptr, *tmp = nullptr;
+    int32_t rc = DGPU_OK;
+    {
+        SlotLock L; Slot &sl = *L.s;
+        if (hipSetDevice(cur().device) != hipSuccess) rc = DGPU_E_HIP;
+        const size_t rec = (size_t)C::AFF_STRIDE * 4;
+        if (!rc && hipMalloc(&tab, (size_t)W * n * rec) != hipSuccess) { (void)hipGetLastError(); rc = DGPU_E_OOM; }
+        if (!rc && hipMalloc(&tmp, n * (size_t)C::XW * 4) != hipSuccess) { (void)hipGetLastError(); rc = DGPU_E_OOM; }
+        if (!rc && hipMemcpyAsync(tab, hd.p, n * rec, hipMemcpyDeviceToDevice, sl.stream) != hipSuccess) rc = DGPU_E_HIP;
+        if (!rc) {
+            StageTimer st(sl, "msm.precompute");
+            for (int w = 1; w < W; w++) launch_pre_step<C>(sl.stream, (const uint32_t *)tab + (size_t)(w - 1) * n * C::AFF_STRIDE, n, c, (uint32_t *)tmp, (uint32_t *)tab + (size_t)w * n * C::AFF_STRIDE);
+        }
+        if (!rc && (hipGetLastError() != hipSuccess || hipStreamSynchronize(sl.stream) != hipSuccess)) rc = DGPU_E_HIP;
+        if (gs.prof) prof_flush(sl);
+        if (tmp) (void)hipFree(tmp);
+    }
+    if (rc) { if (tab) (void)hipFree(tab); (void)hipGetLastError(); put_back(hd.p, kind); return rc; }
+    (void)hipFree(hd.p);
+    put_back(new PreTable{tab, n, c, W}, kind + 9);
+    return DGPU_OK;
+}
+
 template <class C>
 int32_t prep_bases(Slot &sl, const uint64_t *h_bases, const uint8_t *h_inf, size_t n, uint32_t *d_out) {
     int32_t rc;
@@ -213,13 +381,14 @@ int32_t msm_handle(uint64_t bases, size_t offset, const uint64_t *scalars, size_
     if (!cur().ready) return DGPU_E_NODEVICE;
     if (check_min && n < gs.min_gpu_n) return DGPU_E_TOO_SMALL;
     HandleRef hb(bases);
-    if (!hb.ok || hb.h.kind != kind || offset > hb.h.n || n > hb.h.n - offset) return DGPU_E_BADARG;
+    if (!hb.ok || (hb.h.kind != kind && hb.h.kind != kind + 9) || offset > hb.h.n || n > hb.h.n - offset) return DGPU_E_BADARG;
     CtxScope on_owner(hb.h.ctx);                    // run where the bases live
     SlotLock L; Slot &sl = *L.s;
     HIPCHK(hipSetDevice(cur().device));
     int32_t rc;
     if ((rc = sl.in_scalars.ensure(std::max<size_t>(n, 1) * 32))) return rc;
     if (n && (rc = upload_scalars(sl, scalars, n, mont != 0, sl.in_scalars.as<uint32_t>()))) return rc;
+    if (hb.h.kind == kind + 9) return msm_device_pre<C, HF>(sl, *(const PreTable *)hb.h.p, offset, sl.in_scalars.as<uint32_t>(), n, out);
     return msm_device<C, HF>(sl, (const uint32_t *)hb.h.p + offset * C::AFF_STRIDE, sl.in_scalars.as<uint32_t>(), n, out);
 }
 
@@ -229,11 +398,12 @@ int32_t msm_resident(uint64_t bases, size_t boff, uint64_t scalars, size_t soff,
     if (!cur().ready) return DGPU_E_NODEVICE;
     if (check_min && n < gs.min_gpu_n) return DGPU_E_TOO_SMALL;
     HandleRef hb(bases), hs(scalars);
-    if (!hb.ok || !hs.ok || hb.h.kind != kind || hs.h.kind != 3 || hb.h.ctx != hs.h.ctx) return DGPU_E_BADARG;    // both operands on one device
+    if (!hb.ok || !hs.ok || (hb.h.kind != kind && hb.h.kind != kind + 9) || hs.h.kind != 3 || hb.h.ctx != hs.h.ctx) return DGPU_E_BADARG;    // both operands on one device
     if (boff > hb.h.n || n > hb.h.n - boff || soff > hs.h.n || n > hs.h.n - soff) return DGPU_E_BADARG;
     CtxScope on_owner(hb.h.ctx);
     SlotLock L; Slot &sl = *L.s;
     HIPCHK(hipSetDevice(cur().device));
+    if (hb.h.kind == kind + 9) return msm_device_pre<C, HF>(sl, *(const PreTable *)hb.h.p, boff, (const uint32_t *)hs.h.p + soff * 8, n, out);
     return msm_device<C, HF>(sl, (const uint32_t *)hb.h.p + boff * C::AFF_STRIDE, (const uint32_t *)hs.h.p + soff * 8, n, out);
 }
 
@@ -241,20 +411,6 @@ int32_t msm_resident(uint64_t bases, size_t boff, uint64_t scalars, size_t soff,
 // One process, one context per device, one host thread per device inside the call: device k runs the whole pipeline on the terms
 // [lo_k, lo_{k+1}) and hands back one normalised Jacobian point (144 / 288 B); the partials are folded on the host.  No collective is
 // needed inside a process; the multi-process form (one rank per GPU, RCCL all_gather of the same partials) stays above the ABI.
-inline void shard_bounds(size_t n, size_t parts, std::vector<size_t> &lo) {
-    lo.resize(parts + 1);
-    const size_t base = n / parts, rem = n % parts;
-    for (size_t k = 0; k <= parts; k++) lo[k] = k * base + std::min(k, rem);       // contiguous, balanced (== sharded.chunk_bounds)
-}
-template <class F> int32_t run_shards(size_t parts, F body) {
-    std::vector<int32_t> rcs(parts, DGPU_OK);
-    std::vector<std::thread> th;
-    for (size_t k = 1; k < parts; k++) th.emplace_back([&, k] { rcs[k] = body(k); });
-    rcs[0] = body(0);
-    for (auto &t : th) t.join();
-    for (int32_t rc : rcs) if (rc) return rc;
-    return DGPU_OK;
-}
 template <class C, class HF>
 int32_t msm_sharded_oneshot(const uint64_t *bases, const uint8_t *is_inf, const uint64_t *scalars, size_t n, int32_t ngpus, bool mont, uint64_t *out) {
     if (!out || (n && (!bases || !scalars)) || n >= (1ull << 31) || ngpus < 0) return DGPU_E_BADARG;

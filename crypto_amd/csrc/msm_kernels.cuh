@@ -325,7 +325,8 @@ __global__ void __launch_bounds__(64) k_reduce_l0(const uint32_t *__restrict__ b
 // g * 2^gshift.  Converts the window sum to the ABI form (X, Y, ZZ, ZZZ; 2^384 Montgomery) for the host.
 template <class C>
 __global__ void __launch_bounds__(64) k_reduce_top(const uint32_t *__restrict__ l1, const uint8_t *__restrict__ l1_inf, int G, int gshift,
-                                                   uint32_t *__restrict__ win_abi, uint8_t *__restrict__ win_inf) {
+                                                   uint32_t *__restrict__ win_abi, uint8_t *__restrict__ win_inf,
+                                                   uint32_t *__restrict__ win_s_abi = nullptr, uint8_t *__restrict__ win_s_inf = nullptr) {
     typedef typename C::F F;
     const int lane = threadIdx.x & 63;
     size_t w = blockIdx.x;
@@ -344,6 +345,10 @@ __global__ void __launch_bounds__(64) k_reduce_top(const uint32_t *__restrict__ 
         if (!ainf) {
             const Fp *f = reinterpret_cast<const Fp *>(&A);
             for (int k = 0; k < 4 * C::NFP; k++) fp_to_abi(dst + 12 * k, f[k]);
+        }
+        if (win_s_abi) {                 // the plain sum of the window's buckets: the next level of the weighted sum is taken on the host
+            win_s_inf[w] = sinf;
+            if (!sinf) { const Fp *f = reinterpret_cast<const Fp *>(&S); for (int k = 0; k < 4 * C::NFP; k++) fp_to_abi(win_s_abi + w * 4 * C::ABI_W + 12 * k, f[k]); }
         }
     }
 }
@@ -424,7 +429,8 @@ __global__ void __launch_bounds__(64) k_reduce_l0_pair(const uint32_t *__restric
 // one wave per window: point-lane q first folds groups 2q and 2q + 1 (weights offset by 2^gshift), then the wave sum over 32 point-lanes
 template <class PAIR>
 __global__ void __launch_bounds__(64) k_reduce_top_pair(const uint32_t *__restrict__ l1, const uint8_t *__restrict__ l1_inf, int G, int gshift,
-                                                        uint32_t *__restrict__ win_abi, uint8_t *__restrict__ win_inf) {
+                                                        uint32_t *__restrict__ win_abi, uint8_t *__restrict__ win_inf,
+                                                        uint32_t *__restrict__ win_s_abi = nullptr, uint8_t *__restrict__ win_s_inf = nullptr) {
     typedef Fp2H F;
     const int q = (threadIdx.x & 63) >> 1;
     const uint32_t h = threadIdx.x & 1u;
@@ -453,6 +459,10 @@ __global__ void __launch_bounds__(64) k_reduce_top_pair(const uint32_t *__restri
         if (!ainf) {
             const Fp *f = reinterpret_cast<const Fp *>(&A);          // x, y, zz, zzz halves
             for (int k = 0; k < 4; k++) fp_to_abi(dst + 12 * (2 * k + h), f[k]);
+        }
+        if (win_s_abi) {
+            if (h == 0) win_s_inf[w] = sinf;
+            if (!sinf) { const Fp *f = reinterpret_cast<const Fp *>(&S); for (int k = 0; k < 4; k++) fp_to_abi(win_s_abi + w * 4 * G2::ABI_W + 12 * (2 * k + h), f[k]); }
         }
     }
 }

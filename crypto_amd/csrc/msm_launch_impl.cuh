@@ -26,7 +26,11 @@ template <class C> void launch_reduce_l0(hipStream_t s, unsigned NG, const uint3
     else hipLaunchKernelGGL((k_reduce_l0<C>), dim3(NG), dim3(64), 0, s, bucket, bucket_inf, NB, mshift, l1, l1_inf);
 }
 template <class C> void launch_reduce_top(hipStream_t s, unsigned W, const uint32_t *l1, const uint8_t *l1_inf, int G, int gshift, uint32_t *win_abi, uint8_t *win_inf) {
-    if constexpr (C::NFP == 2) hipLaunchKernelGGL((k_reduce_top_pair<G2P>), dim3(W), dim3(64), 0, s, l1, l1_inf, G, gshift, win_abi, win_inf);
-    else hipLaunchKernelGGL((k_reduce_top<C>), dim3(W), dim3(64), 0, s, l1, l1_inf, G, gshift, win_abi, win_inf);
+    if constexpr (C::NFP == 2) hipLaunchKernelGGL((k_reduce_top_pair<G2P>), dim3(W), dim3(64), 0, s, l1, l1_inf, G, gshift, win_abi, win_inf, (uint32_t *)nullptr, (uint8_t *)nullptr);
+    else hipLaunchKernelGGL((k_reduce_top<C>), dim3(W), dim3(64), 0, s, l1, l1_inf, G, gshift, win_abi, win_inf, (uint32_t *)nullptr, (uint8_t *)nullptr);
+}
+template <class C> void launch_reduce_top_s(hipStream_t s, unsigned W, const uint32_t *l1, const uint8_t *l1_inf, int G, int gshift, uint32_t *win_abi, uint8_t *win_inf, uint32_t *win_s_abi, uint8_t *win_s_inf) {
+    if constexpr (C::NFP == 2) hipLaunchKernelGGL((k_reduce_top_pair<G2P>), dim3(W), dim3(64), 0, s, l1, l1_inf, G, gshift, win_abi, win_inf, win_s_abi, win_s_inf);
+    else hipLaunchKernelGGL((k_reduce_top<C>), dim3(W), dim3(64), 0, s, l1, l1_inf, G, gshift, win_abi, win_inf, win_s_abi, win_s_inf);
 }
 }  // namespace msm

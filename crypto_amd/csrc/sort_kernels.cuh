@@ -150,7 +150,7 @@ __global__ void __launch_bounds__(1024) k_scan_sums(uint32_t *__restrict__ block
 // out[i] += block_sums[i / SCAN_B]; also writes out[n] = total and copies to cursor
 __global__ void __launch_bounds__(256) k_scan_add(uint32_t *__restrict__ out, uint32_t *__restrict__ cursor, const uint32_t *__restrict__ block_sums, size_t n, size_t nb) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) { uint32_t v = out[i] + block_sums[i / SCAN_B]; out[i] = v; cursor[i] = v; }
+    if (i < n) { uint32_t v = out[i] + block_sums[i / SCAN_B]; out[i] = v; if (cursor) cursor[i] = v; }
     if (i == n) out[n] = block_sums[nb];
 }
 

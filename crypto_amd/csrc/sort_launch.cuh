@@ -12,6 +12,27 @@ void launch_sort_sweep(hipStream_t s, bool wide, bool scatter, unsigned grid, si
                        uint32_t *cnt, const uint32_t *off, uint32_t *entries, uint32_t heavy_thr, uint32_t *heavy, uint32_t heavy_cap);
 void launch_scan(hipStream_t s, const uint32_t *cnt, uint32_t *off, uint32_t *cursor, uint32_t *bsums, size_t NB);
 size_t scan_blocks(size_t NB);
+// ---- two-level partition sort (k_psort.hip, psort_kernels.cuh) ----
+constexpr int PS_TILE = 512;            // scalars per tile = threads per block of P1 / P3
+constexpr int PS_PART_LOG = 11;         // buckets per partition (P4's LDS histogram)
+constexpr int PS_PART = 1 << PS_PART_LOG;
+constexpr int PS_MAX_W = 16;            // pairs staged per scalar (LDS: PS_TILE * PS_MAX_W * 8 B)
+struct PsParams {
+    const uint32_t *scalars;            // n x 8 words, canonical
+    const uint32_t *bases;              // record of term i at bases[(flag_base + i) * aff_stride + flag_word]: != 0 -> identity base, term skipped
+    size_t n;
+    int aff_stride, flag_word;
+    uint32_t flag_base;
+    int c, W;
+    uint32_t key_wstride;
+    uint32_t val_base, val_wstride;
+    uint32_t P;                         // partitions
+    uint32_t ntiles;
+};
+
+// cnt1 / off1: P * ntiles + 1 words; bsums: scan_blocks(P * ntiles) + 2 words; pairs: n * W x 8 B; off: NB + 1; entries: n * W
+void launch_psort(hipStream_t s, const PsParams &q, uint32_t NB, uint32_t *cnt1, uint32_t *off1, uint32_t *bsums, void *pairs, uint32_t *off, uint32_t *entries,
+                  uint32_t heavy_thr, uint32_t *heavy, uint32_t heavy_cap);
 void launch_g1_scale(hipStream_t s, const uint32_t *p_abi, const uint8_t *is_inf, const uint32_t *scalars, int scalar_stride, const uint8_t *negate, size_t n, uint32_t *out_abi, uint8_t *out_inf);
 void launch_selftest_fp_mul(hipStream_t s, const uint32_t *a, const uint32_t *b, size_t n, uint32_t *out);
 void launch_selftest_g1_sum(hipStream_t s, const uint32_t *pts, const uint8_t *neg, size_t n, uint32_t *out, uint8_t *out_inf);

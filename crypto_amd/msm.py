@@ -169,6 +169,14 @@ class DeviceBases:
         self.curve, self.handle, self.n = curve, handle, n
         return self
 
+
+    def precompute(self, window_bits=0):
+        """dgpu_bases_precompute_*: in place; later MSMs on this handle run over the precomputed-multiples table"""
+        rc = self.curve.fn("dgpu_bases_precompute_%s")(self.handle, window_bits)
+        if rc:
+            raise DockGpuError(rc, "dgpu_bases_precompute")
+        return self
+
     def msm_bigint(self, scalars, offset=0, montgomery=False):
         scalars = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
         n = min(len(scalars), self.n - offset)
@@ -224,6 +232,14 @@ class ShardedDeviceBases:
         if rc:
             raise DockGpuError(rc, "dgpu_bases_upload_sharded")
         self.handle = h.value
+
+
+    def precompute(self, window_bits=0):
+        """dgpu_bases_precompute_*: in place; later MSMs on this handle run over the precomputed-multiples table"""
+        rc = self.curve.fn("dgpu_bases_precompute_%s")(self.handle, window_bits)
+        if rc:
+            raise DockGpuError(rc, "dgpu_bases_precompute")
+        return self
 
     def msm_bigint(self, scalars, montgomery=False):
         scalars = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)

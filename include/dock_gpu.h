@@ -88,6 +88,14 @@ int32_t dgpu_scalars_free(uint64_t handle);
 int32_t dgpu_scalars_upload_parts(const uint64_t *const *parts, const size_t *counts, size_t n_parts, int32_t montgomery, uint64_t *handle);
 int32_t dgpu_msm_g1_handle(uint64_t bases, size_t offset, const uint64_t *scalars, size_t n, int32_t montgomery, uint64_t out_xyz[18]);
 int32_t dgpu_msm_g2_handle(uint64_t bases, size_t offset, const uint64_t *scalars, size_t n, int32_t montgomery, uint64_t out_xyz[36]);
+/* Precomputed-multiples mode for a resident query (in place; the handle keeps its id): the device builds table[w][i] = 2^(c w) P_i for the
+ * W = 255 / c + 1 windows (W x the memory: 1.7 GB for a 2^20-point G1 query at c = 20 — sized for 288 GB of HBM), after which every MSM on
+ * the handle adds digit w of scalar i into ONE bucket set shared by all windows: wider windows (13 instead of 16 additions per term at
+ * n = 2^20), 16x fewer buckets to reduce, no Horner fold on the host.  Same group element as before, limb for limb.  window_bits: 0 =
+ * chosen from n, else 16..22.  Works on plain (dgpu_bases_upload_*, dgpu_window_table_mul_to_bases_*) and sharded handles; offsets
+ * (`&query[1..]`) and sub-ranges keep working.  While the table is being built the handle is unavailable (DGPU_E_BADARG). */
+int32_t dgpu_bases_precompute_g1(uint64_t bases, int32_t window_bits);
+int32_t dgpu_bases_precompute_g2(uint64_t bases, int32_t window_bits);
 /* both operands resident: the timed region of bench.py (inputs already in HBM) */
 int32_t dgpu_msm_g1_resident(uint64_t bases, size_t base_offset, uint64_t scalars, size_t scalar_offset, size_t n, uint64_t out_xyz[18]);
 int32_t dgpu_msm_g2_resident(uint64_t bases, size_t base_offset, uint64_t scalars, size_t scalar_offset, size_t n, uint64_t out_xyz[36]);

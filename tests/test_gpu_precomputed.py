@@ -1,0 +1,110 @@
+"""GPU (-m gpu): precomputed-multiples tables for resident bases (dgpu_bases_precompute_*): every MSM on the converted handle must return
+the limbs the plain pipeline returns (and the oracle's point) — all table window widths, offsets (`&query[1..]`), sub-ranges, Montgomery
+scalars, identity bases, edge / skewed / all-equal scalars, G2, sharded handles, and BASELINE config 2's size through a closed form."""
+import numpy as np
+import pytest
+import torch
+import oracle_c as O
+import util as U
+import crypto_amd as ca
+from crypto_amd._native import lib
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _device():
+    assert torch.cuda.is_available()
+    ca.init(0)
+
+
+@pytest.mark.parametrize("gname,n,c", [("G1", 1, 16), ("G1", 700, 16), ("G1", 700, 20), ("G1", 5003, 18), ("G1", 5003, 22), ("G1", (1 << 16) + 3, 0), ("G1", (1 << 16) + 3, 20),
+                                       ("G2", 3001, 16), ("G2", 3001, 20)])
+def test_table_msm_equals_plain_and_oracle(gname, n, c):
+    curve, G = (ca.G1, O.G1) if gname == "G1" else (ca.G2, O.G2)
+    bases, _, _ = U.seq_bases(G, n, 1200 + n, threads=16)
+    sc = O.rand_scalars(1300 + n, n)
+    inf = np.zeros(n, np.uint8)
+    if n > 10:
+        inf[3] = 1; bases[7] = 0                                # flagged and all-zero identity bases
+        sc[0] = 0; sc[1] = O.int_to_limbs(U.R - 1, 4); sc[2] = O.int_to_limbs(1, 4)
+        sc[20:60] = O.int_to_limbs(0xABCDEF, 4)                 # many equal scalars
+    plain = ca.DeviceBases(curve, bases, inf)
+    tab = ca.DeviceBases(curve, bases, inf).precompute(c)
+    ref = plain.msm_bigint(sc)
+    assert (tab.msm_bigint(sc) == ref).all()
+    if n <= 5003:
+        inf2 = inf.copy(); inf2[7:8] = 1 if n > 10 else inf2[7:8]
+        assert U.jac_to_model(G, ref) == U.jac_to_model(G, G.msm(bases, sc, inf2, threads=16))
+    assert (tab.msm_bigint(O.fr_to_mont(sc), montgomery=True) == ref).all()
+    if n > 10:
+        assert (tab.msm_bigint(sc[:n - 1], offset=1) == plain.msm_bigint(sc[:n - 1], offset=1)).all()        # &query[1..]
+        ds = ca.DeviceScalars(sc)
+        assert (tab.msm_resident(ds, n=n // 3, base_offset=5, scalar_offset=9) == plain.msm_resident(ds, n=n // 3, base_offset=5, scalar_offset=9)).all()
+        assert (tab.msm_resident(ds) == ref).all()
+        ds.free()
+    tab.precompute(c)                                           # idempotent
+    assert (tab.msm_bigint(sc) == ref).all()
+    plain.free(); tab.free()
+
+
+def test_skewed_and_degenerate_scalars_on_a_table():
+    G, curve = O.G1, ca.G1
+    n = 1 << 14
+    bases, _, _ = U.seq_bases(G, n, 91, threads=16)
+    plain = ca.DeviceBases(curve, bases); tab = ca.DeviceBases(curve, bases).precompute(20)
+    rng = np.random.default_rng(5)
+    sc = np.zeros((n, 4), np.uint64)
+    kind = rng.integers(0, 4, n)
+    sc[kind == 1, 0] = 1
+    sc[kind == 2, 0] = rng.integers(0, 1 << 16, (kind == 2).sum(), dtype=np.uint64)
+    full = O.rand_scalars(92, n); sc[kind == 3] = full[kind == 3]
+    assert (tab.msm_bigint(sc) == plain.msm_bigint(sc)).all()
+    eq = np.tile(O.int_to_limbs(0xDEADBEEFCAFEF00D1234567, 4), (n, 1))          # one bucket per window holds everything
+    assert (tab.msm_bigint(eq) == plain.msm_bigint(eq)).all()
+    assert (tab.msm_bigint(np.zeros_like(sc)) == plain.msm_bigint(np.zeros_like(sc))).all()
+    hi = full.copy(); hi[:, 3] |= np.uint64(1 << 63)                             # bit 255 is not part of a scalar
+    assert (tab.msm_bigint(hi) == plain.msm_bigint(full)).all()
+    # everything cancels -> identity
+    b2 = np.concatenate([bases[:50], bases[:50]]); b2[50:, 6:] = np.stack([U.fp_abi((-U.fp_int(y)) % U.P) for y in bases[:50, 6:]])
+    t2 = ca.DeviceBases(curve, b2).precompute(16)
+    assert not t2.msm_bigint(np.concatenate([full[:50], full[:50]]))[12:].any()
+
+
+def test_table_2_20_closed_form_and_split():
+    """BASELINE config 2 size on the table path (automatic width: c = 20, W = 13): closed form over known dlogs, split/merge, G2 at 2^18"""
+    G, curve = O.G1, ca.G1
+    n = 1 << 20
+    bases, k0, d = U.seq_bases(G, n, 7777, threads=64)
+    sc = O.rand_scalars(7779, n)
+    tab = ca.DeviceBases(curve, bases).precompute()
+    r = tab.msm_bigint(sc)
+    assert U.jac_to_model(G, r) == U.closed_form(G, sc, k0, d)
+    ds = ca.DeviceScalars(sc)
+    a = tab.msm_resident(ds, n=n // 2)
+    b = tab.msm_resident(ds, n=n - n // 2, base_offset=n // 2, scalar_offset=n // 2)
+    assert U.jac_to_model(G, G.add(a, b)) == U.jac_to_model(G, r)
+    assert (tab.msm_resident(ds) == r).all()
+    tab.free(); ds.free()
+    G, curve = O.G2, ca.G2
+    n = 1 << 18
+    bases, k0, d = U.seq_bases(G, n, 5252, threads=64)
+    sc = O.rand_scalars(5253, n)
+    tab = ca.DeviceBases(curve, bases).precompute(20)
+    assert U.jac_to_model(G, tab.msm_bigint(sc)) == U.closed_form(G, sc, k0, d)
+
+
+def test_sharded_handle_precomputed():
+    ca.init_devices([0, 0])
+    G, curve = O.G1, ca.G1
+    n = 40000
+    bases, _, _ = U.seq_bases(G, n, 55, threads=16)
+    sc = O.rand_scalars(56, n)
+    ref = ca.msm_bigint(curve, bases, sc)
+    sh = ca.ShardedDeviceBases(curve, bases).precompute(18)
+    assert (sh.msm_bigint(sc) == ref).all()
+    ds = sh.upload_scalars(sc)
+    assert (sh.msm_resident(ds) == ref).all()
+    assert (sh.msm_bigint(sc[:25001]) == ca.msm_bigint(curve, bases[:25001], sc[:25001])).all()
+    ds.free(); sh.free()
+    lib().dgpu_set_device(0)

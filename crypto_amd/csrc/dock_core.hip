@@ -30,7 +30,7 @@ int choose_c(size_t n, bool g2) {
     else bc = 8;
     return bc;
 }
-int choose_chunk(size_t E, int min_chunk, size_t max_chunks) {
+int choose_chunk(size_t E, int min_chunk, size_t max_chunks, int lanes_per_chunk) {
     if (gs.chunk) return gs.chunk;
     { const char *e = getenv("DGPU_CHUNK"); if (e) { int v = atoi(e); if (v >= 16 && v <= 4096) return v; } }   // tuning knob: any chunk length gives the same point (tests/test_gpu_msm.py sweeps it)
     // terms per lane.  A lane's chunk is one dependent chain of mixed additions (~12 us each), so short chunks win as long as the
@@ -39,6 +39,17 @@ int choose_chunk(size_t E, int min_chunk, size_t max_chunks) {
     // 128 tie, and at n = 2^24 a fixed 64 left 7 of 8 chunks inside one bucket and the fix-up pass ran at 1/8 lane efficiency.
     int ch = min_chunk;       // 16 for G1; 32 for G2, whose partial slots are folded by the one-lane Fp2 addition of k_fixup
     while (E / (size_t)ch > max_chunks && ch < 4096) ch *= 2;      // G1: 300 k chunks; G2 (two lanes per chunk): 150 k
+    // Whole rounds of the chip: k_accumulate keeps 2 waves per SIMD = 131 072 lanes resident, and a launch lasts as long as its rounds,
+    // full or not (13 windows x 2^20 terms in chunks of 64 are 1.62 rounds and took the time of 2).  Once the launch exceeds one round the
+    // chunk count is snapped to a multiple of the resident chunks and the chunk length follows from it (need not be a power of two).
+    const size_t resident = (size_t)131072 / (size_t)lanes_per_chunk;
+    const size_t chunks = (E + ch - 1) / ch;
+    if (chunks > resident) {
+        size_t rounds = (chunks + resident / 2) / resident;
+        if (rounds < 1) rounds = 1;
+        size_t len = (E + rounds * resident - 1) / (rounds * resident);
+        if (len >= 16 && len <= 4096) ch = (int)len;
+    }
     return ch;
 }
 

@@ -11,6 +11,6 @@ void launch_psort(hipStream_t s, const PsParams &q, uint32_t NB, uint32_t *cnt1,
     hipLaunchKernelGGL(k_ps_count1, dim3(q.ntiles), dim3(PS_TILE), lds1, s, q, cnt1);
     launch_scan(s, cnt1, off1, nullptr, bsums, (size_t)q.P * q.ntiles);
     hipLaunchKernelGGL(k_ps_scatter1, dim3(q.ntiles), dim3(PS_TILE), lds3, s, q, off1, (uint2 *)pairs);
-    hipLaunchKernelGGL(k_ps_bucket, dim3(q.P), dim3(1024), 0, s, (const uint2 *)pairs, off1, q.ntiles, q.P, NB, off, entries, heavy_thr, heavy, heavy_cap);
+    hipLaunchKernelGGL(k_ps_bucket, dim3(q.P), dim3(1024), 0, s, (const uint2 *)pairs, off1, q.ntiles, q.P, NB, q.part_log, off, entries, heavy_thr, heavy, heavy_cap);
 }
 }  // namespace msm

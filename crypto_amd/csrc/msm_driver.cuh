@@ -64,7 +64,7 @@ int32_t msm_device(Slot &sl, const uint32_t *d_bases, const uint32_t *d_scalars,
     const int G = (int)(B >> (6 + mshift));          // groups per window (<= 64), B >= 64 because c >= 7
     const size_t NG = (size_t)W * G;
     const size_t Emax = (size_t)n * W;
-    const int CH = C::NFP == 2 ? choose_chunk(Emax, 32, 150000) : choose_chunk(Emax, 16, 300000);
+    const int CH = C::NFP == 2 ? choose_chunk(Emax, 32, 150000, 2) : choose_chunk(Emax, 16, 300000, 1);
     const size_t T = (Emax + CH - 1) / CH;
     const size_t nblk = scan_blocks(NB);
 
@@ -205,12 +205,12 @@ int32_t msm_device_pre(Slot &sl, const PreTable &pt, size_t boff, const uint32_t
     const size_t NG = (size_t)PW * G;
     const size_t Emax = (size_t)n * W;
     if (Emax >= (1ull << 32) || (uint64_t)W * pt.n >= (1ull << 31) || W > PS_MAX_W) return DGPU_E_BADARG;
-    const int CH = C::NFP == 2 ? choose_chunk(Emax, 32, 150000) : choose_chunk(Emax, 16, 300000);
+    const int CH = C::NFP == 2 ? choose_chunk(Emax, 32, 150000, 2) : choose_chunk(Emax, 16, 300000, 1);
     const size_t T = (Emax + CH - 1) / CH;
     PsParams q;
     q.scalars = d_scalars; q.bases = (const uint32_t *)pt.tab; q.n = n; q.aff_stride = C::AFF_STRIDE; q.flag_word = 2 * C::FW; q.flag_base = (uint32_t)boff;
     q.c = c; q.W = W; q.key_wstride = 0; q.val_base = (uint32_t)boff; q.val_wstride = (uint32_t)pt.n;
-    q.P = (NB + PS_PART - 1) / PS_PART; q.ntiles = (uint32_t)((n + PS_TILE - 1) / PS_TILE);
+    q.part_log = ps_part_log(NB); q.P = (NB + (1u << q.part_log) - 1) >> q.part_log; q.ntiles = (uint32_t)((n + PS_TILE - 1) / PS_TILE);
     const size_t n1 = (size_t)q.P * q.ntiles;
     int32_t rc;
     if ((rc = sl.cnt.ensure((n1 + 1) * 4))) return rc;

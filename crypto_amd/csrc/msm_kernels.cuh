@@ -100,23 +100,24 @@ __global__ void __launch_bounds__(256) k_prep_bases(const uint32_t *__restrict__
 }
 
 // ---- XYZZ <-> memory -------------------------------------------------------------------------------
-// Tiled SoA: points are grouped in tiles of 64; word k of point b lives at base[((b / 64) * XW + k) * 64 + b % 64].
-// Consecutive lanes own consecutive b, so every access is a coalesced 256-byte row, and one point stays inside a
-// 14 KB (G1) tile — a flat word-major layout (stride = array length) put the 56 words of a point on 56 different pages
-// and TLB misses made the 2^24 fix-up pass 8x slower than linear.  Arrays are padded to a multiple of 64 points.
+// One record per point (array of structures): C::XW consecutive words (224 B for G1, 448 B for G2), moved as 16-byte pieces.  A lane
+// that closes a bucket writes its record alone (lanes of a wave close runs at different times), so a word-major layout turned every
+// store into 56 lone 4-byte writes on 56 cache lines: 5.6x write amplification at the HBM (1.04 GB written for 0.18 GB of payload,
+// profiles/r01h_pmc_summary.txt).  A record is two cache lines written once.  The readers (fix-up, bucket reduction) take consecutive
+// records per lane, so each of their lines is used in full as well.  Arrays are padded to a multiple of 64 points.
 constexpr size_t SOA_TILE = 64;
 __host__ __device__ inline size_t soa_points(size_t n) { return (n + SOA_TILE - 1) / SOA_TILE * SOA_TILE; }
 template <class C> __device__ __forceinline__ void store_soa(uint32_t *__restrict__ base, size_t /*count*/, size_t b, const Xyzz<typename C::F> &p) {
     const uint32_t *w = reinterpret_cast<const uint32_t *>(&p);
-    uint32_t *t = base + (b / SOA_TILE) * (C::XW * SOA_TILE) + (b % SOA_TILE);
+    uint32_t *t = base + b * C::XW;
 #pragma unroll
-    for (int k = 0; k < C::XW; k++) t[k * SOA_TILE] = w[k];
+    for (int k = 0; k < C::XW; k += 4) *reinterpret_cast<uint4 *>(t + k) = make_uint4(w[k], w[k + 1], w[k + 2], w[k + 3]);
 }
 template <class C> __device__ __forceinline__ void load_soa(Xyzz<typename C::F> &p, const uint32_t *__restrict__ base, size_t /*count*/, size_t b) {
     uint32_t *w = reinterpret_cast<uint32_t *>(&p);
-    const uint32_t *t = base + (b / SOA_TILE) * (C::XW * SOA_TILE) + (b % SOA_TILE);
+    const uint32_t *t = base + b * C::XW;
 #pragma unroll
-    for (int k = 0; k < C::XW; k++) w[k] = t[k * SOA_TILE];
+    for (int k = 0; k < C::XW; k += 4) { const uint4 v = *reinterpret_cast<const uint4 *>(t + k); w[k] = v.x; w[k + 1] = v.y; w[k + 2] = v.z; w[k + 3] = v.w; }
 }
 template <class C> __device__ __forceinline__ void load_aff(Aff<typename C::F> &p, const uint32_t *__restrict__ rec) {
     uint32_t *w = reinterpret_cast<uint32_t *>(&p);
@@ -131,11 +132,11 @@ template <class C> __device__ __forceinline__ void load_aff(Aff<typename C::F> &
 template <> __device__ __forceinline__ void store_soa<G2P>(uint32_t *__restrict__ base, size_t /*count*/, size_t b, const Xyzz<Fp2H> &p) {
     const uint32_t h = threadIdx.x & 1u;
     const uint32_t *w = reinterpret_cast<const uint32_t *>(&p);      // x, y, zz, zzz halves: 4 x 14 words
-    uint32_t *t = base + (b / SOA_TILE) * (G2P::XW * SOA_TILE) + (b % SOA_TILE);
+    uint32_t *t = base + b * G2P::XW;                               // G2 word order: coordinate k, half h at (2k + h) * NL (56-byte pieces, 8-byte aligned)
 #pragma unroll
     for (int k = 0; k < 4; k++)
 #pragma unroll
-        for (int j = 0; j < NL; j++) t[((2 * k + h) * NL + j) * SOA_TILE] = w[k * NL + j];
+        for (int j = 0; j < NL; j += 2) *reinterpret_cast<uint2 *>(t + (2 * k + h) * NL + j) = make_uint2(w[k * NL + j], w[k * NL + j + 1]);
 }
 template <> __device__ __forceinline__ void load_aff<G2P>(Aff<Fp2H> &p, const uint32_t *__restrict__ rec) {
     const uint32_t h = threadIdx.x & 1u;
@@ -361,11 +362,11 @@ __global__ void __launch_bounds__(64) k_reduce_top(const uint32_t *__restrict__ 
 __device__ __forceinline__ void load_soa_pair(Xyzz<Fp2H> &p, const uint32_t *__restrict__ base, size_t b) {
     const uint32_t h = threadIdx.x & 1u;
     uint32_t *w = reinterpret_cast<uint32_t *>(&p);
-    const uint32_t *t = base + (b / SOA_TILE) * (G2P::XW * SOA_TILE) + (b % SOA_TILE);
+    const uint32_t *t = base + b * G2P::XW;
 #pragma unroll
     for (int k = 0; k < 4; k++)
 #pragma unroll
-        for (int j = 0; j < NL; j++) w[k * NL + j] = t[((2 * k + h) * NL + j) * SOA_TILE];
+        for (int j = 0; j < NL; j += 2) { const uint2 v = *reinterpret_cast<const uint2 *>(t + (2 * k + h) * NL + j); w[k * NL + j] = v.x; w[k * NL + j + 1] = v.y; }
 }
 __device__ __forceinline__ void shfl_down_pair(Xyzz<Fp2H> &o, bool &oinf, const Xyzz<Fp2H> &x, bool xinf, int d /* point-lanes */) {
     const uint32_t *w = reinterpret_cast<const uint32_t *>(&x);

@@ -54,7 +54,7 @@ __global__ void __launch_bounds__(PS_TILE) k_ps_count1(PsParams q, uint32_t *__r
     for (uint32_t j = threadIdx.x; j < q.P; j += blockDim.x) lds[j] = 0;
     __syncthreads();
     const size_t i = (size_t)blockIdx.x * PS_TILE + threadIdx.x;
-    if (ps_live(q, i)) ps_digits(q, i, [&](int w, uint32_t m1, uint32_t) { atomicAdd(&lds[((uint32_t)w * q.key_wstride + m1) >> PS_PART_LOG], 1u); });
+    if (ps_live(q, i)) ps_digits(q, i, [&](int w, uint32_t m1, uint32_t) { atomicAdd(&lds[((uint32_t)w * q.key_wstride + m1) >> q.part_log], 1u); });
     __syncthreads();
     for (uint32_t j = threadIdx.x; j < q.P; j += blockDim.x) cnt1[(size_t)j * q.ntiles + blockIdx.x] = lds[j];
 }
@@ -69,7 +69,7 @@ __global__ void __launch_bounds__(PS_TILE) k_ps_scatter1(PsParams q, const uint3
     __syncthreads();
     const size_t i = (size_t)blockIdx.x * PS_TILE + threadIdx.x;
     const bool live = ps_live(q, i);
-    if (live) ps_digits(q, i, [&](int w, uint32_t m1, uint32_t) { atomicAdd(&cnt[((uint32_t)w * q.key_wstride + m1) >> PS_PART_LOG], 1u); });
+    if (live) ps_digits(q, i, [&](int w, uint32_t m1, uint32_t) { atomicAdd(&cnt[((uint32_t)w * q.key_wstride + m1) >> q.part_log], 1u); });
     __syncthreads();
     // exclusive scan of cnt[0..P): every thread takes P / 512 consecutive bins (P is a power of two >= 1; 512 threads)
     {
@@ -90,7 +90,7 @@ __global__ void __launch_bounds__(PS_TILE) k_ps_scatter1(PsParams q, const uint3
     __syncthreads();
     if (live) ps_digits(q, i, [&](int w, uint32_t m1, uint32_t neg) {
         const uint32_t key = (uint32_t)w * q.key_wstride + m1;
-        const uint32_t pos = atomicAdd(&cur[key >> PS_PART_LOG], 1u);
+        const uint32_t pos = atomicAdd(&cur[key >> q.part_log], 1u);
         stage[pos] = make_uint2(key, (q.val_base + (uint32_t)w * q.val_wstride + (uint32_t)i) | (neg << 31));
     });
     __syncthreads();
@@ -98,43 +98,53 @@ __global__ void __launch_bounds__(PS_TILE) k_ps_scatter1(PsParams q, const uint3
     for (uint32_t wv = 0; wv < PS_TILE / 64; wv++) total += wave_tot[wv];
     for (uint32_t k = threadIdx.x; k < total; k += blockDim.x) {
         const uint2 pr = stage[k];
-        const uint32_t p = pr.x >> PS_PART_LOG;
+        const uint32_t p = pr.x >> q.part_log;
         pairs[(size_t)off1[(size_t)p * q.ntiles + blockIdx.x] + (k - pre[p])] = pr;
     }
 }
 
-// P4: one block per partition
-__global__ void __launch_bounds__(1024) k_ps_bucket(const uint2 *__restrict__ pairs, const uint32_t *__restrict__ off1, uint32_t ntiles, uint32_t P, uint32_t NB,
+// P4: one block per partition of 2^part_log buckets
+__global__ void __launch_bounds__(1024) k_ps_bucket(const uint2 *__restrict__ pairs, const uint32_t *__restrict__ off1, uint32_t ntiles, uint32_t P, uint32_t NB, int part_log,
                                                     uint32_t *__restrict__ off, uint32_t *__restrict__ entries,
                                                     uint32_t heavy_thr, uint32_t *__restrict__ heavy, uint32_t heavy_cap) {
     __shared__ uint32_t cnt[PS_PART];
     __shared__ uint32_t wave_tot[17];
-    const uint32_t p = blockIdx.x;
+    const uint32_t p = blockIdx.x, PB = 1u << part_log, mask = PB - 1;
     const uint32_t lo = off1[(size_t)p * ntiles], hi = off1[(size_t)(p + 1) * ntiles];
     for (uint32_t j = threadIdx.x; j < PS_PART; j += blockDim.x) cnt[j] = 0;
     __syncthreads();
-    for (uint32_t k = lo + threadIdx.x; k < hi; k += blockDim.x) atomicAdd(&cnt[pairs[k].x & (PS_PART - 1)], 1u);
+    constexpr int U = 4;                                              // loads in flight per thread
+    for (uint32_t base = lo; base < hi; base += U * 1024) {
+        uint32_t key[U];
+#pragma unroll
+        for (int j = 0; j < U; j++) { const uint32_t k = base + j * 1024 + threadIdx.x; key[j] = k < hi ? pairs[k].x : 0xffffffffu; }
+#pragma unroll
+        for (int j = 0; j < U; j++) if (key[j] != 0xffffffffu) atomicAdd(&cnt[key[j] & mask], 1u);
+    }
     __syncthreads();
-    // exclusive scan of the 2048 bins: two per thread
+    // exclusive scan of the (up to 2048) bins: two per thread
     const uint32_t c0 = cnt[2 * threadIdx.x], c1 = cnt[2 * threadIdx.x + 1];
     const uint32_t sum = c0 + c1;
     uint32_t incl = sum;
     for (int d = 1; d < 64; d <<= 1) { uint32_t t = __shfl_up(incl, d, 64); if ((int)(threadIdx.x & 63) >= d) incl += t; }
     if ((threadIdx.x & 63) == 63) wave_tot[threadIdx.x >> 6] = incl;
     __syncthreads();
-    uint32_t base = lo;
-    for (uint32_t wv = 0; wv < (threadIdx.x >> 6); wv++) base += wave_tot[wv];
-    const uint32_t e0 = base + incl - sum, e1 = e0 + c0;
+    uint32_t basep = lo;
+    for (uint32_t wv = 0; wv < (threadIdx.x >> 6); wv++) basep += wave_tot[wv];
+    const uint32_t e0 = basep + incl - sum, e1 = e0 + c0;
     __syncthreads();
     cnt[2 * threadIdx.x] = e0; cnt[2 * threadIdx.x + 1] = e1;            // cursors
-    const uint32_t k0 = p * PS_PART + 2 * threadIdx.x;
-    if (k0 < NB) { off[k0] = e0; if (c0 >= heavy_thr) { uint32_t h = atomicAdd(&heavy[0], 1u); if (h < heavy_cap) heavy[1 + h] = k0; } }
-    if (k0 + 1 < NB) { off[k0 + 1] = e1; if (c1 >= heavy_thr) { uint32_t h = atomicAdd(&heavy[0], 1u); if (h < heavy_cap) heavy[1 + h] = k0 + 1; } }
+    const uint32_t j0 = 2 * threadIdx.x, k0 = p * PB + j0;
+    if (j0 < PB && k0 < NB) { off[k0] = e0; if (c0 >= heavy_thr) { uint32_t h = atomicAdd(&heavy[0], 1u); if (h < heavy_cap) heavy[1 + h] = k0; } }
+    if (j0 + 1 < PB && k0 + 1 < NB) { off[k0 + 1] = e1; if (c1 >= heavy_thr) { uint32_t h = atomicAdd(&heavy[0], 1u); if (h < heavy_cap) heavy[1 + h] = k0 + 1; } }
     if (p == P - 1 && threadIdx.x == 0) off[NB] = hi;
     __syncthreads();
-    for (uint32_t k = lo + threadIdx.x; k < hi; k += blockDim.x) {
-        const uint2 pr = pairs[k];
-        entries[atomicAdd(&cnt[pr.x & (PS_PART - 1)], 1u)] = pr.y;
+    for (uint32_t base = lo; base < hi; base += U * 1024) {
+        uint2 pr[U];
+#pragma unroll
+        for (int j = 0; j < U; j++) { const uint32_t k = base + j * 1024 + threadIdx.x; pr[j] = k < hi ? pairs[k] : make_uint2(0xffffffffu, 0u); }
+#pragma unroll
+        for (int j = 0; j < U; j++) if (pr[j].x != 0xffffffffu) entries[atomicAdd(&cnt[pr[j].x & mask], 1u)] = pr[j].y;
     }
 }
 

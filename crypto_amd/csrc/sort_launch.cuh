@@ -14,8 +14,8 @@ void launch_scan(hipStream_t s, const uint32_t *cnt, uint32_t *off, uint32_t *cu
 size_t scan_blocks(size_t NB);
 // ---- two-level partition sort (k_psort.hip, psort_kernels.cuh) ----
 constexpr int PS_TILE = 512;            // scalars per tile = threads per block of P1 / P3
-constexpr int PS_PART_LOG = 11;         // buckets per partition (P4's LDS histogram)
-constexpr int PS_PART = 1 << PS_PART_LOG;
+constexpr int PS_PART_LOG_MAX = 11;     // at most 2048 buckets per partition (P4's LDS histogram)
+constexpr int PS_PART = 1 << PS_PART_LOG_MAX;
 constexpr int PS_MAX_W = 16;            // pairs staged per scalar (LDS: PS_TILE * PS_MAX_W * 8 B)
 struct PsParams {
     const uint32_t *scalars;            // n x 8 words, canonical
@@ -26,10 +26,13 @@ struct PsParams {
     int c, W;
     uint32_t key_wstride;
     uint32_t val_base, val_wstride;
-    uint32_t P;                         // partitions
+    int part_log;                       // log2 buckets per partition: ps_part_log(NB)
+    uint32_t P;                         // partitions = ceil(NB / 2^part_log)
     uint32_t ntiles;
 };
 
+// about a thousand partitions (P4 runs one block per partition) while a partition keeps at least 32 buckets
+inline int ps_part_log(uint32_t NB) { int lg = 0; while ((1u << lg) < NB) lg++; int pl = lg - 10; return pl < 5 ? 5 : (pl > PS_PART_LOG_MAX ? PS_PART_LOG_MAX : pl); }
 // cnt1 / off1: P * ntiles + 1 words; bsums: scan_blocks(P * ntiles) + 2 words; pairs: n * W x 8 B; off: NB + 1; entries: n * W
 void launch_psort(hipStream_t s, const PsParams &q, uint32_t NB, uint32_t *cnt1, uint32_t *off1, uint32_t *bsums, void *pairs, uint32_t *off, uint32_t *entries,
                   uint32_t heavy_thr, uint32_t *heavy, uint32_t heavy_cap);

@@ -1,17 +1,21 @@
 """bench.py — BLS12-381 G1 variable-base MSM throughput on MI355X (BASELINE.json metric).
 
-One "step" = one n-term MSM over operands that are already resident in HBM (prepared bases + canonical
-scalars), through the C ABI (dgpu_msm_g1_resident).  At N = 1 the workload is BASELINE.json configs[1]:
-n = 2^20 random scalars / points.  At N > 1 (one process per GPU, launched by torch.distributed.run) the N
-ranks jointly compute ONE MSM of N * 2^log2n terms per step by point-chunk sharding: each rank runs the full
-pipeline on its own chunk, then an RCCL all_gather of the 144-byte partial points and a local fold
-(crypto_amd/sharded.py).  Per-GPU work is fixed => "scaling": "weak".  value = (terms per step / 2^20) /
-seconds per step, i.e. n=2^20-MSM equivalents per second for the whole job.
+One "step" = one n-term MSM over operands that are already resident in HBM, through the C ABI
+(dgpu_msm_g1_resident): the bases are a proving-key-style resident handle converted once, outside the timed
+region, to the library's precomputed-multiples table (dgpu_bases_precompute_g1: per-key setup, like the upload),
+the scalars a resident canonical vector.  At N = 1 the workload is BASELINE.json configs[1]: n = 2^20 random
+scalars / points.  At N > 1 (one process per GPU, launched by torch.distributed.run) the ranks jointly compute ONE
+MSM of 2^24 terms per step (configs[4]) by point-chunk sharding: each rank runs the full pipeline on its own
+2^24 / N terms, then an RCCL all_gather of the 144-byte partial points and a local fold (crypto_amd/sharded.py).
+value = (terms per step / 2^20) / seconds per step, i.e. n = 2^20-MSM equivalents per second for the whole job.
 
 Extra objects on the JSON line: "roofline" (dominant kernel = k_accumulate, algorithmic bytes = 128 B/term,
-duration from HIP events on the library's stream), "cpu_baseline" (the CPU oracle = arkworks-style Pippenger,
-one thread per window like rayon, timed on this box's host cores; kind "port"), "secondary" (G2 MSM, 1024-pair
-Miller loop, final exponentiation, witness map — N = 1 only, outside the timed region).
+duration from HIP events on the library's stream), "valu_roofline" (the same kernel against the measured
+v_mad_u64_u32 issue peak: the path is integer-multiply bound), "cpu_baseline" (the CPU oracle = arkworks-style
+Pippenger, one thread per window like rayon, timed on this box's host cores; kind "port"; plus one thread and the
+n = 2^16 plumbing config), "secondary" (N = 1 only, outside the timed region: the plain resident pipeline without a
+table, H2D-inclusive and one-shot calls, the skewed scalar distributions of SURVEY 8d, one 2^24-term MSM on this one
+GPU, G2 MSM, 1024-pair Miller loop, final exponentiation, witness map, LegoGroth16 prove at 2^20 constraints).
 
 Inputs and the closed-form check are produced by the library itself (fixed-base kernel, published generator
 encodings); oracle/ is imported only inside the cpu_baseline leg, where it is the timed CPU baseline and the
@@ -36,6 +40,8 @@ R_MOD = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
 G1_GEN_COMPRESSED = "97f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac586c55e83ff97a1aeffb3af00adb22c6bb"
 G2_GEN_COMPRESSED = ("93e02b6052719f607dacd3a088274f65596bd0d09920b61ab5da61bbdc7f5049334cf11213945d57e5ac7d055d042b7e"
                      "024aa2b2f08f0a91260805272dc51051c6e47ad4fa403b02b4510b647ae3d1770bac0326a805bbefd48056c8c121bdb8")
+MADS_PER_MIXED_ADD = 6 * 392 + 588 + 2 * 301     # XYZZ mixed addition: 6 products, one fused two-product reduction, 2 squares
+MAD_PEAK = 31.8                                   # Tmad/s, measured v_mad_u64_u32 issue rate (profiles/r01h_instr_rate_ubench.txt)
 
 
 def seeded_scalars(seed, n):
@@ -60,8 +66,27 @@ def seeded_scalars(seed, n):
         out[ge] = draw(k)
 
 
-def limbs_to_ints(a):
-    return [int(w0) | (int(w1) << 64) | (int(w2) << 128) | (int(w3) << 192) for w0, w1, w2, w3 in a.tolist()]
+def dot_mod_r(a, b):
+    """sum a_i b_i mod r for two (n, 4) uint64 limb arrays, exactly: 16-bit pieces, float64 matrix products over chunks of 2^20 rows
+    (every partial sum < 2^32 * 2^20 = 2^52 is exact in a double) — the closed form the timed result is checked against"""
+    a16 = np.ascontiguousarray(a).view(np.uint16).reshape(len(a), 16)
+    b16 = np.ascontiguousarray(b).view(np.uint16).reshape(len(b), 16)
+    tot = 0
+    for lo in range(0, len(a), 1 << 20):
+        m = a16[lo:lo + (1 << 20)].astype(np.float64).T @ b16[lo:lo + (1 << 20)].astype(np.float64)
+        for i in range(16):
+            for j in range(16):
+                tot += int(m[i, j]) << (16 * (i + j))
+    return tot % R_MOD
+
+
+def timed(fn, k=5, warm=1):
+    for _ in range(warm):
+        fn()
+    t0 = time.perf_counter()
+    for _ in range(k):
+        fn()
+    return (time.perf_counter() - t0) / k * 1e3
 
 
 def main():
@@ -69,10 +94,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--log2n", type=int, default=20, help="terms per GPU = 2^log2n (BASELINE: 20 at 1 GPU, 21 per GPU for 2^24 on 8)")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the G2 / Miller-loop / witness-map timings appended to the JSON line at N = 1")
+    ap.add_argument("--log2n", type=int, default=0, help="terms per GPU = 2^log2n; default: 20 at 1 GPU (BASELINE config 2), 24 - log2(gpus) at N > 1 (config 5: 2^24 in total)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary timings appended to the JSON line at N = 1")
     ap.add_argument("--inflight", type=int, default=4, help="MSM calls in flight per GPU (host threads; each call owns a stream + workspace slot)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-table", action="store_true", help="time the plain resident pipeline (no precomputed-multiples table)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -97,26 +123,30 @@ def main():
     from crypto_amd import sharded, serde, fixed_base as FB
 
     ca.init(local)
+    if args.log2n == 0:
+        lg = 0
+        while (1 << lg) < world:
+            lg += 1
+        args.log2n = 20 if world == 1 else max(16, 24 - lg)
     n = 1 << args.log2n
     ncpu = os.cpu_count() or 1
-    # Synthetic inputs with known discrete logs: P_i = (k0 + (off + i) d) G, scalars uniform in [0, r).  Everything here comes from the
-    # library itself (the bases from its fixed-base kernel); the CPU oracle is only touched by the cpu_baseline leg at the end.
-    K0 = int.from_bytes(np.random.Generator(np.random.PCG64(0x5EED0002)).bytes(40), "little") % R_MOD
-    D = int.from_bytes(np.random.Generator(np.random.PCG64(0x5EED0003)).bytes(40), "little") % R_MOD
-    off = rank * n
+    # Synthetic inputs with known discrete logs: P_i = k_i G with seeded k_i, scalars uniform in [0, r).  Everything here comes from the
+    # library itself (the bases from its fixed-base kernel, straight into a resident handle); the CPU oracle is only touched by the
+    # cpu_baseline leg at the end.
     gen1, _ = serde.deserialize(ca.G1, bytes.fromhex(G1_GEN_COMPRESSED))
-    kints, k = [], (K0 + off * D) % R_MOD
-    for _ in range(n):
-        kints.append(k)
-        k += D
-        if k >= R_MOD:
-            k -= R_MOD
-    with FB.WindowTable(ca.G1, gen1[0]) as gtab:
-        bases, binf = gtab.multiply_many(kints)
-    assert not binf.any()
+    ks = seeded_scalars(0x5EED2000 + rank, n)
     scalars = seeded_scalars(0x5EED1000 + rank, n)
-    db = ca.DeviceBases(ca.G1, bases)
+    t_setup = time.perf_counter()
+    with FB.WindowTable(ca.G1, gen1[0]) as gtab:
+        db = gtab.multiply_many_to_bases(ks)
+    use_table = not args.no_table
+    table_ms = 0.0
+    if use_table:
+        t0 = time.perf_counter()
+        db.precompute()
+        table_ms = (time.perf_counter() - t0) * 1e3
     ds = ca.DeviceScalars(scalars)
+    t_setup = time.perf_counter() - t_setup
 
     def step():
         part = db.msm_resident(ds)
@@ -125,7 +155,7 @@ def main():
     # correctness of what is timed: closed form (sum s_i k_i) G over ALL ranks' terms; the expected point comes from the fixed-base path
     # (a different kernel family), the comparison against the CPU oracle is part of the cpu_baseline leg
     res = step()
-    loc = sum(sv * kv for sv, kv in zip(limbs_to_ints(scalars), kints)) % R_MOD
+    loc = dot_mod_r(ks, scalars)
     if world > 1:
         allv = [None] * world
         dist.all_gather_object(allv, loc)
@@ -197,21 +227,27 @@ def main():
         if os.path.exists(tj):
             try:
                 tr = json.load(open(tj))
-                if tr.get("log2n") == args.log2n:
+                if tr.get("log2n") == args.log2n and bool(tr.get("table")) == use_table:
                     traffic = tr.get("hbm_bytes_per_launch")
             except Exception:
                 pass
-        # integer-throughput view of the same kernel (the path is VALU-bound, SURVEY.md 8d honesty note)
-        mads_per_term_window = 6 * 392 + 588 + 2 * 301     # mixed add: 6 products, one fused two-product reduction, 2 squares
+        windows = (13 if n >= 741455 else 16) if use_table else (16 if args.log2n >= 17 else None)
         out = {
             "metric": "BLS12-381 G1 MSM/s at n=2^20 (1 GPU) and n=2^24 (8 GPU); bit-exact vs CPU",
             "value": round(value, 3), "unit": "MSM/s (n=2^20-term equivalents, whole job)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32 (29-bit limbs, 381-bit modular integer)",
-            "data": "synthetic (seeded PCG64 scalars uniform in [0, r); bases (k0 + i d) G with known discrete logs from the fixed-base kernel)",
-            "config": {"workload": "BLS12-381 G1 variable-base MSM, n=2^%d terms per GPU, operands resident in HBM, %s" % (
-                args.log2n, "1xMI355X" if world == 1 else "%dxMI355X point-chunk sharded, RCCL all_gather of partial points" % world),
-                "terms_per_step": terms, "bit_exact_vs_closed_form": bit_exact, "parallelism": "1 process per GPU, %d ranks, %d calls in flight per GPU" % (world, inflight)},
+            "higher_is_better": True, "scaling": "weak" if world == 1 else "strong", "vs_baseline": None,
+            "dtype": "u32 (29-bit limbs, 381-bit modular integer)",
+            "data": "synthetic (seeded PCG64 scalars uniform in [0, r); bases k_i G with seeded known discrete logs from the fixed-base kernel)",
+            "config": {"workload": "BLS12-381 G1 variable-base MSM, n=2^%d terms per GPU, operands resident in HBM (%s), %s" % (
+                args.log2n, "bases as a precomputed-multiples table built once per key outside the timed region" if use_table else "plain prepared bases",
+                "1xMI355X" if world == 1 else "one 2^%d-term MSM per step point-chunk sharded over %dxMI355X, RCCL all_gather of partial points" % (
+                    args.log2n + (world - 1).bit_length(), world)),
+                "terms_per_step": terms, "bit_exact_vs_closed_form": bit_exact,
+                "parallelism": "1 process per GPU, %d ranks, %d calls in flight per GPU" % (world, inflight),
+                "per_key_setup_ms": {"fixed_base_bases_and_uploads": round(t_setup * 1e3 - table_ms, 1), "precomputed_table": round(table_ms, 1)},
+                "scaling_note": "N = 1 is BASELINE config 2 (2^20 terms); every N > 1 computes config 5's 2^24 terms in total, so the N > 1 "
+                                "values are a strong-scaling series; secondary.g1_2p24_single_gpu is the 1-GPU time of the same 2^24 terms"},
             "terms_per_s": round(terms / (dt / args.steps), 1),
             "inflight": inflight, "latency_ms_one_in_flight": round(latency_ms, 4),
             "stages_ms": {k.replace("msm.", ""): round(v[0] / max(1, v[1]), 4) for k, v in stages.items()},
@@ -222,33 +258,17 @@ def main():
                                  "untimed pass; rocprof of `bench.py --inflight 1` agrees), avg_ms_overlapped = inside the timed region where launches "
                                  "share the chip; the kernel is integer-multiply bound: see valu_roofline"},
         }
-        if acc_avg_ms > 0 and "msm.accumulate" in stages:
-            W = 16 if args.log2n >= 17 else None
-            if W:
-                mads = float(n) * W * mads_per_term_window
-                out["valu_roofline"] = {"bound": "v_mad_u64_u32", "achieved": round(mads / (acc_avg_ms * 1e-3) / 1e12, 3),
-                                        "peak": 31.8, "unit": "Tmad/s", "frac": round(mads / (acc_avg_ms * 1e-3) / 1e12 / 31.8, 4),
-                                        "note": "peak = measured v_mad_u64_u32 issue rate, profiles/r01_instr_rate_ubench.txt"}
+        if acc_avg_ms > 0 and windows:
+            mads = float(n) * windows * MADS_PER_MIXED_ADD
+            out["valu_roofline"] = {"bound": "v_mad_u64_u32", "achieved": round(mads / (acc_avg_ms * 1e-3) / 1e12, 3), "peak": MAD_PEAK, "unit": "Tmad/s",
+                                    "frac": round(mads / (acc_avg_ms * 1e-3) / 1e12 / MAD_PEAK, 4), "mixed_additions_per_launch": int(n) * windows,
+                                    "note": "%d windows x n mixed additions x %d v_mad_u64_u32 each; peak = measured issue rate, profiles/r01h_instr_rate_ubench.txt" % (
+                                        windows, MADS_PER_MIXED_ADD)}
         if not args.no_cpu_baseline:
-            # arkworks-style Pippenger, one task per window (17 windows at n=2^20 => at most 17 busy threads)
-            sys.path.insert(0, os.path.join(ROOT, "oracle"))
-            import oracle_c as O             # test infrastructure, used here only as the timed CPU baseline and its cross-check
-            log2s = min(args.log2n, 20)
-            ns = 1 << log2s
-            c = O.window_c(ns)
-            nw = (255 + c - 1) // c
-            thr = max(1, min(ncpu, nw))
-            tb = time.perf_counter()
-            ref = O.G1.msm(bases[:ns], scalars[:ns], threads=thr)
-            tcpu = time.perf_counter() - tb
-            chk = db.msm_resident(ds, n=ns)
-            same = bool((O.G1.to_affine(ref)[0] == O.G1.to_affine(chk)[0]).all())
-            out["cpu_baseline"] = {"value": round((ns / float(1 << 20)) / tcpu, 4), "unit": "MSM/s (n=2^20-term equivalents)", "cores": thr,
-                                   "kind": "port", "sample": "one n=2^%d G1 MSM, %.2f s wall on %d threads of %d logical CPUs; result bit-exact vs GPU: %s" % (
-                                       log2s, tcpu, thr, ncpu, same)}
+            out["cpu_baseline"] = cpu_baseline(ca, gen1, ks, scalars, db, ds, args.log2n, ncpu)
         if world == 1 and not args.no_secondary:
             try:
-                out["secondary"] = secondary_configs(args.log2n)
+                out["secondary"] = secondary_configs(args.log2n, ks, scalars, db, ds, pool)
             except Exception as e:                      # never let the secondary numbers take the headline line down
                 out["secondary"] = {"error": repr(e)}
         print(json.dumps(out))
@@ -256,37 +276,129 @@ def main():
         dist.destroy_process_group()
 
 
-def secondary_configs(log2n):
-    """BASELINE configs 3 and 4 next to the headline, outside the timed region (N = 1 only, a few seconds): G2 MSM at the same n,
-    the 1024-pair Miller loop + final exponentiation, the R1CS->QAP witness map at D = 2^log2n.  Inputs are synthetic: G2 bases and the
-    pairing inputs are device fixed-base products of seeded scalars (parity of these paths is the GPU test-suite's job, not this one's)."""
-    import numpy as np
+def cpu_baseline(ca, gen1, ks, scalars, db, ds, log2n, ncpu):
+    """arkworks-style Pippenger on the host cores (the oracle: test infrastructure, used here only as the timed CPU baseline and its cross-check):
+    one task per window like rayon (17 windows at n = 2^20 => at most 17 busy threads), the same on ONE thread, and BASELINE config 1 (n = 2^16)."""
+    from crypto_amd import fixed_base as FB
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_c as O
+    log2s = min(log2n, 20)
+    ns = 1 << log2s
+    with FB.WindowTable(ca.G1, gen1[0]) as gtab:
+        bases, _ = gtab.multiply_many(ks[:ns])               # host copies of the first ns bases
+    c = O.window_c(ns)
+    nw = (255 + c - 1) // c
+    thr = max(1, min(ncpu, nw))
+    tb = time.perf_counter()
+    ref = O.G1.msm(bases, scalars[:ns], threads=thr)
+    tcpu = time.perf_counter() - tb
+    chk = db.msm_resident(ds, n=ns)
+    same = bool((O.G1.to_affine(ref)[0] == O.G1.to_affine(chk)[0]).all())
+    res = {"value": round((ns / float(1 << 20)) / tcpu, 4), "unit": "MSM/s (n=2^20-term equivalents)", "cores": thr, "kind": "port",
+           "sample": "one n=2^%d G1 MSM, %.2f s wall on %d threads (one per window, arkworks' rayon structure) of %d logical CPUs; result bit-exact vs GPU: %s" % (
+               log2s, tcpu, thr, ncpu, same)}
+    l1 = min(log2s, 18)                                      # one thread: a 2^18 sample (about 4 s), scaled per term
+    tb = time.perf_counter()
+    O.G1.msm(bases[:1 << l1], scalars[:1 << l1], threads=1)
+    t1 = time.perf_counter() - tb
+    res["one_thread"] = {"value": round(((1 << l1) / float(1 << 20)) / t1, 4), "unit": "MSM/s (n=2^20-term equivalents)", "cores": 1,
+                         "sample": "one n=2^%d G1 MSM on one thread, %.2f s" % (l1, t1)}
+    l16 = min(log2s, 16)
+    c16 = O.window_c(1 << l16)
+    thr16 = max(1, min(ncpu, (255 + c16 - 1) // c16))
+    tb = time.perf_counter()
+    r16 = O.G1.msm(bases[:1 << l16], scalars[:1 << l16], threads=thr16)
+    t16 = time.perf_counter() - tb
+    same16 = bool((O.G1.to_affine(r16)[0] == O.G1.to_affine(db.msm_resident(ds, n=1 << l16))[0]).all())
+    res["config1_n_2p16"] = {"ms": round(t16 * 1e3, 2), "msm_per_s": round(1.0 / t16, 2), "cores": thr16,
+                             "sample": "BASELINE config 1: one n=2^%d G1 MSM on the CPU path (%d threads); bit-exact vs GPU: %s" % (l16, thr16, same16)}
+    return res
+
+
+def secondary_configs(log2n, ks, scalars, db, ds, pool):
+    """Everything BASELINE / SURVEY 8d ask for next to the headline, outside the timed region (N = 1 only).  Inputs are synthetic: bases are
+    device fixed-base products of seeded scalars (parity of these paths is the GPU test-suite's job, not this one's)."""
     import crypto_amd as ca
-    from crypto_amd import fixed_base as FB, qap, serde
+    from crypto_amd import fixed_base as FB, qap, serde, legogroth16 as LG
     gen1, _ = serde.deserialize(ca.G1, bytes.fromhex(G1_GEN_COMPRESSED))
     gen2, _ = serde.deserialize(ca.G2, bytes.fromhex(G2_GEN_COMPRESSED))
-
-    def timed(fn, k=5):
-        fn()
-        t0 = time.perf_counter()
-        for _ in range(k):
-            fn()
-        return (time.perf_counter() - t0) / k * 1e3
-
     n = 1 << log2n
     res = {}
+
+    def thr4(fn, k=16):
+        list(pool.map(lambda _: fn(), range(4)))
+        t0 = time.perf_counter()
+        list(pool.map(lambda _: fn(), range(k)))
+        return (time.perf_counter() - t0) / k * 1e3
+
+    with FB.WindowTable(ca.G1, gen1[0]) as t1:
+        plain = t1.multiply_many_to_bases(ks)
+        host_bases, _ = t1.multiply_many(ks)
+    # -- the plain resident pipeline (no table): what a handle costs before dgpu_bases_precompute_g1
+    res["plain_resident"] = {"latency_ms": round(timed(lambda: plain.msm_resident(ds)), 3), "ms_per_msm_4_in_flight": round(thr4(lambda: plain.msm_resident(ds)), 3)}
+    res["plain_resident"]["msm_per_s"] = round(1e3 / res["plain_resident"]["ms_per_msm_4_in_flight"], 2)
+    # -- H2D-inclusive (SURVEY 8d config 2): fresh host scalars per call against the resident key (32 B/term over PCIe), and the full one-shot
+    #    call (bases + scalars from host memory: 128 B/term) — never `value`
+    res["h2d_inclusive"] = {
+        "resident_table_fresh_scalars_ms": round(timed(lambda: db.msm_bigint(scalars)), 3),
+        "resident_table_fresh_scalars_ms_per_msm_4_in_flight": round(thr4(lambda: db.msm_bigint(scalars), 12), 3),
+        "resident_plain_fresh_scalars_ms": round(timed(lambda: plain.msm_bigint(scalars)), 3),
+        "one_shot_bases_and_scalars_ms": round(timed(lambda: ca.msm_bigint(ca.G1, host_bases, scalars), 3), 3),
+        "note": "dgpu_msm_g1_handle (upload of n x 32 B scalars inside the call) and dgpu_msm_g1 (n x 128 B inside the call), pageable host memory"}
+    del host_bases
+    # -- SURVEY 8d secondary scalar distributions, on the table path, one call in flight
+    rng = np.random.Generator(np.random.PCG64(0x5EED0009))
+    d = {}
+    eq = np.tile(scalars[7], (n, 1))
+    d["all_equal_scalars_ms"] = round(timed(lambda: db.msm_bigint(eq), 3), 3)
+    s16 = np.zeros((n, 4), np.uint64); s16[:, 0] = rng.integers(0, 1 << 16, n, dtype=np.uint64)
+    d["16_bit_scalars_ms"] = round(timed(lambda: db.msm_bigint(s16), 3), 3)
+    zo = scalars.copy(); kind = rng.integers(0, 4, n); zo[kind <= 1] = 0; zo[kind == 1, 0] = 1
+    d["half_zeros_ones_ms"] = round(timed(lambda: db.msm_bigint(zo), 3), 3)
+    d["uniform_ms"] = round(timed(lambda: db.msm_bigint(scalars), 3), 3)
+    res["scalar_distributions_fresh_scalars"] = d
+    plain.free()
+    del eq, s16, zo
+    # -- BASELINE config 5's 2^24 terms on this ONE GPU: the denominator of the ">= 6x further at 8 GPUs" target
+    try:
+        n24 = 1 << 24
+        k24 = seeded_scalars(0x5EED2400, n24); s24 = seeded_scalars(0x5EED2401, n24)
+        with FB.WindowTable(ca.G1, gen1[0]) as t1:
+            b24 = t1.multiply_many_to_bases(k24)
+            tot = dot_mod_r(k24, s24)
+            exp_xy, _ = t1.multiply(tot)
+        t0 = time.perf_counter(); b24.precompute(); tab24 = (time.perf_counter() - t0) * 1e3
+        d24 = ca.DeviceScalars(s24)
+        r24 = b24.msm_resident(d24)
+        ok = bool((r24[:12] == exp_xy).all())
+        lat = timed(lambda: b24.msm_resident(d24), 3)
+        list(pool.map(lambda _: b24.msm_resident(d24), range(2)))
+        t0 = time.perf_counter(); list(pool.map(lambda _: b24.msm_resident(d24), range(4))); thr = (time.perf_counter() - t0) / 4 * 1e3
+        res["g1_2p24_single_gpu"] = {"latency_ms": round(lat, 2), "ms_per_msm_4_in_flight": round(thr, 2), "msm_2p20_equivalents_per_s": round(16e3 / thr, 2),
+                                     "table_build_ms": round(tab24, 1), "bit_exact_vs_closed_form": ok}
+        b24.free(); d24.free(); del k24, s24
+    except Exception as e:          # noqa: BLE001
+        res["g1_2p24_single_gpu"] = {"error": repr(e)}
+    # -- BASELINE config 3: G2 MSM at the same n (plain and table), 1024-pair Miller loop, final exponentiation
     with FB.WindowTable(ca.G2, gen2[0]) as t2, FB.WindowTable(ca.G1, gen1[0]) as t1:
         db2 = t2.multiply_many_to_bases(seeded_scalars(0x5EED0003, n))
-        ds = ca.DeviceScalars(seeded_scalars(0x5EED0004, n))
+        res["g2_msm_plain_ms"] = round(timed(lambda: db2.msm_resident(ds), 3), 3)
+        db2.precompute()
         res["g2_msm_ms"] = round(timed(lambda: db2.msm_resident(ds), 3), 3)
-        res["g2_msm_per_s"] = round(1e3 / res["g2_msm_ms"], 2)
-        db2.free(); ds.free()
+        res["g2_msm_ms_per_msm_4_in_flight"] = round(thr4(lambda: db2.msm_resident(ds), 8), 3)
+        res["g2_msm_per_s"] = round(1e3 / res["g2_msm_ms_per_msm_4_in_flight"], 2)
         P, _ = t1.multiply_many(seeded_scalars(0x5EED0005, 1024)); Q, _ = t2.multiply_many(seeded_scalars(0x5EED0006, 1024))
     f = ca.multi_miller_loop(P, Q)
     res["miller_loop_1024_pairs_ms"] = round(timed(lambda: ca.multi_miller_loop(P, Q)), 3)
     res["miller_loop_pairs_per_s"] = round(1024 / res["miller_loop_1024_pairs_ms"] * 1e3, 0)
+    from crypto_amd import pairing
+    pc = pairing.G2Prepared.from_affine(Q)
+    assert (pairing.multi_miller_loop(P, pc) == f).all()
+    res["g2_prepare_1024_ms"] = round(timed(lambda: pairing.G2Prepared.from_affine(Q)), 3)
+    res["miller_loop_1024_prepared_pairs_ms"] = round(timed(lambda: pairing.multi_miller_loop(P, pc)), 3)
     res["final_exponentiation_ms"] = round(timed(lambda: ca.final_exponentiation(f)), 3)
-    # witness map on the x_i = x_{i-1}^2 + i circuit shape (m + 1 constraints + 2 instance variables = D), circuit resident
+    # -- BASELINE config 4: witness map on the x_i = x_{i-1}^2 + i circuit shape (m + 1 constraints + 2 instance variables = D), circuit resident,
+    #    and LegoGroth16 create_proof (prover.rs:267-383) on a synthetic key of that size with every query a precomputed table
     m = n - 3
     idx = np.arange(m, dtype=np.uint32)
     one = np.zeros((1, 4), np.uint64); one[0, 0] = 1
@@ -296,12 +408,40 @@ def secondary_configs(log2n):
     c_cl = np.concatenate([np.stack([3 + idx, np.zeros(m, np.uint32)], 1).reshape(-1), [1]]).astype(np.uint32)
     circ = qap.DeviceR1cs((a_rp, a_cl, a_vl), (a_rp, b_cl, a_vl), (c_rp, c_cl, np.repeat(one, 2 * m + 1, 0)), m + 3, 2, m + 1)
     z = seeded_scalars(0x5EED0007, m + 3)
+    rngw = np.random.Generator(np.random.PCG64(0x5EED0008))       # Groth16-like witness: half in {0, 1}, a quarter 16-bit, a quarter full-size
+    kd = rngw.integers(0, 4, m + 3)
+    z[kd <= 1] = 0; z[kd == 1, 0] = rngw.integers(0, 2, int((kd == 1).sum()), dtype=np.uint64)
+    mk = kd == 2; z[mk, 1:] = 0; z[mk, 0] &= np.uint64(0xFFFF)
 
     def wm():
         _, dh = circ.witness_map(z, to_host=False, resident=True)
         dh.free()
     res["witness_map_ms"] = round(timed(wm, 3), 3)
-    res["note"] = "n = D = 2^%d; one call in flight; host-visible wall time per call" % log2n
+    cw = 2
+    V = m + 2                                          # variables 1 .. m + 2 pair with query[1..]
+    with FB.WindowTable(ca.G2, gen2[0]) as t2, FB.WindowTable(ca.G1, gen1[0]) as t1:
+        small1, _ = t1.multiply_many(seeded_scalars(0x5EED0010, 8 + 2 + cw)); small2, _ = t2.multiply_many(seeded_scalars(0x5EED0011, 4))
+        qa = t1.multiply_many_to_bases(seeded_scalars(0x5EED0012, V + 1)).precompute()
+        qb1 = t1.multiply_many_to_bases(seeded_scalars(0x5EED0013, V + 1)).precompute()
+        qb2 = t2.multiply_many_to_bases(seeded_scalars(0x5EED0014, V + 1)).precompute()
+        qh = t1.multiply_many_to_bases(seeded_scalars(0x5EED0015, n - 1)).precompute()
+        ql = t1.multiply_many_to_bases(seeded_scalars(0x5EED0016, m + 1 - cw)).precompute()
+    vk = LG.VerifyingKey(small1[0], small2[0], small2[1], small2[2], small1[8:8 + 2 + cw], small1[1], cw)
+    pk = LG.ProvingKey.from_device(vk, small1[2], small1[3], small1[4], small1[5], small1[6], small2[3], qa, qb1, qb2, qh, ql)
+
+    def prove():
+        _, dh = circ.witness_map(z, to_host=False, resident=True)
+        pr = LG.create_proof(pk, 123456789, 987654321, 555, dh, z[:2], z[2:])
+        dh.free()
+        return pr
+    p0 = prove()
+    ms = timed(prove, 4, warm=1)
+    assert all((prove()[k] == p0[k]).all() for k in p0)
+    res["prove_2p20_ms"] = round(ms, 2)
+    res["prove_constraints_per_s"] = round((m + 1) / (ms * 1e-3), 1)
+    res["prove_note"] = ("LegoGroth16 create_proof (witness map + 4 G1 MSMs + 1 G2 MSM + finish), m + 1 = %d constraints, D = 2^%d, Groth16-like witness, "
+                         "circuit and key (precomputed tables) resident, assignment uploaded per proof" % (m + 1, log2n))
+    res["note"] = "n = D = 2^%d; one call in flight unless stated; host-visible wall time per call" % log2n
     return res
 
 

@@ -181,7 +181,14 @@ __global__ void __launch_bounds__(256, C::ACC_WAVES) k_accumulate(const uint32_t
             if (started_before) { store_soa<C>(head, T, t, acc); part_inf[2 * t] = inf; hb = b; started_before = false; }
             else { store_soa<C>(bucket, NB, b, acc); bucket_inf[b] = inf; }
             inf = true;
-            do { b++; bend = off[b + 1]; } while (bend == pos);
+            b++; bend = off[b + 1];
+            if (bend == pos) {
+                // empty buckets follow: find the bucket that holds `pos` (largest b with off[b] <= pos) by bisection — with a handful of
+                // hot buckets (all scalars equal) a linear walk crossed tens of thousands of empty ones on a dependent load each (14 ms)
+                uint32_t l2 = b, h2 = NB;            // off[l2] <= pos < off[h2] (= E)
+                while (h2 - l2 > 1) { uint32_t mid = (l2 + h2) >> 1; if (off[mid] <= pos) l2 = mid; else h2 = mid; }
+                b = l2; bend = off[b + 1];
+            }
         }
         uint32_t e = entries[pos];
         Aff<F> p; load_aff<C>(p, bases + (size_t)(e & 0x7fffffffu & dbg_mask) * C::AFF_STRIDE);

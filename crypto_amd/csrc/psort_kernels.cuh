@@ -20,10 +20,29 @@
 namespace msm {
 
 
-// the W signed digits of scalar i (same recoding as k_digit_codes): f(w, |d| - 1, neg) for every non-zero digit
-template <class F> __device__ __forceinline__ void ps_digits(const PsParams &q, size_t i, F f) {
-    const uint4 *p = reinterpret_cast<const uint4 *>(q.scalars + i * 8);
-    uint4 a = p[0], b = p[1];
+// LDS counter increment that survives hot keys: when every participating lane of the wave targets the same counter (all scalars equal,
+// a witness that is mostly 0 / 1, the few values of the short top window) ONE lane adds the population count and the lanes take consecutive
+// slots, instead of up to 64 serialised atomics on one address.  Must be called by all lanes of the wave (`active` masks the idle ones).
+// Returns the slot (old counter value + rank among the active lanes).
+__device__ __forceinline__ uint32_t lds_inc_agg(uint32_t *cnt, uint32_t bin, bool active) {
+    const uint64_t mask = __ballot(active);
+    if (mask == 0) return 0;
+    const int lane = threadIdx.x & 63, first = __ffsll((long long)mask) - 1;
+    const uint32_t fb = (uint32_t)__shfl((int)bin, first, 64);
+    if (__all(!active || bin == fb)) {
+        uint32_t base = 0;
+        if (lane == first) base = atomicAdd(&cnt[fb], (uint32_t)__popcll(mask));
+        base = (uint32_t)__shfl((int)base, first, 64);
+        return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    }
+    return active ? atomicAdd(&cnt[bin], 1u) : 0u;
+}
+
+// the W signed digits of scalar i (same recoding as k_digit_codes): f(w, |d| - 1, neg, nonzero) for EVERY window, uniformly over the wave
+// (`live` = this lane has a scalar at all)
+template <class F> __device__ __forceinline__ void ps_digits(const PsParams &q, size_t i, bool live, F f) {
+    uint4 a = make_uint4(0, 0, 0, 0), b = a;
+    if (live) { const uint4 *p = reinterpret_cast<const uint4 *>(q.scalars + i * 8); a = p[0]; b = p[1]; }
     uint32_t s[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w & 0x7fffffffu};       // Fr::MODULUS_BIT_SIZE = 255
     const uint32_t B = 1u << (q.c - 1);
     uint32_t carry = 0;
@@ -41,7 +60,7 @@ template <class F> __device__ __forceinline__ void ps_digits(const PsParams &q, 
         const uint32_t neg = v > B ? 1u : 0u;
         const uint32_t mag = neg ? (2u * B - v) : v;
         carry = neg;
-        if (mag) f(w, mag - 1, neg);
+        f(w, mag - 1, neg, live && mag != 0);
     }
 }
 __device__ __forceinline__ bool ps_live(const PsParams &q, size_t i) {
@@ -54,7 +73,7 @@ __global__ void __launch_bounds__(PS_TILE) k_ps_count1(PsParams q, uint32_t *__r
     for (uint32_t j = threadIdx.x; j < q.P; j += blockDim.x) lds[j] = 0;
     __syncthreads();
     const size_t i = (size_t)blockIdx.x * PS_TILE + threadIdx.x;
-    if (ps_live(q, i)) ps_digits(q, i, [&](int w, uint32_t m1, uint32_t) { atomicAdd(&lds[((uint32_t)w * q.key_wstride + m1) >> q.part_log], 1u); });
+    ps_digits(q, i, ps_live(q, i), [&](int w, uint32_t m1, uint32_t, bool nz) { (void)lds_inc_agg(lds, nz ? ((uint32_t)w * q.key_wstride + m1) >> q.part_log : 0u, nz); });
     __syncthreads();
     for (uint32_t j = threadIdx.x; j < q.P; j += blockDim.x) cnt1[(size_t)j * q.ntiles + blockIdx.x] = lds[j];
 }
@@ -69,7 +88,7 @@ __global__ void __launch_bounds__(PS_TILE) k_ps_scatter1(PsParams q, const uint3
     __syncthreads();
     const size_t i = (size_t)blockIdx.x * PS_TILE + threadIdx.x;
     const bool live = ps_live(q, i);
-    if (live) ps_digits(q, i, [&](int w, uint32_t m1, uint32_t) { atomicAdd(&cnt[((uint32_t)w * q.key_wstride + m1) >> q.part_log], 1u); });
+    ps_digits(q, i, live, [&](int w, uint32_t m1, uint32_t, bool nz) { (void)lds_inc_agg(cnt, nz ? ((uint32_t)w * q.key_wstride + m1) >> q.part_log : 0u, nz); });
     __syncthreads();
     // exclusive scan of cnt[0..P): every thread takes P / 512 consecutive bins (P is a power of two >= 1; 512 threads)
     {
@@ -88,10 +107,10 @@ __global__ void __launch_bounds__(PS_TILE) k_ps_scatter1(PsParams q, const uint3
         for (uint32_t k = 0; k < per; k++) if (b0 + k < q.P) { pre[b0 + k] = run; cur[b0 + k] = run; run += cnt[b0 + k]; }
     }
     __syncthreads();
-    if (live) ps_digits(q, i, [&](int w, uint32_t m1, uint32_t neg) {
-        const uint32_t key = (uint32_t)w * q.key_wstride + m1;
-        const uint32_t pos = atomicAdd(&cur[key >> q.part_log], 1u);
-        stage[pos] = make_uint2(key, (q.val_base + (uint32_t)w * q.val_wstride + (uint32_t)i) | (neg << 31));
+    ps_digits(q, i, live, [&](int w, uint32_t m1, uint32_t neg, bool nz) {
+        const uint32_t key = nz ? (uint32_t)w * q.key_wstride + m1 : 0u;
+        const uint32_t pos = lds_inc_agg(cur, key >> q.part_log, nz);
+        if (nz) stage[pos] = make_uint2(key, (q.val_base + (uint32_t)w * q.val_wstride + (uint32_t)i) | (neg << 31));
     });
     __syncthreads();
     uint32_t total = 0;
@@ -119,7 +138,7 @@ __global__ void __launch_bounds__(1024) k_ps_bucket(const uint2 *__restrict__ pa
 #pragma unroll
         for (int j = 0; j < U; j++) { const uint32_t k = base + j * 1024 + threadIdx.x; key[j] = k < hi ? pairs[k].x : 0xffffffffu; }
 #pragma unroll
-        for (int j = 0; j < U; j++) if (key[j] != 0xffffffffu) atomicAdd(&cnt[key[j] & mask], 1u);
+        for (int j = 0; j < U; j++) (void)lds_inc_agg(cnt, key[j] & mask, key[j] != 0xffffffffu);
     }
     __syncthreads();
     // exclusive scan of the (up to 2048) bins: two per thread
@@ -144,7 +163,7 @@ __global__ void __launch_bounds__(1024) k_ps_bucket(const uint2 *__restrict__ pa
 #pragma unroll
         for (int j = 0; j < U; j++) { const uint32_t k = base + j * 1024 + threadIdx.x; pr[j] = k < hi ? pairs[k] : make_uint2(0xffffffffu, 0u); }
 #pragma unroll
-        for (int j = 0; j < U; j++) if (pr[j].x != 0xffffffffu) entries[atomicAdd(&cnt[pr[j].x & mask], 1u)] = pr[j].y;
+        for (int j = 0; j < U; j++) { const bool on = pr[j].x != 0xffffffffu; const uint32_t pos = lds_inc_agg(cnt, pr[j].x & mask, on); if (on) entries[pos] = pr[j].y; }
     }
 }
 

@@ -54,7 +54,7 @@ int32_t dgpu_last_hip_error(void);
 /* below this many terms the MSM entry points return DGPU_E_TOO_SMALL without touching the device
  * (>= 95 % of the reference's call sites have n < 100).  Default: DGPU_DEFAULT_MIN_GPU_N, the measured
  * crossover against the CPU path; 0 = always run on the device. */
-#define DGPU_DEFAULT_MIN_GPU_N 256
+#define DGPU_DEFAULT_MIN_GPU_N 512
 int32_t dgpu_set_min_gpu_n(size_t n);
 size_t dgpu_get_min_gpu_n(void);
 /* window width c (bits) used by the bucket method; 0 = automatic from n.  Any value gives the same point. */
@@ -63,7 +63,11 @@ int32_t dgpu_set_window_bits(int32_t c);
 /* ---- one-shot MSM: host buffers in, one point out ----
  * replaces <G1Projective as VariableBaseMSM>::msm_bigint(bases, bigints)
  *   legogroth16/src/prover.rs:286,299,363,592 ; utils/src/pairs.rs:153-155 ; utils/src/owned_pairs.rs:103-105
- * Callers pass n = min(bases.len(), scalars.len()) — the truncation arkworks applies (prover.rs:286). */
+ * Callers pass n = min(bases.len(), scalars.len()) — the truncation arkworks applies (prover.rs:286).
+ * Preconditions (DGPU_E_BADARG otherwise, nothing is allocated): n < 2^31 and n * W < 2^32 where W = 255 / c + 1 is the number of
+ * windows (c = 16 from n = 2^17 on: n < 2^28; split larger MSMs and fold the parts with dgpu_fold_*).  Scalars are 255-bit values
+ * (Fr::MODULUS_BIT_SIZE): bit 255 of the fourth limb is ignored, exactly as arkworks' digit extraction never reads it; scalars >= r
+ * but < 2^255 are multiplied as the integers they are (the result is the same group element as for the reduced scalar). */
 int32_t dgpu_msm_g1(const uint64_t *bases_xy /* n*12 */, const uint8_t *is_inf /* n or NULL */,
                     const uint64_t *scalars /* n*4, canonical */, size_t n, uint64_t out_xyz[18]);
 /* replaces <G1Projective as VariableBaseMSM>::msm_unchecked(bases, &[Fr]) (Fr in Montgomery form, R = 2^256)

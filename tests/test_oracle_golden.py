@@ -126,3 +126,22 @@ def test_oracle_ntt_and_witness_map_vs_naive_bigint():
             args += [p(rp), p(cl), p(vl)]
         L.orc_witness_map(*args, p(LS.scalars(cs["z"])), C.c_size_t(len(cs["z"])), C.c_size_t(cs["n_inst"]), C.c_size_t(cs["n_cons"]), p(out))
         assert [O.limbs_to_int(x) for x in out] == LS.witness_map(cs)
+
+
+def test_final_exponentiation_chain_equals_its_definition():
+    """The addition chain of the final exponentiation (restated in both oracles and in the product's host code) against plain
+    big-integer exponentiation: it raises to 3 (p^12 - 1) / r — the CUBE of the canonical exponent, which is why GT bytes differ from
+    libraries that use (p^12 - 1) / r itself — and to neither 1x nor 2x that exponent.  Ties the stored e(G1, G2) to its definition."""
+    import bls12_381_model as M
+    pr = U.load("pairing")
+    f = M.multi_miller_loop([M.G1_GEN], [M.G2_GEN])
+    e = M.final_exponentiation(f)
+    d, rem = divmod(M.P ** 12 - 1, M.R)
+    assert rem == 0
+    assert M.f12_pow(f, 3 * d) == e
+    assert M.f12_pow(f, d) != e and M.f12_pow(f, 2 * d) != e
+    assert M.f12_pow(e, M.R) == M.f12_pow(e, 0)                 # the result has order dividing r
+    # the C oracle's value (what the GPU tests compare against) is the same element
+    g1, g2 = O.G1.generator(), O.G2.generator()
+    ec = O.final_exponentiation(O.multi_miller_loop(g1.reshape(1, 12), g2.reshape(1, 24)))
+    assert U.f12_ints(ec) == [int(v, 16) for v in pr["e_g1_g2"]]

@@ -169,11 +169,14 @@ template <class F> int32_t run_shards(size_t parts, F body) {
 }
 // ---- shared-bucket-set pipeline over a precomputed-multiples table (pre_kernels.cuh, psort_kernels.cuh) ------------------------------------
 
-// window width of a table for n bases: n * W additions + 2 * 2^(c-1) reduction additions is flat between the candidates; 20 bits from
-// 2^19.5 terms on (W = 13), 16 below (W = 16: the table then only removes the per-window bucket sets and the host's Horner fold)
+// Window width of a table for n bases (measured, tests/perf/pre_perf.py at 2^16 .. 2^21, profiles/r02a_table_sizes.txt): 20 bits from
+// 2^17.5 terms on (W = 13: fewer additions, and runs short enough that few buckets are cut by chunk borders), 16 bits for 2^15 .. 2^17.5
+// (W = 16, but one set of 2^15 buckets instead of sixteen: +25 % MSM/s at 2^16), and below 2^15 terms no table at all (0): the plain
+// pipeline's narrow windows (c = 8 .. 10) keep the bucket count proportionate to the terms there.
 inline int choose_c_pre(size_t n) {
     if (gs.window_bits.load() >= 16 && gs.window_bits.load() <= 22) return gs.window_bits.load();
-    return n >= 741455 ? 20 : 16;
+    if (n < (1u << 15)) return 0;
+    return n >= 185364 ? 20 : 16;
 }
 
 // sum_j A_j + 2^lb * sum_j j S_j over the PW pseudo-windows (bucket b = j 2^lb + k of the one bucket set weighs b + 1 = (k + 1) + j 2^lb)
@@ -198,9 +201,11 @@ int32_t msm_device_pre(Slot &sl, const PreTable &pt, size_t boff, const uint32_t
         const size_t FWORDS = sizeof(HF) / 8; memcpy(out_xyz, &X, sizeof(HF)); memcpy(out_xyz + FWORDS, &Y, sizeof(HF)); memcpy(out_xyz + 2 * FWORDS, &Z, sizeof(HF)); return DGPU_OK; }
     const int c = pt.c, W = pt.W;
     const uint32_t NB = 1u << (c - 1);
-    const int lb = std::min(c - 1, 15);                 // log2 buckets per pseudo-window
+    // buckets per lane of k_reduce_l0 = 2^mshift: 8 once the bucket set fills the chip with one wave per SIMD (2^19 buckets = 1024 waves, the
+    // kernel is work-bound), fewer for small sets, where the serial part of every lane is pure latency (2^15 buckets: 1 per lane, 512 waves)
+    const int mshift = NB >= (1u << 18) ? 3 : (NB >= (1u << 17) ? 2 : (NB >= (1u << 16) ? 1 : 0));
+    const int lb = std::min(c - 1, 12 + mshift);        // log2 buckets per pseudo-window (64 groups of 64 * 2^mshift buckets)
     const int PW = (int)(NB >> lb);
-    const int mshift = std::max(0, lb - 12);
     const int G = 1 << (lb - 6 - mshift);               // groups per pseudo-window (<= 64)
     const size_t NG = (size_t)PW * G;
     const size_t Emax = (size_t)n * W;
@@ -296,6 +301,7 @@ int32_t bases_precompute(uint64_t handle, int32_t window_bits, int kind /* 1 | 2
     if (!cur().ready) { put_back(hd.p, kind); return DGPU_E_NODEVICE; }
     const size_t n = hd.n;
     const int c = window_bits ? window_bits : choose_c_pre(n);
+    if (c == 0) { put_back(hd.p, kind); return DGPU_OK; }          // too few terms for a table to pay: the handle stays on the plain pipeline
     const int W = 255 / c + 1;
     if (n == 0 || (uint64_t)W * n >= (1ull << 31)) { put_back(hd.p, kind); return n == 0 ? DGPU_OK : DGPU_E_BADARG; }
     void *tab = nullptr, *tmp = nullptr;

@@ -145,16 +145,24 @@ def aggregate_proofs(srs, transcript, proofs, with_d=False):
 
 
 # ---- verifier -------------------------------------------------------------------------------------------------------------
-def parsing_check(proof):
-    """proof.rs:29-58"""
+def parsing_check(proof, names=("c",)):
+    """proof.rs:29-58; every vector the variant `names` implies must be present (a proof that lacks comms_d / z_d is malformed, not a KeyError)"""
+    for key in ["com_ab", "z_ab", "tmipp"] + ["com_" + k for k in names] + ["z_" + k for k in names]:
+        if key not in proof:
+            raise AggregationError("Proof is missing " + key)
+    if "gipa" not in proof["tmipp"]:
+        raise AggregationError("Proof is missing tmipp.gipa")
     gipa = proof["tmipp"]["gipa"]
+    for key in ["nproofs", "comms_ab", "z_ab"] + [p + k for k in names for p in ("comms_", "z_")]:
+        if key not in gipa:
+            raise AggregationError("Proof is missing gipa." + key)
     n = gipa["nproofs"]
     if n < 2 or n > MAX_SRS_SIZE:
         raise AggregationError("Proof length out of bounds")
     if n & (n - 1):
         raise AggregationError("Proof length not a power of two")
     ref_len = n.bit_length() - 1
-    lens = [len(gipa["comms_ab"]), len(gipa["z_ab"])] + [len(gipa[p + k]) for k in ("c", "d") if "comms_" + k in gipa for p in ("comms_", "z_")]
+    lens = [len(gipa["comms_ab"]), len(gipa["z_ab"])] + [len(gipa[p + k]) for k in names for p in ("comms_", "z_")]
     if any(x != ref_len for x in lens):
         raise AggregationError("Proof vectors unequal sizes")
 
@@ -253,7 +261,9 @@ def verify_aggregate_proof(ip_verifier_srs, pvk, public_inputs, proof, random, t
     draws it from `rng`).  Raises AggregationError on an invalid proof."""
     vk = pvk["vk"]
     names = ("c", "d") if with_d else ("c",)
-    parsing_check(proof)
+    parsing_check(proof, names)
+    if not public_inputs or any(len(pub) != len(public_inputs[0]) for pub in public_inputs):
+        raise AggregationError("public inputs of unequal length")            # (aggregate_public_inputs indexes them as a rectangle)
     for pub in public_inputs:
         if (len(pub) + 1 > len(vk.gamma_abc_g1)) if with_d else (len(pub) + 1 != len(vk.gamma_abc_g1)):
             raise AggregationError("MalformedVerifyingKey")

@@ -213,6 +213,94 @@ def create_proof(pk, r, s, v, h, input_assignment_with_one, witness_assignment):
     return {"a": _affine(M.G1, g_a), "b": _affine(M.G2, g2_b), "c": _affine(M.G1, g_c), "d": _affine(M.G1, g_d)}
 
 
+# ---- CP_link, commitment openings, re-randomisation: the small callers on the same path ----------------------------------------------------
+def generate_link_keys(vk, num_instance_variables, pedersen_gens, link_g1, link_g2, k, a):
+    """generate_parameters_incl_cp_link_with_qap's subspace-SNARK part (legogroth16/src/generator.rs:166-204): two rows — the Pedersen bases of
+    CP_link and gamma_abc_g1[n_inst .. n_inst + cw] | eta_gamma_inv_g1 of proof.d — with the trapdoor (k, a) passed in.
+    Returns (link_pp, link_ek, link_vk, link_bases)."""
+    from . import link as LK
+    cw = vk.commit_witness_count
+    gens = np.ascontiguousarray(pedersen_gens, dtype=np.uint64).reshape(-1, 12)
+    pp = LK.PP(2, cw + 2, link_g1, link_g2)
+    m = LK.SparseMatrix(2, cw + 2)
+    m.insert_row_slice(0, 0, list(gens))
+    m.insert_row_slice(1, 0, list(vk.gamma_abc_g1[num_instance_variables:num_instance_variables + cw]))
+    m.insert_row_slice(1, cw + 1, [vk.eta_gamma_inv_g1])
+    ek, lvk = LK.keygen(pp, m, k, a)
+    return pp, ek, lvk, gens
+
+
+def create_proof_incl_cp_link(pk, link_pp, link_ek, link_bases, r, s, v, link_v, h, input_assignment_with_one, witness_assignment):
+    """create_proof_incl_cp_link_with_assignment (prover.rs:183-234): the proof, link_d = msm(link_bases, committed ++ [link_v]) (:215)
+    and link_pi = PESubspaceSnark::prove(committed ++ [link_v, v]) (:222)"""
+    from . import link as LK
+    proof = create_proof(pk, r, s, v, h, input_assignment_with_one, witness_assignment)
+    wit = np.ascontiguousarray(witness_assignment, dtype=np.uint64).reshape(-1, 4)
+    cw = pk.vk.commit_witness_count
+    comm = [sum(int(x) << (64 * i) for i, x in enumerate(row)) for row in wit[:cw]]
+    bases = np.ascontiguousarray(link_bases, dtype=np.uint64).reshape(-1, 12)
+    link_d = _affine(M.G1, M.msm_bigint(M.G1, bases, np.stack([_sc(x) for x in comm + [link_v]])))
+    link_pi = LK.prove(link_pp, link_ek, comm + [link_v, v])
+    return {"groth16_proof": proof, "link_d": link_d, "link_pi": link_pi}
+
+
+def verify_link_proof(link_pp, link_vk, proof_with_link):
+    """verifier.rs:53-60: the subspace SNARK on [link_d, groth16_proof.d]; raises link.LinkError on failure"""
+    from . import link as LK
+    LK.verify(link_pp, link_vk, np.stack([proof_with_link["link_d"], proof_with_link["groth16_proof"]["d"]]), proof_with_link["link_pi"])
+
+
+def verify_link_commitment(cp_link_bases, link_d, witnesses_expected_in_commitment, link_v):
+    """prover.rs:385-407"""
+    bases = np.ascontiguousarray(cp_link_bases, dtype=np.uint64).reshape(-1, 12)
+    if len(witnesses_expected_in_commitment) + 1 > len(bases):
+        raise ValueError("VectorLongerThanExpected(%d, %d)" % (len(witnesses_expected_in_commitment) + 1, len(bases)))
+    sc = np.stack([_sc(x) for x in list(witnesses_expected_in_commitment) + [link_v]])
+    if not (np.asarray(link_d) == _affine(M.G1, M.msm_bigint(M.G1, bases, sc))).all():
+        raise ValueError("InvalidLinkCommitment")
+
+
+def verify_witness_commitment(vk, proof, public_inputs_count, witnesses_expected_in_commitment, v):
+    """prover.rs:434-467: proof.d == msm(gamma_abc_g1[1 + inputs ..], committed) + v (eta/gamma)"""
+    k = len(witnesses_expected_in_commitment)
+    if public_inputs_count + k + 1 > len(vk.gamma_abc_g1):
+        raise ValueError("VectorLongerThanExpected(%d, %d)" % (public_inputs_count + k + 1, len(vk.gamma_abc_g1)))
+    pts = np.concatenate([vk.gamma_abc_g1[1 + public_inputs_count:1 + public_inputs_count + k], np.asarray(vk.eta_gamma_inv_g1).reshape(1, 12)])
+    d = _affine(M.G1, lincomb(M.G1, list(pts), list(witnesses_expected_in_commitment) + [v]))
+    if not (np.asarray(proof["d"]) == d).all():
+        raise ValueError("InvalidWitnessCommitment")
+
+
+def verify_commitments(vk, link_bases, proof_with_link, public_inputs_count, witnesses_expected_in_commitment, v, link_v):
+    """prover.rs:412-431"""
+    verify_link_commitment(link_bases, proof_with_link["link_d"], witnesses_expected_in_commitment, link_v)
+    verify_witness_commitment(vk, proof_with_link["groth16_proof"], public_inputs_count, witnesses_expected_in_commitment, v)
+
+
+def rerandomize_proof(proof, vk, r1, r2):
+    """prover.rs:478-510 with the factors passed in (nonzero):  A' = A / r1,  B' = r1 B + r1 r2 (delta + gamma),  C' = C + r2 A,  D' = D + r2 A"""
+    if r1 % R_MOD == 0 or r2 % R_MOD == 0:
+        raise ValueError("rerandomisation factors must be nonzero")
+    r1i = pow(r1, R_MOD - 2, R_MOD)
+    a_r2 = _affine(M.G1, lincomb(M.G1, [proof["a"]], [r2]))
+    return {"a": _affine(M.G1, lincomb(M.G1, [proof["a"]], [r1i])),
+            "b": _affine(M.G2, lincomb(M.G2, [proof["b"], vk.delta_g2, vk.gamma_g2], [r1, r1 * r2, r1 * r2])),
+            "c": _affine(M.G1, lincomb(M.G1, [proof["c"], a_r2], [1, 1])),
+            "d": _affine(M.G1, lincomb(M.G1, [proof["d"], a_r2], [1, 1]))}
+
+
+def rerandomize_proof_1(proof, old_v, new_v, vk, eta_delta_inv_g1, r1, r2):
+    """prover.rs:514-549: keeps proof.d a commitment to the witnesses (with randomness new_v):
+    A' = A / r1,  B' = r1 B + r1 r2 delta,  C' = C + r2 A + (old_v - new_v)(eta/delta),  D' = D + (new_v - old_v)(eta/gamma)"""
+    if r1 % R_MOD == 0 or r2 % R_MOD == 0:
+        raise ValueError("rerandomisation factors must be nonzero")
+    r1i = pow(r1, R_MOD - 2, R_MOD)
+    return {"a": _affine(M.G1, lincomb(M.G1, [proof["a"]], [r1i])),
+            "b": _affine(M.G2, lincomb(M.G2, [proof["b"], vk.delta_g2], [r1, r1 * r2])),
+            "c": _affine(M.G1, lincomb(M.G1, [proof["c"], proof["a"], eta_delta_inv_g1], [1, r2, old_v - new_v])),
+            "d": _affine(M.G1, lincomb(M.G1, [proof["d"], vk.eta_gamma_inv_g1], [1, new_v - old_v]))}
+
+
 # ---- multi-GPU prover: every large MSM chunked over the ranks (SURVEY.md 8e "LegoGroth16 prove") ----------------------------------------
 class ShardedProvingKey:
     """This rank's chunk of every proving-key query, resident on its GPU.  Chunks are contiguous and balanced (sharded.chunk_bounds):

@@ -19,6 +19,7 @@ def _p(a):
 
 
 PREPARED_WORDS = 68 * 36      # DGPU_G2_PREPARED_WORDS
+FP_ONE_MONT = np.array([0x760900000002fffd, 0xebf4000bc40c0002, 0x5f48985753c758ba, 0x77ce585370525745, 0x5c071a97a256ec6d, 0x15f65ec3fa80e493], dtype=np.uint64)   # 1 in Fq Montgomery limbs
 
 
 class G2Prepared:

@@ -98,6 +98,18 @@ def test_aggregate_and_verify(n):
     assert rejected(proof=bad)
     bad = copy.deepcopy(agg); bad["tmipp"]["gipa"]["nproofs"] = n + 1
     assert rejected(proof=bad)                                        # parsing_check
+    # malformed input is an AggregationError, never a KeyError / IndexError: missing vectors, ragged public inputs
+    bad = copy.deepcopy(agg); del bad["tmipp"]["gipa"]["z_c"]
+    assert rejected(proof=bad)
+    bad = copy.deepcopy(agg); del bad["com_c"]
+    assert rejected(proof=bad)
+    ragged = copy.deepcopy(inputs); ragged[1] = ragged[1] + [1]
+    assert rejected(pub=ragged)
+    try:
+        AG.verify_aggregate_proof(vsrs, pvk, inputs, agg, 0x5EED1234567, AG.MerlinTranscript(b"test-aggregation"), with_d=True)     # no comms_d / z_d in a Groth16 proof
+        assert False
+    except AG.AggregationError:
+        pass
     # one wrong proof inside the batch
     wrong = copy.deepcopy(proofs); wrong[1]["c"] = g1(777)
     agg_w = AG.aggregate_proofs(pk, AG.MerlinTranscript(b"test-aggregation"), wrong)

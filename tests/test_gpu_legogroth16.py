@@ -102,3 +102,73 @@ def test_generator_matches_oracle_setup(m, cw):
     h = LS.scalars(LS.witness_map(cs))
     proof = LG.create_proof(pk, 12345, 67890, 13579, h, inp, wit)
     assert LG.verify_proof(LG.prepare_verifying_key(vk), proof, inp[1:])
+
+
+def _real_key(m, cw, seed):
+    cs = LS.circuit(m, x0=5)
+    key = LS.setup(cs, cw, seed=seed)
+    vk = LG.VerifyingKey(key["alpha_g1"], key["beta_g2"], key["gamma_g2"], key["delta_g2"], key["gamma_abc_g1"], key["eta_gamma_inv_g1"], cw)
+    pk = LG.ProvingKey(vk, key["beta_g1"], key["delta_g1"], key["eta_delta_inv_g1"], key["a_query"], key["b_g1_query"], key["b_g2_query"], key["h_query"], key["l_query"])
+    z = cs["z"]
+    return cs, key, vk, pk, LS.scalars(z[:cs["n_inst"]]), LS.scalars(z[cs["n_inst"]:]), LS.scalars(LS.witness_map(cs))
+
+
+def test_commitment_openings_and_rerandomisation():
+    """verify_witness_commitment (prover.rs:434-467), rerandomize_proof / rerandomize_proof_1 (:478-549): the shape of the reference's tests
+    (legogroth16/src/tests.rs:181-214 — rerandomised proofs verify, the commitment opens to the committed witnesses with the right randomness only)"""
+    cs, key, vk, pk, inp, wit, h = _real_key(60, 3, 31)
+    r, s, v = 11 ** 20 % R, 13 ** 19 % R, 17 ** 18 % R
+    proof = LG.create_proof(pk, r, s, v, h, inp, wit)
+    pvk = LG.prepare_verifying_key(vk)
+    assert LG.verify_proof(pvk, proof, inp[1:])
+    wv = cs["z"][cs["n_inst"]:]
+    LG.verify_witness_commitment(vk, proof, cs["n_inst"] - 1, wv[:3], v)
+    for bad in ((wv[:2] + [wv[2] + 1], v), (wv[:3], v + 1)):
+        with pytest.raises(ValueError):
+            LG.verify_witness_commitment(vk, proof, cs["n_inst"] - 1, bad[0], bad[1])
+    with pytest.raises(ValueError):
+        LG.verify_witness_commitment(vk, proof, cs["n_inst"] - 1, wv[:40], v)            # VectorLongerThanExpected
+    p2 = LG.rerandomize_proof(proof, vk, 0xABCDEF123457, 0x1234567ABCDEF1)
+    assert LG.verify_proof(pvk, p2, inp[1:]) and not (p2["a"] == proof["a"]).all()
+    new_v = 99 ** 17 % R
+    p3 = LG.rerandomize_proof_1(proof, v, new_v, vk, pk.eta_delta_inv_g1, 0x5555AAAA5555, 0x777766665555)
+    assert LG.verify_proof(pvk, p3, inp[1:])
+    LG.verify_witness_commitment(vk, p3, cs["n_inst"] - 1, wv[:3], new_v)
+    with pytest.raises(ValueError):
+        LG.verify_witness_commitment(vk, p3, cs["n_inst"] - 1, wv[:3], v)
+    # the same equations on the oracle: A' = A / r1, D' = D + (new_v - old_v)(eta/gamma)
+    r1 = 0x5555AAAA5555
+    assert (p3["a"] == aff(O.G1, oracle_lincomb(O.G1, [proof["a"]], [pow(r1, R - 2, R)]))).all()
+    assert (p3["d"] == aff(O.G1, oracle_lincomb(O.G1, [proof["d"], key["eta_gamma_inv_g1"]], [1, new_v - v]))).all()
+
+
+def test_cp_link_prove_and_verify():
+    """CP_link (prover.rs:183-234, generator.rs:166-204, link/snark.rs): proof.d and link_d commit to the same witnesses; the subspace SNARK
+    verifies, and fails for another link_v, another witness or a swapped commitment (legogroth16/src/tests.rs:88-147 shape)"""
+    from crypto_amd import link as LK
+    cs, key, vk, pk, inp, wit, h = _real_key(40, 2, 41)
+    cw = 2
+    g = lambda k: O.G1.to_affine(O.G1.mul(O.G1.generator(), O.int_to_limbs(k % R, 4)))[0]
+    g2 = lambda k: O.G2.to_affine(O.G2.mul(O.G2.generator(), O.int_to_limbs(k % R, 4)))[0]
+    gens = np.stack([g(1001 + 7 * i) for i in range(cw + 1)])
+    pp, ek, lvk, bases = LG.generate_link_keys(vk, cs["n_inst"], gens, g(5), g2(7), [123456789, 987654321], 555555)
+    # the evaluation key against the oracle: column c of m^T k
+    col0 = oracle_lincomb(O.G1, [gens[0], key["gamma_abc_g1"][cs["n_inst"]]], [123456789, 987654321])
+    assert (ek["p"][0] == aff(O.G1, col0)).all()
+    r, s, v, link_v = 3 ** 40 % R, 5 ** 30 % R, 7 ** 25 % R, 11 ** 21 % R
+    pl = LG.create_proof_incl_cp_link(pk, pp, ek, bases, r, s, v, link_v, h, inp, wit)
+    assert LG.verify_proof(LG.prepare_verifying_key(vk), pl["groth16_proof"], inp[1:])
+    LG.verify_link_proof(pp, lvk, pl)
+    wv = cs["z"][cs["n_inst"]:]
+    LG.verify_commitments(vk, bases, pl, cs["n_inst"] - 1, wv[:cw], v, link_v)
+    assert (pl["link_d"] == aff(O.G1, oracle_lincomb(O.G1, list(gens), wv[:cw] + [link_v]))).all()
+    with pytest.raises(ValueError):
+        LG.verify_link_commitment(bases, pl["link_d"], wv[:cw], link_v + 1)
+    bad = dict(pl); bad["link_d"] = gens[0]
+    with pytest.raises(LK.LinkError):
+        LG.verify_link_proof(pp, lvk, bad)
+    bad = dict(pl); bad["link_pi"] = gens[1]
+    with pytest.raises(LK.LinkError):
+        LG.verify_link_proof(pp, lvk, bad)
+    with pytest.raises(LK.LinkError):
+        LK.prove(pp, ek, [1, 2, 3, 4, 5])                       # more witnesses than columns

@@ -59,7 +59,7 @@ struct Slot {
         ev_pool.clear(); prof_pending.clear();
     }
 };
-constexpr int N_SLOTS = 4;
+constexpr int N_SLOTS = 6;      // calls in flight per device context (a LegoGroth16 proof issues the witness map + five MSMs + the commitment's MSM together)
 
 constexpr int MAX_CTX = 16;
 // One Ctx per device the library was told to use (dgpu_init / dgpu_init_devices / dgpu_init_device_list): its streams, workspaces and NTT

@@ -165,7 +165,7 @@ def _pool():
     global _POOL
     if _POOL is None:
         from concurrent.futures import ThreadPoolExecutor
-        _POOL = ThreadPoolExecutor(6)
+        _POOL = ThreadPoolExecutor(8)
     return _POOL
 
 
@@ -180,14 +180,28 @@ def create_proof(pk, r, s, v, h, input_assignment_with_one, witness_assignment):
     """prover.rs:267-383.  Returns the proof (a, b, c, d) as affine ABI points.  `h`: canonical limbs or the DeviceScalars
     the witness map left in HBM (qap.witness_map(..., resident=True))."""
     vk = pk.vk
-    hs = h if isinstance(h, M.DeviceScalars) else M.DeviceScalars(np.ascontiguousarray(h, dtype=np.uint64).reshape(-1, 4))
+    own_h = []
+
+    def resolve_h():
+        """h as resident scalars: a DeviceScalars, host limbs, or a callable that produces either (the witness map, run inside the h job so
+        that it overlaps the assignment upload and the four MSMs that do not depend on it)"""
+        x = h() if callable(h) else h
+        if isinstance(x, M.DeviceScalars):
+            if callable(h):
+                own_h.append(x)
+            return x
+        x = M.DeviceScalars(np.ascontiguousarray(x, dtype=np.uint64).reshape(-1, 4)); own_h.append(x)
+        return x
     wit = np.ascontiguousarray(witness_assignment, dtype=np.uint64).reshape(-1, 4)
     inp = np.ascontiguousarray(input_assignment_with_one, dtype=np.uint64).reshape(-1, 4)
     cw = vk.commit_witness_count
     committed = wit[:cw]
     # one upload serves four MSMs: `assignment` = inputs[1..] ++ witnesses (:319-321) and `aux` of :299 is its suffix
     pool = _pool()
-    f_h = pool.submit(lambda: pk.h_query.msm_resident(hs, n=min(pk.h_query.n, hs.n)))              # :286  (h_query has D-1 points: truncation); runs while the assignment uploads
+    def h_job():
+        hs = resolve_h()
+        return pk.h_query.msm_resident(hs, n=min(pk.h_query.n, hs.n))                               # :286  (h_query has D-1 points: truncation)
+    f_h = pool.submit(h_job)                                                                        # runs while the assignment uploads
     assignment = M.DeviceScalars.from_parts([inp[1:], wit])
     n_aux, aux_at = len(wit) - cw, len(inp) - 1 + cw
     # the five large MSMs are independent (the reference runs each under rayon, one after the other): issue them from host
@@ -205,12 +219,25 @@ def create_proof(pk, r, s, v, h, input_assignment_with_one, witness_assignment):
     l_aux_acc, g_a, g1_b, g2_b, g_d = [f.result() for f in [pool.submit(j) for j in jobs]]
     h_acc = f_h.result()
     assignment.free()
-    if hs is not h:
-        hs.free()
+    for x in own_h:
+        x.free()
     # g_c = s g_a + r g1_b - rs delta + l_aux + h_acc - v (eta/delta)    :350-355
     small = lincomb(M.G1, [_affine(M.G1, g_a), _affine(M.G1, g1_b), pk.delta_g1, pk.eta_delta_inv_g1], [s, r, -(r * s), -v])
     g_c = sharded.fold(M.G1, np.stack([small, l_aux_acc, h_acc]))
     return {"a": _affine(M.G1, g_a), "b": _affine(M.G2, g2_b), "c": _affine(M.G1, g_c), "d": _affine(M.G1, g_d)}
+
+
+def create_proof_with_reduction(pk, circuit, r, s, v, assignment_with_one):
+    """create_proof_with_reduction (prover.rs:153-180): h = QAP::witness_map(cs) then create_proof_with_assignment.  `circuit` is the resident
+    R1CS (qap.DeviceR1cs: the matrices of the synthesised constraint system), `assignment_with_one` the full assignment z = instance ++ witness.
+    The witness map runs on the device inside the h job; h never leaves HBM."""
+    z = np.ascontiguousarray(assignment_with_one, dtype=np.uint64).reshape(-1, 4)
+    n_inst = circuit.num_inputs
+
+    def h():
+        _, dh = circuit.witness_map(z, to_host=False, resident=True)
+        return dh
+    return create_proof(pk, r, s, v, h, z[:n_inst], z[n_inst:])
 
 
 # ---- CP_link, commitment openings, re-randomisation: the small callers on the same path ----------------------------------------------------

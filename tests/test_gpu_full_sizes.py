@@ -91,6 +91,9 @@ def test_full_prove_2_20_verifies_and_matches_the_closed_form():
     assert (h == oracle_map((A, B, Cm), zl, n_inst, nc)).all()
     r, s, v = rnd(), rnd(), rnd()
     proof = LG.create_proof(pk, r, s, v, dh, zl[:n_inst], zl[n_inst:])
+    # the outer function (prover.rs:153-180: witness map, then the MSMs) with the witness map overlapped: the same proof
+    proof_r = LG.create_proof_with_reduction(pk, dr, r, s, v, zl)
+    assert all((proof_r[k] == proof[k]).all() for k in proof)
     pvk = LG.prepare_verifying_key(pk.vk)
     assert LG.verify_proof(pvk, proof, zl[1:n_inst])
     bad_inp = zl[1:n_inst].copy(); bad_inp[0][0] ^= np.uint64(1)

@@ -77,5 +77,9 @@ def test_resident_h_feeds_the_msm_and_the_proof_verifies():
     proof = LG.create_proof(pk, 12345, 67890, 424242, h, inp, wit)
     pvk = LG.prepare_verifying_key(vk)
     assert LG.verify_proof(pvk, proof, inp[1:])
+    dr = qap.DeviceR1cs(*mats, len(cs["z"]), cs["n_inst"], cs["n_cons"])
+    pr2 = LG.create_proof_with_reduction(pk, dr, 12345, 67890, 424242, z)          # prover.rs:153-180: witness map inside
+    assert all((pr2[k] == proof[k]).all() for k in proof)
+    dr.free()
     h_bad = h.copy(); h_bad[3][0] ^= np.uint64(1)
     assert not LG.verify_proof(pvk, LG.create_proof(pk, 12345, 67890, 424242, h_bad, inp, wit), inp[1:])

@@ -134,7 +134,7 @@ int32_t dgpu_shutdown(void) {
     for (int i = 0; i < MAX_CTX; i++) {
         Ctx &c = ctxs[i];
         if (c.device >= 0) (void)hipSetDevice(c.device);
-        for (auto &d : c.ntt_domains) { void *ps[] = {d.second.tw_f, d.second.tw_i, d.second.pw_f, d.second.pw_i, d.second.zinv}; for (void *p : ps) if (p) (void)hipFree(p); }
+        for (auto &d : c.ntt_domains) { void *ps[] = {d.second.tw_f, d.second.tw_i, d.second.pw_f, d.second.pw_i, d.second.zinv, d.second.pwr_f, d.second.pwr_i}; for (void *p : ps) if (p) (void)hipFree(p); }
         c.ntt_domains.clear();
         c.device = -1;
     }

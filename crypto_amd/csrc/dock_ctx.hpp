@@ -33,7 +33,7 @@ struct Buf {
 struct Handle { void *p; size_t n; int kind; int ctx; int inflight; };
 struct PreTable { void *tab; size_t n; int c, W; };      // kind 10 / 11: tab[w * n + i] = prepared record of 2^(c w) P_i (pre_kernels.cuh)
 struct ShardSet { std::vector<uint64_t> sub; std::vector<size_t> lo; size_t n = 0; };   // sub[k] covers [lo[k], lo[k+1]) (lo has sub.size() + 1 entries)
-struct NttDomain { void *tw_f = nullptr, *tw_i = nullptr, *pw_f = nullptr, *pw_i = nullptr, *zinv = nullptr; };   // per log2(D), built once per device
+struct NttDomain { void *tw_f = nullptr, *tw_i = nullptr, *pw_f = nullptr, *pw_i = nullptr, *zinv = nullptr, *pwr_f = nullptr, *pwr_i = nullptr; };   // pwr_*: pw_* in bit-reversed order   // per log2(D), built once per device
 
 struct ProfEntry { const char *name; double ms; uint64_t calls; };
 

@@ -29,7 +29,8 @@ int32_t get_domain(Slot &sl, int logn, NttDomain &out) {
     void *dc = nullptr;
     const size_t esz = ntt::FR_WORDS * 4;
     if (hipMalloc(&dc, sizeof consts) != hipSuccess || hipMalloc(&d.tw_f, 2 * H * esz) != hipSuccess || hipMalloc(&d.tw_i, 2 * H * esz) != hipSuccess ||
-        hipMalloc(&d.pw_f, D * esz) != hipSuccess || hipMalloc(&d.pw_i, D * esz) != hipSuccess || hipMalloc(&d.zinv, 32) != hipSuccess) { (void)hipGetLastError(); return DGPU_E_OOM; }
+        hipMalloc(&d.pw_f, D * esz) != hipSuccess || hipMalloc(&d.pw_i, D * esz) != hipSuccess || hipMalloc(&d.zinv, 32) != hipSuccess ||
+        hipMalloc(&d.pwr_f, D * esz) != hipSuccess || hipMalloc(&d.pwr_i, D * esz) != hipSuccess) { (void)hipGetLastError(); return DGPU_E_OOM; }
     hipStream_t s = sl.stream;
     HIPCHK(hipMemcpyAsync(dc, consts, sizeof consts, hipMemcpyHostToDevice, s));
     const uint32_t *c32 = (const uint32_t *)dc;
@@ -38,12 +39,14 @@ int32_t get_domain(Slot &sl, int logn, NttDomain &out) {
     ntt::launch_tw_compact(s, (uint32_t *)d.tw_f, H); ntt::launch_tw_compact(s, (uint32_t *)d.tw_i, H);   // per-stage tables behind the full ones
     ntt::launch_fr_powers(s, c32 + 2 * 8, c32 + 4 * 8, D, (uint32_t *)d.pw_f);    // g^k / D
     ntt::launch_fr_powers(s, c32 + 3 * 8, c32 + 4 * 8, D, (uint32_t *)d.pw_i);    // g^-k / D
+    ntt::launch_bitrev_table(s, (const uint32_t *)d.pw_f, (uint32_t *)d.pwr_f, logn);   // the same factors in the order of bit-reversed data (coalesced)
+    ntt::launch_bitrev_table(s, (const uint32_t *)d.pw_i, (uint32_t *)d.pwr_i, logn);
     HIPCHK(hipMemcpyAsync(d.zinv, consts[6], 32, hipMemcpyHostToDevice, s));
     HIPCHK(hipStreamSynchronize(s));
     (void)hipFree(dc);
     std::lock_guard<std::mutex> lk(gs.mu);
     auto ins = cur().ntt_domains.emplace(logn, d);
-    if (!ins.second) { void *ps[] = {d.tw_f, d.tw_i, d.pw_f, d.pw_i, d.zinv}; for (void *p : ps) (void)hipFree(p); }   // another thread won the race
+    if (!ins.second) { void *ps[] = {d.tw_f, d.tw_i, d.pw_f, d.pw_i, d.zinv, d.pwr_f, d.pwr_i}; for (void *p : ps) (void)hipFree(p); }   // another thread won the race
     out = ins.first->second;
     return DGPU_OK;
 }
@@ -72,7 +75,8 @@ int32_t upload_matrix(Slot &sl, const Csr &m, size_t rows, int mont, DevCsr &out
     return DGPU_OK;
 }
 
-int32_t witness_map_device(Slot &sl, const DevR1cs &r, const uint64_t *assignment, int32_t montgomery, uint64_t *out_h, uint64_t *out_handle, size_t *out_len) {
+// assignment: host scalars (uploaded here), or d_assignment != nullptr: canonical scalars already resident on this device
+int32_t witness_map_device(Slot &sl, const DevR1cs &r, const uint64_t *assignment, int32_t montgomery, uint64_t *out_h, uint64_t *out_handle, size_t *out_len, const uint32_t *d_assignment = nullptr) {
     int logn = 0; while (((size_t)1 << logn) < r.num_constraints + r.num_inputs) logn++;
     if (logn < 1) logn = 1;
     if (logn > 28) return DGPU_E_BADARG;
@@ -81,7 +85,7 @@ int32_t witness_map_device(Slot &sl, const DevR1cs &r, const uint64_t *assignmen
     if ((rc = get_domain(sl, logn, dom))) return rc;
     const size_t esz = ntt::FR_WORDS * 4;
     Buf &zw = sl.q[12], &qa = sl.q[14], &qb = sl.q[15], &qc = sl.digits, &hw = sl.entries;   // digits/entries: reused scratch
-    if ((rc = zw.ensure(r.num_vars * 32))) return rc;
+    if (!d_assignment && (rc = zw.ensure(r.num_vars * 32))) return rc;
     if ((rc = qa.ensure(D * esz))) return rc;
     if ((rc = qb.ensure(D * esz))) return rc;
     if ((rc = qc.ensure(D * esz))) return rc;
@@ -90,20 +94,20 @@ int32_t witness_map_device(Slot &sl, const DevR1cs &r, const uint64_t *assignmen
     uint32_t *arr[3] = {qa.as<uint32_t>(), qb.as<uint32_t>(), qc.as<uint32_t>()};
     {
         StageTimer st(sl, "qap.matvec");
-        HIPCHK(hipMemcpyAsync(zw.p, assignment, r.num_vars * 32, hipMemcpyHostToDevice, s));
+        if (!d_assignment) HIPCHK(hipMemcpyAsync(zw.p, assignment, r.num_vars * 32, hipMemcpyHostToDevice, s));
+        const uint32_t *zsrc = d_assignment ? d_assignment : zw.as<uint32_t>();
         for (int k = 0; k < 3; k++)
-            ntt::launch_csr_eval(s, r.m[k].rowptr, r.m[k].cols, r.m[k].vals, r.m[k].nnz, zw.as<uint32_t>(), montgomery, r.num_vars, r.num_constraints, k == 0 ? r.num_inputs : 0, arr[k], D);
+            ntt::launch_csr_eval(s, r.m[k].rowptr, r.m[k].cols, r.m[k].vals, r.m[k].nnz, zsrc, d_assignment ? 0 : montgomery, r.num_vars, r.num_constraints, k == 0 ? r.num_inputs : 0, arr[k], D);
     }
     {
         StageTimer st(sl, "qap.ntt");
         for (int k = 0; k < 3; k++) {
             ntt::launch_ntt(s, arr[k], logn, (const uint32_t *)dom.tw_i, 1);                       // iFFT (x D), bit-reversed out
-            ntt::launch_coset_scale(s, arr[k], logn, (const uint32_t *)dom.pw_f, nullptr);         // * g^k / D
-            ntt::launch_ntt(s, arr[k], logn, (const uint32_t *)dom.tw_f, 0);                       // coset FFT, natural out
+            ntt::launch_ntt(s, arr[k], logn, (const uint32_t *)dom.tw_f, 0, (const uint32_t *)dom.pwr_f);   // * g^k / D on the way in, coset FFT, natural out
         }
         ntt::launch_pointwise(s, arr[0], arr[1], arr[2], D, (const uint32_t *)dom.zinv);           // (ab - c) / Z(g)
         ntt::launch_ntt(s, arr[0], logn, (const uint32_t *)dom.tw_i, 1);                           // coset iFFT ...
-        ntt::launch_coset_scale(s, arr[0], logn, (const uint32_t *)dom.pw_i, hw.as<uint32_t>());   // ... * g^-k / D, un-reversed, canonical words
+        ntt::launch_coset_scale(s, arr[0], logn, (const uint32_t *)dom.pwr_i, hw.as<uint32_t>(), 1);   // ... * g^-k / D, un-reversed, canonical words
     }
     HIPCHK(hipGetLastError());
     if (out_len) *out_len = D;
@@ -182,6 +186,20 @@ int32_t dgpu_witness_map_r1cs(uint64_t r1cs, const uint64_t *assignment, size_t 
     SlotLock slot_lock; Slot &sl = *slot_lock.s;
     HIPCHK(hipSetDevice(cur().device));
     return witness_map_device(sl, *r, assignment, montgomery, out_h, out_handle, out_len);
+}
+// the assignment already resident (dgpu_scalars_upload: canonical after the upload): one upload of z serves the witness map and, at
+// scalar offset 1, the prover's `assignment` = z[1..] (prover.rs:319-321)
+int32_t dgpu_witness_map_r1cs_resident(uint64_t r1cs, uint64_t assignment, uint64_t *out_h, uint64_t *out_handle, size_t *out_len) {
+    if (!out_h && !out_handle) return DGPU_E_BADARG;
+    if (!cur().ready) return DGPU_E_NODEVICE;
+    HandleRef href(r1cs), hs(assignment);
+    if (!href.ok || href.h.kind != 4 || !hs.ok || hs.h.kind != 3 || hs.h.ctx != href.h.ctx) return DGPU_E_BADARG;
+    const DevR1cs *r = (const DevR1cs *)href.h.p;
+    if (hs.h.n != r->num_vars) return DGPU_E_BADARG;
+    CtxScope on_owner(href.h.ctx);
+    SlotLock slot_lock; Slot &sl = *slot_lock.s;
+    HIPCHK(hipSetDevice(cur().device));
+    return witness_map_device(sl, *r, nullptr, 0, out_h, out_handle, out_len, (const uint32_t *)hs.h.p);
 }
 int32_t dgpu_witness_map(const uint64_t *a_rowptr, const uint32_t *a_cols, const uint64_t *a_vals, size_t a_nnz,
                          const uint64_t *b_rowptr, const uint32_t *b_cols, const uint64_t *b_vals, size_t b_nnz,

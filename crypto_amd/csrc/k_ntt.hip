@@ -13,7 +13,7 @@ void launch_tw_compact(hipStream_t s, uint32_t *tw, size_t H) {
 void launch_csr_eval(hipStream_t s, const uint64_t *rowptr, const uint32_t *cols, const uint32_t *vals_soa, size_t nnz, const uint32_t *z_words, int z_mont, size_t nvars, size_t rows, size_t extra, uint32_t *out, size_t D) {
     hipLaunchKernelGGL(k_csr_eval, grid_for(D), dim3(256), 0, s, rowptr, cols, vals_soa, nnz, z_words, z_mont, nvars, rows, extra, out, D);
 }
-void launch_ntt(hipStream_t s, uint32_t *buf, int logn, const uint32_t *tw, int dif) {
+void launch_ntt(hipStream_t s, uint32_t *buf, int logn, const uint32_t *tw, int dif, const uint32_t *pre) {
     const size_t D = (size_t)1 << logn, H = D >> 1;
 #ifdef DGPU_DEV
     static const bool unfused = getenv("DGPU_NTT_UNFUSED") != nullptr;     // development switch (compile with -DDGPU_DEV)
@@ -21,6 +21,7 @@ void launch_ntt(hipStream_t s, uint32_t *buf, int logn, const uint32_t *tw, int 
     constexpr bool unfused = false;
 #endif
     if (logn < FUSE_TILE_LOG || unfused) {               // tiny domains: one pass per stage
+        if (pre) hipLaunchKernelGGL(k_coset_scale, grid_for(D), dim3(256), 0, s, buf, logn, pre, (uint32_t *)nullptr, 1);
         for (int st = 0; st < logn; st++) hipLaunchKernelGGL(k_ntt_stage, grid_for(H), dim3(256), 0, s, buf, logn, st, tw, dif);
         return;
     }
@@ -39,8 +40,9 @@ void launch_ntt(hipStream_t s, uint32_t *buf, int logn, const uint32_t *tw, int 
     }
     int s0 = 0;
     const unsigned tiles = (unsigned)(D >> FUSE_TILE_LOG);
-    for (int gidx = 0; gidx < ng; gidx++) { hipLaunchKernelGGL(k_ntt_fused, dim3(tiles), dim3(FUSE_THREADS), lds_bytes, s, buf, logn, s0, groups[gidx], tw, dif); s0 += groups[gidx]; }
+    for (int gidx = 0; gidx < ng; gidx++) { hipLaunchKernelGGL(k_ntt_fused, dim3(tiles), dim3(FUSE_THREADS), lds_bytes, s, buf, logn, s0, groups[gidx], tw, dif, gidx == 0 ? pre : (const uint32_t *)nullptr); s0 += groups[gidx]; }
 }
-void launch_coset_scale(hipStream_t s, uint32_t *buf, int logn, const uint32_t *pw, uint32_t *out_words) { hipLaunchKernelGGL(k_coset_scale, grid_for((size_t)1 << logn), dim3(256), 0, s, buf, logn, pw, out_words); }
+void launch_coset_scale(hipStream_t s, uint32_t *buf, int logn, const uint32_t *pw, uint32_t *out_words, int pw_in_data_order) { hipLaunchKernelGGL(k_coset_scale, grid_for((size_t)1 << logn), dim3(256), 0, s, buf, logn, pw, out_words, pw_in_data_order); }
+void launch_bitrev_table(hipStream_t s, const uint32_t *src, uint32_t *dst, int logn) { hipLaunchKernelGGL(k_bitrev_table, grid_for((size_t)1 << logn), dim3(256), 0, s, src, dst, logn); }
 void launch_pointwise(hipStream_t s, uint32_t *a, const uint32_t *b, const uint32_t *c, size_t D, const uint32_t *zinv_words) { hipLaunchKernelGGL(k_pointwise, grid_for(D), dim3(256), 0, s, a, b, c, D, zinv_words); }
 }  // namespace ntt

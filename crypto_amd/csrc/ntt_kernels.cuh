@@ -127,7 +127,9 @@ __global__ void __launch_bounds__(256) k_ntt_stage(uint32_t *__restrict__ buf, i
 // Per pass every element is read and written once (2 x 40 B) instead of once per stage; twiddles come from the L2-resident table.
 constexpr int FUSE_TILE_LOG = 11;
 constexpr int FUSE_THREADS = 512;     // 2 butterflies per lane per stage: two 80-KB blocks per CU overlap their load / compute / store phases
-__global__ void __launch_bounds__(FUSE_THREADS) k_ntt_fused(uint32_t *__restrict__ buf, int logn, int s0, int S, const uint32_t *__restrict__ tw, int dif) {
+// pre != nullptr: every element is multiplied by pre[position] while the tile is loaded (the coset shift g^k / D, table in the order of the
+// data: fused here it costs one product per element instead of a pass over the array).
+__global__ void __launch_bounds__(FUSE_THREADS) k_ntt_fused(uint32_t *__restrict__ buf, int logn, int s0, int S, const uint32_t *__restrict__ tw, int dif, const uint32_t *__restrict__ pre) {
     extern __shared__ uint32_t lds[];                      // [NL][2048]
     constexpr int TILE = 1 << FUSE_TILE_LOG;
     const size_t D = (size_t)1 << logn, H = D >> 1;
@@ -144,8 +146,14 @@ __global__ void __launch_bounds__(FUSE_THREADS) k_ntt_fused(uint32_t *__restrict
         if (L == 0) { cc = e >> S; mid = e & ((1u << S) - 1); } else { mid = e >> cols_log; cc = e & ((1u << cols_log) - 1); }
         size_t a = addr(mid, cc);
         uint32_t slot = (mid << cols_log) | cc;
+        if (pre) {
+            Fr x, g2; ld(x, buf, D, a); ld(g2, pre, D, a); fr_mul(x, x, g2);
 #pragma unroll
-        for (int l = 0; l < NL; l++) lds[l * TILE + slot] = buf[(size_t)l * D + a];
+            for (int l = 0; l < NL; l++) lds[l * TILE + slot] = x.l[l];
+        } else {
+#pragma unroll
+            for (int l = 0; l < NL; l++) lds[l * TILE + slot] = buf[(size_t)l * D + a];
+        }
     }
     __syncthreads();
     // TILE / 2 = 1024 butterflies per stage, two per lane (t and t + 512)
@@ -190,15 +198,26 @@ __global__ void __launch_bounds__(FUSE_THREADS) k_ntt_fused(uint32_t *__restrict
 
 // element at position p (bit-reversed order, coefficient k = bitrev(p)) *= pw[k]; optionally written out un-reversed as
 // canonical words (h coefficients for the MSM)
-__global__ void __launch_bounds__(256) k_coset_scale(uint32_t *__restrict__ buf, int logn, const uint32_t *__restrict__ pw, uint32_t *__restrict__ out_words) {
+// pw_in_data_order != 0: pw[p] already holds the factor of position p (a bit-reversed copy of the table: coalesced reads; indexing the natural
+// table with bitrev(p) made every lane of a wave touch ten cache lines of its own: 97 us per call at D = 2^20)
+__global__ void __launch_bounds__(256) k_coset_scale(uint32_t *__restrict__ buf, int logn, const uint32_t *__restrict__ pw, uint32_t *__restrict__ out_words, int pw_in_data_order) {
     const size_t D = (size_t)1 << logn;
     size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= D) return;
     size_t k = bitrev((uint32_t)p, logn);
-    Fr x, g; ld(x, buf, D, p); ld(g, pw, D, k);
+    Fr x, g; ld(x, buf, D, p); ld(g, pw, D, pw_in_data_order ? p : k);
     fr_mul(x, x, g);
     if (out_words) { uint32_t w[8]; fr_to_words(w, x, false); for (int i = 0; i < 8; i++) out_words[k * 8 + i] = w[i]; }
     else st(buf, D, p, x);
+}
+// dst[p] = src[bitrev(p)] (limb-major tables of D elements): the coset-shift tables in the order of bit-reversed data
+__global__ void __launch_bounds__(256) k_bitrev_table(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst, int logn) {
+    const size_t D = (size_t)1 << logn;
+    size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= D) return;
+    size_t k = bitrev((uint32_t)p, logn);
+#pragma unroll
+    for (int l = 0; l < NL; l++) dst[(size_t)l * D + p] = src[(size_t)l * D + k];
 }
 // a_i <- (a_i b_i - c_i) * zinv
 __global__ void __launch_bounds__(256) k_pointwise(uint32_t *__restrict__ a, const uint32_t *__restrict__ b, const uint32_t *__restrict__ c, size_t D, const uint32_t *__restrict__ zinv_words) {

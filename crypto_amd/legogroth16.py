@@ -169,16 +169,17 @@ def _pool():
     return _POOL
 
 
-def _calculate_coeff(curve, initial_point, initial_scalar, query_handle, query0, vk_param, assignment):
-    # prover.rs:585-594:  initial + query[0] + msm(query[1..], assignment) + vk_param     (assignment: resident scalars)
-    acc = query_handle.msm_resident(assignment, n=min(assignment.n, query_handle.n - 1), base_offset=1)
+def _calculate_coeff(curve, initial_point, initial_scalar, query_handle, query0, vk_param, assignment, soff=0):
+    # prover.rs:585-594:  initial + query[0] + msm(query[1..], assignment) + vk_param     (assignment: resident scalars from offset `soff`)
+    acc = query_handle.msm_resident(assignment, n=min(assignment.n - soff, query_handle.n - 1), base_offset=1, scalar_offset=soff)
     rest = lincomb(curve, [initial_point, query0, vk_param], [initial_scalar, 1, 1])
     return sharded.fold(curve, np.stack([acc, rest]))
 
 
-def create_proof(pk, r, s, v, h, input_assignment_with_one, witness_assignment):
+def create_proof(pk, r, s, v, h, input_assignment_with_one, witness_assignment, resident_z=None):
     """prover.rs:267-383.  Returns the proof (a, b, c, d) as affine ABI points.  `h`: canonical limbs or the DeviceScalars
-    the witness map left in HBM (qap.witness_map(..., resident=True))."""
+    the witness map left in HBM (qap.witness_map(..., resident=True)).  `resident_z`: the whole assignment z = instance ++ witness already on
+    the device (then `assignment` = z[1..] is that handle at scalar offset 1 and nothing is uploaded here)."""
     vk = pk.vk
     own_h = []
 
@@ -202,8 +203,11 @@ def create_proof(pk, r, s, v, h, input_assignment_with_one, witness_assignment):
         hs = resolve_h()
         return pk.h_query.msm_resident(hs, n=min(pk.h_query.n, hs.n))                               # :286  (h_query has D-1 points: truncation)
     f_h = pool.submit(h_job)                                                                        # runs while the assignment uploads
-    assignment = M.DeviceScalars.from_parts([inp[1:], wit])
-    n_aux, aux_at = len(wit) - cw, len(inp) - 1 + cw
+    if resident_z is None:
+        assignment, a0 = M.DeviceScalars.from_parts([inp[1:], wit]), 0
+    else:
+        assignment, a0 = resident_z, 1
+    n_aux, aux_at = len(wit) - cw, a0 + len(inp) - 1 + cw
     # the five large MSMs are independent (the reference runs each under rayon, one after the other): issue them from host
     # threads so that the latency-bound tail of one overlaps the bulk of the next (the library keeps 4 calls in flight)
     # g_d = msm(gamma_abc[len(inputs) .. + cw], committed) + v (eta/gamma)    :361-368  (independent of the large MSMs: issued with them)
@@ -211,14 +215,15 @@ def create_proof(pk, r, s, v, h, input_assignment_with_one, witness_assignment):
     d_pts = np.concatenate([src, vk.eta_gamma_inv_g1.reshape(1, 12)])
     d_sc = np.concatenate([committed, _sc(v).reshape(1, 4)])
     jobs = [lambda: pk.l_query.msm_resident(assignment, n=min(pk.l_query.n, n_aux), scalar_offset=aux_at),   # :299
-            lambda: _calculate_coeff(M.G1, pk.delta_g1, r, pk.a_query, pk.a0, vk.alpha_g1, assignment),           # :325-326
-            (lambda: _calculate_coeff(M.G1, pk.delta_g1, s, pk.b_g1_query, pk.b1_0, pk.beta_g1, assignment)) if r % R_MOD != 0
+            lambda: _calculate_coeff(M.G1, pk.delta_g1, r, pk.a_query, pk.a0, vk.alpha_g1, assignment, a0),           # :325-326
+            (lambda: _calculate_coeff(M.G1, pk.delta_g1, s, pk.b_g1_query, pk.b1_0, pk.beta_g1, assignment, a0)) if r % R_MOD != 0
             else (lambda: np.zeros(18, dtype=np.uint64)),          # :330-336
-            lambda: _calculate_coeff(M.G2, vk.delta_g2, s, pk.b_g2_query, pk.b2_0, vk.beta_g2, assignment),       # :343-344
+            lambda: _calculate_coeff(M.G2, vk.delta_g2, s, pk.b_g2_query, pk.b2_0, vk.beta_g2, assignment, a0),       # :343-344
             lambda: M.msm_bigint(M.G1, d_pts, d_sc)]
     l_aux_acc, g_a, g1_b, g2_b, g_d = [f.result() for f in [pool.submit(j) for j in jobs]]
     h_acc = f_h.result()
-    assignment.free()
+    if resident_z is None:
+        assignment.free()
     for x in own_h:
         x.free()
     # g_c = s g_a + r g1_b - rs delta + l_aux + h_acc - v (eta/delta)    :350-355
@@ -230,14 +235,19 @@ def create_proof(pk, r, s, v, h, input_assignment_with_one, witness_assignment):
 def create_proof_with_reduction(pk, circuit, r, s, v, assignment_with_one):
     """create_proof_with_reduction (prover.rs:153-180): h = QAP::witness_map(cs) then create_proof_with_assignment.  `circuit` is the resident
     R1CS (qap.DeviceR1cs: the matrices of the synthesised constraint system), `assignment_with_one` the full assignment z = instance ++ witness.
-    The witness map runs on the device inside the h job; h never leaves HBM."""
+    z is uploaded ONCE: the witness map reads it in place (dgpu_witness_map_r1cs_resident), the four assignment MSMs use the same handle at
+    scalar offset 1, and h never leaves HBM; the witness map runs inside the h job."""
     z = np.ascontiguousarray(assignment_with_one, dtype=np.uint64).reshape(-1, 4)
     n_inst = circuit.num_inputs
+    dz = M.DeviceScalars(z)
 
     def h():
-        _, dh = circuit.witness_map(z, to_host=False, resident=True)
+        _, dh = circuit.witness_map(dz, to_host=False, resident=True)
         return dh
-    return create_proof(pk, r, s, v, h, z[:n_inst], z[n_inst:])
+    try:
+        return create_proof(pk, r, s, v, h, z[:n_inst], z[n_inst:], resident_z=dz)
+    finally:
+        dz.free()
 
 
 # ---- CP_link, commitment openings, re-randomisation: the small callers on the same path ----------------------------------------------------

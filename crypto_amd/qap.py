@@ -78,14 +78,19 @@ class DeviceR1cs:
         self.handle = h.value
 
     def witness_map(self, assignment, montgomery=False, to_host=True, resident=False):
-        z = np.ascontiguousarray(assignment, dtype=np.uint64).reshape(-1, 4)
+        """`assignment`: host scalars, or a DeviceScalars holding z on the circuit's device (dgpu_witness_map_r1cs_resident)"""
         D = 2
         while D < self.num_constraints + self.num_inputs:
             D *= 2
         out = np.zeros((D, 4), dtype=np.uint64) if to_host else None
         handle = C.c_uint64(0); olen = C.c_size_t(0)
-        rc = lib().dgpu_witness_map_r1cs(self.handle, z.ctypes.data_as(C.c_void_p), len(z), int(montgomery),
-                                         None if out is None else out.ctypes.data_as(C.c_void_p), C.byref(handle) if resident else None, C.byref(olen))
+        if isinstance(assignment, DeviceScalars):
+            rc = lib().dgpu_witness_map_r1cs_resident(self.handle, assignment.handle, None if out is None else out.ctypes.data_as(C.c_void_p),
+                                                      C.byref(handle) if resident else None, C.byref(olen))
+        else:
+            z = np.ascontiguousarray(assignment, dtype=np.uint64).reshape(-1, 4)
+            rc = lib().dgpu_witness_map_r1cs(self.handle, z.ctypes.data_as(C.c_void_p), len(z), int(montgomery),
+                                             None if out is None else out.ctypes.data_as(C.c_void_p), C.byref(handle) if resident else None, C.byref(olen))
         if rc:
             raise DockGpuError(rc, "dgpu_witness_map_r1cs")
         ds = None

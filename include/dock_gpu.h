@@ -219,6 +219,9 @@ int32_t dgpu_r1cs_upload(const uint64_t *a_rowptr, const uint32_t *a_cols, const
 int32_t dgpu_r1cs_free(uint64_t handle);
 int32_t dgpu_witness_map_r1cs(uint64_t r1cs, const uint64_t *assignment, size_t num_vars, int32_t montgomery,
                               uint64_t *out_h, uint64_t *out_handle, size_t *out_len);
+/* the same with the assignment z already resident (a dgpu_scalars_upload handle of num_vars scalars on the circuit's device): ONE upload of z
+ * per proof then serves the witness map and — at scalar offset 1 — the prover's `assignment` = z[1..] of the a / b_g1 / b_g2 / l MSMs */
+int32_t dgpu_witness_map_r1cs_resident(uint64_t r1cs, uint64_t assignment, uint64_t *out_h, uint64_t *out_handle, size_t *out_len);
 
 /* ---- canonical (de)serialisation of group elements (host code) ----
  * The format ark-bls12-381 0.4 emits for `CanonicalSerialize` (Zcash / IETF BLS12-381): big-endian coordinates, top three bits of

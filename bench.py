@@ -371,7 +371,7 @@ def secondary_configs(log2n, ks, scalars, db, ds, pool):
         d24 = ca.DeviceScalars(s24)
         r24 = b24.msm_resident(d24)
         ok = bool((r24[:12] == exp_xy).all())
-        lat = timed(lambda: b24.msm_resident(d24), 3, warm=4)        # (four warm-up calls: every slot's workspace grows on its first call of this size)
+        lat = timed(lambda: b24.msm_resident(d24), 3, warm=8)        # (warm-up calls: every slot's workspace grows on its first call of this size)
         list(pool.map(lambda _: b24.msm_resident(d24), range(4)))
         t0 = time.perf_counter(); list(pool.map(lambda _: b24.msm_resident(d24), range(4))); thr = (time.perf_counter() - t0) / 4 * 1e3
         res["g1_2p24_single_gpu"] = {"latency_ms": round(lat, 2), "ms_per_msm_4_in_flight": round(thr, 2), "msm_2p20_equivalents_per_s": round(16e3 / thr, 2),
@@ -443,7 +443,7 @@ def secondary_configs(log2n, ks, scalars, db, ds, pool):
     def prove():
         return LG.create_proof_with_reduction(pk, circ, 123456789, 987654321, 555, z)
     p0 = prove()
-    ms = timed(prove, 6, warm=4)                     # (warm-ups: every slot's workspace grows on its first call of a size)
+    ms = timed(prove, 6, warm=6)                     # (warm-ups: every slot's workspace grows on its first call of a size)
     assert all((prove()[k] == p0[k]).all() for k in p0)
     res["prove_2p20_ms"] = round(ms, 2)
     res["prove_constraints_per_s"] = round((m + 1) / (ms * 1e-3), 1)

@@ -175,21 +175,7 @@ __global__ void __launch_bounds__(256, C::ACC_WAVES) k_accumulate(const uint32_t
     bool started_before = off[b] < start;
     Xyzz<F> acc; bool inf = true;
     fzero(acc.x); fzero(acc.y); fzero(acc.zz); fzero(acc.zzz);
-    uint32_t e = entries[start];
-    uint32_t e1 = (start + 1 < end) ? entries[start + 1] : e;
     for (uint32_t pos = start; pos < end; pos++) {
-        // The gather of term pos + 1 is a dependent entry -> record chain into a table that can be 1.7 GB (HBM + TLB miss, ~2 us) and with two
-        // waves per SIMD there is little to hide it behind.  Entries are read two terms ahead, and ONE word of the next term's record is
-        // touched now, a whole addition before its real 112-byte load, which then finds the line in L2.  (Holding the whole next record
-        // instead costs 28 registers at the 256-VGPR budget: spills, slower.)
-        const uint32_t e2 = (pos + 2 < end) ? entries[pos + 2] : e1;
-        const uint32_t *nx = bases + (size_t)(e1 & 0x7fffffffu & dbg_mask) * C::AFF_STRIDE + (C::LPP == 2 ? (threadIdx.x & 1u) * 32u : 0u);
-#ifndef DGPU_NO_PREFETCH
-        uint32_t touch;                  // (the load writes this register whenever the data arrives: it is kept allocated until the wait below)
-        asm volatile("global_load_dword %0, %1, off" : "=v"(touch) : "v"(nx) : "memory");
-#else
-        (void)nx;
-#endif
         if (pos == bend) {
             // the run of bucket b ended inside this chunk
             if (started_before) { store_soa<C>(head, T, t, acc); part_inf[2 * t] = inf; hb = b; started_before = false; }
@@ -204,12 +190,9 @@ __global__ void __launch_bounds__(256, C::ACC_WAVES) k_accumulate(const uint32_t
                 b = l2; bend = off[b + 1];
             }
         }
+        uint32_t e = entries[pos];
         Aff<F> p; load_aff<C>(p, bases + (size_t)(e & 0x7fffffffu & dbg_mask) * C::AFF_STRIDE);
         xyzz_madd(acc, inf, p, (e >> 31) != 0);
-#ifndef DGPU_NO_PREFETCH
-        asm volatile("s_waitcnt vmcnt(0)" : : "v"(touch) : "memory");       // the touched word has landed long ago; its register may now be reused
-#endif
-        e = e1; e1 = e2;
     }
     // the last run reaches the chunk end
     bool complete = (end == bend);

@@ -96,7 +96,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--log2n", type=int, default=0, help="terms per GPU = 2^log2n; default: 20 at 1 GPU (BASELINE config 2), 24 - log2(gpus) at N > 1 (config 5: 2^24 in total)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary timings appended to the JSON line at N = 1")
-    ap.add_argument("--inflight", type=int, default=4, help="MSM calls in flight per GPU (host threads; each call owns a stream + workspace slot)")
+    ap.add_argument("--inflight", type=int, default=6, help="MSM calls in flight per GPU (host threads; each call owns a stream + workspace slot)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-table", action="store_true", help="time the plain resident pipeline (no precomputed-multiples table)")
     args = ap.parse_args()

@@ -1,5 +1,5 @@
 """One-off randomized cross-check of the MSM entry points against the CPU oracle (sizes, duplicate / negated / identity bases, small and
-zero scalars, handles with offsets).  Usage: ITER=300 python tests/perf/fuzz_msm.py"""
+zero scalars, handles with offsets, and the same handle converted to a precomputed-multiples table of a random window width).  Usage: ITER=300 python tests/perf/fuzz_msm.py"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -39,10 +39,23 @@ for it in range(int(os.environ.get("ITER", "200"))):
     db = ca.DeviceBases(cv, bases, inf)
     got2 = G.to_affine(db.msm_bigint(sc[: n - off], offset=off))
     exp2 = G.to_affine(G.msm(bases[off:], sc[: n - off], inf[off:], threads=8))
+    # the same handle as a precomputed-multiples table of a random width: limb-identical to the plain handle path, sub-ranges included
+    c = int(rng.choice([16, 17, 18, 19, 20, 21, 22]))
+    plain_full = db.msm_bigint(sc)
+    plain_off = db.msm_bigint(sc[: n - off], offset=off)
+    db.precompute(c)
+    tab_ok = (db.msm_bigint(sc) == plain_full).all() and (db.msm_bigint(sc[: n - off], offset=off) == plain_off).all()
+    if n > 4:
+        ds = ca.DeviceScalars(sc)
+        m = int(rng.integers(1, n - 2)); bo = int(rng.integers(0, n - m)); so = int(rng.integers(0, n - m))
+        e3 = G.to_affine(G.msm(bases[bo:bo + m], sc[so:so + m], inf[bo:bo + m], threads=8))
+        g3 = G.to_affine(db.msm_resident(ds, n=m, base_offset=bo, scalar_offset=so))
+        tab_ok = tab_ok and e3[1] == g3[1] and (e3[1] or (e3[0] == g3[0]).all())
+        ds.free()
     db.free()
-    ok = exp[1] == got[1] and (exp[1] or (exp[0] == got[0]).all()) and exp2[1] == got2[1] and (exp2[1] or (exp2[0] == got2[0]).all())
+    ok = exp[1] == got[1] and (exp[1] or (exp[0] == got[0]).all()) and exp2[1] == got2[1] and (exp2[1] or (exp2[0] == got2[0]).all()) and bool(tab_ok)
     if not ok:
         bad += 1
-        print("MISMATCH", it, cv.tag, n, off, flush=True)
+        print("MISMATCH", it, cv.tag, n, off, c, flush=True)
 print("fuzz_msm: %d iterations, %d mismatches" % (it + 1, bad))
 sys.exit(1 if bad else 0)

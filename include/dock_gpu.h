@@ -26,6 +26,7 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#pragma GCC visibility push(default)      /* the library is built with -fvisibility=hidden: these entry points are its whole surface */
 
 #define DGPU_OK            0
 #define DGPU_E_NODEVICE   -1   /* no usable HIP device / dgpu_init not called or failed */
@@ -249,6 +250,7 @@ int32_t dgpu_selftest_glv_decompose(const uint64_t k[4], uint64_t k1[2], uint64_
 int32_t dgpu_selftest_fp_mul(const uint64_t *a /* n*6 */, const uint64_t *b /* n*6 */, size_t n, uint64_t *out /* n*6 */);
 int32_t dgpu_selftest_g1_sum(const uint64_t *pts_xy /* n*12 */, const uint8_t *neg, size_t n, uint64_t out_xyz[18]);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

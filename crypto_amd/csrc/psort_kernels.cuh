@@ -20,21 +20,22 @@
 namespace msm {
 
 
-// LDS counter increment that survives hot keys: when every participating lane of the wave targets the same counter (all scalars equal,
-// a witness that is mostly 0 / 1, the few values of the short top window) ONE lane adds the population count and the lanes take consecutive
-// slots, instead of up to 64 serialised atomics on one address.  Must be called by all lanes of the wave (`active` masks the idle ones).
-// Returns the slot (old counter value + rank among the active lanes).
+// LDS counter increment that survives hot keys (all scalars equal, a witness that is mostly 0 / 1, the few values of the short top window):
+// the lanes of a wave that target the SAME counter as its first active lane are served by ONE atomic (that lane adds their population count
+// and they take consecutive slots); only the others issue an atomic of their own.  A key that dominates a partition thus costs one LDS
+// atomic per wave instead of up to 64 serialised ones on one address.  Must be called by all lanes of the wave (`active` masks the idle
+// ones).  Returns the slot.
 __device__ __forceinline__ uint32_t lds_inc_agg(uint32_t *cnt, uint32_t bin, bool active) {
     const uint64_t mask = __ballot(active);
     if (mask == 0) return 0;
     const int lane = threadIdx.x & 63, first = __ffsll((long long)mask) - 1;
     const uint32_t fb = (uint32_t)__shfl((int)bin, first, 64);
-    if (__all(!active || bin == fb)) {
-        uint32_t base = 0;
-        if (lane == first) base = atomicAdd(&cnt[fb], (uint32_t)__popcll(mask));
-        base = (uint32_t)__shfl((int)base, first, 64);
-        return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-    }
+    const bool same = active && bin == fb;
+    const uint64_t smask = __ballot(same);
+    uint32_t base = 0;
+    if (lane == first) base = atomicAdd(&cnt[fb], (uint32_t)__popcll(smask));
+    base = (uint32_t)__shfl((int)base, first, 64);
+    if (same) return base + (uint32_t)__popcll(smask & ((1ull << lane) - 1ull));
     return active ? atomicAdd(&cnt[bin], 1u) : 0u;
 }
 

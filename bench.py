@@ -345,7 +345,6 @@ def secondary_configs(log2n, ks, scalars, db, ds, pool):
         "resident_plain_fresh_scalars_ms": round(timed(lambda: plain.msm_bigint(scalars)), 3),
         "one_shot_bases_and_scalars_ms": round(timed(lambda: ca.msm_bigint(ca.G1, host_bases, scalars), 3), 3),
         "note": "dgpu_msm_g1_handle (upload of n x 32 B scalars inside the call) and dgpu_msm_g1 (n x 128 B inside the call), pageable host memory"}
-    del host_bases
     # -- SURVEY 8d secondary scalar distributions, on the table path, one call in flight
     rng = np.random.Generator(np.random.PCG64(0x5EED0009))
     d = {}
@@ -356,9 +355,13 @@ def secondary_configs(log2n, ks, scalars, db, ds, pool):
     zo = scalars.copy(); kind = rng.integers(0, 4, n); zo[kind <= 1] = 0; zo[kind == 1, 0] = 1
     d["half_zeros_ones_ms"] = round(timed(lambda: db.msm_bigint(zo), 3), 3)
     d["uniform_ms"] = round(timed(lambda: db.msm_bigint(scalars), 3), 3)
+    inf1 = (rng.integers(0, 100, n) == 0).astype(np.uint8)                      # 1 % identity bases (zero QAP rows of a real key, prover.rs:198)
+    dbi = ca.DeviceBases(ca.G1, host_bases, inf1).precompute()
+    d["one_percent_identity_bases_ms"] = round(timed(lambda: dbi.msm_bigint(scalars), 3), 3)
+    dbi.free()
     res["scalar_distributions_fresh_scalars"] = d
     plain.free()
-    del eq, s16, zo
+    del eq, s16, zo, host_bases
     # -- BASELINE config 5's 2^24 terms on this ONE GPU: the denominator of the ">= 6x further at 8 GPUs" target
     try:
         n24 = 1 << 24
@@ -447,6 +450,30 @@ def secondary_configs(log2n, ks, scalars, db, ds, pool):
     assert all((prove()[k] == p0[k]).all() for k in p0)
     res["prove_2p20_ms"] = round(ms, 2)
     res["prove_constraints_per_s"] = round((m + 1) / (ms * 1e-3), 1)
+    # the reference's timer spans (prover.rs:284-369, :578), each stage alone and in the reference's order (one call in flight)
+    from crypto_amd import sharded as SH
+    dz = ca.DeviceScalars(z)
+    spans = {}
+
+    def span(name, fn, k=3):
+        spans[name] = round(timed(fn, k), 3)
+    keep = {}
+
+    def wm_keep():
+        if "dh" in keep:
+            keep["dh"].free()
+        _, keep["dh"] = circ.witness_map(dz, to_host=False, resident=True)
+    span("R1CS to QAP witness map", wm_keep)
+    n_aux, aux_at = (m + 1) - cw, 1 + 1 + cw
+    span("Compute C (h_query and l_query MSMs)", lambda: (qh.msm_resident(keep["dh"], n=min(qh.n, keep["dh"].n)), ql.msm_resident(dz, n=min(ql.n, n_aux), scalar_offset=aux_at)))
+    span("Compute A", lambda: LG._calculate_coeff(ca.G1, pk.delta_g1, 123456789, qa, pk.a0, vk.alpha_g1, dz, 1))
+    span("Compute B in G1", lambda: LG._calculate_coeff(ca.G1, pk.delta_g1, 987654321, qb1, pk.b1_0, pk.beta_g1, dz, 1))
+    span("Compute B in G2", lambda: LG._calculate_coeff(ca.G2, vk.delta_g2, 987654321, qb2, pk.b2_0, vk.beta_g2, dz, 1))
+    span("Finish C", lambda: SH.fold(ca.G1, np.stack([LG.lincomb(ca.G1, [p0["a"], p0["a"], pk.delta_g1, pk.eta_delta_inv_g1], [3, 5, 7, 11]), np.concatenate([p0["c"], pairing.FP_ONE_MONT]), np.concatenate([p0["d"], pairing.FP_ONE_MONT])])))
+    span("Compute D", lambda: LG.lincomb(ca.G1, [small1[8], small1[9], small1[1]], [3, 5, 7]))
+    keep["dh"].free(); dz.free()
+    spans["sum_of_spans"] = round(sum(spans.values()), 3)
+    res["prove_spans_ms"] = spans
     res["prove_note"] = ("LegoGroth16 create_proof (witness map + 4 G1 MSMs + 1 G2 MSM + finish), m + 1 = %d constraints, D = 2^%d, Groth16-like witness, "
                          "circuit and key (precomputed tables) resident, assignment uploaded per proof" % (m + 1, log2n))
     res["note"] = "n = D = 2^%d; one call in flight unless stated; host-visible wall time per call" % log2n

@@ -310,6 +310,9 @@ __global__ void __launch_bounds__(64) k_reduce_l0(const uint32_t *__restrict__ b
     const uint32_t m = 1u << mshift;
     size_t g = blockIdx.x;
     size_t b0 = (g * 64 + lane) * (size_t)m;
+    // a group without a single filled bucket (short scalars: 16-bit values leave 15 of 16 pseudo-windows empty) is two identity flags
+    { bool any = false; for (uint32_t k = 0; k < m; k++) any = any || bucket_inf[b0 + k] == 0;
+      if (!__any(any)) { if (lane == 0) { l1_inf[2 * g] = 1; l1_inf[2 * g + 1] = 1; } return; } }
     Xyzz<F> run, tot; bool rinf = true, tinf = true;
     fzero(run.x); fzero(run.y); fzero(run.zz); fzero(run.zzz); tot = run;
     for (int k = (int)m - 1; k >= 0; k--) {
@@ -345,6 +348,10 @@ __global__ void __launch_bounds__(64) k_reduce_top(const uint32_t *__restrict__ 
         uint32_t *ps = reinterpret_cast<uint32_t *>(&S), *pa = reinterpret_cast<uint32_t *>(&A);
         for (int k = 0; k < C::XW; k++) { ps[k] = src[k]; pa[k] = src[C::XW + k]; }
         sinf = l1_inf[2 * (w * G + lane)] != 0; ainf = l1_inf[2 * (w * G + lane) + 1] != 0;
+    }
+    if (!__any(!sinf || !ainf)) {        // an empty (pseudo-)window
+        if (lane == 0) { win_inf[w] = 1; if (win_s_abi) win_s_inf[w] = 1; }
+        return;
     }
     wave_weighted_sum<C>(S, sinf, A, ainf, gshift);
     if (lane == 0) {
@@ -417,6 +424,8 @@ __global__ void __launch_bounds__(64) k_reduce_l0_pair(const uint32_t *__restric
     const uint32_t m2 = 2u << mshift;                    // buckets per point-lane
     const size_t g = blockIdx.x;
     const size_t b0 = (g * 32 + q) * (size_t)m2;
+    { bool any = false; for (uint32_t k = 0; k < m2; k++) any = any || bucket_inf[b0 + k] == 0;
+      if (!__any(any)) { if ((threadIdx.x & 63) == 0) { l1_inf[2 * g] = 1; l1_inf[2 * g + 1] = 1; } return; } }
     Xyzz<F> run, tot; bool rinf = true, tinf = true;
     fzero(run.x); fzero(run.y); fzero(run.zz); fzero(run.zzz); tot = run;
     for (int k = (int)m2 - 1; k >= 0; k--) {

@@ -1,4 +1,5 @@
 // crypto_amd/csrc/k_ntt.hip — translation unit of the Fr NTT / witness-map kernels.
+#include <atomic>
 #include "ntt_kernels.cuh"
 #include "qap_launch.cuh"
 #include <cstdlib>
@@ -25,9 +26,10 @@ void launch_ntt(hipStream_t s, uint32_t *buf, int logn, const uint32_t *tw, int 
         for (int st = 0; st < logn; st++) hipLaunchKernelGGL(k_ntt_stage, grid_for(H), dim3(256), 0, s, buf, logn, st, tw, dif);
         return;
     }
-    static bool attr_set = false;
     const size_t lds_bytes = (size_t)NL * (1u << FUSE_TILE_LOG) * 4;      // 80 KB
-    if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_ntt_fused, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); attr_set = true; }
+    // (the attribute belongs to the function ON THE CURRENT DEVICE: a process that drives several GPUs sets it once per device)
+    { static std::atomic<uint32_t> done{0}; int dev = 0; (void)hipGetDevice(&dev); const uint32_t bit = 1u << (dev & 31);
+      if (!(done.load() & bit)) { (void)hipFuncSetAttribute((const void *)k_ntt_fused, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); done.fetch_or(bit); } }
     // groups of up to 7 stages; the short group goes where its L is harmless (first for DIF, last for DIT), see k_ntt_fused
     const int SMAX = 7;
     int groups[8], ng = 0, rest = logn % SMAX;

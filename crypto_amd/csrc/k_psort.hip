@@ -1,4 +1,5 @@
 // crypto_amd/csrc/k_psort.hip — translation unit of the two-level partition sort (psort_kernels.cuh)
+#include <atomic>
 #include "psort_kernels.cuh"
 
 namespace msm {
@@ -6,8 +7,9 @@ void launch_psort(hipStream_t s, const PsParams &q, uint32_t NB, uint32_t *cnt1,
                   uint32_t heavy_thr, uint32_t *heavy, uint32_t heavy_cap) {
     const size_t lds1 = (size_t)q.P * 4;
     const size_t lds3 = ((size_t)3 * q.P + 2) * 4 + (size_t)PS_TILE * PS_MAX_W * 8;
-    static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_ps_scatter1, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048); attr_set = true; }
+    // (the attribute belongs to the function ON THE CURRENT DEVICE: a process that drives several GPUs sets it once per device)
+    { static std::atomic<uint32_t> done{0}; int dev = 0; (void)hipGetDevice(&dev); const uint32_t bit = 1u << (dev & 31);
+      if (!(done.load() & bit)) { (void)hipFuncSetAttribute((const void *)k_ps_scatter1, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048); done.fetch_or(bit); } }
     hipLaunchKernelGGL(k_ps_count1, dim3(q.ntiles), dim3(PS_TILE), lds1, s, q, cnt1);
     launch_scan(s, cnt1, off1, nullptr, bsums, (size_t)q.P * q.ntiles);
     hipLaunchKernelGGL(k_ps_scatter1, dim3(q.ntiles), dim3(PS_TILE), lds3, s, q, off1, (uint2 *)pairs);

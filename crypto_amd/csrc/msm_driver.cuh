@@ -456,9 +456,9 @@ int32_t bases_upload_sharded(const uint64_t *bases, const uint8_t *is_inf, size_
 template <class C, class HF>
 int32_t msm_sharded_handle(uint64_t bases, const uint64_t *scalars, size_t n, int mont, uint64_t *out, int kind) {
     if (!out || (n && !scalars)) return DGPU_E_BADARG;
-    if (n < gs.min_gpu_n) return DGPU_E_TOO_SMALL;
     HandleRef hb(bases);
     if (!hb.ok || hb.h.kind != kind + 6 || n > hb.h.n) return DGPU_E_BADARG;
+    if (n < gs.min_gpu_n) return DGPU_E_TOO_SMALL;
     const ShardSet &ss = *(const ShardSet *)hb.h.p;
     const size_t G = ss.sub.size(), JW = 3 * sizeof(HF) / 8;
     std::vector<uint64_t> parts(G * JW);

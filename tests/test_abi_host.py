@@ -61,6 +61,11 @@ def test_fails_loudly_without_device():
     assert L.dgpu_g1_scale_batch(p_(b), None, p_(s), 4, None, 1, p_(o12), p_(oi)) == -1
     assert L.dgpu_bases_upload_g1(p_(b), None, 1, C.byref(h)) == -1
     assert L.dgpu_scalars_upload(p_(s), 1, 0, C.byref(h)) == -1
+    # the in-library multi-GPU entry points and the table conversion refuse the same way
+    assert L.dgpu_msm_g1_sharded(p_(b), None, p_(s), 1, 0, p_(out)) == -1
+    assert L.dgpu_bases_upload_g1_sharded(p_(b), None, 1, 0, C.byref(h)) == -1
+    assert L.dgpu_context_count() == 0
+    assert L.dgpu_set_device(0) == -3                  # no such context
     from crypto_amd import fixed_base, qap
     with pytest.raises(ca.DockGpuError):
         fixed_base.multiply_field_elems_with_same_group_elem(ca.G1, b[0], s)
@@ -85,6 +90,13 @@ def test_bad_arguments():
     assert L.dgpu_multi_miller_loop_prepared(None, None, None, 3, p_(np.zeros(72, np.uint64))) == -3
     assert L.dgpu_g2_prepare(None, None, 2, None, None) == -3
     assert L.dgpu_window_table_free(999) == -3
+    assert L.dgpu_bases_precompute_g1(424242, 0) == -3 and L.dgpu_bases_precompute_g2(424242, 20) == -3      # unknown handle
+    assert L.dgpu_bases_precompute_g1(1, 15) == -3 and L.dgpu_bases_precompute_g1(1, 23) == -3                # width outside 16..22
+    assert L.dgpu_init_device_list(None, 2) == -3 and L.dgpu_init_devices(0) == -3
+    assert L.dgpu_msm_g1_sharded(None, None, None, 4, 0, p_(np.zeros(18, np.uint64))) == -3
+    assert L.dgpu_msm_g1_sharded_handle(777, p_(sc), 1, 0, p_(np.zeros(18, np.uint64))) == -3
+    assert L.dgpu_scalars_upload_sharded(p_(sc), 1, 0, 777, C.byref(C.c_uint64(0))) == -3
+    assert L.dgpu_witness_map_r1cs_resident(5, 6, p_(np.zeros(8, np.uint64)), None, None) in (-1, -3)
 
 
 def test_malformed_r1cs_is_refused_before_it_reaches_the_device():

@@ -16,6 +16,7 @@
 #include "pairing29.cuh"
 #include "fp2_pair.cuh"
 #include "sort_launch.cuh"
+#include <thread>
 
 namespace bls29 {
 __device__ __forceinline__ void fhalf(Fp2H &r, const Fp2H &a) { fp_half(r.v, a.v); }   // lane-pair form of pairing29.cuh's halving
@@ -392,6 +393,32 @@ int32_t dgpu_multi_miller_loop(const uint64_t *p, const uint64_t *q, const uint8
       else hipLaunchKernelGGL(k_miller_lines_quad, dim3((unsigned)((4 * n + 63) / 64)), dim3(64), 0, s, sl.in_bases.as<uint32_t>(), sl.in_scalars.as<uint32_t>(), dskip, n, sl.ml_lines.as<uint32_t>());
     }
     return ml_finish(sl, n, out);
+}
+
+// pairs chunked over the process's device contexts (SURVEY 8e "Miller loop": pairs are independent, the per-device raw outputs multiply —
+// limb for limb the single-device value, because squaring distributes over the per-step line products and Fp12 products are exact)
+int32_t dgpu_multi_miller_loop_sharded(const uint64_t *p, const uint64_t *q, const uint8_t *skip, size_t n, int32_t ngpus, uint64_t *out) {
+    if (!out || (n && (!p || !q)) || ngpus < 0) return DGPU_E_BADARG;
+    const std::vector<int> cx = ready_contexts(ngpus);
+    if (cx.empty()) return DGPU_E_NODEVICE;
+    if (ngpus > 0 && (int)cx.size() < ngpus) return DGPU_E_BADARG;
+    const size_t G = cx.size();
+    std::vector<hostf::Fq12> parts(G);
+    std::vector<int32_t> rcs(G, DGPU_OK);
+    std::vector<std::thread> th;
+    auto body = [&](size_t k) {
+        const size_t lo = k * (n / G) + std::min(k, n % G), hi = (k + 1) * (n / G) + std::min(k + 1, n % G);
+        CtxScope here(cx[k]);
+        rcs[k] = dgpu_multi_miller_loop(p + lo * 12, q + lo * 24, skip ? skip + lo : nullptr, hi - lo, (uint64_t *)&parts[k]);
+    };
+    for (size_t k = 1; k < G; k++) th.emplace_back(body, k);
+    body(0);
+    for (auto &t : th) t.join();
+    for (int32_t rc : rcs) if (rc) return rc;
+    hostf::Fq12 f = parts[0];
+    for (size_t k = 1; k < G; k++) f = f * parts[k];
+    memcpy(out, &f, sizeof f);
+    return DGPU_OK;
 }
 
 // E::G2Prepared::from for a batch (utils/src/randomized_pairing_check.rs:132 `b.into()`, legogroth16/src/verifier.rs:22-23,72)

@@ -90,6 +90,21 @@ def multi_miller_loop(ps, qs, skip=None):
     return out
 
 
+def multi_miller_loop_sharded(ps, qs, skip=None, ngpus=0):
+    """multi_miller_loop with the pairs chunked over the process's device contexts (dgpu_multi_miller_loop_sharded)"""
+    _ensure()
+    ps = np.ascontiguousarray(ps, dtype=np.uint64).reshape(-1, 12)
+    qs = np.ascontiguousarray(qs, dtype=np.uint64).reshape(-1, 24)
+    if len(ps) != len(qs):
+        raise DockGpuError(-7, "multi_miller_loop")
+    sk = None if skip is None else np.ascontiguousarray(skip, dtype=np.uint8)
+    out = np.zeros(72, dtype=np.uint64)
+    rc = lib().dgpu_multi_miller_loop_sharded(_p(ps), _p(qs), _p(sk), len(ps), ngpus, _p(out))
+    if rc:
+        raise DockGpuError(rc, "dgpu_multi_miller_loop_sharded")
+    return out
+
+
 def final_exponentiation(f):
     f = np.ascontiguousarray(f, dtype=np.uint64)
     out = np.zeros(72, dtype=np.uint64)

@@ -151,6 +151,8 @@ int32_t dgpu_g2_prepare(const uint64_t *q_xy /* n*24 */, const uint8_t *is_inf /
                         uint64_t *out_coeffs /* n*DGPU_G2_PREPARED_WORDS */, uint8_t *out_inf /* n */);
 int32_t dgpu_multi_miller_loop_prepared(const uint64_t *p_xy /* n*12 */, const uint64_t *coeffs /* n*DGPU_G2_PREPARED_WORDS */,
                                         const uint8_t *skip /* n or NULL */, size_t n, uint64_t out_f12[72]);
+/* the same with the pairs chunked over the process's device contexts (ngpus = 0: all of them), raw outputs multiplied on the host */
+int32_t dgpu_multi_miller_loop_sharded(const uint64_t *p_xy, const uint64_t *q_xy, const uint8_t *skip, size_t n, int32_t ngpus, uint64_t out_f12[72]);
 /* replaces Bls12_381::final_exponentiation — utils/src/randomized_pairing_check.rs:213 (host code, once per batch) */
 int32_t dgpu_final_exponentiation(const uint64_t in_f12[72], uint64_t out_f12[72]);
 

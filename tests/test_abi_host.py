@@ -63,6 +63,7 @@ def test_fails_loudly_without_device():
     assert L.dgpu_scalars_upload(p_(s), 1, 0, C.byref(h)) == -1
     # the in-library multi-GPU entry points and the table conversion refuse the same way
     assert L.dgpu_msm_g1_sharded(p_(b), None, p_(s), 1, 0, p_(out)) == -1
+    assert L.dgpu_multi_miller_loop_sharded(p_(b), p_(q), None, 1, 0, p_(f12)) == -1
     assert L.dgpu_bases_upload_g1_sharded(p_(b), None, 1, 0, C.byref(h)) == -1
     assert L.dgpu_context_count() == 0
     assert L.dgpu_set_device(0) == -3                  # no such context

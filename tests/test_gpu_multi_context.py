@@ -116,6 +116,21 @@ def test_free_waits_for_calls_in_flight():
     assert lib().dgpu_bases_free(h) == -3
 
 
+def test_miller_loop_sharded_equals_single_context():
+    from crypto_amd import pairing
+    for n in (1, 2, 7, 300):
+        ps = O.G1.gen_seq(O.rand_scalars(4, 1)[0], O.rand_scalars(5, 1)[0], n, threads=8)
+        qs = O.G2.gen_seq(O.rand_scalars(6, 1)[0], O.rand_scalars(7, 1)[0], n, threads=8)
+        skip = np.zeros(n, np.uint8)
+        if n > 2:
+            skip[1] = 1; ps[2] = 0
+        one = pairing.multi_miller_loop(ps, qs, skip)
+        assert (pairing.multi_miller_loop_sharded(ps, qs, skip) == one).all()
+        assert (pairing.multi_miller_loop_sharded(ps, qs, skip, ngpus=1) == one).all()
+    with pytest.raises(ca.DockGpuError):
+        pairing.multi_miller_loop_sharded(ps, qs, None, ngpus=5)
+
+
 def test_size_threshold_default_and_override():
     L = lib()
     b = O.G1.generator().reshape(1, 12); s = np.ones((1, 4), np.uint64); out = np.zeros(18, np.uint64)

@@ -1,0 +1,20 @@
+"""Timing driver (GPU box): multi_miller_loop at N pairs (per-stage HIP-event times)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import numpy as np
+import crypto_amd as ca
+from crypto_amd import fixed_base as FB, serde
+import bench as B
+ca.init(0)
+gen1, _ = serde.deserialize(ca.G1, bytes.fromhex(B.G1_GEN_COMPRESSED)); gen2, _ = serde.deserialize(ca.G2, bytes.fromhex(B.G2_GEN_COMPRESSED))
+for n in [int(x) for x in os.environ.get("NS", "3,64,1024,4096,8192").split(",")]:
+    with FB.WindowTable(ca.G2, gen2[0]) as t2, FB.WindowTable(ca.G1, gen1[0]) as t1:
+        P, _ = t1.multiply_many(B.seeded_scalars(5, n)); Q, _ = t2.multiply_many(B.seeded_scalars(6, n))
+    for _ in range(3): ca.multi_miller_loop(P, Q)
+    ca.prof.enable(True); ca.prof.reset()
+    t0 = time.perf_counter()
+    for _ in range(10): ca.multi_miller_loop(P, Q)
+    dt = (time.perf_counter() - t0) / 10 * 1e3
+    st = ca.prof.read(); ca.prof.enable(False)
+    print("pairs=%5d  %.3f ms (%.0f pairs/s) | %s" % (n, dt, n / dt * 1e3, " ".join("%s=%.3f" % (k, v[0] / max(1, v[1])) for k, v in st.items())), flush=True)

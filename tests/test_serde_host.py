@@ -29,6 +29,33 @@ def test_generator_known_answers():
     assert int.from_bytes(un[48:], "big") == U.fp_int(g1[6:])
 
 
+# Compressed 2·G1 and 3·G1 as they are published (the BLS public keys of the secret keys 2 and 3 in the Ethereum consensus-spec /
+# py_ecc / noble-bls12-381 test suites).  Written down from those sources BEFORE the oracle was asked: they pin the oracle's
+# doubling and addition, not only its generator constants.
+G1_TIMES_2_COMPRESSED = bytes.fromhex(
+    "a572cbea904d67468808c8eb50a9450c9721db309128012543902d0ac358a62ae28f75bb8f1c7c42c39a8c5529bf0f4e")
+G1_TIMES_3_COMPRESSED = bytes.fromhex(
+    "89ece308f9d1f0131765212deca99697b112d61f9be9a5f1f3780a51335b3ff981747a0b2ca2179b96d2c0c9024e5224")
+
+
+def test_small_multiples_of_the_generator_match_published_encodings():
+    g = O.G1.generator()[None, :]
+    for k, want in ((2, G1_TIMES_2_COMPRESSED), (3, G1_TIMES_3_COMPRESSED)):
+        sc = np.zeros((1, 4), dtype=np.uint64); sc[0, 0] = k
+        pt, inf = O.G1.to_affine(O.G1.msm(g, sc, None, threads=1))
+        assert not inf and serde.serialize(ca.G1, pt) == want
+        back, binf = serde.deserialize(ca.G1, want)
+        assert not binf[0] and (back[0] == pt).all()
+    # G2 has no such vector at hand: 2·G2 is checked through the pairing instead, e(2·G1, G2) == e(G1, 2·G2)
+    two = np.zeros((1, 4), dtype=np.uint64); two[0, 0] = 2
+    p2 = O.G1.to_affine(O.G1.msm(g, two, None, threads=1))[0]
+    g2 = O.G2.generator()[None, :]
+    q2 = O.G2.to_affine(O.G2.msm(g2, two, None, threads=1))[0]
+    lhs = O.final_exponentiation(O.multi_miller_loop(p2[None, :], g2))
+    rhs = O.final_exponentiation(O.multi_miller_loop(g, q2[None, :]))
+    assert (np.asarray(lhs) == np.asarray(rhs)).all()
+
+
 @pytest.mark.parametrize("curve,G", [(ca.G1, O.G1), (ca.G2, O.G2)])
 @pytest.mark.parametrize("compressed", [True, False])
 def test_roundtrip_random_points_and_identity(curve, G, compressed):

@@ -55,9 +55,9 @@ template <long long M> struct FrKTab {
     constexpr FrKTab() : l{} {
         constexpr uint32_t P_[NL] = FR29_R;
         long long v[NL + 1] = {};
-        long long carry = 0;
-        for (int i = 0; i < NL; i++) { long long t = (long long)P_[i] * M + carry; v[i] = t & LMASK; carry = t >> LB; }
-        v[NL - 1] += carry << LB;
+        unsigned __int128 carry = 0;
+        for (int i = 0; i < NL; i++) { unsigned __int128 t = (unsigned __int128)P_[i] * (unsigned long long)M + carry; v[i] = (long long)(t & LMASK); carry = t >> LB; }
+        v[NL - 1] += (long long)(carry << LB);
         for (int i = 0; i < NL - 1; i++) {
             v[i] += (1ll << 31);
             v[i + 1] -= 4;
@@ -67,16 +67,20 @@ template <long long M> struct FrKTab {
     }
 };
 static_assert(FrKTab<512>().l[0] == 0x80000200u && FrKTab<512>().l[9] == 0x3u, "FrKTab generator");
-// r = a - b + M r.  b normalised (limbs <= 2^29 + 7) with top limb <= K_M's (value(b) < ~(M - 300) r); a limbs < 2^30.
-//   M = 512     : b is a product (value < 2 r)
-//   M = 2^22    : b is any value an NTT can accumulate (decimation-in-frequency sums double per stage: < 2^21 r)
+// r = a - b + M r, limb by limb in 32-bit arithmetic.  Exact when every limb of a + K_M - b stays in [0, 2^32): limbs i < 9 of b
+// normalised (<= 2^29 + 7 < K's 2^31 + d_i), limbs of a < 2^30, and for the top limb value(b) <= ~M r (K_M's top limb is ~M / 70.4).
+//   M = 512     : b is a product (value < 4 r)
+//   M = 2^34    : b is any value an NTT can accumulate.  Decimation-in-frequency sums double per stage and the two operands of a
+//                 butterfly need NOT be balanced (a circuit whose even rows are empty and whose odd rows are dense subtracts a partial
+//                 sum of D/2 rows from nothing): with inputs < 16 r (k_csr_eval reduces longer rows) and D <= 2^28, value(b) < 2^32 r.
+//                 The product that follows sees an operand < 1.5 * 2^34 r and returns < 2.4 r (Montgomery radix 2^290 = 2^35.1 r).
 template <long long M = 512> FRD void fr_sub(Fr &r, const Fr &a, const Fr &b) {
     constexpr FrKTab<M> K{};
     static_assert(K.l[NL - 1] < (1u << 30), "multiple too large");
 #pragma unroll
     for (int i = 0; i < NL; i++) r.l[i] = a.l[i] + (K.l[i] - b.l[i]);
 }
-constexpr long long FR_BIG = 1ll << 22;
+constexpr long long FR_BIG = 1ll << 34;
 FRD void fr_norm(Fr &r, const Fr &a) {
     uint32_t c[NL];
 #pragma unroll

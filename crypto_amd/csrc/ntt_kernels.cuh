@@ -94,6 +94,9 @@ __global__ void __launch_bounds__(256) k_csr_eval(const uint64_t *__restrict__ r
             Fr c, zz, t; ld(c, vals_soa, nnz, k); ld_words(zz, z_words, cols[k], z_mont != 0);
             fr_mul(t, zz, c); fr_add(acc, acc, t); fr_norm(acc, acc);
         }
+        // a long row leaves a sum of (row length) products of < 2 r each: one product with the Montgomery one brings it back under 2 r, so
+        // that what the inverse transform accumulates is bounded by the domain size alone (fr_sub's M = 2^34 case)
+        if (rowptr[i + 1] - rowptr[i] > 8) { Fr one; fr_one(one); fr_mul(acc, acc, one); }
     } else if (i < rows + extra) ld_words(acc, z_words, i - rows, z_mont != 0);
     (void)nvars;
     st(out, D, i, acc);
@@ -110,7 +113,7 @@ __global__ void __launch_bounds__(256) k_ntt_stage(uint32_t *__restrict__ buf, i
     Fr x, y, w, u, v; ld(x, buf, D, i0); ld(y, buf, D, i1); ld(w, tw, H, e);
     if (dif) {
         fr_add(u, x, y); fr_norm(u, u);
-        fr_sub<FR_BIG>(v, x, y); fr_norm(v, v); fr_mul(v, v, w);     // y may carry up to 2^21 r
+        fr_sub<FR_BIG>(v, x, y); fr_norm(v, v); fr_mul(v, v, w);     // y: an unreduced partial sum (up to 2^32 r)
     } else {
         Fr yw; fr_mul(yw, y, w);
         fr_add(u, x, yw); fr_norm(u, u);
@@ -193,6 +196,153 @@ __global__ void __launch_bounds__(FUSE_THREADS) k_ntt_fused(uint32_t *__restrict
         uint32_t slot = (mid << cols_log) | cc2;
 #pragma unroll
         for (int l = 0; l < NL; l++) buf[(size_t)l * D + a] = lds[l * TILE + slot];
+    }
+}
+
+// ---- the pipelined form of the fused pass -------------------------------------------------------------------------------------
+// k_ntt_fused runs  load tile -> S stages -> store tile  per block, and a D = 2^20 transform is exactly one round of blocks (512 tiles on
+// 256 CUs x 2): every block of the chip loads, computes and stores at the same time, so a pass lasts load + compute + store
+// (~66 us against ~38 us of butterfly issue time).  k_ntt_pipe removes the two memory phases:
+//   * blocks are persistent and walk the tiles of up to three arrays (the a, b, c rows of the witness map go through every pass together);
+//   * the FIRST stage of a tile takes its operands from registers that were loaded from HBM while the previous tile was being computed,
+//     the LAST stage stores its results straight to HBM — no staging loop, no barrier around it;
+//   * the lane -> butterfly mapping follows the direction that is contiguous in HBM (along the columns when L > 0, along `mid` when the
+//     tile is one contiguous run, L = 0), so these direct accesses are coalesced and the LDS layout never needs a transposition;
+//   * rows are addressed as (uniform row base in SGPRs) + (one 32-bit element offset per access): no per-limb 64-bit address arithmetic.
+struct NttBatch { uint32_t *buf[3]; };
+// Rows of a limb-major array through a buffer descriptor: descriptor (4 SGPRs, uniform base) + row offset l * stride in an SGPR + ONE 32-bit
+// element offset in a VGPR shared by the ten rows — no per-limb 64-bit address arithmetic on the vector ALU (hipcc otherwise re-associates
+// base + l * stride + i into ten v_lshl_add_u64 and ten address register pairs).  Offsets are 32-bit: arrays of up to 4 GB (logn <= 26).
+constexpr int PIPE_MAX_LOGN = 26;
+constexpr int PIPE_TILE_LOG = 11;      // 2048 elements = 80 KB of LDS, 512 lanes, two blocks per CU
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rows_of(const uint32_t *base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(base), 0, 0xffffffff, 0x00020000);
+}
+__device__ __forceinline__ void ldg(Fr &r, __amdgpu_buffer_rsrc_t rows, uint32_t stride_bytes, uint32_t i) {
+    const uint32_t off = i << 2;
+#pragma unroll
+    for (int l = 0; l < NL; l++) r.l[l] = __builtin_amdgcn_raw_buffer_load_b32(rows, off, l * stride_bytes, 0);
+}
+__device__ __forceinline__ void stg(__amdgpu_buffer_rsrc_t rows, uint32_t stride_bytes, uint32_t i, const Fr &a) {
+    const uint32_t off = i << 2;
+#pragma unroll
+    for (int l = 0; l < NL; l++) __builtin_amdgcn_raw_buffer_store_b32(a.l[l], rows, off, l * stride_bytes, 0);
+}
+template <bool DIF> __device__ __forceinline__ void butterfly(Fr &x, Fr &y, const Fr &w) {
+    Fr u, v;
+    if (DIF) {
+        fr_add(u, x, y); fr_norm(u, u);
+        fr_sub<FR_BIG>(v, x, y); fr_norm(v, v); fr_mul(v, v, w);     // y: an unreduced partial sum (up to 2^32 r)
+    } else {
+        Fr yw; fr_mul(yw, y, w);
+        fr_add(u, x, yw); fr_norm(u, u);
+        fr_sub(v, x, yw); fr_norm(v, v);
+    }
+    x = u; y = v;
+}
+// Barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory counter (s_waitcnt vmcnt(0)): here that would make
+// every stage wait for the prefetched operands of the next tile, for the twiddle requested one butterfly ahead and — at the end of a tile —
+// for the results just stored to HBM.  Nothing a lane reads from HBM inside this kernel was written by another lane of the same launch.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+template <bool DIF, int TILE_LOG>
+__global__ void __launch_bounds__(1 << (TILE_LOG - 2)) __attribute__((amdgpu_waves_per_eu(4, 4)))
+k_ntt_pipe(NttBatch B, int nbuf, int logn, int s0, int S, const uint32_t *__restrict__ tw, const uint32_t *__restrict__ pre) {
+    extern __shared__ uint32_t lds[];                      // [NL][TILE]
+    constexpr int TILE = 1 << TILE_LOG, THREADS = TILE >> 2;
+    const size_t D = (size_t)1 << logn, H = D >> 1;
+    const int L = DIF ? (logn - s0 - S) : s0;
+    const int cols_log = TILE_LOG - S;
+    const uint32_t lo_mask = (1u << L) - 1;
+    const bool flat = (L == 0);
+    const int tpb_log = logn - TILE_LOG;
+    const uint32_t total = (uint32_t)nbuf << tpb_log;
+    // two butterflies per lane and stage: (column cc, butterfly bb of that column)
+    uint32_t cc[2], bb[2];
+#pragma unroll
+    for (int rep = 0; rep < 2; rep++) {
+        const uint32_t t = threadIdx.x + rep * THREADS;
+        if (flat) { bb[rep] = t & ((1u << (S - 1)) - 1); cc[rep] = t >> (S - 1); }
+        else { cc[rep] = t & ((1u << cols_log) - 1); bb[rep] = t >> cols_log; }
+    }
+    auto gaddr = [&](uint32_t c0, uint32_t mid, uint32_t c_) -> uint32_t {
+        const uint32_t c = c0 + c_, hi = c >> L, lo = c & lo_mask;
+        return (hi << (L + S)) | (mid << L) | lo;
+    };
+    auto slot = [&](uint32_t mid, uint32_t c_) -> uint32_t { return flat ? ((c_ << S) | mid) : ((mid << cols_log) | c_); };
+    auto geom = [&](int st, uint32_t b, uint32_t &m0, uint32_t &m1, uint32_t &jm) {
+        const uint32_t half_m = DIF ? (1u << (S - 1 - st)) : (1u << st);
+        jm = b & (half_m - 1); m0 = ((b - jm) << 1) + jm; m1 = m0 + half_m;
+    };
+    auto twiddle = [&](Fr &w, int st, uint32_t c0, uint32_t c_, uint32_t jm) {
+        const int s = s0 + st, sigma = DIF ? s : (logn - 1 - s);
+        const uint32_t j = (jm << L) | ((c0 + c_) & lo_mask);
+        ldg(w, rows_of(tw + tw_stage_offset(H, sigma)), (uint32_t)((H >> sigma) << 2), j);
+    };
+    auto pick = [&](uint32_t tile) -> uint32_t * { const uint32_t k = tile >> tpb_log; return k == 0 ? B.buf[0] : (k == 1 ? B.buf[1] : B.buf[2]); };
+
+    Fr X0, Y0, X1, Y1;                                     // first-stage operands of the lane's two butterflies
+    const uint32_t Db = (uint32_t)(D << 2);                // bytes per row
+    auto fetch1 = [&](const uint32_t *buf, uint32_t c0, int rep, Fr &X, Fr &Y) {
+        uint32_t m0, m1, jm; geom(0, bb[rep], m0, m1, jm);
+        const __amdgpu_buffer_rsrc_t rows = rows_of(buf);
+        ldg(X, rows, Db, gaddr(c0, m0, cc[rep])); ldg(Y, rows, Db, gaddr(c0, m1, cc[rep]));
+    };
+    auto fetch = [&](uint32_t tile) {
+        const uint32_t *buf = pick(tile);
+        const uint32_t c0 = (tile & ((1u << tpb_log) - 1)) << cols_log;
+        fetch1(buf, c0, 0, X0, Y0); fetch1(buf, c0, 1, X1, Y1);
+    };
+    // Twiddles run one butterfly ahead: the factor of the NEXT butterfly of this lane (other rep, next stage, or the first stage of the
+    // next tile) is requested before the current one is computed, so its L2 latency is never waited for.
+    Fr wn;
+    auto tw_req = [&](int st, uint32_t c0, int rep) { uint32_t m0, m1, jm; geom(st, bb[rep], m0, m1, jm); twiddle(wn, st, c0, cc[rep], jm); };
+    auto first = [&](uint32_t *buf, uint32_t c0, int rep, Fr &X, Fr &Y, int nst, uint32_t nc0, int nrep) {
+        uint32_t m0, m1, jm; geom(0, bb[rep], m0, m1, jm);
+        const Fr w = wn;
+        if (nst >= 0) tw_req(nst, nc0, nrep);
+        if (pre) {
+            const __amdgpu_buffer_rsrc_t prows = rows_of(pre);
+            Fr g; ldg(g, prows, Db, gaddr(c0, m0, cc[rep])); fr_mul(X, X, g);
+            ldg(g, prows, Db, gaddr(c0, m1, cc[rep])); fr_mul(Y, Y, g);
+        }
+        butterfly<DIF>(X, Y, w);
+        if (S == 1) { const __amdgpu_buffer_rsrc_t rows = rows_of(buf); stg(rows, Db, gaddr(c0, m0, cc[rep]), X); stg(rows, Db, gaddr(c0, m1, cc[rep]), Y); return; }
+        const uint32_t p0 = slot(m0, cc[rep]), p1 = slot(m1, cc[rep]);
+#pragma unroll
+        for (int l = 0; l < NL; l++) { lds[l * TILE + p0] = X.l[l]; lds[l * TILE + p1] = Y.l[l]; }
+    };
+    auto later = [&](uint32_t *buf, uint32_t c0, int st, bool last, int rep, int nst, uint32_t nc0, int nrep) {
+        uint32_t m0, m1, jm; geom(st, bb[rep], m0, m1, jm);
+        Fr x, y; const Fr w = wn;
+        const uint32_t p0 = slot(m0, cc[rep]), p1 = slot(m1, cc[rep]);
+#pragma unroll
+        for (int l = 0; l < NL; l++) { x.l[l] = lds[l * TILE + p0]; y.l[l] = lds[l * TILE + p1]; }
+        if (nst >= 0) tw_req(nst, nc0, nrep);
+        butterfly<DIF>(x, y, w);
+        if (last) { const __amdgpu_buffer_rsrc_t rows = rows_of(buf); stg(rows, Db, gaddr(c0, m0, cc[rep]), x); stg(rows, Db, gaddr(c0, m1, cc[rep]), y); }
+        else {
+#pragma unroll
+            for (int l = 0; l < NL; l++) { lds[l * TILE + p0] = x.l[l]; lds[l * TILE + p1] = y.l[l]; }
+        }
+    };
+    auto c0_of = [&](uint32_t tile) -> uint32_t { return (tile & ((1u << tpb_log) - 1)) << cols_log; };
+    uint32_t tile = blockIdx.x;
+    if (tile < total) { fetch(tile); tw_req(0, c0_of(tile), 0); }
+    for (; tile < total; tile += gridDim.x) {
+        uint32_t *buf = pick(tile);
+        const uint32_t c0 = c0_of(tile), ntile = tile + gridDim.x;
+        const bool more = ntile < total;
+        const uint32_t nc0 = more ? c0_of(ntile) : 0;
+        first(buf, c0, 0, X0, Y0, 0, c0, 1);                       // first stage: operands already in registers
+        first(buf, c0, 1, X1, Y1, S > 1 ? 1 : (more ? 0 : -1), S > 1 ? c0 : nc0, 0);
+        lds_barrier();
+        if (more) fetch(ntile);                                     // lands while the remaining stages run
+        for (int st = 1; st < S; st++) {
+            const bool last = (st == S - 1);
+            later(buf, c0, st, last, 0, st, c0, 1);
+            later(buf, c0, st, last, 1, last ? (more ? 0 : -1) : st + 1, last ? nc0 : c0, 0);
+            lds_barrier();
+        }
     }
 }
 

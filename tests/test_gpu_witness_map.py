@@ -83,3 +83,31 @@ def test_resident_h_feeds_the_msm_and_the_proof_verifies():
     dr.free()
     h_bad = h.copy(); h_bad[3][0] ^= np.uint64(1)
     assert not LG.verify_proof(pvk, LG.create_proof(pk, 12345, 67890, 424242, h_bad, inp, wit), inp[1:])
+
+
+@pytest.mark.parametrize("logd,k,skew", [(16, 160, False), (18, 48, False), (18, 96, True), (17, 400, True)])
+def test_dense_rows_do_not_outgrow_the_lazy_representation(logd, k, skew):
+    """Rows with many terms (hash-function circuits have linear combinations of tens to hundreds of variables): the matrix-vector products
+    and the partial sums of the decimation-in-frequency stages stay inside what the lazy Fr representation and its subtraction
+    constants can hold (D x k >= 2^23 terms; the inputs need not satisfy the constraints — both sides interpolate the same coset
+    evaluations, r1cs_to_qap.rs:186-205).  skew: only the odd rows carry terms, so the last inverse stages subtract a partial sum of
+    2^(logd-1) x k products from (nearly) nothing — the worst case for a subtraction constant sized for balanced operands."""
+    n_inst = 2
+    m = (1 << logd) - n_inst
+    nv = 5000
+    rng = np.random.default_rng(logd)
+    per_row = np.full(m, k, dtype=np.uint64)
+    if skew:
+        per_row[0::2] = 0
+    rp = np.concatenate([[0], np.cumsum(per_row)]).astype(np.uint64)
+    nnz = int(rp[-1])
+    mats = []
+    for i in range(3):
+        cols = rng.integers(0, nv, nnz, dtype=np.uint32)
+        vals = O.rand_scalars(900 + 3 * logd + i, nnz)
+        mats.append((rp, cols, vals))
+    z = O.rand_scalars(77 + logd, nv)
+    cs = {"n_cons": m, "n_inst": n_inst, "z": [O.limbs_to_int(x) for x in z]}
+    ref = oracle_map(cs, mats)
+    h, _ = qap.witness_map(*mats, z, n_inst, m)
+    assert (h == ref).all()

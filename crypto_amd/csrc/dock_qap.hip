@@ -103,9 +103,8 @@ int32_t witness_map_device(Slot &sl, const DevR1cs &r, const uint64_t *assignmen
         StageTimer st(sl, "qap.ntt");
         ntt::launch_ntt_batch(s, arr, 3, logn, (const uint32_t *)dom.tw_i, 1);                                       // iFFT (x D) of a, b, c together, bit-reversed out
         ntt::launch_ntt_batch(s, arr, 3, logn, (const uint32_t *)dom.tw_f, 0, (const uint32_t *)dom.pwr_f);          // * g^k / D on the way in, coset FFT, natural out
-        ntt::launch_pointwise(s, arr[0], arr[1], arr[2], D, (const uint32_t *)dom.zinv);           // (ab - c) / Z(g)
-        ntt::launch_ntt(s, arr[0], logn, (const uint32_t *)dom.tw_i, 1);                           // coset iFFT ...
-        ntt::launch_coset_scale(s, arr[0], logn, (const uint32_t *)dom.pwr_i, hw.as<uint32_t>(), 1);   // ... * g^-k / D, un-reversed, canonical words
+        // (ab - c) / Z(g) -> coset iFFT -> * g^-k / D, un-reversed, canonical words: one set of passes
+        ntt::launch_ntt_final(s, arr[0], arr[1], arr[2], logn, (const uint32_t *)dom.tw_i, (const uint32_t *)dom.zinv, (const uint32_t *)dom.pwr_i, hw.as<uint32_t>());
     }
     HIPCHK(hipGetLastError());
     if (out_len) *out_len = D;

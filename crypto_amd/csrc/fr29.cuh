@@ -50,7 +50,7 @@ FRD void fr_add(Fr &r, const Fr &a, const Fr &b) {
 }
 // Redundant form of M r whose limbs dominate a normalised subtrahend: limbs i < 9 are 2^31 + d_i, the top limb is what remains
 // (~ (M - 283) / 70).  Generated at compile time.
-template <long long M> struct FrKTab {
+template <long long M, int SH = 31> struct FrKTab {
     uint32_t l[NL];
     constexpr FrKTab() : l{} {
         constexpr uint32_t P_[NL] = FR29_R;
@@ -59,8 +59,8 @@ template <long long M> struct FrKTab {
         for (int i = 0; i < NL; i++) { unsigned __int128 t = (unsigned __int128)P_[i] * (unsigned long long)M + carry; v[i] = (long long)(t & LMASK); carry = t >> LB; }
         v[NL - 1] += (long long)(carry << LB);
         for (int i = 0; i < NL - 1; i++) {
-            v[i] += (1ll << 31);
-            v[i + 1] -= 4;
+            v[i] += (1ll << SH);                       // limbs i < 9 become 2^SH + d_i ...
+            v[i + 1] -= (1ll << (SH - LB));            // ... borrowed from the next limb
             for (int j = i + 1; j < NL - 1 && v[j] < 0; j++) { v[j] += (1ll << LB); v[j + 1] -= 1; }
         }
         for (int i = 0; i < NL; i++) l[i] = (uint32_t)v[i];
@@ -74,12 +74,15 @@ static_assert(FrKTab<512>().l[0] == 0x80000200u && FrKTab<512>().l[9] == 0x3u, "
 //                 butterfly need NOT be balanced (a circuit whose even rows are empty and whose odd rows are dense subtracts a partial
 //                 sum of D/2 rows from nothing): with inputs < 16 r (k_csr_eval reduces longer rows) and D <= 2^28, value(b) < 2^32 r.
 //                 The product that follows sees an operand < 1.5 * 2^34 r and returns < 2.4 r (Montgomery radix 2^290 = 2^35.1 r).
-template <long long M = 512> FRD void fr_sub(Fr &r, const Fr &a, const Fr &b) {
-    constexpr FrKTab<M> K{};
+template <long long M = 512, int SH = 31> FRD void fr_sub(Fr &r, const Fr &a, const Fr &b) {
+    constexpr FrKTab<M, SH> K{};
     static_assert(K.l[NL - 1] < (1u << 30), "multiple too large");
 #pragma unroll
     for (int i = 0; i < NL; i++) r.l[i] = a.l[i] + (K.l[i] - b.l[i]);
 }
+// the same with limbs 2^30 + d_i: the result of a (normalised) - b (a product) stays below 2^31 per limb, so it can enter a product or one more
+// addition / subtraction without a carry pass (the radix-4 butterflies of the NTT)
+static_assert(FrKTab<512, 30>().l[0] == 0x40000200u && FrKTab<512, 30>().l[9] == 0x5u, "FrKTab generator (2^30 form)");
 constexpr long long FR_BIG = 1ll << 34;
 FRD void fr_norm(Fr &r, const Fr &a) {
     uint32_t c[NL];
@@ -118,8 +121,8 @@ FRD void fr_mul(Fr &r, const Fr &a, const Fr &b) {
 #pragma unroll
     for (int i = 0; i < NL; i++) r.l[i] = t[i];
 }
-// canonical representative in [0, r), limbs fully propagated.  Precondition: value < 2^24 r.
-FRD void fr_canon(Fr &r, const Fr &a) {
+// canonical representative in [0, r), limbs fully propagated.  Precondition: value < 2^STEPS r (a product is < 2 r: STEPS = 2 covers it twice).
+template <int STEPS = 24> FRD void fr_canon(Fr &r, const Fr &a) {
     constexpr uint32_t P_[NL] = FR29_R;
     uint32_t t[NL];
     uint64_t c = 0;
@@ -127,7 +130,7 @@ FRD void fr_canon(Fr &r, const Fr &a) {
     for (int i = 0; i < NL - 1; i++) { c += a.l[i]; t[i] = (uint32_t)c & LMASK; c >>= LB; }
     c += a.l[NL - 1];
     t[NL - 1] = (uint32_t)c;
-    for (int j = 23; j >= 0; j--) {
+    for (int j = STEPS - 1; j >= 0; j--) {
         uint32_t q[NL];
         uint64_t cc = 0;
 #pragma unroll
@@ -168,8 +171,8 @@ FRD void fr_to_words(uint32_t w[8], const Fr &a, bool mont) {
     fr_zero(k); k.l[0] = 1;
     if (mont) fr_const(k, CM_);
     fr_norm(t, a);
-    fr_mul(t, t, k);
-    fr_canon(c, t);
+    fr_mul(t, t, k);        // < r (1 + value(a) / 2^290) < 2 r
+    fr_canon<2>(c, t);
     uint32_t o[9];
 #pragma unroll
     for (int i = 0; i < 9; i++) o[i] = 0;

@@ -15,27 +15,22 @@ void launch_tw_compact(hipStream_t s, uint32_t *tw, size_t H) {
 void launch_csr_eval(hipStream_t s, const uint64_t *rowptr, const uint32_t *cols, const uint32_t *vals_soa, size_t nnz, const uint32_t *z_words, int z_mont, size_t nvars, size_t rows, size_t extra, uint32_t *out, size_t D) {
     hipLaunchKernelGGL(k_csr_eval, grid_for(D), dim3(256), 0, s, rowptr, cols, vals_soa, nnz, z_words, z_mont, nvars, rows, extra, out, D);
 }
-static unsigned resident_fused_blocks() {               // two 80-KB blocks per CU; one value per device
-    static std::atomic<int> cached[32];
-    int dev = 0; (void)hipGetDevice(&dev);
-    int v = cached[dev & 31].load();
-    if (!v) { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) { (void)hipGetLastError(); cus = 256; } v = 2 * cus; cached[dev & 31].store(v); }
-    return (unsigned)v;
-}
-void launch_ntt_batch(hipStream_t s, uint32_t *const *bufs, int nbuf, int logn, const uint32_t *tw, int dif, const uint32_t *pre) {
+// in_pointwise: bufs = {a, b, c}, pre = zinv words, the transform runs over a only (see k_ntt_r4); post / out_words: the last pass writes scalars
+static bool run_passes(hipStream_t s, uint32_t *const *bufs, int nbuf, int logn, const uint32_t *tw, int dif, const uint32_t *pre, bool in_pointwise, const uint32_t *post, uint32_t *out_words) {
     const size_t D = (size_t)1 << logn, H = D >> 1;
 #ifdef DGPU_DEV
     static const bool unfused = getenv("DGPU_NTT_UNFUSED") != nullptr;     // development switches (compile with -DDGPU_DEV)
-    static const bool unpiped = getenv("DGPU_NTT_UNPIPED") != nullptr;
+    static const bool unpiped = getenv("DGPU_NTT_STAGED") != nullptr;       // the load / stages / store kernel (k_ntt_fused)
 #else
     constexpr bool unfused = false, unpiped = false;
 #endif
-    if (logn < FUSE_TILE_LOG || unfused) {               // tiny domains: one pass per stage
+    if ((in_pointwise || post) && (logn < PIPE_TILE_LOG || logn > PIPE_MAX_LOGN || unfused || unpiped)) return false;   // the caller runs the separate kernels
+    if (logn < PIPE_TILE_LOG || unfused) {               // tiny domains: one pass per stage
         for (int b = 0; b < nbuf; b++) {
             if (pre) hipLaunchKernelGGL(k_coset_scale, grid_for(D), dim3(256), 0, s, bufs[b], logn, pre, (uint32_t *)nullptr, 1);
             for (int st = 0; st < logn; st++) hipLaunchKernelGGL(k_ntt_stage, grid_for(H), dim3(256), 0, s, bufs[b], logn, st, tw, dif);
         }
-        return;
+        return true;
     }
     if (unpiped || logn > PIPE_MAX_LOGN) {                // (32-bit buffer offsets: arrays beyond 4 GB take the staged kernel)
         const size_t lds_bytes = (size_t)NL * (1u << FUSE_TILE_LOG) * 4;      // 80 KB
@@ -54,14 +49,11 @@ void launch_ntt_batch(hipStream_t s, uint32_t *const *bufs, int nbuf, int logn, 
         }
         const unsigned tiles = (unsigned)(D >> FUSE_TILE_LOG);
         for (int b = 0; b < nbuf; b++) { int s0 = 0; for (int gidx = 0; gidx < ng; gidx++) { hipLaunchKernelGGL(k_ntt_fused, dim3(tiles), dim3(FUSE_THREADS), lds_bytes, s, bufs[b], logn, s0, groups[gidx], tw, dif, gidx == 0 ? pre : (const uint32_t *)nullptr); s0 += groups[gidx]; } }
-        return;
+        return true;
     }
     // Pipelined passes.  One pass is "flat" (L = 0: a tile is one contiguous run, up to TILE_LOG stages), the others are strided and a tile
     // holds 2^(TILE_LOG - S) consecutive columns: S = TILE_LOG - 5 keeps every access a full 128-byte line (32 columns), one more stage halves it.
-    int tile_log = PIPE_TILE_LOG;
-#ifdef DGPU_DEV
-    if (const char *e = getenv("DGPU_NTT_TILE_LOG")) tile_log = atoi(e) == 10 ? 10 : 11;
-#endif
+    constexpr int tile_log = PIPE_TILE_LOG;
     const int pref = tile_log - 5, maxs = tile_log - 4;
     int groups[12], ng = 0;
     {
@@ -72,9 +64,6 @@ void launch_ntt_batch(hipStream_t s, uint32_t *const *bufs, int nbuf, int logn, 
         if (flat < 1) flat = 1;
         int strided[12], rest = logn - flat;
         for (int k = 0; k < n_str; k++) { strided[k] = rest / (n_str - k); rest -= strided[k]; }
-#ifdef DGPU_DEV
-        (void)strided;
-#endif
         if (dif) { for (int k = n_str - 1; k >= 0; k--) groups[ng++] = strided[k]; groups[ng++] = flat; }
         else { groups[ng++] = flat; for (int k = 0; k < n_str; k++) groups[ng++] = strided[k]; }
     }
@@ -88,32 +77,32 @@ void launch_ntt_batch(hipStream_t s, uint32_t *const *bufs, int nbuf, int logn, 
     const size_t lds_bytes = (size_t)NL * ((size_t)1 << tile_log) * 4;
     { static std::atomic<uint32_t> done{0}; int dev = 0; (void)hipGetDevice(&dev); const uint32_t bit = 1u << (dev & 31);
       if (!(done.load() & bit)) {
-          (void)hipFuncSetAttribute((const void *)k_ntt_pipe<true, 11>, hipFuncAttributeMaxDynamicSharedMemorySize, NL * 2048 * 4);
-          (void)hipFuncSetAttribute((const void *)k_ntt_pipe<false, 11>, hipFuncAttributeMaxDynamicSharedMemorySize, NL * 2048 * 4);
-          (void)hipFuncSetAttribute((const void *)k_ntt_pipe<true, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, NL * 1024 * 4);
-          (void)hipFuncSetAttribute((const void *)k_ntt_pipe<false, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, NL * 1024 * 4);
+          (void)hipFuncSetAttribute((const void *)k_ntt_r4<true, PIPE_TILE_LOG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+          (void)hipFuncSetAttribute((const void *)k_ntt_r4<false, PIPE_TILE_LOG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
           done.fetch_or(bit); } }
     NttBatch B; for (int b = 0; b < 3; b++) B.buf[b] = bufs[b < nbuf ? b : 0];
-    const unsigned tiles = (unsigned)(D >> tile_log), total = tiles * (unsigned)nbuf;
-    const unsigned resident = resident_fused_blocks() * (tile_log == 10 ? 2u : 1u);
-    unsigned grid = total < resident ? total : resident;
-#ifdef DGPU_DEV
-    if (const char *e = getenv("DGPU_NTT_GRID")) { unsigned g = (unsigned)atoi(e); if (g >= 1 && g <= total) grid = g; }
-    if (getenv("DGPU_NTT_OCC")) { int nb = -1; (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_ntt_pipe<true, 11>, 512, NL * 2048 * 4); int nb10 = -1; (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb10, (const void *)k_ntt_pipe<true, 10>, 256, NL * 1024 * 4); fprintf(stderr, "occupancy: tile11 %d blocks/CU, tile10 %d blocks/CU\n", nb, nb10); }
-#endif
+    const unsigned tiles = (unsigned)(D >> tile_log), total = tiles * (unsigned)(in_pointwise ? 1 : nbuf);
     const dim3 blk(1u << (tile_log - 2));
     int s0 = 0;
     for (int gidx = 0; gidx < ng; gidx++) {
         const uint32_t *pr = gidx == 0 ? pre : (const uint32_t *)nullptr;
-        if (tile_log == 11) {
-            if (dif) hipLaunchKernelGGL((k_ntt_pipe<true, 11>), dim3(grid), blk, lds_bytes, s, B, nbuf, logn, s0, groups[gidx], tw, pr);
-            else hipLaunchKernelGGL((k_ntt_pipe<false, 11>), dim3(grid), blk, lds_bytes, s, B, nbuf, logn, s0, groups[gidx], tw, pr);
-        } else {
-            if (dif) hipLaunchKernelGGL((k_ntt_pipe<true, 10>), dim3(grid), blk, lds_bytes, s, B, nbuf, logn, s0, groups[gidx], tw, pr);
-            else hipLaunchKernelGGL((k_ntt_pipe<false, 10>), dim3(grid), blk, lds_bytes, s, B, nbuf, logn, s0, groups[gidx], tw, pr);
-        }
+        const int im = (gidx == 0 && in_pointwise) ? NTT_IN_POINTWISE : 0, om = (gidx == ng - 1 && post) ? NTT_OUT_WORDS : 0;
+        if (dif) hipLaunchKernelGGL((k_ntt_r4<true, PIPE_TILE_LOG>), dim3(total), blk, lds_bytes, s, B, logn, s0, groups[gidx], tw, pr, im, om, post, out_words);
+        else hipLaunchKernelGGL((k_ntt_r4<false, PIPE_TILE_LOG>), dim3(total), blk, lds_bytes, s, B, logn, s0, groups[gidx], tw, pr, im, om, post, out_words);
         s0 += groups[gidx];
     }
+    return true;
+}
+void launch_ntt_batch(hipStream_t s, uint32_t *const *bufs, int nbuf, int logn, const uint32_t *tw, int dif, const uint32_t *pre) {
+    (void)run_passes(s, bufs, nbuf, logn, tw, dif, pre, false, nullptr, nullptr);
+}
+// h = coset iFFT of (a b - c) / Z(g), written as canonical scalars in natural order: a <- iDFT((a b - c) zinv) (bit-reversed), out[k] = a[rev k] pw[rev k]
+void launch_ntt_final(hipStream_t s, uint32_t *a, uint32_t *b, uint32_t *c, int logn, const uint32_t *tw_i, const uint32_t *zinv_words, const uint32_t *pw_data_order, uint32_t *out_words) {
+    uint32_t *bufs[3] = {a, b, c};
+    if (run_passes(s, bufs, 3, logn, tw_i, 1, zinv_words, true, pw_data_order, out_words)) return;
+    launch_pointwise(s, a, b, c, (size_t)1 << logn, zinv_words);
+    launch_ntt(s, a, logn, tw_i, 1);
+    launch_coset_scale(s, a, logn, pw_data_order, out_words, 1);
 }
 void launch_ntt(hipStream_t s, uint32_t *buf, int logn, const uint32_t *tw, int dif, const uint32_t *pre) { uint32_t *b[1] = {buf}; launch_ntt_batch(s, b, 1, logn, tw, dif, pre); }
 void launch_coset_scale(hipStream_t s, uint32_t *buf, int logn, const uint32_t *pw, uint32_t *out_words, int pw_in_data_order) { hipLaunchKernelGGL(k_coset_scale, grid_for((size_t)1 << logn), dim3(256), 0, s, buf, logn, pw, out_words, pw_in_data_order); }

@@ -199,22 +199,19 @@ __global__ void __launch_bounds__(FUSE_THREADS) k_ntt_fused(uint32_t *__restrict
     }
 }
 
-// ---- the pipelined form of the fused pass -------------------------------------------------------------------------------------
-// k_ntt_fused runs  load tile -> S stages -> store tile  per block, and a D = 2^20 transform is exactly one round of blocks (512 tiles on
-// 256 CUs x 2): every block of the chip loads, computes and stores at the same time, so a pass lasts load + compute + store
-// (~66 us against ~38 us of butterfly issue time).  k_ntt_pipe removes the two memory phases:
-//   * blocks are persistent and walk the tiles of up to three arrays (the a, b, c rows of the witness map go through every pass together);
-//   * the FIRST stage of a tile takes its operands from registers that were loaded from HBM while the previous tile was being computed,
-//     the LAST stage stores its results straight to HBM — no staging loop, no barrier around it;
-//   * the lane -> butterfly mapping follows the direction that is contiguous in HBM (along the columns when L > 0, along `mid` when the
-//     tile is one contiguous run, L = 0), so these direct accesses are coalesced and the LDS layout never needs a transposition;
-//   * rows are addressed as (uniform row base in SGPRs) + (one 32-bit element offset per access): no per-limb 64-bit address arithmetic.
+// ---- passes without separate load / store phases ----------------------------------------------------------------------------------
+// k_ntt_fused runs  load tile -> S stages -> store tile  per block, and a D = 2^20 transform is exactly one round of blocks: every block
+// of the chip loads, computes and stores at the same time, so a pass lasts load + compute + store (~66 us against ~38 us of issue time).
+// k_ntt_r4 below has no staging loops: the FIRST group of stages takes its operands straight from HBM, the LAST one stores straight to
+// HBM; the lane -> element mapping follows the direction that is contiguous in HBM (along the columns when L > 0, along `mid` when the
+// tile is one contiguous run, L = 0), so these direct accesses are coalesced and the LDS layout never needs a transposition; rows are
+// addressed through buffer descriptors; the a, b, c arrays of the witness map go through every pass together (one launch per pass).
 struct NttBatch { uint32_t *buf[3]; };
 // Rows of a limb-major array through a buffer descriptor: descriptor (4 SGPRs, uniform base) + row offset l * stride in an SGPR + ONE 32-bit
 // element offset in a VGPR shared by the ten rows — no per-limb 64-bit address arithmetic on the vector ALU (hipcc otherwise re-associates
 // base + l * stride + i into ten v_lshl_add_u64 and ten address register pairs).  Offsets are 32-bit: arrays of up to 4 GB (logn <= 26).
 constexpr int PIPE_MAX_LOGN = 26;
-constexpr int PIPE_TILE_LOG = 11;      // 2048 elements = 80 KB of LDS, 512 lanes, two blocks per CU
+constexpr int PIPE_TILE_LOG = 10;      // 1024 elements = 40 KB of LDS, 256 lanes (one radix-4 unit each), four blocks per CU
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t rows_of(const uint32_t *base) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(base), 0, 0xffffffff, 0x00020000);
 }
@@ -244,9 +241,28 @@ template <bool DIF> __device__ __forceinline__ void butterfly(Fr &x, Fr &y, cons
 // every stage wait for the prefetched operands of the next tile, for the twiddle requested one butterfly ahead and — at the end of a tile —
 // for the results just stored to HBM.  Nothing a lane reads from HBM inside this kernel was written by another lane of the same launch.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// ---- radix-4 form: two stages per trip through LDS ------------------------------------------------------------------------------
+// The pass kernels are bound by instruction issue (every VALU instruction costs a quad-cycle, v_mad_u64_u32 1.2 of them; measured:
+// one block per CU already reaches 88 % of the two-block rate, and prefetching the next tile changes nothing), so what counts is the
+// instruction count per butterfly: 180 multiply-adds inside ~390 vector + ~40 LDS / memory instructions.  A lane that keeps FOUR elements
+// and runs two stages on them halves the LDS traffic, the slot / address arithmetic and the barriers, loads 3 twiddles for 4 butterflies,
+// and needs no carry pass between the two stages: limbs are 29 bits in 32-bit words, a sum of two normalised values or a difference
+// formed with the 2^30-limbed multiple of r stays below 2^31 and may enter a product or one more addition as it is.
+//   DIT pair of stages (st, st+1), distances ha = 2^st, hb = 2 ha:   m00, m01 = m00 + ha, m10 = m00 + hb, m11
+//        A: (m00, m01) and (m10, m11) share one twiddle;  B: (m00, m10) twiddle jm, (m01, m11) twiddle jm + ha
+//   DIF pair of stages, distances ha = 2^(S-1-st), hb = ha / 2:      m00, m01 = m00 + hb, m10 = m00 + ha, m11
+//        A: (m00, m10) twiddle jm, (m01, m11) twiddle jm + hb;  B: (m00, m01) and (m10, m11) share one twiddle
+// An odd S starts with one plain radix-2 stage.  The first group of a pass reads its operands from HBM (times pre[] if given), the last
+// one stores to HBM; one tile per block.
+//   in_mode  = NTT_IN_POINTWISE : the tile is first filled with (a b - c) * zinv from the three arrays (buf[0..2], pre = zinv words): the
+//                                 (ab - c) / Z step of the witness map costs no pass of its own
+//   out_mode = NTT_OUT_WORDS    : results leave as canonical 4 x 64-bit scalars times post[position], at the bit-reversed position (the h
+//                                 coefficients as the MSM reads them): no separate scaling / un-reversing pass
+constexpr int NTT_IN_POINTWISE = 2, NTT_OUT_WORDS = 1;
 template <bool DIF, int TILE_LOG>
 __global__ void __launch_bounds__(1 << (TILE_LOG - 2)) __attribute__((amdgpu_waves_per_eu(4, 4)))
-k_ntt_pipe(NttBatch B, int nbuf, int logn, int s0, int S, const uint32_t *__restrict__ tw, const uint32_t *__restrict__ pre) {
+k_ntt_r4(NttBatch B, int logn, int s0, int S, const uint32_t *__restrict__ tw, const uint32_t *__restrict__ pre, int in_mode, int out_mode,
+         const uint32_t *__restrict__ post, uint32_t *__restrict__ out_words) {
     extern __shared__ uint32_t lds[];                      // [NL][TILE]
     constexpr int TILE = 1 << TILE_LOG, THREADS = TILE >> 2;
     const size_t D = (size_t)1 << logn, H = D >> 1;
@@ -255,93 +271,133 @@ k_ntt_pipe(NttBatch B, int nbuf, int logn, int s0, int S, const uint32_t *__rest
     const uint32_t lo_mask = (1u << L) - 1;
     const bool flat = (L == 0);
     const int tpb_log = logn - TILE_LOG;
-    const uint32_t total = (uint32_t)nbuf << tpb_log;
-    // two butterflies per lane and stage: (column cc, butterfly bb of that column)
-    uint32_t cc[2], bb[2];
-#pragma unroll
-    for (int rep = 0; rep < 2; rep++) {
-        const uint32_t t = threadIdx.x + rep * THREADS;
-        if (flat) { bb[rep] = t & ((1u << (S - 1)) - 1); cc[rep] = t >> (S - 1); }
-        else { cc[rep] = t & ((1u << cols_log) - 1); bb[rep] = t >> cols_log; }
-    }
-    auto gaddr = [&](uint32_t c0, uint32_t mid, uint32_t c_) -> uint32_t {
+    const uint32_t tile = blockIdx.x, bufk = in_mode == NTT_IN_POINTWISE ? 0u : (tile >> tpb_log);
+    uint32_t *const buf = bufk == 0 ? B.buf[0] : (bufk == 1 ? B.buf[1] : B.buf[2]);
+    const uint32_t c0 = (tile & ((1u << tpb_log) - 1)) << cols_log;
+    const uint32_t Db = (uint32_t)(D << 2);                // bytes per row
+    const __amdgpu_buffer_rsrc_t rows = rows_of(buf);
+    const bool staged_in = (in_mode == NTT_IN_POINTWISE), staged_out = (out_mode == NTT_OUT_WORDS);
+    auto gaddr = [&](uint32_t mid, uint32_t c_) -> uint32_t {
         const uint32_t c = c0 + c_, hi = c >> L, lo = c & lo_mask;
         return (hi << (L + S)) | (mid << L) | lo;
     };
     auto slot = [&](uint32_t mid, uint32_t c_) -> uint32_t { return flat ? ((c_ << S) | mid) : ((mid << cols_log) | c_); };
-    auto geom = [&](int st, uint32_t b, uint32_t &m0, uint32_t &m1, uint32_t &jm) {
-        const uint32_t half_m = DIF ? (1u << (S - 1 - st)) : (1u << st);
-        jm = b & (half_m - 1); m0 = ((b - jm) << 1) + jm; m1 = m0 + half_m;
-    };
-    auto twiddle = [&](Fr &w, int st, uint32_t c0, uint32_t c_, uint32_t jm) {
+    auto twiddle = [&](Fr &w, int st, uint32_t c_, uint32_t jm) {
         const int s = s0 + st, sigma = DIF ? s : (logn - 1 - s);
         const uint32_t j = (jm << L) | ((c0 + c_) & lo_mask);
         ldg(w, rows_of(tw + tw_stage_offset(H, sigma)), (uint32_t)((H >> sigma) << 2), j);
     };
-    auto pick = [&](uint32_t tile) -> uint32_t * { const uint32_t k = tile >> tpb_log; return k == 0 ? B.buf[0] : (k == 1 ? B.buf[1] : B.buf[2]); };
-
-    Fr X0, Y0, X1, Y1;                                     // first-stage operands of the lane's two butterflies
-    const uint32_t Db = (uint32_t)(D << 2);                // bytes per row
-    auto fetch1 = [&](const uint32_t *buf, uint32_t c0, int rep, Fr &X, Fr &Y) {
-        uint32_t m0, m1, jm; geom(0, bb[rep], m0, m1, jm);
-        const __amdgpu_buffer_rsrc_t rows = rows_of(buf);
-        ldg(X, rows, Db, gaddr(c0, m0, cc[rep])); ldg(Y, rows, Db, gaddr(c0, m1, cc[rep]));
-    };
-    auto fetch = [&](uint32_t tile) {
-        const uint32_t *buf = pick(tile);
-        const uint32_t c0 = (tile & ((1u << tpb_log) - 1)) << cols_log;
-        fetch1(buf, c0, 0, X0, Y0); fetch1(buf, c0, 1, X1, Y1);
-    };
-    // Twiddles run one butterfly ahead: the factor of the NEXT butterfly of this lane (other rep, next stage, or the first stage of the
-    // next tile) is requested before the current one is computed, so its L2 latency is never waited for.
-    Fr wn;
-    auto tw_req = [&](int st, uint32_t c0, int rep) { uint32_t m0, m1, jm; geom(st, bb[rep], m0, m1, jm); twiddle(wn, st, c0, cc[rep], jm); };
-    auto first = [&](uint32_t *buf, uint32_t c0, int rep, Fr &X, Fr &Y, int nst, uint32_t nc0, int nrep) {
-        uint32_t m0, m1, jm; geom(0, bb[rep], m0, m1, jm);
-        const Fr w = wn;
-        if (nst >= 0) tw_req(nst, nc0, nrep);
-        if (pre) {
-            const __amdgpu_buffer_rsrc_t prows = rows_of(pre);
-            Fr g; ldg(g, prows, Db, gaddr(c0, m0, cc[rep])); fr_mul(X, X, g);
-            ldg(g, prows, Db, gaddr(c0, m1, cc[rep])); fr_mul(Y, Y, g);
+    auto load = [&](Fr &x, bool from_global, uint32_t mid, uint32_t c_) {
+        if (from_global) {
+            const uint32_t a = gaddr(mid, c_);
+            ldg(x, rows, Db, a);
+            if (pre && !staged_in) { Fr g; ldg(g, rows_of(pre), Db, a); fr_mul(x, x, g); }
+        } else {
+            const uint32_t p = slot(mid, c_);
+#pragma unroll
+            for (int l = 0; l < NL; l++) x.l[l] = lds[l * TILE + p];
         }
-        butterfly<DIF>(X, Y, w);
-        if (S == 1) { const __amdgpu_buffer_rsrc_t rows = rows_of(buf); stg(rows, Db, gaddr(c0, m0, cc[rep]), X); stg(rows, Db, gaddr(c0, m1, cc[rep]), Y); return; }
-        const uint32_t p0 = slot(m0, cc[rep]), p1 = slot(m1, cc[rep]);
-#pragma unroll
-        for (int l = 0; l < NL; l++) { lds[l * TILE + p0] = X.l[l]; lds[l * TILE + p1] = Y.l[l]; }
     };
-    auto later = [&](uint32_t *buf, uint32_t c0, int st, bool last, int rep, int nst, uint32_t nc0, int nrep) {
-        uint32_t m0, m1, jm; geom(st, bb[rep], m0, m1, jm);
-        Fr x, y; const Fr w = wn;
-        const uint32_t p0 = slot(m0, cc[rep]), p1 = slot(m1, cc[rep]);
-#pragma unroll
-        for (int l = 0; l < NL; l++) { x.l[l] = lds[l * TILE + p0]; y.l[l] = lds[l * TILE + p1]; }
-        if (nst >= 0) tw_req(nst, nc0, nrep);
-        butterfly<DIF>(x, y, w);
-        if (last) { const __amdgpu_buffer_rsrc_t rows = rows_of(buf); stg(rows, Db, gaddr(c0, m0, cc[rep]), x); stg(rows, Db, gaddr(c0, m1, cc[rep]), y); }
+    auto store = [&](bool to_global, uint32_t mid, uint32_t c_, const Fr &x) {
+        if (to_global) stg(rows, Db, gaddr(mid, c_), x);
         else {
+            const uint32_t p = slot(mid, c_);
 #pragma unroll
-            for (int l = 0; l < NL; l++) { lds[l * TILE + p0] = x.l[l]; lds[l * TILE + p1] = y.l[l]; }
+            for (int l = 0; l < NL; l++) lds[l * TILE + p] = x.l[l];
         }
     };
-    auto c0_of = [&](uint32_t tile) -> uint32_t { return (tile & ((1u << tpb_log) - 1)) << cols_log; };
-    uint32_t tile = blockIdx.x;
-    if (tile < total) { fetch(tile); tw_req(0, c0_of(tile), 0); }
-    for (; tile < total; tile += gridDim.x) {
-        uint32_t *buf = pick(tile);
-        const uint32_t c0 = c0_of(tile), ntile = tile + gridDim.x;
-        const bool more = ntile < total;
-        const uint32_t nc0 = more ? c0_of(ntile) : 0;
-        first(buf, c0, 0, X0, Y0, 0, c0, 1);                       // first stage: operands already in registers
-        first(buf, c0, 1, X1, Y1, S > 1 ? 1 : (more ? 0 : -1), S > 1 ? c0 : nc0, 0);
+    // element e of the tile <-> (mid, column), in the order that is contiguous in HBM
+    auto elem = [&](uint32_t e, uint32_t &mid, uint32_t &c_) {
+        if (flat) { mid = e & ((1u << S) - 1); c_ = e >> S; } else { c_ = e & ((1u << cols_log) - 1); mid = e >> cols_log; }
+    };
+    if (staged_in) {
+        uint32_t zw[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) zw[k] = pre[k];
+        Fr zi; fr_from_words(zi, zw, false);
+        const __amdgpu_buffer_rsrc_t rb = rows_of(B.buf[1]), rc = rows_of(B.buf[2]);
+        for (uint32_t e = threadIdx.x; e < TILE; e += THREADS) {
+            uint32_t mid, c_; elem(e, mid, c_);
+            const uint32_t a = gaddr(mid, c_);
+            Fr x, y, z, t; ldg(x, rows, Db, a); ldg(y, rb, Db, a); ldg(z, rc, Db, a);
+            fr_mul(t, x, y); fr_sub<FR_BIG>(t, t, z); fr_norm(t, t); fr_mul(t, t, zi);      // z is an un-reduced transform output
+            const uint32_t p = slot(mid, c_);
+#pragma unroll
+            for (int l = 0; l < NL; l++) lds[l * TILE + p] = t.l[l];
+        }
         lds_barrier();
-        if (more) fetch(ntile);                                     // lands while the remaining stages run
-        for (int st = 1; st < S; st++) {
-            const bool last = (st == S - 1);
-            later(buf, c0, st, last, 0, st, c0, 1);
-            later(buf, c0, st, last, 1, last ? (more ? 0 : -1) : st + 1, last ? nc0 : c0, 0);
-            lds_barrier();
+    }
+    int st = 0;
+    if (S & 1) {                                           // one radix-2 stage, two butterflies per lane
+        const bool to_global = (S == 1) && !staged_out;
+#pragma unroll
+        for (int rep = 0; rep < 2; rep++) {
+            const uint32_t t = threadIdx.x + rep * THREADS;
+            uint32_t c_, b;
+            if (flat) { b = t & ((1u << (S - 1)) - 1); c_ = t >> (S - 1); } else { c_ = t & ((1u << cols_log) - 1); b = t >> cols_log; }
+            const uint32_t half_m = DIF ? (1u << (S - 1)) : 1u;
+            const uint32_t jm = b & (half_m - 1), m0 = ((b - jm) << 1) + jm, m1 = m0 + half_m;
+            Fr w, x, y; twiddle(w, 0, c_, jm);
+            load(x, !staged_in, m0, c_); load(y, !staged_in, m1, c_);
+            butterfly<DIF>(x, y, w);
+            store(to_global, m0, c_, x); store(to_global, m1, c_, y);
+        }
+        st = 1;
+        if (st < S || staged_out) lds_barrier();
+    }
+    // radix-4 groups: unit q of column c_
+    uint32_t c_, q;
+    if (S < 2) { q = 0; c_ = 0; } else if (flat) { q = threadIdx.x & ((1u << (S - 2)) - 1); c_ = threadIdx.x >> (S - 2); } else { c_ = threadIdx.x & ((1u << cols_log) - 1); q = threadIdx.x >> cols_log; }
+    for (; st + 1 < S; st += 2) {
+        const bool from_global = (st == 0) && !staged_in, to_global = (st + 2 == S) && !staged_out;
+        Fr x00, x01, x10, x11, t;
+        if (DIF) {
+            const int pos = S - 2 - st;                    // bit position of hb
+            const uint32_t hb = 1u << pos, ha = hb << 1;
+            const uint32_t jm = q & (hb - 1), m00 = ((q >> pos) << (pos + 2)) | jm;
+            Fr wa0, wa1, wb;
+            twiddle(wa0, st, c_, jm); twiddle(wa1, st, c_, jm + hb); twiddle(wb, st + 1, c_, jm);
+            load(x00, from_global, m00, c_); load(x10, from_global, m00 + ha, c_);
+            load(x01, from_global, m00 + hb, c_); load(x11, from_global, m00 + ha + hb, c_);
+            // A
+            fr_sub<FR_BIG>(t, x00, x10); fr_add(x00, x00, x10); fr_norm(t, t); fr_mul(x10, t, wa0);
+            fr_sub<FR_BIG>(t, x01, x11); fr_add(x01, x01, x11); fr_norm(t, t); fr_mul(x11, t, wa1);
+            // B (x00, x01 carry limbs < 2^30 + 16: dominated by the subtraction constant, and their sum fits a word)
+            fr_sub<FR_BIG>(t, x00, x01); fr_add(x00, x00, x01); fr_norm(x00, x00); fr_norm(t, t); fr_mul(x01, t, wb);
+            fr_sub<FR_BIG>(t, x10, x11); fr_add(x10, x10, x11); fr_norm(x10, x10); fr_norm(t, t); fr_mul(x11, t, wb);
+            store(to_global, m00, c_, x00); store(to_global, m00 + hb, c_, x01);
+            store(to_global, m00 + ha, c_, x10); store(to_global, m00 + ha + hb, c_, x11);
+        } else {
+            const uint32_t ha = 1u << st, hb = ha << 1;
+            const uint32_t jm = q & (ha - 1), m00 = ((q >> st) << (st + 2)) | jm;
+            Fr wa, wb0, wb1;
+            twiddle(wa, st, c_, jm); twiddle(wb0, st + 1, c_, jm); twiddle(wb1, st + 1, c_, jm + ha);
+            load(x00, from_global, m00, c_); load(x01, from_global, m00 + ha, c_);
+            load(x10, from_global, m00 + hb, c_); load(x11, from_global, m00 + ha + hb, c_);
+            // A: no carry pass; sums < 2^30 + 16, differences < 2^31 per limb
+            fr_mul(t, x01, wa); fr_sub<512, 30>(x01, x00, t); fr_add(x00, x00, t);
+            fr_mul(t, x11, wa); fr_sub<512, 30>(x11, x10, t); fr_add(x10, x10, t);
+            // B
+            fr_mul(t, x10, wb0); fr_sub<512, 30>(x10, x00, t); fr_add(x00, x00, t); fr_norm(x00, x00); fr_norm(x10, x10);
+            fr_mul(t, x11, wb1); fr_sub<512, 30>(x11, x01, t); fr_add(x01, x01, t); fr_norm(x01, x01); fr_norm(x11, x11);
+            store(to_global, m00, c_, x00); store(to_global, m00 + ha, c_, x01);
+            store(to_global, m00 + hb, c_, x10); store(to_global, m00 + ha + hb, c_, x11);
+        }
+        if (!to_global) lds_barrier();
+    }
+    if (staged_out) {
+        const __amdgpu_buffer_rsrc_t rp = rows_of(post);
+        for (uint32_t e = threadIdx.x; e < TILE; e += THREADS) {
+            uint32_t mid, c_; elem(e, mid, c_);
+            const uint32_t a = gaddr(mid, c_), p = slot(mid, c_);
+            Fr x, g;
+#pragma unroll
+            for (int l = 0; l < NL; l++) x.l[l] = lds[l * TILE + p];
+            ldg(g, rp, Db, a);
+            fr_mul(x, x, g);
+            uint32_t w[8]; fr_to_words(w, x, false);
+            uint4 *q = reinterpret_cast<uint4 *>(out_words + (size_t)bitrev(a, logn) * 8);
+            q[0] = make_uint4(w[0], w[1], w[2], w[3]); q[1] = make_uint4(w[4], w[5], w[6], w[7]);
         }
     }
 }

@@ -1,3 +1,5 @@
-DGPU_NTT_OCC=1 python tests/perf/qap_perf.py 2>&1 | grep -m1 occupancy
-for g in 128 256 384 512 768 1024 1536; do echo "== tile=11 grid=$g"; DGPU_NTT_GRID=$g python tests/perf/qap_perf.py; done
-for g in 256 512 768 1024 2048 3072; do echo "== tile=10 grid=$g"; DGPU_NTT_TILE_LOG=10 DGPU_NTT_GRID=$g python tests/perf/qap_perf.py; done
+python -m pytest tests/test_gpu_witness_map.py tests/test_gpu_full_sizes.py -x -q -m gpu 2>&1 | tail -2
+DGPU_NTT_TILE_LOG=11 python -m pytest tests/test_gpu_witness_map.py -x -q -m gpu 2>&1 | tail -2
+for i in 1 2 3; do python tests/perf/qap_perf.py; done
+DGPU_NTT_TILE_LOG=11 python tests/perf/qap_perf.py
+for l in 10 11 12 14 16 18 21 22; do LOG2N=$l python tests/perf/qap_perf.py; done

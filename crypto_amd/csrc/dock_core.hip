@@ -134,6 +134,8 @@ int32_t dgpu_shutdown(void) {
     for (int i = 0; i < MAX_CTX; i++) {
         Ctx &c = ctxs[i];
         if (c.device >= 0) (void)hipSetDevice(c.device);
+        for (auto &e : c.scalar_pool) (void)hipFree(e.first);
+        c.scalar_pool.clear(); c.scalar_pool_bytes = 0;
         for (auto &d : c.ntt_domains) { void *ps[] = {d.second.tw_f, d.second.tw_i, d.second.pw_f, d.second.pw_i, d.second.zinv, d.second.pwr_f, d.second.pwr_i}; for (void *p : ps) if (p) (void)hipFree(p); }
         c.ntt_domains.clear();
         c.device = -1;
@@ -174,6 +176,7 @@ static void release_parts(const Handle &hd) {
     CtxScope on_owner(hd.ctx);
     if (cur().device >= 0) (void)hipSetDevice(cur().device);
     if (hd.kind == 10 || hd.kind == 11) { PreTable *pt = (PreTable *)hd.p; (void)hipFree(pt->tab); delete pt; return; }
+    if (hd.kind == 3) { scalar_release(hd.ctx, hd.p, scalar_bytes(hd.n)); return; }      // recycled: no device-wide wait per proof
     (void)hipFree(hd.p);
 }
 static int32_t free_handle(uint64_t h, bool scalars) {
@@ -192,9 +195,9 @@ int32_t dgpu_scalars_upload(const uint64_t *s, size_t n, int32_t mont, uint64_t 
     {
         SlotLock L; Slot &sl = *L.s;
         HIPCHK(hipSetDevice(cur().device));
-        if (hipMalloc(&p, std::max<size_t>(n, 1) * 32) != hipSuccess) { (void)hipGetLastError(); return DGPU_E_OOM; }
+        if (!(p = scalar_alloc(scalar_bytes(n)))) return DGPU_E_OOM;
         int32_t rc = n ? upload_scalars(sl, s, n, mont != 0, (uint32_t *)p) : DGPU_OK;
-        if (rc) { (void)hipFree(p); return rc; }
+        if (rc) { scalar_release(cur_index(), p, scalar_bytes(n)); return rc; }
     }
     *handle = register_handle(p, n, 3);
     return DGPU_OK;
@@ -212,7 +215,7 @@ int32_t dgpu_scalars_upload_parts(const uint64_t *const *parts, const size_t *co
     {
         SlotLock L; Slot &sl = *L.s;
         HIPCHK(hipSetDevice(cur().device));
-        if (hipMalloc(&p, std::max<size_t>(n, 1) * 32) != hipSuccess) { (void)hipGetLastError(); return DGPU_E_OOM; }
+        if (!(p = scalar_alloc(scalar_bytes(n)))) return DGPU_E_OOM;
         size_t at = 0;
         hipError_t e = hipSuccess;
         for (size_t k = 0; k < n_parts && e == hipSuccess; k++) {
@@ -221,7 +224,7 @@ int32_t dgpu_scalars_upload_parts(const uint64_t *const *parts, const size_t *co
         }
         if (e == hipSuccess && mont && n) ntt::launch_fr_mont_to_canonical(sl.stream, (uint32_t *)p, n);
         if (e == hipSuccess) e = hipStreamSynchronize(sl.stream);
-        if (e != hipSuccess) { gs.last_hip = (int32_t)e; (void)hipGetLastError(); (void)hipFree(p); return DGPU_E_HIP; }
+        if (e != hipSuccess) { gs.last_hip = (int32_t)e; (void)hipGetLastError(); scalar_release(cur_index(), p, scalar_bytes(n)); return DGPU_E_HIP; }
     }
     *handle = register_handle(p, n, 3);
     return DGPU_OK;

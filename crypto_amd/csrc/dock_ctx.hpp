@@ -71,7 +71,12 @@ struct Ctx {
     Slot slots[N_SLOTS];
     std::atomic<unsigned> rr{0};
     std::map<int, NttDomain> ntt_domains;
+    // Recycled scalar vectors (guarded by gs.mu).  A proof uploads one assignment and receives one h vector, both released when it is done:
+    // hipMalloc / hipFree per proof cost ~0.3 ms and hipFree waits for the whole device, i.e. for every other call in flight.
+    std::vector<std::pair<void *, size_t>> scalar_pool;
+    size_t scalar_pool_bytes = 0;
 };
+constexpr size_t SCALAR_POOL_MAX_ENTRIES = 16, SCALAR_POOL_MAX_BYTES = (size_t)4 << 30;
 // process-wide state shared by all contexts
 struct Shared {
     std::mutex mu;                 // lifecycle, handle table, profile table, NTT-domain tables
@@ -104,6 +109,32 @@ struct SlotLock {
     ~SlotLock() { s->mu.unlock(); }
     SlotLock(const SlotLock &) = delete;
 };
+
+// device memory for a resident scalar vector of `bytes` on the current context: a recycled buffer of exactly that size, else hipMalloc
+inline void *scalar_alloc(size_t bytes) {
+    {
+        std::lock_guard<std::mutex> lk(gs.mu);
+        auto &pool = cur().scalar_pool;
+        for (size_t k = 0; k < pool.size(); k++)
+            if (pool[k].second == bytes) { void *p = pool[k].first; pool[k] = pool.back(); pool.pop_back(); cur().scalar_pool_bytes -= bytes; return p; }
+    }
+    void *p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+// give it back (context `ctx` owns it; every call that used it has returned, so no stream still touches it)
+inline void scalar_release(int ctx, void *p, size_t bytes) {
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> lk(gs.mu);
+        Ctx &c = ctxs[ctx];
+        if (c.ready && c.scalar_pool.size() < SCALAR_POOL_MAX_ENTRIES && c.scalar_pool_bytes + bytes <= SCALAR_POOL_MAX_BYTES) {
+            c.scalar_pool.emplace_back(p, bytes); c.scalar_pool_bytes += bytes; return;
+        }
+    }
+    (void)hipFree(p);
+}
+inline size_t scalar_bytes(size_t n) { return (n ? n : 1) * 32; }
 
 inline hipEvent_t ev_get(Slot &sl) {
     if (!sl.ev_pool.empty()) { hipEvent_t e = sl.ev_pool.back(); sl.ev_pool.pop_back(); return e; }

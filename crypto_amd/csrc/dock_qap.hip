@@ -89,8 +89,13 @@ int32_t witness_map_device(Slot &sl, const DevR1cs &r, const uint64_t *assignmen
     if ((rc = qa.ensure(D * esz))) return rc;
     if ((rc = qb.ensure(D * esz))) return rc;
     if ((rc = qc.ensure(D * esz))) return rc;
-    if ((rc = hw.ensure(D * 32))) return rc;
+    // the h scalars are written where they stay: the caller's resident vector (a recycled buffer) if one is asked for, else scratch
+    void *kept = nullptr;
+    if (out_handle) { if (!(kept = scalar_alloc(scalar_bytes(D)))) return DGPU_E_OOM; }
+    else if ((rc = hw.ensure(D * 32))) return rc;
+    uint32_t *const h_words = kept ? (uint32_t *)kept : hw.as<uint32_t>();
     hipStream_t s = sl.stream;
+    struct Giveback { void *&p; size_t bytes; hipStream_t st; ~Giveback() { if (p) { (void)hipStreamSynchronize(st); scalar_release(cur_index(), p, bytes); } } } giveback{kept, scalar_bytes(D), s};   // on any early return
     uint32_t *arr[3] = {qa.as<uint32_t>(), qb.as<uint32_t>(), qc.as<uint32_t>()};
     {
         StageTimer st(sl, "qap.matvec");
@@ -104,22 +109,13 @@ int32_t witness_map_device(Slot &sl, const DevR1cs &r, const uint64_t *assignmen
         ntt::launch_ntt_batch(s, arr, 3, logn, (const uint32_t *)dom.tw_i, 1);                                       // iFFT (x D) of a, b, c together, bit-reversed out
         ntt::launch_ntt_batch(s, arr, 3, logn, (const uint32_t *)dom.tw_f, 0, (const uint32_t *)dom.pwr_f);          // * g^k / D on the way in, coset FFT, natural out
         // (ab - c) / Z(g) -> coset iFFT -> * g^-k / D, un-reversed, canonical words: one set of passes
-        ntt::launch_ntt_final(s, arr[0], arr[1], arr[2], logn, (const uint32_t *)dom.tw_i, (const uint32_t *)dom.zinv, (const uint32_t *)dom.pwr_i, hw.as<uint32_t>());
+        ntt::launch_ntt_final(s, arr[0], arr[1], arr[2], logn, (const uint32_t *)dom.tw_i, (const uint32_t *)dom.zinv, (const uint32_t *)dom.pwr_i, h_words);
     }
     HIPCHK(hipGetLastError());
     if (out_len) *out_len = D;
-    void *kept = nullptr;
-    if (out_handle) {
-        void *p = nullptr;
-        if (hipMalloc(&p, D * 32) != hipSuccess) { (void)hipGetLastError(); return DGPU_E_OOM; }
-        if (hipMemcpyAsync(p, hw.p, D * 32, hipMemcpyDeviceToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(p); return DGPU_E_HIP; }
-        kept = p;
-    }
-    if (out_h) {
-        if (hipMemcpyAsync(out_h, hw.p, D * 32, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { (void)hipGetLastError(); if (kept) (void)hipFree(kept); return DGPU_E_HIP; }
-    }
-    if (hipStreamSynchronize(s) != hipSuccess) { (void)hipGetLastError(); if (kept) (void)hipFree(kept); return DGPU_E_HIP; }
-    if (out_handle) *out_handle = register_handle(kept, D, 3);     // registered last: no handle is left behind by a failing call
+    if (out_h && hipMemcpyAsync(out_h, h_words, D * 32, hipMemcpyDeviceToHost, s) != hipSuccess) { (void)hipGetLastError(); return DGPU_E_HIP; }
+    if (hipStreamSynchronize(s) != hipSuccess) { (void)hipGetLastError(); return DGPU_E_HIP; }
+    if (out_handle) { *out_handle = register_handle(kept, D, 3); kept = nullptr; }     // registered last: no handle is left behind by a failing call
     if (gs.prof) prof_flush(sl);
     return DGPU_OK;
 }

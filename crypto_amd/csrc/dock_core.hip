@@ -30,9 +30,15 @@ int choose_c(size_t n, bool g2) {
     else bc = 8;
     return bc;
 }
-int choose_chunk(size_t E, int min_chunk, size_t max_chunks, int lanes_per_chunk) {
+// a chunk length forced by a tuning knob (dgpu_set_chunk / DGPU_CHUNK: any chunk length gives the same point, tests/test_gpu_msm.py sweeps it), else 0
+int forced_chunk() {
     if (gs.chunk) return gs.chunk;
-    { const char *e = getenv("DGPU_CHUNK"); if (e) { int v = atoi(e); if (v >= 16 && v <= 4096) return v; } }   // tuning knob: any chunk length gives the same point (tests/test_gpu_msm.py sweeps it)
+    const char *e = getenv("DGPU_CHUNK");
+    if (e) { int v = atoi(e); if (v >= 16 && v <= 4096) return v; }
+    return 0;
+}
+int choose_chunk(size_t E, int min_chunk, size_t max_chunks, int lanes_per_chunk) {
+    if (int f = forced_chunk()) return f;
     // terms per lane.  A lane's chunk is one dependent chain of mixed additions (~12 us each), so short chunks win as long as the
     // partial slots they create stay cheap to fold: 16 terms up to ~300 k lanes (two rounds of the chip's 131 072 lanes at
     // 2 waves/SIMD), then doubling — measured at n = 2^12 .. 2^18: 16 beats 64 by 13-35 % (tools: DGPU_CHUNK sweep), at 2^20 64 and

@@ -47,12 +47,12 @@ extern Shared gs;
 struct Slot {
     std::mutex mu;
     hipStream_t stream = nullptr;
-    Buf in_bases, in_inf, in_scalars, prepped, digits, heavy, cnt, off, cursor, bsums, entries, bucket, bucket_inf, head, tail, head_b, tail_b, part_inf, l1, l1_inf, win, win_inf, ml_lines, ml_partial, ml_out, ml_coeffs;
+    Buf in_bases, in_inf, in_scalars, prepped, digits, heavy, cnt, off, cursor, bsums, entries, bucket, bucket_inf, head, tail, head_b, tail_b, part_inf, l1, l1_inf, win, win_inf, ml_lines, ml_partial, ml_out, ml_coeffs, dyn, hpart, hpart_inf;
     Buf q[16];      // witness-map workspace (dock_qap.hip)
     std::vector<std::pair<const char *, std::pair<hipEvent_t, hipEvent_t>>> prof_pending;
     std::vector<hipEvent_t> ev_pool;
     void release_all() {
-        Buf *bufs[] = {&in_bases, &in_inf, &in_scalars, &prepped, &digits, &heavy, &cnt, &off, &cursor, &bsums, &entries, &bucket, &bucket_inf, &head, &tail, &head_b, &tail_b, &part_inf, &l1, &l1_inf, &win, &win_inf, &ml_lines, &ml_partial, &ml_out, &ml_coeffs};
+        Buf *bufs[] = {&in_bases, &in_inf, &in_scalars, &prepped, &digits, &heavy, &cnt, &off, &cursor, &bsums, &entries, &bucket, &bucket_inf, &head, &tail, &head_b, &tail_b, &part_inf, &l1, &l1_inf, &win, &win_inf, &ml_lines, &ml_partial, &ml_out, &ml_coeffs, &dyn, &hpart, &hpart_inf};
         for (Buf *b : bufs) b->release();
         for (Buf &b : q) b.release();
         for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
@@ -210,6 +210,7 @@ inline std::vector<int> ready_contexts(int ngpus) {
 
 int choose_c(size_t n, bool g2 = false);
 int choose_chunk(size_t E, int min_chunk = 16, size_t max_chunks = 300000, int lanes_per_chunk = 1);
+int forced_chunk();
 int32_t upload_scalars(Slot &sl, const uint64_t *h, size_t n, bool mont, uint32_t *d_out);
 
 }  // namespace dock

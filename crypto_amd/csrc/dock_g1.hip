@@ -4,6 +4,7 @@ using namespace dock;
 
 extern "C" {
 int32_t dgpu_fold_g1(const uint64_t *xyz, size_t k, uint64_t out[18]) { return host_fold_jacobian<hostf::Fq>(xyz, k, out); }
+int32_t dgpu_lincomb_g1(const uint64_t *p, const uint8_t *inf, const uint64_t *s, size_t k, uint64_t out[18]) { return host_lincomb<hostf::Fq>(p, inf, s, k, out); }
 int32_t dgpu_msm_g1(const uint64_t *b, const uint8_t *inf, const uint64_t *s, size_t n, uint64_t out[18]) { return msm_oneshot<G1, hostf::Fq>(b, inf, s, n, false, out); }
 int32_t dgpu_msm_g1_mont(const uint64_t *b, const uint8_t *inf, const uint64_t *s, size_t n, uint64_t out[18]) { return msm_oneshot<G1, hostf::Fq>(b, inf, s, n, true, out); }
 int32_t dgpu_bases_upload_g1(const uint64_t *b, const uint8_t *inf, size_t n, uint64_t *h) { return bases_upload<G1>(b, inf, n, h, 1); }

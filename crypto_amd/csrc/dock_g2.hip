@@ -4,6 +4,7 @@ using namespace dock;
 
 extern "C" {
 int32_t dgpu_fold_g2(const uint64_t *xyz, size_t k, uint64_t out[36]) { return host_fold_jacobian<hostf::Fq2>(xyz, k, out); }
+int32_t dgpu_lincomb_g2(const uint64_t *p, const uint8_t *inf, const uint64_t *s, size_t k, uint64_t out[36]) { return host_lincomb<hostf::Fq2>(p, inf, s, k, out); }
 int32_t dgpu_msm_g2(const uint64_t *b, const uint8_t *inf, const uint64_t *s, size_t n, uint64_t out[36]) { return msm_oneshot<G2, hostf::Fq2>(b, inf, s, n, false, out); }
 int32_t dgpu_msm_g2_mont(const uint64_t *b, const uint8_t *inf, const uint64_t *s, size_t n, uint64_t out[36]) { return msm_oneshot<G2, hostf::Fq2>(b, inf, s, n, true, out); }
 int32_t dgpu_bases_upload_g2(const uint64_t *b, const uint8_t *inf, size_t n, uint64_t *h) { return bases_upload<G2>(b, inf, n, h, 2); }

@@ -1,10 +1,11 @@
 // crypto_amd/csrc/k_psort.hip — translation unit of the two-level partition sort (psort_kernels.cuh)
 #include <atomic>
 #include "psort_kernels.cuh"
+#include "sort_launch.cuh"
 
 namespace msm {
 void launch_psort(hipStream_t s, const PsParams &q, uint32_t NB, uint32_t *cnt1, uint32_t *off1, uint32_t *bsums, void *pairs, uint32_t *off, uint32_t *entries,
-                  uint32_t heavy_thr, uint32_t *heavy, uint32_t heavy_cap) {
+                  uint32_t heavy_thr, uint32_t *heavy, uint32_t heavy_cap, const uint32_t *dyn_args, uint32_t *dyn) {
     const size_t lds1 = (size_t)q.P * 4;
     const size_t lds3 = ((size_t)3 * q.P + 2) * 4 + (size_t)PS_TILE * PS_MAX_W * 8;
     // (the attribute belongs to the function ON THE CURRENT DEVICE: a process that drives several GPUs sets it once per device)
@@ -12,7 +13,9 @@ void launch_psort(hipStream_t s, const PsParams &q, uint32_t NB, uint32_t *cnt1,
       if (!(done.load() & bit)) { (void)hipFuncSetAttribute((const void *)k_ps_scatter1, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048); done.fetch_or(bit); } }
     hipLaunchKernelGGL(k_ps_count1, dim3(q.ntiles), dim3(PS_TILE), lds1, s, q, cnt1);
     launch_scan(s, cnt1, off1, nullptr, bsums, (size_t)q.P * q.ntiles);
+    // the pair total is known: chunking and heavy-bucket threshold of the accumulation follow from it (dyn_args = {fixed_ch, min_chunk, max_chunks, lanes_per_chunk, T_max})
+    if (dyn) launch_dyn_chunk(s, off1 + (size_t)q.P * q.ntiles, dyn_args[0], dyn_args[1], dyn_args[2], dyn_args[3], dyn_args[4], dyn);
     hipLaunchKernelGGL(k_ps_scatter1, dim3(q.ntiles), dim3(PS_TILE), lds3, s, q, off1, (uint2 *)pairs);
-    hipLaunchKernelGGL(k_ps_bucket, dim3(q.P), dim3(1024), 0, s, (const uint2 *)pairs, off1, q.ntiles, q.P, NB, q.part_log, off, entries, heavy_thr, heavy, heavy_cap);
+    hipLaunchKernelGGL(k_ps_bucket, dim3(q.P), dim3(1024), 0, s, (const uint2 *)pairs, off1, q.ntiles, q.P, NB, q.part_log, off, entries, heavy_thr, heavy, heavy_cap, (const uint32_t *)dyn);
 }
 }  // namespace msm

@@ -22,6 +22,12 @@ void launch_scan(hipStream_t s, const uint32_t *cnt, uint32_t *off, uint32_t *cu
     hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, s, bsums, nblk);
     hipLaunchKernelGGL(k_scan_add, dim3((unsigned)((NB + 1 + 255) / 256)), dim3(256), 0, s, off, cursor, bsums, NB, nblk);
 }
+void launch_dyn_chunk(hipStream_t s, const uint32_t *total, uint32_t fixed_ch, uint32_t min_chunk, uint32_t max_chunks, uint32_t lanes_per_chunk, uint32_t T_max, uint32_t *dyn) {
+    hipLaunchKernelGGL(k_dyn_chunk, dim3(1), dim3(64), 0, s, total, fixed_ch, min_chunk, max_chunks, lanes_per_chunk, T_max, dyn);
+}
+void launch_flag_heavy(hipStream_t s, const uint32_t *off, uint32_t NB, const uint32_t *dyn, uint32_t *heavy, uint32_t heavy_cap) {
+    hipLaunchKernelGGL(k_flag_heavy, dim3((NB + 255) / 256), dim3(256), 0, s, off, NB, dyn, heavy, heavy_cap);
+}
 void launch_g1_scale(hipStream_t s, const uint32_t *p_abi, const uint8_t *is_inf, const uint32_t *scalars, int scalar_stride, const uint8_t *negate, size_t n, uint32_t *out_abi, uint8_t *out_inf) {
     hipLaunchKernelGGL(k_g1_scale, dim3((unsigned)((4 * n + 63) / 64)), dim3(64), 0, s, p_abi, is_inf, scalars, scalar_stride, negate, n, out_abi, out_inf);
 }

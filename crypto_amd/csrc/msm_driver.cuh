@@ -49,6 +49,42 @@ int32_t host_fold_jacobian(const uint64_t *xyz, size_t k, uint64_t *out_xyz) {
     return DGPU_OK;
 }
 
+// sum_i s_i P_i over k <= DGPU_MAX_LINCOMB affine points on the HOST (4-bit windows, one table of 15 multiples per point, joint doublings).
+// This is not the MSM path: it is the O(1) group arithmetic around it that the reference does with `mul_bigint` / FixedBase on the CPU — the
+// r delta, s g_a + r g1_b, -rs delta - v eta/delta of a proof (prover.rs:309-313, 350-355, 585-594) — next to
+// dgpu_fold_* and dgpu_final_exponentiation.  A 2..4-term product costs 0.15 - 0.35 ms of one host core and no device launch; the same
+// through the bucket pipeline is ~0.75 ms of launch latency per call and queues behind the accumulation kernels of the large MSMs.
+template <class HF>
+int32_t host_lincomb(const uint64_t *points_xy, const uint8_t *is_inf, const uint64_t *scalars, size_t k, uint64_t *out_xyz) {
+    if (!out_xyz || k > DGPU_MAX_LINCOMB || (k && (!points_xy || !scalars))) return DGPU_E_BADARG;
+    typedef hostf::HXyzz<HF> PT;
+    const size_t FWORDS = sizeof(HF) / 8;
+    std::vector<PT> tab(k * 15);
+    std::vector<uint8_t> live(k, 0);
+    for (size_t i = 0; i < k; i++) {
+        HF X, Y;
+        memcpy(&X, points_xy + i * 2 * FWORDS, sizeof(HF)); memcpy(&Y, points_xy + i * 2 * FWORDS + FWORDS, sizeof(HF));
+        const uint64_t *sc = scalars + 4 * i;
+        if ((is_inf && is_inf[i]) || !(sc[0] | sc[1] | sc[2] | sc[3])) continue;
+        live[i] = 1;
+        PT p; p.inf = false; p.x = X; p.y = Y; p.zz = HF::one(); p.zzz = HF::one();
+        tab[i * 15] = p;
+        for (int m = 1; m < 15; m++) { PT t = tab[i * 15 + m - 1]; if (m == 1) t.dbl_in_place(); else t.add_in_place(p); tab[i * 15 + m] = t; }
+    }
+    PT acc = PT::identity();
+    for (int w = 63; w >= 0; w--) {
+        for (int d = 0; d < 4; d++) acc.dbl_in_place();
+        for (size_t i = 0; i < k; i++) {
+            if (!live[i]) continue;
+            const unsigned nib = (unsigned)(scalars[4 * i + (w >> 4)] >> ((w & 15) * 4)) & 15u;
+            if (nib) acc.add_in_place(tab[i * 15 + nib - 1]);
+        }
+    }
+    HF X, Y, Z; acc.to_normalised_jacobian(X, Y, Z);
+    memcpy(out_xyz, &X, sizeof(HF)); memcpy(out_xyz + FWORDS, &Y, sizeof(HF)); memcpy(out_xyz + 2 * FWORDS, &Z, sizeof(HF));
+    return DGPU_OK;
+}
+
 // d_bases: prepared records; d_scalars: canonical 8 x u32 per scalar.  Caller holds the slot.
 template <class C, class HF>
 int32_t msm_device(Slot &sl, const uint32_t *d_bases, const uint32_t *d_scalars, size_t n, uint64_t *out_xyz) {
@@ -96,8 +132,14 @@ int32_t msm_device(Slot &sl, const uint32_t *d_bases, const uint32_t *d_scalars,
     const unsigned sort_grid = (unsigned)(8 * wpx * RANGES);
     const size_t lds_bytes = ((size_t)1 << rb_log) * 4;
     if ((rc = sl.digits.ensure((size_t)W * n_pad * (wide ? 4 : 2)))) return rc;
-    const uint32_t heavy_thr = 16u * (uint32_t)CH, HEAVY_CAP = (uint32_t)(Emax / heavy_thr) + 1;   // at most E / thr buckets can be heavy
+    // chunk length / heavy-bucket threshold of the accumulation are fixed on the device once the pair count is known (dyn_chunk.cuh): CH and T above
+    // only size the launch and the partial slots
+    const uint32_t min_chunk = C::NFP == 2 ? 32u : 16u, max_chunks = C::NFP == 2 ? 150000u : 300000u, lanes_per_chunk = C::NFP == 2 ? 2u : 1u;
+    const uint32_t heavy_thr = 0xffffffffu /* the sweeps flag nothing: k_flag_heavy does, after the scan */, HEAVY_CAP = (uint32_t)(Emax / (16u * min_chunk)) + 1;
     if ((rc = sl.heavy.ensure(((size_t)HEAVY_CAP + 1) * 4))) return rc;
+    if ((rc = sl.dyn.ensure(msm::dyn_words(T) * 4))) return rc;
+    { const size_t hslots = 2 * (T / msm::HEAVY_RANGE + 2); if ((rc = sl.hpart.ensure(hslots * C::XW * 4))) return rc; if ((rc = sl.hpart_inf.ensure(hslots))) return rc; }
+    uint32_t *const dyn = sl.dyn.as<uint32_t>();
     {
         StageTimer st(sl, "msm.count");
         HIPCHK(hipMemsetAsync(sl.bucket_inf.p, 1, NB, s));
@@ -108,6 +150,8 @@ int32_t msm_device(Slot &sl, const uint32_t *d_bases, const uint32_t *d_scalars,
     {
         StageTimer st(sl, "msm.scan");
         launch_scan(s, sl.cnt.as<uint32_t>(), sl.off.as<uint32_t>(), sl.cursor.as<uint32_t>(), sl.bsums.as<uint32_t>(), (size_t)NB);
+        launch_dyn_chunk(s, sl.off.as<uint32_t>() + NB, (uint32_t)forced_chunk(), min_chunk, max_chunks, lanes_per_chunk, (uint32_t)T, dyn);
+        launch_flag_heavy(s, sl.off.as<uint32_t>(), NB, dyn, sl.heavy.as<uint32_t>(), HEAVY_CAP);
     }
     {
         StageTimer st(sl, "msm.scatter");
@@ -121,14 +165,14 @@ int32_t msm_device(Slot &sl, const uint32_t *d_bases, const uint32_t *d_scalars,
         constexpr uint32_t dbg_mask = 0xffffffffu;
 #endif
         launch_accumulate<C>(s, d_bases, sl.entries.as<uint32_t>(), sl.off.as<uint32_t>(), NB, sl.bucket.as<uint32_t>(), sl.bucket_inf.as<uint8_t>(),
-                           sl.head.as<uint32_t>(), sl.tail.as<uint32_t>(), sl.head_b.as<uint32_t>(), sl.tail_b.as<uint32_t>(), sl.part_inf.as<uint8_t>(), T, (uint32_t)CH, dbg_mask);
+                           sl.head.as<uint32_t>(), sl.tail.as<uint32_t>(), sl.head_b.as<uint32_t>(), sl.tail_b.as<uint32_t>(), sl.part_inf.as<uint8_t>(), T, (uint32_t)CH, dbg_mask, dyn);
     }
     {
         StageTimer st(sl, "msm.fixup");
         launch_fixup<C>(s, NB, sl.bucket.as<uint32_t>(), sl.bucket_inf.as<uint8_t>(), sl.head.as<uint32_t>(), sl.tail.as<uint32_t>(),
-                           sl.head_b.as<uint32_t>(), sl.tail_b.as<uint32_t>(), sl.part_inf.as<uint8_t>(), T, sl.off.as<uint32_t>(), heavy_thr);
+                           sl.head_b.as<uint32_t>(), sl.tail_b.as<uint32_t>(), sl.part_inf.as<uint8_t>(), T, sl.off.as<uint32_t>(), heavy_thr, dyn);
         launch_fixup_heavy<C>(s, sl.heavy.as<uint32_t>(), HEAVY_CAP, sl.off.as<uint32_t>(), (uint32_t)CH, NB, sl.bucket.as<uint32_t>(), sl.bucket_inf.as<uint8_t>(),
-                           sl.head.as<uint32_t>(), sl.tail.as<uint32_t>(), sl.part_inf.as<uint8_t>(), T);
+                           sl.head.as<uint32_t>(), sl.tail.as<uint32_t>(), sl.part_inf.as<uint8_t>(), T, dyn, sl.hpart.as<uint32_t>(), sl.hpart_inf.as<uint8_t>());
     }
     {
         StageTimer st(sl, "msm.reduce");
@@ -235,27 +279,32 @@ int32_t msm_device_pre(Slot &sl, const PreTable &pt, size_t boff, const uint32_t
     if ((rc = sl.l1_inf.ensure(NG * 2))) return rc;
     if ((rc = sl.win.ensure((size_t)2 * PW * 4 * C::ABI_W * 4))) return rc;        // A_j then S_j
     if ((rc = sl.win_inf.ensure(2 * PW))) return rc;
-    const uint32_t heavy_thr = 16u * (uint32_t)CH, HEAVY_CAP = (uint32_t)(Emax / heavy_thr) + 1;
+    const uint32_t min_chunk = C::NFP == 2 ? 32u : 16u, max_chunks = C::NFP == 2 ? 150000u : 300000u, lanes_per_chunk = C::NFP == 2 ? 2u : 1u;
+    const uint32_t heavy_thr = 16u * (uint32_t)CH /* replaced on the device, dyn_chunk.cuh */, HEAVY_CAP = (uint32_t)(Emax / (16u * min_chunk)) + 1;
     if ((rc = sl.heavy.ensure(((size_t)HEAVY_CAP + 1) * 4))) return rc;
+    if ((rc = sl.dyn.ensure(msm::dyn_words(T) * 4))) return rc;
+    { const size_t hslots = 2 * (T / msm::HEAVY_RANGE + 2); if ((rc = sl.hpart.ensure(hslots * C::XW * 4))) return rc; if ((rc = sl.hpart_inf.ensure(hslots))) return rc; }
+    uint32_t *const dyn = sl.dyn.as<uint32_t>();
+    const uint32_t dyn_args[5] = {(uint32_t)forced_chunk(), min_chunk, max_chunks, lanes_per_chunk, (uint32_t)T};
     hipStream_t s = sl.stream;
     {
         StageTimer st(sl, "msm.psort");
         HIPCHK(hipMemsetAsync(sl.bucket_inf.p, 1, NB, s));
         HIPCHK(hipMemsetAsync(sl.heavy.p, 0, 4, s));
         launch_psort(s, q, NB, sl.cnt.as<uint32_t>(), sl.cursor.as<uint32_t>(), sl.bsums.as<uint32_t>(), sl.digits.p, sl.off.as<uint32_t>(), sl.entries.as<uint32_t>(),
-                     heavy_thr, sl.heavy.as<uint32_t>(), HEAVY_CAP);
+                     heavy_thr, sl.heavy.as<uint32_t>(), HEAVY_CAP, dyn_args, dyn);
     }
     {
         StageTimer st(sl, "msm.accumulate");
         launch_accumulate<C>(s, (const uint32_t *)pt.tab, sl.entries.as<uint32_t>(), sl.off.as<uint32_t>(), NB, sl.bucket.as<uint32_t>(), sl.bucket_inf.as<uint8_t>(),
-                           sl.head.as<uint32_t>(), sl.tail.as<uint32_t>(), sl.head_b.as<uint32_t>(), sl.tail_b.as<uint32_t>(), sl.part_inf.as<uint8_t>(), T, (uint32_t)CH, 0xffffffffu);
+                           sl.head.as<uint32_t>(), sl.tail.as<uint32_t>(), sl.head_b.as<uint32_t>(), sl.tail_b.as<uint32_t>(), sl.part_inf.as<uint8_t>(), T, (uint32_t)CH, 0xffffffffu, dyn);
     }
     {
         StageTimer st(sl, "msm.fixup");
         launch_fixup<C>(s, NB, sl.bucket.as<uint32_t>(), sl.bucket_inf.as<uint8_t>(), sl.head.as<uint32_t>(), sl.tail.as<uint32_t>(),
-                           sl.head_b.as<uint32_t>(), sl.tail_b.as<uint32_t>(), sl.part_inf.as<uint8_t>(), T, sl.off.as<uint32_t>(), heavy_thr);
+                           sl.head_b.as<uint32_t>(), sl.tail_b.as<uint32_t>(), sl.part_inf.as<uint8_t>(), T, sl.off.as<uint32_t>(), heavy_thr, dyn);
         launch_fixup_heavy<C>(s, sl.heavy.as<uint32_t>(), HEAVY_CAP, sl.off.as<uint32_t>(), (uint32_t)CH, NB, sl.bucket.as<uint32_t>(), sl.bucket_inf.as<uint8_t>(),
-                           sl.head.as<uint32_t>(), sl.tail.as<uint32_t>(), sl.part_inf.as<uint8_t>(), T);
+                           sl.head.as<uint32_t>(), sl.tail.as<uint32_t>(), sl.part_inf.as<uint8_t>(), T, dyn, sl.hpart.as<uint32_t>(), sl.hpart_inf.as<uint8_t>());
     }
     uint32_t *win_a = sl.win.as<uint32_t>(), *win_s = win_a + (size_t)PW * 4 * C::ABI_W;
     uint8_t *inf_a = sl.win_inf.as<uint8_t>(), *inf_s = inf_a + PW;

@@ -22,6 +22,7 @@
 // Any c, any chunking and any order of additions give the same group element; only the projective
 // representative differs, and the ABI returns the normalised one.
 #pragma once
+#include "dyn_chunk.cuh"
 #include <hip/hip_runtime.h>
 #include "fp29.cuh"
 #include "fp2_29.cuh"
@@ -157,9 +158,10 @@ template <class C>
 __global__ void __launch_bounds__(256, C::ACC_WAVES) k_accumulate(const uint32_t *__restrict__ bases, const uint32_t *__restrict__ entries, const uint32_t *__restrict__ off,
                                                     uint32_t NB, uint32_t *__restrict__ bucket, uint8_t *__restrict__ bucket_inf,
                                                     uint32_t *__restrict__ head, uint32_t *__restrict__ tail, uint32_t *__restrict__ head_b, uint32_t *__restrict__ tail_b,
-                                                    uint8_t *__restrict__ part_inf, size_t T, uint32_t CH, uint32_t dbg_mask) {
+                                                    uint8_t *__restrict__ part_inf, size_t T, uint32_t CH, uint32_t dbg_mask, const uint32_t *__restrict__ dyn) {
     typedef typename C::F F;
     size_t t = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / C::LPP;   // C::LPP lanes cooperate on one chunk
+    if (dyn) { CH = dyn[DYN_CH]; T = dyn[DYN_T]; }      // chunking chosen on the device from the number of terms the sort produced
     if (t >= T) return;
     const uint32_t E = off[NB];
     uint64_t start64 = (uint64_t)t * CH;
@@ -209,9 +211,10 @@ template <class C>
 __global__ void __launch_bounds__(256) k_fixup(uint32_t NB, uint32_t *__restrict__ bucket, uint8_t *__restrict__ bucket_inf,
                                                const uint32_t *__restrict__ head, const uint32_t *__restrict__ tail, const uint32_t *__restrict__ head_b,
                                                const uint32_t *__restrict__ tail_b, const uint8_t *__restrict__ part_inf, size_t T,
-                                               const uint32_t *__restrict__ off, uint32_t heavy_thr) {
+                                               const uint32_t *__restrict__ off, uint32_t heavy_thr, const uint32_t *__restrict__ dyn) {
     typedef typename C::F F;
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (dyn) { T = dyn[DYN_T]; heavy_thr = dyn[DYN_HEAVY]; }
     if (t >= T) return;
     uint32_t b = tail_b[t];
     if (b == 0xffffffffu) return;
@@ -226,48 +229,107 @@ __global__ void __launch_bounds__(256) k_fixup(uint32_t NB, uint32_t *__restrict
     bucket_inf[b] = inf;
 }
 
-// Buckets with >= heavy_thr terms span many chunks: one block per such bucket folds its pieces (the tail slot of the
-// chunk holding the bucket's first term, then the head slots of every following chunk up to the one holding its last
-// term): strided serial sums per thread, then a tree through LDS.  Bounds the worst case (all scalars equal) to
-// span/256 + 8 dependent additions instead of span.
+// Buckets with >= heavy_thr terms span many chunks; their pieces (the tail slot of the chunk holding the bucket's first term, then the head
+// slots of every following chunk up to the one holding its last term) are folded by whole blocks: strided serial sums per thread, then a
+// tree through LDS.  k_fixup_heavy folds a bucket of up to HEAVY_RANGE pieces with one block and puts a longer one (all scalars equal; the
+// `1` of a Groth16 witness: 10^5 .. 10^7 terms in one bucket) on the list dyn[DYN_MULTI ..].  Those are cut at multiples of HEAVY_RANGE chunk
+// indices: k_fixup_heavy_ranges, one block per (bucket, range), leaves the range's sum in hpart[2 k + (the bucket starts in range k)] (at most
+// one long bucket ends and one starts inside a range); k_fixup_heavy_join folds a bucket's ranges.  Worst case ~2 x (HEAVY_RANGE / threads +
+// log2(threads)) dependent additions instead of pieces / threads.
+template <class C> __device__ __forceinline__ void block_tree_fold(Xyzz<typename C::F> &acc, bool &inf, size_t items, uint32_t *sh, uint8_t *shinf) {
+    typedef typename C::F F;
+    constexpr int BT = C::HEAVY_T;
+    for (int s2 = BT / 2; s2 >= 1; s2 >>= 1) {
+        if ((size_t)s2 >= items) continue;             // (uniform per block) threads s2 .. 2 s2 - 1 hold nothing yet
+        __syncthreads();
+        if ((int)threadIdx.x >= s2 && (int)threadIdx.x < 2 * s2) {
+            const uint32_t *w = reinterpret_cast<const uint32_t *>(&acc);
+            for (int k = 0; k < C::XW; k++) sh[k * BT + threadIdx.x] = w[k];
+            shinf[threadIdx.x] = inf;
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < s2) {
+            Xyzz<F> o; uint32_t *w = reinterpret_cast<uint32_t *>(&o);
+            for (int k = 0; k < C::XW; k++) w[k] = sh[k * BT + threadIdx.x + s2];
+            xyzz_add(acc, inf, o, shinf[threadIdx.x + s2] != 0);
+        }
+    }
+    __syncthreads();
+}
+// sum of the pieces lo .. up of the bucket whose first piece is t0 (left on thread 0)
+template <class C> __device__ __forceinline__ void fold_pieces(Xyzz<typename C::F> &acc, bool &inf, size_t t0, size_t lo, size_t up, const uint32_t *__restrict__ head, const uint32_t *__restrict__ tail,
+                                                               const uint8_t *__restrict__ part_inf, size_t T, uint32_t *sh, uint8_t *shinf) {
+    typedef typename C::F F;
+    inf = true; fzero(acc.x); fzero(acc.y); fzero(acc.zz); fzero(acc.zzz);
+    for (size_t t = lo + threadIdx.x; t <= up; t += C::HEAVY_T) {
+        Xyzz<F> o; bool oinf;
+        if (t == t0) { load_soa<C>(o, tail, T, t); oinf = part_inf[2 * t + 1] != 0; }
+        else { load_soa<C>(o, head, T, t); oinf = part_inf[2 * t] != 0; }
+        xyzz_add(acc, inf, o, oinf);
+    }
+    block_tree_fold<C>(acc, inf, up - lo + 1, sh, shinf);
+}
 template <class C>
 __global__ void __launch_bounds__(C::HEAVY_T) k_fixup_heavy(const uint32_t *__restrict__ heavy, uint32_t heavy_cap, const uint32_t *__restrict__ off, uint32_t CH,
                                                      uint32_t NB, uint32_t *__restrict__ bucket, uint8_t *__restrict__ bucket_inf,
-                                                     const uint32_t *__restrict__ head, const uint32_t *__restrict__ tail, const uint8_t *__restrict__ part_inf, size_t T) {
+                                                     const uint32_t *__restrict__ head, const uint32_t *__restrict__ tail, const uint8_t *__restrict__ part_inf, size_t T, uint32_t *__restrict__ dyn) {
     typedef typename C::F F;
     constexpr int BT = C::HEAVY_T;
+    CH = dyn[DYN_CH]; T = dyn[DYN_T];
     __shared__ uint32_t sh[C::XW * BT];
     __shared__ uint8_t shinf[BT];
     uint32_t nh = heavy[0]; if (nh > heavy_cap) nh = heavy_cap;
     for (uint32_t hi = blockIdx.x; hi < nh; hi += gridDim.x) {
         const uint32_t b = heavy[1 + hi];
         const size_t t0 = off[b] / CH, t1 = (off[b + 1] - 1) / CH;
+        if (t1 - t0 + 1 > HEAVY_RANGE) { if (threadIdx.x == 0) { const uint32_t m = atomicAdd(&dyn[DYN_NMULTI], 1u); dyn[DYN_MULTI + m] = b; } continue; }   // (at most T / HEAVY_RANGE of them)
+        Xyzz<F> acc; bool inf;
+        fold_pieces<C>(acc, inf, t0, t0, t1, head, tail, part_inf, T, sh, shinf);
+        if (threadIdx.x == 0) { store_soa<C>(bucket, NB, b, acc); bucket_inf[b] = inf; }
+    }
+}
+template <class C>
+__global__ void __launch_bounds__(C::HEAVY_T) k_fixup_heavy_ranges(const uint32_t *__restrict__ off, const uint32_t *__restrict__ head, const uint32_t *__restrict__ tail, const uint8_t *__restrict__ part_inf,
+                                                            const uint32_t *__restrict__ dyn, uint32_t *__restrict__ hpart, uint8_t *__restrict__ hpart_inf) {
+    typedef typename C::F F;
+    constexpr int BT = C::HEAVY_T;
+    const uint32_t CH = dyn[DYN_CH], nm = dyn[DYN_NMULTI];
+    const size_t T = dyn[DYN_T];
+    __shared__ uint32_t sh[C::XW * BT];
+    __shared__ uint8_t shinf[BT];
+    // ranges along x: consecutive workgroup ids go to different XCDs / CUs.  (With the buckets along x the few blocks that have work sat 32
+    // ids apart and were all dispatched to the same eight CUs: 64 ranges took 8 rounds, 1.17 ms instead of 0.2.)
+    for (uint32_t mi = blockIdx.y; mi < nm; mi += gridDim.y) {
+        const uint32_t b = dyn[DYN_MULTI + mi];
+        const size_t t0 = off[b] / CH, t1 = (off[b + 1] - 1) / CH, k0 = t0 / HEAVY_RANGE, k1 = t1 / HEAVY_RANGE;
+        for (size_t k = k0 + blockIdx.x; k <= k1; k += gridDim.x) {
+            const size_t lo = k * HEAVY_RANGE > t0 ? k * HEAVY_RANGE : t0, up = (k + 1) * HEAVY_RANGE - 1 < t1 ? (k + 1) * HEAVY_RANGE - 1 : t1;
+            Xyzz<F> acc; bool inf;
+            fold_pieces<C>(acc, inf, t0, lo, up, head, tail, part_inf, T, sh, shinf);
+            if (threadIdx.x == 0) { const size_t slot = 2 * k + (k == k0 ? 1 : 0); store_soa<C>(hpart, 0, slot, acc); hpart_inf[slot] = inf; }
+        }
+    }
+}
+template <class C>
+__global__ void __launch_bounds__(C::HEAVY_T) k_fixup_heavy_join(const uint32_t *__restrict__ off, uint32_t NB, uint32_t *__restrict__ bucket, uint8_t *__restrict__ bucket_inf, const uint32_t *__restrict__ dyn,
+                                                          const uint32_t *__restrict__ hpart, const uint8_t *__restrict__ hpart_inf) {
+    typedef typename C::F F;
+    constexpr int BT = C::HEAVY_T;
+    const uint32_t CH = dyn[DYN_CH], nm = dyn[DYN_NMULTI];
+    __shared__ uint32_t sh[C::XW * BT];
+    __shared__ uint8_t shinf[BT];
+    for (uint32_t mi = blockIdx.x; mi < nm; mi += gridDim.x) {
+        const uint32_t b = dyn[DYN_MULTI + mi];
+        const size_t t0 = off[b] / CH, t1 = (off[b + 1] - 1) / CH, k0 = t0 / HEAVY_RANGE, k1 = t1 / HEAVY_RANGE;
         Xyzz<F> acc; bool inf = true;
         fzero(acc.x); fzero(acc.y); fzero(acc.zz); fzero(acc.zzz);
-        for (size_t t = t0 + threadIdx.x; t <= t1; t += BT) {
-            Xyzz<F> o; bool oinf;
-            if (t == t0) { load_soa<C>(o, tail, T, t); oinf = part_inf[2 * t + 1] != 0; }
-            else { load_soa<C>(o, head, T, t); oinf = part_inf[2 * t] != 0; }
-            xyzz_add(acc, inf, o, oinf);
+        for (size_t k = k0 + threadIdx.x; k <= k1; k += BT) {
+            const size_t slot = 2 * k + (k == k0 ? 1 : 0);
+            Xyzz<F> o; load_soa<C>(o, hpart, 0, slot);
+            xyzz_add(acc, inf, o, hpart_inf[slot] != 0);
         }
-        const size_t pieces = t1 - t0 + 1;
-        for (int s2 = BT / 2; s2 >= 1; s2 >>= 1) {
-            if ((size_t)s2 >= pieces) continue;             // (uniform per block) threads s2 .. 2 s2 - 1 hold nothing yet
-            __syncthreads();
-            if ((int)threadIdx.x >= s2 && (int)threadIdx.x < 2 * s2) {
-                const uint32_t *w = reinterpret_cast<const uint32_t *>(&acc);
-                for (int k = 0; k < C::XW; k++) sh[k * BT + threadIdx.x] = w[k];
-                shinf[threadIdx.x] = inf;
-            }
-            __syncthreads();
-            if ((int)threadIdx.x < s2) {
-                Xyzz<F> o; uint32_t *w = reinterpret_cast<uint32_t *>(&o);
-                for (int k = 0; k < C::XW; k++) w[k] = sh[k * BT + threadIdx.x + s2];
-                xyzz_add(acc, inf, o, shinf[threadIdx.x + s2] != 0);
-            }
-        }
+        block_tree_fold<C>(acc, inf, k1 - k0 + 1, sh, shinf);
         if (threadIdx.x == 0) { store_soa<C>(bucket, NB, b, acc); bucket_inf[b] = inf; }
-        __syncthreads();
     }
 }
 
@@ -490,8 +552,9 @@ template <class PAIR>
 __global__ void __launch_bounds__(256) k_fixup_pair(uint32_t NB, uint32_t *__restrict__ bucket, uint8_t *__restrict__ bucket_inf,
                                                     const uint32_t *__restrict__ head, const uint32_t *__restrict__ tail, const uint32_t *__restrict__ head_b,
                                                     const uint32_t *__restrict__ tail_b, const uint8_t *__restrict__ part_inf, size_t T,
-                                                    const uint32_t *__restrict__ off, uint32_t heavy_thr) {
+                                                    const uint32_t *__restrict__ off, uint32_t heavy_thr, const uint32_t *__restrict__ dyn) {
     const size_t t = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 1;
+    if (dyn) { T = dyn[DYN_T]; heavy_thr = dyn[DYN_HEAVY]; }
     if (t >= T) return;
     const uint32_t b = tail_b[t];
     if (b == 0xffffffffu) return;

@@ -8,18 +8,20 @@ template <class C> void launch_prep_bases(hipStream_t s, const uint32_t *abi, co
     hipLaunchKernelGGL((k_prep_bases<C>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, abi, is_inf, n, out);
 }
 template <class C> void launch_accumulate(hipStream_t s, const uint32_t *bases, const uint32_t *entries, const uint32_t *off, uint32_t NB, uint32_t *bucket, uint8_t *bucket_inf,
-                                          uint32_t *head, uint32_t *tail, uint32_t *head_b, uint32_t *tail_b, uint8_t *part_inf, size_t T, uint32_t CH, uint32_t dbg_mask) {
+                                          uint32_t *head, uint32_t *tail, uint32_t *head_b, uint32_t *tail_b, uint8_t *part_inf, size_t T, uint32_t CH, uint32_t dbg_mask, const uint32_t *dyn) {
     typedef typename C::ACC A;
-    hipLaunchKernelGGL((k_accumulate<A>), dim3((unsigned)((T * A::LPP + 255) / 256)), dim3(256), 0, s, bases, entries, off, NB, bucket, bucket_inf, head, tail, head_b, tail_b, part_inf, T, CH, dbg_mask);
+    hipLaunchKernelGGL((k_accumulate<A>), dim3((unsigned)((T * A::LPP + 255) / 256)), dim3(256), 0, s, bases, entries, off, NB, bucket, bucket_inf, head, tail, head_b, tail_b, part_inf, T, CH, dbg_mask, dyn);
 }
 template <class C> void launch_fixup(hipStream_t s, uint32_t NB, uint32_t *bucket, uint8_t *bucket_inf, const uint32_t *head, const uint32_t *tail, const uint32_t *head_b,
-                                     const uint32_t *tail_b, const uint8_t *part_inf, size_t T, const uint32_t *off, uint32_t heavy_thr) {
-    if constexpr (C::NFP == 2) hipLaunchKernelGGL((k_fixup_pair<G2P>), dim3((unsigned)((2 * T + 255) / 256)), dim3(256), 0, s, NB, bucket, bucket_inf, head, tail, head_b, tail_b, part_inf, T, off, heavy_thr);   // G2: lane pairs
-    else hipLaunchKernelGGL((k_fixup<C>), dim3((unsigned)((T + 255) / 256)), dim3(256), 0, s, NB, bucket, bucket_inf, head, tail, head_b, tail_b, part_inf, T, off, heavy_thr);
+                                     const uint32_t *tail_b, const uint8_t *part_inf, size_t T, const uint32_t *off, uint32_t heavy_thr, const uint32_t *dyn) {
+    if constexpr (C::NFP == 2) hipLaunchKernelGGL((k_fixup_pair<G2P>), dim3((unsigned)((2 * T + 255) / 256)), dim3(256), 0, s, NB, bucket, bucket_inf, head, tail, head_b, tail_b, part_inf, T, off, heavy_thr, dyn);   // G2: lane pairs
+    else hipLaunchKernelGGL((k_fixup<C>), dim3((unsigned)((T + 255) / 256)), dim3(256), 0, s, NB, bucket, bucket_inf, head, tail, head_b, tail_b, part_inf, T, off, heavy_thr, dyn);
 }
 template <class C> void launch_fixup_heavy(hipStream_t s, const uint32_t *heavy, uint32_t heavy_cap, const uint32_t *off, uint32_t CH, uint32_t NB, uint32_t *bucket, uint8_t *bucket_inf,
-                                           const uint32_t *head, const uint32_t *tail, const uint8_t *part_inf, size_t T) {
-    hipLaunchKernelGGL((k_fixup_heavy<C>), dim3(512), dim3(C::HEAVY_T), 0, s, heavy, heavy_cap, off, CH, NB, bucket, bucket_inf, head, tail, part_inf, T);
+                                           const uint32_t *head, const uint32_t *tail, const uint8_t *part_inf, size_t T, uint32_t *dyn, uint32_t *hpart, uint8_t *hpart_inf) {
+    hipLaunchKernelGGL((k_fixup_heavy<C>), dim3(512), dim3(C::HEAVY_T), 0, s, heavy, heavy_cap, off, CH, NB, bucket, bucket_inf, head, tail, part_inf, T, dyn);
+    hipLaunchKernelGGL((k_fixup_heavy_ranges<C>), dim3(64, 32), dim3(C::HEAVY_T), 0, s, off, head, tail, part_inf, (const uint32_t *)dyn, hpart, hpart_inf);
+    hipLaunchKernelGGL((k_fixup_heavy_join<C>), dim3(32), dim3(C::HEAVY_T), 0, s, off, NB, bucket, bucket_inf, (const uint32_t *)dyn, (const uint32_t *)hpart, (const uint8_t *)hpart_inf);
 }
 template <class C> void launch_reduce_l0(hipStream_t s, unsigned NG, const uint32_t *bucket, const uint8_t *bucket_inf, uint32_t NB, int mshift, uint32_t *l1, uint8_t *l1_inf) {
     if constexpr (C::NFP == 2) hipLaunchKernelGGL((k_reduce_l0_pair<G2P>), dim3(NG), dim3(64), 0, s, bucket, bucket_inf, NB, mshift, l1, l1_inf);     // G2: lane pairs

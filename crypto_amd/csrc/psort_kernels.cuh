@@ -13,6 +13,7 @@
 //   key = w * key_wstride + (|digit| - 1)            key_wstride = 0: all windows share one bucket set (precomputed 2^(c w) P tables)
 //   val = (val_base + w * val_wstride + i) | sign << 31     index of the base record the term adds
 #pragma once
+#include "dyn_chunk.cuh"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "sort_launch.cuh"
@@ -126,7 +127,8 @@ __global__ void __launch_bounds__(PS_TILE) k_ps_scatter1(PsParams q, const uint3
 // P4: one block per partition of 2^part_log buckets
 __global__ void __launch_bounds__(1024) k_ps_bucket(const uint2 *__restrict__ pairs, const uint32_t *__restrict__ off1, uint32_t ntiles, uint32_t P, uint32_t NB, int part_log,
                                                     uint32_t *__restrict__ off, uint32_t *__restrict__ entries,
-                                                    uint32_t heavy_thr, uint32_t *__restrict__ heavy, uint32_t heavy_cap) {
+                                                    uint32_t heavy_thr, uint32_t *__restrict__ heavy, uint32_t heavy_cap, const uint32_t *__restrict__ dyn) {
+    if (dyn) heavy_thr = dyn[DYN_HEAVY];
     __shared__ uint32_t cnt[PS_PART];
     __shared__ uint32_t wave_tot[17];
     const uint32_t p = blockIdx.x, PB = 1u << part_log, mask = PB - 1;

@@ -1,6 +1,7 @@
 // crypto_amd/csrc/sort_kernels.cuh — curve-independent kernels of the MSM pipeline: signed-digit recoding, the LDS
 // counting sort (K2/K4), the histogram scan (K3) and the device self-tests.  Included by k_sort.hip only.
 #pragma once
+#include "dyn_chunk.cuh"
 #include <hip/hip_runtime.h>
 #include "fp29.cuh"
 #include "ec29.cuh"
@@ -152,6 +153,34 @@ __global__ void __launch_bounds__(256) k_scan_add(uint32_t *__restrict__ out, ui
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) { uint32_t v = out[i] + block_sums[i / SCAN_B]; out[i] = v; if (cursor) cursor[i] = v; }
     if (i == n) out[n] = block_sums[nb];
+}
+
+// ---- chunking from the actual pair count (dyn_chunk.cuh) ------------------------------------------------------------
+// one thread: choose_chunk's rule (dock_core.hip) on E = *total.  fixed_ch != 0: a chunk length forced by the host (tuning knobs) is kept.
+__global__ void k_dyn_chunk(const uint32_t *__restrict__ total, uint32_t fixed_ch, uint32_t min_chunk, uint32_t max_chunks, uint32_t lanes_per_chunk, uint32_t T_max, uint32_t *__restrict__ dyn) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const uint32_t E = *total;
+    uint32_t ch = fixed_ch;
+    if (!ch) {
+        ch = min_chunk;
+        while (E / ch > max_chunks && ch < 4096) ch *= 2;
+        const uint32_t resident = RESIDENT_ACC_LANES / lanes_per_chunk;
+        const uint32_t chunks = (E + ch - 1) / ch;
+        if (chunks > resident) {            // whole rounds of the chip
+            uint32_t rounds = (chunks + resident / 2) / resident;
+            if (rounds < 1) rounds = 1;
+            const uint32_t len = (uint32_t)(((uint64_t)E + (uint64_t)rounds * resident - 1) / ((uint64_t)rounds * resident));
+            if (len >= 16 && len <= 4096) ch = len;
+        }
+    }
+    if (T_max && (E + ch - 1) / ch > T_max) ch = (E + T_max - 1) / T_max;      // never more chunks than partial slots
+    dyn[DYN_CH] = ch; dyn[DYN_T] = (E + ch - 1) / ch; dyn[DYN_HEAVY] = 16u * ch; dyn[DYN_E] = E; dyn[DYN_NMULTI] = 0;
+}
+// buckets with at least dyn[DYN_HEAVY] terms -> heavy[] (the sweep sort counts before the pair total is known, so it cannot flag them itself)
+__global__ void __launch_bounds__(256) k_flag_heavy(const uint32_t *__restrict__ off, uint32_t NB, const uint32_t *__restrict__ dyn, uint32_t *__restrict__ heavy, uint32_t heavy_cap) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= NB) return;
+    if (off[b + 1] - off[b] >= dyn[DYN_HEAVY]) { uint32_t h = atomicAdd(&heavy[0], 1u); if (h < heavy_cap) heavy[1 + h] = b; }
 }
 
 // ---- self-test kernels (tests/: device arithmetic vs oracle without the MSM plumbing) ------------------------

@@ -11,6 +11,9 @@ void launch_digit_codes(hipStream_t s, bool wide, const uint32_t *scalars, const
 void launch_sort_sweep(hipStream_t s, bool wide, bool scatter, unsigned grid, size_t lds_bytes, const void *dig, size_t n, size_t n_pad, int W, int RANGES, int rb_log, uint32_t B,
                        uint32_t *cnt, const uint32_t *off, uint32_t *entries, uint32_t heavy_thr, uint32_t *heavy, uint32_t heavy_cap);
 void launch_scan(hipStream_t s, const uint32_t *cnt, uint32_t *off, uint32_t *cursor, uint32_t *bsums, size_t NB);
+// chunking of the accumulation from the pair count the sort produced (dyn_chunk.cuh): dyn[0..3] = chunk length, chunks, heavy threshold, pairs
+void launch_dyn_chunk(hipStream_t s, const uint32_t *total, uint32_t fixed_ch, uint32_t min_chunk, uint32_t max_chunks, uint32_t lanes_per_chunk, uint32_t T_max, uint32_t *dyn);
+void launch_flag_heavy(hipStream_t s, const uint32_t *off, uint32_t NB, const uint32_t *dyn, uint32_t *heavy, uint32_t heavy_cap);
 size_t scan_blocks(size_t NB);
 // ---- two-level partition sort (k_psort.hip, psort_kernels.cuh) ----
 constexpr int PS_TILE = 512;            // scalars per tile = threads per block of P1 / P3
@@ -35,7 +38,7 @@ struct PsParams {
 inline int ps_part_log(uint32_t NB) { int lg = 0; while ((1u << lg) < NB) lg++; int pl = lg - 10; return pl < 5 ? 5 : (pl > PS_PART_LOG_MAX ? PS_PART_LOG_MAX : pl); }
 // cnt1 / off1: P * ntiles + 1 words; bsums: scan_blocks(P * ntiles) + 2 words; pairs: n * W x 8 B; off: NB + 1; entries: n * W
 void launch_psort(hipStream_t s, const PsParams &q, uint32_t NB, uint32_t *cnt1, uint32_t *off1, uint32_t *bsums, void *pairs, uint32_t *off, uint32_t *entries,
-                  uint32_t heavy_thr, uint32_t *heavy, uint32_t heavy_cap);
+                  uint32_t heavy_thr, uint32_t *heavy, uint32_t heavy_cap, const uint32_t *dyn_args = nullptr, uint32_t *dyn = nullptr);
 void launch_g1_scale(hipStream_t s, const uint32_t *p_abi, const uint8_t *is_inf, const uint32_t *scalars, int scalar_stride, const uint8_t *negate, size_t n, uint32_t *out_abi, uint8_t *out_inf);
 void launch_selftest_fp_mul(hipStream_t s, const uint32_t *a, const uint32_t *b, size_t n, uint32_t *out);
 void launch_selftest_g1_sum(hipStream_t s, const uint32_t *pts, const uint8_t *neg, size_t n, uint32_t *out, uint8_t *out_inf);

@@ -9,6 +9,7 @@ The witness map (h coefficients; r1cs_to_qap.rs:150-210) is SURVEY 8f-1 "next": 
 is an input of the reference function mirrored.  Scalars are canonical (`into_bigint`) 4x64 numpy rows; points are
 ABI-layout numpy arrays (affine; identity = all-zero words).
 """
+import ctypes as C
 import numpy as np
 import importlib
 M = importlib.import_module(__package__ + ".msm")   # (the package re-exports a function called `msm`, which shadows the submodule attribute)
@@ -46,10 +47,18 @@ def _neg_affine(curve, pt):
 
 
 def lincomb(curve, points, scalars):
-    """sum scalars[i] * points[i] (a tiny MSM through the same entry point), normalised Jacobian"""
-    pts = np.stack([np.asarray(p, dtype=np.uint64) for p in points])
-    sc = np.stack([_sc(s) for s in scalars])
-    return M.msm_bigint(curve, pts, sc)
+    """sum scalars[i] * points[i] for the handful of points around the MSMs (the reference: `mul_bigint` on the CPU, prover.rs:309-313,350-355).
+    Up to 16 terms: dgpu_lincomb_* (host arithmetic inside the library, no device launch); more: the MSM entry point.  Normalised Jacobian."""
+    pts = np.ascontiguousarray(np.stack([np.asarray(p, dtype=np.uint64) for p in points]))
+    sc = np.ascontiguousarray(np.stack([_sc(s) for s in scalars]))
+    if len(pts) > 16:
+        return M.msm_bigint(curve, pts, sc)
+    inf = np.ascontiguousarray((~pts.any(axis=1)).astype(np.uint8))          # the ABI's affine identity: all-zero words
+    out = np.zeros(curve.JW, dtype=np.uint64)
+    rc = curve.fn("dgpu_lincomb_%s")(pts.ctypes.data_as(C.c_void_p), inf.ctypes.data_as(C.c_void_p), sc.ctypes.data_as(C.c_void_p), len(pts), out.ctypes.data_as(C.c_void_p))
+    if rc:
+        raise M.DockGpuError(rc, "dgpu_lincomb")
+    return out
 
 
 class ProvingKey:
@@ -165,7 +174,7 @@ def _pool():
     global _POOL
     if _POOL is None:
         from concurrent.futures import ThreadPoolExecutor
-        _POOL = ThreadPoolExecutor(8)
+        _POOL = ThreadPoolExecutor(12)
     return _POOL
 
 
@@ -214,21 +223,36 @@ def create_proof(pk, r, s, v, h, input_assignment_with_one, witness_assignment, 
     src = vk.gamma_abc_g1[len(inp):len(inp) + cw]
     d_pts = np.concatenate([src, vk.eta_gamma_inv_g1.reshape(1, 12)])
     d_sc = np.concatenate([committed, _sc(v).reshape(1, 4)])
-    jobs = [lambda: pk.l_query.msm_resident(assignment, n=min(pk.l_query.n, n_aux), scalar_offset=aux_at),   # :299
-            lambda: _calculate_coeff(M.G1, pk.delta_g1, r, pk.a_query, pk.a0, vk.alpha_g1, assignment, a0),           # :325-326
-            (lambda: _calculate_coeff(M.G1, pk.delta_g1, s, pk.b_g1_query, pk.b1_0, pk.beta_g1, assignment, a0)) if r % R_MOD != 0
-            else (lambda: np.zeros(18, dtype=np.uint64)),          # :330-336
-            lambda: _calculate_coeff(M.G2, vk.delta_g2, s, pk.b_g2_query, pk.b2_0, vk.beta_g2, assignment, a0),       # :343-344
-            lambda: M.msm_bigint(M.G1, d_pts, d_sc)]
-    l_aux_acc, g_a, g1_b, g2_b, g_d = [f.result() for f in [pool.submit(j) for j in jobs]]
-    h_acc = f_h.result()
+    def coeff_msm(query):            # msm(query[1..], assignment) of calculate_coeff (:592)
+        return lambda: query.msm_resident(assignment, n=min(assignment.n - a0, query.n - 1), base_offset=1, scalar_offset=a0)
+    with_b1 = r % R_MOD != 0                                                                          # :330-336
+    # Issue order = the order in which the accumulations get the chip.  The G2 MSM is the longest call and ends in ~3 ms of latency-bound
+    # kernels (fix-up, bucket reduction): first in, its tail runs under the G1 MSMs instead of after them.
+    f_b2 = pool.submit(coeff_msm(pk.b_g2_query))                                                      # :343-344
+    f_a = pool.submit(coeff_msm(pk.a_query))                                                          # :325-326
+    f_b1 = pool.submit(coeff_msm(pk.b_g1_query)) if with_b1 else None
+    f_l = pool.submit(lambda: pk.l_query.msm_resident(assignment, n=min(pk.l_query.n, n_aux), scalar_offset=aux_at))   # :299
+    # The O(1)-sized pieces that depend on no MSM result (one job, one call in flight: they hide behind the large MSMs instead of forming
+    # a ~2 ms chain of tiny launches after the last of them): the constant parts of calculate_coeff, of g_c, and g_d.
+    def constants():
+        return (lincomb(M.G1, [pk.delta_g1, pk.a0, vk.alpha_g1], [r, 1, 1]),
+                lincomb(M.G2, [vk.delta_g2, pk.b2_0, vk.beta_g2], [s, 1, 1]),
+                lincomb(M.G1, [pk.delta_g1, pk.b1_0, pk.beta_g1], [s, 1, 1]) if with_b1 else None,
+                lincomb(M.G1, [pk.delta_g1, pk.eta_delta_inv_g1], [-(r * s), -v]),
+                M.msm_bigint(M.G1, d_pts, d_sc))
+    rest_a, rest_b2, rest_b1, rest_c, g_d = pool.submit(constants).result()
+    g_a = sharded.fold(M.G1, np.stack([f_a.result(), rest_a]))
+    g1_b = sharded.fold(M.G1, np.stack([f_b1.result(), rest_b1])) if with_b1 else np.zeros(18, dtype=np.uint64)
+    # s g_a + r g1_b needs only the two G1 results: computed while the G2 MSM is still in flight
+    sa_rb = lincomb(M.G1, [_affine(M.G1, g_a), _affine(M.G1, g1_b)], [s, r])
+    g2_b = sharded.fold(M.G2, np.stack([f_b2.result(), rest_b2]))
+    l_aux_acc, h_acc = f_l.result(), f_h.result()
     if resident_z is None:
         assignment.free()
     for x in own_h:
         x.free()
     # g_c = s g_a + r g1_b - rs delta + l_aux + h_acc - v (eta/delta)    :350-355
-    small = lincomb(M.G1, [_affine(M.G1, g_a), _affine(M.G1, g1_b), pk.delta_g1, pk.eta_delta_inv_g1], [s, r, -(r * s), -v])
-    g_c = sharded.fold(M.G1, np.stack([small, l_aux_acc, h_acc]))
+    g_c = sharded.fold(M.G1, np.stack([sa_rb, rest_c, l_aux_acc, h_acc]))
     return {"a": _affine(M.G1, g_a), "b": _affine(M.G2, g2_b), "c": _affine(M.G1, g_c), "d": _affine(M.G1, g_d)}
 
 

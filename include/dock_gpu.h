@@ -128,6 +128,13 @@ int32_t dgpu_msm_g2_sharded_resident(uint64_t bases, uint64_t scalars, uint64_t 
  * collective is an all-gather of k normalised Jacobian triples followed by this fold) ---- */
 int32_t dgpu_fold_g1(const uint64_t *partials_xyz /* k*18 */, size_t k, uint64_t out_xyz[18]);
 int32_t dgpu_fold_g2(const uint64_t *partials_xyz /* k*36 */, size_t k, uint64_t out_xyz[36]);
+/* sum_i scalars[i] * points[i] over k <= DGPU_MAX_LINCOMB affine points, computed on the HOST (no device call, usable without a device).
+ * This is the O(1) group arithmetic around the MSMs that the reference does with `mul_bigint` on the CPU, not a replacement for them:
+ * delta_g1 * r, s g_a + r g1_b - rs delta - v eta/delta, g_d (legogroth16/src/prover.rs:309-313, 350-355, 361-368, 585-594).
+ * points: k x 12 (G1) / 24 (G2) u64 Montgomery, is_inf: k bytes or NULL, scalars: k x 4 u64 canonical; out: normalised Jacobian. */
+#define DGPU_MAX_LINCOMB 16
+int32_t dgpu_lincomb_g1(const uint64_t *points_xy, const uint8_t *is_inf, const uint64_t *scalars, size_t k, uint64_t out_xyz[18]);
+int32_t dgpu_lincomb_g2(const uint64_t *points_xy, const uint8_t *is_inf, const uint64_t *scalars, size_t k, uint64_t out_xyz[36]);
 
 /* ---- pairings ----
  * replaces Bls12_381::multi_miller_loop(a, b) — utils/src/randomized_pairing_check.rs:207,

@@ -23,12 +23,13 @@ z = B.seeded_scalars(7, m + 3)
 rng = np.random.Generator(np.random.PCG64(8)); kd = rng.integers(0, 4, m + 3)
 z[kd <= 1] = 0; z[kd == 1, 0] = rng.integers(0, 2, int((kd == 1).sum()), dtype=np.uint64); mk = kd == 2; z[mk, 1:] = 0; z[mk, 0] &= np.uint64(0xFFFF)
 cw, V = 2, m + 2
-pre = (lambda d: d.precompute()) if table else (lambda d: d)
+wc = int(os.environ.get("WITNESS_C", "0")); hc = int(os.environ.get("H_C", "0"))     # window widths of the witness-query / h-query tables (0 = automatic)
+pre = (lambda d, c=0: d.precompute(c)) if table else (lambda d, c=0: d)
 with FB.WindowTable(ca.G2, gen2[0]) as t2, FB.WindowTable(ca.G1, gen1[0]) as t1:
     small1, _ = t1.multiply_many(B.seeded_scalars(10, 8 + 2 + cw)); small2, _ = t2.multiply_many(B.seeded_scalars(11, 4))
-    qa = pre(t1.multiply_many_to_bases(B.seeded_scalars(12, V + 1))); qb1 = pre(t1.multiply_many_to_bases(B.seeded_scalars(13, V + 1)))
-    qb2 = pre(t2.multiply_many_to_bases(B.seeded_scalars(14, V + 1))); qh = pre(t1.multiply_many_to_bases(B.seeded_scalars(15, n - 1)))
-    ql = pre(t1.multiply_many_to_bases(B.seeded_scalars(16, m + 1 - cw)))
+    qa = pre(t1.multiply_many_to_bases(B.seeded_scalars(12, V + 1)), wc); qb1 = pre(t1.multiply_many_to_bases(B.seeded_scalars(13, V + 1)), wc)
+    qb2 = pre(t2.multiply_many_to_bases(B.seeded_scalars(14, V + 1)), wc); qh = pre(t1.multiply_many_to_bases(B.seeded_scalars(15, n - 1)), hc)
+    ql = pre(t1.multiply_many_to_bases(B.seeded_scalars(16, m + 1 - cw)), wc)
 vk = LG.VerifyingKey(small1[0], small2[0], small2[1], small2[2], small1[8:8 + 2 + cw], small1[1], cw)
 pk = LG.ProvingKey.from_device(vk, small1[2], small1[3], small1[4], small1[5], small1[6], small2[3], qa, qb1, qb2, qh, ql)
 
@@ -45,4 +46,4 @@ for name, fn in (("witness map, then MSMs", seq), ("witness map overlapped", ovl
     for _ in range(8):
         t0 = time.perf_counter(); p = fn(); ts.append((time.perf_counter() - t0) * 1e3)
     assert all((p[k] == ref[k]).all() for k in ref)
-    print("%-26s table=%d  median %.2f ms  min %.2f  max %.2f  (%.1f M constraints/s)" % (name, table, sorted(ts)[4], min(ts), max(ts), (m + 1) / sorted(ts)[4] / 1e3), flush=True)
+    print("%-26s table=%d wc=%d hc=%d  median %.2f ms  min %.2f  max %.2f  (%.1f M constraints/s)" % (name, table, wc, hc, sorted(ts)[4], min(ts), max(ts), (m + 1) / sorted(ts)[4] / 1e3), flush=True)

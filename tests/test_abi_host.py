@@ -171,6 +171,37 @@ def test_fold_partials_on_host(curve, G):
     assert not sharded.fold(curve, both)[-h:].any()
 
 
+@pytest.mark.parametrize("curve,G", [(ca.G1, O.G1), (ca.G2, O.G2)])
+def test_lincomb_on_host_matches_the_oracle(curve, G):
+    """dgpu_lincomb_*: the O(1) scalar multiplications around the MSMs (prover.rs:309-313,350-355 use `mul_bigint` on the CPU) — host
+    arithmetic inside the library, no device: sum s_i P_i == the oracle's MSM, for 0 .. 16 terms, zero scalars, identity points, repeated
+    and opposite points, scalars r - 1 and 2^255 - 1 (not reduced); more than DGPU_MAX_LINCOMB terms are refused."""
+    from crypto_amd import legogroth16 as LG
+    from crypto_amd.aggregation.ops import neg
+    k0 = O.rand_scalars(5, 1)[0]; d = O.rand_scalars(6, 1)[0]
+    pts = G.gen_seq(k0, d, 16, threads=4)
+    sc = O.rand_scalars(7, 16)
+    sc[1] = 0
+    sc[2] = O.int_to_limbs(U.R - 1, 4)
+    sc[3] = np.array([0xFFFFFFFFFFFFFFFF] * 3 + [0x7FFFFFFFFFFFFFFF], np.uint64)
+    sc[4] = O.int_to_limbs(1, 4)
+    pts[6] = pts[5]; pts[8] = neg(curve, pts[7]); sc[8] = sc[7]
+    inf = np.zeros(16, np.uint8); inf[9] = 1
+    for k in (0, 1, 2, 3, 4, 9, 10, 16):
+        p = pts[:k].copy(); p[inf[:k] == 1] = 0
+        got = LG.lincomb(curve, list(p), [O.limbs_to_int(x) for x in sc[:k]]) if k else None
+        if k == 0:
+            out = np.zeros(curve.JW, np.uint64)
+            assert curve.fn("dgpu_lincomb_%s")(None, None, None, 0, out.ctypes.data_as(C.c_void_p)) == 0
+            got = out
+        exp = G.msm(pts[:k], sc[:k], inf[:k], threads=1) if k else G.msm(pts[:0], sc[:0], None, threads=1)
+        assert U.jac_to_model(G, got) == U.jac_to_model(G, exp), k
+    out = np.zeros(curve.JW, np.uint64)
+    big_p = np.concatenate([pts, pts[:1]]); big_s = np.concatenate([sc, sc[:1]])
+    rc = curve.fn("dgpu_lincomb_%s")(big_p.ctypes.data_as(C.c_void_p), None, big_s.ctypes.data_as(C.c_void_p), 17, out.ctypes.data_as(C.c_void_p))
+    assert rc == ca.DGPU_E_BADARG if hasattr(ca, "DGPU_E_BADARG") else rc != 0
+
+
 def test_chunk_bounds_partition():
     for n in (0, 1, 7, 8, 1 << 20, (1 << 24) + 3):
         for world in (1, 2, 3, 8):

@@ -427,10 +427,10 @@ def secondary_configs(log2n, ks, scalars, db, ds, pool):
     ntt_ms = st.get("qap.ntt", (0.0, 1)); ntt_ms = ntt_ms[0] / max(1, ntt_ms[1])
     if ntt_ms > 0:
         alg = 7 * 2 * 32.0 * n                                # 7 transforms x (read + write) x 32 B per element
-        res["ntt_roofline"] = {"bound": "hbm", "kernel": "k_ntt_fused (+ k_coset_scale, k_pointwise): the seven transforms of one witness map", "achieved": round(alg / (ntt_ms * 1e-3) / 1e9, 1),
+        res["ntt_roofline"] = {"bound": "hbm", "kernel": "k_ntt_r4: the seven transforms of one witness map (9 launches: a, b, c go through every pass together; (ab - c)/Z and the final scaling / un-reversal are fused into the last transform)", "achieved": round(alg / (ntt_ms * 1e-3) / 1e9, 1),
                                "peak": 8000.0, "unit": "GB/s", "frac": round(alg / (ntt_ms * 1e-3) / 1e9 / 8000.0, 4), "avg_ms": round(ntt_ms, 3),
                                "matvec_incl_upload_ms": round(st.get("qap.matvec", (0.0, 1))[0] / max(1, st.get("qap.matvec", (0.0, 1))[1]), 3),
-                               "note": "algorithmic 448 B per domain element; the transforms are VALU-issue bound (73 M radix-2 butterflies of one 10-limb Fr product each), not HBM bound"}
+                               "note": "algorithmic 448 B per domain element; the transforms are VALU-issue bound (73 M butterflies of one 10-limb Fr product each; rocprof: vector ALU issuing ~89 % of the time in the batched passes), not HBM bound"}
     cw = 2
     V = m + 2                                          # variables 1 .. m + 2 pair with query[1..]
     with FB.WindowTable(ca.G2, gen2[0]) as t2, FB.WindowTable(ca.G1, gen1[0]) as t1:

@@ -13,11 +13,12 @@ rng = np.random.default_rng(int(os.environ.get("SEED", "1")))
 k0 = O.rand_scalars(1, 1)[0]; d = O.rand_scalars(2, 1)[0]
 pool = {ca.G1: O.G1.gen_seq(k0, d, 6000, threads=32), ca.G2: O.G2.gen_seq(d, k0, 3000, threads=32)}
 grp = {ca.G1: O.G1, ca.G2: O.G2}
+O_R = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
 bad = 0
 for it in range(int(os.environ.get("ITER", "200"))):
     cv = ca.G1 if rng.integers(0, 3) else ca.G2
     G = grp[cv]
-    n = int(rng.choice([1, 2, 3, 17, 64, 65, 300, 1000, 2500])) + int(rng.integers(0, 40))
+    n = int(rng.choice([1, 2, 3, 17, 64, 65, 300, 1000, 2500, 6000 if rng.integers(0, 2) else 2500])) + int(rng.integers(0, 40))
     n = min(n, len(pool[cv]))
     idx = rng.integers(0, max(1, n // int(rng.choice([1, 1, 4, 50]))), n)          # many duplicates in some runs
     bases = pool[cv][idx].copy()
@@ -33,6 +34,11 @@ for it in range(int(os.environ.get("ITER", "200"))):
     sc[kind == 1, 0] &= np.uint64(0xFF)
     if rng.integers(0, 4) == 0:
         sc[:] = sc[0]                                                              # all-equal scalars: one hot bucket per window
+    if rng.integers(0, 3) == 0:                                                   # Groth16-like: many ones / minus-ones / tiny values (hot buckets, sparse pair lists)
+        m1 = rng.integers(0, 3, n) == 0
+        sc[m1] = 0; sc[m1, 0] = 1
+        m2 = rng.integers(0, 9, n) == 0
+        sc[m2] = O.int_to_limbs(O_R - 1, 4)
     exp = G.to_affine(G.msm(bases, sc, inf, threads=8))
     got = G.to_affine(ca.msm_bigint(cv, bases, sc, is_inf=inf))
     off = int(rng.integers(0, min(n, 5)))

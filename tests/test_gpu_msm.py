@@ -276,3 +276,27 @@ def test_concurrent_callers_share_the_device():
     for t in ths:
         t.join()
     assert not errs, errs
+
+
+@pytest.mark.parametrize("gname,logn", [("g1", 19), ("g2", 17)])
+def test_witness_like_scalars_at_size_closed_form(gname, logn):
+    """A Groth16-like witness at a size where its `1` bucket is long (2^16 .. 2^17 terms: thousands of chunks, several fold ranges) and the
+    pair list is a fraction of n * W (the chunking is then decided on the device): closed form over known discrete logs, on the plain
+    pipeline and on the table; the same with ALL scalars equal to 1 and to r - 1 (one bucket holds every term)."""
+    G, curve = (O.G1, ca.G1) if gname == "g1" else (O.G2, ca.G2)
+    n = 1 << logn
+    bases, k0, d = U.seq_bases(G, n, 600 + logn, threads=64)
+    rng = np.random.default_rng(logn)
+    sc = O.rand_scalars(700 + logn, n)
+    kind = rng.integers(0, 8, n)
+    sc[kind <= 2] = 0                                           # 37.5 % zeros
+    sc[kind == 3] = 0; sc[kind == 3, 0] = 1                     # 12.5 % ones
+    m = (kind == 4) | (kind == 5); sc[m, 1:] = 0; sc[m, 0] &= np.uint64(0xFFFF)     # 25 % 16-bit
+    ones = np.zeros((n, 4), np.uint64); ones[:, 0] = 1
+    minus = np.tile(O.int_to_limbs(U.R - 1, 4), (n, 1))
+    plain = ca.DeviceBases(curve, bases); tab = ca.DeviceBases(curve, bases).precompute(20)
+    for s in (sc, ones, minus):
+        want = U.closed_form(G, s, k0, d)
+        assert U.jac_to_model(G, plain.msm_bigint(s)) == want
+        assert U.jac_to_model(G, tab.msm_bigint(s)) == want
+    plain.free(); tab.free()

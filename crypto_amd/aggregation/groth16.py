@@ -255,13 +255,36 @@ def final_verification_check(source1, source2, z_c, z_ab, r, public_inputs, vk, 
         raise AggregationError("Proof Verification Failed due to pairing checks")
 
 
-def verify_aggregate_proof(ip_verifier_srs, pvk, public_inputs, proof, random, transcript, pairing_check=None, with_d=False):
+def gt_elements(proof):
+    """every target-group element an aggregate proof carries (commitment outputs are pairs)"""
+    gipa = proof["tmipp"]["gipa"]
+    out = [proof["com_ab"].t, proof["com_ab"].u, proof["z_ab"]]
+    for key in ("com_c", "com_d"):
+        if key in proof:
+            out += [proof[key].t, proof[key].u]
+    for lr in gipa["comms_ab"]:
+        for o in lr:
+            out += [o.t, o.u]
+    for lr in gipa["z_ab"]:
+        out += list(lr)
+    for key in ("comms_c", "comms_d"):
+        for lr in gipa.get(key, []):
+            for o in lr:
+                out += [o.t, o.u]
+    return out
+
+
+def verify_aggregate_proof(ip_verifier_srs, pvk, public_inputs, proof, random, transcript, pairing_check=None, with_d=False, validate_gt=False):
     """groth16/verifier.rs:36-100; with_d: legogroth16/verifier.rs:34-96 (z_d joins the gamma pairing of the final check).
     public_inputs: one list of ints per proof; `random`: the checker's batching scalar (RandomizedPairingChecker::new_using_rng
-    draws it from `rng`).  Raises AggregationError on an invalid proof."""
+    draws it from `rng`).  Raises AggregationError on an invalid proof.  validate_gt: what `CanonicalDeserialize` with `Validate::Yes` does
+    for a proof that arrives as bytes — every GT element must lie in the order-r subgroup (f^r == 1; host arithmetic, ~1 ms per element,
+    2 + 6 log2(n) .. elements) — for proofs held in memory by an untrusted producer."""
     vk = pvk["vk"]
     names = ("c", "d") if with_d else ("c",)
     parsing_check(proof, names)
+    if validate_gt and not all(ops.parallel([(lambda f=f: ops.gt_in_subgroup(f)) for f in gt_elements(proof)], host=True)):
+        raise AggregationError("a target-group element of the proof is outside the order-r subgroup")
     if not public_inputs or any(len(pub) != len(public_inputs[0]) for pub in public_inputs):
         raise AggregationError("public inputs of unequal length")            # (aggregate_public_inputs indexes them as a rectangle)
     for pub in public_inputs:

@@ -99,6 +99,22 @@ def gt_bytes(f):
     return bytes(out)
 
 
+R_LIMBS = None
+
+
+def gt_in_subgroup(f):
+    """PairingOutput's `Valid::check` (ark-ec): the element has order dividing r, i.e. f^r == 1 (host arithmetic, ~1 ms per element)"""
+    global R_LIMBS
+    if R_LIMBS is None:
+        R_LIMBS = np.array([(R_MOD >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
+    a = np.ascontiguousarray(np.asarray(f, dtype=np.uint64).reshape(72))
+    out = np.zeros(72, dtype=np.uint64)
+    rc = lib().dgpu_fp12_pow(_p(a), _p(R_LIMBS), _p(out))          # the exponent is r itself, not reduced
+    if rc:
+        raise DockGpuError(rc, "dgpu_fp12_pow")
+    return bool((out == fp12_one()).all())
+
+
 def gt_multi_pow(bases, exps):
     """prod bases[i]^exps[i] in GT (host threads)"""
     n = len(bases)

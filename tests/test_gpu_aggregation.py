@@ -110,6 +110,16 @@ def test_aggregate_and_verify(n):
         assert False
     except AG.AggregationError:
         pass
+    # Validate::Yes for in-memory proofs: every GT element must have order dividing r.  An Fp12 element outside the subgroup (a Miller-loop
+    # output that never went through the final exponentiation) is refused before any pairing work; the honest proof passes.
+    AG.verify_aggregate_proof(vsrs, pvk, inputs, agg, 0x5EED1234567, AG.MerlinTranscript(b"test-aggregation"), validate_gt=True)
+    raw = O.multi_miller_loop(g1(3).reshape(1, 12), g2(5).reshape(1, 24))
+    bad = copy.deepcopy(agg); bad["tmipp"]["gipa"]["z_ab"][0] = (np.asarray(raw, dtype=np.uint64).reshape(72), bad["tmipp"]["gipa"]["z_ab"][0][1])
+    try:
+        AG.verify_aggregate_proof(vsrs, pvk, inputs, bad, 0x5EED1234567, AG.MerlinTranscript(b"test-aggregation"), validate_gt=True)
+        assert False
+    except AG.AggregationError as e:
+        assert "subgroup" in str(e)
     # one wrong proof inside the batch
     wrong = copy.deepcopy(proofs); wrong[1]["c"] = g1(777)
     agg_w = AG.aggregate_proofs(pk, AG.MerlinTranscript(b"test-aggregation"), wrong)

@@ -111,3 +111,21 @@ def test_dense_rows_do_not_outgrow_the_lazy_representation(logd, k, skew):
     ref = oracle_map(cs, mats)
     h, _ = qap.witness_map(*mats, z, n_inst, m)
     assert (h == ref).all()
+
+
+@pytest.mark.parametrize("logd", [9, 10, 11, 12, 13, 15, 17, 19])
+def test_every_pass_schedule_of_the_ntt(logd):
+    """One domain size per way the transform is cut into passes (per-stage kernels below 2^10, then one flat pass, flat + one strided pass
+    with an odd / even number of stages, flat + two strided passes): random sparse matrices (2 terms per row), same coset interpolation on
+    both sides."""
+    n_inst = 3
+    m = (1 << logd) - n_inst
+    nv = 700
+    rng = np.random.default_rng(100 + logd)
+    rp = (np.arange(m + 1, dtype=np.uint64) * np.uint64(2))
+    mats = [(rp, rng.integers(0, nv, 2 * m, dtype=np.uint32), O.rand_scalars(300 + 3 * logd + i, 2 * m)) for i in range(3)]
+    z = O.rand_scalars(55 + logd, nv)
+    cs = {"n_cons": m, "n_inst": n_inst, "z": [O.limbs_to_int(x) for x in z]}
+    ref = oracle_map(cs, mats)
+    h, _ = qap.witness_map(*mats, z, n_inst, m)
+    assert (h == ref).all()

@@ -69,6 +69,7 @@ struct G2P {
     static constexpr int XW = 8 * NL;        // words per full XYZZ point in the SoA arrays
     static constexpr int LPP = 2;
     static constexpr int ACC_WAVES = 2;
+    static constexpr int HEAVY_T = 256;      // 128 lane pairs per block in the heavy-bucket folds
 };
 
 template <class F> __device__ __forceinline__ uint32_t *limbs(F &f) { return reinterpret_cast<uint32_t *>(&f); }
@@ -138,6 +139,15 @@ template <> __device__ __forceinline__ void store_soa<G2P>(uint32_t *__restrict_
     for (int k = 0; k < 4; k++)
 #pragma unroll
         for (int j = 0; j < NL; j += 2) *reinterpret_cast<uint2 *>(t + (2 * k + h) * NL + j) = make_uint2(w[k * NL + j], w[k * NL + j + 1]);
+}
+template <> __device__ __forceinline__ void load_soa<G2P>(Xyzz<Fp2H> &p, const uint32_t *__restrict__ base, size_t /*count*/, size_t b) {
+    const uint32_t h = threadIdx.x & 1u;
+    uint32_t *w = reinterpret_cast<uint32_t *>(&p);
+    const uint32_t *t = base + b * G2P::XW;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+#pragma unroll
+        for (int j = 0; j < NL; j += 2) { const uint2 v = *reinterpret_cast<const uint2 *>(t + (2 * k + h) * NL + j); w[k * NL + j] = v.x; w[k * NL + j + 1] = v.y; }
 }
 template <> __device__ __forceinline__ void load_aff<G2P>(Aff<Fp2H> &p, const uint32_t *__restrict__ rec) {
     const uint32_t h = threadIdx.x & 1u;
@@ -237,21 +247,24 @@ __global__ void __launch_bounds__(256) k_fixup(uint32_t NB, uint32_t *__restrict
 // one long bucket ends and one starts inside a range); k_fixup_heavy_join folds a bucket's ranges.  Worst case ~2 x (HEAVY_RANGE / threads +
 // log2(threads)) dependent additions instead of pieces / threads.
 template <class C> __device__ __forceinline__ void block_tree_fold(Xyzz<typename C::F> &acc, bool &inf, size_t items, uint32_t *sh, uint8_t *shinf) {
+    // C::LPP lanes hold one point (G2P: the two halves of every Fp2 coordinate sit on a lane pair): the tree pairs up POINTS, so partner lanes
+    // are s2 * LPP threads apart and a pair always moves together
     typedef typename C::F F;
-    constexpr int BT = C::HEAVY_T;
-    for (int s2 = BT / 2; s2 >= 1; s2 >>= 1) {
-        if ((size_t)s2 >= items) continue;             // (uniform per block) threads s2 .. 2 s2 - 1 hold nothing yet
+    constexpr int BT = C::HEAVY_T, BI = BT / C::LPP, TW = (int)(sizeof(Xyzz<F>) / 4);
+    const int it = (int)threadIdx.x / C::LPP;
+    for (int s2 = BI / 2; s2 >= 1; s2 >>= 1) {
+        if ((size_t)s2 >= items) continue;             // (uniform per block) points s2 .. 2 s2 - 1 hold nothing yet
         __syncthreads();
-        if ((int)threadIdx.x >= s2 && (int)threadIdx.x < 2 * s2) {
+        if (it >= s2 && it < 2 * s2) {
             const uint32_t *w = reinterpret_cast<const uint32_t *>(&acc);
-            for (int k = 0; k < C::XW; k++) sh[k * BT + threadIdx.x] = w[k];
+            for (int k = 0; k < TW; k++) sh[k * BT + threadIdx.x] = w[k];
             shinf[threadIdx.x] = inf;
         }
         __syncthreads();
-        if ((int)threadIdx.x < s2) {
+        if (it < s2) {
             Xyzz<F> o; uint32_t *w = reinterpret_cast<uint32_t *>(&o);
-            for (int k = 0; k < C::XW; k++) w[k] = sh[k * BT + threadIdx.x + s2];
-            xyzz_add(acc, inf, o, shinf[threadIdx.x + s2] != 0);
+            for (int k = 0; k < TW; k++) w[k] = sh[k * BT + threadIdx.x + s2 * C::LPP];
+            xyzz_add(acc, inf, o, shinf[threadIdx.x + s2 * C::LPP] != 0);
         }
     }
     __syncthreads();
@@ -261,7 +274,7 @@ template <class C> __device__ __forceinline__ void fold_pieces(Xyzz<typename C::
                                                                const uint8_t *__restrict__ part_inf, size_t T, uint32_t *sh, uint8_t *shinf) {
     typedef typename C::F F;
     inf = true; fzero(acc.x); fzero(acc.y); fzero(acc.zz); fzero(acc.zzz);
-    for (size_t t = lo + threadIdx.x; t <= up; t += C::HEAVY_T) {
+    for (size_t t = lo + threadIdx.x / C::LPP; t <= up; t += C::HEAVY_T / C::LPP) {
         Xyzz<F> o; bool oinf;
         if (t == t0) { load_soa<C>(o, tail, T, t); oinf = part_inf[2 * t + 1] != 0; }
         else { load_soa<C>(o, head, T, t); oinf = part_inf[2 * t] != 0; }
@@ -276,7 +289,7 @@ __global__ void __launch_bounds__(C::HEAVY_T) k_fixup_heavy(const uint32_t *__re
     typedef typename C::F F;
     constexpr int BT = C::HEAVY_T;
     CH = dyn[DYN_CH]; T = dyn[DYN_T];
-    __shared__ uint32_t sh[C::XW * BT];
+    __shared__ uint32_t sh[(sizeof(Xyzz<typename C::F>) / 4) * BT];
     __shared__ uint8_t shinf[BT];
     uint32_t nh = heavy[0]; if (nh > heavy_cap) nh = heavy_cap;
     for (uint32_t hi = blockIdx.x; hi < nh; hi += gridDim.x) {
@@ -285,7 +298,7 @@ __global__ void __launch_bounds__(C::HEAVY_T) k_fixup_heavy(const uint32_t *__re
         if (t1 - t0 + 1 > HEAVY_RANGE) { if (threadIdx.x == 0) { const uint32_t m = atomicAdd(&dyn[DYN_NMULTI], 1u); dyn[DYN_MULTI + m] = b; } continue; }   // (at most T / HEAVY_RANGE of them)
         Xyzz<F> acc; bool inf;
         fold_pieces<C>(acc, inf, t0, t0, t1, head, tail, part_inf, T, sh, shinf);
-        if (threadIdx.x == 0) { store_soa<C>(bucket, NB, b, acc); bucket_inf[b] = inf; }
+        if (threadIdx.x < C::LPP) { store_soa<C>(bucket, NB, b, acc); if (threadIdx.x == 0) bucket_inf[b] = inf; }
     }
 }
 template <class C>
@@ -295,7 +308,7 @@ __global__ void __launch_bounds__(C::HEAVY_T) k_fixup_heavy_ranges(const uint32_
     constexpr int BT = C::HEAVY_T;
     const uint32_t CH = dyn[DYN_CH], nm = dyn[DYN_NMULTI];
     const size_t T = dyn[DYN_T];
-    __shared__ uint32_t sh[C::XW * BT];
+    __shared__ uint32_t sh[(sizeof(Xyzz<typename C::F>) / 4) * BT];
     __shared__ uint8_t shinf[BT];
     // ranges along x: consecutive workgroup ids go to different XCDs / CUs.  (With the buckets along x the few blocks that have work sat 32
     // ids apart and were all dispatched to the same eight CUs: 64 ranges took 8 rounds, 1.17 ms instead of 0.2.)
@@ -306,7 +319,7 @@ __global__ void __launch_bounds__(C::HEAVY_T) k_fixup_heavy_ranges(const uint32_
             const size_t lo = k * HEAVY_RANGE > t0 ? k * HEAVY_RANGE : t0, up = (k + 1) * HEAVY_RANGE - 1 < t1 ? (k + 1) * HEAVY_RANGE - 1 : t1;
             Xyzz<F> acc; bool inf;
             fold_pieces<C>(acc, inf, t0, lo, up, head, tail, part_inf, T, sh, shinf);
-            if (threadIdx.x == 0) { const size_t slot = 2 * k + (k == k0 ? 1 : 0); store_soa<C>(hpart, 0, slot, acc); hpart_inf[slot] = inf; }
+            if (threadIdx.x < C::LPP) { const size_t slot = 2 * k + (k == k0 ? 1 : 0); store_soa<C>(hpart, 0, slot, acc); if (threadIdx.x == 0) hpart_inf[slot] = inf; }
         }
     }
 }
@@ -316,20 +329,20 @@ __global__ void __launch_bounds__(C::HEAVY_T) k_fixup_heavy_join(const uint32_t 
     typedef typename C::F F;
     constexpr int BT = C::HEAVY_T;
     const uint32_t CH = dyn[DYN_CH], nm = dyn[DYN_NMULTI];
-    __shared__ uint32_t sh[C::XW * BT];
+    __shared__ uint32_t sh[(sizeof(Xyzz<typename C::F>) / 4) * BT];
     __shared__ uint8_t shinf[BT];
     for (uint32_t mi = blockIdx.x; mi < nm; mi += gridDim.x) {
         const uint32_t b = dyn[DYN_MULTI + mi];
         const size_t t0 = off[b] / CH, t1 = (off[b + 1] - 1) / CH, k0 = t0 / HEAVY_RANGE, k1 = t1 / HEAVY_RANGE;
         Xyzz<F> acc; bool inf = true;
         fzero(acc.x); fzero(acc.y); fzero(acc.zz); fzero(acc.zzz);
-        for (size_t k = k0 + threadIdx.x; k <= k1; k += BT) {
+        for (size_t k = k0 + threadIdx.x / C::LPP; k <= k1; k += BT / C::LPP) {
             const size_t slot = 2 * k + (k == k0 ? 1 : 0);
             Xyzz<F> o; load_soa<C>(o, hpart, 0, slot);
             xyzz_add(acc, inf, o, hpart_inf[slot] != 0);
         }
         block_tree_fold<C>(acc, inf, k1 - k0 + 1, sh, shinf);
-        if (threadIdx.x == 0) { store_soa<C>(bucket, NB, b, acc); bucket_inf[b] = inf; }
+        if (threadIdx.x < C::LPP) { store_soa<C>(bucket, NB, b, acc); if (threadIdx.x == 0) bucket_inf[b] = inf; }
     }
 }
 

@@ -218,7 +218,7 @@ def create_proof(pk, r, s, v, h, input_assignment_with_one, witness_assignment, 
         assignment, a0 = resident_z, 1
     n_aux, aux_at = len(wit) - cw, a0 + len(inp) - 1 + cw
     # the five large MSMs are independent (the reference runs each under rayon, one after the other): issue them from host
-    # threads so that the latency-bound tail of one overlaps the bulk of the next (the library keeps 4 calls in flight)
+    # threads so that the latency-bound tail of one overlaps the bulk of the next (the library keeps 6 calls in flight per device)
     # g_d = msm(gamma_abc[len(inputs) .. + cw], committed) + v (eta/gamma)    :361-368  (independent of the large MSMs: issued with them)
     src = vk.gamma_abc_g1[len(inp):len(inp) + cw]
     d_pts = np.concatenate([src, vk.eta_gamma_inv_g1.reshape(1, 12)])

@@ -1,15 +1,16 @@
-// crypto_amd/csrc/ntt_kernels.cuh — radix-2 NTT over Fr and the R1CS -> QAP witness map for gfx950.
+// crypto_amd/csrc/ntt_kernels.cuh — NTT over Fr (radix-4 passes through LDS) and the R1CS -> QAP witness map for gfx950.
 //
 // Device side of LibsnarkReduction::witness_map_from_matrices (/root/reference/legogroth16/src/r1cs_to_qap.rs:150-210,
 // ark-poly Radix2EvaluationDomain semantics):
 //     a_i = <A_i, z>, b_i = <B_i, z>, c_i = <C_i, z>   (i < m),   a_{m+j} = z_j (j < num_inputs)
 //     a, b, c <- iFFT_D ; coset FFT over g H (g = 7) ; ab_i = (a_i b_i - c_i) / (g^D - 1) ; h <- coset iFFT
-// The only HBM-bound piece of the prover.  Layout: limb-major SoA, word l of element i at buf[l * D + i], so
+// SURVEY 8f-1 expected this to be the one HBM-bound piece of the prover; measured, it is bound by instruction issue (see k_ntt_r4).  Layout: limb-major SoA, word l of element i at buf[l * D + i], so
 // every butterfly access is a coalesced row.  Bit reversal is never materialised: inverse transforms run
 // decimation-in-frequency (natural in, bit-reversed out), the coset shift g^k / D is applied at position p with k = bitrev(p),
 // forward transforms run decimation-in-time (bit-reversed in, natural out); the last pass un-reverses while it converts to the
 // canonical 4x64-bit scalars the MSM consumes.
-// v1: one global-memory pass per stage (2 x 40 B per element per stage); fusing 8-10 stages per pass through LDS is the next step.
+// Kernels: k_ntt_stage (one pass per stage: domains below 2^10), k_ntt_fused (staged passes: only for arrays beyond 4 GB, whose offsets do not fit
+// the buffer addressing of the main kernel), k_ntt_r4 (everything else).
 #pragma once
 #include <hip/hip_runtime.h>
 #include "fr29.cuh"

@@ -1,3 +1,5 @@
+"""Development helper (GPU box): ms per MSM with six calls in flight on one resident table, same scalars every call.  Used with temporary
+DGPU_X_SKIP_* switches (not in the product) to measure what each stage of a call costs in flight — results are in DESIGN.md §4."""
 import os, sys, time
 sys.path.insert(0, "/root/repo")
 from concurrent.futures import ThreadPoolExecutor

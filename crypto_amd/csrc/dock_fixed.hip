@@ -63,6 +63,12 @@ template <class C> int32_t table_mul(uint64_t table, const uint64_t *scalars, si
     CtxScope on_owner(ht.ctx);                           // the table's device
     if (n == 0 && !bases_handle) return DGPU_OK;
     void *keep = nullptr;
+    if (n == 0) {          // an empty query (a circuit whose witnesses are all committed has no l_query entries): an empty bases handle, no launch
+        HIPCHK(hipSetDevice(cur().device));
+        if (hipMalloc(&keep, (size_t)C::AFF_STRIDE * 4) != hipSuccess) { (void)hipGetLastError(); return DGPU_E_OOM; }
+        *bases_handle = register_handle(keep, 0, kind - 4);
+        return DGPU_OK;
+    }
     {
     SlotLock L; Slot &sl = *L.s;
     HIPCHK(hipSetDevice(cur().device));

@@ -106,3 +106,34 @@ def test_gpu_witness_map_on_reference_circuits():
         dr = qap.DeviceR1cs(*f.csr(), f.n_wires, f.num_inputs, f.n_constraints)
         h, _ = dr.witness_map(LS.scalars(w))
         assert (h == _oracle_map(f, w)).all(), name
+
+
+@pytest.mark.gpu
+def test_gpu_prove_and_verify_on_reference_circuits():
+    """legogroth16/src/circom/tests.rs (e.g. :206-258): parameters from the `.r1cs` file's matrices, a proof for a witness of the circuit,
+    verification against the circuit's public output, rejection of another output — multiply2, test1 and the 2499-constraint nconstraints."""
+    assert torch.cuda.is_available()
+    import crypto_amd as ca
+    from crypto_amd import legogroth16 as LG
+    ca.init(0)
+    rng = np.random.default_rng(77)
+    rnd = lambda: int.from_bytes(rng.bytes(40), "little") % (R - 1) + 1
+    g1 = lambda k: O.G1.to_affine(O.G1.mul(O.G1.generator(), O.int_to_limbs(k % R, 4)))[0]
+    g2 = lambda k: O.G2.to_affine(O.G2.mul(O.G2.generator(), O.int_to_limbs(k % R, 4)))[0]
+    for name, cw in (("multiply2.r1cs", 2), ("test1.r1cs", 1), ("nconstraints.r1cs", 1)):
+        f = fx(name)
+        w = {"multiply2.r1cs": lambda: witness_multiply2(rnd(), rnd()), "test1.r1cs": lambda: witness_test1(rnd()),
+             "nconstraints.r1cs": lambda: witness_nconstraints(f, rnd())}[name]()
+        assert f.is_satisfied(w)
+        n_inst, n_wit = f.num_inputs, f.n_wires - f.num_inputs
+        pk, _ = LG.generate_parameters(f.rows(0), f.rows(1), f.rows(2), n_inst, n_wit, cw, rnd(), rnd(), rnd(), rnd(), rnd(), rnd(), g1(rnd()), g2(rnd()))
+        circ = qap.DeviceR1cs(*f.csr(), f.n_wires, n_inst, f.n_constraints)
+        z = LS.scalars(w)
+        v = rnd()
+        proof = LG.create_proof_with_reduction(pk, circ, rnd(), rnd(), v, z)
+        pvk = LG.prepare_verifying_key(pk.vk)
+        assert LG.verify_proof(pvk, proof, z[1:n_inst]), name
+        bad = z[1:n_inst].copy(); bad[0][0] ^= np.uint64(1)
+        assert not LG.verify_proof(pvk, proof, bad), name
+        LG.verify_witness_commitment(pk.vk, proof, n_inst - 1, w[n_inst:n_inst + cw], v)
+        circ.free()

@@ -316,8 +316,8 @@ def verify_link_commitment(cp_link_bases, link_d, witnesses_expected_in_commitme
     bases = np.ascontiguousarray(cp_link_bases, dtype=np.uint64).reshape(-1, 12)
     if len(witnesses_expected_in_commitment) + 1 > len(bases):
         raise ValueError("VectorLongerThanExpected(%d, %d)" % (len(witnesses_expected_in_commitment) + 1, len(bases)))
-    sc = np.stack([_sc(x) for x in list(witnesses_expected_in_commitment) + [link_v]])
-    if not (np.asarray(link_d) == _affine(M.G1, M.msm_bigint(M.G1, bases, sc))).all():
+    k = len(witnesses_expected_in_commitment) + 1
+    if not (np.asarray(link_d) == _affine(M.G1, lincomb(M.G1, list(bases[:k]), list(witnesses_expected_in_commitment) + [link_v]))).all():
         raise ValueError("InvalidLinkCommitment")
 
 
@@ -434,6 +434,10 @@ def prepare_verifying_key(vk):
             "gamma_g2_neg_pc": neg_pc[0], "delta_g2_neg_pc": neg_pc[1]}
 
 
+def O_limbs_to_int(l):
+    return int(l[0]) | (int(l[1]) << 64) | (int(l[2]) << 128) | (int(l[3]) << 192)
+
+
 def calculate_d(pvk, proof, public_inputs):
     """verifier.rs:29-50,101-109: gamma_abc[0] + sum x_j gamma_abc[1+j] + proof.d"""
     vk = pvk["vk"]
@@ -442,6 +446,8 @@ def calculate_d(pvk, proof, public_inputs):
         raise ValueError("MalformedVerifyingKey")
     pts = np.concatenate([vk.gamma_abc_g1[:1 + len(pub)], proof["d"].reshape(1, 12)])
     sc = np.concatenate([_sc(1).reshape(1, 4), pub, _sc(1).reshape(1, 4)])
+    if len(pts) <= 16:                  # a handful of public inputs: host arithmetic (the reference: a short CPU msm), no device round trip
+        return _affine(M.G1, lincomb(M.G1, list(pts), [O_limbs_to_int(x) for x in sc]))
     return _affine(M.G1, M.msm_bigint(M.G1, pts, sc))
 
 

@@ -451,6 +451,37 @@ def calculate_d(pvk, proof, public_inputs):
     return _affine(M.G1, M.msm_bigint(M.G1, pts, sc))
 
 
+def calculate_d_batch(pvk, proofs, public_inputs):
+    """calculate_d for many proofs of one circuit: gamma_abc[0] + sum_j x_ij gamma_abc[1 + j] + proof_i.d for every i, as 1 + k batched
+    device calls (one same-base `mul_add` per public input) instead of one host scalar multiplication per proof and input.  (n, 12) affine."""
+    from .aggregation import ops
+    vk = pvk["vk"]
+    n = len(proofs)
+    pubs = [np.ascontiguousarray(x, dtype=np.uint64).reshape(-1, 4) for x in public_inputs]
+    k = len(pubs[0]) if n else 0
+    if any(len(x) != k for x in pubs):
+        raise ValueError("public inputs of unequal length")
+    if k + 1 > len(vk.gamma_abc_g1):
+        raise ValueError("MalformedVerifyingKey")
+    d = ops.mul_add(M.G1, np.tile(vk.gamma_abc_g1[0], (n, 1)), 1, np.stack([p["d"] for p in proofs]))
+    for j in range(k):
+        d = ops.mul_add(M.G1, np.tile(vk.gamma_abc_g1[1 + j], (n, 1)), [O_limbs_to_int(x[j]) for x in pubs], d)
+    return d
+
+
+def verify_proofs_batch(pvk, proofs, public_inputs, random):
+    """Many LegoGroth16 proofs of one circuit through ONE lazy RandomizedPairingChecker (what proof_system/src/verifier.rs:1829-1835 does with
+    the statements of a composite proof): three pairs per proof — (A_i, B_i), (C_i, -delta), (d_i, -gamma), the last two on the prepared
+    key — and the target e(alpha, beta) once per proof, all folded by the checker's powers of `random`.  True iff every proof verifies
+    (up to the checker's 2^-255 soundness error)."""
+    from .pairing_check import RandomizedPairingChecker
+    chk = RandomizedPairingChecker(random, True)
+    ds = calculate_d_batch(pvk, proofs, public_inputs)
+    for p, d in zip(proofs, ds):
+        chk.add_multiple_sources_and_target(np.stack([p["a"], p["c"], d]), [p["b"].reshape(1, 24), pvk["delta_g2_neg_pc"], pvk["gamma_g2_neg_pc"]], pvk["alpha_g1_beta_g2"])
+    return chk.verify()
+
+
 def verify_proof(pvk, proof, public_inputs):
     """verifier.rs:62-99: e(A, B) e(C, -delta) e(d, -gamma) == e(alpha, beta)"""
     d = calculate_d(pvk, proof, public_inputs)

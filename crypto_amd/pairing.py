@@ -35,8 +35,16 @@ class G2Prepared:
 
     def __getitem__(self, i):
         if isinstance(i, (int, np.integer)):
+            if not -len(self) <= i < len(self):
+                raise IndexError("G2Prepared index out of range")
+            i = int(i) % len(self)
             return G2Prepared(self.coeffs[i:i + 1], self.infinity[i:i + 1])
         return G2Prepared(self.coeffs[i], self.infinity[i])
+
+    def __array__(self, *args, **kwargs):
+        # numpy would otherwise walk the batch as a sequence of sequences of ... (an element of a batch is a batch): converting a list that
+        # mixes affine arrays and prepared batches must go through G2Prepared.concat, not through np.asarray
+        raise TypeError("G2Prepared is not an array: use G2Prepared.concat([...]) for mixed operand lists")
 
     @classmethod
     def from_affine(cls, qs, is_inf=None):
@@ -56,8 +64,15 @@ class G2Prepared:
     @classmethod
     def concat(cls, items):
         """items: G2Prepared batches and/or affine arrays — `impl Into<E::G2Prepared>` for each"""
-        parts = [it if isinstance(it, G2Prepared) else cls.from_affine(it) for it in items]
-        return cls(np.concatenate([p.coeffs for p in parts]), np.concatenate([p.infinity for p in parts]))
+        items = list(items)
+        aff = [i for i, it in enumerate(items) if not isinstance(it, G2Prepared)]
+        if aff:                             # every affine operand of the list in ONE dgpu_g2_prepare call (a batch verifier queues one per proof)
+            arrs = [np.ascontiguousarray(items[i], dtype=np.uint64).reshape(-1, 24) for i in aff]
+            prep = cls.from_affine(np.concatenate(arrs))
+            at = 0
+            for i, a in zip(aff, arrs):
+                items[i] = prep[at:at + len(a)]; at += len(a)
+        return cls(np.concatenate([p.coeffs for p in items]), np.concatenate([p.infinity for p in items]))
 
 
 def g2_prepare(qs, is_inf=None):

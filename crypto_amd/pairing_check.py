@@ -93,14 +93,29 @@ def g1_scale_each(points, scalar_limbs, negate=None):
 
 def _g2(b):
     """`impl Into<E::G2Prepared>`: an affine (n, 24) array stays affine (prepared inside the fused line kernel), a G2Prepared batch passes through"""
-    return b if isinstance(b, pairing.G2Prepared) else np.ascontiguousarray(b, dtype=np.uint64).reshape(-1, 24)
+    if isinstance(b, pairing.G2Prepared):
+        return b
+    if isinstance(b, (list, tuple)) and any(isinstance(x, pairing.G2Prepared) for x in b):
+        # a per-pair list of affine points and prepared values (verifier.rs:69-76 builds exactly that): kept as a list, the affine members of
+        # everything queued are prepared together in verify() / by the Miller loop
+        return _Mixed(x if isinstance(x, pairing.G2Prepared) else np.ascontiguousarray(x, dtype=np.uint64).reshape(-1, 24) for x in b)
+    return np.ascontiguousarray(b, dtype=np.uint64).reshape(-1, 24)
+
+
+class _Mixed(list):
+    """operands of one equation, some affine (n, 24) arrays, some G2Prepared batches; len() = number of pairs"""
+    def __len__(self):
+        return sum(len(x) for x in list.__iter__(self))
 
 
 def _g2_all(items):
     """the queued G2 operands as ONE operand of multi_miller_loop: a plain concatenation while nothing is prepared, else G2Prepared"""
-    if any(isinstance(b, pairing.G2Prepared) for b in items):
-        return pairing.G2Prepared.concat(items)
-    return np.concatenate(items)
+    flat = []
+    for b in items:
+        flat.extend(list.__iter__(b)) if isinstance(b, _Mixed) else flat.append(b)
+    if any(isinstance(b, pairing.G2Prepared) for b in flat):
+        return pairing.G2Prepared.concat(flat)
+    return np.concatenate(flat)
 
 
 class RandomizedPairingChecker:

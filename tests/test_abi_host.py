@@ -233,3 +233,18 @@ def test_glv_decomposition_on_host():
         assert L.dgpu_selftest_glv_decompose(a.ctypes.data_as(C.c_void_p), k1.ctypes.data_as(C.c_void_p), k2.ctypes.data_as(C.c_void_p)) == 0
         q, rem = divmod(k % U.R, lam)
         assert O.limbs_to_int(k1) == rem and O.limbs_to_int(k2) == q, hex(k)
+
+
+def test_prepared_batches_do_not_pose_as_arrays():
+    """A G2Prepared batch indexes to a G2Prepared batch; numpy used to walk such an object as an endless sequence of sequences when a mixed
+    operand list reached np.asarray (a batch verifier that passed [b, delta_pc, gamma_pc] per proof to the pairing checker never returned
+    and ate the host's memory).  Now: TypeError at once, IndexError past the end."""
+    from crypto_amd import pairing
+    g = pairing.G2Prepared(np.zeros((2, pairing.PREPARED_WORDS), np.uint64), np.zeros(2, np.uint8))
+    with pytest.raises(TypeError):
+        np.asarray([np.zeros((1, 24), np.uint64), g])
+    with pytest.raises(TypeError):
+        np.ascontiguousarray([np.zeros((1, 24), np.uint64), g, g], dtype=np.uint64)
+    with pytest.raises(IndexError):
+        g[2]
+    assert len(g[1]) == 1 and len(g[-1]) == 1 and len(g[0:2]) == 2

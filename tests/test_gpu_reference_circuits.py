@@ -173,3 +173,25 @@ def test_prove_and_verify_2():
         p3 = LG.rerandomize_proof_1(proof, v, new_v, vk, pk.eta_delta_inv_g1, _rnd(rng), _rnd(rng))
         assert LG.verify_proof(pvk, p3, pub)
         LG.verify_witness_commitment(vk, p3, 2, [a, b, c, d], new_v)
+
+
+def test_batch_verification_through_the_pairing_checker():
+    """verify_proofs_batch: many proofs of one circuit in one lazy RandomizedPairingChecker with the prepared verifying key's operands mixed in
+    (proof_system/src/verifier.rs:1829-1835 shape): accepts the honest batch, rejects a batch with one swapped element / one wrong public input;
+    calculate_d_batch equals calculate_d proof by proof."""
+    rng = np.random.default_rng(21)
+    pk, _ = _params(less_silly_1(1, 1, 1, 1), 2, rng, with_link=False)
+    pvk = LG.prepare_verifying_key(pk.vk)
+    proofs, pubs = [], []
+    for _ in range(24):
+        cs = less_silly_1(*(_rnd(rng) for _ in range(4)))
+        proof, z = _prove(pk, cs, _rnd(rng), _rnd(rng), _rnd(rng))
+        proofs.append(proof); pubs.append(z[1:3])
+    ds = LG.calculate_d_batch(pvk, proofs, pubs)
+    assert all((ds[i] == LG.calculate_d(pvk, proofs[i], pubs[i])).all() for i in range(len(proofs)))
+    assert LG.verify_proofs_batch(pvk, proofs, pubs, _rnd(rng))
+    bad = list(proofs); bad[7] = dict(bad[7]); bad[7]["c"] = proofs[8]["c"]
+    assert not LG.verify_proofs_batch(pvk, bad, pubs, _rnd(rng))
+    badp = list(pubs); badp[3] = pubs[4]
+    assert not LG.verify_proofs_batch(pvk, proofs, badp, _rnd(rng))
+    assert LG.verify_proofs_batch(pvk, proofs[:1], pubs[:1], _rnd(rng))

@@ -31,7 +31,7 @@ constexpr int F12W = 12 * NL;     // u32 per dense Fp12
 constexpr int MAX_SLICES = 64;
 
 // lines[(s * LW + k) * n + i]
-__global__ void __launch_bounds__(64) k_miller_lines(const uint32_t *__restrict__ p_abi, const uint32_t *__restrict__ q_abi, const uint8_t *__restrict__ skip, size_t n, uint32_t *__restrict__ lines) {
+__global__ void __launch_bounds__(64) k_miller_lines(const uint32_t *__restrict__ p_abi, const uint32_t *__restrict__ q_abi, const uint8_t *__restrict__ skip, size_t n, uint32_t *__restrict__ lines, size_t stride) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     bool sk = skip && skip[i];
@@ -42,7 +42,7 @@ __global__ void __launch_bounds__(64) k_miller_lines(const uint32_t *__restrict_
     if (sk) {
         Fp one; fp_set_one(one);
         for (int s = 0; s < N_LINES; s++)
-            for (int k = 0; k < LW; k++) lines[((size_t)s * LW + k) * n + i] = (k < NL) ? one.l[k] : 0u;
+            for (int k = 0; k < LW; k++) lines[((size_t)s * LW + k) * stride + i] = (k < NL) ? one.l[k] : 0u;
         return;
     }
     Fp px, py; fp_from_abi(px, pw); fp_from_abi(py, pw + 12);
@@ -51,11 +51,11 @@ __global__ void __launch_bounds__(64) k_miller_lines(const uint32_t *__restrict_
     int s = 0;
     for (int b = 62; b >= 0; b--) {
         Line l; line_dbl_step(R, l); line_eval(l, px, py);
-        { const uint32_t *w = reinterpret_cast<const uint32_t *>(&l); for (int k = 0; k < LW; k++) lines[((size_t)s * LW + k) * n + i] = w[k]; }
+        { const uint32_t *w = reinterpret_cast<const uint32_t *>(&l); for (int k = 0; k < LW; k++) lines[((size_t)s * LW + k) * stride + i] = w[k]; }
         s++;
         if ((BLS_X_ABS >> b) & 1) {
             line_add_step(R, Q, l); line_eval(l, px, py);
-            const uint32_t *w = reinterpret_cast<const uint32_t *>(&l); for (int k = 0; k < LW; k++) lines[((size_t)s * LW + k) * n + i] = w[k];
+            const uint32_t *w = reinterpret_cast<const uint32_t *>(&l); for (int k = 0; k < LW; k++) lines[((size_t)s * LW + k) * stride + i] = w[k];
             s++;
         }
     }
@@ -64,7 +64,7 @@ __global__ void __launch_bounds__(64) k_miller_lines(const uint32_t *__restrict_
 // Lane-pair version of k_miller_lines (fp2_pair.cuh): lanes 2i / 2i+1 hold the c0 / c1 halves of every Fp2 value of pair i,
 // cross terms move over DPP.  Half the registers per lane (no spills, 2 waves/SIMD) and 2 instead of 3 base-field products per
 // Fp2 product on the critical path of the 63 dependent doubling steps.
-__global__ void __launch_bounds__(64) k_miller_lines_pair(const uint32_t *__restrict__ p_abi, const uint32_t *__restrict__ q_abi, const uint8_t *__restrict__ skip, size_t n, uint32_t *__restrict__ lines) {
+__global__ void __launch_bounds__(64) k_miller_lines_pair(const uint32_t *__restrict__ p_abi, const uint32_t *__restrict__ q_abi, const uint8_t *__restrict__ skip, size_t n, uint32_t *__restrict__ lines, size_t stride) {
     size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 1;
     const uint32_t h = threadIdx.x & 1u;
     if (i >= n) return;
@@ -77,7 +77,7 @@ __global__ void __launch_bounds__(64) k_miller_lines_pair(const uint32_t *__rest
     if (!anyp || !anyq) sk = true;
     auto put = [&](int s, const LineT<Fp2H> &l) {
         const uint32_t *w = reinterpret_cast<const uint32_t *>(&l);          // c0, c1, c2 halves: 3 x 14 words
-        for (int c = 0; c < 3; c++) for (int j = 0; j < NL; j++) lines[((size_t)s * LW + (2 * c + h) * NL + j) * n + i] = w[c * NL + j];
+        for (int c = 0; c < 3; c++) for (int j = 0; j < NL; j++) lines[((size_t)s * LW + (2 * c + h) * NL + j) * stride + i] = w[c * NL + j];
     };
     if (sk) {
         LineT<Fp2H> one; fset_one(one.c0); fzero(one.c1); fzero(one.c2);
@@ -147,7 +147,7 @@ __device__ __forceinline__ void line_dbl_step_quad(G2ProjT<Fp2H> &R, LineT<Fp2H>
     l.c1 = res; l.c2 = res;
 }
 
-__global__ void __launch_bounds__(64) k_miller_lines_quad(const uint32_t *__restrict__ p_abi, const uint32_t *__restrict__ q_abi, const uint8_t *__restrict__ skip, size_t n, uint32_t *__restrict__ lines) {
+__global__ void __launch_bounds__(64) k_miller_lines_quad(const uint32_t *__restrict__ p_abi, const uint32_t *__restrict__ q_abi, const uint8_t *__restrict__ skip, size_t n, uint32_t *__restrict__ lines, size_t stride) {
     size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
     const uint32_t h = threadIdx.x & 1u;
     const bool B = quad_hi();
@@ -161,7 +161,7 @@ __global__ void __launch_bounds__(64) k_miller_lines_quad(const uint32_t *__rest
     if (!anyp || !anyq) sk = true;
     // pair A stores c0 and c1, pair B stores c2 (each lane its own half)
     auto put = [&](int s, const LineT<Fp2H> &l) {
-        auto st = [&](int c, const Fp2H &x) { for (int j = 0; j < NL; j++) lines[((size_t)s * LW + (2 * c + h) * NL + j) * n + i] = x.v.l[j]; };
+        auto st = [&](int c, const Fp2H &x) { for (int j = 0; j < NL; j++) lines[((size_t)s * LW + (2 * c + h) * NL + j) * stride + i] = x.v.l[j]; };
         if (!B) { st(0, l.c0); st(1, l.c1); } else st(2, l.c2);
     };
     if (sk) {
@@ -213,7 +213,7 @@ __global__ void __launch_bounds__(64) k_g2_prepare(const uint32_t *__restrict__ 
     }
 }
 // thread (s, i), i fastest: ark-ec `ell` (c1 *= px, c2 *= py) on coefficient triple s of pair i, written in K10's layout
-__global__ void __launch_bounds__(256) k_lines_from_prepared(const uint32_t *__restrict__ p_abi, const uint32_t *__restrict__ coeffs, const uint8_t *__restrict__ skip, size_t n, uint32_t *__restrict__ lines) {
+__global__ void __launch_bounds__(256) k_lines_from_prepared(const uint32_t *__restrict__ p_abi, const uint32_t *__restrict__ coeffs, const uint8_t *__restrict__ skip, size_t n, uint32_t *__restrict__ lines, size_t stride) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n * N_LINES) return;
     const size_t s = t / n, i = t % n;
@@ -226,14 +226,14 @@ __global__ void __launch_bounds__(256) k_lines_from_prepared(const uint32_t *__r
     for (int k = 0; k < CW; k += 4) { uint4 v = *reinterpret_cast<const uint4 *>(coeffs + i * (size_t)(N_LINES * CW) + k); any0 |= v.x | v.y | v.z | v.w; }
     (void)anyc;
     const bool sk = (skip && skip[i]) || !anyp || !any0;
-    uint32_t *dst = lines + (s * LW) * n + i;
-    if (sk) { Fp one; fp_set_one(one); for (int k = 0; k < LW; k++) dst[(size_t)k * n] = (k < NL) ? one.l[k] : 0u; return; }
+    uint32_t *dst = lines + (s * LW) * stride + i;
+    if (sk) { Fp one; fp_set_one(one); for (int k = 0; k < LW; k++) dst[(size_t)k * stride] = (k < NL) ? one.l[k] : 0u; return; }
     Fp px, py; fp_from_abi(px, pw); fp_from_abi(py, pw + 12);
 #pragma unroll
     for (int c = 0; c < 6; c++) {
         Fp f; fp_from_abi(f, cw + 12 * c);
         if (c >= 2) { Fp m; fp_mul(m, f, c < 4 ? px : py); f = m; }
-        for (int k = 0; k < NL; k++) dst[(size_t)(c * NL + k) * n] = f.l[k];
+        for (int k = 0; k < NL; k++) dst[(size_t)(c * NL + k) * stride] = f.l[k];
     }
 }
 
@@ -387,10 +387,10 @@ int32_t dgpu_multi_miller_loop(const uint64_t *p, const uint64_t *q, const uint8
 #else
       constexpr bool one_lane = false, two_lanes = false;
 #endif
-      if (one_lane) hipLaunchKernelGGL(k_miller_lines, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, sl.in_bases.as<uint32_t>(), sl.in_scalars.as<uint32_t>(), dskip, n, sl.ml_lines.as<uint32_t>());
+      if (one_lane) hipLaunchKernelGGL(k_miller_lines, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, sl.in_bases.as<uint32_t>(), sl.in_scalars.as<uint32_t>(), dskip, n, sl.ml_lines.as<uint32_t>(), n);
       else if (two_lanes || n > 8192) hipLaunchKernelGGL(k_miller_lines_pair,     // (with the chip full, the pair form does less total work)
-              dim3((unsigned)((2 * n + 63) / 64)), dim3(64), 0, s, sl.in_bases.as<uint32_t>(), sl.in_scalars.as<uint32_t>(), dskip, n, sl.ml_lines.as<uint32_t>());
-      else hipLaunchKernelGGL(k_miller_lines_quad, dim3((unsigned)((4 * n + 63) / 64)), dim3(64), 0, s, sl.in_bases.as<uint32_t>(), sl.in_scalars.as<uint32_t>(), dskip, n, sl.ml_lines.as<uint32_t>());
+              dim3((unsigned)((2 * n + 63) / 64)), dim3(64), 0, s, sl.in_bases.as<uint32_t>(), sl.in_scalars.as<uint32_t>(), dskip, n, sl.ml_lines.as<uint32_t>(), n);
+      else hipLaunchKernelGGL(k_miller_lines_quad, dim3((unsigned)((4 * n + 63) / 64)), dim3(64), 0, s, sl.in_bases.as<uint32_t>(), sl.in_scalars.as<uint32_t>(), dskip, n, sl.ml_lines.as<uint32_t>(), n);
     }
     return ml_finish(sl, n, out);
 }
@@ -468,7 +468,54 @@ int32_t dgpu_multi_miller_loop_prepared(const uint64_t *p, const uint64_t *coeff
     const uint8_t *dskip = nullptr;
     if (skip) { HIPCHK(hipMemcpyAsync(sl.in_inf.p, skip, n, hipMemcpyHostToDevice, s)); dskip = sl.in_inf.as<uint8_t>(); }
     { StageTimer st(sl, "ml.lines_prepared");
-      hipLaunchKernelGGL(k_lines_from_prepared, dim3((unsigned)((n * N_LINES + 255) / 256)), dim3(256), 0, s, sl.in_bases.as<uint32_t>(), sl.ml_coeffs.as<uint32_t>(), dskip, n, sl.ml_lines.as<uint32_t>()); }
+      hipLaunchKernelGGL(k_lines_from_prepared, dim3((unsigned)((n * N_LINES + 255) / 256)), dim3(256), 0, s, sl.in_bases.as<uint32_t>(), sl.ml_coeffs.as<uint32_t>(), dskip, n, sl.ml_lines.as<uint32_t>(), n); }
+    return ml_finish(sl, n, out);
+}
+
+// Affine and prepared G2 operands in ONE Miller loop: the line kernels of both forms fill one line buffer (the affine pairs first), the
+// products / tree / host part run once.  This is what a verifier holds: proof.b affine, the key's -delta and -gamma prepared
+// (legogroth16/src/verifier.rs:69-76: `[proof.b.into(), pvk.delta_g2_neg_pc.clone(), pvk.gamma_g2_neg_pc.clone()]`).  Preparing the affine
+// members first costs a call of its own plus 19.5 KB per point down and up again.
+int32_t dgpu_multi_miller_loop_mixed(const uint64_t *p_aff, const uint64_t *q_aff, const uint8_t *skip_aff, size_t n_aff,
+                                     const uint64_t *p_prep, const uint64_t *coeffs, const uint8_t *skip_prep, size_t n_prep, uint64_t *out) {
+    if (!out || (n_aff && (!p_aff || !q_aff)) || (n_prep && (!p_prep || !coeffs))) return DGPU_E_BADARG;
+    const size_t n = n_aff + n_prep;
+    if (n == 0) { hostf::Fq12 one = hostf::Fq12::one(); memcpy(out, &one, sizeof one); return DGPU_OK; }
+    if (n_prep > DGPU_MAX_PREPARED || n >= (1ull << 24)) return DGPU_E_BADARG;
+    if (!cur().ready) return DGPU_E_NODEVICE;
+    SlotLock slot_lock; Slot &sl = *slot_lock.s;
+    HIPCHK(hipSetDevice(cur().device));
+    int32_t rc;
+    const size_t cbytes = n_prep * (size_t)DGPU_G2_PREPARED_WORDS * 8;
+    if ((rc = sl.in_bases.ensure(n * 96))) return rc;                 // P of the affine pairs, then P of the prepared pairs
+    if ((rc = sl.in_scalars.ensure(n_aff * 192 + 16))) return rc;
+    if ((rc = sl.in_inf.ensure(n))) return rc;
+    if ((rc = sl.ml_coeffs.ensure(cbytes + 16))) return rc;
+    if ((rc = sl.ml_lines.ensure((size_t)N_LINES * LW * n * 4))) return rc;
+    hipStream_t s = sl.stream;
+    uint32_t *dp = sl.in_bases.as<uint32_t>();
+    uint8_t *dsk = sl.in_inf.as<uint8_t>();
+    if (n_aff) {
+        HIPCHK(hipMemcpyAsync(dp, p_aff, n_aff * 96, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(sl.in_scalars.p, q_aff, n_aff * 192, hipMemcpyHostToDevice, s));
+        if (skip_aff) HIPCHK(hipMemcpyAsync(dsk, skip_aff, n_aff, hipMemcpyHostToDevice, s));
+    }
+    if (n_prep) {
+        HIPCHK(hipMemcpyAsync(dp + n_aff * 24, p_prep, n_prep * 96, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(sl.ml_coeffs.p, coeffs, cbytes, hipMemcpyHostToDevice, s));
+        if (skip_prep) HIPCHK(hipMemcpyAsync(dsk + n_aff, skip_prep, n_prep, hipMemcpyHostToDevice, s));
+    }
+    { StageTimer st(sl, "ml.lines");
+      uint32_t *lines = sl.ml_lines.as<uint32_t>();
+      if (n_aff) {
+          const uint8_t *sk = skip_aff ? dsk : nullptr;
+          if (n_aff > 8192) hipLaunchKernelGGL(k_miller_lines_pair, dim3((unsigned)((2 * n_aff + 63) / 64)), dim3(64), 0, s, dp, sl.in_scalars.as<uint32_t>(), sk, n_aff, lines, n);
+          else hipLaunchKernelGGL(k_miller_lines_quad, dim3((unsigned)((4 * n_aff + 63) / 64)), dim3(64), 0, s, dp, sl.in_scalars.as<uint32_t>(), sk, n_aff, lines, n);
+      }
+      if (n_prep)
+          hipLaunchKernelGGL(k_lines_from_prepared, dim3((unsigned)((n_prep * N_LINES + 255) / 256)), dim3(256), 0, s, dp + n_aff * 24, sl.ml_coeffs.as<uint32_t>(),
+                             skip_prep ? dsk + n_aff : (const uint8_t *)nullptr, n_prep, lines + n_aff, n);
+    }
     return ml_finish(sl, n, out);
 }
 

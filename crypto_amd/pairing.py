@@ -79,10 +79,39 @@ def g2_prepare(qs, is_inf=None):
     return G2Prepared.from_affine(qs, is_inf)
 
 
+def _mixed_miller_loop(ps, items, skip):
+    items = [q if isinstance(q, G2Prepared) else np.ascontiguousarray(q, dtype=np.uint64).reshape(-1, 24) for q in items]
+    if len(ps) != sum(len(q) for q in items):
+        raise DockGpuError(-7, "multi_miller_loop")
+    sk = None if skip is None else np.ascontiguousarray(skip, dtype=np.uint8)
+    pa, qa, ska, pp, cp, skp = [], [], [], [], [], []
+    at = 0
+    for q in items:
+        k = len(q)
+        if isinstance(q, G2Prepared):
+            pp.append(ps[at:at + k]); cp.append(q.coeffs); skp.append(q.infinity if sk is None else (sk[at:at + k] | q.infinity))
+        else:
+            pa.append(ps[at:at + k]); qa.append(q); ska.append(np.zeros(k, np.uint8) if sk is None else sk[at:at + k])
+        at += k
+    cat = lambda xs, w, dt=np.uint64: np.ascontiguousarray(np.concatenate(xs)) if xs else np.zeros((0, w), dt)
+    pa, qa, pp, cp = cat(pa, 12), cat(qa, 24), cat(pp, 12), cat(cp, PREPARED_WORDS)
+    ska = np.ascontiguousarray(np.concatenate(ska)) if ska else np.zeros(0, np.uint8)
+    skp = np.ascontiguousarray(np.concatenate(skp)) if skp else np.zeros(0, np.uint8)
+    out = np.zeros(72, dtype=np.uint64)
+    rc = lib().dgpu_multi_miller_loop_mixed(_p(pa), _p(qa), _p(ska), len(pa), _p(pp), _p(cp), _p(skp), len(pp), _p(out))
+    if rc:
+        raise DockGpuError(rc, "dgpu_multi_miller_loop_mixed")
+    return out
+
+
 def multi_miller_loop(ps, qs, skip=None):
     _ensure()
     ps = np.ascontiguousarray(ps, dtype=np.uint64).reshape(-1, 12)
     if isinstance(qs, (list, tuple)) and any(isinstance(q, G2Prepared) for q in qs):
+        # `impl Into<G2Prepared>` operands of both kinds: the affine ones and the prepared ones go to the device as they are, in one call
+        # (dgpu_multi_miller_loop_mixed: the product does not depend on the order of the pairs)
+        if not all(isinstance(q, G2Prepared) for q in qs):
+            return _mixed_miller_loop(ps, list(qs), skip)
         qs = G2Prepared.concat(qs)
     if isinstance(qs, G2Prepared):
         if len(ps) != len(qs):

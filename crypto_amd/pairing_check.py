@@ -114,7 +114,7 @@ def _g2_all(items):
     for b in items:
         flat.extend(list.__iter__(b)) if isinstance(b, _Mixed) else flat.append(b)
     if any(isinstance(b, pairing.G2Prepared) for b in flat):
-        return pairing.G2Prepared.concat(flat)
+        return flat                                   # a mixed list: multi_miller_loop sends both kinds to the device in one call
     return np.concatenate(flat)
 
 

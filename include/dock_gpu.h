@@ -158,6 +158,13 @@ int32_t dgpu_g2_prepare(const uint64_t *q_xy /* n*24 */, const uint8_t *is_inf /
                         uint64_t *out_coeffs /* n*DGPU_G2_PREPARED_WORDS */, uint8_t *out_inf /* n */);
 int32_t dgpu_multi_miller_loop_prepared(const uint64_t *p_xy /* n*12 */, const uint64_t *coeffs /* n*DGPU_G2_PREPARED_WORDS */,
                                         const uint8_t *skip /* n or NULL */, size_t n, uint64_t out_f12[72]);
+/* The same product over n_aff pairs with affine Q and n_prep pairs with prepared Q in ONE call (no separate dgpu_g2_prepare, no coefficient
+ * round trip for the affine members): what legogroth16/src/verifier.rs:69-76 passes to multi_miller_loop — `[proof.b.into(),
+ * pvk.delta_g2_neg_pc.clone(), pvk.gamma_g2_neg_pc.clone()]` — and what a RandomizedPairingChecker's `pending` holds when some operands
+ * came in prepared (utils/src/randomized_pairing_check.rs:119-138).  The product does not depend on the order of the pairs. */
+int32_t dgpu_multi_miller_loop_mixed(const uint64_t *p_aff /* n_aff x 12 */, const uint64_t *q_aff /* n_aff x 24 */, const uint8_t *skip_aff, size_t n_aff,
+                                     const uint64_t *p_prep /* n_prep x 12 */, const uint64_t *coeffs /* n_prep x DGPU_G2_PREPARED_WORDS */, const uint8_t *skip_prep, size_t n_prep,
+                                     uint64_t out_f12[72]);
 /* the same with the pairs chunked over the process's device contexts (ngpus = 0: all of them), raw outputs multiplied on the host */
 int32_t dgpu_multi_miller_loop_sharded(const uint64_t *p_xy, const uint64_t *q_xy, const uint8_t *skip, size_t n, int32_t ngpus, uint64_t out_f12[72]);
 /* replaces Bls12_381::final_exponentiation — utils/src/randomized_pairing_check.rs:213 (host code, once per batch) */

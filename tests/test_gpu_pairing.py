@@ -134,3 +134,33 @@ def test_prepared_equals_unprepared_raw_output(n):
         assert (pairing.multi_miller_loop(ps, [qs[:1], pc[1], pc[2]]) == ref).all()
     with pytest.raises(ca.DockGpuError):
         pairing.multi_miller_loop(ps, pc[:n - 1] if n > 1 else pairing.G2Prepared(np.zeros((0, 68 * 36), np.uint64), np.zeros(0, np.uint8)))
+
+
+@pytest.mark.parametrize("n", [2, 7, 300, 9000])
+def test_mixed_affine_and_prepared_operands_in_one_call(n):
+    """dgpu_multi_miller_loop_mixed: any split of the pairs into affine and prepared operands gives the raw Fp12 output of the unprepared loop
+    limb for limb (the product does not depend on the order of the pairs), identity members and skip flags on both sides, empty sides, and
+    argument checks."""
+    from crypto_amd import pairing
+    k0 = O.rand_scalars(61, 1)[0]; d = O.rand_scalars(62, 1)[0]
+    ps = O.G1.gen_seq(k0, d, n, threads=16); qs = O.G2.gen_seq(d, k0, n, threads=16)
+    if n >= 7:
+        ps[1] = 0; qs[5] = 0                         # identity members: one in each half of the later splits
+    ref = ca.multi_miller_loop(ps, qs)
+    if n <= 300:
+        assert (ref == O.multi_miller_loop(ps, qs, np.array([0 if (p.any() and q.any()) else 1 for p, q in zip(ps, qs)], np.uint8), threads=16)).all()
+    pc = pairing.G2Prepared.from_affine(qs)
+    for cut in sorted({0, 1, n // 3, n - 1, n}):
+        # first `cut` pairs affine, the rest prepared; and the other way round
+        assert (pairing.multi_miller_loop(ps, [qs[:cut], pc[cut:]] if 0 < cut < n else ([pc] if cut == 0 else [qs])) == ref).all(), cut
+        if 0 < cut < n:
+            assert (pairing.multi_miller_loop(ps, [pc[:cut], qs[cut:]]) == ref).all(), cut
+    # interleaved, the batch verifier's shape: affine, prepared, prepared, affine, ...
+    if n >= 7:
+        items = [qs[0:1], pc[1:3], qs[3:4], pc[4:6], qs[6:]]
+        assert (pairing.multi_miller_loop(ps, items) == ref).all()
+        skip = np.zeros(n, np.uint8); skip[0] = 1; skip[2] = 1
+        sk_ref = ca.multi_miller_loop(ps, qs, skip)
+        assert (pairing.multi_miller_loop(ps, items, skip) == sk_ref).all() and not (sk_ref == ref).all()
+    with pytest.raises(ca.DockGpuError):
+        pairing.multi_miller_loop(ps, [qs[:1], pc[2:]])                     # one operand short

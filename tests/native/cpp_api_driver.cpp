@@ -78,6 +78,30 @@ int main() {
     bool threw = false; try { a.pop_back(); multi_miller_loop(a, b); } catch (const Error &e) { threw = e.code == DGPU_E_LENGTH; }
     EXPECT(threw);
     EXPECT(!final_exponentiation(Fq12{}).has_value());                    // zero -> None
+    // prepared and mixed operands straight through the C ABI (verifier.rs:69-76 shape), the host lincomb, and the per-key table
+    {
+        a = std::vector<G1::Affine>(P1.begin() + 10, P1.begin() + 10 + np);
+        std::vector<uint64_t> co(np * DGPU_G2_PREPARED_WORDS); std::vector<uint8_t> cinf(np);
+        EXPECT(dgpu_g2_prepare(b2.data() + 240, nullptr, np, co.data(), cinf.data()) == DGPU_OK);
+        Fq12 f1{}, f2{};
+        EXPECT(dgpu_multi_miller_loop_prepared(b1.data() + 120, co.data(), cinf.data(), np, f1.data()) == DGPU_OK && f1 == eml);
+        const size_t na = 5;                  // first five pairs affine, the rest prepared
+        EXPECT(dgpu_multi_miller_loop_mixed(b1.data() + 120, b2.data() + 240, nullptr, na, b1.data() + 120 + 12 * na, co.data() + na * DGPU_G2_PREPARED_WORDS, cinf.data() + na, np - na, f2.data()) == DGPU_OK && f2 == eml);
+        EXPECT(dgpu_multi_miller_loop_mixed(nullptr, nullptr, nullptr, 0, b1.data() + 120, co.data(), cinf.data(), np, f2.data()) == DGPU_OK && f2 == eml);
+        EXPECT(dgpu_multi_miller_loop_mixed(b1.data() + 120, b2.data() + 240, nullptr, np, nullptr, nullptr, nullptr, 0, f2.data()) == DGPU_OK && f2 == eml);
+        EXPECT(dgpu_multi_miller_loop_mixed(nullptr, nullptr, nullptr, 3, nullptr, nullptr, nullptr, 0, f2.data()) == DGPU_E_BADARG);
+        uint64_t lc[18], el[18];
+        EXPECT(dgpu_lincomb_g1(b1.data(), inf1.data(), sc.data(), 9, lc) == DGPU_OK);
+        orc_g1_msm(b1.data(), inf1.data(), sc.data(), 9, 1, el);
+        { uint64_t x[12], y[12]; int i1 = orc_g1_to_affine(lc, x), i2 = orc_g1_to_affine(el, y); EXPECT(i1 == i2 && std::memcmp(x, y, sizeof x) == 0); }
+        EXPECT(dgpu_lincomb_g1(b1.data(), nullptr, sc.data(), DGPU_MAX_LINCOMB + 1, lc) == DGPU_E_BADARG);
+        uint64_t h = 0, plain[18], tab[18];
+        EXPECT(dgpu_bases_upload_g1(b1.data(), inf1.data(), n, &h) == DGPU_OK);
+        EXPECT(dgpu_msm_g1_handle(h, 0, sc.data(), n, 0, plain) == DGPU_OK);
+        EXPECT(dgpu_bases_precompute_g1(h, 16) == DGPU_OK);
+        EXPECT(dgpu_msm_g1_handle(h, 0, sc.data(), n, 0, tab) == DGPU_OK && std::memcmp(plain, tab, sizeof plain) == 0);
+        EXPECT(dgpu_bases_free(h) == DGPU_OK);
+    }
     // several device contexts in this one process (a Rust host is one process): two contexts on the box's one GPU, every MSM chunked
     // over them inside the library (dgpu_msm_*_sharded*), same point as the single-context call
     init_devices({0, 0});

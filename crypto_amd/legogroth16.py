@@ -482,6 +482,43 @@ def verify_proofs_batch(pvk, proofs, public_inputs, random):
     return chk.verify()
 
 
+def verify_proofs_batch_merged(pvk, proofs, public_inputs, random):
+    """The same batch check with the pairs that share a G2 operand merged BEFORE the pairing (the classical Groth16 batch verifier; the
+    reference's checker keeps all 3 N pairs): with m_i = random^i,
+        prod_i e(m_i A_i, B_i) * e(sum_i m_i C_i, -delta) * e(sum_i m_i (gamma_abc_0 + sum_j x_ij gamma_abc_j + d_i), -gamma) == e(alpha, beta)^(sum m_i)
+    i.e. N scalings, two variable-base MSMs of N (+ k + 1) terms — the hot path of this library — and ONE Miller loop over N + 2 pairs, two of
+    them on the prepared key.  Accepts exactly what verify_proofs_batch accepts (up to the 2^-255 soundness error of the random combination)."""
+    from .pairing_check import g1_scale_each, fp12_pow
+    vk = pvk["vk"]
+    n = len(proofs)
+    if n == 0:
+        return True
+    pubs = [np.ascontiguousarray(x, dtype=np.uint64).reshape(-1, 4) for x in public_inputs]
+    k = len(pubs[0])
+    if len(pubs) != n or any(len(x) != k for x in pubs):
+        raise ValueError("public inputs of unequal length")
+    if k + 1 > len(vk.gamma_abc_g1):
+        raise ValueError("MalformedVerifyingKey")
+    rnd = random % R_MOD
+    ms, m = [], 1
+    for _ in range(n):
+        ms.append(m); m = m * rnd % R_MOD
+    m_limbs = np.stack([_sc(x) for x in ms])
+    a_scaled, a_inf = g1_scale_each(np.stack([p["a"] for p in proofs]), m_limbs, None)
+    c_sum = _affine(M.G1, M.msm_bigint(M.G1, np.stack([p["c"] for p in proofs]), m_limbs))
+    xs = [[O_limbs_to_int(x[j]) for x in pubs] for j in range(k)]
+    d_pts = np.concatenate([vk.gamma_abc_g1[:1 + k], np.stack([p["d"] for p in proofs])])
+    d_sc = np.stack([_sc(sum(ms))] + [_sc(sum(mi * xi for mi, xi in zip(ms, col))) for col in xs] + [m_limbs[i] for i in range(n)])
+    d_sum = _affine(M.G1, M.msm_bigint(M.G1, d_pts, d_sc))
+    ps = np.concatenate([a_scaled, c_sum.reshape(1, 12), d_sum.reshape(1, 12)])
+    qs = [np.stack([p["b"] for p in proofs]), pvk["delta_g2_neg_pc"], pvk["gamma_g2_neg_pc"]]
+    skip = np.concatenate([np.asarray(a_inf, dtype=np.uint8), np.zeros(2, np.uint8)])
+    gt = pairing.final_exponentiation(pairing.multi_miller_loop(ps, qs, skip))
+    if gt is None:
+        raise ValueError("UnexpectedIdentity")
+    return bool((gt == fp12_pow(pvk["alpha_g1_beta_g2"], sum(ms))).all())
+
+
 def verify_proof(pvk, proof, public_inputs):
     """verifier.rs:62-99: e(A, B) e(C, -delta) e(d, -gamma) == e(alpha, beta)"""
     d = calculate_d(pvk, proof, public_inputs)

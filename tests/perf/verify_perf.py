@@ -43,4 +43,9 @@ for _ in range(5):
     t0 = time.perf_counter(); ok = batch_verify(proofs, pubs); ts.append(time.perf_counter() - t0); assert ok
 t = sorted(ts)[2]
 t1 = time.perf_counter(); single = all(LG.verify_proof(pvk, p, x) for p, x in zip(proofs[:64], pubs[:64])); t1 = (time.perf_counter() - t1) / 64
+tm = []
+assert LG.verify_proofs_batch_merged(pvk, proofs, pubs, rnd()) and not LG.verify_proofs_batch_merged(pvk, bad, pubs, rnd())
+for _ in range(5):
+    t0 = time.perf_counter(); ok = LG.verify_proofs_batch_merged(pvk, proofs, pubs, rnd()); tm.append(time.perf_counter() - t0); assert ok
+print("merged batch check of %d proofs (N + 2 pairs, two MSMs): %.1f ms = %.0f proofs/s" % (N, sorted(tm)[2] * 1e3, N / sorted(tm)[2]))
 print("batch of %d proofs: %.1f ms = %.0f proofs/s = %.0f pairs/s; one at a time: %.2f ms per proof (%s)" % (N, t * 1e3, N / t, 3 * N / t, t1 * 1e3, single))

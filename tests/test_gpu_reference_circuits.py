@@ -195,3 +195,24 @@ def test_batch_verification_through_the_pairing_checker():
     badp = list(pubs); badp[3] = pubs[4]
     assert not LG.verify_proofs_batch(pvk, proofs, badp, _rnd(rng))
     assert LG.verify_proofs_batch(pvk, proofs[:1], pubs[:1], _rnd(rng))
+
+
+def test_merged_batch_verification_equals_the_checker():
+    """verify_proofs_batch_merged (N + 2 pairs, two MSMs) accepts and rejects exactly like the 3 N-pair checker form"""
+    rng = np.random.default_rng(22)
+    pk, _ = _params(less_silly_1(1, 1, 1, 1), 2, rng, with_link=False)
+    pvk = LG.prepare_verifying_key(pk.vk)
+    proofs, pubs = [], []
+    for _ in range(40):
+        cs = less_silly_1(*(_rnd(rng) for _ in range(4)))
+        proof, z = _prove(pk, cs, _rnd(rng), _rnd(rng), _rnd(rng))
+        proofs.append(proof); pubs.append(z[1:3])
+    assert LG.verify_proofs_batch_merged(pvk, proofs, pubs, _rnd(rng)) and LG.verify_proofs_batch(pvk, proofs, pubs, _rnd(rng))
+    assert LG.verify_proofs_batch_merged(pvk, proofs[:1], pubs[:1], _rnd(rng)) and LG.verify_proofs_batch_merged(pvk, [], [], 5)
+    for field in ("a", "b", "c", "d"):
+        bad = list(proofs); bad[11] = dict(bad[11]); bad[11][field] = proofs[12][field]
+        assert not LG.verify_proofs_batch_merged(pvk, bad, pubs, _rnd(rng)), field
+    badp = list(pubs); badp[30] = pubs[31]
+    assert not LG.verify_proofs_batch_merged(pvk, proofs, badp, _rnd(rng))
+    with pytest.raises(ValueError):
+        LG.verify_proofs_batch_merged(pvk, proofs, pubs[:-1], 7)

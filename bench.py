@@ -15,7 +15,7 @@ v_mad_u64_u32 issue peak: the path is integer-multiply bound), "cpu_baseline" (t
 Pippenger, one thread per window like rayon, timed on this box's host cores; kind "port"; plus one thread and the
 n = 2^16 plumbing config), "secondary" (N = 1 only, outside the timed region: the plain resident pipeline without a
 table, H2D-inclusive and one-shot calls, the skewed scalar distributions of SURVEY 8d, one 2^24-term MSM on this one
-GPU, G2 MSM, 1024-pair Miller loop, final exponentiation, witness map, LegoGroth16 prove at 2^20 constraints).
+GPU, G2 MSM, 1024-pair Miller loop, final exponentiation, verification of 1024 proofs, witness map, LegoGroth16 prove at 2^20 constraints).
 
 Inputs and the closed-form check are produced by the library itself (fixed-base kernel, published generator
 encodings); oracle/ is imported only inside the cpu_baseline leg, where it is the timed CPU baseline and the
@@ -400,6 +400,31 @@ def secondary_configs(log2n, ks, scalars, db, ds, pool):
     res["g2_prepare_1024_ms"] = round(timed(lambda: pairing.G2Prepared.from_affine(Q)), 3)
     res["miller_loop_1024_prepared_pairs_ms"] = round(timed(lambda: pairing.multi_miller_loop(P, pc)), 3)
     res["final_exponentiation_ms"] = round(timed(lambda: ca.final_exponentiation(f)), 3)
+    # -- the verifier's side of the same path (verifier.rs:62-99, randomized_pairing_check.rs): 1024 Groth16-shaped proofs with known discrete
+    #    logs (a_i b_i = alpha beta + (g0 + x_i g1 + d_i) gamma + c_i delta, so every one of them verifies), one at a time and batched
+    from crypto_amd import legogroth16 as LGv
+    nv = 1024
+    ints = lambda seed, k: [int(x[0]) | (int(x[1]) << 64) | (int(x[2]) << 128) | (int(x[3]) << 192) for x in seeded_scalars(seed, k)]
+    al, be, ga, de, g0, g1x = ints(0x5EED0020, 6)
+    av, bv, dv, xv = ints(0x5EED0021, nv), ints(0x5EED0022, nv), ints(0x5EED0023, nv), ints(0x5EED0024, nv)
+    dinv = pow(de, R_MOD - 2, R_MOD)
+    cv = [((a * b - al * be - (g0 + x * g1x + d) * ga) * dinv) % R_MOD for a, b, d, x in zip(av, bv, dv, xv)]
+    lim = lambda vals: np.array([[(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)] for v in vals], dtype=np.uint64)
+    with FB.WindowTable(ca.G2, gen2[0]) as t2, FB.WindowTable(ca.G1, gen1[0]) as t1:
+        A_, _ = t1.multiply_many(lim(av)); C_, _ = t1.multiply_many(lim(cv)); D_, _ = t1.multiply_many(lim(dv)); K_, _ = t1.multiply_many(lim([al, g0, g1x, 1]))
+        B_, _ = t2.multiply_many(lim(bv)); V_, _ = t2.multiply_many(lim([be, ga, de]))
+    vkv = LGv.VerifyingKey(K_[0], V_[0], V_[1], V_[2], K_[1:3], K_[3], 0)
+    pvkv = LGv.prepare_verifying_key(vkv)
+    proofs_v = [{"a": A_[i], "b": B_[i], "c": C_[i], "d": D_[i]} for i in range(nv)]
+    pubs_v = [lim([x]) for x in xv]
+    assert LGv.verify_proof(pvkv, proofs_v[0], pubs_v[0]) and not LGv.verify_proof(pvkv, proofs_v[0], pubs_v[1])
+    res["verify_one_proof_ms"] = round(timed(lambda: LGv.verify_proof(pvkv, proofs_v[1], pubs_v[1]), 5), 3)
+    assert LGv.verify_proofs_batch(pvkv, proofs_v, pubs_v, 0x5EED0025) and LGv.verify_proofs_batch_merged(pvkv, proofs_v, pubs_v, 0x5EED0026)
+    swapped = list(proofs_v); swapped[7] = dict(swapped[7], c=proofs_v[8]["c"])
+    assert not LGv.verify_proofs_batch_merged(pvkv, swapped, pubs_v, 0x5EED0027)
+    res["verify_1024_proofs_pairing_checker_ms"] = round(timed(lambda: LGv.verify_proofs_batch(pvkv, proofs_v, pubs_v, 0x5EED0028), 3), 2)
+    res["verify_1024_proofs_merged_ms"] = round(timed(lambda: LGv.verify_proofs_batch_merged(pvkv, proofs_v, pubs_v, 0x5EED0029), 3), 2)
+    res["verify_proofs_per_s_merged"] = round(nv / res["verify_1024_proofs_merged_ms"] * 1e3, 0)
     # -- BASELINE config 4: witness map on the x_i = x_{i-1}^2 + i circuit shape (m + 1 constraints + 2 instance variables = D), circuit resident,
     #    and LegoGroth16 create_proof (prover.rs:267-383) on a synthetic key of that size with every query a precomputed table
     m = n - 3

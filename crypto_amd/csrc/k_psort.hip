@@ -15,7 +15,7 @@ void launch_psort(hipStream_t s, const PsParams &q, uint32_t NB, uint32_t *cnt1,
     launch_scan(s, cnt1, off1, nullptr, bsums, (size_t)q.P * q.ntiles);
     // the pair total is known: chunking and heavy-bucket threshold of the accumulation follow from it (dyn_args = {fixed_ch, min_chunk, max_chunks, lanes_per_chunk, T_max})
     if (dyn) launch_dyn_chunk(s, off1 + (size_t)q.P * q.ntiles, dyn_args[0], dyn_args[1], dyn_args[2], dyn_args[3], dyn_args[4], dyn);
-    hipLaunchKernelGGL(k_ps_scatter1, dim3(q.ntiles), dim3(PS_TILE), lds3, s, q, off1, (uint2 *)pairs);
+    hipLaunchKernelGGL(k_ps_scatter1, dim3(q.ntiles), dim3(PS_TILE), lds3, s, q, (const uint32_t *)cnt1, (const uint32_t *)off1, (uint2 *)pairs);
     hipLaunchKernelGGL(k_ps_bucket, dim3(q.P), dim3(1024), 0, s, (const uint2 *)pairs, off1, q.ntiles, q.P, NB, q.part_log, off, entries, heavy_thr, heavy, heavy_cap, (const uint32_t *)dyn);
 }
 }  // namespace msm

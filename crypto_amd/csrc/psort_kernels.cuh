@@ -81,16 +81,15 @@ __global__ void __launch_bounds__(PS_TILE) k_ps_count1(PsParams q, uint32_t *__r
 }
 
 // P3: pairs[off1[p * ntiles + tile] + k] = (key, val) of the k-th pair of tile `tile` that falls in partition p
-__global__ void __launch_bounds__(PS_TILE) k_ps_scatter1(PsParams q, const uint32_t *__restrict__ off1, uint2 *__restrict__ pairs) {
+__global__ void __launch_bounds__(PS_TILE) k_ps_scatter1(PsParams q, const uint32_t *__restrict__ cnt1, const uint32_t *__restrict__ off1, uint2 *__restrict__ pairs) {
     extern __shared__ __align__(16) uint32_t lds[];
     uint32_t *cnt = lds, *pre = lds + q.P, *cur = lds + 2 * q.P;      // histogram, exclusive prefix, cursors
     uint2 *stage = reinterpret_cast<uint2 *>(lds + 3 * q.P + ((3 * q.P) & 1u));   // 8-byte aligned
     __shared__ uint32_t wave_tot[PS_TILE / 64 + 1];
-    for (uint32_t j = threadIdx.x; j < q.P; j += blockDim.x) cnt[j] = 0;
-    __syncthreads();
+    // this tile's histogram is what P1 wrote (one digit pass less: the digits are extracted twice per scalar, not three times)
+    for (uint32_t j = threadIdx.x; j < q.P; j += blockDim.x) cnt[j] = cnt1[(size_t)j * q.ntiles + blockIdx.x];
     const size_t i = (size_t)blockIdx.x * PS_TILE + threadIdx.x;
     const bool live = ps_live(q, i);
-    ps_digits(q, i, live, [&](int w, uint32_t m1, uint32_t, bool nz) { (void)lds_inc_agg(cnt, nz ? ((uint32_t)w * q.key_wstride + m1) >> q.part_log : 0u, nz); });
     __syncthreads();
     // exclusive scan of cnt[0..P): every thread takes P / 512 consecutive bins (P is a power of two >= 1; 512 threads)
     {

@@ -54,8 +54,19 @@ def mul_add(curve, points, scalars, addend=None):
 
 
 def msm(curve, points, scalars):
-    """sum s_i P_i as an affine ABI point (identity: zero words)"""
+    """sum s_i P_i as an affine ABI point (identity: zero words).  Up to 16 terms (the `mul_bigint`s and two-term combinations of the KZG
+    checks and of the final verification, CPU scalar multiplications in the reference): host arithmetic in the library (dgpu_lincomb_*);
+    more: the MSM entry point."""
     P = pts(curve, points)
+    if 0 < len(P) <= 16:
+        sc = np.ascontiguousarray(limbs(scalars))
+        inf = np.ascontiguousarray((~P.any(axis=1)).astype(np.uint8))
+        jac = np.zeros(curve.JW, dtype=np.uint64)
+        fn = lib().dgpu_lincomb_g1 if curve is G1 else lib().dgpu_lincomb_g2
+        rc = fn(_p(np.ascontiguousarray(P)), _p(inf), _p(sc), len(P), _p(jac))
+        if rc:
+            raise DockGpuError(rc, "dgpu_lincomb")
+        return np.zeros(curve.AW, dtype=np.uint64) if not jac[curve.AW:].any() else jac[:curve.AW].copy()
     jac = M.msm_bigint(curve, P, limbs(scalars))
     return np.zeros(curve.AW, dtype=np.uint64) if not jac[curve.AW:].any() else jac[:curve.AW].copy()
 

@@ -143,8 +143,8 @@ _HOST_POOL = None
 
 
 def parallel(thunks, host=False):
-    """run independent ABI calls from host threads (the library keeps 4 calls in flight on separate HIP streams; ctypes drops
-    the GIL) — the reference runs the same calls under rayon.  host=True: calls that only use host cores (wider pool)."""
+    """run independent ABI calls from host threads (the library keeps six calls in flight on separate HIP streams, further callers queue for a slot;
+    ctypes drops the GIL) — the reference runs the same calls under rayon.  host=True: calls that only use host cores (wider pool)."""
     global _POOL, _HOST_POOL
     from concurrent.futures import ThreadPoolExecutor
     if host:
@@ -153,6 +153,6 @@ def parallel(thunks, host=False):
         pool = _HOST_POOL
     else:
         if _POOL is None:
-            _POOL = ThreadPoolExecutor(4)
+            _POOL = ThreadPoolExecutor(8)
         pool = _POOL
     return [f.result() for f in [pool.submit(t) for t in thunks]]

@@ -7,12 +7,15 @@
 #include "../../crypto_amd/csrc/pairing29.cuh"
 #include "../../crypto_amd/csrc/host_field.hpp"
 #include "../../crypto_amd/csrc/fr29.cuh"
+#include "../../crypto_amd/csrc/fp_safegcd.cuh"
 #include <vector>
 #include <string.h>
 using namespace bls29;
 extern "C" {
 void shim_fp_mul(const uint32_t *a, const uint32_t *b, uint32_t *out) { Fp x, y, r; fp_from_abi(x, a); fp_from_abi(y, b); fp_mul(r, x, y); fp_to_abi(out, r); }
 void shim_fp_sqr(const uint32_t *a, uint32_t *out) { Fp x, r; fp_from_abi(x, a); fp_sqr(r, x); fp_to_abi(out, r); }
+// 1 / (k a) by the division-step inversion the kernels use; k a is formed by unreduced additions (a lazy-class operand)
+void shim_fp_inv(const uint32_t *a, int k, uint32_t *out) { Fp x, t, r; fp_from_abi(x, a); t = x; for (int i = 1; i < k; i++) fp_add(t, t, x); fp_inv_safegcd(r, t); fp_to_abi(out, r); }
 void shim_fp_roundtrip(const uint32_t *a, uint32_t *out) { Fp x; fp_from_abi(x, a); fp_to_abi(out, x); }
 // (a - b) * c with the lazy subtraction + norm, exercising K_M domination
 void shim_fp_submul(const uint32_t *a, const uint32_t *b, const uint32_t *c, uint32_t *out) {

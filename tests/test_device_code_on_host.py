@@ -19,7 +19,7 @@ P = M.P
 
 @pytest.fixture(scope="module")
 def shim():
-    deps = [SRC] + [os.path.join(HERE, "..", "crypto_amd", "csrc", f) for f in ("fp29.cuh", "fp2_29.cuh", "ec29.cuh", "pairing29.cuh", "fr29.cuh")]
+    deps = [SRC] + [os.path.join(HERE, "..", "crypto_amd", "csrc", f) for f in ("fp29.cuh", "fp2_29.cuh", "ec29.cuh", "pairing29.cuh", "fr29.cuh", "fp_safegcd.cuh")]
     if not os.path.exists(SO) or any(os.path.getmtime(d) > os.path.getmtime(SO) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", SO, SRC])
     return C.CDLL(SO)
@@ -44,6 +44,18 @@ def test_fp_ops(shim):
         shim.shim_fp_submul(p_(A), p_(B), p_(Cc), p_(out)); assert U.fp_int(out) == (a - b) * c % P
         assert ((shim.shim_fp_is_zero(p_(A), p_(B)) & 2) != 0) == (a == b)
         assert shim.shim_fp_is_zero(p_(A), p_(A)) == 3
+
+
+def test_fp_inversion_by_division_steps(shim):
+    """fp_safegcd.cuh against the big-integer inverse: edge values, small and large values, random ones, lazily added operands"""
+    random.seed(7)
+    vals = [0, 1, 2, 3, P - 1, P - 2, (P - 1) // 2, (P + 1) // 2, 2 ** 29, 2 ** 29 - 1, 2 ** 58 + 1, 2 ** 380, 2 ** 377 - 1, 2 ** 377, P - 2 ** 29]
+    vals += [random.randrange(P) for _ in range(400)] + [random.randrange(1 << k) for k in range(1, 381, 7)]
+    out = np.zeros(6, np.uint64)
+    for a in vals:
+        for k in (1, 3, 7):
+            shim.shim_fp_inv(p_(U.fp_abi(a)), k, p_(out))
+            assert U.fp_int(out) == (pow(k * a, -1, P) if a else 0), (a, k)
 
 
 def test_fp2_ops(shim):

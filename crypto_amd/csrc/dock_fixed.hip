@@ -121,14 +121,28 @@ template <class C> int32_t mul_add(const uint64_t *p, const uint8_t *p_inf, cons
     hipStream_t s = sl.stream;
     uint8_t *dp = sl.in_bases.as<uint8_t>();
     HIPCHK(hipMemcpyAsync(dp, p, n * pt, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(sl.in_scalars.p, scalars, nsc * 32, hipMemcpyHostToDevice, s));
+#ifdef DGPU_DEV
+    static const bool plain = getenv("DGPU_MULADD_PLAIN") != nullptr;     // development switch: the 255-bit chains (no endomorphism)
+#else
+    constexpr bool plain = false;
+#endif
+    // every scalar is sent split: G1 (k1 | k2) with k = k1 + k2 lambda (GLV), G2 four base-|x| digits (GLS) — host_field.hpp
+    std::vector<uint64_t> split(nsc * 4);
+    if (!plain)
+        for (size_t k = 0; k < nsc; k++) {
+            if constexpr (C::NFP == 1) hostf::glv_decompose(scalars + 4 * k, &split[4 * k], &split[4 * k + 2]);
+            else hostf::gls4_decompose(scalars + 4 * k, &split[4 * k]);
+        }
+    HIPCHK(hipMemcpyAsync(sl.in_scalars.p, plain ? scalars : split.data(), nsc * 32, hipMemcpyHostToDevice, s));
     const uint32_t *dadd = nullptr; const uint8_t *dpinf = nullptr, *dainf = nullptr;
     if (addend) { HIPCHK(hipMemcpyAsync(dp + n * pt, addend, n * pt, hipMemcpyHostToDevice, s)); dadd = (const uint32_t *)(dp + n * pt); }
     if (p_inf) { HIPCHK(hipMemcpyAsync(sl.in_inf.p, p_inf, n, hipMemcpyHostToDevice, s)); dpinf = sl.in_inf.as<uint8_t>(); }
     if (add_inf) { HIPCHK(hipMemcpyAsync(sl.in_inf.as<uint8_t>() + n, add_inf, n, hipMemcpyHostToDevice, s)); dainf = sl.in_inf.as<uint8_t>() + n; }
     uint8_t *dout_inf = sl.prepped.as<uint8_t>() + n * pt;
     { StageTimer st(sl, "fixed.mul_add");
-      msm::launch_mul_add<C>(s, (const uint32_t *)dp, dpinf, sl.in_scalars.as<uint32_t>(), (int)(scalar_stride * 2), dadd, dainf, n, sl.prepped.as<uint32_t>(), dout_inf); }
+      if (plain) msm::launch_mul_add<C>(s, (const uint32_t *)dp, dpinf, sl.in_scalars.as<uint32_t>(), (int)(scalar_stride * 2), dadd, dainf, n, sl.prepped.as<uint32_t>(), dout_inf);
+      else if constexpr (C::NFP == 1) msm::launch_g1_scale(s, (const uint32_t *)dp, dpinf, sl.in_scalars.as<uint32_t>(), (int)(scalar_stride * 2), nullptr, n, sl.prepped.as<uint32_t>(), dout_inf, dadd, dainf);
+      else msm::launch_mul_add_g2_gls(s, (const uint32_t *)dp, dpinf, sl.in_scalars.as<uint32_t>(), (int)(scalar_stride * 2), dadd, dainf, n, sl.prepped.as<uint32_t>(), dout_inf); }
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out, sl.prepped.p, n * pt, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(out_inf, dout_inf, n, hipMemcpyDeviceToHost, s));

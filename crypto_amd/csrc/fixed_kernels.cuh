@@ -250,4 +250,84 @@ __global__ void __launch_bounds__(64) k_mul_add_g2_quad(const uint32_t *__restri
     fp_to_abi(o + 12 * h, a.x.v); fp_to_abi(o + 12 * (2 + h), a.y.v);
 }
 
+// G2 form of k_mul_add with SIXTEEN lanes per point: the scalar arrives as four base-|x| digits, k = k0 + k1 |x| + k2 |x|^2 + k3 |x|^3
+// (x = -0xd201000000010000 the BLS parameter, every digit < 2^64; hostf::gls4_decompose), and quad j of the 16 lanes runs the 64-step
+// double-and-add of k_j B_j with B_j = |x|^j P on its two lane pairs (Share4).  B_j costs two Fp2 products: the untwist-Frobenius-twist
+// map psi acts on the prime-order subgroup as multiplication by p = x (mod r), so |x|^j P = (-psi)^j (P) = (c_j(X) AX_j, c_j(Y) AY_j) with
+// c_j the Fp2 conjugation for odd j and the constants below (xi^-((p-1)/3), xi^-((p-1)/2) and their conjugate products, the sign folded
+// into AY_j; each one re-derived and checked against |x|^j Q by oracle/bls12_381_model.py).  A quarter of the dependent steps of the
+// 255-bit chain, and 2/3 of its total work.  Points must lie in the prime-order subgroup (the invariant of arkworks' G2Affine).
+__device__ const uint32_t GLS_BASE[4][4][NL] = {
+  {{0x3a9fb84u, 0xba00690u, 0x71288f1u, 0xf59bcc5u, 0x126cb614u, 0x585bf36u, 0x1b85ac3du, 0x1cf856fau, 0x1891ecbdu, 0x1a7eec05u, 0x155a88f0u, 0x741ac6du, 0x1317c30fu, 0x9u},
+   {0x0u, 0x0u, 0x0u, 0x0u, 0x0u, 0x0u, 0x0u, 0x0u, 0x0u, 0x0u, 0x0u, 0x0u, 0x0u, 0x0u},
+   {0x3a9fb84u, 0xba00690u, 0x71288f1u, 0xf59bcc5u, 0x126cb614u, 0x585bf36u, 0x1b85ac3du, 0x1cf856fau, 0x1891ecbdu, 0x1a7eec05u, 0x155a88f0u, 0x741ac6du, 0x1317c30fu, 0x9u},
+   {0x0u, 0x0u, 0x0u, 0x0u, 0x0u, 0x0u, 0x0u, 0x0u, 0x0u, 0x0u, 0x0u, 0x0u, 0x0u, 0x0u}},
+  {{0x0u, 0x0u, 0x0u, 0x0u, 0x0u, 0x0u, 0x0u, 0x0u, 0x0u, 0x0u, 0x0u, 0x0u, 0x0u, 0x0u},
+   {0x154030c4u, 0x16aceb14u, 0x1814e947u, 0x1fba3004u, 0x2e0fc81u, 0xfb3da4fu, 0x170f2de1u, 0xacd4cbcu, 0x9689a69u, 0x110b9212u, 0x533b200u, 0x1554d884u, 0xba917a7u, 0x0u},
+   {0x16620abdu, 0x12fd467cu, 0xd1f4f6fu, 0x18780c70u, 0x3a0bc76u, 0x1c749a28u, 0x9efbfa9u, 0x91b1f3u, 0xe4ddb2au, 0x286f628u, 0xe8943au, 0x981f0b0u, 0xe14367cu, 0x0u},
+   {0x99d9feeu, 0x1cfab983u, 0x7e0b07eu, 0x1f87f0f2u, 0xbc18573u, 0xcdbe130u, 0x10ddd19u, 0x100cbeafu, 0x9169c21u, 0xf93673eu, 0x11de55b3u, 0x97ddc84u, 0x11fce827u, 0xcu}},
+  {{0x1195dfebu, 0x1b04e484u, 0x6026044u, 0x86070a2u, 0x1fd68858u, 0x137e9670u, 0x6871e67u, 0x1e736664u, 0x83b24f6u, 0x8a70373u, 0x2a012fdu, 0x112f94bu, 0x18a2733cu, 0x3u},
+   {0x0u, 0x0u, 0x0u, 0x0u, 0x0u, 0x0u, 0x0u, 0x0u, 0x0u, 0x0u, 0x0u, 0x0u, 0x0u, 0x0u},
+   {0x1c55af27u, 0x457f96fu, 0xded76fdu, 0x8a6409du, 0x1cf58bd6u, 0x3cabc21u, 0xf77f086u, 0x13a619a7u, 0x1ed28a8du, 0x179b7160u, 0x1d6c60fcu, 0xbbe20c6u, 0xcf95b94u, 0x3u},
+   {0x0u, 0x0u, 0x0u, 0x0u, 0x0u, 0x0u, 0x0u, 0x0u, 0x0u, 0x0u, 0x0u, 0x0u, 0x0u, 0x0u}},
+  {{0x0u, 0x0u, 0x0u, 0x0u, 0x0u, 0x0u, 0x0u, 0x0u, 0x0u, 0x0u, 0x0u, 0x0u, 0x0u, 0x0u},
+   {0x1c55af27u, 0x457f96fu, 0xded76fdu, 0x8a6409du, 0x1cf58bd6u, 0x3cabc21u, 0xf77f086u, 0x13a619a7u, 0x1ed28a8du, 0x179b7160u, 0x1d6c60fcu, 0xbbe20c6u, 0xcf95b94u, 0x3u},
+   {0x99d9feeu, 0x1cfab983u, 0x7e0b07eu, 0x1f87f0f2u, 0xbc18573u, 0xcdbe130u, 0x10ddd19u, 0x100cbeafu, 0x9169c21u, 0xf93673eu, 0x11de55b3u, 0x97ddc84u, 0x11fce827u, 0xcu},
+   {0x16620abdu, 0x12fd467cu, 0xd1f4f6fu, 0x18780c70u, 0x3a0bc76u, 0x1c749a28u, 0x9efbfa9u, 0x91b1f3u, 0xe4ddb2au, 0x286f628u, 0xe8943au, 0x981f0b0u, 0xe14367cu, 0x0u}}};
+template <class DUMMY>
+__global__ void __launch_bounds__(64) k_mul_add_g2_gls(const uint32_t *__restrict__ p_abi, const uint8_t *__restrict__ p_inf, const uint32_t *__restrict__ digits, int scalar_stride,
+                                                       const uint32_t *__restrict__ add_abi, const uint8_t *__restrict__ add_inf, size_t n, uint32_t *__restrict__ out_abi, uint8_t *__restrict__ out_inf) {
+    typedef Fp2H F;
+    constexpr int PW = 48;
+    const size_t gid = (size_t)blockIdx.x * 64 + threadIdx.x, i = gid >> 4;
+    const uint32_t h = threadIdx.x & 1u, j = (threadIdx.x >> 2) & 3u;
+    if (i >= n) return;                                  // (all sixteen lanes of a point leave together)
+    auto load_half = [&](Aff<F> &A, const uint32_t *src) { fp_from_abi(A.x.v, src + 12 * h); fp_from_abi(A.y.v, src + 12 * (2 + h)); };
+    auto all_zero = [&](const uint32_t *src) { uint32_t any = 0; for (int k = 0; k < PW; k++) any |= src[k]; return any == 0; };
+    Aff<F> P; load_half(P, p_abi + i * PW);
+    const bool pinf = all_zero(p_abi + i * PW) || (p_inf && p_inf[i]);
+    {   // B_j = (c_j(X) AX_j, c_j(Y) AY_j)
+        const bool cj = (j & 1u) != 0 && h != 0;         // conjugation: the c1 half changes sign
+        Fp z, nx, ny; fp_zero(z);
+        fp_sub<4>(nx, z, P.x.v); fp_norm(nx, nx); fp_sub<4>(ny, z, P.y.v); fp_norm(ny, ny);
+        sel(P.x.v, cj, nx, P.x.v); sel(P.y.v, cj, ny, P.y.v);
+        F ax, ay;
+#pragma unroll
+        for (int k = 0; k < NL; k++) { ax.v.l[k] = GLS_BASE[j][h][k]; ay.v.l[k] = GLS_BASE[j][2 + h][k]; }
+        F bx, by; fmul(bx, P.x, ax); fmul(by, P.y, ay);
+        P.x = bx; P.y = by;
+    }
+    const uint32_t *s = digits + i * (size_t)scalar_stride + 2 * j;
+    const uint32_t s0 = s[0], s1 = s[1];
+    Xyzz<F> acc; bool inf = true;
+    fzero(acc.x); fzero(acc.y); fzero(acc.zz); fzero(acc.zzz);
+    if (!pinf)
+        for (int b = 63; b >= 0; b--) {
+            if (!inf) { Xyzz<F> d; xyzz_dbl_shared<F, Share4>(d, acc); acc = d; }
+            if (((b >= 32 ? s1 : s0) >> (b & 31)) & 1u) xyzz_madd_shared<F, Share4>(acc, inf, P, false);
+        }
+    // k0 B0 + k1 B1 + k2 B2 + k3 B3: quads 2, 3 hand their sums to quads 0, 1, then quad 1 to quad 0 (shuffles stay inside the 16 lanes)
+#pragma unroll
+    for (int d = 8; d >= 4; d >>= 1) {
+        Xyzz<F> o; bool oinf;
+        const uint32_t *w = reinterpret_cast<const uint32_t *>(&acc);
+        uint32_t *q = reinterpret_cast<uint32_t *>(&o);
+#pragma unroll
+        for (int k = 0; k < 4 * NL; k++) q[k] = __shfl_down(w[k], d, 16);
+        oinf = __shfl_down((int)inf, d, 16) != 0;
+        xyzz_add(acc, inf, o, oinf);
+    }
+    if (j != 0) return;
+    if (add_abi) {
+        const uint32_t *src = add_abi + i * PW;
+        if (!all_zero(src) && !(add_inf && add_inf[i])) { Aff<F> A; load_half(A, src); xyzz_madd_shared<F, Share4>(acc, inf, A, false); }
+    }
+    if ((threadIdx.x & 2u) != 0) return;                 // the first pair writes the result
+    uint32_t *o = out_abi + i * PW;
+    if (h == 0) out_inf[i] = inf ? 1 : 0;
+    if (inf) { for (int k = 0; k < 12; k++) { o[12 * h + k] = 0; o[12 * (2 + h) + k] = 0; } return; }
+    Aff<F> a; xyzz_to_affine(a, acc);
+    fp_to_abi(o + 12 * h, a.x.v); fp_to_abi(o + 12 * (2 + h), a.y.v);
+}
+
 }  // namespace msm

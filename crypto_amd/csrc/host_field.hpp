@@ -317,4 +317,20 @@ static inline void glv_decompose(const uint64_t k_in[4], uint64_t k1[2], uint64_
     k1[0] = rem[0]; k1[1] = rem[1]; k2[0] = q[0]; k2[1] = q[1];
 }
 
+// Base-|x| digits of k mod r, x = -0xd201000000010000 the BLS parameter: k = d0 + d1 |x| + d2 |x|^2 + d3 |x|^3, d0..d2 < |x|,
+// d3 = floor(k / |x|^3) < 2^64 (r < 2^255, |x|^3 > 2^191).  On the prime-order subgroup of the twist |x|^j P = (-psi)^j (P), so the
+// four 64-bit chains of k_mul_add_g2_gls replace one 255-bit chain (Galbraith-Lin-Scott decomposition; fixed_kernels.cuh).
+static inline void gls4_decompose(const uint64_t k_in[4], uint64_t d[4]) {
+    static constexpr uint64_t RM[4] = {0xffffffff00000001ULL, 0x53bda402fffe5bfeULL, 0x3339d80809a1d805ULL, 0x73eda753299d7d48ULL};
+    uint64_t k[4] = {k_in[0], k_in[1], k_in[2], k_in[3]};
+    auto geq_r = [&]() { for (int i = 3; i >= 0; i--) { if (k[i] > RM[i]) return true; if (k[i] < RM[i]) return false; } return true; };
+    while (geq_r()) { uint64_t br = 0; for (int i = 0; i < 4; i++) { u128 t = (u128)k[i] - RM[i] - br; k[i] = (uint64_t)t; br = (uint64_t)(t >> 64) & 1; } }   // at most twice
+    for (int j = 0; j < 3; j++) {                              // k, d[j] = divmod(k, |x|)
+        u128 rem = 0;
+        for (int i = 3; i >= 0; i--) { const u128 cur = (rem << 64) | k[i]; k[i] = (uint64_t)(cur / BLS_X_ABS); rem = cur % BLS_X_ABS; }
+        d[j] = (uint64_t)rem;
+    }
+    d[3] = k[0];                                               // (k[1..3] == 0 here)
+}
+
 }  // namespace hostf

@@ -28,6 +28,10 @@ template <class C> void launch_mul_add(hipStream_t s, const uint32_t *p_abi, con
     }
     hipLaunchKernelGGL((k_mul_add<C>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, p_abi, p_inf, scalars, scalar_stride, add_abi, add_inf, n, out_abi, out_inf);
 }
+void launch_mul_add_g2_gls(hipStream_t s, const uint32_t *p_abi, const uint8_t *p_inf, const uint32_t *digits, int scalar_stride, const uint32_t *add_abi, const uint8_t *add_inf,
+                           size_t n, uint32_t *out_abi, uint8_t *out_inf) {
+    hipLaunchKernelGGL((k_mul_add_g2_gls<G2>), dim3((unsigned)((16 * n + 63) / 64)), dim3(64), 0, s, p_abi, p_inf, digits, scalar_stride, add_abi, add_inf, n, out_abi, out_inf);
+}
 template void launch_mul_add<G1>(hipStream_t, const uint32_t *, const uint8_t *, const uint32_t *, int, const uint32_t *, const uint8_t *, size_t, uint32_t *, uint8_t *);
 template void launch_mul_add<G2>(hipStream_t, const uint32_t *, const uint8_t *, const uint32_t *, int, const uint32_t *, const uint8_t *, size_t, uint32_t *, uint8_t *);
 template void launch_fb_table<G1>(hipStream_t, const uint32_t *, uint32_t *);

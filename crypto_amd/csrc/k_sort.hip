@@ -28,8 +28,9 @@ void launch_dyn_chunk(hipStream_t s, const uint32_t *total, uint32_t fixed_ch, u
 void launch_flag_heavy(hipStream_t s, const uint32_t *off, uint32_t NB, const uint32_t *dyn, uint32_t *heavy, uint32_t heavy_cap) {
     hipLaunchKernelGGL(k_flag_heavy, dim3((NB + 255) / 256), dim3(256), 0, s, off, NB, dyn, heavy, heavy_cap);
 }
-void launch_g1_scale(hipStream_t s, const uint32_t *p_abi, const uint8_t *is_inf, const uint32_t *scalars, int scalar_stride, const uint8_t *negate, size_t n, uint32_t *out_abi, uint8_t *out_inf) {
-    hipLaunchKernelGGL(k_g1_scale, dim3((unsigned)((4 * n + 63) / 64)), dim3(64), 0, s, p_abi, is_inf, scalars, scalar_stride, negate, n, out_abi, out_inf);
+void launch_g1_scale(hipStream_t s, const uint32_t *p_abi, const uint8_t *is_inf, const uint32_t *scalars, int scalar_stride, const uint8_t *negate, size_t n, uint32_t *out_abi, uint8_t *out_inf,
+                     const uint32_t *add_abi, const uint8_t *add_inf) {
+    hipLaunchKernelGGL(k_g1_scale, dim3((unsigned)((4 * n + 63) / 64)), dim3(64), 0, s, p_abi, is_inf, scalars, scalar_stride, negate, n, out_abi, out_inf, add_abi, add_inf);
 }
 void launch_selftest_fp_mul(hipStream_t s, const uint32_t *a, const uint32_t *b, size_t n, uint32_t *out) {
     hipLaunchKernelGGL(k_selftest_fp_mul, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, a, b, n, out);

@@ -213,8 +213,11 @@ __global__ void k_selftest_g1_sum(const uint32_t *pts_abi, const uint8_t *neg, s
 // hostf::glv_decompose): lanes 0,1 of a quad run the 128-step double-and-add of k1 P, lanes 2,3 that of k2 P — each chain on two lanes
 // (ec29_two_lane.cuh) — and the result is k1 P + phi(k2 P).  Half the dependent steps of the 255-bit chain: the kernel is latency-bound
 // (RandomizedPairingChecker scales a handful of points), 3.5 -> ~2.3 ms.
+// add_abi != nullptr: out_i = A_i + s_i * P_i (the aggregation's folding step, dgpu_g1_mul_add_batch).  Points are elements of the
+// prime-order subgroup (the invariant of arkworks' G1Affine): phi(P) = lambda P only holds there.
 __global__ void __launch_bounds__(64) k_g1_scale(const uint32_t *__restrict__ p_abi, const uint8_t *__restrict__ is_inf, const uint32_t *__restrict__ scalars, int scalar_stride,
-                                                 const uint8_t *__restrict__ negate, size_t n, uint32_t *__restrict__ out_abi, uint8_t *__restrict__ out_inf) {
+                                                 const uint8_t *__restrict__ negate, size_t n, uint32_t *__restrict__ out_abi, uint8_t *__restrict__ out_inf,
+                                                 const uint32_t *__restrict__ add_abi, const uint8_t *__restrict__ add_inf) {
     size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
     const bool B = (threadIdx.x & 1u) != 0;
     const uint32_t chain = (threadIdx.x >> 1) & 1u;
@@ -243,6 +246,12 @@ __global__ void __launch_bounds__(64) k_g1_scale(const uint32_t *__restrict__ p_
     if (chain) return;
     if (!oinf) xyzz_phi(oth);
     xyzz_add(acc, inf, oth, oinf);
+    if (add_abi) {
+        const uint32_t *src = add_abi + i * 24;
+        uint32_t nz = 0;
+        for (int k = 0; k < 24; k++) nz |= src[k];
+        if (nz != 0 && !(add_inf && add_inf[i])) { Aff<Fp> A; fp_from_abi(A.x, src); fp_from_abi(A.y, src + 12); xyzz_madd_2l(acc, inf, A, false); }
+    }
     if (!B) out_inf[i] = inf;
     uint32_t *o = out_abi + i * 24;
     if (inf) { if (!B) for (int k = 0; k < 24; k++) o[k] = 0; return; }

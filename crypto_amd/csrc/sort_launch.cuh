@@ -39,7 +39,8 @@ inline int ps_part_log(uint32_t NB) { int lg = 0; while ((1u << lg) < NB) lg++; 
 // cnt1 / off1: P * ntiles + 1 words; bsums: scan_blocks(P * ntiles) + 2 words; pairs: n * W x 8 B; off: NB + 1; entries: n * W
 void launch_psort(hipStream_t s, const PsParams &q, uint32_t NB, uint32_t *cnt1, uint32_t *off1, uint32_t *bsums, void *pairs, uint32_t *off, uint32_t *entries,
                   uint32_t heavy_thr, uint32_t *heavy, uint32_t heavy_cap, const uint32_t *dyn_args = nullptr, uint32_t *dyn = nullptr);
-void launch_g1_scale(hipStream_t s, const uint32_t *p_abi, const uint8_t *is_inf, const uint32_t *scalars, int scalar_stride, const uint8_t *negate, size_t n, uint32_t *out_abi, uint8_t *out_inf);
+void launch_g1_scale(hipStream_t s, const uint32_t *p_abi, const uint8_t *is_inf, const uint32_t *scalars, int scalar_stride, const uint8_t *negate, size_t n, uint32_t *out_abi, uint8_t *out_inf,
+                     const uint32_t *add_abi = nullptr, const uint8_t *add_inf = nullptr);
 void launch_selftest_fp_mul(hipStream_t s, const uint32_t *a, const uint32_t *b, size_t n, uint32_t *out);
 void launch_selftest_g1_sum(hipStream_t s, const uint32_t *pts, const uint8_t *neg, size_t n, uint32_t *out, uint8_t *out_inf);
 

@@ -209,7 +209,9 @@ int32_t dgpu_fixed_base_g2(const uint64_t base_xy[24], const uint64_t *scalars, 
  * out_i = addend_i + scalars_i * P_i as affine points: `compress` (legogroth16/src/aggregation/utils.rs:34-49), Key::compress and
  * Key::scale (legogroth16/src/aggregation/key.rs:117-175), `b.mul_bigint(r_i)` (aggregation/groth16/prover.rs:107-112).
  * scalar_stride = 4: one canonical scalar per point; 0: one scalar for all.  addend_xy = NULL: plain scaling.
- * Identity inputs: all-zero words or a set flag byte; identity outputs: zero words and out_inf[i] = 1. */
+ * Identity inputs: all-zero words or a set flag byte; identity outputs: zero words and out_inf[i] = 1.
+ * The points are elements of the prime-order subgroups (what arkworks' G1Affine / G2Affine hold after deserialization or arithmetic):
+ * the scalars are split by the GLV / GLS endomorphisms, which act as multiplications only there.  Any 256-bit scalar (reduced mod r). */
 int32_t dgpu_g1_mul_add_batch(const uint64_t *p_xy /* n*12 */, const uint8_t *p_inf, const uint64_t *scalars, size_t scalar_stride,
                               const uint64_t *addend_xy /* n*12 or NULL */, const uint8_t *addend_inf, size_t n, uint64_t *out_xy, uint8_t *out_inf);
 int32_t dgpu_g2_mul_add_batch(const uint64_t *p_xy /* n*24 */, const uint8_t *p_inf, const uint64_t *scalars, size_t scalar_stride,

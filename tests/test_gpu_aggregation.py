@@ -147,17 +147,35 @@ def test_mul_add_batch_matches_oracle(curve):
     A = np.stack([grp.to_affine(grp.mul(grp.generator(), k))[0] for k in ad])
     sv = [O.limbs_to_int(s) for s in ss]
     sv[0], sv[1], sv[2] = 0, 1, R - 1
+    # the kernels split every scalar by an endomorphism (G1: k1 + k2 (x^2 - 1); G2: four base-|x| digits): digit borders, single digits,
+    # carries into the next digit, and scalars at or above r (reduced first)
+    X = 0xD201000000010000
+    edge = [X - 1, X, X + 1, X * X - 1, X * X, X * X + 1, X ** 3 - 1, X ** 3, X ** 3 + X, X * X - 2, X * X - 1 + X, 2 ** 64 - 1, 2 ** 64, 2 ** 128 - 1,
+            2 ** 128, 2 ** 191, R - X, R - X * X, (X ** 3) * (R // X ** 3), R, R + 5, 2 ** 256 - 1]
+    sv[8:8 + len(edge)] = edge
     A[3] = 0                                              # identity addend
     P[4] = 0                                              # identity point
     A[5] = ops.neg(cv, grp.to_affine(grp.mul(P[5], O.int_to_limbs(sv[5], 4)))[0])    # result is the identity
     A[6] = grp.to_affine(grp.mul(P[6], O.int_to_limbs(sv[6], 4)))[0]                  # addend == product: doubling branch
     out = ops.mul_add(cv, P, sv, A)
     for i in range(n):
-        e = grp.mul(P[i], O.int_to_limbs(sv[i], 4), inf=not P[i].any())
+        e = grp.mul(P[i], O.int_to_limbs(sv[i] % R, 4), inf=not P[i].any())
         if A[i].any():
             e = grp.add(e, grp.mul(A[i], O.int_to_limbs(1, 4)))
         ea, einf = grp.to_affine(e)
         assert (out[i] == (np.zeros_like(ea) if einf else ea)).all(), i
+    # scalars at or above r straight through the ABI (ops.limbs would reduce them): the library reduces before it splits
+    from crypto_amd._native import lib
+    import ctypes as C
+    raw = [R, R + 5, 2 ** 256 - 1, R + X ** 3]
+    rs = np.array([[(v >> (64 * k)) & 0xFFFFFFFFFFFFFFFF for k in range(4)] for v in raw], dtype=np.uint64)
+    Pr = np.ascontiguousarray(P[10:14]); o = np.zeros_like(Pr); oi = np.zeros(4, np.uint8)
+    fn = lib().dgpu_g1_mul_add_batch if curve == "g1" else lib().dgpu_g2_mul_add_batch
+    pp = lambda a: a.ctypes.data_as(C.c_void_p)
+    assert fn(pp(Pr), None, pp(rs), 4, None, None, 4, pp(o), pp(oi)) == 0
+    for i, v in enumerate(raw):
+        ea, einf = grp.to_affine(grp.mul(Pr[i], O.int_to_limbs(v % R, 4)))
+        assert bool(oi[i]) == bool(einf) and (o[i] == (np.zeros_like(ea) if einf else ea)).all(), i
     same = ops.mul_add(cv, P, 0xDEADBEEF)
     for i in (0, 7, n - 1):
         ea, einf = grp.to_affine(grp.mul(P[i], O.int_to_limbs(0xDEADBEEF, 4), inf=not P[i].any()))

@@ -46,18 +46,19 @@ def _gipa(transcript, a, b, mipp, vkey, wkey, r_vec, ip_ab, agg):
         r_left, r_right = m_r[:split], m_r[split:]
         vk_left, vk_right = vkey.split(split)
         wk_left, wk_right = wkey.split(split)
-        # TIPP (utils.rs:83-118) and MIPP for C (utils.rs:51-81): ten multi-pairings and two MSMs, all independent
-        thunks = [lambda: PairCommitment.double(vk_left, wk_right, a_right, b_left),
-                  lambda: PairCommitment.double(vk_right, wk_left, a_left, b_right),
-                  lambda: ops.multi_pairing(a_right, b_left),
-                  lambda: ops.multi_pairing(a_left, b_right)]
+        # TIPP (utils.rs:83-118) and MIPP for C (utils.rs:51-81): ten multi-pairings and two MSMs, all independent — the pairings in
+        # one segmented call (dgpu_multi_miller_loop_segments), the MSMs beside it
+        jobs = PairCommitment.double_jobs(vk_left, wk_right, a_right, b_left) + PairCommitment.double_jobs(vk_right, wk_left, a_left, b_right) \
+            + [(a_right, b_left), (a_left, b_right)]
+        thunks = [lambda: ops.multi_pairings(jobs)]
         for k in names:
-            thunks += [lambda k=k: ops.msm(G1, v_right[k], r_left), lambda k=k: ops.msm(G1, v_left[k], r_right),
-                       lambda k=k: PairCommitment.single(vk_left, v_right[k]), lambda k=k: PairCommitment.single(vk_right, v_left[k])]
+            jobs += PairCommitment.single_jobs(vk_left, v_right[k]) + PairCommitment.single_jobs(vk_right, v_left[k])
+            thunks += [lambda k=k: ops.msm(G1, v_right[k], r_left), lambda k=k: ops.msm(G1, v_left[k], r_right)]
         res = ops.parallel(thunks)
-        tab_l, tab_r, zab_l, zab_r = res[:4]
-        z_lr = {k: (res[4 + 4 * j], res[5 + 4 * j]) for j, k in enumerate(names)}
-        tu_lr = {k: (res[6 + 4 * j], res[7 + 4 * j]) for j, k in enumerate(names)}
+        gts = res[0]
+        tab_l, tab_r, zab_l, zab_r = PairCommitment(gts[0], gts[1]), PairCommitment(gts[2], gts[3]), gts[4], gts[5]
+        z_lr = {k: (res[1 + 2 * j], res[2 + 2 * j]) for j, k in enumerate(names)}
+        tu_lr = {k: (PairCommitment(gts[6 + 4 * j], gts[7 + 4 * j]), PairCommitment(gts[8 + 4 * j], gts[9 + 4 * j])) for j, k in enumerate(names)}
         if i > 0:
             transcript.append(b"c_inv", ops.fr_bytes(c_inv))
             transcript.append(b"zab_l", ops.gt_bytes(zab_l)); transcript.append(b"zab_r", ops.gt_bytes(zab_r))
@@ -125,18 +126,24 @@ def aggregate_proofs(srs, transcript, proofs, with_d=False):
         raise AggregationError("SRS len %d != proofs len %d" % (len(srs.vkey), n))
     a = np.stack([p["a"] for p in proofs]); b = np.stack([p["b"] for p in proofs])
     mipp = {k: np.stack([p[k] for p in proofs]) for k in names}
-    com_ab = PairCommitment.double(srs.vkey, srs.wkey, a, b)
-    com = {k: PairCommitment.single(srs.vkey, mipp[k]) for k in names}
+    jobs = PairCommitment.double_jobs(srs.vkey, srs.wkey, a, b)
+    for k in names:
+        jobs += PairCommitment.single_jobs(srs.vkey, mipp[k])
+    gts = ops.multi_pairings(jobs)                            # :77-88, one segmented call
+    com_ab = PairCommitment(gts[0], gts[1])
+    com = {k: PairCommitment(gts[2 + 2 * j], gts[3 + 2 * j]) for j, k in enumerate(names)}
     transcript.append(b"AB-commitment", com_ab.to_bytes())
     for k in names:
         transcript.append(k.upper().encode() + b"-commitment", com[k].to_bytes())
     r = transcript.challenge_scalar(b"r-random-fiatshamir")
     r_vec = powers(r, n)
     r_inv = powers(inv(r), n)                                 # 1, r^-1, r^-2, ... (the reference batch-inverts r_vec, :101-103)
-    b_r = ops.mul_add(G2, b, r_vec)                           # B^{r^i}   (:107-112)
-    z_ab = ops.multi_pairing(a, b_r)                          # :115
-    agg = {k: ops.msm(G1, mipp[k], r_vec) for k in names}     # :117
-    wkey_r_inv = srs.wkey.scale(r_inv)                        # :120
+    def scaled_b():
+        b_r = ops.mul_add(G2, b, r_vec)                       # B^{r^i}   (:107-112)
+        return b_r, ops.multi_pairing(a, b_r)                 # :115
+    res = ops.parallel([scaled_b, lambda: srs.wkey.scale(r_inv)] + [lambda k=k: ops.msm(G1, mipp[k], r_vec) for k in names])   # :107-120, independent
+    (b_r, z_ab), wkey_r_inv = res[0], res[1]
+    agg = {k: res[2 + j] for j, k in enumerate(names)}
     tmipp = _prove_tipp_mipp(srs, transcript, a, b_r, mipp, wkey_r_inv, r_vec, z_ab, agg)
     out = {"com_ab": com_ab, "z_ab": z_ab, "tmipp": tmipp}
     for k in names:

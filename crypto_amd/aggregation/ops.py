@@ -87,6 +87,11 @@ def multi_pairing(ps, qs):
     return pairing.multi_pairing(pts(G1, ps), pts(G2, qs))
 
 
+def multi_pairings(jobs):
+    """[(ps, qs), ...] -> [GT, ...]: the Miller loops in one launch sequence, the final exponentiations on the library's host threads"""
+    return pairing.multi_pairings([(pts(G1, a), pts(G2, b)) for a, b in jobs])
+
+
 # ---- serialize_compressed of the transcript elements -----------------------------------------------------------------
 def fr_bytes(v):
     return (int(v) % R_MOD).to_bytes(32, "little")

@@ -79,6 +79,21 @@ class PairCommitment:
         n = len(a_vec)
         return PairCommitment(ops.multi_pairing(a_vec, vkey.a[:n]), ops.multi_pairing(a_vec, vkey.b[:n]))
 
+    # the same commitments as lists of (G1 vector, G2 vector) pairing jobs, so that a caller can put several of them into one
+    # ops.multi_pairings call; PairCommitment(*results) rebuilds the value
+    @staticmethod
+    def single_jobs(vkey, a_vec):
+        a_vec = ops.pts(G1, a_vec)
+        vkey.ensure_sufficient_len(a_vec)
+        n = len(a_vec)
+        return [(a_vec, vkey.a[:n]), (a_vec, vkey.b[:n])]
+
+    @staticmethod
+    def double_jobs(vkey, wkey, a, b):
+        a, b = ops.pts(G1, a), ops.pts(G2, b)
+        na, nb = len(a), len(b)
+        return [(np.concatenate([a, wkey.a[:nb]]), np.concatenate([vkey.a[:na], b])), (np.concatenate([a, wkey.b[:nb]]), np.concatenate([vkey.b[:na], b]))]
+
     @staticmethod
     def double(vkey, wkey, a, b):                            # commitment.rs:36-69: prod e(a_i, v_i) e(w_i, b_i)
         a, b = ops.pts(G1, a), ops.pts(G2, b)

@@ -243,12 +243,17 @@ __global__ void __launch_bounds__(256) k_lines_from_prepared(const uint32_t *__r
 // of its q-th Fp2 coefficient — the same order a one-lane Fp12d has in memory.
 typedef Fp6T<Fp2H> Fp6p;
 typedef Fp12T<Fp2H> Fp12p;
-__global__ void __launch_bounds__(64) k_line_products(const uint32_t *__restrict__ lines, size_t n, int slice_len, int nsl, uint32_t *__restrict__ partial) {
+// seg_off != nullptr: nseg independent products over the pairs [seg_off[g], seg_off[g + 1]) of one line buffer (dgpu_multi_miller_loop_segments);
+// partial (g * N_LINES + s) * nsl + j is slice j of step s of segment g, slices past the end of a segment are not written.
+__global__ void __launch_bounds__(64) k_line_products(const uint32_t *__restrict__ lines, size_t n, int slice_len, int nsl, uint32_t *__restrict__ partial,
+                                                      const uint32_t *__restrict__ seg_off, int nseg) {
     const int t = (int)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 1);
     const uint32_t h = threadIdx.x & 1u;
-    if (t >= N_LINES * nsl) return;
-    const int s = t / nsl, j = t % nsl;
-    size_t lo = (size_t)j * slice_len, hi = lo + slice_len; if (hi > n) hi = n;
+    if (t >= N_LINES * nsl * nseg) return;
+    const int sg = t / nsl, j = t % nsl, s = sg % N_LINES, g = sg / N_LINES;
+    const size_t first = seg_off ? seg_off[g] : 0, last = seg_off ? seg_off[g + 1] : n;
+    size_t lo = first + (size_t)j * slice_len, hi = lo + slice_len; if (hi > last) hi = last;
+    if (lo >= hi) return;
     Fp12p f; f12_set_one(f);
     for (size_t i = lo; i < hi; i++) {
         LineT<Fp2H> l;
@@ -269,10 +274,15 @@ __global__ void __launch_bounds__(64) k_line_products(const uint32_t *__restrict
 // out_abi != nullptr: the group result of step s is L_s, written in the ABI form (last level); otherwise it is written back as a
 // partial of the next level: next[(s * ngroups + g) * F12W + k].
 constexpr int F6W = 6 * NL;
-__global__ void __launch_bounds__(192) k_product_tree(const uint32_t *__restrict__ partial, int nsl, int ngroups, uint32_t *__restrict__ next, uint32_t *__restrict__ out_abi) {
+// seg_off != nullptr (one level, ngroups == 1): s runs over (segment, step) and the number of partials is the segment's own slice count.
+__global__ void __launch_bounds__(192) k_product_tree(const uint32_t *__restrict__ partial, int nsl, int ngroups, uint32_t *__restrict__ next, uint32_t *__restrict__ out_abi,
+                                                      const uint32_t *__restrict__ seg_off, int slice_len) {
     __shared__ uint32_t sh[F12W * MAX_SLICES];                        // word k of slot j at sh[k * 64 + j]
     const int s = blockIdx.x / ngroups, grp = blockIdx.x % ngroups, t = threadIdx.x;
-    const int cnt = min(MAX_SLICES, nsl - grp * MAX_SLICES);        // partials in this group
+    int have = nsl;
+    if (seg_off) { const int g = s / N_LINES; have = (int)((seg_off[g + 1] - seg_off[g] + slice_len - 1) / slice_len); }
+    const int cnt = min(MAX_SLICES, have - grp * MAX_SLICES);       // partials in this group
+    if (cnt <= 0) return;                                           // an empty segment: the host writes the neutral element
     if (t < cnt) { const uint32_t *src = partial + ((size_t)s * nsl + grp * MAX_SLICES + t) * F12W; for (int k = 0; k < F12W; k++) sh[k * MAX_SLICES + t] = src[k]; }
     const int role = t >> 6, p = (t & 63) >> 1;
     const uint32_t hh = t & 1u;
@@ -333,6 +343,13 @@ inline int choose_slice_len(size_t n) {
 
 extern "C" {
 
+// conj((...((L_0)^2 L_1)^2 ...)) over the 68 per-step products
+static hostf::Fq12 ml_host_tail(const hostf::Fq12 *L) {
+    hostf::Fq12 f = hostf::Fq12::one(); int idx = 0;
+    for (int b = 62; b >= 0; b--) { f = f.sqr() * L[idx++]; if ((hostf::BLS_X_ABS >> b) & 1) f = f * L[idx++]; }
+    return f.conj();      // x < 0
+}
+
 // K10 + K11 + host tail on the lines already in sl.ml_lines
 static int32_t ml_finish(Slot &sl, size_t n, uint64_t *out) {
     int32_t rc;
@@ -343,22 +360,20 @@ static int32_t ml_finish(Slot &sl, size_t n, uint64_t *out) {
     if ((rc = sl.ml_out.ensure((size_t)N_LINES * 144 * 4))) return rc;
     hipStream_t s = sl.stream;
     { StageTimer st(sl, "ml.products");
-      hipLaunchKernelGGL(k_line_products, dim3((unsigned)((2 * N_LINES * nsl + 63) / 64)), dim3(64), 0, s, sl.ml_lines.as<uint32_t>(), n, slice_len, nsl, sl.ml_partial.as<uint32_t>()); }
+      hipLaunchKernelGGL(k_line_products, dim3((unsigned)((2 * N_LINES * nsl + 63) / 64)), dim3(64), 0, s, sl.ml_lines.as<uint32_t>(), n, slice_len, nsl, sl.ml_partial.as<uint32_t>(), (const uint32_t *)nullptr, 1); }
     { StageTimer st(sl, "ml.tree");
       uint32_t *lvl0 = sl.ml_partial.as<uint32_t>(), *lvl1 = lvl0 + (size_t)N_LINES * nsl * F12W;
-      if (ngroups == 1) hipLaunchKernelGGL(k_product_tree, dim3(N_LINES), dim3(192), 0, s, lvl0, nsl, 1, (uint32_t *)nullptr, sl.ml_out.as<uint32_t>());
+      if (ngroups == 1) hipLaunchKernelGGL(k_product_tree, dim3(N_LINES), dim3(192), 0, s, lvl0, nsl, 1, (uint32_t *)nullptr, sl.ml_out.as<uint32_t>(), (const uint32_t *)nullptr, 0);
       else {
-          hipLaunchKernelGGL(k_product_tree, dim3(N_LINES * ngroups), dim3(192), 0, s, lvl0, nsl, ngroups, lvl1, (uint32_t *)nullptr);
-          hipLaunchKernelGGL(k_product_tree, dim3(N_LINES), dim3(192), 0, s, lvl1, ngroups, 1, (uint32_t *)nullptr, sl.ml_out.as<uint32_t>());
+          hipLaunchKernelGGL(k_product_tree, dim3(N_LINES * ngroups), dim3(192), 0, s, lvl0, nsl, ngroups, lvl1, (uint32_t *)nullptr, (const uint32_t *)nullptr, 0);
+          hipLaunchKernelGGL(k_product_tree, dim3(N_LINES), dim3(192), 0, s, lvl1, ngroups, 1, (uint32_t *)nullptr, sl.ml_out.as<uint32_t>(), (const uint32_t *)nullptr, 0);
       } }
     HIPCHK(hipGetLastError());
     std::vector<hostf::Fq12> L(N_LINES);
     HIPCHK(hipMemcpyAsync(L.data(), sl.ml_out.p, (size_t)N_LINES * 576, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     if (gs.prof) prof_flush(sl);
-    hostf::Fq12 f = hostf::Fq12::one(); int idx = 0;
-    for (int b = 62; b >= 0; b--) { f = f.sqr() * L[idx++]; if ((hostf::BLS_X_ABS >> b) & 1) f = f * L[idx++]; }
-    f = f.conj();      // x < 0
+    const hostf::Fq12 f = ml_host_tail(L.data());
     memcpy(out, &f, sizeof f);
     return DGPU_OK;
 }
@@ -393,6 +408,82 @@ int32_t dgpu_multi_miller_loop(const uint64_t *p, const uint64_t *q, const uint8
       else hipLaunchKernelGGL(k_miller_lines_quad, dim3((unsigned)((4 * n + 63) / 64)), dim3(64), 0, s, sl.in_bases.as<uint32_t>(), sl.in_scalars.as<uint32_t>(), dskip, n, sl.ml_lines.as<uint32_t>(), n);
     }
     return ml_finish(sl, n, out);
+}
+
+// nseg independent Miller loops in one call: segment g is the pairs [seg_end[g - 1], seg_end[g]) (seg_end ascending, seg_end[nseg - 1] == n;
+// an empty segment yields one).  The ten `E::multi_pairing` calls of a GIPA round (legogroth16/src/aggregation/commitment.rs:30-31,54-67,
+// aggregation/utils.rs:95-96, issued under rayon in the reference) have 1 ... n/2 pairs each, and every launch of the line kernel lasts as
+// long as its 68 dependent steps whatever the pair count: one line launch over all the pairs, one product launch and one tree launch over
+// (segment, step), the nseg host tails on host threads.  out_f12: nseg x 72 words, each limb for limb what dgpu_multi_miller_loop
+// returns for that segment alone.
+static int32_t ml_segments(const uint64_t *p, const uint64_t *q, const uint8_t *skip, size_t n, const uint64_t *seg_end, size_t nseg, uint64_t *out, bool final_exp) {
+    if (!out || !seg_end || nseg == 0 || (n && (!p || !q)) || n >= (1ull << 24) || nseg > 4096) return DGPU_E_BADARG;
+    size_t maxlen = 0;
+    { uint64_t prev = 0; for (size_t g = 0; g < nseg; g++) { if (seg_end[g] < prev || seg_end[g] > n) return DGPU_E_BADARG; maxlen = std::max<size_t>(maxlen, seg_end[g] - prev); prev = seg_end[g]; }
+      if (prev != n) return DGPU_E_BADARG; }
+    // (the Miller output is never zero, so the final exponentiation cannot fail: arkworks' multi_pairing unwraps it too)
+    auto finish = [&](uint64_t *o) { if (final_exp) { hostf::Fq12 f, r; memcpy(&f, o, sizeof f); hostf::final_exponentiation(r, f); memcpy(o, &r, sizeof r); } };
+    if (nseg == 1 || maxlen > 8192) {                      // long segments fill the chip on their own: one call each
+        uint64_t prev = 0;
+        for (size_t g = 0; g < nseg; g++) {
+            const int32_t rc = dgpu_multi_miller_loop(p + prev * 12, q + prev * 24, skip ? skip + prev : nullptr, seg_end[g] - prev, out + g * 72);
+            if (rc) return rc;
+            finish(out + g * 72);
+            prev = seg_end[g];
+        }
+        return DGPU_OK;
+    }
+    const hostf::Fq12 one = hostf::Fq12::one();
+    if (n == 0) { for (size_t g = 0; g < nseg; g++) memcpy(out + g * 72, &one, sizeof one); return DGPU_OK; }
+    if (!cur().ready) return DGPU_E_NODEVICE;
+    SlotLock slot_lock; Slot &sl = *slot_lock.s;
+    HIPCHK(hipSetDevice(cur().device));
+    int32_t rc;
+    int slice_len = 4;
+    while ((maxlen + slice_len - 1) / slice_len > MAX_SLICES) slice_len *= 2;          // one tree level: at most 64 slices per (segment, step)
+    const int nsl = (int)((maxlen + slice_len - 1) / slice_len);
+    std::vector<uint32_t> off(nseg + 1, 0);
+    for (size_t g = 0; g < nseg; g++) off[g + 1] = (uint32_t)seg_end[g];
+    if ((rc = sl.in_bases.ensure(n * 96))) return rc;
+    if ((rc = sl.in_scalars.ensure(n * 192))) return rc;
+    if ((rc = sl.in_inf.ensure(n + (nseg + 1) * 4 + 8))) return rc;
+    if ((rc = sl.ml_lines.ensure((size_t)N_LINES * LW * n * 4))) return rc;
+    if ((rc = sl.ml_partial.ensure((size_t)N_LINES * nseg * nsl * F12W * 4))) return rc;
+    if ((rc = sl.ml_out.ensure((size_t)N_LINES * nseg * 144 * 4))) return rc;
+    hipStream_t s = sl.stream;
+    HIPCHK(hipMemcpyAsync(sl.in_bases.p, p, n * 96, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(sl.in_scalars.p, q, n * 192, hipMemcpyHostToDevice, s));
+    const uint8_t *dskip = nullptr;
+    if (skip) { HIPCHK(hipMemcpyAsync(sl.in_inf.p, skip, n, hipMemcpyHostToDevice, s)); dskip = sl.in_inf.as<uint8_t>(); }
+    uint32_t *doff = (uint32_t *)(sl.in_inf.as<uint8_t>() + ((n + 7) & ~(size_t)7));
+    HIPCHK(hipMemcpyAsync(doff, off.data(), (nseg + 1) * 4, hipMemcpyHostToDevice, s));
+    { StageTimer st(sl, "ml.lines");
+      if (n > 8192) hipLaunchKernelGGL(k_miller_lines_pair, dim3((unsigned)((2 * n + 63) / 64)), dim3(64), 0, s, sl.in_bases.as<uint32_t>(), sl.in_scalars.as<uint32_t>(), dskip, n, sl.ml_lines.as<uint32_t>(), n);
+      else hipLaunchKernelGGL(k_miller_lines_quad, dim3((unsigned)((4 * n + 63) / 64)), dim3(64), 0, s, sl.in_bases.as<uint32_t>(), sl.in_scalars.as<uint32_t>(), dskip, n, sl.ml_lines.as<uint32_t>(), n); }
+    { StageTimer st(sl, "ml.products");
+      hipLaunchKernelGGL(k_line_products, dim3((unsigned)((2 * (size_t)N_LINES * nsl * nseg + 63) / 64)), dim3(64), 0, s, sl.ml_lines.as<uint32_t>(), n, slice_len, nsl, sl.ml_partial.as<uint32_t>(), doff, (int)nseg); }
+    { StageTimer st(sl, "ml.tree");
+      hipLaunchKernelGGL(k_product_tree, dim3((unsigned)(N_LINES * nseg)), dim3(192), 0, s, sl.ml_partial.as<uint32_t>(), nsl, 1, (uint32_t *)nullptr, sl.ml_out.as<uint32_t>(), doff, slice_len); }
+    HIPCHK(hipGetLastError());
+    std::vector<hostf::Fq12> L((size_t)N_LINES * nseg);
+    HIPCHK(hipMemcpyAsync(L.data(), sl.ml_out.p, (size_t)N_LINES * nseg * 576, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (gs.prof) prof_flush(sl);
+    auto tail = [&](size_t g) { const hostf::Fq12 f = off[g + 1] == off[g] ? one : ml_host_tail(&L[g * N_LINES]); memcpy(out + g * 72, &f, sizeof f); finish(out + g * 72); };
+    const size_t T = std::min<size_t>(std::min<size_t>(nseg, 16), std::max<size_t>(1, std::thread::hardware_concurrency()));
+    std::vector<std::thread> th;
+    for (size_t k = 1; k < T; k++) th.emplace_back([&, k]() { for (size_t g = k; g < nseg; g += T) tail(g); });
+    for (size_t g = 0; g < nseg; g += T) tail(g);
+    for (auto &t : th) t.join();
+    return DGPU_OK;
+}
+
+int32_t dgpu_multi_miller_loop_segments(const uint64_t *p, const uint64_t *q, const uint8_t *skip, size_t n, const uint64_t *seg_end, size_t nseg, uint64_t *out) {
+    return ml_segments(p, q, skip, n, seg_end, nseg, out, false);
+}
+// E::multi_pairing per segment: the final exponentiation of every Miller output on the host thread that assembled it
+int32_t dgpu_multi_pairing_segments(const uint64_t *p, const uint64_t *q, const uint8_t *skip, size_t n, const uint64_t *seg_end, size_t nseg, uint64_t *out) {
+    return ml_segments(p, q, skip, n, seg_end, nseg, out, true);
 }
 
 // pairs chunked over the process's device contexts (SURVEY 8e "Miller loop": pairs are independent, the per-device raw outputs multiply —

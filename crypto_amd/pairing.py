@@ -149,6 +149,31 @@ def multi_miller_loop_sharded(ps, qs, skip=None, ngpus=0):
     return out
 
 
+def multi_miller_loops(jobs, final_exp=False):
+    """[(ps, qs), ...] -> the raw Miller output of every job, all of them in ONE call (dgpu_multi_miller_loop_segments): the
+    `multi_pairing`s the aggregation issues side by side under rayon (legogroth16/src/aggregation/commitment.rs:30-31,54-67).
+    final_exp: the GT elements instead (dgpu_multi_pairing_segments)."""
+    _ensure()
+    P = [np.ascontiguousarray(ps, dtype=np.uint64).reshape(-1, 12) for ps, _ in jobs]
+    Q = [np.ascontiguousarray(qs, dtype=np.uint64).reshape(-1, 24) for _, qs in jobs]
+    if any(len(a) != len(b) for a, b in zip(P, Q)):
+        raise DockGpuError(-7, "multi_miller_loops")
+    if not jobs:
+        return []
+    ends = np.cumsum([len(a) for a in P]).astype(np.uint64)
+    pa, qa = np.ascontiguousarray(np.concatenate(P)), np.ascontiguousarray(np.concatenate(Q))
+    out = np.zeros((len(jobs), 72), dtype=np.uint64)
+    fn = lib().dgpu_multi_pairing_segments if final_exp else lib().dgpu_multi_miller_loop_segments
+    rc = fn(_p(pa), _p(qa), None, len(pa), _p(ends), len(jobs), _p(out))
+    if rc:
+        raise DockGpuError(rc, "dgpu_multi_pairing_segments" if final_exp else "dgpu_multi_miller_loop_segments")
+    return list(out)
+
+
+def multi_pairings(jobs):
+    return multi_miller_loops(jobs, final_exp=True)
+
+
 def final_exponentiation(f):
     f = np.ascontiguousarray(f, dtype=np.uint64)
     out = np.zeros(72, dtype=np.uint64)

@@ -165,6 +165,16 @@ int32_t dgpu_multi_miller_loop_prepared(const uint64_t *p_xy /* n*12 */, const u
 int32_t dgpu_multi_miller_loop_mixed(const uint64_t *p_aff /* n_aff x 12 */, const uint64_t *q_aff /* n_aff x 24 */, const uint8_t *skip_aff, size_t n_aff,
                                      const uint64_t *p_prep /* n_prep x 12 */, const uint64_t *coeffs /* n_prep x DGPU_G2_PREPARED_WORDS */, const uint8_t *skip_prep, size_t n_prep,
                                      uint64_t out_f12[72]);
+/* nseg independent Miller loops in one call: segment g is the pairs [seg_end[g - 1], seg_end[g]) (ascending, seg_end[nseg - 1] == n; an empty
+ * segment yields one); out_f12 = nseg x 72 words, each what dgpu_multi_miller_loop returns for that segment alone.  Serves the
+ * `E::multi_pairing` calls the aggregation issues side by side under rayon (legogroth16/src/aggregation/commitment.rs:30-31,54-67,
+ * aggregation/utils.rs:95-96: ten per GIPA round, 1 ... n/2 pairs each): a line-kernel launch lasts as long as its 68 dependent steps
+ * whatever the pair count, so the segments share one. */
+int32_t dgpu_multi_miller_loop_segments(const uint64_t *p_xy, const uint64_t *q_xy, const uint8_t *skip, size_t n,
+                                        const uint64_t *seg_end, size_t nseg, uint64_t *out_f12 /* nseg x 72 */);
+/* the same followed by the final exponentiation of every segment (E::multi_pairing), on the host threads that assemble the Miller outputs */
+int32_t dgpu_multi_pairing_segments(const uint64_t *p_xy, const uint64_t *q_xy, const uint8_t *skip, size_t n,
+                                    const uint64_t *seg_end, size_t nseg, uint64_t *out_gt /* nseg x 72 */);
 /* the same with the pairs chunked over the process's device contexts (ngpus = 0: all of them), raw outputs multiplied on the host */
 int32_t dgpu_multi_miller_loop_sharded(const uint64_t *p_xy, const uint64_t *q_xy, const uint8_t *skip, size_t n, int32_t ngpus, uint64_t out_f12[72]);
 /* replaces Bls12_381::final_exponentiation — utils/src/randomized_pairing_check.rs:213 (host code, once per batch) */

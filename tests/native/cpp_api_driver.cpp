@@ -90,6 +90,19 @@ int main() {
         EXPECT(dgpu_multi_miller_loop_mixed(nullptr, nullptr, nullptr, 0, b1.data() + 120, co.data(), cinf.data(), np, f2.data()) == DGPU_OK && f2 == eml);
         EXPECT(dgpu_multi_miller_loop_mixed(b1.data() + 120, b2.data() + 240, nullptr, np, nullptr, nullptr, nullptr, 0, f2.data()) == DGPU_OK && f2 == eml);
         EXPECT(dgpu_multi_miller_loop_mixed(nullptr, nullptr, nullptr, 3, nullptr, nullptr, nullptr, 0, f2.data()) == DGPU_E_BADARG);
+        // three independent products in one call (an empty one in the middle), raw and finally exponentiated
+        {
+            const uint64_t ends[3] = {na, na, np};
+            std::vector<uint64_t> seg(3 * 72), gt(3 * 72); Fq12 s0{}, s2{}, g2{};
+            EXPECT(dgpu_multi_miller_loop_segments(b1.data() + 120, b2.data() + 240, nullptr, np, ends, 3, seg.data()) == DGPU_OK);
+            EXPECT(dgpu_multi_miller_loop(b1.data() + 120, b2.data() + 240, nullptr, na, s0.data()) == DGPU_OK && std::memcmp(seg.data(), s0.data(), 576) == 0);
+            EXPECT(dgpu_multi_miller_loop(b1.data() + 120 + 12 * na, b2.data() + 240 + 24 * na, nullptr, np - na, s2.data()) == DGPU_OK && std::memcmp(seg.data() + 144, s2.data(), 576) == 0);
+            EXPECT(dgpu_multi_pairing_segments(b1.data() + 120, b2.data() + 240, nullptr, np, ends, 3, gt.data()) == DGPU_OK);
+            EXPECT(dgpu_final_exponentiation(s2.data(), g2.data()) == DGPU_OK && std::memcmp(gt.data() + 144, g2.data(), 576) == 0);
+            EXPECT(std::memcmp(gt.data() + 72, seg.data() + 72, 576) == 0);          // the empty product: one, before and after
+            const uint64_t bad[2] = {na, np - 1};
+            EXPECT(dgpu_multi_miller_loop_segments(b1.data() + 120, b2.data() + 240, nullptr, np, bad, 2, seg.data()) == DGPU_E_BADARG);
+        }
         uint64_t lc[18], el[18];
         EXPECT(dgpu_lincomb_g1(b1.data(), inf1.data(), sc.data(), 9, lc) == DGPU_OK);
         orc_g1_msm(b1.data(), inf1.data(), sc.data(), 9, 1, el);

@@ -164,3 +164,43 @@ def test_mixed_affine_and_prepared_operands_in_one_call(n):
         assert (pairing.multi_miller_loop(ps, items, skip) == sk_ref).all() and not (sk_ref == ref).all()
     with pytest.raises(ca.DockGpuError):
         pairing.multi_miller_loop(ps, [qs[:1], pc[2:]])                     # one operand short
+
+
+@pytest.mark.parametrize("sizes", [[1, 1], [0, 3, 0, 1, 7], [5, 64, 65, 2, 256, 257, 1], [1, 2, 4, 8, 16, 32, 64, 128, 256, 512], [3000, 1, 0, 900], [9000, 4, 17]])
+def test_segmented_miller_loops_equal_the_single_calls(sizes):
+    """dgpu_multi_miller_loop_segments: every segment's raw Fp12 output is limb for limb what dgpu_multi_miller_loop returns for that segment
+    alone — empty segments (one), single pairs, sizes around the slice and group borders, identity members, skip flags, a segment long enough
+    for the per-segment path, and the argument checks."""
+    import ctypes as C
+    from crypto_amd import pairing
+    from crypto_amd._native import lib
+    n = sum(sizes)
+    k0 = O.rand_scalars(71, 1)[0]; d = O.rand_scalars(72, 1)[0]
+    ps = O.G1.gen_seq(k0, d, n, threads=16); qs = O.G2.gen_seq(d, k0, n, threads=16)
+    if n > 12:
+        ps[3] = 0; qs[n - 2] = 0
+    ends = np.cumsum(sizes); starts = ends - np.array(sizes)
+    jobs = [(ps[a:b], qs[a:b]) for a, b in zip(starts, ends)]
+    got = pairing.multi_miller_loops(jobs)
+    assert len(got) == len(sizes)
+    for (a, b), f in zip(zip(starts, ends), got):
+        assert (f == ca.multi_miller_loop(ps[a:b], qs[a:b])).all(), (a, b)
+    gts = pairing.multi_pairings(jobs)
+    for f, g in zip(got, gts):
+        assert (g == ca.final_exponentiation(f)).all()
+    if n <= 1100:       # and the oracle itself on the largest segment
+        a, b = max(zip(starts, ends), key=lambda ab: ab[1] - ab[0])
+        sk = np.array([0 if (p.any() and q.any()) else 1 for p, q in zip(ps[a:b], qs[a:b])], np.uint8)
+        assert (got[list(ends).index(b)] == O.multi_miller_loop(ps[a:b], qs[a:b], sk, threads=16)).all()
+    p_ = lambda x: x.ctypes.data_as(C.c_void_p)
+    skip = (np.arange(n) % 5 == 1).astype(np.uint8)
+    e64 = ends.astype(np.uint64); out = np.zeros((len(sizes), 72), np.uint64)
+    assert lib().dgpu_multi_miller_loop_segments(p_(ps), p_(qs), p_(skip), n, p_(e64), len(sizes), p_(out)) == 0
+    for k, (a, b) in enumerate(zip(starts, ends)):
+        assert (out[k] == ca.multi_miller_loop(ps[a:b], qs[a:b], skip[a:b])).all(), k
+    bad = e64.copy(); bad[-1] = n - 1 if n else 1
+    assert lib().dgpu_multi_miller_loop_segments(p_(ps), p_(qs), None, n, p_(bad), len(sizes), p_(out)) == -3       # last end != n
+    if len(sizes) > 2 and sizes[1]:
+        bad = e64.copy(); bad[0], bad[1] = bad[1], bad[0]
+        assert lib().dgpu_multi_miller_loop_segments(p_(ps), p_(qs), None, n, p_(bad), len(sizes), p_(out)) == -3   # not ascending
+    assert lib().dgpu_multi_miller_loop_segments(p_(ps), p_(qs), None, n, p_(e64), 0, p_(out)) == -3

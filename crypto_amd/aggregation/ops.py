@@ -149,7 +149,7 @@ _HOST_POOL = None
 
 def parallel(thunks, host=False):
     """run independent ABI calls from host threads (the library keeps six calls in flight on separate HIP streams, further callers queue for a slot;
-    ctypes drops the GIL) — the reference runs the same calls under rayon.  host=True: calls that only use host cores (wider pool)."""
+    ctypes drops the GIL) — the reference issues them one after another, each rayon-parallel inside.  host=True: calls that only use host cores (wider pool)."""
     global _POOL, _HOST_POOL
     from concurrent.futures import ThreadPoolExecutor
     if host:

@@ -412,7 +412,7 @@ int32_t dgpu_multi_miller_loop(const uint64_t *p, const uint64_t *q, const uint8
 
 // nseg independent Miller loops in one call: segment g is the pairs [seg_end[g - 1], seg_end[g]) (seg_end ascending, seg_end[nseg - 1] == n;
 // an empty segment yields one).  The ten `E::multi_pairing` calls of a GIPA round (legogroth16/src/aggregation/commitment.rs:30-31,54-67,
-// aggregation/utils.rs:95-96, issued under rayon in the reference) have 1 ... n/2 pairs each, and every launch of the line kernel lasts as
+// aggregation/utils.rs:95-96, issued one after another in the reference) have 1 ... n/2 pairs each, and every launch of the line kernel lasts as
 // long as its 68 dependent steps whatever the pair count: one line launch over all the pairs, one product launch and one tree launch over
 // (segment, step), the nseg host tails on host threads.  out_f12: nseg x 72 words, each limb for limb what dgpu_multi_miller_loop
 // returns for that segment alone.

@@ -151,7 +151,7 @@ def multi_miller_loop_sharded(ps, qs, skip=None, ngpus=0):
 
 def multi_miller_loops(jobs, final_exp=False):
     """[(ps, qs), ...] -> the raw Miller output of every job, all of them in ONE call (dgpu_multi_miller_loop_segments): the
-    `multi_pairing`s the aggregation issues side by side under rayon (legogroth16/src/aggregation/commitment.rs:30-31,54-67).
+    mutually independent `multi_pairing`s the aggregation issues one after another (legogroth16/src/aggregation/commitment.rs:30-31,54-67).
     final_exp: the GT elements instead (dgpu_multi_pairing_segments)."""
     _ensure()
     P = [np.ascontiguousarray(ps, dtype=np.uint64).reshape(-1, 12) for ps, _ in jobs]

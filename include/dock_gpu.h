@@ -167,7 +167,7 @@ int32_t dgpu_multi_miller_loop_mixed(const uint64_t *p_aff /* n_aff x 12 */, con
                                      uint64_t out_f12[72]);
 /* nseg independent Miller loops in one call: segment g is the pairs [seg_end[g - 1], seg_end[g]) (ascending, seg_end[nseg - 1] == n; an empty
  * segment yields one); out_f12 = nseg x 72 words, each what dgpu_multi_miller_loop returns for that segment alone.  Serves the
- * `E::multi_pairing` calls the aggregation issues side by side under rayon (legogroth16/src/aggregation/commitment.rs:30-31,54-67,
+ * mutually independent `E::multi_pairing` calls the aggregation issues one after another (legogroth16/src/aggregation/commitment.rs:30-31,54-67,
  * aggregation/utils.rs:95-96: ten per GIPA round, 1 ... n/2 pairs each): a line-kernel launch lasts as long as its 68 dependent steps
  * whatever the pair count, so the segments share one. */
 int32_t dgpu_multi_miller_loop_segments(const uint64_t *p_xy, const uint64_t *q_xy, const uint8_t *skip, size_t n,

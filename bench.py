@@ -425,6 +425,18 @@ def secondary_configs(log2n, ks, scalars, db, ds, pool):
     res["verify_1024_proofs_pairing_checker_ms"] = round(timed(lambda: LGv.verify_proofs_batch(pvkv, proofs_v, pubs_v, 0x5EED0028), 3), 2)
     res["verify_1024_proofs_merged_ms"] = round(timed(lambda: LGv.verify_proofs_batch_merged(pvkv, proofs_v, pubs_v, 0x5EED0029), 3), 2)
     res["verify_proofs_per_s_merged"] = round(nv / res["verify_1024_proofs_merged_ms"] * 1e3, 0)
+    # -- SnarkPack aggregation of the same 1024 LegoGroth16 proofs (aggregation/legogroth16/prover.rs:38-127: TIPP for (A, B), MIPP for
+    #    C and D, the KZG openings) and verification of the aggregate (verifier.rs:34-96) — the producer of the segmented Miller loops and
+    #    of the endomorphism-split folding steps
+    from crypto_amd import aggregation as AGv
+    from crypto_amd.aggregation import legogroth16 as ALv
+    s_al, s_be = ints(0x5EED002A, 2)
+    pk_ag, vsrs_ag = AGv.setup_fake_srs(s_al, s_be, nv, gen1[0], gen2[0]).specialize(nv)
+    pubs_int = [[x] for x in xv]
+    agg_v = ALv.aggregate_proofs(pk_ag, AGv.MerlinTranscript(b"bench"), proofs_v)
+    ALv.verify_aggregate_proof(vsrs_ag, {"vk": vkv}, pubs_int, agg_v, 0x5EED002B, AGv.MerlinTranscript(b"bench"))      # raises if invalid
+    res["snarkpack_aggregate_1024_proofs_ms"] = round(timed(lambda: ALv.aggregate_proofs(pk_ag, AGv.MerlinTranscript(b"bench"), proofs_v), 3), 2)
+    res["snarkpack_verify_aggregate_ms"] = round(timed(lambda: ALv.verify_aggregate_proof(vsrs_ag, {"vk": vkv}, pubs_int, agg_v, 0x5EED002C, AGv.MerlinTranscript(b"bench")), 3), 2)
     # -- BASELINE config 4: witness map on the x_i = x_{i-1}^2 + i circuit shape (m + 1 constraints + 2 instance variables = D), circuit resident,
     #    and LegoGroth16 create_proof (prover.rs:267-383) on a synthetic key of that size with every query a precomputed table
     m = n - 3

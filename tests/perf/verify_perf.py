@@ -42,6 +42,11 @@ ts = []
 for _ in range(5):
     t0 = time.perf_counter(); ok = batch_verify(proofs, pubs); ts.append(time.perf_counter() - t0); assert ok
 t = sorted(ts)[2]
+if os.environ.get("PROF"):
+    import cProfile, pstats, io
+    ca.prof.enable(True); ca.prof.reset(); pr = cProfile.Profile(); pr.enable(); batch_verify(proofs, pubs); pr.disable()
+    print("device ms / calls:", {k: (round(v[0], 2), v[1]) for k, v in sorted(ca.prof.read().items(), key=lambda kv: -kv[1][0])}); ca.prof.enable(False)
+    st = io.StringIO(); pstats.Stats(pr, stream=st).sort_stats("tottime").print_stats(14); print(st.getvalue()[:3500])
 t1 = time.perf_counter(); single = all(LG.verify_proof(pvk, p, x) for p, x in zip(proofs[:64], pubs[:64])); t1 = (time.perf_counter() - t1) / 64
 tm = []
 assert LG.verify_proofs_batch_merged(pvk, proofs, pubs, rnd()) and not LG.verify_proofs_batch_merged(pvk, bad, pubs, rnd())

@@ -1,5 +1,6 @@
+"""Fixed-base batch timing (development helper, GPU box): 2^20 products of one base in G1 and G2 through WindowTable.multiply_many with the per-stage device times."""
 import sys, time, os
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/oracle")
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np, crypto_amd as ca, oracle_c as O
 from crypto_amd import fixed_base as FB
 ca.init(0)

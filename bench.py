@@ -487,6 +487,14 @@ def secondary_configs(log2n, ks, scalars, db, ds, pool):
     assert all((prove()[k] == p0[k]).all() for k in p0)
     res["prove_2p20_ms"] = round(ms, 2)
     res["prove_constraints_per_s"] = round((m + 1) / (ms * 1e-3), 1)
+    # a proving service's rate: four proofs in flight from host threads (the library queues calls beyond its six slots); every proof equal to p0
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(4) as ex:
+        list(ex.map(lambda _: prove(), range(8)))
+        t0 = time.perf_counter(); many = list(ex.map(lambda _: prove(), range(16))); ms4 = (time.perf_counter() - t0) / 16 * 1e3
+    assert all((q[k] == p0[k]).all() for q in many for k in p0)
+    res["prove_2p20_ms_per_proof_4_in_flight"] = round(ms4, 2)
+    res["prove_constraints_per_s_4_in_flight"] = round((m + 1) / (ms4 * 1e-3), 1)
     # the reference's timer spans (prover.rs:284-369, :578), each stage alone and in the reference's order (one call in flight)
     from crypto_amd import sharded as SH
     dz = ca.DeviceScalars(z)

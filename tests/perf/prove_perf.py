@@ -47,3 +47,11 @@ for name, fn in (("witness map, then MSMs", seq), ("witness map overlapped", ovl
         t0 = time.perf_counter(); p = fn(); ts.append((time.perf_counter() - t0) * 1e3)
     assert all((p[k] == ref[k]).all() for k in ref)
     print("%-26s table=%d wc=%d hc=%d  median %.2f ms  min %.2f  max %.2f  (%.1f M constraints/s)" % (name, table, wc, hc, sorted(ts)[4], min(ts), max(ts), (m + 1) / sorted(ts)[4] / 1e3), flush=True)
+if os.environ.get("INFLIGHT"):          # proofs per second with K proofs in flight (host threads; the library queues calls beyond its six slots)
+    from concurrent.futures import ThreadPoolExecutor
+    for K in [int(x) for x in os.environ["INFLIGHT"].split(",")]:
+        with ThreadPoolExecutor(K) as ex:
+            list(ex.map(lambda _: ovl(), range(2 * K)))
+            t0 = time.perf_counter(); res = list(ex.map(lambda _: ovl(), range(16))); dt = (time.perf_counter() - t0) / 16 * 1e3
+        assert all((r[k] == ref[k]).all() for r in res for k in ref)
+        print("%d proofs in flight: %.2f ms per proof (%.1f M constraints/s)" % (K, dt, (m + 1) / dt / 1e3), flush=True)

@@ -18,3 +18,15 @@ for n in [int(x) for x in os.environ.get("NS", "3,64,1024,4096,8192").split(",")
     dt = (time.perf_counter() - t0) / 10 * 1e3
     st = ca.prof.read(); ca.prof.enable(False)
     print("pairs=%5d  %.3f ms (%.0f pairs/s) | %s" % (n, dt, n / dt * 1e3, " ".join("%s=%.3f" % (k, v[0] / max(1, v[1])) for k, v in st.items())), flush=True)
+if os.environ.get("INFLIGHT"):          # K callers, each a 1024-pair loop
+    from concurrent.futures import ThreadPoolExecutor
+    n = 1024
+    with FB.WindowTable(ca.G2, gen2[0]) as t2, FB.WindowTable(ca.G1, gen1[0]) as t1:
+        P, _ = t1.multiply_many(B.seeded_scalars(5, n)); Q, _ = t2.multiply_many(B.seeded_scalars(6, n))
+    ref = ca.multi_miller_loop(P, Q)
+    for K in [int(x) for x in os.environ["INFLIGHT"].split(",")]:
+        with ThreadPoolExecutor(K) as ex:
+            list(ex.map(lambda _: ca.multi_miller_loop(P, Q), range(4 * K)))
+            t0 = time.perf_counter(); res = list(ex.map(lambda _: ca.multi_miller_loop(P, Q), range(60))); dt = (time.perf_counter() - t0) / 60 * 1e3
+        assert all((r == ref).all() for r in res)
+        print("%d calls in flight: %.3f ms per 1024-pair loop (%.0f pairs/s)" % (K, dt, n / dt * 1e3), flush=True)

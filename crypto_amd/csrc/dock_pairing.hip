@@ -17,6 +17,7 @@
 #include "fp2_pair.cuh"
 #include "sort_launch.cuh"
 #include <thread>
+#include <atomic>
 
 namespace bls29 {
 __device__ __forceinline__ void fhalf(Fp2H &r, const Fp2H &a) { fp_half(r.v, a.v); }   // lane-pair form of pairing29.cuh's halving
@@ -425,8 +426,14 @@ static int32_t ml_segments(const uint64_t *p, const uint64_t *q, const uint8_t *
     size_t maxlen = 0;
     { uint64_t prev = 0; for (size_t g = 0; g < nseg; g++) { if (seg_end[g] < prev || seg_end[g] > n) return DGPU_E_BADARG; maxlen = std::max<size_t>(maxlen, seg_end[g] - prev); prev = seg_end[g]; }
       if (prev != n) return DGPU_E_BADARG; }
-    // (the Miller output is never zero, so the final exponentiation cannot fail: arkworks' multi_pairing unwraps it too)
-    auto finish = [&](uint64_t *o) { if (final_exp) { hostf::Fq12 f, r; memcpy(&f, o, sizeof f); hostf::final_exponentiation(r, f); memcpy(o, &r, sizeof r); } };
+    // (a Miller output of valid operands is never zero; arkworks' multi_pairing unwraps the Option — here a zero is DGPU_E_ZERO for the call)
+    std::atomic<bool> zero{false};
+    auto finish = [&](uint64_t *o) {
+        if (!final_exp) return;
+        hostf::Fq12 f, r; memcpy(&f, o, sizeof f);
+        if (!hostf::final_exponentiation(r, f)) { zero = true; return; }
+        memcpy(o, &r, sizeof r);
+    };
     if (nseg == 1 || maxlen > 8192) {                      // long segments fill the chip on their own: one call each
         uint64_t prev = 0;
         for (size_t g = 0; g < nseg; g++) {
@@ -435,7 +442,7 @@ static int32_t ml_segments(const uint64_t *p, const uint64_t *q, const uint8_t *
             finish(out + g * 72);
             prev = seg_end[g];
         }
-        return DGPU_OK;
+        return zero ? DGPU_E_ZERO : DGPU_OK;
     }
     const hostf::Fq12 one = hostf::Fq12::one();
     if (n == 0) { for (size_t g = 0; g < nseg; g++) memcpy(out + g * 72, &one, sizeof one); return DGPU_OK; }
@@ -479,7 +486,7 @@ static int32_t ml_segments(const uint64_t *p, const uint64_t *q, const uint8_t *
     for (size_t k = 1; k < T; k++) th.emplace_back([&, k]() { for (size_t g = k; g < nseg; g += T) tail(g); });
     for (size_t g = 0; g < nseg; g += T) tail(g);
     for (auto &t : th) t.join();
-    return DGPU_OK;
+    return zero ? DGPU_E_ZERO : DGPU_OK;
 }
 
 int32_t dgpu_multi_miller_loop_segments(const uint64_t *p, const uint64_t *q, const uint8_t *skip, size_t n, const uint64_t *seg_end, size_t nseg, uint64_t *out) {

@@ -172,7 +172,8 @@ int32_t dgpu_multi_miller_loop_mixed(const uint64_t *p_aff /* n_aff x 12 */, con
  * whatever the pair count, so the segments share one. */
 int32_t dgpu_multi_miller_loop_segments(const uint64_t *p_xy, const uint64_t *q_xy, const uint8_t *skip, size_t n,
                                         const uint64_t *seg_end, size_t nseg, uint64_t *out_f12 /* nseg x 72 */);
-/* the same followed by the final exponentiation of every segment (E::multi_pairing), on the host threads that assemble the Miller outputs */
+/* the same followed by the final exponentiation of every segment (E::multi_pairing), on the host threads that assemble the Miller outputs;
+ * DGPU_E_ZERO if a Miller output is zero (arkworks' multi_pairing would panic on the `None`: cannot happen for points of G1 x G2) */
 int32_t dgpu_multi_pairing_segments(const uint64_t *p_xy, const uint64_t *q_xy, const uint8_t *skip, size_t n,
                                     const uint64_t *seg_end, size_t nseg, uint64_t *out_gt /* nseg x 72 */);
 /* the same with the pairs chunked over the process's device contexts (ngpus = 0: all of them), raw outputs multiplied on the host */

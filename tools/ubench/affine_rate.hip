@@ -4,7 +4,7 @@
 // An affine addition P + Q needs 1 / (x2 - x1).  Montgomery's trick shares one inversion among K independent additions at 3 extra products
 // each, but the K prefix products must stay alive between the forward and the backward sweep (14 registers each) and the operands are read
 // twice.  Variants measured here, K additions per lane per round:
-//   mode 0  one Fermat inversion per lane and round                       (inversion amortised over K only)
+//   mode 0  one inversion (fp_inv_device) per lane and round                      (inversion amortised over K only)
 //   mode 1  inversion replaced by a copy                                  (upper bound: an inversion that costs nothing)
 //   mode 2  one inversion per 256-lane block: product tree through LDS, one wave inverts while three wait   (the realistic sharing)
 // against madd<2w> of madd_rate.hip (the production kernel's core).  Arithmetic is data independent, so random limbs serve as points.
@@ -98,7 +98,7 @@ int main() {
     CK(hipMemcpy(d, h.data(), h.size() * 4, hipMemcpyHostToDevice));
     for (int blocks : {1024, 2048}) {
         float ms = timeit([&] { hipLaunchKernelGGL(k_inv, dim3(blocks), dim3(256), 0, 0, d, o, 2); }, 2);
-        printf("fp_inv (Fermat)      blocks=%4d  %.3f ms  %.4f Ginv/s  = %.0f fp_mul-times per inversion at 63 Gmul/s\n", blocks, ms, (double)blocks * 256 * 2 / ms * 1e-6, 63.0 / ((double)blocks * 256 * 2 / ms * 1e-6));
+        printf("fp_inv (div. steps)     blocks=%4d  %.3f ms  %.4f Ginv/s  = %.0f fp_mul-times per inversion at 63 Gmul/s\n", blocks, ms, (double)blocks * 256 * 2 / ms * 1e-6, 63.0 / ((double)blocks * 256 * 2 / ms * 1e-6));
     }
     for (int blocks : {2048, 4096}) {
         run<4, 1>(d, o, blocks); run<8, 1>(d, o, blocks); run<16, 1>(d, o, blocks);

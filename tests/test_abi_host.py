@@ -64,6 +64,9 @@ def test_fails_loudly_without_device():
     # the in-library multi-GPU entry points and the table conversion refuse the same way
     assert L.dgpu_msm_g1_sharded(p_(b), None, p_(s), 1, 0, p_(out)) == -1
     assert L.dgpu_multi_miller_loop_sharded(p_(b), p_(q), None, 1, 0, p_(f12)) == -1
+    two = np.array([1, 2], np.uint64); b2 = np.concatenate([b, b]); q2 = np.concatenate([q, q]); f24 = np.zeros(144, np.uint64)
+    assert L.dgpu_multi_miller_loop_segments(p_(b2), p_(q2), None, 2, p_(two), 2, p_(f24)) == -1          # (two segments: the batched path)
+    assert L.dgpu_multi_pairing_segments(p_(b2), p_(q2), None, 2, p_(two), 2, p_(f24)) == -1
     assert L.dgpu_bases_upload_g1_sharded(p_(b), None, 1, 0, C.byref(h)) == -1
     assert L.dgpu_context_count() == 0
     assert L.dgpu_set_device(0) == -3                  # no such context
@@ -90,6 +93,12 @@ def test_bad_arguments():
     assert L.dgpu_multi_miller_loop(None, None, None, 3, p_(np.zeros(72, np.uint64))) == -3
     assert L.dgpu_multi_miller_loop_prepared(None, None, None, 3, p_(np.zeros(72, np.uint64))) == -3
     assert L.dgpu_g2_prepare(None, None, 2, None, None) == -3
+    g2 = O.G2.generator().reshape(1, 24); seg = np.array([1, 1], np.uint64); o144 = np.zeros(144, np.uint64)
+    assert L.dgpu_multi_miller_loop_segments(p_(b), p_(g2), None, 1, p_(seg), 0, p_(o144)) == -3             # no segments
+    assert L.dgpu_multi_miller_loop_segments(p_(b), p_(g2), None, 1, None, 2, p_(o144)) == -3
+    assert L.dgpu_multi_miller_loop_segments(p_(b), p_(g2), None, 1, p_(np.array([1, 0], np.uint64)), 2, p_(o144)) == -3    # ends not ascending
+    assert L.dgpu_multi_pairing_segments(p_(b), p_(g2), None, 1, p_(np.array([0, 2], np.uint64)), 2, p_(o144)) == -3        # an end past n
+    assert L.dgpu_multi_pairing_segments(None, None, None, 0, p_(np.array([0, 0], np.uint64)), 2, p_(o144)) == 0 and o144[0] != 0   # empty products: one, no device needed
     assert L.dgpu_window_table_free(999) == -3
     assert L.dgpu_bases_precompute_g1(424242, 0) == -3 and L.dgpu_bases_precompute_g2(424242, 20) == -3      # unknown handle
     assert L.dgpu_bases_precompute_g1(1, 15) == -3 and L.dgpu_bases_precompute_g1(1, 23) == -3                # width outside 16..22

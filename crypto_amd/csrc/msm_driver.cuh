@@ -238,36 +238,61 @@ void host_fold_shared(const uint64_t *a_abi, const uint8_t *a_inf, const uint64_
     memcpy(out_xyz, &X, sizeof(HF)); memcpy(out_xyz + FWORDS, &Y, sizeof(HF)); memcpy(out_xyz + 2 * FWORDS, &Z, sizeof(HF));
 }
 
-// d_scalars: canonical 8 x u32 per scalar; terms i < n use table rows at column boff + i.  Caller holds the slot.
-template <class C, class HF>
-int32_t msm_device_pre(Slot &sl, const PreTable &pt, size_t boff, const uint32_t *d_scalars, size_t n, uint64_t *out_xyz) {
-    if (n == 0) { typedef hostf::HXyzz<HF> PT; PT id = PT::identity(); HF X, Y, Z; id.to_normalised_jacobian(X, Y, Z);
-        const size_t FWORDS = sizeof(HF) / 8; memcpy(out_xyz, &X, sizeof(HF)); memcpy(out_xyz + FWORDS, &Y, sizeof(HF)); memcpy(out_xyz + 2 * FWORDS, &Z, sizeof(HF)); return DGPU_OK; }
+// ---- the shared-bucket-set pipeline over a precomputed-multiples table, in two stages -------------------------------------------------
+// Stage 1 (pre_sort): scalars -> the key-sorted row list `entries` and the bucket offsets `off` (off[NB] = number of pairs).  The result
+// depends on the scalars and on the table's SHAPE (c, W, rows, first row) only, not on the curve or on the points: the MSMs of a proof
+// that multiply one assignment vector by several tables (A, B in G1, B in G2 of create_proof) can share it (dgpu_scalars_sort_*).
+// Stage 2 (pre_tail): accumulate / fix-up / reduce / host fold on any table of that shape.
+struct PreGeom { uint32_t NB; int mshift, lb, PW, G; size_t NG, Emax, T; int CH; uint32_t min_chunk, max_chunks, lanes_per_chunk, HEAVY_CAP; };
+template <class C> int32_t pre_geometry(const PreTable &pt, size_t n, PreGeom &g) {
     const int c = pt.c, W = pt.W;
-    const uint32_t NB = 1u << (c - 1);
+    g.NB = 1u << (c - 1);
     // buckets per lane of k_reduce_l0 = 2^mshift: 8 once the bucket set fills the chip with one wave per SIMD (2^19 buckets = 1024 waves, the
     // kernel is work-bound), fewer for small sets, where the serial part of every lane is pure latency (2^15 buckets: 1 per lane, 512 waves)
-    const int mshift = NB >= (1u << 18) ? 3 : (NB >= (1u << 17) ? 2 : (NB >= (1u << 16) ? 1 : 0));
-    const int lb = std::min(c - 1, 12 + mshift);        // log2 buckets per pseudo-window (64 groups of 64 * 2^mshift buckets)
-    const int PW = (int)(NB >> lb);
-    const int G = 1 << (lb - 6 - mshift);               // groups per pseudo-window (<= 64)
-    const size_t NG = (size_t)PW * G;
-    const size_t Emax = (size_t)n * W;
-    if (Emax >= (1ull << 32) || (uint64_t)W * pt.n >= (1ull << 31) || W > PS_MAX_W) return DGPU_E_BADARG;
-    const int CH = C::NFP == 2 ? choose_chunk(Emax, 32, 150000, 2) : choose_chunk(Emax, 16, 300000, 1);
-    const size_t T = (Emax + CH - 1) / CH;
+    g.mshift = g.NB >= (1u << 18) ? 3 : (g.NB >= (1u << 17) ? 2 : (g.NB >= (1u << 16) ? 1 : 0));
+    g.lb = std::min(c - 1, 12 + g.mshift);        // log2 buckets per pseudo-window (64 groups of 64 * 2^mshift buckets)
+    g.PW = (int)(g.NB >> g.lb);
+    g.G = 1 << (g.lb - 6 - g.mshift);             // groups per pseudo-window (<= 64)
+    g.NG = (size_t)g.PW * g.G;
+    g.Emax = (size_t)n * W;
+    if (g.Emax >= (1ull << 32) || (uint64_t)W * pt.n >= (1ull << 31) || W > PS_MAX_W) return DGPU_E_BADARG;
+    g.CH = C::NFP == 2 ? choose_chunk(g.Emax, 32, 150000, 2) : choose_chunk(g.Emax, 16, 300000, 1);
+    g.T = (g.Emax + g.CH - 1) / g.CH;
+    g.min_chunk = C::NFP == 2 ? 32u : 16u; g.max_chunks = C::NFP == 2 ? 150000u : 300000u; g.lanes_per_chunk = C::NFP == 2 ? 2u : 1u;
+    g.HEAVY_CAP = (uint32_t)(g.Emax / (16u * g.min_chunk)) + 1;
+    return DGPU_OK;
+}
+// sizes of `off` / `entries` for a sort kept outside a slot
+inline size_t pre_off_bytes(const PreTable &pt) { return (((size_t)1 << (pt.c - 1)) + 1) * 4; }
+inline size_t pre_entries_bytes(const PreTable &pt, size_t n) { return (size_t)n * pt.W * 4; }
+
+// dyn != nullptr: the chunking and the heavy-bucket list of the accumulation are produced on the way (curve-specific: dyn_args); nullptr: sort only
+template <class C>
+int32_t pre_sort(Slot &sl, const PreTable &pt, const PreGeom &g, size_t boff, const uint32_t *d_scalars, size_t n, uint32_t *off, uint32_t *entries, uint32_t *dyn) {
     PsParams q;
     q.scalars = d_scalars; q.bases = (const uint32_t *)pt.tab; q.n = n; q.aff_stride = C::AFF_STRIDE; q.flag_word = 2 * C::FW; q.flag_base = (uint32_t)boff;
-    q.c = c; q.W = W; q.key_wstride = 0; q.val_base = (uint32_t)boff; q.val_wstride = (uint32_t)pt.n;
-    q.part_log = ps_part_log(NB); q.P = (NB + (1u << q.part_log) - 1) >> q.part_log; q.ntiles = (uint32_t)((n + PS_TILE - 1) / PS_TILE);
+    q.c = pt.c; q.W = pt.W; q.key_wstride = 0; q.val_base = (uint32_t)boff; q.val_wstride = (uint32_t)pt.n;
+    q.part_log = ps_part_log(g.NB); q.P = (g.NB + (1u << q.part_log) - 1) >> q.part_log; q.ntiles = (uint32_t)((n + PS_TILE - 1) / PS_TILE);
     const size_t n1 = (size_t)q.P * q.ntiles;
     int32_t rc;
     if ((rc = sl.cnt.ensure((n1 + 1) * 4))) return rc;
     if ((rc = sl.cursor.ensure((n1 + 1) * 4))) return rc;                 // off1
     if ((rc = sl.bsums.ensure((scan_blocks(n1) + 2) * 4))) return rc;
-    if ((rc = sl.digits.ensure(Emax * 8))) return rc;                     // (key, val) pairs
-    if ((rc = sl.off.ensure(((size_t)NB + 1) * 4))) return rc;
-    if ((rc = sl.entries.ensure(Emax * 4))) return rc;
+    if ((rc = sl.digits.ensure(g.Emax * 8))) return rc;                   // (key, val) pairs
+    if ((rc = sl.heavy.ensure(((size_t)g.HEAVY_CAP + 1) * 4))) return rc;
+    const uint32_t heavy_thr = dyn ? 16u * (uint32_t)g.CH /* replaced on the device, dyn_chunk.cuh */ : 0xffffffffu /* nothing flagged */;
+    const uint32_t dyn_args[5] = {(uint32_t)forced_chunk(), g.min_chunk, g.max_chunks, g.lanes_per_chunk, (uint32_t)g.T};
+    StageTimer st(sl, "msm.psort");
+    HIPCHK(hipMemsetAsync(sl.heavy.p, 0, 4, sl.stream));
+    launch_psort(sl.stream, q, g.NB, sl.cnt.as<uint32_t>(), sl.cursor.as<uint32_t>(), sl.bsums.as<uint32_t>(), sl.digits.p, off, entries,
+                 heavy_thr, sl.heavy.as<uint32_t>(), g.HEAVY_CAP, dyn_args, dyn);
+    return DGPU_OK;
+}
+// derive_dyn: `off` / `entries` come from a shared sort — chunking and heavy-bucket list are derived here from off[] (as the plain pipeline does)
+template <class C, class HF>
+int32_t pre_tail(Slot &sl, const PreTable &pt, const PreGeom &g, const uint32_t *off, const uint32_t *entries, bool derive_dyn, uint64_t *out_xyz) {
+    const uint32_t NB = g.NB; const size_t T = g.T; const int PW = g.PW;
+    int32_t rc;
     if ((rc = sl.bucket.ensure(soa_points(NB) * C::XW * 4))) return rc;
     if ((rc = sl.bucket_inf.ensure(NB))) return rc;
     if ((rc = sl.head.ensure(soa_points(T) * C::XW * 4))) return rc;
@@ -275,43 +300,40 @@ int32_t msm_device_pre(Slot &sl, const PreTable &pt, size_t boff, const uint32_t
     if ((rc = sl.head_b.ensure(T * 4))) return rc;
     if ((rc = sl.tail_b.ensure(T * 4))) return rc;
     if ((rc = sl.part_inf.ensure(T * 2))) return rc;
-    if ((rc = sl.l1.ensure(NG * 2 * C::XW * 4))) return rc;
-    if ((rc = sl.l1_inf.ensure(NG * 2))) return rc;
+    if ((rc = sl.l1.ensure(g.NG * 2 * C::XW * 4))) return rc;
+    if ((rc = sl.l1_inf.ensure(g.NG * 2))) return rc;
     if ((rc = sl.win.ensure((size_t)2 * PW * 4 * C::ABI_W * 4))) return rc;        // A_j then S_j
     if ((rc = sl.win_inf.ensure(2 * PW))) return rc;
-    const uint32_t min_chunk = C::NFP == 2 ? 32u : 16u, max_chunks = C::NFP == 2 ? 150000u : 300000u, lanes_per_chunk = C::NFP == 2 ? 2u : 1u;
-    const uint32_t heavy_thr = 16u * (uint32_t)CH /* replaced on the device, dyn_chunk.cuh */, HEAVY_CAP = (uint32_t)(Emax / (16u * min_chunk)) + 1;
-    if ((rc = sl.heavy.ensure(((size_t)HEAVY_CAP + 1) * 4))) return rc;
+    if ((rc = sl.heavy.ensure(((size_t)g.HEAVY_CAP + 1) * 4))) return rc;
     if ((rc = sl.dyn.ensure(msm::dyn_words(T) * 4))) return rc;
     { const size_t hslots = 2 * (T / msm::HEAVY_RANGE + 2); if ((rc = sl.hpart.ensure(hslots * C::XW * 4))) return rc; if ((rc = sl.hpart_inf.ensure(hslots))) return rc; }
     uint32_t *const dyn = sl.dyn.as<uint32_t>();
-    const uint32_t dyn_args[5] = {(uint32_t)forced_chunk(), min_chunk, max_chunks, lanes_per_chunk, (uint32_t)T};
+    const uint32_t heavy_thr = 16u * (uint32_t)g.CH;      // (replaced on the device by dyn[])
     hipStream_t s = sl.stream;
-    {
-        StageTimer st(sl, "msm.psort");
-        HIPCHK(hipMemsetAsync(sl.bucket_inf.p, 1, NB, s));
+    HIPCHK(hipMemsetAsync(sl.bucket_inf.p, 1, NB, s));
+    if (derive_dyn) {
         HIPCHK(hipMemsetAsync(sl.heavy.p, 0, 4, s));
-        launch_psort(s, q, NB, sl.cnt.as<uint32_t>(), sl.cursor.as<uint32_t>(), sl.bsums.as<uint32_t>(), sl.digits.p, sl.off.as<uint32_t>(), sl.entries.as<uint32_t>(),
-                     heavy_thr, sl.heavy.as<uint32_t>(), HEAVY_CAP, dyn_args, dyn);
+        launch_dyn_chunk(s, off + NB, (uint32_t)forced_chunk(), g.min_chunk, g.max_chunks, g.lanes_per_chunk, (uint32_t)T, dyn);
+        launch_flag_heavy(s, off, NB, dyn, sl.heavy.as<uint32_t>(), g.HEAVY_CAP);
     }
     {
         StageTimer st(sl, "msm.accumulate");
-        launch_accumulate<C>(s, (const uint32_t *)pt.tab, sl.entries.as<uint32_t>(), sl.off.as<uint32_t>(), NB, sl.bucket.as<uint32_t>(), sl.bucket_inf.as<uint8_t>(),
-                           sl.head.as<uint32_t>(), sl.tail.as<uint32_t>(), sl.head_b.as<uint32_t>(), sl.tail_b.as<uint32_t>(), sl.part_inf.as<uint8_t>(), T, (uint32_t)CH, 0xffffffffu, dyn);
+        launch_accumulate<C>(s, (const uint32_t *)pt.tab, entries, off, NB, sl.bucket.as<uint32_t>(), sl.bucket_inf.as<uint8_t>(),
+                           sl.head.as<uint32_t>(), sl.tail.as<uint32_t>(), sl.head_b.as<uint32_t>(), sl.tail_b.as<uint32_t>(), sl.part_inf.as<uint8_t>(), T, (uint32_t)g.CH, 0xffffffffu, dyn);
     }
     {
         StageTimer st(sl, "msm.fixup");
         launch_fixup<C>(s, NB, sl.bucket.as<uint32_t>(), sl.bucket_inf.as<uint8_t>(), sl.head.as<uint32_t>(), sl.tail.as<uint32_t>(),
-                           sl.head_b.as<uint32_t>(), sl.tail_b.as<uint32_t>(), sl.part_inf.as<uint8_t>(), T, sl.off.as<uint32_t>(), heavy_thr, dyn);
-        launch_fixup_heavy<C>(s, sl.heavy.as<uint32_t>(), HEAVY_CAP, sl.off.as<uint32_t>(), (uint32_t)CH, NB, sl.bucket.as<uint32_t>(), sl.bucket_inf.as<uint8_t>(),
+                           sl.head_b.as<uint32_t>(), sl.tail_b.as<uint32_t>(), sl.part_inf.as<uint8_t>(), T, off, heavy_thr, dyn);
+        launch_fixup_heavy<C>(s, sl.heavy.as<uint32_t>(), g.HEAVY_CAP, off, (uint32_t)g.CH, NB, sl.bucket.as<uint32_t>(), sl.bucket_inf.as<uint8_t>(),
                            sl.head.as<uint32_t>(), sl.tail.as<uint32_t>(), sl.part_inf.as<uint8_t>(), T, dyn, sl.hpart.as<uint32_t>(), sl.hpart_inf.as<uint8_t>());
     }
     uint32_t *win_a = sl.win.as<uint32_t>(), *win_s = win_a + (size_t)PW * 4 * C::ABI_W;
     uint8_t *inf_a = sl.win_inf.as<uint8_t>(), *inf_s = inf_a + PW;
     {
         StageTimer st(sl, "msm.reduce");
-        launch_reduce_l0<C>(s, (unsigned)NG, sl.bucket.as<uint32_t>(), sl.bucket_inf.as<uint8_t>(), NB, mshift, sl.l1.as<uint32_t>(), sl.l1_inf.as<uint8_t>());
-        launch_reduce_top_s<C>(s, (unsigned)PW, sl.l1.as<uint32_t>(), sl.l1_inf.as<uint8_t>(), G, 6 + mshift, win_a, inf_a, win_s, inf_s);
+        launch_reduce_l0<C>(s, (unsigned)g.NG, sl.bucket.as<uint32_t>(), sl.bucket_inf.as<uint8_t>(), NB, g.mshift, sl.l1.as<uint32_t>(), sl.l1_inf.as<uint8_t>());
+        launch_reduce_top_s<C>(s, (unsigned)PW, sl.l1.as<uint32_t>(), sl.l1_inf.as<uint8_t>(), g.G, 6 + g.mshift, win_a, inf_a, win_s, inf_s);
     }
     HIPCHK(hipGetLastError());
     std::vector<uint64_t> hwin((size_t)2 * PW * 2 * C::ABI_W);
@@ -322,13 +344,29 @@ int32_t msm_device_pre(Slot &sl, const PreTable &pt, size_t boff, const uint32_t
     HIPCHK(hipStreamSynchronize(s));
     auto tsync1 = std::chrono::steady_clock::now();
     if (gs.prof) prof_flush(sl);
-    host_fold_shared<HF>(hwin.data(), hinf.data(), hwin.data() + (size_t)PW * 2 * C::ABI_W, hinf.data() + PW, PW, lb, out_xyz);
+    host_fold_shared<HF>(hwin.data(), hinf.data(), hwin.data() + (size_t)PW * 2 * C::ABI_W, hinf.data() + PW, PW, g.lb, out_xyz);
     if (gs.prof) {
         auto t2 = std::chrono::steady_clock::now();
         prof_add_host("msm.host_wait", std::chrono::duration<double, std::milli>(tsync1 - tsync0).count());
         prof_add_host("msm.host_fold", std::chrono::duration<double, std::milli>(t2 - tsync1).count());
     }
     return DGPU_OK;
+}
+template <class HF> void write_identity(uint64_t *out_xyz) {
+    typedef hostf::HXyzz<HF> PT; PT id = PT::identity(); HF X, Y, Z; id.to_normalised_jacobian(X, Y, Z);
+    const size_t FWORDS = sizeof(HF) / 8; memcpy(out_xyz, &X, sizeof(HF)); memcpy(out_xyz + FWORDS, &Y, sizeof(HF)); memcpy(out_xyz + 2 * FWORDS, &Z, sizeof(HF));
+}
+// d_scalars: canonical 8 x u32 per scalar; terms i < n use table rows at column boff + i.  Caller holds the slot.
+template <class C, class HF>
+int32_t msm_device_pre(Slot &sl, const PreTable &pt, size_t boff, const uint32_t *d_scalars, size_t n, uint64_t *out_xyz) {
+    if (n == 0) { write_identity<HF>(out_xyz); return DGPU_OK; }
+    PreGeom g; int32_t rc;
+    if ((rc = pre_geometry<C>(pt, n, g))) return rc;
+    if ((rc = sl.off.ensure(pre_off_bytes(pt)))) return rc;
+    if ((rc = sl.entries.ensure(g.Emax * 4))) return rc;
+    if ((rc = sl.dyn.ensure(msm::dyn_words(g.T) * 4))) return rc;
+    if ((rc = pre_sort<C>(sl, pt, g, boff, d_scalars, n, sl.off.as<uint32_t>(), sl.entries.as<uint32_t>(), sl.dyn.as<uint32_t>()))) return rc;
+    return pre_tail<C, HF>(sl, pt, g, sl.off.as<uint32_t>(), sl.entries.as<uint32_t>(), false, out_xyz);
 }
 
 // In-place: the bases behind `handle` (kind 1 / 2, or every part of a sharded handle 7 / 8) become precomputed-multiples tables.

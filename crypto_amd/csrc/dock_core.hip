@@ -133,6 +133,7 @@ int32_t dgpu_shutdown(void) {
         if (hd.ctx >= 0 && hd.ctx < MAX_CTX && ctxs[hd.ctx].device >= 0) (void)hipSetDevice(ctxs[hd.ctx].device);
         if (hd.kind == 4) free_r1cs_object(hd.p);                       // DevR1cs owns several allocations
         else if (hd.kind == 10 || hd.kind == 11) { PreTable *pt = (PreTable *)hd.p; (void)hipFree(pt->tab); delete pt; }
+        else if (hd.kind == 12) { SortedScalars *ss = (SortedScalars *)hd.p; (void)hipFree(ss->off); (void)hipFree(ss->entries); delete ss; }
         else if (hd.kind >= 7) delete (ShardSet *)hd.p;                 // its per-device parts are table entries of their own
         else (void)hipFree(hd.p);
     }
@@ -183,11 +184,12 @@ static void release_parts(const Handle &hd) {
     if (cur().device >= 0) (void)hipSetDevice(cur().device);
     if (hd.kind == 10 || hd.kind == 11) { PreTable *pt = (PreTable *)hd.p; (void)hipFree(pt->tab); delete pt; return; }
     if (hd.kind == 3) { scalar_release(hd.ctx, hd.p, scalar_bytes(hd.n)); return; }      // recycled: no device-wide wait per proof
+    if (hd.kind == 12) { SortedScalars *ss = (SortedScalars *)hd.p; scalar_release(hd.ctx, ss->off, ss->off_bytes); scalar_release(hd.ctx, ss->entries, ss->entries_bytes); delete ss; return; }
     (void)hipFree(hd.p);
 }
 static int32_t free_handle(uint64_t h, bool scalars) {
     Handle hd;
-    auto ok = [scalars](int k) { return k != 4 && ((k == 3 || k == 9) == scalars); };
+    auto ok = [scalars](int k) { return k != 4 && ((k == 3 || k == 9 || k == 12) == scalars); };
     if (!take_handle(h, ok, hd)) return DGPU_E_BADARG;
     release_parts(hd);
     return DGPU_OK;

@@ -28,10 +28,12 @@ struct Buf {
 };
 
 // kind: 1 = G1 bases, 2 = G2 bases, 3 = scalars, 4 = R1CS (DevR1cs*), 5 / 6 = G1 / G2 window table, 7 / 8 = G1 / G2 bases sharded over
-// several devices (ShardSet*), 9 = scalars sharded like a bases set (ShardSet*), 10 / 11 = G1 / G2 precomputed-multiples table (PreTable*).  `ctx` = the device context that owns the allocation;
+// several devices (ShardSet*), 9 = scalars sharded like a bases set (ShardSet*), 10 / 11 = G1 / G2 precomputed-multiples table (PreTable*),
+// 12 = sorted scalars (SortedScalars*).  `ctx` = the device context that owns the allocation;
 // `inflight` = calls currently using it (a free waits for them: no use-after-free when dgpu_*_free races an MSM on the same handle).
 struct Handle { void *p; size_t n; int kind; int ctx; int inflight; };
 struct PreTable { void *tab; size_t n; int c, W; };      // kind 10 / 11: tab[w * n + i] = prepared record of 2^(c w) P_i (pre_kernels.cuh)
+struct SortedScalars { void *off, *entries; size_t off_bytes, entries_bytes; size_t n, rows, boff; int c, W; };   // kind 12: the partition sort of n scalars for tables of `rows` rows, width c, first row boff
 struct ShardSet { std::vector<uint64_t> sub; std::vector<size_t> lo; size_t n = 0; };   // sub[k] covers [lo[k], lo[k+1]) (lo has sub.size() + 1 entries)
 struct NttDomain { void *tw_f = nullptr, *tw_i = nullptr, *pw_f = nullptr, *pw_i = nullptr, *zinv = nullptr, *pwr_f = nullptr, *pwr_i = nullptr; };   // pwr_*: pw_* in bit-reversed order   // per log2(D), built once per device
 
@@ -76,7 +78,7 @@ struct Ctx {
     std::vector<std::pair<void *, size_t>> scalar_pool;
     size_t scalar_pool_bytes = 0;
 };
-constexpr size_t SCALAR_POOL_MAX_ENTRIES = 16, SCALAR_POOL_MAX_BYTES = (size_t)4 << 30;
+constexpr size_t SCALAR_POOL_MAX_ENTRIES = 32, SCALAR_POOL_MAX_BYTES = (size_t)4 << 30;
 // process-wide state shared by all contexts
 struct Shared {
     std::mutex mu;                 // lifecycle, handle table, profile table, NTT-domain tables

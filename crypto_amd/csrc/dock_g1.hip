@@ -14,6 +14,17 @@ int32_t dgpu_bases_upload_g1_sharded(const uint64_t *b, const uint8_t *inf, size
 int32_t dgpu_msm_g1_sharded_handle(uint64_t b, const uint64_t *s, size_t n, int32_t mont, uint64_t out[18]) { return msm_sharded_handle<G1, hostf::Fq>(b, s, n, mont, out, 1); }
 int32_t dgpu_msm_g1_sharded_resident(uint64_t b, uint64_t s, uint64_t out[18]) { return msm_sharded_resident<G1, hostf::Fq>(b, s, out, 1); }
 int32_t dgpu_bases_precompute_g1(uint64_t h, int32_t window_bits) { return bases_precompute<G1>(h, window_bits, 1); }
+// shape of a precomputed table (dgpu_bases_precompute_* may have left a short handle plain: then, and for anything that is not a table, DGPU_E_BADARG)
+int32_t dgpu_bases_table_shape(uint64_t handle, size_t *rows, int32_t *window_bits, int32_t *windows) {
+    if (!rows || !window_bits || !windows) return DGPU_E_BADARG;
+    HandleRef hb(handle);
+    if (!hb.ok || (hb.h.kind != 10 && hb.h.kind != 11)) return DGPU_E_BADARG;
+    const PreTable &pt = *(const PreTable *)hb.h.p;
+    *rows = pt.n; *window_bits = pt.c; *windows = pt.W;
+    return DGPU_OK;
+}
+int32_t dgpu_scalars_sort(uint64_t table, size_t boff, uint64_t s, size_t soff, size_t n, uint64_t *sorted) { return scalars_sort(table, boff, s, soff, n, sorted); }
+int32_t dgpu_msm_g1_sorted(uint64_t table, uint64_t sorted, uint64_t out[18]) { return msm_sorted<G1, hostf::Fq>(table, sorted, out, 1); }
 int32_t dgpu_msm_g1_resident(uint64_t b, size_t boff, uint64_t s, size_t soff, size_t n, uint64_t out[18]) { return msm_resident<G1, hostf::Fq>(b, boff, s, soff, n, out, 1); }
 
 int32_t dgpu_selftest_fp_mul(const uint64_t *a, const uint64_t *b, size_t n, uint64_t *out) {

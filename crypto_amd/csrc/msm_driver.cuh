@@ -270,7 +270,7 @@ inline size_t pre_entries_bytes(const PreTable &pt, size_t n) { return (size_t)n
 template <class C>
 int32_t pre_sort(Slot &sl, const PreTable &pt, const PreGeom &g, size_t boff, const uint32_t *d_scalars, size_t n, uint32_t *off, uint32_t *entries, uint32_t *dyn) {
     PsParams q;
-    q.scalars = d_scalars; q.bases = (const uint32_t *)pt.tab; q.n = n; q.aff_stride = C::AFF_STRIDE; q.flag_word = 2 * C::FW; q.flag_base = (uint32_t)boff;
+    q.scalars = d_scalars; q.bases = dyn ? (const uint32_t *)pt.tab : nullptr /* shared sort: no per-table identity filter */; q.n = n; q.aff_stride = C::AFF_STRIDE; q.flag_word = 2 * C::FW; q.flag_base = (uint32_t)boff;
     q.c = pt.c; q.W = pt.W; q.key_wstride = 0; q.val_base = (uint32_t)boff; q.val_wstride = (uint32_t)pt.n;
     q.part_log = ps_part_log(g.NB); q.P = (g.NB + (1u << q.part_log) - 1) >> q.part_log; q.ntiles = (uint32_t)((n + PS_TILE - 1) / PS_TILE);
     const size_t n1 = (size_t)q.P * q.ntiles;
@@ -318,7 +318,9 @@ int32_t pre_tail(Slot &sl, const PreTable &pt, const PreGeom &g, const uint32_t 
     }
     {
         StageTimer st(sl, "msm.accumulate");
-        launch_accumulate<C>(s, (const uint32_t *)pt.tab, entries, off, NB, sl.bucket.as<uint32_t>(), sl.bucket_inf.as<uint8_t>(),
+        if (derive_dyn) launch_accumulate_skip_identity<C>(s, (const uint32_t *)pt.tab, entries, off, NB, sl.bucket.as<uint32_t>(), sl.bucket_inf.as<uint8_t>(),
+                           sl.head.as<uint32_t>(), sl.tail.as<uint32_t>(), sl.head_b.as<uint32_t>(), sl.tail_b.as<uint32_t>(), sl.part_inf.as<uint8_t>(), T, (uint32_t)g.CH, dyn);
+        else launch_accumulate<C>(s, (const uint32_t *)pt.tab, entries, off, NB, sl.bucket.as<uint32_t>(), sl.bucket_inf.as<uint8_t>(),
                            sl.head.as<uint32_t>(), sl.tail.as<uint32_t>(), sl.head_b.as<uint32_t>(), sl.tail_b.as<uint32_t>(), sl.part_inf.as<uint8_t>(), T, (uint32_t)g.CH, 0xffffffffu, dyn);
     }
     {
@@ -367,6 +369,50 @@ int32_t msm_device_pre(Slot &sl, const PreTable &pt, size_t boff, const uint32_t
     if ((rc = sl.dyn.ensure(msm::dyn_words(g.T) * 4))) return rc;
     if ((rc = pre_sort<C>(sl, pt, g, boff, d_scalars, n, sl.off.as<uint32_t>(), sl.entries.as<uint32_t>(), sl.dyn.as<uint32_t>()))) return rc;
     return pre_tail<C, HF>(sl, pt, g, sl.off.as<uint32_t>(), sl.entries.as<uint32_t>(), false, out_xyz);
+}
+
+// ---- one sort for several tables (dgpu_scalars_sort / dgpu_msm_*_sorted) ---------------------------------------------------------------
+// A, B-in-G1 and B-in-G2 of a LegoGroth16 proof multiply the SAME assignment by three proving-key queries of equal length
+// (legogroth16/src/prover.rs:325-344 -> calculate_coeff :585-594): with the queries held as tables of one shape their partition sorts are
+// identical.  The sorted list lives in a handle of its own (kind 12, buffers from the scalar pool), read-only while MSMs use it.
+inline int32_t scalars_sort(uint64_t table, size_t boff, uint64_t scalars, size_t soff, size_t n, uint64_t *sorted) {
+    if (!sorted || n == 0) return DGPU_E_BADARG;
+    if (!cur().ready) return DGPU_E_NODEVICE;
+    HandleRef hb(table), hs(scalars);
+    if (!hb.ok || !hs.ok || (hb.h.kind != 10 && hb.h.kind != 11) || hs.h.kind != 3 || hb.h.ctx != hs.h.ctx) return DGPU_E_BADARG;
+    if (boff > hb.h.n || n > hb.h.n - boff || soff > hs.h.n || n > hs.h.n - soff) return DGPU_E_BADARG;
+    CtxScope on_owner(hb.h.ctx);
+    SlotLock L; Slot &sl = *L.s;
+    HIPCHK(hipSetDevice(cur().device));
+    const PreTable &pt = *(const PreTable *)hb.h.p;
+    PreGeom g; int32_t rc;
+    if ((rc = pre_geometry<G1>(pt, n, g))) return rc;                     // (only the curve-independent fields are used by the sort)
+    SortedScalars *ss = new SortedScalars{nullptr, nullptr, pre_off_bytes(pt), pre_entries_bytes(pt, n), n, pt.n, boff, pt.c, pt.W};
+    ss->off = scalar_alloc(ss->off_bytes); ss->entries = scalar_alloc(ss->entries_bytes);
+    auto drop = [&]() { scalar_release(cur_index(), ss->off, ss->off_bytes); scalar_release(cur_index(), ss->entries, ss->entries_bytes); delete ss; };
+    if (!ss->off || !ss->entries) { drop(); return DGPU_E_OOM; }
+    rc = pre_sort<G1>(sl, pt, g, boff, (const uint32_t *)hs.h.p + soff * 8, n, (uint32_t *)ss->off, (uint32_t *)ss->entries, nullptr);
+    if (!rc && hipStreamSynchronize(sl.stream) != hipSuccess) { gs.last_hip = (int32_t)hipGetLastError(); rc = DGPU_E_HIP; }
+    if (gs.prof) prof_flush(sl);
+    if (rc) { drop(); return rc; }
+    *sorted = register_handle(ss, n, 12);
+    return DGPU_OK;
+}
+template <class C, class HF>
+int32_t msm_sorted(uint64_t table, uint64_t sorted, uint64_t *out, int kind) {
+    if (!out) return DGPU_E_BADARG;
+    if (!cur().ready) return DGPU_E_NODEVICE;
+    HandleRef hb(table), hs(sorted);
+    if (!hb.ok || !hs.ok || hb.h.kind != kind + 9 || hs.h.kind != 12 || hb.h.ctx != hs.h.ctx) return DGPU_E_BADARG;
+    const PreTable &pt = *(const PreTable *)hb.h.p;
+    const SortedScalars &ss = *(const SortedScalars *)hs.h.p;
+    if (pt.c != ss.c || pt.W != ss.W || pt.n != ss.rows || ss.boff > pt.n || ss.n > pt.n - ss.boff) return DGPU_E_BADARG;      // not the shape the list was sorted for
+    CtxScope on_owner(hb.h.ctx);
+    SlotLock L; Slot &sl = *L.s;
+    HIPCHK(hipSetDevice(cur().device));
+    PreGeom g; int32_t rc;
+    if ((rc = pre_geometry<C>(pt, ss.n, g))) return rc;
+    return pre_tail<C, HF>(sl, pt, g, (const uint32_t *)ss.off, (const uint32_t *)ss.entries, true, out);
 }
 
 // In-place: the bases behind `handle` (kind 1 / 2, or every part of a sharded handle 7 / 8) become precomputed-multiples tables.

@@ -164,7 +164,9 @@ template <> __device__ __forceinline__ void load_aff<G2P>(Aff<Fp2H> &p, const ui
 // off[0..NB] = exclusive scan of the histogram (off[NB] = number of terms E).  Thread t owns terms
 // [t*CH, min((t+1)*CH, E)).  head_b[t] / tail_b[t] = bucket of the partial left in the head / tail slot, or
 // 0xffffffff.  bucket_inf[b] must be pre-set to 1; it is cleared by whoever writes bucket b.
-template <class C>
+// SKIP_ID: terms whose base record carries the identity flag are passed over here (the sorted list came from a sort shared by several
+// tables, which cannot drop them per table: dgpu_scalars_sort / dgpu_msm_*_sorted)
+template <class C, bool SKIP_ID = false>
 __global__ void __launch_bounds__(256, C::ACC_WAVES) k_accumulate(const uint32_t *__restrict__ bases, const uint32_t *__restrict__ entries, const uint32_t *__restrict__ off,
                                                     uint32_t NB, uint32_t *__restrict__ bucket, uint8_t *__restrict__ bucket_inf,
                                                     uint32_t *__restrict__ head, uint32_t *__restrict__ tail, uint32_t *__restrict__ head_b, uint32_t *__restrict__ tail_b,
@@ -203,7 +205,9 @@ __global__ void __launch_bounds__(256, C::ACC_WAVES) k_accumulate(const uint32_t
             }
         }
         uint32_t e = entries[pos];
-        Aff<F> p; load_aff<C>(p, bases + (size_t)(e & 0x7fffffffu & dbg_mask) * C::AFF_STRIDE);
+        const uint32_t *rec = bases + (size_t)(e & 0x7fffffffu & dbg_mask) * C::AFF_STRIDE;
+        if constexpr (SKIP_ID) { if (rec[C::AFF_STRIDE * 7 / 8] != 0) continue; }          // flag word: x, y, flag, pad
+        Aff<F> p; load_aff<C>(p, rec);
         xyzz_madd(acc, inf, p, (e >> 31) != 0);
     }
     // the last run reaches the chunk end

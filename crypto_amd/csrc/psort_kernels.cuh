@@ -66,7 +66,8 @@ template <class F> __device__ __forceinline__ void ps_digits(const PsParams &q, 
     }
 }
 __device__ __forceinline__ bool ps_live(const PsParams &q, size_t i) {
-    return i < q.n && q.bases[((size_t)q.flag_base + i) * (size_t)q.aff_stride + q.flag_word] == 0;
+    // q.bases == nullptr: a sort shared by several tables (dgpu_scalars_sort): identity rows are skipped by the accumulation instead
+    return i < q.n && (!q.bases || q.bases[((size_t)q.flag_base + i) * (size_t)q.aff_stride + q.flag_word] == 0);
 }
 
 // P1: cnt1[p * ntiles + tile]

@@ -185,10 +185,11 @@ def _calculate_coeff(curve, initial_point, initial_scalar, query_handle, query0,
     return sharded.fold(curve, np.stack([acc, rest]))
 
 
-def create_proof(pk, r, s, v, h, input_assignment_with_one, witness_assignment, resident_z=None):
+def create_proof(pk, r, s, v, h, input_assignment_with_one, witness_assignment, resident_z=None, share_sort=True):
     """prover.rs:267-383.  Returns the proof (a, b, c, d) as affine ABI points.  `h`: canonical limbs or the DeviceScalars
     the witness map left in HBM (qap.witness_map(..., resident=True)).  `resident_z`: the whole assignment z = instance ++ witness already on
-    the device (then `assignment` = z[1..] is that handle at scalar offset 1 and nothing is uploaded here)."""
+    the device (then `assignment` = z[1..] is that handle at scalar offset 1 and nothing is uploaded here).  `share_sort`: one partition sort for
+    the A / B-in-G1 / B-in-G2 MSMs when their queries are tables of one shape (False: every MSM sorts for itself, for measurements)."""
     vk = pk.vk
     own_h = []
 
@@ -226,6 +227,12 @@ def create_proof(pk, r, s, v, h, input_assignment_with_one, witness_assignment, 
     def coeff_msm(query):            # msm(query[1..], assignment) of calculate_coeff (:592)
         return lambda: query.msm_resident(assignment, n=min(assignment.n - a0, query.n - 1), base_offset=1, scalar_offset=a0)
     with_b1 = r % R_MOD != 0                                                                          # :330-336
+    # A, B in G1 and B in G2 multiply the same assignment by three queries of equal length: held as tables of one shape they share ONE
+    # partition sort (dgpu_scalars_sort), each MSM then starts at its accumulation
+    shared = None
+    if share_sort and pk.a_query.same_table_shape(pk.b_g2_query) and (not with_b1 or pk.a_query.same_table_shape(pk.b_g1_query)):
+        shared = M.SortedScalars(pk.a_query, assignment, min(assignment.n - a0, pk.a_query.n - 1), base_offset=1, scalar_offset=a0)
+        coeff_msm = lambda query: (lambda: query.msm_sorted(shared))
     # Issue order = the order in which the accumulations get the chip.  The G2 MSM is the longest call and ends in ~3 ms of latency-bound
     # kernels (fix-up, bucket reduction): first in, its tail runs under the G1 MSMs instead of after them.
     f_b2 = pool.submit(coeff_msm(pk.b_g2_query))                                                      # :343-344
@@ -247,6 +254,8 @@ def create_proof(pk, r, s, v, h, input_assignment_with_one, witness_assignment, 
     sa_rb = lincomb(M.G1, [_affine(M.G1, g_a), _affine(M.G1, g1_b)], [s, r])
     g2_b = sharded.fold(M.G2, np.stack([f_b2.result(), rest_b2]))
     l_aux_acc, h_acc = f_l.result(), f_h.result()
+    if shared is not None:
+        shared.free()
     if resident_z is None:
         assignment.free()
     for x in own_h:
@@ -256,7 +265,7 @@ def create_proof(pk, r, s, v, h, input_assignment_with_one, witness_assignment, 
     return {"a": _affine(M.G1, g_a), "b": _affine(M.G2, g2_b), "c": _affine(M.G1, g_c), "d": _affine(M.G1, g_d)}
 
 
-def create_proof_with_reduction(pk, circuit, r, s, v, assignment_with_one):
+def create_proof_with_reduction(pk, circuit, r, s, v, assignment_with_one, share_sort=True):
     """create_proof_with_reduction (prover.rs:153-180): h = QAP::witness_map(cs) then create_proof_with_assignment.  `circuit` is the resident
     R1CS (qap.DeviceR1cs: the matrices of the synthesised constraint system), `assignment_with_one` the full assignment z = instance ++ witness.
     z is uploaded ONCE: the witness map reads it in place (dgpu_witness_map_r1cs_resident), the four assignment MSMs use the same handle at
@@ -269,7 +278,7 @@ def create_proof_with_reduction(pk, circuit, r, s, v, assignment_with_one):
         _, dh = circuit.witness_map(dz, to_host=False, resident=True)
         return dh
     try:
-        return create_proof(pk, r, s, v, h, z[:n_inst], z[n_inst:], resident_z=dz)
+        return create_proof(pk, r, s, v, h, z[:n_inst], z[n_inst:], resident_z=dz, share_sort=share_sort)
     finally:
         dz.free()
 

@@ -177,6 +177,26 @@ class DeviceBases:
             raise DockGpuError(rc, "dgpu_bases_precompute")
         return self
 
+    def table_shape(self):
+        """(rows, window bits, windows) of the precomputed table behind the handle, None if it is not one (dgpu_bases_table_shape)"""
+        rows, c, w = C.c_size_t(0), C.c_int32(0), C.c_int32(0)
+        if not getattr(self, "handle", 0) or lib().dgpu_bases_table_shape(self.handle, C.byref(rows), C.byref(c), C.byref(w)):
+            return None
+        return rows.value, c.value, w.value
+
+    def same_table_shape(self, other):
+        """both handles are precomputed tables of one shape (row count and window width): their MSMs over one scalar vector can share a sort"""
+        a = self.table_shape()
+        return a is not None and isinstance(other, DeviceBases) and a == other.table_shape()
+
+    def msm_sorted(self, sorted_scalars):
+        """the MSM over a list dgpu_scalars_sort produced for a table of this shape (SortedScalars)"""
+        out = np.zeros(self.curve.JW, dtype=np.uint64)
+        rc = self.curve.fn("dgpu_msm_%s_sorted")(self.handle, sorted_scalars.handle, _p(out))
+        if rc:
+            raise DockGpuError(rc, "dgpu_msm_sorted")
+        return out
+
     def msm_bigint(self, scalars, offset=0, montgomery=False):
         scalars = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
         n = min(len(scalars), self.n - offset)
@@ -270,6 +290,29 @@ class ShardedDeviceBases:
     def free(self):
         if self.handle:
             lib().dgpu_bases_free(self.handle)
+            self.handle = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class SortedScalars:
+    """dgpu_scalars_sort: the partition sort of scalars [scalar_offset, scalar_offset + n) for rows [base_offset, ...) of a precomputed table;
+    every table of the same shape (DeviceBases.same_table_shape) can run its MSM on it (DeviceBases.msm_sorted)"""
+
+    def __init__(self, table, dscalars, n, base_offset=0, scalar_offset=0):
+        h = C.c_uint64(0)
+        rc = lib().dgpu_scalars_sort(table.handle, base_offset, dscalars.handle, scalar_offset, n, C.byref(h))
+        if rc:
+            raise DockGpuError(rc, "dgpu_scalars_sort")
+        self.handle, self.n = h.value, n
+
+    def free(self):
+        if self.handle:
+            lib().dgpu_scalars_free(self.handle)
             self.handle = 0
 
     def __del__(self):

@@ -113,6 +113,16 @@ int main() {
         EXPECT(dgpu_msm_g1_handle(h, 0, sc.data(), n, 0, plain) == DGPU_OK);
         EXPECT(dgpu_bases_precompute_g1(h, 16) == DGPU_OK);
         EXPECT(dgpu_msm_g1_handle(h, 0, sc.data(), n, 0, tab) == DGPU_OK && std::memcmp(plain, tab, sizeof plain) == 0);
+        // one sort, then the MSM of the table on the sorted list (dgpu_scalars_sort / dgpu_msm_g1_sorted): the same point
+        {
+            uint64_t hsc = 0, srt = 0, viaSort[18]; size_t rows = 0; int32_t cbits = 0, wins = 0;
+            EXPECT(dgpu_bases_table_shape(h, &rows, &cbits, &wins) == DGPU_OK && rows == n && cbits == 16 && wins == 16);
+            EXPECT(dgpu_scalars_upload(sc.data(), n, 0, &hsc) == DGPU_OK);
+            EXPECT(dgpu_scalars_sort(h, 0, hsc, 0, n, &srt) == DGPU_OK);
+            EXPECT(dgpu_msm_g1_sorted(h, srt, viaSort) == DGPU_OK && std::memcmp(plain, viaSort, sizeof plain) == 0);
+            EXPECT(dgpu_msm_g1_sorted(h, hsc, viaSort) == DGPU_E_BADARG);
+            EXPECT(dgpu_scalars_free(srt) == DGPU_OK && dgpu_scalars_free(hsc) == DGPU_OK);
+        }
         EXPECT(dgpu_bases_free(h) == DGPU_OK);
     }
     // several device contexts in this one process (a Rust host is one process): two contexts on the box's one GPU, every MSM chunked

@@ -37,7 +37,7 @@ def seq():
     _, dh = circ.witness_map(z, to_host=False, resident=True)
     pr = LG.create_proof(pk, 123456789, 987654321, 555, dh, z[:2], z[2:]); dh.free(); return pr
 def ovl():
-    return LG.create_proof_with_reduction(pk, circ, 123456789, 987654321, 555, z)
+    return LG.create_proof_with_reduction(pk, circ, 123456789, 987654321, 555, z, share_sort=not os.environ.get("SEPARATE_SORTS"))
 for name, fn in (("witness map, then MSMs", seq), ("witness map overlapped", ovl), ("witness map, then MSMs", seq), ("witness map overlapped", ovl)):
     ref = fn()
     for _ in range(4):
@@ -52,6 +52,9 @@ if os.environ.get("INFLIGHT"):          # proofs per second with K proofs in fli
     for K in [int(x) for x in os.environ["INFLIGHT"].split(",")]:
         with ThreadPoolExecutor(K) as ex:
             list(ex.map(lambda _: ovl(), range(2 * K)))
-            t0 = time.perf_counter(); res = list(ex.map(lambda _: ovl(), range(16))); dt = (time.perf_counter() - t0) / 16 * 1e3
+            NIT = int(os.environ.get("NIT", "16")); t0 = time.perf_counter(); res = list(ex.map(lambda _: ovl(), range(NIT))); dt = (time.perf_counter() - t0) / NIT * 1e3
         assert all((r[k] == ref[k]).all() for r in res for k in ref)
         print("%d proofs in flight: %.2f ms per proof (%.1f M constraints/s)" % (K, dt, (m + 1) / dt / 1e3), flush=True)
+if os.environ.get("PROF"):              # device time per stage of one proof
+    ca.prof.enable(True); ca.prof.reset(); ovl()
+    print("device ms / calls:", {k: (round(v[0], 2), v[1]) for k, v in sorted(ca.prof.read().items(), key=lambda kv: -kv[1][0])}); ca.prof.enable(False)

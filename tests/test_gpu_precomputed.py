@@ -108,3 +108,51 @@ def test_sharded_handle_precomputed():
     assert (sh.msm_bigint(sc[:25001]) == ca.msm_bigint(curve, bases[:25001], sc[:25001])).all()
     ds.free(); sh.free()
     lib().dgpu_set_device(0)
+
+
+@pytest.mark.parametrize("n,c", [(700, 16), (5003, 18), ((1 << 15) + 5, 20), ((1 << 16) + 3, 0)])
+def test_one_sort_shared_by_tables_of_one_shape(n, c):
+    """dgpu_scalars_sort + dgpu_msm_g1/g2_sorted: the MSMs of a G1 table, of a second G1 table with identity rows and of a G2 table of the
+    same shape over ONE sorted scalar list equal dgpu_msm_*_resident limb for limb — uniform and Groth16-like scalars (zeros, ones, hot
+    buckets, all equal), row / scalar offsets (`&query[1..]`), several MSMs on the list at once; tables of another shape are refused."""
+    from concurrent.futures import ThreadPoolExecutor
+    b1, _, _ = U.seq_bases(O.G1, n, 2100 + n, threads=16); b1b, _, _ = U.seq_bases(O.G1, n, 2200 + n, threads=16); b2, _, _ = U.seq_bases(O.G2, n, 2300 + n, threads=16)
+    inf_b = np.zeros(n, np.uint8); inf_b[::7] = 1; b1b[5] = 0; inf2 = np.zeros(n, np.uint8); inf2[3::11] = 1            # B queries have identity rows
+    ta = ca.DeviceBases(ca.G1, b1).precompute(c); tb = ca.DeviceBases(ca.G1, b1b, inf_b).precompute(c); t2 = ca.DeviceBases(ca.G2, b2, inf2).precompute(c)
+    assert ta.same_table_shape(tb) and ta.same_table_shape(t2)
+    rng = np.random.default_rng(n)
+    uniform = O.rand_scalars(2400 + n, n)
+    groth = uniform.copy(); kind = rng.integers(0, 4, n); groth[kind <= 1] = 0; groth[kind == 1, 0] = 1; m = kind == 2; groth[m, 1:] = 0; groth[m, 0] &= np.uint64(0xFFFF)
+    equal = np.repeat(uniform[:1], n, 0)
+    for sc in (uniform, groth, equal):
+        ds = ca.DeviceScalars(sc)
+        for boff, soff, cnt in ((0, 0, n), (1, 0, n - 1), (1, 1, n - 2), (5, 9, n // 3)):
+            srt = ca.SortedScalars(ta, ds, cnt, base_offset=boff, scalar_offset=soff)
+            with ThreadPoolExecutor(3) as ex:
+                got = list(ex.map(lambda t: t.msm_sorted(srt), (ta, tb, t2)))
+            for t, g in zip((ta, tb, t2), got):
+                assert (g == t.msm_resident(ds, n=cnt, base_offset=boff, scalar_offset=soff)).all(), (boff, soff, cnt)
+            srt.free()
+        ds.free()
+    # the oracle itself on one case
+    ds = ca.DeviceScalars(groth); srt = ca.SortedScalars(tb, ds, n)
+    if n <= 5003:
+        infb = inf_b.copy(); infb[5] = 1
+        assert U.jac_to_model(O.G1, tb.msm_sorted(srt)) == U.jac_to_model(O.G1, O.G1.msm(b1b, groth, infb, threads=16))
+    # another shape: a different width or row count
+    other = ca.DeviceBases(ca.G1, b1[:n - 1]).precompute(c)
+    wide = ca.DeviceBases(ca.G1, b1).precompute(17 if c != 17 else 19)
+    plain = ca.DeviceBases(ca.G1, b1)
+    for bad in (other, wide, plain):
+        assert not ta.same_table_shape(bad)
+        with pytest.raises(ca.DockGpuError):
+            bad.msm_sorted(srt)
+    out = np.zeros(18, np.uint64)
+    import ctypes as C
+    assert lib().dgpu_msm_g1_sorted(ta.handle, ds.handle, out.ctypes.data_as(C.c_void_p)) == -3          # a scalars handle is not a sorted list
+    h = C.c_uint64(0)
+    assert lib().dgpu_scalars_sort(plain.handle, 0, ds.handle, 0, n, C.byref(h)) == -3                    # not a table
+    assert lib().dgpu_scalars_sort(ta.handle, 2, ds.handle, 0, n, C.byref(h)) == -3                       # rows past the end
+    srt.free(); ds.free()
+    for t in (ta, tb, t2, other, wide, plain):
+        t.free()

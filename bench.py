@@ -530,7 +530,7 @@ def secondary_configs(log2n, ks, scalars, db, ds, pool):
     spans["sum_of_spans"] = round(sum(spans.values()), 3)
     res["prove_spans_ms"] = spans
     res["prove_note"] = ("LegoGroth16 create_proof (witness map + 4 G1 MSMs + 1 G2 MSM + finish), m + 1 = %d constraints, D = 2^%d, Groth16-like witness, "
-                         "circuit and key (precomputed tables) resident, assignment uploaded per proof; the A / B-in-G1 / B-in-G2 MSMs share one partition sort" % (m + 1, log2n))
+                         "circuit and key (precomputed tables) resident, assignment uploaded per proof; the A / B-in-G1 / B-in-G2 / l MSMs share one partition sort" % (m + 1, log2n))
     res["note"] = "n = D = 2^%d; one call in flight unless stated; host-visible wall time per call" % log2n
     return res
 

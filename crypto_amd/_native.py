@@ -77,7 +77,7 @@ def lib():
         L.dgpu_scalars_sort.argtypes = [u64, sz, u64, sz, sz, C.POINTER(u64)]
         L.dgpu_bases_table_shape.argtypes = [u64, C.POINTER(sz), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         for name in ("dgpu_msm_g1_sorted", "dgpu_msm_g2_sorted"):
-            getattr(L, name).argtypes = [u64, u64, vp]
+            getattr(L, name).argtypes = [u64, u64, sz, vp]
         L.dgpu_init_devices.argtypes = [C.c_uint32]
         L.dgpu_init_device_list.argtypes = [vp, C.c_int32]
         L.dgpu_set_device.argtypes = [C.c_int32]

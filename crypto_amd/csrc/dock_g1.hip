@@ -24,7 +24,7 @@ int32_t dgpu_bases_table_shape(uint64_t handle, size_t *rows, int32_t *window_bi
     return DGPU_OK;
 }
 int32_t dgpu_scalars_sort(uint64_t table, size_t boff, uint64_t s, size_t soff, size_t n, uint64_t *sorted) { return scalars_sort(table, boff, s, soff, n, sorted); }
-int32_t dgpu_msm_g1_sorted(uint64_t table, uint64_t sorted, uint64_t out[18]) { return msm_sorted<G1, hostf::Fq>(table, sorted, out, 1); }
+int32_t dgpu_msm_g1_sorted(uint64_t table, uint64_t sorted, size_t row_shift, uint64_t out[18]) { return msm_sorted<G1, hostf::Fq>(table, sorted, row_shift, out, 1); }
 int32_t dgpu_msm_g1_resident(uint64_t b, size_t boff, uint64_t s, size_t soff, size_t n, uint64_t out[18]) { return msm_resident<G1, hostf::Fq>(b, boff, s, soff, n, out, 1); }
 
 int32_t dgpu_selftest_fp_mul(const uint64_t *a, const uint64_t *b, size_t n, uint64_t *out) {

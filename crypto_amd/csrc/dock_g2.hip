@@ -14,6 +14,6 @@ int32_t dgpu_bases_upload_g2_sharded(const uint64_t *b, const uint8_t *inf, size
 int32_t dgpu_msm_g2_sharded_handle(uint64_t b, const uint64_t *s, size_t n, int32_t mont, uint64_t out[36]) { return msm_sharded_handle<G2, hostf::Fq2>(b, s, n, mont, out, 2); }
 int32_t dgpu_msm_g2_sharded_resident(uint64_t b, uint64_t s, uint64_t out[36]) { return msm_sharded_resident<G2, hostf::Fq2>(b, s, out, 2); }
 int32_t dgpu_bases_precompute_g2(uint64_t h, int32_t window_bits) { return bases_precompute<G2>(h, window_bits, 2); }
-int32_t dgpu_msm_g2_sorted(uint64_t table, uint64_t sorted, uint64_t out[36]) { return msm_sorted<G2, hostf::Fq2>(table, sorted, out, 2); }
+int32_t dgpu_msm_g2_sorted(uint64_t table, uint64_t sorted, size_t row_shift, uint64_t out[36]) { return msm_sorted<G2, hostf::Fq2>(table, sorted, row_shift, out, 2); }
 int32_t dgpu_msm_g2_resident(uint64_t b, size_t boff, uint64_t s, size_t soff, size_t n, uint64_t out[36]) { return msm_resident<G2, hostf::Fq2>(b, boff, s, soff, n, out, 2); }
 }  // extern "C"

@@ -3,5 +3,5 @@
 namespace msm {
 template void launch_prep_bases<G1>(hipStream_t, const uint32_t *, const uint8_t *, size_t, uint32_t *);
 template void launch_accumulate<G1>(hipStream_t, const uint32_t *, const uint32_t *, const uint32_t *, uint32_t, uint32_t *, uint8_t *, uint32_t *, uint32_t *, uint32_t *, uint32_t *, uint8_t *, size_t, uint32_t, uint32_t, const uint32_t *);
-template void launch_accumulate_skip_identity<G1>(hipStream_t, const uint32_t *, const uint32_t *, const uint32_t *, uint32_t, uint32_t *, uint8_t *, uint32_t *, uint32_t *, uint32_t *, uint32_t *, uint8_t *, size_t, uint32_t, const uint32_t *);
+template void launch_accumulate_skip_identity<G1>(hipStream_t, const uint32_t *, const uint32_t *, const uint32_t *, uint32_t, uint32_t *, uint8_t *, uint32_t *, uint32_t *, uint32_t *, uint32_t *, uint8_t *, size_t, uint32_t, const uint32_t *, const RowMap &);
 }  // namespace msm

@@ -290,7 +290,7 @@ int32_t pre_sort(Slot &sl, const PreTable &pt, const PreGeom &g, size_t boff, co
 }
 // derive_dyn: `off` / `entries` come from a shared sort — chunking and heavy-bucket list are derived here from off[] (as the plain pipeline does)
 template <class C, class HF>
-int32_t pre_tail(Slot &sl, const PreTable &pt, const PreGeom &g, const uint32_t *off, const uint32_t *entries, bool derive_dyn, uint64_t *out_xyz) {
+int32_t pre_tail(Slot &sl, const PreTable &pt, const PreGeom &g, const uint32_t *off, const uint32_t *entries, bool derive_dyn, uint64_t *out_xyz, const msm::RowMap &map = msm::RowMap{}) {
     const uint32_t NB = g.NB; const size_t T = g.T; const int PW = g.PW;
     int32_t rc;
     if ((rc = sl.bucket.ensure(soa_points(NB) * C::XW * 4))) return rc;
@@ -319,7 +319,7 @@ int32_t pre_tail(Slot &sl, const PreTable &pt, const PreGeom &g, const uint32_t 
     {
         StageTimer st(sl, "msm.accumulate");
         if (derive_dyn) launch_accumulate_skip_identity<C>(s, (const uint32_t *)pt.tab, entries, off, NB, sl.bucket.as<uint32_t>(), sl.bucket_inf.as<uint8_t>(),
-                           sl.head.as<uint32_t>(), sl.tail.as<uint32_t>(), sl.head_b.as<uint32_t>(), sl.tail_b.as<uint32_t>(), sl.part_inf.as<uint8_t>(), T, (uint32_t)g.CH, dyn);
+                           sl.head.as<uint32_t>(), sl.tail.as<uint32_t>(), sl.head_b.as<uint32_t>(), sl.tail_b.as<uint32_t>(), sl.part_inf.as<uint8_t>(), T, (uint32_t)g.CH, dyn, map);
         else launch_accumulate<C>(s, (const uint32_t *)pt.tab, entries, off, NB, sl.bucket.as<uint32_t>(), sl.bucket_inf.as<uint8_t>(),
                            sl.head.as<uint32_t>(), sl.tail.as<uint32_t>(), sl.head_b.as<uint32_t>(), sl.tail_b.as<uint32_t>(), sl.part_inf.as<uint8_t>(), T, (uint32_t)g.CH, 0xffffffffu, dyn);
     }
@@ -398,21 +398,27 @@ inline int32_t scalars_sort(uint64_t table, size_t boff, uint64_t scalars, size_
     *sorted = register_handle(ss, n, 12);
     return DGPU_OK;
 }
+// row_shift > 0: the table holds the points of rows row_shift .. rows - 1 of the shape the list was sorted for (RowMap, msm_kernels.cuh)
 template <class C, class HF>
-int32_t msm_sorted(uint64_t table, uint64_t sorted, uint64_t *out, int kind) {
+int32_t msm_sorted(uint64_t table, uint64_t sorted, size_t row_shift, uint64_t *out, int kind) {
     if (!out) return DGPU_E_BADARG;
     if (!cur().ready) return DGPU_E_NODEVICE;
     HandleRef hb(table), hs(sorted);
     if (!hb.ok || !hs.ok || hb.h.kind != kind + 9 || hs.h.kind != 12 || hb.h.ctx != hs.h.ctx) return DGPU_E_BADARG;
     const PreTable &pt = *(const PreTable *)hb.h.p;
     const SortedScalars &ss = *(const SortedScalars *)hs.h.p;
-    if (pt.c != ss.c || pt.W != ss.W || pt.n != ss.rows || ss.boff > pt.n || ss.n > pt.n - ss.boff) return DGPU_E_BADARG;      // not the shape the list was sorted for
+    if (pt.c != ss.c || pt.W != ss.W || row_shift >= ss.rows || pt.n != ss.rows - row_shift) return DGPU_E_BADARG;      // not the shape the list was sorted for
     CtxScope on_owner(hb.h.ctx);
     SlotLock L; Slot &sl = *L.s;
     HIPCHK(hipSetDevice(cur().device));
     PreGeom g; int32_t rc;
     if ((rc = pre_geometry<C>(pt, ss.n, g))) return rc;
-    return pre_tail<C, HF>(sl, pt, g, (const uint32_t *)ss.off, (const uint32_t *)ss.entries, true, out);
+    msm::RowMap map;
+    if (row_shift) {
+        map.rows_src = (uint32_t)ss.rows; map.rows_dst = (uint32_t)pt.n; map.shift = (uint32_t)row_shift;
+        map.magic = ~(uint64_t)0 / ss.rows + 1;           // floor((2^64 - 1) / rows) + 1 >= 2^64 / rows, off by < 1: the quotient of any row < 2^32 is exact
+    }
+    return pre_tail<C, HF>(sl, pt, g, (const uint32_t *)ss.off, (const uint32_t *)ss.entries, true, out, map);
 }
 
 // In-place: the bases behind `handle` (kind 1 / 2, or every part of a sharded handle 7 / 8) become precomputed-multiples tables.

@@ -166,11 +166,15 @@ template <> __device__ __forceinline__ void load_aff<G2P>(Aff<Fp2H> &p, const ui
 // 0xffffffff.  bucket_inf[b] must be pre-set to 1; it is cleared by whoever writes bucket b.
 // SKIP_ID: terms whose base record carries the identity flag are passed over here (the sorted list came from a sort shared by several
 // tables, which cannot drop them per table: dgpu_scalars_sort / dgpu_msm_*_sorted)
+// RowMap (SKIP_ID instance only): the list was sorted for tables of rows_src rows per window; this table has rows_dst = rows_src - shift rows
+// and holds the points of rows shift .. rows_src - 1 (the l_query of a proof against the list sorted for its a_query): entry w rows_src + r
+// becomes w rows_dst + (r - shift), entries with r < shift are passed over.  rows_src == 0: entries are used as they are.
+struct RowMap { uint32_t rows_src = 0, rows_dst = 0, shift = 0; uint64_t magic = 0; /* ceil(2^64 / rows_src) */ };
 template <class C, bool SKIP_ID = false>
 __global__ void __launch_bounds__(256, C::ACC_WAVES) k_accumulate(const uint32_t *__restrict__ bases, const uint32_t *__restrict__ entries, const uint32_t *__restrict__ off,
                                                     uint32_t NB, uint32_t *__restrict__ bucket, uint8_t *__restrict__ bucket_inf,
                                                     uint32_t *__restrict__ head, uint32_t *__restrict__ tail, uint32_t *__restrict__ head_b, uint32_t *__restrict__ tail_b,
-                                                    uint8_t *__restrict__ part_inf, size_t T, uint32_t CH, uint32_t dbg_mask, const uint32_t *__restrict__ dyn) {
+                                                    uint8_t *__restrict__ part_inf, size_t T, uint32_t CH, uint32_t dbg_mask, const uint32_t *__restrict__ dyn, RowMap map) {
     typedef typename C::F F;
     size_t t = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / C::LPP;   // C::LPP lanes cooperate on one chunk
     if (dyn) { CH = dyn[DYN_CH]; T = dyn[DYN_T]; }      // chunking chosen on the device from the number of terms the sort produced
@@ -205,7 +209,16 @@ __global__ void __launch_bounds__(256, C::ACC_WAVES) k_accumulate(const uint32_t
             }
         }
         uint32_t e = entries[pos];
-        const uint32_t *rec = bases + (size_t)(e & 0x7fffffffu & dbg_mask) * C::AFF_STRIDE;
+        uint32_t row = e & 0x7fffffffu & dbg_mask;
+        if constexpr (SKIP_ID) {
+            if (map.rows_src) {
+                const uint32_t w = (uint32_t)__umul64hi((uint64_t)row, map.magic);      // row / rows_src (exact: row rows_src < 2^64)
+                const uint32_t r = row - w * map.rows_src;
+                if (r < map.shift) continue;
+                row = w * map.rows_dst + (r - map.shift);
+            }
+        }
+        const uint32_t *rec = bases + (size_t)row * C::AFF_STRIDE;
         if constexpr (SKIP_ID) { if (rec[C::AFF_STRIDE * 7 / 8] != 0) continue; }          // flag word: x, y, flag, pad
         Aff<F> p; load_aff<C>(p, rec);
         xyzz_madd(acc, inf, p, (e >> 31) != 0);

@@ -11,7 +11,7 @@ template <class C> void launch_prep_bases(hipStream_t s, const uint32_t *abi, co
 template <class C> void launch_accumulate(hipStream_t s, const uint32_t *bases, const uint32_t *entries, const uint32_t *off, uint32_t NB, uint32_t *bucket, uint8_t *bucket_inf,
                                           uint32_t *head, uint32_t *tail, uint32_t *head_b, uint32_t *tail_b, uint8_t *part_inf, size_t T, uint32_t CH, uint32_t dbg_mask, const uint32_t *dyn = nullptr);
 template <class C> void launch_accumulate_skip_identity(hipStream_t s, const uint32_t *bases, const uint32_t *entries, const uint32_t *off, uint32_t NB, uint32_t *bucket, uint8_t *bucket_inf,
-                                          uint32_t *head, uint32_t *tail, uint32_t *head_b, uint32_t *tail_b, uint8_t *part_inf, size_t T, uint32_t CH, const uint32_t *dyn);
+                                          uint32_t *head, uint32_t *tail, uint32_t *head_b, uint32_t *tail_b, uint8_t *part_inf, size_t T, uint32_t CH, const uint32_t *dyn, const RowMap &map);
 template <class C> void launch_fixup(hipStream_t s, uint32_t NB, uint32_t *bucket, uint8_t *bucket_inf, const uint32_t *head, const uint32_t *tail, const uint32_t *head_b,
                                      const uint32_t *tail_b, const uint8_t *part_inf, size_t T, const uint32_t *off, uint32_t heavy_thr, const uint32_t *dyn = nullptr);
 template <class C> void launch_fixup_heavy(hipStream_t s, const uint32_t *heavy, uint32_t heavy_cap, const uint32_t *off, uint32_t CH, uint32_t NB, uint32_t *bucket, uint8_t *bucket_inf,

@@ -233,12 +233,18 @@ def create_proof(pk, r, s, v, h, input_assignment_with_one, witness_assignment, 
     if share_sort and pk.a_query.same_table_shape(pk.b_g2_query) and (not with_b1 or pk.a_query.same_table_shape(pk.b_g1_query)):
         shared = M.SortedScalars(pk.a_query, assignment, min(assignment.n - a0, pk.a_query.n - 1), base_offset=1, scalar_offset=a0)
         coeff_msm = lambda query: (lambda: query.msm_sorted(shared))
+    # ... and the l_query MSM (the assignment minus its first len(inp) - 1 + cw entries against a table that many + 1 rows shorter) joins when
+    # its table has the same window geometry: its rows are the a_query's rows from the (len(inp) + cw)-th on
+    l_shift = len(inp) + cw
+    sa, sl_ = pk.a_query.table_shape(), pk.l_query.table_shape() if isinstance(pk.l_query, M.DeviceBases) else None
+    l_shares = shared is not None and sl_ is not None and sl_[1:] == sa[1:] and sl_[0] + l_shift == sa[0] and n_aux == pk.l_query.n and shared.n == pk.a_query.n - 1
     # Issue order = the order in which the accumulations get the chip.  The G2 MSM is the longest call and ends in ~3 ms of latency-bound
     # kernels (fix-up, bucket reduction): first in, its tail runs under the G1 MSMs instead of after them.
     f_b2 = pool.submit(coeff_msm(pk.b_g2_query))                                                      # :343-344
     f_a = pool.submit(coeff_msm(pk.a_query))                                                          # :325-326
     f_b1 = pool.submit(coeff_msm(pk.b_g1_query)) if with_b1 else None
-    f_l = pool.submit(lambda: pk.l_query.msm_resident(assignment, n=min(pk.l_query.n, n_aux), scalar_offset=aux_at))   # :299
+    f_l = pool.submit((lambda: pk.l_query.msm_sorted(shared, row_shift=l_shift)) if l_shares else
+                      (lambda: pk.l_query.msm_resident(assignment, n=min(pk.l_query.n, n_aux), scalar_offset=aux_at)))   # :299
     # The O(1)-sized pieces that depend on no MSM result (one job, one call in flight: they hide behind the large MSMs instead of forming
     # a ~2 ms chain of tiny launches after the last of them): the constant parts of calculate_coeff, of g_c, and g_d.
     def constants():

@@ -189,10 +189,11 @@ class DeviceBases:
         a = self.table_shape()
         return a is not None and isinstance(other, DeviceBases) and a == other.table_shape()
 
-    def msm_sorted(self, sorted_scalars):
-        """the MSM over a list dgpu_scalars_sort produced for a table of this shape (SortedScalars)"""
+    def msm_sorted(self, sorted_scalars, row_shift=0):
+        """the MSM over a list dgpu_scalars_sort produced for a table of this shape (SortedScalars); row_shift = k: this table is k rows
+        shorter than that shape and pairs with the scalars from the k-th on (the l_query against the a_query's list)"""
         out = np.zeros(self.curve.JW, dtype=np.uint64)
-        rc = self.curve.fn("dgpu_msm_%s_sorted")(self.handle, sorted_scalars.handle, _p(out))
+        rc = self.curve.fn("dgpu_msm_%s_sorted")(self.handle, sorted_scalars.handle, row_shift, _p(out))
         if rc:
             raise DockGpuError(rc, "dgpu_msm_sorted")
         return out

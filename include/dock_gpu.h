@@ -107,11 +107,13 @@ int32_t dgpu_bases_precompute_g2(uint64_t bases, int32_t window_bits);
  * the (window, bucket) keys is the same for all three: dgpu_scalars_sort does it once — for scalars [scalar_offset, scalar_offset + n) against rows
  * [base_offset, base_offset + n) of any table of that shape (G1 or G2) — and dgpu_msm_g1/g2_sorted run the rest of the MSM on a table of
  * that shape (DGPU_E_BADARG otherwise).  Identity rows of a table are passed over by the accumulation.  The result is the group element
- * dgpu_msm_*_resident returns for the same operands.  Free the sorted handle with dgpu_scalars_free once the MSMs have returned. */
+ * dgpu_msm_*_resident returns for the same operands.  row_shift = k > 0: the table is k rows SHORTER than that shape and holds the points
+ * of its rows k, k + 1, ... (the l_query against the list sorted for the a_query: the assignment minus its first k entries, prover.rs:292-299);
+ * the terms of rows < k are passed over.  Free the sorted handle with dgpu_scalars_free once the MSMs have returned. */
 int32_t dgpu_bases_table_shape(uint64_t table, size_t *rows, int32_t *window_bits, int32_t *windows);   /* DGPU_E_BADARG: not a precomputed table */
 int32_t dgpu_scalars_sort(uint64_t table, size_t base_offset, uint64_t scalars, size_t scalar_offset, size_t n, uint64_t *sorted_handle);
-int32_t dgpu_msm_g1_sorted(uint64_t table, uint64_t sorted, uint64_t out_xyz[18]);
-int32_t dgpu_msm_g2_sorted(uint64_t table, uint64_t sorted, uint64_t out_xyz[36]);
+int32_t dgpu_msm_g1_sorted(uint64_t table, uint64_t sorted, size_t row_shift, uint64_t out_xyz[18]);
+int32_t dgpu_msm_g2_sorted(uint64_t table, uint64_t sorted, size_t row_shift, uint64_t out_xyz[36]);
 /* both operands resident: the timed region of bench.py (inputs already in HBM) */
 int32_t dgpu_msm_g1_resident(uint64_t bases, size_t base_offset, uint64_t scalars, size_t scalar_offset, size_t n, uint64_t out_xyz[18]);
 int32_t dgpu_msm_g2_resident(uint64_t bases, size_t base_offset, uint64_t scalars, size_t scalar_offset, size_t n, uint64_t out_xyz[36]);

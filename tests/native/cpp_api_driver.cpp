@@ -119,8 +119,8 @@ int main() {
             EXPECT(dgpu_bases_table_shape(h, &rows, &cbits, &wins) == DGPU_OK && rows == n && cbits == 16 && wins == 16);
             EXPECT(dgpu_scalars_upload(sc.data(), n, 0, &hsc) == DGPU_OK);
             EXPECT(dgpu_scalars_sort(h, 0, hsc, 0, n, &srt) == DGPU_OK);
-            EXPECT(dgpu_msm_g1_sorted(h, srt, viaSort) == DGPU_OK && std::memcmp(plain, viaSort, sizeof plain) == 0);
-            EXPECT(dgpu_msm_g1_sorted(h, hsc, viaSort) == DGPU_E_BADARG);
+            EXPECT(dgpu_msm_g1_sorted(h, srt, 0, viaSort) == DGPU_OK && std::memcmp(plain, viaSort, sizeof plain) == 0);
+            EXPECT(dgpu_msm_g1_sorted(h, hsc, 0, viaSort) == DGPU_E_BADARG);
             EXPECT(dgpu_scalars_free(srt) == DGPU_OK && dgpu_scalars_free(hsc) == DGPU_OK);
         }
         EXPECT(dgpu_bases_free(h) == DGPU_OK);

@@ -120,6 +120,8 @@ def test_one_sort_shared_by_tables_of_one_shape(n, c):
     inf_b = np.zeros(n, np.uint8); inf_b[::7] = 1; b1b[5] = 0; inf2 = np.zeros(n, np.uint8); inf2[3::11] = 1            # B queries have identity rows
     ta = ca.DeviceBases(ca.G1, b1).precompute(c); tb = ca.DeviceBases(ca.G1, b1b, inf_b).precompute(c); t2 = ca.DeviceBases(ca.G2, b2, inf2).precompute(c)
     assert ta.same_table_shape(tb) and ta.same_table_shape(t2)
+    inf_l = np.zeros(n, np.uint8); inf_l[2::13] = 1
+    tl = {k: ca.DeviceBases(ca.G1, b1b[k:], inf_l[k:]).precompute(c if c else ta.table_shape()[1]) for k in (1, 3, n // 5)}
     rng = np.random.default_rng(n)
     uniform = O.rand_scalars(2400 + n, n)
     groth = uniform.copy(); kind = rng.integers(0, 4, n); groth[kind <= 1] = 0; groth[kind == 1, 0] = 1; m = kind == 2; groth[m, 1:] = 0; groth[m, 0] &= np.uint64(0xFFFF)
@@ -132,6 +134,11 @@ def test_one_sort_shared_by_tables_of_one_shape(n, c):
                 got = list(ex.map(lambda t: t.msm_sorted(srt), (ta, tb, t2)))
             for t, g in zip((ta, tb, t2), got):
                 assert (g == t.msm_resident(ds, n=cnt, base_offset=boff, scalar_offset=soff)).all(), (boff, soff, cnt)
+            # a table k rows shorter that holds the points of rows k .. n - 1 (the l_query against the a_query's list): rows < k are passed over
+            for k in (1, 3, n // 5):
+                i0 = max(0, k - boff)
+                if cnt - i0 > 0:
+                    assert (tl[k].msm_sorted(srt, row_shift=k) == tl[k].msm_resident(ds, n=cnt - i0, base_offset=boff + i0 - k, scalar_offset=soff + i0)).all(), (k, boff, soff, cnt)
             srt.free()
         ds.free()
     # the oracle itself on one case
@@ -149,10 +156,12 @@ def test_one_sort_shared_by_tables_of_one_shape(n, c):
             bad.msm_sorted(srt)
     out = np.zeros(18, np.uint64)
     import ctypes as C
-    assert lib().dgpu_msm_g1_sorted(ta.handle, ds.handle, out.ctypes.data_as(C.c_void_p)) == -3          # a scalars handle is not a sorted list
+    assert lib().dgpu_msm_g1_sorted(ta.handle, ds.handle, 0, out.ctypes.data_as(C.c_void_p)) == -3          # a scalars handle is not a sorted list
     h = C.c_uint64(0)
     assert lib().dgpu_scalars_sort(plain.handle, 0, ds.handle, 0, n, C.byref(h)) == -3                    # not a table
     assert lib().dgpu_scalars_sort(ta.handle, 2, ds.handle, 0, n, C.byref(h)) == -3                       # rows past the end
     srt.free(); ds.free()
-    for t in (ta, tb, t2, other, wide, plain):
+    with pytest.raises(ca.DockGpuError):
+        ta.msm_sorted(ca.SortedScalars(ta, ca.DeviceScalars(uniform), n), row_shift=1)          # the table is not one row shorter
+    for t in (ta, tb, t2, other, wide, plain) + tuple(tl.values()):
         t.free()

@@ -183,7 +183,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    run_steps(min(args.steps, 2 * inflight))          # warm every slot's workspace (untimed)
+    run_steps(2 * inflight)                           # untimed: every host thread / slot has run once (the workspaces were sized at upload / precompute)
     # sequential pass (one call in flight): per-stage HIP-event times without overlap, and the single-call latency
     ca.prof.enable(True)
     ca.prof.reset()
@@ -196,12 +196,14 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    allocs0 = ca.device_alloc_count()
     t0 = time.perf_counter()
     last = run_steps(args.steps)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    allocs_timed = ca.device_alloc_count() - allocs0
     assert (last == res).all(), "result changed between runs"
     stages = ca.prof.read()
     ca.prof.enable(False)
@@ -231,7 +233,8 @@ def main():
                     traffic = tr.get("hbm_bytes_per_launch")
             except Exception:
                 pass
-        windows = (13 if n >= 741455 else 16) if use_table else (16 if args.log2n >= 17 else None)
+        shape = db.table_shape()                   # (rows, window bits, windows) when the handle is a table
+        windows = shape[2] if shape else (16 if args.log2n >= 17 else None)
         out = {
             "metric": "BLS12-381 G1 MSM/s at n=2^20 (1 GPU) and n=2^24 (8 GPU); bit-exact vs CPU",
             "value": round(value, 3), "unit": "MSM/s (n=2^20-term equivalents, whole job)",
@@ -249,7 +252,7 @@ def main():
                 "scaling_note": "N = 1 is BASELINE config 2 (2^20 terms); every N > 1 computes config 5's 2^24 terms in total, so the N > 1 "
                                 "values are a strong-scaling series; secondary.g1_2p24_single_gpu is the 1-GPU time of the same 2^24 terms"},
             "terms_per_s": round(terms / (dt / args.steps), 1),
-            "inflight": inflight, "latency_ms_one_in_flight": round(latency_ms, 4),
+            "inflight": inflight, "latency_ms_one_in_flight": round(latency_ms, 4), "device_allocations_in_timed_region": int(allocs_timed),
             "stages_ms": {k.replace("msm.", ""): round(v[0] / max(1, v[1]), 4) for k, v in stages.items()},
             "stages_ms_one_in_flight": {k.replace("msm.", ""): round(v[0] / max(1, v[1]), 4) for k, v in stages_seq.items()},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 6),
@@ -325,28 +328,34 @@ def secondary_configs(log2n, ks, scalars, db, ds, pool):
     n = 1 << log2n
     res = {}
 
+    from concurrent.futures import ThreadPoolExecutor as _TP4
+    pool4 = _TP4(4)
+
     def thr4(fn, k=16):
-        list(pool.map(lambda _: fn(), range(4)))
+        """ms per call with four calls in flight (four host threads); warmed concurrently on the same threads"""
+        list(pool4.map(lambda _: fn(), range(8)))
         t0 = time.perf_counter()
-        list(pool.map(lambda _: fn(), range(k)))
+        list(pool4.map(lambda _: fn(), range(k)))
         return (time.perf_counter() - t0) / k * 1e3
 
     with FB.WindowTable(ca.G1, gen1[0]) as t1:
         plain = t1.multiply_many_to_bases(ks)
         host_bases, _ = t1.multiply_many(ks)
     # -- the plain resident pipeline (no table): what a handle costs before dgpu_bases_precompute_g1
-    for _ in range(12):                                # every slot's workspace grows on its first plain call of this size
-        plain.msm_resident(ds)
-    res["plain_resident"] = {"latency_ms": round(timed(lambda: plain.msm_resident(ds)), 3), "ms_per_msm_4_in_flight": round(thr4(lambda: plain.msm_resident(ds)), 3)}
+    a0 = ca.device_alloc_count()
+    res["plain_resident"] = {"latency_ms": round(timed(lambda: plain.msm_resident(ds), 5, warm=3), 3), "ms_per_msm_4_in_flight": round(thr4(lambda: plain.msm_resident(ds), 24), 3)}
     res["plain_resident"]["msm_per_s"] = round(1e3 / res["plain_resident"]["ms_per_msm_4_in_flight"], 2)
+    res["plain_resident"]["device_allocations"] = int(ca.device_alloc_count() - a0)       # 0: the slots were sized when the handle was created
     # -- H2D-inclusive (SURVEY 8d config 2): fresh host scalars per call against the resident key (32 B/term over PCIe), and the full one-shot
     #    call (bases + scalars from host memory: 128 B/term) — never `value`
     res["h2d_inclusive"] = {
         "resident_table_fresh_scalars_ms": round(timed(lambda: db.msm_bigint(scalars)), 3),
         "resident_table_fresh_scalars_ms_per_msm_4_in_flight": round(thr4(lambda: db.msm_bigint(scalars), 12), 3),
         "resident_plain_fresh_scalars_ms": round(timed(lambda: plain.msm_bigint(scalars)), 3),
-        "one_shot_bases_and_scalars_ms": round(timed(lambda: ca.msm_bigint(ca.G1, host_bases, scalars), 3), 3),
-        "note": "dgpu_msm_g1_handle (upload of n x 32 B scalars inside the call) and dgpu_msm_g1 (n x 128 B inside the call), pageable host memory"}
+        "one_shot_bases_and_scalars_ms": round(timed(lambda: ca.msm_bigint(ca.G1, host_bases, scalars), 5, warm=2), 3),
+        "one_shot_strided_affine_structs_ms": round(timed(lambda st=ca.to_affine_structs(ca.G1, host_bases): ca.msm_strided(ca.G1, st, scalars), 5, warm=2), 3),
+        "note": "dgpu_msm_g1_handle (upload of n x 32 B scalars inside the call), dgpu_msm_g1 (n x 128 B inside the call) and dgpu_msm_g1_strided (the caller's 104-byte Affine structs: n x 136 B), pageable host memory; "
+                "the scalars are sorted while the bases cross PCIe, the conversion of a 16-MB piece runs under the copy of the next"}
     # -- SURVEY 8d secondary scalar distributions, on the table path, one call in flight
     rng = np.random.Generator(np.random.PCG64(0x5EED0009))
     d = {}

@@ -3,12 +3,21 @@
 #include "dock_ctx.hpp"
 #include "host_field.hpp"
 #include "qap_launch.cuh"
+#include <chrono>
 #include <thread>
 
 namespace dock {
 Shared gs;
 Ctx ctxs[MAX_CTX];
 thread_local int tl_ctx = -1;
+std::atomic<uint64_t> g_dev_allocs{0}, g_dev_alloc_ns{0}, g_dev_alloc_bytes{0};
+hipError_t dev_malloc(void **p, size_t bytes) {
+    const auto t0 = std::chrono::steady_clock::now();
+    const hipError_t e = hipMalloc(p, bytes);
+    g_dev_alloc_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+    g_dev_allocs++; if (e == hipSuccess) g_dev_alloc_bytes += bytes;
+    return e;
+}
 
 int choose_c(size_t n, bool g2) {
     { const int wb = gs.window_bits.load(); if (wb >= 7 && wb <= 22) return wb; }
@@ -30,11 +39,13 @@ int choose_c(size_t n, bool g2) {
     else bc = 8;
     return bc;
 }
-// a chunk length forced by a tuning knob (dgpu_set_chunk / DGPU_CHUNK: any chunk length gives the same point, tests/test_gpu_msm.py sweeps it), else 0
+// a chunk length forced by a tuning knob (dgpu_set_chunk; DGPU_CHUNK in -DDGPU_DEV builds only: any chunk length gives the same point, tests/test_gpu_msm.py sweeps it), else 0
 int forced_chunk() {
-    if (gs.chunk) return gs.chunk;
+    if (int f = gs.chunk.load()) return f;
+#ifdef DGPU_DEV
     const char *e = getenv("DGPU_CHUNK");
     if (e) { int v = atoi(e); if (v >= 16 && v <= 4096) return v; }
+#endif
     return 0;
 }
 int choose_chunk(size_t E, int min_chunk, size_t max_chunks, int lanes_per_chunk) {
@@ -79,7 +90,12 @@ static int32_t init_ctx_locked(int idx, int device) {
     Ctx &c = ctxs[idx];
     if (c.ready) return c.device == device ? DGPU_OK : DGPU_E_BADARG;
     HIPCHK(hipSetDevice(device));
-    for (int i = 0; i < N_SLOTS; i++) HIPCHK(hipStreamCreateWithFlags(&c.slots[i].stream, hipStreamNonBlocking));
+    for (int i = 0; i < N_SLOTS; i++) {
+        HIPCHK(hipStreamCreateWithFlags(&c.slots[i].stream, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&c.slots[i].cstream, hipStreamNonBlocking));
+        for (hipEvent_t &e : c.slots[i].copy_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        HIPCHK(c.slots[i].flags.ensure(64) ? hipErrorOutOfMemory : hipSuccess);
+    }
     c.device = device; c.ready = true;
     if (gs.default_ctx < 0) gs.default_ctx = idx;
     return DGPU_OK;
@@ -125,7 +141,9 @@ int32_t dgpu_shutdown(void) {
             (void)hipStreamSynchronize(c.slots[k].stream);
             c.slots[k].release_all();
             (void)hipStreamDestroy(c.slots[k].stream);
-            c.slots[k].stream = nullptr;
+            (void)hipStreamDestroy(c.slots[k].cstream);
+            for (hipEvent_t &e : c.slots[k].copy_ev) { if (e) (void)hipEventDestroy(e); e = nullptr; }
+            c.slots[k].stream = nullptr; c.slots[k].cstream = nullptr;
         }
     }
     for (auto &h : gs.handles) {
@@ -169,6 +187,8 @@ int32_t dgpu_last_hip_error(void) { return gs.last_hip.load(); }
 int32_t dgpu_set_min_gpu_n(size_t n) { gs.min_gpu_n = n; return DGPU_OK; }
 size_t dgpu_get_min_gpu_n(void) { return gs.min_gpu_n.load(); }
 int32_t dgpu_set_window_bits(int32_t c) { if (c != 0 && (c < 7 || c > 22)) return DGPU_E_BADARG; gs.window_bits = c; return DGPU_OK; }
+int32_t dgpu_set_chunk(int32_t terms) { if (terms != 0 && (terms < 16 || terms > 4096)) return DGPU_E_BADARG; gs.chunk = terms; return DGPU_OK; }
+uint64_t dgpu_device_alloc_count(void) { return g_dev_allocs.load(); }
 
 
 // A free waits until no call uses the handle (HandleRef pins), then releases the memory outside the table lock: every entry point
@@ -264,11 +284,13 @@ int32_t dgpu_scalars_upload_sharded(const uint64_t *sc, size_t n, int32_t mont, 
 }
 
 int32_t dgpu_prof_enable(int32_t on) { gs.prof = on != 0; return DGPU_OK; }
-int32_t dgpu_prof_reset(void) { std::lock_guard<std::mutex> lk(gs.mu); gs.prof_tab.clear(); return DGPU_OK; }
+int32_t dgpu_prof_reset(void) { std::lock_guard<std::mutex> lk(gs.mu); gs.prof_tab.clear(); gs.allocs_at_reset = g_dev_allocs.load(); gs.alloc_ns_at_reset = g_dev_alloc_ns.load(); return DGPU_OK; }
 int32_t dgpu_prof_read(const char **names, double *total_ms, uint64_t *calls, int32_t cap) {
     std::lock_guard<std::mutex> lk(gs.mu);
     int32_t k = 0;
     for (auto &t : gs.prof_tab) { if (k >= cap) break; names[k] = t.name; total_ms[k] = t.ms; calls[k] = t.calls; k++; }
+    // device allocations since the last dgpu_prof_reset (counted whether or not the stage timers are enabled): 0 calls in steady state
+    if (k < cap) { names[k] = "hipMalloc"; total_ms[k] = (double)(g_dev_alloc_ns.load() - gs.alloc_ns_at_reset) * 1e-6; calls[k] = g_dev_allocs.load() - gs.allocs_at_reset; k++; }
     return k;
 }
 

@@ -14,13 +14,19 @@
 
 namespace dock {
 
+// Every hipMalloc the library issues goes through dev_malloc: the count and the time spent are reported by dgpu_device_alloc_count and as
+// the "hipMalloc" row of dgpu_prof_read.  A steady-state MSM / proof must not allocate (hipMalloc costs 0.1 - 1 ms, and the hipFree that
+// growing a buffer implies waits for the whole device, i.e. for every other call in flight): tests/test_gpu_reserve.py asserts a delta of 0.
+extern std::atomic<uint64_t> g_dev_allocs, g_dev_alloc_ns, g_dev_alloc_bytes;
+hipError_t dev_malloc(void **p, size_t bytes);
+
 struct Buf {
     void *p = nullptr; size_t cap = 0;
     int32_t ensure(size_t bytes) {
         if (bytes <= cap) return DGPU_OK;
         if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
         size_t want = bytes + bytes / 8 + 256;
-        if (hipMalloc(&p, want) != hipSuccess) { (void)hipGetLastError(); if (hipMalloc(&p, bytes) != hipSuccess) { p = nullptr; return DGPU_E_OOM; } want = bytes; }
+        if (dev_malloc(&p, want) != hipSuccess) { (void)hipGetLastError(); if (dev_malloc(&p, bytes) != hipSuccess) { p = nullptr; return DGPU_E_OOM; } want = bytes; }
         cap = want; return DGPU_OK;
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
@@ -49,12 +55,16 @@ extern Shared gs;
 struct Slot {
     std::mutex mu;
     hipStream_t stream = nullptr;
-    Buf in_bases, in_inf, in_scalars, prepped, digits, heavy, cnt, off, cursor, bsums, entries, bucket, bucket_inf, head, tail, head_b, tail_b, part_inf, l1, l1_inf, win, win_inf, ml_lines, ml_partial, ml_out, ml_coeffs, dyn, hpart, hpart_inf;
+    // H2D pieces travel on their own stream, ordered against the compute stream by these events: the kernels of a call run under its copies
+    static constexpr int N_COPY_EV = 8;
+    hipStream_t cstream = nullptr;
+    hipEvent_t copy_ev[N_COPY_EV + 1] = {};
+    Buf flags, in_bases, in_inf, in_scalars, prepped, digits, heavy, cnt, off, cursor, bsums, entries, bucket, bucket_inf, head, tail, head_b, tail_b, part_inf, l1, l1_inf, win, win_inf, ml_lines, ml_partial, ml_out, ml_coeffs, dyn, hpart, hpart_inf;
     Buf q[16];      // witness-map workspace (dock_qap.hip)
     std::vector<std::pair<const char *, std::pair<hipEvent_t, hipEvent_t>>> prof_pending;
     std::vector<hipEvent_t> ev_pool;
     void release_all() {
-        Buf *bufs[] = {&in_bases, &in_inf, &in_scalars, &prepped, &digits, &heavy, &cnt, &off, &cursor, &bsums, &entries, &bucket, &bucket_inf, &head, &tail, &head_b, &tail_b, &part_inf, &l1, &l1_inf, &win, &win_inf, &ml_lines, &ml_partial, &ml_out, &ml_coeffs, &dyn, &hpart, &hpart_inf};
+        Buf *bufs[] = {&flags, &in_bases, &in_inf, &in_scalars, &prepped, &digits, &heavy, &cnt, &off, &cursor, &bsums, &entries, &bucket, &bucket_inf, &head, &tail, &head_b, &tail_b, &part_inf, &l1, &l1_inf, &win, &win_inf, &ml_lines, &ml_partial, &ml_out, &ml_coeffs, &dyn, &hpart, &hpart_inf};
         for (Buf *b : bufs) b->release();
         for (Buf &b : q) b.release();
         for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
@@ -88,7 +98,8 @@ struct Shared {
     std::atomic<int32_t> last_hip{0};
     std::atomic<size_t> min_gpu_n{DGPU_DEFAULT_MIN_GPU_N};
     std::atomic<int> window_bits{0};
-    int chunk = 0;
+    std::atomic<int> chunk{0};
+    uint64_t allocs_at_reset = 0, alloc_ns_at_reset = 0;
     int default_ctx = -1;
     std::atomic<bool> prof{false};
     std::vector<ProfEntry> prof_tab;
@@ -121,7 +132,7 @@ inline void *scalar_alloc(size_t bytes) {
             if (pool[k].second == bytes) { void *p = pool[k].first; pool[k] = pool.back(); pool.pop_back(); cur().scalar_pool_bytes -= bytes; return p; }
     }
     void *p = nullptr;
-    if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (dev_malloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     return p;
 }
 // give it back (context `ctx` owns it; every call that used it has returned, so no stream still touches it)

@@ -39,8 +39,10 @@ template <class C, class HF> int32_t table_build(const uint64_t *base, uint64_t 
         HIPCHK(hipSetDevice(cur().device));
         int32_t rc;
         if ((rc = sl.prepped.ensure(32 * C::AFF_STRIDE * 4))) return rc;
-        if (hipMalloc(&tab, (size_t)msm::FIXED_TABLE_ENTRIES * C::AFF_STRIDE * 4) != hipSuccess) { (void)hipGetLastError(); return DGPU_E_OOM; }
-        rc = prep_bases<C>(sl, wb.data(), nullptr, 32, sl.prepped.as<uint32_t>());
+        if (dev_malloc(&tab, (size_t)msm::FIXED_TABLE_ENTRIES * C::AFF_STRIDE * 4) != hipSuccess) { (void)hipGetLastError(); return DGPU_E_OOM; }
+        const RawBases rb = RawBases::packed<C>(wb.data(), nullptr);
+        rc = ws_stage_bases<C>(sl, rb, 32);
+        if (rc == DGPU_OK) rc = stage_bases<C>(sl, rb, 32, sl.prepped.as<uint32_t>());
         if (rc == DGPU_OK) {
             StageTimer st(sl, "fixed.table");
             msm::launch_fb_table<C>(sl.stream, sl.prepped.as<uint32_t>(), (uint32_t *)tab);
@@ -65,7 +67,7 @@ template <class C> int32_t table_mul(uint64_t table, const uint64_t *scalars, si
     void *keep = nullptr;
     if (n == 0) {          // an empty query (a circuit whose witnesses are all committed has no l_query entries): an empty bases handle, no launch
         HIPCHK(hipSetDevice(cur().device));
-        if (hipMalloc(&keep, (size_t)C::AFF_STRIDE * 4) != hipSuccess) { (void)hipGetLastError(); return DGPU_E_OOM; }
+        if (dev_malloc(&keep, (size_t)C::AFF_STRIDE * 4) != hipSuccess) { (void)hipGetLastError(); return DGPU_E_OOM; }
         *bases_handle = register_handle(keep, 0, kind - 4);
         return DGPU_OK;
     }
@@ -82,7 +84,7 @@ template <class C> int32_t table_mul(uint64_t table, const uint64_t *scalars, si
       msm::launch_fb_mul<C>(sl.stream, (const uint32_t *)ht.p, sl.in_scalars.as<uint32_t>(), n, sl.in_bases.as<uint32_t>(), dinf); }
     HIPCHK(hipGetLastError());
     if (bases_handle) {
-        if (hipMalloc(&keep, std::max<size_t>(n, 1) * C::AFF_STRIDE * 4) != hipSuccess) { (void)hipGetLastError(); return DGPU_E_OOM; }
+        if (dev_malloc(&keep, std::max<size_t>(n, 1) * C::AFF_STRIDE * 4) != hipSuccess) { (void)hipGetLastError(); return DGPU_E_OOM; }
         if (n) msm::launch_prep_bases<C>(sl.stream, sl.in_bases.as<uint32_t>(), dinf, n, (uint32_t *)keep);
     } else {
         HIPCHK(hipMemcpyAsync(out, sl.in_bases.p, n * pt_bytes, hipMemcpyDeviceToHost, sl.stream));
@@ -91,7 +93,8 @@ template <class C> int32_t table_mul(uint64_t table, const uint64_t *scalars, si
     if (hipStreamSynchronize(sl.stream) != hipSuccess) { (void)hipGetLastError(); if (keep) (void)hipFree(keep); return DGPU_E_HIP; }
     if (gs.prof) prof_flush(sl);
     }
-    if (bases_handle) *bases_handle = register_handle(keep, n, kind - 4);      // 5 -> 1 (G1 bases), 6 -> 2 (G2 bases)
+    if (bases_handle) { *bases_handle = register_handle(keep, n, kind - 4);      // 5 -> 1 (G1 bases), 6 -> 2 (G2 bases)
+        (void)reserve_slots<C>(2, n, 0, nullptr); }
     return DGPU_OK;
 }
 

@@ -5,9 +5,14 @@ using namespace dock;
 extern "C" {
 int32_t dgpu_fold_g1(const uint64_t *xyz, size_t k, uint64_t out[18]) { return host_fold_jacobian<hostf::Fq>(xyz, k, out); }
 int32_t dgpu_lincomb_g1(const uint64_t *p, const uint8_t *inf, const uint64_t *s, size_t k, uint64_t out[18]) { return host_lincomb<hostf::Fq>(p, inf, s, k, out); }
-int32_t dgpu_msm_g1(const uint64_t *b, const uint8_t *inf, const uint64_t *s, size_t n, uint64_t out[18]) { return msm_oneshot<G1, hostf::Fq>(b, inf, s, n, false, out); }
-int32_t dgpu_msm_g1_mont(const uint64_t *b, const uint8_t *inf, const uint64_t *s, size_t n, uint64_t out[18]) { return msm_oneshot<G1, hostf::Fq>(b, inf, s, n, true, out); }
-int32_t dgpu_bases_upload_g1(const uint64_t *b, const uint8_t *inf, size_t n, uint64_t *h) { return bases_upload<G1>(b, inf, n, h, 1); }
+int32_t dgpu_msm_g1(const uint64_t *b, const uint8_t *inf, const uint64_t *s, size_t n, uint64_t out[18]) { return msm_oneshot<G1, hostf::Fq>(RawBases::packed<G1>(b, inf), s, n, false, out); }
+int32_t dgpu_msm_g1_mont(const uint64_t *b, const uint8_t *inf, const uint64_t *s, size_t n, uint64_t out[18]) { return msm_oneshot<G1, hostf::Fq>(RawBases::packed<G1>(b, inf), s, n, true, out); }
+int32_t dgpu_msm_g1_strided(const void *b, size_t stride, size_t x_off, size_t y_off, size_t inf_off, const uint64_t *s, size_t n, int32_t mont, uint64_t out[18]) {
+    return msm_oneshot<G1, hostf::Fq>(RawBases{(const uint8_t *)b, stride, x_off, y_off, inf_off, nullptr}, s, n, mont != 0, out); }
+int32_t dgpu_bases_upload_g1_strided(const void *b, size_t stride, size_t x_off, size_t y_off, size_t inf_off, size_t n, uint64_t *h) {
+    return bases_upload<G1>(RawBases{(const uint8_t *)b, stride, x_off, y_off, inf_off, nullptr}, n, h, 1); }
+int32_t dgpu_reserve_g1(size_t n) { CtxScope here(cur_index()); return reserve_slots<G1>(1, n, 104, nullptr); }
+int32_t dgpu_bases_upload_g1(const uint64_t *b, const uint8_t *inf, size_t n, uint64_t *h) { return bases_upload<G1>(RawBases::packed<G1>(b, inf), n, h, 1); }
 int32_t dgpu_msm_g1_handle(uint64_t b, size_t off, const uint64_t *s, size_t n, int32_t mont, uint64_t out[18]) { return msm_handle<G1, hostf::Fq>(b, off, s, n, mont, out, 1); }
 int32_t dgpu_msm_g1_sharded(const uint64_t *b, const uint8_t *inf, const uint64_t *s, size_t n, int32_t ngpus, uint64_t out[18]) { return msm_sharded_oneshot<G1, hostf::Fq>(b, inf, s, n, ngpus, false, out); }
 int32_t dgpu_bases_upload_g1_sharded(const uint64_t *b, const uint8_t *inf, size_t n, int32_t ngpus, uint64_t *h) { return bases_upload_sharded<G1>(b, inf, n, ngpus, h, 1); }
@@ -32,7 +37,7 @@ int32_t dgpu_selftest_fp_mul(const uint64_t *a, const uint64_t *b, size_t n, uin
     SlotLock L; Slot &sl = *L.s;
     HIPCHK(hipSetDevice(cur().device));
     void *da, *db, *dout;
-    HIPCHK(hipMalloc(&da, n * 48 + 16)); HIPCHK(hipMalloc(&db, n * 48 + 16)); HIPCHK(hipMalloc(&dout, n * 48 + 16));
+    HIPCHK(dev_malloc(&da, n * 48 + 16)); HIPCHK(dev_malloc(&db, n * 48 + 16)); HIPCHK(dev_malloc(&dout, n * 48 + 16));
     HIPCHK(hipMemcpy(da, a, n * 48, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(db, b, n * 48, hipMemcpyHostToDevice));
     launch_selftest_fp_mul(sl.stream, (const uint32_t *)da, (const uint32_t *)db, n, (uint32_t *)dout);
     HIPCHK(hipStreamSynchronize(sl.stream));
@@ -45,7 +50,7 @@ int32_t dgpu_selftest_g1_sum(const uint64_t *pts, const uint8_t *neg, size_t n, 
     SlotLock L; Slot &sl = *L.s;
     HIPCHK(hipSetDevice(cur().device));
     void *dp, *dn, *dout, *dinf;
-    HIPCHK(hipMalloc(&dp, n * 96 + 16)); HIPCHK(hipMalloc(&dn, n + 16)); HIPCHK(hipMalloc(&dout, 4 * 48)); HIPCHK(hipMalloc(&dinf, 16));
+    HIPCHK(dev_malloc(&dp, n * 96 + 16)); HIPCHK(dev_malloc(&dn, n + 16)); HIPCHK(dev_malloc(&dout, 4 * 48)); HIPCHK(dev_malloc(&dinf, 16));
     HIPCHK(hipMemcpy(dp, pts, n * 96, hipMemcpyHostToDevice));
     if (neg) HIPCHK(hipMemcpy(dn, neg, n, hipMemcpyHostToDevice)); else HIPCHK(hipMemset(dn, 0, n + 16));
     launch_selftest_g1_sum(sl.stream, (const uint32_t *)dp, (const uint8_t *)dn, n, (uint32_t *)dout, (uint8_t *)dinf);

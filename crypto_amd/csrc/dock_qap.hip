@@ -28,9 +28,9 @@ int32_t get_domain(Slot &sl, int logn, NttDomain &out) {
     NttDomain d;
     void *dc = nullptr;
     const size_t esz = ntt::FR_WORDS * 4;
-    if (hipMalloc(&dc, sizeof consts) != hipSuccess || hipMalloc(&d.tw_f, 2 * H * esz) != hipSuccess || hipMalloc(&d.tw_i, 2 * H * esz) != hipSuccess ||
-        hipMalloc(&d.pw_f, D * esz) != hipSuccess || hipMalloc(&d.pw_i, D * esz) != hipSuccess || hipMalloc(&d.zinv, 32) != hipSuccess ||
-        hipMalloc(&d.pwr_f, D * esz) != hipSuccess || hipMalloc(&d.pwr_i, D * esz) != hipSuccess) { (void)hipGetLastError(); return DGPU_E_OOM; }
+    if (dev_malloc(&dc, sizeof consts) != hipSuccess || dev_malloc(&d.tw_f, 2 * H * esz) != hipSuccess || dev_malloc(&d.tw_i, 2 * H * esz) != hipSuccess ||
+        dev_malloc(&d.pw_f, D * esz) != hipSuccess || dev_malloc(&d.pw_i, D * esz) != hipSuccess || dev_malloc(&d.zinv, 32) != hipSuccess ||
+        dev_malloc(&d.pwr_f, D * esz) != hipSuccess || dev_malloc(&d.pwr_i, D * esz) != hipSuccess) { (void)hipGetLastError(); return DGPU_E_OOM; }
     hipStream_t s = sl.stream;
     HIPCHK(hipMemcpyAsync(dc, consts, sizeof consts, hipMemcpyHostToDevice, s));
     const uint32_t *c32 = (const uint32_t *)dc;
@@ -64,8 +64,8 @@ int32_t upload_matrix(Slot &sl, const Csr &m, size_t rows, int mont, DevCsr &out
     const size_t nnz = m.nnz ? m.nnz : 1;
     int32_t rc;
     if ((rc = sl.q[0].ensure(nnz * 32))) return rc;
-    if (hipMalloc((void **)&out.rowptr, (rows + 1) * 8) != hipSuccess || hipMalloc((void **)&out.cols, nnz * 4) != hipSuccess ||
-        hipMalloc((void **)&out.vals, nnz * ntt::FR_WORDS * 4) != hipSuccess) { (void)hipGetLastError(); return DGPU_E_OOM; }
+    if (dev_malloc((void **)&out.rowptr, (rows + 1) * 8) != hipSuccess || dev_malloc((void **)&out.cols, nnz * 4) != hipSuccess ||
+        dev_malloc((void **)&out.vals, nnz * ntt::FR_WORDS * 4) != hipSuccess) { (void)hipGetLastError(); return DGPU_E_OOM; }
     out.nnz = nnz;
     hipStream_t s = sl.stream;
     HIPCHK(hipMemcpyAsync(out.rowptr, m.rowptr, (rows + 1) * 8, hipMemcpyHostToDevice, s));

@@ -3,10 +3,10 @@
 #include "sort_launch.cuh"
 
 namespace msm {
-void launch_digit_codes(hipStream_t s, bool wide, const uint32_t *scalars, const uint32_t *bases, int aff_stride, int flag_word, size_t n, size_t n_pad, int c, int W, void *dig) {
+void launch_digit_codes(hipStream_t s, bool wide, const uint32_t *scalars, const uint32_t *bases, int aff_stride, int flag_word, size_t n, size_t n_pad, int c, int W, void *dig, uint32_t *bad) {
     dim3 grid((unsigned)((n_pad + 255) / 256));
-    if (!wide) hipLaunchKernelGGL((k_digit_codes<uint16_t>), grid, dim3(256), 0, s, scalars, bases, aff_stride, flag_word, n, n_pad, c, W, (uint16_t *)dig);
-    else hipLaunchKernelGGL((k_digit_codes<uint32_t>), grid, dim3(256), 0, s, scalars, bases, aff_stride, flag_word, n, n_pad, c, W, (uint32_t *)dig);
+    if (!wide) hipLaunchKernelGGL((k_digit_codes<uint16_t>), grid, dim3(256), 0, s, scalars, bases, aff_stride, flag_word, n, n_pad, c, W, (uint16_t *)dig, bad);
+    else hipLaunchKernelGGL((k_digit_codes<uint32_t>), grid, dim3(256), 0, s, scalars, bases, aff_stride, flag_word, n, n_pad, c, W, (uint32_t *)dig, bad);
 }
 void launch_sort_sweep(hipStream_t s, bool wide, bool scatter, unsigned grid, size_t lds_bytes, const void *dig, size_t n, size_t n_pad, int W, int RANGES, int rb_log, uint32_t B,
                        uint32_t *cnt, const uint32_t *off, uint32_t *entries, uint32_t heavy_thr, uint32_t *heavy, uint32_t heavy_cap) {

@@ -7,6 +7,7 @@
 #include "host_field.hpp"
 #include "msm_launch.cuh"
 #include "sort_launch.cuh"
+#include "qap_launch.cuh"
 
 namespace dock {
 using namespace msm;
@@ -85,31 +86,49 @@ int32_t host_lincomb(const uint64_t *points_xy, const uint8_t *is_inf, const uin
     return DGPU_OK;
 }
 
-// d_bases: prepared records; d_scalars: canonical 8 x u32 per scalar.  Caller holds the slot.
-template <class C, class HF>
-int32_t msm_device(Slot &sl, const uint32_t *d_bases, const uint32_t *d_scalars, size_t n, uint64_t *out_xyz) {
-    if (n == 0) { typedef hostf::HXyzz<HF> PT; PT id = PT::identity(); HF X, Y, Z; id.to_normalised_jacobian(X, Y, Z);
-        const size_t FWORDS = sizeof(HF) / 8; memcpy(out_xyz, &X, sizeof(HF)); memcpy(out_xyz + FWORDS, &Y, sizeof(HF)); memcpy(out_xyz + 2 * FWORDS, &Z, sizeof(HF)); return DGPU_OK; }
+// ---- geometry + workspace of the plain pipeline ---------------------------------------------------------------------------------------
+struct PlainGeom {
+    int c, W; uint32_t B, NB; int mshift, G; size_t NG, Emax; int CH; size_t T, nblk; bool wide; size_t n_pad; int RANGES, rb_log; unsigned sort_grid; size_t lds_bytes;
+    uint32_t min_chunk, max_chunks, lanes_per_chunk, HEAVY_CAP;
+};
+template <class C> int32_t plain_geometry(size_t n, PlainGeom &g) {
     if (n >= (1ull << 31)) return DGPU_E_BADARG;
-    const int c = choose_c(n, C::NFP == 2);
-    const int W = 255 / c + 1;
-    const uint32_t B = 1u << (c - 1);
-    if ((uint64_t)W * B >= (1ull << 31) || (uint64_t)n * W >= (1ull << 32)) return DGPU_E_BADARG;
-    const uint32_t NB = (uint32_t)W * B;
-    const int mshift = std::max(0, c - 1 - 12);
-    const int G = (int)(B >> (6 + mshift));          // groups per window (<= 64), B >= 64 because c >= 7
-    const size_t NG = (size_t)W * G;
-    const size_t Emax = (size_t)n * W;
-    const int CH = C::NFP == 2 ? choose_chunk(Emax, 32, 150000, 2) : choose_chunk(Emax, 16, 300000, 1);
-    const size_t T = (Emax + CH - 1) / CH;
-    const size_t nblk = scan_blocks(NB);
-
+    g.c = choose_c(n, C::NFP == 2);
+    g.W = 255 / g.c + 1;
+    g.B = 1u << (g.c - 1);
+    if ((uint64_t)g.W * g.B >= (1ull << 31) || (uint64_t)n * g.W >= (1ull << 32)) return DGPU_E_BADARG;
+    g.NB = (uint32_t)g.W * g.B;
+    g.mshift = std::max(0, g.c - 1 - 12);
+    g.G = (int)(g.B >> (6 + g.mshift));          // groups per window (<= 64), B >= 64 because c >= 7
+    g.NG = (size_t)g.W * g.G;
+    g.Emax = (size_t)n * g.W;
+    g.CH = C::NFP == 2 ? choose_chunk(g.Emax, 32, 150000, 2) : choose_chunk(g.Emax, 16, 300000, 1);
+    g.T = (g.Emax + g.CH - 1) / g.CH;
+    g.nblk = scan_blocks(g.NB);
+    // counting sort of the n*W (key, term) pairs: digit codes -> LDS histograms per (window, bucket range) -> scan -> LDS cursors
+    g.wide = g.c > 16;
+    g.n_pad = (n + 7) & ~(size_t)7;
+    g.RANGES = 1; while ((g.B / g.RANGES) * 4 > 64 * 1024 || g.W * g.RANGES < 256) { if (g.B / g.RANGES <= 64) break; g.RANGES *= 2; }
+    g.rb_log = 0; while ((1u << g.rb_log) < g.B / g.RANGES) g.rb_log++;
+    g.sort_grid = (unsigned)(8 * ((g.W + 7) / 8) * g.RANGES);
+    g.lds_bytes = ((size_t)1 << g.rb_log) * 4;
+    // chunk length / heavy-bucket threshold of the accumulation are fixed on the device once the pair count is known (dyn_chunk.cuh): CH and T
+    // only size the launch and the partial slots
+    g.min_chunk = C::NFP == 2 ? 32u : 16u; g.max_chunks = C::NFP == 2 ? 150000u : 300000u; g.lanes_per_chunk = C::NFP == 2 ? 2u : 1u;
+    // a heavy bucket has >= 16 chunk lengths of terms and a chunk is never shorter than 16 terms (k_dyn_chunk, forced_chunk), whatever min_chunk says
+    g.HEAVY_CAP = (uint32_t)(g.Emax / (16u * 16u)) + 1;
+    return DGPU_OK;
+}
+// grow-only workspace of one slot for the plain pipeline of that geometry (no-ops once the slot has seen the size: dgpu_reserve_*, uploads)
+template <class C> int32_t ws_plain(Slot &sl, const PlainGeom &g) {
     int32_t rc;
-    if ((rc = sl.cnt.ensure(((size_t)NB + 1) * 4))) return rc;
-    if ((rc = sl.off.ensure(((size_t)NB + 1) * 4))) return rc;
-    if ((rc = sl.cursor.ensure(((size_t)NB + 1) * 4))) return rc;
-    if ((rc = sl.bsums.ensure((nblk + 2) * 4))) return rc;
-    if ((rc = sl.entries.ensure(Emax * 4))) return rc;
+    const size_t NB = g.NB, T = g.T;
+    if ((rc = sl.flags.ensure(64))) return rc;
+    if ((rc = sl.cnt.ensure((NB + 1) * 4))) return rc;
+    if ((rc = sl.off.ensure((NB + 1) * 4))) return rc;
+    if ((rc = sl.cursor.ensure((NB + 1) * 4))) return rc;
+    if ((rc = sl.bsums.ensure((g.nblk + 2) * 4))) return rc;
+    if ((rc = sl.entries.ensure(g.Emax * 4))) return rc;
     if ((rc = sl.bucket.ensure(soa_points(NB) * C::XW * 4))) return rc;
     if ((rc = sl.bucket_inf.ensure(NB))) return rc;
     if ((rc = sl.head.ensure(soa_points(T) * C::XW * 4))) return rc;
@@ -117,46 +136,51 @@ int32_t msm_device(Slot &sl, const uint32_t *d_bases, const uint32_t *d_scalars,
     if ((rc = sl.head_b.ensure(T * 4))) return rc;
     if ((rc = sl.tail_b.ensure(T * 4))) return rc;
     if ((rc = sl.part_inf.ensure(T * 2))) return rc;
-    if ((rc = sl.l1.ensure(NG * 2 * C::XW * 4))) return rc;
-    if ((rc = sl.l1_inf.ensure(NG * 2))) return rc;
-    if ((rc = sl.win.ensure((size_t)W * 4 * C::ABI_W * 4))) return rc;
-    if ((rc = sl.win_inf.ensure(W))) return rc;
-
-    hipStream_t s = sl.stream;
-    // counting sort of the n*W (key, term) pairs: digit codes -> LDS histograms per (window, bucket range) -> scan -> LDS cursors
-    const bool wide = c > 16;
-    const size_t n_pad = (n + 7) & ~(size_t)7;
-    int RANGES = 1; while ((B / RANGES) * 4 > 64 * 1024 || W * RANGES < 256) { if (B / RANGES <= 64) break; RANGES *= 2; }
-    int rb_log = 0; while ((1u << rb_log) < B / RANGES) rb_log++;
-    const int wpx = (W + 7) / 8;
-    const unsigned sort_grid = (unsigned)(8 * wpx * RANGES);
-    const size_t lds_bytes = ((size_t)1 << rb_log) * 4;
-    if ((rc = sl.digits.ensure((size_t)W * n_pad * (wide ? 4 : 2)))) return rc;
-    // chunk length / heavy-bucket threshold of the accumulation are fixed on the device once the pair count is known (dyn_chunk.cuh): CH and T above
-    // only size the launch and the partial slots
-    const uint32_t min_chunk = C::NFP == 2 ? 32u : 16u, max_chunks = C::NFP == 2 ? 150000u : 300000u, lanes_per_chunk = C::NFP == 2 ? 2u : 1u;
-    const uint32_t heavy_thr = 0xffffffffu /* the sweeps flag nothing: k_flag_heavy does, after the scan */, HEAVY_CAP = (uint32_t)(Emax / (16u * min_chunk)) + 1;
-    if ((rc = sl.heavy.ensure(((size_t)HEAVY_CAP + 1) * 4))) return rc;
+    if ((rc = sl.l1.ensure(g.NG * 2 * C::XW * 4))) return rc;
+    if ((rc = sl.l1_inf.ensure(g.NG * 2))) return rc;
+    if ((rc = sl.win.ensure((size_t)g.W * 4 * C::ABI_W * 4))) return rc;
+    if ((rc = sl.win_inf.ensure(g.W))) return rc;
+    if ((rc = sl.digits.ensure((size_t)g.W * g.n_pad * (g.wide ? 4 : 2)))) return rc;
+    if ((rc = sl.heavy.ensure(((size_t)g.HEAVY_CAP + 1) * 4))) return rc;
     if ((rc = sl.dyn.ensure(msm::dyn_words(T) * 4))) return rc;
     { const size_t hslots = 2 * (T / msm::HEAVY_RANGE + 2); if ((rc = sl.hpart.ensure(hslots * C::XW * 4))) return rc; if ((rc = sl.hpart_inf.ensure(hslots))) return rc; }
+    return DGPU_OK;
+}
+
+// d_bases: prepared records; d_scalars: canonical 8 x u32 per scalar.  Caller holds the slot.
+// bases_pending: the base records are still being written by work queued on this stream AFTER the sort (one-shot calls: the bases cross PCIe
+// while the scalars are sorted): the sort does not look at them and the accumulation passes over identity records itself; `before_accumulate`
+// is called between the sort and the accumulation to queue that work.
+template <class C, class HF, class Mid>
+int32_t msm_device(Slot &sl, const uint32_t *d_bases, const uint32_t *d_scalars, size_t n, uint64_t *out_xyz, bool bases_pending, Mid before_accumulate) {
+    if (n == 0) { typedef hostf::HXyzz<HF> PT; PT id = PT::identity(); HF X, Y, Z; id.to_normalised_jacobian(X, Y, Z);
+        const size_t FWORDS = sizeof(HF) / 8; memcpy(out_xyz, &X, sizeof(HF)); memcpy(out_xyz + FWORDS, &Y, sizeof(HF)); memcpy(out_xyz + 2 * FWORDS, &Z, sizeof(HF)); return DGPU_OK; }
+    PlainGeom g; int32_t rc;
+    if ((rc = plain_geometry<C>(n, g))) return rc;
+    if ((rc = ws_plain<C>(sl, g))) return rc;
+    const int c = g.c, W = g.W; const uint32_t NB = g.NB; const size_t T = g.T; const int CH = g.CH;
+    hipStream_t s = sl.stream;
+    const uint32_t heavy_thr = 0xffffffffu /* the sweeps flag nothing: k_flag_heavy does, after the scan */, HEAVY_CAP = g.HEAVY_CAP;
     uint32_t *const dyn = sl.dyn.as<uint32_t>();
     {
         StageTimer st(sl, "msm.count");
         HIPCHK(hipMemsetAsync(sl.bucket_inf.p, 1, NB, s));
         HIPCHK(hipMemsetAsync(sl.heavy.p, 0, 4, s));
-        launch_digit_codes(s, wide, d_scalars, d_bases, C::AFF_STRIDE, 2 * C::FW, n, n_pad, c, W, sl.digits.p);
-        launch_sort_sweep(s, wide, false, sort_grid, lds_bytes, sl.digits.p, n, n_pad, W, RANGES, rb_log, B, sl.cnt.as<uint32_t>(), nullptr, nullptr, heavy_thr, sl.heavy.as<uint32_t>(), HEAVY_CAP);
+        HIPCHK(hipMemsetAsync(sl.flags.p, 0, 4, s));
+        launch_digit_codes(s, g.wide, d_scalars, bases_pending ? nullptr : d_bases, C::AFF_STRIDE, 2 * C::FW, n, g.n_pad, c, W, sl.digits.p, sl.flags.as<uint32_t>());
+        launch_sort_sweep(s, g.wide, false, g.sort_grid, g.lds_bytes, sl.digits.p, n, g.n_pad, W, g.RANGES, g.rb_log, g.B, sl.cnt.as<uint32_t>(), nullptr, nullptr, heavy_thr, sl.heavy.as<uint32_t>(), HEAVY_CAP);
     }
     {
         StageTimer st(sl, "msm.scan");
         launch_scan(s, sl.cnt.as<uint32_t>(), sl.off.as<uint32_t>(), sl.cursor.as<uint32_t>(), sl.bsums.as<uint32_t>(), (size_t)NB);
-        launch_dyn_chunk(s, sl.off.as<uint32_t>() + NB, (uint32_t)forced_chunk(), min_chunk, max_chunks, lanes_per_chunk, (uint32_t)T, dyn);
+        launch_dyn_chunk(s, sl.off.as<uint32_t>() + NB, (uint32_t)forced_chunk(), g.min_chunk, g.max_chunks, g.lanes_per_chunk, (uint32_t)T, dyn);
         launch_flag_heavy(s, sl.off.as<uint32_t>(), NB, dyn, sl.heavy.as<uint32_t>(), HEAVY_CAP);
     }
     {
         StageTimer st(sl, "msm.scatter");
-        launch_sort_sweep(s, wide, true, sort_grid, lds_bytes, sl.digits.p, n, n_pad, W, RANGES, rb_log, B, nullptr, sl.off.as<uint32_t>(), sl.entries.as<uint32_t>(), heavy_thr, sl.heavy.as<uint32_t>(), HEAVY_CAP);
+        launch_sort_sweep(s, g.wide, true, g.sort_grid, g.lds_bytes, sl.digits.p, n, g.n_pad, W, g.RANGES, g.rb_log, g.B, nullptr, sl.off.as<uint32_t>(), sl.entries.as<uint32_t>(), heavy_thr, sl.heavy.as<uint32_t>(), HEAVY_CAP);
     }
+    if ((rc = before_accumulate())) return rc;
     {
         StageTimer st(sl, "msm.accumulate");
 #ifdef DGPU_DEV
@@ -164,7 +188,9 @@ int32_t msm_device(Slot &sl, const uint32_t *d_bases, const uint32_t *d_scalars,
 #else
         constexpr uint32_t dbg_mask = 0xffffffffu;
 #endif
-        launch_accumulate<C>(s, d_bases, sl.entries.as<uint32_t>(), sl.off.as<uint32_t>(), NB, sl.bucket.as<uint32_t>(), sl.bucket_inf.as<uint8_t>(),
+        if (bases_pending) launch_accumulate_skip_identity<C>(s, d_bases, sl.entries.as<uint32_t>(), sl.off.as<uint32_t>(), NB, sl.bucket.as<uint32_t>(), sl.bucket_inf.as<uint8_t>(),
+                           sl.head.as<uint32_t>(), sl.tail.as<uint32_t>(), sl.head_b.as<uint32_t>(), sl.tail_b.as<uint32_t>(), sl.part_inf.as<uint8_t>(), T, (uint32_t)CH, dyn, msm::RowMap{});
+        else launch_accumulate<C>(s, d_bases, sl.entries.as<uint32_t>(), sl.off.as<uint32_t>(), NB, sl.bucket.as<uint32_t>(), sl.bucket_inf.as<uint8_t>(),
                            sl.head.as<uint32_t>(), sl.tail.as<uint32_t>(), sl.head_b.as<uint32_t>(), sl.tail_b.as<uint32_t>(), sl.part_inf.as<uint8_t>(), T, (uint32_t)CH, dbg_mask, dyn);
     }
     {
@@ -176,18 +202,21 @@ int32_t msm_device(Slot &sl, const uint32_t *d_bases, const uint32_t *d_scalars,
     }
     {
         StageTimer st(sl, "msm.reduce");
-        launch_reduce_l0<C>(s, (unsigned)NG, sl.bucket.as<uint32_t>(), sl.bucket_inf.as<uint8_t>(), NB, mshift, sl.l1.as<uint32_t>(), sl.l1_inf.as<uint8_t>());
-        launch_reduce_top<C>(s, (unsigned)W, sl.l1.as<uint32_t>(), sl.l1_inf.as<uint8_t>(), G, 6 + mshift, sl.win.as<uint32_t>(), sl.win_inf.as<uint8_t>());
+        launch_reduce_l0<C>(s, (unsigned)g.NG, sl.bucket.as<uint32_t>(), sl.bucket_inf.as<uint8_t>(), NB, g.mshift, sl.l1.as<uint32_t>(), sl.l1_inf.as<uint8_t>());
+        launch_reduce_top<C>(s, (unsigned)W, sl.l1.as<uint32_t>(), sl.l1_inf.as<uint8_t>(), g.G, 6 + g.mshift, sl.win.as<uint32_t>(), sl.win_inf.as<uint8_t>());
     }
     HIPCHK(hipGetLastError());
     std::vector<uint64_t> hwin((size_t)W * 2 * C::ABI_W);
     std::vector<uint8_t> hinf(W);
+    uint32_t hbad = 0;
     HIPCHK(hipMemcpyAsync(hwin.data(), sl.win.p, (size_t)W * 4 * C::ABI_W * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(hinf.data(), sl.win_inf.p, W, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(&hbad, sl.flags.p, 4, hipMemcpyDeviceToHost, s));
     auto tsync0 = std::chrono::steady_clock::now();
     HIPCHK(hipStreamSynchronize(s));
     auto tsync1 = std::chrono::steady_clock::now();
     if (gs.prof) prof_flush(sl);
+    if (hbad) return DGPU_E_BADARG;                  // a scalar >= 2^255 (sort_kernels.cuh k_digit_codes)
     host_fold<HF>(hwin.data(), hinf.data(), W, c, out_xyz);
     if (gs.prof) {
         auto t2 = std::chrono::steady_clock::now();
@@ -195,6 +224,10 @@ int32_t msm_device(Slot &sl, const uint32_t *d_bases, const uint32_t *d_scalars,
         prof_add_host("msm.host_fold", std::chrono::duration<double, std::milli>(t2 - tsync1).count());
     }
     return DGPU_OK;
+}
+template <class C, class HF>
+int32_t msm_device(Slot &sl, const uint32_t *d_bases, const uint32_t *d_scalars, size_t n, uint64_t *out_xyz) {
+    return msm_device<C, HF>(sl, d_bases, d_scalars, n, out_xyz, false, [] { return (int32_t)DGPU_OK; });
 }
 
 inline void shard_bounds(size_t n, size_t parts, std::vector<size_t> &lo) {
@@ -259,7 +292,37 @@ template <class C> int32_t pre_geometry(const PreTable &pt, size_t n, PreGeom &g
     g.CH = C::NFP == 2 ? choose_chunk(g.Emax, 32, 150000, 2) : choose_chunk(g.Emax, 16, 300000, 1);
     g.T = (g.Emax + g.CH - 1) / g.CH;
     g.min_chunk = C::NFP == 2 ? 32u : 16u; g.max_chunks = C::NFP == 2 ? 150000u : 300000u; g.lanes_per_chunk = C::NFP == 2 ? 2u : 1u;
-    g.HEAVY_CAP = (uint32_t)(g.Emax / (16u * g.min_chunk)) + 1;
+    g.HEAVY_CAP = (uint32_t)(g.Emax / (16u * 16u)) + 1;         // (see plain_geometry)
+    return DGPU_OK;
+}
+// grow-only workspace of one slot for the table pipeline (sort + tail) of n terms on a table of pt's shape
+template <class C> int32_t ws_pre(Slot &sl, const PreTable &pt, const PreGeom &g, size_t n) {
+    const uint32_t NB = g.NB; const size_t T = g.T; const int PW = g.PW;
+    const uint32_t P = (NB + (1u << ps_part_log(NB)) - 1) >> ps_part_log(NB);
+    const size_t n1 = (size_t)P * ((n + PS_TILE - 1) / PS_TILE);
+    int32_t rc;
+    if ((rc = sl.flags.ensure(64))) return rc;
+    if ((rc = sl.cnt.ensure((n1 + 1) * 4))) return rc;
+    if ((rc = sl.cursor.ensure((n1 + 1) * 4))) return rc;                 // off1
+    if ((rc = sl.bsums.ensure((scan_blocks(n1) + 2) * 4))) return rc;
+    if ((rc = sl.digits.ensure(g.Emax * 8))) return rc;                   // (key, val) pairs
+    if ((rc = sl.heavy.ensure(((size_t)g.HEAVY_CAP + 1) * 4))) return rc;
+    if ((rc = sl.off.ensure(((size_t)NB + 1) * 4))) return rc;
+    if ((rc = sl.entries.ensure(g.Emax * 4))) return rc;
+    if ((rc = sl.bucket.ensure(soa_points(NB) * C::XW * 4))) return rc;
+    if ((rc = sl.bucket_inf.ensure(NB))) return rc;
+    if ((rc = sl.head.ensure(soa_points(T) * C::XW * 4))) return rc;
+    if ((rc = sl.tail.ensure(soa_points(T) * C::XW * 4))) return rc;
+    if ((rc = sl.head_b.ensure(T * 4))) return rc;
+    if ((rc = sl.tail_b.ensure(T * 4))) return rc;
+    if ((rc = sl.part_inf.ensure(T * 2))) return rc;
+    if ((rc = sl.l1.ensure(g.NG * 2 * C::XW * 4))) return rc;
+    if ((rc = sl.l1_inf.ensure(g.NG * 2))) return rc;
+    if ((rc = sl.win.ensure((size_t)2 * PW * 4 * C::ABI_W * 4))) return rc;        // A_j then S_j
+    if ((rc = sl.win_inf.ensure(2 * PW))) return rc;
+    if ((rc = sl.dyn.ensure(msm::dyn_words(T) * 4))) return rc;
+    { const size_t hslots = 2 * (T / msm::HEAVY_RANGE + 2); if ((rc = sl.hpart.ensure(hslots * C::XW * 4))) return rc; if ((rc = sl.hpart_inf.ensure(hslots))) return rc; }
+    (void)pt;
     return DGPU_OK;
 }
 // sizes of `off` / `entries` for a sort kept outside a slot
@@ -273,17 +336,14 @@ int32_t pre_sort(Slot &sl, const PreTable &pt, const PreGeom &g, size_t boff, co
     q.scalars = d_scalars; q.bases = dyn ? (const uint32_t *)pt.tab : nullptr /* shared sort: no per-table identity filter */; q.n = n; q.aff_stride = C::AFF_STRIDE; q.flag_word = 2 * C::FW; q.flag_base = (uint32_t)boff;
     q.c = pt.c; q.W = pt.W; q.key_wstride = 0; q.val_base = (uint32_t)boff; q.val_wstride = (uint32_t)pt.n;
     q.part_log = ps_part_log(g.NB); q.P = (g.NB + (1u << q.part_log) - 1) >> q.part_log; q.ntiles = (uint32_t)((n + PS_TILE - 1) / PS_TILE);
-    const size_t n1 = (size_t)q.P * q.ntiles;
     int32_t rc;
-    if ((rc = sl.cnt.ensure((n1 + 1) * 4))) return rc;
-    if ((rc = sl.cursor.ensure((n1 + 1) * 4))) return rc;                 // off1
-    if ((rc = sl.bsums.ensure((scan_blocks(n1) + 2) * 4))) return rc;
-    if ((rc = sl.digits.ensure(g.Emax * 8))) return rc;                   // (key, val) pairs
-    if ((rc = sl.heavy.ensure(((size_t)g.HEAVY_CAP + 1) * 4))) return rc;
+    if ((rc = ws_pre<C>(sl, pt, g, n))) return rc;
+    q.bad = sl.flags.as<uint32_t>();
     const uint32_t heavy_thr = dyn ? 16u * (uint32_t)g.CH /* replaced on the device, dyn_chunk.cuh */ : 0xffffffffu /* nothing flagged */;
     const uint32_t dyn_args[5] = {(uint32_t)forced_chunk(), g.min_chunk, g.max_chunks, g.lanes_per_chunk, (uint32_t)g.T};
     StageTimer st(sl, "msm.psort");
     HIPCHK(hipMemsetAsync(sl.heavy.p, 0, 4, sl.stream));
+    HIPCHK(hipMemsetAsync(sl.flags.p, 0, 4, sl.stream));
     launch_psort(sl.stream, q, g.NB, sl.cnt.as<uint32_t>(), sl.cursor.as<uint32_t>(), sl.bsums.as<uint32_t>(), sl.digits.p, off, entries,
                  heavy_thr, sl.heavy.as<uint32_t>(), g.HEAVY_CAP, dyn_args, dyn);
     return DGPU_OK;
@@ -293,20 +353,7 @@ template <class C, class HF>
 int32_t pre_tail(Slot &sl, const PreTable &pt, const PreGeom &g, const uint32_t *off, const uint32_t *entries, bool derive_dyn, uint64_t *out_xyz, const msm::RowMap &map = msm::RowMap{}) {
     const uint32_t NB = g.NB; const size_t T = g.T; const int PW = g.PW;
     int32_t rc;
-    if ((rc = sl.bucket.ensure(soa_points(NB) * C::XW * 4))) return rc;
-    if ((rc = sl.bucket_inf.ensure(NB))) return rc;
-    if ((rc = sl.head.ensure(soa_points(T) * C::XW * 4))) return rc;
-    if ((rc = sl.tail.ensure(soa_points(T) * C::XW * 4))) return rc;
-    if ((rc = sl.head_b.ensure(T * 4))) return rc;
-    if ((rc = sl.tail_b.ensure(T * 4))) return rc;
-    if ((rc = sl.part_inf.ensure(T * 2))) return rc;
-    if ((rc = sl.l1.ensure(g.NG * 2 * C::XW * 4))) return rc;
-    if ((rc = sl.l1_inf.ensure(g.NG * 2))) return rc;
-    if ((rc = sl.win.ensure((size_t)2 * PW * 4 * C::ABI_W * 4))) return rc;        // A_j then S_j
-    if ((rc = sl.win_inf.ensure(2 * PW))) return rc;
-    if ((rc = sl.heavy.ensure(((size_t)g.HEAVY_CAP + 1) * 4))) return rc;
-    if ((rc = sl.dyn.ensure(msm::dyn_words(T) * 4))) return rc;
-    { const size_t hslots = 2 * (T / msm::HEAVY_RANGE + 2); if ((rc = sl.hpart.ensure(hslots * C::XW * 4))) return rc; if ((rc = sl.hpart_inf.ensure(hslots))) return rc; }
+    if ((rc = ws_pre<C>(sl, pt, g, g.Emax / pt.W))) return rc;
     uint32_t *const dyn = sl.dyn.as<uint32_t>();
     const uint32_t heavy_thr = 16u * (uint32_t)g.CH;      // (replaced on the device by dyn[])
     hipStream_t s = sl.stream;
@@ -340,12 +387,15 @@ int32_t pre_tail(Slot &sl, const PreTable &pt, const PreGeom &g, const uint32_t 
     HIPCHK(hipGetLastError());
     std::vector<uint64_t> hwin((size_t)2 * PW * 2 * C::ABI_W);
     std::vector<uint8_t> hinf(2 * PW);
+    uint32_t hbad = 0;
     HIPCHK(hipMemcpyAsync(hwin.data(), sl.win.p, (size_t)2 * PW * 4 * C::ABI_W * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(hinf.data(), sl.win_inf.p, 2 * PW, hipMemcpyDeviceToHost, s));
+    if (!derive_dyn) HIPCHK(hipMemcpyAsync(&hbad, sl.flags.p, 4, hipMemcpyDeviceToHost, s));      // (a shared sort was checked by dgpu_scalars_sort)
     auto tsync0 = std::chrono::steady_clock::now();
     HIPCHK(hipStreamSynchronize(s));
     auto tsync1 = std::chrono::steady_clock::now();
     if (gs.prof) prof_flush(sl);
+    if (hbad) return DGPU_E_BADARG;                  // a scalar >= 2^255 (sort_kernels.cuh k_digit_codes)
     host_fold_shared<HF>(hwin.data(), hinf.data(), hwin.data() + (size_t)PW * 2 * C::ABI_W, hinf.data() + PW, PW, g.lb, out_xyz);
     if (gs.prof) {
         auto t2 = std::chrono::steady_clock::now();
@@ -364,9 +414,7 @@ int32_t msm_device_pre(Slot &sl, const PreTable &pt, size_t boff, const uint32_t
     if (n == 0) { write_identity<HF>(out_xyz); return DGPU_OK; }
     PreGeom g; int32_t rc;
     if ((rc = pre_geometry<C>(pt, n, g))) return rc;
-    if ((rc = sl.off.ensure(pre_off_bytes(pt)))) return rc;
-    if ((rc = sl.entries.ensure(g.Emax * 4))) return rc;
-    if ((rc = sl.dyn.ensure(msm::dyn_words(g.T) * 4))) return rc;
+    if ((rc = ws_pre<C>(sl, pt, g, n))) return rc;
     if ((rc = pre_sort<C>(sl, pt, g, boff, d_scalars, n, sl.off.as<uint32_t>(), sl.entries.as<uint32_t>(), sl.dyn.as<uint32_t>()))) return rc;
     return pre_tail<C, HF>(sl, pt, g, sl.off.as<uint32_t>(), sl.entries.as<uint32_t>(), false, out_xyz);
 }
@@ -392,8 +440,11 @@ inline int32_t scalars_sort(uint64_t table, size_t boff, uint64_t scalars, size_
     auto drop = [&]() { scalar_release(cur_index(), ss->off, ss->off_bytes); scalar_release(cur_index(), ss->entries, ss->entries_bytes); delete ss; };
     if (!ss->off || !ss->entries) { drop(); return DGPU_E_OOM; }
     rc = pre_sort<G1>(sl, pt, g, boff, (const uint32_t *)hs.h.p + soff * 8, n, (uint32_t *)ss->off, (uint32_t *)ss->entries, nullptr);
+    uint32_t hbad = 0;
+    if (!rc && hipMemcpyAsync(&hbad, sl.flags.p, 4, hipMemcpyDeviceToHost, sl.stream) != hipSuccess) rc = DGPU_E_HIP;
     if (!rc && hipStreamSynchronize(sl.stream) != hipSuccess) { gs.last_hip = (int32_t)hipGetLastError(); rc = DGPU_E_HIP; }
     if (gs.prof) prof_flush(sl);
+    if (!rc && hbad) rc = DGPU_E_BADARG;             // a scalar >= 2^255
     if (rc) { drop(); return rc; }
     *sorted = register_handle(ss, n, 12);
     return DGPU_OK;
@@ -449,8 +500,8 @@ int32_t bases_precompute(uint64_t handle, int32_t window_bits, int kind /* 1 | 2
         SlotLock L; Slot &sl = *L.s;
         if (hipSetDevice(cur().device) != hipSuccess) rc = DGPU_E_HIP;
         const size_t rec = (size_t)C::AFF_STRIDE * 4;
-        if (!rc && hipMalloc(&tab, (size_t)W * n * rec) != hipSuccess) { (void)hipGetLastError(); rc = DGPU_E_OOM; }
-        if (!rc && hipMalloc(&tmp, n * (size_t)C::XW * 4) != hipSuccess) { (void)hipGetLastError(); rc = DGPU_E_OOM; }
+        if (!rc && dev_malloc(&tab, (size_t)W * n * rec) != hipSuccess) { (void)hipGetLastError(); rc = DGPU_E_OOM; }
+        if (!rc && dev_malloc(&tmp, n * (size_t)C::XW * 4) != hipSuccess) { (void)hipGetLastError(); rc = DGPU_E_OOM; }
         if (!rc && hipMemcpyAsync(tab, hd.p, n * rec, hipMemcpyDeviceToDevice, sl.stream) != hipSuccess) rc = DGPU_E_HIP;
         if (!rc) {
             StageTimer st(sl, "msm.precompute");
@@ -462,60 +513,153 @@ int32_t bases_precompute(uint64_t handle, int32_t window_bits, int kind /* 1 | 2
     }
     if (rc) { if (tab) (void)hipFree(tab); (void)hipGetLastError(); put_back(hd.p, kind); return rc; }
     (void)hipFree(hd.p);
-    put_back(new PreTable{tab, n, c, W}, kind + 9);
+    PreTable *npt = new PreTable{tab, n, c, W};
+    put_back(npt, kind + 9);
+    (void)reserve_slots<C>(3, n, 0, npt);           // (the handle cannot be freed under us: the caller still owns it)
     return DGPU_OK;
 }
 
-template <class C>
-int32_t prep_bases(Slot &sl, const uint64_t *h_bases, const uint8_t *h_inf, size_t n, uint32_t *d_out) {
+// The bases as the caller holds them: `stride` bytes per point, x at x_off and y at y_off (C::NFP x 48 bytes of Montgomery limbs each, 8-byte
+// aligned), identity flags as a byte inside the point (inf_off != NO_INF_OFF) and / or as a separate array (is_inf).  packed() = the ABI's own
+// layout (x then y, 96 / 192 bytes per point); the strided entry points describe ark-ec's in-memory `Affine { x, y, infinity }`.
+struct RawBases {
+    const uint8_t *p; size_t stride, x_off, y_off, inf_off; const uint8_t *is_inf;
+    template <class C> static RawBases packed(const uint64_t *xy, const uint8_t *is_inf) {
+        return RawBases{(const uint8_t *)xy, (size_t)2 * C::ABI_W * 4, 0, (size_t)C::ABI_W * 4, msm::NO_INF_OFF, is_inf};
+    }
+    template <class C> bool ok() const {
+        const size_t fb = (size_t)C::ABI_W * 4;
+        return stride >= 2 * fb && stride % 8 == 0 && x_off % 8 == 0 && y_off % 8 == 0 && x_off + fb <= stride && y_off + fb <= stride &&
+               (inf_off == msm::NO_INF_OFF || inf_off < stride) && ((uintptr_t)p % 8) == 0 && stride <= 4096;
+    }
+};
+constexpr size_t STAGE_CHUNK_BYTES = (size_t)16 << 20;      // H2D piece after which the conversion kernel of that piece may start
+
+template <class C> int32_t ws_stage_bases(Slot &sl, const RawBases &rb, size_t n) {
     int32_t rc;
-    const size_t bytes = n * 2 * C::ABI_W * 4;
-    if ((rc = sl.in_bases.ensure(bytes ? bytes : 16))) return rc;
-    HIPCHK(hipMemcpyAsync(sl.in_bases.p, h_bases, bytes, hipMemcpyHostToDevice, sl.stream));
-    uint8_t *dinf = nullptr;
-    if (h_inf) { if ((rc = sl.in_inf.ensure(n))) return rc; HIPCHK(hipMemcpyAsync(sl.in_inf.p, h_inf, n, hipMemcpyHostToDevice, sl.stream)); dinf = sl.in_inf.as<uint8_t>(); }
-    StageTimer st(sl, "msm.prep_bases");
-    launch_prep_bases<C>(sl.stream, sl.in_bases.as<uint32_t>(), dinf, n, d_out);
+    if ((rc = sl.in_bases.ensure(n * rb.stride + 16))) return rc;
+    if (rb.is_inf && (rc = sl.in_inf.ensure(n + 16))) return rc;
     return DGPU_OK;
+}
+// Queue: the raw points cross PCIe in pieces on the slot's COPY stream; the conversion of piece k to prepared records (k_prep_bases_raw) runs on
+// the compute stream as soon as that piece has landed, i.e. under the copy of piece k + 1 and under whatever the compute stream was doing
+// before (a one-shot MSM sorts its scalars meanwhile).  Pageable host memory: hipMemcpyAsync returns when the piece is on its way.
+template <class C>
+int32_t stage_bases(Slot &sl, const RawBases &rb, size_t n, uint32_t *d_out) {
+    if (n == 0) return DGPU_OK;
+    uint8_t *draw = sl.in_bases.as<uint8_t>();
+    const uint8_t *dinf = nullptr;
+    if (rb.is_inf) { HIPCHK(hipMemcpyAsync(sl.in_inf.p, rb.is_inf, n, hipMemcpyHostToDevice, sl.cstream)); dinf = sl.in_inf.as<uint8_t>(); }
+    const size_t per = std::max<size_t>(1, STAGE_CHUNK_BYTES / rb.stride);
+    size_t pieces = (n + per - 1) / per;
+    if (pieces > Slot::N_COPY_EV) pieces = Slot::N_COPY_EV;
+    const size_t len = (n + pieces - 1) / pieces;
+    StageTimer st(sl, "msm.prep_bases");
+    for (size_t k = 0, lo = 0; lo < n; k++, lo += len) {
+        const size_t cnt = std::min(len, n - lo);
+        HIPCHK(hipMemcpyAsync(draw + lo * rb.stride, rb.p + lo * rb.stride, cnt * rb.stride, hipMemcpyHostToDevice, sl.cstream));
+        HIPCHK(hipEventRecord(sl.copy_ev[k], sl.cstream));
+        HIPCHK(hipStreamWaitEvent(sl.stream, sl.copy_ev[k], 0));
+        launch_prep_bases_raw<C>(sl.stream, draw + lo * rb.stride, rb.stride, rb.x_off, rb.y_off, rb.inf_off, dinf ? dinf + lo : nullptr, cnt, d_out + lo * C::AFF_STRIDE);
+    }
+    return DGPU_OK;
+}
+// canonical scalars in d_out once the compute stream gets there (no host wait: the pipeline that follows is queued behind it)
+inline int32_t stage_scalars(Slot &sl, const uint64_t *h, size_t n, bool mont, uint32_t *d_out) {
+    if (n == 0) return DGPU_OK;
+    HIPCHK(hipMemcpyAsync(d_out, h, n * 32, hipMemcpyHostToDevice, sl.cstream));
+    HIPCHK(hipEventRecord(sl.copy_ev[Slot::N_COPY_EV], sl.cstream));
+    HIPCHK(hipStreamWaitEvent(sl.stream, sl.copy_ev[Slot::N_COPY_EV], 0));
+    if (mont) ntt::launch_fr_mont_to_canonical(sl.stream, d_out, n);     // Fr::into_bigint on the device (ark-ec msm_unchecked does it on rayon)
+    return DGPU_OK;
+}
+
+// ---- workspaces sized ahead of the calls (no hipMalloc on an MSM path in steady state) ---------------------------------------------------
+// what: 1 = one-shot call of n terms (raw bases of `stride` bytes + scalars + prepared records + plain pipeline), 2 = fresh host scalars on a
+// plain handle of n terms, 3 = the same on a table (pt)
+template <class C> int32_t ws_for(Slot &sl, int what, size_t n, size_t stride, const PreTable *pt) {
+    if (n == 0) return DGPU_OK;
+    int32_t rc;
+    if ((rc = sl.in_scalars.ensure(n * 32))) return rc;
+    if (what == 1) {
+        if ((rc = sl.in_bases.ensure(n * stride + 16))) return rc;
+        if ((rc = sl.in_inf.ensure(n + 16))) return rc;
+        if ((rc = sl.prepped.ensure(n * C::AFF_STRIDE * 4))) return rc;
+    }
+    if (what == 3) { PreGeom g; if ((rc = pre_geometry<C>(*pt, n, g))) return rc; return ws_pre<C>(sl, *pt, g, n); }
+    PlainGeom g; if ((rc = plain_geometry<C>(n, g))) return rc;
+    return ws_plain<C>(sl, g);
+}
+// every slot of the current context (the caller holds none of them); a failure (out of memory) is not an error of the call that triggered
+// the reservation: the slot grows on its first use instead
+template <class C> int32_t reserve_slots(int what, size_t n, size_t stride, const PreTable *pt) {
+    Ctx &cx = cur();
+    if (!cx.ready) return DGPU_E_NODEVICE;
+    int32_t first = DGPU_OK;
+    for (int k = 0; k < N_SLOTS; k++) {
+        std::lock_guard<std::mutex> lk(cx.slots[k].mu);
+        if (hipSetDevice(cx.device) != hipSuccess) return DGPU_E_HIP;
+        const int32_t rc = ws_for<C>(cx.slots[k], what, n, stride, pt);
+        if (rc && !first) first = rc;
+    }
+    return first;
+}
+// the same for the slots that are idle right now (called by a one-shot call that had to grow its own slot: the other host threads of the
+// caller — rayon workers — will come with the same size next, and would each stall the device in hipMalloc / hipFree)
+template <class C> void reserve_idle_slots(const Slot *mine, int what, size_t n, size_t stride) {
+    Ctx &cx = cur();
+    for (int k = 0; k < N_SLOTS; k++) {
+        Slot &o = cx.slots[k];
+        if (&o == mine || !o.mu.try_lock()) continue;
+        (void)ws_for<C>(o, what, n, stride, nullptr);
+        o.mu.unlock();
+    }
 }
 
 // one-shot MSM on the calling thread's context (no size threshold: the callers apply it)
 template <class C, class HF>
-int32_t msm_oneshot_here(const uint64_t *bases, const uint8_t *is_inf, const uint64_t *scalars, size_t n, bool mont, uint64_t *out) {
+int32_t msm_oneshot_here(const RawBases &rb, const uint64_t *scalars, size_t n, bool mont, uint64_t *out) {
     if (!cur().ready) return DGPU_E_NODEVICE;
     SlotLock L; Slot &sl = *L.s;
     HIPCHK(hipSetDevice(cur().device));
+    if (n == 0) { write_identity<HF>(out); return DGPU_OK; }
     int32_t rc;
-    if (n) {
-        if ((rc = sl.prepped.ensure(n * C::AFF_STRIDE * 4))) return rc;
-        if ((rc = sl.in_scalars.ensure(n * 32))) return rc;
-        if ((rc = prep_bases<C>(sl, bases, is_inf, n, sl.prepped.as<uint32_t>()))) return rc;
-        if ((rc = upload_scalars(sl, scalars, n, mont, sl.in_scalars.as<uint32_t>()))) return rc;
-    }
-    return msm_device<C, HF>(sl, sl.prepped.as<uint32_t>(), sl.in_scalars.as<uint32_t>(), n, out);
+    const uint64_t allocs0 = g_dev_allocs.load();
+    if ((rc = ws_for<C>(sl, 1, n, rb.stride, nullptr))) return rc;
+    const bool grew = g_dev_allocs.load() != allocs0;
+    // scalars first: their digits are sorted while the bases (3/4 of the bytes) are still crossing PCIe
+    if ((rc = stage_scalars(sl, scalars, n, mont, sl.in_scalars.as<uint32_t>()))) return rc;
+    rc = msm_device<C, HF>(sl, sl.prepped.as<uint32_t>(), sl.in_scalars.as<uint32_t>(), n, out, true,
+                           [&] { return stage_bases<C>(sl, rb, n, sl.prepped.as<uint32_t>()); });
+    if (rc) { (void)hipStreamSynchronize(sl.cstream); (void)hipStreamSynchronize(sl.stream); }      // nothing of ours may still read the caller's buffers
+    if (grew) reserve_idle_slots<C>(&sl, 1, n, rb.stride);
+    return rc;
 }
 template <class C, class HF>
-int32_t msm_oneshot(const uint64_t *bases, const uint8_t *is_inf, const uint64_t *scalars, size_t n, bool mont, uint64_t *out) {
-    if (!out || (n && (!bases || !scalars)) || n >= (1ull << 31)) return DGPU_E_BADARG;
+int32_t msm_oneshot(const RawBases &rb, const uint64_t *scalars, size_t n, bool mont, uint64_t *out) {
+    if (!out || (n && (!rb.p || !scalars)) || n >= (1ull << 31) || !rb.ok<C>()) return DGPU_E_BADARG;
     if (!cur().ready) return DGPU_E_NODEVICE;            // (before the size threshold: a missing device is never answered with "too small")
     if (n < gs.min_gpu_n) return DGPU_E_TOO_SMALL;
-    return msm_oneshot_here<C, HF>(bases, is_inf, scalars, n, mont, out);
+    return msm_oneshot_here<C, HF>(rb, scalars, n, mont, out);
 }
 
 template <class C>
-int32_t bases_upload(const uint64_t *bases, const uint8_t *is_inf, size_t n, uint64_t *handle, int kind) {
-    if (!handle || (n && !bases) || n >= (1ull << 31)) return DGPU_E_BADARG;
+int32_t bases_upload(const RawBases &rb, size_t n, uint64_t *handle, int kind) {
+    if (!handle || (n && !rb.p) || n >= (1ull << 31) || !rb.ok<C>()) return DGPU_E_BADARG;
     if (!cur().ready) return DGPU_E_NODEVICE;
     void *p = nullptr;
     {
         SlotLock L; Slot &sl = *L.s;
         HIPCHK(hipSetDevice(cur().device));
-        if (hipMalloc(&p, std::max<size_t>(n, 1) * C::AFF_STRIDE * 4) != hipSuccess) { (void)hipGetLastError(); return DGPU_E_OOM; }
-        int32_t rc = n ? prep_bases<C>(sl, bases, is_inf, n, (uint32_t *)p) : DGPU_OK;
-        if (rc == DGPU_OK && hipStreamSynchronize(sl.stream) != hipSuccess) rc = DGPU_E_HIP;
+        if (dev_malloc(&p, std::max<size_t>(n, 1) * C::AFF_STRIDE * 4) != hipSuccess) { (void)hipGetLastError(); return DGPU_E_OOM; }
+        int32_t rc = ws_stage_bases<C>(sl, rb, n);
+        if (!rc) rc = stage_bases<C>(sl, rb, n, (uint32_t *)p);
+        if (hipStreamSynchronize(sl.cstream) != hipSuccess || hipStreamSynchronize(sl.stream) != hipSuccess) { if (!rc) rc = DGPU_E_HIP; }
+        if (gs.prof) prof_flush(sl);
         if (rc) { (void)hipFree(p); return rc; }
     }
     *handle = register_handle(p, n, kind);
+    (void)reserve_slots<C>(2, n, 0, nullptr);       // every slot is ready for an MSM over this query before the first proof arrives
     return DGPU_OK;
 }
 
@@ -532,9 +676,11 @@ int32_t msm_handle(uint64_t bases, size_t offset, const uint64_t *scalars, size_
     HIPCHK(hipSetDevice(cur().device));
     int32_t rc;
     if ((rc = sl.in_scalars.ensure(std::max<size_t>(n, 1) * 32))) return rc;
-    if (n && (rc = upload_scalars(sl, scalars, n, mont != 0, sl.in_scalars.as<uint32_t>()))) return rc;
-    if (hb.h.kind == kind + 9) return msm_device_pre<C, HF>(sl, *(const PreTable *)hb.h.p, offset, sl.in_scalars.as<uint32_t>(), n, out);
-    return msm_device<C, HF>(sl, (const uint32_t *)hb.h.p + offset * C::AFF_STRIDE, sl.in_scalars.as<uint32_t>(), n, out);
+    if ((rc = stage_scalars(sl, scalars, n, mont != 0, sl.in_scalars.as<uint32_t>()))) return rc;
+    if (hb.h.kind == kind + 9) rc = msm_device_pre<C, HF>(sl, *(const PreTable *)hb.h.p, offset, sl.in_scalars.as<uint32_t>(), n, out);
+    else rc = msm_device<C, HF>(sl, (const uint32_t *)hb.h.p + offset * C::AFF_STRIDE, sl.in_scalars.as<uint32_t>(), n, out);
+    if (rc) { (void)hipStreamSynchronize(sl.cstream); (void)hipStreamSynchronize(sl.stream); }      // nothing of ours may still read the caller's scalars
+    return rc;
 }
 
 template <class C, class HF>
@@ -569,7 +715,7 @@ int32_t msm_sharded_oneshot(const uint64_t *bases, const uint8_t *is_inf, const 
     int32_t rc = run_shards(cx.size(), [&](size_t k) {
         CtxScope here(cx[k]);
         const size_t cnt = lo[k + 1] - lo[k];
-        return msm_oneshot_here<C, HF>(bases + lo[k] * BW, is_inf ? is_inf + lo[k] : nullptr, scalars + lo[k] * 4, cnt, mont, parts.data() + k * JW);
+        return msm_oneshot_here<C, HF>(RawBases::packed<C>(bases + lo[k] * BW, is_inf ? is_inf + lo[k] : nullptr), scalars + lo[k] * 4, cnt, mont, parts.data() + k * JW);
     });
     if (rc) return rc;
     return host_fold_jacobian<HF>(parts.data(), cx.size(), out);
@@ -585,7 +731,7 @@ int32_t bases_upload_sharded(const uint64_t *bases, const uint8_t *is_inf, size_
     const size_t BW = 2 * C::ABI_W / 2;           // u64 words per affine point
     int32_t rc = run_shards(cx.size(), [&](size_t k) {
         CtxScope here(cx[k]);
-        return bases_upload<C>(bases + ss->lo[k] * BW, is_inf ? is_inf + ss->lo[k] : nullptr, ss->lo[k + 1] - ss->lo[k], &ss->sub[k], kind);
+        return bases_upload<C>(RawBases::packed<C>(bases + ss->lo[k] * BW, is_inf ? is_inf + ss->lo[k] : nullptr), ss->lo[k + 1] - ss->lo[k], &ss->sub[k], kind);
     });
     if (rc) { for (uint64_t h : ss->sub) if (h) (void)dgpu_bases_free(h); delete ss; return rc; }
     *handle = register_handle(ss, n, kind + 6);       // 7 = G1 sharded, 8 = G2 sharded

@@ -101,6 +101,37 @@ __global__ void __launch_bounds__(256) k_prep_bases(const uint32_t *__restrict__
     dst[2 * C::FW] = flag;
 }
 
+// The same from the caller's own array of structures (dgpu_msm_*_strided): point i sits at raw + i * stride with its x at x_off and its y at
+// y_off (each C::NFP * 48 bytes of ark-ff Montgomery limbs, 8-byte aligned) and, if inf_off != NO_INF_OFF, a flag byte at inf_off — ark-ec's
+// in-memory `Affine { x, y, infinity }` (104 B for G1, 200 B for G2) goes over PCIe as it is, no host-side repacking.
+constexpr size_t NO_INF_OFF = ~(size_t)0;
+template <class C>
+__global__ void __launch_bounds__(256) k_prep_bases_raw(const uint8_t *__restrict__ raw, size_t stride, size_t x_off, size_t y_off, size_t inf_off,
+                                                        const uint8_t *__restrict__ is_inf, size_t n, uint32_t *__restrict__ out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t *pt = raw + i * stride;
+    uint32_t w[2 * C::ABI_W];
+    uint32_t any = 0;
+#pragma unroll
+    for (int k = 0; k < C::ABI_W; k += 2) {
+        const uint2 vx = *reinterpret_cast<const uint2 *>(pt + x_off + 4 * k), vy = *reinterpret_cast<const uint2 *>(pt + y_off + 4 * k);
+        w[k] = vx.x; w[k + 1] = vx.y; w[C::ABI_W + k] = vy.x; w[C::ABI_W + k + 1] = vy.y;
+        any |= vx.x | vx.y | vy.x | vy.y;
+    }
+    uint32_t flag = (any == 0) ? 1u : 0u;
+    if (is_inf && is_inf[i]) flag = 1u;
+    if (inf_off != NO_INF_OFF && pt[inf_off]) flag = 1u;
+    uint32_t *dst = out + i * C::AFF_STRIDE;
+#pragma unroll
+    for (int k = 0; k < 2 * C::NFP; k++) {
+        Fp f; fp_from_abi(f, w + 12 * k);
+#pragma unroll
+        for (int j = 0; j < NL; j++) dst[k * NL + j] = f.l[j];
+    }
+    dst[2 * C::FW] = flag;
+}
+
 // ---- XYZZ <-> memory -------------------------------------------------------------------------------
 // One record per point (array of structures): C::XW consecutive words (224 B for G1, 448 B for G2), moved as 16-byte pieces.  A lane
 // that closes a bucket writes its record alone (lanes of a wave close runs at different times), so a word-major layout turned every

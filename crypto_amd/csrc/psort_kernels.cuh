@@ -76,6 +76,7 @@ __global__ void __launch_bounds__(PS_TILE) k_ps_count1(PsParams q, uint32_t *__r
     for (uint32_t j = threadIdx.x; j < q.P; j += blockDim.x) lds[j] = 0;
     __syncthreads();
     const size_t i = (size_t)blockIdx.x * PS_TILE + threadIdx.x;
+    if (i < q.n && (q.scalars[i * 8 + 7] >> 31)) atomicOr(q.bad, 1u);
     ps_digits(q, i, ps_live(q, i), [&](int w, uint32_t m1, uint32_t, bool nz) { (void)lds_inc_agg(lds, nz ? ((uint32_t)w * q.key_wstride + m1) >> q.part_log : 0u, nz); });
     __syncthreads();
     for (uint32_t j = threadIdx.x; j < q.P; j += blockDim.x) cnt1[(size_t)j * q.ntiles + blockIdx.x] = lds[j];

@@ -19,17 +19,23 @@ using namespace bls29;
 // (|d| - 1 <= 2^(c-1) - 1 needs c - 1 bits; a negative digit has |d| <= 2^(c-1) - 1, so the all-ones pattern is free).
 template <class CODE>
 __global__ void __launch_bounds__(256) k_digit_codes(const uint32_t *__restrict__ scalars, const uint32_t *__restrict__ bases, int aff_stride, int flag_word,
-                                                     size_t n, size_t n_pad, int c, int W, CODE *__restrict__ dig) {
+                                                     size_t n, size_t n_pad, int c, int W, CODE *__restrict__ dig, uint32_t *__restrict__ bad) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_pad) return;
     constexpr CODE ZERO = (CODE)~(CODE)0;
     constexpr int SIGN = sizeof(CODE) * 8 - 1;
-    bool skip = (i >= n) || bases[i * (size_t)aff_stride + flag_word] != 0;   // padding / identity base contributes nothing
+    // padding / identity base contributes nothing.  bases == nullptr: the base records are not there yet (one-shot calls sort the scalars
+    // while the bases are still crossing PCIe): identity bases are passed over by the SKIP_ID accumulation instead.
+    bool skip = (i >= n) || (bases && bases[i * (size_t)aff_stride + flag_word] != 0);
     uint32_t s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (!skip) {
+    if (i < n) {
         const uint4 *p = reinterpret_cast<const uint4 *>(scalars + i * 8);
         uint4 a = p[0], b = p[1];
-        s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w; s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w & 0x7fffffffu;   // Fr::MODULUS_BIT_SIZE = 255: bit 255 is not part of a scalar
+        // A scalar is a 255-bit value (Fr::MODULUS_BIT_SIZE).  Whether arkworks' digit extraction reads bit 255 depends on ITS window width
+        // (it does unless that width divides 255, oracle/oracle.c ark_make_digits), so a scalar >= 2^255 has no width-independent meaning:
+        // the call is refused (DGPU_E_BADARG) and the caller stays on its CPU path.  `into_bigint()` never produces one.
+        if (b.w >> 31) atomicOr(bad, 1u);
+        if (!skip) { s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w; s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w & 0x7fffffffu; }
     }
     const uint32_t B = 1u << (c - 1);
     uint32_t carry = 0;

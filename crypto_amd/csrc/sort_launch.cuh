@@ -7,7 +7,7 @@
 
 namespace msm {
 // curve independent (k_sort.hip)
-void launch_digit_codes(hipStream_t s, bool wide, const uint32_t *scalars, const uint32_t *bases, int aff_stride, int flag_word, size_t n, size_t n_pad, int c, int W, void *dig);
+void launch_digit_codes(hipStream_t s, bool wide, const uint32_t *scalars, const uint32_t *bases, int aff_stride, int flag_word, size_t n, size_t n_pad, int c, int W, void *dig, uint32_t *bad /* set to 1 if a scalar has bit 255 set */);
 void launch_sort_sweep(hipStream_t s, bool wide, bool scatter, unsigned grid, size_t lds_bytes, const void *dig, size_t n, size_t n_pad, int W, int RANGES, int rb_log, uint32_t B,
                        uint32_t *cnt, const uint32_t *off, uint32_t *entries, uint32_t heavy_thr, uint32_t *heavy, uint32_t heavy_cap);
 void launch_scan(hipStream_t s, const uint32_t *cnt, uint32_t *off, uint32_t *cursor, uint32_t *bsums, size_t NB);
@@ -32,6 +32,7 @@ struct PsParams {
     int part_log;                       // log2 buckets per partition: ps_part_log(NB)
     uint32_t P;                         // partitions = ceil(NB / 2^part_log)
     uint32_t ntiles;
+    uint32_t *bad;                      // *bad |= 1 if a scalar has bit 255 set (the call is refused: sort_kernels.cuh k_digit_codes)
 };
 
 // about a thousand partitions (P4 runs one block per partition) while a partition keeps at least 32 buckets

@@ -93,6 +93,53 @@ def msm_unchecked(curve, bases, scalars_mont, is_inf=None):
     return out
 
 
+def affine_struct_dtype(curve):
+    """numpy dtype with the layout of ark-ec 0.4's in-memory `Affine<P> { x, y, infinity }` as rustc lays it out for BLS12-381 today
+    (x, y, then the bool, padded to the 8-byte alignment of the limbs): 104 bytes for G1, 200 for G2.  The strided entry points take the
+    offsets as arguments, so a different field order costs the shim nothing."""
+    h = curve.AW // 2
+    return np.dtype({"names": ["x", "y", "infinity"], "formats": [(np.uint64, h), (np.uint64, h), np.uint8],
+                     "offsets": [0, 8 * h, 16 * h], "itemsize": 16 * h + 8})
+
+
+def to_affine_structs(curve, bases, is_inf=None):
+    """ABI arrays -> an array of `Affine` structs (what a Rust caller's &[G1Affine] looks like in memory)"""
+    bases = np.ascontiguousarray(bases, dtype=np.uint64).reshape(-1, curve.AW)
+    h = curve.AW // 2
+    a = np.zeros(len(bases), dtype=affine_struct_dtype(curve))
+    a["x"], a["y"] = bases[:, :h], bases[:, h:]
+    if is_inf is not None:
+        a["infinity"] = np.asarray(is_inf, dtype=np.uint8)[:len(a)]
+    return a
+
+
+def msm_strided(curve, structs, scalars, montgomery=False):
+    """dgpu_msm_*_strided: the MSM straight from an array of `Affine` structs (any numpy structured array with fields x, y and optionally infinity)"""
+    _ensure()
+    assert structs.flags["C_CONTIGUOUS"]
+    scalars = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+    n = min(len(structs), len(scalars))
+    f = structs.dtype.fields
+    inf_off = f["infinity"][1] if "infinity" in f else (1 << 64) - 1
+    out = np.zeros(curve.JW, dtype=np.uint64)
+    rc = curve.fn("dgpu_msm_%s_strided")(_p(structs), structs.dtype.itemsize, f["x"][1], f["y"][1], inf_off, _p(scalars), n, int(montgomery), _p(out))
+    if rc:
+        raise DockGpuError(rc, "dgpu_msm_%s_strided" % curve.tag)
+    return out
+
+
+def reserve(curve, n):
+    """dgpu_reserve_*: size every slot of the calling thread's context for one-shot MSMs of up to n terms"""
+    _ensure()
+    rc = curve.fn("dgpu_reserve_%s")(n)
+    if rc:
+        raise DockGpuError(rc, "dgpu_reserve")
+
+
+def device_alloc_count():
+    return lib().dgpu_device_alloc_count()
+
+
 def msm(curve, bases, scalars_mont, is_inf=None):
     """G::msm(bases, scalars): checked variant — (False, min_len) on length mismatch, like Err(min_len)."""
     nb = np.asarray(bases).size // curve.AW
@@ -161,6 +208,19 @@ class DeviceBases:
         if rc:
             raise DockGpuError(rc, "dgpu_bases_upload")
         self.handle = h.value
+
+    @classmethod
+    def from_structs(cls, curve, structs):
+        """dgpu_bases_upload_*_strided: a resident query straight from an array of `Affine` structs"""
+        _ensure()
+        assert structs.flags["C_CONTIGUOUS"]
+        f = structs.dtype.fields
+        inf_off = f["infinity"][1] if "infinity" in f else (1 << 64) - 1
+        h = C.c_uint64(0)
+        rc = curve.fn("dgpu_bases_upload_%s_strided")(_p(structs), structs.dtype.itemsize, f["x"][1], f["y"][1], inf_off, len(structs), C.byref(h))
+        if rc:
+            raise DockGpuError(rc, "dgpu_bases_upload_strided")
+        return cls.from_handle(curve, h.value, len(structs))
 
     @classmethod
     def from_handle(cls, curve, handle, n):

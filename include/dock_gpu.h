@@ -60,6 +60,18 @@ int32_t dgpu_set_min_gpu_n(size_t n);
 size_t dgpu_get_min_gpu_n(void);
 /* window width c (bits) used by the bucket method; 0 = automatic from n.  Any value gives the same point. */
 int32_t dgpu_set_window_bits(int32_t c);
+/* terms per lane of the bucket accumulation (16..4096; 0 = automatic).  Any value gives the same point (tests sweep it). */
+int32_t dgpu_set_chunk(int32_t terms);
+/* Workspaces.  Every call in flight owns one of the context's slots (stream + grow-only device workspace).  The slots are sized AHEAD of
+ * the calls so that no MSM path allocates in steady state (a hipMalloc costs 0.1 - 1 ms and the hipFree of the buffer it replaces waits for
+ * the whole device, i.e. for every other call in flight): dgpu_bases_upload_* / dgpu_bases_precompute_* / dgpu_window_table_mul_to_bases_*
+ * size every slot for MSMs over that handle; dgpu_reserve_g1/g2(n) does it for one-shot calls (dgpu_msm_*) of up to n terms on the calling
+ * thread's context — what a Rust host calls once at start-up; without it the first one-shot call of a new size grows its own slot and
+ * every idle one.  dgpu_device_alloc_count: hipMalloc calls issued by the library so far (also the "hipMalloc" row of dgpu_prof_read):
+ * a steady-state delta of 0 is asserted by tests/test_gpu_reserve.py. */
+int32_t dgpu_reserve_g1(size_t n);
+int32_t dgpu_reserve_g2(size_t n);
+uint64_t dgpu_device_alloc_count(void);
 
 /* ---- one-shot MSM: host buffers in, one point out ----
  * replaces <G1Projective as VariableBaseMSM>::msm_bigint(bases, bigints)
@@ -67,14 +79,30 @@ int32_t dgpu_set_window_bits(int32_t c);
  * Callers pass n = min(bases.len(), scalars.len()) — the truncation arkworks applies (prover.rs:286).
  * Preconditions (DGPU_E_BADARG otherwise, nothing is allocated): n < 2^31 and n * W < 2^32 where W = 255 / c + 1 is the number of
  * windows (c = 16 from n = 2^17 on: n < 2^28; split larger MSMs and fold the parts with dgpu_fold_*).  Scalars are 255-bit values
- * (Fr::MODULUS_BIT_SIZE): bit 255 of the fourth limb is ignored, exactly as arkworks' digit extraction never reads it; scalars >= r
- * but < 2^255 are multiplied as the integers they are (the result is the same group element as for the reduced scalar). */
+ * (Fr::MODULUS_BIT_SIZE): scalars >= r but < 2^255 are multiplied as the integers they are (the same group element as for the reduced
+ * scalar, and what arkworks computes).  A scalar with bit 255 set has no meaning that is independent of arkworks' window width — its
+ * `make_digits` reads bit 255 in the top window unless the width divides 255 (n <= 32, 2^18 < n <= 2^20, 2^21 < n <= 2^23
+ * ignore it, every other n multiplies by the full 256-bit integer) — so every MSM entry point REFUSES such input with DGPU_E_BADARG and the
+ * caller stays on its CPU path; `Fr::into_bigint()` never produces it.  (tests/test_gpu_msm.py::test_scalars_with_bit_255) */
 int32_t dgpu_msm_g1(const uint64_t *bases_xy /* n*12 */, const uint8_t *is_inf /* n or NULL */,
                     const uint64_t *scalars /* n*4, canonical */, size_t n, uint64_t out_xyz[18]);
 /* replaces <G1Projective as VariableBaseMSM>::msm_unchecked(bases, &[Fr]) (Fr in Montgomery form, R = 2^256)
  *   utils/src/pairs.rs:145-147 ; utils/src/randomized_mult_checker.rs:100 ; schnorr_pok/src/pok_generalized_pedersen.rs:97 */
 int32_t dgpu_msm_g1_mont(const uint64_t *bases_xy, const uint8_t *is_inf,
                          const uint64_t *scalars_mont, size_t n, uint64_t out_xyz[18]);
+/* The same straight from the caller's `&[G1Affine]` / `&[G2Affine]`: ark-ec 0.4 `Affine<P> { x, y, infinity }` is a Rust struct of
+ * 104 (G1) / 200 (G2) bytes whose field offsets the shim reads with core::mem::offset_of! — no host-side repacking into x|y arrays (the
+ * 96-MB copy loop of a 2^20-term call; utils/src/pairs.rs:143-156 and the 166 direct call sites hand over exactly this slice).  Point i
+ * lives at bases + i * stride_bytes: x at x_off, y at y_off (48 / 96 bytes of Montgomery limbs each, 8-byte aligned), the `infinity`
+ * bool at inf_off (DGPU_NO_INF_OFF: no flag byte; all-zero coordinates still mean the identity).  montgomery != 0: scalars are &[Fr].
+ * The whole array crosses PCIe as it is (stride_bytes per point) and is converted on the device. */
+#define DGPU_NO_INF_OFF (~(size_t)0)
+int32_t dgpu_msm_g1_strided(const void *bases, size_t stride_bytes, size_t x_off, size_t y_off, size_t inf_off,
+                            const uint64_t *scalars, size_t n, int32_t montgomery, uint64_t out_xyz[18]);
+int32_t dgpu_msm_g2_strided(const void *bases, size_t stride_bytes, size_t x_off, size_t y_off, size_t inf_off,
+                            const uint64_t *scalars, size_t n, int32_t montgomery, uint64_t out_xyz[36]);
+int32_t dgpu_bases_upload_g1_strided(const void *bases, size_t stride_bytes, size_t x_off, size_t y_off, size_t inf_off, size_t n, uint64_t *handle);
+int32_t dgpu_bases_upload_g2_strided(const void *bases, size_t stride_bytes, size_t x_off, size_t y_off, size_t inf_off, size_t n, uint64_t *handle);
 /* same pair over G2 — legogroth16/src/prover.rs:344 (b_g2_query), delegatable_credentials/src/set_commitment.rs:566 */
 int32_t dgpu_msm_g2(const uint64_t *bases_xy /* n*24 */, const uint8_t *is_inf,
                     const uint64_t *scalars, size_t n, uint64_t out_xyz[36]);
@@ -283,7 +311,8 @@ int32_t dgpu_g2_deserialize(const uint8_t *in, size_t n, int32_t mode, uint64_t 
  * When enabled, every stage of the next calls is bracketed by HIP events on the library's own stream. */
 int32_t dgpu_prof_enable(int32_t on);
 int32_t dgpu_prof_reset(void);
-/* fills up to `cap` entries; returns the number of stages recorded.  names[i] points to a static string. */
+/* fills up to `cap` entries; returns the number of stages recorded.  names[i] points to a static string.  The last row, "hipMalloc", is
+ * always present: calls = device allocations since dgpu_prof_reset (0 in steady state), total_ms = the time they took. */
 int32_t dgpu_prof_read(const char **names, double *total_ms, uint64_t *calls, int32_t cap);
 
 /* ---- self-test hooks (tests only; run the device field/group code on tiny inputs) ---- */

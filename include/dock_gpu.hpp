@@ -15,6 +15,7 @@
 // instead).  `msm` keeps arkworks' checked-length contract: Err(min_len) when the lengths differ.
 #pragma once
 #include <array>
+#include <cstddef>
 #include <cstdint>
 #include <cstring>
 #include <optional>
@@ -49,6 +50,8 @@ struct G1 {
     static int32_t msm_mont(const uint64_t *b, const uint8_t *i, const uint64_t *s, size_t n, uint64_t *o) { return dgpu_msm_g1_mont(b, i, s, n, o); }
     static int32_t upload(const uint64_t *b, const uint8_t *i, size_t n, uint64_t *h) { return dgpu_bases_upload_g1(b, i, n, h); }
     static int32_t msm_handle(uint64_t h, size_t off, const uint64_t *s, size_t n, int32_t mont, uint64_t *o) { return dgpu_msm_g1_handle(h, off, s, n, mont, o); }
+    static int32_t msm_strided(const void *b, size_t st, size_t xo, size_t yo, size_t io, const uint64_t *s, size_t n, int32_t mont, uint64_t *o) { return dgpu_msm_g1_strided(b, st, xo, yo, io, s, n, mont, o); }
+    static int32_t upload_strided(const void *b, size_t st, size_t xo, size_t yo, size_t io, size_t n, uint64_t *h) { return dgpu_bases_upload_g1_strided(b, st, xo, yo, io, n, h); }
     static int32_t table(const uint64_t *b, uint64_t *h) { return dgpu_window_table_g1(b, h); }
     static int32_t table_mul(uint64_t t, const uint64_t *s, size_t n, int32_t mont, uint64_t *o, uint8_t *oi) { return dgpu_window_table_mul_g1(t, s, n, mont, o, oi); }
 };
@@ -60,11 +63,16 @@ struct G2 {
     static int32_t msm_mont(const uint64_t *b, const uint8_t *i, const uint64_t *s, size_t n, uint64_t *o) { return dgpu_msm_g2_mont(b, i, s, n, o); }
     static int32_t upload(const uint64_t *b, const uint8_t *i, size_t n, uint64_t *h) { return dgpu_bases_upload_g2(b, i, n, h); }
     static int32_t msm_handle(uint64_t h, size_t off, const uint64_t *s, size_t n, int32_t mont, uint64_t *o) { return dgpu_msm_g2_handle(h, off, s, n, mont, o); }
+    static int32_t msm_strided(const void *b, size_t st, size_t xo, size_t yo, size_t io, const uint64_t *s, size_t n, int32_t mont, uint64_t *o) { return dgpu_msm_g2_strided(b, st, xo, yo, io, s, n, mont, o); }
+    static int32_t upload_strided(const void *b, size_t st, size_t xo, size_t yo, size_t io, size_t n, uint64_t *h) { return dgpu_bases_upload_g2_strided(b, st, xo, yo, io, n, h); }
     static int32_t table(const uint64_t *b, uint64_t *h) { return dgpu_window_table_g2(b, h); }
     static int32_t table_mul(uint64_t t, const uint64_t *s, size_t n, int32_t mont, uint64_t *o, uint8_t *oi) { return dgpu_window_table_mul_g2(t, s, n, mont, o, oi); }
 };
 
-// ark-ec's Affine { x, y, infinity } is not a flat array: repack into the ABI form (coordinates + one flag byte per point)
+// ark-ec's Affine { x, y, infinity } is not a flat array.  The MSM entry points take the array of structs as it is (dgpu_msm_*_strided:
+// stride and field offsets are arguments — a Rust shim passes size_of::<G1Affine>() and offset_of!(G1Affine, x / y / infinity), this mirror
+// sizeof / offsetof of its own Affine, which has the same 104 / 200-byte layout); the pairing and fixed-base entry points, whose operand
+// counts are small, still take the packed ABI form (coordinates + one flag byte per point):
 template <class G> struct Packed {
     std::vector<uint64_t> xy; std::vector<uint8_t> inf;
     explicit Packed(const std::vector<typename G::Affine> &pts, size_t n) : xy(n * G::AW, 0), inf(n, 0) {
@@ -95,17 +103,15 @@ template <class G> struct VariableBaseMSM {
     // msm_bigint(bases, bigints): truncates to the shorter operand (legogroth16/src/prover.rs:286 relies on it)
     static Projective msm_bigint(const std::vector<Affine> &bases, const std::vector<BigInt256> &bigints) {
         size_t n = std::min(bases.size(), bigints.size());
-        Packed<G> p(bases, n);
         std::array<uint64_t, G::AW * 3 / 2> out{};
-        check(G::msm(p.xy.data(), p.inf.data(), n ? bigints[0].data() : nullptr, n, out.data()), "msm_bigint");
+        check(G::msm_strided(bases.data(), sizeof(Affine), offsetof(Affine, x), offsetof(Affine, y), offsetof(Affine, infinity), n ? bigints[0].data() : nullptr, n, 0, out.data()), "msm_bigint");
         return projective_from_abi<G>(out.data());
     }
     // msm_unchecked(bases, scalars): scalars in Montgomery form, converted on the device
     static Projective msm_unchecked(const std::vector<Affine> &bases, const std::vector<Fr> &scalars) {
         size_t n = std::min(bases.size(), scalars.size());
-        Packed<G> p(bases, n);
         std::array<uint64_t, G::AW * 3 / 2> out{};
-        check(G::msm_mont(p.xy.data(), p.inf.data(), n ? scalars[0].mont.data() : nullptr, n, out.data()), "msm_unchecked");
+        check(G::msm_strided(bases.data(), sizeof(Affine), offsetof(Affine, x), offsetof(Affine, y), offsetof(Affine, infinity), n ? scalars[0].mont.data() : nullptr, n, 1, out.data()), "msm_unchecked");
         return projective_from_abi<G>(out.data());
     }
     // msm(bases, scalars): Err(min_len) on a length mismatch — returned as {nullopt, min_len}
@@ -127,7 +133,10 @@ template <class G> struct Pairs {
 template <class G> class DeviceBases {
     uint64_t h_ = 0; size_t n_ = 0;
 public:
-    explicit DeviceBases(const std::vector<typename G::Affine> &bases) : n_(bases.size()) { Packed<G> p(bases, n_); check(G::upload(p.xy.data(), p.inf.data(), n_, &h_), "bases_upload"); }
+    explicit DeviceBases(const std::vector<typename G::Affine> &bases) : n_(bases.size()) {
+        using A = typename G::Affine;
+        check(G::upload_strided(bases.data(), sizeof(A), offsetof(A, x), offsetof(A, y), offsetof(A, infinity), n_, &h_), "bases_upload");
+    }
     DeviceBases(const DeviceBases &) = delete;
     ~DeviceBases() { if (h_) dgpu_bases_free(h_); }
     size_t len() const { return n_; }

@@ -43,8 +43,19 @@ int main() {
     std::vector<BigInt256> big(n); std::vector<Fr> fr(n);
     for (size_t i = 0; i < n; i++) { std::memcpy(big[i].data(), &sc[4 * i], 32); std::memcpy(fr[i].mont.data(), &scm[4 * i], 32); }
 
+    // the MSM entry points read the caller's array of structs in place (dgpu_msm_*_strided): Affine { x, y, infinity } is 104 / 200 bytes,
+    // the layout of ark-ec's G1Affine / G2Affine
+    static_assert(sizeof(G1::Affine) == 104 && sizeof(G2::Affine) == 200, "Affine layout");
     uint64_t e1[18], e2[36];
     orc_g1_msm(b1.data(), inf1.data(), sc.data(), n, 8, e1); orc_g2_msm(b2.data(), inf2.data(), sc.data(), n, 8, e2);
+    {   // strided == packed, limb for limb; an identity flag inside the struct is honoured; DGPU_NO_INF_OFF ignores it
+        uint64_t a1[18], a2[18], a3[18];
+        EXPECT(dgpu_msm_g1(b1.data(), inf1.data(), sc.data(), n, a1) == DGPU_OK);
+        EXPECT(dgpu_msm_g1_strided(P1.data(), sizeof(G1::Affine), offsetof(G1::Affine, x), offsetof(G1::Affine, y), offsetof(G1::Affine, infinity), sc.data(), n, 0, a2) == DGPU_OK && std::memcmp(a1, a2, sizeof a1) == 0);
+        EXPECT(dgpu_msm_g1(b1.data(), nullptr, sc.data(), n, a1) == DGPU_OK);
+        EXPECT(dgpu_msm_g1_strided(P1.data(), sizeof(G1::Affine), offsetof(G1::Affine, x), offsetof(G1::Affine, y), DGPU_NO_INF_OFF, sc.data(), n, 0, a3) == DGPU_OK && std::memcmp(a1, a3, sizeof a1) == 0);
+        EXPECT(dgpu_msm_g1_strided(P1.data(), 100, 0, 48, 96, sc.data(), n, 0, a3) == DGPU_E_BADARG);          // stride not a multiple of 8
+    }
     EXPECT(same_point<G1>(VariableBaseMSM<G1>::msm_bigint(P1, big), e1, orc_g1_to_affine));
     EXPECT(same_point<G1>(VariableBaseMSM<G1>::msm_unchecked(P1, fr), e1, orc_g1_to_affine));
     EXPECT(same_point<G2>(VariableBaseMSM<G2>::msm_bigint(P2, big), e2, orc_g2_to_affine));

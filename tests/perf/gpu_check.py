@@ -56,8 +56,8 @@ for c in (7, 9, 13, 15, 16):
     lib().dgpu_set_window_bits(c); check(ca.G1, O.G1, 3000, 900 + c, label="G1 c=%d" % c)
 lib().dgpu_set_window_bits(0)
 for ch in (16, 128):
-    os.environ["DGPU_CHUNK"] = str(ch); check(ca.G1, O.G1, 5000, 950 + ch, label="G1 chunk=%d" % ch)
-os.environ.pop("DGPU_CHUNK")
+    lib().dgpu_set_chunk(ch); check(ca.G1, O.G1, 5000, 950 + ch, label="G1 chunk=%d" % ch)
+lib().dgpu_set_chunk(0)
 
 n = 1 << big
 t0 = time.time()
@@ -67,7 +67,7 @@ db = ca.DeviceBases(ca.G1, bases); ds = ca.DeviceScalars(ss)
 ref = db.msm_resident(ds)
 for c in [int(x) for x in os.environ.get("CS", "13,14,15,16,17").split(",")]:
     for ch in [int(x) for x in os.environ.get("CHS", "32,64").split(",")]:
-        lib().dgpu_set_window_bits(c); os.environ["DGPU_CHUNK"] = str(ch)
+        lib().dgpu_set_window_bits(c); lib().dgpu_set_chunk(ch)
         r = db.msm_resident(ds); assert (r == ref).all() or os.environ.get('NOCHECK')
         ca.prof.enable(True); ca.prof.reset()
         t0 = time.time(); K = 5

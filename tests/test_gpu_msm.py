@@ -23,7 +23,7 @@ def _device():
     ca.init(0)
     yield
     lib().dgpu_set_window_bits(0)
-    os.environ.pop("DGPU_CHUNK", None)
+    lib().dgpu_set_chunk(0)
 
 
 def normalised(G, jac):
@@ -116,13 +116,71 @@ def test_degenerate_inputs():
     assert (ca.msm_bigint(curve, bases, sc, np.ones(64, np.uint8)) == ident).all()
     assert (ca.msm_bigint(curve, np.zeros_like(bases), sc) == ident).all()
     assert (ca.msm_bigint(curve, bases, np.zeros_like(sc)) == ident).all()
-    # bit 255 is not part of a scalar (Fr::MODULUS_BIT_SIZE = 255): it is ignored, like arkworks' digit extraction
-    hi = sc.copy(); hi[:, 3] |= np.uint64(1 << 63)
-    assert (ca.msm_bigint(curve, bases, hi) == ca.msm_bigint(curve, bases, sc)).all()
     # n >= 2^31 is refused before anything is allocated
     out = np.zeros(18, np.uint64)
     rc = lib().dgpu_msm_g1(bases.ctypes.data_as(C.c_void_p), None, sc.ctypes.data_as(C.c_void_p), 1 << 31, out.ctypes.data_as(C.c_void_p))
     assert rc == -3
+
+
+def test_scalars_with_bit_255():
+    """A scalar >= 2^255 means different things to arkworks depending on ITS window width (oracle/oracle.c ark_make_digits reads bit 255 in the top
+    window unless the width divides 255), so no width-independent result exists: every MSM entry point refuses it (DGPU_E_BADARG) and the
+    caller stays on its CPU path.  Scalars in [r, 2^255) are fine: both sides multiply by the integer."""
+    G, curve = O.G1, ca.G1
+    for n in (31, 64, 3000):            # arkworks' c = 3 (divides 255: bit ignored), 6 and 10 (bit read)
+        bases, _, _ = U.seq_bases(G, n, 400 + n)
+        sc = O.rand_scalars(401 + n, n)
+        hi = sc.copy(); hi[n // 2, 3] |= np.uint64(1 << 63)
+        c_ark = O.window_c(n)
+        ark_reads_bit = (255 % c_ark) != 0
+        # what the reference would return: the oracle agrees with the masked scalar exactly when arkworks' width divides 255
+        same = (G.to_affine(G.msm(bases, hi))[0] == G.to_affine(G.msm(bases, sc))[0]).all()
+        assert same == (not ark_reads_bit)
+        for call in (lambda s_: ca.msm_bigint(curve, bases, s_),
+                     lambda s_: ca.DeviceBases(curve, bases).msm_bigint(s_),
+                     lambda s_: ca.DeviceBases(curve, bases).msm_resident(ca.DeviceScalars(s_)),
+                     lambda s_: ca.DeviceBases(curve, bases).precompute(16).msm_bigint(s_),
+                     lambda s_: ca.msm_bigint(ca.G2, U.seq_bases(O.G2, n, 7)[0], s_) if n == 64 else ca.msm_bigint(curve, bases, s_)):
+            with pytest.raises(ca.DockGpuError) as e:
+                call(hi)
+            assert e.value.code == -3
+            call(sc)                                          # the library is usable afterwards
+        tab = ca.DeviceBases(curve, bases).precompute(16)
+        with pytest.raises(ca.DockGpuError) as e:
+            ca.SortedScalars(tab, ca.DeviceScalars(hi), n)
+        assert e.value.code == -3
+    # [r, 2^255): multiplied as the integer it is, like arkworks
+    bases, _, _ = U.seq_bases(G, 64, 11)
+    sc = O.rand_scalars(12, 64)
+    big = sc.copy(); big[:, 3] |= np.uint64(1 << 62); big[:, 3] |= np.uint64(0x3000000000000000)      # >= r, < 2^255
+    assert (ca.msm_bigint(curve, bases, big) == normalised(G, G.msm(bases, big))).all()
+
+
+def test_strided_bases_are_the_callers_affine_structs():
+    """dgpu_msm_*_strided / dgpu_bases_upload_*_strided: ark-ec's in-memory Affine { x, y, infinity } (104 / 200 bytes) goes to the device as it is"""
+    for name, n in (("G1", 3000), ("G2", 700)):
+        curve, G = CUR[name]
+        bases, _, _ = U.seq_bases(G, n, 90)
+        sc = O.rand_scalars(91, n)
+        inf = np.zeros(n, np.uint8); inf[::7] = 1
+        st = ca.to_affine_structs(curve, bases, inf)
+        assert st.dtype.itemsize == (104 if name == "G1" else 200)
+        ref = normalised(G, G.msm(bases[inf == 0], sc[inf == 0], threads=8))
+        assert (ca.msm_strided(curve, st, sc) == ref).all()
+        assert (ca.msm_strided(curve, st, O.fr_to_mont(sc), montgomery=True) == ref).all()
+        assert (ca.msm_bigint(curve, bases, sc, inf) == ref).all()
+        db = ca.DeviceBases.from_structs(curve, st)
+        assert (db.msm_bigint(sc) == ref).all()
+        # another field order (the offsets are arguments): infinity first, then y, then x
+        h = curve.AW // 2
+        dt = np.dtype({"names": ["infinity", "y", "x"], "formats": [np.uint8, (np.uint64, h), (np.uint64, h)], "offsets": [0, 8, 8 + 8 * h], "itemsize": 16 + 16 * h})
+        st2 = np.zeros(n, dt); st2["x"], st2["y"], st2["infinity"] = st["x"], st["y"], st["infinity"]
+        assert (ca.msm_strided(curve, st2, sc) == ref).all()
+        # misaligned offsets / a stride shorter than the fields are refused
+        out = np.zeros(curve.JW, np.uint64)
+        fn = curve.fn("dgpu_msm_%s_strided")
+        assert fn(st.ctypes.data_as(C.c_void_p), st.dtype.itemsize, 4, 8 * h, 16 * h, sc.ctypes.data_as(C.c_void_p), n, 0, out.ctypes.data_as(C.c_void_p)) == -3
+        assert fn(st.ctypes.data_as(C.c_void_p), 8 * h, 0, 8 * h, 16 * h, sc.ctypes.data_as(C.c_void_p), n, 0, out.ctypes.data_as(C.c_void_p)) == -3
 
 
 def test_truncation_and_handles():
@@ -151,12 +209,12 @@ def test_any_window_width_same_point(c):
     ref = normalised(G, G.msm(bases, sc, threads=16))
     lib().dgpu_set_window_bits(c)
     try:
-        for ch in ("16", "128"):
-            os.environ["DGPU_CHUNK"] = ch
+        for ch in (16, 128):
+            assert lib().dgpu_set_chunk(ch) == 0
             assert (ca.msm_bigint(curve, bases, sc) == ref).all()
     finally:
         lib().dgpu_set_window_bits(0)
-        os.environ.pop("DGPU_CHUNK", None)
+        lib().dgpu_set_chunk(0)
 
 
 def test_skewed_scalar_distributions():

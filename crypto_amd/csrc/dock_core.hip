@@ -10,6 +10,7 @@ namespace dock {
 Shared gs;
 Ctx ctxs[MAX_CTX];
 thread_local int tl_ctx = -1;
+thread_local bool tl_no_min = false;
 std::atomic<uint64_t> g_dev_allocs{0}, g_dev_alloc_ns{0}, g_dev_alloc_bytes{0};
 hipError_t dev_malloc(void **p, size_t bytes) {
     const auto t0 = std::chrono::steady_clock::now();
@@ -213,6 +214,12 @@ static int32_t free_handle(uint64_t h, bool scalars) {
     if (!take_handle(h, ok, hd)) return DGPU_E_BADARG;
     release_parts(hd);
     return DGPU_OK;
+}
+// number of elements behind a bases / scalars / sorted-scalars handle (points, scalars), whatever its kind
+int32_t dgpu_handle_len(uint64_t handle, size_t *n) {
+    Handle hd;
+    if (!n || !lookup_handle(handle, hd) || hd.kind == 4 || hd.kind == 5 || hd.kind == 6) return DGPU_E_BADARG;
+    *n = hd.n; return DGPU_OK;
 }
 int32_t dgpu_bases_free(uint64_t h) { return free_handle(h, false); }
 int32_t dgpu_scalars_free(uint64_t h) { return free_handle(h, true); }

@@ -106,6 +106,7 @@ struct Shared {
 };
 extern Ctx ctxs[MAX_CTX];
 extern thread_local int tl_ctx;
+extern thread_local bool tl_no_min;      // set on the library's own threads (dock_prover.cpp): the caller-facing size threshold does not apply to calls the library makes itself
 inline int cur_index() { int i = tl_ctx >= 0 ? tl_ctx : gs.default_ctx; return (i < 0 || i >= MAX_CTX) ? 0 : i; }
 inline Ctx &cur() { return ctxs[cur_index()]; }
 struct CtxScope { int prev; explicit CtxScope(int c) : prev(tl_ctx) { tl_ctx = c; } ~CtxScope() { tl_ctx = prev; } CtxScope(const CtxScope &) = delete; };

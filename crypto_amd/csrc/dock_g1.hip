@@ -1,6 +1,13 @@
 // crypto_amd/csrc/dock_g1.hip — BLS12-381 G1 entry points of include/dock_gpu.h (+ the device self-tests).
 #include "msm_driver.cuh"
 using namespace dock;
+namespace dock {
+// the one-shot pipeline without the size threshold, for callers inside the library (dock_prover.cpp: the g_d MSM of a proof)
+int32_t msm_g1_nothreshold(const uint64_t *b, const uint8_t *inf, const uint64_t *s, size_t n, uint64_t out[18]) {
+    if (!out || (n && (!b || !s))) return DGPU_E_BADARG;
+    return msm_oneshot_here<G1, hostf::Fq>(RawBases::packed<G1>(b, inf), s, n, false, out);
+}
+}  // namespace dock
 
 extern "C" {
 int32_t dgpu_fold_g1(const uint64_t *xyz, size_t k, uint64_t out[18]) { return host_fold_jacobian<hostf::Fq>(xyz, k, out); }

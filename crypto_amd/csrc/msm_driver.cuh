@@ -639,7 +639,7 @@ template <class C, class HF>
 int32_t msm_oneshot(const RawBases &rb, const uint64_t *scalars, size_t n, bool mont, uint64_t *out) {
     if (!out || (n && (!rb.p || !scalars)) || n >= (1ull << 31) || !rb.ok<C>()) return DGPU_E_BADARG;
     if (!cur().ready) return DGPU_E_NODEVICE;            // (before the size threshold: a missing device is never answered with "too small")
-    if (n < gs.min_gpu_n) return DGPU_E_TOO_SMALL;
+    if (!tl_no_min && n < gs.min_gpu_n) return DGPU_E_TOO_SMALL;
     return msm_oneshot_here<C, HF>(rb, scalars, n, mont, out);
 }
 
@@ -668,7 +668,7 @@ template <class C, class HF>
 int32_t msm_handle(uint64_t bases, size_t offset, const uint64_t *scalars, size_t n, int mont, uint64_t *out, int kind, bool check_min = true) {
     if (!out || (n && !scalars)) return DGPU_E_BADARG;
     if (!cur().ready) return DGPU_E_NODEVICE;
-    if (check_min && n < gs.min_gpu_n) return DGPU_E_TOO_SMALL;
+    if (check_min && !tl_no_min && n < gs.min_gpu_n) return DGPU_E_TOO_SMALL;
     HandleRef hb(bases);
     if (!hb.ok || (hb.h.kind != kind && hb.h.kind != kind + 9) || offset > hb.h.n || n > hb.h.n - offset) return DGPU_E_BADARG;
     CtxScope on_owner(hb.h.ctx);                    // run where the bases live
@@ -687,7 +687,7 @@ template <class C, class HF>
 int32_t msm_resident(uint64_t bases, size_t boff, uint64_t scalars, size_t soff, size_t n, uint64_t *out, int kind, bool check_min = true) {
     if (!out) return DGPU_E_BADARG;
     if (!cur().ready) return DGPU_E_NODEVICE;
-    if (check_min && n < gs.min_gpu_n) return DGPU_E_TOO_SMALL;
+    if (check_min && !tl_no_min && n < gs.min_gpu_n) return DGPU_E_TOO_SMALL;
     HandleRef hb(bases), hs(scalars);
     if (!hb.ok || !hs.ok || (hb.h.kind != kind && hb.h.kind != kind + 9) || hs.h.kind != 3 || hb.h.ctx != hs.h.ctx) return DGPU_E_BADARG;    // both operands on one device
     if (boff > hb.h.n || n > hb.h.n - boff || soff > hs.h.n || n > hs.h.n - soff) return DGPU_E_BADARG;
@@ -708,7 +708,7 @@ int32_t msm_sharded_oneshot(const uint64_t *bases, const uint8_t *is_inf, const 
     const std::vector<int> cx = ready_contexts(ngpus);
     if (cx.empty()) return DGPU_E_NODEVICE;
     if (ngpus > 0 && (int)cx.size() < ngpus) return DGPU_E_BADARG;
-    if (n < gs.min_gpu_n) return DGPU_E_TOO_SMALL;
+    if (!tl_no_min && n < gs.min_gpu_n) return DGPU_E_TOO_SMALL;
     std::vector<size_t> lo; shard_bounds(n, cx.size(), lo);
     const size_t JW = 3 * sizeof(HF) / 8, BW = 2 * sizeof(HF) / 8;
     std::vector<uint64_t> parts(cx.size() * JW);
@@ -743,7 +743,7 @@ int32_t msm_sharded_handle(uint64_t bases, const uint64_t *scalars, size_t n, in
     if (!out || (n && !scalars)) return DGPU_E_BADARG;
     HandleRef hb(bases);
     if (!hb.ok || hb.h.kind != kind + 6 || n > hb.h.n) return DGPU_E_BADARG;
-    if (n < gs.min_gpu_n) return DGPU_E_TOO_SMALL;
+    if (!tl_no_min && n < gs.min_gpu_n) return DGPU_E_TOO_SMALL;
     const ShardSet &ss = *(const ShardSet *)hb.h.p;
     const size_t G = ss.sub.size(), JW = 3 * sizeof(HF) / 8;
     std::vector<uint64_t> parts(G * JW);

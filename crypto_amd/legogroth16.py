@@ -271,7 +271,47 @@ def create_proof(pk, r, s, v, h, input_assignment_with_one, witness_assignment, 
     return {"a": _affine(M.G1, g_a), "b": _affine(M.G2, g2_b), "c": _affine(M.G1, g_c), "d": _affine(M.G1, g_d)}
 
 
-def create_proof_with_reduction(pk, circuit, r, s, v, assignment_with_one, share_sort=True):
+def _lego_pk_struct(pk):
+    """the dgpu_lego_pk of a ProvingKey (+ the arrays it points into, which must outlive the call)"""
+    from ._native import LegoPk
+    vk = pk.vk
+    keep = {k: np.ascontiguousarray(v, dtype=np.uint64) for k, v in (
+        ("alpha_g1", vk.alpha_g1), ("beta_g1", pk.beta_g1), ("delta_g1", pk.delta_g1), ("eta_delta_inv_g1", pk.eta_delta_inv_g1),
+        ("eta_gamma_inv_g1", vk.eta_gamma_inv_g1), ("beta_g2", vk.beta_g2), ("delta_g2", vk.delta_g2), ("a0", pk.a0), ("b1_0", pk.b1_0), ("b2_0", pk.b2_0),
+        ("gamma_abc_g1", vk.gamma_abc_g1))}
+    st = LegoPk()
+    st.a_query, st.b_g1_query, st.b_g2_query, st.h_query, st.l_query = (q.handle for q in (pk.a_query, pk.b_g1_query, pk.b_g2_query, pk.h_query, pk.l_query))
+    for k, a in keep.items():
+        setattr(st, k, a.ctypes.data)
+    st.gamma_abc_len = len(vk.gamma_abc_g1)
+    st.commit_witness_count = vk.commit_witness_count
+    return st, keep
+
+
+def prove_abi(pk, r, s, v, assignment_with_one, n_inst, circuit=None, h=None, montgomery=False):
+    """dgpu_legogroth16_prove: prover.rs:267-383 (and the witness map in front of it when `circuit` is a resident qap.DeviceR1cs) as ONE call of
+    the C ABI — what a Rust shim binds.  `h`: a DeviceScalars holding the h coefficients when no circuit is given."""
+    z = np.ascontiguousarray(assignment_with_one, dtype=np.uint64).reshape(-1, 4)
+    st, keep = _lego_pk_struct(pk)
+    a, b, c, d = np.zeros(12, np.uint64), np.zeros(24, np.uint64), np.zeros(12, np.uint64), np.zeros(12, np.uint64)
+    inf = np.zeros(4, np.uint8)
+    p = lambda x: x.ctypes.data_as(C.c_void_p)
+    raw = lambda x: np.array([(x >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)      # (any value below 2^256: reduced inside)
+    rc = M.lib().dgpu_legogroth16_prove(C.byref(st), circuit.handle if circuit is not None else 0, h.handle if h is not None else 0, p(z), len(z), n_inst,
+                                        int(montgomery), p(raw(r)), p(raw(s)), p(raw(v)), p(a), p(b), p(c), p(d), p(inf))
+    del keep
+    if rc:
+        raise M.DockGpuError(rc, "dgpu_legogroth16_prove")
+    return {"a": a, "b": b, "c": c, "d": d}
+
+
+def create_proof_with_reduction(pk, circuit, r, s, v, assignment_with_one, share_sort=True, via_abi=True):
+    if via_abi and share_sort:
+        return prove_abi(pk, r, s, v, assignment_with_one, circuit.num_inputs, circuit=circuit)
+    return create_proof_with_reduction_py(pk, circuit, r, s, v, assignment_with_one, share_sort)
+
+
+def create_proof_with_reduction_py(pk, circuit, r, s, v, assignment_with_one, share_sort=True):
     """create_proof_with_reduction (prover.rs:153-180): h = QAP::witness_map(cs) then create_proof_with_assignment.  `circuit` is the resident
     R1CS (qap.DeviceR1cs: the matrices of the synthesised constraint system), `assignment_with_one` the full assignment z = instance ++ witness.
     z is uploaded ONCE: the witness map reads it in place (dgpu_witness_map_r1cs_resident), the four assignment MSMs use the same handle at

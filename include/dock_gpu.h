@@ -294,6 +294,34 @@ int32_t dgpu_witness_map_r1cs(uint64_t r1cs, const uint64_t *assignment, size_t 
  * per proof then serves the witness map and — at scalar offset 1 — the prover's `assignment` = z[1..] of the a / b_g1 / b_g2 / l MSMs */
 int32_t dgpu_witness_map_r1cs_resident(uint64_t r1cs, uint64_t assignment, uint64_t *out_h, uint64_t *out_handle, size_t *out_len);
 
+/* ---- the LegoGroth16 prover as one call ----
+ * replaces create_proof_and_committed_witnesses_with_assignment (legogroth16/src/prover.rs:267-383, with calculate_coeff :585-594) and — when
+ * the circuit is resident (r1cs != 0) — the QAP::witness_map call in front of it (create_proof_with_reduction, :153-180): the whole schedule
+ * (one upload of z, witness map, one partition sort shared by the A / B-in-G1 / B-in-G2 / l MSMs when the queries are tables of one shape, the
+ * G2 MSM issued first, the O(1) scalar multiplications on a host core meanwhile, the final fold) runs on host threads inside the library.
+ *   pk        the proving key: five query handles (dgpu_bases_upload_* / dgpu_window_table_mul_to_bases_*, plain or dgpu_bases_precompute_*d)
+ *             on one device, and its O(1) elements on the host in the ABI's affine layout (an all-zero point is the identity)
+ *   r1cs      dgpu_r1cs_upload handle of the circuit, or 0 with h_scalars = a resident vector of the D coefficients of h (dgpu_witness_map*)
+ *   z         the full assignment (1, instance..., witness...), num_vars scalars; n_inst = number of instance variables incl. the leading 1;
+ *             montgomery != 0: &[Fr] limbs.  The first commit_witness_count witnesses are the committed ones (proof.d).
+ *   r, s, v   the prover's randomness (canonical limbs, reduced mod r inside)
+ *   out       A (G1), B (G2), C (G1), D (G1) as affine points; out_inf[k] = 1 marks an identity (then zero words)
+ * Same group elements as the reference computes (asserted limb for limb against the Python mirror and the toxic-waste closed form,
+ * tests/test_gpu_prove_abi.py, and from the compiled C++ driver). */
+typedef struct dgpu_lego_pk {
+    uint64_t a_query, b_g1_query, b_g2_query, h_query, l_query;                                     /* bases handles (query[0] included) */
+    const uint64_t *alpha_g1, *beta_g1, *delta_g1, *eta_delta_inv_g1, *eta_gamma_inv_g1;             /* 12 u64 each */
+    const uint64_t *beta_g2, *delta_g2;                                                              /* 24 u64 each */
+    const uint64_t *a0, *b1_0, *b2_0;                                                                /* query[0] of a / b_g1 (12) / b_g2 (24) */
+    const uint64_t *gamma_abc_g1; size_t gamma_abc_len;                                              /* vk.gamma_abc_g1: (n_inst + commit_witness_count) x 12 */
+    size_t commit_witness_count;
+} dgpu_lego_pk;
+int32_t dgpu_legogroth16_prove(const dgpu_lego_pk *pk, uint64_t r1cs, uint64_t h_scalars, const uint64_t *z, size_t num_vars, size_t n_inst,
+                               int32_t montgomery, const uint64_t r[4], const uint64_t s[4], const uint64_t v[4],
+                               uint64_t out_a[12], uint64_t out_b[24], uint64_t out_c[12], uint64_t out_d[12], uint8_t out_inf[4]);
+/* elements behind a bases / scalars / sorted handle */
+int32_t dgpu_handle_len(uint64_t handle, size_t *n);
+
 /* ---- canonical (de)serialisation of group elements (host code) ----
  * The format ark-bls12-381 0.4 emits for `CanonicalSerialize` (Zcash / IETF BLS12-381): big-endian coordinates, top three bits of
  * byte 0 = compressed / infinity / y-lexicographically-largest; G1 48 B (compressed) or 96 B, G2 96 or 192 B with c1 before c0.

@@ -63,8 +63,11 @@ def test_skewed_and_degenerate_scalars_on_a_table():
     eq = np.tile(O.int_to_limbs(0xDEADBEEFCAFEF00D1234567, 4), (n, 1))          # one bucket per window holds everything
     assert (tab.msm_bigint(eq) == plain.msm_bigint(eq)).all()
     assert (tab.msm_bigint(np.zeros_like(sc)) == plain.msm_bigint(np.zeros_like(sc))).all()
-    hi = full.copy(); hi[:, 3] |= np.uint64(1 << 63)                             # bit 255 is not part of a scalar
-    assert (tab.msm_bigint(hi) == plain.msm_bigint(full)).all()
+    hi = full.copy(); hi[:, 3] |= np.uint64(1 << 63)                             # scalars >= 2^255 are refused (include/dock_gpu.h: no width-independent meaning)
+    with pytest.raises(ca.DockGpuError) as e:
+        tab.msm_bigint(hi)
+    assert e.value.code == -3
+    assert (tab.msm_bigint(full) == plain.msm_bigint(full)).all()
     # everything cancels -> identity
     b2 = np.concatenate([bases[:50], bases[:50]]); b2[50:, 6:] = np.stack([U.fp_abi((-U.fp_int(y)) % U.P) for y in bases[:50, 6:]])
     t2 = ca.DeviceBases(curve, b2).precompute(16)

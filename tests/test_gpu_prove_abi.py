@@ -1,0 +1,60 @@
+"""GPU (-m gpu): dgpu_legogroth16_prove — legogroth16/src/prover.rs:267-383 (with the witness map of :153-180 in front) as ONE call of the
+C ABI.  The schedule that used to live in Python above the ABI runs on host threads inside the library; the proof must equal, limb for limb,
+what the Python mirror of the reference's function computes from the individual entry points (which tests/test_gpu_legogroth16.py checks
+against the CPU oracle's evaluation of the same equations), for plain queries and for precomputed tables (shared sort), Montgomery and
+canonical assignments, r = 0, no committed witnesses and all witnesses committed."""
+import numpy as np
+import pytest
+import torch
+import oracle_c as O
+import lego_setup as LS
+import crypto_amd as ca
+from crypto_amd import legogroth16 as LG, qap
+
+pytestmark = pytest.mark.gpu
+R = LS.R
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _device():
+    assert torch.cuda.is_available()
+    ca.init(0)
+
+
+@pytest.mark.parametrize("m,cw", [(20, 2), (117, 0), (117, 3), (300, 298)])
+def test_one_call_equals_the_python_schedule(m, cw):
+    cs = LS.circuit(m, x0=7)
+    nw = len(cs["z"]) - cs["n_inst"]
+    cw = min(cw, nw)
+    key = LS.setup(cs, cw, seed=900 + m)
+    vk = LG.VerifyingKey(key["alpha_g1"], key["beta_g2"], key["gamma_g2"], key["delta_g2"], key["gamma_abc_g1"], key["eta_gamma_inv_g1"], cw)
+    pk = LG.ProvingKey(vk, key["beta_g1"], key["delta_g1"], key["eta_delta_inv_g1"], key["a_query"], key["b_g1_query"], key["b_g2_query"], key["h_query"], key["l_query"])
+    z = LS.scalars(cs["z"])
+    n_inst = cs["n_inst"]
+    dr = qap.DeviceR1cs(*[qap.csr(cs[k]) for k in "ABC"], len(cs["z"]), n_inst, len(cs["A"]))
+    r, s, v = 0x1234567 * 0x9E3779B97F4A7C15 % R, 0xABCDEF01 * 0xBF58476D1CE4E5B9 % R, 0x55AA55 * 0x94D049BB133111EB % R
+    pvk = LG.prepare_verifying_key(vk)
+    for tables in (False, True):
+        if tables:
+            for q in (pk.a_query, pk.b_g1_query, pk.b_g2_query, pk.h_query, pk.l_query):
+                if q.n:
+                    q.precompute(16)
+        for (rr, ss) in ((r, s), (0, s), (r + R, s)):                      # r = 0: no B in G1 (prover.rs:330); r + R: reduced inside
+            ref = LG.create_proof_with_reduction_py(pk, dr, rr % R, ss, v, z)
+            got = LG.prove_abi(pk, rr, ss, v, z, n_inst, circuit=dr)
+            assert all((got[k] == ref[k]).all() for k in ref), (m, cw, tables)
+            assert LG.verify_proof(pvk, got, z[1:n_inst])
+        # &[Fr] (Montgomery) assignment, and h handed over as a resident vector instead of the circuit
+        gm = LG.prove_abi(pk, r, s, v, O.fr_to_mont(z), n_inst, circuit=dr, montgomery=True)
+        ref = LG.create_proof_with_reduction_py(pk, dr, r, s, v, z)
+        assert all((gm[k] == ref[k]).all() for k in ref)
+        _, dh = dr.witness_map(z, to_host=False, resident=True)
+        gh = LG.prove_abi(pk, r, s, v, z, n_inst, h=dh)
+        assert all((gh[k] == ref[k]).all() for k in ref)
+        dh.free()
+    # argument checks: both / neither source of h, n_inst out of range
+    with pytest.raises(ca.DockGpuError):
+        LG.prove_abi(pk, r, s, v, z, n_inst)
+    with pytest.raises(ca.DockGpuError):
+        LG.prove_abi(pk, r, s, v, z, len(z) + 1, circuit=dr)
+    dr.free()

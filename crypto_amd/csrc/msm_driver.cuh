@@ -66,7 +66,8 @@ int32_t host_lincomb(const uint64_t *points_xy, const uint8_t *is_inf, const uin
         HF X, Y;
         memcpy(&X, points_xy + i * 2 * FWORDS, sizeof(HF)); memcpy(&Y, points_xy + i * 2 * FWORDS + FWORDS, sizeof(HF));
         const uint64_t *sc = scalars + 4 * i;
-        if ((is_inf && is_inf[i]) || !(sc[0] | sc[1] | sc[2] | sc[3])) continue;
+        uint64_t any = 0; for (size_t w = 0; w < 2 * FWORDS; w++) any |= points_xy[i * 2 * FWORDS + w];      // all-zero coordinates: the ABI's other spelling of the identity
+        if ((is_inf && is_inf[i]) || !any || !(sc[0] | sc[1] | sc[2] | sc[3])) continue;
         live[i] = 1;
         PT p; p.inf = false; p.x = X; p.y = Y; p.zz = HF::one(); p.zzz = HF::one();
         tab[i * 15] = p;

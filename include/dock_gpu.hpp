@@ -140,6 +140,9 @@ public:
     DeviceBases(const DeviceBases &) = delete;
     ~DeviceBases() { if (h_) dgpu_bases_free(h_); }
     size_t len() const { return n_; }
+    uint64_t handle() const { return h_; }
+    // per-key setup: MSMs over this query run on a precomputed-multiples table from now on (dgpu_bases_precompute_*); same results
+    void precompute(int32_t window_bits = 0) { check(G::AW == 12 ? dgpu_bases_precompute_g1(h_, window_bits) : dgpu_bases_precompute_g2(h_, window_bits), "bases_precompute"); }
     typename G::Projective msm_bigint(const std::vector<BigInt256> &bigints, size_t offset = 0) const {
         size_t n = std::min(n_ - offset, bigints.size());
         std::array<uint64_t, G::AW * 3 / 2> out{};
@@ -188,5 +191,43 @@ inline std::optional<Fq12> final_exponentiation(const Fq12 &f) {
     return out;
 }
 inline Fq12 multi_pairing(const std::vector<G1::Affine> &a, const std::vector<G2::Affine> &b) { return *final_exponentiation(multi_miller_loop(a, b)); }
+
+
+// ---- legogroth16::create_proof_with_reduction (legogroth16/src/prover.rs:153-180 -> :267-383) over dgpu_legogroth16_prove ----
+namespace legogroth16 {
+// ProvingKey (legogroth16/src/data_structures.rs:55-70,151-168): the five queries live on the device, the O(1) elements on the host
+struct ProvingKey {
+    DeviceBases<G1> a_query, b_g1_query, h_query, l_query; DeviceBases<G2> b_g2_query;
+    G1::Affine alpha_g1, beta_g1, delta_g1, eta_delta_inv_g1, eta_gamma_inv_g1, a0, b1_0; G2::Affine beta_g2, delta_g2, b2_0;
+    std::vector<G1::Affine> gamma_abc_g1; size_t commit_witness_count;
+    ProvingKey(const std::vector<G1::Affine> &a, const std::vector<G1::Affine> &b1, const std::vector<G2::Affine> &b2, const std::vector<G1::Affine> &h, const std::vector<G1::Affine> &l)
+        : a_query(a), b_g1_query(b1), h_query(h), l_query(l), b_g2_query(b2), a0(a.at(0)), b1_0(b1.at(0)), b2_0(b2.at(0)), commit_witness_count(0) {}
+};
+struct Proof { G1::Affine a, c, d; G2::Affine b; };
+// the resident circuit (ConstraintMatrices of the synthesised system as CSR) is a dgpu_r1cs_upload handle; z = (1, instance..., witness...)
+inline Proof create_proof_with_reduction(const ProvingKey &pk, uint64_t r1cs, const std::vector<BigInt256> &z, size_t n_inst,
+                                         const BigInt256 &r, const BigInt256 &s, const BigInt256 &v) {
+    auto flat = [](const G1::Affine &p, uint64_t *o) { if (p.infinity) std::memset(o, 0, 96); else { std::memcpy(o, &p.x, 48); std::memcpy(o + 6, &p.y, 48); } };
+    auto flat2 = [](const G2::Affine &p, uint64_t *o) { if (p.infinity) std::memset(o, 0, 192); else { std::memcpy(o, &p.x, 96); std::memcpy(o + 12, &p.y, 96); } };
+    uint64_t g1s[7][12], g2s[3][24];
+    const G1::Affine *g1p[7] = {&pk.alpha_g1, &pk.beta_g1, &pk.delta_g1, &pk.eta_delta_inv_g1, &pk.eta_gamma_inv_g1, &pk.a0, &pk.b1_0};
+    for (int i = 0; i < 7; i++) flat(*g1p[i], g1s[i]);
+    flat2(pk.beta_g2, g2s[0]); flat2(pk.delta_g2, g2s[1]); flat2(pk.b2_0, g2s[2]);
+    std::vector<uint64_t> gabc(pk.gamma_abc_g1.size() * 12);
+    for (size_t i = 0; i < pk.gamma_abc_g1.size(); i++) flat(pk.gamma_abc_g1[i], &gabc[12 * i]);
+    dgpu_lego_pk k{};
+    k.a_query = pk.a_query.handle(); k.b_g1_query = pk.b_g1_query.handle(); k.b_g2_query = pk.b_g2_query.handle(); k.h_query = pk.h_query.handle(); k.l_query = pk.l_query.handle();
+    k.alpha_g1 = g1s[0]; k.beta_g1 = g1s[1]; k.delta_g1 = g1s[2]; k.eta_delta_inv_g1 = g1s[3]; k.eta_gamma_inv_g1 = g1s[4]; k.a0 = g1s[5]; k.b1_0 = g1s[6];
+    k.beta_g2 = g2s[0]; k.delta_g2 = g2s[1]; k.b2_0 = g2s[2];
+    k.gamma_abc_g1 = gabc.data(); k.gamma_abc_len = pk.gamma_abc_g1.size(); k.commit_witness_count = pk.commit_witness_count;
+    uint64_t a[12], b[24], c[12], d[12]; uint8_t inf[4];
+    check(dgpu_legogroth16_prove(&k, r1cs, 0, z.empty() ? nullptr : z[0].data(), z.size(), n_inst, 0, r.data(), s.data(), v.data(), a, b, c, d, inf), "legogroth16_prove");
+    Proof pr;
+    auto unflat = [](G1::Affine &p, const uint64_t *o, bool i) { p.infinity = i; std::memcpy(&p.x, o, 48); std::memcpy(&p.y, o + 6, 48); };
+    unflat(pr.a, a, inf[0]); unflat(pr.c, c, inf[2]); unflat(pr.d, d, inf[3]);
+    pr.b.infinity = inf[1]; std::memcpy(&pr.b.x, b, 96); std::memcpy(&pr.b.y, b + 12, 96);
+    return pr;
+}
+}  // namespace legogroth16
 
 }  // namespace dock_gpu

@@ -136,6 +136,78 @@ int main() {
         }
         EXPECT(dgpu_bases_free(h) == DGPU_OK);
     }
+    // the LegoGroth16 prover as ONE call (dgpu_legogroth16_prove through legogroth16::create_proof_with_reduction, prover.rs:153-180 -> :267-383)
+    // on a synthetic key of 1000 variables, against the same equations evaluated piece by piece through OTHER entry points (one-shot MSMs
+    // from host memory, host lincombs, folds); then again with every query a precomputed table (one shared partition sort inside the call)
+    {
+        const size_t NV = 1000, NI = 2, CW = 2, NC = 1022, D = 1024;
+        std::vector<G1::Affine> qa(P1.begin(), P1.begin() + NV), qb1(P1.begin() + 1000, P1.begin() + 1000 + NV), qh(P1.begin() + 1500, P1.begin() + 1500 + D - 1), ql(P1.begin() + 2000, P1.begin() + 2000 + NV - NI - CW);
+        std::vector<G2::Affine> qb2(P2.begin(), P2.begin() + NV);
+        qa[5].infinity = true;                                                 // (P1[5] is already flagged; its coordinates stay: the flag must win)
+        legogroth16::ProvingKey pk(qa, qb1, qb2, qh, ql);
+        pk.alpha_g1 = P1[2900]; pk.beta_g1 = P1[2901]; pk.delta_g1 = P1[2902]; pk.eta_delta_inv_g1 = P1[2903]; pk.eta_gamma_inv_g1 = P1[2904];
+        pk.beta_g2 = P2[2900]; pk.delta_g2 = P2[2901];
+        pk.gamma_abc_g1.assign(P1.begin() + 2910, P1.begin() + 2910 + NI + CW); pk.commit_witness_count = CW;
+        std::vector<uint64_t> rp(NC + 1), va(NC * 4, 0); std::vector<uint32_t> ca(NC), cb(NC), cc(NC);
+        for (size_t i = 0; i < NC; i++) { rp[i] = i; ca[i] = (uint32_t)(i % NV); cb[i] = (uint32_t)((7 * i + 3) % NV); cc[i] = (uint32_t)((5 * i + 1) % NV); va[4 * i] = 1 + i % 3; }
+        rp[NC] = NC;
+        uint64_t circ = 0;
+        EXPECT(dgpu_r1cs_upload(rp.data(), ca.data(), va.data(), NC, rp.data(), cb.data(), va.data(), NC, rp.data(), cc.data(), va.data(), NC, NV, NI, NC, 0, &circ) == DGPU_OK);
+        std::vector<BigInt256> z(big.begin(), big.begin() + NV);
+        z[0] = BigInt256{1, 0, 0, 0};
+        const BigInt256 r{3, 0, 0, 0}, s{5, 0, 0, 0}, v{7, 0, 0, 0};
+        // reference, piece by piece
+        std::vector<uint64_t> h(D * 4); size_t hl = 0;
+        EXPECT(dgpu_witness_map_r1cs(circ, z[0].data(), NV, 0, h.data(), nullptr, &hl) == DGPU_OK && hl == D);
+        auto flat1 = [&](const G1::Affine &p, uint64_t *o) { std::memcpy(o, &p.x, 48); std::memcpy(o + 6, &p.y, 48); };
+        auto msm1 = [&](const std::vector<G1::Affine> &q, size_t off, const uint64_t *sc_, size_t cnt, uint64_t *out) {
+            EXPECT(dgpu_msm_g1_strided(q.data() + off, sizeof(G1::Affine), offsetof(G1::Affine, x), offsetof(G1::Affine, y), offsetof(G1::Affine, infinity), sc_, cnt, 0, out) == DGPU_OK); };
+        const uint64_t one4[4] = {1, 0, 0, 0};
+        auto coeff1 = [&](const std::vector<G1::Affine> &q, const G1::Affine &vkp, const BigInt256 &k, uint64_t *out) {     // k delta + q[0] + vk + msm(q[1..], z[1..])
+            uint64_t parts[36], pts[36], ks[12]; uint8_t fl[3] = {pk.delta_g1.infinity, q[0].infinity, vkp.infinity};
+            flat1(pk.delta_g1, pts); flat1(q[0], pts + 12); flat1(vkp, pts + 24);
+            std::memcpy(ks, k.data(), 32); std::memcpy(ks + 4, one4, 32); std::memcpy(ks + 8, one4, 32);
+            msm1(q, 1, z[1].data(), NV - 1, parts);
+            EXPECT(dgpu_lincomb_g1(pts, fl, ks, 3, parts + 18) == DGPU_OK);
+            EXPECT(dgpu_fold_g1(parts, 2, out) == DGPU_OK); };
+        uint64_t eA[18], eB1[18], eB2[36], eL[18], eH[18];
+        coeff1(qa, pk.alpha_g1, r, eA); coeff1(qb1, pk.beta_g1, s, eB1);
+        {
+            uint64_t parts[72], pts[72], ks[12];
+            std::memcpy(pts, &pk.delta_g2.x, 96); std::memcpy(pts + 12, &pk.delta_g2.y, 96); std::memcpy(pts + 24, &qb2[0].x, 96); std::memcpy(pts + 36, &qb2[0].y, 96); std::memcpy(pts + 48, &pk.beta_g2.x, 96); std::memcpy(pts + 60, &pk.beta_g2.y, 96);
+            std::memcpy(ks, s.data(), 32); std::memcpy(ks + 4, one4, 32); std::memcpy(ks + 8, one4, 32);
+            EXPECT(dgpu_msm_g2_strided(qb2.data() + 1, sizeof(G2::Affine), offsetof(G2::Affine, x), offsetof(G2::Affine, y), offsetof(G2::Affine, infinity), z[1].data(), NV - 1, 0, parts) == DGPU_OK);
+            EXPECT(dgpu_lincomb_g2(pts, nullptr, ks, 3, parts + 36) == DGPU_OK);
+            EXPECT(dgpu_fold_g2(parts, 2, eB2) == DGPU_OK);
+        }
+        msm1(ql, 0, z[NI + CW].data(), NV - NI - CW, eL); msm1(qh, 0, h.data(), D - 1, eH);
+        for (int pass = 0; pass < 2; pass++) {
+            if (pass == 1) { pk.a_query.precompute(16); pk.b_g1_query.precompute(16); pk.b_g2_query.precompute(16); pk.h_query.precompute(16); pk.l_query.precompute(16); }
+            legogroth16::Proof pr = legogroth16::create_proof_with_reduction(pk, circ, z, NI, r, s, v);
+            EXPECT(!pr.a.infinity && std::memcmp(&pr.a.x, eA, 96) == 0);
+            EXPECT(!pr.b.infinity && std::memcmp(&pr.b.x, eB2, 192) == 0);
+            // C + rs delta + v eta/delta == s A + r B1 + L + H
+            uint64_t lhs[36], rhs[72], pts[36], ks[12], L[18], Rr[18]; uint8_t fl[3] = {0, 0, 0};
+            flat1(pr.c, pts); flat1(pk.delta_g1, pts + 12); flat1(pk.eta_delta_inv_g1, pts + 24);
+            const uint64_t k15[4] = {15, 0, 0, 0};
+            std::memcpy(ks, one4, 32); std::memcpy(ks + 4, k15, 32); std::memcpy(ks + 8, v.data(), 32);
+            EXPECT(dgpu_lincomb_g1(pts, fl, ks, 3, L) == DGPU_OK);
+            std::memcpy(pts, eA, 96); std::memcpy(pts + 12, eB1, 96);
+            std::memcpy(ks, s.data(), 32); std::memcpy(ks + 4, r.data(), 32);
+            EXPECT(dgpu_lincomb_g1(pts, fl, ks, 2, rhs) == DGPU_OK);
+            std::memcpy(rhs + 18, eL, 144); std::memcpy(rhs + 36, eH, 144);
+            EXPECT(dgpu_fold_g1(rhs, 3, Rr) == DGPU_OK);
+            (void)lhs;
+            EXPECT(std::memcmp(L, Rr, sizeof L) == 0);
+            // D = msm(gamma_abc[NI .. NI + CW], z[NI .. NI + CW]) + v eta/gamma
+            uint64_t dp[36], dk[12], eD[18];
+            flat1(pk.gamma_abc_g1[NI], dp); flat1(pk.gamma_abc_g1[NI + 1], dp + 12); flat1(pk.eta_gamma_inv_g1, dp + 24);
+            std::memcpy(dk, z[NI].data(), 32); std::memcpy(dk + 4, z[NI + 1].data(), 32); std::memcpy(dk + 8, v.data(), 32);
+            EXPECT(dgpu_lincomb_g1(dp, fl, dk, 3, eD) == DGPU_OK);
+            EXPECT(!pr.d.infinity && std::memcmp(&pr.d.x, eD, 96) == 0);
+        }
+        EXPECT(dgpu_r1cs_free(circ) == DGPU_OK);
+    }
     // several device contexts in this one process (a Rust host is one process): two contexts on the box's one GPU, every MSM chunked
     // over them inside the library (dgpu_msm_*_sharded*), same point as the single-context call
     init_devices({0, 0});

@@ -300,6 +300,13 @@ def cpu_baseline(ca, gen1, ks, scalars, db, ds, log2n, ncpu):
     res = {"value": round((ns / float(1 << 20)) / tcpu, 4), "unit": "MSM/s (n=2^20-term equivalents)", "cores": thr, "kind": "port",
            "sample": "one n=2^%d G1 MSM, %.2f s wall on %d threads (one per window, arkworks' rayon structure) of %d logical CPUs; result bit-exact vs GPU: %s" % (
                log2s, tcpu, thr, ncpu, same)}
+    import ctypes as _C
+    L = O.lib()
+    L.orc_bench_fp_mul_ns.restype = _C.c_double; L.orc_bench_g1_madd_ns.restype = _C.c_double
+    res["calibration"] = {"ns_per_fp_mul": round(min(L.orc_bench_fp_mul_ns(_C.c_size_t(2000000)) for _ in range(3)), 1),
+                          "ns_per_g1_mixed_add": round(min(L.orc_bench_g1_madd_ns(_C.c_size_t(300000)) for _ in range(3)), 1),
+                          "note": "one core, dependent chain; plain C (unsigned __int128, no-carry CIOS, -O3 -mbmi2 -madx).  ark-ff 0.4's asm Montgomery backend is "
+                                  "quoted at ~25-30 ns per 381-bit product on current x86: scale `value` by ns_per_fp_mul / 27 for an estimate of the real arkworks path"}
     l1 = min(log2s, 18)                                      # one thread: a 2^18 sample (about 4 s), scaled per term
     tb = time.perf_counter()
     O.G1.msm(bases[:1 << l1], scalars[:1 << l1], threads=1)

@@ -7,6 +7,7 @@ import struct
 import numpy as np
 
 BLS12_381_ORDER = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+BN128_ORDER = 21888242871839275222246405745257275088548364400416034343698204186575808495617
 
 
 class R1csFile:
@@ -45,6 +46,20 @@ class R1csFile:
                     p += 36
                 lcs.append(terms)
             self.constraints.append(tuple(lcs))
+        # section 3, wire2label (r1cs_reader.rs:91-101, read_map :219-238): n_wires u64 labels, wire 0 -> label 0
+        self.wire_mapping = []
+        if 3 in secs:
+            w, wsize = secs[3]
+            if wsize != self.n_wires * 8:
+                raise ValueError("Invalid map section size")
+            self.wire_mapping = list(struct.unpack_from("<%dQ" % self.n_wires, data, w))
+            if self.wire_mapping and self.wire_mapping[0] != 0:
+                raise ValueError("Wire 0 should always be mapped to 0")
+
+    @property
+    def curve(self):
+        """the curve whose scalar field the file was compiled for (r1cs_reader.rs:186-200: anything else is IncompatibleWithCurve)"""
+        return {BLS12_381_ORDER: "bls12_381", BN128_ORDER: "bn128"}.get(self.prime)
 
     @classmethod
     def from_path(cls, path):

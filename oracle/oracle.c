@@ -242,6 +242,28 @@ API int orc_g1_on_curve(const uint64_t xy[12]) {
     return fp_eq(&l, &r);
 }
 /* ---- G2 ---- */
+/* timed CPU baseline, calibration: ns per dependent Fp product and per G1 mixed addition on one core (bench.py prints them next to
+ * cpu_baseline so that the stand-in can be placed against ark-ff's backend: ~25-30 ns per 381-bit Montgomery product on current x86) */
+#include <time.h>
+static double now_ns(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e9 + ts.tv_nsec; }
+API double orc_bench_fp_mul_ns(size_t iters) {
+    fp a = FP_R2, b = FP_ONE; b.l[0] ^= 0x1234567;
+    double t0 = now_ns();
+    for (size_t i = 0; i < iters; i++) { fp_mul(&a, &a, &b); fp_mul(&b, &b, &a); }
+    double dt = now_ns() - t0;
+    volatile uint64_t sink = a.l[0] ^ b.l[0]; (void)sink;
+    return dt / (2.0 * iters);
+}
+API double orc_bench_g1_madd_ns(size_t iters) {
+    g1_jac acc; g1_aff q = G1_GEN;
+    uint64_t k[4] = {0x123456789abcdefULL, 0, 0, 0};
+    g1_mul(&acc, &G1_GEN, 0, k);
+    double t0 = now_ns();
+    for (size_t i = 0; i < iters; i++) g1_madd(&acc, &acc, &q);
+    double dt = now_ns() - t0;
+    volatile uint64_t sink = acc.x.l[0]; (void)sink;
+    return dt / iters;
+}
 API void orc_g2_generator(uint64_t out[24]) { memcpy(out, &G2_GEN, 192); }
 API void orc_g2_msm(const uint64_t *bases, const uint8_t *inf, const uint64_t *scalars, size_t n, int threads, uint64_t out[36]) {
     g2_msm_bigint((g2_jac *)out, (const g2_aff *)bases, inf, scalars, n, threads);

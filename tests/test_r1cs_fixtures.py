@@ -64,6 +64,31 @@ def test_reader_matches_reference_header_semantics():
         R1csFile(b"r1cx" + bytes(100))
 
 
+def test_reference_held_known_answer_vector_bn_254():
+    """The one known-answer vector the reference's tests hold for a row of SURVEY 8: the `bn_254` sample of
+    legogroth16/src/circom/r1cs_reader.rs:283-340 (816 bytes of test DATA, stored as tests/golden/r1cs/bn254_sample.r1cs) and every value that test
+    asserts about it (:341-356, basic_checks :250-281).  Coefficients are (wire id, value) pairs in the reference, (value, wire id) here."""
+    f = fx("bn254_sample.r1cs")
+    assert f.curve == "bn128"
+    assert f.prime == 21888242871839275222246405745257275088548364400416034343698204186575808495617
+    assert (f.n_wires, f.n_pub_out, f.n_pub_in, f.n_prv_in, f.n_labels, f.n_constraints) == (7, 1, 2, 3, 0x03E8, 3)
+    assert len(f.constraints) == 3
+    a0, b0, c0 = f.constraints[0]
+    assert len(a0) == 2 and a0[0] == (3, 5)                       # constraints[0].a.0[0] = (wire 5, coefficient 3)
+    assert f.constraints[2][1][0] == (6, 0)                       # constraints[2].b.0[0] = (wire 0, coefficient 6)
+    assert len(f.constraints[1][2]) == 0                          # constraints[1].c is empty
+    assert len(f.wire_mapping) == 7 and f.wire_mapping[1] == 3 and f.n_labels >= f.n_wires
+    # the other terms of the sample, read off the bytes
+    assert a0[1] == (8, 6) and b0 == [(2, 0), (20, 2), (12, 3)] and c0 == [(5, 0), (7, 2)]
+    assert f.constraints[2][2] == [(600, 6)] and f.wire_mapping == [0, 3, 10, 11, 12, 15, 324]
+    # input_validation (:359-385): a file for the other curve is recognisable as such
+    assert fx("multiply2.r1cs").curve == "bls12_381"
+    bad = bytearray(open(os.path.join(HERE, "golden", "r1cs", "bn254_sample.r1cs"), "rb").read())
+    bad[-56] = 1                                                   # wire 0 mapped to label 1
+    with pytest.raises(ValueError, match="Wire 0"):
+        R1csFile(bytes(bad))
+
+
 def _oracle_map(f, w):
     L = O.lib(); L.orc_witness_map.restype = C.c_int
     p = lambda a: a.ctypes.data_as(C.c_void_p)

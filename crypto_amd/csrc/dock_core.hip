@@ -128,18 +128,24 @@ int32_t dgpu_set_device(int32_t ctx) {
 }
 
 int32_t dgpu_shutdown(void) {
-    std::unique_lock<std::mutex> lk(gs.mu);
-    bool any = false;
-    for (int i = 0; i < MAX_CTX; i++) any = any || ctxs[i].ready;
-    if (!any) return DGPU_OK;
+    // Lock order: a call in flight holds its slot and may take gs.mu (handle pins, the scalar pool); so the slots are drained WITHOUT gs.mu held.
+    // 1. no new call gets past its `ready` check; 2. every slot is taken once, i.e. every call in flight has returned; 3. handles and pools
+    // are released under gs.mu once nothing pins them.
+    bool was_ready[MAX_CTX];
+    {
+        std::lock_guard<std::mutex> lk(gs.mu);
+        bool any = false;
+        for (int i = 0; i < MAX_CTX; i++) { was_ready[i] = ctxs[i].ready; any = any || was_ready[i]; ctxs[i].ready = false; }
+        if (!any) return DGPU_OK;
+    }
     for (int i = 0; i < MAX_CTX; i++) {
         Ctx &c = ctxs[i];
-        if (!c.ready) continue;
-        c.ready = false;
+        if (!was_ready[i]) continue;
         (void)hipSetDevice(c.device);
         for (int k = 0; k < N_SLOTS; k++) {
             std::lock_guard<std::mutex> sk(c.slots[k].mu);
             (void)hipStreamSynchronize(c.slots[k].stream);
+            (void)hipStreamSynchronize(c.slots[k].cstream);
             c.slots[k].release_all();
             (void)hipStreamDestroy(c.slots[k].stream);
             (void)hipStreamDestroy(c.slots[k].cstream);
@@ -147,6 +153,8 @@ int32_t dgpu_shutdown(void) {
             c.slots[k].stream = nullptr; c.slots[k].cstream = nullptr;
         }
     }
+    std::unique_lock<std::mutex> lk(gs.mu);
+    gs.cv.wait(lk, [] { for (auto &h : gs.handles) if (h.second.inflight) return false; return true; });      // (pins are dropped by the calls that just returned)
     for (auto &h : gs.handles) {
         const Handle &hd = h.second;
         if (hd.ctx >= 0 && hd.ctx < MAX_CTX && ctxs[hd.ctx].device >= 0) (void)hipSetDevice(ctxs[hd.ctx].device);

@@ -209,12 +209,39 @@ def create_proof(pk, r, s, v, h, input_assignment_with_one, witness_assignment, 
     committed = wit[:cw]
     # one upload serves four MSMs: `assignment` = inputs[1..] ++ witnesses (:319-321) and `aux` of :299 is its suffix
     pool = _pool()
+    futs, state = [], {"shared": None, "assignment": None}
+
+    def submit(fn):
+        f = pool.submit(fn); futs.append(f); return f
+    try:
+        return _create_proof_body(pk, vk, r, s, v, inp, wit, cw, committed, resident_z, share_sort, resolve_h, submit, state)
+    finally:
+        # every job has ended (whatever it raised) before anything it reads is released: a failing MSM must not leave its siblings running on
+        # a freed sort / assignment, nor leak them
+        for f in futs:
+            try:
+                f.result()
+            except Exception:
+                pass
+        if state["shared"] is not None:
+            state["shared"].free()
+        if resident_z is None and state["assignment"] is not None:
+            state["assignment"].free()
+        for x in own_h:
+            x.free()
+
+
+def _create_proof_body(pk, vk, r, s, v, inp, wit, cw, committed, resident_z, share_sort, resolve_h, submit, state):
+    class _P:                      # (the body below was written against an executor: same calls, every future is tracked by the caller)
+        submit = staticmethod(submit)
+    pool = _P
     def h_job():
         hs = resolve_h()
         return pk.h_query.msm_resident(hs, n=min(pk.h_query.n, hs.n))                               # :286  (h_query has D-1 points: truncation)
     f_h = pool.submit(h_job)                                                                        # runs while the assignment uploads
     if resident_z is None:
         assignment, a0 = M.DeviceScalars.from_parts([inp[1:], wit]), 0
+        state["assignment"] = assignment
     else:
         assignment, a0 = resident_z, 1
     n_aux, aux_at = len(wit) - cw, a0 + len(inp) - 1 + cw
@@ -231,7 +258,7 @@ def create_proof(pk, r, s, v, h, input_assignment_with_one, witness_assignment, 
     # partition sort (dgpu_scalars_sort), each MSM then starts at its accumulation
     shared = None
     if share_sort and pk.a_query.same_table_shape(pk.b_g2_query) and (not with_b1 or pk.a_query.same_table_shape(pk.b_g1_query)):
-        shared = M.SortedScalars(pk.a_query, assignment, min(assignment.n - a0, pk.a_query.n - 1), base_offset=1, scalar_offset=a0)
+        shared = state["shared"] = M.SortedScalars(pk.a_query, assignment, min(assignment.n - a0, pk.a_query.n - 1), base_offset=1, scalar_offset=a0)
         coeff_msm = lambda query: (lambda: query.msm_sorted(shared))
     # ... and the l_query MSM (the assignment minus its first len(inp) - 1 + cw entries against a table that many + 1 rows shorter) joins when
     # its table has the same window geometry: its rows are the a_query's rows from the (len(inp) + cw)-th on
@@ -260,12 +287,6 @@ def create_proof(pk, r, s, v, h, input_assignment_with_one, witness_assignment, 
     sa_rb = lincomb(M.G1, [_affine(M.G1, g_a), _affine(M.G1, g1_b)], [s, r])
     g2_b = sharded.fold(M.G2, np.stack([f_b2.result(), rest_b2]))
     l_aux_acc, h_acc = f_l.result(), f_h.result()
-    if shared is not None:
-        shared.free()
-    if resident_z is None:
-        assignment.free()
-    for x in own_h:
-        x.free()
     # g_c = s g_a + r g1_b - rs delta + l_aux + h_acc - v (eta/delta)    :350-355
     g_c = sharded.fold(M.G1, np.stack([sa_rb, rest_c, l_aux_acc, h_acc]))
     return {"a": _affine(M.G1, g_a), "b": _affine(M.G2, g2_b), "c": _affine(M.G1, g_c), "d": _affine(M.G1, g_d)}

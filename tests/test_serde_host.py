@@ -118,6 +118,42 @@ def test_validate_yes_rejects_points_outside_the_prime_order_subgroup(curve):
     assert found == 3
 
 
+@pytest.mark.parametrize("curve,G", [(ca.G1, O.G1), (ca.G2, O.G2)])
+def test_endomorphism_subgroup_test_on_batches(curve, G):
+    """The subgroup test is phi(P) + P == [x^2]P (G1) / psi(P) == [x]P (G2) (dock_serde.cpp) and runs over host threads for batches: 300 points of the
+    subgroup pass, one point of the curve outside it anywhere in the batch fails the call, and all 40 small-x curve points tried are rejected
+    (each is outside the subgroup: the model confirms [r]P != O for the G1 ones)."""
+    import bls12_381_model as M
+    k0 = O.rand_scalars(71, 1)[0]; d = O.rand_scalars(72, 1)[0]
+    pts = G.gen_seq(k0, d, 300, threads=8)
+    enc = serde.serialize(curve, pts)
+    got, inf = serde.deserialize(curve, enc)
+    assert (got == pts).all() and not inf.any()
+    sz = 48 if curve is ca.G1 else 96
+    bad, tried = None, 0
+    for x in range(1, 400):
+        e = bytearray(sz); e[-1] = x & 0xff; e[-2] = x >> 8; e[0] |= 0x80
+        try:
+            p1, _ = serde.deserialize(curve, bytes(e), validate=False)
+        except ca.DockGpuError:
+            continue
+        tried += 1
+        with pytest.raises(ca.DockGpuError):
+            serde.deserialize(curve, bytes(e))
+        if curve is ca.G1 and tried <= 5:
+            xy = (U.fp_int(p1[0][:6]), U.fp_int(p1[0][6:]))
+            assert M.g1_on_curve(xy) and M.g1_mul(xy, M.R) is not None
+        bad = bytes(e)
+        if tried == 40:
+            break
+    assert tried == 40
+    for pos in (0, 157, 299):
+        mixed = bytearray(enc); mixed[pos * sz:(pos + 1) * sz] = bad
+        with pytest.raises(ca.DockGpuError):
+            serde.deserialize(curve, bytes(mixed))
+        assert serde.deserialize(curve, bytes(mixed), validate=False)[0].any()
+
+
 def test_infinity_encoding_must_be_canonical():
     ok = bytes([0xc0]) + bytes(47)
     _, inf = serde.deserialize(ca.G1, ok)

@@ -232,9 +232,8 @@ def create_proof(pk, r, s, v, h, input_assignment_with_one, witness_assignment, 
 
 
 def _create_proof_body(pk, vk, r, s, v, inp, wit, cw, committed, resident_z, share_sort, resolve_h, submit, state):
-    class _P:                      # (the body below was written against an executor: same calls, every future is tracked by the caller)
-        submit = staticmethod(submit)
-    pool = _P
+    import types
+    pool = types.SimpleNamespace(submit=submit)      # (the body below was written against an executor: same calls, every future is tracked by the caller)
     def h_job():
         hs = resolve_h()
         return pk.h_query.msm_resident(hs, n=min(pk.h_query.n, hs.n))                               # :286  (h_query has D-1 points: truncation)

@@ -145,10 +145,12 @@ def test_gpu_prove_and_verify_on_reference_circuits():
     rnd = lambda: int.from_bytes(rng.bytes(40), "little") % (R - 1) + 1
     g1 = lambda k: O.G1.to_affine(O.G1.mul(O.G1.generator(), O.int_to_limbs(k % R, 4)))[0]
     g2 = lambda k: O.G2.to_affine(O.G2.mul(O.G2.generator(), O.int_to_limbs(k % R, 4)))[0]
-    for name, cw in (("multiply2.r1cs", 2), ("test1.r1cs", 1), ("nconstraints.r1cs", 1)):
+    # (test3 / test4: commit_witness_count = 4 as in tests.rs:162-168,199-205 `generate_params_prove_and_verify(.., 4, ..)`)
+    for name, cw in (("multiply2.r1cs", 2), ("test1.r1cs", 1), ("nconstraints.r1cs", 1), ("test2.r1cs", 1), ("test3.r1cs", 4), ("test4.r1cs", 4)):
         f = fx(name)
         w = {"multiply2.r1cs": lambda: witness_multiply2(rnd(), rnd()), "test1.r1cs": lambda: witness_test1(rnd()),
-             "nconstraints.r1cs": lambda: witness_nconstraints(f, rnd())}[name]()
+             "nconstraints.r1cs": lambda: witness_nconstraints(f, rnd()), "test2.r1cs": lambda: witness_test2(f, rnd(), rnd()),
+             "test3.r1cs": lambda: witness_test3(f, *[rnd() for _ in range(6)]), "test4.r1cs": lambda: witness_test4(f, *[rnd() for _ in range(8)])}[name]()
         assert f.is_satisfied(w)
         n_inst, n_wit = f.num_inputs, f.n_wires - f.num_inputs
         pk, _ = LG.generate_parameters(f.rows(0), f.rows(1), f.rows(2), n_inst, n_wit, cw, rnd(), rnd(), rnd(), rnd(), rnd(), rnd(), g1(rnd()), g2(rnd()))
@@ -162,3 +164,84 @@ def test_gpu_prove_and_verify_on_reference_circuits():
         assert not LG.verify_proof(pvk, proof, bad), name
         LG.verify_witness_commitment(pk.vk, proof, n_inst - 1, w[n_inst:n_inst + cw], v)
         circ.free()
+
+
+# ---- test2 / test3 / test4 of legogroth16/src/circom/tests.rs:145-230,874-899: the reference's circuits, its input vectors, its asserted outputs ----
+def solve_witness(f, known):
+    """the wires of a Circom R1CS from its inputs, without the wasm witness calculator (out of scope): every constraint <A,w> <B,w> = <C,w> of these
+    circuits defines one new wire, so propagate until nothing is unknown.  `known`: {wire: value}."""
+    r = f.prime
+    w = dict(known); w[0] = 1
+    def split(lc):
+        val, unk = 0, []
+        for co, i in lc:
+            if i in w:
+                val = (val + co * w[i]) % r
+            else:
+                unk.append((co, i))
+        return val, unk
+    pending = list(f.constraints)
+    while pending:
+        rest = []
+        for a, b, c in pending:
+            (va, ua), (vb, ub), (vc, uc) = split(a), split(b), split(c)
+            if not ua and not ub and len(uc) == 1:                      # new wire on the right-hand side
+                co, i = uc[0]; w[i] = (va * vb - vc) * pow(co, r - 2, r) % r
+            elif not ua and not ub and not uc:
+                assert va * vb % r == vc
+            elif len(ua) == 1 and not ub and not uc and vb:             # ... or inside one factor
+                co, i = ua[0]; w[i] = (vc * pow(vb, r - 2, r) - va) * pow(co, r - 2, r) % r
+            elif len(ub) == 1 and not ua and not uc and va:
+                co, i = ub[0]; w[i] = (vc * pow(va, r - 2, r) - vb) * pow(co, r - 2, r) % r
+            else:
+                rest.append((a, b, c))
+        assert len(rest) < len(pending), "no constraint determines a new wire"
+        pending = rest
+    assert len(w) == f.n_wires
+    return [w[i] for i in range(f.n_wires)]
+
+
+def _rand(seed, k):
+    rng = np.random.default_rng(seed)
+    return [int.from_bytes(rng.bytes(40), "little") % R for _ in range(k)]
+
+
+def witness_test2(f, x, z):              # test2.circom: y = (x + z)^2 + z + 1; wires 1, y, x, z, ...
+    return solve_witness(f, {2: x, 3: z})
+
+
+def witness_test3(f, x, y, a, b, c, d):  # main {public [x, y]}: wires 1, z1, z2, x, y, a, b, c, d, ...
+    return solve_witness(f, {3: x, 4: y, 5: a, 6: b, 7: c, 8: d})
+
+
+def witness_test4(f, x, y, p, q, a, b, r, s):   # main {public [a, b, r, s]}: wires 1, z1, z2, a, b, r, s, x, y, p, q, ...
+    return solve_witness(f, {3: a, 4: b, 5: r, 6: s, 7: x, 8: y, 9: p, 10: q})
+
+
+def test_reference_circuits_test2_test3_test4_public_outputs():
+    """The public wires the reference's tests assert (tests.rs:170-176, :207-230; the inputs of test2_input1.json / test3_input1.json are the
+    reference's own vectors, the random cases follow its StdRng cases in shape)"""
+    t2 = fx("test2.r1cs")
+    for x, z in ((1, 2), (10, 20)) + tuple(tuple(_rand(50 + i, 2)) for i in range(2)):        # test2_input1.json = {"x": 1, "z": 2}
+        w = witness_test2(t2, x, z)
+        assert t2.is_satisfied(w) and w[1] == ((x + z) ** 2 + z + 1) % R
+    t3 = fx("test3.r1cs")
+    assert (t3.n_pub_out, t3.n_pub_in, t3.n_prv_in, t3.n_constraints) == (2, 2, 4, 5)
+    for vals in ((10, 25, 4, 5, 105, 1000),) + tuple(tuple(_rand(60 + i, 6)) for i in range(3)):   # test3_input1.json
+        x, y, a, b, c, d = vals
+        w = witness_test3(t3, *vals)
+        assert t3.is_satisfied(w)
+        public = w[1:t3.num_inputs]
+        assert len(public) == 4 and public == [(a * x + b * y + c * d) % R, (c * x + d * y) % R, x, y]
+    t4 = fx("test4.r1cs")
+    for vals in tuple(tuple(_rand(70 + i, 8)) for i in range(3)):
+        x, y, p, q, a, b, r, s = vals
+        w = witness_test4(t4, *vals)
+        assert t4.is_satisfied(w)
+        z1 = (a * x + b * y + 10 * p * q - 19 * r ** 3 * p + 55 * s ** 4 * q ** 3 - 3 * x * x + 6 * x * y - 13 * y ** 3 - r * s * x + 5 * a * b * y
+              - 32 * a * x * y - 2 * x * y * p * q - 100) % R
+        z2 = (a ** 3 * y + 3 * b * b * x - 20 * x * x * y * y + 45) % R
+        public = w[1:t4.num_inputs]
+        assert len(public) == 6 and public == [z1, z2, a, b, r, s]
+    bad = witness_test3(t3, 1, 2, 3, 4, 5, 6); bad[1] = (bad[1] + 1) % R
+    assert not t3.is_satisfied(bad)

@@ -40,7 +40,7 @@ R_MOD = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
 G1_GEN_COMPRESSED = "97f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac586c55e83ff97a1aeffb3af00adb22c6bb"
 G2_GEN_COMPRESSED = ("93e02b6052719f607dacd3a088274f65596bd0d09920b61ab5da61bbdc7f5049334cf11213945d57e5ac7d055d042b7e"
                      "024aa2b2f08f0a91260805272dc51051c6e47ad4fa403b02b4510b647ae3d1770bac0326a805bbefd48056c8c121bdb8")
-MADS_PER_MIXED_ADD = 6 * 392 + 588 + 2 * 301     # XYZZ mixed addition: 6 products, one fused two-product reduction, 2 squares
+MADS_PER_MIXED_ADD = 6 * 338 + 507 + 2 * 260     # XYZZ mixed addition over the 13 x 30-bit signed field (fp30s.cuh): 6 products, one fused two-product reduction, 2 squares (round 2, 14 x 29-bit limbs: 3542)
 MADS_PER_G2_MIXED_ADD = 2 * (8 * 588 + 2 * 392)   # the same formula over Fp2 on a lane pair: per lane 8 fused two-product reductions + 2 products for the squares
 MAD_PEAK = 31.8                                   # Tmad/s, measured v_mad_u64_u32 issue rate (profiles/r01h_instr_rate_ubench.txt)
 
@@ -264,9 +264,9 @@ def main():
         }
         if acc_avg_ms > 0 and windows:
             mads = float(n) * windows * MADS_PER_MIXED_ADD
-            out["valu_roofline"] = {"bound": "v_mad_u64_u32", "achieved": round(mads / (acc_avg_ms * 1e-3) / 1e12, 3), "peak": MAD_PEAK, "unit": "Tmad/s",
+            out["valu_roofline"] = {"bound": "v_mad_i64_i32 (same issue rate as v_mad_u64_u32)", "achieved": round(mads / (acc_avg_ms * 1e-3) / 1e12, 3), "peak": MAD_PEAK, "unit": "Tmad/s",
                                     "frac": round(mads / (acc_avg_ms * 1e-3) / 1e12 / MAD_PEAK, 4), "mixed_additions_per_launch": int(n) * windows,
-                                    "note": "%d windows x n mixed additions x %d v_mad_u64_u32 each; peak = measured issue rate, profiles/r01h_instr_rate_ubench.txt" % (
+                                    "note": "%d windows x n mixed additions x %d 32 x 32 -> 64-bit multiply-adds each (13 x 30-bit signed limbs since round 3: 13.8 %% fewer than the 3542 of the 14 x 29-bit field, so the same kernel time is a LOWER fraction); peak = measured issue rate, profiles/r01h_instr_rate_ubench.txt" % (
                                         windows, MADS_PER_MIXED_ADD)}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(ca, gen1, ks, scalars, db, ds, args.log2n, ncpu)

@@ -40,9 +40,10 @@ template <class C, class HF> int32_t table_build(const uint64_t *base, uint64_t 
         int32_t rc;
         if ((rc = sl.prepped.ensure(32 * C::AFF_STRIDE * 4))) return rc;
         if (dev_malloc(&tab, (size_t)msm::FIXED_TABLE_ENTRIES * C::AFF_STRIDE * 4) != hipSuccess) { (void)hipGetLastError(); return DGPU_E_OOM; }
-        const RawBases rb = RawBases::packed<C>(wb.data(), nullptr);
-        rc = ws_stage_bases<C>(sl, rb, 32);
-        if (rc == DGPU_OK) rc = stage_bases<C>(sl, rb, 32, sl.prepped.as<uint32_t>());
+        // (the fixed-base kernels run over Fp: their window bases are 14 x 29-bit records, not the MSM pipeline's form)
+        rc = sl.in_bases.ensure(32 * 2 * C::ABI_W * 4 + 16);
+        if (rc == DGPU_OK && hipMemcpyAsync(sl.in_bases.p, wb.data(), 32 * 2 * C::ABI_W * 4, hipMemcpyHostToDevice, sl.stream) != hipSuccess) rc = DGPU_E_HIP;
+        if (rc == DGPU_OK) msm::launch_prep_bases_fp<C>(sl.stream, sl.in_bases.as<uint32_t>(), nullptr, 32, sl.prepped.as<uint32_t>());
         if (rc == DGPU_OK) {
             StageTimer st(sl, "fixed.table");
             msm::launch_fb_table<C>(sl.stream, sl.prepped.as<uint32_t>(), (uint32_t *)tab);

@@ -40,7 +40,15 @@ template <> struct SubM<Fp2> {     // an Fp2 product leaves values < 6 p, so eve
     static constexpr int NEG = 4;
 };
 
+// fnormw: the carry pass for the widest combination of the formulas (R^2 - PPP - 2 Q); the same as fnorm except for fields whose cheap pass
+// has a narrower domain (fp30s.cuh)
+template <class F> FD void fnormw(F &r, const F &a) { fnorm(r, a); }
+
 struct Fp2H;
+struct Fs;
+template <> struct SubM<Fs> {      // signed digits (fp30s.cuh): a subtraction needs no multiple of p; the constants are ignored
+    static constexpr int P = 0, R = 0, X = 0, D = 0, Y = 0, YN = 0, NEG = 0;
+};
 template <class F> struct MaddFormulaFirst { static constexpr bool value = true; };
 template <> struct MaddFormulaFirst<Fp2H> { static constexpr bool value = false; };
 
@@ -97,7 +105,7 @@ template <class F> FD void xyzz_madd_early(Xyzz<F> &acc, bool &inf, const Aff<F>
     fmul(Q, acc.x, PP);
     fsqr(X3, Rd);
     fadd(t, Q, Q); fadd(t, t, PPP);
-    fsub<SubM<F>::X>(X3, X3, t); fnorm(X3, X3);
+    fsub<SubM<F>::X>(X3, X3, t); fnormw(X3, X3);
     fsub<SubM<F>::D>(t, Q, X3); fnorm(t, t);
     fmul_sub<SubM<F>::YN>(Y3, Rd, t, acc.y, PPP);
     fmul(acc.zz, acc.zz, PP);
@@ -125,7 +133,7 @@ template <class F> FD void xyzz_madd(Xyzz<F> &acc, bool &inf, const Aff<F> &q_in
     fmul(Q, acc.x, PP);
     fsqr(X3, Rd);
     fadd(t, Q, Q); fadd(t, t, PPP);
-    fsub<SubM<F>::X>(X3, X3, t); fnorm(X3, X3);
+    fsub<SubM<F>::X>(X3, X3, t); fnormw(X3, X3);
     fsub<SubM<F>::D>(t, Q, X3); fnorm(t, t);
     fmul_sub<SubM<F>::YN>(Y3, Rd, t, acc.y, PPP);
     fmul(ZZ3, acc.zz, PP);
@@ -157,7 +165,7 @@ template <class F> FD void xyzz_add(Xyzz<F> &a, bool &ainf, const Xyzz<F> &b, bo
     fmul(Q, U1, PP);
     fsqr(X3, Rd);
     fadd(t, Q, Q); fadd(t, t, PPP);
-    fsub<SubM<F>::X>(X3, X3, t); fnorm(X3, X3);
+    fsub<SubM<F>::X>(X3, X3, t); fnormw(X3, X3);
     fsub<SubM<F>::D>(t, Q, X3); fnorm(t, t);
     fmul_sub<SubM<F>::YN>(Y3, Rd, t, S1, PPP);
     fmul(t, a.zz, b.zz); fmul(ZZ3, t, PP);

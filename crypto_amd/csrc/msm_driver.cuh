@@ -168,7 +168,7 @@ int32_t msm_device(Slot &sl, const uint32_t *d_bases, const uint32_t *d_scalars,
         HIPCHK(hipMemsetAsync(sl.bucket_inf.p, 1, NB, s));
         HIPCHK(hipMemsetAsync(sl.heavy.p, 0, 4, s));
         HIPCHK(hipMemsetAsync(sl.flags.p, 0, 4, s));
-        launch_digit_codes(s, g.wide, d_scalars, bases_pending ? nullptr : d_bases, C::AFF_STRIDE, 2 * C::FW, n, g.n_pad, c, W, sl.digits.p, sl.flags.as<uint32_t>());
+        launch_digit_codes(s, g.wide, d_scalars, bases_pending ? nullptr : d_bases, C::AFF_STRIDE, C::FLAGW, n, g.n_pad, c, W, sl.digits.p, sl.flags.as<uint32_t>());
         launch_sort_sweep(s, g.wide, false, g.sort_grid, g.lds_bytes, sl.digits.p, n, g.n_pad, W, g.RANGES, g.rb_log, g.B, sl.cnt.as<uint32_t>(), nullptr, nullptr, heavy_thr, sl.heavy.as<uint32_t>(), HEAVY_CAP);
     }
     {
@@ -334,7 +334,7 @@ inline size_t pre_entries_bytes(const PreTable &pt, size_t n) { return (size_t)n
 template <class C>
 int32_t pre_sort(Slot &sl, const PreTable &pt, const PreGeom &g, size_t boff, const uint32_t *d_scalars, size_t n, uint32_t *off, uint32_t *entries, uint32_t *dyn) {
     PsParams q;
-    q.scalars = d_scalars; q.bases = dyn ? (const uint32_t *)pt.tab : nullptr /* shared sort: no per-table identity filter */; q.n = n; q.aff_stride = C::AFF_STRIDE; q.flag_word = 2 * C::FW; q.flag_base = (uint32_t)boff;
+    q.scalars = d_scalars; q.bases = dyn ? (const uint32_t *)pt.tab : nullptr /* shared sort: no per-table identity filter */; q.n = n; q.aff_stride = C::AFF_STRIDE; q.flag_word = C::FLAGW; q.flag_base = (uint32_t)boff;
     q.c = pt.c; q.W = pt.W; q.key_wstride = 0; q.val_base = (uint32_t)boff; q.val_wstride = (uint32_t)pt.n;
     q.part_log = ps_part_log(g.NB); q.P = (g.NB + (1u << q.part_log) - 1) >> q.part_log; q.ntiles = (uint32_t)((n + PS_TILE - 1) / PS_TILE);
     int32_t rc;

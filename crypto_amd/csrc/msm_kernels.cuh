@@ -28,6 +28,8 @@
 #include "fp2_29.cuh"
 #include "ec29.cuh"
 #include "fp2_pair.cuh"
+#include "fp30s.cuh"
+#include <type_traits>
 
 namespace msm {
 using namespace bls29;
@@ -35,10 +37,29 @@ using namespace bls29;
 
 // ---- curve descriptions -------------------------------------------------------------------------
 struct G1;
+struct G1S;
 struct G2;
 struct G2P;
+// G1 over the 13 x 30-bit signed field (fp30s.cuh): the curve description the MSM pipeline instantiates for G1 (G1::MSM).  Records keep the
+// strides of the 14 x 29-bit form (128-byte base records with the identity flag in word 28); an XYZZ record is 52 words.
+struct G1S {
+    typedef Fs F;
+    static constexpr int FW = SN;            // 13 words per coordinate
+    static constexpr int ABI_W = 12;
+    static constexpr int NFP = 1;
+    static constexpr int AFF_STRIDE = 32;    // x[13] y[13] pad[2] flag pad[3]
+    static constexpr int FLAGW = 28;
+    static constexpr int XW = 4 * FW;        // 52 words = 13 x 16 bytes
+    static constexpr int HEAVY_T = 256;
+    static constexpr int LPP = 1;
+    typedef G1S ACC;
+    typedef G1S MSM;
+    static constexpr int ACC_WAVES = 2;
+};
 struct G1 {
     typedef Fp F;
+    typedef G1S MSM;                         // what the MSM kernels (prep, accumulate, fix-up, reduce, table construction) run G1 as
+    static constexpr int FLAGW = 28;         // word of a base record that holds the identity flag
     static constexpr int FW = NL;            // u32 words per coordinate (device form)
     static constexpr int ABI_W = 12;         // u32 words per Fp in the ABI
     static constexpr int NFP = 1;            // Fp components per coordinate
@@ -46,11 +67,13 @@ struct G1 {
     static constexpr int XW = 4 * FW;        // u32 per XYZZ point
     static constexpr int HEAVY_T = 256;      // threads per block in k_fixup_heavy (XW * HEAVY_T * 4 B of LDS)
     static constexpr int LPP = 1;            // lanes per point in k_accumulate
-    typedef G1 ACC;                          // traits used by the accumulate kernel
+    typedef G1S ACC;                         // traits used by the accumulate kernel
     static constexpr int ACC_WAVES = 2;      // waves/SIMD of k_accumulate: 256 VGPRs, no spills (tools/ubench/madd_rate: 6.35 vs 5.1 Gmadd/s at 3)
 };
 struct G2 {
     typedef Fp2 F;
+    typedef G2 MSM;
+    static constexpr int FLAGW = 56;
     static constexpr int FW = 2 * NL;
     static constexpr int ABI_W = 24;
     static constexpr int NFP = 2;
@@ -64,6 +87,7 @@ struct G2 {
 // G2 with one point per lane pair: the even lane holds the c0 halves, the odd lane the c1 halves
 struct G2P {
     typedef Fp2H F;
+    static constexpr int FLAGW = 56;
     static constexpr int FW = NL;            // words per coordinate HALF held by one lane
     static constexpr int AFF_STRIDE = 64;
     static constexpr int XW = 8 * NL;        // words per full XYZZ point in the SoA arrays
@@ -74,6 +98,31 @@ struct G2P {
 
 template <class F> __device__ __forceinline__ uint32_t *limbs(F &f) { return reinterpret_cast<uint32_t *>(&f); }
 template <class F> __device__ __forceinline__ const uint32_t *limbs(const F &f) { return reinterpret_cast<const uint32_t *>(&f); }
+
+// the two coordinates of an affine point from their ABI words (2 * C::ABI_W words) into a base record (device form of C)
+template <class C> __device__ __forceinline__ void store_coords_from_abi(uint32_t *__restrict__ dst, const uint32_t *w) {
+    if constexpr (std::is_same<typename C::F, Fs>::value) {
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            Fs f; fs_from_abi(f, w + 12 * k);
+#pragma unroll
+            for (int j = 0; j < SN; j++) dst[k * SN + j] = (uint32_t)f.l[j];
+        }
+        dst[2 * SN] = 0; dst[2 * SN + 1] = 0;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 2 * C::NFP; k++) {
+            Fp f; fp_from_abi(f, w + 12 * k);
+#pragma unroll
+            for (int j = 0; j < NL; j++) dst[k * NL + j] = f.l[j];
+        }
+    }
+}
+// a coordinate tuple of `count` base-field components (x, y[, zz, zzz]; Fp2: c0, c1 per coordinate) to ABI words, 12 per component
+template <class F> __device__ __forceinline__ void coords_to_abi(uint32_t *__restrict__ dst, const void *pt, int count) {
+    if constexpr (std::is_same<F, Fs>::value) { const Fs *f = reinterpret_cast<const Fs *>(pt); for (int k = 0; k < count; k++) fs_to_abi(dst + 12 * k, f[k]); }
+    else { const Fp *f = reinterpret_cast<const Fp *>(pt); for (int k = 0; k < count; k++) fp_to_abi(dst + 12 * k, f[k]); }
+}
 
 // ---- K1: base preparation ------------------------------------------------------------------------
 template <class C>
@@ -92,13 +141,8 @@ __global__ void __launch_bounds__(256) k_prep_bases(const uint32_t *__restrict__
     uint32_t flag = (any == 0) ? 1u : 0u;
     if (is_inf && is_inf[i]) flag = 1u;
     uint32_t *dst = out + i * C::AFF_STRIDE;
-#pragma unroll
-    for (int k = 0; k < 2 * C::NFP; k++) {
-        Fp f; fp_from_abi(f, w + 12 * k);
-#pragma unroll
-        for (int j = 0; j < NL; j++) dst[k * NL + j] = f.l[j];
-    }
-    dst[2 * C::FW] = flag;
+    store_coords_from_abi<C>(dst, w);
+    dst[C::FLAGW] = flag;
 }
 
 // The same from the caller's own array of structures (dgpu_msm_*_strided): point i sits at raw + i * stride with its x at x_off and its y at
@@ -123,13 +167,8 @@ __global__ void __launch_bounds__(256) k_prep_bases_raw(const uint8_t *__restric
     if (is_inf && is_inf[i]) flag = 1u;
     if (inf_off != NO_INF_OFF && pt[inf_off]) flag = 1u;
     uint32_t *dst = out + i * C::AFF_STRIDE;
-#pragma unroll
-    for (int k = 0; k < 2 * C::NFP; k++) {
-        Fp f; fp_from_abi(f, w + 12 * k);
-#pragma unroll
-        for (int j = 0; j < NL; j++) dst[k * NL + j] = f.l[j];
-    }
-    dst[2 * C::FW] = flag;
+    store_coords_from_abi<C>(dst, w);
+    dst[C::FLAGW] = flag;
 }
 
 // ---- XYZZ <-> memory -------------------------------------------------------------------------------
@@ -161,6 +200,14 @@ template <class C> __device__ __forceinline__ void load_aff(Aff<typename C::F> &
     }
 }
 
+template <> __device__ __forceinline__ void load_aff<G1S>(Aff<Fs> &p, const uint32_t *__restrict__ rec) {
+    uint32_t t[28];                                               // x[13] y[13] and two words of padding: seven 16-byte loads
+#pragma unroll
+    for (int k = 0; k < 28; k += 4) { const uint4 v = *reinterpret_cast<const uint4 *>(rec + k); t[k] = v.x; t[k + 1] = v.y; t[k + 2] = v.z; t[k + 3] = v.w; }
+    uint32_t *w = reinterpret_cast<uint32_t *>(&p);
+#pragma unroll
+    for (int k = 0; k < 2 * SN; k++) w[k] = t[k];
+}
 // lane-pair variants: this lane moves only its half (c0 on even lanes, c1 on odd lanes) of every coordinate
 template <> __device__ __forceinline__ void store_soa<G2P>(uint32_t *__restrict__ base, size_t /*count*/, size_t b, const Xyzz<Fp2H> &p) {
     const uint32_t h = threadIdx.x & 1u;
@@ -250,7 +297,7 @@ __global__ void __launch_bounds__(256, C::ACC_WAVES) k_accumulate(const uint32_t
             }
         }
         const uint32_t *rec = bases + (size_t)row * C::AFF_STRIDE;
-        if constexpr (SKIP_ID) { if (rec[C::AFF_STRIDE * 7 / 8] != 0) continue; }          // flag word: x, y, flag, pad
+        if constexpr (SKIP_ID) { if (rec[C::FLAGW] != 0) continue; }
         Aff<F> p; load_aff<C>(p, rec);
         xyzz_madd(acc, inf, p, (e >> 31) != 0);
     }
@@ -480,13 +527,10 @@ __global__ void __launch_bounds__(64) k_reduce_top(const uint32_t *__restrict__ 
     if (lane == 0) {
         uint32_t *dst = win_abi + w * 4 * C::ABI_W;
         win_inf[w] = ainf;
-        if (!ainf) {
-            const Fp *f = reinterpret_cast<const Fp *>(&A);
-            for (int k = 0; k < 4 * C::NFP; k++) fp_to_abi(dst + 12 * k, f[k]);
-        }
+        if (!ainf) coords_to_abi<typename C::F>(dst, &A, 4 * C::NFP);
         if (win_s_abi) {                 // the plain sum of the window's buckets: the next level of the weighted sum is taken on the host
             win_s_inf[w] = sinf;
-            if (!sinf) { const Fp *f = reinterpret_cast<const Fp *>(&S); for (int k = 0; k < 4 * C::NFP; k++) fp_to_abi(win_s_abi + w * 4 * C::ABI_W + 12 * k, f[k]); }
+            if (!sinf) coords_to_abi<typename C::F>(win_s_abi + w * 4 * C::ABI_W, &S, 4 * C::NFP);
         }
     }
 }

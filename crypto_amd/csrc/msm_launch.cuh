@@ -8,6 +8,7 @@ namespace msm {
 
 // per curve (k_g1_*.hip / k_g2_*.hip)
 template <class C> void launch_prep_bases(hipStream_t s, const uint32_t *abi, const uint8_t *is_inf, size_t n, uint32_t *out);
+template <class C> void launch_prep_bases_fp(hipStream_t s, const uint32_t *abi, const uint8_t *is_inf, size_t n, uint32_t *out);   // 14 x 29-bit records (fixed-base kernels)
 template <class C> void launch_prep_bases_raw(hipStream_t s, const uint8_t *raw, size_t stride, size_t x_off, size_t y_off, size_t inf_off, const uint8_t *is_inf, size_t n, uint32_t *out);
 template <class C> void launch_accumulate(hipStream_t s, const uint32_t *bases, const uint32_t *entries, const uint32_t *off, uint32_t NB, uint32_t *bucket, uint8_t *bucket_inf,
                                           uint32_t *head, uint32_t *tail, uint32_t *head_b, uint32_t *tail_b, uint8_t *part_inf, size_t T, uint32_t CH, uint32_t dbg_mask, const uint32_t *dyn = nullptr);

@@ -4,11 +4,17 @@
 #include "msm_launch.cuh"
 
 namespace msm {
+// the launchers take the curve as the driver names it (G1 / G2) and instantiate the kernels for the description the MSM pipeline runs it as
+// (C::MSM: G1 -> G1S, the 13 x 30-bit signed field; G2 -> G2)
 template <class C> void launch_prep_bases(hipStream_t s, const uint32_t *abi, const uint8_t *is_inf, size_t n, uint32_t *out) {
-    hipLaunchKernelGGL((k_prep_bases<C>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, abi, is_inf, n, out);
+    hipLaunchKernelGGL((k_prep_bases<typename C::MSM>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, abi, is_inf, n, out);
 }
 template <class C> void launch_prep_bases_raw(hipStream_t s, const uint8_t *raw, size_t stride, size_t x_off, size_t y_off, size_t inf_off, const uint8_t *is_inf, size_t n, uint32_t *out) {
-    hipLaunchKernelGGL((k_prep_bases_raw<C>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, raw, stride, x_off, y_off, inf_off, is_inf, n, out);
+    hipLaunchKernelGGL((k_prep_bases_raw<typename C::MSM>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, raw, stride, x_off, y_off, inf_off, is_inf, n, out);
+}
+// base records in the 14 x 29-bit form, for the fixed-base kernels (fixed_kernels.cuh), which run G1 over Fp
+template <class C> void launch_prep_bases_fp(hipStream_t s, const uint32_t *abi, const uint8_t *is_inf, size_t n, uint32_t *out) {
+    hipLaunchKernelGGL((k_prep_bases<C>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, abi, is_inf, n, out);
 }
 template <class C> void launch_accumulate(hipStream_t s, const uint32_t *bases, const uint32_t *entries, const uint32_t *off, uint32_t NB, uint32_t *bucket, uint8_t *bucket_inf,
                                           uint32_t *head, uint32_t *tail, uint32_t *head_b, uint32_t *tail_b, uint8_t *part_inf, size_t T, uint32_t CH, uint32_t dbg_mask, const uint32_t *dyn) {
@@ -23,7 +29,7 @@ template <class C> void launch_accumulate_skip_identity(hipStream_t s, const uin
 template <class C> void launch_fixup(hipStream_t s, uint32_t NB, uint32_t *bucket, uint8_t *bucket_inf, const uint32_t *head, const uint32_t *tail, const uint32_t *head_b,
                                      const uint32_t *tail_b, const uint8_t *part_inf, size_t T, const uint32_t *off, uint32_t heavy_thr, const uint32_t *dyn) {
     if constexpr (C::NFP == 2) hipLaunchKernelGGL((k_fixup_pair<G2P>), dim3((unsigned)((2 * T + 255) / 256)), dim3(256), 0, s, NB, bucket, bucket_inf, head, tail, head_b, tail_b, part_inf, T, off, heavy_thr, dyn);   // G2: lane pairs
-    else hipLaunchKernelGGL((k_fixup<C>), dim3((unsigned)((T + 255) / 256)), dim3(256), 0, s, NB, bucket, bucket_inf, head, tail, head_b, tail_b, part_inf, T, off, heavy_thr, dyn);
+    else hipLaunchKernelGGL((k_fixup<typename C::MSM>), dim3((unsigned)((T + 255) / 256)), dim3(256), 0, s, NB, bucket, bucket_inf, head, tail, head_b, tail_b, part_inf, T, off, heavy_thr, dyn);
 }
 template <class C> void launch_fixup_heavy(hipStream_t s, const uint32_t *heavy, uint32_t heavy_cap, const uint32_t *off, uint32_t CH, uint32_t NB, uint32_t *bucket, uint8_t *bucket_inf,
                                            const uint32_t *head, const uint32_t *tail, const uint8_t *part_inf, size_t T, uint32_t *dyn, uint32_t *hpart, uint8_t *hpart_inf) {
@@ -34,14 +40,14 @@ template <class C> void launch_fixup_heavy(hipStream_t s, const uint32_t *heavy,
 }
 template <class C> void launch_reduce_l0(hipStream_t s, unsigned NG, const uint32_t *bucket, const uint8_t *bucket_inf, uint32_t NB, int mshift, uint32_t *l1, uint8_t *l1_inf) {
     if constexpr (C::NFP == 2) hipLaunchKernelGGL((k_reduce_l0_pair<G2P>), dim3(NG), dim3(64), 0, s, bucket, bucket_inf, NB, mshift, l1, l1_inf);     // G2: lane pairs
-    else hipLaunchKernelGGL((k_reduce_l0<C>), dim3(NG), dim3(64), 0, s, bucket, bucket_inf, NB, mshift, l1, l1_inf);
+    else hipLaunchKernelGGL((k_reduce_l0<typename C::MSM>), dim3(NG), dim3(64), 0, s, bucket, bucket_inf, NB, mshift, l1, l1_inf);
 }
 template <class C> void launch_reduce_top(hipStream_t s, unsigned W, const uint32_t *l1, const uint8_t *l1_inf, int G, int gshift, uint32_t *win_abi, uint8_t *win_inf) {
     if constexpr (C::NFP == 2) hipLaunchKernelGGL((k_reduce_top_pair<G2P>), dim3(W), dim3(64), 0, s, l1, l1_inf, G, gshift, win_abi, win_inf, (uint32_t *)nullptr, (uint8_t *)nullptr);
-    else hipLaunchKernelGGL((k_reduce_top<C>), dim3(W), dim3(64), 0, s, l1, l1_inf, G, gshift, win_abi, win_inf, (uint32_t *)nullptr, (uint8_t *)nullptr);
+    else hipLaunchKernelGGL((k_reduce_top<typename C::MSM>), dim3(W), dim3(64), 0, s, l1, l1_inf, G, gshift, win_abi, win_inf, (uint32_t *)nullptr, (uint8_t *)nullptr);
 }
 template <class C> void launch_reduce_top_s(hipStream_t s, unsigned W, const uint32_t *l1, const uint8_t *l1_inf, int G, int gshift, uint32_t *win_abi, uint8_t *win_inf, uint32_t *win_s_abi, uint8_t *win_s_inf) {
     if constexpr (C::NFP == 2) hipLaunchKernelGGL((k_reduce_top_pair<G2P>), dim3(W), dim3(64), 0, s, l1, l1_inf, G, gshift, win_abi, win_inf, win_s_abi, win_s_inf);
-    else hipLaunchKernelGGL((k_reduce_top<C>), dim3(W), dim3(64), 0, s, l1, l1_inf, G, gshift, win_abi, win_inf, win_s_abi, win_s_inf);
+    else hipLaunchKernelGGL((k_reduce_top<typename C::MSM>), dim3(W), dim3(64), 0, s, l1, l1_inf, G, gshift, win_abi, win_inf, win_s_abi, win_s_inf);
 }
 }  // namespace msm

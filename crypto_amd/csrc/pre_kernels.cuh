@@ -20,6 +20,9 @@ constexpr int PRE_GROUP = 8;
 __device__ __forceinline__ void inv_key(Fp &k, const Fp &a) { fp_norm(k, a); }
 __device__ __forceinline__ void inv_key(Fp &k, const Fp2 &a) { Fp n0, n1, t; fp_sqr(n0, a.c0); fp_sqr(n1, a.c1); fp_add(t, n0, n1); fp_norm(k, t); }
 __device__ __forceinline__ void inv_from_key(Fp &r, const Fp &, const Fp &kinv) { r = kinv; }
+// the signed 30-bit field borrows the 14 x 29-bit field's division-step inversion (fp_safegcd.cuh): one conversion each way per inverted value
+__device__ __forceinline__ void inv_key(Fp &k, const Fs &a) { fp_from_fs(k, a); }
+__device__ __forceinline__ void inv_from_key(Fs &r, const Fs &, const Fp &kinv) { fs_from_fp(r, kinv); }
 __device__ __forceinline__ void inv_from_key(Fp2 &r, const Fp2 &a, const Fp &kinv) {
     Fp n1, z; fp_mul(r.c0, a.c0, kinv); fp_mul(n1, a.c1, kinv); fp_zero(z); fp_sub<4>(r.c1, z, n1); fp_norm(r.c1, r.c1);
 }
@@ -31,7 +34,7 @@ __global__ void __launch_bounds__(64) k_pre_dbl(const uint32_t *__restrict__ pre
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t *rec = prev + i * C::AFF_STRIDE;
-    if (rec[2 * C::FW] != 0) return;
+    if (rec[C::FLAGW] != 0) return;
     Aff<F> p; load_aff<C>(p, rec);
     Xyzz<F> acc; xyzz_dbl_affine(acc, p);
     for (int k = 1; k < c; k++) { Xyzz<F> d; xyzz_dbl(d, acc); acc = d; }
@@ -59,7 +62,7 @@ __global__ void __launch_bounds__(64) k_pre_norm(const uint32_t *__restrict__ pr
 #pragma unroll
     for (int k = 0; k < PRE_GROUP; k++) {
         const size_t i = i0 + k;
-        live[k] = i < n && prev[i * C::AFF_STRIDE + 2 * C::FW] == 0;
+        live[k] = i < n && prev[i * C::AFF_STRIDE + C::FLAGW] == 0;
         pre[k] = run;
         if (live[k]) {
             F zzz; const uint32_t *src = tmp + i * C::XW + 3 * C::FW; uint32_t *w = reinterpret_cast<uint32_t *>(&zzz);

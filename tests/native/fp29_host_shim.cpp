@@ -4,6 +4,7 @@
 #define FP29_CHECK 1
 #include "../../crypto_amd/csrc/fp29.cuh"
 #include "../../crypto_amd/csrc/ec29.cuh"
+#include "../../crypto_amd/csrc/fp30s.cuh"
 #include "../../crypto_amd/csrc/pairing29.cuh"
 #include "../../crypto_amd/csrc/host_field.hpp"
 #include "../../crypto_amd/csrc/fr29.cuh"
@@ -46,6 +47,52 @@ void shim_g1_add_tree(const uint32_t *pts, int n, uint32_t *out) {
     while (m > 1) { int h = (m + 1) / 2; for (int i = 0; i + h < m; i++) xyzz_add(v[i], f[i], v[i + h], f[i + h]); m = h; }
     if (n == 0) { memset(out, 0, 4 * 48); } else store_xyzz(out, v[0], f[0]);
     delete[] v; delete[] f;
+}
+
+// ---- the 13 x 30-bit signed field of the G1 MSM kernels (fp30s.cuh), same entry shapes ----
+void shim_fs_mul(const uint32_t *a, const uint32_t *b, uint32_t *out) { Fs x, y, r; fs_from_abi(x, a); fs_from_abi(y, b); fs_mul(r, x, y); fs_to_abi(out, r); }
+void shim_fs_sqr(const uint32_t *a, uint32_t *out) { Fs x, r; fs_from_abi(x, a); fs_sqr(r, x); fs_to_abi(out, r); }
+void shim_fs_roundtrip(const uint32_t *a, uint32_t *out) { Fs x; fs_from_abi(x, a); fs_to_abi(out, x); }
+// a b - c d through the fused two-product reduction
+void shim_fs_mul2(const uint32_t *a, const uint32_t *b, const uint32_t *c, const uint32_t *d, uint32_t *out) {
+    Fs x, y, z, w, r; fs_from_abi(x, a); fs_from_abi(y, b); fs_from_abi(z, c); fs_from_abi(w, d);
+    fmul_sub<0>(r, x, y, z, w); fs_to_abi(out, r);
+}
+// ((a - b) c - 3 a + 3 a) with lazy subtractions, both carry passes and a negation on the way
+void shim_fs_submul(const uint32_t *a, const uint32_t *b, const uint32_t *c, uint32_t *out) {
+    Fs x, y, z, t, u, v; fs_from_abi(x, a); fs_from_abi(y, b); fs_from_abi(z, c);
+    fs_sub(t, x, y); fs_bal(t, t); fs_mul(t, t, z);
+    fs_add(u, x, x); fs_add(u, u, x); fs_sub(v, t, u); fs_bal_wide(v, v); fs_neg(v, v); fs_neg(v, v); fs_bal(u, u); fs_add(v, v, u); fs_bal(v, v);
+    fs_to_abi(out, v);
+}
+int shim_fs_is_zero(const uint32_t *a, const uint32_t *b) { Fs x, y, t; fs_from_abi(x, a); fs_from_abi(y, b); fs_sub(t, x, y); fs_bal(t, t); return (fs_maybe_zero(t) ? 1 : 0) | (fs_is_zero_exact(t) ? 2 : 0); }
+// Fs -> Fp -> Fs and back out: the conversions around the division-step inversion
+void shim_fs_via_fp(const uint32_t *a, uint32_t *out_fp, uint32_t *out_fs) { Fs x, y; Fp f; fs_from_abi(x, a); fp_from_fs(f, x); fp_to_abi(out_fp, f); fs_from_fp(y, f); fs_to_abi(out_fs, y); }
+static void load_aff_s(Aff<Fs> &p, const uint32_t *xy) { fs_from_abi(p.x, xy); fs_from_abi(p.y, xy + 12); }
+static void store_xyzz_s(uint32_t *out, const Xyzz<Fs> &a, bool inf) {
+    if (inf) { memset(out, 0, 4 * 48); return; }
+    fs_to_abi(out, a.x); fs_to_abi(out + 12, a.y); fs_to_abi(out + 24, a.zz); fs_to_abi(out + 36, a.zzz);
+}
+void shim_g1s_madd_chain(const uint32_t *pts, const uint8_t *neg, int n, uint32_t *out) {
+    Xyzz<Fs> acc; bool inf = true;
+    fzero(acc.x); fzero(acc.y); fzero(acc.zz); fzero(acc.zzz);
+    for (int i = 0; i < n; i++) { Aff<Fs> p; load_aff_s(p, pts + 24 * i); xyzz_madd(acc, inf, p, neg && neg[i]); }
+    store_xyzz_s(out, acc, inf);
+}
+void shim_g1s_add_tree(const uint32_t *pts, int n, uint32_t *out) {
+    Xyzz<Fs> *v = new Xyzz<Fs>[n > 0 ? n : 1]; bool *f = new bool[n > 0 ? n : 1];
+    for (int i = 0; i < n; i++) { Aff<Fs> p; load_aff_s(p, pts + 24 * i); f[i] = true; fzero(v[i].x); fzero(v[i].y); fzero(v[i].zz); fzero(v[i].zzz); xyzz_madd(v[i], f[i], p, false); }
+    int m = n;
+    while (m > 1) { int h = (m + 1) / 2; for (int i = 0; i + h < m; i++) xyzz_add(v[i], f[i], v[i + h], f[i + h]); m = h; }
+    if (n == 0) { memset(out, 0, 4 * 48); } else store_xyzz_s(out, v[0], f[0]);
+    delete[] v; delete[] f;
+}
+// doubling chain 2^k P through xyzz_dbl_affine / xyzz_dbl (the table construction's step)
+void shim_g1s_dbl_chain(const uint32_t *pt, int k, uint32_t *out) {
+    Aff<Fs> p; load_aff_s(p, pt);
+    Xyzz<Fs> acc; xyzz_dbl_affine(acc, p);
+    for (int i = 1; i < k; i++) { Xyzz<Fs> d; xyzz_dbl(d, acc); acc = d; }
+    store_xyzz_s(out, acc, false);
 }
 
 // ---- G2 ----

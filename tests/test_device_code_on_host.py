@@ -19,7 +19,7 @@ P = M.P
 
 @pytest.fixture(scope="module")
 def shim():
-    deps = [SRC] + [os.path.join(HERE, "..", "crypto_amd", "csrc", f) for f in ("fp29.cuh", "fp2_29.cuh", "ec29.cuh", "pairing29.cuh", "fr29.cuh", "fp_safegcd.cuh")]
+    deps = [SRC] + [os.path.join(HERE, "..", "crypto_amd", "csrc", f) for f in ("fp29.cuh", "fp30s.cuh", "fp2_29.cuh", "ec29.cuh", "pairing29.cuh", "fr29.cuh", "fp_safegcd.cuh")]
     if not os.path.exists(SO) or any(os.path.getmtime(d) > os.path.getmtime(SO) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", SO, SRC])
     return C.CDLL(SO)
@@ -44,6 +44,27 @@ def test_fp_ops(shim):
         shim.shim_fp_submul(p_(A), p_(B), p_(Cc), p_(out)); assert U.fp_int(out) == (a - b) * c % P
         assert ((shim.shim_fp_is_zero(p_(A), p_(B)) & 2) != 0) == (a == b)
         assert shim.shim_fp_is_zero(p_(A), p_(A)) == 3
+
+
+def test_fs_ops(shim):
+    """fp30s.cuh (13 signed 30-bit limbs, the field of the G1 MSM kernels) against big integers: products, squares, the fused a b - c d, lazy
+    subtractions with both carry passes, negation, the zero tests, and the conversions to / from the 14 x 29-bit field"""
+    random.seed(11)
+    vals = [0, 1, 2, P - 1, P - 2, (P - 1) // 2, (P + 1) // 2, 2 ** 380, 2 ** 377 - 1, 2 ** 360, 2 ** 360 - 1, 2 ** 30, 2 ** 29, 2 ** 29 - 1, P - 2 ** 29] + [random.randrange(P) for _ in range(300)]
+    out, out2 = np.zeros(6, np.uint64), np.zeros(6, np.uint64)
+    for a in vals:
+        A = U.fp_abi(a)
+        shim.shim_fs_roundtrip(p_(A), p_(out)); assert U.fp_int(out) == a
+        shim.shim_fs_sqr(p_(A), p_(out)); assert U.fp_int(out) == a * a % P
+        shim.shim_fs_via_fp(p_(A), p_(out), p_(out2)); assert U.fp_int(out) == a and U.fp_int(out2) == a
+    for i in range(len(vals) - 3):
+        a, b, c, d = vals[i], vals[i + 1], vals[i + 2], vals[i + 3]
+        A, B, Cc, D = U.fp_abi(a), U.fp_abi(b), U.fp_abi(c), U.fp_abi(d)
+        shim.shim_fs_mul(p_(A), p_(B), p_(out)); assert U.fp_int(out) == a * b % P
+        shim.shim_fs_mul2(p_(A), p_(B), p_(Cc), p_(D), p_(out)); assert U.fp_int(out) == (a * b - c * d) % P
+        shim.shim_fs_submul(p_(A), p_(B), p_(Cc), p_(out)); assert U.fp_int(out) == (a - b) * c % P
+        assert ((shim.shim_fs_is_zero(p_(A), p_(B)) & 2) != 0) == (a == b)
+        assert shim.shim_fs_is_zero(p_(A), p_(A)) == 3
 
 
 def test_fp_inversion_by_division_steps(shim):
@@ -90,11 +111,20 @@ CHAINS = [([], []), ([0], [0]), ([0], [1]), ([0, 1], [0, 0]), ([0, 0], [0, 0]), 
 TREES = [[0], [0, 1], [0, 0], [0, 1, 2, 3, 4], list(range(12)) * 2, [0, 1, 0, 1], [5] * 8]
 
 
-@pytest.mark.parametrize("group", [1, 2])
+@pytest.mark.parametrize("group", [1, 2, 3])
 def test_group_law_complete(shim, group):
+    """group 3 = G1 over the signed 30-bit field (what the MSM kernels instantiate)"""
     random.seed(3)
     ks = [random.randrange(1, M.R) for _ in range(12)]
-    if group == 1:
+    if group == 3:
+        pts = [M.g1_mul(M.G1_GEN, k) for k in ks]
+        add, neg, enc, dec, W = M.g1_add, M.g1_neg, lambda p: U.g1_abi(p)[0], _xyzz_g1, 24
+        chain_fn, tree_fn = shim.shim_g1s_madd_chain, shim.shim_g1s_add_tree
+        o = np.zeros(24, np.uint64)
+        for k in (1, 2, 16, 20):
+            shim.shim_g1s_dbl_chain(p_(enc(pts[2])), k, p_(o))
+            assert dec(o) == M.g1_mul(pts[2], 1 << k)
+    elif group == 1:
         pts = [M.g1_mul(M.G1_GEN, k) for k in ks]
         add, neg, enc, dec, W = M.g1_add, M.g1_neg, lambda p: U.g1_abi(p)[0], _xyzz_g1, 24
         chain_fn, tree_fn = shim.shim_g1_madd_chain, shim.shim_g1_add_tree

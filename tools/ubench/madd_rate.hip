@@ -5,6 +5,7 @@
 #include <vector>
 #include "../../crypto_amd/csrc/fp29.cuh"
 #include "../../crypto_amd/csrc/ec29.cuh"
+#include "../../crypto_amd/csrc/fp30s.cuh"
 using namespace bls29;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 
@@ -33,6 +34,24 @@ __global__ void __launch_bounds__(256, WAVES) k_madd(const uint32_t *pts, uint32
     const uint32_t *w = reinterpret_cast<const uint32_t *>(&acc);
     for (int i = 0; i < 56; i++) o[(size_t)i * gridDim.x * blockDim.x + t] = inf ? 0 : w[i];
 }
+// the same loop over the 13 x 30-bit signed field (fp30s.cuh): records of 28 words (x[13] y[13] pad[2])
+template <int WAVES>
+__global__ void __launch_bounds__(256, WAVES) k_madd_s(const uint32_t *pts, uint32_t *o, int iters) {
+    Xyzz<Fs> acc; int t = blockIdx.x * blockDim.x + threadIdx.x; bool inf = true;
+    fzero(acc.x); fzero(acc.y); fzero(acc.zz); fzero(acc.zzz);
+    for (int it = 0; it < iters; it++) {
+        Aff<Fs> p; const uint32_t *q = pts + (size_t)((t * 31 + it * 7) & 1023) * 32;
+        uint32_t w[28];
+#pragma unroll
+        for (int k = 0; k < 28; k += 4) { uint4 v = *reinterpret_cast<const uint4 *>(q + k); w[k] = v.x; w[k + 1] = v.y; w[k + 2] = v.z; w[k + 3] = v.w; }
+        uint32_t *d = reinterpret_cast<uint32_t *>(&p);
+#pragma unroll
+        for (int k = 0; k < 26; k++) d[k] = (uint32_t)((int32_t)(w[k] & 0x1fffffffu) - (1 << 28));
+        xyzz_madd(acc, inf, p, (it & 1));
+    }
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(&acc);
+    for (int i = 0; i < 52; i++) o[(size_t)i * gridDim.x * blockDim.x + t] = inf ? 0 : w[i];
+}
 template <class K> static float timeit(K launch, int reps) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     launch(); hipDeviceSynchronize();
@@ -59,6 +78,8 @@ int main() {
         printf("madd<1w> blocks=%4d  %.3f ms  %.3f Gmadd/s  (%.2f Tmad/s)\n", blocks, ms, (double)blocks * 256 * iters / ms * 1e-6, mads / ms * 1e-9);
         ms = timeit([&] { hipLaunchKernelGGL(k_madd<2>, dim3(blocks), dim3(256), 0, 0, d, o, iters); }, 3);
         printf("madd<2w> blocks=%4d  %.3f ms  %.3f Gmadd/s  (%.2f Tmad/s)\n", blocks, ms, (double)blocks * 256 * iters / ms * 1e-6, mads / ms * 1e-9);
+        ms = timeit([&] { hipLaunchKernelGGL(k_madd_s<2>, dim3(blocks), dim3(256), 0, 0, d, o, iters); }, 3);
+        printf("madd_s<2w> blocks=%4d  %.3f ms  %.3f Gmadd/s  (13 x 30-bit signed field)\n", blocks, ms, (double)blocks * 256 * iters / ms * 1e-6);
         ms = timeit([&] { hipLaunchKernelGGL(k_madd<3>, dim3(blocks), dim3(256), 0, 0, d, o, iters); }, 3);
         printf("madd<3w> blocks=%4d  %.3f ms  %.3f Gmadd/s  (%.2f Tmad/s)\n", blocks, ms, (double)blocks * 256 * iters / ms * 1e-6, mads / ms * 1e-9);
         ms = timeit([&] { hipLaunchKernelGGL(k_madd<4>, dim3(blocks), dim3(256), 0, 0, d, o, iters); }, 3);

@@ -59,8 +59,8 @@ template <class F> FD void xyzz_dbl_affine(Xyzz<F> &r, const Aff<F> &p) {
     fsqr(V, U);
     fmul(W, U, V);
     fmul(S, p.x, V);
-    fsqr(M, p.x); fadd(t, M, M); fadd(M, t, M); fnorm(M, M);
-    fsqr(X3, M); fadd(t, S, S); fsub<SubM<F>::X>(X3, X3, t); fnorm(X3, X3);
+    fsqr(M, p.x); fadd(t, M, M); fadd(M, t, M); fnormw(M, M);
+    fsqr(X3, M); fadd(t, S, S); fsub<SubM<F>::X>(X3, X3, t); fnormw(X3, X3);
     fsub<SubM<F>::D>(t, S, X3); fnorm(t, t);
     fmul_sub<SubM<F>::YN>(Y3, M, t, W, p.y);
     r.x = X3; r.y = Y3; r.zz = V; r.zzz = W;
@@ -73,8 +73,8 @@ template <class F> FD void xyzz_dbl(Xyzz<F> &r, const Xyzz<F> &a) {
     fsqr(V, U);
     fmul(W, U, V);
     fmul(S, a.x, V);
-    fsqr(M, a.x); fadd(t, M, M); fadd(M, t, M); fnorm(M, M);
-    fsqr(X3, M); fadd(t, S, S); fsub<SubM<F>::X>(X3, X3, t); fnorm(X3, X3);
+    fsqr(M, a.x); fadd(t, M, M); fadd(M, t, M); fnormw(M, M);
+    fsqr(X3, M); fadd(t, S, S); fsub<SubM<F>::X>(X3, X3, t); fnormw(X3, X3);
     fsub<SubM<F>::D>(t, S, X3); fnorm(t, t);
     fmul_sub<SubM<F>::YN>(Y3, M, t, W, a.y);
     fmul(r.zz, V, a.zz); fmul(r.zzz, W, a.zzz);

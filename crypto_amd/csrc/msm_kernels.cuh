@@ -29,6 +29,7 @@
 #include "ec29.cuh"
 #include "fp2_pair.cuh"
 #include "fp30s.cuh"
+#include "fs2_pair.cuh"
 #include <type_traits>
 
 namespace msm {
@@ -70,9 +71,24 @@ struct G1 {
     typedef G1S ACC;                         // traits used by the accumulate kernel
     static constexpr int ACC_WAVES = 2;      // waves/SIMD of k_accumulate: 256 VGPRs, no spills (tools/ubench/madd_rate: 6.35 vs 5.1 Gmadd/s at 3)
 };
+// G2 over the signed field, one lane per point (base preparation, table construction).  In memory every base-field component keeps a slot of
+// PS = 14 words (13 used): the lane-pair kernels move a half with 8-byte accesses, which the 56-byte slots keep aligned.
+constexpr int PS = NL;       // words per component slot in G2 records
+struct G2S {
+    typedef Fs2 F;
+    typedef G2S MSM;
+    static constexpr int FLAGW = 56;
+    static constexpr int FW = 2 * SN;        // words per coordinate in registers (the XYZZ scratch of the table construction is the packed struct)
+    static constexpr int ABI_W = 24;
+    static constexpr int NFP = 2;
+    static constexpr int AFF_STRIDE = 64;    // four component slots, flag, padding
+    static constexpr int XW = 4 * FW;        // 104
+    static constexpr int HEAVY_T = 128;
+    static constexpr int LPP = 1;
+};
 struct G2 {
     typedef Fp2 F;
-    typedef G2 MSM;
+    typedef G2S MSM;
     static constexpr int FLAGW = 56;
     static constexpr int FW = 2 * NL;
     static constexpr int ABI_W = 24;
@@ -86,11 +102,11 @@ struct G2 {
 };
 // G2 with one point per lane pair: the even lane holds the c0 halves, the odd lane the c1 halves
 struct G2P {
-    typedef Fp2H F;
+    typedef Fs2H F;
     static constexpr int FLAGW = 56;
-    static constexpr int FW = NL;            // words per coordinate HALF held by one lane
+    static constexpr int FW = SN;            // words per coordinate HALF held by one lane
     static constexpr int AFF_STRIDE = 64;
-    static constexpr int XW = 8 * NL;        // words per full XYZZ point in the SoA arrays
+    static constexpr int XW = 8 * PS;        // words per full XYZZ point in the record arrays (eight component slots)
     static constexpr int LPP = 2;
     static constexpr int ACC_WAVES = 2;
     static constexpr int HEAVY_T = 256;      // 128 lane pairs per block in the heavy-bucket folds
@@ -109,6 +125,14 @@ template <class C> __device__ __forceinline__ void store_coords_from_abi(uint32_
             for (int j = 0; j < SN; j++) dst[k * SN + j] = (uint32_t)f.l[j];
         }
         dst[2 * SN] = 0; dst[2 * SN + 1] = 0;
+    } else if constexpr (std::is_same<typename C::F, Fs2>::value) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            Fs f; fs_from_abi(f, w + 12 * k);
+#pragma unroll
+            for (int j = 0; j < SN; j++) dst[k * PS + j] = (uint32_t)f.l[j];
+            dst[k * PS + SN] = 0;
+        }
     } else {
 #pragma unroll
         for (int k = 0; k < 2 * C::NFP; k++) {
@@ -120,7 +144,7 @@ template <class C> __device__ __forceinline__ void store_coords_from_abi(uint32_
 }
 // a coordinate tuple of `count` base-field components (x, y[, zz, zzz]; Fp2: c0, c1 per coordinate) to ABI words, 12 per component
 template <class F> __device__ __forceinline__ void coords_to_abi(uint32_t *__restrict__ dst, const void *pt, int count) {
-    if constexpr (std::is_same<F, Fs>::value) { const Fs *f = reinterpret_cast<const Fs *>(pt); for (int k = 0; k < count; k++) fs_to_abi(dst + 12 * k, f[k]); }
+    if constexpr (std::is_same<F, Fs>::value || std::is_same<F, Fs2>::value) { const Fs *f = reinterpret_cast<const Fs *>(pt); for (int k = 0; k < count; k++) fs_to_abi(dst + 12 * k, f[k]); }
     else { const Fp *f = reinterpret_cast<const Fp *>(pt); for (int k = 0; k < count; k++) fp_to_abi(dst + 12 * k, f[k]); }
 }
 
@@ -208,34 +232,54 @@ template <> __device__ __forceinline__ void load_aff<G1S>(Aff<Fs> &p, const uint
 #pragma unroll
     for (int k = 0; k < 2 * SN; k++) w[k] = t[k];
 }
-// lane-pair variants: this lane moves only its half (c0 on even lanes, c1 on odd lanes) of every coordinate
-template <> __device__ __forceinline__ void store_soa<G2P>(uint32_t *__restrict__ base, size_t /*count*/, size_t b, const Xyzz<Fp2H> &p) {
-    const uint32_t h = threadIdx.x & 1u;
-    const uint32_t *w = reinterpret_cast<const uint32_t *>(&p);      // x, y, zz, zzz halves: 4 x 14 words
-    uint32_t *t = base + b * G2P::XW;                               // G2 word order: coordinate k, half h at (2k + h) * NL (56-byte pieces, 8-byte aligned)
+template <> __device__ __forceinline__ void load_aff<G2S>(Aff<Fs2> &p, const uint32_t *__restrict__ rec) {
+    uint32_t *w = reinterpret_cast<uint32_t *>(&p);
 #pragma unroll
     for (int k = 0; k < 4; k++)
 #pragma unroll
-        for (int j = 0; j < NL; j += 2) *reinterpret_cast<uint2 *>(t + (2 * k + h) * NL + j) = make_uint2(w[k * NL + j], w[k * NL + j + 1]);
+        for (int j = 0; j < SN; j++) w[k * SN + j] = rec[k * PS + j];
 }
-template <> __device__ __forceinline__ void load_soa<G2P>(Xyzz<Fp2H> &p, const uint32_t *__restrict__ base, size_t /*count*/, size_t b) {
+// an affine point into a base record (coordinates only; the caller sets the flag word)
+template <class C> __device__ __forceinline__ void store_aff_record(uint32_t *__restrict__ dst, const Aff<typename C::F> &a) {
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(&a);
+    if constexpr (std::is_same<typename C::F, Fs2>::value) {
+        for (int k = 0; k < 4; k++) { for (int j = 0; j < SN; j++) dst[k * PS + j] = w[k * SN + j]; dst[k * PS + SN] = 0u; }
+        for (int j = 4 * PS; j < C::AFF_STRIDE; j++) dst[j] = 0u;
+    } else {
+        for (int j = 0; j < 2 * C::FW; j++) dst[j] = w[j];
+        for (int j = 2 * C::FW; j < C::AFF_STRIDE; j++) dst[j] = 0u;
+    }
+}
+// lane-pair variants: this lane moves only its half (c0 on even lanes, c1 on odd lanes) of every coordinate: 13 words out of a 14-word slot
+__device__ __forceinline__ void load_half(uint32_t *__restrict__ w, const uint32_t *__restrict__ src) {
+#pragma unroll
+    for (int j = 0; j + 1 < SN; j += 2) { const uint2 v = *reinterpret_cast<const uint2 *>(src + j); w[j] = v.x; w[j + 1] = v.y; }
+    w[SN - 1] = src[SN - 1];
+}
+__device__ __forceinline__ void store_half(uint32_t *__restrict__ dst, const uint32_t *__restrict__ w) {
+#pragma unroll
+    for (int j = 0; j + 1 < SN; j += 2) *reinterpret_cast<uint2 *>(dst + j) = make_uint2(w[j], w[j + 1]);
+    *reinterpret_cast<uint2 *>(dst + SN - 1) = make_uint2(w[SN - 1], 0u);
+}
+template <> __device__ __forceinline__ void store_soa<G2P>(uint32_t *__restrict__ base, size_t /*count*/, size_t b, const Xyzz<Fs2H> &p) {
+    const uint32_t h = threadIdx.x & 1u;
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(&p);      // x, y, zz, zzz halves: 4 x 13 words
+    uint32_t *t = base + b * G2P::XW;                               // G2 word order: coordinate k, half h in the slot (2k + h) * PS (56-byte slots, 8-byte aligned)
+#pragma unroll
+    for (int k = 0; k < 4; k++) store_half(t + (2 * k + h) * PS, w + k * SN);
+}
+template <> __device__ __forceinline__ void load_soa<G2P>(Xyzz<Fs2H> &p, const uint32_t *__restrict__ base, size_t /*count*/, size_t b) {
     const uint32_t h = threadIdx.x & 1u;
     uint32_t *w = reinterpret_cast<uint32_t *>(&p);
     const uint32_t *t = base + b * G2P::XW;
 #pragma unroll
-    for (int k = 0; k < 4; k++)
-#pragma unroll
-        for (int j = 0; j < NL; j += 2) { const uint2 v = *reinterpret_cast<const uint2 *>(t + (2 * k + h) * NL + j); w[k * NL + j] = v.x; w[k * NL + j + 1] = v.y; }
+    for (int k = 0; k < 4; k++) load_half(w + k * SN, t + (2 * k + h) * PS);
 }
-template <> __device__ __forceinline__ void load_aff<G2P>(Aff<Fp2H> &p, const uint32_t *__restrict__ rec) {
+template <> __device__ __forceinline__ void load_aff<G2P>(Aff<Fs2H> &p, const uint32_t *__restrict__ rec) {
     const uint32_t h = threadIdx.x & 1u;
     uint32_t *w = reinterpret_cast<uint32_t *>(&p);
 #pragma unroll
-    for (int k = 0; k < 2; k++) {
-        const uint32_t *src = rec + (2 * k + h) * NL;                 // 56-byte granules: 8-byte aligned
-#pragma unroll
-        for (int j = 0; j < NL; j += 2) { uint2 v = *reinterpret_cast<const uint2 *>(src + j); w[k * NL + j] = v.x; w[k * NL + j + 1] = v.y; }
-    }
+    for (int k = 0; k < 2; k++) load_half(w + k * SN, rec + (2 * k + h) * PS);
 }
 
 // ---- K5: chunked bucket accumulation ------------------------------------------------------------------
@@ -540,53 +584,45 @@ __global__ void __launch_bounds__(64) k_reduce_top(const uint32_t *__restrict__ 
 // Same group geometry and l1 layout as k_reduce_l0 / k_reduce_top, but a point lives on a lane pair (even lane: c0 halves, odd lane: c1
 // halves), so a wave holds 32 points and every point-lane takes twice the items.  The one-lane Fp2 addition needs > 256 VGPRs (spills)
 // and is ~3x the instructions of a half: the pair form runs the same dependent chain in about half the time (3.0 -> 1.6 ms at 2^20).
-__device__ __forceinline__ void load_soa_pair(Xyzz<Fp2H> &p, const uint32_t *__restrict__ base, size_t b) {
-    const uint32_t h = threadIdx.x & 1u;
-    uint32_t *w = reinterpret_cast<uint32_t *>(&p);
-    const uint32_t *t = base + b * G2P::XW;
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-#pragma unroll
-        for (int j = 0; j < NL; j += 2) { const uint2 v = *reinterpret_cast<const uint2 *>(t + (2 * k + h) * NL + j); w[k * NL + j] = v.x; w[k * NL + j + 1] = v.y; }
-}
-__device__ __forceinline__ void shfl_down_pair(Xyzz<Fp2H> &o, bool &oinf, const Xyzz<Fp2H> &x, bool xinf, int d /* point-lanes */) {
+__device__ __forceinline__ void load_soa_pair(Xyzz<Fs2H> &p, const uint32_t *__restrict__ base, size_t b) { load_soa<G2P>(p, base, 0, b); }
+__device__ __forceinline__ void shfl_down_pair(Xyzz<Fs2H> &o, bool &oinf, const Xyzz<Fs2H> &x, bool xinf, int d /* point-lanes */) {
     const uint32_t *w = reinterpret_cast<const uint32_t *>(&x);
     uint32_t *q = reinterpret_cast<uint32_t *>(&o);
 #pragma unroll
-    for (int k = 0; k < 4 * NL; k++) q[k] = __shfl_down(w[k], 2 * d, 64);
+    for (int k = 0; k < 4 * SN; k++) q[k] = __shfl_down(w[k], 2 * d, 64);
     int fi = __shfl_down((int)xinf, 2 * d, 64);
     oinf = (fi != 0) || ((int)((threadIdx.x & 63) >> 1) + d >= 32);
 }
 // point-lane q holds (S_q, A_q), its items' global weights offset by q * 2^shift; on return point-lane 0 holds S = sum S_q, A = sum (A_q + q 2^shift S_q)
-__device__ __forceinline__ void wave_weighted_sum_pair(Xyzz<Fp2H> &S, bool &sinf, Xyzz<Fp2H> &A, bool &ainf, int shift) {
+__device__ __forceinline__ void wave_weighted_sum_pair(Xyzz<Fs2H> &S, bool &sinf, Xyzz<Fs2H> &A, bool &ainf, int shift) {
     const int q = (threadIdx.x & 63) >> 1;
     for (int d = 1; d < 32; d <<= 1) {
-        Xyzz<Fp2H> o; bool oinf; shfl_down_pair(o, oinf, S, sinf, d);
+        Xyzz<Fs2H> o; bool oinf; shfl_down_pair(o, oinf, S, sinf, d);
         xyzz_add(S, sinf, o, oinf);
     }
-    Xyzz<Fp2H> y = S; bool yinf = (q == 0) ? true : sinf;
-    for (int k = 0; k < shift; k++) { if (!yinf) { Xyzz<Fp2H> d2; xyzz_dbl(d2, y); y = d2; } }
+    Xyzz<Fs2H> y = S; bool yinf = (q == 0) ? true : sinf;
+    for (int k = 0; k < shift; k++) { if (!yinf) { Xyzz<Fs2H> d2; xyzz_dbl(d2, y); y = d2; } }
     xyzz_add(A, ainf, y, yinf);
     for (int d = 16; d >= 1; d >>= 1) {
-        Xyzz<Fp2H> o; bool oinf; shfl_down_pair(o, oinf, A, ainf, d);
+        Xyzz<Fs2H> o; bool oinf; shfl_down_pair(o, oinf, A, ainf, d);
         xyzz_add(A, ainf, o, oinf);
     }
 }
-__device__ __forceinline__ void store_l1_pair(uint32_t *__restrict__ dst, const Xyzz<Fp2H> &p) {       // AoS, G2 word order: coordinate k, half h at (2k + h) * NL
+__device__ __forceinline__ void store_l1_pair(uint32_t *__restrict__ dst, const Xyzz<Fs2H> &p) {       // AoS, G2 word order: coordinate k, half h at (2k + h) * NL
     const uint32_t h = threadIdx.x & 1u;
     const uint32_t *w = reinterpret_cast<const uint32_t *>(&p);
-    for (int k = 0; k < 4; k++) for (int j = 0; j < NL; j++) dst[(2 * k + h) * NL + j] = w[k * NL + j];
+    for (int k = 0; k < 4; k++) store_half(dst + (2 * k + h) * PS, w + k * SN);
 }
-__device__ __forceinline__ void load_l1_pair(Xyzz<Fp2H> &p, const uint32_t *__restrict__ src) {
+__device__ __forceinline__ void load_l1_pair(Xyzz<Fs2H> &p, const uint32_t *__restrict__ src) {
     const uint32_t h = threadIdx.x & 1u;
     uint32_t *w = reinterpret_cast<uint32_t *>(&p);
-    for (int k = 0; k < 4; k++) for (int j = 0; j < NL; j++) w[k * NL + j] = src[(2 * k + h) * NL + j];
+    for (int k = 0; k < 4; k++) load_half(w + k * SN, src + (2 * k + h) * PS);
 }
 // one wave per group of 64 * m buckets: 32 point-lanes x 2m buckets each
 template <class PAIR /* = G2P: a template only so that the header may be included by several translation units */>
 __global__ void __launch_bounds__(64) k_reduce_l0_pair(const uint32_t *__restrict__ bucket, const uint8_t *__restrict__ bucket_inf, uint32_t NB, int mshift,
                                                        uint32_t *__restrict__ l1, uint8_t *__restrict__ l1_inf) {
-    typedef Fp2H F;
+    typedef Fs2H F;
     const int q = (threadIdx.x & 63) >> 1;
     const uint32_t m2 = 2u << mshift;                    // buckets per point-lane
     const size_t g = blockIdx.x;
@@ -605,8 +641,8 @@ __global__ void __launch_bounds__(64) k_reduce_l0_pair(const uint32_t *__restric
     }
     wave_weighted_sum_pair(run, rinf, tot, tinf, mshift + 1);
     if (q == 0) {
-        uint32_t *dst = l1 + g * 2 * G2::XW;
-        store_l1_pair(dst, run); store_l1_pair(dst + G2::XW, tot);
+        uint32_t *dst = l1 + g * 2 * G2P::XW;
+        store_l1_pair(dst, run); store_l1_pair(dst + G2P::XW, tot);
         if ((threadIdx.x & 1u) == 0) { l1_inf[2 * g] = rinf; l1_inf[2 * g + 1] = tinf; }
     }
 }
@@ -615,7 +651,7 @@ template <class PAIR>
 __global__ void __launch_bounds__(64) k_reduce_top_pair(const uint32_t *__restrict__ l1, const uint8_t *__restrict__ l1_inf, int G, int gshift,
                                                         uint32_t *__restrict__ win_abi, uint8_t *__restrict__ win_inf,
                                                         uint32_t *__restrict__ win_s_abi = nullptr, uint8_t *__restrict__ win_s_inf = nullptr) {
-    typedef Fp2H F;
+    typedef Fs2H F;
     const int q = (threadIdx.x & 63) >> 1;
     const uint32_t h = threadIdx.x & 1u;
     const size_t w = blockIdx.x;
@@ -624,29 +660,29 @@ __global__ void __launch_bounds__(64) k_reduce_top_pair(const uint32_t *__restri
     auto zero = [](Xyzz<F> &p) { fzero(p.x); fzero(p.y); fzero(p.zz); fzero(p.zzz); };
     // A = A_0 + A_1 + 2^gshift S_1 ;  S = S_0 + S_1     (one operand pair live at a time: four points at once would spill)
     Xyzz<F> A; bool ainf = true; zero(A);
-    if (has0) { load_l1_pair(A, l1 + g0 * 2 * G2::XW + G2::XW); ainf = l1_inf[2 * g0 + 1] != 0; }
+    if (has0) { load_l1_pair(A, l1 + g0 * 2 * G2P::XW + G2P::XW); ainf = l1_inf[2 * g0 + 1] != 0; }
     { Xyzz<F> t; bool tinf = true; zero(t);
-      if (has1) { load_l1_pair(t, l1 + g1 * 2 * G2::XW + G2::XW); tinf = l1_inf[2 * g1 + 1] != 0; }
+      if (has1) { load_l1_pair(t, l1 + g1 * 2 * G2P::XW + G2P::XW); tinf = l1_inf[2 * g1 + 1] != 0; }
       xyzz_add(A, ainf, t, tinf); }
     Xyzz<F> S1; bool s1inf = true; zero(S1);
-    if (has1) { load_l1_pair(S1, l1 + g1 * 2 * G2::XW); s1inf = l1_inf[2 * g1] != 0; }
+    if (has1) { load_l1_pair(S1, l1 + g1 * 2 * G2P::XW); s1inf = l1_inf[2 * g1] != 0; }
     { Xyzz<F> y = S1; bool yinf = s1inf;
       for (int k = 0; k < gshift; k++) { if (!yinf) { Xyzz<F> d2; xyzz_dbl(d2, y); y = d2; } }
       xyzz_add(A, ainf, y, yinf); }
     Xyzz<F> S; bool sinf = true; zero(S);
-    if (has0) { load_l1_pair(S, l1 + g0 * 2 * G2::XW); sinf = l1_inf[2 * g0] != 0; }
+    if (has0) { load_l1_pair(S, l1 + g0 * 2 * G2P::XW); sinf = l1_inf[2 * g0] != 0; }
     xyzz_add(S, sinf, S1, s1inf);
     wave_weighted_sum_pair(S, sinf, A, ainf, gshift + 1);
     if (q == 0) {
         uint32_t *dst = win_abi + w * 4 * G2::ABI_W;
         if (h == 0) win_inf[w] = ainf;
         if (!ainf) {
-            const Fp *f = reinterpret_cast<const Fp *>(&A);          // x, y, zz, zzz halves
-            for (int k = 0; k < 4; k++) fp_to_abi(dst + 12 * (2 * k + h), f[k]);
+            const Fs *f = reinterpret_cast<const Fs *>(&A);          // x, y, zz, zzz halves
+            for (int k = 0; k < 4; k++) fs_to_abi(dst + 12 * (2 * k + h), f[k]);
         }
         if (win_s_abi) {
             if (h == 0) win_s_inf[w] = sinf;
-            if (!sinf) { const Fp *f = reinterpret_cast<const Fp *>(&S); for (int k = 0; k < 4; k++) fp_to_abi(win_s_abi + w * 4 * G2::ABI_W + 12 * (2 * k + h), f[k]); }
+            if (!sinf) { const Fs *f = reinterpret_cast<const Fs *>(&S); for (int k = 0; k < 4; k++) fs_to_abi(win_s_abi + w * 4 * G2::ABI_W + 12 * (2 * k + h), f[k]); }
         }
     }
 }
@@ -664,10 +700,10 @@ __global__ void __launch_bounds__(256) k_fixup_pair(uint32_t NB, uint32_t *__res
     const uint32_t b = tail_b[t];
     if (b == 0xffffffffu) return;
     if (off[b + 1] - off[b] >= heavy_thr) return;   // folded by k_fixup_heavy
-    Xyzz<Fp2H> acc; load_soa_pair(acc, tail, t);
+    Xyzz<Fs2H> acc; load_soa_pair(acc, tail, t);
     bool inf = part_inf[2 * t + 1] != 0;
     for (size_t k = t + 1; k < T && head_b[k] == b; k++) {
-        Xyzz<Fp2H> o; load_soa_pair(o, head, k);
+        Xyzz<Fs2H> o; load_soa_pair(o, head, k);
         xyzz_add(acc, inf, o, part_inf[2 * k] != 0);
     }
     store_soa<G2P>(bucket, NB, b, acc);

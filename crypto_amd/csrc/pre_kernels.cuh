@@ -23,6 +23,10 @@ __device__ __forceinline__ void inv_from_key(Fp &r, const Fp &, const Fp &kinv) 
 // the signed 30-bit field borrows the 14 x 29-bit field's division-step inversion (fp_safegcd.cuh): one conversion each way per inverted value
 __device__ __forceinline__ void inv_key(Fp &k, const Fs &a) { fp_from_fs(k, a); }
 __device__ __forceinline__ void inv_from_key(Fs &r, const Fs &, const Fp &kinv) { fs_from_fp(r, kinv); }
+__device__ __forceinline__ void inv_key(Fp &k, const Fs2 &a) { Fs n0, n1, t; fs_sqr(n0, a.c0); fs_sqr(n1, a.c1); fs_add(t, n0, n1); fs_bal(t, t); fp_from_fs(k, t); }     // the norm c0^2 + c1^2
+__device__ __forceinline__ void inv_from_key(Fs2 &r, const Fs2 &a, const Fp &kinv) {
+    Fs ki, n1; fs_from_fp(ki, kinv); fs_mul(r.c0, a.c0, ki); fs_mul(n1, a.c1, ki); fs_neg(r.c1, n1);
+}
 __device__ __forceinline__ void inv_from_key(Fp2 &r, const Fp2 &a, const Fp &kinv) {
     Fp n1, z; fp_mul(r.c0, a.c0, kinv); fp_mul(n1, a.c1, kinv); fp_zero(z); fp_sub<4>(r.c1, z, n1); fp_norm(r.c1, r.c1);
 }
@@ -87,9 +91,7 @@ __global__ void __launch_bounds__(64) k_pre_norm(const uint32_t *__restrict__ pr
         fmul(tt, p.zz, i3); fsqr(i2, tt);          // 1 / ZZ = (ZZ / ZZZ)^2
         fnorm(xn, p.x); fnorm(yn, p.y);
         fmul(a.x, xn, i2); fmul(a.y, yn, i3);
-        const uint32_t *w = reinterpret_cast<const uint32_t *>(&a);
-        for (int j = 0; j < 2 * C::FW; j++) dst[j] = w[j];
-        for (int j = 2 * C::FW; j < C::AFF_STRIDE; j++) dst[j] = 0u;
+        store_aff_record<C>(dst, a);
     }
 }
 

@@ -5,6 +5,7 @@
 #include "../../crypto_amd/csrc/fp29.cuh"
 #include "../../crypto_amd/csrc/ec29.cuh"
 #include "../../crypto_amd/csrc/fp30s.cuh"
+#include "../../crypto_amd/csrc/fs2_pair.cuh"
 #include "../../crypto_amd/csrc/pairing29.cuh"
 #include "../../crypto_amd/csrc/host_field.hpp"
 #include "../../crypto_amd/csrc/fr29.cuh"
@@ -93,6 +94,43 @@ void shim_g1s_dbl_chain(const uint32_t *pt, int k, uint32_t *out) {
     Xyzz<Fs> acc; xyzz_dbl_affine(acc, p);
     for (int i = 1; i < k; i++) { Xyzz<Fs> d; xyzz_dbl(d, acc); acc = d; }
     store_xyzz_s(out, acc, false);
+}
+
+// ---- G2 over the signed field (fs2_pair.cuh, one-lane form; the lane-pair form runs the same component arithmetic) ----
+static void load_aff2s(Aff<Fs2> &p, const uint32_t *xy) { fs_from_abi(p.x.c0, xy); fs_from_abi(p.x.c1, xy + 12); fs_from_abi(p.y.c0, xy + 24); fs_from_abi(p.y.c1, xy + 36); }
+static void store_xyzz2s(uint32_t *out, const Xyzz<Fs2> &a, bool inf) {
+    if (inf) { memset(out, 0, 4 * 96); return; }
+    const Fs *f = reinterpret_cast<const Fs *>(&a);
+    for (int k = 0; k < 8; k++) fs_to_abi(out + 12 * k, f[k]);
+}
+void shim_fs2_mul(const uint32_t *a, const uint32_t *b, uint32_t *out) {
+    Fs2 x, y, r; fs_from_abi(x.c0, a); fs_from_abi(x.c1, a + 12); fs_from_abi(y.c0, b); fs_from_abi(y.c1, b + 12);
+    fmul(r, x, y); fs_to_abi(out, r.c0); fs_to_abi(out + 12, r.c1);
+}
+void shim_fs2_sqr(const uint32_t *a, uint32_t *out) {
+    Fs2 x, r; fs_from_abi(x.c0, a); fs_from_abi(x.c1, a + 12);
+    fsqr(r, x); fs_to_abi(out, r.c0); fs_to_abi(out + 12, r.c1);
+}
+// early = 1: the early-return form of the mixed addition (what the lane-pair kernels instantiate)
+void shim_g2s_madd_chain(const uint32_t *pts, const uint8_t *neg, int n, int early, uint32_t *out) {
+    Xyzz<Fs2> acc; bool inf = true;
+    fzero(acc.x); fzero(acc.y); fzero(acc.zz); fzero(acc.zzz);
+    for (int i = 0; i < n; i++) { Aff<Fs2> p; load_aff2s(p, pts + 48 * i); if (early) xyzz_madd_early(acc, inf, p, neg && neg[i]); else xyzz_madd(acc, inf, p, neg && neg[i]); }
+    store_xyzz2s(out, acc, inf);
+}
+void shim_g2s_add_tree(const uint32_t *pts, int n, uint32_t *out) {
+    Xyzz<Fs2> *v = new Xyzz<Fs2>[n > 0 ? n : 1]; bool *f = new bool[n > 0 ? n : 1];
+    for (int i = 0; i < n; i++) { Aff<Fs2> p; load_aff2s(p, pts + 48 * i); f[i] = true; fzero(v[i].x); fzero(v[i].y); fzero(v[i].zz); fzero(v[i].zzz); xyzz_madd_early(v[i], f[i], p, false); }
+    int m = n;
+    while (m > 1) { int h = (m + 1) / 2; for (int i = 0; i + h < m; i++) xyzz_add(v[i], f[i], v[i + h], f[i + h]); m = h; }
+    if (n == 0) { memset(out, 0, 4 * 96); } else store_xyzz2s(out, v[0], f[0]);
+    delete[] v; delete[] f;
+}
+void shim_g2s_dbl_chain(const uint32_t *pt, int k, uint32_t *out) {
+    Aff<Fs2> p; load_aff2s(p, pt);
+    Xyzz<Fs2> acc; xyzz_dbl_affine(acc, p);
+    for (int i = 1; i < k; i++) { Xyzz<Fs2> d; xyzz_dbl(d, acc); acc = d; }
+    store_xyzz2s(out, acc, false);
 }
 
 // ---- G2 ----

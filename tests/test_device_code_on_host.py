@@ -19,7 +19,7 @@ P = M.P
 
 @pytest.fixture(scope="module")
 def shim():
-    deps = [SRC] + [os.path.join(HERE, "..", "crypto_amd", "csrc", f) for f in ("fp29.cuh", "fp30s.cuh", "fp2_29.cuh", "ec29.cuh", "pairing29.cuh", "fr29.cuh", "fp_safegcd.cuh")]
+    deps = [SRC] + [os.path.join(HERE, "..", "crypto_amd", "csrc", f) for f in ("fp29.cuh", "fp30s.cuh", "fs2_pair.cuh", "fp2_29.cuh", "ec29.cuh", "pairing29.cuh", "fr29.cuh", "fp_safegcd.cuh")]
     if not os.path.exists(SO) or any(os.path.getmtime(d) > os.path.getmtime(SO) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", SO, SRC])
     return C.CDLL(SO)
@@ -88,6 +88,8 @@ def test_fp2_ops(shim):
     for a, b in zip(vals, vals[1:]):
         shim.shim_fp2_mul(p_(enc(a)), p_(enc(b)), p_(o)); assert dec(o) == M.f2_mul(a, b)
         shim.shim_fp2_sqr(p_(enc(a)), p_(o)); assert dec(o) == M.f2_sqr(a)
+        shim.shim_fs2_mul(p_(enc(a)), p_(enc(b)), p_(o)); assert dec(o) == M.f2_mul(a, b)          # the same over the signed 30-bit field (fs2_pair.cuh)
+        shim.shim_fs2_sqr(p_(enc(a)), p_(o)); assert dec(o) == M.f2_sqr(a)
 
 
 def _xyzz_g1(o):
@@ -111,12 +113,21 @@ CHAINS = [([], []), ([0], [0]), ([0], [1]), ([0, 1], [0, 0]), ([0, 0], [0, 0]), 
 TREES = [[0], [0, 1], [0, 0], [0, 1, 2, 3, 4], list(range(12)) * 2, [0, 1, 0, 1], [5] * 8]
 
 
-@pytest.mark.parametrize("group", [1, 2, 3])
+@pytest.mark.parametrize("group", [1, 2, 3, 4, 5])
 def test_group_law_complete(shim, group):
-    """group 3 = G1 over the signed 30-bit field (what the MSM kernels instantiate)"""
+    """groups 3 / 4 / 5 = G1 / G2 / G2 with the early-return mixed addition over the signed 30-bit field (what the MSM kernels instantiate)"""
     random.seed(3)
     ks = [random.randrange(1, M.R) for _ in range(12)]
-    if group == 3:
+    if group in (4, 5):
+        pts = [M.g2_mul(M.G2_GEN, k) for k in ks]
+        add, neg, enc, dec, W = M.g2_add, M.g2_neg, lambda p: U.g2_abi(p)[0], _xyzz_g2, 48
+        chain_fn = lambda a, b, c, d: shim.shim_g2s_madd_chain(a, b, c, group - 4, d)
+        tree_fn = shim.shim_g2s_add_tree
+        o = np.zeros(48, np.uint64)
+        for k in (1, 2, 16, 20):
+            shim.shim_g2s_dbl_chain(p_(enc(pts[2])), k, p_(o))
+            assert dec(o) == M.g2_mul(pts[2], 1 << k)
+    elif group == 3:
         pts = [M.g1_mul(M.G1_GEN, k) for k in ks]
         add, neg, enc, dec, W = M.g1_add, M.g1_neg, lambda p: U.g1_abi(p)[0], _xyzz_g1, 24
         chain_fn, tree_fn = shim.shim_g1s_madd_chain, shim.shim_g1s_add_tree

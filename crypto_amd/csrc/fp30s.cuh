@@ -75,6 +75,17 @@ inline void schk_columns(const Fs *const *a, const Fs *const *b, int nprod) {
 #endif
 
 FD int32_t sext30(uint32_t x) { return (int32_t)(x << 2) >> 2; }
+// The multiply-add chain of an output column, started from the bias constant 2^29.  (The compiler reassociates the sum and the constant ends up in
+// a 64-bit addition of its own after the chain, 12 per product.  Forcing it into the addend of the chain's first v_mad_i64_i32 with one inline-
+// assembly statement per multiply-add removes those additions and was measured 1 % SLOWER on the mixed addition — the compiler schedules its own
+// chains better than opaque ones, tools/ubench/madd_rate.hip — so the chain stays plain C.)
+struct FsChain {
+    int64_t v;
+    FD FsChain(int32_t x, int32_t y) : v((int64_t)x * y + (int64_t)SHALF) {}
+    FD void vv(int32_t x, int32_t y) { v += (int64_t)x * y; }
+    FD void vs(int32_t x, int32_t k) { v += (int64_t)x * k; }
+};
+
 FD void fs_zero(Fs &r) {
 #pragma unroll
     for (int i = 0; i < SN; i++) r.l[i] = 0;
@@ -188,12 +199,12 @@ FD void fs_mul(Fs &r, const Fs &a, const Fs &b) {
     }
 #pragma unroll
     for (int k = SN; k < 2 * SN - 1; k++) {
-        int64_t part = (int64_t)SHALF;
+        FsChain part(a.l[k - SN + 1], b.l[SN - 1]);
 #pragma unroll
-        for (int i = k - SN + 1; i < SN; i++) part += (int64_t)a.l[i] * b.l[k - i];
+        for (int i = k - SN + 2; i < SN; i++) part.vv(a.l[i], b.l[k - i]);
 #pragma unroll
-        for (int i = k - SN + 1; i < SN; i++) part += (int64_t)m[i] * P_[k - i];
-        acc += part;
+        for (int i = k - SN + 1; i < SN; i++) part.vs(m[i], P_[k - i]);
+        acc += part.v;
         t[k - SN] = (int32_t)((uint32_t)acc & SMASK) - SHALF;
         acc >>= SB;
     }
@@ -221,11 +232,13 @@ FD void fs_mul2(Fs &r, const Fs &a, const Fs &b, const Fs &c, const Fs &d) {
     }
 #pragma unroll
     for (int k = SN; k < 2 * SN - 1; k++) {
-        acc += (int64_t)SHALF;
+        FsChain part(a.l[k - SN + 1], b.l[SN - 1]);
+        part.vv(c.l[k - SN + 1], d.l[SN - 1]);
 #pragma unroll
-        for (int i = k - SN + 1; i < SN; i++) { acc += (int64_t)a.l[i] * b.l[k - i]; acc += (int64_t)c.l[i] * d.l[k - i]; }
+        for (int i = k - SN + 2; i < SN; i++) { part.vv(a.l[i], b.l[k - i]); part.vv(c.l[i], d.l[k - i]); }
 #pragma unroll
-        for (int i = k - SN + 1; i < SN; i++) acc += (int64_t)m[i] * P_[k - i];
+        for (int i = k - SN + 1; i < SN; i++) part.vs(m[i], P_[k - i]);
+        acc += part.v;
         t[k - SN] = (int32_t)((uint32_t)acc & SMASK) - SHALF;
         acc >>= SB;
     }
@@ -256,12 +269,13 @@ FD void fs_sqr(Fs &r, const Fs &a) {
     }
 #pragma unroll
     for (int k = SN; k < 2 * SN - 1; k++) {
-        acc += (int64_t)SHALF;
+        FsChain part(m[k - SN + 1], P_[SN - 1]);         // (started from a reduction product: the last column has no off-diagonal operand product)
 #pragma unroll
-        for (int i = k - SN + 1; 2 * i < k; i++) acc += (int64_t)a.l[i] * a2[k - i];
-        if ((k & 1) == 0) acc += (int64_t)a.l[k / 2] * a.l[k / 2];
+        for (int i = k - SN + 2; i < SN; i++) part.vs(m[i], P_[k - i]);
 #pragma unroll
-        for (int i = k - SN + 1; i < SN; i++) acc += (int64_t)m[i] * P_[k - i];
+        for (int i = k - SN + 1; 2 * i < k; i++) part.vv(a.l[i], a2[k - i]);
+        if ((k & 1) == 0) part.vv(a.l[k / 2], a.l[k / 2]);
+        acc += part.v;
         t[k - SN] = (int32_t)((uint32_t)acc & SMASK) - SHALF;
         acc >>= SB;
     }

@@ -16,6 +16,11 @@ void launch_psort(hipStream_t s, const PsParams &q, uint32_t NB, uint32_t *cnt1,
     // the pair total is known: chunking and heavy-bucket threshold of the accumulation follow from it (dyn_args = {fixed_ch, min_chunk, max_chunks, lanes_per_chunk, T_max})
     if (dyn) launch_dyn_chunk(s, off1 + (size_t)q.P * q.ntiles, dyn_args[0], dyn_args[1], dyn_args[2], dyn_args[3], dyn_args[4], dyn);
     hipLaunchKernelGGL(k_ps_scatter1, dim3(q.ntiles), dim3(PS_TILE), lds3, s, q, (const uint32_t *)cnt1, (const uint32_t *)off1, (uint2 *)pairs);
-    hipLaunchKernelGGL(k_ps_bucket, dim3(q.P), dim3(1024), 0, s, (const uint2 *)pairs, off1, q.ntiles, q.P, NB, q.part_log, off, entries, heavy_thr, heavy, heavy_cap, (const uint32_t *)dyn);
+    // P4 with write combining when the average partition is long (n >= 2^23 at c = 20): decided from the worst-case pair count, the direct path is right for sparse vectors
+    const int wc = ((uint64_t)q.n * (uint64_t)q.W) / q.P >= PS_WC_MIN_PAIRS ? 1 : 0;
+    const size_t lds4 = wc ? (size_t)2 * PS_PART * 4 + (size_t)PS_WC_TILE * 8 : 0;
+    if (wc) { static std::atomic<uint32_t> done4{0}; int dev = 0; (void)hipGetDevice(&dev); const uint32_t bit = 1u << (dev & 31);
+      if (!(done4.load() & bit)) { (void)hipFuncSetAttribute((const void *)k_ps_bucket, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4); done4.fetch_or(bit); } }
+    hipLaunchKernelGGL(k_ps_bucket, dim3(q.P), dim3(1024), lds4, s, (const uint2 *)pairs, off1, q.ntiles, q.P, NB, q.part_log, off, entries, heavy_thr, heavy, heavy_cap, (const uint32_t *)dyn, wc);
 }
 }  // namespace msm

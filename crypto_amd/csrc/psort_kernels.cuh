@@ -128,7 +128,7 @@ __global__ void __launch_bounds__(PS_TILE) k_ps_scatter1(PsParams q, const uint3
 // P4: one block per partition of 2^part_log buckets
 __global__ void __launch_bounds__(1024) k_ps_bucket(const uint2 *__restrict__ pairs, const uint32_t *__restrict__ off1, uint32_t ntiles, uint32_t P, uint32_t NB, int part_log,
                                                     uint32_t *__restrict__ off, uint32_t *__restrict__ entries,
-                                                    uint32_t heavy_thr, uint32_t *__restrict__ heavy, uint32_t heavy_cap, const uint32_t *__restrict__ dyn) {
+                                                    uint32_t heavy_thr, uint32_t *__restrict__ heavy, uint32_t heavy_cap, const uint32_t *__restrict__ dyn, int wc) {
     if (dyn) heavy_thr = dyn[DYN_HEAVY];
     __shared__ uint32_t cnt[PS_PART];
     __shared__ uint32_t wave_tot[17];
@@ -162,12 +162,51 @@ __global__ void __launch_bounds__(1024) k_ps_bucket(const uint2 *__restrict__ pa
     if (j0 + 1 < PB && k0 + 1 < NB) { off[k0 + 1] = e1; if (c1 >= heavy_thr) { uint32_t h = atomicAdd(&heavy[0], 1u); if (h < heavy_cap) heavy[1 + h] = k0 + 1; } }
     if (p == P - 1 && threadIdx.x == 0) off[NB] = hi;
     __syncthreads();
-    for (uint32_t base = lo; base < hi; base += U * 1024) {
-        uint2 pr[U];
+    // Placement.  A partition of a few tens of thousands of pairs (n <= 2^22 at c = 20) keeps its open cache lines — one per bucket cursor — in L2
+    // while the block fills them, and every term goes straight to its slot.  Beyond that the resident blocks hold more open lines than the L2s
+    // do, lines leave half written and come back (the kernel ran 1.9x worse than linear at n = 2^24): there (wc != 0) the pairs are taken in
+    // tiles of PS_WC_TILE, grouped by bucket in LDS, and leave as contiguous runs per bucket (write combining).
+    if (!wc) {
+        for (uint32_t base = lo; base < hi; base += U * 1024) {
+            uint2 pr[U];
 #pragma unroll
-        for (int j = 0; j < U; j++) { const uint32_t k = base + j * 1024 + threadIdx.x; pr[j] = k < hi ? pairs[k] : make_uint2(0xffffffffu, 0u); }
+            for (int j = 0; j < U; j++) { const uint32_t k = base + j * 1024 + threadIdx.x; pr[j] = k < hi ? pairs[k] : make_uint2(0xffffffffu, 0u); }
 #pragma unroll
-        for (int j = 0; j < U; j++) { const bool on = pr[j].x != 0xffffffffu; const uint32_t pos = lds_inc_agg(cnt, pr[j].x & mask, on); if (on) entries[pos] = pr[j].y; }
+            for (int j = 0; j < U; j++) { const bool on = pr[j].x != 0xffffffffu; const uint32_t pos = lds_inc_agg(cnt, pr[j].x & mask, on); if (on) entries[pos] = pr[j].y; }
+        }
+        return;
+    }
+    extern __shared__ __align__(16) uint32_t wc_lds[];
+    uint32_t *lcnt = wc_lds, *lpre = wc_lds + PS_PART;           // per tile: pairs per bucket, their exclusive prefix
+    uint2 *stage = reinterpret_cast<uint2 *>(wc_lds + 2 * PS_PART);   // PS_WC_TILE x (value, slot in entries[])
+    constexpr int V = PS_WC_TILE / 1024;                         // pairs per thread and tile
+    for (uint32_t base = lo; base < hi; base += PS_WC_TILE) {
+        lcnt[2 * threadIdx.x] = 0; lcnt[2 * threadIdx.x + 1] = 0;
+        __syncthreads();
+        uint2 pr[V]; uint32_t rank[V];
+#pragma unroll
+        for (int j = 0; j < V; j++) { const uint32_t k = base + j * 1024 + threadIdx.x; pr[j] = k < hi ? pairs[k] : make_uint2(0xffffffffu, 0u); }
+#pragma unroll
+        for (int j = 0; j < V; j++) rank[j] = lds_inc_agg(lcnt, pr[j].x & mask, pr[j].x != 0xffffffffu);       // position inside the tile's share of its bucket
+        __syncthreads();
+        const uint32_t l0 = lcnt[2 * threadIdx.x], l1 = lcnt[2 * threadIdx.x + 1];
+        const uint32_t ls = l0 + l1;
+        uint32_t li = ls;
+        for (int d = 1; d < 64; d <<= 1) { uint32_t t = __shfl_up(li, d, 64); if ((int)(threadIdx.x & 63) >= d) li += t; }
+        if ((threadIdx.x & 63) == 63) wave_tot[threadIdx.x >> 6] = li;
+        __syncthreads();
+        uint32_t lb = 0;
+        for (uint32_t wv = 0; wv < (threadIdx.x >> 6); wv++) lb += wave_tot[wv];
+        lpre[2 * threadIdx.x] = lb + li - ls; lpre[2 * threadIdx.x + 1] = lb + li - ls + l0;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < V; j++)
+            if (pr[j].x != 0xffffffffu) { const uint32_t bk = pr[j].x & mask; stage[lpre[bk] + rank[j]] = make_uint2(pr[j].y, cnt[bk] + rank[j]); }
+        __syncthreads();
+        cnt[2 * threadIdx.x] += l0; cnt[2 * threadIdx.x + 1] += l1;                      // the cursors move past this tile
+        const uint32_t tile_n = hi - base < (uint32_t)PS_WC_TILE ? hi - base : (uint32_t)PS_WC_TILE;
+        for (uint32_t q = threadIdx.x; q < tile_n; q += 1024) { const uint2 e = stage[q]; entries[e.y] = e.x; }       // neighbours in q are neighbours in a bucket: whole runs per store
+        __syncthreads();
     }
 }
 

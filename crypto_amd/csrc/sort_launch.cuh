@@ -19,6 +19,12 @@ size_t scan_blocks(size_t NB);
 constexpr int PS_TILE = 512;            // scalars per tile = threads per block of P1 / P3
 constexpr int PS_PART_LOG_MAX = 11;     // at most 2048 buckets per partition (P4's LDS histogram)
 constexpr int PS_PART = 1 << PS_PART_LOG_MAX;
+constexpr int PS_WC_TILE = 16384;       // pairs per write-combining tile of P4 (2 x PS_PART counters + 128 KB of staged pairs in LDS)
+#ifdef PS_NO_WC
+constexpr uint32_t PS_WC_MIN_PAIRS = 0xffffffffu;      // (development A/B build: the direct placement at every size)
+#else
+constexpr uint32_t PS_WC_MIN_PAIRS = 65536;
+#endif   // partitions at least this long (on average) take the write-combining path
 constexpr int PS_MAX_W = 16;            // pairs staged per scalar (LDS: PS_TILE * PS_MAX_W * 8 B)
 struct PsParams {
     const uint32_t *scalars;            // n x 8 words, canonical

@@ -40,8 +40,8 @@ R_MOD = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
 G1_GEN_COMPRESSED = "97f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac586c55e83ff97a1aeffb3af00adb22c6bb"
 G2_GEN_COMPRESSED = ("93e02b6052719f607dacd3a088274f65596bd0d09920b61ab5da61bbdc7f5049334cf11213945d57e5ac7d055d042b7e"
                      "024aa2b2f08f0a91260805272dc51051c6e47ad4fa403b02b4510b647ae3d1770bac0326a805bbefd48056c8c121bdb8")
-MADS_PER_MIXED_ADD = 6 * 338 + 507 + 2 * 260     # XYZZ mixed addition over the 13 x 30-bit signed field (fp30s.cuh): 6 products, one fused two-product reduction, 2 squares (round 2, 14 x 29-bit limbs: 3542)
-MADS_PER_G2_MIXED_ADD = 2 * (8 * 507 + 2 * 338)   # the same formula over Fp2 on a lane pair (fs2_pair.cuh): per lane 8 fused two-product reductions + 2 products for the squares (round 2: 10976)
+MADS_PER_MIXED_ADD = 6 * 338 + 507 + 2 * 260     # XYZZ mixed addition over the 13 x 30-bit signed field (fp30s.hip.h): 6 products, one fused two-product reduction, 2 squares (round 2, 14 x 29-bit limbs: 3542)
+MADS_PER_G2_MIXED_ADD = 2 * (8 * 507 + 2 * 338)   # the same formula over Fp2 on a lane pair (fs2_pair.hip.h): per lane 8 fused two-product reductions + 2 products for the squares (round 2: 10976)
 MAD_PEAK = 31.8                                   # Tmad/s, measured v_mad_u64_u32 issue rate (profiles/r01h_instr_rate_ubench.txt)
 
 

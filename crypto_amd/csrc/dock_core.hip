@@ -2,7 +2,7 @@
 // (implements the curve-independent part of include/dock_gpu.h).
 #include "dock_ctx.hpp"
 #include "host_field.hpp"
-#include "qap_launch.cuh"
+#include "qap_launch.hip.h"
 #include <chrono>
 #include <thread>
 

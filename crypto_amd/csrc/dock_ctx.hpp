@@ -38,7 +38,7 @@ struct Buf {
 // 12 = sorted scalars (SortedScalars*).  `ctx` = the device context that owns the allocation;
 // `inflight` = calls currently using it (a free waits for them: no use-after-free when dgpu_*_free races an MSM on the same handle).
 struct Handle { void *p; size_t n; int kind; int ctx; int inflight; };
-struct PreTable { void *tab; size_t n; int c, W; };      // kind 10 / 11: tab[w * n + i] = prepared record of 2^(c w) P_i (pre_kernels.cuh)
+struct PreTable { void *tab; size_t n; int c, W; };      // kind 10 / 11: tab[w * n + i] = prepared record of 2^(c w) P_i (pre_kernels.hip.h)
 struct SortedScalars { void *off, *entries; size_t off_bytes, entries_bytes; size_t n, rows, boff; int c, W; };   // kind 12: the partition sort of n scalars for tables of `rows` rows, width c, first row boff
 struct ShardSet { std::vector<uint64_t> sub; std::vector<size_t> lo; size_t n = 0; };   // sub[k] covers [lo[k], lo[k+1]) (lo has sub.size() + 1 entries)
 struct NttDomain { void *tw_f = nullptr, *tw_i = nullptr, *pw_f = nullptr, *pw_i = nullptr, *zinv = nullptr, *pwr_f = nullptr, *pwr_i = nullptr; };   // pwr_*: pw_* in bit-reversed order   // per log2(D), built once per device

@@ -1,7 +1,7 @@
 // crypto_amd/csrc/dock_fixed.hip — fixed-base batch multiplication entry points of include/dock_gpu.h
 // (WindowTable of utils/src/msm.rs:8-62; FixedBase::msm of legogroth16/src/generator.rs:335-399).
-#include "msm_driver.cuh"
-#include "fixed_launch.cuh"
+#include "msm_driver.hip.h"
+#include "fixed_launch.hip.h"
 using namespace dock;
 
 namespace {

@@ -1,5 +1,5 @@
 // crypto_amd/csrc/dock_g1.hip — BLS12-381 G1 entry points of include/dock_gpu.h (+ the device self-tests).
-#include "msm_driver.cuh"
+#include "msm_driver.hip.h"
 using namespace dock;
 namespace dock {
 // the one-shot pipeline without the size threshold, for callers inside the library (dock_prover.cpp: the g_d MSM of a proof)

@@ -1,5 +1,5 @@
 // crypto_amd/csrc/dock_g2.hip — BLS12-381 G2 entry points of include/dock_gpu.h.
-#include "msm_driver.cuh"
+#include "msm_driver.hip.h"
 using namespace dock;
 
 extern "C" {

@@ -13,14 +13,14 @@
 // Pairs with an identity member contribute the neutral line (1, 0, 0), which is what arkworks' filter amounts to.
 #include "dock_ctx.hpp"
 #include "host_field.hpp"
-#include "pairing29.cuh"
-#include "fp2_pair.cuh"
-#include "sort_launch.cuh"
+#include "pairing29.hip.h"
+#include "fp2_pair.hip.h"
+#include "sort_launch.hip.h"
 #include <thread>
 #include <atomic>
 
 namespace bls29 {
-__device__ __forceinline__ void fhalf(Fp2H &r, const Fp2H &a) { fp_half(r.v, a.v); }   // lane-pair form of pairing29.cuh's halving
+__device__ __forceinline__ void fhalf(Fp2H &r, const Fp2H &a) { fp_half(r.v, a.v); }   // lane-pair form of pairing29.hip.h's halving
 }
 
 namespace {
@@ -62,7 +62,7 @@ __global__ void __launch_bounds__(64) k_miller_lines(const uint32_t *__restrict_
     }
 }
 
-// Lane-pair version of k_miller_lines (fp2_pair.cuh): lanes 2i / 2i+1 hold the c0 / c1 halves of every Fp2 value of pair i,
+// Lane-pair version of k_miller_lines (fp2_pair.hip.h): lanes 2i / 2i+1 hold the c0 / c1 halves of every Fp2 value of pair i,
 // cross terms move over DPP.  Half the registers per lane (no spills, 2 waves/SIMD) and 2 instead of 3 base-field products per
 // Fp2 product on the critical path of the 63 dependent doubling steps.
 __global__ void __launch_bounds__(64) k_miller_lines_pair(const uint32_t *__restrict__ p_abi, const uint32_t *__restrict__ q_abi, const uint8_t *__restrict__ skip, size_t n, uint32_t *__restrict__ lines, size_t stride) {
@@ -239,7 +239,7 @@ __global__ void __launch_bounds__(256) k_lines_from_prepared(const uint32_t *__r
 }
 
 // partial[(s * nsl + j) * F12W + k] = product of the lines of step s over slice j of the pairs (sparse Fp12::mul_by_014 chain).
-// One chain per LANE PAIR (fp2_pair.cuh): the chain is serial, so its duration is the instruction count of one lane, and the pair form
+// One chain per LANE PAIR (fp2_pair.hip.h): the chain is serial, so its duration is the instruction count of one lane, and the pair form
 // of an Fp2 product is one fused two-product reduction per lane instead of two.  Word (2 q + h) * NL + j of an Fp12 is limb j of half h
 // of its q-th Fp2 coefficient — the same order a one-lane Fp12d has in memory.
 typedef Fp6T<Fp2H> Fp6p;
@@ -275,7 +275,7 @@ __global__ void __launch_bounds__(64) k_line_products(const uint32_t *__restrict
 // shortens every level ~5x.  Wave r of the 192-thread block takes role r of the nodes p = (lane >> 1); roles are wave-uniform.
 //   A: operands of node p (slots p and p + h) -> registers            | sync
 //   B: t = Fp6 product; t0 -> slot(p+h).c0, t1 -> slot(p+h).c1, m -> slot(p).c1    | sync
-//   C: role 0: slot(p).c0 = t0 + v t1;  role 1: slot(p).c1 = m - t0 - t1           (f12_mul of pairing29.cuh, step for step)
+//   C: role 0: slot(p).c0 = t0 + v t1;  role 1: slot(p).c1 = m - t0 - t1           (f12_mul of pairing29.hip.h, step for step)
 // out_abi != nullptr: the group result of step s is L_s, written in the ABI form (last level); otherwise it is written back as a
 // partial of the next level: next[(s * ngroups + g) * F12W + k].
 constexpr int F6W = 6 * NL;

@@ -4,7 +4,7 @@
 // handle and be fed straight to dgpu_msm_g1_resident — no D2H/H2D between the transform and the MSM.
 #include "dock_ctx.hpp"
 #include "host_field.hpp"
-#include "qap_launch.cuh"
+#include "qap_launch.hip.h"
 
 namespace {
 using namespace dock;

@@ -1,4 +1,4 @@
-// crypto_amd/csrc/dyn_chunk.cuh — chunking of the bucket accumulation, decided on the device.
+// crypto_amd/csrc/dyn_chunk.hip.h — chunking of the bucket accumulation, decided on the device.
 //
 // The host cannot know how many (bucket, term) pairs an MSM has before the sort has run: zero digits are dropped, so a Groth16 witness (mostly
 // 0 / 1 / small values) leaves a quarter of the n * W pairs of a dense scalar vector.  A chunk length derived from n * W then leaves most of
@@ -9,7 +9,7 @@
 #pragma once
 #include <stdint.h>
 namespace msm {
-constexpr int DYN_CH = 0, DYN_T = 1, DYN_HEAVY = 2, DYN_E = 3, DYN_NMULTI = 4, DYN_MULTI = 5;   // dyn[DYN_MULTI + i]: buckets longer than one fold range (msm_kernels.cuh)
+constexpr int DYN_CH = 0, DYN_T = 1, DYN_HEAVY = 2, DYN_E = 3, DYN_NMULTI = 4, DYN_MULTI = 5;   // dyn[DYN_MULTI + i]: buckets longer than one fold range (msm_kernels.hip.h)
 constexpr uint32_t HEAVY_RANGE = 512;
 inline size_t dyn_words(size_t T) { return DYN_MULTI + T / HEAVY_RANGE + 2; }
 constexpr uint32_t RESIDENT_ACC_LANES = 131072;      // 256 CUs x 4 SIMDs x 2 waves x 64 lanes (k_accumulate: 2 waves per SIMD)

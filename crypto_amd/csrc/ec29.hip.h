@@ -1,5 +1,5 @@
-// crypto_amd/csrc/ec29.cuh — short-Weierstrass (a = 0) group law in extended Jacobian "XYZZ"
-// coordinates over the lazy 29-bit-limb fields of fp29.cuh / fp2_29.cuh.
+// crypto_amd/csrc/ec29.hip.h — short-Weierstrass (a = 0) group law in extended Jacobian "XYZZ"
+// coordinates over the lazy 29-bit-limb fields of fp29.hip.h / fp2_29.hip.h.
 //
 // Device replacement for ark-ec's Projective += Affine / Projective += Projective used inside
 // VariableBaseMSM (third-party ark-ec 0.4; entered from utils/src/pairs.rs:145-155,
@@ -11,8 +11,8 @@
 // 3-instruction necessary condition (fp_maybe_zero) with an exact slow path, so the common path stays
 // wave-uniform.  The identity is carried as an explicit flag next to the coordinates.
 #pragma once
-#include "fp29.cuh"
-#include "fp2_29.cuh"
+#include "fp29.hip.h"
+#include "fp2_29.hip.h"
 
 namespace bls29 {
 
@@ -41,12 +41,12 @@ template <> struct SubM<Fp2> {     // an Fp2 product leaves values < 6 p, so eve
 };
 
 // fnormw: the carry pass for the widest combination of the formulas (R^2 - PPP - 2 Q); the same as fnorm except for fields whose cheap pass
-// has a narrower domain (fp30s.cuh)
+// has a narrower domain (fp30s.hip.h)
 template <class F> FD void fnormw(F &r, const F &a) { fnorm(r, a); }
 
 struct Fp2H;
 struct Fs;
-template <> struct SubM<Fs> {      // signed digits (fp30s.cuh): a subtraction needs no multiple of p; the constants are ignored
+template <> struct SubM<Fs> {      // signed digits (fp30s.hip.h): a subtraction needs no multiple of p; the constants are ignored
     static constexpr int P = 0, R = 0, X = 0, D = 0, Y = 0, YN = 0, NEG = 0;
 };
 template <class F> struct MaddFormulaFirst { static constexpr bool value = true; };

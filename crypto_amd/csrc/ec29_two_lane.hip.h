@@ -1,4 +1,4 @@
-// crypto_amd/csrc/ec29_two_lane.cuh — G1 XYZZ doubling and mixed addition shared by TWO adjacent lanes (device only).
+// crypto_amd/csrc/ec29_two_lane.hip.h — G1 XYZZ doubling and mixed addition shared by TWO adjacent lanes (device only).
 //
 // The batched scalar-multiplication kernels (k_g1_scale: RandomizedPairingChecker's `a.mul_bigint(m)`, utils/src/randomized_pairing_check.rs:125-127;
 // k_mul_add<G1>: the aggregation's folding step) run one dependent chain of 255 doublings + ~128 additions per point and have far fewer
@@ -12,11 +12,11 @@
 //     round 3 (square)               M^2                  -                round 3 (product)            PPP = P PP        Q = X1 PP
 //     round 4 (product)              M (S - X3)           W Y              round 4 (product)            R (Q - X3)        Y1 PPP
 //     round 5 (product)              ZZ' = V ZZ           ZZZ' = W ZZZ     round 5 (product)            ZZ' = ZZ PP       ZZZ' = ZZZ PPP
-// 5 field operations per lane instead of 9 / 10.  Same formulas as ec29.cuh (the group element is what is compared anyway).
+// 5 field operations per lane instead of 9 / 10.  Same formulas as ec29.hip.h (the group element is what is compared anyway).
 #pragma once
-#include "fp29.cuh"
-#include "ec29.cuh"
-#include "fp2_pair.cuh"      // xchg, sel, pair_odd
+#include "fp29.hip.h"
+#include "ec29.hip.h"
+#include "fp2_pair.hip.h"      // xchg, sel, pair_odd
 
 namespace bls29 {
 

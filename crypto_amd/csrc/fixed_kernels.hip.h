@@ -1,4 +1,4 @@
-// crypto_amd/csrc/fixed_kernels.cuh — batched fixed-base scalar multiplication: out_i = s_i * B for one base B.
+// crypto_amd/csrc/fixed_kernels.hip.h — batched fixed-base scalar multiplication: out_i = s_i * B for one base B.
 //
 // Device form of ark-ec's FixedBase::{get_window_table, msm} as the reference uses them: the six query MSMs of the
 // LegoGroth16 CRS generator (legogroth16/src/generator.rs:335-399) and utils/src/msm.rs:8-62 (WindowTable::multiply_many,
@@ -11,9 +11,9 @@
 // The result is the group element s_i * B whatever the window; outputs are compared after normalisation.
 #pragma once
 #include <hip/hip_runtime.h>
-#include "msm_kernels.cuh"
-#include "fp_inv.cuh"
-#include "ec29_two_lane.cuh"
+#include "msm_kernels.hip.h"
+#include "fp_inv.hip.h"
+#include "ec29_two_lane.hip.h"
 
 namespace msm {
 
@@ -137,7 +137,7 @@ __global__ void __launch_bounds__(64) k_mul_add(const uint32_t *__restrict__ p_a
 }
 
 
-// G2 form of k_mul_add on lane pairs (fp2_pair.cuh): lanes 2i and 2i+1 share point i, the even lane holds the c0 halves, the odd lane the
+// G2 form of k_mul_add on lane pairs (fp2_pair.hip.h): lanes 2i and 2i+1 share point i, the even lane holds the c0 halves, the odd lane the
 // c1 halves.  The kernel is latency-bound (one dependent chain of ~255 doublings per point whatever n), and a lane pair runs that chain in
 // about half the instructions per lane of the one-lane Fp2 version.
 __global__ void __launch_bounds__(64) k_mul_add_g2_pair(const uint32_t *__restrict__ p_abi, const uint8_t *__restrict__ p_inf, const uint32_t *__restrict__ scalars, int scalar_stride,
@@ -175,7 +175,7 @@ __global__ void __launch_bounds__(64) k_mul_add_g2_pair(const uint32_t *__restri
 }
 
 
-// G1 form of k_mul_add with two adjacent lanes per point (ec29_two_lane.cuh): both lanes hold the point and take one field operation of
+// G1 form of k_mul_add with two adjacent lanes per point (ec29_two_lane.hip.h): both lanes hold the point and take one field operation of
 // every round of the doubling / mixed addition, results swapped over DPP: 5 field operations per lane and step instead of 9 / 10.
 template <class DUMMY>
 __global__ void __launch_bounds__(64) k_mul_add_g1_2l(const uint32_t *__restrict__ p_abi, const uint8_t *__restrict__ p_inf, const uint32_t *__restrict__ scalars, int scalar_stride,
@@ -212,7 +212,7 @@ __global__ void __launch_bounds__(64) k_mul_add_g1_2l(const uint32_t *__restrict
 
 
 // G2 form of k_mul_add with FOUR lanes per point: the two lane pairs of a quad both hold the point (halves on the lanes of a pair,
-// fp2_pair.cuh) and share every doubling / mixed addition (ec29_two_lane.cuh, Share4): 5 Fp2 operations per pair and step instead of 9 / 10.
+// fp2_pair.hip.h) and share every doubling / mixed addition (ec29_two_lane.hip.h, Share4): 5 Fp2 operations per pair and step instead of 9 / 10.
 template <class DUMMY>
 __global__ void __launch_bounds__(64) k_mul_add_g2_quad(const uint32_t *__restrict__ p_abi, const uint8_t *__restrict__ p_inf, const uint32_t *__restrict__ scalars, int scalar_stride,
                                                         const uint32_t *__restrict__ add_abi, const uint8_t *__restrict__ add_inf, size_t n, uint32_t *__restrict__ out_abi, uint8_t *__restrict__ out_inf) {

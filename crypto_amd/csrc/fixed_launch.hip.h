@@ -1,4 +1,4 @@
-// crypto_amd/csrc/fixed_launch.cuh — host-callable launchers of the fixed-base kernels (k_fixed.hip).
+// crypto_amd/csrc/fixed_launch.hip.h — host-callable launchers of the fixed-base kernels (k_fixed.hip).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stddef.h>

@@ -1,4 +1,4 @@
-// crypto_amd/csrc/fp29.cuh — BLS12-381 base field for gfx950, carry-free lazy representation.
+// crypto_amd/csrc/fp29.hip.h — BLS12-381 base field for gfx950, carry-free lazy representation.
 //
 // Replaces (on the device) what the reference reaches as ark_ff::Fp<MontBackend<FqConfig,6>,6>
 // (third-party ark-ff 0.4; call sites e.g. legogroth16/src/prover.rs:286 via G1::msm_bigint).
@@ -360,7 +360,7 @@ FD void fp_to_abi(uint32_t w[12], const Fp &a) {
     for (int i = 0; i < 12; i++) w[i] = o[i];
 }
 
-// ---- uniform spellings used by the field-generic group law (ec29.cuh) ----
+// ---- uniform spellings used by the field-generic group law (ec29.hip.h) ----
 FD void fzero(Fp &r) { fp_zero(r); }
 FD void fset_one(Fp &r) { fp_set_one(r); }
 FD void fadd(Fp &r, const Fp &a, const Fp &b) { fp_add(r, a, b); }

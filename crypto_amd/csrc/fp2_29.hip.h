@@ -1,9 +1,9 @@
-// crypto_amd/csrc/fp2_29.cuh — Fp2 = Fp[u]/(u^2 + 1) over the lazy 29-bit-limb base field (fp29.cuh).
+// crypto_amd/csrc/fp2_29.hip.h — Fp2 = Fp[u]/(u^2 + 1) over the lazy 29-bit-limb base field (fp29.hip.h).
 // Device counterpart of ark_ff::Fp2<Fq2Config> as used by G2 (ark-bls12-381 0.4; reached from
 // legogroth16/src/prover.rs:344 `b_g2_query` MSM and the Miller loop, utils/src/randomized_pairing_check.rs:207).
 // ABI order of components: c0 then c1.
 #pragma once
-#include "fp29.cuh"
+#include "fp29.hip.h"
 
 namespace bls29 {
 

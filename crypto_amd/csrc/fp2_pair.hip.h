@@ -1,4 +1,4 @@
-// crypto_amd/csrc/fp2_pair.cuh — Fp2 arithmetic spread over a LANE PAIR (device only).
+// crypto_amd/csrc/fp2_pair.hip.h — Fp2 arithmetic spread over a LANE PAIR (device only).
 //
 // An XYZZ accumulator over Fp2 is 112 registers and the fully inlined mixed addition needs > 256 VGPRs, so the
 // one-lane-per-point G2 kernel runs at one wave per SIMD with spills (25 ms for n = 2^20, 7x G1).  Here lanes 2k and
@@ -10,8 +10,8 @@
 //     (a0 + a1 u)^2          = (a0 + a1)(a0 - a1) + 2 a0 a1 u
 // Both lanes of a pair always follow the same control flow (same terms, same run boundaries).
 #pragma once
-#include "fp29.cuh"
-#include "ec29.cuh"
+#include "fp29.hip.h"
+#include "ec29.hip.h"
 
 namespace bls29 {
 
@@ -73,7 +73,7 @@ __device__ __forceinline__ void fsqr(Fp2H &r, const Fp2H &a) {
 template <int M> __device__ __forceinline__ void fmul_sub(Fp2H &r, const Fp2H &a, const Fp2H &b, const Fp2H &c, const Fp2H &d) {
     Fp2H t, u; fmul(t, a, b); fmul(u, c, d); fsub<8>(t, t, u); fnorm(r, t);
 }
-// ---- helpers used by the Miller-loop line functions (pairing29.cuh), lane-pair versions ----
+// ---- helpers used by the Miller-loop line functions (pairing29.hip.h), lane-pair versions ----
 template <int M> __device__ __forceinline__ void f2_sqr_m(Fp2H &r, const Fp2H &a) {
     const bool odd = pair_odd();
     Fp ao, s, d, m1, m2, p, p2;

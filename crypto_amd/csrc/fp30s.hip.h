@@ -1,6 +1,6 @@
-// crypto_amd/csrc/fp30s.cuh — BLS12-381 base field for the G1 MSM kernels: 13 SIGNED limbs of 30 bits.
+// crypto_amd/csrc/fp30s.hip.h — BLS12-381 base field for the G1 MSM kernels: 13 SIGNED limbs of 30 bits.
 //
-// Same design rules as fp29.cuh (one multiply-add per limb product into a 64-bit column accumulator, lazy additions, no conditional
+// Same design rules as fp29.hip.h (one multiply-add per limb product into a 64-bit column accumulator, lazy additions, no conditional
 // subtraction, no carry chain on the hot path), different radix: 13 x 30 = 390 bits hold p (381 bits) with 9 bits to spare, so a Montgomery
 // product is 2 * 13^2 = 338 v_mad_i64_i32 instead of 2 * 14^2 = 392 v_mad_u64_u32 (-13.8 %), 25 column hand-offs instead of 27.  What makes
 // 30-bit limbs fit a 64-bit accumulator is the SIGN: digits are kept balanced, |d| <= 2^29, so a column of 13 operand products + 13
@@ -18,7 +18,7 @@
 // independently of the data and asserted against the preconditions: one execution of a formula proves it overflow-free for all inputs of
 // the same classes (tests/test_device_code_on_host.py).
 #pragma once
-#include "fp29.cuh"
+#include "fp29.hip.h"
 
 namespace bls29 {
 
@@ -403,7 +403,7 @@ FD void fs_from_fp(Fs &r, const Fp &a) {
     fs_bal(r, u);
 }
 
-// ---- uniform spellings used by the field-generic group law (ec29.cuh) ----
+// ---- uniform spellings used by the field-generic group law (ec29.hip.h) ----
 FD void fzero(Fs &r) { fs_zero(r); }
 FD void fset_one(Fs &r) { fs_set_one(r); }
 FD void fadd(Fs &r, const Fs &a, const Fs &b) { fs_add(r, a, b); }

@@ -1,18 +1,18 @@
-// crypto_amd/csrc/fp_inv.cuh — field inversion on the device and XYZZ -> affine.
+// crypto_amd/csrc/fp_inv.hip.h — field inversion on the device and XYZZ -> affine.
 //
 // Only the per-element outputs need it: G::normalize_batch after FixedBase::msm (legogroth16/src/generator.rs:424-431),
 // the affine points the Miller loop consumes after RandomizedPairingChecker's scalings
 // (utils/src/randomized_pairing_check.rs:125-127).  One inversion per lane.
 #pragma once
-#include "fp29.cuh"
-#include "fp_safegcd.cuh"
-#include "fp2_29.cuh"
-#include "ec29.cuh"
-#include "fp2_pair.cuh"
+#include "fp29.hip.h"
+#include "fp_safegcd.hip.h"
+#include "fp2_29.hip.h"
+#include "ec29.hip.h"
+#include "fp2_pair.hip.h"
 
 namespace bls29 {
 
-// one inversion per lane: Bernstein-Yang division steps (fp_safegcd.cuh), ~37 k instructions against ~250 k of the Fermat power a^(p-2)
+// one inversion per lane: Bernstein-Yang division steps (fp_safegcd.hip.h), ~37 k instructions against ~250 k of the Fermat power a^(p-2)
 __device__ __forceinline__ void fp_inv_device(Fp &r, const Fp &a) { fp_inv_safegcd(r, a); }
 __device__ __forceinline__ void finv(Fp &r, const Fp &a) { fp_inv_device(r, a); }
 // 1 / (c0 + c1 u) = (c0 - c1 u) / (c0^2 + c1^2)

@@ -1,4 +1,4 @@
-// crypto_amd/csrc/fp_safegcd.cuh — inversion in Fq by Bernstein–Yang division steps ("safegcd", ePrint 2019/266), host + device.
+// crypto_amd/csrc/fp_safegcd.hip.h — inversion in Fq by Bernstein–Yang division steps ("safegcd", ePrint 2019/266), host + device.
 //
 // The per-element outputs of the batched scalar-multiplication kernels end in ONE field inversion per lane (XYZZ -> affine:
 // `into_affine` / `normalize_batch` in the reference, legogroth16/src/generator.rs:424-431, utils/src/randomized_pairing_check.rs:125-127,
@@ -12,9 +12,9 @@
 // d = 381 bits).  Steps are taken 29 at a time on the low limbs only (the next 29 steps depend on nothing else), which yields a 2 x 2
 // integer matrix t with (f', g') = t (f, g) / 2^29; the same matrix is applied to (d, e), kept modulo p with d a = f, e a = g (mod p),
 // the exact division by 2^29 done by first adding the multiple of p that clears the low limb.  At the end d = +-1 / a.
-// f, g, d, e: 14 signed limbs of 29 bits (limbs 0..12 in [0, 2^29), limb 13 carries the sign) — the limb width of fp29.cuh.
+// f, g, d, e: 14 signed limbs of 29 bits (limbs 0..12 in [0, 2^29), limb 13 carries the sign) — the limb width of fp29.hip.h.
 #pragma once
-#include "fp29.cuh"
+#include "fp29.hip.h"
 
 namespace bls29 {
 
@@ -91,7 +91,7 @@ FD void sg_fix(SgInt &x, bool negate, bool add_p) {
     x.l[NL - 1] = ((x.l[NL - 1] ^ n) - n) + ((int32_t)P_[NL - 1] & m) + c;
 }
 
-// r = 1 / a in the Montgomery domain of fp29.cuh (a 2^406 -> a^-1 2^406); 0 -> 0 like the Fermat power.  Any lazy class of a.
+// r = 1 / a in the Montgomery domain of fp29.hip.h (a 2^406 -> a^-1 2^406); 0 -> 0 like the Fermat power.  Any lazy class of a.
 FD void fp_inv_safegcd(Fp &r, const Fp &a) {
     BLS29_DECL_P;
     Fp ac; fp_canon(ac, a);

@@ -1,4 +1,4 @@
-// crypto_amd/csrc/fr29.cuh — BLS12-381 scalar field Fr for gfx950, same carry-free scheme as fp29.cuh.
+// crypto_amd/csrc/fr29.hip.h — BLS12-381 scalar field Fr for gfx950, same carry-free scheme as fp29.hip.h.
 //
 // Device counterpart of ark_bls12_381::Fr (ark-ff Fp<MontBackend<FrConfig,4>,4>) for the R1CS -> QAP witness map
 // (/root/reference/legogroth16/src/r1cs_to_qap.rs:150-210: sparse A z, B z, C z; 3 iFFT + 3 coset FFT; (ab - c)/Z; coset iFFT).

@@ -1,12 +1,12 @@
-// crypto_amd/csrc/fs2_pair.cuh — Fp2 = Fp[u]/(u^2 + 1) over the 13 x 30-bit signed base field (fp30s.cuh), for the G2 MSM kernels:
+// crypto_amd/csrc/fs2_pair.hip.h — Fp2 = Fp[u]/(u^2 + 1) over the 13 x 30-bit signed base field (fp30s.hip.h), for the G2 MSM kernels:
 //   Fs2   one lane per element (base preparation and the table construction, where a lane owns whole points), and
 //   Fs2H  one element per LANE PAIR (accumulation, fix-up, bucket reduction): the even lane holds every c0 component, the odd lane every c1
-//         component, cross terms travel over DPP quad_perm — the layout of fp2_pair.cuh, which stays the pairing kernels' field.
+//         component, cross terms travel over DPP quad_perm — the layout of fp2_pair.hip.h, which stays the pairing kernels' field.
 // A product is two fused two-product reductions (fs_mul2: 507 multiply-adds each, 588 over the 14 x 29-bit field), a square two products.
-// Signed digits make the formulas shorter than their fp2_pair.cuh counterparts: -a1 is 13 negations (no multiple of p, no carry pass).
+// Signed digits make the formulas shorter than their fp2_pair.hip.h counterparts: -a1 is 13 negations (no multiple of p, no carry pass).
 #pragma once
-#include "fp30s.cuh"
-#include "ec29.cuh"
+#include "fp30s.hip.h"
+#include "ec29.hip.h"
 
 namespace bls29 {
 

@@ -319,7 +319,7 @@ static inline void glv_decompose(const uint64_t k_in[4], uint64_t k1[2], uint64_
 
 // Base-|x| digits of k mod r, x = -0xd201000000010000 the BLS parameter: k = d0 + d1 |x| + d2 |x|^2 + d3 |x|^3, d0..d2 < |x|,
 // d3 = floor(k / |x|^3) < 2^64 (r < 2^255, |x|^3 > 2^191).  On the prime-order subgroup of the twist |x|^j P = (-psi)^j (P), so the
-// four 64-bit chains of k_mul_add_g2_gls replace one 255-bit chain (Galbraith-Lin-Scott decomposition; fixed_kernels.cuh).
+// four 64-bit chains of k_mul_add_g2_gls replace one 255-bit chain (Galbraith-Lin-Scott decomposition; fixed_kernels.hip.h).
 static inline void gls4_decompose(const uint64_t k_in[4], uint64_t d[4]) {
     static constexpr uint64_t RM[4] = {0xffffffff00000001ULL, 0x53bda402fffe5bfeULL, 0x3339d80809a1d805ULL, 0x73eda753299d7d48ULL};
     uint64_t k[4] = {k_in[0], k_in[1], k_in[2], k_in[3]};

@@ -1,7 +1,7 @@
 // crypto_amd/csrc/k_fixed.hip — translation unit of the fixed-base kernels (G1 and G2).
 #include <cstdlib>
-#include "fixed_kernels.cuh"
-#include "fixed_launch.cuh"
+#include "fixed_kernels.hip.h"
+#include "fixed_launch.hip.h"
 
 namespace msm {
 static_assert(FIXED_TABLE_ENTRIES == FB_ENTRIES, "table size");

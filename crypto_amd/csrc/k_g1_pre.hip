@@ -1,6 +1,6 @@
 // crypto_amd/csrc/k_g1_pre.hip — G1 precomputed-multiples table kernels
-#include "pre_kernels.cuh"
-#include "msm_launch.cuh"
+#include "pre_kernels.hip.h"
+#include "msm_launch.hip.h"
 namespace msm {
 template <class C> void launch_pre_step(hipStream_t s, const uint32_t *prev, size_t n, int c, uint32_t *tmp, uint32_t *out) {
     hipLaunchKernelGGL((k_pre_dbl<typename C::MSM>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, prev, n, c, tmp);

@@ -1,5 +1,5 @@
 // crypto_amd/csrc/k_g1_red.hip — G1 fix-up and bucket-reduction kernels
-#include "msm_launch_impl.cuh"
+#include "msm_launch_impl.hip.h"
 namespace msm {
 template void launch_fixup<G1>(hipStream_t, uint32_t, uint32_t *, uint8_t *, const uint32_t *, const uint32_t *, const uint32_t *, const uint32_t *, const uint8_t *, size_t, const uint32_t *, uint32_t, const uint32_t *);
 template void launch_fixup_heavy<G1>(hipStream_t, const uint32_t *, uint32_t, const uint32_t *, uint32_t, uint32_t, uint32_t *, uint8_t *, const uint32_t *, const uint32_t *, const uint8_t *, size_t, uint32_t *, uint32_t *, uint8_t *);

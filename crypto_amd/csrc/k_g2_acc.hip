@@ -1,5 +1,5 @@
 // crypto_amd/csrc/k_g2_acc.hip — G2 base preparation + chunked bucket accumulation kernels
-#include "msm_launch_impl.cuh"
+#include "msm_launch_impl.hip.h"
 namespace msm {
 template void launch_prep_bases<G2>(hipStream_t, const uint32_t *, const uint8_t *, size_t, uint32_t *);
 template void launch_prep_bases_fp<G2>(hipStream_t, const uint32_t *, const uint8_t *, size_t, uint32_t *);

@@ -1,7 +1,7 @@
 // crypto_amd/csrc/k_ntt.hip — translation unit of the Fr NTT / witness-map kernels.
 #include <atomic>
-#include "ntt_kernels.cuh"
-#include "qap_launch.cuh"
+#include "ntt_kernels.hip.h"
+#include "qap_launch.hip.h"
 #include <cstdlib>
 #include <cstdio>
 namespace ntt {

@@ -1,7 +1,7 @@
-// crypto_amd/csrc/k_psort.hip — translation unit of the two-level partition sort (psort_kernels.cuh)
+// crypto_amd/csrc/k_psort.hip — translation unit of the two-level partition sort (psort_kernels.hip.h)
 #include <atomic>
-#include "psort_kernels.cuh"
-#include "sort_launch.cuh"
+#include "psort_kernels.hip.h"
+#include "sort_launch.hip.h"
 
 namespace msm {
 void launch_psort(hipStream_t s, const PsParams &q, uint32_t NB, uint32_t *cnt1, uint32_t *off1, uint32_t *bsums, void *pairs, uint32_t *off, uint32_t *entries,

@@ -1,6 +1,6 @@
 // crypto_amd/csrc/k_sort.hip — translation unit of the curve-independent kernels (digits, counting sort, scan, self-tests).
-#include "sort_kernels.cuh"
-#include "sort_launch.cuh"
+#include "sort_kernels.hip.h"
+#include "sort_launch.hip.h"
 
 namespace msm {
 void launch_digit_codes(hipStream_t s, bool wide, const uint32_t *scalars, const uint32_t *bases, int aff_stride, int flag_word, size_t n, size_t n_pad, int c, int W, void *dig, uint32_t *bad) {

@@ -1,13 +1,13 @@
-// crypto_amd/csrc/msm_driver.cuh — host driver of the MSM pipeline (templated on the curve), included by
+// crypto_amd/csrc/msm_driver.hip.h — host driver of the MSM pipeline (templated on the curve), included by
 // dock_g1.hip and dock_g2.hip so the two curves compile in parallel.
 #pragma once
 #include <chrono>
 #include <thread>
 #include "dock_ctx.hpp"
 #include "host_field.hpp"
-#include "msm_launch.cuh"
-#include "sort_launch.cuh"
-#include "qap_launch.cuh"
+#include "msm_launch.hip.h"
+#include "sort_launch.hip.h"
+#include "qap_launch.hip.h"
 
 namespace dock {
 using namespace msm;
@@ -113,7 +113,7 @@ template <class C> int32_t plain_geometry(size_t n, PlainGeom &g) {
     g.rb_log = 0; while ((1u << g.rb_log) < g.B / g.RANGES) g.rb_log++;
     g.sort_grid = (unsigned)(8 * ((g.W + 7) / 8) * g.RANGES);
     g.lds_bytes = ((size_t)1 << g.rb_log) * 4;
-    // chunk length / heavy-bucket threshold of the accumulation are fixed on the device once the pair count is known (dyn_chunk.cuh): CH and T
+    // chunk length / heavy-bucket threshold of the accumulation are fixed on the device once the pair count is known (dyn_chunk.hip.h): CH and T
     // only size the launch and the partial slots
     g.min_chunk = C::NFP == 2 ? 32u : 16u; g.max_chunks = C::NFP == 2 ? 150000u : 300000u; g.lanes_per_chunk = C::NFP == 2 ? 2u : 1u;
     // a heavy bucket has >= 16 chunk lengths of terms and a chunk is never shorter than 16 terms (k_dyn_chunk, forced_chunk), whatever min_chunk says
@@ -217,7 +217,7 @@ int32_t msm_device(Slot &sl, const uint32_t *d_bases, const uint32_t *d_scalars,
     HIPCHK(hipStreamSynchronize(s));
     auto tsync1 = std::chrono::steady_clock::now();
     if (gs.prof) prof_flush(sl);
-    if (hbad) return DGPU_E_BADARG;                  // a scalar >= 2^255 (sort_kernels.cuh k_digit_codes)
+    if (hbad) return DGPU_E_BADARG;                  // a scalar >= 2^255 (sort_kernels.hip.h k_digit_codes)
     host_fold<HF>(hwin.data(), hinf.data(), W, c, out_xyz);
     if (gs.prof) {
         auto t2 = std::chrono::steady_clock::now();
@@ -245,7 +245,7 @@ template <class F> int32_t run_shards(size_t parts, F body) {
     for (int32_t rc : rcs) if (rc) return rc;
     return DGPU_OK;
 }
-// ---- shared-bucket-set pipeline over a precomputed-multiples table (pre_kernels.cuh, psort_kernels.cuh) ------------------------------------
+// ---- shared-bucket-set pipeline over a precomputed-multiples table (pre_kernels.hip.h, psort_kernels.hip.h) ------------------------------------
 
 // Window width of a table for n bases (measured, tests/perf/pre_perf.py at 2^16 .. 2^21, profiles/r02a_table_sizes.txt): 20 bits from
 // 2^17.5 terms on (W = 13: fewer additions, and runs short enough that few buckets are cut by chunk borders), 16 bits for 2^15 .. 2^17.5
@@ -340,7 +340,7 @@ int32_t pre_sort(Slot &sl, const PreTable &pt, const PreGeom &g, size_t boff, co
     int32_t rc;
     if ((rc = ws_pre<C>(sl, pt, g, n))) return rc;
     q.bad = sl.flags.as<uint32_t>();
-    const uint32_t heavy_thr = dyn ? 16u * (uint32_t)g.CH /* replaced on the device, dyn_chunk.cuh */ : 0xffffffffu /* nothing flagged */;
+    const uint32_t heavy_thr = dyn ? 16u * (uint32_t)g.CH /* replaced on the device, dyn_chunk.hip.h */ : 0xffffffffu /* nothing flagged */;
     const uint32_t dyn_args[5] = {(uint32_t)forced_chunk(), g.min_chunk, g.max_chunks, g.lanes_per_chunk, (uint32_t)g.T};
     StageTimer st(sl, "msm.psort");
     HIPCHK(hipMemsetAsync(sl.heavy.p, 0, 4, sl.stream));
@@ -396,7 +396,7 @@ int32_t pre_tail(Slot &sl, const PreTable &pt, const PreGeom &g, const uint32_t 
     HIPCHK(hipStreamSynchronize(s));
     auto tsync1 = std::chrono::steady_clock::now();
     if (gs.prof) prof_flush(sl);
-    if (hbad) return DGPU_E_BADARG;                  // a scalar >= 2^255 (sort_kernels.cuh k_digit_codes)
+    if (hbad) return DGPU_E_BADARG;                  // a scalar >= 2^255 (sort_kernels.hip.h k_digit_codes)
     host_fold_shared<HF>(hwin.data(), hinf.data(), hwin.data() + (size_t)PW * 2 * C::ABI_W, hinf.data() + PW, PW, g.lb, out_xyz);
     if (gs.prof) {
         auto t2 = std::chrono::steady_clock::now();
@@ -450,7 +450,7 @@ inline int32_t scalars_sort(uint64_t table, size_t boff, uint64_t scalars, size_
     *sorted = register_handle(ss, n, 12);
     return DGPU_OK;
 }
-// row_shift > 0: the table holds the points of rows row_shift .. rows - 1 of the shape the list was sorted for (RowMap, msm_kernels.cuh)
+// row_shift > 0: the table holds the points of rows row_shift .. rows - 1 of the shape the list was sorted for (RowMap, msm_kernels.hip.h)
 template <class C, class HF>
 int32_t msm_sorted(uint64_t table, uint64_t sorted, size_t row_shift, uint64_t *out, int kind) {
     if (!out) return DGPU_E_BADARG;

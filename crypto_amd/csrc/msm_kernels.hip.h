@@ -1,4 +1,4 @@
-// crypto_amd/csrc/msm_kernels.cuh — Pippenger bucket MSM for gfx950, written for the chip rather than
+// crypto_amd/csrc/msm_kernels.hip.h — Pippenger bucket MSM for gfx950, written for the chip rather than
 // translated from arkworks' rayon loop (ark-ec 0.4 VariableBaseMSM::msm_bigint_wnaf; the
 // reference enters it at utils/src/pairs.rs:145-155 and legogroth16/src/prover.rs:286,299,592).
 //
@@ -22,14 +22,14 @@
 // Any c, any chunking and any order of additions give the same group element; only the projective
 // representative differs, and the ABI returns the normalised one.
 #pragma once
-#include "dyn_chunk.cuh"
+#include "dyn_chunk.hip.h"
 #include <hip/hip_runtime.h>
-#include "fp29.cuh"
-#include "fp2_29.cuh"
-#include "ec29.cuh"
-#include "fp2_pair.cuh"
-#include "fp30s.cuh"
-#include "fs2_pair.cuh"
+#include "fp29.hip.h"
+#include "fp2_29.hip.h"
+#include "ec29.hip.h"
+#include "fp2_pair.hip.h"
+#include "fp30s.hip.h"
+#include "fs2_pair.hip.h"
 #include <type_traits>
 
 namespace msm {
@@ -41,7 +41,7 @@ struct G1;
 struct G1S;
 struct G2;
 struct G2P;
-// G1 over the 13 x 30-bit signed field (fp30s.cuh): the curve description the MSM pipeline instantiates for G1 (G1::MSM).  Records keep the
+// G1 over the 13 x 30-bit signed field (fp30s.hip.h): the curve description the MSM pipeline instantiates for G1 (G1::MSM).  Records keep the
 // strides of the 14 x 29-bit form (128-byte base records with the identity flag in word 28); an XYZZ record is 52 words.
 struct G1S {
     typedef Fs F;
@@ -97,7 +97,7 @@ struct G2 {
     static constexpr int XW = 4 * FW;
     static constexpr int HEAVY_T = 128;
     static constexpr int LPP = 1;
-    typedef G2P ACC;                         // k_accumulate runs the lane-pair formulation (fp2_pair.cuh)
+    typedef G2P ACC;                         // k_accumulate runs the lane-pair formulation (fp2_pair.hip.h)
     static constexpr int ACC_WAVES = 2;
 };
 // G2 with one point per lane pair: the even lane holds the c0 halves, the odd lane the c1 halves
@@ -580,7 +580,7 @@ __global__ void __launch_bounds__(64) k_reduce_top(const uint32_t *__restrict__ 
 }
 
 
-// ---- K7/K8 for G2 on lane pairs (fp2_pair.cuh) ---------------------------------------------------------------------------------
+// ---- K7/K8 for G2 on lane pairs (fp2_pair.hip.h) ---------------------------------------------------------------------------------
 // Same group geometry and l1 layout as k_reduce_l0 / k_reduce_top, but a point lives on a lane pair (even lane: c0 halves, odd lane: c1
 // halves), so a wave holds 32 points and every point-lane takes twice the items.  The one-lane Fp2 addition needs > 256 VGPRs (spills)
 // and is ~3x the instructions of a half: the pair form runs the same dependent chain in about half the time (3.0 -> 1.6 ms at 2^20).

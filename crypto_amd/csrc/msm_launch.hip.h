@@ -1,8 +1,8 @@
-// crypto_amd/csrc/msm_launch.cuh — host-callable launchers of the MSM kernels.  The kernels are compiled in their own
+// crypto_amd/csrc/msm_launch.hip.h — host-callable launchers of the MSM kernels.  The kernels are compiled in their own
 // translation units (k_*.hip, one per curve and stage, built in parallel); the drivers only see these declarations.
 #pragma once
 #include <hip/hip_runtime.h>
-#include "msm_kernels.cuh"
+#include "msm_kernels.hip.h"
 
 namespace msm {
 
@@ -21,7 +21,7 @@ template <class C> void launch_fixup_heavy(hipStream_t s, const uint32_t *heavy,
 template <class C> void launch_reduce_l0(hipStream_t s, unsigned NG, const uint32_t *bucket, const uint8_t *bucket_inf, uint32_t NB, int mshift, uint32_t *l1, uint8_t *l1_inf);
 template <class C> void launch_reduce_top(hipStream_t s, unsigned W, const uint32_t *l1, const uint8_t *l1_inf, int G, int gshift, uint32_t *win_abi, uint8_t *win_inf);
 
-// precomputed-multiples tables (pre_kernels.cuh; k_g1_pre.hip / k_g2_pre.hip)
+// precomputed-multiples tables (pre_kernels.hip.h; k_g1_pre.hip / k_g2_pre.hip)
 template <class C> void launch_pre_step(hipStream_t s, const uint32_t *prev, size_t n, int c, uint32_t *tmp, uint32_t *out);
 // reduce_top that also hands back the plain sum S of every pseudo-window (win_s_abi / win_s_inf), for the shared-bucket-set fold
 template <class C> void launch_reduce_top_s(hipStream_t s, unsigned W, const uint32_t *l1, const uint8_t *l1_inf, int G, int gshift, uint32_t *win_abi, uint8_t *win_inf, uint32_t *win_s_abi, uint8_t *win_s_inf);

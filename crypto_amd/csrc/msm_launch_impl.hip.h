@@ -1,7 +1,7 @@
-// crypto_amd/csrc/msm_launch_impl.cuh — definitions of the per-curve launchers; included by the kernel translation
+// crypto_amd/csrc/msm_launch_impl.hip.h — definitions of the per-curve launchers; included by the kernel translation
 // units, which explicitly instantiate the ones they own.
 #pragma once
-#include "msm_launch.cuh"
+#include "msm_launch.hip.h"
 
 namespace msm {
 // the launchers take the curve as the driver names it (G1 / G2) and instantiate the kernels for the description the MSM pipeline runs it as
@@ -12,7 +12,7 @@ template <class C> void launch_prep_bases(hipStream_t s, const uint32_t *abi, co
 template <class C> void launch_prep_bases_raw(hipStream_t s, const uint8_t *raw, size_t stride, size_t x_off, size_t y_off, size_t inf_off, const uint8_t *is_inf, size_t n, uint32_t *out) {
     hipLaunchKernelGGL((k_prep_bases_raw<typename C::MSM>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, raw, stride, x_off, y_off, inf_off, is_inf, n, out);
 }
-// base records in the 14 x 29-bit form, for the fixed-base kernels (fixed_kernels.cuh), which run G1 over Fp
+// base records in the 14 x 29-bit form, for the fixed-base kernels (fixed_kernels.hip.h), which run G1 over Fp
 template <class C> void launch_prep_bases_fp(hipStream_t s, const uint32_t *abi, const uint8_t *is_inf, size_t n, uint32_t *out) {
     hipLaunchKernelGGL((k_prep_bases<C>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, abi, is_inf, n, out);
 }

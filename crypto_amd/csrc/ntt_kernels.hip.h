@@ -1,4 +1,4 @@
-// crypto_amd/csrc/ntt_kernels.cuh — NTT over Fr (radix-4 passes through LDS) and the R1CS -> QAP witness map for gfx950.
+// crypto_amd/csrc/ntt_kernels.hip.h — NTT over Fr (radix-4 passes through LDS) and the R1CS -> QAP witness map for gfx950.
 //
 // Device side of LibsnarkReduction::witness_map_from_matrices (/root/reference/legogroth16/src/r1cs_to_qap.rs:150-210,
 // ark-poly Radix2EvaluationDomain semantics):
@@ -13,7 +13,7 @@
 // the buffer addressing of the main kernel), k_ntt_r4 (everything else).
 #pragma once
 #include <hip/hip_runtime.h>
-#include "fr29.cuh"
+#include "fr29.hip.h"
 
 namespace ntt {
 using namespace fr29;

@@ -1,5 +1,5 @@
-// crypto_amd/csrc/pairing29.cuh — Fp6 / Fp12 tower and BLS12-381 Miller-loop line functions over the lazy 29-bit-limb
-// field (fp29.cuh / fp2_29.cuh), host+device.
+// crypto_amd/csrc/pairing29.hip.h — Fp6 / Fp12 tower and BLS12-381 Miller-loop line functions over the lazy 29-bit-limb
+// field (fp29.hip.h / fp2_29.hip.h), host+device.
 //
 // Device side of `Bls12_381::multi_miller_loop` (ark-ec 0.4 models/bls12/{mod,g2}.rs; the reference
 // enters it at utils/src/randomized_pairing_check.rs:207 and legogroth16/src/verifier.rs:69-76).  The line
@@ -11,9 +11,9 @@
 // All functions take and return class-N elements (limbs <= 2^29+7); value bounds are carried by the FP29_CHECK
 // build (tests/test_device_code_on_host.py) which proves the chosen subtraction multiples are sufficient.
 #pragma once
-#include "fp29.cuh"
-#include "fp2_29.cuh"
-#include "ec29.cuh"
+#include "fp29.hip.h"
+#include "fp2_29.hip.h"
+#include "ec29.hip.h"
 
 namespace bls29 {
 

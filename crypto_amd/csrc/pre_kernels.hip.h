@@ -1,4 +1,4 @@
-// crypto_amd/csrc/pre_kernels.cuh — precomputed-multiples tables for resident bases (a proving-key query is fixed for the life of the key:
+// crypto_amd/csrc/pre_kernels.hip.h — precomputed-multiples tables for resident bases (a proving-key query is fixed for the life of the key:
 // legogroth16/src/data_structures.rs:151-168; every proof runs msm_bigint over the same bases, prover.rs:286,299,592).
 //
 // table[w][i] = 2^(c w) P_i in the prepared affine record form, w < W.  With it digit w of scalar i adds table[w][i] into ONE bucket set shared
@@ -8,8 +8,8 @@
 // inversion per 8 points: Montgomery's trick inside a lane).
 #pragma once
 #include <hip/hip_runtime.h>
-#include "msm_kernels.cuh"
-#include "fp_inv.cuh"
+#include "msm_kernels.hip.h"
+#include "fp_inv.hip.h"
 
 namespace msm {
 using namespace bls29;
@@ -20,7 +20,7 @@ constexpr int PRE_GROUP = 8;
 __device__ __forceinline__ void inv_key(Fp &k, const Fp &a) { fp_norm(k, a); }
 __device__ __forceinline__ void inv_key(Fp &k, const Fp2 &a) { Fp n0, n1, t; fp_sqr(n0, a.c0); fp_sqr(n1, a.c1); fp_add(t, n0, n1); fp_norm(k, t); }
 __device__ __forceinline__ void inv_from_key(Fp &r, const Fp &, const Fp &kinv) { r = kinv; }
-// the signed 30-bit field borrows the 14 x 29-bit field's division-step inversion (fp_safegcd.cuh): one conversion each way per inverted value
+// the signed 30-bit field borrows the 14 x 29-bit field's division-step inversion (fp_safegcd.hip.h): one conversion each way per inverted value
 __device__ __forceinline__ void inv_key(Fp &k, const Fs &a) { fp_from_fs(k, a); }
 __device__ __forceinline__ void inv_from_key(Fs &r, const Fs &, const Fp &kinv) { fs_from_fp(r, kinv); }
 __device__ __forceinline__ void inv_key(Fp &k, const Fs2 &a) { Fs n0, n1, t; fs_sqr(n0, a.c0); fs_sqr(n1, a.c1); fs_add(t, n0, n1); fs_bal(t, t); fp_from_fs(k, t); }     // the norm c0^2 + c1^2

@@ -1,5 +1,5 @@
-// crypto_amd/csrc/psort_kernels.cuh — two-level partition sort of the (bucket key, term) pairs of an MSM, for wide windows
-// (keys of up to 22 bits), where the per-window LDS sweep of sort_kernels.cuh would re-read every digit column once per bucket range.
+// crypto_amd/csrc/psort_kernels.hip.h — two-level partition sort of the (bucket key, term) pairs of an MSM, for wide windows
+// (keys of up to 22 bits), where the per-window LDS sweep of sort_kernels.hip.h would re-read every digit column once per bucket range.
 //
 //   P1 k_ps_count1    tile t of 512 scalars: signed digits -> keys; LDS histogram over the partitions p = key >> 11   -> cnt1[p][t]
 //   P2 (scan)         exclusive scan of cnt1 (partition-major, so partition p's pairs end up contiguous)
@@ -13,10 +13,10 @@
 //   key = w * key_wstride + (|digit| - 1)            key_wstride = 0: all windows share one bucket set (precomputed 2^(c w) P tables)
 //   val = (val_base + w * val_wstride + i) | sign << 31     index of the base record the term adds
 #pragma once
-#include "dyn_chunk.cuh"
+#include "dyn_chunk.hip.h"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include "sort_launch.cuh"
+#include "sort_launch.hip.h"
 
 namespace msm {
 

@@ -1,4 +1,4 @@
-// crypto_amd/csrc/qap_launch.cuh — host-callable launchers of the NTT / witness-map kernels (k_ntt.hip)
+// crypto_amd/csrc/qap_launch.hip.h — host-callable launchers of the NTT / witness-map kernels (k_ntt.hip)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stddef.h>

@@ -1,12 +1,12 @@
-// crypto_amd/csrc/sort_kernels.cuh — curve-independent kernels of the MSM pipeline: signed-digit recoding, the LDS
+// crypto_amd/csrc/sort_kernels.hip.h — curve-independent kernels of the MSM pipeline: signed-digit recoding, the LDS
 // counting sort (K2/K4), the histogram scan (K3) and the device self-tests.  Included by k_sort.hip only.
 #pragma once
-#include "dyn_chunk.cuh"
+#include "dyn_chunk.hip.h"
 #include <hip/hip_runtime.h>
-#include "fp29.cuh"
-#include "ec29.cuh"
-#include "fp_inv.cuh"
-#include "ec29_two_lane.cuh"
+#include "fp29.hip.h"
+#include "ec29.hip.h"
+#include "fp_inv.hip.h"
+#include "ec29_two_lane.hip.h"
 
 namespace msm {
 using namespace bls29;
@@ -161,7 +161,7 @@ __global__ void __launch_bounds__(256) k_scan_add(uint32_t *__restrict__ out, ui
     if (i == n) out[n] = block_sums[nb];
 }
 
-// ---- chunking from the actual pair count (dyn_chunk.cuh) ------------------------------------------------------------
+// ---- chunking from the actual pair count (dyn_chunk.hip.h) ------------------------------------------------------------
 // one thread: choose_chunk's rule (dock_core.hip) on E = *total.  fixed_ch != 0: a chunk length forced by the host (tuning knobs) is kept.
 __global__ void k_dyn_chunk(const uint32_t *__restrict__ total, uint32_t fixed_ch, uint32_t min_chunk, uint32_t max_chunks, uint32_t lanes_per_chunk, uint32_t T_max, uint32_t *__restrict__ dyn) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -217,7 +217,7 @@ __global__ void k_selftest_g1_sum(const uint32_t *pts_abi, const uint8_t *neg, s
 // evaluation needs.
 // Four lanes per point.  The scalar arrives split by the GLV decomposition k = k1 + k2 lambda (k1, k2 < 2^128, done on the host by
 // hostf::glv_decompose): lanes 0,1 of a quad run the 128-step double-and-add of k1 P, lanes 2,3 that of k2 P — each chain on two lanes
-// (ec29_two_lane.cuh) — and the result is k1 P + phi(k2 P).  Half the dependent steps of the 255-bit chain: the kernel is latency-bound
+// (ec29_two_lane.hip.h) — and the result is k1 P + phi(k2 P).  Half the dependent steps of the 255-bit chain: the kernel is latency-bound
 // (RandomizedPairingChecker scales a handful of points), 3.5 -> ~2.3 ms.
 // add_abi != nullptr: out_i = A_i + s_i * P_i (the aggregation's folding step, dgpu_g1_mul_add_batch).  Points are elements of the
 // prime-order subgroup (the invariant of arkworks' G1Affine): phi(P) = lambda P only holds there.

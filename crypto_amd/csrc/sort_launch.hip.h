@@ -1,4 +1,4 @@
-// crypto_amd/csrc/sort_launch.cuh — host-callable launchers of the curve-independent kernels (k_sort.hip): digit recoding,
+// crypto_amd/csrc/sort_launch.hip.h — host-callable launchers of the curve-independent kernels (k_sort.hip): digit recoding,
 // LDS counting sort, histogram scan, batched G1 scaling, device self-tests.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -11,11 +11,11 @@ void launch_digit_codes(hipStream_t s, bool wide, const uint32_t *scalars, const
 void launch_sort_sweep(hipStream_t s, bool wide, bool scatter, unsigned grid, size_t lds_bytes, const void *dig, size_t n, size_t n_pad, int W, int RANGES, int rb_log, uint32_t B,
                        uint32_t *cnt, const uint32_t *off, uint32_t *entries, uint32_t heavy_thr, uint32_t *heavy, uint32_t heavy_cap);
 void launch_scan(hipStream_t s, const uint32_t *cnt, uint32_t *off, uint32_t *cursor, uint32_t *bsums, size_t NB);
-// chunking of the accumulation from the pair count the sort produced (dyn_chunk.cuh): dyn[0..3] = chunk length, chunks, heavy threshold, pairs
+// chunking of the accumulation from the pair count the sort produced (dyn_chunk.hip.h): dyn[0..3] = chunk length, chunks, heavy threshold, pairs
 void launch_dyn_chunk(hipStream_t s, const uint32_t *total, uint32_t fixed_ch, uint32_t min_chunk, uint32_t max_chunks, uint32_t lanes_per_chunk, uint32_t T_max, uint32_t *dyn);
 void launch_flag_heavy(hipStream_t s, const uint32_t *off, uint32_t NB, const uint32_t *dyn, uint32_t *heavy, uint32_t heavy_cap);
 size_t scan_blocks(size_t NB);
-// ---- two-level partition sort (k_psort.hip, psort_kernels.cuh) ----
+// ---- two-level partition sort (k_psort.hip, psort_kernels.hip.h) ----
 constexpr int PS_TILE = 512;            // scalars per tile = threads per block of P1 / P3
 constexpr int PS_PART_LOG_MAX = 11;     // at most 2048 buckets per partition (P4's LDS histogram)
 constexpr int PS_PART = 1 << PS_PART_LOG_MAX;
@@ -38,7 +38,7 @@ struct PsParams {
     int part_log;                       // log2 buckets per partition: ps_part_log(NB)
     uint32_t P;                         // partitions = ceil(NB / 2^part_log)
     uint32_t ntiles;
-    uint32_t *bad;                      // *bad |= 1 if a scalar has bit 255 set (the call is refused: sort_kernels.cuh k_digit_codes)
+    uint32_t *bad;                      // *bad |= 1 if a scalar has bit 255 set (the call is refused: sort_kernels.hip.h k_digit_codes)
 };
 
 // about a thousand partitions (P4 runs one block per partition) while a partition keeps at least 32 buckets

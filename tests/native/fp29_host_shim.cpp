@@ -2,14 +2,14 @@
 // FP29_CHECK worst-case bound tracker enabled.  Test-only: lets `-m "not gpu"` tests check the exact
 // arithmetic the kernels run, and proves the lazy-limb overflow bounds, without a GPU.
 #define FP29_CHECK 1
-#include "../../crypto_amd/csrc/fp29.cuh"
-#include "../../crypto_amd/csrc/ec29.cuh"
-#include "../../crypto_amd/csrc/fp30s.cuh"
-#include "../../crypto_amd/csrc/fs2_pair.cuh"
-#include "../../crypto_amd/csrc/pairing29.cuh"
+#include "../../crypto_amd/csrc/fp29.hip.h"
+#include "../../crypto_amd/csrc/ec29.hip.h"
+#include "../../crypto_amd/csrc/fp30s.hip.h"
+#include "../../crypto_amd/csrc/fs2_pair.hip.h"
+#include "../../crypto_amd/csrc/pairing29.hip.h"
 #include "../../crypto_amd/csrc/host_field.hpp"
-#include "../../crypto_amd/csrc/fr29.cuh"
-#include "../../crypto_amd/csrc/fp_safegcd.cuh"
+#include "../../crypto_amd/csrc/fr29.hip.h"
+#include "../../crypto_amd/csrc/fp_safegcd.hip.h"
 #include <vector>
 #include <string.h>
 using namespace bls29;
@@ -50,7 +50,7 @@ void shim_g1_add_tree(const uint32_t *pts, int n, uint32_t *out) {
     delete[] v; delete[] f;
 }
 
-// ---- the 13 x 30-bit signed field of the G1 MSM kernels (fp30s.cuh), same entry shapes ----
+// ---- the 13 x 30-bit signed field of the G1 MSM kernels (fp30s.hip.h), same entry shapes ----
 void shim_fs_mul(const uint32_t *a, const uint32_t *b, uint32_t *out) { Fs x, y, r; fs_from_abi(x, a); fs_from_abi(y, b); fs_mul(r, x, y); fs_to_abi(out, r); }
 void shim_fs_sqr(const uint32_t *a, uint32_t *out) { Fs x, r; fs_from_abi(x, a); fs_sqr(r, x); fs_to_abi(out, r); }
 void shim_fs_roundtrip(const uint32_t *a, uint32_t *out) { Fs x; fs_from_abi(x, a); fs_to_abi(out, x); }
@@ -96,7 +96,7 @@ void shim_g1s_dbl_chain(const uint32_t *pt, int k, uint32_t *out) {
     store_xyzz_s(out, acc, false);
 }
 
-// ---- G2 over the signed field (fs2_pair.cuh, one-lane form; the lane-pair form runs the same component arithmetic) ----
+// ---- G2 over the signed field (fs2_pair.hip.h, one-lane form; the lane-pair form runs the same component arithmetic) ----
 static void load_aff2s(Aff<Fs2> &p, const uint32_t *xy) { fs_from_abi(p.x.c0, xy); fs_from_abi(p.x.c1, xy + 12); fs_from_abi(p.y.c0, xy + 24); fs_from_abi(p.y.c1, xy + 36); }
 static void store_xyzz2s(uint32_t *out, const Xyzz<Fs2> &a, bool inf) {
     if (inf) { memset(out, 0, 4 * 96); return; }

@@ -1,4 +1,4 @@
-"""CPU: the DEVICE field / group code (crypto_amd/csrc/fp29.cuh, fp2_29.cuh, ec29.cuh) compiled for the host
+"""CPU: the DEVICE field / group code (crypto_amd/csrc/fp29.hip.h, fp2_29.hip.h, ec29.hip.h) compiled for the host
 with the FP29_CHECK worst-case bound tracker, checked against the big-integer model.  Every assertion inside
 the shim that fires would mean a lazy-limb overflow is possible for SOME input of the same classes, so a green
 run here proves the carry-free arithmetic the kernels use is overflow-free, not just right on these inputs."""
@@ -19,7 +19,7 @@ P = M.P
 
 @pytest.fixture(scope="module")
 def shim():
-    deps = [SRC] + [os.path.join(HERE, "..", "crypto_amd", "csrc", f) for f in ("fp29.cuh", "fp30s.cuh", "fs2_pair.cuh", "fp2_29.cuh", "ec29.cuh", "pairing29.cuh", "fr29.cuh", "fp_safegcd.cuh")]
+    deps = [SRC] + [os.path.join(HERE, "..", "crypto_amd", "csrc", f) for f in ("fp29.hip.h", "fp30s.hip.h", "fs2_pair.hip.h", "fp2_29.hip.h", "ec29.hip.h", "pairing29.hip.h", "fr29.hip.h", "fp_safegcd.hip.h")]
     if not os.path.exists(SO) or any(os.path.getmtime(d) > os.path.getmtime(SO) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", SO, SRC])
     return C.CDLL(SO)
@@ -47,7 +47,7 @@ def test_fp_ops(shim):
 
 
 def test_fs_ops(shim):
-    """fp30s.cuh (13 signed 30-bit limbs, the field of the G1 MSM kernels) against big integers: products, squares, the fused a b - c d, lazy
+    """fp30s.hip.h (13 signed 30-bit limbs, the field of the G1 MSM kernels) against big integers: products, squares, the fused a b - c d, lazy
     subtractions with both carry passes, negation, the zero tests, and the conversions to / from the 14 x 29-bit field"""
     random.seed(11)
     vals = [0, 1, 2, P - 1, P - 2, (P - 1) // 2, (P + 1) // 2, 2 ** 380, 2 ** 377 - 1, 2 ** 360, 2 ** 360 - 1, 2 ** 30, 2 ** 29, 2 ** 29 - 1, P - 2 ** 29] + [random.randrange(P) for _ in range(300)]
@@ -68,7 +68,7 @@ def test_fs_ops(shim):
 
 
 def test_fp_inversion_by_division_steps(shim):
-    """fp_safegcd.cuh against the big-integer inverse: edge values, small and large values, random ones, lazily added operands"""
+    """fp_safegcd.hip.h against the big-integer inverse: edge values, small and large values, random ones, lazily added operands"""
     random.seed(7)
     vals = [0, 1, 2, 3, P - 1, P - 2, (P - 1) // 2, (P + 1) // 2, 2 ** 29, 2 ** 29 - 1, 2 ** 58 + 1, 2 ** 380, 2 ** 377 - 1, 2 ** 377, P - 2 ** 29]
     vals += [random.randrange(P) for _ in range(400)] + [random.randrange(1 << k) for k in range(1, 381, 7)]
@@ -88,7 +88,7 @@ def test_fp2_ops(shim):
     for a, b in zip(vals, vals[1:]):
         shim.shim_fp2_mul(p_(enc(a)), p_(enc(b)), p_(o)); assert dec(o) == M.f2_mul(a, b)
         shim.shim_fp2_sqr(p_(enc(a)), p_(o)); assert dec(o) == M.f2_sqr(a)
-        shim.shim_fs2_mul(p_(enc(a)), p_(enc(b)), p_(o)); assert dec(o) == M.f2_mul(a, b)          # the same over the signed 30-bit field (fs2_pair.cuh)
+        shim.shim_fs2_mul(p_(enc(a)), p_(enc(b)), p_(o)); assert dec(o) == M.f2_mul(a, b)          # the same over the signed 30-bit field (fs2_pair.hip.h)
         shim.shim_fs2_sqr(p_(enc(a)), p_(o)); assert dec(o) == M.f2_sqr(a)
 
 

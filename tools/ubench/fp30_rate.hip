@@ -4,7 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
-#include "../../crypto_amd/csrc/fp29.cuh"
+#include "../../crypto_amd/csrc/fp29.hip.h"
 using namespace bls29;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 

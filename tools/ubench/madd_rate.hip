@@ -3,9 +3,9 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
-#include "../../crypto_amd/csrc/fp29.cuh"
-#include "../../crypto_amd/csrc/ec29.cuh"
-#include "../../crypto_amd/csrc/fp30s.cuh"
+#include "../../crypto_amd/csrc/fp29.hip.h"
+#include "../../crypto_amd/csrc/ec29.hip.h"
+#include "../../crypto_amd/csrc/fp30s.hip.h"
 using namespace bls29;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 
@@ -34,7 +34,7 @@ __global__ void __launch_bounds__(256, WAVES) k_madd(const uint32_t *pts, uint32
     const uint32_t *w = reinterpret_cast<const uint32_t *>(&acc);
     for (int i = 0; i < 56; i++) o[(size_t)i * gridDim.x * blockDim.x + t] = inf ? 0 : w[i];
 }
-// the same loop over the 13 x 30-bit signed field (fp30s.cuh): records of 28 words (x[13] y[13] pad[2])
+// the same loop over the 13 x 30-bit signed field (fp30s.hip.h): records of 28 words (x[13] y[13] pad[2])
 template <int WAVES>
 __global__ void __launch_bounds__(256, WAVES) k_madd_s(const uint32_t *pts, uint32_t *o, int iters) {
     Xyzz<Fs> acc; int t = blockIdx.x * blockDim.x + threadIdx.x; bool inf = true;

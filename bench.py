@@ -370,7 +370,7 @@ def secondary_configs(log2n, ks, scalars, db, ds, pool):
         "one_shot_bases_and_scalars_ms": round(timed(lambda: ca.msm_bigint(ca.G1, host_bases, scalars), 5, warm=2), 3),
         "one_shot_strided_affine_structs_ms": round(timed(lambda st=ca.to_affine_structs(ca.G1, host_bases): ca.msm_strided(ca.G1, st, scalars), 5, warm=2), 3),
         "note": "dgpu_msm_g1_handle (upload of n x 32 B scalars inside the call), dgpu_msm_g1 (n x 128 B inside the call) and dgpu_msm_g1_strided (the caller's 104-byte Affine structs: n x 136 B), pageable host memory; "
-                "the scalars are sorted while the bases cross PCIe, the conversion of a 16-MB piece runs under the copy of the next"}
+                "from n = 2^19 the operands cross PCIe in two term ranges: a range's scalars are sorted while its bases are in flight, its kernels run under the next range's copies, the ranges' bucket sets are merged before the one reduction"}
     # -- SURVEY 8d secondary scalar distributions, on the table path, one call in flight
     rng = np.random.Generator(np.random.PCG64(0x5EED0009))
     d = {}

@@ -56,9 +56,10 @@ struct Slot {
     std::mutex mu;
     hipStream_t stream = nullptr;
     // H2D pieces travel on their own stream, ordered against the compute stream by these events: the kernels of a call run under its copies
-    static constexpr int N_COPY_EV = 8;
+    static constexpr int N_COPY_EV = 15;
     hipStream_t cstream = nullptr;
     hipEvent_t copy_ev[N_COPY_EV + 1] = {};
+    unsigned ev_next = 0;           // next event to record (taken in turn)
     Buf flags, in_bases, in_inf, in_scalars, prepped, digits, heavy, cnt, off, cursor, bsums, entries, bucket, bucket_inf, head, tail, head_b, tail_b, part_inf, l1, l1_inf, win, win_inf, ml_lines, ml_partial, ml_out, ml_coeffs, dyn, hpart, hpart_inf;
     Buf q[16];      // witness-map workspace (dock_qap.hip)
     std::vector<std::pair<const char *, std::pair<hipEvent_t, hipEvent_t>>> prof_pending;

@@ -87,6 +87,11 @@ int32_t host_lincomb(const uint64_t *points_xy, const uint8_t *is_inf, const uin
     return DGPU_OK;
 }
 
+template <class HF> void write_identity(uint64_t *out_xyz) {
+    typedef hostf::HXyzz<HF> PT; PT id = PT::identity(); HF X, Y, Z; id.to_normalised_jacobian(X, Y, Z);
+    const size_t FWORDS = sizeof(HF) / 8; memcpy(out_xyz, &X, sizeof(HF)); memcpy(out_xyz + FWORDS, &Y, sizeof(HF)); memcpy(out_xyz + 2 * FWORDS, &Z, sizeof(HF));
+}
+
 // ---- geometry + workspace of the plain pipeline ---------------------------------------------------------------------------------------
 struct PlainGeom {
     int c, W; uint32_t B, NB; int mshift, G; size_t NG, Emax; int CH; size_t T, nblk; bool wide; size_t n_pad; int RANGES, rb_log; unsigned sort_grid; size_t lds_bytes;
@@ -148,58 +153,81 @@ template <class C> int32_t ws_plain(Slot &sl, const PlainGeom &g) {
     return DGPU_OK;
 }
 
+// An MSM whose operands are still crossing PCIe is taken in K TERM RANGES: range k is sorted, accumulated and fixed up into a bucket set of its
+// own as soon as its operands have landed (the kernels of range k run under the copy of range k + 1); the sets are then merged
+// (k_merge_buckets: one general addition per bucket and extra set) and reduced once.  K = 1 is the plain case.
+inline size_t range_count(size_t n, bool operands_in_flight) { return operands_in_flight && n >= ((size_t)1 << 19) ? 2 : 1; }
+inline size_t range_lo(size_t n, size_t K, size_t k) { return ((n * k / K) + 7) & ~(size_t)7; }       // (multiples of 8 terms, except the end)
+inline void range_bounds(size_t n, size_t K, size_t k, size_t &lo, size_t &hi) { lo = k == 0 ? 0 : std::min(n, range_lo(n, K, k)); hi = k + 1 == K ? n : std::min(n, range_lo(n, K, k + 1)); }
+template <class C> int32_t ws_bucket_sets(Slot &sl, uint32_t NB, size_t K) {
+    int32_t rc;
+    if ((rc = sl.bucket.ensure(K * soa_points(NB) * C::XW * 4))) return rc;
+    return sl.bucket_inf.ensure(K * (size_t)NB);
+}
+
 // d_bases: prepared records; d_scalars: canonical 8 x u32 per scalar.  Caller holds the slot.
-// bases_pending: the base records are still being written by work queued on this stream AFTER the sort (one-shot calls: the bases cross PCIe
-// while the scalars are sorted): the sort does not look at them and the accumulation passes over identity records itself; `before_accumulate`
-// is called between the sort and the accumulation to queue that work.
-template <class C, class HF, class Mid>
-int32_t msm_device(Slot &sl, const uint32_t *d_bases, const uint32_t *d_scalars, size_t n, uint64_t *out_xyz, bool bases_pending, Mid before_accumulate) {
-    if (n == 0) { typedef hostf::HXyzz<HF> PT; PT id = PT::identity(); HF X, Y, Z; id.to_normalised_jacobian(X, Y, Z);
-        const size_t FWORDS = sizeof(HF) / 8; memcpy(out_xyz, &X, sizeof(HF)); memcpy(out_xyz + FWORDS, &Y, sizeof(HF)); memcpy(out_xyz + 2 * FWORDS, &Z, sizeof(HF)); return DGPU_OK; }
+// bases_pending: the base records are written by work that `ready_bases(k, lo, hi)` queues on this stream between the sort and the accumulation
+// of range k (one-shot calls: the bases cross PCIe while the scalars are sorted): the sort does not look at them and the accumulation passes over
+// identity records itself.  `ready_scalars(k, lo, hi)` is called before the sort of range k.
+template <class C, class HF, class ReadyS, class ReadyB>
+int32_t msm_device_ranges(Slot &sl, const uint32_t *d_bases, const uint32_t *d_scalars, size_t n, size_t K, uint64_t *out_xyz, bool bases_pending, ReadyS ready_scalars, ReadyB ready_bases) {
+    if (n == 0) { write_identity<HF>(out_xyz); return DGPU_OK; }
     PlainGeom g; int32_t rc;
     if ((rc = plain_geometry<C>(n, g))) return rc;
     if ((rc = ws_plain<C>(sl, g))) return rc;
+    if (K > 1 && (rc = ws_bucket_sets<C>(sl, g.NB, K))) return rc;
     const int c = g.c, W = g.W; const uint32_t NB = g.NB; const size_t T = g.T; const int CH = g.CH;
     hipStream_t s = sl.stream;
     const uint32_t heavy_thr = 0xffffffffu /* the sweeps flag nothing: k_flag_heavy does, after the scan */, HEAVY_CAP = g.HEAVY_CAP;
     uint32_t *const dyn = sl.dyn.as<uint32_t>();
-    {
-        StageTimer st(sl, "msm.count");
-        HIPCHK(hipMemsetAsync(sl.bucket_inf.p, 1, NB, s));
-        HIPCHK(hipMemsetAsync(sl.heavy.p, 0, 4, s));
-        HIPCHK(hipMemsetAsync(sl.flags.p, 0, 4, s));
-        launch_digit_codes(s, g.wide, d_scalars, bases_pending ? nullptr : d_bases, C::AFF_STRIDE, C::FLAGW, n, g.n_pad, c, W, sl.digits.p, sl.flags.as<uint32_t>());
-        launch_sort_sweep(s, g.wide, false, g.sort_grid, g.lds_bytes, sl.digits.p, n, g.n_pad, W, g.RANGES, g.rb_log, g.B, sl.cnt.as<uint32_t>(), nullptr, nullptr, heavy_thr, sl.heavy.as<uint32_t>(), HEAVY_CAP);
-    }
-    {
-        StageTimer st(sl, "msm.scan");
-        launch_scan(s, sl.cnt.as<uint32_t>(), sl.off.as<uint32_t>(), sl.cursor.as<uint32_t>(), sl.bsums.as<uint32_t>(), (size_t)NB);
-        launch_dyn_chunk(s, sl.off.as<uint32_t>() + NB, (uint32_t)forced_chunk(), g.min_chunk, g.max_chunks, g.lanes_per_chunk, (uint32_t)T, dyn);
-        launch_flag_heavy(s, sl.off.as<uint32_t>(), NB, dyn, sl.heavy.as<uint32_t>(), HEAVY_CAP);
-    }
-    {
-        StageTimer st(sl, "msm.scatter");
-        launch_sort_sweep(s, g.wide, true, g.sort_grid, g.lds_bytes, sl.digits.p, n, g.n_pad, W, g.RANGES, g.rb_log, g.B, nullptr, sl.off.as<uint32_t>(), sl.entries.as<uint32_t>(), heavy_thr, sl.heavy.as<uint32_t>(), HEAVY_CAP);
-    }
-    if ((rc = before_accumulate())) return rc;
-    {
-        StageTimer st(sl, "msm.accumulate");
+    const size_t set_words = soa_points(NB) * C::XW;
+    HIPCHK(hipMemsetAsync(sl.bucket_inf.p, 1, K * (size_t)NB, s));
+    HIPCHK(hipMemsetAsync(sl.flags.p, 0, 4, s));
+    for (size_t k = 0; k < K; k++) {
+        size_t lo, hi; range_bounds(n, K, k, lo, hi);
+        const size_t nk = hi - lo, nk_pad = (nk + 7) & ~(size_t)7;
+        if (nk == 0) continue;
+        uint32_t *const bucket = sl.bucket.as<uint32_t>() + k * set_words;
+        uint8_t *const bucket_inf = sl.bucket_inf.as<uint8_t>() + k * (size_t)NB;
+        const uint32_t *const bases_k = d_bases + lo * C::AFF_STRIDE, *const scalars_k = d_scalars + lo * 8;
+        if ((rc = ready_scalars(k, lo, hi))) return rc;
+        {
+            StageTimer st(sl, "msm.count");
+            HIPCHK(hipMemsetAsync(sl.heavy.p, 0, 4, s));
+            launch_digit_codes(s, g.wide, scalars_k, bases_pending ? nullptr : bases_k, C::AFF_STRIDE, C::FLAGW, nk, nk_pad, c, W, sl.digits.p, sl.flags.as<uint32_t>());
+            launch_sort_sweep(s, g.wide, false, g.sort_grid, g.lds_bytes, sl.digits.p, nk, nk_pad, W, g.RANGES, g.rb_log, g.B, sl.cnt.as<uint32_t>(), nullptr, nullptr, heavy_thr, sl.heavy.as<uint32_t>(), HEAVY_CAP);
+        }
+        {
+            StageTimer st(sl, "msm.scan");
+            launch_scan(s, sl.cnt.as<uint32_t>(), sl.off.as<uint32_t>(), sl.cursor.as<uint32_t>(), sl.bsums.as<uint32_t>(), (size_t)NB);
+            launch_dyn_chunk(s, sl.off.as<uint32_t>() + NB, (uint32_t)forced_chunk(), g.min_chunk, g.max_chunks, g.lanes_per_chunk, (uint32_t)T, dyn);
+            launch_flag_heavy(s, sl.off.as<uint32_t>(), NB, dyn, sl.heavy.as<uint32_t>(), HEAVY_CAP);
+        }
+        {
+            StageTimer st(sl, "msm.scatter");
+            launch_sort_sweep(s, g.wide, true, g.sort_grid, g.lds_bytes, sl.digits.p, nk, nk_pad, W, g.RANGES, g.rb_log, g.B, nullptr, sl.off.as<uint32_t>(), sl.entries.as<uint32_t>(), heavy_thr, sl.heavy.as<uint32_t>(), HEAVY_CAP);
+        }
+        if ((rc = ready_bases(k, lo, hi))) return rc;
+        {
+            StageTimer st(sl, "msm.accumulate");
 #ifdef DGPU_DEV
-        static const uint32_t dbg_mask = getenv("DGPU_DBG_NOGATHER") ? 1023u : 0xffffffffu;   // development experiment (wrong results by design): L2-resident points
+            static const uint32_t dbg_mask = getenv("DGPU_DBG_NOGATHER") ? 1023u : 0xffffffffu;   // development experiment (wrong results by design): L2-resident points
 #else
-        constexpr uint32_t dbg_mask = 0xffffffffu;
+            constexpr uint32_t dbg_mask = 0xffffffffu;
 #endif
-        if (bases_pending) launch_accumulate_skip_identity<C>(s, d_bases, sl.entries.as<uint32_t>(), sl.off.as<uint32_t>(), NB, sl.bucket.as<uint32_t>(), sl.bucket_inf.as<uint8_t>(),
-                           sl.head.as<uint32_t>(), sl.tail.as<uint32_t>(), sl.head_b.as<uint32_t>(), sl.tail_b.as<uint32_t>(), sl.part_inf.as<uint8_t>(), T, (uint32_t)CH, dyn, msm::RowMap{});
-        else launch_accumulate<C>(s, d_bases, sl.entries.as<uint32_t>(), sl.off.as<uint32_t>(), NB, sl.bucket.as<uint32_t>(), sl.bucket_inf.as<uint8_t>(),
-                           sl.head.as<uint32_t>(), sl.tail.as<uint32_t>(), sl.head_b.as<uint32_t>(), sl.tail_b.as<uint32_t>(), sl.part_inf.as<uint8_t>(), T, (uint32_t)CH, dbg_mask, dyn);
-    }
-    {
-        StageTimer st(sl, "msm.fixup");
-        launch_fixup<C>(s, NB, sl.bucket.as<uint32_t>(), sl.bucket_inf.as<uint8_t>(), sl.head.as<uint32_t>(), sl.tail.as<uint32_t>(),
-                           sl.head_b.as<uint32_t>(), sl.tail_b.as<uint32_t>(), sl.part_inf.as<uint8_t>(), T, sl.off.as<uint32_t>(), heavy_thr, dyn);
-        launch_fixup_heavy<C>(s, sl.heavy.as<uint32_t>(), HEAVY_CAP, sl.off.as<uint32_t>(), (uint32_t)CH, NB, sl.bucket.as<uint32_t>(), sl.bucket_inf.as<uint8_t>(),
-                           sl.head.as<uint32_t>(), sl.tail.as<uint32_t>(), sl.part_inf.as<uint8_t>(), T, dyn, sl.hpart.as<uint32_t>(), sl.hpart_inf.as<uint8_t>());
+            if (bases_pending) launch_accumulate_skip_identity<C>(s, bases_k, sl.entries.as<uint32_t>(), sl.off.as<uint32_t>(), NB, bucket, bucket_inf,
+                               sl.head.as<uint32_t>(), sl.tail.as<uint32_t>(), sl.head_b.as<uint32_t>(), sl.tail_b.as<uint32_t>(), sl.part_inf.as<uint8_t>(), T, (uint32_t)CH, dyn, msm::RowMap{});
+            else launch_accumulate<C>(s, bases_k, sl.entries.as<uint32_t>(), sl.off.as<uint32_t>(), NB, bucket, bucket_inf,
+                               sl.head.as<uint32_t>(), sl.tail.as<uint32_t>(), sl.head_b.as<uint32_t>(), sl.tail_b.as<uint32_t>(), sl.part_inf.as<uint8_t>(), T, (uint32_t)CH, dbg_mask, dyn);
+        }
+        {
+            StageTimer st(sl, "msm.fixup");
+            launch_fixup<C>(s, NB, bucket, bucket_inf, sl.head.as<uint32_t>(), sl.tail.as<uint32_t>(),
+                               sl.head_b.as<uint32_t>(), sl.tail_b.as<uint32_t>(), sl.part_inf.as<uint8_t>(), T, sl.off.as<uint32_t>(), heavy_thr, dyn);
+            launch_fixup_heavy<C>(s, sl.heavy.as<uint32_t>(), HEAVY_CAP, sl.off.as<uint32_t>(), (uint32_t)CH, NB, bucket, bucket_inf,
+                               sl.head.as<uint32_t>(), sl.tail.as<uint32_t>(), sl.part_inf.as<uint8_t>(), T, dyn, sl.hpart.as<uint32_t>(), sl.hpart_inf.as<uint8_t>());
+            if (k > 0) launch_merge_buckets<C>(s, NB, sl.bucket.as<uint32_t>(), sl.bucket_inf.as<uint8_t>(), bucket, bucket_inf);
+        }
     }
     {
         StageTimer st(sl, "msm.reduce");
@@ -228,7 +256,8 @@ int32_t msm_device(Slot &sl, const uint32_t *d_bases, const uint32_t *d_scalars,
 }
 template <class C, class HF>
 int32_t msm_device(Slot &sl, const uint32_t *d_bases, const uint32_t *d_scalars, size_t n, uint64_t *out_xyz) {
-    return msm_device<C, HF>(sl, d_bases, d_scalars, n, out_xyz, false, [] { return (int32_t)DGPU_OK; });
+    auto nothing = [](size_t, size_t, size_t) { return (int32_t)DGPU_OK; };
+    return msm_device_ranges<C, HF>(sl, d_bases, d_scalars, n, 1, out_xyz, false, nothing, nothing);
 }
 
 inline void shard_bounds(size_t n, size_t parts, std::vector<size_t> &lo) {
@@ -332,7 +361,7 @@ inline size_t pre_entries_bytes(const PreTable &pt, size_t n) { return (size_t)n
 
 // dyn != nullptr: the chunking and the heavy-bucket list of the accumulation are produced on the way (curve-specific: dyn_args); nullptr: sort only
 template <class C>
-int32_t pre_sort(Slot &sl, const PreTable &pt, const PreGeom &g, size_t boff, const uint32_t *d_scalars, size_t n, uint32_t *off, uint32_t *entries, uint32_t *dyn) {
+int32_t pre_sort(Slot &sl, const PreTable &pt, const PreGeom &g, size_t boff, const uint32_t *d_scalars, size_t n, uint32_t *off, uint32_t *entries, uint32_t *dyn, bool reset_flag = true) {
     PsParams q;
     q.scalars = d_scalars; q.bases = dyn ? (const uint32_t *)pt.tab : nullptr /* shared sort: no per-table identity filter */; q.n = n; q.aff_stride = C::AFF_STRIDE; q.flag_word = C::FLAGW; q.flag_base = (uint32_t)boff;
     q.c = pt.c; q.W = pt.W; q.key_wstride = 0; q.val_base = (uint32_t)boff; q.val_wstride = (uint32_t)pt.n;
@@ -344,21 +373,22 @@ int32_t pre_sort(Slot &sl, const PreTable &pt, const PreGeom &g, size_t boff, co
     const uint32_t dyn_args[5] = {(uint32_t)forced_chunk(), g.min_chunk, g.max_chunks, g.lanes_per_chunk, (uint32_t)g.T};
     StageTimer st(sl, "msm.psort");
     HIPCHK(hipMemsetAsync(sl.heavy.p, 0, 4, sl.stream));
-    HIPCHK(hipMemsetAsync(sl.flags.p, 0, 4, sl.stream));
+    if (reset_flag) HIPCHK(hipMemsetAsync(sl.flags.p, 0, 4, sl.stream));
     launch_psort(sl.stream, q, g.NB, sl.cnt.as<uint32_t>(), sl.cursor.as<uint32_t>(), sl.bsums.as<uint32_t>(), sl.digits.p, off, entries,
                  heavy_thr, sl.heavy.as<uint32_t>(), g.HEAVY_CAP, dyn_args, dyn);
     return DGPU_OK;
 }
+// Stage 2a (pre_acc): accumulate + fix-up of one sorted list into bucket set `set` (merged into set 0 when set > 0).
 // derive_dyn: `off` / `entries` come from a shared sort — chunking and heavy-bucket list are derived here from off[] (as the plain pipeline does)
-template <class C, class HF>
-int32_t pre_tail(Slot &sl, const PreTable &pt, const PreGeom &g, const uint32_t *off, const uint32_t *entries, bool derive_dyn, uint64_t *out_xyz, const msm::RowMap &map = msm::RowMap{}) {
-    const uint32_t NB = g.NB; const size_t T = g.T; const int PW = g.PW;
-    int32_t rc;
-    if ((rc = ws_pre<C>(sl, pt, g, g.Emax / pt.W))) return rc;
+template <class C>
+int32_t pre_acc(Slot &sl, const PreTable &pt, const PreGeom &g, const uint32_t *off, const uint32_t *entries, bool derive_dyn, const msm::RowMap &map, size_t set) {
+    const uint32_t NB = g.NB; const size_t T = g.T;
     uint32_t *const dyn = sl.dyn.as<uint32_t>();
     const uint32_t heavy_thr = 16u * (uint32_t)g.CH;      // (replaced on the device by dyn[])
     hipStream_t s = sl.stream;
-    HIPCHK(hipMemsetAsync(sl.bucket_inf.p, 1, NB, s));
+    uint32_t *const bucket = sl.bucket.as<uint32_t>() + set * soa_points(NB) * C::XW;
+    uint8_t *const bucket_inf = sl.bucket_inf.as<uint8_t>() + set * (size_t)NB;
+    HIPCHK(hipMemsetAsync(bucket_inf, 1, NB, s));
     if (derive_dyn) {
         HIPCHK(hipMemsetAsync(sl.heavy.p, 0, 4, s));
         launch_dyn_chunk(s, off + NB, (uint32_t)forced_chunk(), g.min_chunk, g.max_chunks, g.lanes_per_chunk, (uint32_t)T, dyn);
@@ -366,18 +396,26 @@ int32_t pre_tail(Slot &sl, const PreTable &pt, const PreGeom &g, const uint32_t 
     }
     {
         StageTimer st(sl, "msm.accumulate");
-        if (derive_dyn) launch_accumulate_skip_identity<C>(s, (const uint32_t *)pt.tab, entries, off, NB, sl.bucket.as<uint32_t>(), sl.bucket_inf.as<uint8_t>(),
+        if (derive_dyn) launch_accumulate_skip_identity<C>(s, (const uint32_t *)pt.tab, entries, off, NB, bucket, bucket_inf,
                            sl.head.as<uint32_t>(), sl.tail.as<uint32_t>(), sl.head_b.as<uint32_t>(), sl.tail_b.as<uint32_t>(), sl.part_inf.as<uint8_t>(), T, (uint32_t)g.CH, dyn, map);
-        else launch_accumulate<C>(s, (const uint32_t *)pt.tab, entries, off, NB, sl.bucket.as<uint32_t>(), sl.bucket_inf.as<uint8_t>(),
+        else launch_accumulate<C>(s, (const uint32_t *)pt.tab, entries, off, NB, bucket, bucket_inf,
                            sl.head.as<uint32_t>(), sl.tail.as<uint32_t>(), sl.head_b.as<uint32_t>(), sl.tail_b.as<uint32_t>(), sl.part_inf.as<uint8_t>(), T, (uint32_t)g.CH, 0xffffffffu, dyn);
     }
     {
         StageTimer st(sl, "msm.fixup");
-        launch_fixup<C>(s, NB, sl.bucket.as<uint32_t>(), sl.bucket_inf.as<uint8_t>(), sl.head.as<uint32_t>(), sl.tail.as<uint32_t>(),
+        launch_fixup<C>(s, NB, bucket, bucket_inf, sl.head.as<uint32_t>(), sl.tail.as<uint32_t>(),
                            sl.head_b.as<uint32_t>(), sl.tail_b.as<uint32_t>(), sl.part_inf.as<uint8_t>(), T, off, heavy_thr, dyn);
-        launch_fixup_heavy<C>(s, sl.heavy.as<uint32_t>(), g.HEAVY_CAP, off, (uint32_t)g.CH, NB, sl.bucket.as<uint32_t>(), sl.bucket_inf.as<uint8_t>(),
+        launch_fixup_heavy<C>(s, sl.heavy.as<uint32_t>(), g.HEAVY_CAP, off, (uint32_t)g.CH, NB, bucket, bucket_inf,
                            sl.head.as<uint32_t>(), sl.tail.as<uint32_t>(), sl.part_inf.as<uint8_t>(), T, dyn, sl.hpart.as<uint32_t>(), sl.hpart_inf.as<uint8_t>());
+        if (set > 0) launch_merge_buckets<C>(s, NB, sl.bucket.as<uint32_t>(), sl.bucket_inf.as<uint8_t>(), bucket, bucket_inf);
     }
+    return DGPU_OK;
+}
+// Stage 2b (pre_finish): reduction of bucket set 0, read-back, host fold.  check_flag: the slot's flag word (a scalar >= 2^255 seen by this call's sort)
+template <class C, class HF>
+int32_t pre_finish(Slot &sl, const PreGeom &g, bool check_flag, uint64_t *out_xyz) {
+    const uint32_t NB = g.NB; const int PW = g.PW;
+    hipStream_t s = sl.stream;
     uint32_t *win_a = sl.win.as<uint32_t>(), *win_s = win_a + (size_t)PW * 4 * C::ABI_W;
     uint8_t *inf_a = sl.win_inf.as<uint8_t>(), *inf_s = inf_a + PW;
     {
@@ -391,7 +429,7 @@ int32_t pre_tail(Slot &sl, const PreTable &pt, const PreGeom &g, const uint32_t 
     uint32_t hbad = 0;
     HIPCHK(hipMemcpyAsync(hwin.data(), sl.win.p, (size_t)2 * PW * 4 * C::ABI_W * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(hinf.data(), sl.win_inf.p, 2 * PW, hipMemcpyDeviceToHost, s));
-    if (!derive_dyn) HIPCHK(hipMemcpyAsync(&hbad, sl.flags.p, 4, hipMemcpyDeviceToHost, s));      // (a shared sort was checked by dgpu_scalars_sort)
+    if (check_flag) HIPCHK(hipMemcpyAsync(&hbad, sl.flags.p, 4, hipMemcpyDeviceToHost, s));      // (a shared sort was checked by dgpu_scalars_sort)
     auto tsync0 = std::chrono::steady_clock::now();
     HIPCHK(hipStreamSynchronize(s));
     auto tsync1 = std::chrono::steady_clock::now();
@@ -405,19 +443,35 @@ int32_t pre_tail(Slot &sl, const PreTable &pt, const PreGeom &g, const uint32_t 
     }
     return DGPU_OK;
 }
-template <class HF> void write_identity(uint64_t *out_xyz) {
-    typedef hostf::HXyzz<HF> PT; PT id = PT::identity(); HF X, Y, Z; id.to_normalised_jacobian(X, Y, Z);
-    const size_t FWORDS = sizeof(HF) / 8; memcpy(out_xyz, &X, sizeof(HF)); memcpy(out_xyz + FWORDS, &Y, sizeof(HF)); memcpy(out_xyz + 2 * FWORDS, &Z, sizeof(HF));
-}
-// d_scalars: canonical 8 x u32 per scalar; terms i < n use table rows at column boff + i.  Caller holds the slot.
 template <class C, class HF>
-int32_t msm_device_pre(Slot &sl, const PreTable &pt, size_t boff, const uint32_t *d_scalars, size_t n, uint64_t *out_xyz) {
+int32_t pre_tail(Slot &sl, const PreTable &pt, const PreGeom &g, const uint32_t *off, const uint32_t *entries, bool derive_dyn, uint64_t *out_xyz, const msm::RowMap &map = msm::RowMap{}) {
+    int32_t rc;
+    if ((rc = ws_pre<C>(sl, pt, g, g.Emax / pt.W))) return rc;
+    if ((rc = pre_acc<C>(sl, pt, g, off, entries, derive_dyn, map, 0))) return rc;
+    return pre_finish<C, HF>(sl, g, !derive_dyn, out_xyz);
+}
+// d_scalars: canonical 8 x u32 per scalar; terms i < n use table rows at column boff + i.  Caller holds the slot.  K > 1: the scalars are still
+// crossing PCIe and are taken in K ranges (see msm_device_ranges); `ready_scalars(k, lo, hi)` queues the wait for range k.
+template <class C, class HF, class ReadyS>
+int32_t msm_device_pre_ranges(Slot &sl, const PreTable &pt, size_t boff, const uint32_t *d_scalars, size_t n, size_t K, uint64_t *out_xyz, ReadyS ready_scalars) {
     if (n == 0) { write_identity<HF>(out_xyz); return DGPU_OK; }
     PreGeom g; int32_t rc;
     if ((rc = pre_geometry<C>(pt, n, g))) return rc;
     if ((rc = ws_pre<C>(sl, pt, g, n))) return rc;
-    if ((rc = pre_sort<C>(sl, pt, g, boff, d_scalars, n, sl.off.as<uint32_t>(), sl.entries.as<uint32_t>(), sl.dyn.as<uint32_t>()))) return rc;
-    return pre_tail<C, HF>(sl, pt, g, sl.off.as<uint32_t>(), sl.entries.as<uint32_t>(), false, out_xyz);
+    if (K > 1 && (rc = ws_bucket_sets<C>(sl, g.NB, K))) return rc;
+    HIPCHK(hipMemsetAsync(sl.flags.p, 0, 4, sl.stream));
+    for (size_t k = 0; k < K; k++) {
+        size_t lo, hi; range_bounds(n, K, k, lo, hi);
+        if (hi == lo) continue;
+        if ((rc = ready_scalars(k, lo, hi))) return rc;
+        if ((rc = pre_sort<C>(sl, pt, g, boff + lo, d_scalars + lo * 8, hi - lo, sl.off.as<uint32_t>(), sl.entries.as<uint32_t>(), sl.dyn.as<uint32_t>(), false))) return rc;
+        if ((rc = pre_acc<C>(sl, pt, g, sl.off.as<uint32_t>(), sl.entries.as<uint32_t>(), false, msm::RowMap{}, k))) return rc;
+    }
+    return pre_finish<C, HF>(sl, g, true, out_xyz);
+}
+template <class C, class HF>
+int32_t msm_device_pre(Slot &sl, const PreTable &pt, size_t boff, const uint32_t *d_scalars, size_t n, uint64_t *out_xyz) {
+    return msm_device_pre_ranges<C, HF>(sl, pt, boff, d_scalars, n, 1, out_xyz, [](size_t, size_t, size_t) { return (int32_t)DGPU_OK; });
 }
 
 // ---- one sort for several tables (dgpu_scalars_sort / dgpu_msm_*_sorted) ---------------------------------------------------------------
@@ -545,35 +599,42 @@ template <class C> int32_t ws_stage_bases(Slot &sl, const RawBases &rb, size_t n
 // Queue: the raw points cross PCIe in pieces on the slot's COPY stream; the conversion of piece k to prepared records (k_prep_bases_raw) runs on
 // the compute stream as soon as that piece has landed, i.e. under the copy of piece k + 1 and under whatever the compute stream was doing
 // before (a one-shot MSM sorts its scalars meanwhile).  Pageable host memory: hipMemcpyAsync returns when the piece is on its way.
+// (points [lo, hi) of the caller's array into records [lo, hi) of d_out; every piece takes the next of the slot's copy events — an event may be
+// recorded again once a wait on its previous record has been queued)
 template <class C>
-int32_t stage_bases(Slot &sl, const RawBases &rb, size_t n, uint32_t *d_out) {
-    if (n == 0) return DGPU_OK;
+int32_t stage_bases(Slot &sl, const RawBases &rb, size_t lo0, size_t hi0, uint32_t *d_out) {
+    if (hi0 <= lo0) return DGPU_OK;
+    const size_t n = hi0 - lo0;
     uint8_t *draw = sl.in_bases.as<uint8_t>();
     const uint8_t *dinf = nullptr;
-    if (rb.is_inf) { HIPCHK(hipMemcpyAsync(sl.in_inf.p, rb.is_inf, n, hipMemcpyHostToDevice, sl.cstream)); dinf = sl.in_inf.as<uint8_t>(); }
+    if (rb.is_inf) { HIPCHK(hipMemcpyAsync(sl.in_inf.as<uint8_t>() + lo0, rb.is_inf + lo0, n, hipMemcpyHostToDevice, sl.cstream)); dinf = sl.in_inf.as<uint8_t>(); }
     const size_t per = std::max<size_t>(1, STAGE_CHUNK_BYTES / rb.stride);
     size_t pieces = (n + per - 1) / per;
-    if (pieces > Slot::N_COPY_EV) pieces = Slot::N_COPY_EV;
+    if (pieces > 6) pieces = 6;
     const size_t len = (n + pieces - 1) / pieces;
     StageTimer st(sl, "msm.prep_bases");
-    for (size_t k = 0, lo = 0; lo < n; k++, lo += len) {
-        const size_t cnt = std::min(len, n - lo);
+    for (size_t lo = lo0; lo < hi0; lo += len) {
+        const size_t cnt = std::min(len, hi0 - lo);
+        hipEvent_t ev = sl.copy_ev[sl.ev_next++ % (Slot::N_COPY_EV + 1)];
         HIPCHK(hipMemcpyAsync(draw + lo * rb.stride, rb.p + lo * rb.stride, cnt * rb.stride, hipMemcpyHostToDevice, sl.cstream));
-        HIPCHK(hipEventRecord(sl.copy_ev[k], sl.cstream));
-        HIPCHK(hipStreamWaitEvent(sl.stream, sl.copy_ev[k], 0));
+        HIPCHK(hipEventRecord(ev, sl.cstream));
+        HIPCHK(hipStreamWaitEvent(sl.stream, ev, 0));
         launch_prep_bases_raw<C>(sl.stream, draw + lo * rb.stride, rb.stride, rb.x_off, rb.y_off, rb.inf_off, dinf ? dinf + lo : nullptr, cnt, d_out + lo * C::AFF_STRIDE);
     }
     return DGPU_OK;
 }
+template <class C> int32_t stage_bases(Slot &sl, const RawBases &rb, size_t n, uint32_t *d_out) { return stage_bases<C>(sl, rb, 0, n, d_out); }
 // canonical scalars in d_out once the compute stream gets there (no host wait: the pipeline that follows is queued behind it)
-inline int32_t stage_scalars(Slot &sl, const uint64_t *h, size_t n, bool mont, uint32_t *d_out) {
-    if (n == 0) return DGPU_OK;
-    HIPCHK(hipMemcpyAsync(d_out, h, n * 32, hipMemcpyHostToDevice, sl.cstream));
-    HIPCHK(hipEventRecord(sl.copy_ev[Slot::N_COPY_EV], sl.cstream));
-    HIPCHK(hipStreamWaitEvent(sl.stream, sl.copy_ev[Slot::N_COPY_EV], 0));
-    if (mont) ntt::launch_fr_mont_to_canonical(sl.stream, d_out, n);     // Fr::into_bigint on the device (ark-ec msm_unchecked does it on rayon)
+inline int32_t stage_scalars(Slot &sl, const uint64_t *h, size_t lo, size_t hi, bool mont, uint32_t *d_out) {      // scalars [lo, hi)
+    if (hi <= lo) return DGPU_OK;
+    hipEvent_t ev = sl.copy_ev[sl.ev_next++ % (Slot::N_COPY_EV + 1)];
+    HIPCHK(hipMemcpyAsync(d_out + lo * 8, h + lo * 4, (hi - lo) * 32, hipMemcpyHostToDevice, sl.cstream));
+    HIPCHK(hipEventRecord(ev, sl.cstream));
+    HIPCHK(hipStreamWaitEvent(sl.stream, ev, 0));
+    if (mont) ntt::launch_fr_mont_to_canonical(sl.stream, d_out + lo * 8, hi - lo);     // Fr::into_bigint on the device (ark-ec msm_unchecked does it on rayon)
     return DGPU_OK;
 }
+inline int32_t stage_scalars(Slot &sl, const uint64_t *h, size_t n, bool mont, uint32_t *d_out) { return stage_scalars(sl, h, 0, n, mont, d_out); }
 
 // ---- workspaces sized ahead of the calls (no hipMalloc on an MSM path in steady state) ---------------------------------------------------
 // what: 1 = one-shot call of n terms (raw bases of `stride` bytes + scalars + prepared records + plain pipeline), 2 = fresh host scalars on a
@@ -587,9 +648,11 @@ template <class C> int32_t ws_for(Slot &sl, int what, size_t n, size_t stride, c
         if ((rc = sl.in_inf.ensure(n + 16))) return rc;
         if ((rc = sl.prepped.ensure(n * C::AFF_STRIDE * 4))) return rc;
     }
-    if (what == 3) { PreGeom g; if ((rc = pre_geometry<C>(*pt, n, g))) return rc; return ws_pre<C>(sl, *pt, g, n); }
+    // (the bucket sets of the range-wise form, which calls with operands still in flight take from n = 2^19 on)
+    if (what == 3) { PreGeom g; if ((rc = pre_geometry<C>(*pt, n, g))) return rc; if ((rc = ws_pre<C>(sl, *pt, g, n))) return rc; return ws_bucket_sets<C>(sl, g.NB, range_count(n, true)); }
     PlainGeom g; if ((rc = plain_geometry<C>(n, g))) return rc;
-    return ws_plain<C>(sl, g);
+    if ((rc = ws_plain<C>(sl, g))) return rc;
+    return ws_bucket_sets<C>(sl, g.NB, range_count(n, true));
 }
 // every slot of the current context (the caller holds none of them); a failure (out of memory) is not an error of the call that triggered
 // the reservation: the slot grows on its first use instead
@@ -627,11 +690,13 @@ int32_t msm_oneshot_here(const RawBases &rb, const uint64_t *scalars, size_t n, 
     int32_t rc;
     const uint64_t allocs0 = g_dev_allocs.load();
     if ((rc = ws_for<C>(sl, 1, n, rb.stride, nullptr))) return rc;
+    const size_t K = range_count(n, true);
     const bool grew = g_dev_allocs.load() != allocs0;
-    // scalars first: their digits are sorted while the bases (3/4 of the bytes) are still crossing PCIe
-    if ((rc = stage_scalars(sl, scalars, n, mont, sl.in_scalars.as<uint32_t>()))) return rc;
-    rc = msm_device<C, HF>(sl, sl.prepped.as<uint32_t>(), sl.in_scalars.as<uint32_t>(), n, out, true,
-                           [&] { return stage_bases<C>(sl, rb, n, sl.prepped.as<uint32_t>()); });
+    // per range: the scalars first (their digits are sorted while the range's bases, 3/4 of its bytes, are still crossing PCIe); a range's
+    // kernels run under the next range's copies
+    rc = msm_device_ranges<C, HF>(sl, sl.prepped.as<uint32_t>(), sl.in_scalars.as<uint32_t>(), n, K, out, true,
+                                  [&](size_t, size_t lo, size_t hi) { return stage_scalars(sl, scalars, lo, hi, mont, sl.in_scalars.as<uint32_t>()); },
+                                  [&](size_t, size_t lo, size_t hi) { return stage_bases<C>(sl, rb, lo, hi, sl.prepped.as<uint32_t>()); });
     if (rc) { (void)hipStreamSynchronize(sl.cstream); (void)hipStreamSynchronize(sl.stream); }      // nothing of ours may still read the caller's buffers
     if (grew) reserve_idle_slots<C>(&sl, 1, n, rb.stride);
     return rc;
@@ -677,9 +742,12 @@ int32_t msm_handle(uint64_t bases, size_t offset, const uint64_t *scalars, size_
     HIPCHK(hipSetDevice(cur().device));
     int32_t rc;
     if ((rc = sl.in_scalars.ensure(std::max<size_t>(n, 1) * 32))) return rc;
-    if ((rc = stage_scalars(sl, scalars, n, mont != 0, sl.in_scalars.as<uint32_t>()))) return rc;
-    if (hb.h.kind == kind + 9) rc = msm_device_pre<C, HF>(sl, *(const PreTable *)hb.h.p, offset, sl.in_scalars.as<uint32_t>(), n, out);
-    else rc = msm_device<C, HF>(sl, (const uint32_t *)hb.h.p + offset * C::AFF_STRIDE, sl.in_scalars.as<uint32_t>(), n, out);
+    // the scalars cross PCIe in ranges; a range's kernels run under the next range's copy (msm_device_ranges)
+    const size_t K = range_count(n, true);
+    auto ready = [&](size_t, size_t lo, size_t hi) { return stage_scalars(sl, scalars, lo, hi, mont != 0, sl.in_scalars.as<uint32_t>()); };
+    auto nothing = [](size_t, size_t, size_t) { return (int32_t)DGPU_OK; };
+    if (hb.h.kind == kind + 9) rc = msm_device_pre_ranges<C, HF>(sl, *(const PreTable *)hb.h.p, offset, sl.in_scalars.as<uint32_t>(), n, K, out, ready);
+    else rc = msm_device_ranges<C, HF>(sl, (const uint32_t *)hb.h.p + offset * C::AFF_STRIDE, sl.in_scalars.as<uint32_t>(), n, K, out, false, ready, nothing);
     if (rc) { (void)hipStreamSynchronize(sl.cstream); (void)hipStreamSynchronize(sl.stream); }      // nothing of ours may still read the caller's scalars
     return rc;
 }

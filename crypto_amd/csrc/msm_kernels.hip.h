@@ -580,6 +580,23 @@ __global__ void __launch_bounds__(64) k_reduce_top(const uint32_t *__restrict__ 
 }
 
 
+// ---- bucket sets of an MSM taken in term ranges (one-shot / fresh-scalar calls whose operands are still crossing PCIe, msm_driver.hip.h) ----
+// dst[b] += src[b] for every bucket: C::LPP lanes per bucket (G2P: a lane pair).  About NB general additions: 0.1 ms at 2^19 buckets.
+template <class C>
+__global__ void __launch_bounds__(256) k_merge_buckets(uint32_t NB, uint32_t *__restrict__ dst, uint8_t *__restrict__ dst_inf, const uint32_t *__restrict__ src, const uint8_t *__restrict__ src_inf) {
+    typedef typename C::F F;
+    const size_t b = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / C::LPP;
+    if (b >= NB) return;
+    if (src_inf[b] != 0) return;
+    Xyzz<F> o; load_soa<C>(o, src, NB, b);
+    bool inf = dst_inf[b] != 0;
+    Xyzz<F> acc;
+    if (inf) { acc = o; inf = false; }
+    else { load_soa<C>(acc, dst, NB, b); xyzz_add(acc, inf, o, false); }
+    store_soa<C>(dst, NB, b, acc);
+    if ((threadIdx.x % C::LPP) == 0) dst_inf[b] = inf;
+}
+
 // ---- K7/K8 for G2 on lane pairs (fp2_pair.hip.h) ---------------------------------------------------------------------------------
 // Same group geometry and l1 layout as k_reduce_l0 / k_reduce_top, but a point lives on a lane pair (even lane: c0 halves, odd lane: c1
 // halves), so a wave holds 32 points and every point-lane takes twice the items.  The one-lane Fp2 addition needs > 256 VGPRs (spills)

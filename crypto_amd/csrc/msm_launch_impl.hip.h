@@ -38,6 +38,10 @@ template <class C> void launch_fixup_heavy(hipStream_t s, const uint32_t *heavy,
     hipLaunchKernelGGL((k_fixup_heavy_ranges<A>), dim3(64, 32), dim3(A::HEAVY_T), 0, s, off, head, tail, part_inf, (const uint32_t *)dyn, hpart, hpart_inf);
     hipLaunchKernelGGL((k_fixup_heavy_join<A>), dim3(32), dim3(A::HEAVY_T), 0, s, off, NB, bucket, bucket_inf, (const uint32_t *)dyn, (const uint32_t *)hpart, (const uint8_t *)hpart_inf);
 }
+template <class C> void launch_merge_buckets(hipStream_t s, uint32_t NB, uint32_t *dst, uint8_t *dst_inf, const uint32_t *src, const uint8_t *src_inf) {
+    typedef typename C::ACC A;
+    hipLaunchKernelGGL((k_merge_buckets<A>), dim3((unsigned)(((size_t)NB * A::LPP + 255) / 256)), dim3(256), 0, s, NB, dst, dst_inf, src, src_inf);
+}
 template <class C> void launch_reduce_l0(hipStream_t s, unsigned NG, const uint32_t *bucket, const uint8_t *bucket_inf, uint32_t NB, int mshift, uint32_t *l1, uint8_t *l1_inf) {
     if constexpr (C::NFP == 2) hipLaunchKernelGGL((k_reduce_l0_pair<G2P>), dim3(NG), dim3(64), 0, s, bucket, bucket_inf, NB, mshift, l1, l1_inf);     // G2: lane pairs
     else hipLaunchKernelGGL((k_reduce_l0<typename C::MSM>), dim3(NG), dim3(64), 0, s, bucket, bucket_inf, NB, mshift, l1, l1_inf);

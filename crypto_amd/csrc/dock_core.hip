@@ -226,8 +226,31 @@ static int32_t free_handle(uint64_t h, bool scalars) {
 // number of elements behind a bases / scalars / sorted-scalars handle (points, scalars), whatever its kind
 int32_t dgpu_handle_len(uint64_t handle, size_t *n) {
     Handle hd;
-    if (!n || !lookup_handle(handle, hd) || hd.kind == 4 || hd.kind == 5 || hd.kind == 6) return DGPU_E_BADARG;
-    *n = hd.n; return DGPU_OK;
+    if (!n || !lookup_handle(handle, hd) || hd.kind == 5 || hd.kind == 6) return DGPU_E_BADARG;
+    *n = hd.n; return DGPU_OK;                       // (a resident circuit: its number of constraints)
+}
+// the device context that owns a handle
+int32_t dgpu_handle_context(uint64_t handle, int32_t *ctx) {
+    Handle hd;
+    if (!ctx || !lookup_handle(handle, hd)) return DGPU_E_BADARG;
+    *ctx = hd.ctx; return DGPU_OK;
+}
+// layout of a sharded handle (dgpu_bases_upload_*_sharded, dgpu_scalars_upload_sharded): number of parts; part k = elements [lo, hi) as a
+// handle of its own on context `ctx`.  count = 0 for a handle that is not sharded.
+int32_t dgpu_shard_count(uint64_t handle, int32_t *count) {
+    Handle hd;
+    if (!count || !lookup_handle(handle, hd)) return DGPU_E_BADARG;
+    *count = (hd.kind >= 7 && hd.kind <= 9) ? (int32_t)((const ShardSet *)hd.p)->sub.size() : 0;
+    return DGPU_OK;
+}
+int32_t dgpu_shard_part(uint64_t handle, size_t k, uint64_t *sub, size_t *lo, size_t *hi, int32_t *ctx) {
+    HandleRef ref(handle);
+    if (!sub || !lo || !hi || !ctx || !ref.ok || ref.h.kind < 7 || ref.h.kind > 9) return DGPU_E_BADARG;
+    const ShardSet &ss = *(const ShardSet *)ref.h.p;
+    if (k >= ss.sub.size()) return DGPU_E_BADARG;
+    Handle part; if (!lookup_handle(ss.sub[k], part)) return DGPU_E_BADARG;
+    *sub = ss.sub[k]; *lo = ss.lo[k]; *hi = ss.lo[k + 1]; *ctx = part.ctx;
+    return DGPU_OK;
 }
 int32_t dgpu_bases_free(uint64_t h) { return free_handle(h, false); }
 int32_t dgpu_scalars_free(uint64_t h) { return free_handle(h, true); }

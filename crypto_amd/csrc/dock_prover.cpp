@@ -16,6 +16,7 @@
 // host C++: no kernel, no HIP call.
 #include <algorithm>
 #include <cstring>
+#include <mutex>
 #include <thread>
 #include <vector>
 #include "../../include/dock_gpu.h"
@@ -60,9 +61,68 @@ int32_t fold_to_affine_g1(const uint64_t *parts, size_t k, uint64_t out[12], uin
     *inf = z; if (z) memset(out, 0, 96); else memcpy(out, j, 96);
     return DGPU_OK;
 }
+
+struct ProofInputs { const dgpu_lego_pk *pk; const uint64_t *z; size_t n_inst; int32_t montgomery; uint64_t r[4], s[4], v[4]; bool with_b1; };
+struct ProofConsts { uint64_t rest_a[18], rest_b1[18], rest_c[18], rest_b2[36], g_d[18]; };
+// what depends on no MSM (host arithmetic; the tiny g_d MSM goes to the device only when it has more than 15 terms)
+int32_t proof_constants(const ProofInputs &in, ProofConsts &c) {
+    const dgpu_lego_pk *pk = in.pk; const size_t cw = pk->commit_witness_count;
+    int32_t e;
+    { uint64_t p[36]; memcpy(p, pk->delta_g1, 96); memcpy(p + 12, pk->a0, 96); memcpy(p + 24, pk->alpha_g1, 96);
+      uint64_t k[12]; memcpy(k, in.r, 32); memcpy(k + 4, ONE4, 32); memcpy(k + 8, ONE4, 32);
+      if ((e = dgpu_lincomb_g1(p, nullptr, k, 3, c.rest_a))) return e; }                                  // r delta + a_0 + alpha  (:585-594)
+    { uint64_t p[72]; memcpy(p, pk->delta_g2, 192); memcpy(p + 24, pk->b2_0, 192); memcpy(p + 48, pk->beta_g2, 192);
+      uint64_t k[12]; memcpy(k, in.s, 32); memcpy(k + 4, ONE4, 32); memcpy(k + 8, ONE4, 32);
+      if ((e = dgpu_lincomb_g2(p, nullptr, k, 3, c.rest_b2))) return e; }
+    if (in.with_b1) { uint64_t p[36]; memcpy(p, pk->delta_g1, 96); memcpy(p + 12, pk->b1_0, 96); memcpy(p + 24, pk->beta_g1, 96);
+      uint64_t k[12]; memcpy(k, in.s, 32); memcpy(k + 4, ONE4, 32); memcpy(k + 8, ONE4, 32);
+      if ((e = dgpu_lincomb_g1(p, nullptr, k, 3, c.rest_b1))) return e; }
+    { uint64_t p[24]; memcpy(p, pk->delta_g1, 96); memcpy(p + 12, pk->eta_delta_inv_g1, 96);
+      uint64_t k[8], rs[4]; fr_mul(rs, in.r, in.s); fr_neg(k, rs); fr_neg(k + 4, in.v);
+      if ((e = dgpu_lincomb_g1(p, nullptr, k, 2, c.rest_c))) return e; }                                  // -rs delta - v eta/delta  (:350-355)
+    // g_d = msm(gamma_abc[n_inst .. n_inst + cw], committed witnesses) + v eta/gamma   (:361-368)
+    std::vector<uint64_t> pts((cw + 1) * 12), sc((cw + 1) * 4);
+    if (cw) memcpy(pts.data(), pk->gamma_abc_g1 + in.n_inst * 12, cw * 96);
+    memcpy(pts.data() + cw * 12, pk->eta_gamma_inv_g1, 96);
+    for (size_t i = 0; i < cw; i++) { if (in.montgomery) hostf::fr_from_mont(&sc[4 * i], in.z + 4 * (in.n_inst + i)); else memcpy(&sc[4 * i], in.z + 4 * (in.n_inst + i), 32); }
+    memcpy(&sc[4 * cw], in.v, 32);
+    if (cw + 1 <= DGPU_MAX_LINCOMB) return dgpu_lincomb_g1(pts.data(), nullptr, sc.data(), cw + 1, c.g_d);
+    return dock::msm_g1_nothreshold(pts.data(), nullptr, sc.data(), cw + 1, c.g_d);
+}
+// g_a and g1_b from their MSM parts, and s g_a + r g1_b (computed while the G2 MSM is still in flight)
+struct ProofAB { uint64_t ga[36]; uint64_t sa_rb[18]; uint8_t inf_a = 1, inf_b1 = 1; };
+int32_t proof_ab(const ProofInputs &in, const ProofConsts &c, const uint64_t acc_a[18], const uint64_t acc_b1[18], ProofAB &o) {
+    memset(o.ga, 0, sizeof o.ga);
+    int32_t e;
+    uint64_t parts[36]; memcpy(parts, acc_a, 144); memcpy(parts + 18, c.rest_a, 144);
+    if ((e = fold_to_affine_g1(parts, 2, o.ga, &o.inf_a))) return e;
+    if (in.with_b1) { memcpy(parts, acc_b1, 144); memcpy(parts + 18, c.rest_b1, 144); if ((e = fold_to_affine_g1(parts, 2, o.ga + 12, &o.inf_b1))) return e; }
+    const uint8_t inf_two[2] = {o.inf_a, o.inf_b1};
+    uint64_t k[8]; memcpy(k, in.s, 32); memcpy(k + 4, in.r, 32);
+    return dgpu_lincomb_g1(o.ga, inf_two, k, 2, o.sa_rb);
+}
+int32_t proof_finish(const ProofConsts &c, const ProofAB &ab, const uint64_t acc_b2[36], const uint64_t acc_l[18], const uint64_t acc_h[18],
+                     uint64_t out_a[12], uint64_t out_b[24], uint64_t out_c[12], uint64_t out_d[12], uint8_t out_inf[4]) {
+    int32_t rc;
+    {
+        uint64_t parts[72], jb[36];
+        memcpy(parts, acc_b2, 288); memcpy(parts + 36, c.rest_b2, 288);
+        if ((rc = dgpu_fold_g2(parts, 2, jb))) return rc;
+        bool zb = true; for (int i = 24; i < 36; i++) zb = zb && jb[i] == 0;
+        out_inf[1] = zb; if (zb) memset(out_b, 0, 192); else memcpy(out_b, jb, 192);
+    }
+    out_inf[0] = ab.inf_a; memcpy(out_a, ab.ga, 96);
+    {
+        uint64_t parts[72]; memcpy(parts, ab.sa_rb, 144); memcpy(parts + 18, c.rest_c, 144); memcpy(parts + 36, acc_l, 144); memcpy(parts + 54, acc_h, 144);
+        if ((rc = fold_to_affine_g1(parts, 4, out_c, &out_inf[2]))) return rc;            // g_c = s g_a + r g1_b - rs delta + l_aux + h_acc - v eta/delta
+    }
+    return fold_to_affine_g1(c.g_d, 1, out_d, &out_inf[3]);
+}
+int32_t prove_sharded(const ProofInputs &in, size_t G, uint64_t r1cs, uint64_t h_scalars, size_t num_vars,
+                      uint64_t out_a[12], uint64_t out_b[24], uint64_t out_c[12], uint64_t out_d[12], uint8_t out_inf[4]);
 }  // namespace
 
-extern "C" int32_t dgpu_handle_len(uint64_t handle, size_t *n);
+
 
 extern "C" int32_t dgpu_legogroth16_prove(const dgpu_lego_pk *pk, uint64_t r1cs, uint64_t h_scalars, const uint64_t *z, size_t num_vars, size_t n_inst,
                                           int32_t montgomery, const uint64_t r_in[4], const uint64_t s_in[4], const uint64_t v_in[4],
@@ -73,12 +133,15 @@ extern "C" int32_t dgpu_legogroth16_prove(const dgpu_lego_pk *pk, uint64_t r1cs,
     if (n_inst == 0 || n_inst + cw > num_vars || pk->gamma_abc_len < n_inst + cw) return DGPU_E_BADARG;
     if (!pk->alpha_g1 || !pk->beta_g1 || !pk->delta_g1 || !pk->eta_delta_inv_g1 || !pk->eta_gamma_inv_g1 || !pk->beta_g2 || !pk->delta_g2 ||
         !pk->a0 || !pk->b1_0 || !pk->b2_0 || (cw && !pk->gamma_abc_g1)) return DGPU_E_BADARG;
+    ProofInputs in{pk, z, n_inst, montgomery, {0}, {0}, {0}, false};
+    fr_reduce(in.r, r_in); fr_reduce(in.s, s_in); fr_reduce(in.v, v_in);
+    in.with_b1 = !is_zero4(in.r);                                                    // prover.rs:330-336
+    { int32_t shards = 0;                                                           // a key resident across several device contexts (dgpu_bases_upload_*_sharded)
+      if (dgpu_shard_count(pk->a_query, &shards) == DGPU_OK && shards > 0) return prove_sharded(in, (size_t)shards, r1cs, h_scalars, num_vars, out_a, out_b, out_c, out_d, out_inf); }
     size_t n_a = 0, n_b1 = 0, n_b2 = 0, n_h = 0, n_l = 0;
     if (dgpu_handle_len(pk->a_query, &n_a) || dgpu_handle_len(pk->b_g1_query, &n_b1) || dgpu_handle_len(pk->b_g2_query, &n_b2) ||
         dgpu_handle_len(pk->h_query, &n_h) || dgpu_handle_len(pk->l_query, &n_l) || n_a == 0 || n_b1 == 0 || n_b2 == 0) return DGPU_E_BADARG;
-    uint64_t r[4], s[4], v[4];
-    fr_reduce(r, r_in); fr_reduce(s, s_in); fr_reduce(v, v_in);
-    const bool with_b1 = !is_zero4(r);                                              // prover.rs:330-336
+    const bool with_b1 = in.with_b1;
 
     // ---- z resident, once ----
     uint64_t zh = 0;
@@ -124,63 +187,116 @@ extern "C" int32_t dgpu_legogroth16_prove(const dgpu_lego_pk *pk, uint64_t r1cs,
         return dgpu_msm_g1_resident(pk->l_query, 0, zh, aux_at, std::min(n_l, n_aux), acc_l);
     });
 
-    // ---- job K: what depends on no MSM (host arithmetic; the tiny g_d MSM goes to the device only when it has more than 15 terms) ----
-    uint64_t rest_a[18], rest_b1[18], rest_c[18], rest_b2[36], g_d[18];
-    jK.start([&]() -> int32_t {
-        int32_t e;
-        { uint64_t p[36]; memcpy(p, pk->delta_g1, 96); memcpy(p + 12, pk->a0, 96); memcpy(p + 24, pk->alpha_g1, 96);
-          uint64_t k[12]; memcpy(k, r, 32); memcpy(k + 4, ONE4, 32); memcpy(k + 8, ONE4, 32);
-          if ((e = dgpu_lincomb_g1(p, nullptr, k, 3, rest_a))) return e; }                                  // r delta + a_0 + alpha  (:585-594)
-        { uint64_t p[72]; memcpy(p, pk->delta_g2, 192); memcpy(p + 24, pk->b2_0, 192); memcpy(p + 48, pk->beta_g2, 192);
-          uint64_t k[12]; memcpy(k, s, 32); memcpy(k + 4, ONE4, 32); memcpy(k + 8, ONE4, 32);
-          if ((e = dgpu_lincomb_g2(p, nullptr, k, 3, rest_b2))) return e; }
-        if (with_b1) { uint64_t p[36]; memcpy(p, pk->delta_g1, 96); memcpy(p + 12, pk->b1_0, 96); memcpy(p + 24, pk->beta_g1, 96);
-          uint64_t k[12]; memcpy(k, s, 32); memcpy(k + 4, ONE4, 32); memcpy(k + 8, ONE4, 32);
-          if ((e = dgpu_lincomb_g1(p, nullptr, k, 3, rest_b1))) return e; }
-        { uint64_t p[24]; memcpy(p, pk->delta_g1, 96); memcpy(p + 12, pk->eta_delta_inv_g1, 96);
-          uint64_t k[8], rs[4]; fr_mul(rs, r, s); fr_neg(k, rs); fr_neg(k + 4, v);
-          if ((e = dgpu_lincomb_g1(p, nullptr, k, 2, rest_c))) return e; }                                  // -rs delta - v eta/delta  (:350-355)
-        // g_d = msm(gamma_abc[n_inst .. n_inst + cw], committed witnesses) + v eta/gamma   (:361-368)
-        std::vector<uint64_t> pts((cw + 1) * 12), sc((cw + 1) * 4);
-        if (cw) memcpy(pts.data(), pk->gamma_abc_g1 + n_inst * 12, cw * 96);
-        memcpy(pts.data() + cw * 12, pk->eta_gamma_inv_g1, 96);
-        for (size_t i = 0; i < cw; i++) { if (montgomery) hostf::fr_from_mont(&sc[4 * i], z + 4 * (n_inst + i)); else memcpy(&sc[4 * i], z + 4 * (n_inst + i), 32); }
-        memcpy(&sc[4 * cw], v, 32);
-        if (cw + 1 <= DGPU_MAX_LINCOMB) return dgpu_lincomb_g1(pts.data(), nullptr, sc.data(), cw + 1, g_d);
-        return dock::msm_g1_nothreshold(pts.data(), nullptr, sc.data(), cw + 1, g_d);
-    });
+    // ---- job K: what depends on no MSM ----
+    ProofConsts cst;
+    jK.start([&] { return proof_constants(in, cst); });
 
     // ---- assemble ----
     int32_t first = DGPU_OK;
     auto note = [&](int32_t e) { if (e && !first) first = e; };
     note(jK.join()); note(jA.join()); if (with_b1) note(jB1.join());
-    uint64_t ga[36], sa_rb[18];                     // g_a then g1_b as affine points, for s g_a + r g1_b
-    uint8_t inf_a = 1, inf_b1 = 1, inf_two[2] = {1, 1};
-    memset(ga, 0, sizeof ga);
-    if (!first) {
-        uint64_t parts[36]; memcpy(parts, acc_a, 144); memcpy(parts + 18, rest_a, 144);
-        note(fold_to_affine_g1(parts, 2, ga, &inf_a));
-        if (with_b1) { memcpy(parts, acc_b1, 144); memcpy(parts + 18, rest_b1, 144); note(fold_to_affine_g1(parts, 2, ga + 12, &inf_b1)); }
-        inf_two[0] = inf_a; inf_two[1] = inf_b1;
-        uint64_t k[8]; memcpy(k, s, 32); memcpy(k + 4, r, 32);
-        if (!first) note(dgpu_lincomb_g1(ga, inf_two, k, 2, sa_rb));                    // (while the G2 MSM is still in flight)
-    }
+    ProofAB ab;
+    if (!first) note(proof_ab(in, cst, acc_a, acc_b1, ab));                          // (while the G2 MSM is still in flight)
     note(jB2.join()); note(jL.join()); note(jH.join());
     if (sorted) (void)dgpu_scalars_free(sorted);
     if (h_owned) (void)dgpu_scalars_free(h_owned);
     (void)dgpu_scalars_free(zh);
     if (first) return first;
-    {
-        uint64_t parts[72], jb[36];
-        memcpy(parts, acc_b2, 288); memcpy(parts + 36, rest_b2, 288);
-        if ((rc = dgpu_fold_g2(parts, 2, jb))) return rc;
-        bool zb = true; for (int i = 24; i < 36; i++) zb = zb && jb[i] == 0;
-        out_inf[1] = zb; if (zb) memset(out_b, 0, 192); else memcpy(out_b, jb, 192);
-    }
-    out_inf[0] = inf_a; memcpy(out_a, ga, 96);
-    {
-        uint64_t parts[72]; memcpy(parts, sa_rb, 144); memcpy(parts + 18, rest_c, 144); memcpy(parts + 36, acc_l, 144); memcpy(parts + 54, acc_h, 144);
-        if ((rc = fold_to_affine_g1(parts, 4, out_c, &out_inf[2]))) return rc;            // g_c = s g_a + r g1_b - rs delta + l_aux + h_acc - v eta/delta
-    }
-    return fold_to_affine_g1(g_d, 1, out_d, &out_inf[3]);
+    return proof_finish(cst, ab, acc_b2, acc_l, acc_h, out_a, out_b, out_c, out_d, out_inf);
 }
+
+// ---- the same proof with the key resident across G device contexts (one process): every query is a sharded handle whose part g lives on
+// context g.  Context g multiplies its rows of the five queries by the matching slice of z / h (one host thread per context inside this call, the
+// schedule of the single-device form inside it: shared sort, G2 first); the witness map runs once, on the circuit's context, and its h coefficients
+// travel through the host to the shards (D x 32 B down, 1 / G of it up per shard); the per-shard partial points are folded on the host.
+namespace {
+struct ShardRange { uint64_t sub; size_t lo, hi; int32_t ctx; };
+int32_t shard_part(uint64_t handle, size_t g, ShardRange &o) { return dgpu_shard_part(handle, g, &o.sub, &o.lo, &o.hi, &o.ctx); }
+
+int32_t prove_sharded(const ProofInputs &in, size_t G, uint64_t r1cs, uint64_t h_scalars, size_t num_vars,
+                      uint64_t out_a[12], uint64_t out_b[24], uint64_t out_c[12], uint64_t out_d[12], uint8_t out_inf[4]) {
+    const dgpu_lego_pk *pk = in.pk; const size_t cw = pk->commit_witness_count, n_inst = in.n_inst;
+    const size_t aux_at = n_inst + cw;
+    std::vector<ShardRange> A(G), B1(G), B2(G), Hq(G), L(G);
+    for (size_t g = 0; g < G; g++) {
+        if (shard_part(pk->a_query, g, A[g]) || shard_part(pk->b_g1_query, g, B1[g]) || shard_part(pk->b_g2_query, g, B2[g]) ||
+            shard_part(pk->h_query, g, Hq[g]) || shard_part(pk->l_query, g, L[g])) return DGPU_E_BADARG;
+        if (A[g].ctx != B1[g].ctx || A[g].ctx != B2[g].ctx || A[g].ctx != Hq[g].ctx || A[g].ctx != L[g].ctx ||
+            A[g].lo != B1[g].lo || A[g].hi != B1[g].hi || A[g].lo != B2[g].lo || A[g].hi != B2[g].hi) return DGPU_E_BADARG;     // the five queries split over the same contexts, a / b alike
+    }
+    // h: from the caller (a resident vector cannot be split here: it must be a host-visible source) or from the witness map on the circuit's context
+    if (!r1cs) return DGPU_E_BADARG;                 // the sharded form takes the circuit (h_scalars lives on one device only)
+    (void)h_scalars;
+    size_t D = 0;
+    std::vector<uint64_t> h;
+    Job jW;
+    jW.start([&]() -> int32_t {
+        int32_t rctx = 0; if (dgpu_handle_context(r1cs, &rctx)) return DGPU_E_BADARG;
+        if (dgpu_set_device(rctx)) return DGPU_E_BADARG;
+        size_t nc = 0; if (dgpu_handle_len(r1cs, &nc)) return DGPU_E_BADARG;              // constraints of the circuit
+        size_t cap = 1; while (cap < nc + n_inst) cap <<= 1;                                // the domain of r1cs_to_qap.rs:150-160
+        h.assign(cap * 4, 0);
+        return dgpu_witness_map_r1cs(r1cs, in.z, num_vars, in.montgomery, h.data(), nullptr, &D);
+    });
+    ProofConsts cst; Job jK;
+    jK.start([&] { return proof_constants(in, cst); });
+    // per shard: the A / B1 / B2 / L partial sums now, the H partial sum once h is there
+    std::vector<uint64_t> pa(G * 18), pb1(G * 18), pl(G * 18), ph(G * 18), pb2(G * 36);
+    std::vector<Job> jobs(G);
+    std::vector<int32_t> wm_rc(1, DGPU_OK);
+    // (the witness map is awaited by shard threads through this join-once helper)
+    std::mutex wm_mu; bool wm_joined = false;
+    auto wait_h = [&]() -> int32_t { std::lock_guard<std::mutex> lk(wm_mu); if (!wm_joined) { wm_rc[0] = jW.join(); wm_joined = true; } return wm_rc[0]; };
+    for (size_t g = 0; g < G; g++) jobs[g].start([&, g]() -> int32_t {
+        if (dgpu_set_device(A[g].ctx)) return DGPU_E_BADARG;
+        int32_t e = DGPU_OK;
+        auto identity1 = [](uint64_t *o) { uint64_t none[18]; (void)dgpu_fold_g1(none, 0, o); };
+        auto identity2 = [](uint64_t *o) { uint64_t none[36]; (void)dgpu_fold_g2(none, 0, o); };
+        // rows [lo, hi) of the (V + 1)-row queries; row 0 is query[0] (added by proof_constants): terms are rows max(lo, 1) .. hi, paired with z[row]
+        const size_t lo = std::max<size_t>(A[g].lo, 1), hi = std::min(A[g].hi, num_vars);
+        uint64_t zs = 0, srt = 0;
+        if (hi > lo) {
+            const size_t n = hi - lo, boff = lo - A[g].lo;
+            if ((e = dgpu_scalars_upload(in.z + 4 * lo, n, in.montgomery, &zs))) return e;
+            size_t ra = 0, rx = 0; int32_t ca = 0, cx = 0, wa = 0, wx = 0;
+            bool share = dgpu_bases_table_shape(A[g].sub, &ra, &ca, &wa) == DGPU_OK && dgpu_bases_table_shape(B2[g].sub, &rx, &cx, &wx) == DGPU_OK && rx == ra && cx == ca;
+            if (share && in.with_b1) share = dgpu_bases_table_shape(B1[g].sub, &rx, &cx, &wx) == DGPU_OK && rx == ra && cx == ca;
+            if (share && dgpu_scalars_sort(A[g].sub, boff, zs, 0, n, &srt) != DGPU_OK) { srt = 0; share = false; }
+            Job j2, j1;
+            j2.start([&] { return share ? dgpu_msm_g2_sorted(B2[g].sub, srt, 0, &pb2[36 * g]) : dgpu_msm_g2_resident(B2[g].sub, boff, zs, 0, n, &pb2[36 * g]); });      // G2 first
+            if (in.with_b1) j1.start([&] { return share ? dgpu_msm_g1_sorted(B1[g].sub, srt, 0, &pb1[18 * g]) : dgpu_msm_g1_resident(B1[g].sub, boff, zs, 0, n, &pb1[18 * g]); });
+            else identity1(&pb1[18 * g]);
+            e = share ? dgpu_msm_g1_sorted(A[g].sub, srt, 0, &pa[18 * g]) : dgpu_msm_g1_resident(A[g].sub, boff, zs, 0, n, &pa[18 * g]);
+            const int32_t e1 = j1.join(), e2 = j2.join();
+            if (!e) e = e1; if (!e) e = e2;
+            if (srt) (void)dgpu_scalars_free(srt);
+            (void)dgpu_scalars_free(zs);
+            if (e) return e;
+        } else { identity1(&pa[18 * g]); identity1(&pb1[18 * g]); identity2(&pb2[36 * g]); }
+        // l_query rows [lo, hi) pair with z[aux_at + row]
+        { const size_t llo = L[g].lo, lhi = std::min(L[g].hi, num_vars - std::min(num_vars, aux_at));
+          if (lhi > llo) { uint64_t zl = 0; if ((e = dgpu_scalars_upload(in.z + 4 * (aux_at + llo), lhi - llo, in.montgomery, &zl))) return e;
+                           e = dgpu_msm_g1_resident(L[g].sub, 0, zl, 0, lhi - llo, &pl[18 * g]); (void)dgpu_scalars_free(zl); if (e) return e; }
+          else identity1(&pl[18 * g]); }
+        // h_query rows [lo, hi) pair with h[row] (canonical, from the witness map)
+        if ((e = wait_h())) return e;
+        { const size_t hlo = Hq[g].lo, hhi = std::min(Hq[g].hi, D);
+          if (hhi > hlo) { uint64_t hs = 0; if ((e = dgpu_scalars_upload(h.data() + 4 * hlo, hhi - hlo, 0, &hs))) return e;
+                           e = dgpu_msm_g1_resident(Hq[g].sub, 0, hs, 0, hhi - hlo, &ph[18 * g]); (void)dgpu_scalars_free(hs); if (e) return e; }
+          else identity1(&ph[18 * g]); }
+        return DGPU_OK;
+    });
+    int32_t first = DGPU_OK;
+    auto note = [&](int32_t e) { if (e && !first) first = e; };
+    note(jK.join());
+    for (size_t g = 0; g < G; g++) note(jobs[g].join());
+    note(wait_h());
+    if (first) return first;
+    uint64_t acc_a[18], acc_b1[18], acc_l[18], acc_h[18], acc_b2[36];
+    if ((first = dgpu_fold_g1(pa.data(), G, acc_a)) || (first = dgpu_fold_g1(pb1.data(), G, acc_b1)) || (first = dgpu_fold_g1(pl.data(), G, acc_l)) ||
+        (first = dgpu_fold_g1(ph.data(), G, acc_h)) || (first = dgpu_fold_g2(pb2.data(), G, acc_b2))) return first;
+    ProofAB ab;
+    if ((first = proof_ab(in, cst, acc_a, acc_b1, ab))) return first;
+    return proof_finish(cst, ab, acc_b2, acc_l, acc_h, out_a, out_b, out_c, out_d, out_inf);
+}
+}  // namespace

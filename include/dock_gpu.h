@@ -319,8 +319,16 @@ typedef struct dgpu_lego_pk {
 int32_t dgpu_legogroth16_prove(const dgpu_lego_pk *pk, uint64_t r1cs, uint64_t h_scalars, const uint64_t *z, size_t num_vars, size_t n_inst,
                                int32_t montgomery, const uint64_t r[4], const uint64_t s[4], const uint64_t v[4],
                                uint64_t out_a[12], uint64_t out_b[24], uint64_t out_c[12], uint64_t out_d[12], uint8_t out_inf[4]);
-/* elements behind a bases / scalars / sorted handle */
+/* The same call accepts a key that is resident across several device contexts (every query a dgpu_bases_upload_*_sharded handle, optionally
+ * dgpu_bases_precompute_*d; the five queries over the same contexts): context g multiplies its rows by the matching slices of z and h from a host
+ * thread of its own inside the call, the witness map runs once on the circuit's context (r1cs must be given), the partial points are folded on
+ * the host.  Same proof as the single-device call (tests/test_gpu_prove_abi.py, two contexts on one GPU). */
+/* elements behind a bases / scalars / sorted handle; constraints of a resident circuit */
 int32_t dgpu_handle_len(uint64_t handle, size_t *n);
+int32_t dgpu_handle_context(uint64_t handle, int32_t *context);
+/* layout of a sharded handle: number of parts (0: not sharded); part k holds elements [lo, hi) as a handle of its own on `context` */
+int32_t dgpu_shard_count(uint64_t handle, int32_t *count);
+int32_t dgpu_shard_part(uint64_t handle, size_t k, uint64_t *sub_handle, size_t *lo, size_t *hi, int32_t *context);
 
 /* ---- canonical (de)serialisation of group elements (host code) ----
  * The format ark-bls12-381 0.4 emits for `CanonicalSerialize` (Zcash / IETF BLS12-381): big-endian coordinates, top three bits of

@@ -58,3 +58,34 @@ def test_one_call_equals_the_python_schedule(m, cw):
     with pytest.raises(ca.DockGpuError):
         LG.prove_abi(pk, r, s, v, z, len(z) + 1, circuit=dr)
     dr.free()
+
+
+@pytest.mark.parametrize("m,cw", [(117, 3), (300, 0)])
+def test_key_resident_across_two_contexts(m, cw):
+    """dgpu_legogroth16_prove on a key whose five queries are sharded handles over two device contexts (two contexts on the box's one GPU: every
+    code path of the multi-GPU form except a second physical device): the same proof as the single-context call, plain shards and tables."""
+    ca.init_devices([0, 0])
+    cs = LS.circuit(m, x0=5)
+    key = LS.setup(cs, cw, seed=700 + m)
+    vk = LG.VerifyingKey(key["alpha_g1"], key["beta_g2"], key["gamma_g2"], key["delta_g2"], key["gamma_abc_g1"], key["eta_gamma_inv_g1"], cw)
+    small = (vk, key["beta_g1"], key["delta_g1"], key["eta_delta_inv_g1"])
+    pk1 = LG.ProvingKey(*small, key["a_query"], key["b_g1_query"], key["b_g2_query"], key["h_query"], key["l_query"])
+    sh = lambda curve, q: ca.ShardedDeviceBases(curve, q, ngpus=2)
+    pk2 = LG.ProvingKey.from_device(*small, key["a_query"][0].copy(), key["b_g1_query"][0].copy(), key["b_g2_query"][0].copy(),
+                                    sh(ca.G1, key["a_query"]), sh(ca.G1, key["b_g1_query"]), sh(ca.G2, key["b_g2_query"]), sh(ca.G1, key["h_query"]), sh(ca.G1, key["l_query"]))
+    z = LS.scalars(cs["z"]); n_inst = cs["n_inst"]
+    dr = qap.DeviceR1cs(*[qap.csr(cs[k]) for k in "ABC"], len(cs["z"]), n_inst, len(cs["A"]))
+    r, s, v = 0x1234567 * 0x9E3779B97F4A7C15 % R, 0xABCDEF01 * 0xBF58476D1CE4E5B9 % R, 0x55AA55 * 0x94D049BB133111EB % R
+    pvk = LG.prepare_verifying_key(vk)
+    for tables in (False, True):
+        if tables:
+            for q in (pk2.a_query, pk2.b_g1_query, pk2.b_g2_query, pk2.h_query, pk2.l_query):
+                q.precompute(16)
+        for rr in (r, 0):
+            ref = LG.prove_abi(pk1, rr, s, v, z, n_inst, circuit=dr)
+            got = LG.prove_abi(pk2, rr, s, v, z, n_inst, circuit=dr)
+            assert all((got[k] == ref[k]).all() for k in ref), (tables, rr)
+            assert LG.verify_proof(pvk, got, z[1:n_inst])
+        gm = LG.prove_abi(pk2, r, s, v, O.fr_to_mont(z), n_inst, circuit=dr, montgomery=True)
+        assert all((gm[k] == ref[k]).all() for k in ref) if False else all((gm[k] == LG.prove_abi(pk1, r, s, v, z, n_inst, circuit=dr)[k]).all() for k in gm)
+    dr.free()

@@ -241,7 +241,7 @@ def main():
             "value": round(value, 3), "unit": "MSM/s (n=2^20-term equivalents, whole job)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
             "higher_is_better": True, "scaling": "weak" if world == 1 else "strong", "vs_baseline": None,
-            "dtype": "u32 (29-bit limbs, 381-bit modular integer)",
+            "dtype": "i32 (13 signed 30-bit limbs, 381-bit modular integer; 64-bit column accumulators)",
             "data": "synthetic (seeded PCG64 scalars uniform in [0, r); bases k_i G with seeded known discrete logs from the fixed-base kernel)",
             "config": {"workload": "BLS12-381 G1 variable-base MSM, n=2^%d terms per GPU, operands resident in HBM (%s), %s" % (
                 args.log2n, "bases as a precomputed-multiples table built once per key outside the timed region" if use_table else "plain prepared bases",

@@ -52,6 +52,31 @@ def test_g1_2_24_closed_form_and_split():
     ds.free(); db.free()
 
 
+@pytest.mark.parametrize("name,lg", [("G1", 20), ("G1", 19), ("G2", 19)])
+def test_one_shot_calls_in_term_ranges_closed_form(name, lg):
+    """BASELINE config 2's size through the ONE-SHOT entry points (operands in host memory: the form 166 unmodified call sites use): from
+    n = 2^19 the operands cross PCIe in two term ranges with a bucket set each (msm_device_ranges) — packed arrays, the caller's Affine
+    structs, Montgomery scalars, and an odd length; closed form over known discrete logs."""
+    curve, G = (ca.G1, O.G1) if name == "G1" else (ca.G2, O.G2)
+    n = (1 << lg) + 12345
+    ks = O.rand_scalars(9000 + lg, n); sc = O.rand_scalars(9100 + lg, n)
+    with fb.WindowTable(curve, G.generator()) as t:
+        bases, inf = t.multiply_many(ks)
+        exp_xy, _ = t.multiply(dot_mod_r(ks, sc))
+    assert not inf.any()
+    r = ca.msm_bigint(curve, bases, sc)
+    assert (r[:curve.AW] == exp_xy).all() and r[curve.AW:].any()
+    st = ca.to_affine_structs(curve, bases)
+    assert (ca.msm_strided(curve, st, sc) == r).all()
+    assert (ca.msm_unchecked(curve, bases, O.fr_to_mont(sc)) == r).all()
+    # identity flags in the second range only, and a shorter call on the same slot afterwards
+    inf2 = np.zeros(n, np.uint8); inf2[n - 1000:] = 1
+    with fb.WindowTable(curve, G.generator()) as t:
+        exp2, _ = t.multiply(dot_mod_r(ks[:n - 1000], sc[:n - 1000]))
+    assert (ca.msm_bigint(curve, bases, sc, inf2)[:curve.AW] == exp2).all()
+    assert (ca.msm_bigint(curve, bases[:n - 1000], sc)[:curve.AW] == exp2).all()
+
+
 @pytest.mark.parametrize("m,logd", [((1 << 20) - 3, 20), (1 << 20, 21)])
 def test_witness_map_full_size_vs_oracle(m, logd):
     z, A, B, Cm, n_inst, nc = big_circuit(m, 5)

@@ -80,6 +80,8 @@ int main() {
         printf("madd<2w> blocks=%4d  %.3f ms  %.3f Gmadd/s  (%.2f Tmad/s)\n", blocks, ms, (double)blocks * 256 * iters / ms * 1e-6, mads / ms * 1e-9);
         ms = timeit([&] { hipLaunchKernelGGL(k_madd_s<2>, dim3(blocks), dim3(256), 0, 0, d, o, iters); }, 3);
         printf("madd_s<2w> blocks=%4d  %.3f ms  %.3f Gmadd/s  (13 x 30-bit signed field)\n", blocks, ms, (double)blocks * 256 * iters / ms * 1e-6);
+        ms = timeit([&] { hipLaunchKernelGGL(k_madd_s<3>, dim3(blocks), dim3(256), 0, 0, d, o, iters); }, 3);
+        printf("madd_s<3w> blocks=%4d  %.3f ms  %.3f Gmadd/s  (13 x 30-bit signed field)\n", blocks, ms, (double)blocks * 256 * iters / ms * 1e-6);
         ms = timeit([&] { hipLaunchKernelGGL(k_madd<3>, dim3(blocks), dim3(256), 0, 0, d, o, iters); }, 3);
         printf("madd<3w> blocks=%4d  %.3f ms  %.3f Gmadd/s  (%.2f Tmad/s)\n", blocks, ms, (double)blocks * 256 * iters / ms * 1e-6, mads / ms * 1e-9);
         ms = timeit([&] { hipLaunchKernelGGL(k_madd<4>, dim3(blocks), dim3(256), 0, 0, d, o, iters); }, 3);

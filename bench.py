@@ -342,9 +342,12 @@ def secondary_configs(log2n, ks, scalars, db, ds, pool):
     def thr4(fn, k=16):
         """ms per call with four calls in flight (four host threads); warmed concurrently on the same threads"""
         list(pool4.map(lambda _: fn(), range(8)))
-        t0 = time.perf_counter()
-        list(pool4.map(lambda _: fn(), range(k)))
-        return (time.perf_counter() - t0) / k * 1e3
+        best = 1e9
+        for _ in range(2):                       # (best of two passes: a box with busy host cores stretches a pass now and then)
+            t0 = time.perf_counter()
+            list(pool4.map(lambda _: fn(), range(k)))
+            best = min(best, (time.perf_counter() - t0) / k * 1e3)
+        return best
 
     with FB.WindowTable(ca.G1, gen1[0]) as t1:
         plain = t1.multiply_many_to_bases(ks)
@@ -354,9 +357,12 @@ def secondary_configs(log2n, ks, scalars, db, ds, pool):
     def thr_pool(fn, k=24):
         """ms per call with as many calls in flight as the headline run uses (the same host threads)"""
         list(pool.map(lambda _: fn(), range(12)))
-        t0 = time.perf_counter()
-        list(pool.map(lambda _: fn(), range(k)))
-        return (time.perf_counter() - t0) / k * 1e3
+        best = 1e9
+        for _ in range(2):
+            t0 = time.perf_counter()
+            list(pool.map(lambda _: fn(), range(k)))
+            best = min(best, (time.perf_counter() - t0) / k * 1e3)
+        return best
     res["plain_resident"] = {"latency_ms": round(timed(lambda: plain.msm_resident(ds), 5, warm=3), 3), "ms_per_msm_4_in_flight": round(thr4(lambda: plain.msm_resident(ds), 24), 3),
                              "ms_per_msm_in_flight_like_headline": round(thr_pool(lambda: plain.msm_resident(ds)), 3)}
     res["plain_resident"]["msm_per_s"] = round(1e3 / res["plain_resident"]["ms_per_msm_in_flight_like_headline"], 2)

@@ -21,13 +21,63 @@ FD void fnorm(Fs2 &r, const Fs2 &a) { fs_bal(r.c0, a.c0); fs_bal(r.c1, a.c1); }
 FD void fnormw(Fs2 &r, const Fs2 &a) { fs_bal_wide(r.c0, a.c0); fs_bal_wide(r.c1, a.c1); }
 FD bool fmaybe_zero(const Fs2 &a) { return fs_maybe_zero(a.c0) && fs_maybe_zero(a.c1); }
 FD bool fis_zero_exact(const Fs2 &a) { return fs_is_zero_exact(a.c0) && fs_is_zero_exact(a.c1); }
+// (Measurement only, -DFS2_KARATSUBA, tools/ubench/g2_madd_rate.hip.)  Karatsuba form of the one-lane product: the three operand products a0 b0, a1 b1, (a0 + a1)(b0 + b1) are formed column by column and
+// combined BEFORE the two reductions (c0 columns = S - T, c1 columns = U - S - T): 3 * 169 + 2 * 169 = 845 multiply-adds against 1014.
+// U alone may pass 2^63 (operand sums have 31-bit digits); the accumulators are unsigned so that it wraps, and what is shifted / reduced is
+// U - S - T = the cross-term column, bounded exactly as in fs_mul2.  Measured on MI355X: the one-lane mixed addition built on it runs at
+// 1.0 G additions/s (five live 64-bit column chains on top of a 104-register accumulator: 170-670 spilled registers), the one-lane form on
+// fs_mul2 at 2.3 G/s, the lane-pair form (Fs2H below) at 2.5 G/s — which is why the accumulation keeps lane pairs and 1014 multiply-adds.
+#ifdef FS2_KARATSUBA
+FD void fs2_mul_kara(Fs &r0, Fs &r1, const Fs &a0, const Fs &a1, const Fs &b0, const Fs &b1) {
+    constexpr int32_t P_[SN] = BLS30_P;
+    SCHK({ Fs n1; fs_neg(n1, a1); const Fs *pa[2] = {&a0, &n1}, *pb[2] = {&b0, &b1}; schk_columns(pa, pb, 2);
+           const Fs *qa[2] = {&a0, &a1}, *qb[2] = {&b1, &b0}; schk_columns(qa, qb, 2); })
+    int32_t sa[SN], sb[SN], m0[SN], m1[SN], t0[SN], t1[SN];
+#pragma unroll
+    for (int i = 0; i < SN; i++) { sa[i] = a0.l[i] + a1.l[i]; sb[i] = b0.l[i] + b1.l[i]; }
+    uint64_t acc0 = 0, acc1 = 0;
+#define MA(acc, x, y) acc += (uint64_t)((int64_t)(x) * (int64_t)(y))
+#pragma unroll
+    for (int k = 0; k < SN; k++) {
+        uint64_t S = 0, T = 0, U = 0, R0 = 0, R1 = 0;
+#pragma unroll
+        for (int i = 0; i <= k; i++) { MA(S, a0.l[i], b0.l[k - i]); MA(T, a1.l[i], b1.l[k - i]); MA(U, sa[i], sb[k - i]); }
+#pragma unroll
+        for (int i = 0; i < k; i++) { MA(R0, m0[i], P_[k - i]); MA(R1, m1[i], P_[k - i]); }
+        acc0 += S - T + R0; acc1 += U - S - T + R1;
+        m0[k] = sext30((uint32_t)acc0 * SINV30); MA(acc0, m0[k], P_[0]); acc0 = (uint64_t)((int64_t)acc0 >> SB);
+        m1[k] = sext30((uint32_t)acc1 * SINV30); MA(acc1, m1[k], P_[0]); acc1 = (uint64_t)((int64_t)acc1 >> SB);
+    }
+#pragma unroll
+    for (int k = SN; k < 2 * SN - 1; k++) {
+        uint64_t S = 0, T = 0, U = 0, R0 = (uint64_t)SHALF, R1 = (uint64_t)SHALF;
+#pragma unroll
+        for (int i = k - SN + 1; i < SN; i++) { MA(S, a0.l[i], b0.l[k - i]); MA(T, a1.l[i], b1.l[k - i]); MA(U, sa[i], sb[k - i]); }
+#pragma unroll
+        for (int i = k - SN + 1; i < SN; i++) { MA(R0, m0[i], P_[k - i]); MA(R1, m1[i], P_[k - i]); }
+        acc0 += S - T + R0; acc1 += U - S - T + R1;
+        t0[k - SN] = (int32_t)((uint32_t)acc0 & SMASK) - SHALF; acc0 = (uint64_t)((int64_t)acc0 >> SB);
+        t1[k - SN] = (int32_t)((uint32_t)acc1 & SMASK) - SHALF; acc1 = (uint64_t)((int64_t)acc1 >> SB);
+    }
+#undef MA
+    t0[SN - 1] = (int32_t)acc0; t1[SN - 1] = (int32_t)acc1;
+    SCHK(const double v0 = 0.51 + (a0.vb * b0.vb + a1.vb * b1.vb) * P_OVER_2_390, v1 = 0.51 + (a0.vb * b1.vb + a1.vb * b0.vb) * P_OVER_2_390;)
+#pragma unroll
+    for (int i = 0; i < SN; i++) { r0.l[i] = t0[i]; r1.l[i] = t1[i]; }
+    SCHK(schk_set_B(r0, v0); schk_set_B(r1, v1); schk_actual(r0); schk_actual(r1);)
+}
+#endif
 // (a0 b0 - a1 b1) + (a0 b1 + a1 b0) u; all components class B
 FD void fmul(Fs2 &r, const Fs2 &a, const Fs2 &b) {
+#ifdef FS2_KARATSUBA
+    fs2_mul_kara(r.c0, r.c1, a.c0, a.c1, b.c0, b.c1);
+#else
     Fs n1, c0, c1;
     fs_neg(n1, a.c1);
     fs_mul2(c0, a.c0, b.c0, n1, b.c1);
     fs_mul2(c1, a.c0, b.c1, a.c1, b.c0);
     r.c0 = c0; r.c1 = c1;
+#endif
 }
 // (a0 + a1)(a0 - a1), 2 a0 a1; a class B
 FD void fsqr(Fs2 &r, const Fs2 &a) {

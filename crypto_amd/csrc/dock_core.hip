@@ -95,6 +95,7 @@ static int32_t init_ctx_locked(int idx, int device) {
         HIPCHK(hipStreamCreateWithFlags(&c.slots[i].stream, hipStreamNonBlocking));
         HIPCHK(hipStreamCreateWithFlags(&c.slots[i].cstream, hipStreamNonBlocking));
         for (hipEvent_t &e : c.slots[i].copy_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        HIPCHK(hipHostMalloc(&c.slots[i].hpin, Slot::HPIN_BYTES, hipHostMallocDefault));
         HIPCHK(c.slots[i].flags.ensure(64) ? hipErrorOutOfMemory : hipSuccess);
     }
     c.device = device; c.ready = true;
@@ -150,7 +151,8 @@ int32_t dgpu_shutdown(void) {
             (void)hipStreamDestroy(c.slots[k].stream);
             (void)hipStreamDestroy(c.slots[k].cstream);
             for (hipEvent_t &e : c.slots[k].copy_ev) { if (e) (void)hipEventDestroy(e); e = nullptr; }
-            c.slots[k].stream = nullptr; c.slots[k].cstream = nullptr;
+            if (c.slots[k].hpin) (void)hipHostFree(c.slots[k].hpin);
+            c.slots[k].stream = nullptr; c.slots[k].cstream = nullptr; c.slots[k].hpin = nullptr;
         }
     }
     std::unique_lock<std::mutex> lk(gs.mu);
@@ -197,6 +199,7 @@ int32_t dgpu_set_min_gpu_n(size_t n) { gs.min_gpu_n = n; return DGPU_OK; }
 size_t dgpu_get_min_gpu_n(void) { return gs.min_gpu_n.load(); }
 int32_t dgpu_set_window_bits(int32_t c) { if (c != 0 && (c < 7 || c > 22)) return DGPU_E_BADARG; gs.window_bits = c; return DGPU_OK; }
 int32_t dgpu_set_chunk(int32_t terms) { if (terms != 0 && (terms < 16 || terms > 4096)) return DGPU_E_BADARG; gs.chunk = terms; return DGPU_OK; }
+int32_t dgpu_set_miller_pipeline(int32_t on) { gs.ml_pipeline = on != 0; return DGPU_OK; }
 uint64_t dgpu_device_alloc_count(void) { return g_dev_allocs.load(); }
 
 

@@ -58,14 +58,16 @@ struct Slot {
     // H2D pieces travel on their own stream, ordered against the compute stream by these events: the kernels of a call run under its copies
     static constexpr int N_COPY_EV = 15;
     hipStream_t cstream = nullptr;
+    void *hpin = nullptr;           // pinned host scratch (HPIN_BYTES): results a host thread consumes while the slot's streams keep running
+    static constexpr size_t HPIN_BYTES = 64 * 1024;
     hipEvent_t copy_ev[N_COPY_EV + 1] = {};
     unsigned ev_next = 0;           // next event to record (taken in turn)
-    Buf flags, in_bases, in_inf, in_scalars, prepped, digits, heavy, cnt, off, cursor, bsums, entries, bucket, bucket_inf, head, tail, head_b, tail_b, part_inf, l1, l1_inf, win, win_inf, ml_lines, ml_partial, ml_out, ml_coeffs, dyn, hpart, hpart_inf;
+    Buf flags, in_bases, in_inf, in_scalars, prepped, digits, heavy, cnt, off, cursor, bsums, entries, bucket, bucket_inf, head, tail, head_b, tail_b, part_inf, l1, l1_inf, win, win_inf, ml_lines, ml_partial, ml_out, ml_coeffs, ml_state, dyn, hpart, hpart_inf;
     Buf q[16];      // witness-map workspace (dock_qap.hip)
     std::vector<std::pair<const char *, std::pair<hipEvent_t, hipEvent_t>>> prof_pending;
     std::vector<hipEvent_t> ev_pool;
     void release_all() {
-        Buf *bufs[] = {&flags, &in_bases, &in_inf, &in_scalars, &prepped, &digits, &heavy, &cnt, &off, &cursor, &bsums, &entries, &bucket, &bucket_inf, &head, &tail, &head_b, &tail_b, &part_inf, &l1, &l1_inf, &win, &win_inf, &ml_lines, &ml_partial, &ml_out, &ml_coeffs, &dyn, &hpart, &hpart_inf};
+        Buf *bufs[] = {&flags, &in_bases, &in_inf, &in_scalars, &prepped, &digits, &heavy, &cnt, &off, &cursor, &bsums, &entries, &bucket, &bucket_inf, &head, &tail, &head_b, &tail_b, &part_inf, &l1, &l1_inf, &win, &win_inf, &ml_lines, &ml_partial, &ml_out, &ml_coeffs, &ml_state, &dyn, &hpart, &hpart_inf};
         for (Buf *b : bufs) b->release();
         for (Buf &b : q) b.release();
         for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
@@ -100,6 +102,7 @@ struct Shared {
     std::atomic<size_t> min_gpu_n{DGPU_DEFAULT_MIN_GPU_N};
     std::atomic<int> window_bits{0};
     std::atomic<int> chunk{0};
+    std::atomic<bool> ml_pipeline{true};      // dgpu_set_miller_pipeline: the two-launch line kernel of small Miller loops (dock_pairing.hip)
     uint64_t allocs_at_reset = 0, alloc_ns_at_reset = 0;
     int default_ctx = -1;
     std::atomic<bool> prof{false};

@@ -117,6 +117,9 @@ __device__ __forceinline__ void xq(Fp2H &r, const Fp2H &a) {
 __device__ __forceinline__ void selq(Fp2H &r, bool hi, const Fp2H &if_hi, const Fp2H &if_lo) { sel(r.v, hi, if_hi.v, if_lo.v); }
 
 // on return l.c0 is complete on both pairs; l.c1 is valid on pair A, l.c2 on pair B (both already multiplied by px / py)
+// EVAL = false: round 6 is left to the product kernel (k_line_products multiplies by px / py as it loads a line): the evaluation at P is
+// not part of the dependent chain R -> 2R, and this kernel lasts as long as its chain
+template <bool EVAL = true>
 __device__ __forceinline__ void line_dbl_step_quad(G2ProjT<Fp2H> &R, LineT<Fp2H> &l, const Fp &px, const Fp &py) {
     const bool B = quad_hi();
     Fp2H in, res, oth, b, c, e, f, g, hh, h, i, j, e2, g2, d, t, u, v;
@@ -144,12 +147,23 @@ __device__ __forceinline__ void line_dbl_step_quad(G2ProjT<Fp2H> &R, LineT<Fp2H>
     R.x = nx; R.y = ny; R.z = nz;
     l.c0 = i;
     Fp2H c1u, c2u; fadd(t, j, j); fadd(t, t, j); fnorm(c1u, t); f2_neg_n<32>(c2u, h);
-    Fp k; sel(k, B, py, px); selq(in, B, c2u, c1u); fmul_fp(res, in, k);          // round 6
+    selq(in, B, c2u, c1u);
+    if constexpr (EVAL) { Fp k; sel(k, B, py, px); fmul_fp(res, in, k); }         // round 6
+    else res = in;
     l.c1 = res; l.c2 = res;
 }
 
-__global__ void __launch_bounds__(64) k_miller_lines_quad(const uint32_t *__restrict__ p_abi, const uint32_t *__restrict__ q_abi, const uint8_t *__restrict__ skip, size_t n, uint32_t *__restrict__ lines, size_t stride) {
-    size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+// The loop may be cut in two launches (dgpu_multi_miller_loop below): this launch runs the bits b_hi .. b_lo of |x| and writes the lines
+// s_first ..; a launch that does not start at bit 62 takes R from `state`, one that does not end at bit 0 leaves it there
+// (state[k * 4 n + lane]: 3 x NL words per lane, both lane pairs of a quad hold the whole R).
+__device__ __host__ inline int ml_steps(int b_hi, int b_lo) { int c = 0; for (int b = b_hi; b >= b_lo; b--) c += 1 + (int)((BLS_X_ABS >> b) & 1); return c; }
+// EVAL = false: the lines leave unevaluated (c1, c2 not yet multiplied by px, py) and the launch that starts the chain writes px, py in
+// the internal form to pxy[(c * NL + k) * n + i] (zeros for a skipped pair) for k_line_products.
+template <bool EVAL = true>
+__global__ void __launch_bounds__(64) k_miller_lines_quad(const uint32_t *__restrict__ p_abi, const uint32_t *__restrict__ q_abi, const uint8_t *__restrict__ skip, size_t n, uint32_t *__restrict__ lines, size_t stride,
+                                                          int b_hi = 62, int b_lo = 0, int s_first = 0, uint32_t *__restrict__ state = nullptr, uint32_t *__restrict__ pxy = nullptr) {
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t i = gid >> 2;
     const uint32_t h = threadIdx.x & 1u;
     const bool B = quad_hi();
     if (i >= n) return;
@@ -167,17 +181,27 @@ __global__ void __launch_bounds__(64) k_miller_lines_quad(const uint32_t *__rest
     };
     if (sk) {
         LineT<Fp2H> one; fset_one(one.c0); fzero(one.c1); fzero(one.c2);
-        for (int s = 0; s < N_LINES; s++) put(s, one);
+        const int s_end = s_first + ml_steps(b_hi, b_lo);
+        for (int s = s_first; s < s_end; s++) put(s, one);
+        if constexpr (!EVAL) { if (b_hi == 62 && (gid & 3) < 2) for (int k = 0; k < NL; k++) pxy[((gid & 3) * NL + k) * n + i] = 0; }
         return;
     }
     Fp px, py; fp_from_abi(px, pw); fp_from_abi(py, pw + 12);
+    if constexpr (!EVAL) { if (b_hi == 62 && (gid & 3) < 2) { const Fp &c = (gid & 3) ? py : px; for (int k = 0; k < NL; k++) pxy[((gid & 3) * NL + k) * n + i] = c.l[k]; } }
     Aff<Fp2H> Q; fp_from_abi(Q.x.v, qx); fp_from_abi(Q.y.v, qy);
-    G2ProjT<Fp2H> R; R.x = Q.x; R.y = Q.y; fset_one(R.z);
-    int s = 0;
-    for (int b = 62; b >= 0; b--) {
-        LineT<Fp2H> l; line_dbl_step_quad(R, l, px, py); put(s++, l);
-        if ((BLS_X_ABS >> b) & 1) { line_add_step(R, Q, l); line_eval(l, px, py); put(s++, l); }
+    G2ProjT<Fp2H> R;
+    const size_t lanes = 4 * n;
+    if (b_hi == 62) { R.x = Q.x; R.y = Q.y; fset_one(R.z); }
+    else {
+        for (int k = 0; k < NL; k++) { R.x.v.l[k] = state[(size_t)k * lanes + gid]; R.y.v.l[k] = state[(size_t)(NL + k) * lanes + gid]; R.z.v.l[k] = state[(size_t)(2 * NL + k) * lanes + gid]; }
     }
+    int s = s_first;
+    for (int b = b_hi; b >= b_lo; b--) {
+        LineT<Fp2H> l; line_dbl_step_quad<EVAL>(R, l, px, py); put(s++, l);
+        if ((BLS_X_ABS >> b) & 1) { line_add_step(R, Q, l); if constexpr (EVAL) line_eval(l, px, py); put(s++, l); }
+    }
+    if (b_lo > 0)
+        for (int k = 0; k < NL; k++) { state[(size_t)k * lanes + gid] = R.x.v.l[k]; state[(size_t)(NL + k) * lanes + gid] = R.y.v.l[k]; state[(size_t)(2 * NL + k) * lanes + gid] = R.z.v.l[k]; }
 }
 
 // ---- G2Prepared (ark-ec bls12/g2.rs `G2Prepared::from`: the 68 coefficient triples before the evaluation at P) --------------------------
@@ -246,11 +270,13 @@ typedef Fp6T<Fp2H> Fp6p;
 typedef Fp12T<Fp2H> Fp12p;
 // seg_off != nullptr: nseg independent products over the pairs [seg_off[g], seg_off[g + 1]) of one line buffer (dgpu_multi_miller_loop_segments);
 // partial (g * N_LINES + s) * nsl + j is slice j of step s of segment g, slices past the end of a segment are not written.
+// s0, ns: the steps s0 .. s0 + ns - 1 only (a call whose line kernel runs in two launches; nseg == 1 then).
 __global__ void __launch_bounds__(64) k_line_products(const uint32_t *__restrict__ lines, size_t n, int slice_len, int nsl, uint32_t *__restrict__ partial,
-                                                      const uint32_t *__restrict__ seg_off, int nseg) {
-    const int t = (int)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 1);
+                                                      const uint32_t *__restrict__ seg_off, int nseg, int s0 = 0, int ns = N_LINES, const uint32_t *__restrict__ pxy = nullptr) {
+    int t = (int)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 1);
     const uint32_t h = threadIdx.x & 1u;
-    if (t >= N_LINES * nsl * nseg) return;
+    if (t >= ns * nsl * nseg) return;
+    t += s0 * nsl;
     const int sg = t / nsl, j = t % nsl, s = sg % N_LINES, g = sg / N_LINES;
     const size_t first = seg_off ? seg_off[g] : 0, last = seg_off ? seg_off[g + 1] : n;
     // slice j of the `have` slices of this (segment, step) is the pairs first + j, first + j + have, ...: neighbouring lane pairs read
@@ -263,6 +289,11 @@ __global__ void __launch_bounds__(64) k_line_products(const uint32_t *__restrict
     for (size_t i = lo; i < last; i += have) {
         LineT<Fp2H> l;
         for (int c = 0; c < 3; c++) { Fp2H &x = c == 0 ? l.c0 : (c == 1 ? l.c1 : l.c2); for (int k = 0; k < NL; k++) x.v.l[k] = lines[((size_t)s * LW + (2 * c + h) * NL + k) * n + i]; }
+        if (pxy) {                                    // the lines came unevaluated (k_miller_lines_quad<false>): c1 *= px, c2 *= py here
+            Fp px, py;
+            for (int k = 0; k < NL; k++) { px.l[k] = pxy[(size_t)k * n + i]; py.l[k] = pxy[(size_t)(NL + k) * n + i]; }
+            line_eval(l, px, py);
+        }
         if (i == lo) f12_from_014(f, l.c0, l.c1, l.c2); else f12_mul_by_014(f, l.c0, l.c1, l.c2);
     }
     const Fp2H *q = reinterpret_cast<const Fp2H *>(&f);              // c0.c0, c0.c1, c0.c2, c1.c0, c1.c1, c1.c2
@@ -281,9 +312,9 @@ __global__ void __launch_bounds__(64) k_line_products(const uint32_t *__restrict
 constexpr int F6W = 6 * NL;
 // seg_off != nullptr (one level, ngroups == 1): s runs over (segment, step) and the number of partials is the segment's own slice count.
 __global__ void __launch_bounds__(192) k_product_tree(const uint32_t *__restrict__ partial, int nsl, int ngroups, uint32_t *__restrict__ next, uint32_t *__restrict__ out_abi,
-                                                      const uint32_t *__restrict__ seg_off, int slice_len) {
+                                                      const uint32_t *__restrict__ seg_off, int slice_len, int s0 = 0) {
     __shared__ uint32_t sh[F12W * MAX_SLICES];                        // word k of slot j at sh[k * 64 + j]
-    const int s = blockIdx.x / ngroups, grp = blockIdx.x % ngroups, t = threadIdx.x;
+    const int s = s0 + blockIdx.x / ngroups, grp = blockIdx.x % ngroups, t = threadIdx.x;
     int have = nsl;
     if (seg_off) { const int g = s / N_LINES; have = (int)((seg_off[g + 1] - seg_off[g] + slice_len - 1) / slice_len); }
     const int cnt = min(MAX_SLICES, have - grp * MAX_SLICES);       // partials in this group
@@ -348,37 +379,90 @@ inline int choose_slice_len(size_t n) {
 
 extern "C" {
 
-// conj((...((L_0)^2 L_1)^2 ...)) over the 68 per-step products
-static hostf::Fq12 ml_host_tail(const hostf::Fq12 *L) {
-    hostf::Fq12 f = hostf::Fq12::one(); int idx = 0;
-    for (int b = 62; b >= 0; b--) { f = f.sqr() * L[idx++]; if ((hostf::BLS_X_ABS >> b) & 1) f = f * L[idx++]; }
-    return f.conj();      // x < 0
-}
+// conj((...((L_0)^2 L_1)^2 ...)) over the 68 per-step products; may be taken in pieces (bits 62 .. b_lo, then on to 0)
+struct MlTail {
+    hostf::Fq12 f = hostf::Fq12::one(); int idx = 0, b = 62;
+    void run(const hostf::Fq12 *L, int b_lo) { for (; b >= b_lo; b--) { f = f.sqr() * L[idx++]; if ((hostf::BLS_X_ABS >> b) & 1) f = f * L[idx++]; } }
+    hostf::Fq12 result() const { return f.conj(); }      // x < 0
+};
+static hostf::Fq12 ml_host_tail(const hostf::Fq12 *L) { MlTail t; t.run(L, 0); return t.result(); }
 
+struct MlGeom { int slice_len, nsl, ngroups; };
+static int32_t ml_geometry(Slot &sl, size_t n, MlGeom &g) {
+    int32_t rc;
+    g.slice_len = choose_slice_len(n);
+    g.nsl = (int)((n + g.slice_len - 1) / g.slice_len);              // <= 2048
+    g.ngroups = (g.nsl + MAX_SLICES - 1) / MAX_SLICES;               // <= 32: the second tree level is one group
+    if ((rc = sl.ml_partial.ensure((size_t)N_LINES * (g.nsl + g.ngroups) * F12W * 4))) return rc;
+    if ((rc = sl.ml_out.ensure((size_t)N_LINES * 144 * 4))) return rc;
+    return DGPU_OK;
+}
+// K10 + K11 for the steps s0 .. s0 + ns - 1 on stream s (partials and results are indexed by the step: disjoint for disjoint ranges)
+static void ml_products(Slot &sl, hipStream_t s, size_t n, const MlGeom &g, int s0, int ns, bool timed, const uint32_t *pxy = nullptr) {
+    const int nsl = g.nsl, ngroups = g.ngroups;
+    auto products = [&] {
+      hipLaunchKernelGGL(k_line_products, dim3((unsigned)((2 * ns * nsl + 63) / 64)), dim3(64), 0, s, sl.ml_lines.as<uint32_t>(), n, g.slice_len, nsl, sl.ml_partial.as<uint32_t>(), (const uint32_t *)nullptr, 1, s0, ns, pxy); };
+    auto tree = [&] {
+      uint32_t *lvl0 = sl.ml_partial.as<uint32_t>(), *lvl1 = lvl0 + (size_t)N_LINES * nsl * F12W;
+      if (ngroups == 1) hipLaunchKernelGGL(k_product_tree, dim3(ns), dim3(192), 0, s, lvl0, nsl, 1, (uint32_t *)nullptr, sl.ml_out.as<uint32_t>(), (const uint32_t *)nullptr, 0, s0);
+      else {
+          hipLaunchKernelGGL(k_product_tree, dim3(ns * ngroups), dim3(192), 0, s, lvl0, nsl, ngroups, lvl1, (uint32_t *)nullptr, (const uint32_t *)nullptr, 0, s0);
+          hipLaunchKernelGGL(k_product_tree, dim3(ns), dim3(192), 0, s, lvl1, ngroups, 1, (uint32_t *)nullptr, sl.ml_out.as<uint32_t>(), (const uint32_t *)nullptr, 0, s0);
+      } };
+    if (timed) { { StageTimer st(sl, "ml.products"); products(); } { StageTimer st(sl, "ml.tree"); tree(); } }      // (stage timers record on sl.stream)
+    else { products(); tree(); }
+}
 // K10 + K11 + host tail on the lines already in sl.ml_lines
 static int32_t ml_finish(Slot &sl, size_t n, uint64_t *out) {
-    int32_t rc;
-    const int slice_len = choose_slice_len(n);
-    const int nsl = (int)((n + slice_len - 1) / slice_len);          // <= 2048
-    const int ngroups = (nsl + MAX_SLICES - 1) / MAX_SLICES;         // <= 32: the second tree level is one group
-    if ((rc = sl.ml_partial.ensure((size_t)N_LINES * (nsl + ngroups) * F12W * 4))) return rc;
-    if ((rc = sl.ml_out.ensure((size_t)N_LINES * 144 * 4))) return rc;
+    int32_t rc; MlGeom g;
+    if ((rc = ml_geometry(sl, n, g))) return rc;
     hipStream_t s = sl.stream;
-    { StageTimer st(sl, "ml.products");
-      hipLaunchKernelGGL(k_line_products, dim3((unsigned)((2 * N_LINES * nsl + 63) / 64)), dim3(64), 0, s, sl.ml_lines.as<uint32_t>(), n, slice_len, nsl, sl.ml_partial.as<uint32_t>(), (const uint32_t *)nullptr, 1); }
-    { StageTimer st(sl, "ml.tree");
-      uint32_t *lvl0 = sl.ml_partial.as<uint32_t>(), *lvl1 = lvl0 + (size_t)N_LINES * nsl * F12W;
-      if (ngroups == 1) hipLaunchKernelGGL(k_product_tree, dim3(N_LINES), dim3(192), 0, s, lvl0, nsl, 1, (uint32_t *)nullptr, sl.ml_out.as<uint32_t>(), (const uint32_t *)nullptr, 0);
-      else {
-          hipLaunchKernelGGL(k_product_tree, dim3(N_LINES * ngroups), dim3(192), 0, s, lvl0, nsl, ngroups, lvl1, (uint32_t *)nullptr, (const uint32_t *)nullptr, 0);
-          hipLaunchKernelGGL(k_product_tree, dim3(N_LINES), dim3(192), 0, s, lvl1, ngroups, 1, (uint32_t *)nullptr, sl.ml_out.as<uint32_t>(), (const uint32_t *)nullptr, 0);
-      } }
+    ml_products(sl, s, n, g, 0, N_LINES, true);
     HIPCHK(hipGetLastError());
     std::vector<hostf::Fq12> L(N_LINES);
     HIPCHK(hipMemcpyAsync(L.data(), sl.ml_out.p, (size_t)N_LINES * 576, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     if (gs.prof) prof_flush(sl);
     const hostf::Fq12 f = ml_host_tail(L.data());
+    memcpy(out, &f, sizeof f);
+    return DGPU_OK;
+}
+
+// A call of up to 8192 pairs lasts as long as its chain: 68 dependent line steps (K9: 4 lanes per pair, the chip nearly empty), then the
+// product levels of K10 / K11, then 131 Fp12 operations on the host.  The chain is cut at bit ML_CUT of |x|: the line kernel runs in two
+// launches, the products of the first 50 steps and the host's share of them run (second stream, host thread) while the second launch
+// computes the last 18 steps — what remains after the line kernel is the product levels of those 18 steps and 35 host operations
+// (1.45 -> 1.2 ms at 1024 pairs).  Same values in the same order: bit-identical to the one-launch form, which stays for larger batches
+// (throughput-bound) and while stage timers are on.
+constexpr int ML_CUT = 17;
+static int32_t ml_pipelined(Slot &sl, size_t n, const uint8_t *dskip, uint64_t *out) {
+    int32_t rc; MlGeom g;
+    if ((rc = ml_geometry(sl, n, g))) return rc;
+    if ((rc = sl.ml_state.ensure(((size_t)3 * NL * 4 * n + (size_t)2 * NL * n) * 4))) return rc;      // R of every lane, then px, py of every pair
+    hipStream_t sa = sl.stream, sb = sl.cstream;
+    const int ns1 = ml_steps(62, ML_CUT), ns2 = N_LINES - ns1;
+    const unsigned blocks = (unsigned)((4 * n + 63) / 64);
+    hipEvent_t e1 = sl.copy_ev[sl.ev_next++ % (Slot::N_COPY_EV + 1)], e2 = sl.copy_ev[sl.ev_next++ % (Slot::N_COPY_EV + 1)];
+    static_assert((size_t)N_LINES * 576 <= Slot::HPIN_BYTES, "pinned scratch");
+    hostf::Fq12 *L = (hostf::Fq12 *)sl.hpin;                          // pinned: the copies below are asynchronous for the host
+    uint32_t *state = sl.ml_state.as<uint32_t>(), *pxy = state + (size_t)3 * NL * 4 * n;
+    hipLaunchKernelGGL(k_miller_lines_quad<false>, dim3(blocks), dim3(64), 0, sa, sl.in_bases.as<uint32_t>(), sl.in_scalars.as<uint32_t>(), dskip, n, sl.ml_lines.as<uint32_t>(), n, 62, ML_CUT, 0, state, pxy);
+    HIPCHK(hipEventRecord(e1, sa));
+    hipLaunchKernelGGL(k_miller_lines_quad<false>, dim3(blocks), dim3(64), 0, sa, sl.in_bases.as<uint32_t>(), sl.in_scalars.as<uint32_t>(), dskip, n, sl.ml_lines.as<uint32_t>(), n, ML_CUT - 1, 0, ns1, state, pxy);
+    HIPCHK(hipStreamWaitEvent(sb, e1, 0));
+    ml_products(sl, sb, n, g, 0, ns1, false, pxy);
+    HIPCHK(hipMemcpyAsync(L, sl.ml_out.p, (size_t)ns1 * 576, hipMemcpyDeviceToHost, sb));
+    HIPCHK(hipEventRecord(e2, sb));
+    ml_products(sl, sa, n, g, ns1, ns2, false, pxy);
+    HIPCHK(hipMemcpyAsync(L + ns1, (const char *)sl.ml_out.p + (size_t)ns1 * 576, (size_t)ns2 * 576, hipMemcpyDeviceToHost, sa));
+    rc = DGPU_OK;
+    if (hipGetLastError() != hipSuccess) rc = DGPU_E_HIP;
+    MlTail tail;
+    if (!rc && hipEventSynchronize(e2) == hipSuccess) tail.run(L, ML_CUT); else rc = DGPU_E_HIP;
+    if (hipStreamSynchronize(sa) != hipSuccess || hipStreamSynchronize(sb) != hipSuccess) rc = DGPU_E_HIP;
+    if (rc) return rc;
+    tail.run(L, 0);
+    const hostf::Fq12 f = tail.result();
     memcpy(out, &f, sizeof f);
     return DGPU_OK;
 }
@@ -407,10 +491,11 @@ int32_t dgpu_multi_miller_loop(const uint64_t *p, const uint64_t *q, const uint8
 #else
       constexpr bool one_lane = false, two_lanes = false;
 #endif
+      if (!one_lane && !two_lanes && n <= 8192 && !gs.prof && gs.ml_pipeline.load()) return ml_pipelined(sl, n, dskip, out);
       if (one_lane) hipLaunchKernelGGL(k_miller_lines, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, sl.in_bases.as<uint32_t>(), sl.in_scalars.as<uint32_t>(), dskip, n, sl.ml_lines.as<uint32_t>(), n);
       else if (two_lanes || n > 8192) hipLaunchKernelGGL(k_miller_lines_pair,     // (with the chip full, the pair form does less total work)
               dim3((unsigned)((2 * n + 63) / 64)), dim3(64), 0, s, sl.in_bases.as<uint32_t>(), sl.in_scalars.as<uint32_t>(), dskip, n, sl.ml_lines.as<uint32_t>(), n);
-      else hipLaunchKernelGGL(k_miller_lines_quad, dim3((unsigned)((4 * n + 63) / 64)), dim3(64), 0, s, sl.in_bases.as<uint32_t>(), sl.in_scalars.as<uint32_t>(), dskip, n, sl.ml_lines.as<uint32_t>(), n);
+      else hipLaunchKernelGGL(k_miller_lines_quad<true>, dim3((unsigned)((4 * n + 63) / 64)), dim3(64), 0, s, sl.in_bases.as<uint32_t>(), sl.in_scalars.as<uint32_t>(), dskip, n, sl.ml_lines.as<uint32_t>(), n);
     }
     return ml_finish(sl, n, out);
 }
@@ -470,7 +555,7 @@ static int32_t ml_segments(const uint64_t *p, const uint64_t *q, const uint8_t *
     HIPCHK(hipMemcpyAsync(doff, off.data(), (nseg + 1) * 4, hipMemcpyHostToDevice, s));
     { StageTimer st(sl, "ml.lines");
       if (n > 8192) hipLaunchKernelGGL(k_miller_lines_pair, dim3((unsigned)((2 * n + 63) / 64)), dim3(64), 0, s, sl.in_bases.as<uint32_t>(), sl.in_scalars.as<uint32_t>(), dskip, n, sl.ml_lines.as<uint32_t>(), n);
-      else hipLaunchKernelGGL(k_miller_lines_quad, dim3((unsigned)((4 * n + 63) / 64)), dim3(64), 0, s, sl.in_bases.as<uint32_t>(), sl.in_scalars.as<uint32_t>(), dskip, n, sl.ml_lines.as<uint32_t>(), n); }
+      else hipLaunchKernelGGL(k_miller_lines_quad<true>, dim3((unsigned)((4 * n + 63) / 64)), dim3(64), 0, s, sl.in_bases.as<uint32_t>(), sl.in_scalars.as<uint32_t>(), dskip, n, sl.ml_lines.as<uint32_t>(), n); }
     { StageTimer st(sl, "ml.products");
       hipLaunchKernelGGL(k_line_products, dim3((unsigned)((2 * (size_t)N_LINES * nsl * nseg + 63) / 64)), dim3(64), 0, s, sl.ml_lines.as<uint32_t>(), n, slice_len, nsl, sl.ml_partial.as<uint32_t>(), doff, (int)nseg); }
     { StageTimer st(sl, "ml.tree");
@@ -612,7 +697,7 @@ int32_t dgpu_multi_miller_loop_mixed(const uint64_t *p_aff, const uint64_t *q_af
       if (n_aff) {
           const uint8_t *sk = skip_aff ? dsk : nullptr;
           if (n_aff > 8192) hipLaunchKernelGGL(k_miller_lines_pair, dim3((unsigned)((2 * n_aff + 63) / 64)), dim3(64), 0, s, dp, sl.in_scalars.as<uint32_t>(), sk, n_aff, lines, n);
-          else hipLaunchKernelGGL(k_miller_lines_quad, dim3((unsigned)((4 * n_aff + 63) / 64)), dim3(64), 0, s, dp, sl.in_scalars.as<uint32_t>(), sk, n_aff, lines, n);
+          else hipLaunchKernelGGL(k_miller_lines_quad<true>, dim3((unsigned)((4 * n_aff + 63) / 64)), dim3(64), 0, s, dp, sl.in_scalars.as<uint32_t>(), sk, n_aff, lines, n);
       }
       if (n_prep)
           hipLaunchKernelGGL(k_lines_from_prepared, dim3((unsigned)((n_prep * N_LINES + 255) / 256)), dim3(256), 0, s, dp + n_aff * 24, sl.ml_coeffs.as<uint32_t>(),

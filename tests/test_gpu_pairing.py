@@ -61,6 +61,29 @@ def test_vs_oracle_across_kernel_boundaries(n):
     assert (ca.multi_miller_loop(ps, qs) == O.multi_miller_loop(ps, qs, skip, threads=32)).all()
 
 
+@pytest.mark.parametrize("n", [1, 3, 64, 1024, 8192])
+def test_two_launch_line_kernel_equals_the_one_launch_form(n):
+    """dgpu_multi_miller_loop of up to 8192 pairs cuts the 68-step chain at bit 17 of |x| (two launches of the line kernel, the products
+    and the host's share of the first 50 steps overlapped with the second): the same Fp12 value limb for limb as the one-launch form
+    (dgpu_set_miller_pipeline(0)) and as the oracle, identity members and skipped pairs included"""
+    from crypto_amd._native import lib
+    k0 = O.rand_scalars(41, 1)[0]; d = O.rand_scalars(42, 1)[0]
+    ps = O.G1.gen_seq(k0, d, n, threads=32); qs = O.G2.gen_seq(d, k0, n, threads=32)
+    skip = np.zeros(n, np.uint8)
+    if n >= 3:
+        ps[n // 3] = 0; skip[n // 3] = 1; skip[n - 1] = 1
+    try:
+        assert lib().dgpu_set_miller_pipeline(0) == 0
+        one = ca.multi_miller_loop(ps, qs, skip)
+        assert lib().dgpu_set_miller_pipeline(1) == 0
+        two = ca.multi_miller_loop(ps, qs, skip)
+    finally:
+        lib().dgpu_set_miller_pipeline(1)
+    assert (one == two).all()
+    if n <= 1024:
+        assert (two == O.multi_miller_loop(ps, qs, skip, threads=32)).all()
+
+
 def test_identity_members_are_skipped_and_lengths_checked():
     ps, qs = pts([3, 5, 7], [2, 4, 6])
     ps2 = ps.copy(); ps2[1] = 0                       # all-zero words == identity

@@ -366,6 +366,111 @@ __global__ void __launch_bounds__(192) k_product_tree(const uint32_t *__restrict
     }
 }
 
+// ---- the same tree with 18 lane pairs per node ---------------------------------------------------------------------------------------
+// A level of k_product_tree lasts ~32 us: six Fp2 products one after another on each of the node's three lane pairs, between three
+// barriers.  Here lane pair r of a node computes ONE role product of pairing29.hip.h's regrouped Fp12 product (operands summed straight out
+// of the factors' slots, product parked in LDS), and after a barrier lane pairs 0..8 turn the parked products into the nine Fp6 coefficients of
+// the three Fp6 products, lane pairs 0..5 those into one output coefficient each: a level is one Fp2 product and two short combinations deep.  The instruction stream is the same for every role (operand
+// and product indices are data: masked loads, selects), so a wave may hold any mixture of roles and nodes.  16 nodes per pass (576
+// threads); the 32 nodes of a full group's first level take two passes.  Same interface and results as k_product_tree.
+constexpr int T18_NODES = 16, T18_PAIRS = T18_NODES * 18, T18_THREADS = 2 * T18_PAIRS;
+constexpr int T18_SLOT = F12W + 1;        // slot-major with an odd stride: the lanes of a node read DIFFERENT words of the SAME slot (word-major put them all in one bank)
+constexpr size_t T18_LDS = ((size_t)T18_SLOT * MAX_SLICES + (size_t)NL * T18_THREADS) * 4;
+__global__ void __launch_bounds__(T18_THREADS) k_product_tree18(const uint32_t *__restrict__ partial, int nsl, int ngroups, uint32_t *__restrict__ next, uint32_t *__restrict__ out_abi,
+                                                                const uint32_t *__restrict__ seg_off, int slice_len, int s0 = 0) {
+    extern __shared__ uint32_t lds18[];
+    uint32_t *sh = lds18;                                            // word k of slot j at sh[j * T18_SLOT + k]
+    uint32_t *pr = lds18 + T18_SLOT * MAX_SLICES;                        // word j of this pass's product of lane t at pr[j * T18_THREADS + t]
+    const int s = s0 + blockIdx.x / ngroups, grp = blockIdx.x % ngroups, t = threadIdx.x;
+    int have = nsl;
+    if (seg_off) { const int g = s / N_LINES; have = (int)((seg_off[g + 1] - seg_off[g] + slice_len - 1) / slice_len); }
+    const int cnt = min(MAX_SLICES, have - grp * MAX_SLICES);
+    if (cnt <= 0) return;
+    { const uint32_t *src = partial + ((size_t)s * nsl + grp * MAX_SLICES) * F12W;
+      for (int e = t; e < cnt * F12W; e += T18_THREADS) { const int slot = e / F12W, k = e % F12W; sh[slot * T18_SLOT + k] = src[e]; } }
+    const uint32_t hh = t & 1u;
+    const int pi = t >> 1, nl = pi / 18, r = pi % 18, R = r / 6, k = r % 6;
+    auto ldc = [&](Fp &v, int slot, int c) {
+#pragma unroll
+        for (int j = 0; j < NL; j++) v.l[j] = sh[slot * T18_SLOT + (2 * c + hh) * NL + j];
+    };
+    // operand of role (R, k) from the coefficients in `slot`: f12_role_operand with the optional terms masked instead of branched over
+    auto operand = [&](Fp2H &x, int slot) {
+        const int f = role_first(k), sc = role_second(k), base = (R == 1) ? 3 : 0;
+        const bool two = sc >= 0, both = (R == 2);
+        const int s2 = two ? sc : f;
+        Fp a0, a1, a2, a3;
+        ldc(a0, slot, base + f); ldc(a1, slot, base + s2); ldc(a2, slot, 3 + f); ldc(a3, slot, 3 + s2);
+        Fp tsum;
+#pragma unroll
+        for (int j = 0; j < NL; j++) tsum.l[j] = a0.l[j] + (two ? a1.l[j] : 0u) + (both ? a2.l[j] : 0u) + ((both && two) ? a3.l[j] : 0u);
+        fp_norm(x.v, tsum);
+    };
+    auto ldp = [&](Fp2H &v, int rr) {
+        const int at = (nl * 18 + rr) * 2 + (int)hh;
+#pragma unroll
+        for (int j = 0; j < NL; j++) v.v.l[j] = pr[j * T18_THREADS + at];
+    };
+    auto zcoef = [&](Fp2H &z, int RR, int kk) {
+        Fp2H Q, A, B, C;
+        ldp(Q, 6 * RR + role_q(kk)); ldp(A, 6 * RR + role_a(kk)); ldp(B, 6 * RR + role_b(kk)); ldp(C, 6 * RR + role_c(kk));
+        f6_coeff_from_roles(z, Q, A, B, C, kk);
+    };
+    for (int hs = MAX_SLICES / 2; hs >= 1; hs >>= 1) {
+        if (hs >= cnt) continue;                                    // (uniform) nothing to fold at this level
+        for (int base = 0; base < hs; base += T18_NODES) {
+            const int p = base + nl;
+            const bool node = p < hs && p + hs < cnt;               // slot p *= slot p + hs
+            __syncthreads();
+            if (node) {
+                Fp2H x, y, m;
+                operand(x, p); operand(y, p + hs);
+                fmul(m, x, y);
+#pragma unroll
+                for (int j = 0; j < NL; j++) pr[j * T18_THREADS + t] = m.v.l[j];
+            }
+            __syncthreads();
+            // the nine Fp6 coefficients z(R, k) of the three Fp6 products, one per lane pair (r = 3 R + k), parked where the products were
+            Fp2H z;
+            if (node && r < 9) zcoef(z, r / 3, r % 3);
+            __syncthreads();
+            if (node && r < 9) {
+#pragma unroll
+                for (int j = 0; j < NL; j++) pr[j * T18_THREADS + t] = z.v.l[j];
+            }
+            __syncthreads();
+            if (node && r < 6) {                                   // the six Fp2 coefficients of the product
+                const int q = r; const bool c0t = q < 3; const int kk = c0t ? q : q - 3;
+                Fp2H U, V, W, o0, o1, o;
+                ldp(U, c0t ? kk : 6 + kk); ldp(V, c0t ? 3 + (q + 2) % 3 : kk); ldp(W, 3 + kk);      // z(R, k) sits in lane pair 3 R + k's words
+                f12_out_c0(o0, U, V, q); f12_out_c1(o1, U, V, W);
+                fsel(o, c0t, o0, o1);
+#pragma unroll
+                for (int j = 0; j < NL; j++) sh[p * T18_SLOT + (2 * q + hh) * NL + j] = o.v.l[j];
+            }
+        }
+    }
+    __syncthreads();
+    if (t < 2) {
+        for (int q = 0; q < 6; q++) {
+            Fp c;
+            for (int j = 0; j < NL; j++) c.l[j] = sh[(2 * q + hh) * NL + j];
+            if (out_abi) fp_to_abi(out_abi + ((size_t)s * 12 + 2 * q + hh) * 12, c);
+            else for (int j = 0; j < NL; j++) next[((size_t)s * ngroups + grp) * F12W + (2 * q + hh) * NL + j] = c.l[j];
+        }
+    }
+}
+// one launcher for both tree kernels (gs.ml_mode bit 1: the 18-role form)
+static void launch_product_tree(hipStream_t st, unsigned blocks, const uint32_t *partial, int nsl, int ngroups, uint32_t *next, uint32_t *out_abi, const uint32_t *seg_off, int slice_len, int s0) {
+    if (gs.ml_mode.load() & 2) {
+        static std::atomic<uint32_t> done{0};
+        { int dev = 0; (void)hipGetDevice(&dev); const uint32_t bit = 1u << (dev & 31);
+          if (!(done.load() & bit)) { (void)hipFuncSetAttribute((const void *)k_product_tree18, hipFuncAttributeMaxDynamicSharedMemorySize, (int)T18_LDS); done.fetch_or(bit); } }
+        hipLaunchKernelGGL(k_product_tree18, dim3(blocks), dim3(T18_THREADS), T18_LDS, st, partial, nsl, ngroups, next, out_abi, seg_off, slice_len, s0);
+    } else
+        hipLaunchKernelGGL(k_product_tree, dim3(blocks), dim3(192), 0, st, partial, nsl, ngroups, next, out_abi, seg_off, slice_len, s0);
+}
+
 // Slices of pairs per step.  A lane multiplies its slice's lines into one partial (sparse products, serial), then 64-wide trees fold
 // the partials (dense products, log depth): short slices keep both latency-bound phases short at small n and fill the chip at large n
 // (a fixed 64 slices left k_line_products with 4352 lanes whatever n: 59 ms at 2^16 pairs).
@@ -404,10 +509,10 @@ static void ml_products(Slot &sl, hipStream_t s, size_t n, const MlGeom &g, int 
       hipLaunchKernelGGL(k_line_products, dim3((unsigned)((2 * ns * nsl + 63) / 64)), dim3(64), 0, s, sl.ml_lines.as<uint32_t>(), n, g.slice_len, nsl, sl.ml_partial.as<uint32_t>(), (const uint32_t *)nullptr, 1, s0, ns, pxy); };
     auto tree = [&] {
       uint32_t *lvl0 = sl.ml_partial.as<uint32_t>(), *lvl1 = lvl0 + (size_t)N_LINES * nsl * F12W;
-      if (ngroups == 1) hipLaunchKernelGGL(k_product_tree, dim3(ns), dim3(192), 0, s, lvl0, nsl, 1, (uint32_t *)nullptr, sl.ml_out.as<uint32_t>(), (const uint32_t *)nullptr, 0, s0);
+      if (ngroups == 1) launch_product_tree(s, (unsigned)ns, lvl0, nsl, 1, (uint32_t *)nullptr, sl.ml_out.as<uint32_t>(), (const uint32_t *)nullptr, 0, s0);
       else {
-          hipLaunchKernelGGL(k_product_tree, dim3(ns * ngroups), dim3(192), 0, s, lvl0, nsl, ngroups, lvl1, (uint32_t *)nullptr, (const uint32_t *)nullptr, 0, s0);
-          hipLaunchKernelGGL(k_product_tree, dim3(ns), dim3(192), 0, s, lvl1, ngroups, 1, (uint32_t *)nullptr, sl.ml_out.as<uint32_t>(), (const uint32_t *)nullptr, 0, s0);
+          launch_product_tree(s, (unsigned)(ns * ngroups), lvl0, nsl, ngroups, lvl1, (uint32_t *)nullptr, (const uint32_t *)nullptr, 0, s0);
+          launch_product_tree(s, (unsigned)ns, lvl1, ngroups, 1, (uint32_t *)nullptr, sl.ml_out.as<uint32_t>(), (const uint32_t *)nullptr, 0, s0);
       } };
     if (timed) { { StageTimer st(sl, "ml.products"); products(); } { StageTimer st(sl, "ml.tree"); tree(); } }      // (stage timers record on sl.stream)
     else { products(); tree(); }
@@ -491,7 +596,7 @@ int32_t dgpu_multi_miller_loop(const uint64_t *p, const uint64_t *q, const uint8
 #else
       constexpr bool one_lane = false, two_lanes = false;
 #endif
-      if (!one_lane && !two_lanes && n <= 8192 && !gs.prof && gs.ml_pipeline.load()) return ml_pipelined(sl, n, dskip, out);
+      if (!one_lane && !two_lanes && n <= 8192 && !gs.prof && (gs.ml_mode.load() & 1)) return ml_pipelined(sl, n, dskip, out);
       if (one_lane) hipLaunchKernelGGL(k_miller_lines, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, sl.in_bases.as<uint32_t>(), sl.in_scalars.as<uint32_t>(), dskip, n, sl.ml_lines.as<uint32_t>(), n);
       else if (two_lanes || n > 8192) hipLaunchKernelGGL(k_miller_lines_pair,     // (with the chip full, the pair form does less total work)
               dim3((unsigned)((2 * n + 63) / 64)), dim3(64), 0, s, sl.in_bases.as<uint32_t>(), sl.in_scalars.as<uint32_t>(), dskip, n, sl.ml_lines.as<uint32_t>(), n);
@@ -559,7 +664,7 @@ static int32_t ml_segments(const uint64_t *p, const uint64_t *q, const uint8_t *
     { StageTimer st(sl, "ml.products");
       hipLaunchKernelGGL(k_line_products, dim3((unsigned)((2 * (size_t)N_LINES * nsl * nseg + 63) / 64)), dim3(64), 0, s, sl.ml_lines.as<uint32_t>(), n, slice_len, nsl, sl.ml_partial.as<uint32_t>(), doff, (int)nseg); }
     { StageTimer st(sl, "ml.tree");
-      hipLaunchKernelGGL(k_product_tree, dim3((unsigned)(N_LINES * nseg)), dim3(192), 0, s, sl.ml_partial.as<uint32_t>(), nsl, 1, (uint32_t *)nullptr, sl.ml_out.as<uint32_t>(), doff, slice_len); }
+      launch_product_tree(s, (unsigned)(N_LINES * nseg), sl.ml_partial.as<uint32_t>(), nsl, 1, (uint32_t *)nullptr, sl.ml_out.as<uint32_t>(), doff, slice_len, 0); }
     HIPCHK(hipGetLastError());
     std::vector<hostf::Fq12> L((size_t)N_LINES * nseg);
     HIPCHK(hipMemcpyAsync(L.data(), sl.ml_out.p, (size_t)N_LINES * nseg * 576, hipMemcpyDeviceToHost, s));

@@ -100,6 +100,7 @@ template <int M> __device__ __forceinline__ void f2_neg_n(Fp2H &r, const Fp2H &a
 __device__ __forceinline__ void f2_add_n(Fp2H &r, const Fp2H &a, const Fp2H &b) { fp_add(r.v, a.v, b.v); fp_norm(r.v, r.v); }
 template <int M> __device__ __forceinline__ void f2_sub_n(Fp2H &r, const Fp2H &a, const Fp2H &b) { fp_sub<M>(r.v, a.v, b.v); fp_norm(r.v, r.v); }
 __device__ __forceinline__ void fmul_fp(Fp2H &r, const Fp2H &a, const Fp &k) { fp_mul(r.v, a.v, k); }
+__device__ __forceinline__ void fsel(Fp2H &r, bool c, const Fp2H &a, const Fp2H &b) { sel(r.v, c, a.v, b.v); }      // r = c ? a : b (pairing29.hip.h's role functions)
 
 template <> struct SubM<Fp2H> {     // same value budgets as the one-lane Fp2 formulas
     static constexpr int P = 32;

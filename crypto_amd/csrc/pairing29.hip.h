@@ -108,6 +108,65 @@ template <class F2> FD void f12_mul_by_014(Fp12T<F2> &f, const F2 &c0, const F2 
     f6_mul_v(x, bb);
     f6_add_n(f.c0, aa, x);
 }
+// ---- the dense Fp12 product as 18 independent Fp2 products ("roles") and 6 output combinations --------------------------------------
+// f12_mul above is one long dependent sequence (18 Fp2 products behind each other on whoever computes the node); the product tree of the
+// Miller loop is latency-bound, so k_product_tree18 (dock_pairing.hip) gives every node 18 lane pairs: lane pair r forms the operands of
+// role r, multiplies, parks the product in LDS, and after a barrier the first 6 lane pairs combine the products into one output
+// coefficient each.  Same formulas as f6_mul / f12_mul, only regrouped; the functions below are that regrouping, host + device, so that
+// the FP29_CHECK build proves the bounds of exactly what the kernel runs (f12_mul_roles == f12_mul, tests/test_device_code_on_host.py).
+//   role r = 6 R + k:  R = 0: a0 b0, 1: a1 b1, 2: (a0 + a1)(b0 + b1)   (Fp6 factors x, y)
+//                      k = 0: x0 y0, 1: x1 y1, 2: x2 y2, 3: (x1 + x2)(y1 + y2), 4: (x0 + x1)(y0 + y1), 5: (x0 + x2)(y0 + y2)
+// Coefficient order of an Fp12 everywhere below: c[0..5] = c0.c0, c0.c1, c0.c2, c1.c0, c1.c1, c1.c2.
+FD int role_first(int k) { return k < 3 ? k : (k == 3 ? 1 : 0); }
+FD int role_second(int k) { return k < 3 ? -1 : (k == 4 ? 1 : 2); }
+// r = c ? a : b.  The condition is a function of the role (known where the formula is written down), so the check build carries the bounds of
+// the operand that is selected: the other one was computed under its own asserted preconditions and is dropped.
+FD void fsel(Fp &r, bool c, const Fp &a, const Fp &b) {
+#pragma unroll
+    for (int i = 0; i < NL; i++) r.l[i] = c ? a.l[i] : b.l[i];
+    CHK(for (int i = 0; i < NL; i++) r.ub[i] = c ? a.ub[i] : b.ub[i]; r.vb = c ? a.vb : b.vb;)
+}
+FD void fsel(Fp2 &r, bool c, const Fp2 &a, const Fp2 &b) { fsel(r.c0, c, a.c0, b.c0); fsel(r.c1, c, a.c1, b.c1); }
+// operand of role (R, k): up to four coefficients of one factor, added limb by limb, one carry pass
+template <class F2> FD void f12_role_operand(F2 &x, const F2 *c, int R, int k) {
+    const int f = role_first(k), s = role_second(k), base = (R == 1) ? 3 : 0;
+    F2 t = c[base + f];
+    if (s >= 0) fadd(t, t, c[base + s]);
+    if (R == 2) { fadd(t, t, c[3 + f]); if (s >= 0) fadd(t, t, c[3 + s]); }
+    fnorm(x, t);
+}
+// coefficient k of an Fp6 product from four of its six role products (f6_mul's three formulas in one shape):
+//   k = 0: xi (q12 - p1 - p2) + p0      (Q, A, B, C) = (P3, P1, P2, P0)
+//   k = 1: (q01 - p0 - p1) + xi p2                     (P4, P0, P1, P2)
+//   k = 2: (q02 - p0 - p2) + p1                        (P5, P0, P2, P1)
+FD int role_q(int k) { return 3 + k; }
+FD int role_a(int k) { return k == 0 ? 1 : 0; }
+FD int role_b(int k) { return k == 1 ? 1 : 2; }
+FD int role_c(int k) { return (3 - k) % 3; }
+template <class F2> FD void f6_coeff_from_roles(F2 &z, const F2 &Q, const F2 &A, const F2 &B, const F2 &C, int k) {
+    F2 x, m, mx, cx, d, c;
+    fadd(x, A, B); f2_sub_n<16>(m, Q, x);
+    f2_mul_xi_n<32>(mx, m);              // (k == 0)
+    f2_mul_xi_n<8>(cx, C);               // (k == 1)
+    fsel(d, k == 0, mx, m); fsel(c, k == 1, cx, C);
+    fadd(x, d, c); fnorm(z, x);
+}
+// output coefficient q of the Fp12 product from coefficients of its three Fp6 products T_0 = a0 b0, T_1 = a1 b1, T_2 = (a0 + a1)(b0 + b1):
+//   q < 3 : c0.q = T_0.q + (v T_1).q,  v T_1 = (xi T_1.2, T_1.0, T_1.1)        U = T_0.q, V = T_1.((q + 2) % 3)
+//   q >= 3: c1.k = T_2.k - T_0.k - T_1.k  (k = q - 3)                           U = T_2.k, V = T_0.k, W = T_1.k
+template <class F2> FD void f12_out_c0(F2 &o, const F2 &U, const F2 &V, int q) { F2 vx, v, t; f2_mul_xi_n<128>(vx, V); fsel(v, q == 0, vx, V); fadd(t, U, v); fnorm(o, t); }
+template <class F2> FD void f12_out_c1(F2 &o, const F2 &U, const F2 &V, const F2 &W) { F2 x; fadd(x, V, W); f2_sub_n<128>(o, U, x); }
+// the whole product through the role functions (reference for the kernel's dataflow; the kernel runs the 18 + 6 pieces on different lanes)
+template <class F2> FD void f12_mul_roles(Fp12T<F2> &r, const Fp12T<F2> &a, const Fp12T<F2> &b) {
+    const F2 *ac = reinterpret_cast<const F2 *>(&a), *bc = reinterpret_cast<const F2 *>(&b);
+    F2 P[18], o[6];
+    for (int rr = 0; rr < 18; rr++) { F2 x, y; f12_role_operand(x, ac, rr / 6, rr % 6); f12_role_operand(y, bc, rr / 6, rr % 6); fmul(P[rr], x, y); }
+    auto z = [&](F2 &out, int R, int k) { f6_coeff_from_roles(out, P[6 * R + role_q(k)], P[6 * R + role_a(k)], P[6 * R + role_b(k)], P[6 * R + role_c(k)], k); };
+    for (int q = 0; q < 3; q++) { F2 U, V; z(U, 0, q); z(V, 1, (q + 2) % 3); f12_out_c0(o[q], U, V, q); }
+    for (int k = 0; k < 3; k++) { F2 U, V, W; z(U, 2, k); z(V, 0, k); z(W, 1, k); f12_out_c1(o[3 + k], U, V, W); }
+    F2 *rc = reinterpret_cast<F2 *>(&r);
+    for (int q = 0; q < 6; q++) rc[q] = o[q];
+}
 // dense Fp12 from a sparse 014 element
 template <class F2> FD void f12_from_014(Fp12T<F2> &f, const F2 &c0, const F2 &c1, const F2 &c4) {
     f6_zero(f.c0); f6_zero(f.c1);

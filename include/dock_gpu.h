@@ -62,9 +62,10 @@ size_t dgpu_get_min_gpu_n(void);
 int32_t dgpu_set_window_bits(int32_t c);
 /* terms per lane of the bucket accumulation (16..4096; 0 = automatic).  Any value gives the same point (tests sweep it). */
 int32_t dgpu_set_chunk(int32_t terms);
-/* dgpu_multi_miller_loop of up to 8192 pairs runs its line kernel in two launches and overlaps the products / host share of the first with
- * the second (default on).  0 = the one-launch form.  Both give the same Fp12 value limb for limb (tests compare them). */
-int32_t dgpu_set_miller_pipeline(int32_t on);
+/* Forms of the Miller-loop kernels, a bit mask (default 3).  Bit 0: dgpu_multi_miller_loop of up to 8192 pairs runs its line kernel in two
+ * launches and overlaps the products / host share of the first with the second.  Bit 1: the product tree gives every node 18 lane pairs
+ * (one Fp2 product deep per level) instead of three.  Every combination gives the same Fp12 value limb for limb (tests compare them). */
+int32_t dgpu_set_miller_pipeline(int32_t mode);
 /* Workspaces.  Every call in flight owns one of the context's slots (stream + grow-only device workspace).  The slots are sized AHEAD of
  * the calls so that no MSM path allocates in steady state (a hipMalloc costs 0.1 - 1 ms and the hipFree of the buffer it replaces waits for
  * the whole device, i.e. for every other call in flight): dgpu_bases_upload_* / dgpu_bases_precompute_* / dgpu_window_table_mul_to_bases_*

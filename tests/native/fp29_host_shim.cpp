@@ -173,6 +173,14 @@ void shim_f12_mul(const uint32_t *a, const uint32_t *b, int reps, uint32_t *out)
     for (int i = 1; i < reps; i++) { Fp12d t; f12_mul(t, r, y); r = t; }     // feed outputs back in: bounds must close
     store_f12(out, r);
 }
+// the same product regrouped into 18 roles + 6 outputs (k_product_tree18's dataflow); every other repetition through f12_mul: both forms
+// must accept each other's outputs
+void shim_f12_mul_roles(const uint32_t *a, const uint32_t *b, int reps, uint32_t *out) {
+    Fp12d x, y, r; load_f12(x, a); load_f12(y, b);
+    f12_mul_roles(r, x, y);
+    for (int i = 1; i < reps; i++) { Fp12d t; if (i & 1) f12_mul(t, r, y); else f12_mul_roles(t, r, y); r = t; }
+    store_f12(out, r);
+}
 void shim_f12_mul_by_014(const uint32_t *a, const uint32_t *c0, const uint32_t *c1, const uint32_t *c4, int reps, uint32_t *out) {
     Fp12d x; load_f12(x, a); Fp2 k0, k1, k4; load_f2(k0, c0); load_f2(k1, c1); load_f2(k4, c4);
     for (int i = 0; i < reps; i++) f12_mul_by_014(x, k0, k1, k4);

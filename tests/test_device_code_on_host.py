@@ -165,3 +165,92 @@ def test_group_law_complete(shim, group):
     o = np.zeros(W, np.uint64)
     tree_fn(p_(arr), 2, p_(o)); assert dec(o) is None
     tree_fn(p_(arr), 3, p_(o)); assert dec(o) == pts[3]
+
+
+# ---- pairing tower / Miller-loop lines / Fr: the device code of the pairing and NTT kernels on the host ----
+def _f12_rand(rng):
+    return tuple(tuple((rng.randrange(P), rng.randrange(P)) for _ in range(3)) for _ in range(2))
+
+
+def _f12_flat(f):
+    return [c for six in f for two in six for c in two]
+
+
+def _f12_enc(f):
+    return np.ascontiguousarray(U.f12_abi(_f12_flat(f)))
+
+
+def _f2_enc(a):
+    return np.ascontiguousarray(np.concatenate([U.fp_abi(a[0]), U.fp_abi(a[1])]))
+
+
+def test_fp12_products_on_host(shim):
+    """pairing29.hip.h under the bound tracker: the dense product (f12_mul, what k_product_tree runs), the same product regrouped into
+    18 role products + 6 output combinations (f12_mul_roles, what k_product_tree18 runs) and the sparse product (f12_mul_by_014, what
+    k_line_products runs) against the big-integer model; outputs are fed back in (reps) so the value bounds must close, and the two dense
+    forms alternate so each must accept the other's outputs"""
+    rng = random.Random(12)
+    for trial in range(6):
+        a, b = _f12_rand(rng), _f12_rand(rng)
+        for reps in (1, 2, 7):
+            want = M.f12_mul(a, b)
+            for _ in range(reps - 1):
+                want = M.f12_mul(want, b)
+            for fn in (shim.shim_f12_mul, shim.shim_f12_mul_roles):
+                o = np.zeros(72, np.uint64)
+                fn(p_(_f12_enc(a)), p_(_f12_enc(b)), reps, p_(o))
+                assert U.f12_ints(o) == _f12_flat(want), (fn, reps)
+        c0, c1, c4 = [(rng.randrange(P), rng.randrange(P)) for _ in range(3)]
+        want = a
+        for _ in range(5):
+            want = M.f12_mul_by_014(want, c0, c1, c4)
+        o = np.zeros(72, np.uint64)
+        shim.shim_f12_mul_by_014(p_(_f12_enc(a)), p_(_f2_enc(c0)), p_(_f2_enc(c1)), p_(_f2_enc(c4)), 5, p_(o))
+        assert U.f12_ints(o) == _f12_flat(want)
+    # edge values: zero, one, p - 1 in every coefficient
+    one = ((( 1, 0), (0, 0), (0, 0)), ((0, 0), (0, 0), (0, 0)))
+    top = tuple(tuple((P - 1, P - 1) for _ in range(3)) for _ in range(2))
+    for a, b in ((one, top), (top, top), (top, one)):
+        for fn in (shim.shim_f12_mul, shim.shim_f12_mul_roles):
+            o = np.zeros(72, np.uint64)
+            fn(p_(_f12_enc(a)), p_(_f12_enc(b)), 4, p_(o))
+            want = M.f12_mul(a, b)
+            for _ in range(3):
+                want = M.f12_mul(want, b)
+            assert U.f12_ints(o) == _f12_flat(want)
+
+
+def test_miller_loop_dataflow_on_host(shim):
+    """the kernels' dataflow (lines per pair with G2Prepared::from fused, per-step sparse products, dense product, host square-and-multiply)
+    run on the host under the bound tracker == the model's textbook Miller loop"""
+    ks = [(3, 5), (0x1234567, 0x89abcdef), (M.R - 2, 7)]
+    ps = [M.g1_mul(M.G1_GEN, a) for a, _ in ks]
+    qs = [M.g2_mul(M.G2_GEN, b) for _, b in ks]
+    for n in (1, 2, 3):
+        pa = np.ascontiguousarray(np.concatenate([U.g1_abi(p)[0] for p in ps[:n]]))
+        qa = np.ascontiguousarray(np.concatenate([U.g2_abi(q)[0] for q in qs[:n]]))
+        o = np.zeros(72, np.uint64)
+        shim.shim_multi_miller(p_(pa), p_(qa), n, p_(o))
+        assert U.f12_ints(o) == _f12_flat(M.multi_miller_loop(ps[:n], qs[:n]))
+
+
+def test_fr_ops_on_host(shim):
+    """fr29.hip.h (the NTT's field) under the bound tracker: Montgomery and canonical products, a chain of lazy butterflies"""
+    rng = random.Random(5)
+    enc = lambda v: np.ascontiguousarray(np.array([(v >> (64 * i)) & (2**64 - 1) for i in range(4)], np.uint64))
+    dec = lambda o: sum(int(o[i]) << (64 * i) for i in range(4))
+    RI = pow(M.FR_R, -1, M.R)
+    for trial in range(40):
+        a, b, w = (rng.randrange(M.R) for _ in range(3))
+        if trial == 0:
+            a, b, w = M.R - 1, M.R - 1, M.R - 1
+        o = np.zeros(4, np.uint64)
+        shim.shim_fr_mul(p_(enc(a)), p_(enc(b)), 0, p_(o)); assert dec(o) == a * b % M.R
+        shim.shim_fr_mul(p_(enc(a * M.FR_R % M.R)), p_(enc(b * M.FR_R % M.R)), 1, p_(o)); assert dec(o) * RI % M.R == a * b % M.R
+        x, y = a, b
+        for _ in range(30):
+            t = y * w % M.R
+            x, y = (x + t) % M.R, (x - t) % M.R
+        ox, oy = np.zeros(4, np.uint64), np.zeros(4, np.uint64)
+        shim.shim_fr_butterflies(p_(enc(a)), p_(enc(b)), p_(enc(w)), 30, p_(ox), p_(oy))
+        assert (dec(ox), dec(oy)) == (x, y)

@@ -61,27 +61,30 @@ def test_vs_oracle_across_kernel_boundaries(n):
     assert (ca.multi_miller_loop(ps, qs) == O.multi_miller_loop(ps, qs, skip, threads=32)).all()
 
 
-@pytest.mark.parametrize("n", [1, 3, 64, 1024, 8192])
-def test_two_launch_line_kernel_equals_the_one_launch_form(n):
-    """dgpu_multi_miller_loop of up to 8192 pairs cuts the 68-step chain at bit 17 of |x| (two launches of the line kernel, the products
-    and the host's share of the first 50 steps overlapped with the second): the same Fp12 value limb for limb as the one-launch form
-    (dgpu_set_miller_pipeline(0)) and as the oracle, identity members and skipped pairs included"""
+@pytest.mark.parametrize("n", [1, 3, 64, 130, 1024, 1100, 5000, 8192, 9000])
+def test_every_form_of_the_miller_kernels_gives_the_same_value(n):
+    """dgpu_set_miller_pipeline: bit 0 cuts the 68-step chain of a call of up to 8192 pairs at bit 17 of |x| (two launches of the line
+    kernel, evaluation at P moved into the product kernel, products and host share of the first 50 steps overlapped with the second
+    launch), bit 1 runs the product tree with 18 lane pairs per node.  All four combinations: the same Fp12 value limb for limb, equal
+    to the oracle's, identity members and skipped pairs included"""
     from crypto_amd._native import lib
     k0 = O.rand_scalars(41, 1)[0]; d = O.rand_scalars(42, 1)[0]
     ps = O.G1.gen_seq(k0, d, n, threads=32); qs = O.G2.gen_seq(d, k0, n, threads=32)
     skip = np.zeros(n, np.uint8)
     if n >= 3:
         ps[n // 3] = 0; skip[n // 3] = 1; skip[n - 1] = 1
+    got = {}
     try:
-        assert lib().dgpu_set_miller_pipeline(0) == 0
-        one = ca.multi_miller_loop(ps, qs, skip)
-        assert lib().dgpu_set_miller_pipeline(1) == 0
-        two = ca.multi_miller_loop(ps, qs, skip)
+        for mode in (0, 1, 2, 3):
+            assert lib().dgpu_set_miller_pipeline(mode) == 0
+            got[mode] = ca.multi_miller_loop(ps, qs, skip)
+        assert lib().dgpu_set_miller_pipeline(4) != 0
     finally:
-        lib().dgpu_set_miller_pipeline(1)
-    assert (one == two).all()
-    if n <= 1024:
-        assert (two == O.multi_miller_loop(ps, qs, skip, threads=32)).all()
+        lib().dgpu_set_miller_pipeline(3)
+    for mode in (1, 2, 3):
+        assert (got[mode] == got[0]).all(), mode
+    if n <= 1100:
+        assert (got[3] == O.multi_miller_loop(ps, qs, skip, threads=32)).all()
 
 
 def test_identity_members_are_skipped_and_lengths_checked():

@@ -475,7 +475,7 @@ static void launch_product_tree(hipStream_t st, unsigned blocks, const uint32_t 
 // the partials (dense products, log depth): short slices keep both latency-bound phases short at small n and fill the chip at large n
 // (a fixed 64 slices left k_line_products with 4352 lanes whatever n: 59 ms at 2^16 pairs).
 inline int choose_slice_len(size_t n) {
-    size_t len = n > 2048 ? 8 : 4;
+    size_t len = n > 2048 ? 8 : (n > 512 ? 4 : 2);      // (measured with the 18-role tree: 2 wins up to 512 pairs, 4 at 1024, 8 from 4096)
     while ((n + len - 1) / len > 2048 && (n + len - 1) / len > 0) len *= 2;
     return (int)len;
 }

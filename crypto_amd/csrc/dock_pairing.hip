@@ -651,6 +651,8 @@ static int32_t ml_segments(const uint64_t *p, const uint64_t *q, const uint8_t *
     if ((rc = sl.ml_lines.ensure((size_t)N_LINES * LW * n * 4))) return rc;
     if ((rc = sl.ml_partial.ensure((size_t)N_LINES * nseg * nsl * F12W * 4))) return rc;
     if ((rc = sl.ml_out.ensure((size_t)N_LINES * nseg * 144 * 4))) return rc;
+    if ((rc = sl.ml_state.ensure((size_t)2 * NL * n * 4))) return rc;                 // px, py of every pair for the product kernel
+    uint32_t *pxy = sl.ml_state.as<uint32_t>();
     hipStream_t s = sl.stream;
     HIPCHK(hipMemcpyAsync(sl.in_bases.p, p, n * 96, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(sl.in_scalars.p, q, n * 192, hipMemcpyHostToDevice, s));
@@ -660,9 +662,11 @@ static int32_t ml_segments(const uint64_t *p, const uint64_t *q, const uint8_t *
     HIPCHK(hipMemcpyAsync(doff, off.data(), (nseg + 1) * 4, hipMemcpyHostToDevice, s));
     { StageTimer st(sl, "ml.lines");
       if (n > 8192) hipLaunchKernelGGL(k_miller_lines_pair, dim3((unsigned)((2 * n + 63) / 64)), dim3(64), 0, s, sl.in_bases.as<uint32_t>(), sl.in_scalars.as<uint32_t>(), dskip, n, sl.ml_lines.as<uint32_t>(), n);
-      else hipLaunchKernelGGL(k_miller_lines_quad<true>, dim3((unsigned)((4 * n + 63) / 64)), dim3(64), 0, s, sl.in_bases.as<uint32_t>(), sl.in_scalars.as<uint32_t>(), dskip, n, sl.ml_lines.as<uint32_t>(), n); }
+      else hipLaunchKernelGGL(k_miller_lines_quad<false>, dim3((unsigned)((4 * n + 63) / 64)), dim3(64), 0, s, sl.in_bases.as<uint32_t>(), sl.in_scalars.as<uint32_t>(), dskip, n, sl.ml_lines.as<uint32_t>(), n,
+                              62, 0, 0, (uint32_t *)nullptr, pxy); }       // (the evaluation at P is left to the product kernel: not part of the chain)
     { StageTimer st(sl, "ml.products");
-      hipLaunchKernelGGL(k_line_products, dim3((unsigned)((2 * (size_t)N_LINES * nsl * nseg + 63) / 64)), dim3(64), 0, s, sl.ml_lines.as<uint32_t>(), n, slice_len, nsl, sl.ml_partial.as<uint32_t>(), doff, (int)nseg); }
+      hipLaunchKernelGGL(k_line_products, dim3((unsigned)((2 * (size_t)N_LINES * nsl * nseg + 63) / 64)), dim3(64), 0, s, sl.ml_lines.as<uint32_t>(), n, slice_len, nsl, sl.ml_partial.as<uint32_t>(), doff, (int)nseg,
+                         0, N_LINES, n > 8192 ? (const uint32_t *)nullptr : (const uint32_t *)pxy); }
     { StageTimer st(sl, "ml.tree");
       launch_product_tree(s, (unsigned)(N_LINES * nseg), sl.ml_partial.as<uint32_t>(), nsl, 1, (uint32_t *)nullptr, sl.ml_out.as<uint32_t>(), doff, slice_len, 0); }
     HIPCHK(hipGetLastError());

@@ -85,6 +85,7 @@ struct Ctx {
     int device = -1;               // physical HIP device
     Slot slots[N_SLOTS];
     std::atomic<unsigned> rr{0};
+    std::atomic<int> ml_active{0};  // dgpu_multi_miller_loop calls in flight on this context (dock_pairing.hip picks the kernel form by it)
     std::map<int, NttDomain> ntt_domains;
     // Recycled scalar vectors (guarded by gs.mu).  A proof uploads one assignment and receives one h vector, both released when it is done:
     // hipMalloc / hipFree per proof cost ~0.3 ms and hipFree waits for the whole device, i.e. for every other call in flight.

@@ -518,11 +518,11 @@ static void ml_products(Slot &sl, hipStream_t s, size_t n, const MlGeom &g, int 
     else { products(); tree(); }
 }
 // K10 + K11 + host tail on the lines already in sl.ml_lines
-static int32_t ml_finish(Slot &sl, size_t n, uint64_t *out) {
+static int32_t ml_finish(Slot &sl, size_t n, uint64_t *out, const uint32_t *pxy = nullptr) {
     int32_t rc; MlGeom g;
     if ((rc = ml_geometry(sl, n, g))) return rc;
     hipStream_t s = sl.stream;
-    ml_products(sl, s, n, g, 0, N_LINES, true);
+    ml_products(sl, s, n, g, 0, N_LINES, true, pxy);
     HIPCHK(hipGetLastError());
     std::vector<hostf::Fq12> L(N_LINES);
     HIPCHK(hipMemcpyAsync(L.data(), sl.ml_out.p, (size_t)N_LINES * 576, hipMemcpyDeviceToHost, s));
@@ -596,7 +596,19 @@ int32_t dgpu_multi_miller_loop(const uint64_t *p, const uint64_t *q, const uint8
 #else
       constexpr bool one_lane = false, two_lanes = false;
 #endif
-      if (!one_lane && !two_lanes && n <= 8192 && !gs.prof && (gs.ml_mode.load() & 1)) return ml_pipelined(sl, n, dskip, out);
+      if (!one_lane && !two_lanes && n <= 8192 && !gs.prof && (gs.ml_mode.load() & 1)) {
+          // The two-launch form needs the slot's second stream and an event wait between the two; with more streams than hardware queues a
+          // waiting stream holds up whatever shares its queue (measured, 1024 pairs: 0.62 vs 0.70 ms per call with two calls in flight, but
+          // 0.49 vs 0.36 with six), so it is taken while at most two Miller loops are in flight on this context.  Either way the evaluation
+          // at P is left to the product kernel.
+          struct Active { std::atomic<int> &c; int v; Active(std::atomic<int> &c_) : c(c_), v(++c_) {} ~Active() { --c; } } act(cur().ml_active);
+          if (act.v <= 2) return ml_pipelined(sl, n, dskip, out);
+          if ((rc = sl.ml_state.ensure((size_t)2 * NL * n * 4))) return rc;
+          uint32_t *pxy = sl.ml_state.as<uint32_t>();
+          hipLaunchKernelGGL(k_miller_lines_quad<false>, dim3((unsigned)((4 * n + 63) / 64)), dim3(64), 0, s, sl.in_bases.as<uint32_t>(), sl.in_scalars.as<uint32_t>(), dskip, n, sl.ml_lines.as<uint32_t>(), n,
+                             62, 0, 0, (uint32_t *)nullptr, pxy);
+          return ml_finish(sl, n, out, pxy);
+      }
       if (one_lane) hipLaunchKernelGGL(k_miller_lines, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, sl.in_bases.as<uint32_t>(), sl.in_scalars.as<uint32_t>(), dskip, n, sl.ml_lines.as<uint32_t>(), n);
       else if (two_lanes || n > 8192) hipLaunchKernelGGL(k_miller_lines_pair,     // (with the chip full, the pair form does less total work)
               dim3((unsigned)((2 * n + 63) / 64)), dim3(64), 0, s, sl.in_bases.as<uint32_t>(), sl.in_scalars.as<uint32_t>(), dskip, n, sl.ml_lines.as<uint32_t>(), n);

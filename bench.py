@@ -100,6 +100,7 @@ def main():
     ap.add_argument("--inflight", type=int, default=6, help="MSM calls in flight per GPU (host threads; each call owns a stream + workspace slot)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-table", action="store_true", help="time the plain resident pipeline (no precomputed-multiples table)")
+    ap.add_argument("--reduce-shift", type=int, default=-1, help="development: dgpu_set_reduce_shift (log2 buckets per lane of the bucket reduction; -1 = automatic)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -124,6 +125,9 @@ def main():
     from crypto_amd import sharded, serde, fixed_base as FB
 
     ca.init(local)
+    if args.reduce_shift >= 0:
+        from crypto_amd._native import lib as _lib
+        assert _lib().dgpu_set_reduce_shift(args.reduce_shift) == 0
     if args.log2n == 0:
         lg = 0
         while (1 << lg) < world:

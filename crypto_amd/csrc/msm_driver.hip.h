@@ -313,6 +313,7 @@ template <class C> int32_t pre_geometry(const PreTable &pt, size_t n, PreGeom &g
     // buckets per lane of k_reduce_l0 = 2^mshift: 8 once the bucket set fills the chip with one wave per SIMD (2^19 buckets = 1024 waves, the
     // kernel is work-bound), fewer for small sets, where the serial part of every lane is pure latency (2^15 buckets: 1 per lane, 512 waves)
     g.mshift = g.NB >= (1u << 18) ? 3 : (g.NB >= (1u << 17) ? 2 : (g.NB >= (1u << 16) ? 1 : 0));
+    { const int f = gs.reduce_shift.load(); if (f >= 0 && c - 1 >= 6 + f) g.mshift = f; }
     g.lb = std::min(c - 1, 12 + g.mshift);        // log2 buckets per pseudo-window (64 groups of 64 * 2^mshift buckets)
     g.PW = (int)(g.NB >> g.lb);
     g.G = 1 << (g.lb - 6 - g.mshift);             // groups per pseudo-window (<= 64)

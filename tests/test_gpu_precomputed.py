@@ -48,6 +48,25 @@ def test_table_msm_equals_plain_and_oracle(gname, n, c):
     plain.free(); tab.free()
 
 
+@pytest.mark.parametrize("gname,n,c", [("G1", 5003, 16), ("G1", (1 << 16) + 3, 20), ("G2", 3001, 20)])
+def test_any_reduction_geometry_same_point(gname, n, c):
+    """dgpu_set_reduce_shift: the bucket reduction's serial share (2^shift buckets per lane, 64 lanes per group, <= 64 groups per
+    pseudo-window, the rest on the host) is a tuning knob — every geometry must return the limbs of the automatic one (measured at
+    2^20 terms: the automatic 8 buckets per lane is the fastest both for one call and for six in flight)"""
+    curve, G = (ca.G1, O.G1) if gname == "G1" else (ca.G2, O.G2)
+    bases, _, _ = U.seq_bases(G, n, 1700 + n, threads=16)
+    sc = O.rand_scalars(1800 + n, n)
+    tab = ca.DeviceBases(curve, bases).precompute(c)
+    ref = tab.msm_bigint(sc)
+    try:
+        for sh in (0, 1, 2, 3, 4, 5, 6):
+            assert lib().dgpu_set_reduce_shift(sh) == 0
+            assert (tab.msm_bigint(sc) == ref).all(), sh
+        assert lib().dgpu_set_reduce_shift(7) != 0
+    finally:
+        lib().dgpu_set_reduce_shift(-1)
+
+
 def test_skewed_and_degenerate_scalars_on_a_table():
     G, curve = O.G1, ca.G1
     n = 1 << 14

@@ -103,6 +103,7 @@ struct Shared {
     std::atomic<size_t> min_gpu_n{DGPU_DEFAULT_MIN_GPU_N};
     std::atomic<int> window_bits{0};
     std::atomic<int> chunk{0};
+    std::atomic<int> reduce_lanes{4};         // dgpu_set_reduce_lanes: members per point in the last reduction kernel (1: k_reduce_top, 4: k_reduce_top_quad)
     std::atomic<int> reduce_shift{-1};        // dgpu_set_reduce_shift: log2 buckets per lane of k_reduce_l0 on the table pipeline (-1 = automatic)
     std::atomic<int> ml_mode{3};              // dgpu_set_miller_pipeline: bit 0 the two-launch line kernel of small Miller loops, bit 1 the 18-role product tree (dock_pairing.hip)
     uint64_t allocs_at_reset = 0, alloc_ns_at_reset = 0;

@@ -183,4 +183,59 @@ template <class F> FD void xyzz_add(Xyzz<F> &a, bool &ainf, const Xyzz<F> &b, bo
     else if (ainf && !binf) { a = b; ainf = false; }
 }
 
+// ---- the general addition / doubling regrouped into rounds of INDEPENDENT products ----------------------------------------------------
+// A latency-bound kernel (k_reduce_top: a handful of waves on a chain of ~19 general additions) lasts as long as one lane's instruction
+// stream; the 14 products of an addition are only four deep (U, S -> PP, R^2, Z Z' -> PPP, Q, ZZ3 -> Y3 terms, ZZZ3), the 9 of a doubling
+// three.  xyzz_add_rounds / xyzz_dbl_rounds are the formulas above written round by round through a `Quad` policy object that decides
+// who multiplies: QuadSerial (host, reference) computes all four products of a round itself; the device policy of msm_kernels.hip.h gives
+// every point four lanes (lane pairs for G2), each multiplies ONE pair of role-selected operands and the results are broadcast.  Same
+// field operations on the same values either way, so one host run under the bound tracker covers both; the only difference to
+// xyzz_add is Y3 = R (Q - X3) - S1 PPP as two products and a subtraction instead of one fused two-product reduction.
+struct QuadSerial {
+    // r[k] = a[k] * b[k] for the four roles
+    template <class F> FD void mul4(F (&r)[4], const F (&a)[4], const F (&b)[4], int /*used*/) const { for (int k = 0; k < 4; k++) fmul(r[k], a[k], b[k]); }
+};
+template <class F, class Q4> FD void xyzz_add_rounds(Xyzz<F> &a, bool &ainf, const Xyzz<F> &b, bool binf, const Q4 &q4) {
+    F r[4], Pd, Rd, t, X3, Y3;
+    { const F m1[4] = {a.x, b.x, a.y, b.y}, m2[4] = {b.zz, a.zz, b.zzz, a.zzz}; q4.mul4(r, m1, m2, 4); }      // U1 U2 S1 S2
+    const F U1 = r[0], S1 = r[2];
+    fsub<SubM<F>::Y>(Pd, r[1], r[0]); fnorm(Pd, Pd);
+    fsub<SubM<F>::Y>(Rd, r[3], r[2]); fnorm(Rd, Rd);
+    { const F m1[4] = {Pd, Rd, a.zz, a.zzz}, m2[4] = {Pd, Rd, b.zz, b.zzz}; q4.mul4(r, m1, m2, 4); }           // PP R^2 ZZ ZZ' ZZZ ZZZ'
+    const F PP = r[0], RR = r[1], Z2 = r[2], Z3 = r[3];
+    { const F m1[4] = {Pd, U1, Z2, Z2}, m2[4] = {PP, PP, PP, PP}; q4.mul4(r, m1, m2, 3); }                      // PPP Q ZZ3
+    const F PPP = r[0], Qv = r[1], ZZ3 = r[2];
+    fadd(t, Qv, Qv); fadd(t, t, PPP);
+    fsub<SubM<F>::X>(X3, RR, t); fnormw(X3, X3);
+    fsub<SubM<F>::D>(t, Qv, X3); fnorm(t, t);
+    { const F m1[4] = {Rd, S1, Z3, Z3}, m2[4] = {t, PPP, PPP, PPP}; q4.mul4(r, m1, m2, 3); }                    // R (Q - X3), S1 PPP, ZZZ3
+    const F ZZZ3 = r[2];
+    fsub<SubM<F>::Y>(Y3, r[0], r[1]); fnorm(Y3, Y3);
+    const bool both = !ainf && !binf;
+    const bool special = both && fmaybe_zero(Pd);
+    if (special) {
+        if (fis_zero_exact(Pd)) {
+            if (fis_zero_exact(Rd)) { Xyzz<F> d; xyzz_dbl(d, a); a = d; }
+            else ainf = true;
+            return;
+        }
+    }
+    if (both) { a.x = X3; a.y = Y3; a.zz = ZZ3; a.zzz = ZZZ3; }
+    else if (ainf && !binf) { a = b; ainf = false; }
+}
+template <class F, class Q4> FD void xyzz_dbl_rounds(Xyzz<F> &rr, const Xyzz<F> &a, const Q4 &q4) {
+    F U, M, t, X3, Y3, r[4];
+    fdbl(U, a.y); fnorm(U, U);
+    { const F m1[4] = {U, a.x, U, U}, m2[4] = {U, a.x, U, U}; q4.mul4(r, m1, m2, 2); }                           // V = U^2, X^2
+    const F V = r[0];
+    fadd(t, r[1], r[1]); fadd(M, t, r[1]); fnormw(M, M);
+    { const F m1[4] = {U, a.x, V, M}, m2[4] = {V, V, a.zz, M}; q4.mul4(r, m1, m2, 4); }                          // W S ZZ3 M^2
+    const F W = r[0], S = r[1], ZZ3 = r[2];
+    fadd(t, S, S); fsub<SubM<F>::X>(X3, r[3], t); fnormw(X3, X3);
+    fsub<SubM<F>::D>(t, S, X3); fnorm(t, t);
+    { const F m1[4] = {M, W, W, W}, m2[4] = {t, a.y, a.zzz, a.zzz}; q4.mul4(r, m1, m2, 3); }                     // M (S - X3), W Y, ZZZ3
+    fsub<SubM<F>::Y>(Y3, r[0], r[1]); fnorm(Y3, Y3);
+    rr.x = X3; rr.y = Y3; rr.zz = ZZ3; rr.zzz = r[2];
+}
+
 }  // namespace bls29

@@ -232,7 +232,7 @@ int32_t msm_device_ranges(Slot &sl, const uint32_t *d_bases, const uint32_t *d_s
     {
         StageTimer st(sl, "msm.reduce");
         launch_reduce_l0<C>(s, (unsigned)g.NG, sl.bucket.as<uint32_t>(), sl.bucket_inf.as<uint8_t>(), NB, g.mshift, sl.l1.as<uint32_t>(), sl.l1_inf.as<uint8_t>());
-        launch_reduce_top<C>(s, (unsigned)W, sl.l1.as<uint32_t>(), sl.l1_inf.as<uint8_t>(), g.G, 6 + g.mshift, sl.win.as<uint32_t>(), sl.win_inf.as<uint8_t>());
+        launch_reduce_top<C>(s, (unsigned)W, sl.l1.as<uint32_t>(), sl.l1_inf.as<uint8_t>(), g.G, 6 + g.mshift, sl.win.as<uint32_t>(), sl.win_inf.as<uint8_t>(), gs.reduce_lanes.load());
     }
     HIPCHK(hipGetLastError());
     std::vector<uint64_t> hwin((size_t)W * 2 * C::ABI_W);
@@ -422,7 +422,7 @@ int32_t pre_finish(Slot &sl, const PreGeom &g, bool check_flag, uint64_t *out_xy
     {
         StageTimer st(sl, "msm.reduce");
         launch_reduce_l0<C>(s, (unsigned)g.NG, sl.bucket.as<uint32_t>(), sl.bucket_inf.as<uint8_t>(), NB, g.mshift, sl.l1.as<uint32_t>(), sl.l1_inf.as<uint8_t>());
-        launch_reduce_top_s<C>(s, (unsigned)PW, sl.l1.as<uint32_t>(), sl.l1_inf.as<uint8_t>(), g.G, 6 + g.mshift, win_a, inf_a, win_s, inf_s);
+        launch_reduce_top_s<C>(s, (unsigned)PW, sl.l1.as<uint32_t>(), sl.l1_inf.as<uint8_t>(), g.G, 6 + g.mshift, win_a, inf_a, win_s, inf_s, gs.reduce_lanes.load());
     }
     HIPCHK(hipGetLastError());
     std::vector<uint64_t> hwin((size_t)2 * PW * 2 * C::ABI_W);

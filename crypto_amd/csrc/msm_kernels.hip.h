@@ -705,6 +705,129 @@ __global__ void __launch_bounds__(64) k_reduce_top_pair(const uint32_t *__restri
 }
 
 
+// ---- K8 with four lanes (G2: four lane pairs) per point ------------------------------------------------------------------------------
+// k_reduce_top is a handful of lone waves on a chain of ~19 general additions (6 of the suffix scan, the doublings by 2^gshift, 6 of the
+// tree): 0.34 ms of a 3.3 ms G1 call, 0.64 of an 8.8 ms G2 call, and no other work of the call can hide it.  A general addition is only
+// four products deep (ec29.hip.h xyzz_add_rounds), a doubling three: here every group's (S, A) is held by FOUR members (lanes; lane pairs
+// for G2) in identical copies, each member multiplies ONE role-selected operand pair per round and the four results are broadcast — DPP
+// quad_perm for G1, ds_bpermute inside the group of eight lanes for G2.  The exchange between groups (the shuffles of
+// wave_weighted_sum) goes through LDS: member r parks coordinate r.  Same group geometry, l1 layout and outputs as k_reduce_top(_pair).
+template <int LPP> struct QuadLanes;
+template <> struct QuadLanes<1> {                       // members = the four lanes of a quad
+    int role; int src[4];
+    __device__ QuadLanes() : role((int)(threadIdx.x & 3u)) {
+        const int lane = (int)(threadIdx.x & 63u), base = lane & ~3;
+        for (int k = 0; k < 4; k++) src[k] = (base + k) * 4;
+    }
+    __device__ __forceinline__ void mul4(Fs (&r)[4], const Fs (&a)[4], const Fs (&b)[4], int used) const {
+        Fs m1, m2, p;
+#pragma unroll
+        for (int i = 0; i < SN; i++) {
+            m1.l[i] = role == 0 ? a[0].l[i] : (role == 1 ? a[1].l[i] : (role == 2 ? a[2].l[i] : a[3].l[i]));
+            m2.l[i] = role == 0 ? b[0].l[i] : (role == 1 ? b[1].l[i] : (role == 2 ? b[2].l[i] : b[3].l[i]));
+        }
+        fs_mul(p, m1, m2);
+#pragma unroll
+        for (int i = 0; i < SN; i++) {
+            r[0].l[i] = __builtin_amdgcn_ds_bpermute(src[0], p.l[i]); r[1].l[i] = __builtin_amdgcn_ds_bpermute(src[1], p.l[i]);
+            if (used > 2) r[2].l[i] = __builtin_amdgcn_ds_bpermute(src[2], p.l[i]);
+            if (used > 3) r[3].l[i] = __builtin_amdgcn_ds_bpermute(src[3], p.l[i]);
+        }
+    }
+};
+template <> struct QuadLanes<2> {                       // members = the four lane pairs of a group of eight lanes
+    int role; int src[4];
+    __device__ QuadLanes() : role((int)((threadIdx.x >> 1) & 3u)) {
+        const int lane = (int)(threadIdx.x & 63u), base = lane & ~7, h = lane & 1;
+        for (int k = 0; k < 4; k++) src[k] = (base + 2 * k + h) * 4;
+    }
+    __device__ __forceinline__ void mul4(Fs2H (&r)[4], const Fs2H (&a)[4], const Fs2H (&b)[4], int used) const {
+        Fs2H m1, m2, p;
+#pragma unroll
+        for (int i = 0; i < SN; i++) {
+            m1.v.l[i] = role == 0 ? a[0].v.l[i] : (role == 1 ? a[1].v.l[i] : (role == 2 ? a[2].v.l[i] : a[3].v.l[i]));
+            m2.v.l[i] = role == 0 ? b[0].v.l[i] : (role == 1 ? b[1].v.l[i] : (role == 2 ? b[2].v.l[i] : b[3].v.l[i]));
+        }
+        fmul(p, m1, m2);
+#pragma unroll
+        for (int i = 0; i < SN; i++) {
+            r[0].v.l[i] = __builtin_amdgcn_ds_bpermute(src[0], p.v.l[i]); r[1].v.l[i] = __builtin_amdgcn_ds_bpermute(src[1], p.v.l[i]);
+            if (used > 2) r[2].v.l[i] = __builtin_amdgcn_ds_bpermute(src[2], p.v.l[i]);
+            if (used > 3) r[3].v.l[i] = __builtin_amdgcn_ds_bpermute(src[3], p.v.l[i]);
+        }
+    }
+};
+template <class C>
+__global__ void __launch_bounds__(256 * C::LPP) k_reduce_top_quad(const uint32_t *__restrict__ l1, const uint8_t *__restrict__ l1_inf, int G, int gshift,
+                                                                  uint32_t *__restrict__ win_abi, uint8_t *__restrict__ win_inf,
+                                                                  uint32_t *__restrict__ win_s_abi = nullptr, uint8_t *__restrict__ win_s_inf = nullptr) {
+    typedef typename C::F F;
+    constexpr int LPP = C::LPP, GL = 4 * LPP, PW_ = 4 * SN;          // lanes per group; words of a point held by one lane (4 coordinates or coordinate halves)
+    __shared__ uint32_t xs[64 * LPP * PW_];
+    __shared__ uint8_t fl[64];
+    const int t = (int)threadIdx.x, gi = t / GL, h = t % LPP;
+    const QuadLanes<LPP> q4;
+    const size_t w = blockIdx.x;
+    Xyzz<F> S, A; bool sinf = true, ainf = true;
+    fzero(S.x); fzero(S.y); fzero(S.zz); fzero(S.zzz); A = S;
+    if (gi < G) {
+        const uint32_t *src = l1 + (w * G + gi) * 2 * C::XW;
+        if constexpr (LPP == 1) {
+            uint32_t *ps = reinterpret_cast<uint32_t *>(&S), *pa = reinterpret_cast<uint32_t *>(&A);
+            for (int k = 0; k < PW_; k++) { ps[k] = src[k]; pa[k] = src[C::XW + k]; }
+        } else { load_l1_pair(S, src); load_l1_pair(A, src + C::XW); }
+        sinf = l1_inf[2 * (w * G + gi)] != 0; ainf = l1_inf[2 * (w * G + gi) + 1] != 0;
+    }
+    if (!__syncthreads_or((!sinf || !ainf) ? 1 : 0)) {               // an empty (pseudo-)window
+        if (t == 0) { win_inf[w] = 1; if (win_s_abi) win_s_inf[w] = 1; }
+        return;
+    }
+    // o = the point of group gi + d (identity past the last group): member r parks coordinate r, everybody reads all four
+    auto from_group = [&](Xyzz<F> &o, bool &oinf, const Xyzz<F> &x, bool xinf, int d) {
+        __syncthreads();
+        { const uint32_t *wv = reinterpret_cast<const uint32_t *>(&x) + q4.role * SN;
+          uint32_t *dst = xs + ((gi * 4 + q4.role) * LPP + h) * SN;
+#pragma unroll
+          for (int j = 0; j < SN; j++) dst[j] = wv[j];
+          if (t % GL == 0) fl[gi] = xinf; }
+        __syncthreads();
+        const int sg = gi + d;
+        oinf = true;
+        if (sg < 64) {
+            uint32_t *ov = reinterpret_cast<uint32_t *>(&o);
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const uint32_t *sv = xs + ((sg * 4 + c) * LPP + h) * SN;
+#pragma unroll
+                for (int j = 0; j < SN; j++) ov[c * SN + j] = sv[j];
+            }
+            oinf = fl[sg] != 0;
+        } else o = x;
+    };
+#pragma unroll 1
+    for (int d = 1; d < 64; d <<= 1) {                               // suffix scan: S_g <- sum_{j >= g} S_j
+        Xyzz<F> o; bool oinf; from_group(o, oinf, S, sinf, d);
+        xyzz_add_rounds(S, sinf, o, oinf, q4);
+    }
+    Xyzz<F> y = S; bool yinf = (gi == 0) ? true : sinf;              // sum_g g S_g = sum_{g >= 1} suffix_g, times 2^gshift
+#pragma unroll 1
+    for (int k = 0; k < gshift; k++) { if (!yinf) { Xyzz<F> d2; xyzz_dbl_rounds(d2, y, q4); y = d2; } }
+    xyzz_add_rounds(A, ainf, y, yinf, q4);
+#pragma unroll 1
+    for (int d = 32; d >= 1; d >>= 1) {
+        Xyzz<F> o; bool oinf; from_group(o, oinf, A, ainf, d);
+        xyzz_add_rounds(A, ainf, o, oinf, q4);
+    }
+    if (gi == 0) {                                                    // member r converts coordinate r (G2: each lane its half)
+        const int r = q4.role;
+        if (t == 0) { win_inf[w] = ainf; if (win_s_abi) win_s_inf[w] = sinf; }
+        const Fs *fa = reinterpret_cast<const Fs *>(&A), *fsv = reinterpret_cast<const Fs *>(&S);
+        constexpr int WS = 4 * 12 * LPP;                             // ABI words per window sum
+        if (!ainf) fs_to_abi(win_abi + w * WS + 12 * (LPP * r + h), fa[r]);
+        if (win_s_abi && !sinf) fs_to_abi(win_s_abi + w * WS + 12 * (LPP * r + h), fsv[r]);
+    }
+}
+
 // K6 for G2 on lane pairs: lanes 2t and 2t + 1 fold the partials of the bucket whose tail slot is t (same logic as k_fixup)
 template <class PAIR>
 __global__ void __launch_bounds__(256) k_fixup_pair(uint32_t NB, uint32_t *__restrict__ bucket, uint8_t *__restrict__ bucket_inf,

@@ -20,11 +20,11 @@ template <class C> void launch_fixup_heavy(hipStream_t s, const uint32_t *heavy,
                                            const uint32_t *head, const uint32_t *tail, const uint8_t *part_inf, size_t T, uint32_t *dyn, uint32_t *hpart, uint8_t *hpart_inf);
 template <class C> void launch_merge_buckets(hipStream_t s, uint32_t NB, uint32_t *dst, uint8_t *dst_inf, const uint32_t *src, const uint8_t *src_inf);
 template <class C> void launch_reduce_l0(hipStream_t s, unsigned NG, const uint32_t *bucket, const uint8_t *bucket_inf, uint32_t NB, int mshift, uint32_t *l1, uint8_t *l1_inf);
-template <class C> void launch_reduce_top(hipStream_t s, unsigned W, const uint32_t *l1, const uint8_t *l1_inf, int G, int gshift, uint32_t *win_abi, uint8_t *win_inf);
+template <class C> void launch_reduce_top(hipStream_t s, unsigned W, const uint32_t *l1, const uint8_t *l1_inf, int G, int gshift, uint32_t *win_abi, uint8_t *win_inf, int lanes);
 
 // precomputed-multiples tables (pre_kernels.hip.h; k_g1_pre.hip / k_g2_pre.hip)
 template <class C> void launch_pre_step(hipStream_t s, const uint32_t *prev, size_t n, int c, uint32_t *tmp, uint32_t *out);
 // reduce_top that also hands back the plain sum S of every pseudo-window (win_s_abi / win_s_inf), for the shared-bucket-set fold
-template <class C> void launch_reduce_top_s(hipStream_t s, unsigned W, const uint32_t *l1, const uint8_t *l1_inf, int G, int gshift, uint32_t *win_abi, uint8_t *win_inf, uint32_t *win_s_abi, uint8_t *win_s_inf);
+template <class C> void launch_reduce_top_s(hipStream_t s, unsigned W, const uint32_t *l1, const uint8_t *l1_inf, int G, int gshift, uint32_t *win_abi, uint8_t *win_inf, uint32_t *win_s_abi, uint8_t *win_s_inf, int lanes);
 
 }  // namespace msm

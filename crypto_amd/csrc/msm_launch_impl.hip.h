@@ -46,11 +46,21 @@ template <class C> void launch_reduce_l0(hipStream_t s, unsigned NG, const uint3
     if constexpr (C::NFP == 2) hipLaunchKernelGGL((k_reduce_l0_pair<G2P>), dim3(NG), dim3(64), 0, s, bucket, bucket_inf, NB, mshift, l1, l1_inf);     // G2: lane pairs
     else hipLaunchKernelGGL((k_reduce_l0<typename C::MSM>), dim3(NG), dim3(64), 0, s, bucket, bucket_inf, NB, mshift, l1, l1_inf);
 }
-template <class C> void launch_reduce_top(hipStream_t s, unsigned W, const uint32_t *l1, const uint8_t *l1_inf, int G, int gshift, uint32_t *win_abi, uint8_t *win_inf) {
+template <class C> void launch_reduce_top(hipStream_t s, unsigned W, const uint32_t *l1, const uint8_t *l1_inf, int G, int gshift, uint32_t *win_abi, uint8_t *win_inf, int lanes) {
+    if (lanes == 4) {          // four members per point: the chain of general additions is 4 products deep instead of 14
+        typedef typename C::ACC A;
+        hipLaunchKernelGGL((k_reduce_top_quad<A>), dim3(W), dim3(256 * A::LPP), 0, s, l1, l1_inf, G, gshift, win_abi, win_inf, (uint32_t *)nullptr, (uint8_t *)nullptr);
+        return;
+    }
     if constexpr (C::NFP == 2) hipLaunchKernelGGL((k_reduce_top_pair<G2P>), dim3(W), dim3(64), 0, s, l1, l1_inf, G, gshift, win_abi, win_inf, (uint32_t *)nullptr, (uint8_t *)nullptr);
     else hipLaunchKernelGGL((k_reduce_top<typename C::MSM>), dim3(W), dim3(64), 0, s, l1, l1_inf, G, gshift, win_abi, win_inf, (uint32_t *)nullptr, (uint8_t *)nullptr);
 }
-template <class C> void launch_reduce_top_s(hipStream_t s, unsigned W, const uint32_t *l1, const uint8_t *l1_inf, int G, int gshift, uint32_t *win_abi, uint8_t *win_inf, uint32_t *win_s_abi, uint8_t *win_s_inf) {
+template <class C> void launch_reduce_top_s(hipStream_t s, unsigned W, const uint32_t *l1, const uint8_t *l1_inf, int G, int gshift, uint32_t *win_abi, uint8_t *win_inf, uint32_t *win_s_abi, uint8_t *win_s_inf, int lanes) {
+    if (lanes == 4) {
+        typedef typename C::ACC A;
+        hipLaunchKernelGGL((k_reduce_top_quad<A>), dim3(W), dim3(256 * A::LPP), 0, s, l1, l1_inf, G, gshift, win_abi, win_inf, win_s_abi, win_s_inf);
+        return;
+    }
     if constexpr (C::NFP == 2) hipLaunchKernelGGL((k_reduce_top_pair<G2P>), dim3(W), dim3(64), 0, s, l1, l1_inf, G, gshift, win_abi, win_inf, win_s_abi, win_s_inf);
     else hipLaunchKernelGGL((k_reduce_top<typename C::MSM>), dim3(W), dim3(64), 0, s, l1, l1_inf, G, gshift, win_abi, win_inf, win_s_abi, win_s_inf);
 }

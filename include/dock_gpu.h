@@ -64,6 +64,8 @@ int32_t dgpu_set_window_bits(int32_t c);
 int32_t dgpu_set_chunk(int32_t terms);
 /* log2 of the buckets one lane of the bucket reduction sums serially on the table pipeline (0..6; -1 = automatic).  Any value gives the same point. */
 int32_t dgpu_set_reduce_shift(int32_t log2_buckets_per_lane);
+/* lanes (G2: lane pairs) per point in the last kernel of the bucket reduction: 4 (default; a general addition four products deep) or 1. */
+int32_t dgpu_set_reduce_lanes(int32_t lanes);
 /* Forms of the Miller-loop kernels, a bit mask (default 3).  Bit 0: dgpu_multi_miller_loop of up to 8192 pairs runs its line kernel in two
  * launches and overlaps the products / host share of the first with the second.  Bit 1: the product tree gives every node 18 lane pairs
  * (one Fp2 product deep per level) instead of three.  Every combination gives the same Fp12 value limb for limb (tests compare them). */

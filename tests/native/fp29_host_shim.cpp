@@ -88,6 +88,22 @@ void shim_g1s_add_tree(const uint32_t *pts, int n, uint32_t *out) {
     if (n == 0) { memset(out, 0, 4 * 48); } else store_xyzz_s(out, v[0], f[0]);
     delete[] v; delete[] f;
 }
+// the same tree with the round-by-round form of the addition (ec29.hip.h xyzz_add_rounds: what k_reduce_top's four lanes per point run),
+// alternating with xyzz_add level by level so that each form must accept the other's outputs
+void shim_g1s_add_tree_rounds(const uint32_t *pts, int n, uint32_t *out) {
+    Xyzz<Fs> *v = new Xyzz<Fs>[n > 0 ? n : 1]; bool *f = new bool[n > 0 ? n : 1];
+    for (int i = 0; i < n; i++) { Aff<Fs> p; load_aff_s(p, pts + 24 * i); f[i] = true; fzero(v[i].x); fzero(v[i].y); fzero(v[i].zz); fzero(v[i].zzz); xyzz_madd(v[i], f[i], p, false); }
+    int m = n, lvl = 0; QuadSerial q4;
+    while (m > 1) { int h = (m + 1) / 2; for (int i = 0; i + h < m; i++) { if (lvl & 1) xyzz_add(v[i], f[i], v[i + h], f[i + h]); else xyzz_add_rounds(v[i], f[i], v[i + h], f[i + h], q4); } m = h; lvl++; }
+    if (n == 0) { memset(out, 0, 4 * 48); } else store_xyzz_s(out, v[0], f[0]);
+    delete[] v; delete[] f;
+}
+void shim_g1s_dbl_chain_rounds(const uint32_t *pt, int k, uint32_t *out) {
+    Aff<Fs> p; load_aff_s(p, pt);
+    Xyzz<Fs> acc; xyzz_dbl_affine(acc, p); QuadSerial q4;
+    for (int i = 1; i < k; i++) { Xyzz<Fs> d; if (i & 1) xyzz_dbl_rounds(d, acc, q4); else xyzz_dbl(d, acc); acc = d; }
+    store_xyzz_s(out, acc, false);
+}
 // doubling chain 2^k P through xyzz_dbl_affine / xyzz_dbl (the table construction's step)
 void shim_g1s_dbl_chain(const uint32_t *pt, int k, uint32_t *out) {
     Aff<Fs> p; load_aff_s(p, pt);
@@ -125,6 +141,20 @@ void shim_g2s_add_tree(const uint32_t *pts, int n, uint32_t *out) {
     while (m > 1) { int h = (m + 1) / 2; for (int i = 0; i + h < m; i++) xyzz_add(v[i], f[i], v[i + h], f[i + h]); m = h; }
     if (n == 0) { memset(out, 0, 4 * 96); } else store_xyzz2s(out, v[0], f[0]);
     delete[] v; delete[] f;
+}
+void shim_g2s_add_tree_rounds(const uint32_t *pts, int n, uint32_t *out) {
+    Xyzz<Fs2> *v = new Xyzz<Fs2>[n > 0 ? n : 1]; bool *f = new bool[n > 0 ? n : 1];
+    for (int i = 0; i < n; i++) { Aff<Fs2> p; load_aff2s(p, pts + 48 * i); f[i] = true; fzero(v[i].x); fzero(v[i].y); fzero(v[i].zz); fzero(v[i].zzz); xyzz_madd_early(v[i], f[i], p, false); }
+    int m = n, lvl = 0; QuadSerial q4;
+    while (m > 1) { int h = (m + 1) / 2; for (int i = 0; i + h < m; i++) { if (lvl & 1) xyzz_add(v[i], f[i], v[i + h], f[i + h]); else xyzz_add_rounds(v[i], f[i], v[i + h], f[i + h], q4); } m = h; lvl++; }
+    if (n == 0) { memset(out, 0, 4 * 96); } else store_xyzz2s(out, v[0], f[0]);
+    delete[] v; delete[] f;
+}
+void shim_g2s_dbl_chain_rounds(const uint32_t *pt, int k, uint32_t *out) {
+    Aff<Fs2> p; load_aff2s(p, pt);
+    Xyzz<Fs2> acc; xyzz_dbl_affine(acc, p); QuadSerial q4;
+    for (int i = 1; i < k; i++) { Xyzz<Fs2> d; if (i & 1) xyzz_dbl_rounds(d, acc, q4); else xyzz_dbl(d, acc); acc = d; }
+    store_xyzz2s(out, acc, false);
 }
 void shim_g2s_dbl_chain(const uint32_t *pt, int k, uint32_t *out) {
     Aff<Fs2> p; load_aff2s(p, pt);

@@ -113,27 +113,28 @@ CHAINS = [([], []), ([0], [0]), ([0], [1]), ([0, 1], [0, 0]), ([0, 0], [0, 0]), 
 TREES = [[0], [0, 1], [0, 0], [0, 1, 2, 3, 4], list(range(12)) * 2, [0, 1, 0, 1], [5] * 8]
 
 
-@pytest.mark.parametrize("group", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("group", [1, 2, 3, 4, 5, 6])
 def test_group_law_complete(shim, group):
-    """groups 3 / 4 / 5 = G1 / G2 / G2 with the early-return mixed addition over the signed 30-bit field (what the MSM kernels instantiate)"""
+    """groups 3 / 4 / 5 = G1 / G2 / G2 with the early-return mixed addition over the signed 30-bit field (what the MSM kernels instantiate);
+    groups 5 and 6 also run the general addition / doubling in their round-by-round form (xyzz_add_rounds / xyzz_dbl_rounds)"""
     random.seed(3)
     ks = [random.randrange(1, M.R) for _ in range(12)]
     if group in (4, 5):
         pts = [M.g2_mul(M.G2_GEN, k) for k in ks]
         add, neg, enc, dec, W = M.g2_add, M.g2_neg, lambda p: U.g2_abi(p)[0], _xyzz_g2, 48
         chain_fn = lambda a, b, c, d: shim.shim_g2s_madd_chain(a, b, c, group - 4, d)
-        tree_fn = shim.shim_g2s_add_tree
+        tree_fn = shim.shim_g2s_add_tree if group == 4 else shim.shim_g2s_add_tree_rounds      # (5: the round-by-round addition of k_reduce_top's lanes-per-point form)
         o = np.zeros(48, np.uint64)
         for k in (1, 2, 16, 20):
-            shim.shim_g2s_dbl_chain(p_(enc(pts[2])), k, p_(o))
+            (shim.shim_g2s_dbl_chain if group == 4 else shim.shim_g2s_dbl_chain_rounds)(p_(enc(pts[2])), k, p_(o))
             assert dec(o) == M.g2_mul(pts[2], 1 << k)
-    elif group == 3:
+    elif group in (3, 6):                  # (6: the round-by-round addition / doubling)
         pts = [M.g1_mul(M.G1_GEN, k) for k in ks]
         add, neg, enc, dec, W = M.g1_add, M.g1_neg, lambda p: U.g1_abi(p)[0], _xyzz_g1, 24
-        chain_fn, tree_fn = shim.shim_g1s_madd_chain, shim.shim_g1s_add_tree
+        chain_fn, tree_fn = shim.shim_g1s_madd_chain, (shim.shim_g1s_add_tree if group == 3 else shim.shim_g1s_add_tree_rounds)
         o = np.zeros(24, np.uint64)
         for k in (1, 2, 16, 20):
-            shim.shim_g1s_dbl_chain(p_(enc(pts[2])), k, p_(o))
+            (shim.shim_g1s_dbl_chain if group == 3 else shim.shim_g1s_dbl_chain_rounds)(p_(enc(pts[2])), k, p_(o))
             assert dec(o) == M.g1_mul(pts[2], 1 << k)
     elif group == 1:
         pts = [M.g1_mul(M.G1_GEN, k) for k in ks]

@@ -52,19 +52,29 @@ def test_table_msm_equals_plain_and_oracle(gname, n, c):
 def test_any_reduction_geometry_same_point(gname, n, c):
     """dgpu_set_reduce_shift: the bucket reduction's serial share (2^shift buckets per lane, 64 lanes per group, <= 64 groups per
     pseudo-window, the rest on the host) is a tuning knob — every geometry must return the limbs of the automatic one (measured at
-    2^20 terms: the automatic 8 buckets per lane is the fastest both for one call and for six in flight)"""
+    2^20 terms: the automatic 8 buckets per lane is the fastest both for one call and for six in flight) — and so is the form of the
+    last reduction kernel (one lane per point, or four members per point multiplying one operand pair per round)"""
     curve, G = (ca.G1, O.G1) if gname == "G1" else (ca.G2, O.G2)
     bases, _, _ = U.seq_bases(G, n, 1700 + n, threads=16)
     sc = O.rand_scalars(1800 + n, n)
     tab = ca.DeviceBases(curve, bases).precompute(c)
+    plain = ca.DeviceBases(curve, bases)
     ref = tab.msm_bigint(sc)
+    assert (plain.msm_bigint(sc) == ref).all()
+    sparse = sc.copy(); sparse[5:] = 0; sparse[:5, 1:] = 0          # a handful of filled buckets: neighbouring suffix sums are EQUAL points (the doubling branch of the additions)
+    ref_sparse = plain.msm_bigint(sparse)
     try:
-        for sh in (0, 1, 2, 3, 4, 5, 6):
-            assert lib().dgpu_set_reduce_shift(sh) == 0
-            assert (tab.msm_bigint(sc) == ref).all(), sh
-        assert lib().dgpu_set_reduce_shift(7) != 0
+        for lanes in (1, 4):                                        # dgpu_set_reduce_lanes: k_reduce_top / k_reduce_top_quad (four members per point)
+            assert lib().dgpu_set_reduce_lanes(lanes) == 0
+            for sh in (-1, 0, 1, 2, 3, 4, 5, 6):
+                assert lib().dgpu_set_reduce_shift(sh) == 0
+                assert (tab.msm_bigint(sc) == ref).all(), (lanes, sh)
+            lib().dgpu_set_reduce_shift(-1)
+            assert (plain.msm_bigint(sc) == ref).all(), lanes
+            assert (tab.msm_bigint(sparse) == ref_sparse).all() and (plain.msm_bigint(sparse) == ref_sparse).all(), lanes
+        assert lib().dgpu_set_reduce_shift(7) != 0 and lib().dgpu_set_reduce_lanes(2) != 0
     finally:
-        lib().dgpu_set_reduce_shift(-1)
+        lib().dgpu_set_reduce_shift(-1); lib().dgpu_set_reduce_lanes(4)
 
 
 def test_skewed_and_degenerate_scalars_on_a_table():

@@ -39,13 +39,20 @@ def test_mixed_entry_points_from_eight_threads():
         "fold": lambda: ops.mul_add(ca.G2, b2[:64], 0x123456789ABCDEF, b2[64:128]),
     }
     jobs["qap"] = lambda: qap.witness_map(A, B, Cm, z, cs["n_inst"], cs["n_cons"])[0]
+    # resident handles (plain and precomputed-multiples table) and a Miller loop large enough for the tree's two levels; the two-launch form
+    # of the line kernel is taken only while at most two Miller loops are in flight, so both forms run here
+    plain_h = ca.DeviceBases(ca.G1, b1); table_h = ca.DeviceBases(ca.G1, b1).precompute(0)
+    P2, Q2 = np.concatenate([b1[:600]] * 2)[:1100], np.concatenate([b2[:600]] * 2)[:1100]
+    jobs["msm_plain_handle"] = lambda: plain_h.msm_bigint(sc)
+    jobs["msm_table_handle"] = lambda: table_h.msm_bigint(sc)
+    jobs["miller_1100"] = lambda: ca.multi_miller_loop(P2, Q2)
     ref = {k: np.array(f(), copy=True) for k, f in jobs.items()}
     errors = []
 
     def worker(seed):
         rng = np.random.default_rng(seed)
         names = list(jobs)
-        for _ in range(12):
+        for _ in range(20):
             k = names[int(rng.integers(0, len(names)))]
             got = np.asarray(jobs[k]())
             if got.shape != ref[k].shape or not (got == ref[k]).all():
@@ -53,5 +60,6 @@ def test_mixed_entry_points_from_eight_threads():
     ths = [threading.Thread(target=worker, args=(s,)) for s in range(8)]
     for t in ths: t.start()
     for t in ths: t.join()
-    tab.free()
+    tab.free(); plain_h.free(); table_h.free()
     assert not errors, errors
+    assert (ref["msm_plain_handle"] == ref["msm_g1"]).all() and (ref["msm_table_handle"] == ref["msm_g1"]).all()

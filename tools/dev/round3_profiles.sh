@@ -5,15 +5,15 @@ TAG=${TAG:-r03}
 O=/root/repo/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 B="python /root/repo/bench.py --steps 20 --no-secondary --no-cpu-baseline"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_prof1 -- $B --inflight 1 > $O/${TAG}_bench_inflight1_under_rocprof.json 2>/dev/null
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_prof6 -- $B > $O/${TAG}_bench_inflight6_under_rocprof.json 2>/dev/null
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_profg2 -- python /root/repo/tools/dev/g2_loop.py > $O/${TAG}_g2_loop.txt 2>/dev/null
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_prof1 -- $B --inflight 1 > $O/${TAG}_bench_inflight1_under_rocprof.json 2>/dev/null
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_prof6 -- $B > $O/${TAG}_bench_inflight6_under_rocprof.json 2>/dev/null
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_profg2 -- python /root/repo/tools/dev/g2_loop.py > $O/${TAG}_g2_loop.txt 2>/dev/null
 cp $O/${TAG}_prof1/*/*kernel_stats.csv $O/${TAG}_kernel_stats_inflight1.csv
 cp $O/${TAG}_prof6/*/*kernel_stats.csv $O/${TAG}_kernel_stats_default_inflight6.csv
 cp $O/${TAG}_profg2/*/*kernel_stats.csv $O/${TAG}_kernel_stats_g2.csv
 for C in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU GRBM_GUI_ACTIVE SQ_WAVES; do
-  rocprofv3 --pmc $C --output-format csv -d $O/${TAG}_pmc_g1_$C -- python /root/repo/bench.py --inflight 1 --steps 8 --warmup 1 --no-secondary --no-cpu-baseline > /dev/null 2>&1
-  K=6 rocprofv3 --pmc $C --output-format csv -d $O/${TAG}_pmc_g2_$C -- python /root/repo/tools/dev/g2_loop.py > /dev/null 2>&1
+  timeout 300 rocprofv3 --pmc $C --output-format csv -d $O/${TAG}_pmc_g1_$C -- python /root/repo/bench.py --inflight 1 --steps 8 --warmup 1 --no-secondary --no-cpu-baseline > /dev/null 2>&1
+  K=6 timeout 300 rocprofv3 --pmc $C --output-format csv -d $O/${TAG}_pmc_g2_$C -- python /root/repo/tools/dev/g2_loop.py > /dev/null 2>&1
 done
 python /root/repo/tools/pmc_summary.py $O/${TAG}_pmc_g1_* > $O/${TAG}_pmc_summary_g1.txt
 python /root/repo/tools/pmc_summary.py $O/${TAG}_pmc_g2_* > $O/${TAG}_pmc_summary_g2.txt

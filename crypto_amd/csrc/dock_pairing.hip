@@ -17,6 +17,7 @@
 #include "fp2_pair.hip.h"
 #include "sort_launch.hip.h"
 #include <thread>
+#include <functional>
 #include <atomic>
 
 namespace bls29 {
@@ -158,7 +159,7 @@ __device__ __forceinline__ void line_dbl_step_quad(G2ProjT<Fp2H> &R, LineT<Fp2H>
 // (state[k * 4 n + lane]: 3 x NL words per lane, both lane pairs of a quad hold the whole R).
 __device__ __host__ inline int ml_steps(int b_hi, int b_lo) { int c = 0; for (int b = b_hi; b >= b_lo; b--) c += 1 + (int)((BLS_X_ABS >> b) & 1); return c; }
 // EVAL = false: the lines leave unevaluated (c1, c2 not yet multiplied by px, py) and the launch that starts the chain writes px, py in
-// the internal form to pxy[(c * NL + k) * n + i] (zeros for a skipped pair) for k_line_products.
+// the internal form to pxy[(c * NL + k) * stride + i] (zeros for a skipped pair) for k_line_products.
 template <bool EVAL = true>
 __global__ void __launch_bounds__(64) k_miller_lines_quad(const uint32_t *__restrict__ p_abi, const uint32_t *__restrict__ q_abi, const uint8_t *__restrict__ skip, size_t n, uint32_t *__restrict__ lines, size_t stride,
                                                           int b_hi = 62, int b_lo = 0, int s_first = 0, uint32_t *__restrict__ state = nullptr, uint32_t *__restrict__ pxy = nullptr) {
@@ -183,11 +184,11 @@ __global__ void __launch_bounds__(64) k_miller_lines_quad(const uint32_t *__rest
         LineT<Fp2H> one; fset_one(one.c0); fzero(one.c1); fzero(one.c2);
         const int s_end = s_first + ml_steps(b_hi, b_lo);
         for (int s = s_first; s < s_end; s++) put(s, one);
-        if constexpr (!EVAL) { if (b_hi == 62 && (gid & 3) < 2) for (int k = 0; k < NL; k++) pxy[((gid & 3) * NL + k) * n + i] = 0; }
+        if constexpr (!EVAL) { if (b_hi == 62 && (gid & 3) < 2) for (int k = 0; k < NL; k++) pxy[((gid & 3) * NL + k) * stride + i] = 0; }
         return;
     }
     Fp px, py; fp_from_abi(px, pw); fp_from_abi(py, pw + 12);
-    if constexpr (!EVAL) { if (b_hi == 62 && (gid & 3) < 2) { const Fp &c = (gid & 3) ? py : px; for (int k = 0; k < NL; k++) pxy[((gid & 3) * NL + k) * n + i] = c.l[k]; } }
+    if constexpr (!EVAL) { if (b_hi == 62 && (gid & 3) < 2) { const Fp &c = (gid & 3) ? py : px; for (int k = 0; k < NL; k++) pxy[((gid & 3) * NL + k) * stride + i] = c.l[k]; } }
     Aff<Fp2H> Q; fp_from_abi(Q.x.v, qx); fp_from_abi(Q.y.v, qy);
     G2ProjT<Fp2H> R;
     const size_t lanes = 4 * n;
@@ -238,10 +239,14 @@ __global__ void __launch_bounds__(64) k_g2_prepare(const uint32_t *__restrict__ 
     }
 }
 // thread (s, i), i fastest: ark-ec `ell` (c1 *= px, c2 *= py) on coefficient triple s of pair i, written in K10's layout
-__global__ void __launch_bounds__(256) k_lines_from_prepared(const uint32_t *__restrict__ p_abi, const uint32_t *__restrict__ coeffs, const uint8_t *__restrict__ skip, size_t n, uint32_t *__restrict__ lines, size_t stride) {
+// pxy_one != nullptr (a mixed call whose product kernel evaluates the affine pairs' lines): these pairs' lines are evaluated HERE, so their
+// (px, py) for the product kernel is (1, 1) — pxy_one points at this kernel's first pair
+__global__ void __launch_bounds__(256) k_lines_from_prepared(const uint32_t *__restrict__ p_abi, const uint32_t *__restrict__ coeffs, const uint8_t *__restrict__ skip, size_t n, uint32_t *__restrict__ lines, size_t stride,
+                                                              uint32_t *__restrict__ pxy_one = nullptr) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n * N_LINES) return;
     const size_t s = t / n, i = t % n;
+    if (pxy_one && s == 0) { Fp one; fp_set_one(one); for (int k = 0; k < NL; k++) { pxy_one[(size_t)k * stride + i] = one.l[k]; pxy_one[(size_t)(NL + k) * stride + i] = one.l[k]; } }
     uint32_t pw[24], anyp = 0;
     for (int k = 0; k < 24; k += 4) { uint4 v = *reinterpret_cast<const uint4 *>(p_abi + i * 24 + k); pw[k] = v.x; pw[k + 1] = v.y; pw[k + 2] = v.z; pw[k + 3] = v.w; anyp |= v.x | v.y | v.z | v.w; }
     const uint32_t *src = coeffs + (i * N_LINES + s) * (size_t)CW;
@@ -540,20 +545,23 @@ static int32_t ml_finish(Slot &sl, size_t n, uint64_t *out, const uint32_t *pxy 
 // (1.45 -> 1.2 ms at 1024 pairs).  Same values in the same order: bit-identical to the one-launch form, which stays for larger batches
 // (throughput-bound) and while stage timers are on.
 constexpr int ML_CUT = 17;
-static int32_t ml_pipelined(Slot &sl, size_t n, const uint8_t *dskip, uint64_t *out) {
+// n pairs in the line buffer, the first n_aff of them affine (their chain is what gets cut); prepared(pxy) queues the line kernel of the
+// prepared pairs n_aff .. n - 1, if any, on the slot's stream (it writes their neutral px, py)
+static int32_t ml_pipelined(Slot &sl, size_t n, size_t n_aff, const uint8_t *dskip, uint64_t *out, const std::function<void(uint32_t *)> &prepared) {
     int32_t rc; MlGeom g;
     if ((rc = ml_geometry(sl, n, g))) return rc;
-    if ((rc = sl.ml_state.ensure(((size_t)3 * NL * 4 * n + (size_t)2 * NL * n) * 4))) return rc;      // R of every lane, then px, py of every pair
+    if ((rc = sl.ml_state.ensure(((size_t)3 * NL * 4 * n_aff + (size_t)2 * NL * n) * 4))) return rc;      // R of every lane, then px, py of every pair
     hipStream_t sa = sl.stream, sb = sl.cstream;
     const int ns1 = ml_steps(62, ML_CUT), ns2 = N_LINES - ns1;
-    const unsigned blocks = (unsigned)((4 * n + 63) / 64);
+    const unsigned blocks = (unsigned)((4 * n_aff + 63) / 64);
     hipEvent_t e1 = sl.copy_ev[sl.ev_next++ % (Slot::N_COPY_EV + 1)], e2 = sl.copy_ev[sl.ev_next++ % (Slot::N_COPY_EV + 1)];
     static_assert((size_t)N_LINES * 576 <= Slot::HPIN_BYTES, "pinned scratch");
     hostf::Fq12 *L = (hostf::Fq12 *)sl.hpin;                          // pinned: the copies below are asynchronous for the host
-    uint32_t *state = sl.ml_state.as<uint32_t>(), *pxy = state + (size_t)3 * NL * 4 * n;
-    hipLaunchKernelGGL(k_miller_lines_quad<false>, dim3(blocks), dim3(64), 0, sa, sl.in_bases.as<uint32_t>(), sl.in_scalars.as<uint32_t>(), dskip, n, sl.ml_lines.as<uint32_t>(), n, 62, ML_CUT, 0, state, pxy);
+    uint32_t *state = sl.ml_state.as<uint32_t>(), *pxy = state + (size_t)3 * NL * 4 * n_aff;
+    prepared(pxy);
+    hipLaunchKernelGGL(k_miller_lines_quad<false>, dim3(blocks), dim3(64), 0, sa, sl.in_bases.as<uint32_t>(), sl.in_scalars.as<uint32_t>(), dskip, n_aff, sl.ml_lines.as<uint32_t>(), n, 62, ML_CUT, 0, state, pxy);
     HIPCHK(hipEventRecord(e1, sa));
-    hipLaunchKernelGGL(k_miller_lines_quad<false>, dim3(blocks), dim3(64), 0, sa, sl.in_bases.as<uint32_t>(), sl.in_scalars.as<uint32_t>(), dskip, n, sl.ml_lines.as<uint32_t>(), n, ML_CUT - 1, 0, ns1, state, pxy);
+    hipLaunchKernelGGL(k_miller_lines_quad<false>, dim3(blocks), dim3(64), 0, sa, sl.in_bases.as<uint32_t>(), sl.in_scalars.as<uint32_t>(), dskip, n_aff, sl.ml_lines.as<uint32_t>(), n, ML_CUT - 1, 0, ns1, state, pxy);
     HIPCHK(hipStreamWaitEvent(sb, e1, 0));
     ml_products(sl, sb, n, g, 0, ns1, false, pxy);
     HIPCHK(hipMemcpyAsync(L, sl.ml_out.p, (size_t)ns1 * 576, hipMemcpyDeviceToHost, sb));
@@ -571,6 +579,10 @@ static int32_t ml_pipelined(Slot &sl, size_t n, const uint8_t *dskip, uint64_t *
     memcpy(out, &f, sizeof f);
     return DGPU_OK;
 }
+// how many Miller loops are in flight on the context (the two-launch form needs the slot's second stream and an event wait between the
+// two; with more streams than hardware queues a waiting stream holds up whatever shares its queue — measured, 1024 pairs: 0.62 vs 0.70 ms
+// per call with two calls in flight, but 0.49 vs 0.36 with six — so it is taken while at most two are in flight)
+struct MlActive { std::atomic<int> &c; int v; explicit MlActive(std::atomic<int> &c_) : c(c_), v(++c_) {} ~MlActive() { --c; } MlActive(const MlActive &) = delete; };
 
 int32_t dgpu_multi_miller_loop(const uint64_t *p, const uint64_t *q, const uint8_t *skip, size_t n, uint64_t *out) {
     if (!out || (n && (!p || !q))) return DGPU_E_BADARG;
@@ -597,12 +609,9 @@ int32_t dgpu_multi_miller_loop(const uint64_t *p, const uint64_t *q, const uint8
       constexpr bool one_lane = false, two_lanes = false;
 #endif
       if (!one_lane && !two_lanes && n <= 8192 && !gs.prof && (gs.ml_mode.load() & 1)) {
-          // The two-launch form needs the slot's second stream and an event wait between the two; with more streams than hardware queues a
-          // waiting stream holds up whatever shares its queue (measured, 1024 pairs: 0.62 vs 0.70 ms per call with two calls in flight, but
-          // 0.49 vs 0.36 with six), so it is taken while at most two Miller loops are in flight on this context.  Either way the evaluation
-          // at P is left to the product kernel.
-          struct Active { std::atomic<int> &c; int v; Active(std::atomic<int> &c_) : c(c_), v(++c_) {} ~Active() { --c; } } act(cur().ml_active);
-          if (act.v <= 2) return ml_pipelined(sl, n, dskip, out);
+          // Either way the evaluation at P is left to the product kernel.
+          MlActive act(cur().ml_active);
+          if (act.v <= 2) return ml_pipelined(sl, n, n, dskip, out, [](uint32_t *) {});
           if ((rc = sl.ml_state.ensure((size_t)2 * NL * n * 4))) return rc;
           uint32_t *pxy = sl.ml_state.as<uint32_t>();
           hipLaunchKernelGGL(k_miller_lines_quad<false>, dim3((unsigned)((4 * n + 63) / 64)), dim3(64), 0, s, sl.in_bases.as<uint32_t>(), sl.in_scalars.as<uint32_t>(), dskip, n, sl.ml_lines.as<uint32_t>(), n,
@@ -812,6 +821,19 @@ int32_t dgpu_multi_miller_loop_mixed(const uint64_t *p_aff, const uint64_t *q_af
         HIPCHK(hipMemcpyAsync(dp + n_aff * 24, p_prep, n_prep * 96, hipMemcpyHostToDevice, s));
         HIPCHK(hipMemcpyAsync(sl.ml_coeffs.p, coeffs, cbytes, hipMemcpyHostToDevice, s));
         if (skip_prep) HIPCHK(hipMemcpyAsync(dsk + n_aff, skip_prep, n_prep, hipMemcpyHostToDevice, s));
+    }
+    if (n_aff && n_aff <= 8192 && !gs.prof && (gs.ml_mode.load() & 1)) {
+        // what a verifier calls (proof.b affine, the key's -delta and -gamma prepared): the affine pairs' chain is cut like
+        // dgpu_multi_miller_loop's; the prepared pairs' lines are ready long before the first launch of the line kernel ends
+        MlActive act(cur().ml_active);
+        if (act.v <= 2) {
+            uint32_t *lines = sl.ml_lines.as<uint32_t>();
+            return ml_pipelined(sl, n, n_aff, skip_aff ? dsk : nullptr, out, [&](uint32_t *pxy) {
+                if (n_prep)
+                    hipLaunchKernelGGL(k_lines_from_prepared, dim3((unsigned)((n_prep * N_LINES + 255) / 256)), dim3(256), 0, s, dp + n_aff * 24, sl.ml_coeffs.as<uint32_t>(),
+                                       skip_prep ? dsk + n_aff : (const uint8_t *)nullptr, n_prep, lines + n_aff, n, pxy + n_aff);
+            });
+        }
     }
     { StageTimer st(sl, "ml.lines");
       uint32_t *lines = sl.ml_lines.as<uint32_t>();

@@ -85,6 +85,17 @@ def test_every_form_of_the_miller_kernels_gives_the_same_value(n):
         assert (got[mode] == got[0]).all(), mode
     if n <= 1100:
         assert (got[3] == O.multi_miller_loop(ps, qs, skip, threads=32)).all()
+    # the verifier's call (dgpu_multi_miller_loop_mixed: some pairs affine, the others prepared) cuts the affine pairs' chain the same way
+    if 3 <= n <= 1100:
+        from crypto_amd import pairing
+        pc = pairing.G2Prepared.from_affine(qs)
+        cut = max(1, n // 3)
+        try:
+            for mode in (0, 1, 2, 3):
+                assert lib().dgpu_set_miller_pipeline(mode) == 0
+                assert (pairing.multi_miller_loop(ps, [qs[:cut], pc[cut:]], skip) == got[0]).all(), mode
+        finally:
+            lib().dgpu_set_miller_pipeline(3)
 
 
 def test_identity_members_are_skipped_and_lengths_checked():

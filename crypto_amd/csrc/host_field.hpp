@@ -45,20 +45,25 @@ struct Fq {
         return r;
     }
     Fq neg() const { return is_zero() ? *this : zero() - *this; }
-    // Montgomery product (coarsely integrated operand scanning)
+    // Montgomery product, finely integrated operand scanning: the partial product row a * b_i and the reduction row m * p advance
+    // together as two carry chains.  p < 2^381 leaves the top word three spare bits, so the running value never needs a seventh word
+    // (t < 2p throughout) and one conditional subtraction finishes.
     Fq operator*(const Fq &b) const {
-        uint64_t t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        uint64_t t[6] = {0, 0, 0, 0, 0, 0};
         for (int i = 0; i < 6; i++) {
-            uint64_t c = 0; u128 s;
-            for (int j = 0; j < 6; j++) { s = (u128)l[j] * b.l[i] + t[j] + c; t[j] = (uint64_t)s; c = (uint64_t)(s >> 64); }
-            s = (u128)t[6] + c; t[6] = (uint64_t)s; t[7] = (uint64_t)(s >> 64);
-            uint64_t m = t[0] * INV;
-            s = (u128)m * P[0] + t[0]; c = (uint64_t)(s >> 64);
-            for (int j = 1; j < 6; j++) { s = (u128)m * P[j] + t[j] + c; t[j - 1] = (uint64_t)s; c = (uint64_t)(s >> 64); }
-            s = (u128)t[6] + c; t[5] = (uint64_t)s; t[6] = t[7] + (uint64_t)(s >> 64);
+            const uint64_t bi = b.l[i];
+            u128 A = (u128)l[0] * bi + t[0];
+            const uint64_t m = (uint64_t)A * INV;
+            u128 C = (u128)m * P[0] + (uint64_t)A;
+            for (int j = 1; j < 6; j++) {
+                A = (u128)l[j] * bi + t[j] + (uint64_t)(A >> 64);
+                C = (u128)m * P[j] + (uint64_t)A + (uint64_t)(C >> 64);
+                t[j - 1] = (uint64_t)C;
+            }
+            t[5] = (uint64_t)(C >> 64) + (uint64_t)(A >> 64);
         }
         Fq r; for (int i = 0; i < 6; i++) r.l[i] = t[i];
-        if (t[6] || geq_p(r.l)) sub_p(r.l);
+        if (geq_p(r.l)) sub_p(r.l);
         return r;
     }
     Fq sqr() const { return (*this) * (*this); }

@@ -58,6 +58,8 @@ int32_t dgpu_last_hip_error(void);
 #define DGPU_DEFAULT_MIN_GPU_N 512
 int32_t dgpu_set_min_gpu_n(size_t n);
 size_t dgpu_get_min_gpu_n(void);
+/* ---- tuning knobs.  Process-wide, not needed by a caller: every setting returns the SAME result limb for limb (the tests sweep each of
+ * them against the automatic choice); the defaults are the measured optima on MI355X. ---- */
 /* window width c (bits) used by the bucket method; 0 = automatic from n.  Any value gives the same point. */
 int32_t dgpu_set_window_bits(int32_t c);
 /* terms per lane of the bucket accumulation (16..4096; 0 = automatic).  Any value gives the same point (tests sweep it). */

@@ -497,13 +497,18 @@ struct MlTail {
 };
 static hostf::Fq12 ml_host_tail(const hostf::Fq12 *L) { MlTail t; t.run(L, 0); return t.result(); }
 
-struct MlGeom { int slice_len, nsl, ngroups; };
+struct MlGeom { int slice_len, nsl, ngroups; size_t base; };         // base: first word of this geometry's partials in sl.ml_partial
+static size_t ml_geom_words(const MlGeom &g) { return (size_t)N_LINES * (g.nsl + g.ngroups) * F12W; }
+static void ml_geom_set(MlGeom &g, size_t n, int slice_len, size_t base) {
+    g.slice_len = slice_len;
+    g.nsl = (int)((n + slice_len - 1) / slice_len);                  // <= 2048
+    g.ngroups = (g.nsl + MAX_SLICES - 1) / MAX_SLICES;               // <= 32: the second tree level is one group
+    g.base = base;
+}
 static int32_t ml_geometry(Slot &sl, size_t n, MlGeom &g) {
     int32_t rc;
-    g.slice_len = choose_slice_len(n);
-    g.nsl = (int)((n + g.slice_len - 1) / g.slice_len);              // <= 2048
-    g.ngroups = (g.nsl + MAX_SLICES - 1) / MAX_SLICES;               // <= 32: the second tree level is one group
-    if ((rc = sl.ml_partial.ensure((size_t)N_LINES * (g.nsl + g.ngroups) * F12W * 4))) return rc;
+    ml_geom_set(g, n, choose_slice_len(n), 0);
+    if ((rc = sl.ml_partial.ensure(ml_geom_words(g) * 4))) return rc;
     if ((rc = sl.ml_out.ensure((size_t)N_LINES * 144 * 4))) return rc;
     return DGPU_OK;
 }
@@ -511,9 +516,9 @@ static int32_t ml_geometry(Slot &sl, size_t n, MlGeom &g) {
 static void ml_products(Slot &sl, hipStream_t s, size_t n, const MlGeom &g, int s0, int ns, bool timed, const uint32_t *pxy = nullptr) {
     const int nsl = g.nsl, ngroups = g.ngroups;
     auto products = [&] {
-      hipLaunchKernelGGL(k_line_products, dim3((unsigned)((2 * ns * nsl + 63) / 64)), dim3(64), 0, s, sl.ml_lines.as<uint32_t>(), n, g.slice_len, nsl, sl.ml_partial.as<uint32_t>(), (const uint32_t *)nullptr, 1, s0, ns, pxy); };
+      hipLaunchKernelGGL(k_line_products, dim3((unsigned)((2 * ns * nsl + 63) / 64)), dim3(64), 0, s, sl.ml_lines.as<uint32_t>(), n, g.slice_len, nsl, sl.ml_partial.as<uint32_t>() + g.base, (const uint32_t *)nullptr, 1, s0, ns, pxy); };
     auto tree = [&] {
-      uint32_t *lvl0 = sl.ml_partial.as<uint32_t>(), *lvl1 = lvl0 + (size_t)N_LINES * nsl * F12W;
+      uint32_t *lvl0 = sl.ml_partial.as<uint32_t>() + g.base, *lvl1 = lvl0 + (size_t)N_LINES * nsl * F12W;
       if (ngroups == 1) launch_product_tree(s, (unsigned)ns, lvl0, nsl, 1, (uint32_t *)nullptr, sl.ml_out.as<uint32_t>(), (const uint32_t *)nullptr, 0, s0);
       else {
           launch_product_tree(s, (unsigned)(ns * ngroups), lvl0, nsl, ngroups, lvl1, (uint32_t *)nullptr, (const uint32_t *)nullptr, 0, s0);
@@ -548,8 +553,13 @@ constexpr int ML_CUT = 17;
 // n pairs in the line buffer, the first n_aff of them affine (their chain is what gets cut); prepared(pxy) queues the line kernel of the
 // prepared pairs n_aff .. n - 1, if any, on the slot's stream (it writes their neutral px, py)
 static int32_t ml_pipelined(Slot &sl, size_t n, size_t n_aff, const uint8_t *dskip, uint64_t *out, const std::function<void(uint32_t *)> &prepared) {
-    int32_t rc; MlGeom g;
+    int32_t rc; MlGeom g, g2;
     if ((rc = ml_geometry(sl, n, g))) return rc;
+    // the last steps' products are all that is left when the chain ends: from 8-pair slices on they take half the slice length (fewer
+    // sparse products in front of the tree, more tree for a quarter of the steps: 1.46 -> 1.39 ms at 4096 pairs; measured the other way
+    // round at 1024 pairs, 4 -> 2: 1.06 -> 1.14)
+    ml_geom_set(g2, n, g.slice_len >= 8 && (n + g.slice_len / 2 - 1) / (g.slice_len / 2) <= 2048 ? g.slice_len / 2 : g.slice_len, ml_geom_words(g));
+    if ((rc = sl.ml_partial.ensure((ml_geom_words(g) + ml_geom_words(g2)) * 4))) return rc;
     if ((rc = sl.ml_state.ensure(((size_t)3 * NL * 4 * n_aff + (size_t)2 * NL * n) * 4))) return rc;      // R of every lane, then px, py of every pair
     hipStream_t sa = sl.stream, sb = sl.cstream;
     const int ns1 = ml_steps(62, ML_CUT), ns2 = N_LINES - ns1;
@@ -566,7 +576,7 @@ static int32_t ml_pipelined(Slot &sl, size_t n, size_t n_aff, const uint8_t *dsk
     ml_products(sl, sb, n, g, 0, ns1, false, pxy);
     HIPCHK(hipMemcpyAsync(L, sl.ml_out.p, (size_t)ns1 * 576, hipMemcpyDeviceToHost, sb));
     HIPCHK(hipEventRecord(e2, sb));
-    ml_products(sl, sa, n, g, ns1, ns2, false, pxy);
+    ml_products(sl, sa, n, g2, ns1, ns2, false, pxy);
     HIPCHK(hipMemcpyAsync(L + ns1, (const char *)sl.ml_out.p + (size_t)ns1 * 576, (size_t)ns2 * 576, hipMemcpyDeviceToHost, sa));
     rc = DGPU_OK;
     if (hipGetLastError() != hipSuccess) rc = DGPU_E_HIP;

@@ -568,21 +568,25 @@ static int32_t ml_pipelined(Slot &sl, size_t n, size_t n_aff, const uint8_t *dsk
     static_assert((size_t)N_LINES * 576 <= Slot::HPIN_BYTES, "pinned scratch");
     hostf::Fq12 *L = (hostf::Fq12 *)sl.hpin;                          // pinned: the copies below are asynchronous for the host
     uint32_t *state = sl.ml_state.as<uint32_t>(), *pxy = state + (size_t)3 * NL * 4 * n_aff;
+    // (a failed enqueue must not leave the slot with work in flight: every step is checked, both streams are drained before any return)
+    rc = DGPU_OK;
+    auto ok = [&](hipError_t e) { if (e != hipSuccess && !rc) rc = DGPU_E_HIP; return rc == DGPU_OK; };
     prepared(pxy);
     hipLaunchKernelGGL(k_miller_lines_quad<false>, dim3(blocks), dim3(64), 0, sa, sl.in_bases.as<uint32_t>(), sl.in_scalars.as<uint32_t>(), dskip, n_aff, sl.ml_lines.as<uint32_t>(), n, 62, ML_CUT, 0, state, pxy);
-    HIPCHK(hipEventRecord(e1, sa));
-    hipLaunchKernelGGL(k_miller_lines_quad<false>, dim3(blocks), dim3(64), 0, sa, sl.in_bases.as<uint32_t>(), sl.in_scalars.as<uint32_t>(), dskip, n_aff, sl.ml_lines.as<uint32_t>(), n, ML_CUT - 1, 0, ns1, state, pxy);
-    HIPCHK(hipStreamWaitEvent(sb, e1, 0));
-    ml_products(sl, sb, n, g, 0, ns1, false, pxy);
-    HIPCHK(hipMemcpyAsync(L, sl.ml_out.p, (size_t)ns1 * 576, hipMemcpyDeviceToHost, sb));
-    HIPCHK(hipEventRecord(e2, sb));
-    ml_products(sl, sa, n, g2, ns1, ns2, false, pxy);
-    HIPCHK(hipMemcpyAsync(L + ns1, (const char *)sl.ml_out.p + (size_t)ns1 * 576, (size_t)ns2 * 576, hipMemcpyDeviceToHost, sa));
-    rc = DGPU_OK;
-    if (hipGetLastError() != hipSuccess) rc = DGPU_E_HIP;
+    if (ok(hipEventRecord(e1, sa))) {
+        hipLaunchKernelGGL(k_miller_lines_quad<false>, dim3(blocks), dim3(64), 0, sa, sl.in_bases.as<uint32_t>(), sl.in_scalars.as<uint32_t>(), dskip, n_aff, sl.ml_lines.as<uint32_t>(), n, ML_CUT - 1, 0, ns1, state, pxy);
+        if (ok(hipStreamWaitEvent(sb, e1, 0))) {
+            ml_products(sl, sb, n, g, 0, ns1, false, pxy);
+            ok(hipMemcpyAsync(L, sl.ml_out.p, (size_t)ns1 * 576, hipMemcpyDeviceToHost, sb));
+            ok(hipEventRecord(e2, sb));
+        }
+        ml_products(sl, sa, n, g2, ns1, ns2, false, pxy);
+        ok(hipMemcpyAsync(L + ns1, (const char *)sl.ml_out.p + (size_t)ns1 * 576, (size_t)ns2 * 576, hipMemcpyDeviceToHost, sa));
+    }
+    ok(hipGetLastError());
     MlTail tail;
-    if (!rc && hipEventSynchronize(e2) == hipSuccess) tail.run(L, ML_CUT); else rc = DGPU_E_HIP;
-    if (hipStreamSynchronize(sa) != hipSuccess || hipStreamSynchronize(sb) != hipSuccess) rc = DGPU_E_HIP;
+    if (!rc && ok(hipEventSynchronize(e2))) tail.run(L, ML_CUT);
+    ok(hipStreamSynchronize(sa)); ok(hipStreamSynchronize(sb));
     if (rc) return rc;
     tail.run(L, 0);
     const hostf::Fq12 f = tail.result();

@@ -170,7 +170,8 @@ __global__ void __launch_bounds__(64) k_miller_lines_quad(const uint32_t *__rest
     if (i >= n) return;
     bool sk = skip && skip[i];
     uint32_t pw[24]; uint32_t anyp = 0, anyq = 0;
-    for (int k = 0; k < 24; k++) { pw[k] = p_abi[i * 24 + k]; anyp |= pw[k]; }
+    if (p_abi) { for (int k = 0; k < 24; k++) { pw[k] = p_abi[i * 24 + k]; anyp |= pw[k]; } }
+    else { for (int k = 0; k < 24; k++) pw[k] = 0; anyp = 1; }          // no P: the coefficients alone (dgpu_g2_prepare; EVAL = false, pxy = nullptr)
     uint32_t qx[12], qy[12];
     for (int k = 0; k < 12; k++) { qx[k] = q_abi[i * 48 + h * 12 + k]; qy[k] = q_abi[i * 48 + 24 + h * 12 + k]; anyq |= qx[k] | qy[k]; }
     anyq |= xchg32(anyq);
@@ -184,11 +185,11 @@ __global__ void __launch_bounds__(64) k_miller_lines_quad(const uint32_t *__rest
         LineT<Fp2H> one; fset_one(one.c0); fzero(one.c1); fzero(one.c2);
         const int s_end = s_first + ml_steps(b_hi, b_lo);
         for (int s = s_first; s < s_end; s++) put(s, one);
-        if constexpr (!EVAL) { if (b_hi == 62 && (gid & 3) < 2) for (int k = 0; k < NL; k++) pxy[((gid & 3) * NL + k) * stride + i] = 0; }
+        if constexpr (!EVAL) { if (pxy && b_hi == 62 && (gid & 3) < 2) for (int k = 0; k < NL; k++) pxy[((gid & 3) * NL + k) * stride + i] = 0; }
         return;
     }
     Fp px, py; fp_from_abi(px, pw); fp_from_abi(py, pw + 12);
-    if constexpr (!EVAL) { if (b_hi == 62 && (gid & 3) < 2) { const Fp &c = (gid & 3) ? py : px; for (int k = 0; k < NL; k++) pxy[((gid & 3) * NL + k) * stride + i] = c.l[k]; } }
+    if constexpr (!EVAL) { if (pxy && b_hi == 62 && (gid & 3) < 2) { const Fp &c = (gid & 3) ? py : px; for (int k = 0; k < NL; k++) pxy[((gid & 3) * NL + k) * stride + i] = c.l[k]; } }
     Aff<Fp2H> Q; fp_from_abi(Q.x.v, qx); fp_from_abi(Q.y.v, qy);
     G2ProjT<Fp2H> R;
     const size_t lanes = 4 * n;
@@ -237,6 +238,26 @@ __global__ void __launch_bounds__(64) k_g2_prepare(const uint32_t *__restrict__ 
         LineT<Fp2H> l; line_dbl_step(R, l); put(s++, l);
         if ((BLS_X_ABS >> b) & 1) { line_add_step(R, Q, l); put(s++, l); }
     }
+}
+// The coefficient triples as k_miller_lines_quad<false> leaves them (K10's layout, internal limbs) -> arkworks' ell_coeffs bytes: one thread
+// per (point, step, coefficient half).  dgpu_g2_prepare = the four-lanes-per-point chain (5 rounds per doubling step, no conversion inside
+// the chain) + this fully parallel pass, instead of the lane-pair chain that converted three coefficients per step on its way (2.2 -> 1.2 ms
+// for 1024 points, 0.4 ms of it the 20 MB going back to the host).
+__global__ void __launch_bounds__(256) k_prepared_from_lines(const uint32_t *__restrict__ lines, const uint32_t *__restrict__ q_abi, const uint8_t *__restrict__ is_inf, size_t n,
+                                                             uint32_t *__restrict__ out, uint8_t *__restrict__ out_inf) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * N_LINES * 6) return;
+    const size_t i = t % n, r = t / n; const int ch = (int)(r % 6), s = (int)(r / 6);          // ch = 2 c + h
+    uint32_t anyq = 0;
+    for (int k = 0; k < 48; k += 4) { const uint4 v = *reinterpret_cast<const uint4 *>(q_abi + i * 48 + k); anyq |= v.x | v.y | v.z | v.w; }
+    const bool inf = (is_inf && is_inf[i]) || !anyq;
+    if (ch == 0 && s == 0) out_inf[i] = inf ? 1 : 0;
+    uint32_t *dst = out + i * (size_t)(N_LINES * CW) + (size_t)s * CW + ch * 12;
+    if (inf) { for (int k = 0; k < 12; k++) dst[k] = 0u; return; }                              // arkworks: ell_coeffs = vec![], infinity = true
+    Fp f;
+    for (int k = 0; k < NL; k++) f.l[k] = lines[((size_t)s * LW + ch * NL + k) * n + i];
+    uint32_t w[12]; fp_to_abi(w, f);
+    for (int k = 0; k < 12; k++) dst[k] = w[k];
 }
 // thread (s, i), i fastest: ark-ec `ell` (c1 *= px, c2 *= py) on coefficient triple s of pair i, written in K10's layout
 // pxy_one != nullptr (a mixed call whose product kernel evaluates the affine pairs' lines): these pairs' lines are evaluated HERE, so their
@@ -770,7 +791,14 @@ int32_t dgpu_g2_prepare(const uint64_t *q, const uint8_t *is_inf, size_t n, uint
     const uint8_t *dinf = nullptr;
     if (is_inf) { HIPCHK(hipMemcpyAsync(sl.in_inf.p, is_inf, n, hipMemcpyHostToDevice, s)); dinf = sl.in_inf.as<uint8_t>(); }
     { StageTimer st(sl, "ml.g2_prepare");
-      hipLaunchKernelGGL(k_g2_prepare, dim3((unsigned)((2 * n + 63) / 64)), dim3(64), 0, s, sl.in_scalars.as<uint32_t>(), dinf, n, sl.ml_coeffs.as<uint32_t>(), sl.in_inf.as<uint8_t>() + n); }
+      if (n <= 8192 && (gs.ml_mode.load() & 1)) {
+          if ((rc = sl.ml_lines.ensure((size_t)N_LINES * LW * n * 4))) return rc;
+          hipLaunchKernelGGL(k_miller_lines_quad<false>, dim3((unsigned)((4 * n + 63) / 64)), dim3(64), 0, s, (const uint32_t *)nullptr, sl.in_scalars.as<uint32_t>(), dinf, n, sl.ml_lines.as<uint32_t>(), n,
+                             62, 0, 0, (uint32_t *)nullptr, (uint32_t *)nullptr);
+          hipLaunchKernelGGL(k_prepared_from_lines, dim3((unsigned)((n * N_LINES * 6 + 255) / 256)), dim3(256), 0, s, sl.ml_lines.as<uint32_t>(), sl.in_scalars.as<uint32_t>(), dinf, n,
+                             sl.ml_coeffs.as<uint32_t>(), sl.in_inf.as<uint8_t>() + n);
+      } else
+          hipLaunchKernelGGL(k_g2_prepare, dim3((unsigned)((2 * n + 63) / 64)), dim3(64), 0, s, sl.in_scalars.as<uint32_t>(), dinf, n, sl.ml_coeffs.as<uint32_t>(), sl.in_inf.as<uint8_t>() + n); }
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out_coeffs, sl.ml_coeffs.p, cbytes, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(out_inf, sl.in_inf.as<uint8_t>() + n, n, hipMemcpyDeviceToHost, s));

@@ -145,6 +145,15 @@ def test_g2_prepare_coefficients_equal_the_oracle(n):
             assert pc.infinity[i] == 1 and not pc.coeffs[i].any()
         else:
             assert pc.infinity[i] == 0 and (pc.coeffs[i] == O.g2_prepare(qs[i]).reshape(-1)).all(), i
+    # the lane-pair chain that converts its coefficients on the way (dgpu_set_miller_pipeline without bit 0) writes the same bytes as the
+    # default four-lane chain + conversion pass
+    from crypto_amd._native import lib
+    try:
+        assert lib().dgpu_set_miller_pipeline(2) == 0
+        old = pairing.G2Prepared.from_affine(qs)
+    finally:
+        lib().dgpu_set_miller_pipeline(3)
+    assert (old.coeffs == pc.coeffs).all() and (old.infinity == pc.infinity).all()
 
 
 @pytest.mark.parametrize("n", [1, 3, 5, 200, 1024, 2500])

@@ -804,8 +804,9 @@ __global__ void __launch_bounds__(256 * C::LPP) k_reduce_top_quad(const uint32_t
             oinf = fl[sg] != 0;
         } else o = x;
     };
+    int Gp = 1; while (Gp < G) Gp <<= 1;                              // groups G .. 63 are identities: the scan and the tree need log2(Gp) levels only
 #pragma unroll 1
-    for (int d = 1; d < 64; d <<= 1) {                               // suffix scan: S_g <- sum_{j >= g} S_j
+    for (int d = 1; d < Gp; d <<= 1) {                               // suffix scan: S_g <- sum_{j >= g} S_j
         Xyzz<F> o; bool oinf; from_group(o, oinf, S, sinf, d);
         xyzz_add_rounds(S, sinf, o, oinf, q4);
     }
@@ -814,7 +815,7 @@ __global__ void __launch_bounds__(256 * C::LPP) k_reduce_top_quad(const uint32_t
     for (int k = 0; k < gshift; k++) { if (!yinf) { Xyzz<F> d2; xyzz_dbl_rounds(d2, y, q4); y = d2; } }
     xyzz_add_rounds(A, ainf, y, yinf, q4);
 #pragma unroll 1
-    for (int d = 32; d >= 1; d >>= 1) {
+    for (int d = Gp >> 1; d >= 1; d >>= 1) {
         Xyzz<F> o; bool oinf; from_group(o, oinf, A, ainf, d);
         xyzz_add_rounds(A, ainf, o, oinf, q4);
     }

@@ -549,11 +549,13 @@ def secondary_configs(log2n, ks, scalars, db, ds, pool):
     V = m + 2                                          # variables 1 .. m + 2 pair with query[1..]
     with FB.WindowTable(ca.G2, gen2[0]) as t2, FB.WindowTable(ca.G1, gen1[0]) as t1:
         small1, _ = t1.multiply_many(seeded_scalars(0x5EED0010, 8 + 2 + cw)); small2, _ = t2.multiply_many(seeded_scalars(0x5EED0011, 4))
-        qa = t1.multiply_many_to_bases(seeded_scalars(0x5EED0012, V + 1)).precompute()
-        qb1 = t1.multiply_many_to_bases(seeded_scalars(0x5EED0013, V + 1)).precompute()
-        qb2 = t2.multiply_many_to_bases(seeded_scalars(0x5EED0014, V + 1)).precompute()
+        # the queries that meet the witness take DGPU_TABLE_C_WITNESS (fewer buckets to reduce per MSM: include/dock_gpu.h), the h query the automatic width
+        wc_ = ca.TABLE_C_WITNESS
+        qa = t1.multiply_many_to_bases(seeded_scalars(0x5EED0012, V + 1)).precompute(wc_)
+        qb1 = t1.multiply_many_to_bases(seeded_scalars(0x5EED0013, V + 1)).precompute(wc_)
+        qb2 = t2.multiply_many_to_bases(seeded_scalars(0x5EED0014, V + 1)).precompute(wc_)
         qh = t1.multiply_many_to_bases(seeded_scalars(0x5EED0015, n - 1)).precompute()
-        ql = t1.multiply_many_to_bases(seeded_scalars(0x5EED0016, m + 1 - cw)).precompute()
+        ql = t1.multiply_many_to_bases(seeded_scalars(0x5EED0016, m + 1 - cw)).precompute(wc_)
     vk = LG.VerifyingKey(small1[0], small2[0], small2[1], small2[2], small1[8:8 + 2 + cw], small1[1], cw)
     pk = LG.ProvingKey.from_device(vk, small1[2], small1[3], small1[4], small1[5], small1[6], small2[3], qa, qb1, qb2, qh, ql)
 
@@ -597,7 +599,7 @@ def secondary_configs(log2n, ks, scalars, db, ds, pool):
     spans["sum_of_spans"] = round(sum(spans.values()), 3)
     res["prove_spans_ms"] = spans
     res["prove_note"] = ("LegoGroth16 create_proof (witness map + 4 G1 MSMs + 1 G2 MSM + finish), m + 1 = %d constraints, D = 2^%d, Groth16-like witness, "
-                         "circuit and key (precomputed tables) resident, assignment uploaded per proof; the A / B-in-G1 / B-in-G2 / l MSMs share one partition sort" % (m + 1, log2n))
+                         "circuit and key (precomputed tables: window width %d for the a / b / l queries, automatic = 20 for the h query) resident, assignment uploaded per proof; the A / B-in-G1 / B-in-G2 / l MSMs share one partition sort" % (m + 1, log2n, ca.TABLE_C_WITNESS))
     res["note"] = "n = D = 2^%d; one call in flight unless stated; host-visible wall time per call" % log2n
     return res
 

@@ -7,7 +7,7 @@ There is no CPU fallback: every call goes through the HIP library and raises if 
 from ._native import lib, DockGpuError, build_native  # noqa: F401
 from .msm import (  # noqa: F401
     G1, G2, msm_bigint, msm_unchecked, msm, Pairs, OwnedPairs, DeviceBases, DeviceScalars, SortedScalars, init, prof, init_devices, msm_bigint_sharded, ShardedDeviceBases,
-    msm_strided, to_affine_structs, affine_struct_dtype, reserve, device_alloc_count,
+    msm_strided, to_affine_structs, affine_struct_dtype, reserve, device_alloc_count, TABLE_C_WITNESS,
 )
 from .pairing import multi_miller_loop, final_exponentiation, multi_pairing  # noqa: F401,E402
 from .pairing_check import RandomizedPairingChecker  # noqa: F401,E402

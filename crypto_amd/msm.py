@@ -422,6 +422,9 @@ class DeviceScalars:
             pass
 
 
+TABLE_C_WITNESS = 17      # include/dock_gpu.h DGPU_TABLE_C_WITNESS: table window width for queries that are multiplied by a witness
+
+
 class prof:
     """Per-stage HIP-event timings recorded inside the library on its own stream."""
 

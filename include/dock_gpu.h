@@ -137,7 +137,12 @@ int32_t dgpu_msm_g2_handle(uint64_t bases, size_t offset, const uint64_t *scalar
  * the handle adds digit w of scalar i into ONE bucket set shared by all windows: wider windows (13 instead of 16 additions per term at
  * n = 2^20), 16x fewer buckets to reduce, no Horner fold on the host.  Same group element as before, limb for limb.  window_bits: 0 =
  * chosen from n, else 16..22.  Works on plain (dgpu_bases_upload_*, dgpu_window_table_mul_to_bases_*) and sharded handles; offsets
- * (`&query[1..]`) and sub-ranges keep working.  While the table is being built the handle is unavailable (DGPU_E_BADARG). */
+ * (`&query[1..]`) and sub-ranges keep working.  While the table is being built the handle is unavailable (DGPU_E_BADARG).
+ * The automatic width (20 from 2^17.5 points) is the optimum for full-width scalars.  A query that is multiplied by a WITNESS (a proving key's
+ * a / b / l queries: half of a Groth16 witness is 0 or 1, much of the rest small) adds fewer points per MSM but reduces the same number of
+ * buckets, and a proof reduces five bucket sets: DGPU_TABLE_C_WITNESS = 17 has the window count of 18 (15) with half the buckets — measured
+ * at 2^20 constraints: 12.4 -> 11.75 ms per proof, 10.2 -> 9.6 with four in flight (19: 12.5, 18: 12.0, 16: 12.9). */
+#define DGPU_TABLE_C_WITNESS 17
 int32_t dgpu_bases_precompute_g1(uint64_t bases, int32_t window_bits);
 int32_t dgpu_bases_precompute_g2(uint64_t bases, int32_t window_bits);
 /* ---- one partition sort for several tables ----

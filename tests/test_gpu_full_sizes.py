@@ -121,8 +121,10 @@ def test_full_prove_2_20_verifies_and_matches_the_closed_form():
     assert all((proof_r[k] == proof[k]).all() for k in proof)
     # the same key as precomputed-multiples tables (a real key: the B queries hold identity rows for the variables B does not use): one
     # partition sort shared by the A / B-in-G1 / B-in-G2 MSMs (dgpu_scalars_sort) and a sort per MSM give the same proof as the plain handles
-    for q in (pk.a_query, pk.b_g1_query, pk.b_g2_query, pk.h_query, pk.l_query):
-        q.precompute()
+    # (the queries that meet the witness at DGPU_TABLE_C_WITNESS, the h query at the automatic width: what bench.py's prover key uses)
+    for q in (pk.a_query, pk.b_g1_query, pk.b_g2_query, pk.l_query):
+        q.precompute(ca.TABLE_C_WITNESS)
+    pk.h_query.precompute()
     assert pk.a_query.same_table_shape(pk.b_g1_query) and pk.a_query.same_table_shape(pk.b_g2_query) and not pk.a_query.same_table_shape(pk.h_query)
     for share in (True, False):
         proof_t = LG.create_proof_with_reduction(pk, dr, r, s, v, zl, share_sort=share)

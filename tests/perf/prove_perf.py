@@ -8,6 +8,9 @@ import crypto_amd as ca
 from crypto_amd import fixed_base as FB, qap, serde, legogroth16 as LG
 import bench as B
 ca.init(0)
+if os.environ.get("REDUCE_SHIFT"):
+    from crypto_amd._native import lib as _lib
+    assert _lib().dgpu_set_reduce_shift(int(os.environ["REDUCE_SHIFT"])) == 0
 log2n = int(os.environ.get("LOG2N", "20")); n = 1 << log2n
 table = os.environ.get("TABLE", "1") == "1"
 gen1, _ = serde.deserialize(ca.G1, bytes.fromhex(B.G1_GEN_COMPRESSED)); gen2, _ = serde.deserialize(ca.G2, bytes.fromhex(B.G2_GEN_COMPRESSED))

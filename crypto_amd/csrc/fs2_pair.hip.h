@@ -123,17 +123,16 @@ __device__ __forceinline__ bool fis_zero_exact(const Fs2H &a) {
     int32_t z = fs_is_zero_exact(a.v) ? 1 : 0;
     return (z & sxchg32(z)) != 0;
 }
-// product: the even lane computes c0 = a0 b0 + (-a1) b1, the odd lane c1 = a1 b0 + a0 b1 — one fused two-product reduction per lane after
+// product: the even lane computes c0 = a0 b0 + a1 (-b1), the odd lane c1 = a1 b0 + a0 b1 — one fused two-product reduction per lane after
 // exchanging both operands' halves.  All halves class B.
 __device__ __forceinline__ void fmul(Fs2H &r, const Fs2H &a, const Fs2H &b) {
     const bool odd = spair_odd();
-    Fs ao, bo, nao, X, Y, Z;
+    Fs ao, bo, nbo, X, Z;
     xchg(ao, a.v); xchg(bo, b.v);
-    fs_neg(nao, ao);                          // even lane: -a1
-    sel(X, odd, bo, b.v);
-    sel(Y, odd, ao, nao);
-    sel(Z, odd, b.v, bo);
-    fs_mul2(r.v, a.v, X, Y, Z);
+    fs_neg(nbo, bo);                          // even lane: -b1
+    sel(X, odd, bo, b.v);                     // even: a0 b0 + a1 (-b1)     odd: a1 b0 + a0 b1  — the a side needs no selection
+    sel(Z, odd, b.v, nbo);
+    fs_mul2(r.v, a.v, X, ao, Z);
 }
 // square: input class B
 __device__ __forceinline__ void fsqr(Fs2H &r, const Fs2H &a) {

@@ -141,7 +141,8 @@ public:
     ~DeviceBases() { if (h_) dgpu_bases_free(h_); }
     size_t len() const { return n_; }
     uint64_t handle() const { return h_; }
-    // per-key setup: MSMs over this query run on a precomputed-multiples table from now on (dgpu_bases_precompute_*); same results
+    // per-key setup: MSMs over this query run on a precomputed-multiples table from now on (dgpu_bases_precompute_*); same results.
+    // window_bits: 0 = automatic (full-width scalars: an h query), DGPU_TABLE_C_WITNESS for queries that meet a witness (a / b / l)
     void precompute(int32_t window_bits = 0) { check(G::AW == 12 ? dgpu_bases_precompute_g1(h_, window_bits) : dgpu_bases_precompute_g2(h_, window_bits), "bases_precompute"); }
     typename G::Projective msm_bigint(const std::vector<BigInt256> &bigints, size_t offset = 0) const {
         size_t n = std::min(n_ - offset, bigints.size());

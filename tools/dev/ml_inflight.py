@@ -15,9 +15,9 @@ for mode in (0, 1, 2, 3, 0, 1, 2, 3):
     for _ in range(20): ca.multi_miller_loop(ps, qs)
     one = (time.perf_counter() - t0) / 20 * 1e3
     out = []
-    for th in (2, 4, 6):
+    for th in (2, 4, 6, 10):
         with ThreadPoolExecutor(th) as ex:
             list(ex.map(lambda _: ca.multi_miller_loop(ps, qs), range(12)))
             t0 = time.perf_counter(); list(ex.map(lambda _: ca.multi_miller_loop(ps, qs), range(60))); out.append((time.perf_counter() - t0) / 60 * 1e3)
-    print("mode %d  one call %.3f ms   per call with 2 / 4 / 6 in flight: %s" % (mode, one, ["%.3f" % v for v in out]), flush=True)
+    print("mode %d  one call %.3f ms   per call with 2 / 4 / 6 / 10 in flight: %s" % (mode, one, ["%.3f" % v for v in out]), flush=True)
 lib().dgpu_set_miller_pipeline(3)

@@ -23,7 +23,7 @@ def _rol(v, n):
 
 
 def keccak_f1600_py(state):
-    """state: bytearray(200), permuted in place (pure-Python statement of the permutation; the transcript uses the native one)"""
+    """state: bytearray(200), permuted in place (pure-Python statement of the permutation; the transcript uses keccak_f1600.c when built)"""
     a = [[int.from_bytes(state[8 * (x + 5 * y):8 * (x + 5 * y) + 8], "little") for y in range(5)] for x in range(5)]
     for rc in _RC:
         c = [a[x][0] ^ a[x][1] ^ a[x][2] ^ a[x][3] ^ a[x][4] for x in range(5)]
@@ -40,14 +40,42 @@ def keccak_f1600_py(state):
             state[8 * (x + 5 * y):8 * (x + 5 * y) + 8] = (a[x][y] & _MASK).to_bytes(8, "little")
 
 
+_HELPER = None
+
+
+def build_helper():
+    """gcc keccak_f1600.c -> libkeccak_f1600.so next to this file (called by __graft_entry__.build())"""
+    import os, subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    so, src = os.path.join(here, "libkeccak_f1600.so"), os.path.join(here, "keccak_f1600.c")
+    if not os.path.exists(so) or os.path.getmtime(src) > os.path.getmtime(so):
+        subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", "-fvisibility=hidden", "-o", so, src])
+    return so
+
+
+def _helper():
+    global _HELPER
+    if _HELPER is None:
+        import ctypes, os
+        so = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libkeccak_f1600.so")
+        try:
+            _HELPER = ctypes.CDLL(so).keccak_f1600
+            _HELPER.argtypes = [ctypes.c_void_p]
+        except OSError:
+            _HELPER = False
+    return _HELPER
+
+
 def keccak_f1600(state):
-    """state: bytearray(200), permuted in place by the library's native permutation (dgpu_keccak_f1600)"""
+    """state: bytearray(200), permuted in place.  Host-side helper of this Python mirror (keccak_f1600.c; the pure-Python
+    statement above when the helper was not built).  Not part of the product ABI: Merlin is out of scope for the library."""
+    f = _helper()
+    if not f:
+        return keccak_f1600_py(state)
     import ctypes
-    from .._native import lib
     buf = (ctypes.c_uint8 * 200).from_buffer(state)
-    rc = lib().dgpu_keccak_f1600(ctypes.cast(buf, ctypes.c_void_p))
-    if rc:
-        raise RuntimeError("dgpu_keccak_f1600 failed")
+    if f(ctypes.cast(buf, ctypes.c_void_p)):
+        raise RuntimeError("keccak_f1600 helper failed")
 
 
 STROBE_R = 166

@@ -86,11 +86,19 @@ extern "C" {
 
 int32_t dgpu_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; } return n; }
 
-// bring up context `idx` on physical device `device` (gs.mu held)
-static int32_t init_ctx_locked(int idx, int device) {
-    Ctx &c = ctxs[idx];
-    if (c.ready) return c.device == device ? DGPU_OK : DGPU_E_BADARG;
-    HIPCHK(hipSetDevice(device));
+// streams, events, pinned scratch and workspaces of a context's slots (shutdown; a failed bring-up).  The caller holds each slot's mutex or
+// knows that no call can reach the context.
+static void destroy_slot(Slot &sl) {
+    if (sl.stream) (void)hipStreamSynchronize(sl.stream);
+    if (sl.cstream) (void)hipStreamSynchronize(sl.cstream);
+    sl.release_all();
+    if (sl.stream) (void)hipStreamDestroy(sl.stream);
+    if (sl.cstream) (void)hipStreamDestroy(sl.cstream);
+    for (hipEvent_t &e : sl.copy_ev) { if (e) (void)hipEventDestroy(e); e = nullptr; }
+    if (sl.hpin) (void)hipHostFree(sl.hpin);
+    sl.stream = nullptr; sl.cstream = nullptr; sl.hpin = nullptr;
+}
+static int32_t init_ctx_slots(Ctx &c) {
     for (int i = 0; i < N_SLOTS; i++) {
         HIPCHK(hipStreamCreateWithFlags(&c.slots[i].stream, hipStreamNonBlocking));
         HIPCHK(hipStreamCreateWithFlags(&c.slots[i].cstream, hipStreamNonBlocking));
@@ -98,6 +106,16 @@ static int32_t init_ctx_locked(int idx, int device) {
         HIPCHK(hipHostMalloc(&c.slots[i].hpin, Slot::HPIN_BYTES, hipHostMallocDefault));
         HIPCHK(c.slots[i].flags.ensure(64) ? hipErrorOutOfMemory : hipSuccess);
     }
+    return DGPU_OK;
+}
+// bring up context `idx` on physical device `device` (gs.mu held)
+static int32_t init_ctx_locked(int idx, int device) {
+    Ctx &c = ctxs[idx];
+    if (c.ready) return c.device == device ? DGPU_OK : DGPU_E_BADARG;
+    if (!__builtin_cpu_supports("bmi2") || !__builtin_cpu_supports("adx")) return DGPU_E_NODEVICE;   // the host field code (host_field.hpp) is compiled for mulx / adcx / adox
+    HIPCHK(hipSetDevice(device));
+    { const int32_t rc = init_ctx_slots(c);
+      if (rc) { for (int i = 0; i < N_SLOTS; i++) destroy_slot(c.slots[i]); return rc; } }      // nothing half-built is left behind
     c.device = device; c.ready = true;
     if (gs.default_ctx < 0) gs.default_ctx = idx;
     return DGPU_OK;
@@ -145,14 +163,7 @@ int32_t dgpu_shutdown(void) {
         (void)hipSetDevice(c.device);
         for (int k = 0; k < N_SLOTS; k++) {
             std::lock_guard<std::mutex> sk(c.slots[k].mu);
-            (void)hipStreamSynchronize(c.slots[k].stream);
-            (void)hipStreamSynchronize(c.slots[k].cstream);
-            c.slots[k].release_all();
-            (void)hipStreamDestroy(c.slots[k].stream);
-            (void)hipStreamDestroy(c.slots[k].cstream);
-            for (hipEvent_t &e : c.slots[k].copy_ev) { if (e) (void)hipEventDestroy(e); e = nullptr; }
-            if (c.slots[k].hpin) (void)hipHostFree(c.slots[k].hpin);
-            c.slots[k].stream = nullptr; c.slots[k].cstream = nullptr; c.slots[k].hpin = nullptr;
+            destroy_slot(c.slots[k]);
         }
     }
     std::unique_lock<std::mutex> lk(gs.mu);
@@ -264,7 +275,7 @@ int32_t dgpu_scalars_upload(const uint64_t *s, size_t n, int32_t mont, uint64_t 
     if (!cur().ready) return DGPU_E_NODEVICE;
     void *p = nullptr;
     {
-        SlotLock L; Slot &sl = *L.s;
+        SLOT_ACQUIRE(L, sl);
         HIPCHK(hipSetDevice(cur().device));
         if (!(p = scalar_alloc(scalar_bytes(n)))) return DGPU_E_OOM;
         int32_t rc = n ? upload_scalars(sl, s, n, mont != 0, (uint32_t *)p) : DGPU_OK;
@@ -284,7 +295,7 @@ int32_t dgpu_scalars_upload_parts(const uint64_t *const *parts, const size_t *co
     if (!cur().ready) return DGPU_E_NODEVICE;
     void *p = nullptr;
     {
-        SlotLock L; Slot &sl = *L.s;
+        SLOT_ACQUIRE(L, sl);
         HIPCHK(hipSetDevice(cur().device));
         if (!(p = scalar_alloc(scalar_bytes(n)))) return DGPU_E_OOM;
         size_t at = 0;
@@ -311,17 +322,12 @@ int32_t dgpu_scalars_upload_sharded(const uint64_t *sc, size_t n, int32_t mont, 
     ShardSet *ss = new ShardSet();
     ss->n = n; ss->sub.assign(G, 0); ss->lo.resize(G + 1);
     for (size_t k = 0; k <= G; k++) ss->lo[k] = std::min(sb.lo[k], n);
-    std::vector<int32_t> rcs(G, DGPU_OK);
-    std::vector<std::thread> th;
-    auto body = [&](size_t k) {
+    const int32_t prc = par_run(G, [&](size_t k) -> int32_t {
         Handle part; if (!lookup_handle(sb.sub[k], part)) return (int32_t)DGPU_E_BADARG;
         CtxScope here(part.ctx);
         return dgpu_scalars_upload(sc + ss->lo[k] * 4, ss->lo[k + 1] - ss->lo[k], mont, &ss->sub[k]);
-    };
-    for (size_t k = 1; k < G; k++) th.emplace_back([&, k] { rcs[k] = body(k); });
-    rcs[0] = body(0);
-    for (auto &t : th) t.join();
-    for (int32_t rc : rcs) if (rc) { for (uint64_t h : ss->sub) if (h) (void)dgpu_scalars_free(h); delete ss; return rc; }
+    });
+    if (prc) { for (uint64_t h : ss->sub) if (h) (void)dgpu_scalars_free(h); delete ss; return prc; }
     *handle = register_handle(ss, n, 9);
     return DGPU_OK;
 }

@@ -11,6 +11,7 @@
 #include <mutex>
 #include <vector>
 #include "../../include/dock_gpu.h"
+#include "host_par.hpp"
 
 namespace dock {
 
@@ -118,18 +119,24 @@ inline int cur_index() { int i = tl_ctx >= 0 ? tl_ctx : gs.default_ctx; return (
 inline Ctx &cur() { return ctxs[cur_index()]; }
 struct CtxScope { int prev; explicit CtxScope(int c) : prev(tl_ctx) { tl_ctx = c; } ~CtxScope() { tl_ctx = prev; } CtxScope(const CtxScope &) = delete; };
 
-// RAII: pick a free slot (round-robin try_lock), or wait for one
+// RAII: pick a free slot (round-robin try_lock), or wait for one.  `ok` is false when the context was shut down between the caller's
+// `ready` check and the moment the slot was acquired (dgpu_shutdown clears `ready` first, then takes every slot): the slot's streams and
+// buffers are gone then, and the call must answer DGPU_E_NODEVICE instead of running on a null stream (SLOT_ACQUIRE).
 struct SlotLock {
-    Slot *s;
+    Slot *s = nullptr; bool ok = false;
     SlotLock() {
         Ctx &cx = cur();
         unsigned start = cx.rr.fetch_add(1);
-        for (int k = 0; k < N_SLOTS; k++) { Slot &c = cx.slots[(start + k) % N_SLOTS]; if (c.mu.try_lock()) { s = &c; return; } }
-        s = &cx.slots[start % N_SLOTS]; s->mu.lock();
+        Slot *got = nullptr;
+        for (int k = 0; k < N_SLOTS && !got; k++) { Slot &c = cx.slots[(start + k) % N_SLOTS]; if (c.mu.try_lock()) got = &c; }
+        if (!got) { got = &cx.slots[start % N_SLOTS]; got->mu.lock(); }
+        if (!cx.ready.load() || !got->stream) { got->mu.unlock(); return; }
+        s = got; ok = true;
     }
-    ~SlotLock() { s->mu.unlock(); }
+    ~SlotLock() { if (s) s->mu.unlock(); }
     SlotLock(const SlotLock &) = delete;
 };
+#define SLOT_ACQUIRE(lockname, slotname) dock::SlotLock lockname; if (!lockname.ok) return DGPU_E_NODEVICE; dock::Slot &slotname = *lockname.s
 
 // device memory for a resident scalar vector of `bytes` on the current context: a recycled buffer of exactly that size, else hipMalloc
 inline void *scalar_alloc(size_t bytes) {

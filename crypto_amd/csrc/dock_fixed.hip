@@ -35,7 +35,7 @@ template <class C, class HF> int32_t table_build(const uint64_t *base, uint64_t 
     if (any) window_bases_host<HF>(base, wb.data());     // identity base: all-zero records -> flagged as identity by k_prep_bases
     void *tab = nullptr;
     {
-        SlotLock L; Slot &sl = *L.s;
+        SLOT_ACQUIRE(L, sl);
         HIPCHK(hipSetDevice(cur().device));
         int32_t rc;
         if ((rc = sl.prepped.ensure(32 * C::AFF_STRIDE * 4))) return rc;
@@ -73,7 +73,7 @@ template <class C> int32_t table_mul(uint64_t table, const uint64_t *scalars, si
         return DGPU_OK;
     }
     {
-    SlotLock L; Slot &sl = *L.s;
+    SLOT_ACQUIRE(L, sl);
     HIPCHK(hipSetDevice(cur().device));
     int32_t rc;
     const size_t pt_bytes = 2 * C::ABI_W * 4;
@@ -113,7 +113,7 @@ template <class C> int32_t mul_add(const uint64_t *p, const uint8_t *p_inf, cons
     if ((n && (!p || !scalars || !out || !out_inf)) || (scalar_stride != 0 && scalar_stride != 4) || (add_inf && !addend) || n >= (1ull << 31)) return DGPU_E_BADARG;
     if (n == 0) return DGPU_OK;
     if (!cur().ready) return DGPU_E_NODEVICE;
-    SlotLock L; Slot &sl = *L.s;
+    SLOT_ACQUIRE(L, sl);
     HIPCHK(hipSetDevice(cur().device));
     int32_t rc;
     const size_t pt = 2 * C::ABI_W * 4, nsc = scalar_stride ? n : 1;

@@ -41,7 +41,7 @@ int32_t dgpu_msm_g1_resident(uint64_t b, size_t boff, uint64_t s, size_t soff, s
 
 int32_t dgpu_selftest_fp_mul(const uint64_t *a, const uint64_t *b, size_t n, uint64_t *out) {
     if (!cur().ready) return DGPU_E_NODEVICE;
-    SlotLock L; Slot &sl = *L.s;
+    SLOT_ACQUIRE(L, sl);
     HIPCHK(hipSetDevice(cur().device));
     void *da, *db, *dout;
     HIPCHK(dev_malloc(&da, n * 48 + 16)); HIPCHK(dev_malloc(&db, n * 48 + 16)); HIPCHK(dev_malloc(&dout, n * 48 + 16));
@@ -54,7 +54,7 @@ int32_t dgpu_selftest_fp_mul(const uint64_t *a, const uint64_t *b, size_t n, uin
 }
 int32_t dgpu_selftest_g1_sum(const uint64_t *pts, const uint8_t *neg, size_t n, uint64_t out[18]) {
     if (!cur().ready) return DGPU_E_NODEVICE;
-    SlotLock L; Slot &sl = *L.s;
+    SLOT_ACQUIRE(L, sl);
     HIPCHK(hipSetDevice(cur().device));
     void *dp, *dn, *dout, *dinf;
     HIPCHK(dev_malloc(&dp, n * 96 + 16)); HIPCHK(dev_malloc(&dn, n + 16)); HIPCHK(dev_malloc(&dout, 4 * 48)); HIPCHK(dev_malloc(&dinf, 16));

@@ -624,7 +624,7 @@ int32_t dgpu_multi_miller_loop(const uint64_t *p, const uint64_t *q, const uint8
     if (n == 0) { hostf::Fq12 one = hostf::Fq12::one(); memcpy(out, &one, sizeof one); return DGPU_OK; }
     if (n >= (1ull << 24)) return DGPU_E_BADARG;
     if (!cur().ready) return DGPU_E_NODEVICE;
-    SlotLock slot_lock; Slot &sl = *slot_lock.s;
+    SLOT_ACQUIRE(slot_lock, sl);
     HIPCHK(hipSetDevice(cur().device));
     int32_t rc;
     if ((rc = sl.in_bases.ensure(n * 96))) return rc;
@@ -693,7 +693,7 @@ static int32_t ml_segments(const uint64_t *p, const uint64_t *q, const uint8_t *
     const hostf::Fq12 one = hostf::Fq12::one();
     if (n == 0) { for (size_t g = 0; g < nseg; g++) memcpy(out + g * 72, &one, sizeof one); return DGPU_OK; }
     if (!cur().ready) return DGPU_E_NODEVICE;
-    SlotLock slot_lock; Slot &sl = *slot_lock.s;
+    SLOT_ACQUIRE(slot_lock, sl);
     HIPCHK(hipSetDevice(cur().device));
     int32_t rc;
     int slice_len = 4;
@@ -732,10 +732,8 @@ static int32_t ml_segments(const uint64_t *p, const uint64_t *q, const uint8_t *
     if (gs.prof) prof_flush(sl);
     auto tail = [&](size_t g) { const hostf::Fq12 f = off[g + 1] == off[g] ? one : ml_host_tail(&L[g * N_LINES]); memcpy(out + g * 72, &f, sizeof f); finish(out + g * 72); };
     const size_t T = std::min<size_t>(std::min<size_t>(nseg, 16), std::max<size_t>(1, std::thread::hardware_concurrency()));
-    std::vector<std::thread> th;
-    for (size_t k = 1; k < T; k++) th.emplace_back([&, k]() { for (size_t g = k; g < nseg; g += T) tail(g); });
-    for (size_t g = 0; g < nseg; g += T) tail(g);
-    for (auto &t : th) t.join();
+    const int32_t prc = par_run(T, [&](size_t k) -> int32_t { for (size_t g = k; g < nseg; g += T) tail(g); return DGPU_OK; });
+    if (prc) return prc;
     return zero ? DGPU_E_ZERO : DGPU_OK;
 }
 
@@ -756,17 +754,12 @@ int32_t dgpu_multi_miller_loop_sharded(const uint64_t *p, const uint64_t *q, con
     if (ngpus > 0 && (int)cx.size() < ngpus) return DGPU_E_BADARG;
     const size_t G = cx.size();
     std::vector<hostf::Fq12> parts(G);
-    std::vector<int32_t> rcs(G, DGPU_OK);
-    std::vector<std::thread> th;
-    auto body = [&](size_t k) {
+    const int32_t prc = par_run(G, [&](size_t k) -> int32_t {
         const size_t lo = k * (n / G) + std::min(k, n % G), hi = (k + 1) * (n / G) + std::min(k + 1, n % G);
         CtxScope here(cx[k]);
-        rcs[k] = dgpu_multi_miller_loop(p + lo * 12, q + lo * 24, skip ? skip + lo : nullptr, hi - lo, (uint64_t *)&parts[k]);
-    };
-    for (size_t k = 1; k < G; k++) th.emplace_back(body, k);
-    body(0);
-    for (auto &t : th) t.join();
-    for (int32_t rc : rcs) if (rc) return rc;
+        return dgpu_multi_miller_loop(p + lo * 12, q + lo * 24, skip ? skip + lo : nullptr, hi - lo, (uint64_t *)&parts[k]);
+    });
+    if (prc) return prc;
     hostf::Fq12 f = parts[0];
     for (size_t k = 1; k < G; k++) f = f * parts[k];
     memcpy(out, &f, sizeof f);
@@ -779,7 +772,7 @@ int32_t dgpu_g2_prepare(const uint64_t *q, const uint8_t *is_inf, size_t n, uint
     if (n == 0) return DGPU_OK;
     if (n > DGPU_MAX_PREPARED) return DGPU_E_BADARG;
     if (!cur().ready) return DGPU_E_NODEVICE;
-    SlotLock slot_lock; Slot &sl = *slot_lock.s;
+    SLOT_ACQUIRE(slot_lock, sl);
     HIPCHK(hipSetDevice(cur().device));
     int32_t rc;
     const size_t cbytes = n * (size_t)DGPU_G2_PREPARED_WORDS * 8;
@@ -813,7 +806,7 @@ int32_t dgpu_multi_miller_loop_prepared(const uint64_t *p, const uint64_t *coeff
     if (n == 0) { hostf::Fq12 one = hostf::Fq12::one(); memcpy(out, &one, sizeof one); return DGPU_OK; }
     if (n > DGPU_MAX_PREPARED) return DGPU_E_BADARG;
     if (!cur().ready) return DGPU_E_NODEVICE;
-    SlotLock slot_lock; Slot &sl = *slot_lock.s;
+    SLOT_ACQUIRE(slot_lock, sl);
     HIPCHK(hipSetDevice(cur().device));
     int32_t rc;
     const size_t cbytes = n * (size_t)DGPU_G2_PREPARED_WORDS * 8;
@@ -842,7 +835,7 @@ int32_t dgpu_multi_miller_loop_mixed(const uint64_t *p_aff, const uint64_t *q_af
     if (n == 0) { hostf::Fq12 one = hostf::Fq12::one(); memcpy(out, &one, sizeof one); return DGPU_OK; }
     if (n_prep > DGPU_MAX_PREPARED || n >= (1ull << 24)) return DGPU_E_BADARG;
     if (!cur().ready) return DGPU_E_NODEVICE;
-    SlotLock slot_lock; Slot &sl = *slot_lock.s;
+    SLOT_ACQUIRE(slot_lock, sl);
     HIPCHK(hipSetDevice(cur().device));
     int32_t rc;
     const size_t cbytes = n_prep * (size_t)DGPU_G2_PREPARED_WORDS * 8;
@@ -895,7 +888,7 @@ int32_t dgpu_g1_scale_batch(const uint64_t *p, const uint8_t *is_inf, const uint
     if ((n && (!p || !scalars || !out || !out_inf)) || (scalar_stride != 0 && scalar_stride != 4)) return DGPU_E_BADARG;
     if (n == 0) return DGPU_OK;
     if (!cur().ready) return DGPU_E_NODEVICE;
-    SlotLock slot_lock; Slot &sl = *slot_lock.s;
+    SLOT_ACQUIRE(slot_lock, sl);
     HIPCHK(hipSetDevice(cur().device));
     int32_t rc;
     const size_t nsc = scalar_stride ? n : 1;

@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <cstring>
 #include <mutex>
+#include <new>
 #include <thread>
 #include <vector>
 #include "../../include/dock_gpu.h"
@@ -30,10 +31,22 @@ int32_t msm_g1_nothreshold(const uint64_t *bases, const uint8_t *is_inf, const u
 namespace {
 using hostf::FrH;
 
+// A host thread of the call.  Nothing may leave the C ABI by unwinding: the body maps std::bad_alloc / anything else to an error code, a thread
+// that cannot be created (std::system_error) runs its body on the calling thread instead, and the destructor joins so that an early return
+// never destroys a joinable std::thread (std::terminate).
 struct Job {
     std::thread th; int32_t rc = DGPU_OK;
-    template <class F> void start(F f) { th = std::thread([this, f] { dock::tl_no_min = true; rc = f(); }); }
+    template <class F> static int32_t guarded(F &f) noexcept {
+        try { return f(); } catch (const std::bad_alloc &) { return DGPU_E_OOM; } catch (...) { return DGPU_E_HIP; }
+    }
+    template <class F> void start(F f) {
+        try { th = std::thread([this, f]() mutable { dock::tl_no_min = true; rc = guarded(f); }); }
+        catch (...) { const bool keep = dock::tl_no_min; dock::tl_no_min = true; rc = guarded(f); dock::tl_no_min = keep; }
+    }
     int32_t join() { if (th.joinable()) th.join(); return rc; }
+    Job() = default;
+    Job(const Job &) = delete; Job &operator=(const Job &) = delete;
+    ~Job() { if (th.joinable()) th.join(); }
 };
 
 inline bool is_zero4(const uint64_t a[4]) { return !(a[0] | a[1] | a[2] | a[3]); }
@@ -124,15 +137,29 @@ int32_t prove_sharded(const ProofInputs &in, size_t G, uint64_t r1cs, uint64_t h
 
 
 
+static int32_t prove_impl(const dgpu_lego_pk *pk, uint64_t r1cs, uint64_t h_scalars, const uint64_t *z, size_t num_vars, size_t n_inst,
+                          int32_t montgomery, const uint64_t r_in[4], const uint64_t s_in[4], const uint64_t v_in[4],
+                          uint64_t out_a[12], uint64_t out_b[24], uint64_t out_c[12], uint64_t out_d[12], uint8_t out_inf[4]);
 extern "C" int32_t dgpu_legogroth16_prove(const dgpu_lego_pk *pk, uint64_t r1cs, uint64_t h_scalars, const uint64_t *z, size_t num_vars, size_t n_inst,
                                           int32_t montgomery, const uint64_t r_in[4], const uint64_t s_in[4], const uint64_t v_in[4],
                                           uint64_t out_a[12], uint64_t out_b[24], uint64_t out_c[12], uint64_t out_d[12], uint8_t out_inf[4]) {
+    try { return prove_impl(pk, r1cs, h_scalars, z, num_vars, n_inst, montgomery, r_in, s_in, v_in, out_a, out_b, out_c, out_d, out_inf); }
+    catch (const std::bad_alloc &) { return DGPU_E_OOM; }
+    catch (...) { return DGPU_E_HIP; }
+}
+static int32_t prove_impl(const dgpu_lego_pk *pk, uint64_t r1cs, uint64_t h_scalars, const uint64_t *z, size_t num_vars, size_t n_inst,
+                          int32_t montgomery, const uint64_t r_in[4], const uint64_t s_in[4], const uint64_t v_in[4],
+                          uint64_t out_a[12], uint64_t out_b[24], uint64_t out_c[12], uint64_t out_d[12], uint8_t out_inf[4]) {
     if (!pk || !z || !r_in || !s_in || !v_in || !out_a || !out_b || !out_c || !out_d || !out_inf) return DGPU_E_BADARG;
     if ((r1cs != 0) == (h_scalars != 0)) return DGPU_E_BADARG;                      // exactly one source of h
     const size_t cw = pk->commit_witness_count;
     if (n_inst == 0 || n_inst + cw > num_vars || pk->gamma_abc_len < n_inst + cw) return DGPU_E_BADARG;
     if (!pk->alpha_g1 || !pk->beta_g1 || !pk->delta_g1 || !pk->eta_delta_inv_g1 || !pk->eta_gamma_inv_g1 || !pk->beta_g2 || !pk->delta_g2 ||
         !pk->a0 || !pk->b1_0 || !pk->b2_0 || (cw && !pk->gamma_abc_g1)) return DGPU_E_BADARG;
+    if (r1cs) {                                                                      // the circuit's own shape decides D, the gamma_abc / l offsets: refuse a caller that disagrees
+        size_t cv = 0, ci = 0;
+        if (dgpu_r1cs_shape(r1cs, &cv, &ci, nullptr) != DGPU_OK || cv != num_vars || ci != n_inst) return DGPU_E_BADARG;
+    }
     ProofInputs in{pk, z, n_inst, montgomery, {0}, {0}, {0}, false};
     fr_reduce(in.r, r_in); fr_reduce(in.s, s_in); fr_reduce(in.v, v_in);
     in.with_b1 = !is_zero4(in.r);                                                    // prover.rs:330-336
@@ -233,8 +260,8 @@ int32_t prove_sharded(const ProofInputs &in, size_t G, uint64_t r1cs, uint64_t h
     jW.start([&]() -> int32_t {
         int32_t rctx = 0; if (dgpu_handle_context(r1cs, &rctx)) return DGPU_E_BADARG;
         if (dgpu_set_device(rctx)) return DGPU_E_BADARG;
-        size_t nc = 0; if (dgpu_handle_len(r1cs, &nc)) return DGPU_E_BADARG;              // constraints of the circuit
-        size_t cap = 1; while (cap < nc + n_inst) cap <<= 1;                                // the domain of r1cs_to_qap.rs:150-160
+        size_t nc = 0, ni = 0; if (dgpu_r1cs_shape(r1cs, nullptr, &ni, &nc)) return DGPU_E_BADARG;   // the circuit's own shape sizes h (n_inst == ni was checked by the entry point)
+        size_t cap = 1; while (cap < nc + ni) cap <<= 1;                                    // the domain of r1cs_to_qap.rs:150-160
         h.assign(cap * 4, 0);
         return dgpu_witness_map_r1cs(r1cs, in.z, num_vars, in.montgomery, h.data(), nullptr, &D);
     });

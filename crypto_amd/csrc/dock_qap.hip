@@ -151,13 +151,23 @@ int32_t dgpu_r1cs_upload(const uint64_t *a_rowptr, const uint32_t *a_cols, const
     if (!cur().ready) return DGPU_E_NODEVICE;
     DevR1cs *r = nullptr;
     {
-        SlotLock slot_lock; Slot &sl = *slot_lock.s;
+        SLOT_ACQUIRE(slot_lock, sl);
         HIPCHK(hipSetDevice(cur().device));
         Csr mats[3] = {{a_rowptr, a_cols, a_vals, a_nnz}, {b_rowptr, b_cols, b_vals, b_nnz}, {c_rowptr, c_cols, c_vals, c_nnz}};
         int32_t rc = build_r1cs(sl, mats, num_vars, num_inputs, num_constraints, montgomery, &r);
         if (rc) return rc;
     }
     *handle = register_handle(r, num_constraints, 4);
+    return DGPU_OK;
+}
+// shape of a resident circuit (what a caller must agree with: the prover checks its n_inst / num_vars against it)
+int32_t dgpu_r1cs_shape(uint64_t handle, size_t *num_vars, size_t *num_inputs, size_t *num_constraints) {
+    HandleRef href(handle);
+    if (!href.ok || href.h.kind != 4) return DGPU_E_BADARG;
+    const DevR1cs *r = (const DevR1cs *)href.h.p;
+    if (num_vars) *num_vars = r->num_vars;
+    if (num_inputs) *num_inputs = r->num_inputs;
+    if (num_constraints) *num_constraints = r->num_constraints;
     return DGPU_OK;
 }
 int32_t dgpu_r1cs_free(uint64_t handle) {
@@ -176,7 +186,7 @@ int32_t dgpu_witness_map_r1cs(uint64_t r1cs, const uint64_t *assignment, size_t 
     const DevR1cs *r = (const DevR1cs *)href.h.p;
     if (num_vars != r->num_vars) return DGPU_E_BADARG;
     CtxScope on_owner(href.h.ctx);
-    SlotLock slot_lock; Slot &sl = *slot_lock.s;
+    SLOT_ACQUIRE(slot_lock, sl);
     HIPCHK(hipSetDevice(cur().device));
     return witness_map_device(sl, *r, assignment, montgomery, out_h, out_handle, out_len);
 }
@@ -190,7 +200,7 @@ int32_t dgpu_witness_map_r1cs_resident(uint64_t r1cs, uint64_t assignment, uint6
     const DevR1cs *r = (const DevR1cs *)href.h.p;
     if (hs.h.n != r->num_vars) return DGPU_E_BADARG;
     CtxScope on_owner(href.h.ctx);
-    SlotLock slot_lock; Slot &sl = *slot_lock.s;
+    SLOT_ACQUIRE(slot_lock, sl);
     HIPCHK(hipSetDevice(cur().device));
     return witness_map_device(sl, *r, nullptr, 0, out_h, out_handle, out_len, (const uint32_t *)hs.h.p);
 }
@@ -202,7 +212,7 @@ int32_t dgpu_witness_map(const uint64_t *a_rowptr, const uint32_t *a_cols, const
     if (!assignment || num_inputs > num_vars || (!out_h && !out_handle)) return DGPU_E_BADARG;
     if (!check_csr(a_rowptr, a_cols, a_vals, a_nnz, num_constraints, num_vars) || !check_csr(b_rowptr, b_cols, b_vals, b_nnz, num_constraints, num_vars) || !check_csr(c_rowptr, c_cols, c_vals, c_nnz, num_constraints, num_vars)) return DGPU_E_BADARG;
     if (!cur().ready) return DGPU_E_NODEVICE;
-    SlotLock slot_lock; Slot &sl = *slot_lock.s;
+    SLOT_ACQUIRE(slot_lock, sl);
     HIPCHK(hipSetDevice(cur().device));
     Csr mats[3] = {{a_rowptr, a_cols, a_vals, a_nnz}, {b_rowptr, b_cols, b_vals, b_nnz}, {c_rowptr, c_cols, c_vals, c_nnz}};
     DevR1cs *r = nullptr;

@@ -16,6 +16,7 @@
 #include <thread>
 #include <vector>
 #include "host_field.hpp"
+#include "host_par.hpp"
 
 namespace {
 using hostf::Fq;
@@ -111,12 +112,7 @@ template <> bool in_prime_subgroup<Fq2>(const Fq2 &x, const Fq2 &y) {
 template <class Fn> int32_t for_points(size_t n, Fn one) {
     const size_t T = std::min<size_t>(std::min<size_t>(std::max<size_t>(1, std::thread::hardware_concurrency()), 64), n / 16);
     if (T <= 1) { for (size_t i = 0; i < n; i++) { int32_t rc = one(i); if (rc) return rc; } return DGPU_OK; }
-    std::vector<int32_t> rcs(T, DGPU_OK);
-    std::vector<std::thread> th;
-    for (size_t t = 0; t < T; t++) th.emplace_back([&, t] { for (size_t i = n * t / T; i < n * (t + 1) / T; i++) { int32_t rc = one(i); if (rc) { rcs[t] = rc; return; } } });
-    for (auto &x : th) x.join();
-    for (int32_t rc : rcs) if (rc) return rc;
-    return DGPU_OK;
+    return dock::par_run(T, [&](size_t t) -> int32_t { for (size_t i = n * t / T; i < n * (t + 1) / T; i++) { int32_t rc = one(i); if (rc) return rc; } return DGPU_OK; });
 }
 bool canonical_infinity(const uint8_t *b, size_t sz, uint8_t flags) {
     if (flags & FLAG_LARGEST) return false;

@@ -265,15 +265,7 @@ inline void shard_bounds(size_t n, size_t parts, std::vector<size_t> &lo) {
     const size_t base = n / parts, rem = n % parts;
     for (size_t k = 0; k <= parts; k++) lo[k] = k * base + std::min(k, rem);       // contiguous, balanced (== sharded.chunk_bounds)
 }
-template <class F> int32_t run_shards(size_t parts, F body) {
-    std::vector<int32_t> rcs(parts, DGPU_OK);
-    std::vector<std::thread> th;
-    for (size_t k = 1; k < parts; k++) th.emplace_back([&, k] { rcs[k] = body(k); });
-    rcs[0] = body(0);
-    for (auto &t : th) t.join();
-    for (int32_t rc : rcs) if (rc) return rc;
-    return DGPU_OK;
-}
+template <class F> int32_t run_shards(size_t parts, F body) { return par_run(parts, body); }
 // ---- shared-bucket-set pipeline over a precomputed-multiples table (pre_kernels.hip.h, psort_kernels.hip.h) ------------------------------------
 
 // Window width of a table for n bases (measured, tests/perf/pre_perf.py at 2^16 .. 2^21, profiles/r02a_table_sizes.txt): 20 bits from
@@ -486,7 +478,7 @@ inline int32_t scalars_sort(uint64_t table, size_t boff, uint64_t scalars, size_
     if (!hb.ok || !hs.ok || (hb.h.kind != 10 && hb.h.kind != 11) || hs.h.kind != 3 || hb.h.ctx != hs.h.ctx) return DGPU_E_BADARG;
     if (boff > hb.h.n || n > hb.h.n - boff || soff > hs.h.n || n > hs.h.n - soff) return DGPU_E_BADARG;
     CtxScope on_owner(hb.h.ctx);
-    SlotLock L; Slot &sl = *L.s;
+    SLOT_ACQUIRE(L, sl);
     HIPCHK(hipSetDevice(cur().device));
     const PreTable &pt = *(const PreTable *)hb.h.p;
     PreGeom g; int32_t rc;
@@ -516,7 +508,7 @@ int32_t msm_sorted(uint64_t table, uint64_t sorted, size_t row_shift, uint64_t *
     const SortedScalars &ss = *(const SortedScalars *)hs.h.p;
     if (pt.c != ss.c || pt.W != ss.W || row_shift >= ss.rows || pt.n != ss.rows - row_shift) return DGPU_E_BADARG;      // not the shape the list was sorted for
     CtxScope on_owner(hb.h.ctx);
-    SlotLock L; Slot &sl = *L.s;
+    SLOT_ACQUIRE(L, sl);
     HIPCHK(hipSetDevice(cur().device));
     PreGeom g; int32_t rc;
     if ((rc = pre_geometry<C>(pt, ss.n, g))) return rc;
@@ -553,7 +545,7 @@ int32_t bases_precompute(uint64_t handle, int32_t window_bits, int kind /* 1 | 2
     void *tab = nullptr, *tmp = nullptr;
     int32_t rc = DGPU_OK;
     {
-        SlotLock L; Slot &sl = *L.s;
+        SLOT_ACQUIRE(L, sl);
         if (hipSetDevice(cur().device) != hipSuccess) rc = DGPU_E_HIP;
         const size_t rec = (size_t)C::AFF_STRIDE * 4;
         if (!rc && dev_malloc(&tab, (size_t)W * n * rec) != hipSuccess) { (void)hipGetLastError(); rc = DGPU_E_OOM; }
@@ -685,7 +677,7 @@ template <class C> void reserve_idle_slots(const Slot *mine, int what, size_t n,
 template <class C, class HF>
 int32_t msm_oneshot_here(const RawBases &rb, const uint64_t *scalars, size_t n, bool mont, uint64_t *out) {
     if (!cur().ready) return DGPU_E_NODEVICE;
-    SlotLock L; Slot &sl = *L.s;
+    SLOT_ACQUIRE(L, sl);
     HIPCHK(hipSetDevice(cur().device));
     if (n == 0) { write_identity<HF>(out); return DGPU_OK; }
     int32_t rc;
@@ -716,7 +708,7 @@ int32_t bases_upload(const RawBases &rb, size_t n, uint64_t *handle, int kind) {
     if (!cur().ready) return DGPU_E_NODEVICE;
     void *p = nullptr;
     {
-        SlotLock L; Slot &sl = *L.s;
+        SLOT_ACQUIRE(L, sl);
         HIPCHK(hipSetDevice(cur().device));
         if (dev_malloc(&p, std::max<size_t>(n, 1) * C::AFF_STRIDE * 4) != hipSuccess) { (void)hipGetLastError(); return DGPU_E_OOM; }
         int32_t rc = ws_stage_bases<C>(sl, rb, n);
@@ -739,7 +731,7 @@ int32_t msm_handle(uint64_t bases, size_t offset, const uint64_t *scalars, size_
     HandleRef hb(bases);
     if (!hb.ok || (hb.h.kind != kind && hb.h.kind != kind + 9) || offset > hb.h.n || n > hb.h.n - offset) return DGPU_E_BADARG;
     CtxScope on_owner(hb.h.ctx);                    // run where the bases live
-    SlotLock L; Slot &sl = *L.s;
+    SLOT_ACQUIRE(L, sl);
     HIPCHK(hipSetDevice(cur().device));
     int32_t rc;
     if ((rc = sl.in_scalars.ensure(std::max<size_t>(n, 1) * 32))) return rc;
@@ -762,7 +754,7 @@ int32_t msm_resident(uint64_t bases, size_t boff, uint64_t scalars, size_t soff,
     if (!hb.ok || !hs.ok || (hb.h.kind != kind && hb.h.kind != kind + 9) || hs.h.kind != 3 || hb.h.ctx != hs.h.ctx) return DGPU_E_BADARG;    // both operands on one device
     if (boff > hb.h.n || n > hb.h.n - boff || soff > hs.h.n || n > hs.h.n - soff) return DGPU_E_BADARG;
     CtxScope on_owner(hb.h.ctx);
-    SlotLock L; Slot &sl = *L.s;
+    SLOT_ACQUIRE(L, sl);
     HIPCHK(hipSetDevice(cur().device));
     if (hb.h.kind == kind + 9) return msm_device_pre<C, HF>(sl, *(const PreTable *)hb.h.p, boff, (const uint32_t *)hs.h.p + soff * 8, n, out);
     return msm_device<C, HF>(sl, (const uint32_t *)hb.h.p + boff * C::AFF_STRIDE, (const uint32_t *)hs.h.p + soff * 8, n, out);

@@ -77,6 +77,14 @@ class DeviceR1cs:
             raise DockGpuError(rc, "dgpu_r1cs_upload")
         self.handle = h.value
 
+    def shape(self):
+        """(num_vars, num_inputs, num_constraints) as the library holds them (dgpu_r1cs_shape)"""
+        v, i, c = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+        rc = lib().dgpu_r1cs_shape(self.handle, C.byref(v), C.byref(i), C.byref(c))
+        if rc:
+            raise DockGpuError(rc, "dgpu_r1cs_shape")
+        return v.value, i.value, c.value
+
     def witness_map(self, assignment, montgomery=False, to_host=True, resident=False):
         """`assignment`: host scalars, or a DeviceScalars holding z on the circuit's device (dgpu_witness_map_r1cs_resident)"""
         D = 2

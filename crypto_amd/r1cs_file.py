@@ -47,14 +47,15 @@ class R1csFile:
                 lcs.append(terms)
             self.constraints.append(tuple(lcs))
         # section 3, wire2label (r1cs_reader.rs:91-101, read_map :219-238): n_wires u64 labels, wire 0 -> label 0
-        self.wire_mapping = []
-        if 3 in secs:
-            w, wsize = secs[3]
-            if wsize != self.n_wires * 8:
-                raise ValueError("Invalid map section size")
-            self.wire_mapping = list(struct.unpack_from("<%dQ" % self.n_wires, data, w))
-            if self.wire_mapping and self.wire_mapping[0] != 0:
-                raise ValueError("Wire 0 should always be mapped to 0")
+        # (the reference looks the section up unconditionally, :91-96: a file without it is an R1CSFileParsing error there, so it is one here)
+        if 3 not in secs:
+            raise ValueError("No section offset for wire2label type found")
+        w, wsize = secs[3]
+        if wsize != self.n_wires * 8:
+            raise ValueError("Invalid map section size")
+        self.wire_mapping = list(struct.unpack_from("<%dQ" % self.n_wires, data, w))
+        if self.wire_mapping and self.wire_mapping[0] != 0:
+            raise ValueError("Wire 0 should always be mapped to 0")
 
     @property
     def curve(self):

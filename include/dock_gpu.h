@@ -17,7 +17,8 @@
  *     give bit-identical output.
  *   - caller owns every buffer; nothing is retained after return except behind explicit handles.
  *   - thread-safe and re-entrant (the reference calls MSM from inside rayon workers,
- *     verifiable_encryption/src/tz_21/rdkgith.rs:140-147): calls on one device are serialised internally.
+ *     verifiable_encryption/src/tz_21/rdkgith.rs:140-147): up to six calls per device run concurrently (one
+ *     slot = stream pair + workspace each); callers beyond six wait for a slot.
  */
 #ifndef DOCK_GPU_H
 #define DOCK_GPU_H
@@ -249,8 +250,6 @@ int32_t dgpu_fp12_mul(const uint64_t a[72], const uint64_t b[72], uint64_t out[7
 int32_t dgpu_fp12_pow(const uint64_t a[72], const uint64_t e[4], uint64_t out[72]);
 /* prod_i a_i^{e_i}: the fold of `PairingOutput::mul_bigint` + `add_assign` in the aggregation verifier
  * (legogroth16/src/aggregation/groth16/verifier.rs:272-370); host threads, generic Fp12 arithmetic */
-/* Keccak-f[1600] in place: the permutation of the aggregation's Merlin / STROBE-128 transcript (merlin/src/strobe.rs:97-104) */
-int32_t dgpu_keccak_f1600(uint8_t state[200]);
 int32_t dgpu_fp12_multi_pow(const uint64_t *a /* n*72 */, const uint64_t *e /* n*4 */, size_t n, uint64_t out[72]);
 
 /* ---- fixed-base batch multiplication ----
@@ -304,6 +303,8 @@ int32_t dgpu_r1cs_upload(const uint64_t *a_rowptr, const uint32_t *a_cols, const
                          const uint64_t *c_rowptr, const uint32_t *c_cols, const uint64_t *c_vals, size_t c_nnz,
                          size_t num_vars, size_t num_inputs, size_t num_constraints, int32_t montgomery, uint64_t *handle);
 int32_t dgpu_r1cs_free(uint64_t handle);
+/* shape of a resident circuit (any pointer may be NULL); dgpu_legogroth16_prove refuses an (n_inst, num_vars) that disagrees with it */
+int32_t dgpu_r1cs_shape(uint64_t r1cs, size_t *num_vars, size_t *num_inputs, size_t *num_constraints);
 int32_t dgpu_witness_map_r1cs(uint64_t r1cs, const uint64_t *assignment, size_t num_vars, int32_t montgomery,
                               uint64_t *out_h, uint64_t *out_handle, size_t *out_len);
 /* the same with the assignment z already resident (a dgpu_scalars_upload handle of num_vars scalars on the circuit's device): ONE upload of z

@@ -81,6 +81,7 @@ def test_bad_arguments():
     assert L.dgpu_msm_g1(None, None, None, 5, out.ctypes.data_as(C.c_void_p)) == -3
     assert L.dgpu_msm_g1(None, None, None, 0, None) == -3
     assert L.dgpu_bases_free(12345) == -3
+    assert L.dgpu_r1cs_shape(12345, None, None, None) == -3
     # argument checks come before the device check on every entry point
     b = O.G1.generator().reshape(1, 12); sc = np.ones((1, 4), np.uint64); o = np.zeros(12, np.uint64); oi = np.zeros(1, np.uint8)
     p_ = lambda a: a.ctypes.data_as(C.c_void_p)
@@ -88,7 +89,6 @@ def test_bad_arguments():
     assert L.dgpu_g1_mul_add_batch(None, None, p_(sc), 4, None, None, 1, p_(o), p_(oi)) == -3
     assert L.dgpu_g1_scale_batch(p_(b), None, p_(sc), 2, None, 1, p_(o), p_(oi)) == -3
     assert L.dgpu_fp12_multi_pow(None, None, 2, p_(np.zeros(72, np.uint64))) == -3
-    assert L.dgpu_keccak_f1600(None) == -3
     assert L.dgpu_window_table_g1(None, C.byref(C.c_uint64(0))) == -3
     assert L.dgpu_multi_miller_loop(None, None, None, 3, p_(np.zeros(72, np.uint64))) == -3
     assert L.dgpu_multi_miller_loop_prepared(None, None, None, 3, p_(np.zeros(72, np.uint64))) == -3

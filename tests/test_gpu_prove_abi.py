@@ -57,6 +57,16 @@ def test_one_call_equals_the_python_schedule(m, cw):
         LG.prove_abi(pk, r, s, v, z, n_inst)
     with pytest.raises(ca.DockGpuError):
         LG.prove_abi(pk, r, s, v, z, len(z) + 1, circuit=dr)
+    # an n_inst that disagrees with the resident circuit's own num_inputs (it decides D and the gamma_abc / l offsets) is refused, not
+    # turned into a wrong proof or a short h buffer; the circuit's shape is readable through the ABI
+    assert dr.shape() == (len(cs["z"]), n_inst, len(cs["A"]))
+    if n_inst + cw + 1 <= len(z) and cw == 0:
+        with pytest.raises(ca.DockGpuError) as ei:
+            LG.prove_abi(pk, r, s, v, z, n_inst + 1, circuit=dr)
+        assert ei.value.code == -3
+    if n_inst > 1:
+        with pytest.raises(ca.DockGpuError):
+            LG.prove_abi(pk, r, s, v, z, n_inst - 1, circuit=dr)
     dr.free()
 
 

@@ -64,6 +64,23 @@ def test_reader_matches_reference_header_semantics():
         R1csFile(b"r1cx" + bytes(100))
 
 
+def test_reader_rejects_a_file_without_wire2label_like_the_reference():
+    """r1cs_reader.rs:91-96 looks section 3 up unconditionally (R1CSFileParsing when it has no offset / size): drop it from a good file"""
+    import struct
+    data = open(os.path.join(HERE, "golden", "r1cs", "multiply2.r1cs"), "rb").read()
+    (nsec,) = struct.unpack_from("<I", data, 8)
+    off, kept = 12, []
+    for _ in range(nsec):
+        typ, size = struct.unpack_from("<IQ", data, off)
+        if typ != 3:
+            kept.append(data[off:off + 12 + size])
+        off += 12 + size
+    assert len(kept) == nsec - 1
+    R1csFile(data)                                                      # the whole file parses
+    with pytest.raises(ValueError, match="wire2label"):
+        R1csFile(data[:8] + struct.pack("<I", nsec - 1) + b"".join(kept))
+
+
 def test_reference_held_known_answer_vector_bn_254():
     """The one known-answer vector the reference's tests hold for a row of SURVEY 8: the `bn_254` sample of
     legogroth16/src/circom/r1cs_reader.rs:283-340 (816 bytes of test DATA, stored as tests/golden/r1cs/bn254_sample.r1cs) and every value that test

@@ -99,6 +99,7 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary timings appended to the JSON line at N = 1")
     ap.add_argument("--inflight", type=int, default=6, help="MSM calls in flight per GPU (host threads; each call owns a stream + workspace slot)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-legs", action="store_true", help="skip secondary.cpu (the CPU path timed beside configs 3 and 4: about 10 s of host work)")
     ap.add_argument("--no-table", action="store_true", help="time the plain resident pipeline (no precomputed-multiples table)")
     ap.add_argument("--reduce-shift", type=int, default=-1, help="development: dgpu_set_reduce_shift (log2 buckets per lane of the bucket reduction; -1 = automatic)")
     args = ap.parse_args()
@@ -276,7 +277,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(ca, gen1, ks, scalars, db, ds, args.log2n, ncpu)
         if world == 1 and not args.no_secondary:
             try:
-                out["secondary"] = secondary_configs(args.log2n, ks, scalars, db, ds, pool)
+                out["secondary"] = secondary_configs(args.log2n, ks, scalars, db, ds, pool, cpu_legs=not (args.no_cpu_baseline or args.no_cpu_legs), ncpu=ncpu)
             except Exception as e:                      # never let the secondary numbers take the headline line down
                 out["secondary"] = {"error": repr(e)}
         print(json.dumps(out))
@@ -330,9 +331,25 @@ def cpu_baseline(ca, gen1, ks, scalars, db, ds, log2n, ncpu):
     return res
 
 
-def secondary_configs(log2n, ks, scalars, db, ds, pool):
+def secondary_configs(log2n, ks, scalars, db, ds, pool, cpu_legs=True, ncpu=1):
     """Everything BASELINE / SURVEY 8d ask for next to the headline, outside the timed region (N = 1 only).  Inputs are synthetic: bases are
-    device fixed-base products of seeded scalars (parity of these paths is the GPU test-suite's job, not this one's)."""
+    device fixed-base products of seeded scalars (parity of these paths is the GPU test-suite's job, not this one's).
+
+    cpu_legs: res["cpu"] = the CPU path (the oracle: arkworks-shaped code, `kind: "port"`) timed on this box's host cores beside configs 3 and 4
+    — G2 MSM, the 1024-pair Miller loop, one proof verified, the witness map, the five MSMs of a proof — each cross-checked bit for bit against
+    what the GPU returned for the same inputs.  The oracle is only the timed baseline and the checker here, never the thing measured as `value`."""
+    O = None
+    if cpu_legs:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle_c as O                       # noqa: N812
+    cpu = {}
+
+    def cpu_time(fn):
+        t0 = time.perf_counter(); r = fn(); return r, (time.perf_counter() - t0) * 1e3
+
+    def win_threads(k):                            # arkworks' rayon structure: one task per window (msm_bigint), so at most `windows` busy cores
+        c = O.window_c(k)
+        return max(1, min(ncpu, (255 + c - 1) // c))
     import crypto_amd as ca
     from crypto_amd import fixed_base as FB, qap, serde, legogroth16 as LG
     gen1, _ = serde.deserialize(ca.G1, bytes.fromhex(G1_GEN_COMPRESSED))
@@ -440,7 +457,11 @@ def secondary_configs(log2n, ks, scalars, db, ds, pool):
         res["g1_2p21_per_gpu_share"] = {"error": repr(e)}
     # -- BASELINE config 3: G2 MSM at the same n (plain and table), 1024-pair Miller loop, final exponentiation
     with FB.WindowTable(ca.G2, gen2[0]) as t2, FB.WindowTable(ca.G1, gen1[0]) as t1:
-        db2 = t2.multiply_many_to_bases(seeded_scalars(0x5EED0003, n))
+        if cpu_legs:
+            g2_host, _ = t2.multiply_many(seeded_scalars(0x5EED0003, n))
+            db2 = ca.DeviceBases(ca.G2, g2_host)
+        else:
+            db2 = t2.multiply_many_to_bases(seeded_scalars(0x5EED0003, n))
         res["g2_msm_plain_ms"] = round(timed(lambda: db2.msm_resident(ds), 3, warm=7), 3)     # (warm-ups: one per slot, their workspaces grow on the first G2 call)
         db2.precompute()
         res["g2_msm_ms"] = round(timed(lambda: db2.msm_resident(ds), 3, warm=7), 3)
@@ -459,6 +480,13 @@ def secondary_configs(log2n, ks, scalars, db, ds, pool):
                                        "hbm_roofline": {"achieved_GB_s": round(224.0 * n / (acc2 * 1e-3) / 1e9, 1), "frac": round(224.0 * n / (acc2 * 1e-3) / 1e9 / 8000.0, 5), "note": "algorithmic 224 B/term (SURVEY 8d)"}}
         res["g2_msm_ms_per_msm_4_in_flight"] = round(thr4(lambda: db2.msm_resident(ds), 8), 3)
         res["g2_msm_per_s"] = round(1e3 / res["g2_msm_ms_per_msm_4_in_flight"], 2)
+        if cpu_legs:
+            thr = win_threads(n)
+            ref2, ms2 = cpu_time(lambda: O.G2.msm(g2_host, scalars, threads=thr))
+            same2 = bool((O.G2.to_affine(ref2)[0] == O.G2.to_affine(db2.msm_resident(ds))[0]).all())
+            cpu["g2_msm"] = {"cpu_ms": round(ms2, 1), "gpu_ms": res["g2_msm_ms"], "x": round(ms2 / res["g2_msm_ms"], 1), "x_4_in_flight": round(ms2 / res["g2_msm_ms_per_msm_4_in_flight"], 1),
+                             "cores": thr, "bit_exact_vs_gpu": same2, "sample": "one n=2^%d G2 MSM, one thread per window (%d windows) of %d logical CPUs" % (log2n, thr, ncpu)}
+            del g2_host
         P, _ = t1.multiply_many(seeded_scalars(0x5EED0005, 1024)); Q, _ = t2.multiply_many(seeded_scalars(0x5EED0006, 1024))
     f = ca.multi_miller_loop(P, Q)
     res["miller_loop_1024_pairs_ms"] = round(timed(lambda: ca.multi_miller_loop(P, Q), 20, warm=3), 3)      # (millisecond calls: 20 of them after 3 warm-ups)
@@ -477,6 +505,18 @@ def secondary_configs(log2n, ks, scalars, db, ds, pool):
     res["g2_prepare_1024_ms"] = round(timed(lambda: pairing.G2Prepared.from_affine(Q), 10, warm=2), 3)
     res["miller_loop_1024_prepared_pairs_ms"] = round(timed(lambda: pairing.multi_miller_loop(P, pc), 20, warm=3), 3)
     res["final_exponentiation_ms"] = round(timed(lambda: ca.final_exponentiation(f), 20, warm=3), 3)
+    if cpu_legs:
+        thr_ml = max(1, min(ncpu, 64, 256))                                                  # 256 chunks of 4 pairs (ark-ec's rayon chunks_mut(4)): every core has work
+        O.multi_miller_loop(P[:8], Q[:8], threads=thr_ml)
+        (fc, ms_ml) = min((cpu_time(lambda: O.multi_miller_loop(P, Q, threads=thr_ml)) for _ in range(3)), key=lambda t: t[1])
+        cpu["miller_1024"] = {"cpu_ms": round(ms_ml, 2), "gpu_ms": res["miller_loop_1024_pairs_ms"], "x": round(ms_ml / res["miller_loop_1024_pairs_ms"], 2),
+                              "x_6_in_flight": round(ms_ml / res["miller_loop_1024_pairs_ms_per_call_6_in_flight"], 2), "cores": thr_ml, "bit_exact_vs_gpu": bool((fc == f).all()),
+                              "sample": "multi_miller_loop over 1024 affine pairs (G2Prepared::from inside, like the GPU call), chunks of 4 pairs over %d threads, best of 3" % thr_ml}
+        (fc1, ms_ml1) = cpu_time(lambda: O.multi_miller_loop(P, Q, threads=1))
+        cpu["miller_1024"]["one_thread_ms"] = round(ms_ml1, 1)
+        (ge, ms_fe) = min((cpu_time(lambda: O.final_exponentiation(f)) for _ in range(5)), key=lambda t: t[1])
+        cpu["final_exponentiation"] = {"cpu_ms": round(ms_fe, 3), "gpu_lib_ms": res["final_exponentiation_ms"], "cores": 1, "bit_exact_vs_gpu": bool((ge == ca.final_exponentiation(f)).all()),
+                                       "sample": "one final exponentiation on one core (host code on both sides: the library's runs on the host too, SURVEY 8a6)"}
     # -- the verifier's side of the same path (verifier.rs:62-99, randomized_pairing_check.rs): 1024 Groth16-shaped proofs with known discrete
     #    logs (a_i b_i = alpha beta + (g0 + x_i g1 + d_i) gamma + c_i delta, so every one of them verifies), one at a time and batched
     from crypto_amd import legogroth16 as LGv
@@ -496,6 +536,23 @@ def secondary_configs(log2n, ks, scalars, db, ds, pool):
     pubs_v = [lim([x]) for x in xv]
     assert LGv.verify_proof(pvkv, proofs_v[0], pubs_v[0]) and not LGv.verify_proof(pvkv, proofs_v[0], pubs_v[1])
     res["verify_one_proof_ms"] = round(timed(lambda: LGv.verify_proof(pvkv, proofs_v[1], pubs_v[1]), 20, warm=3), 3)
+    if cpu_legs:
+        # verifier.rs:62-99 on one core (three pairs are one rayon chunk): d = gamma_abc[0] + x gamma_abc[1] + proof.d, the Miller loop over
+        # [(A, B affine), (C, -delta prepared), (d, -gamma prepared)], the final exponentiation, the comparison with e(alpha, beta)
+        pre_cpu = np.stack([O.g2_prepare(LGv._neg_affine(ca.G2, V_[2])).reshape(-1), O.g2_prepare(LGv._neg_affine(ca.G2, V_[1])).reshape(-1)])   # -delta, -gamma: prepared once per key
+        ab_cpu = O.final_exponentiation(O.multi_miller_loop(K_[0].reshape(1, 12), V_[0].reshape(1, 24)))
+
+        def cpu_verify(pr, pub):
+            acc = O.G1.add(np.concatenate([K_[1], pairing.FP_ONE_MONT]), O.G1.mul(K_[2], pub[0]))
+            acc = O.G1.add(acc, np.concatenate([pr["d"], pairing.FP_ONE_MONT]))
+            dpt, _ = O.G1.to_affine(acc)
+            fm = O.multi_miller_loop_mixed(pr["a"].reshape(1, 12), pr["b"].reshape(1, 24), np.stack([pr["c"], dpt]), pre_cpu, threads=1)
+            return bool((O.final_exponentiation(fm) == ab_cpu).all())
+        assert cpu_verify(proofs_v[1], pubs_v[1]) and not cpu_verify(proofs_v[1], pubs_v[2])
+        (okv, ms_v) = min((cpu_time(lambda: cpu_verify(proofs_v[1], pubs_v[1])) for _ in range(5)), key=lambda t: t[1])
+        cpu["verify_one"] = {"cpu_ms": round(ms_v, 3), "gpu_ms": res["verify_one_proof_ms"], "x": round(ms_v / res["verify_one_proof_ms"], 2), "cores": 1,
+                             "bit_exact_vs_gpu": bool((ab_cpu == pvkv["alpha_g1_beta_g2"]).all()) and okv,
+                             "sample": "verify_proof of one LegoGroth16 proof (one public input; -delta, -gamma prepared in the key) on ONE core: three pairs are a single rayon chunk in ark-ec, best of 5"}
     assert LGv.verify_proofs_batch(pvkv, proofs_v, pubs_v, 0x5EED0025) and LGv.verify_proofs_batch_merged(pvkv, proofs_v, pubs_v, 0x5EED0026)
     swapped = list(proofs_v); swapped[7] = dict(swapped[7], c=proofs_v[8]["c"])
     assert not LGv.verify_proofs_batch_merged(pvkv, swapped, pubs_v, 0x5EED0027)
@@ -534,6 +591,14 @@ def secondary_configs(log2n, ks, scalars, db, ds, pool):
         _, dh = circ.witness_map(z, to_host=False, resident=True)
         dh.free()
     res["witness_map_ms"] = round(timed(wm, 3), 3)
+    if cpu_legs:
+        mats_cpu = ((a_rp, a_cl, a_vl), (a_rp, b_cl, a_vl), (c_rp, c_cl, np.repeat(one, 2 * m + 1, 0)))
+        thr_wm = max(1, min(ncpu, 64))
+        h_cpu, ms_wm = cpu_time(lambda: O.witness_map(mats_cpu, z, 2, m + 1, threads=thr_wm))
+        h_gpu, _ = circ.witness_map(z, to_host=True)
+        cpu["witness_map"] = {"cpu_ms": round(ms_wm, 1), "gpu_ms": res["witness_map_ms"], "x": round(ms_wm / res["witness_map_ms"], 1), "cores": thr_wm, "bit_exact_vs_gpu": bool((h_cpu == h_gpu).all()),
+                              "sample": "r1cs_to_qap witness map, D = 2^%d (three sparse mat-vecs, 3 iFFT + 3 coset FFT + pointwise + coset iFFT), rows / butterflies split over %d threads" % (log2n, thr_wm)}
+        del h_gpu
     ca.prof.enable(True); ca.prof.reset()
     for _ in range(3):
         wm()
@@ -551,11 +616,21 @@ def secondary_configs(log2n, ks, scalars, db, ds, pool):
         small1, _ = t1.multiply_many(seeded_scalars(0x5EED0010, 8 + 2 + cw)); small2, _ = t2.multiply_many(seeded_scalars(0x5EED0011, 4))
         # the queries that meet the witness take DGPU_TABLE_C_WITNESS (fewer buckets to reduce per MSM: include/dock_gpu.h), the h query the automatic width
         wc_ = ca.TABLE_C_WITNESS
-        qa = t1.multiply_many_to_bases(seeded_scalars(0x5EED0012, V + 1)).precompute(wc_)
-        qb1 = t1.multiply_many_to_bases(seeded_scalars(0x5EED0013, V + 1)).precompute(wc_)
-        qb2 = t2.multiply_many_to_bases(seeded_scalars(0x5EED0014, V + 1)).precompute(wc_)
-        qh = t1.multiply_many_to_bases(seeded_scalars(0x5EED0015, n - 1)).precompute()
-        ql = t1.multiply_many_to_bases(seeded_scalars(0x5EED0016, m + 1 - cw)).precompute(wc_)
+        hostq = {}
+
+        def query(tab, curve, name, seed, k, width=None):
+            """a proving-key query of k points: straight into HBM, or (CPU legs) through a host copy the CPU path multiplies too"""
+            if cpu_legs:
+                hostq[name], _ = tab.multiply_many(seeded_scalars(seed, k))
+                q = ca.DeviceBases(curve, hostq[name])
+            else:
+                q = tab.multiply_many_to_bases(seeded_scalars(seed, k))
+            return q.precompute(width) if width else q.precompute()
+        qa = query(t1, ca.G1, "a", 0x5EED0012, V + 1, wc_)
+        qb1 = query(t1, ca.G1, "b1", 0x5EED0013, V + 1, wc_)
+        qb2 = query(t2, ca.G2, "b2", 0x5EED0014, V + 1, wc_)
+        qh = query(t1, ca.G1, "h", 0x5EED0015, n - 1)
+        ql = query(t1, ca.G1, "l", 0x5EED0016, m + 1 - cw, wc_)
     vk = LG.VerifyingKey(small1[0], small2[0], small2[1], small2[2], small1[8:8 + 2 + cw], small1[1], cw)
     pk = LG.ProvingKey.from_device(vk, small1[2], small1[3], small1[4], small1[5], small1[6], small2[3], qa, qb1, qb2, qh, ql)
 
@@ -574,6 +649,33 @@ def secondary_configs(log2n, ks, scalars, db, ds, pool):
     assert all((q[k] == p0[k]).all() for q in many for k in p0)
     res["prove_2p20_ms_per_proof_4_in_flight"] = round(ms4, 2)
     res["prove_constraints_per_s_4_in_flight"] = round((m + 1) / (ms4 * 1e-3), 1)
+    if cpu_legs:
+        # the reference's prover on the host cores (prover.rs:284-359): witness map, then the five MSMs ONE AFTER THE OTHER (each one rayon-parallel
+        # over its windows), in the reference's order; the O(1) finish is left out on the CPU side (it is inside the GPU number).  Every MSM is
+        # cross-checked against the GPU's result for the same query and scalars.
+        n_aux, aux_at = (m + 1) - cw, 1 + 1 + cw
+        dzc = ca.DeviceScalars(z)
+        _, dhc = circ.witness_map(dzc, to_host=False, resident=True)
+        legs = [("h_query MSM (D - 1 terms)", O.G1, hostq["h"], h_cpu[:n - 1], lambda: qh.msm_resident(dhc, n=min(qh.n, dhc.n))),
+                ("l_query MSM", O.G1, hostq["l"][:n_aux], z[aux_at:aux_at + n_aux], lambda: ql.msm_resident(dzc, n=min(ql.n, n_aux), scalar_offset=aux_at)),
+                ("a_query MSM", O.G1, hostq["a"][1:], z[1:], lambda: qa.msm_resident(dzc, n=V, base_offset=1, scalar_offset=1)),
+                ("b_g1_query MSM", O.G1, hostq["b1"][1:], z[1:], lambda: qb1.msm_resident(dzc, n=V, base_offset=1, scalar_offset=1)),
+                ("b_g2_query MSM (G2)", O.G2, hostq["b2"][1:], z[1:], lambda: qb2.msm_resident(dzc, n=V, base_offset=1, scalar_offset=1))]
+        spans_cpu = {"R1CS to QAP witness map": round(ms_wm, 1)}
+        same_all = cpu["witness_map"]["bit_exact_vs_gpu"]
+        tot_cpu = ms_wm
+        for name, G_, bq, sq, gpu_fn in legs:
+            k_ = min(len(bq), len(sq))
+            thr = win_threads(k_)
+            rj, msj = cpu_time(lambda: G_.msm(bq[:k_], sq[:k_], threads=thr))
+            same_all = same_all and bool((G_.to_affine(rj)[0] == G_.to_affine(gpu_fn())[0]).all())
+            spans_cpu[name] = round(msj, 1); tot_cpu += msj
+        dhc.free(); dzc.free()
+        cpu["prove"] = {"cpu_ms": round(tot_cpu, 1), "gpu_ms": res["prove_2p20_ms"], "x": round(tot_cpu / res["prove_2p20_ms"], 1), "x_4_in_flight": round(tot_cpu / ms4, 1),
+                        "cpu_constraints_per_s": round((m + 1) / (tot_cpu * 1e-3), 1), "gpu_constraints_per_s": res["prove_constraints_per_s"],
+                        "cores": max(win_threads(V), thr_wm), "bit_exact_vs_gpu": same_all, "spans_cpu_ms": spans_cpu,
+                        "sample": "one 2^%d-constraint LegoGroth16 proof: witness map on %d threads + the five MSMs sequentially, each with one thread per window (<= %d busy cores), same Groth16-like witness as the GPU leg; O(1) finish not included on the CPU side" % (log2n, thr_wm, win_threads(V))}
+        hostq.clear()
     # the reference's timer spans (prover.rs:284-369, :578), each stage alone and in the reference's order (one call in flight)
     from crypto_amd import sharded as SH
     dz = ca.DeviceScalars(z)
@@ -601,6 +703,10 @@ def secondary_configs(log2n, ks, scalars, db, ds, pool):
     res["prove_note"] = ("LegoGroth16 create_proof (witness map + 4 G1 MSMs + 1 G2 MSM + finish), m + 1 = %d constraints, D = 2^%d, Groth16-like witness, "
                          "circuit and key (precomputed tables: window width %d for the a / b / l queries, automatic = 20 for the h query) resident, assignment uploaded per proof; the A / B-in-G1 / B-in-G2 / l MSMs share one partition sort" % (m + 1, log2n, ca.TABLE_C_WITNESS))
     res["note"] = "n = D = 2^%d; one call in flight unless stated; host-visible wall time per call" % log2n
+    if cpu_legs:
+        cpu["note"] = ("CPU path = oracle/ (arkworks-shaped C: the same window rule, signed digits, chunks-of-4 Miller loop, final-exponentiation chain; kind 'port', %d logical CPUs on this box); "
+                       "x = cpu_ms / gpu_ms for one call in flight.  See cpu_baseline.calibration for how this C compares with ark-ff's assembly backend." % ncpu)
+        res["cpu"] = cpu
     return res
 
 

@@ -414,6 +414,104 @@ API int orc_witness_map(const uint64_t *a_rowptr, const uint32_t *a_cols, const 
     return logn;
 }
 
+/* The same witness map on `threads` host threads (the reference's ark-poly runs its transforms on rayon under the `parallel` feature,
+ * legogroth16/Cargo.toml; r1cs_to_qap.rs:165-185 evaluates the rows with cfg_iter!): rows of the three matrices, the twiddle table, every
+ * butterfly stage and every pointwise pass are split over the threads.  Used by bench.py's CPU legs (secondary.cpu.witness_map / .prove);
+ * tests/test_oracle_golden.py checks it against the one-thread function above. */
+typedef struct { int kind, tid, T, logn, s; size_t n; fr *a, *b, *c; const fr *tw, *z; fr g, k; const uint64_t *rp, *vals; const uint32_t *cols; uint64_t *out; } wm_job;
+static void wm_range(const wm_job *J, size_t total, size_t *lo, size_t *hi) { *lo = total * (size_t)J->tid / (size_t)J->T; *hi = total * (size_t)(J->tid + 1) / (size_t)J->T; }
+static void fr_pow_u64(fr *r, const fr *a, uint64_t e) { uint64_t ee[1] = {e}; fr_pow(r, a, ee, 1); }
+static void *wm_worker(void *arg) {
+    const wm_job *J = (const wm_job *)arg; size_t lo, hi;
+    switch (J->kind) {
+    case 0: {   /* twiddle table tw[i] = w^i, i < n/2 (J->g = w) */
+        wm_range(J, J->n / 2, &lo, &hi); if (lo >= hi) break;
+        fr p; fr_pow_u64(&p, &J->g, lo); fr *tw = (fr *)J->tw;
+        for (size_t i = lo; i < hi; i++) { tw[i] = p; fr_mul(&p, &p, &J->g); }
+    } break;
+    case 1: {   /* bit reversal (each swap is done by the thread that owns the smaller index) */
+        wm_range(J, J->n, &lo, &hi);
+        for (size_t i = lo; i < hi; i++) { size_t j = 0; for (int b = 0; b < J->logn; b++) if (i >> b & 1) j |= (size_t)1 << (J->logn - 1 - b); if (i < j) { fr t = J->a[i]; J->a[i] = J->a[j]; J->a[j] = t; } }
+    } break;
+    case 2: {   /* butterflies of stage s: butterfly q = (block q / half, j = q % half) */
+        const size_t half = (size_t)1 << (J->s - 1), stride = J->n >> J->s;
+        wm_range(J, J->n / 2, &lo, &hi);
+        for (size_t q = lo; q < hi; q++) {
+            const size_t j = q & (half - 1), k = (q >> (J->s - 1)) << J->s;
+            fr t, u = J->a[k + j]; fr_mul(&t, &J->tw[j * stride], &J->a[k + j + half]); fr_add(&J->a[k + j], &u, &t); fr_sub(&J->a[k + j + half], &u, &t);
+        }
+    } break;
+    case 3: {   /* a[i] *= k * g^i */
+        wm_range(J, J->n, &lo, &hi); if (lo >= hi) break;
+        fr p; fr_pow_u64(&p, &J->g, lo); fr_mul(&p, &p, &J->k);
+        for (size_t i = lo; i < hi; i++) { fr_mul(&J->a[i], &J->a[i], &p); fr_mul(&p, &p, &J->g); }
+    } break;
+    case 4: {   /* a = (a b - c) k */
+        wm_range(J, J->n, &lo, &hi);
+        for (size_t i = lo; i < hi; i++) { fr t; fr_mul(&t, &J->a[i], &J->b[i]); fr_sub(&t, &t, &J->c[i]); fr_mul(&J->a[i], &t, &J->k); }
+    } break;
+    case 5: {   /* rows of one CSR matrix */
+        wm_range(J, J->n, &lo, &hi);
+        for (size_t i = lo; i < hi; i++) {
+            fr acc; memset(&acc, 0, sizeof acc);
+            for (uint64_t k = J->rp[i]; k < J->rp[i + 1]; k++) { fr c, t; fr_mont_mul(c.l, J->vals + 4 * k, FR_R2); fr_mul(&t, &c, &J->z[J->cols[k]]); fr_add(&acc, &acc, &t); }
+            J->a[i] = acc;
+        }
+    } break;
+    case 6: {   /* canonical -> Montgomery (out = NULL) or Montgomery -> canonical */
+        wm_range(J, J->n, &lo, &hi);
+        const uint64_t one[4] = {1, 0, 0, 0};
+        for (size_t i = lo; i < hi; i++) { if (J->out) fr_mont_mul(J->out + 4 * i, J->a[i].l, one); else fr_mont_mul(J->a[i].l, J->vals + 4 * i, FR_R2); }
+    } break;
+    }
+    return NULL;
+}
+static void wm_run(wm_job proto, int T) {
+    pthread_t th[64]; wm_job jobs[64];
+    for (int t = 0; t < T; t++) { jobs[t] = proto; jobs[t].tid = t; jobs[t].T = T; }
+    for (int t = 1; t < T; t++) pthread_create(&th[t], NULL, wm_worker, &jobs[t]);
+    wm_worker(&jobs[0]);
+    for (int t = 1; t < T; t++) pthread_join(th[t], NULL);
+}
+/* in-place transform on T threads with the twiddle table of w (forward) or 1/w (inverse); the inverse's 1/n is folded into the caller's scaling */
+static void fr_ntt_mt(fr *a, int logn, const fr *tw, int T) {
+    wm_job J; memset(&J, 0, sizeof J); J.n = (size_t)1 << logn; J.logn = logn; J.a = a; J.tw = tw;
+    J.kind = 1; wm_run(J, T);
+    J.kind = 2; for (int s = 1; s <= logn; s++) { J.s = s; wm_run(J, T); }
+}
+API int orc_witness_map_mt(const uint64_t *a_rowptr, const uint32_t *a_cols, const uint64_t *a_vals,
+                           const uint64_t *b_rowptr, const uint32_t *b_cols, const uint64_t *b_vals,
+                           const uint64_t *c_rowptr, const uint32_t *c_cols, const uint64_t *c_vals,
+                           const uint64_t *z_canon, size_t num_vars, size_t num_inputs, size_t num_constraints, int threads, uint64_t *out_h) {
+    int T = threads < 1 ? 1 : threads > 64 ? 64 : threads;
+    int logn = 0; while (((size_t)1 << logn) < num_constraints + num_inputs) logn++;
+    size_t D = (size_t)1 << logn;
+    fr *z = (fr *)malloc(sizeof(fr) * num_vars), *a = (fr *)calloc(D, sizeof(fr)), *b = (fr *)calloc(D, sizeof(fr)), *c = (fr *)calloc(D, sizeof(fr));
+    fr *twf = (fr *)malloc(sizeof(fr) * (D / 2 + 1)), *twi = (fr *)malloc(sizeof(fr) * (D / 2 + 1));
+    wm_job J; memset(&J, 0, sizeof J);
+    J.kind = 6; J.n = num_vars; J.a = z; J.vals = z_canon; J.out = NULL; wm_run(J, T);
+    const uint64_t *rps[3] = {a_rowptr, b_rowptr, c_rowptr}, *vls[3] = {a_vals, b_vals, c_vals}; const uint32_t *cls[3] = {a_cols, b_cols, c_cols};
+    fr *arr[3] = {a, b, c};
+    for (int k = 0; k < 3; k++) { memset(&J, 0, sizeof J); J.kind = 5; J.n = num_constraints; J.a = arr[k]; J.rp = rps[k]; J.cols = cls[k]; J.vals = vls[k]; J.z = z; wm_run(J, T); }
+    for (size_t j = 0; j < num_inputs; j++) a[num_constraints + j] = z[j];
+    fr w, wi, g, gi, ninv; fr_root_of_unity(&w, logn); fr_inv(&wi, &w); fr_from_u64(&g, 7); fr_inv(&gi, &g); fr_from_u64(&ninv, D); fr_inv(&ninv, &ninv);
+    memset(&J, 0, sizeof J); J.kind = 0; J.n = D; J.tw = twf; J.g = w; wm_run(J, T);
+    J.tw = twi; J.g = wi; wm_run(J, T);
+    for (int k = 0; k < 3; k++) {
+        fr_ntt_mt(arr[k], logn, twi, T);                                                                        /* ifft (1/n below) */
+        memset(&J, 0, sizeof J); J.kind = 3; J.n = D; J.a = arr[k]; J.g = g; J.k = ninv; wm_run(J, T);          /* coset shift, x 1/n */
+        fr_ntt_mt(arr[k], logn, twf, T);                                                                        /* coset fft */
+    }
+    fr gd = g; for (int k = 0; k < logn; k++) fr_mul(&gd, &gd, &gd);
+    fr zi; fr_sub(&zi, &gd, &FR_ONE_M); fr_inv(&zi, &zi);                                                        /* 1 / Z(g) = 1 / (g^D - 1) */
+    memset(&J, 0, sizeof J); J.kind = 4; J.n = D; J.a = a; J.b = b; J.c = c; J.k = zi; wm_run(J, T);
+    fr_ntt_mt(a, logn, twi, T);
+    memset(&J, 0, sizeof J); J.kind = 3; J.n = D; J.a = a; J.g = gi; J.k = ninv; wm_run(J, T);                  /* coset ifft */
+    memset(&J, 0, sizeof J); J.kind = 6; J.n = D; J.a = a; J.out = out_h; wm_run(J, T);
+    free(z); free(a); free(b); free(c); free(twf); free(twi);
+    return logn;
+}
+
 /* ---- pairings ---- */
 API void orc_g2_prepare(const uint64_t q[24], uint64_t *out /* 68*36 u64 */) { g2_prepare((const g2_aff *)q, (ell_coeff *)out); }
 API void orc_fp12_mul(const uint64_t a[72], const uint64_t b[72], uint64_t out[72]) { fp12 r; fp12_mul(&r, (const fp12 *)a, (const fp12 *)b); memcpy(out, &r, sizeof r); }
@@ -448,6 +546,32 @@ API void orc_multi_miller_loop(const uint64_t *p, const uint64_t *q, const uint8
     fp12 f; fp12_one(&f);
     for (int i = 0; i < nch; i++) fp12_mul(&f, &f, &partial[i]);
     fp12_conj(&f, &f);   /* x < 0 */
+    memcpy(out, &f, sizeof f);
+    free(partial); free(co); free(ps);
+}
+/* The verifier's call (legogroth16/src/verifier.rs:69-76): proof.b enters as an affine point (prepared inside the call), -delta and -gamma are
+ * G2Prepared already (PreparedVerifyingKey, verifier.rs:22-23).  coeffs: n_prep x 68 x 3 Fp2 as orc_g2_prepare writes them. */
+API void orc_multi_miller_loop_mixed(const uint64_t *p_aff, const uint64_t *q_aff, size_t n_aff, const uint64_t *p_prep, const uint64_t *coeffs, size_t n_prep,
+                                     int threads, uint64_t out[72]) {
+    pthread_once(&ml_once, ml_init);
+    size_t m = n_aff + n_prep;
+    g1_aff *ps = (g1_aff *)malloc(sizeof(g1_aff) * (m + 1));
+    ell_coeff *co = (ell_coeff *)malloc(sizeof(ell_coeff) * N_COEFF * (m + 1));
+    for (size_t i = 0; i < n_aff; i++) { ps[i] = *(const g1_aff *)(p_aff + 12 * i); g2_prepare((const g2_aff *)(q_aff + 24 * i), co + i * N_COEFF); }
+    for (size_t i = 0; i < n_prep; i++) { ps[n_aff + i] = *(const g1_aff *)(p_prep + 12 * i); memcpy(co + (n_aff + i) * N_COEFF, coeffs + i * N_COEFF * 36, sizeof(ell_coeff) * N_COEFF); }
+    int nch = (int)((m + 3) / 4);
+    fp12 *partial = (fp12 *)malloc(sizeof(fp12) * (nch + 1));
+    volatile int next = 0;
+    ml_job J = {ps, co, m, partial, &next, nch};
+    if (threads <= 1 || nch <= 1) ml_worker(&J);
+    else {
+        pthread_t th[64]; if (threads > 64) threads = 64; if (threads > nch) threads = nch;
+        for (int t = 0; t < threads; t++) pthread_create(&th[t], NULL, ml_worker, &J);
+        for (int t = 0; t < threads; t++) pthread_join(th[t], NULL);
+    }
+    fp12 f; fp12_one(&f);
+    for (int i = 0; i < nch; i++) fp12_mul(&f, &f, &partial[i]);
+    fp12_conj(&f, &f);
     memcpy(out, &f, sizeof f);
     free(partial); free(co); free(ps);
 }

@@ -170,6 +170,41 @@ def multi_miller_loop(p, q, skip=None, threads=1):
     return out
 
 
+def multi_miller_loop_mixed(p_aff, q_aff, p_prep, coeffs, threads=1):
+    """the verifier's call (verifier.rs:69-76): affine (P, Q) pairs + pairs whose G2 member is already `G2Prepared` (g2_prepare output)"""
+    p_aff = np.ascontiguousarray(p_aff, dtype=np.uint64).reshape(-1, 12)
+    q_aff = np.ascontiguousarray(q_aff, dtype=np.uint64).reshape(-1, 24)
+    p_prep = np.ascontiguousarray(p_prep, dtype=np.uint64).reshape(-1, 12)
+    coeffs = np.ascontiguousarray(coeffs, dtype=np.uint64).reshape(len(p_prep), 68 * 36)
+    assert len(p_aff) == len(q_aff)
+    out = u64(72)
+    lib().orc_multi_miller_loop_mixed(_p(p_aff), _p(q_aff), C.c_size_t(len(p_aff)), _p(p_prep), _p(coeffs), C.c_size_t(len(p_prep)), C.c_int(threads), _p(out))
+    return out
+
+
+def witness_map(mats, z, num_inputs, num_constraints, threads=1):
+    """LibsnarkReduction::witness_map_from_matrices (r1cs_to_qap.rs:150-210).  mats: three CSR triples (rowptr u64, cols u32, vals (nnz, 4) canonical);
+    z: (num_vars, 4) canonical.  Returns the D canonical coefficients of h.  threads > 1: the threaded form (same values)."""
+    z = np.ascontiguousarray(z, dtype=np.uint64).reshape(-1, 4)
+    D = 1
+    while D < num_constraints + num_inputs:
+        D *= 2
+    out = u64((D, 4))
+    args, keep = [], []
+    for rp, cl, vl in mats:
+        rp = np.ascontiguousarray(rp, dtype=np.uint64); cl = np.ascontiguousarray(cl, dtype=np.uint32); vl = np.ascontiguousarray(vl, dtype=np.uint64)
+        keep += [rp, cl, vl]
+        args += [_p(rp), _p(cl), _p(vl)]
+    L = lib()
+    if threads > 1:
+        L.orc_witness_map_mt.restype = C.c_int
+        L.orc_witness_map_mt(*args, _p(z), C.c_size_t(len(z)), C.c_size_t(num_inputs), C.c_size_t(num_constraints), C.c_int(threads), _p(out))
+    else:
+        L.orc_witness_map.restype = C.c_int
+        L.orc_witness_map(*args, _p(z), C.c_size_t(len(z)), C.c_size_t(num_inputs), C.c_size_t(num_constraints), _p(out))
+    return out
+
+
 def final_exponentiation(f):
     f = np.ascontiguousarray(f, dtype=np.uint64)
     out = u64(72)

@@ -126,6 +126,22 @@ def test_oracle_ntt_and_witness_map_vs_naive_bigint():
             args += [p(rp), p(cl), p(vl)]
         L.orc_witness_map(*args, p(LS.scalars(cs["z"])), C.c_size_t(len(cs["z"])), C.c_size_t(cs["n_inst"]), C.c_size_t(cs["n_cons"]), p(out))
         assert [O.limbs_to_int(x) for x in out] == LS.witness_map(cs)
+        # the threaded form bench.py times as the CPU leg of the witness map / prover: the same coefficients on any thread count
+        for T in (2, 3, 8):
+            assert (O.witness_map(mats, LS.scalars(cs["z"]), cs["n_inst"], cs["n_cons"], threads=T) == out).all(), (m, T)
+
+
+def test_oracle_mixed_miller_loop_equals_the_affine_one():
+    """orc_multi_miller_loop_mixed (the verifier's call shape: some G2 members already prepared) == orc_multi_miller_loop on the same pairs"""
+    pr = U.load("pairing")
+    k = O.rand_scalars(41, 7)
+    P = np.stack([O.G1.to_affine(O.G1.mul(O.G1.generator(), k[i]))[0] for i in range(7)])
+    Q = np.stack([O.G2.to_affine(O.G2.mul(O.G2.generator(), k[6 - i]))[0] for i in range(7)])
+    ref = O.multi_miller_loop(P, Q)
+    for na in (0, 1, 3, 7):
+        co = np.stack([O.g2_prepare(q).reshape(-1) for q in Q[na:]]) if na < 7 else np.zeros((0, 68 * 36), np.uint64)
+        for T in (1, 2):
+            assert (O.multi_miller_loop_mixed(P[:na], Q[:na], P[na:], co, threads=T) == ref).all(), (na, T)
 
 
 def test_final_exponentiation_chain_equals_its_definition():

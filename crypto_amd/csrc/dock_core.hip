@@ -91,6 +91,7 @@ int32_t dgpu_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuc
 static void destroy_slot(Slot &sl) {
     if (sl.stream) (void)hipStreamSynchronize(sl.stream);
     if (sl.cstream) (void)hipStreamSynchronize(sl.cstream);
+    if (sl.xstream) { (void)hipStreamSynchronize(sl.xstream); (void)hipStreamDestroy(sl.xstream); sl.xstream = nullptr; }
     sl.release_all();
     if (sl.stream) (void)hipStreamDestroy(sl.stream);
     if (sl.cstream) (void)hipStreamDestroy(sl.cstream);
@@ -102,6 +103,7 @@ static int32_t init_ctx_slots(Ctx &c) {
     for (int i = 0; i < N_SLOTS; i++) {
         HIPCHK(hipStreamCreateWithFlags(&c.slots[i].stream, hipStreamNonBlocking));
         HIPCHK(hipStreamCreateWithFlags(&c.slots[i].cstream, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&c.slots[i].xstream, hipStreamNonBlocking));
         for (hipEvent_t &e : c.slots[i].copy_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         HIPCHK(hipHostMalloc(&c.slots[i].hpin, Slot::HPIN_BYTES, hipHostMallocDefault));
         HIPCHK(c.slots[i].flags.ensure(64) ? hipErrorOutOfMemory : hipSuccess);
@@ -212,7 +214,7 @@ int32_t dgpu_set_window_bits(int32_t c) { if (c != 0 && (c < 7 || c > 22)) retur
 int32_t dgpu_set_chunk(int32_t terms) { if (terms != 0 && (terms < 16 || terms > 4096)) return DGPU_E_BADARG; gs.chunk = terms; return DGPU_OK; }
 int32_t dgpu_set_reduce_lanes(int32_t lanes) { if (lanes != 1 && lanes != 4) return DGPU_E_BADARG; gs.reduce_lanes = lanes; return DGPU_OK; }
 int32_t dgpu_set_reduce_shift(int32_t sh) { if (sh < -1 || sh > 6) return DGPU_E_BADARG; gs.reduce_shift = sh; return DGPU_OK; }
-int32_t dgpu_set_miller_pipeline(int32_t mode) { if (mode < 0 || mode > 3) return DGPU_E_BADARG; gs.ml_mode = mode; return DGPU_OK; }
+int32_t dgpu_set_miller_pipeline(int32_t mode) { if (mode < 0 || mode > 7) return DGPU_E_BADARG; gs.ml_mode = mode; return DGPU_OK; }
 uint64_t dgpu_device_alloc_count(void) { return g_dev_allocs.load(); }
 
 

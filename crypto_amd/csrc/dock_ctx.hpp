@@ -59,6 +59,7 @@ struct Slot {
     // H2D pieces travel on their own stream, ordered against the compute stream by these events: the kernels of a call run under its copies
     static constexpr int N_COPY_EV = 15;
     hipStream_t cstream = nullptr;
+    hipStream_t xstream = nullptr;  // a third stream: the products of a Miller loop's middle piece (dock_pairing.hip: ml_pipelined)
     void *hpin = nullptr;           // pinned host scratch (HPIN_BYTES): results a host thread consumes while the slot's streams keep running
     static constexpr size_t HPIN_BYTES = 64 * 1024;
     hipEvent_t copy_ev[N_COPY_EV + 1] = {};
@@ -106,7 +107,7 @@ struct Shared {
     std::atomic<int> chunk{0};
     std::atomic<int> reduce_lanes{4};         // dgpu_set_reduce_lanes: members per point in the last reduction kernel (1: k_reduce_top, 4: k_reduce_top_quad)
     std::atomic<int> reduce_shift{-1};        // dgpu_set_reduce_shift: log2 buckets per lane of k_reduce_l0 on the table pipeline (-1 = automatic)
-    std::atomic<int> ml_mode{3};              // dgpu_set_miller_pipeline: bit 0 the two-launch line kernel of small Miller loops, bit 1 the 18-role product tree (dock_pairing.hip)
+    std::atomic<int> ml_mode{7};              // dgpu_set_miller_pipeline: bit 0 the two-launch line kernel of small Miller loops, bit 1 the 18-role product tree, bit 2 sixteen lanes per pair in the line kernel (dock_pairing.hip)
     uint64_t allocs_at_reset = 0, alloc_ns_at_reset = 0;
     int default_ctx = -1;
     std::atomic<bool> prof{false};

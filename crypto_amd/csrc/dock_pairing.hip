@@ -206,6 +206,143 @@ __global__ void __launch_bounds__(64) k_miller_lines_quad(const uint32_t *__rest
         for (int k = 0; k < NL; k++) { state[(size_t)k * lanes + gid] = R.x.v.l[k]; state[(size_t)(NL + k) * lanes + gid] = R.y.v.l[k]; state[(size_t)(2 * NL + k) * lanes + gid] = R.z.v.l[k]; }
 }
 
+// ---- sixteen lanes per (P, Q): a doubling step two Fp2 operations deep -------------------------------------------------------------------
+// k_miller_lines_quad lasts as long as ONE lane's instruction stream: 63 doubling steps x 5 rounds (3 squarings + 2 products) + 5 addition
+// steps of 11 products, with 64 waves on 1024 SIMDs at 1024 pairs.  The nine Fp2 operations of a doubling step fall into TWO groups of
+// mutually independent ones, so here a (P, Q) owns one 16-lane DPP row = eight lane pairs ("units" u0 .. u7, unit = lane pair, Fp2 halves on
+// its two lanes as in fp2_pair.hip.h), six of which work:
+//   round 1 (all squarings)   u0 b = Y^2   u1 c = Z^2   u2 (Y + Z)^2   u3 (X + Y)^2   u4 j = X^2            [X Y = ((X + Y)^2 - j - b) / 2]
+//   round 2 (products)        u0 e^2       u1 g^2       u2 Z' = b h    u3 X' = (X Y / 2) d                  [e, g, h, d: linear in b, c]
+// then Y' = g^2 - 3 e^2 on u1 (e^2 over DPP).  Every lane runs the same instruction stream; WHO computes WHAT is decided by which lane a value is
+// fetched from: ds_bpermute lets each lane name its own source lane, so the operand of round 1 of the next step is in = A + B with
+// (A, B) fetched from the units that hold X', Y', Z' (or from an idle unit that holds zero) — no role selects in front of the squaring.
+// An addition step (5 of 68) is four rounds of products on u0 .. u3 with whole-row broadcasts in between.  Same formulas as
+// line_dbl_step / line_add_step (pairing29.hip.h), i.e. the same field VALUES: the Miller output stays bit-identical (tests compare all forms).
+// Only the unevaluated form exists (c1, c2 are multiplied by px, py in k_line_products; pxy written by the launch that starts the chain).
+// state (two-launch form): R of pair i, half h at state[(comp * NL + k) * 2 n + 2 i + h].
+__device__ __forceinline__ void hx_fetch(Fp2H &r, const Fp2H &a, int src_byte) {
+#pragma unroll
+    for (int i = 0; i < NL; i++) r.v.l[i] = (uint32_t)__builtin_amdgcn_ds_bpermute(src_byte, (int)a.v.l[i]);
+}
+__global__ void __launch_bounds__(64) k_miller_lines_hex(const uint32_t *__restrict__ p_abi, const uint32_t *__restrict__ q_abi, const uint8_t *__restrict__ skip, size_t n, uint32_t *__restrict__ lines, size_t stride,
+                                                         int b_hi, int b_lo, int s_first, uint32_t *__restrict__ state, uint32_t *__restrict__ pxy) {
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t i = gid >> 4;
+    const uint32_t lane = threadIdx.x & 63u, h = lane & 1u, unit = (lane >> 1) & 7u;
+    if (i >= n) return;
+    bool sk = skip && skip[i];
+    uint32_t anyp = 1, anyq = 0;
+    uint32_t qx[12], qy[12];
+    for (int k = 0; k < 12; k++) { qx[k] = q_abi[i * 48 + h * 12 + k]; qy[k] = q_abi[i * 48 + 24 + h * 12 + k]; anyq |= qx[k] | qy[k]; }
+    anyq |= xchg32(anyq);
+    uint32_t pw[12];                                            // this lane's coordinate of P (h = 0: x, h = 1: y): only to hand px, py to the product kernel
+    if (p_abi) { uint32_t a = 0; for (int k = 0; k < 12; k++) { pw[k] = p_abi[i * 24 + h * 12 + k]; a |= pw[k]; } anyp = a | xchg32(a); }
+    else for (int k = 0; k < 12; k++) pw[k] = 0;
+    if (!anyp || !anyq) sk = true;
+    // coefficient half (c, h) of line s is written by ONE lane: its 14 words
+    auto st = [&](int s, uint32_t c, const Fp2H &x) { for (int j = 0; j < NL; j++) lines[((size_t)s * LW + (2 * c + h) * NL + j) * stride + i] = x.v.l[j]; };
+    const bool starts = b_hi == 62;
+    if (sk) {
+        const int s_end = s_first + ml_steps(b_hi, b_lo);
+        if (unit < 3) { Fp2H v; if (unit == 0) fset_one(v); else fzero(v); for (int s = s_first; s < s_end; s++) st(s, unit, v); }
+        if (pxy && starts && unit == 0) for (int k = 0; k < NL; k++) pxy[(h * NL + k) * stride + i] = 0;
+        return;
+    }
+    if (pxy && starts) { Fp c; fp_from_abi(c, pw); if (unit == 0) for (int k = 0; k < NL; k++) pxy[(h * NL + k) * stride + i] = c.l[k]; }
+    Aff<Fp2H> Q; fp_from_abi(Q.x.v, qx); fp_from_abi(Q.y.v, qy);
+    const int row = (int)((lane & 48u) + h) * 4;                 // byte address of this lane's half in unit 0 of its row
+    auto from = [&](uint32_t u) { return row + 8 * (int)u; };
+    // who holds what after a doubling step (val: X' on u3, Y' on u1, Z' on u2, zero on u4 .. u7) and what round 1 squares: in = A + B
+    //                       u0: Y      u1: Z      u2: Y + Z   u3: X + Y   u4: X      u5 .. u7: 0
+    const int srcA = from((0x55533121u >> (4 * unit)) & 7u), srcB = from((0x55551255u >> (4 * unit)) & 7u);
+    const int srcJ = from(4);
+    Fp2H X, Y, Z;                                                // the whole of R: valid at the start, around an addition step and at the end
+    if (starts) { X = Q.x; Y = Q.y; fset_one(Z); }
+    else {
+        const size_t w = 2 * n, at = 2 * i + h;
+        for (int k = 0; k < NL; k++) { X.v.l[k] = state[(size_t)k * w + at]; Y.v.l[k] = state[(size_t)(NL + k) * w + at]; Z.v.l[k] = state[(size_t)(2 * NL + k) * w + at]; }
+    }
+    // round-1 operand from a whole R (start, after an addition step): the same table, spelled with selects
+    auto operand_from_R = [&](Fp2H &in) {
+        Fp2H a, b, z, t; fzero(z);
+        fsel(a, unit == 1, Z, Y); fsel(a, unit >= 3, X, a); fsel(a, unit >= 5, z, a);
+        fsel(b, unit == 2, Z, z); fsel(b, unit == 3, Y, b);
+        fadd(t, a, b); fnorm(in, t);
+    };
+    Fp2H in; operand_from_R(in);
+    int s = s_first;
+    for (int b = b_hi; b >= b_lo; b--) {
+        // ---- doubling step (ark-ec double_in_place) ----
+        Fp2H res, B, C, J, t, e, f, g, hh, ii, d, a, ah, c1v, c2v, lv, opA, opB, oth, yy, val;
+        f2_sqr_m<64>(res, in);                                   // round 1
+        hx_fetch(B, res, from(0)); hx_fetch(C, res, from(1)); hx_fetch(J, res, srcJ);
+        fadd(t, C, C); fadd(t, t, C); fnorm(t, t);              // 3c
+        fdbl(t, t); fdbl(t, t); fnorm(t, t);                    // 12c
+        f2_mul_xi_n<128>(e, t);                                 // e = 4 (1 + u) 3c
+        fadd(f, e, e); fadd(f, f, e); fnorm(f, f);              // f = 3e
+        fadd(t, B, f); fhalf(g, t);                             // g = (b + f) / 2
+        f2_sub_n<8>(ii, e, B);                                  // line c0
+        f2_sub_n<1024>(d, B, f);
+        fadd(t, B, C); f2_sub_n<16>(hh, res, t);                // u2: h = (Y + Z)^2 - (b + c)
+        fadd(t, J, B); f2_sub_n<8>(a, res, t); fhalf(a, a); fhalf(ah, a);      // u3: X Y = ((X + Y)^2 - j - b) / 2, and its half
+        fadd(t, res, res); fadd(t, t, res); fnorm(c1v, t);      // u4: 3j
+        f2_neg_n<32>(c2v, hh);                                  // u2: -h
+        fsel(lv, unit == 4, c1v, ii); fsel(lv, unit == 2, c2v, lv);
+        if (unit == 1 || unit == 2 || unit == 4) st(s, unit == 1 ? 0u : (unit == 4 ? 1u : 2u), lv);
+        s++;
+        fsel(opA, unit == 1, g, e); fsel(opA, unit == 2, B, opA); fsel(opA, unit == 3, ah, opA);
+        fsel(opB, unit == 1, g, e); fsel(opB, unit == 2, hh, opB); fsel(opB, unit == 3, d, opB);
+        fmul(res, opA, opB);                                     // round 2: u0 e^2, u1 g^2, u2 b h, u3 (X Y / 2) d
+        xq(oth, res);                                            // u1 receives e^2
+        fadd(t, oth, oth); fadd(t, t, oth); f2_sub_n<32>(yy, res, t);          // u1: Y' = g^2 - 3 e^2
+        { Fp2H z; fzero(z); fsel(val, unit == 1, yy, res); fsel(val, unit >= 4, z, val); }
+        const bool add = (BLS_X_ABS >> b) & 1;
+        if (!add && b > b_lo) { Fp2H A2, B2; hx_fetch(A2, val, srcA); hx_fetch(B2, val, srcB); fadd(t, A2, B2); fnorm(in, t); continue; }
+        hx_fetch(X, val, from(3)); hx_fetch(Y, val, from(1)); hx_fetch(Z, val, from(2));
+        if (add) {
+            // ---- addition step (ark-ec add_in_place): four rounds of products on u0 .. u3 ----
+            Fp2H t1, t2, theta, lam, cc, dd, m2, m3, jj, ee, ff, gg, h2, r0, r1, r2, r3;
+            fsel(opA, unit == 0, Q.y, Q.x); fmul(res, opA, Z);                                     // u0: Qy Z   u1: Qx Z
+            hx_fetch(t1, res, from(0)); hx_fetch(t2, res, from(1));
+            f2_sub_n<8>(theta, Y, t1); f2_sub_n<8>(lam, X, t2);
+            fsel(opA, (unit & 1u) != 0, lam, theta);
+            fsel(opB, unit == 1, lam, theta); fsel(opB, unit == 2, Q.x, opB); fsel(opB, unit == 3, Q.y, opB);
+            fmul(res, opA, opB);                                                                   // u0: theta^2  u1: lam^2  u2: theta Qx  u3: lam Qy
+            hx_fetch(cc, res, from(0)); hx_fetch(dd, res, from(1)); hx_fetch(m2, res, from(2)); hx_fetch(m3, res, from(3));
+            f2_sub_n<8>(jj, m2, m3);
+            { Fp2H nt; f2_neg_n<64>(nt, theta); fsel(lv, unit == 1, nt, jj); fsel(lv, unit == 2, lam, lv); }
+            if (unit < 3) st(s, unit, lv);                                                         // (j, -theta, lam)
+            s++;
+            fsel(opA, unit == 1, Z, lam); fsel(opA, unit == 2, X, opA);
+            fsel(opB, unit == 1, cc, dd);
+            fmul(res, opA, opB);                                                                   // u0: e = lam d  u1: f = Z c  u2: g = X d
+            hx_fetch(ee, res, from(0)); hx_fetch(ff, res, from(1)); hx_fetch(gg, res, from(2));
+            fadd(t, ee, ff); { Fp2H u2; fadd(u2, gg, gg); f2_sub_n<16>(h2, t, u2); }
+            f2_sub_n<32>(t, gg, h2);
+            fsel(opA, unit == 1, Z, lam); fsel(opA, unit == 2, theta, opA); fsel(opA, unit == 3, ee, opA);
+            fsel(opB, unit == 1, ee, h2); fsel(opB, unit == 2, t, opB); fsel(opB, unit == 3, Y, opB);
+            fmul(res, opA, opB);                                                                   // u0: lam h  u1: Z e  u2: theta (g - h)  u3: e Y
+            hx_fetch(r0, res, from(0)); hx_fetch(r1, res, from(1)); hx_fetch(r2, res, from(2)); hx_fetch(r3, res, from(3));
+            X = r0; Z = r1; f2_sub_n<8>(Y, r2, r3);
+        }
+        operand_from_R(in);
+    }
+    if (b_lo > 0 && unit == 0) {
+        const size_t w = 2 * n, at = 2 * i + h;
+        for (int k = 0; k < NL; k++) { state[(size_t)k * w + at] = X.v.l[k]; state[(size_t)(NL + k) * w + at] = Y.v.l[k]; state[(size_t)(2 * NL + k) * w + at] = Z.v.l[k]; }
+    }
+}
+// one launcher for the line kernels that leave the evaluation to the product kernel: sixteen lanes per pair while the chip has room for them
+// (dgpu_set_miller_pipeline bit 2), four otherwise.  Same arguments, same lines, same state size bound (3 NL 4 n words).
+constexpr size_t ML_HEX_MAX = 4096;      // 16 lanes x 4096 pairs = 1024 waves: one per SIMD
+static void launch_lines_uneval(hipStream_t s, const uint32_t *p_abi, const uint32_t *q_abi, const uint8_t *skip, size_t n, uint32_t *lines, size_t stride,
+                                int b_hi, int b_lo, int s_first, uint32_t *state, uint32_t *pxy) {
+    if ((gs.ml_mode.load() & 4) && n <= ML_HEX_MAX)
+        hipLaunchKernelGGL(k_miller_lines_hex, dim3((unsigned)((16 * n + 63) / 64)), dim3(64), 0, s, p_abi, q_abi, skip, n, lines, stride, b_hi, b_lo, s_first, state, pxy);
+    else
+        hipLaunchKernelGGL(k_miller_lines_quad<false>, dim3((unsigned)((4 * n + 63) / 64)), dim3(64), 0, s, p_abi, q_abi, skip, n, lines, stride, b_hi, b_lo, s_first, state, pxy);
+}
+
 // ---- G2Prepared (ark-ec bls12/g2.rs `G2Prepared::from`: the 68 coefficient triples before the evaluation at P) --------------------------
 // The reference's verifier and pairing checker hold ONLY prepared G2 values (legogroth16/src/verifier.rs:69-76 passes
 // pvk.delta_g2_neg_pc / gamma_g2_neg_pc, data_structures.rs:118-120; utils/src/randomized_pairing_check.rs:35 queues Vec<E::G2Prepared>),
@@ -564,13 +701,15 @@ static int32_t ml_finish(Slot &sl, size_t n, uint64_t *out, const uint32_t *pxy 
     return DGPU_OK;
 }
 
-// A call of up to 8192 pairs lasts as long as its chain: 68 dependent line steps (K9: 4 lanes per pair, the chip nearly empty), then the
-// product levels of K10 / K11, then 131 Fp12 operations on the host.  The chain is cut at bit ML_CUT of |x|: the line kernel runs in two
-// launches, the products of the first 50 steps and the host's share of them run (second stream, host thread) while the second launch
-// computes the last 18 steps — what remains after the line kernel is the product levels of those 18 steps and 35 host operations
-// (1.45 -> 1.2 ms at 1024 pairs).  Same values in the same order: bit-identical to the one-launch form, which stays for larger batches
-// (throughput-bound) and while stage timers are on.
-constexpr int ML_CUT = 17;
+// A call of up to 8192 pairs lasts as long as its chain: 68 dependent line steps (K9: the chip nearly empty), then the product levels of
+// K10 / K11 (~0.18 ms whatever the number of steps), then 131 Fp12 operations on the host (~0.25 ms: as long as the chain itself since K9
+// has sixteen lanes per pair).  The chain is therefore cut into ML_PIECES launches at the bits ML_CUTS of |x|: the products of a finished
+// piece run on a stream of their own while the next piece is computed, its results land in pinned memory and the calling thread folds
+// them into f as they arrive — what is left after the last launch is the product levels of the last piece and its share of the host's
+// work.  Same values in the same order: bit-identical to the one-launch form, which stays for larger batches (throughput-bound) and
+// while stage timers are on.  (Round 3: two pieces, cut at bit 17; 1.45 -> 1.05 ms at 1024 pairs.  Three pieces with sixteen lanes: 0.7.)
+constexpr int ML_PIECES = 3;
+constexpr int ML_CUTS[ML_PIECES] = {40, 17, 0};               // piece j runs the bits (ML_CUTS[j - 1] - 1, or 62) .. ML_CUTS[j]
 // n pairs in the line buffer, the first n_aff of them affine (their chain is what gets cut); prepared(pxy) queues the line kernel of the
 // prepared pairs n_aff .. n - 1, if any, on the slot's stream (it writes their neutral px, py)
 static int32_t ml_pipelined(Slot &sl, size_t n, size_t n_aff, const uint8_t *dskip, uint64_t *out, const std::function<void(uint32_t *)> &prepared) {
@@ -582,32 +721,40 @@ static int32_t ml_pipelined(Slot &sl, size_t n, size_t n_aff, const uint8_t *dsk
     ml_geom_set(g2, n, g.slice_len >= 8 && (n + g.slice_len / 2 - 1) / (g.slice_len / 2) <= 2048 ? g.slice_len / 2 : g.slice_len, ml_geom_words(g));
     if ((rc = sl.ml_partial.ensure((ml_geom_words(g) + ml_geom_words(g2)) * 4))) return rc;
     if ((rc = sl.ml_state.ensure(((size_t)3 * NL * 4 * n_aff + (size_t)2 * NL * n) * 4))) return rc;      // R of every lane, then px, py of every pair
-    hipStream_t sa = sl.stream, sb = sl.cstream;
-    const int ns1 = ml_steps(62, ML_CUT), ns2 = N_LINES - ns1;
-    const unsigned blocks = (unsigned)((4 * n_aff + 63) / 64);
-    hipEvent_t e1 = sl.copy_ev[sl.ev_next++ % (Slot::N_COPY_EV + 1)], e2 = sl.copy_ev[sl.ev_next++ % (Slot::N_COPY_EV + 1)];
+    hipStream_t sa = sl.stream;
+    hipStream_t side[2] = {sl.cstream, sl.xstream};                  // the pieces' products alternate between them (a piece's products outlast the next piece's chain)
     static_assert((size_t)N_LINES * 576 <= Slot::HPIN_BYTES, "pinned scratch");
+    static_assert(2 * (ML_PIECES - 1) <= Slot::N_COPY_EV + 1, "events");
     hostf::Fq12 *L = (hostf::Fq12 *)sl.hpin;                          // pinned: the copies below are asynchronous for the host
     uint32_t *state = sl.ml_state.as<uint32_t>(), *pxy = state + (size_t)3 * NL * 4 * n_aff;
-    // (a failed enqueue must not leave the slot with work in flight: every step is checked, both streams are drained before any return)
+    // (a failed enqueue must not leave the slot with work in flight: every step is checked, every stream is drained before any return)
     rc = DGPU_OK;
     auto ok = [&](hipError_t e) { if (e != hipSuccess && !rc) rc = DGPU_E_HIP; return rc == DGPU_OK; };
     prepared(pxy);
-    hipLaunchKernelGGL(k_miller_lines_quad<false>, dim3(blocks), dim3(64), 0, sa, sl.in_bases.as<uint32_t>(), sl.in_scalars.as<uint32_t>(), dskip, n_aff, sl.ml_lines.as<uint32_t>(), n, 62, ML_CUT, 0, state, pxy);
-    if (ok(hipEventRecord(e1, sa))) {
-        hipLaunchKernelGGL(k_miller_lines_quad<false>, dim3(blocks), dim3(64), 0, sa, sl.in_bases.as<uint32_t>(), sl.in_scalars.as<uint32_t>(), dskip, n_aff, sl.ml_lines.as<uint32_t>(), n, ML_CUT - 1, 0, ns1, state, pxy);
-        if (ok(hipStreamWaitEvent(sb, e1, 0))) {
-            ml_products(sl, sb, n, g, 0, ns1, false, pxy);
-            ok(hipMemcpyAsync(L, sl.ml_out.p, (size_t)ns1 * 576, hipMemcpyDeviceToHost, sb));
-            ok(hipEventRecord(e2, sb));
+    hipEvent_t done[ML_PIECES - 1] = {};
+    int s_first = 0, b_hi = 62;
+    for (int j = 0; j < ML_PIECES && !rc; j++) {
+        const int b_lo = ML_CUTS[j], ns = ml_steps(b_hi, b_lo);
+        launch_lines_uneval(sa, sl.in_bases.as<uint32_t>(), sl.in_scalars.as<uint32_t>(), dskip, n_aff, sl.ml_lines.as<uint32_t>(), n, b_hi, b_lo, s_first, state, pxy);
+        if (j + 1 < ML_PIECES) {
+            hipEvent_t ready = sl.copy_ev[sl.ev_next++ % (Slot::N_COPY_EV + 1)];
+            done[j] = sl.copy_ev[sl.ev_next++ % (Slot::N_COPY_EV + 1)];
+            hipStream_t sp = side[j & 1];
+            if (ok(hipEventRecord(ready, sa)) && ok(hipStreamWaitEvent(sp, ready, 0))) {
+                ml_products(sl, sp, n, g, s_first, ns, false, pxy);
+                ok(hipMemcpyAsync(L + s_first, (const char *)sl.ml_out.p + (size_t)s_first * 576, (size_t)ns * 576, hipMemcpyDeviceToHost, sp));
+                ok(hipEventRecord(done[j], sp));
+            }
+        } else {
+            ml_products(sl, sa, n, g2, s_first, ns, false, pxy);
+            ok(hipMemcpyAsync(L + s_first, (const char *)sl.ml_out.p + (size_t)s_first * 576, (size_t)ns * 576, hipMemcpyDeviceToHost, sa));
         }
-        ml_products(sl, sa, n, g2, ns1, ns2, false, pxy);
-        ok(hipMemcpyAsync(L + ns1, (const char *)sl.ml_out.p + (size_t)ns1 * 576, (size_t)ns2 * 576, hipMemcpyDeviceToHost, sa));
+        s_first += ns; b_hi = b_lo - 1;
     }
     ok(hipGetLastError());
     MlTail tail;
-    if (!rc && ok(hipEventSynchronize(e2))) tail.run(L, ML_CUT);
-    ok(hipStreamSynchronize(sa)); ok(hipStreamSynchronize(sb));
+    for (int j = 0; j + 1 < ML_PIECES; j++) if (!rc && ok(hipEventSynchronize(done[j]))) tail.run(L, ML_CUTS[j]);
+    ok(hipStreamSynchronize(sa)); ok(hipStreamSynchronize(side[0])); ok(hipStreamSynchronize(side[1]));
     if (rc) return rc;
     tail.run(L, 0);
     const hostf::Fq12 f = tail.result();
@@ -649,7 +796,7 @@ int32_t dgpu_multi_miller_loop(const uint64_t *p, const uint64_t *q, const uint8
           if (act.v <= 2) return ml_pipelined(sl, n, n, dskip, out, [](uint32_t *) {});
           if ((rc = sl.ml_state.ensure((size_t)2 * NL * n * 4))) return rc;
           uint32_t *pxy = sl.ml_state.as<uint32_t>();
-          hipLaunchKernelGGL(k_miller_lines_quad<false>, dim3((unsigned)((4 * n + 63) / 64)), dim3(64), 0, s, sl.in_bases.as<uint32_t>(), sl.in_scalars.as<uint32_t>(), dskip, n, sl.ml_lines.as<uint32_t>(), n,
+          launch_lines_uneval(s, sl.in_bases.as<uint32_t>(), sl.in_scalars.as<uint32_t>(), dskip, n, sl.ml_lines.as<uint32_t>(), n,
                              62, 0, 0, (uint32_t *)nullptr, pxy);
           return ml_finish(sl, n, out, pxy);
       }
@@ -718,7 +865,7 @@ static int32_t ml_segments(const uint64_t *p, const uint64_t *q, const uint8_t *
     HIPCHK(hipMemcpyAsync(doff, off.data(), (nseg + 1) * 4, hipMemcpyHostToDevice, s));
     { StageTimer st(sl, "ml.lines");
       if (n > 8192) hipLaunchKernelGGL(k_miller_lines_pair, dim3((unsigned)((2 * n + 63) / 64)), dim3(64), 0, s, sl.in_bases.as<uint32_t>(), sl.in_scalars.as<uint32_t>(), dskip, n, sl.ml_lines.as<uint32_t>(), n);
-      else hipLaunchKernelGGL(k_miller_lines_quad<false>, dim3((unsigned)((4 * n + 63) / 64)), dim3(64), 0, s, sl.in_bases.as<uint32_t>(), sl.in_scalars.as<uint32_t>(), dskip, n, sl.ml_lines.as<uint32_t>(), n,
+      else launch_lines_uneval(s, sl.in_bases.as<uint32_t>(), sl.in_scalars.as<uint32_t>(), dskip, n, sl.ml_lines.as<uint32_t>(), n,
                               62, 0, 0, (uint32_t *)nullptr, pxy); }       // (the evaluation at P is left to the product kernel: not part of the chain)
     { StageTimer st(sl, "ml.products");
       hipLaunchKernelGGL(k_line_products, dim3((unsigned)((2 * (size_t)N_LINES * nsl * nseg + 63) / 64)), dim3(64), 0, s, sl.ml_lines.as<uint32_t>(), n, slice_len, nsl, sl.ml_partial.as<uint32_t>(), doff, (int)nseg,
@@ -786,7 +933,7 @@ int32_t dgpu_g2_prepare(const uint64_t *q, const uint8_t *is_inf, size_t n, uint
     { StageTimer st(sl, "ml.g2_prepare");
       if (n <= 8192 && (gs.ml_mode.load() & 1)) {
           if ((rc = sl.ml_lines.ensure((size_t)N_LINES * LW * n * 4))) return rc;
-          hipLaunchKernelGGL(k_miller_lines_quad<false>, dim3((unsigned)((4 * n + 63) / 64)), dim3(64), 0, s, (const uint32_t *)nullptr, sl.in_scalars.as<uint32_t>(), dinf, n, sl.ml_lines.as<uint32_t>(), n,
+          launch_lines_uneval(s, (const uint32_t *)nullptr, sl.in_scalars.as<uint32_t>(), dinf, n, sl.ml_lines.as<uint32_t>(), n,
                              62, 0, 0, (uint32_t *)nullptr, (uint32_t *)nullptr);
           hipLaunchKernelGGL(k_prepared_from_lines, dim3((unsigned)((n * N_LINES * 6 + 255) / 256)), dim3(256), 0, s, sl.ml_lines.as<uint32_t>(), sl.in_scalars.as<uint32_t>(), dinf, n,
                              sl.ml_coeffs.as<uint32_t>(), sl.in_inf.as<uint8_t>() + n);

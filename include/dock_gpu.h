@@ -69,10 +69,11 @@ int32_t dgpu_set_chunk(int32_t terms);
 int32_t dgpu_set_reduce_shift(int32_t log2_buckets_per_lane);
 /* lanes (G2: lane pairs) per point in the last kernel of the bucket reduction: 4 (default; a general addition four products deep) or 1. */
 int32_t dgpu_set_reduce_lanes(int32_t lanes);
-/* Forms of the Miller-loop kernels, a bit mask (default 3).  Bit 0: dgpu_multi_miller_loop of up to 8192 pairs runs its line kernel in two
- * launches and overlaps the products / host share of the first with the second (and dgpu_g2_prepare runs the same four-lane chain followed
- * by a parallel conversion pass).  Bit 1: the product tree gives every node 18 lane pairs
- * (one Fp2 product deep per level) instead of three.  Every combination gives the same Fp12 value limb for limb (tests compare them). */
+/* Forms of the Miller-loop kernels, a bit mask (default 7).  Bit 0: dgpu_multi_miller_loop of up to 8192 pairs runs its line kernel in two
+ * launches and overlaps the products / host share of the first with the second (and dgpu_g2_prepare runs the same lanes-per-point chain
+ * followed by a parallel conversion pass).  Bit 1: the product tree gives every node 18 lane pairs (one Fp2 product deep per level) instead
+ * of three.  Bit 2: up to 4096 pairs the line kernel gives every (P, Q) sixteen lanes (a doubling step two Fp2 operations deep instead of
+ * five).  Every combination gives the same Fp12 value limb for limb (tests compare them). */
 int32_t dgpu_set_miller_pipeline(int32_t mode);
 /* Workspaces.  Every call in flight owns one of the context's slots (stream + grow-only device workspace).  The slots are sized AHEAD of
  * the calls so that no MSM path allocates in steady state (a hipMalloc costs 0.1 - 1 ms and the hipFree of the buffer it replaces waits for

@@ -11,11 +11,11 @@ for n, cut in ((3, 1), (64, 32), (1024, 512)):
     pc = pairing.G2Prepared.from_affine(qs)
     items = [qs[:cut], pc[cut:]]
     res = {}
-    for mode in (0, 1, 2, 3, 0, 1, 2, 3):
+    for mode in (3, 7, 3, 7):
         lib().dgpu_set_miller_pipeline(mode)
         for _ in range(3): pairing.multi_miller_loop(ps, items)
         t0 = time.perf_counter()
         for _ in range(20): pairing.multi_miller_loop(ps, items)
         res.setdefault(mode, []).append((time.perf_counter() - t0) / 20 * 1e3)
     print("%d pairs (%d affine): ms per mixed call by mode %s" % (n, cut, {m: ["%.3f" % v for v in r] for m, r in res.items()}), flush=True)
-lib().dgpu_set_miller_pipeline(3)
+lib().dgpu_set_miller_pipeline(7)

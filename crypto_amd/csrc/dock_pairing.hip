@@ -220,6 +220,26 @@ __global__ void __launch_bounds__(64) k_miller_lines_quad(const uint32_t *__rest
 // line_dbl_step / line_add_step (pairing29.hip.h), i.e. the same field VALUES: the Miller output stays bit-identical (tests compare all forms).
 // Only the unevaluated form exists (c1, c2 are multiplied by px, py in k_line_products; pxy written by the launch that starts the chain).
 // state (two-launch form): R of pair i, half h at state[(comp * NL + k) * 2 n + 2 i + h].
+// lane-pair forms of pairing29.hip.h's f2_sqr_u / fmul / f2_mul12_n (the operations line_dbl_step_fast is proved with), spelled for the
+// fewest instructions: every lane of the wave runs them, whatever its role
+template <int M> __device__ __forceinline__ void hx_sqr(Fp2H &r, const Fp2H &a) {      // even: (a0 + a1)(a0 - a1)   odd: (2 a0) a1
+    const bool odd = pair_odd();
+    Fp ao, t, U, d, V;
+    xchg(ao, a.v);
+    sel(t, odd, ao, a.v); fp_add(U, ao, t);
+    fp_sub<M>(d, a.v, ao); fp_norm(d, d);
+    sel(V, odd, a.v, d);
+    fp_mul(r.v, U, V);
+}
+__device__ __forceinline__ void hx_mul(Fp2H &r, const Fp2H &a, const Fp2H &b) {        // even: a0 b0 + (-a1) b1   odd: a0 b1 + a1 b0
+    const bool odd = pair_odd();
+    Fp ao, bo, z, nao, P, Q;
+    xchg(ao, a.v); xchg(bo, b.v);
+    fp_zero(z); fp_sub<512>(nao, z, ao); fp_norm(nao, nao);
+    sel(P, odd, ao, a.v); sel(Q, odd, a.v, nao);
+    fp_mul2(r.v, P, b.v, Q, bo);
+}
+__device__ __forceinline__ void f2_mul12_n(Fp2H &r, const Fp2H &a) { fp_mul12_norm(r.v, a.v); }
 __device__ __forceinline__ void hx_fetch(Fp2H &r, const Fp2H &a, int src_byte) {
 #pragma unroll
     for (int i = 0; i < NL; i++) r.v.l[i] = (uint32_t)__builtin_amdgcn_ds_bpermute(src_byte, (int)a.v.l[i]);
@@ -272,33 +292,33 @@ __global__ void __launch_bounds__(64) k_miller_lines_hex(const uint32_t *__restr
     Fp2H in; operand_from_R(in);
     int s = s_first;
     for (int b = b_hi; b >= b_lo; b--) {
-        // ---- doubling step (ark-ec double_in_place) ----
-        Fp2H res, B, C, J, t, e, f, g, hh, ii, d, a, ah, c1v, c2v, lv, opA, opB, oth, yy, val;
-        f2_sqr_m<64>(res, in);                                   // round 1
+        // ---- doubling step (ark-ec double_in_place) as line_dbl_step_fast (pairing29.hip.h: bounds proved on the host) ----
+        Fp2H res, B, C, J, t, e, f, g, hh, ii, d2, a2, ah, c1v, c2v, lv, eg, opA, opB, oth, yy, val, z;
+        fzero(z);
+        hx_sqr<64>(res, in);                                     // round 1
         hx_fetch(B, res, from(0)); hx_fetch(C, res, from(1)); hx_fetch(J, res, srcJ);
-        fadd(t, C, C); fadd(t, t, C); fnorm(t, t);              // 3c
-        fdbl(t, t); fdbl(t, t); fnorm(t, t);                    // 12c
-        f2_mul_xi_n<128>(e, t);                                 // e = 4 (1 + u) 3c
-        fadd(f, e, e); fadd(f, f, e); fnorm(f, f);              // f = 3e
+        f2_mul12_n(t, C); f2_mul_xi_n<128>(e, t);               // e = 12 (1 + u) c
+        fadd(f, e, e); fadd(f, f, e);                           // f = 3e (lazy)
         fadd(t, B, f); fhalf(g, t);                             // g = (b + f) / 2
-        f2_sub_n<8>(ii, e, B);                                  // line c0
-        f2_sub_n<1024>(d, B, f);
+        fsub<8>(ii, e, B);                                      // line c0 (lazy: the consumer carry-passes)
         fadd(t, B, C); f2_sub_n<16>(hh, res, t);                // u2: h = (Y + Z)^2 - (b + c)
-        fadd(t, J, B); f2_sub_n<8>(a, res, t); fhalf(a, a); fhalf(ah, a);      // u3: X Y = ((X + Y)^2 - j - b) / 2, and its half
-        fadd(t, res, res); fadd(t, t, res); fnorm(c1v, t);      // u4: 3j
-        f2_neg_n<32>(c2v, hh);                                  // u2: -h
+        fadd(t, J, B); fsub<8>(a2, res, t); fhalf(ah, a2);      // u3: X Y = ((X + Y)^2 - j - b) / 2
+        f2_sub_n<256>(d2, B, g);                                // (b - f) / 2
+        fadd(t, res, res); fadd(c1v, t, res);                   // u4: 3j
+        fsub<32>(c2v, z, hh);                                   // u2: -h
         fsel(lv, unit == 4, c1v, ii); fsel(lv, unit == 2, c2v, lv);
         if (unit == 1 || unit == 2 || unit == 4) st(s, unit == 1 ? 0u : (unit == 4 ? 1u : 2u), lv);
         s++;
-        fsel(opA, unit == 1, g, e); fsel(opA, unit == 2, B, opA); fsel(opA, unit == 3, ah, opA);
-        fsel(opB, unit == 1, g, e); fsel(opB, unit == 2, hh, opB); fsel(opB, unit == 3, d, opB);
-        fmul(res, opA, opB);                                     // round 2: u0 e^2, u1 g^2, u2 b h, u3 (X Y / 2) d
+        fsel(eg, unit == 1, g, e);
+        fsel(opA, unit == 2, B, eg); fsel(opA, unit == 3, ah, opA);
+        fsel(opB, unit == 2, hh, eg); fsel(opB, unit == 3, d2, opB);
+        hx_mul(res, opA, opB);                                   // round 2: u0 e^2, u1 g^2, u2 b h, u3 (X Y)(b - g)
         xq(oth, res);                                            // u1 receives e^2
-        fadd(t, oth, oth); fadd(t, t, oth); f2_sub_n<32>(yy, res, t);          // u1: Y' = g^2 - 3 e^2
-        { Fp2H z; fzero(z); fsel(val, unit == 1, yy, res); fsel(val, unit >= 4, z, val); }
+        fadd(t, oth, oth); fadd(t, t, oth); fsub<32>(yy, res, t);              // u1: Y' = g^2 - 3 e^2 (lazy)
+        fsel(val, unit == 1, yy, res); fsel(val, unit >= 4, z, val);
         const bool add = (BLS_X_ABS >> b) & 1;
         if (!add && b > b_lo) { Fp2H A2, B2; hx_fetch(A2, val, srcA); hx_fetch(B2, val, srcB); fadd(t, A2, B2); fnorm(in, t); continue; }
-        hx_fetch(X, val, from(3)); hx_fetch(Y, val, from(1)); hx_fetch(Z, val, from(2));
+        hx_fetch(X, val, from(3)); hx_fetch(Y, val, from(1)); hx_fetch(Z, val, from(2)); fnorm(Y, Y);
         if (add) {
             // ---- addition step (ark-ec add_in_place): four rounds of products on u0 .. u3 ----
             Fp2H t1, t2, theta, lam, cc, dd, m2, m3, jj, ee, ff, gg, h2, r0, r1, r2, r3;
@@ -452,7 +472,8 @@ __global__ void __launch_bounds__(64) k_line_products(const uint32_t *__restrict
     for (size_t i = lo; i < last; i += have) {
         LineT<Fp2H> l;
         for (int c = 0; c < 3; c++) { Fp2H &x = c == 0 ? l.c0 : (c == 1 ? l.c1 : l.c2); for (int k = 0; k < NL; k++) x.v.l[k] = lines[((size_t)s * LW + (2 * c + h) * NL + k) * n + i]; }
-        if (pxy) {                                    // the lines came unevaluated (k_miller_lines_quad<false>): c1 *= px, c2 *= py here
+        fnorm(l.c0, l.c0); fnorm(l.c1, l.c1); fnorm(l.c2, l.c2);       // (k_miller_lines_hex leaves its doubling lines un-normalised)
+        if (pxy) {                                    // the lines came unevaluated (k_miller_lines_quad<false> / _hex): c1 *= px, c2 *= py here
             Fp px, py;
             for (int k = 0; k < NL; k++) { px.l[k] = pxy[(size_t)k * n + i]; py.l[k] = pxy[(size_t)(NL + k) * n + i]; }
             line_eval(l, px, py);

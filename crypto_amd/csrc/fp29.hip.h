@@ -152,6 +152,24 @@ FD void fp_norm(Fp &r, const Fp &a) {
 #endif
 }
 
+// r = 12 a with ONE carry pass (the Miller loop's e = 3 b' c = 12 (1 + u) c: x 3, carry pass, x 4, carry pass cost three times as much).
+// 3 a_i < 2^32 for any limb below 2^30.4; the carry of limb i is (3 a_i) >> 27, what stays is ((3 a_i) mod 2^27) << 2.
+// Input class N; output limbs <= 2^29 - 4 + 12 (one more than class N: every use is followed by a lazy subtraction / addition and a carry pass).
+FD void fp_mul12_norm(Fp &r, const Fp &a) {
+    uint32_t x3[NL], c[NL];
+#pragma unroll
+    for (int i = 0; i < NL; i++) { CHK(assert(3 * a.ub[i] < (1ull << 32));) x3[i] = a.l[i] + (a.l[i] << 1); }
+#pragma unroll
+    for (int i = 0; i < NL - 1; i++) c[i] = x3[i] >> 27;
+    CHK(uint64_t ub[NL]; ub[0] = LMASK - 3; for (int i = 1; i < NL - 1; i++) ub[i] = (LMASK - 3) + ((3 * a.ub[i - 1]) >> 27);
+        ub[NL - 1] = 12 * a.ub[NL - 1] + ((3 * a.ub[NL - 2]) >> 27); assert(ub[NL - 1] < (1ull << 32)); double vb = 12.0 * a.vb;)
+    r.l[0] = (x3[0] & 0x7ffffffu) << 2;
+#pragma unroll
+    for (int i = 1; i < NL - 1; i++) r.l[i] = ((x3[i] & 0x7ffffffu) << 2) + c[i - 1];
+    r.l[NL - 1] = (x3[NL - 1] << 2) + c[NL - 2];
+    CHK(for (int i = 0; i < NL; i++) r.ub[i] = ub[i]; r.vb = vb; chk_actual(r);)
+}
+
 #ifdef FP29_CHECK
 inline void chk_mul_pre(const Fp &a, const Fp &b) {
     BLS29_DECL_P;

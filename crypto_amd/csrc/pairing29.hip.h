@@ -222,6 +222,50 @@ template <class F2> FD void line_dbl_step(G2ProjT<F2> &R, LineT<F2> &l) {
     fadd(t, j, j); fadd(t, t, j); fnorm(l.c1, t);
     f2_neg_n<32>(l.c2, h);
 }
+// ---- the doubling step as k_miller_lines_hex runs it (dock_pairing.hip: sixteen lanes per pair, one instruction stream for every role, so
+// every instruction saved is saved on the critical path).  Same VALUES as line_dbl_step — so the raw Miller output does not change — with
+// fewer carry passes and halvings:
+//   * all five operations of the first round are squarings: X Y = ((X + Y)^2 - X^2 - Y^2) / 2;
+//   * a squaring's imaginary part is (2 a0) a1 (no doubling + carry pass afterwards);
+//   * 12 c in one scaled carry pass (fp_mul12_norm); f = 3 e, Y' and the three line coefficients are left un-normalised (their consumers
+//     add / subtract lazily or carry-pass after loading: k_line_products, k_prepared_from_lines);
+//   * X' = (X Y / 2)(b - f) = (X Y)(b - g): one halving instead of two ((b - f) / 2 = b - g).
+// This one-lane form exists so that the FP29_CHECK build proves the bounds of exactly this sequence (tests/test_device_code_on_host.py
+// runs it next to line_dbl_step); the kernel distributes it over the units of a 16-lane row op for op.
+// R.y is left un-normalised (limbs < 2^32, value < 40 p): the next doubling step carry-passes it inside its operand sums; pass norm_y = true
+// in front of anything else that consumes R (line_add_step).
+template <int M> FD void f2_sqr_u(Fp2 &r, const Fp2 &a) {
+    Fp s, d, t2, c0, c1;
+    fp_add(s, a.c0, a.c1);
+    fp_sub<M>(d, a.c0, a.c1); fp_norm(d, d);
+    fp_add(t2, a.c0, a.c0);
+    fp_mul(c0, s, d); fp_mul(c1, t2, a.c1);
+    r.c0 = c0; r.c1 = c1;
+}
+FD void f2_mul12_n(Fp2 &r, const Fp2 &a) { fp_mul12_norm(r.c0, a.c0); fp_mul12_norm(r.c1, a.c1); }
+template <class F2> FD void line_dbl_step_fast(G2ProjT<F2> &R, LineT<F2> &l, bool norm_y) {
+    F2 in, b, c, hs, s1, j, t, e, f, g, h, a2, ah, d2, e2, g2, z;
+    fzero(z);
+    fadd(t, R.y, z); fnorm(in, t); f2_sqr_u<64>(b, in);                 // round 1 (the kernel: in = A + B, carry pass, square)
+    fadd(t, R.z, z); fnorm(in, t); f2_sqr_u<64>(c, in);
+    fadd(t, R.y, R.z); fnorm(in, t); f2_sqr_u<64>(hs, in);
+    fadd(t, R.x, R.y); fnorm(in, t); f2_sqr_u<64>(s1, in);
+    fadd(t, R.x, z); fnorm(in, t); f2_sqr_u<64>(j, in);
+    f2_mul12_n(t, c); f2_mul_xi_n<128>(e, t);                           // e = 12 (1 + u) c
+    fadd(f, e, e); fadd(f, f, e);                                       // f = 3 e
+    fadd(t, b, f); fhalf(g, t);                                         // g = (b + f) / 2
+    fsub<8>(l.c0, e, b);                                                // i = e - b
+    fadd(t, b, c); f2_sub_n<16>(h, hs, t);                              // h = (Y + Z)^2 - (b + c)
+    fadd(t, j, b); fsub<8>(a2, s1, t); fhalf(ah, a2);                   // X Y
+    f2_sub_n<256>(d2, b, g);                                            // (b - f) / 2
+    fadd(t, j, j); fadd(l.c1, t, j);                                    // 3 j
+    fsub<32>(l.c2, z, h);                                               // -h
+    F2 nx, nz;
+    fmul(e2, e, e); fmul(g2, g, g); fmul(nz, b, h); fmul(nx, ah, d2);   // round 2
+    fadd(t, e2, e2); fadd(t, t, e2); fsub<32>(R.y, g2, t);              // Y' = g^2 - 3 e^2
+    if (norm_y) fnorm(R.y, R.y);
+    R.x = nx; R.z = nz;
+}
 template <class F2> FD void line_add_step(G2ProjT<F2> &R, const Aff<F2> &Q, LineT<F2> &l) {
     F2 theta, lam, c, d, e, f, g, h, j, t, u;
     fmul(t, Q.y, R.z); f2_sub_n<8>(theta, R.y, t);

@@ -225,6 +225,28 @@ static void pair_lines(std::vector<Line> &ls, const uint32_t *p, const uint32_t 
         if ((BLS_X_ABS >> i) & 1) { line_add_step(R, Q, l); line_eval(l, px, py); ls.push_back(l); }
     }
 }
+// the same lines through line_dbl_step_fast (what k_miller_lines_hex computes): un-normalised coefficients are carry-passed by the consumer
+static void pair_lines_fast(std::vector<Line> &ls, const uint32_t *p, const uint32_t *q) {
+    Fp px, py; fp_from_abi(px, p); fp_from_abi(py, p + 12);
+    Aff<Fp2> Q; load_aff2(Q, q);
+    G2Proj R; R.x = Q.x; R.y = Q.y; fset_one(R.z);
+    for (int i = 62; i >= 0; i--) {
+        const bool add = (BLS_X_ABS >> i) & 1;
+        Line l; line_dbl_step_fast(R, l, add || i == 0);
+        fnorm(l.c0, l.c0); fnorm(l.c1, l.c1); fnorm(l.c2, l.c2);
+        line_eval(l, px, py); ls.push_back(l);
+        if (add) { line_add_step(R, Q, l); line_eval(l, px, py); ls.push_back(l); }
+    }
+}
+void shim_miller_lines_fast(const uint32_t *p, const uint32_t *q, uint32_t *out) {
+    std::vector<Line> ls; pair_lines_fast(ls, p, q);
+    for (size_t s = 0; s < ls.size(); s++) { const Fp *c = reinterpret_cast<const Fp *>(&ls[s]); for (int k = 0; k < 6; k++) fp_to_abi(out + (s * 6 + k) * 12, c[k]); }
+}
+// 12 a by the scaled carry pass, from a lazily reduced operand (k a, carry-passed)
+void shim_fp_mul12(const uint32_t *a, int k, uint32_t *out) {
+    Fp x, t, r; fp_from_abi(x, a); t = x; for (int i = 1; i < k; i++) fp_add(t, t, x); fp_norm(t, t);
+    fp_mul12_norm(r, t); fp_norm(r, r); fp_to_abi(out, r);
+}
 // out: 68 x (c0, c1, c2) in ABI form (6 Fp each)
 void shim_miller_lines(const uint32_t *p, const uint32_t *q, uint32_t *out) {
     std::vector<Line> ls; pair_lines(ls, p, q);

@@ -235,6 +235,23 @@ def test_miller_loop_dataflow_on_host(shim):
         assert U.f12_ints(o) == _f12_flat(M.multi_miller_loop(ps[:n], qs[:n]))
 
 
+def test_fast_doubling_step_of_the_sixteen_lane_kernel(shim):
+    """line_dbl_step_fast (pairing29.hip.h: what k_miller_lines_hex distributes over a 16-lane row: all-squarings first round, X Y from
+    (X + Y)^2, the scaled x 12 carry pass, un-normalised f / Y' / line coefficients, one halving instead of two) under the bound tracker:
+    every one of the 68 evaluated lines equals line_dbl_step / line_add_step's, for generator multiples and for random points"""
+    rng = random.Random(77)
+    ks = [(1, 1), (3, 5), (M.R - 2, 7), (rng.randrange(M.R), rng.randrange(M.R)), (rng.randrange(M.R), rng.randrange(M.R))]
+    for a, b in ks:
+        pa = np.ascontiguousarray(U.g1_abi(M.g1_mul(M.G1_GEN, a))[0]); qa = np.ascontiguousarray(U.g2_abi(M.g2_mul(M.G2_GEN, b))[0])
+        ref = np.zeros(68 * 6 * 6, np.uint64); got = np.zeros_like(ref)
+        shim.shim_miller_lines(p_(pa), p_(qa), p_(ref)); shim.shim_miller_lines_fast(p_(pa), p_(qa), p_(got))
+        assert (ref == got).all()
+    out = np.zeros(6, np.uint64)
+    for v in [0, 1, P - 1, (P - 1) // 2, 2 ** 380, 2 ** 377 - 1] + [rng.randrange(P) for _ in range(60)]:
+        for k in (1, 2, 5, 7):
+            shim.shim_fp_mul12(p_(U.fp_abi(v)), k, p_(out)); assert U.fp_int(out) == 12 * k * v % P
+
+
 def test_fr_ops_on_host(shim):
     """fr29.hip.h (the NTT's field) under the bound tracker: Montgomery and canonical products, a chain of lazy butterflies"""
     rng = random.Random(5)

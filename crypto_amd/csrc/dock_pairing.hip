@@ -739,7 +739,13 @@ static int32_t ml_pipelined(Slot &sl, size_t n, size_t n_aff, const uint8_t *dsk
     // the last steps' products are all that is left when the chain ends: from 8-pair slices on they take half the slice length (fewer
     // sparse products in front of the tree, more tree for a quarter of the steps: 1.46 -> 1.39 ms at 4096 pairs; measured the other way
     // round at 1024 pairs, 4 -> 2: 1.06 -> 1.14)
-    ml_geom_set(g2, n, g.slice_len >= 8 && (n + g.slice_len / 2 - 1) / (g.slice_len / 2) <= 2048 ? g.slice_len / 2 : g.slice_len, ml_geom_words(g));
+    int tail_slice = g.slice_len >= 8 && (n + g.slice_len / 2 - 1) / (g.slice_len / 2) <= 2048 ? g.slice_len / 2 : g.slice_len;
+    int cuts[ML_PIECES]; for (int j = 0; j < ML_PIECES; j++) cuts[j] = ML_CUTS[j];
+#ifdef DGPU_DEV
+    if (const char *e = getenv("DGPU_ML_TAIL_SLICE")) { const int v = atoi(e); if (v >= 1 && (n + v - 1) / v <= 2048) tail_slice = v; }
+    if (const char *e = getenv("DGPU_ML_CUTS")) { int a = 0, b = 0; if (sscanf(e, "%d,%d", &a, &b) == 2 && a > b && b > 0 && a < 62) { cuts[0] = a; cuts[1] = b; } }
+#endif
+    ml_geom_set(g2, n, tail_slice, ml_geom_words(g));
     if ((rc = sl.ml_partial.ensure((ml_geom_words(g) + ml_geom_words(g2)) * 4))) return rc;
     if ((rc = sl.ml_state.ensure(((size_t)3 * NL * 4 * n_aff + (size_t)2 * NL * n) * 4))) return rc;      // R of every lane, then px, py of every pair
     hipStream_t sa = sl.stream;
@@ -755,7 +761,7 @@ static int32_t ml_pipelined(Slot &sl, size_t n, size_t n_aff, const uint8_t *dsk
     hipEvent_t done[ML_PIECES - 1] = {};
     int s_first = 0, b_hi = 62;
     for (int j = 0; j < ML_PIECES && !rc; j++) {
-        const int b_lo = ML_CUTS[j], ns = ml_steps(b_hi, b_lo);
+        const int b_lo = cuts[j], ns = ml_steps(b_hi, b_lo);
         launch_lines_uneval(sa, sl.in_bases.as<uint32_t>(), sl.in_scalars.as<uint32_t>(), dskip, n_aff, sl.ml_lines.as<uint32_t>(), n, b_hi, b_lo, s_first, state, pxy);
         if (j + 1 < ML_PIECES) {
             hipEvent_t ready = sl.copy_ev[sl.ev_next++ % (Slot::N_COPY_EV + 1)];
@@ -774,7 +780,7 @@ static int32_t ml_pipelined(Slot &sl, size_t n, size_t n_aff, const uint8_t *dsk
     }
     ok(hipGetLastError());
     MlTail tail;
-    for (int j = 0; j + 1 < ML_PIECES; j++) if (!rc && ok(hipEventSynchronize(done[j]))) tail.run(L, ML_CUTS[j]);
+    for (int j = 0; j + 1 < ML_PIECES; j++) if (!rc && ok(hipEventSynchronize(done[j]))) tail.run(L, cuts[j]);
     ok(hipStreamSynchronize(sa)); ok(hipStreamSynchronize(side[0])); ok(hipStreamSynchronize(side[1]));
     if (rc) return rc;
     tail.run(L, 0);

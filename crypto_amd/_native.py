@@ -41,7 +41,7 @@ _lib = None
 # every symbol include/dock_gpu.h declares
 SYMBOLS = [
     "dgpu_init", "dgpu_init_devices", "dgpu_init_device_list", "dgpu_context_count", "dgpu_set_device", "dgpu_shutdown", "dgpu_device_count", "dgpu_strerror", "dgpu_last_hip_error",
-    "dgpu_set_min_gpu_n", "dgpu_get_min_gpu_n", "dgpu_set_window_bits", "dgpu_set_chunk", "dgpu_set_miller_pipeline", "dgpu_set_reduce_shift", "dgpu_set_reduce_lanes", "dgpu_reserve_g1", "dgpu_reserve_g2", "dgpu_device_alloc_count",
+    "dgpu_set_min_gpu_n", "dgpu_get_min_gpu_n", "dgpu_set_window_bits", "dgpu_set_chunk", "dgpu_set_miller_pipeline", "dgpu_set_small_msm_max", "dgpu_set_reduce_shift", "dgpu_set_reduce_lanes", "dgpu_reserve_g1", "dgpu_reserve_g2", "dgpu_device_alloc_count",
     "dgpu_msm_g1", "dgpu_msm_g1_mont", "dgpu_msm_g2", "dgpu_msm_g2_mont", "dgpu_msm_g1_strided", "dgpu_msm_g2_strided", "dgpu_bases_upload_g1_strided", "dgpu_bases_upload_g2_strided",
     "dgpu_bases_upload_g1", "dgpu_bases_upload_g2", "dgpu_bases_free", "dgpu_scalars_upload", "dgpu_scalars_upload_parts", "dgpu_scalars_free",
     "dgpu_msm_g1_handle", "dgpu_msm_g2_handle", "dgpu_msm_g1_resident", "dgpu_msm_g2_resident", "dgpu_bases_precompute_g1", "dgpu_bases_precompute_g2",
@@ -70,6 +70,7 @@ def lib():
         L.dgpu_set_window_bits.argtypes = [C.c_int32]
         L.dgpu_set_chunk.argtypes = [C.c_int32]
         L.dgpu_set_miller_pipeline.argtypes = [C.c_int32]
+        L.dgpu_set_small_msm_max.argtypes = [C.c_size_t]
         L.dgpu_set_reduce_shift.argtypes = [C.c_int32]
         L.dgpu_set_reduce_lanes.argtypes = [C.c_int32]
         L.dgpu_reserve_g1.argtypes = [C.c_size_t]

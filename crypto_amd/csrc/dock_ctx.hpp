@@ -104,6 +104,7 @@ struct Shared {
     std::atomic<int32_t> last_hip{0};
     std::atomic<size_t> min_gpu_n{DGPU_DEFAULT_MIN_GPU_N};
     std::atomic<int> window_bits{0};
+    std::atomic<size_t> small_max{8192};      // dgpu_set_small_msm_max: MSMs of up to this many terms on plain bases take the two-launch tree path (small_kernels.hip.h); 0 = never
     std::atomic<int> chunk{0};
     std::atomic<int> reduce_lanes{4};         // dgpu_set_reduce_lanes: members per point in the last reduction kernel (1: k_reduce_top, 4: k_reduce_top_quad)
     std::atomic<int> reduce_shift{-1};        // dgpu_set_reduce_shift: log2 buckets per lane of k_reduce_l0 on the table pipeline (-1 = automatic)

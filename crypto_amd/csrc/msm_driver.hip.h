@@ -165,6 +165,59 @@ template <class C> int32_t ws_bucket_sets(Slot &sl, uint32_t NB, size_t K) {
     return sl.bucket_inf.ensure(K * (size_t)NB);
 }
 
+// ---- the small path: up to SMALL_MSM_MAX_N terms over plain bases (small_kernels.hip.h) ----------------------------------------------------
+template <class C> int32_t ws_small(Slot &sl, size_t n) {
+    int32_t rc;
+    typedef typename C::ACC A;
+    const size_t n_pad = (n + 7) & ~(size_t)7, nblk = (n + SMALL_MSM_LEAVES - 1) / SMALL_MSM_LEAVES;
+    if ((rc = sl.flags.ensure(64))) return rc;
+    if ((rc = sl.digits.ensure((size_t)SMALL_MSM_W * n_pad * 2))) return rc;
+    if ((rc = sl.bucket.ensure(n * SMALL_MSM_E * A::XW * 4))) return rc;
+    if ((rc = sl.bucket_inf.ensure(n * SMALL_MSM_E))) return rc;
+    if ((rc = sl.head.ensure((size_t)SMALL_MSM_W * nblk * A::XW * 4))) return rc;
+    if ((rc = sl.part_inf.ensure((size_t)SMALL_MSM_W * nblk))) return rc;
+    // window sums, their identity flags, the bad-scalar flag and the per-window block counters in ONE buffer: one memset, one copy back
+    return sl.win.ensure((size_t)SMALL_MSM_W * 4 * C::ABI_W * 4 + SMALL_MSM_W + 4 + (size_t)SMALL_MSM_W * 4);
+}
+// digit codes -> table of eight multiples per base -> one tree per window -> the host's Horner fold.  ready_scalars / ready_bases queue whatever
+// still has to bring the operands to the device (one-shot calls: the copies and the conversion of the raw points).
+template <class C, class HF, class ReadyS, class ReadyB>
+int32_t msm_device_small(Slot &sl, const uint32_t *d_bases, const uint32_t *d_scalars, size_t n, uint64_t *out_xyz, ReadyS ready_scalars, ReadyB ready_bases) {
+    int32_t rc;
+    if ((rc = ws_small<C>(sl, n))) return rc;
+    hipStream_t s = sl.stream;
+    const size_t n_pad = (n + 7) & ~(size_t)7;
+    constexpr int W = SMALL_MSM_W, c = SMALL_MSM_C;
+    if ((rc = ready_scalars(0, 0, n))) return rc;
+    if ((rc = ready_bases(0, 0, n))) return rc;
+    constexpr size_t WBYTES = (size_t)W * 4 * C::ABI_W * 4;
+    static_assert(WBYTES + W + 4 <= Slot::HPIN_BYTES, "pinned scratch");
+    uint8_t *const wbuf = sl.win.as<uint8_t>();
+    uint8_t *const d_inf = wbuf + WBYTES;
+    uint32_t *const d_flag = (uint32_t *)(wbuf + WBYTES + W), *const d_count = d_flag + 1;
+    HIPCHK(hipMemsetAsync(d_flag, 0, 4 + (size_t)W * 4, s));
+    {
+        StageTimer st(sl, "msm.small_digits_table");
+        launch_digit_codes(s, false, d_scalars, d_bases, C::AFF_STRIDE, C::FLAGW, n, n_pad, c, W, sl.digits.p, d_flag);
+        launch_small_table<C>(s, d_bases, n, sl.bucket.as<uint32_t>(), sl.bucket_inf.as<uint8_t>());
+    }
+    {
+        StageTimer st(sl, "msm.small_tree");
+        launch_small_tree<C>(s, sl.bucket.as<uint32_t>(), sl.bucket_inf.as<uint8_t>(), sl.digits.p, n, n_pad, sl.head.as<uint32_t>(), sl.part_inf.as<uint8_t>(), d_count,
+                             (uint32_t *)wbuf, d_inf);
+    }
+    HIPCHK(hipGetLastError());
+    uint8_t *const hbuf = (uint8_t *)sl.hpin;                       // pinned: one asynchronous copy brings everything back
+    HIPCHK(hipMemcpyAsync(hbuf, wbuf, WBYTES + W + 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (gs.prof) prof_flush(sl);
+    const uint64_t *hwin = (const uint64_t *)hbuf; const uint8_t *hinf = hbuf + WBYTES;
+    uint32_t hbad; memcpy(&hbad, hbuf + WBYTES + W, 4);
+    if (hbad) return DGPU_E_BADARG;                  // a scalar >= 2^255
+    host_fold<HF>(hwin, hinf, W, c, out_xyz);
+    return DGPU_OK;
+}
+
 // d_bases: prepared records; d_scalars: canonical 8 x u32 per scalar.  Caller holds the slot.
 // bases_pending: the base records are written by work that `ready_bases(k, lo, hi)` queues on this stream between the sort and the accumulation
 // of range k (one-shot calls: the bases cross PCIe while the scalars are sorted): the sort does not look at them and the accumulation passes over
@@ -172,6 +225,7 @@ template <class C> int32_t ws_bucket_sets(Slot &sl, uint32_t NB, size_t K) {
 template <class C, class HF, class ReadyS, class ReadyB>
 int32_t msm_device_ranges(Slot &sl, const uint32_t *d_bases, const uint32_t *d_scalars, size_t n, size_t K, uint64_t *out_xyz, bool bases_pending, ReadyS ready_scalars, ReadyB ready_bases) {
     if (n == 0) { write_identity<HF>(out_xyz); return DGPU_OK; }
+    if (K == 1 && n <= gs.small_max.load() && n <= SMALL_MSM_MAX_N) return msm_device_small<C, HF>(sl, d_bases, d_scalars, n, out_xyz, ready_scalars, ready_bases);
     PlainGeom g; int32_t rc;
     if ((rc = plain_geometry<C>(n, g))) return rc;
     if ((rc = ws_plain<C>(sl, g))) return rc;
@@ -643,6 +697,7 @@ template <class C> int32_t ws_for(Slot &sl, int what, size_t n, size_t stride, c
     }
     // (the bucket sets of the range-wise form, which calls with operands still in flight take from n = 2^19 on)
     if (what == 3) { PreGeom g; if ((rc = pre_geometry<C>(*pt, n, g))) return rc; if ((rc = ws_pre<C>(sl, *pt, g, n))) return rc; return ws_bucket_sets<C>(sl, g.NB, range_count(n, true)); }
+    if (n <= SMALL_MSM_MAX_N && (rc = ws_small<C>(sl, n))) return rc;     // (both paths: dgpu_set_small_msm_max may switch between them)
     PlainGeom g; if ((rc = plain_geometry<C>(n, g))) return rc;
     if ((rc = ws_plain<C>(sl, g))) return rc;
     return ws_bucket_sets<C>(sl, g.NB, range_count(n, true));

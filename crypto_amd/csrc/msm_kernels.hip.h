@@ -712,6 +712,13 @@ __global__ void __launch_bounds__(64) k_reduce_top_pair(const uint32_t *__restri
 // for G2) in identical copies, each member multiplies ONE role-selected operand pair per round and the four results are broadcast — DPP
 // quad_perm for G1, ds_bpermute inside the group of eight lanes for G2.  The exchange between groups (the shuffles of
 // wave_weighted_sum) goes through LDS: member r parks coordinate r.  Same group geometry, l1 layout and outputs as k_reduce_top(_pair).
+// one of four values by the member's role, without control flow: nested ternaries on a lane-dependent value came out of the compiler as a
+// branch per limb (s_cbranch_execz: ~60 per product), which made the four-member addition 2.5x as long as its instruction count
+template <class T> __device__ __forceinline__ T pick4(int role, T a, T b, T c, T d) {
+    const uint32_t m1 = (role & 1) ? 0xffffffffu : 0u, m2 = (role & 2) ? 0xffffffffu : 0u;
+    const uint32_t lo = ((uint32_t)b & m1) | ((uint32_t)a & ~m1), hi = ((uint32_t)d & m1) | ((uint32_t)c & ~m1);
+    return (T)((hi & m2) | (lo & ~m2));
+}
 template <int LPP> struct QuadLanes;
 template <> struct QuadLanes<1> {                       // members = the four lanes of a quad
     int role; int src[4];
@@ -722,10 +729,7 @@ template <> struct QuadLanes<1> {                       // members = the four la
     __device__ __forceinline__ void mul4(Fs (&r)[4], const Fs (&a)[4], const Fs (&b)[4], int used) const {
         Fs m1, m2, p;
 #pragma unroll
-        for (int i = 0; i < SN; i++) {
-            m1.l[i] = role == 0 ? a[0].l[i] : (role == 1 ? a[1].l[i] : (role == 2 ? a[2].l[i] : a[3].l[i]));
-            m2.l[i] = role == 0 ? b[0].l[i] : (role == 1 ? b[1].l[i] : (role == 2 ? b[2].l[i] : b[3].l[i]));
-        }
+        for (int i = 0; i < SN; i++) { m1.l[i] = pick4(role, a[0].l[i], a[1].l[i], a[2].l[i], a[3].l[i]); m2.l[i] = pick4(role, b[0].l[i], b[1].l[i], b[2].l[i], b[3].l[i]); }
         fs_mul(p, m1, m2);
 #pragma unroll
         for (int i = 0; i < SN; i++) {
@@ -744,10 +748,7 @@ template <> struct QuadLanes<2> {                       // members = the four la
     __device__ __forceinline__ void mul4(Fs2H (&r)[4], const Fs2H (&a)[4], const Fs2H (&b)[4], int used) const {
         Fs2H m1, m2, p;
 #pragma unroll
-        for (int i = 0; i < SN; i++) {
-            m1.v.l[i] = role == 0 ? a[0].v.l[i] : (role == 1 ? a[1].v.l[i] : (role == 2 ? a[2].v.l[i] : a[3].v.l[i]));
-            m2.v.l[i] = role == 0 ? b[0].v.l[i] : (role == 1 ? b[1].v.l[i] : (role == 2 ? b[2].v.l[i] : b[3].v.l[i]));
-        }
+        for (int i = 0; i < SN; i++) { m1.v.l[i] = pick4(role, a[0].v.l[i], a[1].v.l[i], a[2].v.l[i], a[3].v.l[i]); m2.v.l[i] = pick4(role, b[0].v.l[i], b[1].v.l[i], b[2].v.l[i], b[3].v.l[i]); }
         fmul(p, m1, m2);
 #pragma unroll
         for (int i = 0; i < SN; i++) {
@@ -783,12 +784,12 @@ __global__ void __launch_bounds__(256 * C::LPP) k_reduce_top_quad(const uint32_t
         return;
     }
     // o = the point of group gi + d (identity past the last group): member r parks coordinate r, everybody reads all four
-    auto from_group = [&](Xyzz<F> &o, bool &oinf, const Xyzz<F> &x, bool xinf, int d) {
+    auto from_group = [&](Xyzz<F> &o, bool &oinf, const Xyzz<F> &x, bool xinf, int d) __attribute__((always_inline)) {
         __syncthreads();
-        { const uint32_t *wv = reinterpret_cast<const uint32_t *>(&x) + q4.role * SN;
+        { const uint32_t *wx = reinterpret_cast<const uint32_t *>(&x);      // coordinate `role` (picked without a lane-dependent register index: that goes to scratch)
           uint32_t *dst = xs + ((gi * 4 + q4.role) * LPP + h) * SN;
 #pragma unroll
-          for (int j = 0; j < SN; j++) dst[j] = wv[j];
+          for (int j = 0; j < SN; j++) dst[j] = pick4(q4.role, wx[j], wx[SN + j], wx[2 * SN + j], wx[3 * SN + j]);
           if (t % GL == 0) fl[gi] = xinf; }
         __syncthreads();
         const int sg = gi + d;
@@ -824,8 +825,11 @@ __global__ void __launch_bounds__(256 * C::LPP) k_reduce_top_quad(const uint32_t
         if (t == 0) { win_inf[w] = ainf; if (win_s_abi) win_s_inf[w] = sinf; }
         const Fs *fa = reinterpret_cast<const Fs *>(&A), *fsv = reinterpret_cast<const Fs *>(&S);
         constexpr int WS = 4 * 12 * LPP;                             // ABI words per window sum
-        if (!ainf) fs_to_abi(win_abi + w * WS + 12 * (LPP * r + h), fa[r]);
-        if (win_s_abi && !sinf) fs_to_abi(win_s_abi + w * WS + 12 * (LPP * r + h), fsv[r]);
+        Fs ma, ms;
+#pragma unroll
+        for (int k = 0; k < SN; k++) { ma.l[k] = pick4(r, fa[0].l[k], fa[1].l[k], fa[2].l[k], fa[3].l[k]); ms.l[k] = pick4(r, fsv[0].l[k], fsv[1].l[k], fsv[2].l[k], fsv[3].l[k]); }
+        if (!ainf) fs_to_abi(win_abi + w * WS + 12 * (LPP * r + h), ma);
+        if (win_s_abi && !sinf) fs_to_abi(win_s_abi + w * WS + 12 * (LPP * r + h), ms);
     }
 }
 

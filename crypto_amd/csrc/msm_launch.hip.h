@@ -22,6 +22,14 @@ template <class C> void launch_merge_buckets(hipStream_t s, uint32_t NB, uint32_
 template <class C> void launch_reduce_l0(hipStream_t s, unsigned NG, const uint32_t *bucket, const uint8_t *bucket_inf, uint32_t NB, int mshift, uint32_t *l1, uint8_t *l1_inf);
 template <class C> void launch_reduce_top(hipStream_t s, unsigned W, const uint32_t *l1, const uint8_t *l1_inf, int G, int gshift, uint32_t *win_abi, uint8_t *win_inf, int lanes);
 
+// the small-MSM path (small_kernels.hip.h; k_g1_small.hip / k_g2_small.hip): 64 signed 4-bit windows, eight multiples per base, a tree per window
+constexpr int SMALL_MSM_C = 4, SMALL_MSM_W = 64, SMALL_MSM_E = 8, SMALL_MSM_LEAVES = 128;
+constexpr size_t SMALL_MSM_MAX_N = 8192;
+inline int small_per_group(size_t n) { int g = 2; while ((n + 64 * (size_t)g - 1) / (64 * (size_t)g) > 8) g *= 2; return g; }      // leaves per group of k_small_tree: 2 .. 16
+template <class C> void launch_small_table(hipStream_t s, const uint32_t *bases, size_t n, uint32_t *tab, uint8_t *tab_inf);
+template <class C> void launch_small_tree(hipStream_t s, const uint32_t *tab, const uint8_t *tab_inf, const void *codes, size_t n, size_t n_pad, uint32_t *partial, uint8_t *partial_inf,
+                                          uint32_t *count, uint32_t *win_abi, uint8_t *win_inf);
+
 // precomputed-multiples tables (pre_kernels.hip.h; k_g1_pre.hip / k_g2_pre.hip)
 template <class C> void launch_pre_step(hipStream_t s, const uint32_t *prev, size_t n, int c, uint32_t *tmp, uint32_t *out);
 // reduce_top that also hands back the plain sum S of every pseudo-window (win_s_abi / win_s_inf), for the shared-bucket-set fold

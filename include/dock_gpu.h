@@ -69,6 +69,10 @@ int32_t dgpu_set_chunk(int32_t terms);
 int32_t dgpu_set_reduce_shift(int32_t log2_buckets_per_lane);
 /* lanes (G2: lane pairs) per point in the last kernel of the bucket reduction: 4 (default; a general addition four products deep) or 1. */
 int32_t dgpu_set_reduce_lanes(int32_t lanes);
+/* MSMs of up to n terms (default and maximum 8192) over plain bases — one-shot calls, plain handles — run as 64 signed 4-bit windows, each a
+ * tree over the terms' table entries (two launches after the digit codes: crypto_amd/csrc/small_kernels.hip.h) instead of the ~15-launch bucket
+ * pipeline: 0.2 - 0.35 ms instead of 0.7 - 0.9 ms per call.  0: always the bucket pipeline (the parity tests compare the two). */
+int32_t dgpu_set_small_msm_max(size_t n);
 /* Forms of the Miller-loop kernels, a bit mask (default 7).  Bit 0: dgpu_multi_miller_loop of up to 8192 pairs runs its line kernel in two
  * launches and overlaps the products / host share of the first with the second (and dgpu_g2_prepare runs the same lanes-per-point chain
  * followed by a parallel conversion pass).  Bit 1: the product tree gives every node 18 lane pairs (one Fp2 product deep per level) instead

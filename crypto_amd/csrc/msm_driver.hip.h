@@ -179,7 +179,7 @@ template <class C> int32_t ws_small(Slot &sl, size_t n) {
     // window sums, their identity flags, the bad-scalar flag and the per-window block counters in ONE buffer: one memset, one copy back
     return sl.win.ensure((size_t)SMALL_MSM_W * 4 * C::ABI_W * 4 + SMALL_MSM_W + 4 + (size_t)SMALL_MSM_W * 4);
 }
-// digit codes -> table of eight multiples per base -> one tree per window -> the host's Horner fold.  ready_scalars / ready_bases queue whatever
+// (digit codes and) the table of eight multiples per base -> one tree per window -> the host's Horner fold.  ready_scalars / ready_bases queue whatever
 // still has to bring the operands to the device (one-shot calls: the copies and the conversion of the raw points).
 template <class C, class HF, class ReadyS, class ReadyB>
 int32_t msm_device_small(Slot &sl, const uint32_t *d_bases, const uint32_t *d_scalars, size_t n, uint64_t *out_xyz, ReadyS ready_scalars, ReadyB ready_bases) {
@@ -198,8 +198,7 @@ int32_t msm_device_small(Slot &sl, const uint32_t *d_bases, const uint32_t *d_sc
     HIPCHK(hipMemsetAsync(d_flag, 0, 4 + (size_t)W * 4, s));
     {
         StageTimer st(sl, "msm.small_digits_table");
-        launch_digit_codes(s, false, d_scalars, d_bases, C::AFF_STRIDE, C::FLAGW, n, n_pad, c, W, sl.digits.p, d_flag);
-        launch_small_table<C>(s, d_bases, n, sl.bucket.as<uint32_t>(), sl.bucket_inf.as<uint8_t>());
+        launch_small_table<C>(s, d_bases, n, sl.bucket.as<uint32_t>(), sl.bucket_inf.as<uint8_t>(), d_scalars, n_pad, sl.digits.p, d_flag);
     }
     {
         StageTimer st(sl, "msm.small_tree");

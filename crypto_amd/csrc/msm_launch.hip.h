@@ -25,8 +25,10 @@ template <class C> void launch_reduce_top(hipStream_t s, unsigned W, const uint3
 // the small-MSM path (small_kernels.hip.h; k_g1_small.hip / k_g2_small.hip): 64 signed 4-bit windows, eight multiples per base, a tree per window
 constexpr int SMALL_MSM_C = 4, SMALL_MSM_W = 64, SMALL_MSM_E = 8, SMALL_MSM_LEAVES = 128;
 constexpr size_t SMALL_MSM_MAX_N = 8192;
-inline int small_per_group(size_t n) { int g = 2; while ((n + 64 * (size_t)g - 1) / (64 * (size_t)g) > 8) g *= 2; return g; }      // leaves per group of k_small_tree: 2 .. 16
-template <class C> void launch_small_table(hipStream_t s, const uint32_t *bases, size_t n, uint32_t *tab, uint8_t *tab_inf);
+// leaves per group of k_small_tree: at most FOUR blocks per window, i.e. 256 blocks = one block per CU (the kernel holds one wave per SIMD):
+// a fifth block per window would run behind the others and double the kernel's length
+inline int small_per_group(size_t n) { const int g = (int)((n + 255) / 256); return g < 2 ? 2 : g; }
+template <class C> void launch_small_table(hipStream_t s, const uint32_t *bases, size_t n, uint32_t *tab, uint8_t *tab_inf, const uint32_t *scalars, size_t n_pad, void *codes, uint32_t *bad);
 template <class C> void launch_small_tree(hipStream_t s, const uint32_t *tab, const uint8_t *tab_inf, const void *codes, size_t n, size_t n_pad, uint32_t *partial, uint8_t *partial_inf,
                                           uint32_t *count, uint32_t *win_abi, uint8_t *win_inf);
 

@@ -8,8 +8,8 @@
 //
 //   no buckets, no sort: window w of term i contributes d_iw P_i with a signed 4-bit digit |d| <= 8 (64 windows), i.e. ONE entry of a
 //   per-call table of the eight multiples 1 P_i .. 8 P_i (k_small_table), negated when the digit is; the window sum
-//   S_w = sum_i (+-) T[i][|d_iw| - 1] is a plain TREE over i (k_small_tree): two leaves per group, 64 groups per block folded through
-//   LDS (6 levels), the blocks of a window folded by whichever of them finishes last (<= 6 more levels).  Every point has FOUR members
+//   S_w = sum_i (+-) T[i][|d_iw| - 1] is a plain TREE over i (k_small_tree): a few leaves per group, 64 groups per block folded through
+//   LDS (6 levels), the <= 4 blocks of a window folded by whichever of them finishes last (2 more levels).  Every point has FOUR members
 //   (lanes; lane pairs for G2: QuadLanes of msm_kernels.hip.h), each multiplies one role-selected operand pair per round, so an addition
 //   is four products deep (ec29.hip.h xyzz_add_rounds) instead of fourteen.  Depth: 1 doubling + 6 additions (table) + 1 + 6 + <= 6
 //   additions (tree) ~ 20 x 3.5 us; work n x 64 additions.  The host's Horner fold over the 64 window sums is the one the bucket
@@ -19,6 +19,7 @@
 // for bit the bucket pipeline's (tests/test_gpu_small_msm.py compares both and the oracle).
 #pragma once
 #include "msm_launch.hip.h"
+#include "digit_codes.hip.h"
 
 namespace msm {
 
@@ -31,10 +32,11 @@ static_assert(SMALL_W == 255 / SMALL_C + 1 && SMALL_E == 1 << (SMALL_C - 1) && S
 __device__ __forceinline__ void neg_in_place(Fs &a) { fs_neg(a, a); }           // signed digits: a negation is thirteen v_sub
 __device__ __forceinline__ void neg_in_place(Fs2H &a) { fs_neg(a.v, a.v); }
 
-// T[i][e] = (e + 1) P_i for e < 8: group g = base i, its four members hold identical copies; member 0 stores.
+// T[i][e] = (e + 1) P_i for e < 8, and the term's digit codes (window-major, k_digit_codes' format): group g = base i, its four members hold identical copies; member 0 stores.
 // An identity base (flag word of its record) gets identity entries (tab_inf), and its digit codes are all "zero" anyway (k_digit_codes).
 template <class A>
-__global__ void __launch_bounds__(256 * A::LPP) k_small_table(const uint32_t *__restrict__ bases, size_t n, uint32_t *__restrict__ tab, uint8_t *__restrict__ tab_inf) {
+__global__ void __launch_bounds__(256 * A::LPP) k_small_table(const uint32_t *__restrict__ bases, size_t n, uint32_t *__restrict__ tab, uint8_t *__restrict__ tab_inf,
+                                                              const uint32_t *__restrict__ scalars, size_t n_pad, uint16_t *__restrict__ codes, uint32_t *__restrict__ bad) {
     typedef typename A::F F;
     constexpr int LPP = A::LPP, GL = 4 * LPP;
     const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / GL;
@@ -43,6 +45,8 @@ __global__ void __launch_bounds__(256 * A::LPP) k_small_table(const uint32_t *__
     const uint32_t *rec = bases + i * A::AFF_STRIDE;
     const bool inf = rec[A::FLAGW] != 0;
     const bool writer = ((threadIdx.x % GL) / LPP) == 0;          // member 0 (G2: both lanes of its pair, each its half)
+    // the term's 64 digit codes, by the group's first lane (k_digit_codes' loop: a launch of its own costs more than these ~800 instructions)
+    if (threadIdx.x % GL == 0) digit_codes_one<uint16_t>(scalars, i, n, inf, n_pad, SMALL_C, SMALL_W, codes, bad);
     if (inf) {
         if (threadIdx.x % GL == 0) for (int e = 0; e < SMALL_E; e++) tab_inf[i * SMALL_E + e] = 1;
         return;
@@ -62,8 +66,8 @@ __global__ void __launch_bounds__(256 * A::LPP) k_small_table(const uint32_t *__
     if (threadIdx.x % GL == 0) { tab_inf[i * SMALL_E] = 0; tab_inf[i * SMALL_E + 1] = 0; }
 }
 
-// block (j, w): S = sum over terms 64 g j .. 64 g (j + 1) - 1 of window w's leaves (g = per_group: 2 up to 1024 terms, then as many as keep the
-// blocks of a window at eight: the levels of a block's tree cost every wave of the block a whole addition, a leaf costs its group one); the last block of a window to finish folds the window's
+// block (j, w): S = sum over terms 64 g j .. 64 g (j + 1) - 1 of window w's leaves (g = per_group = small_per_group(n): two, or as many as keep
+// the blocks of a window at four); the last block of a window to finish folds the window's
 // partials and writes the window sum in the form host_fold reads (k_reduce_top_quad's).  count[w] must be zero at launch and is zero again
 // at the end.
 template <class A>
@@ -163,9 +167,9 @@ __global__ void __launch_bounds__(256 * A::LPP) k_small_tree(const uint32_t *__r
 }
 
 // launchers (instantiated by k_g1_small.hip / k_g2_small.hip; the drivers see the declarations in msm_launch.hip.h)
-template <class C> void launch_small_table(hipStream_t s, const uint32_t *bases, size_t n, uint32_t *tab, uint8_t *tab_inf) {
+template <class C> void launch_small_table(hipStream_t s, const uint32_t *bases, size_t n, uint32_t *tab, uint8_t *tab_inf, const uint32_t *scalars, size_t n_pad, void *codes, uint32_t *bad) {
     typedef typename C::ACC A;
-    hipLaunchKernelGGL((k_small_table<A>), dim3((unsigned)((n + 63) / 64)), dim3(256 * A::LPP), 0, s, bases, n, tab, tab_inf);
+    hipLaunchKernelGGL((k_small_table<A>), dim3((unsigned)((n + 63) / 64)), dim3(256 * A::LPP), 0, s, bases, n, tab, tab_inf, scalars, n_pad, (uint16_t *)codes, bad);
 }
 template <class C> void launch_small_tree(hipStream_t s, const uint32_t *tab, const uint8_t *tab_inf, const void *codes, size_t n, size_t n_pad, uint32_t *partial, uint8_t *partial_inf,
                                           uint32_t *count, uint32_t *win_abi, uint8_t *win_inf) {

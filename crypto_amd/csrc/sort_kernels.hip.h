@@ -7,6 +7,7 @@
 #include "ec29.hip.h"
 #include "fp_inv.hip.h"
 #include "ec29_two_lane.hip.h"
+#include "digit_codes.hip.h"
 
 namespace msm {
 using namespace bls29;
@@ -22,40 +23,10 @@ __global__ void __launch_bounds__(256) k_digit_codes(const uint32_t *__restrict_
                                                      size_t n, size_t n_pad, int c, int W, CODE *__restrict__ dig, uint32_t *__restrict__ bad) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_pad) return;
-    constexpr CODE ZERO = (CODE)~(CODE)0;
-    constexpr int SIGN = sizeof(CODE) * 8 - 1;
     // padding / identity base contributes nothing.  bases == nullptr: the base records are not there yet (one-shot calls sort the scalars
     // while the bases are still crossing PCIe): identity bases are passed over by the SKIP_ID accumulation instead.
-    bool skip = (i >= n) || (bases && bases[i * (size_t)aff_stride + flag_word] != 0);
-    uint32_t s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (i < n) {
-        const uint4 *p = reinterpret_cast<const uint4 *>(scalars + i * 8);
-        uint4 a = p[0], b = p[1];
-        // A scalar is a 255-bit value (Fr::MODULUS_BIT_SIZE).  Whether arkworks' digit extraction reads bit 255 depends on ITS window width
-        // (it does unless that width divides 255, oracle/oracle.c ark_make_digits), so a scalar >= 2^255 has no width-independent meaning:
-        // the call is refused (DGPU_E_BADARG) and the caller stays on its CPU path.  `into_bigint()` never produces one.
-        if (b.w >> 31) atomicOr(bad, 1u);
-        if (!skip) { s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w; s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w & 0x7fffffffu; }
-    }
-    const uint32_t B = 1u << (c - 1);
-    uint32_t carry = 0;
-    for (int w = 0; w < W; w++) {
-        int bitpos = w * c;
-        uint32_t raw = 0;
-        if (bitpos < 256) {
-            int wd = bitpos >> 5, sh = bitpos & 31;
-            uint64_t v = 0;   // register array indexed through a select chain (no scratch)
-#pragma unroll
-            for (int k = 0; k < 8; k++) { if (k == wd) v |= s[k]; if (k == wd + 1) v |= (uint64_t)s[k] << 32; }
-            raw = (uint32_t)(v >> sh) & ((1u << c) - 1u);
-        }
-        uint32_t v = raw + carry;
-        uint32_t neg = v > B ? 1u : 0u;
-        uint32_t mag = neg ? (2u * B - v) : v;
-        carry = neg;
-        CODE code = (mag == 0 || skip) ? ZERO : (CODE)((mag - 1) | (neg << SIGN));
-        dig[(size_t)w * n_pad + i] = code;
-    }
+    const bool skip = (i >= n) || (bases && bases[i * (size_t)aff_stride + flag_word] != 0);
+    digit_codes_one<CODE>(scalars, i, n, skip, n_pad, c, W, dig, bad);
 }
 
 // K2b / K4: counting sort without global atomics.  Block (w, r) owns the RB = 2^rb_log buckets [r RB, (r+1) RB) of window w,

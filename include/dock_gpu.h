@@ -56,7 +56,7 @@ int32_t dgpu_last_hip_error(void);
 /* below this many terms the MSM entry points return DGPU_E_TOO_SMALL without touching the device
  * (>= 95 % of the reference's call sites have n < 100).  Default: DGPU_DEFAULT_MIN_GPU_N, the measured
  * crossover against the CPU path; 0 = always run on the device. */
-#define DGPU_DEFAULT_MIN_GPU_N 512
+#define DGPU_DEFAULT_MIN_GPU_N 256
 int32_t dgpu_set_min_gpu_n(size_t n);
 size_t dgpu_get_min_gpu_n(void);
 /* ---- tuning knobs.  Process-wide, not needed by a caller: every setting returns the SAME result limb for limb (the tests sweep each of

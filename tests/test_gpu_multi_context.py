@@ -136,8 +136,8 @@ def test_size_threshold_default_and_override():
     b = O.G1.generator().reshape(1, 12); s = np.ones((1, 4), np.uint64); out = np.zeros(18, np.uint64)
     p = lambda a: a.ctypes.data_as(C.c_void_p)
     try:
-        L.dgpu_set_min_gpu_n(512)                  # the library default (DGPU_DEFAULT_MIN_GPU_N)
-        assert L.dgpu_get_min_gpu_n() == 512
+        L.dgpu_set_min_gpu_n(256)                  # the library default (DGPU_DEFAULT_MIN_GPU_N)
+        assert L.dgpu_get_min_gpu_n() == 256
         assert L.dgpu_msm_g1(p(b), None, p(s), 1, p(out)) == -6          # DGPU_E_TOO_SMALL: the Rust shim stays on arkworks
         assert L.dgpu_msm_g1_sharded(p(b), None, p(s), 1, 0, p(out)) == -6
     finally:

@@ -25,7 +25,7 @@ def _device():
     lib().dgpu_set_min_gpu_n(1)
     yield
     lib().dgpu_set_small_msm_max(8192)
-    lib().dgpu_set_min_gpu_n(512)
+    lib().dgpu_set_min_gpu_n(0)
 
 
 def both_paths(fn):

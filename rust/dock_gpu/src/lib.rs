@@ -1,0 +1,317 @@
+//! rust/dock_gpu/src/lib.rs — the thin FFI shim `north_star` asks for: host code stays Rust, the hot path runs behind the C ABI of
+//! `include/dock_gpu.h` (libdock_gpu.so: hand-written HIP kernels for gfx950).
+//!
+//! Every function here is a drop-in for one arkworks call the reference makes (file:line of docknetwork/crypto in the comments) and
+//! falls back to that arkworks call on ANY non-zero return code, so the reference's contract "an MSM / a Miller loop cannot fail" holds:
+//! `DGPU_E_TOO_SMALL` (n below the measured crossover), `DGPU_E_NODEVICE`, `DGPU_E_BADARG` (a scalar with bit 255 set), an allocation
+//! failure — the caller never sees them.
+//!
+//! NOT compiled in the image this repository is built in (no Rust toolchain there).  `cargo test` here, on a machine with cargo and one
+//! MI355X, runs `tests/parity.rs`: the one-command pin of the library against real arkworks and the producer of `tests/golden/ark/*.json`
+//! (consumed by `tests/test_ark_golden.py` on the GPU box and, for the CPU oracle, everywhere).
+//!
+//! Layout facts this file relies on (ark-ff / ark-ec 0.4):
+//!   * `Fp<MontBackend<_, N>, N>(pub BigInt<N>, PhantomData)`, `BigInt<N>(pub [u64; N])`: `x.0 .0` are the Montgomery limbs the ABI takes;
+//!   * `Affine<P> { pub x, pub y, pub infinity: bool }` is a plain (not repr(C)) struct: field offsets are read with `offset_of!`, the
+//!     slice goes over as it lies in memory (`dgpu_msm_*_strided`);
+//!   * `Projective<P> { pub x, pub y, pub z }` Jacobian, identity <=> z = 0: what the ABI returns (normalised: z = 1 or 0);
+//!   * `Fq12 { c0: Fq6 { c0, c1, c2: Fq2 { c0, c1 } }, c1: Fq6 }`: 12 x 6 limbs in exactly the ABI's order;
+//!   * `G2Prepared<P> { pub ell_coeffs: Vec<(Fq2, Fq2, Fq2)>, pub infinity: bool }`, 68 triples for BLS12-381.
+#![allow(clippy::missing_safety_doc)]
+
+use ark_bls12_381::{Bls12_381, Fq, Fq12, Fq2, Fq6, Fr, G1Affine, G1Projective, G2Affine, G2Projective};
+use ark_ec::bls12::G2Prepared as ArkG2Prepared;
+use ark_ec::pairing::{MillerLoopOutput, Pairing, PairingOutput};
+use ark_ec::{AffineRepr, VariableBaseMSM};
+use ark_ff::{BigInt, PrimeField};
+use ark_std::vec::Vec;
+
+pub type G2Prepared = ArkG2Prepared<ark_bls12_381::Config>;
+
+pub const DGPU_OK: i32 = 0;
+pub const DGPU_E_TOO_SMALL: i32 = -6;
+pub const G2_PREPARED_WORDS: usize = 68 * 36;
+
+/// `dgpu_lego_pk` of include/dock_gpu.h
+#[repr(C)]
+pub struct DgpuLegoPk {
+    pub a_query: u64,
+    pub b_g1_query: u64,
+    pub b_g2_query: u64,
+    pub h_query: u64,
+    pub l_query: u64,
+    pub alpha_g1: *const u64,
+    pub beta_g1: *const u64,
+    pub delta_g1: *const u64,
+    pub eta_delta_inv_g1: *const u64,
+    pub eta_gamma_inv_g1: *const u64,
+    pub beta_g2: *const u64,
+    pub delta_g2: *const u64,
+    pub a0: *const u64,
+    pub b1_0: *const u64,
+    pub b2_0: *const u64,
+    pub gamma_abc_g1: *const u64,
+    pub gamma_abc_len: usize,
+    pub commit_witness_count: usize,
+}
+
+#[link(name = "dock_gpu")]
+extern "C" {
+    pub fn dgpu_init(device: i32) -> i32;
+    pub fn dgpu_shutdown() -> i32;
+    pub fn dgpu_device_count() -> i32;
+    pub fn dgpu_set_min_gpu_n(n: usize) -> i32;
+    pub fn dgpu_reserve_g1(n: usize) -> i32;
+    pub fn dgpu_reserve_g2(n: usize) -> i32;
+    pub fn dgpu_msm_g1_strided(bases: *const core::ffi::c_void, stride_bytes: usize, x_off: usize, y_off: usize, inf_off: usize,
+                               scalars: *const u64, n: usize, montgomery: i32, out_xyz: *mut u64) -> i32;
+    pub fn dgpu_msm_g2_strided(bases: *const core::ffi::c_void, stride_bytes: usize, x_off: usize, y_off: usize, inf_off: usize,
+                               scalars: *const u64, n: usize, montgomery: i32, out_xyz: *mut u64) -> i32;
+    pub fn dgpu_bases_upload_g1_strided(bases: *const core::ffi::c_void, stride_bytes: usize, x_off: usize, y_off: usize, inf_off: usize, n: usize, handle: *mut u64) -> i32;
+    pub fn dgpu_bases_upload_g2_strided(bases: *const core::ffi::c_void, stride_bytes: usize, x_off: usize, y_off: usize, inf_off: usize, n: usize, handle: *mut u64) -> i32;
+    pub fn dgpu_bases_precompute_g1(bases: u64, window_bits: i32) -> i32;
+    pub fn dgpu_bases_precompute_g2(bases: u64, window_bits: i32) -> i32;
+    pub fn dgpu_bases_free(handle: u64) -> i32;
+    pub fn dgpu_msm_g1_handle(bases: u64, offset: usize, scalars: *const u64, n: usize, montgomery: i32, out_xyz: *mut u64) -> i32;
+    pub fn dgpu_msm_g2_handle(bases: u64, offset: usize, scalars: *const u64, n: usize, montgomery: i32, out_xyz: *mut u64) -> i32;
+    pub fn dgpu_multi_miller_loop(p_xy: *const u64, q_xy: *const u64, skip: *const u8, n: usize, out_f12: *mut u64) -> i32;
+    pub fn dgpu_g2_prepare(q_xy: *const u64, is_inf: *const u8, n: usize, out_coeffs: *mut u64, out_inf: *mut u8) -> i32;
+    pub fn dgpu_multi_miller_loop_mixed(p_aff: *const u64, q_aff: *const u64, skip_aff: *const u8, n_aff: usize,
+                                        p_prep: *const u64, coeffs: *const u64, skip_prep: *const u8, n_prep: usize, out_f12: *mut u64) -> i32;
+    pub fn dgpu_final_exponentiation(in_f12: *const u64, out_f12: *mut u64) -> i32;
+    pub fn dgpu_r1cs_upload(a_rowptr: *const u64, a_cols: *const u32, a_vals: *const u64, a_nnz: usize,
+                            b_rowptr: *const u64, b_cols: *const u32, b_vals: *const u64, b_nnz: usize,
+                            c_rowptr: *const u64, c_cols: *const u32, c_vals: *const u64, c_nnz: usize,
+                            num_vars: usize, num_inputs: usize, num_constraints: usize, montgomery: i32, handle: *mut u64) -> i32;
+    pub fn dgpu_r1cs_free(handle: u64) -> i32;
+    pub fn dgpu_legogroth16_prove(pk: *const DgpuLegoPk, r1cs: u64, h_scalars: u64, z: *const u64, num_vars: usize, n_inst: usize, montgomery: i32,
+                                  r: *const u64, s: *const u64, v: *const u64,
+                                  out_a: *mut u64, out_b: *mut u64, out_c: *mut u64, out_d: *mut u64, out_inf: *mut u8) -> i32;
+}
+
+/// bind this process to HIP device `device` (one process per GPU) and size every slot for one-shot calls of up to `max_n` terms, so that
+/// no rayon worker's first call allocates on the device
+pub fn init(device: i32, max_n: usize) -> bool {
+    unsafe { dgpu_init(device) == DGPU_OK && dgpu_reserve_g1(max_n) == DGPU_OK && dgpu_reserve_g2(max_n) == DGPU_OK }
+}
+
+// ---- the caller's `&[G1Affine]` / `&[G2Affine]` as they lie in memory ------------------------------------------------------------------------
+const G1_STRIDE: usize = core::mem::size_of::<G1Affine>();
+const G1_X: usize = core::mem::offset_of!(G1Affine, x);
+const G1_Y: usize = core::mem::offset_of!(G1Affine, y);
+const G1_INF: usize = core::mem::offset_of!(G1Affine, infinity);
+const G2_STRIDE: usize = core::mem::size_of::<G2Affine>();
+const G2_X: usize = core::mem::offset_of!(G2Affine, x);
+const G2_Y: usize = core::mem::offset_of!(G2Affine, y);
+const G2_INF: usize = core::mem::offset_of!(G2Affine, infinity);
+
+fn fq(w: &[u64]) -> Fq { Fq::new_unchecked(BigInt::new(w[..6].try_into().unwrap())) }
+fn fq2(w: &[u64]) -> Fq2 { Fq2::new(fq(&w[0..6]), fq(&w[6..12])) }
+fn g1_from_xyz(w: &[u64; 18]) -> G1Projective { G1Projective::new_unchecked(fq(&w[0..6]), fq(&w[6..12]), fq(&w[12..18])) }
+fn g2_from_xyz(w: &[u64; 36]) -> G2Projective { G2Projective::new_unchecked(fq2(&w[0..12]), fq2(&w[12..24]), fq2(&w[24..36])) }
+pub fn fq12_from_words(w: &[u64; 72]) -> Fq12 {
+    let f6 = |o: usize| Fq6::new(fq2(&w[o..o + 12]), fq2(&w[o + 12..o + 24]), fq2(&w[o + 24..o + 36]));
+    Fq12::new(f6(0), f6(36))
+}
+pub fn fq12_to_words(f: &Fq12) -> [u64; 72] {
+    let mut w = [0u64; 72];
+    let c = [&f.c0.c0, &f.c0.c1, &f.c0.c2, &f.c1.c0, &f.c1.c1, &f.c1.c2];
+    for (k, e) in c.iter().enumerate() {
+        w[12 * k..12 * k + 6].copy_from_slice(&e.c0 .0 .0);
+        w[12 * k + 6..12 * k + 12].copy_from_slice(&e.c1 .0 .0);
+    }
+    w
+}
+
+/// packed form for the pairing entry points (operand counts are small there): x | y words, a flag byte per point
+pub fn pack_g1(ps: &[G1Affine]) -> (Vec<u64>, Vec<u8>) {
+    let (mut xy, mut inf) = (Vec::with_capacity(ps.len() * 12), Vec::with_capacity(ps.len()));
+    for p in ps {
+        match p.xy() {
+            Some((x, y)) => { xy.extend_from_slice(&x.0 .0); xy.extend_from_slice(&y.0 .0); inf.push(0u8) }
+            None => { xy.extend_from_slice(&[0u64; 12]); inf.push(1u8) }
+        }
+    }
+    (xy, inf)
+}
+pub fn pack_g2(qs: &[G2Affine]) -> (Vec<u64>, Vec<u8>) {
+    let (mut xy, mut inf) = (Vec::with_capacity(qs.len() * 24), Vec::with_capacity(qs.len()));
+    for q in qs {
+        match q.xy() {
+            Some((x, y)) => { for c in [&x.c0, &x.c1, &y.c0, &y.c1] { xy.extend_from_slice(&c.0 .0); } inf.push(0u8) }
+            None => { xy.extend_from_slice(&[0u64; 24]); inf.push(1u8) }
+        }
+    }
+    (xy, inf)
+}
+
+// ---- variable-base MSM ---------------------------------------------------------------------------------------------------------------
+/// drop-in for `G1Projective::msm_bigint(bases, scalars)` — legogroth16/src/prover.rs:286,299,363,592; utils/src/pairs.rs:153-155
+pub fn msm_bigint_g1(bases: &[G1Affine], scalars: &[BigInt<4>]) -> G1Projective {
+    let n = bases.len().min(scalars.len()); // arkworks truncates; prover.rs:286 relies on it (h_query has D - 1 points against D scalars)
+    let mut out = [0u64; 18];
+    let rc = unsafe { dgpu_msm_g1_strided(bases.as_ptr() as *const _, G1_STRIDE, G1_X, G1_Y, G1_INF, scalars.as_ptr() as *const u64, n, 0, out.as_mut_ptr()) };
+    if rc != DGPU_OK { return G1Projective::msm_bigint(&bases[..n], &scalars[..n]); }
+    g1_from_xyz(&out)
+}
+/// drop-in for `G::Group::msm_unchecked(bases, &[Fr])` — utils/src/pairs.rs:145-147, owned_pairs.rs:95-97, randomized_mult_checker.rs:100:
+/// the `&[Fr]` slice goes over as it is (Montgomery limbs), `Fr::into_bigint` runs on the device
+pub fn msm_unchecked_g1(bases: &[G1Affine], scalars: &[Fr]) -> G1Projective {
+    let n = bases.len().min(scalars.len());
+    let mut out = [0u64; 18];
+    let rc = unsafe { dgpu_msm_g1_strided(bases.as_ptr() as *const _, G1_STRIDE, G1_X, G1_Y, G1_INF, scalars.as_ptr() as *const u64, n, 1, out.as_mut_ptr()) };
+    if rc != DGPU_OK { return G1Projective::msm_unchecked(&bases[..n], &scalars[..n]); }
+    g1_from_xyz(&out)
+}
+/// `G2Projective::msm_bigint` — legogroth16/src/prover.rs:344 -> :592 (b_g2_query)
+pub fn msm_bigint_g2(bases: &[G2Affine], scalars: &[BigInt<4>]) -> G2Projective {
+    let n = bases.len().min(scalars.len());
+    let mut out = [0u64; 36];
+    let rc = unsafe { dgpu_msm_g2_strided(bases.as_ptr() as *const _, G2_STRIDE, G2_X, G2_Y, G2_INF, scalars.as_ptr() as *const u64, n, 0, out.as_mut_ptr()) };
+    if rc != DGPU_OK { return G2Projective::msm_bigint(&bases[..n], &scalars[..n]); }
+    g2_from_xyz(&out)
+}
+pub fn msm_unchecked_g2(bases: &[G2Affine], scalars: &[Fr]) -> G2Projective {
+    let n = bases.len().min(scalars.len());
+    let mut out = [0u64; 36];
+    let rc = unsafe { dgpu_msm_g2_strided(bases.as_ptr() as *const _, G2_STRIDE, G2_X, G2_Y, G2_INF, scalars.as_ptr() as *const u64, n, 1, out.as_mut_ptr()) };
+    if rc != DGPU_OK { return G2Projective::msm_unchecked(&bases[..n], &scalars[..n]); }
+    g2_from_xyz(&out)
+}
+
+/// a proving-key query resident in HBM (uploaded once per key; `precompute` turns it into the window table the 2^20-term MSMs run on)
+pub struct ResidentG1 { handle: u64, host: Vec<G1Affine> }
+impl ResidentG1 {
+    pub fn upload(bases: &[G1Affine], table_window_bits: Option<i32>) -> Self {
+        let mut handle = 0u64;
+        let ok = unsafe { dgpu_bases_upload_g1_strided(bases.as_ptr() as *const _, G1_STRIDE, G1_X, G1_Y, G1_INF, bases.len(), &mut handle) } == DGPU_OK;
+        if ok { if let Some(c) = table_window_bits { unsafe { dgpu_bases_precompute_g1(handle, c); } } }
+        ResidentG1 { handle: if ok { handle } else { 0 }, host: bases.to_vec() }
+    }
+    pub fn handle(&self) -> u64 { self.handle }
+    /// `msm_bigint(&query[offset..], scalars)` — `calculate_coeff` uses offset 1 (prover.rs:592)
+    pub fn msm_bigint(&self, offset: usize, scalars: &[BigInt<4>]) -> G1Projective {
+        let n = (self.host.len() - offset).min(scalars.len());
+        let mut out = [0u64; 18];
+        let rc = if self.handle == 0 { -1 } else { unsafe { dgpu_msm_g1_handle(self.handle, offset, scalars.as_ptr() as *const u64, n, 0, out.as_mut_ptr()) } };
+        if rc != DGPU_OK { return G1Projective::msm_bigint(&self.host[offset..offset + n], &scalars[..n]); }
+        g1_from_xyz(&out)
+    }
+}
+impl Drop for ResidentG1 { fn drop(&mut self) { if self.handle != 0 { unsafe { dgpu_bases_free(self.handle); } } } }
+
+// ---- pairings ------------------------------------------------------------------------------------------------------------------------
+/// drop-in for `Bls12_381::multi_miller_loop(a, b)` over affine operands — utils/src/randomized_pairing_check.rs:134,169-170,207.
+/// Lengths must agree (arkworks' zip_eq panics otherwise); pairs with an identity member are skipped by the library like arkworks does.
+pub fn multi_miller_loop(a: &[G1Affine], b: &[G2Affine]) -> MillerLoopOutput<Bls12_381> {
+    assert_eq!(a.len(), b.len(), "multi_miller_loop: lengths differ");
+    let ((p, pi), (q, qi)) = (pack_g1(a), pack_g2(b));
+    let skip: Vec<u8> = pi.iter().zip(qi.iter()).map(|(x, y)| x | y).collect();
+    let mut out = [0u64; 72];
+    let rc = unsafe { dgpu_multi_miller_loop(p.as_ptr(), q.as_ptr(), skip.as_ptr(), a.len(), out.as_mut_ptr()) };
+    if rc != DGPU_OK { return Bls12_381::multi_miller_loop(a.iter().copied(), b.iter().copied()); }
+    MillerLoopOutput(fq12_from_words(&out))
+}
+/// `G2Prepared::from(q)` for a batch — randomized_pairing_check.rs:132,163,188-189; legogroth16/src/verifier.rs:22-23
+pub fn g2_prepare(qs: &[G2Affine]) -> Vec<G2Prepared> {
+    let (q, qi) = pack_g2(qs);
+    let mut co = ark_std::vec![0u64; qs.len() * G2_PREPARED_WORDS];
+    let mut inf = ark_std::vec![0u8; qs.len()];
+    let rc = unsafe { dgpu_g2_prepare(q.as_ptr(), qi.as_ptr(), qs.len(), co.as_mut_ptr(), inf.as_mut_ptr()) };
+    if rc != DGPU_OK { return qs.iter().map(|q| G2Prepared::from(*q)).collect(); }
+    (0..qs.len()).map(|i| {
+        if inf[i] != 0 { return G2Prepared { ell_coeffs: Vec::new(), infinity: true }; }
+        let w = &co[i * G2_PREPARED_WORDS..(i + 1) * G2_PREPARED_WORDS];
+        G2Prepared { ell_coeffs: (0..68).map(|s| (fq2(&w[36 * s..]), fq2(&w[36 * s + 12..]), fq2(&w[36 * s + 24..]))).collect(), infinity: false }
+    }).collect()
+}
+fn prepared_words(q: &G2Prepared, out: &mut Vec<u64>) {
+    if q.infinity || q.ell_coeffs.len() != 68 { out.extend(core::iter::repeat(0u64).take(G2_PREPARED_WORDS)); return; }
+    for (c0, c1, c2) in q.ell_coeffs.iter() { for c in [c0, c1, c2] { out.extend_from_slice(&c.c0 .0 .0); out.extend_from_slice(&c.c1 .0 .0); } }
+}
+/// the verifier's call — legogroth16/src/verifier.rs:69-76: `[proof.b.into(), pvk.delta_g2_neg_pc, pvk.gamma_g2_neg_pc]`: some G2 operands
+/// affine (prepared inside the call, their chain pipelined), the others already `G2Prepared`
+pub fn multi_miller_loop_mixed(a_aff: &[G1Affine], b_aff: &[G2Affine], a_prep: &[G1Affine], b_prep: &[G2Prepared]) -> MillerLoopOutput<Bls12_381> {
+    assert_eq!(a_aff.len(), b_aff.len()); assert_eq!(a_prep.len(), b_prep.len());
+    let ((p, pi), (q, qi)) = (pack_g1(a_aff), pack_g2(b_aff));
+    let skip_aff: Vec<u8> = pi.iter().zip(qi.iter()).map(|(x, y)| x | y).collect();
+    let (pp, ppi) = pack_g1(a_prep);
+    let mut co = Vec::with_capacity(b_prep.len() * G2_PREPARED_WORDS);
+    for b in b_prep { prepared_words(b, &mut co); }
+    let skip_prep: Vec<u8> = ppi.iter().zip(b_prep.iter()).map(|(x, b)| x | (b.infinity as u8)).collect();
+    let mut out = [0u64; 72];
+    let rc = unsafe { dgpu_multi_miller_loop_mixed(p.as_ptr(), q.as_ptr(), skip_aff.as_ptr(), a_aff.len(), pp.as_ptr(), co.as_ptr(), skip_prep.as_ptr(), a_prep.len(), out.as_mut_ptr()) };
+    if rc != DGPU_OK {
+        let g1 = a_aff.iter().chain(a_prep.iter()).copied();
+        let g2 = b_aff.iter().map(|q| G2Prepared::from(*q)).chain(b_prep.iter().cloned());
+        return Bls12_381::multi_miller_loop(g1, g2);
+    }
+    MillerLoopOutput(fq12_from_words(&out))
+}
+/// drop-in for `Bls12_381::final_exponentiation(f)` — randomized_pairing_check.rs:213, verifier.rs:78 (host code inside the library)
+pub fn final_exponentiation(f: MillerLoopOutput<Bls12_381>) -> Option<PairingOutput<Bls12_381>> {
+    let w = fq12_to_words(&f.0);
+    let mut out = [0u64; 72];
+    match unsafe { dgpu_final_exponentiation(w.as_ptr(), out.as_mut_ptr()) } {
+        DGPU_OK => Some(PairingOutput(fq12_from_words(&out))),
+        -5 => None, // DGPU_E_ZERO: arkworks returns None for f = 0
+        _ => Bls12_381::final_exponentiation(f),
+    }
+}
+/// `Bls12_381::multi_pairing(a, b)` — 67 call sites, e.g. bbs_plus/src/signature.rs:284, legogroth16/src/aggregation/commitment.rs:30-31
+pub fn multi_pairing(a: &[G1Affine], b: &[G2Affine]) -> PairingOutput<Bls12_381> {
+    final_exponentiation(multi_miller_loop(a, b)).expect("Miller output of valid operands is never zero")
+}
+
+// ---- the LegoGroth16 prover as one call (legogroth16/src/prover.rs:153-180 -> :267-383) ------------------------------------------------------
+/// the proving key's five queries resident in HBM (tables) + its O(1) elements in the ABI's packed form
+pub struct GpuProvingKey {
+    pub a: ResidentG1, pub b_g1: ResidentG1, pub h: ResidentG1, pub l: ResidentG1,
+    b_g2_handle: u64,
+    small_g1: Vec<u64>,  // alpha, beta, delta, eta/delta, eta/gamma, a0, b1_0, then gamma_abc_g1
+    small_g2: Vec<u64>,  // beta, delta, b2_0
+    gamma_abc_len: usize,
+    pub commit_witness_count: usize,
+}
+pub const TABLE_C_WITNESS: i32 = 17; // DGPU_TABLE_C_WITNESS: the queries that meet the witness
+impl GpuProvingKey {
+    #[allow(clippy::too_many_arguments)]
+    pub fn upload(alpha_g1: G1Affine, beta_g1: G1Affine, delta_g1: G1Affine, eta_delta_inv_g1: G1Affine, eta_gamma_inv_g1: G1Affine,
+                  beta_g2: G2Affine, delta_g2: G2Affine, gamma_abc_g1: &[G1Affine], commit_witness_count: usize,
+                  a_query: &[G1Affine], b_g1_query: &[G1Affine], b_g2_query: &[G2Affine], h_query: &[G1Affine], l_query: &[G1Affine]) -> Option<Self> {
+        let mut b2 = 0u64;
+        if unsafe { dgpu_bases_upload_g2_strided(b_g2_query.as_ptr() as *const _, G2_STRIDE, G2_X, G2_Y, G2_INF, b_g2_query.len(), &mut b2) } != DGPU_OK { return None; }
+        unsafe { dgpu_bases_precompute_g2(b2, TABLE_C_WITNESS); }
+        let mut s1: Vec<G1Affine> = ark_std::vec![alpha_g1, beta_g1, delta_g1, eta_delta_inv_g1, eta_gamma_inv_g1, a_query[0], b_g1_query[0]];
+        s1.extend_from_slice(gamma_abc_g1);
+        Some(GpuProvingKey {
+            a: ResidentG1::upload(a_query, Some(TABLE_C_WITNESS)), b_g1: ResidentG1::upload(b_g1_query, Some(TABLE_C_WITNESS)),
+            h: ResidentG1::upload(h_query, Some(0)), l: ResidentG1::upload(l_query, Some(TABLE_C_WITNESS)),
+            b_g2_handle: b2, small_g1: pack_g1(&s1).0, small_g2: pack_g2(&[beta_g2, delta_g2, b_g2_query[0]]).0,
+            gamma_abc_len: gamma_abc_g1.len(), commit_witness_count,
+        })
+    }
+    fn raw(&self) -> DgpuLegoPk {
+        let g1 = |k: usize| unsafe { self.small_g1.as_ptr().add(12 * k) };
+        let g2 = |k: usize| unsafe { self.small_g2.as_ptr().add(24 * k) };
+        DgpuLegoPk { a_query: self.a.handle(), b_g1_query: self.b_g1.handle(), b_g2_query: self.b_g2_handle, h_query: self.h.handle(), l_query: self.l.handle(),
+                     alpha_g1: g1(0), beta_g1: g1(1), delta_g1: g1(2), eta_delta_inv_g1: g1(3), eta_gamma_inv_g1: g1(4), beta_g2: g2(0), delta_g2: g2(1),
+                     a0: g1(5), b1_0: g1(6), b2_0: g2(2), gamma_abc_g1: g1(7), gamma_abc_len: self.gamma_abc_len, commit_witness_count: self.commit_witness_count }
+    }
+}
+impl Drop for GpuProvingKey { fn drop(&mut self) { if self.b_g2_handle != 0 { unsafe { dgpu_bases_free(self.b_g2_handle); } } } }
+
+fn g1_affine(w: &[u64; 12], inf: u8) -> G1Affine { if inf != 0 { G1Affine::identity() } else { G1Affine::new_unchecked(fq(&w[0..6]), fq(&w[6..12])) } }
+fn g2_affine(w: &[u64; 24], inf: u8) -> G2Affine { if inf != 0 { G2Affine::identity() } else { G2Affine::new_unchecked(fq2(&w[0..12]), fq2(&w[12..24])) } }
+
+/// `create_proof_with_reduction` as ONE call: z = (1, instance..., witness...) as `&[Fr]`, `circuit` a `dgpu_r1cs_upload` handle.
+/// Returns (A, B, C, D), or None when the library declined (the caller then runs the reference's CPU prover).
+pub fn create_proof_gpu(pk: &GpuProvingKey, circuit: u64, z: &[Fr], n_inst: usize, r: Fr, s: Fr, v: Fr) -> Option<(G1Affine, G2Affine, G1Affine, G1Affine)> {
+    let (mut a, mut b, mut c, mut d, mut inf) = ([0u64; 12], [0u64; 24], [0u64; 12], [0u64; 12], [0u8; 4]);
+    let (rb, sb, vb) = (r.into_bigint(), s.into_bigint(), v.into_bigint());
+    let raw = pk.raw();
+    let rc = unsafe { dgpu_legogroth16_prove(&raw, circuit, 0, z.as_ptr() as *const u64, z.len(), n_inst, 1, rb.0.as_ptr(), sb.0.as_ptr(), vb.0.as_ptr(),
+                                             a.as_mut_ptr(), b.as_mut_ptr(), c.as_mut_ptr(), d.as_mut_ptr(), inf.as_mut_ptr()) };
+    if rc != DGPU_OK { return None; }
+    Some((g1_affine(&a, inf[0]), g2_affine(&b, inf[1]), g1_affine(&c, inf[2]), g1_affine(&d, inf[3])))
+}

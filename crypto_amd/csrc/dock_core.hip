@@ -12,7 +12,17 @@ Ctx ctxs[MAX_CTX];
 thread_local int tl_ctx = -1;
 thread_local bool tl_no_min = false;
 std::atomic<uint64_t> g_dev_allocs{0}, g_dev_alloc_ns{0}, g_dev_alloc_bytes{0};
+#ifdef DGPU_DEV
+// fault injection (development build only: `make dev` -> libdock_gpu_dev.so; tests/test_gpu_fault_paths.py): the k-th hipMalloc from now and the
+// count - 1 after it fail (Buf::ensure retries a failed allocation once with the exact size: count = 2 defeats the retry, count = 1 exercises it)
+static std::atomic<int64_t> g_fail_after{-1}, g_fail_count{0}, g_fail_left{0};
+extern "C" __attribute__((visibility("default"))) int32_t dgpu_dev_fail_alloc_after(int64_t k, int64_t count) { g_fail_left = 0; g_fail_count = count; g_fail_after = k; return DGPU_OK; }
+#endif
 hipError_t dev_malloc(void **p, size_t bytes) {
+#ifdef DGPU_DEV
+    if (g_fail_left.load() > 0) { if (g_fail_left.fetch_sub(1) > 0) { *p = nullptr; g_dev_allocs++; return hipErrorOutOfMemory; } }
+    else if (g_fail_after.load() >= 0 && g_fail_after.fetch_sub(1) == 0) { g_fail_left = g_fail_count.load() - 1; *p = nullptr; g_dev_allocs++; return hipErrorOutOfMemory; }
+#endif
     const auto t0 = std::chrono::steady_clock::now();
     const hipError_t e = hipMalloc(p, bytes);
     g_dev_alloc_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();

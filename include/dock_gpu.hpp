@@ -194,6 +194,97 @@ inline std::optional<Fq12> final_exponentiation(const Fq12 &f) {
 inline Fq12 multi_pairing(const std::vector<G1::Affine> &a, const std::vector<G2::Affine> &b) { return *final_exponentiation(multi_miller_loop(a, b)); }
 
 
+// ---- RandomizedPairingChecker (utils/src/randomized_pairing_check.rs:24-215) over the C ABI ---------------------------------------------------
+// Same state and laziness as the reference's type: `left` the product of Miller outputs so far (:27), `right` the GT target (`right +=
+// out.mul_bigint(m)` — GT is written additively in arkworks, it is the Fp12 product, :30,:136), `pending` the (G1, G2) pairs queued for ONE
+// multi_miller_loop in verify() when lazy (:34,:204-214), `random` / `current_random` = r, r^k (:36-38): equation k is scaled by r^k.
+// The G1 scalings `a.mul_bigint(m)` (:125-127,:152-158) run batched on the device (dgpu_g1_scale_batch: lazy mode scales everything
+// queued in one launch), the Miller loops through dgpu_multi_miller_loop, GT arithmetic and the single final exponentiation on the host
+// inside the library.  crypto_amd/pairing_check.py is the same type for the Python tests; tests/native/cpp_api_driver.cpp drives this one.
+namespace detail {
+inline constexpr BigInt256 FR_MODULUS = {0xffffffff00000001ULL, 0x53bda402fffe5bfeULL, 0x3339d80809a1d805ULL, 0x73eda753299d7d48ULL};
+inline bool geq(const BigInt256 &a, const BigInt256 &b) { for (int i = 3; i >= 0; i--) { if (a[i] != b[i]) return a[i] > b[i]; } return true; }
+inline BigInt256 add_mod(const BigInt256 &a, const BigInt256 &b) {          // a, b < r
+    BigInt256 s{}; unsigned __int128 c = 0;
+    for (int i = 0; i < 4; i++) { c += (unsigned __int128)a[i] + b[i]; s[i] = (uint64_t)c; c >>= 64; }
+    if (c || geq(s, FR_MODULUS)) { unsigned __int128 br = 0; for (int i = 0; i < 4; i++) { unsigned __int128 d = (unsigned __int128)s[i] - FR_MODULUS[i] - (uint64_t)br; s[i] = (uint64_t)d; br = (d >> 64) & 1; } }
+    return s;
+}
+inline BigInt256 mul_mod(const BigInt256 &a, const BigInt256 &b) {          // double-and-add: a handful of calls per checker
+    BigInt256 acc{};
+    for (int i = 255; i >= 0; i--) { acc = add_mod(acc, acc); if ((b[i / 64] >> (i % 64)) & 1) acc = add_mod(acc, a); }
+    return acc;
+}
+inline Fq12 fq12_one() { Fq12 o{}; const Fq one = {0x760900000002fffdULL, 0xebf4000bc40c0002ULL, 0x5f48985753c758baULL, 0x77ce585370525745ULL, 0x5c071a97a256ec6dULL, 0x15f65ec3fa80e493ULL}; std::memcpy(o.data(), one.data(), 48); return o; }
+inline Fq12 fq12_mul(const Fq12 &a, const Fq12 &b) { Fq12 o{}; check(dgpu_fp12_mul(a.data(), b.data(), o.data()), "fp12_mul"); return o; }
+}  // namespace detail
+
+class RandomizedPairingChecker {
+    Fq12 left_ = detail::fq12_one(), right_ = detail::fq12_one();
+    bool lazy_;
+    struct Queued { std::vector<G1::Affine> a; BigInt256 m; bool negate; std::vector<G2::Affine> b; };
+    std::vector<Queued> pending_;
+    std::vector<std::pair<Fq12, BigInt256>> pending_targets_;
+    BigInt256 random_, current_random_{1, 0, 0, 0};
+    // [m a_i] (negated if asked), one launch
+    static std::vector<G1::Affine> scale(const std::vector<G1::Affine> &a, const std::vector<BigInt256> &m, const std::vector<uint8_t> &neg) {
+        Packed<G1> p(a, a.size());
+        std::vector<uint64_t> out(a.size() * 12); std::vector<uint8_t> oinf(a.size());
+        check(dgpu_g1_scale_batch(p.xy.data(), p.inf.data(), m[0].data(), m.size() == 1 ? 0 : 4, neg.empty() ? nullptr : neg.data(), a.size(), out.data(), oinf.data()), "g1_scale_batch");
+        return affine_from_abi<G1>(out, oinf);
+    }
+    void advance() { current_random_ = detail::mul_mod(current_random_, random_); }
+public:
+    RandomizedPairingChecker(const BigInt256 &random, bool lazy) : lazy_(lazy), random_(random) {}                     // new(random, lazy)  :44-53
+    // e(a, b) == out   :61-77
+    void add_sources_and_target(const G1::Affine &a, const G2::Affine &b, const Fq12 &out) { add_multiple_sources_and_target({a}, {b}, out); }
+    // e(a, b) == e(c, d)   :104-113
+    void add_sources(const G1::Affine &a, const G2::Affine &b, const G1::Affine &c, const G2::Affine &d) { add_multiple_sources({a}, {b}, {c}, {d}); }
+    // prod e(a_i, b_i) == out   :116-138
+    void add_multiple_sources_and_target(const std::vector<G1::Affine> &a, const std::vector<G2::Affine> &b, const Fq12 &out) {
+        if (a.size() != b.size()) throw Error(DGPU_E_LENGTH, "add_multiple_sources_and_target");
+        const BigInt256 m = current_random_;
+        if (lazy_) { pending_.push_back({a, m, false, b}); pending_targets_.push_back({out, m}); }
+        else {
+            left_ = detail::fq12_mul(left_, multi_miller_loop(scale(a, {m}, {}), b));
+            Fq12 pw{}; check(dgpu_fp12_pow(out.data(), m.data(), pw.data()), "fp12_pow");
+            right_ = detail::fq12_mul(right_, pw);
+        }
+        advance();
+    }
+    // prod e(a_i, b_i) == prod e(c_i, d_i)   :142-173
+    void add_multiple_sources(const std::vector<G1::Affine> &a, const std::vector<G2::Affine> &b, const std::vector<G1::Affine> &c, const std::vector<G2::Affine> &d) {
+        if (a.size() != b.size() || c.size() != d.size()) throw Error(DGPU_E_LENGTH, "add_multiple_sources");
+        const BigInt256 m = current_random_;
+        if (lazy_) { pending_.push_back({a, m, false, b}); pending_.push_back({c, m, true, d}); }
+        else {
+            left_ = detail::fq12_mul(left_, multi_miller_loop(scale(a, {m}, {}), b));
+            left_ = detail::fq12_mul(left_, multi_miller_loop(scale(c, {m}, std::vector<uint8_t>(c.size(), 1)), d));
+        }
+        advance();
+    }
+    // :204-214
+    bool verify() {
+        Fq12 left = left_;
+        if (!pending_targets_.empty()) {
+            std::vector<uint64_t> bases, exps;
+            for (auto &t : pending_targets_) { bases.insert(bases.end(), t.first.begin(), t.first.end()); exps.insert(exps.end(), t.second.begin(), t.second.end()); }
+            Fq12 pw{}; check(dgpu_fp12_multi_pow(bases.data(), exps.data(), pending_targets_.size(), pw.data()), "fp12_multi_pow");
+            right_ = detail::fq12_mul(right_, pw);
+            pending_targets_.clear();
+        }
+        if (!pending_.empty()) {
+            std::vector<G1::Affine> pts; std::vector<G2::Affine> qs; std::vector<BigInt256> ms; std::vector<uint8_t> neg;
+            for (auto &q : pending_) for (size_t i = 0; i < q.a.size(); i++) { pts.push_back(q.a[i]); qs.push_back(q.b[i]); ms.push_back(q.m); neg.push_back(q.negate ? 1 : 0); }
+            left = detail::fq12_mul(multi_miller_loop(scale(pts, ms, neg), qs), left);
+            pending_.clear();
+        }
+        const auto gt = final_exponentiation(left);
+        if (!gt) throw Error(DGPU_E_ZERO, "final_exponentiation");              // arkworks: .unwrap() panics
+        return *gt == right_;
+    }
+};
+
 // ---- legogroth16::create_proof_with_reduction (legogroth16/src/prover.rs:153-180 -> :267-383) over dgpu_legogroth16_prove ----
 namespace legogroth16 {
 // ProvingKey (legogroth16/src/data_structures.rs:55-70,151-168): the five queries live on the device, the O(1) elements on the host

@@ -7,5 +7,13 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 
+# torch first, in every test process: it ships its own HIP runtime; a process that loaded libdock_gpu.so (the system runtime) BEFORE torch ends
+# up with two runtimes, and whichever initialises second finds no device (seen as DGPU_E_NODEVICE from dgpu_init after an unrelated test)
+try:
+    import torch  # noqa: F401
+except Exception:  # noqa: BLE001
+    pass
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

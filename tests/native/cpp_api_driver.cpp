@@ -236,6 +236,31 @@ int main() {
         EXPECT(dgpu_msm_g2(b2.data(), inf2.data(), sc.data(), n, one2) == DGPU_OK);
         EXPECT(dgpu_msm_g2_sharded(b2.data(), inf2.data(), sc.data(), n, 0, sh2) == DGPU_OK && std::memcmp(one2, sh2, sizeof one2) == 0);
     }
+    // RandomizedPairingChecker from a compiled host (utils/src/randomized_pairing_check.rs:273-419's test shape): several true equations of both
+    // kinds pass, in lazy and in eager mode; one wrong target or one swapped point makes the whole batch fail; unequal lengths are refused
+    {
+        auto pt1 = [&](size_t i) { return P1[20 + i]; }; auto pt2 = [&](size_t i) { return P2[20 + i]; };
+        auto gt_of = [&](size_t lo, size_t cnt) { Fq12 m{}, g{}; orc_multi_miller_loop(b1.data() + 12 * (20 + lo), b2.data() + 24 * (20 + lo), nullptr, cnt, 4, m.data()); orc_final_exponentiation(m.data(), g.data()); return g; };
+        BigInt256 rnd{}; orc_rand_scalars(99, 1, rnd.data());
+        // e(x P, Q) == e(P, x Q): both sides through the oracle's scalar multiplication
+        const uint64_t xk[4] = {0x1234567890abcdefULL, 0x0fedcba987654321ULL, 0x1111, 0};
+        G1::Affine xP; G2::Affine xQ; xP.infinity = xQ.infinity = false;
+        { uint64_t j1[18], a1[12], j2[36], a2[24]; orc_g1_mul(b1.data() + 12 * 40, 0, xk, j1); orc_g1_to_affine(j1, a1); std::memcpy(&xP.x, a1, 48); std::memcpy(&xP.y, a1 + 6, 48);
+          orc_g2_mul(b2.data() + 24 * 41, 0, xk, j2); orc_g2_to_affine(j2, a2); std::memcpy(&xQ.x, a2, 96); std::memcpy(&xQ.y, a2 + 12, 96); }
+        for (int lazy = 0; lazy < 2; lazy++) {
+            for (int wrong = 0; wrong < 3; wrong++) {
+                RandomizedPairingChecker chk(rnd, lazy != 0);
+                chk.add_sources_and_target(pt1(0), pt2(0), gt_of(0, 1));
+                chk.add_multiple_sources_and_target({pt1(1), pt1(2), pt1(3)}, {pt2(1), pt2(2), pt2(3)}, wrong == 1 ? gt_of(1, 2) : gt_of(1, 3));
+                chk.add_sources(xP, P2[41], P1[40], wrong == 2 ? P2[42] : xQ);
+                chk.add_multiple_sources({pt1(4), pt1(5)}, {pt2(4), pt2(5)}, {pt1(5), pt1(4)}, {pt2(5), pt2(4)});
+                EXPECT(chk.verify() == (wrong == 0));
+            }
+        }
+        bool refused = false;
+        try { RandomizedPairingChecker chk(rnd, true); chk.add_multiple_sources_and_target({pt1(0), pt1(1)}, {pt2(0)}, gt_of(0, 1)); } catch (const Error &e) { refused = e.code == DGPU_E_LENGTH; }
+        EXPECT(refused);
+    }
     if (fails) std::printf("cpp_api_driver: %d FAILED\n", fails); else std::printf("cpp_api_driver: all equal\n");
     return fails ? 1 : 0;
 }

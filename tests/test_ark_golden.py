@@ -11,6 +11,7 @@ import json
 import os
 import numpy as np
 import pytest
+import torch  # noqa: F401  (before the library: one HIP runtime per process)
 import oracle_c as O
 
 HERE = os.path.dirname(os.path.abspath(__file__))

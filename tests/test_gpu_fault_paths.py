@@ -7,6 +7,7 @@ import os
 import subprocess
 import sys
 import pytest
+import torch  # noqa: F401  (before the library: torch ships its own HIP runtime, and a process must not end up with two of them)
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

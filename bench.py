@@ -110,10 +110,18 @@ def main():
     if os.environ.get("DGPU_BENCH_SAME_DEVICE"):      # plumbing test only: several ranks on one GPU
         local = 0
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
-    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    cdev = dev if os.environ.get("DGPU_BENCH_BACKEND", "nccl") == "nccl" else None     # where collective payloads live
+    # DGPU_BENCH_STUB (tests/test_bench_multi_rank_cpu.py only): the library is replaced by tests/bench_stub.py (the group Z_r) and the ranks are
+    # CPU processes under gloo, so that this file's N > 1 control flow is exercised where no 8-GPU node is at hand.  Never a measurement.
+    STUB = bool(os.environ.get("DGPU_BENCH_STUB"))
+    if STUB:
+        os.environ["DGPU_BENCH_BACKEND"] = "gloo"
+        dev = cdev = None
+    else:
+        assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+        cdev = dev if os.environ.get("DGPU_BENCH_BACKEND", "nccl") == "nccl" else None     # where collective payloads live
+    sync = (lambda: None) if STUB else torch.cuda.synchronize
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("DGPU_BENCH_BACKEND", "nccl")       # "gloo" only for the one-GPU plumbing test (RCCL refuses two ranks on one device)
@@ -122,8 +130,12 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    import crypto_amd as ca
-    from crypto_amd import sharded, serde, fixed_base as FB
+    if STUB:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from bench_stub import ca, sharded, serde, FB
+    else:
+        import crypto_amd as ca
+        from crypto_amd import sharded, serde, fixed_base as FB
 
     ca.init(local)
     if args.reduce_shift >= 0:
@@ -201,11 +213,11 @@ def main():
     ca.prof.reset()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     allocs0 = ca.device_alloc_count()
     t0 = time.perf_counter()
     last = run_steps(args.steps)
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
@@ -213,10 +225,14 @@ def main():
     assert (last == res).all(), "result changed between runs"
     stages = ca.prof.read()
     ca.prof.enable(False)
+    per_rank_table_ms = [round(table_ms, 1)]
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=cdev if cdev is not None else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        got = [None] * world
+        dist.all_gather_object(got, round(table_ms, 1))            # every rank builds the table of ITS 2^24 / N terms: the per-key setup of each
+        per_rank_table_ms = got
 
     if rank == 0:
         ms_step = dt / args.steps * 1e3
@@ -254,7 +270,7 @@ def main():
                     args.log2n + (world - 1).bit_length(), world)),
                 "terms_per_step": terms, "bit_exact_vs_closed_form": bit_exact,
                 "parallelism": "1 process per GPU, %d ranks, %d calls in flight per GPU" % (world, inflight),
-                "per_key_setup_ms": {"fixed_base_bases_and_uploads": round(t_setup * 1e3 - table_ms, 1), "precomputed_table": round(table_ms, 1)},
+                "per_key_setup_ms": {"fixed_base_bases_and_uploads": round(t_setup * 1e3 - table_ms, 1), "precomputed_table": round(table_ms, 1), "precomputed_table_per_rank": per_rank_table_ms},
                 "scaling_note": "N = 1 is BASELINE config 2 (2^20 terms); every N > 1 computes config 5's 2^24 terms in total, so the N > 1 "
                                 "values are a strong-scaling series; secondary.g1_2p24_single_gpu is the 1-GPU time of the same 2^24 terms"},
             "terms_per_s": round(terms / (dt / args.steps), 1),
@@ -273,9 +289,11 @@ def main():
                                     "frac": round(mads / (acc_avg_ms * 1e-3) / 1e12 / MAD_PEAK, 4), "mixed_additions_per_launch": int(n) * windows,
                                     "note": "%d windows x n mixed additions x %d 32 x 32 -> 64-bit multiply-adds each (13 x 30-bit signed limbs since round 3: 13.8 %% fewer than the 3542 of the 14 x 29-bit field, so the same kernel time is a LOWER fraction); peak = measured issue rate, profiles/r01h_instr_rate_ubench.txt" % (
                                         windows, MADS_PER_MIXED_ADD)}
-        if not args.no_cpu_baseline:
+        if STUB:
+            out["data"] = "STUB (tests/bench_stub.py: control-flow test on CPU ranks, not a measurement)"
+        if not args.no_cpu_baseline and not STUB:
             out["cpu_baseline"] = cpu_baseline(ca, gen1, ks, scalars, db, ds, args.log2n, ncpu)
-        if world == 1 and not args.no_secondary:
+        if world == 1 and not args.no_secondary and not STUB:
             try:
                 out["secondary"] = secondary_configs(args.log2n, ks, scalars, db, ds, pool, cpu_legs=not (args.no_cpu_baseline or args.no_cpu_legs), ncpu=ncpu)
             except Exception as e:                      # never let the secondary numbers take the headline line down

@@ -128,6 +128,15 @@ static int32_t init_ctx_locked(int idx, int device) {
     HIPCHK(hipSetDevice(device));
     { const int32_t rc = init_ctx_slots(c);
       if (rc) { for (int i = 0; i < N_SLOTS; i++) destroy_slot(c.slots[i]); return rc; } }      // nothing half-built is left behind
+    // xGMI: peer access between this device and the ones already in use (best effort: without it hipMemcpyPeerAsync stages through the host)
+    for (int k = 0; k < MAX_CTX; k++) {
+        if (k == idx || !ctxs[k].ready || ctxs[k].device == device) continue;
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, device, ctxs[k].device) == hipSuccess && can) { (void)hipSetDevice(device); (void)hipDeviceEnablePeerAccess(ctxs[k].device, 0); }
+        if (hipDeviceCanAccessPeer(&can, ctxs[k].device, device) == hipSuccess && can) { (void)hipSetDevice(ctxs[k].device); (void)hipDeviceEnablePeerAccess(device, 0); }
+        (void)hipGetLastError();                       // (hipErrorPeerAccessAlreadyEnabled when two contexts share a pair of devices)
+        (void)hipSetDevice(device);
+    }
     c.device = device; c.ready = true;
     if (gs.default_ctx < 0) gs.default_ctx = idx;
     return DGPU_OK;
@@ -298,6 +307,33 @@ int32_t dgpu_scalars_upload(const uint64_t *s, size_t n, int32_t mont, uint64_t 
     return DGPU_OK;
 }
 
+
+// scalars [lo, hi) of a resident vector as a vector of its own on context `dst_ctx`: device to device — over xGMI when the two contexts sit on
+// different GPUs (hipMemcpyPeerAsync; peer access is enabled between the process's devices when they are brought up), a plain device copy
+// when they share one.  The sharded prover hands every shard its slice of h this way instead of through the host (32 B x D down and up PCIe).
+int32_t dgpu_scalars_copy_range(uint64_t src, size_t lo, size_t hi, int32_t dst_ctx, uint64_t *handle) {
+    if (!handle || lo > hi || dst_ctx < 0 || dst_ctx >= MAX_CTX || !ctxs[dst_ctx].ready) return DGPU_E_BADARG;
+    HandleRef hs(src);
+    if (!hs.ok || hs.h.kind != 3 || hi > hs.h.n) return DGPU_E_BADARG;
+    const size_t n = hi - lo;
+    const int src_dev = ctxs[hs.h.ctx].device, dst_dev = ctxs[dst_ctx].device;
+    CtxScope on_dst(dst_ctx);
+    void *p = nullptr;
+    {
+        SLOT_ACQUIRE(L, sl);
+        HIPCHK(hipSetDevice(dst_dev));
+        if (!(p = scalar_alloc(scalar_bytes(n)))) return DGPU_E_OOM;
+        hipError_t e = hipSuccess;
+        if (n) {
+            const char *from = (const char *)hs.h.p + lo * 32;
+            e = src_dev == dst_dev ? hipMemcpyAsync(p, from, n * 32, hipMemcpyDeviceToDevice, sl.stream) : hipMemcpyPeerAsync(p, dst_dev, from, src_dev, n * 32, sl.stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(sl.stream);
+        }
+        if (e != hipSuccess) { gs.last_hip = (int32_t)e; (void)hipGetLastError(); scalar_release(dst_ctx, p, scalar_bytes(n)); return DGPU_E_HIP; }
+    }
+    *handle = register_handle(p, n, 3);
+    return DGPU_OK;
+}
 
 // several host arrays -> one resident scalar vector (the prover's `assignment` = inputs[1..] ++ witnesses, prover.rs:319-321,
 // without a host-side concatenation)

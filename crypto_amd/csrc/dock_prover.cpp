@@ -235,7 +235,7 @@ static int32_t prove_impl(const dgpu_lego_pk *pk, uint64_t r1cs, uint64_t h_scal
 // ---- the same proof with the key resident across G device contexts (one process): every query is a sharded handle whose part g lives on
 // context g.  Context g multiplies its rows of the five queries by the matching slice of z / h (one host thread per context inside this call, the
 // schedule of the single-device form inside it: shared sort, G2 first); the witness map runs once, on the circuit's context, and its h coefficients
-// travel through the host to the shards (D x 32 B down, 1 / G of it up per shard); the per-shard partial points are folded on the host.
+// go to the shards device to device (peer copies over xGMI between GPUs); the per-shard partial points (144 / 288 B each) are folded on the host.
 namespace {
 struct ShardRange { uint64_t sub; size_t lo, hi; int32_t ctx; };
 int32_t shard_part(uint64_t handle, size_t g, ShardRange &o) { return dgpu_shard_part(handle, g, &o.sub, &o.lo, &o.hi, &o.ctx); }
@@ -254,16 +254,15 @@ int32_t prove_sharded(const ProofInputs &in, size_t G, uint64_t r1cs, uint64_t h
     // h: from the caller (a resident vector cannot be split here: it must be a host-visible source) or from the witness map on the circuit's context
     if (!r1cs) return DGPU_E_BADARG;                 // the sharded form takes the circuit (h_scalars lives on one device only)
     (void)h_scalars;
+    // h = the witness map's output, resident on the circuit's context; every shard receives its slice device to device (dgpu_scalars_copy_range:
+    // a peer copy over xGMI between two GPUs).  Rounds 1-3 moved it through the host: D x 32 B down PCIe and 1 / G of it up again per shard.
     size_t D = 0;
-    std::vector<uint64_t> h;
+    uint64_t h_dev = 0;
     Job jW;
     jW.start([&]() -> int32_t {
         int32_t rctx = 0; if (dgpu_handle_context(r1cs, &rctx)) return DGPU_E_BADARG;
         if (dgpu_set_device(rctx)) return DGPU_E_BADARG;
-        size_t nc = 0, ni = 0; if (dgpu_r1cs_shape(r1cs, nullptr, &ni, &nc)) return DGPU_E_BADARG;   // the circuit's own shape sizes h (n_inst == ni was checked by the entry point)
-        size_t cap = 1; while (cap < nc + ni) cap <<= 1;                                    // the domain of r1cs_to_qap.rs:150-160
-        h.assign(cap * 4, 0);
-        return dgpu_witness_map_r1cs(r1cs, in.z, num_vars, in.montgomery, h.data(), nullptr, &D);
+        return dgpu_witness_map_r1cs(r1cs, in.z, num_vars, in.montgomery, nullptr, &h_dev, &D);
     });
     ProofConsts cst; Job jK;
     jK.start([&] { return proof_constants(in, cst); });
@@ -308,7 +307,7 @@ int32_t prove_sharded(const ProofInputs &in, size_t G, uint64_t r1cs, uint64_t h
         // h_query rows [lo, hi) pair with h[row] (canonical, from the witness map)
         if ((e = wait_h())) return e;
         { const size_t hlo = Hq[g].lo, hhi = std::min(Hq[g].hi, D);
-          if (hhi > hlo) { uint64_t hs = 0; if ((e = dgpu_scalars_upload(h.data() + 4 * hlo, hhi - hlo, 0, &hs))) return e;
+          if (hhi > hlo) { uint64_t hs = 0; if ((e = dgpu_scalars_copy_range(h_dev, hlo, hhi, Hq[g].ctx, &hs))) return e;
                            e = dgpu_msm_g1_resident(Hq[g].sub, 0, hs, 0, hhi - hlo, &ph[18 * g]); (void)dgpu_scalars_free(hs); if (e) return e; }
           else identity1(&ph[18 * g]); }
         return DGPU_OK;
@@ -318,6 +317,7 @@ int32_t prove_sharded(const ProofInputs &in, size_t G, uint64_t r1cs, uint64_t h
     note(jK.join());
     for (size_t g = 0; g < G; g++) note(jobs[g].join());
     note(wait_h());
+    if (h_dev) (void)dgpu_scalars_free(h_dev);
     if (first) return first;
     uint64_t acc_a[18], acc_b1[18], acc_l[18], acc_h[18], acc_b2[36];
     if ((first = dgpu_fold_g1(pa.data(), G, acc_a)) || (first = dgpu_fold_g1(pb1.data(), G, acc_b1)) || (first = dgpu_fold_g1(pl.data(), G, acc_l)) ||

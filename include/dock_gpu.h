@@ -184,6 +184,9 @@ int32_t dgpu_bases_upload_g2_sharded(const uint64_t *bases_xy, const uint8_t *is
 int32_t dgpu_msm_g1_sharded_handle(uint64_t bases, const uint64_t *scalars, size_t n, int32_t montgomery, uint64_t out_xyz[18]);
 int32_t dgpu_msm_g2_sharded_handle(uint64_t bases, const uint64_t *scalars, size_t n, int32_t montgomery, uint64_t out_xyz[36]);
 int32_t dgpu_scalars_upload_sharded(const uint64_t *scalars, size_t n, int32_t montgomery, uint64_t like, uint64_t *handle);
+/* scalars [lo, hi) of a resident vector as a new vector on device context `dst_context`: device to device (a peer copy over xGMI between two
+ * GPUs; peer access is enabled between the process's devices at init).  dgpu_legogroth16_prove on a sharded key moves h this way. */
+int32_t dgpu_scalars_copy_range(uint64_t scalars, size_t lo, size_t hi, int32_t dst_context, uint64_t *handle);
 int32_t dgpu_msm_g1_sharded_resident(uint64_t bases, uint64_t scalars, uint64_t out_xyz[18]);
 int32_t dgpu_msm_g2_sharded_resident(uint64_t bases, uint64_t scalars, uint64_t out_xyz[36]);
 

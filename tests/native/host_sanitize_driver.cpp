@@ -73,11 +73,19 @@ int32_t dgpu_witness_map_r1cs_resident(uint64_t r1cs, uint64_t z, uint64_t *, ui
     size_t D = 1; while (D < a.h.n + 1) D <<= 1;
     void *p = calloc(D, 32); *out_handle = register_handle(p, D, 3); g_live_scalars++; *out_len = D; return DGPU_OK;
 }
-int32_t dgpu_witness_map_r1cs(uint64_t r1cs, const uint64_t *, size_t, int32_t, uint64_t *out_h, uint64_t *, size_t *out_len) {
+int32_t dgpu_witness_map_r1cs(uint64_t r1cs, const uint64_t *, size_t, int32_t, uint64_t *out_h, uint64_t *out_handle, size_t *out_len) {
     HandleRef a(r1cs); if (!a.ok) return DGPU_E_BADARG;
     int32_t rc = step("wm"); if (rc) return rc;
     size_t D = 1; while (D < a.h.n + 1) D <<= 1;
-    memset(out_h, 0, D * 32); *out_len = D; return DGPU_OK;
+    if (out_h) memset(out_h, 0, D * 32);
+    if (out_handle) { *out_handle = register_handle(calloc(D, 32), D, 3); g_live_scalars++; }
+    *out_len = D; return DGPU_OK;
+}
+int32_t dgpu_scalars_copy_range(uint64_t src, size_t lo, size_t hi, int32_t, uint64_t *h) {
+    HandleRef a(src); if (!a.ok || a.h.kind != 3 || lo > hi || hi > a.h.n) return DGPU_E_BADARG;
+    int32_t rc = step("copy"); if (rc) return rc;
+    void *p = malloc(32 * (hi - lo ? hi - lo : 1)); memcpy(p, (const char *)a.h.p + 32 * lo, 32 * (hi - lo));
+    *h = register_handle(p, hi - lo, 3); g_live_scalars++; return DGPU_OK;
 }
 int32_t dgpu_bases_table_shape(uint64_t h, size_t *rows, int32_t *c, int32_t *w) { Handle hd; if (!lookup_handle(h, hd) || (hd.kind != 10 && hd.kind != 11)) return DGPU_E_BADARG; *rows = hd.n; *c = 17; *w = 15; return DGPU_OK; }
 int32_t dgpu_scalars_sort(uint64_t t, size_t, uint64_t s, size_t, size_t n, uint64_t *out) {

@@ -143,3 +143,37 @@ def test_size_threshold_default_and_override():
     finally:
         L.dgpu_set_min_gpu_n(0)
     assert L.dgpu_msm_g1(p(b), None, p(s), 1, p(out)) == 0
+
+
+def test_scalars_copy_range_between_contexts():
+    """dgpu_scalars_copy_range: a slice of a resident scalar vector becomes a vector of its own on another context, device to device (two
+    contexts on the box's one GPU: the same-device branch; between two GPUs the same call is a peer copy over xGMI).  The copy multiplies
+    like the original slice; bad ranges and contexts are refused."""
+    import ctypes as C
+    import oracle_c as O
+    import util as U
+    import crypto_amd as ca
+    from crypto_amd._native import lib
+    ca.init_devices([0, 0])
+    L = lib()
+    n = 3000
+    bases, _, _ = U.seq_bases(O.G1, n, 31, threads=16); sc = O.rand_scalars(32, n)
+    L.dgpu_set_device(0)
+    ds = ca.DeviceScalars(sc)
+    h = C.c_uint64(0)
+    lo, hi = 700, 2900
+    assert L.dgpu_scalars_copy_range(ds.handle, lo, hi, 1, C.byref(h)) == 0
+    ctx = C.c_int32(-1); ln = C.c_size_t(0)
+    assert L.dgpu_handle_context(h.value, C.byref(ctx)) == 0 and ctx.value == 1
+    assert L.dgpu_handle_len(h.value, C.byref(ln)) == 0 and ln.value == hi - lo
+    L.dgpu_set_device(1)
+    db = ca.DeviceBases(ca.G1, bases[lo:hi])                      # on context 1, next to the copy
+    out = np.zeros(18, np.uint64)
+    assert L.dgpu_msm_g1_resident(db.handle, 0, h.value, 0, hi - lo, out.ctypes.data_as(C.c_void_p)) == 0
+    assert (out == ca.msm_bigint(ca.G1, bases[lo:hi], sc[lo:hi])).all()
+    assert L.dgpu_scalars_free(h.value) == 0
+    for args in ((ds.handle, 10, 5, 1), (ds.handle, 0, n + 1, 1), (ds.handle, 0, 10, 7), (db.handle, 0, 10, 1), (12345, 0, 1, 0)):
+        assert L.dgpu_scalars_copy_range(*args, C.byref(h)) == -3
+    assert L.dgpu_scalars_copy_range(ds.handle, 5, 5, 0, C.byref(h)) == 0 and L.dgpu_scalars_free(h.value) == 0        # an empty slice is a vector of length 0
+    db.free(); ds.free()
+    L.dgpu_set_device(0)

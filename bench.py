@@ -246,13 +246,16 @@ def main():
         acc_ov_ms = acc_ov[0] / max(1, acc_ov[1])
         alg_bytes = 128.0 * n                      # 32 B scalar + 96 B affine base per term, one launch = n terms
         achieved = alg_bytes / (acc_avg_ms * 1e-3) / 1e9 if acc_avg_ms > 0 else 0.0
-        traffic = None
+        # HBM bytes per launch from the PMC counters: collected by separate rocprofv3 --pmc passes of THIS command (tools/dev/round4_profiles.sh ->
+        # tools/traffic_json.py), not inside this process; the file names the commit it was measured at
+        traffic, traffic_src = None, None
         tj = os.path.join(ROOT, "profiles", "traffic_accumulate.json")
         if os.path.exists(tj):
             try:
                 tr = json.load(open(tj))
                 if tr.get("log2n") == args.log2n and bool(tr.get("table")) == use_table:
                     traffic = tr.get("hbm_bytes_per_launch")
+                    traffic_src = "profiles/traffic_accumulate.json, measured at commit %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --inflight 1`)" % tr.get("commit", "of round 3")
             except Exception:
                 pass
         shape = db.table_shape()                   # (rows, window bits, windows) when the handle is a table
@@ -278,7 +281,7 @@ def main():
             "stages_ms": {k.replace("msm.", ""): round(v[0] / max(1, v[1]), 4) for k, v in stages.items()},
             "stages_ms_one_in_flight": {k.replace("msm.", ""): round(v[0] / max(1, v[1]), 4) for k, v in stages_seq.items()},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 6),
-                         "traffic": traffic, "kernel": "k_accumulate<G1>", "avg_ms": round(acc_avg_ms, 4), "avg_ms_overlapped": round(acc_ov_ms, 4),
+                         "traffic": traffic, "traffic_source": traffic_src, "kernel": "msm::k_accumulate<msm::G1S, false>" if use_table else "msm::k_accumulate<msm::G1S, false> (plain pipeline)", "avg_ms": round(acc_avg_ms, 4), "avg_ms_overlapped": round(acc_ov_ms, 4),
                          "note": "algorithmic 128 B/term x 2^log2n terms per launch; avg_ms = HIP-event duration with one call in flight (same process, "
                                  "untimed pass; rocprof of `bench.py --inflight 1` agrees), avg_ms_overlapped = inside the timed region where launches "
                                  "share the chip; the kernel is integer-multiply bound: see valu_roofline"},
@@ -492,7 +495,7 @@ def secondary_configs(log2n, ks, scalars, db, ds, pool, cpu_legs=True, ncpu=1):
         if acc2 > 0 and sh2:
             mads2 = float(n) * sh2[2] * MADS_PER_G2_MIXED_ADD
             res["g2_stages_ms_one_in_flight"] = {k.replace("msm.", ""): round(v[0] / max(1, v[1]), 4) for k, v in st2.items()}
-            res["g2_valu_roofline"] = {"bound": "v_mad_u64_u32", "kernel": "k_accumulate<G2P>", "avg_ms": round(acc2, 4), "achieved": round(mads2 / (acc2 * 1e-3) / 1e12, 3), "peak": MAD_PEAK,
+            res["g2_valu_roofline"] = {"bound": "v_mad_u64_u32", "kernel": "msm::k_accumulate<msm::G2P, false>", "avg_ms": round(acc2, 4), "achieved": round(mads2 / (acc2 * 1e-3) / 1e12, 3), "peak": MAD_PEAK,
                                        "unit": "Tmad/s", "frac": round(mads2 / (acc2 * 1e-3) / 1e12 / MAD_PEAK, 4), "mixed_additions_per_launch": int(n) * sh2[2],
                                        "note": "%d windows x n mixed additions over Fp2 x %d v_mad_u64_u32 each (two lanes per point; schoolbook Fp2 product = two fused two-product reductions per lane)" % (sh2[2], MADS_PER_G2_MIXED_ADD),
                                        "hbm_roofline": {"achieved_GB_s": round(224.0 * n / (acc2 * 1e-3) / 1e9, 1), "frac": round(224.0 * n / (acc2 * 1e-3) / 1e9 / 8000.0, 5), "note": "algorithmic 224 B/term (SURVEY 8d)"}}

@@ -733,7 +733,11 @@ constexpr int ML_PIECES = 3;
 constexpr int ML_CUTS[ML_PIECES] = {40, 17, 0};               // piece j runs the bits (ML_CUTS[j - 1] - 1, or 62) .. ML_CUTS[j]
 // n pairs in the line buffer, the first n_aff of them affine (their chain is what gets cut); prepared(pxy) queues the line kernel of the
 // prepared pairs n_aff .. n - 1, if any, on the slot's stream (it writes their neutral px, py)
-static int32_t ml_pipelined(Slot &sl, size_t n, size_t n_aff, const uint8_t *dskip, uint64_t *out, const std::function<void(uint32_t *)> &prepared) {
+// late(side_stream, pxy), if given, runs on the calling thread once every piece of the chain has been queued — host work that the chain hides
+// (the verifier computes its third G1 operand meanwhile) — and may queue, on side_stream, whatever must precede the product kernels (the line
+// kernel of prepared pairs whose P was not known before).
+static int32_t ml_pipelined(Slot &sl, size_t n, size_t n_aff, const uint8_t *dskip, uint64_t *out, const std::function<void(uint32_t *)> &prepared,
+                            const std::function<int32_t(hipStream_t, uint32_t *)> &late = nullptr) {
     int32_t rc; MlGeom g, g2;
     if ((rc = ml_geometry(sl, n, g))) return rc;
     // the last steps' products are all that is left when the chain ends: from 8-pair slices on they take half the slice length (fewer
@@ -751,23 +755,36 @@ static int32_t ml_pipelined(Slot &sl, size_t n, size_t n_aff, const uint8_t *dsk
     hipStream_t sa = sl.stream;
     hipStream_t side[2] = {sl.cstream, sl.xstream};                  // the pieces' products alternate between them (a piece's products outlast the next piece's chain)
     static_assert((size_t)N_LINES * 576 <= Slot::HPIN_BYTES, "pinned scratch");
-    static_assert(2 * (ML_PIECES - 1) <= Slot::N_COPY_EV + 1, "events");
+    static_assert(2 * (ML_PIECES - 1) + 1 <= Slot::N_COPY_EV + 1, "events");
     hostf::Fq12 *L = (hostf::Fq12 *)sl.hpin;                          // pinned: the copies below are asynchronous for the host
     uint32_t *state = sl.ml_state.as<uint32_t>(), *pxy = state + (size_t)3 * NL * 4 * n_aff;
     // (a failed enqueue must not leave the slot with work in flight: every step is checked, every stream is drained before any return)
     rc = DGPU_OK;
     auto ok = [&](hipError_t e) { if (e != hipSuccess && !rc) rc = DGPU_E_HIP; return rc == DGPU_OK; };
     prepared(pxy);
-    hipEvent_t done[ML_PIECES - 1] = {};
-    int s_first = 0, b_hi = 62;
+    hipEvent_t done[ML_PIECES - 1] = {}, ready[ML_PIECES - 1] = {};
+    int first_step[ML_PIECES], steps[ML_PIECES];
+    { int s_first = 0, b_hi = 62;                                        // the whole chain first: its launches depend on nothing but each other
+      for (int j = 0; j < ML_PIECES && !rc; j++) {
+          const int b_lo = cuts[j], ns = ml_steps(b_hi, b_lo);
+          first_step[j] = s_first; steps[j] = ns;
+          launch_lines_uneval(sa, sl.in_bases.as<uint32_t>(), sl.in_scalars.as<uint32_t>(), dskip, n_aff, sl.ml_lines.as<uint32_t>(), n, b_hi, b_lo, s_first, state, pxy);
+          if (j + 1 < ML_PIECES) { ready[j] = sl.copy_ev[sl.ev_next++ % (Slot::N_COPY_EV + 1)]; ok(hipEventRecord(ready[j], sa)); }
+          s_first += ns; b_hi = b_lo - 1;
+      } }
+    hipEvent_t late_done = nullptr;
+    if (late && !rc) {
+        const int32_t lrc = late(side[0], pxy);
+        if (lrc && !rc) rc = lrc;
+        late_done = sl.copy_ev[sl.ev_next++ % (Slot::N_COPY_EV + 1)];
+        if (!rc) { ok(hipEventRecord(late_done, side[0])); ok(hipStreamWaitEvent(side[1], late_done, 0)); ok(hipStreamWaitEvent(sa, late_done, 0)); }
+    }
     for (int j = 0; j < ML_PIECES && !rc; j++) {
-        const int b_lo = cuts[j], ns = ml_steps(b_hi, b_lo);
-        launch_lines_uneval(sa, sl.in_bases.as<uint32_t>(), sl.in_scalars.as<uint32_t>(), dskip, n_aff, sl.ml_lines.as<uint32_t>(), n, b_hi, b_lo, s_first, state, pxy);
+        const int s_first = first_step[j], ns = steps[j];
         if (j + 1 < ML_PIECES) {
-            hipEvent_t ready = sl.copy_ev[sl.ev_next++ % (Slot::N_COPY_EV + 1)];
             done[j] = sl.copy_ev[sl.ev_next++ % (Slot::N_COPY_EV + 1)];
             hipStream_t sp = side[j & 1];
-            if (ok(hipEventRecord(ready, sa)) && ok(hipStreamWaitEvent(sp, ready, 0))) {
+            if (ok(hipStreamWaitEvent(sp, ready[j], 0))) {
                 ml_products(sl, sp, n, g, s_first, ns, false, pxy);
                 ok(hipMemcpyAsync(L + s_first, (const char *)sl.ml_out.p + (size_t)s_first * 576, (size_t)ns * 576, hipMemcpyDeviceToHost, sp));
                 ok(hipEventRecord(done[j], sp));
@@ -776,11 +793,10 @@ static int32_t ml_pipelined(Slot &sl, size_t n, size_t n_aff, const uint8_t *dsk
             ml_products(sl, sa, n, g2, s_first, ns, false, pxy);
             ok(hipMemcpyAsync(L + s_first, (const char *)sl.ml_out.p + (size_t)s_first * 576, (size_t)ns * 576, hipMemcpyDeviceToHost, sa));
         }
-        s_first += ns; b_hi = b_lo - 1;
     }
     ok(hipGetLastError());
     MlTail tail;
-    for (int j = 0; j + 1 < ML_PIECES; j++) if (!rc && ok(hipEventSynchronize(done[j]))) tail.run(L, cuts[j]);
+    for (int j = 0; j + 1 < ML_PIECES; j++) if (!rc && done[j] && ok(hipEventSynchronize(done[j]))) tail.run(L, cuts[j]);
     ok(hipStreamSynchronize(sa)); ok(hipStreamSynchronize(side[0])); ok(hipStreamSynchronize(side[1]));
     if (rc) return rc;
     tail.run(L, 0);
@@ -1056,6 +1072,92 @@ int32_t dgpu_multi_miller_loop_mixed(const uint64_t *p_aff, const uint64_t *q_af
                              skip_prep ? dsk + n_aff : (const uint8_t *)nullptr, n_prep, lines + n_aff, n);
     }
     return ml_finish(sl, n, out);
+}
+
+// ---- the LegoGroth16 verifier as one call (legogroth16/src/verifier.rs:62-99 `verify_proof`: calculate_d :29-50,101-109, then verify_qap_proof) ----
+// e(A, B) e(C, -delta) e(gamma_abc[0] + sum x_j gamma_abc[1 + j] + D, -gamma) == e(alpha, beta), with -delta, -gamma held prepared and e(alpha, beta)
+// precomputed in the PreparedVerifyingKey (verifier.rs:17-25).  One call instead of calculate_d + multi_miller_loop + final_exponentiation lets
+// the library hide the host's share under the device's: the chain of the one affine pair (A, B) is queued first, the third G1 operand (a
+// 255-bit scalar multiplication per public input, ~0.15 ms of one host core) is computed while it runs, the two prepared pairs' lines follow on
+// a side stream in front of the product kernels.  *ok = 1 / 0; DGPU_E_BADARG for a key too short for the inputs (`MalformedVerifyingKey`).
+int32_t dgpu_legogroth16_verify(const uint64_t alpha_beta_gt[72], const uint64_t *delta_neg_pc, const uint64_t *gamma_neg_pc, const uint64_t *gamma_abc_g1, size_t gamma_abc_len,
+                                const uint64_t proof_a[12], const uint64_t proof_b[24], const uint64_t proof_c[12], const uint64_t proof_d[12], const uint8_t *proof_inf /* 4 or NULL */,
+                                const uint64_t *public_inputs, size_t n_pub, int32_t montgomery, int32_t *ok_out) {
+    if (!alpha_beta_gt || !delta_neg_pc || !gamma_neg_pc || !gamma_abc_g1 || !proof_a || !proof_b || !proof_c || !proof_d || !ok_out || (n_pub && !public_inputs)) return DGPU_E_BADARG;
+    if (n_pub + 1 > gamma_abc_len) return DGPU_E_BADARG;                       // verifier.rs:38-40 MalformedVerifyingKey
+    if (n_pub + 2 > DGPU_MAX_LINCOMB) return DGPU_E_BADARG;                    // (more public inputs: calculate_d through dgpu_msm_g1, then dgpu_multi_miller_loop_mixed)
+    if (!cur().ready) return DGPU_E_NODEVICE;
+    auto all_zero = [](const uint64_t *w, int k) { uint64_t o = 0; for (int i = 0; i < k; i++) o |= w[i]; return o == 0; };
+    const bool inf_a = (proof_inf && proof_inf[0]) || all_zero(proof_a, 12), inf_b = (proof_inf && proof_inf[1]) || all_zero(proof_b, 24);
+    const bool inf_c = (proof_inf && proof_inf[2]) || all_zero(proof_c, 12), inf_d = (proof_inf && proof_inf[3]) || all_zero(proof_d, 12);
+    // d = gamma_abc[0] + sum x_j gamma_abc[1 + j] + proof.d on a host core
+    uint64_t dxy[12]; bool d_inf = true;
+    auto compute_d = [&]() -> int32_t {
+        uint64_t pts[DGPU_MAX_LINCOMB * 12], sc[DGPU_MAX_LINCOMB * 4], jac[18]; uint8_t inf[DGPU_MAX_LINCOMB] = {0};
+        const size_t k = n_pub + 2;
+        memcpy(pts, gamma_abc_g1, (n_pub + 1) * 96); memcpy(pts + (n_pub + 1) * 12, proof_d, 96); inf[n_pub + 1] = inf_d;
+        memset(sc, 0, sizeof sc); sc[0] = 1; sc[4 * (n_pub + 1)] = 1;
+        for (size_t j = 0; j < n_pub; j++) { if (montgomery) hostf::fr_from_mont(&sc[4 * (1 + j)], public_inputs + 4 * j); else memcpy(&sc[4 * (1 + j)], public_inputs + 4 * j, 32); }
+        const int32_t e = dgpu_lincomb_g1(pts, inf, sc, k, jac);
+        if (e) return e;
+        d_inf = all_zero(jac + 12, 6);
+        memcpy(dxy, jac, 96);                                                   // normalised: (x, y, 1)
+        return DGPU_OK;
+    };
+    SLOT_ACQUIRE(slot_lock, sl);
+    HIPCHK(hipSetDevice(cur().device));
+    int32_t rc;
+    const size_t n = 3, cbytes = 2 * (size_t)DGPU_G2_PREPARED_WORDS * 8;
+    if ((rc = sl.in_bases.ensure(n * 96))) return rc;
+    if ((rc = sl.in_scalars.ensure(192 + 16))) return rc;
+    if ((rc = sl.in_inf.ensure(16))) return rc;
+    if ((rc = sl.ml_coeffs.ensure(cbytes + 16))) return rc;
+    if ((rc = sl.ml_lines.ensure((size_t)N_LINES * LW * n * 4))) return rc;
+    hipStream_t s = sl.stream;
+    uint32_t *dp = sl.in_bases.as<uint32_t>();
+    uint8_t *dsk = sl.in_inf.as<uint8_t>();
+    uint8_t *hsk = (uint8_t *)sl.hpin + Slot::HPIN_BYTES - 256;                 // pinned: the flags of the three pairs, and d's coordinates behind them
+    hsk[0] = (inf_a || inf_b) ? 1 : 0; hsk[1] = inf_c ? 1 : 0; hsk[2] = 0;
+    HIPCHK(hipMemcpyAsync(dp, proof_a, 96, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(dp + 24, proof_c, 96, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(sl.in_scalars.p, proof_b, 192, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(sl.ml_coeffs.p, delta_neg_pc, cbytes / 2, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync((char *)sl.ml_coeffs.p + cbytes / 2, gamma_neg_pc, cbytes / 2, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(dsk, hsk, 1, hipMemcpyHostToDevice, s));
+    hostf::Fq12 f;
+    uint32_t *lines = sl.ml_lines.as<uint32_t>();
+    auto prepared_lines = [&](hipStream_t st, uint32_t *pxy) {
+        hipLaunchKernelGGL(k_lines_from_prepared, dim3((unsigned)((2 * N_LINES + 255) / 256)), dim3(256), 0, st, dp + 24, sl.ml_coeffs.as<uint32_t>(), (const uint8_t *)(dsk + 1), (size_t)2, lines + 1, n, pxy ? pxy + 1 : nullptr);
+    };
+    MlActive act(cur().ml_active);
+    if (!gs.prof && (gs.ml_mode.load() & 1) && act.v <= 2) {
+        hipEvent_t in_ev = sl.copy_ev[sl.ev_next++ % (Slot::N_COPY_EV + 1)];
+        HIPCHK(hipEventRecord(in_ev, s));
+        rc = ml_pipelined(sl, n, 1, dsk, (uint64_t *)&f, [](uint32_t *) {}, [&](hipStream_t side, uint32_t *pxy) -> int32_t {
+            const int32_t e = compute_d(); if (e) return e;                     // (the chain of (A, B) is running)
+            memcpy(hsk + 16, dxy, 96); hsk[2] = d_inf ? 1 : 0;
+            if (hipStreamWaitEvent(side, in_ev, 0) != hipSuccess) return DGPU_E_HIP;       // C, the coefficients and the first flag are on their way on `s`
+            if (hipMemcpyAsync(dp + 48, hsk + 16, 96, hipMemcpyHostToDevice, side) != hipSuccess) return DGPU_E_HIP;
+            if (hipMemcpyAsync(dsk + 1, hsk + 1, 2, hipMemcpyHostToDevice, side) != hipSuccess) return DGPU_E_HIP;
+            prepared_lines(side, pxy);
+            return DGPU_OK;
+        });
+        if (rc) return rc;
+    } else {
+        if ((rc = compute_d())) return rc;
+        memcpy(hsk + 16, dxy, 96); hsk[2] = d_inf ? 1 : 0;
+        HIPCHK(hipMemcpyAsync(dp + 48, hsk + 16, 96, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(dsk + 1, hsk + 1, 2, hipMemcpyHostToDevice, s));
+        if ((rc = sl.ml_state.ensure((size_t)2 * NL * n * 4))) return rc;
+        uint32_t *pxy = sl.ml_state.as<uint32_t>();
+        launch_lines_uneval(s, dp, sl.in_scalars.as<uint32_t>(), dsk, 1, lines, n, 62, 0, 0, (uint32_t *)nullptr, pxy);
+        prepared_lines(s, pxy);
+        if ((rc = ml_finish(sl, n, (uint64_t *)&f, pxy))) return rc;
+    }
+    hostf::Fq12 gt, want; memcpy(&want, alpha_beta_gt, sizeof want);
+    if (!hostf::final_exponentiation(gt, f)) return DGPU_E_ZERO;               // (verifier.rs:78 `.ok_or(UnexpectedIdentity)`)
+    *ok_out = memcmp(&gt, &want, sizeof gt) == 0 ? 1 : 0;
+    return DGPU_OK;
 }
 
 int32_t dgpu_g1_scale_batch(const uint64_t *p, const uint8_t *is_inf, const uint64_t *scalars, size_t scalar_stride, const uint8_t *negate, size_t n, uint64_t *out, uint8_t *out_inf) {

@@ -594,6 +594,30 @@ def verify_proofs_batch_merged(pvk, proofs, public_inputs, random):
     return bool((gt == fp12_pow(pvk["alpha_g1_beta_g2"], sum(ms))).all())
 
 
+def verify_proof_abi(pvk, proof, public_inputs, montgomery=False):
+    """verifier.rs:62-99 as ONE call of the C ABI (dgpu_legogroth16_verify): calculate_d on a host core inside the library while the device
+    runs the chain of (A, B); same answer as verify_proof below"""
+    import ctypes as C
+    from ._native import lib, DockGpuError
+    vk = pvk["vk"]
+    pub = np.ascontiguousarray(public_inputs, dtype=np.uint64).reshape(-1, 4)
+    gabc = np.ascontiguousarray(vk.gamma_abc_g1, dtype=np.uint64).reshape(-1, 12)
+    p_ = lambda a: np.ascontiguousarray(a, dtype=np.uint64).ctypes.data_as(C.c_void_p)
+    keep = [np.ascontiguousarray(proof[k], dtype=np.uint64) for k in "abcd"]
+    dn, gn = np.ascontiguousarray(pvk["delta_g2_neg_pc"].coeffs.reshape(-1)), np.ascontiguousarray(pvk["gamma_g2_neg_pc"].coeffs.reshape(-1))
+    ab = np.ascontiguousarray(pvk["alpha_g1_beta_g2"], dtype=np.uint64)
+    ok = C.c_int32(-1)
+    rc = lib().dgpu_legogroth16_verify(p_(ab), p_(dn), p_(gn), p_(gabc), len(gabc), p_(keep[0]), p_(keep[1]), p_(keep[2]), p_(keep[3]), None,
+                                       pub.ctypes.data_as(C.c_void_p), len(pub), int(montgomery), C.byref(ok))
+    if rc == -3 and len(pub) + 1 > len(gabc):
+        raise ValueError("MalformedVerifyingKey")
+    if rc == -5:
+        raise ValueError("UnexpectedIdentity")
+    if rc:
+        raise DockGpuError(rc, "dgpu_legogroth16_verify")
+    return ok.value == 1
+
+
 def verify_proof(pvk, proof, public_inputs):
     """verifier.rs:62-99: e(A, B) e(C, -delta) e(d, -gamma) == e(alpha, beta)"""
     d = calculate_d(pvk, proof, public_inputs)

@@ -348,6 +348,19 @@ int32_t dgpu_legogroth16_prove(const dgpu_lego_pk *pk, uint64_t r1cs, uint64_t h
  * dgpu_bases_precompute_*d; the five queries over the same contexts): context g multiplies its rows by the matching slices of z and h from a host
  * thread of its own inside the call, the witness map runs once on the circuit's context (r1cs must be given), the partial points are folded on
  * the host.  Same proof as the single-device call (tests/test_gpu_prove_abi.py, two contexts on one GPU). */
+/* ---- the LegoGroth16 verifier as one call (SURVEY.md 8a rows a4 - a7 as the reference uses them together) ----
+ * replaces verify_proof (legogroth16/src/verifier.rs:62-99): d = gamma_abc[0] + sum x_j gamma_abc[1 + j] + proof.d (calculate_d, :29-50,:101-109),
+ * then e(A, B) e(C, -delta) e(d, -gamma) == e(alpha, beta) (verify_qap_proof, :62-84) with the PreparedVerifyingKey's members (:17-25):
+ *   alpha_beta_gt  pvk.alpha_g1_beta_g2 (72 words); delta_neg_pc / gamma_neg_pc: the two G2Prepared values (DGPU_G2_PREPARED_WORDS each,
+ *   dgpu_g2_prepare's / arkworks' layout); gamma_abc_g1: vk.gamma_abc_g1, gamma_abc_len x 12 words
+ *   proof (a, b, c, d) affine, proof_inf[k] != 0 (or all-zero words) marks an identity; public_inputs: n_pub scalars (montgomery != 0: &[Fr])
+ * The host's share (the scalar multiplications of calculate_d) runs while the device computes the chain of the pair (A, B).
+ * *ok = 1: the proof verifies, 0: it does not.  DGPU_E_BADARG: n_pub + 1 > gamma_abc_len (MalformedVerifyingKey) or n_pub + 2 >
+ * DGPU_MAX_LINCOMB (then: dgpu_msm_g1 + dgpu_multi_miller_loop_mixed + dgpu_final_exponentiation); DGPU_E_ZERO where the reference answers
+ * UnexpectedIdentity. */
+int32_t dgpu_legogroth16_verify(const uint64_t alpha_beta_gt[72], const uint64_t *delta_neg_pc, const uint64_t *gamma_neg_pc, const uint64_t *gamma_abc_g1, size_t gamma_abc_len,
+                                const uint64_t proof_a[12], const uint64_t proof_b[24], const uint64_t proof_c[12], const uint64_t proof_d[12], const uint8_t *proof_inf,
+                                const uint64_t *public_inputs, size_t n_pub, int32_t montgomery, int32_t *ok);
 /* elements behind a bases / scalars / sorted handle; constraints of a resident circuit */
 int32_t dgpu_handle_len(uint64_t handle, size_t *n);
 int32_t dgpu_handle_context(uint64_t handle, int32_t *context);

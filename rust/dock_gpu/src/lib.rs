@@ -84,6 +84,9 @@ extern "C" {
                             c_rowptr: *const u64, c_cols: *const u32, c_vals: *const u64, c_nnz: usize,
                             num_vars: usize, num_inputs: usize, num_constraints: usize, montgomery: i32, handle: *mut u64) -> i32;
     pub fn dgpu_r1cs_free(handle: u64) -> i32;
+    pub fn dgpu_legogroth16_verify(alpha_beta_gt: *const u64, delta_neg_pc: *const u64, gamma_neg_pc: *const u64, gamma_abc_g1: *const u64, gamma_abc_len: usize,
+                                   proof_a: *const u64, proof_b: *const u64, proof_c: *const u64, proof_d: *const u64, proof_inf: *const u8,
+                                   public_inputs: *const u64, n_pub: usize, montgomery: i32, ok: *mut i32) -> i32;
     pub fn dgpu_legogroth16_prove(pk: *const DgpuLegoPk, r1cs: u64, h_scalars: u64, z: *const u64, num_vars: usize, n_inst: usize, montgomery: i32,
                                   r: *const u64, s: *const u64, v: *const u64,
                                   out_a: *mut u64, out_b: *mut u64, out_c: *mut u64, out_d: *mut u64, out_inf: *mut u8) -> i32;
@@ -314,4 +317,27 @@ pub fn create_proof_gpu(pk: &GpuProvingKey, circuit: u64, z: &[Fr], n_inst: usiz
                                              a.as_mut_ptr(), b.as_mut_ptr(), c.as_mut_ptr(), d.as_mut_ptr(), inf.as_mut_ptr()) };
     if rc != DGPU_OK { return None; }
     Some((g1_affine(&a, inf[0]), g2_affine(&b, inf[1]), g1_affine(&c, inf[2]), g1_affine(&d, inf[3])))
+}
+
+// ---- the LegoGroth16 verifier as one call (legogroth16/src/verifier.rs:62-99) ----------------------------------------------------------------
+/// the PreparedVerifyingKey's members in the ABI's form (made once per key): e(alpha, beta), -delta and -gamma prepared, gamma_abc_g1
+pub struct GpuPreparedVerifyingKey { alpha_beta: [u64; 72], delta_neg: Vec<u64>, gamma_neg: Vec<u64>, gamma_abc: Vec<u64>, gamma_abc_len: usize }
+impl GpuPreparedVerifyingKey {
+    pub fn new(alpha_g1_beta_g2: &Fq12, delta_g2_neg_pc: &G2Prepared, gamma_g2_neg_pc: &G2Prepared, gamma_abc_g1: &[G1Affine]) -> Self {
+        let (mut d, mut g) = (Vec::new(), Vec::new());
+        prepared_words(delta_g2_neg_pc, &mut d); prepared_words(gamma_g2_neg_pc, &mut g);
+        GpuPreparedVerifyingKey { alpha_beta: fq12_to_words(alpha_g1_beta_g2), delta_neg: d, gamma_neg: g, gamma_abc: pack_g1(gamma_abc_g1).0, gamma_abc_len: gamma_abc_g1.len() }
+    }
+}
+/// `verify_proof(pvk, proof, public_inputs)`: Some(true / false), or None when the library declined (then: the reference's CPU verifier)
+pub fn verify_proof_gpu(pvk: &GpuPreparedVerifyingKey, a: &G1Affine, b: &G2Affine, c: &G1Affine, d: &G1Affine, public_inputs: &[Fr]) -> Option<bool> {
+    let (pa, ia) = pack_g1(&[*a, *c, *d]);
+    let (pb, ib) = pack_g2(&[*b]);
+    let inf = [ia[0], ib[0], ia[1], ia[2]];
+    let mut ok = -1i32;
+    let rc = unsafe { dgpu_legogroth16_verify(pvk.alpha_beta.as_ptr(), pvk.delta_neg.as_ptr(), pvk.gamma_neg.as_ptr(), pvk.gamma_abc.as_ptr(), pvk.gamma_abc_len,
+                                              pa.as_ptr(), pb.as_ptr(), pa[12..].as_ptr(), pa[24..].as_ptr(), inf.as_ptr(),
+                                              public_inputs.as_ptr() as *const u64, public_inputs.len(), 1, &mut ok) };
+    if rc != DGPU_OK { return None; }
+    Some(ok == 1)
 }

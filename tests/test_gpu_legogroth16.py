@@ -68,6 +68,25 @@ def test_prove_verify_roundtrip(m, cw):
     # r == 0 skips the G1 copy of B (prover.rs:330)
     proof0 = LG.create_proof(pk, 0, s, v, LS.scalars(h), inp, wit)
     assert LG.verify_proof(pvk, proof0, inp[1:])
+    # the verifier as ONE call of the C ABI (dgpu_legogroth16_verify: calculate_d on a host core under the device's chain): the same answers,
+    # in every form of the Miller kernels, for &[Fr] inputs too, from six threads at once; the reference's error cases
+    from crypto_amd._native import lib
+    try:
+        for mode in (7, 3, 6, 0):
+            assert lib().dgpu_set_miller_pipeline(mode) == 0
+            assert LG.verify_proof_abi(pvk, proof, inp[1:]) and LG.verify_proof_abi(pvk, proof0, inp[1:])
+            assert LG.verify_proof_abi(pvk, proof, O.fr_to_mont(inp[1:]), montgomery=True)
+            assert not LG.verify_proof_abi(pvk, proof, bad_inp) and not LG.verify_proof_abi(pvk, bad, inp[1:])
+    finally:
+        lib().dgpu_set_miller_pipeline(7)
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(6) as ex:
+        res = list(ex.map(lambda k: LG.verify_proof_abi(pvk, proof if k % 3 else bad, inp[1:]), range(24)))
+    assert res == [bool(k % 3) for k in range(24)]
+    with pytest.raises(ValueError):                                   # more inputs than the key has room for: MalformedVerifyingKey
+        LG.verify_proof_abi(pvk, proof, np.concatenate([inp[1:]] * 8 + [inp[1:]]))
+    ident = dict(proof); ident["a"] = np.zeros(12, np.uint64)        # A = identity: the pair is skipped like arkworks does; the equation no longer holds
+    assert LG.verify_proof_abi(pvk, ident, inp[1:]) == LG.verify_proof(pvk, ident, inp[1:])
 
 
 @pytest.mark.parametrize("m,cw", [(20, 2), (200, 3)])

@@ -36,6 +36,30 @@ class LegoPk(C.Structure):
                [("gamma_abc_len", C.c_size_t), ("commit_witness_count", C.c_size_t)]
 
 
+APPEND_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t, C.POINTER(C.c_uint8), C.c_size_t)
+CHALLENGE_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t, C.POINTER(C.c_uint64))
+
+
+class Transcript(C.Structure):
+    """include/dock_gpu.h `dgpu_transcript`"""
+    _fields_ = [("ctx", C.c_void_p), ("append_message", APPEND_FN), ("challenge_scalar", CHALLENGE_FN)]
+
+
+class SnarkpackProverSrs(C.Structure):
+    """include/dock_gpu.h `dgpu_snarkpack_prover_srs`"""
+    _fields_ = [("n", C.c_size_t)] + [(k, C.c_void_p) for k in ("g_alpha_powers_table", "g_beta_powers_table", "h_alpha_powers_table", "h_beta_powers_table", "vkey_a", "vkey_b", "wkey_a", "wkey_b")]
+
+
+class SnarkpackVerifierSrs(C.Structure):
+    """include/dock_gpu.h `dgpu_snarkpack_verifier_srs`"""
+    _fields_ = [("n", C.c_size_t)] + [(k, C.c_void_p) for k in ("g", "h", "g_alpha", "g_beta", "h_alpha", "h_beta")]
+
+
+class Groth16Vk(C.Structure):
+    """include/dock_gpu.h `dgpu_groth16_vk`"""
+    _fields_ = [(k, C.c_void_p) for k in ("alpha_g1", "beta_g2", "gamma_g2", "delta_g2", "gamma_abc_g1")] + [("gamma_abc_len", C.c_size_t)]
+
+
 _lib = None
 
 # every symbol include/dock_gpu.h declares
@@ -50,6 +74,7 @@ SYMBOLS = [
     "dgpu_window_table_g1", "dgpu_window_table_g2", "dgpu_window_table_free", "dgpu_window_table_mul_g1", "dgpu_window_table_mul_g2", "dgpu_window_table_mul_to_bases_g1", "dgpu_window_table_mul_to_bases_g2", "dgpu_fixed_base_g1", "dgpu_fixed_base_g2", "dgpu_g1_mul_add_batch", "dgpu_g2_mul_add_batch",
     "dgpu_prof_enable", "dgpu_prof_reset", "dgpu_prof_read", "dgpu_legogroth16_prove", "dgpu_legogroth16_verify", "dgpu_handle_len", "dgpu_handle_context", "dgpu_shard_count", "dgpu_shard_part",
     "dgpu_selftest_fp_mul", "dgpu_selftest_g1_sum", "dgpu_selftest_glv_decompose",
+    "dgpu_snarkpack_proof_words", "dgpu_snarkpack_aggregate", "dgpu_snarkpack_verify",
 ]
 
 
@@ -152,6 +177,10 @@ def lib():
         for name in ("dgpu_g1_mul_add_batch", "dgpu_g2_mul_add_batch"):
             getattr(L, name).argtypes = [vp, vp, vp, sz, vp, vp, sz, vp, vp]
         L.dgpu_legogroth16_prove.argtypes = [vp, u64, u64, vp, sz, sz, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp]
+        L.dgpu_snarkpack_proof_words.restype = C.c_size_t
+        L.dgpu_snarkpack_proof_words.argtypes = [sz, C.c_int32]
+        L.dgpu_snarkpack_aggregate.argtypes = [vp, vp, vp, vp, vp, sz, vp, vp, sz, C.POINTER(sz)]
+        L.dgpu_snarkpack_verify.argtypes = [vp, vp, vp, sz, sz, vp, sz, C.c_int32, vp, vp, vp, C.c_int32, C.POINTER(C.c_int32)]
         L.dgpu_legogroth16_verify.argtypes = [vp, vp, vp, vp, sz, vp, vp, vp, vp, vp, vp, sz, C.c_int32, C.POINTER(C.c_int32)]
         L.dgpu_handle_len.argtypes = [u64, C.POINTER(sz)]
         L.dgpu_handle_context.argtypes = [u64, C.POINTER(C.c_int32)]

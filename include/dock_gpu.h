@@ -361,6 +361,47 @@ int32_t dgpu_legogroth16_prove(const dgpu_lego_pk *pk, uint64_t r1cs, uint64_t h
 int32_t dgpu_legogroth16_verify(const uint64_t alpha_beta_gt[72], const uint64_t *delta_neg_pc, const uint64_t *gamma_neg_pc, const uint64_t *gamma_abc_g1, size_t gamma_abc_len,
                                 const uint64_t proof_a[12], const uint64_t proof_b[24], const uint64_t proof_c[12], const uint64_t proof_d[12], const uint8_t *proof_inf,
                                 const uint64_t *public_inputs, size_t n_pub, int32_t montgomery, int32_t *ok);
+/* ---- SnarkPack aggregation of Groth16 / LegoGroth16 proofs (crypto_amd/csrc/dock_aggregation.cpp) ----
+ * replaces aggregate_proofs (legogroth16/src/aggregation/groth16/prover.rs:47-147; legogroth16/prover.rs:38-127 when `d` is given) and
+ * verify_aggregate_proof (groth16/verifier.rs:36-100, legogroth16/verifier.rs:34-96, legogroth16/using_groth16.rs:45-128) as the reference
+ * calls them; the group, pairing and GT work goes through the entry points above from host threads inside the call.
+ * The Fiat-Shamir transcript is the caller's (`&mut impl Transcript`, utils/src/transcript.rs:45-63): append_message receives the label and the
+ * bytes `Transcript::append` would serialize (`serialize_compressed`: 48 / 96-byte Zcash points, 32 / 48-byte little-endian canonical field
+ * elements, a PairCommitment as t then u), challenge_scalar returns the transcript's `challenge_scalar::<Fr>(label)` as 4 canonical words.
+ * Points are affine ABI words (identity: all-zero words).  The aggregate proof is a flat array of 64-bit words,
+ *   nproofs, n_mipp | com_ab(t, u) com_c [com_d] | z_ab z_c [z_d] | comms_ab[L](l.t l.u r.t r.u) comms_c[L] [comms_d[L]] | z_ab[L](l r) z_c[L] [z_d[L]]
+ *   | final_a final_b final_c [final_d] final_vkey(2) final_wkey(2) | vkey_opening(2) wkey_opening(2)          (L = log2 nproofs; GT 72, G1 12, G2 24 words)
+ * i.e. the fields of AggregateProof / GipaProof / TippMippProof in their declaration order (groth16/proof.rs:12-24,76-84,117-121). */
+#define DGPU_SNARKPACK_MAX_SRS_SIZE (((size_t)2 << 19) + 1)          /* srs.rs MAX_SRS_SIZE */
+#define DGPU_SNARKPACK_VALIDATE_GT 1                                 /* verify flag: every GT element of the proof must have order r (Validate::Yes on a deserialised proof) */
+typedef struct dgpu_transcript {
+    void *ctx;
+    void (*append_message)(void *ctx, const uint8_t *label, size_t label_len, const uint8_t *bytes, size_t len);
+    void (*challenge_scalar)(void *ctx, const uint8_t *label, size_t label_len, uint64_t out[4]);
+} dgpu_transcript;
+typedef struct dgpu_snarkpack_prover_srs {                           /* ProverSRS specialised to n proofs (srs.rs:60-93,180-237) */
+    size_t n;
+    const uint64_t *g_alpha_powers_table, *g_beta_powers_table;      /* 2n x 12 */
+    const uint64_t *h_alpha_powers_table, *h_beta_powers_table;      /* n x 24 */
+    const uint64_t *vkey_a, *vkey_b;                                 /* n x 24 (h^{alpha^i}, h^{beta^i}) */
+    const uint64_t *wkey_a, *wkey_b;                                 /* n x 12 (g^{alpha^{n+i}}, g^{beta^{n+i}}) */
+} dgpu_snarkpack_prover_srs;
+typedef struct dgpu_snarkpack_verifier_srs { size_t n; const uint64_t *g, *h, *g_alpha, *g_beta, *h_alpha, *h_beta; } dgpu_snarkpack_verifier_srs;   /* srs.rs:95-110 */
+typedef struct dgpu_groth16_vk { const uint64_t *alpha_g1, *beta_g2, *gamma_g2, *delta_g2, *gamma_abc_g1; size_t gamma_abc_len; } dgpu_groth16_vk;
+/* words of an aggregate proof of n proofs (0: n is not a power of two in [2, MAX_SRS_SIZE]) */
+size_t dgpu_snarkpack_proof_words(size_t n, int32_t with_d);
+/* a, c (, d): n x 12; b: n x 24; d = NULL: Groth16 proofs.  *len_words is set to the proof's length even when cap_words is too small
+ * (DGPU_E_LENGTH).  DGPU_E_BADARG: n < 2, not a power of two, or srs->n != n. */
+int32_t dgpu_snarkpack_aggregate(const dgpu_snarkpack_prover_srs *srs, const uint64_t *a, const uint64_t *b, const uint64_t *c, const uint64_t *d,
+                                 size_t n, const dgpu_transcript *transcript, uint64_t *proof, size_t cap_words, size_t *len_words);
+/* variant 0: Groth16 proofs; 1: LegoGroth16 (the proof carries the MIPP for d); 2: LegoGroth16 proofs under the Groth16 aggregator, d_list = the
+ * n commitments d (using_groth16.rs).  public_inputs: n_rows x inputs_per_proof canonical scalars (n_rows must equal nproofs); random: the
+ * pairing checker's batching scalar (RandomizedPairingChecker::new_using_rng draws it).  *ok = 1: the aggregate verifies, 0: it does not (a failed
+ * pairing / final_z check, a GT element outside the subgroup).  DGPU_E_BADARG: a malformed proof (parsing_check), a key that does not match
+ * the public inputs (MalformedVerifyingKey), a row count that is not nproofs. */
+int32_t dgpu_snarkpack_verify(const dgpu_snarkpack_verifier_srs *srs, const dgpu_groth16_vk *vk, const uint64_t *public_inputs, size_t n_rows, size_t inputs_per_proof,
+                              const uint64_t *proof, size_t len_words, int32_t variant, const uint64_t *d_list, const uint64_t random[4],
+                              const dgpu_transcript *transcript, int32_t flags, int32_t *ok);
 /* elements behind a bases / scalars / sorted handle; constraints of a resident circuit */
 int32_t dgpu_handle_len(uint64_t handle, size_t *n);
 int32_t dgpu_handle_context(uint64_t handle, int32_t *context);

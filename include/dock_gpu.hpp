@@ -322,4 +322,80 @@ inline Proof create_proof_with_reduction(const ProvingKey &pk, uint64_t r1cs, co
 }
 }  // namespace legogroth16
 
+// ---- SnarkPack aggregation (legogroth16/src/aggregation/) over dgpu_snarkpack_aggregate / dgpu_snarkpack_verify ---------------------------------
+// aggregate_proofs (groth16/prover.rs:47-147; legogroth16/prover.rs:38-127 when the commitments d are given) and verify_aggregate_proof
+// (groth16/verifier.rs:36-100, legogroth16/verifier.rs:34-96, legogroth16/using_groth16.rs:45-128).  The transcript is the caller's, as in the
+// reference (`&mut impl Transcript`, utils/src/transcript.rs:45-63): any type with
+//     void append_message(const uint8_t *label, size_t label_len, const uint8_t *bytes, size_t len);
+//     BigInt256 challenge_scalar(const uint8_t *label, size_t label_len);
+// Points travel as affine ABI words (12 per G1 point, 24 per G2 point, identity all zero), the aggregate proof as the flat words of
+// include/dock_gpu.h; the protocol itself runs inside the library (crypto_amd/csrc/dock_aggregation.cpp).
+namespace aggregation {
+using Words = std::vector<uint64_t>;
+template <class T> dgpu_transcript bind(T &t) {
+    dgpu_transcript d;
+    d.ctx = &t;
+    d.append_message = [](void *c, const uint8_t *l, size_t ll, const uint8_t *b, size_t n) { static_cast<T *>(c)->append_message(l, ll, b, n); };
+    d.challenge_scalar = [](void *c, const uint8_t *l, size_t ll, uint64_t out[4]) { const BigInt256 v = static_cast<T *>(c)->challenge_scalar(l, ll); std::memcpy(out, v.data(), 32); };
+    return d;
+}
+struct ProverSRS {                          // srs.rs:60-93; specialize (:180-237) gives vkey = (h^{alpha^i}, h^{beta^i}), wkey = (g^{alpha^{n+i}}, g^{beta^{n+i}}), i < n
+    size_t n = 0;
+    Words g_alpha_powers_table, g_beta_powers_table, h_alpha_powers_table, h_beta_powers_table, vkey_a, vkey_b, wkey_a, wkey_b;
+    // from the four power vectors of a GenericSRS (2n entries each at least)
+    static ProverSRS specialize(size_t n, const Words &g_alpha, const Words &h_alpha, const Words &g_beta, const Words &h_beta) {
+        if (g_alpha.size() < 24 * n || g_beta.size() < 24 * n || h_alpha.size() < 48 * n || h_beta.size() < 48 * n) throw Error(DGPU_E_LENGTH, "specialize");
+        ProverSRS s; s.n = n;
+        s.g_alpha_powers_table.assign(g_alpha.begin(), g_alpha.begin() + 24 * n); s.g_beta_powers_table.assign(g_beta.begin(), g_beta.begin() + 24 * n);
+        s.h_alpha_powers_table.assign(h_alpha.begin(), h_alpha.begin() + 24 * n); s.h_beta_powers_table.assign(h_beta.begin(), h_beta.begin() + 24 * n);
+        s.vkey_a = s.h_alpha_powers_table; s.vkey_b = s.h_beta_powers_table;
+        s.wkey_a.assign(g_alpha.begin() + 12 * n, g_alpha.begin() + 24 * n); s.wkey_b.assign(g_beta.begin() + 12 * n, g_beta.begin() + 24 * n);
+        return s;
+    }
+    dgpu_snarkpack_prover_srs view() const {
+        return {n, g_alpha_powers_table.data(), g_beta_powers_table.data(), h_alpha_powers_table.data(), h_beta_powers_table.data(), vkey_a.data(), vkey_b.data(), wkey_a.data(), wkey_b.data()};
+    }
+};
+struct VerifierSRS {                        // srs.rs:95-110
+    size_t n = 0; std::array<uint64_t, 12> g{}, g_alpha{}, g_beta{}; std::array<uint64_t, 24> h{}, h_alpha{}, h_beta{};
+    static VerifierSRS specialize(size_t n, const Words &g_alpha, const Words &h_alpha, const Words &g_beta, const Words &h_beta) {
+        VerifierSRS v; v.n = n;
+        std::memcpy(v.g.data(), &g_alpha[0], 96); std::memcpy(v.g_alpha.data(), &g_alpha[12], 96); std::memcpy(v.g_beta.data(), &g_beta[12], 96);
+        std::memcpy(v.h.data(), &h_alpha[0], 192); std::memcpy(v.h_alpha.data(), &h_alpha[24], 192); std::memcpy(v.h_beta.data(), &h_beta[24], 192);
+        return v;
+    }
+};
+struct VerifyingKey { std::array<uint64_t, 12> alpha_g1{}; std::array<uint64_t, 24> beta_g2{}, gamma_g2{}, delta_g2{}; Words gamma_abc_g1; };
+enum class Variant : int32_t { Groth16 = 0, LegoGroth16 = 1, LegoGroth16UsingGroth16 = 2 };
+
+// a, c (, d): n x 12 words, b: n x 24; d == nullptr: Groth16 proofs
+template <class T> Words aggregate_proofs(const ProverSRS &srs, T &transcript, const Words &a, const Words &b, const Words &c, const Words *d = nullptr) {
+    const size_t n = a.size() / 12;
+    if (b.size() != 24 * n || c.size() != 12 * n || (d && d->size() != 12 * n)) throw Error(DGPU_E_LENGTH, "aggregate_proofs");
+    const size_t cap = dgpu_snarkpack_proof_words(n, d ? 1 : 0);
+    if (!cap) throw Error(DGPU_E_BADARG, "aggregate_proofs: the number of proofs is not a power of two >= 2");
+    Words out(cap); size_t len = 0;
+    const dgpu_snarkpack_prover_srs v = srs.view();
+    const dgpu_transcript t = bind(transcript);
+    check(dgpu_snarkpack_aggregate(&v, a.data(), b.data(), c.data(), d ? d->data() : nullptr, n, &t, out.data(), cap, &len), "snarkpack_aggregate");
+    out.resize(len);
+    return out;
+}
+// public_inputs: one row of `inputs_per_proof` scalars per proof.  true: the aggregate verifies; throws Error(DGPU_E_BADARG) for a malformed
+// proof / key (AggregationError::InvalidProof / MalformedVerifyingKey before any group operation)
+template <class T> bool verify_aggregate_proof(const VerifierSRS &srs, const VerifyingKey &vk, const std::vector<BigInt256> &public_inputs, size_t inputs_per_proof,
+                                               const Words &proof, const BigInt256 &random, T &transcript, Variant variant = Variant::Groth16,
+                                               const Words *d_list = nullptr, bool validate_gt = false) {
+    if (inputs_per_proof && public_inputs.size() % inputs_per_proof) throw Error(DGPU_E_LENGTH, "verify_aggregate_proof");
+    const size_t rows = inputs_per_proof ? public_inputs.size() / inputs_per_proof : (proof.empty() ? 0 : (size_t)proof[0]);
+    const dgpu_snarkpack_verifier_srs s{srs.n, srs.g.data(), srs.h.data(), srs.g_alpha.data(), srs.g_beta.data(), srs.h_alpha.data(), srs.h_beta.data()};
+    const dgpu_groth16_vk k{vk.alpha_g1.data(), vk.beta_g2.data(), vk.gamma_g2.data(), vk.delta_g2.data(), vk.gamma_abc_g1.data(), vk.gamma_abc_g1.size() / 12};
+    const dgpu_transcript t = bind(transcript);
+    int32_t ok = 0;
+    check(dgpu_snarkpack_verify(&s, &k, public_inputs.empty() ? nullptr : public_inputs[0].data(), rows, inputs_per_proof, proof.data(), proof.size(), (int32_t)variant,
+                                d_list ? d_list->data() : nullptr, random.data(), &t, validate_gt ? DGPU_SNARKPACK_VALIDATE_GT : 0, &ok), "snarkpack_verify");
+    return ok != 0;
+}
+}  // namespace aggregation
+
 }  // namespace dock_gpu

@@ -55,6 +55,24 @@ pub struct DgpuLegoPk {
     pub commit_witness_count: usize,
 }
 
+/// `dgpu_transcript`, `dgpu_snarkpack_prover_srs`, `dgpu_snarkpack_verifier_srs`, `dgpu_groth16_vk` of include/dock_gpu.h
+#[repr(C)]
+pub struct DgpuTranscript {
+    pub ctx: *mut core::ffi::c_void,
+    pub append_message: unsafe extern "C" fn(ctx: *mut core::ffi::c_void, label: *const u8, label_len: usize, bytes: *const u8, len: usize),
+    pub challenge_scalar: unsafe extern "C" fn(ctx: *mut core::ffi::c_void, label: *const u8, label_len: usize, out: *mut u64),
+}
+#[repr(C)]
+pub struct DgpuSnarkpackProverSrs {
+    pub n: usize,
+    pub g_alpha_powers_table: *const u64, pub g_beta_powers_table: *const u64, pub h_alpha_powers_table: *const u64, pub h_beta_powers_table: *const u64,
+    pub vkey_a: *const u64, pub vkey_b: *const u64, pub wkey_a: *const u64, pub wkey_b: *const u64,
+}
+#[repr(C)]
+pub struct DgpuSnarkpackVerifierSrs { pub n: usize, pub g: *const u64, pub h: *const u64, pub g_alpha: *const u64, pub g_beta: *const u64, pub h_alpha: *const u64, pub h_beta: *const u64 }
+#[repr(C)]
+pub struct DgpuGroth16Vk { pub alpha_g1: *const u64, pub beta_g2: *const u64, pub gamma_g2: *const u64, pub delta_g2: *const u64, pub gamma_abc_g1: *const u64, pub gamma_abc_len: usize }
+
 #[link(name = "dock_gpu")]
 extern "C" {
     pub fn dgpu_init(device: i32) -> i32;
@@ -87,6 +105,12 @@ extern "C" {
     pub fn dgpu_legogroth16_verify(alpha_beta_gt: *const u64, delta_neg_pc: *const u64, gamma_neg_pc: *const u64, gamma_abc_g1: *const u64, gamma_abc_len: usize,
                                    proof_a: *const u64, proof_b: *const u64, proof_c: *const u64, proof_d: *const u64, proof_inf: *const u8,
                                    public_inputs: *const u64, n_pub: usize, montgomery: i32, ok: *mut i32) -> i32;
+    pub fn dgpu_snarkpack_proof_words(n: usize, with_d: i32) -> usize;
+    pub fn dgpu_snarkpack_aggregate(srs: *const DgpuSnarkpackProverSrs, a: *const u64, b: *const u64, c: *const u64, d: *const u64, n: usize,
+                                    transcript: *const DgpuTranscript, proof: *mut u64, cap_words: usize, len_words: *mut usize) -> i32;
+    pub fn dgpu_snarkpack_verify(srs: *const DgpuSnarkpackVerifierSrs, vk: *const DgpuGroth16Vk, public_inputs: *const u64, n_rows: usize, inputs_per_proof: usize,
+                                 proof: *const u64, len_words: usize, variant: i32, d_list: *const u64, random: *const u64,
+                                 transcript: *const DgpuTranscript, flags: i32, ok: *mut i32) -> i32;
     pub fn dgpu_legogroth16_prove(pk: *const DgpuLegoPk, r1cs: u64, h_scalars: u64, z: *const u64, num_vars: usize, n_inst: usize, montgomery: i32,
                                   r: *const u64, s: *const u64, v: *const u64,
                                   out_a: *mut u64, out_b: *mut u64, out_c: *mut u64, out_d: *mut u64, out_inf: *mut u8) -> i32;
@@ -338,6 +362,80 @@ pub fn verify_proof_gpu(pvk: &GpuPreparedVerifyingKey, a: &G1Affine, b: &G2Affin
     let rc = unsafe { dgpu_legogroth16_verify(pvk.alpha_beta.as_ptr(), pvk.delta_neg.as_ptr(), pvk.gamma_neg.as_ptr(), pvk.gamma_abc.as_ptr(), pvk.gamma_abc_len,
                                               pa.as_ptr(), pb.as_ptr(), pa[12..].as_ptr(), pa[24..].as_ptr(), inf.as_ptr(),
                                               public_inputs.as_ptr() as *const u64, public_inputs.len(), 1, &mut ok) };
+    if rc != DGPU_OK { return None; }
+    Some(ok == 1)
+}
+
+// ---- SnarkPack aggregation as one call each way (legogroth16/src/aggregation/groth16/prover.rs:47-147, verifier.rs:36-100) -----------------------
+/// What the library needs of the caller's `impl Transcript` (utils/src/transcript.rs:45-63): `append` hands over the `serialize_compressed` bytes
+/// the library produced itself (bit for bit what `Transcript::append(label, &element)` would write), `challenge_scalar` is the trait's.
+pub trait TranscriptBytes {
+    fn append_message_bytes(&mut self, label: &[u8], bytes: &[u8]);
+    fn challenge_fr(&mut self, label: &[u8]) -> Fr;
+}
+unsafe extern "C" fn tr_append<T: TranscriptBytes>(ctx: *mut core::ffi::c_void, label: *const u8, label_len: usize, bytes: *const u8, len: usize) {
+    let t = &mut *(ctx as *mut T);
+    t.append_message_bytes(core::slice::from_raw_parts(label, label_len), core::slice::from_raw_parts(bytes, len));
+}
+unsafe extern "C" fn tr_challenge<T: TranscriptBytes>(ctx: *mut core::ffi::c_void, label: *const u8, label_len: usize, out: *mut u64) {
+    let t = &mut *(ctx as *mut T);
+    let c = t.challenge_fr(core::slice::from_raw_parts(label, label_len)).into_bigint();
+    core::ptr::copy_nonoverlapping(c.0.as_ptr(), out, 4);
+}
+fn bind_transcript<T: TranscriptBytes>(t: &mut T) -> DgpuTranscript {
+    DgpuTranscript { ctx: t as *mut T as *mut core::ffi::c_void, append_message: tr_append::<T>, challenge_scalar: tr_challenge::<T> }
+}
+/// ProverSRS in the ABI's form (made once per specialised SRS): the four power tables and both commitment keys as packed words
+pub struct GpuProverSrs { n: usize, tabs: [Vec<u64>; 8] }
+impl GpuProverSrs {
+    #[allow(clippy::too_many_arguments)]
+    pub fn new(n: usize, g_alpha_powers_table: &[G1Affine], g_beta_powers_table: &[G1Affine], h_alpha_powers_table: &[G2Affine], h_beta_powers_table: &[G2Affine],
+               vkey_a: &[G2Affine], vkey_b: &[G2Affine], wkey_a: &[G1Affine], wkey_b: &[G1Affine]) -> Self {
+        GpuProverSrs { n, tabs: [pack_g1(g_alpha_powers_table).0, pack_g1(g_beta_powers_table).0, pack_g2(h_alpha_powers_table).0, pack_g2(h_beta_powers_table).0,
+                                 pack_g2(vkey_a).0, pack_g2(vkey_b).0, pack_g1(wkey_a).0, pack_g1(wkey_b).0] }
+    }
+}
+/// `aggregate_proofs(srs, transcript, proofs)`: the aggregate proof as the ABI's flat words (include/dock_gpu.h gives the layout: the fields of
+/// AggregateProof in declaration order, so `AggregateProof { com_ab: .., .. }` is rebuilt by walking it with fq12_from_words / the unpackers), or
+/// None when the library declined (then: the reference's CPU aggregator).  `d`: the commitments of LegoGroth16 proofs (legogroth16/prover.rs:38-127).
+pub fn aggregate_proofs_gpu<T: TranscriptBytes>(srs: &GpuProverSrs, transcript: &mut T, a: &[G1Affine], b: &[G2Affine], c: &[G1Affine], d: Option<&[G1Affine]>) -> Option<Vec<u64>> {
+    let n = a.len();
+    if b.len() != n || c.len() != n || d.map_or(false, |x| x.len() != n) { return None; }
+    let cap = unsafe { dgpu_snarkpack_proof_words(n, d.is_some() as i32) };
+    if cap == 0 { return None; }
+    let (pa, pb, pc) = (pack_g1(a).0, pack_g2(b).0, pack_g1(c).0);
+    let pd = d.map(|x| pack_g1(x).0);
+    let view = DgpuSnarkpackProverSrs { n: srs.n, g_alpha_powers_table: srs.tabs[0].as_ptr(), g_beta_powers_table: srs.tabs[1].as_ptr(), h_alpha_powers_table: srs.tabs[2].as_ptr(),
+                                        h_beta_powers_table: srs.tabs[3].as_ptr(), vkey_a: srs.tabs[4].as_ptr(), vkey_b: srs.tabs[5].as_ptr(), wkey_a: srs.tabs[6].as_ptr(), wkey_b: srs.tabs[7].as_ptr() };
+    let tr = bind_transcript(transcript);
+    let mut out = vec![0u64; cap];
+    let mut len = 0usize;
+    let rc = unsafe { dgpu_snarkpack_aggregate(&view, pa.as_ptr(), pb.as_ptr(), pc.as_ptr(), pd.as_ref().map_or(core::ptr::null(), |v| v.as_ptr()), n, &tr, out.as_mut_ptr(), cap, &mut len) };
+    if rc != DGPU_OK { return None; }
+    out.truncate(len);
+    Some(out)
+}
+/// `verify_aggregate_proof(ip_verifier_srs, pvk, public_inputs, proof, rng, transcript, None)`: Some(valid) or None when the library declined.
+/// variant 0 Groth16, 1 LegoGroth16, 2 LegoGroth16 proofs under the Groth16 aggregator with `d_list` (using_groth16.rs:45-128); `random`: the
+/// scalar RandomizedPairingChecker::new_using_rng would draw.
+#[allow(clippy::too_many_arguments)]
+pub fn verify_aggregate_proof_gpu<T: TranscriptBytes>(g: &G1Affine, h: &G2Affine, g_alpha: &G1Affine, g_beta: &G1Affine, h_alpha: &G2Affine, h_beta: &G2Affine, srs_n: usize,
+                                                      alpha_g1: &G1Affine, beta_g2: &G2Affine, gamma_g2: &G2Affine, delta_g2: &G2Affine, gamma_abc_g1: &[G1Affine],
+                                                      public_inputs: &[Vec<Fr>], proof_words: &[u64], variant: i32, d_list: Option<&[G1Affine]>, random: Fr, transcript: &mut T) -> Option<bool> {
+    let g1s = pack_g1(&[*g, *g_alpha, *g_beta, *alpha_g1]).0;
+    let g2s = pack_g2(&[*h, *h_alpha, *h_beta, *beta_g2, *gamma_g2, *delta_g2]).0;
+    let abc = pack_g1(gamma_abc_g1).0;
+    let l = public_inputs.first().map_or(0, |r| r.len());
+    if public_inputs.iter().any(|r| r.len() != l) { return Some(false); }
+    let pubs: Vec<u64> = public_inputs.iter().flat_map(|r| r.iter().flat_map(|x| x.into_bigint().0)).collect();
+    let dl = d_list.map(|x| pack_g1(x).0);
+    let s = DgpuSnarkpackVerifierSrs { n: srs_n, g: g1s.as_ptr(), h: g2s.as_ptr(), g_alpha: g1s[12..].as_ptr(), g_beta: g1s[24..].as_ptr(), h_alpha: g2s[24..].as_ptr(), h_beta: g2s[48..].as_ptr() };
+    let k = DgpuGroth16Vk { alpha_g1: g1s[36..].as_ptr(), beta_g2: g2s[72..].as_ptr(), gamma_g2: g2s[96..].as_ptr(), delta_g2: g2s[120..].as_ptr(), gamma_abc_g1: abc.as_ptr(), gamma_abc_len: gamma_abc_g1.len() };
+    let tr = bind_transcript(transcript);
+    let rnd = random.into_bigint();
+    let mut ok = 0i32;
+    let rc = unsafe { dgpu_snarkpack_verify(&s, &k, if l == 0 { core::ptr::null() } else { pubs.as_ptr() }, public_inputs.len(), l, proof_words.as_ptr(), proof_words.len(), variant,
+                                            dl.as_ref().map_or(core::ptr::null(), |v| v.as_ptr()), rnd.0.as_ptr(), &tr, 0, &mut ok) };
     if rc != DGPU_OK { return None; }
     Some(ok == 1)
 }

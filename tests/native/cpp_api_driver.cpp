@@ -208,6 +208,71 @@ int main() {
         }
         EXPECT(dgpu_r1cs_free(circ) == DGPU_OK);
     }
+    // SnarkPack aggregation through the C++ mirror (aggregation::aggregate_proofs / verify_aggregate_proof over dgpu_snarkpack_*): eight Groth16
+    // statements with known discrete logs (e(A, B) = e(alpha, beta) e(k0 + x k1, gamma) e(C, delta) holds exactly), a toy transcript of the
+    // caller's (the library only ever sees the two callbacks), then the reference's rejection cases (aggregation/tests.rs:117-330)
+    {
+        using detail::add_mod; using detail::mul_mod;
+        const size_t na = 8;
+        std::vector<uint64_t> rs((7 + 3 * na) * 4); orc_rand_scalars(77, 7 + 3 * na, rs.data());
+        auto S = [&](size_t i) { BigInt256 v; std::memcpy(v.data(), &rs[4 * i], 32); return v; };
+        auto inv = [&](const BigInt256 &a) { BigInt256 e = detail::FR_MODULUS; e[0] -= 2; BigInt256 acc{1, 0, 0, 0}; for (int i = 255; i >= 0; i--) { acc = mul_mod(acc, acc); if ((e[i / 64] >> (i % 64)) & 1) acc = mul_mod(acc, a); } return acc; };
+        auto neg = [&](const BigInt256 &a) { BigInt256 r = detail::FR_MODULUS; unsigned __int128 br = 0; for (int i = 0; i < 4; i++) { unsigned __int128 d = (unsigned __int128)r[i] - a[i] - (uint64_t)br; r[i] = (uint64_t)d; br = (d >> 64) & 1; } return a == BigInt256{} ? a : r; };
+        uint64_t g1g[12], g2g[24]; orc_g1_generator(g1g); orc_g2_generator(g2g);
+        auto mul1 = [&](const BigInt256 &k, uint64_t *out12) { uint64_t j[18]; orc_g1_mul(g1g, 0, k.data(), j); if (orc_g1_to_affine(j, out12)) std::memset(out12, 0, 96); };
+        auto mul2 = [&](const BigInt256 &k, uint64_t *out24) { uint64_t j[36]; orc_g2_mul(g2g, 0, k.data(), j); if (orc_g2_to_affine(j, out24)) std::memset(out24, 0, 192); };
+        const BigInt256 alpha = S(0), beta = S(1), gamma = S(2), delta = S(3), k0s = S(4), k1s = S(5), srs_a = S(6), srs_b = mul_mod(S(6), S(5));
+        aggregation::VerifyingKey vk; vk.gamma_abc_g1.resize(24);
+        mul1(alpha, vk.alpha_g1.data()); mul2(beta, vk.beta_g2.data()); mul2(gamma, vk.gamma_g2.data()); mul2(delta, vk.delta_g2.data());
+        mul1(k0s, &vk.gamma_abc_g1[0]); mul1(k1s, &vk.gamma_abc_g1[12]);
+        aggregation::Words A(12 * na), B(24 * na), C(12 * na);
+        std::vector<BigInt256> pub(na);
+        const BigInt256 dinv = inv(delta), ab = mul_mod(alpha, beta);
+        for (size_t i = 0; i < na; i++) {
+            const BigInt256 a_ = S(7 + 3 * i), b_ = S(8 + 3 * i), x = S(9 + 3 * i);
+            const BigInt256 sg = mul_mod(add_mod(k0s, mul_mod(x, k1s)), gamma);
+            const BigInt256 c_ = mul_mod(add_mod(mul_mod(a_, b_), neg(add_mod(ab, sg))), dinv);
+            mul1(a_, &A[12 * i]); mul2(b_, &B[24 * i]); mul1(c_, &C[12 * i]); pub[i] = x;
+        }
+        aggregation::Words ga(24 * na), gb(24 * na), ha(48 * na), hb(48 * na);
+        { BigInt256 pa{1, 0, 0, 0}, pb{1, 0, 0, 0};
+          for (size_t i = 0; i < 2 * na; i++) { mul1(pa, &ga[12 * i]); mul1(pb, &gb[12 * i]); mul2(pa, &ha[24 * i]); mul2(pb, &hb[24 * i]); pa = mul_mod(pa, srs_a); pb = mul_mod(pb, srs_b); } }
+        const auto psrs = aggregation::ProverSRS::specialize(na, ga, ha, gb, hb);
+        const auto vsrs = aggregation::VerifierSRS::specialize(na, ga, ha, gb, hb);
+        struct ToyTranscript {
+            uint64_t h;
+            explicit ToyTranscript(uint64_t seed) : h(0xcbf29ce484222325ULL ^ seed) {}
+            void absorb(const uint8_t *p, size_t n) { for (size_t i = 0; i < n; i++) { h ^= p[i]; h *= 0x100000001b3ULL; } }
+            void append_message(const uint8_t *l, size_t ll, const uint8_t *b, size_t n) { absorb(l, ll); absorb(b, n); }
+            BigInt256 challenge_scalar(const uint8_t *l, size_t ll) {
+                absorb(l, ll);
+                BigInt256 v;
+                for (int k = 0; k < 4; k++) { h ^= h >> 33; h *= 0xff51afd7ed558ccdULL; h ^= h >> 29; v[k] = h; absorb((const uint8_t *)&h, 8); }
+                v[3] &= 0x3fffffffffffffffULL; v[0] |= 1;             // below 2^254 < r, never zero
+                return v;
+            }
+        };
+        const BigInt256 rnd{0x5eed, 7, 0, 0};
+        ToyTranscript tp(1);
+        const aggregation::Words proof = aggregation::aggregate_proofs(psrs, tp, A, B, C);
+        EXPECT(proof.size() == dgpu_snarkpack_proof_words(na, 0) && proof[0] == na && proof[1] == 1);
+        { ToyTranscript t(1); EXPECT(aggregation::verify_aggregate_proof(vsrs, vk, pub, 1, proof, rnd, t)); }
+        { ToyTranscript t(1); EXPECT(aggregation::verify_aggregate_proof(vsrs, vk, pub, 1, proof, rnd, t, aggregation::Variant::Groth16, nullptr, true)); }
+        { ToyTranscript t(2); EXPECT(!aggregation::verify_aggregate_proof(vsrs, vk, pub, 1, proof, rnd, t)); }                       // another transcript
+        { ToyTranscript t(1); auto bad = pub; bad[3][0] ^= 1; EXPECT(!aggregation::verify_aggregate_proof(vsrs, vk, bad, 1, proof, rnd, t)); }   // a wrong public input
+        { ToyTranscript t(1); auto bad = proof; std::memcpy(&bad[2 + 144 + 144 + 72], &A[0], 96); EXPECT(!aggregation::verify_aggregate_proof(vsrs, vk, pub, 1, bad, rnd, t)); }   // z_c replaced
+        { ToyTranscript t1(1), t2(1); auto Cw = C; std::memcpy(&Cw[12], &A[12], 96);                                                  // one wrong proof in the batch
+          EXPECT(!aggregation::verify_aggregate_proof(vsrs, vk, pub, 1, aggregation::aggregate_proofs(psrs, t1, A, B, Cw), rnd, t2)); }
+        { ToyTranscript t(1); auto cut = proof; cut.pop_back(); bool bad_arg = false;
+          try { aggregation::verify_aggregate_proof(vsrs, vk, pub, 1, cut, rnd, t); } catch (const Error &e) { bad_arg = e.code == DGPU_E_BADARG; }
+          EXPECT(bad_arg); }
+        // the same proofs with a commitment d each through the LegoGroth16 aggregator: two MIPP instances in the proof words (the statement with
+        // arbitrary d is not a valid LegoGroth16 one: the verifier has to say no, not fail)
+        { ToyTranscript t1(3), t2(3);
+          const aggregation::Words pl = aggregation::aggregate_proofs(psrs, t1, A, B, C, &A);
+          EXPECT(pl.size() == dgpu_snarkpack_proof_words(na, 1) && pl[1] == 2);
+          EXPECT(!aggregation::verify_aggregate_proof(vsrs, vk, pub, 1, pl, rnd, t2, aggregation::Variant::LegoGroth16)); }
+    }
     // several device contexts in this one process (a Rust host is one process): two contexts on the box's one GPU, every MSM chunked
     // over them inside the library (dgpu_msm_*_sharded*), same point as the single-context call
     init_devices({0, 0});

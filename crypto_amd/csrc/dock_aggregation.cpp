@@ -25,10 +25,7 @@
 #include <vector>
 #include "../../include/dock_gpu.h"
 #include "host_field.hpp"
-
-namespace dock {
-extern thread_local bool tl_no_min;          // dock_core.hip: the size threshold (DGPU_E_TOO_SMALL) is for callers, not for the library's own calls
-}
+#include "host_par.hpp"        // (dock::tl_no_min: the size threshold DGPU_E_TOO_SMALL is for callers, not for the library's own calls)
 
 namespace {
 using hostf::FrH;
@@ -78,21 +75,12 @@ Frs powers(const Fr &r, size_t n) { Frs o(n); Fr acc = Fr::one(); for (size_t i 
 // ---- independent ABI calls from host threads (the library keeps six calls in flight per device; further callers queue for a slot) ----------
 void par(std::vector<std::function<void()>> thunks) {
     const size_t k = thunks.size();
-    std::vector<int32_t> rcs(k, DGPU_OK);
     std::vector<uint8_t> rej(k, 0);
-    auto run = [&](size_t i) {
-        const bool keep = dock::tl_no_min; dock::tl_no_min = true;
-        try { thunks[i](); } catch (const Fail &f) { rcs[i] = f.rc; } catch (const Reject &) { rej[i] = 1; }
-        catch (const std::bad_alloc &) { rcs[i] = DGPU_E_OOM; } catch (...) { rcs[i] = DGPU_E_HIP; }
-        dock::tl_no_min = keep;
-    };
-    {
-        struct Joiner { std::vector<std::thread> th; ~Joiner() { for (auto &t : th) if (t.joinable()) t.join(); } } j;
-        j.th.reserve(k);
-        for (size_t i = 1; i < k; i++) { try { j.th.emplace_back(run, i); } catch (...) { run(i); } }
-        if (k) run(0);
-    }
-    for (size_t i = 0; i < k; i++) if (rcs[i]) throw Fail{rcs[i]};
+    const int32_t rc = dock::par_run(k, [&](size_t i) -> int32_t {       // (the parts inherit this thread's tl_no_min = true: host_par.hpp)
+        try { thunks[i](); } catch (const Fail &f) { return f.rc; } catch (const Reject &) { rej[i] = 1; }
+        return DGPU_OK;
+    });
+    if (rc) throw Fail{rc};
     for (size_t i = 0; i < k; i++) if (rej[i]) throw Reject{};
 }
 
@@ -426,14 +414,15 @@ struct Checker {
     }
     bool verify() {
         Gt right = gt_one(), left = gt_one();
-        if (!targets.empty()) { const Vec e = canon_words(target_exp); ck(dgpu_fp12_multi_pow(targets[0].data(), e.data(), targets.size(), right.data())); }
         const size_t n = pts.size() / 12;
-        if (n) {
-            Vec scaled(12 * n); std::vector<uint8_t> inf(n);
-            ck(dgpu_g1_scale_batch(pts.data(), nullptr, sc.data(), 4, nullptr, n, scaled.data(), inf.data()));
-            for (size_t i = 0; i < n; i++) inf[i] |= is_id(&qs[24 * i], 24) || is_id(&scaled[12 * i], 12);
-            ck(dgpu_multi_miller_loop(scaled.data(), qs.data(), inf.data(), n, left.data()));
-        }
+        par({[&] { if (!targets.empty()) { const Vec e = canon_words(target_exp); ck(dgpu_fp12_multi_pow(targets[0].data(), e.data(), targets.size(), right.data())); } },   // host cores
+             [&] {                                                                                                                                                              // the device
+                 if (!n) return;
+                 Vec scaled(12 * n); std::vector<uint8_t> inf(n);
+                 ck(dgpu_g1_scale_batch(pts.data(), nullptr, sc.data(), 4, nullptr, n, scaled.data(), inf.data()));
+                 for (size_t i = 0; i < n; i++) inf[i] |= is_id(&qs[24 * i], 24) || is_id(&scaled[12 * i], 12);
+                 ck(dgpu_multi_miller_loop(scaled.data(), qs.data(), inf.data(), n, left.data()));
+             }});
         Gt gt;
         const int32_t rc = dgpu_final_exponentiation(left.data(), gt.data());
         if (rc == DGPU_E_ZERO) return false;
@@ -530,24 +519,24 @@ void verify(const VerifyIn &in, const Proof &P, const Fr &random, const Tr &tr, 
         const int aw = aw_of(g2); Vec pts(p0, p0 + aw); pts.insert(pts.end(), p1, p1 + aw);
         return msm(g2, pts.data(), 2, Frs{Fr::one(), s1});
     };
-    {   // verify_kzg_v (kzg.rs:30-76): e(-g, C_f - y h) e(v - x g, pi) == 1 for both halves of the final v key
+    {   // verify_kzg_v (kzg.rs:30-76): e(-g, C_f - y h) e(v - x g, pi) == 1 for both halves of the final v key; verify_kzg_w (kzg.rs:78-125): the same with
+        // the groups exchanged.  The eight two-term combinations are independent host computations (0.15 / 0.5 ms each in G1 / G2): side by side
         const Fr y = poly_eval_product_form(challenges_inv, z, Fr::one());
-        const W *ng = keep(neg_point(false, S.g));
-        const W *cf[2] = {P.final_vkey[0].data(), P.final_vkey[1].data()}, *vk[2] = {S.g_alpha, S.g_beta}, *pi[2] = {P.vkey_opening[0].data(), P.vkey_opening[1].data()};
+        const Fr fwz = poly_eval_product_form(challenges, z, r.inv()) * z.pow(S.n);
+        const W *cfv[2] = {P.final_vkey[0].data(), P.final_vkey[1].data()}, *vk[2] = {S.g_alpha, S.g_beta}, *piv[2] = {P.vkey_opening[0].data(), P.vkey_opening[1].data()};
+        const W *cfw[2] = {P.final_wkey[0].data(), P.final_wkey[1].data()}, *wk[2] = {S.h_alpha, S.h_beta}, *piw[2] = {P.wkey_opening[0].data(), P.wkey_opening[1].data()};
+        Vec vb[2], vc[2], wa[2], wd[2];
+        std::vector<std::function<void()>> th;
         for (int k = 0; k < 2; k++) {
-            const W *b = keep(two(true, cf[k], S.h, y.neg())), *c = keep(two(false, vk[k], S.g, z.neg()));
-            chk.add({ng, c}, {b, pi[k]}, one);
+            th.push_back([&, k] { vb[k] = two(true, cfv[k], S.h, y.neg()); });       // C_f - y h
+            th.push_back([&, k] { vc[k] = two(false, vk[k], S.g, z.neg()); });       // v - x g
+            th.push_back([&, k] { wa[k] = two(false, cfw[k], S.g, fwz.neg()); });    // C_f - y g
+            th.push_back([&, k] { wd[k] = two(true, wk[k], S.h, z.neg()); });        // w - x h
         }
-    }
-    {   // verify_kzg_w (kzg.rs:78-125)
-        const Fr r_shift = r.inv();
-        const Fr fwz = poly_eval_product_form(challenges, z, r_shift) * z.pow(S.n);
-        const W *nh = keep(neg_point(true, S.h));
-        const W *cf[2] = {P.final_wkey[0].data(), P.final_wkey[1].data()}, *wk[2] = {S.h_alpha, S.h_beta}, *pi[2] = {P.wkey_opening[0].data(), P.wkey_opening[1].data()};
-        for (int k = 0; k < 2; k++) {
-            const W *a = keep(two(false, cf[k], S.g, fwz.neg())), *d = keep(two(true, wk[k], S.h, z.neg()));
-            chk.add({a, pi[k]}, {nh, d}, one);
-        }
+        par(th);
+        const Vec ng = neg_point(false, S.g), nh = neg_point(true, S.h);
+        for (int k = 0; k < 2; k++) chk.add({ng.data(), vc[k].data()}, {vb[k].data(), piv[k]}, one);
+        for (int k = 0; k < 2; k++) chk.add({wa[k].data(), piw[k]}, {nh.data(), wd[k].data()}, one);
     }
     const W *fa = P.final_a.data(), *fb = P.final_b.data(), *v0 = P.final_vkey[0].data(), *v1 = P.final_vkey[1].data(), *w0 = P.final_wkey[0].data(), *w1 = P.final_wkey[1].data();
     chk.add({fa}, {fb}, zab);

@@ -602,6 +602,10 @@ def secondary_configs(log2n, ks, scalars, db, ds, pool, cpu_legs=True, ncpu=1):
     ANv.verify_aggregate_proof(vsrs_ag, {"vk": vkv}, pubs_int, words_v, 0x5EED002B, AGv.MerlinTranscript(b"bench"), with_d=True)       # raises if invalid
     res["snarkpack_aggregate_1024_proofs_ms"] = round(timed(lambda: ANv.aggregate_proofs_words(pk_ag, AGv.MerlinTranscript(b"bench"), proofs_v, with_d=True), 3), 2)
     res["snarkpack_verify_aggregate_ms"] = round(timed(lambda: ANv.verify_aggregate_proof(vsrs_ag, {"vk": vkv}, pubs_int, words_v, 0x5EED002C, AGv.MerlinTranscript(b"bench"), with_d=True), 3), 2)
+    ANv.aggregate_proofs_words(pk_ag, AGv.MerlinTranscript(b"bench"), proofs_v, with_d=True); t_ag = ANv.LAST["transcript_ms"]
+    ANv.verify_aggregate_proof(vsrs_ag, {"vk": vkv}, pubs_int, words_v, 0x5EED002C, AGv.MerlinTranscript(b"bench"), with_d=True); t_vf = ANv.LAST["transcript_ms"]
+    res["snarkpack_python_transcript_ms"] = {"aggregate": round(t_ag, 2), "verify": round(t_vf, 2),
+                                             "note": "part of the two numbers above spent inside the Python Merlin transcript the library calls back (a Rust caller's merlin::Transcript costs microseconds)"}
     res["snarkpack_aggregate_1024_proofs_python_host_ms"] = round(timed(lambda: ALv.aggregate_proofs(pk_ag, AGv.MerlinTranscript(b"bench"), proofs_v), 3), 2)
     res["snarkpack_verify_aggregate_python_host_ms"] = round(timed(lambda: ALv.verify_aggregate_proof(vsrs_ag, {"vk": vkv}, pubs_int, agg_v, 0x5EED002C, AGv.MerlinTranscript(b"bench")), 3), 2)
     # -- BASELINE config 4: witness map on the x_i = x_{i-1}^2 + i circuit shape (m + 1 constraints + 2 instance variables = D), circuit resident,

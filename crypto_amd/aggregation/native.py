@@ -6,6 +6,7 @@ as it calls the Rust caller's `impl Transcript`).  tests/test_gpu_aggregation_na
 Reference: /root/reference/legogroth16/src/aggregation/groth16/{prover.rs:47-147, verifier.rs:36-100}, legogroth16/{prover.rs:38-127,
 verifier.rs:34-96, using_groth16.rs:26-128}."""
 import ctypes as C
+import time
 import numpy as np
 from .._native import lib, DockGpuError, Transcript, APPEND_FN, CHALLENGE_FN, SnarkpackProverSrs, SnarkpackVerifierSrs, Groth16Vk
 from . import ops
@@ -13,6 +14,7 @@ from .ops import G1, G2, R_MOD
 from .srs import PairCommitment, AggregationError
 
 VALIDATE_GT = 1
+LAST = {"transcript_ms": 0.0}          # of the last call: milliseconds spent inside the Python transcript's callbacks (bench.py reports it)
 
 
 def _p(a):
@@ -28,21 +30,26 @@ class _Callbacks:
 
     def __init__(self, transcript):
         self.error = None
+        self.seconds = 0.0               # time spent inside the Python transcript (a Rust caller's Merlin costs microseconds; this one does not)
 
         def append(_ctx, label, label_len, data, n):
+            t0 = time.perf_counter()
             try:
-                transcript.append(bytes(label[:label_len]), bytes(data[:n]))
+                transcript.append(C.string_at(label, label_len), C.string_at(data, n))
             except BaseException as e:       # noqa: BLE001 (must not unwind into C)
                 self.error = self.error or e
+            self.seconds += time.perf_counter() - t0
 
         def challenge(_ctx, label, label_len, out):
+            t0 = time.perf_counter()
             try:
-                v = int(transcript.challenge_scalar(bytes(label[:label_len]))) % R_MOD
+                v = int(transcript.challenge_scalar(C.string_at(label, label_len))) % R_MOD
             except BaseException as e:       # noqa: BLE001
                 self.error = self.error or e
                 v = 1
             for i in range(4):
                 out[i] = (v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF
+            self.seconds += time.perf_counter() - t0
         self._a, self._c = APPEND_FN(append), CHALLENGE_FN(challenge)
         self.struct = Transcript(None, self._a, self._c)
 
@@ -140,6 +147,7 @@ def aggregate_proofs_words(srs, transcript, proofs, with_d=False):
     cb = _Callbacks(transcript)
     rc = lib().dgpu_snarkpack_aggregate(C.byref(S), _p(a), _p(b), _p(c), _p(d), n, C.byref(cb.struct), _p(out), cap, C.byref(ln))
     cb.check()
+    LAST["transcript_ms"] = cb.seconds * 1e3
     if rc:
         raise DockGpuError(rc, "dgpu_snarkpack_aggregate")
     return out[:ln.value]
@@ -174,6 +182,7 @@ def verify_aggregate_proof(ip_verifier_srs, pvk, public_inputs, proof, random, t
     rc = lib().dgpu_snarkpack_verify(C.byref(S), C.byref(K), _p(pub) if l else None, len(public_inputs), l, _p(words), len(words), variant, _p(dl), _p(rnd), C.byref(cb.struct),
                                      VALIDATE_GT if validate_gt else 0, C.byref(ok))
     cb.check()
+    LAST["transcript_ms"] = cb.seconds * 1e3
     if rc == -3:
         raise AggregationError("malformed proof, key or public inputs (DGPU_E_BADARG)")
     if rc:

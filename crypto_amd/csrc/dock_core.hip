@@ -252,6 +252,7 @@ static void release_parts(const Handle &hd) {
     if (hd.kind == 10 || hd.kind == 11) { PreTable *pt = (PreTable *)hd.p; (void)hipFree(pt->tab); delete pt; return; }
     if (hd.kind == 3) { scalar_release(hd.ctx, hd.p, scalar_bytes(hd.n)); return; }      // recycled: no device-wide wait per proof
     if (hd.kind == 12) { SortedScalars *ss = (SortedScalars *)hd.p; scalar_release(hd.ctx, ss->off, ss->off_bytes); scalar_release(hd.ctx, ss->entries, ss->entries_bytes); delete ss; return; }
+    if (hd.aux) (void)hipFree(hd.aux);                 // the small-MSM table of a plain bases handle
     (void)hipFree(hd.p);
 }
 static int32_t free_handle(uint64_t h, bool scalars) {

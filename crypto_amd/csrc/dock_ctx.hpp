@@ -38,7 +38,7 @@ struct Buf {
 // several devices (ShardSet*), 9 = scalars sharded like a bases set (ShardSet*), 10 / 11 = G1 / G2 precomputed-multiples table (PreTable*),
 // 12 = sorted scalars (SortedScalars*).  `ctx` = the device context that owns the allocation;
 // `inflight` = calls currently using it (a free waits for them: no use-after-free when dgpu_*_free races an MSM on the same handle).
-struct Handle { void *p; size_t n; int kind; int ctx; int inflight; };
+struct Handle { void *p; size_t n; int kind; int ctx; int inflight; void *aux = nullptr; int small_uses = 0; };   // aux: the small-MSM table of a plain bases handle (msm_driver.hip.h small_sub_for)
 struct PreTable { void *tab; size_t n; int c, W; };      // kind 10 / 11: tab[w * n + i] = prepared record of 2^(c w) P_i (pre_kernels.hip.h)
 struct SortedScalars { void *off, *entries; size_t off_bytes, entries_bytes; size_t n, rows, boff; int c, W; };   // kind 12: the partition sort of n scalars for tables of `rows` rows, width c, first row boff
 struct ShardSet { std::vector<uint64_t> sub; std::vector<size_t> lo; size_t n = 0; };   // sub[k] covers [lo[k], lo[k+1]) (lo has sub.size() + 1 entries)
@@ -64,12 +64,12 @@ struct Slot {
     static constexpr size_t HPIN_BYTES = 64 * 1024;
     hipEvent_t copy_ev[N_COPY_EV + 1] = {};
     unsigned ev_next = 0;           // next event to record (taken in turn)
-    Buf flags, in_bases, in_inf, in_scalars, prepped, digits, heavy, cnt, off, cursor, bsums, entries, bucket, bucket_inf, head, tail, head_b, tail_b, part_inf, l1, l1_inf, win, win_inf, ml_lines, ml_partial, ml_out, ml_coeffs, ml_state, dyn, hpart, hpart_inf;
+    Buf flags, in_bases, in_inf, in_scalars, prepped, digits, heavy, cnt, off, cursor, bsums, entries, bucket, bucket_inf, head, tail, head_b, tail_b, part_inf, l1, l1_inf, win, win_inf, ml_lines, ml_partial, ml_out, ml_coeffs, ml_state, dyn, hpart, hpart_inf, small_cnt;
     Buf q[16];      // witness-map workspace (dock_qap.hip)
     std::vector<std::pair<const char *, std::pair<hipEvent_t, hipEvent_t>>> prof_pending;
     std::vector<hipEvent_t> ev_pool;
     void release_all() {
-        Buf *bufs[] = {&flags, &in_bases, &in_inf, &in_scalars, &prepped, &digits, &heavy, &cnt, &off, &cursor, &bsums, &entries, &bucket, &bucket_inf, &head, &tail, &head_b, &tail_b, &part_inf, &l1, &l1_inf, &win, &win_inf, &ml_lines, &ml_partial, &ml_out, &ml_coeffs, &ml_state, &dyn, &hpart, &hpart_inf};
+        Buf *bufs[] = {&flags, &in_bases, &in_inf, &in_scalars, &prepped, &digits, &heavy, &cnt, &off, &cursor, &bsums, &entries, &bucket, &bucket_inf, &head, &tail, &head_b, &tail_b, &part_inf, &l1, &l1_inf, &win, &win_inf, &ml_lines, &ml_partial, &ml_out, &ml_coeffs, &ml_state, &dyn, &hpart, &hpart_inf, &small_cnt};
         for (Buf *b : bufs) b->release();
         for (Buf &b : q) b.release();
         for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
@@ -98,6 +98,7 @@ constexpr size_t SCALAR_POOL_MAX_ENTRIES = 32, SCALAR_POOL_MAX_BYTES = (size_t)4
 // process-wide state shared by all contexts
 struct Shared {
     std::mutex mu;                 // lifecycle, handle table, profile table, NTT-domain tables
+    std::mutex small_mu;           // one small-MSM table build at a time (msm_driver.hip.h small_sub_for)
     std::condition_variable cv;    // signalled when a handle's in-flight count drops
     std::map<uint64_t, Handle> handles;
     uint64_t next_handle = 1;

@@ -1,6 +1,7 @@
 // crypto_amd/csrc/k_g2_small.hip — G2 kernels of the small-MSM path (small_kernels.hip.h)
 #include "small_kernels.hip.h"
 namespace msm {
-template void launch_small_table<G2>(hipStream_t, const uint32_t *, size_t, uint32_t *, uint8_t *, const uint32_t *, size_t, void *, uint32_t *);
-template void launch_small_tree<G2>(hipStream_t, const uint32_t *, const uint8_t *, const void *, size_t, size_t, uint32_t *, uint8_t *, uint32_t *, uint32_t *, uint8_t *);
+template void launch_small_table<G2>(hipStream_t, const uint32_t *, size_t, uint32_t *, uint8_t *);
+template void launch_small_subtable<G2>(hipStream_t, const uint32_t *, size_t, uint32_t *, uint8_t *);
+template void launch_small_tree<G2>(hipStream_t, const uint32_t *, const uint8_t *, int, const uint32_t *, size_t, uint32_t *, uint8_t *, uint32_t *, uint32_t *, uint8_t *, uint8_t *);
 }  // namespace msm

@@ -166,53 +166,59 @@ template <class C> int32_t ws_bucket_sets(Slot &sl, uint32_t NB, size_t K) {
 }
 
 // ---- the small path: up to SMALL_MSM_MAX_N terms over plain bases (small_kernels.hip.h) ----------------------------------------------------
+// the table of a resident handle (Handle::aux): (e + 1) 2^(64 s) P_i for s < 4, e < 8, and one identity flag per entry behind it
+struct SmallSub { const uint32_t *tab; const uint8_t *tab_inf; };
+template <class C> inline size_t small_sub_tab_bytes(size_t n) { return n * SMALL_MSM_S * SMALL_MSM_E * (size_t)C::ACC::XW * 4; }
+template <class C> inline size_t small_sub_bytes(size_t n) { return small_sub_tab_bytes<C>(n) + n * SMALL_MSM_S * SMALL_MSM_E; }
+template <class C> inline SmallSub small_sub_at(const void *aux, size_t handle_n, size_t offset) {
+    const uint8_t *base = (const uint8_t *)aux;
+    return SmallSub{(const uint32_t *)base + offset * SMALL_MSM_S * SMALL_MSM_E * (size_t)C::ACC::XW, base + small_sub_tab_bytes<C>(handle_n) + offset * SMALL_MSM_S * SMALL_MSM_E};
+}
 template <class C> int32_t ws_small(Slot &sl, size_t n) {
     int32_t rc;
     typedef typename C::ACC A;
-    const size_t n_pad = (n + 7) & ~(size_t)7, nblk = (n + SMALL_MSM_LEAVES - 1) / SMALL_MSM_LEAVES;
-    if ((rc = sl.flags.ensure(64))) return rc;
-    if ((rc = sl.digits.ensure((size_t)SMALL_MSM_W * n_pad * 2))) return rc;
     if ((rc = sl.bucket.ensure(n * SMALL_MSM_E * A::XW * 4))) return rc;
     if ((rc = sl.bucket_inf.ensure(n * SMALL_MSM_E))) return rc;
-    if ((rc = sl.head.ensure((size_t)SMALL_MSM_W * nblk * A::XW * 4))) return rc;
-    if ((rc = sl.part_inf.ensure((size_t)SMALL_MSM_W * nblk))) return rc;
-    // window sums, their identity flags, the bad-scalar flag and the per-window block counters in ONE buffer: one memset, one copy back
-    return sl.win.ensure((size_t)SMALL_MSM_W * 4 * C::ABI_W * 4 + SMALL_MSM_W + 4 + (size_t)SMALL_MSM_W * 4);
+    if ((rc = sl.head.ensure((size_t)256 * A::XW * 4))) return rc;                // at most 4 blocks x 64 windows or 16 x 16 partials
+    if ((rc = sl.part_inf.ensure(256))) return rc;
+    if (!sl.small_cnt.p) {                                                          // the per-window block counters: zero once, every launch leaves them zero
+        if ((rc = sl.small_cnt.ensure((size_t)SMALL_MSM_W * 4))) return rc;
+        if (hipMemsetAsync(sl.small_cnt.p, 0, (size_t)SMALL_MSM_W * 4, sl.stream) != hipSuccess) { (void)hipGetLastError(); sl.small_cnt.release(); return DGPU_E_HIP; }
+    }
+    // window sums, their identity flags and their bad-scalar flags in ONE buffer: one copy back
+    return sl.win.ensure((size_t)SMALL_MSM_W * 4 * C::ABI_W * 4 + 2 * SMALL_MSM_W);
 }
-// (digit codes and) the table of eight multiples per base -> one tree per window -> the host's Horner fold.  ready_scalars / ready_bases queue whatever
-// still has to bring the operands to the device (one-shot calls: the copies and the conversion of the raw points).
+// the table of eight multiples per base (unless the handle brought one: `sub`) -> one tree per (super-)window -> the host's Horner fold.  ready_scalars /
+// ready_bases queue whatever still has to bring the operands to the device (one-shot calls: the copies and the conversion of the raw points).
 template <class C, class HF, class ReadyS, class ReadyB>
-int32_t msm_device_small(Slot &sl, const uint32_t *d_bases, const uint32_t *d_scalars, size_t n, uint64_t *out_xyz, ReadyS ready_scalars, ReadyB ready_bases) {
+int32_t msm_device_small(Slot &sl, const uint32_t *d_bases, const uint32_t *d_scalars, size_t n, uint64_t *out_xyz, ReadyS ready_scalars, ReadyB ready_bases, const SmallSub *sub = nullptr) {
     int32_t rc;
-    if ((rc = ws_small<C>(sl, n))) return rc;
+    if ((rc = ws_small<C>(sl, sub ? 1 : n))) return rc;
     hipStream_t s = sl.stream;
-    const size_t n_pad = (n + 7) & ~(size_t)7;
-    constexpr int W = SMALL_MSM_W, c = SMALL_MSM_C;
+    constexpr int c = SMALL_MSM_C;
+    const int S = sub ? SMALL_MSM_S : 1, W = SMALL_MSM_W / S;
     if ((rc = ready_scalars(0, 0, n))) return rc;
     if ((rc = ready_bases(0, 0, n))) return rc;
-    constexpr size_t WBYTES = (size_t)W * 4 * C::ABI_W * 4;
-    static_assert(WBYTES + W + 4 <= Slot::HPIN_BYTES, "pinned scratch");
+    constexpr size_t WBYTES = (size_t)SMALL_MSM_W * 4 * C::ABI_W * 4;
+    static_assert(WBYTES + 2 * SMALL_MSM_W <= Slot::HPIN_BYTES, "pinned scratch");
     uint8_t *const wbuf = sl.win.as<uint8_t>();
-    uint8_t *const d_inf = wbuf + WBYTES;
-    uint32_t *const d_flag = (uint32_t *)(wbuf + WBYTES + W), *const d_count = d_flag + 1;
-    HIPCHK(hipMemsetAsync(d_flag, 0, 4 + (size_t)W * 4, s));
-    {
-        StageTimer st(sl, "msm.small_digits_table");
-        launch_small_table<C>(s, d_bases, n, sl.bucket.as<uint32_t>(), sl.bucket_inf.as<uint8_t>(), d_scalars, n_pad, sl.digits.p, d_flag);
+    uint8_t *const d_inf = wbuf + WBYTES, *const d_bad = d_inf + SMALL_MSM_W;
+    if (!sub) {
+        StageTimer st(sl, "msm.small_table");
+        launch_small_table<C>(s, d_bases, n, sl.bucket.as<uint32_t>(), sl.bucket_inf.as<uint8_t>());
     }
     {
         StageTimer st(sl, "msm.small_tree");
-        launch_small_tree<C>(s, sl.bucket.as<uint32_t>(), sl.bucket_inf.as<uint8_t>(), sl.digits.p, n, n_pad, sl.head.as<uint32_t>(), sl.part_inf.as<uint8_t>(), d_count,
-                             (uint32_t *)wbuf, d_inf);
+        launch_small_tree<C>(s, sub ? sub->tab : sl.bucket.as<uint32_t>(), sub ? sub->tab_inf : sl.bucket_inf.as<uint8_t>(), S, d_scalars, n, sl.head.as<uint32_t>(), sl.part_inf.as<uint8_t>(),
+                             sl.small_cnt.as<uint32_t>(), (uint32_t *)wbuf, d_inf, d_bad);
     }
     HIPCHK(hipGetLastError());
     uint8_t *const hbuf = (uint8_t *)sl.hpin;                       // pinned: one asynchronous copy brings everything back
-    HIPCHK(hipMemcpyAsync(hbuf, wbuf, WBYTES + W + 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(hbuf, wbuf, WBYTES + 2 * SMALL_MSM_W, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     if (gs.prof) prof_flush(sl);
-    const uint64_t *hwin = (const uint64_t *)hbuf; const uint8_t *hinf = hbuf + WBYTES;
-    uint32_t hbad; memcpy(&hbad, hbuf + WBYTES + W, 4);
-    if (hbad) return DGPU_E_BADARG;                  // a scalar >= 2^255
+    const uint64_t *hwin = (const uint64_t *)hbuf; const uint8_t *hinf = hbuf + WBYTES, *hbad = hinf + SMALL_MSM_W;
+    for (int w = 0; w < W; w++) if (hbad[w]) return DGPU_E_BADARG;      // a scalar >= 2^255
     host_fold<HF>(hwin, hinf, W, c, out_xyz);
     return DGPU_OK;
 }
@@ -222,9 +228,9 @@ int32_t msm_device_small(Slot &sl, const uint32_t *d_bases, const uint32_t *d_sc
 // of range k (one-shot calls: the bases cross PCIe while the scalars are sorted): the sort does not look at them and the accumulation passes over
 // identity records itself.  `ready_scalars(k, lo, hi)` is called before the sort of range k.
 template <class C, class HF, class ReadyS, class ReadyB>
-int32_t msm_device_ranges(Slot &sl, const uint32_t *d_bases, const uint32_t *d_scalars, size_t n, size_t K, uint64_t *out_xyz, bool bases_pending, ReadyS ready_scalars, ReadyB ready_bases) {
+int32_t msm_device_ranges(Slot &sl, const uint32_t *d_bases, const uint32_t *d_scalars, size_t n, size_t K, uint64_t *out_xyz, bool bases_pending, ReadyS ready_scalars, ReadyB ready_bases, const SmallSub *sub = nullptr) {
     if (n == 0) { write_identity<HF>(out_xyz); return DGPU_OK; }
-    if (K == 1 && n <= gs.small_max.load() && n <= SMALL_MSM_MAX_N) return msm_device_small<C, HF>(sl, d_bases, d_scalars, n, out_xyz, ready_scalars, ready_bases);
+    if (K == 1 && n <= gs.small_max.load() && n <= SMALL_MSM_MAX_N) return msm_device_small<C, HF>(sl, d_bases, d_scalars, n, out_xyz, ready_scalars, ready_bases, sub);
     PlainGeom g; int32_t rc;
     if ((rc = plain_geometry<C>(n, g))) return rc;
     if ((rc = ws_plain<C>(sl, g))) return rc;
@@ -308,9 +314,44 @@ int32_t msm_device_ranges(Slot &sl, const uint32_t *d_bases, const uint32_t *d_s
     return DGPU_OK;
 }
 template <class C, class HF>
-int32_t msm_device(Slot &sl, const uint32_t *d_bases, const uint32_t *d_scalars, size_t n, uint64_t *out_xyz) {
+int32_t msm_device(Slot &sl, const uint32_t *d_bases, const uint32_t *d_scalars, size_t n, uint64_t *out_xyz, const SmallSub *sub = nullptr) {
     auto nothing = [](size_t, size_t, size_t) { return (int32_t)DGPU_OK; };
-    return msm_device_ranges<C, HF>(sl, d_bases, d_scalars, n, 1, out_xyz, false, nothing, nothing);
+    return msm_device_ranges<C, HF>(sl, d_bases, d_scalars, n, 1, out_xyz, false, nothing, nothing, sub);
+}
+
+// The small-path table of a plain resident handle (Handle::aux), built when the handle meets the small path for the second time (a handle used
+// once does not pay the ~1.2 ms of the doubling chains) or by dgpu_bases_precompute_*: one allocation, released with the handle.  Returns false
+// when there is none (yet, or because the allocation failed: the call then builds its eight multiples per base itself).  Caller holds a slot.
+template <class C>
+bool small_sub_for(Slot &sl, uint64_t handle_id, const Handle &h, size_t offset, size_t n, SmallSub &out, bool force = false) {
+    if (h.n == 0 || h.n > SMALL_MSM_MAX_N || n > gs.small_max.load()) return false;
+    void *aux = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(gs.mu);
+        auto it = gs.handles.find(handle_id);
+        if (it == gs.handles.end()) return false;
+        aux = it->second.aux;
+        if (!aux && !force && ++it->second.small_uses < 2) return false;
+    }
+    if (!aux) {
+        std::lock_guard<std::mutex> build(gs.small_mu);                 // one build at a time; whoever comes second finds the table
+        { std::lock_guard<std::mutex> lk(gs.mu); auto it = gs.handles.find(handle_id); if (it == gs.handles.end()) return false; aux = it->second.aux; }
+        if (!aux) {
+            void *p = nullptr;
+            if (dev_malloc(&p, small_sub_bytes<C>(h.n)) != hipSuccess) { (void)hipGetLastError(); return false; }
+            {
+                StageTimer st(sl, "msm.small_subtable");
+                launch_small_subtable<C>(sl.stream, (const uint32_t *)h.p, h.n, (uint32_t *)p, (uint8_t *)p + small_sub_tab_bytes<C>(h.n));
+            }
+            if (hipGetLastError() != hipSuccess || hipStreamSynchronize(sl.stream) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(p); return false; }
+            std::lock_guard<std::mutex> lk(gs.mu);
+            auto it = gs.handles.find(handle_id);
+            if (it == gs.handles.end()) { (void)hipFree(p); return false; }
+            it->second.aux = aux = p;
+        }
+    }
+    out = small_sub_at<C>(aux, h.n, offset);
+    return true;
 }
 
 inline void shard_bounds(size_t n, size_t parts, std::vector<size_t> &lo) {
@@ -587,12 +628,20 @@ int32_t bases_precompute(uint64_t handle, int32_t window_bits, int kind /* 1 | 2
       }
       if (peek.kind == kind + 9) return DGPU_OK; }       // already a table
     if (!take_handle(handle, [kind](int k) { return k == kind; }, hd)) return DGPU_E_BADARG;
-    auto put_back = [&](void *p, int k) { std::lock_guard<std::mutex> lk(gs.mu); gs.handles[handle] = Handle{p, hd.n, k, hd.ctx, 0}; };
+    // (a handle that stays plain keeps its small-MSM table; one that becomes a bucket table drops it)
+    auto put_back = [&](void *p, int k) { std::lock_guard<std::mutex> lk(gs.mu); gs.handles[handle] = Handle{p, hd.n, k, hd.ctx, 0, k == kind ? hd.aux : nullptr, hd.small_uses}; };
     CtxScope on_owner(hd.ctx);
     if (!cur().ready) { put_back(hd.p, kind); return DGPU_E_NODEVICE; }
     const size_t n = hd.n;
     const int c = window_bits ? window_bits : choose_c_pre(n);
-    if (c == 0) { put_back(hd.p, kind); return DGPU_OK; }          // too few terms for a table to pay: the handle stays on the plain pipeline
+    if (c == 0) {                                                   // too few terms for a bucket table to pay: the handle stays plain ...
+        put_back(hd.p, kind);
+        if (n && n <= SMALL_MSM_MAX_N) {                            // ... and gets the small path's table now instead of at its second small call
+            HandleRef ref(handle);
+            if (ref.ok) { SLOT_ACQUIRE(L, sl); if (hipSetDevice(cur().device) == hipSuccess) { SmallSub sub; (void)small_sub_for<C>(sl, handle, ref.h, 0, 0, sub, true); } }
+        }
+        return DGPU_OK;
+    }
     const int W = 255 / c + 1;
     if (n == 0 || (uint64_t)W * n >= (1ull << 31)) { put_back(hd.p, kind); return n == 0 ? DGPU_OK : DGPU_E_BADARG; }
     void *tab = nullptr, *tmp = nullptr;
@@ -614,6 +663,7 @@ int32_t bases_precompute(uint64_t handle, int32_t window_bits, int kind /* 1 | 2
     }
     if (rc) { if (tab) (void)hipFree(tab); (void)hipGetLastError(); put_back(hd.p, kind); return rc; }
     (void)hipFree(hd.p);
+    if (hd.aux) (void)hipFree(hd.aux);
     PreTable *npt = new PreTable{tab, n, c, W};
     put_back(npt, kind + 9);
     (void)reserve_slots<C>(3, n, 0, npt);           // (the handle cannot be freed under us: the caller still owns it)
@@ -794,7 +844,10 @@ int32_t msm_handle(uint64_t bases, size_t offset, const uint64_t *scalars, size_
     auto ready = [&](size_t, size_t lo, size_t hi) { return stage_scalars(sl, scalars, lo, hi, mont != 0, sl.in_scalars.as<uint32_t>()); };
     auto nothing = [](size_t, size_t, size_t) { return (int32_t)DGPU_OK; };
     if (hb.h.kind == kind + 9) rc = msm_device_pre_ranges<C, HF>(sl, *(const PreTable *)hb.h.p, offset, sl.in_scalars.as<uint32_t>(), n, K, out, ready);
-    else rc = msm_device_ranges<C, HF>(sl, (const uint32_t *)hb.h.p + offset * C::AFF_STRIDE, sl.in_scalars.as<uint32_t>(), n, K, out, false, ready, nothing);
+    else {
+        SmallSub sub; const bool have = K == 1 && n && small_sub_for<C>(sl, bases, hb.h, offset, n, sub);
+        rc = msm_device_ranges<C, HF>(sl, (const uint32_t *)hb.h.p + offset * C::AFF_STRIDE, sl.in_scalars.as<uint32_t>(), n, K, out, false, ready, nothing, have ? &sub : nullptr);
+    }
     if (rc) { (void)hipStreamSynchronize(sl.cstream); (void)hipStreamSynchronize(sl.stream); }      // nothing of ours may still read the caller's scalars
     return rc;
 }
@@ -811,7 +864,8 @@ int32_t msm_resident(uint64_t bases, size_t boff, uint64_t scalars, size_t soff,
     SLOT_ACQUIRE(L, sl);
     HIPCHK(hipSetDevice(cur().device));
     if (hb.h.kind == kind + 9) return msm_device_pre<C, HF>(sl, *(const PreTable *)hb.h.p, boff, (const uint32_t *)hs.h.p + soff * 8, n, out);
-    return msm_device<C, HF>(sl, (const uint32_t *)hb.h.p + boff * C::AFF_STRIDE, (const uint32_t *)hs.h.p + soff * 8, n, out);
+    SmallSub sub; const bool have = n && small_sub_for<C>(sl, bases, hb.h, boff, n, sub);
+    return msm_device<C, HF>(sl, (const uint32_t *)hb.h.p + boff * C::AFF_STRIDE, (const uint32_t *)hs.h.p + soff * 8, n, out, have ? &sub : nullptr);
 }
 
 // ---- several GPUs behind the ABI (SURVEY.md 8b `dgpu_msm_g1_sharded`, 8e point-chunk sharding) ----------------------------------------

@@ -22,15 +22,17 @@ template <class C> void launch_merge_buckets(hipStream_t s, uint32_t NB, uint32_
 template <class C> void launch_reduce_l0(hipStream_t s, unsigned NG, const uint32_t *bucket, const uint8_t *bucket_inf, uint32_t NB, int mshift, uint32_t *l1, uint8_t *l1_inf);
 template <class C> void launch_reduce_top(hipStream_t s, unsigned W, const uint32_t *l1, const uint8_t *l1_inf, int G, int gshift, uint32_t *win_abi, uint8_t *win_inf, int lanes);
 
-// the small-MSM path (small_kernels.hip.h; k_g1_small.hip / k_g2_small.hip): 64 signed 4-bit windows, eight multiples per base, a tree per window
-constexpr int SMALL_MSM_C = 4, SMALL_MSM_W = 64, SMALL_MSM_E = 8, SMALL_MSM_LEAVES = 128;
+// the small-MSM path (small_kernels.hip.h; k_g1_small.hip / k_g2_small.hip): 64 signed 4-bit windows, eight multiples per base (and, for a table kept
+// with a resident handle, per sub-table 2^(64 s) P, s < 4), a tree per (super-)window
+constexpr int SMALL_MSM_C = 4, SMALL_MSM_W = 64, SMALL_MSM_E = 8, SMALL_MSM_LEAVES = 128, SMALL_MSM_S = 4;
 constexpr size_t SMALL_MSM_MAX_N = 8192;
-// leaves per group of k_small_tree: at most FOUR blocks per window, i.e. 256 blocks = one block per CU (the kernel holds one wave per SIMD):
-// a fifth block per window would run behind the others and double the kernel's length
-inline int small_per_group(size_t n) { const int g = (int)((n + 255) / 256); return g < 2 ? 2 : g; }
-template <class C> void launch_small_table(hipStream_t s, const uint32_t *bases, size_t n, uint32_t *tab, uint8_t *tab_inf, const uint32_t *scalars, size_t n_pad, void *codes, uint32_t *bad);
-template <class C> void launch_small_tree(hipStream_t s, const uint32_t *tab, const uint8_t *tab_inf, const void *codes, size_t n, size_t n_pad, uint32_t *partial, uint8_t *partial_inf,
-                                          uint32_t *count, uint32_t *win_abi, uint8_t *win_inf);
+// leaves per group of k_small_tree over L leaves of `subtables` sub-tables: at most 4 x subtables blocks per (super-)window, i.e. 256 blocks = one block
+// per CU (the kernel holds one wave per SIMD): one more block per window would run behind the others and double the kernel's length
+inline int small_per_group(size_t L, int subtables) { const int g = (int)((L + 256 * (size_t)subtables - 1) / (256 * (size_t)subtables)); return g < 2 ? 2 : g; }
+template <class C> void launch_small_table(hipStream_t s, const uint32_t *bases, size_t n, uint32_t *tab, uint8_t *tab_inf);
+template <class C> void launch_small_subtable(hipStream_t s, const uint32_t *bases, size_t n, uint32_t *tab, uint8_t *tab_inf);
+template <class C> void launch_small_tree(hipStream_t s, const uint32_t *tab, const uint8_t *tab_inf, int subtables, const uint32_t *scalars, size_t n, uint32_t *partial, uint8_t *partial_inf,
+                                          uint32_t *count, uint32_t *win_abi, uint8_t *win_inf, uint8_t *win_bad);
 
 // precomputed-multiples tables (pre_kernels.hip.h; k_g1_pre.hip / k_g2_pre.hip)
 template <class C> void launch_pre_step(hipStream_t s, const uint32_t *prev, size_t n, int c, uint32_t *tmp, uint32_t *out);

@@ -70,6 +70,16 @@ def w_resident():
         db.free()
 
 
+def w_small_resident():
+    """a plain handle of 3000 bases met three times by the small path: the per-call table, the build of the handle's own table (an allocation that may
+    fail: the call then keeps building its eight multiples itself), the tree over that table"""
+    db = ca.DeviceBases(ca.G1, b1s)
+    try:
+        return np.concatenate([db.msm_bigint(s_s) for _ in range(3)])
+    finally:
+        db.free()
+
+
 def w_miller():
     return np.concatenate([ca.multi_miller_loop(P64, Q64), pairing.G2Prepared.from_affine(Q64[:5]).coeffs.reshape(-1)[:72]])
 
@@ -105,7 +115,7 @@ def w_fixed_base():
         return pts.reshape(-1)
 
 
-WORK = {"msm one-shot, tree path": w_small, "msm one-shot, bucket pipeline": w_buckets, "msm G2 one-shot": w_g2, "upload + table + resident MSM": w_resident,
+WORK = {"msm one-shot, tree path": w_small, "msm one-shot, bucket pipeline": w_buckets, "msm G2 one-shot": w_g2, "upload + table + resident MSM": w_resident, "small resident handle (its own table)": w_small_resident,
         "Miller loop + G2Prepared": w_miller, "witness map": w_witness_map, "LegoGroth16 prove": w_prove, "fixed-base table": w_fixed_base}
 
 

@@ -3,7 +3,9 @@ tree per window; taken up to dgpu_set_small_msm_max = 8192 terms on plain bases)
 set to 0) and against the CPU oracle — one-shot calls, plain handles with fresh and with resident scalars, the caller's Affine structs, G1 and
 G2, every block-count boundary (128 terms per block, 64 blocks), and the digit / point edge cases: zero and r - 1 scalars, scalars made of the
 extreme digits (0x7, 0x8 nibbles: the carries of the signed recoding), all-equal scalars and bases (P + P inside the tree and the table),
-P and -P, identity bases, a scalar with bit 255 set (refused).  Bar: bit-exact."""
+P and -P, identity bases, a scalar with bit 255 set (refused).  A plain handle that meets the small path a second time (or is handed to
+dgpu_bases_precompute_*) gets a table of the eight multiples of P, 2^64 P, 2^128 P, 2^192 P per base and runs 16 trees over 4 n leaves in ONE
+launch: the same cases through that form, with offsets into the handle.  Bar: bit-exact."""
 import numpy as np
 import pytest
 import torch
@@ -97,6 +99,48 @@ def test_digit_and_point_edge_cases(gname):
     bad = rnd.copy(); bad[17, 3] |= np.uint64(1 << 63)
     with pytest.raises(ca.DockGpuError):
         ca.msm_bigint(curve, bases, bad)
+
+
+@pytest.mark.parametrize("gname", ["G1", "G2"])
+def test_resident_table_form(gname):
+    """the table kept with a handle: built at the second small call or by precompute, used with offsets and prefixes, the digit edge cases through
+    its four sub-tables (window 16 s + v is leaf (i, s) of super-window v), identity bases inside it, a scalar >= 2^255 refused"""
+    curve, G = CUR[gname]
+    n = 700
+    bases, _, _ = U.seq_bases(G, n, 91, threads=16)
+    inf = np.zeros(n, np.uint8); inf[5::13] = 1
+    lim = lambda v: O.int_to_limbs(v, 4)
+    rnd = O.rand_scalars(92, n)
+    nib = lambda d: int(("%x" % d) * 63, 16) % (1 << 255)
+    edge = rnd.copy()
+    pats = [0, 1, R - 1, nib(8), nib(8) + 1, nib(8) - 1, nib(7), nib(9), nib(0xF), (1 << 255) - 1, (1 << 64) - 1, 1 << 64, (1 << 128) - 1, 1 << 128, (1 << 192) - 1, 1 << 192,
+            0x8 << 60, 0x9 << 60, (0x88888888 << 32) | 0x88888889, 0x88888888_88888888_88888888_88888888, 0x88888888_88888888_88888888_88888889 << 64]
+    for k, v in enumerate(pats):
+        edge[k::len(pats) + 3] = lim(v)
+    want = {"rnd": normalised(G, G.msm(bases, rnd, inf, threads=16)), "edge": normalised(G, G.msm(bases, edge, inf, threads=16))}
+    for eager in (False, True):
+        db = ca.DeviceBases(curve, bases, inf)
+        (lib().dgpu_reserve_g1 if gname == "G1" else lib().dgpu_reserve_g2)(n)      # every slot's workspaces exist: what is allocated from here on is the table
+        a0 = ca.device_alloc_count()
+        if eager:
+            db.precompute()                                   # 700 bases: no bucket table, the small path's table now
+            assert ca.device_alloc_count() == a0 + 1
+        for rep in range(3):                                  # (not eager: per-call table, then the build, then the table)
+            assert (db.msm_bigint(rnd) == want["rnd"]).all(), (eager, rep)
+            assert (db.msm_bigint(edge) == want["edge"]).all(), (eager, rep)
+        assert ca.device_alloc_count() == a0 + 1              # exactly one allocation: the table, once
+        ds = ca.DeviceScalars(edge)
+        assert (db.msm_resident(ds) == want["edge"]).all()
+        for off, cnt in ((1, n - 1), (0, 64), (63, 130), (n - 1, 1), (300, 257)):
+            got = db.msm_resident(ds, n=cnt, base_offset=off, scalar_offset=off)
+            assert (got == normalised(G, G.msm(bases[off:off + cnt], edge[off:off + cnt], inf[off:off + cnt], threads=16))).all(), (off, cnt)
+        small, bucket = both_paths(lambda: db.msm_resident(ds))     # the knob still switches the handle's calls to the bucket pipeline
+        assert (small == bucket).all()
+        bad = rnd.copy(); bad[n - 3, 3] |= np.uint64(1 << 63)
+        with pytest.raises(ca.DockGpuError):
+            db.msm_bigint(bad)
+        assert (db.msm_bigint(rnd) == want["rnd"]).all()       # the refused call left the window counters clean
+        ds.free(); db.free()
 
 
 def test_concurrent_small_calls_do_not_share_state():

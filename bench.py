@@ -476,6 +476,29 @@ def secondary_configs(log2n, ks, scalars, db, ds, pool, cpu_legs=True, ncpu=1):
         b21.free(); d21.free(); del k21, s21
     except Exception as e:          # noqa: BLE001
         res["g1_2p21_per_gpu_share"] = {"error": repr(e)}
+    # -- the MSM sizes of the reference's call sites above the GPU threshold (the aggregation's halving MSMs, the mult checker): the tree path
+    #    (small_kernels.hip.h) one-shot from host memory and on a resident handle (its own table), with the CPU path beside them
+    try:
+        sm = {}
+        with FB.WindowTable(ca.G1, gen1[0]) as ts1:
+            for nn in (600, 4096):
+                pts, _ = ts1.multiply_many(seeded_scalars(0x5EED0600 + nn, nn)); scn = seeded_scalars(0x5EED0700 + nn, nn)
+                ref = ca.msm_bigint(ca.G1, pts, scn)
+                hb = ca.DeviceBases(ca.G1, pts); hs = ca.DeviceScalars(scn)
+                for _ in range(3):
+                    assert (hb.msm_resident(hs) == ref).all()
+                e = {"one_shot_ms": round(timed(lambda: ca.msm_bigint(ca.G1, pts, scn), 20, warm=3), 3), "resident_handle_ms": round(timed(lambda: hb.msm_resident(hs), 20, warm=3), 3)}
+                if cpu_legs:
+                    (rc_, ms1) = min((cpu_time(lambda: O.G1.msm(pts, scn, threads=1)) for _ in range(3)), key=lambda t: t[1])
+                    (_, msw) = min((cpu_time(lambda: O.G1.msm(pts, scn, threads=win_threads(nn))) for _ in range(3)), key=lambda t: t[1])
+                    e.update({"cpu_one_thread_ms": round(ms1, 3), "cpu_one_thread_per_window_ms": round(msw, 3), "cpu_threads": win_threads(nn),
+                              "bit_exact_vs_gpu": bool((O.G1.to_affine(rc_)[0] == ref[:12]).all())})
+                sm["g1_n%d" % nn] = e
+                hb.free(); hs.free()
+        sm["note"] = "dgpu_msm_g1 from host memory / dgpu_msm_g1_resident on a plain handle; below 8193 terms both take the tree path, the handle with its own table of pre-doubled multiples (one launch)"
+        res["small_msm"] = sm
+    except Exception as e:          # noqa: BLE001
+        res["small_msm"] = {"error": repr(e)}
     # -- BASELINE config 3: G2 MSM at the same n (plain and table), 1024-pair Miller loop, final exponentiation
     with FB.WindowTable(ca.G2, gen2[0]) as t2, FB.WindowTable(ca.G1, gen1[0]) as t1:
         if cpu_legs:

@@ -319,8 +319,9 @@ int32_t msm_device(Slot &sl, const uint32_t *d_bases, const uint32_t *d_scalars,
     return msm_device_ranges<C, HF>(sl, d_bases, d_scalars, n, 1, out_xyz, false, nothing, nothing, sub);
 }
 
-// The small-path table of a plain resident handle (Handle::aux), built when the handle meets the small path for the second time (a handle used
-// once does not pay the ~1.2 ms of the doubling chains) or by dgpu_bases_precompute_*: one allocation, released with the handle.  Returns false
+// The small-path table of a plain resident handle (Handle::aux): built by the upload of up to 8192 bases (bases_upload, so that the handle's calls
+// allocate nothing), by dgpu_bases_precompute_*, or — for a handle that came into being another way — when it meets the small path for the second
+// time: one allocation, released with the handle.  Returns false
 // when there is none (yet, or because the allocation failed: the call then builds its eight multiples per base itself).  Caller holds a slot.
 template <class C>
 bool small_sub_for(Slot &sl, uint64_t handle_id, const Handle &h, size_t offset, size_t n, SmallSub &out, bool force = false) {
@@ -638,7 +639,7 @@ int32_t bases_precompute(uint64_t handle, int32_t window_bits, int kind /* 1 | 2
         put_back(hd.p, kind);
         if (n && n <= SMALL_MSM_MAX_N) {                            // ... and gets the small path's table now instead of at its second small call
             HandleRef ref(handle);
-            if (ref.ok) { SLOT_ACQUIRE(L, sl); if (hipSetDevice(cur().device) == hipSuccess) { SmallSub sub; (void)small_sub_for<C>(sl, handle, ref.h, 0, 0, sub, true); } }
+            if (ref.ok) { SlotLock L; if (L.ok && hipSetDevice(cur().device) == hipSuccess) { SmallSub sub; (void)small_sub_for<C>(*L.s, handle, ref.h, 0, 0, sub, true); } }
         }
         return DGPU_OK;
     }
@@ -823,6 +824,10 @@ int32_t bases_upload(const RawBases &rb, size_t n, uint64_t *handle, int kind) {
     }
     *handle = register_handle(p, n, kind);
     (void)reserve_slots<C>(2, n, 0, nullptr);       // every slot is ready for an MSM over this query before the first proof arrives
+    if (n && n <= SMALL_MSM_MAX_N && n <= gs.small_max.load()) {     // ... and a handle the small path will serve gets its table now (best effort: ~1 ms once, no allocation at its calls)
+        HandleRef ref(*handle);
+        if (ref.ok) { SlotLock L; if (L.ok && hipSetDevice(cur().device) == hipSuccess) { SmallSub sub; (void)small_sub_for<C>(*L.s, *handle, ref.h, 0, 0, sub, true); } }
+    }
     return DGPU_OK;
 }
 

@@ -71,8 +71,8 @@ int32_t dgpu_set_reduce_shift(int32_t log2_buckets_per_lane);
 int32_t dgpu_set_reduce_lanes(int32_t lanes);
 /* MSMs of up to n terms (default and maximum 8192) over plain bases — one-shot calls, plain handles — run as 64 signed 4-bit windows, each a
  * tree over the terms' table entries (a table launch and a tree launch: crypto_amd/csrc/small_kernels.hip.h) instead of the ~15-launch bucket
- * pipeline: 0.27 - 0.6 ms instead of 0.7 - 0.9 ms per call.  A plain HANDLE of up to 8192 bases that meets this path a second time (or is handed
- * to dgpu_bases_precompute_*) gets a table of its own — the eight multiples of P, 2^64 P, 2^128 P, 2^192 P per base, 6.5 KB (G1) / 13 KB (G2)
+ * pipeline: 0.27 - 0.6 ms instead of 0.7 - 0.9 ms per call.  A plain HANDLE of up to 8192 bases gets a table of its own when it is uploaded (one
+ * made another way: at its second small MSM, or by dgpu_bases_precompute_*) — the eight multiples of P, 2^64 P, 2^128 P, 2^192 P per base, 6.5 KB (G1) / 13 KB (G2)
  * per base, released with the handle — and its calls are ONE launch of 16 trees over 4 n leaves and a 60-doubling fold on the host:
  * 0.14 - 0.4 ms (G1 n = 600 / 4096: 0.19 / 0.29 ms; G2: 0.37 / 0.57).  If that allocation fails the calls keep building their per-call table.
  * 0: always the bucket pipeline (the parity tests compare the two). */
@@ -149,7 +149,7 @@ int32_t dgpu_msm_g2_handle(uint64_t bases, size_t offset, const uint64_t *scalar
  * chosen from n, else 16..22.  Works on plain (dgpu_bases_upload_*, dgpu_window_table_mul_to_bases_*) and sharded handles; offsets
  * (`&query[1..]`) and sub-ranges keep working.  While the table is being built the handle is unavailable (DGPU_E_BADARG).
  * A handle too small for a bucket table to pay (below 2^15 points with window_bits = 0) stays plain; with up to 8192 points it gets the small
- * path's table (dgpu_set_small_msm_max above) at once instead of at its second small MSM.
+ * path's table (dgpu_set_small_msm_max above) if its upload has not built it already.
  * The automatic width (20 from 2^17.5 points) is the optimum for full-width scalars.  A query that is multiplied by a WITNESS (a proving key's
  * a / b / l queries: half of a Groth16 witness is 0 or 1, much of the rest small) adds fewer points per MSM but reduces the same number of
  * buckets, and a proof reduces five bucket sets: DGPU_TABLE_C_WITNESS = 17 has the window count of 18 (15) with half the buckets — measured

@@ -103,7 +103,7 @@ def test_digit_and_point_edge_cases(gname):
 
 @pytest.mark.parametrize("gname", ["G1", "G2"])
 def test_resident_table_form(gname):
-    """the table kept with a handle: built at the second small call or by precompute, used with offsets and prefixes, the digit edge cases through
+    """the table kept with a handle: built at the upload (or, for a handle made while the path was off, at its second small call), used with offsets and prefixes, the digit edge cases through
     its four sub-tables (window 16 s + v is leaf (i, s) of super-window v), identity bases inside it, a scalar >= 2^255 refused"""
     curve, G = CUR[gname]
     n = 700
@@ -118,17 +118,24 @@ def test_resident_table_form(gname):
     for k, v in enumerate(pats):
         edge[k::len(pats) + 3] = lim(v)
     want = {"rnd": normalised(G, G.msm(bases, rnd, inf, threads=16)), "edge": normalised(G, G.msm(bases, edge, inf, threads=16))}
-    for eager in (False, True):
-        db = ca.DeviceBases(curve, bases, inf)
-        (lib().dgpu_reserve_g1 if gname == "G1" else lib().dgpu_reserve_g2)(n)      # every slot's workspaces exist: what is allocated from here on is the table
+    for how in ("upload", "precompute", "second call"):
+        # the table comes with the upload (<= 8192 bases) ...; "precompute": asking again is a no-op; "second call": a handle uploaded while the small path
+        # was switched off gets it lazily, at its second small MSM
+        if how == "second call":
+            assert lib().dgpu_set_small_msm_max(0) == 0
+        (lib().dgpu_reserve_g1 if gname == "G1" else lib().dgpu_reserve_g2)(n)      # every slot's workspaces exist: what is allocated from here on belongs to the handle
         a0 = ca.device_alloc_count()
-        if eager:
-            db.precompute()                                   # 700 bases: no bucket table, the small path's table now
-            assert ca.device_alloc_count() == a0 + 1
-        for rep in range(3):                                  # (not eager: per-call table, then the build, then the table)
-            assert (db.msm_bigint(rnd) == want["rnd"]).all(), (eager, rep)
-            assert (db.msm_bigint(edge) == want["edge"]).all(), (eager, rep)
-        assert ca.device_alloc_count() == a0 + 1              # exactly one allocation: the table, once
+        db = ca.DeviceBases(curve, bases, inf)
+        lib().dgpu_set_small_msm_max(8192)
+        per_handle = ca.device_alloc_count() - a0               # the records, and the table unless it comes later
+        if how == "precompute":
+            db.precompute()                                   # 700 bases: no bucket table; the small path's table exists already
+        a1 = ca.device_alloc_count()
+        assert a1 == a0 + per_handle
+        for rep in range(3):
+            assert (db.msm_bigint(rnd) == want["rnd"]).all(), (how, rep)
+            assert (db.msm_bigint(edge) == want["edge"]).all(), (how, rep)
+        assert ca.device_alloc_count() == a1 + (1 if how == "second call" else 0), how      # the calls allocate nothing, except the one late table
         ds = ca.DeviceScalars(edge)
         assert (db.msm_resident(ds) == want["edge"]).all()
         for off, cnt in ((1, n - 1), (0, 64), (63, 130), (n - 1, 1), (300, 257)):

@@ -836,7 +836,8 @@ template <class C, class HF>
 int32_t msm_handle(uint64_t bases, size_t offset, const uint64_t *scalars, size_t n, int mont, uint64_t *out, int kind, bool check_min = true) {
     if (!out || (n && !scalars)) return DGPU_E_BADARG;
     if (!cur().ready) return DGPU_E_NODEVICE;
-    if (check_min && !tl_no_min && n < gs.min_gpu_n) return DGPU_E_TOO_SMALL;
+    // (bases behind a handle have their small-path table with them: one launch, 0.14 ms at 16 terms against 0.64 ms of one CPU thread)
+    if (check_min && !tl_no_min && n < std::min<size_t>(gs.min_gpu_n, DGPU_MIN_GPU_N_HANDLE)) return DGPU_E_TOO_SMALL;
     HandleRef hb(bases);
     if (!hb.ok || (hb.h.kind != kind && hb.h.kind != kind + 9) || offset > hb.h.n || n > hb.h.n - offset) return DGPU_E_BADARG;
     CtxScope on_owner(hb.h.ctx);                    // run where the bases live
@@ -861,7 +862,7 @@ template <class C, class HF>
 int32_t msm_resident(uint64_t bases, size_t boff, uint64_t scalars, size_t soff, size_t n, uint64_t *out, int kind, bool check_min = true) {
     if (!out) return DGPU_E_BADARG;
     if (!cur().ready) return DGPU_E_NODEVICE;
-    if (check_min && !tl_no_min && n < gs.min_gpu_n) return DGPU_E_TOO_SMALL;
+    if (check_min && !tl_no_min && n < std::min<size_t>(gs.min_gpu_n, DGPU_MIN_GPU_N_HANDLE)) return DGPU_E_TOO_SMALL;
     HandleRef hb(bases), hs(scalars);
     if (!hb.ok || !hs.ok || (hb.h.kind != kind && hb.h.kind != kind + 9) || hs.h.kind != 3 || hb.h.ctx != hs.h.ctx) return DGPU_E_BADARG;    // both operands on one device
     if (boff > hb.h.n || n > hb.h.n - boff || soff > hs.h.n || n > hs.h.n - soff) return DGPU_E_BADARG;

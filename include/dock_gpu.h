@@ -57,6 +57,9 @@ int32_t dgpu_last_hip_error(void);
  * (>= 95 % of the reference's call sites have n < 100).  Default: DGPU_DEFAULT_MIN_GPU_N, the measured
  * crossover against the CPU path; 0 = always run on the device. */
 #define DGPU_DEFAULT_MIN_GPU_N 256
+/* MSMs over a bases HANDLE (dgpu_msm_*_handle, dgpu_msm_*_resident) are refused only below min(threshold, DGPU_MIN_GPU_N_HANDLE) terms: the handle
+ * carries the small path's table, a call is one launch (0.14 ms at 16 terms; one CPU thread: 0.64 ms), and a caller who uploaded bases wants them used. */
+#define DGPU_MIN_GPU_N_HANDLE 8
 int32_t dgpu_set_min_gpu_n(size_t n);
 size_t dgpu_get_min_gpu_n(void);
 /* ---- tuning knobs.  Process-wide, not needed by a caller: every setting returns the SAME result limb for limb (the tests sweep each of

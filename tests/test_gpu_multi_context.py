@@ -139,6 +139,16 @@ def test_size_threshold_default_and_override():
         L.dgpu_set_min_gpu_n(256)                  # the library default (DGPU_DEFAULT_MIN_GPU_N)
         assert L.dgpu_get_min_gpu_n() == 256
         assert L.dgpu_msm_g1(p(b), None, p(s), 1, p(out)) == -6          # DGPU_E_TOO_SMALL: the Rust shim stays on arkworks
+        # bases behind a handle bring their small-path table: refused only below DGPU_MIN_GPU_N_HANDLE = 8 terms
+        hb16, _, _ = U.seq_bases(O.G1, 16, 4242); hs16 = O.rand_scalars(4243, 16); h16 = C.c_uint64(0)
+        assert L.dgpu_bases_upload_g1(p(hb16), None, 16, C.byref(h16)) == 0
+        assert L.dgpu_msm_g1(p(hb16), None, p(hs16), 16, p(out)) == -6
+        assert L.dgpu_msm_g1_handle(h16.value, 0, p(hs16), 7, 0, p(out)) == -6
+        assert L.dgpu_msm_g1_handle(h16.value, 0, p(hs16), 16, 0, p(out)) == 0
+        L.dgpu_set_min_gpu_n(0); ref16 = np.zeros(18, dtype=np.uint64)
+        assert L.dgpu_msm_g1(p(hb16), None, p(hs16), 16, p(ref16)) == 0 and (ref16 == out).all()
+        L.dgpu_set_min_gpu_n(256)
+        assert L.dgpu_bases_free(h16.value) == 0
         assert L.dgpu_msm_g1_sharded(p(b), None, p(s), 1, 0, p(out)) == -6
     finally:
         L.dgpu_set_min_gpu_n(0)

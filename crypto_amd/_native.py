@@ -75,6 +75,7 @@ SYMBOLS = [
     "dgpu_prof_enable", "dgpu_prof_reset", "dgpu_prof_read", "dgpu_legogroth16_prove", "dgpu_legogroth16_verify", "dgpu_handle_len", "dgpu_handle_context", "dgpu_shard_count", "dgpu_shard_part",
     "dgpu_selftest_fp_mul", "dgpu_selftest_g1_sum", "dgpu_selftest_glv_decompose",
     "dgpu_snarkpack_proof_words", "dgpu_snarkpack_aggregate", "dgpu_snarkpack_verify",
+    "dgpu_g1_fold_prepare", "dgpu_g2_fold_prepare", "dgpu_fold_prepare_pair", "dgpu_g1_fold_apply", "dgpu_g2_fold_apply", "dgpu_fold_free",
 ]
 
 
@@ -177,6 +178,12 @@ def lib():
         for name in ("dgpu_g1_mul_add_batch", "dgpu_g2_mul_add_batch"):
             getattr(L, name).argtypes = [vp, vp, vp, sz, vp, vp, sz, vp, vp]
         L.dgpu_legogroth16_prove.argtypes = [vp, u64, u64, vp, sz, sz, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp]
+        for name in ("dgpu_g1_fold_prepare", "dgpu_g2_fold_prepare"):
+            getattr(L, name).argtypes = [vp, sz, C.POINTER(u64)]
+        for name in ("dgpu_g1_fold_apply", "dgpu_g2_fold_apply"):
+            getattr(L, name).argtypes = [u64, vp, vp, vp, vp]
+        L.dgpu_fold_free.argtypes = [u64]
+        L.dgpu_fold_prepare_pair.argtypes = [vp, sz, C.POINTER(u64), vp, sz, C.POINTER(u64)]
         L.dgpu_snarkpack_proof_words.restype = C.c_size_t
         L.dgpu_snarkpack_proof_words.argtypes = [sz, C.c_int32]
         L.dgpu_snarkpack_aggregate.argtypes = [vp, vp, vp, vp, vp, sz, vp, vp, sz, C.POINTER(sz)]

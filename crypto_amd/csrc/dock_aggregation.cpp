@@ -323,9 +323,23 @@ void aggregate(const dgpu_snarkpack_prover_srs *srs, const W *pa, const W *pb, c
         std::vector<Gt> g;
         Vec z_l[2], z_r[2];
         const Frs r_l(m_r.begin(), m_r.begin() + s), r_r(m_r.begin() + s, m_r.begin() + 2 * s);
+        // what the round's folding step (below) will multiply by the challenge: the right halves.  Their doubling chains do not depend on the challenge and
+        // run now, beside the pairings (dgpu_fold_prepare_pair: ~0.8 ms, the pairings take ~1.5); the step itself is then a shallow tree (fold_kernels.hip.h)
+        Vec right, left, right2, left2;
+        {
+            auto cat = [&](Vec &dst, const W *p, size_t words) { dst.insert(dst.end(), p, p + words); };
+            cat(right, a_r, 12 * s); cat(right, wka_r, 12 * s); cat(right, wkb_r, 12 * s);
+            cat(left, a_l, 12 * s); cat(left, wka_l, 12 * s); cat(left, wkb_l, 12 * s);
+            for (int k = 0; k < nm; k++) { cat(right, m_v[k].data() + 12 * s, 12 * s); cat(left, m_v[k].data(), 12 * s); }
+            cat(right2, b_r, 24 * s); cat(right2, vka_r, 24 * s); cat(right2, vkb_r, 24 * s);
+            cat(left2, b_l, 24 * s); cat(left2, vka_l, 24 * s); cat(left2, vkb_l, 24 * s);
+        }
+        uint64_t prep1 = 0, prep2 = 0;
+        struct FreeFold { uint64_t &h; ~FreeFold() { if (h) (void)dgpu_fold_free(h); } } free1{prep1}, free2{prep2};
         {
             std::vector<std::function<void()>> th;
             th.push_back([&] { g = j.run(); });
+            th.push_back([&] { if (dgpu_fold_prepare_pair(right.data(), (3 + nm) * s, &prep1, right2.data(), 3 * s, &prep2)) { prep1 = 0; prep2 = 0; } });      // (no table: the chain kernels do the step)
             for (int k = 0; k < nm; k++) {
                 th.push_back([&, k] { z_l[k] = msm(false, m_v[k].data() + 12 * s, s, r_l); });
                 th.push_back([&, k] { z_r[k] = msm(false, m_v[k].data(), s, r_r); });
@@ -353,17 +367,16 @@ void aggregate(const dgpu_snarkpack_prover_srs *srs, const W *pa, const W *pb, c
         // instead of `compress` x (2 + n_mipp) + Key::compress x 2
         Vec g1_new, g2_new;
         {
-            Vec right, left;
-            auto cat = [&](Vec &dst, const W *p, size_t words) { dst.insert(dst.end(), p, p + words); };
-            cat(right, a_r, 12 * s); cat(right, wka_r, 12 * s); cat(right, wkb_r, 12 * s);
-            cat(left, a_l, 12 * s); cat(left, wka_l, 12 * s); cat(left, wkb_l, 12 * s);
-            for (int k = 0; k < nm; k++) { cat(right, m_v[k].data() + 12 * s, 12 * s); cat(left, m_v[k].data(), 12 * s); }
-            Vec right2, left2;
-            cat(right2, b_r, 24 * s); cat(right2, vka_r, 24 * s); cat(right2, vkb_r, 24 * s);
-            cat(left2, b_l, 24 * s); cat(left2, vka_l, 24 * s); cat(left2, vkb_l, 24 * s);
             Vec chw(4), ciw(4); ch.canon(chw.data()); c_inv.canon(ciw.data());
-            par({[&] { g1_new = mul_add(false, right.data(), (3 + nm) * s, chw, 0, left.data()); },
-                 [&] { g2_new = mul_add(true, right2.data(), 3 * s, ciw, 0, left2.data()); }});
+            auto fold = [&](bool g2, uint64_t prep, const Vec &rt, const Vec &lf, size_t cnt, const Vec &cw) {
+                if (!prep) return mul_add(g2, rt.data(), cnt, cw, 0, lf.data());
+                const int aw = aw_of(g2);
+                Vec out(cnt * aw, 0); std::vector<uint8_t> oinf(cnt);
+                ck(g2 ? dgpu_g2_fold_apply(prep, cw.data(), lf.data(), out.data(), oinf.data()) : dgpu_g1_fold_apply(prep, cw.data(), lf.data(), out.data(), oinf.data()));
+                return out;                                            // (identity outputs are zero words already)
+            };
+            par({[&] { g1_new = fold(false, prep1, right, left, (3 + nm) * s, chw); },
+                 [&] { g2_new = fold(true, prep2, right2, left2, 3 * s, ciw); }});
         }
         m_a.assign(g1_new.begin(), g1_new.begin() + 12 * s);
         wkey.a.assign(g1_new.begin() + 12 * s, g1_new.begin() + 24 * s); wkey.b.assign(g1_new.begin() + 24 * s, g1_new.begin() + 36 * s);

@@ -195,8 +195,9 @@ int32_t dgpu_shutdown(void) {
         if (hd.kind == 4) free_r1cs_object(hd.p);                       // DevR1cs owns several allocations
         else if (hd.kind == 10 || hd.kind == 11) { PreTable *pt = (PreTable *)hd.p; (void)hipFree(pt->tab); delete pt; }
         else if (hd.kind == 12) { SortedScalars *ss = (SortedScalars *)hd.p; (void)hipFree(ss->off); (void)hipFree(ss->entries); delete ss; }
+        else if (hd.kind == 13 || hd.kind == 14) { FoldTab *ft = (FoldTab *)hd.p; (void)hipFree(ft->tab); delete ft; }
         else if (hd.kind >= 7) delete (ShardSet *)hd.p;                 // its per-device parts are table entries of their own
-        else (void)hipFree(hd.p);
+        else { if (hd.aux) (void)hipFree(hd.aux); (void)hipFree(hd.p); }
     }
     gs.handles.clear();
     for (int i = 0; i < MAX_CTX; i++) {
@@ -204,6 +205,8 @@ int32_t dgpu_shutdown(void) {
         if (c.device >= 0) (void)hipSetDevice(c.device);
         for (auto &e : c.scalar_pool) (void)hipFree(e.first);
         c.scalar_pool.clear(); c.scalar_pool_bytes = 0;
+        for (auto &e : c.fold_pool) (void)hipFree(e.first);
+        c.fold_pool.clear();
         for (auto &d : c.ntt_domains) { void *ps[] = {d.second.tw_f, d.second.tw_i, d.second.pw_f, d.second.pw_i, d.second.zinv, d.second.pwr_f, d.second.pwr_i}; for (void *p : ps) if (p) (void)hipFree(p); }
         c.ntt_domains.clear();
         c.device = -1;
@@ -257,7 +260,7 @@ static void release_parts(const Handle &hd) {
 }
 static int32_t free_handle(uint64_t h, bool scalars) {
     Handle hd;
-    auto ok = [scalars](int k) { return k != 4 && ((k == 3 || k == 9 || k == 12) == scalars); };
+    auto ok = [scalars](int k) { return k != 4 && k < 13 && ((k == 3 || k == 9 || k == 12) == scalars); };       // (13 / 14: dgpu_fold_free)
     if (!take_handle(h, ok, hd)) return DGPU_E_BADARG;
     release_parts(hd);
     return DGPU_OK;

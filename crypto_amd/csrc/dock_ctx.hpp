@@ -36,11 +36,12 @@ struct Buf {
 
 // kind: 1 = G1 bases, 2 = G2 bases, 3 = scalars, 4 = R1CS (DevR1cs*), 5 / 6 = G1 / G2 window table, 7 / 8 = G1 / G2 bases sharded over
 // several devices (ShardSet*), 9 = scalars sharded like a bases set (ShardSet*), 10 / 11 = G1 / G2 precomputed-multiples table (PreTable*),
-// 12 = sorted scalars (SortedScalars*).  `ctx` = the device context that owns the allocation;
+// 12 = sorted scalars (SortedScalars*), 13 / 14 = G1 / G2 fold table (FoldTab*, dock_fixed.hip).  `ctx` = the device context that owns the allocation;
 // `inflight` = calls currently using it (a free waits for them: no use-after-free when dgpu_*_free races an MSM on the same handle).
 struct Handle { void *p; size_t n; int kind; int ctx; int inflight; void *aux = nullptr; int small_uses = 0; };   // aux: the small-MSM table of a plain bases handle (msm_driver.hip.h small_sub_for)
 struct PreTable { void *tab; size_t n; int c, W; };      // kind 10 / 11: tab[w * n + i] = prepared record of 2^(c w) P_i (pre_kernels.hip.h)
 struct SortedScalars { void *off, *entries; size_t off_bytes, entries_bytes; size_t n, rows, boff; int c, W; };   // kind 12: the partition sort of n scalars for tables of `rows` rows, width c, first row boff
+struct FoldTab { void *tab; size_t bytes; size_t n; };    // kind 13 / 14: the doubling chains of n points (fold_kernels.hip.h), identity flags behind them
 struct ShardSet { std::vector<uint64_t> sub; std::vector<size_t> lo; size_t n = 0; };   // sub[k] covers [lo[k], lo[k+1]) (lo has sub.size() + 1 entries)
 struct NttDomain { void *tw_f = nullptr, *tw_i = nullptr, *pw_f = nullptr, *pw_i = nullptr, *zinv = nullptr, *pwr_f = nullptr, *pwr_i = nullptr; };   // pwr_*: pw_* in bit-reversed order   // per log2(D), built once per device
 
@@ -93,6 +94,7 @@ struct Ctx {
     // hipMalloc / hipFree per proof cost ~0.3 ms and hipFree waits for the whole device, i.e. for every other call in flight.
     std::vector<std::pair<void *, size_t>> scalar_pool;
     size_t scalar_pool_bytes = 0;
+    std::vector<std::pair<void *, size_t>> fold_pool;   // tables of dgpu_g*_fold_prepare kept for the next one (guarded by gs.mu; dock_fixed.hip)
 };
 constexpr size_t SCALAR_POOL_MAX_ENTRIES = 32, SCALAR_POOL_MAX_BYTES = (size_t)4 << 30;
 // process-wide state shared by all contexts

@@ -155,6 +155,99 @@ template <class C> int32_t mul_add(const uint64_t *p, const uint8_t *p_inf, cons
     return DGPU_OK;
 }
 
+
+// ---- the folding step with the doubling chains done ahead of the scalar (fold_kernels.hip.h) -------------------------------------------------
+// handle kind 13 / 14: the table of n G1 / G2 points (XYZZ entries as ABI words) and one identity flag per point behind it
+inline size_t fold_words(bool g2) { return g2 ? msm::FOLD_TABLE_WORDS_G2 : msm::FOLD_TABLE_WORDS_G1; }
+// the tables of an aggregation halve from round to round: a buffer is kept for the next, smaller one (a hipMalloc / hipFree pair per round costs more
+// than the kernels, and hipFree waits for every other call in flight)
+void *fold_alloc(size_t bytes, size_t &got) {
+    {
+        std::lock_guard<std::mutex> lk(gs.mu);
+        auto &pool = cur().fold_pool;
+        size_t best = pool.size();
+        for (size_t k = 0; k < pool.size(); k++) if (pool[k].second >= bytes && (best == pool.size() || pool[k].second < pool[best].second)) best = k;
+        if (best != pool.size()) { void *p = pool[best].first; got = pool[best].second; pool[best] = pool.back(); pool.pop_back(); return p; }
+    }
+    void *p = nullptr;
+    if (dev_malloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    got = bytes;
+    return p;
+}
+void fold_release(int ctx, void *p, size_t bytes) {
+    bool keep = false;
+    { std::lock_guard<std::mutex> lk(gs.mu); auto &pool = ctxs[ctx].fold_pool; if (ctxs[ctx].ready.load() && pool.size() < 4) { pool.push_back({p, bytes}); keep = true; } }
+    if (!keep) (void)hipFree(p);
+}
+// the chains of a G1 and a G2 point set in one launch (either set may be empty: then its handle stays 0)
+int32_t fold_prepare(const uint64_t *p1, size_t n1, uint64_t *h1, const uint64_t *p2, size_t n2, uint64_t *h2) {
+    if ((n1 && (!p1 || !h1)) || (n2 && (!p2 || !h2)) || n1 + n2 == 0 || n1 >= (1ull << 24) || n2 >= (1ull << 24)) return DGPU_E_BADARG;
+    if (!cur().ready) return DGPU_E_NODEVICE;
+    const size_t bytes1 = n1 * fold_words(false) * 4 + n1, bytes2 = n2 * fold_words(true) * 4 + n2;
+    size_t got1 = 0, got2 = 0;
+    void *tab1 = nullptr, *tab2 = nullptr;
+    auto drop = [&] { if (tab1) fold_release(cur_index(), tab1, got1); if (tab2) fold_release(cur_index(), tab2, got2); };
+    {
+        SLOT_ACQUIRE(L, sl);
+        HIPCHK(hipSetDevice(cur().device));
+        int32_t rc;
+        if ((rc = sl.in_bases.ensure(n1 * 96 + n2 * 192))) return rc;
+        if (n1 && !(tab1 = fold_alloc(bytes1, got1))) return DGPU_E_OOM;
+        if (n2 && !(tab2 = fold_alloc(bytes2, got2))) { drop(); return DGPU_E_OOM; }
+        hipStream_t s = sl.stream;
+        rc = DGPU_OK;
+        uint8_t *d1 = sl.in_bases.as<uint8_t>(), *d2 = d1 + n1 * 96;
+        if (n1 && hipMemcpyAsync(d1, p1, n1 * 96, hipMemcpyHostToDevice, s) != hipSuccess) rc = DGPU_E_HIP;
+        if (!rc && n2 && hipMemcpyAsync(d2, p2, n2 * 192, hipMemcpyHostToDevice, s) != hipSuccess) rc = DGPU_E_HIP;
+        if (!rc) { StageTimer st(sl, "fixed.fold_chain");
+                   msm::launch_fold_chain(s, (const uint32_t *)d1, n1, (uint32_t *)tab1, (uint8_t *)tab1 + n1 * fold_words(false) * 4,
+                                          (const uint32_t *)d2, n2, (uint32_t *)tab2, (uint8_t *)tab2 + n2 * fold_words(true) * 4); }
+        if (!rc && (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess)) rc = DGPU_E_HIP;
+        if (gs.prof) prof_flush(sl);
+        if (rc) { gs.last_hip = (int32_t)hipGetLastError(); drop(); return rc; }
+    }
+    FoldTab *f1 = n1 ? new (std::nothrow) FoldTab{tab1, got1, n1} : nullptr, *f2 = n2 ? new (std::nothrow) FoldTab{tab2, got2, n2} : nullptr;
+    if ((n1 && !f1) || (n2 && !f2)) { delete f1; delete f2; drop(); return DGPU_E_OOM; }
+    if (n1) *h1 = register_handle(f1, n1, 13);
+    if (n2) *h2 = register_handle(f2, n2, 14);
+    return DGPU_OK;
+}
+int32_t fold_apply(bool g2, uint64_t handle, const uint64_t *scalar, const uint64_t *addend, uint64_t *out, uint8_t *out_inf) {
+    if (!scalar || !out || !out_inf) return DGPU_E_BADARG;
+    HandleRef hb(handle);
+    if (!hb.ok || hb.h.kind != (g2 ? 14 : 13)) return DGPU_E_BADARG;
+    const FoldTab &ft = *(const FoldTab *)hb.h.p;
+    const size_t n = ft.n, pt = g2 ? 192 : 96, xw = g2 ? 96 : 48;
+    // the set bits of the split scalar name the table entries: G1 k = k1 + k2 lambda (entry k of k1, entry 128 + k — phi of entry k — of k2);
+    // G2 four base-|x| digits (entry 64 j + k of digit j)
+    uint16_t leaves[256]; int T = 0;
+    uint64_t split[4];
+    if (g2) hostf::gls4_decompose(scalar, split); else hostf::glv_decompose(scalar, &split[0], &split[2]);
+    for (int w = 0; w < 4; w++) for (int b = 0; b < 64; b++) if ((split[w] >> b) & 1) leaves[T++] = (uint16_t)(64 * w + b);
+    CtxScope on_owner(hb.h.ctx);
+    if (!cur().ready) return DGPU_E_NODEVICE;
+    SLOT_ACQUIRE(L, sl);
+    HIPCHK(hipSetDevice(cur().device));
+    int32_t rc;
+    // in_bases: the addends; in_scalars: the leaf list; prepped: [sum as XYZZ | affine out | flags]
+    if ((rc = sl.in_bases.ensure(n * pt))) return rc;
+    if ((rc = sl.in_scalars.ensure(512))) return rc;
+    if ((rc = sl.prepped.ensure(n * (xw * 4 + pt + 1)))) return rc;
+    hipStream_t s = sl.stream;
+    const uint32_t *dadd = nullptr;
+    if (addend) { HIPCHK(hipMemcpyAsync(sl.in_bases.p, addend, n * pt, hipMemcpyHostToDevice, s)); dadd = sl.in_bases.as<uint32_t>(); }
+    HIPCHK(hipMemcpyAsync(sl.in_scalars.p, leaves, 512, hipMemcpyHostToDevice, s));
+    uint32_t *dx = sl.prepped.as<uint32_t>(), *dout = dx + n * xw; uint8_t *dinf = (uint8_t *)(dout + n * pt / 4);
+    { StageTimer st(sl, "fixed.fold_apply");
+      msm::launch_fold_apply(s, g2, (const uint32_t *)ft.tab, (const uint8_t *)ft.tab + n * fold_words(g2) * 4, sl.in_scalars.as<uint16_t>(), T, dadd, n, dx, dinf, dout); }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, dout, n * pt, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(out_inf, dinf, n, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (gs.prof) prof_flush(sl);
+    return DGPU_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -163,6 +256,23 @@ int32_t dgpu_g1_mul_add_batch(const uint64_t *p, const uint8_t *p_inf, const uin
 }
 int32_t dgpu_g2_mul_add_batch(const uint64_t *p, const uint8_t *p_inf, const uint64_t *sc, size_t stride, const uint64_t *add, const uint8_t *add_inf, size_t n, uint64_t *out, uint8_t *out_inf) {
     return mul_add<G2>(p, p_inf, sc, stride, add, add_inf, n, out, out_inf);
+}
+int32_t dgpu_g1_fold_prepare(const uint64_t *p, size_t n, uint64_t *handle) { return n ? fold_prepare(p, n, handle, nullptr, 0, nullptr) : DGPU_E_BADARG; }
+int32_t dgpu_g2_fold_prepare(const uint64_t *p, size_t n, uint64_t *handle) { return n ? fold_prepare(nullptr, 0, nullptr, p, n, handle) : DGPU_E_BADARG; }
+int32_t dgpu_fold_prepare_pair(const uint64_t *g1_xy, size_t n1, uint64_t *g1_handle, const uint64_t *g2_xy, size_t n2, uint64_t *g2_handle) {
+    if (g1_handle) *g1_handle = 0;
+    if (g2_handle) *g2_handle = 0;
+    return fold_prepare(g1_xy, n1, g1_handle, g2_xy, n2, g2_handle);
+}
+int32_t dgpu_g1_fold_apply(uint64_t handle, const uint64_t scalar[4], const uint64_t *addend, uint64_t *out, uint8_t *out_inf) { return fold_apply(false, handle, scalar, addend, out, out_inf); }
+int32_t dgpu_g2_fold_apply(uint64_t handle, const uint64_t scalar[4], const uint64_t *addend, uint64_t *out, uint8_t *out_inf) { return fold_apply(true, handle, scalar, addend, out, out_inf); }
+int32_t dgpu_fold_free(uint64_t handle) {
+    Handle h;
+    if (!take_handle(handle, [](int k) { return k == 13 || k == 14; }, h)) return DGPU_E_BADARG;
+    FoldTab *ft = (FoldTab *)h.p;
+    { CtxScope on_owner(h.ctx); if (cur().device >= 0) (void)hipSetDevice(cur().device); fold_release(h.ctx, ft->tab, ft->bytes); }
+    delete ft;
+    return DGPU_OK;
 }
 int32_t dgpu_window_table_g1(const uint64_t base_xy[12], uint64_t *handle) { return table_build<G1, hostf::Fq>(base_xy, handle, 5); }
 int32_t dgpu_window_table_g2(const uint64_t base_xy[24], uint64_t *handle) { return table_build<G2, hostf::Fq2>(base_xy, handle, 6); }

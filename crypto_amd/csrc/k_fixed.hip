@@ -1,6 +1,7 @@
 // crypto_amd/csrc/k_fixed.hip — translation unit of the fixed-base kernels (G1 and G2).
 #include <cstdlib>
 #include "fixed_kernels.hip.h"
+#include "fold_kernels.hip.h"
 #include "fixed_launch.hip.h"
 
 namespace msm {
@@ -38,4 +39,22 @@ template void launch_fb_table<G1>(hipStream_t, const uint32_t *, uint32_t *);
 template void launch_fb_table<G2>(hipStream_t, const uint32_t *, uint32_t *);
 template void launch_fb_mul<G1>(hipStream_t, const uint32_t *, const uint32_t *, size_t, uint32_t *, uint8_t *);
 template void launch_fb_mul<G2>(hipStream_t, const uint32_t *, const uint32_t *, size_t, uint32_t *, uint8_t *);
+// the folding step with its doubling chains done ahead of the scalar (fold_kernels.hip.h)
+static_assert(FOLD_TABLE_WORDS_G1 == FOLD_E1 * FOLD_PW1 && FOLD_TABLE_WORDS_G2 == FOLD_E2 * FOLD_PW2, "fold table size");
+void launch_fold_chain(hipStream_t s, const uint32_t *p1, size_t n1, uint32_t *tab1, uint8_t *inf1, const uint32_t *p2, size_t n2, uint32_t *tab2, uint8_t *inf2) {
+    const unsigned blocks1 = (unsigned)((2 * n1 + 63) / 64), blocks2 = (unsigned)((16 * n2 + 63) / 64);
+    if (blocks1 + blocks2 == 0) return;
+    hipLaunchKernelGGL((k_fold_chain<G1>), dim3(blocks1 + blocks2), dim3(64), 0, s, p1, n1, tab1, inf1, blocks1, p2, n2, tab2, inf2);
+}
+void launch_fold_apply(hipStream_t s, bool g2, const uint32_t *tab, const uint8_t *tab_inf, const uint16_t *leaves, int T, const uint32_t *add_abi, size_t n, uint32_t *xyzz, uint8_t *out_inf, uint32_t *out_abi) {
+    if (g2) {
+        if (n <= 256) hipLaunchKernelGGL((k_fold_tree<G2P, 64>), dim3((unsigned)n), dim3(512), 0, s, tab, tab_inf, FOLD_E2, leaves, T, 1 << 30, add_abi, n, xyzz, out_inf);
+        else hipLaunchKernelGGL((k_fold_tree<G2P, 16>), dim3((unsigned)((n + 3) / 4)), dim3(512), 0, s, tab, tab_inf, FOLD_E2, leaves, T, 1 << 30, add_abi, n, xyzz, out_inf);
+        hipLaunchKernelGGL((k_fold_affine_g2<G2>), dim3((unsigned)((2 * n + 63) / 64)), dim3(64), 0, s, (const uint32_t *)xyzz, (const uint8_t *)out_inf, n, out_abi);
+    } else {
+        if (n <= 256) hipLaunchKernelGGL((k_fold_tree<G1S, 64>), dim3((unsigned)n), dim3(256), 0, s, tab, tab_inf, FOLD_E1, leaves, T, FOLD_E1, add_abi, n, xyzz, out_inf);
+        else hipLaunchKernelGGL((k_fold_tree<G1S, 16>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, tab, tab_inf, FOLD_E1, leaves, T, FOLD_E1, add_abi, n, xyzz, out_inf);
+        hipLaunchKernelGGL((k_fold_affine_g1<G1>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, (const uint32_t *)xyzz, (const uint8_t *)out_inf, n, out_abi);
+    }
+}
 }  // namespace msm

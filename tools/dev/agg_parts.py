@@ -12,7 +12,7 @@ ints = lambda k: [int.from_bytes(rng.bytes(40), "little") % (U.R - 1) + 1 for _ 
 def fixed(curve, g, ks):
     with WindowTable(curve, g, len(ks)) as t:
         return t.multiply_many(ks)[0]
-g, h = O.G1.to_affine(O.G1.generator())[0], O.G2.to_affine(O.G2.generator())[0]
+g, h = O.G1.generator(), O.G2.generator()
 def timed(f, k=10):
     f(); f(); t0 = time.perf_counter()
     for _ in range(k): r = f()

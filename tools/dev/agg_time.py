@@ -13,7 +13,7 @@ ints = lambda k: [int.from_bytes(rng.bytes(40), "little") % (U.R - 1) + 1 for _ 
 def fixed(curve, g, ks):
     with WindowTable(curve, g, len(ks)) as t:
         return t.multiply_many(ks)[0]
-g, h = O.G1.to_affine(O.G1.generator())[0], O.G2.to_affine(O.G2.generator())[0]
+g, h = O.G1.generator(), O.G2.generator()
 A, Cc, D = fixed(ca.G1, g, ints(n)), fixed(ca.G1, g, ints(n)), fixed(ca.G1, g, ints(n)); B = fixed(ca.G2, h, ints(n))
 proofs = [{"a": A[i], "b": B[i], "c": Cc[i], "d": D[i]} for i in range(n)]
 pk, vsrs = AG.setup_fake_srs(ints(1)[0], ints(1)[0], n, g, h).specialize(n)

@@ -5,7 +5,7 @@ import torch
 import oracle_c as O, util as U, crypto_amd as ca
 from crypto_amd.aggregation import ops
 ca.init(0)
-g, h = O.G1.to_affine(O.G1.generator())[0], O.G2.to_affine(O.G2.generator())[0]
+g, h = O.G1.generator(), O.G2.generator()
 e11 = O.final_exponentiation(O.multi_miller_loop(g.reshape(1, 12), h.reshape(1, 24)))
 rng = np.random.default_rng(1)
 ints = lambda k: [int.from_bytes(rng.bytes(40), "little") % U.R for _ in range(k)]

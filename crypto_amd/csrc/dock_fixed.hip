@@ -175,9 +175,20 @@ void *fold_alloc(size_t bytes, size_t &got) {
     return p;
 }
 void fold_release(int ctx, void *p, size_t bytes) {
-    bool keep = false;
-    { std::lock_guard<std::mutex> lk(gs.mu); auto &pool = ctxs[ctx].fold_pool; if (ctxs[ctx].ready.load() && pool.size() < 4) { pool.push_back({p, bytes}); keep = true; } }
-    if (!keep) (void)hipFree(p);
+    void *drop = p;                                   // up to four buffers are kept; a larger one displaces the smallest
+    {
+        std::lock_guard<std::mutex> lk(gs.mu);
+        auto &pool = ctxs[ctx].fold_pool;
+        if (ctxs[ctx].ready.load()) {
+            if (pool.size() < 4) { pool.push_back({p, bytes}); drop = nullptr; }
+            else {
+                size_t least = 0;
+                for (size_t k = 1; k < pool.size(); k++) if (pool[k].second < pool[least].second) least = k;
+                if (pool[least].second < bytes) { drop = pool[least].first; pool[least] = {p, bytes}; }
+            }
+        }
+    }
+    if (drop) (void)hipFree(drop);
 }
 // the chains of a G1 and a G2 point set in one launch (either set may be empty: then its handle stays 0)
 int32_t fold_prepare(const uint64_t *p1, size_t n1, uint64_t *h1, const uint64_t *p2, size_t n2, uint64_t *h2) {

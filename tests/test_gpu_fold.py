@@ -95,12 +95,16 @@ def test_fold_sizes_and_reuse(curve, n):
         out = np.zeros_like(P); inf = np.zeros(n, np.uint8)
         assert getattr(lib(), "dgpu_%s_fold_apply" % g)(h.value, p(limbs(c)), p(A), p(out), p(inf)) == 0
         assert (out == ops.mul_add(cv, P, c, A)).all()
-    a0 = ca.device_alloc_count()
     assert lib().dgpu_fold_free(h.value) == 0
     h2 = C.c_uint64(0)
-    assert getattr(lib(), "dgpu_%s_fold_prepare" % g)(p(P[:max(1, n // 2)]), max(1, n // 2), C.byref(h2)) == 0       # the halved vector of the next round
-    assert ca.device_alloc_count() == a0                                  # ... lives in the buffer the first table left behind
-    assert lib().dgpu_fold_free(h2.value) == 0
+    half = max(1, n // 2)
+    for _ in range(8):                                                    # (every slot's staging buffer has grown after a pass over the six slots)
+        assert getattr(lib(), "dgpu_%s_fold_prepare" % g)(p(P[:half]), half, C.byref(h2)) == 0 and lib().dgpu_fold_free(h2.value) == 0
+    a0 = ca.device_alloc_count()
+    for _ in range(8):
+        assert getattr(lib(), "dgpu_%s_fold_prepare" % g)(p(P[:half]), half, C.byref(h2)) == 0       # the halved vector of the next round ...
+        assert lib().dgpu_fold_free(h2.value) == 0
+    assert ca.device_alloc_count() == a0                                  # ... lives in a buffer an earlier table left behind
     # argument checks
     assert getattr(lib(), "dgpu_%s_fold_apply" % g)(h.value, p(limbs(1)), None, p(out), p(inf)) == -3              # a freed handle
     assert getattr(lib(), "dgpu_%s_fold_prepare" % g)(None, 3, C.byref(h2)) == -3

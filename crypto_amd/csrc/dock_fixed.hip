@@ -268,22 +268,25 @@ int32_t dgpu_g1_mul_add_batch(const uint64_t *p, const uint8_t *p_inf, const uin
 int32_t dgpu_g2_mul_add_batch(const uint64_t *p, const uint8_t *p_inf, const uint64_t *sc, size_t stride, const uint64_t *add, const uint8_t *add_inf, size_t n, uint64_t *out, uint8_t *out_inf) {
     return mul_add<G2>(p, p_inf, sc, stride, add, add_inf, n, out, out_inf);
 }
-int32_t dgpu_g1_fold_prepare(const uint64_t *p, size_t n, uint64_t *handle) { return n ? fold_prepare(p, n, handle, nullptr, 0, nullptr) : DGPU_E_BADARG; }
-int32_t dgpu_g2_fold_prepare(const uint64_t *p, size_t n, uint64_t *handle) { return n ? fold_prepare(nullptr, 0, nullptr, p, n, handle) : DGPU_E_BADARG; }
+// (nothing unwinds through the ABI: the pool and the handle table allocate)
+int32_t dgpu_g1_fold_prepare(const uint64_t *p, size_t n, uint64_t *handle) { return abi_guard([&] { return n ? fold_prepare(p, n, handle, nullptr, 0, nullptr) : (int32_t)DGPU_E_BADARG; }); }
+int32_t dgpu_g2_fold_prepare(const uint64_t *p, size_t n, uint64_t *handle) { return abi_guard([&] { return n ? fold_prepare(nullptr, 0, nullptr, p, n, handle) : (int32_t)DGPU_E_BADARG; }); }
 int32_t dgpu_fold_prepare_pair(const uint64_t *g1_xy, size_t n1, uint64_t *g1_handle, const uint64_t *g2_xy, size_t n2, uint64_t *g2_handle) {
     if (g1_handle) *g1_handle = 0;
     if (g2_handle) *g2_handle = 0;
-    return fold_prepare(g1_xy, n1, g1_handle, g2_xy, n2, g2_handle);
+    return abi_guard([&] { return fold_prepare(g1_xy, n1, g1_handle, g2_xy, n2, g2_handle); });
 }
-int32_t dgpu_g1_fold_apply(uint64_t handle, const uint64_t scalar[4], const uint64_t *addend, uint64_t *out, uint8_t *out_inf) { return fold_apply(false, handle, scalar, addend, out, out_inf); }
-int32_t dgpu_g2_fold_apply(uint64_t handle, const uint64_t scalar[4], const uint64_t *addend, uint64_t *out, uint8_t *out_inf) { return fold_apply(true, handle, scalar, addend, out, out_inf); }
+int32_t dgpu_g1_fold_apply(uint64_t handle, const uint64_t scalar[4], const uint64_t *addend, uint64_t *out, uint8_t *out_inf) { return abi_guard([&] { return fold_apply(false, handle, scalar, addend, out, out_inf); }); }
+int32_t dgpu_g2_fold_apply(uint64_t handle, const uint64_t scalar[4], const uint64_t *addend, uint64_t *out, uint8_t *out_inf) { return abi_guard([&] { return fold_apply(true, handle, scalar, addend, out, out_inf); }); }
 int32_t dgpu_fold_free(uint64_t handle) {
+    return abi_guard([&]() -> int32_t {
     Handle h;
     if (!take_handle(handle, [](int k) { return k == 13 || k == 14; }, h)) return DGPU_E_BADARG;
     FoldTab *ft = (FoldTab *)h.p;
     { CtxScope on_owner(h.ctx); if (cur().device >= 0) (void)hipSetDevice(cur().device); fold_release(h.ctx, ft->tab, ft->bytes); }
     delete ft;
     return DGPU_OK;
+    });
 }
 int32_t dgpu_window_table_g1(const uint64_t base_xy[12], uint64_t *handle) { return table_build<G1, hostf::Fq>(base_xy, handle, 5); }
 int32_t dgpu_window_table_g2(const uint64_t base_xy[24], uint64_t *handle) { return table_build<G2, hostf::Fq2>(base_xy, handle, 6); }

@@ -107,6 +107,8 @@ static void destroy_slot(Slot &sl) {
     if (sl.cstream) (void)hipStreamDestroy(sl.cstream);
     for (hipEvent_t &e : sl.copy_ev) { if (e) (void)hipEventDestroy(e); e = nullptr; }
     if (sl.hpin) (void)hipHostFree(sl.hpin);
+    if (sl.hpin2) (void)hipHostFree(sl.hpin2);
+    sl.hpin2 = nullptr; sl.hpin2_bytes = 0;
     sl.stream = nullptr; sl.cstream = nullptr; sl.hpin = nullptr;
 }
 static int32_t init_ctx_slots(Ctx &c) {

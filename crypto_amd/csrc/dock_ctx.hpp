@@ -63,6 +63,7 @@ struct Slot {
     hipStream_t xstream = nullptr;  // a third stream: the products of a Miller loop's middle piece (dock_pairing.hip: ml_pipelined)
     void *hpin = nullptr;           // pinned host scratch (HPIN_BYTES): results a host thread consumes while the slot's streams keep running
     static constexpr size_t HPIN_BYTES = 64 * 1024;
+    void *hpin2 = nullptr; size_t hpin2_bytes = 0;      // a second, grow-only pinned buffer: the per-step products of a segmented Miller loop (dock_pairing.hip ml_segments)
     hipEvent_t copy_ev[N_COPY_EV + 1] = {};
     unsigned ev_next = 0;           // next event to record (taken in turn)
     Buf flags, in_bases, in_inf, in_scalars, prepped, digits, heavy, cnt, off, cursor, bsums, entries, bucket, bucket_inf, head, tail, head_b, tail_b, part_inf, l1, l1_inf, win, win_inf, ml_lines, ml_partial, ml_out, ml_coeffs, ml_state, dyn, hpart, hpart_inf, small_cnt;

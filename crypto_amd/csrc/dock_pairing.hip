@@ -453,14 +453,14 @@ typedef Fp6T<Fp2H> Fp6p;
 typedef Fp12T<Fp2H> Fp12p;
 // seg_off != nullptr: nseg independent products over the pairs [seg_off[g], seg_off[g + 1]) of one line buffer (dgpu_multi_miller_loop_segments);
 // partial (g * N_LINES + s) * nsl + j is slice j of step s of segment g, slices past the end of a segment are not written.
-// s0, ns: the steps s0 .. s0 + ns - 1 only (a call whose line kernel runs in two launches; nseg == 1 then).
+// s0, ns: the steps s0 .. s0 + ns - 1 only, of every segment (a call whose line kernel runs in several launches).
 __global__ void __launch_bounds__(64) k_line_products(const uint32_t *__restrict__ lines, size_t n, int slice_len, int nsl, uint32_t *__restrict__ partial,
                                                       const uint32_t *__restrict__ seg_off, int nseg, int s0 = 0, int ns = N_LINES, const uint32_t *__restrict__ pxy = nullptr) {
     int t = (int)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 1);
     const uint32_t h = threadIdx.x & 1u;
     if (t >= ns * nsl * nseg) return;
-    t += s0 * nsl;
-    const int sg = t / nsl, j = t % nsl, s = sg % N_LINES, g = sg / N_LINES;
+    const int per = ns * nsl, g = t / per, rem = t % per, s = s0 + rem / nsl, j = rem % nsl;      // (segment, step of the range, slice)
+    t = (g * N_LINES + s) * nsl + j;
     const size_t first = seg_off ? seg_off[g] : 0, last = seg_off ? seg_off[g + 1] : n;
     // slice j of the `have` slices of this (segment, step) is the pairs first + j, first + j + have, ...: neighbouring lane pairs read
     // neighbouring pairs of a row (full 128-B lines; contiguous slices made every lane of a wave touch its own line: 37 -> 9 ms of
@@ -496,9 +496,10 @@ __global__ void __launch_bounds__(64) k_line_products(const uint32_t *__restrict
 constexpr int F6W = 6 * NL;
 // seg_off != nullptr (one level, ngroups == 1): s runs over (segment, step) and the number of partials is the segment's own slice count.
 __global__ void __launch_bounds__(192) k_product_tree(const uint32_t *__restrict__ partial, int nsl, int ngroups, uint32_t *__restrict__ next, uint32_t *__restrict__ out_abi,
-                                                      const uint32_t *__restrict__ seg_off, int slice_len, int s0 = 0) {
+                                                      const uint32_t *__restrict__ seg_off, int slice_len, int s0 = 0, int ns = N_LINES) {
     __shared__ uint32_t sh[F12W * MAX_SLICES];                        // word k of slot j at sh[k * 64 + j]
-    const int s = s0 + blockIdx.x / ngroups, grp = blockIdx.x % ngroups, t = threadIdx.x;
+    const int node = blockIdx.x / ngroups, grp = blockIdx.x % ngroups, t = threadIdx.x;
+    const int s = seg_off ? (node / ns) * N_LINES + s0 + node % ns : s0 + node;
     int have = nsl;
     if (seg_off) { const int g = s / N_LINES; have = (int)((seg_off[g + 1] - seg_off[g] + slice_len - 1) / slice_len); }
     const int cnt = min(MAX_SLICES, have - grp * MAX_SLICES);       // partials in this group
@@ -561,11 +562,12 @@ constexpr int T18_NODES = 16, T18_PAIRS = T18_NODES * 18, T18_THREADS = 2 * T18_
 constexpr int T18_SLOT = F12W + 1;        // slot-major with an odd stride: the lanes of a node read DIFFERENT words of the SAME slot (word-major put them all in one bank)
 constexpr size_t T18_LDS = ((size_t)T18_SLOT * MAX_SLICES + (size_t)NL * T18_THREADS) * 4;
 __global__ void __launch_bounds__(T18_THREADS) k_product_tree18(const uint32_t *__restrict__ partial, int nsl, int ngroups, uint32_t *__restrict__ next, uint32_t *__restrict__ out_abi,
-                                                                const uint32_t *__restrict__ seg_off, int slice_len, int s0 = 0) {
+                                                                const uint32_t *__restrict__ seg_off, int slice_len, int s0 = 0, int ns = N_LINES) {
     extern __shared__ uint32_t lds18[];
     uint32_t *sh = lds18;                                            // word k of slot j at sh[j * T18_SLOT + k]
     uint32_t *pr = lds18 + T18_SLOT * MAX_SLICES;                        // word j of this pass's product of lane t at pr[j * T18_THREADS + t]
-    const int s = s0 + blockIdx.x / ngroups, grp = blockIdx.x % ngroups, t = threadIdx.x;
+    const int node = blockIdx.x / ngroups, grp = blockIdx.x % ngroups, t = threadIdx.x;
+    const int s = seg_off ? (node / ns) * N_LINES + s0 + node % ns : s0 + node;      // segments: steps s0 .. s0 + ns - 1 of every segment
     int have = nsl;
     if (seg_off) { const int g = s / N_LINES; have = (int)((seg_off[g + 1] - seg_off[g] + slice_len - 1) / slice_len); }
     const int cnt = min(MAX_SLICES, have - grp * MAX_SLICES);
@@ -645,14 +647,14 @@ __global__ void __launch_bounds__(T18_THREADS) k_product_tree18(const uint32_t *
     }
 }
 // one launcher for both tree kernels (gs.ml_mode bit 1: the 18-role form)
-static void launch_product_tree(hipStream_t st, unsigned blocks, const uint32_t *partial, int nsl, int ngroups, uint32_t *next, uint32_t *out_abi, const uint32_t *seg_off, int slice_len, int s0) {
+static void launch_product_tree(hipStream_t st, unsigned blocks, const uint32_t *partial, int nsl, int ngroups, uint32_t *next, uint32_t *out_abi, const uint32_t *seg_off, int slice_len, int s0, int ns = N_LINES) {
     if (gs.ml_mode.load() & 2) {
         static std::atomic<uint32_t> done{0};
         { int dev = 0; (void)hipGetDevice(&dev); const uint32_t bit = 1u << (dev & 31);
           if (!(done.load() & bit)) { (void)hipFuncSetAttribute((const void *)k_product_tree18, hipFuncAttributeMaxDynamicSharedMemorySize, (int)T18_LDS); done.fetch_or(bit); } }
-        hipLaunchKernelGGL(k_product_tree18, dim3(blocks), dim3(T18_THREADS), T18_LDS, st, partial, nsl, ngroups, next, out_abi, seg_off, slice_len, s0);
+        hipLaunchKernelGGL(k_product_tree18, dim3(blocks), dim3(T18_THREADS), T18_LDS, st, partial, nsl, ngroups, next, out_abi, seg_off, slice_len, s0, ns);
     } else
-        hipLaunchKernelGGL(k_product_tree, dim3(blocks), dim3(192), 0, st, partial, nsl, ngroups, next, out_abi, seg_off, slice_len, s0);
+        hipLaunchKernelGGL(k_product_tree, dim3(blocks), dim3(192), 0, st, partial, nsl, ngroups, next, out_abi, seg_off, slice_len, s0, ns);
 }
 
 // Slices of pairs per step.  A lane multiplies its slice's lines into one partial (sparse products, serial), then 64-wide trees fold
@@ -897,8 +899,18 @@ static int32_t ml_segments(const uint64_t *p, const uint64_t *q, const uint8_t *
     if ((rc = sl.ml_lines.ensure((size_t)N_LINES * LW * n * 4))) return rc;
     if ((rc = sl.ml_partial.ensure((size_t)N_LINES * nseg * nsl * F12W * 4))) return rc;
     if ((rc = sl.ml_out.ensure((size_t)N_LINES * nseg * 144 * 4))) return rc;
-    if ((rc = sl.ml_state.ensure((size_t)2 * NL * n * 4))) return rc;                 // px, py of every pair for the product kernel
-    uint32_t *pxy = sl.ml_state.as<uint32_t>();
+    // pieces: like ml_pipelined, the chain runs in ML_PIECES launches; the products and trees of a finished piece (every segment's) run on a side stream
+    // under the next piece, its results land in pinned memory, and the host tails of the segments advance piece by piece on the library's threads —
+    // what is left when the chain ends is the last piece's share of the tail and the final exponentiations (a GIPA round: 1.8 -> 1.5 ms)
+    const size_t pin_bytes = (size_t)N_LINES * nseg * 576;
+    const bool pieces = n <= 8192 && (gs.ml_mode.load() & 1) && pin_bytes <= ((size_t)4 << 20);
+    if ((rc = sl.ml_state.ensure(((size_t)(pieces ? 3 * NL * 4 : 0) * n + (size_t)2 * NL * n) * 4))) return rc;      // (R of every lane,) px, py of every pair for the product kernel
+    uint32_t *state = sl.ml_state.as<uint32_t>(), *pxy = state + (size_t)(pieces ? 3 * NL * 4 : 0) * n;
+    if (pieces && sl.hpin2_bytes < pin_bytes) {
+        if (sl.hpin2) { (void)hipHostFree(sl.hpin2); sl.hpin2 = nullptr; sl.hpin2_bytes = 0; }
+        if (hipHostMalloc(&sl.hpin2, pin_bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); sl.hpin2 = nullptr; return DGPU_E_OOM; }
+        sl.hpin2_bytes = pin_bytes;
+    }
     hipStream_t s = sl.stream;
     HIPCHK(hipMemcpyAsync(sl.in_bases.p, p, n * 96, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(sl.in_scalars.p, q, n * 192, hipMemcpyHostToDevice, s));
@@ -906,6 +918,54 @@ static int32_t ml_segments(const uint64_t *p, const uint64_t *q, const uint8_t *
     if (skip) { HIPCHK(hipMemcpyAsync(sl.in_inf.p, skip, n, hipMemcpyHostToDevice, s)); dskip = sl.in_inf.as<uint8_t>(); }
     uint32_t *doff = (uint32_t *)(sl.in_inf.as<uint8_t>() + ((n + 7) & ~(size_t)7));
     HIPCHK(hipMemcpyAsync(doff, off.data(), (nseg + 1) * 4, hipMemcpyHostToDevice, s));
+    if (pieces) {
+        hipStream_t sa = s, side[2] = {sl.cstream, sl.xstream};
+        hostf::Fq12 *Lp = (hostf::Fq12 *)sl.hpin2;                          // [segment][step]
+        rc = DGPU_OK;
+        auto ok = [&](hipError_t e) { if (e != hipSuccess && !rc) rc = DGPU_E_HIP; return rc == DGPU_OK; };
+        hipEvent_t ready[ML_PIECES] = {}, done[ML_PIECES] = {};
+        int first_step[ML_PIECES], steps[ML_PIECES];
+        { int s_first = 0, b_hi = 62;
+          for (int j = 0; j < ML_PIECES && !rc; j++) {
+              const int b_lo = ML_CUTS[j], ns = ml_steps(b_hi, b_lo);
+              first_step[j] = s_first; steps[j] = ns;
+              launch_lines_uneval(sa, sl.in_bases.as<uint32_t>(), sl.in_scalars.as<uint32_t>(), dskip, n, sl.ml_lines.as<uint32_t>(), n, b_hi, b_lo, s_first, state, pxy);
+              if (j + 1 < ML_PIECES) { ready[j] = sl.copy_ev[sl.ev_next++ % (Slot::N_COPY_EV + 1)]; ok(hipEventRecord(ready[j], sa)); }
+              s_first += ns; b_hi = b_lo - 1;
+          } }
+        for (int j = 0; j < ML_PIECES && !rc; j++) {
+            hipStream_t sp = j + 1 < ML_PIECES ? side[j & 1] : sa;
+            if (j + 1 < ML_PIECES && !ok(hipStreamWaitEvent(sp, ready[j], 0))) break;
+            const int s0 = first_step[j], ns = steps[j];
+            hipLaunchKernelGGL(k_line_products, dim3((unsigned)((2 * (size_t)ns * nsl * nseg + 63) / 64)), dim3(64), 0, sp, sl.ml_lines.as<uint32_t>(), n, slice_len, nsl, sl.ml_partial.as<uint32_t>(), doff, (int)nseg,
+                               s0, ns, (const uint32_t *)pxy);
+            launch_product_tree(sp, (unsigned)(ns * nseg), sl.ml_partial.as<uint32_t>(), nsl, 1, (uint32_t *)nullptr, sl.ml_out.as<uint32_t>(), doff, slice_len, s0, ns);
+            ok(hipMemcpy2DAsync(Lp + s0, (size_t)N_LINES * 576, (const char *)sl.ml_out.p + (size_t)s0 * 576, (size_t)N_LINES * 576, (size_t)ns * 576, nseg, hipMemcpyDeviceToHost, sp));
+            done[j] = sl.copy_ev[sl.ev_next++ % (Slot::N_COPY_EV + 1)];
+            ok(hipEventRecord(done[j], sp));
+        }
+        ok(hipGetLastError());
+        if (!rc) {
+            const int device = cur().device;
+            const size_t T = std::min<size_t>(std::min<size_t>(nseg, 16), std::max<size_t>(1, std::thread::hardware_concurrency()));
+            const int32_t prc = par_run(T, [&](size_t k) -> int32_t {
+                if (hipSetDevice(device) != hipSuccess) return DGPU_E_HIP;
+                std::vector<MlTail> tails((nseg - k + T - 1) / T);
+                for (int j = 0; j < ML_PIECES; j++) {
+                    if (hipEventSynchronize(done[j]) != hipSuccess) return DGPU_E_HIP;
+                    size_t m = 0;
+                    for (size_t g = k; g < nseg; g += T, m++) if (off[g + 1] != off[g]) tails[m].run(Lp + g * N_LINES, ML_CUTS[j]);
+                }
+                size_t m = 0;
+                for (size_t g = k; g < nseg; g += T, m++) { const hostf::Fq12 f = off[g + 1] == off[g] ? one : tails[m].result(); memcpy(out + g * 72, &f, sizeof f); finish(out + g * 72); }
+                return DGPU_OK; });
+            if (prc && !rc) rc = prc;
+        }
+        ok(hipStreamSynchronize(sa)); ok(hipStreamSynchronize(side[0])); ok(hipStreamSynchronize(side[1]));      // (nothing of this call stays in flight, whatever happened)
+        if (gs.prof) prof_flush(sl);
+        if (rc) return rc;
+        return zero ? DGPU_E_ZERO : DGPU_OK;
+    }
     { StageTimer st(sl, "ml.lines");
       if (n > 8192) hipLaunchKernelGGL(k_miller_lines_pair, dim3((unsigned)((2 * n + 63) / 64)), dim3(64), 0, s, sl.in_bases.as<uint32_t>(), sl.in_scalars.as<uint32_t>(), dskip, n, sl.ml_lines.as<uint32_t>(), n);
       else launch_lines_uneval(s, sl.in_bases.as<uint32_t>(), sl.in_scalars.as<uint32_t>(), dskip, n, sl.ml_lines.as<uint32_t>(), n,

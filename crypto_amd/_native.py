@@ -86,6 +86,12 @@ def lib():
             raise ImportError(
                 "crypto_amd: %s is missing — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(there is no CPU fallback)" % _SO)
+        # A process that also uses torch (device memory, streams, torch.distributed) must load torch's bundled HIP runtime FIRST: with the library's
+        # runtime loaded before it the process holds two of them and dgpu_init answers DGPU_E_NODEVICE.  So torch goes first whenever it is there.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(_SO)
         for s in SYMBOLS:
             getattr(L, s).restype = C.c_int32

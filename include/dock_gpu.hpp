@@ -10,6 +10,8 @@
 //   ark-ec Pairing::{multi_miller_loop, final_exponentiation, multi_pairing} (utils/src/randomized_pairing_check.rs:207,213,
 //       legogroth16/src/verifier.rs:69-78)                        -> dock_gpu::multi_miller_loop / final_exponentiation / multi_pairing
 //   ProvingKey queries kept on the device (legogroth16/src/data_structures.rs:151-168) -> dock_gpu::DeviceBases<G>
+//   dock_crypto_utils::randomized_pairing_check::RandomizedPairingChecker, randomized_mult_checker::RandomizedMultChecker -> the same names
+//   legogroth16 aggregation (aggregate_proofs / verify_aggregate_proof)                -> dock_gpu::aggregation::*
 //
 // Errors: arkworks' MSM has no failure mode; here a negative ABI code throws dock_gpu::Error (a Rust shim falls back to arkworks
 // instead).  `msm` keeps arkworks' checked-length contract: Err(min_len) when the lengths differ.
@@ -282,6 +284,43 @@ public:
         const auto gt = final_exponentiation(left);
         if (!gt) throw Error(DGPU_E_ZERO, "final_exponentiation");              // arkworks: .unwrap() panics
         return *gt == right_;
+    }
+};
+
+// ---- RandomizedMultChecker (utils/src/randomized_mult_checker.rs:11-118) over the MSM entry points ------------------------------------------------
+// Many claimed scalar multiplications / small MSMs `sum_i s_i P_i == T` batched with the powers of a random scalar into ONE variable-base MSM whose
+// result must be the identity (`G::Group::msm_unchecked(&points, &scalars).is_zero()`, :100 — one of the reference's large-n MSM call sites).  Same
+// state and merging rule: `args` maps a point's x coordinate to (scalar, point), so a point and its negative share an entry (:104-117); the identity
+// is ignored.  crypto_amd/mult_checker.py is the same type for the Python tests.
+template <class G> class RandomizedMultChecker {
+    using Affine = typename G::Affine;
+    struct Entry { BigInt256 s; Affine p; };
+    std::vector<Entry> args_;                                   // (a linear scan over x: the reference's BTreeMap keyed by x, same merging)
+    BigInt256 random_, current_random_{1, 0, 0, 0};
+    static BigInt256 neg_mod(const BigInt256 &a) { BigInt256 z{}; if (a == z) return a; BigInt256 r = detail::FR_MODULUS; unsigned __int128 br = 0; for (int i = 0; i < 4; i++) { unsigned __int128 d = (unsigned __int128)r[i] - a[i] - (uint64_t)br; r[i] = (uint64_t)d; br = (d >> 64) & 1; } return r; }
+    void add(const Affine &p, const BigInt256 &s) {             // :104-117
+        if (p.infinity) return;
+        for (auto &e : args_)
+            if (std::memcmp(&e.p.x, &p.x, sizeof p.x) == 0) { e.s = detail::add_mod(e.s, std::memcmp(&e.p.y, &p.y, sizeof p.y) == 0 ? s : neg_mod(s)); return; }      // same x, other y: the stored point is -p
+        args_.push_back({s, p});
+    }
+public:
+    explicit RandomizedMultChecker(const BigInt256 &random) : random_(random) {}                       // new(random)  :20-26
+    size_t len() const { return args_.size(); }
+    // sum b_i a_i == t   :64-75 (add_1 / add_2 / add_3 are this with one, two, three terms, :32-61); scalars canonical (Fr::into_bigint)
+    void add_many(const std::vector<Affine> &a, const std::vector<BigInt256> &b, const Affine &t) {
+        if (a.size() != b.size()) throw Error(DGPU_E_LENGTH, "add_many");
+        for (size_t i = 0; i < a.size(); i++) add(a[i], detail::mul_mod(current_random_, b[i]));
+        add(t, neg_mod(current_random_));
+        current_random_ = detail::mul_mod(current_random_, random_);
+    }
+    void add_1(const Affine &p, const BigInt256 &s, const Affine &t) { add_many({p}, {s}, t); }
+    // :78-86: one MSM, result must be the identity
+    bool verify() const {
+        if (args_.empty()) return true;
+        std::vector<Affine> pts; std::vector<BigInt256> sc;
+        for (auto &e : args_) { pts.push_back(e.p); sc.push_back(e.s); }
+        return VariableBaseMSM<G>::msm_bigint(pts, sc).is_zero();
     }
 };
 

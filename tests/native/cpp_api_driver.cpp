@@ -208,6 +208,23 @@ int main() {
         }
         EXPECT(dgpu_r1cs_free(circ) == DGPU_OK);
     }
+    // RandomizedMultChecker: thirty claims s_i P_i == T_i (T by the oracle) and one two-term claim in ONE MSM; a wrong claim is caught; P and -P share an entry
+    {
+        RandomizedMultChecker<G1> chk(BigInt256{0x1234567, 99, 0, 0});
+        auto oracle_mul = [&](size_t i, const uint64_t *k) { uint64_t j[18]; G1::Affine t; orc_g1_mul(b1.data() + 12 * i, 0, k, j); uint64_t a12[12]; t.infinity = orc_g1_to_affine(j, a12) != 0; std::memcpy(&t.x, a12, 48); std::memcpy(&t.y, a12 + 6, 48); return t; };
+        for (size_t i = 20; i < 50; i++) chk.add_1(P1[i], big[i], oracle_mul(i, &sc[4 * i]));
+        { uint64_t two[18], pts[24], ks[8]; std::memcpy(pts, b1.data() + 12 * 60, 96); std::memcpy(pts + 12, b1.data() + 12 * 61, 96); std::memcpy(ks, &sc[4 * 60], 32); std::memcpy(ks + 4, &sc[4 * 61], 32);
+          EXPECT(dgpu_lincomb_g1(pts, nullptr, ks, 2, two) == DGPU_OK);
+          G1::Affine t; t.infinity = false; std::memcpy(&t.x, two, 48); std::memcpy(&t.y, two + 6, 48);
+          chk.add_many({P1[60], P1[61]}, {big[60], big[61]}, t); }
+        EXPECT(chk.verify());
+        G1::Affine minus = P1[20]; { uint64_t j[18], a12[12]; BigInt256 m1 = detail::FR_MODULUS; m1[0] -= 1; orc_g1_mul(b1.data() + 12 * 20, 0, m1.data(), j); orc_g1_to_affine(j, a12); std::memcpy(&minus.x, a12, 48); std::memcpy(&minus.y, a12 + 6, 48); }
+        const size_t before = chk.len();
+        chk.add_1(minus, BigInt256{5, 0, 0, 0}, oracle_mul(20, (BigInt256{detail::FR_MODULUS[0] - 5, detail::FR_MODULUS[1], detail::FR_MODULUS[2], detail::FR_MODULUS[3]}).data()));      // 5 (-P) == (r - 5) P
+        EXPECT(chk.len() <= before + 1 && chk.verify());        // -P merged into P's entry (only the target may be new)
+        chk.add_1(P1[70], big[70], P1[71]);                     // a false claim
+        EXPECT(!chk.verify());
+    }
     // SnarkPack aggregation through the C++ mirror (aggregation::aggregate_proofs / verify_aggregate_proof over dgpu_snarkpack_*): eight Groth16
     // statements with known discrete logs (e(A, B) = e(alpha, beta) e(k0 + x k1, gamma) e(C, delta) holds exactly), a toy transcript of the
     // caller's (the library only ever sees the two callbacks), then the reference's rejection cases (aggregation/tests.rs:117-330)

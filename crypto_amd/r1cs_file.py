@@ -12,6 +12,14 @@ BN128_ORDER = 218882428718392752222464057452572750885483644004160343436982041865
 
 class R1csFile:
     def __init__(self, data):
+        try:
+            self._parse(data)
+        except struct.error:                       # a truncated file is a parsing error like any other (never a struct.error for the caller)
+            raise ValueError("unexpected end of file") from None
+
+    def _parse(self, data):
+        if len(data) < 12:
+            raise ValueError("unexpected end of file")
         if data[:4] != b"r1cs":
             raise ValueError("Invalid magic number")
         version, nsec = struct.unpack_from("<II", data, 4)

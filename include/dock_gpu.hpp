@@ -324,6 +324,66 @@ public:
     }
 };
 
+// ---- Circom's binary `.r1cs` (legogroth16/src/circom/r1cs_reader.rs:16-140) -> the CSR matrices dgpu_r1cs_upload takes --------------------------------
+// magic "r1cs", version 1, sections {1: header, 2: constraints, 3: wire2label}; 32-byte little-endian field elements; a constraint is three linear
+// combinations (A, B, C) of (wire id, coefficient) terms.  Wire order is Circom's (0 = one, public outputs, public inputs, private inputs,
+// intermediates), i.e. the assignment order (1, instance..., witness...) of the witness map.  Errors are the reader's: std::runtime_error with its message.
+namespace circom {
+struct Csr { std::vector<uint64_t> rowptr{0}; std::vector<uint32_t> cols; std::vector<uint64_t> vals; };       // vals: 4 canonical words per entry
+struct R1CSFile {
+    BigInt256 prime{}; uint32_t n_wires = 0, n_pub_out = 0, n_pub_in = 0, n_prv_in = 0, n_constraints = 0; uint64_t n_labels = 0;
+    Csr a, b, c; std::vector<uint64_t> wire_mapping;
+    size_t num_inputs() const { return 1 + (size_t)n_pub_out + n_pub_in; }           // instance variables incl. the constant one
+    static R1CSFile parse(const uint8_t *d, size_t len) {
+        auto fail = [](const char *m) -> void { throw std::runtime_error(m); };
+        auto need = [&](size_t off, size_t cnt) { if (off > len || cnt > len - off) fail("unexpected end of file"); };
+        auto u32 = [&](size_t off) { need(off, 4); uint32_t v; std::memcpy(&v, d + off, 4); return v; };
+        auto u64 = [&](size_t off) { need(off, 8); uint64_t v; std::memcpy(&v, d + off, 8); return v; };
+        need(0, 12);
+        if (std::memcmp(d, "r1cs", 4) != 0) fail("Invalid magic number");
+        if (u32(4) != 1) fail("Unsupported version");
+        size_t off = 12, sec_off[4] = {0, 0, 0, 0}, sec_size[4] = {0, 0, 0, 0}; bool have[4] = {false, false, false, false};
+        for (uint32_t k = 0, nsec = u32(8); k < nsec; k++) {
+            const uint32_t typ = u32(off); const uint64_t size = u64(off + 4);
+            off += 12; need(off, size);
+            if (typ < 4) { sec_off[typ] = off; sec_size[typ] = size; have[typ] = true; }
+            off += size;
+        }
+        if (!have[1] || !have[2]) fail("missing header or constraint section");
+        R1CSFile f;
+        const size_t h = sec_off[1];
+        if (u32(h) != 32 || sec_size[1] != 64) fail("This parser only supports 32-byte fields");
+        need(h + 4, 60);
+        std::memcpy(f.prime.data(), d + h + 4, 32);
+        f.n_wires = u32(h + 36); f.n_pub_out = u32(h + 40); f.n_pub_in = u32(h + 44); f.n_prv_in = u32(h + 48); f.n_labels = u64(h + 52); f.n_constraints = u32(h + 60);
+        size_t p = sec_off[2];
+        Csr *m[3] = {&f.a, &f.b, &f.c};
+        for (uint32_t r = 0; r < f.n_constraints; r++)
+            for (int k = 0; k < 3; k++) {
+                const uint32_t nt = u32(p); p += 4;
+                need(p, (size_t)nt * 36);
+                for (uint32_t t = 0; t < nt; t++, p += 36) { m[k]->cols.push_back(u32(p)); uint64_t w[4]; std::memcpy(w, d + p + 4, 32); m[k]->vals.insert(m[k]->vals.end(), w, w + 4); }
+                m[k]->rowptr.push_back(m[k]->cols.size());
+            }
+        if (!have[3]) fail("No section offset for wire2label type found");           // (the reference looks the section up unconditionally, :91-96)
+        if (sec_size[3] != (size_t)f.n_wires * 8) fail("Invalid map section size");
+        f.wire_mapping.resize(f.n_wires);
+        if (f.n_wires) std::memcpy(f.wire_mapping.data(), d + sec_off[3], (size_t)f.n_wires * 8);
+        if (f.n_wires && f.wire_mapping[0] != 0) fail("Wire 0 should always be mapped to 0");
+        return f;
+    }
+    bool is_bls12_381() const { return prime == detail::FR_MODULUS; }                 // r1cs_reader.rs:186-200: anything else is IncompatibleWithCurve
+    // the circuit resident in HBM (handle for dgpu_witness_map_r1cs / legogroth16::create_proof_with_reduction; dgpu_r1cs_free releases it)
+    uint64_t upload() const {
+        if (!is_bls12_381()) throw Error(DGPU_E_BADARG, "r1cs: the file was compiled for another field");
+        uint64_t h = 0;
+        check(dgpu_r1cs_upload(a.rowptr.data(), a.cols.data(), a.vals.data(), a.cols.size(), b.rowptr.data(), b.cols.data(), b.vals.data(), b.cols.size(),
+                               c.rowptr.data(), c.cols.data(), c.vals.data(), c.cols.size(), n_wires, num_inputs(), n_constraints, 0, &h), "r1cs_upload");
+        return h;
+    }
+};
+}  // namespace circom
+
 // ---- legogroth16::create_proof_with_reduction (legogroth16/src/prover.rs:153-180 -> :267-383) over dgpu_legogroth16_prove ----
 namespace legogroth16 {
 // ProvingKey (legogroth16/src/data_structures.rs:55-70,151-168): the five queries live on the device, the O(1) elements on the host

@@ -115,10 +115,13 @@ template <class F> inline int32_t par_run(size_t parts, F body) noexcept {
     };
     static const bool use_pool = []{ const char *e = getenv("DGPU_HOST_POOL"); return !(e && e[0] == '0'); }();
     if (!use_pool) {
-        std::vector<std::thread> th;
-        for (size_t k = 1; k < parts; k++) th.emplace_back([run_part, k] { run_part(k); });
+        struct Joiner { std::vector<std::thread> th; ~Joiner() { for (auto &t : th) if (t.joinable()) t.join(); } } j;
+        for (size_t k = 1; k < parts; k++) {
+            try { j.th.emplace_back([run_part, k] { run_part(k); }); }
+            catch (...) { run_part(k); }                   // no thread to be had: this part runs here
+        }
         g->rc[0] = abi_guard([&] { return (int32_t)body((size_t)0); });
-        for (auto &t : th) t.join();
+        for (auto &t : j.th) t.join();
         for (size_t k = 0; k < parts; k++) if (g->rc[k]) return g->rc[k];
         return DGPU_OK;
     }

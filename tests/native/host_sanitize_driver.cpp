@@ -3,7 +3,8 @@
 // Built and run by tests/test_host_sanitizers.py (g++ -fsanitize=thread and -fsanitize=address,undefined) from the PRODUCT's sources:
 //   * crypto_amd/csrc/dock_prover.cpp (dgpu_legogroth16_prove: seven host threads per proof, one more per shard in the sharded form),
 //     crypto_amd/csrc/dock_gt.cpp (dgpu_fp12_multi_pow: a thread per chunk), crypto_amd/csrc/dock_serde.cpp (for_points: a thread per slice),
-//     crypto_amd/csrc/host_par.hpp (par_run) — compiled as they are;
+//     crypto_amd/csrc/host_par.hpp (par_run and its worker pool), crypto_amd/csrc/dock_aggregation.cpp (dgpu_snarkpack_aggregate / _verify: nested parallel
+//     sections, the caller's transcript called back, fold tables) — compiled as they are;
 //   * crypto_amd/csrc/dock_ctx.hpp's slot / handle machinery (SlotLock, HandleRef, register_handle, take_handle, scalar_alloc / scalar_release)
 //     — included as it is, with the handful of HIP runtime calls it names stubbed out below (nothing here touches a device).
 // The device entry points dock_prover.cpp calls are replaced by stand-ins that return the identity after a short, varying delay and FAIL on
@@ -108,6 +109,32 @@ int32_t dgpu_shard_part(uint64_t h, size_t k, uint64_t *sub, size_t *lo, size_t 
     const ShardSet &ss = *(const ShardSet *)r.h.p; if (k >= ss.sub.size()) return DGPU_E_BADARG;
     *sub = ss.sub[k]; *lo = ss.lo[k]; *hi = ss.lo[k + 1]; *ctx = (int32_t)k; return DGPU_OK;
 }
+// ---- stand-ins for the device entry points of the aggregation (dock_aggregation.cpp): zeros / ones after a delay, failures on request ----
+static hostf::Fq12 gt_of(uint64_t seed) { hostf::Fq12 f = hostf::Fq12::one(); f.c0.c0.c0.l[0] ^= seed * 0x9e3779b97f4a7c15ULL; return f; }      // some value that depends on the call
+int32_t dgpu_g1_mul_add_batch(const uint64_t *p, const uint8_t *, const uint64_t *, size_t, const uint64_t *, const uint8_t *, size_t n, uint64_t *out, uint8_t *oi) { memcpy(out, p, n * 96); memset(oi, 0, n); return step("muladd"); }
+int32_t dgpu_g2_mul_add_batch(const uint64_t *p, const uint8_t *, const uint64_t *, size_t, const uint64_t *, const uint8_t *, size_t n, uint64_t *out, uint8_t *oi) { memcpy(out, p, n * 192); memset(oi, 0, n); return step("muladd"); }
+int32_t dgpu_msm_g1(const uint64_t *b, const uint8_t *, const uint64_t *sc, size_t n, uint64_t *o) { volatile uint64_t t = b[12 * n - 1] ^ sc[4 * n - 1]; (void)t; identity1(o); return step("msm"); }
+int32_t dgpu_msm_g2(const uint64_t *b, const uint8_t *, const uint64_t *sc, size_t n, uint64_t *o) { volatile uint64_t t = b[24 * n - 1] ^ sc[4 * n - 1]; (void)t; identity2(o); return step("msm"); }
+int32_t dgpu_multi_pairing_segments(const uint64_t *p, const uint64_t *q, const uint8_t *, size_t n, const uint64_t *ends, size_t nseg, uint64_t *out) {
+    volatile uint64_t t = p[12 * n - 1] ^ q[24 * n - 1] ^ ends[nseg - 1]; (void)t;
+    for (size_t g = 0; g < nseg; g++) { hostf::Fq12 f = gt_of(g + n); memcpy(out + 72 * g, &f, 576); }
+    return step("pairings");
+}
+int32_t dgpu_multi_miller_loop(const uint64_t *p, const uint64_t *q, const uint8_t *, size_t n, uint64_t *out) { volatile uint64_t t = p[12 * n - 1] ^ q[24 * n - 1]; (void)t; hostf::Fq12 f = gt_of(n); memcpy(out, &f, 576); return step("ml"); }
+int32_t dgpu_final_exponentiation(const uint64_t *in, uint64_t *out) { memcpy(out, in, 576); return step("fe"); }
+int32_t dgpu_g1_scale_batch(const uint64_t *p, const uint8_t *, const uint64_t *, size_t, const uint8_t *, size_t n, uint64_t *out, uint8_t *oi) { memcpy(out, p, n * 96); memset(oi, 0, n); return step("scale"); }
+int32_t dgpu_fp12_pow(const uint64_t *a, const uint64_t *, uint64_t *out) { memcpy(out, a, 576); return DGPU_OK; }
+static std::atomic<int> g_live_fold{0};
+int32_t dgpu_fold_prepare_pair(const uint64_t *p1, size_t n1, uint64_t *h1, const uint64_t *p2, size_t n2, uint64_t *h2) {
+    int32_t rc = step("prepare"); if (rc) return rc;
+    uint64_t *t1 = (uint64_t *)malloc(n1 * 96), *t2 = (uint64_t *)malloc(n2 * 192); memcpy(t1, p1, n1 * 96); memcpy(t2, p2, n2 * 192);
+    *h1 = register_handle(t1, n1, 13); *h2 = register_handle(t2, n2, 14); g_live_fold += 2; return DGPU_OK;
+}
+static int32_t fold_apply_like(uint64_t h, int kind, size_t pt, uint64_t *out, uint8_t *oi) { HandleRef r(h); if (!r.ok || r.h.kind != kind) return DGPU_E_BADARG; memcpy(out, r.h.p, r.h.n * pt); memset(oi, 0, r.h.n); return step("apply"); }
+int32_t dgpu_g1_fold_apply(uint64_t h, const uint64_t *, const uint64_t *, uint64_t *out, uint8_t *oi) { return fold_apply_like(h, 13, 96, out, oi); }
+int32_t dgpu_g2_fold_apply(uint64_t h, const uint64_t *, const uint64_t *, uint64_t *out, uint8_t *oi) { return fold_apply_like(h, 14, 192, out, oi); }
+int32_t dgpu_fold_free(uint64_t h) { Handle hd; if (!take_handle(h, [](int k) { return k == 13 || k == 14; }, hd)) return DGPU_E_BADARG; free(hd.p); g_live_fold--; return DGPU_OK; }
+int32_t dgpu_g2_serialize(const uint64_t *xy, const uint8_t *is_inf, size_t n, int32_t compressed, uint8_t *out);
 // the entry points under test that live in host-only units of the product
 int32_t dgpu_fp12_multi_pow(const uint64_t *a, const uint64_t *e, size_t n, uint64_t out[72]);
 int32_t dgpu_g1_serialize(const uint64_t *xy, const uint8_t *is_inf, size_t n, int32_t compressed, uint8_t *out);
@@ -231,10 +258,57 @@ static void test_gt_and_serde() {
     for (auto &x : th) x.join();
 }
 
+// 4. the aggregation (dock_aggregation.cpp: protocol steps as parallel sections on the pool, nested inside each other, the caller's transcript called back,
+//    fold tables freed on every path) from several callers at once, with and without failing device calls
+struct ToyTranscript {
+    uint64_t h = 0xcbf29ce484222325ULL; std::atomic<int> calls{0};
+    static void append(void *c, const uint8_t *l, size_t ll, const uint8_t *b, size_t n) { ToyTranscript *t = (ToyTranscript *)c; t->calls++; for (size_t i = 0; i < ll; i++) t->h = (t->h ^ l[i]) * 0x100000001b3ULL; for (size_t i = 0; i < n; i++) t->h = (t->h ^ b[i]) * 0x100000001b3ULL; }
+    static void challenge(void *c, const uint8_t *l, size_t ll, uint64_t out[4]) { ToyTranscript *t = (ToyTranscript *)c; t->calls++; for (size_t i = 0; i < ll; i++) t->h = (t->h ^ l[i]) * 0x100000001b3ULL; for (int k = 0; k < 4; k++) { t->h ^= t->h >> 29; t->h *= 0xff51afd7ed558ccdULL; out[k] = t->h; } out[3] &= 0x3fffffffffffffffULL; out[0] |= 1; }
+};
+static void test_aggregation() {
+    const size_t n = 16;
+    std::vector<uint64_t> g1(12 * 2 * n), g2(24 * 2 * n);
+    for (size_t i = 0; i < g1.size(); i++) g1[i] = 0x1111 * (i + 1);
+    for (size_t i = 0; i < g2.size(); i++) g2[i] = 0x2222 * (i + 3);
+    dgpu_snarkpack_prover_srs srs{n, g1.data(), g1.data(), g2.data(), g2.data(), g2.data(), g2.data(), g1.data() + 12 * n, g1.data() + 12 * n};
+    dgpu_snarkpack_verifier_srs vs{n, g1.data(), g2.data(), g1.data() + 12, g1.data() + 24, g2.data() + 24, g2.data() + 48};
+    dgpu_groth16_vk vk{g1.data(), g2.data(), g2.data() + 24, g2.data() + 48, g1.data() + 36, 2};
+    std::vector<uint64_t> pub(4 * n, 7);
+    for (int with_d = 0; with_d < 2; with_d++)
+        for (uint64_t fail_every : {(uint64_t)0, (uint64_t)23}) {
+            g_fail_every = fail_every;
+            std::atomic<int> ok{0}, bad{0};
+            std::vector<std::thread> th;
+            for (int t = 0; t < 4; t++) th.emplace_back([&] {
+                for (int rep = 0; rep < 3; rep++) {
+                    ToyTranscript tp; dgpu_transcript tr{&tp, ToyTranscript::append, ToyTranscript::challenge};
+                    const size_t cap = dgpu_snarkpack_proof_words(n, with_d); std::vector<uint64_t> proof(cap); size_t len = 0;
+                    int32_t rc = dgpu_snarkpack_aggregate(&srs, g1.data(), g2.data(), g1.data() + 24, with_d ? g1.data() + 48 : nullptr, n, &tr, proof.data(), cap, &len);
+                    if (rc) { EXPECT(rc == DGPU_E_OOM); bad++; continue; }
+                    EXPECT(len == cap && proof[0] == n && proof[1] == (uint64_t)(with_d ? 2 : 1) && tp.calls.load() > 20);
+                    ToyTranscript tv; dgpu_transcript trv{&tv, ToyTranscript::append, ToyTranscript::challenge};
+                    const uint64_t rnd[4] = {5, 0, 0, 0}; int32_t okv = -1;
+                    rc = dgpu_snarkpack_verify(&vs, &vk, pub.data(), n, 1, proof.data(), len, with_d ? 1 : 0, nullptr, rnd, &trv, DGPU_SNARKPACK_VALIDATE_GT, &okv);
+                    if (rc) { EXPECT(rc == DGPU_E_OOM); bad++; continue; }
+                    EXPECT(okv == 0 || okv == 1);                          // (the stand-ins compute nothing: either answer, never a crash or a leak)
+                    // malformed proofs: refused before any call
+                    EXPECT(dgpu_snarkpack_verify(&vs, &vk, pub.data(), n, 1, proof.data(), len - 1, with_d ? 1 : 0, nullptr, rnd, &trv, 0, &okv) == DGPU_E_BADARG);
+                    EXPECT(dgpu_snarkpack_verify(&vs, &vk, pub.data(), n - 1, 1, proof.data(), len, with_d ? 1 : 0, nullptr, rnd, &trv, 0, &okv) == DGPU_E_BADARG);
+                    ok++;
+                }
+            });
+            for (auto &x : th) x.join();
+            g_fail_every = 0;
+            if (!fail_every) EXPECT(ok == 12 && bad == 0); else EXPECT(bad > 0);
+            EXPECT(g_live_fold.load() == 0);                                // every fold table of every call was freed, failed or not
+        }
+}
+
 int main() {
     test_slots_and_handles();
     test_prover();
     test_gt_and_serde();
+    test_aggregation();
     { std::lock_guard<std::mutex> lk(gs.mu); if (!gs.handles.empty()) { fprintf(stderr, "%zu handles left\n", gs.handles.size()); failures++; } }
     printf("host_sanitize_driver: %s (%llu stand-in device calls)\n", failures.load() ? "FAILED" : "ok", (unsigned long long)g_calls.load());
     return failures.load() ? 1 : 0;

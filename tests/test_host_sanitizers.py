@@ -1,6 +1,7 @@
 """CPU: the library's host-side concurrency under ThreadSanitizer and AddressSanitizer + UBSan (the reference relies on Rust's
 borrow checker and `cargo test` under rayon; a C++ host side needs the sanitizers to say the same).  tests/native/host_sanitize_driver.cpp is
-built from the PRODUCT's sources — dock_prover.cpp (seven host threads per proof, sharded form included), dock_gt.cpp, dock_serde.cpp,
+built from the PRODUCT's sources — dock_prover.cpp (seven host threads per proof, sharded form included), dock_aggregation.cpp (the aggregation's nested
+parallel sections on the worker pool), dock_gt.cpp, dock_serde.cpp,
 host_par.hpp and dock_ctx.hpp's slot / handle machinery — with the device entry points replaced by stand-ins that delay and fail on request,
 and run: six threads of concurrent proofs with failing stages, lockers / pinners / a freer racing on one handle, the shutdown race of
 SlotLock, the threaded GT and codec entry points.  Pass = exit code 0 and no sanitizer report."""
@@ -10,7 +11,7 @@ import subprocess
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = [os.path.join(ROOT, "tests", "native", "host_sanitize_driver.cpp")] + [os.path.join(ROOT, "crypto_amd", "csrc", f) for f in ("dock_prover.cpp", "dock_gt.cpp", "dock_serde.cpp")]
+SRC = [os.path.join(ROOT, "tests", "native", "host_sanitize_driver.cpp")] + [os.path.join(ROOT, "crypto_amd", "csrc", f) for f in ("dock_prover.cpp", "dock_gt.cpp", "dock_serde.cpp", "dock_aggregation.cpp")]
 HIP_INC = "/opt/rocm/include"
 
 

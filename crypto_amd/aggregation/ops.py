@@ -115,20 +115,15 @@ def gt_bytes(f):
     return bytes(out)
 
 
-R_LIMBS = None
-
-
 def gt_in_subgroup(f):
-    """PairingOutput's `Valid::check` (ark-ec): the element has order dividing r, i.e. f^r == 1 (host arithmetic, ~1 ms per element)"""
-    global R_LIMBS
-    if R_LIMBS is None:
-        R_LIMBS = np.array([(R_MOD >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
-    a = np.ascontiguousarray(np.asarray(f, dtype=np.uint64).reshape(72))
-    out = np.zeros(72, dtype=np.uint64)
-    rc = lib().dgpu_fp12_pow(_p(a), _p(R_LIMBS), _p(out))          # the exponent is r itself, not reduced
+    """PairingOutput's `Valid::check` (ark-ec): the element has order dividing r (dgpu_gt_in_subgroup: a Frobenius identity and f^p == f^x on the host,
+    ~0.1 ms per element instead of the 1.3 ms of f^r)"""
+    a = np.ascontiguousarray(np.asarray(f, dtype=np.uint64).reshape(-1, 72))
+    ok = np.zeros(len(a), dtype=np.uint8)
+    rc = lib().dgpu_gt_in_subgroup(_p(a), len(a), _p(ok))
     if rc:
-        raise DockGpuError(rc, "dgpu_fp12_pow")
-    return bool((out == fp12_one()).all())
+        raise DockGpuError(rc, "dgpu_gt_in_subgroup")
+    return bool(ok.all())
 
 
 def gt_multi_pow(bases, exps):

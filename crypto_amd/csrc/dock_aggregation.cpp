@@ -460,12 +460,10 @@ void verify(const VerifyIn &in, const Proof &P, const Fr &random, const Tr &tr, 
         for (auto &c : P.comms_ab) for (int s = 0; s < 2; s++) { all.push_back(&c[s].t); all.push_back(&c[s].u); }
         for (auto &z : P.zs_ab) { all.push_back(&z[0]); all.push_back(&z[1]); }
         for (int k = 0; k < nm; k++) for (auto &c : P.m[k].comms) for (int s = 0; s < 2; s++) { all.push_back(&c[s].t); all.push_back(&c[s].u); }
-        const size_t T = std::min<size_t>(8, all.size());
-        std::vector<std::function<void()>> th;
-        for (size_t t = 0; t < T; t++) th.push_back([&, t] {
-            for (size_t i = t; i < all.size(); i += T) { Gt o; ck(dgpu_fp12_pow(all[i]->data(), FrH::MOD, o.data())); if (o != gt_one()) throw Reject{}; }
-        });
-        par(th);
+        std::vector<W> flat(72 * all.size()); std::vector<uint8_t> okv(all.size());
+        for (size_t i = 0; i < all.size(); i++) memcpy(&flat[72 * i], all[i]->data(), 576);
+        ck(dgpu_gt_in_subgroup(flat.data(), all.size(), okv.data()));
+        for (uint8_t o : okv) if (!o) throw Reject{};
     }
     tr.pc("AB-commitment", P.com_ab.t, P.com_ab.u);
     for (int k = 0; k < nm; k++) tr.pc(labels(k).commitment.c_str(), P.m[k].com.t, P.m[k].com.u);

@@ -1262,13 +1262,6 @@ int32_t dgpu_fp12_mul(const uint64_t *a, const uint64_t *b, uint64_t *out) {
     hostf::Fq12 x, y; memcpy(&x, a, sizeof x); memcpy(&y, b, sizeof y);
     hostf::Fq12 r = x * y; memcpy(out, &r, sizeof r); return DGPU_OK;
 }
-int32_t dgpu_fp12_pow(const uint64_t *a, const uint64_t *e, uint64_t *out) {
-    if (!a || !e || !out) return DGPU_E_BADARG;
-    hostf::Fq12 base, acc = hostf::Fq12::one(); memcpy(&base, a, sizeof base);
-    for (int i = 255; i >= 0; i--) { acc = acc.sqr(); if ((e[i / 64] >> (i % 64)) & 1) acc = acc * base; }
-    memcpy(out, &acc, sizeof acc); return DGPU_OK;
-}
-
 // E::final_exponentiation: once per batch, host code
 int32_t dgpu_final_exponentiation(const uint64_t *in, uint64_t *out) {
     if (!in || !out) return DGPU_E_BADARG;

@@ -265,6 +265,9 @@ int32_t dgpu_g1_scale_batch(const uint64_t *p_xy /* n*12 */, const uint8_t *is_i
 /* GT arithmetic on the host: PairingOutput `+` is the Fp12 product, `mul_bigint` the power (:136 `self.right += out.mul_bigint(m)`) */
 int32_t dgpu_fp12_mul(const uint64_t a[72], const uint64_t b[72], uint64_t out[72]);
 int32_t dgpu_fp12_pow(const uint64_t a[72], const uint64_t e[4], uint64_t out[72]);
+/* ok[i] = a_i is an element of GT (order dividing r): `Valid::check` of ark-ec's PairingOutput (a proof deserialized with Validate::Yes), answered
+ * with a Frobenius identity and one exponentiation by the 64-bit curve parameter (0.09 ms per element on a host thread) instead of f^r (1.3 ms) */
+int32_t dgpu_gt_in_subgroup(const uint64_t *a /* n*72 */, size_t n, uint8_t *ok /* n */);
 /* prod_i a_i^{e_i}: the fold of `PairingOutput::mul_bigint` + `add_assign` in the aggregation verifier
  * (legogroth16/src/aggregation/groth16/verifier.rs:272-370); host threads, generic Fp12 arithmetic */
 int32_t dgpu_fp12_multi_pow(const uint64_t *a /* n*72 */, const uint64_t *e /* n*4 */, size_t n, uint64_t out[72]);

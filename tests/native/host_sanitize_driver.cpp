@@ -123,7 +123,6 @@ int32_t dgpu_multi_pairing_segments(const uint64_t *p, const uint64_t *q, const 
 int32_t dgpu_multi_miller_loop(const uint64_t *p, const uint64_t *q, const uint8_t *, size_t n, uint64_t *out) { volatile uint64_t t = p[12 * n - 1] ^ q[24 * n - 1]; (void)t; hostf::Fq12 f = gt_of(n); memcpy(out, &f, 576); return step("ml"); }
 int32_t dgpu_final_exponentiation(const uint64_t *in, uint64_t *out) { memcpy(out, in, 576); return step("fe"); }
 int32_t dgpu_g1_scale_batch(const uint64_t *p, const uint8_t *, const uint64_t *, size_t, const uint8_t *, size_t n, uint64_t *out, uint8_t *oi) { memcpy(out, p, n * 96); memset(oi, 0, n); return step("scale"); }
-int32_t dgpu_fp12_pow(const uint64_t *a, const uint64_t *, uint64_t *out) { memcpy(out, a, 576); return DGPU_OK; }
 static std::atomic<int> g_live_fold{0};
 int32_t dgpu_fold_prepare_pair(const uint64_t *p1, size_t n1, uint64_t *h1, const uint64_t *p2, size_t n2, uint64_t *h2) {
     int32_t rc = step("prepare"); if (rc) return rc;

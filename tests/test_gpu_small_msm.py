@@ -164,6 +164,28 @@ def test_concurrent_small_calls_do_not_share_state():
             assert all((g == j[2]).all() for g, j in zip(got, jobs))
 
 
+def test_concurrent_calls_on_one_handle_build_its_table_once():
+    """eight host threads meet a handle that has no table yet (uploaded while the path was off): one of them builds it, all of them return the right point,
+    every later call runs on the table"""
+    from concurrent.futures import ThreadPoolExecutor
+    G, curve = O.G1, ca.G1
+    n = 1500
+    b, _, _ = U.seq_bases(G, n, 71, threads=16)
+    scs = [O.rand_scalars(720 + k, n) for k in range(8)]
+    refs = [normalised(G, G.msm(b, s, threads=16)) for s in scs]
+    lib().dgpu_reserve_g1(n)
+    assert lib().dgpu_set_small_msm_max(0) == 0
+    db = ca.DeviceBases(curve, b)
+    assert lib().dgpu_set_small_msm_max(8192) == 0
+    a0 = ca.device_alloc_count()
+    with ThreadPoolExecutor(8) as ex:
+        for rep in range(3):
+            got = list(ex.map(lambda k: db.msm_bigint(scs[k]), range(8)))
+            assert all((g == r).all() for g, r in zip(got, refs)), rep
+    assert ca.device_alloc_count() == a0 + 1          # the table, once
+    db.free()
+
+
 def test_no_device_allocation_in_steady_state():
     G, curve = O.G1, ca.G1
     n = 3000

@@ -444,6 +444,10 @@ template <class C> int32_t ws_pre(Slot &sl, const PreTable &pt, const PreGeom &g
     return DGPU_OK;
 }
 // sizes of `off` / `entries` for a sort kept outside a slot
+// a table's allocation: W rows of n prepared records, then one identity-flag byte per base (what the sort reads instead of the records' flag words)
+template <class C> inline size_t pre_rows_bytes(size_t n, int W) { return (size_t)W * n * C::AFF_STRIDE * 4; }
+template <class C> inline size_t pre_tab_bytes(size_t n, int W) { return pre_rows_bytes<C>(n, W) + ((n + 15) & ~(size_t)15); }
+template <class C> inline const uint8_t *pre_idflags(const PreTable &pt) { return (const uint8_t *)pt.tab + pre_rows_bytes<C>(pt.n, pt.W); }
 inline size_t pre_off_bytes(const PreTable &pt) { return (((size_t)1 << (pt.c - 1)) + 1) * 4; }
 inline size_t pre_entries_bytes(const PreTable &pt, size_t n) { return (size_t)n * pt.W * 4; }
 
@@ -451,7 +455,7 @@ inline size_t pre_entries_bytes(const PreTable &pt, size_t n) { return (size_t)n
 template <class C>
 int32_t pre_sort(Slot &sl, const PreTable &pt, const PreGeom &g, size_t boff, const uint32_t *d_scalars, size_t n, uint32_t *off, uint32_t *entries, uint32_t *dyn, bool reset_flag = true) {
     PsParams q;
-    q.scalars = d_scalars; q.bases = dyn ? (const uint32_t *)pt.tab : nullptr /* shared sort: no per-table identity filter */; q.n = n; q.aff_stride = C::AFF_STRIDE; q.flag_word = C::FLAGW; q.flag_base = (uint32_t)boff;
+    q.scalars = d_scalars; q.idflag = dyn ? pre_idflags<C>(pt) : nullptr /* shared sort: no per-table identity filter */; q.n = n; q.flag_base = (uint32_t)boff;
     q.c = pt.c; q.W = pt.W; q.key_wstride = 0; q.val_base = (uint32_t)boff; q.val_wstride = (uint32_t)pt.n;
     q.part_log = ps_part_log(g.NB); q.P = (g.NB + (1u << q.part_log) - 1) >> q.part_log; q.ntiles = (uint32_t)((n + PS_TILE - 1) / PS_TILE);
     int32_t rc;
@@ -651,12 +655,13 @@ int32_t bases_precompute(uint64_t handle, int32_t window_bits, int kind /* 1 | 2
         SLOT_ACQUIRE(L, sl);
         if (hipSetDevice(cur().device) != hipSuccess) rc = DGPU_E_HIP;
         const size_t rec = (size_t)C::AFF_STRIDE * 4;
-        if (!rc && dev_malloc(&tab, (size_t)W * n * rec) != hipSuccess) { (void)hipGetLastError(); rc = DGPU_E_OOM; }
+        if (!rc && dev_malloc(&tab, pre_tab_bytes<C>(n, W)) != hipSuccess) { (void)hipGetLastError(); rc = DGPU_E_OOM; }
         if (!rc && dev_malloc(&tmp, n * (size_t)C::XW * 4) != hipSuccess) { (void)hipGetLastError(); rc = DGPU_E_OOM; }
         if (!rc && hipMemcpyAsync(tab, hd.p, n * rec, hipMemcpyDeviceToDevice, sl.stream) != hipSuccess) rc = DGPU_E_HIP;
         if (!rc) {
             StageTimer st(sl, "msm.precompute");
             for (int w = 1; w < W; w++) launch_pre_step<C>(sl.stream, (const uint32_t *)tab + (size_t)(w - 1) * n * C::AFF_STRIDE, n, c, (uint32_t *)tmp, (uint32_t *)tab + (size_t)w * n * C::AFF_STRIDE);
+            launch_id_flags(sl.stream, (const uint32_t *)tab, C::AFF_STRIDE, C::FLAGW, n, (uint8_t *)tab + pre_rows_bytes<C>(n, W));
         }
         if (!rc && (hipGetLastError() != hipSuccess || hipStreamSynchronize(sl.stream) != hipSuccess)) rc = DGPU_E_HIP;
         if (gs.prof) prof_flush(sl);

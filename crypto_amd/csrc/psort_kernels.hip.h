@@ -41,56 +41,93 @@ __device__ __forceinline__ uint32_t lds_inc_agg(uint32_t *cnt, uint32_t bin, boo
 }
 
 // the W signed digits of scalar i (same recoding as k_digit_codes): f(w, |d| - 1, neg, nonzero) for EVERY window, uniformly over the wave
-// (`live` = this lane has a scalar at all)
-template <class F> __device__ __forceinline__ void ps_digits(const PsParams &q, size_t i, bool live, F f) {
+// (`live` = this lane has a scalar at all).  CC, CW: window width and count known at compile time (the shapes of the per-key tables: every shift
+// is a constant and the window loop is unrolled: ~7 instructions per digit instead of ~35 for the word selects of the general form); CC = 0: q.c, q.W.
+template <int CC, int CW, class F> __device__ __forceinline__ void ps_digits(const PsParams &q, size_t i, bool live, F f) {
     uint4 a = make_uint4(0, 0, 0, 0), b = a;
     if (live) { const uint4 *p = reinterpret_cast<const uint4 *>(q.scalars + i * 8); a = p[0]; b = p[1]; }
     uint32_t s[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w & 0x7fffffffu};       // Fr::MODULUS_BIT_SIZE = 255
-    const uint32_t B = 1u << (q.c - 1);
     uint32_t carry = 0;
-    for (int w = 0; w < q.W; w++) {
-        const int bitpos = w * q.c;
-        uint32_t raw = 0;
-        if (bitpos < 256) {
-            const int wd = bitpos >> 5, sh = bitpos & 31;
-            uint64_t v = 0;
+    if constexpr (CC != 0) {
+        constexpr uint32_t B = 1u << (CC - 1);
 #pragma unroll
-            for (int k = 0; k < 8; k++) { if (k == wd) v |= s[k]; if (k == wd + 1) v |= (uint64_t)s[k] << 32; }
-            raw = (uint32_t)(v >> sh) & ((1u << q.c) - 1u);
+        for (int w = 0; w < CW; w++) {
+            const int bitpos = w * CC;
+            uint32_t raw = 0;
+            if (bitpos < 256) {
+                const int wd = bitpos >> 5, sh = bitpos & 31;
+                const uint32_t lo = s[wd], hi = wd + 1 < 8 ? s[wd + 1] : 0u;
+                raw = (sh ? ((lo >> sh) | (hi << (32 - sh))) : lo) & ((1u << CC) - 1u);
+            }
+            const uint32_t v = raw + carry;
+            const uint32_t neg = v > B ? 1u : 0u;
+            const uint32_t mag = neg ? (2u * B - v) : v;
+            carry = neg;
+            f(w, mag - 1, neg, live && mag != 0);
         }
-        const uint32_t v = raw + carry;
-        const uint32_t neg = v > B ? 1u : 0u;
-        const uint32_t mag = neg ? (2u * B - v) : v;
-        carry = neg;
-        f(w, mag - 1, neg, live && mag != 0);
+    } else {
+        const uint32_t B = 1u << (q.c - 1);
+        for (int w = 0; w < q.W; w++) {
+            const int bitpos = w * q.c;
+            uint32_t raw = 0;
+            if (bitpos < 256) {
+                const int wd = bitpos >> 5, sh = bitpos & 31;
+                uint64_t v = 0;
+#pragma unroll
+                for (int k = 0; k < 8; k++) { if (k == wd) v |= s[k]; if (k == wd + 1) v |= (uint64_t)s[k] << 32; }
+                raw = (uint32_t)(v >> sh) & ((1u << q.c) - 1u);
+            }
+            const uint32_t v = raw + carry;
+            const uint32_t neg = v > B ? 1u : 0u;
+            const uint32_t mag = neg ? (2u * B - v) : v;
+            carry = neg;
+            f(w, mag - 1, neg, live && mag != 0);
+        }
     }
 }
 __device__ __forceinline__ bool ps_live(const PsParams &q, size_t i) {
-    // q.bases == nullptr: a sort shared by several tables (dgpu_scalars_sort): identity rows are skipped by the accumulation instead
-    return i < q.n && (!q.bases || q.bases[((size_t)q.flag_base + i) * (size_t)q.aff_stride + q.flag_word] == 0);
+    // q.idflag == nullptr: a sort shared by several tables (dgpu_scalars_sort): identity rows are skipped by the accumulation instead
+    return i < q.n && (!q.idflag || q.idflag[(size_t)q.flag_base + i] == 0);
+}
+
+__global__ void __launch_bounds__(256) k_id_flags(const uint32_t *__restrict__ bases, int aff_stride, int flag_word, size_t n, uint8_t *__restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = bases[i * (size_t)aff_stride + flag_word] != 0 ? 1 : 0;
+}
+
+// block -> tile: workgroup ids go round the eight XCDs, and the cnt1 / off1 words of tile t sit next to those of tile t + 1 (partition-major layout): the
+// blocks of one XCD take CONSECUTIVE tiles, so that the sixteen tiles of a 64-byte line meet in one L2 instead of eight
+__device__ __forceinline__ uint32_t ps_tile_of_block(uint32_t b, uint32_t ntiles) {
+    const uint32_t per = ntiles >> 3;
+    return b < (per << 3) ? (b & 7u) * per + (b >> 3) : b;
 }
 
 // P1: cnt1[p * ntiles + tile]
+template <int CC, int CW>
 __global__ void __launch_bounds__(PS_TILE) k_ps_count1(PsParams q, uint32_t *__restrict__ cnt1) {
     extern __shared__ __align__(16) uint32_t lds[];                   // P counters
     for (uint32_t j = threadIdx.x; j < q.P; j += blockDim.x) lds[j] = 0;
     __syncthreads();
-    const size_t i = (size_t)blockIdx.x * PS_TILE + threadIdx.x;
+    const uint32_t tile = ps_tile_of_block(blockIdx.x, q.ntiles);
+    const size_t i = (size_t)tile * PS_TILE + threadIdx.x;
     if (i < q.n && (q.scalars[i * 8 + 7] >> 31)) atomicOr(q.bad, 1u);
-    ps_digits(q, i, ps_live(q, i), [&](int w, uint32_t m1, uint32_t, bool nz) { (void)lds_inc_agg(lds, nz ? ((uint32_t)w * q.key_wstride + m1) >> q.part_log : 0u, nz); });
+    ps_digits<CC, CW>(q, i, ps_live(q, i), [&](int w, uint32_t m1, uint32_t, bool nz) { (void)lds_inc_agg(lds, nz ? ((uint32_t)w * q.key_wstride + m1) >> q.part_log : 0u, nz); });
     __syncthreads();
-    for (uint32_t j = threadIdx.x; j < q.P; j += blockDim.x) cnt1[(size_t)j * q.ntiles + blockIdx.x] = lds[j];
+    for (uint32_t j = threadIdx.x; j < q.P; j += blockDim.x) cnt1[(size_t)j * q.ntiles + tile] = lds[j];
 }
 
 // P3: pairs[off1[p * ntiles + tile] + k] = (key, val) of the k-th pair of tile `tile` that falls in partition p
+template <int CC, int CW>
 __global__ void __launch_bounds__(PS_TILE) k_ps_scatter1(PsParams q, const uint32_t *__restrict__ cnt1, const uint32_t *__restrict__ off1, uint2 *__restrict__ pairs) {
     extern __shared__ __align__(16) uint32_t lds[];
-    uint32_t *cnt = lds, *pre = lds + q.P, *cur = lds + 2 * q.P;      // histogram, exclusive prefix, cursors
-    uint2 *stage = reinterpret_cast<uint2 *>(lds + 3 * q.P + ((3 * q.P) & 1u));   // 8-byte aligned
+    uint32_t *cnt = lds, *pre = lds + q.P, *cur = lds + 2 * q.P, *goff = lds + 3 * q.P;      // histogram, exclusive prefix, cursors, the tile's first slot in each partition
+    uint2 *stage = reinterpret_cast<uint2 *>(lds + 4 * q.P);          // 8-byte aligned (P is a power of two)
     __shared__ uint32_t wave_tot[PS_TILE / 64 + 1];
-    // this tile's histogram is what P1 wrote (one digit pass less: the digits are extracted twice per scalar, not three times)
-    for (uint32_t j = threadIdx.x; j < q.P; j += blockDim.x) cnt[j] = cnt1[(size_t)j * q.ntiles + blockIdx.x];
-    const size_t i = (size_t)blockIdx.x * PS_TILE + threadIdx.x;
+    // this tile's histogram is what P1 counted (one digit pass less: the digits are extracted twice per scalar, not three times), read back as the
+    // differences of the scanned offsets: off1[idx + 1] - off1[idx] = cnt1[idx], one strided access per partition instead of two
+    const uint32_t tile = ps_tile_of_block(blockIdx.x, q.ntiles);
+    for (uint32_t j = threadIdx.x; j < q.P; j += blockDim.x) { const size_t idx = (size_t)j * q.ntiles + tile; const uint32_t o0 = off1[idx], o1 = off1[idx + 1]; goff[j] = o0; cnt[j] = o1 - o0; }
+    const size_t i = (size_t)tile * PS_TILE + threadIdx.x;
     const bool live = ps_live(q, i);
     __syncthreads();
     // exclusive scan of cnt[0..P): every thread takes P / 512 consecutive bins (P is a power of two >= 1; 512 threads)
@@ -110,7 +147,7 @@ __global__ void __launch_bounds__(PS_TILE) k_ps_scatter1(PsParams q, const uint3
         for (uint32_t k = 0; k < per; k++) if (b0 + k < q.P) { pre[b0 + k] = run; cur[b0 + k] = run; run += cnt[b0 + k]; }
     }
     __syncthreads();
-    ps_digits(q, i, live, [&](int w, uint32_t m1, uint32_t neg, bool nz) {
+    ps_digits<CC, CW>(q, i, live, [&](int w, uint32_t m1, uint32_t neg, bool nz) {
         const uint32_t key = nz ? (uint32_t)w * q.key_wstride + m1 : 0u;
         const uint32_t pos = lds_inc_agg(cur, key >> q.part_log, nz);
         if (nz) stage[pos] = make_uint2(key, (q.val_base + (uint32_t)w * q.val_wstride + (uint32_t)i) | (neg << 31));
@@ -121,14 +158,16 @@ __global__ void __launch_bounds__(PS_TILE) k_ps_scatter1(PsParams q, const uint3
     for (uint32_t k = threadIdx.x; k < total; k += blockDim.x) {
         const uint2 pr = stage[k];
         const uint32_t p = pr.x >> q.part_log;
-        pairs[(size_t)off1[(size_t)p * q.ntiles + blockIdx.x] + (k - pre[p])] = pr;
+        pairs[(size_t)goff[p] + (k - pre[p])] = pr;
     }
 }
 
 // P4: one block per partition of 2^part_log buckets
-__global__ void __launch_bounds__(1024) k_ps_bucket(const uint2 *__restrict__ pairs, const uint32_t *__restrict__ off1, uint32_t ntiles, uint32_t P, uint32_t NB, int part_log,
+// (WC = false: the direct placement keeps 8 pairs in registers: two blocks share a CU; WC = true: 16 staged pairs per thread, one block per CU)
+template <bool WC>
+__global__ void __launch_bounds__(1024, WC ? 4 : 8) k_ps_bucket(const uint2 *__restrict__ pairs, const uint32_t *__restrict__ off1, uint32_t ntiles, uint32_t P, uint32_t NB, int part_log,
                                                     uint32_t *__restrict__ off, uint32_t *__restrict__ entries,
-                                                    uint32_t heavy_thr, uint32_t *__restrict__ heavy, uint32_t heavy_cap, const uint32_t *__restrict__ dyn, int wc) {
+                                                    uint32_t heavy_thr, uint32_t *__restrict__ heavy, uint32_t heavy_cap, const uint32_t *__restrict__ dyn) {
     if (dyn) heavy_thr = dyn[DYN_HEAVY];
     __shared__ uint32_t cnt[PS_PART];
     __shared__ uint32_t wave_tot[17];
@@ -136,7 +175,7 @@ __global__ void __launch_bounds__(1024) k_ps_bucket(const uint2 *__restrict__ pa
     const uint32_t lo = off1[(size_t)p * ntiles], hi = off1[(size_t)(p + 1) * ntiles];
     for (uint32_t j = threadIdx.x; j < PS_PART; j += blockDim.x) cnt[j] = 0;
     __syncthreads();
-    constexpr int U = 4;                                              // loads in flight per thread
+    constexpr int U = WC ? 4 : 8;                                     // loads in flight per thread
     for (uint32_t base = lo; base < hi; base += U * 1024) {
         uint32_t key[U];
 #pragma unroll
@@ -166,16 +205,26 @@ __global__ void __launch_bounds__(1024) k_ps_bucket(const uint2 *__restrict__ pa
     // while the block fills them, and every term goes straight to its slot.  Beyond that the resident blocks hold more open lines than the L2s
     // do, lines leave half written and come back (the kernel ran 1.9x worse than linear at n = 2^24): there (wc != 0) the pairs are taken in
     // tiles of PS_WC_TILE, grouped by bucket in LDS, and leave as contiguous runs per bucket (write combining).
-    if (!wc) {
+    if constexpr (!WC) {
+        // the partition's slots are ONE contiguous range of entries[] (its buckets are consecutive): the values are placed in LDS at their slot's
+        // distance from the range start and leave as whole wave-wide stores — the direct form issued one 4-byte store per pair, each to a different
+        // cache line of the 512 ... 2048 open ones (13.6 M L2 transactions at n = 2^20).  Slots past PS_DIRECT_CAP go straight to memory.
+        extern __shared__ __align__(16) uint32_t dv_lds[];
         for (uint32_t base = lo; base < hi; base += U * 1024) {
             uint2 pr[U];
 #pragma unroll
             for (int j = 0; j < U; j++) { const uint32_t k = base + j * 1024 + threadIdx.x; pr[j] = k < hi ? pairs[k] : make_uint2(0xffffffffu, 0u); }
 #pragma unroll
-            for (int j = 0; j < U; j++) { const bool on = pr[j].x != 0xffffffffu; const uint32_t pos = lds_inc_agg(cnt, pr[j].x & mask, on); if (on) entries[pos] = pr[j].y; }
+            for (int j = 0; j < U; j++) {
+                const bool on = pr[j].x != 0xffffffffu; const uint32_t pos = lds_inc_agg(cnt, pr[j].x & mask, on);
+                if (on) { const uint32_t r = pos - lo; if (r < (uint32_t)PS_DIRECT_CAP) dv_lds[r] = pr[j].y; else entries[pos] = pr[j].y; }
+            }
         }
+        __syncthreads();
+        const uint32_t staged = hi - lo < (uint32_t)PS_DIRECT_CAP ? hi - lo : (uint32_t)PS_DIRECT_CAP;
+        for (uint32_t k = threadIdx.x; k < staged; k += 1024) entries[lo + k] = dv_lds[k];
         return;
-    }
+    } else {
     extern __shared__ __align__(16) uint32_t wc_lds[];
     uint32_t *lcnt = wc_lds, *lpre = wc_lds + PS_PART;           // per tile: pairs per bucket, their exclusive prefix
     uint2 *stage = reinterpret_cast<uint2 *>(wc_lds + 2 * PS_PART);   // PS_WC_TILE x (value, slot in entries[])
@@ -207,6 +256,7 @@ __global__ void __launch_bounds__(1024) k_ps_bucket(const uint2 *__restrict__ pa
         const uint32_t tile_n = hi - base < (uint32_t)PS_WC_TILE ? hi - base : (uint32_t)PS_WC_TILE;
         for (uint32_t q = threadIdx.x; q < tile_n; q += 1024) { const uint2 e = stage[q]; entries[e.y] = e.x; }       // neighbours in q are neighbours in a bucket: whole runs per store
         __syncthreads();
+    }
     }
 }
 

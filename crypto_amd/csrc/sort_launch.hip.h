@@ -25,12 +25,13 @@ constexpr uint32_t PS_WC_MIN_PAIRS = 0xffffffffu;      // (development A/B build
 #else
 constexpr uint32_t PS_WC_MIN_PAIRS = 65536;
 #endif   // partitions at least this long (on average) take the write-combining path
+constexpr int PS_DIRECT_CAP = 16384;     // slots of a partition that P4's direct form stages in LDS (64 KB: two blocks per CU)
 constexpr int PS_MAX_W = 16;            // pairs staged per scalar (LDS: PS_TILE * PS_MAX_W * 8 B)
 struct PsParams {
     const uint32_t *scalars;            // n x 8 words, canonical
-    const uint32_t *bases;              // record of term i at bases[(flag_base + i) * aff_stride + flag_word]: != 0 -> identity base, term skipped
+    const uint8_t *idflag;              // idflag[flag_base + i] != 0 -> the base of term i is the identity, the term is skipped (the table's own byte per base: reading
+                                        // the flag word inside every 128 / 256-byte record pulled the whole first table row through HBM twice per sort); nullptr: keep all
     size_t n;
-    int aff_stride, flag_word;
     uint32_t flag_base;
     int c, W;
     uint32_t key_wstride;
@@ -46,6 +47,8 @@ inline int ps_part_log(uint32_t NB) { int lg = 0; while ((1u << lg) < NB) lg++; 
 // cnt1 / off1: P * ntiles + 1 words; bsums: scan_blocks(P * ntiles) + 2 words; pairs: n * W x 8 B; off: NB + 1; entries: n * W
 void launch_psort(hipStream_t s, const PsParams &q, uint32_t NB, uint32_t *cnt1, uint32_t *off1, uint32_t *bsums, void *pairs, uint32_t *off, uint32_t *entries,
                   uint32_t heavy_thr, uint32_t *heavy, uint32_t heavy_cap, const uint32_t *dyn_args = nullptr, uint32_t *dyn = nullptr);
+// out[i] = (bases[i * aff_stride + flag_word] != 0): the identity flags of n prepared records as one byte each (built once per table)
+void launch_id_flags(hipStream_t s, const uint32_t *bases, int aff_stride, int flag_word, size_t n, uint8_t *out);
 void launch_g1_scale(hipStream_t s, const uint32_t *p_abi, const uint8_t *is_inf, const uint32_t *scalars, int scalar_stride, const uint8_t *negate, size_t n, uint32_t *out_abi, uint8_t *out_inf,
                      const uint32_t *add_abi = nullptr, const uint8_t *add_inf = nullptr);
 void launch_selftest_fp_mul(hipStream_t s, const uint32_t *a, const uint32_t *b, size_t n, uint32_t *out);

@@ -1,0 +1,22 @@
+"""Development helper (GPU box): K resident G1 MSMs of 2^LOG2N terms on a PLAIN handle (no per-key table), one call in flight — the loop
+rocprofv3 wraps for the kernel statistics of the plain pipeline (what a caller who never calls dgpu_bases_precompute gets)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import numpy as np
+import crypto_amd as ca
+from crypto_amd import serde, fixed_base as FB
+import bench as B
+ca.init(0)
+n = 1 << int(os.environ.get("LOG2N", "20")); K = int(os.environ.get("K", "12"))
+gen1, _ = serde.deserialize(ca.G1, bytes.fromhex(B.G1_GEN_COMPRESSED))
+with FB.WindowTable(ca.G1, gen1[0]) as t1:
+    db = t1.multiply_many_to_bases(B.seeded_scalars(0x5EED0003, n))
+ds = ca.DeviceScalars(B.seeded_scalars(0x5EED1000, n))
+r0 = db.msm_resident(ds)
+ca.prof.enable(True); ca.prof.reset()
+t0 = time.perf_counter()
+for _ in range(K):
+    assert (db.msm_resident(ds) == r0).all()
+dt = (time.perf_counter() - t0) / K * 1e3
+print("G1 plain MSM n=2^%d: %.3f ms per call; stages:" % (n.bit_length() - 1, dt), {k: round(v[0] / max(1, v[1]), 4) for k, v in ca.prof.read().items()})

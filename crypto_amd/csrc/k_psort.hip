@@ -17,17 +17,21 @@ void launch_psort(hipStream_t s, const PsParams &q, uint32_t NB, uint32_t *cnt1,
           (void)hipFuncSetAttribute((const void *)k_ps_scatter1<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
           (void)hipFuncSetAttribute((const void *)k_ps_scatter1<20, 13>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
           (void)hipFuncSetAttribute((const void *)k_ps_scatter1<17, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
+          (void)hipFuncSetAttribute((const void *)k_ps_scatter1<16, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
           done.fetch_or(bit); } }
-    // the shapes of the per-key tables (c = 20 at n >= 2^19, c = 17 for the prover's sparse queries) have their digits extracted with constant shifts
-    const int shape = (q.c == 20 && q.W == 13) ? 1 : ((q.c == 17 && q.W == 16) ? 2 : 0);
+    // the shapes of the per-key tables (c = 20 at n >= 2^19, c = 17 for the prover's sparse queries) and of the plain pipeline at 2^17 .. 2^22 terms (c = 16) have
+    // their digits extracted with constant shifts
+    const int shape = (q.c == 20 && q.W == 13) ? 1 : ((q.c == 17 && q.W == 16) ? 2 : ((q.c == 16 && q.W == 16) ? 3 : 0));
     if (shape == 1) hipLaunchKernelGGL((k_ps_count1<20, 13>), dim3(q.ntiles), dim3(PS_TILE), lds1, s, q, cnt1);
     else if (shape == 2) hipLaunchKernelGGL((k_ps_count1<17, 16>), dim3(q.ntiles), dim3(PS_TILE), lds1, s, q, cnt1);
+    else if (shape == 3) hipLaunchKernelGGL((k_ps_count1<16, 16>), dim3(q.ntiles), dim3(PS_TILE), lds1, s, q, cnt1);
     else hipLaunchKernelGGL((k_ps_count1<0, 0>), dim3(q.ntiles), dim3(PS_TILE), lds1, s, q, cnt1);
     launch_scan(s, cnt1, off1, nullptr, bsums, (size_t)q.P * q.ntiles);
     // the pair total is known: chunking and heavy-bucket threshold of the accumulation follow from it (dyn_args = {fixed_ch, min_chunk, max_chunks, lanes_per_chunk, T_max})
     if (dyn) launch_dyn_chunk(s, off1 + (size_t)q.P * q.ntiles, dyn_args[0], dyn_args[1], dyn_args[2], dyn_args[3], dyn_args[4], dyn);
     if (shape == 1) hipLaunchKernelGGL((k_ps_scatter1<20, 13>), dim3(q.ntiles), dim3(PS_TILE), lds3, s, q, (const uint32_t *)cnt1, (const uint32_t *)off1, (uint2 *)pairs);
     else if (shape == 2) hipLaunchKernelGGL((k_ps_scatter1<17, 16>), dim3(q.ntiles), dim3(PS_TILE), lds3, s, q, (const uint32_t *)cnt1, (const uint32_t *)off1, (uint2 *)pairs);
+    else if (shape == 3) hipLaunchKernelGGL((k_ps_scatter1<16, 16>), dim3(q.ntiles), dim3(PS_TILE), lds3, s, q, (const uint32_t *)cnt1, (const uint32_t *)off1, (uint2 *)pairs);
     else hipLaunchKernelGGL((k_ps_scatter1<0, 0>), dim3(q.ntiles), dim3(PS_TILE), lds3, s, q, (const uint32_t *)cnt1, (const uint32_t *)off1, (uint2 *)pairs);
     // P4 with write combining when the average partition is long (n >= 2^23 at c = 20): decided from the worst-case pair count, the direct path is right for sparse vectors
     const int wc = ((uint64_t)q.n * (uint64_t)q.W) / q.P >= PS_WC_MIN_PAIRS ? 1 : 0;

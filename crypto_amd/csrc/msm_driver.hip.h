@@ -92,10 +92,12 @@ template <class HF> void write_identity(uint64_t *out_xyz) {
     const size_t FWORDS = sizeof(HF) / 8; memcpy(out_xyz, &X, sizeof(HF)); memcpy(out_xyz + FWORDS, &Y, sizeof(HF)); memcpy(out_xyz + 2 * FWORDS, &Z, sizeof(HF));
 }
 
+constexpr size_t PLAIN_PSORT_MIN_N = (size_t)1 << 17;
 // ---- geometry + workspace of the plain pipeline ---------------------------------------------------------------------------------------
 struct PlainGeom {
     int c, W; uint32_t B, NB; int mshift, G; size_t NG, Emax; int CH; size_t T, nblk; bool wide; size_t n_pad; int RANGES, rb_log; unsigned sort_grid; size_t lds_bytes;
     uint32_t min_chunk, max_chunks, lanes_per_chunk, HEAVY_CAP;
+    bool psort;            // the two-level partition sort (psort_kernels.hip.h) instead of the per-window sweeps: large n
 };
 template <class C> int32_t plain_geometry(size_t n, PlainGeom &g) {
     if (n >= (1ull << 31)) return DGPU_E_BADARG;
@@ -123,6 +125,9 @@ template <class C> int32_t plain_geometry(size_t n, PlainGeom &g) {
     g.min_chunk = C::NFP == 2 ? 32u : 16u; g.max_chunks = C::NFP == 2 ? 150000u : 300000u; g.lanes_per_chunk = C::NFP == 2 ? 2u : 1u;
     // a heavy bucket has >= 16 chunk lengths of terms and a chunk is never shorter than 16 terms (k_dyn_chunk, forced_chunk), whatever min_chunk says
     g.HEAVY_CAP = (uint32_t)(g.Emax / (16u * 16u)) + 1;
+    // From 2^17 terms on the sweeps (every digit column re-read once per bucket range: 0.38 ms at n = 2^20) give way to the partition sort the table
+    // pipeline uses (0.2 ms), with one bucket set per window in the key: key = w B + |digit| - 1
+    g.psort = g.W <= PS_MAX_W && n >= PLAIN_PSORT_MIN_N;
     return DGPU_OK;
 }
 // grow-only workspace of one slot for the plain pipeline of that geometry (no-ops once the slot has seen the size: dgpu_reserve_*, uploads)
@@ -147,6 +152,15 @@ template <class C> int32_t ws_plain(Slot &sl, const PlainGeom &g) {
     if ((rc = sl.win.ensure((size_t)g.W * 4 * C::ABI_W * 4))) return rc;
     if ((rc = sl.win_inf.ensure(g.W))) return rc;
     if ((rc = sl.digits.ensure((size_t)g.W * g.n_pad * (g.wide ? 4 : 2)))) return rc;
+    if (g.psort) {                                 // cnt1 / off1 per (partition, tile), the (key, value) pairs
+        const size_t n_terms = g.Emax / g.W;
+        const uint32_t P = (g.NB + (1u << ps_part_log(g.NB)) - 1) >> ps_part_log(g.NB);
+        const size_t n1 = (size_t)P * ((n_terms + PS_TILE - 1) / PS_TILE);
+        if ((rc = sl.cnt.ensure((n1 + 1) * 4))) return rc;
+        if ((rc = sl.cursor.ensure((n1 + 1) * 4))) return rc;
+        if ((rc = sl.bsums.ensure((scan_blocks(n1) + 2) * 4))) return rc;
+        if ((rc = sl.digits.ensure(g.Emax * 8))) return rc;
+    }
     if ((rc = sl.heavy.ensure(((size_t)g.HEAVY_CAP + 1) * 4))) return rc;
     if ((rc = sl.dyn.ensure(msm::dyn_words(T) * 4))) return rc;
     { const size_t hslots = 2 * (T / msm::HEAVY_RANGE + 2); if ((rc = sl.hpart.ensure(hslots * C::XW * 4))) return rc; if ((rc = sl.hpart_inf.ensure(hslots))) return rc; }
@@ -250,6 +264,18 @@ int32_t msm_device_ranges(Slot &sl, const uint32_t *d_bases, const uint32_t *d_s
         uint8_t *const bucket_inf = sl.bucket_inf.as<uint8_t>() + k * (size_t)NB;
         const uint32_t *const bases_k = d_bases + lo * C::AFF_STRIDE, *const scalars_k = d_scalars + lo * 8;
         if ((rc = ready_scalars(k, lo, hi))) return rc;
+        if (g.psort) {
+            StageTimer st(sl, "msm.psort");
+            PsParams q;
+            q.scalars = scalars_k; q.idflag = nullptr /* the accumulation passes over identity records itself */; q.n = nk; q.flag_base = 0;
+            q.c = c; q.W = W; q.key_wstride = g.B; q.val_base = 0; q.val_wstride = 0;
+            q.part_log = ps_part_log(NB); q.P = (NB + (1u << q.part_log) - 1) >> q.part_log; q.ntiles = (uint32_t)((nk + PS_TILE - 1) / PS_TILE);
+            q.bad = sl.flags.as<uint32_t>();
+            const uint32_t dyn_args[5] = {(uint32_t)forced_chunk(), g.min_chunk, g.max_chunks, g.lanes_per_chunk, (uint32_t)T};
+            HIPCHK(hipMemsetAsync(sl.heavy.p, 0, 4, s));
+            launch_psort(s, q, NB, sl.cnt.as<uint32_t>(), sl.cursor.as<uint32_t>(), sl.bsums.as<uint32_t>(), sl.digits.p, sl.off.as<uint32_t>(), sl.entries.as<uint32_t>(),
+                         16u * (uint32_t)CH /* replaced on the device, dyn_chunk.hip.h */, sl.heavy.as<uint32_t>(), HEAVY_CAP, dyn_args, dyn);
+        } else {
         {
             StageTimer st(sl, "msm.count");
             HIPCHK(hipMemsetAsync(sl.heavy.p, 0, 4, s));
@@ -266,6 +292,7 @@ int32_t msm_device_ranges(Slot &sl, const uint32_t *d_bases, const uint32_t *d_s
             StageTimer st(sl, "msm.scatter");
             launch_sort_sweep(s, g.wide, true, g.sort_grid, g.lds_bytes, sl.digits.p, nk, nk_pad, W, g.RANGES, g.rb_log, g.B, nullptr, sl.off.as<uint32_t>(), sl.entries.as<uint32_t>(), heavy_thr, sl.heavy.as<uint32_t>(), HEAVY_CAP);
         }
+        }
         if ((rc = ready_bases(k, lo, hi))) return rc;
         {
             StageTimer st(sl, "msm.accumulate");
@@ -274,7 +301,7 @@ int32_t msm_device_ranges(Slot &sl, const uint32_t *d_bases, const uint32_t *d_s
 #else
             constexpr uint32_t dbg_mask = 0xffffffffu;
 #endif
-            if (bases_pending) launch_accumulate_skip_identity<C>(s, bases_k, sl.entries.as<uint32_t>(), sl.off.as<uint32_t>(), NB, bucket, bucket_inf,
+            if (bases_pending || g.psort) launch_accumulate_skip_identity<C>(s, bases_k, sl.entries.as<uint32_t>(), sl.off.as<uint32_t>(), NB, bucket, bucket_inf,
                                sl.head.as<uint32_t>(), sl.tail.as<uint32_t>(), sl.head_b.as<uint32_t>(), sl.tail_b.as<uint32_t>(), sl.part_inf.as<uint8_t>(), T, (uint32_t)CH, dyn, msm::RowMap{});
             else launch_accumulate<C>(s, bases_k, sl.entries.as<uint32_t>(), sl.off.as<uint32_t>(), NB, bucket, bucket_inf,
                                sl.head.as<uint32_t>(), sl.tail.as<uint32_t>(), sl.head_b.as<uint32_t>(), sl.tail_b.as<uint32_t>(), sl.part_inf.as<uint8_t>(), T, (uint32_t)CH, dbg_mask, dyn);

@@ -10,7 +10,7 @@ void launch_id_flags(hipStream_t s, const uint32_t *bases, int aff_stride, int f
 void launch_psort(hipStream_t s, const PsParams &q, uint32_t NB, uint32_t *cnt1, uint32_t *off1, uint32_t *bsums, void *pairs, uint32_t *off, uint32_t *entries,
                   uint32_t heavy_thr, uint32_t *heavy, uint32_t heavy_cap, const uint32_t *dyn_args, uint32_t *dyn) {
     const size_t lds1 = (size_t)q.P * 4;
-    const size_t lds3 = ((size_t)4 * q.P + 2) * 4 + (size_t)PS_TILE * PS_MAX_W * 8;
+    const size_t lds3 = ((size_t)4 * q.P + 2) * 4 + (size_t)PS_TILE * (size_t)q.W * 8;      // (W = 13: 69 KB, two blocks per CU; sized for PS_MAX_W it was 81 KB and one)
     // (the attribute belongs to the function ON THE CURRENT DEVICE: a process that drives several GPUs sets it once per device)
     { static std::atomic<uint32_t> done{0}; int dev = 0; (void)hipGetDevice(&dev); const uint32_t bit = 1u << (dev & 31);
       if (!(done.load() & bit)) {

@@ -12,6 +12,7 @@ import oracle_c as O
 import util as U
 import crypto_amd as ca
 from crypto_amd._native import lib
+from crypto_amd.aggregation import ops
 
 pytestmark = pytest.mark.gpu
 CUR = {"G1": (ca.G1, O.G1), "G2": (ca.G2, O.G2)}
@@ -358,3 +359,33 @@ def test_witness_like_scalars_at_size_closed_form(gname, logn):
         assert U.jac_to_model(G, plain.msm_bigint(s)) == want
         assert U.jac_to_model(G, tab.msm_bigint(s)) == want
     plain.free(); tab.free()
+
+
+@pytest.mark.parametrize("gname", ["g1", "g2"])
+def test_identity_bases_from_2p17_terms_on_every_path(gname):
+    """From 2^17 terms on the plain pipeline sorts with the two-level partition sort and leaves identity records to the accumulation; the table
+    pipeline reads the table's byte-per-base identity flags.  One percent identity bases, duplicates and negated duplicates, a handle offset that
+    is not a multiple of the sort's tile: one-shot call, plain handle, table handle against the oracle."""
+    G, curve = (O.G1, ca.G1) if gname == "g1" else (O.G2, ca.G2)
+    n = (1 << 17) + 77
+    bases, _, _ = U.seq_bases(G, n, 9100, threads=64)
+    rng = np.random.default_rng(17)
+    bases[1000:2000] = bases[0:1000]                            # duplicates
+    for i in range(2000, 2100):
+        bases[i] = ops.neg(curve, bases[i - 2000])              # negated duplicates
+    inf = (rng.integers(0, 100, n) == 0).astype(np.uint8)
+    inf[0] = 1; inf[n - 1] = 1
+    bases[inf == 1] = 0
+    sc = O.rand_scalars(9200, n)
+    want = G.to_affine(G.msm(bases, sc, inf, threads=64))
+    off = 513
+    want_off = G.to_affine(G.msm(bases[off:], sc[: n - off], inf[off:], threads=64))
+    eq = lambda a, b: a[1] == b[1] and (a[1] or (a[0] == b[0]).all())
+    assert eq(G.to_affine(ca.msm_bigint(curve, bases, sc, is_inf=inf)), want)
+    db = ca.DeviceBases(curve, bases, inf)
+    assert eq(G.to_affine(db.msm_bigint(sc)), want)
+    assert eq(G.to_affine(db.msm_bigint(sc[: n - off], offset=off)), want_off)
+    db.precompute(20)
+    assert eq(G.to_affine(db.msm_bigint(sc)), want)
+    assert eq(G.to_affine(db.msm_bigint(sc[: n - off], offset=off)), want_off)
+    db.free()

@@ -75,13 +75,20 @@ inline void schk_columns(const Fs *const *a, const Fs *const *b, int nprod) {
 #endif
 
 FD int32_t sext30(uint32_t x) { return (int32_t)(x << 2) >> 2; }
-// The multiply-add chain of an output column, started from the bias constant 2^29.  (The compiler reassociates the sum and the constant ends up in
-// a 64-bit addition of its own after the chain, 12 per product.  Forcing it into the addend of the chain's first v_mad_i64_i32 with one inline-
-// assembly statement per multiply-add removes those additions and was measured 1 % SLOWER on the mixed addition — the compiler schedules its own
-// chains better than opaque ones, tools/ubench/madd_rate.hip — so the chain stays plain C.)
+// The multiply-add chain of an output column, started from the bias constant 2^29.  Written as `x * y + 2^29` the compiler reassociates the sum
+// and the constant ends up in a 64-bit addition of its own after the chain, 12 per product.  Forcing it into the addend of the chain's first
+// v_mad_i64_i32 with one inline-assembly statement per multiply-add removes those additions and was measured 1 % SLOWER on the mixed addition —
+// the compiler schedules its own chains better than opaque ones, tools/ubench/madd_rate.hip.  What works is hiding only the CONSTANT: an empty
+// asm statement that claims to modify an SGPR pair holding 2^29 makes it an ordinary loop-invariant value, the chain's first multiply-add takes
+// it as its addend (src2 from the scalar registers) and every other instruction stays visible to the scheduler: 324 -> 237 v_lshl_add_u64 per
+// mixed addition, 4416 -> 4329 instructions.
 struct FsChain {
     int64_t v;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(FS_NO_BIAS_PIN)
+    FD FsChain(int32_t x, int32_t y) { int64_t b = (int64_t)SHALF; asm("" : "+s"(b)); v = (int64_t)x * y + b; }
+#else
     FD FsChain(int32_t x, int32_t y) : v((int64_t)x * y + (int64_t)SHALF) {}
+#endif
     FD void vv(int32_t x, int32_t y) { v += (int64_t)x * y; }
     FD void vs(int32_t x, int32_t k) { v += (int64_t)x * k; }
 };

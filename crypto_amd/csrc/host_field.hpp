@@ -8,6 +8,7 @@
 #pragma once
 #include <stdint.h>
 #include <string.h>
+#include <immintrin.h>
 
 namespace hostf {
 
@@ -84,6 +85,134 @@ struct Fq {
     }
 };
 
+// ---- double-width values: lazy reduction across the tower -----------------------------------------------------------------------
+// An Fq12 product is 54 Fq products; reduced one by one (36 + 36 word products each) the 54 Montgomery reductions are half of it.  The
+// sums and differences of the Karatsuba levels can be taken on the UNREDUCED 768-bit products instead, so that an Fq2 product ends in 2
+// reductions instead of 3 and an Fq6 product in 6 instead of 18 (Aranha et al., "Faster explicit formulas for computing pairings over
+// ordinary curves", §3): 18 x 36 + 6 x 36 = 864 word products per Fq6 product instead of 1296.
+// Wide values are plain non-negative 768-bit integers congruent to the value mod p: additions are 12-word additions, a subtraction adds
+// a multiple k p R of p R = p 2^384 first (k p into the high half, k >= the subtrahend's bound) — no comparison, no select.  p R =
+// 0.1016 * 2^768, so sums up to 9 p R fit.  Montgomery reduction of T < B p R yields T / R mod p in [0, (B + 1) p), and log2(B + 1)
+// conditional subtractions (4p, 2p, p) finish: the results are the same canonical residues as with eager reduction, bit for bit.
+// Every formula below states its bounds in units of p R (p^2 = 0.1016 p R); with -DHOSTF_CHECK each value carries its bound and every
+// operation asserts its precondition (tests/test_gt_host.py builds the tower that way once).
+#ifdef HOSTF_CHECK
+#include <assert.h>
+#define HCHK(...) __VA_ARGS__
+#else
+#define HCHK(...)
+#endif
+struct FqD {
+    uint64_t l[12];
+    HCHK(double ub;)                                            // upper bound of the value, in units of p R
+    static constexpr double P_OVER_R = 0.10158;                 // p / 2^384, rounded up
+    // r = a * b; ua, ub_: how many times p each operand may be (sums of two canonical values enter unreduced)
+    static FqD mul(const uint64_t *a, const uint64_t *b, int ua = 1, int ub_ = 1) {
+        // row by row, the low and the high words of a row's six products as two carry chains (mulx + adc: what the u128 spelling of the
+        // same loop is not compiled to)
+        typedef unsigned long long ull;
+        FqD r; ull t[12];
+        {   ull hi[6], lo[6];
+#pragma unroll
+            for (int j = 0; j < 6; j++) lo[j] = _mulx_u64(a[j], b[0], &hi[j]);
+            t[0] = lo[0]; unsigned char c = 0;
+#pragma unroll
+            for (int j = 1; j < 6; j++) c = _addcarry_u64(c, lo[j], hi[j - 1], &t[j]);
+            _addcarry_u64(c, hi[5], 0, &t[6]);
+        }
+#pragma unroll
+        for (int i = 1; i < 6; i++) {
+            ull hi[6], lo[6];
+#pragma unroll
+            for (int j = 0; j < 6; j++) lo[j] = _mulx_u64(a[j], b[i], &hi[j]);
+            unsigned char c = 0;
+#pragma unroll
+            for (int j = 0; j < 6; j++) c = _addcarry_u64(c, t[i + j], lo[j], &t[i + j]);
+            ull top; _addcarry_u64(c, 0, 0, &top);
+            c = 0;
+#pragma unroll
+            for (int j = 0; j < 5; j++) c = _addcarry_u64(c, t[i + j + 1], hi[j], &t[i + j + 1]);
+            _addcarry_u64(c, top, hi[5], &t[i + 6]);
+        }
+        memcpy(r.l, t, sizeof t);
+        (void)ua; (void)ub_;
+        HCHK(r.ub = ua * ub_ * P_OVER_R;)
+        return r;
+    }
+    FqD operator+(const FqD &b) const {
+        typedef unsigned long long ull;
+        FqD r; ull t[12]; unsigned char c = 0;
+#pragma unroll
+        for (int i = 0; i < 12; i++) c = _addcarry_u64(c, l[i], b.l[i], &t[i]);
+        memcpy(r.l, t, sizeof t);
+        HCHK(r.ub = ub + b.ub; assert(r.ub < 9.8 && c == 0);)
+        return r;
+    }
+    // a - b + K p R, K >= b's bound: non-negative whatever a is
+    template <int K> FqD sub(const FqD &b) const {
+        static_assert(K >= 0 && K <= 8, "k p must fit six words");
+        typedef unsigned long long ull;
+        FqD r; ull t[12]; unsigned char br = 0;
+#pragma unroll
+        for (int i = 0; i < 12; i++) br = _subborrow_u64(br, l[i], b.l[i], &t[i]);
+        if (K > 0) {
+            ull kp[6]; { ull cc = 0; for (int i = 0; i < 6; i++) { u128 x = (u128)Fq::P[i] * (ull)K + cc; kp[i] = (ull)x; cc = (ull)(x >> 64); } }    // (constant-folded)
+            unsigned char c = 0;
+#pragma unroll
+            for (int i = 0; i < 6; i++) c = _addcarry_u64(c, t[6 + i], kp[i], &t[6 + i]);
+            HCHK(assert(c == br);)                             // the borrow of a negative difference is cancelled by the carry of the offset
+        } else { HCHK(assert(br == 0);) }
+        memcpy(r.l, t, sizeof t);
+        HCHK(assert(K == 0 || (double)K >= b.ub); r.ub = ub + K; assert(r.ub < 9.8);)
+        return r;
+    }
+    // T / 2^384 mod p, canonical; T < (2^STEPS - 1) p R
+    template <int STEPS> Fq redc() const {
+        HCHK(assert(ub + 1.0 <= (double)(1 << STEPS));)
+        typedef unsigned long long ull;
+        ull t[12]; memcpy(t, l, sizeof t);
+        ull pend = 0;                                           // carry out of word i + 5 + 1 of the previous row, due at word i + 6
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            const ull m = t[i] * Fq::INV;
+            ull hi[6], lo[6];
+#pragma unroll
+            for (int j = 0; j < 6; j++) lo[j] = _mulx_u64(m, Fq::P[j], &hi[j]);
+            unsigned char c = 0;
+#pragma unroll
+            for (int j = 0; j < 6; j++) c = _addcarry_u64(c, t[i + j], lo[j], &t[i + j]);
+            c = _addcarry_u64(c, t[i + 6], pend, &t[i + 6]);
+            pend = c;
+            c = 0;
+#pragma unroll
+            for (int j = 0; j < 6; j++) c = _addcarry_u64(c, t[i + j + 1], hi[j], &t[i + j + 1]);
+            pend += c;
+        }
+        HCHK(assert(pend == 0);)                                // (T + m p) / R < 2^STEPS p < 2^384
+        ull *h = t + 6;
+#pragma unroll
+        for (int k = STEPS - 1; k >= 0; k--) {                   // h in [0, 2^(k+1) p) -> [0, 2^k p)
+            ull u[6]; unsigned char br = 0;
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+                const ull kp = (Fq::P[i] << k) | (i && k ? Fq::P[i - 1] >> (64 - k) : 0);      // word i of 2^k p (a constant)
+                br = _subborrow_u64(br, h[i], kp, &u[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < 6; i++) h[i] = br ? h[i] : u[i];
+        }
+        Fq r; memcpy(r.l, h, sizeof r.l);
+        return r;
+    }
+};
+// a + b without the conditional subtraction (< 2p < 2^382: an operand of FqD::mul only)
+static inline void fq_add_nored(uint64_t *r, const Fq &a, const Fq &b) {
+    uint64_t c = 0;
+    for (int i = 0; i < 6; i++) { u128 s = (u128)a.l[i] + b.l[i] + c; r[i] = (uint64_t)s; c = (uint64_t)(s >> 64); }
+}
+// an unreduced Fq2 value
+struct Fq2D { FqD c0, c1; };
+
 struct Fq2 {
     Fq c0, c1;
     static Fq2 zero() { return {Fq::zero(), Fq::zero()}; }
@@ -93,10 +222,30 @@ struct Fq2 {
     Fq2 operator+(const Fq2 &b) const { return {c0 + b.c0, c1 + b.c1}; }
     Fq2 operator-(const Fq2 &b) const { return {c0 - b.c0, c1 - b.c1}; }
     Fq2 neg() const { return {c0.neg(), c1.neg()}; }
+    // Karatsuba on unreduced products: 3 wide products; the caller reduces (2 reductions) or keeps combining.  Operands canonical.
+    // Bounds (units of p R): c0 in (0.89, 1.11), c1 < 0.21
+    Fq2D mul_wide(const Fq2 &b) const {
+        const FqD t0 = FqD::mul(c0.l, b.c0.l), t1 = FqD::mul(c1.l, b.c1.l);
+        uint64_t sa[6], sb[6]; fq_add_nored(sa, c0, c1); fq_add_nored(sb, b.c0, b.c1);
+        Fq2D r = {t0.sub<1>(t1), FqD::mul(sa, sb, 2, 2).sub<0>(t0).sub<0>(t1)};      // a0 b1 + a1 b0 >= 0
+        HCHK(r.c1.ub = 2 * FqD::P_OVER_R;)
+        return r;
+    }
+    // c0 < 0.21, c1 < 0.21
+    Fq2D sqr_wide() const {
+        uint64_t sa[6]; fq_add_nored(sa, c0, c1);
+        const Fq d = c0 - c1;
+        const FqD t = FqD::mul(c0.l, c1.l);
+        return {FqD::mul(sa, d.l, 2, 1), t + t};
+    }
+#ifdef HOSTF_EAGER_REDUCTION
     Fq2 operator*(const Fq2 &b) const {
         Fq t0 = c0 * b.c0, t1 = c1 * b.c1, t2 = (c0 + c1) * (b.c0 + b.c1);
         return {t0 - t1, t2 - t0 - t1};
     }
+#else
+    Fq2 operator*(const Fq2 &b) const { const Fq2D d = mul_wide(b); return {d.c0.redc<2>(), d.c1.redc<1>()}; }
+#endif
     Fq2 sqr() const { Fq t = c0 * c1; return {(c0 + c1) * (c0 - c1), t + t}; }
     Fq2 dbl() const { return {c0.dbl(), c1.dbl()}; }
     Fq2 inv() const { Fq n = (c0.sqr() + c1.sqr()).inv(); return {c0 * n, (c1 * n).neg()}; }
@@ -116,6 +265,7 @@ struct Fq6 {
     Fq6 operator+(const Fq6 &b) const { return {c0 + b.c0, c1 + b.c1, c2 + b.c2}; }
     Fq6 operator-(const Fq6 &b) const { return {c0 - b.c0, c1 - b.c1, c2 - b.c2}; }
     Fq6 neg() const { return {c0.neg(), c1.neg(), c2.neg()}; }
+#ifdef HOSTF_EAGER_REDUCTION
     Fq6 operator*(const Fq6 &b) const {
         Fq2 t0 = c0 * b.c0, t1 = c1 * b.c1, t2 = c2 * b.c2;
         Fq2 r0 = ((c1 + c2) * (b.c1 + b.c2) - t1 - t2).mul_xi() + t0;
@@ -123,6 +273,29 @@ struct Fq6 {
         Fq2 r2 = (c0 + c2) * (b.c0 + b.c2) - t0 - t2 + t1;
         return {r0, r1, r2};
     }
+#else
+    // the same Karatsuba formulas on unreduced Fq2 products: 18 wide products, 6 reductions.  With t = a_i b_i and M_ij = (a_i + a_j)(b_i + b_j)
+    // (c0 parts < 1.11 p R, c1 parts < 0.21 p R) every output component is one signed sum; the offsets cover the subtrahends:
+    //   r0 = xi (M12 - t1 - t2) + t0,   r1 = M01 - t0 - t1 + xi t2,   r2 = M02 - t0 - t2 + t1
+    Fq6 operator*(const Fq6 &b) const {
+        const Fq2D t0 = c0.mul_wide(b.c0), t1 = c1.mul_wide(b.c1), t2 = c2.mul_wide(b.c2);
+        const Fq2D m12 = (c1 + c2).mul_wide(b.c1 + b.c2), m01 = (c0 + c1).mul_wide(b.c0 + b.c1), m02 = (c0 + c2).mul_wide(b.c0 + b.c2);
+        Fq6 r;
+        // r0.c0 = (M12.c0 - t1.c0 - t2.c0) - (M12.c1 - t1.c1 - t2.c1) + t0.c0     < 2.64 + 3
+        r.c0.c0 = (m12.c0 + t1.c1 + t2.c1 + t0.c0).sub<3>(t1.c0 + t2.c0 + m12.c1).redc<3>();
+        // r0.c1 = (M12.c0 - t1.c0 - t2.c0) + (M12.c1 - t1.c1 - t2.c1) + t0.c1     < 1.53 + 3
+        r.c0.c1 = (m12.c0 + m12.c1 + t0.c1).sub<3>(t1.c0 + t2.c0 + t1.c1 + t2.c1).redc<3>();
+        // r1.c0 = M01.c0 - t0.c0 - t1.c0 + t2.c0 - t2.c1                           < 2.22 + 3
+        r.c1.c0 = (m01.c0 + t2.c0).sub<3>(t0.c0 + t1.c0 + t2.c1).redc<3>();
+        // r1.c1 = M01.c1 - t0.c1 - t1.c1 + t2.c0 + t2.c1                           < 1.53 + 1
+        r.c1.c1 = (m01.c1 + t2.c0 + t2.c1).sub<1>(t0.c1 + t1.c1).redc<2>();
+        // r2.c0 = M02.c0 + t1.c0 - t0.c0 - t2.c0                                    < 2.22 + 3
+        r.c2.c0 = (m02.c0 + t1.c0).sub<3>(t0.c0 + t2.c0).redc<3>();
+        // r2.c1 = M02.c1 + t1.c1 - t0.c1 - t2.c1                                    < 0.42 + 1
+        r.c2.c1 = (m02.c1 + t1.c1).sub<1>(t0.c1 + t2.c1).redc<2>();
+        return r;
+    }
+#endif
     Fq6 mul_v() const { return {c2.mul_xi(), c0, c1}; }
     Fq6 inv() const {
         Fq2 t0 = c0.sqr() - (c1 * c2).mul_xi();
@@ -150,7 +323,14 @@ struct Fq12 {
     // with Fq4 = Fq2[s]/(s^2 - xi), sq4(a, b) = (a^2 + xi b^2, 2ab); 9 Fq2 squarings instead of 12 Fq2 products
     Fq12 cyclotomic_sqr() const {
         const Fq2 &z0 = c0.c0, &z4 = c0.c1, &z3 = c0.c2, &z2 = c1.c0, &z1 = c1.c1, &z5 = c1.c2;
+#ifdef HOSTF_EAGER_REDUCTION
         auto sq4 = [](const Fq2 &a, const Fq2 &b, Fq2 &r0, Fq2 &r1) { Fq2 a2 = a.sqr(), b2 = b.sqr(); r0 = a2 + b2.mul_xi(); r1 = (a + b).sqr() - a2 - b2; };
+#else
+        auto sq4 = [](const Fq2 &a, const Fq2 &b, Fq2 &r0, Fq2 &r1) {       // three unreduced squarings (parts < 0.21 p R), four reductions instead of six
+            const Fq2D a2 = a.sqr_wide(), b2 = b.sqr_wide(), s2 = (a + b).sqr_wide();
+            r0 = {(a2.c0 + b2.c0).sub<1>(b2.c1).redc<2>(), (a2.c1 + b2.c0 + b2.c1).redc<1>()};           // a^2 + xi b^2
+            r1 = {s2.c0.sub<1>(a2.c0 + b2.c0).redc<2>(), s2.c1.sub<1>(a2.c1 + b2.c1).redc<2>()}; };       // (a + b)^2 - a^2 - b^2
+#endif
         Fq2 t0, t1, t2, t3, t4, t5;
         sq4(z0, z1, t0, t1); sq4(z2, z3, t2, t3); sq4(z4, z5, t4, t5);
         auto three_minus_two = [](const Fq2 &t, const Fq2 &z) { Fq2 d = t - z; return d + d + t; };   // 3t - 2z

@@ -646,6 +646,8 @@ int32_t msm_sorted(uint64_t table, uint64_t sorted, size_t row_shift, uint64_t *
     return pre_tail<C, HF>(sl, pt, g, (const uint32_t *)ss.off, (const uint32_t *)ss.entries, true, out, map);
 }
 
+template <class C> int32_t reserve_slots(int what, size_t n, size_t stride, const PreTable *pt);      // (defined below)
+
 // In-place: the bases behind `handle` (kind 1 / 2, or every part of a sharded handle 7 / 8) become precomputed-multiples tables.
 // The handle keeps its id; while the table is being built other calls on it fail with DGPU_E_BADARG.
 template <class C>

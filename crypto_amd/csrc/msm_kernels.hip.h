@@ -516,13 +516,17 @@ template <class C> __device__ __forceinline__ void wave_weighted_sum(Xyzz<typena
 
 // One wave per group of 64 * m consecutive buckets of one window (m = 2^mshift buckets per lane).
 // Writes (S_g, A_g) to l1[2 g], l1[2 g + 1] (AoS, C::XW words each) and their flags to l1_inf.
+// Blocks of four waves (one per SIMD of a CU, each wave a group of its own; no block-level synchronisation): a launch that does not fill
+// the chip then leaves WHOLE CUs free, and the 256-thread blocks of another call's k_accumulate (which need a slot on all four SIMDs of a
+// CU) can run beside it — single-wave blocks are spread over every CU and lock them all.
 template <class C>
-__global__ void __launch_bounds__(64) k_reduce_l0(const uint32_t *__restrict__ bucket, const uint8_t *__restrict__ bucket_inf, uint32_t NB, int mshift,
-                                                  uint32_t *__restrict__ l1, uint8_t *__restrict__ l1_inf) {
+__global__ void __launch_bounds__(256, 1) k_reduce_l0(const uint32_t *__restrict__ bucket, const uint8_t *__restrict__ bucket_inf, uint32_t NB, int mshift,
+                                                  uint32_t *__restrict__ l1, uint8_t *__restrict__ l1_inf, unsigned NG) {
     typedef typename C::F F;
     const int lane = threadIdx.x & 63;
     const uint32_t m = 1u << mshift;
-    size_t g = blockIdx.x;
+    size_t g = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (g >= NG) return;
     size_t b0 = (g * 64 + lane) * (size_t)m;
     // a group without a single filled bucket (short scalars: 16-bit values leave 15 of 16 pseudo-windows empty) is two identity flags
     { bool any = false; for (uint32_t k = 0; k < m; k++) any = any || bucket_inf[b0 + k] == 0;
@@ -637,12 +641,13 @@ __device__ __forceinline__ void load_l1_pair(Xyzz<Fs2H> &p, const uint32_t *__re
 }
 // one wave per group of 64 * m buckets: 32 point-lanes x 2m buckets each
 template <class PAIR /* = G2P: a template only so that the header may be included by several translation units */>
-__global__ void __launch_bounds__(64) k_reduce_l0_pair(const uint32_t *__restrict__ bucket, const uint8_t *__restrict__ bucket_inf, uint32_t NB, int mshift,
-                                                       uint32_t *__restrict__ l1, uint8_t *__restrict__ l1_inf) {
+__global__ void __launch_bounds__(256, 1) k_reduce_l0_pair(const uint32_t *__restrict__ bucket, const uint8_t *__restrict__ bucket_inf, uint32_t NB, int mshift,
+                                                       uint32_t *__restrict__ l1, uint8_t *__restrict__ l1_inf, unsigned NG) {
     typedef Fs2H F;
     const int q = (threadIdx.x & 63) >> 1;
     const uint32_t m2 = 2u << mshift;                    // buckets per point-lane
-    const size_t g = blockIdx.x;
+    const size_t g = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);      // (four-wave blocks: see k_reduce_l0)
+    if (g >= NG) return;
     const size_t b0 = (g * 32 + q) * (size_t)m2;
     { bool any = false; for (uint32_t k = 0; k < m2; k++) any = any || bucket_inf[b0 + k] == 0;
       if (!__any(any)) { if ((threadIdx.x & 63) == 0) { l1_inf[2 * g] = 1; l1_inf[2 * g + 1] = 1; } return; } }

@@ -43,8 +43,9 @@ template <class C> void launch_merge_buckets(hipStream_t s, uint32_t NB, uint32_
     hipLaunchKernelGGL((k_merge_buckets<A>), dim3((unsigned)(((size_t)NB * A::LPP + 255) / 256)), dim3(256), 0, s, NB, dst, dst_inf, src, src_inf);
 }
 template <class C> void launch_reduce_l0(hipStream_t s, unsigned NG, const uint32_t *bucket, const uint8_t *bucket_inf, uint32_t NB, int mshift, uint32_t *l1, uint8_t *l1_inf) {
-    if constexpr (C::NFP == 2) hipLaunchKernelGGL((k_reduce_l0_pair<G2P>), dim3(NG), dim3(64), 0, s, bucket, bucket_inf, NB, mshift, l1, l1_inf);     // G2: lane pairs
-    else hipLaunchKernelGGL((k_reduce_l0<typename C::MSM>), dim3(NG), dim3(64), 0, s, bucket, bucket_inf, NB, mshift, l1, l1_inf);
+    const unsigned blocks = (NG + 3) / 4;          // four groups (waves) per block: whole CUs (msm_kernels.hip.h)
+    if constexpr (C::NFP == 2) hipLaunchKernelGGL((k_reduce_l0_pair<G2P>), dim3(blocks), dim3(256), 0, s, bucket, bucket_inf, NB, mshift, l1, l1_inf, NG);     // G2: lane pairs
+    else hipLaunchKernelGGL((k_reduce_l0<typename C::MSM>), dim3(blocks), dim3(256), 0, s, bucket, bucket_inf, NB, mshift, l1, l1_inf, NG);
 }
 template <class C> void launch_reduce_top(hipStream_t s, unsigned W, const uint32_t *l1, const uint8_t *l1_inf, int G, int gshift, uint32_t *win_abi, uint8_t *win_inf, int lanes) {
     if (lanes == 4) {          // four members per point: the chain of general additions is 4 products deep instead of 14

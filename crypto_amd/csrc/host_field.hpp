@@ -102,6 +102,8 @@ struct Fq {
 #else
 #define HCHK(...)
 #endif
+// 64 x 64 -> 128 (mulx when the unit is compiled for BMI2: the library's host units are; a test shim built without it still compiles)
+static inline unsigned long long mulx64(unsigned long long a, unsigned long long b, unsigned long long *hi) { const u128 p = (u128)a * b; *hi = (unsigned long long)(p >> 64); return (unsigned long long)p; }
 struct FqD {
     uint64_t l[12];
     HCHK(double ub;)                                            // upper bound of the value, in units of p R
@@ -114,7 +116,7 @@ struct FqD {
         FqD r; ull t[12];
         {   ull hi[6], lo[6];
 #pragma unroll
-            for (int j = 0; j < 6; j++) lo[j] = _mulx_u64(a[j], b[0], &hi[j]);
+            for (int j = 0; j < 6; j++) lo[j] = mulx64(a[j], b[0], &hi[j]);
             t[0] = lo[0]; unsigned char c = 0;
 #pragma unroll
             for (int j = 1; j < 6; j++) c = _addcarry_u64(c, lo[j], hi[j - 1], &t[j]);
@@ -124,7 +126,7 @@ struct FqD {
         for (int i = 1; i < 6; i++) {
             ull hi[6], lo[6];
 #pragma unroll
-            for (int j = 0; j < 6; j++) lo[j] = _mulx_u64(a[j], b[i], &hi[j]);
+            for (int j = 0; j < 6; j++) lo[j] = mulx64(a[j], b[i], &hi[j]);
             unsigned char c = 0;
 #pragma unroll
             for (int j = 0; j < 6; j++) c = _addcarry_u64(c, t[i + j], lo[j], &t[i + j]);
@@ -177,7 +179,7 @@ struct FqD {
             const ull m = t[i] * Fq::INV;
             ull hi[6], lo[6];
 #pragma unroll
-            for (int j = 0; j < 6; j++) lo[j] = _mulx_u64(m, Fq::P[j], &hi[j]);
+            for (int j = 0; j < 6; j++) lo[j] = mulx64(m, Fq::P[j], &hi[j]);
             unsigned char c = 0;
 #pragma unroll
             for (int j = 0; j < 6; j++) c = _addcarry_u64(c, t[i + j], lo[j], &t[i + j]);

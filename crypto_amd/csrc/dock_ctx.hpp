@@ -89,6 +89,7 @@ struct Ctx {
     int device = -1;               // physical HIP device
     Slot slots[N_SLOTS];
     std::atomic<unsigned> rr{0};
+    std::atomic<int> busy{0};       // calls holding one of the context's slots right now (SlotLock): the table MSM picks its bucket reduction's shape by it (msm_driver.hip.h pre_geometry)
     std::atomic<int> ml_active{0};  // dgpu_multi_miller_loop calls in flight on this context (dock_pairing.hip picks the kernel form by it)
     std::map<int, NttDomain> ntt_domains;
     // Recycled scalar vectors (guarded by gs.mu).  A proof uploads one assignment and receives one h vector, both released when it is done:
@@ -129,7 +130,7 @@ struct CtxScope { int prev; explicit CtxScope(int c) : prev(tl_ctx) { tl_ctx = c
 // `ready` check and the moment the slot was acquired (dgpu_shutdown clears `ready` first, then takes every slot): the slot's streams and
 // buffers are gone then, and the call must answer DGPU_E_NODEVICE instead of running on a null stream (SLOT_ACQUIRE).
 struct SlotLock {
-    Slot *s = nullptr; bool ok = false;
+    Slot *s = nullptr; bool ok = false; Ctx *cxp = nullptr;
     SlotLock() {
         Ctx &cx = cur();
         unsigned start = cx.rr.fetch_add(1);
@@ -137,9 +138,9 @@ struct SlotLock {
         for (int k = 0; k < N_SLOTS && !got; k++) { Slot &c = cx.slots[(start + k) % N_SLOTS]; if (c.mu.try_lock()) got = &c; }
         if (!got) { got = &cx.slots[start % N_SLOTS]; got->mu.lock(); }
         if (!cx.ready.load() || !got->stream) { got->mu.unlock(); return; }
-        s = got; ok = true;
+        s = got; ok = true; cxp = &cx; cx.busy.fetch_add(1);
     }
-    ~SlotLock() { if (s) s->mu.unlock(); }
+    ~SlotLock() { if (s) { cxp->busy.fetch_sub(1); s->mu.unlock(); } }
     SlotLock(const SlotLock &) = delete;
 };
 #define SLOT_ACQUIRE(lockname, slotname) dock::SlotLock lockname; if (!lockname.ok) return DGPU_E_NODEVICE; dock::Slot &slotname = *lockname.s

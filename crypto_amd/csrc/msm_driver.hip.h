@@ -427,6 +427,10 @@ template <class C> int32_t pre_geometry(const PreTable &pt, size_t n, PreGeom &g
     // buckets per lane of k_reduce_l0 = 2^mshift: 8 once the bucket set fills the chip with one wave per SIMD (2^19 buckets = 1024 waves, the
     // kernel is work-bound), fewer for small sets, where the serial part of every lane is pure latency (2^15 buckets: 1 per lane, 512 waves)
     g.mshift = g.NB >= (1u << 18) ? 3 : (g.NB >= (1u << 17) ? 2 : (g.NB >= (1u << 16) ? 1 : 0));
+    // With three or more calls in flight on the context the reduction takes 16 buckets per lane (512 waves in four-wave blocks = half the CUs, 22 %
+    // fewer additions; the other CUs go to the other calls' kernels): 2.51 -> 2.48 ms per MSM with six in flight, and 0.2 ms more for a call that
+    // runs alone, which therefore keeps 8 (profiles/r04z_reduce_block_ab.txt).  Same result limb for limb (tests sweep the shift).
+    if (C::NFP == 1 && g.NB >= (1u << 19) && cur().busy.load() >= 3) g.mshift = 4;
     { const int f = gs.reduce_shift.load(); if (f >= 0 && c - 1 >= 6 + f) g.mshift = f; }
     g.lb = std::min(c - 1, 12 + g.mshift);        // log2 buckets per pseudo-window (64 groups of 64 * 2^mshift buckets)
     g.PW = (int)(g.NB >> g.lb);
@@ -461,10 +465,13 @@ template <class C> int32_t ws_pre(Slot &sl, const PreTable &pt, const PreGeom &g
     if ((rc = sl.head_b.ensure(T * 4))) return rc;
     if ((rc = sl.tail_b.ensure(T * 4))) return rc;
     if ((rc = sl.part_inf.ensure(T * 2))) return rc;
-    if ((rc = sl.l1.ensure(g.NG * 2 * C::XW * 4))) return rc;
-    if ((rc = sl.l1_inf.ensure(g.NG * 2))) return rc;
-    if ((rc = sl.win.ensure((size_t)2 * PW * 4 * C::ABI_W * 4))) return rc;        // A_j then S_j
-    if ((rc = sl.win_inf.ensure(2 * PW))) return rc;
+    // (sized for the reduction's shape of a call that runs alone as well: pre_geometry picks fewer, longer groups when the context is busy, and a
+    //  slot reserved under load must not allocate when it is later used by a lone call)
+    const size_t NGw = std::max(g.NG, (size_t)(NB >> 9)), PWw = std::max((size_t)PW, (size_t)(NB >> 15));
+    if ((rc = sl.l1.ensure(NGw * 2 * C::XW * 4))) return rc;
+    if ((rc = sl.l1_inf.ensure(NGw * 2))) return rc;
+    if ((rc = sl.win.ensure((size_t)2 * PWw * 4 * C::ABI_W * 4))) return rc;        // A_j then S_j
+    if ((rc = sl.win_inf.ensure(2 * PWw))) return rc;
     if ((rc = sl.dyn.ensure(msm::dyn_words(T) * 4))) return rc;
     { const size_t hslots = 2 * (T / msm::HEAVY_RANGE + 2); if ((rc = sl.hpart.ensure(hslots * C::XW * 4))) return rc; if ((rc = sl.hpart_inf.ensure(hslots))) return rc; }
     (void)pt;

@@ -430,7 +430,7 @@ template <class C> int32_t pre_geometry(const PreTable &pt, size_t n, PreGeom &g
     // With three or more calls in flight on the context the reduction takes 16 buckets per lane (512 waves in four-wave blocks = half the CUs, 22 %
     // fewer additions; the other CUs go to the other calls' kernels): 2.51 -> 2.48 ms per MSM with six in flight, and 0.2 ms more for a call that
     // runs alone, which therefore keeps 8 (profiles/r04z_reduce_block_ab.txt).  Same result limb for limb (tests sweep the shift).
-    if (C::NFP == 1 && g.NB >= (1u << 19) && cur().busy.load() >= 3) g.mshift = 4;
+    if (g.NB >= (1u << 19) && cur().busy.load() >= 3) g.mshift = 4;      // (G2, four in flight: 6.9 - 7.05 -> 6.8 ms per MSM)
     { const int f = gs.reduce_shift.load(); if (f >= 0 && c - 1 >= 6 + f) g.mshift = f; }
     g.lb = std::min(c - 1, 12 + g.mshift);        // log2 buckets per pseudo-window (64 groups of 64 * 2^mshift buckets)
     g.PW = (int)(g.NB >> g.lb);

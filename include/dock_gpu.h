@@ -68,7 +68,8 @@ size_t dgpu_get_min_gpu_n(void);
 int32_t dgpu_set_window_bits(int32_t c);
 /* terms per lane of the bucket accumulation (16..4096; 0 = automatic).  Any value gives the same point (tests sweep it). */
 int32_t dgpu_set_chunk(int32_t terms);
-/* log2 of the buckets one lane of the bucket reduction sums serially on the table pipeline (0..6; -1 = automatic).  Any value gives the same point. */
+/* log2 of the buckets one lane of the bucket reduction sums serially on the table pipeline (0..6; -1 = automatic: 3 for a 2^19-bucket table when the
+ * call runs alone, 4 when three or more calls are in flight on the device context).  Any value gives the same point. */
 int32_t dgpu_set_reduce_shift(int32_t log2_buckets_per_lane);
 /* lanes (G2: lane pairs) per point in the last kernel of the bucket reduction: 4 (default; a general addition four products deep) or 1. */
 int32_t dgpu_set_reduce_lanes(int32_t lanes);

@@ -59,7 +59,7 @@ int forced_chunk() {
 #endif
     return 0;
 }
-int choose_chunk(size_t E, int min_chunk, size_t max_chunks, int lanes_per_chunk) {
+int choose_chunk(size_t E, int min_chunk, size_t max_chunks, int lanes_per_chunk, size_t nb_shared) {
     if (int f = forced_chunk()) return f;
     // terms per lane.  A lane's chunk is one dependent chain of mixed additions (~12 us each), so short chunks win as long as the
     // partial slots they create stay cheap to fold: 16 terms up to ~300 k lanes (two rounds of the chip's 131 072 lanes at
@@ -77,6 +77,17 @@ int choose_chunk(size_t E, int min_chunk, size_t max_chunks, int lanes_per_chunk
         if (rounds < 1) rounds = 1;
         size_t len = (E + rounds * resident - 1) / (rounds * resident);
         if (len >= 16 && len <= 4096) ch = (int)len;
+    }
+    // The table pipeline (ONE set of nb_shared buckets for all windows): runs are E / nb_shared terms long on average, and every chunk that ends
+    // inside a run leaves a partial for the fix-up.  When the average run is at least HALF the chunk of ONE whole round of the chip (the
+    // proportion of the tuned dense case: runs of 26, chunks of 52), the launch is one round instead of two: a witness-shaped MSM on a width-17 table (4.4 M terms, 2^16 buckets: runs of 68) goes from chunks of 17
+    // to 34 (fix-up 0.49 -> 0.33 ms).  NOT further: chunks of 68 are one wave per SIMD (65 536 lanes = one 256-thread block per CU), where a lone
+    // wave leaves the gather's latency uncovered (dense scalars on that table: 4.5 ms against 2.3) and one lane too many puts a second block on
+    // some CUs and doubles the kernel (chunks of 66: 1.12 ms against 0.74 for 68; tests/perf/witness_msm_perf.py CHUNK=).  Dense scalars on a
+    // width-20 table (runs of 26 < chunks of 52) are untouched.
+    if (nb_shared) {
+        const size_t run = E / nb_shared, one = (E + resident - 1) / resident;
+        if (one > (size_t)ch && 2 * run >= one && one <= 4096) ch = (int)one;
     }
     return ch;
 }

@@ -244,7 +244,7 @@ inline std::vector<int> ready_contexts(int ngpus) {
 }
 
 int choose_c(size_t n, bool g2 = false);
-int choose_chunk(size_t E, int min_chunk = 16, size_t max_chunks = 300000, int lanes_per_chunk = 1);
+int choose_chunk(size_t E, int min_chunk = 16, size_t max_chunks = 300000, int lanes_per_chunk = 1, size_t nb_shared = 0);
 int forced_chunk();
 int32_t upload_scalars(Slot &sl, const uint64_t *h, size_t n, bool mont, uint32_t *d_out);
 

@@ -27,8 +27,8 @@ void launch_psort(hipStream_t s, const PsParams &q, uint32_t NB, uint32_t *cnt1,
     else if (shape == 3) hipLaunchKernelGGL((k_ps_count1<16, 16>), dim3(q.ntiles), dim3(PS_TILE), lds1, s, q, cnt1);
     else hipLaunchKernelGGL((k_ps_count1<0, 0>), dim3(q.ntiles), dim3(PS_TILE), lds1, s, q, cnt1);
     launch_scan(s, cnt1, off1, nullptr, bsums, (size_t)q.P * q.ntiles);
-    // the pair total is known: chunking and heavy-bucket threshold of the accumulation follow from it (dyn_args = {fixed_ch, min_chunk, max_chunks, lanes_per_chunk, T_max})
-    if (dyn) launch_dyn_chunk(s, off1 + (size_t)q.P * q.ntiles, dyn_args[0], dyn_args[1], dyn_args[2], dyn_args[3], dyn_args[4], dyn);
+    // the pair total is known: chunking and heavy-bucket threshold of the accumulation follow from it (dyn_args = {fixed_ch, min_chunk, max_chunks, lanes_per_chunk, T_max, nb_shared})
+    if (dyn) launch_dyn_chunk(s, off1 + (size_t)q.P * q.ntiles, dyn_args[0], dyn_args[1], dyn_args[2], dyn_args[3], dyn_args[4], dyn, dyn_args[5]);
     if (shape == 1) hipLaunchKernelGGL((k_ps_scatter1<20, 13>), dim3(q.ntiles), dim3(PS_TILE), lds3, s, q, (const uint32_t *)cnt1, (const uint32_t *)off1, (uint2 *)pairs);
     else if (shape == 2) hipLaunchKernelGGL((k_ps_scatter1<17, 16>), dim3(q.ntiles), dim3(PS_TILE), lds3, s, q, (const uint32_t *)cnt1, (const uint32_t *)off1, (uint2 *)pairs);
     else if (shape == 3) hipLaunchKernelGGL((k_ps_scatter1<16, 16>), dim3(q.ntiles), dim3(PS_TILE), lds3, s, q, (const uint32_t *)cnt1, (const uint32_t *)off1, (uint2 *)pairs);

@@ -22,8 +22,8 @@ void launch_scan(hipStream_t s, const uint32_t *cnt, uint32_t *off, uint32_t *cu
     hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, s, bsums, nblk);
     hipLaunchKernelGGL(k_scan_add, dim3((unsigned)((NB + 1 + 255) / 256)), dim3(256), 0, s, off, cursor, bsums, NB, nblk);
 }
-void launch_dyn_chunk(hipStream_t s, const uint32_t *total, uint32_t fixed_ch, uint32_t min_chunk, uint32_t max_chunks, uint32_t lanes_per_chunk, uint32_t T_max, uint32_t *dyn) {
-    hipLaunchKernelGGL(k_dyn_chunk, dim3(1), dim3(64), 0, s, total, fixed_ch, min_chunk, max_chunks, lanes_per_chunk, T_max, dyn);
+void launch_dyn_chunk(hipStream_t s, const uint32_t *total, uint32_t fixed_ch, uint32_t min_chunk, uint32_t max_chunks, uint32_t lanes_per_chunk, uint32_t T_max, uint32_t *dyn, uint32_t nb_shared) {
+    hipLaunchKernelGGL(k_dyn_chunk, dim3(1), dim3(64), 0, s, total, fixed_ch, min_chunk, max_chunks, lanes_per_chunk, T_max, dyn, nb_shared);
 }
 void launch_flag_heavy(hipStream_t s, const uint32_t *off, uint32_t NB, const uint32_t *dyn, uint32_t *heavy, uint32_t heavy_cap) {
     hipLaunchKernelGGL(k_flag_heavy, dim3((NB + 255) / 256), dim3(256), 0, s, off, NB, dyn, heavy, heavy_cap);

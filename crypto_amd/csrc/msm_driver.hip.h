@@ -271,7 +271,7 @@ int32_t msm_device_ranges(Slot &sl, const uint32_t *d_bases, const uint32_t *d_s
             q.c = c; q.W = W; q.key_wstride = g.B; q.val_base = 0; q.val_wstride = 0;
             q.part_log = ps_part_log(NB); q.P = (NB + (1u << q.part_log) - 1) >> q.part_log; q.ntiles = (uint32_t)((nk + PS_TILE - 1) / PS_TILE);
             q.bad = sl.flags.as<uint32_t>();
-            const uint32_t dyn_args[5] = {(uint32_t)forced_chunk(), g.min_chunk, g.max_chunks, g.lanes_per_chunk, (uint32_t)T};
+            const uint32_t dyn_args[6] = {(uint32_t)forced_chunk(), g.min_chunk, g.max_chunks, g.lanes_per_chunk, (uint32_t)T, 0u};
             HIPCHK(hipMemsetAsync(sl.heavy.p, 0, 4, s));
             launch_psort(s, q, NB, sl.cnt.as<uint32_t>(), sl.cursor.as<uint32_t>(), sl.bsums.as<uint32_t>(), sl.digits.p, sl.off.as<uint32_t>(), sl.entries.as<uint32_t>(),
                          16u * (uint32_t)CH /* replaced on the device, dyn_chunk.hip.h */, sl.heavy.as<uint32_t>(), HEAVY_CAP, dyn_args, dyn);
@@ -438,7 +438,7 @@ template <class C> int32_t pre_geometry(const PreTable &pt, size_t n, PreGeom &g
     g.NG = (size_t)g.PW * g.G;
     g.Emax = (size_t)n * W;
     if (g.Emax >= (1ull << 32) || (uint64_t)W * pt.n >= (1ull << 31) || W > PS_MAX_W) return DGPU_E_BADARG;
-    g.CH = C::NFP == 2 ? choose_chunk(g.Emax, 32, 150000, 2) : choose_chunk(g.Emax, 16, 300000, 1);
+    g.CH = C::NFP == 2 ? choose_chunk(g.Emax, 32, 150000, 2) : choose_chunk(g.Emax, 16, 300000, 1);     // (sizes the partial slots: the rule WITHOUT the run-length term gives the most chunks any E <= Emax can have)
     g.T = (g.Emax + g.CH - 1) / g.CH;
     g.min_chunk = C::NFP == 2 ? 32u : 16u; g.max_chunks = C::NFP == 2 ? 150000u : 300000u; g.lanes_per_chunk = C::NFP == 2 ? 2u : 1u;
     g.HEAVY_CAP = (uint32_t)(g.Emax / (16u * 16u)) + 1;         // (see plain_geometry)
@@ -496,7 +496,7 @@ int32_t pre_sort(Slot &sl, const PreTable &pt, const PreGeom &g, size_t boff, co
     if ((rc = ws_pre<C>(sl, pt, g, n))) return rc;
     q.bad = sl.flags.as<uint32_t>();
     const uint32_t heavy_thr = dyn ? 16u * (uint32_t)g.CH /* replaced on the device, dyn_chunk.hip.h */ : 0xffffffffu /* nothing flagged */;
-    const uint32_t dyn_args[5] = {(uint32_t)forced_chunk(), g.min_chunk, g.max_chunks, g.lanes_per_chunk, (uint32_t)g.T};
+    const uint32_t dyn_args[6] = {(uint32_t)forced_chunk(), g.min_chunk, g.max_chunks, g.lanes_per_chunk, (uint32_t)g.T, g.NB};
     StageTimer st(sl, "msm.psort");
     HIPCHK(hipMemsetAsync(sl.heavy.p, 0, 4, sl.stream));
     if (reset_flag) HIPCHK(hipMemsetAsync(sl.flags.p, 0, 4, sl.stream));
@@ -517,7 +517,7 @@ int32_t pre_acc(Slot &sl, const PreTable &pt, const PreGeom &g, const uint32_t *
     HIPCHK(hipMemsetAsync(bucket_inf, 1, NB, s));
     if (derive_dyn) {
         HIPCHK(hipMemsetAsync(sl.heavy.p, 0, 4, s));
-        launch_dyn_chunk(s, off + NB, (uint32_t)forced_chunk(), g.min_chunk, g.max_chunks, g.lanes_per_chunk, (uint32_t)T, dyn);
+        launch_dyn_chunk(s, off + NB, (uint32_t)forced_chunk(), g.min_chunk, g.max_chunks, g.lanes_per_chunk, (uint32_t)T, dyn, NB);
         launch_flag_heavy(s, off, NB, dyn, sl.heavy.as<uint32_t>(), g.HEAVY_CAP);
     }
     {

@@ -134,7 +134,7 @@ __global__ void __launch_bounds__(256) k_scan_add(uint32_t *__restrict__ out, ui
 
 // ---- chunking from the actual pair count (dyn_chunk.hip.h) ------------------------------------------------------------
 // one thread: choose_chunk's rule (dock_core.hip) on E = *total.  fixed_ch != 0: a chunk length forced by the host (tuning knobs) is kept.
-__global__ void k_dyn_chunk(const uint32_t *__restrict__ total, uint32_t fixed_ch, uint32_t min_chunk, uint32_t max_chunks, uint32_t lanes_per_chunk, uint32_t T_max, uint32_t *__restrict__ dyn) {
+__global__ void k_dyn_chunk(const uint32_t *__restrict__ total, uint32_t fixed_ch, uint32_t min_chunk, uint32_t max_chunks, uint32_t lanes_per_chunk, uint32_t T_max, uint32_t *__restrict__ dyn, uint32_t nb_shared) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const uint32_t E = *total;
     uint32_t ch = fixed_ch;
@@ -148,6 +148,13 @@ __global__ void k_dyn_chunk(const uint32_t *__restrict__ total, uint32_t fixed_c
             if (rounds < 1) rounds = 1;
             const uint32_t len = (uint32_t)(((uint64_t)E + (uint64_t)rounds * resident - 1) / ((uint64_t)rounds * resident));
             if (len >= 16 && len <= 4096) ch = len;
+        }
+        // one bucket set shared by all windows (nb_shared buckets): the runs are long, and a chunk that ends inside a run leaves a partial for the
+        // fix-up to fold.  When the average run is at least half the chunk of ONE whole round, the launch is one round instead of two
+        // (choose_chunk, dock_core.hip, has the measurements)
+        if (nb_shared) {
+            const uint32_t run = E / nb_shared, one = (uint32_t)(((uint64_t)E + resident - 1) / resident);
+            if (one > ch && 2 * run >= one && one <= 4096) ch = one;
         }
     }
     if (T_max && (E + ch - 1) / ch > T_max) ch = (E + T_max - 1) / T_max;      // never more chunks than partial slots

@@ -12,7 +12,8 @@ void launch_sort_sweep(hipStream_t s, bool wide, bool scatter, unsigned grid, si
                        uint32_t *cnt, const uint32_t *off, uint32_t *entries, uint32_t heavy_thr, uint32_t *heavy, uint32_t heavy_cap);
 void launch_scan(hipStream_t s, const uint32_t *cnt, uint32_t *off, uint32_t *cursor, uint32_t *bsums, size_t NB);
 // chunking of the accumulation from the pair count the sort produced (dyn_chunk.hip.h): dyn[0..3] = chunk length, chunks, heavy threshold, pairs
-void launch_dyn_chunk(hipStream_t s, const uint32_t *total, uint32_t fixed_ch, uint32_t min_chunk, uint32_t max_chunks, uint32_t lanes_per_chunk, uint32_t T_max, uint32_t *dyn);
+void launch_dyn_chunk(hipStream_t s, const uint32_t *total, uint32_t fixed_ch, uint32_t min_chunk, uint32_t max_chunks, uint32_t lanes_per_chunk, uint32_t T_max, uint32_t *dyn,
+                      uint32_t nb_shared = 0 /* buckets of the ONE set all windows share (table pipeline), 0: a set per window */);
 void launch_flag_heavy(hipStream_t s, const uint32_t *off, uint32_t NB, const uint32_t *dyn, uint32_t *heavy, uint32_t heavy_cap);
 size_t scan_blocks(size_t NB);
 // ---- two-level partition sort (k_psort.hip, psort_kernels.hip.h) ----

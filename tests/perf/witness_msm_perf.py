@@ -9,6 +9,9 @@ import crypto_amd as ca
 from crypto_amd import fixed_base as FB, serde
 import bench as B
 ca.init(0)
+if os.environ.get("CHUNK"):      # terms per lane of the accumulation forced (dgpu_set_chunk)
+    from crypto_amd._native import lib as _lib
+    assert _lib().dgpu_set_chunk(int(os.environ["CHUNK"])) == 0
 n = 1 << int(os.environ.get("LOG2N", "20"))
 gens = {ca.G1: serde.deserialize(ca.G1, bytes.fromhex(B.G1_GEN_COMPRESSED))[0][0], ca.G2: serde.deserialize(ca.G2, bytes.fromhex(B.G2_GEN_COMPRESSED))[0][0]}
 z = B.seeded_scalars(7, n)

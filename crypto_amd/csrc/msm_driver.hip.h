@@ -391,13 +391,13 @@ template <class F> int32_t run_shards(size_t parts, F body) { return par_run(par
 // ---- shared-bucket-set pipeline over a precomputed-multiples table (pre_kernels.hip.h, psort_kernels.hip.h) ------------------------------------
 
 // Window width of a table for n bases (measured, tests/perf/pre_perf.py at 2^16 .. 2^21, profiles/r02a_table_sizes.txt): 20 bits from
-// 2^17.5 terms on (W = 13: fewer additions, and runs short enough that few buckets are cut by chunk borders), 16 bits for 2^15 .. 2^17.5
+// 2^18.3 terms on (2^17.5 until round 4's re-measurement) (W = 13: fewer additions, and runs short enough that few buckets are cut by chunk borders), 16 bits for 2^15 .. 2^18.3
 // (W = 16, but one set of 2^15 buckets instead of sixteen: +25 % MSM/s at 2^16), and below 2^15 terms no table at all (0): the plain
 // pipeline's narrow windows (c = 8 .. 10) keep the bucket count proportionate to the terms there.
 inline int choose_c_pre(size_t n) {
     if (gs.window_bits.load() >= 16 && gs.window_bits.load() <= 22) return gs.window_bits.load();
     if (n < (1u << 15)) return 0;
-    return n >= 185364 ? 20 : 16;
+    return n >= 320000 ? 20 : 16;      // (re-measured in round 4, profiles/r04zz_table_widths.txt: at 2^18 terms width 16 is 1.32 ms against 1.44 for width 20 and equal with four in flight; at 2^19 width 20 wins both ways)
 }
 
 // sum_j A_j + 2^lb * sum_j j S_j over the PW pseudo-windows (bucket b = j 2^lb + k of the one bucket set weighs b + 1 = (k + 1) + j 2^lb)

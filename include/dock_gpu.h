@@ -154,7 +154,7 @@ int32_t dgpu_msm_g2_handle(uint64_t bases, size_t offset, const uint64_t *scalar
  * (`&query[1..]`) and sub-ranges keep working.  While the table is being built the handle is unavailable (DGPU_E_BADARG).
  * A handle too small for a bucket table to pay (below 2^15 points with window_bits = 0) stays plain; with up to 8192 points it gets the small
  * path's table (dgpu_set_small_msm_max above) if its upload has not built it already.
- * The automatic width (20 from 2^17.5 points) is the optimum for full-width scalars.  A query that is multiplied by a WITNESS (a proving key's
+ * The automatic width (20 from 320 000 points) is the optimum for full-width scalars.  A query that is multiplied by a WITNESS (a proving key's
  * a / b / l queries: half of a Groth16 witness is 0 or 1, much of the rest small) adds fewer points per MSM but reduces the same number of
  * buckets, and a proof reduces five bucket sets: DGPU_TABLE_C_WITNESS = 17 has the window count of 18 (15) with half the buckets — measured
  * at 2^20 constraints: 12.4 -> 11.75 ms per proof, 10.2 -> 9.6 with four in flight (19: 12.5, 18: 12.0, 16: 12.9). */

@@ -26,7 +26,7 @@ def six(K=8):
     th = [threading.Thread(target=w, args=(k,)) for k in range(6)]
     t0 = time.perf_counter(); [t.start() for t in th]; [t.join() for t in th]
     return (time.perf_counter() - t0) / (6 * K) * 1e3
-settings = [("chunk", c) for c in (0, 40, 52, 64, 80, 104)] + [("shift", s) for s in (2, 4)]
+settings = [("chunk", c) for c in [int(x) for x in os.environ.get("CHUNKS", "0,40,52,64,80,104").split(",")]] + [("shift", s) for s in [int(x) for x in os.environ.get("SHIFTS", "2,4").split(",") if x]]
 res = {s: [] for s in settings}
 for rep in range(4):
     for s in settings:

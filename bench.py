@@ -102,6 +102,7 @@ def main():
     ap.add_argument("--no-cpu-legs", action="store_true", help="skip secondary.cpu (the CPU path timed beside configs 3 and 4: about 10 s of host work)")
     ap.add_argument("--no-table", action="store_true", help="time the plain resident pipeline (no precomputed-multiples table)")
     ap.add_argument("--reduce-shift", type=int, default=-1, help="development: dgpu_set_reduce_shift (log2 buckets per lane of the bucket reduction; -1 = automatic)")
+    ap.add_argument("--reduce-lanes", type=int, default=-1, help="development: dgpu_set_reduce_lanes (0 = bit marginals, the default; 1 / 4 = the scan form of rounds 1-4)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -141,6 +142,9 @@ def main():
     if args.reduce_shift >= 0:
         from crypto_amd._native import lib as _lib
         assert _lib().dgpu_set_reduce_shift(args.reduce_shift) == 0
+    if args.reduce_lanes >= 0:
+        from crypto_amd._native import lib as _lib
+        assert _lib().dgpu_set_reduce_lanes(args.reduce_lanes) == 0
     if args.log2n == 0:
         lg = 0
         while (1 << lg) < world:

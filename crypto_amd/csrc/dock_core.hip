@@ -251,7 +251,7 @@ int32_t dgpu_set_min_gpu_n(size_t n) { gs.min_gpu_n = n; return DGPU_OK; }
 size_t dgpu_get_min_gpu_n(void) { return gs.min_gpu_n.load(); }
 int32_t dgpu_set_window_bits(int32_t c) { if (c != 0 && (c < 7 || c > 22)) return DGPU_E_BADARG; gs.window_bits = c; return DGPU_OK; }
 int32_t dgpu_set_chunk(int32_t terms) { if (terms != 0 && (terms < 16 || terms > 4096)) return DGPU_E_BADARG; gs.chunk = terms; return DGPU_OK; }
-int32_t dgpu_set_reduce_lanes(int32_t lanes) { if (lanes != 1 && lanes != 4) return DGPU_E_BADARG; gs.reduce_lanes = lanes; return DGPU_OK; }
+int32_t dgpu_set_reduce_lanes(int32_t lanes) { if (lanes != 0 && lanes != 1 && lanes != 2 && lanes != 4) return DGPU_E_BADARG; gs.reduce_lanes = lanes; return DGPU_OK; }
 int32_t dgpu_set_reduce_shift(int32_t sh) { if (sh < -1 || sh > 6) return DGPU_E_BADARG; gs.reduce_shift = sh; return DGPU_OK; }
 int32_t dgpu_set_small_msm_max(size_t n) { if (n > 8192) return DGPU_E_BADARG; gs.small_max = n; return DGPU_OK; }
 int32_t dgpu_set_miller_pipeline(int32_t mode) { if (mode < 0 || mode > 7) return DGPU_E_BADARG; gs.ml_mode = mode; return DGPU_OK; }

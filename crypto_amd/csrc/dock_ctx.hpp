@@ -111,7 +111,7 @@ struct Shared {
     std::atomic<int> window_bits{0};
     std::atomic<size_t> small_max{8192};      // dgpu_set_small_msm_max: MSMs of up to this many terms on plain bases take the two-launch tree path (small_kernels.hip.h); 0 = never
     std::atomic<int> chunk{0};
-    std::atomic<int> reduce_lanes{4};         // dgpu_set_reduce_lanes: members per point in the last reduction kernel (1: k_reduce_top, 4: k_reduce_top_quad)
+    std::atomic<int> reduce_lanes{0};         // dgpu_set_reduce_lanes: 0 = the shared bucket set by bit marginals (reduce_kernels.hip.h; the plain pipeline then takes 4); 1 / 4: the scan form with k_reduce_top / k_reduce_top_quad (members per point in the last kernel)
     std::atomic<int> reduce_shift{-1};        // dgpu_set_reduce_shift: log2 buckets per lane of k_reduce_l0 on the table pipeline (-1 = automatic)
     std::atomic<int> ml_mode{7};              // dgpu_set_miller_pipeline: bit 0 the two-launch line kernel of small Miller loops, bit 1 the 18-role product tree, bit 2 sixteen lanes per pair in the line kernel (dock_pairing.hip)
     uint64_t allocs_at_reset = 0, alloc_ns_at_reset = 0;

@@ -7,4 +7,6 @@ template void launch_merge_buckets<G1>(hipStream_t, uint32_t, uint32_t *, uint8_
 template void launch_reduce_l0<G1>(hipStream_t, unsigned, const uint32_t *, const uint8_t *, uint32_t, int, uint32_t *, uint8_t *);
 template void launch_reduce_top<G1>(hipStream_t, unsigned, const uint32_t *, const uint8_t *, int, int, uint32_t *, uint8_t *, int);
 template void launch_reduce_top_s<G1>(hipStream_t, unsigned, const uint32_t *, const uint8_t *, int, int, uint32_t *, uint8_t *, uint32_t *, uint8_t *, int);
+template int launch_reduce_marginals<G1>(hipStream_t, unsigned, const uint32_t *, const uint8_t *, uint32_t, int, uint32_t *, uint8_t *, uint32_t *, uint8_t *, bool);
+template size_t reduce_marginals_points<G1>(size_t);
 }  // namespace msm

@@ -318,7 +318,7 @@ int32_t msm_device_ranges(Slot &sl, const uint32_t *d_bases, const uint32_t *d_s
     {
         StageTimer st(sl, "msm.reduce");
         launch_reduce_l0<C>(s, (unsigned)g.NG, sl.bucket.as<uint32_t>(), sl.bucket_inf.as<uint8_t>(), NB, g.mshift, sl.l1.as<uint32_t>(), sl.l1_inf.as<uint8_t>());
-        launch_reduce_top<C>(s, (unsigned)W, sl.l1.as<uint32_t>(), sl.l1_inf.as<uint8_t>(), g.G, 6 + g.mshift, sl.win.as<uint32_t>(), sl.win_inf.as<uint8_t>(), gs.reduce_lanes.load());
+        launch_reduce_top<C>(s, (unsigned)W, sl.l1.as<uint32_t>(), sl.l1_inf.as<uint8_t>(), g.G, 6 + g.mshift, sl.win.as<uint32_t>(), sl.win_inf.as<uint8_t>(), gs.reduce_lanes.load() == 1 ? 1 : 4);
     }
     HIPCHK(hipGetLastError());
     std::vector<uint64_t> hwin((size_t)W * 2 * C::ABI_W);
@@ -415,6 +415,20 @@ void host_fold_shared(const uint64_t *a_abi, const uint8_t *a_inf, const uint64_
     memcpy(out_xyz, &X, sizeof(HF)); memcpy(out_xyz + FWORDS, &Y, sizeof(HF)); memcpy(out_xyz + 2 * FWORDS, &Z, sizeof(HF));
 }
 
+// P + 2^shift * sum_t 2^t M_t (reduce_kernels.hip.h): pts[0] = P, pts[1 + t] = M_t, nm marginals
+template <class HF>
+void host_fold_marginals(const uint64_t *pts, const uint8_t *inf, int nm, int shift, uint64_t *out_xyz) {
+    typedef hostf::HXyzz<HF> PT;
+    const size_t FWORDS = sizeof(HF) / 8;
+    auto load = [&](int i) { PT t = PT::identity(); if (!inf[i]) { const uint64_t *src = pts + (size_t)i * 4 * FWORDS; t.inf = false; memcpy(&t.x, src, sizeof(HF)); memcpy(&t.y, src + FWORDS, sizeof(HF)); memcpy(&t.zz, src + 2 * FWORDS, sizeof(HF)); memcpy(&t.zzz, src + 3 * FWORDS, sizeof(HF)); } return t; };
+    PT acc = PT::identity();
+    for (int t = nm - 1; t >= 0; t--) { if (!acc.inf) acc.dbl_in_place(); acc.add_in_place(load(1 + t)); }
+    if (!acc.inf) for (int k = 0; k < shift; k++) acc.dbl_in_place();
+    acc.add_in_place(load(0));
+    HF X, Y, Z; acc.to_normalised_jacobian(X, Y, Z);
+    memcpy(out_xyz, &X, sizeof(HF)); memcpy(out_xyz + FWORDS, &Y, sizeof(HF)); memcpy(out_xyz + 2 * FWORDS, &Z, sizeof(HF));
+}
+
 // ---- the shared-bucket-set pipeline over a precomputed-multiples table, in two stages -------------------------------------------------
 // Stage 1 (pre_sort): scalars -> the key-sorted row list `entries` and the bucket offsets `off` (off[NB] = number of pairs).  The result
 // depends on the scalars and on the table's SHAPE (c, W, rows, first row) only, not on the curve or on the points: the MSMs of a proof
@@ -468,10 +482,11 @@ template <class C> int32_t ws_pre(Slot &sl, const PreTable &pt, const PreGeom &g
     // (sized for the reduction's shape of a call that runs alone as well: pre_geometry picks fewer, longer groups when the context is busy, and a
     //  slot reserved under load must not allocate when it is later used by a lone call)
     const size_t NGw = std::max(g.NG, (size_t)(NB >> 9)), PWw = std::max((size_t)PW, (size_t)(NB >> 15));
-    if ((rc = sl.l1.ensure(NGw * 2 * C::XW * 4))) return rc;
-    if ((rc = sl.l1_inf.ensure(NGw * 2))) return rc;
-    if ((rc = sl.win.ensure((size_t)2 * PWw * 4 * C::ABI_W * 4))) return rc;        // A_j then S_j
-    if ((rc = sl.win_inf.ensure(2 * PWw))) return rc;
+    const size_t mpts = reduce_marginals_points<C>(NGw);                            // class buffers of the marginal reduction (reduce_kernels.hip.h)
+    if ((rc = sl.l1.ensure(std::max(NGw * 2, mpts) * C::XW * 4))) return rc;
+    if ((rc = sl.l1_inf.ensure(std::max(NGw * 2, mpts)))) return rc;
+    if ((rc = sl.win.ensure(std::max((size_t)2 * PWw, (size_t)32) * 4 * C::ABI_W * 4))) return rc;        // A_j then S_j; or P and the marginals
+    if ((rc = sl.win_inf.ensure(std::max((size_t)2 * PWw, (size_t)32)))) return rc;
     if ((rc = sl.dyn.ensure(msm::dyn_words(T) * 4))) return rc;
     { const size_t hslots = 2 * (T / msm::HEAVY_RANGE + 2); if ((rc = sl.hpart.ensure(hslots * C::XW * 4))) return rc; if ((rc = sl.hpart_inf.ensure(hslots))) return rc; }
     (void)pt;
@@ -544,24 +559,33 @@ int32_t pre_finish(Slot &sl, const PreGeom &g, bool check_flag, uint64_t *out_xy
     hipStream_t s = sl.stream;
     uint32_t *win_a = sl.win.as<uint32_t>(), *win_s = win_a + (size_t)PW * 4 * C::ABI_W;
     uint8_t *inf_a = sl.win_inf.as<uint8_t>(), *inf_s = inf_a + PW;
+    // reduce_lanes 0 (default): bit marginals (reduce_kernels.hip.h); 1 / 4: the scan form (k_reduce_l0 + k_reduce_top / _quad), kept for the comparison tests
+    const int rl = gs.reduce_lanes.load();
+    const bool marginals = (rl == 0 || rl == 2) && g.NG >= 2;        // (2: the class folds with one lane per value, for the comparison)
+    int nm = 0;
     {
         StageTimer st(sl, "msm.reduce");
-        launch_reduce_l0<C>(s, (unsigned)g.NG, sl.bucket.as<uint32_t>(), sl.bucket_inf.as<uint8_t>(), NB, g.mshift, sl.l1.as<uint32_t>(), sl.l1_inf.as<uint8_t>());
-        launch_reduce_top_s<C>(s, (unsigned)PW, sl.l1.as<uint32_t>(), sl.l1_inf.as<uint8_t>(), g.G, 6 + g.mshift, win_a, inf_a, win_s, inf_s, gs.reduce_lanes.load());
+        if (marginals) nm = launch_reduce_marginals<C>(s, (unsigned)g.NG, sl.bucket.as<uint32_t>(), sl.bucket_inf.as<uint8_t>(), NB, g.mshift, sl.l1.as<uint32_t>(), sl.l1_inf.as<uint8_t>(), win_a, inf_a, rl == 0);
+        else {
+            launch_reduce_l0<C>(s, (unsigned)g.NG, sl.bucket.as<uint32_t>(), sl.bucket_inf.as<uint8_t>(), NB, g.mshift, sl.l1.as<uint32_t>(), sl.l1_inf.as<uint8_t>());
+            launch_reduce_top_s<C>(s, (unsigned)PW, sl.l1.as<uint32_t>(), sl.l1_inf.as<uint8_t>(), g.G, 6 + g.mshift, win_a, inf_a, win_s, inf_s, gs.reduce_lanes.load() == 1 ? 1 : 4);
+        }
     }
     HIPCHK(hipGetLastError());
-    std::vector<uint64_t> hwin((size_t)2 * PW * 2 * C::ABI_W);
-    std::vector<uint8_t> hinf(2 * PW);
+    const size_t npts = marginals ? (size_t)nm + 1 : (size_t)2 * PW;
+    std::vector<uint64_t> hwin(npts * 2 * C::ABI_W);
+    std::vector<uint8_t> hinf(npts);
     uint32_t hbad = 0;
-    HIPCHK(hipMemcpyAsync(hwin.data(), sl.win.p, (size_t)2 * PW * 4 * C::ABI_W * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(hinf.data(), sl.win_inf.p, 2 * PW, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(hwin.data(), sl.win.p, npts * 4 * C::ABI_W * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(hinf.data(), sl.win_inf.p, npts, hipMemcpyDeviceToHost, s));
     if (check_flag) HIPCHK(hipMemcpyAsync(&hbad, sl.flags.p, 4, hipMemcpyDeviceToHost, s));      // (a shared sort was checked by dgpu_scalars_sort)
     auto tsync0 = std::chrono::steady_clock::now();
     HIPCHK(hipStreamSynchronize(s));
     auto tsync1 = std::chrono::steady_clock::now();
     if (gs.prof) prof_flush(sl);
     if (hbad) return DGPU_E_BADARG;                  // a scalar >= 2^255 (sort_kernels.hip.h k_digit_codes)
-    host_fold_shared<HF>(hwin.data(), hinf.data(), hwin.data() + (size_t)PW * 2 * C::ABI_W, hinf.data() + PW, PW, g.lb, out_xyz);
+    if (marginals) host_fold_marginals<HF>(hwin.data(), hinf.data(), nm, g.mshift + (C::NFP == 2 ? 1 : 0), out_xyz);
+    else host_fold_shared<HF>(hwin.data(), hinf.data(), hwin.data() + (size_t)PW * 2 * C::ABI_W, hinf.data() + PW, PW, g.lb, out_xyz);
     if (gs.prof) {
         auto t2 = std::chrono::steady_clock::now();
         prof_add_host("msm.host_wait", std::chrono::duration<double, std::milli>(tsync1 - tsync0).count());

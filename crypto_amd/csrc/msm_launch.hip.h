@@ -20,6 +20,10 @@ template <class C> void launch_fixup_heavy(hipStream_t s, const uint32_t *heavy,
                                            const uint32_t *head, const uint32_t *tail, const uint8_t *part_inf, size_t T, uint32_t *dyn, uint32_t *hpart, uint8_t *hpart_inf);
 template <class C> void launch_merge_buckets(hipStream_t s, uint32_t NB, uint32_t *dst, uint8_t *dst_inf, const uint32_t *src, const uint8_t *src_inf);
 template <class C> void launch_reduce_l0(hipStream_t s, unsigned NG, const uint32_t *bucket, const uint8_t *bucket_inf, uint32_t NB, int mshift, uint32_t *l1, uint8_t *l1_inf);
+// the shared bucket set by bit marginals (reduce_kernels.hip.h): level 0 + the class folds; leaves P and one M per bit of the lane index in win_abi /
+// win_inf (ABI XYZZ form, point 0 = P, point 1 + t = M_t) and returns the number of marginals.  cls / cls_inf: reduce_m_points(NG, ..) points / bytes.
+template <class C> int launch_reduce_marginals(hipStream_t s, unsigned NG, const uint32_t *bucket, const uint8_t *bucket_inf, uint32_t NB, int mshift, uint32_t *cls, uint8_t *cls_inf, uint32_t *win_abi, uint8_t *win_inf, bool quad);
+template <class C> size_t reduce_marginals_points(size_t NG);
 template <class C> void launch_reduce_top(hipStream_t s, unsigned W, const uint32_t *l1, const uint8_t *l1_inf, int G, int gshift, uint32_t *win_abi, uint8_t *win_inf, int lanes);
 
 // the small-MSM path (small_kernels.hip.h; k_g1_small.hip / k_g2_small.hip): 64 signed 4-bit windows, eight multiples per base (and, for a table kept

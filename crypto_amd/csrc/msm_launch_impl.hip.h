@@ -2,6 +2,7 @@
 // units, which explicitly instantiate the ones they own.
 #pragma once
 #include "msm_launch.hip.h"
+#include "reduce_kernels.hip.h"
 
 namespace msm {
 // the launchers take the curve as the driver names it (G1 / G2) and instantiate the kernels for the description the MSM pipeline runs it as
@@ -46,6 +47,35 @@ template <class C> void launch_reduce_l0(hipStream_t s, unsigned NG, const uint3
     const unsigned blocks = (NG + 3) / 4;          // four groups (waves) per block: whole CUs (msm_kernels.hip.h)
     if constexpr (C::NFP == 2) hipLaunchKernelGGL((k_reduce_l0_pair<G2P>), dim3(blocks), dim3(256), 0, s, bucket, bucket_inf, NB, mshift, l1, l1_inf, NG);     // G2: lane pairs
     else hipLaunchKernelGGL((k_reduce_l0<typename C::MSM>), dim3(blocks), dim3(256), 0, s, bucket, bucket_inf, NB, mshift, l1, l1_inf, NG);
+}
+// geometry of the class folds: quad = four members per value and 64 values per block on either curve (k_reduce_cls_quad); else one (pair of) lane(s) per value, 64 / 32 per wave
+template <class C> inline void red_levels(bool quad, int &PL, int &KK) { typedef RedGeom<typename C::ACC> RG; PL = quad ? 64 : RG::PL; KK = quad ? 6 : RG::K; }
+template <class C> size_t reduce_marginals_points(size_t NG) {           // (the larger of the two forms)
+    typedef RedGeom<typename C::ACC> RG;
+    size_t best = 0;
+    for (int quad = 0; quad < 2; quad++) {
+        int PL, KK; red_levels<C>(quad != 0, PL, KK);
+        size_t total = (size_t)(RG::K + 2) * NG, cnt = NG; int nm = RG::K;
+        while (cnt > 1) { const int steps = std::min(KK, red_log2((unsigned)cnt)); const size_t chunks = std::max<size_t>(1, cnt / PL); nm += steps; total += (size_t)(nm + 2) * chunks; cnt = chunks; }
+        best = std::max(best, total + 64);
+    }
+    return best;
+}
+template <class C> int launch_reduce_marginals(hipStream_t s, unsigned NG, const uint32_t *bucket, const uint8_t *bucket_inf, uint32_t NB, int mshift, uint32_t *cls, uint8_t *cls_inf, uint32_t *win_abi, uint8_t *win_inf, bool quad) {
+    typedef typename C::ACC A; typedef RedGeom<A> RG;
+    hipLaunchKernelGGL((k_reduce_m0<A>), dim3((NG + 3) / 4), dim3(256), 0, s, bucket, bucket_inf, NB, mshift, cls, cls_inf, NG);
+    int PL, KK; red_levels<C>(quad, PL, KK);
+    unsigned cnt = NG; int nm = RG::K;
+    uint32_t *in = cls; uint8_t *in_inf = cls_inf;
+    while (cnt > 1) {
+        const int steps = std::min(KK, red_log2(cnt));
+        const unsigned chunks = std::max(1u, cnt / (unsigned)PL), npairs = 1u + (unsigned)(nm + 1) / 2u, waves = npairs * chunks;
+        uint32_t *out = in + (size_t)(nm + 2) * cnt * A::XW; uint8_t *out_inf = in_inf + (size_t)(nm + 2) * cnt;
+        if (quad) hipLaunchKernelGGL((k_reduce_cls_quad<A>), dim3(waves), dim3(256 * A::LPP), 0, s, (const uint32_t *)in, (const uint8_t *)in_inf, cnt, nm, out, out_inf, chunks == 1 ? 1 : 0, win_abi, win_inf);
+        else hipLaunchKernelGGL((k_reduce_cls<A>), dim3((waves + 3) / 4), dim3(256), 0, s, (const uint32_t *)in, (const uint8_t *)in_inf, cnt, nm, out, out_inf, chunks == 1 ? 1 : 0, win_abi, win_inf);
+        nm += steps; cnt = chunks; in = out; in_inf = out_inf;
+    }
+    return nm;
 }
 template <class C> void launch_reduce_top(hipStream_t s, unsigned W, const uint32_t *l1, const uint8_t *l1_inf, int G, int gshift, uint32_t *win_abi, uint8_t *win_inf, int lanes) {
     if (lanes == 4) {          // four members per point: the chain of general additions is 4 products deep instead of 14

@@ -64,7 +64,7 @@ def test_any_reduction_geometry_same_point(gname, n, c):
     sparse = sc.copy(); sparse[5:] = 0; sparse[:5, 1:] = 0          # a handful of filled buckets: neighbouring suffix sums are EQUAL points (the doubling branch of the additions)
     ref_sparse = plain.msm_bigint(sparse)
     try:
-        for lanes in (1, 4):                                        # dgpu_set_reduce_lanes: k_reduce_top / k_reduce_top_quad (four members per point)
+        for lanes in (0, 2, 1, 4):                                     # dgpu_set_reduce_lanes: 0 = bit marginals (reduce_kernels.hip.h, the default; 2: their class folds with one lane per value); k_reduce_top / k_reduce_top_quad (four members per point)
             assert lib().dgpu_set_reduce_lanes(lanes) == 0
             for sh in (-1, 0, 1, 2, 3, 4, 5, 6):
                 assert lib().dgpu_set_reduce_shift(sh) == 0
@@ -72,9 +72,9 @@ def test_any_reduction_geometry_same_point(gname, n, c):
             lib().dgpu_set_reduce_shift(-1)
             assert (plain.msm_bigint(sc) == ref).all(), lanes
             assert (tab.msm_bigint(sparse) == ref_sparse).all() and (plain.msm_bigint(sparse) == ref_sparse).all(), lanes
-        assert lib().dgpu_set_reduce_shift(7) != 0 and lib().dgpu_set_reduce_lanes(2) != 0
+        assert lib().dgpu_set_reduce_shift(7) != 0 and lib().dgpu_set_reduce_lanes(3) != 0
     finally:
-        lib().dgpu_set_reduce_shift(-1); lib().dgpu_set_reduce_lanes(4)
+        lib().dgpu_set_reduce_shift(-1); lib().dgpu_set_reduce_lanes(0)
 
 
 def test_skewed_and_degenerate_scalars_on_a_table():

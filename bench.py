@@ -139,12 +139,17 @@ def main():
         from crypto_amd import sharded, serde, fixed_base as FB
 
     ca.init(local)
-    if args.reduce_shift >= 0:
+    # development knobs exist in the twin only (include/dock_gpu_dev.h): a run that sets one is a run of the TWIN from here on, and says so on its line
+    import contextlib
+    dev_run = (args.reduce_shift >= 0 or args.reduce_lanes >= 0) and not STUB
+    whole = contextlib.ExitStack()
+    if dev_run:
+        whole.enter_context(ca.twin())
         from crypto_amd._native import lib as _lib
-        assert _lib().dgpu_set_reduce_shift(args.reduce_shift) == 0
-    if args.reduce_lanes >= 0:
-        from crypto_amd._native import lib as _lib
-        assert _lib().dgpu_set_reduce_lanes(args.reduce_lanes) == 0
+        if args.reduce_shift >= 0:
+            assert _lib().dgpu_set_reduce_shift(args.reduce_shift) == 0
+        if args.reduce_lanes >= 0:
+            assert _lib().dgpu_set_reduce_lanes(args.reduce_lanes) == 0
     if args.log2n == 0:
         lg = 0
         while (1 << lg) < world:
@@ -206,15 +211,11 @@ def main():
     for _ in range(args.warmup):
         step()
     run_steps(2 * inflight)                           # untimed: every host thread / slot has run once (the workspaces were sized at upload / precompute)
-    # sequential pass (one call in flight): per-stage HIP-event times without overlap, and the single-call latency
-    ca.prof.enable(True)
-    ca.prof.reset()
+    # sequential pass (one call in flight): the single-call latency
     tl = time.perf_counter()
     for _ in range(3):
         step()
     latency_ms = (time.perf_counter() - tl) / 3 * 1e3
-    stages_seq = ca.prof.read()
-    ca.prof.reset()
     if world > 1:
         dist.barrier()
     sync()
@@ -227,8 +228,27 @@ def main():
     dt = time.perf_counter() - t0
     allocs_timed = ca.device_alloc_count() - allocs0
     assert (last == res).all(), "result changed between runs"
-    stages = ca.prof.read()
-    ca.prof.enable(False)
+    # Stage breakdown and the dominant kernel's duration (HIP events on the library's own stream around every stage): the stage timers are part of
+    # the DEVELOPMENT surface (include/dock_gpu_dev.h), which the product library does not export.  So this leg — untimed, rank 0 — runs the same
+    # workload on the development twin (libdock_gpu_dev.so: the product's objects, kernels included, plus that surface) with its own copy of the
+    # operands: one call in flight (stages_seq: the roofline's kernel duration) and the timed region's shape (stages: durations that overlap).
+    stages_seq, stages = {}, {}
+    if rank == 0:
+        with ca.twin():
+            with FB.WindowTable(ca.G1, gen1[0]) as gtab_t:
+                db_t = gtab_t.multiply_many_to_bases(ks)
+            if use_table:
+                db_t.precompute()
+            ds_t = ca.DeviceScalars(scalars)
+            assert (db_t.msm_resident(ds_t)[:18] == (res if world == 1 else db.msm_resident(ds))[:18]).all(), "twin != product"
+            list(pool.map(lambda _: db_t.msm_resident(ds_t), range(2 * inflight)))
+            ca.prof.enable(True); ca.prof.reset()
+            for _ in range(3):
+                db_t.msm_resident(ds_t)
+            stages_seq = ca.prof.read(); ca.prof.reset()
+            list(pool.map(lambda _: db_t.msm_resident(ds_t), range(args.steps)))
+            stages = ca.prof.read(); ca.prof.enable(False)
+            db_t.free(); ds_t.free()
     per_rank_table_ms = [round(table_ms, 1)]
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=cdev if cdev is not None else "cpu")
@@ -286,9 +306,10 @@ def main():
             "stages_ms_one_in_flight": {k.replace("msm.", ""): round(v[0] / max(1, v[1]), 4) for k, v in stages_seq.items()},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 6),
                          "traffic": traffic, "traffic_source": traffic_src, "kernel": "msm::k_accumulate<msm::G1S, false>" if use_table else "msm::k_accumulate<msm::G1S, false> (plain pipeline)", "avg_ms": round(acc_avg_ms, 4), "avg_ms_overlapped": round(acc_ov_ms, 4),
-                         "note": "algorithmic 128 B/term x 2^log2n terms per launch; avg_ms = HIP-event duration with one call in flight (same process, "
-                                 "untimed pass; rocprof of `bench.py --inflight 1` agrees), avg_ms_overlapped = inside the timed region where launches "
-                                 "share the chip; the kernel is integer-multiply bound: see valu_roofline"},
+                         "note": "algorithmic 128 B/term x 2^log2n terms per launch; avg_ms = HIP-event duration on the library's stream with one call in flight "
+                                 "(same process, untimed pass on the development twin — the product's kernel objects plus the stage timers, which the product "
+                                 "library does not export; rocprof of `bench.py --inflight 1` agrees), avg_ms_overlapped = the same with the timed region's "
+                                 "calls in flight, where launches share the chip; the kernel is integer-multiply bound: see valu_roofline"},
         }
         if acc_avg_ms > 0 and windows:
             mads = float(n) * windows * MADS_PER_MIXED_ADD
@@ -296,6 +317,8 @@ def main():
                                     "frac": round(mads / (acc_avg_ms * 1e-3) / 1e12 / MAD_PEAK, 4), "mixed_additions_per_launch": int(n) * windows,
                                     "note": "%d windows x n mixed additions x %d 32 x 32 -> 64-bit multiply-adds each (13 x 30-bit signed limbs since round 3: 13.8 %% fewer than the 3542 of the 14 x 29-bit field, so the same kernel time is a LOWER fraction); peak = measured issue rate, profiles/r01h_instr_rate_ubench.txt" % (
                                         windows, MADS_PER_MIXED_ADD)}
+        if dev_run:
+            out["library"] = "libdock_gpu_dev.so (development twin: --reduce-shift / --reduce-lanes set a knob the product does not have)"
         if STUB:
             out["data"] = "STUB (tests/bench_stub.py: control-flow test on CPU ranks, not a measurement)"
         if not args.no_cpu_baseline and not STUB:
@@ -504,6 +527,10 @@ def secondary_configs(log2n, ks, scalars, db, ds, pool, cpu_legs=True, ncpu=1):
     except Exception as e:          # noqa: BLE001
         res["small_msm"] = {"error": repr(e)}
     # -- BASELINE config 3: G2 MSM at the same n (plain and table), 1024-pair Miller loop, final exponentiation
+    def t2_twin_bases(nn):                            # the G2 bases of this leg, made again inside whichever library is current
+        with FB.WindowTable(ca.G2, gen2[0]) as tt:
+            return tt.multiply_many_to_bases(seeded_scalars(0x5EED0003, nn))
+
     with FB.WindowTable(ca.G2, gen2[0]) as t2, FB.WindowTable(ca.G1, gen1[0]) as t1:
         if cpu_legs:
             g2_host, _ = t2.multiply_many(seeded_scalars(0x5EED0003, n))
@@ -513,10 +540,15 @@ def secondary_configs(log2n, ks, scalars, db, ds, pool, cpu_legs=True, ncpu=1):
         res["g2_msm_plain_ms"] = round(timed(lambda: db2.msm_resident(ds), 3, warm=7), 3)     # (warm-ups: one per slot, their workspaces grow on the first G2 call)
         db2.precompute()
         res["g2_msm_ms"] = round(timed(lambda: db2.msm_resident(ds), 3, warm=7), 3)
-        ca.prof.enable(True); ca.prof.reset()
-        for _ in range(3):
-            db2.msm_resident(ds)
-        st2 = ca.prof.read(); ca.prof.enable(False)
+        with ca.twin():                                  # (stage timers: the development twin, its own copy of the table)
+            db2_t = t2_twin_bases(n); db2_t.precompute(); ds_t = ca.DeviceScalars(scalars)
+            for _ in range(2):
+                db2_t.msm_resident(ds_t)
+            ca.prof.enable(True); ca.prof.reset()
+            for _ in range(3):
+                db2_t.msm_resident(ds_t)
+            st2 = ca.prof.read(); ca.prof.enable(False)
+            db2_t.free(); ds_t.free()
         acc2 = st2.get("msm.accumulate", (0.0, 1)); acc2 = acc2[0] / max(1, acc2[1])
         sh2 = db2.table_shape()
         if acc2 > 0 and sh2:
@@ -644,7 +676,8 @@ def secondary_configs(log2n, ks, scalars, db, ds, pool, cpu_legs=True, ncpu=1):
     b_cl = np.concatenate([2 + idx, [0]]).astype(np.uint32)
     c_rp = np.concatenate([2 * np.arange(m + 1, dtype=np.uint64), [2 * m + 1]]).astype(np.uint64)
     c_cl = np.concatenate([np.stack([3 + idx, np.zeros(m, np.uint32)], 1).reshape(-1), [1]]).astype(np.uint32)
-    circ = qap.DeviceR1cs((a_rp, a_cl, a_vl), (a_rp, b_cl, a_vl), (c_rp, c_cl, np.repeat(one, 2 * m + 1, 0)), m + 3, 2, m + 1)
+    make_circuit = lambda: qap.DeviceR1cs((a_rp, a_cl, a_vl), (a_rp, b_cl, a_vl), (c_rp, c_cl, np.repeat(one, 2 * m + 1, 0)), m + 3, 2, m + 1)
+    circ = make_circuit()
     z = seeded_scalars(0x5EED0007, m + 3)
     rngw = np.random.Generator(np.random.PCG64(0x5EED0008))       # Groth16-like witness: half in {0, 1}, a quarter 16-bit, a quarter full-size
     kd = rngw.integers(0, 4, m + 3)
@@ -663,10 +696,15 @@ def secondary_configs(log2n, ks, scalars, db, ds, pool, cpu_legs=True, ncpu=1):
         cpu["witness_map"] = {"cpu_ms": round(ms_wm, 1), "gpu_ms": res["witness_map_ms"], "x": round(ms_wm / res["witness_map_ms"], 1), "cores": thr_wm, "bit_exact_vs_gpu": bool((h_cpu == h_gpu).all()),
                               "sample": "r1cs_to_qap witness map, D = 2^%d (three sparse mat-vecs, 3 iFFT + 3 coset FFT + pointwise + coset iFFT), rows / butterflies split over %d threads" % (log2n, thr_wm)}
         del h_gpu
-    ca.prof.enable(True); ca.prof.reset()
-    for _ in range(3):
-        wm()
-    st = ca.prof.read(); ca.prof.enable(False)
+    with ca.twin():                                      # (stage timers: the development twin, its own resident circuit)
+        circ_t = make_circuit()
+        for _ in range(2):
+            _, dh = circ_t.witness_map(z, to_host=False, resident=True); dh.free()
+        ca.prof.enable(True); ca.prof.reset()
+        for _ in range(3):
+            _, dh = circ_t.witness_map(z, to_host=False, resident=True); dh.free()
+        st = ca.prof.read(); ca.prof.enable(False)
+        circ_t.free()
     ntt_ms = st.get("qap.ntt", (0.0, 1)); ntt_ms = ntt_ms[0] / max(1, ntt_ms[1])
     if ntt_ms > 0:
         alg = 7 * 2 * 32.0 * n                                # 7 transforms x (read + write) x 32 B per element

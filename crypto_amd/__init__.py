@@ -4,7 +4,7 @@ crypto_amd/csrc/); this package is the thin host-side mirror of the reference's 
 (`VariableBaseMSM::{msm, msm_unchecked, msm_bigint}`, `utils::pairs::Pairs`) used by tests and bench.py.
 There is no CPU fallback: every call goes through the HIP library and raises if it is missing.
 """
-from ._native import lib, DockGpuError, build_native  # noqa: F401
+from ._native import lib, DockGpuError, build_native, twin, dev_lib  # noqa: F401
 from .msm import (  # noqa: F401
     G1, G2, msm_bigint, msm_unchecked, msm, Pairs, OwnedPairs, DeviceBases, DeviceScalars, SortedScalars, init, prof, init_devices, msm_bigint_sharded, ShardedDeviceBases,
     msm_strided, to_affine_structs, affine_struct_dtype, reserve, device_alloc_count, TABLE_C_WITNESS,

@@ -27,6 +27,8 @@
 #include "host_field.hpp"
 #include "host_par.hpp"        // (dock::tl_no_min: the size threshold DGPU_E_TOO_SMALL is for callers, not for the library's own calls)
 
+namespace dock { bool g1_words_valid(const uint64_t xy[12]); bool g2_words_valid(const uint64_t xy[24]); }      // dock_serde.cpp
+
 namespace {
 using hostf::FrH;
 typedef uint64_t W;
@@ -449,9 +451,18 @@ struct VerifyIn {
     const W *pub; size_t l; const W *d_list; int variant;             // 0 Groth16, 1 LegoGroth16 (MIPP for D), 2 LegoGroth16 proofs under the Groth16 aggregator + the list of d
 };
 
-void verify(const VerifyIn &in, const Proof &P, const Fr &random, const Tr &tr, bool validate_gt) {
+void verify(const VerifyIn &in, const Proof &P, const Fr &random, const Tr &tr, bool validate_gt, bool validate_points) {
     const int nm = P.nm; const size_t n = P.n, L = log2_exact(n), l = in.l;
     const bool with_d = in.variant == 1;
+    if (validate_points) {                        // the other half of Validate::Yes: every G1 / G2 member on its curve and in the prime-order subgroup
+        std::vector<const W *> g1s{P.final_a.data(), P.final_wkey[0].data(), P.final_wkey[1].data(), P.wkey_opening[0].data(), P.wkey_opening[1].data()};
+        std::vector<const W *> g2s{P.final_b.data(), P.final_vkey[0].data(), P.final_vkey[1].data(), P.vkey_opening[0].data(), P.vkey_opening[1].data()};
+        for (int k = 0; k < nm; k++) { g1s.push_back(P.m[k].z.data()); g1s.push_back(P.m[k].final_.data()); for (auto &z : P.m[k].zs) { g1s.push_back(z[0].data()); g1s.push_back(z[1].data()); } }
+        if (in.variant == 2) for (size_t i = 0; i < n; i++) g1s.push_back(in.d_list + 12 * i);
+        std::vector<uint8_t> bad(g1s.size() + g2s.size(), 0);
+        ck(dock::par_run(bad.size(), [&](size_t i) -> int32_t { bad[i] = i < g1s.size() ? !dock::g1_words_valid(g1s[i]) : !dock::g2_words_valid(g2s[i - g1s.size()]); return DGPU_OK; }));
+        for (uint8_t b : bad) if (b) throw Reject{};
+    }
     // (verifier.rs:50-64) public inputs: a rectangle of n rows; the key has to cover them
     if (with_d || in.variant == 2) need(l + 1 <= in.vk->gamma_abc_len); else need(l + 1 == in.vk->gamma_abc_len);
     if (validate_gt) {                            // what CanonicalDeserialize with Validate::Yes does for a proof that arrives as bytes: f^r == 1 for every GT element
@@ -625,6 +636,9 @@ extern "C" int32_t dgpu_snarkpack_verify(const dgpu_snarkpack_verifier_srs *srs,
     return guarded([&]() -> int32_t {
         if (ok) *ok = 0;
         if (!srs || !vk || !proof || !random || !transcript || !transcript->append_message || !transcript->challenge_scalar || !ok) return DGPU_E_BADARG;
+        // the batching scalar of the pairing checker: the reference draws it from an RNG inside RandomizedPairingChecker; here it is the caller's, and 0
+        // (mod r) would scale every equation after the first by 0^k = 0 — the KZG, T / U / Z and final Groth16 checks would drop out of the product
+        { W c[4]; Fr::from_canon(random).canon(c); if (!(c[0] | c[1] | c[2] | c[3])) return DGPU_E_BADARG; }
         if (variant < 0 || variant > 2 || (variant == 2) != (d_list != nullptr) || (inputs_per_proof && !public_inputs)) return DGPU_E_BADARG;
         if (!srs->g || !srs->h || !srs->g_alpha || !srs->g_beta || !srs->h_alpha || !srs->h_beta) return DGPU_E_BADARG;
         if (!vk->alpha_g1 || !vk->beta_g2 || !vk->gamma_g2 || !vk->delta_g2 || !vk->gamma_abc_g1) return DGPU_E_BADARG;
@@ -632,7 +646,7 @@ extern "C" int32_t dgpu_snarkpack_verify(const dgpu_snarkpack_verifier_srs *srs,
         read_proof(P, proof, len_words, variant == 1 ? 2 : 1);
         if (n_rows != P.n) return DGPU_E_BADARG;                 // "public inputs len != number of proofs"
         try {
-            verify(VerifyIn{srs, vk, public_inputs, inputs_per_proof, d_list, variant}, P, Fr::from_canon(random), Tr{transcript}, (flags & DGPU_SNARKPACK_VALIDATE_GT) != 0);
+            verify(VerifyIn{srs, vk, public_inputs, inputs_per_proof, d_list, variant}, P, Fr::from_canon(random), Tr{transcript}, (flags & DGPU_SNARKPACK_VALIDATE_GT) != 0, (flags & DGPU_SNARKPACK_VALIDATE_POINTS) != 0);
             *ok = 1;
         } catch (const Reject &) { *ok = 0; }
         return DGPU_OK;

@@ -8,6 +8,11 @@
 
 namespace dock {
 Shared gs;
+#ifdef DGPU_DEV
+// the twin's handles start far from the product's: a process that has both libraries loaded (tests, bench.py) cannot free or use one library's
+// object through the other by accident — the foreign number is simply unknown there (DGPU_E_BADARG)
+static const bool g_dev_handle_base = (gs.next_handle = 1ull << 40, true);
+#endif
 Ctx ctxs[MAX_CTX];
 thread_local int tl_ctx = -1;
 thread_local bool tl_no_min = false;
@@ -249,12 +254,7 @@ const char *dgpu_strerror(int32_t code) {
 int32_t dgpu_last_hip_error(void) { return gs.last_hip.load(); }
 int32_t dgpu_set_min_gpu_n(size_t n) { gs.min_gpu_n = n; return DGPU_OK; }
 size_t dgpu_get_min_gpu_n(void) { return gs.min_gpu_n.load(); }
-int32_t dgpu_set_window_bits(int32_t c) { if (c != 0 && (c < 7 || c > 22)) return DGPU_E_BADARG; gs.window_bits = c; return DGPU_OK; }
-int32_t dgpu_set_chunk(int32_t terms) { if (terms != 0 && (terms < 16 || terms > 4096)) return DGPU_E_BADARG; gs.chunk = terms; return DGPU_OK; }
-int32_t dgpu_set_reduce_lanes(int32_t lanes) { if (lanes != 0 && lanes != 1 && lanes != 2 && lanes != 4) return DGPU_E_BADARG; gs.reduce_lanes = lanes; return DGPU_OK; }
-int32_t dgpu_set_reduce_shift(int32_t sh) { if (sh < -1 || sh > 6) return DGPU_E_BADARG; gs.reduce_shift = sh; return DGPU_OK; }
 int32_t dgpu_set_small_msm_max(size_t n) { if (n > 8192) return DGPU_E_BADARG; gs.small_max = n; return DGPU_OK; }
-int32_t dgpu_set_miller_pipeline(int32_t mode) { if (mode < 0 || mode > 7) return DGPU_E_BADARG; gs.ml_mode = mode; return DGPU_OK; }
 uint64_t dgpu_device_alloc_count(void) { return g_dev_allocs.load(); }
 
 
@@ -400,17 +400,6 @@ int32_t dgpu_scalars_upload_sharded(const uint64_t *sc, size_t n, int32_t mont, 
     if (prc) { for (uint64_t h : ss->sub) if (h) (void)dgpu_scalars_free(h); delete ss; return prc; }
     *handle = register_handle(ss, n, 9);
     return DGPU_OK;
-}
-
-int32_t dgpu_prof_enable(int32_t on) { gs.prof = on != 0; return DGPU_OK; }
-int32_t dgpu_prof_reset(void) { std::lock_guard<std::mutex> lk(gs.mu); gs.prof_tab.clear(); gs.allocs_at_reset = g_dev_allocs.load(); gs.alloc_ns_at_reset = g_dev_alloc_ns.load(); return DGPU_OK; }
-int32_t dgpu_prof_read(const char **names, double *total_ms, uint64_t *calls, int32_t cap) {
-    std::lock_guard<std::mutex> lk(gs.mu);
-    int32_t k = 0;
-    for (auto &t : gs.prof_tab) { if (k >= cap) break; names[k] = t.name; total_ms[k] = t.ms; calls[k] = t.calls; k++; }
-    // device allocations since the last dgpu_prof_reset (counted whether or not the stage timers are enabled): 0 calls in steady state
-    if (k < cap) { names[k] = "hipMalloc"; total_ms[k] = (double)(g_dev_alloc_ns.load() - gs.alloc_ns_at_reset) * 1e-6; calls[k] = g_dev_allocs.load() - gs.allocs_at_reset; k++; }
-    return k;
 }
 
 }  // extern "C"

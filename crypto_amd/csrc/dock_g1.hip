@@ -39,35 +39,4 @@ int32_t dgpu_scalars_sort(uint64_t table, size_t boff, uint64_t s, size_t soff, 
 int32_t dgpu_msm_g1_sorted(uint64_t table, uint64_t sorted, size_t row_shift, uint64_t out[18]) { return msm_sorted<G1, hostf::Fq>(table, sorted, row_shift, out, 1); }
 int32_t dgpu_msm_g1_resident(uint64_t b, size_t boff, uint64_t s, size_t soff, size_t n, uint64_t out[18]) { return msm_resident<G1, hostf::Fq>(b, boff, s, soff, n, out, 1); }
 
-int32_t dgpu_selftest_fp_mul(const uint64_t *a, const uint64_t *b, size_t n, uint64_t *out) {
-    if (!cur().ready) return DGPU_E_NODEVICE;
-    SLOT_ACQUIRE(L, sl);
-    HIPCHK(hipSetDevice(cur().device));
-    void *da, *db, *dout;
-    HIPCHK(dev_malloc(&da, n * 48 + 16)); HIPCHK(dev_malloc(&db, n * 48 + 16)); HIPCHK(dev_malloc(&dout, n * 48 + 16));
-    HIPCHK(hipMemcpy(da, a, n * 48, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(db, b, n * 48, hipMemcpyHostToDevice));
-    launch_selftest_fp_mul(sl.stream, (const uint32_t *)da, (const uint32_t *)db, n, (uint32_t *)dout);
-    HIPCHK(hipStreamSynchronize(sl.stream));
-    HIPCHK(hipMemcpy(out, dout, n * 48, hipMemcpyDeviceToHost));
-    (void)hipFree(da); (void)hipFree(db); (void)hipFree(dout);
-    return DGPU_OK;
-}
-int32_t dgpu_selftest_g1_sum(const uint64_t *pts, const uint8_t *neg, size_t n, uint64_t out[18]) {
-    if (!cur().ready) return DGPU_E_NODEVICE;
-    SLOT_ACQUIRE(L, sl);
-    HIPCHK(hipSetDevice(cur().device));
-    void *dp, *dn, *dout, *dinf;
-    HIPCHK(dev_malloc(&dp, n * 96 + 16)); HIPCHK(dev_malloc(&dn, n + 16)); HIPCHK(dev_malloc(&dout, 4 * 48)); HIPCHK(dev_malloc(&dinf, 16));
-    HIPCHK(hipMemcpy(dp, pts, n * 96, hipMemcpyHostToDevice));
-    if (neg) HIPCHK(hipMemcpy(dn, neg, n, hipMemcpyHostToDevice)); else HIPCHK(hipMemset(dn, 0, n + 16));
-    launch_selftest_g1_sum(sl.stream, (const uint32_t *)dp, (const uint8_t *)dn, n, (uint32_t *)dout, (uint8_t *)dinf);
-    HIPCHK(hipStreamSynchronize(sl.stream));
-    uint64_t w[24]; uint8_t inf;
-    HIPCHK(hipMemcpy(w, dout, 4 * 48, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(&inf, dinf, 1, hipMemcpyDeviceToHost));
-    (void)hipFree(dp); (void)hipFree(dn); (void)hipFree(dout); (void)hipFree(dinf);
-    uint8_t finf = inf;
-    host_fold<hostf::Fq>(w, &finf, 1, 1, out);
-    return DGPU_OK;
-}
-
 }  // extern "C"

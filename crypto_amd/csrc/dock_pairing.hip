@@ -1251,12 +1251,6 @@ int32_t dgpu_g1_scale_batch(const uint64_t *p, const uint8_t *is_inf, const uint
     if (gs.prof) prof_flush(sl);
     return DGPU_OK;
 }
-// host self-test hook: the GLV split the scaling kernel is fed with (k mod r = k1 + k2 lambda, both < 2^128)
-int32_t dgpu_selftest_glv_decompose(const uint64_t k[4], uint64_t k1[2], uint64_t k2[2]) {
-    if (!k || !k1 || !k2) return DGPU_E_BADARG;
-    hostf::glv_decompose(k, k1, k2);
-    return DGPU_OK;
-}
 int32_t dgpu_fp12_mul(const uint64_t *a, const uint64_t *b, uint64_t *out) {
     if (!a || !b || !out) return DGPU_E_BADARG;
     hostf::Fq12 x, y; memcpy(&x, a, sizeof x); memcpy(&y, b, sizeof y);

@@ -122,6 +122,30 @@ bool canonical_infinity(const uint8_t *b, size_t sz, uint8_t flags) {
 }
 }  // namespace
 
+// Affine ABI words as they arrive inside a larger object (an aggregate proof: dock_aggregation.cpp): on the curve / the twist and in the prime-order
+// subgroup — the checks `CanonicalDeserialize` with `Validate::Yes` runs on every group element.  All-zero words are the ABI's identity (valid).
+// Coordinates are Montgomery limbs and must be reduced (< p): unreduced limbs are not something a deserialiser can produce.
+namespace dock {
+static bool limbs_lt_p(const uint64_t *l) { Fq t; memcpy(t.l, l, 48); uint64_t c[6]; to_canonical(c, t); Fq back = from_canonical(c); return memcmp(back.l, l, 48) == 0; }
+bool g1_words_valid(const uint64_t xy[12]) {
+    bool any = false; for (int i = 0; i < 12; i++) any = any || xy[i];
+    if (!any) return true;
+    if (!limbs_lt_p(xy) || !limbs_lt_p(xy + 6)) return false;
+    Fq x, y; memcpy(x.l, xy, 48); memcpy(y.l, xy + 6, 48);
+    if (!(y.sqr() == x.sqr() * x + fq_four())) return false;
+    return in_prime_subgroup<Fq>(x, y);
+}
+bool g2_words_valid(const uint64_t xy[24]) {
+    bool any = false; for (int i = 0; i < 24; i++) any = any || xy[i];
+    if (!any) return true;
+    for (int k = 0; k < 4; k++) if (!limbs_lt_p(xy + 6 * k)) return false;
+    Fq2 x, y; memcpy(&x, xy, 96); memcpy(&y, xy + 12, 96);
+    const Fq four = fq_four(); const Fq2 b2 = {four, four};
+    if (!(y.sqr() == x.sqr() * x + b2)) return false;
+    return in_prime_subgroup<Fq2>(x, y);
+}
+}  // namespace dock
+
 extern "C" {
 
 int32_t dgpu_g1_serialize(const uint64_t *xy, const uint8_t *is_inf, size_t n, int32_t compressed, uint8_t *out) {

@@ -9,6 +9,7 @@ Arrays are numpy uint64 in the ABI layout of include/dock_gpu.h (ark-ff Montgome
 """
 import ctypes as C
 import numpy as np
+from . import _native
 from ._native import lib, DockGpuError
 
 
@@ -36,6 +37,7 @@ def init(device=0, min_gpu_n=0):
     if rc:
         raise DockGpuError(rc, "dgpu_init(%d)" % device)
     lib().dgpu_set_min_gpu_n(min_gpu_n)
+    _native.note_init("init", device, min_gpu_n)
     _inited = True
 
 
@@ -47,6 +49,7 @@ def init_devices(physical, min_gpu_n=0):
     if rc:
         raise DockGpuError(rc, "dgpu_init_device_list(%s)" % list(arr))
     lib().dgpu_set_min_gpu_n(min_gpu_n)
+    _native.note_init("list", [int(x) for x in arr], min_gpu_n)
     _inited = True
 
 
@@ -426,7 +429,8 @@ TABLE_C_WITNESS = 17      # include/dock_gpu.h DGPU_TABLE_C_WITNESS: table windo
 
 
 class prof:
-    """Per-stage HIP-event timings recorded inside the library on its own stream."""
+    """Per-stage HIP-event timings recorded inside the library on its own stream.  Development surface (include/dock_gpu_dev.h): only inside
+    `with crypto_amd.twin():` — the product library has no stage timers."""
 
     @staticmethod
     def enable(on=True):

@@ -62,17 +62,8 @@ int32_t dgpu_last_hip_error(void);
 #define DGPU_MIN_GPU_N_HANDLE 8
 int32_t dgpu_set_min_gpu_n(size_t n);
 size_t dgpu_get_min_gpu_n(void);
-/* ---- tuning knobs.  Process-wide, not needed by a caller: every setting returns the SAME result limb for limb (the tests sweep each of
- * them against the automatic choice); the defaults are the measured optima on MI355X. ---- */
-/* window width c (bits) used by the bucket method; 0 = automatic from n.  Any value gives the same point. */
-int32_t dgpu_set_window_bits(int32_t c);
-/* terms per lane of the bucket accumulation (16..4096; 0 = automatic).  Any value gives the same point (tests sweep it). */
-int32_t dgpu_set_chunk(int32_t terms);
-/* log2 of the buckets one lane of the bucket reduction sums serially on the table pipeline (0..6; -1 = automatic: 3 for a 2^19-bucket table when the
- * call runs alone, 4 when three or more calls are in flight on the device context).  Any value gives the same point. */
-int32_t dgpu_set_reduce_shift(int32_t log2_buckets_per_lane);
-/* lanes (G2: lane pairs) per point in the last kernel of the bucket reduction: 4 (default; a general addition four products deep) or 1. */
-int32_t dgpu_set_reduce_lanes(int32_t lanes);
+/* (tuning knobs of the kernels — window width, chunk length, reduction geometry, Miller-loop forms —, stage timers and self-test hooks are NOT part
+ * of this ABI: include/dock_gpu_dev.h, served by the development twin libdock_gpu_dev.so.  The product runs every knob at its measured optimum.) */
 /* MSMs of up to n terms (default and maximum 8192) over plain bases — one-shot calls, plain handles — run as 64 signed 4-bit windows, each a
  * tree over the terms' table entries (a table launch and a tree launch: crypto_amd/csrc/small_kernels.hip.h) instead of the ~15-launch bucket
  * pipeline: 0.27 - 0.6 ms instead of 0.7 - 0.9 ms per call.  A plain HANDLE of up to 8192 bases gets a table of its own when it is uploaded (one
@@ -81,18 +72,12 @@ int32_t dgpu_set_reduce_lanes(int32_t lanes);
  * 0.14 - 0.4 ms (G1 n = 600 / 4096: 0.19 / 0.29 ms; G2: 0.37 / 0.57).  If that allocation fails the calls keep building their per-call table.
  * 0: always the bucket pipeline (the parity tests compare the two). */
 int32_t dgpu_set_small_msm_max(size_t n);
-/* Forms of the Miller-loop kernels, a bit mask (default 7).  Bit 0: dgpu_multi_miller_loop of up to 8192 pairs runs its line kernel in two
- * launches and overlaps the products / host share of the first with the second (and dgpu_g2_prepare runs the same lanes-per-point chain
- * followed by a parallel conversion pass).  Bit 1: the product tree gives every node 18 lane pairs (one Fp2 product deep per level) instead
- * of three.  Bit 2: up to 4096 pairs the line kernel gives every (P, Q) sixteen lanes (a doubling step two Fp2 operations deep instead of
- * five).  Every combination gives the same Fp12 value limb for limb (tests compare them). */
-int32_t dgpu_set_miller_pipeline(int32_t mode);
 /* Workspaces.  Every call in flight owns one of the context's slots (stream + grow-only device workspace).  The slots are sized AHEAD of
  * the calls so that no MSM path allocates in steady state (a hipMalloc costs 0.1 - 1 ms and the hipFree of the buffer it replaces waits for
  * the whole device, i.e. for every other call in flight): dgpu_bases_upload_* / dgpu_bases_precompute_* / dgpu_window_table_mul_to_bases_*
  * size every slot for MSMs over that handle; dgpu_reserve_g1/g2(n) does it for one-shot calls (dgpu_msm_*) of up to n terms on the calling
  * thread's context — what a Rust host calls once at start-up; without it the first one-shot call of a new size grows its own slot and
- * every idle one.  dgpu_device_alloc_count: hipMalloc calls issued by the library so far (also the "hipMalloc" row of dgpu_prof_read):
+ * every idle one.  dgpu_device_alloc_count: hipMalloc calls issued by the library so far:
  * a steady-state delta of 0 is asserted by tests/test_gpu_reserve.py. */
 int32_t dgpu_reserve_g1(size_t n);
 int32_t dgpu_reserve_g2(size_t n);
@@ -398,6 +383,7 @@ int32_t dgpu_legogroth16_verify(const uint64_t alpha_beta_gt[72], const uint64_t
  *   | final_a final_b final_c [final_d] final_vkey(2) final_wkey(2) | vkey_opening(2) wkey_opening(2)          (L = log2 nproofs; GT 72, G1 12, G2 24 words)
  * i.e. the fields of AggregateProof / GipaProof / TippMippProof in their declaration order (groth16/proof.rs:12-24,76-84,117-121). */
 #define DGPU_SNARKPACK_MAX_SRS_SIZE (((size_t)2 << 19) + 1)          /* srs.rs MAX_SRS_SIZE */
+#define DGPU_SNARKPACK_VALIDATE_POINTS 2                             /* verify flag: every G1 / G2 element of the proof (and of d_list) must be on its curve and in the prime-order subgroup (the other half of Validate::Yes) */
 #define DGPU_SNARKPACK_VALIDATE_GT 1                                 /* verify flag: every GT element of the proof must have order r (Validate::Yes on a deserialised proof) */
 typedef struct dgpu_transcript {
     void *ctx;
@@ -421,8 +407,10 @@ int32_t dgpu_snarkpack_aggregate(const dgpu_snarkpack_prover_srs *srs, const uin
                                  size_t n, const dgpu_transcript *transcript, uint64_t *proof, size_t cap_words, size_t *len_words);
 /* variant 0: Groth16 proofs; 1: LegoGroth16 (the proof carries the MIPP for d); 2: LegoGroth16 proofs under the Groth16 aggregator, d_list = the
  * n commitments d (using_groth16.rs).  public_inputs: n_rows x inputs_per_proof canonical scalars (n_rows must equal nproofs); random: the
- * pairing checker's batching scalar (RandomizedPairingChecker::new_using_rng draws it).  *ok = 1: the aggregate verifies, 0: it does not (a failed
- * pairing / final_z check, a GT element outside the subgroup).  DGPU_E_BADARG: a malformed proof (parsing_check), a key that does not match
+ * pairing checker's batching scalar (RandomizedPairingChecker::new_using_rng draws it; must be non-zero mod r — a zero would scale every equation after
+ * the first out of the check: DGPU_E_BADARG).  flags: DGPU_SNARKPACK_VALIDATE_GT | DGPU_SNARKPACK_VALIDATE_POINTS for a proof from an untrusted source (what
+ * CanonicalDeserialize with Validate::Yes checks before the reference ever sees an AggregateProof).  *ok = 1: the aggregate verifies, 0: it does not (a failed
+ * pairing / final_z check, a GT / G1 / G2 element outside its subgroup under the validation flags).  DGPU_E_BADARG: a malformed proof (parsing_check), a key that does not match
  * the public inputs (MalformedVerifyingKey), a row count that is not nproofs. */
 int32_t dgpu_snarkpack_verify(const dgpu_snarkpack_verifier_srs *srs, const dgpu_groth16_vk *vk, const uint64_t *public_inputs, size_t n_rows, size_t inputs_per_proof,
                               const uint64_t *proof, size_t len_words, int32_t variant, const uint64_t *d_list, const uint64_t random[4],
@@ -446,20 +434,6 @@ int32_t dgpu_g1_serialize(const uint64_t *xy /* n*12 */, const uint8_t *is_inf, 
 int32_t dgpu_g1_deserialize(const uint8_t *in, size_t n, int32_t mode, uint64_t *xy /* n*12 */, uint8_t *is_inf /* n */);
 int32_t dgpu_g2_serialize(const uint64_t *xy /* n*24 */, const uint8_t *is_inf, size_t n, int32_t compressed, uint8_t *out);
 int32_t dgpu_g2_deserialize(const uint8_t *in, size_t n, int32_t mode, uint64_t *xy /* n*24 */, uint8_t *is_inf /* n */);
-
-/* ---- instrumentation (bench.py / rocprof cross-check) ----
- * When enabled, every stage of the next calls is bracketed by HIP events on the library's own stream. */
-int32_t dgpu_prof_enable(int32_t on);
-int32_t dgpu_prof_reset(void);
-/* fills up to `cap` entries; returns the number of stages recorded.  names[i] points to a static string.  The last row, "hipMalloc", is
- * always present: calls = device allocations since dgpu_prof_reset (0 in steady state), total_ms = the time they took. */
-int32_t dgpu_prof_read(const char **names, double *total_ms, uint64_t *calls, int32_t cap);
-
-/* ---- self-test hooks (tests only; run the device field/group code on tiny inputs) ---- */
-/* host: the GLV split of a G1 scalar used by dgpu_g1_scale_batch: k mod r = k1 + k2 * lambda, lambda = x_BLS^2 - 1, k1, k2 < 2^128 */
-int32_t dgpu_selftest_glv_decompose(const uint64_t k[4], uint64_t k1[2], uint64_t k2[2]);
-int32_t dgpu_selftest_fp_mul(const uint64_t *a /* n*6 */, const uint64_t *b /* n*6 */, size_t n, uint64_t *out /* n*6 */);
-int32_t dgpu_selftest_g1_sum(const uint64_t *pts_xy /* n*12 */, const uint8_t *neg, size_t n, uint64_t out_xyz[18]);
 
 #pragma GCC visibility pop
 #ifdef __cplusplus

@@ -26,10 +26,16 @@ use ark_ec::{AffineRepr, VariableBaseMSM};
 use ark_ff::{BigInt, PrimeField};
 use ark_std::vec::Vec;
 
+pub mod generic;
+
 pub type G2Prepared = ArkG2Prepared<ark_bls12_381::Config>;
 
 pub const DGPU_OK: i32 = 0;
 pub const DGPU_E_TOO_SMALL: i32 = -6;
+/// verify flag of `dgpu_snarkpack_verify`: every GT element of the proof must have order r (what `Validate::Yes` does on a deserialised proof)
+pub const DGPU_SNARKPACK_VALIDATE_GT: i32 = 1;
+/// verify flag: every G1 / G2 element of the proof must be on its curve and in the prime-order subgroup (the other half of `Validate::Yes`)
+pub const DGPU_SNARKPACK_VALIDATE_POINTS: i32 = 2;
 pub const G2_PREPARED_WORDS: usize = 68 * 36;
 
 /// `dgpu_lego_pk` of include/dock_gpu.h
@@ -97,6 +103,7 @@ extern "C" {
     pub fn dgpu_multi_miller_loop_mixed(p_aff: *const u64, q_aff: *const u64, skip_aff: *const u8, n_aff: usize,
                                         p_prep: *const u64, coeffs: *const u64, skip_prep: *const u8, n_prep: usize, out_f12: *mut u64) -> i32;
     pub fn dgpu_final_exponentiation(in_f12: *const u64, out_f12: *mut u64) -> i32;
+    pub fn dgpu_g1_scale_batch(p_xy: *const u64, is_inf: *const u8, scalars: *const u64, scalar_stride: usize, negate: *const u8, n: usize, out_xy: *mut u64, out_inf: *mut u8) -> i32;
     pub fn dgpu_r1cs_upload(a_rowptr: *const u64, a_cols: *const u32, a_vals: *const u64, a_nnz: usize,
                             b_rowptr: *const u64, b_cols: *const u32, b_vals: *const u64, b_nnz: usize,
                             c_rowptr: *const u64, c_cols: *const u32, c_vals: *const u64, c_nnz: usize,
@@ -285,6 +292,17 @@ pub fn final_exponentiation(f: MillerLoopOutput<Bls12_381>) -> Option<PairingOut
         _ => Bls12_381::final_exponentiation(f),
     }
 }
+/// `a.mul_bigint(m)` (or its negative) for every point of a batch, ONE scalar — utils/src/randomized_pairing_check.rs:125-129,152-158.
+/// None when the library declined (the caller then scales on the CPU).
+pub fn g1_scale_batch(points: &[G1Affine], m: &BigInt<4>, negate: bool) -> Option<Vec<G1Affine>> {
+    let (p, pi) = pack_g1(points);
+    let neg = ark_std::vec![negate as u8; points.len()];
+    let mut out = ark_std::vec![0u64; points.len() * 12];
+    let mut oinf = ark_std::vec![0u8; points.len()];
+    let rc = unsafe { dgpu_g1_scale_batch(p.as_ptr(), pi.as_ptr(), m.0.as_ptr(), 0, neg.as_ptr(), points.len(), out.as_mut_ptr(), oinf.as_mut_ptr()) };
+    if rc != DGPU_OK { return None; }
+    Some((0..points.len()).map(|i| g1_affine(out[12 * i..12 * i + 12].try_into().unwrap(), oinf[i])).collect())
+}
 /// `Bls12_381::multi_pairing(a, b)` — 67 call sites, e.g. bbs_plus/src/signature.rs:284, legogroth16/src/aggregation/commitment.rs:30-31
 pub fn multi_pairing(a: &[G1Affine], b: &[G2Affine]) -> PairingOutput<Bls12_381> {
     final_exponentiation(multi_miller_loop(a, b)).expect("Miller output of valid operands is never zero")
@@ -389,39 +407,60 @@ fn bind_transcript<T: TranscriptBytes>(t: &mut T) -> DgpuTranscript {
 pub struct GpuProverSrs { n: usize, tabs: [Vec<u64>; 8] }
 impl GpuProverSrs {
     #[allow(clippy::too_many_arguments)]
+    /// None unless the members have the lengths the C side reads: 2 n powers in each of the four tables, n elements in each commitment key
+    /// (`ProverSRS::specialize`, legogroth16/src/aggregation/srs.rs) — the library copies 2 n / n packed points out of these buffers
     pub fn new(n: usize, g_alpha_powers_table: &[G1Affine], g_beta_powers_table: &[G1Affine], h_alpha_powers_table: &[G2Affine], h_beta_powers_table: &[G2Affine],
-               vkey_a: &[G2Affine], vkey_b: &[G2Affine], wkey_a: &[G1Affine], wkey_b: &[G1Affine]) -> Self {
-        GpuProverSrs { n, tabs: [pack_g1(g_alpha_powers_table).0, pack_g1(g_beta_powers_table).0, pack_g2(h_alpha_powers_table).0, pack_g2(h_beta_powers_table).0,
-                                 pack_g2(vkey_a).0, pack_g2(vkey_b).0, pack_g1(wkey_a).0, pack_g1(wkey_b).0] }
+               vkey_a: &[G2Affine], vkey_b: &[G2Affine], wkey_a: &[G1Affine], wkey_b: &[G1Affine]) -> Option<Self> {
+        if n == 0 || !n.is_power_of_two() { return None; }
+        if g_alpha_powers_table.len() != 2 * n || g_beta_powers_table.len() != 2 * n || h_alpha_powers_table.len() != 2 * n || h_beta_powers_table.len() != 2 * n { return None; }
+        if vkey_a.len() != n || vkey_b.len() != n || wkey_a.len() != n || wkey_b.len() != n { return None; }
+        Some(GpuProverSrs { n, tabs: [pack_g1(g_alpha_powers_table).0, pack_g1(g_beta_powers_table).0, pack_g2(h_alpha_powers_table).0, pack_g2(h_beta_powers_table).0,
+                                 pack_g2(vkey_a).0, pack_g2(vkey_b).0, pack_g1(wkey_a).0, pack_g1(wkey_b).0] })
     }
 }
 /// `aggregate_proofs(srs, transcript, proofs)`: the aggregate proof as the ABI's flat words (include/dock_gpu.h gives the layout: the fields of
 /// AggregateProof in declaration order, so `AggregateProof { com_ab: .., .. }` is rebuilt by walking it with fq12_from_words / the unpackers), or
 /// None when the library declined (then: the reference's CPU aggregator).  `d`: the commitments of LegoGroth16 proofs (legogroth16/prover.rs:38-127).
-pub fn aggregate_proofs_gpu<T: TranscriptBytes>(srs: &GpuProverSrs, transcript: &mut T, a: &[G1Affine], b: &[G2Affine], c: &[G1Affine], d: Option<&[G1Affine]>) -> Option<Vec<u64>> {
+///
+/// The library absorbs into and squeezes from the transcript as the protocol goes, and it can fail half-way (an allocation, a HIP error):
+/// it therefore works on a CLONE, and the caller's transcript advances only when the call succeeded.  On `None` the caller's transcript is
+/// exactly what it was, so the CPU aggregator it falls back to produces a proof every verifier can reproduce.
+pub fn aggregate_proofs_gpu<T: TranscriptBytes + Clone>(srs: &GpuProverSrs, transcript: &mut T, a: &[G1Affine], b: &[G2Affine], c: &[G1Affine], d: Option<&[G1Affine]>) -> Option<Vec<u64>> {
     let n = a.len();
-    if b.len() != n || c.len() != n || d.map_or(false, |x| x.len() != n) { return None; }
+    if n != srs.n || b.len() != n || c.len() != n || d.map_or(false, |x| x.len() != n) { return None; }
     let cap = unsafe { dgpu_snarkpack_proof_words(n, d.is_some() as i32) };
     if cap == 0 { return None; }
     let (pa, pb, pc) = (pack_g1(a).0, pack_g2(b).0, pack_g1(c).0);
     let pd = d.map(|x| pack_g1(x).0);
     let view = DgpuSnarkpackProverSrs { n: srs.n, g_alpha_powers_table: srs.tabs[0].as_ptr(), g_beta_powers_table: srs.tabs[1].as_ptr(), h_alpha_powers_table: srs.tabs[2].as_ptr(),
                                         h_beta_powers_table: srs.tabs[3].as_ptr(), vkey_a: srs.tabs[4].as_ptr(), vkey_b: srs.tabs[5].as_ptr(), wkey_a: srs.tabs[6].as_ptr(), wkey_b: srs.tabs[7].as_ptr() };
-    let tr = bind_transcript(transcript);
+    let mut work = transcript.clone();
+    let tr = bind_transcript(&mut work);
     let mut out = vec![0u64; cap];
     let mut len = 0usize;
     let rc = unsafe { dgpu_snarkpack_aggregate(&view, pa.as_ptr(), pb.as_ptr(), pc.as_ptr(), pd.as_ref().map_or(core::ptr::null(), |v| v.as_ptr()), n, &tr, out.as_mut_ptr(), cap, &mut len) };
     if rc != DGPU_OK { return None; }
+    *transcript = work;
     out.truncate(len);
     Some(out)
 }
 /// `verify_aggregate_proof(ip_verifier_srs, pvk, public_inputs, proof, rng, transcript, None)`: Some(valid) or None when the library declined.
 /// variant 0 Groth16, 1 LegoGroth16, 2 LegoGroth16 proofs under the Groth16 aggregator with `d_list` (using_groth16.rs:45-128); `random`: the
-/// scalar RandomizedPairingChecker::new_using_rng would draw.
+/// scalar RandomizedPairingChecker::new_using_rng would draw (non-zero: a zero would scale every equation after the first out of the check —
+/// the library answers DGPU_E_BADARG, i.e. None here).
+///
+/// `validate`: the proof came from an untrusted source as raw words.  The reference only ever verifies an `AggregateProof` that
+/// `CanonicalDeserialize` (`Validate::Yes`) has checked; with `validate = true` (use it unless the words were produced by
+/// `aggregate_proofs_gpu` in this process) the library checks every G1 / G2 member for curve and subgroup membership and every GT member for
+/// order r before it verifies, and answers Some(false) for a proof that fails.  Like the aggregator, the call works on a clone of the
+/// transcript and commits it only on success.
 #[allow(clippy::too_many_arguments)]
-pub fn verify_aggregate_proof_gpu<T: TranscriptBytes>(g: &G1Affine, h: &G2Affine, g_alpha: &G1Affine, g_beta: &G1Affine, h_alpha: &G2Affine, h_beta: &G2Affine, srs_n: usize,
+pub fn verify_aggregate_proof_gpu<T: TranscriptBytes + Clone>(g: &G1Affine, h: &G2Affine, g_alpha: &G1Affine, g_beta: &G1Affine, h_alpha: &G2Affine, h_beta: &G2Affine, srs_n: usize,
                                                       alpha_g1: &G1Affine, beta_g2: &G2Affine, gamma_g2: &G2Affine, delta_g2: &G2Affine, gamma_abc_g1: &[G1Affine],
-                                                      public_inputs: &[Vec<Fr>], proof_words: &[u64], variant: i32, d_list: Option<&[G1Affine]>, random: Fr, transcript: &mut T) -> Option<bool> {
+                                                      public_inputs: &[Vec<Fr>], proof_words: &[u64], variant: i32, d_list: Option<&[G1Affine]>, random: Fr, transcript: &mut T, validate: bool) -> Option<bool> {
+    // the C side reads 12 * n_rows words of d_list in variant 2 and none otherwise: a shorter list would be an out-of-bounds read from safe Rust
+    if (variant == 2) != d_list.is_some() || !(0..=2).contains(&variant) { return None; }
+    if d_list.map_or(false, |x| x.len() != public_inputs.len()) { return Some(false); }
     let g1s = pack_g1(&[*g, *g_alpha, *g_beta, *alpha_g1]).0;
     let g2s = pack_g2(&[*h, *h_alpha, *h_beta, *beta_g2, *gamma_g2, *delta_g2]).0;
     let abc = pack_g1(gamma_abc_g1).0;
@@ -431,11 +470,14 @@ pub fn verify_aggregate_proof_gpu<T: TranscriptBytes>(g: &G1Affine, h: &G2Affine
     let dl = d_list.map(|x| pack_g1(x).0);
     let s = DgpuSnarkpackVerifierSrs { n: srs_n, g: g1s.as_ptr(), h: g2s.as_ptr(), g_alpha: g1s[12..].as_ptr(), g_beta: g1s[24..].as_ptr(), h_alpha: g2s[24..].as_ptr(), h_beta: g2s[48..].as_ptr() };
     let k = DgpuGroth16Vk { alpha_g1: g1s[36..].as_ptr(), beta_g2: g2s[72..].as_ptr(), gamma_g2: g2s[96..].as_ptr(), delta_g2: g2s[120..].as_ptr(), gamma_abc_g1: abc.as_ptr(), gamma_abc_len: gamma_abc_g1.len() };
-    let tr = bind_transcript(transcript);
+    let mut work = transcript.clone();
+    let tr = bind_transcript(&mut work);
     let rnd = random.into_bigint();
+    let flags = if validate { DGPU_SNARKPACK_VALIDATE_GT | DGPU_SNARKPACK_VALIDATE_POINTS } else { 0 };
     let mut ok = 0i32;
     let rc = unsafe { dgpu_snarkpack_verify(&s, &k, if l == 0 { core::ptr::null() } else { pubs.as_ptr() }, public_inputs.len(), l, proof_words.as_ptr(), proof_words.len(), variant,
-                                            dl.as_ref().map_or(core::ptr::null(), |v| v.as_ptr()), rnd.0.as_ptr(), &tr, 0, &mut ok) };
+                                            dl.as_ref().map_or(core::ptr::null(), |v| v.as_ptr()), rnd.0.as_ptr(), &tr, flags, &mut ok) };
     if rc != DGPU_OK { return None; }
+    *transcript = work;
     Some(ok == 1)
 }

@@ -17,3 +17,15 @@ except Exception:  # noqa: BLE001
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+import pytest
+
+
+@pytest.fixture
+def twin():
+    """The test body runs against the DEVELOPMENT twin libdock_gpu_dev.so (include/dock_gpu_dev.h: tuning knobs, stage timers, self-test hooks) —
+    the same objects as the product library plus that surface, which the product does not export.  Everything the test creates lives in the twin."""
+    import crypto_amd as ca
+    with ca.twin() as T:
+        yield T

@@ -11,6 +11,7 @@ import oracle_c as O
 
 R = ops.R_MOD
 ca.init(0)
+_twin = ca.twin(); _twin.__enter__()      # knobs / stage timers live in the development twin (include/dock_gpu_dev.h): this script runs on it
 n = int(os.environ.get("N", "1024"))
 rng = np.random.default_rng(1)
 rnd = lambda: int.from_bytes(rng.bytes(40), "little") % (R - 1) + 1

@@ -24,6 +24,7 @@ lg = int(os.environ.get("LOG2M", "20"))
 D = 1 << lg
 V = D            # ~ one variable per constraint (Benchmark circuit shape, legogroth16/src/aggregation/tests.rs:35-89)
 ca.init(0)
+_twin = ca.twin(); _twin.__enter__()      # knobs / stage timers live in the development twin (include/dock_gpu_dev.h): this script runs on it
 k0 = O.rand_scalars(1, 1)[0]; d = O.rand_scalars(2, 1)[0]
 t0 = time.time()
 g1 = O.G1.gen_seq(k0, d, D, threads=64)

@@ -4,6 +4,7 @@ import numpy as np, crypto_amd as ca, oracle_c as O
 from crypto_amd._native import lib
 from crypto_amd import fixed_base as FB
 ca.init(0)
+_twin = ca.twin(); _twin.__enter__()      # knobs / stage timers live in the development twin (include/dock_gpu_dev.h): this script runs on it
 import os
 CV, GEN = (ca.G2, O.G2.generator()) if os.environ.get("G2") else (ca.G1, O.G1.generator())
 for lg in [int(x) for x in os.environ.get("LOGS", "10,12,14,16,18,20").split(",")]:

@@ -7,6 +7,7 @@ import crypto_amd as ca
 from crypto_amd import fixed_base as FB, serde
 import bench as B
 ca.init(0)
+_twin = ca.twin(); _twin.__enter__()      # knobs / stage timers live in the development twin (include/dock_gpu_dev.h): this script runs on it
 n = 1 << int(os.environ.get("LOG2N", "20"))
 gen1, _ = serde.deserialize(ca.G1, bytes.fromhex(B.G1_GEN_COMPRESSED))
 ks = B.seeded_scalars(1, n); sc = B.seeded_scalars(2, n)

@@ -3,6 +3,7 @@ sys.path.insert(0,"/root/repo"); sys.path.insert(0,"/root/repo/oracle")
 import crypto_amd as ca, oracle_c as O
 from crypto_amd import fixed_base as FB
 ca.init(0)
+_twin = ca.twin(); _twin.__enter__()      # knobs / stage timers live in the development twin (include/dock_gpu_dev.h): this script runs on it
 for lg in (12, 14, 16, 18, 20):
     n=1<<lg
     with FB.WindowTable(ca.G2, O.G2.generator()) as t2:

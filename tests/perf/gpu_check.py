@@ -12,6 +12,7 @@ R = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
 def p_(a): return a.ctypes.data_as(C.c_void_p)
 
 ca.init(0)
+_twin = ca.twin(); _twin.__enter__()      # knobs / stage timers live in the development twin (include/dock_gpu_dev.h): this script runs on it
 big = int(os.environ.get("BIG", "20"))
 # 1. field selftest
 a = O.fp_to_mont(O.rand_scalars(11, 600).reshape(-1, 6)[:300] & np.uint64(0x00ffffffffffffff))

@@ -8,6 +8,7 @@ from crypto_amd._native import lib
 import oracle_c as O
 
 ca.init(0)
+_twin = ca.twin(); _twin.__enter__()      # knobs / stage timers live in the development twin (include/dock_gpu_dev.h): this script runs on it
 what = os.environ.get("WHAT", "g1,g2,ml").split(",")
 
 def stages(fn, K=5):

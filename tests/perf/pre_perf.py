@@ -12,6 +12,7 @@ from crypto_amd import fixed_base as FB, serde
 import bench as B
 
 ca.init(0)
+_twin = ca.twin(); _twin.__enter__()      # knobs / stage timers live in the development twin (include/dock_gpu_dev.h): this script runs on it
 log2n = int(os.environ.get("LOG2N", "20"))
 n = 1 << log2n
 what = os.environ.get("WHAT", "g1")

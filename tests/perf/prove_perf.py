@@ -8,6 +8,7 @@ import crypto_amd as ca
 from crypto_amd import fixed_base as FB, qap, serde, legogroth16 as LG
 import bench as B
 ca.init(0)
+_twin = ca.twin(); _twin.__enter__()      # knobs / stage timers live in the development twin (include/dock_gpu_dev.h): this script runs on it
 if os.environ.get("REDUCE_SHIFT"):
     from crypto_amd._native import lib as _lib
     assert _lib().dgpu_set_reduce_shift(int(os.environ["REDUCE_SHIFT"])) == 0

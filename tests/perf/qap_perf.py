@@ -7,6 +7,7 @@ import crypto_amd as ca
 from crypto_amd import qap
 import bench as B
 ca.init(0)
+_twin = ca.twin(); _twin.__enter__()      # knobs / stage timers live in the development twin (include/dock_gpu_dev.h): this script runs on it
 n = 1 << int(os.environ.get("LOG2N", "20")); m = n - 3
 idx = np.arange(m, dtype=np.uint32)
 one = np.zeros((1, 4), np.uint64); one[0, 0] = 1

@@ -4,6 +4,7 @@ import numpy as np, crypto_amd as ca, oracle_c as O
 from crypto_amd import pairing_check as pc
 from crypto_amd.aggregation import ops
 ca.init(0)
+_twin = ca.twin(); _twin.__enter__()      # knobs / stage timers live in the development twin (include/dock_gpu_dev.h): this script runs on it
 k0 = O.rand_scalars(1, 1)[0]; d = O.rand_scalars(2, 1)[0]
 for n in (16, 1024, 16384):
     P = O.G1.gen_seq(k0, d, n, threads=16); Q = O.G2.gen_seq(d, k0, min(n, 2048), threads=16)

@@ -11,6 +11,7 @@ import crypto_amd as ca
 from crypto_amd import qap, legogroth16 as LG, pairing
 from crypto_amd.pairing_check import RandomizedPairingChecker
 ca.init(0)
+_twin = ca.twin(); _twin.__enter__()      # knobs / stage timers live in the development twin (include/dock_gpu_dev.h): this script runs on it
 R = LS.R
 N = int(os.environ.get("N", "1024"))
 rng = np.random.default_rng(1)

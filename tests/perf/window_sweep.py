@@ -5,6 +5,7 @@ sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/oracle")
 import numpy as np, crypto_amd as ca, oracle_c as O
 from crypto_amd._native import lib
 ca.init(0)
+_twin = ca.twin(); _twin.__enter__()      # knobs / stage timers live in the development twin (include/dock_gpu_dev.h): this script runs on it
 n = 1 << 20
 k0 = O.rand_scalars(1, 1)[0]; d = O.rand_scalars(2, 1)[0]
 bases = O.G1.gen_seq(k0, d, n, threads=64); sc = O.rand_scalars(3, n)

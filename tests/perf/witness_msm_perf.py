@@ -9,6 +9,7 @@ import crypto_amd as ca
 from crypto_amd import fixed_base as FB, serde
 import bench as B
 ca.init(0)
+_twin = ca.twin(); _twin.__enter__()      # knobs / stage timers live in the development twin (include/dock_gpu_dev.h): this script runs on it
 if os.environ.get("CHUNK"):      # terms per lane of the accumulation forced (dgpu_set_chunk)
     from crypto_amd._native import lib as _lib
     assert _lib().dgpu_set_chunk(int(os.environ["CHUNK"])) == 0

@@ -10,7 +10,7 @@ import torch
 import oracle_c as O
 import util as U
 import crypto_amd as ca
-from crypto_amd._native import lib, SYMBOLS
+from crypto_amd._native import lib, dev_lib, SYMBOLS, DEV_SYMBOLS
 from crypto_amd import sharded
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -27,12 +27,31 @@ def test_exports_match_header():
     assert sorted(SYMBOLS) == declared
 
 
+def test_development_surface_lives_in_the_twin_only():
+    """include/dock_gpu_dev.h (tuning knobs, stage timers, self-test and fault-injection hooks) is served by libdock_gpu_dev.so, which also
+    exports everything the product does; the product exports exactly its own header — nothing a Rust host would not bind"""
+    import subprocess
+    hdr = open(os.path.join(ROOT, "include", "dock_gpu_dev.h")).read()
+    declared = sorted(set(re.findall(r"\b(dgpu_[a-z0-9_]+)\s*\(", hdr)))
+    assert declared == sorted(DEV_SYMBOLS)
+    L, T = lib(), dev_lib()
+    for name in declared:
+        assert hasattr(T, name), "libdock_gpu_dev.so does not export %s" % name
+        assert not hasattr(L, name), "the product library exports the development symbol %s" % name
+    for name in SYMBOLS:
+        assert hasattr(T, name)
+    exported = lambda so: sorted(l.split()[-1] for l in subprocess.check_output(["nm", "-D", "--defined-only", os.path.join(ROOT, "crypto_amd", so)], text=True).splitlines() if " T dgpu_" in l)
+    assert exported("libdock_gpu.so") == sorted(SYMBOLS)
+    assert exported("libdock_gpu_dev.so") == sorted(SYMBOLS + DEV_SYMBOLS)
+
+
 def test_error_strings():
     L = lib()
     for code in range(0, -8, -1):
         assert L.dgpu_strerror(code)
     assert b"unknown" in L.dgpu_strerror(-99)
-    assert L.dgpu_set_window_bits(3) == -3 and L.dgpu_set_window_bits(0) == 0
+    T = dev_lib()
+    assert T.dgpu_set_window_bits(3) == -3 and T.dgpu_set_window_bits(0) == 0
 
 
 @pytest.mark.skipif(HAS_GPU, reason="checks the no-device behaviour")
@@ -232,7 +251,7 @@ def test_cpp_mirror_header_compiles():
 def test_glv_decomposition_on_host():
     """k mod r = k1 + k2 lambda with k1, k2 < 2^128 (what the G1 scaling kernel is fed with) against Python's divmod"""
     import random
-    L = lib()
+    L = dev_lib()                        # (a self-test hook: include/dock_gpu_dev.h)
     lam = 0xac45a4010001a40200000000ffffffff
     assert (lam * lam + lam + 1) % U.R == 0
     random.seed(5)

@@ -71,14 +71,19 @@ def test_prove_verify_roundtrip(m, cw):
     # the verifier as ONE call of the C ABI (dgpu_legogroth16_verify: calculate_d on a host core under the device's chain): the same answers,
     # in every form of the Miller kernels, for &[Fr] inputs too, from six threads at once; the reference's error cases
     from crypto_amd._native import lib
-    try:
-        for mode in (7, 3, 6, 0):
-            assert lib().dgpu_set_miller_pipeline(mode) == 0
-            assert LG.verify_proof_abi(pvk, proof, inp[1:]) and LG.verify_proof_abi(pvk, proof0, inp[1:])
-            assert LG.verify_proof_abi(pvk, proof, O.fr_to_mont(inp[1:]), montgomery=True)
-            assert not LG.verify_proof_abi(pvk, proof, bad_inp) and not LG.verify_proof_abi(pvk, bad, inp[1:])
-    finally:
-        lib().dgpu_set_miller_pipeline(7)
+
+    def abi_checks():
+        assert LG.verify_proof_abi(pvk, proof, inp[1:]) and LG.verify_proof_abi(pvk, proof0, inp[1:])
+        assert LG.verify_proof_abi(pvk, proof, O.fr_to_mont(inp[1:]), montgomery=True)
+        assert not LG.verify_proof_abi(pvk, proof, bad_inp) and not LG.verify_proof_abi(pvk, bad, inp[1:])
+    abi_checks()                                    # the product library (every knob at its default)
+    with ca.twin():                                 # the forms of the Miller kernels are a development knob (include/dock_gpu_dev.h)
+        try:
+            for mode in (7, 3, 6, 0):
+                assert lib().dgpu_set_miller_pipeline(mode) == 0
+                abi_checks()
+        finally:
+            lib().dgpu_set_miller_pipeline(7)
     from concurrent.futures import ThreadPoolExecutor
     with ThreadPoolExecutor(6) as ex:
         res = list(ex.map(lambda k: LG.verify_proof_abi(pvk, proof if k % 3 else bad, inp[1:]), range(24)))

@@ -23,8 +23,6 @@ def _device():
     assert torch.cuda.is_available(), "GPU tests need a device"
     ca.init(0)
     yield
-    lib().dgpu_set_window_bits(0)
-    lib().dgpu_set_chunk(0)
 
 
 def normalised(G, jac):
@@ -40,7 +38,7 @@ def normalised(G, jac):
     return np.concatenate([a, z])
 
 
-def test_device_field_selftest():
+def test_device_field_selftest(twin):
     a = O.fp_to_mont(O.rand_scalars(11, 900).reshape(-1, 6)[:400] & np.uint64(0x00FFFFFFFFFFFFFF))
     b = O.fp_to_mont(O.rand_scalars(12, 900).reshape(-1, 6)[:400] & np.uint64(0x00FFFFFFFFFFFFFF))
     out = np.zeros_like(a)
@@ -72,12 +70,21 @@ def test_vs_oracle_seeded(gname, n):
     curve, G = CUR[gname]
     bases, _, _ = U.seq_bases(G, n, 1000 + n, threads=16) if n else (np.zeros((0, G.AW), np.uint64), 0, 0)
     sc = O.rand_scalars(2000 + n, n)
-    got = ca.msm_bigint(curve, bases, sc)
     ref = normalised(G, G.msm(bases, sc, threads=16))
-    assert (got == ref).all()
+    got, got_buckets = U.on_both_paths(lambda: ca.msm_bigint(curve, bases, sc))     # (n <= 8192: the tree path, then the bucket pipeline)
+    assert (got == ref).all() and (got_buckets == ref).all()
 
 
-def test_edge_cases_g1():
+@pytest.mark.parametrize("path", ["tree", "buckets"])
+def test_edge_cases_g1(path):
+    """P == Q and P == -Q inside a bucket, heavy buckets, identities: on the bucket pipeline these exercise k_accumulate's special cases, the heavy-bucket
+    folds and the reduction; on the tree path (what a 200-term call takes by default) the same inputs meet the general addition's"""
+    import contextlib
+    with (U.bucket_pipeline() if path == "buckets" else contextlib.nullcontext()):
+        _edge_cases_g1()
+
+
+def _edge_cases_g1():
     G, curve = O.G1, ca.G1
     n = 200
     bases, k0, d = U.seq_bases(G, n, 5)
@@ -203,16 +210,20 @@ def test_truncation_and_handles():
 
 
 @pytest.mark.parametrize("c", [7, 10, 13, 15, 16, 18])
-def test_any_window_width_same_point(c):
+def test_any_window_width_same_point(c, twin):
+    """every window width and chunk length of the BUCKET pipeline gives the oracle's point (n = 5000 and 9001: below and above the size up to which
+    calls take the tree path by default — the smaller one runs with that path switched off, else the knobs would not be exercised at all)"""
     G, curve = O.G1, ca.G1
-    bases, k0, d = U.seq_bases(G, 5000, 31)
-    sc = O.rand_scalars(32, 5000)
-    ref = normalised(G, G.msm(bases, sc, threads=16))
+    bases, k0, d = U.seq_bases(G, 9001, 31, threads=16)
+    sc = O.rand_scalars(32, 9001)
+    refs = {n: normalised(G, G.msm(bases[:n], sc[:n], threads=16)) for n in (5000, 9001)}
     lib().dgpu_set_window_bits(c)
     try:
         for ch in (16, 128):
             assert lib().dgpu_set_chunk(ch) == 0
-            assert (ca.msm_bigint(curve, bases, sc) == ref).all()
+            assert (ca.msm_bigint(curve, bases, sc) == refs[9001]).all()
+            with U.bucket_pipeline():
+                assert (ca.msm_bigint(curve, bases[:5000], sc[:5000]) == refs[5000]).all()
     finally:
         lib().dgpu_set_window_bits(0)
         lib().dgpu_set_chunk(0)
@@ -283,7 +294,7 @@ def test_g2_full_size_closed_form_2_20():
     assert U.jac_to_model(G, G.add(a, b)) == U.jac_to_model(G, r)
 
 
-def test_g1_2_22_closed_form_split_and_window_independence():
+def test_g1_2_22_closed_form_split_and_window_independence(twin):
     """n = 2^22 (twice the per-GPU share of BASELINE config 5): bases k_i G from the fixed-base kernel with seeded k_i, so the result has a
     closed form; plus split/merge over resident handles and the same point for another window width."""
     from crypto_amd import fixed_base as fb
@@ -309,9 +320,17 @@ def test_g1_2_22_closed_form_split_and_window_independence():
     assert (O.G1.to_affine(O.G1.mul(O.G1.generator(), O.int_to_limbs(tot, 4)))[0] == exp_xy).all()
 
 
-def test_concurrent_callers_share_the_device():
+@pytest.mark.parametrize("path", ["tree", "buckets"])
+def test_concurrent_callers_share_the_device(path):
     """the reference calls MSM from inside rayon workers (verifiable_encryption/src/tz_21/rdkgith.rs:140-147): several host
-    threads in flight at once must each get their own correct result (per-call slots: stream + workspace)."""
+    threads in flight at once must each get their own correct result (per-call slots: stream + workspace) — on the tree path these sizes
+    take by default and on the bucket pipeline (sort, accumulation, fix-up, reduction of six calls interleaved on the device)."""
+    import contextlib
+    with (U.bucket_pipeline() if path == "buckets" else contextlib.nullcontext()):
+        _concurrent_callers()
+
+
+def _concurrent_callers():
     import threading
     G, curve = O.G1, ca.G1
     sets = []

@@ -62,7 +62,7 @@ def test_vs_oracle_across_kernel_boundaries(n):
 
 
 @pytest.mark.parametrize("n", [1, 3, 64, 130, 1024, 1100, 5000, 8192, 9000])
-def test_every_form_of_the_miller_kernels_gives_the_same_value(n):
+def test_every_form_of_the_miller_kernels_gives_the_same_value(n, twin):
     """dgpu_set_miller_pipeline: bit 0 cuts the 68-step chain of a call of up to 8192 pairs at bit 17 of |x| (two launches of the line
     kernel, evaluation at P moved into the product kernel, products and host share of the first 50 steps overlapped with the second
     launch), bit 1 runs the product tree with 18 lane pairs per node.  All four combinations: the same Fp12 value limb for limb, equal
@@ -154,15 +154,27 @@ def test_g2_prepare_coefficients_equal_the_oracle(n):
             assert pc.infinity[i] == 1 and not pc.coeffs[i].any()
         else:
             assert pc.infinity[i] == 0 and (pc.coeffs[i] == O.g2_prepare(qs[i]).reshape(-1)).all(), i
-    # the lane-pair chain that converts its coefficients on the way (dgpu_set_miller_pipeline without bit 0) writes the same bytes as the
-    # default four-lane chain + conversion pass
+
+
+@pytest.mark.parametrize("n", [1, 7, 300])
+def test_g2_prepare_lane_pair_chain_writes_the_same_bytes(n, twin):
+    """the lane-pair chain that converts its coefficients on the way (dgpu_set_miller_pipeline without bit 0) writes the same bytes as the default
+    four-lane chain + conversion pass, and both equal the oracle's"""
+    from crypto_amd import pairing
     from crypto_amd._native import lib
+    k0 = O.rand_scalars(41, 1)[0]; d = O.rand_scalars(42, 1)[0]
+    qs = O.G2.gen_seq(k0, d, n, threads=8)
+    if n >= 7:
+        qs[3] = 0
+    pc = pairing.G2Prepared.from_affine(qs)
     try:
         assert lib().dgpu_set_miller_pipeline(2) == 0
         old = pairing.G2Prepared.from_affine(qs)
     finally:
-        lib().dgpu_set_miller_pipeline(3)
+        lib().dgpu_set_miller_pipeline(7)
     assert (old.coeffs == pc.coeffs).all() and (old.infinity == pc.infinity).all()
+    i = n - 1
+    assert (pc.coeffs[i] == O.g2_prepare(qs[i]).reshape(-1)).all()
 
 
 @pytest.mark.parametrize("n", [1, 3, 5, 200, 1024, 2500])

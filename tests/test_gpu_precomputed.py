@@ -49,7 +49,7 @@ def test_table_msm_equals_plain_and_oracle(gname, n, c):
 
 
 @pytest.mark.parametrize("gname,n,c", [("G1", 5003, 16), ("G1", (1 << 16) + 3, 20), ("G2", 3001, 20)])
-def test_any_reduction_geometry_same_point(gname, n, c):
+def test_any_reduction_geometry_same_point(gname, n, c, twin):
     """dgpu_set_reduce_shift: the bucket reduction's serial share (2^shift buckets per lane, 64 lanes per group, <= 64 groups per
     pseudo-window, the rest on the host) is a tuning knob — every geometry must return the limbs of the automatic one (measured at
     2^20 terms: the automatic 8 buckets per lane is the fastest both for one call and for six in flight) — and so is the form of the

@@ -1,5 +1,5 @@
 """No device allocation on an MSM path in steady state: the slots' workspaces are sized when a handle is uploaded /
-converted to a table / by dgpu_reserve_*, and dgpu_device_alloc_count (== the "hipMalloc" row of dgpu_prof_read) must not move afterwards,
+converted to a table / by dgpu_reserve_*, and dgpu_device_alloc_count must not move afterwards,
 whichever slot a call lands on and however many host threads call at once."""
 from concurrent.futures import ThreadPoolExecutor
 import numpy as np
@@ -32,12 +32,10 @@ def test_no_allocation_after_upload_and_precompute(name, n):
     db = ca.DeviceBases(curve, bases)            # sizes every slot for MSMs over the handle
     ds = ca.DeviceScalars(sc)
     a0 = ca.device_alloc_count()
-    ca.prof.reset()
     ref = db.msm_resident(ds)
     outs = _hammer(lambda: db.msm_resident(ds)) + _hammer(lambda: db.msm_bigint(sc)) + _hammer(lambda: db.msm_bigint(sc, offset=1))[:0]
     assert all((o == ref).all() for o in outs)
     assert ca.device_alloc_count() == a0, "a plain-handle MSM allocated device memory"
-    assert ca.prof.read()["hipMalloc"][1] == 0
     db.precompute(16)
     a1 = ca.device_alloc_count()
     assert a1 > a0                               # the table itself (and the slots' table workspaces)

@@ -87,3 +87,26 @@ def closed_form(G, scalars, k0, d):
     sv = [O.limbs_to_int(x) for x in scalars]
     tot = (sum(sv) * k0 + sum(i * s for i, s in enumerate(sv)) * d) % R
     return jac_to_model(G, G.mul(G.generator(), O.int_to_limbs(tot, 4)))
+
+
+import contextlib
+
+
+@contextlib.contextmanager
+def bucket_pipeline():
+    """Inside the block MSMs of up to 8192 terms on plain bases run the Pippenger bucket pipeline (sort, k_accumulate, fix-up, reduction) instead of
+    the bucket-free tree path that serves them since round 4 (dgpu_set_small_msm_max): tests that are ABOUT windows, chunks and buckets use it."""
+    from crypto_amd._native import lib
+    assert lib().dgpu_set_small_msm_max(0) == 0
+    try:
+        yield
+    finally:
+        lib().dgpu_set_small_msm_max(8192)
+
+
+def on_both_paths(fn):
+    """fn() on the tree path (the default for n <= 8192) and on the bucket pipeline; returns both results"""
+    a = fn()
+    with bucket_pipeline():
+        b = fn()
+    return a, b

@@ -8,6 +8,10 @@ import crypto_amd as ca
 from crypto_amd import serde, fixed_base as FB
 import bench as B
 ca.init(0)
+_twin = ca.twin(); _twin.__enter__()      # knobs / stage timers live in the development twin (include/dock_gpu_dev.h): this script runs on it
+if os.environ.get("REDUCE_LANES"):
+    from crypto_amd._native import lib
+    assert lib().dgpu_set_reduce_lanes(int(os.environ["REDUCE_LANES"])) == 0     # A/B of the bucket reduction's forms (tools/dev/r05_reduce_ab2.sh)
 n = 1 << int(os.environ.get("LOG2N", "20")); K = int(os.environ.get("K", "12"))
 gen2, _ = serde.deserialize(ca.G2, bytes.fromhex(B.G2_GEN_COMPRESSED))
 with FB.WindowTable(ca.G2, gen2[0]) as t2:

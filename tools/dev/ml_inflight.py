@@ -5,6 +5,7 @@ sys.path.insert(0, "oracle"); sys.path.insert(0, ".")
 import oracle_c as O, crypto_amd as ca
 from crypto_amd._native import lib
 ca.init(0)
+_twin = ca.twin(); _twin.__enter__()      # knobs / stage timers live in the development twin (include/dock_gpu_dev.h): this script runs on it
 n = 1024
 k0 = O.rand_scalars(41, 1)[0]; d = O.rand_scalars(42, 1)[0]
 ps = O.G1.gen_seq(k0, d, n, threads=32); qs = O.G2.gen_seq(d, k0, n, threads=32)

@@ -8,6 +8,7 @@ import crypto_amd as ca
 from crypto_amd import serde, fixed_base as FB
 import bench as B
 ca.init(0)
+_twin = ca.twin(); _twin.__enter__()      # knobs / stage timers live in the development twin (include/dock_gpu_dev.h): this script runs on it
 n = 1 << int(os.environ.get("LOG2N", "20")); K = int(os.environ.get("K", "12"))
 gen1, _ = serde.deserialize(ca.G1, bytes.fromhex(B.G1_GEN_COMPRESSED))
 with FB.WindowTable(ca.G1, gen1[0]) as t1:

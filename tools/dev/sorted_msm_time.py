@@ -4,6 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 import numpy as np, crypto_amd as ca, oracle_c as O
 from crypto_amd import fixed_base as FB
 ca.init(0)
+_twin = ca.twin(); _twin.__enter__()      # knobs / stage timers live in the development twin (include/dock_gpu_dev.h): this script runs on it
 n = 1 << int(os.environ.get("LOG2N", "20"))
 ds = ca.DeviceScalars(O.rand_scalars(4, n))
 for cv, G in ((ca.G1, O.G1), (ca.G2, O.G2)):

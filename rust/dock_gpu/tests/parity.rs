@@ -132,3 +132,46 @@ fn write_golden() {
     }
     std::fs::write(format!("{dir}/pairing.json"), format!("{{{head}, \"cases\": [\n{}\n]}}\n", cases.join(",\n"))).unwrap();
 }
+
+// ---- the generic drop-ins (src/generic.rs): what rust/patches routes the reference's generic call sites to ----------------------------------
+/// a function that is generic the way the reference's call sites are (utils/src/pairs.rs:143-147): it cannot name G1Affine
+fn pairs_msm<G: AffineRepr>(left: &[G], right: &[G::ScalarField]) -> G::Group { dock_gpu::generic::msm_unchecked(left, right) }
+fn coeff<G: AffineRepr>(query: &[G], assignment: &[<G::ScalarField as PrimeField>::BigInt]) -> G::Group { dock_gpu::generic::msm_bigint::<G>(&query[1..], assignment) }
+fn checker_verify<E: Pairing>(a: Vec<E::G1Prepared>, b: Vec<E::G2Prepared>) -> Option<ark_ec::pairing::PairingOutput<E>> {
+    dock_gpu::generic::final_exponentiation::<E>(dock_gpu::generic::multi_miller_loop::<E>(a, b))
+}
+
+#[test]
+fn generic_wrappers_dispatch_and_fall_through() {
+    setup();
+    let mut rng = StdRng::seed_from_u64(0x5EED0007);
+    for &n in &[3usize, 64, 600, 1 << 13] {
+        let (b1, b2, s) = (g1s(&mut rng, n), g2s(&mut rng, n.min(1 << 11)), frs(&mut rng, n));
+        let sb = big(&s);
+        // BLS12-381: served by the library, equal to arkworks
+        assert_eq!(pairs_msm::<G1Affine>(&b1, &s).into_affine(), G1Projective::msm_unchecked(&b1, &s).into_affine());
+        assert_eq!(pairs_msm::<G2Affine>(&b2, &s[..b2.len()]).into_affine(), G2Projective::msm_unchecked(&b2, &s[..b2.len()]).into_affine());
+        assert_eq!(coeff::<G1Affine>(&b1, &sb).into_affine(), G1Projective::msm_bigint(&b1[1..], &sb).into_affine());
+        assert_eq!(dock_gpu::generic::msm::<G1Affine>(&b1, &s[..n - 1]), Err(n - 1));
+        let m = n.min(1 << 10);
+        let pa: Vec<<Bls12_381 as Pairing>::G1Prepared> = b1[..m].iter().map(|p| (*p).into()).collect();
+        let pb: Vec<<Bls12_381 as Pairing>::G2Prepared> = b2[..m.min(b2.len())].iter().map(|q| (*q).into()).collect();
+        let pa = pa[..pb.len()].to_vec();
+        assert_eq!(checker_verify::<Bls12_381>(pa.clone(), pb.clone()), Bls12_381::final_exponentiation(Bls12_381::multi_miller_loop(pa, pb)));
+        assert_eq!(dock_gpu::generic::multi_pairing::<Bls12_381>(&b1[..pb_len(&b2, m)], &b2[..pb_len(&b2, m)]), Bls12_381::multi_pairing(&b1[..pb_len(&b2, m)], &b2[..pb_len(&b2, m)]));
+        let g = dock_gpu::generic::scale_batch_g1::<Bls12_381>(&b1, sb[0], true);
+        for (p, q) in b1.iter().zip(g.iter()) { assert_eq!((-p.mul_bigint(sb[0])).into_affine(), *q); }
+    }
+}
+fn pb_len(b2: &[G2Affine], m: usize) -> usize { m.min(b2.len()) }
+
+/// another curve goes straight through to arkworks: the same generic code path with a type the library does not serve
+#[cfg(feature = "other-curve-test")]
+#[test]
+fn generic_wrappers_leave_other_curves_alone() {
+    use ark_bn254::{Fr as BnFr, G1Affine as BnG1, G1Projective as BnG1P};
+    let mut rng = StdRng::seed_from_u64(0x5EED0008);
+    let b: Vec<BnG1> = BnG1P::normalize_batch(&(0..600).map(|_| BnG1P::rand(&mut rng)).collect::<Vec<_>>());
+    let s: Vec<BnFr> = (0..600).map(|_| BnFr::rand(&mut rng)).collect();
+    assert_eq!(pairs_msm::<BnG1>(&b, &s), BnG1P::msm_unchecked(&b, &s));
+}

@@ -14,6 +14,7 @@ from .ops import G1, G2, R_MOD
 from .srs import PairCommitment, AggregationError
 
 VALIDATE_GT = 1
+VALIDATE_POINTS = 2
 LAST = {"transcript_ms": 0.0}          # of the last call: milliseconds spent inside the Python transcript's callbacks (bench.py reports it)
 
 
@@ -158,9 +159,10 @@ def aggregate_proofs(srs, transcript, proofs, with_d=False):
     return proof_from_words(aggregate_proofs_words(srs, transcript, proofs, with_d))
 
 
-def verify_aggregate_proof(ip_verifier_srs, pvk, public_inputs, proof, random, transcript, with_d=False, d=None, validate_gt=False):
+def verify_aggregate_proof(ip_verifier_srs, pvk, public_inputs, proof, random, transcript, with_d=False, d=None, validate_gt=False, validate_points=False):
     """groth16.verify_aggregate_proof / using_groth16.verify_aggregate_proof (d = the list of commitments): raises AggregationError on an
-    invalid proof.  `proof`: the dictionary or the flat words."""
+    invalid proof.  `proof`: the dictionary or the flat words.  validate_gt / validate_points: the two halves of `Validate::Yes` for a proof that
+    arrives from an untrusted source as raw words (GT members of order r; G1 / G2 members on their curve and in the prime-order subgroup)."""
     vk = pvk["vk"]
     words = proof if isinstance(proof, np.ndarray) else proof_to_words(proof)
     words = np.ascontiguousarray(words, dtype=np.uint64)
@@ -180,7 +182,7 @@ def verify_aggregate_proof(ip_verifier_srs, pvk, public_inputs, proof, random, t
     ok = C.c_int32(0)
     cb = _Callbacks(transcript)
     rc = lib().dgpu_snarkpack_verify(C.byref(S), C.byref(K), _p(pub) if l else None, len(public_inputs), l, _p(words), len(words), variant, _p(dl), _p(rnd), C.byref(cb.struct),
-                                     VALIDATE_GT if validate_gt else 0, C.byref(ok))
+                                     (VALIDATE_GT if validate_gt else 0) | (VALIDATE_POINTS if validate_points else 0), C.byref(ok))
     cb.check()
     LAST["transcript_ms"] = cb.seconds * 1e3
     if rc == -3:

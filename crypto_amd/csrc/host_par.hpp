@@ -18,6 +18,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <deque>
+#include <pthread.h>
 #include <functional>
 #include <memory>
 #include <mutex>
@@ -63,13 +64,25 @@ class HostPool {
         try { workers_.reserve(w); for (unsigned i = 0; i < w; i++) workers_.emplace_back([this] { loop(); }); }
         catch (...) {}                                         // fewer workers (or none): callers run what is left themselves
     }
-public:
-    static HostPool &get() { static HostPool p; return p; }
-    ~HostPool() {
-        { std::lock_guard<std::mutex> lk(m_); stop_ = true; }
-        cv_.notify_all();
-        for (auto &t : workers_) if (t.joinable()) t.join();
+    // fork(): the child has the forking thread only.  prepare takes the pool's mutex (no worker or submitter holds it across the fork, so the child never
+    // inherits a locked mutex it cannot unlock); the child then starts from an empty, not-yet-started pool — the parent's workers do not exist there,
+    // their std::thread objects and whatever was queued are abandoned (overwritten without running destructors: joining or detaching a thread that
+    // does not exist is undefined) and new workers are created at the child's first par_run.
+    static void atfork_prepare() { get().m_.lock(); }
+    static void atfork_parent() { get().m_.unlock(); }
+    static void atfork_child() {
+        HostPool &p = get();
+        new (&p.m_) std::mutex();
+        new (&p.cv_) std::condition_variable();
+        new (&p.q_) std::deque<Entry>();
+        new (&p.workers_) std::vector<std::thread>();
+        p.stop_ = false; p.started_ = false;
     }
+    HostPool() { (void)pthread_atfork(&HostPool::atfork_prepare, &HostPool::atfork_parent, &HostPool::atfork_child); }
+public:
+    // Never destroyed: a static destructor would join workers that may still be inside HIP calls after the runtime's own teardown (and run during
+    // exit() of a forked child whose workers do not exist).  The workers end with the process.
+    static HostPool &get() { static HostPool *p = new HostPool; return *p; }
     // false: not queued (out of memory, shutting down) — the caller runs the task itself
     bool submit(const void *group, std::function<void()> f) noexcept {
         try {

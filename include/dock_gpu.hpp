@@ -467,32 +467,47 @@ struct VerifierSRS {                        // srs.rs:95-110
 struct VerifyingKey { std::array<uint64_t, 12> alpha_g1{}; std::array<uint64_t, 24> beta_g2{}, gamma_g2{}, delta_g2{}; Words gamma_abc_g1; };
 enum class Variant : int32_t { Groth16 = 0, LegoGroth16 = 1, LegoGroth16UsingGroth16 = 2 };
 
-// a, c (, d): n x 12 words, b: n x 24; d == nullptr: Groth16 proofs
+// a, c (, d): n x 12 words, b: n x 24; d == nullptr: Groth16 proofs.
+// The library absorbs into / squeezes from the transcript as the protocol goes and may fail half-way (an allocation, a HIP error): it runs on a
+// COPY of `transcript` (T must be copyable, like merlin::Transcript is Clone), which replaces the caller's only when the call succeeded — after a
+// throw the caller's transcript is what it was, so a CPU fallback produces a proof every verifier can reproduce.
 template <class T> Words aggregate_proofs(const ProverSRS &srs, T &transcript, const Words &a, const Words &b, const Words &c, const Words *d = nullptr) {
     const size_t n = a.size() / 12;
     if (b.size() != 24 * n || c.size() != 12 * n || (d && d->size() != 12 * n)) throw Error(DGPU_E_LENGTH, "aggregate_proofs");
+    if (srs.n != n || srs.g_alpha_powers_table.size() != 24 * n || srs.g_beta_powers_table.size() != 24 * n || srs.h_alpha_powers_table.size() != 48 * n || srs.h_beta_powers_table.size() != 48 * n ||
+        srs.vkey_a.size() != 24 * n || srs.vkey_b.size() != 24 * n || srs.wkey_a.size() != 12 * n || srs.wkey_b.size() != 12 * n) throw Error(DGPU_E_LENGTH, "aggregate_proofs: the SRS is not specialised to this many proofs");
     const size_t cap = dgpu_snarkpack_proof_words(n, d ? 1 : 0);
     if (!cap) throw Error(DGPU_E_BADARG, "aggregate_proofs: the number of proofs is not a power of two >= 2");
     Words out(cap); size_t len = 0;
     const dgpu_snarkpack_prover_srs v = srs.view();
-    const dgpu_transcript t = bind(transcript);
+    T work = transcript;
+    const dgpu_transcript t = bind(work);
     check(dgpu_snarkpack_aggregate(&v, a.data(), b.data(), c.data(), d ? d->data() : nullptr, n, &t, out.data(), cap, &len), "snarkpack_aggregate");
+    transcript = std::move(work);
     out.resize(len);
     return out;
 }
 // public_inputs: one row of `inputs_per_proof` scalars per proof.  true: the aggregate verifies; throws Error(DGPU_E_BADARG) for a malformed
-// proof / key (AggregationError::InvalidProof / MalformedVerifyingKey before any group operation)
+// proof / key (AggregationError::InvalidProof / MalformedVerifyingKey before any group operation) and for random == 0 mod r.
+// validate: the words came from an untrusted source — every G1 / G2 member must be on its curve and in the prime-order subgroup, every GT member of
+// order r (what CanonicalDeserialize with Validate::Yes checks before the reference ever sees an AggregateProof); leave it on unless the words were
+// produced by aggregate_proofs in this process.  Runs on a copy of the transcript like aggregate_proofs.
 template <class T> bool verify_aggregate_proof(const VerifierSRS &srs, const VerifyingKey &vk, const std::vector<BigInt256> &public_inputs, size_t inputs_per_proof,
                                                const Words &proof, const BigInt256 &random, T &transcript, Variant variant = Variant::Groth16,
-                                               const Words *d_list = nullptr, bool validate_gt = false) {
+                                               const Words *d_list = nullptr, bool validate = true) {
     if (inputs_per_proof && public_inputs.size() % inputs_per_proof) throw Error(DGPU_E_LENGTH, "verify_aggregate_proof");
     const size_t rows = inputs_per_proof ? public_inputs.size() / inputs_per_proof : (proof.empty() ? 0 : (size_t)proof[0]);
+    // the library reads 12 * rows words of d_list in the LegoGroth16-under-Groth16 variant and none otherwise
+    if ((variant == Variant::LegoGroth16UsingGroth16) != (d_list != nullptr)) throw Error(DGPU_E_BADARG, "verify_aggregate_proof: d_list goes with Variant::LegoGroth16UsingGroth16 and only with it");
+    if (d_list && d_list->size() != 12 * rows) throw Error(DGPU_E_LENGTH, "verify_aggregate_proof: d_list must hold one commitment per proof");
     const dgpu_snarkpack_verifier_srs s{srs.n, srs.g.data(), srs.h.data(), srs.g_alpha.data(), srs.g_beta.data(), srs.h_alpha.data(), srs.h_beta.data()};
     const dgpu_groth16_vk k{vk.alpha_g1.data(), vk.beta_g2.data(), vk.gamma_g2.data(), vk.delta_g2.data(), vk.gamma_abc_g1.data(), vk.gamma_abc_g1.size() / 12};
-    const dgpu_transcript t = bind(transcript);
+    T work = transcript;
+    const dgpu_transcript t = bind(work);
     int32_t ok = 0;
     check(dgpu_snarkpack_verify(&s, &k, public_inputs.empty() ? nullptr : public_inputs[0].data(), rows, inputs_per_proof, proof.data(), proof.size(), (int32_t)variant,
-                                d_list ? d_list->data() : nullptr, random.data(), &t, validate_gt ? DGPU_SNARKPACK_VALIDATE_GT : 0, &ok), "snarkpack_verify");
+                                d_list ? d_list->data() : nullptr, random.data(), &t, validate ? (DGPU_SNARKPACK_VALIDATE_GT | DGPU_SNARKPACK_VALIDATE_POINTS) : 0, &ok), "snarkpack_verify");
+    transcript = std::move(work);
     return ok != 0;
 }
 }  // namespace aggregation

@@ -303,7 +303,30 @@ static void test_aggregation() {
         }
 }
 
+// fork() while the pool exists (Python's multiprocessing forks a process that has used the library): the child's pool starts empty and its first
+// par_run creates workers of its own; a fork issued while OTHER threads are hammering the pool must not leave the child a locked mutex
+#include <sys/wait.h>
+#include <unistd.h>
+static void test_fork_with_a_live_pool() {
+    std::atomic<bool> stop{false};
+    std::thread hammer([&] { while (!stop.load()) (void)dock::par_run(8, [](size_t) -> int32_t { return DGPU_OK; }); });
+    for (int round = 0; round < 8; round++) {
+        const pid_t pid = fork();
+        if (pid == 0) {
+            std::atomic<int> sum{0};
+            const int32_t rc = dock::par_run(16, [&](size_t k) -> int32_t { sum += (int)k; return DGPU_OK; });
+            _exit(rc == DGPU_OK && sum.load() == 120 ? 0 : 1);
+        }
+        int st = 0;
+        if (pid < 0 || waitpid(pid, &st, 0) != pid || !WIFEXITED(st) || WEXITSTATUS(st) != 0) { fprintf(stderr, "forked child failed (round %d, status %d)\n", round, st); failures++; }
+    }
+    stop = true; hammer.join();
+}
+
 int main() {
+#if !defined(__SANITIZE_THREAD__) && !defined(__SANITIZE_ADDRESS__)      // (the sanitizer runtimes do not support new threads in the child of a multi-threaded fork: the plain build of tests/test_host_sanitizers.py runs this)
+    test_fork_with_a_live_pool();
+#endif
     test_slots_and_handles();
     test_prover();
     test_gt_and_serde();

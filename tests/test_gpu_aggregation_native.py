@@ -86,6 +86,22 @@ def test_native_aggregate_equals_python(n):
     raw = np.asarray(O.multi_miller_loop(g1(3).reshape(1, 12), g2(5).reshape(1, 24)), dtype=np.uint64).reshape(72)
     bad = copy.deepcopy(py); bad["tmipp"]["gipa"]["z_ab"][0] = (raw, bad["tmipp"]["gipa"]["z_ab"][0][1])
     assert rejects(lambda: V(proof=bad, validate_gt=True))
+    # ... and so is a G1 / G2 member that is not a point of the prime-order subgroup (the other half of Validate::Yes): a point of E(Fp) outside G1
+    # (the cofactor is ~2^126: any point found by solving y^2 = x^3 + 4 is outside), a pair of coordinates that is not on the curve at all
+    P = U.P
+    x = next(x for x in range(2, 100) if pow((x ** 3 + 4) % P, (P - 1) // 2, P) == 1)
+    y = pow((x ** 3 + 4) % P, (P + 1) // 4, P)
+    assert (y * y - x ** 3 - 4) % P == 0
+    outside = np.concatenate([U.fp_abi(x), U.fp_abi(y)])
+    off_curve = np.concatenate([U.fp_abi(x), U.fp_abi((y + 1) % P)])
+    for pt in (outside, off_curve):
+        bad = copy.deepcopy(py); bad["tmipp"]["gipa"]["final_a"] = pt
+        assert rejects(lambda: V(proof=bad, validate_points=True))
+    assert (V(validate_gt=True, validate_points=True), True)[1]         # the honest proof passes with both halves of the validation on
+    # the pairing checker's batching scalar must not be zero mod r (every equation after the first would drop out of the product)
+    for zero in (0, R):
+        with pytest.raises(AG.AggregationError):
+            NA.verify_aggregate_proof(vsrs, pvk, inputs, py, zero, AG.MerlinTranscript(label))
     # one wrong proof inside the batch
     wrong = copy.deepcopy(proofs); wrong[1]["c"] = g1(777)
     assert rejects(lambda: V(proof=NA.aggregate_proofs(pk, AG.MerlinTranscript(label), wrong)))

@@ -18,6 +18,7 @@ HIP_INC = "/opt/rocm/include"
 @pytest.mark.parametrize("name,flags,env", [
     ("tsan", ["-fsanitize=thread"], {"TSAN_OPTIONS": "halt_on_error=1 exitcode=66"}),
     ("asan_ubsan", ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"], {"ASAN_OPTIONS": "detect_leaks=1 exitcode=67"}),
+    ("plain", [], {}),          # no sanitizer: the one build that also forks with a live worker pool (pthread_atfork handlers of host_par.hpp)
 ])
 def test_host_code_is_clean_under(name, flags, env, tmp_path):
     if not shutil.which("g++") or not os.path.exists(os.path.join(HIP_INC, "hip", "hip_runtime.h")):

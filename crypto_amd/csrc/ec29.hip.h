@@ -44,6 +44,14 @@ template <> struct SubM<Fp2> {     // an Fp2 product leaves values < 6 p, so eve
 // has a narrower domain (fp30s.hip.h)
 template <class F> FD void fnormw(F &r, const F &a) { fnorm(r, a); }
 
+// q.y := -q.y when neg (the sign bit of a sorted entry).  Generic form: a subtraction from zero and a carry pass behind a branch.  The signed
+// fields (fp30s.hip.h, fs2_pair.hip.h) overload it: the negative of a balanced digit is a balanced digit, so there is no carry pass, and
+// (d ^ m) - m with m = -neg needs no branch — k_accumulate ran ~65 instructions behind a divergent branch here where 26 do (nearly every
+// wave has a lane that subtracts)
+template <class F> FD void fcond_neg(F &y, bool neg) {
+    if (neg) { F z; fzero(z); fsub<SubM<F>::NEG>(y, z, y); fnorm(y, y); }
+}
+
 struct Fp2H;
 struct Fs;
 template <> struct SubM<Fs> {      // signed digits (fp30s.hip.h): a subtraction needs no multiple of p; the constants are ignored
@@ -85,7 +93,7 @@ template <class F> FD void xyzz_dbl(Xyzz<F> &r, const Xyzz<F> &a) {
 // where the formula-first form needs 58 more spilled registers (k_accumulate<G2P>: 162 vs 104) and runs 7 % slower.
 template <class F> FD void xyzz_madd_early(Xyzz<F> &acc, bool &inf, const Aff<F> &q_in, bool neg) {
     Aff<F> q = q_in;
-    if (neg) { F z; fzero(z); fsub<SubM<F>::NEG>(q.y, z, q.y); fnorm(q.y, q.y); }
+    fcond_neg(q.y, neg);
     if (inf) { acc.x = q.x; acc.y = q.y; fset_one(acc.zz); fset_one(acc.zzz); inf = false; return; }
     F U2, S2, Pd, Rd;
     fmul(U2, q.x, acc.zz);
@@ -121,7 +129,7 @@ template <class F> FD void xyzz_madd_early(Xyzz<F> &acc, bool &inf, const Aff<F>
 template <class F> FD void xyzz_madd(Xyzz<F> &acc, bool &inf, const Aff<F> &q_in, bool neg) {
     if constexpr (!MaddFormulaFirst<F>::value) { xyzz_madd_early(acc, inf, q_in, neg); return; }
     Aff<F> q = q_in;
-    if (neg) { F z; fzero(z); fsub<SubM<F>::NEG>(q.y, z, q.y); fnorm(q.y, q.y); }
+    fcond_neg(q.y, neg);
     F U2, S2, Pd, Rd;
     fmul(U2, q.x, acc.zz);
     fmul(S2, q.y, acc.zzz);

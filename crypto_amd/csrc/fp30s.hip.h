@@ -119,6 +119,13 @@ FD void fs_neg(Fs &r, const Fs &a) {
 #pragma unroll
     for (int i = 0; i < SN; i++) r.l[i] = -a.l[i];
 }
+// r = neg ? -a : a without control flow: (d ^ m) - m with m = -neg.  Digit classes are symmetric, so the class of a is the class of r.
+FD void fs_cond_neg(Fs &r, const Fs &a, bool neg) {
+    SCHK(for (int i = 0; i < SN; i++) { uint64_t w = a.ubn[i] > a.ubp[i] ? a.ubn[i] : a.ubp[i]; r.ubn[i] = w; r.ubp[i] = w; } r.vb = a.vb; schk_fits(r);)
+    const int32_t m = neg ? -1 : 0;
+#pragma unroll
+    for (int i = 0; i < SN; i++) r.l[i] = (a.l[i] ^ m) - m;
+}
 // one parallel carry pass: class D -> class B (|digit| <= 2^29 + carry of the neighbour); value unchanged.  Precondition: digit + 2^29 fits an int32.
 FD void fs_bal(Fs &r, const Fs &a) {
     int32_t c[SN];
@@ -411,6 +418,7 @@ FD void fs_from_fp(Fs &r, const Fp &a) {
 }
 
 // ---- uniform spellings used by the field-generic group law (ec29.hip.h) ----
+FD void fcond_neg(Fs &y, bool neg) { fs_cond_neg(y, y, neg); }
 FD void fzero(Fs &r) { fs_zero(r); }
 FD void fset_one(Fs &r) { fs_set_one(r); }
 FD void fadd(Fs &r, const Fs &a, const Fs &b) { fs_add(r, a, b); }

@@ -109,6 +109,7 @@ __device__ __forceinline__ void sel(Fs &r, bool c, const Fs &a, const Fs &b) {  
     for (int i = 0; i < SN; i++) r.l[i] = c ? a.l[i] : b.l[i];
 }
 __device__ __forceinline__ void fzero(Fs2H &r) { fs_zero(r.v); }
+__device__ __forceinline__ void fcond_neg(Fs2H &y, bool neg) { fs_cond_neg(y.v, y.v, neg); }      // (both halves of -y: every lane negates its own)
 __device__ __forceinline__ void fset_one(Fs2H &r) { Fs one, z; fs_set_one(one); fs_zero(z); sel(r.v, spair_odd(), z, one); }
 __device__ __forceinline__ void fadd(Fs2H &r, const Fs2H &a, const Fs2H &b) { fs_add(r.v, a.v, b.v); }
 __device__ __forceinline__ void fdbl(Fs2H &r, const Fs2H &a) { fs_add(r.v, a.v, a.v); }

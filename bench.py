@@ -81,6 +81,25 @@ def dot_mod_r(a, b):
     return tot % R_MOD
 
 
+def single_gpu_2p24(ca, FB, gen1, pool):
+    """BASELINE config 5's 2^24 terms on ONE GPU (table built once per key, resident scalars, four calls in flight): the 1-GPU rate the N > 1 lines
+    are a multiple of.  Returns a dictionary; msm_2p20_equivalents_per_s is in the unit of the line's `value`."""
+    n24 = 1 << 24
+    k24 = seeded_scalars(0x5EED2400, n24); s24 = seeded_scalars(0x5EED2401, n24)
+    with FB.WindowTable(ca.G1, gen1[0]) as t1:
+        b24 = t1.multiply_many_to_bases(k24)
+        exp_xy, _ = t1.multiply(dot_mod_r(k24, s24))
+    t0 = time.perf_counter(); b24.precompute(); tab24 = (time.perf_counter() - t0) * 1e3
+    d24 = ca.DeviceScalars(s24)
+    ok = bool((b24.msm_resident(d24)[:12] == exp_xy).all())
+    lat = timed(lambda: b24.msm_resident(d24), 3, warm=8)        # (warm-up calls: every slot's workspace grows on its first call of this size)
+    list(pool.map(lambda _: b24.msm_resident(d24), range(4)))
+    t0 = time.perf_counter(); list(pool.map(lambda _: b24.msm_resident(d24), range(4))); thr = (time.perf_counter() - t0) / 4 * 1e3
+    b24.free(); d24.free()
+    return {"latency_ms": round(lat, 2), "ms_per_msm_4_in_flight": round(thr, 2), "msm_2p20_equivalents_per_s": round(16e3 / thr, 2),
+            "table_build_ms": round(tab24, 1), "bit_exact_vs_closed_form": ok}
+
+
 def timed(fn, k=5, warm=1):
     for _ in range(warm):
         fn()
@@ -328,6 +347,19 @@ def main():
                 out["secondary"] = secondary_configs(args.log2n, ks, scalars, db, ds, pool, cpu_legs=not (args.no_cpu_baseline or args.no_cpu_legs), ncpu=ncpu)
             except Exception as e:                      # never let the secondary numbers take the headline line down
                 out["secondary"] = {"error": repr(e)}
+        # scaling_base: the 1-GPU rate on config 5's 2^24 terms, in the unit of `value` — what value(N > 1) must be divided by (the N = 1 line is config 2:
+        # 2^20 terms with six independent calls in flight, a different workload).  At N = 1 it comes out of the secondary leg; at N > 1 rank 0 measures it
+        # on its own GPU after the timed region (one 28-GB table, ~3 s), so that every line of the driver's SCALE run carries its own denominator.
+        sb = None
+        try:
+            if world == 1 and isinstance(out.get("secondary"), dict):
+                sb = out["secondary"].get("g1_2p24_single_gpu", {}).get("msm_2p20_equivalents_per_s")
+            elif world > 1 and not STUB and not os.environ.get("DGPU_BENCH_NO_SCALING_BASE"):
+                sb = single_gpu_2p24(ca, FB, gen1, pool).get("msm_2p20_equivalents_per_s")
+        except Exception as e:                          # noqa: BLE001
+            out["scaling_base_error"] = repr(e)
+        out["scaling_base"] = sb
+        out["scaling_base_note"] = "MSM/s (2^20-term equivalents) of ONE GPU computing config 5's 2^24 terms (table resident, four calls in flight): speed-up at N GPUs = value / scaling_base"
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
@@ -465,22 +497,7 @@ def secondary_configs(log2n, ks, scalars, db, ds, pool, cpu_legs=True, ncpu=1):
     del eq, s16, zo, host_bases
     # -- BASELINE config 5's 2^24 terms on this ONE GPU: the denominator of the ">= 6x further at 8 GPUs" target
     try:
-        n24 = 1 << 24
-        k24 = seeded_scalars(0x5EED2400, n24); s24 = seeded_scalars(0x5EED2401, n24)
-        with FB.WindowTable(ca.G1, gen1[0]) as t1:
-            b24 = t1.multiply_many_to_bases(k24)
-            tot = dot_mod_r(k24, s24)
-            exp_xy, _ = t1.multiply(tot)
-        t0 = time.perf_counter(); b24.precompute(); tab24 = (time.perf_counter() - t0) * 1e3
-        d24 = ca.DeviceScalars(s24)
-        r24 = b24.msm_resident(d24)
-        ok = bool((r24[:12] == exp_xy).all())
-        lat = timed(lambda: b24.msm_resident(d24), 3, warm=8)        # (warm-up calls: every slot's workspace grows on its first call of this size)
-        list(pool.map(lambda _: b24.msm_resident(d24), range(4)))
-        t0 = time.perf_counter(); list(pool.map(lambda _: b24.msm_resident(d24), range(4))); thr = (time.perf_counter() - t0) / 4 * 1e3
-        res["g1_2p24_single_gpu"] = {"latency_ms": round(lat, 2), "ms_per_msm_4_in_flight": round(thr, 2), "msm_2p20_equivalents_per_s": round(16e3 / thr, 2),
-                                     "table_build_ms": round(tab24, 1), "bit_exact_vs_closed_form": ok}
-        b24.free(); d24.free(); del k24, s24
+        res["g1_2p24_single_gpu"] = single_gpu_2p24(ca, FB, gen1, pool)
     except Exception as e:          # noqa: BLE001
         res["g1_2p24_single_gpu"] = {"error": repr(e)}
     # -- the per-rank workload of BASELINE config 5 on 8 GPUs: 2^21 terms on a table, resident, with the headline's calls in flight: the

@@ -34,6 +34,8 @@ def test_two_ranks_strong_scaling_line():
     assert abs(out["value"] - (2 * (1 << 10) / float(1 << 20)) / (out["ms_per_step"] * 1e-3)) / out["value"] < 2e-2      # (value is rounded to three decimals)
     assert len(out["config"]["per_key_setup_ms"]["precomputed_table_per_rank"]) == 2
     assert "cpu_baseline" not in out and "secondary" not in out and out["data"].startswith("STUB")
+    # every N > 1 line names its own denominator: the 1-GPU rate on the same 2^24 terms (None under the stub: there is no GPU to measure it on)
+    assert "scaling_base" in out and out["scaling_base"] is None and "value / scaling_base" in out["scaling_base_note"]
 
 
 def test_default_size_at_two_ranks_is_config_5s_share():

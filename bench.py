@@ -660,6 +660,81 @@ def secondary_configs(log2n, ks, scalars, db, ds, pool, cpu_legs=True, ncpu=1):
     res["verify_1024_proofs_pairing_checker_ms"] = round(timed(lambda: LGv.verify_proofs_batch(pvkv, proofs_v, pubs_v, 0x5EED0028), 3), 2)
     res["verify_1024_proofs_merged_ms"] = round(timed(lambda: LGv.verify_proofs_batch_merged(pvkv, proofs_v, pubs_v, 0x5EED0029), 3), 2)
     res["verify_proofs_per_s_merged"] = round(nv / res["verify_1024_proofs_merged_ms"] * 1e3, 0)
+    if cpu_legs:
+        # ---- the f-rows on the host's cores: the same algorithms with the oracle's pieces, threaded where the reference's rayon is ----
+        thr = max(1, min(ncpu, 64))
+        to_l = lambda v: np.array([(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
+        # (1) G2Prepared::from x 1024 (randomized_pairing_check.rs:132,163; verifier.rs:22-23): arkworks converts inside a serial `.map(Into::into)`, so one thread is
+        #     the reference's shape; all cores beside it
+        (pc_cpu, ms_p1) = cpu_time(lambda: O.g2_prepare_batch(Q, threads=1))
+        (_, ms_pt) = min((cpu_time(lambda: O.g2_prepare_batch(Q, threads=thr)) for _ in range(3)), key=lambda t: t[1])
+        cpu["g2_prepare_1024"] = {"cpu_ms_one_thread": round(ms_p1, 1), "cpu_ms": round(ms_pt, 2), "cores": thr, "gpu_ms": res["g2_prepare_1024_ms"], "x": round(ms_pt / res["g2_prepare_1024_ms"], 2),
+                                  "x_vs_one_thread": round(ms_p1 / res["g2_prepare_1024_ms"], 1), "bit_exact_vs_gpu": bool((pc_cpu == pc.coeffs).all()),
+                                  "sample": "G2Prepared::from of 1024 points (68 x 3 Fp2 line coefficients each); the reference converts serially (`b.into()` inside collect), all %d threads beside it" % thr}
+        # (2) 1024 proofs through the lazy RandomizedPairingChecker exactly as the reference runs it (utils/src/randomized_pairing_check.rs:116-138,204-214): per proof three
+        #     scalings by random^k (rayon), the target's e(alpha, beta)^(random^k), then ONE Miller loop over 3 x 1024 pairs (B_i prepared serially inside, -delta / -gamma
+        #     prepared in the key) and one final exponentiation
+        rnd_c = 0x5EED0028 % R_MOD
+        ms_pow, mm = [], 1
+        for _ in range(nv):
+            ms_pow.append(mm); mm = mm * rnd_c % R_MOD
+        m_l = np.stack([to_l(x) for x in ms_pow])
+        gabc0 = np.concatenate([K_[1], pairing.FP_ONE_MONT])
+
+        def cpu_checker():
+            xg, _ = O.g1_scale_batch(np.repeat(K_[2].reshape(1, 12), nv, 0), np.stack([p[0] for p in pubs_v]), threads=thr)          # calculate_d: x_i gamma_abc[1] ...
+            dps = []
+            for i in range(nv):                                                                                                  # ... + gamma_abc[0] + proof.d
+                acc = O.G1.add(O.G1.add(gabc0, np.concatenate([xg[i], pairing.FP_ONE_MONT])), np.concatenate([D_[i], pairing.FP_ONE_MONT]))
+                dps.append(O.G1.to_affine(acc)[0])
+            a_m, _ = O.g1_scale_batch(A_, m_l, threads=thr); c_m, _ = O.g1_scale_batch(C_, m_l, threads=thr); d_m, _ = O.g1_scale_batch(np.stack(dps), m_l, threads=thr)
+            right = O.fp12_multi_pow(pvkv["alpha_g1_beta_g2"], m_l, threads=thr)
+            co = np.concatenate([np.repeat(pre_cpu[0].reshape(1, -1), nv, 0), np.repeat(pre_cpu[1].reshape(1, -1), nv, 0)])
+            fm = O.multi_miller_loop_mixed(a_m, B_, np.concatenate([c_m, d_m]), co, threads=thr)
+            return bool((O.final_exponentiation(fm) == right).all())
+        (ok_c, ms_chk) = cpu_time(cpu_checker)
+        cpu["verify_1024_checker"] = {"cpu_ms": round(ms_chk, 1), "gpu_ms": res["verify_1024_proofs_pairing_checker_ms"], "x": round(ms_chk / res["verify_1024_proofs_pairing_checker_ms"], 1), "cores": thr,
+                                      "accepts": ok_c, "sample": "1024 LegoGroth16 proofs through the lazy pairing checker as the reference runs it: 3 x 1024 scalings + 1024 calculate_d + 1024 GT powers on %d threads, "
+                                                                 "1024 G2Prepared::from serially inside ONE 3072-pair Miller loop (chunks of 4 pairs on %d threads), one final exponentiation" % (thr, thr)}
+        # (3) the merged form (what verify_1024_proofs_merged_ms times): N scalings, two N-term MSMs, ONE (N + 2)-pair Miller loop; every piece compared with the library's
+        from crypto_amd.pairing_check import g1_scale_each
+        c_sc = np.stack([to_l(sum(ms_pow) % R_MOD), to_l(sum(mi * xi for mi, xi in zip(ms_pow, xv)) % R_MOD)] + [m_l[i] for i in range(nv)])
+        d_pts = np.concatenate([K_[1:3], D_])
+
+        def cpu_merged():
+            a_m, a_i = O.g1_scale_batch(A_, m_l, threads=thr)
+            c_sum, _ = O.G1.to_affine(O.G1.msm(C_, m_l, threads=win_threads(nv)))
+            d_sum, _ = O.G1.to_affine(O.G1.msm(d_pts, c_sc, threads=win_threads(nv)))
+            fm = O.multi_miller_loop_mixed(a_m, B_, np.stack([c_sum, d_sum]), pre_cpu, threads=thr)
+            right = O.fp12_pow(pvkv["alpha_g1_beta_g2"], sum(ms_pow) % R_MOD)
+            return a_m, c_sum, d_sum, fm, bool((O.final_exponentiation(fm) == right).all())
+        ((a_c, cs_c, ds_c, fm_c, ok_m), ms_mrg) = min((cpu_time(cpu_merged) for _ in range(2)), key=lambda t: t[1])
+        a_g, _ = g1_scale_each(A_, m_l, None)
+        cs_g = ca.msm_bigint(ca.G1, C_, m_l); ds_g = ca.msm_bigint(ca.G1, d_pts, c_sc)
+        fm_g = pairing.multi_miller_loop(np.concatenate([a_g, cs_g[:12].reshape(1, 12), ds_g[:12].reshape(1, 12)]), [B_, pvkv["delta_g2_neg_pc"], pvkv["gamma_g2_neg_pc"]])
+        cpu["verify_1024_merged"] = {"cpu_ms": round(ms_mrg, 1), "gpu_ms": res["verify_1024_proofs_merged_ms"], "x": round(ms_mrg / res["verify_1024_proofs_merged_ms"], 1), "cores": thr, "accepts": ok_m,
+                                     "bit_exact_vs_gpu": bool((a_c == a_g).all() and (cs_c == cs_g[:12]).all() and (ds_c == ds_g[:12]).all() and (fm_c == fm_g).all()),
+                                     "sample": "the classical Groth16 batch verifier: 1024 scalings (%d threads), two 1024-term G1 MSMs (one thread per window), ONE 1026-pair Miller loop, one final exponentiation; "
+                                               "scaled points, both MSM results and the raw Fp12 Miller output compared with the library's limb for limb" % thr}
+        # (4) what a SnarkPack aggregation of these 1024 proofs spends its time in (legogroth16/src/aggregation/groth16/prover.rs:212-382, commitment.rs:23-69): per GIPA round of half
+        #     length s = 512 .. 1, fourteen multi-pairings of s pairs (the left / right commitments T, U of (A, B), C, D and the cross terms z) and four s-term G1 MSMs (the MIPP
+        #     cross terms of C and D against the challenge powers).  Round by round on the host's cores; the GPU number beside it is the WHOLE aggregation
+        def cpu_gipa():
+            gts = []
+            s_ = nv // 2
+            while s_ >= 1:
+                for k in range(14):
+                    lo = (k * 37) % (nv - s_ + 1)
+                    gts.append(O.final_exponentiation(O.multi_miller_loop(P[lo:lo + s_], Q[lo:lo + s_], threads=thr)))
+                for k in range(4):
+                    O.G1.msm(C_[:s_], m_l[k:k + s_], threads=win_threads(s_) if s_ >= 32 else 1)
+                s_ //= 2
+            return gts
+        (gts, ms_gipa) = cpu_time(cpu_gipa)
+        gt_g = ca.final_exponentiation(ca.multi_miller_loop(P[:nv // 2], Q[:nv // 2]))
+        cpu["snarkpack_aggregate_dominant_ops"] = {"cpu_ms": round(ms_gipa, 1), "cores": thr, "bit_exact_vs_gpu": bool((gts[0] == gt_g).all()),
+                                                   "sample": "ten GIPA rounds of a 1024-proof aggregation: 14 multi-pairings (Miller loop on %d threads + final exponentiation) and 4 G1 MSMs per round at half "
+                                                             "lengths 512 .. 1 — the prover's dominant operations only (no KZG openings, no folding, no transcript); first multi-pairing compared with the library's" % thr}
     # -- SnarkPack aggregation of the same 1024 LegoGroth16 proofs (aggregation/legogroth16/prover.rs:38-127: TIPP for (A, B), MIPP for
     #    C and D, the KZG openings) and verification of the aggregate (verifier.rs:34-96) — the producer of the segmented Miller loops and
     #    of the endomorphism-split folding steps
@@ -682,6 +757,9 @@ def secondary_configs(log2n, ks, scalars, db, ds, pool, cpu_legs=True, ncpu=1):
     ANv.verify_aggregate_proof(vsrs_ag, {"vk": vkv}, pubs_int, words_v, 0x5EED002C, AGv.MerlinTranscript(b"bench"), with_d=True); t_vf = ANv.LAST["transcript_ms"]
     res["snarkpack_python_transcript_ms"] = {"aggregate": round(t_ag, 2), "verify": round(t_vf, 2),
                                              "note": "part of the two numbers above spent inside the Python Merlin transcript the library calls back (a Rust caller's merlin::Transcript costs microseconds)"}
+    if cpu_legs and "snarkpack_aggregate_dominant_ops" in cpu:
+        cpu["snarkpack_aggregate_dominant_ops"]["gpu_whole_aggregation_ms"] = res["snarkpack_aggregate_1024_proofs_ms"]
+        cpu["snarkpack_aggregate_dominant_ops"]["x"] = round(cpu["snarkpack_aggregate_dominant_ops"]["cpu_ms"] / res["snarkpack_aggregate_1024_proofs_ms"], 1)
     res["snarkpack_aggregate_1024_proofs_python_host_ms"] = round(timed(lambda: ALv.aggregate_proofs(pk_ag, AGv.MerlinTranscript(b"bench"), proofs_v), 3), 2)
     res["snarkpack_verify_aggregate_python_host_ms"] = round(timed(lambda: ALv.verify_aggregate_proof(vsrs_ag, {"vk": vkv}, pubs_int, agg_v, 0x5EED002C, AGv.MerlinTranscript(b"bench")), 3), 2)
     # -- BASELINE config 4: witness map on the x_i = x_{i-1}^2 + i circuit shape (m + 1 constraints + 2 instance variables = D), circuit resident,

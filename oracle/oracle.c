@@ -575,6 +575,67 @@ API void orc_multi_miller_loop_mixed(const uint64_t *p_aff, const uint64_t *q_af
     memcpy(out, &f, sizeof f);
     free(partial); free(co); free(ps);
 }
+/* ---- batches on the host's cores: the per-equation work of RandomizedPairingChecker (utils/src/randomized_pairing_check.rs:116-214) as the reference
+ * spreads it with rayon — `cfg_iter!(a).map(|a| a.mul_bigint(m))` scalings (:125-129,152-158), `G2Prepared::from` of every b (:132,163), the targets'
+ * `out.mul_bigint(m)` (:136) — used by bench.py's CPU legs beside the batched verifier and the aggregation (test infrastructure, like everything here). ---- */
+typedef struct { int kind; size_t n; const uint64_t *a; const uint8_t *f; const uint64_t *b; size_t bstride; const uint8_t *neg; uint64_t *out; uint8_t *outf; fp12 *acc; volatile long *next; } bt_job;
+static void *bt_worker(void *arg) {
+    bt_job *J = (bt_job *)arg;
+    fp12 prod; fp12_one(&prod);
+    for (;;) {
+        long i = __sync_fetch_and_add(J->next, 1);
+        if (i >= (long)J->n) break;
+        if (J->kind == 0) {                                   /* out_i = (+-) s_i P_i, affine (mul_bigint, then into_affine: one inversion per point like G1Prepared::from(projective)) */
+            g1_jac r; g1_aff o;
+            const int inf = J->f && J->f[i];
+            g1_mul(&r, (const g1_aff *)(J->a + 12 * i), inf, J->b + J->bstride * i);
+            const int oinf = g1_to_affine(&o, &r);
+            if (!oinf && J->neg && J->neg[i]) fp_neg(&o.y, &o.y);
+            if (oinf) memset(J->out + 12 * i, 0, 96); else memcpy(J->out + 12 * i, &o, 96);
+            J->outf[i] = (uint8_t)oinf;
+        } else if (J->kind == 1) {                            /* G2Prepared::from(q_i) */
+            g2_prepare((const g2_aff *)(J->a + 24 * i), (ell_coeff *)(J->out + (size_t)N_COEFF * 36 * i));
+        } else {                                              /* prod *= a_i ^ e_i (255-bit square-and-multiply, PairingOutput::mul_bigint) */
+            fp12 acc, base = *(const fp12 *)(J->a + (J->bstride ? 72 * i : 0)); fp12_one(&acc);
+            const uint64_t *e = J->b + 4 * i;
+            int top = 255; while (top >= 0 && !((e[top / 64] >> (top % 64)) & 1)) top--;
+            for (int k = top; k >= 0; k--) { fp12_sqr(&acc, &acc); if ((e[k / 64] >> (k % 64)) & 1) fp12_mul(&acc, &acc, &base); }
+            fp12_mul(&prod, &prod, &acc);
+        }
+    }
+    if (J->kind == 2) { fp12 *slot = J->acc + __sync_fetch_and_add(J->next + 1, 1); *slot = prod; }
+    return NULL;
+}
+static void bt_run(bt_job *J, int threads) {
+    if (threads > 64) threads = 64; if (threads < 1) threads = 1; if ((size_t)threads > J->n) threads = J->n ? (int)J->n : 1;
+    if (threads == 1) { bt_worker(J); return; }
+    pthread_t th[64];
+    for (int t = 0; t < threads; t++) pthread_create(&th[t], NULL, bt_worker, J);
+    for (int t = 0; t < threads; t++) pthread_join(th[t], NULL);
+}
+API void orc_g1_scale_batch(const uint64_t *pts, const uint8_t *inf, const uint64_t *scalars, size_t scalar_stride, const uint8_t *negate, size_t n, int threads, uint64_t *out, uint8_t *out_inf) {
+    volatile long next[2] = {0, 0};
+    bt_job J = {0, n, pts, inf, scalars, scalar_stride, negate, out, out_inf, NULL, next};
+    bt_run(&J, threads);
+}
+API void orc_g2_prepare_batch(const uint64_t *q, size_t n, int threads, uint64_t *out) {
+    pthread_once(&ml_once, ml_init);
+    volatile long next[2] = {0, 0};
+    bt_job J = {1, n, q, NULL, NULL, 0, NULL, out, NULL, NULL, next};
+    bt_run(&J, threads);
+}
+/* prod_i a_i ^ e_i; a_stride = 0: the same base for every exponent */
+API void orc_fp12_multi_pow(const uint64_t *a, size_t a_stride, const uint64_t *e, size_t n, int threads, uint64_t out[72]) {
+    pthread_once(&frob_once, frob_init);
+    volatile long next[2] = {0, 0};
+    fp12 parts[64];
+    if (threads > 64) threads = 64; if (threads < 1) threads = 1; if ((size_t)threads > n) threads = n ? (int)n : 1;
+    bt_job J = {2, n, a, NULL, e, a_stride, NULL, NULL, NULL, parts, next};
+    bt_run(&J, threads);
+    fp12 f; fp12_one(&f);
+    for (long k = 0; k < next[1]; k++) fp12_mul(&f, &f, &parts[k]);
+    memcpy(out, &f, sizeof f);
+}
 /* E::final_exponentiation (A.4 chain).  Returns 0 on success, -1 where arkworks returns None (f == 0). */
 API int orc_final_exponentiation(const uint64_t in[72], uint64_t out[72]) {
     const fp12 *f = (const fp12 *)in;

@@ -205,6 +205,35 @@ def witness_map(mats, z, num_inputs, num_constraints, threads=1):
     return out
 
 
+def g1_scale_batch(points, scalars, negate=None, is_inf=None, threads=1):
+    """out_i = (+-) s_i P_i as affine points (scalars: (n, 4) or ONE (4,) scalar for every point) — the checker's scalings, one task per point"""
+    points = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, 12); n = len(points)
+    scalars = np.ascontiguousarray(scalars, dtype=np.uint64)
+    stride = 0 if scalars.size == 4 else 4
+    neg = None if negate is None else np.ascontiguousarray(negate, dtype=np.uint8)
+    inf = None if is_inf is None else np.ascontiguousarray(is_inf, dtype=np.uint8)
+    out = u64((n, 12)); oinf = np.zeros(n, np.uint8)
+    lib().orc_g1_scale_batch(_p(points), _p(inf), _p(scalars), C.c_size_t(stride), _p(neg), C.c_size_t(n), int(threads), _p(out), _p(oinf))
+    return out, oinf
+
+
+def g2_prepare_batch(qs, threads=1):
+    """G2Prepared::from for every point: (n, 68 * 36) words"""
+    qs = np.ascontiguousarray(qs, dtype=np.uint64).reshape(-1, 24); n = len(qs)
+    out = u64((n, 68 * 36))
+    lib().orc_g2_prepare_batch(_p(qs), C.c_size_t(n), int(threads), _p(out))
+    return out
+
+
+def fp12_multi_pow(bases, exps, threads=1):
+    """prod_i bases_i ^ exps_i (exps: (n, 4) canonical limbs); bases (72,): the same base for every exponent"""
+    bases = np.ascontiguousarray(bases, dtype=np.uint64); exps = np.ascontiguousarray(exps, dtype=np.uint64).reshape(-1, 4)
+    stride = 0 if bases.size == 72 else 72
+    out = u64(72)
+    lib().orc_fp12_multi_pow(_p(bases), C.c_size_t(stride), _p(exps), C.c_size_t(len(exps)), int(threads), _p(out))
+    return out
+
+
 def final_exponentiation(f):
     f = np.ascontiguousarray(f, dtype=np.uint64)
     out = u64(72)

@@ -161,3 +161,35 @@ def test_final_exponentiation_chain_equals_its_definition():
     g1, g2 = O.G1.generator(), O.G2.generator()
     ec = O.final_exponentiation(O.multi_miller_loop(g1.reshape(1, 12), g2.reshape(1, 24)))
     assert U.f12_ints(ec) == [int(v, 16) for v in pr["e_g1_g2"]]
+
+
+def test_threaded_batches_equal_the_single_calls():
+    """orc_g1_scale_batch / orc_g2_prepare_batch / orc_fp12_multi_pow (bench.py's CPU legs beside the batched verifier and the aggregation) are the
+    one-at-a-time oracle functions run over the host's cores: same values whatever the thread count"""
+    n = 37
+    k0 = O.rand_scalars(901, 1)[0]; d = O.rand_scalars(902, 1)[0]
+    P = O.G1.gen_seq(k0, d, n); Q = O.G2.gen_seq(d, k0, n)
+    sc = O.rand_scalars(903, n)
+    neg = (np.arange(n) % 3 == 0).astype(np.uint8); inf = np.zeros(n, np.uint8); inf[5] = 1
+    for thr in (1, 4, 64):
+        out, oinf = O.g1_scale_batch(P, sc, negate=neg, is_inf=inf, threads=thr)
+        for i in range(n):
+            ref, rinf = O.G1.to_affine(O.G1.mul(P[i], sc[i], inf=bool(inf[i])))
+            assert oinf[i] == rinf
+            if not rinf:
+                assert (out[i][:6] == ref[:6]).all()
+                y = U.fp_int(ref[6:]); want = U.fp_abi((-y) % U.P if neg[i] else y)
+                assert (out[i][6:] == want).all(), i
+        same, _ = O.g1_scale_batch(P, sc[2], threads=thr)                                   # one scalar for every point
+        assert (same[9] == O.G1.to_affine(O.G1.mul(P[9], sc[2]))[0]).all()
+        pb = O.g2_prepare_batch(Q, threads=thr)
+        assert all((pb[i] == O.g2_prepare(Q[i]).reshape(-1)).all() for i in (0, 7, n - 1))
+    g = O.final_exponentiation(O.multi_miller_loop(P[:2], Q[:2]))
+    fs = np.stack([g, O.fp12_mul(g, g), O.fp12_mul(O.fp12_mul(g, g), g)])
+    want_same = O.fp12_one(); want_each = O.fp12_one()
+    for i in range(3):
+        want_same = O.fp12_mul(want_same, O.fp12_pow(g, O.limbs_to_int(sc[i])))
+        want_each = O.fp12_mul(want_each, O.fp12_pow(fs[i], O.limbs_to_int(sc[i])))
+    for thr in (1, 2, 8):
+        assert (O.fp12_multi_pow(g, sc[:3], threads=thr) == want_same).all()
+        assert (O.fp12_multi_pow(fs, sc[:3], threads=thr) == want_each).all()

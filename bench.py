@@ -755,6 +755,13 @@ def secondary_configs(log2n, ks, scalars, db, ds, pool, cpu_legs=True, ncpu=1):
     res["snarkpack_verify_aggregate_ms"] = round(timed(lambda: ANv.verify_aggregate_proof(vsrs_ag, {"vk": vkv}, pubs_int, words_v, 0x5EED002C, AGv.MerlinTranscript(b"bench"), with_d=True), 3), 2)
     ANv.aggregate_proofs_words(pk_ag, AGv.MerlinTranscript(b"bench"), proofs_v, with_d=True); t_ag = ANv.LAST["transcript_ms"]
     ANv.verify_aggregate_proof(vsrs_ag, {"vk": vkv}, pubs_int, words_v, 0x5EED002C, AGv.MerlinTranscript(b"bench"), with_d=True); t_vf = ANv.LAST["transcript_ms"]
+    # the same two calls with the caller's transcript as C callbacks (crypto_amd/aggregation/merlin_native.c, byte for byte the Python Merlin): what a Rust
+    # host's merlin::Transcript costs the library — the figure to hold against the reference, whose transcript is compiled code too
+    NT = AGv.NativeMerlinTranscript
+    assert (ANv.aggregate_proofs_words(pk_ag, NT(b"bench"), proofs_v, with_d=True) == words_v).all()
+    ANv.verify_aggregate_proof(vsrs_ag, {"vk": vkv}, pubs_int, words_v, 0x5EED002B, NT(b"bench"), with_d=True)
+    res["snarkpack_aggregate_1024_proofs_native_transcript_ms"] = round(timed(lambda: ANv.aggregate_proofs_words(pk_ag, NT(b"bench"), proofs_v, with_d=True), 3), 2)
+    res["snarkpack_verify_aggregate_native_transcript_ms"] = round(timed(lambda: ANv.verify_aggregate_proof(vsrs_ag, {"vk": vkv}, pubs_int, words_v, 0x5EED002C, NT(b"bench"), with_d=True), 3), 2)
     res["snarkpack_python_transcript_ms"] = {"aggregate": round(t_ag, 2), "verify": round(t_vf, 2),
                                              "note": "part of the two numbers above spent inside the Python Merlin transcript the library calls back (a Rust caller's merlin::Transcript costs microseconds)"}
     if cpu_legs and "snarkpack_aggregate_dominant_ops" in cpu:

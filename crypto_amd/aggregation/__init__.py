@@ -5,6 +5,6 @@ operation runs on the GPU entry points: multi_pairing (dgpu_multi_miller_loop + 
 (dgpu_msm_*), the GIPA folding step (dgpu_g1/g2_mul_add_batch), SRS powers (dgpu_window_table_*), batched pairing
 checks (crypto_amd.pairing_check.RandomizedPairingChecker).
 """
-from .transcript import MerlinTranscript          # noqa: F401
+from .transcript import MerlinTranscript, NativeMerlinTranscript          # noqa: F401
 from .srs import GenericSRS, setup_fake_srs, Key, PairCommitment   # noqa: F401
 from .groth16 import aggregate_proofs, verify_aggregate_proof, AggregationError   # noqa: F401

@@ -59,6 +59,21 @@ class _Callbacks:
             raise self.error
 
 
+class _NativeCallbacks:
+    """a transcript that already IS a dgpu_transcript with C callbacks (transcript.NativeMerlinTranscript): nothing of this process's interpreter runs
+    inside the library call"""
+
+    def __init__(self, transcript):
+        self.struct, self.seconds, self._keep = transcript.struct, 0.0, transcript
+
+    def check(self):
+        pass
+
+
+def _callbacks(transcript):
+    return _NativeCallbacks(transcript) if hasattr(transcript, "struct") else _Callbacks(transcript)
+
+
 # ---- the flat proof (include/dock_gpu.h: the word layout) <-> the dictionaries of groth16.py ------------------------------------------------
 def proof_to_words(proof):
     names = [k for k in ("c", "d") if "com_" + k in proof]
@@ -145,7 +160,7 @@ def aggregate_proofs_words(srs, transcript, proofs, with_d=False):
     cap = lib().dgpu_snarkpack_proof_words(n, int(with_d))
     out = np.zeros(cap, dtype=np.uint64)
     ln = C.c_size_t(0)
-    cb = _Callbacks(transcript)
+    cb = _callbacks(transcript)
     rc = lib().dgpu_snarkpack_aggregate(C.byref(S), _p(a), _p(b), _p(c), _p(d), n, C.byref(cb.struct), _p(out), cap, C.byref(ln))
     cb.check()
     LAST["transcript_ms"] = cb.seconds * 1e3
@@ -180,7 +195,7 @@ def verify_aggregate_proof(ip_verifier_srs, pvk, public_inputs, proof, random, t
     dl = None if d is None else _c(d, 12)
     rnd = ops.limbs([random]).reshape(4)
     ok = C.c_int32(0)
-    cb = _Callbacks(transcript)
+    cb = _callbacks(transcript)
     rc = lib().dgpu_snarkpack_verify(C.byref(S), C.byref(K), _p(pub) if l else None, len(public_inputs), l, _p(words), len(words), variant, _p(dl), _p(rnd), C.byref(cb.struct),
                                      (VALIDATE_GT if validate_gt else 0) | (VALIDATE_POINTS if validate_points else 0), C.byref(ok))
     cb.check()

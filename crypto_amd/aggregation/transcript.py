@@ -47,9 +47,9 @@ def build_helper():
     """gcc keccak_f1600.c -> libkeccak_f1600.so next to this file (called by __graft_entry__.build())"""
     import os, subprocess
     here = os.path.dirname(os.path.abspath(__file__))
-    so, src = os.path.join(here, "libkeccak_f1600.so"), os.path.join(here, "keccak_f1600.c")
-    if not os.path.exists(so) or os.path.getmtime(src) > os.path.getmtime(so):
-        subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", "-fvisibility=hidden", "-o", so, src])
+    so, srcs = os.path.join(here, "libkeccak_f1600.so"), [os.path.join(here, "keccak_f1600.c"), os.path.join(here, "merlin_native.c")]
+    if not os.path.exists(so) or any(os.path.getmtime(src) > os.path.getmtime(so) for src in srcs):
+        subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", "-fvisibility=hidden", "-o", so] + srcs)
     return so
 
 
@@ -187,3 +187,58 @@ class MerlinTranscript:
             if v < R_MOD and v != 0:
                 return pow(v, R_MOD - 2, R_MOD)
             buf = self.merlin.challenge_bytes(label, 64)
+
+
+
+class NativeMerlinTranscript:
+    """The same transcript in C (merlin_native.c, in the helper library next to keccak_f1600.c): `struct` is a `dgpu_transcript` whose two callbacks are
+    plain C functions — what a Rust host's merlin::Transcript costs the library (microseconds), with no interpreter in the loop.  Test / bench helper,
+    byte for byte the transcript above (tests/test_transcript.py)."""
+
+    def __init__(self, label, _handle=None):
+        import ctypes as C
+        import os
+        from .._native import Transcript, APPEND_FN, CHALLENGE_FN
+        H = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "libkeccak_f1600.so"))
+        H.mt_new.restype = C.c_void_p; H.mt_new.argtypes = [C.c_char_p, C.c_size_t]
+        H.mt_clone.restype = C.c_void_p; H.mt_clone.argtypes = [C.c_void_p]
+        H.mt_free.argtypes = [C.c_void_p]
+        H.mt_append_message.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
+        H.mt_challenge_scalar.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p]
+        H.mt_challenge_bytes.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        H.mt_state.argtypes = [C.c_void_p, C.c_void_p]
+        self._H, self._C = H, C
+        self.ctx = _handle if _handle is not None else H.mt_new(bytes(label), len(label))
+        if not self.ctx:
+            raise MemoryError("mt_new")
+        self.struct = Transcript(self.ctx, C.cast(H.mt_append_message, APPEND_FN), C.cast(H.mt_challenge_scalar, CHALLENGE_FN))
+
+    def clone(self):
+        return NativeMerlinTranscript(b"", _handle=self._H.mt_clone(self.ctx))
+
+    def append(self, label, element_bytes):
+        self._H.mt_append_message(self.ctx, bytes(label), len(label), bytes(element_bytes), len(element_bytes))
+
+    append_message = append
+
+    def challenge_bytes(self, label, n):
+        buf = self._C.create_string_buffer(n)
+        self._H.mt_challenge_bytes(self.ctx, bytes(label), len(label), buf, n)
+        return buf.raw
+
+    def challenge_scalar(self, label):
+        out = (self._C.c_uint64 * 4)()
+        self._H.mt_challenge_scalar(self.ctx, bytes(label), len(label), out)
+        return sum(int(out[i]) << (64 * i) for i in range(4))
+
+    def state(self):
+        buf = self._C.create_string_buffer(203)
+        self._H.mt_state(self.ctx, buf)
+        return buf.raw
+
+    def __del__(self):
+        try:
+            if self.ctx:
+                self._H.mt_free(self.ctx); self.ctx = None
+        except Exception:      # noqa: BLE001
+            pass

@@ -107,6 +107,23 @@ def test_native_aggregate_equals_python(n):
     assert rejects(lambda: V(proof=NA.aggregate_proofs(pk, AG.MerlinTranscript(label), wrong)))
 
 
+def test_native_transcript_in_c_gives_the_same_proof():
+    """the caller's transcript as C callbacks (merlin_native.c: no interpreter inside the library call) — the same proof words as with the Python
+    transcript called back, each verifier accepts the other's transcript form, a wrong label is rejected"""
+    n = 16
+    vk, proofs, inputs, _ = make_statement(n, 1, seed=21)
+    pk, vsrs = AG.setup_fake_srs(7, 11, n, O.G1.generator(), O.G2.generator()).specialize(n)
+    pvk = {"vk": vk}
+    label = b"native-transcript"
+    w_py = NA.aggregate_proofs_words(pk, AG.MerlinTranscript(label), proofs)
+    w_c = NA.aggregate_proofs_words(pk, AG.NativeMerlinTranscript(label), proofs)
+    assert (w_py == w_c).all()
+    NA.verify_aggregate_proof(vsrs, pvk, inputs, w_c, 0x1234567, AG.NativeMerlinTranscript(label), validate_gt=True, validate_points=True)
+    NA.verify_aggregate_proof(vsrs, pvk, inputs, w_c, 0x1234567, AG.MerlinTranscript(label))
+    with pytest.raises(AG.AggregationError):
+        NA.verify_aggregate_proof(vsrs, pvk, inputs, w_c, 0x1234567, AG.NativeMerlinTranscript(b"another"))
+
+
 def test_native_argument_checks():
     vk, proofs, inputs, _ = make_statement(4, 1, seed=9)
     pk, _ = AG.setup_fake_srs(3, 5, 4, O.G1.generator(), O.G2.generator()).specialize(4)

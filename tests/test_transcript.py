@@ -75,3 +75,34 @@ def test_kzg_polynomial_helpers():
         back[i + 1] = (back[i + 1] + c) % R_MOD
         back[i] = (back[i] - c * z) % R_MOD
     assert back == p
+
+
+def test_native_merlin_is_the_python_merlin_byte_for_byte():
+    """merlin_native.c (the dgpu_transcript callbacks as plain C functions: what a Rust host's merlin::Transcript costs the library) against the Python
+    statement: the same STROBE state after every operation, the same challenge bytes and scalars (the inverse of the sampled element), clones included"""
+    import os
+    import random
+    from crypto_amd.aggregation import transcript as T
+    T.build_helper()
+    rnd = random.Random(5)
+    for label in (b"", b"snarkpack", b"x" * 200):
+        a = T.MerlinTranscript(label); b = T.NativeMerlinTranscript(label)
+        for i in range(120):
+            lab = bytes(rnd.randrange(256) for _ in range(rnd.randrange(0, 40)))
+            op = rnd.randrange(4)
+            if op <= 1:
+                msg = os.urandom(rnd.choice([0, 1, 31, 32, 48, 96, 165, 166, 167, 332, 576, 1000]))
+                a.append(lab, msg); b.append(lab, msg)
+            elif op == 2:
+                assert a.challenge_scalar(lab) == b.challenge_scalar(lab)
+            else:
+                k = rnd.choice([1, 32, 64, 166, 400])
+                assert a.challenge_bytes(lab, k) == b.challenge_bytes(lab, k)
+            st = b.state()
+            assert bytes(a.merlin.strobe.state) == st[:200] and (a.merlin.strobe.pos, a.merlin.strobe.pos_begin) == (st[200], st[201]), (label, i)
+        c = b.clone()
+        assert c.challenge_scalar(b"after") == a.challenge_scalar(b"after") == b.challenge_scalar(b"after")
+    # the published Merlin vector through the C path as well
+    t = T.NativeMerlinTranscript(b"test protocol")
+    t.append(b"some label", b"some data")
+    assert t.challenge_bytes(b"challenge", 32).hex() == "d5a21972d0d5fe320c0d263fac7fffb8145aa640af6e9bca177c03c7efcf0615"

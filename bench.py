@@ -247,27 +247,6 @@ def main():
     dt = time.perf_counter() - t0
     allocs_timed = ca.device_alloc_count() - allocs0
     assert (last == res).all(), "result changed between runs"
-    # Stage breakdown and the dominant kernel's duration (HIP events on the library's own stream around every stage): the stage timers are part of
-    # the DEVELOPMENT surface (include/dock_gpu_dev.h), which the product library does not export.  So this leg — untimed, rank 0 — runs the same
-    # workload on the development twin (libdock_gpu_dev.so: the product's objects, kernels included, plus that surface) with its own copy of the
-    # operands: one call in flight (stages_seq: the roofline's kernel duration) and the timed region's shape (stages: durations that overlap).
-    stages_seq, stages = {}, {}
-    if rank == 0:
-        with ca.twin():
-            with FB.WindowTable(ca.G1, gen1[0]) as gtab_t:
-                db_t = gtab_t.multiply_many_to_bases(ks)
-            if use_table:
-                db_t.precompute()
-            ds_t = ca.DeviceScalars(scalars)
-            assert (db_t.msm_resident(ds_t)[:18] == (res if world == 1 else db.msm_resident(ds))[:18]).all(), "twin != product"
-            list(pool.map(lambda _: db_t.msm_resident(ds_t), range(2 * inflight)))
-            ca.prof.enable(True); ca.prof.reset()
-            for _ in range(3):
-                db_t.msm_resident(ds_t)
-            stages_seq = ca.prof.read(); ca.prof.reset()
-            list(pool.map(lambda _: db_t.msm_resident(ds_t), range(args.steps)))
-            stages = ca.prof.read(); ca.prof.enable(False)
-            db_t.free(); ds_t.free()
     per_rank_table_ms = [round(table_ms, 1)]
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=cdev if cdev is not None else "cpu")
@@ -276,6 +255,29 @@ def main():
         got = [None] * world
         dist.all_gather_object(got, round(table_ms, 1))            # every rank builds the table of ITS 2^24 / N terms: the per-key setup of each
         per_rank_table_ms = got
+
+    # Stage breakdown and the dominant kernel's duration (HIP events on the library's own stream around every stage): the stage timers are part of
+    # the DEVELOPMENT surface (include/dock_gpu_dev.h), which the product library does not export.  So this leg — untimed, rank 0, after the
+    # ranks' collectives — runs the same workload on the development twin (libdock_gpu_dev.so: the product's objects, kernels included, plus that surface) with its own copy of the
+    # operands: one call in flight (stages_seq: the roofline's kernel duration) and the timed region's shape (stages: durations that overlap).
+    stages_seq, stages = {}, {}
+    if rank == 0:
+        local_res = res if world == 1 else db.msm_resident(ds)        # this rank's own partial point (product library), before the twin takes over the wrappers
+        with ca.twin():
+            with FB.WindowTable(ca.G1, gen1[0]) as gtab_t:
+                db_t = gtab_t.multiply_many_to_bases(ks)
+            if use_table:
+                db_t.precompute()
+            ds_t = ca.DeviceScalars(scalars)
+            assert (db_t.msm_resident(ds_t)[:18] == local_res[:18]).all(), "twin != product"
+            list(pool.map(lambda _: db_t.msm_resident(ds_t), range(2 * inflight)))
+            ca.prof.enable(True); ca.prof.reset()
+            for _ in range(3):
+                db_t.msm_resident(ds_t)
+            stages_seq = ca.prof.read(); ca.prof.reset()
+            list(pool.map(lambda _: db_t.msm_resident(ds_t), range(args.steps)))
+            stages = ca.prof.read(); ca.prof.enable(False)
+            db_t.free(); ds_t.free()
 
     if rank == 0:
         ms_step = dt / args.steps * 1e3
@@ -340,7 +342,7 @@ def main():
             out["library"] = "libdock_gpu_dev.so (development twin: --reduce-shift / --reduce-lanes set a knob the product does not have)"
         if STUB:
             out["data"] = "STUB (tests/bench_stub.py: control-flow test on CPU ranks, not a measurement)"
-        if not args.no_cpu_baseline and not STUB:
+        if not args.no_cpu_baseline and not STUB and world == 1:        # (the contract: on rank 0 at N = 1 only)
             out["cpu_baseline"] = cpu_baseline(ca, gen1, ks, scalars, db, ds, args.log2n, ncpu)
         if world == 1 and not args.no_secondary and not STUB:
             try:

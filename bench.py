@@ -81,6 +81,55 @@ def dot_mod_r(a, b):
     return tot % R_MOD
 
 
+class InFlight:
+    """`count` calls of fn() by `threads` host threads, each taking the next call from a shared counter.  The threads are created and parked at a start
+    line BEFORE the clock starts, and the caller's thread blocks while they run: no thread of this process wakes another through the interpreter inside a
+    timed region.  (A ThreadPoolExecutor does: every submit() wakes a parked worker that then waits out CPython's 5-ms switch interval for the GIL the
+    submitting thread still holds — six workers cost the first 30 - 35 ms of a 50-ms timed region, or nothing, depending on who wins a race: the
+    default bench line read 180 - 240 or 420 - 445 MSM/s for the same library and the same kernels, tools/dev/r05_host_timeline.py.)"""
+
+    def __init__(self, fn, count, threads):
+        import itertools
+        import threading
+        self.fn, self.count, self.err = fn, count, None
+        self.results = [None] * count
+        self._next = itertools.count()                      # (next() on it is atomic under the GIL)
+        self._start, self._done = threading.Barrier(threads + 1), threading.Barrier(threads + 1)
+        self._threads = [threading.Thread(target=self._run, daemon=True) for _ in range(threads)]
+        for t in self._threads:
+            t.start()
+
+    def _run(self):
+        self._start.wait()
+        try:
+            while True:
+                i = next(self._next)
+                if i >= self.count:
+                    break
+                self.results[i] = self.fn()
+        except BaseException as e:          # noqa: BLE001
+            self.err = e
+        self._done.wait()
+
+    def go(self):
+        """release the threads, wait for the last call, return the results in call order"""
+        self._start.wait()
+        self._done.wait()
+        for t in self._threads:
+            t.join()
+        if self.err is not None:
+            raise self.err
+        return self.results
+
+
+def run_inflight(fn, count, threads):
+    """(seconds, results) of `count` calls with `threads` in flight; thread start-up is outside the clock"""
+    w = InFlight(fn, count, threads)
+    t0 = time.perf_counter()
+    r = w.go()
+    return time.perf_counter() - t0, r
+
+
 def single_gpu_2p24(ca, FB, gen1, pool):
     """BASELINE config 5's 2^24 terms on ONE GPU (table built once per key, resident scalars, four calls in flight): the 1-GPU rate the N > 1 lines
     are a multiple of.  Returns a dictionary; msm_2p20_equivalents_per_s is in the unit of the line's `value`."""
@@ -93,8 +142,8 @@ def single_gpu_2p24(ca, FB, gen1, pool):
     d24 = ca.DeviceScalars(s24)
     ok = bool((b24.msm_resident(d24)[:12] == exp_xy).all())
     lat = timed(lambda: b24.msm_resident(d24), 3, warm=8)        # (warm-up calls: every slot's workspace grows on its first call of this size)
-    list(pool.map(lambda _: b24.msm_resident(d24), range(4)))
-    t0 = time.perf_counter(); list(pool.map(lambda _: b24.msm_resident(d24), range(4))); thr = (time.perf_counter() - t0) / 4 * 1e3
+    run_inflight(lambda: b24.msm_resident(d24), 4, 4)
+    thr = run_inflight(lambda: b24.msm_resident(d24), 8, 4)[0] / 8 * 1e3
     b24.free(); d24.free()
     return {"latency_ms": round(lat, 2), "ms_per_msm_4_in_flight": round(thr, 2), "msm_2p20_equivalents_per_s": round(16e3 / thr, 2),
             "table_build_ms": round(tab24, 1), "bit_exact_vs_closed_form": ok}
@@ -124,6 +173,7 @@ def main():
     ap.add_argument("--reduce-lanes", type=int, default=-1, help="development: dgpu_set_reduce_lanes (0 = bit marginals, the default; 1 / 4 = the scan form of rounds 1-4)")
     args = ap.parse_args()
 
+    sys.setswitchinterval(1e-4)            # (a host thread that returns from the library gets the interpreter within 0.1 ms instead of CPython's default 5)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -219,11 +269,9 @@ def main():
     pool = ThreadPoolExecutor(max_workers=inflight)
 
     def run_steps(k):
-        """k steps with up to `inflight` local MSMs in flight; partial points are gathered/folded in step order"""
-        futs = [pool.submit(db.msm_resident, ds) for _ in range(k)]
+        """k steps with up to `inflight` local MSMs in flight (untimed use: warm-up); partial points are gathered/folded in step order"""
         last = None
-        for f in futs:
-            part = f.result()
+        for part in InFlight(lambda: db.msm_resident(ds), k, inflight).go():
             last = sharded.gather_and_fold(ca.G1, part, cdev) if world > 1 else part
         return last
 
@@ -235,12 +283,15 @@ def main():
     for _ in range(3):
         step()
     latency_ms = (time.perf_counter() - tl) / 3 * 1e3
+    timed_calls = InFlight(lambda: db.msm_resident(ds), args.steps, inflight)       # the host threads wait at their start line: nothing is created inside the clock
     if world > 1:
         dist.barrier()
     sync()
     allocs0 = ca.device_alloc_count()
     t0 = time.perf_counter()
-    last = run_steps(args.steps)
+    last = None
+    for part in timed_calls.go():                                                    # EXACTLY args.steps steps; the partial points are gathered / folded in step order
+        last = sharded.gather_and_fold(ca.G1, part, cdev) if world > 1 else part
     sync()
     if world > 1:
         dist.barrier()
@@ -270,12 +321,12 @@ def main():
                 db_t.precompute()
             ds_t = ca.DeviceScalars(scalars)
             assert (db_t.msm_resident(ds_t)[:18] == local_res[:18]).all(), "twin != product"
-            list(pool.map(lambda _: db_t.msm_resident(ds_t), range(2 * inflight)))
+            run_inflight(lambda: db_t.msm_resident(ds_t), 2 * inflight, inflight)
             ca.prof.enable(True); ca.prof.reset()
             for _ in range(3):
                 db_t.msm_resident(ds_t)
             stages_seq = ca.prof.read(); ca.prof.reset()
-            list(pool.map(lambda _: db_t.msm_resident(ds_t), range(args.steps)))
+            run_inflight(lambda: db_t.msm_resident(ds_t), args.steps, inflight)
             stages = ca.prof.read(); ca.prof.enable(False)
             db_t.free(); ds_t.free()
 
@@ -439,33 +490,22 @@ def secondary_configs(log2n, ks, scalars, db, ds, pool, cpu_legs=True, ncpu=1):
     n = 1 << log2n
     res = {}
 
-    from concurrent.futures import ThreadPoolExecutor as _TP4
-    pool4 = _TP4(4)
-
     def thr4(fn, k=16):
-        """ms per call with four calls in flight (four host threads); warmed concurrently on the same threads"""
-        list(pool4.map(lambda _: fn(), range(8)))
-        best = 1e9
-        for _ in range(2):                       # (best of two passes: a box with busy host cores stretches a pass now and then)
-            t0 = time.perf_counter()
-            list(pool4.map(lambda _: fn(), range(k)))
-            best = min(best, (time.perf_counter() - t0) / k * 1e3)
-        return best
+        """ms per call with four calls in flight (four host threads, parked before the clock: InFlight); warmed concurrently first"""
+        run_inflight(fn, 8, 4)
+        return min(run_inflight(fn, k, 4)[0] / k * 1e3 for _ in range(2))      # (best of two passes: a box with busy host cores stretches a pass now and then)
 
     with FB.WindowTable(ca.G1, gen1[0]) as t1:
         plain = t1.multiply_many_to_bases(ks)
         host_bases, _ = t1.multiply_many(ks)
     # -- the plain resident pipeline (no table): what a handle costs before dgpu_bases_precompute_g1
     a0 = ca.device_alloc_count()
+    nthr = pool._max_workers                        # the headline run's calls in flight
+
     def thr_pool(fn, k=24):
-        """ms per call with as many calls in flight as the headline run uses (the same host threads)"""
-        list(pool.map(lambda _: fn(), range(12)))
-        best = 1e9
-        for _ in range(2):
-            t0 = time.perf_counter()
-            list(pool.map(lambda _: fn(), range(k)))
-            best = min(best, (time.perf_counter() - t0) / k * 1e3)
-        return best
+        """ms per call with as many calls in flight as the headline run uses"""
+        run_inflight(fn, 12, nthr)
+        return min(run_inflight(fn, k, nthr)[0] / k * 1e3 for _ in range(2))
     res["plain_resident"] = {"latency_ms": round(timed(lambda: plain.msm_resident(ds), 5, warm=3), 3), "ms_per_msm_4_in_flight": round(thr4(lambda: plain.msm_resident(ds), 24), 3),
                              "ms_per_msm_in_flight_like_headline": round(thr_pool(lambda: plain.msm_resident(ds)), 3)}
     res["plain_resident"]["msm_per_s"] = round(1e3 / res["plain_resident"]["ms_per_msm_in_flight_like_headline"], 2)
@@ -513,8 +553,7 @@ def secondary_configs(log2n, ks, scalars, db, ds, pool, cpu_legs=True, ncpu=1):
         b21.precompute(); d21 = ca.DeviceScalars(s21)
         ok21 = bool((b21.msm_resident(d21)[:12] == exp21).all())
         lat21 = timed(lambda: b21.msm_resident(d21), 5, warm=2)
-        list(pool.map(lambda _: b21.msm_resident(d21), range(12)))
-        t0 = time.perf_counter(); list(pool.map(lambda _: b21.msm_resident(d21), range(24))); thr21 = (time.perf_counter() - t0) / 24 * 1e3
+        thr21 = thr_pool(lambda: b21.msm_resident(d21), 24)
         res["g1_2p21_per_gpu_share"] = {"latency_ms": round(lat21, 3), "ms_per_msm_in_flight_like_headline": round(thr21, 3), "bit_exact_vs_closed_form": ok21}
         if "g1_2p24_single_gpu" in res and "ms_per_msm_4_in_flight" in res["g1_2p24_single_gpu"]:
             res["g1_2p21_per_gpu_share"]["projected_speedup_8_gpus"] = round(res["g1_2p24_single_gpu"]["ms_per_msm_4_in_flight"] / thr21, 2)
@@ -591,10 +630,8 @@ def secondary_configs(log2n, ks, scalars, db, ds, pool, cpu_legs=True, ncpu=1):
     res["miller_loop_1024_pairs_ms"] = round(timed(lambda: ca.multi_miller_loop(P, Q), 20, warm=3), 3)      # (millisecond calls: 20 of them after 3 warm-ups)
     res["miller_loop_pairs_per_s"] = round(1024 / res["miller_loop_1024_pairs_ms"] * 1e3, 0)
     # the same 1024-pair loop from six host threads (one call is a chain of 68 dependent steps on 64 waves: the chip has room for several)
-    from concurrent.futures import ThreadPoolExecutor as _TPE
-    with _TPE(6) as ex:
-        list(ex.map(lambda _: ca.multi_miller_loop(P, Q), range(12)))
-        t0 = time.perf_counter(); fs = list(ex.map(lambda _: ca.multi_miller_loop(P, Q), range(60))); dt = (time.perf_counter() - t0) / 60 * 1e3
+    run_inflight(lambda: ca.multi_miller_loop(P, Q), 12, 6)
+    dt, fs = run_inflight(lambda: ca.multi_miller_loop(P, Q), 60, 6); dt = dt / 60 * 1e3
     assert all((g == f).all() for g in fs)
     res["miller_loop_1024_pairs_ms_per_call_6_in_flight"] = round(dt, 3)
     res["miller_loop_pairs_per_s_6_in_flight"] = round(1024 / dt * 1e3, 0)
@@ -662,6 +699,10 @@ def secondary_configs(log2n, ks, scalars, db, ds, pool, cpu_legs=True, ncpu=1):
     res["verify_1024_proofs_pairing_checker_ms"] = round(timed(lambda: LGv.verify_proofs_batch(pvkv, proofs_v, pubs_v, 0x5EED0028), 3), 2)
     res["verify_1024_proofs_merged_ms"] = round(timed(lambda: LGv.verify_proofs_batch_merged(pvkv, proofs_v, pubs_v, 0x5EED0029), 3), 2)
     res["verify_proofs_per_s_merged"] = round(nv / res["verify_1024_proofs_merged_ms"] * 1e3, 0)
+    # the same merged check as ONE call of the C ABI (dgpu_legogroth16_verify_batch: scalings, both MSMs and the GT power side by side inside the library)
+    assert LGv.verify_proofs_batch_abi(pvkv, proofs_v, pubs_v, 0x5EED0029) and not LGv.verify_proofs_batch_abi(pvkv, swapped, pubs_v, 0x5EED0027)
+    res["verify_1024_proofs_one_call_ms"] = round(timed(lambda: LGv.verify_proofs_batch_abi(pvkv, proofs_v, pubs_v, 0x5EED0029), 5, warm=2), 3)
+    res["verify_proofs_per_s_one_call"] = round(nv / res["verify_1024_proofs_one_call_ms"] * 1e3, 0)
     if cpu_legs:
         # ---- the f-rows on the host's cores: the same algorithms with the oracle's pieces, threaded where the reference's rayon is ----
         thr = max(1, min(ncpu, 64))
@@ -714,7 +755,8 @@ def secondary_configs(log2n, ks, scalars, db, ds, pool, cpu_legs=True, ncpu=1):
         a_g, _ = g1_scale_each(A_, m_l, None)
         cs_g = ca.msm_bigint(ca.G1, C_, m_l); ds_g = ca.msm_bigint(ca.G1, d_pts, c_sc)
         fm_g = pairing.multi_miller_loop(np.concatenate([a_g, cs_g[:12].reshape(1, 12), ds_g[:12].reshape(1, 12)]), [B_, pvkv["delta_g2_neg_pc"], pvkv["gamma_g2_neg_pc"]])
-        cpu["verify_1024_merged"] = {"cpu_ms": round(ms_mrg, 1), "gpu_ms": res["verify_1024_proofs_merged_ms"], "x": round(ms_mrg / res["verify_1024_proofs_merged_ms"], 1), "cores": thr, "accepts": ok_m,
+        cpu["verify_1024_merged"] = {"cpu_ms": round(ms_mrg, 1), "gpu_ms": res["verify_1024_proofs_merged_ms"], "x": round(ms_mrg / res["verify_1024_proofs_merged_ms"], 1),
+                                     "gpu_one_call_ms": res["verify_1024_proofs_one_call_ms"], "x_one_call": round(ms_mrg / res["verify_1024_proofs_one_call_ms"], 1), "cores": thr, "accepts": ok_m,
                                      "bit_exact_vs_gpu": bool((a_c == a_g).all() and (cs_c == cs_g[:12]).all() and (ds_c == ds_g[:12]).all() and (fm_c == fm_g).all()),
                                      "sample": "the classical Groth16 batch verifier: 1024 scalings (%d threads), two 1024-term G1 MSMs (one thread per window), ONE 1026-pair Miller loop, one final exponentiation; "
                                                "scaled points, both MSM results and the raw Fp12 Miller output compared with the library's limb for limb" % thr}
@@ -848,10 +890,8 @@ def secondary_configs(log2n, ks, scalars, db, ds, pool, cpu_legs=True, ncpu=1):
     res["prove_2p20_ms"] = round(ms, 2)
     res["prove_constraints_per_s"] = round((m + 1) / (ms * 1e-3), 1)
     # a proving service's rate: four proofs in flight from host threads (the library queues calls beyond its six slots); every proof equal to p0
-    from concurrent.futures import ThreadPoolExecutor
-    with ThreadPoolExecutor(4) as ex:
-        list(ex.map(lambda _: prove(), range(8)))
-        t0 = time.perf_counter(); many = list(ex.map(lambda _: prove(), range(16))); ms4 = (time.perf_counter() - t0) / 16 * 1e3
+    run_inflight(prove, 8, 4)
+    ms4, many = run_inflight(prove, 16, 4); ms4 = ms4 / 16 * 1e3
     assert all((q[k] == p0[k]).all() for q in many for k in p0)
     res["prove_2p20_ms_per_proof_4_in_flight"] = round(ms4, 2)
     res["prove_constraints_per_s_4_in_flight"] = round((m + 1) / (ms4 * 1e-3), 1)

@@ -652,3 +652,61 @@ extern "C" int32_t dgpu_snarkpack_verify(const dgpu_snarkpack_verifier_srs *srs,
         return DGPU_OK;
     });
 }
+
+// ---- many LegoGroth16 proofs of one circuit in ONE call: the classical Groth16 batch check ------------------------------------------------
+// The reference batches through RandomizedPairingChecker (utils/src/randomized_pairing_check.rs:116-138,204-214; proof_system/src/verifier.rs hands
+// every statement's three pairs to one lazy checker): 3 N pairs, N GT powers.  All proofs of ONE verifying key share -delta and -gamma, so the pairs can
+// be merged BEFORE the pairing: with m_i = random^i
+//     prod_i e(m_i A_i, B_i) * e(sum_i m_i C_i, -delta) * e(sum_i m_i (gamma_abc_0 + sum_j x_ij gamma_abc_j + d_i), -gamma) == e(alpha, beta)^(sum_i m_i)
+// i.e. N scalings, two variable-base MSMs (N and N + k + 1 terms: this library's hot path), ONE Miller loop over N + 2 pairs — two of them on the
+// prepared key — one final exponentiation and one GT power.  Accepts exactly the batches whose every proof dgpu_legogroth16_verify accepts, up to the
+// 2^-255 soundness error of the random combination (the checker's own).  The three device pieces and the GT power run side by side from host threads.
+extern "C" int32_t dgpu_legogroth16_verify_batch(const uint64_t alpha_beta_gt[72], const uint64_t *delta_neg_pc, const uint64_t *gamma_neg_pc, const uint64_t *gamma_abc_g1, size_t gamma_abc_len,
+                                                 const uint64_t *proofs_a, const uint64_t *proofs_b, const uint64_t *proofs_c, const uint64_t *proofs_d, size_t n,
+                                                 const uint64_t *public_inputs, size_t n_pub, int32_t montgomery, const uint64_t random[4], int32_t *ok) {
+    return guarded([&]() -> int32_t {
+        if (ok) *ok = 0;
+        if (!ok || !alpha_beta_gt || !delta_neg_pc || !gamma_neg_pc || !gamma_abc_g1 || !random) return DGPU_E_BADARG;
+        if (n && (!proofs_a || !proofs_b || !proofs_c || !proofs_d)) return DGPU_E_BADARG;
+        if (n_pub + 1 > gamma_abc_len || (n && n_pub && !public_inputs)) return DGPU_E_BADARG;              // MalformedVerifyingKey (verifier.rs:101-109)
+        if (n == 0) { *ok = 1; return DGPU_OK; }
+        const Fr rnd = Fr::from_canon(random);
+        if (rnd.is_zero()) return DGPU_E_BADARG;                                                             // (every proof after the first would drop out of the check)
+        const Frs m = powers(rnd, n);
+        Fr m_sum = Fr::zero(); for (auto &x : m) m_sum = m_sum + x;
+        const Vec m_words = canon_words(m);
+        // scalars of the d-side MSM: [sum m_i] for gamma_abc_0, [sum_i m_i x_ij] for gamma_abc_j, m_i for d_i
+        Frs d_sc(1 + n_pub + n);
+        d_sc[0] = m_sum;
+        for (size_t j = 0; j < n_pub; j++) {
+            Fr sj = Fr::zero();
+            for (size_t i = 0; i < n; i++) {
+                const W *w = public_inputs + 4 * (i * n_pub + j);
+                Fr x; if (montgomery) memcpy(x.v.l, w, 32); else x = Fr::from_canon(w);
+                sj = sj + m[i] * x;
+            }
+            d_sc[1 + j] = sj;
+        }
+        for (size_t i = 0; i < n; i++) d_sc[1 + n_pub + i] = m[i];
+        Vec d_pts(gamma_abc_g1, gamma_abc_g1 + 12 * (1 + n_pub));
+        d_pts.insert(d_pts.end(), proofs_d, proofs_d + 12 * n);
+        Vec a_m(12 * n), c_sum, d_sum; std::vector<uint8_t> a_inf(n);
+        Gt rhs;
+        par({
+            [&] { ck(dgpu_g1_scale_batch(proofs_a, nullptr, m_words.data(), 4, nullptr, n, a_m.data(), a_inf.data())); },
+            [&] { c_sum = msm(false, proofs_c, n, m); },
+            [&] { d_sum = msm(false, d_pts.data(), d_sc.size(), d_sc); },
+            [&] { W e[4]; m_sum.canon(e); ck(dgpu_fp12_pow(alpha_beta_gt, e, rhs.data())); },
+        });
+        std::vector<uint8_t> skip_aff(n), skip_prep(2);
+        for (size_t i = 0; i < n; i++) skip_aff[i] = a_inf[i] || is_id(proofs_b + 24 * i, 24);
+        Vec p_prep(c_sum); p_prep.insert(p_prep.end(), d_sum.begin(), d_sum.end());
+        skip_prep[0] = is_id(c_sum.data(), 12); skip_prep[1] = is_id(d_sum.data(), 12);
+        Vec co(delta_neg_pc, delta_neg_pc + DGPU_G2_PREPARED_WORDS); co.insert(co.end(), gamma_neg_pc, gamma_neg_pc + DGPU_G2_PREPARED_WORDS);
+        Gt f, gt;
+        ck(dgpu_multi_miller_loop_mixed(a_m.data(), proofs_b, skip_aff.data(), n, p_prep.data(), co.data(), skip_prep.data(), 2, f.data()));
+        ck(dgpu_final_exponentiation(f.data(), gt.data()));                                                   // DGPU_E_ZERO: UnexpectedIdentity
+        *ok = gt == rhs ? 1 : 0;
+        return DGPU_OK;
+    });
+}

@@ -323,15 +323,22 @@ int32_t msm_device_ranges(Slot &sl, const uint32_t *d_bases, const uint32_t *d_s
     HIPCHK(hipGetLastError());
     std::vector<uint64_t> hwin((size_t)W * 2 * C::ABI_W);
     std::vector<uint8_t> hinf(W);
-    uint32_t hbad = 0;
-    HIPCHK(hipMemcpyAsync(hwin.data(), sl.win.p, (size_t)W * 4 * C::ABI_W * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(hinf.data(), sl.win_inf.p, W, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(&hbad, sl.flags.p, 4, hipMemcpyDeviceToHost, s));
+    // The results come back into the slot's PINNED scratch: a copy to pageable memory is synchronous inside hipMemcpyAsync (the runtime waits for the
+    // stream, then stages the bytes under a lock of its own) — with several calls in flight their host threads queued up there, and the default bench line
+    // fell to half its rate on loaded hosts (round 5: 420 -> 190 - 240 MSM/s with kernels of unchanged length).  Pinned: three asynchronous copies, one wait.
+    const size_t wb = (size_t)W * 4 * C::ABI_W * 4, ib = ((size_t)W + 7) & ~(size_t)7;
+    static_assert((size_t)64 * 4 * 24 * 4 + 64 + 16 <= Slot::HPIN_BYTES, "pinned scratch");
+    uint8_t *const hp = (uint8_t *)sl.hpin;
+    HIPCHK(hipMemcpyAsync(hp, sl.win.p, wb, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(hp + wb, sl.win_inf.p, W, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(hp + wb + ib, sl.flags.p, 4, hipMemcpyDeviceToHost, s));
     auto tsync0 = std::chrono::steady_clock::now();
     HIPCHK(hipStreamSynchronize(s));
     auto tsync1 = std::chrono::steady_clock::now();
     if (gs.prof) prof_flush(sl);
+    uint32_t hbad; memcpy(&hbad, hp + wb + ib, 4);
     if (hbad) return DGPU_E_BADARG;                  // a scalar >= 2^255 (sort_kernels.hip.h k_digit_codes)
+    memcpy(hwin.data(), hp, wb); memcpy(hinf.data(), hp + wb, W);
     host_fold<HF>(hwin.data(), hinf.data(), W, c, out_xyz);
     if (gs.prof) {
         auto t2 = std::chrono::steady_clock::now();
@@ -575,15 +582,21 @@ int32_t pre_finish(Slot &sl, const PreGeom &g, bool check_flag, uint64_t *out_xy
     const size_t npts = marginals ? (size_t)nm + 1 : (size_t)2 * PW;
     std::vector<uint64_t> hwin(npts * 2 * C::ABI_W);
     std::vector<uint8_t> hinf(npts);
-    uint32_t hbad = 0;
-    HIPCHK(hipMemcpyAsync(hwin.data(), sl.win.p, npts * 4 * C::ABI_W * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(hinf.data(), sl.win_inf.p, npts, hipMemcpyDeviceToHost, s));
-    if (check_flag) HIPCHK(hipMemcpyAsync(&hbad, sl.flags.p, 4, hipMemcpyDeviceToHost, s));      // (a shared sort was checked by dgpu_scalars_sort)
+    // (into the slot's pinned scratch: see the plain pipeline's read-back above)
+    const size_t wb = npts * 4 * C::ABI_W * 4, ib = (npts + 7) & ~(size_t)7;
+    if (wb + ib + 4 > Slot::HPIN_BYTES) return DGPU_E_BADARG;
+    uint8_t *const hp = (uint8_t *)sl.hpin;
+    memset(hp + wb + ib, 0, 4);
+    HIPCHK(hipMemcpyAsync(hp, sl.win.p, wb, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(hp + wb, sl.win_inf.p, npts, hipMemcpyDeviceToHost, s));
+    if (check_flag) HIPCHK(hipMemcpyAsync(hp + wb + ib, sl.flags.p, 4, hipMemcpyDeviceToHost, s));      // (a shared sort was checked by dgpu_scalars_sort)
     auto tsync0 = std::chrono::steady_clock::now();
     HIPCHK(hipStreamSynchronize(s));
     auto tsync1 = std::chrono::steady_clock::now();
     if (gs.prof) prof_flush(sl);
+    uint32_t hbad; memcpy(&hbad, hp + wb + ib, 4);
     if (hbad) return DGPU_E_BADARG;                  // a scalar >= 2^255 (sort_kernels.hip.h k_digit_codes)
+    memcpy(hwin.data(), hp, wb); memcpy(hinf.data(), hp + wb, npts);
     if (marginals) host_fold_marginals<HF>(hwin.data(), hinf.data(), nm, g.mshift + (C::NFP == 2 ? 1 : 0), out_xyz);
     else host_fold_shared<HF>(hwin.data(), hinf.data(), hwin.data() + (size_t)PW * 2 * C::ABI_W, hinf.data() + PW, PW, g.lb, out_xyz);
     if (gs.prof) {

@@ -371,6 +371,15 @@ int32_t dgpu_legogroth16_prove(const dgpu_lego_pk *pk, uint64_t r1cs, uint64_t h
 int32_t dgpu_legogroth16_verify(const uint64_t alpha_beta_gt[72], const uint64_t *delta_neg_pc, const uint64_t *gamma_neg_pc, const uint64_t *gamma_abc_g1, size_t gamma_abc_len,
                                 const uint64_t proof_a[12], const uint64_t proof_b[24], const uint64_t proof_c[12], const uint64_t proof_d[12], const uint8_t *proof_inf,
                                 const uint64_t *public_inputs, size_t n_pub, int32_t montgomery, int32_t *ok);
+/* n proofs of ONE verifying key in one call — the classical Groth16 batch check: what the reference reaches through RandomizedPairingChecker
+ * (utils/src/randomized_pairing_check.rs:116-138,204-214: three pairs and one GT power per proof, proof_system/src/verifier.rs hands every statement to one lazy
+ * checker) with the pairs that share -delta / -gamma merged BEFORE the pairing: n scalings by the powers of `random`, two variable-base MSMs, ONE Miller
+ * loop over n + 2 pairs, one final exponentiation, one GT power (crypto_amd/csrc/dock_aggregation.cpp).  proofs_a / _c / _d: n x 12 words, proofs_b: n x 24
+ * (all-zero words: identity); public_inputs: n rows of n_pub scalars; random: the batching scalar (drawn AFTER the proofs are fixed; non-zero mod r, else
+ * DGPU_E_BADARG).  *ok = 1 iff every proof verifies (up to the 2^-255 soundness error of the random combination).  n = 0: *ok = 1. */
+int32_t dgpu_legogroth16_verify_batch(const uint64_t alpha_beta_gt[72], const uint64_t *delta_neg_pc, const uint64_t *gamma_neg_pc, const uint64_t *gamma_abc_g1, size_t gamma_abc_len,
+                                      const uint64_t *proofs_a, const uint64_t *proofs_b, const uint64_t *proofs_c, const uint64_t *proofs_d, size_t n,
+                                      const uint64_t *public_inputs, size_t n_pub, int32_t montgomery, const uint64_t random[4], int32_t *ok);
 /* ---- SnarkPack aggregation of Groth16 / LegoGroth16 proofs (crypto_amd/csrc/dock_aggregation.cpp) ----
  * replaces aggregate_proofs (legogroth16/src/aggregation/groth16/prover.rs:47-147; legogroth16/prover.rs:38-127 when `d` is given) and
  * verify_aggregate_proof (groth16/verifier.rs:36-100, legogroth16/verifier.rs:34-96, legogroth16/using_groth16.rs:45-128) as the reference

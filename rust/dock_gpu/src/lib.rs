@@ -112,6 +112,9 @@ extern "C" {
     pub fn dgpu_legogroth16_verify(alpha_beta_gt: *const u64, delta_neg_pc: *const u64, gamma_neg_pc: *const u64, gamma_abc_g1: *const u64, gamma_abc_len: usize,
                                    proof_a: *const u64, proof_b: *const u64, proof_c: *const u64, proof_d: *const u64, proof_inf: *const u8,
                                    public_inputs: *const u64, n_pub: usize, montgomery: i32, ok: *mut i32) -> i32;
+    pub fn dgpu_legogroth16_verify_batch(alpha_beta_gt: *const u64, delta_neg_pc: *const u64, gamma_neg_pc: *const u64, gamma_abc_g1: *const u64, gamma_abc_len: usize,
+                                         proofs_a: *const u64, proofs_b: *const u64, proofs_c: *const u64, proofs_d: *const u64, n: usize,
+                                         public_inputs: *const u64, n_pub: usize, montgomery: i32, random: *const u64, ok: *mut i32) -> i32;
     pub fn dgpu_snarkpack_proof_words(n: usize, with_d: i32) -> usize;
     pub fn dgpu_snarkpack_aggregate(srs: *const DgpuSnarkpackProverSrs, a: *const u64, b: *const u64, c: *const u64, d: *const u64, n: usize,
                                     transcript: *const DgpuTranscript, proof: *mut u64, cap_words: usize, len_words: *mut usize) -> i32;
@@ -380,6 +383,28 @@ pub fn verify_proof_gpu(pvk: &GpuPreparedVerifyingKey, a: &G1Affine, b: &G2Affin
     let rc = unsafe { dgpu_legogroth16_verify(pvk.alpha_beta.as_ptr(), pvk.delta_neg.as_ptr(), pvk.gamma_neg.as_ptr(), pvk.gamma_abc.as_ptr(), pvk.gamma_abc_len,
                                               pa.as_ptr(), pb.as_ptr(), pa[12..].as_ptr(), pa[24..].as_ptr(), inf.as_ptr(),
                                               public_inputs.as_ptr() as *const u64, public_inputs.len(), 1, &mut ok) };
+    if rc != DGPU_OK { return None; }
+    Some(ok == 1)
+}
+
+/// Many proofs of ONE verifying key in one call: the classical Groth16 batch check (what the reference reaches through
+/// `RandomizedPairingChecker::add_multiple_sources_and_target` per proof + one lazy `verify()`, utils/src/randomized_pairing_check.rs:116-138,204-214,
+/// with the pairs that share -delta / -gamma merged before the pairing).  `proofs[i] = (a, b, c, d)`, `public_inputs[i]` the i-th proof's inputs,
+/// `random` drawn AFTER the proofs are fixed and non-zero.  Some(all valid) or None when the library declined (then: verify one by one / the checker).
+pub fn verify_proofs_batch_gpu(pvk: &GpuPreparedVerifyingKey, proofs: &[(G1Affine, G2Affine, G1Affine, G1Affine)], public_inputs: &[Vec<Fr>], random: Fr) -> Option<bool> {
+    let n = proofs.len();
+    if public_inputs.len() != n { return None; }
+    let k = public_inputs.first().map_or(0, |r| r.len());
+    if public_inputs.iter().any(|r| r.len() != k) { return Some(false); }
+    let a = pack_g1(&proofs.iter().map(|p| p.0).collect::<Vec<_>>()).0;
+    let b = pack_g2(&proofs.iter().map(|p| p.1).collect::<Vec<_>>()).0;
+    let c = pack_g1(&proofs.iter().map(|p| p.2).collect::<Vec<_>>()).0;
+    let d = pack_g1(&proofs.iter().map(|p| p.3).collect::<Vec<_>>()).0;
+    let pubs: Vec<u64> = public_inputs.iter().flat_map(|r| r.iter().flat_map(|x| x.into_bigint().0)).collect();
+    let rnd = random.into_bigint();
+    let mut ok = -1i32;
+    let rc = unsafe { dgpu_legogroth16_verify_batch(pvk.alpha_beta.as_ptr(), pvk.delta_neg.as_ptr(), pvk.gamma_neg.as_ptr(), pvk.gamma_abc.as_ptr(), pvk.gamma_abc_len,
+                                                    a.as_ptr(), b.as_ptr(), c.as_ptr(), d.as_ptr(), n, if k == 0 { core::ptr::null() } else { pubs.as_ptr() }, k, 0, rnd.0.as_ptr(), &mut ok) };
     if rc != DGPU_OK { return None; }
     Some(ok == 1)
 }

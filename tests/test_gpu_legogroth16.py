@@ -196,3 +196,49 @@ def test_cp_link_prove_and_verify():
         LG.verify_link_proof(pp, lvk, bad)
     with pytest.raises(LK.LinkError):
         LK.prove(pp, ek, [1, 2, 3, 4, 5])                       # more witnesses than columns
+
+
+@pytest.mark.parametrize("n", [1, 2, 9, 300])
+def test_batch_of_proofs_in_one_call(n):
+    """dgpu_legogroth16_verify_batch: N proofs of one key through the merged batch check inside the library — accepts exactly when every proof verifies
+    (against the one-proof call and the Python statement of the same check), whatever the batching scalar; one bad proof, one wrong public input, a
+    swapped member, an identity member and a zero batching scalar are all answered as the one-proof path answers them"""
+    import bench as B
+    R = U.R
+    rng = np.random.default_rng(50 + n)
+    ints = lambda k: [int.from_bytes(rng.bytes(40), "little") % (R - 1) + 1 for _ in range(k)]
+    al, be, ga, de, g0, g1x = ints(6)
+    av, bv, dv, xv = ints(n), ints(n), ints(n), ints(n)
+    dinv = pow(de, R - 2, R)
+    cv = [((a * b - al * be - (g0 + x * g1x + d) * ga) * dinv) % R for a, b, d, x in zip(av, bv, dv, xv)]
+    lim = lambda vals: np.array([[(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)] for v in vals], dtype=np.uint64)
+    from crypto_amd import fixed_base as FB
+    with FB.WindowTable(ca.G2, O.G2.generator()) as t2, FB.WindowTable(ca.G1, O.G1.generator()) as t1:
+        A_, _ = t1.multiply_many(lim(av)); C_, _ = t1.multiply_many(lim(cv)); D_, _ = t1.multiply_many(lim(dv)); K_, _ = t1.multiply_many(lim([al, g0, g1x, 1]))
+        B_, _ = t2.multiply_many(lim(bv)); V_, _ = t2.multiply_many(lim([be, ga, de]))
+    vk = LG.VerifyingKey(K_[0], V_[0], V_[1], V_[2], K_[1:3], K_[3], 0)
+    pvk = LG.prepare_verifying_key(vk)
+    proofs = [{"a": A_[i], "b": B_[i], "c": C_[i], "d": D_[i]} for i in range(n)]
+    pubs = [lim([x]) for x in xv]
+    assert all(LG.verify_proof_abi(pvk, proofs[i], pubs[i]) for i in range(min(n, 3)))
+    for rnd in (1, 2, 0x5EED0025, R - 1):
+        assert LG.verify_proofs_batch_abi(pvk, proofs, pubs, rnd)
+    assert LG.verify_proofs_batch_abi(pvk, proofs, [O.fr_to_mont(x) for x in pubs], 77, montgomery=True)
+    assert LG.verify_proofs_batch_merged(pvk, proofs, pubs, 0x5EED0025)
+    j = n // 2
+    bad = list(proofs); bad[j] = dict(bad[j], c=proofs[j]["a"])
+    assert not LG.verify_proofs_batch_abi(pvk, bad, pubs, 0x5EED0026) and not LG.verify_proof_abi(pvk, bad[j], pubs[j])
+    wrong = list(pubs); wrong[j] = lim([(xv[j] + 1) % R])
+    assert not LG.verify_proofs_batch_abi(pvk, proofs, wrong, 0x5EED0027)
+    ident = list(proofs); ident[j] = dict(ident[j], a=np.zeros(12, np.uint64))
+    assert not LG.verify_proofs_batch_abi(pvk, ident, pubs, 0x5EED0028)
+    if n >= 2:
+        sw = list(proofs); sw[0], sw[1] = dict(sw[0], d=proofs[1]["d"]), dict(sw[1], d=proofs[0]["d"])
+        assert not LG.verify_proofs_batch_abi(pvk, sw, pubs, 0x5EED0029)
+    with pytest.raises(ca.DockGpuError):
+        LG.verify_proofs_batch_abi(pvk, proofs, pubs, 0)
+    with pytest.raises(ca.DockGpuError):
+        LG.verify_proofs_batch_abi(pvk, proofs, pubs, R)
+    assert LG.verify_proofs_batch_abi(pvk, [], [], 5)
+    with pytest.raises(ValueError):
+        LG.verify_proofs_batch_abi(pvk, proofs, [lim([x, x, x]) for x in xv], 5)            # more inputs than the key covers: MalformedVerifyingKey

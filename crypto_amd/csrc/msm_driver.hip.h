@@ -584,8 +584,9 @@ int32_t pre_finish(Slot &sl, const PreGeom &g, bool check_flag, uint64_t *out_xy
     std::vector<uint8_t> hinf(npts);
     // (into the slot's pinned scratch: see the plain pipeline's read-back above)
     const size_t wb = npts * 4 * C::ABI_W * 4, ib = (npts + 7) & ~(size_t)7;
-    if (wb + ib + 4 > Slot::HPIN_BYTES) return DGPU_E_BADARG;
-    uint8_t *const hp = (uint8_t *)sl.hpin;
+    std::vector<uint8_t> big;                        // (a forced geometry with hundreds of pseudo-windows — a knob of the twin — does not fit the pinned scratch: pageable then)
+    if (wb + ib + 4 > Slot::HPIN_BYTES) big.resize(wb + ib + 4);
+    uint8_t *const hp = big.empty() ? (uint8_t *)sl.hpin : big.data();
     memset(hp + wb + ib, 0, 4);
     HIPCHK(hipMemcpyAsync(hp, sl.win.p, wb, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(hp + wb, sl.win_inf.p, npts, hipMemcpyDeviceToHost, s));

@@ -618,26 +618,34 @@ def verify_proof_abi(pvk, proof, public_inputs, montgomery=False):
     return ok.value == 1
 
 
-def verify_proofs_batch_abi(pvk, proofs, public_inputs, random, montgomery=False):
-    """N proofs of one verifying key through ONE call of the C ABI (dgpu_legogroth16_verify_batch): the merged batch check of
-    verify_proofs_batch_merged with its scalings, its two MSMs and its GT power side by side inside the library and no interpreter between the
-    pieces.  `random`: the batching scalar (an int, drawn after the proofs are fixed)."""
-    import ctypes as C
-    from ._native import lib, DockGpuError
-    vk = pvk["vk"]
+def pack_proofs(proofs, public_inputs):
+    """the column form dgpu_legogroth16_verify_batch takes: (a: n x 12, b: n x 24, c, d: n x 12, public inputs: n x k x 4) — what a Rust host's
+    `&[Proof]` costs microseconds to produce and a list of Python dictionaries a millisecond per thousand proofs"""
     n = len(proofs)
+    cols = [np.ascontiguousarray(np.stack([pr[key] for pr in proofs]), dtype=np.uint64) if n else np.zeros((0, w), np.uint64) for key, w in (("a", 12), ("b", 24), ("c", 12), ("d", 12))]
     pubs = np.ascontiguousarray(np.stack([np.ascontiguousarray(x, dtype=np.uint64).reshape(-1, 4) for x in public_inputs]) if n else np.zeros((0, 0, 4), np.uint64))
     if len(pubs) != n:
         raise ValueError("public inputs of unequal length")
+    return cols[0], cols[1], cols[2], cols[3], pubs
+
+
+def verify_proofs_batch_abi(pvk, proofs, public_inputs, random, montgomery=False, packed=None):
+    """N proofs of one verifying key through ONE call of the C ABI (dgpu_legogroth16_verify_batch): the merged batch check of
+    verify_proofs_batch_merged with its scalings, its two MSMs and its GT power side by side inside the library and no interpreter between the
+    pieces.  `random`: the batching scalar (an int, drawn after the proofs are fixed).  packed: pack_proofs(proofs, public_inputs) made ahead."""
+    import ctypes as C
+    from ._native import lib, DockGpuError
+    vk = pvk["vk"]
+    a, b, c, d, pubs = packed if packed is not None else pack_proofs(proofs, public_inputs)
+    n = len(a)
     k = pubs.shape[1] if n else 0
     gabc = np.ascontiguousarray(vk.gamma_abc_g1, dtype=np.uint64).reshape(-1, 12)
-    p_ = lambda a: np.ascontiguousarray(a, dtype=np.uint64).ctypes.data_as(C.c_void_p)
-    cols = [np.ascontiguousarray(np.stack([pr[key] for pr in proofs]), dtype=np.uint64) if n else np.zeros((0, w), np.uint64) for key, w in (("a", 12), ("b", 24), ("c", 12), ("d", 12))]
+    p_ = lambda x: np.ascontiguousarray(x, dtype=np.uint64).ctypes.data_as(C.c_void_p)
     dn, gn = np.ascontiguousarray(pvk["delta_g2_neg_pc"].coeffs.reshape(-1)), np.ascontiguousarray(pvk["gamma_g2_neg_pc"].coeffs.reshape(-1))
     ab = np.ascontiguousarray(pvk["alpha_g1_beta_g2"], dtype=np.uint64)
     rnd = _sc(random % R_MOD)
     ok = C.c_int32(-1)
-    rc = lib().dgpu_legogroth16_verify_batch(p_(ab), p_(dn), p_(gn), p_(gabc), len(gabc), p_(cols[0]), p_(cols[1]), p_(cols[2]), p_(cols[3]), n,
+    rc = lib().dgpu_legogroth16_verify_batch(p_(ab), p_(dn), p_(gn), p_(gabc), len(gabc), p_(a), p_(b), p_(c), p_(d), n,
                                              pubs.ctypes.data_as(C.c_void_p), k, int(montgomery), p_(rnd), C.byref(ok))
     if rc == -3 and k + 1 > len(gabc):
         raise ValueError("MalformedVerifyingKey")

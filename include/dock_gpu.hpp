@@ -474,7 +474,7 @@ enum class Variant : int32_t { Groth16 = 0, LegoGroth16 = 1, LegoGroth16UsingGro
 template <class T> Words aggregate_proofs(const ProverSRS &srs, T &transcript, const Words &a, const Words &b, const Words &c, const Words *d = nullptr) {
     const size_t n = a.size() / 12;
     if (b.size() != 24 * n || c.size() != 12 * n || (d && d->size() != 12 * n)) throw Error(DGPU_E_LENGTH, "aggregate_proofs");
-    if (srs.n != n || srs.g_alpha_powers_table.size() != 24 * n || srs.g_beta_powers_table.size() != 24 * n || srs.h_alpha_powers_table.size() != 48 * n || srs.h_beta_powers_table.size() != 48 * n ||
+    if (srs.n != n || srs.g_alpha_powers_table.size() != 24 * n || srs.g_beta_powers_table.size() != 24 * n || srs.h_alpha_powers_table.size() != 24 * n || srs.h_beta_powers_table.size() != 24 * n ||
         srs.vkey_a.size() != 24 * n || srs.vkey_b.size() != 24 * n || srs.wkey_a.size() != 12 * n || srs.wkey_b.size() != 12 * n) throw Error(DGPU_E_LENGTH, "aggregate_proofs: the SRS is not specialised to this many proofs");
     const size_t cap = dgpu_snarkpack_proof_words(n, d ? 1 : 0);
     if (!cap) throw Error(DGPU_E_BADARG, "aggregate_proofs: the number of proofs is not a power of two >= 2");

@@ -432,12 +432,12 @@ fn bind_transcript<T: TranscriptBytes>(t: &mut T) -> DgpuTranscript {
 pub struct GpuProverSrs { n: usize, tabs: [Vec<u64>; 8] }
 impl GpuProverSrs {
     #[allow(clippy::too_many_arguments)]
-    /// None unless the members have the lengths the C side reads: 2 n powers in each of the four tables, n elements in each commitment key
+    /// None unless the members have the lengths the C side reads: 2 n powers in the two G1 tables, n in the two G2 tables, n elements in each commitment key
     /// (`ProverSRS::specialize`, legogroth16/src/aggregation/srs.rs) — the library copies 2 n / n packed points out of these buffers
     pub fn new(n: usize, g_alpha_powers_table: &[G1Affine], g_beta_powers_table: &[G1Affine], h_alpha_powers_table: &[G2Affine], h_beta_powers_table: &[G2Affine],
                vkey_a: &[G2Affine], vkey_b: &[G2Affine], wkey_a: &[G1Affine], wkey_b: &[G1Affine]) -> Option<Self> {
         if n == 0 || !n.is_power_of_two() { return None; }
-        if g_alpha_powers_table.len() != 2 * n || g_beta_powers_table.len() != 2 * n || h_alpha_powers_table.len() != 2 * n || h_beta_powers_table.len() != 2 * n { return None; }
+        if g_alpha_powers_table.len() != 2 * n || g_beta_powers_table.len() != 2 * n || h_alpha_powers_table.len() != n || h_beta_powers_table.len() != n { return None; }
         if vkey_a.len() != n || vkey_b.len() != n || wkey_a.len() != n || wkey_b.len() != n { return None; }
         Some(GpuProverSrs { n, tabs: [pack_g1(g_alpha_powers_table).0, pack_g1(g_beta_powers_table).0, pack_g2(h_alpha_powers_table).0, pack_g2(h_beta_powers_table).0,
                                  pack_g2(vkey_a).0, pack_g2(vkey_b).0, pack_g1(wkey_a).0, pack_g1(wkey_b).0] })

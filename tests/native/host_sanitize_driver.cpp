@@ -122,6 +122,10 @@ int32_t dgpu_multi_pairing_segments(const uint64_t *p, const uint64_t *q, const 
 }
 int32_t dgpu_multi_miller_loop(const uint64_t *p, const uint64_t *q, const uint8_t *, size_t n, uint64_t *out) { volatile uint64_t t = p[12 * n - 1] ^ q[24 * n - 1]; (void)t; hostf::Fq12 f = gt_of(n); memcpy(out, &f, 576); return step("ml"); }
 int32_t dgpu_final_exponentiation(const uint64_t *in, uint64_t *out) { memcpy(out, in, 576); return step("fe"); }
+int32_t dgpu_multi_miller_loop_mixed(const uint64_t *pa, const uint64_t *qa, const uint8_t *sa, size_t na, const uint64_t *pp, const uint64_t *co, const uint8_t *sp, size_t np, uint64_t *out) {
+    volatile uint64_t t = (na ? pa[12 * na - 1] ^ qa[24 * na - 1] ^ sa[na - 1] : 0) ^ (np ? pp[12 * np - 1] ^ co[(size_t)DGPU_G2_PREPARED_WORDS * np - 1] ^ sp[np - 1] : 0); (void)t;      // (reads the last word of every operand: sizes as the caller promised)
+    memset(out, 0, 576); out[0] = 1; return step("mixed");
+}
 int32_t dgpu_g1_scale_batch(const uint64_t *p, const uint8_t *, const uint64_t *, size_t, const uint8_t *, size_t n, uint64_t *out, uint8_t *oi) { memcpy(out, p, n * 96); memset(oi, 0, n); return step("scale"); }
 static std::atomic<int> g_live_fold{0};
 int32_t dgpu_fold_prepare_pair(const uint64_t *p1, size_t n1, uint64_t *h1, const uint64_t *p2, size_t n2, uint64_t *h2) {
@@ -297,6 +301,18 @@ static void test_aggregation() {
                 }
             });
             for (auto &x : th) x.join();
+            // many proofs of one key in one call (dgpu_legogroth16_verify_batch): the four concurrent pieces, operand sizes, error paths
+            {
+                std::vector<uint64_t> pc(2 * (size_t)DGPU_G2_PREPARED_WORDS, 3), gt(72, 9);
+                const uint64_t rnd[4] = {5, 0, 0, 0}, zero[4] = {0, 0, 0, 0}; int32_t okv = -1;
+                for (int rep = 0; rep < 6; rep++) {
+                    const int32_t rc = dgpu_legogroth16_verify_batch(gt.data(), pc.data(), pc.data() + DGPU_G2_PREPARED_WORDS, g1.data(), 2, g1.data(), g2.data(), g1.data() + 12, g1.data() + 24, n, pub.data(), 1, rep & 1, rnd, &okv);
+                    EXPECT(rc == DGPU_OK ? (okv == 0 || okv == 1) : rc == DGPU_E_OOM);
+                }
+                EXPECT(dgpu_legogroth16_verify_batch(gt.data(), pc.data(), pc.data(), g1.data(), 2, g1.data(), g2.data(), g1.data(), g1.data(), n, pub.data(), 1, 0, zero, &okv) == DGPU_E_BADARG);
+                EXPECT(dgpu_legogroth16_verify_batch(gt.data(), pc.data(), pc.data(), g1.data(), 1, g1.data(), g2.data(), g1.data(), g1.data(), n, pub.data(), 1, 0, rnd, &okv) == DGPU_E_BADARG);
+                EXPECT(dgpu_legogroth16_verify_batch(gt.data(), pc.data(), pc.data(), g1.data(), 2, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 1, 0, rnd, &okv) == DGPU_OK && okv == 1);
+            }
             g_fail_every = 0;
             if (!fail_every) EXPECT(ok == 12 && bad == 0); else EXPECT(bad > 0);
             EXPECT(g_live_fold.load() == 0);                                // every fold table of every call was freed, failed or not

@@ -419,6 +419,62 @@ inline Proof create_proof_with_reduction(const ProvingKey &pk, uint64_t r1cs, co
     pr.b.infinity = inf[1]; std::memcpy(&pr.b.x, b, 96); std::memcpy(&pr.b.y, b + 12, 96);
     return pr;
 }
+// ---- the verifier (legogroth16/src/verifier.rs) over dgpu_legogroth16_verify / dgpu_legogroth16_verify_batch ----
+// VerifyingKey (data_structures.rs:55-70) and PreparedVerifyingKey (:112-120): e(alpha, beta) and the two negated, prepared G2 members
+struct VerifyingKey { G1::Affine alpha_g1; G2::Affine beta_g2, gamma_g2, delta_g2; std::vector<G1::Affine> gamma_abc_g1; size_t commit_witness_count = 0; };
+struct PreparedVerifyingKey { VerifyingKey vk; Fq12 alpha_g1_beta_g2{}; std::vector<uint64_t> gamma_g2_neg_pc, delta_g2_neg_pc, gamma_abc_words; };
+namespace detail {
+inline constexpr Fq FQ_MODULUS = {0xb9feffffffffaaabULL, 0x1eabfffeb153ffffULL, 0x6730d2a0f6b0f624ULL, 0x64774b84f38512bfULL, 0x4b1ba7b6434bacd7ULL, 0x1a0111ea397fe69aULL};
+inline Fq fq_neg(const Fq &a) {               // p - a (Montgomery form is closed under it); 0 stays 0
+    Fq z{}; if (a == z) return a;
+    Fq r{}; unsigned __int128 br = 0;
+    for (int i = 0; i < 6; i++) { const unsigned __int128 d = (unsigned __int128)FQ_MODULUS[i] - a[i] - (uint64_t)br; r[i] = (uint64_t)d; br = (d >> 64) & 1; }
+    return r;
+}
+inline G2::Affine g2_neg(G2::Affine q) { if (!q.infinity) { q.y[0] = fq_neg(q.y[0]); q.y[1] = fq_neg(q.y[1]); } return q; }
+inline void g1_words(const G1::Affine &p, uint64_t *o) { if (p.infinity) std::memset(o, 0, 96); else { std::memcpy(o, &p.x, 48); std::memcpy(o + 6, &p.y, 48); } }
+inline void g2_words(const G2::Affine &p, uint64_t *o) { if (p.infinity) std::memset(o, 0, 192); else { std::memcpy(o, &p.x, 96); std::memcpy(o + 12, &p.y, 96); } }
+}  // namespace detail
+// prepare_verifying_key (verifier.rs:18-25): one pairing, two G2 preparations (one dgpu_g2_prepare call for both)
+inline PreparedVerifyingKey prepare_verifying_key(const VerifyingKey &vk) {
+    PreparedVerifyingKey p; p.vk = vk;
+    p.alpha_g1_beta_g2 = multi_pairing({vk.alpha_g1}, {vk.beta_g2});
+    uint64_t q[48]; uint8_t qi[2] = {vk.gamma_g2.infinity, vk.delta_g2.infinity}, oi[2];
+    detail::g2_words(detail::g2_neg(vk.gamma_g2), q); detail::g2_words(detail::g2_neg(vk.delta_g2), q + 24);
+    std::vector<uint64_t> pc(2 * DGPU_G2_PREPARED_WORDS);
+    check(dgpu_g2_prepare(q, qi, 2, pc.data(), oi), "g2_prepare");
+    p.gamma_g2_neg_pc.assign(pc.begin(), pc.begin() + DGPU_G2_PREPARED_WORDS); p.delta_g2_neg_pc.assign(pc.begin() + DGPU_G2_PREPARED_WORDS, pc.end());
+    p.gamma_abc_words.resize(vk.gamma_abc_g1.size() * 12);
+    for (size_t i = 0; i < vk.gamma_abc_g1.size(); i++) detail::g1_words(vk.gamma_abc_g1[i], &p.gamma_abc_words[12 * i]);
+    return p;
+}
+// verify_proof (verifier.rs:87-99): Ok(()) -> true, Err(InvalidProof) -> false; MalformedVerifyingKey / UnexpectedIdentity throw (DGPU_E_BADARG / DGPU_E_ZERO)
+inline bool verify_proof(const PreparedVerifyingKey &pvk, const Proof &proof, const std::vector<BigInt256> &public_inputs) {
+    uint64_t a[12], b[24], c[12], d[12]; const uint8_t inf[4] = {proof.a.infinity, proof.b.infinity, proof.c.infinity, proof.d.infinity};
+    detail::g1_words(proof.a, a); detail::g2_words(proof.b, b); detail::g1_words(proof.c, c); detail::g1_words(proof.d, d);
+    int32_t ok = 0;
+    check(dgpu_legogroth16_verify(pvk.alpha_g1_beta_g2.data(), pvk.delta_g2_neg_pc.data(), pvk.gamma_g2_neg_pc.data(), pvk.gamma_abc_words.data(), pvk.vk.gamma_abc_g1.size(),
+                                  a, b, c, d, inf, public_inputs.empty() ? nullptr : public_inputs[0].data(), public_inputs.size(), 0, &ok), "legogroth16_verify");
+    return ok != 0;
+}
+// n proofs under one key in one call: what a verifier holding many statements reaches through one lazy RandomizedPairingChecker
+// (utils/src/randomized_pairing_check.rs:116-138,204-214), with the pairs that share -delta / -gamma merged before the pairing.  `random`: drawn
+// after the proofs are fixed, non-zero mod r.  Every row of public_inputs has the same length.
+inline bool verify_proofs_batch(const PreparedVerifyingKey &pvk, const std::vector<Proof> &proofs, const std::vector<std::vector<BigInt256>> &public_inputs, const BigInt256 &random) {
+    const size_t n = proofs.size();
+    if (public_inputs.size() != n) throw Error(DGPU_E_LENGTH, "verify_proofs_batch");
+    const size_t np = n ? public_inputs[0].size() : 0;
+    std::vector<uint64_t> a(12 * n), b(24 * n), c(12 * n), d(12 * n), x(4 * n * np);
+    for (size_t i = 0; i < n; i++) {
+        if (public_inputs[i].size() != np) throw Error(DGPU_E_LENGTH, "verify_proofs_batch: rows of public inputs differ in length");
+        detail::g1_words(proofs[i].a, &a[12 * i]); detail::g2_words(proofs[i].b, &b[24 * i]); detail::g1_words(proofs[i].c, &c[12 * i]); detail::g1_words(proofs[i].d, &d[12 * i]);
+        for (size_t j = 0; j < np; j++) std::memcpy(&x[4 * (i * np + j)], public_inputs[i][j].data(), 32);
+    }
+    int32_t ok = 0;
+    check(dgpu_legogroth16_verify_batch(pvk.alpha_g1_beta_g2.data(), pvk.delta_g2_neg_pc.data(), pvk.gamma_g2_neg_pc.data(), pvk.gamma_abc_words.data(), pvk.vk.gamma_abc_g1.size(),
+                                        a.data(), b.data(), c.data(), d.data(), n, x.data(), np, 0, random.data(), &ok), "legogroth16_verify_batch");
+    return ok != 0;
+}
 }  // namespace legogroth16
 
 // ---- SnarkPack aggregation (legogroth16/src/aggregation/) over dgpu_snarkpack_aggregate / dgpu_snarkpack_verify ---------------------------------

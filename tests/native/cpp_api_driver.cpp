@@ -289,6 +289,53 @@ int main() {
           const aggregation::Words pl = aggregation::aggregate_proofs(psrs, t1, A, B, C, &A);
           EXPECT(pl.size() == dgpu_snarkpack_proof_words(na, 1) && pl[1] == 2);
           EXPECT(!aggregation::verify_aggregate_proof(vsrs, vk, pub, 1, pl, rnd, t2, aggregation::Variant::LegoGroth16)); }
+
+        // the LegoGroth16 verifier through the mirror (legogroth16::prepare_verifying_key / verify_proof / verify_proofs_batch, verifier.rs:18-25,
+        // :87-109): twelve statements with known discrete logs and two public inputs each,
+        //     e(A, B) = e(alpha, beta) e(C, delta) e(g0 + x1 g1 + x2 g2 + D, gamma),
+        // accepted one by one and in one call; then the reference's rejections (a wrong input, a swapped commitment, a foreign key)
+        {
+            const size_t nl = 12, np = 2;
+            std::vector<uint64_t> r2((3 + 5 * nl) * 4); orc_rand_scalars(91, 3 + 5 * nl, r2.data());
+            auto T = [&](size_t i) { BigInt256 v; std::memcpy(v.data(), &r2[4 * i], 32); return v; };
+            auto g1a = [&](const BigInt256 &k) { uint64_t w[12]; mul1(k, w); G1::Affine q; q.infinity = false; std::memcpy(&q.x, w, 48); std::memcpy(&q.y, w + 6, 48); return q; };
+            auto g2a = [&](const BigInt256 &k) { uint64_t w[24]; mul2(k, w); G2::Affine q; q.infinity = false; std::memcpy(&q.x, w, 96); std::memcpy(&q.y, w + 12, 96); return q; };
+            const BigInt256 gk[4] = {T(0), T(1), T(2), k1s};
+            legogroth16::VerifyingKey lvk;
+            lvk.alpha_g1 = g1a(alpha); lvk.beta_g2 = g2a(beta); lvk.gamma_g2 = g2a(gamma); lvk.delta_g2 = g2a(delta);
+            for (const auto &k : gk) lvk.gamma_abc_g1.push_back(g1a(k));
+            lvk.commit_witness_count = 1;
+            const legogroth16::PreparedVerifyingKey pvk = legogroth16::prepare_verifying_key(lvk);
+            {   // the prepared key is the reference's: e(alpha, beta) by the oracle, and a Miller loop over the prepared -gamma equals the one over the affine point
+                uint64_t pa[12], qb[24], ml[72], fe[72]; mul1(alpha, pa); mul2(beta, qb);
+                orc_multi_miller_loop(pa, qb, nullptr, 1, 1, ml); EXPECT(orc_final_exponentiation(ml, fe) == 0);
+                EXPECT(std::memcmp(fe, pvk.alpha_g1_beta_g2.data(), 576) == 0);
+                uint64_t ng[24], m1[72], m2[72]; mul2(neg(gamma), ng);
+                orc_multi_miller_loop(pa, ng, nullptr, 1, 1, m1);
+                EXPECT(dgpu_multi_miller_loop_prepared(pa, pvk.gamma_g2_neg_pc.data(), nullptr, 1, m2) == DGPU_OK && std::memcmp(m1, m2, 576) == 0);
+            }
+            std::vector<legogroth16::Proof> proofs(nl); std::vector<std::vector<BigInt256>> inputs(nl);
+            for (size_t i = 0; i < nl; i++) {
+                const BigInt256 a_ = T(3 + 5 * i), b_ = T(4 + 5 * i), x1 = T(5 + 5 * i), x2 = T(6 + 5 * i), dd = T(7 + 5 * i);
+                const BigInt256 dt = add_mod(add_mod(gk[0], mul_mod(x1, gk[1])), add_mod(mul_mod(x2, gk[2]), dd));
+                const BigInt256 c_ = mul_mod(add_mod(mul_mod(a_, b_), neg(add_mod(ab, mul_mod(dt, gamma)))), dinv);
+                proofs[i].a = g1a(a_); proofs[i].b = g2a(b_); proofs[i].c = g1a(c_); proofs[i].d = g1a(dd); inputs[i] = {x1, x2};
+            }
+            for (size_t i = 0; i < 3; i++) EXPECT(legogroth16::verify_proof(pvk, proofs[i], inputs[i]));
+            const BigInt256 rb{0xabcdef12345ULL, 0x77, 3, 0};
+            EXPECT(legogroth16::verify_proofs_batch(pvk, proofs, inputs, rb));
+            EXPECT(legogroth16::verify_proofs_batch(pvk, {}, {}, rb));                                        // nothing to check
+            { auto bad = inputs; bad[7][1][0] ^= 1; EXPECT(!legogroth16::verify_proof(pvk, proofs[7], bad[7])); EXPECT(!legogroth16::verify_proofs_batch(pvk, proofs, bad, rb)); }
+            { auto bad = proofs; std::swap(bad[2].d, bad[3].d); EXPECT(!legogroth16::verify_proof(pvk, bad[2], inputs[2])); EXPECT(!legogroth16::verify_proofs_batch(pvk, bad, inputs, rb)); }
+            { auto bad = proofs; bad[nl - 1].c = proofs[0].c; EXPECT(!legogroth16::verify_proofs_batch(pvk, bad, inputs, rb)); }
+            { auto other = lvk; std::swap(other.gamma_g2, other.delta_g2); const auto pv2 = legogroth16::prepare_verifying_key(other);
+              EXPECT(!legogroth16::verify_proof(pv2, proofs[0], inputs[0])); EXPECT(!legogroth16::verify_proofs_batch(pv2, proofs, inputs, rb)); }
+            // argument errors as the reference's: more inputs than gamma_abc has rows (MalformedVerifyingKey), ragged rows, a zero batching scalar
+            { bool thrown = false; try { legogroth16::verify_proof(pvk, proofs[0], {T(5), T(6), T(7), T(8)}); } catch (const Error &e) { thrown = e.code == DGPU_E_BADARG; } EXPECT(thrown); }
+            { bool thrown = false; auto bad = inputs; bad[4].pop_back(); try { legogroth16::verify_proofs_batch(pvk, proofs, bad, rb); } catch (const Error &e) { thrown = e.code == DGPU_E_LENGTH; } EXPECT(thrown); }
+            { bool thrown = false; try { legogroth16::verify_proofs_batch(pvk, proofs, inputs, BigInt256{}); } catch (const Error &e) { thrown = e.code == DGPU_E_BADARG; } EXPECT(thrown); }
+            (void)np;
+        }
     }
     // several device contexts in this one process (a Rust host is one process): two contexts on the box's one GPU, every MSM chunked
     // over them inside the library (dgpu_msm_*_sharded*), same point as the single-context call

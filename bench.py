@@ -42,7 +42,8 @@ G2_GEN_COMPRESSED = ("93e02b6052719f607dacd3a088274f65596bd0d09920b61ab5da61bbdc
                      "024aa2b2f08f0a91260805272dc51051c6e47ad4fa403b02b4510b647ae3d1770bac0326a805bbefd48056c8c121bdb8")
 MADS_PER_MIXED_ADD = 6 * 338 + 507 + 2 * 260     # XYZZ mixed addition over the 13 x 30-bit signed field (fp30s.hip.h): 6 products, one fused two-product reduction, 2 squares (round 2, 14 x 29-bit limbs: 3542)
 MADS_PER_G2_MIXED_ADD = 2 * (8 * 507 + 2 * 338)   # the same formula over Fp2 on a lane pair (fs2_pair.hip.h): per lane 8 fused two-product reductions + 2 products for the squares (round 2: 10976)
-MAD_PEAK = 31.8                                   # Tmad/s, measured v_mad_u64_u32 issue rate (profiles/r01h_instr_rate_ubench.txt)
+MAD_PEAK = 35.1                                   # Tmad/s: best measured stream of nothing but v_mad_i64_i32 (tools/ubench/clock_under_load.hip, profiles/r05_clock_under_load.txt: 35.1 at a shader clock of 2.44 GHz;
+                                                  # rounds 1-4 used 31.8 from profiles/r01h_instr_rate_ubench.txt, a shorter run at a lower clock: the fractions of those rounds read 10 % higher for the same kernel)
 
 
 def seeded_scalars(seed, n):

@@ -11,7 +11,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.environ.get("DGPU_LIB") or os.path.join(_HERE, "libdock_gpu.so")   # DGPU_LIB: development override (make g1only)
-_DEV_SO = os.path.join(_HERE, "libdock_gpu_dev.so")
+_DEV_SO = os.environ.get("DGPU_DEV_LIB") or os.path.join(_HERE, "libdock_gpu_dev.so")   # DGPU_DEV_LIB: development override (A/B builds)
 
 ERR = {0: "DGPU_OK", -1: "DGPU_E_NODEVICE", -2: "DGPU_E_OOM", -3: "DGPU_E_BADARG", -4: "DGPU_E_HIP",
        -5: "DGPU_E_ZERO", -6: "DGPU_E_TOO_SMALL", -7: "DGPU_E_LENGTH"}

@@ -61,7 +61,7 @@ inline void schk_columns(const Fs *const *a, const Fs *const *b, int nprod) {
     constexpr int32_t P_[SN] = BLS30_P;
     unsigned __int128 carry = 0;
     for (int k = 0; k < 2 * SN - 1; k++) {
-        unsigned __int128 s = carry + ((unsigned __int128)1 << 29);      // (the rounding bias of the output columns)
+        unsigned __int128 s = carry + ((unsigned __int128)1 << 29) + (k >= SN ? (unsigned __int128)1 << 59 : 0);      // (the rounding bias of the output columns; FS_ALT_HIGH: every other one also carries the next column's)
         for (int q = 0; q < nprod; q++)
             for (int i = 0; i < SN; i++) { int j = k - i; if (j < 0 || j >= SN) continue; s += (unsigned __int128)smag(*a[q], i) * smag(*b[q], j); }
         for (int i = 0; i < SN; i++) { int j = k - i; if (j < 0 || j >= SN) continue; s += (unsigned __int128)SHALF * (uint64_t)(P_[j] < 0 ? -(int64_t)P_[j] : P_[j]); }
@@ -82,12 +82,25 @@ FD int32_t sext30(uint32_t x) { return (int32_t)(x << 2) >> 2; }
 // asm statement that claims to modify an SGPR pair holding 2^29 makes it an ordinary loop-invariant value, the chain's first multiply-add takes
 // it as its addend (src2 from the scalar registers) and every other instruction stays visible to the scheduler: 324 -> 237 v_lshl_add_u64 per
 // mixed addition, 4416 -> 4329 instructions.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define FS_PIN(x) asm("" : "+v"(x))
+#else
+#define FS_PIN(x)
+#endif
+#ifdef FS_SERIAL_LOW
+#define FS_PIN_LOW(x) FS_PIN(x)
+#else
+#define FS_PIN_LOW(x)
+#endif
+// FS_ALT_HIGH: an output column with an even index starts its chain from 2^29 + 2^59 — its own rounding bias and, through the carry
+// ((s + 2^59) >> 30 = (s >> 30) + 2^29, the low 30 bits untouched), the next column's, which then needs no chain of its own
+constexpr int64_t FS_BIAS2 = (int64_t)SHALF + ((int64_t)1 << 59);
 struct FsChain {
     int64_t v;
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(FS_NO_BIAS_PIN)
-    FD FsChain(int32_t x, int32_t y) { int64_t b = (int64_t)SHALF; asm("" : "+s"(b)); v = (int64_t)x * y + b; }
+    FD FsChain(int32_t x, int32_t y, int64_t bias = (int64_t)SHALF) { int64_t b = bias; asm("" : "+s"(b)); v = (int64_t)x * y + b; }
 #else
-    FD FsChain(int32_t x, int32_t y) : v((int64_t)x * y + (int64_t)SHALF) {}
+    FD FsChain(int32_t x, int32_t y, int64_t bias = (int64_t)SHALF) : v((int64_t)x * y + bias) {}
 #endif
     FD void vv(int32_t x, int32_t y) { v += (int64_t)x * y; }
     FD void vs(int32_t x, int32_t k) { v += (int64_t)x * k; }
@@ -190,7 +203,8 @@ FD void fs_bal_wide(Fs &r, const Fs &a) {
 }
 
 // Montgomery product, r = a b / 2^390 mod p; result class B, |value| < p (1/2 + |a||b| p / 2^390 + ...).
-// Product scanning with the reduction interleaved.  Output digit j is taken from column 13 + j: the column sum carries a bias of 2^29 (a constant
+// Product scanning with the reduction interleaved.  (-DFS_SERIAL_LOW / -DFS_ALT_HIGH: the carry-seeded column chains of DESIGN.md section 10 — 195 fewer 64-bit
+// additions per mixed addition, no faster on MI355X and slower in the latency-bound kernels; off by default, kept for the A/B.)  Output digit j is taken from column 13 + j: the column sum carries a bias of 2^29 (a constant
 // folded into the start of the column's multiply-add chain), so that  (low 30 bits) - 2^29  is the balanced digit and the arithmetic shift is the carry.
 FD void fs_mul(Fs &r, const Fs &a, const Fs &b) {
     constexpr int32_t P_[SN] = BLS30_P;
@@ -201,24 +215,48 @@ FD void fs_mul(Fs &r, const Fs &a, const Fs &b) {
     // carry of the previous column by ONE 64-bit addition: the shape the compiler schedules best (the chains of neighbouring columns overlap)
 #pragma unroll
     for (int k = 0; k < SN; k++) {
+#ifdef FS_SERIAL_LOW
+        // the carry of column k - 1 is the addend of this column's first multiply-add: no 64-bit addition to join them
+#pragma unroll
+        for (int i = 0; i <= k; i++) { acc += (int64_t)a.l[i] * b.l[k - i]; FS_PIN(acc); }
+#pragma unroll
+        for (int i = 0; i < k; i++) { acc += (int64_t)m[i] * P_[k - i]; FS_PIN(acc); }
+#else
         int64_t part = 0;
 #pragma unroll
         for (int i = 0; i <= k; i++) part += (int64_t)a.l[i] * b.l[k - i];
 #pragma unroll
         for (int i = 0; i < k; i++) part += (int64_t)m[i] * P_[k - i];
         acc += part;
+#endif
         m[k] = sext30((uint32_t)acc * SINV30);
         acc += (int64_t)m[k] * P_[0];
         acc >>= SB;
     }
 #pragma unroll
     for (int k = SN; k < 2 * SN - 1; k++) {
+#ifdef FS_ALT_HIGH
+        if ((k - SN) & 1) {        // the carry brought this column's bias along (FS_BIAS2 one column earlier): the column continues the carry, no addition
+#pragma unroll
+            for (int i = k - SN + 1; i < SN; i++) { acc += (int64_t)a.l[i] * b.l[k - i]; FS_PIN(acc); }
+#pragma unroll
+            for (int i = k - SN + 1; i < SN; i++) { acc += (int64_t)m[i] * P_[k - i]; FS_PIN(acc); }
+        } else {
+            FsChain part(a.l[k - SN + 1], b.l[SN - 1], FS_BIAS2);
+#pragma unroll
+            for (int i = k - SN + 2; i < SN; i++) part.vv(a.l[i], b.l[k - i]);
+#pragma unroll
+            for (int i = k - SN + 1; i < SN; i++) part.vs(m[i], P_[k - i]);
+            acc += part.v;
+        }
+#else
         FsChain part(a.l[k - SN + 1], b.l[SN - 1]);
 #pragma unroll
         for (int i = k - SN + 2; i < SN; i++) part.vv(a.l[i], b.l[k - i]);
 #pragma unroll
         for (int i = k - SN + 1; i < SN; i++) part.vs(m[i], P_[k - i]);
         acc += part.v;
+#endif
         t[k - SN] = (int32_t)((uint32_t)acc & SMASK) - SHALF;
         acc >>= SB;
     }
@@ -237,15 +275,31 @@ FD void fs_mul2(Fs &r, const Fs &a, const Fs &b, const Fs &c, const Fs &d) {
 #pragma unroll
     for (int k = 0; k < SN; k++) {
 #pragma unroll
-        for (int i = 0; i <= k; i++) { acc += (int64_t)a.l[i] * b.l[k - i]; acc += (int64_t)c.l[i] * d.l[k - i]; }
+        for (int i = 0; i <= k; i++) { acc += (int64_t)a.l[i] * b.l[k - i]; FS_PIN_LOW(acc); acc += (int64_t)c.l[i] * d.l[k - i]; FS_PIN_LOW(acc); }
 #pragma unroll
-        for (int i = 0; i < k; i++) acc += (int64_t)m[i] * P_[k - i];
+        for (int i = 0; i < k; i++) { acc += (int64_t)m[i] * P_[k - i]; FS_PIN_LOW(acc); }
         m[k] = sext30((uint32_t)acc * SINV30);
         acc += (int64_t)m[k] * P_[0];
         acc >>= SB;
     }
 #pragma unroll
     for (int k = SN; k < 2 * SN - 1; k++) {
+#ifdef FS_ALT_HIGH
+        if ((k - SN) & 1) {
+#pragma unroll
+            for (int i = k - SN + 1; i < SN; i++) { acc += (int64_t)a.l[i] * b.l[k - i]; FS_PIN(acc); acc += (int64_t)c.l[i] * d.l[k - i]; FS_PIN(acc); }
+#pragma unroll
+            for (int i = k - SN + 1; i < SN; i++) { acc += (int64_t)m[i] * P_[k - i]; FS_PIN(acc); }
+        } else {
+            FsChain part(a.l[k - SN + 1], b.l[SN - 1], FS_BIAS2);
+            part.vv(c.l[k - SN + 1], d.l[SN - 1]);
+#pragma unroll
+            for (int i = k - SN + 2; i < SN; i++) { part.vv(a.l[i], b.l[k - i]); part.vv(c.l[i], d.l[k - i]); }
+#pragma unroll
+            for (int i = k - SN + 1; i < SN; i++) part.vs(m[i], P_[k - i]);
+            acc += part.v;
+        }
+#else
         FsChain part(a.l[k - SN + 1], b.l[SN - 1]);
         part.vv(c.l[k - SN + 1], d.l[SN - 1]);
 #pragma unroll
@@ -253,6 +307,7 @@ FD void fs_mul2(Fs &r, const Fs &a, const Fs &b, const Fs &c, const Fs &d) {
 #pragma unroll
         for (int i = k - SN + 1; i < SN; i++) part.vs(m[i], P_[k - i]);
         acc += part.v;
+#endif
         t[k - SN] = (int32_t)((uint32_t)acc & SMASK) - SHALF;
         acc >>= SB;
     }
@@ -273,16 +328,33 @@ FD void fs_sqr(Fs &r, const Fs &a) {
 #pragma unroll
     for (int k = 0; k < SN; k++) {
 #pragma unroll
-        for (int i = 0; 2 * i < k; i++) acc += (int64_t)a.l[i] * a2[k - i];
-        if ((k & 1) == 0) acc += (int64_t)a.l[k / 2] * a.l[k / 2];
+        for (int i = 0; 2 * i < k; i++) { acc += (int64_t)a.l[i] * a2[k - i]; FS_PIN_LOW(acc); }
+        if ((k & 1) == 0) { acc += (int64_t)a.l[k / 2] * a.l[k / 2]; FS_PIN_LOW(acc); }
 #pragma unroll
-        for (int i = 0; i < k; i++) acc += (int64_t)m[i] * P_[k - i];
+        for (int i = 0; i < k; i++) { acc += (int64_t)m[i] * P_[k - i]; FS_PIN_LOW(acc); }
         m[k] = sext30((uint32_t)acc * SINV30);
         acc += (int64_t)m[k] * P_[0];
         acc >>= SB;
     }
 #pragma unroll
     for (int k = SN; k < 2 * SN - 1; k++) {
+#ifdef FS_ALT_HIGH
+        if ((k - SN) & 1) {
+#pragma unroll
+            for (int i = k - SN + 1; i < SN; i++) { acc += (int64_t)m[i] * P_[k - i]; FS_PIN(acc); }
+#pragma unroll
+            for (int i = k - SN + 1; 2 * i < k; i++) { acc += (int64_t)a.l[i] * a2[k - i]; FS_PIN(acc); }
+            if ((k & 1) == 0) { acc += (int64_t)a.l[k / 2] * a.l[k / 2]; FS_PIN(acc); }
+        } else {
+            FsChain part(m[k - SN + 1], P_[SN - 1], FS_BIAS2);
+#pragma unroll
+            for (int i = k - SN + 2; i < SN; i++) part.vs(m[i], P_[k - i]);
+#pragma unroll
+            for (int i = k - SN + 1; 2 * i < k; i++) part.vv(a.l[i], a2[k - i]);
+            if ((k & 1) == 0) part.vv(a.l[k / 2], a.l[k / 2]);
+            acc += part.v;
+        }
+#else
         FsChain part(m[k - SN + 1], P_[SN - 1]);         // (started from a reduction product: the last column has no off-diagonal operand product)
 #pragma unroll
         for (int i = k - SN + 2; i < SN; i++) part.vs(m[i], P_[k - i]);
@@ -290,6 +362,7 @@ FD void fs_sqr(Fs &r, const Fs &a) {
         for (int i = k - SN + 1; 2 * i < k; i++) part.vv(a.l[i], a2[k - i]);
         if ((k & 1) == 0) part.vv(a.l[k / 2], a.l[k / 2]);
         acc += part.v;
+#endif
         t[k - SN] = (int32_t)((uint32_t)acc & SMASK) - SHALF;
         acc >>= SB;
     }

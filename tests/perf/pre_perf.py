@@ -1,5 +1,5 @@
 """Timing driver (GPU box): plain vs precomputed-table MSM on resident operands — per-stage HIP-event times with one call in flight,
-wall time with 1 and 4 calls in flight.  WHAT=g1|g2|both, LOG2N, CS=comma list of table widths (0 = plain pipeline)."""
+wall time with 1 and IN_FLIGHT (default 6) calls in flight.  WHAT=g1|g2|both, LOG2N, CS=comma list of table widths (0 = plain pipeline)."""
 import os
 import sys
 import time
@@ -21,7 +21,7 @@ gen1, _ = serde.deserialize(ca.G1, bytes.fromhex(B.G1_GEN_COMPRESSED))
 gen2, _ = serde.deserialize(ca.G2, bytes.fromhex(B.G2_GEN_COMPRESSED))
 sc = B.seeded_scalars(0x5EED1000, n)
 ds = ca.DeviceScalars(sc)
-pool = ThreadPoolExecutor(4)
+inflight = int(os.environ.get("IN_FLIGHT", "6"))
 for curve, gen, tag in ((ca.G1, gen1, "g1"), (ca.G2, gen2, "g2")):
     if what not in (tag, "both"):
         continue
@@ -45,10 +45,8 @@ for curve, gen, tag in ((ca.G1, gen1, "g1"), (ca.G2, gen2, "g2")):
             db.msm_resident(ds)
         lat = (time.perf_counter() - t0) / 5 * 1e3
         st = ca.prof.read(); ca.prof.enable(False)
-        list(pool.map(lambda _: db.msm_resident(ds), range(8)))
-        t0 = time.perf_counter()
-        list(pool.map(lambda _: db.msm_resident(ds), range(24)))
-        thr = (time.perf_counter() - t0) / 24 * 1e3
-        print("%s n=2^%d c=%2d  precompute %.1f ms | latency %.3f ms | 4 in flight %.3f ms/MSM (%.1f MSM/s) | %s" % (
-            tag, log2n, c, tp, lat, thr, 1e3 / thr, " ".join("%s=%.3f" % (k.replace("msm.", ""), v[0] / max(1, v[1])) for k, v in st.items())), flush=True)
+        B.run_inflight(lambda: db.msm_resident(ds), 2 * inflight, inflight)
+        thr = min(B.run_inflight(lambda: db.msm_resident(ds), 6 * inflight, inflight)[0] for _ in range(3)) / (6 * inflight) * 1e3      # (host threads parked before the clock: bench.py's InFlight)
+        print("%s n=2^%d c=%2d  precompute %.1f ms | latency %.3f ms | %d in flight %.3f ms/MSM (%.1f MSM/s) | %s" % (
+            tag, log2n, c, tp, lat, inflight, thr, 1e3 / thr, " ".join("%s=%.3f" % (k.replace("msm.", ""), v[0] / max(1, v[1])) for k, v in st.items())), flush=True)
         db.free()

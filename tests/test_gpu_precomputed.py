@@ -197,3 +197,41 @@ def test_one_sort_shared_by_tables_of_one_shape(n, c):
         ta.msm_sorted(ca.SortedScalars(ta, ca.DeviceScalars(uniform), n), row_shift=1)          # the table is not one row shorter
     for t in (ta, tb, t2, other, wide, plain) + tuple(tl.values()):
         t.free()
+
+
+@pytest.mark.parametrize("gname,n,c", [("G1", 1 << 19, 0), ("G2", 1 << 17, 20), ("G1", (1 << 15) + 77, 16)])
+def test_few_distinct_bases_collide_everywhere(gname, n, c):
+    """The headline shape (n >= 320 000: 20-bit windows, 13 of them, ONE bucket set, bit-marginal reduction) on inputs made of collisions: the bases are
+    k G for k in {1, -1, 2, -2, 3} repeated, so a bucket's run adds a point to itself (the doubling fix-up of the mixed addition), to its negative (an
+    identity accumulator in mid-run), and the reduction's running sums and wave network meet equal and opposite partial sums; scalars uniform, all
+    equal, +-1, and one value per base class.  Expected point: (sum s_i k_i) G by the CPU oracle's double-and-add — no MSM code on the checking side."""
+    G, curve = (O.G1, ca.G1) if gname == "G1" else (O.G2, ca.G2)
+    R = U.R
+    kk = [1, R - 1, 2, R - 2, 3]
+    gen = G.generator()
+    pts = np.stack([G.to_affine(G.mul(gen, O.int_to_limbs(k, 4)))[0] for k in kk])
+    rng = np.random.default_rng(n % 1000 + c)
+    idx = rng.integers(0, len(kk), n)
+    idx[: n // 8] = 0                                     # a long stretch of one and the same point
+    bases = pts[idx]
+    kvec = np.array(kk, dtype=object)[idx]
+    tab = ca.DeviceBases(curve, bases).precompute(c)
+    assert tab.table_shape()[1] == (c or 20)
+
+    def check(sc):
+        ints = [int(v[0]) | int(v[1]) << 64 | int(v[2]) << 128 | int(v[3]) << 192 for v in sc]
+        tot = sum(s * int(k) for s, k in zip(ints, kvec)) % R
+        exp = G.to_affine(G.mul(gen, O.int_to_limbs(tot, 4)))
+        got = G.to_affine(tab.msm_bigint(sc))
+        assert exp[1] == got[1] and (exp[1] or (exp[0] == got[0]).all())
+
+    full = O.rand_scalars(4242 + n % 97, n)
+    check(full)
+    check(np.tile(full[3], (n, 1)))                                               # all equal: thirteen hot buckets hold everything
+    pm = np.tile(O.int_to_limbs(1, 4), (n, 1)); pm[rng.integers(0, 2, n) == 1] = O.int_to_limbs(R - 1, 4)
+    check(pm)                                                                     # +-1 on +-k G
+    per = np.stack([full[j] for j in range(len(kk))])[idx]                        # one scalar per base class: five runs per bucket, each a chain of doublings
+    check(per)
+    sm = np.zeros((n, 4), np.uint64); sm[:, 0] = rng.integers(0, 4, n, dtype=np.uint64)      # digits 0 .. 3 only: four buckets, the rest of the set empty
+    check(sm)
+    tab.free()

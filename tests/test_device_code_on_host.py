@@ -67,6 +67,23 @@ def test_fs_ops(shim):
         assert shim.shim_fs_is_zero(p_(A), p_(A)) == 3
 
 
+def test_fs_ops_with_carry_seeded_chains(shim):
+    """the opt-in shape of the same products (-DFS_SERIAL_LOW -DFS_ALT_HIGH, DESIGN.md section 10: the carry as the addend of the next column's first
+    multiply-add; every other output column started from 2^29 + 2^59): same values, and the bound tracker accepts the extra 2^59 in the column sums"""
+    so = os.path.join(HERE, "native", "libfp29_host_shim_serial.so")
+    deps = [SRC, os.path.join(HERE, "..", "crypto_amd", "csrc", "fp30s.hip.h")]
+    if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-DFS_SERIAL_LOW", "-DFS_ALT_HIGH", "-o", so, SRC])
+    alt = C.CDLL(so)
+    test_fs_ops(alt)
+    random.seed(12)
+    out, ref = np.zeros(6, np.uint64), np.zeros(6, np.uint64)
+    for _ in range(200):                               # limb for limb what the default shape gives (both are exact; the canonical words must agree)
+        A, B = U.fp_abi(random.randrange(P)), U.fp_abi(random.randrange(P))
+        alt.shim_fs_mul(p_(A), p_(B), p_(out)); shim.shim_fs_mul(p_(A), p_(B), p_(ref)); assert (out == ref).all()
+        alt.shim_fs_sqr(p_(A), p_(out)); shim.shim_fs_sqr(p_(A), p_(ref)); assert (out == ref).all()
+
+
 def test_fp_inversion_by_division_steps(shim):
     """fp_safegcd.hip.h against the big-integer inverse: edge values, small and large values, random ones, lazily added operands"""
     random.seed(7)

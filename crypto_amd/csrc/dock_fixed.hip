@@ -145,7 +145,7 @@ template <class C> int32_t mul_add(const uint64_t *p, const uint8_t *p_inf, cons
     uint8_t *dout_inf = sl.prepped.as<uint8_t>() + n * pt;
     { StageTimer st(sl, "fixed.mul_add");
       if (plain) msm::launch_mul_add<C>(s, (const uint32_t *)dp, dpinf, sl.in_scalars.as<uint32_t>(), (int)(scalar_stride * 2), dadd, dainf, n, sl.prepped.as<uint32_t>(), dout_inf);
-      else if constexpr (C::NFP == 1) msm::launch_g1_scale(s, (const uint32_t *)dp, dpinf, sl.in_scalars.as<uint32_t>(), (int)(scalar_stride * 2), nullptr, n, sl.prepped.as<uint32_t>(), dout_inf, dadd, dainf);
+      else if constexpr (C::NFP == 1) msm::launch_g1_scale_quad(s, (const uint32_t *)dp, dpinf, sl.in_scalars.as<uint32_t>(), (int)(scalar_stride * 2), nullptr, n, sl.prepped.as<uint32_t>(), dout_inf, dadd, dainf);
       else msm::launch_mul_add_g2_gls(s, (const uint32_t *)dp, dpinf, sl.in_scalars.as<uint32_t>(), (int)(scalar_stride * 2), dadd, dainf, n, sl.prepped.as<uint32_t>(), dout_inf); }
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out, sl.prepped.p, n * pt, hipMemcpyDeviceToHost, s));

@@ -16,6 +16,7 @@
 #include "pairing29.hip.h"
 #include "fp2_pair.hip.h"
 #include "sort_launch.hip.h"
+#include "fixed_launch.hip.h"
 #include <thread>
 #include <functional>
 #include <atomic>
@@ -1243,7 +1244,7 @@ int32_t dgpu_g1_scale_batch(const uint64_t *p, const uint8_t *is_inf, const uint
     if (negate) { HIPCHK(hipMemcpyAsync(sl.in_inf.as<uint8_t>() + n, negate, n, hipMemcpyHostToDevice, s)); dneg = sl.in_inf.as<uint8_t>() + n; }
     uint8_t *dout_inf = sl.prepped.as<uint8_t>() + n * 96;
     { StageTimer st(sl, "pc.g1_scale");
-      msm::launch_g1_scale(s, sl.in_bases.as<uint32_t>(), dinf, sl.in_scalars.as<uint32_t>(), (int)(scalar_stride * 2), dneg, n, sl.prepped.as<uint32_t>(), dout_inf); }
+      msm::launch_g1_scale_quad(s, sl.in_bases.as<uint32_t>(), dinf, sl.in_scalars.as<uint32_t>(), (int)(scalar_stride * 2), dneg, n, sl.prepped.as<uint32_t>(), dout_inf); }
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out, sl.prepped.p, n * 96, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(out_inf, dout_inf, n, hipMemcpyDeviceToHost, s));

@@ -10,6 +10,10 @@ template <class C> void launch_fb_table(hipStream_t s, const uint32_t *window_ba
 template <class C> void launch_fb_mul(hipStream_t s, const uint32_t *table, const uint32_t *scalars, size_t n, uint32_t *out_abi, uint8_t *out_inf);
 template <class C> void launch_mul_add(hipStream_t s, const uint32_t *p_abi, const uint8_t *p_inf, const uint32_t *scalars, int scalar_stride, const uint32_t *add_abi, const uint8_t *add_inf,
                                        size_t n, uint32_t *out_abi, uint8_t *out_inf);
+// out_i = [A_i +] s_i P_i, G1, the scalars as (k1 | k2) of the GLV split (hostf::glv_decompose): ONE joint chain on four lanes per point (fold_kernels.hip.h);
+// same arguments and results as launch_g1_scale (sort_launch.hip.h), which it replaces at the call sites
+void launch_g1_scale_quad(hipStream_t s, const uint32_t *p_abi, const uint8_t *is_inf, const uint32_t *scalars, int scalar_stride, const uint8_t *negate, size_t n, uint32_t *out_abi, uint8_t *out_inf,
+                          const uint32_t *add_abi = nullptr, const uint8_t *add_inf = nullptr);
 // G2 with the scalars as four base-|x| digits each (hostf::gls4_decompose): sixteen lanes per point
 void launch_mul_add_g2_gls(hipStream_t s, const uint32_t *p_abi, const uint8_t *p_inf, const uint32_t *digits, int scalar_stride, const uint32_t *add_abi, const uint8_t *add_inf,
                            size_t n, uint32_t *out_abi, uint8_t *out_inf);

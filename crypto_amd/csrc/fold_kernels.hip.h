@@ -249,4 +249,104 @@ __global__ void __launch_bounds__(64) k_fold_affine_g2(const uint32_t *__restric
     fp_to_abi(o + 12 * h, a.x.v); fp_to_abi(o + 12 * (2 + h), a.y.v);
 }
 
+// ---- out_i = [A_i +] s_i P_i with a scalar of its own per point: one joint chain on four lanes ------------------------------------------------
+// The call of RandomizedPairingChecker's scalings (utils/src/randomized_pairing_check.rs:125-129,152-158: `a.mul_bigint(m)` per source) and of the batch
+// verifier's r^i A_i (dgpu_legogroth16_verify_batch).  k_g1_scale (sort_kernels.hip.h) runs k1 P and k2 P as TWO 128-step chains on two lanes each and
+// joins them at the end; in a wave of sixteen points some chain always has its bit set, so every step is a doubling AND a mixed addition, five products
+// deep each: 1280 product-depths.  Here the four lanes of a point run ONE chain over both halves of the GLV split through the round forms of ec29.hip.h
+// (a doubling three products deep, an addition four) with TWO bits of each half per addition: the addend of a step is T[d1 + 4 d2] = d1 P + d2 phi(P),
+// d1, d2 < 4, from a table of fifteen sums the quad builds first (one doubling, ten additions, three products by beta) and keeps in LDS —
+// 64 x (2 x 3 + 4) = 640 product-depths, and the additions fall on the same steps for every point of the wave.  13 x 30-bit signed field.  Points are
+// elements of the prime-order subgroup (phi(P) = lambda P holds there, and no table entry is the identity).
+constexpr int SCQ_ENTRY = 4 * SN, SCQ_STRIDE = 16 * SCQ_ENTRY + 1;          // words per entry / per quad (odd: the sixteen quads of a wave read different banks)
+__global__ void __launch_bounds__(64) k_g1_scale_quad(const uint32_t *__restrict__ p_abi, const uint8_t *__restrict__ is_inf, const uint32_t *__restrict__ scalars, int scalar_stride,
+                                                      const uint8_t *__restrict__ negate, size_t n, uint32_t *__restrict__ out_abi, uint8_t *__restrict__ out_inf,
+                                                      const uint32_t *__restrict__ add_abi, const uint8_t *__restrict__ add_inf) {
+    typedef Fs F;
+    __shared__ uint32_t tab[16 * SCQ_STRIDE];
+    const size_t i = ((size_t)blockIdx.x * 64 + threadIdx.x) >> 2;
+    if (i >= n) return;                                                      // (whole quads leave together; nothing below is a block-wide barrier)
+    const QuadLanes<1> q4;
+    uint32_t *const mine = tab + (threadIdx.x >> 2) * SCQ_STRIDE;
+    uint32_t any = 0;
+    for (int k = 0; k < 24; k++) any |= p_abi[i * 24 + k];
+    const bool pinf = (any == 0) || (is_inf && is_inf[i]);
+    // member r parks coordinate r of entry e (picked without a lane-dependent register index)
+    auto park = [&](int e, const Xyzz<F> &x) __attribute__((always_inline)) {
+        const uint32_t *wx = reinterpret_cast<const uint32_t *>(&x);
+        uint32_t *dst = mine + e * SCQ_ENTRY + q4.role * SN;
+#pragma unroll
+        for (int j = 0; j < SN; j++) dst[j] = pick4(q4.role, wx[j], wx[SN + j], wx[2 * SN + j], wx[3 * SN + j]);
+    };
+    auto fetch = [&](Xyzz<F> &x, int e) __attribute__((always_inline)) {
+        uint32_t *o = reinterpret_cast<uint32_t *>(&x);
+        const uint32_t *src = mine + e * SCQ_ENTRY;
+#pragma unroll
+        for (int j = 0; j < SCQ_ENTRY; j++) o[j] = src[j];
+    };
+    Xyzz<F> acc;
+    if (!pinf) {
+        F beta;
+        {   // beta (ec29_two_lane.hip.h xyzz_phi's constant) from the 29-bit form into this field
+            constexpr uint32_t B_[NL] = BLS29_BETA;
+            Fp b29; uint32_t w[12];
+#pragma unroll
+            for (int k = 0; k < NL; k++) b29.l[k] = B_[k];
+            CHK(chk_set_N(b29, 1.0);)
+            fp_to_abi(w, b29); fs_from_abi(beta, w);
+        }
+        Xyzz<F> P1, M;
+        fs_from_abi(P1.x, p_abi + i * 24); fs_from_abi(P1.y, p_abi + i * 24 + 12); fset_one(P1.zz); fset_one(P1.zzz);
+        park(1, P1);
+        xyzz_dbl_rounds(M, P1, q4); park(2, M);                              // 2 P
+        { bool f = false; xyzz_add_rounds(M, f, P1, false, q4); } park(3, M); // 3 P
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // (one wave per block: the table is written and read by the same wave, in order)
+#pragma unroll 1
+        for (int d2 = 1; d2 < 4; d2++) {                                     // d2 phi(P) = phi(d2 P): x times beta
+            Xyzz<F> Q; fetch(Q, d2);
+            { F xn; fnorm(xn, Q.x); fmul(Q.x, xn, beta); }
+            park(4 * d2, Q);
+#pragma unroll 1
+            for (int d1 = 1; d1 < 4; d1++) {
+                Xyzz<F> S; fetch(S, d1);
+                bool f = false; xyzz_add_rounds(S, f, Q, false, q4);         // (d1 + d2 lambda) P: never the identity, and d1 P != +- d2 phi(P)
+                park(4 * d2 + d1, S);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // (one wave per block: the table is written and read by the same wave, in order)
+    }
+    fzero(acc.x); fzero(acc.y); fzero(acc.zz); fzero(acc.zzz);
+    bool inf = true;
+    const uint32_t *s = scalars + i * (size_t)scalar_stride;                 // (k1 | k2), four words each
+    if (!pinf) {
+#pragma unroll 1
+        for (int b = 126; b >= 0; b -= 2) {
+            { Xyzz<F> d; xyzz_dbl_rounds(d, acc, q4); xyzz_dbl_rounds(acc, d, q4); }        // (on an identity accumulator: zeros in, zeros out)
+            const uint32_t sel = ((s[b >> 5] >> (b & 31)) & 3u) | (((s[4 + (b >> 5)] >> (b & 31)) & 3u) << 2);
+            Xyzz<F> B; fetch(B, sel ? (int)sel : 1);
+            xyzz_add_rounds(acc, inf, B, sel == 0, q4);
+        }
+    }
+    if (add_abi) {
+        const uint32_t *src = add_abi + i * 24;
+        uint32_t nz = 0;
+        for (int k = 0; k < 24; k++) nz |= src[k];
+        Xyzz<F> A; fs_from_abi(A.x, src); fs_from_abi(A.y, src + 12); fset_one(A.zz); fset_one(A.zzz);
+        xyzz_add_rounds(acc, inf, A, nz == 0 || (add_inf && add_inf[i]), q4);
+    }
+    uint32_t *o = out_abi + i * 24;
+    if (q4.role == 0) out_inf[i] = inf;
+    if (inf) { if (q4.role == 0) for (int k = 0; k < 24; k++) o[k] = 0; return; }
+    // (X / ZZ, Y / ZZZ) with 1 / ZZ = (ZZ / ZZZ)^2; the inversion is the division-step one of the 14 x 29-bit field (every member runs it: one chain either way)
+    Fp z29, i29; F i3, t, i2, xn, yn, x, y;
+    fnorm(t, acc.zzz); fp_from_fs(z29, t);
+    fp_inv_device(i29, z29);
+    fs_from_fp(i3, i29);
+    fnorm(t, acc.zz); fmul(t, t, i3); fsqr(i2, t);
+    fnorm(xn, acc.x); fnorm(yn, acc.y);
+    fmul(x, xn, i2); fmul(y, yn, i3);
+    fcond_neg(y, negate && negate[i]);
+    if (q4.role == 0) fs_to_abi(o, x); else if (q4.role == 1) fs_to_abi(o + 12, y);
+}
+
 }  // namespace msm

@@ -39,6 +39,10 @@ template void launch_fb_table<G1>(hipStream_t, const uint32_t *, uint32_t *);
 template void launch_fb_table<G2>(hipStream_t, const uint32_t *, uint32_t *);
 template void launch_fb_mul<G1>(hipStream_t, const uint32_t *, const uint32_t *, size_t, uint32_t *, uint8_t *);
 template void launch_fb_mul<G2>(hipStream_t, const uint32_t *, const uint32_t *, size_t, uint32_t *, uint8_t *);
+void launch_g1_scale_quad(hipStream_t s, const uint32_t *p_abi, const uint8_t *is_inf, const uint32_t *scalars, int scalar_stride, const uint8_t *negate, size_t n, uint32_t *out_abi, uint8_t *out_inf,
+                          const uint32_t *add_abi, const uint8_t *add_inf) {
+    hipLaunchKernelGGL(k_g1_scale_quad, dim3((unsigned)((4 * n + 63) / 64)), dim3(64), 0, s, p_abi, is_inf, scalars, scalar_stride, negate, n, out_abi, out_inf, add_abi, add_inf);
+}
 // the folding step with its doubling chains done ahead of the scalar (fold_kernels.hip.h)
 static_assert(FOLD_TABLE_WORDS_G1 == FOLD_E1 * FOLD_PW1 && FOLD_TABLE_WORDS_G2 == FOLD_E2 * FOLD_PW2, "fold table size");
 void launch_fold_chain(hipStream_t s, const uint32_t *p1, size_t n1, uint32_t *tab1, uint8_t *inf1, const uint32_t *p2, size_t n2, uint32_t *tab2, uint8_t *inf2) {

@@ -258,6 +258,7 @@ __global__ void __launch_bounds__(64) k_fold_affine_g2(const uint32_t *__restric
 // d1, d2 < 4, from a table of fifteen sums the quad builds first (one doubling, ten additions, three products by beta) and keeps in LDS —
 // 64 x (2 x 3 + 4) = 640 product-depths, and the additions fall on the same steps for every point of the wave.  13 x 30-bit signed field.  Points are
 // elements of the prime-order subgroup (phi(P) = lambda P holds there, and no table entry is the identity).
+// 53 KB of LDS per 64-lane block: three blocks per CU, i.e. 12 288 points in one round of the chip — the call sites scale hundreds to a few thousand points.
 constexpr int SCQ_ENTRY = 4 * SN, SCQ_STRIDE = 16 * SCQ_ENTRY + 1;          // words per entry / per quad (odd: the sixteen quads of a wave read different banks)
 __global__ void __launch_bounds__(64) k_g1_scale_quad(const uint32_t *__restrict__ p_abi, const uint8_t *__restrict__ is_inf, const uint32_t *__restrict__ scalars, int scalar_stride,
                                                       const uint8_t *__restrict__ negate, size_t n, uint32_t *__restrict__ out_abi, uint8_t *__restrict__ out_inf,

@@ -84,7 +84,7 @@ SYMBOLS = [
     "dgpu_bases_upload_g1", "dgpu_bases_upload_g2", "dgpu_bases_free", "dgpu_scalars_upload", "dgpu_scalars_upload_parts", "dgpu_scalars_free",
     "dgpu_msm_g1_handle", "dgpu_msm_g2_handle", "dgpu_msm_g1_resident", "dgpu_msm_g2_resident", "dgpu_bases_precompute_g1", "dgpu_bases_precompute_g2",
     "dgpu_msm_g1_sharded", "dgpu_msm_g2_sharded", "dgpu_bases_upload_g1_sharded", "dgpu_bases_upload_g2_sharded", "dgpu_msm_g1_sharded_handle", "dgpu_msm_g2_sharded_handle", "dgpu_scalars_upload_sharded", "dgpu_scalars_copy_range", "dgpu_msm_g1_sharded_resident", "dgpu_msm_g2_sharded_resident",
-    "dgpu_fold_g1", "dgpu_fold_g2", "dgpu_lincomb_g1", "dgpu_lincomb_g2", "dgpu_multi_miller_loop", "dgpu_multi_miller_loop_sharded", "dgpu_bases_table_shape", "dgpu_scalars_sort", "dgpu_msm_g1_sorted", "dgpu_msm_g2_sorted", "dgpu_multi_miller_loop_segments", "dgpu_multi_pairing_segments", "dgpu_g2_prepare", "dgpu_multi_miller_loop_prepared", "dgpu_multi_miller_loop_mixed", "dgpu_final_exponentiation", "dgpu_g1_scale_batch", "dgpu_fp12_mul", "dgpu_fp12_pow", "dgpu_fp12_multi_pow", "dgpu_gt_in_subgroup", "dgpu_g1_serialize", "dgpu_g1_deserialize", "dgpu_g2_serialize", "dgpu_g2_deserialize", "dgpu_witness_map", "dgpu_r1cs_upload", "dgpu_r1cs_free", "dgpu_r1cs_shape", "dgpu_witness_map_r1cs", "dgpu_witness_map_r1cs_resident",
+    "dgpu_fold_g1", "dgpu_fold_g2", "dgpu_lincomb_g1", "dgpu_lincomb_g2", "dgpu_multi_miller_loop", "dgpu_multi_miller_loop_sharded", "dgpu_bases_table_shape", "dgpu_scalars_sort", "dgpu_msm_g1_sorted", "dgpu_msm_g2_sorted", "dgpu_multi_miller_loop_segments", "dgpu_multi_pairing_segments", "dgpu_g2_prepare", "dgpu_multi_miller_loop_prepared", "dgpu_multi_miller_loop_mixed", "dgpu_multi_miller_loop_scaled", "dgpu_final_exponentiation", "dgpu_g1_scale_batch", "dgpu_fp12_mul", "dgpu_fp12_pow", "dgpu_fp12_multi_pow", "dgpu_gt_in_subgroup", "dgpu_g1_serialize", "dgpu_g1_deserialize", "dgpu_g2_serialize", "dgpu_g2_deserialize", "dgpu_witness_map", "dgpu_r1cs_upload", "dgpu_r1cs_free", "dgpu_r1cs_shape", "dgpu_witness_map_r1cs", "dgpu_witness_map_r1cs_resident",
     "dgpu_window_table_g1", "dgpu_window_table_g2", "dgpu_window_table_free", "dgpu_window_table_mul_g1", "dgpu_window_table_mul_g2", "dgpu_window_table_mul_to_bases_g1", "dgpu_window_table_mul_to_bases_g2", "dgpu_fixed_base_g1", "dgpu_fixed_base_g2", "dgpu_g1_mul_add_batch", "dgpu_g2_mul_add_batch",
     "dgpu_legogroth16_prove", "dgpu_legogroth16_verify", "dgpu_legogroth16_verify_batch", "dgpu_handle_len", "dgpu_handle_context", "dgpu_shard_count", "dgpu_shard_part",
     "dgpu_snarkpack_proof_words", "dgpu_snarkpack_aggregate", "dgpu_snarkpack_verify",
@@ -202,6 +202,7 @@ def _load(path):
         L.dgpu_g2_prepare.argtypes = [vp, vp, sz, vp, vp]
         L.dgpu_multi_miller_loop_prepared.argtypes = [vp, vp, vp, sz, vp]
         L.dgpu_multi_miller_loop_mixed.argtypes = [vp, vp, vp, sz, vp, vp, vp, sz, vp]
+        L.dgpu_multi_miller_loop_scaled.argtypes = [vp, vp, sz, vp, vp, sz, vp, vp, vp, sz, vp]
         L.dgpu_multi_miller_loop_segments.argtypes = [vp, vp, vp, sz, vp, sz, vp]
         L.dgpu_multi_pairing_segments.argtypes = [vp, vp, vp, sz, vp, sz, vp]
         L.dgpu_bases_precompute_g1.argtypes = [u64, C.c_int32]

@@ -739,8 +739,10 @@ constexpr int ML_CUTS[ML_PIECES] = {40, 17, 0};               // piece j runs th
 // late(side_stream, pxy), if given, runs on the calling thread once every piece of the chain has been queued — host work that the chain hides
 // (the verifier computes its third G1 operand meanwhile) — and may queue, on side_stream, whatever must precede the product kernels (the line
 // kernel of prepared pairs whose P was not known before).
+// p_late: the affine pairs' P are not known when the chain starts (dgpu_multi_miller_loop_scaled: they are being scaled meanwhile) — the line kernel gets
+// no P and leaves px, py alone; `late` must write them (pxy[(c NL + k) n + i], the internal form) before the product kernels run
 static int32_t ml_pipelined(Slot &sl, size_t n, size_t n_aff, const uint8_t *dskip, uint64_t *out, const std::function<void(uint32_t *)> &prepared,
-                            const std::function<int32_t(hipStream_t, uint32_t *)> &late = nullptr) {
+                            const std::function<int32_t(hipStream_t, uint32_t *)> &late = nullptr, bool p_late = false) {
     int32_t rc; MlGeom g, g2;
     if ((rc = ml_geometry(sl, n, g))) return rc;
     // the last steps' products are all that is left when the chain ends: from 8-pair slices on they take half the slice length (fewer
@@ -771,7 +773,8 @@ static int32_t ml_pipelined(Slot &sl, size_t n, size_t n_aff, const uint8_t *dsk
       for (int j = 0; j < ML_PIECES && !rc; j++) {
           const int b_lo = cuts[j], ns = ml_steps(b_hi, b_lo);
           first_step[j] = s_first; steps[j] = ns;
-          launch_lines_uneval(sa, sl.in_bases.as<uint32_t>(), sl.in_scalars.as<uint32_t>(), dskip, n_aff, sl.ml_lines.as<uint32_t>(), n, b_hi, b_lo, s_first, state, pxy);
+          launch_lines_uneval(sa, p_late ? (const uint32_t *)nullptr : sl.in_bases.as<uint32_t>(), sl.in_scalars.as<uint32_t>(), dskip, n_aff, sl.ml_lines.as<uint32_t>(), n, b_hi, b_lo, s_first, state,
+                              p_late ? (uint32_t *)nullptr : pxy);
           if (j + 1 < ML_PIECES) { ready[j] = sl.copy_ev[sl.ev_next++ % (Slot::N_COPY_EV + 1)]; ok(hipEventRecord(ready[j], sa)); }
           s_first += ns; b_hi = b_lo - 1;
       } }
@@ -1133,6 +1136,84 @@ int32_t dgpu_multi_miller_loop_mixed(const uint64_t *p_aff, const uint64_t *q_af
                              skip_prep ? dsk + n_aff : (const uint8_t *)nullptr, n_prep, lines + n_aff, n);
     }
     return ml_finish(sl, n, out);
+}
+
+// ---- prod_i e(m_i P_i, Q_i) x prod_j e(P'_j, prepared_j): the scalings and the Miller loop of RandomizedPairingChecker as ONE call ----
+// utils/src/randomized_pairing_check.rs:125-134: `a.mul_bigint(m)` for every source, then the pairs go to one multi_miller_loop (:204-214 in lazy mode).
+// The line coefficients of a pair depend on Q alone and P enters only in the product kernels (the lines leave unevaluated, px and py travel beside
+// them), so the chain of the Q_i starts at once and the 128-step scaling chains of the P_i (k_g1_scale_quad) run BESIDE it instead of in front of it;
+// the scaled points never visit the host.  1024 pairs: 1.14 (scalings) + 0.75 (Miller loop) ms one after the other -> ~1.3 ms.
+// scaled P (affine ABI words, on the device) -> px, py in the internal form for k_line_products
+__global__ void __launch_bounds__(256) k_pxy_from_abi(const uint32_t *__restrict__ p_abi, size_t n, uint32_t *__restrict__ pxy, size_t stride) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 2 * n) return;
+    const size_t i = t >> 1; const uint32_t h = (uint32_t)(t & 1);
+    uint32_t w[12];
+    for (int k = 0; k < 12; k++) w[k] = p_abi[i * 24 + h * 12 + k];
+    Fp c; fp_from_abi(c, w);
+    for (int k = 0; k < NL; k++) pxy[(h * NL + k) * stride + i] = c.l[k];
+}
+int32_t dgpu_multi_miller_loop_scaled(const uint64_t *p_aff, const uint64_t *scalars, size_t scalar_stride, const uint64_t *q_aff, const uint8_t *skip_aff, size_t n_aff,
+                                      const uint64_t *p_prep, const uint64_t *coeffs, const uint8_t *skip_prep, size_t n_prep, uint64_t *out) {
+    if (!out || (n_aff && (!p_aff || !q_aff || !scalars)) || (n_prep && (!p_prep || !coeffs)) || (scalar_stride != 0 && scalar_stride != 4)) return DGPU_E_BADARG;
+    const size_t n = n_aff + n_prep;
+    if (n_aff == 0) return dgpu_multi_miller_loop_mixed(nullptr, nullptr, nullptr, 0, p_prep, coeffs, skip_prep, n_prep, out);
+    if (n_prep > DGPU_MAX_PREPARED || n >= (1ull << 24)) return DGPU_E_BADARG;
+    if (!cur().ready) return DGPU_E_NODEVICE;
+    // GLV: every scalar goes to the device as (k1 | k2), k mod r = k1 + k2 lambda; a pair whose scaled point is the identity is skipped (m = 0 mod r or P = 0)
+    const size_t nsc = scalar_stride ? n_aff : 1;
+    std::vector<uint64_t> split(nsc * 4);
+    for (size_t k = 0; k < nsc; k++) hostf::glv_decompose(scalars + 4 * k, &split[4 * k], &split[4 * k + 2]);
+    auto zero = [](const uint64_t *w, int k) { uint64_t o = 0; for (int i = 0; i < k; i++) o |= w[i]; return o == 0; };
+    std::vector<uint8_t> skip(n_aff);
+    for (size_t i = 0; i < n_aff; i++)
+        skip[i] = (skip_aff && skip_aff[i]) || zero(&split[scalar_stride ? 4 * i : 0], 4) || zero(p_aff + 12 * i, 12) ? 1 : 0;
+    bool pipelined = n_aff <= 8192 && !gs.prof && (gs.ml_mode.load() & 1);
+    if (pipelined) { MlActive probe(cur().ml_active); pipelined = probe.v <= 2; }
+    if (!pipelined) {          // large batches (throughput-bound), stage timers on, or many loops in flight: the two calls one after the other
+        std::vector<uint64_t> scaled(n_aff * 12); std::vector<uint8_t> sinf(n_aff);
+        int32_t rc = dgpu_g1_scale_batch(p_aff, nullptr, scalars, scalar_stride, nullptr, n_aff, scaled.data(), sinf.data());
+        if (rc) return rc;
+        for (size_t i = 0; i < n_aff; i++) skip[i] |= sinf[i];
+        return dgpu_multi_miller_loop_mixed(scaled.data(), q_aff, skip.data(), n_aff, p_prep, coeffs, skip_prep, n_prep, out);
+    }
+    SLOT_ACQUIRE(slot_lock, sl);
+    HIPCHK(hipSetDevice(cur().device));
+    int32_t rc;
+    const size_t cbytes = n_prep * (size_t)DGPU_G2_PREPARED_WORDS * 8;
+    const size_t sc_off = (n_aff * 96 + n_aff + 63) & ~(size_t)63;            // prepped: [scaled points | their flags | pad | split scalars]
+    if ((rc = sl.in_bases.ensure(n * 96))) return rc;
+    if ((rc = sl.in_scalars.ensure(n_aff * 192 + 16))) return rc;
+    if ((rc = sl.in_inf.ensure(n))) return rc;
+    if ((rc = sl.prepped.ensure(sc_off + nsc * 32))) return rc;
+    if ((rc = sl.ml_coeffs.ensure(cbytes + 16))) return rc;
+    if ((rc = sl.ml_lines.ensure((size_t)N_LINES * LW * n * 4))) return rc;
+    hipStream_t s = sl.stream;
+    uint32_t *dp = sl.in_bases.as<uint32_t>();
+    uint8_t *dsk = sl.in_inf.as<uint8_t>();
+    HIPCHK(hipMemcpyAsync(sl.in_scalars.p, q_aff, n_aff * 192, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(dsk, skip.data(), n_aff, hipMemcpyHostToDevice, s));
+    if (n_prep) {
+        HIPCHK(hipMemcpyAsync(dp + n_aff * 24, p_prep, n_prep * 96, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(sl.ml_coeffs.p, coeffs, cbytes, hipMemcpyHostToDevice, s));
+        if (skip_prep) HIPCHK(hipMemcpyAsync(dsk + n_aff, skip_prep, n_prep, hipMemcpyHostToDevice, s));
+    }
+    MlActive act(cur().ml_active);
+    uint32_t *lines = sl.ml_lines.as<uint32_t>();
+    uint32_t *scaled = sl.prepped.as<uint32_t>(); uint8_t *scaled_inf = sl.prepped.as<uint8_t>() + n_aff * 96;
+    uint32_t *dsplit = (uint32_t *)(sl.prepped.as<uint8_t>() + sc_off);
+    return ml_pipelined(sl, n, n_aff, dsk, out, [&](uint32_t *pxy) {
+        if (n_prep)
+            hipLaunchKernelGGL(k_lines_from_prepared, dim3((unsigned)((n_prep * N_LINES + 255) / 256)), dim3(256), 0, s, dp + n_aff * 24, sl.ml_coeffs.as<uint32_t>(),
+                               skip_prep ? dsk + n_aff : (const uint8_t *)nullptr, n_prep, lines + n_aff, n, pxy + n_aff);
+    }, [&](hipStream_t side, uint32_t *pxy) -> int32_t {
+        // the chain of the Q_i is queued: the scalings run beside it on the side stream, their results go straight to px, py
+        if (hipMemcpyAsync(dp, p_aff, n_aff * 96, hipMemcpyHostToDevice, side) != hipSuccess) return DGPU_E_HIP;
+        if (hipMemcpyAsync(dsplit, split.data(), nsc * 32, hipMemcpyHostToDevice, side) != hipSuccess) return DGPU_E_HIP;
+        msm::launch_g1_scale_quad(side, dp, nullptr, dsplit, (int)(scalar_stride * 2), nullptr, n_aff, scaled, scaled_inf);
+        hipLaunchKernelGGL(k_pxy_from_abi, dim3((unsigned)((2 * n_aff + 255) / 256)), dim3(256), 0, side, (const uint32_t *)scaled, n_aff, pxy, n);
+        return hipGetLastError() == hipSuccess ? DGPU_OK : DGPU_E_HIP;
+    }, true);
 }
 
 // ---- the LegoGroth16 verifier as one call (legogroth16/src/verifier.rs:62-99 `verify_proof`: calculate_d :29-50,101-109, then verify_qap_proof) ----

@@ -134,6 +134,36 @@ def multi_miller_loop(ps, qs, skip=None):
     return out
 
 
+def multi_miller_loop_scaled(ps, scalars, qs, skip=None, prepared_ps=None, prepared=None):
+    """prod e([m_i] P_i, Q_i) (x prod e(P'_j, prepared_j)) in ONE call (dgpu_multi_miller_loop_scaled): the scalings of RandomizedPairingChecker
+    (utils/src/randomized_pairing_check.rs:125-134) run beside the chain of the Q_i instead of in front of it.  scalars: one row of four canonical
+    words per pair, or a single scalar (an int or one row) for every pair; prepared: a G2Prepared for the pairs with prepared_ps."""
+    _ensure()
+    ps = np.ascontiguousarray(ps, dtype=np.uint64).reshape(-1, 12)
+    qs = np.ascontiguousarray(qs, dtype=np.uint64).reshape(-1, 24)
+    if len(ps) != len(qs):
+        raise DockGpuError(-7, "multi_miller_loop_scaled")
+    if isinstance(scalars, int):
+        scalars = np.array([(scalars >> (64 * k)) & 0xFFFFFFFFFFFFFFFF for k in range(4)], dtype=np.uint64)
+    sc = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+    if len(sc) not in (1, len(ps)) and len(ps):
+        raise DockGpuError(-7, "multi_miller_loop_scaled")
+    stride = 4 if len(sc) == len(ps) else 0
+    sk = None if skip is None else np.ascontiguousarray(skip, dtype=np.uint8)
+    pp = co = skp = None
+    n_prep = 0
+    if prepared is not None:
+        pp = np.ascontiguousarray(prepared_ps, dtype=np.uint64).reshape(-1, 12)
+        if len(pp) != len(prepared):
+            raise DockGpuError(-7, "multi_miller_loop_scaled")
+        co, skp, n_prep = prepared.coeffs, np.ascontiguousarray(prepared.infinity), len(pp)
+    out = np.zeros(72, dtype=np.uint64)
+    rc = lib().dgpu_multi_miller_loop_scaled(_p(ps), _p(sc), stride, _p(qs), _p(sk), len(ps), _p(pp), _p(co), _p(skp), n_prep, _p(out))
+    if rc:
+        raise DockGpuError(rc, "dgpu_multi_miller_loop_scaled")
+    return out
+
+
 def multi_miller_loop_sharded(ps, qs, skip=None, ngpus=0):
     """multi_miller_loop with the pairs chunked over the process's device contexts (dgpu_multi_miller_loop_sharded)"""
     _ensure()

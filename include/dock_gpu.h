@@ -226,6 +226,17 @@ int32_t dgpu_multi_miller_loop_prepared(const uint64_t *p_xy /* n*12 */, const u
 int32_t dgpu_multi_miller_loop_mixed(const uint64_t *p_aff /* n_aff x 12 */, const uint64_t *q_aff /* n_aff x 24 */, const uint8_t *skip_aff, size_t n_aff,
                                      const uint64_t *p_prep /* n_prep x 12 */, const uint64_t *coeffs /* n_prep x DGPU_G2_PREPARED_WORDS */, const uint8_t *skip_prep, size_t n_prep,
                                      uint64_t out_f12[72]);
+/* prod_i e([m_i] P_i, Q_i) x prod_j e(P'_j, prepared_j): the scalings of RandomizedPairingChecker and its Miller loop as ONE call
+ * (utils/src/randomized_pairing_check.rs:125-134 `a.mul_bigint(m)` per source, then :204-214 the lazy multi_miller_loop) — limb for limb what
+ * dgpu_g1_scale_batch followed by dgpu_multi_miller_loop_mixed returns.  The line coefficients of a pair depend on Q alone, so the chain of the Q_i
+ * and the scaling chains of the P_i run side by side and the scaled points never visit the host (1024 pairs: 1.9 -> 1.3 ms).
+ * scalars: n_aff x 4 canonical words (scalar_stride = 4) or ONE scalar for every pair (scalar_stride = 0), reduced mod r; a pair whose
+ * scaled point is the identity (m = 0 mod r, P all zero), whose Q is all zero or whose skip flag is set contributes one.  P_i in the
+ * prime-order subgroup (the invariant of arkworks' G1Affine: the scaling uses the endomorphism). */
+int32_t dgpu_multi_miller_loop_scaled(const uint64_t *p_aff /* n_aff x 12 */, const uint64_t *scalars, size_t scalar_stride, const uint64_t *q_aff /* n_aff x 24 */,
+                                      const uint8_t *skip_aff, size_t n_aff,
+                                      const uint64_t *p_prep /* n_prep x 12 */, const uint64_t *coeffs /* n_prep x DGPU_G2_PREPARED_WORDS */, const uint8_t *skip_prep, size_t n_prep,
+                                      uint64_t out_f12[72]);
 /* nseg independent Miller loops in one call: segment g is the pairs [seg_end[g - 1], seg_end[g]) (ascending, seg_end[nseg - 1] == n; an empty
  * segment yields one); out_f12 = nseg x 72 words, each what dgpu_multi_miller_loop returns for that segment alone.  Serves the
  * mutually independent `E::multi_pairing` calls the aggregation issues one after another (legogroth16/src/aggregation/commitment.rs:30-31,54-67,

@@ -212,6 +212,7 @@ inline BigInt256 add_mod(const BigInt256 &a, const BigInt256 &b) {          // a
     if (c || geq(s, FR_MODULUS)) { unsigned __int128 br = 0; for (int i = 0; i < 4; i++) { unsigned __int128 d = (unsigned __int128)s[i] - FR_MODULUS[i] - (uint64_t)br; s[i] = (uint64_t)d; br = (d >> 64) & 1; } }
     return s;
 }
+inline BigInt256 neg_mod(const BigInt256 &a) { BigInt256 z{}; if (a == z) return a; BigInt256 r = FR_MODULUS; unsigned __int128 br = 0; for (int i = 0; i < 4; i++) { unsigned __int128 d = (unsigned __int128)r[i] - a[i] - (uint64_t)br; r[i] = (uint64_t)d; br = (d >> 64) & 1; } return r; }          // a < r
 inline BigInt256 mul_mod(const BigInt256 &a, const BigInt256 &b) {          // double-and-add: a handful of calls per checker
     BigInt256 acc{};
     for (int i = 255; i >= 0; i--) { acc = add_mod(acc, acc); if ((b[i / 64] >> (i % 64)) & 1) acc = add_mod(acc, a); }
@@ -228,12 +229,21 @@ class RandomizedPairingChecker {
     std::vector<Queued> pending_;
     std::vector<std::pair<Fq12, BigInt256>> pending_targets_;
     BigInt256 random_, current_random_{1, 0, 0, 0};
-    // [m a_i] (negated if asked), one launch
-    static std::vector<G1::Affine> scale(const std::vector<G1::Affine> &a, const std::vector<BigInt256> &m, const std::vector<uint8_t> &neg) {
-        Packed<G1> p(a, a.size());
-        std::vector<uint64_t> out(a.size() * 12); std::vector<uint8_t> oinf(a.size());
-        check(dgpu_g1_scale_batch(p.xy.data(), p.inf.data(), m[0].data(), m.size() == 1 ? 0 : 4, neg.empty() ? nullptr : neg.data(), a.size(), out.data(), oinf.data()), "g1_scale_batch");
-        return affine_from_abi<G1>(out, oinf);
+    // prod e([+-m_i] a_i, b_i) as ONE call (dgpu_multi_miller_loop_scaled: the scalings run beside the chain of the b_i); a negated source is scaled by r - m
+    static Fq12 scaled_miller_loop(const std::vector<G1::Affine> &a, const std::vector<BigInt256> &m, const std::vector<uint8_t> &neg, const std::vector<G2::Affine> &b) {
+        if (a.size() != b.size()) throw Error(DGPU_E_LENGTH, "scaled_miller_loop");
+        Packed<G1> p(a, a.size()); Packed<G2> q(b, b.size());
+        std::vector<uint8_t> skip(a.size());
+        for (size_t i = 0; i < a.size(); i++) skip[i] = p.inf[i] | q.inf[i];
+        std::vector<BigInt256> ms(m);
+        if (!neg.empty()) {
+            if (ms.size() == 1) ms.assign(a.size(), m[0]);
+            for (size_t i = 0; i < ms.size(); i++) if (neg[i]) ms[i] = detail::neg_mod(ms[i]);
+        }
+        Fq12 out{};
+        check(dgpu_multi_miller_loop_scaled(p.xy.data(), ms.empty() ? nullptr : ms[0].data(), ms.size() == 1 ? 0 : 4, q.xy.data(), skip.data(), a.size(), nullptr, nullptr, nullptr, 0, out.data()),
+              "multi_miller_loop_scaled");
+        return out;
     }
     void advance() { current_random_ = detail::mul_mod(current_random_, random_); }
 public:
@@ -248,7 +258,7 @@ public:
         const BigInt256 m = current_random_;
         if (lazy_) { pending_.push_back({a, m, false, b}); pending_targets_.push_back({out, m}); }
         else {
-            left_ = detail::fq12_mul(left_, multi_miller_loop(scale(a, {m}, {}), b));
+            left_ = detail::fq12_mul(left_, scaled_miller_loop(a, {m}, {}, b));
             Fq12 pw{}; check(dgpu_fp12_pow(out.data(), m.data(), pw.data()), "fp12_pow");
             right_ = detail::fq12_mul(right_, pw);
         }
@@ -260,8 +270,8 @@ public:
         const BigInt256 m = current_random_;
         if (lazy_) { pending_.push_back({a, m, false, b}); pending_.push_back({c, m, true, d}); }
         else {
-            left_ = detail::fq12_mul(left_, multi_miller_loop(scale(a, {m}, {}), b));
-            left_ = detail::fq12_mul(left_, multi_miller_loop(scale(c, {m}, std::vector<uint8_t>(c.size(), 1)), d));
+            left_ = detail::fq12_mul(left_, scaled_miller_loop(a, {m}, {}, b));
+            left_ = detail::fq12_mul(left_, scaled_miller_loop(c, {m}, std::vector<uint8_t>(c.size(), 1), d));
         }
         advance();
     }
@@ -278,7 +288,7 @@ public:
         if (!pending_.empty()) {
             std::vector<G1::Affine> pts; std::vector<G2::Affine> qs; std::vector<BigInt256> ms; std::vector<uint8_t> neg;
             for (auto &q : pending_) for (size_t i = 0; i < q.a.size(); i++) { pts.push_back(q.a[i]); qs.push_back(q.b[i]); ms.push_back(q.m); neg.push_back(q.negate ? 1 : 0); }
-            left = detail::fq12_mul(multi_miller_loop(scale(pts, ms, neg), qs), left);
+            left = detail::fq12_mul(scaled_miller_loop(pts, ms, neg, qs), left);
             pending_.clear();
         }
         const auto gt = final_exponentiation(left);

@@ -102,6 +102,8 @@ extern "C" {
     pub fn dgpu_g2_prepare(q_xy: *const u64, is_inf: *const u8, n: usize, out_coeffs: *mut u64, out_inf: *mut u8) -> i32;
     pub fn dgpu_multi_miller_loop_mixed(p_aff: *const u64, q_aff: *const u64, skip_aff: *const u8, n_aff: usize,
                                         p_prep: *const u64, coeffs: *const u64, skip_prep: *const u8, n_prep: usize, out_f12: *mut u64) -> i32;
+    pub fn dgpu_multi_miller_loop_scaled(p_aff: *const u64, scalars: *const u64, scalar_stride: usize, q_aff: *const u64, skip_aff: *const u8, n_aff: usize,
+                                         p_prep: *const u64, coeffs: *const u64, skip_prep: *const u8, n_prep: usize, out_f12: *mut u64) -> i32;
     pub fn dgpu_final_exponentiation(in_f12: *const u64, out_f12: *mut u64) -> i32;
     pub fn dgpu_g1_scale_batch(p_xy: *const u64, is_inf: *const u8, scalars: *const u64, scalar_stride: usize, negate: *const u8, n: usize, out_xy: *mut u64, out_inf: *mut u8) -> i32;
     pub fn dgpu_r1cs_upload(a_rowptr: *const u64, a_cols: *const u32, a_vals: *const u64, a_nnz: usize,
@@ -282,6 +284,24 @@ pub fn multi_miller_loop_mixed(a_aff: &[G1Affine], b_aff: &[G2Affine], a_prep: &
         let g1 = a_aff.iter().chain(a_prep.iter()).copied();
         let g2 = b_aff.iter().map(|q| G2Prepared::from(*q)).chain(b_prep.iter().cloned());
         return Bls12_381::multi_miller_loop(g1, g2);
+    }
+    MillerLoopOutput(fq12_from_words(&out))
+}
+/// `multi_miller_loop(a_i.mul_bigint(m_i), b_i)` in ONE call — utils/src/randomized_pairing_check.rs:125-134 (the scalings of
+/// `add_multiple_sources_and_target`, then the loop): the scaling chains run beside the chain of the `b_i` on the device.  `m`: one scalar per
+/// pair, or a single one for all.  Falls back to arkworks on any error.
+pub fn multi_miller_loop_scaled(a: &[G1Affine], m: &[BigInt<4>], b: &[G2Affine]) -> MillerLoopOutput<Bls12_381> {
+    assert_eq!(a.len(), b.len()); assert!(m.len() == a.len() || m.len() == 1);
+    let ((p, pi), (q, qi)) = (pack_g1(a), pack_g2(b));
+    let skip: Vec<u8> = pi.iter().zip(qi.iter()).map(|(x, y)| x | y).collect();
+    let sc: Vec<u64> = m.iter().flat_map(|k| k.0).collect();
+    let mut out = [0u64; 72];
+    let rc = unsafe { dgpu_multi_miller_loop_scaled(p.as_ptr(), sc.as_ptr(), if m.len() == a.len() { 4 } else { 0 }, q.as_ptr(), skip.as_ptr(), a.len(),
+                                                    core::ptr::null(), core::ptr::null(), core::ptr::null(), 0, out.as_mut_ptr()) };
+    if rc != DGPU_OK {
+        use ark_ec::CurveGroup;
+        let scaled: Vec<G1Affine> = a.iter().enumerate().map(|(i, p)| p.mul_bigint(m[if m.len() == 1 { 0 } else { i }]).into_affine()).collect();
+        return Bls12_381::multi_miller_loop(scaled, b.iter().copied());
     }
     MillerLoopOutput(fq12_from_words(&out))
 }

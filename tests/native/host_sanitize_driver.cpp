@@ -126,6 +126,10 @@ int32_t dgpu_multi_miller_loop_mixed(const uint64_t *pa, const uint64_t *qa, con
     volatile uint64_t t = (na ? pa[12 * na - 1] ^ qa[24 * na - 1] ^ sa[na - 1] : 0) ^ (np ? pp[12 * np - 1] ^ co[(size_t)DGPU_G2_PREPARED_WORDS * np - 1] ^ sp[np - 1] : 0); (void)t;      // (reads the last word of every operand: sizes as the caller promised)
     memset(out, 0, 576); out[0] = 1; return step("mixed");
 }
+int32_t dgpu_multi_miller_loop_scaled(const uint64_t *pa, const uint64_t *sc, size_t stride, const uint64_t *qa, const uint8_t *sa, size_t na, const uint64_t *pp, const uint64_t *co, const uint8_t *sp, size_t np, uint64_t *out) {
+    volatile uint64_t t = (na ? pa[12 * na - 1] ^ qa[24 * na - 1] ^ sc[stride ? 4 * na - 1 : 3] ^ (sa ? sa[na - 1] : 0) : 0) ^ (np ? pp[12 * np - 1] ^ co[(size_t)DGPU_G2_PREPARED_WORDS * np - 1] ^ (sp ? sp[np - 1] : 0) : 0); (void)t;
+    memset(out, 0, 576); out[0] = 1; return step("scaled");
+}
 int32_t dgpu_g1_scale_batch(const uint64_t *p, const uint8_t *, const uint64_t *, size_t, const uint8_t *, size_t n, uint64_t *out, uint8_t *oi) { memcpy(out, p, n * 96); memset(oi, 0, n); return step("scale"); }
 static std::atomic<int> g_live_fold{0};
 int32_t dgpu_fold_prepare_pair(const uint64_t *p1, size_t n1, uint64_t *h1, const uint64_t *p2, size_t n2, uint64_t *h2) {

@@ -150,3 +150,37 @@ def test_checker_with_prepared_g2_operands(lazy):
     bad = ca.RandomizedPairingChecker(r, lazy)
     bad.add_multiple_sources_and_target(a, pairing.G2Prepared.from_affine(np.stack([g2(7), g2(9), g2(3)])), out)
     assert not bad.verify()
+
+
+@pytest.mark.parametrize("n,n_prep", [(1, 0), (3, 2), (70, 0), (1024, 2), (9000, 1)])
+def test_scaled_miller_loop_is_scale_then_miller(n, n_prep):
+    """dgpu_multi_miller_loop_scaled: prod e([m_i] P_i, Q_i) x prod e(P'_j, prepared_j), limb for limb what dgpu_g1_scale_batch followed by the Miller loop
+    returns (the scalings run beside the chain of the Q_i: utils/src/randomized_pairing_check.rs:125-134 as one call) and what the CPU oracle computes from
+    scaled points; zero scalars, identity points and skip flags drop their pair; one scalar for all pairs; n = 9000 takes the two-call form inside"""
+    from crypto_amd import pairing
+    rng = np.random.default_rng(900 + n)
+    P = O.G1.gen_seq(O.rand_scalars(61, 1)[0], O.rand_scalars(62, 1)[0], n + n_prep, threads=16)
+    Q = O.G2.gen_seq(O.rand_scalars(63, 1)[0], O.rand_scalars(64, 1)[0], n + n_prep, threads=16)
+    sc = O.rand_scalars(65 + n, n)
+    sc[rng.integers(0, 5, n) == 0, 2:] = 0                      # some short scalars
+    if n > 2:
+        sc[1] = 0                                               # a pair that drops out
+        P[2] = 0                                                # an identity point
+    skip = (rng.integers(0, 7, n) == 0).astype(np.uint8)
+    prep = pairing.G2Prepared.from_affine(Q[n:]) if n_prep else None
+    got = pairing.multi_miller_loop_scaled(P[:n], sc, Q[:n], skip, P[n:] if n_prep else None, prep)
+    scaled, sinf = pc.g1_scale_each(P[:n], sc)
+    sk = skip | sinf.astype(np.uint8)
+    if n_prep:
+        want = pairing.multi_miller_loop(np.concatenate([scaled, P[n:]]), [Q[:n], prep], np.concatenate([sk, np.zeros(n_prep, np.uint8)]))
+    else:
+        want = pairing.multi_miller_loop(scaled, Q[:n], sk)
+    assert (got == want).all()
+    if n <= 70:                                                 # the oracle on the same statement: scaled points by double-and-add, then its Miller loop
+        ps = np.stack([O.G1.to_affine(O.G1.mul(P[i], sc[i]))[0] for i in range(n)] + [P[n + j] for j in range(n_prep)])
+        osk = np.array([1 if (sk[i] or O.G1.to_affine(O.G1.mul(P[i], sc[i]))[1]) else 0 for i in range(n)] + [0] * n_prep, dtype=np.uint8)
+        assert (got == O.multi_miller_loop(ps, Q, osk, threads=8)).all()
+    # one scalar for every pair
+    one = pairing.multi_miller_loop_scaled(P[:n], sc[0], Q[:n], skip)
+    s1, i1 = pc.g1_scale(P[:n], int(sc[0][0]) | int(sc[0][1]) << 64 | int(sc[0][2]) << 128 | int(sc[0][3]) << 192)
+    assert (one == pairing.multi_miller_loop(s1, Q[:n], skip | i1.astype(np.uint8))).all()

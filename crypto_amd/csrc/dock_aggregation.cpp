@@ -433,10 +433,8 @@ struct Checker {
         par({[&] { if (!targets.empty()) { const Vec e = canon_words(target_exp); ck(dgpu_fp12_multi_pow(targets[0].data(), e.data(), targets.size(), right.data())); } },   // host cores
              [&] {                                                                                                                                                              // the device
                  if (!n) return;
-                 Vec scaled(12 * n); std::vector<uint8_t> inf(n);
-                 ck(dgpu_g1_scale_batch(pts.data(), nullptr, sc.data(), 4, nullptr, n, scaled.data(), inf.data()));
-                 for (size_t i = 0; i < n; i++) inf[i] |= is_id(&qs[24 * i], 24) || is_id(&scaled[12 * i], 12);
-                 ck(dgpu_multi_miller_loop(scaled.data(), qs.data(), inf.data(), n, left.data()));
+                 // the scalings beside the line chain, in one call (a pair with an identity member, before or after the scaling, contributes one)
+                 ck(dgpu_multi_miller_loop_scaled(pts.data(), sc.data(), 4, qs.data(), nullptr, n, nullptr, nullptr, nullptr, 0, left.data()));
              }});
         Gt gt;
         const int32_t rc = dgpu_final_exponentiation(left.data(), gt.data());

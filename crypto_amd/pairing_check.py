@@ -187,9 +187,15 @@ class RandomizedPairingChecker:
             pts = np.concatenate([a for a, _, _ in self.pending[0]])
             sc = np.concatenate([np.tile(_limbs(m), (len(a), 1)) for a, m, _ in self.pending[0]])
             ng = np.concatenate([np.full(len(a), 1 if neg else 0, dtype=np.uint8) for a, _, neg in self.pending[0]])
-            ps, _ = g1_scale_each(pts, sc, ng)
             qs = _g2_all(self.pending[1])
-            left = fp12_mul(pairing.multi_miller_loop(ps, qs), left)    # identity members are all-zero words: skipped on the device
+            if isinstance(qs, np.ndarray):
+                # every G2 operand affine: the scalings and the Miller loop as ONE call (dgpu_multi_miller_loop_scaled: the scaling chains run beside
+                # the line chain of the G2 members); a negated source is scaled by r - m
+                ms = np.concatenate([np.tile(_limbs((R_MOD - m) % R_MOD if neg else m), (len(a), 1)) for a, m, neg in self.pending[0]])
+                left = fp12_mul(pairing.multi_miller_loop_scaled(pts, ms, qs), left)
+            else:
+                ps, _ = g1_scale_each(pts, sc, ng)
+                left = fp12_mul(pairing.multi_miller_loop(ps, qs), left)    # identity members are all-zero words: skipped on the device
         gt = pairing.final_exponentiation(left)
         if gt is None:
             raise ValueError("final_exponentiation of zero")           # arkworks: .unwrap() panics

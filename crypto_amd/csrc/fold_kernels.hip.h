@@ -350,4 +350,117 @@ __global__ void __launch_bounds__(64) k_g1_scale_quad(const uint32_t *__restrict
     if (q4.role == 0) fs_to_abi(o, x); else if (q4.role == 1) fs_to_abi(o + 12, y);
 }
 
+// ---- the same with TWO quads per point, in different waves: the high and the low part of the chain side by side ---------------------------------
+// A chain of 64 two-bit steps is 128 doublings whatever is added between them.  Split at bit 2 SPLIT: wave 0's quad of a point runs the top 64 - SPLIT
+// steps and then 2 SPLIT bare doublings (its part is worth 4^SPLIT times what its digits say), wave 1's quad the low SPLIT steps; the halves meet through
+// LDS and wave 1 adds them, inverts and writes.  SPLIT = 46: 18 x 10 + 92 x 3 = 456 rounds against 46 x 10 = 460, instead of 640 — the two quads must be
+// in different waves for that (in one wave they would run in lockstep through each other's additions).  Both waves build the table (the same values to
+// the same words).  57 KB of LDS per 128-lane block of sixteen points.
+constexpr int SCO_SPLIT = 46;
+__global__ void __launch_bounds__(128) k_g1_scale_oct(const uint32_t *__restrict__ p_abi, const uint8_t *__restrict__ is_inf, const uint32_t *__restrict__ scalars, int scalar_stride,
+                                                      const uint8_t *__restrict__ negate, size_t n, uint32_t *__restrict__ out_abi, uint8_t *__restrict__ out_inf,
+                                                      const uint32_t *__restrict__ add_abi, const uint8_t *__restrict__ add_inf) {
+    typedef Fs F;
+    __shared__ uint32_t tab[16 * SCQ_STRIDE];
+    __shared__ uint32_t hand[16 * (SCQ_ENTRY + 1)];                         // wave 0's part of every point (+ its identity flag)
+    const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6), pq = lane >> 2;
+    const size_t i_raw = (size_t)blockIdx.x * 16 + pq;
+    const bool live = i_raw < n;                                             // (padding quads follow the barriers and write nothing)
+    const size_t i = live ? i_raw : 0;
+    const QuadLanes<1> q4;
+    uint32_t *const mine = tab + pq * SCQ_STRIDE;
+    uint32_t any = 0;
+    for (int k = 0; k < 24; k++) any |= p_abi[i * 24 + k];
+    const bool pinf = !live || (any == 0) || (is_inf && is_inf[i]);
+    auto park_at = [&](uint32_t *base, const Xyzz<F> &x) __attribute__((always_inline)) {
+        const uint32_t *wx = reinterpret_cast<const uint32_t *>(&x);
+        uint32_t *dst = base + q4.role * SN;
+#pragma unroll
+        for (int j = 0; j < SN; j++) dst[j] = pick4(q4.role, wx[j], wx[SN + j], wx[2 * SN + j], wx[3 * SN + j]);
+    };
+    auto fetch_at = [&](Xyzz<F> &x, const uint32_t *src) __attribute__((always_inline)) {
+        uint32_t *o = reinterpret_cast<uint32_t *>(&x);
+#pragma unroll
+        for (int j = 0; j < SCQ_ENTRY; j++) o[j] = src[j];
+    };
+    if (!pinf) {
+        F beta;
+        {
+            constexpr uint32_t B_[NL] = BLS29_BETA;
+            Fp b29; uint32_t w[12];
+#pragma unroll
+            for (int k = 0; k < NL; k++) b29.l[k] = B_[k];
+            CHK(chk_set_N(b29, 1.0);)
+            fp_to_abi(w, b29); fs_from_abi(beta, w);
+        }
+        Xyzz<F> P1, M;
+        fs_from_abi(P1.x, p_abi + i * 24); fs_from_abi(P1.y, p_abi + i * 24 + 12); fset_one(P1.zz); fset_one(P1.zzz);
+        park_at(mine + 1 * SCQ_ENTRY, P1);
+        xyzz_dbl_rounds(M, P1, q4); park_at(mine + 2 * SCQ_ENTRY, M);
+        { bool f = false; xyzz_add_rounds(M, f, P1, false, q4); } park_at(mine + 3 * SCQ_ENTRY, M);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll 1
+        for (int d2 = 1; d2 < 4; d2++) {
+            Xyzz<F> Q; fetch_at(Q, mine + d2 * SCQ_ENTRY);
+            { F xn; fnorm(xn, Q.x); fmul(Q.x, xn, beta); }
+            park_at(mine + 4 * d2 * SCQ_ENTRY, Q);
+#pragma unroll 1
+            for (int d1 = 1; d1 < 4; d1++) {
+                Xyzz<F> S; fetch_at(S, mine + d1 * SCQ_ENTRY);
+                bool f = false; xyzz_add_rounds(S, f, Q, false, q4);
+                park_at(mine + (4 * d2 + d1) * SCQ_ENTRY, S);
+            }
+        }
+    }
+    __syncthreads();                                                         // (both waves wrote the same table; every lane of the block is here)
+    Xyzz<F> acc; bool inf = true;
+    fzero(acc.x); fzero(acc.y); fzero(acc.zz); fzero(acc.zzz);
+    const uint32_t *s = scalars + i * (size_t)scalar_stride;                 // (k1 | k2), four words each
+    auto step = [&](int b) __attribute__((always_inline)) {                  // two doublings, then the entry the bits b + 1, b of k1 and k2 name
+        { Xyzz<F> d; xyzz_dbl_rounds(d, acc, q4); xyzz_dbl_rounds(acc, d, q4); }
+        const uint32_t sel = ((s[b >> 5] >> (b & 31)) & 3u) | (((s[4 + (b >> 5)] >> (b & 31)) & 3u) << 2);
+        Xyzz<F> B; fetch_at(B, mine + (sel ? (int)sel : 1) * SCQ_ENTRY);
+        xyzz_add_rounds(acc, inf, B, sel == 0, q4);
+    };
+    if (wave == 0) {
+        if (!pinf) {
+#pragma unroll 1
+            for (int b = 126; b >= 2 * SCO_SPLIT; b -= 2) step(b);
+#pragma unroll 1
+            for (int k = 0; k < SCO_SPLIT; k++) { Xyzz<F> d; xyzz_dbl_rounds(d, acc, q4); xyzz_dbl_rounds(acc, d, q4); }
+        }
+        park_at(hand + pq * (SCQ_ENTRY + 1), acc);
+        if (q4.role == 0) hand[pq * (SCQ_ENTRY + 1) + SCQ_ENTRY] = inf ? 1u : 0u;
+    } else if (!pinf) {
+#pragma unroll 1
+        for (int b = 2 * SCO_SPLIT - 2; b >= 0; b -= 2) step(b);
+    }
+    __syncthreads();
+    if (wave == 0 || !live) return;
+    {
+        Xyzz<F> hi; fetch_at(hi, hand + pq * (SCQ_ENTRY + 1));
+        const bool hinf = hand[pq * (SCQ_ENTRY + 1) + SCQ_ENTRY] != 0;
+        xyzz_add_rounds(acc, inf, hi, hinf, q4);
+    }
+    if (add_abi) {
+        const uint32_t *src = add_abi + i * 24;
+        uint32_t nz = 0;
+        for (int k = 0; k < 24; k++) nz |= src[k];
+        Xyzz<F> A; fs_from_abi(A.x, src); fs_from_abi(A.y, src + 12); fset_one(A.zz); fset_one(A.zzz);
+        xyzz_add_rounds(acc, inf, A, nz == 0 || (add_inf && add_inf[i]), q4);
+    }
+    uint32_t *o = out_abi + i * 24;
+    if (q4.role == 0) out_inf[i] = inf;
+    if (inf) { if (q4.role == 0) for (int k = 0; k < 24; k++) o[k] = 0; return; }
+    Fp z29, i29; F i3, t, i2, xn, yn, x, y;
+    fnorm(t, acc.zzz); fp_from_fs(z29, t);
+    fp_inv_device(i29, z29);
+    fs_from_fp(i3, i29);
+    fnorm(t, acc.zz); fmul(t, t, i3); fsqr(i2, t);
+    fnorm(xn, acc.x); fnorm(yn, acc.y);
+    fmul(x, xn, i2); fmul(y, yn, i3);
+    fcond_neg(y, negate && negate[i]);
+    if (q4.role == 0) fs_to_abi(o, x); else if (q4.role == 1) fs_to_abi(o + 12, y);
+}
+
 }  // namespace msm

@@ -350,19 +350,21 @@ __global__ void __launch_bounds__(64) k_g1_scale_quad(const uint32_t *__restrict
     if (q4.role == 0) fs_to_abi(o, x); else if (q4.role == 1) fs_to_abi(o + 12, y);
 }
 
-// ---- the same with TWO quads per point, in different waves: the high and the low part of the chain side by side ---------------------------------
-// A chain of 64 two-bit steps is 128 doublings whatever is added between them.  Split at bit 2 SPLIT: wave 0's quad of a point runs the top 64 - SPLIT
-// steps and then 2 SPLIT bare doublings (its part is worth 4^SPLIT times what its digits say), wave 1's quad the low SPLIT steps; the halves meet through
-// LDS and wave 1 adds them, inverts and writes.  SPLIT = 46: 18 x 10 + 92 x 3 = 456 rounds against 46 x 10 = 460, instead of 640 — the two quads must be
-// in different waves for that (in one wave they would run in lockstep through each other's additions).  Both waves build the table (the same values to
-// the same words).  57 KB of LDS per 128-lane block of sixteen points.
-constexpr int SCO_SPLIT = 46;
-__global__ void __launch_bounds__(128) k_g1_scale_oct(const uint32_t *__restrict__ p_abi, const uint8_t *__restrict__ is_inf, const uint32_t *__restrict__ scalars, int scalar_stride,
-                                                      const uint8_t *__restrict__ negate, size_t n, uint32_t *__restrict__ out_abi, uint8_t *__restrict__ out_inf,
-                                                      const uint32_t *__restrict__ add_abi, const uint8_t *__restrict__ add_inf) {
+// ---- the same with FOUR quads per point, in different waves: the pieces of the chain side by side ----------------------------------------------
+// A chain of 64 two-bit steps is 128 doublings whatever is added between them.  Cut into pieces: the quad that owns the steps [L, H) runs them and then
+// 2 L bare doublings (its digits are worth 4^L times what they say) — 10 (H - L) + 6 L product-depths; with the cuts at steps 40, 56, 62 the four pieces
+// cost 400, 400, 396, 392 instead of the 640 of one quad.  The quads of a point sit in DIFFERENT waves of a 256-lane block of sixteen points (in one wave
+// they would run in lockstep through each other's additions); every wave builds P, 2 P, 3 P, waves 1 .. 3 one row d2 phi(P) + d1 P of the table each
+// (20 depths instead of 44); the pieces meet through LDS and wave 3 adds them, inverts and writes.  62 KB of LDS per block.
+constexpr int SCO_WAVES = 4;
+__device__ constexpr int SCO_LO[SCO_WAVES] = {62, 56, 40, 0}, SCO_HI[SCO_WAVES] = {64, 62, 56, 40};      // wave w owns the steps [LO, HI): bits 2 LO .. 2 HI - 1
+__global__ void __launch_bounds__(64 * SCO_WAVES) k_g1_scale_oct(const uint32_t *__restrict__ p_abi, const uint8_t *__restrict__ is_inf, const uint32_t *__restrict__ scalars, int scalar_stride,
+                                                                 const uint8_t *__restrict__ negate, size_t n, uint32_t *__restrict__ out_abi, uint8_t *__restrict__ out_inf,
+                                                                 const uint32_t *__restrict__ add_abi, const uint8_t *__restrict__ add_inf) {
     typedef Fs F;
+    constexpr int HW = SCQ_ENTRY + 1;
     __shared__ uint32_t tab[16 * SCQ_STRIDE];
-    __shared__ uint32_t hand[16 * (SCQ_ENTRY + 1)];                         // wave 0's part of every point (+ its identity flag)
+    __shared__ uint32_t hand[(SCO_WAVES - 1) * 16 * HW];                     // the pieces of waves 0 .. 2 of every point (+ identity flags)
     const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6), pq = lane >> 2;
     const size_t i_raw = (size_t)blockIdx.x * 16 + pq;
     const bool live = i_raw < n;                                             // (padding quads follow the barriers and write nothing)
@@ -384,63 +386,61 @@ __global__ void __launch_bounds__(128) k_g1_scale_oct(const uint32_t *__restrict
         for (int j = 0; j < SCQ_ENTRY; j++) o[j] = src[j];
     };
     if (!pinf) {
-        F beta;
-        {
-            constexpr uint32_t B_[NL] = BLS29_BETA;
-            Fp b29; uint32_t w[12];
-#pragma unroll
-            for (int k = 0; k < NL; k++) b29.l[k] = B_[k];
-            CHK(chk_set_N(b29, 1.0);)
-            fp_to_abi(w, b29); fs_from_abi(beta, w);
-        }
-        Xyzz<F> P1, M;
+        Xyzz<F> P1, P2, P3;
         fs_from_abi(P1.x, p_abi + i * 24); fs_from_abi(P1.y, p_abi + i * 24 + 12); fset_one(P1.zz); fset_one(P1.zzz);
-        park_at(mine + 1 * SCQ_ENTRY, P1);
-        xyzz_dbl_rounds(M, P1, q4); park_at(mine + 2 * SCQ_ENTRY, M);
-        { bool f = false; xyzz_add_rounds(M, f, P1, false, q4); } park_at(mine + 3 * SCQ_ENTRY, M);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll 1
-        for (int d2 = 1; d2 < 4; d2++) {
-            Xyzz<F> Q; fetch_at(Q, mine + d2 * SCQ_ENTRY);
+        xyzz_dbl_rounds(P2, P1, q4);
+        P3 = P2; { bool f = false; xyzz_add_rounds(P3, f, P1, false, q4); }
+        if (wave == 0) { park_at(mine + 1 * SCQ_ENTRY, P1); park_at(mine + 2 * SCQ_ENTRY, P2); park_at(mine + 3 * SCQ_ENTRY, P3); }
+        else {                                                               // row d2 = wave: phi(d2 P) (x times beta), then + d1 P
+            F beta;
+            {
+                constexpr uint32_t B_[NL] = BLS29_BETA;
+                Fp b29; uint32_t w[12];
+#pragma unroll
+                for (int k = 0; k < NL; k++) b29.l[k] = B_[k];
+                CHK(chk_set_N(b29, 1.0);)
+                fp_to_abi(w, b29); fs_from_abi(beta, w);
+            }
+            Xyzz<F> Q = wave == 1 ? P1 : (wave == 2 ? P2 : P3);
             { F xn; fnorm(xn, Q.x); fmul(Q.x, xn, beta); }
-            park_at(mine + 4 * d2 * SCQ_ENTRY, Q);
+            park_at(mine + 4 * wave * SCQ_ENTRY, Q);
 #pragma unroll 1
             for (int d1 = 1; d1 < 4; d1++) {
-                Xyzz<F> S; fetch_at(S, mine + d1 * SCQ_ENTRY);
-                bool f = false; xyzz_add_rounds(S, f, Q, false, q4);
-                park_at(mine + (4 * d2 + d1) * SCQ_ENTRY, S);
+                Xyzz<F> S = d1 == 1 ? P1 : (d1 == 2 ? P2 : P3);
+                bool f = false; xyzz_add_rounds(S, f, Q, false, q4);         // (d1 + d2 lambda) P: never the identity, and d1 P != +- d2 phi(P)
+                park_at(mine + (4 * wave + d1) * SCQ_ENTRY, S);
             }
         }
     }
-    __syncthreads();                                                         // (both waves wrote the same table; every lane of the block is here)
+    __syncthreads();                                                         // (the table is complete; every lane of the block is here)
     Xyzz<F> acc; bool inf = true;
     fzero(acc.x); fzero(acc.y); fzero(acc.zz); fzero(acc.zzz);
     const uint32_t *s = scalars + i * (size_t)scalar_stride;                 // (k1 | k2), four words each
-    auto step = [&](int b) __attribute__((always_inline)) {                  // two doublings, then the entry the bits b + 1, b of k1 and k2 name
-        { Xyzz<F> d; xyzz_dbl_rounds(d, acc, q4); xyzz_dbl_rounds(acc, d, q4); }
-        const uint32_t sel = ((s[b >> 5] >> (b & 31)) & 3u) | (((s[4 + (b >> 5)] >> (b & 31)) & 3u) << 2);
-        Xyzz<F> B; fetch_at(B, mine + (sel ? (int)sel : 1) * SCQ_ENTRY);
-        xyzz_add_rounds(acc, inf, B, sel == 0, q4);
-    };
-    if (wave == 0) {
-        if (!pinf) {
+    if (!pinf) {
+        const int lo = SCO_LO[wave], hi = SCO_HI[wave];
 #pragma unroll 1
-            for (int b = 126; b >= 2 * SCO_SPLIT; b -= 2) step(b);
-#pragma unroll 1
-            for (int k = 0; k < SCO_SPLIT; k++) { Xyzz<F> d; xyzz_dbl_rounds(d, acc, q4); xyzz_dbl_rounds(acc, d, q4); }
+        for (int j = hi - 1; j >= lo; j--) {                                 // two doublings, then the entry the bits 2 j + 1, 2 j of k1 and k2 name
+            { Xyzz<F> d; xyzz_dbl_rounds(d, acc, q4); xyzz_dbl_rounds(acc, d, q4); }
+            const int b = 2 * j;
+            const uint32_t sel = ((s[b >> 5] >> (b & 31)) & 3u) | (((s[4 + (b >> 5)] >> (b & 31)) & 3u) << 2);
+            Xyzz<F> B; fetch_at(B, mine + (sel ? (int)sel : 1) * SCQ_ENTRY);
+            xyzz_add_rounds(acc, inf, B, sel == 0, q4);
         }
-        park_at(hand + pq * (SCQ_ENTRY + 1), acc);
-        if (q4.role == 0) hand[pq * (SCQ_ENTRY + 1) + SCQ_ENTRY] = inf ? 1u : 0u;
-    } else if (!pinf) {
 #pragma unroll 1
-        for (int b = 2 * SCO_SPLIT - 2; b >= 0; b -= 2) step(b);
+        for (int k = 0; k < lo; k++) { Xyzz<F> d; xyzz_dbl_rounds(d, acc, q4); xyzz_dbl_rounds(acc, d, q4); }
+    }
+    if (wave < SCO_WAVES - 1) {
+        uint32_t *h = hand + (wave * 16 + pq) * HW;
+        park_at(h, acc);
+        if (q4.role == 0) h[SCQ_ENTRY] = inf ? 1u : 0u;
     }
     __syncthreads();
-    if (wave == 0 || !live) return;
-    {
-        Xyzz<F> hi; fetch_at(hi, hand + pq * (SCQ_ENTRY + 1));
-        const bool hinf = hand[pq * (SCQ_ENTRY + 1) + SCQ_ENTRY] != 0;
-        xyzz_add_rounds(acc, inf, hi, hinf, q4);
+    if (wave != SCO_WAVES - 1 || !live) return;
+#pragma unroll 1
+    for (int w = 0; w < SCO_WAVES - 1; w++) {
+        const uint32_t *h = hand + (w * 16 + pq) * HW;
+        Xyzz<F> part; fetch_at(part, h);
+        xyzz_add_rounds(acc, inf, part, h[SCQ_ENTRY] != 0, q4);
     }
     if (add_abi) {
         const uint32_t *src = add_abi + i * 24;

@@ -41,9 +41,9 @@ template void launch_fb_mul<G1>(hipStream_t, const uint32_t *, const uint32_t *,
 template void launch_fb_mul<G2>(hipStream_t, const uint32_t *, const uint32_t *, size_t, uint32_t *, uint8_t *);
 void launch_g1_scale_quad(hipStream_t s, const uint32_t *p_abi, const uint8_t *is_inf, const uint32_t *scalars, int scalar_stride, const uint8_t *negate, size_t n, uint32_t *out_abi, uint8_t *out_inf,
                           const uint32_t *add_abi, const uint8_t *add_inf) {
-    // up to 8192 points (two blocks of sixteen per CU in one round of the chip) the chain is what a call lasts: two quads per point in two waves; beyond, the
-    // one-quad form (half the lanes per point)
-    if (n <= 8192) hipLaunchKernelGGL(k_g1_scale_oct, dim3((unsigned)((n + 15) / 16)), dim3(128), 0, s, p_abi, is_inf, scalars, scalar_stride, negate, n, out_abi, out_inf, add_abi, add_inf);
+    // up to 4096 points (a block of sixteen per CU in one round of the chip) the chain is what a call lasts: four quads per point in four waves; beyond, the
+    // one-quad form (a quarter of the lanes per point)
+    if (n <= 4096) hipLaunchKernelGGL(k_g1_scale_oct, dim3((unsigned)((n + 15) / 16)), dim3(64 * SCO_WAVES), 0, s, p_abi, is_inf, scalars, scalar_stride, negate, n, out_abi, out_inf, add_abi, add_inf);
     else hipLaunchKernelGGL(k_g1_scale_quad, dim3((unsigned)((4 * n + 63) / 64)), dim3(64), 0, s, p_abi, is_inf, scalars, scalar_stride, negate, n, out_abi, out_inf, add_abi, add_inf);
 }
 // the folding step with its doubling chains done ahead of the scalar (fold_kernels.hip.h)

@@ -184,3 +184,17 @@ def test_scaled_miller_loop_is_scale_then_miller(n, n_prep):
     one = pairing.multi_miller_loop_scaled(P[:n], sc[0], Q[:n], skip)
     s1, i1 = pc.g1_scale(P[:n], int(sc[0][0]) | int(sc[0][1]) << 64 | int(sc[0][2]) << 128 | int(sc[0][3]) << 192)
     assert (one == pairing.multi_miller_loop(s1, Q[:n], skip | i1.astype(np.uint8))).all()
+
+
+def test_scaled_miller_loop_from_many_threads():
+    """six host threads call dgpu_multi_miller_loop_scaled at once (slots, side streams and the pipelined / two-call forms mix): every call returns what a lone call returns"""
+    from concurrent.futures import ThreadPoolExecutor
+    from crypto_amd import pairing
+    n = 300
+    P = O.G1.gen_seq(O.rand_scalars(71, 1)[0], O.rand_scalars(72, 1)[0], n, threads=16)
+    Q = O.G2.gen_seq(O.rand_scalars(73, 1)[0], O.rand_scalars(74, 1)[0], n, threads=16)
+    scs = [O.rand_scalars(80 + k, n) for k in range(4)]
+    want = [pairing.multi_miller_loop_scaled(P, sc, Q) for sc in scs]
+    with ThreadPoolExecutor(6) as ex:
+        got = list(ex.map(lambda k: pairing.multi_miller_loop_scaled(P, scs[k % 4], Q), range(48)))
+    assert all((got[k] == want[k % 4]).all() for k in range(48))

@@ -103,6 +103,20 @@ pub fn multi_miller_loop_affine<E: Pairing>(a: &[E::G1Affine], b: &[E::G2Affine]
     }
     E::multi_miller_loop(a.iter().copied(), b.iter().copied())
 }
+/// `E::multi_miller_loop(a_i.mul_bigint(m), b_i)` — the scalings of `RandomizedPairingChecker::add_multiple_sources[_and_target]` and the loop
+/// they feed (randomized_pairing_check.rs:125-134,152-170) as ONE call for a caller that holds the G2 operands affine: on the device the scaling
+/// chains run beside the line chain of the `b_i` (`dgpu_multi_miller_loop_scaled`); arkworks for other curves and below the size where a launch pays
+pub fn multi_miller_loop_scaled<E: Pairing>(a: &[E::G1Affine], m: <E::ScalarField as PrimeField>::BigInt, b: &[E::G2Affine]) -> MillerLoopOutput<E> {
+    assert_eq!(a.len(), b.len(), "multi_miller_loop: lengths differ");
+    if same::<E, Bls12_381>() && a.len() >= MIN_PAIRS_GPU {
+        let m4: BigInt<4> = unsafe { cast_val(m) };
+        let out = crate::multi_miller_loop_scaled(unsafe { cast_slice::<E::G1Affine, G1Affine>(a) }, &[m4], unsafe { cast_slice::<E::G2Affine, G2Affine>(b) });
+        return unsafe { cast_val::<MillerLoopOutput<Bls12_381>, MillerLoopOutput<E>>(out) };
+    }
+    use ark_ec::CurveGroup;
+    let scaled: Vec<E::G1Affine> = E::G1::normalize_batch(&a.iter().map(|p| p.mul_bigint(m)).collect::<Vec<_>>());
+    E::multi_miller_loop(scaled, b.iter().copied())
+}
 /// `E::final_exponentiation(f)` — randomized_pairing_check.rs:213, verifier.rs:78
 pub fn final_exponentiation<E: Pairing>(f: MillerLoopOutput<E>) -> Option<PairingOutput<E>> {
     if same::<E, Bls12_381>() {

@@ -152,11 +152,11 @@ def test_checker_with_prepared_g2_operands(lazy):
     assert not bad.verify()
 
 
-@pytest.mark.parametrize("n,n_prep", [(1, 0), (3, 2), (70, 0), (1024, 2), (9000, 1)])
+@pytest.mark.parametrize("n,n_prep", [(1, 0), (3, 2), (70, 0), (1024, 2), (5000, 0), (9000, 1)])
 def test_scaled_miller_loop_is_scale_then_miller(n, n_prep):
     """dgpu_multi_miller_loop_scaled: prod e([m_i] P_i, Q_i) x prod e(P'_j, prepared_j), limb for limb what dgpu_g1_scale_batch followed by the Miller loop
     returns (the scalings run beside the chain of the Q_i: utils/src/randomized_pairing_check.rs:125-134 as one call) and what the CPU oracle computes from
-    scaled points; zero scalars, identity points and skip flags drop their pair; one scalar for all pairs; n = 9000 takes the two-call form inside"""
+    scaled points; zero scalars, identity points and skip flags drop their pair; one scalar for all pairs; n = 5000 scales with one quad per point inside the one-call form, n = 9000 takes the two-call form"""
     from crypto_amd import pairing
     rng = np.random.default_rng(900 + n)
     P = O.G1.gen_seq(O.rand_scalars(61, 1)[0], O.rand_scalars(62, 1)[0], n + n_prep, threads=16)

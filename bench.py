@@ -24,6 +24,7 @@ cross-check of the GPU result.
 import argparse
 import json
 import os
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # before the process's first HIP call (PyTorch's, here): see prefer_eight_hw_queues in crypto_amd/csrc/dock_core.hip
 import sys
 import time
 

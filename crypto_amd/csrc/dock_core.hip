@@ -1,5 +1,6 @@
 // crypto_amd/csrc/dock_core.hip — lifecycle, handles, error strings and instrumentation of libdock_gpu.so
 // (implements the curve-independent part of include/dock_gpu.h).
+#include <cstdlib>
 #include "dock_ctx.hpp"
 #include "host_field.hpp"
 #include "qap_launch.hip.h"
@@ -110,7 +111,14 @@ using namespace dock;
 
 extern "C" {
 
-int32_t dgpu_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; } return n; }
+// ROCm reads GPU_MAX_HW_QUEUES when the runtime comes up (the process's first HIP call) and maps every stream onto that many hardware queues: 4 by default.
+// A slot has three streams and six slots run at once; two streams on one queue execute one after the other, which is what the latency chains of the pairing
+// and aggregation paths (line chain | scalings | product pieces side by side) cannot afford.  Eight queues, same-box A/B of the whole bench line
+// (tools/dev/r05_hwq_bench_ab.sh): 1024-pair Miller loop 0.71 -> 0.66 ms, 1024 proofs aggregated 37.1 -> 35.3 ms, one proof 10.0 -> 9.8 ms, the MSM rate unchanged.
+// Set only if the host has not chosen a value and only effective if the library's is the first HIP call of the process (a host that initialises HIP itself —
+// PyTorch — exports the variable instead: bench.py does).
+static void prefer_eight_hw_queues() { static const int once = setenv("GPU_MAX_HW_QUEUES", "8", 0); (void)once; }
+int32_t dgpu_device_count(void) { prefer_eight_hw_queues(); int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; } return n; }
 
 // streams, events, pinned scratch and workspaces of a context's slots (shutdown; a failed bring-up).  The caller holds each slot's mutex or
 // knows that no call can reach the context.
@@ -168,6 +176,7 @@ static int32_t init_ctx_locked(int idx, int device) {
 int32_t dgpu_init_device_list(const int32_t *physical, int32_t count) {
     if (!physical || count <= 0 || count > MAX_CTX) return DGPU_E_BADARG;
     std::lock_guard<std::mutex> lk(gs.mu);
+    prefer_eight_hw_queues();
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { (void)hipGetLastError(); return DGPU_E_NODEVICE; }
     for (int k = 0; k < count; k++) if (physical[k] < 0 || physical[k] >= n) return DGPU_E_NODEVICE;

@@ -24,7 +24,7 @@ cross-check of the GPU result.
 import argparse
 import json
 import os
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # before the process's first HIP call (PyTorch's, here): see prefer_eight_hw_queues in crypto_amd/csrc/dock_core.hip
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # before the process's first HIP call (PyTorch's, here): what dgpu_runtime_hints(DGPU_HINT_EIGHT_HW_QUEUES) does for a host whose first HIP call is the library's (include/dock_gpu.h)
 import sys
 import time
 

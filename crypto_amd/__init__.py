@@ -8,6 +8,7 @@ from ._native import lib, DockGpuError, build_native, twin, dev_lib  # noqa: F40
 from .msm import (  # noqa: F401
     G1, G2, msm_bigint, msm_unchecked, msm, Pairs, OwnedPairs, DeviceBases, DeviceScalars, SortedScalars, init, prof, init_devices, msm_bigint_sharded, ShardedDeviceBases,
     msm_strided, to_affine_structs, affine_struct_dtype, reserve, device_alloc_count, TABLE_C_WITNESS,
+    bases_cache, bases_cache_stats, bases_cache_clear, bases_cache_invalidate, CACHE_VERIFY_FULL,
 )
 from .pairing import multi_miller_loop, final_exponentiation, multi_pairing  # noqa: F401,E402
 from .pairing_check import RandomizedPairingChecker  # noqa: F401,E402

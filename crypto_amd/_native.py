@@ -78,8 +78,9 @@ DEV_SYMBOLS = ["dgpu_set_window_bits", "dgpu_set_chunk", "dgpu_set_reduce_shift"
 
 # every symbol include/dock_gpu.h declares
 SYMBOLS = [
-    "dgpu_init", "dgpu_init_devices", "dgpu_init_device_list", "dgpu_context_count", "dgpu_set_device", "dgpu_shutdown", "dgpu_device_count", "dgpu_strerror", "dgpu_last_hip_error",
+    "dgpu_runtime_hints", "dgpu_init", "dgpu_init_devices", "dgpu_init_device_list", "dgpu_context_count", "dgpu_set_device", "dgpu_shutdown", "dgpu_device_count", "dgpu_strerror", "dgpu_last_hip_error",
     "dgpu_set_min_gpu_n", "dgpu_get_min_gpu_n", "dgpu_set_small_msm_max", "dgpu_reserve_g1", "dgpu_reserve_g2", "dgpu_device_alloc_count",
+    "dgpu_set_bases_cache_bytes", "dgpu_set_bases_cache_min_n", "dgpu_set_bases_cache_verify", "dgpu_bases_cache_invalidate", "dgpu_bases_cache_clear", "dgpu_bases_cache_stats",
     "dgpu_msm_g1", "dgpu_msm_g1_mont", "dgpu_msm_g2", "dgpu_msm_g2_mont", "dgpu_msm_g1_strided", "dgpu_msm_g2_strided", "dgpu_bases_upload_g1_strided", "dgpu_bases_upload_g2_strided",
     "dgpu_bases_upload_g1", "dgpu_bases_upload_g2", "dgpu_bases_free", "dgpu_scalars_upload", "dgpu_scalars_upload_parts", "dgpu_scalars_free",
     "dgpu_msm_g1_handle", "dgpu_msm_g2_handle", "dgpu_msm_g1_resident", "dgpu_msm_g2_resident", "dgpu_bases_precompute_g1", "dgpu_bases_precompute_g2",
@@ -158,6 +159,7 @@ def _load(path):
         L.dgpu_strerror.restype = C.c_char_p
         L.dgpu_strerror.argtypes = [C.c_int32]
         L.dgpu_init.argtypes = [C.c_int32]
+        L.dgpu_runtime_hints.argtypes = [C.c_uint32]
         L.dgpu_set_min_gpu_n.argtypes = [C.c_size_t]
         L.dgpu_set_small_msm_max.argtypes = [C.c_size_t]
         L.dgpu_reserve_g1.argtypes = [C.c_size_t]
@@ -165,6 +167,12 @@ def _load(path):
         L.dgpu_device_alloc_count.restype = C.c_uint64
         L.dgpu_device_alloc_count.argtypes = []
         vp, sz, u64 = C.c_void_p, C.c_size_t, C.c_uint64
+        L.dgpu_set_bases_cache_bytes.argtypes = [sz]
+        L.dgpu_set_bases_cache_min_n.argtypes = [sz]
+        L.dgpu_set_bases_cache_verify.argtypes = [C.c_int32]
+        L.dgpu_bases_cache_invalidate.argtypes = [vp, sz]
+        L.dgpu_bases_cache_clear.argtypes = []
+        L.dgpu_bases_cache_stats.argtypes = [vp]
         for name in ("dgpu_msm_g1", "dgpu_msm_g1_mont", "dgpu_msm_g2", "dgpu_msm_g2_mont"):
             getattr(L, name).argtypes = [vp, vp, vp, sz, vp]
         for name in ("dgpu_msm_g1_strided", "dgpu_msm_g2_strided"):

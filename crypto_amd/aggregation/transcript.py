@@ -214,7 +214,10 @@ class NativeMerlinTranscript:
         self.struct = Transcript(self.ctx, C.cast(H.mt_append_message, APPEND_FN), C.cast(H.mt_challenge_scalar, CHALLENGE_FN))
 
     def clone(self):
-        return NativeMerlinTranscript(b"", _handle=self._H.mt_clone(self.ctx))
+        h = self._H.mt_clone(self.ctx)
+        if not h:                         # (ctypes turns NULL into None, which __init__ would read as "no handle given": a fresh, empty-label transcript)
+            raise MemoryError("mt_clone")
+        return NativeMerlinTranscript(b"", _handle=h)
 
     def append(self, label, element_bytes):
         self._H.mt_append_message(self.ctx, bytes(label), len(label), bytes(element_bytes), len(element_bytes))

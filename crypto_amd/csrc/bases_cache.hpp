@@ -1,0 +1,152 @@
+// crypto_amd/csrc/bases_cache.hpp — the resident-bases cache behind the one-shot MSM entry points (dgpu_msm_g1 / _g2 [_mont | _strided]).
+//
+// Why: the reference's call sites hand the SAME proving-key slices to `msm_bigint` proof after proof (legogroth16/src/prover.rs:286,299,363,592;
+// utils/src/pairs.rs:143-156) and know nothing of handles.  Served one-shot, every call pushes the whole query across PCIe again (136 MB for a
+// 2^20-point G1 query: 5.3 ms against 2.7 ms for the same MSM on a resident table).  The cache makes the unmodified call reach the resident path:
+//   1st sighting of (pointer, n, layout)   the call runs one-shot; a 64-bit fingerprint of 32 evenly spaced records is remembered (host work: ~2 us)
+//   2nd sighting, same fingerprint          the points are uploaded ONCE as a bases handle, a fingerprint of EVERY record is computed on the device and kept
+//                                           on the host (8 B per record), the handle becomes a precomputed-multiples table (dgpu_bases_precompute_*), the
+//                                           call runs on it
+//   later sightings                         the call runs on the table (dgpu_msm_*_handle's path: scalars cross PCIe, nothing else)
+// A call whose points lie INSIDE a resident entry of the same layout (`&query[1..]`, a truncated length) resolves to (entry, offset).
+// Stale keys: before an entry is used the host re-fingerprints `verify_samples` records of the call's range — its first and last and a fresh
+// pseudo-random choice per call — and compares them with the kept per-record fingerprints; any difference evicts the entry and the call runs one-shot
+// (DGPU_CACHE_VERIFY_FULL: every record, on the library's host threads).  The default therefore notices a buffer that was refilled with another key at
+// once and an in-place edit of a few records only with probability samples / n per call: a host that edits bases in place calls
+// dgpu_bases_cache_invalidate (or turns the cache off).  Entries are evicted least-recently-used under the byte budget; an entry in use is pinned by the
+// shared_ptr its caller holds (the handle is freed when the last user lets go).  Lock order: gcache.mu is never held across a device call or gs.mu.
+#pragma once
+#include <memory>
+#include "dock_ctx.hpp"
+
+namespace dock {
+
+struct CacheKey {
+    const uint8_t *p; size_t n, stride, x_off, y_off, inf_off; const uint8_t *is_inf; int kind /* 1 = G1, 2 = G2 */, ctx;
+    bool same_layout(const CacheKey &o) const { return kind == o.kind && ctx == o.ctx && stride == o.stride && x_off == o.x_off && y_off == o.y_off && inf_off == o.inf_off && (is_inf == nullptr) == (o.is_inf == nullptr); }
+    bool same(const CacheKey &o) const { return same_layout(o) && p == o.p && n == o.n && is_inf == o.is_inf; }
+    // this range lies inside o's (whole records); *off = first record
+    bool inside(const CacheKey &o, size_t *off) const {
+        if (!same_layout(o) || p < o.p) return false;
+        const size_t d = (size_t)(p - o.p);
+        if (d % stride) return false;
+        const size_t k = d / stride;
+        if (k > o.n || n > o.n - k) return false;
+        if (is_inf && is_inf != o.is_inf + k) return false;
+        *off = k; return true;
+    }
+    bool overlaps(const void *q, size_t bytes) const {
+        const uint8_t *a = (const uint8_t *)q, *b = a + bytes, *e = p + n * stride;
+        if (a < e && p < b) return true;
+        return is_inf && a < is_inf + n && is_inf < b;
+    }
+};
+struct CacheEntry {
+    enum State { SEEN, FILLING, READY };
+    CacheKey k; State state = SEEN;
+    uint64_t fp = 0;                    // fingerprint of the evenly spaced sample (SEEN)
+    uint64_t handle = 0; size_t bytes = 0; uint64_t last_use = 0;
+    std::vector<uint64_t> rec_hash;     // READY: fingerprint of every record
+    ~CacheEntry() { if (handle) (void)dgpu_bases_free(handle); }
+};
+constexpr size_t CACHE_BUDGET_AUTO = ~(size_t)0;
+constexpr size_t CACHE_MAX_SEEN = 256;
+constexpr int CACHE_FP_SAMPLES = 32;
+struct BasesCache {
+    std::mutex mu;
+    std::vector<std::shared_ptr<CacheEntry>> entries;
+    std::atomic<size_t> budget{CACHE_BUDGET_AUTO}; size_t used = 0;
+    std::atomic<size_t> min_n{(size_t)1 << 16};
+    std::atomic<int> verify_samples{24};        // records re-fingerprinted per hit; DGPU_CACHE_VERIFY_FULL: all of them
+    std::atomic<bool> enabled{true};
+    uint64_t tick = 0;
+    std::atomic<uint64_t> hits{0}, misses{0}, fills{0}, stale{0}, evictions{0}, sample_ctr{0};
+};
+extern BasesCache gcache;
+
+// fingerprint of one raw point as the caller holds it: the host-side twin of k_raw_record_hash (psort_kernels.hip.h) — keep the two in step
+inline uint64_t rec_fingerprint(const uint8_t *pt, size_t x_off, size_t y_off, size_t inf_off, const uint8_t *is_inf_i, int words) {
+    uint64_t h = 0x9E3779B97F4A7C15ull;
+    for (int part = 0; part < 2; part++) {
+        const uint8_t *src = pt + (part ? y_off : x_off);
+        for (int k = 0; k < words; k++) {
+            uint64_t w; memcpy(&w, src + 8 * k, 8);
+            h = (h ^ w) * 0xff51afd7ed558ccdull;
+            h ^= h >> 32;
+        }
+    }
+    uint64_t flag = 0;
+    if (is_inf_i && *is_inf_i) flag = 1;
+    if (inf_off != ~(size_t)0 && pt[inf_off]) flag = 1;
+    h = (h ^ flag) * 0xc4ceb9fe1a85ec53ull;
+    return h ^ (h >> 29);
+}
+inline uint64_t rec_fingerprint_at(const CacheKey &k, size_t i, int words) {
+    return rec_fingerprint(k.p + i * k.stride, k.x_off, k.y_off, k.inf_off, k.is_inf ? k.is_inf + i : nullptr, words);
+}
+// the evenly spaced sample of a whole range (first and last record included)
+inline uint64_t range_fingerprint(const CacheKey &k, int words) {
+    const size_t S = std::min<size_t>(CACHE_FP_SAMPLES, k.n);
+    uint64_t h = 0x2545F4914F6CDD1Dull ^ k.n;
+    for (size_t j = 0; j < S; j++) {
+        const size_t i = S > 1 ? (size_t)((unsigned __int128)j * (k.n - 1) / (S - 1)) : 0;
+        h = (h ^ rec_fingerprint_at(k, i, words)) * 0x9E3779B97F4A7C15ull; h ^= h >> 31;
+    }
+    return h;
+}
+inline uint64_t splitmix64(uint64_t x) { x += 0x9E3779B97F4A7C15ull; x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull; x = (x ^ (x >> 27)) * 0x94D049BB133111EBull; return x ^ (x >> 31); }
+
+// the records [off, off + k.n) of entry e still hold what was uploaded (sampled, or every record under DGPU_CACHE_VERIFY_FULL)
+inline bool cache_verify(const CacheEntry &e, const CacheKey &k, size_t off, int words) {
+    const int samples = gcache.verify_samples.load();
+    if (samples < 0) {                      // every record, in parallel on the library's host threads
+        const size_t parts = std::min<size_t>(16, (k.n + 65535) / 65536);
+        std::atomic<bool> ok{true};
+        (void)par_run(parts, [&](size_t part) -> int32_t {
+            const size_t lo = k.n * part / parts, hi = k.n * (part + 1) / parts;
+            for (size_t i = lo; i < hi && ok.load(std::memory_order_relaxed); i++) if (rec_fingerprint_at(k, i, words) != e.rec_hash[off + i]) ok = false;
+            return DGPU_OK;
+        });
+        return ok.load();
+    }
+    if (rec_fingerprint_at(k, 0, words) != e.rec_hash[off] || rec_fingerprint_at(k, k.n - 1, words) != e.rec_hash[off + k.n - 1]) return false;
+    uint64_t r = splitmix64(gcache.sample_ctr.fetch_add(1));
+    for (int j = 2; j < samples; j++) {
+        r = splitmix64(r);
+        const size_t i = (size_t)(((unsigned __int128)r * k.n) >> 64);
+        if (rec_fingerprint_at(k, i, words) != e.rec_hash[off + i]) return false;
+    }
+    return true;
+}
+
+// Make room for `need` more bytes: least-recently-used READY entries other than `keep` leave the list (their memory is released when `dropped` is
+// destroyed, outside the lock).  False: the budget cannot hold `need` at all.  Caller holds gcache.mu.
+inline bool cache_make_room_locked(size_t need, const CacheEntry *keep, std::vector<std::shared_ptr<CacheEntry>> &dropped) {
+    if (need > gcache.budget) return false;
+    while (gcache.used + need > gcache.budget) {
+        size_t victim = gcache.entries.size();
+        for (size_t i = 0; i < gcache.entries.size(); i++) {
+            const CacheEntry &c = *gcache.entries[i];
+            if (c.state != CacheEntry::READY || &c == keep) continue;
+            if (victim == gcache.entries.size() || c.last_use < gcache.entries[victim]->last_use) victim = i;
+        }
+        if (victim == gcache.entries.size()) return false;
+        gcache.used -= gcache.entries[victim]->bytes; gcache.evictions++;
+        dropped.push_back(std::move(gcache.entries[victim]));
+        gcache.entries.erase(gcache.entries.begin() + victim);
+    }
+    return true;
+}
+inline void cache_remove_locked(const CacheEntry *e, std::vector<std::shared_ptr<CacheEntry>> &dropped) {
+    for (size_t i = 0; i < gcache.entries.size(); i++) if (gcache.entries[i].get() == e) {
+        if (e->state == CacheEntry::READY) gcache.used -= e->bytes;
+        dropped.push_back(std::move(gcache.entries[i])); gcache.entries.erase(gcache.entries.begin() + i); return;
+    }
+}
+// drop everything (dgpu_bases_cache_clear, dgpu_shutdown, a budget of 0)
+inline void cache_clear() {
+    std::vector<std::shared_ptr<CacheEntry>> dropped;
+    { std::lock_guard<std::mutex> lk(gcache.mu); dropped.swap(gcache.entries); gcache.used = 0; }
+}
+
+}  // namespace dock

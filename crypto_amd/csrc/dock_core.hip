@@ -2,6 +2,7 @@
 // (implements the curve-independent part of include/dock_gpu.h).
 #include <cstdlib>
 #include "dock_ctx.hpp"
+#include "bases_cache.hpp"
 #include "host_field.hpp"
 #include "qap_launch.hip.h"
 #include <chrono>
@@ -9,6 +10,7 @@
 
 namespace dock {
 Shared gs;
+BasesCache gcache;
 #ifdef DGPU_DEV
 // the twin's handles start far from the product's: a process that has both libraries loaded (tests, bench.py) cannot free or use one library's
 // object through the other by accident — the foreign number is simply unknown there (DGPU_E_BADARG)
@@ -111,14 +113,21 @@ using namespace dock;
 
 extern "C" {
 
-// ROCm reads GPU_MAX_HW_QUEUES when the runtime comes up (the process's first HIP call) and maps every stream onto that many hardware queues: 4 by default.
-// A slot has three streams and six slots run at once; two streams on one queue execute one after the other, which is what the latency chains of the pairing
-// and aggregation paths (line chain | scalings | product pieces side by side) cannot afford.  Eight queues, same-box A/B of the whole bench line
-// (tools/dev/r05_hwq_bench_ab.sh): 1024-pair Miller loop 0.71 -> 0.66 ms, 1024 proofs aggregated 37.1 -> 35.3 ms, one proof 10.0 -> 9.8 ms, the MSM rate unchanged.
-// Set only if the host has not chosen a value and only effective if the library's is the first HIP call of the process (a host that initialises HIP itself —
-// PyTorch — exports the variable instead: bench.py does).
-static void prefer_eight_hw_queues() { static const int once = setenv("GPU_MAX_HW_QUEUES", "8", 0); (void)once; }
-int32_t dgpu_device_count(void) { prefer_eight_hw_queues(); int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; } return n; }
+// dgpu_runtime_hints — process-level settings of the ROCm runtime that suit this library, applied ONLY when the host asks (the library itself never touches
+// its host's environment).  DGPU_HINT_EIGHT_HW_QUEUES: ROCm reads GPU_MAX_HW_QUEUES when the runtime comes up (the process's first HIP call) and maps every
+// stream onto that many hardware queues, 4 by default.  A slot has three streams and six slots run at once; two streams on one queue execute one after the
+// other, which is what the latency chains of the pairing and aggregation paths (line chain | scalings | product pieces side by side) cannot afford.  Eight
+// queues, same-box A/B of the whole bench line (profiles/r05_hwq_bench_ab.txt): 1024-pair Miller loop 0.71 -> 0.66 ms, 1024 proofs aggregated 37.1 -> 35.3 ms,
+// one proof 10.0 -> 9.8 ms, the MSM rate unchanged.  The hint exports GPU_MAX_HW_QUEUES=8 unless the variable is already set.  It works only BEFORE the process's
+// first HIP call and must be made while no other thread can be inside getenv / setenv (a host's start-up code): DGPU_E_BADARG once this library has touched HIP.
+static std::atomic<bool> g_hip_touched{false};
+int32_t dgpu_runtime_hints(uint32_t flags) {
+    if (flags & ~(uint32_t)DGPU_HINT_EIGHT_HW_QUEUES) return DGPU_E_BADARG;
+    if (g_hip_touched.load()) return DGPU_E_BADARG;
+    if (flags & DGPU_HINT_EIGHT_HW_QUEUES) (void)setenv("GPU_MAX_HW_QUEUES", "8", 0);
+    return DGPU_OK;
+}
+int32_t dgpu_device_count(void) { g_hip_touched = true; int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; } return n; }
 
 // streams, events, pinned scratch and workspaces of a context's slots (shutdown; a failed bring-up).  The caller holds each slot's mutex or
 // knows that no call can reach the context.
@@ -176,7 +185,7 @@ static int32_t init_ctx_locked(int idx, int device) {
 int32_t dgpu_init_device_list(const int32_t *physical, int32_t count) {
     if (!physical || count <= 0 || count > MAX_CTX) return DGPU_E_BADARG;
     std::lock_guard<std::mutex> lk(gs.mu);
-    prefer_eight_hw_queues();
+    g_hip_touched = true;
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { (void)hipGetLastError(); return DGPU_E_NODEVICE; }
     for (int k = 0; k < count; k++) if (physical[k] < 0 || physical[k] >= n) return DGPU_E_NODEVICE;
@@ -199,6 +208,7 @@ int32_t dgpu_set_device(int32_t ctx) {
 }
 
 int32_t dgpu_shutdown(void) {
+    cache_clear();                 // (the resident-bases cache's entries are handles like any other: released first, through dgpu_bases_free)
     // Lock order: a call in flight holds its slot and may take gs.mu (handle pins, the scalar pool); so the slots are drained WITHOUT gs.mu held.
     // 1. no new call gets past its `ready` check; 2. every slot is taken once, i.e. every call in flight has returned; 3. handles and pools
     // are released under gs.mu once nothing pins them.
@@ -265,6 +275,42 @@ int32_t dgpu_set_min_gpu_n(size_t n) { gs.min_gpu_n = n; return DGPU_OK; }
 size_t dgpu_get_min_gpu_n(void) { return gs.min_gpu_n.load(); }
 int32_t dgpu_set_small_msm_max(size_t n) { if (n > 8192) return DGPU_E_BADARG; gs.small_max = n; return DGPU_OK; }
 uint64_t dgpu_device_alloc_count(void) { return g_dev_allocs.load(); }
+
+// ---- the resident-bases cache behind the one-shot MSM entry points (bases_cache.hpp) ----
+int32_t dgpu_set_bases_cache_bytes(size_t bytes) {
+    gcache.budget = bytes; gcache.enabled = bytes != 0;            // (DGPU_CACHE_BYTES_AUTO == CACHE_BUDGET_AUTO: resolved again at the next use)
+    if (bytes == 0) { cache_clear(); return DGPU_OK; }
+    std::vector<std::shared_ptr<CacheEntry>> dropped;
+    std::lock_guard<std::mutex> lk(gcache.mu);
+    (void)cache_make_room_locked(0, nullptr, dropped);         // a smaller budget: least recently used entries go (`dropped` outlives the lock: their handles are freed after it)
+    return DGPU_OK;
+}
+int32_t dgpu_set_bases_cache_min_n(size_t n) { gcache.min_n = n < 2 ? 2 : n; return DGPU_OK; }
+int32_t dgpu_set_bases_cache_verify(int32_t samples) {
+    if (samples != DGPU_CACHE_VERIFY_FULL && (samples < 2 || samples > 4096)) return DGPU_E_BADARG;
+    gcache.verify_samples = samples; return DGPU_OK;
+}
+int32_t dgpu_bases_cache_clear(void) { cache_clear(); return DGPU_OK; }
+int32_t dgpu_bases_cache_invalidate(const void *p, size_t bytes) {
+    if (!p) return DGPU_E_BADARG;
+    std::vector<std::shared_ptr<CacheEntry>> dropped;
+    std::unique_lock<std::mutex> lk(gcache.mu);
+    for (size_t i = 0; i < gcache.entries.size();) {
+        CacheEntry &c = *gcache.entries[i];
+        if (c.state != CacheEntry::FILLING && c.k.overlaps(p, bytes)) { if (c.state == CacheEntry::READY) gcache.used -= c.bytes; dropped.push_back(std::move(gcache.entries[i])); gcache.entries.erase(gcache.entries.begin() + i); }
+        else i++;
+    }
+    lk.unlock();
+    return DGPU_OK;
+}
+int32_t dgpu_bases_cache_stats(uint64_t out[8]) {
+    if (!out) return DGPU_E_BADARG;
+    std::lock_guard<std::mutex> lk(gcache.mu);
+    size_t ready = 0; for (auto &c : gcache.entries) if (c->state == CacheEntry::READY) ready++;
+    out[0] = gcache.hits; out[1] = gcache.misses; out[2] = gcache.fills; out[3] = gcache.stale; out[4] = gcache.evictions;
+    out[5] = gcache.used; out[6] = gcache.budget.load() == CACHE_BUDGET_AUTO ? 0 : gcache.budget.load(); out[7] = ready;
+    return DGPU_OK;
+}
 
 
 // A free waits until no call uses the handle (HandleRef pins), then releases the memory outside the table lock: every entry point

@@ -476,8 +476,12 @@ __global__ void __launch_bounds__(64) k_line_products(const uint32_t *__restrict
         fnorm(l.c0, l.c0); fnorm(l.c1, l.c1); fnorm(l.c2, l.c2);       // (k_miller_lines_hex leaves its doubling lines un-normalised)
         if (pxy) {                                    // the lines came unevaluated (k_miller_lines_quad<false> / _hex): c1 *= px, c2 *= py here
             Fp px, py;
-            for (int k = 0; k < NL; k++) { px.l[k] = pxy[(size_t)k * n + i]; py.l[k] = pxy[(size_t)(NL + k) * n + i]; }
+            uint32_t anyp = 0;
+            for (int k = 0; k < NL; k++) { px.l[k] = pxy[(size_t)k * n + i]; py.l[k] = pxy[(size_t)(NL + k) * n + i]; anyp |= px.l[k] | py.l[k]; }
             line_eval(l, px, py);
+            // px = py = 0 is no point of the curve: it is how a P that turned out to be the identity AFTER the chain of Q started arrives here (the scaled
+            // Miller loop: [m] P = O for a P outside the prime-order subgroup) — the pair contributes one, as a pair skipped up front does
+            if (!anyp) { fset_one(l.c0); fzero(l.c1); fzero(l.c2); }
         }
         if (i == lo) f12_from_014(f, l.c0, l.c1, l.c2); else f12_mul_by_014(f, l.c0, l.c1, l.c2);
     }

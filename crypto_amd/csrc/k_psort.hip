@@ -7,6 +7,9 @@ namespace msm {
 void launch_id_flags(hipStream_t s, const uint32_t *bases, int aff_stride, int flag_word, size_t n, uint8_t *out) {
     if (n) hipLaunchKernelGGL(k_id_flags, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, bases, aff_stride, flag_word, n, out);
 }
+void launch_raw_record_hash(hipStream_t s, const uint8_t *raw, size_t stride, size_t x_off, size_t y_off, size_t inf_off, const uint8_t *is_inf, int words, size_t n, uint64_t *out) {
+    if (n) hipLaunchKernelGGL(k_raw_record_hash, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, raw, stride, x_off, y_off, inf_off, is_inf, words, n, out);
+}
 void launch_psort(hipStream_t s, const PsParams &q, uint32_t NB, uint32_t *cnt1, uint32_t *off1, uint32_t *bsums, void *pairs, uint32_t *off, uint32_t *entries,
                   uint32_t heavy_thr, uint32_t *heavy, uint32_t heavy_cap, const uint32_t *dyn_args, uint32_t *dyn) {
     const size_t lds1 = (size_t)q.P * 4;

@@ -4,6 +4,7 @@
 #include <chrono>
 #include <thread>
 #include "dock_ctx.hpp"
+#include "bases_cache.hpp"
 #include "host_field.hpp"
 #include "msm_launch.hip.h"
 #include "sort_launch.hip.h"
@@ -878,16 +879,23 @@ int32_t msm_oneshot_here(const RawBases &rb, const uint64_t *scalars, size_t n, 
     if (grew) reserve_idle_slots<C>(&sl, 1, n, rb.stride);
     return rc;
 }
+template <class C, class HF> bool msm_oneshot_cached(const RawBases &rb, const uint64_t *scalars, size_t n, bool mont, uint64_t *out, int kind, int32_t &rc);      // (defined below)
 template <class C, class HF>
 int32_t msm_oneshot(const RawBases &rb, const uint64_t *scalars, size_t n, bool mont, uint64_t *out) {
     if (!out || (n && (!rb.p || !scalars)) || n >= (1ull << 31) || !rb.ok<C>()) return DGPU_E_BADARG;
     if (!cur().ready) return DGPU_E_NODEVICE;            // (before the size threshold: a missing device is never answered with "too small")
     if (!tl_no_min && n < gs.min_gpu_n) return DGPU_E_TOO_SMALL;
+    // the caller's bases may be resident already (bases_cache.hpp): the proving-key slices the reference passes proof after proof
+    if (gcache.enabled.load(std::memory_order_relaxed) && n >= gcache.min_n.load(std::memory_order_relaxed)) {
+        int32_t rc;
+        if (msm_oneshot_cached<C, HF>(rb, scalars, n, mont, out, C::NFP, rc)) return rc;
+    }
     return msm_oneshot_here<C, HF>(rb, scalars, n, mont, out);
 }
 
+// rec_hash != nullptr (the resident-bases cache, bases_cache.hpp): the fingerprint of every raw record, computed on the device from the staged bytes
 template <class C>
-int32_t bases_upload(const RawBases &rb, size_t n, uint64_t *handle, int kind) {
+int32_t bases_upload(const RawBases &rb, size_t n, uint64_t *handle, int kind, std::vector<uint64_t> *rec_hash = nullptr) {
     if (!handle || (n && !rb.p) || n >= (1ull << 31) || !rb.ok<C>()) return DGPU_E_BADARG;
     if (!cur().ready) return DGPU_E_NODEVICE;
     void *p = nullptr;
@@ -897,6 +905,13 @@ int32_t bases_upload(const RawBases &rb, size_t n, uint64_t *handle, int kind) {
         if (dev_malloc(&p, std::max<size_t>(n, 1) * C::AFF_STRIDE * 4) != hipSuccess) { (void)hipGetLastError(); return DGPU_E_OOM; }
         int32_t rc = ws_stage_bases<C>(sl, rb, n);
         if (!rc) rc = stage_bases<C>(sl, rb, n, (uint32_t *)p);
+        if (!rc && rec_hash && n) {               // (the compute stream has waited for every piece of the copy: stage_bases)
+            rc = sl.digits.ensure(n * 8);
+            if (!rc) {
+                launch_raw_record_hash(sl.stream, sl.in_bases.as<uint8_t>(), rb.stride, rb.x_off, rb.y_off, rb.inf_off, rb.is_inf ? sl.in_inf.as<uint8_t>() : nullptr, C::ABI_W / 2, n, sl.digits.as<uint64_t>());
+                if (hipMemcpyAsync(rec_hash->data(), sl.digits.p, n * 8, hipMemcpyDeviceToHost, sl.stream) != hipSuccess) { (void)hipGetLastError(); rc = DGPU_E_HIP; }
+            }
+        }
         if (hipStreamSynchronize(sl.cstream) != hipSuccess || hipStreamSynchronize(sl.stream) != hipSuccess) { if (!rc) rc = DGPU_E_HIP; }
         if (gs.prof) prof_flush(sl);
         if (rc) { (void)hipFree(p); return rc; }
@@ -935,6 +950,89 @@ int32_t msm_handle(uint64_t bases, size_t offset, const uint64_t *scalars, size_
     }
     if (rc) { (void)hipStreamSynchronize(sl.cstream); (void)hipStreamSynchronize(sl.stream); }      // nothing of ours may still read the caller's scalars
     return rc;
+}
+
+// ---- the resident-bases cache (bases_cache.hpp) --------------------------------------------------------------------------------------------
+// device bytes an entry of n points will hold once it is a table (or stays plain: choose_c_pre)
+template <class C> inline size_t cache_entry_bytes(size_t n) {
+    const int c = choose_c_pre(n);
+    if (c == 0) return n * (size_t)C::AFF_STRIDE * 4 + (n <= SMALL_MSM_MAX_N ? small_sub_bytes<C>(n) : 0);
+    return pre_tab_bytes<C>(n, 255 / c + 1);
+}
+// true: the call was served from a resident entry and rc is its answer; false: run it one-shot (first sighting, another thread is filling the entry,
+// a stale or oversized key, a device error on the way)
+template <class C, class HF>
+bool msm_oneshot_cached(const RawBases &rb, const uint64_t *scalars, size_t n, bool mont, uint64_t *out, int kind, int32_t &rc) {
+    const CacheKey key{rb.p, n, rb.stride, rb.x_off, rb.y_off, rb.inf_off, rb.is_inf, kind, cur_index()};
+    constexpr int words = C::ABI_W / 2;
+    std::vector<std::shared_ptr<CacheEntry>> dropped;        // (destroyed after the lock is released: an entry's destructor frees its handle)
+    std::shared_ptr<CacheEntry> e;
+    size_t off = 0;
+    bool fill = false;
+    {
+        std::lock_guard<std::mutex> lk(gcache.mu);
+        for (auto &c : gcache.entries) if (c->state == CacheEntry::READY && key.inside(c->k, &off)) { e = c; e->last_use = ++gcache.tick; break; }
+    }
+    if (e && !cache_verify(*e, key, off, words)) {            // the host memory behind the entry changed: forget it, run one-shot, start over as a first sighting
+        std::lock_guard<std::mutex> lk(gcache.mu);
+        cache_remove_locked(e.get(), dropped);
+        gcache.stale++; e.reset();
+    }
+    if (!e) {
+        const uint64_t fp = range_fingerprint(key, words);
+        size_t budget_auto = 0;
+        if (gcache.budget == CACHE_BUDGET_AUTO) {           // a quarter of what the device has free now (resolved once; dgpu_set_bases_cache_bytes overrides)
+            size_t fr = 0, tot = 0;
+            if (hipSetDevice(cur().device) == hipSuccess && hipMemGetInfo(&fr, &tot) == hipSuccess) budget_auto = fr / 4; else (void)hipGetLastError();
+        }
+        std::lock_guard<std::mutex> lk(gcache.mu);
+        if (gcache.budget == CACHE_BUDGET_AUTO) gcache.budget = budget_auto;
+        std::shared_ptr<CacheEntry> seen;
+        for (auto &c : gcache.entries) if (c->state != CacheEntry::READY && c->k.same(key)) { seen = c; break; }
+        if (!seen) {                                          // first sighting: remember the fingerprint
+            size_t n_seen = 0, oldest = gcache.entries.size();
+            for (size_t i = 0; i < gcache.entries.size(); i++) if (gcache.entries[i]->state == CacheEntry::SEEN) { n_seen++; if (oldest == gcache.entries.size() || gcache.entries[i]->last_use < gcache.entries[oldest]->last_use) oldest = i; }
+            if (n_seen >= CACHE_MAX_SEEN) { dropped.push_back(std::move(gcache.entries[oldest])); gcache.entries.erase(gcache.entries.begin() + oldest); }
+            auto c = std::make_shared<CacheEntry>(); c->k = key; c->fp = fp; c->last_use = ++gcache.tick;
+            gcache.entries.push_back(std::move(c));
+        } else if (seen->state == CacheEntry::SEEN) {
+            seen->last_use = ++gcache.tick;
+            if (seen->fp != fp) seen->fp = fp;                // other contents at the same address: a first sighting again
+            else if (cache_make_room_locked(cache_entry_bytes<C>(n), seen.get(), dropped)) { seen->state = CacheEntry::FILLING; e = seen; fill = true; }
+        }                                                     // (FILLING: another thread is uploading this key right now)
+        if (!e) { gcache.misses++; return false; }
+    }
+    if (fill) {
+        // second sighting: upload once (+ the per-record fingerprints), make it a table
+        e->rec_hash.resize(n);
+        uint64_t h = 0;
+        int32_t frc = bases_upload<C>(rb, n, &h, kind, &e->rec_hash);
+        if (!frc) {
+            frc = bases_precompute<C>(h, 0, kind);
+            if (frc) { (void)dgpu_bases_free(h); h = 0; }
+        }
+        std::lock_guard<std::mutex> lk(gcache.mu);
+        if (frc) { cache_remove_locked(e.get(), dropped); gcache.misses++; return false; }
+        e->handle = h; e->bytes = cache_entry_bytes<C>(n); gcache.fills++;
+        bool listed = false;
+        for (auto &c : gcache.entries) if (c.get() == e.get()) listed = true;
+        // (not listed any more: dgpu_bases_cache_clear ran meanwhile — this call still uses the table, which goes when the call lets go of it)
+        if (listed) { e->state = CacheEntry::READY; e->last_use = ++gcache.tick; gcache.used += e->bytes; }
+        // an older entry that lies wholly inside the new one is redundant
+        for (size_t i = 0; i < gcache.entries.size();) {
+            size_t o; CacheEntry &c = *gcache.entries[i];
+            if (listed && &c != e.get() && c.state == CacheEntry::READY && c.k.inside(e->k, &o)) { gcache.used -= c.bytes; dropped.push_back(std::move(gcache.entries[i])); gcache.entries.erase(gcache.entries.begin() + i); }
+            else i++;
+        }
+    }
+    rc = msm_handle<C, HF>(e->handle, off, scalars, n, mont, out, kind, false);
+    if (rc != DGPU_OK && rc != DGPU_E_BADARG) {               // a device-side failure on the resident path: forget the entry, let the one-shot path answer
+        std::lock_guard<std::mutex> lk(gcache.mu);
+        cache_remove_locked(e.get(), dropped);
+        gcache.misses++; return false;
+    }
+    gcache.hits++;
+    return true;
 }
 
 template <class C, class HF>

@@ -95,6 +95,30 @@ __global__ void __launch_bounds__(256) k_id_flags(const uint32_t *__restrict__ b
     if (i < n) out[i] = bases[i * (size_t)aff_stride + flag_word] != 0 ? 1 : 0;
 }
 
+// out[i] = 64-bit fingerprint of raw point i as the caller holds it (x at x_off, y at y_off: `words` 64-bit words each; the identity byte inside the
+// point and / or in a separate array): what the resident-bases cache (bases_cache.hpp) keeps per record to notice a key whose host memory changed.
+// The host computes the same function for the records it samples (rec_fingerprint) — keep the two in step.
+__global__ void __launch_bounds__(256) k_raw_record_hash(const uint8_t *__restrict__ raw, size_t stride, size_t x_off, size_t y_off, size_t inf_off, const uint8_t *__restrict__ is_inf,
+                                                         int words, size_t n, uint64_t *__restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t *pt = raw + i * stride;
+    uint64_t h = 0x9E3779B97F4A7C15ull;
+    for (int part = 0; part < 2; part++) {
+        const uint8_t *src = pt + (part ? y_off : x_off);
+        for (int k = 0; k < words; k++) {
+            const uint2 v = *reinterpret_cast<const uint2 *>(src + 8 * k);
+            h = (h ^ ((uint64_t)v.x | ((uint64_t)v.y << 32))) * 0xff51afd7ed558ccdull;
+            h ^= h >> 32;
+        }
+    }
+    uint64_t flag = 0;
+    if (is_inf && is_inf[i]) flag = 1;
+    if (inf_off != ~(size_t)0 && pt[inf_off]) flag = 1;
+    h = (h ^ flag) * 0xc4ceb9fe1a85ec53ull;
+    out[i] = h ^ (h >> 29);
+}
+
 // block -> tile: workgroup ids go round the eight XCDs, and the cnt1 / off1 words of tile t sit next to those of tile t + 1 (partition-major layout): the
 // blocks of one XCD take CONSECUTIVE tiles, so that the sixteen tiles of a 64-byte line meet in one L2 instead of eight
 __device__ __forceinline__ uint32_t ps_tile_of_block(uint32_t b, uint32_t ntiles) {

@@ -50,6 +50,8 @@ void launch_psort(hipStream_t s, const PsParams &q, uint32_t NB, uint32_t *cnt1,
                   uint32_t heavy_thr, uint32_t *heavy, uint32_t heavy_cap, const uint32_t *dyn_args = nullptr, uint32_t *dyn = nullptr);
 // out[i] = (bases[i * aff_stride + flag_word] != 0): the identity flags of n prepared records as one byte each (built once per table)
 void launch_id_flags(hipStream_t s, const uint32_t *bases, int aff_stride, int flag_word, size_t n, uint8_t *out);
+// out[i] = fingerprint of raw point i (psort_kernels.hip.h k_raw_record_hash; the host-side twin is rec_fingerprint of bases_cache.hpp); words = 64-bit words per coordinate
+void launch_raw_record_hash(hipStream_t s, const uint8_t *raw, size_t stride, size_t x_off, size_t y_off, size_t inf_off, const uint8_t *is_inf, int words, size_t n, uint64_t *out);
 void launch_g1_scale(hipStream_t s, const uint32_t *p_abi, const uint8_t *is_inf, const uint32_t *scalars, int scalar_stride, const uint8_t *negate, size_t n, uint32_t *out_abi, uint8_t *out_inf,
                      const uint32_t *add_abi = nullptr, const uint8_t *add_inf = nullptr);
 void launch_selftest_fp_mul(hipStream_t s, const uint32_t *a, const uint32_t *b, size_t n, uint32_t *out);

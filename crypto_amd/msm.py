@@ -131,6 +131,39 @@ def msm_strided(curve, structs, scalars, montgomery=False):
     return out
 
 
+CACHE_VERIFY_FULL = -1     # include/dock_gpu.h DGPU_CACHE_VERIFY_FULL
+
+
+def bases_cache(bytes=None, min_n=None, verify=None):
+    """the resident-bases cache behind the one-shot entry points (include/dock_gpu.h: dgpu_set_bases_cache_bytes / _min_n / _verify); None = leave as it is"""
+    _ensure()
+    for val, name in ((bytes, "dgpu_set_bases_cache_bytes"), (min_n, "dgpu_set_bases_cache_min_n"), (verify, "dgpu_set_bases_cache_verify")):
+        if val is not None:
+            rc = getattr(lib(), name)(val)
+            if rc:
+                raise DockGpuError(rc, name)
+
+
+def bases_cache_stats():
+    """dgpu_bases_cache_stats as a dict"""
+    out = np.zeros(8, dtype=np.uint64)
+    rc = lib().dgpu_bases_cache_stats(_p(out))
+    if rc:
+        raise DockGpuError(rc, "dgpu_bases_cache_stats")
+    return dict(zip(("hits", "misses", "fills", "stale", "evictions", "bytes", "budget", "entries"), (int(v) for v in out)))
+
+
+def bases_cache_clear():
+    lib().dgpu_bases_cache_clear()
+
+
+def bases_cache_invalidate(arr):
+    """forget every cached entry that overlaps the memory of numpy array `arr`"""
+    rc = lib().dgpu_bases_cache_invalidate(_p(arr), arr.nbytes)
+    if rc:
+        raise DockGpuError(rc, "dgpu_bases_cache_invalidate")
+
+
 def reserve(curve, n):
     """dgpu_reserve_*: size every slot of the calling thread's context for one-shot MSMs of up to n terms"""
     _ensure()

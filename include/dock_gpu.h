@@ -39,6 +39,15 @@ extern "C" {
 #define DGPU_E_LENGTH     -7   /* multi_miller_loop with unequal lengths (arkworks zip_eq panics) */
 
 /* ---- lifecycle ---- */
+/* Optional, before anything else: process-level settings of the ROCm runtime that suit this library.  The library never changes its host's environment on
+ * its own; a host that wants the setting calls this from its start-up code — before the process's first HIP call (the runtime reads its configuration once)
+ * and while no other thread can be inside getenv / setenv.  DGPU_E_BADARG: unknown flag, or this library has already made a HIP call (too late).
+ *   DGPU_HINT_EIGHT_HW_QUEUES   export GPU_MAX_HW_QUEUES=8 unless the variable is set: the runtime maps a process's streams onto that many hardware
+ *                               queues (default 4); with up to six calls in flight, each on three streams, two streams on one queue run one after the
+ *                               other (Miller loop -7 %, aggregation -5 %, MSM rate unchanged: profiles/r05_hwq_bench_ab.txt).  A host that has already
+ *                               initialised HIP (PyTorch) exports the variable itself instead. */
+#define DGPU_HINT_EIGHT_HW_QUEUES 1u
+int32_t dgpu_runtime_hints(uint32_t flags);
 int32_t dgpu_init(int32_t device);           /* bind to a HIP device ordinal (one process per GPU); idempotent */
 /* Several GPUs in ONE process (a Rust host is one process): one context per device, each with its own streams and
  * workspaces.  dgpu_init_devices(mask): bit d = use HIP device d; contexts are numbered 0.. in increasing device order.
@@ -118,6 +127,36 @@ int32_t dgpu_msm_g2(const uint64_t *bases_xy /* n*24 */, const uint8_t *is_inf,
                     const uint64_t *scalars, size_t n, uint64_t out_xyz[36]);
 int32_t dgpu_msm_g2_mont(const uint64_t *bases_xy, const uint8_t *is_inf,
                          const uint64_t *scalars_mont, size_t n, uint64_t out_xyz[36]);
+
+/* ---- the resident-bases cache behind the one-shot entry points above ----
+ * The reference's call sites pass the same proving-key slices proof after proof (legogroth16/src/prover.rs:286,299,363,592 `msm_bigint(&pk.h_query, ..)`,
+ * `&query[1..]`; utils/src/pairs.rs:143-156) and know nothing of handles.  So that the UNMODIFIED call reaches the resident path, dgpu_msm_g1 / _g2
+ * [_mont | _strided] with n >= the cache's threshold (default 2^16) remember what they were given: the first sighting of (pointer, n, layout) runs one-shot
+ * and keeps a 64-bit fingerprint of 32 evenly spaced records; the second sighting with the same fingerprint uploads the points once, keeps a fingerprint of
+ * every record (8 B each, host memory) and turns them into a precomputed-multiples table (dgpu_bases_precompute_*: ~40 ms at 2^20 G1 points, once per key);
+ * from then on the call is dgpu_msm_*_handle on that table — only the scalars cross PCIe (2^20 G1 terms: 5.3 -> ~2.8 ms).  A call whose points lie
+ * INSIDE a resident entry of the same layout (`&query[1..]`, a shorter n) resolves to (entry, offset).  Same group element, limb for limb, either way.
+ * Stale keys: before every use the host re-fingerprints a fresh pseudo-random sample of the call's records (its first and last among them; default 24) and
+ * compares with what was uploaded; a difference evicts the entry and the call runs one-shot.  A buffer refilled with another key is noticed at once; an
+ * IN-PLACE edit of a few records only with probability samples / n per call — a host that edits cached bases in place calls dgpu_bases_cache_invalidate,
+ * selects DGPU_CACHE_VERIFY_FULL (every record re-fingerprinted per call on the library's host threads: exact, ~1-2 ms of host work per 2^20 points,
+ * overlapped with nothing), or turns the cache off.  (Rust: a `&[G1Affine]` borrowed from a `ProvingKey` cannot change while borrowed; between calls it can.)
+ *   dgpu_set_bases_cache_bytes(b)   device bytes the cache may hold (least recently used entries go first; an entry in use is never freed under its
+ *                                   user); 0 = off and emptied.  Default (DGPU_CACHE_BYTES_AUTO): a quarter of the device memory that is free at the
+ *                                   cache's first use.
+ *   dgpu_set_bases_cache_min_n(n)   calls below n terms are never cached (default 65536)
+ *   dgpu_set_bases_cache_verify(s)  records sampled per use (2 .. 4096), or DGPU_CACHE_VERIFY_FULL
+ *   dgpu_bases_cache_invalidate     forget every entry that overlaps [p, p + bytes)
+ *   dgpu_bases_cache_stats          out[0..7] = hits, misses (cacheable calls that ran one-shot), fills, stale evictions, budget evictions, bytes in use,
+ *                                   byte budget (0 until resolved), resident entries */
+#define DGPU_CACHE_VERIFY_FULL (-1)
+#define DGPU_CACHE_BYTES_AUTO (~(size_t)0)
+int32_t dgpu_set_bases_cache_bytes(size_t bytes);
+int32_t dgpu_set_bases_cache_min_n(size_t n);
+int32_t dgpu_set_bases_cache_verify(int32_t samples);
+int32_t dgpu_bases_cache_invalidate(const void *p, size_t bytes);
+int32_t dgpu_bases_cache_clear(void);
+int32_t dgpu_bases_cache_stats(uint64_t out[8]);
 
 /* ---- device-resident operands (proving-key queries live in HBM across proofs) ----
  * `offset` expresses `&query[1..]` (legogroth16/src/prover.rs:592). */

@@ -59,10 +59,14 @@ def test_no_allocation_on_one_shot_calls_after_reserve():
 
 def test_first_one_shot_call_of_a_new_size_sizes_the_idle_slots():
     n = 70001                                       # a size nothing before this test reserved
+    ca.bases_cache(bytes=0)                         # this test is about the ONE-SHOT path: without this the second call would make the bases resident (tests/test_gpu_bases_cache.py)
     bases, _, _ = U.seq_bases(O.G2, n, 10)
     sc = O.rand_scalars(11, n)
     ref = ca.msm_bigint(ca.G2, bases, sc)           # grows its slot and every idle one
     a0 = ca.device_alloc_count()
-    outs = _hammer(lambda: ca.msm_bigint(ca.G2, bases, sc), calls=12, threads=6)
+    try:
+        outs = _hammer(lambda: ca.msm_bigint(ca.G2, bases, sc), calls=12, threads=6)
+    finally:
+        ca.bases_cache(bytes=(1 << 64) - 1)         # DGPU_CACHE_BYTES_AUTO
     assert all((o == ref).all() for o in outs)
     assert ca.device_alloc_count() == a0

@@ -872,11 +872,9 @@ def secondary_configs(log2n, ks, scalars, db, ds, pool, cpu_legs=True, ncpu=1):
 
         def query(tab, curve, name, seed, k, width=None):
             """a proving-key query of k points: straight into HBM, or (CPU legs) through a host copy the CPU path multiplies too"""
-            if cpu_legs:
-                hostq[name], _ = tab.multiply_many(seeded_scalars(seed, k))
-                q = ca.DeviceBases(curve, hostq[name])
-            else:
-                q = tab.multiply_many_to_bases(seeded_scalars(seed, k))
+            # (a host copy of every query: the CPU path multiplies it, and the drop-in leg below hands it over the way a Rust host holds its key)
+            hostq[name], _ = tab.multiply_many(seeded_scalars(seed, k))
+            q = ca.DeviceBases(curve, hostq[name])
             return q.precompute(width) if width else q.precompute()
         qa = query(t1, ca.G1, "a", 0x5EED0012, V + 1, wc_)
         qb1 = query(t1, ca.G1, "b1", 0x5EED0013, V + 1, wc_)
@@ -925,7 +923,66 @@ def secondary_configs(log2n, ks, scalars, db, ds, pool, cpu_legs=True, ncpu=1):
                         "cpu_constraints_per_s": round((m + 1) / (tot_cpu * 1e-3), 1), "gpu_constraints_per_s": res["prove_constraints_per_s"],
                         "cores": max(win_threads(V), thr_wm), "bit_exact_vs_gpu": same_all, "spans_cpu_ms": spans_cpu,
                         "sample": "one 2^%d-constraint LegoGroth16 proof: witness map on %d threads + the five MSMs sequentially, each with one thread per window (<= %d busy cores), same Groth16-like witness as the GPU leg; O(1) finish not included on the CPU side" % (log2n, thr_wm, win_threads(V))}
-        hostq.clear()
+    # -- the DROP-IN: exactly what the reference executes per proof once rust/patches are applied (feature "gpu") — nothing resident that the host put there,
+    #    no handle in the host's hands: witness_map_from_matrices (r1cs_to_qap.rs:150-210, patch 0009) with the matrices and the assignment in host memory and
+    #    h handed back as &[Fr]; then create_proof_and_committed_witnesses_with_assignment (prover.rs:267-383, patch 0005) with the key's queries as slices of
+    #    ark-ec Affine structs in host memory, h and the assignment as &[Fr].  The library's resident-bases cache is what makes the second and later proofs fast.
+    structs = {k_: ca.to_affine_structs(ca.G2 if k_ == "b2" else ca.G1, hostq[k_]) for k_ in ("a", "b1", "b2", "h", "l")}
+    hpk = LG.HostProvingKey(vk, small1[2], small1[3], small1[4], structs["a"], structs["b1"], structs["b2"], structs["h"], structs["l"], a0=small1[5], b1_0=small1[6], b2_0=small2[3])
+    mats_host = ((a_rp, a_cl, a_vl), (a_rp, b_cl, a_vl), (c_rp, c_cl, np.repeat(one, 2 * m + 1, 0)))
+    z_inst, z_wit = np.ascontiguousarray(z[:2]), np.ascontiguousarray(z[2:])
+    ca.bases_cache_clear()
+    di = {}
+
+    def wm_host(circuit_cached):
+        """h as &[Fr] in host memory: the matrices cross PCIe with every call (what the patch does for a constraint system synthesised per proof), or
+        the circuit resident (the Rust glue keys it by a content hash it computes while flattening `ConstraintMatrices`: rust/dock_gpu/src/lib.rs)"""
+        if circuit_cached:
+            return circ.witness_map(z, h_montgomery=True)[0]
+        return qap.witness_map(*mats_host, z, 2, m + 1, h_montgomery=True)[0]
+
+    def drop_in_proof(circuit_cached):
+        h_fr = wm_host(circuit_cached)
+        return LG.prove_host(hpk, 123456789, 987654321, 555, h_fr, z_inst, z_wit, h_montgomery=True)
+    t0 = time.perf_counter(); p_cold = drop_in_proof(False); di["proof_1_cold_ms"] = round((time.perf_counter() - t0) * 1e3, 2)        # every query uploaded for the call
+    t0 = time.perf_counter(); p_fill = drop_in_proof(False); di["proof_2_fill_ms"] = round((time.perf_counter() - t0) * 1e3, 2)        # the cache makes the five queries resident tables
+    assert all((p_cold[k_] == p0[k_]).all() and (p_fill[k_] == p0[k_]).all() for k_ in p0)
+    di["proof_warm_ms"] = round(timed(lambda: drop_in_proof(False), 5, warm=3), 2)
+    di["proof_warm_circuit_cached_ms"] = round(timed(lambda: drop_in_proof(True), 5, warm=3), 2)
+    assert all((drop_in_proof(True)[k_] == p0[k_]).all() for k_ in p0)
+    # create_proof_with_reduction as patched (prover.rs:153-180): the synthesised constraint system's matrices resolve to a resident circuit (content hash in the
+    # Rust glue), the witness map runs inside the prover call, h never leaves the device, z crosses PCIe once
+    p_red = LG.prove_host(hpk, 123456789, 987654321, 555, None, z_inst, z_wit, circuit=circ)
+    assert all((p_red[k_] == p0[k_]).all() for k_ in p0)
+    di["proof_warm_with_reduction_ms"] = round(timed(lambda: LG.prove_host(hpk, 123456789, 987654321, 555, None, z_inst, z_wit, circuit=circ), 6, warm=3), 2)
+    di["witness_map_host_matrices_ms"] = round(timed(lambda: wm_host(False), 3, warm=1), 2)
+    di["witness_map_circuit_cached_ms"] = round(timed(lambda: wm_host(True), 3, warm=1), 2)
+    h_fr = wm_host(True)
+    di["prove_host_warm_ms"] = round(timed(lambda: LG.prove_host(hpk, 123456789, 987654321, 555, h_fr, z_inst, z_wit, h_montgomery=True), 5, warm=2), 2)
+    # the five MSMs as the per-call-site patches of round 5 issue them (one after the other, each its own dgpu_msm_*_strided call): cache on, then off
+    h_can = circ.witness_map(z)[0]
+    n_aux_d, aux_at_d = (m + 1) - cw, 1 + 1 + cw
+
+    def five_msms():
+        return (ca.msm_strided(ca.G1, structs["h"], h_can[:n - 1]), ca.msm_strided(ca.G1, structs["l"][:n_aux_d], z[aux_at_d:aux_at_d + n_aux_d]),
+                ca.msm_strided(ca.G1, structs["a"][1:], z[1:]), ca.msm_strided(ca.G1, structs["b1"][1:], z[1:]), ca.msm_strided(ca.G2, structs["b2"][1:], z[1:]))
+    five_msms(); five_msms()
+    di["five_sequential_strided_msms_warm_ms"] = round(timed(five_msms, 3, warm=1), 2)
+    st_c = ca.bases_cache_stats()
+    di["cache"] = {k_: st_c[k_] for k_ in ("hits", "misses", "fills", "stale", "evictions", "entries")}; di["cache"]["resident_GB"] = round(st_c["bytes"] / 1e9, 2)
+    ca.bases_cache(bytes=0)
+    di["five_sequential_strided_msms_cache_off_ms"] = round(timed(five_msms, 2, warm=1), 2)
+    di["proof_cache_off_ms"] = round(timed(lambda: drop_in_proof(False), 2, warm=1), 2)
+    ca.bases_cache(bytes=(1 << 64) - 1)
+    di["vs_prove_2p20_ms"] = {"warm_with_reduction": round(di["proof_warm_with_reduction_ms"] / res["prove_2p20_ms"], 2), "warm": round(di["proof_warm_ms"] / res["prove_2p20_ms"], 2),
+                              "warm_circuit_cached": round(di["proof_warm_circuit_cached_ms"] / res["prove_2p20_ms"], 2)}
+    if cpu_legs and "prove" in cpu:
+        di["cpu_ms"] = cpu["prove"]["cpu_ms"]; di["x_vs_cpu_warm"] = round(cpu["prove"]["cpu_ms"] / di["proof_warm_ms"], 1)
+    di["note"] = ("one 2^%d-constraint proof through dgpu_witness_map[_r1cs] (h back to the host as &[Fr]) + dgpu_legogroth16_prove_host (queries = host slices of Affine structs, resolved by the "
+                  "resident-bases cache; z and h cross PCIe per proof); bit-identical to prove_2p20_ms's proof; Rust-side costs that cannot be measured here (flattening ConstraintMatrices to CSR) are not included" % log2n)
+    res["drop_in"] = di
+    del structs, hpk
+    hostq.clear()
     # the reference's timer spans (prover.rs:284-369, :578), each stage alone and in the reference's order (one call in flight)
     from crypto_amd import sharded as SH
     dz = ca.DeviceScalars(z)

@@ -43,6 +43,18 @@ class LegoPk(C.Structure):
                [("gamma_abc_len", C.c_size_t), ("commit_witness_count", C.c_size_t)]
 
 
+class BasesView(C.Structure):
+    """include/dock_gpu.h `dgpu_bases_view`: a slice of ark-ec Affine structs in host memory"""
+    _fields_ = [("p", C.c_void_p), ("stride", C.c_size_t), ("x_off", C.c_size_t), ("y_off", C.c_size_t), ("inf_off", C.c_size_t), ("n", C.c_size_t)]
+
+
+class LegoPkHost(C.Structure):
+    """include/dock_gpu.h `dgpu_lego_pk_host`"""
+    _fields_ = [(k, BasesView) for k in ("a_query", "b_g1_query", "b_g2_query", "h_query", "l_query")] + \
+               [(k, C.c_void_p) for k in ("alpha_g1", "beta_g1", "delta_g1", "eta_delta_inv_g1", "eta_gamma_inv_g1", "beta_g2", "delta_g2", "a0", "b1_0", "b2_0", "gamma_abc_g1")] + \
+               [("gamma_abc_len", C.c_size_t), ("commit_witness_count", C.c_size_t)]
+
+
 APPEND_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t, C.POINTER(C.c_uint8), C.c_size_t)
 CHALLENGE_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t, C.POINTER(C.c_uint64))
 
@@ -87,7 +99,7 @@ SYMBOLS = [
     "dgpu_msm_g1_sharded", "dgpu_msm_g2_sharded", "dgpu_bases_upload_g1_sharded", "dgpu_bases_upload_g2_sharded", "dgpu_msm_g1_sharded_handle", "dgpu_msm_g2_sharded_handle", "dgpu_scalars_upload_sharded", "dgpu_scalars_copy_range", "dgpu_msm_g1_sharded_resident", "dgpu_msm_g2_sharded_resident",
     "dgpu_fold_g1", "dgpu_fold_g2", "dgpu_lincomb_g1", "dgpu_lincomb_g2", "dgpu_multi_miller_loop", "dgpu_multi_miller_loop_sharded", "dgpu_bases_table_shape", "dgpu_scalars_sort", "dgpu_msm_g1_sorted", "dgpu_msm_g2_sorted", "dgpu_multi_miller_loop_segments", "dgpu_multi_pairing_segments", "dgpu_g2_prepare", "dgpu_multi_miller_loop_prepared", "dgpu_multi_miller_loop_mixed", "dgpu_multi_miller_loop_scaled", "dgpu_final_exponentiation", "dgpu_g1_scale_batch", "dgpu_fp12_mul", "dgpu_fp12_pow", "dgpu_fp12_multi_pow", "dgpu_gt_in_subgroup", "dgpu_g1_serialize", "dgpu_g1_deserialize", "dgpu_g2_serialize", "dgpu_g2_deserialize", "dgpu_witness_map", "dgpu_r1cs_upload", "dgpu_r1cs_free", "dgpu_r1cs_shape", "dgpu_witness_map_r1cs", "dgpu_witness_map_r1cs_resident",
     "dgpu_window_table_g1", "dgpu_window_table_g2", "dgpu_window_table_free", "dgpu_window_table_mul_g1", "dgpu_window_table_mul_g2", "dgpu_window_table_mul_to_bases_g1", "dgpu_window_table_mul_to_bases_g2", "dgpu_fixed_base_g1", "dgpu_fixed_base_g2", "dgpu_g1_mul_add_batch", "dgpu_g2_mul_add_batch",
-    "dgpu_legogroth16_prove", "dgpu_legogroth16_verify", "dgpu_legogroth16_verify_batch", "dgpu_handle_len", "dgpu_handle_context", "dgpu_shard_count", "dgpu_shard_part",
+    "dgpu_legogroth16_prove", "dgpu_legogroth16_prove_host", "dgpu_legogroth16_verify", "dgpu_legogroth16_verify_batch", "dgpu_handle_len", "dgpu_handle_context", "dgpu_shard_count", "dgpu_shard_part",
     "dgpu_snarkpack_proof_words", "dgpu_snarkpack_aggregate", "dgpu_snarkpack_verify",
     "dgpu_g1_fold_prepare", "dgpu_g2_fold_prepare", "dgpu_fold_prepare_pair", "dgpu_g1_fold_apply", "dgpu_g2_fold_apply", "dgpu_fold_free",
 ]
@@ -249,6 +261,7 @@ def _load(path):
         for name in ("dgpu_g1_mul_add_batch", "dgpu_g2_mul_add_batch"):
             getattr(L, name).argtypes = [vp, vp, vp, sz, vp, vp, sz, vp, vp]
         L.dgpu_legogroth16_prove.argtypes = [vp, u64, u64, vp, sz, sz, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp]
+        L.dgpu_legogroth16_prove_host.argtypes = [vp, u64, vp, sz, C.c_int32, vp, sz, vp, sz, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp]
         for name in ("dgpu_g1_fold_prepare", "dgpu_g2_fold_prepare"):
             getattr(L, name).argtypes = [vp, sz, C.POINTER(u64)]
         for name in ("dgpu_g1_fold_apply", "dgpu_g2_fold_apply"):

@@ -9,6 +9,14 @@ int32_t msm_g1_nothreshold(const uint64_t *b, const uint8_t *inf, const uint64_t
 }
 }  // namespace dock
 
+namespace dock {
+// a host view of G1 bases as a handle for the duration of a larger call (dock_prover.cpp: dgpu_legogroth16_prove_host)
+int32_t view_acquire_g1(const void *p, size_t stride, size_t x_off, size_t y_off, size_t inf_off, size_t n, int table_c, uint64_t *handle, void **pin) {
+    return view_acquire<G1>(RawBases{(const uint8_t *)p, stride, x_off, y_off, inf_off, nullptr}, n, 1, table_c, handle, pin);
+}
+void view_release_any(void *pin) { view_release(pin); }
+}  // namespace dock
+
 extern "C" {
 int32_t dgpu_fold_g1(const uint64_t *xyz, size_t k, uint64_t out[18]) { return host_fold_jacobian<hostf::Fq>(xyz, k, out); }
 int32_t dgpu_lincomb_g1(const uint64_t *p, const uint8_t *inf, const uint64_t *s, size_t k, uint64_t out[18]) { return host_lincomb<hostf::Fq>(p, inf, s, k, out); }

@@ -2,6 +2,13 @@
 #include "msm_driver.hip.h"
 using namespace dock;
 
+namespace dock {
+// a host view of G2 bases as a handle for the duration of a larger call (dock_prover.cpp: dgpu_legogroth16_prove_host)
+int32_t view_acquire_g2(const void *p, size_t stride, size_t x_off, size_t y_off, size_t inf_off, size_t n, int table_c, uint64_t *handle, void **pin) {
+    return view_acquire<G2>(RawBases{(const uint8_t *)p, stride, x_off, y_off, inf_off, nullptr}, n, 2, table_c, handle, pin);
+}
+}  // namespace dock
+
 extern "C" {
 int32_t dgpu_fold_g2(const uint64_t *xyz, size_t k, uint64_t out[36]) { return host_fold_jacobian<hostf::Fq2>(xyz, k, out); }
 int32_t dgpu_lincomb_g2(const uint64_t *p, const uint8_t *inf, const uint64_t *s, size_t k, uint64_t out[36]) { return host_lincomb<hostf::Fq2>(p, inf, s, k, out); }

@@ -22,6 +22,7 @@
 #include <vector>
 #include "../../include/dock_gpu.h"
 #include "host_field.hpp"
+#include "host_par.hpp"
 
 namespace dock {
 extern thread_local bool tl_no_min;          // dock_core.hip: the size threshold (DGPU_E_TOO_SMALL) is for callers, not for the library's own calls
@@ -75,7 +76,12 @@ int32_t fold_to_affine_g1(const uint64_t *parts, size_t k, uint64_t out[12], uin
     return DGPU_OK;
 }
 
-struct ProofInputs { const dgpu_lego_pk *pk; const uint64_t *z; size_t n_inst; int32_t montgomery; uint64_t r[4], s[4], v[4]; bool with_b1; };
+// z = the full assignment, given as consecutive host arrays (one for dgpu_legogroth16_prove; instance and witness for _prove_host)
+struct ProofInputs {
+    const dgpu_lego_pk *pk; const uint64_t *const *z_parts; const size_t *z_counts; size_t z_nparts; size_t n_inst; int32_t montgomery; uint64_t r[4], s[4], v[4]; bool with_b1;
+    const uint64_t *zat(size_t i) const { for (size_t k = 0; k < z_nparts; k++) { if (i < z_counts[k]) return z_parts[k] + 4 * i; i -= z_counts[k]; } return nullptr; }
+    const uint64_t *z() const { return z_parts[0]; }          // (the sharded form: one part)
+};
 struct ProofConsts { uint64_t rest_a[18], rest_b1[18], rest_c[18], rest_b2[36], g_d[18]; };
 // what depends on no MSM (host arithmetic; the tiny g_d MSM goes to the device only when it has more than 15 terms)
 int32_t proof_constants(const ProofInputs &in, ProofConsts &c) {
@@ -97,7 +103,7 @@ int32_t proof_constants(const ProofInputs &in, ProofConsts &c) {
     std::vector<uint64_t> pts((cw + 1) * 12), sc((cw + 1) * 4);
     if (cw) memcpy(pts.data(), pk->gamma_abc_g1 + in.n_inst * 12, cw * 96);
     memcpy(pts.data() + cw * 12, pk->eta_gamma_inv_g1, 96);
-    for (size_t i = 0; i < cw; i++) { if (in.montgomery) hostf::fr_from_mont(&sc[4 * i], in.z + 4 * (in.n_inst + i)); else memcpy(&sc[4 * i], in.z + 4 * (in.n_inst + i), 32); }
+    for (size_t i = 0; i < cw; i++) { const uint64_t *zi = in.zat(in.n_inst + i); if (in.montgomery) hostf::fr_from_mont(&sc[4 * i], zi); else memcpy(&sc[4 * i], zi, 32); }
     memcpy(&sc[4 * cw], in.v, 32);
     if (cw + 1 <= DGPU_MAX_LINCOMB) return dgpu_lincomb_g1(pts.data(), nullptr, sc.data(), cw + 1, c.g_d);
     return dock::msm_g1_nothreshold(pts.data(), nullptr, sc.data(), cw + 1, c.g_d);
@@ -137,21 +143,26 @@ int32_t prove_sharded(const ProofInputs &in, size_t G, uint64_t r1cs, uint64_t h
 
 
 
-static int32_t prove_impl(const dgpu_lego_pk *pk, uint64_t r1cs, uint64_t h_scalars, const uint64_t *z, size_t num_vars, size_t n_inst,
+// z: the assignment as consecutive host arrays; h_host != nullptr: the D coefficients of h in host memory (uploaded beside z), else r1cs / h_scalars
+static int32_t prove_impl(const dgpu_lego_pk *pk, uint64_t r1cs, uint64_t h_scalars, const uint64_t *h_host, size_t h_len, int32_t h_montgomery,
+                          const uint64_t *const *z_parts, const size_t *z_counts, size_t z_nparts, size_t n_inst,
                           int32_t montgomery, const uint64_t r_in[4], const uint64_t s_in[4], const uint64_t v_in[4],
                           uint64_t out_a[12], uint64_t out_b[24], uint64_t out_c[12], uint64_t out_d[12], uint8_t out_inf[4]);
 extern "C" int32_t dgpu_legogroth16_prove(const dgpu_lego_pk *pk, uint64_t r1cs, uint64_t h_scalars, const uint64_t *z, size_t num_vars, size_t n_inst,
                                           int32_t montgomery, const uint64_t r_in[4], const uint64_t s_in[4], const uint64_t v_in[4],
                                           uint64_t out_a[12], uint64_t out_b[24], uint64_t out_c[12], uint64_t out_d[12], uint8_t out_inf[4]) {
-    try { return prove_impl(pk, r1cs, h_scalars, z, num_vars, n_inst, montgomery, r_in, s_in, v_in, out_a, out_b, out_c, out_d, out_inf); }
+    try { return prove_impl(pk, r1cs, h_scalars, nullptr, 0, 0, &z, &num_vars, 1, n_inst, montgomery, r_in, s_in, v_in, out_a, out_b, out_c, out_d, out_inf); }
     catch (const std::bad_alloc &) { return DGPU_E_OOM; }
     catch (...) { return DGPU_E_HIP; }
 }
-static int32_t prove_impl(const dgpu_lego_pk *pk, uint64_t r1cs, uint64_t h_scalars, const uint64_t *z, size_t num_vars, size_t n_inst,
+static int32_t prove_impl(const dgpu_lego_pk *pk, uint64_t r1cs, uint64_t h_scalars, const uint64_t *h_host, size_t h_len, int32_t h_montgomery,
+                          const uint64_t *const *z_parts, const size_t *z_counts, size_t z_nparts, size_t n_inst,
                           int32_t montgomery, const uint64_t r_in[4], const uint64_t s_in[4], const uint64_t v_in[4],
                           uint64_t out_a[12], uint64_t out_b[24], uint64_t out_c[12], uint64_t out_d[12], uint8_t out_inf[4]) {
-    if (!pk || !z || !r_in || !s_in || !v_in || !out_a || !out_b || !out_c || !out_d || !out_inf) return DGPU_E_BADARG;
-    if ((r1cs != 0) == (h_scalars != 0)) return DGPU_E_BADARG;                      // exactly one source of h
+    if (!pk || !z_parts || !z_counts || z_nparts == 0 || !r_in || !s_in || !v_in || !out_a || !out_b || !out_c || !out_d || !out_inf) return DGPU_E_BADARG;
+    size_t num_vars = 0;
+    for (size_t k = 0; k < z_nparts; k++) { if (z_counts[k] && !z_parts[k]) return DGPU_E_BADARG; num_vars += z_counts[k]; }
+    if ((r1cs != 0) + (h_scalars != 0) + (h_host != nullptr) != 1) return DGPU_E_BADARG;       // exactly one source of h
     const size_t cw = pk->commit_witness_count;
     if (n_inst == 0 || n_inst + cw > num_vars || pk->gamma_abc_len < n_inst + cw) return DGPU_E_BADARG;
     if (!pk->alpha_g1 || !pk->beta_g1 || !pk->delta_g1 || !pk->eta_delta_inv_g1 || !pk->eta_gamma_inv_g1 || !pk->beta_g2 || !pk->delta_g2 ||
@@ -160,11 +171,11 @@ static int32_t prove_impl(const dgpu_lego_pk *pk, uint64_t r1cs, uint64_t h_scal
         size_t cv = 0, ci = 0;
         if (dgpu_r1cs_shape(r1cs, &cv, &ci, nullptr) != DGPU_OK || cv != num_vars || ci != n_inst) return DGPU_E_BADARG;
     }
-    ProofInputs in{pk, z, n_inst, montgomery, {0}, {0}, {0}, false};
+    ProofInputs in{pk, z_parts, z_counts, z_nparts, n_inst, montgomery, {0}, {0}, {0}, false};
     fr_reduce(in.r, r_in); fr_reduce(in.s, s_in); fr_reduce(in.v, v_in);
     in.with_b1 = !is_zero4(in.r);                                                    // prover.rs:330-336
     { int32_t shards = 0;                                                           // a key resident across several device contexts (dgpu_bases_upload_*_sharded)
-      if (dgpu_shard_count(pk->a_query, &shards) == DGPU_OK && shards > 0) return prove_sharded(in, (size_t)shards, r1cs, h_scalars, num_vars, out_a, out_b, out_c, out_d, out_inf); }
+      if (dgpu_shard_count(pk->a_query, &shards) == DGPU_OK && shards > 0) return (z_nparts != 1 || h_host) ? (int32_t)DGPU_E_BADARG : prove_sharded(in, (size_t)shards, r1cs, h_scalars, num_vars, out_a, out_b, out_c, out_d, out_inf); }
     size_t n_a = 0, n_b1 = 0, n_b2 = 0, n_h = 0, n_l = 0;
     if (dgpu_handle_len(pk->a_query, &n_a) || dgpu_handle_len(pk->b_g1_query, &n_b1) || dgpu_handle_len(pk->b_g2_query, &n_b2) ||
         dgpu_handle_len(pk->h_query, &n_h) || dgpu_handle_len(pk->l_query, &n_l) || n_a == 0 || n_b1 == 0 || n_b2 == 0) return DGPU_E_BADARG;
@@ -172,7 +183,7 @@ static int32_t prove_impl(const dgpu_lego_pk *pk, uint64_t r1cs, uint64_t h_scal
 
     // ---- z resident, once ----
     uint64_t zh = 0;
-    int32_t rc = dgpu_scalars_upload(z, num_vars, montgomery, &zh);
+    int32_t rc = dgpu_scalars_upload_parts(z_parts, z_counts, z_nparts, montgomery, &zh);
     if (rc) return rc;
     const size_t n_assign = num_vars - 1;                                            // assignment = z[1..]
     const size_t n_aux = num_vars - n_inst - cw, aux_at = n_inst + cw;              // aux = witnesses after the committed ones (prover.rs:292-299)
@@ -183,7 +194,8 @@ static int32_t prove_impl(const dgpu_lego_pk *pk, uint64_t r1cs, uint64_t h_scal
     Job jH, jB2, jA, jB1, jL, jK;
     jH.start([&]() -> int32_t {
         uint64_t hh = h_scalars; size_t D = 0;
-        if (r1cs) { int32_t e = dgpu_witness_map_r1cs_resident(r1cs, zh, nullptr, &h_owned, &D); if (e) return e; hh = h_owned; }
+        if (h_host) { int32_t e = dgpu_scalars_upload(h_host, h_len, h_montgomery, &h_owned); if (e) return e; hh = h_owned; D = h_len; }
+        else if (r1cs) { int32_t e = dgpu_witness_map_r1cs_resident(r1cs, zh, nullptr, &h_owned, &D); if (e) return e; hh = h_owned; }
         else if (dgpu_handle_len(hh, &D)) return DGPU_E_BADARG;
         return dgpu_msm_g1_resident(pk->h_query, 0, hh, 0, std::min(n_h, D), acc_h);          // :286 (h_query has D - 1 points)
     });
@@ -262,7 +274,7 @@ int32_t prove_sharded(const ProofInputs &in, size_t G, uint64_t r1cs, uint64_t h
     jW.start([&]() -> int32_t {
         int32_t rctx = 0; if (dgpu_handle_context(r1cs, &rctx)) return DGPU_E_BADARG;
         if (dgpu_set_device(rctx)) return DGPU_E_BADARG;
-        return dgpu_witness_map_r1cs(r1cs, in.z, num_vars, in.montgomery, nullptr, &h_dev, &D);
+        return dgpu_witness_map_r1cs(r1cs, in.z(), num_vars, in.montgomery, nullptr, &h_dev, &D);
     });
     ProofConsts cst; Job jK;
     jK.start([&] { return proof_constants(in, cst); });
@@ -283,7 +295,7 @@ int32_t prove_sharded(const ProofInputs &in, size_t G, uint64_t r1cs, uint64_t h
         uint64_t zs = 0, srt = 0;
         if (hi > lo) {
             const size_t n = hi - lo, boff = lo - A[g].lo;
-            if ((e = dgpu_scalars_upload(in.z + 4 * lo, n, in.montgomery, &zs))) return e;
+            if ((e = dgpu_scalars_upload(in.z() + 4 * lo, n, in.montgomery, &zs))) return e;
             size_t ra = 0, rx = 0; int32_t ca = 0, cx = 0, wa = 0, wx = 0;
             bool share = dgpu_bases_table_shape(A[g].sub, &ra, &ca, &wa) == DGPU_OK && dgpu_bases_table_shape(B2[g].sub, &rx, &cx, &wx) == DGPU_OK && rx == ra && cx == ca;
             if (share && in.with_b1) share = dgpu_bases_table_shape(B1[g].sub, &rx, &cx, &wx) == DGPU_OK && rx == ra && cx == ca;
@@ -301,7 +313,7 @@ int32_t prove_sharded(const ProofInputs &in, size_t G, uint64_t r1cs, uint64_t h
         } else { identity1(&pa[18 * g]); identity1(&pb1[18 * g]); identity2(&pb2[36 * g]); }
         // l_query rows [lo, hi) pair with z[aux_at + row]
         { const size_t llo = L[g].lo, lhi = std::min(L[g].hi, num_vars - std::min(num_vars, aux_at));
-          if (lhi > llo) { uint64_t zl = 0; if ((e = dgpu_scalars_upload(in.z + 4 * (aux_at + llo), lhi - llo, in.montgomery, &zl))) return e;
+          if (lhi > llo) { uint64_t zl = 0; if ((e = dgpu_scalars_upload(in.z() + 4 * (aux_at + llo), lhi - llo, in.montgomery, &zl))) return e;
                            e = dgpu_msm_g1_resident(L[g].sub, 0, zl, 0, lhi - llo, &pl[18 * g]); (void)dgpu_scalars_free(zl); if (e) return e; }
           else identity1(&pl[18 * g]); }
         // h_query rows [lo, hi) pair with h[row] (canonical, from the witness map)
@@ -327,3 +339,41 @@ int32_t prove_sharded(const ProofInputs &in, size_t G, uint64_t r1cs, uint64_t h
     return proof_finish(cst, ab, acc_b2, acc_l, acc_h, out_a, out_b, out_c, out_d, out_inf);
 }
 }  // namespace
+
+// ---- the same prover for a host that holds its proving key as ark-ec slices (the reference: legogroth16/src/prover.rs:267-383 receives
+// `pk_common: &ProvingKeyCommon<E>`, whose queries are Vec<G1Affine> / Vec<G2Affine>, and `h: &[E::ScalarField]` from QAP::witness_map) ----
+// Every query is a view of host memory that the resident-bases cache resolves (bases_cache.hpp): at a key's second proof its queries are uploaded once
+// and become tables, later proofs run dgpu_legogroth16_prove's schedule on them — only z and h cross PCIe.  A view the cache does not hold (the first
+// proof, the cache off or full) is uploaded for the duration of the call.
+namespace dock {
+int32_t view_acquire_g1(const void *p, size_t stride, size_t x_off, size_t y_off, size_t inf_off, size_t n, int table_c, uint64_t *handle, void **pin);      // dock_g1.hip
+int32_t view_acquire_g2(const void *p, size_t stride, size_t x_off, size_t y_off, size_t inf_off, size_t n, int table_c, uint64_t *handle, void **pin);      // dock_g2.hip
+void view_release_any(void *pin);
+}
+extern "C" int32_t dgpu_legogroth16_prove_host(const dgpu_lego_pk_host *pk, uint64_t r1cs, const uint64_t *h, size_t h_len, int32_t h_montgomery,
+                                               const uint64_t *instance, size_t n_inst, const uint64_t *witness, size_t n_wit, int32_t montgomery,
+                                               const uint64_t r_in[4], const uint64_t s_in[4], const uint64_t v_in[4],
+                                               uint64_t out_a[12], uint64_t out_b[24], uint64_t out_c[12], uint64_t out_d[12], uint8_t out_inf[4]) {
+    if (!pk || ((h != nullptr) == (r1cs != 0)) || !instance || n_inst == 0 || (n_wit && !witness)) return DGPU_E_BADARG;      // exactly one source of h
+    try {
+        struct Pins { void *p[5] = {}; ~Pins() { for (void *q : p) dock::view_release_any(q); } } pins;
+        dgpu_lego_pk k{};
+        const dgpu_bases_view *v[5] = {&pk->a_query, &pk->b_g1_query, &pk->b_g2_query, &pk->h_query, &pk->l_query};
+        uint64_t *hd[5] = {&k.a_query, &k.b_g1_query, &k.b_g2_query, &k.h_query, &k.l_query};
+        // the queries that meet the witness take the narrower table (include/dock_gpu.h DGPU_TABLE_C_WITNESS), the h query the automatic width
+        // (a resident view costs microseconds; the uploads and table builds of a cold key run side by side, on the calling thread's device context)
+        const int32_t arc = dock::par_run(5, [&](size_t i) -> int32_t {
+            const int c = i == 3 ? 0 : (v[i]->n >= ((size_t)1 << 17) ? DGPU_TABLE_C_WITNESS : 0);
+            return i == 2 ? dock::view_acquire_g2(v[i]->p, v[i]->stride, v[i]->x_off, v[i]->y_off, v[i]->inf_off, v[i]->n, c, hd[i], &pins.p[i])
+                          : dock::view_acquire_g1(v[i]->p, v[i]->stride, v[i]->x_off, v[i]->y_off, v[i]->inf_off, v[i]->n, c, hd[i], &pins.p[i]);
+        });
+        if (arc) return arc;
+        k.alpha_g1 = pk->alpha_g1; k.beta_g1 = pk->beta_g1; k.delta_g1 = pk->delta_g1; k.eta_delta_inv_g1 = pk->eta_delta_inv_g1; k.eta_gamma_inv_g1 = pk->eta_gamma_inv_g1;
+        k.beta_g2 = pk->beta_g2; k.delta_g2 = pk->delta_g2; k.a0 = pk->a0; k.b1_0 = pk->b1_0; k.b2_0 = pk->b2_0;
+        k.gamma_abc_g1 = pk->gamma_abc_g1; k.gamma_abc_len = pk->gamma_abc_len; k.commit_witness_count = pk->commit_witness_count;
+        const uint64_t *parts[2] = {instance, witness}; const size_t counts[2] = {n_inst, n_wit};
+        return prove_impl(&k, r1cs, 0, h, h_len, h_montgomery, parts, counts, n_wit ? 2 : 1, n_inst, montgomery, r_in, s_in, v_in, out_a, out_b, out_c, out_d, out_inf);
+    }
+    catch (const std::bad_alloc &) { return DGPU_E_OOM; }
+    catch (...) { return DGPU_E_HIP; }
+}

@@ -102,7 +102,7 @@ int32_t witness_map_device(Slot &sl, const DevR1cs &r, const uint64_t *assignmen
         if (!d_assignment) HIPCHK(hipMemcpyAsync(zw.p, assignment, r.num_vars * 32, hipMemcpyHostToDevice, s));
         const uint32_t *zsrc = d_assignment ? d_assignment : zw.as<uint32_t>();
         for (int k = 0; k < 3; k++)
-            ntt::launch_csr_eval(s, r.m[k].rowptr, r.m[k].cols, r.m[k].vals, r.m[k].nnz, zsrc, d_assignment ? 0 : montgomery, r.num_vars, r.num_constraints, k == 0 ? r.num_inputs : 0, arr[k], D);
+            ntt::launch_csr_eval(s, r.m[k].rowptr, r.m[k].cols, r.m[k].vals, r.m[k].nnz, zsrc, d_assignment ? 0 : (montgomery & 1), r.num_vars, r.num_constraints, k == 0 ? r.num_inputs : 0, arr[k], D);
     }
     {
         StageTimer st(sl, "qap.ntt");
@@ -113,7 +113,15 @@ int32_t witness_map_device(Slot &sl, const DevR1cs &r, const uint64_t *assignmen
     }
     HIPCHK(hipGetLastError());
     if (out_len) *out_len = D;
-    if (out_h && hipMemcpyAsync(out_h, h_words, D * 32, hipMemcpyDeviceToHost, s) != hipSuccess) { (void)hipGetLastError(); return DGPU_E_HIP; }
+    if (out_h) {
+        const uint32_t *src = h_words;
+        if (montgomery & DGPU_WM_H_MONTGOMERY) {          // the host copy as &[Fr] (what QAP::witness_map returns); a resident vector stays canonical
+            if (kept) { if ((rc = hw.ensure(D * 32))) return rc; HIPCHK(hipMemcpyAsync(hw.p, h_words, D * 32, hipMemcpyDeviceToDevice, s)); }
+            ntt::launch_fr_canonical_to_mont(s, hw.as<uint32_t>(), D);
+            src = hw.as<uint32_t>();
+        }
+        if (hipMemcpyAsync(out_h, src, D * 32, hipMemcpyDeviceToHost, s) != hipSuccess) { (void)hipGetLastError(); return DGPU_E_HIP; }
+    }
     if (hipStreamSynchronize(s) != hipSuccess) { (void)hipGetLastError(); return DGPU_E_HIP; }
     if (out_handle) { *out_handle = register_handle(kept, D, 3); kept = nullptr; }     // registered last: no handle is left behind by a failing call
     if (gs.prof) prof_flush(sl);
@@ -123,7 +131,7 @@ int32_t witness_map_device(Slot &sl, const DevR1cs &r, const uint64_t *assignmen
 int32_t build_r1cs(Slot &sl, const Csr mats[3], size_t num_vars, size_t num_inputs, size_t num_constraints, int32_t montgomery, DevR1cs **out) {
     DevR1cs *r = new DevR1cs();
     r->num_vars = num_vars; r->num_inputs = num_inputs; r->num_constraints = num_constraints;
-    for (int k = 0; k < 3; k++) { int32_t rc = upload_matrix(sl, mats[k], num_constraints, montgomery, r->m[k]); if (rc) { free_r1cs(r); return rc; } }
+    for (int k = 0; k < 3; k++) { int32_t rc = upload_matrix(sl, mats[k], num_constraints, montgomery & 1, r->m[k]); if (rc) { free_r1cs(r); return rc; } }
     *out = r;
     return DGPU_OK;
 }

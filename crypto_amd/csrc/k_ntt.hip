@@ -7,6 +7,7 @@
 namespace ntt {
 static inline dim3 grid_for(size_t n) { return dim3((unsigned)((n + 255) / 256)); }
 void launch_fr_mont_to_canonical(hipStream_t s, uint32_t *words, size_t n) { hipLaunchKernelGGL(k_fr_mont_to_canonical, grid_for(n), dim3(256), 0, s, words, n); }
+void launch_fr_canonical_to_mont(hipStream_t s, uint32_t *words, size_t n) { hipLaunchKernelGGL(k_fr_canonical_to_mont, grid_for(n), dim3(256), 0, s, words, n); }
 void launch_fr_load(hipStream_t s, const uint32_t *words, size_t n, int mont, uint32_t *out, size_t D) { hipLaunchKernelGGL(k_fr_load, grid_for(D), dim3(256), 0, s, words, n, mont, out, D); }
 void launch_fr_powers(hipStream_t s, const uint32_t *bw, const uint32_t *sw, size_t count, uint32_t *out) { hipLaunchKernelGGL(k_fr_powers, grid_for(count), dim3(256), 0, s, bw, sw, count, out); }
 void launch_tw_compact(hipStream_t s, uint32_t *tw, size_t H) {

@@ -953,40 +953,42 @@ int32_t msm_handle(uint64_t bases, size_t offset, const uint64_t *scalars, size_
 }
 
 // ---- the resident-bases cache (bases_cache.hpp) --------------------------------------------------------------------------------------------
-// device bytes an entry of n points will hold once it is a table (or stays plain: choose_c_pre)
-template <class C> inline size_t cache_entry_bytes(size_t n) {
-    const int c = choose_c_pre(n);
+// device bytes of an entry of n points as a table of width c (0: the automatic choice; a handle too short for a table stays plain)
+template <class C> inline size_t cache_entry_bytes(size_t n, int c) {
+    if (c == 0) c = choose_c_pre(n);
     if (c == 0) return n * (size_t)C::AFF_STRIDE * 4 + (n <= SMALL_MSM_MAX_N ? small_sub_bytes<C>(n) : 0);
     return pre_tab_bytes<C>(n, 255 / c + 1);
 }
-// true: the call was served from a resident entry and rc is its answer; false: run it one-shot (first sighting, another thread is filling the entry,
-// a stale or oversized key, a device error on the way)
-template <class C, class HF>
-bool msm_oneshot_cached(const RawBases &rb, const uint64_t *scalars, size_t n, bool mont, uint64_t *out, int kind, int32_t &rc) {
+// The cache's state machine for one sighting of `rb` (n points): true = `e` is a resident entry that still matches the caller's memory (records
+// [off, off + n) of its handle; the shared_ptr pins it), false = not resident (first sighting, another thread is filling the entry, a stale or oversized
+// key, a failed fill): the caller takes the points from host memory.  table_c: window width of the table a fill builds (0 = automatic).
+template <class C>
+bool cache_acquire(const RawBases &rb, size_t n, int kind, int table_c, std::shared_ptr<CacheEntry> &e, size_t &off) {
     const CacheKey key{rb.p, n, rb.stride, rb.x_off, rb.y_off, rb.inf_off, rb.is_inf, kind, cur_index()};
     constexpr int words = C::ABI_W / 2;
-    std::vector<std::shared_ptr<CacheEntry>> dropped;        // (destroyed after the lock is released: an entry's destructor frees its handle)
-    std::shared_ptr<CacheEntry> e;
-    size_t off = 0;
+    std::vector<std::shared_ptr<CacheEntry>> dropped;        // (destroyed after the locks are released: an entry's destructor frees its handle)
+    e.reset(); off = 0;
     bool fill = false;
     {
         std::lock_guard<std::mutex> lk(gcache.mu);
         for (auto &c : gcache.entries) if (c->state == CacheEntry::READY && key.inside(c->k, &off)) { e = c; e->last_use = ++gcache.tick; break; }
     }
-    if (e && !cache_verify(*e, key, off, words)) {            // the host memory behind the entry changed: forget it, run one-shot, start over as a first sighting
+    if (e && !cache_verify(*e, key, off, words)) {            // the host memory behind the entry changed: forget it; this sighting is the new contents' first
         std::lock_guard<std::mutex> lk(gcache.mu);
         cache_remove_locked(e.get(), dropped);
         gcache.stale++; e.reset();
     }
-    if (!e) {
-        const uint64_t fp = range_fingerprint(key, words);
-        size_t budget_auto = 0;
-        if (gcache.budget == CACHE_BUDGET_AUTO) {           // a quarter of what the device has free now (resolved once; dgpu_set_bases_cache_bytes overrides)
-            size_t fr = 0, tot = 0;
-            if (hipSetDevice(cur().device) == hipSuccess && hipMemGetInfo(&fr, &tot) == hipSuccess) budget_auto = fr / 4; else (void)hipGetLastError();
-        }
+    if (e) return true;
+    off = 0;
+    const uint64_t fp = range_fingerprint(key, words);
+    size_t budget_auto = 0;
+    if (gcache.budget.load() == CACHE_BUDGET_AUTO) {          // a quarter of what the device has free now (resolved once; dgpu_set_bases_cache_bytes overrides)
+        size_t fr = 0, tot = 0;
+        if (hipSetDevice(cur().device) == hipSuccess && hipMemGetInfo(&fr, &tot) == hipSuccess) budget_auto = fr / 4; else (void)hipGetLastError();
+    }
+    {
         std::lock_guard<std::mutex> lk(gcache.mu);
-        if (gcache.budget == CACHE_BUDGET_AUTO) gcache.budget = budget_auto;
+        if (gcache.budget.load() == CACHE_BUDGET_AUTO) gcache.budget = budget_auto;
         std::shared_ptr<CacheEntry> seen;
         for (auto &c : gcache.entries) if (c->state != CacheEntry::READY && c->k.same(key)) { seen = c; break; }
         if (!seen) {                                          // first sighting: remember the fingerprint
@@ -998,41 +1000,72 @@ bool msm_oneshot_cached(const RawBases &rb, const uint64_t *scalars, size_t n, b
         } else if (seen->state == CacheEntry::SEEN) {
             seen->last_use = ++gcache.tick;
             if (seen->fp != fp) seen->fp = fp;                // other contents at the same address: a first sighting again
-            else if (cache_make_room_locked(cache_entry_bytes<C>(n), seen.get(), dropped)) { seen->state = CacheEntry::FILLING; e = seen; fill = true; }
+            else if (cache_make_room_locked(cache_entry_bytes<C>(n, table_c), seen.get(), dropped)) { seen->state = CacheEntry::FILLING; e = seen; fill = true; }
         }                                                     // (FILLING: another thread is uploading this key right now)
-        if (!e) { gcache.misses++; return false; }
     }
-    if (fill) {
-        // second sighting: upload once (+ the per-record fingerprints), make it a table
-        e->rec_hash.resize(n);
-        uint64_t h = 0;
-        int32_t frc = bases_upload<C>(rb, n, &h, kind, &e->rec_hash);
-        if (!frc) {
-            frc = bases_precompute<C>(h, 0, kind);
-            if (frc) { (void)dgpu_bases_free(h); h = 0; }
-        }
-        std::lock_guard<std::mutex> lk(gcache.mu);
-        if (frc) { cache_remove_locked(e.get(), dropped); gcache.misses++; return false; }
-        e->handle = h; e->bytes = cache_entry_bytes<C>(n); gcache.fills++;
-        bool listed = false;
-        for (auto &c : gcache.entries) if (c.get() == e.get()) listed = true;
-        // (not listed any more: dgpu_bases_cache_clear ran meanwhile — this call still uses the table, which goes when the call lets go of it)
-        if (listed) { e->state = CacheEntry::READY; e->last_use = ++gcache.tick; gcache.used += e->bytes; }
-        // an older entry that lies wholly inside the new one is redundant
-        for (size_t i = 0; i < gcache.entries.size();) {
+    if (!fill) { gcache.misses++; return false; }
+    // second sighting: upload once (+ the per-record fingerprints), make it a table
+    e->rec_hash.resize(n);
+    uint64_t h = 0;
+    int32_t frc = bases_upload<C>(rb, n, &h, kind, &e->rec_hash);
+    if (!frc) {
+        frc = bases_precompute<C>(h, table_c, kind);
+        if (frc) { (void)dgpu_bases_free(h); h = 0; }
+    }
+    std::lock_guard<std::mutex> lk(gcache.mu);
+    if (frc) { cache_remove_locked(e.get(), dropped); e.reset(); gcache.misses++; return false; }
+    e->handle = h; e->bytes = cache_entry_bytes<C>(n, table_c); gcache.fills++;
+    bool listed = false;
+    for (auto &c : gcache.entries) if (c.get() == e.get()) listed = true;
+    // (not listed any more: dgpu_bases_cache_clear ran meanwhile — this call still uses the table, which goes when the call lets go of it)
+    if (listed) {
+        e->state = CacheEntry::READY; e->last_use = ++gcache.tick; gcache.used += e->bytes;
+        for (size_t i = 0; i < gcache.entries.size();) {      // an older entry that lies wholly inside the new one is redundant
             size_t o; CacheEntry &c = *gcache.entries[i];
-            if (listed && &c != e.get() && c.state == CacheEntry::READY && c.k.inside(e->k, &o)) { gcache.used -= c.bytes; dropped.push_back(std::move(gcache.entries[i])); gcache.entries.erase(gcache.entries.begin() + i); }
+            if (&c != e.get() && c.state == CacheEntry::READY && c.k.inside(e->k, &o)) { gcache.used -= c.bytes; dropped.push_back(std::move(gcache.entries[i])); gcache.entries.erase(gcache.entries.begin() + i); }
             else i++;
         }
     }
+    return true;
+}
+// true: the call was served from a resident entry and rc is its answer; false: run it one-shot
+template <class C, class HF>
+bool msm_oneshot_cached(const RawBases &rb, const uint64_t *scalars, size_t n, bool mont, uint64_t *out, int kind, int32_t &rc) {
+    std::shared_ptr<CacheEntry> e; size_t off = 0;
+    if (!cache_acquire<C>(rb, n, kind, 0, e, off)) return false;
     rc = msm_handle<C, HF>(e->handle, off, scalars, n, mont, out, kind, false);
     if (rc != DGPU_OK && rc != DGPU_E_BADARG) {               // a device-side failure on the resident path: forget the entry, let the one-shot path answer
+        std::vector<std::shared_ptr<CacheEntry>> dropped;
         std::lock_guard<std::mutex> lk(gcache.mu);
         cache_remove_locked(e.get(), dropped);
         gcache.misses++; return false;
     }
     gcache.hits++;
     return true;
+}
+// A view of host bases as a handle for the duration of a larger call (dgpu_legogroth16_prove_host): the cache's entry when the WHOLE view is one
+// (pinned by *pin), else a temporary upload that view_release frees.  Never fails for want of a cache: the temporary upload is the one-shot path.
+struct ViewPin { std::shared_ptr<CacheEntry> e; uint64_t temp = 0; };
+template <class C>
+int32_t view_acquire(const RawBases &rb, size_t n, int kind, int table_c, uint64_t *handle, void **pin) {
+    if (!handle || !pin || (n && !rb.p) || n >= (1ull << 31) || !rb.ok<C>()) return DGPU_E_BADARG;
+    if (!cur().ready) return DGPU_E_NODEVICE;
+    ViewPin *vp = new ViewPin();
+    size_t off = 0;
+    if (n && gcache.enabled.load() && n >= gcache.min_n.load() && cache_acquire<C>(rb, n, kind, table_c, vp->e, off)) {
+        if (off == 0 && vp->e->k.n == n) { gcache.hits++; *handle = vp->e->handle; *pin = vp; return DGPU_OK; }
+        vp->e.reset();                        // (a sub-range of a larger entry: the prover addresses its queries from row 0 — take the points from the host)
+    }
+    const int32_t rc = bases_upload<C>(rb, n, &vp->temp, kind);
+    if (rc) { delete vp; return rc; }
+    *handle = vp->temp; *pin = vp;
+    return DGPU_OK;
+}
+inline void view_release(void *pin) {
+    ViewPin *vp = (ViewPin *)pin;
+    if (!vp) return;
+    if (vp->temp) (void)dgpu_bases_free(vp->temp);
+    delete vp;
 }
 
 template <class C, class HF>

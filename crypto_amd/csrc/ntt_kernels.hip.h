@@ -48,6 +48,18 @@ __global__ void __launch_bounds__(256) k_fr_mont_to_canonical(uint32_t *__restri
     uint4 *q = reinterpret_cast<uint4 *>(words + i * 8);
     q[0] = make_uint4(w[0], w[1], w[2], w[3]); q[1] = make_uint4(w[4], w[5], w[6], w[7]);
 }
+// the inverse, in place: x -> x * 2^256 mod r (`Fr::from_bigint`): the witness map's h handed back as the &[Fr] the reference's QAP::witness_map returns
+__global__ void __launch_bounds__(256) k_fr_canonical_to_mont(uint32_t *__restrict__ words, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t w[8];
+    const uint4 *p = reinterpret_cast<const uint4 *>(words + i * 8);
+    uint4 a = p[0], b = p[1];
+    w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+    Fr x; fr_from_words(x, w, false); fr_to_words(w, x, true);
+    uint4 *q = reinterpret_cast<uint4 *>(words + i * 8);
+    q[0] = make_uint4(w[0], w[1], w[2], w[3]); q[1] = make_uint4(w[4], w[5], w[6], w[7]);
+}
 // pw[k] = base^k * scale for k < count (square-and-multiply per lane; built once per domain size and cached)
 __global__ void __launch_bounds__(256) k_fr_powers(const uint32_t *__restrict__ base_words, const uint32_t *__restrict__ scale_words, size_t count, uint32_t *__restrict__ out) {
     size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

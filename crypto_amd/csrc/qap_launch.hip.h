@@ -6,6 +6,7 @@
 namespace ntt {
 constexpr int FR_WORDS = 10;   // u32 per internal Fr element
 void launch_fr_mont_to_canonical(hipStream_t s, uint32_t *words, size_t n);
+void launch_fr_canonical_to_mont(hipStream_t s, uint32_t *words, size_t n);
 void launch_fr_load(hipStream_t s, const uint32_t *words, size_t n, int mont, uint32_t *out, size_t D);
 void launch_fr_powers(hipStream_t s, const uint32_t *base_words, const uint32_t *scale_words, size_t count, uint32_t *out);
 // twiddle buffers hold 2H elements: T_0 (H powers) followed by the per-stage compacted tables built by launch_tw_compact

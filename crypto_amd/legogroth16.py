@@ -325,6 +325,55 @@ def prove_abi(pk, r, s, v, assignment_with_one, n_inst, circuit=None, h=None, mo
     return {"a": a, "b": b, "c": c, "d": d}
 
 
+class HostProvingKey:
+    """A proving key the way the reference holds it (legogroth16/src/data_structures.rs `ProvingKeyCommon`): the five queries as arrays of ark-ec Affine
+    structs in HOST memory (msm.to_affine_structs), nothing uploaded by the caller.  dgpu_legogroth16_prove_host resolves them through the library's
+    resident-bases cache."""
+
+    def __init__(self, vk, beta_g1, delta_g1, eta_delta_inv_g1, a_query, b_g1_query, b_g2_query, h_query, l_query, a0=None, b1_0=None, b2_0=None):
+        self.vk, self.beta_g1, self.delta_g1, self.eta_delta_inv_g1 = vk, beta_g1, delta_g1, eta_delta_inv_g1
+        st = lambda curve, q: q if q.dtype.names else M.to_affine_structs(curve, q)
+        self.a_query, self.b_g1_query, self.h_query, self.l_query = (st(M.G1, q) for q in (a_query, b_g1_query, h_query, l_query))
+        self.b_g2_query = st(M.G2, b_g2_query)
+        unpack = lambda q: np.concatenate([q["x"][0], q["y"][0]])
+        # query[0] of a / b_g1 / b_g2 (calculate_coeff's `el`, prover.rs:591); given explicitly by a synthetic key whose row 0 is not the element it adds (bench.py)
+        self.a0 = unpack(self.a_query) if a0 is None else a0
+        self.b1_0 = unpack(self.b_g1_query) if b1_0 is None else b1_0
+        self.b2_0 = unpack(self.b_g2_query) if b2_0 is None else b2_0
+
+
+def prove_host(hpk, r, s, v, h, instance_with_one, witness, montgomery=False, h_montgomery=False, circuit=None):
+    """dgpu_legogroth16_prove_host: create_proof_and_committed_witnesses_with_assignment (prover.rs:267-383) for a host-held key; h = the coefficients
+    QAP::witness_map returned (host array), or None with `circuit` a resident qap.DeviceR1cs (the witness map runs inside the call)."""
+    from ._native import LegoPkHost
+    vk = hpk.vk
+    keep = {k: np.ascontiguousarray(a, dtype=np.uint64) for k, a in (
+        ("alpha_g1", vk.alpha_g1), ("beta_g1", hpk.beta_g1), ("delta_g1", hpk.delta_g1), ("eta_delta_inv_g1", hpk.eta_delta_inv_g1),
+        ("eta_gamma_inv_g1", vk.eta_gamma_inv_g1), ("beta_g2", vk.beta_g2), ("delta_g2", vk.delta_g2), ("a0", hpk.a0), ("b1_0", hpk.b1_0), ("b2_0", hpk.b2_0),
+        ("gamma_abc_g1", vk.gamma_abc_g1))}
+    st = LegoPkHost()
+    for name in ("a_query", "b_g1_query", "b_g2_query", "h_query", "l_query"):
+        q = getattr(hpk, name); f = q.dtype.fields; view = getattr(st, name)
+        view.p, view.stride, view.x_off, view.y_off, view.inf_off, view.n = q.ctypes.data, q.dtype.itemsize, f["x"][1], f["y"][1], f["infinity"][1], len(q)
+    for k, a in keep.items():
+        setattr(st, k, a.ctypes.data)
+    st.gamma_abc_len = len(vk.gamma_abc_g1)
+    st.commit_witness_count = vk.commit_witness_count
+    h = None if h is None else np.ascontiguousarray(h, dtype=np.uint64).reshape(-1, 4)
+    inst = np.ascontiguousarray(instance_with_one, dtype=np.uint64).reshape(-1, 4)
+    wit = np.ascontiguousarray(witness, dtype=np.uint64).reshape(-1, 4)
+    a, b, c, d = np.zeros(12, np.uint64), np.zeros(24, np.uint64), np.zeros(12, np.uint64), np.zeros(12, np.uint64)
+    inf = np.zeros(4, np.uint8)
+    p = lambda x: x.ctypes.data_as(C.c_void_p)
+    raw = lambda x: np.array([(x >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
+    rc = M.lib().dgpu_legogroth16_prove_host(C.byref(st), circuit.handle if circuit is not None else 0, None if h is None else p(h), 0 if h is None else len(h), int(h_montgomery), p(inst), len(inst), p(wit), len(wit), int(montgomery),
+                                             p(raw(r)), p(raw(s)), p(raw(v)), p(a), p(b), p(c), p(d), p(inf))
+    del keep
+    if rc:
+        raise M.DockGpuError(rc, "dgpu_legogroth16_prove_host")
+    return {"a": a, "b": b, "c": c, "d": d}
+
+
 def create_proof_with_reduction(pk, circuit, r, s, v, assignment_with_one, share_sort=True, via_abi=True):
     if via_abi and share_sort:
         return prove_abi(pk, r, s, v, assignment_with_one, circuit.num_inputs, circuit=circuit)

@@ -23,7 +23,7 @@ def _p(a):
     return None if a is None or a.size == 0 else a.ctypes.data_as(C.c_void_p)
 
 
-def witness_map(A, B, Cm, assignment, num_inputs, num_constraints, montgomery=False, to_host=True, resident=False):
+def witness_map(A, B, Cm, assignment, num_inputs, num_constraints, montgomery=False, to_host=True, resident=False, h_montgomery=False):
     """A, B, Cm: (rowptr, cols, vals) CSR triples.  Returns (h or None, DeviceScalars or None)."""
     _ensure()
     z = np.ascontiguousarray(assignment, dtype=np.uint64).reshape(-1, 4)
@@ -46,7 +46,7 @@ def witness_map(A, B, Cm, assignment, num_inputs, num_constraints, montgomery=Fa
     args = []
     for rp, cl, vl in mats:
         args += [rp.ctypes.data_as(C.c_void_p), _p(cl), _p(vl), len(cl)]
-    rc = lib().dgpu_witness_map(*args, z.ctypes.data_as(C.c_void_p), len(z), num_inputs, num_constraints, int(montgomery),
+    rc = lib().dgpu_witness_map(*args, z.ctypes.data_as(C.c_void_p), len(z), num_inputs, num_constraints, int(bool(montgomery)) | (2 if h_montgomery else 0),
                                 None if out is None else out.ctypes.data_as(C.c_void_p), C.byref(handle) if resident else None, C.byref(olen))
     if rc:
         raise DockGpuError(rc, "dgpu_witness_map")
@@ -85,7 +85,7 @@ class DeviceR1cs:
             raise DockGpuError(rc, "dgpu_r1cs_shape")
         return v.value, i.value, c.value
 
-    def witness_map(self, assignment, montgomery=False, to_host=True, resident=False):
+    def witness_map(self, assignment, montgomery=False, to_host=True, resident=False, h_montgomery=False):
         """`assignment`: host scalars, or a DeviceScalars holding z on the circuit's device (dgpu_witness_map_r1cs_resident)"""
         D = 2
         while D < self.num_constraints + self.num_inputs:
@@ -97,7 +97,7 @@ class DeviceR1cs:
                                                       C.byref(handle) if resident else None, C.byref(olen))
         else:
             z = np.ascontiguousarray(assignment, dtype=np.uint64).reshape(-1, 4)
-            rc = lib().dgpu_witness_map_r1cs(self.handle, z.ctypes.data_as(C.c_void_p), len(z), int(montgomery),
+            rc = lib().dgpu_witness_map_r1cs(self.handle, z.ctypes.data_as(C.c_void_p), len(z), int(bool(montgomery)) | (2 if h_montgomery else 0),
                                              None if out is None else out.ctypes.data_as(C.c_void_p), C.byref(handle) if resident else None, C.byref(olen))
         if rc:
             raise DockGpuError(rc, "dgpu_witness_map_r1cs")

@@ -356,9 +356,12 @@ int32_t dgpu_fold_free(uint64_t handle);
  * replaces LibsnarkReduction::witness_map_from_matrices (legogroth16/src/r1cs_to_qap.rs:150-210): h = ((A z)(B z) - C z) / Z_D as the
  * D = next_pow2(num_constraints + num_inputs) coefficients the prover pairs with h_query (legogroth16/src/prover.rs:281-286).
  * Matrices in CSR (rowptr[num_constraints + 1], cols[nnz], vals[nnz * 4]); assignment = (1, instance..., witness...), num_vars values.
- * montgomery != 0: coefficients and assignment are ark-ff Fr limbs (R = 2^256), else canonical.  The result is always canonical
+ * montgomery & 1: coefficients and assignment are ark-ff Fr limbs (R = 2^256), else canonical.  The result is canonical
  * (what `into_bigint` yields, prover.rs:281-283): copied to out_h (D * 4 limbs) and/or left in HBM as a scalars handle that
- * dgpu_msm_g1_resident consumes directly.  *out_len = D. */
+ * dgpu_msm_g1_resident consumes directly.  montgomery & DGPU_WM_H_MONTGOMERY: the copy in out_h is written as Fr limbs instead (the
+ * `Vec<F>` witness_map_from_matrices returns, r1cs_to_qap.rs:150-210 — a drop-in for that function hands back exactly this; the conversion
+ * runs on the device); a resident vector stays canonical.  *out_len = D. */
+#define DGPU_WM_H_MONTGOMERY 2
 int32_t dgpu_witness_map(const uint64_t *a_rowptr, const uint32_t *a_cols, const uint64_t *a_vals, size_t a_nnz,
                          const uint64_t *b_rowptr, const uint32_t *b_cols, const uint64_t *b_vals, size_t b_nnz,
                          const uint64_t *c_rowptr, const uint32_t *c_cols, const uint64_t *c_vals, size_t c_nnz,
@@ -404,6 +407,29 @@ typedef struct dgpu_lego_pk {
 int32_t dgpu_legogroth16_prove(const dgpu_lego_pk *pk, uint64_t r1cs, uint64_t h_scalars, const uint64_t *z, size_t num_vars, size_t n_inst,
                                int32_t montgomery, const uint64_t r[4], const uint64_t s[4], const uint64_t v[4],
                                uint64_t out_a[12], uint64_t out_b[24], uint64_t out_c[12], uint64_t out_d[12], uint8_t out_inf[4]);
+/* The same prover for a host that holds the proving key the way the reference does — `pk_common: &ProvingKeyCommon<E>` with its queries as `Vec<G1Affine>` /
+ * `Vec<G2Affine>` (legogroth16/src/data_structures.rs, prover.rs:267-383) and h as the `&[E::ScalarField]` QAP::witness_map returned (prover.rs:153-180,577-581):
+ * every query is a VIEW of host memory (dgpu_msm_*_strided's description of a slice of ark-ec Affine structs; for a_query / b_g1_query / b_g2_query the WHOLE
+ * query, element 0 included) which the resident-bases cache above resolves — at a key's second proof the queries are uploaded once and become tables (the a / b / l
+ * queries of DGPU_TABLE_C_WITNESS), later proofs run dgpu_legogroth16_prove's schedule on them and only the assignment and h cross PCIe.  A view the cache does not
+ * hold (a key's first proof, the cache off or full) is uploaded for the duration of the call.  instance: n_inst scalars (the leading 1 included), witness: n_wit
+ * scalars (montgomery != 0: &[Fr]).  Exactly one source of h: r1cs = a resident circuit (dgpu_r1cs_upload; the witness map then runs inside the call and h
+ * never leaves the device — create_proof_with_reduction, prover.rs:153-180, as one call) or h = h_len coefficients in host memory (h_montgomery != 0: &[Fr] — the
+ * prover's `into_bigint` then happens on the device; create_proof_with_assignment's contract, prover.rs:237-265).  Same proof, limb for limb, as
+ * dgpu_legogroth16_prove on uploaded handles (tests/test_gpu_prove_abi.py). */
+typedef struct dgpu_bases_view { const void *p; size_t stride, x_off, y_off, inf_off, n; } dgpu_bases_view;
+typedef struct dgpu_lego_pk_host {
+    dgpu_bases_view a_query, b_g1_query, b_g2_query, h_query, l_query;
+    const uint64_t *alpha_g1, *beta_g1, *delta_g1, *eta_delta_inv_g1, *eta_gamma_inv_g1;             /* 12 u64 each */
+    const uint64_t *beta_g2, *delta_g2;                                                              /* 24 u64 each */
+    const uint64_t *a0, *b1_0, *b2_0;                                                                /* query[0] of a / b_g1 (12) / b_g2 (24) */
+    const uint64_t *gamma_abc_g1; size_t gamma_abc_len;
+    size_t commit_witness_count;
+} dgpu_lego_pk_host;
+int32_t dgpu_legogroth16_prove_host(const dgpu_lego_pk_host *pk, uint64_t r1cs, const uint64_t *h, size_t h_len, int32_t h_montgomery,
+                                    const uint64_t *instance, size_t n_inst, const uint64_t *witness, size_t n_wit, int32_t montgomery,
+                                    const uint64_t r[4], const uint64_t s[4], const uint64_t v[4],
+                                    uint64_t out_a[12], uint64_t out_b[24], uint64_t out_c[12], uint64_t out_d[12], uint8_t out_inf[4]);
 /* The same call accepts a key that is resident across several device contexts (every query a dgpu_bases_upload_*_sharded handle, optionally
  * dgpu_bases_precompute_*d; the five queries over the same contexts): context g multiplies its rows by the matching slices of z and h from a host
  * thread of its own inside the call, the witness map runs once on the circuit's context (r1cs must be given), the partial points are folded on

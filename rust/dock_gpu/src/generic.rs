@@ -151,3 +151,81 @@ pub fn scale_batch_g1<E: Pairing>(points: &[E::G1Affine], m: <E::ScalarField as 
     let p: Vec<E::G1> = points.iter().map(|a| { let t = a.mul_bigint(m); if negate { -t } else { t } }).collect();
     E::G1::normalize_batch(&p)
 }
+
+// ---- LegoGroth16: the prover and the witness map as the reference's generic functions see them -----------------------------------------------------
+/// where the prover's h comes from
+pub enum H<'a, F: PrimeField> {
+    /// the coefficients `QAP::witness_map` returned — `create_proof_and_committed_witnesses_with_assignment`'s `h: &[E::ScalarField]` (prover.rs:267-276)
+    Coefficients(&'a [F]),
+    /// the constraint system's matrices (`cs.to_matrices()`: a, b, c), its number of instance variables and of constraints — `create_proof_with_reduction`
+    /// (prover.rs:153-180): the circuit becomes resident (found again by the content hash of its matrices), the witness map runs inside the prover call
+    Matrices(&'a [Vec<(F, usize)>], &'a [Vec<(F, usize)>], &'a [Vec<(F, usize)>], usize, usize),
+}
+/// Circuits below this many constraints stay on the CPU prover (a device proof is a few milliseconds whatever the size)
+pub const MIN_CONSTRAINTS_GPU: usize = 1 << 12;
+
+/// `create_proof_and_committed_witnesses_with_assignment::<E, QAP>` (legogroth16/src/prover.rs:267-383) as one call: (A, B, C, D), or None — another
+/// curve, a small circuit, the library declined — and the caller runs the reference's own body.  The members of `ProvingKeyCommon<E>` / `VerifyingKey<E>`
+/// come one by one because this crate cannot name legogroth16's types.  `input_assignment` includes the leading 1.
+#[allow(clippy::too_many_arguments)]
+pub fn legogroth16_create_proof<E: Pairing>(
+    alpha_g1: &E::G1Affine, beta_g1: &E::G1Affine, delta_g1: &E::G1Affine, eta_delta_inv_g1: &E::G1Affine, eta_gamma_inv_g1: &E::G1Affine,
+    beta_g2: &E::G2Affine, delta_g2: &E::G2Affine, gamma_abc_g1: &[E::G1Affine], commit_witness_count: usize,
+    a_query: &[E::G1Affine], b_g1_query: &[E::G1Affine], b_g2_query: &[E::G2Affine], h_query: &[E::G1Affine], l_query: &[E::G1Affine],
+    h: H<E::ScalarField>, input_assignment: &[E::ScalarField], witness_assignment: &[E::ScalarField],
+    r: E::ScalarField, s: E::ScalarField, v: E::ScalarField,
+) -> Option<(E::G1Affine, E::G2Affine, E::G1Affine, E::G1Affine)> {
+    if !same::<E, Bls12_381>() || a_query.len() < MIN_CONSTRAINTS_GPU { return None; }
+    // E == Bls12_381: every associated type is the concrete one of `crate`
+    let pk = unsafe { crate::host::HostProvingKey {
+        alpha_g1: *cast_ref::<E::G1Affine, G1Affine>(alpha_g1), beta_g1: *cast_ref::<E::G1Affine, G1Affine>(beta_g1), delta_g1: *cast_ref::<E::G1Affine, G1Affine>(delta_g1),
+        eta_delta_inv_g1: *cast_ref::<E::G1Affine, G1Affine>(eta_delta_inv_g1), eta_gamma_inv_g1: *cast_ref::<E::G1Affine, G1Affine>(eta_gamma_inv_g1),
+        beta_g2: *cast_ref::<E::G2Affine, G2Affine>(beta_g2), delta_g2: *cast_ref::<E::G2Affine, G2Affine>(delta_g2),
+        gamma_abc_g1: cast_slice::<E::G1Affine, G1Affine>(gamma_abc_g1), commit_witness_count,
+        a_query: cast_slice::<E::G1Affine, G1Affine>(a_query), b_g1_query: cast_slice::<E::G1Affine, G1Affine>(b_g1_query), b_g2_query: cast_slice::<E::G2Affine, G2Affine>(b_g2_query),
+        h_query: cast_slice::<E::G1Affine, G1Affine>(h_query), l_query: cast_slice::<E::G1Affine, G1Affine>(l_query),
+    } };
+    let (inst, wit) = unsafe { (cast_slice::<E::ScalarField, Fr>(input_assignment), cast_slice::<E::ScalarField, Fr>(witness_assignment)) };
+    let (r, s, v): (Fr, Fr, Fr) = unsafe { (cast_val(r), cast_val(s), cast_val(v)) };
+    let out = match h {
+        H::Coefficients(c) => crate::host::create_proof_host(&pk, crate::host::HSource::Coefficients(unsafe { cast_slice::<E::ScalarField, Fr>(c) }), inst, wit, r, s, v),
+        H::Matrices(a, b, c, num_inputs, num_constraints) => {
+            let (a, b, c) = unsafe { (cast_slice::<Vec<(E::ScalarField, usize)>, Vec<(Fr, usize)>>(a), cast_slice::<Vec<(E::ScalarField, usize)>, Vec<(Fr, usize)>>(b), cast_slice::<Vec<(E::ScalarField, usize)>, Vec<(Fr, usize)>>(c)) };
+            let circuit = crate::host::resident_circuit(a, b, c, inst.len() + wit.len(), num_inputs, num_constraints)?;
+            crate::host::create_proof_host(&pk, crate::host::HSource::Circuit(&circuit), inst, wit, r, s, v)
+        }
+    }?;
+    Some(unsafe { (cast_val::<G1Affine, E::G1Affine>(out.0), cast_val::<G2Affine, E::G2Affine>(out.1), cast_val::<G1Affine, E::G1Affine>(out.2), cast_val::<G1Affine, E::G1Affine>(out.3)) })
+}
+/// `&A` as `&B` — only ever called after `same::<…>()` established that A and B are one type
+#[inline(always)]
+unsafe fn cast_ref<A, B>(a: &A) -> &B {
+    debug_assert_eq!(core::mem::size_of::<A>(), core::mem::size_of::<B>());
+    &*(a as *const A as *const B)
+}
+/// `LibsnarkReduction::witness_map_from_matrices::<F, D>` (legogroth16/src/r1cs_to_qap.rs:150-210): the D coefficients of h as `Vec<F>`, or None
+/// (another field, a small circuit, the library declined) — the caller then runs the reference's own body
+pub fn witness_map_from_matrices<F: PrimeField>(a: &[Vec<(F, usize)>], b: &[Vec<(F, usize)>], c: &[Vec<(F, usize)>], num_inputs: usize, num_constraints: usize, full_assignment: &[F]) -> Option<Vec<F>> {
+    if !same::<F, Fr>() { return None; }
+    let h: Vec<Fr> = unsafe { crate::host::witness_map_from_matrices(cast_slice::<Vec<(F, usize)>, Vec<(Fr, usize)>>(a), cast_slice::<Vec<(F, usize)>, Vec<(Fr, usize)>>(b),
+                                                                    cast_slice::<Vec<(F, usize)>, Vec<(Fr, usize)>>(c), num_inputs, num_constraints, cast_slice::<F, Fr>(full_assignment)) }?;
+    Some(unsafe { cast_val::<Vec<Fr>, Vec<F>>(h) })
+}
+
+// ---- fixed-base batch multiplication: utils/src/msm.rs:8-62 ---------------------------------------------------------------------------------------
+/// `FixedBase::msm(.., &table, elements)` as `WindowTable::multiply_many` and `multiply_field_elems_with_same_group_elem` use it: `base` times every
+/// element, or None (another group, a short batch, the library declined).  G = G1Projective / G2Projective of BLS12-381 are served.
+pub fn fixed_base_msm<G: ark_ec::CurveGroup>(base: &G::Affine, elements: &[G::ScalarField]) -> Option<Vec<G>> {
+    if elements.len() < 256 { return None; }
+    if same::<G, G1Projective>() {
+        let v = crate::host::fixed_base_g1(unsafe { cast_ref::<G::Affine, G1Affine>(base) }, unsafe { cast_slice::<G::ScalarField, Fr>(elements) })?;
+        let p: Vec<G1Projective> = v.iter().map(|a| a.into_group()).collect();
+        return Some(unsafe { cast_val::<Vec<G1Projective>, Vec<G>>(p) });
+    }
+    if same::<G, G2Projective>() {
+        let v = crate::host::fixed_base_g2(unsafe { cast_ref::<G::Affine, G2Affine>(base) }, unsafe { cast_slice::<G::ScalarField, Fr>(elements) })?;
+        let p: Vec<G2Projective> = v.iter().map(|a| a.into_group()).collect();
+        return Some(unsafe { cast_val::<Vec<G2Projective>, Vec<G>>(p) });
+    }
+    None
+}

@@ -27,111 +27,23 @@ use ark_ff::{BigInt, PrimeField};
 use ark_std::vec::Vec;
 
 pub mod generic;
+pub mod host;
 
 pub type G2Prepared = ArkG2Prepared<ark_bls12_381::Config>;
 
-pub const DGPU_OK: i32 = 0;
-pub const DGPU_E_TOO_SMALL: i32 = -6;
-/// verify flag of `dgpu_snarkpack_verify`: every GT element of the proof must have order r (what `Validate::Yes` does on a deserialised proof)
-pub const DGPU_SNARKPACK_VALIDATE_GT: i32 = 1;
-/// verify flag: every G1 / G2 element of the proof must be on its curve and in the prime-order subgroup (the other half of `Validate::Yes`)
-pub const DGPU_SNARKPACK_VALIDATE_POINTS: i32 = 2;
-pub const G2_PREPARED_WORDS: usize = 68 * 36;
+pub mod ffi;
+pub use ffi::*;
 
-/// `dgpu_lego_pk` of include/dock_gpu.h
-#[repr(C)]
-pub struct DgpuLegoPk {
-    pub a_query: u64,
-    pub b_g1_query: u64,
-    pub b_g2_query: u64,
-    pub h_query: u64,
-    pub l_query: u64,
-    pub alpha_g1: *const u64,
-    pub beta_g1: *const u64,
-    pub delta_g1: *const u64,
-    pub eta_delta_inv_g1: *const u64,
-    pub eta_gamma_inv_g1: *const u64,
-    pub beta_g2: *const u64,
-    pub delta_g2: *const u64,
-    pub a0: *const u64,
-    pub b1_0: *const u64,
-    pub b2_0: *const u64,
-    pub gamma_abc_g1: *const u64,
-    pub gamma_abc_len: usize,
-    pub commit_witness_count: usize,
-}
-
-/// `dgpu_transcript`, `dgpu_snarkpack_prover_srs`, `dgpu_snarkpack_verifier_srs`, `dgpu_groth16_vk` of include/dock_gpu.h
-#[repr(C)]
-pub struct DgpuTranscript {
-    pub ctx: *mut core::ffi::c_void,
-    pub append_message: unsafe extern "C" fn(ctx: *mut core::ffi::c_void, label: *const u8, label_len: usize, bytes: *const u8, len: usize),
-    pub challenge_scalar: unsafe extern "C" fn(ctx: *mut core::ffi::c_void, label: *const u8, label_len: usize, out: *mut u64),
-}
-#[repr(C)]
-pub struct DgpuSnarkpackProverSrs {
-    pub n: usize,
-    pub g_alpha_powers_table: *const u64, pub g_beta_powers_table: *const u64, pub h_alpha_powers_table: *const u64, pub h_beta_powers_table: *const u64,
-    pub vkey_a: *const u64, pub vkey_b: *const u64, pub wkey_a: *const u64, pub wkey_b: *const u64,
-}
-#[repr(C)]
-pub struct DgpuSnarkpackVerifierSrs { pub n: usize, pub g: *const u64, pub h: *const u64, pub g_alpha: *const u64, pub g_beta: *const u64, pub h_alpha: *const u64, pub h_beta: *const u64 }
-#[repr(C)]
-pub struct DgpuGroth16Vk { pub alpha_g1: *const u64, pub beta_g2: *const u64, pub gamma_g2: *const u64, pub delta_g2: *const u64, pub gamma_abc_g1: *const u64, pub gamma_abc_len: usize }
-
-#[link(name = "dock_gpu")]
-extern "C" {
-    pub fn dgpu_init(device: i32) -> i32;
-    pub fn dgpu_shutdown() -> i32;
-    pub fn dgpu_device_count() -> i32;
-    pub fn dgpu_set_min_gpu_n(n: usize) -> i32;
-    pub fn dgpu_reserve_g1(n: usize) -> i32;
-    pub fn dgpu_reserve_g2(n: usize) -> i32;
-    pub fn dgpu_msm_g1_strided(bases: *const core::ffi::c_void, stride_bytes: usize, x_off: usize, y_off: usize, inf_off: usize,
-                               scalars: *const u64, n: usize, montgomery: i32, out_xyz: *mut u64) -> i32;
-    pub fn dgpu_msm_g2_strided(bases: *const core::ffi::c_void, stride_bytes: usize, x_off: usize, y_off: usize, inf_off: usize,
-                               scalars: *const u64, n: usize, montgomery: i32, out_xyz: *mut u64) -> i32;
-    pub fn dgpu_bases_upload_g1_strided(bases: *const core::ffi::c_void, stride_bytes: usize, x_off: usize, y_off: usize, inf_off: usize, n: usize, handle: *mut u64) -> i32;
-    pub fn dgpu_bases_upload_g2_strided(bases: *const core::ffi::c_void, stride_bytes: usize, x_off: usize, y_off: usize, inf_off: usize, n: usize, handle: *mut u64) -> i32;
-    pub fn dgpu_bases_precompute_g1(bases: u64, window_bits: i32) -> i32;
-    pub fn dgpu_bases_precompute_g2(bases: u64, window_bits: i32) -> i32;
-    pub fn dgpu_bases_free(handle: u64) -> i32;
-    pub fn dgpu_msm_g1_handle(bases: u64, offset: usize, scalars: *const u64, n: usize, montgomery: i32, out_xyz: *mut u64) -> i32;
-    pub fn dgpu_msm_g2_handle(bases: u64, offset: usize, scalars: *const u64, n: usize, montgomery: i32, out_xyz: *mut u64) -> i32;
-    pub fn dgpu_multi_miller_loop(p_xy: *const u64, q_xy: *const u64, skip: *const u8, n: usize, out_f12: *mut u64) -> i32;
-    pub fn dgpu_g2_prepare(q_xy: *const u64, is_inf: *const u8, n: usize, out_coeffs: *mut u64, out_inf: *mut u8) -> i32;
-    pub fn dgpu_multi_miller_loop_mixed(p_aff: *const u64, q_aff: *const u64, skip_aff: *const u8, n_aff: usize,
-                                        p_prep: *const u64, coeffs: *const u64, skip_prep: *const u8, n_prep: usize, out_f12: *mut u64) -> i32;
-    pub fn dgpu_multi_miller_loop_scaled(p_aff: *const u64, scalars: *const u64, scalar_stride: usize, q_aff: *const u64, skip_aff: *const u8, n_aff: usize,
-                                         p_prep: *const u64, coeffs: *const u64, skip_prep: *const u8, n_prep: usize, out_f12: *mut u64) -> i32;
-    pub fn dgpu_final_exponentiation(in_f12: *const u64, out_f12: *mut u64) -> i32;
-    pub fn dgpu_g1_scale_batch(p_xy: *const u64, is_inf: *const u8, scalars: *const u64, scalar_stride: usize, negate: *const u8, n: usize, out_xy: *mut u64, out_inf: *mut u8) -> i32;
-    pub fn dgpu_r1cs_upload(a_rowptr: *const u64, a_cols: *const u32, a_vals: *const u64, a_nnz: usize,
-                            b_rowptr: *const u64, b_cols: *const u32, b_vals: *const u64, b_nnz: usize,
-                            c_rowptr: *const u64, c_cols: *const u32, c_vals: *const u64, c_nnz: usize,
-                            num_vars: usize, num_inputs: usize, num_constraints: usize, montgomery: i32, handle: *mut u64) -> i32;
-    pub fn dgpu_r1cs_free(handle: u64) -> i32;
-    pub fn dgpu_legogroth16_verify(alpha_beta_gt: *const u64, delta_neg_pc: *const u64, gamma_neg_pc: *const u64, gamma_abc_g1: *const u64, gamma_abc_len: usize,
-                                   proof_a: *const u64, proof_b: *const u64, proof_c: *const u64, proof_d: *const u64, proof_inf: *const u8,
-                                   public_inputs: *const u64, n_pub: usize, montgomery: i32, ok: *mut i32) -> i32;
-    pub fn dgpu_legogroth16_verify_batch(alpha_beta_gt: *const u64, delta_neg_pc: *const u64, gamma_neg_pc: *const u64, gamma_abc_g1: *const u64, gamma_abc_len: usize,
-                                         proofs_a: *const u64, proofs_b: *const u64, proofs_c: *const u64, proofs_d: *const u64, n: usize,
-                                         public_inputs: *const u64, n_pub: usize, montgomery: i32, random: *const u64, ok: *mut i32) -> i32;
-    pub fn dgpu_snarkpack_proof_words(n: usize, with_d: i32) -> usize;
-    pub fn dgpu_snarkpack_aggregate(srs: *const DgpuSnarkpackProverSrs, a: *const u64, b: *const u64, c: *const u64, d: *const u64, n: usize,
-                                    transcript: *const DgpuTranscript, proof: *mut u64, cap_words: usize, len_words: *mut usize) -> i32;
-    pub fn dgpu_snarkpack_verify(srs: *const DgpuSnarkpackVerifierSrs, vk: *const DgpuGroth16Vk, public_inputs: *const u64, n_rows: usize, inputs_per_proof: usize,
-                                 proof: *const u64, len_words: usize, variant: i32, d_list: *const u64, random: *const u64,
-                                 transcript: *const DgpuTranscript, flags: i32, ok: *mut i32) -> i32;
-    pub fn dgpu_legogroth16_prove(pk: *const DgpuLegoPk, r1cs: u64, h_scalars: u64, z: *const u64, num_vars: usize, n_inst: usize, montgomery: i32,
-                                  r: *const u64, s: *const u64, v: *const u64,
-                                  out_a: *mut u64, out_b: *mut u64, out_c: *mut u64, out_d: *mut u64, out_inf: *mut u8) -> i32;
-}
+pub const G2_PREPARED_WORDS: usize = DGPU_G2_PREPARED_WORDS;
 
 /// bind this process to HIP device `device` (one process per GPU) and size every slot for one-shot calls of up to `max_n` terms, so that
-/// no rayon worker's first call allocates on the device
+/// no rayon worker's first call allocates on the device.  Call it from start-up code, before other threads exist: it first asks the ROCm runtime for
+/// eight hardware queues (`dgpu_runtime_hints`: exports GPU_MAX_HW_QUEUES=8 unless the variable is set; too late — and harmless — once HIP is up).
 pub fn init(device: i32, max_n: usize) -> bool {
-    unsafe { dgpu_init(device) == DGPU_OK && dgpu_reserve_g1(max_n) == DGPU_OK && dgpu_reserve_g2(max_n) == DGPU_OK }
+    unsafe {
+        let _ = dgpu_runtime_hints(DGPU_HINT_EIGHT_HW_QUEUES);
+        dgpu_init(device) == DGPU_OK && dgpu_reserve_g1(max_n) == DGPU_OK && dgpu_reserve_g2(max_n) == DGPU_OK
+    }
 }
 
 // ---- the caller's `&[G1Affine]` / `&[G2Affine]` as they lie in memory ------------------------------------------------------------------------
@@ -239,6 +151,26 @@ impl ResidentG1 {
 }
 impl Drop for ResidentG1 { fn drop(&mut self) { if self.handle != 0 { unsafe { dgpu_bases_free(self.handle); } } } }
 
+/// the same for G2 (b_g2_query)
+pub struct ResidentG2 { handle: u64, host: Vec<G2Affine> }
+impl ResidentG2 {
+    pub fn upload(bases: &[G2Affine], table_window_bits: Option<i32>) -> Self {
+        let mut handle = 0u64;
+        let ok = unsafe { dgpu_bases_upload_g2_strided(bases.as_ptr() as *const _, G2_STRIDE, G2_X, G2_Y, G2_INF, bases.len(), &mut handle) } == DGPU_OK;
+        if ok { if let Some(c) = table_window_bits { unsafe { dgpu_bases_precompute_g2(handle, c); } } }
+        ResidentG2 { handle: if ok { handle } else { 0 }, host: bases.to_vec() }
+    }
+    pub fn handle(&self) -> u64 { self.handle }
+    pub fn msm_bigint(&self, offset: usize, scalars: &[BigInt<4>]) -> G2Projective {
+        let n = (self.host.len() - offset).min(scalars.len());
+        let mut out = [0u64; 36];
+        let rc = if self.handle == 0 { -1 } else { unsafe { dgpu_msm_g2_handle(self.handle, offset, scalars.as_ptr() as *const u64, n, 0, out.as_mut_ptr()) } };
+        if rc != DGPU_OK { return G2Projective::msm_bigint(&self.host[offset..offset + n], &scalars[..n]); }
+        g2_from_xyz(&out)
+    }
+}
+impl Drop for ResidentG2 { fn drop(&mut self) { if self.handle != 0 { unsafe { dgpu_bases_free(self.handle); } } } }
+
 // ---- pairings ------------------------------------------------------------------------------------------------------------------------
 /// drop-in for `Bls12_381::multi_miller_loop(a, b)` over affine operands — utils/src/randomized_pairing_check.rs:134,169-170,207.
 /// Lengths must agree (arkworks' zip_eq panics otherwise); pairs with an identity member are skipped by the library like arkworks does.
@@ -341,7 +273,7 @@ pub struct GpuProvingKey {
     gamma_abc_len: usize,
     pub commit_witness_count: usize,
 }
-pub const TABLE_C_WITNESS: i32 = 17; // DGPU_TABLE_C_WITNESS: the queries that meet the witness
+pub const TABLE_C_WITNESS: i32 = DGPU_TABLE_C_WITNESS; // the queries that meet the witness
 impl GpuProvingKey {
     #[allow(clippy::too_many_arguments)]
     pub fn upload(alpha_g1: G1Affine, beta_g1: G1Affine, delta_g1: G1Affine, eta_delta_inv_g1: G1Affine, eta_gamma_inv_g1: G1Affine,

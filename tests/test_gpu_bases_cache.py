@@ -190,7 +190,11 @@ def test_six_threads_on_one_key_from_cold():
     [x.start() for x in th]; [x.join() for x in th]
     assert not bad, bad
     d = delta(s0)
-    assert d["fills"] == 1 and d["hits"] >= 6 and d["hits"] + d["misses"] == 24, d
+    assert d["fills"] == 1 and d["hits"] >= 1 and d["hits"] + d["misses"] == 24, d      # (the other threads run one-shot while one of them fills the entry)
+    s0 = ca.bases_cache_stats()
+    th = [threading.Thread(target=work, args=(t,)) for t in range(6)]
+    [x.start() for x in th]; [x.join() for x in th]
+    assert not bad and delta(s0) == {"hits": 24, "misses": 0, "fills": 0, "stale": 0, "evictions": 0}
     # a clear while calls are in flight: entries in use are released by their last user
     stop = []
 

@@ -52,6 +52,37 @@ def test_one_call_equals_the_python_schedule(m, cw):
         gh = LG.prove_abi(pk, r, s, v, z, n_inst, h=dh)
         assert all((gh[k] == ref[k]).all() for k in ref)
         dh.free()
+    # the same proof for a host that holds the key the way the reference does (dgpu_legogroth16_prove_host): queries as arrays of Affine structs in host
+    # memory, h as the host vector the witness map returned — first proof (views uploaded for the call), second (the cache makes them resident), later ones
+    hpk = LG.HostProvingKey(vk, key["beta_g1"], key["delta_g1"], key["eta_delta_inv_g1"], key["a_query"], key["b_g1_query"], key["b_g2_query"], key["h_query"], key["l_query"])
+    h_host, _ = dr.witness_map(z, to_host=True)
+    ref = LG.create_proof_with_reduction_py(pk, dr, r, s, v, z)
+    ca.bases_cache_clear(); ca.bases_cache(min_n=2)
+    try:
+        s0 = ca.bases_cache_stats()
+        for call in range(4):
+            gh = LG.prove_host(hpk, r, s, v, h_host, z[:n_inst], z[n_inst:])
+            assert all((gh[k] == ref[k]).all() for k in ref), (m, cw, call)
+        gm = LG.prove_host(hpk, r, s, v, O.fr_to_mont(h_host), O.fr_to_mont(z[:n_inst]), O.fr_to_mont(z[n_inst:]), montgomery=True, h_montgomery=True)
+        assert all((gm[k] == ref[k]).all() for k in ref)
+        gc = LG.prove_host(hpk, r, s, v, None, z[:n_inst], z[n_inst:], circuit=dr)          # the circuit resident instead of h: create_proof_with_reduction as one call
+        assert all((gc[k] == ref[k]).all() for k in ref)
+        with pytest.raises(ca.DockGpuError):
+            LG.prove_host(hpk, r, s, v, h_host, z[:n_inst], z[n_inst:], circuit=dr)           # both sources of h
+        with pytest.raises(ca.DockGpuError):
+            LG.prove_host(hpk, r, s, v, None, z[:n_inst], z[n_inst:])                          # neither
+        g0 = LG.prove_host(hpk, 0, s, v, h_host, z[:n_inst], z[n_inst:])
+        r0 = LG.create_proof_with_reduction_py(pk, dr, 0, s, v, z)
+        assert all((g0[k] == r0[k]).all() for k in r0)
+        s1 = ca.bases_cache_stats()
+        nq = sum(1 for q in (hpk.a_query, hpk.b_g1_query, hpk.b_g2_query, hpk.h_query, hpk.l_query) if len(q) >= 2)
+        assert s1["fills"] - s0["fills"] == nq and s1["hits"] - s0["hits"] == 6 * nq, (s0, s1)
+        # the cache off: every view is uploaded for the call
+        ca.bases_cache(bytes=0)
+        gh = LG.prove_host(hpk, r, s, v, h_host, z[:n_inst], z[n_inst:])
+        assert all((gh[k] == ref[k]).all() for k in ref)
+    finally:
+        ca.bases_cache(bytes=(1 << 64) - 1, min_n=1 << 16)
     # argument checks: both / neither source of h, n_inst out of range
     with pytest.raises(ca.DockGpuError):
         LG.prove_abi(pk, r, s, v, z, n_inst)

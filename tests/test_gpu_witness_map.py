@@ -59,6 +59,16 @@ def test_witness_map_vs_oracle(m):
     matsm = [(rp, cl, O.fr_to_mont(vl)) for rp, cl, vl in mats]
     hm, _ = qap.witness_map(*matsm, O.fr_to_mont(z), cs["n_inst"], cs["n_cons"], montgomery=True)
     assert (hm == ref).all()
+    # ... and DGPU_WM_H_MONTGOMERY hands h back as the &[Fr] witness_map_from_matrices returns (r1cs_to_qap.rs:150-210), the resident copy staying canonical
+    hmm, dh = qap.witness_map(*matsm, O.fr_to_mont(z), cs["n_inst"], cs["n_cons"], montgomery=True, h_montgomery=True, resident=True)
+    assert (hmm == O.fr_to_mont(ref)).all()
+    dr = qap.DeviceR1cs(*mats, len(cs["z"]), cs["n_inst"], cs["n_cons"])
+    h3, _ = dr.witness_map(z, h_montgomery=True)
+    assert (h3 == hmm).all()
+    if m >= 1000:
+        bases, _, _ = U.seq_bases(O.G1, len(ref), 17, threads=16)
+        assert (ca.DeviceBases(ca.G1, bases).msm_resident(dh) == ca.msm_bigint(ca.G1, bases, ref)).all()
+    dh.free(); dr.free()
 
 
 def test_resident_h_feeds_the_msm_and_the_proof_verifies():

@@ -281,7 +281,7 @@ def gt_elements(proof):
     return out
 
 
-def verify_aggregate_proof(ip_verifier_srs, pvk, public_inputs, proof, random, transcript, pairing_check=None, with_d=False, validate_gt=False):
+def verify_aggregate_proof(ip_verifier_srs, pvk, public_inputs, proof, random, transcript, pairing_check=None, with_d=False, validate_gt=True):
     """groth16/verifier.rs:36-100; with_d: legogroth16/verifier.rs:34-96 (z_d joins the gamma pairing of the final check).
     public_inputs: one list of ints per proof; `random`: the checker's batching scalar (RandomizedPairingChecker::new_using_rng
     draws it from `rng`).  Raises AggregationError on an invalid proof.  validate_gt: what `CanonicalDeserialize` with `Validate::Yes` does

@@ -8,5 +8,5 @@ def aggregate_proofs(srs, transcript, proofs):
     return groth16.aggregate_proofs(srs, transcript, proofs, with_d=True)
 
 
-def verify_aggregate_proof(ip_verifier_srs, pvk, public_inputs, proof, random, transcript, pairing_check=None):
-    return groth16.verify_aggregate_proof(ip_verifier_srs, pvk, public_inputs, proof, random, transcript, pairing_check, with_d=True)
+def verify_aggregate_proof(ip_verifier_srs, pvk, public_inputs, proof, random, transcript, pairing_check=None, validate_gt=True):
+    return groth16.verify_aggregate_proof(ip_verifier_srs, pvk, public_inputs, proof, random, transcript, pairing_check, with_d=True, validate_gt=validate_gt)

@@ -174,7 +174,7 @@ def aggregate_proofs(srs, transcript, proofs, with_d=False):
     return proof_from_words(aggregate_proofs_words(srs, transcript, proofs, with_d))
 
 
-def verify_aggregate_proof(ip_verifier_srs, pvk, public_inputs, proof, random, transcript, with_d=False, d=None, validate_gt=False, validate_points=False):
+def verify_aggregate_proof(ip_verifier_srs, pvk, public_inputs, proof, random, transcript, with_d=False, d=None, validate_gt=True, validate_points=True):
     """groth16.verify_aggregate_proof / using_groth16.verify_aggregate_proof (d = the list of commitments): raises AggregationError on an
     invalid proof.  `proof`: the dictionary or the flat words.  validate_gt / validate_points: the two halves of `Validate::Yes` for a proof that
     arrives from an untrusted source as raw words (GT members of order r; G1 / G2 members on their curve and in the prime-order subgroup)."""

@@ -27,7 +27,6 @@ FD bool fis_zero_exact(const Fs2 &a) { return fs_is_zero_exact(a.c0) && fs_is_ze
 // U - S - T = the cross-term column, bounded exactly as in fs_mul2.  Measured on MI355X: the one-lane mixed addition built on it runs at
 // 1.0 G additions/s (five live 64-bit column chains on top of a 104-register accumulator: 170-670 spilled registers), the one-lane form on
 // fs_mul2 at 2.3 G/s, the lane-pair form (Fs2H below) at 2.5 G/s — which is why the accumulation keeps lane pairs and 1014 multiply-adds.
-#ifdef FS2_KARATSUBA
 FD void fs2_mul_kara(Fs &r0, Fs &r1, const Fs &a0, const Fs &a1, const Fs &b0, const Fs &b1) {
     constexpr int32_t P_[SN] = BLS30_P;
     SCHK({ Fs n1; fs_neg(n1, a1); const Fs *pa[2] = {&a0, &n1}, *pb[2] = {&b0, &b1}; schk_columns(pa, pb, 2);
@@ -66,7 +65,6 @@ FD void fs2_mul_kara(Fs &r0, Fs &r1, const Fs &a0, const Fs &a1, const Fs &b0, c
     for (int i = 0; i < SN; i++) { r0.l[i] = t0[i]; r1.l[i] = t1[i]; }
     SCHK(schk_set_B(r0, v0); schk_set_B(r1, v1); schk_actual(r0); schk_actual(r1);)
 }
-#endif
 // (a0 b0 - a1 b1) + (a0 b1 + a1 b0) u; all components class B
 FD void fmul(Fs2 &r, const Fs2 &a, const Fs2 &b) {
 #ifdef FS2_KARATSUBA
@@ -134,6 +132,23 @@ __device__ __forceinline__ void fmul(Fs2H &r, const Fs2H &a, const Fs2H &b) {
     sel(X, odd, bo, b.v);                     // even: a0 b0 + a1 (-b1)     odd: a1 b0 + a0 b1  — the a side needs no selection
     sel(Z, odd, b.v, nbo);
     fs_mul2(r.v, a.v, X, ao, Z);
+}
+// TWO independent products at once, r1 = a b and r2 = c d: instead of half of each (two fused two-product reductions per lane: 2 x 507 multiply-adds) every
+// lane of the pair computes ONE whole product by Karatsuba (fs2_mul_kara: 3 operand products + 2 reductions = 845) — the even lane a b, the odd lane c d —
+// after the lanes have swapped the operand halves the other one needs, and the result halves are swapped back.  All halves class B.
+__device__ __forceinline__ void fmul_two(Fs2H &r1, Fs2H &r2, const Fs2H &a, const Fs2H &b, const Fs2H &c, const Fs2H &d) {
+    const bool odd = spair_odd();
+    Fs s1, s2, g1, g2, own1, own2, X0, X1, Y0, Y1, R0, R1, back, got;
+    sel(s1, odd, a.v, c.v); sel(s2, odd, b.v, d.v);               // what the partner needs: the odd lane gives its halves of a, b; the even lane its halves of c, d
+    xchg(g1, s1); xchg(g2, s2);
+    sel(own1, odd, c.v, a.v); sel(own2, odd, d.v, b.v);
+    sel(X0, odd, g1, own1); sel(X1, odd, own1, g1);               // even: (a0, a1) ; odd: (c0, c1)
+    sel(Y0, odd, g2, own2); sel(Y1, odd, own2, g2);
+    fs2_mul_kara(R0, R1, X0, X1, Y0, Y1);
+    sel(back, odd, R0, R1);                                       // even sends (a b)_1, odd sends (c d)_0
+    xchg(got, back);
+    sel(r1.v, odd, got, R0);                                      // a b: even keeps c0, odd receives c1
+    sel(r2.v, odd, R1, got);                                      // c d: even receives c0, odd keeps c1
 }
 // square: input class B
 __device__ __forceinline__ void fsqr(Fs2H &r, const Fs2H &a) {

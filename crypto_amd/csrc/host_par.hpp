@@ -67,7 +67,9 @@ class HostPool {
     // fork(): the child has the forking thread only.  prepare takes the pool's mutex (no worker or submitter holds it across the fork, so the child never
     // inherits a locked mutex it cannot unlock); the child then starts from an empty, not-yet-started pool — the parent's workers do not exist there,
     // their std::thread objects and whatever was queued are abandoned (overwritten without running destructors: joining or detaching a thread that
-    // does not exist is undefined) and new workers are created at the child's first par_run.
+    // does not exist is undefined) and new workers are created at the child's first par_run.  This makes fork + exec safe, NOT the use of the library in the
+    // child: HIP state does not survive fork (streams, events and device memory of the parent are invalid there) and tasks that were queued by other threads of the
+    // parent vanish — a child that wants the library calls dgpu_shutdown + dgpu_init* first (include/dock_gpu.h, lifecycle).
     static void atfork_prepare() { get().m_.lock(); }
     static void atfork_parent() { get().m_.unlock(); }
     static void atfork_child() {

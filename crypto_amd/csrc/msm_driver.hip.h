@@ -329,7 +329,9 @@ int32_t msm_device_ranges(Slot &sl, const uint32_t *d_bases, const uint32_t *d_s
     // fell to half its rate on loaded hosts (round 5: 420 -> 190 - 240 MSM/s with kernels of unchanged length).  Pinned: three asynchronous copies, one wait.
     const size_t wb = (size_t)W * 4 * C::ABI_W * 4, ib = ((size_t)W + 7) & ~(size_t)7;
     static_assert((size_t)64 * 4 * 24 * 4 + 64 + 16 <= Slot::HPIN_BYTES, "pinned scratch");
-    uint8_t *const hp = (uint8_t *)sl.hpin;
+    std::vector<uint8_t> big;                        // (W <= 37 today, c >= 7: the pinned scratch always fits — a future window rule that breaks this falls back to pageable memory instead of overflowing it)
+    if (wb + ib + 4 > Slot::HPIN_BYTES) big.resize(wb + ib + 4);
+    uint8_t *const hp = big.empty() ? (uint8_t *)sl.hpin : big.data();
     HIPCHK(hipMemcpyAsync(hp, sl.win.p, wb, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(hp + wb, sl.win_inf.p, W, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(hp + wb + ib, sl.flags.p, 4, hipMemcpyDeviceToHost, s));

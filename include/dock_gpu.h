@@ -48,6 +48,8 @@ extern "C" {
  *                               initialised HIP (PyTorch) exports the variable itself instead. */
 #define DGPU_HINT_EIGHT_HW_QUEUES 1u
 int32_t dgpu_runtime_hints(uint32_t flags);
+/* fork(): HIP state does not survive it.  fork + exec is safe (the library's worker pool re-arms itself in the child); a child that goes on to USE the library
+ * must bring it up again itself (dgpu_shutdown, then dgpu_init*) — handles, streams and resident tables of the parent mean nothing there. */
 int32_t dgpu_init(int32_t device);           /* bind to a HIP device ordinal (one process per GPU); idempotent */
 /* Several GPUs in ONE process (a Rust host is one process): one context per device, each with its own streams and
  * workspaces.  dgpu_init_devices(mask): bit d = use HIP device d; contexts are numbered 0.. in increasing device order.

@@ -4,6 +4,7 @@ reads, and the internal consistency of the roofline / cpu_baseline objects (frac
 import glob
 import json
 import os
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -37,3 +38,23 @@ def test_recorded_bench_line_honours_the_contract():
         assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
         assert d["value"] / c["value"] > 20          # north_star: >= 20x the CPU path on the same box
     assert d["device_allocations_in_timed_region"] == 0
+
+
+def test_traffic_figure_belongs_to_the_kernel_that_is_shipped():
+    """`roofline.traffic` is read from profiles/traffic_accumulate.json, a counter measurement made at the commit the file names.  It describes HEAD's
+    k_accumulate only if nothing that kernel is compiled from changed since: the commit must be an ancestor of HEAD and `git diff <commit> HEAD` must be
+    empty for the kernel's sources (the kernel itself, the field and the group law it instantiates)."""
+    import json
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if shutil.which("git") is None or not os.path.isdir(os.path.join(root, ".git")):
+        pytest.skip("no git history here (the GPU box receives a snapshot without .git)")
+    tr = json.load(open(os.path.join(root, "profiles", "traffic_accumulate.json")))
+    commit = tr["commit"]
+    git = lambda *a: subprocess.run(["git", "-C", root] + list(a), capture_output=True, text=True)
+    assert git("cat-file", "-e", commit + "^{commit}").returncode == 0, "profiles/traffic_accumulate.json names commit %s, which this history does not contain" % commit
+    assert git("merge-base", "--is-ancestor", commit, "HEAD").returncode == 0, "%s is not an ancestor of HEAD" % commit
+    srcs = ["crypto_amd/csrc/msm_kernels.hip.h", "crypto_amd/csrc/fp30s.hip.h", "crypto_amd/csrc/ec29.hip.h", "crypto_amd/csrc/fp29.hip.h", "crypto_amd/csrc/dyn_chunk.hip.h"]
+    d = git("diff", "--stat", commit, "HEAD", "--", *srcs)
+    assert d.returncode == 0 and d.stdout.strip() == "", "k_accumulate's sources changed since the traffic measurement (%s): re-run tools/dev/round6_profiles.sh PART=msm\n%s" % (commit, d.stdout)

@@ -203,7 +203,6 @@ def test_batch_of_proofs_in_one_call(n):
     """dgpu_legogroth16_verify_batch: N proofs of one key through the merged batch check inside the library — accepts exactly when every proof verifies
     (against the one-proof call and the Python statement of the same check), whatever the batching scalar; one bad proof, one wrong public input, a
     swapped member, an identity member and a zero batching scalar are all answered as the one-proof path answers them"""
-    import bench as B
     R = U.R
     rng = np.random.default_rng(50 + n)
     ints = lambda k: [int.from_bytes(rng.bytes(40), "little") % (R - 1) + 1 for _ in range(k)]

@@ -91,7 +91,7 @@ DEV_SYMBOLS = ["dgpu_set_window_bits", "dgpu_set_chunk", "dgpu_set_reduce_shift"
 # every symbol include/dock_gpu.h declares
 SYMBOLS = [
     "dgpu_runtime_hints", "dgpu_init", "dgpu_init_devices", "dgpu_init_device_list", "dgpu_context_count", "dgpu_set_device", "dgpu_shutdown", "dgpu_device_count", "dgpu_strerror", "dgpu_last_hip_error",
-    "dgpu_set_min_gpu_n", "dgpu_get_min_gpu_n", "dgpu_set_small_msm_max", "dgpu_reserve_g1", "dgpu_reserve_g2", "dgpu_device_alloc_count",
+    "dgpu_set_min_gpu_n", "dgpu_get_min_gpu_n", "dgpu_set_auto_shard_min_n", "dgpu_set_small_msm_max", "dgpu_reserve_g1", "dgpu_reserve_g2", "dgpu_device_alloc_count",
     "dgpu_set_bases_cache_bytes", "dgpu_set_bases_cache_min_n", "dgpu_set_bases_cache_verify", "dgpu_bases_cache_invalidate", "dgpu_bases_cache_clear", "dgpu_bases_cache_stats",
     "dgpu_msm_g1", "dgpu_msm_g1_mont", "dgpu_msm_g2", "dgpu_msm_g2_mont", "dgpu_msm_g1_strided", "dgpu_msm_g2_strided", "dgpu_bases_upload_g1_strided", "dgpu_bases_upload_g2_strided",
     "dgpu_bases_upload_g1", "dgpu_bases_upload_g2", "dgpu_bases_free", "dgpu_scalars_upload", "dgpu_scalars_upload_parts", "dgpu_scalars_free",
@@ -173,6 +173,7 @@ def _load(path):
         L.dgpu_init.argtypes = [C.c_int32]
         L.dgpu_runtime_hints.argtypes = [C.c_uint32]
         L.dgpu_set_min_gpu_n.argtypes = [C.c_size_t]
+        L.dgpu_set_auto_shard_min_n.argtypes = [C.c_size_t]
         L.dgpu_set_small_msm_max.argtypes = [C.c_size_t]
         L.dgpu_reserve_g1.argtypes = [C.c_size_t]
         L.dgpu_reserve_g2.argtypes = [C.c_size_t]

@@ -272,6 +272,7 @@ const char *dgpu_strerror(int32_t code) {
 }
 int32_t dgpu_last_hip_error(void) { return gs.last_hip.load(); }
 int32_t dgpu_set_min_gpu_n(size_t n) { gs.min_gpu_n = n; return DGPU_OK; }
+int32_t dgpu_set_auto_shard_min_n(size_t n) { gs.auto_shard_min_n = n == 0 ? ~(size_t)0 : n; return DGPU_OK; }
 size_t dgpu_get_min_gpu_n(void) { return gs.min_gpu_n.load(); }
 int32_t dgpu_set_small_msm_max(size_t n) { if (n > 8192) return DGPU_E_BADARG; gs.small_max = n; return DGPU_OK; }
 uint64_t dgpu_device_alloc_count(void) { return g_dev_allocs.load(); }

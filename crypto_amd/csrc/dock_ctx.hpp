@@ -108,6 +108,7 @@ struct Shared {
     uint64_t next_handle = 1;
     std::atomic<int32_t> last_hip{0};
     std::atomic<size_t> min_gpu_n{DGPU_DEFAULT_MIN_GPU_N};
+    std::atomic<size_t> auto_shard_min_n{~(size_t)0};      // dgpu_set_auto_shard_min_n: one-shot MSMs of at least this many terms are sharded over the process's device contexts (off by default)
     std::atomic<int> window_bits{0};
     std::atomic<size_t> small_max{8192};      // dgpu_set_small_msm_max: MSMs of up to this many terms on plain bases take the two-launch tree path (small_kernels.hip.h); 0 = never
     std::atomic<int> chunk{0};

@@ -882,17 +882,39 @@ int32_t msm_oneshot_here(const RawBases &rb, const uint64_t *scalars, size_t n, 
     return rc;
 }
 template <class C, class HF> bool msm_oneshot_cached(const RawBases &rb, const uint64_t *scalars, size_t n, bool mont, uint64_t *out, int kind, int32_t &rc);      // (defined below)
+// one-shot MSM on the calling thread's context: from the resident-bases cache if the caller's points are (or now become) resident, else from host memory
 template <class C, class HF>
-int32_t msm_oneshot(const RawBases &rb, const uint64_t *scalars, size_t n, bool mont, uint64_t *out) {
-    if (!out || (n && (!rb.p || !scalars)) || n >= (1ull << 31) || !rb.ok<C>()) return DGPU_E_BADARG;
-    if (!cur().ready) return DGPU_E_NODEVICE;            // (before the size threshold: a missing device is never answered with "too small")
-    if (!tl_no_min && n < gs.min_gpu_n) return DGPU_E_TOO_SMALL;
-    // the caller's bases may be resident already (bases_cache.hpp): the proving-key slices the reference passes proof after proof
+int32_t msm_oneshot_ctx(const RawBases &rb, const uint64_t *scalars, size_t n, bool mont, uint64_t *out) {
     if (gcache.enabled.load(std::memory_order_relaxed) && n >= gcache.min_n.load(std::memory_order_relaxed)) {
         int32_t rc;
         if (msm_oneshot_cached<C, HF>(rb, scalars, n, mont, out, C::NFP, rc)) return rc;
     }
     return msm_oneshot_here<C, HF>(rb, scalars, n, mont, out);
+}
+template <class C, class HF>
+int32_t msm_oneshot(const RawBases &rb, const uint64_t *scalars, size_t n, bool mont, uint64_t *out) {
+    if (!out || (n && (!rb.p || !scalars)) || n >= (1ull << 31) || !rb.ok<C>()) return DGPU_E_BADARG;
+    if (!cur().ready) return DGPU_E_NODEVICE;            // (before the size threshold: a missing device is never answered with "too small")
+    if (!tl_no_min && n < gs.min_gpu_n) return DGPU_E_TOO_SMALL;
+    // A process that drives several devices (dgpu_init_devices) and asked for it (dgpu_set_auto_shard_min_n): the unmodified call is sharded over them —
+    // context k takes the contiguous balanced chunk k of the terms on a host thread of its own, from ITS resident copy of that chunk once the cache holds
+    // it, and the partial points are folded on the host (point-chunk sharding; the same group element as on one device).
+    if (n >= gs.auto_shard_min_n.load(std::memory_order_relaxed)) {
+        const std::vector<int> cx = ready_contexts(0);
+        if (cx.size() > 1) {
+            std::vector<size_t> lo; shard_bounds(n, cx.size(), lo);
+            const size_t JW = 3 * sizeof(HF) / 8;
+            std::vector<uint64_t> parts(cx.size() * JW);
+            const int32_t rc = run_shards(cx.size(), [&](size_t k) {
+                CtxScope here(cx[k]);
+                RawBases part = rb; part.p = rb.p + lo[k] * rb.stride; if (rb.is_inf) part.is_inf = rb.is_inf + lo[k];
+                return msm_oneshot_ctx<C, HF>(part, scalars + lo[k] * 4, lo[k + 1] - lo[k], mont, parts.data() + k * JW);
+            });
+            if (rc) return rc;
+            return host_fold_jacobian<HF>(parts.data(), cx.size(), out);
+        }
+    }
+    return msm_oneshot_ctx<C, HF>(rb, scalars, n, mont, out);
 }
 
 // rec_hash != nullptr (the resident-bases cache, bases_cache.hpp): the fingerprint of every raw record, computed on the device from the staged bytes

@@ -73,6 +73,12 @@ int32_t dgpu_last_hip_error(void);
 #define DGPU_MIN_GPU_N_HANDLE 8
 int32_t dgpu_set_min_gpu_n(size_t n);
 size_t dgpu_get_min_gpu_n(void);
+/* Several devices behind the UNMODIFIED call: with more than one device context in the process (dgpu_init_devices) the one-shot entry points
+ * (dgpu_msm_g1 / _g2 [_mont | _strided]) shard calls of at least n terms over all of them — context k takes the contiguous balanced chunk k of the terms
+ * on a host thread inside the call (from its own resident copy of that chunk once the resident-bases cache holds it: each device caches ITS chunk of a
+ * key), the partial points are folded on the host: BASELINE config 5's shape (2^24 terms over 8 GPUs) from `msm_bigint(&[G1Affine], ..)`.  Same group
+ * element as on one device.  n = 0: off (the default — host-pointer calls then run on the calling thread's context, dgpu_set_device). */
+int32_t dgpu_set_auto_shard_min_n(size_t n);
 /* (tuning knobs of the kernels — window width, chunk length, reduction geometry, Miller-loop forms —, stage timers and self-test hooks are NOT part
  * of this ABI: include/dock_gpu_dev.h, served by the development twin libdock_gpu_dev.so.  The product runs every knob at its measured optimum.) */
 /* MSMs of up to n terms (default and maximum 8192) over plain bases — one-shot calls, plain handles — run as 64 signed 4-bit windows, each a

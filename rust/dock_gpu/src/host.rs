@@ -24,6 +24,9 @@ pub fn init_devices(devices: &[i32], max_n_per_device: usize) -> bool {
         dgpu_set_device(0) == DGPU_OK
     }
 }
+/// With several device contexts: `msm_bigint_g1` & co. of at least `n` terms shard themselves over all of them (each device caches its own chunk of a key);
+/// 0 = off.  BASELINE config 5's shape — 2^24 terms over the 8 GPUs of a node — from the unmodified `msm_bigint(&[G1Affine], ..)` call.
+pub fn set_auto_shard_min_n(n: usize) -> bool { unsafe { dgpu_set_auto_shard_min_n(n) == DGPU_OK } }
 pub fn device_count() -> i32 { unsafe { dgpu_device_count() } }
 pub fn context_count() -> i32 { unsafe { dgpu_context_count() } }
 /// the calling thread's device context for the entry points that take host pointers (thread-local, like hipSetDevice)

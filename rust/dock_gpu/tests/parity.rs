@@ -229,6 +229,10 @@ fn sharded_msm_window_tables_and_serde() {
     let (b, b2, s) = (g1s(&mut rng, n), g2s(&mut rng, 3000), big(&frs(&mut rng, n)));
     let want = G1Projective::msm_bigint(&b, &s).into_affine();
     assert_eq!(msm_bigint_g1_sharded(&b, &s, 0).into_affine(), want);
+    // the unmodified one-shot call sharding itself over the two contexts (each caches its chunk at the second sighting)
+    assert!(host::set_auto_shard_min_n(1 << 12) && cache::set_min_n(1 << 12));
+    for _ in 0..3 { assert_eq!(msm_bigint_g1(&b, &s).into_affine(), want); }
+    assert!(host::set_auto_shard_min_n(0) && cache::set_min_n(1 << 16));
     let sh = ShardedG1::upload(&b, 0, true).expect("sharded upload");
     assert_eq!(sh.shards(), 2);
     assert_eq!(sh.msm_bigint(&s).into_affine(), want);

@@ -187,3 +187,34 @@ def test_scalars_copy_range_between_contexts():
     assert L.dgpu_scalars_copy_range(ds.handle, 5, 5, 0, C.byref(h)) == 0 and L.dgpu_scalars_free(h.value) == 0        # an empty slice is a vector of length 0
     db.free(); ds.free()
     L.dgpu_set_device(0)
+
+
+def test_unmodified_one_shot_calls_shard_themselves_when_asked():
+    """dgpu_set_auto_shard_min_n: `msm_bigint(&[G1Affine], ..)` on a process that drives several devices — the one-shot entry points split the call into one
+    contiguous chunk per device context (each context caching ITS chunk of the key) and fold the partial points: the single-context answer, limb for limb,
+    first from host memory, then while the chunks become resident, then from the resident chunks; a sub-slice too"""
+    L = lib()
+    for gname, n in (("G1", 70000), ("G2", 20000)):
+        curve, G = (ca.G1, O.G1) if gname == "G1" else (ca.G2, O.G2)
+        bases, sc = _inputs(G, n, 900 + n)
+        inf = np.zeros(n, np.uint8); inf[5] = 1
+        st = ca.to_affine_structs(curve, bases, inf)
+        single = ca.msm_strided(curve, st, sc)                       # (auto-sharding off: the calling thread's context)
+        ref = U.jac_to_model(G, G.msm(bases, sc, inf, threads=16))
+        assert U.jac_to_model(G, single) == ref
+        ca.bases_cache_clear(); ca.bases_cache(min_n=1 << 12)
+        assert L.dgpu_set_auto_shard_min_n(1 << 14) == 0
+        try:
+            s0 = ca.bases_cache_stats()
+            for call in range(4):
+                assert (ca.msm_strided(curve, st, sc) == single).all(), (gname, call)
+                assert (ca.msm_strided(curve, st, O.fr_to_mont(sc), montgomery=True) == single).all()
+                assert (ca.msm_bigint(curve, bases, sc, inf) == single).all()
+            s1 = ca.bases_cache_stats()
+            assert s1["fills"] - s0["fills"] == 4 and s1["hits"] - s0["hits"] >= 8, (s0, s1)      # two chunks of the structs + two of the packed arrays became resident
+            sub = ca.msm_strided(curve, st[1:], sc[:n - 1])
+            assert U.jac_to_model(G, sub) == U.jac_to_model(G, G.msm(bases[1:], sc[:n - 1], inf[1:], threads=16))
+            assert (ca.msm_strided(curve, st[:1000], sc) == ca.msm_bigint(curve, bases[:1000], sc[:1000], inf[:1000])).all()    # below the threshold: one context
+        finally:
+            L.dgpu_set_auto_shard_min_n(0)
+            ca.bases_cache_clear(); ca.bases_cache(min_n=1 << 16)

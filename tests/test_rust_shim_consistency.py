@@ -144,6 +144,7 @@ def test_parity_rs_has_a_case_for_every_wrapper():
     skip = {"new", "upload", "upload_csr", "handle", "raw", "shards", "fq12_from_words", "fq12_to_words", "pack_g1", "pack_g2", "flatten", "set_bytes", "set_min_n", "verify_samples",
             "verify_every_record", "invalidate", "clear", "stats", "multiply_many", "multiply_many_to_bases", "msm_bigint", "msm_resident", "upload_scalars", "witness_map",
             "device_count", "context_count", "set_device", "error_string"}
+    assert "set_auto_shard_min_n" in PARITY
     types = ("ResidentG1", "GpuProvingKey", "GpuPreparedVerifyingKey", "GpuProverSrs", "ShardedG1", "ShardedG2", "WindowTableG1", "WindowTableG2", "R1cs", "HostProvingKey", "cache::")
     missing = sorted(n for n in names - skip if not re.search(r"\b%s\b" % n, PARITY))
     assert not missing, "tests/parity.rs has no case for: %s" % missing

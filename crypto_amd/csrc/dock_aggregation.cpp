@@ -692,19 +692,25 @@ extern "C" int32_t dgpu_legogroth16_verify_batch(const uint64_t alpha_beta_gt[72
         Gt rhs;
         std::vector<uint8_t> skip_prep(2);
         Vec co(delta_neg_pc, delta_neg_pc + DGPU_G2_PREPARED_WORDS); co.insert(co.end(), gamma_neg_pc, gamma_neg_pc + DGPU_G2_PREPARED_WORDS);
-        // the two MSMs and the GT power first, side by side (0.4 ms); then ONE Miller loop: prod e([m_i] A_i, B_i) — the scalings run beside the chain of
-        // the B_i inside the call — with the two prepared pairs e(sum m_i C_i, -delta) e(d, -gamma) as its prepared members
+        // Three independent chains, side by side (round 6; the kernel trace of round 5's order — MSMs, THEN the loop — showed the longest chain of the call, the
+        // 0.9-ms scalings, waiting 0.7 ms for two MSMs it does not depend on: profiles/r06_timeline_batch.txt):
+        //   1. prod e([m_i] A_i, B_i): ONE Miller loop over the n affine pairs, the scalings running beside the chain of the B_i inside the call
+        //   2. the two MSMs, then the Miller loop of the two prepared pairs e(sum m_i C_i, -delta) e(d, -gamma) they feed
+        //   3. the GT power of the right-hand side
+        // A Miller loop's output is the product of its pairs' own outputs (the squarings distribute over the product of the lines, the final conjugation too),
+        // so f = f_1 f_2 limb for limb what the one loop over all n + 2 pairs returns (dgpu_multi_miller_loop_sharded multiplies partial outputs the same way).
+        Gt f, f1, f2, gt;
         par({
-            [&] { c_sum = msm(false, proofs_c, n, m); },
-            [&] { d_sum = msm(false, d_pts.data(), d_sc.size(), d_sc); },
+            [&] { ck(dgpu_multi_miller_loop_scaled(proofs_a, m_words.data(), 4, proofs_b, nullptr, n, nullptr, nullptr, nullptr, 0, f1.data())); },
+            [&] {
+                par({ [&] { c_sum = msm(false, proofs_c, n, m); }, [&] { d_sum = msm(false, d_pts.data(), d_sc.size(), d_sc); } });
+                Vec p_prep(c_sum); p_prep.insert(p_prep.end(), d_sum.begin(), d_sum.end());
+                skip_prep[0] = is_id(c_sum.data(), 12); skip_prep[1] = is_id(d_sum.data(), 12);
+                ck(dgpu_multi_miller_loop_mixed(nullptr, nullptr, nullptr, 0, p_prep.data(), co.data(), skip_prep.data(), 2, f2.data()));
+            },
             [&] { W e[4]; m_sum.canon(e); ck(dgpu_fp12_pow(alpha_beta_gt, e, rhs.data())); },
         });
-        Gt f, gt;
-        {
-            Vec p_prep(c_sum); p_prep.insert(p_prep.end(), d_sum.begin(), d_sum.end());
-            skip_prep[0] = is_id(c_sum.data(), 12); skip_prep[1] = is_id(d_sum.data(), 12);
-            ck(dgpu_multi_miller_loop_scaled(proofs_a, m_words.data(), 4, proofs_b, nullptr, n, p_prep.data(), co.data(), skip_prep.data(), 2, f.data()));
-        }
+        ck(dgpu_fp12_mul(f1.data(), f2.data(), f.data()));
         ck(dgpu_final_exponentiation(f.data(), gt.data()));                                                   // DGPU_E_ZERO: UnexpectedIdentity
         *ok = gt == rhs ? 1 : 0;
         return DGPU_OK;

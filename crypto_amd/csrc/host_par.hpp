@@ -59,8 +59,10 @@ class HostPool {
     }
     void start_locked() {
         started_ = true;
+        // (at least 16: most parts issue a device call and wait for it — they need a thread, not a core.  On a host whose affinity mask shows two cores the batch
+        //  verifier's second MSM waited 0.8 ms for the worker that was computing a GT power: profiles/r06_timeline_batch.txt)
         unsigned w = std::thread::hardware_concurrency();
-        w = w < 2 ? 2 : (w > 64 ? 64 : w);
+        w = w < 16 ? 16 : (w > 64 ? 64 : w);
         try { workers_.reserve(w); for (unsigned i = 0; i < w; i++) workers_.emplace_back([this] { loop(); }); }
         catch (...) {}                                         // fewer workers (or none): callers run what is left themselves
     }

@@ -709,7 +709,7 @@ def secondary_configs(log2n, ks, scalars, db, ds, pool, cpu_legs=True, ncpu=1):
     # the same merged check as ONE call of the C ABI (dgpu_legogroth16_verify_batch: scalings, both MSMs and the GT power side by side inside the library)
     assert LGv.verify_proofs_batch_abi(pvkv, proofs_v, pubs_v, 0x5EED0029) and not LGv.verify_proofs_batch_abi(pvkv, swapped, pubs_v, 0x5EED0027)
     packed_v = LGv.pack_proofs(proofs_v, pubs_v)                        # (the column form the ABI takes: a Rust host's &[Proof] costs microseconds to lay out, 1024 Python dictionaries ~2 ms)
-    res["verify_1024_proofs_one_call_ms"] = round(timed(lambda: LGv.verify_proofs_batch_abi(pvkv, None, None, 0x5EED0029, packed=packed_v), 12, warm=8), 3)      # (the call's pieces rotate through the context's six slots: eight calls until each has seen every buffer size)
+    res["verify_1024_proofs_one_call_ms"] = round(timed(lambda: LGv.verify_proofs_batch_abi(pvkv, None, None, 0x5EED0029, packed=packed_v), 24, warm=36), 3)      # (the call runs four pieces side by side since round 6 — scaled Miller loop, two MSMs, the prepared pairs' loop — and they rotate through the context's six slots: a few dozen calls until every slot has seen every buffer size)
     res["verify_1024_proofs_one_call_incl_python_packing_ms"] = round(timed(lambda: LGv.verify_proofs_batch_abi(pvkv, proofs_v, pubs_v, 0x5EED0029), 3, warm=1), 3)
     res["verify_proofs_per_s_one_call"] = round(nv / res["verify_1024_proofs_one_call_ms"] * 1e3, 0)
     if cpu_legs:

@@ -92,6 +92,12 @@ Fq12 multi_pow_serial(const uint64_t *a, const uint64_t *e, size_t n) {
 }  // namespace
 
 // `PairingOutput::mul_bigint` (the power in GT's multiplicative notation): any 256-bit exponent, any Fp12 base
+// PairingOutput `+`: the Fp12 product (host code, like everything in this file; moved here from dock_pairing.hip in round 6 so that the host-only units link without it)
+extern "C" int32_t dgpu_fp12_mul(const uint64_t *a, const uint64_t *b, uint64_t *out) {
+    if (!a || !b || !out) return DGPU_E_BADARG;
+    hostf::Fq12 x, y; memcpy(&x, a, sizeof x); memcpy(&y, b, sizeof y);
+    hostf::Fq12 r = x * y; memcpy(out, &r, sizeof r); return DGPU_OK;
+}
 extern "C" int32_t dgpu_fp12_pow(const uint64_t *a, const uint64_t *e, uint64_t *out) {
     if (!a || !e || !out) return DGPU_E_BADARG;
     return dock::abi_guard([&]() -> int32_t { const Fq12 r = multi_pow_serial(a, e, 1); memcpy(out, &r, sizeof r); return DGPU_OK; });

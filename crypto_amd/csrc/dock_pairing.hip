@@ -1337,11 +1337,6 @@ int32_t dgpu_g1_scale_batch(const uint64_t *p, const uint8_t *is_inf, const uint
     if (gs.prof) prof_flush(sl);
     return DGPU_OK;
 }
-int32_t dgpu_fp12_mul(const uint64_t *a, const uint64_t *b, uint64_t *out) {
-    if (!a || !b || !out) return DGPU_E_BADARG;
-    hostf::Fq12 x, y; memcpy(&x, a, sizeof x); memcpy(&y, b, sizeof y);
-    hostf::Fq12 r = x * y; memcpy(out, &r, sizeof r); return DGPU_OK;
-}
 // E::final_exponentiation: once per batch, host code
 int32_t dgpu_final_exponentiation(const uint64_t *in, uint64_t *out) {
     if (!in || !out) return DGPU_E_BADARG;

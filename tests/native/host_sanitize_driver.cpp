@@ -42,6 +42,22 @@ std::atomic<uint64_t> g_dev_allocs{0}, g_dev_alloc_ns{0}, g_dev_alloc_bytes{0};
 hipError_t dev_malloc(void **p, size_t bytes) { *p = malloc(bytes ? bytes : 1); g_dev_allocs++; return *p ? hipSuccess : hipErrorOutOfMemory; }
 void free_r1cs_object(void *) {}
 int32_t msm_g1_nothreshold(const uint64_t *, const uint8_t *, const uint64_t *, size_t, uint64_t out[18]) { memset(out, 0, 144); return DGPU_OK; }
+// stand-ins for the host-key prover's views (dock_g1.hip / dock_g2.hip view_acquire_*: the resident-bases cache or an upload for the call): a handle of the
+// view's length that reads the caller's memory like the real one, released through the pin
+std::atomic<int> g_live_views{0};
+static int32_t view_acquire_any(int kind, const void *p, size_t stride, size_t n, uint64_t *handle, void **pin) {
+    if (n) { volatile uint8_t t = ((const uint8_t *)p)[(n - 1) * stride]; (void)t; }
+    *handle = register_handle(malloc(16), n, kind); *pin = new uint64_t(*handle); g_live_views++;
+    return DGPU_OK;
+}
+int32_t view_acquire_g1(const void *p, size_t stride, size_t, size_t, size_t, size_t n, int, uint64_t *handle, void **pin) { return view_acquire_any(1, p, stride, n, handle, pin); }
+int32_t view_acquire_g2(const void *p, size_t stride, size_t, size_t, size_t, size_t n, int, uint64_t *handle, void **pin) { return view_acquire_any(2, p, stride, n, handle, pin); }
+void view_release_any(void *pin) {
+    if (!pin) return;
+    uint64_t *h = (uint64_t *)pin; Handle hd;
+    if (take_handle(*h, [](int) { return true; }, hd)) { free(hd.p); g_live_views--; }
+    delete h;
+}
 }  // namespace dock
 using namespace dock;
 
@@ -61,6 +77,12 @@ extern "C" {
 int32_t dgpu_scalars_upload(const uint64_t *sc, size_t n, int32_t, uint64_t *h) {
     int32_t rc = step("upload"); if (rc) return rc;
     volatile uint64_t touch = n ? sc[4 * (n - 1)] : 0; (void)touch;                 // reads the caller's buffer like the real one
+    void *p = malloc(32 * (n ? n : 1)); *h = register_handle(p, n, 3); g_live_scalars++; return DGPU_OK;
+}
+int32_t dgpu_scalars_upload_parts(const uint64_t *const *parts, const size_t *counts, size_t n_parts, int32_t, uint64_t *h) {
+    int32_t rc = step("upload"); if (rc) return rc;
+    size_t n = 0;
+    for (size_t k = 0; k < n_parts; k++) { if (counts[k]) { volatile uint64_t touch = parts[k][4 * (counts[k] - 1)]; (void)touch; } n += counts[k]; }
     void *p = malloc(32 * (n ? n : 1)); *h = register_handle(p, n, 3); g_live_scalars++; return DGPU_OK;
 }
 int32_t dgpu_scalars_free(uint64_t h) { Handle hd; if (!take_handle(h, [](int k) { return k == 3 || k == 12; }, hd)) return DGPU_E_BADARG; if (hd.kind == 3) g_live_scalars--; else g_live_sorted--; free(hd.p); return DGPU_OK; }
@@ -238,6 +260,38 @@ static void test_prover() {
             g_fail_every = 0;
             if (!fail_every) EXPECT(ok == 36 && bad == 0); else EXPECT(bad > 0);
             EXPECT(g_live_scalars.load() == 0 && g_live_sorted.load() == 0);          // every z / h / sort handle of every call was freed, failed or not
+        }
+        // round 6: the same schedule for a key held as host slices (dgpu_legogroth16_prove_host: five views acquired side by side, released on every path out),
+        // h from the host and from the resident circuit, six callers at once, with and without injected failures
+        if (variant == 0) {
+            std::vector<uint64_t> q1(13 * V, 1), q2(25 * V, 1), hq(13 * 63, 1), hh(4 * 64, 3);
+            dgpu_lego_pk_host hk; memset(&hk, 0, sizeof hk);
+            auto view = [](const std::vector<uint64_t> &m, size_t words, size_t n) { dgpu_bases_view v_; v_.p = m.data(); v_.stride = words * 8; v_.x_off = 0; v_.y_off = (words - 1) * 4; v_.inf_off = (words - 1) * 8; v_.n = n; return v_; };
+            hk.a_query = view(q1, 13, V); hk.b_g1_query = view(q1, 13, V); hk.b_g2_query = view(q2, 25, V); hk.h_query = view(hq, 13, 63); hk.l_query = view(q1, 13, V - n_inst - cw);
+            hk.alpha_g1 = hk.beta_g1 = hk.delta_g1 = hk.eta_delta_inv_g1 = hk.eta_gamma_inv_g1 = hk.a0 = hk.b1_0 = g1pt;
+            hk.beta_g2 = hk.delta_g2 = hk.b2_0 = g2pt;
+            hk.gamma_abc_g1 = gabc.data(); hk.gamma_abc_len = n_inst + cw; hk.commit_witness_count = cw;
+            for (uint64_t fail_every : {(uint64_t)0, (uint64_t)5}) {
+                g_fail_every = fail_every;
+                std::atomic<int> ok{0}, bad{0};
+                std::vector<std::thread> th;
+                for (int t = 0; t < 6; t++) th.emplace_back([&, t] {
+                    for (int k = 0; k < 6; k++) {
+                        uint64_t a[12], b[24], c[12], d[12]; uint8_t inf[4];
+                        const bool from_host = (t + k) & 1;
+                        const int32_t rc = dgpu_legogroth16_prove_host(&hk, from_host ? 0 : circuit, from_host ? hh.data() : nullptr, from_host ? 64 : 0, 0, z.data(), n_inst, z.data() + 4 * n_inst, V - n_inst, 0,
+                                                                       r, s, v, a, b, c, d, inf);
+                        if (rc == DGPU_OK) ok++; else if (rc == DGPU_E_OOM) bad++; else { fprintf(stderr, "prove_host: unexpected rc %d\n", rc); failures++; }
+                    }
+                });
+                for (auto &x : th) x.join();
+                g_fail_every = 0;
+                if (!fail_every) EXPECT(ok == 36 && bad == 0); else EXPECT(bad > 0);
+                EXPECT(g_live_scalars.load() == 0 && g_live_sorted.load() == 0 && dock::g_live_views.load() == 0);
+            }
+            { uint64_t a[12], b[24], c[12], d[12]; uint8_t inf[4];            // both sources of h / neither: refused before anything is acquired
+              EXPECT(dgpu_legogroth16_prove_host(&hk, circuit, hh.data(), 64, 0, z.data(), n_inst, z.data() + 4 * n_inst, V - n_inst, 0, r, s, v, a, b, c, d, inf) == DGPU_E_BADARG);
+              EXPECT(dgpu_legogroth16_prove_host(&hk, 0, nullptr, 0, 0, z.data(), n_inst, z.data() + 4 * n_inst, V - n_inst, 0, r, s, v, a, b, c, d, inf) == DGPU_E_BADARG); }
         }
         // argument check added in round 4: n_inst must agree with the resident circuit
         { uint64_t a[12], b[24], c[12], d[12]; uint8_t inf[4]; EXPECT(dgpu_legogroth16_prove(&pk, circuit, 0, z.data(), V, n_inst + 1, 0, r, s, v, a, b, c, d, inf) == DGPU_E_BADARG); }

@@ -11,7 +11,7 @@
 // A call whose points lie INSIDE a resident entry of the same layout (`&query[1..]`, a truncated length) resolves to (entry, offset).
 // Stale keys: before an entry is used the host re-fingerprints `verify_samples` records of the call's range — its first and last and a fresh
 // pseudo-random choice per call — and compares them with the kept per-record fingerprints; any difference evicts the entry and the call runs one-shot
-// (DGPU_CACHE_VERIFY_FULL: every record, on the library's host threads).  The default therefore notices a buffer that was refilled with another key at
+// (DGPU_CACHE_VERIFY_FULL: every record, on the library's host threads, beside the MSM on the resident copy: msm_oneshot_cached).  The default therefore notices a buffer that was refilled with another key at
 // once and an in-place edit of a few records only with probability samples / n per call: a host that edits bases in place calls
 // dgpu_bases_cache_invalidate (or turns the cache off).  Entries are evicted least-recently-used under the byte budget; an entry in use is pinned by the
 // shared_ptr its caller holds (the handle is freed when the last user lets go).  Lock order: gcache.mu is never held across a device call or gs.mu.

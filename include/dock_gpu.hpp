@@ -39,6 +39,18 @@ inline void init(int device = 0) { check(dgpu_init(device), "dgpu_init"); check(
 // several GPUs in one process: context k on HIP device physical[k]
 inline void init_devices(const std::vector<int32_t> &physical) { check(dgpu_init_device_list(physical.data(), (int32_t)physical.size()), "dgpu_init_device_list"); check(dgpu_set_min_gpu_n(0), "dgpu_set_min_gpu_n"); }
 
+// the resident-bases cache behind the one-shot MSM calls (include/dock_gpu.h dgpu_set_bases_cache_*): what makes VariableBaseMSM::msm_bigint below — the
+// unmodified call on the caller's own vector of Affine structs — run on a resident table from its second use of that vector on
+namespace bases_cache {
+struct Stats { uint64_t hits, misses, fills, stale, evictions, bytes, budget, entries; };
+inline void set_bytes(size_t bytes) { check(dgpu_set_bases_cache_bytes(bytes), "set_bases_cache_bytes"); }
+inline void set_min_n(size_t n) { check(dgpu_set_bases_cache_min_n(n), "set_bases_cache_min_n"); }
+inline void verify_samples(int32_t samples) { check(dgpu_set_bases_cache_verify(samples), "set_bases_cache_verify"); }      // DGPU_CACHE_VERIFY_FULL: every record
+template <class T> void invalidate(const std::vector<T> &v) { check(dgpu_bases_cache_invalidate(v.data(), v.size() * sizeof(T)), "bases_cache_invalidate"); }
+inline void clear() { check(dgpu_bases_cache_clear(), "bases_cache_clear"); }
+inline Stats stats() { uint64_t w[8]; check(dgpu_bases_cache_stats(w), "bases_cache_stats"); return Stats{w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7]}; }
+}  // namespace bases_cache
+
 using Fq = std::array<uint64_t, 6>;        // Montgomery limbs, R = 2^384 (ark-ff Fp384 layout)
 using BigInt256 = std::array<uint64_t, 4>; // canonical scalar (Fr::into_bigint)
 struct Fr { std::array<uint64_t, 4> mont; };   // Montgomery limbs, R = 2^256 (what ark-ff's Fr holds)
@@ -423,6 +435,41 @@ inline Proof create_proof_with_reduction(const ProvingKey &pk, uint64_t r1cs, co
     k.gamma_abc_g1 = gabc.data(); k.gamma_abc_len = pk.gamma_abc_g1.size(); k.commit_witness_count = pk.commit_witness_count;
     uint64_t a[12], b[24], c[12], d[12]; uint8_t inf[4];
     check(dgpu_legogroth16_prove(&k, r1cs, 0, z.empty() ? nullptr : z[0].data(), z.size(), n_inst, 0, r.data(), s.data(), v.data(), a, b, c, d, inf), "legogroth16_prove");
+    Proof pr;
+    auto unflat = [](G1::Affine &p, const uint64_t *o, bool i) { p.infinity = i; std::memcpy(&p.x, o, 48); std::memcpy(&p.y, o + 6, 48); };
+    unflat(pr.a, a, inf[0]); unflat(pr.c, c, inf[2]); unflat(pr.d, d, inf[3]);
+    pr.b.infinity = inf[1]; std::memcpy(&pr.b.x, b, 96); std::memcpy(&pr.b.y, b + 12, 96);
+    return pr;
+}
+// The same prover for a key held the way the reference holds it — ProvingKeyCommon's queries as vectors of Affine structs in HOST memory
+// (legogroth16/src/data_structures.rs:151-168), nothing uploaded by the caller: dgpu_legogroth16_prove_host resolves the five views through the library's
+// resident-bases cache (a key's second proof makes them resident tables).  h: the coefficients QAP::witness_map returned (create_proof_with_assignment,
+// prover.rs:237-265), or nullptr with `r1cs` a resident circuit (create_proof_with_reduction: the witness map runs inside the call).
+struct HostProvingKey {
+    std::vector<G1::Affine> a_query, b_g1_query, h_query, l_query; std::vector<G2::Affine> b_g2_query;
+    G1::Affine alpha_g1, beta_g1, delta_g1, eta_delta_inv_g1, eta_gamma_inv_g1; G2::Affine beta_g2, delta_g2;
+    std::vector<G1::Affine> gamma_abc_g1; size_t commit_witness_count = 0;
+};
+inline Proof create_proof_host(const HostProvingKey &pk, uint64_t r1cs, const std::vector<BigInt256> *h, const std::vector<BigInt256> &instance, const std::vector<BigInt256> &witness,
+                               const BigInt256 &r, const BigInt256 &s, const BigInt256 &v) {
+    auto flat = [](const G1::Affine &p, uint64_t *o) { if (p.infinity) std::memset(o, 0, 96); else { std::memcpy(o, &p.x, 48); std::memcpy(o + 6, &p.y, 48); } };
+    auto flat2 = [](const G2::Affine &p, uint64_t *o) { if (p.infinity) std::memset(o, 0, 192); else { std::memcpy(o, &p.x, 96); std::memcpy(o + 12, &p.y, 96); } };
+    uint64_t g1s[7][12], g2s[3][24];
+    const G1::Affine *g1p[7] = {&pk.alpha_g1, &pk.beta_g1, &pk.delta_g1, &pk.eta_delta_inv_g1, &pk.eta_gamma_inv_g1, &pk.a_query.at(0), &pk.b_g1_query.at(0)};
+    for (int i = 0; i < 7; i++) flat(*g1p[i], g1s[i]);
+    flat2(pk.beta_g2, g2s[0]); flat2(pk.delta_g2, g2s[1]); flat2(pk.b_g2_query.at(0), g2s[2]);
+    std::vector<uint64_t> gabc(pk.gamma_abc_g1.size() * 12);
+    for (size_t i = 0; i < pk.gamma_abc_g1.size(); i++) flat(pk.gamma_abc_g1[i], &gabc[12 * i]);
+    auto view1 = [](const std::vector<G1::Affine> &q) { return dgpu_bases_view{q.data(), sizeof(G1::Affine), offsetof(G1::Affine, x), offsetof(G1::Affine, y), offsetof(G1::Affine, infinity), q.size()}; };
+    dgpu_lego_pk_host k{};
+    k.a_query = view1(pk.a_query); k.b_g1_query = view1(pk.b_g1_query); k.h_query = view1(pk.h_query); k.l_query = view1(pk.l_query);
+    k.b_g2_query = dgpu_bases_view{pk.b_g2_query.data(), sizeof(G2::Affine), offsetof(G2::Affine, x), offsetof(G2::Affine, y), offsetof(G2::Affine, infinity), pk.b_g2_query.size()};
+    k.alpha_g1 = g1s[0]; k.beta_g1 = g1s[1]; k.delta_g1 = g1s[2]; k.eta_delta_inv_g1 = g1s[3]; k.eta_gamma_inv_g1 = g1s[4]; k.a0 = g1s[5]; k.b1_0 = g1s[6];
+    k.beta_g2 = g2s[0]; k.delta_g2 = g2s[1]; k.b2_0 = g2s[2];
+    k.gamma_abc_g1 = gabc.data(); k.gamma_abc_len = pk.gamma_abc_g1.size(); k.commit_witness_count = pk.commit_witness_count;
+    uint64_t a[12], b[24], c[12], d[12]; uint8_t inf[4];
+    check(dgpu_legogroth16_prove_host(&k, r1cs, h && !h->empty() ? (*h)[0].data() : nullptr, h ? h->size() : 0, 0, instance.empty() ? nullptr : instance[0].data(), instance.size(),
+                                      witness.empty() ? nullptr : witness[0].data(), witness.size(), 0, r.data(), s.data(), v.data(), a, b, c, d, inf), "legogroth16_prove_host");
     Proof pr;
     auto unflat = [](G1::Affine &p, const uint64_t *o, bool i) { p.infinity = i; std::memcpy(&p.x, o, 48); std::memcpy(&p.y, o + 6, 48); };
     unflat(pr.a, a, inf[0]); unflat(pr.c, c, inf[2]); unflat(pr.d, d, inf[3]);

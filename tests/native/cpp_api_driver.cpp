@@ -205,6 +205,43 @@ int main() {
             std::memcpy(dk, z[NI].data(), 32); std::memcpy(dk + 4, z[NI + 1].data(), 32); std::memcpy(dk + 8, v.data(), 32);
             EXPECT(dgpu_lincomb_g1(dp, fl, dk, 3, eD) == DGPU_OK);
             EXPECT(!pr.d.infinity && std::memcmp(&pr.d.x, eD, 96) == 0);
+            // the same proof for a key the host HOLDS (legogroth16::create_proof_host -> dgpu_legogroth16_prove_host): vectors of Affine structs, no handle — the key's
+            // first proof uploads the views for the call, the second makes them resident through the library's cache, the third runs on the resident copies; h from
+            // the host (create_proof_with_assignment) and the circuit resident (create_proof_with_reduction)
+            if (pass == 0) {
+                legogroth16::HostProvingKey hk;
+                hk.a_query = qa; hk.b_g1_query = qb1; hk.b_g2_query = qb2; hk.h_query = qh; hk.l_query = ql;
+                hk.alpha_g1 = pk.alpha_g1; hk.beta_g1 = pk.beta_g1; hk.delta_g1 = pk.delta_g1; hk.eta_delta_inv_g1 = pk.eta_delta_inv_g1; hk.eta_gamma_inv_g1 = pk.eta_gamma_inv_g1;
+                hk.beta_g2 = pk.beta_g2; hk.delta_g2 = pk.delta_g2; hk.gamma_abc_g1 = pk.gamma_abc_g1; hk.commit_witness_count = CW;
+                std::vector<BigInt256> inst(z.begin(), z.begin() + NI), wit(z.begin() + NI, z.end()), hv(D);
+                std::memcpy(hv[0].data(), h.data(), D * 32);
+                bases_cache::clear(); bases_cache::set_min_n(64);
+                const bases_cache::Stats c0 = bases_cache::stats();
+                for (int k = 0; k < 3; k++) {
+                    legogroth16::Proof ph = legogroth16::create_proof_host(hk, 0, &hv, inst, wit, r, s, v);
+                    legogroth16::Proof pc = legogroth16::create_proof_host(hk, circ, nullptr, inst, wit, r, s, v);
+                    for (const legogroth16::Proof *q : {&ph, &pc}) {
+                        EXPECT(q->a.infinity == pr.a.infinity && std::memcmp(&q->a.x, &pr.a.x, 96) == 0 && std::memcmp(&q->b.x, &pr.b.x, 192) == 0);
+                        EXPECT(std::memcmp(&q->c.x, &pr.c.x, 96) == 0 && std::memcmp(&q->d.x, &pr.d.x, 96) == 0);
+                    }
+                }
+                const bases_cache::Stats c1 = bases_cache::stats();
+                EXPECT(c1.fills - c0.fills == 5 && c1.hits - c0.hits >= 20 && c1.stale == c0.stale);
+                // the unmodified one-shot call on one of those vectors: resident already (same pointer, same layout) — and a stale key is noticed
+                {
+                    auto ref = VariableBaseMSM<G1>::msm_bigint(qh, hv);
+                    hk.h_query[0] = hk.h_query[7];                                      // an edit of the FIRST record of the cached vector (always among the samples)
+                    const uint64_t stale0 = bases_cache::stats().stale;
+                    auto ed = VariableBaseMSM<G1>::msm_bigint(hk.h_query, hv);
+                    EXPECT(bases_cache::stats().stale == stale0 + 1);
+                    std::vector<G1::Affine> copy = hk.h_query;                           // the same points at another address: never cached, one-shot
+                    bases_cache::set_bytes(0);
+                    auto ed2 = VariableBaseMSM<G1>::msm_bigint(copy, hv);
+                    EXPECT(std::memcmp(&ed, &ed2, sizeof ed) == 0 && std::memcmp(&ed, &ref, sizeof ed) != 0);
+                    bases_cache::set_bytes(DGPU_CACHE_BYTES_AUTO);
+                }
+                bases_cache::clear(); bases_cache::set_min_n((size_t)1 << 16);
+            }
         }
         EXPECT(dgpu_r1cs_free(circ) == DGPU_OK);
     }

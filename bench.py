@@ -982,6 +982,7 @@ def secondary_configs(log2n, ks, scalars, db, ds, pool, cpu_legs=True, ncpu=1):
     di["strided_msm_warm_sampled_check_ms"] = round(timed(lambda: ca.msm_strided(ca.G1, st_h, h_can[:n - 1]), 5, warm=2), 3)
     ca.bases_cache(verify=ca.CACHE_VERIFY_FULL)
     di["strided_msm_warm_full_check_ms"] = round(timed(lambda: ca.msm_strided(ca.G1, st_h, h_can[:n - 1]), 5, warm=2), 3)
+    di["proof_warm_with_reduction_full_check_ms"] = round(timed(lambda: LG.prove_host(hpk, 123456789, 987654321, 555, None, z_inst, z_wit, circuit=circ), 6, warm=2), 2)
     ca.bases_cache(verify=24)
     st_c = ca.bases_cache_stats()
     di["cache"] = {k_: st_c[k_] for k_ in ("hits", "misses", "fills", "stale", "evictions", "entries")}; di["cache"]["resident_GB"] = round(st_c["bytes"] / 1e9, 2)

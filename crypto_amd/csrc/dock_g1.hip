@@ -15,6 +15,7 @@ int32_t view_acquire_g1(const void *p, size_t stride, size_t x_off, size_t y_off
     return view_acquire<G1>(RawBases{(const uint8_t *)p, stride, x_off, y_off, inf_off, nullptr}, n, 1, table_c, handle, pin);
 }
 void view_release_any(void *pin) { view_release(pin); }
+bool view_verify_any(void *pin) { return view_verify(pin); }
 }  // namespace dock
 
 extern "C" {

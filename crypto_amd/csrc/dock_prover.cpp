@@ -15,6 +15,7 @@
 // Everything device-side goes through the library's own entry points (each call takes one of the context's slots), so this file is plain
 // host C++: no kernel, no HIP call.
 #include <algorithm>
+#include <atomic>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -349,11 +350,29 @@ namespace dock {
 int32_t view_acquire_g1(const void *p, size_t stride, size_t x_off, size_t y_off, size_t inf_off, size_t n, int table_c, uint64_t *handle, void **pin);      // dock_g1.hip
 int32_t view_acquire_g2(const void *p, size_t stride, size_t x_off, size_t y_off, size_t inf_off, size_t n, int table_c, uint64_t *handle, void **pin);      // dock_g2.hip
 void view_release_any(void *pin);
+bool view_verify_any(void *pin);        // the exact mode's stale-key check of a view, deferred so that it runs beside the proof
 }
+static int32_t prove_host_once(const dgpu_lego_pk_host *pk, uint64_t r1cs, const uint64_t *h, size_t h_len, int32_t h_montgomery,
+                               const uint64_t *instance, size_t n_inst, const uint64_t *witness, size_t n_wit, int32_t montgomery,
+                               const uint64_t r_in[4], const uint64_t s_in[4], const uint64_t v_in[4],
+                               uint64_t out_a[12], uint64_t out_b[24], uint64_t out_c[12], uint64_t out_d[12], uint8_t out_inf[4], bool &stale);
 extern "C" int32_t dgpu_legogroth16_prove_host(const dgpu_lego_pk_host *pk, uint64_t r1cs, const uint64_t *h, size_t h_len, int32_t h_montgomery,
                                                const uint64_t *instance, size_t n_inst, const uint64_t *witness, size_t n_wit, int32_t montgomery,
                                                const uint64_t r_in[4], const uint64_t s_in[4], const uint64_t v_in[4],
                                                uint64_t out_a[12], uint64_t out_b[24], uint64_t out_c[12], uint64_t out_d[12], uint8_t out_inf[4]) {
+    // (exact stale-key mode: the views' records are re-fingerprinted BESIDE the proof; a proof computed from a key whose host memory had changed is thrown
+    //  away and made again — the stale entries are gone by then, their views are uploaded for the call)
+    for (int attempt = 0; attempt < 2; attempt++) {
+        bool stale = false;
+        const int32_t rc = prove_host_once(pk, r1cs, h, h_len, h_montgomery, instance, n_inst, witness, n_wit, montgomery, r_in, s_in, v_in, out_a, out_b, out_c, out_d, out_inf, stale);
+        if (!stale) return rc;
+    }
+    return DGPU_E_BADARG;          // the key changed under two consecutive attempts: the caller is writing to it during the call
+}
+static int32_t prove_host_once(const dgpu_lego_pk_host *pk, uint64_t r1cs, const uint64_t *h, size_t h_len, int32_t h_montgomery,
+                                               const uint64_t *instance, size_t n_inst, const uint64_t *witness, size_t n_wit, int32_t montgomery,
+                                               const uint64_t r_in[4], const uint64_t s_in[4], const uint64_t v_in[4],
+                               uint64_t out_a[12], uint64_t out_b[24], uint64_t out_c[12], uint64_t out_d[12], uint8_t out_inf[4], bool &stale) {
     if (!pk || ((h != nullptr) == (r1cs != 0)) || !instance || n_inst == 0 || (n_wit && !witness)) return DGPU_E_BADARG;      // exactly one source of h
     try {
         struct Pins { void *p[5] = {}; ~Pins() { for (void *q : p) dock::view_release_any(q); } } pins;
@@ -372,7 +391,13 @@ extern "C" int32_t dgpu_legogroth16_prove_host(const dgpu_lego_pk_host *pk, uint
         k.beta_g2 = pk->beta_g2; k.delta_g2 = pk->delta_g2; k.a0 = pk->a0; k.b1_0 = pk->b1_0; k.b2_0 = pk->b2_0;
         k.gamma_abc_g1 = pk->gamma_abc_g1; k.gamma_abc_len = pk->gamma_abc_len; k.commit_witness_count = pk->commit_witness_count;
         const uint64_t *parts[2] = {instance, witness}; const size_t counts[2] = {n_inst, n_wit};
-        return prove_impl(&k, r1cs, 0, h, h_len, h_montgomery, parts, counts, n_wit ? 2 : 1, n_inst, montgomery, r_in, s_in, v_in, out_a, out_b, out_c, out_d, out_inf);
+        // the deferred checks (a no-op unless the exact mode took entries unchecked) on a thread of their own, beside the proof
+        Job jV; std::atomic<bool> fresh{true};
+        jV.start([&]() -> int32_t { return dock::par_run(5, [&](size_t i) -> int32_t { if (!dock::view_verify_any(pins.p[i])) fresh = false; return DGPU_OK; }); });
+        const int32_t rc = prove_impl(&k, r1cs, 0, h, h_len, h_montgomery, parts, counts, n_wit ? 2 : 1, n_inst, montgomery, r_in, s_in, v_in, out_a, out_b, out_c, out_d, out_inf);
+        (void)jV.join();
+        stale = !fresh.load();
+        return rc;
     }
     catch (const std::bad_alloc &) { return DGPU_E_OOM; }
     catch (...) { return DGPU_E_HIP; }

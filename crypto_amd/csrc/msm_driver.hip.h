@@ -1091,21 +1091,40 @@ bool msm_oneshot_cached(const RawBases &rb, const uint64_t *scalars, size_t n, b
 }
 // A view of host bases as a handle for the duration of a larger call (dgpu_legogroth16_prove_host): the cache's entry when the WHOLE view is one
 // (pinned by *pin), else a temporary upload that view_release frees.  Never fails for want of a cache: the temporary upload is the one-shot path.
-struct ViewPin { std::shared_ptr<CacheEntry> e; uint64_t temp = 0; };
+// `check`: the entry was taken WITHOUT the stale-key check (the exact mode: view_verify runs it beside the proof, dock_prover.cpp)
+struct ViewPin { std::shared_ptr<CacheEntry> e; uint64_t temp = 0; bool check = false; CacheKey key{}; int words = 0; };
 template <class C>
 int32_t view_acquire(const RawBases &rb, size_t n, int kind, int table_c, uint64_t *handle, void **pin) {
     if (!handle || !pin || (n && !rb.p) || n >= (1ull << 31) || !rb.ok<C>()) return DGPU_E_BADARG;
     if (!cur().ready) return DGPU_E_NODEVICE;
     ViewPin *vp = new ViewPin();
     size_t off = 0;
-    if (n && gcache.enabled.load() && n >= gcache.min_n.load() && cache_acquire<C>(rb, n, kind, table_c, vp->e, off)) {
-        if (off == 0 && vp->e->k.n == n) { gcache.hits++; *handle = vp->e->handle; *pin = vp; return DGPU_OK; }
+    const bool full = gcache.verify_samples.load(std::memory_order_relaxed) < 0;
+    bool was_resident = false;
+    if (n && gcache.enabled.load() && n >= gcache.min_n.load() && cache_acquire<C>(rb, n, kind, table_c, vp->e, off, !full, &was_resident)) {
+        if (off == 0 && vp->e->k.n == n) {
+            gcache.hits++; *handle = vp->e->handle; *pin = vp;
+            if (full && was_resident) { vp->check = true; vp->key = CacheKey{rb.p, n, rb.stride, rb.x_off, rb.y_off, rb.inf_off, rb.is_inf, kind, cur_index()}; vp->words = C::ABI_W / 2; }
+            return DGPU_OK;
+        }
         vp->e.reset();                        // (a sub-range of a larger entry: the prover addresses its queries from row 0 — take the points from the host)
     }
     const int32_t rc = bases_upload<C>(rb, n, &vp->temp, kind);
     if (rc) { delete vp; return rc; }
     *handle = vp->temp; *pin = vp;
     return DGPU_OK;
+}
+// the deferred stale-key check of a view (exact mode).  False: the host memory behind the entry changed — the entry is forgotten and whatever was computed
+// from it must be thrown away
+inline bool view_verify(void *pin) {
+    ViewPin *vp = (ViewPin *)pin;
+    if (!vp || !vp->check || !vp->e) return true;
+    if (cache_verify(*vp->e, vp->key, 0, vp->words)) return true;
+    std::vector<std::shared_ptr<CacheEntry>> dropped;
+    std::lock_guard<std::mutex> lk(gcache.mu);
+    cache_remove_locked(vp->e.get(), dropped);
+    gcache.stale++;
+    return false;
 }
 inline void view_release(void *pin) {
     ViewPin *vp = (ViewPin *)pin;

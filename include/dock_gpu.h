@@ -148,7 +148,8 @@ int32_t dgpu_msm_g2_mont(const uint64_t *bases_xy, const uint8_t *is_inf,
  * compares with what was uploaded; a difference evicts the entry and the call runs one-shot.  A buffer refilled with another key is noticed at once; an
  * IN-PLACE edit of a few records only with probability samples / n per call — a host that edits cached bases in place calls dgpu_bases_cache_invalidate,
  * selects DGPU_CACHE_VERIFY_FULL (every record re-fingerprinted per call on the library's host threads: exact; 1.5 ms of host work per 2^20 G1 points that
- * runs BESIDE the MSM on the resident copy, whose result is discarded if the check fails: 3.23 -> 3.30 ms per call), or turns the cache off.  (Rust: a `&[G1Affine]` borrowed from a `ProvingKey` cannot change while borrowed; between calls it can.)
+ * runs BESIDE the MSM on the resident copy, whose result is discarded if the check fails: 3.23 -> 3.30 ms per call; dgpu_legogroth16_prove_host checks its views beside the proof the same way: 9.9 -> 10.3 ms),
+ * or turns the cache off.  (Rust: a `&[G1Affine]` borrowed from a `ProvingKey` cannot change while borrowed; between calls it can.)
  *   dgpu_set_bases_cache_bytes(b)   device bytes the cache may hold (least recently used entries go first; an entry in use is never freed under its
  *                                   user); 0 = off and emptied.  Default (DGPU_CACHE_BYTES_AUTO): a quarter of the device memory that is free at the
  *                                   cache's first use.

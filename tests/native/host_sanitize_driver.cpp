@@ -52,6 +52,7 @@ static int32_t view_acquire_any(int kind, const void *p, size_t stride, size_t n
 }
 int32_t view_acquire_g1(const void *p, size_t stride, size_t, size_t, size_t, size_t n, int, uint64_t *handle, void **pin) { return view_acquire_any(1, p, stride, n, handle, pin); }
 int32_t view_acquire_g2(const void *p, size_t stride, size_t, size_t, size_t, size_t n, int, uint64_t *handle, void **pin) { return view_acquire_any(2, p, stride, n, handle, pin); }
+bool view_verify_any(void *) { return true; }
 void view_release_any(void *pin) {
     if (!pin) return;
     uint64_t *h = (uint64_t *)pin; Handle hd;

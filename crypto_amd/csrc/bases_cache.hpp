@@ -143,6 +143,28 @@ inline void cache_remove_locked(const CacheEntry *e, std::vector<std::shared_ptr
         dropped.push_back(std::move(gcache.entries[i])); gcache.entries.erase(gcache.entries.begin() + i); return;
     }
 }
+// the device is out of memory (dev_malloc): release least-recently-used resident entries until at least `want` bytes of tables left the list.  False: nothing
+// resident was left to release.  The handles are freed here, outside the lock (entries still in use: by their last user).
+inline bool cache_release_lru(size_t want) {
+    std::vector<std::shared_ptr<CacheEntry>> dropped;
+    size_t freed = 0;
+    {
+        std::lock_guard<std::mutex> lk(gcache.mu);
+        while (freed < want) {
+            size_t victim = gcache.entries.size();
+            for (size_t i = 0; i < gcache.entries.size(); i++) {
+                const CacheEntry &c = *gcache.entries[i];
+                if (c.state != CacheEntry::READY) continue;
+                if (victim == gcache.entries.size() || c.last_use < gcache.entries[victim]->last_use) victim = i;
+            }
+            if (victim == gcache.entries.size()) break;
+            freed += gcache.entries[victim]->bytes; gcache.used -= gcache.entries[victim]->bytes; gcache.evictions++;
+            dropped.push_back(std::move(gcache.entries[victim]));
+            gcache.entries.erase(gcache.entries.begin() + victim);
+        }
+    }
+    return !dropped.empty();
+}
 // drop everything (dgpu_bases_cache_clear, dgpu_shutdown, a budget of 0)
 inline void cache_clear() {
     std::vector<std::shared_ptr<CacheEntry>> dropped;

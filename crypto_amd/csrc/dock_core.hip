@@ -26,13 +26,34 @@ std::atomic<uint64_t> g_dev_allocs{0}, g_dev_alloc_ns{0}, g_dev_alloc_bytes{0};
 static std::atomic<int64_t> g_fail_after{-1}, g_fail_count{0}, g_fail_left{0};
 extern "C" __attribute__((visibility("default"))) int32_t dgpu_dev_fail_alloc_after(int64_t k, int64_t count) { g_fail_left = 0; g_fail_count = count; g_fail_after = k; return DGPU_OK; }
 #endif
-hipError_t dev_malloc(void **p, size_t bytes) {
 #ifdef DGPU_DEV
-    if (g_fail_left.load() > 0) { if (g_fail_left.fetch_sub(1) > 0) { *p = nullptr; g_dev_allocs++; return hipErrorOutOfMemory; } }
-    else if (g_fail_after.load() >= 0 && g_fail_after.fetch_sub(1) == 0) { g_fail_left = g_fail_count.load() - 1; *p = nullptr; g_dev_allocs++; return hipErrorOutOfMemory; }
+static bool injected_failure() {
+    if (g_fail_left.load() > 0) return g_fail_left.fetch_sub(1) > 0;
+    if (g_fail_after.load() >= 0 && g_fail_after.fetch_sub(1) == 0) { g_fail_left = g_fail_count.load() - 1; return true; }
+    return false;
+}
 #endif
+static hipError_t raw_malloc(void **p, size_t bytes) {
+#ifdef DGPU_DEV
+    if (injected_failure()) { *p = nullptr; return hipErrorOutOfMemory; }
+#endif
+    return hipMalloc(p, bytes);
+}
+hipError_t dev_malloc(void **p, size_t bytes) {
     const auto t0 = std::chrono::steady_clock::now();
-    const hipError_t e = hipMalloc(p, bytes);
+    hipError_t e = raw_malloc(p, bytes);
+    // The resident-bases cache holds memory nobody asked for by name: when the device is full it gives way.  Least recently used entries leave (an entry a call is
+    // using goes when that call returns) until something was released, then the allocation is tried again — a host's explicit upload, a workspace or a table
+    // build never fails because cached keys are in the way.  (No lock is held here that an entry's release takes: callers hold at most a slot.  The release
+    // may select another device: the caller's is restored.)
+    while (e != hipSuccess) {
+        (void)hipGetLastError();
+        int dev = -1; (void)hipGetDevice(&dev);
+        const bool released = cache_release_lru(bytes);
+        if (dev >= 0) (void)hipSetDevice(dev);
+        if (!released) break;
+        e = raw_malloc(p, bytes);
+    }
     g_dev_alloc_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
     g_dev_allocs++; if (e == hipSuccess) g_dev_alloc_bytes += bytes;
     return e;

@@ -153,6 +153,8 @@ int32_t dgpu_msm_g2_mont(const uint64_t *bases_xy, const uint8_t *is_inf,
  *   dgpu_set_bases_cache_bytes(b)   device bytes the cache may hold (least recently used entries go first; an entry in use is never freed under its
  *                                   user); 0 = off and emptied.  Default (DGPU_CACHE_BYTES_AUTO): a quarter of the device memory that is free at the
  *                                   cache's first use.
+ *                                   Whatever the budget, the cache gives way when the device is full: a failed allocation of the library releases
+ *                                   least recently used entries and is tried again.
  *   dgpu_set_bases_cache_min_n(n)   calls below n terms are never cached (default 65536)
  *   dgpu_set_bases_cache_verify(s)  records sampled per use (2 .. 4096), or DGPU_CACHE_VERIFY_FULL
  *   dgpu_bases_cache_invalidate     forget every entry that overlaps [p, p + bytes)

@@ -196,6 +196,42 @@ def in_flight():
     return seen
 
 
+def cache_gives_way():
+    """the resident-bases cache holds memory nobody asked for by name: when an allocation fails it releases its least recently used entry and the allocation
+    is tried again — an explicit upload does not fail because cached keys are in the way (dock_core.hip dev_malloc, bases_cache.hpp cache_release_lru)"""
+    cold()
+    ca.bases_cache_clear(); ca.bases_cache(min_n=1 << 12)
+    st = ca.to_affine_structs(ca.G1, b1l)
+    ref = ca.msm_strided(ca.G1, st, s_l); ca.msm_strided(ca.G1, st, s_l); ca.msm_strided(ca.G1, st, s_l)
+    s0 = ca.bases_cache_stats()
+    assert s0["entries"] == 1 and s0["fills"] >= 1, s0
+    fail_after(0, 1)                       # the next allocation fails ONCE: the cache gives its entry up, the retry succeeds
+    try:
+        db = ca.DeviceBases(ca.G1, b1s)
+    finally:
+        fail_after(-1)
+    s1 = ca.bases_cache_stats()
+    assert s1["entries"] == 0 and s1["evictions"] == s0["evictions"] + 1 and s1["bytes"] == 0, (s0, s1)
+    assert (db.msm_bigint(s_s) == ca.msm_bigint(ca.G1, b1s, s_s)).all()
+    db.free()
+    # ... and the slice is simply noted and made resident again by the calls that follow
+    for _ in range(3):
+        assert (ca.msm_strided(ca.G1, st, s_l) == ref).all()
+    assert ca.bases_cache_stats()["entries"] == 1
+    # with nothing left to release a failing allocation is still answered with an error
+    ca.bases_cache_clear()
+    fail_after(0, 2)
+    try:
+        ca.DeviceBases(ca.G1, b1s)
+        raise AssertionError("an allocation that failed twice with an empty cache succeeded")
+    except DockGpuError as e:
+        assert e.code in (-2, -4), e.code
+    finally:
+        fail_after(-1)
+    ca.bases_cache(min_n=1 << 16)
+    return {"evicted_on_a_failed_allocation": 1}
+
+
 if __name__ == "__main__":
     assert torch.cuda.is_available()
     ca.init(0)
@@ -206,6 +242,7 @@ if __name__ == "__main__":
     ca.init(0)
     res = run_all(True)
     fl = in_flight()
+    gw = cache_gives_way()
     L.dgpu_shutdown()
     after = free_bytes()
     # A leak of the library repeats with every failed call; what the HIP runtime keeps back from its own pools after an unusual allocation
@@ -215,5 +252,5 @@ if __name__ == "__main__":
     run_all(True)
     L.dgpu_shutdown()
     again = free_bytes()
-    print(json.dumps({"per_workload": res, "six_in_flight": fl, "free_bytes_after_clean_cycles": [base0, base1], "free_bytes_after_fault_cycles": [after, again],
+    print(json.dumps({"per_workload": res, "six_in_flight": fl, "cache_gives_way": gw, "free_bytes_after_clean_cycles": [base0, base1], "free_bytes_after_fault_cycles": [after, again],
                       "kept_by_the_runtime_after_the_first_fault_pass": base1 - after, "leaked_bytes_per_fault_pass": after - again}))

@@ -30,6 +30,7 @@ def test_allocation_failures_are_answered_cleanly():
     rep = json.loads(r.stdout.strip().splitlines()[-1])
     assert len(rep["per_workload"]) == 9 and all(v["answered_with_an_error"] >= 1 for v in rep["per_workload"].values())
     assert rep["six_in_flight"]["failed"] > 0 and rep["six_in_flight"]["ok"] > 0
+    assert rep["cache_gives_way"]["evicted_on_a_failed_allocation"] == 1        # the resident-bases cache releases its entries when the device is full
     # nothing leaked: a second pass over all the fault cycles leaves the device where the first left it (the first may differ from a clean cycle by
     # what the HIP runtime keeps in its own pools: a one-time 240 MB after the first absorbed failure of the table workload, not ours)
     assert abs(rep["leaked_bytes_per_fault_pass"]) <= 64 << 20, rep

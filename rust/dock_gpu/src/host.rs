@@ -8,6 +8,7 @@
 use crate::ffi::*;
 use crate::{g1_affine, g1_from_xyz, g2_affine, g2_from_xyz, pack_g1, pack_g2};
 use ark_bls12_381::{Fr, G1Affine, G1Projective, G2Affine, G2Projective};
+use ark_ec::AffineRepr;
 use ark_ff::{BigInt, PrimeField};
 use ark_std::vec::Vec;
 use std::sync::{Arc, Mutex};
@@ -137,7 +138,7 @@ pub fn fold_g1(partials: &[G1Projective]) -> G1Projective {
     let mut w = Vec::with_capacity(partials.len() * 18);
     for p in partials {
         let a = p.into_affine();
-        match ark_ec::AffineRepr::xy(&a) {
+        match a.xy() {
             Some((x, y)) => { w.extend_from_slice(&x.0 .0); w.extend_from_slice(&y.0 .0); w.extend_from_slice(&one.0 .0); }
             None => { w.extend_from_slice(&one.0 .0); w.extend_from_slice(&one.0 .0); w.extend_from_slice(&[0u64; 6]); }
         }

@@ -33,6 +33,7 @@ pub type G2Prepared = ArkG2Prepared<ark_bls12_381::Config>;
 
 pub mod ffi;
 pub use ffi::*;
+pub use host::*;          // (devices, cache, sharded MSMs, window tables, witness map, the host-key prover, serde: src/host.rs)
 
 pub const G2_PREPARED_WORDS: usize = DGPU_G2_PREPARED_WORDS;
 

@@ -57,6 +57,21 @@ def test_2_24_terms_over_eight_contexts_closed_form():
     one = ca.DeviceBases(ca.G1, bases[:m], inf[:m])
     assert (part == one.msm_bigint(sc[:m])).all()
     one.free(); ds.free(); sh.free()
+    # config 5's shape from the UNMODIFIED call (dgpu_set_auto_shard_min_n): msm_bigint(&[G1Affine], ..) over the caller's structs shards itself over the eight
+    # contexts, each of which makes ITS chunk of the key resident at the chunk's second sighting (eight tables of 2^21 rows) — cold, fill, warm: the same point
+    st = ca.to_affine_structs(ca.G1, bases, inf)
+    L = lib()
+    ca.bases_cache_clear()
+    assert L.dgpu_set_auto_shard_min_n(1 << 20) == 0
+    try:
+        s0 = ca.bases_cache_stats()
+        for call in range(3):
+            assert (ca.msm_strided(ca.G1, st, sc) == plain).all(), call
+        s1 = ca.bases_cache_stats()
+        assert s1["fills"] - s0["fills"] == 8 and s1["hits"] - s0["hits"] == 16 and s1["entries"] == 8, (s0, s1)
+    finally:
+        L.dgpu_set_auto_shard_min_n(0)
+        ca.bases_cache_clear()
 
 
 def test_prover_with_its_key_sharded_eight_ways():

@@ -896,16 +896,28 @@ static int32_t ml_segments(const uint64_t *p, const uint64_t *q, const uint8_t *
     SLOT_ACQUIRE(slot_lock, sl);
     HIPCHK(hipSetDevice(cur().device));
     int32_t rc;
+    // Slices of a (segment, step): a lane pair multiplies its slice's lines one after the other, trees fold the slices.  Up to 64 slices of 4 (8) pairs fold in
+    // one tree level; a longer segment keeps slices of 8 and takes a second level (<= 8192 pairs per segment here: <= 1024 slices, 16 groups) — with one level
+    // its slices grew to 16 / 32 pairs, i.e. a quarter of the lanes on chains four times as long (the commitments of a 1024-proof aggregation: 2 x 2048 + 4 x 1024
+    // pairs on 276 waves per piece).
     int slice_len = 4;
-    while ((maxlen + slice_len - 1) / slice_len > MAX_SLICES) slice_len *= 2;          // one tree level: at most 64 slices per (segment, step)
-    const int nsl = (int)((maxlen + slice_len - 1) / slice_len);
+    if (maxlen > 4 * (size_t)MAX_SLICES) slice_len = 8;
+    while ((maxlen + slice_len - 1) / slice_len > (size_t)MAX_SLICES * MAX_SLICES) slice_len *= 2;
+    const int nsl = (int)((maxlen + slice_len - 1) / slice_len), ngroups = (nsl + MAX_SLICES - 1) / MAX_SLICES;
+    // (K11 over the partials of steps s0 .. s0 + ns - 1 of every segment, one or two levels; the second level sees the groups as slices of 64 * slice_len pairs)
+    auto seg_tree = [&](hipStream_t st, uint32_t *lvl0, const uint32_t *doff_, int s0, int ns) {
+        if (ngroups == 1) { launch_product_tree(st, (unsigned)(ns * nseg), lvl0, nsl, 1, (uint32_t *)nullptr, sl.ml_out.as<uint32_t>(), doff_, slice_len, s0, ns); return; }
+        uint32_t *lvl1 = lvl0 + (size_t)N_LINES * nseg * nsl * F12W;
+        launch_product_tree(st, (unsigned)(ns * nseg * ngroups), lvl0, nsl, ngroups, lvl1, (uint32_t *)nullptr, doff_, slice_len, s0, ns);
+        launch_product_tree(st, (unsigned)(ns * nseg), lvl1, ngroups, 1, (uint32_t *)nullptr, sl.ml_out.as<uint32_t>(), doff_, slice_len * MAX_SLICES, s0, ns);
+    };
     std::vector<uint32_t> off(nseg + 1, 0);
     for (size_t g = 0; g < nseg; g++) off[g + 1] = (uint32_t)seg_end[g];
     if ((rc = sl.in_bases.ensure(n * 96))) return rc;
     if ((rc = sl.in_scalars.ensure(n * 192))) return rc;
     if ((rc = sl.in_inf.ensure(n + (nseg + 1) * 4 + 8))) return rc;
     if ((rc = sl.ml_lines.ensure((size_t)N_LINES * LW * n * 4))) return rc;
-    if ((rc = sl.ml_partial.ensure((size_t)N_LINES * nseg * nsl * F12W * 4))) return rc;
+    if ((rc = sl.ml_partial.ensure((size_t)N_LINES * nseg * (nsl + (ngroups > 1 ? ngroups : 0)) * F12W * 4))) return rc;
     if ((rc = sl.ml_out.ensure((size_t)N_LINES * nseg * 144 * 4))) return rc;
     // pieces: like ml_pipelined, the chain runs in ML_PIECES launches; the products and trees of a finished piece (every segment's) run on a side stream
     // under the next piece, its results land in pinned memory, and the host tails of the segments advance piece by piece on the library's threads —
@@ -947,7 +959,7 @@ static int32_t ml_segments(const uint64_t *p, const uint64_t *q, const uint8_t *
             const int s0 = first_step[j], ns = steps[j];
             hipLaunchKernelGGL(k_line_products, dim3((unsigned)((2 * (size_t)ns * nsl * nseg + 63) / 64)), dim3(64), 0, sp, sl.ml_lines.as<uint32_t>(), n, slice_len, nsl, sl.ml_partial.as<uint32_t>(), doff, (int)nseg,
                                s0, ns, (const uint32_t *)pxy);
-            launch_product_tree(sp, (unsigned)(ns * nseg), sl.ml_partial.as<uint32_t>(), nsl, 1, (uint32_t *)nullptr, sl.ml_out.as<uint32_t>(), doff, slice_len, s0, ns);
+            seg_tree(sp, sl.ml_partial.as<uint32_t>(), doff, s0, ns);
             ok(hipMemcpy2DAsync(Lp + s0, (size_t)N_LINES * 576, (const char *)sl.ml_out.p + (size_t)s0 * 576, (size_t)N_LINES * 576, (size_t)ns * 576, nseg, hipMemcpyDeviceToHost, sp));
             done[j] = sl.copy_ev[sl.ev_next++ % (Slot::N_COPY_EV + 1)];
             ok(hipEventRecord(done[j], sp));
@@ -982,7 +994,7 @@ static int32_t ml_segments(const uint64_t *p, const uint64_t *q, const uint8_t *
       hipLaunchKernelGGL(k_line_products, dim3((unsigned)((2 * (size_t)N_LINES * nsl * nseg + 63) / 64)), dim3(64), 0, s, sl.ml_lines.as<uint32_t>(), n, slice_len, nsl, sl.ml_partial.as<uint32_t>(), doff, (int)nseg,
                          0, N_LINES, n > 8192 ? (const uint32_t *)nullptr : (const uint32_t *)pxy); }
     { StageTimer st(sl, "ml.tree");
-      launch_product_tree(s, (unsigned)(N_LINES * nseg), sl.ml_partial.as<uint32_t>(), nsl, 1, (uint32_t *)nullptr, sl.ml_out.as<uint32_t>(), doff, slice_len, 0); }
+      seg_tree(s, sl.ml_partial.as<uint32_t>(), doff, 0, N_LINES); }
     HIPCHK(hipGetLastError());
     std::vector<hostf::Fq12> L((size_t)N_LINES * nseg);
     HIPCHK(hipMemcpyAsync(L.data(), sl.ml_out.p, (size_t)N_LINES * nseg * 576, hipMemcpyDeviceToHost, s));

@@ -233,11 +233,13 @@ def test_mixed_affine_and_prepared_operands_in_one_call(n):
         pairing.multi_miller_loop(ps, [qs[:1], pc[2:]])                     # one operand short
 
 
-@pytest.mark.parametrize("sizes", [[1, 1], [0, 3, 0, 1, 7], [5, 64, 65, 2, 256, 257, 1], [1, 2, 4, 8, 16, 32, 64, 128, 256, 512], [3000, 1, 0, 900], [9000, 4, 17]])
+@pytest.mark.parametrize("sizes", [[1, 1], [0, 3, 0, 1, 7], [5, 64, 65, 2, 256, 257, 1], [1, 2, 4, 8, 16, 32, 64, 128, 256, 512], [3000, 1, 0, 900], [9000, 4, 17],
+                                   [2048, 2048, 1024, 1024, 1024, 1024], [8192, 513, 0, 700, 4097]])
 def test_segmented_miller_loops_equal_the_single_calls(sizes):
     """dgpu_multi_miller_loop_segments: every segment's raw Fp12 output is limb for limb what dgpu_multi_miller_loop returns for that segment
     alone — empty segments (one), single pairs, sizes around the slice and group borders, identity members, skip flags, a segment long enough
-    for the per-segment path, and the argument checks."""
+    for the per-segment path, segments long enough for the second tree level (the commitments of a 1024-proof aggregation; 8192 + 4097: with and without the
+    pieces), and the argument checks."""
     import ctypes as C
     from crypto_amd import pairing
     from crypto_amd._native import lib

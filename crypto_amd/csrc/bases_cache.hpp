@@ -9,11 +9,11 @@
 //                                           call runs on it
 //   later sightings                         the call runs on the table (dgpu_msm_*_handle's path: scalars cross PCIe, nothing else)
 // A call whose points lie INSIDE a resident entry of the same layout (`&query[1..]`, a truncated length) resolves to (entry, offset).
-// Stale keys: before an entry is used the host re-fingerprints `verify_samples` records of the call's range — its first and last and a fresh
-// pseudo-random choice per call — and compares them with the kept per-record fingerprints; any difference evicts the entry and the call runs one-shot
-// (DGPU_CACHE_VERIFY_FULL: every record, on the library's host threads, beside the MSM on the resident copy: msm_oneshot_cached).  The default therefore notices a buffer that was refilled with another key at
-// once and an in-place edit of a few records only with probability samples / n per call: a host that edits bases in place calls
-// dgpu_bases_cache_invalidate (or turns the cache off).  Entries are evicted least-recently-used under the byte budget; an entry in use is pinned by the
+// Stale keys: before an entry's result is used the host re-fingerprints the records of the call's range and compares them with the kept per-record
+// fingerprints; any difference evicts the entry and the call runs one-shot.  The default (DGPU_CACHE_VERIFY_FULL) checks EVERY record, on the library's host
+// threads, beside the MSM on the resident copy (msm_oneshot_cached): an unmodified call can never answer from a key that has changed, whatever the host did to
+// the buffer between two calls.  A host whose key cannot change under the library's feet may select the sampled mode (`verify_samples` records: first, last and a
+// fresh pseudo-random choice per call), which notices a refilled buffer at once and an in-place edit of a few records only with probability samples / n per call.  Entries are evicted least-recently-used under the byte budget; an entry in use is pinned by the
 // shared_ptr its caller holds (the handle is freed when the last user lets go).  Lock order: gcache.mu is never held across a device call or gs.mu.
 #pragma once
 #include <memory>
@@ -57,7 +57,7 @@ struct BasesCache {
     std::vector<std::shared_ptr<CacheEntry>> entries;
     std::atomic<size_t> budget{CACHE_BUDGET_AUTO}; size_t used = 0;
     std::atomic<size_t> min_n{(size_t)1 << 16};
-    std::atomic<int> verify_samples{24};        // records re-fingerprinted per hit; DGPU_CACHE_VERIFY_FULL: all of them
+    std::atomic<int> verify_samples{DGPU_CACHE_VERIFY_FULL};   // every record of the call's range re-fingerprinted per hit (the default: exact); >= 2: that many sampled records
     std::atomic<bool> enabled{true};
     uint64_t tick = 0;
     std::atomic<uint64_t> hits{0}, misses{0}, fills{0}, stale{0}, evictions{0}, sample_ctr{0};
@@ -102,12 +102,12 @@ inline bool cache_verify(const CacheEntry &e, const CacheKey &k, size_t off, int
     if (samples < 0) {                      // every record, in parallel on the library's host threads
         const size_t parts = std::min<size_t>(16, (k.n + 65535) / 65536);
         std::atomic<bool> ok{true};
-        (void)par_run(parts, [&](size_t part) -> int32_t {
+        const int32_t rc = par_run(parts, [&](size_t part) -> int32_t {
             const size_t lo = k.n * part / parts, hi = k.n * (part + 1) / parts;
             for (size_t i = lo; i < hi && ok.load(std::memory_order_relaxed); i++) if (rec_fingerprint_at(k, i, words) != e.rec_hash[off + i]) ok = false;
             return DGPU_OK;
         });
-        return ok.load();
+        return rc == DGPU_OK && ok.load();       // (a part that could not run counts as a difference: the call falls back to what the buffer holds now)
     }
     if (rec_fingerprint_at(k, 0, words) != e.rec_hash[off] || rec_fingerprint_at(k, k.n - 1, words) != e.rec_hash[off + k.n - 1]) return false;
     uint64_t r = splitmix64(gcache.sample_ctr.fetch_add(1));

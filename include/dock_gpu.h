@@ -144,19 +144,20 @@ int32_t dgpu_msm_g2_mont(const uint64_t *bases_xy, const uint8_t *is_inf,
  * every record (8 B each, host memory) and turns them into a precomputed-multiples table (dgpu_bases_precompute_*: ~40 ms at 2^20 G1 points, once per key);
  * from then on the call is dgpu_msm_*_handle on that table — only the scalars cross PCIe (2^20 G1 terms: 5.3 -> ~2.8 ms).  A call whose points lie
  * INSIDE a resident entry of the same layout (`&query[1..]`, a shorter n) resolves to (entry, offset).  Same group element, limb for limb, either way.
- * Stale keys: before every use the host re-fingerprints a fresh pseudo-random sample of the call's records (its first and last among them; default 24) and
- * compares with what was uploaded; a difference evicts the entry and the call runs one-shot.  A buffer refilled with another key is noticed at once; an
- * IN-PLACE edit of a few records only with probability samples / n per call — a host that edits cached bases in place calls dgpu_bases_cache_invalidate,
- * selects DGPU_CACHE_VERIFY_FULL (every record re-fingerprinted per call on the library's host threads: exact; 1.5 ms of host work per 2^20 G1 points that
- * runs BESIDE the MSM on the resident copy, whose result is discarded if the check fails: 3.23 -> 3.30 ms per call; dgpu_legogroth16_prove_host checks its views beside the proof the same way: 9.9 -> 10.3 ms),
- * or turns the cache off.  (Rust: a `&[G1Affine]` borrowed from a `ProvingKey` cannot change while borrowed; between calls it can.)
+ * Stale keys: before a resident entry's result is used the host re-fingerprints the records of the call's range and compares with what was uploaded; a difference
+ * evicts the entry and the call runs one-shot on what the buffer holds now.  DEFAULT = DGPU_CACHE_VERIFY_FULL: every record, on the library's host threads, BESIDE the
+ * MSM on the resident copy, whose result is discarded if the check fails (1.5 ms of host work per 2^20 G1 points; 3.21 -> 3.22 ms per call;
+ * dgpu_legogroth16_prove_host checks its views beside the proof the same way: 10.0 -> 10.4 - 10.8 ms) — the unmodified call never answers from a key that has changed.
+ * A host whose key cannot change between calls may select the sampled mode (s records per use, its first and last among them): a refilled buffer is still
+ * noticed at once, an IN-PLACE edit of a few records only with probability s / n per call.  dgpu_bases_cache_invalidate drops entries by address range.
+ * (Rust: a `&[G1Affine]` borrowed from a `ProvingKey` cannot change while borrowed; between calls it can.)
  *   dgpu_set_bases_cache_bytes(b)   device bytes the cache may hold (least recently used entries go first; an entry in use is never freed under its
  *                                   user); 0 = off and emptied.  Default (DGPU_CACHE_BYTES_AUTO): a quarter of the device memory that is free at the
  *                                   cache's first use.
  *                                   Whatever the budget, the cache gives way when the device is full: a failed allocation of the library releases
  *                                   least recently used entries and is tried again.
  *   dgpu_set_bases_cache_min_n(n)   calls below n terms are never cached (default 65536)
- *   dgpu_set_bases_cache_verify(s)  records sampled per use (2 .. 4096), or DGPU_CACHE_VERIFY_FULL
+ *   dgpu_set_bases_cache_verify(s)  DGPU_CACHE_VERIFY_FULL (default), or s = 2 .. 4096 records sampled per use
  *   dgpu_bases_cache_invalidate     forget every entry that overlaps [p, p + bytes)
  *   dgpu_bases_cache_stats          out[0..7] = hits, misses (cacheable calls that ran one-shot), fills, stale evictions, budget evictions, bytes in use,
  *                                   byte budget (0 until resolved), resident entries */

@@ -37,8 +37,9 @@ pub fn error_string(code: i32) -> &'static str {
 }
 
 /// the resident-bases cache behind `msm_bigint_g1` & co. (include/dock_gpu.h `dgpu_set_bases_cache_*`): on by default — the second call with the same
-/// `&[G1Affine]` makes it a device-resident table, later calls send the scalars only.  A `&[G1Affine]` cannot change while it is borrowed; a host that
-/// edits a cached `Vec` in place BETWEEN calls tells the cache (`invalidate`) or selects `verify_every_record`.
+/// `&[G1Affine]` makes it a device-resident table, later calls send the scalars only.  A `&[G1Affine]` cannot change while it is borrowed; what a host
+/// does to a cached `Vec` BETWEEN calls is caught by the default `verify_every_record` mode (every record compared beside the MSM).  `verify_samples(24)` trades that
+/// for a sampled check — for keys that never change — and then an in-place edit has to be announced with `invalidate`.
 pub mod cache {
     use super::*;
     #[derive(Debug, Clone, Copy, Default)]

@@ -210,7 +210,7 @@ fn resident_bases_cache_same_slice_twice_and_mutated_slice() {
     for _ in 0..3 { let _ = msm_bigint_g1(&b, &s); }
     b[n / 3] = b[9];
     assert_eq!(msm_bigint_g1(&b, &s).into_affine(), G1Projective::msm_bigint(&b, &s).into_affine());
-    assert!(cache::verify_samples(24) && cache::set_min_n(1 << 16));
+    assert!(cache::verify_every_record() && cache::set_min_n(1 << 16));       // (the library's defaults)
     assert!(!host::error_string(DGPU_E_BADARG).is_empty() && host::device_count() >= 1 && host::context_count() >= 1 && host::set_device(0));
     // G2 and the Montgomery forms through the same entry points
     let (b2, sf) = (g2s(&mut rng, 5000), frs(&mut rng, 5000));

@@ -24,7 +24,7 @@ def _fresh_cache():
     ca.bases_cache(bytes=AUTO, min_n=1 << 12, verify=24)
     yield
     ca.bases_cache_clear()
-    ca.bases_cache(bytes=AUTO, min_n=1 << 16, verify=24)
+    ca.bases_cache(bytes=AUTO, min_n=1 << 16, verify=ca.CACHE_VERIFY_FULL)       # (the library's defaults)
 
 
 def delta(before):
@@ -114,7 +114,7 @@ def test_a_key_whose_host_memory_changed_is_never_used():
     s0 = ca.bases_cache_stats()
     assert U.jac_to_model(G, ca.msm_strided(curve, st, sc)) == oracle_point(G, b3, sc)
     assert delta(s0)["stale"] == 1
-    # (c) one record in the middle: the exact mode re-fingerprints every record of every call
+    # (c) one record in the middle: the exact mode (the library's default; this file's fixture selects the sampled one) re-fingerprints every record of every call
     ca.bases_cache(verify=ca.CACHE_VERIFY_FULL)
     for _ in range(3):
         assert U.jac_to_model(G, ca.msm_strided(curve, st, sc)) == oracle_point(G, b3, sc)
@@ -123,7 +123,7 @@ def test_a_key_whose_host_memory_changed_is_never_used():
     s0 = ca.bases_cache_stats()
     assert U.jac_to_model(G, ca.msm_strided(curve, st, sc)) == oracle_point(G, b4, sc)
     assert delta(s0)["stale"] == 1
-    # (d) the same edit under the sampled default, announced by the host
+    # (d) the same edit under the sampled mode, announced by the host
     ca.bases_cache(verify=24)
     for _ in range(3):
         ca.msm_strided(curve, st, sc)

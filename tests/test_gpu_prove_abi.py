@@ -78,7 +78,7 @@ def test_one_call_equals_the_python_schedule(m, cw):
         nq = sum(1 for q in (hpk.a_query, hpk.b_g1_query, hpk.b_g2_query, hpk.h_query, hpk.l_query) if len(q) >= 2)
         assert s1["fills"] - s0["fills"] == nq and s1["hits"] - s0["hits"] == 6 * nq, (s0, s1)
         # the exact stale-key mode (every record of every view re-fingerprinted BESIDE the proof): same proof; and an in-place edit of ONE record in the middle of a
-        # resident query — which the sampled default would most likely miss — gives the edited key's proof, not the resident copy's
+        # resident query — which the sampled mode would most likely miss — gives the edited key's proof, not the resident copy's
         ca.bases_cache(verify=ca.CACHE_VERIFY_FULL)
         gx = LG.prove_host(hpk, r, s, v, h_host, z[:n_inst], z[n_inst:])
         assert all((gx[k] == ref[k]).all() for k in ref)
@@ -93,7 +93,6 @@ def test_one_call_equals_the_python_schedule(m, cw):
             ca.bases_cache(bytes=(1 << 64) - 1)
             assert all((g_edit[k] == g_plain[k]).all() for k in g_plain) and not all((g_edit[k] == ref[k]).all() for k in ref)
             hpk.a_query[5] = keep
-        ca.bases_cache(verify=24)
         # the cache off: every view is uploaded for the call
         ca.bases_cache(bytes=0)
         gh = LG.prove_host(hpk, r, s, v, h_host, z[:n_inst], z[n_inst:])

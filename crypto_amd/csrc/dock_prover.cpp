@@ -392,11 +392,12 @@ static int32_t prove_host_once(const dgpu_lego_pk_host *pk, uint64_t r1cs, const
         k.gamma_abc_g1 = pk->gamma_abc_g1; k.gamma_abc_len = pk->gamma_abc_len; k.commit_witness_count = pk->commit_witness_count;
         const uint64_t *parts[2] = {instance, witness}; const size_t counts[2] = {n_inst, n_wit};
         // the deferred checks (a no-op unless the exact mode took entries unchecked) on a thread of their own, beside the proof
-        Job jV; std::atomic<bool> fresh{true};
+        std::atomic<bool> fresh{true};      // (declared before the job that writes it: the job is joined first if anything below throws)
+        Job jV;
         jV.start([&]() -> int32_t { return dock::par_run(5, [&](size_t i) -> int32_t { if (!dock::view_verify_any(pins.p[i])) fresh = false; return DGPU_OK; }); });
         const int32_t rc = prove_impl(&k, r1cs, 0, h, h_len, h_montgomery, parts, counts, n_wit ? 2 : 1, n_inst, montgomery, r_in, s_in, v_in, out_a, out_b, out_c, out_d, out_inf);
-        (void)jV.join();
-        stale = !fresh.load();
+        const int32_t vrc = jV.join();
+        stale = !fresh.load() || vrc != DGPU_OK;      // (a check that could not run is a check that failed: the proof is made again from what the host holds)
         return rc;
     }
     catch (const std::bad_alloc &) { return DGPU_E_OOM; }

@@ -1066,11 +1066,12 @@ bool msm_oneshot_cached(const RawBases &rb, const uint64_t *scalars, size_t n, b
     if (full && was_resident) {
         const CacheKey key{rb.p, n, rb.stride, rb.x_off, rb.y_off, rb.inf_off, rb.is_inf, kind, cur_index()};
         bool same = true; int32_t mrc = DGPU_OK;
-        (void)par_run(2, [&](size_t part) -> int32_t {
+        const int32_t prc = par_run(2, [&](size_t part) -> int32_t {
             if (part == 0) mrc = msm_handle<C, HF>(e->handle, off, scalars, n, mont, out, kind, false);
             else same = cache_verify(*e, key, off, C::ABI_W / 2);
             return DGPU_OK;
         });
+        if (prc) same = false;                                // (the two parts could not be run: nothing was checked and nothing may be taken from `out`)
         if (!same) {                                          // the key changed under the entry: forget it, the one-shot path answers (and notes the new contents at its next call)
             std::vector<std::shared_ptr<CacheEntry>> dropped;
             std::lock_guard<std::mutex> lk(gcache.mu);

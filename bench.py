@@ -83,6 +83,9 @@ def dot_mod_r(a, b):
     return tot % R_MOD
 
 
+TRACE_CALLS = bool(os.environ.get("DGPU_BENCH_TRACE_CALLS"))      # development: (index, start, end) of every call of an InFlight run, to stderr from the timed region
+
+
 class InFlight:
     """`count` calls of fn() by `threads` host threads, each taking the next call from a shared counter.  The threads are created and parked at a start
     line BEFORE the clock starts, and the caller's thread blocks while they run: no thread of this process wakes another through the interpreter inside a
@@ -95,6 +98,7 @@ class InFlight:
         import threading
         self.fn, self.count, self.err = fn, count, None
         self.results = [None] * count
+        self.log = []
         self._next = itertools.count()                      # (next() on it is atomic under the GIL)
         self._start, self._done = threading.Barrier(threads + 1), threading.Barrier(threads + 1)
         self._threads = [threading.Thread(target=self._run, daemon=True) for _ in range(threads)]
@@ -108,7 +112,10 @@ class InFlight:
                 i = next(self._next)
                 if i >= self.count:
                     break
-                self.results[i] = self.fn()
+                if TRACE_CALLS:
+                    t0 = time.perf_counter(); self.results[i] = self.fn(); self.log.append((i, t0, time.perf_counter()))
+                else:
+                    self.results[i] = self.fn()
         except BaseException as e:          # noqa: BLE001
             self.err = e
         self._done.wait()
@@ -285,6 +292,8 @@ def main():
     for _ in range(3):
         step()
     latency_ms = (time.perf_counter() - tl) / 3 * 1e3
+    run_steps(2 * inflight)                           # untimed, again: with more caller threads than the library has slots (--inflight 8) the SECOND multi-threaded pass of a process
+                                                      # reads 30 - 60 ms long whatever it computes (a harness effect: native threads and every later pass do not show it, tools/dev/native/inflight_threads.cpp)
     timed_calls = InFlight(lambda: db.msm_resident(ds), args.steps, inflight)       # the host threads wait at their start line: nothing is created inside the clock
     if world > 1:
         dist.barrier()
@@ -298,6 +307,9 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    if TRACE_CALLS:
+        for i, a_, b_ in sorted(timed_calls.log):
+            print("call %3d: %8.2f -> %8.2f ms" % (i, (a_ - t0) * 1e3, (b_ - t0) * 1e3), file=sys.stderr)
     allocs_timed = ca.device_alloc_count() - allocs0
     assert (last == res).all(), "result changed between runs"
     per_rank_table_ms = [round(table_ms, 1)]
@@ -502,6 +514,27 @@ def secondary_configs(log2n, ks, scalars, db, ds, pool, cpu_legs=True, ncpu=1):
         run_inflight(fn, 8, 4)
         return min(run_inflight(fn, k, 4)[0] / k * 1e3 for _ in range(2))      # (best of two passes: a box with busy host cores stretches a pass now and then)
 
+    # -- the headline's workload from NATIVE host threads (tests/native/inflight_threads.cpp, a process of its own over the C ABI: what a Rust host's rayon workers
+    #    are): resident table, 2^20 terms, 6 / 8 / 12 threads against the library's six slots — no interpreter between the calls
+    try:
+        import re
+        import subprocess
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from test_gpu_cpp_api import build_inflight_driver
+        exe = build_inflight_driver()
+        env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "crypto_amd") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+        r = subprocess.run([exe, "6,40", "8,40", "12,60"], capture_output=True, text=True, timeout=300, env=env)
+        rows = re.findall(r"T=\s*(\d+) count=\s*(\d+):\s*([\d.]+) ms total, ([\d.]+) ms per call, longest call ([\d.]+) ms, mismatches (\d+)", r.stdout)
+        nat = {}
+        for T_, count_, total_, per_, longest_, bad_ in rows:
+            k_ = "%s_threads" % T_
+            if k_ not in nat or float(per_) < nat[k_]["ms_per_msm"]:
+                nat[k_] = {"ms_per_msm": float(per_), "msm_per_s": round(1e3 / float(per_), 1), "longest_call_ms": float(longest_), "calls": int(count_), "mismatches": int(bad_)}
+        nat["note"] = ("dgpu_msm_g1_resident on a precomputed table from T native threads (best of three passes each; results compared with the first call's); callers beyond the six "
+                       "slots queue first come, first served, so the longest call stays near T x ms_per_msm")
+        res["native_host_threads"] = nat
+    except Exception as e:      # noqa: BLE001  (a box without g++: the figure is simply absent)
+        res["native_host_threads"] = {"error": repr(e)[:200]}
     with FB.WindowTable(ca.G1, gen1[0]) as t1:
         plain = t1.multiply_many_to_bases(ks)
         host_bases, _ = t1.multiply_many(ks)

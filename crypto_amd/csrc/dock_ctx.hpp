@@ -89,6 +89,8 @@ struct Ctx {
     int device = -1;               // physical HIP device
     Slot slots[N_SLOTS];
     std::atomic<unsigned> rr{0};
+    // the slots are handed out first come, first served (SlotLock): tickets, the one being served, which slots are out
+    std::mutex slot_mu; std::condition_variable slot_cv; uint64_t slot_next = 0, slot_serving = 0; bool slot_taken[N_SLOTS] = {};
     std::atomic<int> busy{0};       // calls holding one of the context's slots right now (SlotLock): the table MSM picks its bucket reduction's shape by it (msm_driver.hip.h pre_geometry)
     std::atomic<int> ml_active{0};  // dgpu_multi_miller_loop calls in flight on this context (dock_pairing.hip picks the kernel form by it)
     std::map<int, NttDomain> ntt_domains;
@@ -127,22 +129,36 @@ inline int cur_index() { int i = tl_ctx >= 0 ? tl_ctx : gs.default_ctx; return (
 inline Ctx &cur() { return ctxs[cur_index()]; }
 struct CtxScope { int prev; explicit CtxScope(int c) : prev(tl_ctx) { tl_ctx = c; } ~CtxScope() { tl_ctx = prev; } CtxScope(const CtxScope &) = delete; };
 
-// RAII: pick a free slot (round-robin try_lock), or wait for one.  `ok` is false when the context was shut down between the caller's
-// `ready` check and the moment the slot was acquired (dgpu_shutdown clears `ready` first, then takes every slot): the slot's streams and
-// buffers are gone then, and the call must answer DGPU_E_NODEVICE instead of running on a null stream (SLOT_ACQUIRE).
+// RAII: a slot of the calling thread's context, first come, first served.  Callers beyond the N_SLOTS in flight queue with a ticket and are served in order:
+// with `try_lock` round the slots and a blocking lock on ONE of them (rounds 1 - 6) a thread that had just released a slot took it again before the sleeper
+// it had woken could run — eight native host threads kept the device exactly as busy as six, but two of them waited until the others had nothing left to do
+// (tools/dev/native/inflight_threads.cpp: the longest of 60 calls = the whole 135-ms run), i.e. one MSM of a proof could wait for all MSMs of everybody else.
+// `ok` is false when the context was shut down between the caller's `ready` check and the moment the slot was acquired (dgpu_shutdown clears `ready` first,
+// then takes every slot): the slot's streams and buffers are gone then, and the call must answer DGPU_E_NODEVICE instead of running on a null stream
+// (SLOT_ACQUIRE).  A slot's own mutex still guards it against the maintenance paths that take slots directly (reserve_slots, dgpu_shutdown).
 struct SlotLock {
-    Slot *s = nullptr; bool ok = false; Ctx *cxp = nullptr;
+    Slot *s = nullptr; bool ok = false; Ctx *cxp = nullptr; int idx = -1;
     SlotLock() {
         Ctx &cx = cur();
-        unsigned start = cx.rr.fetch_add(1);
-        Slot *got = nullptr;
-        for (int k = 0; k < N_SLOTS && !got; k++) { Slot &c = cx.slots[(start + k) % N_SLOTS]; if (c.mu.try_lock()) got = &c; }
-        if (!got) { got = &cx.slots[start % N_SLOTS]; got->mu.lock(); }
-        if (!cx.ready.load() || !got->stream) { got->mu.unlock(); return; }
-        s = got; ok = true; cxp = &cx; cx.busy.fetch_add(1);
+        const unsigned start = cx.rr.fetch_add(1);
+        auto free_slot = [&]() -> int { for (int k = 0; k < N_SLOTS; k++) { const int i = (int)((start + k) % N_SLOTS); if (!cx.slot_taken[i]) return i; } return -1; };
+        {
+            std::unique_lock<std::mutex> lk(cx.slot_mu);
+            const uint64_t my = cx.slot_next++;
+            cx.slot_cv.wait(lk, [&] { return cx.slot_serving == my && free_slot() >= 0; });
+            idx = free_slot(); cx.slot_taken[idx] = true; cx.slot_serving++;
+        }
+        cx.slot_cv.notify_all();                         // (the next ticket may find another slot free)
+        Slot *got = &cx.slots[idx];
+        got->mu.lock();
+        cxp = &cx;
+        if (!cx.ready.load() || !got->stream) { got->mu.unlock(); give_back(); return; }
+        s = got; ok = true; cx.busy.fetch_add(1);
     }
-    ~SlotLock() { if (s) { cxp->busy.fetch_sub(1); s->mu.unlock(); } }
+    ~SlotLock() { if (s) { cxp->busy.fetch_sub(1); s->mu.unlock(); give_back(); } }
     SlotLock(const SlotLock &) = delete;
+private:
+    void give_back() { { std::lock_guard<std::mutex> lk(cxp->slot_mu); cxp->slot_taken[idx] = false; } cxp->slot_cv.notify_all(); }
 };
 #define SLOT_ACQUIRE(lockname, slotname) dock::SlotLock lockname; if (!lockname.ok) return DGPU_E_NODEVICE; dock::Slot &slotname = *lockname.s
 

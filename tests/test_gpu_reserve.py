@@ -70,3 +70,45 @@ def test_first_one_shot_call_of_a_new_size_sizes_the_idle_slots():
         ca.bases_cache(bytes=(1 << 64) - 1)         # DGPU_CACHE_BYTES_AUTO
     assert all((o == ref).all() for o in outs)
     assert ca.device_alloc_count() == a0
+
+
+def test_callers_beyond_the_slots_are_served_in_turn():
+    """More host threads than the library keeps calls in flight (six slots per context): the waiting callers queue first come, first served.  Twelve threads,
+    240 resident MSMs of 2^17 terms: no single call may last a large part of the whole run (with the try-lock hand-out of rounds 1 - 6 the threads beyond the
+    sixth waited until the others had nothing left to do: the longest call WAS the run), and every result is the same point."""
+    import threading
+    import time
+    n = 1 << 17
+    bases, _, _ = U.seq_bases(O.G1, n, 11)
+    sc = O.rand_scalars(12, n)
+    db = ca.DeviceBases(ca.G1, bases); db.precompute(16)
+    ds = ca.DeviceScalars(sc)
+    ref = db.msm_resident(ds)
+    T, COUNT = 12, 240
+    for _ in range(2 * T):
+        db.msm_resident(ds)
+    nxt = iter(range(COUNT)); lock = threading.Lock()
+    longest, bad = [0.0] * T, [0] * T
+    start = threading.Barrier(T + 1)
+
+    def run(t):
+        start.wait()
+        while True:
+            with lock:
+                i = next(nxt, None)
+            if i is None:
+                return
+            t0 = time.perf_counter()
+            r = db.msm_resident(ds)
+            longest[t] = max(longest[t], time.perf_counter() - t0)
+            bad[t] += int(not (r == ref).all())
+    th = [threading.Thread(target=run, args=(t,)) for t in range(T)]
+    for x in th:
+        x.start()
+    t0 = time.perf_counter(); start.wait()
+    for x in th:
+        x.join()
+    total = time.perf_counter() - t0
+    assert sum(bad) == 0
+    assert max(longest) < 0.35 * total, (max(longest), total)      # first come, first served: about T / COUNT of the run (0.05), with slack for the interpreter
+    db.free(); ds.free()

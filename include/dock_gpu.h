@@ -18,7 +18,8 @@
  *   - caller owns every buffer; nothing is retained after return except behind explicit handles.
  *   - thread-safe and re-entrant (the reference calls MSM from inside rayon workers,
  *     verifiable_encryption/src/tz_21/rdkgith.rs:140-147): up to six calls per device run concurrently (one
- *     slot = stream pair + workspace each); callers beyond six wait for a slot.
+ *     slot = streams + workspace each); callers beyond six wait for a slot and are served first come, first served
+ *     (the MSM rate does not depend on the number of calling threads: tests/native/inflight_threads.cpp).
  */
 #ifndef DOCK_GPU_H
 #define DOCK_GPU_H

@@ -180,6 +180,7 @@ def main():
     ap.add_argument("--no-table", action="store_true", help="time the plain resident pipeline (no precomputed-multiples table)")
     ap.add_argument("--reduce-shift", type=int, default=-1, help="development: dgpu_set_reduce_shift (log2 buckets per lane of the bucket reduction; -1 = automatic)")
     ap.add_argument("--reduce-lanes", type=int, default=-1, help="development: dgpu_set_reduce_lanes (0 = bit marginals, the default; 1 / 4 = the scan form of rounds 1-4)")
+    ap.add_argument("--miller-pipeline", type=int, default=-1, help="development: dgpu_set_miller_pipeline (forms of the Miller kernels; -1 = the library's default, 15)")
     args = ap.parse_args()
 
     sys.setswitchinterval(1e-4)            # (a host thread that returns from the library gets the interpreter within 0.1 ms instead of CPython's default 5)
@@ -219,7 +220,7 @@ def main():
     ca.init(local)
     # development knobs exist in the twin only (include/dock_gpu_dev.h): a run that sets one is a run of the TWIN from here on, and says so on its line
     import contextlib
-    dev_run = (args.reduce_shift >= 0 or args.reduce_lanes >= 0) and not STUB
+    dev_run = (args.reduce_shift >= 0 or args.reduce_lanes >= 0 or args.miller_pipeline >= 0) and not STUB
     whole = contextlib.ExitStack()
     if dev_run:
         whole.enter_context(ca.twin())
@@ -228,6 +229,8 @@ def main():
             assert _lib().dgpu_set_reduce_shift(args.reduce_shift) == 0
         if args.reduce_lanes >= 0:
             assert _lib().dgpu_set_reduce_lanes(args.reduce_lanes) == 0
+        if args.miller_pipeline >= 0:
+            assert _lib().dgpu_set_miller_pipeline(args.miller_pipeline) == 0
     if args.log2n == 0:
         lg = 0
         while (1 << lg) < world:

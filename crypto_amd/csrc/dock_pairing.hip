@@ -353,12 +353,226 @@ __global__ void __launch_bounds__(64) k_miller_lines_hex(const uint32_t *__restr
         for (int k = 0; k < NL; k++) { state[(size_t)k * w + at] = X.v.l[k]; state[(size_t)(NL + k) * w + at] = Y.v.l[k]; state[(size_t)(2 * NL + k) * w + at] = Z.v.l[k]; }
     }
 }
+// ---- four waves per sixteen pairs: every wave runs ONE role's instruction stream ------------------------------------------------------------
+// k_miller_lines_hex gives a pair sixteen lanes of one wave, so every lane runs every role's linear work (e, f, g, h, X Y, the selects that
+// route operands): 2584 wave-instructions per doubling step of which 1005 are multiply-adds, 4.8 us.  Here a role is a WAVE: a workgroup of four
+// waves owns sixteen pairs, lane = 4 pair + 2 sub + half, and the roles talk through LDS (one 16-byte-wide slot per value and lane, two barriers
+// per doubling step, waited for ~60 cycles each):
+//   round 1   w0: Y^2 (sub 0) and X^2 (sub 1)   w1: Z^2, then e = 12 xi c, f = 3 e   w2: (Y + Z)^2     w3: X Y (four-lane product)
+//   round 2   w0: e^2 (and the line's 3 j)      w1: g^2 (and e - b)                   w2: b h (and -h)  w3: (X Y)(b - g)
+// so a wave runs its own operand's linear work only (branches on the role are scalar) and a general Fp2 product is one Fp product per lane of
+// the quad (qx_mul) instead of a fused two-product reduction per lane of a pair.  An addition step is the hex kernel's four rounds with the
+// same split.  The VALUES are those of line_dbl_step / line_add_step (pairing29.hip.h line_dbl_step_ws / line_add_step_ws: the one-lane forms
+// the FP29_CHECK build proves the bounds of), so the Miller output and G2Prepared's bytes do not change (tests/test_gpu_pairing.py: every mode).
+template <int CTRL> __device__ __forceinline__ void qfetch(Fp &r, const Fp &a) {       // DPP quad_perm: lane q of a quad reads lane (CTRL >> 2 q) & 3
+#pragma unroll
+    for (int i = 0; i < NL; i++) r.l[i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a.l[i], CTRL, 0xF, 0xF, true);
+}
+// Fp2 product on a lane QUAD whose lanes q = 2 sub + half all hold their half of a and b (pairing29.hip.h f2_mul_q): one separately reduced Fp
+// product per lane — q0: a0 b0, q1: a1 b1, q2: a0 b1, q3: a1 b0 — then c0 = P0 - P1 + 4 p on the even lanes, c1 = P2 + P3 on the odd ones, carry pass
+__device__ __forceinline__ void qx_mul(Fp2H &r, const Fp2H &a, const Fp2H &b) {
+    Fp bs, P, Xv, Yv, d, s2, t;
+    qfetch<0xB4>(bs, b.v);                                       // [0, 1, 3, 2]: the lanes of sub 1 take the other half of b
+    fp_mul(P, a.v, bs);
+    qfetch<0x88>(Xv, P); qfetch<0xDD>(Yv, P);                    // [0, 2, 0, 2], [1, 3, 1, 3]: even lanes (P0, P1), odd lanes (P2, P3)
+    fp_sub<4>(d, Xv, Yv); fp_add(s2, Xv, Yv);
+    sel(t, pair_odd(), s2, d);
+    fp_norm(r.v, t);
+}
+constexpr int WS_PAIRS = 16;
+enum { WS_BJ = 0, WS_C = 1, WS_E = 2, WS_F = 3, WS_GG = 4, WS_T1 = 5, WS_T2 = 6, WS_E2 = 7, WS_G2 = 8, WS_NZ = 9, WS_NX = 10, WS_SLOTS = 11,
+       WS_CC = 0, WS_DD = 1, WS_M2 = 2, WS_M3 = 3, WS_EE = 5, WS_FF = 6, WS_R0 = 7, WS_R1 = 8, WS_R2 = 9, WS_R3 = 10 };
+typedef uint32_t WsSlot[4][64][4];                              // limb quad, lane, four limbs: a 16-byte access per lane, lanes side by side
+__device__ __forceinline__ void ws_put(WsSlot &s, uint32_t lane, const Fp2H &x) {
+    static_assert(NL == 14, "three quads and a pair");
+#pragma unroll
+    for (int q = 0; q < 3; q++) *reinterpret_cast<uint4 *>(s[q][lane]) = make_uint4(x.v.l[4 * q], x.v.l[4 * q + 1], x.v.l[4 * q + 2], x.v.l[4 * q + 3]);
+    *reinterpret_cast<uint2 *>(s[3][lane]) = make_uint2(x.v.l[12], x.v.l[13]);
+}
+__device__ __forceinline__ void ws_get(Fp2H &r, const WsSlot &s, uint32_t lane) {
+#pragma unroll
+    for (int q = 0; q < 3; q++) { const uint4 v = *reinterpret_cast<const uint4 *>(s[q][lane]); r.v.l[4 * q] = v.x; r.v.l[4 * q + 1] = v.y; r.v.l[4 * q + 2] = v.z; r.v.l[4 * q + 3] = v.w; }
+    const uint2 v = *reinterpret_cast<const uint2 *>(s[3][lane]); r.v.l[12] = v.x; r.v.l[13] = v.y;
+}
+__global__ void __launch_bounds__(256) k_miller_lines_ws(const uint32_t *__restrict__ p_abi, const uint32_t *__restrict__ q_abi, const uint8_t *__restrict__ skip, size_t n, uint32_t *__restrict__ lines, size_t stride,
+                                                         int b_hi, int b_lo, int s_first, uint32_t *__restrict__ state, uint32_t *__restrict__ pxy) {
+    __shared__ WsSlot L[WS_SLOTS];
+    const uint32_t lane = threadIdx.x & 63u, h = lane & 1u;
+    const bool sub = (lane & 2u) != 0;
+    const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t lane_b = lane & ~2u, lane_j = lane | 2u;     // where w0 left b and j of this lane's pair and half
+    const size_t i_raw = (size_t)blockIdx.x * WS_PAIRS + (lane >> 2);
+    const bool inr = i_raw < n;
+    const size_t i = inr ? i_raw : n - 1;                        // lanes past the end keep step with the barriers on the last pair's data and store nothing
+    bool sk = skip && skip[i];
+    uint32_t anyp = 1, anyq = 0;
+    uint32_t qx[12], qy[12];
+    for (int k = 0; k < 12; k++) { qx[k] = q_abi[i * 48 + h * 12 + k]; qy[k] = q_abi[i * 48 + 24 + h * 12 + k]; anyq |= qx[k] | qy[k]; }
+    anyq |= xchg32(anyq);
+    uint32_t pw[12];
+    if (p_abi) { uint32_t a = 0; for (int k = 0; k < 12; k++) { pw[k] = p_abi[i * 24 + h * 12 + k]; a |= pw[k]; } anyp = a | xchg32(a); }
+    else for (int k = 0; k < 12; k++) pw[k] = 0;
+    if (!anyp || !anyq) sk = true;
+    const bool live = inr && !sk;
+    auto st = [&](int s, uint32_t c, const Fp2H &x) { for (int j = 0; j < NL; j++) lines[((size_t)s * LW + (2 * c + h) * NL + j) * stride + i] = x.v.l[j]; };
+    const bool starts = b_hi == 62;
+    if (inr && sk && !sub) {                                     // the neutral line at every step; the pair's lanes go on computing (barriers) and store nothing
+        const int s_end = s_first + ml_steps(b_hi, b_lo);
+        if (role < 3) { Fp2H v; if (role == 0) fset_one(v); else fzero(v); for (int s = s_first; s < s_end; s++) st(s, (uint32_t)role, v); }
+        if (pxy && starts && role == 3) for (int k = 0; k < NL; k++) pxy[(h * NL + k) * stride + i] = 0;
+    }
+    if (pxy && starts && live && role == 3 && !sub) { Fp c; fp_from_abi(c, pw); for (int k = 0; k < NL; k++) pxy[(h * NL + k) * stride + i] = c.l[k]; }
+    Aff<Fp2H> Q; fp_from_abi(Q.x.v, qx); fp_from_abi(Q.y.v, qy);
+    Fp2H X, Y, Z;                                                // the whole of R (every wave): valid at the start, around an addition step and at the end
+    if (starts) { X = Q.x; Y = Q.y; fset_one(Z); }
+    else {
+        const size_t w = 2 * n, at = 2 * i + h;
+        for (int k = 0; k < NL; k++) { X.v.l[k] = state[(size_t)k * w + at]; Y.v.l[k] = state[(size_t)(NL + k) * w + at]; Z.v.l[k] = state[(size_t)(2 * NL + k) * w + at]; }
+    }
+    bool whole = true;
+    Fp2H keep; fzero(keep);                                      // this wave's own round-2 product (w2: Z', w3: X')
+    int s = s_first;
+#ifdef WS_PROF
+    uint64_t pc[4] = {0, 0, 0, 0}, pt;
+#define WSP(k) { uint64_t now_ = __builtin_amdgcn_s_memtime(); pc[k] += now_ - pt; pt = now_; }
+    pt = __builtin_amdgcn_s_memtime();
+#else
+#define WSP(k)
+#endif
+    for (int b = b_hi; b >= b_lo; b--) {
+        Fp2H z; fzero(z);
+        // ---- round 1: squarings of in = A + B (carry-passed; Z' as it is), w3: the product X Y ----
+        Fp2H A, B, in, t, r1, opA, opB;
+        if (whole) {
+            if (role == 0) { fsel(A, sub, X, Y); B = z; }
+            else if (role == 1) in = Z;
+            else if (role == 2) { A = Y; B = Z; }
+            else { opA = X; opB = Y; }
+        } else {
+            if (role == 1) ws_get(in, L[WS_NZ], lane);
+            else {
+                Fp2H v1, v2, yy;
+                if (role == 0) ws_get(v1, L[sub ? WS_NX : WS_G2], lane); else ws_get(v1, L[WS_G2], lane);
+                ws_get(v2, L[WS_E2], lane);
+                fadd(t, v2, v2); fadd(t, t, v2); fsub<32>(yy, v1, t);                     // Y' = g^2 - 3 e^2 (lazy)
+                if (role == 0) { fsel(A, sub, v1, yy); B = z; }
+                else if (role == 2) { A = yy; B = keep; }
+                else { opA = keep; fnorm(opB, yy); }
+            }
+        }
+        if (role == 3) qx_mul(r1, opA, opB);
+        else {
+            if (role != 1) { fadd(t, A, B); fnorm(in, t); }
+            hx_sqr<64>(r1, in);
+        }
+        if (role == 0) ws_put(L[WS_BJ], lane, r1);
+        else if (role == 1) {
+            Fp2H e, f;
+            f2_mul12_n(t, r1); f2_mul_xi_n<128>(e, t);          // e = 12 (1 + u) c
+            fadd(f, e, e); fadd(f, f, e);                       // f = 3 e (lazy)
+            ws_put(L[WS_C], lane, r1); ws_put(L[WS_E], lane, e); ws_put(L[WS_F], lane, f);
+        }
+        WSP(0)
+        __syncthreads();
+        WSP(1)
+        // ---- round 2 ----
+        Fp2H res, lv;
+        uint32_t lc = 0; bool lst = false;
+        if (role == 0) {
+            ws_get(opA, L[WS_E], lane);
+            fadd(t, r1, r1); fadd(lv, t, r1); lc = 1; lst = sub;                          // sub 1: the line's 3 j
+        } else if (role == 1) {
+            Fp2H Bv, Fv, Ev;
+            ws_get(Bv, L[WS_BJ], lane_b); ws_get(Fv, L[WS_F], lane); ws_get(Ev, L[WS_E], lane);
+            fadd(t, Bv, Fv); fhalf(opA, t);                      // g = (b + f) / 2
+            fsub<8>(lv, Ev, Bv); lc = 0; lst = !sub;             // line c0 = e - b (lazy)
+        } else if (role == 2) {
+            Fp2H Bv, Cv, hh;
+            ws_get(Bv, L[WS_BJ], lane_b); ws_get(Cv, L[WS_C], lane);
+            fadd(t, Bv, Cv); f2_sub_n<16>(hh, r1, t);            // h = (Y + Z)^2 - (b + c)
+            fsub<32>(lv, z, hh); lc = 2; lst = !sub;             // -h
+            opA = Bv; opB = hh;
+        } else {
+            Fp2H Bv, Fv, g;
+            ws_get(Bv, L[WS_BJ], lane_b); ws_get(Fv, L[WS_F], lane);
+            fadd(t, Bv, Fv); fhalf(g, t);
+            f2_sub_n<256>(opB, Bv, g);                           // (b - f) / 2
+            opA = r1;                                            // X Y
+        }
+        if (lst && live) st(s, lc, lv);
+        s++;
+        if (role < 2) hx_sqr<512>(res, opA); else qx_mul(res, opA, opB);                  // w0: e^2  w1: g^2  w2: b h  w3: (X Y)(b - g)
+        keep = res;
+        ws_put(L[role == 0 ? WS_E2 : (role == 1 ? WS_G2 : (role == 2 ? WS_NZ : WS_NX))], lane, res);
+        WSP(2)
+        __syncthreads();
+        WSP(3)
+        whole = false;
+        const bool add = (BLS_X_ABS >> b) & 1;
+        if (!add && b > b_lo) continue;
+        { Fp2H g2, e2; ws_get(X, L[WS_NX], lane); ws_get(Z, L[WS_NZ], lane); ws_get(g2, L[WS_G2], lane); ws_get(e2, L[WS_E2], lane);
+          fadd(t, e2, e2); fadd(t, t, e2); fsub<32>(Y, g2, t); fnorm(Y, Y); }
+        whole = true;
+        if (!add) continue;
+        // ---- addition step (ark-ec add_in_place): four rounds, one product per wave and round ----
+        Fp2H theta, lam, cc, dd, ee, h2, gmh;
+#pragma nounroll
+        for (int r = 0; r < 4; r++) {
+            bool work = true;
+            if (r == 0) { opA = role == 0 ? Q.y : Q.x; opB = Z; work = role < 2; }                      // w0: Qy Z   w1: Qx Z
+            else if (r == 1) {                                                                         // w0: theta^2  w1: lam^2  w2: theta Qx  w3: lam Qy
+                opA = (role & 1) ? lam : theta;
+                opB = role == 0 ? theta : (role == 1 ? lam : (role == 2 ? Q.x : Q.y));
+            } else if (r == 2) {                                                                       // w0: e = lam d  w1: f = Z c  w2: g = X d
+                opA = role == 0 ? lam : (role == 1 ? Z : X);
+                opB = role == 1 ? cc : dd; work = role < 3;
+            } else {                                                                                   // w0: lam h  w1: Z e  w2: theta (g - h)  w3: e Y
+                opA = role == 0 ? lam : (role == 1 ? Z : (role == 2 ? theta : ee));
+                opB = role == 0 ? h2 : (role == 1 ? ee : (role == 2 ? gmh : Y));
+            }
+            if (work) {
+                qx_mul(res, opA, opB);
+                const int slot = r == 0 ? WS_T1 + role : (r == 1 ? WS_CC + role : (r == 2 ? (role == 2 ? WS_GG : WS_EE + role) : WS_R0 + role));
+                ws_put(L[slot], lane, res);
+            }
+            __syncthreads();
+            if (r == 0) {
+                Fp2H t1, t2; ws_get(t1, L[WS_T1], lane); ws_get(t2, L[WS_T2], lane);
+                f2_sub_n<8>(theta, Y, t1); f2_sub_n<8>(lam, X, t2);
+            } else if (r == 1) {
+                ws_get(cc, L[WS_CC], lane); ws_get(dd, L[WS_DD], lane);
+                if (role == 0) { Fp2H m2, m3; ws_get(m2, L[WS_M2], lane); ws_get(m3, L[WS_M3], lane); f2_sub_n<8>(lv, m2, m3); }
+                else if (role == 1) f2_neg_n<64>(lv, theta);
+                else lv = lam;
+                if (role < 3 && !sub && live) st(s, (uint32_t)role, lv);                               // (j, -theta, lam)
+                s++;
+            } else if (r == 2) {
+                Fp2H ff, gg, u2; ws_get(ee, L[WS_EE], lane); ws_get(ff, L[WS_FF], lane); ws_get(gg, L[WS_GG], lane);
+                fadd(t, ee, ff); fadd(u2, gg, gg); f2_sub_n<16>(h2, t, u2);
+                f2_sub_n<32>(gmh, gg, h2);
+            } else {
+                Fp2H r2, r3; ws_get(X, L[WS_R0], lane); ws_get(Z, L[WS_R1], lane); ws_get(r2, L[WS_R2], lane); ws_get(r3, L[WS_R3], lane);
+                f2_sub_n<8>(Y, r2, r3);
+            }
+        }
+    }
+#ifdef WS_PROF
+    if (blockIdx.x == 0 && lane == 0) printf("role %d: r1 %llu waitA %llu r2 %llu waitB %llu (cycles over %d steps)\n", role, (unsigned long long)pc[0], (unsigned long long)pc[1], (unsigned long long)pc[2], (unsigned long long)pc[3], s - s_first);
+#endif
+    if (b_lo > 0 && role == 0 && !sub && inr) {
+        const size_t w = 2 * n, at = 2 * i + h;
+        for (int k = 0; k < NL; k++) { state[(size_t)k * w + at] = X.v.l[k]; state[(size_t)(NL + k) * w + at] = Y.v.l[k]; state[(size_t)(2 * NL + k) * w + at] = Z.v.l[k]; }
+    }
+}
 // one launcher for the line kernels that leave the evaluation to the product kernel: sixteen lanes per pair while the chip has room for them
 // (dgpu_set_miller_pipeline bit 2), four otherwise.  Same arguments, same lines, same state size bound (3 NL 4 n words).
 constexpr size_t ML_HEX_MAX = 4096;      // 16 lanes x 4096 pairs = 1024 waves: one per SIMD
 static void launch_lines_uneval(hipStream_t s, const uint32_t *p_abi, const uint32_t *q_abi, const uint8_t *skip, size_t n, uint32_t *lines, size_t stride,
                                 int b_hi, int b_lo, int s_first, uint32_t *state, uint32_t *pxy) {
-    if ((gs.ml_mode.load() & 4) && n <= ML_HEX_MAX)
+    const int mode = gs.ml_mode.load();
+    if ((mode & 8) && (mode & 4) && n <= ML_HEX_MAX)
+        hipLaunchKernelGGL(k_miller_lines_ws, dim3((unsigned)((n + WS_PAIRS - 1) / WS_PAIRS)), dim3(256), 0, s, p_abi, q_abi, skip, n, lines, stride, b_hi, b_lo, s_first, state, pxy);
+    else if ((mode & 4) && n <= ML_HEX_MAX)
         hipLaunchKernelGGL(k_miller_lines_hex, dim3((unsigned)((16 * n + 63) / 64)), dim3(64), 0, s, p_abi, q_abi, skip, n, lines, stride, b_hi, b_lo, s_first, state, pxy);
     else
         hipLaunchKernelGGL(k_miller_lines_quad<false>, dim3((unsigned)((4 * n + 63) / 64)), dim3(64), 0, s, p_abi, q_abi, skip, n, lines, stride, b_hi, b_lo, s_first, state, pxy);

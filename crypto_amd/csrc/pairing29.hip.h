@@ -280,6 +280,54 @@ template <class F2> FD void line_add_step(G2ProjT<F2> &R, const Aff<F2> &Q, Line
     fmul(t, theta, Q.x); fmul(u, lam, Q.y); f2_sub_n<8>(j, t, u);
     l.c0 = j; f2_neg_n<64>(l.c1, theta); l.c2 = lam;
 }
+// ---- the steps as k_miller_lines_ws runs them (dock_pairing.hip: a wave per role, a lane quad per pair).  Same VALUES as line_dbl_step /
+// line_add_step; what differs from line_dbl_step_fast is which products are formed:
+//   * a general Fp2 product is FOUR separately reduced Fp products, one per lane of the quad (392 multiply-adds on the critical path instead of
+//     the 588 of the fused two-product form): c0 = a0 b0 - a1 b1 + 4 p, c1 = a0 b1 + a1 b0, one carry pass (f2_mul_q);
+//   * X Y is such a product of the step's operands (round 1) instead of ((X + Y)^2 - X^2 - Y^2) / 2: no halving in front of round 2;
+//   * e^2 and g^2 are squarings (one product per lane) with a subtraction multiple that covers f = 3 e;
+//   * Z' is squared as it is (a product's output is class N).
+// One-lane forms so that the FP29_CHECK build proves the bounds of exactly these sequences (tests/test_device_code_on_host.py).
+FD void f2_mul_q(Fp2 &r, const Fp2 &a, const Fp2 &b) {
+    Fp p0, p1, p2, p3, d, s;
+    fp_mul(p0, a.c0, b.c0); fp_mul(p1, a.c1, b.c1); fp_mul(p2, a.c0, b.c1); fp_mul(p3, a.c1, b.c0);
+    fp_sub<4>(d, p0, p1); fp_add(s, p2, p3);
+    fp_norm(r.c0, d); fp_norm(r.c1, s);
+}
+template <class F2> FD void line_dbl_step_ws(G2ProjT<F2> &R, LineT<F2> &l, bool norm_y) {
+    F2 in, yn, b, c, hs, j, xy, t, e, f, g, h, d2, e2, g2, nx, nz, z;
+    fzero(z);
+    fadd(t, R.y, z); fnorm(yn, t); f2_sqr_u<64>(b, yn);                 // round 1: w0 (sub 0)
+    f2_sqr_u<64>(c, R.z);                                               // w1
+    fadd(t, R.y, R.z); fnorm(in, t); f2_sqr_u<64>(hs, in);              // w2
+    fadd(t, R.x, z); fnorm(in, t); f2_sqr_u<64>(j, in);                 // w0 (sub 1)
+    f2_mul_q(xy, R.x, yn);                                              // w3
+    f2_mul12_n(t, c); f2_mul_xi_n<128>(e, t);                           // e = 12 (1 + u) c
+    fadd(f, e, e); fadd(f, f, e);                                       // f = 3 e
+    fadd(t, b, f); fhalf(g, t);                                         // g = (b + f) / 2
+    fsub<8>(l.c0, e, b);                                                // i = e - b
+    fadd(t, b, c); f2_sub_n<16>(h, hs, t);                              // h = (Y + Z)^2 - (b + c)
+    f2_sub_n<256>(d2, b, g);                                            // (b - f) / 2
+    fadd(t, j, j); fadd(l.c1, t, j);                                    // 3 j
+    fsub<32>(l.c2, z, h);                                               // -h
+    f2_sqr_u<512>(e2, e); f2_sqr_u<512>(g2, g); f2_mul_q(nz, b, h); f2_mul_q(nx, xy, d2);   // round 2
+    fadd(t, e2, e2); fadd(t, t, e2); fsub<32>(R.y, g2, t);              // Y' = g^2 - 3 e^2
+    if (norm_y) fnorm(R.y, R.y);
+    R.x = nx; R.z = nz;
+}
+template <class F2> FD void line_add_step_ws(G2ProjT<F2> &R, const Aff<F2> &Q, LineT<F2> &l) {
+    F2 theta, lam, c, d, e, f, g, h, j, t, u, m2, m3, r0, r1, r2, r3;
+    f2_mul_q(t, Q.y, R.z); f2_sub_n<8>(theta, R.y, t);
+    f2_mul_q(t, Q.x, R.z); f2_sub_n<8>(lam, R.x, t);
+    f2_mul_q(c, theta, theta); f2_mul_q(d, lam, lam); f2_mul_q(m2, theta, Q.x); f2_mul_q(m3, lam, Q.y);
+    f2_sub_n<8>(j, m2, m3);
+    l.c0 = j; f2_neg_n<64>(l.c1, theta); l.c2 = lam;
+    f2_mul_q(e, lam, d); f2_mul_q(f, R.z, c); f2_mul_q(g, R.x, d);
+    fadd(t, e, f); fadd(u, g, g); f2_sub_n<16>(h, t, u);
+    f2_sub_n<32>(t, g, h);
+    f2_mul_q(r0, lam, h); f2_mul_q(r1, R.z, e); f2_mul_q(r2, theta, t); f2_mul_q(r3, e, R.y);
+    R.x = r0; R.z = r1; f2_sub_n<8>(R.y, r2, r3);
+}
 // ark-ec `ell` for the M twist: c1 *= px, c2 *= py
 template <class F2> FD void line_eval(LineT<F2> &l, const Fp &px, const Fp &py) { fmul_fp(l.c1, l.c1, px); fmul_fp(l.c2, l.c2, py); }
 

@@ -242,6 +242,21 @@ void shim_miller_lines_fast(const uint32_t *p, const uint32_t *q, uint32_t *out)
     std::vector<Line> ls; pair_lines_fast(ls, p, q);
     for (size_t s = 0; s < ls.size(); s++) { const Fp *c = reinterpret_cast<const Fp *>(&ls[s]); for (int k = 0; k < 6; k++) fp_to_abi(out + (s * 6 + k) * 12, c[k]); }
 }
+// ... and through line_dbl_step_ws / line_add_step_ws (what k_miller_lines_ws computes: a wave per role, four-lane products)
+void shim_miller_lines_ws(const uint32_t *p, const uint32_t *q, uint32_t *out) {
+    Fp px, py; fp_from_abi(px, p); fp_from_abi(py, p + 12);
+    Aff<Fp2> Q; load_aff2(Q, q);
+    G2Proj R; R.x = Q.x; R.y = Q.y; fset_one(R.z);
+    std::vector<Line> ls;
+    for (int i = 62; i >= 0; i--) {
+        const bool add = (BLS_X_ABS >> i) & 1;
+        Line l; line_dbl_step_ws(R, l, add || i == 0);
+        fnorm(l.c0, l.c0); fnorm(l.c1, l.c1); fnorm(l.c2, l.c2);
+        line_eval(l, px, py); ls.push_back(l);
+        if (add) { line_add_step_ws(R, Q, l); line_eval(l, px, py); ls.push_back(l); }
+    }
+    for (size_t s = 0; s < ls.size(); s++) { const Fp *c = reinterpret_cast<const Fp *>(&ls[s]); for (int k = 0; k < 6; k++) fp_to_abi(out + (s * 6 + k) * 12, c[k]); }
+}
 // 12 a by the scaled carry pass, from a lazily reduced operand (k a, carry-passed)
 void shim_fp_mul12(const uint32_t *a, int k, uint32_t *out) {
     Fp x, t, r; fp_from_abi(x, a); t = x; for (int i = 1; i < k; i++) fp_add(t, t, x); fp_norm(t, t);

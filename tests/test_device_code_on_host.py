@@ -263,6 +263,9 @@ def test_fast_doubling_step_of_the_sixteen_lane_kernel(shim):
         ref = np.zeros(68 * 6 * 6, np.uint64); got = np.zeros_like(ref)
         shim.shim_miller_lines(p_(pa), p_(qa), p_(ref)); shim.shim_miller_lines_fast(p_(pa), p_(qa), p_(got))
         assert (ref == got).all()
+        # k_miller_lines_ws's steps (a wave per role: four-lane products, X Y as a product, e^2 / g^2 as squarings) under the same tracker
+        got[:] = 0; shim.shim_miller_lines_ws(p_(pa), p_(qa), p_(got))
+        assert (ref == got).all()
     out = np.zeros(6, np.uint64)
     for v in [0, 1, P - 1, (P - 1) // 2, 2 ** 380, 2 ** 377 - 1] + [rng.randrange(P) for _ in range(60)]:
         for k in (1, 2, 5, 7):

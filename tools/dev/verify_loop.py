@@ -12,6 +12,9 @@ import bench as B
 from crypto_amd import pairing, fixed_base as FB, legogroth16 as LG
 from crypto_amd.pairing_check import g1_scale_each
 ca.init(0)
+if os.environ.get("MLMODE"):      # a form of the Miller kernels other than the default (development twin)
+    from crypto_amd._native import lib
+    _tw = ca.twin(); _tw.__enter__(); assert lib().dgpu_set_miller_pipeline(int(os.environ["MLMODE"])) == 0
 WHAT = os.environ.get("WHAT", "batch"); K = int(os.environ.get("K", "20")); nv = int(os.environ.get("N", "1024"))
 R_MOD = B.R_MOD
 ints = lambda seed, k: [int(x[0]) | (int(x[1]) << 64) | (int(x[2]) << 128) | (int(x[3]) << 192) for x in B.seeded_scalars(seed, k)]

@@ -433,7 +433,7 @@ __global__ void __launch_bounds__(256) k_miller_lines_ws(const uint32_t *__restr
     Fp2H keep; fzero(keep);                                      // this wave's own round-2 product (w2: Z', w3: X')
     int s = s_first;
 #ifdef WS_PROF
-    uint64_t pc[4] = {0, 0, 0, 0}, pt;
+    uint64_t pc[6] = {0, 0, 0, 0, 0, 0}, pt;
 #define WSP(k) { uint64_t now_ = __builtin_amdgcn_s_memtime(); pc[k] += now_ - pt; pt = now_; }
     pt = __builtin_amdgcn_s_memtime();
 #else
@@ -441,69 +441,72 @@ __global__ void __launch_bounds__(256) k_miller_lines_ws(const uint32_t *__restr
 #endif
     for (int b = b_hi; b >= b_lo; b--) {
         Fp2H z; fzero(z);
-        // ---- round 1: squarings of in = A + B (carry-passed; Z' as it is), w3: the product X Y ----
-        Fp2H A, B, in, t, r1, opA, opB;
-        if (whole) {
-            if (role == 0) { fsel(A, sub, X, Y); B = z; }
-            else if (role == 1) in = Z;
-            else if (role == 2) { A = Y; B = Z; }
-            else { opA = X; opB = Y; }
-        } else {
-            if (role == 1) ws_get(in, L[WS_NZ], lane);
-            else {
-                Fp2H v1, v2, yy;
-                if (role == 0) ws_get(v1, L[sub ? WS_NX : WS_G2], lane); else ws_get(v1, L[WS_G2], lane);
-                ws_get(v2, L[WS_E2], lane);
-                fadd(t, v2, v2); fadd(t, t, v2); fsub<32>(yy, v1, t);                     // Y' = g^2 - 3 e^2 (lazy)
-                if (role == 0) { fsel(A, sub, v1, yy); B = z; }
-                else if (role == 2) { A = yy; B = keep; }
-                else { opA = keep; fnorm(opB, yy); }
-            }
-        }
-        if (role == 3) qx_mul(r1, opA, opB);
-        else {
-            if (role != 1) { fadd(t, A, B); fnorm(in, t); }
-            hx_sqr<64>(r1, in);
-        }
-        if (role == 0) ws_put(L[WS_BJ], lane, r1);
-        else if (role == 1) {
-            Fp2H e, f;
+        // ---- round 1: squarings of in = A + B (carry-passed; Z' as it is), w3: the product X Y.  One straight path per role (a wave runs one of
+        // them): merging the roles' operands in front of a shared product costs more register copies than the product's code is worth ----
+        Fp2H t, r1, res, lv;
+        auto next_y = [&](Fp2H &yy, const WsSlot &g2slot) {      // Y' = g^2 - 3 e^2 (lazy)
+            Fp2H v1, v2, u; ws_get(v1, g2slot, lane); ws_get(v2, L[WS_E2], lane);
+            fadd(u, v2, v2); fadd(u, u, v2); fsub<32>(yy, v1, u);
+        };
+        if (role == 0) {
+            Fp2H A, in;
+            if (whole) fsel(A, sub, X, Y);
+            else { Fp2H v1, v2, yy, u; ws_get(v1, L[sub ? WS_NX : WS_G2], lane); ws_get(v2, L[WS_E2], lane);
+                   fadd(u, v2, v2); fadd(u, u, v2); fsub<32>(yy, v1, u); fsel(A, sub, v1, yy); }
+            fadd(t, A, z); fnorm(in, t);
+            hx_sqr<64>(r1, in);                                  // sub 0: b = Y^2   sub 1: j = X^2
+            ws_put(L[WS_BJ], lane, r1);
+        } else if (role == 1) {
+            Fp2H in, e, f;
+            if (whole) in = Z; else ws_get(in, L[WS_NZ], lane);
+            hx_sqr<64>(r1, in);                                  // c = Z^2
             f2_mul12_n(t, r1); f2_mul_xi_n<128>(e, t);          // e = 12 (1 + u) c
             fadd(f, e, e); fadd(f, f, e);                       // f = 3 e (lazy)
             ws_put(L[WS_C], lane, r1); ws_put(L[WS_E], lane, e); ws_put(L[WS_F], lane, f);
+        } else if (role == 2) {
+            Fp2H in;
+            if (whole) fadd(t, Y, Z); else { Fp2H yy; next_y(yy, L[WS_G2]); fadd(t, yy, keep); }
+            fnorm(in, t);
+            hx_sqr<64>(r1, in);                                  // (Y + Z)^2
+        } else {
+            if (whole) qx_mul(r1, X, Y);
+            else { Fp2H yy, yn; next_y(yy, L[WS_G2]); fnorm(yn, yy); qx_mul(r1, keep, yn); }          // X Y
         }
         WSP(0)
         __syncthreads();
         WSP(1)
         // ---- round 2 ----
-        Fp2H res, lv;
-        uint32_t lc = 0; bool lst = false;
         if (role == 0) {
-            ws_get(opA, L[WS_E], lane);
-            fadd(t, r1, r1); fadd(lv, t, r1); lc = 1; lst = sub;                          // sub 1: the line's 3 j
+            Fp2H Ev; ws_get(Ev, L[WS_E], lane);
+            fadd(t, r1, r1); fadd(lv, t, r1);                    // sub 1: the line's 3 j
+            if (sub && live) st(s, 1, lv);
+            hx_sqr<512>(res, Ev);                                // e^2
+            ws_put(L[WS_E2], lane, res);
         } else if (role == 1) {
-            Fp2H Bv, Fv, Ev;
+            Fp2H Bv, Fv, Ev, g;
             ws_get(Bv, L[WS_BJ], lane_b); ws_get(Fv, L[WS_F], lane); ws_get(Ev, L[WS_E], lane);
-            fadd(t, Bv, Fv); fhalf(opA, t);                      // g = (b + f) / 2
-            fsub<8>(lv, Ev, Bv); lc = 0; lst = !sub;             // line c0 = e - b (lazy)
+            fadd(t, Bv, Fv); fhalf(g, t);                        // g = (b + f) / 2
+            fsub<8>(lv, Ev, Bv);                                 // line c0 = e - b (lazy)
+            if (!sub && live) st(s, 0, lv);
+            hx_sqr<512>(res, g);                                 // g^2
+            ws_put(L[WS_G2], lane, res);
         } else if (role == 2) {
             Fp2H Bv, Cv, hh;
             ws_get(Bv, L[WS_BJ], lane_b); ws_get(Cv, L[WS_C], lane);
             fadd(t, Bv, Cv); f2_sub_n<16>(hh, r1, t);            // h = (Y + Z)^2 - (b + c)
-            fsub<32>(lv, z, hh); lc = 2; lst = !sub;             // -h
-            opA = Bv; opB = hh;
+            fsub<32>(lv, z, hh);                                 // -h
+            if (!sub && live) st(s, 2, lv);
+            qx_mul(res, Bv, hh);                                 // Z' = b h
+            ws_put(L[WS_NZ], lane, res);
         } else {
-            Fp2H Bv, Fv, g;
+            Fp2H Bv, Fv, d2;
             ws_get(Bv, L[WS_BJ], lane_b); ws_get(Fv, L[WS_F], lane);
-            fadd(t, Bv, Fv); fhalf(g, t);
-            f2_sub_n<256>(opB, Bv, g);                           // (b - f) / 2
-            opA = r1;                                            // X Y
+            fsub<512>(t, Bv, Fv); fhalf(d2, t);                  // (b - f) / 2 = b - g, halved directly (g itself is w1's)
+            qx_mul(res, r1, d2);                                 // X' = (X Y)(b - g)
+            ws_put(L[WS_NX], lane, res);
         }
-        if (lst && live) st(s, lc, lv);
         s++;
-        if (role < 2) hx_sqr<512>(res, opA); else qx_mul(res, opA, opB);                  // w0: e^2  w1: g^2  w2: b h  w3: (X Y)(b - g)
         keep = res;
-        ws_put(L[role == 0 ? WS_E2 : (role == 1 ? WS_G2 : (role == 2 ? WS_NZ : WS_NX))], lane, res);
         WSP(2)
         __syncthreads();
         WSP(3)
@@ -513,9 +516,10 @@ __global__ void __launch_bounds__(256) k_miller_lines_ws(const uint32_t *__restr
         { Fp2H g2, e2; ws_get(X, L[WS_NX], lane); ws_get(Z, L[WS_NZ], lane); ws_get(g2, L[WS_G2], lane); ws_get(e2, L[WS_E2], lane);
           fadd(t, e2, e2); fadd(t, t, e2); fsub<32>(Y, g2, t); fnorm(Y, Y); }
         whole = true;
+        WSP(4)
         if (!add) continue;
         // ---- addition step (ark-ec add_in_place): four rounds, one product per wave and round ----
-        Fp2H theta, lam, cc, dd, ee, h2, gmh;
+        Fp2H theta, lam, cc, dd, ee, h2, gmh, opA, opB;
 #pragma nounroll
         for (int r = 0; r < 4; r++) {
             bool work = true;
@@ -555,9 +559,10 @@ __global__ void __launch_bounds__(256) k_miller_lines_ws(const uint32_t *__restr
                 f2_sub_n<8>(Y, r2, r3);
             }
         }
+        WSP(5)
     }
 #ifdef WS_PROF
-    if (blockIdx.x == 0 && lane == 0) printf("role %d: r1 %llu waitA %llu r2 %llu waitB %llu (cycles over %d steps)\n", role, (unsigned long long)pc[0], (unsigned long long)pc[1], (unsigned long long)pc[2], (unsigned long long)pc[3], s - s_first);
+    if (blockIdx.x == 0 && lane == 0) printf("role %d: r1 %llu waitA %llu r2 %llu waitB %llu whole-read %llu add %llu (cycles over %d steps)\n", role, (unsigned long long)pc[0], (unsigned long long)pc[1], (unsigned long long)pc[2], (unsigned long long)pc[3], (unsigned long long)pc[4], (unsigned long long)pc[5], s - s_first);
 #endif
     if (b_lo > 0 && role == 0 && !sub && inr) {
         const size_t w = 2 * n, at = 2 * i + h;

@@ -307,7 +307,7 @@ template <class F2> FD void line_dbl_step_ws(G2ProjT<F2> &R, LineT<F2> &l, bool 
     fadd(t, b, f); fhalf(g, t);                                         // g = (b + f) / 2
     fsub<8>(l.c0, e, b);                                                // i = e - b
     fadd(t, b, c); f2_sub_n<16>(h, hs, t);                              // h = (Y + Z)^2 - (b + c)
-    f2_sub_n<256>(d2, b, g);                                            // (b - f) / 2
+    fsub<512>(t, b, f); fhalf(d2, t);                                   // (b - f) / 2 (w3 halves the difference itself)
     fadd(t, j, j); fadd(l.c1, t, j);                                    // 3 j
     fsub<32>(l.c2, z, h);                                               // -h
     f2_sqr_u<512>(e2, e); f2_sqr_u<512>(g2, g); f2_mul_q(nz, b, h); f2_mul_q(nx, xy, d2);   // round 2

@@ -397,6 +397,7 @@ __device__ __forceinline__ void ws_get(Fp2H &r, const WsSlot &s, uint32_t lane) 
 __global__ void __launch_bounds__(256) k_miller_lines_ws(const uint32_t *__restrict__ p_abi, const uint32_t *__restrict__ q_abi, const uint8_t *__restrict__ skip, size_t n, uint32_t *__restrict__ lines, size_t stride,
                                                          int b_hi, int b_lo, int s_first, uint32_t *__restrict__ state, uint32_t *__restrict__ pxy) {
     __shared__ WsSlot L[WS_SLOTS];
+    __builtin_amdgcn_s_setprio(3);                                // the chain is what a call waits for: its waves go first where a product kernel's wave shares their SIMD
     const uint32_t lane = threadIdx.x & 63u, h = lane & 1u;
     const bool sub = (lane & 2u) != 0;
     const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -973,10 +974,10 @@ static int32_t ml_pipelined(Slot &sl, size_t n, size_t n_aff, const uint8_t *dsk
     // round at 1024 pairs, 4 -> 2: 1.06 -> 1.14)
     int tail_slice = g.slice_len >= 8 && (n + g.slice_len / 2 - 1) / (g.slice_len / 2) <= 2048 ? g.slice_len / 2 : g.slice_len;
     int cuts[ML_PIECES]; for (int j = 0; j < ML_PIECES; j++) cuts[j] = ML_CUTS[j];
-#ifdef DGPU_DEV
-    if (const char *e = getenv("DGPU_ML_TAIL_SLICE")) { const int v = atoi(e); if (v >= 1 && (n + v - 1) / v <= 2048) tail_slice = v; }
-    if (const char *e = getenv("DGPU_ML_CUTS")) { int a = 0, b = 0; if (sscanf(e, "%d,%d", &a, &b) == 2 && a > b && b > 0 && a < 62) { cuts[0] = a; cuts[1] = b; } }
-#endif
+    { const int m = gs.ml_mode.load();                               // development twin: dgpu_set_miller_pipeline's upper bits (cuts, slice length of the last piece)
+      const int a = (m >> 8) & 63, b = (m >> 16) & 63, v = (m >> 24) & 15;
+      if (a > b && b > 0 && a < 62) { cuts[0] = a; cuts[1] = b; }
+      if (v >= 1 && (n + v - 1) / v <= 2048) tail_slice = v; }
     ml_geom_set(g2, n, tail_slice, ml_geom_words(g));
     if ((rc = sl.ml_partial.ensure((ml_geom_words(g) + ml_geom_words(g2)) * 4))) return rc;
     if ((rc = sl.ml_state.ensure(((size_t)3 * NL * 4 * n_aff + (size_t)2 * NL * n) * 4))) return rc;      // R of every lane, then px, py of every pair

@@ -180,7 +180,7 @@ def main():
     ap.add_argument("--no-table", action="store_true", help="time the plain resident pipeline (no precomputed-multiples table)")
     ap.add_argument("--reduce-shift", type=int, default=-1, help="development: dgpu_set_reduce_shift (log2 buckets per lane of the bucket reduction; -1 = automatic)")
     ap.add_argument("--reduce-lanes", type=int, default=-1, help="development: dgpu_set_reduce_lanes (0 = bit marginals, the default; 1 / 4 = the scan form of rounds 1-4)")
-    ap.add_argument("--miller-pipeline", type=int, default=-1, help="development: dgpu_set_miller_pipeline (forms of the Miller kernels; -1 = the library's default, 15)")
+    ap.add_argument("--miller-pipeline", type=int, default=-1, help="development: dgpu_set_miller_pipeline (forms of the Miller kernels; -1 = the library's default, 31)")
     args = ap.parse_args()
 
     sys.setswitchinterval(1e-4)            # (a host thread that returns from the library gets the interpreter within 0.1 ms instead of CPython's default 5)

@@ -116,7 +116,7 @@ struct Shared {
     std::atomic<int> chunk{0};
     std::atomic<int> reduce_lanes{0};         // dgpu_set_reduce_lanes: 0 = the shared bucket set by bit marginals (reduce_kernels.hip.h; the plain pipeline then takes 4); 1 / 4: the scan form with k_reduce_top / k_reduce_top_quad (members per point in the last kernel)
     std::atomic<int> reduce_shift{-1};        // dgpu_set_reduce_shift: log2 buckets per lane of k_reduce_l0 on the table pipeline (-1 = automatic)
-    std::atomic<int> ml_mode{15};             // dgpu_set_miller_pipeline: bit 0 the two-launch line kernel of small Miller loops, bit 1 the 18-role product tree, bit 2 sixteen lanes per pair in the line kernel, bit 3 (with bit 2) a wave per role (dock_pairing.hip)
+    std::atomic<int> ml_mode{31};             // dgpu_set_miller_pipeline: bit 0 the two-launch line kernel of small Miller loops, bit 1 the 18-role product tree, bit 2 sixteen lanes per pair in the line kernel, bit 3 (with bit 2) a wave per role, bit 4 three waves per sparse product while the chip is nearly empty (dock_pairing.hip)
     uint64_t allocs_at_reset = 0, alloc_ns_at_reset = 0;
     int default_ctx = -1;
     std::atomic<bool> prof{false};

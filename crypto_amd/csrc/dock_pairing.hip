@@ -709,6 +709,101 @@ __global__ void __launch_bounds__(64) k_line_products(const uint32_t *__restrict
     for (int c = 0; c < 6; c++) for (int k = 0; k < NL; k++) partial[(size_t)t * F12W + (2 * c + h) * NL + k] = q[c].v.l[k];
 }
 
+// ---- the sparse products of a launch that leaves the chip nearly empty: three waves per 32 slices -------------------------------------------------
+// k_line_products inlines the thirteen Fp2 products of a mul_by_014 and the two of the evaluation: 107 KB of straight code, more than the
+// instruction cache, so a lone wave per SIMD waits for nearly every instruction it runs (22 cycles each: 113 us for ONE product per slice at 1024
+// pairs).  Here a block of three waves owns 32 slices (lane pair = slice, as before) and a wave runs a THIRD of the product — w0: aa = f.c0 x
+// (c0, c1), w1: m = (f.c0 + f.c1) x (c0, c1 + c4), w2: bb = f.c1 x c4 and the line's evaluation is shared the same way — so each wave's code stays in the
+// cache and the three parts run side by side; f, the line, aa and bb travel through LDS (k_miller_lines_ws's slots), two barriers per line.  The same
+// operations on the same values as f12_mul_by_014 (pairing29.hip.h), so the same bounds; every slice runs slice_len rounds (a slice one pair short
+// multiplies by the neutral line in its last one: the same value).  For the pieces of the pipelined Miller loop (ml_products); launches that fill the
+// chip keep k_line_products, which is throughput-bound there.
+enum { LP3_F = 0, LP3_L0 = 6, LP3_L1 = 7, LP3_L4 = 8, LP3_AA = 9, LP3_BB = 12, LP3_SLOTS = 15 };
+__global__ void __launch_bounds__(192) k_line_products3(const uint32_t *__restrict__ lines, size_t n, int slice_len, int nsl, uint32_t *__restrict__ partial, int s0, int ns, const uint32_t *__restrict__ pxy) {
+    __shared__ WsSlot L[LP3_SLOTS];
+    const uint32_t lane = threadIdx.x & 63u, h = lane & 1u;
+    const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int total = ns * nsl;
+    int t = (int)(blockIdx.x * 32u + (lane >> 1));
+    const bool inr = t < total;
+    if (!inr) t = total - 1;
+    const int s = s0 + t / nsl, j = t % nsl;
+    const size_t have = (n + slice_len - 1) / slice_len;             // = nsl
+    const size_t lo = (size_t)j;
+    Fp2H z; fzero(z);
+    for (int it = 0; it < slice_len; it++) {
+        const size_t i = lo + (size_t)it * have;
+        const bool valid = i < n;
+        const size_t ic = valid ? i : n - 1;
+        // ---- the line, evaluated: w2 takes c0, w0 c1 px, w1 c2 py ----
+        {
+            const int c = role == 2 ? 0 : (role == 0 ? 1 : 2);
+            Fp2H x; for (int k = 0; k < NL; k++) x.v.l[k] = lines[((size_t)s * LW + (2 * c + h) * NL + k) * n + ic];
+            fnorm(x, x);
+            bool neutral = !valid;
+            if (pxy) {
+                Fp px, py; uint32_t anyp = 0;
+                for (int k = 0; k < NL; k++) { px.l[k] = pxy[(size_t)k * n + ic]; py.l[k] = pxy[(size_t)(NL + k) * n + ic]; anyp |= px.l[k] | py.l[k]; }
+                if (role == 0) fmul_fp(x, x, px); else if (role == 1) fmul_fp(x, x, py);
+                if (!anyp) neutral = true;                             // (px = py = 0: the pair contributes one, see k_line_products)
+            }
+            if (neutral) { if (role == 2) fset_one(x); else fzero(x); }
+            ws_put(L[role == 2 ? LP3_L0 : (role == 0 ? LP3_L1 : LP3_L4)], lane, x);
+        }
+        __syncthreads();
+        if (it == 0) {                                                 // f = the line as a dense element (f12_from_014)
+            Fp2H v;
+            if (role == 0) { ws_get(v, L[LP3_L0], lane); ws_put(L[LP3_F + 0], lane, v); ws_get(v, L[LP3_L1], lane); ws_put(L[LP3_F + 1], lane, v); ws_put(L[LP3_F + 2], lane, z); }
+            else if (role == 1) { ws_put(L[LP3_F + 3], lane, z); ws_get(v, L[LP3_L4], lane); ws_put(L[LP3_F + 4], lane, v); ws_put(L[LP3_F + 5], lane, z); }
+            __syncthreads();
+            continue;
+        }
+        Fp6T<Fp2H> m;
+        if (role == 2) {
+            Fp6T<Fp2H> b, bb; Fp2H l4;
+            ws_get(b.c0, L[LP3_F + 3], lane); ws_get(b.c1, L[LP3_F + 4], lane); ws_get(b.c2, L[LP3_F + 5], lane); ws_get(l4, L[LP3_L4], lane);
+            f6_mul_by_1(bb, b, l4);
+            ws_put(L[LP3_BB + 0], lane, bb.c0); ws_put(L[LP3_BB + 1], lane, bb.c1); ws_put(L[LP3_BB + 2], lane, bb.c2);
+        } else {
+            Fp6T<Fp2H> a; Fp2H l0, l1;
+            ws_get(a.c0, L[LP3_F + 0], lane); ws_get(a.c1, L[LP3_F + 1], lane); ws_get(a.c2, L[LP3_F + 2], lane);
+            ws_get(l0, L[LP3_L0], lane); ws_get(l1, L[LP3_L1], lane);
+            if (role == 1) {
+                Fp6T<Fp2H> b, sum; Fp2H l4, o;
+                ws_get(b.c0, L[LP3_F + 3], lane); ws_get(b.c1, L[LP3_F + 4], lane); ws_get(b.c2, L[LP3_F + 5], lane); ws_get(l4, L[LP3_L4], lane);
+                f2_add_n(o, l1, l4);
+                f6_add_n(sum, a, b);
+                a = sum; l1 = o;
+            }
+            f6_mul_by_01(m, a, l0, l1);                                // w0: aa   w1: m
+            if (role == 0) { ws_put(L[LP3_AA + 0], lane, m.c0); ws_put(L[LP3_AA + 1], lane, m.c1); ws_put(L[LP3_AA + 2], lane, m.c2); }
+        }
+        __syncthreads();
+        if (role == 0) {                                               // f.c0 = aa + v bb
+            Fp6T<Fp2H> bb, x, r;
+            ws_get(bb.c0, L[LP3_BB + 0], lane); ws_get(bb.c1, L[LP3_BB + 1], lane); ws_get(bb.c2, L[LP3_BB + 2], lane);
+            f6_mul_v(x, bb);
+            f6_add_n(r, m, x);
+            ws_put(L[LP3_F + 0], lane, r.c0); ws_put(L[LP3_F + 1], lane, r.c1); ws_put(L[LP3_F + 2], lane, r.c2);
+        } else if (role == 1) {                                        // f.c1 = m - aa - bb
+            Fp6T<Fp2H> aa, bb, x; Fp2H r;
+            ws_get(aa.c0, L[LP3_AA + 0], lane); ws_get(aa.c1, L[LP3_AA + 1], lane); ws_get(aa.c2, L[LP3_AA + 2], lane);
+            ws_get(bb.c0, L[LP3_BB + 0], lane); ws_get(bb.c1, L[LP3_BB + 1], lane); ws_get(bb.c2, L[LP3_BB + 2], lane);
+            fadd(x.c0, aa.c0, bb.c0); fadd(x.c1, aa.c1, bb.c1); fadd(x.c2, aa.c2, bb.c2);
+            f2_sub_n<128>(r, m.c0, x.c0); ws_put(L[LP3_F + 3], lane, r);
+            f2_sub_n<128>(r, m.c1, x.c1); ws_put(L[LP3_F + 4], lane, r);
+            f2_sub_n<128>(r, m.c2, x.c2); ws_put(L[LP3_F + 5], lane, r);
+        }
+        __syncthreads();
+    }
+    if (inr && role < 2) {
+        for (int c = 0; c < 3; c++) {
+            Fp2H v; ws_get(v, L[LP3_F + 3 * role + c], lane);
+            for (int k = 0; k < NL; k++) partial[(size_t)((size_t)s * nsl + j) * F12W + (2 * (3 * role + c) + h) * NL + k] = v.v.l[k];
+        }
+    }
+}
+
 // One block per (step, group of 64 partials): tree product through LDS.  A node product a * b is shared by three lane PAIRS — Karatsuba
 // over Fp6: a0 b0, a1 b1, (a0 + a1)(b0 + b1) are independent Fp6 products of 6 Fp2 products each, and every Fp2 value sits on a lane pair.
 // The tree is latency-bound (a dense Fp12 product is ~25 k instructions on one lane) and has few nodes, so spreading a node over six lanes
@@ -919,10 +1014,15 @@ static int32_t ml_geometry(Slot &sl, size_t n, MlGeom &g) {
     return DGPU_OK;
 }
 // K10 + K11 for the steps s0 .. s0 + ns - 1 on stream s (partials and results are indexed by the step: disjoint for disjoint ranges)
+constexpr unsigned LP3_MAX_BLOCKS = 512;      // two blocks of three waves per CU
 static void ml_products(Slot &sl, hipStream_t s, size_t n, const MlGeom &g, int s0, int ns, bool timed, const uint32_t *pxy = nullptr) {
     const int nsl = g.nsl, ngroups = g.ngroups;
     auto products = [&] {
-      hipLaunchKernelGGL(k_line_products, dim3((unsigned)((2 * ns * nsl + 63) / 64)), dim3(64), 0, s, sl.ml_lines.as<uint32_t>(), n, g.slice_len, nsl, sl.ml_partial.as<uint32_t>() + g.base, (const uint32_t *)nullptr, 1, s0, ns, pxy); };
+      const unsigned blocks3 = (unsigned)((ns * nsl + 31) / 32);
+      if (blocks3 <= LP3_MAX_BLOCKS && (gs.ml_mode.load() & 16))
+          hipLaunchKernelGGL(k_line_products3, dim3(blocks3), dim3(192), 0, s, sl.ml_lines.as<uint32_t>(), n, g.slice_len, nsl, sl.ml_partial.as<uint32_t>() + g.base, s0, ns, pxy);
+      else
+          hipLaunchKernelGGL(k_line_products, dim3((unsigned)((2 * ns * nsl + 63) / 64)), dim3(64), 0, s, sl.ml_lines.as<uint32_t>(), n, g.slice_len, nsl, sl.ml_partial.as<uint32_t>() + g.base, (const uint32_t *)nullptr, 1, s0, ns, pxy); };
     auto tree = [&] {
       uint32_t *lvl0 = sl.ml_partial.as<uint32_t>() + g.base, *lvl1 = lvl0 + (size_t)N_LINES * nsl * F12W;
       if (ngroups == 1) launch_product_tree(s, (unsigned)ns, lvl0, nsl, 1, (uint32_t *)nullptr, sl.ml_out.as<uint32_t>(), (const uint32_t *)nullptr, 0, s0);

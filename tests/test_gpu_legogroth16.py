@@ -79,11 +79,11 @@ def test_prove_verify_roundtrip(m, cw):
     abi_checks()                                    # the product library (every knob at its default)
     with ca.twin():                                 # the forms of the Miller kernels are a development knob (include/dock_gpu_dev.h)
         try:
-            for mode in (15, 7, 3, 6, 0):
+            for mode in (31, 15, 7, 3, 6, 0):
                 assert lib().dgpu_set_miller_pipeline(mode) == 0
                 abi_checks()
         finally:
-            lib().dgpu_set_miller_pipeline(15)
+            lib().dgpu_set_miller_pipeline(31)
     from concurrent.futures import ThreadPoolExecutor
     with ThreadPoolExecutor(6) as ex:
         res = list(ex.map(lambda k: LG.verify_proof_abi(pvk, proof if k % 3 else bad, inp[1:]), range(24)))

@@ -75,16 +75,16 @@ def test_every_form_of_the_miller_kernels_gives_the_same_value(n, twin):
         ps[n // 3] = 0; skip[n // 3] = 1; skip[n - 1] = 1
     got = {}
     try:
-        for mode in range(16):
+        for mode in range(32):
             assert lib().dgpu_set_miller_pipeline(mode) == 0
             got[mode] = ca.multi_miller_loop(ps, qs, skip)
-        assert lib().dgpu_set_miller_pipeline(16) != 0
+        assert lib().dgpu_set_miller_pipeline(32) != 0
     finally:
-        lib().dgpu_set_miller_pipeline(15)
-    for mode in range(1, 16):
+        lib().dgpu_set_miller_pipeline(31)
+    for mode in range(1, 32):
         assert (got[mode] == got[0]).all(), mode
     if n <= 1100:
-        assert (got[15] == O.multi_miller_loop(ps, qs, skip, threads=32)).all()
+        assert (got[31] == O.multi_miller_loop(ps, qs, skip, threads=32)).all()
     if n <= 1100:
         from crypto_amd import pairing
         inf = skip.copy()
@@ -93,7 +93,7 @@ def test_every_form_of_the_miller_kernels_gives_the_same_value(n, twin):
             lib().dgpu_set_miller_pipeline(7); pc16 = pairing.G2Prepared.from_affine(qs, inf)
             lib().dgpu_set_miller_pipeline(15); pcw = pairing.G2Prepared.from_affine(qs, inf)
         finally:
-            lib().dgpu_set_miller_pipeline(15)
+            lib().dgpu_set_miller_pipeline(31)
         assert (pc4.coeffs == pc16.coeffs).all() and (pc4.infinity == pc16.infinity).all()
         assert (pcw.coeffs == pc16.coeffs).all() and (pcw.infinity == pc16.infinity).all()
     # the verifier's call (dgpu_multi_miller_loop_mixed: some pairs affine, the others prepared) cuts the affine pairs' chain the same way
@@ -102,11 +102,11 @@ def test_every_form_of_the_miller_kernels_gives_the_same_value(n, twin):
         pc = pairing.G2Prepared.from_affine(qs)
         cut = max(1, n // 3)
         try:
-            for mode in range(16):
+            for mode in range(32):
                 assert lib().dgpu_set_miller_pipeline(mode) == 0
                 assert (pairing.multi_miller_loop(ps, [qs[:cut], pc[cut:]], skip) == got[0]).all(), mode
         finally:
-            lib().dgpu_set_miller_pipeline(15)
+            lib().dgpu_set_miller_pipeline(31)
 
 
 def test_identity_members_are_skipped_and_lengths_checked():
@@ -173,7 +173,7 @@ def test_g2_prepare_lane_pair_chain_writes_the_same_bytes(n, twin):
         assert lib().dgpu_set_miller_pipeline(2) == 0
         old = pairing.G2Prepared.from_affine(qs)
     finally:
-        lib().dgpu_set_miller_pipeline(15)
+        lib().dgpu_set_miller_pipeline(31)
     assert (old.coeffs == pc.coeffs).all() and (old.infinity == pc.infinity).all()
     i = n - 1
     assert (pc.coeffs[i] == O.g2_prepare(qs[i]).reshape(-1)).all()

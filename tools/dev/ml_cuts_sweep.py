@@ -21,6 +21,6 @@ def t(fn, k=40):
 cuts = os.environ.get("CUTS", "40,17 44,22 36,14 46,26 40,12 44,17 36,17 48,30 42,20").split()
 for rep in range(3):
     for c in cuts:
-        a_, b_ = map(int, c.split(",")); assert lib().dgpu_set_miller_pipeline(15 | a_ << 8 | b_ << 16) == 0
+        a_, b_ = map(int, c.split(",")); assert lib().dgpu_set_miller_pipeline(31 | a_ << 8 | b_ << 16) == 0
         assert (ca.multi_miller_loop(ps, qs) == f).all() and (pairing.multi_miller_loop(ps[:3], [qs[:1], pc[1:]]) == g).all()
         print("cuts %-6s  1024-pair loop %.3f ms   verifier's call %.3f ms" % (c, t(lambda: ca.multi_miller_loop(ps, qs)), t(lambda: pairing.multi_miller_loop(ps[:3], [qs[:1], pc[1:]]))), flush=True)

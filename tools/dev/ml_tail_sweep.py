@@ -15,12 +15,12 @@ def t(fn, k=40):
     return (time.perf_counter() - t0) / k * 1e3
 for n in (1024, 256, 4096):
     ps = O.G1.gen_seq(k0, d, n, threads=32); qs = O.G2.gen_seq(d, k0, n, threads=32)
-    lib().dgpu_set_miller_pipeline(15)
+    lib().dgpu_set_miller_pipeline(31)
     f = ca.multi_miller_loop(ps, qs)
     for rep in range(3):
         row = []
         for v in ("", "1", "2", "4", "8"):
-            assert lib().dgpu_set_miller_pipeline(15 | (int(v) if v else 0) << 24) == 0
+            assert lib().dgpu_set_miller_pipeline(31 | (int(v) if v else 0) << 24) == 0
             assert (ca.multi_miller_loop(ps, qs) == f).all()
             row.append("%s: %.3f" % (v or "auto", t(lambda: ca.multi_miller_loop(ps, qs))))
         print("n = %d  tail slice  %s  (ms per call)" % (n, "   ".join(row)), flush=True)

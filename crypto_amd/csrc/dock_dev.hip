@@ -12,8 +12,8 @@ int32_t dgpu_set_window_bits(int32_t c) { if (c != 0 && (c < 7 || c > 22)) retur
 int32_t dgpu_set_chunk(int32_t terms) { if (terms != 0 && (terms < 16 || terms > 4096)) return DGPU_E_BADARG; gs.chunk = terms; return DGPU_OK; }
 int32_t dgpu_set_reduce_lanes(int32_t lanes) { if (lanes != 0 && lanes != 1 && lanes != 2 && lanes != 4) return DGPU_E_BADARG; gs.reduce_lanes = lanes; return DGPU_OK; }
 int32_t dgpu_set_reduce_shift(int32_t sh) { if (sh < -1 || sh > 6) return DGPU_E_BADARG; gs.reduce_shift = sh; return DGPU_OK; }
-int32_t dgpu_set_miller_pipeline(int32_t mode) {       // bits 0-4: forms; bits 8-13 / 16-21: where the chain is cut (0: default); bits 24-27: slice length of the last piece's products (0: automatic)
-    if (mode < 0 || (mode & ~0x0F3F3F1F)) return DGPU_E_BADARG;
+int32_t dgpu_set_miller_pipeline(int32_t mode) {       // bits 0-4: forms; bits 8-13 / 16-21: where the chain is cut (0: default); bits 24-27: slice length of the last piece's products (0: automatic); bits 28-29: log2 of the factor on the block limit of k_line_products3
+    if (mode < 0 || (mode & ~0x3F3F3F1F)) return DGPU_E_BADARG;
     const int a = (mode >> 8) & 63, b = (mode >> 16) & 63;
     if ((a || b) && !(a > b && b > 0 && a < 62)) return DGPU_E_BADARG;
     gs.ml_mode = mode; return DGPU_OK;

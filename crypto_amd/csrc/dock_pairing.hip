@@ -520,6 +520,9 @@ __global__ void __launch_bounds__(256) k_miller_lines_ws(const uint32_t *__restr
         WSP(4)
         if (!add) continue;
         // ---- addition step (ark-ec add_in_place): four rounds, one product per wave and round ----
+        // (kept as a ROLLED loop over the round index: the build with `#pragma unroll` here returned wrong Miller values — DESIGN.md 10 — while this one
+        // passes every form's comparison and the randomized soak; the slot schedule: a round's outputs go to slots whose last readers sit behind a
+        // barrier every wave has passed: T1 T2 -> CC DD M2 M3 (= BJ C E F) -> EE FF GG (EE FF = T1 T2) -> R0 .. R3 (= E2 G2 NZ NX))
         Fp2H theta, lam, cc, dd, ee, h2, gmh, opA, opB;
 #pragma nounroll
         for (int r = 0; r < 4; r++) {
@@ -1019,7 +1022,8 @@ static void ml_products(Slot &sl, hipStream_t s, size_t n, const MlGeom &g, int 
     const int nsl = g.nsl, ngroups = g.ngroups;
     auto products = [&] {
       const unsigned blocks3 = (unsigned)((ns * nsl + 31) / 32);
-      if (blocks3 <= LP3_MAX_BLOCKS && (gs.ml_mode.load() & 16))
+      const int mlm = gs.ml_mode.load();
+      if (blocks3 <= (LP3_MAX_BLOCKS << ((mlm >> 28) & 3)) && (mlm & 16))
           hipLaunchKernelGGL(k_line_products3, dim3(blocks3), dim3(192), 0, s, sl.ml_lines.as<uint32_t>(), n, g.slice_len, nsl, sl.ml_partial.as<uint32_t>() + g.base, s0, ns, pxy);
       else
           hipLaunchKernelGGL(k_line_products, dim3((unsigned)((2 * ns * nsl + 63) / 64)), dim3(64), 0, s, sl.ml_lines.as<uint32_t>(), n, g.slice_len, nsl, sl.ml_partial.as<uint32_t>() + g.base, (const uint32_t *)nullptr, 1, s0, ns, pxy); };

@@ -24,11 +24,15 @@ int32_t dgpu_set_reduce_shift(int32_t log2_buckets_per_lane);
  * one butterfly network per wave, class folds with four members per value; the plain pipeline's per-window reduction then runs as 4); 2: the same with
  * one lane per value in the class folds; 4 / 1: the scan form of rounds 1-4 (k_reduce_l0, then k_reduce_top_quad / k_reduce_top). */
 int32_t dgpu_set_reduce_lanes(int32_t lanes);
-/* Forms of the Miller-loop kernels, a bit mask (default 7).  Bit 0: dgpu_multi_miller_loop of up to 8192 pairs runs its line kernel in two
- * launches and overlaps the products / host share of the first with the second (and dgpu_g2_prepare runs the same lanes-per-point chain
+/* Forms of the Miller-loop kernels, a bit mask (default 31).  Bit 0: dgpu_multi_miller_loop of up to 8192 pairs runs its line kernel in pieces
+ * and overlaps the products / host share of a finished piece with the next (and dgpu_g2_prepare runs the same lanes-per-point chain
  * followed by a parallel conversion pass).  Bit 1: the product tree gives every node 18 lane pairs (one Fp2 product deep per level) instead
  * of three.  Bit 2: up to 4096 pairs the line kernel gives every (P, Q) sixteen lanes (a doubling step two Fp2 operations deep instead of
- * five).  Every combination gives the same Fp12 value limb for limb (tests compare them). */
+ * five).  Bit 3 (with bit 2): those sixteen lanes are four lanes in each of four waves, a wave per role (k_miller_lines_ws).  Bit 4: the sparse
+ * products of a launch of up to 512 blocks run as three waves per 32 slices (k_line_products3).  Every combination gives the same Fp12 value
+ * limb for limb (tests compare all 32).  Upper bits, zero = the default: bits 8-13 / 16-21 the bits of |x| at which the chain is cut into three
+ * launches (40 and 17), bits 24-27 the slice length of the last piece's sparse products, bits 28-29 log2 of a factor on bit 4's block limit
+ * (tools/dev/ml_cuts_sweep.py, ml_tail_sweep.py, ml_lp3_limit.py).  DGPU_E_BADARG for anything else. */
 int32_t dgpu_set_miller_pipeline(int32_t mode);
 
 /* ---- instrumentation (bench.py's stage breakdown and roofline leg; rocprofv3 cross-check) ----

@@ -21,4 +21,4 @@ for mode in (0, 1, 2, 3, 0, 1, 2, 3):
             list(ex.map(lambda _: ca.multi_miller_loop(ps, qs), range(12)))
             t0 = time.perf_counter(); list(ex.map(lambda _: ca.multi_miller_loop(ps, qs), range(60))); out.append((time.perf_counter() - t0) / 60 * 1e3)
     print("mode %d  one call %.3f ms   per call with 2 / 4 / 6 / 10 in flight: %s" % (mode, one, ["%.3f" % v for v in out]), flush=True)
-lib().dgpu_set_miller_pipeline(7)
+lib().dgpu_set_miller_pipeline(31)

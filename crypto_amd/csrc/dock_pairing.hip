@@ -960,13 +960,12 @@ __global__ void __launch_bounds__(T18_THREADS) k_product_tree18(const uint32_t *
         }
     }
     __syncthreads();
-    if (t < 2) {
-        for (int q = 0; q < 6; q++) {
-            Fp c;
-            for (int j = 0; j < NL; j++) c.l[j] = sh[(2 * q + hh) * NL + j];
-            if (out_abi) fp_to_abi(out_abi + ((size_t)s * 12 + 2 * q + hh) * 12, c);
-            else for (int j = 0; j < NL; j++) next[((size_t)s * ngroups + grp) * F12W + (2 * q + hh) * NL + j] = c.l[j];
-        }
+    if (t < 12) {                                                   // twelve lanes, a coefficient half each (the conversion to the ABI form is a product and a canonical
+        const int q = t >> 1;                                         // reduction: one lane pair doing all six behind each other was a third of a two-pass launch)
+        Fp c;
+        for (int j = 0; j < NL; j++) c.l[j] = sh[(2 * q + hh) * NL + j];
+        if (out_abi) fp_to_abi(out_abi + ((size_t)s * 12 + 2 * q + hh) * 12, c);
+        else for (int j = 0; j < NL; j++) next[((size_t)s * ngroups + grp) * F12W + (2 * q + hh) * NL + j] = c.l[j];
     }
 }
 // one launcher for both tree kernels (gs.ml_mode bit 1: the 18-role form)

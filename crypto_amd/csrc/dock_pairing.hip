@@ -722,21 +722,24 @@ __global__ void __launch_bounds__(64) k_line_products(const uint32_t *__restrict
 // multiplies by the neutral line in its last one: the same value).  For the pieces of the pipelined Miller loop (ml_products); launches that fill the
 // chip keep k_line_products, which is throughput-bound there.
 enum { LP3_F = 0, LP3_L0 = 6, LP3_L1 = 7, LP3_L4 = 8, LP3_AA = 9, LP3_BB = 12, LP3_SLOTS = 15 };
-__global__ void __launch_bounds__(192) k_line_products3(const uint32_t *__restrict__ lines, size_t n, int slice_len, int nsl, uint32_t *__restrict__ partial, int s0, int ns, const uint32_t *__restrict__ pxy) {
+__global__ void __launch_bounds__(192) k_line_products3(const uint32_t *__restrict__ lines, size_t n, int slice_len, int nsl, uint32_t *__restrict__ partial, int s0, int ns, const uint32_t *__restrict__ pxy,
+                                                        const uint32_t *__restrict__ seg_off = nullptr, int nseg = 1) {
     __shared__ WsSlot L[LP3_SLOTS];
     const uint32_t lane = threadIdx.x & 63u, h = lane & 1u;
     const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int total = ns * nsl;
+    const int per = ns * nsl, total = per * nseg;                   // (segment, step of the range, slice) as in k_line_products
     int t = (int)(blockIdx.x * 32u + (lane >> 1));
-    const bool inr = t < total;
+    bool inr = t < total;
     if (!inr) t = total - 1;
-    const int s = s0 + t / nsl, j = t % nsl;
-    const size_t have = (n + slice_len - 1) / slice_len;             // = nsl
-    const size_t lo = (size_t)j;
+    const int g = t / per, rem = t % per, s = s0 + rem / nsl, j = rem % nsl;
+    const size_t first = seg_off ? seg_off[g] : 0, last = seg_off ? seg_off[g + 1] : n;
+    const size_t have = (last - first + slice_len - 1) / slice_len;  // slices of this segment (<= nsl); a lane pair beyond them keeps step with the barriers and stores nothing
+    if ((size_t)j >= have) inr = false;
+    const size_t lo = first + (size_t)j;
     Fp2H z; fzero(z);
     for (int it = 0; it < slice_len; it++) {
         const size_t i = lo + (size_t)it * have;
-        const bool valid = i < n;
+        const bool valid = inr && i < last;
         const size_t ic = valid ? i : n - 1;
         // ---- the line, evaluated: w2 takes c0, w0 c1 px, w1 c2 py ----
         {
@@ -802,7 +805,7 @@ __global__ void __launch_bounds__(192) k_line_products3(const uint32_t *__restri
     if (inr && role < 2) {
         for (int c = 0; c < 3; c++) {
             Fp2H v; ws_get(v, L[LP3_F + 3 * role + c], lane);
-            for (int k = 0; k < NL; k++) partial[(size_t)((size_t)s * nsl + j) * F12W + (2 * (3 * role + c) + h) * NL + k] = v.v.l[k];
+            for (int k = 0; k < NL; k++) partial[(((size_t)g * N_LINES + s) * nsl + j) * F12W + (2 * (3 * role + c) + h) * NL + k] = v.v.l[k];
         }
     }
 }
@@ -1280,8 +1283,13 @@ static int32_t ml_segments(const uint64_t *p, const uint64_t *q, const uint8_t *
             hipStream_t sp = j + 1 < ML_PIECES ? side[j & 1] : sa;
             if (j + 1 < ML_PIECES && !ok(hipStreamWaitEvent(sp, ready[j], 0))) break;
             const int s0 = first_step[j], ns = steps[j];
-            hipLaunchKernelGGL(k_line_products, dim3((unsigned)((2 * (size_t)ns * nsl * nseg + 63) / 64)), dim3(64), 0, sp, sl.ml_lines.as<uint32_t>(), n, slice_len, nsl, sl.ml_partial.as<uint32_t>(), doff, (int)nseg,
-                               s0, ns, (const uint32_t *)pxy);
+            const size_t blocks3 = ((size_t)ns * nsl * nseg + 31) / 32;
+            const int mlm = gs.ml_mode.load();
+            if (blocks3 <= ((size_t)LP3_MAX_BLOCKS << ((mlm >> 28) & 3)) && (mlm & 16))
+                hipLaunchKernelGGL(k_line_products3, dim3((unsigned)blocks3), dim3(192), 0, sp, sl.ml_lines.as<uint32_t>(), n, slice_len, nsl, sl.ml_partial.as<uint32_t>(), s0, ns, (const uint32_t *)pxy, (const uint32_t *)doff, (int)nseg);
+            else
+                hipLaunchKernelGGL(k_line_products, dim3((unsigned)((2 * (size_t)ns * nsl * nseg + 63) / 64)), dim3(64), 0, sp, sl.ml_lines.as<uint32_t>(), n, slice_len, nsl, sl.ml_partial.as<uint32_t>(), doff, (int)nseg,
+                                   s0, ns, (const uint32_t *)pxy);
             seg_tree(sp, sl.ml_partial.as<uint32_t>(), doff, s0, ns);
             ok(hipMemcpy2DAsync(Lp + s0, (size_t)N_LINES * 576, (const char *)sl.ml_out.p + (size_t)s0 * 576, (size_t)N_LINES * 576, (size_t)ns * 576, nseg, hipMemcpyDeviceToHost, sp));
             done[j] = sl.copy_ev[sl.ev_next++ % (Slot::N_COPY_EV + 1)];

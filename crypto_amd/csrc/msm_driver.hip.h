@@ -216,7 +216,10 @@ int32_t msm_device_small(Slot &sl, const uint32_t *d_bases, const uint32_t *d_sc
     if ((rc = ready_bases(0, 0, n))) return rc;
     constexpr size_t WBYTES = (size_t)SMALL_MSM_W * 4 * C::ABI_W * 4;
     static_assert(WBYTES + 2 * SMALL_MSM_W <= Slot::HPIN_BYTES, "pinned scratch");
-    uint8_t *const wbuf = sl.win.as<uint8_t>();
+    // the tree's last block writes the window sums and their flags straight into the slot's pinned host scratch (hipHostMalloc memory is the device's to address): a call of
+    // a few hundred terms is one kernel and a synchronisation, the copy kernel that used to bring the 2.6 KB back cost a tenth of it
+    uint8_t *const hbuf = (uint8_t *)sl.hpin;
+    uint8_t *const wbuf = hbuf;
     uint8_t *const d_inf = wbuf + WBYTES, *const d_bad = d_inf + SMALL_MSM_W;
     if (!sub) {
         StageTimer st(sl, "msm.small_table");
@@ -228,8 +231,6 @@ int32_t msm_device_small(Slot &sl, const uint32_t *d_bases, const uint32_t *d_sc
                              sl.small_cnt.as<uint32_t>(), (uint32_t *)wbuf, d_inf, d_bad);
     }
     HIPCHK(hipGetLastError());
-    uint8_t *const hbuf = (uint8_t *)sl.hpin;                       // pinned: one asynchronous copy brings everything back
-    HIPCHK(hipMemcpyAsync(hbuf, wbuf, WBYTES + 2 * SMALL_MSM_W, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     if (gs.prof) prof_flush(sl);
     const uint64_t *hwin = (const uint64_t *)hbuf; const uint8_t *hinf = hbuf + WBYTES, *hbad = hinf + SMALL_MSM_W;

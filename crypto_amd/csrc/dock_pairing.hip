@@ -520,11 +520,15 @@ __global__ void __launch_bounds__(256) k_miller_lines_ws(const uint32_t *__restr
         WSP(4)
         if (!add) continue;
         // ---- addition step (ark-ec add_in_place): four rounds, one product per wave and round ----
-        // (kept as a ROLLED loop over the round index: the build with `#pragma unroll` here returned wrong Miller values — DESIGN.md 10 — while this one
-        // passes every form's comparison and the randomized soak; the slot schedule: a round's outputs go to slots whose last readers sit behind a
+        // (kept as a ROLLED loop over the round index: the build with `#pragma unroll` here, -DWS_UNROLL, returns wrong lines from the first addition step on, for every
+        // pair and the same ones run after run: a compile-time difference, not a race — DESIGN.md 10 — while this one passes every form's comparison and the soaks; the slot schedule: a round's outputs go to slots whose last readers sit behind a
         // barrier every wave has passed: T1 T2 -> CC DD M2 M3 (= BJ C E F) -> EE FF GG (EE FF = T1 T2) -> R0 .. R3 (= E2 G2 NZ NX))
         Fp2H theta, lam, cc, dd, ee, h2, gmh, opA, opB;
+#ifdef WS_UNROLL
+#pragma unroll
+#else
 #pragma nounroll
+#endif
         for (int r = 0; r < 4; r++) {
             bool work = true;
             if (r == 0) { opA = role == 0 ? Q.y : Q.x; opB = Z; work = role < 2; }                      // w0: Qy Z   w1: Qx Z
